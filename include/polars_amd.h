@@ -1,0 +1,371 @@
+/*
+ * polars_amd.h -- C ABI of the MI355X-native columnar execution backend for the
+ * Polars hot path (filter / gather, primitive compare + arithmetic, whole-column
+ * and grouped aggregation, hash join), built for gfx950.
+ *
+ * This header is the drop-in boundary (seam B1).  Every entry
+ * point is `extern "C"`, takes plain pointers / sizes / opaque integer handles and
+ * returns an `int` status (0 = ok).  No torch / C++ types cross it.  A Rust
+ * `extern "C"` block in polars-mem-engine binds these 1:1.
+ *
+ * Reference interfaces each group of entry points replaces (paths relative to
+ * the pola-rs/polars tree):
+ *
+ *   plx_version / plx_last_error
+ *       pyo3-polars/pyo3-polars/src/derive.rs:26-66
+ *       (_polars_plugin_get_version, _polars_plugin_get_last_error_message)
+ *       crates/polars-ffi/src/lib.rs:12-13 (MAJOR=0, MINOR=1)
+ *   plx_series_export, plx_column_import_series / plx_column_export_series
+ *       crates/polars-ffi/src/version_0.rs:7-16 (SeriesExport), :61-107
+ *       (export_series / import_series)
+ *   ArrowSchema / ArrowArray, plx_column_import_arrow / plx_column_export_arrow
+ *       crates/polars-arrow/src/ffi/generated.rs:6-34 (Arrow C Data Interface)
+ *   plx_cmp / plx_cmp_scalar
+ *       crates/polars-compute/src/comparisons/mod.rs:4-75 (TotalEqKernel/TotalOrdKernel)
+ *       null rule crates/polars-core/src/chunked_array/ops/arity.rs:203-214,430-454
+ *   plx_bitmap_binop / plx_bitmap_not
+ *       crates/polars-expr/src/expressions/binary.rs:110-118
+ *   plx_arith / plx_arith_scalar
+ *       crates/polars-compute/src/arithmetic/mod.rs:8-150 (ArithmeticKernel)
+ *   plx_cast
+ *       crates/polars-expr/src/expressions/cast.rs (numeric casts only)
+ *   plx_filter
+ *       crates/polars-compute/src/filter/mod.rs:18-28 (filter)
+ *   plx_gather
+ *       crates/polars-compute/src/gather/primitive.rs:9-78 (take_primitive_unchecked)
+ *   plx_reduce
+ *       crates/polars-core/src/chunked_array/ops/aggregate/mod.rs:86-137,240-246,307-316
+ *   plx_groupby_agg
+ *       crates/polars-core/src/frame/group_by/mod.rs:29-98 (group_by_with_series)
+ *       + crates/polars-core/src/frame/group_by/aggregations/mod.rs:854-1018
+ *   plx_join_indices
+ *       crates/polars-ops/src/frame/join/hash_join/single_keys_dispatch.rs:234-357
+ *       (hash_join_inner / hash_join_left -> (left_idx, right_idx))
+ *   plx_hash_partition
+ *       crates/polars-utils/src/hashing.rs:72-121 (HashPartitioner) and
+ *       crates/polars-expr/src/hash_keys.rs:263-314 (gen_idxs_per_partition)
+ *   plx_ir / plx_aexpr / plx_execute_plan
+ *       crates/polars-plan/src/plans/ir/mod.rs:53-187 (IR arena),
+ *       crates/polars-plan/src/plans/aexpr/mod.rs:150-259 (AExpr arena),
+ *       crates/polars-mem-engine/src/planner/lp.rs:75-100,326-878 (create_physical_plan)
+ *       crates/polars-mem-engine/src/executors/executor.rs:10-16 (Executor::execute)
+ *   plx_profile_*
+ *       crates/polars-expr/src/state/node_timer.rs:14-70 (NodeTimer)
+ *
+ * Threading: every call is thread-safe.  Errors never unwind across the ABI;
+ * a non-zero status means `plx_last_error()` (thread-local) holds the message.
+ */
+#ifndef POLARS_AMD_H
+#define POLARS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLX_ABI_MAJOR 0
+#define PLX_ABI_MINOR 1
+
+/* ---- status codes ------------------------------------------------------ */
+#define PLX_OK 0
+#define PLX_ERR_INVALID 1      /* bad argument / dtype mismatch (PolarsError::InvalidOperation) */
+#define PLX_ERR_HIP 2          /* HIP runtime error; message has hipGetErrorString */
+#define PLX_ERR_UNSUPPORTED 3  /* node/dtype outside the hot path -> caller falls back to CPU */
+#define PLX_ERR_OOM 4
+#define PLX_ERR_SHAPE 5        /* length mismatch (PolarsError::ShapeMismatch) */
+#define PLX_ERR_NOT_FOUND 6    /* unknown column (PolarsError::ColumnNotFound) */
+#define PLX_ERR_CANCELLED 7    /* host cancel flag raised (ExecutionState::should_stop) */
+
+/* ---- physical dtypes (Arrow primitive layouts) --------------------------- */
+typedef enum plx_dtype {
+  PLX_BOOL = 0, /* bit-packed LSB-first values bitmap */
+  PLX_I8 = 1,
+  PLX_I16 = 2,
+  PLX_I32 = 3, /* also Date */
+  PLX_I64 = 4, /* also Datetime / Duration */
+  PLX_U8 = 5,
+  PLX_U16 = 6,
+  PLX_U32 = 7, /* also IdxSize, Categorical physical */
+  PLX_U64 = 8,
+  PLX_F32 = 9,
+  PLX_F64 = 10
+} plx_dtype;
+
+/* comparison operators: polars_plan::dsl::Operator (dsl/expr/mod.rs:683-707) */
+typedef enum plx_cmp_op { PLX_EQ = 0, PLX_NE = 1, PLX_LT = 2, PLX_LE = 3, PLX_GT = 4, PLX_GE = 5 } plx_cmp_op;
+
+/* arithmetic operators */
+typedef enum plx_arith_op {
+  PLX_ADD = 0,
+  PLX_SUB = 1,
+  PLX_MUL = 2,
+  PLX_TRUE_DIV = 3,  /* ints -> f64, floats stay */
+  PLX_FLOOR_DIV = 4, /* ints: by zero -> null */
+  PLX_MOD = 5        /* ints: by zero -> null */
+} plx_arith_op;
+
+typedef enum plx_bitmap_op { PLX_AND = 0, PLX_OR = 1, PLX_XOR = 2 } plx_bitmap_op;
+
+/* aggregations: IRAggExpr (plans/aexpr/mod.rs) subset on the hot path */
+typedef enum plx_agg_op {
+  PLX_AGG_SUM = 0,
+  PLX_AGG_MEAN = 1,
+  PLX_AGG_MIN = 2,
+  PLX_AGG_MAX = 3,
+  PLX_AGG_COUNT = 4, /* non-null count, u32 (IdxSize) */
+  PLX_AGG_LEN = 5,   /* row count incl. nulls, u32 */
+  PLX_AGG_FIRST = 6  /* first row of each group (group_by only; used for key columns) */
+} plx_agg_op;
+
+typedef enum plx_join_how { PLX_JOIN_INNER = 0, PLX_JOIN_LEFT = 1 } plx_join_how;
+
+/* A 64-bit scalar passed by bit pattern; interpreted according to a plx_dtype. */
+typedef union plx_scalar {
+  int64_t i;
+  uint64_t u;
+  double f64;
+  float f32;
+} plx_scalar;
+
+/* Opaque handles (0 is never valid). */
+typedef uint64_t plx_column; /* device-resident Arrow-layout column */
+typedef uint64_t plx_frame;  /* ordered set of named columns of equal length */
+
+/* ---- Arrow C Data Interface (standard layout) ------------------------- */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+#endif
+
+/* Mirror of polars_ffi::version_0::SeriesExport (a chunked Arrow array). */
+typedef struct plx_series_export {
+  struct ArrowSchema* field;
+  struct ArrowArray** arrays;
+  size_t len;
+  void (*release)(struct plx_series_export*);
+  void* private_data;
+} plx_series_export;
+
+/* ---- library / device -------------------------------------------------- */
+/* (major << 16) | minor, same packing as _polars_plugin_get_version. */
+uint32_t plx_version(void);
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* plx_last_error(void);
+/* Bind the calling process to one GPU (one process per GPU). Idempotent. */
+int plx_init(int device_ordinal);
+int plx_shutdown(void);
+/* Launch all subsequent work of this thread on `hip_stream` (hipStream_t as void*;
+ * NULL = the library's own stream). */
+int plx_set_stream(void* hip_stream);
+int plx_synchronize(void);
+/* Cooperative cancel flag checked between kernel launches. */
+int plx_set_cancel(int flag);
+/* name (<=255 chars), CU count, HBM bytes of the bound device. */
+int plx_device_info(char* name_out, size_t name_cap, int32_t* cu_count, uint64_t* hbm_bytes);
+/* bytes currently held by the library's device pool / high-water mark */
+int plx_memory_stats(uint64_t* in_use, uint64_t* high_water);
+/* return cached free blocks to the driver */
+int plx_memory_trim(void);
+
+/* ---- columns ----------------------------------------------------------- */
+/* Copy a host Arrow-layout buffer pair to HBM. `validity` may be NULL (no nulls);
+ * `bit_offset` applies to both a PLX_BOOL values bitmap and the validity bitmap
+ * (Arrow `offset`); for non-bool values the caller passes the already-offset
+ * values pointer. */
+int plx_column_from_host(plx_dtype dtype, const void* values, const uint8_t* validity,
+                         int64_t bit_offset, int64_t len, plx_column* out);
+/* Wrap device buffers owned by the caller (e.g. a torch tensor): no copy; the
+ * caller keeps them alive until plx_column_free. validity may be NULL. */
+int plx_column_from_device(plx_dtype dtype, void* dev_values, void* dev_validity, int64_t len,
+                           plx_column* out);
+/* Planning-only column: dtype / length / nullability (/ integer range statistics) but NO
+ * device memory.  Lets plx_describe_fusion run without a GPU; every compute entry point
+ * rejects it. */
+int plx_column_placeholder(plx_dtype dtype, int64_t len, int nullable, int has_range, int64_t range_min, int64_t range_max,
+                           plx_column* out);
+/* Arrow C Data Interface import: copies to HBM, then calls array->release and
+ * schema->release (callee takes ownership: plugin.rs:122-125 convention). */
+int plx_column_import_arrow(struct ArrowArray* array, struct ArrowSchema* schema, plx_column* out);
+/* Chunked import (SeriesExport): chunks are concatenated on device. Takes ownership. */
+int plx_column_import_series(plx_series_export* series, plx_column* out);
+/* Export to host memory owned by the returned structs (released via ->release). */
+int plx_column_export_arrow(plx_column col, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
+int plx_column_export_series(plx_column col, const char* name, plx_series_export* out);
+/* Plain download. values_out must hold len*width bytes (BOOL: (len+7)/8);
+ * validity_out (may be NULL) must hold (len+7)/8 bytes; *has_validity_out tells
+ * whether the column carries a validity bitmap (if not, validity_out is all ones). */
+int plx_column_to_host(plx_column col, void* values_out, uint8_t* validity_out, int32_t* has_validity_out);
+int plx_column_info(plx_column col, plx_dtype* dtype, int64_t* len, int64_t* null_count);
+int plx_column_device_ptrs(plx_column col, void** values, void** validity);
+int plx_column_retain(plx_column col);
+int plx_column_free(plx_column col);
+
+/* ---- kernel-level entry points (one reference kernel family each) -------- */
+/* out: PLX_BOOL, validity = lhs.validity AND rhs.validity. Total-order float
+ * semantics (NaN == NaN, NaN greatest). */
+int plx_cmp(plx_cmp_op op, plx_column lhs, plx_column rhs, plx_column* out);
+int plx_cmp_scalar(plx_cmp_op op, plx_column lhs, plx_scalar rhs, plx_column* out);
+/* Boolean columns: values op, validity AND (binary.rs:110-118). */
+int plx_bitmap_binop(plx_bitmap_op op, plx_column lhs, plx_column rhs, plx_column* out);
+int plx_bitmap_not(plx_column col, plx_column* out);
+/* Same-dtype operands (type coercion happens in the optimizer). */
+int plx_arith(plx_arith_op op, plx_column lhs, plx_column rhs, plx_column* out);
+/* scalar_on_left: computes scalar OP col instead of col OP scalar. */
+int plx_arith_scalar(plx_arith_op op, plx_column col, plx_scalar scalar, int scalar_on_left, plx_column* out);
+/* numeric -> numeric cast (non-strict: out-of-range -> null like polars cast(strict=False)). */
+int plx_cast(plx_column col, plx_dtype to, plx_column* out);
+/* Stream compaction by a PLX_BOOL mask; null mask values are false. */
+int plx_filter(plx_column col, plx_column mask, plx_column* out);
+/* out[i] = col[idx[i]]; idx is PLX_U32 (IdxSize); null idx -> null. */
+int plx_gather(plx_column col, plx_column idx, plx_column* out);
+/* Whole-column reduction. *out_value receives the scalar in the output dtype
+ * *out_dtype (sum: SumCast rule; mean: f64, f32 stays f32; count/len: u32);
+ * *out_valid = 0 when the result is null (mean/min/max of empty or all-null). */
+int plx_reduce(plx_agg_op op, plx_column col, plx_scalar* out_value, plx_dtype* out_dtype, int32_t* out_valid);
+
+/* Hash group-by with in-place aggregation.  n_keys >= 1 key columns (integer,
+ * bool or float; a null key forms its own group; floats canonicalised).
+ * aggs[i] applies to values[i] (ignored for PLX_AGG_LEN, may be 0).
+ * Outputs: out_keys[n_keys] (one row per group) and out_aggs[n_aggs].
+ * Row order of groups is unspecified unless maintain_order != 0 (then groups are
+ * ordered by first occurrence). */
+int plx_groupby_agg(const plx_column* keys, int32_t n_keys, const plx_column* values,
+                    const plx_agg_op* aggs, int32_t n_aggs, int32_t maintain_order,
+                    plx_column* out_keys, plx_column* out_aggs);
+
+/* Equi-join on one key column pair -> row-index pairs (PLX_U32). For LEFT joins the
+ * right index column carries nulls for unmatched left rows. Null keys never match.
+ * Pair order is unspecified (sort before comparing), as in the reference. */
+int plx_join_indices(plx_join_how how, plx_column left_key, plx_column right_key,
+                     plx_column* out_left_idx, plx_column* out_right_idx);
+
+/* Key-hash partitioning for the multi-GPU exchange: partition p of row i is
+ * mulhi(dirty_hash(key[i]) * seed', n_partitions) (HashPartitioner; nulls -> 0).
+ * out_perm (PLX_U32, len rows) lists row indices grouped by partition;
+ * counts_out[n_partitions] (host) receives rows per partition. */
+int plx_hash_partition(plx_column key, int32_t n_partitions, uint64_t seed, plx_column* out_perm,
+                       int64_t* counts_out);
+
+/* ---- frames ------------------------------------------------------------- */
+int plx_frame_new(const char* const* names, const plx_column* cols, int32_t n_cols, plx_frame* out);
+int plx_frame_free(plx_frame f);
+int plx_frame_shape(plx_frame f, int64_t* height, int32_t* width);
+/* name_out points into library-owned storage valid until the frame is freed. */
+int plx_frame_column(plx_frame f, int32_t i, const char** name_out, plx_column* col_out);
+
+/* ---- plan execution (Executor seam) ------------------------------------ */
+typedef enum plx_aexpr_kind {
+  PLX_AE_COLUMN = 0,  /* name */
+  PLX_AE_LITERAL = 1, /* dtype, lit, is_null */
+  PLX_AE_BINARY = 2,  /* op = plx_operator, lhs, rhs */
+  PLX_AE_CAST = 3,    /* lhs, dtype */
+  PLX_AE_AGG = 4,     /* op = plx_agg_op, lhs */
+  PLX_AE_LEN = 5,     /* pl.len() */
+  PLX_AE_ALIAS = 6,   /* lhs, name */
+  PLX_AE_NOT = 7      /* lhs (boolean) */
+} plx_aexpr_kind;
+
+/* polars_plan::dsl::Operator subset */
+typedef enum plx_operator {
+  PLX_OP_EQ = 0, PLX_OP_NE = 1, PLX_OP_LT = 2, PLX_OP_LE = 3, PLX_OP_GT = 4, PLX_OP_GE = 5,
+  PLX_OP_PLUS = 6, PLX_OP_MINUS = 7, PLX_OP_MULTIPLY = 8, PLX_OP_TRUE_DIVIDE = 9,
+  PLX_OP_FLOOR_DIVIDE = 10, PLX_OP_MODULUS = 11, PLX_OP_AND = 12, PLX_OP_OR = 13, PLX_OP_XOR = 14
+} plx_operator;
+
+typedef struct plx_aexpr {
+  int32_t kind; /* plx_aexpr_kind */
+  int32_t op;   /* plx_operator or plx_agg_op */
+  int32_t lhs;  /* arena index of the (left) input, -1 if none */
+  int32_t rhs;  /* arena index of the right input, -1 if none */
+  int32_t dtype; /* literal dtype / cast target (plx_dtype) */
+  int32_t is_null; /* literal is NULL */
+  plx_scalar lit;
+  const char* name; /* column name / alias */
+} plx_aexpr;
+
+typedef enum plx_ir_kind {
+  PLX_IR_SCAN = 0,    /* frame */
+  PLX_IR_FILTER = 1,  /* input, predicate */
+  PLX_IR_SELECT = 2,  /* input, exprs */
+  PLX_IR_HSTACK = 3,  /* input, exprs (with_columns) */
+  PLX_IR_GROUPBY = 4, /* input, keys, exprs (aggs), maintain_order */
+  PLX_IR_JOIN = 5     /* input, input_right, keys (left_on), keys_right (right_on), how, suffix */
+} plx_ir_kind;
+
+typedef struct plx_ir {
+  int32_t kind; /* plx_ir_kind */
+  int32_t input;
+  int32_t input_right;
+  int32_t predicate;
+  plx_frame frame;
+  const int32_t* exprs;
+  int32_t n_exprs;
+  const int32_t* keys;
+  int32_t n_keys;
+  const int32_t* keys_right;
+  int32_t n_keys_right;
+  int32_t how; /* plx_join_how */
+  int32_t maintain_order;
+  const char* suffix; /* join suffix, NULL = "_right" */
+} plx_ir;
+
+/* plan flags */
+#define PLX_PLAN_NO_FUSION 1u /* force one kernel per node (reference-shaped execution) */
+
+/* Build the physical plan for IR node `root` and execute it. The output frame is
+ * owned by the caller (plx_frame_free). PLX_ERR_UNSUPPORTED means: run this
+ * subtree on the CPU engine instead (same contract as docs/user-guide/gpu-support.md). */
+int plx_execute_plan(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int32_t n_exprs, int32_t root,
+                     uint32_t flags, plx_frame* out);
+/* Compile-only: lowers the `[Filter]* -> Select | GroupBy` pipeline rooted at `root`
+ * into its fused register program without launching anything (works on placeholder
+ * columns, no GPU needed).  *fusable = 0 with a reason in why_not if the plan needs the
+ * one-kernel-per-node path; *static_shape_id >= 0 if a pre-instantiated (AOT) kernel
+ * matches.  plx_last_plan_description() then returns a dump of the program. */
+int plx_describe_fusion(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int32_t n_exprs, int32_t root, int32_t* fusable,
+                        int32_t* static_shape_id, char* why_not, size_t why_cap);
+/* Human-readable physical plan (which fused pipeline / kernels were chosen) of the
+ * last plx_execute_plan on this thread. */
+const char* plx_last_plan_description(void);
+
+/* ---- tracing (NodeTimer equivalent) --------------------------------------- */
+typedef struct plx_profile_record {
+  char name[48];      /* kernel / node name */
+  double start_us;    /* hipEvent time relative to plx_profile_enable */
+  double end_us;
+  uint64_t algo_bytes; /* algorithmic bytes of this launch (0 if n/a) */
+  uint64_t rows;
+} plx_profile_record;
+int plx_profile_enable(int on);
+/* Resolves pending events (synchronises), copies up to cap records, returns count in *n. */
+int plx_profile_fetch(plx_profile_record* out, int32_t cap, int32_t* n);
+int plx_profile_clear(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLARS_AMD_H */

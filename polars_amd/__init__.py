@@ -1,0 +1,19 @@
+"""polars_amd -- MI355X-native execution backend for the Polars hot path
+(filter / gather, primitive compare + arithmetic, hash group-by-aggregate, hash join).
+
+The compute lives in ``libpolars_amd.so`` (hand-written gfx950 HIP kernels + C++ host
+engine) behind the C ABI of ``include/polars_amd.h``.  This package is the Python
+stand-in for the Rust host shim: a small mirror of the Polars LazyFrame / Expr API that
+lowers queries to the IR / AExpr arenas the ABI consumes.  There is no CPU fallback.
+"""
+from . import _ffi
+from ._ffi import PlxError, UnsupportedError, init, last_plan
+from .datatypes import (Boolean, Categorical, DataType, Date, Datetime, Float32, Float64, Int8, Int16, Int32, Int64, UInt8,
+                        UInt16, UInt32, UInt64)
+from .expr import Expr, col, count, len, lit, max, mean, min, sum  # noqa: A004
+from .frame import DataFrame, GroupBy, LazyFrame, Series
+
+__all__ = ["init", "last_plan", "PlxError", "UnsupportedError", "DataFrame", "LazyFrame", "GroupBy", "Series", "Expr", "col", "lit",
+           "len", "sum", "mean", "min", "max", "count", "DataType", "Boolean", "Int8", "Int16", "Int32", "Int64", "UInt8", "UInt16",
+           "UInt32", "UInt64", "Float32", "Float64", "Date", "Datetime", "Categorical"]
+__version__ = "0.1.0"

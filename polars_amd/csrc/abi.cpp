@@ -1,0 +1,366 @@
+// abi.cpp -- the extern "C" boundary declared in include/polars_amd.h.
+// Every entry point converts C++ exceptions into a status code + thread-local message
+// (same convention as _polars_plugin_get_last_error_message, pyo3-polars derive.rs:26-45);
+// nothing unwinds across the ABI.
+#include <cstdio>
+#include <cstring>
+
+#include "core.hpp"
+#include "engine.hpp"
+#include "fused_shapes.hpp"
+#include "join.hpp"
+#include "kernels.hpp"
+#include "ops.hpp"
+
+namespace plx {
+void init_device(int ordinal);
+void clear_handles();
+const std::string& last_error_ref();
+}  // namespace plx
+
+using namespace plx;
+
+#define PLX_TRY try {
+#define PLX_CATCH                                                                   \
+  }                                                                                 \
+  catch (const plx::Error& e) { plx::set_last_error(e.msg); return e.code; }        \
+  catch (const std::bad_alloc&) { plx::set_last_error("host out of memory"); return PLX_ERR_OOM; } \
+  catch (const std::exception& e) { plx::set_last_error(std::string("PANIC: ") + e.what()); return PLX_ERR_INVALID; } \
+  catch (...) { plx::set_last_error("PANIC"); return PLX_ERR_INVALID; }              \
+  return PLX_OK;
+
+static thread_local std::string t_plan_desc;
+
+extern "C" {
+
+uint32_t plx_version(void) { return ((uint32_t)PLX_ABI_MAJOR << 16) | (uint32_t)PLX_ABI_MINOR; }
+const char* plx_last_error(void) { return plx::last_error_ref().c_str(); }
+
+int plx_init(int device_ordinal) { PLX_TRY init_device(device_ordinal); PLX_CATCH }
+int plx_shutdown(void) {
+  PLX_TRY
+  clear_handles();
+  pool_trim();
+  PLX_CATCH
+}
+int plx_set_stream(void* hip_stream) { PLX_TRY device(); set_thread_stream((hipStream_t)hip_stream); PLX_CATCH }
+int plx_synchronize(void) { PLX_TRY PLX_HIP(hipStreamSynchronize(stream())); PLX_CATCH }
+int plx_set_cancel(int flag) { PLX_TRY device().cancel.store(flag); PLX_CATCH }
+int plx_device_info(char* name_out, size_t name_cap, int32_t* cu_count, uint64_t* hbm_bytes) {
+  PLX_TRY
+  Device& d = device();
+  if (name_out && name_cap) snprintf(name_out, name_cap, "%s", d.name.c_str());
+  if (cu_count) *cu_count = d.cu_count;
+  if (hbm_bytes) *hbm_bytes = d.hbm_bytes;
+  PLX_CATCH
+}
+int plx_memory_stats(uint64_t* in_use, uint64_t* high_water) { PLX_TRY pool_stats(in_use, high_water); PLX_CATCH }
+int plx_memory_trim(void) { PLX_TRY pool_trim(); PLX_CATCH }
+
+// ---- columns ---------------------------------------------------------------------
+int plx_column_from_host(plx_dtype dtype, const void* values, const uint8_t* validity, int64_t bit_offset, int64_t len, plx_column* out) {
+  PLX_TRY
+  PLX_REQUIRE(out, PLX_ERR_INVALID, "null out pointer");
+  PLX_REQUIRE(values || len == 0, PLX_ERR_INVALID, "null values pointer");
+  *out = register_column(column_from_host(dtype, values, validity, bit_offset, len));
+  PLX_CATCH
+}
+int plx_column_from_device(plx_dtype dtype, void* dev_values, void* dev_validity, int64_t len, plx_column* out) {
+  PLX_TRY
+  device();
+  PLX_REQUIRE(out && (dev_values || len == 0), PLX_ERR_INVALID, "null pointer");
+  auto c = std::make_shared<Column>();
+  c->dtype = dtype; c->len = len;
+  c->values = dev_borrow(dev_values, values_bytes(dtype, len));
+  if (dev_validity) c->validity = dev_borrow(dev_validity, bitmap_bytes(len)); else c->null_count = 0;
+  *out = register_column(c);
+  PLX_CATCH
+}
+int plx_column_placeholder(plx_dtype dtype, int64_t len, int nullable, int has_range, int64_t range_min, int64_t range_max, plx_column* out) {
+  PLX_TRY
+  auto c = std::make_shared<Column>();
+  c->dtype = dtype; c->len = len;
+  c->null_count = nullable ? 1 : 0;
+  if (has_range) { c->range_state = 1; c->range_min = range_min; c->range_max = range_max; }
+  *out = register_column(c);
+  PLX_CATCH
+}
+
+static int dtype_from_format(const char* f) {
+  if (!f) return -1;
+  if (!strcmp(f, "b")) return PLX_BOOL;
+  if (!strcmp(f, "c")) return PLX_I8;
+  if (!strcmp(f, "C")) return PLX_U8;
+  if (!strcmp(f, "s")) return PLX_I16;
+  if (!strcmp(f, "S")) return PLX_U16;
+  if (!strcmp(f, "i")) return PLX_I32;
+  if (!strcmp(f, "I")) return PLX_U32;
+  if (!strcmp(f, "l")) return PLX_I64;
+  if (!strcmp(f, "L")) return PLX_U64;
+  if (!strcmp(f, "f")) return PLX_F32;
+  if (!strcmp(f, "g")) return PLX_F64;
+  if (!strncmp(f, "tdD", 3)) return PLX_I32;                      // date32
+  if (!strncmp(f, "ts", 2) || !strncmp(f, "tD", 2)) return PLX_I64;  // timestamp / duration
+  if (!strncmp(f, "tdm", 3)) return PLX_I64;
+  return -1;
+}
+static const char* format_of_dtype(int dt) {
+  static const char* f[] = {"b", "c", "s", "i", "l", "C", "S", "I", "L", "f", "g"};
+  return f[dt];
+}
+
+static ColumnPtr import_one(struct ArrowArray* a, int dt) {
+  PLX_REQUIRE(a->n_buffers >= 2, PLX_ERR_INVALID, "arrow import: primitive arrays carry 2 buffers");
+  const uint8_t* validity = (const uint8_t*)a->buffers[0];
+  const uint8_t* values = (const uint8_t*)a->buffers[1];
+  if (a->null_count == 0) validity = nullptr;
+  const void* vptr = values;
+  if (dt != PLX_BOOL && values) vptr = values + (size_t)a->offset * dtype_width(dt);
+  return column_from_host(dt, vptr, validity, a->offset, a->length);
+}
+
+int plx_column_import_arrow(struct ArrowArray* array, struct ArrowSchema* schema, plx_column* out) {
+  PLX_TRY
+  PLX_REQUIRE(array && schema && out, PLX_ERR_INVALID, "null pointer");
+  int dt = dtype_from_format(schema->format);
+  if (dt < 0) fail(PLX_ERR_UNSUPPORTED, std::string("arrow import: unsupported format '") + (schema->format ? schema->format : "") + "' (strings enter as dictionary codes)");
+  ColumnPtr c = import_one(array, dt);
+  if (array->release) array->release(array);
+  if (schema->release) schema->release(schema);
+  *out = register_column(c);
+  PLX_CATCH
+}
+
+int plx_column_import_series(plx_series_export* s, plx_column* out) {
+  PLX_TRY
+  PLX_REQUIRE(s && s->field && out, PLX_ERR_INVALID, "null pointer");
+  int dt = dtype_from_format(s->field->format);
+  if (dt < 0) fail(PLX_ERR_UNSUPPORTED, "series import: unsupported dtype");
+  std::vector<ColumnPtr> chunks;
+  for (size_t i = 0; i < s->len; i++) chunks.push_back(import_one(s->arrays[i], dt));
+  ColumnPtr c = chunks.empty() ? column_from_host(dt, nullptr, nullptr, 0, 0) : ops::concat(chunks);
+  if (s->release) s->release(s);  // callee owns the inputs (plugin.rs:122-125)
+  *out = register_column(c);
+  PLX_CATCH
+}
+
+namespace {
+struct ExportHolder {
+  std::vector<uint8_t> values, validity;
+  const void* bufs[2];
+  std::string name;
+};
+void release_array(struct ArrowArray* a) {
+  if (!a || !a->release) return;
+  delete (ExportHolder*)a->private_data;
+  a->release = nullptr;
+}
+void release_schema(struct ArrowSchema* s) {
+  if (!s || !s->release) return;
+  delete (std::string*)s->private_data;
+  s->release = nullptr;
+}
+void fill_export(const ColumnPtr& c, const char* name, struct ArrowArray* oa, struct ArrowSchema* os) {
+  auto* h = new ExportHolder();
+  const size_t vb = c->dtype == PLX_BOOL ? (size_t)((c->len + 7) / 8) : (size_t)c->len * dtype_width(c->dtype);
+  h->values.resize(vb + 8);
+  h->validity.resize((size_t)((c->len + 7) / 8) + 8);
+  int32_t hv = 0;
+  column_to_host(c, h->values.data(), h->validity.data(), &hv);
+  int64_t nulls = hv ? column_null_count(c) : 0;
+  h->bufs[0] = nulls ? h->validity.data() : nullptr;
+  h->bufs[1] = h->values.data();
+  memset(oa, 0, sizeof(*oa));
+  oa->length = c->len; oa->null_count = nulls; oa->offset = 0; oa->n_buffers = 2; oa->buffers = h->bufs; oa->release = release_array; oa->private_data = h;
+  memset(os, 0, sizeof(*os));
+  auto* nm = new std::string(name ? name : "");
+  os->format = format_of_dtype(c->dtype); os->name = nm->c_str(); os->flags = 2 /* ARROW_FLAG_NULLABLE */; os->release = release_schema; os->private_data = nm;
+}
+void release_series(plx_series_export* s) {
+  if (!s || !s->release) return;
+  if (s->arrays) { for (size_t i = 0; i < s->len; i++) { if (s->arrays[i]) { if (s->arrays[i]->release) s->arrays[i]->release(s->arrays[i]); delete s->arrays[i]; } } delete[] s->arrays; }
+  if (s->field) { if (s->field->release) s->field->release(s->field); delete s->field; }
+  s->release = nullptr;
+}
+}  // namespace
+
+int plx_column_export_arrow(plx_column col, struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
+  PLX_TRY
+  PLX_REQUIRE(out_array && out_schema, PLX_ERR_INVALID, "null pointer");
+  fill_export(get_column(col), "", out_array, out_schema);
+  PLX_CATCH
+}
+int plx_column_export_series(plx_column col, const char* name, plx_series_export* out) {
+  PLX_TRY
+  PLX_REQUIRE(out, PLX_ERR_INVALID, "null pointer");
+  out->field = new ArrowSchema();
+  out->arrays = new ArrowArray*[1];
+  out->arrays[0] = new ArrowArray();
+  out->len = 1;
+  fill_export(get_column(col), name, out->arrays[0], out->field);
+  out->release = release_series;
+  out->private_data = out->arrays;  // non-null == success (plugin.rs:127-133)
+  PLX_CATCH
+}
+int plx_column_to_host(plx_column col, void* values_out, uint8_t* validity_out, int32_t* has_validity_out) {
+  PLX_TRY
+  ColumnPtr c = get_column(col);
+  PLX_REQUIRE(c->values || c->len == 0, PLX_ERR_INVALID, "placeholder column has no data");
+  column_to_host(c, values_out, validity_out, has_validity_out);
+  PLX_CATCH
+}
+int plx_column_info(plx_column col, plx_dtype* dtype, int64_t* len, int64_t* null_count) {
+  PLX_TRY
+  ColumnPtr c = get_column(col);
+  if (dtype) *dtype = (plx_dtype)c->dtype;
+  if (len) *len = c->len;
+  if (null_count) *null_count = c->values ? column_null_count(c) : c->null_count;
+  PLX_CATCH
+}
+int plx_column_device_ptrs(plx_column col, void** values, void** validity) {
+  PLX_TRY
+  ColumnPtr c = get_column(col);
+  if (values) *values = c->values ? c->values->ptr : nullptr;
+  if (validity) *validity = c->validity ? c->validity->ptr : nullptr;
+  PLX_CATCH
+}
+int plx_column_retain(plx_column col) { PLX_TRY retain_column(col); PLX_CATCH }
+int plx_column_free(plx_column col) { PLX_TRY free_column(col); PLX_CATCH }
+
+// ---- kernel-level entry points ------------------------------------------------------
+int plx_cmp(plx_cmp_op op, plx_column lhs, plx_column rhs, plx_column* out) { PLX_TRY *out = register_column(ops::cmp(op, get_column(lhs), get_column(rhs))); PLX_CATCH }
+int plx_cmp_scalar(plx_cmp_op op, plx_column lhs, plx_scalar rhs, plx_column* out) { PLX_TRY *out = register_column(ops::cmp_scalar(op, get_column(lhs), rhs)); PLX_CATCH }
+int plx_bitmap_binop(plx_bitmap_op op, plx_column lhs, plx_column rhs, plx_column* out) { PLX_TRY *out = register_column(ops::bool_binop(op, get_column(lhs), get_column(rhs))); PLX_CATCH }
+int plx_bitmap_not(plx_column col, plx_column* out) { PLX_TRY *out = register_column(ops::bool_not(get_column(col))); PLX_CATCH }
+int plx_arith(plx_arith_op op, plx_column lhs, plx_column rhs, plx_column* out) { PLX_TRY *out = register_column(ops::arith(op, get_column(lhs), get_column(rhs))); PLX_CATCH }
+int plx_arith_scalar(plx_arith_op op, plx_column col, plx_scalar scalar, int scalar_on_left, plx_column* out) {
+  PLX_TRY *out = register_column(ops::arith_scalar(op, get_column(col), scalar, scalar_on_left != 0)); PLX_CATCH
+}
+int plx_cast(plx_column col, plx_dtype to, plx_column* out) { PLX_TRY *out = register_column(ops::cast(get_column(col), to)); PLX_CATCH }
+int plx_filter(plx_column col, plx_column mask, plx_column* out) { PLX_TRY *out = register_column(ops::filter(get_column(col), get_column(mask))); PLX_CATCH }
+int plx_gather(plx_column col, plx_column idx, plx_column* out) { PLX_TRY *out = register_column(ops::gather(get_column(col), get_column(idx))); PLX_CATCH }
+int plx_reduce(plx_agg_op op, plx_column col, plx_scalar* out_value, plx_dtype* out_dtype, int32_t* out_valid) {
+  PLX_TRY
+  ops::ScalarValue r = ops::reduce(op, get_column(col));
+  if (out_value) *out_value = r.v;
+  if (out_dtype) *out_dtype = (plx_dtype)r.dtype;
+  if (out_valid) *out_valid = r.valid ? 1 : 0;
+  PLX_CATCH
+}
+
+int plx_groupby_agg(const plx_column* keys, int32_t n_keys, const plx_column* values, const plx_agg_op* aggs, int32_t n_aggs, int32_t maintain_order,
+                    plx_column* out_keys, plx_column* out_aggs) {
+  PLX_TRY
+  PLX_REQUIRE(keys && n_keys >= 1 && (n_aggs == 0 || (values && aggs && out_aggs)) && out_keys, PLX_ERR_INVALID, "bad arguments");
+  std::vector<ColumnPtr> k, v, ok, oa;
+  std::vector<int> a;
+  for (int i = 0; i < n_keys; i++) k.push_back(get_column(keys[i]));
+  for (int i = 0; i < n_aggs; i++) { a.push_back(aggs[i]); v.push_back((aggs[i] == PLX_AGG_LEN || values[i] == 0) ? nullptr : get_column(values[i])); }
+  std::string d;
+  engine::groupby_columns(k, v, a, maintain_order != 0, ok, oa, &d);
+  t_plan_desc = d;
+  for (int i = 0; i < n_keys; i++) out_keys[i] = register_column(ok[i]);
+  for (int i = 0; i < n_aggs; i++) out_aggs[i] = register_column(oa[i]);
+  PLX_CATCH
+}
+
+int plx_join_indices(plx_join_how how, plx_column left_key, plx_column right_key, plx_column* out_left_idx, plx_column* out_right_idx) {
+  PLX_TRY
+  ColumnPtr li, ri;
+  std::string d;
+  join::join_indices(how, get_column(left_key), get_column(right_key), li, ri, &d);
+  t_plan_desc = d;
+  *out_left_idx = register_column(li);
+  *out_right_idx = register_column(ri);
+  PLX_CATCH
+}
+
+int plx_hash_partition(plx_column key, int32_t n_partitions, uint64_t seed, plx_column* out_perm, int64_t* counts_out) {
+  PLX_TRY
+  PLX_REQUIRE(out_perm && counts_out, PLX_ERR_INVALID, "null pointer");
+  ColumnPtr perm;
+  join::hash_partition(get_column(key), n_partitions, seed, perm, counts_out);
+  *out_perm = register_column(perm);
+  PLX_CATCH
+}
+
+// ---- frames -----------------------------------------------------------------------
+int plx_frame_new(const char* const* names, const plx_column* cols, int32_t n_cols, plx_frame* out) {
+  PLX_TRY
+  PLX_REQUIRE(out && (n_cols == 0 || (names && cols)), PLX_ERR_INVALID, "null pointer");
+  auto f = std::make_shared<Frame>();
+  for (int i = 0; i < n_cols; i++) {
+    ColumnPtr c = get_column(cols[i]);
+    if (i == 0) f->height = c->len;
+    PLX_REQUIRE(c->len == f->height, PLX_ERR_SHAPE, std::string("frame columns have different lengths (") + names[i] + ")");
+    PLX_REQUIRE(f->find(names[i]) < 0, PLX_ERR_INVALID, std::string("duplicate column name ") + names[i]);
+    f->names.push_back(names[i]); f->cols.push_back(c);
+  }
+  *out = register_frame(f);
+  PLX_CATCH
+}
+int plx_frame_free(plx_frame f) { PLX_TRY free_frame(f); PLX_CATCH }
+int plx_frame_shape(plx_frame f, int64_t* height, int32_t* width) {
+  PLX_TRY
+  FramePtr fr = get_frame(f);
+  if (height) *height = fr->height;
+  if (width) *width = (int32_t)fr->cols.size();
+  PLX_CATCH
+}
+int plx_frame_column(plx_frame f, int32_t i, const char** name_out, plx_column* col_out) {
+  PLX_TRY
+  FramePtr fr = get_frame(f);
+  PLX_REQUIRE(i >= 0 && i < (int)fr->cols.size(), PLX_ERR_INVALID, "column index out of range");
+  if (name_out) *name_out = fr->names[i].c_str();
+  if (col_out) *col_out = register_column(fr->cols[i]);
+  PLX_CATCH
+}
+
+// ---- plans -------------------------------------------------------------------------
+int plx_execute_plan(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int32_t n_exprs, int32_t root, uint32_t flags, plx_frame* out) {
+  PLX_TRY
+  PLX_REQUIRE(out, PLX_ERR_INVALID, "null out pointer");
+  engine::Plan p = engine::import_plan(ir, n_ir, exprs, n_exprs, flags);
+  FramePtr f = engine::execute(p, root);
+  t_plan_desc = p.desc;
+  *out = register_frame(f);
+  PLX_CATCH
+}
+const char* plx_last_plan_description(void) { return t_plan_desc.c_str(); }
+
+int plx_describe_fusion(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int32_t n_exprs, int32_t root, int32_t* fusable, int32_t* static_shape_id,
+                        char* why_not, size_t why_cap) {
+  PLX_TRY
+  engine::Plan p = engine::import_plan(ir, n_ir, exprs, n_exprs, 0);
+  fused::Shape sh{};
+  int sid = -1;
+  std::string why;
+  bool ok = engine::describe_fusion(p, root, &sh, &sid, &why);
+  if (fusable) *fusable = ok ? 1 : 0;
+  if (static_shape_id) *static_shape_id = sid;
+  if (why_not && why_cap) snprintf(why_not, why_cap, "%s", why.c_str());
+  if (ok) {
+    // dump the program so a mismatch with fused_shapes.hpp is easy to repair
+    std::string d = "inputs=" + std::to_string(sh.n_inputs) + " pred=" + std::to_string(sh.pred) + " key=" + std::to_string(sh.key) + " ops=[";
+    for (int i = 0; i < sh.n_ops; i++) d += "(" + std::to_string(sh.ops[i].code) + "," + std::to_string(sh.ops[i].dst) + "," + std::to_string(sh.ops[i].a) + "," + std::to_string(sh.ops[i].b) + "," + std::to_string(sh.ops[i].c) + ")";
+    d += "] aggs=[";
+    for (int i = 0; i < sh.n_aggs; i++) d += "(" + std::to_string(sh.aggs[i].kind) + "," + std::to_string(sh.aggs[i].src) + ")";
+    d += "] in_dtype=[";
+    for (int i = 0; i < sh.n_inputs; i++) d += std::to_string(sh.in_dtype[i]) + (sh.in_nullable[i] ? "?" : "") + ",";
+    d += "]";
+    t_plan_desc = d;
+  }
+  PLX_CATCH
+}
+
+// ---- tracing -------------------------------------------------------------------------
+int plx_profile_enable(int on) { PLX_TRY device(); profile_enable(on != 0); PLX_CATCH }
+int plx_profile_fetch(plx_profile_record* out, int32_t cap, int32_t* n) {
+  PLX_TRY
+  int c = profile_fetch(out, cap);
+  if (n) *n = c;
+  PLX_CATCH
+}
+int plx_profile_clear(void) { PLX_TRY profile_clear(); PLX_CATCH }
+
+}  // extern "C"

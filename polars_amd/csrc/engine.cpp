@@ -1,0 +1,1015 @@
+// engine.cpp -- plan import, dtype inference, the materialising evaluator, the fused
+// pipeline compiler and the executors.  See engine.hpp for the reference mapping.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <functional>
+#include <numeric>
+#include <sstream>
+
+#include "fused_shapes.hpp"
+#include "join.hpp"
+#include "kernels.hpp"
+#include "kernels_fused.hpp"
+#include "ops.hpp"
+
+namespace plx {
+namespace engine {
+
+using namespace fused;
+
+struct Unsupported : std::exception {
+  std::string why;
+  explicit Unsupported(std::string w) : why(std::move(w)) {}
+  const char* what() const noexcept override { return why.c_str(); }
+};
+
+// ------------------------------------------------------------------ import ----
+Plan import_plan(const plx_ir* ir, int n_ir, const plx_aexpr* ae, int n_ae, uint32_t flags) {
+  Plan p;
+  p.flags = flags;
+  PLX_REQUIRE(ir && n_ir > 0, PLX_ERR_INVALID, "execute_plan: empty IR arena");
+  for (int i = 0; i < n_ae; i++) {
+    AE e;
+    e.kind = ae[i].kind; e.op = ae[i].op; e.lhs = ae[i].lhs; e.rhs = ae[i].rhs; e.dtype = ae[i].dtype; e.is_null = ae[i].is_null; e.lit = ae[i].lit;
+    if (ae[i].name) e.name = ae[i].name;
+    PLX_REQUIRE(e.lhs < i && e.rhs < i, PLX_ERR_INVALID, "AExpr arena must be topologically ordered (children before parents)");
+    p.ae.push_back(std::move(e));
+  }
+  for (int i = 0; i < n_ir; i++) {
+    IRN n;
+    n.kind = ir[i].kind; n.input = ir[i].input; n.input_right = ir[i].input_right; n.predicate = ir[i].predicate; n.frame = ir[i].frame;
+    for (int j = 0; j < ir[i].n_exprs; j++) n.exprs.push_back(ir[i].exprs[j]);
+    for (int j = 0; j < ir[i].n_keys; j++) n.keys.push_back(ir[i].keys[j]);
+    for (int j = 0; j < ir[i].n_keys_right; j++) n.keys_right.push_back(ir[i].keys_right[j]);
+    n.how = ir[i].how; n.maintain_order = ir[i].maintain_order;
+    if (ir[i].suffix) n.suffix = ir[i].suffix;
+    auto chk = [&](int e) { PLX_REQUIRE(e >= 0 && e < n_ae, PLX_ERR_INVALID, "IR node references an expression outside the arena"); };
+    for (int e : n.exprs) chk(e);
+    for (int e : n.keys) chk(e);
+    for (int e : n.keys_right) chk(e);
+    if (n.kind == PLX_IR_FILTER) chk(n.predicate);
+    PLX_REQUIRE(n.input < i && n.input_right < i, PLX_ERR_INVALID, "IR arena must be topologically ordered (inputs before consumers)");
+    p.ir.push_back(std::move(n));
+  }
+  return p;
+}
+
+// -------------------------------------------------------------- dtype rules ----
+static int sum_out_dtype(int dt) {
+  switch (dt) {
+    case PLX_BOOL: return PLX_U32;
+    case PLX_I8: case PLX_I16: case PLX_U8: case PLX_U16: return PLX_I64;
+    default: return dt;
+  }
+}
+static bool is_cmp_op(int op) { return op >= PLX_OP_EQ && op <= PLX_OP_GE; }
+static bool is_arith_op(int op) { return op >= PLX_OP_PLUS && op <= PLX_OP_MODULUS; }
+static bool is_logic_op(int op) { return op >= PLX_OP_AND && op <= PLX_OP_XOR; }
+
+int infer_dtype(const Plan& plan, int e, const Frame& schema) {
+  const AE& x = plan.ae.at(e);
+  switch (x.kind) {
+    case PLX_AE_COLUMN: {
+      int i = schema.find(x.name);
+      if (i < 0) fail(PLX_ERR_NOT_FOUND, "column not found: " + x.name);
+      return schema.cols[i]->dtype;
+    }
+    case PLX_AE_LITERAL: return x.dtype;
+    case PLX_AE_ALIAS: return infer_dtype(plan, x.lhs, schema);
+    case PLX_AE_CAST: return x.dtype;
+    case PLX_AE_NOT: return PLX_BOOL;
+    case PLX_AE_LEN: return PLX_U32;
+    case PLX_AE_AGG: {
+      int in = infer_dtype(plan, x.lhs, schema);
+      switch (x.op) {
+        case PLX_AGG_SUM: return sum_out_dtype(in);
+        case PLX_AGG_MEAN: return in == PLX_F32 ? PLX_F32 : PLX_F64;
+        case PLX_AGG_COUNT: case PLX_AGG_LEN: return PLX_U32;
+        default: return in;
+      }
+    }
+    case PLX_AE_BINARY: {
+      int l = infer_dtype(plan, x.lhs, schema), r = infer_dtype(plan, x.rhs, schema);
+      if (is_cmp_op(x.op) || is_logic_op(x.op)) return PLX_BOOL;
+      PLX_REQUIRE(l == r, PLX_ERR_INVALID, std::string("binary expression operands have different dtypes (") + dtype_name(l) + ", " + dtype_name(r) + "); the optimizer's type coercion must insert casts");
+      if (x.op == PLX_OP_TRUE_DIVIDE && !dtype_is_float(l)) return PLX_F64;
+      return l;
+    }
+    default: fail(PLX_ERR_UNSUPPORTED, "unsupported AExpr kind " + std::to_string(x.kind));
+  }
+}
+
+std::string output_name(const Plan& plan, int e) {
+  const AE& x = plan.ae.at(e);
+  switch (x.kind) {
+    case PLX_AE_ALIAS: return x.name;
+    case PLX_AE_COLUMN: return x.name;
+    case PLX_AE_LITERAL: return "literal";
+    case PLX_AE_LEN: return "len";
+    default: return x.lhs >= 0 ? output_name(plan, x.lhs) : "literal";  // leftmost leaf, like polars
+  }
+}
+
+static bool contains_agg(const Plan& plan, int e) {
+  if (e < 0) return false;
+  const AE& x = plan.ae[e];
+  if (x.kind == PLX_AE_AGG || x.kind == PLX_AE_LEN) return true;
+  return contains_agg(plan, x.lhs) || contains_agg(plan, x.rhs);
+}
+static bool contains_column_outside_agg(const Plan& plan, int e) {
+  if (e < 0) return false;
+  const AE& x = plan.ae[e];
+  if (x.kind == PLX_AE_AGG || x.kind == PLX_AE_LEN) return false;
+  if (x.kind == PLX_AE_COLUMN) return true;
+  return contains_column_outside_agg(plan, x.lhs) || contains_column_outside_agg(plan, x.rhs);
+}
+static void collect_aggs(const Plan& plan, int e, std::vector<int>& out) {
+  if (e < 0) return;
+  const AE& x = plan.ae[e];
+  if (x.kind == PLX_AE_AGG || x.kind == PLX_AE_LEN) { if (std::find(out.begin(), out.end(), e) == out.end()) out.push_back(e); return; }
+  collect_aggs(plan, x.lhs, out);
+  collect_aggs(plan, x.rhs, out);
+}
+
+// -------------------------------------------------- materialising evaluator ----
+// One kernel per node; every node materialises its column (reference-shaped).
+// `overrides` maps expression ids to precomputed columns (aggregation results).
+struct Evaluated { ColumnPtr col; bool scalar; };  // scalar: length-1, broadcastable
+
+static plx_scalar scalar_of(const ColumnPtr& c, bool* valid) {
+  plx_scalar s; s.u = 0;
+  uint8_t v = 0xff; int32_t hv = 0;
+  uint64_t buf[2] = {0, 0};
+  column_to_host(c, buf, &v, &hv);
+  *valid = v & 1;
+  if (c->dtype == PLX_BOOL) s.u = buf[0] & 1; else memcpy(&s, buf, (size_t)dtype_width(c->dtype));
+  return s;
+}
+
+static Evaluated eval(const Plan& plan, int e, const Frame& df, const std::map<int, ColumnPtr>* overrides) {
+  check_cancel();
+  if (overrides) { auto it = overrides->find(e); if (it != overrides->end()) return {it->second, false}; }
+  const AE& x = plan.ae.at(e);
+  switch (x.kind) {
+    case PLX_AE_COLUMN: {
+      int i = df.find(x.name);
+      if (i < 0) fail(PLX_ERR_NOT_FOUND, "column not found: " + x.name);
+      return {df.cols[i], false};
+    }
+    case PLX_AE_LITERAL: return {ops::full_column(x.dtype, x.lit, !x.is_null, 1), true};
+    case PLX_AE_ALIAS: return eval(plan, x.lhs, df, overrides);
+    case PLX_AE_CAST: { Evaluated c = eval(plan, x.lhs, df, overrides); return {ops::cast(c.col, x.dtype), c.scalar}; }
+    case PLX_AE_NOT: { Evaluated c = eval(plan, x.lhs, df, overrides); return {ops::bool_not(c.col), c.scalar}; }
+    case PLX_AE_LEN: { ops::ScalarValue s; s.dtype = PLX_U32; s.valid = true; s.v.u = (uint32_t)df.height; return {ops::scalar_column(s), true}; }
+    case PLX_AE_AGG: {
+      Evaluated c = eval(plan, x.lhs, df, overrides);
+      return {ops::scalar_column(ops::reduce(x.op, c.col)), true};
+    }
+    case PLX_AE_BINARY: {
+      Evaluated l = eval(plan, x.lhs, df, overrides), r = eval(plan, x.rhs, df, overrides);
+      const bool both_scalar = l.scalar && r.scalar;
+      if (is_logic_op(x.op)) {
+        ColumnPtr a = l.col, b = r.col;
+        if (l.scalar && !r.scalar) { bool v; plx_scalar s = scalar_of(a, &v); a = ops::full_column(PLX_BOOL, s, v, b->len); }
+        if (r.scalar && !l.scalar) { bool v; plx_scalar s = scalar_of(b, &v); b = ops::full_column(PLX_BOOL, s, v, a->len); }
+        return {ops::bool_binop(x.op - PLX_OP_AND, a, b), both_scalar};
+      }
+      if (is_cmp_op(x.op)) {
+        const int op = x.op - PLX_OP_EQ;
+        if (r.scalar && !l.scalar) { bool v; plx_scalar s = scalar_of(r.col, &v); PLX_REQUIRE(l.col->dtype == r.col->dtype, PLX_ERR_INVALID, "cmp: dtype mismatch"); return {ops::cmp_scalar(op, l.col, s, !v), false}; }
+        if (l.scalar && !r.scalar) {
+          // lit OP col == col OP' lit with the operator mirrored
+          static const int mirror[6] = {PLX_EQ, PLX_NE, PLX_GT, PLX_GE, PLX_LT, PLX_LE};
+          bool v; plx_scalar s = scalar_of(l.col, &v); PLX_REQUIRE(l.col->dtype == r.col->dtype, PLX_ERR_INVALID, "cmp: dtype mismatch");
+          return {ops::cmp_scalar(mirror[op], r.col, s, !v), false};
+        }
+        return {ops::cmp(op, l.col, r.col), both_scalar};
+      }
+      PLX_REQUIRE(is_arith_op(x.op), PLX_ERR_UNSUPPORTED, "unsupported operator");
+      const int op = x.op - PLX_OP_PLUS;
+      if (r.scalar && !l.scalar) {
+        bool v; plx_scalar s = scalar_of(r.col, &v);
+        PLX_REQUIRE(l.col->dtype == r.col->dtype, PLX_ERR_INVALID, "arith: dtype mismatch");
+        if (!v) return {ops::full_column(op == PLX_TRUE_DIV && !dtype_is_float(l.col->dtype) ? PLX_F64 : l.col->dtype, plx_scalar{0}, false, l.col->len), false};
+        return {ops::arith_scalar(op, l.col, s, false), false};
+      }
+      if (l.scalar && !r.scalar) {
+        bool v; plx_scalar s = scalar_of(l.col, &v);
+        PLX_REQUIRE(l.col->dtype == r.col->dtype, PLX_ERR_INVALID, "arith: dtype mismatch");
+        if (!v) return {ops::full_column(op == PLX_TRUE_DIV && !dtype_is_float(r.col->dtype) ? PLX_F64 : r.col->dtype, plx_scalar{0}, false, r.col->len), false};
+        return {ops::arith_scalar(op, r.col, s, true), false};
+      }
+      return {ops::arith(op, l.col, r.col), both_scalar};
+    }
+    default: fail(PLX_ERR_UNSUPPORTED, "unsupported AExpr kind");
+  }
+}
+
+static ColumnPtr broadcast(const Evaluated& ev, int64_t height) {
+  if (!ev.scalar || ev.col->len == height) return ev.col;
+  bool v; plx_scalar s = scalar_of(ev.col, &v);
+  return ops::full_column(ev.col->dtype, s, v, height);
+}
+
+// ----------------------------------------------------- fused program compiler ----
+struct DNode {
+  uint8_t code = OP_NOP, c = 0;
+  int a = -1, b = -1;
+  uint64_t imm = 0;
+  int col = -1;     // frame column index for OP_LOAD
+  char ty = 'i';    // 'i' signed, 'u' unsigned 64, 'f' f64, 'b' bool
+  bool nullable = false;
+  int uses = 0, slot = -1;
+  bool emitted = false;
+};
+
+class Compiler {
+ public:
+  Compiler(const Plan& p, const Frame& f) : plan(p), df(f) {}
+  const Plan& plan;
+  const Frame& df;
+  std::vector<DNode> nodes;
+  std::map<std::string, int> memo;
+  std::vector<std::pair<uint8_t, int>> aggs;  // (kind, src node or -1)
+  int pred = -1, key = -1;
+
+  int add(DNode n) {
+    std::ostringstream k;
+    k << (int)n.code << ':' << n.a << ':' << n.b << ':' << (int)n.c << ':' << n.imm << ':' << n.col << ':' << n.ty;
+    auto it = memo.find(k.str());
+    if (it != memo.end()) return it->second;
+    nodes.push_back(n);
+    memo[k.str()] = (int)nodes.size() - 1;
+    return (int)nodes.size() - 1;
+  }
+  int mk(uint8_t code, int a, int b, char ty, uint8_t c = 0) {
+    DNode n; n.code = code; n.a = a; n.b = b; n.ty = ty; n.c = c;
+    n.nullable = (a >= 0 && nodes[a].nullable) || (b >= 0 && nodes[b].nullable);
+    return add(n);
+  }
+  int konst(uint64_t bits, char ty) { DNode n; n.code = OP_CONST; n.imm = bits; n.ty = ty; return add(n); }
+  int konst_f(double d) { uint64_t b; memcpy(&b, &d, 8); return konst(b, 'f'); }
+  int ifnull(int a, uint64_t code) { DNode n; n.code = OP_IFNULL; n.a = a; n.b = a; n.imm = code; n.ty = nodes[a].ty; n.nullable = false; return add(n); }
+  int load(int col) {
+    const ColumnPtr& c = df.cols[col];
+    DNode n; n.code = OP_LOAD; n.col = col; n.nullable = (bool)c->validity || c->null_count > 0;
+    switch (c->dtype) {
+      case PLX_F64: n.ty = 'f'; break;
+      case PLX_U64: n.ty = 'u'; break;
+      case PLX_BOOL: n.ty = 'b'; break;
+      case PLX_F32: throw Unsupported("f32 columns are evaluated in f32 by the per-node kernels, not in the f64 fused program");
+      default: n.ty = 'i'; break;
+    }
+    return add(n);
+  }
+  static uint64_t widen_literal(int dt, plx_scalar s) {
+    switch (dt) {
+      case PLX_I8: return (uint64_t)(int64_t)(int8_t)s.u;
+      case PLX_I16: return (uint64_t)(int64_t)(int16_t)s.u;
+      case PLX_I32: return (uint64_t)(int64_t)(int32_t)s.u;
+      case PLX_U8: return s.u & 0xff;
+      case PLX_U16: return s.u & 0xffff;
+      case PLX_U32: return s.u & 0xffffffffull;
+      case PLX_BOOL: return s.u & 1;
+      default: return s.u;
+    }
+  }
+  bool is_literal(int e, double* as_f64, int dt_hint) const {
+    const AE* x = &plan.ae[e];
+    while (x->kind == PLX_AE_ALIAS) x = &plan.ae[x->lhs];
+    if (x->kind != PLX_AE_LITERAL || x->is_null) return false;
+    switch (x->dtype) {
+      case PLX_F64: *as_f64 = x->lit.f64; return true;
+      case PLX_F32: *as_f64 = x->lit.f32; return true;
+      case PLX_U64: *as_f64 = (double)x->lit.u; return true;
+      case PLX_BOOL: return false;
+      default: *as_f64 = (double)(int64_t)widen_literal(x->dtype, x->lit); return true;
+    }
+    (void)dt_hint;
+  }
+
+  int lower(int e) {
+    const AE& x = plan.ae.at(e);
+    switch (x.kind) {
+      case PLX_AE_COLUMN: {
+        int i = df.find(x.name);
+        if (i < 0) fail(PLX_ERR_NOT_FOUND, "column not found: " + x.name);
+        return load(i);
+      }
+      case PLX_AE_LITERAL: {
+        if (x.is_null) throw Unsupported("null literal");
+        if (x.dtype == PLX_F32) throw Unsupported("f32 literal");
+        char ty = x.dtype == PLX_F64 ? 'f' : x.dtype == PLX_U64 ? 'u' : x.dtype == PLX_BOOL ? 'b' : 'i';
+        return konst(widen_literal(x.dtype, x.lit), ty);
+      }
+      case PLX_AE_ALIAS: return lower(x.lhs);
+      case PLX_AE_NOT: { int a = lower(x.lhs); if (nodes[a].ty != 'b') throw Unsupported("not on non-boolean"); return mk(OP_NOT, a, a, 'b'); }
+      case PLX_AE_CAST: {
+        int from = infer_dtype(plan, x.lhs, df), to = x.dtype;
+        int a = lower(x.lhs);
+        if (from == to) return a;
+        if (to == PLX_F64 && dtype_is_int(from)) return mk(nodes[a].ty == 'u' ? OP_U2F : OP_I2F, a, a, 'f');
+        if (dtype_is_int(from) && (to == PLX_I64) && from != PLX_U64) return a;  // value-preserving widening
+        if (dtype_is_unsigned(from) && to == PLX_U64) return a;
+        throw Unsupported(std::string("cast ") + dtype_name(from) + " -> " + dtype_name(to) + " inside a fused program");
+      }
+      case PLX_AE_BINARY: {
+        int ldt = infer_dtype(plan, x.lhs, df), rdt = infer_dtype(plan, x.rhs, df);
+        if (is_logic_op(x.op)) {
+          int a = lower(x.lhs), b = lower(x.rhs);
+          if (nodes[a].ty != 'b' || nodes[b].ty != 'b') throw Unsupported("bitwise and/or on integers");
+          int n = mk(x.op == PLX_OP_AND ? OP_AND : x.op == PLX_OP_OR ? OP_OR : OP_XOR, a, b, 'b');
+          return n;
+        }
+        if (ldt != rdt) fail(PLX_ERR_INVALID, std::string("binary expression operands have different dtypes (") + dtype_name(ldt) + ", " + dtype_name(rdt) + ")");
+        if (is_cmp_op(x.op)) {
+          if (ldt == PLX_BOOL) throw Unsupported("comparison of boolean columns");
+          int a = lower(x.lhs), b = lower(x.rhs);
+          uint8_t code = nodes[a].ty == 'f' ? OP_CMP_F : nodes[a].ty == 'u' ? OP_CMP_U : OP_CMP_I;
+          return mk(code, a, b, 'b', (uint8_t)(x.op - PLX_OP_EQ));
+        }
+        if (!(ldt == PLX_I64 || ldt == PLX_U64 || ldt == PLX_F64)) throw Unsupported(std::string("arithmetic on ") + dtype_name(ldt) + " wraps at the column width; done by the per-node kernels");
+        const bool f = ldt == PLX_F64;
+        switch (x.op) {
+          case PLX_OP_PLUS: { int a = lower(x.lhs), b = lower(x.rhs); return mk(f ? OP_ADD_F : OP_ADD_I, a, b, nodes[a].ty); }
+          case PLX_OP_MINUS: { int a = lower(x.lhs), b = lower(x.rhs); return mk(f ? OP_SUB_F : OP_SUB_I, a, b, nodes[a].ty); }
+          case PLX_OP_MULTIPLY: { int a = lower(x.lhs), b = lower(x.rhs); return mk(f ? OP_MUL_F : OP_MUL_I, a, b, nodes[a].ty); }
+          case PLX_OP_TRUE_DIVIDE: {
+            int a = lower(x.lhs);
+            if (!f) a = mk(nodes[a].ty == 'u' ? OP_U2F : OP_I2F, a, a, 'f');
+            double lit;
+            if (is_literal(x.rhs, &lit, rdt)) {
+              // col / lit == col * (1 / lit)  (float.rs:113-115, signed.rs:218-221)
+              int inv = konst_f(1.0 / lit);
+              return mk(OP_MUL_F, a, inv, 'f');
+            }
+            int b = lower(x.rhs);
+            if (!f) b = mk(nodes[b].ty == 'u' ? OP_U2F : OP_I2F, b, b, 'f');
+            return mk(OP_DIV_F, a, b, 'f');
+          }
+          default: throw Unsupported("floor-div / mod inside a fused program");
+        }
+      }
+      default: throw Unsupported("aggregation nested inside a row expression");
+    }
+  }
+
+  int add_agg(uint8_t kind, int src) {
+    for (size_t i = 0; i < aggs.size(); i++) if (aggs[i].first == kind && aggs[i].second == src) return (int)i;
+    if ((int)aggs.size() >= kMaxAggs) throw Unsupported("more than " + std::to_string(kMaxAggs) + " distinct aggregates in one pass");
+    aggs.push_back({kind, src});
+    return (int)aggs.size() - 1;
+  }
+  int count_agg(int src) { return nodes[src].nullable ? add_agg(AGG_COUNT, src) : add_agg(AGG_LEN, -1); }
+
+  // lowers one AGG / LEN node; returns how to finalise it
+  FinalSpec lower_agg(int e) {
+    const AE& x = plan.ae.at(e);
+    FinalSpec fs{}; fs.a = fs.b = fs.c = kNone;
+    if (x.kind == PLX_AE_LEN) { fs.kind = FIN_TRUNC32; fs.a = (uint8_t)add_agg(AGG_LEN, -1); fs.out_dtype = PLX_U32; return fs; }
+    const int in_dt = infer_dtype(plan, x.lhs, df);
+    if (x.op == PLX_AGG_LEN) { fs.kind = FIN_TRUNC32; fs.a = (uint8_t)add_agg(AGG_LEN, -1); fs.out_dtype = PLX_U32; return fs; }
+    if (in_dt == PLX_BOOL && x.op != PLX_AGG_COUNT) throw Unsupported("aggregating a boolean expression");
+    int src = lower(x.lhs);
+    switch (x.op) {
+      case PLX_AGG_SUM:
+        fs.out_dtype = (uint8_t)sum_out_dtype(in_dt);
+        if (in_dt == PLX_F64) { fs.kind = FIN_COPY64; fs.a = (uint8_t)add_agg(AGG_SUM_F, src); }
+        else { fs.kind = dtype_width(fs.out_dtype) == 4 ? FIN_TRUNC32 : FIN_COPY64; fs.a = (uint8_t)add_agg(AGG_SUM_I, src); }
+        return fs;
+      case PLX_AGG_MEAN: {
+        int sf = src;
+        if (in_dt != PLX_F64) sf = mk(nodes[src].ty == 'u' ? OP_U2F : OP_I2F, src, src, 'f');
+        fs.kind = FIN_MEAN; fs.a = (uint8_t)add_agg(AGG_SUM_F, sf); fs.b = (uint8_t)count_agg(src); fs.out_dtype = PLX_F64;
+        return fs;
+      }
+      case PLX_AGG_MIN: case PLX_AGG_MAX: {
+        const bool mn = x.op == PLX_AGG_MIN;
+        fs.out_dtype = (uint8_t)in_dt;
+        if (in_dt == PLX_F64) { fs.kind = FIN_MINMAX_F; fs.a = (uint8_t)add_agg(mn ? AGG_MIN_F : AGG_MAX_F, src); fs.b = (uint8_t)count_agg(src); fs.c = (uint8_t)add_agg(AGG_COUNT_ORD, src); }
+        else { fs.kind = FIN_MINMAX_I; fs.a = (uint8_t)add_agg(nodes[src].ty == 'u' ? (mn ? AGG_MIN_U : AGG_MAX_U) : (mn ? AGG_MIN_I : AGG_MAX_I), src); fs.b = (uint8_t)count_agg(src); }
+        return fs;
+      }
+      case PLX_AGG_COUNT: fs.kind = FIN_TRUNC32; fs.a = (uint8_t)count_agg(src); fs.out_dtype = PLX_U32; return fs;
+      default: throw Unsupported("aggregation kind");
+    }
+  }
+
+  // ---- scheduling: DFS post-order, lowest-free-slot allocation, slots freed at last use
+  Shape shape{};
+  Args args{};
+  std::vector<int> input_cols;
+  std::vector<bool> slot_busy = std::vector<bool>(kSlots, false);
+
+  void count_uses(int n, std::vector<bool>& seen) {
+    if (n < 0) return;
+    nodes[n].uses++;
+    if (seen[n]) return;
+    seen[n] = true;
+    if (nodes[n].code != OP_LOAD && nodes[n].code != OP_CONST) {
+      count_uses(nodes[n].a, seen);
+      if (nodes[n].b != nodes[n].a) count_uses(nodes[n].b, seen);
+    }
+  }
+  void release(int n) {
+    if (n < 0) return;
+    if (--nodes[n].uses == 0) slot_busy[nodes[n].slot] = false;
+  }
+  int emit(int n) {
+    DNode& d = nodes[n];
+    if (d.emitted) return d.slot;
+    const bool leaf = d.code == OP_LOAD || d.code == OP_CONST;
+    int sa = -1, sb = -1;
+    if (!leaf) {
+      sa = emit(d.a);
+      sb = (d.b == d.a) ? sa : emit(d.b);
+      release(d.a);
+      if (d.b != d.a) release(d.b);
+    }
+    int slot = -1;
+    for (int s = 0; s < kSlots; s++) if (!slot_busy[s]) { slot = s; break; }
+    if (slot < 0) throw Unsupported("expression needs more than 16 live values");
+    slot_busy[slot] = true;
+    if (shape.n_ops >= kMaxOps) throw Unsupported("expression program longer than 32 ops");
+    const int pc = shape.n_ops++;
+    Op op{}; op.code = d.code; op.dst = (uint8_t)slot; op.c = d.c;
+    if (d.code == OP_LOAD) {
+      int idx = -1;
+      for (size_t i = 0; i < input_cols.size(); i++) if (input_cols[i] == d.col) idx = (int)i;
+      if (idx < 0) {
+        if ((int)input_cols.size() >= kMaxInputs) throw Unsupported("more than 10 input columns");
+        input_cols.push_back(d.col); idx = (int)input_cols.size() - 1;
+        const ColumnPtr& c = df.cols[d.col];
+        shape.in_dtype[idx] = (uint8_t)c->dtype; shape.in_nullable[idx] = d.nullable ? 1 : 0;
+        args.in[idx].values = c->data(); args.in[idx].validity = c->valid_words();
+      }
+      op.a = (uint8_t)idx;
+    } else if (d.code == OP_CONST) {
+      args.imm[pc] = d.imm;
+    } else {
+      op.a = (uint8_t)sa; op.b = (uint8_t)sb;
+      if (d.code == OP_IFNULL) args.imm[pc] = d.imm;
+    }
+    shape.ops[pc] = op;
+    d.slot = slot; d.emitted = true;
+    return slot;
+  }
+  void finish() {
+    std::vector<bool> seen(nodes.size(), false);
+    std::vector<int> roots;
+    if (pred >= 0) roots.push_back(pred);
+    if (key >= 0) roots.push_back(key);
+    for (auto& a : aggs) if (a.second >= 0) roots.push_back(a.second);
+    for (int r : roots) count_uses(r, seen);   // each root reference holds its slot to the end
+    shape.pred = kNone; shape.key = kNone;
+    if (pred >= 0) shape.pred = (uint8_t)emit(pred);
+    if (key >= 0) shape.key = (uint8_t)emit(key);
+    shape.n_aggs = (uint8_t)aggs.size();
+    for (size_t i = 0; i < aggs.size(); i++) {
+      shape.aggs[i].kind = aggs[i].first;
+      shape.aggs[i].src = aggs[i].second >= 0 ? (uint8_t)emit(aggs[i].second) : 0;
+    }
+    shape.n_inputs = (uint8_t)input_cols.size();
+    args.n_rows = df.height;
+  }
+};
+
+// ----------------------------------------------------------- group keys -----------
+struct KeyPart {
+  int expr = -1;
+  int dtype = 0;
+  KeyDecode dec{};
+};
+struct KeyPlan {
+  std::vector<KeyPart> parts;
+  bool packed = false;   // keys bit-packed into a dense id (always valid)
+  int total_bits = 64;
+};
+
+static int ceil_log2_u64(uint64_t x) { int b = 0; while (b < 64 && (1ull << b) < x) b++; return b; }
+
+// Lowers the group keys into one 64-bit key node. Narrow / multi-column keys are packed
+// using column min/max statistics; a single wide key is used raw.
+static KeyPlan lower_keys(Compiler& c, const std::vector<int>& key_exprs) {
+  KeyPlan kp;
+  const Plan& plan = c.plan;
+  const int nk = (int)key_exprs.size();
+  std::vector<int> knodes(nk);
+  struct Info { bool have_range = false; int64_t mn = 0, mx = 0; bool nullable = false; ColumnPtr col; };
+  std::vector<Info> info(nk);
+  bool all_packable = true;
+  for (int i = 0; i < nk; i++) {
+    const int e = key_exprs[i];
+    KeyPart part; part.expr = e; part.dtype = infer_dtype(plan, e, c.df);
+    knodes[i] = c.lower(e);
+    info[i].nullable = c.nodes[knodes[i]].nullable;
+    const AE* x = &plan.ae[e];
+    while (x->kind == PLX_AE_ALIAS) x = &plan.ae[x->lhs];
+    if (part.dtype == PLX_BOOL) { info[i].have_range = true; info[i].mn = 0; info[i].mx = 1; }
+    else if (dtype_is_int(part.dtype) && x->kind == PLX_AE_COLUMN) {
+      ColumnPtr col = c.df.cols[c.df.find(x->name)];
+      const bool cheap = dtype_width(part.dtype) <= 2 || nk > 1 || col->range_state != 0;
+      if (part.dtype == PLX_U64) all_packable = false;
+      else if (cheap) {
+        if (col->values && ops::int_range(col, &info[i].mn, &info[i].mx)) info[i].have_range = true;
+        else if (col->range_state == 1) { info[i].have_range = true; info[i].mn = col->range_min; info[i].mx = col->range_max; }
+        else if (col->range_state == 2) { info[i].have_range = true; info[i].mn = 0; info[i].mx = 0; }
+        else all_packable = false;
+      } else all_packable = false;
+    } else all_packable = false;
+    kp.parts.push_back(part);
+  }
+  int bits_total = 0;
+  std::vector<int> bits(nk, 0);
+  if (all_packable) {
+    for (int i = 0; i < nk; i++) {
+      unsigned __int128 range = (unsigned __int128)((__int128)info[i].mx - (__int128)info[i].mn) + 1 + (info[i].nullable ? 1 : 0);
+      if (range > ((unsigned __int128)1 << 62)) { all_packable = false; break; }
+      bits[i] = std::max(1, ceil_log2_u64((uint64_t)range));
+      bits_total += bits[i];
+    }
+    if (bits_total > 62) all_packable = false;
+  }
+  if (all_packable) {
+    kp.packed = true; kp.total_bits = bits_total;
+    int acc = -1, shift = 0;
+    for (int i = 0; i < nk; i++) {
+      int n = knodes[i];
+      if (info[i].mn != 0) n = c.mk(OP_SUB_I, n, c.konst((uint64_t)info[i].mn, 'i'), 'i');
+      const uint64_t null_code = info[i].nullable ? (uint64_t)((__int128)info[i].mx - (__int128)info[i].mn + 1) : ~0ull;
+      if (info[i].nullable) n = c.ifnull(n, null_code);
+      if (shift) n = c.mk(OP_MUL_I, n, c.konst(1ull << shift, 'i'), 'i');
+      acc = acc < 0 ? n : c.mk(OP_ADD_I, acc, n, 'i');
+      KeyDecode& d = kp.parts[i].dec;
+      d.shift = shift; d.mask = (1ull << bits[i]) - 1; d.min = info[i].mn; d.null_code = null_code; d.dtype = kp.parts[i].dtype;
+      shift += bits[i];
+    }
+    c.key = acc;
+    return kp;
+  }
+  if (nk != 1) throw Unsupported("multi-column group keys that do not pack into 62 bits need row encoding (polars-row), not on this path yet");
+  int n = knodes[0];
+  if (kp.parts[0].dtype == PLX_F64) n = c.mk(OP_CANON_F, n, n, 'f');
+  c.key = n;
+  KeyDecode& d = kp.parts[0].dec;
+  d.shift = 0; d.mask = ~0ull; d.min = 0; d.null_code = ~0ull; d.dtype = kp.parts[0].dtype;  // raw key: nullness comes from the valid flag
+  kp.packed = false; kp.total_bits = 64;
+  return kp;
+}
+
+// ------------------------------------------------------ fused pipeline driver -----
+struct FusedAggResult {
+  int64_t n_groups = 0;
+  Buf acc;            // [n_groups][n_aggs] cells
+  Buf packed_keys;    // [n_groups] u64 (group-by only)
+  Buf key_valid;      // [n_groups] u8 flags (raw keys) or null
+  int n_aggs = 0;
+};
+
+static uint64_t next_pow2(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
+
+// distinct-count estimate from a sample: solve d = G (1 - exp(-S / G)) for G
+static double estimate_groups(double d, double S) {
+  if (d >= S * 0.999) return 1e18;
+  double lo = d, hi = 1e15;
+  for (int it = 0; it < 200; it++) { double mid = std::sqrt(lo * hi); double f = mid * (1.0 - std::exp(-S / mid)); if (f < d) lo = mid; else hi = mid; }
+  return hi;
+}
+
+static int64_t run_hash_agg(const Shape& sh, const Args& args, int static_id, int log2_cap, int len_idx, FusedAggResult& out, bool count_only) {
+  const uint64_t cap = 1ull << log2_cap;
+  const int64_t slots = (int64_t)cap + 2;
+  Buf keys = dev_alloc(sizeof(uint64_t) * (size_t)slots);
+  Buf acc = dev_alloc(sizeof(uint64_t) * (size_t)slots * sh.n_aggs);
+  Buf ovf = dev_alloc_zero(8);
+  k::fill_u64(keys->as<uint64_t>(), slots, kEmptyKey);
+  k::init_agg_cells(acc->as<uint64_t>(), slots, sh);
+  HashTable t; t.keys = keys->as<unsigned long long>(); t.acc = acc->as<unsigned long long>(); t.overflow = ovf->as<unsigned int>();
+  t.log2_cap = (uint32_t)log2_cap; t.max_probe = (uint32_t)std::min<uint64_t>(cap, 1u << 14);
+  k::fused_hash_agg(sh, args, t, static_id);
+  uint32_t o = 0; d2h_sync(&o, ovf->ptr, 4);
+  if (o) return -1;
+  if (count_only) return k::table_compact(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, nullptr, nullptr, nullptr);
+  // compact: upper bound on groups = occupied slots; allocate by counting first
+  int64_t g = k::table_compact(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, nullptr, nullptr, nullptr);
+  out.n_groups = g; out.n_aggs = sh.n_aggs;
+  out.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1));
+  out.key_valid = dev_alloc(std::max<int64_t>(g, 1));
+  out.acc = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1) * sh.n_aggs);
+  k::table_compact(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, out.packed_keys->as<uint64_t>(), out.key_valid->as<uint8_t>(), out.acc->as<uint64_t>());
+  (void)len_idx;
+  return g;
+}
+
+static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, FusedAggResult& res, std::string& desc) {
+  const Shape& sh = c.shape;
+  const Args& args = c.args;
+  const int static_id = find_static_shape(sh);
+  const int64_t n = args.n_rows;
+  res.n_aggs = sh.n_aggs;
+  if (n == 0) { res.n_groups = 0; res.acc = dev_alloc(8); res.packed_keys = dev_alloc(8); return; }
+  if (kp.packed && kp.total_bits <= 12 && k::lds_agg_copies(1 << kp.total_bits, sh.n_aggs) > 0) {
+    const int G = 1 << kp.total_bits;
+    Buf cells = dev_alloc(sizeof(uint64_t) * (size_t)G * sh.n_aggs);
+    k::fused_lds_agg(sh, args, G, static_id, cells->as<uint64_t>());
+    desc += std::string("fused_scan[") + (static_id >= 0 ? "aot" : "generic") + "]+lds_table(G=" + std::to_string(G) + ",copies=" + std::to_string(k::lds_agg_copies(G, sh.n_aggs)) + ")";
+    int64_t g = k::table_compact(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, nullptr, nullptr, nullptr);
+    res.n_groups = g;
+    res.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1));
+    res.key_valid = dev_alloc(std::max<int64_t>(g, 1));
+    res.acc = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1) * sh.n_aggs);
+    k::table_compact(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, res.packed_keys->as<uint64_t>(), res.key_valid->as<uint8_t>(), res.acc->as<uint64_t>());
+    res.key_valid = nullptr;  // packed keys carry their own null codes
+    return;
+  }
+  if (kp.packed && kp.total_bits <= 28 && ((size_t)sh.n_aggs << (kp.total_bits + 3)) <= (size_t(8) << 30)) {
+    const int64_t G = (int64_t)1 << kp.total_bits;
+    Buf cells = dev_alloc(sizeof(uint64_t) * (size_t)(G + 1) * sh.n_aggs);
+    k::init_agg_cells(cells->as<uint64_t>(), G + 1, sh);
+    DenseTable t; t.acc = cells->as<unsigned long long>(); t.key_min = 0; t.n_groups = G;
+    k::fused_dense_agg(sh, args, t, static_id);
+    desc += std::string("fused_scan[") + (static_id >= 0 ? "aot" : "generic") + "]+dense_hbm_table(G=" + std::to_string(G) + ")";
+    int64_t g = k::table_compact(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, nullptr, nullptr, nullptr);
+    res.n_groups = g;
+    res.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1));
+    res.key_valid = dev_alloc(std::max<int64_t>(g, 1));
+    res.acc = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1) * sh.n_aggs);
+    k::table_compact(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, res.packed_keys->as<uint64_t>(), res.key_valid->as<uint8_t>(), res.acc->as<uint64_t>());
+    res.key_valid = nullptr;
+    return;
+  }
+  // hash table: size from a sampled distinct-count estimate, grow x4 on overflow
+  int log2_cap;
+  const int64_t S = (int64_t)1 << 22;
+  if (n <= 2 * S) log2_cap = std::max(10, ceil_log2_u64((uint64_t)n * 2));
+  else {
+    Args sa = args; sa.n_rows = S;
+    FusedAggResult tmp;
+    int64_t d = run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true);
+    double G = d < 0 ? 1e18 : estimate_groups((double)d, (double)S);
+    G = std::min(G, (double)n);
+    log2_cap = std::max(12, ceil_log2_u64((uint64_t)(G * 2.0) + 1));
+    desc += "sample(distinct=" + std::to_string(d) + "/" + std::to_string(S) + ")+";
+  }
+  for (int attempt = 0; attempt < 8; attempt++) {
+    int64_t g = run_hash_agg(sh, args, static_id, log2_cap, len_idx, res, false);
+    if (g >= 0) {
+      desc += std::string("fused_scan[") + (static_id >= 0 ? "aot" : "generic") + "]+hash_hbm_table(cap=2^" + std::to_string(log2_cap) + ")";
+      return;
+    }
+    log2_cap += 2;
+    desc += "grow+";
+    PLX_REQUIRE(log2_cap <= 34, PLX_ERR_OOM, "group-by hash table would exceed 2^34 slots");
+  }
+  fail(PLX_ERR_OOM, "group-by hash table kept overflowing");
+}
+
+static ColumnPtr finalize_column(const FusedAggResult& r, const FinalSpec& fs) {
+  const int64_t G = r.n_groups;
+  auto out = std::make_shared<Column>();
+  out->dtype = fs.out_dtype; out->len = G;
+  out->values = dev_alloc(values_bytes(fs.out_dtype, G));
+  const bool nullable = fs.kind == FIN_MEAN || fs.kind == FIN_MINMAX_I || fs.kind == FIN_MINMAX_F;
+  if (nullable) out->validity = dev_alloc_zero(bitmap_bytes(G)); else out->null_count = 0;
+  FinalSpec f = fs;
+  if (fs.kind == FIN_COPY64 && dtype_width(fs.out_dtype) < 4) f.kind = FIN_NARROW;
+  k::finalize_aggs(r.acc->as<uint64_t>(), r.n_aggs, G, f, out->values->ptr, nullable ? out->validity->as<uint64_t>() : nullptr);
+  return out;
+}
+
+static ColumnPtr decode_key_column(const FusedAggResult& r, const KeyPart& part) {
+  const int64_t G = r.n_groups;
+  auto out = std::make_shared<Column>();
+  out->dtype = part.dtype; out->len = G;
+  out->values = part.dtype == PLX_BOOL ? dev_alloc_zero(bitmap_bytes(G)) : dev_alloc(values_bytes(part.dtype, G));
+  out->validity = dev_alloc_zero(bitmap_bytes(G));
+  KeyDecode kd = part.dec;
+  if (part.dtype == PLX_F32) kd.dtype = PLX_F32;
+  k::decode_key(r.packed_keys->as<uint64_t>(), r.key_valid ? r.key_valid->as<uint8_t>() : nullptr, G, kd, out->values->ptr, out->validity->as<uint64_t>());
+  if (column_null_count(out) == 0) { out->validity = nullptr; out->null_count = 0; }
+  return out;
+}
+
+// order groups by first occurrence (maintain_order): host argsort of the FIRST_ROW cells
+static ColumnPtr first_row_permutation(const FusedAggResult& r, int first_idx) {
+  const int64_t G = r.n_groups;
+  std::vector<uint64_t> cells((size_t)G * r.n_aggs);
+  d2h_sync(cells.data(), r.acc->ptr, cells.size() * 8);
+  std::vector<uint32_t> perm((size_t)G);
+  std::iota(perm.begin(), perm.end(), 0u);
+  std::sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return cells[(size_t)a * r.n_aggs + first_idx] < cells[(size_t)b * r.n_aggs + first_idx]; });
+  return column_from_host(PLX_U32, perm.data(), nullptr, 0, G);
+}
+
+// Select(aggregations) over [Filter]* over `src`
+static bool fused_select(Plan& plan, const IRN& node, const std::vector<int>& preds, const FramePtr& src, FramePtr& out, Shape* shape_out, int* sid_out,
+                         std::string* why, bool compile_only) {
+  for (int e : node.exprs) if (!contains_agg(plan, e) || contains_column_outside_agg(plan, e)) { if (why) *why = "select mixes row expressions and aggregations"; return false; }
+  Compiler c(plan, *src);
+  std::vector<int> agg_nodes;
+  std::vector<FinalSpec> specs;
+  try {
+    int p = -1;
+    for (int pe : preds) { int n = c.lower(pe); if (c.nodes[n].ty != 'b') throw Unsupported("predicate is not boolean"); p = p < 0 ? n : c.mk(OP_AND, p, n, 'b'); }
+    c.pred = p;
+    for (int e : node.exprs) collect_aggs(plan, e, agg_nodes);
+    for (int a : agg_nodes) specs.push_back(c.lower_agg(a));
+    c.finish();
+  } catch (const Unsupported& u) { if (why) *why = u.why; return false; }
+  const int static_id = find_static_shape(c.shape);
+  if (shape_out) *shape_out = c.shape;
+  if (sid_out) *sid_out = static_id;
+  if (compile_only) return true;
+  FusedAggResult r; r.n_groups = 1; r.n_aggs = c.shape.n_aggs;
+  std::vector<uint64_t> host(kMaxAggs, 0);
+  if (src->height == 0) { for (int k2 = 0; k2 < c.shape.n_aggs; k2++) host[k2] = agg_identity(c.shape.aggs[k2].kind); }
+  else k::fused_regagg(c.shape, c.args, static_id, host.data());
+  r.acc = dev_alloc(sizeof(uint64_t) * kMaxAggs);
+  h2d_async(r.acc->ptr, host.data(), sizeof(uint64_t) * (size_t)c.shape.n_aggs);
+  PLX_HIP(hipStreamSynchronize(stream()));
+  plan.desc += std::string("FusedFilterAgg{fused_scan[") + (static_id >= 0 ? "aot" : "generic") + "]+register_sink, inputs=" + std::to_string(c.shape.n_inputs) + ", ops=" + std::to_string(c.shape.n_ops) + ", aggs=" + std::to_string(c.shape.n_aggs) + "}; ";
+  std::map<int, ColumnPtr> overrides;
+  for (size_t i = 0; i < agg_nodes.size(); i++) overrides[agg_nodes[i]] = finalize_column(r, specs[i]);
+  out = std::make_shared<Frame>();
+  out->height = 1;
+  Frame one; one.height = 1;
+  for (int e : node.exprs) {
+    Evaluated ev = eval(plan, e, one, &overrides);
+    out->names.push_back(output_name(plan, e));
+    out->cols.push_back(ev.col);
+  }
+  return true;
+}
+
+// GroupBy(keys, aggregations) over [Filter]* over `src`
+static bool fused_groupby(Plan& plan, const IRN& node, const std::vector<int>& preds, const FramePtr& src, FramePtr& out, Shape* shape_out, int* sid_out,
+                          std::string* why, bool compile_only) {
+  for (int e : node.exprs) if (!contains_agg(plan, e) || contains_column_outside_agg(plan, e)) { if (why) *why = "group_by aggregation list contains a non-aggregated column"; return false; }
+  Compiler c(plan, *src);
+  std::vector<int> agg_nodes;
+  std::vector<FinalSpec> specs;
+  KeyPlan kp;
+  int len_idx = -1, first_idx = -1;
+  try {
+    int p = -1;
+    for (int pe : preds) { int n = c.lower(pe); if (c.nodes[n].ty != 'b') throw Unsupported("predicate is not boolean"); p = p < 0 ? n : c.mk(OP_AND, p, n, 'b'); }
+    c.pred = p;
+    kp = lower_keys(c, node.keys);
+    len_idx = c.add_agg(AGG_LEN, -1);
+    for (int e : node.exprs) collect_aggs(plan, e, agg_nodes);
+    for (int a : agg_nodes) specs.push_back(c.lower_agg(a));
+    if (node.maintain_order) first_idx = c.add_agg(AGG_FIRST_ROW, -1);
+    c.finish();
+  } catch (const Unsupported& u) { if (why) *why = u.why; return false; }
+  if (shape_out) *shape_out = c.shape;
+  if (sid_out) *sid_out = find_static_shape(c.shape);
+  if (compile_only) return true;
+  FusedAggResult r;
+  std::string d;
+  run_fused_groupby(c, kp, len_idx, r, d);
+  plan.desc += "FusedFilterGroupBy{" + d + ", inputs=" + std::to_string(c.shape.n_inputs) + ", ops=" + std::to_string(c.shape.n_ops) + ", aggs=" + std::to_string(c.shape.n_aggs) + ", groups=" + std::to_string(r.n_groups) + "}; ";
+  out = std::make_shared<Frame>();
+  out->height = r.n_groups;
+  for (auto& part : kp.parts) { out->names.push_back(output_name(plan, part.expr)); out->cols.push_back(decode_key_column(r, part)); }
+  std::map<int, ColumnPtr> overrides;
+  for (size_t i = 0; i < agg_nodes.size(); i++) overrides[agg_nodes[i]] = finalize_column(r, specs[i]);
+  Frame gframe; gframe.height = r.n_groups;
+  for (int e : node.exprs) {
+    Evaluated ev = eval(plan, e, gframe, &overrides);
+    out->names.push_back(output_name(plan, e));
+    out->cols.push_back(broadcast(ev, r.n_groups));
+  }
+  if (node.maintain_order && r.n_groups > 1) {
+    ColumnPtr perm = first_row_permutation(r, first_idx);
+    for (auto& col : out->cols) col = ops::gather(col, perm);
+  }
+  return true;
+}
+
+// ----------------------------------------------------------------- executors ----
+static FramePtr exec_node(Plan& plan, int node_id);
+
+static FramePtr exec_filter(Plan& plan, const IRN& n) {
+  FramePtr in = exec_node(plan, n.input);
+  Evaluated m = eval(plan, n.predicate, *in, nullptr);
+  ColumnPtr mask = broadcast(m, in->height);
+  PLX_REQUIRE(mask->dtype == PLX_BOOL, PLX_ERR_INVALID, "filter predicate must be boolean");
+  auto pm = ops::prepare_mask(mask);
+  auto out = std::make_shared<Frame>();
+  out->names = in->names;
+  out->height = ops::prepared_rows(*pm);
+  for (auto& c : in->cols) out->cols.push_back(ops::filter_prepared(c, *pm));
+  plan.desc += "Filter{cmp->bitmap, filter_compact x" + std::to_string(in->cols.size()) + "}; ";
+  return out;
+}
+
+static FramePtr exec_select(Plan& plan, const IRN& n, bool hstack) {
+  FramePtr in = exec_node(plan, n.input);
+  auto out = std::make_shared<Frame>();
+  std::vector<Evaluated> evs;
+  bool all_scalar = true;
+  for (int e : n.exprs) { evs.push_back(eval(plan, e, *in, nullptr)); all_scalar = all_scalar && evs.back().scalar; }
+  if (hstack) {
+    *out = *in;
+    for (size_t i = 0; i < n.exprs.size(); i++) {
+      ColumnPtr c = broadcast(evs[i], in->height);
+      std::string name = output_name(plan, n.exprs[i]);
+      int at = out->find(name);
+      if (at >= 0) out->cols[at] = c; else { out->names.push_back(name); out->cols.push_back(c); }
+    }
+    plan.desc += "HStack{per-node kernels}; ";
+    return out;
+  }
+  out->height = all_scalar ? 1 : in->height;
+  for (size_t i = 0; i < n.exprs.size(); i++) {
+    out->names.push_back(output_name(plan, n.exprs[i]));
+    out->cols.push_back(all_scalar ? evs[i].col : broadcast(evs[i], in->height));
+  }
+  plan.desc += "Select{per-node kernels}; ";
+  return out;
+}
+
+static FramePtr exec_groupby_materialised(Plan& plan, const IRN& n, const FramePtr& in) {
+  // evaluate key and aggregation-input expressions as columns, then the generic grouped aggregation
+  std::vector<ColumnPtr> keys, values;
+  std::vector<int> aggs, agg_nodes;
+  for (int e : n.keys) keys.push_back(broadcast(eval(plan, e, *in, nullptr), in->height));
+  for (int e : n.exprs) collect_aggs(plan, e, agg_nodes);
+  for (int a : agg_nodes) {
+    const AE& x = plan.ae[a];
+    if (x.kind == PLX_AE_LEN) { aggs.push_back(PLX_AGG_LEN); values.push_back(nullptr); }
+    else { aggs.push_back(x.op); values.push_back(broadcast(eval(plan, x.lhs, *in, nullptr), in->height)); }
+  }
+  std::vector<ColumnPtr> okeys, oaggs;
+  std::string d;
+  groupby_columns(keys, values, aggs, n.maintain_order != 0, okeys, oaggs, &d);
+  plan.desc += "GroupBy{materialised inputs; " + d + "}; ";
+  auto out = std::make_shared<Frame>();
+  out->height = okeys.empty() ? 0 : okeys[0]->len;
+  for (size_t i = 0; i < n.keys.size(); i++) { out->names.push_back(output_name(plan, n.keys[i])); out->cols.push_back(okeys[i]); }
+  std::map<int, ColumnPtr> overrides;
+  for (size_t i = 0; i < agg_nodes.size(); i++) overrides[agg_nodes[i]] = oaggs[i];
+  Frame gframe; gframe.height = out->height;
+  for (int e : n.exprs) {
+    Evaluated ev = eval(plan, e, gframe, &overrides);
+    out->names.push_back(output_name(plan, e));
+    out->cols.push_back(broadcast(ev, out->height));
+  }
+  return out;
+}
+
+// peel [Filter]* below an aggregation node
+static int peel_filters(const Plan& plan, int input, std::vector<int>& preds) {
+  while (plan.ir[input].kind == PLX_IR_FILTER) { preds.push_back(plan.ir[input].predicate); input = plan.ir[input].input; }
+  std::reverse(preds.begin(), preds.end());
+  return input;
+}
+
+static FramePtr exec_join(Plan& plan, const IRN& n) {
+  FramePtr left = exec_node(plan, n.input);
+  FramePtr right = exec_node(plan, n.input_right);
+  PLX_REQUIRE(n.keys.size() == 1 && n.keys_right.size() == 1, PLX_ERR_UNSUPPORTED, "multi-key joins need row encoding (polars-row), not on this path yet");
+  ColumnPtr lk = broadcast(eval(plan, n.keys[0], *left, nullptr), left->height);
+  ColumnPtr rk = broadcast(eval(plan, n.keys_right[0], *right, nullptr), right->height);
+  ColumnPtr li, ri;
+  std::string d;
+  join::join_indices(n.how, lk, rk, li, ri, &d);
+  plan.desc += "Join{" + d + ", gather x" + std::to_string(left->cols.size() + right->cols.size()) + "}; ";
+  // _finish_join (polars-ops/src/frame/join/general.rs:17-49): left columns, then right columns
+  // except the right key when it is a plain column coalesced into the left key; name clashes get the suffix.
+  auto out = std::make_shared<Frame>();
+  out->height = li->len;
+  for (size_t i = 0; i < left->cols.size(); i++) { out->names.push_back(left->names[i]); out->cols.push_back(ops::gather(left->cols[i], li)); }
+  const AE* rkx = &plan.ae[n.keys_right[0]];
+  while (rkx->kind == PLX_AE_ALIAS) rkx = &plan.ae[rkx->lhs];
+  const AE* lkx = &plan.ae[n.keys[0]];
+  while (lkx->kind == PLX_AE_ALIAS) lkx = &plan.ae[lkx->lhs];
+  for (size_t i = 0; i < right->cols.size(); i++) {
+    if (rkx->kind == PLX_AE_COLUMN && lkx->kind == PLX_AE_COLUMN && right->names[i] == rkx->name) continue;  // coalesced key
+    std::string name = right->names[i];
+    if (out->find(name) >= 0) name += n.suffix;
+    out->names.push_back(name);
+    out->cols.push_back(ops::gather(right->cols[i], ri));
+  }
+  return out;
+}
+
+static FramePtr exec_node(Plan& plan, int node_id) {
+  check_cancel();
+  PLX_REQUIRE(node_id >= 0 && node_id < (int)plan.ir.size(), PLX_ERR_INVALID, "bad IR node index");
+  const IRN& n = plan.ir[node_id];
+  const bool fuse = !(plan.flags & PLX_PLAN_NO_FUSION);
+  switch (n.kind) {
+    case PLX_IR_SCAN: return get_frame(n.frame);
+    case PLX_IR_FILTER: return exec_filter(plan, n);
+    case PLX_IR_HSTACK: return exec_select(plan, n, true);
+    case PLX_IR_SELECT: {
+      if (fuse) {
+        std::vector<int> preds;
+        int src_node = peel_filters(plan, n.input, preds);
+        bool aggs_only = !n.exprs.empty();
+        for (int e : n.exprs) aggs_only = aggs_only && contains_agg(plan, e) && !contains_column_outside_agg(plan, e);
+        if (aggs_only) {
+          FramePtr src = exec_node(plan, src_node);
+          FramePtr out; std::string why;
+          if (fused_select(plan, n, preds, src, out, nullptr, nullptr, &why, false)) return out;
+          plan.desc += "(not fused: " + why + ") ";
+        }
+      }
+      return exec_select(plan, n, false);
+    }
+    case PLX_IR_GROUPBY: {
+      if (fuse) {
+        std::vector<int> preds;
+        int src_node = peel_filters(plan, n.input, preds);
+        FramePtr src = exec_node(plan, src_node);
+        FramePtr out; std::string why;
+        if (fused_groupby(plan, n, preds, src, out, nullptr, nullptr, &why, false)) return out;
+        plan.desc += "(not fused: " + why + ") ";
+      }
+      FramePtr in = exec_node(plan, n.input);
+      return exec_groupby_materialised(plan, n, in);
+    }
+    case PLX_IR_JOIN: return exec_join(plan, n);
+    default: fail(PLX_ERR_UNSUPPORTED, "IR node kind " + std::to_string(n.kind) + " is outside the hot path (run it on the CPU engine)");
+  }
+}
+
+FramePtr execute(Plan& plan, int root) {
+  plan.desc.clear();
+  return exec_node(plan, root);
+}
+
+bool describe_fusion(Plan& plan, int root, Shape* shape, int* static_id, std::string* why_not) {
+  const IRN& n = plan.ir.at(root);
+  std::vector<int> preds;
+  int src_node = peel_filters(plan, n.input, preds);
+  PLX_REQUIRE(plan.ir[src_node].kind == PLX_IR_SCAN, PLX_ERR_UNSUPPORTED, "describe_fusion: source must be a scan");
+  FramePtr src = get_frame(plan.ir[src_node].frame);
+  FramePtr out;
+  if (n.kind == PLX_IR_SELECT) return fused_select(plan, n, preds, src, out, shape, static_id, why_not, true);
+  if (n.kind == PLX_IR_GROUPBY) return fused_groupby(plan, n, preds, src, out, shape, static_id, why_not, true);
+  if (why_not) *why_not = "root is neither Select nor GroupBy";
+  return false;
+}
+
+// generic grouped aggregation over already materialised columns: builds a LOAD-only
+// program and reuses the fused table kernels.
+void groupby_columns(const std::vector<ColumnPtr>& keys, const std::vector<ColumnPtr>& values, const std::vector<int>& aggs, bool maintain_order,
+                     std::vector<ColumnPtr>& out_keys, std::vector<ColumnPtr>& out_aggs, std::string* desc) {
+  PLX_REQUIRE(!keys.empty(), PLX_ERR_INVALID, "group_by needs at least one key");
+  PLX_REQUIRE(values.size() == aggs.size(), PLX_ERR_INVALID, "group_by: values/aggs length mismatch");
+  // synthesise a plan: frame of k0..kn, v0..vm; GroupBy over a scan
+  auto f = std::make_shared<Frame>();
+  f->height = keys[0]->len;
+  Plan p;
+  IRN scan; scan.kind = PLX_IR_SCAN; p.ir.push_back(scan);
+  IRN gb; gb.kind = PLX_IR_GROUPBY; gb.input = 0; gb.maintain_order = maintain_order ? 1 : 0;
+  for (size_t i = 0; i < keys.size(); i++) {
+    PLX_REQUIRE(keys[i]->len == f->height, PLX_ERR_SHAPE, "group_by: key length mismatch");
+    f->names.push_back("__k" + std::to_string(i)); f->cols.push_back(keys[i]);
+    AE c; c.kind = PLX_AE_COLUMN; c.name = f->names.back(); p.ae.push_back(c);
+    gb.keys.push_back((int)p.ae.size() - 1);
+  }
+  for (size_t i = 0; i < values.size(); i++) {
+    AE a;
+    if (aggs[i] == PLX_AGG_LEN || !values[i]) { a.kind = PLX_AE_LEN; }
+    else {
+      PLX_REQUIRE(values[i]->len == f->height, PLX_ERR_SHAPE, "group_by: value length mismatch");
+      f->names.push_back("__v" + std::to_string(i)); f->cols.push_back(values[i]);
+      AE c; c.kind = PLX_AE_COLUMN; c.name = f->names.back(); p.ae.push_back(c);
+      a.kind = PLX_AE_AGG; a.op = aggs[i]; a.lhs = (int)p.ae.size() - 1;
+    }
+    p.ae.push_back(a);
+    AE al; al.kind = PLX_AE_ALIAS; al.lhs = (int)p.ae.size() - 1; al.name = "__a" + std::to_string(i); p.ae.push_back(al);
+    gb.exprs.push_back((int)p.ae.size() - 1);
+  }
+  p.ir.push_back(gb);
+  FramePtr out; std::string why;
+  std::vector<int> preds;
+  if (!fused_groupby(p, p.ir[1], preds, f, out, nullptr, nullptr, &why, false)) {
+    // f32 / bool value columns: aggregate them through an f64 / integer view
+    std::vector<ColumnPtr> v2 = values; bool changed = false;
+    for (size_t i = 0; i < v2.size(); i++) if (v2[i] && v2[i]->dtype == PLX_F32) { v2[i] = ops::cast(v2[i], PLX_F64); changed = true; }
+    std::vector<ColumnPtr> k2 = keys;
+    for (auto& kc : k2) if (kc->dtype == PLX_F32) { kc = ops::cast(kc, PLX_F64); changed = true; }
+    if (!changed) fail(PLX_ERR_UNSUPPORTED, "group_by: " + why);
+    std::vector<ColumnPtr> ok, oa;
+    groupby_columns(k2, v2, aggs, maintain_order, ok, oa, desc);
+    for (size_t i = 0; i < keys.size(); i++) out_keys.push_back(keys[i]->dtype == PLX_F32 ? ops::cast(ok[i], PLX_F32) : ok[i]);
+    for (size_t i = 0; i < values.size(); i++) {
+      bool was_f32 = values[i] && values[i]->dtype == PLX_F32;
+      // f32 sums / means / min / max report f32 (reduce/mean.rs:29-80)
+      out_aggs.push_back(was_f32 && oa[i]->dtype == PLX_F64 && aggs[i] != PLX_AGG_COUNT ? ops::cast(oa[i], PLX_F32) : oa[i]);
+    }
+    return;
+  }
+  if (desc) *desc = p.desc;
+  for (size_t i = 0; i < keys.size(); i++) out_keys.push_back(out->cols[i]);
+  for (size_t i = 0; i < values.size(); i++) out_aggs.push_back(out->cols[keys.size() + i]);
+}
+
+}  // namespace engine
+}  // namespace plx

@@ -1,0 +1,60 @@
+// engine.hpp -- physical planner + executors of the MI355X backend.
+//
+// Mirrors the shape of the reference's in-memory engine
+//   create_physical_plan      polars-mem-engine/src/planner/lp.rs:75-100,326-878
+//   create_physical_expr      polars-expr/src/planner.rs:129-694
+//   Executor::execute         polars-mem-engine/src/executors/executor.rs:10-16
+// but plans FUSED pipelines wherever the IR allows it:
+//   [Filter]* -> Select(aggregations)          => one fused scan kernel (register sink)
+//   [Filter]* -> GroupBy(keys, aggregations)   => one fused scan kernel (LDS / dense / hash sink)
+//   Join -> ...                                => hash join kernels (build / probe / emit)
+// and otherwise falls back to one kernel per node (reference-shaped execution), which is
+// also what PLX_PLAN_NO_FUSION forces.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "core.hpp"
+#include "fused.hpp"
+
+namespace plx {
+namespace engine {
+
+struct AE {
+  int kind = 0, op = 0, lhs = -1, rhs = -1, dtype = 0, is_null = 0;
+  plx_scalar lit{};
+  std::string name;
+};
+struct IRN {
+  int kind = 0, input = -1, input_right = -1, predicate = -1;
+  plx_frame frame = 0;
+  std::vector<int> exprs, keys, keys_right;
+  int how = 0, maintain_order = 0;
+  std::string suffix = "_right";
+};
+struct Plan {
+  std::vector<IRN> ir;
+  std::vector<AE> ae;
+  uint32_t flags = 0;
+  std::string desc;  // physical plan description (which kernels / pipelines ran)
+};
+
+Plan import_plan(const plx_ir* ir, int n_ir, const plx_aexpr* ae, int n_ae, uint32_t flags);
+FramePtr execute(Plan& plan, int root);
+
+// dtype an expression evaluates to over `schema` (AExpr::to_field equivalent)
+int infer_dtype(const Plan& plan, int e, const Frame& schema);
+std::string output_name(const Plan& plan, int e);
+
+// generic group-by used by plx_groupby_agg and the GroupBy executor (keys / values already columns)
+void groupby_columns(const std::vector<ColumnPtr>& keys, const std::vector<ColumnPtr>& values, const std::vector<int>& aggs, bool maintain_order,
+                     std::vector<ColumnPtr>& out_keys, std::vector<ColumnPtr>& out_aggs, std::string* desc);
+
+// compile-only entry used by tests: lowers `Filter*(pred) -> Select/GroupBy` rooted at
+// `root` and reports the fused shape (and whether an AOT specialisation matches)
+// without touching the GPU.  Returns false if the plan is not fusable.
+bool describe_fusion(Plan& plan, int root, fused::Shape* shape, int* static_id, std::string* why_not);
+
+}  // namespace engine
+}  // namespace plx

@@ -1,0 +1,146 @@
+// fused.hpp -- the register-resident expression program shared by the host-side
+// expression compiler (engine) and the fused scan kernels.
+//
+// The reference evaluates `filter -> select/agg` as a tree of PhysicalExpr nodes that
+// each materialise a full column (polars-expr/src/expressions/{binary,aggregation,
+// column,literal,cast}.rs; SURVEY.md 3.2: >= 3 full passes over memory).  Here an AExpr
+// subtree is lowered to a short straight-line program over 16 virtual 64-bit slots
+// that live in VGPRs; a fused kernel streams the input columns once (16-B loads per
+// lane), runs the program per row in registers and hands the row to a sink
+// (register aggregation, hash aggregation, join build, join probe).
+//
+// Control flow of the interpreter is wave-uniform: opcodes and slot numbers come from
+// kernel arguments (SGPRs), so decode runs on the scalar unit and slot selection uses
+// the VGPR index mode (s_set_gpr_idx_on) rather than branches.  Hot shapes (the
+// BASELINE configs, TPC-H Q1/Q3) are additionally pre-instantiated with the program as
+// a compile-time constant so the whole interpreter folds away.
+#pragma once
+#include <stdint.h>
+
+namespace plx {
+namespace fused {
+
+constexpr int kMaxInputs = 10;
+constexpr int kMaxOps = 32;
+constexpr int kSlots = 16;
+constexpr int kMaxAggs = 8;
+constexpr int kRows = 2;            // rows per lane per tile (one 16-B load of an 8-B column)
+constexpr int kTileRows = 64 * kRows;
+constexpr uint8_t kNone = 255;
+
+enum OpCode : uint8_t {
+  OP_NOP = 0,
+  OP_LOAD,     // dst <- input[a] widened to 64 bit (sign/zero extension by dtype; f64 bits)
+  OP_CONST,    // dst <- imm[pc], always valid
+  OP_ADD_F, OP_SUB_F, OP_MUL_F, OP_DIV_F,   // f64
+  OP_ADD_I, OP_SUB_I, OP_MUL_I,             // wrapping 64-bit
+  OP_I2F, OP_U2F,                           // int -> f64 (AExpr::Cast inserted by type coercion)
+  OP_CMP_I, OP_CMP_U, OP_CMP_F,             // c = plx_cmp_op; result 0/1
+  OP_AND, OP_OR, OP_XOR, OP_NOT,            // boolean slots
+  OP_IFNULL,   // dst <- valid(a) ? a : imm[pc]; result always valid (null group code)
+  OP_MOV,
+  OP_CANON_F   // float key canonicalisation: -0 -> +0, any NaN -> 0x7ff8000000000000 (total_ord.rs:40-48)
+};
+
+struct Op {
+  uint8_t code, dst, a, b, c, _pad[3];
+};
+
+enum AggKind : uint8_t {
+  AGG_NONE = 0,
+  AGG_SUM_F,      // f64 sum of valid selected rows
+  AGG_SUM_I,      // wrapping 64-bit sum
+  AGG_COUNT,      // valid selected rows of src
+  AGG_COUNT_ORD,  // valid, selected and not NaN (f64 src)
+  AGG_LEN,        // selected rows
+  AGG_MIN_F, AGG_MAX_F, AGG_MIN_I, AGG_MAX_I, AGG_MIN_U, AGG_MAX_U,
+  AGG_FIRST_ROW   // smallest selected row index (group order / first())
+};
+
+struct Agg {
+  uint8_t kind, src;
+};
+
+// Static part of a program: what AOT specialisations are keyed on (immediates,
+// pointers and sizes are runtime).
+struct Shape {
+  uint8_t n_inputs, n_ops, n_aggs, pred, key;  // pred/key: slot or kNone
+  uint8_t in_dtype[kMaxInputs];                // plx_dtype
+  uint8_t in_nullable[kMaxInputs];
+  Op ops[kMaxOps];
+  Agg aggs[kMaxAggs];
+};
+
+struct Input {
+  const void* values;
+  const uint64_t* validity;
+};
+
+struct Args {
+  Input in[kMaxInputs];
+  uint64_t imm[kMaxOps];
+  int64_t n_rows;
+};
+
+// identity element of an aggregate, as a 64-bit pattern
+inline uint64_t agg_identity(uint8_t kind) {
+  switch (kind) {
+    case AGG_MIN_F: return 0x7ff0000000000000ull;  // +inf
+    case AGG_MAX_F: return 0xfff0000000000000ull;  // -inf
+    case AGG_MIN_I: return 0x7fffffffffffffffull;
+    case AGG_MAX_I: return 0x8000000000000000ull;
+    case AGG_MIN_U: return ~0ull;
+    case AGG_MAX_U: return 0ull;
+    case AGG_FIRST_ROW: return ~0ull;
+    default: return 0ull;
+  }
+}
+
+// ---- result finalisation (aggregate cells -> output column) -------------------------
+enum FinalKind : uint8_t {
+  FIN_COPY64 = 0,  // out (8 B) = cell a
+  FIN_TRUNC32,     // out (4 B) = low 32 bits of cell a (i32/u32 wrapping sums, u32 counts)
+  FIN_MEAN,        // out f64 (or f32) = f64(cell a) / count(cell b); null when count == 0
+  FIN_MINMAX_I,    // out (width by dtype) = cell a; null when count(cell b) == 0
+  FIN_MINMAX_F,    // out f64 = cell a; null when count(b) == 0; NaN when ordered count(c) == 0
+  FIN_NARROW       // out (1/2 B) = low bits of cell a
+};
+struct FinalSpec {
+  uint8_t kind, a, b, c, out_dtype;
+};
+// ---- key decoding (packed group key -> key column) ---------------------------------
+struct KeyDecode {
+  int32_t shift;        // bit position of this key's code inside the packed key
+  uint64_t mask;        // (1 << bits) - 1, or ~0 for a raw 64-bit key
+  int64_t min;          // value = code + min
+  uint64_t null_code;   // code standing for NULL, or ~0 if none (raw keys use the valid flag)
+  int32_t dtype;        // output plx_dtype
+};
+
+// ---- AOT specialisation table ---------------------------------------------------
+// Index into kStaticShapes (fused_shapes.hpp); -1 = run the generic interpreter.
+int find_static_shape(const Shape& s);
+
+// ---- sinks ------------------------------------------------------------------------
+// Hash aggregation table in HBM (open addressing, linear probing; capacity C = 2^k).
+// keys[C+2]: slot C = the null-key group, slot C+1 = the group of the key whose bit
+// pattern equals the EMPTY sentinel.  acc[(C+2) * n_aggs] initialised to identities.
+constexpr uint64_t kEmptyKey = ~0ull;
+struct HashTable {
+  unsigned long long* keys;
+  unsigned long long* acc;
+  unsigned int* overflow;  // set when a probe sequence exceeds max_probe
+  uint32_t log2_cap;
+  uint32_t max_probe;
+};
+
+// Direct-address aggregation (dense keys in [key_min, key_min + n_groups)): acc[(G+1)*n_aggs],
+// slot G = null key.
+struct DenseTable {
+  unsigned long long* acc;
+  int64_t key_min;
+  int64_t n_groups;
+};
+
+}  // namespace fused
+}  // namespace plx

@@ -1,0 +1,20 @@
+// join.hpp -- hash join on one key column pair (kernels_join.hip).
+// Replaces polars-ops/src/frame/join/hash_join/{single_keys.rs:16-167 (build_tables),
+// single_keys_inner.rs:11-149 (probe_inner / hash_join_tuples_inner),
+// single_keys_left.rs:106-195, single_keys_dispatch.rs:234-357,476-553}.
+#pragma once
+#include <string>
+
+#include "core.hpp"
+
+namespace plx {
+namespace join {
+
+// (left_idx, right_idx) as PLX_U32 columns; LEFT join: right_idx nullable.
+void join_indices(int how, const ColumnPtr& left_key, const ColumnPtr& right_key, ColumnPtr& left_idx, ColumnPtr& right_idx, std::string* desc);
+
+// HashPartitioner (polars-utils/src/hashing.rs:72-121): rows grouped by partition.
+void hash_partition(const ColumnPtr& key, int n_partitions, uint64_t seed, ColumnPtr& perm, int64_t* counts_out);
+
+}  // namespace join
+}  // namespace plx

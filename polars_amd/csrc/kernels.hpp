@@ -1,0 +1,63 @@
+// kernels.hpp -- host-callable launchers of the hand-written gfx950 kernels.
+// Every launcher enqueues on plx::stream() and returns immediately unless noted.
+#pragma once
+#include "core.hpp"
+
+namespace plx {
+namespace k {
+
+// launch geometry helpers -------------------------------------------------------
+constexpr int kBlock = 256;          // 4 wave64 per workgroup
+int grid_for(int64_t work_items, int items_per_block, int blocks_per_cu = 8);
+
+// ---- elementwise (kernels_elementwise.hip) -------------------------------------
+// compare -> LSB-first bitmap words (pad bits cleared); b == nullptr => scalar rhs
+void cmp(int dtype, int op, const void* a, const void* b, plx_scalar s, int64_t n, uint64_t* out_bits);
+// mode 0 col-col, 1 col-scalar, 2 scalar-col; out dtype = dtype, f64 for int TRUE_DIV
+void arith(int dtype, int op, int mode, const void* a, const void* b, plx_scalar s, int64_t n, void* out);
+// numeric cast; ok_bits (may be null) receives 1 where the value was representable
+void cast(int from, int to, const void* in, int64_t n, void* out, uint64_t* ok_bits);
+void cast_from_bool(const uint64_t* bits, int to, int64_t n, void* out);
+// bitmap word ops; n_bits used to clear pad bits. b may be nullptr for op NOT (op = 3)
+void bitmap_op(int op, const uint64_t* a, const uint64_t* b, int64_t n_bits, uint64_t* out);
+// out = a & b & c with nullptr meaning all-ones; at least one non-null
+void bitmap_and3(const uint64_t* a, const uint64_t* b, const uint64_t* c, int64_t n_bits, uint64_t* out);
+int64_t bitmap_popcount(const uint64_t* a, int64_t n_bits);  // synchronises
+// Kleene and (op 0) / or (op 1) of boolean columns (polars-compute/src/boolean.rs);
+// validity pointers may be null (= all valid); out_valid may be null when both are null
+void bool_kleene(int op, const uint64_t* lv, const uint64_t* lvalid, const uint64_t* rv, const uint64_t* rvalid, int64_t n_bits,
+                 uint64_t* out_v, uint64_t* out_valid);
+// OR n_bits of src (bit 0 aligned) into dst starting at bit dst_off; dst must be pre-zeroed there
+void bitmap_blit(uint64_t* dst, int64_t dst_off, const uint64_t* src, int64_t n_bits);
+// out[i] = pattern (width 1/2/4/8 bytes)
+void fill(int width, void* out, uint64_t pattern, int64_t n);
+void fill_iota_u32(uint32_t* out, int64_t n);
+
+// ---- reductions (kernels_reduce.hip) ------------------------------------------
+struct ReduceResult {
+  uint64_t isum;      // wrapping 64-bit sum of sign/zero-extended values (ints)
+  double fsum;        // f64 sum (all types)
+  uint64_t minmax_lo; // min bits (T widened to 64 bit / f64)
+  uint64_t minmax_hi; // max bits
+  uint64_t n_valid;   // valid (and mask-selected) rows
+  uint64_t n_ordered; // valid rows that are not NaN (== n_valid for ints)
+};
+// one pass computing every whole-column aggregate; synchronises to return the result
+ReduceResult reduce_all(int dtype, const void* values, const uint64_t* validity, int64_t n);
+
+// ---- filter / gather (kernels_filter.hip) --------------------------------------
+struct FilterPlan {
+  int64_t n = 0;        // input rows
+  int64_t n_out = 0;    // kept rows
+  Buf tile_offsets;     // exclusive prefix of kept rows per 2048-row tile
+  const uint64_t* mask = nullptr;
+};
+FilterPlan filter_prepare(const uint64_t* mask, int64_t n);  // synchronises (needs n_out)
+// width 1/2/4/8 bytes; width 0 compacts a bitmap (`values` = bits). out_validity may be null.
+void filter_apply(const FilterPlan& p, int width, const void* values, const uint64_t* validity, void* out_values,
+                  uint64_t* out_validity);
+void gather(int width, const void* values, const uint64_t* validity, const uint32_t* idx, const uint64_t* idx_validity,
+            int64_t n_idx, void* out, uint64_t* out_validity);
+
+}  // namespace k
+}  // namespace plx

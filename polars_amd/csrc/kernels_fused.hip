@@ -1,0 +1,804 @@
+// kernels_fused.hip -- fused scan kernels: one streaming pass over the input columns,
+// the expression program evaluated per row in VGPRs, rows handed to a sink.
+//
+// Replaces, for `Filter -> Select(agg)` and `Filter -> GroupBy` plans, the chain
+// FilterExec -> ProjectionExec / GroupByExec of the reference
+// (polars-mem-engine/src/executors/{filter.rs:94-145,projection.rs:20-115,
+// group_by.rs:60-98}) which materialises a mask, the filtered frame, every
+// intermediate expression column and per-group index lists.
+//
+// gfx950 mapping
+//   * a wave64 owns 128-row tiles; lane l holds rows 2l, 2l+1 of the tile, so an
+//     8-byte column is ONE global_load_dwordx4 per lane per tile (1 KiB per wave
+//     instruction, fully coalesced); narrower columns use proportionally narrower
+//     loads of the same two rows.  Tiles are handed out grid-stride; the grid is
+//     sized to fill all 256 CUs with >= 2 workgroups each.
+//   * the 16 program slots are two ext_vector registers-of-16 (one per row); slot
+//     numbers are wave-uniform so dynamic slot access is VGPR index mode, and for the
+//     pre-instantiated shapes everything is a compile-time constant.
+//   * register sink (<= 8 dense groups): per-lane accumulators acc[G][n_aggs] in
+//     VGPRs; a group whose ballot is empty in this wave-tile is skipped on the scalar
+//     unit.  End of kernel: wave64 shuffle tree -> LDS across waves -> one partial
+//     per workgroup -> tiny finish kernel.  No atomics, deterministic.
+//   * dense / hash sinks: device-scope atomics straight into an HBM-resident table
+//     (hardware f64 atomic add on gfx950); see HashAggSink.
+#include "dev.hpp"
+#include "fused.hpp"
+#include "fused_shapes.hpp"
+#include "kernels.hpp"
+#include "kernels_fused.hpp"
+#include <cstring>
+#include <vector>
+
+namespace plx {
+namespace k {
+
+using namespace dev;
+using namespace fused;
+
+typedef unsigned long long u64x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+
+struct RegFile {
+  u64x16 v[kRows];
+  u32x16 valid;  // bit r of element s: row r of slot s is valid
+};
+
+__device__ __forceinline__ int dtype_width_dev(int dt) {
+  switch (dt) {
+    case PLX_I8: case PLX_U8: return 1;
+    case PLX_I16: case PLX_U16: return 2;
+    case PLX_I32: case PLX_U32: case PLX_F32: return 4;
+    default: return 8;
+  }
+}
+__device__ __forceinline__ double as_f(uint64_t x) { return __longlong_as_double((long long)x); }
+__device__ __forceinline__ uint64_t as_u(double x) { return (uint64_t)__double_as_longlong(x); }
+
+// ---- column loads -----------------------------------------------------------------
+template <class T, bool FULL>
+__device__ __forceinline__ void load2(const void* base_ptr, int64_t row0, int64_t n, uint64_t out[kRows]) {
+  const T* p = reinterpret_cast<const T*>(base_ptr);
+  if constexpr (FULL) {
+    Pack<T, kRows> x = load_pack<T, kRows>(p + row0);
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if constexpr (is_fp<T>::value) out[r] = as_u((double)x.v[r]);
+      else out[r] = (uint64_t)(long long)x.v[r];  // sign- or zero-extends by T
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      int64_t i = row0 + r; if (i > n - 1) i = n - 1;
+      T x = p[i];
+      if constexpr (is_fp<T>::value) out[r] = as_u((double)x);
+      else out[r] = (uint64_t)(long long)x;
+    }
+  }
+}
+
+template <bool FULL>
+__device__ __forceinline__ void load_input(const Input& in, int dtype, int64_t row0, int64_t n, uint64_t out[kRows], uint32_t& vbits) {
+  switch (dtype) {
+    case PLX_I64: case PLX_U64: case PLX_F64: load2<uint64_t, FULL>(in.values, row0, n, out); break;
+    case PLX_I32: load2<int32_t, FULL>(in.values, row0, n, out); break;
+    case PLX_U32: load2<uint32_t, FULL>(in.values, row0, n, out); break;
+    case PLX_I16: load2<int16_t, FULL>(in.values, row0, n, out); break;
+    case PLX_U16: load2<uint16_t, FULL>(in.values, row0, n, out); break;
+    case PLX_I8: load2<int8_t, FULL>(in.values, row0, n, out); break;
+    case PLX_U8: load2<uint8_t, FULL>(in.values, row0, n, out); break;
+    case PLX_BOOL: {
+      int64_t i = row0; if (!FULL && i > n - 1) i = n - 1;
+      uint64_t w = reinterpret_cast<const uint64_t*>(in.values)[i >> 6] >> (i & 63);
+      out[0] = w & 1; out[1] = (w >> 1) & 1;
+    } break;
+    default: out[0] = out[1] = 0; break;
+  }
+  vbits = (1u << kRows) - 1;
+  if (in.validity) {
+    int64_t i = row0; if (!FULL && i > n - 1) i = n - 1;
+    vbits = (uint32_t)(in.validity[i >> 6] >> (i & 63)) & ((1u << kRows) - 1);
+    if (!FULL && row0 + 1 > n - 1) vbits &= 1u;  // second row clamped: validity irrelevant (row masked out)
+  }
+}
+
+// ---- one program step ---------------------------------------------------------------
+template <bool FULL>
+__device__ __forceinline__ void exec_op(const Op op, const Shape& sh, const Args& args, int pc, int64_t row0, RegFile& rf) {
+  uint64_t a[kRows], b[kRows], d[kRows];
+  uint32_t va = (1u << kRows) - 1, vb = (1u << kRows) - 1, vd;
+  if (op.code == OP_LOAD) {
+    load_input<FULL>(args.in[op.a], sh.in_dtype[op.a], row0, args.n_rows, d, vd);
+  } else if (op.code == OP_CONST) {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) d[r] = args.imm[pc];
+    vd = (1u << kRows) - 1;
+  } else {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) { a[r] = rf.v[r][op.a]; b[r] = rf.v[r][op.b]; }
+    va = rf.valid[op.a]; vb = rf.valid[op.b];
+    vd = va & vb;
+    switch (op.code) {
+      case OP_ADD_F:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = as_u(as_f(a[r]) + as_f(b[r]));
+        break;
+      case OP_SUB_F:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = as_u(as_f(a[r]) - as_f(b[r]));
+        break;
+      case OP_MUL_F:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = as_u(as_f(a[r]) * as_f(b[r]));
+        break;
+      case OP_DIV_F:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = as_u(as_f(a[r]) / as_f(b[r]));
+        break;
+      case OP_ADD_I:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = a[r] + b[r];
+        break;
+      case OP_SUB_I:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = a[r] - b[r];
+        break;
+      case OP_MUL_I:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = a[r] * b[r];
+        break;
+      case OP_I2F:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = as_u((double)(long long)a[r]);
+        vd = va;
+        break;
+      case OP_U2F:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = as_u((double)a[r]);
+        vd = va;
+        break;
+      case OP_CMP_I:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = cmp_apply<long long>(op.c, (long long)a[r], (long long)b[r]) ? 1 : 0;
+        break;
+      case OP_CMP_U:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = cmp_apply<unsigned long long>(op.c, a[r], b[r]) ? 1 : 0;
+        break;
+      case OP_CMP_F:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = cmp_apply<double>(op.c, as_f(a[r]), as_f(b[r])) ? 1 : 0;
+        break;
+      case OP_AND: {  // Kleene (polars-compute/src/boolean.rs: and)
+        uint32_t ta = 0, tb = 0;
+#pragma unroll
+        for (int r = 0; r < kRows; r++) { d[r] = a[r] & b[r] & 1; ta |= (uint32_t)(a[r] & 1) << r; tb |= (uint32_t)(b[r] & 1) << r; }
+        vd = (~tb & vb) | (~ta & va) | (ta & va & tb & vb);
+      } break;
+      case OP_OR: {   // Kleene (boolean.rs: or)
+        uint32_t ta = 0, tb = 0;
+#pragma unroll
+        for (int r = 0; r < kRows; r++) { d[r] = (a[r] | b[r]) & 1; ta |= (uint32_t)(a[r] & 1) << r; tb |= (uint32_t)(b[r] & 1) << r; }
+        vd = (ta & va) | (tb & vb) | (~ta & va & ~tb & vb);
+      } break;
+      case OP_XOR:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = (a[r] ^ b[r]) & 1;
+        break;
+      case OP_NOT:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = (~a[r]) & 1;
+        vd = va;
+        break;
+      case OP_CANON_F:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) { double f = as_f(a[r]); d[r] = (f != f) ? 0x7ff8000000000000ull : as_u(f + 0.0); }
+        vd = va;
+        break;
+      case OP_IFNULL:
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = ((va >> r) & 1) ? a[r] : args.imm[pc];
+        vd = (1u << kRows) - 1;
+        break;
+      default:  // OP_MOV / OP_NOP
+#pragma unroll
+        for (int r = 0; r < kRows; r++) d[r] = a[r];
+        vd = va;
+        break;
+    }
+    vd &= (1u << kRows) - 1;
+  }
+#pragma unroll
+  for (int r = 0; r < kRows; r++) rf.v[r][op.dst] = d[r];
+  rf.valid[op.dst] = vd;
+}
+
+// ---- program providers ----------------------------------------------------------
+struct DynProg { static constexpr bool kStatic = false; static constexpr int kId = -1; };
+template <int ID> struct StatProg { static constexpr bool kStatic = true; static constexpr int kId = ID; };
+
+template <class P, bool FULL>
+__device__ __forceinline__ void run_program(const Shape& dsh, const Args& args, int64_t row0, RegFile& rf) {
+  if constexpr (P::kStatic) {
+    constexpr Shape sh = static_shape(P::kId);
+#pragma unroll
+    for (int pc = 0; pc < sh.n_ops; pc++) exec_op<FULL>(sh.ops[pc], sh, args, pc, row0, rf);
+  } else {
+    for (int pc = 0; pc < dsh.n_ops; pc++) exec_op<FULL>(dsh.ops[pc], dsh, args, pc, row0, rf);
+  }
+}
+
+// ---- aggregate combine (bit patterns) -----------------------------------------------
+__device__ __forceinline__ uint64_t agg_combine(uint8_t kind, uint64_t x, uint64_t y) {
+  switch (kind) {
+    case AGG_SUM_F: return as_u(as_f(x) + as_f(y));
+    case AGG_MIN_F: return as_u(min_ign<double>(as_f(x), as_f(y)));
+    case AGG_MAX_F: return as_u(max_ign<double>(as_f(x), as_f(y)));
+    case AGG_MIN_I: return (uint64_t)((long long)x < (long long)y ? (long long)x : (long long)y);
+    case AGG_MAX_I: return (uint64_t)((long long)x > (long long)y ? (long long)x : (long long)y);
+    case AGG_MIN_U: case AGG_FIRST_ROW: return x < y ? x : y;
+    case AGG_MAX_U: return x > y ? x : y;
+    default: return x + y;  // SUM_I, COUNT, COUNT_ORD, LEN
+  }
+}
+__device__ __forceinline__ uint64_t agg_identity_dev(uint8_t kind) {
+  switch (kind) {
+    case AGG_MIN_F: return 0x7ff0000000000000ull;
+    case AGG_MAX_F: return 0xfff0000000000000ull;
+    case AGG_MIN_I: return 0x7fffffffffffffffull;
+    case AGG_MAX_I: return 0x8000000000000000ull;
+    case AGG_MIN_U: case AGG_FIRST_ROW: return ~0ull;
+    default: return 0ull;
+  }
+}
+// value an aggregate contributes for one row: `sel` = row selected and (where it matters) src valid
+__device__ __forceinline__ uint64_t agg_row_value(uint8_t kind, uint64_t v, bool pass, bool valid, uint64_t row) {
+  switch (kind) {
+    case AGG_LEN: return pass ? 1ull : 0ull;
+    case AGG_COUNT: return (pass && valid) ? 1ull : 0ull;
+    case AGG_COUNT_ORD: { double f = as_f(v); return (pass && valid && f == f) ? 1ull : 0ull; }
+    case AGG_FIRST_ROW: return pass ? row : ~0ull;
+    case AGG_MIN_F: { double f = as_f(v); return (pass && valid && f == f) ? v : 0x7ff0000000000000ull; }
+    case AGG_MAX_F: { double f = as_f(v); return (pass && valid && f == f) ? v : 0xfff0000000000000ull; }
+    case AGG_SUM_F: case AGG_SUM_I: return (pass && valid) ? v : 0ull;   // +0.0 / 0 identities share the zero pattern
+    default: return (pass && valid) ? v : agg_identity_dev(kind);
+  }
+}
+
+// ---- device-scope atomic update of one aggregate cell -------------------------------
+__device__ __forceinline__ void atomic_agg(uint8_t kind, unsigned long long* cell, uint64_t v) {
+  switch (kind) {
+    case AGG_SUM_F: unsafeAtomicAdd(reinterpret_cast<double*>(cell), as_f(v)); break;  // global_atomic_add_f64
+    case AGG_MIN_I: atomicMin(reinterpret_cast<long long*>(cell), (long long)v); break;
+    case AGG_MAX_I: atomicMax(reinterpret_cast<long long*>(cell), (long long)v); break;
+    case AGG_MIN_U: case AGG_FIRST_ROW: atomicMin(cell, (unsigned long long)v); break;
+    case AGG_MAX_U: atomicMax(cell, (unsigned long long)v); break;
+    case AGG_MIN_F: case AGG_MAX_F: {
+      unsigned long long old = *cell;
+      for (;;) {
+        uint64_t nv = agg_combine(kind, old, v);
+        if (nv == old) break;
+        unsigned long long prev = atomicCAS(cell, old, (unsigned long long)nv);
+        if (prev == old) break;
+        old = prev;
+      }
+    } break;
+    default: atomicAdd(cell, (unsigned long long)v); break;
+  }
+}
+
+// ---- sink: per-lane register accumulators (no group-by) ---------------------------------
+struct RegAggSink {
+  struct Params { unsigned long long* partials; };  // [grid][kMaxAggs]
+  uint64_t acc[kMaxAggs];
+  template <class S> __device__ __forceinline__ void init(const S& sh, const Params&) {
+#pragma unroll
+    for (int k = 0; k < kMaxAggs; k++) acc[k] = (k < sh.n_aggs) ? agg_identity_dev(sh.aggs[k].kind) : 0ull;
+  }
+  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params&) {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+#pragma unroll
+      for (int k = 0; k < kMaxAggs; k++) {
+        if (k < sh.n_aggs) {
+          const Agg ag = sh.aggs[k];
+          uint64_t v = rf.v[r][ag.src];
+          bool valid = (rf.valid[ag.src] >> r) & 1;
+          acc[k] = agg_combine(ag.kind, acc[k], agg_row_value(ag.kind, v, pass[r], valid, (uint64_t)(row0 + r)));
+        }
+      }
+    }
+  }
+  template <class S> __device__ __forceinline__ void finish(const S& sh, const Params& p) {
+    __shared__ uint64_t sh_acc[kBlock / 64][kMaxAggs];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kMaxAggs; k++) {
+      if (k < sh.n_aggs) {
+        uint64_t x = acc[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) x = agg_combine(sh.aggs[k].kind, x, shfl_xor_u64(x, m));
+        if (lane == 0) sh_acc[wave][k] = x;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < sh.n_aggs) {
+      const int k = threadIdx.x;
+      uint64_t x = sh_acc[0][k];
+      for (int w = 1; w < (int)(blockDim.x >> 6); w++) x = agg_combine(sh.aggs[k].kind, x, sh_acc[w][k]);
+      p.partials[(size_t)blockIdx.x * kMaxAggs + k] = x;
+    }
+  }
+};
+
+// ---- LDS atomic update of one aggregate cell ----------------------------------------------
+__device__ __forceinline__ void lds_atomic_agg(uint8_t kind, unsigned long long* cell, uint64_t v) {
+  switch (kind) {
+    case AGG_SUM_F: unsafeAtomicAdd(reinterpret_cast<double*>(cell), as_f(v)); break;  // ds_add_f64
+    case AGG_MIN_I: atomicMin(reinterpret_cast<long long*>(cell), (long long)v); break;
+    case AGG_MAX_I: atomicMax(reinterpret_cast<long long*>(cell), (long long)v); break;
+    case AGG_MIN_U: case AGG_FIRST_ROW: atomicMin(cell, (unsigned long long)v); break;
+    case AGG_MAX_U: atomicMax(cell, (unsigned long long)v); break;
+    case AGG_MIN_F: case AGG_MAX_F: {
+      unsigned long long old = *cell;
+      for (;;) {
+        uint64_t nv = agg_combine(kind, old, v);
+        if (nv == old) break;
+        unsigned long long prev = atomicCAS(cell, old, (unsigned long long)nv);
+        if (prev == old) break;
+        old = prev;
+      }
+    } break;
+    default: atomicAdd(cell, (unsigned long long)v); break;
+  }
+}
+
+// ---- sink: workgroup-shared LDS table for dense group ids (1 < G <= ~1024) -----------------
+// Layout lds[(g * n_aggs + k) * C + copy], copy = lane & (C-1).  With C = 16 every
+// 16-lane group of a 64-bit DS instruction touches 16 distinct cells = all 32 banks once,
+// so the LDS atomics run conflict-free at full rate no matter how skewed the groups are
+// (TPC-H Q1: ~50% of rows fall in one group).  At the end the copies are folded and one
+// partial per workgroup is written (G <= 64) or added to the HBM table with atomics.
+struct LdsAggSink {
+  struct Params {
+    unsigned long long* partials;    // [grid][G][n_aggs]  (when global_acc == nullptr)
+    unsigned long long* global_acc;  // [G][n_aggs] device-scope atomics (large G)
+    int n_groups;
+    int copies;                      // power of two
+  };
+  template <class S> __device__ __forceinline__ void init(const S& sh, const Params& p) {
+    extern __shared__ unsigned long long lds_tbl[];
+    const int cells = p.n_groups * sh.n_aggs;
+    for (int i = threadIdx.x; i < cells * p.copies; i += blockDim.x) lds_tbl[i] = agg_identity_dev(sh.aggs[(i / p.copies) % sh.n_aggs].kind);
+    __syncthreads();
+  }
+  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+    extern __shared__ unsigned long long lds_tbl[];
+    const int copy = lane_id() & (p.copies - 1);
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r]) continue;
+      const uint32_t gid = (uint32_t)rf.v[r][sh.key];
+      unsigned long long* cells = lds_tbl + (size_t)gid * sh.n_aggs * p.copies + copy;
+#pragma unroll
+      for (int k = 0; k < kMaxAggs; k++) {
+        if (k < sh.n_aggs) {
+          const Agg ag = sh.aggs[k];
+          uint64_t v = rf.v[r][ag.src];
+          bool valid = (rf.valid[ag.src] >> r) & 1;
+          if ((ag.kind == AGG_SUM_F || ag.kind == AGG_SUM_I || ag.kind == AGG_COUNT) && !valid) continue;
+          uint64_t x = agg_row_value(ag.kind, v, true, valid, (uint64_t)(row0 + r));
+          lds_atomic_agg(ag.kind, cells + k * p.copies, x);
+        }
+      }
+    }
+  }
+  template <class S> __device__ __forceinline__ void finish(const S& sh, const Params& p) {
+    extern __shared__ unsigned long long lds_tbl[];
+    __syncthreads();
+    const int cells = p.n_groups * sh.n_aggs;
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) {
+      const uint8_t kind = sh.aggs[i % sh.n_aggs].kind;
+      uint64_t x = lds_tbl[(size_t)i * p.copies];
+      for (int c = 1; c < p.copies; c++) x = agg_combine(kind, x, lds_tbl[(size_t)i * p.copies + c]);
+      if (p.global_acc) { if (x != agg_identity_dev(kind) || kind == AGG_SUM_F) atomic_agg(kind, p.global_acc + i, x); }
+      else p.partials[(size_t)blockIdx.x * cells + i] = x;
+    }
+  }
+};
+
+template <class S>
+__device__ __forceinline__ void atomic_row(const S& sh, const RegFile& rf, int r, int64_t row, unsigned long long* cells) {
+#pragma unroll
+  for (int k = 0; k < kMaxAggs; k++) {
+    if (k < sh.n_aggs) {
+      const Agg ag = sh.aggs[k];
+      uint64_t v = rf.v[r][ag.src];
+      bool valid = (rf.valid[ag.src] >> r) & 1;
+      uint64_t x = agg_row_value(ag.kind, v, true, valid, (uint64_t)row);
+      if (x != agg_identity_dev(ag.kind) || ag.kind == AGG_SUM_F) {
+        if (ag.kind == AGG_SUM_F && !valid) continue;
+        atomic_agg(ag.kind, cells + k, x);
+      }
+    }
+  }
+}
+
+// ---- sink: direct-address table (dense integer keys) ---------------------------------
+struct DenseAggSink {
+  using Params = DenseTable;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r]) continue;
+      bool kvalid = (rf.valid[sh.key] >> r) & 1;
+      int64_t g = kvalid ? ((int64_t)rf.v[r][sh.key] - p.key_min) : p.n_groups;
+      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)g * sh.n_aggs);
+    }
+  }
+};
+
+// ---- sink: open-addressing hash table in HBM -----------------------------------------
+// slot = top bits of key * RANDOM_ODD (the reference's DirtyHash,
+// polars-utils/src/hashing.rs:124-151: "only the top bits are decent"), linear probing,
+// 64-bit CAS claims a slot, payload updated with device-scope atomics.
+struct HashAggSink {
+  using Params = HashTable;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  __device__ __forceinline__ static int64_t find_slot(const Params& p, uint64_t key) {
+    const uint64_t cap = 1ull << p.log2_cap;
+    uint64_t slot = (key * 0x55fbfd6bfc5458e9ull) >> (64 - p.log2_cap);
+    for (uint32_t probe = 0; probe < p.max_probe; probe++) {
+      unsigned long long cur = p.keys[slot];
+      if (cur == key) return (int64_t)slot;
+      if (cur == kEmptyKey) {
+        unsigned long long old = atomicCAS(&p.keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
+        if (old == kEmptyKey || old == key) return (int64_t)slot;
+      }
+      slot = (slot + 1) & (cap - 1);
+    }
+    atomicExch(p.overflow, 1u);
+    return -1;
+  }
+  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+    const uint64_t cap = 1ull << p.log2_cap;
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r]) continue;
+      bool kvalid = (rf.valid[sh.key] >> r) & 1;
+      uint64_t key = rf.v[r][sh.key];
+      int64_t slot;
+      if (!kvalid) { slot = (int64_t)cap; p.keys[cap] = 0; }
+      else if (key == kEmptyKey) { slot = (int64_t)cap + 1; p.keys[cap + 1] = 0; }
+      else slot = find_slot(p, key);
+      if (slot < 0) continue;
+      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
+    }
+  }
+};
+
+// ---- the scan kernels ------------------------------------------------------------------
+template <class P>
+__device__ __forceinline__ bool tile_rows(const Shape& dsh, const Args& args, int64_t tile, RegFile& rf, bool pass[kRows], int64_t& row0) {
+  const int lane = lane_id();
+  const int64_t base = tile * kTileRows;
+  row0 = base + (int64_t)lane * kRows;
+  const bool full = base + kTileRows <= args.n_rows;  // wave-uniform
+  if (full) run_program<P, true>(dsh, args, row0, rf);
+  else run_program<P, false>(dsh, args, row0, rf);
+  uint8_t pred;
+  if constexpr (P::kStatic) { constexpr Shape sh = static_shape(P::kId); pred = sh.pred; } else pred = dsh.pred;
+#pragma unroll
+  for (int r = 0; r < kRows; r++) {
+    bool ok = full || (row0 + r < args.n_rows);
+    if (pred != kNone) ok = ok && (rf.v[r][pred] & 1) && ((rf.valid[pred] >> r) & 1);
+    pass[r] = ok;
+  }
+  return full;
+}
+
+template <class P, class Sink>
+__global__ __launch_bounds__(kBlock) void fused_scan_kernel(Shape dsh, Args args, typename Sink::Params sp) {
+  Sink sink;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t ntiles = (args.n_rows + kTileRows - 1) / kTileRows;
+  if constexpr (P::kStatic) {
+    constexpr Shape sh = static_shape(P::kId);
+    sink.init(sh, sp);
+    for (int64_t t = wave; t < ntiles; t += nwaves) {
+      RegFile rf; bool pass[kRows]; int64_t row0;
+      tile_rows<P>(dsh, args, t, rf, pass, row0);
+      sink.consume(sh, rf, pass, row0, sp);
+    }
+    sink.finish(sh, sp);
+  } else {
+    sink.init(dsh, sp);
+    for (int64_t t = wave; t < ntiles; t += nwaves) {
+      RegFile rf; bool pass[kRows]; int64_t row0;
+      tile_rows<P>(dsh, args, t, rf, pass, row0);
+      sink.consume(dsh, rf, pass, row0, sp);
+    }
+    sink.finish(dsh, sp);
+  }
+}
+
+// finish: combine per-workgroup partials [np][cells] -> out[cells]; cell = g * n_aggs + k
+__global__ __launch_bounds__(kBlock) void partials_finish_kernel(Shape sh, const unsigned long long* __restrict__ partials, int np, int cells,
+                                                                 int cell_stride, unsigned long long* __restrict__ out) {
+  __shared__ uint64_t red[kBlock / 64];
+  const int cell = blockIdx.x;
+  const uint8_t kind = sh.aggs[cell % sh.n_aggs].kind;
+  uint64_t x = agg_identity_dev(kind);
+  for (int i = threadIdx.x; i < np; i += blockDim.x) x = agg_combine(kind, x, partials[(size_t)i * cell_stride + cell]);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) x = agg_combine(kind, x, shfl_xor_u64(x, m));
+  if (lane_id() == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) x = agg_combine(kind, x, red[w]);
+    out[cell] = x;
+  }
+}
+
+// ---- host launchers ----------------------------------------------------------------------
+static int scan_grid(int64_t n_rows, int blocks_per_cu) {
+  int64_t ntiles = (n_rows + kTileRows - 1) / kTileRows;
+  return grid_for(ntiles, kBlock / 64, blocks_per_cu);
+}
+static uint64_t algo_bytes(const Shape& sh, const Args& args) {
+  uint64_t algo = 0;
+  for (int i = 0; i < sh.n_inputs; i++) algo += (uint64_t)args.n_rows * dtype_width(sh.in_dtype[i]) + (args.in[i].validity ? (uint64_t)args.n_rows / 8 : 0);
+  return algo;
+}
+
+#define PLX_LAUNCH_SCAN(PROG, SINK, grid, lds, sh, args, sp) \
+  hipLaunchKernelGGL((fused_scan_kernel<PROG, SINK>), dim3(grid), dim3(kBlock), (lds), stream(), sh, args, sp)
+
+void fused_regagg(const Shape& sh, const Args& args, int static_id, uint64_t* out_host) {
+  const int grid = scan_grid(args.n_rows, 4);
+  Buf partials = dev_alloc(sizeof(uint64_t) * (size_t)(grid + 1) * kMaxAggs);
+  unsigned long long* pp = partials->as<unsigned long long>();
+  RegAggSink::Params sp{pp};
+  {
+    ProfileScope ps(static_id >= 0 ? "fused_scan_regagg_static" : "fused_scan_regagg_generic", algo_bytes(sh, args), (uint64_t)args.n_rows);
+    switch (static_id) {
+      case SHAPE_CFG2: PLX_LAUNCH_SCAN(StatProg<SHAPE_CFG2>, RegAggSink, grid, 0, sh, args, sp); break;
+      case SHAPE_CFG2_NULLX: PLX_LAUNCH_SCAN(StatProg<SHAPE_CFG2_NULLX>, RegAggSink, grid, 0, sh, args, sp); break;
+      case SHAPE_CFG1: PLX_LAUNCH_SCAN(StatProg<SHAPE_CFG1>, RegAggSink, grid, 0, sh, args, sp); break;
+      default: PLX_LAUNCH_SCAN(DynProg, RegAggSink, grid, 0, sh, args, sp); break;
+    }
+    PLX_HIP(hipGetLastError());
+  }
+  unsigned long long* fin = pp + (size_t)grid * kMaxAggs;
+  hipLaunchKernelGGL(partials_finish_kernel, dim3(sh.n_aggs), dim3(kBlock), 0, stream(), sh, pp, grid, (int)sh.n_aggs, (int)kMaxAggs, fin);
+  PLX_HIP(hipGetLastError());
+  d2h_sync(out_host, fin, (size_t)sh.n_aggs * 8);
+}
+
+int lds_agg_copies(int n_groups, int n_aggs) {
+  const size_t budget = 60 * 1024;  // leaves room for 2 workgroups per CU of the 160 KiB LDS
+  int c = 16;
+  while (c > 1 && (size_t)n_groups * n_aggs * c * 8 > budget) c >>= 1;
+  if ((size_t)n_groups * n_aggs * c * 8 > budget) return 0;
+  return c;
+}
+
+void fused_lds_agg(const Shape& sh, const Args& args, int n_groups, int static_id, uint64_t* out_dev /* [G][n_aggs] */) {
+  const int copies = lds_agg_copies(n_groups, sh.n_aggs);
+  PLX_REQUIRE(copies > 0, PLX_ERR_INVALID, "fused_lds_agg: group table does not fit LDS");
+  const int cells = n_groups * sh.n_aggs;
+  const size_t lds = (size_t)cells * copies * 8;
+  const int grid = scan_grid(args.n_rows, 4);
+  const bool use_partials = n_groups <= 64;
+  Buf partials;
+  LdsAggSink::Params sp{};
+  sp.n_groups = n_groups; sp.copies = copies;
+  if (use_partials) { partials = dev_alloc(sizeof(uint64_t) * (size_t)grid * cells); sp.partials = partials->as<unsigned long long>(); }
+  else { init_agg_cells(out_dev, n_groups, sh); sp.global_acc = (unsigned long long*)out_dev; }
+  {
+    ProfileScope ps(static_id >= 0 ? "fused_scan_ldsagg_static" : "fused_scan_ldsagg_generic", algo_bytes(sh, args), (uint64_t)args.n_rows);
+    switch (static_id) {
+      case SHAPE_Q1: PLX_LAUNCH_SCAN(StatProg<SHAPE_Q1>, LdsAggSink, grid, lds, sh, args, sp); break;
+      default: PLX_LAUNCH_SCAN(DynProg, LdsAggSink, grid, lds, sh, args, sp); break;
+    }
+    PLX_HIP(hipGetLastError());
+  }
+  if (use_partials) {
+    hipLaunchKernelGGL(partials_finish_kernel, dim3(cells), dim3(kBlock), 0, stream(), sh, sp.partials, grid, cells, cells, (unsigned long long*)out_dev);
+    PLX_HIP(hipGetLastError());
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_u64_kernel(unsigned long long* p, int64_t n, unsigned long long v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ __launch_bounds__(kBlock) void init_acc_kernel(unsigned long long* acc, int64_t n_slots, Shape sh) {
+  const int64_t total = n_slots * sh.n_aggs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    acc[i] = agg_identity_dev(sh.aggs[i % sh.n_aggs].kind);
+}
+void fill_u64(uint64_t* p, int64_t n, uint64_t v) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, stream(), (unsigned long long*)p, n, (unsigned long long)v);
+  PLX_HIP(hipGetLastError());
+}
+void init_agg_cells(uint64_t* acc, int64_t n_slots, const Shape& sh) {
+  if (n_slots == 0) return;
+  hipLaunchKernelGGL(init_acc_kernel, dim3(grid_for(n_slots * sh.n_aggs, kBlock * 4)), dim3(kBlock), 0, stream(), (unsigned long long*)acc, n_slots, sh);
+  PLX_HIP(hipGetLastError());
+}
+
+void fused_dense_agg(const Shape& sh, const Args& args, const DenseTable& t, int static_id) {
+  if (args.n_rows == 0) return;
+  ProfileScope ps("fused_scan_denseagg", algo_bytes(sh, args), (uint64_t)args.n_rows);
+  const int grid = scan_grid(args.n_rows, 8);
+  switch (static_id) {
+    case SHAPE_GB_SUM_CNT_I64: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_GB_SUM_CNT_I64>, DenseAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+    case SHAPE_GB_SUM_MEAN_U32_F64: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_GB_SUM_MEAN_U32_F64>, DenseAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+    default: hipLaunchKernelGGL((fused_scan_kernel<DynProg, DenseAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+  }
+  PLX_HIP(hipGetLastError());
+}
+
+void fused_hash_agg(const Shape& sh, const Args& args, const HashTable& t, int static_id) {
+  if (args.n_rows == 0) return;
+  ProfileScope ps("fused_scan_hashagg", algo_bytes(sh, args), (uint64_t)args.n_rows);
+  const int grid = scan_grid(args.n_rows, 8);
+  switch (static_id) {
+    case SHAPE_GB_SUM_CNT_I64: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_GB_SUM_CNT_I64>, HashAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+    case SHAPE_GB_SUM_MEAN_U32_F64: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_GB_SUM_MEAN_U32_F64>, HashAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+    default: hipLaunchKernelGGL((fused_scan_kernel<DynProg, HashAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+  }
+  PLX_HIP(hipGetLastError());
+}
+
+// ---- table compaction: occupied slots -> dense output ----------------------------------
+// Wave-aggregated output allocation: ballot the occupied lanes, one atomicAdd per wave
+// reserves popcount slots, lanes write at base + prefix rank.
+__global__ __launch_bounds__(kBlock) void hash_compact_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ acc,
+                                                              int64_t n_slots, int64_t cap, int n_aggs, int occ_agg /* LEN/COUNT cell or -1 */,
+                                                              unsigned long long* __restrict__ counter, unsigned long long* __restrict__ out_keys,
+                                                              unsigned char* __restrict__ out_key_valid, unsigned long long* __restrict__ out_acc) {
+  const int lane = lane_id();
+  for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n_slots; base += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = base + lane;
+    bool occ = false;
+    if (s < n_slots) {
+      if (occ_agg >= 0) occ = acc[(size_t)s * n_aggs + occ_agg] != 0;  // a group exists iff its row count is non-zero
+      else occ = s < cap ? keys[s] != kEmptyKey : keys[s] == 0;
+    }
+    const uint64_t m = ballot(occ);
+    if (m == 0) continue;
+    unsigned long long o = 0;
+    if (lane == 0) o = atomicAdd(counter, (unsigned long long)popc64(m));
+    o = shfl_u64(o, 0) + (uint64_t)prefix_rank(m);
+    if (occ) {
+      if (out_keys) {
+        uint64_t kv = 0; unsigned char valid = 1;
+        if (cap < 0) kv = (uint64_t)s;                   // dense table: the slot index is the packed key
+        else if (s < cap) kv = keys[s];
+        else if (s == cap) { kv = 0; valid = 0; }        // null-key group
+        else kv = kEmptyKey;                             // the key equal to the sentinel
+        out_keys[o] = kv; out_key_valid[o] = valid;
+      }
+      if (out_acc) for (int k = 0; k < n_aggs; k++) out_acc[o * n_aggs + k] = acc[(size_t)s * n_aggs + k];
+    }
+  }
+}
+
+// ---- aggregate cells -> typed output column ------------------------------------------------
+__global__ __launch_bounds__(kBlock) void finalize_kernel(const unsigned long long* __restrict__ acc, int n_aggs, int64_t G, FinalSpec sp,
+                                                          void* __restrict__ out, uint64_t* __restrict__ out_valid) {
+  const int lane = lane_id();
+  const int64_t nwords = (G + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t w = wave; w < nwords; w += nwaves) {
+    const int64_t g = w * 64 + lane;
+    bool valid = false;
+    if (g < G) {
+      const unsigned long long* cell = acc + (size_t)g * n_aggs;
+      valid = true;
+      switch (sp.kind) {
+        case FIN_COPY64: reinterpret_cast<uint64_t*>(out)[g] = cell[sp.a]; break;
+        case FIN_TRUNC32: reinterpret_cast<uint32_t*>(out)[g] = (uint32_t)cell[sp.a]; break;
+        case FIN_NARROW:
+          if (dtype_width_dev(sp.out_dtype) == 1) reinterpret_cast<uint8_t*>(out)[g] = (uint8_t)cell[sp.a];
+          else reinterpret_cast<uint16_t*>(out)[g] = (uint16_t)cell[sp.a];
+          break;
+        case FIN_MEAN: {
+          const uint64_t cnt = cell[sp.b];
+          valid = cnt != 0;
+          double m = valid ? as_f(cell[sp.a]) / (double)cnt : 0.0;
+          if (sp.out_dtype == PLX_F32) reinterpret_cast<float*>(out)[g] = (float)m; else reinterpret_cast<double*>(out)[g] = m;
+        } break;
+        case FIN_MINMAX_I: {
+          valid = cell[sp.b] != 0;
+          const uint64_t v = valid ? cell[sp.a] : 0;
+          switch (dtype_width_dev(sp.out_dtype)) {
+            case 1: reinterpret_cast<uint8_t*>(out)[g] = (uint8_t)v; break;
+            case 2: reinterpret_cast<uint16_t*>(out)[g] = (uint16_t)v; break;
+            case 4: reinterpret_cast<uint32_t*>(out)[g] = (uint32_t)v; break;
+            default: reinterpret_cast<uint64_t*>(out)[g] = v; break;
+          }
+        } break;
+        default: {  // FIN_MINMAX_F
+          valid = cell[sp.b] != 0;
+          double v = valid ? as_f(cell[sp.a]) : 0.0;
+          if (valid && cell[sp.c] == 0) v = __longlong_as_double(0x7ff8000000000000ll);
+          reinterpret_cast<double*>(out)[g] = v;
+        } break;
+      }
+    }
+    if (out_valid) { uint64_t m = ballot(valid); if (lane == 0) out_valid[w] = m; }
+  }
+}
+void finalize_aggs(const uint64_t* acc, int n_aggs, int64_t G, const FinalSpec& sp, void* out, uint64_t* out_valid) {
+  if (G == 0) return;
+  hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(G, kBlock)), dim3(kBlock), 0, stream(), (const unsigned long long*)acc, n_aggs, G, sp, out, out_valid);
+  PLX_HIP(hipGetLastError());
+}
+
+// packed group key (+ per-group valid flag) -> one key column
+__global__ __launch_bounds__(kBlock) void decode_key_kernel(const unsigned long long* __restrict__ packed, const unsigned char* __restrict__ kvalid, int64_t G,
+                                                            KeyDecode kd, void* __restrict__ out, uint64_t* __restrict__ out_valid) {
+  const int lane = lane_id();
+  const int64_t nwords = (G + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t w = wave; w < nwords; w += nwaves) {
+    const int64_t g = w * 64 + lane;
+    bool valid = false, bit = false;
+    if (g < G) {
+      const uint64_t code = (packed[g] >> kd.shift) & kd.mask;
+      valid = (!kvalid || kvalid[g]) && (kd.mask == ~0ull || code != kd.null_code);
+      const uint64_t v = valid ? code + (uint64_t)kd.min : 0;
+      bit = valid && (v & 1);
+      switch (kd.dtype) {
+        case PLX_BOOL: break;  // written through the ballot below
+        case PLX_I8: case PLX_U8: reinterpret_cast<uint8_t*>(out)[g] = (uint8_t)v; break;
+        case PLX_I16: case PLX_U16: reinterpret_cast<uint16_t*>(out)[g] = (uint16_t)v; break;
+        case PLX_I32: case PLX_U32: reinterpret_cast<uint32_t*>(out)[g] = (uint32_t)v; break;
+        case PLX_F32: { double d = as_f(v); reinterpret_cast<float*>(out)[g] = (float)d; } break;
+        default: reinterpret_cast<uint64_t*>(out)[g] = v; break;
+      }
+    }
+    if (kd.dtype == PLX_BOOL) { uint64_t b = ballot(bit); if (lane == 0) reinterpret_cast<uint64_t*>(out)[w] = b; }
+    if (out_valid) { uint64_t m = ballot(valid); if (lane == 0) out_valid[w] = m; }
+  }
+}
+void decode_key(const uint64_t* packed, const uint8_t* kvalid, int64_t G, const KeyDecode& kd, void* out, uint64_t* out_valid) {
+  if (G == 0) return;
+  hipLaunchKernelGGL(decode_key_kernel, dim3(grid_for(G, kBlock)), dim3(kBlock), 0, stream(), (const unsigned long long*)packed, (const unsigned char*)kvalid, G, kd, out, out_valid);
+  PLX_HIP(hipGetLastError());
+}
+
+int64_t table_compact(const uint64_t* keys, const uint64_t* acc, int64_t n_slots, int64_t cap, int n_aggs, int occ_agg, uint64_t* out_keys,
+                      uint8_t* out_key_valid, uint64_t* out_acc) {
+  Buf counter = dev_alloc_zero(8);
+  ProfileScope ps("table_compact", (uint64_t)n_slots * 8 * (uint64_t)(1 + n_aggs), (uint64_t)n_slots);
+  hipLaunchKernelGGL(hash_compact_kernel, dim3(grid_for(n_slots, kBlock * 2)), dim3(kBlock), 0, stream(), (const unsigned long long*)keys,
+                     (const unsigned long long*)acc, n_slots, cap, n_aggs, occ_agg, counter->as<unsigned long long>(), (unsigned long long*)out_keys,
+                     (unsigned char*)out_key_valid, (unsigned long long*)out_acc);
+  PLX_HIP(hipGetLastError());
+  uint64_t n = 0;
+  d2h_sync(&n, counter->ptr, 8);
+  return (int64_t)n;
+}
+
+}  // namespace k
+
+namespace fused {
+int find_static_shape(const Shape& s) {
+  for (int id = 0; id < kNumStaticShapes; id++) {
+    Shape t = static_shape(id);
+    if (memcmp(&t, &s, sizeof(Shape)) == 0) return id;
+  }
+  return -1;
+}
+}  // namespace fused
+}  // namespace plx

@@ -1,0 +1,38 @@
+// kernels_fused.hpp -- launchers of the fused scan kernels (kernels_fused.hip) and
+// the join kernels (kernels_join.hip).
+#pragma once
+#include "core.hpp"
+#include "fused.hpp"
+
+namespace plx {
+namespace k {
+
+// filter -> exprs -> whole-frame aggregates held in registers.
+// out_host[k] receives the 64-bit pattern of aggregate k
+// (synchronises).  static_id = fused::find_static_shape(sh) or -1.
+void fused_regagg(const fused::Shape& sh, const fused::Args& args, int static_id, uint64_t* out_host);
+// filter -> exprs -> LDS-resident table for dense group ids in [0, n_groups); out_dev
+// [n_groups][n_aggs] 64-bit patterns in HBM.  lds_agg_copies() == 0 => does not fit.
+int lds_agg_copies(int n_groups, int n_aggs);
+void fused_lds_agg(const fused::Shape& sh, const fused::Args& args, int n_groups, int static_id, uint64_t* out_dev);
+
+// filter -> exprs -> atomics into an HBM table. Tables must be initialised with
+// fill_u64(keys, cap + 2, kEmptyKey) / init_agg_cells(acc, slots, sh).
+void fused_dense_agg(const fused::Shape& sh, const fused::Args& args, const fused::DenseTable& t, int static_id);
+void fused_hash_agg(const fused::Shape& sh, const fused::Args& args, const fused::HashTable& t, int static_id);
+void fill_u64(uint64_t* p, int64_t n, uint64_t v);
+void init_agg_cells(uint64_t* acc, int64_t n_slots, const fused::Shape& sh);
+// Gather occupied table slots into dense arrays; returns the group count (synchronises).
+// cap >= 0: hash table with cap regular slots + 2 special; cap < 0: dense table
+// (out_keys = slot index, last slot = null group).  occ_agg: index of an AGG_LEN cell
+// (group exists iff non-zero) or -1 to use the key array.
+int64_t table_compact(const uint64_t* keys, const uint64_t* acc, int64_t n_slots, int64_t cap, int n_aggs, int occ_agg, uint64_t* out_keys,
+                      uint8_t* out_key_valid, uint64_t* out_acc);
+
+// aggregate cells [G][n_aggs] -> typed output column (+ validity bitmap, may be null)
+void finalize_aggs(const uint64_t* acc, int n_aggs, int64_t G, const fused::FinalSpec& sp, void* out, uint64_t* out_valid);
+// packed group keys -> one key column
+void decode_key(const uint64_t* packed, const uint8_t* kvalid, int64_t G, const fused::KeyDecode& kd, void* out, uint64_t* out_valid);
+
+}  // namespace k
+}  // namespace plx

@@ -1,0 +1,253 @@
+// kernels_join.hip -- hash join build / probe / emit and key-hash partitioning.
+//
+// Reference algorithm (restated, not ported): build_tables makes 3 passes and one
+// hashbrown map per partition (polars-ops/src/frame/join/hash_join/single_keys.rs:16-167);
+// probe_inner looks every probe key up and emits (idx_a, idx_b) per build duplicate
+// (single_keys_inner.rs:11-38).  GPU shape:
+//   build  : one open-addressing table in HBM (keys[cap] claimed with 64-bit CAS, slot =
+//            top bits of key * RANDOM_ODD like DirtyHash); duplicates form a chain:
+//            head[slot] = newest row (atomicExch), next[row] = previous head.
+//   probe 1: per probe row, find the slot and count the chain -> counts[i]
+//   scan   : device exclusive scan -> output offsets (kernels_scan.hip)
+//   probe 2: walk the chain again and write the pairs at offsets[i] (coalesced per row run)
+// Keys are read in their physical dtype and widened in registers (no materialised
+// 64-bit key copy); floats are canonicalised (-0 -> +0, one NaN: total_ord.rs:40-48).
+// Null keys never match (nulls_equal = false).
+#include "dev.hpp"
+#include "join.hpp"
+#include "kernels.hpp"
+#include "ops.hpp"
+#include "scan.hpp"
+
+namespace plx {
+namespace join {
+
+using namespace dev;
+using k::kBlock;
+
+constexpr uint64_t kEmpty = ~0ull;
+constexpr uint32_t kNoRow = 0xffffffffu;
+constexpr uint64_t kRandomOdd = 0x55fbfd6bfc5458e9ull;
+
+struct KeyCol {
+  const void* values;
+  const uint64_t* validity;
+  int dtype;
+  int64_t n;
+};
+
+__device__ __forceinline__ uint64_t load_key(const KeyCol& kc, int64_t i) {
+  switch (kc.dtype) {
+    case PLX_I8: return (uint64_t)(long long)reinterpret_cast<const int8_t*>(kc.values)[i];
+    case PLX_I16: return (uint64_t)(long long)reinterpret_cast<const int16_t*>(kc.values)[i];
+    case PLX_I32: return (uint64_t)(long long)reinterpret_cast<const int32_t*>(kc.values)[i];
+    case PLX_U8: return reinterpret_cast<const uint8_t*>(kc.values)[i];
+    case PLX_U16: return reinterpret_cast<const uint16_t*>(kc.values)[i];
+    case PLX_U32: return reinterpret_cast<const uint32_t*>(kc.values)[i];
+    case PLX_F32: { float f = reinterpret_cast<const float*>(kc.values)[i]; double d = (double)f; return (d != d) ? 0x7ff8000000000000ull : (uint64_t)__double_as_longlong(d + 0.0); }
+    case PLX_F64: { double d = reinterpret_cast<const double*>(kc.values)[i]; return (d != d) ? 0x7ff8000000000000ull : (uint64_t)__double_as_longlong(d + 0.0); }
+    case PLX_BOOL: return (reinterpret_cast<const uint64_t*>(kc.values)[i >> 6] >> (i & 63)) & 1;
+    default: return reinterpret_cast<const uint64_t*>(kc.values)[i];
+  }
+}
+__device__ __forceinline__ bool key_valid(const KeyCol& kc, int64_t i) { return !kc.validity || ((kc.validity[i >> 6] >> (i & 63)) & 1); }
+
+struct Table {
+  unsigned long long* keys;  // [cap + 1]; slot cap = the key whose bits equal kEmpty
+  unsigned int* head;        // [cap + 1]
+  unsigned int* next;        // [n_build]
+  unsigned int* flags;       // [0] = a chain longer than 1 exists (build keys not unique)
+  uint32_t log2_cap;
+};
+
+__device__ __forceinline__ int64_t find_or_claim(const Table& t, uint64_t key) {
+  const uint64_t cap = 1ull << t.log2_cap;
+  if (key == kEmpty) return (int64_t)cap;
+  uint64_t slot = (key * kRandomOdd) >> (64 - t.log2_cap);
+  for (;;) {
+    unsigned long long cur = t.keys[slot];
+    if (cur == key) return (int64_t)slot;
+    if (cur == kEmpty) {
+      unsigned long long old = atomicCAS(&t.keys[slot], (unsigned long long)kEmpty, (unsigned long long)key);
+      if (old == kEmpty || old == key) return (int64_t)slot;
+    }
+    slot = (slot + 1) & (cap - 1);
+  }
+}
+__device__ __forceinline__ int64_t find_slot(const Table& t, uint64_t key) {
+  const uint64_t cap = 1ull << t.log2_cap;
+  if (key == kEmpty) return (int64_t)cap;
+  uint64_t slot = (key * kRandomOdd) >> (64 - t.log2_cap);
+  for (;;) {
+    unsigned long long cur = t.keys[slot];
+    if (cur == key) return (int64_t)slot;
+    if (cur == kEmpty) return -1;
+    slot = (slot + 1) & (cap - 1);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void join_build_kernel(KeyCol build, Table t) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < build.n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (!key_valid(build, i)) { t.next[i] = kNoRow; continue; }
+    const int64_t slot = find_or_claim(t, load_key(build, i));
+    const unsigned int old = atomicExch(&t.head[slot], (unsigned int)i);
+    t.next[i] = old;
+    if (old != kNoRow) t.flags[0] = 1u;
+  }
+}
+
+// counts[i] = number of build matches of probe row i (left join: at least 1)
+__global__ __launch_bounds__(kBlock) void join_count_kernel(KeyCol probe, Table t, int left_join, uint32_t* __restrict__ counts) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < probe.n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t c = 0;
+    if (key_valid(probe, i)) {
+      const int64_t slot = find_slot(t, load_key(probe, i));
+      if (slot >= 0) { for (unsigned int r = t.head[slot]; r != kNoRow; r = t.next[r]) c++; }
+    }
+    counts[i] = (left_join && c == 0) ? 1u : c;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void join_emit_kernel(KeyCol probe, Table t, int left_join, const uint64_t* __restrict__ offsets,
+                                                           uint32_t* __restrict__ out_probe, uint32_t* __restrict__ out_build) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < probe.n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t o = offsets[i];
+    bool any = false;
+    if (key_valid(probe, i)) {
+      const int64_t slot = find_slot(t, load_key(probe, i));
+      if (slot >= 0) {
+        for (unsigned int r = t.head[slot]; r != kNoRow; r = t.next[r]) { out_probe[o] = (uint32_t)i; out_build[o] = r; o++; any = true; }
+      }
+    }
+    if (left_join && !any) { out_probe[o] = (uint32_t)i; out_build[o] = kNoRow; }
+  }
+}
+
+static KeyCol key_col(const ColumnPtr& c) { KeyCol kc; kc.values = c->data(); kc.validity = c->valid_words(); kc.dtype = c->dtype; kc.n = c->len; return kc; }
+static int ceil_log2(uint64_t x) { int b = 0; while ((1ull << b) < x) b++; return b; }
+
+void join_indices(int how, const ColumnPtr& left_key, const ColumnPtr& right_key, ColumnPtr& left_idx, ColumnPtr& right_idx, std::string* desc) {
+  PLX_REQUIRE(left_key->dtype == right_key->dtype, PLX_ERR_INVALID,
+              std::string("join keys have different dtypes (") + dtype_name(left_key->dtype) + ", " + dtype_name(right_key->dtype) + ")");
+  PLX_REQUIRE(how == PLX_JOIN_INNER || how == PLX_JOIN_LEFT, PLX_ERR_UNSUPPORTED, "join type outside the hot path");
+  PLX_REQUIRE(left_key->len < 0xffffffffll && right_key->len < 0xffffffffll, PLX_ERR_UNSUPPORTED, "join side exceeds u32 IdxSize");
+  const bool left_join = how == PLX_JOIN_LEFT;
+  // det_hash_prone_order (hash_join/mod.rs:41-50): build on the shorter relation; left join builds on the right
+  const bool swapped = !left_join && !(left_key->len > right_key->len);
+  const ColumnPtr& probe = left_join ? left_key : (swapped ? right_key : left_key);
+  const ColumnPtr& build = left_join ? right_key : (swapped ? left_key : right_key);
+  const int log2_cap = std::max(4, ceil_log2((uint64_t)std::max<int64_t>(build->len, 1) * 2));
+  const uint64_t cap = 1ull << log2_cap;
+  Buf keys = dev_alloc(sizeof(uint64_t) * (cap + 1));
+  Buf head = dev_alloc(sizeof(uint32_t) * (cap + 1));
+  Buf next = dev_alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(build->len, 1));
+  Buf flags = dev_alloc_zero(16);
+  PLX_HIP(hipMemsetAsync(keys->ptr, 0xff, sizeof(uint64_t) * (cap + 1), stream()));
+  PLX_HIP(hipMemsetAsync(head->ptr, 0xff, sizeof(uint32_t) * (cap + 1), stream()));
+  Table t; t.keys = keys->as<unsigned long long>(); t.head = head->as<unsigned int>(); t.next = next->as<unsigned int>(); t.flags = flags->as<unsigned int>(); t.log2_cap = (uint32_t)log2_cap;
+  const int kw = dtype_width(build->dtype) ? dtype_width(build->dtype) : 1;
+  if (build->len) {
+    ProfileScope ps("join_build", (uint64_t)build->len * kw, (uint64_t)build->len);
+    hipLaunchKernelGGL(join_build_kernel, dim3(k::grid_for(build->len, kBlock * 2)), dim3(kBlock), 0, stream(), key_col(build), t);
+    PLX_HIP(hipGetLastError());
+  }
+  const int64_t np = probe->len;
+  Buf counts = dev_alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(np, 1));
+  Buf offsets = dev_alloc(sizeof(uint64_t) * (size_t)(np + 1));
+  if (np) {
+    ProfileScope ps("join_probe_count", (uint64_t)np * (kw + 4), (uint64_t)np);
+    hipLaunchKernelGGL(join_count_kernel, dim3(k::grid_for(np, kBlock * 2)), dim3(kBlock), 0, stream(), key_col(probe), t, left_join ? 1 : 0, counts->as<uint32_t>());
+    PLX_HIP(hipGetLastError());
+  }
+  k::exclusive_scan_u32(counts->as<uint32_t>(), offsets->as<uint64_t>(), np);
+  uint64_t total = 0;
+  d2h_sync(&total, offsets->as<uint64_t>() + np, 8);
+  auto mk_idx = [&](int64_t n) { auto c = std::make_shared<Column>(); c->dtype = PLX_U32; c->len = n; c->values = dev_alloc(values_bytes(PLX_U32, n)); c->null_count = 0; return c; };
+  ColumnPtr pidx = mk_idx((int64_t)total), bidx = mk_idx((int64_t)total);
+  if (total) {
+    ProfileScope ps("join_probe_emit", (uint64_t)np * (kw + 8) + total * 8, (uint64_t)np);
+    hipLaunchKernelGGL(join_emit_kernel, dim3(k::grid_for(np, kBlock * 2)), dim3(kBlock), 0, stream(), key_col(probe), t, left_join ? 1 : 0, offsets->as<uint64_t>(),
+                       pidx->values->as<uint32_t>(), bidx->values->as<uint32_t>());
+    PLX_HIP(hipGetLastError());
+  }
+  if (left_join && total) {
+    // unmatched rows carry the kNoRow sentinel -> validity bitmap
+    plx_scalar s; s.u = kNoRow;
+    ColumnPtr ok = ops::cmp_scalar(PLX_NE, bidx, s);
+    bidx->validity = ok->values; bidx->null_count = -1;
+    if (column_null_count(bidx) == 0) { bidx->validity = nullptr; bidx->null_count = 0; }
+  }
+  if (desc) {
+    uint32_t f = 0; d2h_sync(&f, flags->ptr, 4);
+    *desc = std::string("hash_join[build=") + (left_join ? "right" : (swapped ? "left" : "right")) + " rows=" + std::to_string(build->len) + " cap=2^" + std::to_string(log2_cap) +
+            (f ? " dup-keys" : " unique-keys") + ", probe rows=" + std::to_string(np) + ", pairs=" + std::to_string(total) + "]";
+  }
+  if (left_join || !swapped) { left_idx = pidx; right_idx = bidx; }
+  else { left_idx = bidx; right_idx = pidx; }
+}
+
+// -------------------------------------------------------------- partitioning ---
+__device__ __forceinline__ uint32_t partition_of(const KeyCol& kc, int64_t i, uint64_t seed, uint32_t n_parts) {
+  if (!key_valid(kc, i)) return 0;  // null_partition() == 0
+  const uint64_t h = load_key(kc, i) * kRandomOdd;  // dirty_hash
+  return (uint32_t)__umul64hi(h * seed, (uint64_t)n_parts);
+}
+__global__ __launch_bounds__(kBlock) void partition_count_kernel(KeyCol kc, uint64_t seed, uint32_t n_parts, unsigned long long* __restrict__ counts) {
+  extern __shared__ unsigned int lcount[];
+  for (uint32_t p = threadIdx.x; p < n_parts; p += blockDim.x) lcount[p] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < kc.n; i += (int64_t)gridDim.x * blockDim.x) atomicAdd(&lcount[partition_of(kc, i, seed, n_parts)], 1u);
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < n_parts; p += blockDim.x) if (lcount[p]) atomicAdd(&counts[p], (unsigned long long)lcount[p]);
+}
+__global__ __launch_bounds__(kBlock) void partition_scatter_kernel(KeyCol kc, uint64_t seed, uint32_t n_parts, unsigned long long* __restrict__ cursors,
+                                                                   uint32_t* __restrict__ perm) {
+  // wave-aggregated cursor bump per partition present in the wave
+  const int lane = lane_id();
+  for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < kc.n; base += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = base + lane;
+    const bool active = i < kc.n;
+    const uint32_t p = active ? partition_of(kc, i, seed, n_parts) : 0xffffffffu;
+    uint64_t todo = ballot(active);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t lp = __shfl(p, leader, 64);
+      const uint64_t same = ballot(active && p == lp);
+      unsigned long long o = 0;
+      if (lane == leader) o = atomicAdd(&cursors[lp], (unsigned long long)popc64(same));
+      o = shfl_u64(o, leader);
+      if (active && p == lp) perm[o + (uint64_t)prefix_rank(same)] = (uint32_t)i;
+      todo &= ~same;
+    }
+  }
+}
+
+void hash_partition(const ColumnPtr& key, int n_partitions, uint64_t seed, ColumnPtr& perm, int64_t* counts_out) {
+  PLX_REQUIRE(n_partitions >= 1 && n_partitions <= 4096, PLX_ERR_INVALID, "hash_partition: 1..4096 partitions");
+  // HashPartitioner::new seed mixing (hashing.rs:81-96)
+  auto fold = [](uint64_t a, uint64_t b) { unsigned __int128 r = (unsigned __int128)a * b; return (uint64_t)r ^ (uint64_t)(r >> 64); };
+  uint64_t s = fold(seed ^ 0x85921e81c41226a0ull, 0x3bc1d0faba166294ull);
+  s = fold(s, 0xfbde893e21a73756ull) | 1;
+  const int64_t n = key->len;
+  perm = std::make_shared<Column>();
+  perm->dtype = PLX_U32; perm->len = n; perm->values = dev_alloc(values_bytes(PLX_U32, n)); perm->null_count = 0;
+  Buf counts = dev_alloc_zero(sizeof(uint64_t) * (size_t)n_partitions);
+  Buf cursors = dev_alloc(sizeof(uint64_t) * (size_t)(n_partitions + 1));
+  std::vector<uint64_t> h((size_t)n_partitions, 0);
+  if (n) {
+    ProfileScope ps("hash_partition", (uint64_t)n * (dtype_width(key->dtype) * 2 + 4), (uint64_t)n);
+    const int grid = k::grid_for(n, kBlock * 8);
+    hipLaunchKernelGGL(partition_count_kernel, dim3(grid), dim3(kBlock), sizeof(unsigned int) * (size_t)n_partitions, stream(), key_col(key), s, (uint32_t)n_partitions,
+                       counts->as<unsigned long long>());
+    PLX_HIP(hipGetLastError());
+    k::exclusive_scan_u64(counts->as<uint64_t>(), cursors->as<uint64_t>(), n_partitions);
+    hipLaunchKernelGGL(partition_scatter_kernel, dim3(grid), dim3(kBlock), 0, stream(), key_col(key), s, (uint32_t)n_partitions, cursors->as<unsigned long long>(),
+                       perm->values->as<uint32_t>());
+    PLX_HIP(hipGetLastError());
+    d2h_sync(h.data(), counts->ptr, sizeof(uint64_t) * (size_t)n_partitions);
+  }
+  for (int p = 0; p < n_partitions; p++) counts_out[p] = (int64_t)h[p];
+}
+
+}  // namespace join
+}  // namespace plx

@@ -1,0 +1,520 @@
+"""Series / DataFrame / LazyFrame mirror of the Polars API for the hot path.
+
+``LazyFrame.collect()`` lowers the plan (plan.py) and hands the arenas to
+``plx_execute_plan`` -- the place where, inside Polars, ``create_physical_plan`` would
+dispatch to the GPU executor (crates/polars-mem-engine/src/planner/lp.rs:326-878).
+Columns live in HBM between operators; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, Iterable, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _ffi as F
+from . import datatypes as T
+from . import plan as P
+from .expr import Expr, col as _col
+
+
+def _pack_validity(valid: np.ndarray) -> np.ndarray:
+    return np.packbits(np.asarray(valid, dtype=bool), bitorder="little")
+
+
+class Series:
+    """A named device-resident column (handle into libpolars_amd)."""
+
+    def __init__(self, name: str = "", values: Any = None, dtype: Optional[T.DataType] = None, validity: Any = None, *, _handle: int = 0,
+                 _dtype: Optional[T.DataType] = None, _keepalive: Any = None):
+        self.name = name
+        self._keepalive = _keepalive
+        if _handle:
+            self._h = _handle
+            self.dtype = _dtype if _dtype is not None else self._query_dtype()
+            return
+        F.ensure_init()
+        self._h, self.dtype = _upload(values, dtype, validity)
+
+    # -- construction ----------------------------------------------------------------------
+    @classmethod
+    def _from_handle(cls, name: str, handle: int, dtype: Optional[T.DataType] = None) -> "Series":
+        return cls(name, _handle=handle, _dtype=dtype)
+
+    @classmethod
+    def from_device(cls, name: str, dtype: T.DataType, values_ptr: int, n: int, validity_ptr: int = 0, keepalive: Any = None) -> "Series":
+        """Wrap caller-owned HBM (e.g. a torch tensor's data_ptr()) without copying."""
+        F.ensure_init()
+        h = C.c_uint64()
+        F.check(F.lib().plx_column_from_device(dtype.physical, C.c_void_p(values_ptr), C.c_void_p(validity_ptr or None), n, C.byref(h)))
+        return cls(name, _handle=h.value, _dtype=dtype, _keepalive=keepalive)
+
+    @classmethod
+    def from_torch(cls, name: str, tensor, dtype: Optional[T.DataType] = None) -> "Series":
+        import torch
+        m = {torch.int8: T.Int8, torch.int16: T.Int16, torch.int32: T.Int32, torch.int64: T.Int64, torch.uint8: T.UInt8,
+             torch.float32: T.Float32, torch.float64: T.Float64}
+        t = tensor.contiguous()
+        return cls.from_device(name, dtype or m[t.dtype], t.data_ptr(), t.numel(), keepalive=t)
+
+    @classmethod
+    def from_arrow(cls, name: str, arr) -> "Series":
+        """Import through the Arrow C Data Interface (plx_column_import_arrow)."""
+        import pyarrow as pa
+        F.ensure_init()
+        if isinstance(arr, pa.ChunkedArray):
+            arr = arr.combine_chunks()
+        logical = None
+        if pa.types.is_dictionary(arr.type) or pa.types.is_string(arr.type) or pa.types.is_large_string(arr.type):
+            d = arr if pa.types.is_dictionary(arr.type) else arr.dictionary_encode()
+            logical = T.Categorical(d.dictionary.to_pylist())
+            arr = d.indices.cast(pa.uint32())
+        elif pa.types.is_date32(arr.type):
+            logical = T.Date
+        elif pa.types.is_timestamp(arr.type):
+            logical = T.Datetime
+            arr = arr.cast(pa.timestamp("us"))
+        a, s = F.ArrowArray(), F.ArrowSchema()
+        arr._export_to_c(C.addressof(a), C.addressof(s))
+        h = C.c_uint64()
+        F.check(F.lib().plx_column_import_arrow(C.byref(a), C.byref(s), C.byref(h)))
+        return cls(name, _handle=h.value, _dtype=logical)
+
+    def _query_dtype(self) -> T.DataType:
+        dt = C.c_int32()
+        F.check(F.lib().plx_column_info(self._h, C.byref(dt), None, None))
+        return T.PHYSICAL_TO_DTYPE[dt.value]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", 0) and F._lib is not None:
+                F._lib.plx_column_free(self._h)
+        except Exception:
+            pass
+
+    # -- metadata -----------------------------------------------------------------------------
+    def __len__(self) -> int:
+        n = C.c_int64()
+        F.check(F.lib().plx_column_info(self._h, None, C.byref(n), None))
+        return n.value
+
+    def null_count(self) -> int:
+        n = C.c_int64()
+        F.check(F.lib().plx_column_info(self._h, None, None, C.byref(n)))
+        return n.value
+
+    def rename(self, name: str) -> "Series":
+        F.check(F.lib().plx_column_retain(self._h))
+        return Series(name, _handle=self._h, _dtype=self.dtype, _keepalive=self._keepalive)
+
+    alias = rename
+
+    def device_ptrs(self):
+        v, m = C.c_void_p(), C.c_void_p()
+        F.check(F.lib().plx_column_device_ptrs(self._h, C.byref(v), C.byref(m)))
+        return v.value or 0, m.value or 0
+
+    # -- download -----------------------------------------------------------------------------
+    def _download(self):
+        n = len(self)
+        phys = self.dtype.physical
+        if phys == F.BOOL:
+            vbuf = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
+        else:
+            vbuf = np.zeros(n, dtype=T.PHYSICAL_TO_DTYPE[phys].np_dtype)
+        mbuf = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
+        hv = C.c_int32()
+        F.check(F.lib().plx_column_to_host(self._h, vbuf.ctypes.data_as(C.c_void_p), mbuf.ctypes.data_as(C.c_void_p), C.byref(hv)))
+        values = np.unpackbits(vbuf, bitorder="little")[:n].astype(bool) if phys == F.BOOL else vbuf
+        valid = np.unpackbits(mbuf, bitorder="little")[:n].astype(bool) if hv.value else None
+        if valid is not None and valid.all():
+            valid = None
+        return values, valid
+
+    def to_numpy(self) -> np.ndarray:
+        """Physical values (rows that are null hold unspecified values; see ``validity``)."""
+        return self._download()[0]
+
+    def validity(self) -> Optional[np.ndarray]:
+        return self._download()[1]
+
+    def to_list(self) -> list:
+        values, valid = self._download()
+        out = values.tolist()
+        if isinstance(self.dtype, T.Categorical) and self.dtype.categories:
+            out = [self.dtype.categories[c] if c < len(self.dtype.categories) else None for c in out]
+        if valid is not None:
+            out = [v if ok else None for v, ok in zip(out, valid.tolist())]
+        return out
+
+    def to_arrow(self):
+        import pyarrow as pa
+        a, s = F.ArrowArray(), F.ArrowSchema()
+        F.check(F.lib().plx_column_export_arrow(self._h, C.byref(a), C.byref(s)))
+        return pa.Array._import_from_c(C.addressof(a), C.addressof(s))
+
+    # -- kernel-level operators (one reference kernel family each) ------------------------------
+    def _binary_col(self, fn, op: int, other: "Series") -> "Series":
+        h = C.c_uint64()
+        F.check(fn(op, self._h, other._h, C.byref(h)))
+        return Series._from_handle(self.name, h.value)
+
+    def _scalar(self, value) -> F.Scalar:
+        s = F.Scalar()
+        phys = self.dtype.physical
+        if phys == F.F64:
+            s.f64 = float(value)
+        elif phys == F.F32:
+            s.f32 = float(value)
+        elif phys in (F.U8, F.U16, F.U32, F.U64):
+            s.u = int(value)
+        else:
+            s.i = int(value)
+        return s
+
+    def cmp(self, op: int, other) -> "Series":
+        if isinstance(other, Series):
+            return self._binary_col(F.lib().plx_cmp, op, other)
+        h = C.c_uint64()
+        F.check(F.lib().plx_cmp_scalar(op, self._h, self._scalar(other), C.byref(h)))
+        return Series._from_handle(self.name, h.value, T.Boolean)
+
+    def __gt__(self, o): return self.cmp(F.GT, o)
+    def __ge__(self, o): return self.cmp(F.GE, o)
+    def __lt__(self, o): return self.cmp(F.LT, o)
+    def __le__(self, o): return self.cmp(F.LE, o)
+    def eq(self, o): return self.cmp(F.EQ, o)
+    def ne(self, o): return self.cmp(F.NE, o)
+
+    def arith(self, op: int, other, scalar_on_left: bool = False) -> "Series":
+        if isinstance(other, Series):
+            return self._binary_col(F.lib().plx_arith, op, other)
+        h = C.c_uint64()
+        F.check(F.lib().plx_arith_scalar(op, self._h, self._scalar(other), int(scalar_on_left), C.byref(h)))
+        return Series._from_handle(self.name, h.value)
+
+    def __add__(self, o): return self.arith(F.ADD, o)
+    def __sub__(self, o): return self.arith(F.SUB, o)
+    def __mul__(self, o): return self.arith(F.MUL, o)
+    def __truediv__(self, o): return self.arith(F.TRUE_DIV, o)
+    def __floordiv__(self, o): return self.arith(F.FLOOR_DIV, o)
+    def __mod__(self, o): return self.arith(F.MOD, o)
+    def __radd__(self, o): return self.arith(F.ADD, o, True)
+    def __rsub__(self, o): return self.arith(F.SUB, o, True)
+    def __rmul__(self, o): return self.arith(F.MUL, o, True)
+    def __rtruediv__(self, o): return self.arith(F.TRUE_DIV, o, True)
+    def __rfloordiv__(self, o): return self.arith(F.FLOOR_DIV, o, True)
+    def __rmod__(self, o): return self.arith(F.MOD, o, True)
+
+    def __and__(self, o: "Series"): return self._binary_col(F.lib().plx_bitmap_binop, F.AND, o)
+    def __or__(self, o: "Series"): return self._binary_col(F.lib().plx_bitmap_binop, F.OR, o)
+    def __xor__(self, o: "Series"): return self._binary_col(F.lib().plx_bitmap_binop, F.XOR, o)
+
+    def __invert__(self) -> "Series":
+        h = C.c_uint64()
+        F.check(F.lib().plx_bitmap_not(self._h, C.byref(h)))
+        return Series._from_handle(self.name, h.value, T.Boolean)
+
+    def cast(self, dtype: T.DataType) -> "Series":
+        h = C.c_uint64()
+        F.check(F.lib().plx_cast(self._h, dtype.physical, C.byref(h)))
+        return Series._from_handle(self.name, h.value, dtype)
+
+    def filter(self, mask: "Series") -> "Series":
+        h = C.c_uint64()
+        F.check(F.lib().plx_filter(self._h, mask._h, C.byref(h)))
+        return Series._from_handle(self.name, h.value, self.dtype)
+
+    def gather(self, idx: "Series") -> "Series":
+        h = C.c_uint64()
+        F.check(F.lib().plx_gather(self._h, idx._h, C.byref(h)))
+        return Series._from_handle(self.name, h.value, self.dtype)
+
+    def _reduce(self, op: int):
+        v, dt, ok = F.Scalar(), C.c_int32(), C.c_int32()
+        F.check(F.lib().plx_reduce(op, self._h, C.byref(v), C.byref(dt), C.byref(ok)))
+        if not ok.value:
+            return None
+        d = dt.value
+        if d == F.F64:
+            return v.f64
+        if d == F.F32:
+            return float(np.float32(v.f32))
+        if d in (F.U8, F.U16, F.U32, F.U64):
+            return int(v.u) & ((1 << (8 * F.DTYPE_WIDTH[d])) - 1)
+        if d == F.BOOL:
+            return bool(v.u & 1)
+        w = 8 * F.DTYPE_WIDTH[d]
+        x = int(v.u) & ((1 << w) - 1)
+        return x - (1 << w) if x >= (1 << (w - 1)) else x
+
+    def sum(self): return self._reduce(F.AGG_SUM)
+    def mean(self): return self._reduce(F.AGG_MEAN)
+    def min(self): return self._reduce(F.AGG_MIN)
+    def max(self): return self._reduce(F.AGG_MAX)
+    def count(self): return self._reduce(F.AGG_COUNT)
+    def len(self): return len(self)
+
+    def __repr__(self) -> str:
+        return f"Series({self.name!r}, {self.dtype}, len={len(self)})"
+
+
+def _upload(values: Any, dtype: Optional[T.DataType], validity: Any):
+    """Host data -> HBM column. Accepts numpy arrays, python lists (None = null),
+    numpy masked arrays and pyarrow arrays."""
+    try:
+        import pyarrow as pa
+        if isinstance(values, (pa.Array, pa.ChunkedArray)):
+            s = Series.from_arrow("", values)
+            h = s._h
+            F.check(F.lib().plx_column_retain(h))
+            return h, s.dtype
+    except ImportError:
+        pass
+    valid = None
+    if isinstance(values, np.ma.MaskedArray):
+        valid = ~np.ma.getmaskarray(values)
+        values = values.data
+    if isinstance(values, (list, tuple)):
+        has_none = any(v is None for v in values)
+        if any(isinstance(v, str) for v in values):
+            cats = sorted({v for v in values if v is not None})
+            lut = {c: i for i, c in enumerate(cats)}
+            valid = np.array([v is not None for v in values], dtype=bool) if has_none else None
+            values = np.array([lut[v] if v is not None else 0 for v in values], dtype=np.uint32)
+            dtype = T.Categorical(cats)
+        else:
+            if has_none:
+                valid = np.array([v is not None for v in values], dtype=bool)
+                fill = False if all(isinstance(v, bool) for v in values if v is not None) else 0
+                values = [fill if v is None else v for v in values]
+            if dtype is not None and dtype.np_dtype is not None:
+                values = np.array(values, dtype=dtype.np_dtype)
+            elif dtype == T.Boolean:
+                values = np.array(values, dtype=bool)
+            else:
+                values = np.array(values)
+                if values.dtype == np.dtype("O") or values.size == 0:
+                    values = values.astype(np.float64 if dtype is None else dtype.np_dtype)
+    values = np.ascontiguousarray(values)
+    if validity is not None:
+        valid = np.asarray(validity, dtype=bool)
+    if dtype is None:
+        dtype = T.NP_TO_DTYPE[values.dtype]
+    elif dtype.np_dtype is not None and values.dtype != dtype.np_dtype:
+        values = values.astype(dtype.np_dtype)
+    n = values.shape[0]
+    if dtype == T.Boolean:
+        vbuf = np.packbits(values.astype(bool), bitorder="little")
+    else:
+        vbuf = values
+    vbuf = np.ascontiguousarray(vbuf)
+    vptr = vbuf.ctypes.data_as(C.c_void_p) if vbuf.size else C.c_void_p(0)
+    if n == 0:
+        dummy = np.zeros(8, dtype=np.uint8)
+        vptr = dummy.ctypes.data_as(C.c_void_p)
+    mptr = C.c_void_p(0)
+    mbuf = None
+    if valid is not None and not valid.all():
+        mbuf = _pack_validity(valid)
+        mptr = mbuf.ctypes.data_as(C.c_void_p)
+    h = C.c_uint64()
+    F.check(F.lib().plx_column_from_host(dtype.physical, vptr, mptr, 0, n, C.byref(h)))
+    return h.value, dtype
+
+
+class DataFrame:
+    def __init__(self, data: Union[Dict[str, Any], Sequence[Series], None] = None):
+        self._cols: List[Series] = []
+        self._fh = 0
+        if data is None:
+            return
+        if isinstance(data, dict):
+            for name, v in data.items():
+                self._cols.append(v.rename(name) if isinstance(v, Series) else Series(name, v))
+        else:
+            self._cols = list(data)
+        n = {len(c) for c in self._cols}
+        if len(n) > 1:
+            raise ValueError(f"columns have different lengths: {sorted(n)}")
+
+    # -- schema -----------------------------------------------------------------------------------
+    @property
+    def columns(self) -> List[str]:
+        return [c.name for c in self._cols]
+
+    @property
+    def schema(self) -> Dict[str, T.DataType]:
+        return {c.name: c.dtype for c in self._cols}
+
+    @property
+    def height(self) -> int:
+        return len(self._cols[0]) if self._cols else 0
+
+    @property
+    def shape(self):
+        return (self.height, len(self._cols))
+
+    def __getitem__(self, name: str) -> Series:
+        for c in self._cols:
+            if c.name == name:
+                return c
+        raise KeyError(name)
+
+    def get_columns(self) -> List[Series]:
+        return list(self._cols)
+
+    def _frame_handle(self) -> int:
+        if not self._fh:
+            n = len(self._cols)
+            names = (C.c_char_p * max(n, 1))(*[c.name.encode() for c in self._cols])
+            hs = (C.c_uint64 * max(n, 1))(*[c._h for c in self._cols])
+            h = C.c_uint64()
+            F.check(F.lib().plx_frame_new(names, hs, n, C.byref(h)))
+            self._fh = h.value
+        return self._fh
+
+    def __del__(self):
+        try:
+            if getattr(self, "_fh", 0) and F._lib is not None:
+                F._lib.plx_frame_free(self._fh)
+        except Exception:
+            pass
+
+    @classmethod
+    def _from_frame_handle(cls, fh: int, schema_hint: Optional[Dict[str, T.DataType]] = None) -> "DataFrame":
+        w = C.c_int32()
+        F.check(F.lib().plx_frame_shape(fh, None, C.byref(w)))
+        cols = []
+        for i in range(w.value):
+            name, h = C.c_char_p(), C.c_uint64()
+            F.check(F.lib().plx_frame_column(fh, i, C.byref(name), C.byref(h)))
+            nm = name.value.decode()
+            s = Series._from_handle(nm, h.value)
+            hint = (schema_hint or {}).get(nm)
+            if hint is not None and hint.physical == s.dtype.physical:
+                s.dtype = hint
+            cols.append(s)
+        df = cls(cols)
+        df._fh = fh
+        return df
+
+    # -- eager conveniences (all lazy underneath) ---------------------------------------------
+    def lazy(self) -> "LazyFrame":
+        return LazyFrame(P.Node("scan", frame=self))
+
+    def filter(self, predicate: Expr) -> "DataFrame":
+        return self.lazy().filter(predicate).collect()
+
+    def select(self, *exprs) -> "DataFrame":
+        return self.lazy().select(*exprs).collect()
+
+    def with_columns(self, *exprs) -> "DataFrame":
+        return self.lazy().with_columns(*exprs).collect()
+
+    def group_by(self, *keys, maintain_order: bool = False) -> "GroupBy":
+        return GroupBy(self.lazy(), keys, maintain_order, eager=True)
+
+    def join(self, other: "DataFrame", on=None, how: str = "inner", left_on=None, right_on=None, suffix: str = "_right") -> "DataFrame":
+        return self.lazy().join(other.lazy(), on=on, how=how, left_on=left_on, right_on=right_on, suffix=suffix).collect()
+
+    # -- host export --------------------------------------------------------------------------------
+    def to_dict(self) -> Dict[str, list]:
+        return {c.name: c.to_list() for c in self._cols}
+
+    def rows(self) -> List[tuple]:
+        cols = [c.to_list() for c in self._cols]
+        return list(zip(*cols)) if cols else []
+
+    def to_arrow(self):
+        import pyarrow as pa
+        return pa.table({c.name: c.to_arrow() for c in self._cols})
+
+    def sort_host(self, by: Union[str, Sequence[str]]) -> Dict[str, list]:
+        """Host-side ordering helper for comparing unordered results (sort / top-k are out
+        of scope on the GPU: SURVEY.md section 8e)."""
+        by = [by] if isinstance(by, str) else list(by)
+        d = self.to_dict()
+        n = self.height
+        key = lambda i: tuple((d[b][i] is None, d[b][i]) for b in by)
+        order = sorted(range(n), key=key)
+        return {k: [v[i] for i in order] for k, v in d.items()}
+
+    def __repr__(self) -> str:
+        return f"DataFrame(shape={self.shape}, schema={self.schema})"
+
+
+def _as_exprs(items: Iterable[Any]) -> List[Expr]:
+    out: List[Expr] = []
+    for it in items:
+        if isinstance(it, (list, tuple)):
+            out.extend(_as_exprs(it))
+        elif isinstance(it, str):
+            out.append(_col(it))
+        else:
+            out.append(it)
+    return out
+
+
+class LazyFrame:
+    def __init__(self, node: P.Node):
+        self._node = node
+
+    def filter(self, predicate: Expr) -> "LazyFrame":
+        return LazyFrame(P.Node("filter", input=self._node, predicate=predicate))
+
+    def select(self, *exprs, **named) -> "LazyFrame":
+        es = _as_exprs(exprs) + [e.alias(k) for k, e in named.items()]
+        return LazyFrame(P.Node("select", input=self._node, exprs=es))
+
+    def with_columns(self, *exprs, **named) -> "LazyFrame":
+        es = _as_exprs(exprs) + [e.alias(k) for k, e in named.items()]
+        return LazyFrame(P.Node("with_columns", input=self._node, exprs=es))
+
+    def group_by(self, *keys, maintain_order: bool = False) -> "GroupBy":
+        return GroupBy(self, keys, maintain_order)
+
+    def join(self, other: "LazyFrame", on=None, how: str = "inner", left_on=None, right_on=None, suffix: str = "_right") -> "LazyFrame":
+        if on is not None:
+            left_on = right_on = on
+        lo, ro = _as_exprs([left_on]), _as_exprs([right_on])
+        return LazyFrame(P.Node("join", left=self._node, right=other._node, left_on=lo, right_on=ro, how=how, suffix=suffix))
+
+    # -- execution -----------------------------------------------------------------------------------
+    def _lower(self):
+        low = P.Lowering()
+        root, schema = low.lower_node(self._node)
+        return low, root, schema
+
+    def collect(self, *, no_fusion: bool = False) -> DataFrame:
+        F.ensure_init()
+        low, root, schema = self._lower()
+        ir, n_ir, ae, n_ae, keep = low.to_c()
+        out = C.c_uint64()
+        F.check(F.lib().plx_execute_plan(ir, n_ir, ae, n_ae, root, F.PLAN_NO_FUSION if no_fusion else 0, C.byref(out)))
+        del keep
+        return DataFrame._from_frame_handle(out.value, schema)
+
+    def explain(self) -> str:
+        """Physical plan chosen by the last collect() on this thread."""
+        return F.last_plan()
+
+    def describe_fusion(self):
+        """(fusable, static_shape_id, reason, program dump) -- compile only, no kernel launch."""
+        low, root, _ = self._lower()
+        ir, n_ir, ae, n_ae, keep = low.to_c()
+        fus, sid = C.c_int32(), C.c_int32()
+        why = C.create_string_buffer(512)
+        F.check(F.lib().plx_describe_fusion(ir, n_ir, ae, n_ae, root, C.byref(fus), C.byref(sid), why, 512))
+        del keep
+        return bool(fus.value), sid.value, why.value.decode(), F.last_plan()
+
+
+class GroupBy:
+    def __init__(self, lf: LazyFrame, keys, maintain_order: bool, eager: bool = False):
+        self._lf, self._keys, self._mo, self._eager = lf, _as_exprs(keys), maintain_order, eager
+
+    def agg(self, *aggs, **named):
+        es = _as_exprs(aggs) + [e.alias(k) for k, e in named.items()]
+        out = LazyFrame(P.Node("group_by", input=self._lf._node, keys=self._keys, aggs=es, maintain_order=self._mo))
+        return out.collect() if self._eager else out

@@ -1,0 +1,58 @@
+"""The benchmark queries of BASELINE.json / SURVEY.md section 8(d) and Appendix A, written
+in the mirror API.  Shared by bench.py, the parity tests and tools/gen_fused_shapes.py."""
+from __future__ import annotations
+
+import datetime as dt
+
+from . import expr as E
+
+Q1_CUTOFF = dt.datetime(1998, 9, 2)
+Q3_DATE = dt.datetime(1995, 3, 15)
+
+
+def cfg1(lf, k=2 ** 30):
+    """filter(a > k).select(a.sum())  -- BASELINE config 1"""
+    return lf.filter(E.col("a") > k).select(E.col("a").sum())
+
+
+def cfg2(lf, k=2 ** 30):
+    """filter(a > k).select((x*(1-y)).sum(), x.mean(), a.sum())  -- BASELINE config 2"""
+    return lf.filter(E.col("a") > k).select((E.col("x") * (1 - E.col("y"))).sum().alias("xy"), E.col("x").mean().alias("x_mean"),
+                                            E.col("a").sum().alias("a_sum"))
+
+
+def cfg3(lf):
+    """group_by(key).agg(v.sum(), v.count())  -- BASELINE config 3"""
+    return lf.group_by("key").agg(E.col("v").sum().alias("v_sum"), E.col("v").count().alias("v_count"))
+
+
+def cfg5(lf):
+    """group_by(k).agg(v.sum(), v.mean()) on dictionary-encoded string keys -- BASELINE config 5"""
+    return lf.group_by("k").agg(E.col("v").sum().alias("v_sum"), E.col("v").mean().alias("v_mean"))
+
+
+def q1(lineitem, cutoff=Q1_CUTOFF):
+    """TPC-H Q1; the final sort by (flag, status) happens on the host."""
+    c = E.col
+    disc_price = c("l_extendedprice") * (1 - c("l_discount"))
+    return (lineitem.filter(c("l_shipdate") <= cutoff)
+            .group_by("l_returnflag", "l_linestatus")
+            .agg(c("l_quantity").sum().alias("sum_qty"),
+                 c("l_extendedprice").sum().alias("sum_base_price"),
+                 disc_price.sum().alias("sum_disc_price"),
+                 (disc_price * (1 + c("l_tax"))).sum().alias("sum_charge"),
+                 c("l_quantity").mean().alias("avg_qty"),
+                 c("l_extendedprice").mean().alias("avg_price"),
+                 c("l_discount").mean().alias("avg_disc"),
+                 E.len().alias("count_order")))
+
+
+def q3(lineitem, orders, date=Q3_DATE, seg_mod=5):
+    """TPC-H Q3 restated on the two big tables (SURVEY.md 8(d) cfg 4): the customer
+    market-segment filter is approximated by o_custkey % seg_mod == 0."""
+    c = E.col
+    o = orders.filter((c("o_orderdate") < date) & ((c("o_custkey") % seg_mod) == 0))
+    li = lineitem.filter(c("l_shipdate") > date)
+    return (li.join(o, left_on="l_orderkey", right_on="o_orderkey")
+            .group_by("l_orderkey", "o_orderdate", "o_shippriority")
+            .agg((c("l_extendedprice") * (1 - c("l_discount"))).sum().alias("revenue")))
