@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""bench.py -- TPC-H Q1 (and, as extras, Q3 / BASELINE configs 2 and 3) on MI355X.
+
+One "step" = one complete query over device-resident columns: host plan lowering, the fused
+HIP pipeline behind plx_execute_plan, and the download of the (tiny) result.  Inputs are
+synthetic (polars_amd/datagen.py: dbgen distributions restated) and already sit in HBM when the
+timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload q1|q3|cfg2|cfg3] [--rows R]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, every rank holds its own SF100-sized shard (weak scaling); Q1's
+six-group partials are combined with an all-gather of a few hundred bytes (polars_amd/dist.py),
+no row crosses xGMI.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
+SF100_LINEITEM = 600_000_000
+SF100_ORDERS = 150_000_000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="q1", choices=["q1", "q3", "cfg2", "cfg3"])
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the SF100 / 1e9-row size of the workload)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+class Workload:
+    """name, rows, algorithmic bytes per step, build(pl) -> callable step() returning a host result."""
+
+    def __init__(self, name, rows, algo_bytes, step, kernel, desc):
+        self.name, self.rows, self.algo_bytes, self.step, self.kernel, self.desc = name, rows, algo_bytes, step, kernel, desc
+
+
+def make_workload(pl, name: str, rows: int, seed: int) -> Workload:
+    import torch
+    from polars_amd import datagen, queries
+    if name == "q1":
+        n = rows or SF100_LINEITEM
+        cols = datagen.lineitem_device(n, seed=seed)
+        df = datagen.frame_from_torch(pl, cols, datagen.LINEITEM_Q1_COLS)
+        torch.cuda.synchronize()
+        lf = queries.q1(df.lazy())
+
+        def step():
+            out = lf.collect()
+            return out.to_dict(), (df, cols)
+        return Workload("tpch_q1_sf100", n, n * datagen.Q1_BYTES_PER_ROW, step, "fused_scan_ldsagg_static",
+                        f"TPC-H Q1, lineitem {n} rows x 42 B (SF100 = 6.0e8), filter -> 2-key group_by -> 8 aggregates")
+    if name == "q3":
+        no = (rows // 4) if rows else SF100_ORDERS
+        orders, li = datagen.orders_lineitem_device(no, seed=seed)
+        L = datagen.frame_from_torch(pl, li, datagen.LINEITEM_Q3_COLS)
+        O = datagen.frame_from_torch(pl, orders, datagen.ORDERS_Q3_COLS)
+        torch.cuda.synchronize()
+        lf = queries.q3(L.lazy(), O.lazy())
+        nl = li["l_orderkey"].numel()
+
+        def step():
+            out = lf.collect()
+            return {"groups": out.height}, (L, O, li, orders)
+        return Workload("tpch_q3_sf100", nl + no, nl * datagen.Q3_LINEITEM_BYTES_PER_ROW + no * datagen.Q3_ORDERS_BYTES_PER_ROW, step, "join_probe_emit",
+                        f"TPC-H Q3 (orders {no} x lineitem {nl}), filter both -> hash join -> group_by(orderkey, orderdate, shippriority)")
+    if name == "cfg2":
+        n = rows or 1_000_000_000
+        g = torch.Generator(device="cuda"); g.manual_seed(seed)
+        a = torch.randint(0, 2 ** 31, (n,), generator=g, device="cuda", dtype=torch.int64)
+        x = torch.rand((n,), generator=g, device="cuda", dtype=torch.float64) * 100.0
+        y = torch.rand((n,), generator=g, device="cuda", dtype=torch.float64)
+        df = pl.DataFrame([pl.Series.from_torch("a", a), pl.Series.from_torch("x", x), pl.Series.from_torch("y", y)])
+        torch.cuda.synchronize()
+        lf = queries.cfg2(df.lazy())
+
+        def step():
+            return lf.collect().to_dict(), (df, a, x, y)
+        return Workload("cfg2_filter_arith_agg_1e9", n, n * 24, step, "fused_scan_regagg_static", f"config 2: {n}-row Int64/Float64 frame, filter + arithmetic + sum/mean")
+    if name == "cfg3":
+        n = rows or 1_000_000_000
+        g = torch.Generator(device="cuda"); g.manual_seed(seed)
+        key = torch.randint(0, 1_000_000, (n,), generator=g, device="cuda", dtype=torch.int64)
+        v = torch.randint(0, 1000, (n,), generator=g, device="cuda", dtype=torch.int64)
+        df = pl.DataFrame([pl.Series.from_torch("key", key), pl.Series.from_torch("v", v)])
+        torch.cuda.synchronize()
+        lf = queries.cfg3(df.lazy())
+
+        def step():
+            return {"groups": lf.collect().height}, (df, key, v)
+        return Workload("cfg3_groupby_1e6_keys_1e9", n, n * 16 + 1_000_000 * 20, step, "fused_scan", f"config 3: {n} rows, 1e6 Int64 keys, group_by(key).agg(sum, count)")
+    raise ValueError(name)
+
+
+def kernel_stats(pl):
+    """Per-kernel (name -> [count, total_us, algo_bytes per launch]) from the library's HIP-event tracer."""
+    import ctypes as C
+    F = pl._ffi
+    cap = 65536
+    recs = (F.ProfileRecord * cap)()
+    n = C.c_int32()
+    F.check(F.lib().plx_profile_fetch(recs, cap, C.byref(n)))
+    out = {}
+    for i in range(n.value):
+        r = recs[i]
+        nm = r.name.decode()
+        e = out.setdefault(nm, [0, 0.0, 0])
+        e[0] += 1; e[1] += r.end_us - r.start_us; e[2] = max(e[2], int(r.algo_bytes))
+    return out
+
+
+def timed(pl, wl: Workload, steps: int, warmup: int, distributed: bool, combine=None):
+    import torch
+    import torch.distributed as dist
+    F = pl._ffi
+    res = None
+    for _ in range(warmup):
+        res, _keep = wl.step()
+        if combine:
+            combine(res)
+    F.check(F.lib().plx_profile_clear())
+    F.check(F.lib().plx_profile_enable(1))
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(); F.check(F.lib().plx_synchronize())
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res, _keep = wl.step()
+        if combine:
+            res = combine(res)
+    torch.cuda.synchronize(); F.check(F.lib().plx_synchronize())
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    stats = kernel_stats(pl)
+    F.check(F.lib().plx_profile_enable(0))
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, stats, res
+
+
+def roofline(stats, kernel_prefix):
+    """Dominant kernel = largest total time among the launches of the timed region."""
+    if not stats:
+        return None
+    name = max(stats, key=lambda k: stats[k][1])
+    cnt, tot_us, algo = stats[name]
+    avg_us = tot_us / cnt
+    ach = algo / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+    return {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "avg_kernel_us": round(avg_us, 2), "launches": cnt, "algo_bytes_per_launch": algo, "traffic": None}
+
+
+def cpu_baseline_q1(seconds: float):
+    """The CPU oracle (a restatement of the reference's algorithms, NOT Polars) on all host cores,
+    on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import pyoracle as orc
+    from polars_amd import datagen
+    cores = orc.hardware_threads()
+    orc.set_threads(cores)
+    cutoff = datagen.us(1998, 9, 2)
+    probe = datagen.lineitem_host(1_000_000, seed=99)
+    t0 = time.perf_counter(); orc.q1({k: probe[k] for k in datagen.LINEITEM_Q1_COLS}, cutoff); t1 = time.perf_counter()
+    rate = 1_000_000 / max(t1 - t0, 1e-6)
+    n = int(min(max(rate * seconds, 2_000_000), 60_000_000))
+    li = datagen.lineitem_host(n, seed=98)
+    cols = {k: li[k] for k in datagen.LINEITEM_Q1_COLS}
+    t0 = time.perf_counter(); orc.q1(cols, cutoff); dt = time.perf_counter() - t0
+    orc.set_threads(1)
+    return {"value": round(n / dt, 1), "unit": "rows/s", "cores": cores, "kind": "port", "seconds": round(dt, 2),
+            "sample": f"TPC-H Q1 on {n} synthetic lineitem rows (same generator), oracle/plx_oracle.cpp with {cores} threads; "
+                      "CPU restatement of the Polars in-memory algorithms, not Polars itself (no polars wheel / rustc in the image)"}
+
+
+def main():
+    args = parse()
+    import torch
+    rank, local_rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = ws > 1
+    torch.cuda.set_device(local_rank)
+    import polars_amd as pl
+    from polars_amd import dist as pdist
+    pl.init(local_rank)
+    if distributed:
+        pdist.init_process_group("nccl")
+    wl = make_workload(pl, args.workload, args.rows, seed=10 + rank)
+
+    combine = None
+    if distributed and args.workload == "q1":
+        # per-rank result -> partial states -> all-gather -> combine (tiny)
+        from polars_amd import datagen
+
+        def combine(res):
+            import torch.distributed as dist
+            obj = [None] * ws
+            dist.all_gather_object(obj, res)
+            merged = {}
+            for r in obj:
+                for i in range(len(r["l_returnflag"])):
+                    k = (r["l_returnflag"][i], r["l_linestatus"][i])
+                    m = merged.setdefault(k, {"sum_qty": 0, "sum_base_price": 0.0, "sum_disc_price": 0.0, "sum_charge": 0.0, "disc": 0.0, "count_order": 0})
+                    c = r["count_order"][i]
+                    m["sum_qty"] += r["sum_qty"][i]; m["sum_base_price"] += r["sum_base_price"][i]; m["sum_disc_price"] += r["sum_disc_price"][i]
+                    m["sum_charge"] += r["sum_charge"][i]; m["disc"] += r["avg_disc"][i] * c; m["count_order"] += c
+            return merged
+
+    dt, stats, res = timed(pl, wl, args.steps, args.warmup, distributed, combine)
+    total_rows = wl.rows * ws * args.steps
+    line = {
+        "metric": "rows/sec + achieved HBM GB/s, TPC-H Q1/Q3 SF100, 1/2/4/8 GPU vs CPU",
+        "value": round(total_rows / dt, 1), "unit": "rows/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": wl.name, "description": wl.desc, "rows_per_gpu": wl.rows, "algorithmic_bytes_per_gpu_step": wl.algo_bytes,
+                   "parallelism": f"row-sharded x{ws}, all-gather of group partials" if ws > 1 else "single GPU"},
+        "whole_query_GBps_per_gpu": round(wl.algo_bytes * args.steps / dt / 1e9, 1),
+        "roofline": roofline(stats, wl.kernel),
+        "kernels": {k: {"launches": v[0], "avg_us": round(v[1] / v[0], 2)} for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])[:8]},
+    }
+    if rank == 0 and not args.no_extras and ws == 1:
+        extras = {}
+        del wl
+        torch.cuda.empty_cache()
+        for name in [w for w in ("q3", "cfg2", "cfg3", "q1") if w != args.workload]:
+            try:
+                w2 = make_workload(pl, name, 0, seed=20)
+                d2, s2, _ = timed(pl, w2, max(3, args.steps // 4), 1, False)
+                k2 = max(3, args.steps // 4)
+                extras[w2.name] = {"rows_per_s": round(w2.rows * k2 / d2, 1), "ms_per_step": round(d2 / k2 * 1e3, 3),
+                                   "whole_query_GBps": round(w2.algo_bytes * k2 / d2 / 1e9, 1), "roofline": roofline(s2, w2.kernel),
+                                   "kernels": {k: {"launches": v[0], "avg_us": round(v[1] / v[0], 2)} for k, v in sorted(s2.items(), key=lambda kv: -kv[1][1])[:6]}}
+                del w2
+            except Exception as e:  # a secondary workload must never take the headline line down
+                extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            pl._ffi.lib().plx_memory_trim()
+            torch.cuda.empty_cache()
+        line["extras"] = extras
+    if rank == 0 and ws == 1 and not args.no_cpu:
+        try:
+            line["cpu_baseline"] = cpu_baseline_q1(args.cpu_seconds)
+        except Exception as e:
+            line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if distributed:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -219,6 +219,10 @@ int plx_column_export_series(plx_column col, const char* name, plx_series_export
  * validity_out (may be NULL) must hold (len+7)/8 bytes; *has_validity_out tells
  * whether the column carries a validity bitmap (if not, validity_out is all ones). */
 int plx_column_to_host(plx_column col, void* values_out, uint8_t* validity_out, int32_t* has_validity_out);
+/* Device-to-device copy into caller-owned HBM (e.g. a torch tensor): values (len*width bytes;
+ * BOOL: (len+7)/8) and, if dev_validity_out != NULL, (len+7)/8 validity bytes (all ones when the
+ * column has no bitmap).  Synchronises the library stream before returning. */
+int plx_column_copy_to_device(plx_column col, void* dev_values_out, void* dev_validity_out);
 int plx_column_info(plx_column col, plx_dtype* dtype, int64_t* len, int64_t* null_count);
 int plx_column_device_ptrs(plx_column col, void** values, void** validity);
 int plx_column_retain(plx_column col);

@@ -1,0 +1,336 @@
+"""numpy-facing binding of the CPU oracle (oracle/plx_oracle.cpp -> libplx_oracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; nothing under polars_amd/ does.  The oracle is a
+restatement of the reference (pola-rs/polars 0.55.1) algorithms -- see the header of
+plx_oracle.cpp for the file:line each function follows -- pinned by the golden vectors
+transcribed from the reference's own tests (tests/golden/, tests/test_oracle_golden.py).
+
+The query helpers at the bottom (q_cfg2, q_groupby, q1, q3) execute the benchmark queries
+in the *reference's* operator order: materialise the predicate bitmap, filter every
+column, evaluate each arithmetic node into a full column, build per-group index lists,
+aggregate per group (SURVEY.md sections 3.2-3.4).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplx_oracle.so")
+
+BOOL, I8, I16, I32, I64, U8, U16, U32, U64, F32, F64 = range(11)
+EQ, NE, LT, LE, GT, GE = range(6)
+ADD, SUB, MUL, TRUE_DIV, FLOOR_DIV, MOD = range(6)
+AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT, AGG_LEN, AGG_FIRST = range(7)
+JOIN_INNER, JOIN_LEFT = range(2)
+
+NP_OF = {I8: np.int8, I16: np.int16, I32: np.int32, I64: np.int64, U8: np.uint8, U16: np.uint16, U32: np.uint32, U64: np.uint64,
+         F32: np.float32, F64: np.float64}
+DT_OF = {np.dtype(v): k for k, v in NP_OF.items()}
+
+_lib: Optional[C.CDLL] = None
+
+
+def build() -> None:
+    """Compile the oracle with the committed recipe (oracle/Makefile)."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        l = C.CDLL(LIB_PATH)
+        l.orc_groupby_build.restype = C.c_void_p
+        l.orc_join.restype = C.c_void_p
+        l.orc_groups_count.restype = C.c_int64
+        l.orc_pairs_count.restype = C.c_int64
+        l.orc_partitioner_seed.restype = C.c_uint64
+        l.orc_partitioner_seed.argtypes = [C.c_uint64]
+        _lib = l
+    return _lib
+
+
+def set_threads(n: int) -> None:
+    lib().orc_set_threads(int(n))
+
+
+def hardware_threads() -> int:
+    return int(lib().orc_hardware_threads())
+
+
+def _p(a: Optional[np.ndarray]):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
+
+
+def pack(bits: Optional[np.ndarray]) -> Optional[np.ndarray]:
+    """bool array -> LSB-first bitmap padded to whole u64 words (+8 bytes)."""
+    if bits is None:
+        return None
+    b = np.packbits(np.asarray(bits, dtype=bool), bitorder="little")
+    out = np.zeros(((len(bits) + 63) // 64) * 8 + 8, dtype=np.uint8)
+    out[: len(b)] = b
+    return out
+
+
+def unpack(bitmap: np.ndarray, n: int) -> np.ndarray:
+    return np.unpackbits(bitmap, bitorder="little")[:n].astype(bool)
+
+
+def _dt(a: np.ndarray) -> int:
+    return DT_OF[a.dtype]
+
+
+# ------------------------------------------------------------------- kernels ----
+def cmp(op: int, a: np.ndarray, b) -> np.ndarray:
+    """Values only (validity = AND of inputs is the caller's business, arity.rs:203-214)."""
+    a = np.ascontiguousarray(a)
+    n = len(a)
+    scalar = not isinstance(b, np.ndarray)
+    bb = np.array([b], dtype=a.dtype) if scalar else np.ascontiguousarray(b.astype(a.dtype, copy=False))
+    out = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
+    rc = lib().orc_cmp(_dt(a), op, _p(a), _p(bb), int(scalar), C.c_int64(n), _p(out))
+    assert rc == 0
+    return unpack(out, n)
+
+
+def arith(op: int, a, b, mode: int = 0) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+    """mode 0: col OP col, 1: col OP scalar(b), 2: scalar(a) OP col(b).
+    Returns (values, extra_valid) where extra_valid is the rhs != 0 mask of integer floor-div / mod."""
+    if mode == 2:
+        col = np.ascontiguousarray(b)
+        l = np.array([a], dtype=col.dtype)
+        r = col
+    elif mode == 1:
+        col = np.ascontiguousarray(a)
+        l = col
+        r = np.array([b], dtype=col.dtype)
+    else:
+        col = np.ascontiguousarray(a)
+        l = col
+        r = np.ascontiguousarray(b)
+    n = len(col)
+    dt = _dt(col)
+    odt = F64 if (op == TRUE_DIV and dt not in (F32, F64)) else dt
+    out = np.zeros(n, dtype=NP_OF[odt])
+    extra = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
+    has_extra, out_dt = C.c_int(0), C.c_int(0)
+    rc = lib().orc_arith(dt, op, _p(l), _p(r), mode, C.c_int64(n), _p(out), _p(extra), C.byref(has_extra), C.byref(out_dt))
+    assert rc == 0 and out_dt.value == odt
+    return out, (unpack(extra, n) if has_extra.value else None)
+
+
+def filter(values: np.ndarray, validity: Optional[np.ndarray], mask: np.ndarray, mask_validity: Optional[np.ndarray] = None):
+    """(filtered values, filtered validity or None). `values` bool => bitmap column."""
+    n = len(values)
+    isb = values.dtype == np.bool_
+    vin = pack(values) if isb else np.ascontiguousarray(values)
+    width = 0 if isb else values.dtype.itemsize
+    vout = np.zeros(((n + 63) // 64) * 8 + 8, dtype=np.uint8) if isb else np.zeros(n, dtype=values.dtype)
+    nout = C.c_int64(0)
+    vb = pack(validity) if validity is not None else None
+    vob = np.zeros((n + 7) // 8 + 8, dtype=np.uint8) if validity is not None else None
+    mb, mvb = pack(mask), (pack(mask_validity) if mask_validity is not None else None)
+    rc = lib().orc_filter(width, _p(vin), _p(vb), _p(mb), _p(mvb), C.c_int64(n), _p(vout), _p(vob), C.byref(nout))
+    assert rc == 0
+    k = nout.value
+    ov = unpack(vout, k) if isb else vout[:k].copy()
+    return ov, (unpack(vob, k) if validity is not None else None)
+
+
+def gather(values: np.ndarray, validity: Optional[np.ndarray], idx: np.ndarray, idx_validity: Optional[np.ndarray] = None):
+    n = len(idx)
+    isb = values.dtype == np.bool_
+    vin = pack(values) if isb else np.ascontiguousarray(values)
+    width = 0 if isb else values.dtype.itemsize
+    out = np.zeros((n + 7) // 8 + 8, dtype=np.uint8) if isb else np.zeros(n, dtype=values.dtype)
+    ov = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    rc = lib().orc_gather(width, _p(vin), _p(pack(validity)), _p(idx), _p(pack(idx_validity)), C.c_int64(n), _p(out), _p(ov))
+    assert rc == 0
+    return (unpack(out, n) if isb else out), unpack(ov, n)
+
+
+def _scalar_from_bits(bits: int, dt: int):
+    raw = np.array([bits], dtype=np.uint64)
+    if dt == F64:
+        return float(raw.view(np.float64)[0])
+    if dt == F32:
+        return float(raw.view(np.float32)[0])
+    if dt in (U8, U16, U32, U64):
+        return int(bits) & ((1 << (8 * np.dtype(NP_OF[dt]).itemsize)) - 1)
+    w = 8 * np.dtype(NP_OF[dt]).itemsize
+    x = int(bits) & ((1 << w) - 1)
+    return x - (1 << w) if x >= (1 << (w - 1)) else x
+
+
+def reduce(op: int, values: np.ndarray, validity: Optional[np.ndarray] = None):
+    """-> (python value or None, output dtype code)."""
+    n = len(values)
+    isb = values.dtype == np.bool_
+    vin = pack(values) if isb else np.ascontiguousarray(values)
+    dt = BOOL if isb else _dt(values)
+    bits, odt, ok = C.c_uint64(0), C.c_int(0), C.c_int(0)
+    rc = lib().orc_reduce(dt, op, _p(vin), _p(pack(validity)), C.c_int64(n), C.byref(bits), C.byref(odt), C.byref(ok))
+    assert rc == 0, f"orc_reduce rc={rc}"
+    if not ok.value:
+        return None, odt.value
+    return _scalar_from_bits(bits.value, odt.value), odt.value
+
+
+def key_bits(k: np.ndarray) -> np.ndarray:
+    """to_bit_repr (into_groups.rs:156-186) + float canonicalisation (total_ord.rs:40-48)."""
+    if k.dtype == np.bool_:
+        return k.astype(np.uint64)
+    if k.dtype.kind == "f":
+        d = k.astype(np.float64) + 0.0
+        bits = d.view(np.uint64).copy()
+        bits[np.isnan(d)] = np.uint64(0x7FF8000000000000)
+        return bits
+    if k.dtype.kind == "i":
+        return k.astype(np.int64).view(np.uint64).copy()
+    return k.astype(np.uint64)
+
+
+class Groups:
+    def __init__(self, keys: Sequence[np.ndarray], valids: Sequence[Optional[np.ndarray]], maintain_order: bool = False):
+        self.n = len(keys[0])
+        self._kb = [np.ascontiguousarray(key_bits(k)) for k in keys]
+        self._vb = [pack(v) for v in valids]
+        nk = len(keys)
+        kp = (C.c_void_p * nk)(*[b.ctypes.data for b in self._kb])
+        vp = (C.c_void_p * nk)(*[(b.ctypes.data if b is not None else None) for b in self._vb])
+        self._g = C.c_void_p(lib().orc_groupby_build(nk, kp, vp, C.c_int64(self.n), int(maintain_order)))
+        assert self._g.value, "orc_groupby_build failed"
+        self.count = int(lib().orc_groups_count(self._g))
+        self.first = np.zeros(self.count, dtype=np.uint32)
+        lib().orc_groups_first(self._g, _p(self.first))
+
+    def agg(self, op: int, values: Optional[np.ndarray], validity: Optional[np.ndarray] = None):
+        """-> (out values, out validity bool array)."""
+        G = self.count
+        if op == AGG_LEN or values is None:
+            out = np.zeros(G, dtype=np.uint32)
+            ov = np.zeros((G + 7) // 8 + 8, dtype=np.uint8)
+            odt = C.c_int(0)
+            rc = lib().orc_groups_agg(self._g, I64, AGG_LEN, None, None, _p(out), _p(ov), C.byref(odt))
+            assert rc == 0
+            return out, unpack(ov, G)
+        isb = values.dtype == np.bool_
+        v = values.astype(np.uint8) if isb else np.ascontiguousarray(values)
+        dt = _dt(v)
+        out = np.zeros(max(G, 1) * 8, dtype=np.uint8)
+        ov = np.zeros((G + 7) // 8 + 8, dtype=np.uint8)
+        odt = C.c_int(0)
+        rc = lib().orc_groups_agg(self._g, dt, op, _p(v), _p(pack(validity)), _p(out), _p(ov), C.byref(odt))
+        assert rc == 0
+        o = out.view(NP_OF[odt.value])[:G].copy()
+        return o, unpack(ov, G)
+
+    def __del__(self):
+        try:
+            if self._g:
+                lib().orc_groups_free(self._g)
+        except Exception:
+            pass
+
+
+def join(how: int, lk: np.ndarray, lv: Optional[np.ndarray], rk: np.ndarray, rv: Optional[np.ndarray]):
+    """-> (left_idx u32, right_idx u32, right_valid bool or None)"""
+    a, b = np.ascontiguousarray(key_bits(lk)), np.ascontiguousarray(key_bits(rk))
+    p = C.c_void_p(lib().orc_join(how, _p(a), _p(pack(lv)), C.c_int64(len(a)), _p(b), _p(pack(rv)), C.c_int64(len(b))))
+    m = int(lib().orc_pairs_count(p))
+    li, ri = np.zeros(m, dtype=np.uint32), np.zeros(m, dtype=np.uint32)
+    rvb = np.zeros((m + 7) // 8 + 8, dtype=np.uint8)
+    lib().orc_pairs_get(p, _p(li), _p(ri), _p(rvb))
+    lib().orc_pairs_free(p)
+    return li, ri, (unpack(rvb, m) if how == JOIN_LEFT else None)
+
+
+def hash_partition(keys: np.ndarray, valid: Optional[np.ndarray], n_parts: int, seed: int = 0) -> np.ndarray:
+    kb = np.ascontiguousarray(key_bits(keys))
+    out = np.zeros(len(kb), dtype=np.uint32)
+    lib().orc_hash_partition(_p(kb), _p(pack(valid)), C.c_int64(len(kb)), int(n_parts), C.c_uint64(seed), _p(out))
+    return out
+
+
+# --------------------------------------------------- reference-shaped query plans ----
+def q_filter_agg_cfg2(a: np.ndarray, x: np.ndarray, y: np.ndarray, k: int, x_valid: Optional[np.ndarray] = None) -> Dict[str, object]:
+    """filter(a > k).select((x*(1-y)).sum(), x.mean(), a.sum())  (BASELINE config 2).
+    FilterExec materialises the mask and filters all three columns (filter.rs:94-114),
+    then ProjectionExec evaluates each expression node into a column."""
+    m = cmp(GT, a, k)
+    af, _ = filter(a, None, m)
+    xf, xv = filter(x, x_valid, m)
+    yf, _ = filter(y, None, m)
+    one_minus, _ = arith(SUB, 1.0, yf, mode=2)
+    prod, _ = arith(MUL, xf, one_minus, mode=0)
+    return {"xy": reduce(AGG_SUM, prod, xv)[0], "x_mean": reduce(AGG_MEAN, xf, xv)[0], "a_sum": reduce(AGG_SUM, af)[0], "rows": int(m.sum())}
+
+
+def q_filter_sum_cfg1(a: np.ndarray, k: int) -> int:
+    m = cmp(GT, a, k)
+    af, _ = filter(a, None, m)
+    return reduce(AGG_SUM, af)[0]
+
+
+def q_groupby(keys: Sequence[np.ndarray], key_valids: Sequence[Optional[np.ndarray]], aggs: List[Tuple[str, int, Optional[np.ndarray], Optional[np.ndarray]]],
+              maintain_order: bool = False) -> Dict[str, Tuple[np.ndarray, Optional[np.ndarray]]]:
+    """group_by(keys).agg(...): aggs = [(name, op, values, validity)].  Returns
+    {key_i: (values, validity), name: (values, validity)} in the oracle's group order."""
+    g = Groups(keys, key_valids, maintain_order)
+    out: Dict[str, Tuple[np.ndarray, Optional[np.ndarray]]] = {}
+    for i, (k, kv) in enumerate(zip(keys, key_valids)):
+        vals, val = gather(k, kv, g.first)
+        out[f"key_{i}"] = (vals, val)
+    for name, op, v, vv in aggs:
+        out[name] = g.agg(op, v, vv)
+    return out
+
+
+def q1(cols: Dict[str, np.ndarray], cutoff: int) -> Dict[str, np.ndarray]:
+    """TPC-H Q1 in the reference's operator order; returns rows
+    sorted by (l_returnflag, l_linestatus)."""
+    m = cmp(LE, cols["l_shipdate"], cutoff)
+    f = {k: filter(v, None, m)[0] for k, v in cols.items()}
+    one_minus, _ = arith(SUB, 1.0, f["l_discount"], mode=2)
+    disc_price, _ = arith(MUL, f["l_extendedprice"], one_minus)
+    one_plus, _ = arith(ADD, 1.0, f["l_tax"], mode=2)
+    charge, _ = arith(MUL, disc_price, one_plus)
+    r = q_groupby([f["l_returnflag"], f["l_linestatus"]], [None, None], [
+        ("sum_qty", AGG_SUM, f["l_quantity"], None), ("sum_base_price", AGG_SUM, f["l_extendedprice"], None),
+        ("sum_disc_price", AGG_SUM, disc_price, None), ("sum_charge", AGG_SUM, charge, None),
+        ("avg_qty", AGG_MEAN, f["l_quantity"], None), ("avg_price", AGG_MEAN, f["l_extendedprice"], None),
+        ("avg_disc", AGG_MEAN, f["l_discount"], None), ("count_order", AGG_LEN, None, None)])
+    order = np.lexsort((r["key_1"][0], r["key_0"][0]))
+    out = {"l_returnflag": r["key_0"][0][order], "l_linestatus": r["key_1"][0][order]}
+    for k in ("sum_qty", "sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc", "count_order"):
+        out[k] = r[k][0][order]
+    return out
+
+
+def q3(li: Dict[str, np.ndarray], orders: Dict[str, np.ndarray], date: int, seg_mod: int = 5) -> Dict[str, np.ndarray]:
+    """Q3 restated on the two big tables (SURVEY.md 8(d) cfg 4): filter both sides, inner join
+    on orderkey, gather payload, revenue = price*(1-disc), group by (orderkey, orderdate, shippriority).
+    Returns rows sorted by l_orderkey."""
+    mo1 = cmp(LT, orders["o_orderdate"], date)
+    modv, _ = arith(MOD, orders["o_custkey"], seg_mod, mode=1)
+    mo = mo1 & cmp(EQ, modv, 0)
+    o = {k: filter(v, None, mo)[0] for k, v in orders.items()}
+    ml = cmp(GT, li["l_shipdate"], date)
+    l = {k: filter(v, None, ml)[0] for k, v in li.items()}
+    lidx, ridx, _ = join(JOIN_INNER, l["l_orderkey"], None, o["o_orderkey"], None)
+    j = {k: gather(v, None, lidx)[0] for k, v in l.items()}
+    j.update({k: gather(v, None, ridx)[0] for k, v in o.items() if k != "o_orderkey"})
+    one_minus, _ = arith(SUB, 1.0, j["l_discount"], mode=2)
+    rev, _ = arith(MUL, j["l_extendedprice"], one_minus)
+    r = q_groupby([j["l_orderkey"], j["o_orderdate"], j["o_shippriority"]], [None, None, None], [("revenue", AGG_SUM, rev, None)])
+    order = np.argsort(r["key_0"][0], kind="stable")
+    return {"l_orderkey": r["key_0"][0][order], "o_orderdate": r["key_1"][0][order], "o_shippriority": r["key_2"][0][order],
+            "revenue": r["revenue"][0][order]}

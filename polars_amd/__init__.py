@@ -17,3 +17,9 @@ __all__ = ["init", "last_plan", "PlxError", "UnsupportedError", "DataFrame", "La
            "len", "sum", "mean", "min", "max", "count", "DataType", "Boolean", "Int8", "Int16", "Int32", "Int64", "UInt8", "UInt16",
            "UInt32", "UInt64", "Float32", "Float64", "Date", "Datetime", "Categorical"]
 __version__ = "0.1.0"
+
+
+def datagen_categories(column: str):
+    """Dictionary of a dictionary-encoded TPC-H column (host side)."""
+    from . import datagen
+    return {"l_returnflag": datagen.FLAGS, "l_linestatus": datagen.STATUS}[column]

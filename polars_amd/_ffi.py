@@ -113,6 +113,7 @@ SIGNATURES = {
     "plx_column_export_arrow": (C.c_int, [C.c_uint64, C.POINTER(ArrowArray), C.POINTER(ArrowSchema)]),
     "plx_column_export_series": (C.c_int, [C.c_uint64, C.c_char_p, C.POINTER(SeriesExport)]),
     "plx_column_to_host": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, _i32p]),
+    "plx_column_copy_to_device": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p]),
     "plx_column_info": (C.c_int, [C.c_uint64, _i32p, _i64p, _i64p]),
     "plx_column_device_ptrs": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "plx_column_retain": (C.c_int, [C.c_uint64]),

@@ -209,6 +209,20 @@ int plx_column_to_host(plx_column col, void* values_out, uint8_t* validity_out, 
   column_to_host(c, values_out, validity_out, has_validity_out);
   PLX_CATCH
 }
+int plx_column_copy_to_device(plx_column col, void* dev_values_out, void* dev_validity_out) {
+  PLX_TRY
+  ColumnPtr c = get_column(col);
+  PLX_REQUIRE(c->values || c->len == 0, PLX_ERR_INVALID, "placeholder column has no data");
+  const size_t vb = c->dtype == PLX_BOOL ? (size_t)((c->len + 7) / 8) : (size_t)c->len * dtype_width(c->dtype);
+  const size_t nb = (size_t)((c->len + 7) / 8);
+  if (dev_values_out && vb) PLX_HIP(hipMemcpyAsync(dev_values_out, c->values->ptr, vb, hipMemcpyDeviceToDevice, stream()));
+  if (dev_validity_out && nb) {
+    if (c->validity) PLX_HIP(hipMemcpyAsync(dev_validity_out, c->validity->ptr, nb, hipMemcpyDeviceToDevice, stream()));
+    else PLX_HIP(hipMemsetAsync(dev_validity_out, 0xff, nb, stream()));
+  }
+  PLX_HIP(hipStreamSynchronize(stream()));
+  PLX_CATCH
+}
 int plx_column_info(plx_column col, plx_dtype* dtype, int64_t* len, int64_t* null_count) {
   PLX_TRY
   ColumnPtr c = get_column(col);

@@ -1,0 +1,169 @@
+"""Synthetic inputs of the benchmark configurations:
+TPC-H-style lineitem / orders columns (dbgen distributions restated, column types from the
+reference's examples/datasets/pds_heads/*.feather) and the config 2 / 3 / 5 frames.
+
+Two generators with the same distributions: numpy (host; parity tests and the CPU-baseline
+sample) and torch (device-resident; bench.py at SF100, where the columns must already sit in
+HBM when the timed region starts).  Values differ between the two (different RNGs); parity is
+always checked on the same arrays.
+"""
+from __future__ import annotations
+
+import datetime as _dt
+from typing import Dict, Tuple
+
+import numpy as np
+
+DAY_US = 86_400_000_000
+FLAGS = ["A", "N", "R"]      # l_returnflag dictionary (codes 0,1,2)
+STATUS = ["F", "O"]          # l_linestatus dictionary (codes 0,1)
+LINEITEM_Q1_COLS = ["l_shipdate", "l_returnflag", "l_linestatus", "l_quantity", "l_extendedprice", "l_discount", "l_tax"]
+LINEITEM_Q3_COLS = ["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"]
+ORDERS_Q3_COLS = ["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"]
+Q1_BYTES_PER_ROW = 8 + 1 + 1 + 8 * 4   # 42 B/row
+Q3_LINEITEM_BYTES_PER_ROW = 32
+Q3_ORDERS_BYTES_PER_ROW = 32
+
+
+def us(y: int, m: int, d: int) -> int:
+    """Datetime[us] physical value (microseconds since epoch) of a date."""
+    return (_dt.date(y, m, d) - _dt.date(1970, 1, 1)).days * DAY_US
+
+
+START = us(1992, 1, 1)
+END_ORDERS = us(1998, 8, 2)
+CURRENT = us(1995, 6, 17)
+
+
+def logical_dtypes(pl) -> Dict[str, object]:
+    return {"l_shipdate": pl.Datetime, "o_orderdate": pl.Datetime, "l_returnflag": pl.Categorical(FLAGS, pl.UInt8),
+            "l_linestatus": pl.Categorical(STATUS, pl.UInt8)}
+
+
+def to_frame(pl, cols: Dict[str, np.ndarray], names):
+    """Upload host columns as a DataFrame with the logical dtypes of the TPC-H schema."""
+    lt = logical_dtypes(pl)
+    return pl.DataFrame([pl.Series(n, cols[n], dtype=lt.get(n)) for n in names])
+
+
+# ------------------------------------------------------------------------ numpy ----
+def _line_columns_host(rng: np.random.Generator, shipdate: np.ndarray) -> Dict[str, np.ndarray]:
+    n = len(shipdate)
+    qty = rng.integers(1, 51, n, dtype=np.int64)
+    price = np.round(qty.astype(np.float64) * rng.integers(90_000, 210_000, n).astype(np.float64) / 100.0, 2)
+    disc = rng.integers(0, 11, n).astype(np.float64) / 100.0
+    tax = rng.integers(0, 9, n).astype(np.float64) / 100.0
+    receipt = shipdate + rng.integers(1, 31, n, dtype=np.int64) * DAY_US
+    flag = np.where(receipt <= CURRENT, np.where(rng.random(n) < 0.5, 0, 2), 1).astype(np.uint8)
+    status = (shipdate > CURRENT).astype(np.uint8)
+    return {"l_shipdate": shipdate, "l_returnflag": flag, "l_linestatus": status, "l_quantity": qty, "l_extendedprice": price,
+            "l_discount": disc, "l_tax": tax}
+
+
+def lineitem_host(n_rows: int, seed: int = 10) -> Dict[str, np.ndarray]:
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ship = START + rng.integers(1, 2526 + 121, n_rows, dtype=np.int64) * DAY_US
+    return _line_columns_host(rng, ship)
+
+
+def orders_lineitem_host(n_orders: int, seed: int = 10) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
+    """orders (sparse keys: 8 of every 32 used) and its lineitem (1-7 lines per order,
+    l_shipdate = o_orderdate + U[1,121] days)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    i = np.arange(n_orders, dtype=np.int64)
+    okey = (i // 8) * 32 + (i % 8) + 1
+    perm = rng.permutation(n_orders)     # orders are not stored in key order
+    okey = okey[perm]
+    odate = START + rng.integers(0, (END_ORDERS - START) // DAY_US + 1, n_orders, dtype=np.int64) * DAY_US
+    orders = {"o_orderkey": okey, "o_custkey": rng.integers(1, max(2, n_orders // 10) + 1, n_orders, dtype=np.int64),
+              "o_orderdate": odate, "o_shippriority": np.zeros(n_orders, dtype=np.int64)}
+    cnt = rng.integers(1, 8, n_orders)
+    lkey = np.repeat(okey, cnt)
+    ship = np.repeat(odate, cnt) + rng.integers(1, 122, len(lkey), dtype=np.int64) * DAY_US
+    shuffle = rng.permutation(len(lkey))
+    li = _line_columns_host(rng, ship[shuffle])
+    li["l_orderkey"] = lkey[shuffle]
+    return orders, li
+
+
+def cfg2_host(n: int, null_frac: float = 0.0):
+    a = np.random.Generator(np.random.PCG64(1)).integers(0, 2 ** 31, n, dtype=np.int64)
+    x = np.random.Generator(np.random.PCG64(2)).uniform(0, 100, n)
+    y = np.random.Generator(np.random.PCG64(3)).uniform(0, 1, n)
+    xv = None
+    if null_frac > 0:
+        xv = np.ones(n, dtype=bool)
+        xv[np.random.Generator(np.random.PCG64(4)).choice(n, int(n * null_frac), replace=False)] = False
+    return a, x, y, xv
+
+
+def cfg3_host(n: int, n_keys: int = 1_000_000, zipf: float = 0.0):
+    if zipf > 0:
+        key = (np.random.Generator(np.random.PCG64(6)).zipf(zipf, n) - 1) % n_keys
+        key = key.astype(np.int64)
+    else:
+        key = np.random.Generator(np.random.PCG64(5)).integers(0, n_keys, n, dtype=np.int64)
+    v = np.random.Generator(np.random.PCG64(7)).integers(0, 1000, n, dtype=np.int64)
+    return key, v
+
+
+def cfg5_host(n: int, n_keys: int = 1_000_000):
+    """Dictionary codes of keys "id%010d" (H2O id3 style); the dictionary itself is
+    ["id%010d" % i for i in 1..n_keys] and stays on the host."""
+    codes = np.random.Generator(np.random.PCG64(8)).integers(0, n_keys, n, dtype=np.uint32)
+    v = np.random.Generator(np.random.PCG64(2)).uniform(0, 100, n)
+    return codes, v
+
+
+# ------------------------------------------------------------------------ torch ----
+def _line_columns_device(torch, g, shipdate):
+    n = shipdate.numel()
+    dev = shipdate.device
+    qty = torch.randint(1, 51, (n,), generator=g, device=dev, dtype=torch.int64)
+    price = (qty.to(torch.float64) * torch.randint(90_000, 210_000, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.float64) / 100.0)
+    price = torch.round(price * 100.0) / 100.0
+    disc = torch.randint(0, 11, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.float64) / 100.0
+    tax = torch.randint(0, 9, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.float64) / 100.0
+    receipt = shipdate + torch.randint(1, 31, (n,), generator=g, device=dev, dtype=torch.int64) * DAY_US
+    coin = torch.rand((n,), generator=g, device=dev) < 0.5
+    flag = torch.where(receipt <= CURRENT, torch.where(coin, 0, 2), 1).to(torch.uint8)
+    del receipt, coin
+    status = (shipdate > CURRENT).to(torch.uint8)
+    return {"l_shipdate": shipdate, "l_returnflag": flag, "l_linestatus": status, "l_quantity": qty, "l_extendedprice": price,
+            "l_discount": disc, "l_tax": tax}
+
+
+def lineitem_device(n_rows: int, seed: int = 10, device: str = "cuda"):
+    import torch
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    ship = START + torch.randint(1, 2526 + 121, (n_rows,), generator=g, device=device, dtype=torch.int64) * DAY_US
+    return _line_columns_device(torch, g, ship)
+
+
+def orders_lineitem_device(n_orders: int, seed: int = 10, device: str = "cuda"):
+    import torch
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    i = torch.arange(n_orders, device=device, dtype=torch.int64)
+    okey = (i // 8) * 32 + (i % 8) + 1
+    okey = okey[torch.randperm(n_orders, generator=g, device=device)]
+    odate = START + torch.randint(0, (END_ORDERS - START) // DAY_US + 1, (n_orders,), generator=g, device=device, dtype=torch.int64) * DAY_US
+    orders = {"o_orderkey": okey, "o_custkey": torch.randint(1, max(2, n_orders // 10) + 1, (n_orders,), generator=g, device=device, dtype=torch.int64),
+              "o_orderdate": odate, "o_shippriority": torch.zeros(n_orders, device=device, dtype=torch.int64)}
+    cnt = torch.randint(1, 8, (n_orders,), generator=g, device=device, dtype=torch.int64)
+    lkey = torch.repeat_interleave(okey, cnt)
+    ship = torch.repeat_interleave(odate, cnt) + torch.randint(1, 122, (lkey.numel(),), generator=g, device=device, dtype=torch.int64) * DAY_US
+    shuffle = torch.randperm(lkey.numel(), generator=g, device=device)
+    lkey, ship = lkey[shuffle], ship[shuffle]
+    del shuffle, cnt
+    n = lkey.numel()
+    qty = torch.randint(1, 51, (n,), generator=g, device=device, dtype=torch.int64)
+    price = torch.round(qty.to(torch.float64) * torch.randint(90_000, 210_000, (n,), generator=g, device=device, dtype=torch.int64).to(torch.float64)) / 100.0
+    disc = torch.randint(0, 11, (n,), generator=g, device=device, dtype=torch.int64).to(torch.float64) / 100.0
+    li = {"l_orderkey": lkey, "l_extendedprice": price, "l_discount": disc, "l_shipdate": ship}
+    return orders, li
+
+
+def frame_from_torch(pl, cols, names):
+    """Wrap device tensors as a DataFrame without copying (plx_column_from_device)."""
+    lt = logical_dtypes(pl)
+    return pl.DataFrame([pl.Series.from_torch(n, cols[n], dtype=lt.get(n)) for n in names])

@@ -1,0 +1,206 @@
+"""Multi-GPU execution: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on the GPU box; "gloo" in the CPU tests).
+
+The reference has no distributed backend; its intra-process exchange is the HashPartitioner
+(crates/polars-utils/src/hashing.rs:72-121) writing per-partition index lists that other
+threads read (crates/polars-expr/src/hash_keys.rs:263-314), and its partitioned group-by
+rewrites every aggregate into a per-partition partial plus a final combine
+(crates/polars-stream/src/nodes/group_by.rs:252-497 `combine_locals`).  This module keeps those
+two ideas with GPUs as the partitions:
+
+* low-cardinality group-by / whole-frame aggregates (TPC-H Q1): every rank aggregates its row
+  shard locally, the G x state partials are all-gathered (a few hundred bytes) and combined --
+  no row ever crosses xGMI;
+* high-cardinality group-by and joins: rows are routed by key hash with ONE all-to-all per
+  operator input (`exchange_by_key`), after which every rank owns a disjoint key set and runs
+  the single-GPU operator unchanged; results stay sharded (concatenation of disjoint parts).
+
+Everything here moves `torch.Tensor`s; the per-rank compute is delegated to a `LocalOps`
+object.  The product `HipLocalOps` calls libpolars_amd through the C ABI on device memory; the
+CPU tests inject an oracle-backed LocalOps to exercise the exchange logic under gloo.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# partial/final decomposition of the aggregates on the hot path: op -> (partial ops, combine ops)
+#   sum -> sum | sum ; count/len -> count/len | sum ; min/max -> min/max | min/max ;
+#   mean -> (sum as f64, count) | sum, sum then divide   (reduce/mean.rs:82-132 keeps (f64, usize))
+PARTIALS = {"sum": [("sum", "sum")], "count": [("count", "sum")], "len": [("len", "sum")], "min": [("min", "min")], "max": [("max", "max")],
+            "mean": [("sum_f64", "sum"), ("count", "sum")]}
+
+
+def world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_process_group(backend: Optional[str] = None):
+    """Rendezvous from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, ws = world()
+    if ws == 1 or dist.is_initialized():
+        return
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+
+
+class LocalOps:
+    """Per-rank compute used by the exchange layer (tensors in, tensors out)."""
+
+    def hash_partition(self, key, n_parts: int, seed: int = 0):
+        """-> (perm int64 tensor grouping rows by partition, counts list[int])"""
+        raise NotImplementedError
+
+    def take(self, col, perm):
+        return col[perm]
+
+    def groupby_partial(self, keys: Dict[str, object], values: Dict[str, object], aggs: Sequence[Tuple[str, str, str]]):
+        """aggs = [(out_name, value column, partial op)] -> dict of tensors, one row per local group (keys + outs)."""
+        raise NotImplementedError
+
+
+class HipLocalOps(LocalOps):
+    """LocalOps on libpolars_amd (device tensors are wrapped zero-copy, results copied D2D)."""
+
+    def __init__(self, pl):
+        self.pl = pl
+
+    def _series(self, name, t):
+        return self.pl.Series.from_torch(name, t)
+
+    def hash_partition(self, key, n_parts: int, seed: int = 0):
+        import ctypes as C
+
+        import torch
+        F = self.pl._ffi
+        torch.cuda.current_stream().synchronize()
+        s = self._series("k", key)
+        h = C.c_uint64()
+        counts = (C.c_int64 * n_parts)()
+        F.check(F.lib().plx_hash_partition(s._h, n_parts, seed, C.byref(h), counts))
+        perm = self.pl.Series._from_handle("perm", h.value, self.pl.UInt32)
+        return perm.to_torch().to(torch.int64), list(counts)
+
+    def groupby_partial(self, keys, values, aggs):
+        import torch
+        pl = self.pl
+        torch.cuda.current_stream().synchronize()
+        cols = [self._series(n, t) for n, t in keys.items()] + [self._series(n, t) for n, t in values.items()]
+        exprs = []
+        for out, col, op in aggs:
+            e = pl.col(col) if col else None
+            if op == "sum_f64":
+                e = e.cast(pl.Float64).sum()
+            elif op == "len":
+                e = pl.len()
+            else:
+                e = getattr(e, op)()
+            exprs.append(e.alias(out))
+        df = pl.DataFrame(cols).lazy().group_by(*keys.keys()).agg(*exprs).collect()
+        return {c: df[c].to_torch() for c in df.columns}
+
+
+def allgather_concat(t, group=None):
+    """Variable-length all-gather of a 1-D tensor (sizes first, then padded payload)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    ws = dist.get_world_size(group)
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes + [1])
+    pad = torch.zeros(m, dtype=t.dtype, device=t.device)
+    pad[: t.numel()] = t
+    outs = [torch.zeros_like(pad) for _ in range(ws)]
+    dist.all_gather(outs, pad, group=group)
+    return torch.cat([o[:s] for o, s in zip(outs, sizes)])
+
+
+def exchange_by_key(ops: LocalOps, key, cols: Dict[str, object], seed: int = 0, group=None) -> Dict[str, object]:
+    """Route every row to rank hash_partition(key) with one all-to-all per column.
+    Nulls (none on this path yet) would go to partition 0 like the reference's null_partition()."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return dict(cols)
+    ws = dist.get_world_size(group)
+    perm, counts = ops.hash_partition(key, ws, seed)
+    send = torch.tensor(counts, dtype=torch.int64, device=key.device)
+    recv = torch.zeros_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    recv_counts = [int(x) for x in recv.tolist()]
+    out = {}
+    for name, t in cols.items():
+        src = ops.take(t, perm).contiguous()
+        dst = torch.empty(sum(recv_counts), dtype=t.dtype, device=t.device)
+        dist.all_to_all_single(dst, src, output_split_sizes=recv_counts, input_split_sizes=counts, group=group)
+        out[name] = dst
+    return out
+
+
+def _combine(op: str, t, inverse, n_groups: int):
+    import torch
+    if t.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8):
+        t = t.to(torch.int64)   # counts / narrow partials combine in 64 bit
+    if op == "sum":
+        return torch.zeros(n_groups, dtype=t.dtype, device=t.device).index_add_(0, inverse, t)
+    red = "amin" if op == "min" else "amax"
+    init = torch.full((n_groups,), float("inf") if op == "min" else float("-inf"), dtype=torch.float64, device=t.device) if t.dtype.is_floating_point else \
+        torch.full((n_groups,), torch.iinfo(t.dtype).max if op == "min" else torch.iinfo(t.dtype).min, dtype=t.dtype, device=t.device)
+    return init.to(t.dtype).scatter_reduce_(0, inverse, t, reduce=red)
+
+
+def groupby_agg(ops: LocalOps, keys: Dict[str, object], values: Dict[str, object], aggs: Sequence[Tuple[str, str, str]], *, mode: str = "auto",
+                group=None) -> Dict[str, object]:
+    """Sharded group_by(keys).agg(...): aggs = [(out_name, value column, op)], op in PARTIALS.
+
+    mode "gather" : local aggregate -> all-gather partials -> every rank combines (replicated, tiny result)
+    mode "shuffle": all-to-all rows by key hash -> local aggregate -> result stays sharded by key
+    mode "auto"   : "gather" unless the local aggregate shrinks the data by less than 8x.
+    Result columns: keys + out_names.  mean is null-free here (count == 0 groups cannot exist without nulls).
+    """
+    import torch
+    import torch.distributed as dist
+    distributed = dist.is_initialized() and dist.get_world_size(group) > 1
+    partial_aggs: List[Tuple[str, str, str]] = []
+    for out, col, op in aggs:
+        for i, (pop, _) in enumerate(PARTIALS[op]):
+            partial_aggs.append((f"{out}__p{i}", col, pop))
+    if mode == "shuffle" and distributed:
+        if len(keys) != 1:
+            raise NotImplementedError("shuffle mode routes on a single key column")
+        kname = next(iter(keys))
+        moved = exchange_by_key(ops, keys[kname], {**keys, **values}, group=group)
+        keys = {k: moved[k] for k in keys}
+        values = {k: moved[k] for k in values}
+        distributed = False   # key sets are disjoint now: the local result is final
+    part = ops.groupby_partial(keys, values, partial_aggs)
+    if distributed:
+        part = {k: allgather_concat(v, group) for k, v in part.items()}
+        # combine partials of equal keys: pack the key tuple into rows and unique them
+        kt = torch.stack([part[k].to(torch.int64) for k in keys], dim=1)
+        uniq, inverse = torch.unique(kt, dim=0, return_inverse=True)
+        n = uniq.shape[0]
+        comb = {k: uniq[:, i].to(part[k].dtype) for i, k in enumerate(keys)}
+        for out, col, op in aggs:
+            for i, (_, cop) in enumerate(PARTIALS[op]):
+                comb[f"{out}__p{i}"] = _combine(cop, part[f"{out}__p{i}"], inverse, n)
+        part = comb
+    res = {k: part[k] for k in keys}
+    for out, col, op in aggs:
+        if op == "mean":
+            res[out] = part[f"{out}__p0"].to(torch.float64) / part[f"{out}__p1"].to(torch.float64)
+        else:
+            res[out] = part[f"{out}__p0"]
+    return res

@@ -147,6 +147,20 @@ class Series:
             out = [v if ok else None for v, ok in zip(out, valid.tolist())]
         return out
 
+    def to_torch(self):
+        """Device-to-device copy into a torch tensor on the current CUDA device (values only;
+        the column must be null-free).  u16/u32/u64 are reinterpreted as the signed torch dtype."""
+        import torch
+        if self.null_count():
+            raise ValueError("to_torch: column has nulls")
+        m = {F.I8: torch.int8, F.I16: torch.int16, F.I32: torch.int32, F.I64: torch.int64, F.U8: torch.uint8, F.U16: torch.int16,
+             F.U32: torch.int32, F.U64: torch.int64, F.F32: torch.float32, F.F64: torch.float64}
+        n = len(self)
+        t = torch.empty(n, dtype=m[self.dtype.physical], device="cuda")
+        if n:
+            F.check(F.lib().plx_column_copy_to_device(self._h, C.c_void_p(t.data_ptr()), None))
+        return t
+
     def to_arrow(self):
         import pyarrow as pa
         a, s = F.ArrowArray(), F.ArrowSchema()

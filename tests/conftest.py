@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure)."""
+    from oracle import pyoracle
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def pl():
+    """The product: polars_amd bound to GPU 0.  Fails loudly without the HIP library / a GPU."""
+    import polars_amd
+    polars_amd.init(0)
+    return polars_amd

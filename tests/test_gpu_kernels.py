@@ -1,0 +1,343 @@
+"""Kernel-level parity: every kernel family behind the C ABI (plx_cmp, plx_arith, plx_cast,
+plx_filter, plx_gather, plx_reduce, plx_groupby_agg, plx_join_indices, plx_hash_partition)
+against the CPU oracle on the same seeded inputs.  Integer / boolean / index results
+bit-exact; float aggregates within 1e-6 relative (BASELINE.json north_star)."""
+import math
+
+import numpy as np
+import pytest
+
+from tests import kat
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+PLDT = {"i8": "Int8", "i16": "Int16", "i32": "Int32", "i64": "Int64", "u8": "UInt8", "u16": "UInt16", "u32": "UInt32", "u64": "UInt64",
+        "f32": "Float32", "f64": "Float64"}
+SIZES = [0, 1, 63, 64, 65, 127, 128, 129, 255, 256, 257, 2047, 2048, 2049, 4097, 100_003]
+
+
+def rand(rng, dt, n, small=False):
+    npdt = kat.NP[dt]
+    if np.dtype(npdt).kind == "f":
+        x = rng.uniform(-100, 100, n).astype(npdt)
+        if n > 8:
+            x[rng.integers(0, n, 3)] = np.nan
+            x[rng.integers(0, n, 2)] = np.inf
+            x[rng.integers(0, n, 2)] = -0.0
+        return x
+    info = np.iinfo(npdt)
+    if small:
+        return rng.integers(max(info.min, -50), min(info.max, 50), n, dtype=npdt, endpoint=True)
+    return rng.integers(info.min, info.max, n, dtype=npdt, endpoint=True)
+
+
+def validity(rng, n, frac=0.1):
+    return rng.uniform(size=n) >= frac
+
+
+def S(pl, name, arr, dt, valid=None):
+    return pl.Series(name, arr, dtype=pl.Boolean if dt == "bool" else getattr(pl, PLDT[dt]), validity=valid)
+
+
+@pytest.mark.parametrize("dt", list(PLDT))
+def test_cmp(pl, orc, dt):
+    rng = np.random.default_rng(100)
+    for n in SIZES:
+        a, b = rand(rng, dt, n, small=True), rand(rng, dt, n, small=True)
+        va, vb = validity(rng, n), validity(rng, n)
+        sa, sb = S(pl, "a", a, dt, va), S(pl, "b", b, dt, vb)
+        for op in range(6):
+            out = sa.cmp(op, sb)
+            vals, ok = out._download()
+            ok = np.ones(n, bool) if ok is None else ok
+            exp_ok = va & vb
+            assert np.array_equal(ok, exp_ok), (dt, n, op)
+            assert np.array_equal(vals[exp_ok], orc.cmp(op, a, b)[exp_ok]), (dt, n, op)
+            if n:
+                sc = b[0].item()
+                vals, ok = sa.cmp(op, sc)._download()
+                ok = np.ones(n, bool) if ok is None else ok
+                assert np.array_equal(ok, va) and np.array_equal(vals[va], orc.cmp(op, a, b[0])[va]), (dt, n, op, "scalar")
+
+
+@pytest.mark.parametrize("dt", list(PLDT))
+def test_arith(pl, orc, dt):
+    rng = np.random.default_rng(101)
+    isf = dt.startswith("f")
+    for n in [0, 1, 63, 64, 65, 1000, 4099]:
+        a, b = rand(rng, dt, n), rand(rng, dt, n, small=True)
+        va = validity(rng, n)
+        sa, sb = S(pl, "a", a, dt, va), S(pl, "b", b, dt)
+        for op in range(6):
+            got = sa.arith(op, sb)
+            vals, ok = got._download()
+            ok = np.ones(n, bool) if ok is None else ok
+            ev, extra = orc.arith(op, a, b)
+            eok = va & (extra if extra is not None else True)
+            assert np.array_equal(ok, eok), (dt, n, op)
+            assert vals.dtype == ev.dtype
+            assert np.array_equal(vals[eok], ev[eok], equal_nan=True), (dt, n, op)
+            if n:
+                for sc in ([b[0].item(), 0, 1, -1, 2] if not dt.startswith("u") else [b[0].item(), 0, 1, 2]):
+                    if isf:
+                        sc = float(sc)
+                    ev, extra = orc.arith(op, a, sc, mode=1)
+                    vals, ok = sa.arith(op, sc)._download()
+                    ok = np.ones(n, bool) if ok is None else ok
+                    eok = va & (extra if extra is not None else True)
+                    assert np.array_equal(ok, eok), (dt, n, op, sc)
+                    assert np.array_equal(vals[eok], ev[eok], equal_nan=True), (dt, n, op, sc, "col-scalar")
+                    ev, extra = orc.arith(op, sc, a, mode=2)
+                    vals, ok = sa.arith(op, sc, scalar_on_left=True)._download()
+                    ok = np.ones(n, bool) if ok is None else ok
+                    eok = va & (extra if extra is not None else True)
+                    assert np.array_equal(ok, eok), (dt, n, op, sc)
+                    assert np.array_equal(vals[eok], ev[eok], equal_nan=True), (dt, n, op, sc, "scalar-col")
+
+
+@pytest.mark.parametrize("dt", ["bool"] + list(PLDT))
+def test_filter_with_nulls(pl, orc, dt):
+    rng = np.random.default_rng(102)
+    for n in SIZES:
+        for sel in (0.0, 0.03, 0.5, 0.97, 1.0):
+            a = (rng.uniform(size=n) < 0.5) if dt == "bool" else rand(rng, dt, n)
+            va = validity(rng, n)
+            m, mv = rng.uniform(size=n) < sel, validity(rng, n, 0.05)
+            got = S(pl, "a", a, dt, va).filter(pl.Series("m", m, dtype=pl.Boolean, validity=mv))
+            vals, ok = got._download()
+            ev, eok = orc.filter(a, va, m, mv)
+            assert len(vals) == len(ev), (dt, n, sel)
+            ok = np.ones(len(ev), bool) if ok is None else ok
+            assert np.array_equal(ok, eok), (dt, n, sel)
+            assert np.array_equal(vals[eok], ev[eok], equal_nan=True), (dt, n, sel)
+
+
+@pytest.mark.parametrize("dt", ["bool", "i8", "i32", "i64", "f64"])
+def test_gather(pl, orc, dt):
+    rng = np.random.default_rng(103)
+    for n, m in [(1, 0), (1, 5), (100, 1000), (5000, 100_003)]:
+        a = (rng.uniform(size=n) < 0.5) if dt == "bool" else rand(rng, dt, n)
+        va = validity(rng, n)
+        idx = rng.integers(0, n, m).astype(np.uint32)
+        iv = validity(rng, m, 0.05)
+        got = S(pl, "a", a, dt, va).gather(pl.Series("i", idx, dtype=pl.UInt32, validity=iv))
+        vals, ok = got._download()
+        ev, eok = orc.gather(a, va, idx, iv)
+        ok = np.ones(m, bool) if ok is None else ok
+        assert np.array_equal(ok, eok), (dt, n, m)
+        assert np.array_equal(vals[eok], ev[eok], equal_nan=True), (dt, n, m)
+
+
+@pytest.mark.parametrize("dt", list(PLDT))
+def test_reduce(pl, orc, dt):
+    rng = np.random.default_rng(104)
+    isf = dt.startswith("f")
+    for n in SIZES + [1_000_003]:
+        a = rand(rng, dt, n)
+        if isf:
+            a = np.nan_to_num(a, nan=1.5, posinf=2.5, neginf=-2.5)
+        for v in (None, validity(rng, n, 0.2), np.zeros(n, bool)):
+            s = S(pl, "a", a, dt, v)
+            for op, name in ((orc.AGG_SUM, "sum"), (orc.AGG_MEAN, "mean"), (orc.AGG_MIN, "min"), (orc.AGG_MAX, "max"), (orc.AGG_COUNT, "count")):
+                got = getattr(s, name)()
+                exp, _ = orc.reduce(op, a, v)
+                if exp is None or got is None:
+                    assert exp is None and got is None, (dt, n, name, got, exp)
+                elif isinstance(exp, float):
+                    tol = RTOL if dt == "f64" or name == "mean" else 1e-4   # f32 sums accumulate in f32 in the reference
+                    assert math.isclose(got, exp, rel_tol=tol, abs_tol=tol * (abs(a.astype(np.float64)).sum() if n else 0) * 1e-3 + 1e-300), (dt, n, name, got, exp)
+                else:
+                    assert got == exp, (dt, n, name, got, exp)
+    # NaN handling of min / max / mean
+    if isf:
+        x = np.array([np.nan, 1.0, -3.0, np.nan], dtype=kat.NP[dt])
+        s = S(pl, "x", x, dt)
+        assert s.min() == -3.0 and s.max() == 1.0 and math.isnan(s.mean())
+        assert math.isnan(S(pl, "x", x[[0, 3]], dt).min())
+
+
+def _check_groupby(pl, orc, keys, kvalids, kdts, vals, vvalid, vdt, maintain_order=False):
+    n = len(keys[0])
+    ks = [S(pl, f"k{i}", k, d, v) for i, (k, v, d) in enumerate(zip(keys, kvalids, kdts))]
+    vs = S(pl, "v", vals, vdt, vvalid)
+    df = pl.DataFrame(ks + [vs])
+    c = pl.col("v")
+    out = df.lazy().group_by(*[f"k{i}" for i in range(len(keys))], maintain_order=maintain_order).agg(
+        c.sum().alias("s"), c.mean().alias("m"), c.min().alias("mn"), c.max().alias("mx"), c.count().alias("c"), pl.len().alias("n")).collect()
+    plan = pl.last_plan()
+    r = orc.q_groupby(keys, kvalids, [("s", orc.AGG_SUM, vals, vvalid), ("m", orc.AGG_MEAN, vals, vvalid), ("mn", orc.AGG_MIN, vals, vvalid),
+                                       ("mx", orc.AGG_MAX, vals, vvalid), ("c", orc.AGG_COUNT, vals, vvalid), ("n", orc.AGG_LEN, None, None)],
+                      maintain_order=maintain_order)
+    nk = len(keys)
+
+    def rows_of(getcol, G):
+        rows = []
+        for g in range(G):
+            rows.append(tuple(getcol(name, g) for name in [f"k{i}" for i in range(nk)] + ["s", "m", "mn", "mx", "c", "n"]))
+        return rows
+    d = out.to_dict()
+    got = rows_of(lambda name, g: d[name][g], out.height)
+
+    def ocol(name, g):
+        key = f"key_{name[1:]}" if name.startswith("k") and name[1:].isdigit() else name
+        v, ok = r[key]
+        return v[g].item() if ok[g] else None
+    exp = rows_of(ocol, len(r["key_0"][0]))
+    if not maintain_order:
+        kf = lambda row: tuple((x is None, 0 if x is None or (isinstance(x, float) and math.isnan(x)) else x, isinstance(x, float) and math.isnan(x)) for x in row[:nk])
+        got.sort(key=kf); exp.sort(key=kf)
+    assert len(got) == len(exp), (plan, len(got), len(exp))
+    for a, b in zip(got, exp):
+        for x, y in zip(a, b):
+            if isinstance(y, float) and y is not None and x is not None:
+                assert (math.isnan(x) and math.isnan(y)) or math.isclose(x, y, rel_tol=RTOL, abs_tol=1e-9), (plan, a, b)
+            else:
+                assert x == y, (plan, a, b)
+    return plan
+
+
+@pytest.mark.parametrize("kdt", ["i8", "u8", "i16", "i32", "u32", "i64", "u64", "f64", "bool"])
+@pytest.mark.parametrize("vdt", ["i64", "f64", "i32", "u8"])
+def test_groupby_single_key(pl, orc, kdt, vdt):
+    rng = np.random.default_rng(105)
+    for n, card in [(0, 1), (1, 1), (1000, 7), (50_000, 300), (200_000, 70_000)]:
+        if kdt == "bool":
+            k = rng.uniform(size=n) < 0.5
+        elif kdt == "f64":
+            k = rng.integers(-card // 2, card // 2 + 1, n).astype(np.float64) / 4
+            if n > 10:
+                k[:3] = [np.nan, -0.0, 0.0]
+        else:
+            info = np.iinfo(kat.NP[kdt])
+            k = (rng.integers(0, card, n) + max(info.min, -3)).astype(kat.NP[kdt]) if card < info.max - 4 else rng.integers(info.min, info.max, n, dtype=kat.NP[kdt])
+        kv = validity(rng, n, 0.02)
+        v = rand(rng, vdt, n, small=True) if not vdt.startswith("f") else rng.uniform(0, 100, n)
+        vv = validity(rng, n, 0.1)
+        _check_groupby(pl, orc, [k], [kv], [kdt], v, vv, vdt)
+
+
+def test_groupby_sentinel_and_extreme_keys(pl, orc):
+    """Keys equal to the hash table's EMPTY sentinel (all ones), min/max ints, plus nulls."""
+    k = np.array([-1, -1, 0, 2**63 - 1, -2**63, -1, 5, 5, 0], dtype=np.int64)
+    kv = np.array([1, 1, 1, 1, 1, 0, 1, 1, 0], dtype=bool)
+    v = np.arange(9, dtype=np.int64)
+    plan = _check_groupby(pl, orc, [k], [kv], ["i64"], v, None, "i64")
+    assert "hash" in plan, plan
+    ku = k.view(np.uint64)
+    _check_groupby(pl, orc, [ku], [kv], ["u64"], v, None, "i64")
+
+
+def test_groupby_two_keys_packed(pl, orc):
+    rng = np.random.default_rng(106)
+    n = 100_000
+    k0 = rng.integers(0, 3, n).astype(np.uint8)
+    k1 = rng.integers(-5, 5, n).astype(np.int32)
+    k1v = validity(rng, n, 0.05)
+    v = rng.uniform(0, 1, n)
+    plan = _check_groupby(pl, orc, [k0, k1], [None, k1v], ["u8", "i32"], v, None, "f64")
+    assert "lds_table" in plan, plan
+    _check_groupby(pl, orc, [k0, k1], [None, k1v], ["u8", "i32"], v, None, "f64", maintain_order=True)
+
+
+def test_groupby_multi_key_wide(pl, orc):
+    """Three 64-bit keys that cannot be bit-packed (the Q3 group-by shape)."""
+    rng = np.random.default_rng(107)
+    n = 60_000
+    k0 = rng.integers(0, 2**40, 5000)[rng.integers(0, 5000, n)].astype(np.int64)
+    k1 = (k0 * 7919) % (2**50) - 2**49
+    k2 = rng.integers(0, 2, n).astype(np.int64) * (2**62)
+    k2v = validity(rng, n, 0.1)
+    v = rng.uniform(0, 1, n)
+    plan = _check_groupby(pl, orc, [k0, k1, k2], [None, None, k2v], ["i64", "i64", "i64"], v, None, "f64")
+    assert "hash" in plan, plan
+
+
+@pytest.mark.parametrize("kdt", ["i8", "i32", "i64", "u64", "f64"])
+@pytest.mark.parametrize("how", ["inner", "left"])
+def test_join_indices(pl, orc, kdt, how):
+    rng = np.random.default_rng(108)
+    for nl, nr, card in [(0, 5, 3), (5, 0, 3), (100, 100, 20), (5000, 3000, 700), (3000, 50_000, 100_000), (100_000, 20_000, 1000)]:
+        if kdt == "f64":
+            lk, rk = rng.integers(0, card, nl) / 2.0, rng.integers(0, card, nr) / 2.0
+            if nl > 3 and nr > 3:
+                lk[0], rk[0], lk[1], rk[1] = np.nan, np.nan, -0.0, 0.0
+        else:
+            info = np.iinfo(kat.NP[kdt])
+            c = min(card, int(info.max) - 1)
+            lk, rk = rng.integers(0, c, nl).astype(kat.NP[kdt]), rng.integers(0, c, nr).astype(kat.NP[kdt])
+            if kdt in ("i64", "u64") and nl > 3 and nr > 3:
+                lk[0] = rk[0] = kat.NP[kdt](-1) if kdt == "i64" else np.uint64(2**64 - 1)   # the EMPTY sentinel as a real key
+        lv, rv = validity(rng, nl, 0.05), validity(rng, nr, 0.05)
+        L = pl.DataFrame([S(pl, "k", lk, kdt, lv), pl.Series("li", np.arange(nl, dtype=np.uint32))])
+        R = pl.DataFrame([S(pl, "k", rk, kdt, rv), pl.Series("ri", np.arange(nr, dtype=np.uint32))])
+        out = L.join(R, on="k", how=how)
+        d = out.to_dict()
+        got = sorted(zip(d["li"], [(-1 if x is None else x) for x in d["ri"]]))
+        li, ri, rvalid = orc.join(orc.JOIN_LEFT if how == "left" else orc.JOIN_INNER, lk, lv, rk, rv)
+        exp = sorted(zip(li.tolist(), [(-1 if (rvalid is not None and not ok) else int(r)) for r, ok in zip(ri, rvalid if rvalid is not None else np.ones(len(ri), bool))]))
+        assert got == exp, (kdt, how, nl, nr)
+        # joined key column: coalesced from the left side
+        kk, kok = L["k"].gather(pl.Series("i", np.array([g[0] for g in got], dtype=np.uint32)))._download()
+        assert out.columns == ["k", "li", "ri"]
+
+
+def test_hash_partition(pl, orc):
+    import ctypes as C
+    rng = np.random.default_rng(109)
+    F = pl._ffi
+    for n, parts in [(0, 4), (1000, 2), (100_000, 8), (100_000, 64)]:
+        k = rng.integers(-2**62, 2**62, n, dtype=np.int64)
+        kv = validity(rng, n, 0.05)
+        s = pl.Series("k", k, dtype=pl.Int64, validity=kv)
+        h = C.c_uint64(); counts = (C.c_int64 * parts)()
+        F.check(F.lib().plx_hash_partition(s._h, parts, 0, C.byref(h), counts))
+        perm = pl.Series._from_handle("perm", h.value, pl.UInt32).to_numpy()
+        exp = orc.hash_partition(k, kv, parts, 0)
+        assert list(counts) == np.bincount(exp, minlength=parts).tolist()
+        assert sorted(perm.tolist()) == list(range(n))
+        assert np.array_equal(exp[perm], np.sort(exp))      # rows grouped by partition
+
+
+def test_cast(pl, orc):
+    rng = np.random.default_rng(110)
+    for f in PLDT:
+        a = rand(rng, f, 3000)
+        for t in PLDT:
+            got = S(pl, "a", a, f).cast(getattr(pl, PLDT[t]))
+            vals, ok = got._download()
+            import ctypes as C
+            ev = np.zeros(len(a), dtype=kat.NP[t]); okb = np.zeros((len(a) + 7) // 8 + 8, dtype=np.uint8)
+            rc = orc.lib().orc_cast(orc.DT_OF[a.dtype], orc.DT_OF[np.dtype(kat.NP[t])], a.ctypes.data_as(C.c_void_p), C.c_int64(len(a)), ev.ctypes.data_as(C.c_void_p), okb.ctypes.data_as(C.c_void_p))
+            assert rc == 0
+            eok = orc.unpack(okb, len(a))
+            ok = np.ones(len(a), bool) if ok is None else ok
+            assert np.array_equal(ok, eok), (f, t)
+            assert np.array_equal(vals[eok], ev[eok], equal_nan=True), (f, t)
+
+
+def test_arrow_roundtrip_and_series_export(pl):
+    pa = pytest.importorskip("pyarrow")
+    arr = pa.array([1, None, 3, 4, None], type=pa.int64())
+    s = pl.Series.from_arrow("a", arr)
+    assert s.to_list() == [1, None, 3, 4, None] and s.null_count() == 2
+    assert s.to_arrow().to_pylist() == [1, None, 3, 4, None]
+    sliced = pa.array(list(range(100)), type=pa.int32()).slice(37, 40)     # Arrow offset honoured
+    assert pl.Series.from_arrow("b", sliced).to_list() == list(range(37, 77))
+    b = pa.array([True, None, False, True] * 20).slice(3, 61)
+    assert pl.Series.from_arrow("c", b).to_list() == b.to_pylist()
+    st = pa.array(["x", "y", None, "x"])
+    assert pl.Series.from_arrow("d", st).to_list() == ["x", "y", None, "x"]
+
+
+def test_errors_are_status_codes_not_crashes(pl):
+    a = pl.Series("a", np.arange(10, dtype=np.int64))
+    b = pl.Series("b", np.arange(11, dtype=np.int64))
+    with pytest.raises(pl.PlxError) as e:
+        a.cmp(0, b)
+    assert e.value.code == 5          # PLX_ERR_SHAPE
+    with pytest.raises(pl.PlxError) as e:
+        a.cmp(0, pl.Series("c", np.arange(10, dtype=np.int32)))
+    assert e.value.code == 1          # PLX_ERR_INVALID (type coercion is the optimizer's job)
+    with pytest.raises(pl.PlxError) as e:
+        pl.DataFrame([a]).lazy().select(pl.col("nope").sum()).collect()
+    assert e.value.code == 6          # PLX_ERR_NOT_FOUND

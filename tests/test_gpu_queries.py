@@ -1,0 +1,178 @@
+"""Query-level parity: the BASELINE.json configurations and TPC-H Q1 / Q3 through
+plx_execute_plan, (a) fused pipelines, (b) PLX_PLAN_NO_FUSION (one kernel per IR node, the
+reference's execution shape), (c) the CPU oracle -- the reference's own engine-parity pattern
+(py-polars/tests/unit/streaming/test_streaming_group_by.py:149-196: same query, two executors,
+frame-equal with check_row_order=False).  Integer results bit-exact, float aggregates 1e-6 rel."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def close(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.allclose(a, b, rtol=RTOL, atol=0.0, equal_nan=True)
+
+
+def test_cfg1_filter_sum(pl, orc):
+    """BASELINE config 1 (1e7-row Int64, filter(a > k).sum()): exact."""
+    from polars_amd import queries
+    a = np.random.Generator(np.random.PCG64(0)).integers(0, 2**31, 10_000_000, dtype=np.int64)
+    df = pl.DataFrame({"a": a})
+    for nf in (False, True):
+        out = queries.cfg1(df.lazy()).collect(no_fusion=nf)
+        assert out.rows() == [(orc.q_filter_sum_cfg1(a, 2**30),)]
+    assert out.rows()[0][0] == int(a[a > 2**30].sum())
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.05])
+@pytest.mark.parametrize("n", [0, 1, 127, 128, 129, 100_000, 3_000_001])
+def test_cfg2_filter_arith_agg(pl, orc, n, null_frac):
+    from polars_amd import datagen, queries
+    a, x, y, xv = datagen.cfg2_host(n, null_frac if n > 100 else 0.0)
+    df = pl.DataFrame([pl.Series("a", a), pl.Series("x", x, validity=xv), pl.Series("y", y)])
+    exp = orc.q_filter_agg_cfg2(a, x, y, 2**30, xv)
+    for nf in (False, True):
+        out = queries.cfg2(df.lazy()).collect(no_fusion=nf)
+        plan = pl.last_plan()
+        assert ("fused_scan[aot]" in plan) == (not nf), plan
+        (xy, xm, asum), = out.rows()
+        assert asum == exp["a_sum"]
+        if exp["x_mean"] is None:
+            assert xm is None and xy == 0.0
+        else:
+            assert math.isclose(xm, exp["x_mean"], rel_tol=RTOL) and math.isclose(xy, exp["xy"], rel_tol=RTOL)
+        assert out.schema == {"xy": pl.Float64, "x_mean": pl.Float64, "a_sum": pl.Int64}
+
+
+@pytest.mark.parametrize("zipf", [0.0, 1.1])
+def test_cfg3_groupby_1e6_keys(pl, orc, zipf):
+    """BASELINE config 3 at 4e6 rows / 1e6 keys (the oracle finishes in seconds)."""
+    from polars_amd import datagen, queries
+    key, v = datagen.cfg3_host(4_000_000, 1_000_000, zipf)
+    df = pl.DataFrame({"key": key, "v": v})
+    out = queries.cfg3(df.lazy()).collect()
+    plan = pl.last_plan()
+    assert "fused_scan[aot]" in plan, plan
+    k = out["key"].to_numpy(); order = np.argsort(k)
+    uk, inv = np.unique(key, return_inverse=True)
+    assert np.array_equal(k[order], uk)
+    assert np.array_equal(out["v_sum"].to_numpy()[order], np.bincount(inv, weights=None, minlength=len(uk)) * 0 + np.bincount(inv, v).astype(np.int64))
+    assert np.array_equal(out["v_count"].to_numpy()[order], np.bincount(inv).astype(np.uint32))
+    r = orc.q_groupby([key[:500_000]], [None], [("s", orc.AGG_SUM, v[:500_000], None)])
+    small = queries.cfg3(pl.DataFrame({"key": key[:500_000], "v": v[:500_000]}).lazy()).collect(no_fusion=True)
+    o1, o2 = np.argsort(r["key_0"][0]), np.argsort(small["key"].to_numpy())
+    assert np.array_equal(r["s"][0][o1], small["v_sum"].to_numpy()[o2])
+    assert out.schema == {"key": pl.Int64, "v_sum": pl.Int64, "v_count": pl.UInt32}
+
+
+def test_cfg5_dictionary_string_keys(pl, orc):
+    from polars_amd import datagen, queries
+    codes, v = datagen.cfg5_host(2_000_000, 1_000_000)
+    df = pl.DataFrame([pl.Series("k", codes, dtype=pl.Categorical([], pl.UInt32)), pl.Series("v", v)])
+    out = queries.cfg5(df.lazy()).collect()
+    k = out["k"].to_numpy(); order = np.argsort(k)
+    uk, inv = np.unique(codes, return_inverse=True)
+    assert np.array_equal(k[order], uk)
+    s = np.bincount(inv, v); c = np.bincount(inv)
+    assert close(out["v_sum"].to_numpy()[order], s) and close(out["v_mean"].to_numpy()[order], s / c)
+
+
+@pytest.mark.parametrize("n", [0, 5, 1000, 200_000, 2_000_003])
+def test_q1(pl, orc, n):
+    from polars_amd import datagen, queries
+    li = datagen.lineitem_host(n, seed=21)
+    df = datagen.to_frame(pl, li, datagen.LINEITEM_Q1_COLS)
+    exp = orc.q1({k: li[k] for k in datagen.LINEITEM_Q1_COLS}, datagen.us(1998, 9, 2))
+    for nf in (False, True):
+        out = queries.q1(df.lazy()).collect(no_fusion=nf)
+        plan = pl.last_plan()
+        if not nf and n:
+            assert "fused_scan[aot]" in plan and "lds_table" in plan, plan
+        g = out.sort_host(["l_returnflag", "l_linestatus"])
+        assert [datagen.FLAGS.index(x) for x in g["l_returnflag"]] == exp["l_returnflag"].tolist(), plan
+        assert [datagen.STATUS.index(x) for x in g["l_linestatus"]] == exp["l_linestatus"].tolist()
+        assert g["sum_qty"] == exp["sum_qty"].tolist() and g["count_order"] == exp["count_order"].tolist()
+        for c in ("sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc"):
+            assert close(g[c], exp[c]), (c, nf)
+    assert out.schema["sum_qty"] == pl.Int64 and out.schema["count_order"] == pl.UInt32 and out.schema["avg_qty"] == pl.Float64
+
+
+@pytest.mark.parametrize("n_orders", [0, 10, 5000, 150_000])
+def test_q3(pl, orc, n_orders):
+    from polars_amd import datagen, queries
+    orders, li = datagen.orders_lineitem_host(n_orders, seed=22)
+    L = datagen.to_frame(pl, li, datagen.LINEITEM_Q3_COLS)
+    O = datagen.to_frame(pl, orders, datagen.ORDERS_Q3_COLS)
+    exp = orc.q3({k: li[k] for k in datagen.LINEITEM_Q3_COLS}, {k: orders[k] for k in datagen.ORDERS_Q3_COLS}, datagen.us(1995, 3, 15))
+    for nf in (False, True):
+        out = queries.q3(L.lazy(), O.lazy()).collect(no_fusion=nf)
+        g = out.sort_host("l_orderkey")
+        assert g["l_orderkey"] == exp["l_orderkey"].tolist(), pl.last_plan()
+        assert g["o_orderdate"] == exp["o_orderdate"].tolist() and g["o_shippriority"] == exp["o_shippriority"].tolist()
+        assert close(g["revenue"], exp["revenue"])
+    assert out.columns == ["l_orderkey", "o_orderdate", "o_shippriority", "revenue"]
+
+
+def test_generic_interpreter_matches_aot(pl, orc):
+    """A query shape with no pre-instantiated kernel runs the scalar-unit-decoded interpreter;
+    it must agree with the per-node path and the oracle."""
+    rng = np.random.default_rng(7)
+    n = 300_001
+    a = rng.integers(-1000, 1000, n).astype(np.int32)
+    b = rng.integers(0, 5, n).astype(np.int64)
+    x = rng.uniform(-1, 1, n)
+    xv = rng.uniform(size=n) > 0.1
+    df = pl.DataFrame([pl.Series("a", a), pl.Series("b", b), pl.Series("x", x, validity=xv)])
+    q = (df.lazy().filter((pl.col("a") >= -500) & (pl.col("x") < 0.9) | (pl.col("b") == 3))
+         .select(((pl.col("x") + 2.0) * pl.col("x") / 4).sum().alias("e"), pl.col("a").min().alias("amin"), pl.col("a").max().alias("amax"),
+                 (pl.col("b") * pl.col("b") - 1).sum().alias("bb"), pl.col("x").count().alias("xc"), pl.len().alias("n"), pl.col("x").max().alias("xmax")))
+    o1 = q.collect(); p1 = pl.last_plan()
+    o2 = q.collect(no_fusion=True)
+    assert "fused_scan[generic]" in p1, p1
+    m = ((a >= -500) & (x < 0.9) & xv) | (b == 3)    # Kleene: null & x -> null unless other side False; null | True -> True
+    m_null = ((a >= -500) & ~xv) & ~(b == 3)
+    keep = m & ~m_null
+    xe = x[keep & xv]
+    exp = {"e": ((xe + 2.0) * xe * 0.25).sum(), "amin": int(a[keep].min()), "amax": int(a[keep].max()), "bb": int((b[keep] * b[keep] - 1).sum()),
+           "xc": int((keep & xv).sum()), "n": int(keep.sum()), "xmax": float(xe.max())}
+    for o in (o1, o2):
+        d = {k: v[0] for k, v in o.to_dict().items()}
+        assert d["amin"] == exp["amin"] and d["amax"] == exp["amax"] and d["bb"] == exp["bb"] and d["xc"] == exp["xc"] and d["n"] == exp["n"]
+        assert math.isclose(d["e"], exp["e"], rel_tol=RTOL) and d["xmax"] == exp["xmax"]
+
+
+def test_full_size_properties_q1(pl):
+    """Size-independent properties at a size the oracle cannot cover in seconds (6e7 rows):
+    count_order sums to the selected rows, sum_qty is the exact integer sum, avg = sum / count,
+    and doubling the input doubles every sum (linearity)."""
+    import torch
+    from polars_amd import datagen, queries
+    n = 60_000_000
+    cols = datagen.lineitem_device(n, seed=5)
+    torch.cuda.synchronize()
+    df = datagen.frame_from_torch(pl, cols, datagen.LINEITEM_Q1_COLS)
+    out = queries.q1(df.lazy()).collect()
+    g = out.sort_host(["l_returnflag", "l_linestatus"])
+    sel = cols["l_shipdate"] <= datagen.us(1998, 9, 2)
+    assert sum(g["count_order"]) == int(sel.sum().item())
+    assert sum(g["sum_qty"]) == int(cols["l_quantity"][sel].sum().item())
+    gid = (cols["l_returnflag"].to(torch.int64) * 2 + cols["l_linestatus"].to(torch.int64))[sel]
+    for i, (f, s) in enumerate(zip(g["l_returnflag"], g["l_linestatus"])):
+        code = datagen.FLAGS.index(f) * 2 + datagen.STATUS.index(s)
+        m = gid == code
+        assert g["count_order"][i] == int(m.sum().item())
+        assert g["sum_qty"][i] == int(cols["l_quantity"][sel][m].sum().item())
+        ref = cols["l_extendedprice"][sel][m].sum().item()
+        assert math.isclose(g["sum_base_price"][i], ref, rel_tol=RTOL)
+        assert math.isclose(g["avg_price"][i], ref / g["count_order"][i], rel_tol=RTOL)
+        assert math.isclose(g["avg_qty"][i], g["sum_qty"][i] / g["count_order"][i], rel_tol=1e-12)
+    # linearity: the same rows twice
+    twice = {k: torch.cat([v, v]) for k, v in cols.items()}
+    torch.cuda.synchronize()
+    g2 = queries.q1(datagen.frame_from_torch(pl, twice, datagen.LINEITEM_Q1_COLS).lazy()).collect().sort_host(["l_returnflag", "l_linestatus"])
+    assert g2["count_order"] == [2 * c for c in g["count_order"]] and g2["sum_qty"] == [2 * c for c in g["sum_qty"]]
+    assert close(g2["sum_charge"], [2 * c for c in g["sum_charge"]]) and close(g2["avg_disc"], g["avg_disc"])

@@ -1,0 +1,253 @@
+"""Pins the CPU oracle (oracle/plx_oracle.cpp) against the known-answer vectors transcribed
+from the reference's own tests (tests/golden/reference_kats.json, each case cites its
+source) and against independent implementations (numpy, pyarrow, pandas), the way the
+reference cross-checks against pandas (py-polars/tests/unit/streaming/test_streaming_join.py:61-112).
+CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+from tests import kat
+
+AGG = {"sum": 0, "mean": 1, "min": 2, "max": 3, "count": 4, "len": 5}
+
+
+def _to_py(v, ok):
+    if not ok:
+        return None
+    return v.item() if hasattr(v, "item") else v
+
+
+@pytest.mark.parametrize("case", kat.load_cases("groupby"), ids=lambda c: c["id"])
+@pytest.mark.parametrize("threads", [1, 3])
+def test_groupby_kats(orc, case, threads):
+    orc.set_threads(threads)
+    keys, kvalid, cats = [], [], {}
+    for name, spec in case["keys"].items():
+        a, v, c = kat.column(spec, case["key_dtypes"][name])
+        keys.append(a); kvalid.append(v); cats[name] = c
+    aggs = []
+    for col, op in case["aggs"]:
+        a, v, _ = kat.column(case["values"][col], case["value_dtypes"][col])
+        aggs.append((f"{col}_{op}", AGG[op], a, v))
+    r = orc.q_groupby(keys, kvalid, aggs, maintain_order=case["maintain_order"])
+    G = len(r["key_0"][0])
+    rows = []
+    for g in range(G):
+        row = []
+        for i, name in enumerate(case["keys"]):
+            v, ok = r[f"key_{i}"]
+            x = _to_py(v[g], ok[g])
+            if x is not None and cats[name] is not None:
+                x = cats[name][x]
+            row.append(x)
+        for name, _, _, _ in aggs:
+            v, ok = r[name]
+            row.append(_to_py(v[g], ok[g]))
+        rows.append(row)
+    exp_cols = list(case["keys"].keys()) + [n for n, _, _, _ in aggs]
+    exp_rows = [[case["expect"][c][g] for c in exp_cols] for g in range(len(case["expect"][exp_cols[0]]))]
+    if not case["maintain_order"]:
+        keyf = lambda row: tuple((x is None, x) for x in row[: len(case["keys"])])
+        rows.sort(key=keyf); exp_rows.sort(key=keyf)
+    assert len(rows) == len(exp_rows)
+    for got, exp in zip(rows, exp_rows):
+        for g, e in zip(got, exp):
+            assert kat.same_value(g, e), (case["id"], got, exp)
+    for name, dt in case.get("expect_dtypes", {}).items():
+        assert r[name][0].dtype == kat.NP[dt], (case["id"], name, r[name][0].dtype)
+    orc.set_threads(1)
+
+
+@pytest.mark.parametrize("case", kat.load_cases("reduce"), ids=lambda c: c["id"])
+def test_reduce_kats(orc, case):
+    a, v, _ = kat.column(case["values"], case["dtype"])
+    got, _ = orc.reduce(AGG[case["op"]], a, v)
+    assert kat.same_value(got, case["expect"], case.get("rtol", 1e-12))
+
+
+def _join_frames(orc, case):
+    L, R = {}, {}
+    cats = {}
+    # strings on both sides share one dictionary
+    for side, dst in (("left", L), ("right", R)):
+        for name, spec in case[side].items():
+            dt = case[side + "_dtypes"][name]
+            if dt == "str":
+                allv = sorted({v for s in ("left", "right") for v in case[s].get(name, []) if v is not None})
+                lut = {c: i for i, c in enumerate(allv)}
+                vals = list(spec)
+                valid = np.array([x is not None for x in vals])
+                dst[name] = (np.array([lut[x] if x is not None else 0 for x in vals], dtype=np.uint32), None if valid.all() else valid)
+                cats[name] = allv
+            else:
+                a, v, _ = kat.column(spec, dt)
+                dst[name] = (a, v)
+    return L, R, cats
+
+
+@pytest.mark.parametrize("case", kat.load_cases("join"), ids=lambda c: c["id"])
+@pytest.mark.parametrize("threads", [1, 2, 7])
+def test_join_kats(orc, case, threads):
+    """crates/polars/tests/it/core/joins.rs:53-78 runs the same vectors for 1..7 threads."""
+    orc.set_threads(threads)
+    L, R, cats = _join_frames(orc, case)
+    on = case["on"]
+    how = orc.JOIN_LEFT if case["how"] == "left" else orc.JOIN_INNER
+    li, ri, rvalid = orc.join(how, L[on][0], L[on][1], R[on][0], R[on][1])
+    out = {}
+    for name, (a, v) in L.items():
+        vals, ok = orc.gather(a, v, li)
+        out[name] = [(_to_py(x, o)) for x, o in zip(vals, ok)]
+    for name, (a, v) in R.items():
+        if name == on:
+            continue
+        vals, ok = orc.gather(a, v, ri, rvalid)
+        nm = name + "_right" if name in out else name
+        out[nm] = [(_to_py(x, o)) for x, o in zip(vals, ok)]
+    if "expect" in case:
+        exp = case["expect"]
+        cols = list(exp.keys())
+        got_rows = sorted([tuple(out[c][i] for c in cols) for i in range(len(li))], key=lambda r: tuple((x is None, x) for x in r))
+        exp_rows = sorted([tuple(exp[c][i] for c in cols) for i in range(len(exp[cols[0]]))], key=lambda r: tuple((x is None, x) for x in r))
+        assert len(got_rows) == len(exp_rows), (got_rows, exp_rows)
+        for g, e in zip(got_rows, exp_rows):
+            for a, b in zip(g, e):
+                assert kat.same_value(a, b), (case["id"], got_rows, exp_rows)
+    else:
+        for c, expv in case["expect_column_sorted_by_key"].items():
+            order = sorted(range(len(li)), key=lambda i: (out[on][i], i))
+            # probe order (left rows in order, build duplicates in insertion order) == maintain_order="left_right"
+            assert [out[c][i] for i in order] == expv
+    orc.set_threads(1)
+
+
+def test_total_ordering_floats(orc):
+    """py-polars/tests/unit/operations/test_comparison.py:209-226: normal < nan, nan == nan."""
+    case = kat.load_cases("cmp_total_order")[0]
+    vals = [kat.scalar(v) for v in case["values"] if v is not None]
+    for dt in case["dtypes"]:
+        a = np.array([l for l in vals for _ in vals], dtype=kat.NP[dt])
+        b = np.array([r for _ in vals for r in vals], dtype=kat.NP[dt])
+
+        def ref(l, r):
+            if math.isnan(l) and math.isnan(r): return "="
+            if math.isnan(l) or l > r: return ">"
+            if math.isnan(r) or l < r: return "<"
+            return "="
+        order = [ref(float(l), float(r)) for l, r in zip(a, b)]
+        exp = {orc.EQ: [o == "=" for o in order], orc.NE: [o != "=" for o in order], orc.LT: [o == "<" for o in order],
+               orc.LE: [o in "<=" for o in order], orc.GT: [o == ">" for o in order], orc.GE: [o in ">=" for o in order]}
+        for op, e in exp.items():
+            assert orc.cmp(op, a, b).tolist() == e, (dt, op)
+            # broadcast form (verify_total_ordering_broadcast)
+            for j, r in enumerate(vals):
+                sel = slice(j, None, len(vals))
+                assert orc.cmp(op, a[sel].copy(), kat.NP[dt](r)).tolist() == e[sel], (dt, op, r)
+
+
+def test_filter_sweep(orc):
+    case = kat.load_cases("filter_sweep")[0]
+    for dt in case["dtypes"]:
+        for size in case["sizes"]:
+            for sel in case["selectivities"]:
+                p, m, exp = kat.filter_sweep_inputs(dt, size, sel)
+                got, _ = orc.filter(p, None, m)
+                assert got.dtype == exp.dtype and np.array_equal(got, exp), (dt, size, sel)
+
+
+@pytest.mark.parametrize("case", kat.load_cases("arith"), ids=lambda c: c["id"])
+def test_arith_kats(orc, case):
+    a, _, _ = kat.column(case["lhs"], case["dtype"])
+    b, _, _ = kat.column(case["rhs"], case["dtype"])
+    OPS = {"add": orc.ADD, "sub": orc.SUB, "mul": orc.MUL, "floor_div": orc.FLOOR_DIV, "mod": orc.MOD}
+    for name, exp in case["expect"].items():
+        vals, extra = orc.arith(OPS[name], a, b)
+        got = [None if (extra is not None and not extra[i]) else int(vals[i]) for i in range(len(vals))]
+        assert got == exp, (name, got, exp)
+        # scalar forms must agree with the column form element by element
+        for i in range(len(a)):
+            v1, e1 = orc.arith(OPS[name], a[i:i + 1].copy(), b[i].item(), mode=1)
+            g1 = None if (e1 is not None and not e1[0]) else int(v1[0])
+            assert g1 == exp[i], (name, "col-scalar", i)
+
+
+# ---- independent cross-checks --------------------------------------------------------------------
+def test_float_sum_matches_numpy_pairwise_tolerance(orc):
+    rng = np.random.default_rng(0)
+    for n in [0, 1, 127, 128, 129, 1000, 4096, 100_003]:
+        x = rng.uniform(-1, 1, n) * 1e6
+        got, _ = orc.reduce(orc.AGG_SUM, x)
+        assert math.isclose(got, math.fsum(x), rel_tol=1e-9, abs_tol=1e-6)
+        v = rng.uniform(size=n) < 0.9
+        if n:
+            got, _ = orc.reduce(orc.AGG_SUM, x, v)
+            assert math.isclose(got, math.fsum(x[v]), rel_tol=1e-9, abs_tol=1e-6)
+
+
+def test_int_sums_wrap_and_upcast(orc):
+    rng = np.random.default_rng(1)
+    for dt in ["i8", "i16", "u8", "u16"]:
+        x = rng.integers(np.iinfo(kat.NP[dt]).min, np.iinfo(kat.NP[dt]).max, 10_000, dtype=kat.NP[dt])
+        got, odt = orc.reduce(orc.AGG_SUM, x)
+        assert odt == orc.I64 and got == int(x.astype(np.int64).sum())
+    x = np.array([2**62, 2**62, 2**62], dtype=np.int64)
+    got, odt = orc.reduce(orc.AGG_SUM, x)
+    assert odt == orc.I64 and got == ((3 * 2**62 + 2**63) % 2**64) - 2**63
+    xi = np.array([2**31 - 1, 1], dtype=np.int32)
+    got, odt = orc.reduce(orc.AGG_SUM, xi)
+    assert odt == orc.I32 and got == -2**31
+
+
+def test_groupby_matches_pandas(orc):
+    pd = pytest.importorskip("pandas")
+    rng = np.random.default_rng(2)
+    n = 20_000
+    key = rng.integers(0, 100, n).astype(np.int64)
+    v = rng.integers(-1000, 1000, n).astype(np.int64)
+    x = rng.uniform(0, 100, n)
+    xv = rng.uniform(size=n) > 0.05   # 5% nulls as in benchmark/conftest.py:7-9
+    for threads in (1, 4):
+        orc.set_threads(threads)
+        r = orc.q_groupby([key], [None], [("s", orc.AGG_SUM, v, None), ("c", orc.AGG_COUNT, x, xv), ("m", orc.AGG_MEAN, x, xv),
+                                          ("mn", orc.AGG_MIN, x, xv), ("mx", orc.AGG_MAX, v, None), ("n", orc.AGG_LEN, None, None)])
+        order = np.argsort(r["key_0"][0])
+        df = pd.DataFrame({"k": key, "v": v, "x": np.where(xv, x, np.nan)})
+        g = df.groupby("k")
+        assert np.array_equal(r["key_0"][0][order], np.array(sorted(g.groups.keys())))
+        assert np.array_equal(r["s"][0][order], g["v"].sum().to_numpy())
+        assert np.array_equal(r["c"][0][order], g["x"].count().to_numpy())
+        assert np.allclose(r["m"][0][order], g["x"].mean().to_numpy(), rtol=1e-12)
+        assert np.array_equal(r["mn"][0][order], g["x"].min().to_numpy())
+        assert np.array_equal(r["mx"][0][order], g["v"].max().to_numpy())
+        assert np.array_equal(r["n"][0][order], g.size().to_numpy())
+    orc.set_threads(1)
+
+
+def test_join_matches_pandas(orc):
+    """inner / left on one key vs pandas.merge after sorting (test_streaming_join.py:61-112)."""
+    pd = pytest.importorskip("pandas")
+    rng = np.random.default_rng(3)
+    lk = rng.integers(0, 500, 5000).astype(np.int64)
+    rk = rng.integers(0, 700, 3000).astype(np.int64)
+    for how, name in ((orc.JOIN_INNER, "inner"), (orc.JOIN_LEFT, "left")):
+        for threads in (1, 5):
+            orc.set_threads(threads)
+            li, ri, rv = orc.join(how, lk, None, rk, None)
+            got = sorted(zip(li.tolist(), [(-1 if (rv is not None and not ok) else int(r)) for r, ok in zip(ri, rv if rv is not None else np.ones(len(ri), bool))]))
+            m = pd.merge(pd.DataFrame({"k": lk, "li": np.arange(len(lk))}), pd.DataFrame({"k": rk, "ri": np.arange(len(rk))}), on="k", how=name)
+            exp = sorted(zip(m["li"].tolist(), m["ri"].fillna(-1).astype(int).tolist()))
+            assert got == exp
+    orc.set_threads(1)
+
+
+def test_hash_partition_is_stable_and_balanced(orc):
+    keys = np.arange(100_000, dtype=np.int64)
+    p = orc.hash_partition(keys, None, 8, seed=0)
+    assert p.max() == 7 and p.min() == 0
+    counts = np.bincount(p, minlength=8)
+    assert counts.min() > 100_000 / 8 * 0.9
+    valid = np.ones(len(keys), bool); valid[::7] = False
+    pn = orc.hash_partition(keys, valid, 8, seed=0)
+    assert (pn[::7] == 0).all() and np.array_equal(pn[valid], p[valid])   # nulls -> partition 0
