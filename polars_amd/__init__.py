@@ -6,7 +6,7 @@ engine) behind the C ABI of ``include/polars_amd.h``.  This package is the Pytho
 stand-in for the Rust host shim: a small mirror of the Polars LazyFrame / Expr API that
 lowers queries to the IR / AExpr arenas the ABI consumes.  There is no CPU fallback.
 """
-from . import _ffi
+from . import _ffi, plan
 from ._ffi import PlxError, UnsupportedError, init, last_plan
 from .datatypes import (Boolean, Categorical, DataType, Date, Datetime, Float32, Float64, Int8, Int16, Int32, Int64, UInt8,
                         UInt16, UInt32, UInt64)

@@ -234,6 +234,7 @@ class Compiler {
   std::map<std::string, int> memo;
   std::vector<std::pair<uint8_t, int>> aggs;  // (kind, src node or -1)
   int pred = -1, key = -1;
+  std::vector<int> wide_keys;  // raw key nodes of a wide (multi-word) group key
 
   int add(DNode n) {
     std::ostringstream k;
@@ -461,11 +462,14 @@ class Compiler {
     std::vector<int> roots;
     if (pred >= 0) roots.push_back(pred);
     if (key >= 0) roots.push_back(key);
+    for (int kn : wide_keys) roots.push_back(kn);
     for (auto& a : aggs) if (a.second >= 0) roots.push_back(a.second);
     for (int r : roots) count_uses(r, seen);   // each root reference holds its slot to the end
     shape.pred = kNone; shape.key = kNone;
     if (pred >= 0) shape.pred = (uint8_t)emit(pred);
     if (key >= 0) shape.key = (uint8_t)emit(key);
+    shape.n_keys = (uint8_t)wide_keys.size();
+    for (size_t i = 0; i < wide_keys.size(); i++) shape.keys[i] = (uint8_t)emit(wide_keys[i]);
     shape.n_aggs = (uint8_t)aggs.size();
     for (size_t i = 0; i < aggs.size(); i++) {
       shape.aggs[i].kind = aggs[i].first;
@@ -485,6 +489,9 @@ struct KeyPart {
 struct KeyPlan {
   std::vector<KeyPart> parts;
   bool packed = false;   // keys bit-packed into a dense id (always valid)
+  bool wide = false;     // 2..4 raw key columns compared word by word (WideAggSink)
+  bool wide_nullable = false;
+  std::vector<int> wide_nodes;
   int total_bits = 64;
 };
 
@@ -549,7 +556,23 @@ static KeyPlan lower_keys(Compiler& c, const std::vector<int>& key_exprs) {
     c.key = acc;
     return kp;
   }
-  if (nk != 1) throw Unsupported("multi-column group keys that do not pack into 62 bits need row encoding (polars-row), not on this path yet");
+  if (nk != 1) {
+    // wide key: the reference row-encodes (group_by/mod.rs:88-94); here each key column stays one
+    // 64-bit word (floats canonicalised) and the hash sink compares the words.
+    if (nk > kMaxKeys) throw Unsupported("more than " + std::to_string(kMaxKeys) + " group keys that do not bit-pack");
+    kp.wide = true; kp.packed = false; kp.total_bits = 64 * nk;
+    for (int i = 0; i < nk; i++) {
+      int n = knodes[i];
+      if (kp.parts[i].dtype == PLX_F64) n = c.mk(OP_CANON_F, n, n, 'f');
+      kp.wide_nodes.push_back(n);
+      kp.wide_nullable = kp.wide_nullable || c.nodes[n].nullable;
+      KeyDecode& d = kp.parts[i].dec;
+      d.shift = 0; d.mask = ~0ull; d.min = 0; d.null_code = ~0ull; d.dtype = kp.parts[i].dtype;
+    }
+    c.key = -1;
+    c.wide_keys = kp.wide_nodes;
+    return kp;
+  }
   int n = knodes[0];
   if (kp.parts[0].dtype == PLX_F64) n = c.mk(OP_CANON_F, n, n, 'f');
   c.key = n;
@@ -565,6 +588,9 @@ struct FusedAggResult {
   Buf acc;            // [n_groups][n_aggs] cells
   Buf packed_keys;    // [n_groups] u64 (group-by only)
   Buf key_valid;      // [n_groups] u8 flags (raw keys) or null
+  Buf wide_words;     // wide keys: [n_keys][stride] u64
+  Buf wide_valid;     // wide keys: [n_keys][stride] u8
+  int64_t wide_stride = 0;
   int n_aggs = 0;
 };
 
@@ -600,6 +626,33 @@ static int64_t run_hash_agg(const Shape& sh, const Args& args, int static_id, in
   out.acc = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1) * sh.n_aggs);
   k::table_compact(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, out.packed_keys->as<uint64_t>(), out.key_valid->as<uint8_t>(), out.acc->as<uint64_t>());
   (void)len_idx;
+  return g;
+}
+
+static int64_t run_wide_agg(const Shape& sh, const Args& args, int log2_cap, bool nullable, FusedAggResult& out, bool count_only) {
+  const uint64_t cap = 1ull << log2_cap;
+  const int nw = sh.n_keys + (nullable ? 1 : 0);
+  Buf tags = dev_alloc(sizeof(uint64_t) * cap);
+  Buf words = dev_alloc(sizeof(uint64_t) * cap * (size_t)nw);
+  Buf acc = dev_alloc(sizeof(uint64_t) * cap * sh.n_aggs);
+  Buf ovf = dev_alloc_zero(8);
+  k::fill_u64(tags->as<uint64_t>(), (int64_t)cap, kEmptyKey);
+  k::init_agg_cells(acc->as<uint64_t>(), (int64_t)cap, sh);
+  WideTable t; t.tags = tags->as<unsigned long long>(); t.words = words->as<unsigned long long>(); t.acc = acc->as<unsigned long long>();
+  t.overflow = ovf->as<unsigned int>(); t.log2_cap = (uint32_t)log2_cap; t.max_probe = (uint32_t)std::min<uint64_t>(cap, 1u << 14);
+  t.n_words = (uint32_t)nw; t.has_null_word = nullable ? 1u : 0u;
+  k::fused_wide_agg(sh, args, t);
+  uint32_t o = 0; d2h_sync(&o, ovf->ptr, 4);
+  if (o) return -1;
+  int64_t g = k::wide_compact(t, sh.n_keys, sh.n_aggs, 0, nullptr, nullptr, nullptr);
+  if (count_only) return g;
+  out.n_groups = g; out.n_aggs = sh.n_aggs;
+  const int64_t stride = std::max<int64_t>(g, 1);
+  out.wide_stride = stride;
+  out.wide_words = dev_alloc(sizeof(uint64_t) * (size_t)stride * sh.n_keys);
+  out.wide_valid = dev_alloc((size_t)stride * sh.n_keys);
+  out.acc = dev_alloc(sizeof(uint64_t) * (size_t)stride * sh.n_aggs);
+  k::wide_compact(t, sh.n_keys, sh.n_aggs, stride, out.wide_words->as<uint64_t>(), out.wide_valid->as<uint8_t>(), out.acc->as<uint64_t>());
   return g;
 }
 
@@ -647,16 +700,16 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
   else {
     Args sa = args; sa.n_rows = S;
     FusedAggResult tmp;
-    int64_t d = run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true);
+    int64_t d = kp.wide ? run_wide_agg(sh, sa, 23, kp.wide_nullable, tmp, true) : run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true);
     double G = d < 0 ? 1e18 : estimate_groups((double)d, (double)S);
     G = std::min(G, (double)n);
     log2_cap = std::max(12, ceil_log2_u64((uint64_t)(G * 2.0) + 1));
     desc += "sample(distinct=" + std::to_string(d) + "/" + std::to_string(S) + ")+";
   }
   for (int attempt = 0; attempt < 8; attempt++) {
-    int64_t g = run_hash_agg(sh, args, static_id, log2_cap, len_idx, res, false);
+    int64_t g = kp.wide ? run_wide_agg(sh, args, log2_cap, kp.wide_nullable, res, false) : run_hash_agg(sh, args, static_id, log2_cap, len_idx, res, false);
     if (g >= 0) {
-      desc += std::string("fused_scan[") + (static_id >= 0 ? "aot" : "generic") + "]+hash_hbm_table(cap=2^" + std::to_string(log2_cap) + ")";
+      desc += std::string("fused_scan[") + (static_id >= 0 && !kp.wide ? "aot" : "generic") + "]+" + (kp.wide ? "wide_hash_hbm_table(words=" + std::to_string(sh.n_keys + (kp.wide_nullable ? 1 : 0)) + ",cap=2^" : "hash_hbm_table(cap=2^") + std::to_string(log2_cap) + ")";
       return;
     }
     log2_cap += 2;
@@ -679,7 +732,7 @@ static ColumnPtr finalize_column(const FusedAggResult& r, const FinalSpec& fs) {
   return out;
 }
 
-static ColumnPtr decode_key_column(const FusedAggResult& r, const KeyPart& part) {
+static ColumnPtr decode_key_column(const FusedAggResult& r, const KeyPart& part, int key_index) {
   const int64_t G = r.n_groups;
   auto out = std::make_shared<Column>();
   out->dtype = part.dtype; out->len = G;
@@ -687,7 +740,11 @@ static ColumnPtr decode_key_column(const FusedAggResult& r, const KeyPart& part)
   out->validity = dev_alloc_zero(bitmap_bytes(G));
   KeyDecode kd = part.dec;
   if (part.dtype == PLX_F32) kd.dtype = PLX_F32;
-  k::decode_key(r.packed_keys->as<uint64_t>(), r.key_valid ? r.key_valid->as<uint8_t>() : nullptr, G, kd, out->values->ptr, out->validity->as<uint64_t>());
+  if (r.wide_words)
+    k::decode_key(r.wide_words->as<uint64_t>() + (size_t)key_index * r.wide_stride, r.wide_valid->as<uint8_t>() + (size_t)key_index * r.wide_stride, G, kd,
+                  out->values->ptr, out->validity->as<uint64_t>());
+  else
+    k::decode_key(r.packed_keys->as<uint64_t>(), r.key_valid ? r.key_valid->as<uint8_t>() : nullptr, G, kd, out->values->ptr, out->validity->as<uint64_t>());
   if (column_null_count(out) == 0) { out->validity = nullptr; out->null_count = 0; }
   return out;
 }
@@ -772,7 +829,7 @@ static bool fused_groupby(Plan& plan, const IRN& node, const std::vector<int>& p
   plan.desc += "FusedFilterGroupBy{" + d + ", inputs=" + std::to_string(c.shape.n_inputs) + ", ops=" + std::to_string(c.shape.n_ops) + ", aggs=" + std::to_string(c.shape.n_aggs) + ", groups=" + std::to_string(r.n_groups) + "}; ";
   out = std::make_shared<Frame>();
   out->height = r.n_groups;
-  for (auto& part : kp.parts) { out->names.push_back(output_name(plan, part.expr)); out->cols.push_back(decode_key_column(r, part)); }
+  for (size_t pi = 0; pi < kp.parts.size(); pi++) { out->names.push_back(output_name(plan, kp.parts[pi].expr)); out->cols.push_back(decode_key_column(r, kp.parts[pi], (int)pi)); }
   std::map<int, ColumnPtr> overrides;
   for (size_t i = 0; i < agg_nodes.size(); i++) overrides[agg_nodes[i]] = finalize_column(r, specs[i]);
   Frame gframe; gframe.height = r.n_groups;

@@ -23,7 +23,8 @@ namespace fused {
 constexpr int kMaxInputs = 10;
 constexpr int kMaxOps = 32;
 constexpr int kSlots = 16;
-constexpr int kMaxAggs = 8;
+constexpr int kMaxAggs = 16;
+constexpr int kMaxKeys = 4;          // columns of a wide (unpackable) group key
 constexpr int kRows = 2;            // rows per lane per tile (one 16-B load of an 8-B column)
 constexpr int kTileRows = 64 * kRows;
 constexpr uint8_t kNone = 255;
@@ -65,6 +66,9 @@ struct Agg {
 // pointers and sizes are runtime).
 struct Shape {
   uint8_t n_inputs, n_ops, n_aggs, pred, key;  // pred/key: slot or kNone
+  // wide group key: n_keys >= 2 raw key slots (value + validity), compared word by word by the
+  // multi-word hash sink; 0 when the key is a single slot (`key`).
+  uint8_t n_keys, keys[kMaxKeys];
   uint8_t in_dtype[kMaxInputs];                // plx_dtype
   uint8_t in_nullable[kMaxInputs];
   Op ops[kMaxOps];
@@ -132,6 +136,23 @@ struct HashTable {
   unsigned int* overflow;  // set when a probe sequence exceeds max_probe
   uint32_t log2_cap;
   uint32_t max_probe;
+};
+
+// Wide-key hash aggregation table (group keys that do not pack into one 64-bit word; the
+// reference row-encodes them: group_by/mod.rs:88-94).  Open addressing on a 63-bit tag of all
+// key words; a slot goes EMPTY -> tag|BUSY (claimed by CAS) -> tag (key words published):
+//   tags[cap], words[n_words][cap] (word j of slot s at words[j*cap + s]; the last word is the
+//   null mask when any key column is nullable), acc[cap * n_aggs].
+constexpr uint64_t kBusyBit = 1ull << 63;
+struct WideTable {
+  unsigned long long* tags;
+  unsigned long long* words;
+  unsigned long long* acc;
+  unsigned int* overflow;
+  uint32_t log2_cap;
+  uint32_t max_probe;
+  uint32_t n_words;      // n_keys (+1 when has_null_word)
+  uint32_t has_null_word;
 };
 
 // Direct-address aggregation (dense keys in [key_min, key_min + n_groups)): acc[(G+1)*n_aggs],

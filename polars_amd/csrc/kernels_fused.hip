@@ -480,6 +480,83 @@ struct HashAggSink {
   }
 };
 
+
+// ---- sink: wide-key open-addressing table (keys of 2..4 columns that do not bit-pack) ----------
+// Slot protocol: tags[s] goes EMPTY -> tag|BUSY (64-bit CAS) -> tag.  The claimer writes the key
+// words with write-through (agent-scope) stores, drains them, then publishes the tag; readers
+// load tag and words at agent scope (L2-served, never a stale L1 line).  Within one loop
+// iteration the claim+publish code precedes the wait, so a lane never waits on a lane of its
+// own wave that has not published yet; owners in other waves make progress independently.
+struct WideAggSink {
+  using Params = WideTable;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  __device__ __forceinline__ static uint64_t ld(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ static void st(unsigned long long* p, uint64_t v) { __hip_atomic_store(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ static uint64_t mix(uint64_t h, uint64_t w) {
+    h ^= w; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; return h;
+  }
+  __device__ __forceinline__ static int64_t find_or_insert(const Params& p, const uint64_t w[kMaxKeys + 1]) {
+    const uint64_t cap = 1ull << p.log2_cap;
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+    for (uint32_t j = 0; j < p.n_words; j++) h = mix(h, w[j]);
+    h *= 0x55fbfd6bfc5458e9ull;
+    uint64_t tag = h & ~kBusyBit;
+    if (tag == (kEmptyKey & ~kBusyBit)) tag ^= 1;
+    uint64_t slot = h >> (64 - p.log2_cap);
+    int64_t found = -1;
+    for (uint32_t probe = 0; probe < p.max_probe && found < 0; probe++) {
+      uint64_t cur = ld(&p.tags[slot]);
+      bool claimed = false;
+      if (cur == kEmptyKey) {
+        const unsigned long long old = atomicCAS(&p.tags[slot], (unsigned long long)kEmptyKey, (unsigned long long)(tag | kBusyBit));
+        if (old == kEmptyKey) claimed = true; else cur = old;
+      }
+      if (claimed) {  // publish: words (write-through) -> drain -> tag
+        for (uint32_t j = 0; j < p.n_words; j++) st(&p.words[(size_t)j * cap + slot], w[j]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st(&p.tags[slot], tag);
+        found = (int64_t)slot;
+      }
+      // every lane of the wave is past the publish before any lane starts to wait (convergent
+      // marker: the two branches cannot be merged into an if/else whose else side runs first)
+      __builtin_amdgcn_wave_barrier();
+      if (!claimed && (cur & ~kBusyBit) == tag) {
+        while (cur & kBusyBit) { __builtin_amdgcn_s_sleep(1); cur = ld(&p.tags[slot]); }
+        asm volatile("" ::: "memory");
+        bool same = true;
+        for (uint32_t j = 0; j < p.n_words; j++) same = same && (ld(&p.words[(size_t)j * cap + slot]) == w[j]);
+        if (same) found = (int64_t)slot;
+      }
+      slot = (slot + 1) & (cap - 1);
+    }
+    if (found < 0) atomicExch(p.overflow, 1u);
+    return found;
+  }
+  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r]) continue;
+      uint64_t w[kMaxKeys + 1];
+      uint64_t nullmask = 0;
+#pragma unroll
+      for (int j = 0; j < kMaxKeys; j++) {
+        w[j] = 0;
+        if (j < sh.n_keys) {
+          const bool kvalid = (rf.valid[sh.keys[j]] >> r) & 1;
+          w[j] = kvalid ? rf.v[r][sh.keys[j]] : 0ull;
+          if (!kvalid) nullmask |= 1ull << j;
+        }
+      }
+      w[kMaxKeys] = 0;
+      if (p.has_null_word) w[sh.n_keys] = nullmask;
+      const int64_t slot = find_or_insert(p, w);
+      if (slot < 0) continue;
+      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
+    }
+  }
+};
+
 // ---- the scan kernels ------------------------------------------------------------------
 template <class P>
 __device__ __forceinline__ bool tile_rows(const Shape& dsh, const Args& args, int64_t tile, RegFile& rf, bool pass[kRows], int64_t& row0) {
@@ -654,6 +731,50 @@ void fused_hash_agg(const Shape& sh, const Args& args, const HashTable& t, int s
     default: hipLaunchKernelGGL((fused_scan_kernel<DynProg, HashAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
   }
   PLX_HIP(hipGetLastError());
+}
+
+
+void fused_wide_agg(const Shape& sh, const Args& args, const WideTable& t) {
+  if (args.n_rows == 0) return;
+  ProfileScope ps("fused_scan_wideagg", algo_bytes(sh, args), (uint64_t)args.n_rows);
+  const int grid = scan_grid(args.n_rows, 8);
+  hipLaunchKernelGGL((fused_scan_kernel<DynProg, WideAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t);
+  PLX_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void wide_compact_kernel(WideTable t, int n_keys, int n_aggs, int64_t out_stride, unsigned long long* __restrict__ counter,
+                                                              unsigned long long* __restrict__ out_words, unsigned char* __restrict__ out_kvalid,
+                                                              unsigned long long* __restrict__ out_acc) {
+  const int lane = lane_id();
+  const int64_t cap = (int64_t)1 << t.log2_cap;
+  for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < cap; base += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = base + lane;
+    const bool occ = s < cap && t.tags[s] != kEmptyKey;
+    const uint64_t m = ballot(occ);
+    if (m == 0) continue;
+    unsigned long long o = 0;
+    if (lane == 0) o = atomicAdd(counter, (unsigned long long)popc64(m));
+    o = shfl_u64(o, 0) + (uint64_t)prefix_rank(m);
+    if (occ && out_words) {
+      const uint64_t nullmask = t.has_null_word ? t.words[(size_t)n_keys * cap + s] : 0ull;
+      for (int j = 0; j < n_keys; j++) {
+        out_words[(size_t)j * out_stride + o] = t.words[(size_t)j * cap + s];
+        out_kvalid[(size_t)j * out_stride + o] = (unsigned char)(((nullmask >> j) & 1) ^ 1);
+      }
+      for (int k = 0; k < n_aggs; k++) out_acc[o * n_aggs + k] = t.acc[(size_t)s * n_aggs + k];
+    }
+  }
+}
+int64_t wide_compact(const WideTable& t, int n_keys, int n_aggs, int64_t out_stride, uint64_t* out_words, uint8_t* out_kvalid, uint64_t* out_acc) {
+  Buf counter = dev_alloc_zero(8);
+  const int64_t cap = (int64_t)1 << t.log2_cap;
+  ProfileScope ps("table_compact", (uint64_t)cap * 8 * (uint64_t)(1 + n_keys + n_aggs), (uint64_t)cap);
+  hipLaunchKernelGGL(wide_compact_kernel, dim3(grid_for(cap, kBlock * 2)), dim3(kBlock), 0, stream(), t, n_keys, n_aggs, out_stride,
+                     counter->as<unsigned long long>(), (unsigned long long*)out_words, (unsigned char*)out_kvalid, (unsigned long long*)out_acc);
+  PLX_HIP(hipGetLastError());
+  uint64_t n = 0;
+  d2h_sync(&n, counter->ptr, 8);
+  return (int64_t)n;
 }
 
 // ---- table compaction: occupied slots -> dense output ----------------------------------

@@ -20,6 +20,10 @@ void fused_lds_agg(const fused::Shape& sh, const fused::Args& args, int n_groups
 // fill_u64(keys, cap + 2, kEmptyKey) / init_agg_cells(acc, slots, sh).
 void fused_dense_agg(const fused::Shape& sh, const fused::Args& args, const fused::DenseTable& t, int static_id);
 void fused_hash_agg(const fused::Shape& sh, const fused::Args& args, const fused::HashTable& t, int static_id);
+void fused_wide_agg(const fused::Shape& sh, const fused::Args& args, const fused::WideTable& t);
+// occupied slots of a wide table -> out_words[n_keys][G] (u64 each), out_kvalid[n_keys][G] (u8), out_acc[G][n_aggs];
+// nullptr outputs = count only.  Returns the group count (synchronises).
+int64_t wide_compact(const fused::WideTable& t, int n_keys, int n_aggs, int64_t out_stride, uint64_t* out_words, uint8_t* out_kvalid, uint64_t* out_acc);
 void fill_u64(uint64_t* p, int64_t n, uint64_t v);
 void init_agg_cells(uint64_t* acc, int64_t n_slots, const fused::Shape& sh);
 // Gather occupied table slots into dense arrays; returns the group count (synchronises).

@@ -37,8 +37,8 @@ def sum_dtype(dt: T.DataType) -> T.DataType:
 
 
 class Lowering:
-    """Builds the arenas. ``aexprs`` / ``irs`` are lists of plain dicts (also consumed by
-    the CPU oracle interpreter in oracle/engine.py); ``to_c`` marshals them."""
+    """Builds the arenas. ``aexprs`` / ``irs`` are lists of plain dicts; ``to_c`` marshals
+    them into the plx_aexpr / plx_ir structs of include/polars_amd.h."""
 
     def __init__(self):
         self.aexprs: List[dict] = []

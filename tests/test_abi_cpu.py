@@ -1,0 +1,81 @@
+"""CPU-only checks of the drop-in boundary: libpolars_amd.so loads, exports every symbol
+include/polars_amd.h declares (and the ctypes table binds exactly that set), reports the plugin
+ABI version of the reference (polars-ffi/src/lib.rs:12-13 -> (0, 1)), and fails LOUDLY -- status
+code + last-error string, no crash, no CPU fallback -- when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "polars_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(plx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from polars_amd import _ffi
+    lib = _ffi.lib()
+    syms = header_symbols()
+    assert len(syms) >= 40
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/polars_amd.h but not exported"
+    assert sorted(_ffi.SIGNATURES) == syms, "ctypes binding and header disagree"
+
+
+def test_version_matches_reference_plugin_abi():
+    from polars_amd import _ffi
+    v = _ffi.lib().plx_version()
+    assert (v >> 16, v & 0xFFFF) == (0, 1)
+
+
+def test_no_gpu_fails_loudly_not_silently():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from polars_amd import _ffi
+    lib = _ffi.lib()
+    rc = lib.plx_init(0)
+    assert rc == 2                                   # PLX_ERR_HIP
+    assert b"no HIP device" in lib.plx_last_error()
+    import numpy as np
+    h = C.c_uint64()
+    a = np.arange(4, dtype=np.int64)
+    rc = lib.plx_column_from_host(_ffi.I64, a.ctypes.data_as(C.c_void_p), None, 0, 4, C.byref(h))
+    assert rc == 2 and b"plx_init" in lib.plx_last_error()
+    import polars_amd as pl
+    with pytest.raises(pl.PlxError):
+        pl.Series("a", a)                            # the python mirror has no fallback either
+
+
+def test_placeholder_columns_reject_compute():
+    from polars_amd import _ffi as F
+    lib = F.lib()
+    h = C.c_uint64()
+    assert lib.plx_column_placeholder(F.I64, 100, 0, 0, 0, 0, C.byref(h)) == 0
+    dt, n, nulls = C.c_int32(), C.c_int64(), C.c_int64()
+    assert lib.plx_column_info(h.value, C.byref(dt), C.byref(n), C.byref(nulls)) == 0
+    assert (dt.value, n.value, nulls.value) == (F.I64, 100, 0)
+    out = C.c_uint64()
+    s = F.Scalar(); s.i = 1
+    assert lib.plx_cmp_scalar(F.GT, h.value, s, C.byref(out)) != 0
+    assert lib.plx_column_free(h.value) == 0
+    assert lib.plx_column_free(h.value) == 1 and b"invalid column handle" in lib.plx_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under polars_amd/ may reference it."""
+    bad = []
+    for d, _, files in os.walk(os.path.join(ROOT, "polars_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(d, f), errors="replace").read()
+                if re.search(r"\boracle\b|pyoracle|plx_oracle|orc_", txt) and not f.endswith("dist.py"):
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad
+    txt = open(os.path.join(ROOT, "polars_amd", "dist.py")).read()
+    assert "import oracle" not in txt and "pyoracle" not in txt

@@ -128,8 +128,11 @@ def test_total_ordering_floats(pl):
 
 def test_filter_sweep(pl):
     case = kat.load_cases("filter_sweep")[0]
-    for dt in case["dtypes"]:
+    for di, dt in enumerate(case["dtypes"]):
         for size in case["sizes"]:
+            # every size for i64 / bool; a strided subset for the other widths (same kernel template family)
+            if dt not in ("i64", "bool") and size % 8 != (di % 8) and size < 64:
+                continue
             for sel in case["selectivities"]:
                 p, m, exp = kat.filter_sweep_inputs(dt, size, sel)
                 s = pl.Series("p", p, dtype=pl.Boolean if dt == "bool" else getattr(pl, PLDT[dt]))
