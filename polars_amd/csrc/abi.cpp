@@ -346,15 +346,8 @@ int plx_describe_fusion(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, 
                         char* why_not, size_t why_cap) {
   PLX_TRY
   engine::Plan p = engine::import_plan(ir, n_ir, exprs, n_exprs, 0);
-  fused::Shape sh{};
-  int sid = -1;
-  std::string why;
-  bool ok = engine::describe_fusion(p, root, &sh, &sid, &why);
-  if (fusable) *fusable = ok ? 1 : 0;
-  if (static_shape_id) *static_shape_id = sid;
-  if (why_not && why_cap) snprintf(why_not, why_cap, "%s", why.c_str());
-  if (ok) {
-    // dump the program so a mismatch with fused_shapes.hpp is easy to repair
+  // dump of one program, so a mismatch with fused_shapes.hpp is easy to repair
+  auto dump = [](const fused::Shape& sh) {
     std::string d = "inputs=" + std::to_string(sh.n_inputs) + " pred=" + std::to_string(sh.pred) + " key=" + std::to_string(sh.key) + " ops=[";
     for (int i = 0; i < sh.n_ops; i++) d += "(" + std::to_string(sh.ops[i].code) + "," + std::to_string(sh.ops[i].dst) + "," + std::to_string(sh.ops[i].a) + "," + std::to_string(sh.ops[i].b) + "," + std::to_string(sh.ops[i].c) + ")";
     d += "] aggs=[";
@@ -362,8 +355,26 @@ int plx_describe_fusion(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, 
     d += "] in_dtype=[";
     for (int i = 0; i < sh.n_inputs; i++) d += std::to_string(sh.in_dtype[i]) + (sh.in_nullable[i] ? "?" : "") + ",";
     d += "]";
-    t_plan_desc = d;
+    return d;
+  };
+  std::string why;
+  int sid = -1;
+  bool ok;
+  PLX_REQUIRE(root >= 0 && root < (int)p.ir.size(), PLX_ERR_INVALID, "bad root");
+  const engine::IRN& rn = p.ir[root];
+  if (rn.kind == PLX_IR_GROUPBY && rn.input >= 0 && p.ir[rn.input].kind == PLX_IR_JOIN) {
+    // fused join -> aggregate: three programs (count, build, probe), one per line; the id is the probe program's
+    std::vector<fused::Shape> shapes;
+    ok = engine::describe_join_fusion(p, root, &shapes, &why);
+    if (ok) { sid = fused::find_static_shape(shapes[2]); t_plan_desc = dump(shapes[0]) + "\n" + dump(shapes[1]) + "\n" + dump(shapes[2]); }
+  } else {
+    fused::Shape sh{};
+    ok = engine::describe_fusion(p, root, &sh, &sid, &why);
+    if (ok) t_plan_desc = dump(sh);
   }
+  if (fusable) *fusable = ok ? 1 : 0;
+  if (static_shape_id) *static_shape_id = sid;
+  if (why_not && why_cap) snprintf(why_not, why_cap, "%s", why.c_str());
   PLX_CATCH
 }
 

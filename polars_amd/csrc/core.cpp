@@ -76,19 +76,29 @@ DevBuf::~DevBuf() {
   if (!owned || !ptr) return;
   std::lock_guard<std::mutex> lk(g_pool.mu);
   g_pool.in_use -= cap;
-  if (cap >= (size_t(1) << 30)) { (void)hipStreamSynchronize(stream()); (void)hipFree(ptr); }
-  else { g_pool.free_blocks.emplace(cap, ptr); g_pool.cached += cap; }
+  // Every block is cached, multi-GB ones included: hipMalloc / hipFree of a filtered SF100 column
+  // costs tens of milliseconds (page-table work + an implicit device sync), far more than the
+  // kernels that fill it, and 288 GB of HBM leaves room.  dev_alloc trims the cache on OOM and
+  // when it grows past half of the device memory.
+  g_pool.free_blocks.emplace(cap, ptr);
+  g_pool.cached += cap;
 }
 
 Buf dev_alloc(size_t bytes) {
-  device();
+  Device& dev = device();
   size_t cap = size_class(bytes);
   void* p = nullptr;
+  bool over = false;
   {
     std::lock_guard<std::mutex> lk(g_pool.mu);
-    auto it = g_pool.free_blocks.find(cap);
-    if (it != g_pool.free_blocks.end()) { p = it->second; g_pool.free_blocks.erase(it); g_pool.cached -= cap; }
+    auto it = g_pool.free_blocks.lower_bound(cap);
+    // exact class below 2 MiB; best fit within +25% above (large blocks rarely repeat their exact size)
+    if (it != g_pool.free_blocks.end() && (it->first == cap || (cap > (size_t(1) << 21) && it->first <= cap + cap / 4))) {
+      p = it->second; cap = it->first; g_pool.free_blocks.erase(it); g_pool.cached -= cap;
+    }
+    over = g_pool.cached > dev.hbm_bytes / 2;
   }
+  if (over) pool_trim();
   if (!p) {
     hipError_t e = hipMalloc(&p, cap);
     if (e != hipSuccess) {

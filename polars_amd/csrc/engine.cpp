@@ -227,9 +227,11 @@ struct DNode {
 
 class Compiler {
  public:
-  Compiler(const Plan& p, const Frame& f) : plan(p), df(f) {}
+  Compiler(const Plan& p, const Frame& f) : plan(p), df(&f), n_rows(f.height) {}
   const Plan& plan;
-  const Frame& df;
+  const Frame* df;               // name resolution / dtype inference scope (may be switched to a view of the same rows)
+  int64_t n_rows;
+  std::vector<ColumnPtr> cols;   // distinct input columns referenced so far
   std::vector<DNode> nodes;
   std::map<std::string, int> memo;
   std::vector<std::pair<uint8_t, int>> aggs;  // (kind, src node or -1)
@@ -253,8 +255,14 @@ class Compiler {
   int konst(uint64_t bits, char ty) { DNode n; n.code = OP_CONST; n.imm = bits; n.ty = ty; return add(n); }
   int konst_f(double d) { uint64_t b; memcpy(&b, &d, 8); return konst(b, 'f'); }
   int ifnull(int a, uint64_t code) { DNode n; n.code = OP_IFNULL; n.a = a; n.b = a; n.imm = code; n.ty = nodes[a].ty; n.nullable = false; return add(n); }
-  int load(int col) {
-    const ColumnPtr& c = df.cols[col];
+  int col_id(const ColumnPtr& c) {
+    for (size_t i = 0; i < cols.size(); i++) if (cols[i].get() == c.get()) return (int)i;
+    cols.push_back(c);
+    return (int)cols.size() - 1;
+  }
+  int load(int frame_col) {
+    const ColumnPtr& c = df->cols[frame_col];
+    const int col = col_id(c);
     DNode n; n.code = OP_LOAD; n.col = col; n.nullable = (bool)c->validity || c->null_count > 0;
     switch (c->dtype) {
       case PLX_F64: n.ty = 'f'; break;
@@ -295,7 +303,7 @@ class Compiler {
     const AE& x = plan.ae.at(e);
     switch (x.kind) {
       case PLX_AE_COLUMN: {
-        int i = df.find(x.name);
+        int i = df->find(x.name);
         if (i < 0) fail(PLX_ERR_NOT_FOUND, "column not found: " + x.name);
         return load(i);
       }
@@ -308,7 +316,7 @@ class Compiler {
       case PLX_AE_ALIAS: return lower(x.lhs);
       case PLX_AE_NOT: { int a = lower(x.lhs); if (nodes[a].ty != 'b') throw Unsupported("not on non-boolean"); return mk(OP_NOT, a, a, 'b'); }
       case PLX_AE_CAST: {
-        int from = infer_dtype(plan, x.lhs, df), to = x.dtype;
+        int from = infer_dtype(plan, x.lhs, *df), to = x.dtype;
         int a = lower(x.lhs);
         if (from == to) return a;
         if (to == PLX_F64 && dtype_is_int(from)) return mk(nodes[a].ty == 'u' ? OP_U2F : OP_I2F, a, a, 'f');
@@ -317,7 +325,7 @@ class Compiler {
         throw Unsupported(std::string("cast ") + dtype_name(from) + " -> " + dtype_name(to) + " inside a fused program");
       }
       case PLX_AE_BINARY: {
-        int ldt = infer_dtype(plan, x.lhs, df), rdt = infer_dtype(plan, x.rhs, df);
+        int ldt = infer_dtype(plan, x.lhs, *df), rdt = infer_dtype(plan, x.rhs, *df);
         if (is_logic_op(x.op)) {
           int a = lower(x.lhs), b = lower(x.rhs);
           if (nodes[a].ty != 'b' || nodes[b].ty != 'b') throw Unsupported("bitwise and/or on integers");
@@ -350,7 +358,16 @@ class Compiler {
             if (!f) b = mk(nodes[b].ty == 'u' ? OP_U2F : OP_I2F, b, b, 'f');
             return mk(OP_DIV_F, a, b, 'f');
           }
-          default: throw Unsupported("floor-div / mod inside a fused program");
+          case PLX_OP_FLOOR_DIVIDE: case PLX_OP_MODULUS: {
+            if (f) throw Unsupported("float floor-div / mod inside a fused program");
+            int a = lower(x.lhs), b = lower(x.rhs);
+            const bool u = nodes[a].ty == 'u';
+            const uint8_t code = x.op == PLX_OP_FLOOR_DIVIDE ? (u ? OP_FDIV_U : OP_FDIV_I) : (u ? OP_MOD_U : OP_MOD_I);
+            int n = mk(code, a, b, nodes[a].ty);
+            nodes[n].nullable = true;   // divisor 0 -> null (signed.rs:35-70)
+            return n;
+          }
+          default: throw Unsupported("operator inside a fused program");
         }
       }
       default: throw Unsupported("aggregation nested inside a row expression");
@@ -370,7 +387,7 @@ class Compiler {
     const AE& x = plan.ae.at(e);
     FinalSpec fs{}; fs.a = fs.b = fs.c = kNone;
     if (x.kind == PLX_AE_LEN) { fs.kind = FIN_TRUNC32; fs.a = (uint8_t)add_agg(AGG_LEN, -1); fs.out_dtype = PLX_U32; return fs; }
-    const int in_dt = infer_dtype(plan, x.lhs, df);
+    const int in_dt = infer_dtype(plan, x.lhs, *df);
     if (x.op == PLX_AGG_LEN) { fs.kind = FIN_TRUNC32; fs.a = (uint8_t)add_agg(AGG_LEN, -1); fs.out_dtype = PLX_U32; return fs; }
     if (in_dt == PLX_BOOL && x.op != PLX_AGG_COUNT) throw Unsupported("aggregating a boolean expression");
     int src = lower(x.lhs);
@@ -442,7 +459,7 @@ class Compiler {
       if (idx < 0) {
         if ((int)input_cols.size() >= kMaxInputs) throw Unsupported("more than 10 input columns");
         input_cols.push_back(d.col); idx = (int)input_cols.size() - 1;
-        const ColumnPtr& c = df.cols[d.col];
+        const ColumnPtr& c = cols[d.col];
         shape.in_dtype[idx] = (uint8_t)c->dtype; shape.in_nullable[idx] = d.nullable ? 1 : 0;
         args.in[idx].values = c->data(); args.in[idx].validity = c->valid_words();
       }
@@ -476,7 +493,7 @@ class Compiler {
       shape.aggs[i].src = aggs[i].second >= 0 ? (uint8_t)emit(aggs[i].second) : 0;
     }
     shape.n_inputs = (uint8_t)input_cols.size();
-    args.n_rows = df.height;
+    args.n_rows = n_rows;
   }
 };
 
@@ -509,14 +526,14 @@ static KeyPlan lower_keys(Compiler& c, const std::vector<int>& key_exprs) {
   bool all_packable = true;
   for (int i = 0; i < nk; i++) {
     const int e = key_exprs[i];
-    KeyPart part; part.expr = e; part.dtype = infer_dtype(plan, e, c.df);
+    KeyPart part; part.expr = e; part.dtype = infer_dtype(plan, e, *c.df);
     knodes[i] = c.lower(e);
     info[i].nullable = c.nodes[knodes[i]].nullable;
     const AE* x = &plan.ae[e];
     while (x->kind == PLX_AE_ALIAS) x = &plan.ae[x->lhs];
     if (part.dtype == PLX_BOOL) { info[i].have_range = true; info[i].mn = 0; info[i].mx = 1; }
     else if (dtype_is_int(part.dtype) && x->kind == PLX_AE_COLUMN) {
-      ColumnPtr col = c.df.cols[c.df.find(x->name)];
+      ColumnPtr col = c.df->cols[c.df->find(x->name)];
       const bool cheap = dtype_width(part.dtype) <= 2 || nk > 1 || col->range_state != 0;
       if (part.dtype == PLX_U64) all_packable = false;
       else if (cheap) {
@@ -845,6 +862,166 @@ static bool fused_groupby(Plan& plan, const IRN& node, const std::vector<int>& p
   return true;
 }
 
+
+// peel [Filter]* below an aggregation node
+static int peel_filters(const Plan& plan, int input, std::vector<int>& preds) {
+  while (plan.ir[input].kind == PLX_IR_FILTER) { preds.push_back(plan.ir[input].predicate); input = plan.ir[input].input; }
+  std::reverse(preds.begin(), preds.end());
+  return input;
+}
+
+// ------------------------------------------------ fused Join -> GroupBy pipeline ----
+// GroupBy(keys, aggs) directly over an inner Join of two ([Filter]* Scan) inputs, when
+//   * the join has one plain-column integer key pair,
+//   * the group keys are the join key plus plain columns of the BUILD side (the shorter input,
+//     hash_join/mod.rs:41-50), so a group is one build row,
+//   * every aggregate reads PROBE-side columns only,
+//   * the build keys that survive the build-side predicate are unique (checked at run time).
+// TPC-H Q3 has this shape.  Pipeline: count build rows -> build scan (predicate fused) -> probe scan
+// (predicate + expressions fused, aggregates land in the matching slot) -> compact -> gather the
+// build-side key columns.  Anything else returns false and the caller runs the per-node path.
+static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::string* why, std::vector<Shape>* shapes_out = nullptr, bool compile_only = false) {
+  auto no = [&](const char* m) { if (why) *why = m; return false; };
+  if (gb.input < 0 || plan.ir[gb.input].kind != PLX_IR_JOIN) return no("input is not a join");
+  const IRN& jn = plan.ir[gb.input];
+  if (jn.how != PLX_JOIN_INNER || jn.keys.size() != 1 || jn.keys_right.size() != 1) return no("not a single-key inner join");
+  if (gb.maintain_order) return no("maintain_order");
+  auto plain = [&](int e) -> const AE* { const AE* x = &plan.ae[e]; while (x->kind == PLX_AE_ALIAS) x = &plan.ae[x->lhs]; return x->kind == PLX_AE_COLUMN ? x : nullptr; };
+  const AE* lkx = plain(jn.keys[0]);
+  const AE* rkx = plain(jn.keys_right[0]);
+  if (!lkx || !rkx) return no("join keys are expressions");
+  std::vector<int> lpreds, rpreds;
+  const int lsrc = peel_filters(plan, jn.input, lpreds), rsrc = peel_filters(plan, jn.input_right, rpreds);
+  if (plan.ir[lsrc].kind != PLX_IR_SCAN || plan.ir[rsrc].kind != PLX_IR_SCAN) return no("join inputs are not filtered scans");
+  FramePtr L = get_frame(plan.ir[lsrc].frame), R = get_frame(plan.ir[rsrc].frame);
+  const int lki = L->find(lkx->name), rki = R->find(rkx->name);
+  if (lki < 0 || rki < 0) return no("join key column not found");
+  const int kdt = L->cols[lki]->dtype;
+  if (kdt != R->cols[rki]->dtype || !dtype_is_int(kdt)) return no("join key is not an integer column pair of one dtype");
+  if (L->height >= 0xffffffffll || R->height >= 0xffffffffll) return no("side exceeds u32 row indices");
+  const bool build_right = L->height > R->height;   // det_hash_prone_order: probe = the longer relation
+  const FramePtr& B = build_right ? R : L;
+  const FramePtr& P = build_right ? L : R;
+  const int bki = build_right ? rki : lki, pki = build_right ? lki : rki;
+  const std::vector<int>& bpreds = build_right ? rpreds : lpreds;
+  const std::vector<int>& ppreds = build_right ? lpreds : rpreds;
+  // joined-frame naming (_finish_join, general.rs:17-49): left columns, then right columns except the coalesced right key
+  struct Src { int side; int idx; };   // side 0 = left, 1 = right
+  std::map<std::string, Src> joined;
+  for (size_t i = 0; i < L->names.size(); i++) joined[L->names[i]] = {0, (int)i};
+  for (size_t i = 0; i < R->names.size(); i++) {
+    if ((int)i == rki) continue;
+    std::string name = R->names[i];
+    if (joined.count(name)) name += jn.suffix;
+    if (joined.count(name)) return no("duplicate output column name");
+    joined[name] = {1, (int)i};
+  }
+  const int build_side = build_right ? 1 : 0;
+  // group keys
+  struct GKey { bool is_join_key; int build_col; int expr; int dtype; };
+  std::vector<GKey> gkeys;
+  bool has_join_key = false;
+  for (int e : gb.keys) {
+    const AE* x = plain(e);
+    if (!x) return no("group key is an expression");
+    auto it = joined.find(x->name);
+    if (it == joined.end()) fail(PLX_ERR_NOT_FOUND, "column not found: " + x->name);
+    const Src sc = it->second;
+    const bool is_key = (sc.side == 0 && sc.idx == lki);   // the coalesced key column carries the left name
+    if (is_key) { has_join_key = true; gkeys.push_back({true, -1, e, kdt}); }
+    else if (sc.side == build_side) gkeys.push_back({false, sc.idx, e, B->cols[sc.idx]->dtype});
+    else return no("group key from the probe side that is not the join key");
+  }
+  if (!has_join_key) return no("group keys do not include the join key");
+  // aggregates: probe-side columns only, resolved through the joined names
+  Frame pview; pview.height = P->height;
+  for (auto& kv : joined) if (kv.second.side != build_side) { pview.names.push_back(kv.first); pview.cols.push_back(P->cols[kv.second.idx]); }
+  if (!build_right) { pview.names.push_back(lkx->name); pview.cols.push_back(P->cols[pki]); }  // coalesced key: probe values == build values on matches
+  std::function<bool(int)> probe_only = [&](int e) -> bool {
+    if (e < 0) return true;
+    const AE& x = plan.ae[e];
+    if (x.kind == PLX_AE_COLUMN) return pview.find(x.name) >= 0;
+    return probe_only(x.lhs) && probe_only(x.rhs);
+  };
+  for (int e : gb.exprs) {
+    if (!contains_agg(plan, e) || contains_column_outside_agg(plan, e)) return no("aggregation list contains a non-aggregated column");
+    if (!probe_only(e)) return no("aggregate reads a build-side column");
+  }
+  // ---- compile the three programs
+  Compiler cnt(plan, *B), cb(plan, *B), cp(plan, *P);
+  std::vector<int> agg_nodes; std::vector<FinalSpec> specs;
+  int len_idx = -1;
+  try {
+    auto and_preds = [&](Compiler& c, const std::vector<int>& preds) { int p = -1; for (int pe : preds) { int n = c.lower(pe); if (c.nodes[n].ty != 'b') throw Unsupported("predicate is not boolean"); p = p < 0 ? n : c.mk(OP_AND, p, n, 'b'); } return p; };
+    cnt.pred = and_preds(cnt, bpreds);
+    const int bk_cnt = cnt.load(bki);
+    cnt.add_agg(cnt.nodes[bk_cnt].nullable ? AGG_COUNT : AGG_LEN, cnt.nodes[bk_cnt].nullable ? bk_cnt : -1);
+    cnt.finish();
+    cb.pred = and_preds(cb, bpreds);
+    cb.key = cb.load(bki);
+    cb.finish();
+    cp.pred = and_preds(cp, ppreds);
+    cp.key = cp.load(pki);
+    cp.df = &pview;
+    len_idx = cp.add_agg(AGG_LEN, -1);
+    for (int e : gb.exprs) collect_aggs(plan, e, agg_nodes);
+    for (int a : agg_nodes) specs.push_back(cp.lower_agg(a));
+    cp.finish();
+  } catch (const Unsupported& u) { if (why) *why = u.why; return false; }
+  if (shapes_out) { shapes_out->push_back(cnt.shape); shapes_out->push_back(cb.shape); shapes_out->push_back(cp.shape); }
+  if (compile_only) return true;
+  // ---- run
+  uint64_t nb = 0;
+  if (B->height > 0) { std::vector<uint64_t> host(kMaxAggs, 0); k::fused_regagg(cnt.shape, cnt.args, find_static_shape(cnt.shape), host.data()); nb = host[0]; }
+  const int log2_cap = std::max(4, ceil_log2_u64(std::max<uint64_t>(nb, 1) * 2));
+  const uint64_t cap = 1ull << log2_cap;
+  Buf keys = dev_alloc(sizeof(uint64_t) * (cap + 1)), head = dev_alloc(sizeof(uint32_t) * (cap + 1)), flags = dev_alloc_zero(16);
+  Buf acc = dev_alloc(sizeof(uint64_t) * (cap + 1) * cp.shape.n_aggs);
+  PLX_HIP(hipMemsetAsync(keys->ptr, 0xff, sizeof(uint64_t) * (cap + 1), stream()));
+  PLX_HIP(hipMemsetAsync(head->ptr, 0xff, sizeof(uint32_t) * (cap + 1), stream()));
+  JoinAggTable t; t.keys = keys->as<unsigned long long>(); t.head = head->as<unsigned int>(); t.flags = flags->as<unsigned int>(); t.acc = acc->as<unsigned long long>();
+  t.log2_cap = (uint32_t)log2_cap;
+  k::fused_join_build(cb.shape, cb.args, t, find_static_shape(cb.shape));
+  uint32_t fl[2] = {0, 0};
+  d2h_sync(fl, flags->ptr, 8);
+  if (fl[0]) return no("build keys are not unique");
+  PLX_REQUIRE(!fl[1], PLX_ERR_OOM, "join build: probe sequence overflow");
+  k::init_agg_cells(acc->as<uint64_t>(), (int64_t)cap + 1, cp.shape);
+  const int static_id = find_static_shape(cp.shape);
+  k::fused_probe_agg(cp.shape, cp.args, t, static_id);
+  FusedAggResult r; r.n_aggs = cp.shape.n_aggs;
+  const int64_t G = k::join_agg_compact(t, r.n_aggs, len_idx, nullptr, nullptr, nullptr);
+  r.n_groups = G;
+  const int64_t g1 = std::max<int64_t>(G, 1);
+  r.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)g1);
+  r.acc = dev_alloc(sizeof(uint64_t) * (size_t)g1 * r.n_aggs);
+  auto rows = std::make_shared<Column>();
+  rows->dtype = PLX_U32; rows->len = G; rows->values = dev_alloc(values_bytes(PLX_U32, g1)); rows->null_count = 0;
+  if (G) k::join_agg_compact(t, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
+  plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " cap=2^" + std::to_string(log2_cap) +
+               " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + (static_id >= 0 ? "aot" : "generic") + "]+probe_agg, aggs=" + std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
+  // ---- output frame: keys, then aggregates
+  out = std::make_shared<Frame>();
+  out->height = G;
+  for (auto& gk : gkeys) {
+    out->names.push_back(output_name(plan, gk.expr));
+    if (gk.is_join_key) {
+      KeyPart part; part.expr = gk.expr; part.dtype = gk.dtype;
+      part.dec.shift = 0; part.dec.mask = ~0ull; part.dec.min = 0; part.dec.null_code = ~0ull; part.dec.dtype = gk.dtype;
+      out->cols.push_back(decode_key_column(r, part, 0));
+    } else out->cols.push_back(ops::gather(B->cols[gk.build_col], rows));
+  }
+  std::map<int, ColumnPtr> overrides;
+  for (size_t i = 0; i < agg_nodes.size(); i++) overrides[agg_nodes[i]] = finalize_column(r, specs[i]);
+  Frame gframe; gframe.height = G;
+  for (int e : gb.exprs) {
+    Evaluated ev = eval(plan, e, gframe, &overrides);
+    out->names.push_back(output_name(plan, e));
+    out->cols.push_back(broadcast(ev, G));
+  }
+  return true;
+}
+
 // ----------------------------------------------------------------- executors ----
 static FramePtr exec_node(Plan& plan, int node_id);
 
@@ -917,12 +1094,6 @@ static FramePtr exec_groupby_materialised(Plan& plan, const IRN& n, const FrameP
   return out;
 }
 
-// peel [Filter]* below an aggregation node
-static int peel_filters(const Plan& plan, int input, std::vector<int>& preds) {
-  while (plan.ir[input].kind == PLX_IR_FILTER) { preds.push_back(plan.ir[input].predicate); input = plan.ir[input].input; }
-  std::reverse(preds.begin(), preds.end());
-  return input;
-}
 
 static FramePtr exec_join(Plan& plan, const IRN& n) {
   FramePtr left = exec_node(plan, n.input);
@@ -978,6 +1149,11 @@ static FramePtr exec_node(Plan& plan, int node_id) {
       return exec_select(plan, n, false);
     }
     case PLX_IR_GROUPBY: {
+      if (fuse && n.input >= 0 && plan.ir[n.input].kind == PLX_IR_JOIN) {
+        FramePtr out; std::string why;
+        if (fused_join_groupby(plan, n, out, &why)) return out;
+        plan.desc += "(join+group_by not fused: " + why + ") ";
+      }
       if (fuse) {
         std::vector<int> preds;
         int src_node = peel_filters(plan, n.input, preds);
@@ -997,6 +1173,12 @@ static FramePtr exec_node(Plan& plan, int node_id) {
 FramePtr execute(Plan& plan, int root) {
   plan.desc.clear();
   return exec_node(plan, root);
+}
+
+bool describe_join_fusion(Plan& plan, int root, std::vector<Shape>* shapes, std::string* why_not) {
+  const IRN& n = plan.ir.at(root);
+  FramePtr out;
+  return fused_join_groupby(plan, n, out, why_not, shapes, true);
 }
 
 bool describe_fusion(Plan& plan, int root, Shape* shape, int* static_id, std::string* why_not) {

@@ -40,7 +40,9 @@ enum OpCode : uint8_t {
   OP_AND, OP_OR, OP_XOR, OP_NOT,            // boolean slots
   OP_IFNULL,   // dst <- valid(a) ? a : imm[pc]; result always valid (null group code)
   OP_MOV,
-  OP_CANON_F   // float key canonicalisation: -0 -> +0, any NaN -> 0x7ff8000000000000 (total_ord.rs:40-48)
+  OP_CANON_F,  // float key canonicalisation: -0 -> +0, any NaN -> 0x7ff8000000000000 (total_ord.rs:40-48)
+  // 64-bit integer floor division / modulo, Python sign rules; divisor 0 -> null (signed.rs:35-70)
+  OP_FDIV_I, OP_MOD_I, OP_FDIV_U, OP_MOD_U
 };
 
 struct Op {
@@ -153,6 +155,19 @@ struct WideTable {
   uint32_t max_probe;
   uint32_t n_words;      // n_keys (+1 when has_null_word)
   uint32_t has_null_word;
+};
+
+// Fused join -> aggregate (group keys = join key + build-side columns, unique build keys):
+// the build scan inserts key -> build row, the probe scan adds straight into the cells of the
+// matching slot.  keys[cap+1] / head[cap+1] (slot cap = the key whose bits equal EMPTY),
+// acc[(cap+1) * n_aggs].
+constexpr uint32_t kNoRow32 = 0xffffffffu;
+struct JoinAggTable {
+  unsigned long long* keys;
+  unsigned int* head;     // build row of the slot
+  unsigned int* flags;    // [0] = duplicate build key seen, [1] = probe sequence overflow
+  unsigned long long* acc;
+  uint32_t log2_cap;
 };
 
 // Direct-address aggregation (dense keys in [key_min, key_min + n_groups)): acc[(G+1)*n_aggs],

@@ -30,6 +30,20 @@
 #include <cstring>
 #include <vector>
 
+// Launch cases of the join-pipeline AOT shapes; empty when fused_shapes.hpp was generated without them.
+#ifdef PLX_HAVE_Q3_SHAPES
+#define PLX_STATIC_JOIN_BUILD_CASES \
+  case SHAPE_Q3_BUILD: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_BUILD>, JoinBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+#define PLX_STATIC_PROBE_AGG_CASES \
+  case SHAPE_Q3_PROBE: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_PROBE>, ProbeAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+#define PLX_STATIC_REGAGG_EXTRA_CASES \
+  case SHAPE_Q3_COUNT: PLX_LAUNCH_SCAN(StatProg<SHAPE_Q3_COUNT>, RegAggSink, grid, 0, sh, args, sp); break;
+#else
+#define PLX_STATIC_JOIN_BUILD_CASES
+#define PLX_STATIC_PROBE_AGG_CASES
+#define PLX_STATIC_REGAGG_EXTRA_CASES
+#endif
+
 namespace plx {
 namespace k {
 
@@ -195,6 +209,29 @@ __device__ __forceinline__ void exec_op(const Op op, const Shape& sh, const Args
         for (int r = 0; r < kRows; r++) { double f = as_f(a[r]); d[r] = (f != f) ? 0x7ff8000000000000ull : as_u(f + 0.0); }
         vd = va;
         break;
+      case OP_FDIV_I: case OP_MOD_I: {
+        uint32_t nz = 0;
+#pragma unroll
+        for (int r = 0; r < kRows; r++) {
+          const long long x = (long long)a[r], y = (long long)b[r];
+          long long q = 0, m = 0;
+          if (y == -1) { q = (long long)(0ull - (unsigned long long)x); m = 0; }   // wrapping_div(MIN, -1) = MIN
+          else if (y != 0) { q = x / y; m = x % y; if (m != 0 && ((x < 0) != (y < 0))) { q -= 1; m += y; } }
+          d[r] = (uint64_t)(op.code == OP_FDIV_I ? q : m);
+          nz |= (uint32_t)(y != 0) << r;
+        }
+        vd &= nz;
+      } break;
+      case OP_FDIV_U: case OP_MOD_U: {
+        uint32_t nz = 0;
+#pragma unroll
+        for (int r = 0; r < kRows; r++) {
+          const uint64_t x = a[r], y = b[r];
+          d[r] = y ? (op.code == OP_FDIV_U ? x / y : x % y) : 0ull;
+          nz |= (uint32_t)(y != 0) << r;
+        }
+        vd &= nz;
+      } break;
       case OP_IFNULL:
 #pragma unroll
         for (int r = 0; r < kRows; r++) d[r] = ((va >> r) & 1) ? a[r] : args.imm[pc];
@@ -557,6 +594,72 @@ struct WideAggSink {
   }
 };
 
+
+// ---- sinks: fused join build / probe->aggregate ---------------------------------------------
+// Replaces, for `GroupBy(join key + build-side columns) over Join(inner)`, the chain
+// build_tables -> probe_inner -> gather of every payload column -> group_by of the reference
+// (polars-ops/src/frame/join/hash_join/single_keys.rs:16-167, single_keys_inner.rs:11-149,
+// polars-mem-engine/src/executors/{join.rs:41-121, group_by.rs:60-98}): no filtered frames,
+// no (left_idx, right_idx) pairs and no joined frame are materialised.
+struct JoinBuildSink {
+  using Params = JoinAggTable;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+    const uint64_t cap = 1ull << p.log2_cap;
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r] || !((rf.valid[sh.key] >> r) & 1)) continue;  // null keys never match
+      const uint64_t key = rf.v[r][sh.key];
+      uint64_t slot;
+      if (key == kEmptyKey) { slot = cap; p.keys[cap] = 0; }
+      else {
+        slot = (key * 0x55fbfd6bfc5458e9ull) >> (64 - p.log2_cap);
+        uint32_t probe = 0;
+        for (;; probe++) {
+          unsigned long long cur = p.keys[slot];
+          if (cur == key) break;
+          if (cur == kEmptyKey) {
+            const unsigned long long old = atomicCAS(&p.keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
+            if (old == kEmptyKey || old == key) break;
+          }
+          slot = (slot + 1) & (cap - 1);
+          if (probe > (1u << 16)) { p.flags[1] = 1u; break; }
+        }
+      }
+      const unsigned int old = atomicExch(&p.head[slot], (unsigned int)(row0 + r));
+      if (old != kNoRow32) p.flags[0] = 1u;
+    }
+  }
+};
+
+struct ProbeAggSink {
+  using Params = JoinAggTable;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+    const uint64_t cap = 1ull << p.log2_cap;
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r] || !((rf.valid[sh.key] >> r) & 1)) continue;
+      const uint64_t key = rf.v[r][sh.key];
+      int64_t slot = -1;
+      if (key == kEmptyKey) { if (p.head[cap] != kNoRow32) slot = (int64_t)cap; }
+      else {
+        uint64_t s = (key * 0x55fbfd6bfc5458e9ull) >> (64 - p.log2_cap);
+        for (;;) {
+          const unsigned long long cur = p.keys[s];
+          if (cur == key) { slot = (int64_t)s; break; }
+          if (cur == kEmptyKey) break;
+          s = (s + 1) & (cap - 1);
+        }
+      }
+      if (slot < 0) continue;
+      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
+    }
+  }
+};
+
 // ---- the scan kernels ------------------------------------------------------------------
 template <class P>
 __device__ __forceinline__ bool tile_rows(const Shape& dsh, const Args& args, int64_t tile, RegFile& rf, bool pass[kRows], int64_t& row0) {
@@ -646,6 +749,7 @@ void fused_regagg(const Shape& sh, const Args& args, int static_id, uint64_t* ou
       case SHAPE_CFG2: PLX_LAUNCH_SCAN(StatProg<SHAPE_CFG2>, RegAggSink, grid, 0, sh, args, sp); break;
       case SHAPE_CFG2_NULLX: PLX_LAUNCH_SCAN(StatProg<SHAPE_CFG2_NULLX>, RegAggSink, grid, 0, sh, args, sp); break;
       case SHAPE_CFG1: PLX_LAUNCH_SCAN(StatProg<SHAPE_CFG1>, RegAggSink, grid, 0, sh, args, sp); break;
+      PLX_STATIC_REGAGG_EXTRA_CASES
       default: PLX_LAUNCH_SCAN(DynProg, RegAggSink, grid, 0, sh, args, sp); break;
     }
     PLX_HIP(hipGetLastError());
@@ -734,6 +838,46 @@ void fused_hash_agg(const Shape& sh, const Args& args, const HashTable& t, int s
 }
 
 
+
+// ---- slot compaction skeleton -----------------------------------------------------------------
+// Every workgroup takes chunks of kBlock * kCompactItems slots; a thread tests kCompactItems slots,
+// the workgroup scans the per-thread counts (wave shuffle scan + LDS) and reserves its output range
+// with ONE device atomic per chunk.  (One atomic per wave-with-a-hit on a single counter word
+// saturates at ~88 atomics/us: a 2^25-slot table took 5.6 ms that way, 0.3 ms this way.)
+constexpr int kCompactItems = 8;
+template <class Occ, class Emit>
+__device__ __forceinline__ void compact_slots(int64_t n_slots, unsigned long long* counter, Occ occ, Emit emit) {
+  __shared__ uint32_t wave_tot[kBlock / 64];
+  __shared__ unsigned long long chunk_base;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int64_t chunk = (int64_t)kBlock * kCompactItems;
+  const int64_t nchunks = (n_slots + chunk - 1) / chunk;
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {   // trip count is uniform across the workgroup
+    const int64_t s0 = c * chunk + threadIdx.x;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < kCompactItems; j++) { const int64_t s = s0 + (int64_t)j * kBlock; if (s < n_slots && occ(s)) bits |= 1u << j; }
+    const uint32_t cnt = (uint32_t)__popc(bits);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) { if (w < wave) wave_off += wave_tot[w]; total += wave_tot[w]; }
+    if (threadIdx.x == 0 && total) chunk_base = atomicAdd(counter, (unsigned long long)total);
+    __syncthreads();
+    if (total) {
+      uint64_t o = chunk_base + wave_off + (incl - cnt);
+#pragma unroll
+      for (int j = 0; j < kCompactItems; j++) if ((bits >> j) & 1) { emit(s0 + (int64_t)j * kBlock, o); o++; }
+    }
+    __syncthreads();   // chunk_base / wave_tot are reused by the next chunk
+  }
+}
+static int compact_grid(int64_t n_slots) { return grid_for(n_slots, kBlock * kCompactItems, 8); }
+
 void fused_wide_agg(const Shape& sh, const Args& args, const WideTable& t) {
   if (args.n_rows == 0) return;
   ProfileScope ps("fused_scan_wideagg", algo_bytes(sh, args), (uint64_t)args.n_rows);
@@ -745,32 +889,69 @@ void fused_wide_agg(const Shape& sh, const Args& args, const WideTable& t) {
 __global__ __launch_bounds__(kBlock) void wide_compact_kernel(WideTable t, int n_keys, int n_aggs, int64_t out_stride, unsigned long long* __restrict__ counter,
                                                               unsigned long long* __restrict__ out_words, unsigned char* __restrict__ out_kvalid,
                                                               unsigned long long* __restrict__ out_acc) {
-  const int lane = lane_id();
   const int64_t cap = (int64_t)1 << t.log2_cap;
-  for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < cap; base += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t s = base + lane;
-    const bool occ = s < cap && t.tags[s] != kEmptyKey;
-    const uint64_t m = ballot(occ);
-    if (m == 0) continue;
-    unsigned long long o = 0;
-    if (lane == 0) o = atomicAdd(counter, (unsigned long long)popc64(m));
-    o = shfl_u64(o, 0) + (uint64_t)prefix_rank(m);
-    if (occ && out_words) {
-      const uint64_t nullmask = t.has_null_word ? t.words[(size_t)n_keys * cap + s] : 0ull;
-      for (int j = 0; j < n_keys; j++) {
-        out_words[(size_t)j * out_stride + o] = t.words[(size_t)j * cap + s];
-        out_kvalid[(size_t)j * out_stride + o] = (unsigned char)(((nullmask >> j) & 1) ^ 1);
-      }
-      for (int k = 0; k < n_aggs; k++) out_acc[o * n_aggs + k] = t.acc[(size_t)s * n_aggs + k];
-    }
-  }
+  compact_slots(cap, counter, [&](int64_t s) { return t.tags[s] != kEmptyKey; },
+                [&](int64_t s, uint64_t o) {
+                  if (!out_words) return;
+                  const uint64_t nullmask = t.has_null_word ? t.words[(size_t)n_keys * cap + s] : 0ull;
+                  for (int j = 0; j < n_keys; j++) {
+                    out_words[(size_t)j * out_stride + o] = t.words[(size_t)j * cap + s];
+                    out_kvalid[(size_t)j * out_stride + o] = (unsigned char)(((nullmask >> j) & 1) ^ 1);
+                  }
+                  for (int k = 0; k < n_aggs; k++) out_acc[o * n_aggs + k] = t.acc[(size_t)s * n_aggs + k];
+                });
 }
 int64_t wide_compact(const WideTable& t, int n_keys, int n_aggs, int64_t out_stride, uint64_t* out_words, uint8_t* out_kvalid, uint64_t* out_acc) {
   Buf counter = dev_alloc_zero(8);
   const int64_t cap = (int64_t)1 << t.log2_cap;
   ProfileScope ps("table_compact", (uint64_t)cap * 8 * (uint64_t)(1 + n_keys + n_aggs), (uint64_t)cap);
-  hipLaunchKernelGGL(wide_compact_kernel, dim3(grid_for(cap, kBlock * 2)), dim3(kBlock), 0, stream(), t, n_keys, n_aggs, out_stride,
+  hipLaunchKernelGGL(wide_compact_kernel, dim3(compact_grid(cap)), dim3(kBlock), 0, stream(), t, n_keys, n_aggs, out_stride,
                      counter->as<unsigned long long>(), (unsigned long long*)out_words, (unsigned char*)out_kvalid, (unsigned long long*)out_acc);
+  PLX_HIP(hipGetLastError());
+  uint64_t n = 0;
+  d2h_sync(&n, counter->ptr, 8);
+  return (int64_t)n;
+}
+
+
+void fused_join_build(const Shape& sh, const Args& args, const JoinAggTable& t, int static_id) {
+  if (args.n_rows == 0) return;
+  ProfileScope ps(static_id >= 0 ? "fused_scan_join_build_static" : "fused_scan_join_build", algo_bytes(sh, args), (uint64_t)args.n_rows);
+  const int grid = scan_grid(args.n_rows, 8);
+  switch (static_id) {
+    PLX_STATIC_JOIN_BUILD_CASES
+    default: hipLaunchKernelGGL((fused_scan_kernel<DynProg, JoinBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+  }
+  PLX_HIP(hipGetLastError());
+}
+void fused_probe_agg(const Shape& sh, const Args& args, const JoinAggTable& t, int static_id) {
+  if (args.n_rows == 0) return;
+  ProfileScope ps(static_id >= 0 ? "fused_scan_probe_agg_static" : "fused_scan_probe_agg", algo_bytes(sh, args), (uint64_t)args.n_rows);
+  const int grid = scan_grid(args.n_rows, 8);
+  switch (static_id) {
+    PLX_STATIC_PROBE_AGG_CASES
+    default: hipLaunchKernelGGL((fused_scan_kernel<DynProg, ProbeAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+  }
+  PLX_HIP(hipGetLastError());
+}
+__global__ __launch_bounds__(kBlock) void join_agg_compact_kernel(JoinAggTable t, int n_aggs, int len_idx, unsigned long long* __restrict__ counter,
+                                                                  unsigned long long* __restrict__ out_keys, unsigned int* __restrict__ out_rows,
+                                                                  unsigned long long* __restrict__ out_acc) {
+  const int64_t cap = (int64_t)1 << t.log2_cap;
+  compact_slots(cap + 1, counter, [&](int64_t s) { return t.acc[(size_t)s * n_aggs + len_idx] != 0; },
+                [&](int64_t s, uint64_t o) {
+                  if (!out_keys) return;
+                  out_keys[o] = s < cap ? t.keys[s] : kEmptyKey;
+                  out_rows[o] = t.head[s];
+                  for (int k = 0; k < n_aggs; k++) out_acc[o * n_aggs + k] = t.acc[(size_t)s * n_aggs + k];
+                });
+}
+int64_t join_agg_compact(const JoinAggTable& t, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc) {
+  Buf counter = dev_alloc_zero(8);
+  const int64_t n_slots = ((int64_t)1 << t.log2_cap) + 1;
+  ProfileScope ps("table_compact", (uint64_t)n_slots * 8 * (uint64_t)(2 + n_aggs), (uint64_t)n_slots);
+  hipLaunchKernelGGL(join_agg_compact_kernel, dim3(compact_grid(n_slots)), dim3(kBlock), 0, stream(), t, n_aggs, len_idx, counter->as<unsigned long long>(),
+                     (unsigned long long*)out_keys, (unsigned int*)out_rows, (unsigned long long*)out_acc);
   PLX_HIP(hipGetLastError());
   uint64_t n = 0;
   d2h_sync(&n, counter->ptr, 8);
@@ -784,31 +965,22 @@ __global__ __launch_bounds__(kBlock) void hash_compact_kernel(const unsigned lon
                                                               int64_t n_slots, int64_t cap, int n_aggs, int occ_agg /* LEN/COUNT cell or -1 */,
                                                               unsigned long long* __restrict__ counter, unsigned long long* __restrict__ out_keys,
                                                               unsigned char* __restrict__ out_key_valid, unsigned long long* __restrict__ out_acc) {
-  const int lane = lane_id();
-  for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n_slots; base += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t s = base + lane;
-    bool occ = false;
-    if (s < n_slots) {
-      if (occ_agg >= 0) occ = acc[(size_t)s * n_aggs + occ_agg] != 0;  // a group exists iff its row count is non-zero
-      else occ = s < cap ? keys[s] != kEmptyKey : keys[s] == 0;
-    }
-    const uint64_t m = ballot(occ);
-    if (m == 0) continue;
-    unsigned long long o = 0;
-    if (lane == 0) o = atomicAdd(counter, (unsigned long long)popc64(m));
-    o = shfl_u64(o, 0) + (uint64_t)prefix_rank(m);
-    if (occ) {
-      if (out_keys) {
-        uint64_t kv = 0; unsigned char valid = 1;
-        if (cap < 0) kv = (uint64_t)s;                   // dense table: the slot index is the packed key
-        else if (s < cap) kv = keys[s];
-        else if (s == cap) { kv = 0; valid = 0; }        // null-key group
-        else kv = kEmptyKey;                             // the key equal to the sentinel
-        out_keys[o] = kv; out_key_valid[o] = valid;
-      }
-      if (out_acc) for (int k = 0; k < n_aggs; k++) out_acc[o * n_aggs + k] = acc[(size_t)s * n_aggs + k];
-    }
-  }
+  compact_slots(n_slots, counter,
+                [&](int64_t s) {
+                  if (occ_agg >= 0) return acc[(size_t)s * n_aggs + occ_agg] != 0;   // a group exists iff its row count is non-zero
+                  return s < cap ? keys[s] != kEmptyKey : keys[s] == 0;
+                },
+                [&](int64_t s, uint64_t o) {
+                  if (out_keys) {
+                    uint64_t kv = 0; unsigned char valid = 1;
+                    if (cap < 0) kv = (uint64_t)s;                   // dense table: the slot index is the packed key
+                    else if (s < cap) kv = keys[s];
+                    else if (s == cap) { kv = 0; valid = 0; }        // null-key group
+                    else kv = kEmptyKey;                             // the key equal to the sentinel
+                    out_keys[o] = kv; out_key_valid[o] = valid;
+                  }
+                  if (out_acc) for (int k = 0; k < n_aggs; k++) out_acc[o * n_aggs + k] = acc[(size_t)s * n_aggs + k];
+                });
 }
 
 // ---- aggregate cells -> typed output column ------------------------------------------------
@@ -902,7 +1074,7 @@ int64_t table_compact(const uint64_t* keys, const uint64_t* acc, int64_t n_slots
                       uint8_t* out_key_valid, uint64_t* out_acc) {
   Buf counter = dev_alloc_zero(8);
   ProfileScope ps("table_compact", (uint64_t)n_slots * 8 * (uint64_t)(1 + n_aggs), (uint64_t)n_slots);
-  hipLaunchKernelGGL(hash_compact_kernel, dim3(grid_for(n_slots, kBlock * 2)), dim3(kBlock), 0, stream(), (const unsigned long long*)keys,
+  hipLaunchKernelGGL(hash_compact_kernel, dim3(compact_grid(n_slots)), dim3(kBlock), 0, stream(), (const unsigned long long*)keys,
                      (const unsigned long long*)acc, n_slots, cap, n_aggs, occ_agg, counter->as<unsigned long long>(), (unsigned long long*)out_keys,
                      (unsigned char*)out_key_valid, (unsigned long long*)out_acc);
   PLX_HIP(hipGetLastError());

@@ -24,6 +24,11 @@ void fused_wide_agg(const fused::Shape& sh, const fused::Args& args, const fused
 // occupied slots of a wide table -> out_words[n_keys][G] (u64 each), out_kvalid[n_keys][G] (u8), out_acc[G][n_aggs];
 // nullptr outputs = count only.  Returns the group count (synchronises).
 int64_t wide_compact(const fused::WideTable& t, int n_keys, int n_aggs, int64_t out_stride, uint64_t* out_words, uint8_t* out_kvalid, uint64_t* out_acc);
+// fused join->aggregate: build scan (key = sh.key, rows passing sh.pred) / probe scan (aggregates into t.acc)
+void fused_join_build(const fused::Shape& sh, const fused::Args& args, const fused::JoinAggTable& t, int static_id);
+void fused_probe_agg(const fused::Shape& sh, const fused::Args& args, const fused::JoinAggTable& t, int static_id);
+// slots whose AGG_LEN cell (len_idx) is non-zero -> out_keys (u64), out_rows (u32 build row), out_acc; nullptr outputs = count only
+int64_t join_agg_compact(const fused::JoinAggTable& t, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc);
 void fill_u64(uint64_t* p, int64_t n, uint64_t v);
 void init_agg_cells(uint64_t* acc, int64_t n_slots, const fused::Shape& sh);
 // Gather occupied table slots into dense arrays; returns the group count (synchronises).

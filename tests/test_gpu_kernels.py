@@ -256,7 +256,7 @@ def test_groupby_multi_key_wide(pl, orc):
 @pytest.mark.parametrize("how", ["inner", "left"])
 def test_join_indices(pl, orc, kdt, how):
     rng = np.random.default_rng(108)
-    for nl, nr, card in [(0, 5, 3), (5, 0, 3), (100, 100, 20), (5000, 3000, 700), (3000, 50_000, 100_000), (100_000, 20_000, 1000)]:
+    for nl, nr, card in [(0, 5, 3), (5, 0, 3), (100, 100, 20), (5000, 3000, 700), (3000, 50_000, 100_000), (30_000, 20_000, 1000)]:
         if kdt == "f64":
             lk, rk = rng.integers(0, card, nl) / 2.0, rng.integers(0, card, nr) / 2.0
             if nl > 3 and nr > 3:

@@ -110,6 +110,8 @@ def test_q3(pl, orc, n_orders):
     exp = orc.q3({k: li[k] for k in datagen.LINEITEM_Q3_COLS}, {k: orders[k] for k in datagen.ORDERS_Q3_COLS}, datagen.us(1995, 3, 15))
     for nf in (False, True):
         out = queries.q3(L.lazy(), O.lazy()).collect(no_fusion=nf)
+        if n_orders:
+            assert ("FusedJoinGroupBy" in pl.last_plan()) == (not nf), pl.last_plan()
         g = out.sort_host("l_orderkey")
         assert g["l_orderkey"] == exp["l_orderkey"].tolist(), pl.last_plan()
         assert g["o_orderdate"] == exp["o_orderdate"].tolist() and g["o_shippriority"] == exp["o_shippriority"].tolist()
@@ -176,3 +178,115 @@ def test_full_size_properties_q1(pl):
     g2 = queries.q1(datagen.frame_from_torch(pl, twice, datagen.LINEITEM_Q1_COLS).lazy()).collect().sort_host(["l_returnflag", "l_linestatus"])
     assert g2["count_order"] == [2 * c for c in g["count_order"]] and g2["sum_qty"] == [2 * c for c in g["sum_qty"]]
     assert close(g2["sum_charge"], [2 * c for c in g["sum_charge"]]) and close(g2["avg_disc"], g["avg_disc"])
+
+
+def _join_groupby_reference(lk, lx, rk, ry):
+    """numpy: inner join on key, group by (key, ry), sum(lx), count."""
+    import collections
+    pos = collections.defaultdict(list)
+    for j, k in enumerate(rk.tolist()):
+        pos[k].append(j)
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for i, k in enumerate(lk.tolist()):
+        for j in pos.get(k, ()):
+            a = acc[(k, int(ry[j]))]
+            a[0] += float(lx[i]); a[1] += 1
+    return sorted((k[0], k[1], v[0], v[1]) for k, v in acc.items())
+
+
+@pytest.mark.parametrize("shape", ["build_right", "build_left", "dup_build_keys", "probe_side_group_key", "sentinel_key"])
+def test_join_groupby_fusion_and_fallbacks(pl, shape):
+    """The fused join->aggregate pipeline only fires when a group is one build row; every other
+    shape must fall back to the per-node path and still agree with a plain numpy evaluation."""
+    rng = np.random.default_rng(31)
+    nl, nr = (40_000, 3_000) if shape != "build_left" else (3_000, 40_000)
+    rk = rng.permutation(200_000)[:nr].astype(np.int64) - 100_000
+    if shape == "dup_build_keys":
+        rk[: nr // 2] = rk[nr // 2: nr // 2 * 2]
+    if shape == "sentinel_key":
+        rk[0] = -1                                   # the table's EMPTY bit pattern as a real key
+    lk = rng.choice(np.concatenate([rk, rng.integers(300_000, 400_000, 1000)]), nl).astype(np.int64)
+    if shape == "build_left":
+        lk = rng.permutation(np.unique(lk))[: nl]
+        nl = len(lk)
+    lx = rng.uniform(0, 10, nl)
+    lz = rng.integers(0, 3, nl).astype(np.int64)
+    ry = rng.integers(0, 50, nr).astype(np.int64)
+    L = pl.DataFrame({"k": lk, "x": lx, "z": lz})
+    R = pl.DataFrame({"k": rk, "y": ry})
+    keys = ["k", "y"] if shape != "probe_side_group_key" else ["k", "z"]
+    val = "x" if shape != "build_left" else "y"
+    q = (L.lazy().filter(pl.col("x") >= 0.0).join(R.lazy().filter(pl.col("y") < 1000), on="k")
+         .group_by(*keys).agg(pl.col(val).sum().alias("s"), pl.len().alias("n")))
+    out = q.collect()
+    plan = pl.last_plan()
+    fused = shape in ("build_right", "build_left", "sentinel_key")
+    if shape == "build_left":   # aggregate reads the probe (= right, longer) side: y; group keys k + ... y is probe side -> not a build column
+        fused = False
+    assert ("FusedJoinGroupBy" in plan) == fused, plan
+    d = out.to_dict()
+    got = sorted(zip(d[keys[0]], d[keys[1]], d["s"], d["n"]))
+    if shape == "probe_side_group_key":
+        import collections
+        pos = {int(k): j for j, k in enumerate(rk.tolist())}
+        acc = collections.defaultdict(lambda: [0.0, 0])
+        for i, k in enumerate(lk.tolist()):
+            if k in pos:
+                a = acc[(k, int(lz[i]))]; a[0] += float(lx[i]); a[1] += 1
+        exp = sorted((k[0], k[1], v[0], v[1]) for k, v in acc.items())
+    elif shape == "build_left":
+        exp = _join_groupby_reference(lk, np.zeros(nl), rk, ry)
+        exp = sorted((k, y, float(y) * n, n) for k, y, _, n in exp)
+    else:
+        exp = _join_groupby_reference(lk, lx, rk, ry)
+    assert len(got) == len(exp), (plan, len(got), len(exp))
+    for a, b in zip(got, exp):
+        assert a[0] == b[0] and a[1] == b[1] and a[3] == b[3] and math.isclose(a[2], b[2], rel_tol=RTOL, abs_tol=1e-9), (plan, a, b)
+    o2 = q.collect(no_fusion=True).to_dict()
+    got2 = sorted(zip(o2[keys[0]], o2[keys[1]], o2["s"], o2["n"]))
+    assert [g[:2] + g[3:] for g in got2] == [g[:2] + g[3:] for g in got]
+
+
+def test_join_groupby_build_left_fused(pl):
+    """Left input shorter -> it is the build side; aggregates read the right (probe) input."""
+    rng = np.random.default_rng(32)
+    lk = rng.permutation(50_000)[:2_000].astype(np.int32)
+    lname = rng.integers(0, 9, 2_000).astype(np.int64)
+    rk = rng.integers(0, 50_000, 60_000).astype(np.int32)
+    rv = rng.integers(-5, 5, 60_000).astype(np.int64)
+    L = pl.DataFrame({"k": lk, "name": lname})
+    R = pl.DataFrame({"k": rk, "v": rv})
+    out = L.lazy().join(R.lazy().filter(pl.col("v") != 0), on="k").group_by("k", "name").agg(pl.col("v").sum().alias("s"), pl.col("v").min().alias("mn"), pl.len().alias("n")).collect()
+    assert "FusedJoinGroupBy{build=left" in pl.last_plan(), pl.last_plan()
+    d = out.to_dict()
+    got = sorted(zip(d["k"], d["name"], d["s"], d["mn"], d["n"]))
+    name_of = dict(zip(lk.tolist(), lname.tolist()))
+    import collections
+    acc = collections.defaultdict(list)
+    for k, v in zip(rk.tolist(), rv.tolist()):
+        if v != 0 and k in name_of:
+            acc[k].append(v)
+    exp = sorted((k, name_of[k], sum(v), min(v), len(v)) for k, v in acc.items())
+    assert got == exp
+    assert out.schema == {"k": pl.Int32, "name": pl.Int64, "s": pl.Int64, "mn": pl.Int64, "n": pl.UInt32}
+
+
+def test_fused_int_floor_div_mod_null_on_zero(pl):
+    """x // 0 and x % 0 are null (signed.rs:35-70) -> a null predicate drops the row; Python sign rules."""
+    rng = np.random.default_rng(33)
+    n = 100_003
+    a = rng.integers(-1000, 1000, n).astype(np.int64)
+    b = rng.integers(-3, 4, n).astype(np.int64)
+    a[:4] = [-2**63, -2**63, 2**63 - 1, 7]; b[:4] = [-1, 2, -1, 0]
+    df = pl.DataFrame({"a": a, "b": b})
+    q = df.lazy().filter(((pl.col("a") % pl.col("b")) == 1) | ((pl.col("a") // pl.col("b")) < -400)).select(pl.col("a").sum().alias("s"), pl.len().alias("n"), (pl.col("a") // pl.col("b")).min().alias("qmin"))
+    o1 = q.collect(); p1 = pl.last_plan(); o2 = q.collect(no_fusion=True)
+    assert "fused_scan" in p1, p1
+    nz = b != 0
+    with np.errstate(all="ignore"):
+        fm = np.where(nz, np.mod(a, np.where(nz, b, 1)), 0)
+        fd = np.where(nz, np.floor_divide(a, np.where(nz, b, 1)), 0)
+    fd[0] = -2**63      # wrapping_div(MIN, -1)
+    keep = nz & ((fm == 1) | (fd < -400))
+    exp = (int(a[keep].sum()), int(keep.sum()), int(fd[keep].min()))
+    assert o1.rows() == [exp] and o2.rows() == [exp]

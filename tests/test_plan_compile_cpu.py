@@ -47,6 +47,9 @@ def test_unfusable_shapes_report_a_reason():
     df = pl.DataFrame([ph("a", pl.Int64), ph("b", pl.Int64)])
     q = df.lazy().filter(pl.col("a") // pl.col("b") > 3).select(pl.col("a").sum())
     fusable, sid, why, _ = q.describe_fusion()
+    assert fusable, why           # 64-bit integer floor-div / mod run inside the fused program (divisor 0 -> null)
+    dfx = pl.DataFrame([ph("x", pl.Float64), ph("y", pl.Float64)])
+    fusable, sid, why, _ = dfx.lazy().filter(pl.col("x") // pl.col("y") > 3.0).select(pl.col("x").sum()).describe_fusion()
     assert not fusable and "floor-div" in why
     q = df.lazy().select(pl.col("a").sum(), pl.col("b"))
     fusable, sid, why, _ = q.describe_fusion()
