@@ -1,0 +1,75 @@
+"""Worker of tests/test_dist_gloo_cpu.py: one process per rank, gloo backend, CPU tensors.
+The per-rank compute is an oracle-backed LocalOps (test infrastructure) -- what is under test
+is polars_amd.dist: key-hash routing with one all-to-all, partial/final aggregate
+decomposition, variable-length all-gather."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as orc  # noqa: E402
+from polars_amd import dist as pdist  # noqa: E402
+
+AGG = {"sum": orc.AGG_SUM, "count": orc.AGG_COUNT, "len": orc.AGG_LEN, "min": orc.AGG_MIN, "max": orc.AGG_MAX}
+
+
+class OracleLocalOps(pdist.LocalOps):
+    def hash_partition(self, key, n_parts, seed=0):
+        p = orc.hash_partition(key.numpy(), None, n_parts, seed)
+        perm = np.argsort(p, kind="stable")
+        return torch.from_numpy(perm.astype(np.int64)), np.bincount(p, minlength=n_parts).tolist()
+
+    def groupby_partial(self, keys, values, aggs):
+        ks = [k.numpy() for k in keys.values()]
+        spec = []
+        for out, col, op in aggs:
+            v = values[col].numpy() if col else None
+            if op == "sum_f64":
+                spec.append((out, orc.AGG_SUM, v.astype(np.float64), None))
+            else:
+                spec.append((out, AGG[op], v, None))
+        r = orc.q_groupby(ks, [None] * len(ks), spec)
+        res = {name: torch.from_numpy(np.ascontiguousarray(r[f"key_{i}"][0])) for i, name in enumerate(keys)}
+        for out, _, _ in aggs:
+            a = r[out][0]
+            res[out] = torch.from_numpy(np.ascontiguousarray(a.astype(np.int64) if a.dtype == np.uint32 else a))
+        return res
+
+
+def main():
+    pdist.init_process_group("gloo")
+    rank, ws = dist.get_rank(), dist.get_world_size()
+    ops = OracleLocalOps()
+    out_dir = sys.argv[1]
+    # every rank owns a different row shard of the same logical table
+    rng = np.random.default_rng(1000 + rank)
+    n = 20_000 + 1000 * rank
+    key = torch.from_numpy(rng.integers(0, 3000, n).astype(np.int64))
+    flag = torch.from_numpy(rng.integers(0, 3, n).astype(np.int64))
+    v = torch.from_numpy(rng.integers(-50, 50, n).astype(np.int64))
+    x = torch.from_numpy(rng.uniform(0, 1, n))
+    aggs = [("s", "v", "sum"), ("m", "x", "mean"), ("mn", "v", "min"), ("mx", "x", "max"), ("n", "", "len")]
+    # (a) exchange_by_key: every row lands on the rank its key hashes to, nothing lost
+    moved = pdist.exchange_by_key(ops, key, {"key": key, "v": v})
+    owner = orc.hash_partition(moved["key"].numpy(), None, ws, 0)
+    assert (owner == rank).all(), "row routed to the wrong rank"
+    tot = torch.tensor([moved["key"].numel(), int(moved["v"].sum())], dtype=torch.int64)
+    mine = torch.tensor([n, int(v.sum())], dtype=torch.int64)
+    dist.all_reduce(tot); dist.all_reduce(mine)
+    assert torch.equal(tot, mine), "rows or values lost in the all-to-all"
+    # (b) low-cardinality group-by: local partials + all-gather + combine (replicated result)
+    g = pdist.groupby_agg(ops, {"flag": flag}, {"v": v, "x": x}, aggs, mode="gather")
+    # (c) high-cardinality group-by: shuffle by key hash, result sharded by key
+    s = pdist.groupby_agg(ops, {"key": key}, {"v": v, "x": x}, aggs, mode="shuffle")
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), key=key.numpy(), flag=flag.numpy(), v=v.numpy(), x=x.numpy(),
+             **{f"g_{k}": t.numpy() for k, t in g.items()}, **{f"s_{k}": t.numpy() for k, t in s.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
