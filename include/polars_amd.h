@@ -280,6 +280,11 @@ int plx_frame_free(plx_frame f);
 int plx_frame_shape(plx_frame f, int64_t* height, int32_t* width);
 /* name_out points into library-owned storage valid until the frame is freed. */
 int plx_frame_column(plx_frame f, int32_t i, const char** name_out, plx_column* col_out);
+/* dtypes_out[width] (plx_dtype) of the frame's columns. */
+int plx_frame_dtypes(plx_frame f, int32_t* dtypes_out);
+/* Download every column with one stream synchronisation: values_out[i] / validity_out[i] as in
+ * plx_column_to_host (validity_out[i] may be NULL), has_validity_out[width]. */
+int plx_frame_to_host(plx_frame f, void* const* values_out, uint8_t* const* validity_out, int32_t* has_validity_out);
 
 /* ---- plan execution (Executor seam) ------------------------------------ */
 typedef enum plx_aexpr_kind {

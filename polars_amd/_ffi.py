@@ -135,6 +135,8 @@ SIGNATURES = {
     "plx_frame_free": (C.c_int, [C.c_uint64]),
     "plx_frame_shape": (C.c_int, [C.c_uint64, _i64p, _i32p]),
     "plx_frame_column": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_char_p), _u64p]),
+    "plx_frame_dtypes": (C.c_int, [C.c_uint64, _i32p]),
+    "plx_frame_to_host": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i32p]),
     "plx_execute_plan": (C.c_int, [C.POINTER(IR), C.c_int32, C.POINTER(AExpr), C.c_int32, C.c_int32, C.c_uint32, _u64p]),
     "plx_describe_fusion": (C.c_int, [C.POINTER(IR), C.c_int32, C.POINTER(AExpr), C.c_int32, C.c_int32, _i32p, _i32p, C.c_char_p, C.c_size_t]),
     "plx_last_plan_description": (C.c_char_p, []),

@@ -330,6 +330,32 @@ int plx_frame_column(plx_frame f, int32_t i, const char** name_out, plx_column* 
   PLX_CATCH
 }
 
+int plx_frame_dtypes(plx_frame f, int32_t* dtypes_out) {
+  PLX_TRY
+  FramePtr fr = get_frame(f);
+  PLX_REQUIRE(dtypes_out || fr->cols.empty(), PLX_ERR_INVALID, "null pointer");
+  for (size_t i = 0; i < fr->cols.size(); i++) dtypes_out[i] = fr->cols[i]->dtype;
+  PLX_CATCH
+}
+int plx_frame_to_host(plx_frame f, void* const* values_out, uint8_t* const* validity_out, int32_t* has_validity_out) {
+  PLX_TRY
+  FramePtr fr = get_frame(f);
+  for (size_t i = 0; i < fr->cols.size(); i++) {
+    const ColumnPtr& c = fr->cols[i];
+    PLX_REQUIRE(c->values || c->len == 0, PLX_ERR_INVALID, "placeholder column has no data");
+    const size_t vb = c->dtype == PLX_BOOL ? (size_t)((c->len + 7) / 8) : (size_t)c->len * dtype_width(c->dtype);
+    const size_t nb = (size_t)((c->len + 7) / 8);
+    if (values_out && values_out[i] && vb) PLX_HIP(hipMemcpyAsync(values_out[i], c->values->ptr, vb, hipMemcpyDeviceToHost, stream()));
+    if (validity_out && validity_out[i] && nb) {
+      if (c->validity) PLX_HIP(hipMemcpyAsync(validity_out[i], c->validity->ptr, nb, hipMemcpyDeviceToHost, stream()));
+      else memset(validity_out[i], 0xff, nb);
+    }
+    if (has_validity_out) has_validity_out[i] = c->validity ? 1 : 0;
+  }
+  PLX_HIP(hipStreamSynchronize(stream()));
+  PLX_CATCH
+}
+
 // ---- plans -------------------------------------------------------------------------
 int plx_execute_plan(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int32_t n_exprs, int32_t root, uint32_t flags, plx_frame* out) {
   PLX_TRY

@@ -501,6 +501,7 @@ class Compiler {
 struct KeyPart {
   int expr = -1;
   int dtype = 0;
+  bool nullable = false;   // the key expression can be null (=> the output key column carries a validity bitmap)
   KeyDecode dec{};
 };
 struct KeyPlan {
@@ -529,6 +530,7 @@ static KeyPlan lower_keys(Compiler& c, const std::vector<int>& key_exprs) {
     KeyPart part; part.expr = e; part.dtype = infer_dtype(plan, e, *c.df);
     knodes[i] = c.lower(e);
     info[i].nullable = c.nodes[knodes[i]].nullable;
+    part.nullable = info[i].nullable;
     const AE* x = &plan.ae[e];
     while (x->kind == PLX_AE_ALIAS) x = &plan.ae[x->lhs];
     if (part.dtype == PLX_BOOL) { info[i].have_range = true; info[i].mn = 0; info[i].mx = 1; }
@@ -621,6 +623,20 @@ static double estimate_groups(double d, double S) {
   return hi;
 }
 
+// occupied slots of an aggregation table -> dense (packed key, valid flag, cells) arrays in `res`.
+// Small tables are compacted in ONE pass into slot-count-sized outputs (no count pass, one sync).
+static int64_t compact_into(const uint64_t* keys, const uint64_t* acc, int64_t n_slots, int64_t cap, int n_aggs, int occ_agg, FusedAggResult& res) {
+  int64_t upper = n_slots;
+  if (n_slots > (int64_t(1) << 16)) upper = k::table_compact(keys, acc, n_slots, cap, n_aggs, occ_agg, nullptr, nullptr, nullptr);
+  const int64_t g1 = std::max<int64_t>(upper, 1);
+  res.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)g1);
+  res.key_valid = dev_alloc((size_t)g1);
+  res.acc = dev_alloc(sizeof(uint64_t) * (size_t)g1 * n_aggs);
+  const int64_t g = k::table_compact(keys, acc, n_slots, cap, n_aggs, occ_agg, res.packed_keys->as<uint64_t>(), res.key_valid->as<uint8_t>(), res.acc->as<uint64_t>());
+  res.n_groups = g; res.n_aggs = n_aggs;
+  return g;
+}
+
 static int64_t run_hash_agg(const Shape& sh, const Args& args, int static_id, int log2_cap, int len_idx, FusedAggResult& out, bool count_only) {
   const uint64_t cap = 1ull << log2_cap;
   const int64_t slots = (int64_t)cap + 2;
@@ -635,15 +651,8 @@ static int64_t run_hash_agg(const Shape& sh, const Args& args, int static_id, in
   uint32_t o = 0; d2h_sync(&o, ovf->ptr, 4);
   if (o) return -1;
   if (count_only) return k::table_compact(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, nullptr, nullptr, nullptr);
-  // compact: upper bound on groups = occupied slots; allocate by counting first
-  int64_t g = k::table_compact(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, nullptr, nullptr, nullptr);
-  out.n_groups = g; out.n_aggs = sh.n_aggs;
-  out.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1));
-  out.key_valid = dev_alloc(std::max<int64_t>(g, 1));
-  out.acc = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1) * sh.n_aggs);
-  k::table_compact(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, out.packed_keys->as<uint64_t>(), out.key_valid->as<uint8_t>(), out.acc->as<uint64_t>());
   (void)len_idx;
-  return g;
+  return compact_into(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, out);
 }
 
 static int64_t run_wide_agg(const Shape& sh, const Args& args, int log2_cap, bool nullable, FusedAggResult& out, bool count_only) {
@@ -685,12 +694,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     Buf cells = dev_alloc(sizeof(uint64_t) * (size_t)G * sh.n_aggs);
     k::fused_lds_agg(sh, args, G, static_id, cells->as<uint64_t>());
     desc += std::string("fused_scan[") + (static_id >= 0 ? "aot" : "generic") + "]+lds_table(G=" + std::to_string(G) + ",copies=" + std::to_string(k::lds_agg_copies(G, sh.n_aggs)) + ")";
-    int64_t g = k::table_compact(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, nullptr, nullptr, nullptr);
-    res.n_groups = g;
-    res.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1));
-    res.key_valid = dev_alloc(std::max<int64_t>(g, 1));
-    res.acc = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1) * sh.n_aggs);
-    k::table_compact(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, res.packed_keys->as<uint64_t>(), res.key_valid->as<uint8_t>(), res.acc->as<uint64_t>());
+    compact_into(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, res);
     res.key_valid = nullptr;  // packed keys carry their own null codes
     return;
   }
@@ -701,12 +705,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     DenseTable t; t.acc = cells->as<unsigned long long>(); t.key_min = 0; t.n_groups = G;
     k::fused_dense_agg(sh, args, t, static_id);
     desc += std::string("fused_scan[") + (static_id >= 0 ? "aot" : "generic") + "]+dense_hbm_table(G=" + std::to_string(G) + ")";
-    int64_t g = k::table_compact(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, nullptr, nullptr, nullptr);
-    res.n_groups = g;
-    res.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1));
-    res.key_valid = dev_alloc(std::max<int64_t>(g, 1));
-    res.acc = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(g, 1) * sh.n_aggs);
-    k::table_compact(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, res.packed_keys->as<uint64_t>(), res.key_valid->as<uint8_t>(), res.acc->as<uint64_t>());
+    compact_into(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, res);
     res.key_valid = nullptr;
     return;
   }
@@ -736,7 +735,9 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
   fail(PLX_ERR_OOM, "group-by hash table kept overflowing");
 }
 
-static ColumnPtr finalize_column(const FusedAggResult& r, const FinalSpec& fs) {
+// Output columns are allocated here and filled by ONE finalize_batch launch per query
+// (was one launch per key and per aggregate: ~10 launches + 2 popcount syncs for TPC-H Q1).
+static ColumnPtr finalize_column(const FusedAggResult& r, const FinalSpec& fs, FinBatch& batch) {
   const int64_t G = r.n_groups;
   auto out = std::make_shared<Column>();
   out->dtype = fs.out_dtype; out->len = G;
@@ -745,24 +746,32 @@ static ColumnPtr finalize_column(const FusedAggResult& r, const FinalSpec& fs) {
   if (nullable) out->validity = dev_alloc_zero(bitmap_bytes(G)); else out->null_count = 0;
   FinalSpec f = fs;
   if (fs.kind == FIN_COPY64 && dtype_width(fs.out_dtype) < 4) f.kind = FIN_NARROW;
-  k::finalize_aggs(r.acc->as<uint64_t>(), r.n_aggs, G, f, out->values->ptr, nullable ? out->validity->as<uint64_t>() : nullptr);
+  PLX_REQUIRE(batch.n < kMaxFinJobs, PLX_ERR_UNSUPPORTED, "too many output columns in one fused aggregation");
+  FinJob& j = batch.jobs[batch.n++];
+  j = FinJob{};
+  j.is_key = 0; j.fs = f; j.out = out->values->ptr; j.out_valid = nullable ? out->validity->as<uint64_t>() : nullptr;
   return out;
 }
 
-static ColumnPtr decode_key_column(const FusedAggResult& r, const KeyPart& part, int key_index) {
+static ColumnPtr decode_key_column(const FusedAggResult& r, const KeyPart& part, int key_index, FinBatch& batch) {
   const int64_t G = r.n_groups;
   auto out = std::make_shared<Column>();
   out->dtype = part.dtype; out->len = G;
   out->values = part.dtype == PLX_BOOL ? dev_alloc_zero(bitmap_bytes(G)) : dev_alloc(values_bytes(part.dtype, G));
-  out->validity = dev_alloc_zero(bitmap_bytes(G));
+  if (part.nullable) out->validity = dev_alloc_zero(bitmap_bytes(G)); else out->null_count = 0;   // a null key forms its own group
   KeyDecode kd = part.dec;
   if (part.dtype == PLX_F32) kd.dtype = PLX_F32;
-  if (r.wide_words)
-    k::decode_key(r.wide_words->as<uint64_t>() + (size_t)key_index * r.wide_stride, r.wide_valid->as<uint8_t>() + (size_t)key_index * r.wide_stride, G, kd,
-                  out->values->ptr, out->validity->as<uint64_t>());
-  else
-    k::decode_key(r.packed_keys->as<uint64_t>(), r.key_valid ? r.key_valid->as<uint8_t>() : nullptr, G, kd, out->values->ptr, out->validity->as<uint64_t>());
-  if (column_null_count(out) == 0) { out->validity = nullptr; out->null_count = 0; }
+  PLX_REQUIRE(batch.n < kMaxFinJobs, PLX_ERR_UNSUPPORTED, "too many output columns in one fused aggregation");
+  FinJob& j = batch.jobs[batch.n++];
+  j = FinJob{};
+  j.is_key = 1; j.kd = kd; j.out = out->values->ptr; j.out_valid = part.nullable ? out->validity->as<uint64_t>() : nullptr;
+  if (r.wide_words) {
+    j.packed = r.wide_words->as<unsigned long long>() + (size_t)key_index * r.wide_stride;
+    j.kvalid = r.wide_valid->as<unsigned char>() + (size_t)key_index * r.wide_stride;
+  } else {
+    j.packed = r.packed_keys->as<unsigned long long>();
+    j.kvalid = r.key_valid ? r.key_valid->as<unsigned char>() : nullptr;
+  }
   return out;
 }
 
@@ -805,7 +814,9 @@ static bool fused_select(Plan& plan, const IRN& node, const std::vector<int>& pr
   PLX_HIP(hipStreamSynchronize(stream()));
   plan.desc += std::string("FusedFilterAgg{fused_scan[") + (static_id >= 0 ? "aot" : "generic") + "]+register_sink, inputs=" + std::to_string(c.shape.n_inputs) + ", ops=" + std::to_string(c.shape.n_ops) + ", aggs=" + std::to_string(c.shape.n_aggs) + "}; ";
   std::map<int, ColumnPtr> overrides;
-  for (size_t i = 0; i < agg_nodes.size(); i++) overrides[agg_nodes[i]] = finalize_column(r, specs[i]);
+  FinBatch batch{};
+  for (size_t i = 0; i < agg_nodes.size(); i++) overrides[agg_nodes[i]] = finalize_column(r, specs[i], batch);
+  k::finalize_batch(r.acc->as<uint64_t>(), r.n_aggs, r.n_groups, batch);
   out = std::make_shared<Frame>();
   out->height = 1;
   Frame one; one.height = 1;
@@ -846,9 +857,11 @@ static bool fused_groupby(Plan& plan, const IRN& node, const std::vector<int>& p
   plan.desc += "FusedFilterGroupBy{" + d + ", inputs=" + std::to_string(c.shape.n_inputs) + ", ops=" + std::to_string(c.shape.n_ops) + ", aggs=" + std::to_string(c.shape.n_aggs) + ", groups=" + std::to_string(r.n_groups) + "}; ";
   out = std::make_shared<Frame>();
   out->height = r.n_groups;
-  for (size_t pi = 0; pi < kp.parts.size(); pi++) { out->names.push_back(output_name(plan, kp.parts[pi].expr)); out->cols.push_back(decode_key_column(r, kp.parts[pi], (int)pi)); }
+  FinBatch batch{};
+  for (size_t pi = 0; pi < kp.parts.size(); pi++) { out->names.push_back(output_name(plan, kp.parts[pi].expr)); out->cols.push_back(decode_key_column(r, kp.parts[pi], (int)pi, batch)); }
   std::map<int, ColumnPtr> overrides;
-  for (size_t i = 0; i < agg_nodes.size(); i++) overrides[agg_nodes[i]] = finalize_column(r, specs[i]);
+  for (size_t i = 0; i < agg_nodes.size(); i++) overrides[agg_nodes[i]] = finalize_column(r, specs[i], batch);
+  k::finalize_batch(r.acc->as<uint64_t>(), r.n_aggs, r.n_groups, batch);
   Frame gframe; gframe.height = r.n_groups;
   for (int e : node.exprs) {
     Evaluated ev = eval(plan, e, gframe, &overrides);
@@ -1003,16 +1016,18 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   // ---- output frame: keys, then aggregates
   out = std::make_shared<Frame>();
   out->height = G;
+  FinBatch batch{};
   for (auto& gk : gkeys) {
     out->names.push_back(output_name(plan, gk.expr));
     if (gk.is_join_key) {
       KeyPart part; part.expr = gk.expr; part.dtype = gk.dtype;
       part.dec.shift = 0; part.dec.mask = ~0ull; part.dec.min = 0; part.dec.null_code = ~0ull; part.dec.dtype = gk.dtype;
-      out->cols.push_back(decode_key_column(r, part, 0));
+      out->cols.push_back(decode_key_column(r, part, 0, batch));
     } else out->cols.push_back(ops::gather(B->cols[gk.build_col], rows));
   }
   std::map<int, ColumnPtr> overrides;
-  for (size_t i = 0; i < agg_nodes.size(); i++) overrides[agg_nodes[i]] = finalize_column(r, specs[i]);
+  for (size_t i = 0; i < agg_nodes.size(); i++) overrides[agg_nodes[i]] = finalize_column(r, specs[i], batch);
+  k::finalize_batch(r.acc->as<uint64_t>(), r.n_aggs, G, batch);
   Frame gframe; gframe.height = G;
   for (int e : gb.exprs) {
     Evaluated ev = eval(plan, e, gframe, &overrides);

@@ -123,6 +123,22 @@ struct KeyDecode {
   int32_t dtype;        // output plx_dtype
 };
 
+// ---- batched result finalisation: every output column of a query in ONE launch ---------------
+constexpr int kMaxFinJobs = 24;
+struct FinJob {
+  uint8_t is_key;                     // 1: decode a group key (kd, packed, kvalid); 0: finalise an aggregate (fs)
+  FinalSpec fs;
+  KeyDecode kd;
+  const unsigned long long* packed;
+  const unsigned char* kvalid;
+  void* out;
+  uint64_t* out_valid;                // may be null
+};
+struct FinBatch {
+  int32_t n;
+  FinJob jobs[kMaxFinJobs];
+};
+
 // ---- AOT specialisation table ---------------------------------------------------
 // Index into kStaticShapes (fused_shapes.hpp); -1 = run the generic interpreter.
 int find_static_shape(const Shape& s);

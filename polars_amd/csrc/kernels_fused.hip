@@ -211,14 +211,28 @@ __device__ __forceinline__ void exec_op(const Op op, const Shape& sh, const Args
         break;
       case OP_FDIV_I: case OP_MOD_I: {
         uint32_t nz = 0;
+        // 64-bit integer division is a ~100-instruction software routine on gfx950; when every lane's
+        // operands are non-negative and fit 31 bits (wave-uniform test) the 32-bit divide gives the same result.
+        bool narrow = true;
 #pragma unroll
-        for (int r = 0; r < kRows; r++) {
-          const long long x = (long long)a[r], y = (long long)b[r];
-          long long q = 0, m = 0;
-          if (y == -1) { q = (long long)(0ull - (unsigned long long)x); m = 0; }   // wrapping_div(MIN, -1) = MIN
-          else if (y != 0) { q = x / y; m = x % y; if (m != 0 && ((x < 0) != (y < 0))) { q -= 1; m += y; } }
-          d[r] = (uint64_t)(op.code == OP_FDIV_I ? q : m);
-          nz |= (uint32_t)(y != 0) << r;
+        for (int r = 0; r < kRows; r++) narrow = narrow && (((a[r] | b[r]) >> 31) == 0);
+        if (__all(narrow)) {
+#pragma unroll
+          for (int r = 0; r < kRows; r++) {
+            const uint32_t x = (uint32_t)a[r], y = (uint32_t)b[r];
+            d[r] = y ? (uint64_t)(op.code == OP_FDIV_I ? x / y : x % y) : 0ull;
+            nz |= (uint32_t)(y != 0) << r;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < kRows; r++) {
+            const long long x = (long long)a[r], y = (long long)b[r];
+            long long q = 0, m = 0;
+            if (y == -1) { q = (long long)(0ull - (unsigned long long)x); m = 0; }   // wrapping_div(MIN, -1) = MIN
+            else if (y != 0) { q = x / y; m = x % y; if (m != 0 && ((x < 0) != (y < 0))) { q -= 1; m += y; } }
+            d[r] = (uint64_t)(op.code == OP_FDIV_I ? q : m);
+            nz |= (uint32_t)(y != 0) << r;
+          }
         }
         vd &= nz;
       } break;
@@ -984,6 +998,58 @@ __global__ __launch_bounds__(kBlock) void hash_compact_kernel(const unsigned lon
 }
 
 // ---- aggregate cells -> typed output column ------------------------------------------------
+// one aggregate cell row -> one output element; returns validity
+__device__ __forceinline__ bool finalize_one(const unsigned long long* cell, const FinalSpec& sp, void* out, int64_t g) {
+  bool valid = true;
+  switch (sp.kind) {
+    case FIN_COPY64: reinterpret_cast<uint64_t*>(out)[g] = cell[sp.a]; break;
+    case FIN_TRUNC32: reinterpret_cast<uint32_t*>(out)[g] = (uint32_t)cell[sp.a]; break;
+    case FIN_NARROW:
+      if (dtype_width_dev(sp.out_dtype) == 1) reinterpret_cast<uint8_t*>(out)[g] = (uint8_t)cell[sp.a];
+      else reinterpret_cast<uint16_t*>(out)[g] = (uint16_t)cell[sp.a];
+      break;
+    case FIN_MEAN: {
+      const uint64_t cnt = cell[sp.b];
+      valid = cnt != 0;
+      double m = valid ? as_f(cell[sp.a]) / (double)cnt : 0.0;
+      if (sp.out_dtype == PLX_F32) reinterpret_cast<float*>(out)[g] = (float)m; else reinterpret_cast<double*>(out)[g] = m;
+    } break;
+    case FIN_MINMAX_I: {
+      valid = cell[sp.b] != 0;
+      const uint64_t v = valid ? cell[sp.a] : 0;
+      switch (dtype_width_dev(sp.out_dtype)) {
+        case 1: reinterpret_cast<uint8_t*>(out)[g] = (uint8_t)v; break;
+        case 2: reinterpret_cast<uint16_t*>(out)[g] = (uint16_t)v; break;
+        case 4: reinterpret_cast<uint32_t*>(out)[g] = (uint32_t)v; break;
+        default: reinterpret_cast<uint64_t*>(out)[g] = v; break;
+      }
+    } break;
+    default: {  // FIN_MINMAX_F
+      valid = cell[sp.b] != 0;
+      double v = valid ? as_f(cell[sp.a]) : 0.0;
+      if (valid && cell[sp.c] == 0) v = __longlong_as_double(0x7ff8000000000000ll);
+      reinterpret_cast<double*>(out)[g] = v;
+    } break;
+  }
+  return valid;
+}
+// packed key (+ per-group valid flag) -> one key element; `bit` receives the value of a boolean key
+__device__ __forceinline__ bool decode_one(const unsigned long long* packed, const unsigned char* kvalid, const KeyDecode& kd, void* out, int64_t g, bool& bit) {
+  const uint64_t code = (packed[g] >> kd.shift) & kd.mask;
+  const bool valid = (!kvalid || kvalid[g]) && (kd.mask == ~0ull || code != kd.null_code);
+  const uint64_t v = valid ? code + (uint64_t)kd.min : 0;
+  bit = valid && (v & 1);
+  switch (kd.dtype) {
+    case PLX_BOOL: break;  // written through a ballot by the caller
+    case PLX_I8: case PLX_U8: reinterpret_cast<uint8_t*>(out)[g] = (uint8_t)v; break;
+    case PLX_I16: case PLX_U16: reinterpret_cast<uint16_t*>(out)[g] = (uint16_t)v; break;
+    case PLX_I32: case PLX_U32: reinterpret_cast<uint32_t*>(out)[g] = (uint32_t)v; break;
+    case PLX_F32: { double d = as_f(v); reinterpret_cast<float*>(out)[g] = (float)d; } break;
+    default: reinterpret_cast<uint64_t*>(out)[g] = v; break;
+  }
+  return valid;
+}
+
 __global__ __launch_bounds__(kBlock) void finalize_kernel(const unsigned long long* __restrict__ acc, int n_aggs, int64_t G, FinalSpec sp,
                                                           void* __restrict__ out, uint64_t* __restrict__ out_valid) {
   const int lane = lane_id();
@@ -993,42 +1059,31 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const unsigned long lo
   for (int64_t w = wave; w < nwords; w += nwaves) {
     const int64_t g = w * 64 + lane;
     bool valid = false;
-    if (g < G) {
-      const unsigned long long* cell = acc + (size_t)g * n_aggs;
-      valid = true;
-      switch (sp.kind) {
-        case FIN_COPY64: reinterpret_cast<uint64_t*>(out)[g] = cell[sp.a]; break;
-        case FIN_TRUNC32: reinterpret_cast<uint32_t*>(out)[g] = (uint32_t)cell[sp.a]; break;
-        case FIN_NARROW:
-          if (dtype_width_dev(sp.out_dtype) == 1) reinterpret_cast<uint8_t*>(out)[g] = (uint8_t)cell[sp.a];
-          else reinterpret_cast<uint16_t*>(out)[g] = (uint16_t)cell[sp.a];
-          break;
-        case FIN_MEAN: {
-          const uint64_t cnt = cell[sp.b];
-          valid = cnt != 0;
-          double m = valid ? as_f(cell[sp.a]) / (double)cnt : 0.0;
-          if (sp.out_dtype == PLX_F32) reinterpret_cast<float*>(out)[g] = (float)m; else reinterpret_cast<double*>(out)[g] = m;
-        } break;
-        case FIN_MINMAX_I: {
-          valid = cell[sp.b] != 0;
-          const uint64_t v = valid ? cell[sp.a] : 0;
-          switch (dtype_width_dev(sp.out_dtype)) {
-            case 1: reinterpret_cast<uint8_t*>(out)[g] = (uint8_t)v; break;
-            case 2: reinterpret_cast<uint16_t*>(out)[g] = (uint16_t)v; break;
-            case 4: reinterpret_cast<uint32_t*>(out)[g] = (uint32_t)v; break;
-            default: reinterpret_cast<uint64_t*>(out)[g] = v; break;
-          }
-        } break;
-        default: {  // FIN_MINMAX_F
-          valid = cell[sp.b] != 0;
-          double v = valid ? as_f(cell[sp.a]) : 0.0;
-          if (valid && cell[sp.c] == 0) v = __longlong_as_double(0x7ff8000000000000ll);
-          reinterpret_cast<double*>(out)[g] = v;
-        } break;
-      }
-    }
+    if (g < G) valid = finalize_one(acc + (size_t)g * n_aggs, sp, out, g);
     if (out_valid) { uint64_t m = ballot(valid); if (lane == 0) out_valid[w] = m; }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void finalize_batch_kernel(const unsigned long long* __restrict__ acc, int n_aggs, int64_t G, FinBatch b) {
+  const int lane = lane_id();
+  const int64_t nwords = (G + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t w = wave; w < nwords; w += nwaves) {
+    const int64_t g = w * 64 + lane;
+    for (int j = 0; j < b.n; j++) {   // wave-uniform job list (kernel arguments)
+      const FinJob& job = b.jobs[j];
+      bool valid = false, bit = false;
+      if (g < G) valid = job.is_key ? decode_one(job.packed, job.kvalid, job.kd, job.out, g, bit) : finalize_one(acc + (size_t)g * n_aggs, job.fs, job.out, g);
+      if (job.is_key && job.kd.dtype == PLX_BOOL) { uint64_t bb = ballot(bit); if (lane == 0) reinterpret_cast<uint64_t*>(job.out)[w] = bb; }
+      if (job.out_valid) { uint64_t m = ballot(valid); if (lane == 0) job.out_valid[w] = m; }
+    }
+  }
+}
+void finalize_batch(const uint64_t* acc, int n_aggs, int64_t G, const FinBatch& b) {
+  if (G == 0 || b.n == 0) return;
+  hipLaunchKernelGGL(finalize_batch_kernel, dim3(grid_for(G, kBlock)), dim3(kBlock), 0, stream(), (const unsigned long long*)acc, n_aggs, G, b);
+  PLX_HIP(hipGetLastError());
 }
 void finalize_aggs(const uint64_t* acc, int n_aggs, int64_t G, const FinalSpec& sp, void* out, uint64_t* out_valid) {
   if (G == 0) return;
@@ -1046,20 +1101,7 @@ __global__ __launch_bounds__(kBlock) void decode_key_kernel(const unsigned long 
   for (int64_t w = wave; w < nwords; w += nwaves) {
     const int64_t g = w * 64 + lane;
     bool valid = false, bit = false;
-    if (g < G) {
-      const uint64_t code = (packed[g] >> kd.shift) & kd.mask;
-      valid = (!kvalid || kvalid[g]) && (kd.mask == ~0ull || code != kd.null_code);
-      const uint64_t v = valid ? code + (uint64_t)kd.min : 0;
-      bit = valid && (v & 1);
-      switch (kd.dtype) {
-        case PLX_BOOL: break;  // written through the ballot below
-        case PLX_I8: case PLX_U8: reinterpret_cast<uint8_t*>(out)[g] = (uint8_t)v; break;
-        case PLX_I16: case PLX_U16: reinterpret_cast<uint16_t*>(out)[g] = (uint16_t)v; break;
-        case PLX_I32: case PLX_U32: reinterpret_cast<uint32_t*>(out)[g] = (uint32_t)v; break;
-        case PLX_F32: { double d = as_f(v); reinterpret_cast<float*>(out)[g] = (float)d; } break;
-        default: reinterpret_cast<uint64_t*>(out)[g] = v; break;
-      }
-    }
+    if (g < G) valid = decode_one(packed, kvalid, kd, out, g, bit);
     if (kd.dtype == PLX_BOOL) { uint64_t b = ballot(bit); if (lane == 0) reinterpret_cast<uint64_t*>(out)[w] = b; }
     if (out_valid) { uint64_t m = ballot(valid); if (lane == 0) out_valid[w] = m; }
   }

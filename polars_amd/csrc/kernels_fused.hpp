@@ -40,6 +40,8 @@ int64_t table_compact(const uint64_t* keys, const uint64_t* acc, int64_t n_slots
 
 // aggregate cells [G][n_aggs] -> typed output column (+ validity bitmap, may be null)
 void finalize_aggs(const uint64_t* acc, int n_aggs, int64_t G, const fused::FinalSpec& sp, void* out, uint64_t* out_valid);
+// all jobs of a batch (key decodes + aggregate finalisations) in one launch
+void finalize_batch(const uint64_t* acc, int n_aggs, int64_t G, const fused::FinBatch& b);
 // packed group keys -> one key column
 void decode_key(const uint64_t* packed, const uint8_t* kvalid, int64_t G, const fused::KeyDecode& kd, void* out, uint64_t* out_valid);
 

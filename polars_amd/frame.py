@@ -433,8 +433,44 @@ class DataFrame:
         return self.lazy().join(other.lazy(), on=on, how=how, left_on=left_on, right_on=right_on, suffix=suffix).collect()
 
     # -- host export --------------------------------------------------------------------------------
+    def _download_all(self):
+        """[(values, validity or None)] for every column with ONE device synchronisation
+        (plx_frame_to_host)."""
+        ncol = len(self._cols)
+        if ncol == 0:
+            return []
+        fh = self._frame_handle()
+        h = C.c_int64()
+        F.check(F.lib().plx_frame_shape(fh, C.byref(h), None))
+        n = h.value
+        vbufs, mbufs = [], []
+        for c in self._cols:
+            phys = c.dtype.physical
+            vbufs.append(np.zeros((n + 7) // 8 + 8, dtype=np.uint8) if phys == F.BOOL else np.zeros(n, dtype=T.PHYSICAL_TO_DTYPE[phys].np_dtype))
+            mbufs.append(np.zeros((n + 7) // 8 + 8, dtype=np.uint8))
+        vp = (C.c_void_p * ncol)(*[b.ctypes.data for b in vbufs])
+        mp = (C.c_void_p * ncol)(*[b.ctypes.data for b in mbufs])
+        hv = (C.c_int32 * ncol)()
+        F.check(F.lib().plx_frame_to_host(fh, vp, mp, hv))
+        out = []
+        for i, c in enumerate(self._cols):
+            values = np.unpackbits(vbufs[i], bitorder="little")[:n].astype(bool) if c.dtype.physical == F.BOOL else vbufs[i]
+            valid = np.unpackbits(mbufs[i], bitorder="little")[:n].astype(bool) if hv[i] else None
+            if valid is not None and valid.all():
+                valid = None
+            out.append((values, valid))
+        return out
+
     def to_dict(self) -> Dict[str, list]:
-        return {c.name: c.to_list() for c in self._cols}
+        res = {}
+        for c, (values, valid) in zip(self._cols, self._download_all()):
+            out = values.tolist()
+            if isinstance(c.dtype, T.Categorical) and c.dtype.categories:
+                out = [c.dtype.categories[x] if x < len(c.dtype.categories) else None for x in out]
+            if valid is not None:
+                out = [v if ok else None for v, ok in zip(out, valid.tolist())]
+            res[c.name] = out
+        return res
 
     def rows(self) -> List[tuple]:
         cols = [c.to_list() for c in self._cols]
