@@ -344,6 +344,7 @@ typedef struct plx_ir {
 
 /* plan flags */
 #define PLX_PLAN_NO_FUSION 1u /* force one kernel per node (reference-shaped execution) */
+#define PLX_PLAN_NO_DIRECT_JOIN 2u /* fused join->aggregate: always use the hash table, never the direct-address table */
 
 /* Build the physical plan for IR node `root` and execute it. The output frame is
  * owned by the caller (plx_frame_free). PLX_ERR_UNSUPPORTED means: run this

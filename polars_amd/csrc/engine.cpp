@@ -986,6 +986,44 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   // ---- run
   uint64_t nb = 0;
   if (B->height > 0) { std::vector<uint64_t> host(kMaxAggs, 0); k::fused_regagg(cnt.shape, cnt.args, find_static_shape(cnt.shape), host.data()); nb = host[0]; }
+  const int probe_static_id = find_static_shape(cp.shape);
+  FusedAggResult r; r.n_aggs = cp.shape.n_aggs;
+  auto rows = std::make_shared<Column>();
+  rows->dtype = PLX_U32; rows->null_count = 0;
+  int64_t G = 0;
+  bool done = false;
+  // -- direct-address table when the build key range is small (cached column statistics)
+  int64_t kmn = 0, kmx = 0;
+  if (!(plan.flags & PLX_PLAN_NO_DIRECT_JOIN) && nb > 0 && kdt != PLX_U64 && ops::int_range(B->cols[bki], &kmn, &kmx)) {
+    const unsigned __int128 range128 = (unsigned __int128)((__int128)kmx - (__int128)kmn) + 1;
+    if (range128 <= ((unsigned __int128)1 << 32) && range128 <= (unsigned __int128)B->height * 64 && nb < 0xfffffff0ull) {
+      const uint64_t range = (uint64_t)range128;
+      Buf dir = dev_alloc(sizeof(uint32_t) * range), okey = dev_alloc(sizeof(uint64_t) * nb), orow = dev_alloc(sizeof(uint32_t) * nb), ctr = dev_alloc_zero(16), fl2 = dev_alloc_zero(16);
+      Buf acc2 = dev_alloc(sizeof(uint64_t) * nb * cp.shape.n_aggs);
+      PLX_HIP(hipMemsetAsync(dir->ptr, 0xff, sizeof(uint32_t) * range, stream()));
+      DirectJoinTable dt; dt.dir = dir->as<unsigned int>(); dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>();
+      dt.counter = ctr->as<unsigned int>(); dt.flags = fl2->as<unsigned int>(); dt.acc = acc2->as<unsigned long long>(); dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)nb;
+      k::fused_direct_build(cb.shape, cb.args, dt, find_static_shape(cb.shape));
+      uint32_t f2[2] = {0, 0};
+      d2h_sync(f2, fl2->ptr, 8);
+      if (f2[0]) return no("build keys are not unique");
+      PLX_REQUIRE(!f2[1], PLX_ERR_INVALID, "direct join build: ordinal overflow");
+      k::init_agg_cells(acc2->as<uint64_t>(), (int64_t)nb, cp.shape);
+      k::fused_direct_probe_agg(cp.shape, cp.args, dt, probe_static_id);
+      G = k::direct_agg_compact(dt, (int64_t)nb, r.n_aggs, len_idx, nullptr, nullptr, nullptr);
+      const int64_t g1 = std::max<int64_t>(G, 1);
+      r.n_groups = G;
+      r.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)g1);
+      r.acc = dev_alloc(sizeof(uint64_t) * (size_t)g1 * r.n_aggs);
+      rows->len = G; rows->values = dev_alloc(values_bytes(PLX_U32, g1));
+      if (G) k::direct_agg_compact(dt, (int64_t)nb, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
+      plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " direct-address table range=" +
+                   std::to_string(range) + " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + (probe_static_id >= 0 ? "aot" : "generic") + "]+probe_agg, aggs=" +
+                   std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
+      done = true;
+    }
+  }
+  if (!done) {
   const int log2_cap = std::max(4, ceil_log2_u64(std::max<uint64_t>(nb, 1) * 2));
   const uint64_t cap = 1ull << log2_cap;
   Buf keys = dev_alloc(sizeof(uint64_t) * (cap + 1)), head = dev_alloc(sizeof(uint32_t) * (cap + 1)), flags = dev_alloc_zero(16);
@@ -1000,19 +1038,17 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   if (fl[0]) return no("build keys are not unique");
   PLX_REQUIRE(!fl[1], PLX_ERR_OOM, "join build: probe sequence overflow");
   k::init_agg_cells(acc->as<uint64_t>(), (int64_t)cap + 1, cp.shape);
-  const int static_id = find_static_shape(cp.shape);
-  k::fused_probe_agg(cp.shape, cp.args, t, static_id);
-  FusedAggResult r; r.n_aggs = cp.shape.n_aggs;
-  const int64_t G = k::join_agg_compact(t, r.n_aggs, len_idx, nullptr, nullptr, nullptr);
+  k::fused_probe_agg(cp.shape, cp.args, t, probe_static_id);
+  G = k::join_agg_compact(t, r.n_aggs, len_idx, nullptr, nullptr, nullptr);
   r.n_groups = G;
   const int64_t g1 = std::max<int64_t>(G, 1);
   r.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)g1);
   r.acc = dev_alloc(sizeof(uint64_t) * (size_t)g1 * r.n_aggs);
-  auto rows = std::make_shared<Column>();
-  rows->dtype = PLX_U32; rows->len = G; rows->values = dev_alloc(values_bytes(PLX_U32, g1)); rows->null_count = 0;
+  rows->len = G; rows->values = dev_alloc(values_bytes(PLX_U32, g1));
   if (G) k::join_agg_compact(t, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
-  plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " cap=2^" + std::to_string(log2_cap) +
-               " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + (static_id >= 0 ? "aot" : "generic") + "]+probe_agg, aggs=" + std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
+  plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " hash table cap=2^" + std::to_string(log2_cap) +
+               " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + (probe_static_id >= 0 ? "aot" : "generic") + "]+probe_agg, aggs=" + std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
+  }  // hash-table path
   // ---- output frame: keys, then aggregates
   out = std::make_shared<Frame>();
   out->height = G;

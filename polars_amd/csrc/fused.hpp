@@ -186,6 +186,22 @@ struct JoinAggTable {
   uint32_t log2_cap;
 };
 
+// Direct-address ("perfect hash") variant of the fused join -> aggregate table, used when the build
+// key range is small (max - min + 1 <= a few x the build rows, e.g. TPC-H orderkeys): dir[key - kmin]
+// holds the ordinal of the build row, so probes of a key-ordered probe side are sequential reads
+// instead of one ~128-B fabric transfer per random probe.  ord_key / ord_row / acc are indexed by ordinal.
+struct DirectJoinTable {
+  unsigned int* dir;             // [range] ordinal or kNoRow32
+  unsigned long long* ord_key;   // [n_build_passing]
+  unsigned int* ord_row;         // [n_build_passing]
+  unsigned int* counter;         // [0] next ordinal
+  unsigned int* flags;           // [0] duplicate build key, [1] ordinal overflow
+  unsigned long long* acc;       // [n_build_passing * n_aggs]
+  long long kmin;
+  unsigned long long range;
+  unsigned int n_ord;            // capacity of the ordinal arrays
+};
+
 // Direct-address aggregation (dense keys in [key_min, key_min + n_groups)): acc[(G+1)*n_aggs],
 // slot G = null key.
 struct DenseTable {

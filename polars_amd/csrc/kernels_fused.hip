@@ -38,7 +38,13 @@
   case SHAPE_Q3_PROBE: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_PROBE>, ProbeAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
 #define PLX_STATIC_REGAGG_EXTRA_CASES \
   case SHAPE_Q3_COUNT: PLX_LAUNCH_SCAN(StatProg<SHAPE_Q3_COUNT>, RegAggSink, grid, 0, sh, args, sp); break;
+#define PLX_STATIC_DIRECT_BUILD_CASES \
+  case SHAPE_Q3_BUILD: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_BUILD>, DirectBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+#define PLX_STATIC_DIRECT_PROBE_CASES \
+  case SHAPE_Q3_PROBE: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_PROBE>, DirectProbeAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
 #else
+#define PLX_STATIC_DIRECT_BUILD_CASES
+#define PLX_STATIC_DIRECT_PROBE_CASES
 #define PLX_STATIC_JOIN_BUILD_CASES
 #define PLX_STATIC_PROBE_AGG_CASES
 #define PLX_STATIC_REGAGG_EXTRA_CASES
@@ -625,24 +631,25 @@ struct JoinBuildSink {
     for (int r = 0; r < kRows; r++) {
       if (!pass[r] || !((rf.valid[sh.key] >> r) & 1)) continue;  // null keys never match
       const uint64_t key = rf.v[r][sh.key];
-      uint64_t slot;
-      if (key == kEmptyKey) { slot = cap; p.keys[cap] = 0; }
-      else {
-        slot = (key * 0x55fbfd6bfc5458e9ull) >> (64 - p.log2_cap);
-        uint32_t probe = 0;
-        for (;; probe++) {
-          unsigned long long cur = p.keys[slot];
-          if (cur == key) break;
-          if (cur == kEmptyKey) {
-            const unsigned long long old = atomicCAS(&p.keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
-            if (old == kEmptyKey || old == key) break;
-          }
-          slot = (slot + 1) & (cap - 1);
-          if (probe > (1u << 16)) { p.flags[1] = 1u; break; }
-        }
+      // One atomic per build row: the CAS winner owns the slot and stores its row with a plain store;
+      // meeting the same key again means the build keys are not unique -> flag, the caller falls back.
+      if (key == kEmptyKey) {
+        const unsigned int old = atomicExch(&p.head[cap], (unsigned int)(row0 + r));
+        if (old != kNoRow32) p.flags[0] = 1u;
+        continue;
       }
-      const unsigned int old = atomicExch(&p.head[slot], (unsigned int)(row0 + r));
-      if (old != kNoRow32) p.flags[0] = 1u;
+      uint64_t slot = (key * 0x55fbfd6bfc5458e9ull) >> (64 - p.log2_cap);
+      for (uint32_t probe = 0;; probe++) {
+        const unsigned long long cur = p.keys[slot];
+        if (cur == key) { p.flags[0] = 1u; break; }
+        if (cur == kEmptyKey) {
+          const unsigned long long old = atomicCAS(&p.keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
+          if (old == kEmptyKey) { p.head[slot] = (unsigned int)(row0 + r); break; }
+          if (old == key) { p.flags[0] = 1u; break; }
+        }
+        slot = (slot + 1) & (cap - 1);
+        if (probe > (1u << 16)) { p.flags[1] = 1u; break; }
+      }
     }
   }
 };
@@ -670,6 +677,51 @@ struct ProbeAggSink {
       }
       if (slot < 0) continue;
       atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
+    }
+  }
+};
+
+
+struct DirectBuildSink {
+  using Params = DirectJoinTable;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      const bool ins = pass[r] && ((rf.valid[sh.key] >> r) & 1);
+      // wave-aggregated ordinal allocation: one device atomic per wave-row
+      const uint64_t m = ballot(ins);
+      if (m == 0) continue;
+      unsigned int base = 0;
+      if (lane_id() == __ffsll((long long)m) - 1) base = atomicAdd(p.counter, (unsigned int)popc64(m));
+      base = __shfl(base, __ffsll((long long)m) - 1, 64);
+      if (!ins) continue;
+      const unsigned int ord = base + (unsigned int)prefix_rank(m);
+      if (ord >= p.n_ord) { p.flags[1] = 1u; continue; }
+      const uint64_t key = rf.v[r][sh.key];
+      const uint64_t idx = key - (uint64_t)p.kmin;       // < range by construction (kmin/kmax cover the whole build column)
+      p.ord_key[ord] = key;
+      p.ord_row[ord] = (unsigned int)(row0 + r);
+      const unsigned int old = atomicCAS(&p.dir[idx], kNoRow32, ord);
+      if (old != kNoRow32) p.flags[0] = 1u;               // duplicate build key -> the caller falls back
+    }
+  }
+};
+
+struct DirectProbeAggSink {
+  using Params = DirectJoinTable;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r] || !((rf.valid[sh.key] >> r) & 1)) continue;
+      const uint64_t idx = rf.v[r][sh.key] - (uint64_t)p.kmin;
+      if (idx >= p.range) continue;
+      const unsigned int ord = p.dir[idx];
+      if (ord == kNoRow32) continue;
+      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)ord * sh.n_aggs);
     }
   }
 };
@@ -948,6 +1000,50 @@ void fused_probe_agg(const Shape& sh, const Args& args, const JoinAggTable& t, i
   }
   PLX_HIP(hipGetLastError());
 }
+
+void fused_direct_build(const Shape& sh, const Args& args, const DirectJoinTable& t, int static_id) {
+  if (args.n_rows == 0) return;
+  ProfileScope ps(static_id >= 0 ? "fused_scan_direct_build_static" : "fused_scan_direct_build", algo_bytes(sh, args), (uint64_t)args.n_rows);
+  const int grid = scan_grid(args.n_rows, 8);
+  switch (static_id) {
+    PLX_STATIC_DIRECT_BUILD_CASES
+    default: hipLaunchKernelGGL((fused_scan_kernel<DynProg, DirectBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+  }
+  PLX_HIP(hipGetLastError());
+}
+void fused_direct_probe_agg(const Shape& sh, const Args& args, const DirectJoinTable& t, int static_id) {
+  if (args.n_rows == 0) return;
+  ProfileScope ps(static_id >= 0 ? "fused_scan_direct_probe_agg_static" : "fused_scan_direct_probe_agg", algo_bytes(sh, args), (uint64_t)args.n_rows);
+  const int grid = scan_grid(args.n_rows, 8);
+  switch (static_id) {
+    PLX_STATIC_DIRECT_PROBE_CASES
+    default: hipLaunchKernelGGL((fused_scan_kernel<DynProg, DirectProbeAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+  }
+  PLX_HIP(hipGetLastError());
+}
+__global__ __launch_bounds__(kBlock) void direct_agg_compact_kernel(DirectJoinTable t, int64_t n_ord, int n_aggs, int len_idx, unsigned long long* __restrict__ counter,
+                                                                    unsigned long long* __restrict__ out_keys, unsigned int* __restrict__ out_rows,
+                                                                    unsigned long long* __restrict__ out_acc) {
+  compact_slots(n_ord, counter, [&](int64_t s) { return t.acc[(size_t)s * n_aggs + len_idx] != 0; },
+                [&](int64_t s, uint64_t o) {
+                  if (!out_keys) return;
+                  out_keys[o] = t.ord_key[s];
+                  out_rows[o] = t.ord_row[s];
+                  for (int k = 0; k < n_aggs; k++) out_acc[o * n_aggs + k] = t.acc[(size_t)s * n_aggs + k];
+                });
+}
+int64_t direct_agg_compact(const DirectJoinTable& t, int64_t n_ord, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc) {
+  if (n_ord == 0) return 0;
+  Buf counter = dev_alloc_zero(8);
+  ProfileScope ps("table_compact", (uint64_t)n_ord * 8 * (uint64_t)(2 + n_aggs), (uint64_t)n_ord);
+  hipLaunchKernelGGL(direct_agg_compact_kernel, dim3(compact_grid(n_ord)), dim3(kBlock), 0, stream(), t, n_ord, n_aggs, len_idx, counter->as<unsigned long long>(),
+                     (unsigned long long*)out_keys, (unsigned int*)out_rows, (unsigned long long*)out_acc);
+  PLX_HIP(hipGetLastError());
+  uint64_t n = 0;
+  d2h_sync(&n, counter->ptr, 8);
+  return (int64_t)n;
+}
+
 __global__ __launch_bounds__(kBlock) void join_agg_compact_kernel(JoinAggTable t, int n_aggs, int len_idx, unsigned long long* __restrict__ counter,
                                                                   unsigned long long* __restrict__ out_keys, unsigned int* __restrict__ out_rows,
                                                                   unsigned long long* __restrict__ out_acc) {

@@ -29,6 +29,10 @@ void fused_join_build(const fused::Shape& sh, const fused::Args& args, const fus
 void fused_probe_agg(const fused::Shape& sh, const fused::Args& args, const fused::JoinAggTable& t, int static_id);
 // slots whose AGG_LEN cell (len_idx) is non-zero -> out_keys (u64), out_rows (u32 build row), out_acc; nullptr outputs = count only
 int64_t join_agg_compact(const fused::JoinAggTable& t, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc);
+// direct-address variants (DirectJoinTable)
+void fused_direct_build(const fused::Shape& sh, const fused::Args& args, const fused::DirectJoinTable& t, int static_id);
+void fused_direct_probe_agg(const fused::Shape& sh, const fused::Args& args, const fused::DirectJoinTable& t, int static_id);
+int64_t direct_agg_compact(const fused::DirectJoinTable& t, int64_t n_ord, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc);
 void fill_u64(uint64_t* p, int64_t n, uint64_t v);
 void init_agg_cells(uint64_t* acc, int64_t n_slots, const fused::Shape& sh);
 // Gather occupied table slots into dense arrays; returns the group count (synchronises).

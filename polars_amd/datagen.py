@@ -66,23 +66,26 @@ def lineitem_host(n_rows: int, seed: int = 10) -> Dict[str, np.ndarray]:
     return _line_columns_host(rng, ship)
 
 
-def orders_lineitem_host(n_orders: int, seed: int = 10) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
+def orders_lineitem_host(n_orders: int, seed: int = 10, ordered: bool = False) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
     """orders (sparse keys: 8 of every 32 used) and its lineitem (1-7 lines per order,
-    l_shipdate = o_orderdate + U[1,121] days)."""
+    l_shipdate = o_orderdate + U[1,121] days).  ordered=True keeps dbgen's row order (both tables
+    ascending in orderkey); the default shuffles both tables (adversarial for hash probing)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     i = np.arange(n_orders, dtype=np.int64)
     okey = (i // 8) * 32 + (i % 8) + 1
-    perm = rng.permutation(n_orders)     # orders are not stored in key order
-    okey = okey[perm]
+    if not ordered:
+        okey = okey[rng.permutation(n_orders)]
     odate = START + rng.integers(0, (END_ORDERS - START) // DAY_US + 1, n_orders, dtype=np.int64) * DAY_US
     orders = {"o_orderkey": okey, "o_custkey": rng.integers(1, max(2, n_orders // 10) + 1, n_orders, dtype=np.int64),
               "o_orderdate": odate, "o_shippriority": np.zeros(n_orders, dtype=np.int64)}
     cnt = rng.integers(1, 8, n_orders)
     lkey = np.repeat(okey, cnt)
     ship = np.repeat(odate, cnt) + rng.integers(1, 122, len(lkey), dtype=np.int64) * DAY_US
-    shuffle = rng.permutation(len(lkey))
-    li = _line_columns_host(rng, ship[shuffle])
-    li["l_orderkey"] = lkey[shuffle]
+    if not ordered:
+        shuffle = rng.permutation(len(lkey))
+        lkey, ship = lkey[shuffle], ship[shuffle]
+    li = _line_columns_host(rng, ship)
+    li["l_orderkey"] = lkey
     return orders, li
 
 
@@ -140,21 +143,27 @@ def lineitem_device(n_rows: int, seed: int = 10, device: str = "cuda"):
     return _line_columns_device(torch, g, ship)
 
 
-def orders_lineitem_device(n_orders: int, seed: int = 10, device: str = "cuda"):
+def orders_lineitem_device(n_orders: int, seed: int = 10, device: str = "cuda", ordered: bool = True):
+    """Device-resident orders / lineitem.  ordered=True (default) = dbgen row order: orders ascending in
+    o_orderkey, lineitem ascending in l_orderkey -- what TPC-H / PDS-H data looks like; ordered=False
+    shuffles both tables."""
     import torch
     g = torch.Generator(device=device); g.manual_seed(seed)
     i = torch.arange(n_orders, device=device, dtype=torch.int64)
     okey = (i // 8) * 32 + (i % 8) + 1
-    okey = okey[torch.randperm(n_orders, generator=g, device=device)]
+    if not ordered:
+        okey = okey[torch.randperm(n_orders, generator=g, device=device)]
     odate = START + torch.randint(0, (END_ORDERS - START) // DAY_US + 1, (n_orders,), generator=g, device=device, dtype=torch.int64) * DAY_US
     orders = {"o_orderkey": okey, "o_custkey": torch.randint(1, max(2, n_orders // 10) + 1, (n_orders,), generator=g, device=device, dtype=torch.int64),
               "o_orderdate": odate, "o_shippriority": torch.zeros(n_orders, device=device, dtype=torch.int64)}
     cnt = torch.randint(1, 8, (n_orders,), generator=g, device=device, dtype=torch.int64)
     lkey = torch.repeat_interleave(okey, cnt)
     ship = torch.repeat_interleave(odate, cnt) + torch.randint(1, 122, (lkey.numel(),), generator=g, device=device, dtype=torch.int64) * DAY_US
-    shuffle = torch.randperm(lkey.numel(), generator=g, device=device)
-    lkey, ship = lkey[shuffle], ship[shuffle]
-    del shuffle, cnt
+    if not ordered:
+        shuffle = torch.randperm(lkey.numel(), generator=g, device=device)
+        lkey, ship = lkey[shuffle], ship[shuffle]
+        del shuffle
+    del cnt
     n = lkey.numel()
     qty = torch.randint(1, 51, (n,), generator=g, device=device, dtype=torch.int64)
     price = torch.round(qty.to(torch.float64) * torch.randint(90_000, 210_000, (n,), generator=g, device=device, dtype=torch.int64).to(torch.float64)) / 100.0

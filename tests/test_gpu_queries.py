@@ -101,10 +101,11 @@ def test_q1(pl, orc, n):
     assert out.schema["sum_qty"] == pl.Int64 and out.schema["count_order"] == pl.UInt32 and out.schema["avg_qty"] == pl.Float64
 
 
+@pytest.mark.parametrize("ordered", [False, True])
 @pytest.mark.parametrize("n_orders", [0, 10, 5000, 150_000])
-def test_q3(pl, orc, n_orders):
+def test_q3(pl, orc, n_orders, ordered):
     from polars_amd import datagen, queries
-    orders, li = datagen.orders_lineitem_host(n_orders, seed=22)
+    orders, li = datagen.orders_lineitem_host(n_orders, seed=22, ordered=ordered)
     L = datagen.to_frame(pl, li, datagen.LINEITEM_Q3_COLS)
     O = datagen.to_frame(pl, orders, datagen.ORDERS_Q3_COLS)
     exp = orc.q3({k: li[k] for k in datagen.LINEITEM_Q3_COLS}, {k: orders[k] for k in datagen.ORDERS_Q3_COLS}, datagen.us(1995, 3, 15))
@@ -112,11 +113,18 @@ def test_q3(pl, orc, n_orders):
         out = queries.q3(L.lazy(), O.lazy()).collect(no_fusion=nf)
         if n_orders:
             assert ("FusedJoinGroupBy" in pl.last_plan()) == (not nf), pl.last_plan()
+            if not nf and n_orders > 10:
+                assert "direct-address table" in pl.last_plan(), pl.last_plan()   # orderkey range = 4x the order count
         g = out.sort_host("l_orderkey")
         assert g["l_orderkey"] == exp["l_orderkey"].tolist(), pl.last_plan()
         assert g["o_orderdate"] == exp["o_orderdate"].tolist() and g["o_shippriority"] == exp["o_shippriority"].tolist()
         assert close(g["revenue"], exp["revenue"])
     assert out.columns == ["l_orderkey", "o_orderdate", "o_shippriority", "revenue"]
+    if n_orders:   # the hash-table variant of the fused pipeline must agree too
+        out = queries.q3(L.lazy(), O.lazy()).collect(no_direct_join=True)
+        assert "hash table cap" in pl.last_plan(), pl.last_plan()
+        g = out.sort_host("l_orderkey")
+        assert g["l_orderkey"] == exp["l_orderkey"].tolist() and g["o_orderdate"] == exp["o_orderdate"].tolist() and close(g["revenue"], exp["revenue"])
 
 
 def test_generic_interpreter_matches_aot(pl, orc):
@@ -290,3 +298,32 @@ def test_fused_int_floor_div_mod_null_on_zero(pl):
     keep = nz & ((fm == 1) | (fd < -400))
     exp = (int(a[keep].sum()), int(keep.sum()), int(fd[keep].min()))
     assert o1.rows() == [exp] and o2.rows() == [exp]
+
+
+def test_join_groupby_direct_address_edge_keys(pl):
+    """Direct-address join table: negative key range, probe keys outside [kmin, kmax], null keys on both
+    sides, i32 keys; must agree with the hash-table variant and with numpy."""
+    rng = np.random.default_rng(34)
+    nb, npr = 5_000, 80_000
+    bk = (rng.permutation(20_000)[:nb] - 10_000).astype(np.int32)            # unique, range 20k <= 64 * nb
+    bv = rng.uniform(size=nb) > 0.03
+    pay = rng.integers(0, 7, nb).astype(np.int64)
+    pk = rng.integers(-15_000, 15_000, npr).astype(np.int32)                # some outside the build range
+    pv = rng.uniform(size=npr) > 0.03
+    x = rng.integers(-9, 9, npr).astype(np.int64)
+    B = pl.DataFrame([pl.Series("k", bk, validity=bv), pl.Series("pay", pay)])
+    P = pl.DataFrame([pl.Series("k", pk, validity=pv), pl.Series("x", x)])
+    q = P.lazy().filter(pl.col("x") != 0).join(B.lazy().filter(pl.col("pay") < 6), on="k").group_by("k", "pay").agg(pl.col("x").sum().alias("s"), pl.len().alias("n"))
+    o1 = q.collect(); p1 = pl.last_plan()
+    o2 = q.collect(no_direct_join=True); p2 = pl.last_plan()
+    assert "direct-address table" in p1 and "hash table cap" in p2, (p1, p2)
+    row_of = {int(k): j for j, k in enumerate(bk.tolist()) if bv[j] and pay[j] < 6}
+    import collections
+    acc = collections.defaultdict(lambda: [0, 0])
+    for k, ok, xv in zip(pk.tolist(), pv.tolist(), x.tolist()):
+        if ok and xv != 0 and k in row_of:
+            a = acc[k]; a[0] += xv; a[1] += 1
+    exp = sorted((k, int(pay[row_of[k]]), v[0], v[1]) for k, v in acc.items())
+    for o in (o1, o2):
+        d = o.to_dict()
+        assert sorted(zip(d["k"], d["pay"], d["s"], d["n"])) == exp
