@@ -998,25 +998,31 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     const unsigned __int128 range128 = (unsigned __int128)((__int128)kmx - (__int128)kmn) + 1;
     if (range128 <= ((unsigned __int128)1 << 32) && range128 <= (unsigned __int128)B->height * 64 && nb < 0xfffffff0ull) {
       const uint64_t range = (uint64_t)range128;
-      Buf dir = dev_alloc(sizeof(uint32_t) * range), okey = dev_alloc(sizeof(uint64_t) * nb), orow = dev_alloc(sizeof(uint32_t) * nb), ctr = dev_alloc_zero(16), fl2 = dev_alloc_zero(16);
-      Buf acc2 = dev_alloc(sizeof(uint64_t) * nb * cp.shape.n_aggs);
+      // ordinals are reserved in per-wave chunks of 1024 (kOrdChunk): capacity = passing rows + one chunk per wave
+      const uint64_t ord_cap = nb + (uint64_t)k::scan_waves(B->height) * 1024 + 1024;
+      PLX_REQUIRE(ord_cap < 0xfffffff0ull, PLX_ERR_UNSUPPORTED, "direct join: too many build rows");
+      Buf dir = dev_alloc(sizeof(uint32_t) * range), okey = dev_alloc(sizeof(uint64_t) * ord_cap), orow = dev_alloc(sizeof(uint32_t) * ord_cap), ctr = dev_alloc_zero(16), fl2 = dev_alloc_zero(16);
+      Buf acc2 = dev_alloc(sizeof(uint64_t) * ord_cap * cp.shape.n_aggs);
       PLX_HIP(hipMemsetAsync(dir->ptr, 0xff, sizeof(uint32_t) * range, stream()));
       DirectJoinTable dt; dt.dir = dir->as<unsigned int>(); dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>();
-      dt.counter = ctr->as<unsigned int>(); dt.flags = fl2->as<unsigned int>(); dt.acc = acc2->as<unsigned long long>(); dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)nb;
+      dt.counter = ctr->as<unsigned int>(); dt.flags = fl2->as<unsigned int>(); dt.acc = acc2->as<unsigned long long>(); dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)ord_cap;
+      k::init_agg_cells(acc2->as<uint64_t>(), (int64_t)ord_cap, cp.shape);   // LEN = 0 everywhere: unused ordinals never show up
       k::fused_direct_build(cb.shape, cb.args, dt, find_static_shape(cb.shape));
       uint32_t f2[2] = {0, 0};
       d2h_sync(f2, fl2->ptr, 8);
       if (f2[0]) return no("build keys are not unique");
       PLX_REQUIRE(!f2[1], PLX_ERR_INVALID, "direct join build: ordinal overflow");
-      k::init_agg_cells(acc2->as<uint64_t>(), (int64_t)nb, cp.shape);
+      uint32_t n_used = 0;
+      d2h_sync(&n_used, ctr->ptr, 4);
+      const int64_t n_ord_used = (int64_t)std::min<uint64_t>(n_used, ord_cap);
       k::fused_direct_probe_agg(cp.shape, cp.args, dt, probe_static_id);
-      G = k::direct_agg_compact(dt, (int64_t)nb, r.n_aggs, len_idx, nullptr, nullptr, nullptr);
+      G = k::direct_agg_compact(dt, n_ord_used, r.n_aggs, len_idx, nullptr, nullptr, nullptr);
       const int64_t g1 = std::max<int64_t>(G, 1);
       r.n_groups = G;
       r.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)g1);
       r.acc = dev_alloc(sizeof(uint64_t) * (size_t)g1 * r.n_aggs);
       rows->len = G; rows->values = dev_alloc(values_bytes(PLX_U32, g1));
-      if (G) k::direct_agg_compact(dt, (int64_t)nb, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
+      if (G) k::direct_agg_compact(dt, n_ord_used, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
       plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " direct-address table range=" +
                    std::to_string(range) + " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + (probe_static_id >= 0 ? "aot" : "generic") + "]+probe_agg, aggs=" +
                    std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
