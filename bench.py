@@ -168,25 +168,36 @@ def roofline(stats, kernel_prefix):
 
 
 def cpu_baseline_q1(seconds: float):
-    """The CPU oracle (a restatement of the reference's algorithms, NOT Polars) on all host cores,
-    on a bounded sample of the same workload."""
+    """TPC-H Q1 on the host cores with the CPU oracle -- a C++ restatement of the reference's algorithms
+    (NOT Polars itself: no polars wheel / rustc in the image), on a bounded sample of the same workload.
+    Timed: orc_q1_streaming, the morsel-driven partitioned group-by the reference dispatches this shape to
+    (GroupByStreamingExec); also reported: orc_q1, the in-memory FilterExec -> GroupByExec sequence."""
     import numpy as np
     from oracle import pyoracle as orc
     from polars_amd import datagen
     cores = orc.hardware_threads()
     orc.set_threads(cores)
     cutoff = datagen.us(1998, 9, 2)
-    probe = datagen.lineitem_host(1_000_000, seed=99)
-    t0 = time.perf_counter(); orc.q1({k: probe[k] for k in datagen.LINEITEM_Q1_COLS}, cutoff); t1 = time.perf_counter()
-    rate = 1_000_000 / max(t1 - t0, 1e-6)
-    n = int(min(max(rate * seconds, 2_000_000), 60_000_000))
+    probe = datagen.lineitem_host(4_000_000, seed=99)
+    pc = {k: probe[k] for k in datagen.LINEITEM_Q1_COLS}
+    t0 = time.perf_counter(); orc.q1_native(pc, cutoff, streaming=True); t1 = time.perf_counter()
+    rate = 4_000_000 / max(t1 - t0, 1e-6)
+    n = int(min(max(rate * seconds, 8_000_000), 200_000_000))
     li = datagen.lineitem_host(n, seed=98)
     cols = {k: li[k] for k in datagen.LINEITEM_Q1_COLS}
-    t0 = time.perf_counter(); orc.q1(cols, cutoff); dt = time.perf_counter() - t0
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter(); orc.q1_native(cols, cutoff, streaming=True); dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    n_mem = min(n, 16_000_000)
+    cm = {k: v[:n_mem] for k, v in cols.items()}
+    t0 = time.perf_counter(); orc.q1_native(cm, cutoff, streaming=False); dt_mem = time.perf_counter() - t0
     orc.set_threads(1)
-    return {"value": round(n / dt, 1), "unit": "rows/s", "cores": cores, "kind": "port", "seconds": round(dt, 2),
-            "sample": f"TPC-H Q1 on {n} synthetic lineitem rows (same generator), oracle/plx_oracle.cpp with {cores} threads; "
-                      "CPU restatement of the Polars in-memory algorithms, not Polars itself (no polars wheel / rustc in the image)"}
+    return {"value": round(n / best, 1), "unit": "rows/s", "cores": cores, "kind": "port", "seconds": round(best, 3),
+            "in_memory_engine_rows_per_s": round(n_mem / dt_mem, 1),
+            "sample": f"TPC-H Q1 on {n} synthetic lineitem rows (same generator, best of 3), oracle/plx_oracle.cpp orc_q1_streaming with {cores} threads: "
+                      "C++ restatement of the reference's streaming/partitioned group-by path (morsels, thread-local hot tables), not Polars itself; "
+                      f"in_memory_engine_rows_per_s = orc_q1 (FilterExec -> GroupByExec with per-group index lists) on {n_mem} rows"}
 
 
 def main():

@@ -868,3 +868,157 @@ int orc_hash_partition(const uint64_t* keys, const uint8_t* valid, int64_t n, in
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// TPC-H Q1 end to end in the reference's operator order, without any Python between the steps
+// (this is what bench.py's cpu_baseline times):
+//   FilterExec      predicate bitmap (comparisons/simd.rs), then every column filtered; the frame is
+//                   split into one chunk per thread and the chunks are filtered in parallel
+//                   (polars-mem-engine/src/executors/filter.rs:60-114), then re-assembled
+//   expressions     1 - disc, price * (.), 1 + tax, (.) * (.)  -- one materialised column per
+//                   BinaryExpr node (polars-expr/src/expressions/binary.rs:48-123)
+//   GroupByExec     groups = (first, [idx...]) per distinct (flag, status) via partition-by-hash over
+//                   threads (group_by/hashing.rs:116-167), then one aggregation per expression over
+//                   the index lists (aggregations/mod.rs:854-1018), rayon over groups
+// Outputs: up to `cap` groups, unsorted.  Returns the group count.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+static std::vector<T> filter_parallel(const T* v, const uint8_t* mask, int64_t n) {
+  int nt = std::max(1, g_threads);
+  int64_t per = ((n + nt - 1) / nt + 63) / 64 * 64;
+  if (per == 0) per = 64;
+  nt = (int)((n + per - 1) / per);
+  std::vector<std::vector<T>> parts((size_t)std::max(nt, 1));
+  parallel_tasks(nt, [&](int t) {
+    int64_t b = per * t, e = std::min<int64_t>(n, b + per);
+    parts[t].resize((size_t)(e - b));
+    int64_t w = scalar_filter<T>(v + b, mask + b / 8, e - b, parts[t].data());
+    parts[t].resize((size_t)w);
+  });
+  std::vector<int64_t> off((size_t)nt + 1, 0);
+  for (int t = 0; t < nt; t++) off[t + 1] = off[t] + (int64_t)parts[t].size();
+  std::vector<T> out((size_t)off[nt]);
+  parallel_tasks(nt, [&](int t) { if (!parts[t].empty()) memcpy(out.data() + off[t], parts[t].data(), parts[t].size() * sizeof(T)); });
+  return out;
+}
+
+extern "C" int64_t orc_q1(const int64_t* shipdate, const uint8_t* flag, const uint8_t* status, const int64_t* qty, const double* price,
+                          const double* disc, const double* tax, int64_t n, int64_t cutoff, int cap, uint8_t* o_flag, uint8_t* o_status,
+                          int64_t* o_sum_qty, double* o_sum_base, double* o_sum_disc_price, double* o_sum_charge, double* o_avg_qty,
+                          double* o_avg_price, double* o_avg_disc, uint32_t* o_count) {
+  // FilterExec
+  std::vector<uint8_t> mask((size_t)((n + 63) / 64 * 8 + 8), 0);
+  int64_t c = cutoff;
+  cmp_impl<int64_t>(LE, shipdate, &c, true, n, mask.data());
+  auto f_flag = filter_parallel<uint8_t>(flag, mask.data(), n);
+  auto f_status = filter_parallel<uint8_t>(status, mask.data(), n);
+  auto f_qty = filter_parallel<int64_t>(qty, mask.data(), n);
+  auto f_price = filter_parallel<double>(price, mask.data(), n);
+  auto f_disc = filter_parallel<double>(disc, mask.data(), n);
+  auto f_tax = filter_parallel<double>(tax, mask.data(), n);
+  const int64_t m = (int64_t)f_qty.size();
+  // expression nodes, one materialised column each
+  std::vector<double> one_minus((size_t)m), disc_price((size_t)m), one_plus((size_t)m), charge((size_t)m);
+  int he = 0; double one = 1.0;
+  arith_impl<double>(SUB, &one, f_disc.data(), 2, m, one_minus.data(), nullptr, &he);
+  arith_impl<double>(MUL, f_price.data(), one_minus.data(), 0, m, disc_price.data(), nullptr, &he);
+  arith_impl<double>(ADD, &one, f_tax.data(), 2, m, one_plus.data(), nullptr, &he);
+  arith_impl<double>(MUL, disc_price.data(), one_plus.data(), 0, m, charge.data(), nullptr, &he);
+  // GroupByExec on (flag, status)
+  std::vector<uint64_t> k0((size_t)m), k1((size_t)m);
+  parallel_ranges(m, 64, [&](int64_t b, int64_t e, int) { for (int64_t i = b; i < e; i++) { k0[i] = f_flag[i]; k1[i] = f_status[i]; } });
+  const uint64_t* keys[2] = {k0.data(), k1.data()};
+  const uint8_t* valids[2] = {nullptr, nullptr};
+  std::unique_ptr<Groups> g(build_groups(2, keys, valids, m, 0));
+  const int64_t G = (int64_t)g->first.size();
+  if (G > cap) return -1;
+  std::vector<uint8_t> ov((size_t)(G + 7) / 8 + 8);
+  int odt = 0;
+  for (int64_t j = 0; j < G; j++) { o_flag[j] = f_flag[g->first[j]]; o_status[j] = f_status[g->first[j]]; }
+  group_agg_impl<int64_t>(g.get(), I64, AGG_SUM, f_qty.data(), nullptr, o_sum_qty, ov.data(), &odt);
+  group_agg_impl<double>(g.get(), F64, AGG_SUM, f_price.data(), nullptr, o_sum_base, ov.data(), &odt);
+  group_agg_impl<double>(g.get(), F64, AGG_SUM, disc_price.data(), nullptr, o_sum_disc_price, ov.data(), &odt);
+  group_agg_impl<double>(g.get(), F64, AGG_SUM, charge.data(), nullptr, o_sum_charge, ov.data(), &odt);
+  group_agg_impl<int64_t>(g.get(), I64, AGG_MEAN, f_qty.data(), nullptr, o_avg_qty, ov.data(), &odt);
+  group_agg_impl<double>(g.get(), F64, AGG_MEAN, f_price.data(), nullptr, o_avg_price, ov.data(), &odt);
+  group_agg_impl<double>(g.get(), F64, AGG_MEAN, f_disc.data(), nullptr, o_avg_disc, ov.data(), &odt);
+  group_agg_impl<int64_t>(g.get(), I64, AGG_LEN, nullptr, nullptr, o_count, ov.data(), &odt);
+  return G;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TPC-H Q1 the way the reference actually runs this shape: two plain-column keys, every aggregate
+// pre-aggregatable and a sampled key cardinality <= 1000 => GroupByStreamingExec
+// (polars-mem-engine/src/planner/lp.rs:19-50,660-693, executors/group_by_streaming.rs:117-257), i.e. the
+// morsel-driven pipeline of polars-stream: each worker pulls morsels (POLARS_IDEAL_MORSEL_SIZE rows),
+// evaluates the predicate and filters the morsel's columns, evaluates the expression nodes column-at-a-time
+// on the (cache-resident) morsel, hashes the key pair into a thread-local fixed-size hot table
+// (polars-expr/src/hot_groups/fixed_index_table.rs:19-165, 4096 slots) and updates the grouped reductions
+// with plain `+=` (reduce/sum.rs:15-112, mean.rs:82-132 keeps (f64 sum, count), count.rs); the per-thread
+// tables are combined at the end (nodes/group_by.rs:252-497).  Keys here are two u8 dictionary codes, so the
+// hot table is indexed by (flag << 8 | status) and never evicts.
+// ---------------------------------------------------------------------------------------------
+extern "C" int64_t orc_q1_streaming(const int64_t* shipdate, const uint8_t* flag, const uint8_t* status, const int64_t* qty, const double* price,
+                                    const double* disc, const double* tax, int64_t n, int64_t cutoff, int64_t morsel, int cap, uint8_t* o_flag,
+                                    uint8_t* o_status, int64_t* o_sum_qty, double* o_sum_base, double* o_sum_disc_price, double* o_sum_charge,
+                                    double* o_avg_qty, double* o_avg_price, double* o_avg_disc, uint32_t* o_count) {
+  struct State { int64_t sum_qty = 0; double sum_base = 0, sum_dp = 0, sum_ch = 0, sum_qty_f = 0, sum_disc = 0; uint64_t cnt = 0; bool used = false; };
+  const int nt = std::max(1, g_threads);
+  if (morsel <= 0) morsel = 100000;
+  // hot table: 65536-entry slot index (keys are two u8 codes) -> compact state vector
+  std::vector<std::vector<int32_t>> slot_of((size_t)nt);
+  std::vector<std::vector<State>> local((size_t)nt);
+  std::atomic<int64_t> next{0};
+  auto worker = [&](int tid) {
+    std::vector<int32_t>& slot = slot_of[tid];
+    slot.assign(65536, -1);
+    std::vector<State>& tbl = local[tid];
+    tbl.reserve(64);
+    std::vector<uint8_t> mask((size_t)(morsel + 63) / 64 * 8 + 8), ff((size_t)morsel), fs((size_t)morsel);
+    std::vector<int64_t> fq((size_t)morsel);
+    std::vector<double> fp((size_t)morsel), fd((size_t)morsel), ft((size_t)morsel), t1((size_t)morsel), dp((size_t)morsel), t2((size_t)morsel), ch((size_t)morsel);
+    for (;;) {
+      const int64_t b = next.fetch_add(morsel);
+      if (b >= n) break;
+      const int64_t len = std::min<int64_t>(morsel, n - b);
+      // filter node: predicate -> bitmap, then every column of the morsel is compacted
+      memset(mask.data(), 0, mask.size());
+      for (int64_t i = 0; i < len; i++) if (shipdate[b + i] <= cutoff) mask[i >> 3] |= uint8_t(1u << (i & 7));
+      const int64_t m = scalar_filter<uint8_t>(flag + b, mask.data(), len, ff.data());
+      scalar_filter<uint8_t>(status + b, mask.data(), len, fs.data());
+      scalar_filter<int64_t>(qty + b, mask.data(), len, fq.data());
+      scalar_filter<double>(price + b, mask.data(), len, fp.data());
+      scalar_filter<double>(disc + b, mask.data(), len, fd.data());
+      scalar_filter<double>(tax + b, mask.data(), len, ft.data());
+      // select node: one materialised (morsel-sized) column per BinaryExpr
+      for (int64_t i = 0; i < m; i++) t1[i] = 1.0 - fd[i];
+      for (int64_t i = 0; i < m; i++) dp[i] = fp[i] * t1[i];
+      for (int64_t i = 0; i < m; i++) t2[i] = 1.0 + ft[i];
+      for (int64_t i = 0; i < m; i++) ch[i] = dp[i] * t2[i];
+      // group-by node: hot-table slot per row, then one pass per reduction
+      for (int64_t i = 0; i < m; i++) {
+        int32_t& sl = slot[(size_t)ff[i] << 8 | fs[i]];
+        if (sl < 0) { sl = (int32_t)tbl.size(); tbl.emplace_back(); }
+        State& st = tbl[(size_t)sl];
+        st.used = true;
+        st.sum_qty += fq[i]; st.sum_base += fp[i]; st.sum_dp += dp[i]; st.sum_ch += ch[i]; st.sum_qty_f += (double)fq[i]; st.sum_disc += fd[i]; st.cnt++;
+      }
+    }
+  };
+  if (nt == 1) worker(0);
+  else { std::vector<std::thread> ts; for (int t = 0; t < nt; t++) ts.emplace_back(worker, t); for (auto& t : ts) t.join(); }
+  int64_t G = 0;
+  for (int k = 0; k < 65536; k++) {
+    State tot; bool used = false;
+    for (int t = 0; t < nt; t++) { if (slot_of[t].empty() || slot_of[t][k] < 0) continue; const State& s = local[t][(size_t)slot_of[t][k]]; used = true;
+      tot.sum_qty += s.sum_qty; tot.sum_base += s.sum_base; tot.sum_dp += s.sum_dp; tot.sum_ch += s.sum_ch; tot.sum_qty_f += s.sum_qty_f; tot.sum_disc += s.sum_disc; tot.cnt += s.cnt; }
+    if (!used) continue;
+    if (G >= cap) return -1;
+    o_flag[G] = (uint8_t)(k >> 8); o_status[G] = (uint8_t)(k & 255);
+    o_sum_qty[G] = tot.sum_qty; o_sum_base[G] = tot.sum_base; o_sum_disc_price[G] = tot.sum_dp; o_sum_charge[G] = tot.sum_ch;
+    o_avg_qty[G] = tot.sum_qty_f / (double)tot.cnt; o_avg_price[G] = tot.sum_base / (double)tot.cnt; o_avg_disc[G] = tot.sum_disc / (double)tot.cnt;
+    o_count[G] = (uint32_t)tot.cnt;
+    G++;
+  }
+  return G;
+}

@@ -334,3 +334,26 @@ def q3(li: Dict[str, np.ndarray], orders: Dict[str, np.ndarray], date: int, seg_
     order = np.argsort(r["key_0"][0], kind="stable")
     return {"l_orderkey": r["key_0"][0][order], "o_orderdate": r["key_1"][0][order], "o_shippriority": r["key_2"][0][order],
             "revenue": r["revenue"][0][order]}
+
+
+def q1_native(cols: Dict[str, np.ndarray], cutoff: int, streaming: bool = False, morsel: int = 100_000) -> Dict[str, np.ndarray]:
+    """TPC-H Q1 end to end in C++ (multi-threaded per orc_set_threads), no Python between the steps.
+    streaming=False: orc_q1, the in-memory FilterExec -> GroupByExec sequence (index lists per group);
+    streaming=True : orc_q1_streaming, the morsel-driven partitioned group-by the reference picks for this
+    shape (thread-local hot tables).  Same result layout as q1()."""
+    n = len(cols["l_shipdate"])
+    cap = 64
+    o = {"l_returnflag": np.zeros(cap, np.uint8), "l_linestatus": np.zeros(cap, np.uint8), "sum_qty": np.zeros(cap, np.int64),
+         "sum_base_price": np.zeros(cap), "sum_disc_price": np.zeros(cap), "sum_charge": np.zeros(cap), "avg_qty": np.zeros(cap),
+         "avg_price": np.zeros(cap), "avg_disc": np.zeros(cap), "count_order": np.zeros(cap, np.uint32)}
+    c = {k: np.ascontiguousarray(v) for k, v in cols.items()}
+    f = lib().orc_q1_streaming if streaming else lib().orc_q1
+    f.restype = C.c_int64
+    head = [_p(c["l_shipdate"]), _p(c["l_returnflag"]), _p(c["l_linestatus"]), _p(c["l_quantity"]), _p(c["l_extendedprice"]), _p(c["l_discount"]),
+            _p(c["l_tax"]), C.c_int64(n), C.c_int64(cutoff)]
+    if streaming:
+        head.append(C.c_int64(morsel))
+    G = f(*head, cap, *[_p(o[k]) for k in o])
+    assert G >= 0
+    order = np.lexsort((o["l_linestatus"][:G], o["l_returnflag"][:G]))
+    return {k: v[:G][order] for k, v in o.items()}

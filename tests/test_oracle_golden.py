@@ -251,3 +251,23 @@ def test_hash_partition_is_stable_and_balanced(orc):
     valid = np.ones(len(keys), bool); valid[::7] = False
     pn = orc.hash_partition(keys, valid, 8, seed=0)
     assert (pn[::7] == 0).all() and np.array_equal(pn[valid], p[valid])   # nulls -> partition 0
+
+
+def test_q1_native_drivers_agree(orc):
+    """The C++ Q1 drivers used as bench.py's cpu_baseline (in-memory GroupByExec shape and the streaming /
+    partitioned group-by shape) agree with the step-by-step Python-driven oracle."""
+    from polars_amd import datagen
+    li = datagen.lineitem_host(300_000, seed=5)
+    cols = {k: li[k] for k in datagen.LINEITEM_Q1_COLS}
+    cut = datagen.us(1998, 9, 2)
+    ref = orc.q1(cols, cut)
+    for threads in (1, 4):
+        orc.set_threads(threads)
+        for streaming in (False, True):
+            got = orc.q1_native(cols, cut, streaming=streaming, morsel=7_000)
+            for k in ref:
+                if ref[k].dtype.kind == "f":
+                    assert np.allclose(got[k], ref[k], rtol=1e-9, atol=0), (k, streaming, threads)
+                else:
+                    assert np.array_equal(got[k], ref[k]), (k, streaming, threads)
+    orc.set_threads(1)
