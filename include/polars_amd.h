@@ -344,6 +344,7 @@ typedef struct plx_ir {
 
 /* plan flags */
 #define PLX_PLAN_NO_FUSION 1u /* force one kernel per node (reference-shaped execution) */
+#define PLX_PLAN_NO_PARTITION 4u /* high-cardinality group-by: always the HBM-table sink, never the partitioned LDS path */
 #define PLX_PLAN_NO_DIRECT_JOIN 2u /* fused join->aggregate: always use the hash table, never the direct-address table */
 
 /* Build the physical plan for IR node `root` and execute it. The output frame is

@@ -27,6 +27,7 @@ AE_COLUMN, AE_LITERAL, AE_BINARY, AE_CAST, AE_AGG, AE_LEN, AE_ALIAS, AE_NOT = ra
 IR_SCAN, IR_FILTER, IR_SELECT, IR_HSTACK, IR_GROUPBY, IR_JOIN = range(6)
 PLAN_NO_FUSION = 1
 PLAN_NO_DIRECT_JOIN = 2
+PLAN_NO_PARTITION = 4
 ERR_UNSUPPORTED = 3
 
 DTYPE_WIDTH = {BOOL: 0, I8: 1, I16: 2, I32: 4, I64: 8, U8: 1, U16: 2, U32: 4, U64: 8, F32: 4, F64: 8}

@@ -721,6 +721,24 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     G = std::min(G, (double)n);
     log2_cap = std::max(12, ceil_log2_u64((uint64_t)(G * 2.0) + 1));
     desc += "sample(distinct=" + std::to_string(d) + "/" + std::to_string(S) + ")+";
+    // many rows, many groups: per-row global atomics are bound by the ~24 G/s device atomic rate; partition the
+    // rows and aggregate each partition in LDS instead (kernels_partition.hip)
+    if (!kp.wide && !(c.plan.flags & PLX_PLAN_NO_PARTITION) && G >= 4096.0 && n >= ((int64_t)1 << 24)) {
+      bool any_null = c.key >= 0 && c.nodes[c.key].nullable;
+      for (auto& a : c.aggs) if (a.second >= 0 && c.nodes[a.second].nullable) any_null = true;
+      PartitionPlan pp;
+      if (k::partition_plan(sh, G * 1.3, any_null, &pp)) {
+        std::string pd;
+        Buf ok, okv, oacc;
+        const int64_t g = k::partitioned_agg(sh, args, pp, static_id, &ok, &okv, &oacc, &pd);
+        if (g >= 0) {
+          res.n_groups = g; res.n_aggs = sh.n_aggs; res.packed_keys = ok; res.key_valid = okv; res.acc = oacc;
+          desc += std::string("fused_scan[") + (static_id >= 0 ? "aot" : "generic") + "]+" + pd;
+          return;
+        }
+        desc += "lds-overflow+";
+      }
+    }
   }
   for (int attempt = 0; attempt < 8; attempt++) {
     int64_t g = kp.wide ? run_wide_agg(sh, args, log2_cap, kp.wide_nullable, res, false) : run_hash_agg(sh, args, static_id, log2_cap, len_idx, res, false);

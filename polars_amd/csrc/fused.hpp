@@ -123,6 +123,19 @@ struct KeyDecode {
   int32_t dtype;        // output plx_dtype
 };
 
+// ---- partitioned group-by (kernels_partition.hip) ---------------------------------------------
+struct PartitionPlan {
+  uint32_t log2_parts;         // P = 1 << log2_parts hash partitions
+  uint32_t log2_slots;         // slots of the per-partition LDS table
+  uint32_t rec_words;          // u64 words per record: key + sources (+ validity word) (+ row id)
+  uint32_t n_src;              // distinct aggregate source slots
+  uint32_t has_valid;          // records carry a validity word (bit j = source j valid, bit 63 = key valid)
+  uint32_t has_rowid;          // records carry the row index (AGG_FIRST_ROW)
+  uint32_t buf_rows;           // records per LDS write-combining buffer (even)
+  uint8_t src_slot[kMaxAggs];  // program slot of source j
+  uint8_t agg_src[kMaxAggs];   // aggregate k reads source agg_src[k] (kNone: LEN / FIRST_ROW)
+};
+
 // ---- batched result finalisation: every output column of a query in ONE launch ---------------
 constexpr int kMaxFinJobs = 24;
 struct FinJob {

@@ -22,10 +22,7 @@
 //     per workgroup -> tiny finish kernel.  No atomics, deterministic.
 //   * dense / hash sinks: device-scope atomics straight into an HBM-resident table
 //     (hardware f64 atomic add on gfx950); see HashAggSink.
-#include "dev.hpp"
-#include "fused.hpp"
-#include "fused_shapes.hpp"
-#include "kernels.hpp"
+#include "fused_device.hpp"
 #include "kernels_fused.hpp"
 #include <cstring>
 #include <vector>
@@ -55,294 +52,6 @@ namespace k {
 
 using namespace dev;
 using namespace fused;
-
-typedef unsigned long long u64x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
-
-struct RegFile {
-  u64x16 v[kRows];
-  u32x16 valid;  // bit r of element s: row r of slot s is valid
-};
-
-__device__ __forceinline__ int dtype_width_dev(int dt) {
-  switch (dt) {
-    case PLX_I8: case PLX_U8: return 1;
-    case PLX_I16: case PLX_U16: return 2;
-    case PLX_I32: case PLX_U32: case PLX_F32: return 4;
-    default: return 8;
-  }
-}
-__device__ __forceinline__ double as_f(uint64_t x) { return __longlong_as_double((long long)x); }
-__device__ __forceinline__ uint64_t as_u(double x) { return (uint64_t)__double_as_longlong(x); }
-
-// ---- column loads -----------------------------------------------------------------
-template <class T, bool FULL>
-__device__ __forceinline__ void load2(const void* base_ptr, int64_t row0, int64_t n, uint64_t out[kRows]) {
-  const T* p = reinterpret_cast<const T*>(base_ptr);
-  if constexpr (FULL) {
-    Pack<T, kRows> x = load_pack<T, kRows>(p + row0);
-#pragma unroll
-    for (int r = 0; r < kRows; r++) {
-      if constexpr (is_fp<T>::value) out[r] = as_u((double)x.v[r]);
-      else out[r] = (uint64_t)(long long)x.v[r];  // sign- or zero-extends by T
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < kRows; r++) {
-      int64_t i = row0 + r; if (i > n - 1) i = n - 1;
-      T x = p[i];
-      if constexpr (is_fp<T>::value) out[r] = as_u((double)x);
-      else out[r] = (uint64_t)(long long)x;
-    }
-  }
-}
-
-template <bool FULL>
-__device__ __forceinline__ void load_input(const Input& in, int dtype, int64_t row0, int64_t n, uint64_t out[kRows], uint32_t& vbits) {
-  switch (dtype) {
-    case PLX_I64: case PLX_U64: case PLX_F64: load2<uint64_t, FULL>(in.values, row0, n, out); break;
-    case PLX_I32: load2<int32_t, FULL>(in.values, row0, n, out); break;
-    case PLX_U32: load2<uint32_t, FULL>(in.values, row0, n, out); break;
-    case PLX_I16: load2<int16_t, FULL>(in.values, row0, n, out); break;
-    case PLX_U16: load2<uint16_t, FULL>(in.values, row0, n, out); break;
-    case PLX_I8: load2<int8_t, FULL>(in.values, row0, n, out); break;
-    case PLX_U8: load2<uint8_t, FULL>(in.values, row0, n, out); break;
-    case PLX_BOOL: {
-      int64_t i = row0; if (!FULL && i > n - 1) i = n - 1;
-      uint64_t w = reinterpret_cast<const uint64_t*>(in.values)[i >> 6] >> (i & 63);
-      out[0] = w & 1; out[1] = (w >> 1) & 1;
-    } break;
-    default: out[0] = out[1] = 0; break;
-  }
-  vbits = (1u << kRows) - 1;
-  if (in.validity) {
-    int64_t i = row0; if (!FULL && i > n - 1) i = n - 1;
-    vbits = (uint32_t)(in.validity[i >> 6] >> (i & 63)) & ((1u << kRows) - 1);
-    if (!FULL && row0 + 1 > n - 1) vbits &= 1u;  // second row clamped: validity irrelevant (row masked out)
-  }
-}
-
-// ---- one program step ---------------------------------------------------------------
-template <bool FULL>
-__device__ __forceinline__ void exec_op(const Op op, const Shape& sh, const Args& args, int pc, int64_t row0, RegFile& rf) {
-  uint64_t a[kRows], b[kRows], d[kRows];
-  uint32_t va = (1u << kRows) - 1, vb = (1u << kRows) - 1, vd;
-  if (op.code == OP_LOAD) {
-    load_input<FULL>(args.in[op.a], sh.in_dtype[op.a], row0, args.n_rows, d, vd);
-  } else if (op.code == OP_CONST) {
-#pragma unroll
-    for (int r = 0; r < kRows; r++) d[r] = args.imm[pc];
-    vd = (1u << kRows) - 1;
-  } else {
-#pragma unroll
-    for (int r = 0; r < kRows; r++) { a[r] = rf.v[r][op.a]; b[r] = rf.v[r][op.b]; }
-    va = rf.valid[op.a]; vb = rf.valid[op.b];
-    vd = va & vb;
-    switch (op.code) {
-      case OP_ADD_F:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = as_u(as_f(a[r]) + as_f(b[r]));
-        break;
-      case OP_SUB_F:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = as_u(as_f(a[r]) - as_f(b[r]));
-        break;
-      case OP_MUL_F:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = as_u(as_f(a[r]) * as_f(b[r]));
-        break;
-      case OP_DIV_F:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = as_u(as_f(a[r]) / as_f(b[r]));
-        break;
-      case OP_ADD_I:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = a[r] + b[r];
-        break;
-      case OP_SUB_I:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = a[r] - b[r];
-        break;
-      case OP_MUL_I:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = a[r] * b[r];
-        break;
-      case OP_I2F:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = as_u((double)(long long)a[r]);
-        vd = va;
-        break;
-      case OP_U2F:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = as_u((double)a[r]);
-        vd = va;
-        break;
-      case OP_CMP_I:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = cmp_apply<long long>(op.c, (long long)a[r], (long long)b[r]) ? 1 : 0;
-        break;
-      case OP_CMP_U:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = cmp_apply<unsigned long long>(op.c, a[r], b[r]) ? 1 : 0;
-        break;
-      case OP_CMP_F:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = cmp_apply<double>(op.c, as_f(a[r]), as_f(b[r])) ? 1 : 0;
-        break;
-      case OP_AND: {  // Kleene (polars-compute/src/boolean.rs: and)
-        uint32_t ta = 0, tb = 0;
-#pragma unroll
-        for (int r = 0; r < kRows; r++) { d[r] = a[r] & b[r] & 1; ta |= (uint32_t)(a[r] & 1) << r; tb |= (uint32_t)(b[r] & 1) << r; }
-        vd = (~tb & vb) | (~ta & va) | (ta & va & tb & vb);
-      } break;
-      case OP_OR: {   // Kleene (boolean.rs: or)
-        uint32_t ta = 0, tb = 0;
-#pragma unroll
-        for (int r = 0; r < kRows; r++) { d[r] = (a[r] | b[r]) & 1; ta |= (uint32_t)(a[r] & 1) << r; tb |= (uint32_t)(b[r] & 1) << r; }
-        vd = (ta & va) | (tb & vb) | (~ta & va & ~tb & vb);
-      } break;
-      case OP_XOR:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = (a[r] ^ b[r]) & 1;
-        break;
-      case OP_NOT:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = (~a[r]) & 1;
-        vd = va;
-        break;
-      case OP_CANON_F:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) { double f = as_f(a[r]); d[r] = (f != f) ? 0x7ff8000000000000ull : as_u(f + 0.0); }
-        vd = va;
-        break;
-      case OP_FDIV_I: case OP_MOD_I: {
-        uint32_t nz = 0;
-        // 64-bit integer division is a ~100-instruction software routine on gfx950; when every lane's
-        // operands are non-negative and fit 31 bits (wave-uniform test) the 32-bit divide gives the same result.
-        bool narrow = true;
-#pragma unroll
-        for (int r = 0; r < kRows; r++) narrow = narrow && (((a[r] | b[r]) >> 31) == 0);
-        if (__all(narrow)) {
-#pragma unroll
-          for (int r = 0; r < kRows; r++) {
-            const uint32_t x = (uint32_t)a[r], y = (uint32_t)b[r];
-            d[r] = y ? (uint64_t)(op.code == OP_FDIV_I ? x / y : x % y) : 0ull;
-            nz |= (uint32_t)(y != 0) << r;
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < kRows; r++) {
-            const long long x = (long long)a[r], y = (long long)b[r];
-            long long q = 0, m = 0;
-            if (y == -1) { q = (long long)(0ull - (unsigned long long)x); m = 0; }   // wrapping_div(MIN, -1) = MIN
-            else if (y != 0) { q = x / y; m = x % y; if (m != 0 && ((x < 0) != (y < 0))) { q -= 1; m += y; } }
-            d[r] = (uint64_t)(op.code == OP_FDIV_I ? q : m);
-            nz |= (uint32_t)(y != 0) << r;
-          }
-        }
-        vd &= nz;
-      } break;
-      case OP_FDIV_U: case OP_MOD_U: {
-        uint32_t nz = 0;
-#pragma unroll
-        for (int r = 0; r < kRows; r++) {
-          const uint64_t x = a[r], y = b[r];
-          d[r] = y ? (op.code == OP_FDIV_U ? x / y : x % y) : 0ull;
-          nz |= (uint32_t)(y != 0) << r;
-        }
-        vd &= nz;
-      } break;
-      case OP_IFNULL:
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = ((va >> r) & 1) ? a[r] : args.imm[pc];
-        vd = (1u << kRows) - 1;
-        break;
-      default:  // OP_MOV / OP_NOP
-#pragma unroll
-        for (int r = 0; r < kRows; r++) d[r] = a[r];
-        vd = va;
-        break;
-    }
-    vd &= (1u << kRows) - 1;
-  }
-#pragma unroll
-  for (int r = 0; r < kRows; r++) rf.v[r][op.dst] = d[r];
-  rf.valid[op.dst] = vd;
-}
-
-// ---- program providers ----------------------------------------------------------
-struct DynProg { static constexpr bool kStatic = false; static constexpr int kId = -1; };
-template <int ID> struct StatProg { static constexpr bool kStatic = true; static constexpr int kId = ID; };
-
-template <class P, bool FULL>
-__device__ __forceinline__ void run_program(const Shape& dsh, const Args& args, int64_t row0, RegFile& rf) {
-  if constexpr (P::kStatic) {
-    constexpr Shape sh = static_shape(P::kId);
-#pragma unroll
-    for (int pc = 0; pc < sh.n_ops; pc++) exec_op<FULL>(sh.ops[pc], sh, args, pc, row0, rf);
-  } else {
-    for (int pc = 0; pc < dsh.n_ops; pc++) exec_op<FULL>(dsh.ops[pc], dsh, args, pc, row0, rf);
-  }
-}
-
-// ---- aggregate combine (bit patterns) -----------------------------------------------
-__device__ __forceinline__ uint64_t agg_combine(uint8_t kind, uint64_t x, uint64_t y) {
-  switch (kind) {
-    case AGG_SUM_F: return as_u(as_f(x) + as_f(y));
-    case AGG_MIN_F: return as_u(min_ign<double>(as_f(x), as_f(y)));
-    case AGG_MAX_F: return as_u(max_ign<double>(as_f(x), as_f(y)));
-    case AGG_MIN_I: return (uint64_t)((long long)x < (long long)y ? (long long)x : (long long)y);
-    case AGG_MAX_I: return (uint64_t)((long long)x > (long long)y ? (long long)x : (long long)y);
-    case AGG_MIN_U: case AGG_FIRST_ROW: return x < y ? x : y;
-    case AGG_MAX_U: return x > y ? x : y;
-    default: return x + y;  // SUM_I, COUNT, COUNT_ORD, LEN
-  }
-}
-__device__ __forceinline__ uint64_t agg_identity_dev(uint8_t kind) {
-  switch (kind) {
-    case AGG_MIN_F: return 0x7ff0000000000000ull;
-    case AGG_MAX_F: return 0xfff0000000000000ull;
-    case AGG_MIN_I: return 0x7fffffffffffffffull;
-    case AGG_MAX_I: return 0x8000000000000000ull;
-    case AGG_MIN_U: case AGG_FIRST_ROW: return ~0ull;
-    default: return 0ull;
-  }
-}
-// value an aggregate contributes for one row: `sel` = row selected and (where it matters) src valid
-__device__ __forceinline__ uint64_t agg_row_value(uint8_t kind, uint64_t v, bool pass, bool valid, uint64_t row) {
-  switch (kind) {
-    case AGG_LEN: return pass ? 1ull : 0ull;
-    case AGG_COUNT: return (pass && valid) ? 1ull : 0ull;
-    case AGG_COUNT_ORD: { double f = as_f(v); return (pass && valid && f == f) ? 1ull : 0ull; }
-    case AGG_FIRST_ROW: return pass ? row : ~0ull;
-    case AGG_MIN_F: { double f = as_f(v); return (pass && valid && f == f) ? v : 0x7ff0000000000000ull; }
-    case AGG_MAX_F: { double f = as_f(v); return (pass && valid && f == f) ? v : 0xfff0000000000000ull; }
-    case AGG_SUM_F: case AGG_SUM_I: return (pass && valid) ? v : 0ull;   // +0.0 / 0 identities share the zero pattern
-    default: return (pass && valid) ? v : agg_identity_dev(kind);
-  }
-}
-
-// ---- device-scope atomic update of one aggregate cell -------------------------------
-__device__ __forceinline__ void atomic_agg(uint8_t kind, unsigned long long* cell, uint64_t v) {
-  switch (kind) {
-    case AGG_SUM_F: unsafeAtomicAdd(reinterpret_cast<double*>(cell), as_f(v)); break;  // global_atomic_add_f64
-    case AGG_MIN_I: atomicMin(reinterpret_cast<long long*>(cell), (long long)v); break;
-    case AGG_MAX_I: atomicMax(reinterpret_cast<long long*>(cell), (long long)v); break;
-    case AGG_MIN_U: case AGG_FIRST_ROW: atomicMin(cell, (unsigned long long)v); break;
-    case AGG_MAX_U: atomicMax(cell, (unsigned long long)v); break;
-    case AGG_MIN_F: case AGG_MAX_F: {
-      unsigned long long old = *cell;
-      for (;;) {
-        uint64_t nv = agg_combine(kind, old, v);
-        if (nv == old) break;
-        unsigned long long prev = atomicCAS(cell, old, (unsigned long long)nv);
-        if (prev == old) break;
-        old = prev;
-      }
-    } break;
-    default: atomicAdd(cell, (unsigned long long)v); break;
-  }
-}
 
 // ---- sink: per-lane register accumulators (no group-by) ---------------------------------
 struct RegAggSink {
@@ -387,28 +96,6 @@ struct RegAggSink {
     }
   }
 };
-
-// ---- LDS atomic update of one aggregate cell ----------------------------------------------
-__device__ __forceinline__ void lds_atomic_agg(uint8_t kind, unsigned long long* cell, uint64_t v) {
-  switch (kind) {
-    case AGG_SUM_F: unsafeAtomicAdd(reinterpret_cast<double*>(cell), as_f(v)); break;  // ds_add_f64
-    case AGG_MIN_I: atomicMin(reinterpret_cast<long long*>(cell), (long long)v); break;
-    case AGG_MAX_I: atomicMax(reinterpret_cast<long long*>(cell), (long long)v); break;
-    case AGG_MIN_U: case AGG_FIRST_ROW: atomicMin(cell, (unsigned long long)v); break;
-    case AGG_MAX_U: atomicMax(cell, (unsigned long long)v); break;
-    case AGG_MIN_F: case AGG_MAX_F: {
-      unsigned long long old = *cell;
-      for (;;) {
-        uint64_t nv = agg_combine(kind, old, v);
-        if (nv == old) break;
-        unsigned long long prev = atomicCAS(cell, old, (unsigned long long)nv);
-        if (prev == old) break;
-        old = prev;
-      }
-    } break;
-    default: atomicAdd(cell, (unsigned long long)v); break;
-  }
-}
 
 // ---- sink: workgroup-shared LDS table for dense group ids (1 < G <= ~1024) -----------------
 // Layout lds[(g * n_aggs + k) * C + copy], copy = lane & (C-1).  With C = 16 every
@@ -463,23 +150,6 @@ struct LdsAggSink {
     }
   }
 };
-
-template <class S>
-__device__ __forceinline__ void atomic_row(const S& sh, const RegFile& rf, int r, int64_t row, unsigned long long* cells) {
-#pragma unroll
-  for (int k = 0; k < kMaxAggs; k++) {
-    if (k < sh.n_aggs) {
-      const Agg ag = sh.aggs[k];
-      uint64_t v = rf.v[r][ag.src];
-      bool valid = (rf.valid[ag.src] >> r) & 1;
-      uint64_t x = agg_row_value(ag.kind, v, true, valid, (uint64_t)row);
-      if (x != agg_identity_dev(ag.kind) || ag.kind == AGG_SUM_F) {
-        if (ag.kind == AGG_SUM_F && !valid) continue;
-        atomic_agg(ag.kind, cells + k, x);
-      }
-    }
-  }
-}
 
 // ---- sink: direct-address table (dense integer keys) ---------------------------------
 struct DenseAggSink {
@@ -734,26 +404,6 @@ struct DirectProbeAggSink {
     }
   }
 };
-
-// ---- the scan kernels ------------------------------------------------------------------
-template <class P>
-__device__ __forceinline__ bool tile_rows(const Shape& dsh, const Args& args, int64_t tile, RegFile& rf, bool pass[kRows], int64_t& row0) {
-  const int lane = lane_id();
-  const int64_t base = tile * kTileRows;
-  row0 = base + (int64_t)lane * kRows;
-  const bool full = base + kTileRows <= args.n_rows;  // wave-uniform
-  if (full) run_program<P, true>(dsh, args, row0, rf);
-  else run_program<P, false>(dsh, args, row0, rf);
-  uint8_t pred;
-  if constexpr (P::kStatic) { constexpr Shape sh = static_shape(P::kId); pred = sh.pred; } else pred = dsh.pred;
-#pragma unroll
-  for (int r = 0; r < kRows; r++) {
-    bool ok = full || (row0 + r < args.n_rows);
-    if (pred != kNone) ok = ok && (rf.v[r][pred] & 1) && ((rf.valid[pred] >> r) & 1);
-    pass[r] = ok;
-  }
-  return full;
-}
 
 template <class P, class Sink>
 __global__ __launch_bounds__(kBlock) void fused_scan_kernel(Shape dsh, Args args, typename Sink::Params sp) {

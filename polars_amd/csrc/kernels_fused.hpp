@@ -1,6 +1,8 @@
 // kernels_fused.hpp -- launchers of the fused scan kernels (kernels_fused.hip) and
 // the join kernels (kernels_join.hip).
 #pragma once
+#include <string>
+
 #include "core.hpp"
 #include "fused.hpp"
 
@@ -46,6 +48,11 @@ int64_t table_compact(const uint64_t* keys, const uint64_t* acc, int64_t n_slots
 
 // aggregate cells [G][n_aggs] -> typed output column (+ validity bitmap, may be null)
 void finalize_aggs(const uint64_t* acc, int n_aggs, int64_t G, const fused::FinalSpec& sp, void* out, uint64_t* out_valid);
+// partitioned high-cardinality group-by (kernels_partition.hip): plan (false = does not apply) and run
+// (returns the group count, -1 = an LDS table overflowed: use the HBM-table sink instead)
+bool partition_plan(const fused::Shape& sh, double est_groups, bool any_nullable, fused::PartitionPlan* out);
+int64_t partitioned_agg(const fused::Shape& sh, const fused::Args& args, const fused::PartitionPlan& pp, int static_id, Buf* out_keys, Buf* out_kvalid,
+                        Buf* out_acc, std::string* desc);
 // all jobs of a batch (key decodes + aggregate finalisations) in one launch
 void finalize_batch(const uint64_t* acc, int n_aggs, int64_t G, const fused::FinBatch& b);
 // packed group keys -> one key column

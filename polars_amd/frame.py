@@ -536,12 +536,12 @@ class LazyFrame:
         root, schema = low.lower_node(self._node)
         return low, root, schema
 
-    def collect(self, *, no_fusion: bool = False, no_direct_join: bool = False) -> DataFrame:
+    def collect(self, *, no_fusion: bool = False, no_direct_join: bool = False, no_partition: bool = False) -> DataFrame:
         F.ensure_init()
         low, root, schema = self._lower()
         ir, n_ir, ae, n_ae, keep = low.to_c()
         out = C.c_uint64()
-        flags = (F.PLAN_NO_FUSION if no_fusion else 0) | (F.PLAN_NO_DIRECT_JOIN if no_direct_join else 0)
+        flags = (F.PLAN_NO_FUSION if no_fusion else 0) | (F.PLAN_NO_DIRECT_JOIN if no_direct_join else 0) | (F.PLAN_NO_PARTITION if no_partition else 0)
         F.check(F.lib().plx_execute_plan(ir, n_ir, ae, n_ae, root, flags, C.byref(out)))
         del keep
         return DataFrame._from_frame_handle(out.value, schema)

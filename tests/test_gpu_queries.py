@@ -327,3 +327,60 @@ def test_join_groupby_direct_address_edge_keys(pl):
     for o in (o1, o2):
         d = o.to_dict()
         assert sorted(zip(d["k"], d["pay"], d["s"], d["n"])) == exp
+
+
+@pytest.mark.parametrize("variant", ["i64_sum_count", "nullable_f64_all_aggs", "filtered_maintain_order"])
+def test_partitioned_groupby_matches_hbm_table_path(pl, variant):
+    """>= 2^24 rows and >= 4096 groups take the partitioned LDS path (kernels_partition.hip); it must agree
+    bit-for-bit (ints) / 1e-6 (floats) with the HBM-table sink and with numpy."""
+    rng = np.random.default_rng(41)
+    n = 20_000_000
+    G = 300_000
+    key = rng.integers(0, G, n).astype(np.int64) * 7919 - 10**9
+    key[:5] = [-1, -1, 2**63 - 1, -2**63, -1]          # EMPTY-sentinel bit pattern and extremes as real keys
+    v = rng.integers(-1000, 1000, n).astype(np.int64)
+    if variant == "i64_sum_count":
+        df = pl.DataFrame({"key": key, "v": v})
+        q = df.lazy().group_by("key").agg(pl.col("v").sum().alias("s"), pl.col("v").count().alias("c"))
+    elif variant == "nullable_f64_all_aggs":
+        x = rng.uniform(-1, 1, n)
+        xv = rng.uniform(size=n) > 0.1
+        kv = rng.uniform(size=n) > 0.001
+        df = pl.DataFrame([pl.Series("key", key, validity=kv), pl.Series("v", v), pl.Series("x", x, validity=xv)])
+        q = df.lazy().group_by("key").agg(pl.col("x").sum().alias("s"), pl.col("x").mean().alias("m"), pl.col("x").min().alias("mn"), pl.col("v").max().alias("mx"),
+                                          pl.col("x").count().alias("c"), pl.len().alias("n"))
+    else:
+        df = pl.DataFrame({"key": key, "v": v})
+        q = df.lazy().filter(pl.col("v") >= -500).group_by("key", maintain_order=True).agg(pl.col("v").sum().alias("s"), pl.len().alias("n"))
+    o1 = q.collect(); p1 = pl.last_plan()
+    o2 = q.collect(no_partition=True); p2 = pl.last_plan()
+    assert "partitioned(" in p1 and "lds_hash_table" in p1, p1
+    assert "hash_hbm_table" in p2, p2
+    d1, d2 = o1.to_dict(), o2.to_dict()
+    cols = list(d1.keys())
+    assert cols == list(d2.keys()) and o1.height == o2.height
+    if variant == "filtered_maintain_order":
+        keep = v >= -500
+        kk = key[keep]
+        _, first = np.unique(kk, return_index=True)
+        exp_keys = kk[np.sort(first)]
+        assert d1["key"] == exp_keys.tolist() and d2["key"] == exp_keys.tolist()      # first-occurrence order
+        order1 = order2 = list(range(o1.height))
+    else:
+        kf = lambda i, d: (d["key"][i] is None, d["key"][i] or 0)
+        order1 = sorted(range(o1.height), key=lambda i: kf(i, d1)); order2 = sorted(range(o2.height), key=lambda i: kf(i, d2))
+    for c in cols:
+        a = [d1[c][i] for i in order1]; b = [d2[c][i] for i in order2]
+        if c in ("s", "m") and variant == "nullable_f64_all_aggs":
+            fa = np.array([np.nan if z is None else z for z in a]); fb = np.array([np.nan if z is None else z for z in b])
+            assert np.allclose(fa, fb, rtol=RTOL, atol=1e-9, equal_nan=True), c
+        else:
+            assert a == b, c
+    # numpy spot check of the sums
+    uk, inv = np.unique(key if variant != "filtered_maintain_order" else key[v >= -500], return_inverse=True)
+    if variant == "i64_sum_count":
+        got = dict(zip(d1["key"], zip(d1["s"], d1["c"])))
+        s = np.bincount(inv, v).astype(np.int64); c = np.bincount(inv)
+        assert len(got) == len(uk)
+        for j in rng.integers(0, len(uk), 2000):
+            assert got[int(uk[j])] == (int(s[j]), int(c[j]))
