@@ -483,6 +483,22 @@ class Compiler {
     for (auto& a : aggs) if (a.second >= 0) roots.push_back(a.second);
     for (int r : roots) count_uses(r, seen);   // each root reference holds its slot to the end
     shape.pred = kNone; shape.key = kNone;
+    // Loads first: every column load of a row tile is issued before the first dependent op, so a lane has all
+    // its input columns in flight at once (memory-level parallelism) instead of load -> wait -> use per column.
+    {
+      std::vector<int> order;
+      std::vector<bool> vis(nodes.size(), false);
+      std::function<void(int)> dfs = [&](int n) {
+        if (n < 0 || vis[n]) return;
+        vis[n] = true;
+        if (nodes[n].code == OP_LOAD) { order.push_back(n); return; }
+        if (nodes[n].code == OP_CONST) return;
+        dfs(nodes[n].a);
+        if (nodes[n].b != nodes[n].a) dfs(nodes[n].b);
+      };
+      for (int r : roots) dfs(r);
+      for (int n : order) emit(n);
+    }
     if (pred >= 0) shape.pred = (uint8_t)emit(pred);
     if (key >= 0) shape.key = (uint8_t)emit(key);
     shape.n_keys = (uint8_t)wide_keys.size();

@@ -13,8 +13,8 @@
 //                    per-workgroup LDS histogram -> global histogram -> exclusive scan = partition offsets
 //   2. part_scatter  same fused scan; each row becomes a record [key, source values..., (validity), (row id)];
 //                    records are staged in workgroup-shared LDS write-combining buffers (P x B records) and
-//                    flushed B at a time (a whole 128-B line for 16-B records) at an offset reserved with ONE
-//                    global atomic per flush
+//                    flushed B at a time (a whole 128-B line for 16-B records); pass 1's per-workgroup histogram
+//                    fixes every workgroup's write offsets in advance: no global atomics, deterministic output
 //   3. part_agg      one workgroup per partition: LDS open-addressing table (CAS on the key word, LDS atomics
 //                    on the cells); when the partition is done its groups are written straight to the dense
 //                    output arrays (one global atomic per partition) -- no table in HBM, no compaction pass
@@ -35,54 +35,86 @@ __device__ __forceinline__ uint32_t part_of(uint64_t key, bool kvalid, uint32_t 
   return (uint32_t)((key * 0x55fbfd6bfc5458e9ull) >> (64 - log2_parts));
 }
 
-// ---- pass 1: histogram (runs inside fused_scan_kernel) -------------------------------------------
-struct PartCountSink {
-  struct Params { unsigned long long* hist; uint32_t log2_parts; };
-  template <class S> __device__ __forceinline__ void init(const S&, const Params& p) {
-    extern __shared__ unsigned long long lds_raw[];
-    unsigned int* cnt = reinterpret_cast<unsigned int*>(lds_raw);
-    for (uint32_t i = threadIdx.x; i < (1u << p.log2_parts); i += blockDim.x) cnt[i] = 0;
-    __syncthreads();
-  }
-  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t, const Params& p) {
-    extern __shared__ unsigned long long lds_raw[];
-    unsigned int* cnt = reinterpret_cast<unsigned int*>(lds_raw);
+// ---- round structure shared by pass 1 and pass 2 ---------------------------------------------------
+// Workgroup-synchronous: round rd covers kRoundTiles tiles per wave (kBlock * kRows * kRoundTiles rows); workgroup b
+// handles rounds b, b + grid, ...  Both passes use the SAME grid, so pass 1's per-workgroup histogram tells pass 2
+// exactly where each workgroup writes each partition: no atomics on the scatter path, deterministic output.
+constexpr int kRoundTiles = 4;
+constexpr int kRoundRows = kRows * kRoundTiles;
+
+// Evaluates the program for the kRoundTiles tiles of round `rd` owned by this wave.  When the whole round lies inside
+// the input (wave-uniform test) the tiles run back to back in straight-line code, so the compiler can issue the column
+// loads of all tiles before the first use; the tail round takes the bounds-checked path.
+template <class P>
+__device__ __forceinline__ void round_rows(const Shape& dsh, const Args& args, int64_t rd, int wave_in_block, RegFile rf[kRoundTiles], bool pass[kRoundTiles][kRows]) {
+  const int lane = lane_id();
+  const int64_t first_tile = rd * kRoundTiles * (kBlock / 64);
+  const bool all_full = (first_tile + (int64_t)kRoundTiles * (kBlock / 64)) * kTileRows <= args.n_rows;
+  uint8_t pred;
+  if constexpr (P::kStatic) { constexpr Shape sh = static_shape(P::kId); pred = sh.pred; } else pred = dsh.pred;
+  if (all_full) {
 #pragma unroll
-    for (int r = 0; r < kRows; r++) {
-      if (!pass[r]) continue;
-      atomicAdd(&cnt[part_of(rf.v[r][sh.key], (rf.valid[sh.key] >> r) & 1, p.log2_parts)], 1u);
+    for (int t = 0; t < kRoundTiles; t++) {
+      const int64_t row0 = (first_tile + (int64_t)t * (kBlock / 64) + wave_in_block) * kTileRows + (int64_t)lane * kRows;
+      run_program<P, true>(dsh, args, row0, rf[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < kRoundTiles; t++) {
+#pragma unroll
+      for (int r = 0; r < kRows; r++) pass[t][r] = pred == kNone || ((rf[t].v[r][pred] & 1) && ((rf[t].valid[pred] >> r) & 1));
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < kRoundTiles; t++) { int64_t row0; tile_rows<P>(dsh, args, first_tile + (int64_t)t * (kBlock / 64) + wave_in_block, rf[t], pass[t], row0); }
+  }
+}
+__device__ __forceinline__ int64_t round_row0(int64_t rd, int t, int wave_in_block) {
+  return ((rd * kRoundTiles + t) * (kBlock / 64) + wave_in_block) * (int64_t)kTileRows + (int64_t)lane_id() * kRows;
+}
+
+// ---- pass 1: per-workgroup partition histogram -----------------------------------------------------
+template <class P>
+__global__ __launch_bounds__(kBlock) void part_count_kernel(Shape dsh, Args args, uint32_t log2_parts, unsigned int* __restrict__ hist /* [grid][NP] */) {
+  extern __shared__ unsigned long long lds_raw[];
+  unsigned int* cnt = reinterpret_cast<unsigned int*>(lds_raw);
+  const uint32_t NP = 1u << log2_parts;
+  for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
+  const int64_t rows_per_round = (int64_t)kBlock * kRoundRows;
+  const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
+  const int wave_in_block = threadIdx.x >> 6;
+  uint8_t key_slot;
+  if constexpr (P::kStatic) { constexpr Shape sh = static_shape(P::kId); key_slot = sh.key; } else key_slot = dsh.key;
+  for (int64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
+    RegFile rf[kRoundTiles]; bool pass[kRoundTiles][kRows];
+    round_rows<P>(dsh, args, rd, wave_in_block, rf, pass);
+#pragma unroll
+    for (int t = 0; t < kRoundTiles; t++) {
+#pragma unroll
+      for (int r = 0; r < kRows; r++) {
+        if (!pass[t][r]) continue;
+        atomicAdd(&cnt[part_of(rf[t].v[r][key_slot], (rf[t].valid[key_slot] >> r) & 1, log2_parts)], 1u);
+      }
     }
   }
-  template <class S> __device__ __forceinline__ void finish(const S&, const Params& p) {
-    extern __shared__ unsigned long long lds_raw[];
-    unsigned int* cnt = reinterpret_cast<unsigned int*>(lds_raw);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < (1u << p.log2_parts); i += blockDim.x) if (cnt[i]) atomicAdd(&p.hist[i], (unsigned long long)cnt[i]);
-  }
-};
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) hist[(size_t)blockIdx.x * NP + i] = cnt[i];
+}
 
-template <class P>
-__global__ __launch_bounds__(kBlock) void part_count_kernel(Shape dsh, Args args, PartCountSink::Params sp) {
-  PartCountSink sink;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int64_t ntiles = (args.n_rows + kTileRows - 1) / kTileRows;
-  if constexpr (P::kStatic) {
-    constexpr Shape sh = static_shape(P::kId);
-    sink.init(sh, sp);
-    for (int64_t t = wave; t < ntiles; t += nwaves) { RegFile rf; bool pass[kRows]; int64_t row0; tile_rows<P>(dsh, args, t, rf, pass, row0); sink.consume(sh, rf, pass, row0, sp); }
-    sink.finish(sh, sp);
-  } else {
-    sink.init(dsh, sp);
-    for (int64_t t = wave; t < ntiles; t += nwaves) { RegFile rf; bool pass[kRows]; int64_t row0; tile_rows<P>(dsh, args, t, rf, pass, row0); sink.consume(dsh, rf, pass, row0, sp); }
-    sink.finish(dsh, sp);
-  }
+// hist[grid][NP] -> wg_prefix[grid][NP] (records of partition p written by workgroups < b) and total[NP]
+__global__ __launch_bounds__(kBlock) void part_prefix_kernel(const unsigned int* __restrict__ hist, int grid, uint32_t NP, unsigned long long* __restrict__ wg_prefix,
+                                                             unsigned long long* __restrict__ total) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= NP) return;
+  unsigned long long run = 0;
+  for (int b = 0; b < grid; b++) { wg_prefix[(size_t)b * NP + p] = run; run += hist[(size_t)b * NP + p]; }
+  total[p] = run;
 }
 
 // ---- pass 2: scatter through LDS write-combining buffers ------------------------------------------
 // Workgroup-synchronous tile loop (every wave of the workgroup runs the same number of iterations, so
 // __syncthreads inside the loop is legal -- unlike fused_scan_kernel, whose tiles are handed out per wave).
-constexpr int kMaxSrc = 8;   // distinct aggregate sources carried by a record
+constexpr int kMaxSrc = 4;   // distinct aggregate sources carried by a record (more => the HBM-table sink runs)
 
 struct Rec {
   uint64_t key, vbits, rowid;
@@ -114,45 +146,54 @@ __device__ __forceinline__ void store_record(unsigned long long* dst, const Part
 }
 
 template <class P>
-__global__ __launch_bounds__(kBlock) void part_scatter_kernel(Shape dsh, Args args, PartitionPlan pp, unsigned long long* __restrict__ cursor,
-                                                              unsigned long long* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void part_scatter_kernel(Shape dsh, Args args, PartitionPlan pp, const unsigned long long* __restrict__ part_off,
+                                                              const unsigned long long* __restrict__ wg_prefix, unsigned long long* __restrict__ out) {
   extern __shared__ unsigned long long lds_raw[];
   const uint32_t NP = 1u << pp.log2_parts, B = pp.buf_rows, R = pp.rec_words;
   unsigned long long* buf = lds_raw;                                        // [NP][B][R]
   unsigned long long* fbase = buf + (size_t)NP * B * R;                     // [NP] global record index of a flush
-  unsigned int* cnt = reinterpret_cast<unsigned int*>(fbase + NP);          // [NP]
+  unsigned long long* cur = fbase + NP;                                     // [NP] this workgroup's next record index per partition
+  unsigned int* cnt = reinterpret_cast<unsigned int*>(cur + NP);            // [NP]
   unsigned int* flist = cnt + NP;                                           // [NP]
   unsigned int& nflush = flist[NP];                                         // kept in the dynamic region: a static __shared__ in front of it
                                                                             // would break the 16-byte alignment the ulonglong2 copies need
-  for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) cnt[i] = 0;
+  for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) { cnt[i] = 0; cur[i] = part_off[i] + wg_prefix[(size_t)blockIdx.x * NP + i]; }
   __syncthreads();
-  const int64_t rows_per_block_tile = (int64_t)kBlock * kRows;
-  const int64_t nbt = (args.n_rows + rows_per_block_tile - 1) / rows_per_block_tile;
+  // One barrier round covers kRoundTiles tiles per wave: the loads of all tiles are independent, so several are in
+  // flight per lane while the round's appends/flushes run once.
+  const int64_t rows_per_round = (int64_t)kBlock * kRoundRows;
+  const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
   const int wave_in_block = threadIdx.x >> 6;
-  for (int64_t bt = blockIdx.x; bt < nbt; bt += gridDim.x) {
-    RegFile rf; bool pass[kRows]; int64_t row0;
-    const int64_t tile = bt * (kBlock / 64) + wave_in_block;
-    tile_rows<P>(dsh, args, tile, rf, pass, row0);
-    Rec rec[kRows];
-    uint32_t part[kRows];
-    bool pending[kRows];
+  for (int64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
+    Rec rec[kRoundRows];
+    uint32_t part[kRoundRows];
+    bool pending[kRoundRows];
+    {
+      RegFile rf[kRoundTiles]; bool pass[kRoundTiles][kRows];
+      round_rows<P>(dsh, args, rd, wave_in_block, rf, pass);
 #pragma unroll
-    for (int r = 0; r < kRows; r++) {
-      pending[r] = pass[r];
-      if constexpr (P::kStatic) { constexpr Shape sh = static_shape(P::kId); make_record(sh, pp, rf, r, row0 + r, rec[r]); }
-      else make_record(dsh, pp, rf, r, row0 + r, rec[r]);
-      part[r] = part_of(rec[r].key, (rec[r].vbits >> 63) & 1, pp.log2_parts);
+      for (int t = 0; t < kRoundTiles; t++) {
+        const int64_t row0 = round_row0(rd, t, wave_in_block);
+#pragma unroll
+        for (int r = 0; r < kRows; r++) {
+          const int q = t * kRows + r;
+          pending[q] = pass[t][r];
+          if constexpr (P::kStatic) { constexpr Shape sh = static_shape(P::kId); make_record(sh, pp, rf[t], r, row0 + r, rec[q]); }
+          else make_record(dsh, pp, rf[t], r, row0 + r, rec[q]);
+          part[q] = part_of(rec[q].key, (rec[q].vbits >> 63) & 1, pp.log2_parts);
+        }
+      }
     }
     int any;
     do {
       if (threadIdx.x == 0) nflush = 0;
 #pragma unroll
-      for (int r = 0; r < kRows; r++) {
-        if (!pending[r]) continue;
-        const unsigned int pos = atomicAdd(&cnt[part[r]], 1u);
+      for (int q = 0; q < kRoundRows; q++) {
+        if (!pending[q]) continue;
+        const unsigned int pos = atomicAdd(&cnt[part[q]], 1u);
         if (pos < B) {
-          store_record(buf + ((size_t)part[r] * B + pos) * R, pp, rec[r]);
-          pending[r] = false;
+          store_record(buf + ((size_t)part[q] * B + pos) * R, pp, rec[q]);
+          pending[q] = false;
         }
       }
       __syncthreads();
@@ -160,7 +201,8 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(Shape dsh, Args ar
         if (cnt[p] >= B) {
           const unsigned int slot = atomicAdd(&nflush, 1u);
           flist[slot] = p;
-          fbase[slot] = atomicAdd(&cursor[p], (unsigned long long)B);
+          fbase[slot] = cur[p];      // only this thread touches cur[p] in this phase
+          cur[p] += B;
           cnt[p] = 0;
         }
       }
@@ -174,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(Shape dsh, Args ar
       }
       bool mine = false;
 #pragma unroll
-      for (int r = 0; r < kRows; r++) mine = mine || pending[r];
+      for (int q = 0; q < kRoundRows; q++) mine = mine || pending[q];
       any = __syncthreads_or(mine ? 1 : 0);
     } while (any);
   }
@@ -183,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(Shape dsh, Args ar
   for (uint32_t p = threadIdx.x; p < NP; p += blockDim.x) {
     const unsigned int c = cnt[p] < B ? cnt[p] : B;
     if (!c) continue;
-    const unsigned long long base = atomicAdd(&cursor[p], (unsigned long long)c);
+    const unsigned long long base = cur[p];
     for (uint32_t j = 0; j < c * R; j++) out[(size_t)base * R + j] = buf[(size_t)p * B * R + j];
   }
 }
@@ -200,7 +242,7 @@ struct PartAggParams {
   uint32_t log2_slots;
   uint32_t max_groups;                  // capacity of the output arrays
 };
-constexpr int kAggBlock = 512;
+constexpr int kAggBlock = 1024;
 
 __global__ __launch_bounds__(kAggBlock) void part_agg_kernel(Shape sh, PartitionPlan pp, PartAggParams ap) {
   extern __shared__ unsigned long long lds_raw[];
@@ -215,9 +257,24 @@ __global__ __launch_bounds__(kAggBlock) void part_agg_kernel(Shape sh, Partition
     if (threadIdx.x == 0) { n_occ = 0; cursor_l = 0; full = 0; }
     __syncthreads();
     const uint64_t beg = ap.part_off[p], end = ap.part_off[p + 1];
-    for (uint64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    constexpr int kInFlight = 8;   // records loaded per thread before any is consumed
+    for (uint64_t i0 = beg + threadIdx.x; i0 < end; i0 += (uint64_t)blockDim.x * kInFlight) {
+     unsigned long long w0[kInFlight], w1[kInFlight];
+#pragma unroll
+     for (int u = 0; u < kInFlight; u++) {
+       const uint64_t i = i0 + (uint64_t)u * blockDim.x;
+       w0[u] = 0; w1[u] = 0;
+       if (i < end) {
+         if (R == 2) { const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(ap.recs + i * 2); w0[u] = v.x; w1[u] = v.y; }
+         else { w0[u] = ap.recs[i * R]; w1[u] = R > 1 ? ap.recs[i * R + 1] : 0ull; }
+       }
+     }
+#pragma unroll
+     for (int u = 0; u < kInFlight; u++) {
+      const uint64_t i = i0 + (uint64_t)u * blockDim.x;
+      if (i >= end) continue;
       const unsigned long long* rec = ap.recs + i * R;
-      const uint64_t key = rec[0];
+      const uint64_t key = w0[u];
       const uint64_t vbits = pp.has_valid ? rec[1 + pp.n_src] : ~0ull;
       const uint64_t rowid = pp.has_rowid ? rec[1 + pp.n_src + (pp.has_valid ? 1 : 0)] : 0ull;
       uint32_t slot;
@@ -242,7 +299,7 @@ __global__ __launch_bounds__(kAggBlock) void part_agg_kernel(Shape sh, Partition
       for (uint32_t k = 0; k < n_aggs; k++) {
         const uint8_t kind = sh.aggs[k].kind;
         const uint8_t sj = pp.agg_src[k];
-        const uint64_t v = sj != kNone ? rec[1 + sj] : 0ull;
+        const uint64_t v = sj != kNone ? (sj == 0 ? w1[u] : rec[1 + sj]) : 0ull;
         const bool valid = sj != kNone ? ((vbits >> sj) & 1) : true;
         const uint64_t x = agg_row_value(kind, v, true, valid, rowid);
         if (x != agg_identity_dev(kind) || kind == AGG_SUM_F) {
@@ -250,6 +307,7 @@ __global__ __launch_bounds__(kAggBlock) void part_agg_kernel(Shape sh, Partition
           lds_atomic_agg(kind, cell + k, x);
         }
       }
+     }
     }
     __syncthreads();
     if (full) { if (threadIdx.x == 0) atomicExch(ap.overflow, 1u); __syncthreads(); continue; }
@@ -292,7 +350,7 @@ bool partition_plan(const Shape& sh, double est_groups, bool any_nullable, Parti
     if (j < 0) { j = (int)pp.n_src; pp.src_slot[pp.n_src++] = sh.aggs[k].src; }
     pp.agg_src[k] = (uint8_t)j;
   }
-  if (pp.n_src > 8) return false;   // kMaxSrc
+  if (pp.n_src > 4) return false;   // kMaxSrc
   pp.has_valid = any_nullable ? 1 : 0;
   pp.rec_words = 1 + pp.n_src + pp.has_valid + pp.has_rowid;
   // LDS table of pass 3: as many slots as fit ~144 KB; partitions so that a partition holds <= slots / 2 groups
@@ -308,7 +366,7 @@ bool partition_plan(const Shape& sh, double est_groups, bool any_nullable, Parti
   pp.log2_slots = log2_slots;
   // write-combining buffers of pass 2
   uint32_t B = 8;
-  auto scatter_lds = [&](uint32_t b) { return ((size_t)(1u << log2_parts) * b * pp.rec_words + (1u << log2_parts)) * 8 + (size_t)(1u << log2_parts) * 8 + 16; };
+  auto scatter_lds = [&](uint32_t b) { return ((size_t)(1u << log2_parts) * b * pp.rec_words + 2 * (1u << log2_parts)) * 8 + (size_t)(1u << log2_parts) * 8 + 16; };
   while (B > 2 && scatter_lds(B) > lds_budget) B -= 2;
   if (scatter_lds(B) > lds_budget) return false;
   pp.buf_rows = B;
@@ -328,34 +386,36 @@ bool partition_plan(const Shape& sh, double est_groups, bool any_nullable, Parti
 // groups, or -1 if an LDS table overflowed (the caller falls back to the HBM-table sink).
 int64_t partitioned_agg(const Shape& sh, const Args& args, const PartitionPlan& pp, int static_id, Buf* out_keys, Buf* out_kvalid, Buf* out_acc, std::string* desc) {
   const uint32_t NP = 1u << pp.log2_parts;
-  const int grid = grid_for((args.n_rows + kTileRows - 1) / kTileRows, kBlock / 64, 8);
-  Buf hist = dev_alloc_zero(sizeof(uint64_t) * (NP + 1));
+  const size_t slds = ((size_t)NP * pp.buf_rows * pp.rec_words + 2 * NP) * 8 + (size_t)NP * 8 + 16;
+  const int64_t rows_per_round = (int64_t)kBlock * kRoundRows;
+  const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
+  const int sgrid = (int)std::min<int64_t>(nrounds, (int64_t)device().cu_count * (slds > 76 * 1024 ? 1 : 2));   // the SAME grid for pass 1 and pass 2
+  Buf hist = dev_alloc(sizeof(uint32_t) * (size_t)sgrid * NP);
+  Buf wg_prefix = dev_alloc(sizeof(uint64_t) * (size_t)sgrid * NP);
+  Buf totals = dev_alloc(sizeof(uint64_t) * (NP + 1));
   Buf part_off = dev_alloc(sizeof(uint64_t) * (NP + 2));
   {
     ProfileScope ps("part_count", scan_bytes(sh, args), (uint64_t)args.n_rows);
-    PartCountSink::Params cp{hist->as<unsigned long long>(), pp.log2_parts};
     const size_t lds = sizeof(unsigned int) * NP;
     switch (static_id) {
-      PLX_PART_STATIC_CASES(part_count_kernel, dim3(grid), dim3(kBlock), lds, stream(), sh, args, cp)
-      default: hipLaunchKernelGGL((part_count_kernel<DynProg>), dim3(grid), dim3(kBlock), lds, stream(), sh, args, cp); break;
+      PLX_PART_STATIC_CASES(part_count_kernel, dim3(sgrid), dim3(kBlock), lds, stream(), sh, args, pp.log2_parts, hist->as<unsigned int>())
+      default: hipLaunchKernelGGL((part_count_kernel<DynProg>), dim3(sgrid), dim3(kBlock), lds, stream(), sh, args, pp.log2_parts, hist->as<unsigned int>()); break;
     }
     PLX_HIP(hipGetLastError());
   }
-  exclusive_scan_u64(hist->as<uint64_t>(), part_off->as<uint64_t>(), NP);   // writes NP + 1 entries
+  hipLaunchKernelGGL(part_prefix_kernel, dim3((NP + kBlock - 1) / kBlock), dim3(kBlock), 0, stream(), hist->as<unsigned int>(), sgrid, NP, wg_prefix->as<unsigned long long>(),
+                     totals->as<unsigned long long>());
+  PLX_HIP(hipGetLastError());
+  exclusive_scan_u64(totals->as<uint64_t>(), part_off->as<uint64_t>(), NP);   // writes NP + 1 entries
   uint64_t total = 0;
   d2h_sync(&total, part_off->as<uint64_t>() + NP, 8);
   if (total == 0) { *out_keys = dev_alloc(8); *out_kvalid = dev_alloc(8); *out_acc = dev_alloc(8); return 0; }
   Buf recs = dev_alloc(sizeof(uint64_t) * (size_t)total * pp.rec_words + 64);
-  Buf cursor = dev_alloc(sizeof(uint64_t) * NP);
-  PLX_HIP(hipMemcpyAsync(cursor->ptr, part_off->ptr, sizeof(uint64_t) * NP, hipMemcpyDeviceToDevice, stream()));
   {
     ProfileScope ps("part_scatter", scan_bytes(sh, args) + total * pp.rec_words * 8, (uint64_t)args.n_rows);
-    const size_t lds = ((size_t)NP * pp.buf_rows * pp.rec_words + NP) * 8 + (size_t)NP * 8 + 16;
-    const int64_t nbt = (args.n_rows + (int64_t)kBlock * kRows - 1) / ((int64_t)kBlock * kRows);
-    const int sgrid = (int)std::min<int64_t>(nbt, (int64_t)device().cu_count * (lds > 72 * 1024 ? 1 : 2));
     switch (static_id) {
-      PLX_PART_STATIC_CASES(part_scatter_kernel, dim3(sgrid), dim3(kBlock), lds, stream(), sh, args, pp, cursor->as<unsigned long long>(), recs->as<unsigned long long>())
-      default: hipLaunchKernelGGL((part_scatter_kernel<DynProg>), dim3(sgrid), dim3(kBlock), lds, stream(), sh, args, pp, cursor->as<unsigned long long>(), recs->as<unsigned long long>()); break;
+      PLX_PART_STATIC_CASES(part_scatter_kernel, dim3(sgrid), dim3(kBlock), slds, stream(), sh, args, pp, part_off->as<unsigned long long>(), wg_prefix->as<unsigned long long>(), recs->as<unsigned long long>())
+      default: hipLaunchKernelGGL((part_scatter_kernel<DynProg>), dim3(sgrid), dim3(kBlock), slds, stream(), sh, args, pp, part_off->as<unsigned long long>(), wg_prefix->as<unsigned long long>(), recs->as<unsigned long long>()); break;
     }
     PLX_HIP(hipGetLastError());
   }
