@@ -80,13 +80,80 @@ __device__ __forceinline__ void load_input(const Input& in, int dtype, int64_t r
   }
 }
 
-// ---- one program step ---------------------------------------------------------------
+// ---- generic interpreter: column prefetch ------------------------------------------------------------
+// The interpreter's OP_LOAD writes a dynamically indexed register, so the loaded value is needed at once and
+// the loads of a tile would run one after the other (load -> wait -> next load).  Instead the first kPrefetch
+// input columns are fetched up front into statically indexed registers as RAW bits (no dependent ALU until
+// OP_LOAD converts them): all of a tile's columns are in flight together.
+constexpr int kPrefetch = 8;
+typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
+struct Prefetched {
+  u64x8 bits0, bits1;  // zero-extended raw element bits of rows 0 / 1 (BOOL: the bitmap word of row 0)
+  u64x8 vword;         // raw validity word of row 0 (all ones when the column has no bitmap)
+};
+
 template <bool FULL>
-__device__ __forceinline__ void exec_op(const Op op, const Shape& sh, const Args& args, int pc, int64_t row0, RegFile& rf) {
+__device__ __forceinline__ void prefetch_inputs(const Shape& sh, const Args& args, int64_t row0, Prefetched& pf) {
+#pragma unroll
+  for (int i = 0; i < kPrefetch; i++) {
+    if (i < sh.n_inputs) {   // wave-uniform; keeps the loop fully unrolled so register indices stay static
+    const Input& in = args.in[i];
+    int64_t i0 = row0, i1 = row0 + 1;
+    if (!FULL) { if (i0 > args.n_rows - 1) i0 = args.n_rows - 1; if (i1 > args.n_rows - 1) i1 = args.n_rows - 1; }
+    uint64_t b0 = 0, b1 = 0;
+    switch (dtype_width_dev(sh.in_dtype[i]) * (sh.in_dtype[i] == PLX_BOOL ? 0 : 1)) {
+      case 8: if (FULL) { const Pack<uint64_t, 2> x = load_pack<uint64_t, 2>(reinterpret_cast<const uint64_t*>(in.values) + row0); b0 = x.v[0]; b1 = x.v[1]; }
+              else { b0 = reinterpret_cast<const uint64_t*>(in.values)[i0]; b1 = reinterpret_cast<const uint64_t*>(in.values)[i1]; } break;
+      case 4: if (FULL) { const Pack<uint32_t, 2> x = load_pack<uint32_t, 2>(reinterpret_cast<const uint32_t*>(in.values) + row0); b0 = x.v[0]; b1 = x.v[1]; }
+              else { b0 = reinterpret_cast<const uint32_t*>(in.values)[i0]; b1 = reinterpret_cast<const uint32_t*>(in.values)[i1]; } break;
+      case 2: if (FULL) { const Pack<uint16_t, 2> x = load_pack<uint16_t, 2>(reinterpret_cast<const uint16_t*>(in.values) + row0); b0 = x.v[0]; b1 = x.v[1]; }
+              else { b0 = reinterpret_cast<const uint16_t*>(in.values)[i0]; b1 = reinterpret_cast<const uint16_t*>(in.values)[i1]; } break;
+      case 1: if (FULL) { const Pack<uint8_t, 2> x = load_pack<uint8_t, 2>(reinterpret_cast<const uint8_t*>(in.values) + row0); b0 = x.v[0]; b1 = x.v[1]; }
+              else { b0 = reinterpret_cast<const uint8_t*>(in.values)[i0]; b1 = reinterpret_cast<const uint8_t*>(in.values)[i1]; } break;
+      default: b0 = reinterpret_cast<const uint64_t*>(in.values)[i0 >> 6]; break;   // BOOL: bitmap word of row 0 (rows 2l, 2l+1 share it)
+    }
+    pf.bits0[i] = b0; pf.bits1[i] = b1;
+    pf.vword[i] = in.validity ? in.validity[i0 >> 6] : ~0ull;
+    }
+  }
+}
+
+// Element `idx` (wave-uniform, run-time) of a vector whose elements were written with compile-time indices.  A select
+// chain, not v[idx]: LLVM scalarises such a vector and a dynamic extract would force it into scratch memory.
+__device__ __forceinline__ uint64_t pick8(const u64x8& v, int idx) {
+  uint64_t r = v[0];
+#pragma unroll
+  for (int j = 1; j < kPrefetch; j++) r = (idx == j) ? v[j] : r;
+  return r;
+}
+
+// OP_LOAD from prefetched raw bits: widen by dtype (sign / zero extension), extract validity bits
+template <bool FULL>
+__device__ __forceinline__ void load_prefetched(const Prefetched& pf, int idx, int dtype, bool has_validity, int64_t row0, int64_t n, uint64_t out[kRows], uint32_t& vbits) {
+  const uint64_t b0 = pick8(pf.bits0, idx), b1 = pick8(pf.bits1, idx);
+  int64_t i0 = row0; if (!FULL && i0 > n - 1) i0 = n - 1;
+  switch (dtype) {
+    case PLX_I32: out[0] = (uint64_t)(long long)(int32_t)b0; out[1] = (uint64_t)(long long)(int32_t)b1; break;
+    case PLX_I16: out[0] = (uint64_t)(long long)(int16_t)b0; out[1] = (uint64_t)(long long)(int16_t)b1; break;
+    case PLX_I8: out[0] = (uint64_t)(long long)(int8_t)b0; out[1] = (uint64_t)(long long)(int8_t)b1; break;
+    case PLX_BOOL: { const uint64_t w = b0 >> (i0 & 63); out[0] = w & 1; out[1] = (w >> 1) & 1; } break;
+    default: out[0] = b0; out[1] = b1; break;   // 64-bit types and zero-extended unsigned types
+  }
+  vbits = (1u << kRows) - 1;
+  if (has_validity) {
+    vbits = (uint32_t)(pick8(pf.vword, idx) >> (i0 & 63)) & ((1u << kRows) - 1);
+    if (!FULL && row0 + 1 > n - 1) vbits &= 1u;
+  }
+}
+
+// ---- one program step ---------------------------------------------------------------
+template <bool FULL, bool PRE = false>
+__device__ __forceinline__ void exec_op(const Op op, const Shape& sh, const Args& args, int pc, int64_t row0, RegFile& rf, const Prefetched& pf) {
   uint64_t a[kRows], b[kRows], d[kRows];
   uint32_t va = (1u << kRows) - 1, vb = (1u << kRows) - 1, vd;
   if (op.code == OP_LOAD) {
-    load_input<FULL>(args.in[op.a], sh.in_dtype[op.a], row0, args.n_rows, d, vd);
+    if (PRE && op.a < kPrefetch) load_prefetched<FULL>(pf, op.a, sh.in_dtype[op.a], args.in[op.a].validity != nullptr, row0, args.n_rows, d, vd);
+    else load_input<FULL>(args.in[op.a], sh.in_dtype[op.a], row0, args.n_rows, d, vd);
   } else if (op.code == OP_CONST) {
 #pragma unroll
     for (int r = 0; r < kRows; r++) d[r] = args.imm[pc];
@@ -236,10 +303,14 @@ template <class P, bool FULL>
 __device__ __forceinline__ void run_program(const Shape& dsh, const Args& args, int64_t row0, RegFile& rf) {
   if constexpr (P::kStatic) {
     constexpr Shape sh = static_shape(P::kId);
+    Prefetched none;   // unused by AOT programs (their loads are compile-time scheduled)
 #pragma unroll
-    for (int pc = 0; pc < sh.n_ops; pc++) exec_op<FULL>(sh.ops[pc], sh, args, pc, row0, rf);
+    for (int pc = 0; pc < sh.n_ops; pc++) exec_op<FULL, false>(sh.ops[pc], sh, args, pc, row0, rf, none);
   } else {
-    for (int pc = 0; pc < dsh.n_ops; pc++) exec_op<FULL>(dsh.ops[pc], dsh, args, pc, row0, rf);
+    Prefetched pf;
+    pf.bits0 = 0; pf.bits1 = 0; pf.vword = 0;
+    prefetch_inputs<FULL>(dsh, args, row0, pf);
+    for (int pc = 0; pc < dsh.n_ops; pc++) exec_op<FULL, true>(dsh.ops[pc], dsh, args, pc, row0, rf, pf);
   }
 }
 

@@ -39,14 +39,17 @@ __device__ __forceinline__ uint32_t part_of(uint64_t key, bool kvalid, uint32_t 
 // Workgroup-synchronous: round rd covers kRoundTiles tiles per wave (kBlock * kRows * kRoundTiles rows); workgroup b
 // handles rounds b, b + grid, ...  Both passes use the SAME grid, so pass 1's per-workgroup histogram tells pass 2
 // exactly where each workgroup writes each partition: no atomics on the scatter path, deterministic output.
-constexpr int kRoundTiles = 4;
-constexpr int kRoundRows = kRows * kRoundTiles;
+// AOT programs run 4 tiles per round (their register files are small); the generic interpreter's dynamically
+// indexed register file is large, so it runs 1 tile per round.
+constexpr int kStaticRoundTiles = 4;
+template <class P> struct Round { static constexpr int kTiles = P::kStatic ? kStaticRoundTiles : 1; static constexpr int kRowsPerLane = kRows * kTiles; };
 
 // Evaluates the program for the kRoundTiles tiles of round `rd` owned by this wave.  When the whole round lies inside
 // the input (wave-uniform test) the tiles run back to back in straight-line code, so the compiler can issue the column
 // loads of all tiles before the first use; the tail round takes the bounds-checked path.
 template <class P>
-__device__ __forceinline__ void round_rows(const Shape& dsh, const Args& args, int64_t rd, int wave_in_block, RegFile rf[kRoundTiles], bool pass[kRoundTiles][kRows]) {
+__device__ __forceinline__ void round_rows(const Shape& dsh, const Args& args, int64_t rd, int wave_in_block, RegFile rf[Round<P>::kTiles], bool pass[Round<P>::kTiles][kRows]) {
+  constexpr int kRoundTiles = Round<P>::kTiles;
   const int lane = lane_id();
   const int64_t first_tile = rd * kRoundTiles * (kBlock / 64);
   const bool all_full = (first_tile + (int64_t)kRoundTiles * (kBlock / 64)) * kTileRows <= args.n_rows;
@@ -68,8 +71,9 @@ __device__ __forceinline__ void round_rows(const Shape& dsh, const Args& args, i
     for (int t = 0; t < kRoundTiles; t++) { int64_t row0; tile_rows<P>(dsh, args, first_tile + (int64_t)t * (kBlock / 64) + wave_in_block, rf[t], pass[t], row0); }
   }
 }
+template <class P>
 __device__ __forceinline__ int64_t round_row0(int64_t rd, int t, int wave_in_block) {
-  return ((rd * kRoundTiles + t) * (kBlock / 64) + wave_in_block) * (int64_t)kTileRows + (int64_t)lane_id() * kRows;
+  return ((rd * Round<P>::kTiles + t) * (kBlock / 64) + wave_in_block) * (int64_t)kTileRows + (int64_t)lane_id() * kRows;
 }
 
 // ---- pass 1: per-workgroup partition histogram -----------------------------------------------------
@@ -80,7 +84,8 @@ __global__ __launch_bounds__(kBlock) void part_count_kernel(Shape dsh, Args args
   const uint32_t NP = 1u << log2_parts;
   for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) cnt[i] = 0;
   __syncthreads();
-  const int64_t rows_per_round = (int64_t)kBlock * kRoundRows;
+  constexpr int kRoundTiles = Round<P>::kTiles;
+  const int64_t rows_per_round = (int64_t)kBlock * Round<P>::kRowsPerLane;
   const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
   const int wave_in_block = threadIdx.x >> 6;
   uint8_t key_slot;
@@ -161,6 +166,8 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(Shape dsh, Args ar
   __syncthreads();
   // One barrier round covers kRoundTiles tiles per wave: the loads of all tiles are independent, so several are in
   // flight per lane while the round's appends/flushes run once.
+  constexpr int kRoundTiles = Round<P>::kTiles;
+  constexpr int kRoundRows = Round<P>::kRowsPerLane;
   const int64_t rows_per_round = (int64_t)kBlock * kRoundRows;
   const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
   const int wave_in_block = threadIdx.x >> 6;
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(Shape dsh, Args ar
       round_rows<P>(dsh, args, rd, wave_in_block, rf, pass);
 #pragma unroll
       for (int t = 0; t < kRoundTiles; t++) {
-        const int64_t row0 = round_row0(rd, t, wave_in_block);
+        const int64_t row0 = round_row0<P>(rd, t, wave_in_block);
 #pragma unroll
         for (int r = 0; r < kRows; r++) {
           const int q = t * kRows + r;
@@ -387,7 +394,8 @@ bool partition_plan(const Shape& sh, double est_groups, bool any_nullable, Parti
 int64_t partitioned_agg(const Shape& sh, const Args& args, const PartitionPlan& pp, int static_id, Buf* out_keys, Buf* out_kvalid, Buf* out_acc, std::string* desc) {
   const uint32_t NP = 1u << pp.log2_parts;
   const size_t slds = ((size_t)NP * pp.buf_rows * pp.rec_words + 2 * NP) * 8 + (size_t)NP * 8 + 16;
-  const int64_t rows_per_round = (int64_t)kBlock * kRoundRows;
+  const bool is_static = static_id == SHAPE_GB_SUM_CNT_I64 || static_id == SHAPE_GB_SUM_MEAN_U32_F64;   // the cases of PLX_PART_STATIC_CASES
+  const int64_t rows_per_round = (int64_t)kBlock * kRows * (is_static ? kStaticRoundTiles : 1);
   const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
   const int sgrid = (int)std::min<int64_t>(nrounds, (int64_t)device().cu_count * (slds > 76 * 1024 ? 1 : 2));   // the SAME grid for pass 1 and pass 2
   Buf hist = dev_alloc(sizeof(uint32_t) * (size_t)sgrid * NP);
