@@ -86,7 +86,20 @@ struct Args {
   Input in[kMaxInputs];
   uint64_t imm[kMaxOps];
   int64_t n_rows;
+  // generic interpreter only: its register file lives in dynamic LDS behind the sink's own LDS (set by the launcher)
+  uint32_t rf_lds_offset;
+  uint32_t rf_slots;
 };
+// slots a program touches (size of the generic interpreter's LDS register file)
+inline uint32_t program_slots(const Shape& s) {
+  uint32_t m = 0;
+  auto up = [&](uint32_t v) { if (v != kNone && v + 1 > m) m = v + 1; };
+  for (int i = 0; i < s.n_ops; i++) { up(s.ops[i].dst); }
+  up(s.pred); up(s.key);
+  for (int i = 0; i < s.n_keys; i++) up(s.keys[i]);
+  for (int i = 0; i < s.n_aggs; i++) up(s.aggs[i].src);
+  return m ? m : 1;
+}
 
 // identity element of an aggregate, as a 64-bit pattern
 inline uint64_t agg_identity(uint8_t kind) {

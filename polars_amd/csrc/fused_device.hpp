@@ -17,10 +17,31 @@ using namespace fused;
 typedef unsigned long long u64x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
 
+// Register file of the expression program: kSlots 64-bit values per row + a validity bit per (slot, row).
+//  * RegFile (VGPRs): used by the AOT programs, where every slot index is a compile-time constant.
+//  * LdsRegFile: used by the generic interpreter, where slot numbers are run-time (wave-uniform) values.  A
+//    dynamically indexed VGPR vector is lowered to a tree of scalar compare/branch per access (the generic scan
+//    kernel was 28.8 k instructions and ran at 0.7 TB/s); in LDS a slot access is one ds_read/ds_write_b64 at
+//    base + ((slot * kRows + row) * 64 + lane) * 8 -- wave-private, consecutive lanes on consecutive banks.
 struct RegFile {
   u64x16 v[kRows];
   u32x16 valid;  // bit r of element s: row r of slot s is valid
+  __device__ __forceinline__ uint64_t get(int r, int s) const { return v[r][s]; }
+  __device__ __forceinline__ uint32_t getv(int s) const { return valid[s]; }
+  __device__ __forceinline__ void set(int r, int s, uint64_t x) { v[r][s] = x; }
+  __device__ __forceinline__ void setv(int s, uint32_t m) { valid[s] = m; }
 };
+struct LdsRegFile {
+  unsigned long long* vals;   // [slots][kRows][64]
+  unsigned int* vbits;        // [slots][64]
+  int lane;
+  __device__ __forceinline__ uint64_t get(int r, int s) const { return vals[(s * kRows + r) * 64 + lane]; }
+  __device__ __forceinline__ uint32_t getv(int s) const { return vbits[s * 64 + lane]; }
+  __device__ __forceinline__ void set(int r, int s, uint64_t x) { vals[(s * kRows + r) * 64 + lane] = x; }
+  __device__ __forceinline__ void setv(int s, uint32_t m) { vbits[s * 64 + lane] = m; }
+};
+// bytes of LDS one wave's LdsRegFile needs
+__host__ __device__ constexpr unsigned lds_regfile_bytes_per_wave(unsigned slots) { return slots * (kRows * 64 * 8 + 64 * 4); }
 
 __device__ __forceinline__ int dtype_width_dev(int dt) {
   switch (dt) {
@@ -118,50 +139,50 @@ __device__ __forceinline__ void prefetch_inputs(const Shape& sh, const Args& arg
   }
 }
 
-// Element `idx` (wave-uniform, run-time) of a vector whose elements were written with compile-time indices.  A select
-// chain, not v[idx]: LLVM scalarises such a vector and a dynamic extract would force it into scratch memory.
-__device__ __forceinline__ uint64_t pick8(const u64x8& v, int idx) {
-  uint64_t r = v[0];
+// Phase 2 of the generic prologue: the LOAD ops are the first n_inputs ops of every program and op i reads input i
+// (the host compiler emits loads first, one per distinct column -- engine.cpp Compiler::finish), so input i's raw
+// bits (static register index) are widened by dtype and written to the LDS slot op i names.
+template <bool FULL, class RF>
+__device__ __forceinline__ void store_prefetched(const Shape& sh, const Args& args, int64_t row0, const Prefetched& pf, RF& rf) {
+  int64_t i0 = row0; if (!FULL && i0 > args.n_rows - 1) i0 = args.n_rows - 1;
 #pragma unroll
-  for (int j = 1; j < kPrefetch; j++) r = (idx == j) ? v[j] : r;
-  return r;
-}
-
-// OP_LOAD from prefetched raw bits: widen by dtype (sign / zero extension), extract validity bits
-template <bool FULL>
-__device__ __forceinline__ void load_prefetched(const Prefetched& pf, int idx, int dtype, bool has_validity, int64_t row0, int64_t n, uint64_t out[kRows], uint32_t& vbits) {
-  const uint64_t b0 = pick8(pf.bits0, idx), b1 = pick8(pf.bits1, idx);
-  int64_t i0 = row0; if (!FULL && i0 > n - 1) i0 = n - 1;
-  switch (dtype) {
-    case PLX_I32: out[0] = (uint64_t)(long long)(int32_t)b0; out[1] = (uint64_t)(long long)(int32_t)b1; break;
-    case PLX_I16: out[0] = (uint64_t)(long long)(int16_t)b0; out[1] = (uint64_t)(long long)(int16_t)b1; break;
-    case PLX_I8: out[0] = (uint64_t)(long long)(int8_t)b0; out[1] = (uint64_t)(long long)(int8_t)b1; break;
-    case PLX_BOOL: { const uint64_t w = b0 >> (i0 & 63); out[0] = w & 1; out[1] = (w >> 1) & 1; } break;
-    default: out[0] = b0; out[1] = b1; break;   // 64-bit types and zero-extended unsigned types
-  }
-  vbits = (1u << kRows) - 1;
-  if (has_validity) {
-    vbits = (uint32_t)(pick8(pf.vword, idx) >> (i0 & 63)) & ((1u << kRows) - 1);
-    if (!FULL && row0 + 1 > n - 1) vbits &= 1u;
+  for (int i = 0; i < kPrefetch; i++) {
+    if (i < sh.n_inputs) {
+      const uint64_t b0 = pf.bits0[i], b1 = pf.bits1[i];
+      uint64_t o0, o1;
+      switch (sh.in_dtype[i]) {
+        case PLX_I32: o0 = (uint64_t)(long long)(int32_t)b0; o1 = (uint64_t)(long long)(int32_t)b1; break;
+        case PLX_I16: o0 = (uint64_t)(long long)(int16_t)b0; o1 = (uint64_t)(long long)(int16_t)b1; break;
+        case PLX_I8: o0 = (uint64_t)(long long)(int8_t)b0; o1 = (uint64_t)(long long)(int8_t)b1; break;
+        case PLX_BOOL: { const uint64_t w = b0 >> (i0 & 63); o0 = w & 1; o1 = (w >> 1) & 1; } break;
+        default: o0 = b0; o1 = b1; break;   // 64-bit types and zero-extended unsigned types
+      }
+      uint32_t vb = (1u << kRows) - 1;
+      if (args.in[i].validity) {
+        vb = (uint32_t)(pf.vword[i] >> (i0 & 63)) & ((1u << kRows) - 1);
+        if (!FULL && row0 + 1 > args.n_rows - 1) vb &= 1u;
+      }
+      const int dst = sh.ops[i].dst;
+      rf.set(0, dst, o0); rf.set(1, dst, o1); rf.setv(dst, vb);
+    }
   }
 }
 
 // ---- one program step ---------------------------------------------------------------
-template <bool FULL, bool PRE = false>
-__device__ __forceinline__ void exec_op(const Op op, const Shape& sh, const Args& args, int pc, int64_t row0, RegFile& rf, const Prefetched& pf) {
+template <bool FULL, class RF>
+__device__ __forceinline__ void exec_op(const Op op, const Shape& sh, const Args& args, int pc, int64_t row0, RF& rf) {
   uint64_t a[kRows], b[kRows], d[kRows];
   uint32_t va = (1u << kRows) - 1, vb = (1u << kRows) - 1, vd;
   if (op.code == OP_LOAD) {
-    if (PRE && op.a < kPrefetch) load_prefetched<FULL>(pf, op.a, sh.in_dtype[op.a], args.in[op.a].validity != nullptr, row0, args.n_rows, d, vd);
-    else load_input<FULL>(args.in[op.a], sh.in_dtype[op.a], row0, args.n_rows, d, vd);
+    load_input<FULL>(args.in[op.a], sh.in_dtype[op.a], row0, args.n_rows, d, vd);
   } else if (op.code == OP_CONST) {
 #pragma unroll
     for (int r = 0; r < kRows; r++) d[r] = args.imm[pc];
     vd = (1u << kRows) - 1;
   } else {
 #pragma unroll
-    for (int r = 0; r < kRows; r++) { a[r] = rf.v[r][op.a]; b[r] = rf.v[r][op.b]; }
-    va = rf.valid[op.a]; vb = rf.valid[op.b];
+    for (int r = 0; r < kRows; r++) { a[r] = rf.get(r, op.a); b[r] = rf.get(r, op.b); }
+    va = rf.getv(op.a); vb = rf.getv(op.b);
     vd = va & vb;
     switch (op.code) {
       case OP_ADD_F:
@@ -291,26 +312,47 @@ __device__ __forceinline__ void exec_op(const Op op, const Shape& sh, const Args
     vd &= (1u << kRows) - 1;
   }
 #pragma unroll
-  for (int r = 0; r < kRows; r++) rf.v[r][op.dst] = d[r];
-  rf.valid[op.dst] = vd;
+  for (int r = 0; r < kRows; r++) rf.set(r, op.dst, d[r]);
+  rf.setv(op.dst, vd);
 }
 
 // ---- program providers ----------------------------------------------------------
 struct DynProg { static constexpr bool kStatic = false; static constexpr int kId = -1; };
 template <int ID> struct StatProg { static constexpr bool kStatic = true; static constexpr int kId = ID; };
 
-template <class P, bool FULL>
-__device__ __forceinline__ void run_program(const Shape& dsh, const Args& args, int64_t row0, RegFile& rf) {
+template <class P, bool FULL, class RF>
+__device__ __forceinline__ void run_program(const Shape& dsh, const Args& args, int64_t row0, RF& rf) {
   if constexpr (P::kStatic) {
     constexpr Shape sh = static_shape(P::kId);
-    Prefetched none;   // unused by AOT programs (their loads are compile-time scheduled)
 #pragma unroll
-    for (int pc = 0; pc < sh.n_ops; pc++) exec_op<FULL, false>(sh.ops[pc], sh, args, pc, row0, rf, none);
+    for (int pc = 0; pc < sh.n_ops; pc++) exec_op<FULL>(sh.ops[pc], sh, args, pc, row0, rf);
   } else {
+    // generic interpreter: all column loads in flight first, then widen + store into the LDS slots, then the ops
     Prefetched pf;
     pf.bits0 = 0; pf.bits1 = 0; pf.vword = 0;
     prefetch_inputs<FULL>(dsh, args, row0, pf);
-    for (int pc = 0; pc < dsh.n_ops; pc++) exec_op<FULL, true>(dsh.ops[pc], dsh, args, pc, row0, rf, pf);
+    store_prefetched<FULL>(dsh, args, row0, pf, rf);
+    const int first = dsh.n_inputs < kPrefetch ? dsh.n_inputs : kPrefetch;
+    for (int pc = first; pc < dsh.n_ops; pc++) exec_op<FULL>(dsh.ops[pc], dsh, args, pc, row0, rf);
+  }
+}
+
+// Register file of a kernel running program provider P: VGPRs for AOT programs, the wave's slice of dynamic LDS
+// (at args.rf_lds_offset, after the sink's own LDS) for the generic interpreter.
+template <class P> struct RegFileOf { using type = RegFile; };
+template <> struct RegFileOf<DynProg> { using type = LdsRegFile; };
+template <class P>
+__device__ __forceinline__ typename RegFileOf<P>::type make_regfile(const Args& args) {
+  if constexpr (P::kStatic) { return RegFile{}; }
+  else {
+    extern __shared__ unsigned long long plx_dyn_lds[];
+    const unsigned per_wave = lds_regfile_bytes_per_wave(args.rf_slots);
+    unsigned char* base = reinterpret_cast<unsigned char*>(plx_dyn_lds) + args.rf_lds_offset + (threadIdx.x >> 6) * per_wave;
+    LdsRegFile rf;
+    rf.vals = reinterpret_cast<unsigned long long*>(base);
+    rf.vbits = reinterpret_cast<unsigned int*>(base + (size_t)args.rf_slots * kRows * 64 * 8);
+    rf.lane = lane_id();
+    return rf;
   }
 }
 
@@ -395,14 +437,14 @@ __device__ __forceinline__ void lds_atomic_agg(uint8_t kind, unsigned long long*
   }
 }
 
-template <class S>
-__device__ __forceinline__ void atomic_row(const S& sh, const RegFile& rf, int r, int64_t row, unsigned long long* cells) {
+template <class S, class RF>
+__device__ __forceinline__ void atomic_row(const S& sh, const RF& rf, int r, int64_t row, unsigned long long* cells) {
 #pragma unroll
   for (int k = 0; k < kMaxAggs; k++) {
     if (k < sh.n_aggs) {
       const Agg ag = sh.aggs[k];
-      uint64_t v = rf.v[r][ag.src];
-      bool valid = (rf.valid[ag.src] >> r) & 1;
+      uint64_t v = rf.get(r, ag.src);
+      bool valid = (rf.getv(ag.src) >> r) & 1;
       uint64_t x = agg_row_value(ag.kind, v, true, valid, (uint64_t)row);
       if (x != agg_identity_dev(ag.kind) || ag.kind == AGG_SUM_F) {
         if (ag.kind == AGG_SUM_F && !valid) continue;
@@ -413,8 +455,8 @@ __device__ __forceinline__ void atomic_row(const S& sh, const RegFile& rf, int r
 }
 
 // ---- the scan kernels ------------------------------------------------------------------
-template <class P>
-__device__ __forceinline__ bool tile_rows(const Shape& dsh, const Args& args, int64_t tile, RegFile& rf, bool pass[kRows], int64_t& row0) {
+template <class P, class RF>
+__device__ __forceinline__ bool tile_rows(const Shape& dsh, const Args& args, int64_t tile, RF& rf, bool pass[kRows], int64_t& row0) {
   const int lane = lane_id();
   const int64_t base = tile * kTileRows;
   row0 = base + (int64_t)lane * kRows;
@@ -426,10 +468,21 @@ __device__ __forceinline__ bool tile_rows(const Shape& dsh, const Args& args, in
 #pragma unroll
   for (int r = 0; r < kRows; r++) {
     bool ok = full || (row0 + r < args.n_rows);
-    if (pred != kNone) ok = ok && (rf.v[r][pred] & 1) && ((rf.valid[pred] >> r) & 1);
+    if (pred != kNone) ok = ok && (rf.get(r, pred) & 1) && ((rf.getv(pred) >> r) & 1);
     pass[r] = ok;
   }
   return full;
+}
+
+// ---- host: launching the generic interpreter -----------------------------------------------------------
+// Its register file lives in dynamic LDS behind the sink's own LDS: returns the Args / LDS size to launch with.
+struct DynLaunch { Args args; size_t lds; };
+inline DynLaunch dyn_launch(const Shape& sh, const Args& a, size_t sink_lds) {
+  DynLaunch d{a, 0};
+  d.args.rf_slots = program_slots(sh);
+  d.args.rf_lds_offset = (uint32_t)((sink_lds + 15) & ~(size_t)15);
+  d.lds = d.args.rf_lds_offset + (size_t)(kBlock / 64) * lds_regfile_bytes_per_wave(d.args.rf_slots);
+  return d;
 }
 
 }  // namespace k

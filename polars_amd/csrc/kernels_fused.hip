@@ -61,15 +61,15 @@ struct RegAggSink {
 #pragma unroll
     for (int k = 0; k < kMaxAggs; k++) acc[k] = (k < sh.n_aggs) ? agg_identity_dev(sh.aggs[k].kind) : 0ull;
   }
-  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params&) {
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params&) {
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
 #pragma unroll
       for (int k = 0; k < kMaxAggs; k++) {
         if (k < sh.n_aggs) {
           const Agg ag = sh.aggs[k];
-          uint64_t v = rf.v[r][ag.src];
-          bool valid = (rf.valid[ag.src] >> r) & 1;
+          uint64_t v = rf.get(r, ag.src);
+          bool valid = (rf.getv(ag.src) >> r) & 1;
           acc[k] = agg_combine(ag.kind, acc[k], agg_row_value(ag.kind, v, pass[r], valid, (uint64_t)(row0 + r)));
         }
       }
@@ -116,20 +116,20 @@ struct LdsAggSink {
     for (int i = threadIdx.x; i < cells * p.copies; i += blockDim.x) lds_tbl[i] = agg_identity_dev(sh.aggs[(i / p.copies) % sh.n_aggs].kind);
     __syncthreads();
   }
-  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
     extern __shared__ unsigned long long lds_tbl[];
     const int copy = lane_id() & (p.copies - 1);
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
       if (!pass[r]) continue;
-      const uint32_t gid = (uint32_t)rf.v[r][sh.key];
+      const uint32_t gid = (uint32_t)rf.get(r, sh.key);
       unsigned long long* cells = lds_tbl + (size_t)gid * sh.n_aggs * p.copies + copy;
 #pragma unroll
       for (int k = 0; k < kMaxAggs; k++) {
         if (k < sh.n_aggs) {
           const Agg ag = sh.aggs[k];
-          uint64_t v = rf.v[r][ag.src];
-          bool valid = (rf.valid[ag.src] >> r) & 1;
+          uint64_t v = rf.get(r, ag.src);
+          bool valid = (rf.getv(ag.src) >> r) & 1;
           if ((ag.kind == AGG_SUM_F || ag.kind == AGG_SUM_I || ag.kind == AGG_COUNT) && !valid) continue;
           uint64_t x = agg_row_value(ag.kind, v, true, valid, (uint64_t)(row0 + r));
           lds_atomic_agg(ag.kind, cells + k * p.copies, x);
@@ -156,12 +156,12 @@ struct DenseAggSink {
   using Params = DenseTable;
   template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
   template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
-  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
       if (!pass[r]) continue;
-      bool kvalid = (rf.valid[sh.key] >> r) & 1;
-      int64_t g = kvalid ? ((int64_t)rf.v[r][sh.key] - p.key_min) : p.n_groups;
+      bool kvalid = (rf.getv(sh.key) >> r) & 1;
+      int64_t g = kvalid ? ((int64_t)rf.get(r, sh.key) - p.key_min) : p.n_groups;
       atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)g * sh.n_aggs);
     }
   }
@@ -190,13 +190,13 @@ struct HashAggSink {
     atomicExch(p.overflow, 1u);
     return -1;
   }
-  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
     const uint64_t cap = 1ull << p.log2_cap;
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
       if (!pass[r]) continue;
-      bool kvalid = (rf.valid[sh.key] >> r) & 1;
-      uint64_t key = rf.v[r][sh.key];
+      bool kvalid = (rf.getv(sh.key) >> r) & 1;
+      uint64_t key = rf.get(r, sh.key);
       int64_t slot;
       if (!kvalid) { slot = (int64_t)cap; p.keys[cap] = 0; }
       else if (key == kEmptyKey) { slot = (int64_t)cap + 1; p.keys[cap + 1] = 0; }
@@ -260,7 +260,7 @@ struct WideAggSink {
     if (found < 0) atomicExch(p.overflow, 1u);
     return found;
   }
-  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
       if (!pass[r]) continue;
@@ -270,8 +270,8 @@ struct WideAggSink {
       for (int j = 0; j < kMaxKeys; j++) {
         w[j] = 0;
         if (j < sh.n_keys) {
-          const bool kvalid = (rf.valid[sh.keys[j]] >> r) & 1;
-          w[j] = kvalid ? rf.v[r][sh.keys[j]] : 0ull;
+          const bool kvalid = (rf.getv(sh.keys[j]) >> r) & 1;
+          w[j] = kvalid ? rf.get(r, sh.keys[j]) : 0ull;
           if (!kvalid) nullmask |= 1ull << j;
         }
       }
@@ -295,12 +295,12 @@ struct JoinBuildSink {
   using Params = JoinAggTable;
   template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
   template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
-  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
     const uint64_t cap = 1ull << p.log2_cap;
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
-      if (!pass[r] || !((rf.valid[sh.key] >> r) & 1)) continue;  // null keys never match
-      const uint64_t key = rf.v[r][sh.key];
+      if (!pass[r] || !((rf.getv(sh.key) >> r) & 1)) continue;  // null keys never match
+      const uint64_t key = rf.get(r, sh.key);
       // One atomic per build row: the CAS winner owns the slot and stores its row with a plain store;
       // meeting the same key again means the build keys are not unique -> flag, the caller falls back.
       if (key == kEmptyKey) {
@@ -328,12 +328,12 @@ struct ProbeAggSink {
   using Params = JoinAggTable;
   template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
   template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
-  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
     const uint64_t cap = 1ull << p.log2_cap;
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
-      if (!pass[r] || !((rf.valid[sh.key] >> r) & 1)) continue;
-      const uint64_t key = rf.v[r][sh.key];
+      if (!pass[r] || !((rf.getv(sh.key) >> r) & 1)) continue;
+      const uint64_t key = rf.get(r, sh.key);
       int64_t slot = -1;
       if (key == kEmptyKey) { if (p.head[cap] != kNoRow32) slot = (int64_t)cap; }
       else {
@@ -361,10 +361,10 @@ struct DirectBuildSink {
   unsigned int next = 0, end = 0;   // wave-uniform
   template <class S> __device__ __forceinline__ void init(const S&, const Params&) { next = 0; end = 0; }
   template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
-  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
-      const bool ins = pass[r] && ((rf.valid[sh.key] >> r) & 1);
+      const bool ins = pass[r] && ((rf.getv(sh.key) >> r) & 1);
       const uint64_t m = ballot(ins);
       if (m == 0) continue;
       const unsigned int need = (unsigned int)popc64(m);
@@ -378,7 +378,7 @@ struct DirectBuildSink {
       next += need;
       if (!ins) continue;
       if (ord >= p.n_ord) { p.flags[1] = 1u; continue; }
-      const uint64_t key = rf.v[r][sh.key];
+      const uint64_t key = rf.get(r, sh.key);
       const uint64_t idx = key - (uint64_t)p.kmin;       // < range by construction (kmin/kmax cover the whole build column)
       p.ord_key[ord] = key;
       p.ord_row[ord] = (unsigned int)(row0 + r);
@@ -392,11 +392,11 @@ struct DirectProbeAggSink {
   using Params = DirectJoinTable;
   template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
   template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
-  template <class S> __device__ __forceinline__ void consume(const S& sh, const RegFile& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
-      if (!pass[r] || !((rf.valid[sh.key] >> r) & 1)) continue;
-      const uint64_t idx = rf.v[r][sh.key] - (uint64_t)p.kmin;
+      if (!pass[r] || !((rf.getv(sh.key) >> r) & 1)) continue;
+      const uint64_t idx = rf.get(r, sh.key) - (uint64_t)p.kmin;
       if (idx >= p.range) continue;
       const unsigned int ord = p.dir[idx];
       if (ord == kNoRow32) continue;
@@ -408,6 +408,7 @@ struct DirectProbeAggSink {
 template <class P, class Sink>
 __global__ __launch_bounds__(kBlock) void fused_scan_kernel(Shape dsh, Args args, typename Sink::Params sp) {
   Sink sink;
+  typename RegFileOf<P>::type rf = make_regfile<P>(args);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t ntiles = (args.n_rows + kTileRows - 1) / kTileRows;
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(kBlock) void fused_scan_kernel(Shape dsh, Args args
     constexpr Shape sh = static_shape(P::kId);
     sink.init(sh, sp);
     for (int64_t t = wave; t < ntiles; t += nwaves) {
-      RegFile rf; bool pass[kRows]; int64_t row0;
+      bool pass[kRows]; int64_t row0;
       tile_rows<P>(dsh, args, t, rf, pass, row0);
       sink.consume(sh, rf, pass, row0, sp);
     }
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void fused_scan_kernel(Shape dsh, Args args
   } else {
     sink.init(dsh, sp);
     for (int64_t t = wave; t < ntiles; t += nwaves) {
-      RegFile rf; bool pass[kRows]; int64_t row0;
+      bool pass[kRows]; int64_t row0;
       tile_rows<P>(dsh, args, t, rf, pass, row0);
       sink.consume(dsh, rf, pass, row0, sp);
     }
@@ -476,7 +477,7 @@ void fused_regagg(const Shape& sh, const Args& args, int static_id, uint64_t* ou
       case SHAPE_CFG2_NULLX: PLX_LAUNCH_SCAN(StatProg<SHAPE_CFG2_NULLX>, RegAggSink, grid, 0, sh, args, sp); break;
       case SHAPE_CFG1: PLX_LAUNCH_SCAN(StatProg<SHAPE_CFG1>, RegAggSink, grid, 0, sh, args, sp); break;
       PLX_STATIC_REGAGG_EXTRA_CASES
-      default: PLX_LAUNCH_SCAN(DynProg, RegAggSink, grid, 0, sh, args, sp); break;
+      default: { const DynLaunch d = dyn_launch(sh, args, 0); PLX_LAUNCH_SCAN(DynProg, RegAggSink, grid, d.lds, sh, d.args, sp); } break;
     }
     PLX_HIP(hipGetLastError());
   }
@@ -510,7 +511,7 @@ void fused_lds_agg(const Shape& sh, const Args& args, int n_groups, int static_i
     ProfileScope ps(static_id >= 0 ? "fused_scan_ldsagg_static" : "fused_scan_ldsagg_generic", algo_bytes(sh, args), (uint64_t)args.n_rows);
     switch (static_id) {
       case SHAPE_Q1: PLX_LAUNCH_SCAN(StatProg<SHAPE_Q1>, LdsAggSink, grid, lds, sh, args, sp); break;
-      default: PLX_LAUNCH_SCAN(DynProg, LdsAggSink, grid, lds, sh, args, sp); break;
+      default: { const DynLaunch d = dyn_launch(sh, args, lds); PLX_LAUNCH_SCAN(DynProg, LdsAggSink, grid, d.lds, sh, d.args, sp); } break;
     }
     PLX_HIP(hipGetLastError());
   }
@@ -546,7 +547,7 @@ void fused_dense_agg(const Shape& sh, const Args& args, const DenseTable& t, int
   switch (static_id) {
     case SHAPE_GB_SUM_CNT_I64: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_GB_SUM_CNT_I64>, DenseAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
     case SHAPE_GB_SUM_MEAN_U32_F64: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_GB_SUM_MEAN_U32_F64>, DenseAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
-    default: hipLaunchKernelGGL((fused_scan_kernel<DynProg, DenseAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+    default: { const DynLaunch d = dyn_launch(sh, args, 0); hipLaunchKernelGGL((fused_scan_kernel<DynProg, DenseAggSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, t); } break;
   }
   PLX_HIP(hipGetLastError());
 }
@@ -558,7 +559,7 @@ void fused_hash_agg(const Shape& sh, const Args& args, const HashTable& t, int s
   switch (static_id) {
     case SHAPE_GB_SUM_CNT_I64: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_GB_SUM_CNT_I64>, HashAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
     case SHAPE_GB_SUM_MEAN_U32_F64: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_GB_SUM_MEAN_U32_F64>, HashAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
-    default: hipLaunchKernelGGL((fused_scan_kernel<DynProg, HashAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+    default: { const DynLaunch d = dyn_launch(sh, args, 0); hipLaunchKernelGGL((fused_scan_kernel<DynProg, HashAggSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, t); } break;
   }
   PLX_HIP(hipGetLastError());
 }
@@ -608,7 +609,8 @@ void fused_wide_agg(const Shape& sh, const Args& args, const WideTable& t) {
   if (args.n_rows == 0) return;
   ProfileScope ps("fused_scan_wideagg", algo_bytes(sh, args), (uint64_t)args.n_rows);
   const int grid = scan_grid(args.n_rows, 8);
-  hipLaunchKernelGGL((fused_scan_kernel<DynProg, WideAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t);
+  const DynLaunch d = dyn_launch(sh, args, 0);
+  hipLaunchKernelGGL((fused_scan_kernel<DynProg, WideAggSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, t);
   PLX_HIP(hipGetLastError());
 }
 
@@ -646,7 +648,7 @@ void fused_join_build(const Shape& sh, const Args& args, const JoinAggTable& t, 
   const int grid = scan_grid(args.n_rows, 8);
   switch (static_id) {
     PLX_STATIC_JOIN_BUILD_CASES
-    default: hipLaunchKernelGGL((fused_scan_kernel<DynProg, JoinBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+    default: { const DynLaunch d = dyn_launch(sh, args, 0); hipLaunchKernelGGL((fused_scan_kernel<DynProg, JoinBuildSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, t); } break;
   }
   PLX_HIP(hipGetLastError());
 }
@@ -656,7 +658,7 @@ void fused_probe_agg(const Shape& sh, const Args& args, const JoinAggTable& t, i
   const int grid = scan_grid(args.n_rows, 8);
   switch (static_id) {
     PLX_STATIC_PROBE_AGG_CASES
-    default: hipLaunchKernelGGL((fused_scan_kernel<DynProg, ProbeAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+    default: { const DynLaunch d = dyn_launch(sh, args, 0); hipLaunchKernelGGL((fused_scan_kernel<DynProg, ProbeAggSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, t); } break;
   }
   PLX_HIP(hipGetLastError());
 }
@@ -667,7 +669,7 @@ void fused_direct_build(const Shape& sh, const Args& args, const DirectJoinTable
   const int grid = scan_grid(args.n_rows, 8);
   switch (static_id) {
     PLX_STATIC_DIRECT_BUILD_CASES
-    default: hipLaunchKernelGGL((fused_scan_kernel<DynProg, DirectBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+    default: { const DynLaunch d = dyn_launch(sh, args, 0); hipLaunchKernelGGL((fused_scan_kernel<DynProg, DirectBuildSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, t); } break;
   }
   PLX_HIP(hipGetLastError());
 }
@@ -677,7 +679,7 @@ void fused_direct_probe_agg(const Shape& sh, const Args& args, const DirectJoinT
   const int grid = scan_grid(args.n_rows, 8);
   switch (static_id) {
     PLX_STATIC_DIRECT_PROBE_CASES
-    default: hipLaunchKernelGGL((fused_scan_kernel<DynProg, DirectProbeAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+    default: { const DynLaunch d = dyn_launch(sh, args, 0); hipLaunchKernelGGL((fused_scan_kernel<DynProg, DirectProbeAggSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, t); } break;
   }
   PLX_HIP(hipGetLastError());
 }

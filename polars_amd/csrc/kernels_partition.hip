@@ -47,8 +47,8 @@ template <class P> struct Round { static constexpr int kTiles = P::kStatic ? kSt
 // Evaluates the program for the kRoundTiles tiles of round `rd` owned by this wave.  When the whole round lies inside
 // the input (wave-uniform test) the tiles run back to back in straight-line code, so the compiler can issue the column
 // loads of all tiles before the first use; the tail round takes the bounds-checked path.
-template <class P>
-__device__ __forceinline__ void round_rows(const Shape& dsh, const Args& args, int64_t rd, int wave_in_block, RegFile rf[Round<P>::kTiles], bool pass[Round<P>::kTiles][kRows]) {
+template <class P, class RF>
+__device__ __forceinline__ void round_rows(const Shape& dsh, const Args& args, int64_t rd, int wave_in_block, RF rf[Round<P>::kTiles], bool pass[Round<P>::kTiles][kRows]) {
   constexpr int kRoundTiles = Round<P>::kTiles;
   const int lane = lane_id();
   const int64_t first_tile = rd * kRoundTiles * (kBlock / 64);
@@ -64,7 +64,7 @@ __device__ __forceinline__ void round_rows(const Shape& dsh, const Args& args, i
 #pragma unroll
     for (int t = 0; t < kRoundTiles; t++) {
 #pragma unroll
-      for (int r = 0; r < kRows; r++) pass[t][r] = pred == kNone || ((rf[t].v[r][pred] & 1) && ((rf[t].valid[pred] >> r) & 1));
+      for (int r = 0; r < kRows; r++) pass[t][r] = pred == kNone || ((rf[t].get(r, pred) & 1) && ((rf[t].getv(pred) >> r) & 1));
     }
   } else {
 #pragma unroll
@@ -91,14 +91,14 @@ __global__ __launch_bounds__(kBlock) void part_count_kernel(Shape dsh, Args args
   uint8_t key_slot;
   if constexpr (P::kStatic) { constexpr Shape sh = static_shape(P::kId); key_slot = sh.key; } else key_slot = dsh.key;
   for (int64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
-    RegFile rf[kRoundTiles]; bool pass[kRoundTiles][kRows];
+    typename RegFileOf<P>::type rf[kRoundTiles] = {make_regfile<P>(args)}; bool pass[kRoundTiles][kRows];
     round_rows<P>(dsh, args, rd, wave_in_block, rf, pass);
 #pragma unroll
     for (int t = 0; t < kRoundTiles; t++) {
 #pragma unroll
       for (int r = 0; r < kRows; r++) {
         if (!pass[t][r]) continue;
-        atomicAdd(&cnt[part_of(rf[t].v[r][key_slot], (rf[t].valid[key_slot] >> r) & 1, log2_parts)], 1u);
+        atomicAdd(&cnt[part_of(rf[t].get(r, key_slot), (rf[t].getv(key_slot) >> r) & 1, log2_parts)], 1u);
       }
     }
   }
@@ -126,18 +126,18 @@ struct Rec {
   uint64_t src[kMaxSrc];
 };
 // Register-resident record (all indices compile-time: a dynamically indexed array would live in scratch).
-template <class S>
-__device__ __forceinline__ void make_record(const S& sh, const PartitionPlan& pp, const RegFile& rf, int r, int64_t row, Rec& rec) {
-  const bool kvalid = (rf.valid[sh.key] >> r) & 1;
-  rec.key = kvalid ? rf.v[r][sh.key] : 0ull;
+template <class S, class RF>
+__device__ __forceinline__ void make_record(const S& sh, const PartitionPlan& pp, const RF& rf, int r, int64_t row, Rec& rec) {
+  const bool kvalid = (rf.getv(sh.key) >> r) & 1;
+  rec.key = kvalid ? rf.get(r, sh.key) : 0ull;
   rec.vbits = kvalid ? (1ull << 63) : 0ull;
   rec.rowid = (uint64_t)row;
 #pragma unroll
   for (int j = 0; j < kMaxSrc; j++) {
     rec.src[j] = 0;
     if (j < (int)pp.n_src) {
-      rec.src[j] = rf.v[r][pp.src_slot[j]];
-      if ((rf.valid[pp.src_slot[j]] >> r) & 1) rec.vbits |= 1ull << j;
+      rec.src[j] = rf.get(r, pp.src_slot[j]);
+      if ((rf.getv(pp.src_slot[j]) >> r) & 1) rec.vbits |= 1ull << j;
     }
   }
 }
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(Shape dsh, Args ar
     uint32_t part[kRoundRows];
     bool pending[kRoundRows];
     {
-      RegFile rf[kRoundTiles]; bool pass[kRoundTiles][kRows];
+      typename RegFileOf<P>::type rf[kRoundTiles] = {make_regfile<P>(args)}; bool pass[kRoundTiles][kRows];
       round_rows<P>(dsh, args, rd, wave_in_block, rf, pass);
 #pragma unroll
       for (int t = 0; t < kRoundTiles; t++) {
@@ -407,7 +407,7 @@ int64_t partitioned_agg(const Shape& sh, const Args& args, const PartitionPlan& 
     const size_t lds = sizeof(unsigned int) * NP;
     switch (static_id) {
       PLX_PART_STATIC_CASES(part_count_kernel, dim3(sgrid), dim3(kBlock), lds, stream(), sh, args, pp.log2_parts, hist->as<unsigned int>())
-      default: hipLaunchKernelGGL((part_count_kernel<DynProg>), dim3(sgrid), dim3(kBlock), lds, stream(), sh, args, pp.log2_parts, hist->as<unsigned int>()); break;
+      default: { const DynLaunch d = dyn_launch(sh, args, lds); hipLaunchKernelGGL((part_count_kernel<DynProg>), dim3(sgrid), dim3(kBlock), d.lds, stream(), sh, d.args, pp.log2_parts, hist->as<unsigned int>()); } break;
     }
     PLX_HIP(hipGetLastError());
   }
@@ -423,7 +423,7 @@ int64_t partitioned_agg(const Shape& sh, const Args& args, const PartitionPlan& 
     ProfileScope ps("part_scatter", scan_bytes(sh, args) + total * pp.rec_words * 8, (uint64_t)args.n_rows);
     switch (static_id) {
       PLX_PART_STATIC_CASES(part_scatter_kernel, dim3(sgrid), dim3(kBlock), slds, stream(), sh, args, pp, part_off->as<unsigned long long>(), wg_prefix->as<unsigned long long>(), recs->as<unsigned long long>())
-      default: hipLaunchKernelGGL((part_scatter_kernel<DynProg>), dim3(sgrid), dim3(kBlock), slds, stream(), sh, args, pp, part_off->as<unsigned long long>(), wg_prefix->as<unsigned long long>(), recs->as<unsigned long long>()); break;
+      default: { const DynLaunch d = dyn_launch(sh, args, slds); hipLaunchKernelGGL((part_scatter_kernel<DynProg>), dim3(sgrid), dim3(kBlock), d.lds, stream(), sh, d.args, pp, part_off->as<unsigned long long>(), wg_prefix->as<unsigned long long>(), recs->as<unsigned long long>()); } break;
     }
     PLX_HIP(hipGetLastError());
   }
