@@ -359,6 +359,15 @@ int plx_execute_plan(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int
  * matches.  plx_last_plan_description() then returns a dump of the program. */
 int plx_describe_fusion(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int32_t n_exprs, int32_t root, int32_t* fusable,
                         int32_t* static_shape_id, char* why_not, size_t why_cap);
+/* Run-time kernel specialisation (hiprtc): query shapes without a pre-instantiated kernel get one compiled on
+ * first use (inputs of >= PLX_JIT_MIN_ROWS rows, default 2^22; PLX_JIT=0 disables; failures fall back to the
+ * generic interpreter).  plx_jit_selftest compiles (does not run: no GPU needed) the kernels of the fused pipeline
+ * rooted at `root` -- same arguments as plx_describe_fusion -- and returns PLX_OK, or PLX_ERR_INVALID with the
+ * compiler log in plx_last_error().  plx_jit_stats: kernels compiled so far / total compile milliseconds. */
+int plx_jit_selftest(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int32_t n_exprs, int32_t root);
+int plx_jit_stats(int32_t* compiled, double* compile_ms);
+/* Inputs of at least min_rows rows use the JIT (default 2^22); min_rows < 0 disables it. */
+int plx_jit_set_min_rows(int64_t min_rows);
 /* Human-readable physical plan (which fused pipeline / kernels were chosen) of the
  * last plx_execute_plan on this thread. */
 const char* plx_last_plan_description(void);

@@ -141,6 +141,9 @@ SIGNATURES = {
     "plx_frame_to_host": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i32p]),
     "plx_execute_plan": (C.c_int, [C.POINTER(IR), C.c_int32, C.POINTER(AExpr), C.c_int32, C.c_int32, C.c_uint32, _u64p]),
     "plx_describe_fusion": (C.c_int, [C.POINTER(IR), C.c_int32, C.POINTER(AExpr), C.c_int32, C.c_int32, _i32p, _i32p, C.c_char_p, C.c_size_t]),
+    "plx_jit_selftest": (C.c_int, [C.POINTER(IR), C.c_int32, C.POINTER(AExpr), C.c_int32, C.c_int32]),
+    "plx_jit_stats": (C.c_int, [_i32p, C.POINTER(C.c_double)]),
+    "plx_jit_set_min_rows": (C.c_int, [C.c_int64]),
     "plx_last_plan_description": (C.c_char_p, []),
     "plx_profile_enable": (C.c_int, [C.c_int]),
     "plx_profile_fetch": (C.c_int, [C.POINTER(ProfileRecord), C.c_int32, _i32p]),
@@ -195,3 +198,14 @@ def ensure_init() -> None:
 
 def last_plan() -> str:
     return lib().plx_last_plan_description().decode()
+
+
+def jit_set_min_rows(min_rows: int) -> None:
+    """Inputs of at least ``min_rows`` rows get a run-time specialised kernel (hiprtc); negative disables the JIT."""
+    check(lib().plx_jit_set_min_rows(int(min_rows)))
+
+
+def jit_stats():
+    n, ms = C.c_int32(), C.c_double()
+    check(lib().plx_jit_stats(C.byref(n), C.byref(ms)))
+    return n.value, ms.value

@@ -8,6 +8,7 @@
 #include "core.hpp"
 #include "engine.hpp"
 #include "fused_shapes.hpp"
+#include "jit.hpp"
 #include "join.hpp"
 #include "kernels.hpp"
 #include "ops.hpp"
@@ -401,6 +402,40 @@ int plx_describe_fusion(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, 
   if (fusable) *fusable = ok ? 1 : 0;
   if (static_shape_id) *static_shape_id = sid;
   if (why_not && why_cap) snprintf(why_not, why_cap, "%s", why.c_str());
+  PLX_CATCH
+}
+
+int plx_jit_selftest(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int32_t n_exprs, int32_t root) {
+  PLX_TRY
+  engine::Plan p = engine::import_plan(ir, n_ir, exprs, n_exprs, 0);
+  PLX_REQUIRE(root >= 0 && root < (int)p.ir.size(), PLX_ERR_INVALID, "bad root");
+  const engine::IRN& rn = p.ir[root];
+  std::string why;
+  std::vector<std::pair<fused::Shape, jit::Sink>> jobs;
+  if (rn.kind == PLX_IR_GROUPBY && rn.input >= 0 && p.ir[rn.input].kind == PLX_IR_JOIN) {
+    std::vector<fused::Shape> shapes;
+    PLX_REQUIRE(engine::describe_join_fusion(p, root, &shapes, &why), PLX_ERR_UNSUPPORTED, "not fusable: " + why);
+    jobs = {{shapes[0], jit::REGAGG}, {shapes[1], jit::JOIN_BUILD}, {shapes[1], jit::DIRECT_BUILD}, {shapes[2], jit::PROBE_AGG}, {shapes[2], jit::DIRECT_PROBE}};
+  } else {
+    fused::Shape sh{}; int sid = -1;
+    PLX_REQUIRE(engine::describe_fusion(p, root, &sh, &sid, &why), PLX_ERR_UNSUPPORTED, "not fusable: " + why);
+    if (rn.kind == PLX_IR_SELECT) jobs = {{sh, jit::REGAGG}};
+    else jobs = {{sh, jit::LDSAGG}, {sh, jit::DENSE}, {sh, jit::HASH}};
+    if (sh.n_keys >= 2) jobs = {{sh, jit::WIDE}};
+  }
+  for (auto& j : jobs) {
+    const std::string log = jit::selftest(j.first, j.second);
+    if (!log.empty()) fail(PLX_ERR_INVALID, "jit selftest failed: " + log.substr(0, 4000));
+  }
+  PLX_CATCH
+}
+int plx_jit_set_min_rows(int64_t min_rows) { PLX_TRY jit::set_min_rows(min_rows); PLX_CATCH }
+int plx_jit_stats(int32_t* compiled, double* compile_ms) {
+  PLX_TRY
+  int c = 0; double ms = 0;
+  jit::stats(&c, &ms);
+  if (compiled) *compiled = c;
+  if (compile_ms) *compile_ms = ms;
   PLX_CATCH
 }
 

@@ -6,7 +6,7 @@
 #include "dev.hpp"
 #include "fused.hpp"
 #include "fused_shapes.hpp"
-#include "kernels.hpp"
+#include "kconfig.hpp"
 
 namespace plx {
 namespace k {
@@ -318,12 +318,15 @@ __device__ __forceinline__ void exec_op(const Op op, const Shape& sh, const Args
 
 // ---- program providers ----------------------------------------------------------
 struct DynProg { static constexpr bool kStatic = false; static constexpr int kId = -1; };
-template <int ID> struct StatProg { static constexpr bool kStatic = true; static constexpr int kId = ID; };
+template <int ID> struct StatProg {
+  static constexpr bool kStatic = true; static constexpr int kId = ID;
+  static constexpr Shape shape() { return static_shape(ID); }
+};
 
 template <class P, bool FULL, class RF>
 __device__ __forceinline__ void run_program(const Shape& dsh, const Args& args, int64_t row0, RF& rf) {
   if constexpr (P::kStatic) {
-    constexpr Shape sh = static_shape(P::kId);
+    constexpr Shape sh = P::shape();
 #pragma unroll
     for (int pc = 0; pc < sh.n_ops; pc++) exec_op<FULL>(sh.ops[pc], sh, args, pc, row0, rf);
   } else {
@@ -464,7 +467,7 @@ __device__ __forceinline__ bool tile_rows(const Shape& dsh, const Args& args, in
   if (full) run_program<P, true>(dsh, args, row0, rf);
   else run_program<P, false>(dsh, args, row0, rf);
   uint8_t pred;
-  if constexpr (P::kStatic) { constexpr Shape sh = static_shape(P::kId); pred = sh.pred; } else pred = dsh.pred;
+  if constexpr (P::kStatic) { constexpr Shape sh = P::shape(); pred = sh.pred; } else pred = dsh.pred;
 #pragma unroll
   for (int r = 0; r < kRows; r++) {
     bool ok = full || (row0 + r < args.n_rows);

@@ -1,0 +1,395 @@
+// fused_sinks.hpp -- the sinks of the fused scan kernel and the kernel body itself (device-only header: compiled
+// ahead of time by kernels_fused.hip for the benchmark shapes and the generic interpreter, and at run time by
+// hiprtc (jit.cpp) for any other program shape).  See kernels_fused.hip for the design notes.
+#pragma once
+#include "fused_device.hpp"
+
+namespace plx {
+namespace k {
+
+// ---- sink: per-lane register accumulators (no group-by) ---------------------------------
+struct RegAggSink {
+  struct Params { unsigned long long* partials; };  // [grid][kMaxAggs]
+  uint64_t acc[kMaxAggs];
+  template <class S> __device__ __forceinline__ void init(const S& sh, const Params&) {
+#pragma unroll
+    for (int k = 0; k < kMaxAggs; k++) acc[k] = (k < sh.n_aggs) ? agg_identity_dev(sh.aggs[k].kind) : 0ull;
+  }
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params&) {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+#pragma unroll
+      for (int k = 0; k < kMaxAggs; k++) {
+        if (k < sh.n_aggs) {
+          const Agg ag = sh.aggs[k];
+          uint64_t v = rf.get(r, ag.src);
+          bool valid = (rf.getv(ag.src) >> r) & 1;
+          acc[k] = agg_combine(ag.kind, acc[k], agg_row_value(ag.kind, v, pass[r], valid, (uint64_t)(row0 + r)));
+        }
+      }
+    }
+  }
+  template <class S> __device__ __forceinline__ void finish(const S& sh, const Params& p) {
+    __shared__ uint64_t sh_acc[kBlock / 64][kMaxAggs];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kMaxAggs; k++) {
+      if (k < sh.n_aggs) {
+        uint64_t x = acc[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) x = agg_combine(sh.aggs[k].kind, x, shfl_xor_u64(x, m));
+        if (lane == 0) sh_acc[wave][k] = x;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < sh.n_aggs) {
+      const int k = threadIdx.x;
+      uint64_t x = sh_acc[0][k];
+      for (int w = 1; w < (int)(blockDim.x >> 6); w++) x = agg_combine(sh.aggs[k].kind, x, sh_acc[w][k]);
+      p.partials[(size_t)blockIdx.x * kMaxAggs + k] = x;
+    }
+  }
+};
+
+// ---- sink: workgroup-shared LDS table for dense group ids (1 < G <= ~1024) -----------------
+// Layout lds[(g * n_aggs + k) * C + copy], copy = lane & (C-1).  With C = 16 every
+// 16-lane group of a 64-bit DS instruction touches 16 distinct cells = all 32 banks once,
+// so the LDS atomics run conflict-free at full rate no matter how skewed the groups are
+// (TPC-H Q1: ~50% of rows fall in one group).  At the end the copies are folded and one
+// partial per workgroup is written (G <= 64) or added to the HBM table with atomics.
+struct LdsAggSink {
+  struct Params {
+    unsigned long long* partials;    // [grid][G][n_aggs]  (when global_acc == nullptr)
+    unsigned long long* global_acc;  // [G][n_aggs] device-scope atomics (large G)
+    int n_groups;
+    int copies;                      // power of two
+  };
+  template <class S> __device__ __forceinline__ void init(const S& sh, const Params& p) {
+    extern __shared__ unsigned long long lds_tbl[];
+    const int cells = p.n_groups * sh.n_aggs;
+    for (int i = threadIdx.x; i < cells * p.copies; i += blockDim.x) lds_tbl[i] = agg_identity_dev(sh.aggs[(i / p.copies) % sh.n_aggs].kind);
+    __syncthreads();
+  }
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+    extern __shared__ unsigned long long lds_tbl[];
+    const int copy = lane_id() & (p.copies - 1);
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r]) continue;
+      const uint32_t gid = (uint32_t)rf.get(r, sh.key);
+      unsigned long long* cells = lds_tbl + (size_t)gid * sh.n_aggs * p.copies + copy;
+#pragma unroll
+      for (int k = 0; k < kMaxAggs; k++) {
+        if (k < sh.n_aggs) {
+          const Agg ag = sh.aggs[k];
+          uint64_t v = rf.get(r, ag.src);
+          bool valid = (rf.getv(ag.src) >> r) & 1;
+          if ((ag.kind == AGG_SUM_F || ag.kind == AGG_SUM_I || ag.kind == AGG_COUNT) && !valid) continue;
+          uint64_t x = agg_row_value(ag.kind, v, true, valid, (uint64_t)(row0 + r));
+          lds_atomic_agg(ag.kind, cells + k * p.copies, x);
+        }
+      }
+    }
+  }
+  template <class S> __device__ __forceinline__ void finish(const S& sh, const Params& p) {
+    extern __shared__ unsigned long long lds_tbl[];
+    __syncthreads();
+    const int cells = p.n_groups * sh.n_aggs;
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) {
+      const uint8_t kind = sh.aggs[i % sh.n_aggs].kind;
+      uint64_t x = lds_tbl[(size_t)i * p.copies];
+      for (int c = 1; c < p.copies; c++) x = agg_combine(kind, x, lds_tbl[(size_t)i * p.copies + c]);
+      if (p.global_acc) { if (x != agg_identity_dev(kind) || kind == AGG_SUM_F) atomic_agg(kind, p.global_acc + i, x); }
+      else p.partials[(size_t)blockIdx.x * cells + i] = x;
+    }
+  }
+};
+
+// ---- sink: direct-address table (dense integer keys) ---------------------------------
+struct DenseAggSink {
+  using Params = DenseTable;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r]) continue;
+      bool kvalid = (rf.getv(sh.key) >> r) & 1;
+      int64_t g = kvalid ? ((int64_t)rf.get(r, sh.key) - p.key_min) : p.n_groups;
+      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)g * sh.n_aggs);
+    }
+  }
+};
+
+// ---- sink: open-addressing hash table in HBM -----------------------------------------
+// slot = top bits of key * RANDOM_ODD (the reference's DirtyHash,
+// polars-utils/src/hashing.rs:124-151: "only the top bits are decent"), linear probing,
+// 64-bit CAS claims a slot, payload updated with device-scope atomics.
+struct HashAggSink {
+  using Params = HashTable;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  __device__ __forceinline__ static int64_t find_slot(const Params& p, uint64_t key) {
+    const uint64_t cap = 1ull << p.log2_cap;
+    uint64_t slot = (key * 0x55fbfd6bfc5458e9ull) >> (64 - p.log2_cap);
+    for (uint32_t probe = 0; probe < p.max_probe; probe++) {
+      unsigned long long cur = p.keys[slot];
+      if (cur == key) return (int64_t)slot;
+      if (cur == kEmptyKey) {
+        unsigned long long old = atomicCAS(&p.keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
+        if (old == kEmptyKey || old == key) return (int64_t)slot;
+      }
+      slot = (slot + 1) & (cap - 1);
+    }
+    atomicExch(p.overflow, 1u);
+    return -1;
+  }
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+    const uint64_t cap = 1ull << p.log2_cap;
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r]) continue;
+      bool kvalid = (rf.getv(sh.key) >> r) & 1;
+      uint64_t key = rf.get(r, sh.key);
+      int64_t slot;
+      if (!kvalid) { slot = (int64_t)cap; p.keys[cap] = 0; }
+      else if (key == kEmptyKey) { slot = (int64_t)cap + 1; p.keys[cap + 1] = 0; }
+      else slot = find_slot(p, key);
+      if (slot < 0) continue;
+      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
+    }
+  }
+};
+
+
+// ---- sink: wide-key open-addressing table (keys of 2..4 columns that do not bit-pack) ----------
+// Slot protocol: tags[s] goes EMPTY -> tag|BUSY (64-bit CAS) -> tag.  The claimer writes the key
+// words with write-through (agent-scope) stores, drains them, then publishes the tag; readers
+// load tag and words at agent scope (L2-served, never a stale L1 line).  Within one loop
+// iteration the claim+publish code precedes the wait, so a lane never waits on a lane of its
+// own wave that has not published yet; owners in other waves make progress independently.
+struct WideAggSink {
+  using Params = WideTable;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  __device__ __forceinline__ static uint64_t ld(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ static void st(unsigned long long* p, uint64_t v) { __hip_atomic_store(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ __forceinline__ static uint64_t mix(uint64_t h, uint64_t w) {
+    h ^= w; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; return h;
+  }
+  __device__ __forceinline__ static int64_t find_or_insert(const Params& p, const uint64_t w[kMaxKeys + 1]) {
+    const uint64_t cap = 1ull << p.log2_cap;
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+    for (uint32_t j = 0; j < p.n_words; j++) h = mix(h, w[j]);
+    h *= 0x55fbfd6bfc5458e9ull;
+    uint64_t tag = h & ~kBusyBit;
+    if (tag == (kEmptyKey & ~kBusyBit)) tag ^= 1;
+    uint64_t slot = h >> (64 - p.log2_cap);
+    int64_t found = -1;
+    for (uint32_t probe = 0; probe < p.max_probe && found < 0; probe++) {
+      uint64_t cur = ld(&p.tags[slot]);
+      bool claimed = false;
+      if (cur == kEmptyKey) {
+        const unsigned long long old = atomicCAS(&p.tags[slot], (unsigned long long)kEmptyKey, (unsigned long long)(tag | kBusyBit));
+        if (old == kEmptyKey) claimed = true; else cur = old;
+      }
+      if (claimed) {  // publish: words (write-through) -> drain -> tag
+        for (uint32_t j = 0; j < p.n_words; j++) st(&p.words[(size_t)j * cap + slot], w[j]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st(&p.tags[slot], tag);
+        found = (int64_t)slot;
+      }
+      // every lane of the wave is past the publish before any lane starts to wait (convergent
+      // marker: the two branches cannot be merged into an if/else whose else side runs first)
+      __builtin_amdgcn_wave_barrier();
+      if (!claimed && (cur & ~kBusyBit) == tag) {
+        while (cur & kBusyBit) { __builtin_amdgcn_s_sleep(1); cur = ld(&p.tags[slot]); }
+        asm volatile("" ::: "memory");
+        bool same = true;
+        for (uint32_t j = 0; j < p.n_words; j++) same = same && (ld(&p.words[(size_t)j * cap + slot]) == w[j]);
+        if (same) found = (int64_t)slot;
+      }
+      slot = (slot + 1) & (cap - 1);
+    }
+    if (found < 0) atomicExch(p.overflow, 1u);
+    return found;
+  }
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r]) continue;
+      uint64_t w[kMaxKeys + 1];
+      uint64_t nullmask = 0;
+#pragma unroll
+      for (int j = 0; j < kMaxKeys; j++) {
+        w[j] = 0;
+        if (j < sh.n_keys) {
+          const bool kvalid = (rf.getv(sh.keys[j]) >> r) & 1;
+          w[j] = kvalid ? rf.get(r, sh.keys[j]) : 0ull;
+          if (!kvalid) nullmask |= 1ull << j;
+        }
+      }
+      w[kMaxKeys] = 0;
+      if (p.has_null_word) w[sh.n_keys] = nullmask;
+      const int64_t slot = find_or_insert(p, w);
+      if (slot < 0) continue;
+      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
+    }
+  }
+};
+
+
+// ---- sinks: fused join build / probe->aggregate ---------------------------------------------
+// Replaces, for `GroupBy(join key + build-side columns) over Join(inner)`, the chain
+// build_tables -> probe_inner -> gather of every payload column -> group_by of the reference
+// (polars-ops/src/frame/join/hash_join/single_keys.rs:16-167, single_keys_inner.rs:11-149,
+// polars-mem-engine/src/executors/{join.rs:41-121, group_by.rs:60-98}): no filtered frames,
+// no (left_idx, right_idx) pairs and no joined frame are materialised.
+struct JoinBuildSink {
+  using Params = JoinAggTable;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+    const uint64_t cap = 1ull << p.log2_cap;
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r] || !((rf.getv(sh.key) >> r) & 1)) continue;  // null keys never match
+      const uint64_t key = rf.get(r, sh.key);
+      // One atomic per build row: the CAS winner owns the slot and stores its row with a plain store;
+      // meeting the same key again means the build keys are not unique -> flag, the caller falls back.
+      if (key == kEmptyKey) {
+        const unsigned int old = atomicExch(&p.head[cap], (unsigned int)(row0 + r));
+        if (old != kNoRow32) p.flags[0] = 1u;
+        continue;
+      }
+      uint64_t slot = (key * 0x55fbfd6bfc5458e9ull) >> (64 - p.log2_cap);
+      for (uint32_t probe = 0;; probe++) {
+        const unsigned long long cur = p.keys[slot];
+        if (cur == key) { p.flags[0] = 1u; break; }
+        if (cur == kEmptyKey) {
+          const unsigned long long old = atomicCAS(&p.keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
+          if (old == kEmptyKey) { p.head[slot] = (unsigned int)(row0 + r); break; }
+          if (old == key) { p.flags[0] = 1u; break; }
+        }
+        slot = (slot + 1) & (cap - 1);
+        if (probe > (1u << 16)) { p.flags[1] = 1u; break; }
+      }
+    }
+  }
+};
+
+struct ProbeAggSink {
+  using Params = JoinAggTable;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+    const uint64_t cap = 1ull << p.log2_cap;
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r] || !((rf.getv(sh.key) >> r) & 1)) continue;
+      const uint64_t key = rf.get(r, sh.key);
+      int64_t slot = -1;
+      if (key == kEmptyKey) { if (p.head[cap] != kNoRow32) slot = (int64_t)cap; }
+      else {
+        uint64_t s = (key * 0x55fbfd6bfc5458e9ull) >> (64 - p.log2_cap);
+        for (;;) {
+          const unsigned long long cur = p.keys[s];
+          if (cur == key) { slot = (int64_t)s; break; }
+          if (cur == kEmptyKey) break;
+          s = (s + 1) & (cap - 1);
+        }
+      }
+      if (slot < 0) continue;
+      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
+    }
+  }
+};
+
+
+// Ordinals are handed out in per-wave chunks: a wave reserves kOrdChunk ordinals with ONE device atomic
+// and sub-allocates from them (one atomic per wave-row on a single counter word took 26 ms for the 1.5e8-row
+// TPC-H orders scan; ~12 k atomics this way).  Unused tails of chunks stay empty (LEN cell 0).
+constexpr unsigned int kOrdChunk = 1024;
+struct DirectBuildSink {
+  using Params = DirectJoinTable;
+  unsigned int next = 0, end = 0;   // wave-uniform
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) { next = 0; end = 0; }
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      const bool ins = pass[r] && ((rf.getv(sh.key) >> r) & 1);
+      const uint64_t m = ballot(ins);
+      if (m == 0) continue;
+      const unsigned int need = (unsigned int)popc64(m);
+      if (next + need > end) {   // wave-uniform: reserve a fresh chunk
+        unsigned int base = 0;
+        if (lane_id() == 0) base = atomicAdd(p.counter, kOrdChunk);
+        next = __shfl(base, 0, 64);
+        end = next + kOrdChunk;
+      }
+      const unsigned int ord = next + (unsigned int)prefix_rank(m);
+      next += need;
+      if (!ins) continue;
+      if (ord >= p.n_ord) { p.flags[1] = 1u; continue; }
+      const uint64_t key = rf.get(r, sh.key);
+      const uint64_t idx = key - (uint64_t)p.kmin;       // < range by construction (kmin/kmax cover the whole build column)
+      p.ord_key[ord] = key;
+      p.ord_row[ord] = (unsigned int)(row0 + r);
+      const unsigned int old = atomicCAS(&p.dir[idx], kNoRow32, ord);
+      if (old != kNoRow32) p.flags[0] = 1u;               // duplicate build key -> the caller falls back
+    }
+  }
+};
+
+struct DirectProbeAggSink {
+  using Params = DirectJoinTable;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r] || !((rf.getv(sh.key) >> r) & 1)) continue;
+      const uint64_t idx = rf.get(r, sh.key) - (uint64_t)p.kmin;
+      if (idx >= p.range) continue;
+      const unsigned int ord = p.dir[idx];
+      if (ord == kNoRow32) continue;
+      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)ord * sh.n_aggs);
+    }
+  }
+};
+
+template <class P, class Sink>
+__device__ __forceinline__ void fused_scan_body(const Shape& dsh, const Args& args, const typename Sink::Params& sp) {
+  Sink sink;
+  typename RegFileOf<P>::type rf = make_regfile<P>(args);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t ntiles = (args.n_rows + kTileRows - 1) / kTileRows;
+  if constexpr (P::kStatic) {
+    constexpr Shape sh = P::shape();
+    sink.init(sh, sp);
+    for (int64_t t = wave; t < ntiles; t += nwaves) {
+      bool pass[kRows]; int64_t row0;
+      tile_rows<P>(dsh, args, t, rf, pass, row0);
+      sink.consume(sh, rf, pass, row0, sp);
+    }
+    sink.finish(sh, sp);
+  } else {
+    sink.init(dsh, sp);
+    for (int64_t t = wave; t < ntiles; t += nwaves) {
+      bool pass[kRows]; int64_t row0;
+      tile_rows<P>(dsh, args, t, rf, pass, row0);
+      sink.consume(dsh, rf, pass, row0, sp);
+    }
+    sink.finish(dsh, sp);
+  }
+}
+
+template <class P, class Sink>
+__global__ __launch_bounds__(kBlock) void fused_scan_kernel(Shape dsh, Args args, typename Sink::Params sp) {
+  fused_scan_body<P, Sink>(dsh, args, sp);
+}
+
+}  // namespace k
+}  // namespace plx

@@ -1,0 +1,169 @@
+// jit.cpp -- hiprtc instantiation of fused_scan_body<JitProg, Sink> for run-time program shapes (see jit.hpp).
+#include "jit.hpp"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <hip/hiprtc.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "core.hpp"
+#include "kconfig.hpp"
+
+namespace plx {
+namespace jit {
+
+using namespace fused;
+
+namespace {
+struct Entry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; bool failed = false; };
+std::mutex g_mu;
+std::map<std::string, Entry> g_cache;
+int g_compiled = 0;
+double g_ms = 0;
+
+const char* sink_type(Sink s) {
+  static const char* n[] = {"RegAggSink", "LdsAggSink", "DenseAggSink", "HashAggSink", "WideAggSink", "JoinBuildSink", "ProbeAggSink", "DirectBuildSink", "DirectProbeAggSink"};
+  return n[s];
+}
+
+std::string include_dir() {
+  if (const char* e = getenv("PLX_JIT_INCLUDE")) return e;
+  Dl_info info;
+  if (dladdr((const void*)&stats, &info) && info.dli_fname) {
+    std::string p = info.dli_fname;          // .../polars_amd/libpolars_amd.so
+    size_t k = p.rfind('/');
+    return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/csrc";
+  }
+  return "polars_amd/csrc";
+}
+
+// clang's own <stddef.h>/<stdint.h>: hiprtc has no system include paths
+std::string resource_include() {
+  if (const char* e = getenv("PLX_JIT_CLANG_INCLUDE")) return e;
+  const char* roots[] = {"/opt/rocm/lib/llvm/lib/clang", "/opt/rocm/llvm/lib/clang"};
+  for (const char* r : roots) {
+    for (int v = 30; v >= 14; v--) {
+      const std::string p = std::string(r) + "/" + std::to_string(v) + "/include";
+      if (FILE* f = fopen((p + "/stddef.h").c_str(), "r")) { fclose(f); return p; }
+    }
+  }
+  return "/opt/rocm/lib/llvm/lib/clang/22/include";
+}
+std::vector<std::string> compile_options() {
+  return {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wno-pass-failed", "-ffreestanding",
+          "-I" + include_dir(), "-I/opt/rocm/include", "-I" + resource_include()};
+}
+
+std::string source_for(const Shape& sh, Sink sink) {
+  std::ostringstream o;
+  o << "#include \"fused_sinks.hpp\"\nnamespace plx { namespace k {\n"
+       "struct JitProg {\n  static constexpr bool kStatic = true; static constexpr int kId = -2;\n  static constexpr Shape shape() {\n    Shape s{};\n";
+  o << "    s.n_inputs = " << (int)sh.n_inputs << "; s.n_ops = " << (int)sh.n_ops << "; s.n_aggs = " << (int)sh.n_aggs << "; s.pred = " << (int)sh.pred
+    << "; s.key = " << (int)sh.key << "; s.n_keys = " << (int)sh.n_keys << ";\n";
+  for (int i = 0; i < kMaxKeys; i++) o << "    s.keys[" << i << "] = " << (int)sh.keys[i] << ";\n";
+  for (int i = 0; i < sh.n_inputs; i++) o << "    s.in_dtype[" << i << "] = " << (int)sh.in_dtype[i] << "; s.in_nullable[" << i << "] = " << (int)sh.in_nullable[i] << ";\n";
+  for (int i = 0; i < sh.n_ops; i++)
+    o << "    s.ops[" << i << "] = mkop(" << (int)sh.ops[i].code << ", " << (int)sh.ops[i].dst << ", " << (int)sh.ops[i].a << ", " << (int)sh.ops[i].b << ", " << (int)sh.ops[i].c << ");\n";
+  for (int i = 0; i < sh.n_aggs; i++) o << "    s.aggs[" << i << "] = Agg{" << (int)sh.aggs[i].kind << ", " << (int)sh.aggs[i].src << "};\n";
+  o << "    return s;\n  }\n};\n"
+       "extern \"C\" __global__ __launch_bounds__(kBlock) void plx_jit_kernel(Shape dsh, Args args, "
+    << sink_type(sink) << "::Params sp) {\n  fused_scan_body<JitProg, " << sink_type(sink) << ">(dsh, args, sp);\n}\n}}\n";
+  return o.str();
+}
+
+std::atomic<int64_t> g_min_rows{-2};   // -2: not initialised, -1: disabled
+bool enabled(int64_t n_rows) {
+  int64_t m = g_min_rows.load(std::memory_order_relaxed);
+  if (m == -2) {
+    const char* off = getenv("PLX_JIT");
+    const char* e = getenv("PLX_JIT_MIN_ROWS");
+    m = (off && off[0] == '0') ? -1 : (e ? (int64_t)atoll(e) : (int64_t)1 << 22);
+    g_min_rows.store(m, std::memory_order_relaxed);
+  }
+  return m >= 0 && n_rows >= m;
+}
+
+Entry compile(const Shape& sh, Sink sink) {
+  Entry e;
+  const auto t0 = std::chrono::steady_clock::now();
+  const std::string src = source_for(sh, sink);
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "plx_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { e.failed = true; return e; }
+  const std::vector<std::string> optv = compile_options();
+  std::vector<const char*> opts;
+  for (auto& x : optv) opts.push_back(x.c_str());
+  const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+  if (rc != HIPRTC_SUCCESS) {
+    size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n, 0); if (n) hiprtcGetProgramLog(prog, &log[0]);
+    set_last_error("jit: hiprtc compile failed: " + log.substr(0, 2000));
+    if (getenv("PLX_JIT_VERBOSE")) fprintf(stderr, "[plx jit] compile failed:\n%s\n", log.c_str());
+    hiprtcDestroyProgram(&prog);
+    e.failed = true;
+    return e;
+  }
+  size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
+  std::vector<char> code(cs);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+  if (hipModuleLoadData(&e.mod, code.data()) != hipSuccess || hipModuleGetFunction(&e.fn, e.mod, "plx_jit_kernel") != hipSuccess) { e.failed = true; return e; }
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  g_compiled++; g_ms += ms;
+  if (getenv("PLX_JIT_VERBOSE")) fprintf(stderr, "[plx jit] %s: %.0f ms, %zu bytes\n", sink_type(sink), ms, cs);
+  return e;
+}
+}  // namespace
+
+// compile-only check (no GPU needed: hiprtc cross-compiles): returns "" on success, else the compiler log
+std::string selftest(const Shape& sh, Sink sink) {
+  const std::string src = source_for(sh, sink);
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "plx_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return "hiprtcCreateProgram failed";
+  const std::vector<std::string> optv = compile_options();
+  std::vector<const char*> opts;
+  for (auto& x : optv) opts.push_back(x.c_str());
+  const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+  std::string log;
+  if (rc != HIPRTC_SUCCESS) { size_t n = 0; hiprtcGetProgramLogSize(prog, &n); log.assign(n, 0); if (n) hiprtcGetProgramLog(prog, &log[0]); if (log.empty()) log = "hiprtc error"; }
+  hiprtcDestroyProgram(&prog);
+  return log;
+}
+
+void set_min_rows(int64_t min_rows) { g_min_rows.store(min_rows < 0 ? -1 : min_rows, std::memory_order_relaxed); }
+
+void stats(int* compiled, double* compile_ms) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (compiled) *compiled = g_compiled;
+  if (compile_ms) *compile_ms = g_ms;
+}
+
+bool launch(const Shape& sh, const Args& args, Sink sink, const void* params, int grid, size_t lds_bytes) {
+  if (!enabled(args.n_rows)) return false;
+  std::string key((const char*)&sh, sizeof(Shape));
+  key.push_back((char)sink);
+  hipFunction_t fn = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_cache.find(key);
+    if (it == g_cache.end()) it = g_cache.emplace(key, compile(sh, sink)).first;
+    if (it->second.failed) return false;
+    fn = it->second.fn;
+  }
+  Shape shc = sh; Args ac = args;
+  void* kargs[] = {(void*)&shc, (void*)&ac, const_cast<void*>(params)};
+  const hipError_t rc = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, (unsigned)k::kBlock, 1, 1, (unsigned)lds_bytes, stream(), kargs, nullptr);
+  if (rc != hipSuccess) { set_last_error(std::string("jit: launch failed: ") + hipGetErrorString(rc)); return false; }
+  return true;
+}
+
+}  // namespace jit
+}  // namespace plx

@@ -1,0 +1,31 @@
+// jit.hpp -- run-time specialisation of the fused scan kernel (hiprtc).
+//
+// The benchmark shapes are instantiated ahead of time (fused_shapes.hpp); any other program shape used to run
+// the generic interpreter, which is instruction-fetch bound (~30 k instructions of switch bodies; 0.8 TB/s against
+// 5.8 TB/s for an AOT shape).  jit::launch instantiates the SAME template (fused_sinks.hpp: fused_scan_body<P, Sink>)
+// with the program as a compile-time constant for the shape at hand, once per (shape, sink) and process
+// (~1-2 s of hiprtc, amortised over large inputs: only used from PLX_JIT_MIN_ROWS rows, default 2^22), and launches it.
+// Returns false when JIT is disabled (PLX_JIT=0), the input is small, or compilation failed -- the caller then runs
+// the generic interpreter, so results never depend on the JIT.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "fused.hpp"
+
+namespace plx {
+namespace jit {
+
+enum Sink { REGAGG = 0, LDSAGG, DENSE, HASH, WIDE, JOIN_BUILD, PROBE_AGG, DIRECT_BUILD, DIRECT_PROBE, kNumSinks };
+
+bool launch(const fused::Shape& sh, const fused::Args& args, Sink sink, const void* params, int grid, size_t lds_bytes);
+// compile-only check of the JIT toolchain for one (shape, sink): "" on success, else the compiler log (no GPU needed)
+std::string selftest(const fused::Shape& sh, Sink sink);
+// inputs of at least min_rows rows use the JIT; < 0 disables it (overrides PLX_JIT / PLX_JIT_MIN_ROWS)
+void set_min_rows(int64_t min_rows);
+// statistics for tests / explain: kernels compiled so far, total compile milliseconds
+void stats(int* compiled, double* compile_ms);
+
+}  // namespace jit
+}  // namespace plx

@@ -2,12 +2,12 @@
 // Every launcher enqueues on plx::stream() and returns immediately unless noted.
 #pragma once
 #include "core.hpp"
+#include "kconfig.hpp"
 
 namespace plx {
 namespace k {
 
 // launch geometry helpers -------------------------------------------------------
-constexpr int kBlock = 256;          // 4 wave64 per workgroup
 int grid_for(int64_t work_items, int items_per_block, int blocks_per_cu = 8);
 
 // ---- elementwise (kernels_elementwise.hip) -------------------------------------

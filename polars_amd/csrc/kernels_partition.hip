@@ -21,6 +21,7 @@
 // HBM traffic: (1) reads the key/predicate columns, (2) reads all inputs + writes the records, (3) reads the
 // records: ~3x the algorithmic bytes instead of a fraction of the atomic rate.
 #include "fused_device.hpp"
+#include "kernels.hpp"
 #include "kernels_fused.hpp"
 #include "scan.hpp"
 
@@ -54,7 +55,7 @@ __device__ __forceinline__ void round_rows(const Shape& dsh, const Args& args, i
   const int64_t first_tile = rd * kRoundTiles * (kBlock / 64);
   const bool all_full = (first_tile + (int64_t)kRoundTiles * (kBlock / 64)) * kTileRows <= args.n_rows;
   uint8_t pred;
-  if constexpr (P::kStatic) { constexpr Shape sh = static_shape(P::kId); pred = sh.pred; } else pred = dsh.pred;
+  if constexpr (P::kStatic) { constexpr Shape sh = P::shape(); pred = sh.pred; } else pred = dsh.pred;
   if (all_full) {
 #pragma unroll
     for (int t = 0; t < kRoundTiles; t++) {
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void part_count_kernel(Shape dsh, Args args
   const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
   const int wave_in_block = threadIdx.x >> 6;
   uint8_t key_slot;
-  if constexpr (P::kStatic) { constexpr Shape sh = static_shape(P::kId); key_slot = sh.key; } else key_slot = dsh.key;
+  if constexpr (P::kStatic) { constexpr Shape sh = P::shape(); key_slot = sh.key; } else key_slot = dsh.key;
   for (int64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
     typename RegFileOf<P>::type rf[kRoundTiles] = {make_regfile<P>(args)}; bool pass[kRoundTiles][kRows];
     round_rows<P>(dsh, args, rd, wave_in_block, rf, pass);
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(Shape dsh, Args ar
         for (int r = 0; r < kRows; r++) {
           const int q = t * kRows + r;
           pending[q] = pass[t][r];
-          if constexpr (P::kStatic) { constexpr Shape sh = static_shape(P::kId); make_record(sh, pp, rf[t], r, row0 + r, rec[q]); }
+          if constexpr (P::kStatic) { constexpr Shape sh = P::shape(); make_record(sh, pp, rf[t], r, row0 + r, rec[q]); }
           else make_record(dsh, pp, rf[t], r, row0 + r, rec[q]);
           part[q] = part_of(rec[q].key, (rec[q].vbits >> 63) & 1, pp.log2_parts);
         }

@@ -550,6 +550,14 @@ class LazyFrame:
         """Physical plan chosen by the last collect() on this thread."""
         return F.last_plan()
 
+    def jit_selftest(self) -> None:
+        """Compile (not run) the run-time specialised kernels of this query with hiprtc; raises PlxError with the
+        compiler log on failure.  Needs no GPU."""
+        low, root, _ = self._lower()
+        ir, n_ir, ae, n_ae, keep = low.to_c()
+        F.check(F.lib().plx_jit_selftest(ir, n_ir, ae, n_ae, root))
+        del keep
+
     def describe_fusion(self):
         """(fusable, static_shape_id, reason, program dump) -- compile only, no kernel launch."""
         low, root, _ = self._lower()

@@ -384,3 +384,54 @@ def test_partitioned_groupby_matches_hbm_table_path(pl, variant):
         assert len(got) == len(uk)
         for j in rng.integers(0, len(uk), 2000):
             assert got[int(uk[j])] == (int(s[j]), int(c[j]))
+
+
+def test_jit_specialised_kernels_match_generic_interpreter(pl, orc):
+    """Query shapes without an AOT kernel: the hiprtc-specialised kernel (forced on for tiny inputs here) and the
+    generic interpreter (JIT disabled) must give identical integer results and 1e-6 float results, for the register,
+    LDS-table, hash-table, wide-key and join-pipeline sinks."""
+    F = pl._ffi
+    rng = np.random.default_rng(51)
+    n = 120_001
+    a = rng.integers(-1000, 1000, n).astype(np.int32)
+    k = rng.integers(0, 50_000, n).astype(np.int64) * 3 - 70_000
+    k2 = rng.integers(0, 3, n).astype(np.int64) * 2**40
+    g8 = rng.integers(0, 5, n).astype(np.uint8)
+    x = rng.uniform(-1, 1, n); xv = rng.uniform(size=n) > 0.1
+    df = pl.DataFrame([pl.Series("a", a), pl.Series("k", k), pl.Series("k2", k2), pl.Series("g8", g8), pl.Series("x", x, validity=xv)])
+    bk = rng.permutation(60_000)[:4_000].astype(np.int64) * 3 - 70_000
+    small = pl.DataFrame({"k": bk, "pay": rng.integers(0, 9, 4_000).astype(np.int64)})
+    c = pl.col
+    queries = {
+        "regagg": df.lazy().filter((c("a") > -500) & (c("x") < 0.9)).select((c("x") * 2 + 1).sum().alias("e"), c("a").max().alias("mx"), c("x").min().alias("mn"), pl.len().alias("n"), (c("k") % 7).sum().alias("m7")),
+        "lds": df.lazy().filter(c("a") != 3).group_by("g8").agg(c("x").sum().alias("s"), c("x").mean().alias("m"), c("a").min().alias("mn"), pl.len().alias("n")),
+        "hash": df.lazy().group_by("k").agg(c("x").sum().alias("s"), c("a").max().alias("mx"), c("x").count().alias("c")),
+        "wide": df.lazy().group_by("k", "k2").agg(c("a").sum().alias("s"), pl.len().alias("n")),
+        "join": df.lazy().filter(c("a") > -900).join(small.lazy().filter(c("pay") < 7), on="k").group_by("k", "pay").agg((c("x") * 0.5).sum().alias("s"), pl.len().alias("n")),
+    }
+    try:
+        res = {}
+        for mode, min_rows in (("jit", 0), ("generic", -1)):
+            F.jit_set_min_rows(min_rows)
+            before = F.jit_stats()[0]
+            for name, q in queries.items():
+                out = q.collect()
+                keys = [cn for cn in out.columns if cn in ("g8", "k", "k2", "pay")]
+                d = out.to_dict()
+                rows = sorted(zip(*[d[cn] for cn in out.columns]), key=lambda r: tuple((v is None, v) for v in r[: len(keys)])) if keys else list(zip(*[d[cn] for cn in out.columns]))
+                res[(mode, name)] = (out.columns, rows)
+            if mode == "jit":
+                assert F.jit_stats()[0] - before >= 5, "the JIT did not compile the expected kernels"
+            else:
+                assert F.jit_stats()[0] == before
+        for name in queries:
+            cj, rj = res[("jit", name)]; cg, rg = res[("generic", name)]
+            assert cj == cg and len(rj) == len(rg), name
+            for r1, r2 in zip(rj, rg):
+                for v1, v2 in zip(r1, r2):
+                    if isinstance(v1, float) and v2 is not None:
+                        assert math.isclose(v1, v2, rel_tol=RTOL, abs_tol=1e-12), (name, r1, r2)
+                    else:
+                        assert v1 == v2, (name, r1, r2)
+    finally:
+        F.jit_set_min_rows(1 << 22)
