@@ -9,6 +9,7 @@
 #include <sstream>
 
 #include "fused_shapes.hpp"
+#include "jit.hpp"
 #include "join.hpp"
 #include "kernels.hpp"
 #include "kernels_fused.hpp"
@@ -709,7 +710,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     const int G = 1 << kp.total_bits;
     Buf cells = dev_alloc(sizeof(uint64_t) * (size_t)G * sh.n_aggs);
     k::fused_lds_agg(sh, args, G, static_id, cells->as<uint64_t>());
-    desc += std::string("fused_scan[") + (static_id >= 0 ? "aot" : "generic") + "]+lds_table(G=" + std::to_string(G) + ",copies=" + std::to_string(k::lds_agg_copies(G, sh.n_aggs)) + ")";
+    desc += std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+lds_table(G=" + std::to_string(G) + ",copies=" + std::to_string(k::lds_agg_copies(G, sh.n_aggs)) + ")";
     compact_into(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, res);
     res.key_valid = nullptr;  // packed keys carry their own null codes
     return;
@@ -720,7 +721,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     k::init_agg_cells(cells->as<uint64_t>(), G + 1, sh);
     DenseTable t; t.acc = cells->as<unsigned long long>(); t.key_min = 0; t.n_groups = G;
     k::fused_dense_agg(sh, args, t, static_id);
-    desc += std::string("fused_scan[") + (static_id >= 0 ? "aot" : "generic") + "]+dense_hbm_table(G=" + std::to_string(G) + ")";
+    desc += std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+dense_hbm_table(G=" + std::to_string(G) + ")";
     compact_into(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, res);
     res.key_valid = nullptr;
     return;
@@ -749,7 +750,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
         const int64_t g = k::partitioned_agg(sh, args, pp, static_id, &ok, &okv, &oacc, &pd);
         if (g >= 0) {
           res.n_groups = g; res.n_aggs = sh.n_aggs; res.packed_keys = ok; res.key_valid = okv; res.acc = oacc;
-          desc += std::string("fused_scan[") + (static_id >= 0 ? "aot" : "generic") + "]+" + pd;
+          desc += std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+" + pd;
           return;
         }
         desc += "lds-overflow+";
@@ -759,7 +760,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
   for (int attempt = 0; attempt < 8; attempt++) {
     int64_t g = kp.wide ? run_wide_agg(sh, args, log2_cap, kp.wide_nullable, res, false) : run_hash_agg(sh, args, static_id, log2_cap, len_idx, res, false);
     if (g >= 0) {
-      desc += std::string("fused_scan[") + (static_id >= 0 && !kp.wide ? "aot" : "generic") + "]+" + (kp.wide ? "wide_hash_hbm_table(words=" + std::to_string(sh.n_keys + (kp.wide_nullable ? 1 : 0)) + ",cap=2^" : "hash_hbm_table(cap=2^") + std::to_string(log2_cap) + ")";
+      desc += std::string("fused_scan[") + jit::program_mode(kp.wide ? -1 : static_id, args.n_rows) + "]+" + (kp.wide ? "wide_hash_hbm_table(words=" + std::to_string(sh.n_keys + (kp.wide_nullable ? 1 : 0)) + ",cap=2^" : "hash_hbm_table(cap=2^") + std::to_string(log2_cap) + ")";
       return;
     }
     log2_cap += 2;
@@ -846,7 +847,7 @@ static bool fused_select(Plan& plan, const IRN& node, const std::vector<int>& pr
   r.acc = dev_alloc(sizeof(uint64_t) * kMaxAggs);
   h2d_async(r.acc->ptr, host.data(), sizeof(uint64_t) * (size_t)c.shape.n_aggs);
   PLX_HIP(hipStreamSynchronize(stream()));
-  plan.desc += std::string("FusedFilterAgg{fused_scan[") + (static_id >= 0 ? "aot" : "generic") + "]+register_sink, inputs=" + std::to_string(c.shape.n_inputs) + ", ops=" + std::to_string(c.shape.n_ops) + ", aggs=" + std::to_string(c.shape.n_aggs) + "}; ";
+  plan.desc += std::string("FusedFilterAgg{fused_scan[") + jit::program_mode(static_id, c.args.n_rows) + "]+register_sink, inputs=" + std::to_string(c.shape.n_inputs) + ", ops=" + std::to_string(c.shape.n_ops) + ", aggs=" + std::to_string(c.shape.n_aggs) + "}; ";
   std::map<int, ColumnPtr> overrides;
   FinBatch batch{};
   for (size_t i = 0; i < agg_nodes.size(); i++) overrides[agg_nodes[i]] = finalize_column(r, specs[i], batch);
@@ -1058,7 +1059,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       rows->len = G; rows->values = dev_alloc(values_bytes(PLX_U32, g1));
       if (G) k::direct_agg_compact(dt, n_ord_used, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
       plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " direct-address table range=" +
-                   std::to_string(range) + " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + (probe_static_id >= 0 ? "aot" : "generic") + "]+probe_agg, aggs=" +
+                   std::to_string(range) + " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+probe_agg, aggs=" +
                    std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
       done = true;
     }
@@ -1087,7 +1088,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   rows->len = G; rows->values = dev_alloc(values_bytes(PLX_U32, g1));
   if (G) k::join_agg_compact(t, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
   plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " hash table cap=2^" + std::to_string(log2_cap) +
-               " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + (probe_static_id >= 0 ? "aot" : "generic") + "]+probe_agg, aggs=" + std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
+               " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+probe_agg, aggs=" + std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
   }  // hash-table path
   // ---- output frame: keys, then aggregates
   out = std::make_shared<Frame>();

@@ -138,6 +138,8 @@ std::string selftest(const Shape& sh, Sink sink) {
   return log;
 }
 
+const char* program_mode(int static_id, int64_t n_rows) { return static_id >= 0 ? "aot" : (enabled(n_rows) ? "jit" : "generic"); }
+
 void set_min_rows(int64_t min_rows) { g_min_rows.store(min_rows < 0 ? -1 : min_rows, std::memory_order_relaxed); }
 
 void stats(int* compiled, double* compile_ms) {

@@ -22,6 +22,8 @@ enum Sink { REGAGG = 0, LDSAGG, DENSE, HASH, WIDE, JOIN_BUILD, PROBE_AGG, DIRECT
 bool launch(const fused::Shape& sh, const fused::Args& args, Sink sink, const void* params, int grid, size_t lds_bytes);
 // compile-only check of the JIT toolchain for one (shape, sink): "" on success, else the compiler log (no GPU needed)
 std::string selftest(const fused::Shape& sh, Sink sink);
+// "aot" (pre-instantiated), "jit" (run-time specialised) or "generic" (interpreter): how a program of this size runs
+const char* program_mode(int static_id, int64_t n_rows);
 // inputs of at least min_rows rows use the JIT; < 0 disables it (overrides PLX_JIT / PLX_JIT_MIN_ROWS)
 void set_min_rows(int64_t min_rows);
 // statistics for tests / explain: kernels compiled so far, total compile milliseconds
