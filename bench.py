@@ -155,7 +155,22 @@ def timed(pl, wl: Workload, steps: int, warmup: int, distributed: bool, combine=
     return dt, stats, res
 
 
-def roofline(stats, kernel_prefix):
+def pmc_traffic(workload_name: str, kernel: str, rows: int):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, profiles/r01/*_pmc.json).  bench.py cannot run rocprofv3 on itself, so this is the number measured by
+    `tools/pmc_round.sh` on the same workload at the SF100 size; None for any other size / kernel."""
+    try:
+        if workload_name == "tpch_q1_sf100" and rows == SF100_LINEITEM and kernel.startswith("fused_scan_ldsagg"):
+            return int(json.load(open(os.path.join(ROOT, "profiles", "r01", "q1_sf100_pmc.json")))["hbm_bytes_per_launch"])
+        if workload_name == "tpch_q3_sf100" and kernel.startswith("fused_scan_direct_probe_agg"):
+            d = json.load(open(os.path.join(ROOT, "profiles", "r01", "q3_sf100_pmc.json")))["kernels"]
+            return int(next(v for k, v in d.items() if k.startswith("probe"))["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
+def roofline(stats, wl):
     """Dominant kernel = largest total time among the launches of the timed region."""
     if not stats:
         return None
@@ -164,7 +179,7 @@ def roofline(stats, kernel_prefix):
     avg_us = tot_us / cnt
     ach = algo / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
     return {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "avg_kernel_us": round(avg_us, 2), "launches": cnt, "algo_bytes_per_launch": algo, "traffic": None}
+            "avg_kernel_us": round(avg_us, 2), "launches": cnt, "algo_bytes_per_launch": algo, "traffic": pmc_traffic(wl.name, name, wl.rows)}
 
 
 def cpu_baseline_q1(seconds: float):
@@ -242,7 +257,7 @@ def main():
         "config": {"workload": wl.name, "description": wl.desc, "rows_per_gpu": wl.rows, "algorithmic_bytes_per_gpu_step": wl.algo_bytes,
                    "parallelism": f"row-sharded x{ws}, all-gather of group partials" if ws > 1 else "single GPU"},
         "whole_query_GBps_per_gpu": round(wl.algo_bytes * args.steps / dt / 1e9, 1),
-        "roofline": roofline(stats, wl.kernel),
+        "roofline": roofline(stats, wl),
         "kernels": {k: {"launches": v[0], "avg_us": round(v[1] / v[0], 2)} for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])[:8]},
     }
     if rank == 0 and not args.no_extras and ws == 1:
@@ -255,7 +270,7 @@ def main():
                 d2, s2, _ = timed(pl, w2, max(3, args.steps // 4), 1, False)
                 k2 = max(3, args.steps // 4)
                 extras[w2.name] = {"rows_per_s": round(w2.rows * k2 / d2, 1), "ms_per_step": round(d2 / k2 * 1e3, 3),
-                                   "whole_query_GBps": round(w2.algo_bytes * k2 / d2 / 1e9, 1), "roofline": roofline(s2, w2.kernel),
+                                   "whole_query_GBps": round(w2.algo_bytes * k2 / d2 / 1e9, 1), "roofline": roofline(s2, w2),
                                    "kernels": {k: {"launches": v[0], "avg_us": round(v[1] / v[0], 2)} for k, v in sorted(s2.items(), key=lambda kv: -kv[1][1])[:6]}}
                 del w2
             except Exception as e:  # a secondary workload must never take the headline line down
