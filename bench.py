@@ -215,6 +215,27 @@ def cpu_baseline_q1(seconds: float):
                       f"in_memory_engine_rows_per_s = orc_q1 (FilterExec -> GroupByExec with per-group index lists) on {n_mem} rows"}
 
 
+def combine_q1_results(per_rank):
+    """Merge the Q1 results of row-sharded ranks: sums and counts add, averages are recombined from
+    (avg x count) -- the partial/final decomposition of polars_amd.dist.PARTIALS applied to the finished frames."""
+    merged = {}
+    for r in per_rank:
+        for i in range(len(r["l_returnflag"])):
+            k = (r["l_returnflag"][i], r["l_linestatus"][i])
+            m = merged.setdefault(k, {"sum_qty": 0, "sum_base_price": 0.0, "sum_disc_price": 0.0, "sum_charge": 0.0, "_disc": 0.0, "count_order": 0})
+            c = r["count_order"][i]
+            m["sum_qty"] += r["sum_qty"][i]; m["sum_base_price"] += r["sum_base_price"][i]; m["sum_disc_price"] += r["sum_disc_price"][i]
+            m["sum_charge"] += r["sum_charge"][i]; m["_disc"] += r["avg_disc"][i] * c; m["count_order"] += c
+    out = {k: [] for k in ("l_returnflag", "l_linestatus", "sum_qty", "sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc", "count_order")}
+    for (f, s_), m in sorted(merged.items()):
+        c = m["count_order"]
+        out["l_returnflag"].append(f); out["l_linestatus"].append(s_)
+        for k in ("sum_qty", "sum_base_price", "sum_disc_price", "sum_charge", "count_order"):
+            out[k].append(m[k])
+        out["avg_qty"].append(m["sum_qty"] / c); out["avg_price"].append(m["sum_base_price"] / c); out["avg_disc"].append(m["_disc"] / c)
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -230,22 +251,12 @@ def main():
 
     combine = None
     if distributed and args.workload == "q1":
-        # per-rank result -> partial states -> all-gather -> combine (tiny)
-        from polars_amd import datagen
-
+        # per-rank result -> all-gather of the (tiny) per-group partial states -> combine
         def combine(res):
             import torch.distributed as dist
             obj = [None] * ws
             dist.all_gather_object(obj, res)
-            merged = {}
-            for r in obj:
-                for i in range(len(r["l_returnflag"])):
-                    k = (r["l_returnflag"][i], r["l_linestatus"][i])
-                    m = merged.setdefault(k, {"sum_qty": 0, "sum_base_price": 0.0, "sum_disc_price": 0.0, "sum_charge": 0.0, "disc": 0.0, "count_order": 0})
-                    c = r["count_order"][i]
-                    m["sum_qty"] += r["sum_qty"][i]; m["sum_base_price"] += r["sum_base_price"][i]; m["sum_disc_price"] += r["sum_disc_price"][i]
-                    m["sum_charge"] += r["sum_charge"][i]; m["disc"] += r["avg_disc"][i] * c; m["count_order"] += c
-            return merged
+            return combine_q1_results(obj)
 
     dt, stats, res = timed(pl, wl, args.steps, args.warmup, distributed, combine)
     total_rows = wl.rows * ws * args.steps

@@ -51,3 +51,26 @@ def test_partial_final_decomposition_table():
     from polars_amd import dist as pdist
     assert pdist.PARTIALS["mean"] == [("sum_f64", "sum"), ("count", "sum")]          # reduce/mean.rs keeps (f64 sum, count)
     assert pdist.PARTIALS["count"] == [("count", "sum")] and pdist.PARTIALS["min"] == [("min", "min")]
+
+
+def test_bench_q1_rank_combine_matches_single_shard():
+    """bench.py --gpus N: the per-rank Q1 frames are merged with combine_q1_results; merging the oracle's results on
+    two row shards must equal the oracle on the whole table."""
+    import numpy as np
+    import bench
+    from oracle import pyoracle as orc
+    from polars_amd import datagen
+    li = datagen.lineitem_host(60_000, seed=3)
+    cols = {k: li[k] for k in datagen.LINEITEM_Q1_COLS}
+    cut = datagen.us(1998, 9, 2)
+    whole = orc.q1_native(cols, cut, streaming=True)
+    parts = []
+    for lo, hi in ((0, 25_001), (25_001, 60_000)):
+        r = orc.q1_native({k: v[lo:hi] for k, v in cols.items()}, cut, streaming=True)
+        parts.append({k: v.tolist() for k, v in r.items()})
+    merged = bench.combine_q1_results(parts)
+    for k, v in whole.items():
+        if v.dtype.kind == "f":
+            assert np.allclose(np.array(merged[k]), v, rtol=1e-9), k
+        else:
+            assert merged[k] == v.tolist(), k

@@ -441,3 +441,45 @@ def test_jit_specialised_kernels_match_generic_interpreter(pl, orc):
                         assert v1 == v2, (name, r1, r2)
     finally:
         F.jit_set_min_rows(1 << 22)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_grouped_agg_fuzz(pl, seed):
+    """Randomised grouped aggregation (the idea of the reference's Hypothesis test, py-polars/tests/unit/operations/
+    test_group_by.py:2500-2600: group_by(key % 4).agg(f(x)) must equal evaluating f per group): random dtype, size,
+    null rates and key cardinality; every aggregate against a plain per-group numpy evaluation."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 7, 64, 129, 1000, 40_000]))
+    kdt = rng.choice(["i8", "i32", "i64", "u16"])
+    vdt = rng.choice(["i64", "f64", "i32", "u8"])
+    card = int(rng.choice([1, 4, 37, 5000]))
+    NP = {"i8": np.int8, "i32": np.int32, "i64": np.int64, "u16": np.uint16, "f64": np.float64, "u8": np.uint8}
+    key = (rng.integers(0, card, n) % 100).astype(NP[kdt]) if kdt == "i8" else rng.integers(0, card, n).astype(NP[kdt])
+    kv = rng.uniform(size=n) > rng.choice([0.0, 0.1])
+    vals = rng.uniform(-5, 5, n) if vdt == "f64" else rng.integers(0, 200, n).astype(NP[vdt])
+    vv = rng.uniform(size=n) > rng.choice([0.0, 0.3])
+    PL = {"i8": pl.Int8, "i32": pl.Int32, "i64": pl.Int64, "u16": pl.UInt16, "f64": pl.Float64, "u8": pl.UInt8}
+    df = pl.DataFrame([pl.Series("k", key, dtype=PL[kdt], validity=kv), pl.Series("v", vals, dtype=PL[vdt], validity=vv)])
+    c = pl.col("v")
+    out = df.lazy().group_by("k").agg(c.sum().alias("s"), c.mean().alias("m"), c.min().alias("mn"), c.max().alias("mx"), c.count().alias("c"), pl.len().alias("n")).collect()
+    d = out.to_dict()
+    got = {d["k"][i]: tuple(d[x][i] for x in ("s", "m", "mn", "mx", "c", "n")) for i in range(out.height)}
+    groups = {}
+    for i in range(n):
+        groups.setdefault(int(key[i]) if kv[i] else None, []).append(i)
+    assert set(got) == set(groups)
+    for gk, idx in groups.items():
+        idx = np.array(idx)
+        ok = vv[idx]
+        x = vals[idx][ok]
+        s, m, mn, mx, cnt, ln = got[gk]
+        assert ln == len(idx) and cnt == int(ok.sum())
+        if vdt == "f64":
+            assert math.isclose(s, float(x.sum()), rel_tol=RTOL, abs_tol=1e-9)
+        else:
+            assert s == int(x.astype(np.int64).sum())
+        if len(x) == 0:
+            assert m is None and mn is None and mx is None
+        else:
+            assert math.isclose(m, float(x.astype(np.float64).mean()), rel_tol=RTOL, abs_tol=1e-9)
+            assert mn == x.min().item() and mx == x.max().item()
