@@ -65,6 +65,14 @@ def main():
     g = pdist.groupby_agg(ops, {"flag": flag}, {"v": v, "x": x}, aggs, mode="gather")
     # (c) high-cardinality group-by: shuffle by key hash, result sharded by key
     s = pdist.groupby_agg(ops, {"key": key}, {"v": v, "x": x}, aggs, mode="shuffle")
+    # (d) bench.py --gpus N: per-rank Q1 frames are all-gathered as one fixed-size tensor and merged on every rank
+    import bench
+    from polars_amd import datagen
+    li = datagen.lineitem_host(30_000 + 500 * rank, seed=200 + rank)
+    qcols = {c: li[c] for c in datagen.LINEITEM_Q1_COLS}
+    mine = {c: a.tolist() for c, a in orc.q1_native(qcols, datagen.us(1998, 9, 2), streaming=True).items()}
+    merged = bench.combine_q1_results(bench.allgather_q1(mine, ws))
+    np.savez(os.path.join(out_dir, f"q1_rank{rank}.npz"), **{c: np.asarray(a) for c, a in qcols.items()}, **{"m_" + c: np.asarray(a) for c, a in merged.items()})
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), key=key.numpy(), flag=flag.numpy(), v=v.numpy(), x=x.numpy(),
              **{f"g_{k}": t.numpy() for k, t in g.items()}, **{f"s_{k}": t.numpy() for k, t in s.items()})
     dist.barrier()

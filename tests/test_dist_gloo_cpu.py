@@ -21,6 +21,16 @@ def test_sharded_groupby_and_exchange(tmp_path, ws):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    # Q1 merged across ranks == oracle on the concatenated shards, identical on every rank
+    from oracle import pyoracle as orc
+    from polars_amd import datagen
+    qfiles = [np.load(f) for f in sorted(glob.glob(str(tmp_path / "q1_rank*.npz")))]
+    assert len(qfiles) == ws
+    whole = orc.q1_native({c: np.concatenate([q[c] for q in qfiles]) for c in datagen.LINEITEM_Q1_COLS}, datagen.us(1998, 9, 2), streaming=True)
+    for q in qfiles:
+        for c, v in whole.items():
+            got = q["m_" + c]
+            assert np.allclose(got.astype(np.float64), v.astype(np.float64), rtol=1e-9), c
     files = sorted(glob.glob(str(tmp_path / "rank*.npz")))
     assert len(files) == ws
     parts = [np.load(f) for f in files]
@@ -68,7 +78,11 @@ def test_bench_q1_rank_combine_matches_single_shard():
     for lo, hi in ((0, 25_001), (25_001, 60_000)):
         r = orc.q1_native({k: v[lo:hi] for k, v in cols.items()}, cut, streaming=True)
         parts.append({k: v.tolist() for k, v in r.items()})
-    merged = bench.combine_q1_results(parts)
+    # through the fixed-size tensor packing used by the all-gather
+    import torch
+    packed = torch.stack([bench.pack_q1(p) for p in parts])
+    parts2 = bench.unpack_q1(packed)
+    merged = bench.combine_q1_results(parts2)
     for k, v in whole.items():
         if v.dtype.kind == "f":
             assert np.allclose(np.array(merged[k]), v, rtol=1e-9), k
