@@ -137,16 +137,48 @@ struct KeyDecode {
 };
 
 // ---- partitioned group-by (kernels_partition.hip) ---------------------------------------------
+#if defined(__HIPCC__) || defined(__HIP__)
+#define PLX_FHD __host__ __device__
+#else
+#define PLX_FHD
+#endif
+constexpr int kMaxSrc = 4;     // distinct aggregate sources a record carries (more => the HBM-table sink runs)
+// Record layout: [key, source 0 .. n_src-1, (validity word), (row id)] as u64 words.  A pure function of the program
+// shape, so AOT / JIT kernels have it as a compile-time constant and the host derives the identical layout.
+struct RecLayout {
+  uint32_t n_src;              // distinct aggregate source slots (> kMaxSrc: not representable)
+  uint32_t has_valid;          // validity word (bit j = source j valid, bit 63 = key valid)
+  uint32_t has_rowid;          // row index (AGG_FIRST_ROW)
+  uint32_t rec_words;
+  uint8_t src_slot[kMaxAggs];  // program slot of source j
+  uint8_t agg_src[kMaxAggs];   // aggregate k reads source agg_src[k] (kNone: LEN / FIRST_ROW)
+};
+PLX_FHD constexpr bool shape_may_have_nulls(const Shape& sh) {
+  for (int i = 0; i < sh.n_inputs; i++) if (sh.in_nullable[i]) return true;
+  for (int i = 0; i < sh.n_ops; i++) if (sh.ops[i].code >= OP_FDIV_I) return true;   // integer div / mod: divisor 0 -> null
+  return false;
+}
+PLX_FHD constexpr RecLayout rec_layout(const Shape& sh) {
+  RecLayout L{};
+  for (int k = 0; k < kMaxAggs; k++) { L.agg_src[k] = kNone; L.src_slot[k] = 0; }
+  for (int k = 0; k < sh.n_aggs; k++) {
+    const uint8_t kind = sh.aggs[k].kind;
+    if (kind == AGG_LEN) continue;
+    if (kind == AGG_FIRST_ROW) { L.has_rowid = 1; continue; }
+    int j = -1;
+    for (uint32_t t = 0; t < L.n_src; t++) if (L.src_slot[t] == sh.aggs[k].src) j = (int)t;
+    if (j < 0) { j = (int)L.n_src; if (L.n_src < (uint32_t)kMaxAggs) L.src_slot[L.n_src] = sh.aggs[k].src; L.n_src++; }
+    L.agg_src[k] = (uint8_t)j;
+  }
+  L.has_valid = shape_may_have_nulls(sh) ? 1 : 0;
+  L.rec_words = 1 + L.n_src + L.has_valid + L.has_rowid;
+  return L;
+}
 struct PartitionPlan {
   uint32_t log2_parts;         // P = 1 << log2_parts hash partitions
   uint32_t log2_slots;         // slots of the per-partition LDS table
-  uint32_t rec_words;          // u64 words per record: key + sources (+ validity word) (+ row id)
-  uint32_t n_src;              // distinct aggregate source slots
-  uint32_t has_valid;          // records carry a validity word (bit j = source j valid, bit 63 = key valid)
-  uint32_t has_rowid;          // records carry the row index (AGG_FIRST_ROW)
   uint32_t buf_rows;           // records per LDS write-combining buffer (even)
-  uint8_t src_slot[kMaxAggs];  // program slot of source j
-  uint8_t agg_src[kMaxAggs];   // aggregate k reads source agg_src[k] (kNone: LEN / FIRST_ROW)
+  RecLayout rec;               // == rec_layout(shape)
 };
 
 // ---- batched result finalisation: every output column of a query in ONE launch ---------------

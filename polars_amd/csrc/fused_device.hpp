@@ -340,6 +340,29 @@ __device__ __forceinline__ void run_program(const Shape& dsh, const Args& args, 
   }
 }
 
+// Split execution for software pipelining (AOT programs only): the host compiler emits every column load first, so
+// ops [0, n_leading_loads) can be issued for the NEXT tile while the current tile is still being processed; the
+// loaded registers are simply not touched until run_rest.
+__host__ __device__ constexpr int leading_loads(const Shape& s) {
+  int n = 0;
+  while (n < s.n_ops && s.ops[n].code == OP_LOAD) n++;
+  return n;
+}
+template <class P, class RF>
+__device__ __forceinline__ void run_loads_full(const Args& args, int64_t row0, RF& rf) {
+  constexpr Shape sh = P::shape();
+  constexpr int nl = leading_loads(sh);
+#pragma unroll
+  for (int pc = 0; pc < nl; pc++) exec_op<true>(sh.ops[pc], sh, args, pc, row0, rf);
+}
+template <class P, class RF>
+__device__ __forceinline__ void run_rest_full(const Args& args, int64_t row0, RF& rf) {
+  constexpr Shape sh = P::shape();
+  constexpr int nl = leading_loads(sh);
+#pragma unroll
+  for (int pc = nl; pc < sh.n_ops; pc++) exec_op<true>(sh.ops[pc], sh, args, pc, row0, rf);
+}
+
 // Register file of a kernel running program provider P: VGPRs for AOT programs, the wave's slice of dynamic LDS
 // (at args.rf_lds_offset, after the sink's own LDS) for the generic interpreter.
 template <class P> struct RegFileOf { using type = RegFile; };

@@ -73,6 +73,10 @@ __device__ __forceinline__ void round_rows(const Shape& dsh, const Args& args, i
   }
 }
 template <class P>
+__device__ __forceinline__ bool round_is_full(const Args& args, int64_t rd) {
+  return (rd + 1) * Round<P>::kTiles * (kBlock / 64) * (int64_t)kTileRows <= args.n_rows;
+}
+template <class P>
 __device__ __forceinline__ int64_t round_row0(int64_t rd, int t, int wave_in_block) {
   return ((rd * Round<P>::kTiles + t) * (kBlock / 64) + wave_in_block) * (int64_t)kTileRows + (int64_t)lane_id() * kRows;
 }
@@ -120,7 +124,16 @@ __global__ __launch_bounds__(kBlock) void part_prefix_kernel(const unsigned int*
 // ---- pass 2: scatter through LDS write-combining buffers ------------------------------------------
 // Workgroup-synchronous tile loop (every wave of the workgroup runs the same number of iterations, so
 // __syncthreads inside the loop is legal -- unlike fused_scan_kernel, whose tiles are handed out per wave).
-constexpr int kMaxSrc = 4;   // distinct aggregate sources carried by a record (more => the HBM-table sink runs)
+// Layout provider: compile-time for AOT / JIT programs, the plan's copy for the generic interpreter.
+template <class P> struct LayoutOf {
+  static constexpr bool kConst = true;
+  static constexpr RecLayout kL = rec_layout(P::shape());
+  __device__ __forceinline__ static constexpr RecLayout get(const PartitionPlan&) { return kL; }
+};
+template <> struct LayoutOf<DynProg> {
+  static constexpr bool kConst = false;
+  __device__ __forceinline__ static const RecLayout& get(const PartitionPlan& pp) { return pp.rec; }
+};
 
 struct Rec {
   uint64_t key, vbits, rowid;
@@ -128,7 +141,7 @@ struct Rec {
 };
 // Register-resident record (all indices compile-time: a dynamically indexed array would live in scratch).
 template <class S, class RF>
-__device__ __forceinline__ void make_record(const S& sh, const PartitionPlan& pp, const RF& rf, int r, int64_t row, Rec& rec) {
+__device__ __forceinline__ void make_record(const S& sh, const RecLayout& L, const RF& rf, int r, int64_t row, Rec& rec) {
   const bool kvalid = (rf.getv(sh.key) >> r) & 1;
   rec.key = kvalid ? rf.get(r, sh.key) : 0ull;
   rec.vbits = kvalid ? (1ull << 63) : 0ull;
@@ -136,26 +149,27 @@ __device__ __forceinline__ void make_record(const S& sh, const PartitionPlan& pp
 #pragma unroll
   for (int j = 0; j < kMaxSrc; j++) {
     rec.src[j] = 0;
-    if (j < (int)pp.n_src) {
-      rec.src[j] = rf.get(r, pp.src_slot[j]);
-      if ((rf.getv(pp.src_slot[j]) >> r) & 1) rec.vbits |= 1ull << j;
+    if (j < (int)L.n_src) {
+      rec.src[j] = rf.get(r, L.src_slot[j]);
+      if ((rf.getv(L.src_slot[j]) >> r) & 1) rec.vbits |= 1ull << j;
     }
   }
 }
-__device__ __forceinline__ void store_record(unsigned long long* dst, const PartitionPlan& pp, const Rec& rec) {
+__device__ __forceinline__ void store_record(unsigned long long* dst, const RecLayout& L, const Rec& rec) {
   dst[0] = rec.key;
 #pragma unroll
-  for (int j = 0; j < kMaxSrc; j++) if (j < (int)pp.n_src) dst[1 + j] = rec.src[j];
-  uint32_t w = 1 + pp.n_src;
-  if (pp.has_valid) dst[w++] = rec.vbits;
-  if (pp.has_rowid) dst[w] = rec.rowid;
+  for (int j = 0; j < kMaxSrc; j++) if (j < (int)L.n_src) dst[1 + j] = rec.src[j];
+  uint32_t w = 1 + L.n_src;
+  if (L.has_valid) dst[w++] = rec.vbits;
+  if (L.has_rowid) dst[w] = rec.rowid;
 }
 
 template <class P>
 __global__ __launch_bounds__(kBlock) void part_scatter_kernel(Shape dsh, Args args, PartitionPlan pp, const unsigned long long* __restrict__ part_off,
                                                               const unsigned long long* __restrict__ wg_prefix, unsigned long long* __restrict__ out) {
   extern __shared__ unsigned long long lds_raw[];
-  const uint32_t NP = 1u << pp.log2_parts, B = pp.buf_rows, R = pp.rec_words;
+  const RecLayout L = LayoutOf<P>::get(pp);   // compile-time constant for AOT programs
+  const uint32_t NP = 1u << pp.log2_parts, B = pp.buf_rows, R = L.rec_words;
   unsigned long long* buf = lds_raw;                                        // [NP][B][R]
   unsigned long long* fbase = buf + (size_t)NP * B * R;                     // [NP] global record index of a flush
   unsigned long long* cur = fbase + NP;                                     // [NP] this workgroup's next record index per partition
@@ -172,26 +186,57 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(Shape dsh, Args ar
   const int64_t rows_per_round = (int64_t)kBlock * kRoundRows;
   const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
   const int wave_in_block = threadIdx.x >> 6;
-  for (int64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
-    Rec rec[kRoundRows];
-    uint32_t part[kRoundRows];
-    bool pending[kRoundRows];
-    {
-      typename RegFileOf<P>::type rf[kRoundTiles] = {make_regfile<P>(args)}; bool pass[kRoundTiles][kRows];
-      round_rows<P>(dsh, args, rd, wave_in_block, rf, pass);
+  // Software pipeline (AOT programs): the column loads of round r+1 are ISSUED before round r's records are appended
+  // and flushed (a few microseconds of LDS work and barriers -- barriers do not drain VMEM), and only consumed
+  // afterwards.  One register file and one record set: no copies.
+  typename RegFileOf<P>::type rf[kRoundTiles] = {make_regfile<P>(args)};
+  Rec rec[kRoundRows];
+  uint32_t part[kRoundRows];
+  bool pending[kRoundRows];
+  auto finish_round = [&](int64_t rd, bool preloaded) {
+    bool pass[kRoundTiles][kRows];
+    bool done = false;
+    if constexpr (P::kStatic) {
+      if (preloaded) {
+        constexpr Shape psh = P::shape();
 #pragma unroll
-      for (int t = 0; t < kRoundTiles; t++) {
-        const int64_t row0 = round_row0<P>(rd, t, wave_in_block);
+        for (int t = 0; t < kRoundTiles; t++) {
+          run_rest_full<P>(args, round_row0<P>(rd, t, wave_in_block), rf[t]);
 #pragma unroll
-        for (int r = 0; r < kRows; r++) {
-          const int q = t * kRows + r;
-          pending[q] = pass[t][r];
-          if constexpr (P::kStatic) { constexpr Shape sh = P::shape(); make_record(sh, pp, rf[t], r, row0 + r, rec[q]); }
-          else make_record(dsh, pp, rf[t], r, row0 + r, rec[q]);
-          part[q] = part_of(rec[q].key, (rec[q].vbits >> 63) & 1, pp.log2_parts);
+          for (int r = 0; r < kRows; r++) pass[t][r] = psh.pred == kNone || ((rf[t].get(r, psh.pred) & 1) && ((rf[t].getv(psh.pred) >> r) & 1));
         }
+        done = true;
       }
     }
+    if (!done) round_rows<P>(dsh, args, rd, wave_in_block, rf, pass);
+#pragma unroll
+    for (int t = 0; t < kRoundTiles; t++) {
+      const int64_t row0 = round_row0<P>(rd, t, wave_in_block);
+#pragma unroll
+      for (int r = 0; r < kRows; r++) {
+        const int q = t * kRows + r;
+        pending[q] = pass[t][r];
+        if constexpr (P::kStatic) { constexpr Shape sh = P::shape(); make_record(sh, L, rf[t], r, row0 + r, rec[q]); }
+        else make_record(dsh, L, rf[t], r, row0 + r, rec[q]);
+        part[q] = part_of(rec[q].key, (rec[q].vbits >> 63) & 1, pp.log2_parts);
+      }
+    }
+  };
+  auto issue_loads = [&](int64_t rd) -> bool {   // true if the loads of round rd are now in flight
+    if constexpr (P::kStatic) {
+      if (rd < nrounds && round_is_full<P>(args, rd)) {
+#pragma unroll
+        for (int t = 0; t < kRoundTiles; t++) run_loads_full<P>(args, round_row0<P>(rd, t, wave_in_block), rf[t]);
+        return true;
+      }
+    }
+    return false;
+  };
+  if ((int64_t)blockIdx.x < nrounds) finish_round(blockIdx.x, issue_loads(blockIdx.x));
+  for (int64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
+    // records of round rd are in rec[]: they are copied out of the register file, which is free for the next round
+    const int64_t rd_next = rd + gridDim.x;
+    const bool preloaded = issue_loads(rd_next);
     int any;
     do {
       if (threadIdx.x == 0) nflush = 0;
@@ -200,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(Shape dsh, Args ar
         if (!pending[q]) continue;
         const unsigned int pos = atomicAdd(&cnt[part[q]], 1u);
         if (pos < B) {
-          store_record(buf + ((size_t)part[q] * B + pos) * R, pp, rec[q]);
+          store_record(buf + ((size_t)part[q] * B + pos) * R, L, rec[q]);
           pending[q] = false;
         }
       }
@@ -227,6 +272,7 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(Shape dsh, Args ar
       for (int q = 0; q < kRoundRows; q++) mine = mine || pending[q];
       any = __syncthreads_or(mine ? 1 : 0);
     } while (any);
+    if (rd_next < nrounds) finish_round(rd_next, preloaded);
   }
   // partial buffers
   __syncthreads();
@@ -252,42 +298,53 @@ struct PartAggParams {
 };
 constexpr int kAggBlock = 1024;
 
-__global__ __launch_bounds__(kAggBlock) void part_agg_kernel(Shape sh, PartitionPlan pp, PartAggParams ap) {
+// Aggregate kinds and record layout are compile-time constants for AOT programs (the per-record agg loop is then
+// straight-line code; with run-time kinds it is a chain of scalar switches and the kernel is instruction-bound).
+template <class S>
+__device__ __forceinline__ void part_agg_body(const S& sh, const RecLayout& L, const PartitionPlan& pp, const PartAggParams& ap) {
   extern __shared__ unsigned long long lds_raw[];
-  const uint32_t S = 1u << ap.log2_slots, n_aggs = sh.n_aggs, R = pp.rec_words, NP = 1u << pp.log2_parts;
-  unsigned long long* keys = lds_raw;                 // [S + 2]: slot S = null-key group, S + 1 = the key equal to EMPTY
-  unsigned long long* cells = keys + S + 2;           // [(S + 2) * n_aggs]
+  const uint32_t NS = 1u << ap.log2_slots, n_aggs = sh.n_aggs, R = L.rec_words, NP = 1u << pp.log2_parts;
+  unsigned long long* keys = lds_raw;                 // [NS + 2]: slot NS = null-key group, NS + 1 = the key equal to EMPTY
+  unsigned long long* cells = keys + NS + 2;           // [(NS + 2) * n_aggs]
   __shared__ unsigned int n_occ, cursor_l, full;
   __shared__ unsigned long long gbase;
   for (uint32_t p = blockIdx.x; p < NP; p += gridDim.x) {
-    for (uint32_t i = threadIdx.x; i < S + 2; i += blockDim.x) keys[i] = kEmptyKey;
-    for (uint32_t i = threadIdx.x; i < (S + 2) * n_aggs; i += blockDim.x) cells[i] = agg_identity_dev(sh.aggs[i % n_aggs].kind);
+    for (uint32_t i = threadIdx.x; i < NS + 2; i += blockDim.x) keys[i] = kEmptyKey;
+    for (uint32_t i = threadIdx.x; i < (NS + 2) * n_aggs; i += blockDim.x) cells[i] = agg_identity_dev(sh.aggs[i % n_aggs].kind);
     if (threadIdx.x == 0) { n_occ = 0; cursor_l = 0; full = 0; }
     __syncthreads();
     const uint64_t beg = ap.part_off[p], end = ap.part_off[p + 1];
-    constexpr int kInFlight = 8;   // records loaded per thread before any is consumed
-    for (uint64_t i0 = beg + threadIdx.x; i0 < end; i0 += (uint64_t)blockDim.x * kInFlight) {
+    constexpr int kInFlight = 8;   // records per thread per batch; the next batch is loaded while this one is consumed
+    unsigned long long n0[kInFlight], n1[kInFlight];
+    auto load_batch = [&](uint64_t i0, unsigned long long* a0, unsigned long long* a1) {
+#pragma unroll
+      for (int u = 0; u < kInFlight; u++) {
+        const uint64_t i = i0 + (uint64_t)u * blockDim.x;
+        a0[u] = 0; a1[u] = 0;
+        if (i < end) {
+          if (R == 2) { const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(ap.recs + i * 2); a0[u] = v.x; a1[u] = v.y; }
+          else { a0[u] = ap.recs[i * R]; a1[u] = R > 1 ? ap.recs[i * R + 1] : 0ull; }
+        }
+      }
+    };
+    const uint64_t step = (uint64_t)blockDim.x * kInFlight;
+    if (beg + threadIdx.x < end) load_batch(beg + threadIdx.x, n0, n1);
+    for (uint64_t i0 = beg + threadIdx.x; i0 < end; i0 += step) {
      unsigned long long w0[kInFlight], w1[kInFlight];
 #pragma unroll
-     for (int u = 0; u < kInFlight; u++) {
-       const uint64_t i = i0 + (uint64_t)u * blockDim.x;
-       w0[u] = 0; w1[u] = 0;
-       if (i < end) {
-         if (R == 2) { const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(ap.recs + i * 2); w0[u] = v.x; w1[u] = v.y; }
-         else { w0[u] = ap.recs[i * R]; w1[u] = R > 1 ? ap.recs[i * R + 1] : 0ull; }
-       }
-     }
+     for (int u = 0; u < kInFlight; u++) { w0[u] = n0[u]; w1[u] = n1[u]; }
+     if (i0 + step < end) load_batch(i0 + step, n0, n1);
 #pragma unroll
      for (int u = 0; u < kInFlight; u++) {
       const uint64_t i = i0 + (uint64_t)u * blockDim.x;
       if (i >= end) continue;
       const unsigned long long* rec = ap.recs + i * R;
       const uint64_t key = w0[u];
-      const uint64_t vbits = pp.has_valid ? rec[1 + pp.n_src] : ~0ull;
-      const uint64_t rowid = pp.has_rowid ? rec[1 + pp.n_src + (pp.has_valid ? 1 : 0)] : 0ull;
+      const uint64_t vbits = L.has_valid ? rec[1 + L.n_src] : ~0ull;
+      const uint64_t rowid = L.has_rowid ? rec[1 + L.n_src + (L.has_valid ? 1 : 0)] : 0ull;
       uint32_t slot;
-      if (!(vbits >> 63)) { slot = S; keys[S] = 0; }
-      else if (key == kEmptyKey) { slot = S + 1; keys[S + 1] = 0; }
+      if (!(vbits >> 63)) { slot = NS; keys[NS] = 0; }
+      else if (key == kEmptyKey) { slot = NS + 1; keys[NS + 1] = 0; }
       else {
         slot = (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> (64 - ap.log2_slots));   // a second hash: the partition consumed the top bits of the first
         uint32_t probe = 0;
@@ -298,15 +355,17 @@ __global__ __launch_bounds__(kAggBlock) void part_agg_kernel(Shape sh, Partition
             const unsigned long long old = atomicCAS(&keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
             if (old == kEmptyKey || old == key) break;
           }
-          slot = (slot + 1) & (S - 1);
-          if (probe >= S) { full = 1; break; }
+          slot = (slot + 1) & (NS - 1);
+          if (probe >= NS) { full = 1; break; }
         }
-        if (probe >= S) continue;
+        if (probe >= NS) continue;
       }
       unsigned long long* cell = cells + (size_t)slot * n_aggs;
-      for (uint32_t k = 0; k < n_aggs; k++) {
+#pragma unroll
+      for (uint32_t k = 0; k < (uint32_t)kMaxAggs; k++) {
+        if (k >= n_aggs) break;
         const uint8_t kind = sh.aggs[k].kind;
-        const uint8_t sj = pp.agg_src[k];
+        const uint8_t sj = L.agg_src[k];
         const uint64_t v = sj != kNone ? (sj == 0 ? w1[u] : rec[1 + sj]) : 0ull;
         const bool valid = sj != kNone ? ((vbits >> sj) & 1) : true;
         const uint64_t x = agg_row_value(kind, v, true, valid, rowid);
@@ -321,21 +380,27 @@ __global__ __launch_bounds__(kAggBlock) void part_agg_kernel(Shape sh, Partition
     if (full) { if (threadIdx.x == 0) atomicExch(ap.overflow, 1u); __syncthreads(); continue; }
     // emit the partition's groups: count, reserve once, write
     uint32_t mine = 0;
-    for (uint32_t s = threadIdx.x; s < S + 2; s += blockDim.x) mine += keys[s] != kEmptyKey;
+    for (uint32_t s = threadIdx.x; s < NS + 2; s += blockDim.x) mine += keys[s] != kEmptyKey;
     if (mine) atomicAdd(&n_occ, mine);
     __syncthreads();
     if (threadIdx.x == 0) gbase = n_occ ? atomicAdd(ap.counter, (unsigned long long)n_occ) : 0ull;
     __syncthreads();
     if (gbase + n_occ > ap.max_groups) { if (threadIdx.x == 0) atomicExch(ap.overflow, 2u); __syncthreads(); continue; }
-    for (uint32_t s = threadIdx.x; s < S + 2; s += blockDim.x) {
+    for (uint32_t s = threadIdx.x; s < NS + 2; s += blockDim.x) {
       if (keys[s] == kEmptyKey) continue;
       const uint64_t o = gbase + atomicAdd(&cursor_l, 1u);
-      ap.out_keys[o] = s < S ? keys[s] : (s == S ? 0ull : kEmptyKey);
-      ap.out_kvalid[o] = s == S ? 0 : 1;
+      ap.out_keys[o] = s < NS ? keys[s] : (s == NS ? 0ull : kEmptyKey);
+      ap.out_kvalid[o] = s == NS ? 0 : 1;
       for (uint32_t k = 0; k < n_aggs; k++) ap.out_acc[o * n_aggs + k] = cells[(size_t)s * n_aggs + k];
     }
     __syncthreads();
   }
+}
+
+template <class P>
+__global__ __launch_bounds__(kAggBlock) void part_agg_kernel(Shape dsh, PartitionPlan pp, PartAggParams ap) {
+  if constexpr (P::kStatic) { constexpr Shape csh = P::shape(); constexpr RecLayout cl = rec_layout(P::shape()); part_agg_body(csh, cl, pp, ap); }
+  else part_agg_body(dsh, pp.rec, pp, ap);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
@@ -347,26 +412,15 @@ static uint64_t scan_bytes(const Shape& sh, const Args& args) {
 
 bool partition_plan(const Shape& sh, double est_groups, bool any_nullable, PartitionPlan* out) {
   PartitionPlan pp{};
-  // distinct aggregate sources
-  for (int k = 0; k < kMaxAggs; k++) pp.agg_src[k] = kNone;
-  for (int k = 0; k < sh.n_aggs; k++) {
-    const uint8_t kind = sh.aggs[k].kind;
-    if (kind == AGG_LEN) continue;
-    if (kind == AGG_FIRST_ROW) { pp.has_rowid = 1; continue; }
-    int j = -1;
-    for (uint32_t t = 0; t < pp.n_src; t++) if (pp.src_slot[t] == sh.aggs[k].src) j = (int)t;
-    if (j < 0) { j = (int)pp.n_src; pp.src_slot[pp.n_src++] = sh.aggs[k].src; }
-    pp.agg_src[k] = (uint8_t)j;
-  }
-  if (pp.n_src > 4) return false;   // kMaxSrc
-  pp.has_valid = any_nullable ? 1 : 0;
-  pp.rec_words = 1 + pp.n_src + pp.has_valid + pp.has_rowid;
+  pp.rec = rec_layout(sh);     // the layout AOT / JIT kernels derive at compile time from the same shape
+  (void)any_nullable;          // rec_layout decides from the shape (nullable inputs, ops that can yield null)
+  if (pp.rec.n_src > (uint32_t)kMaxSrc) return false;
   // LDS table of pass 3: as many slots as fit ~144 KB; partitions so that a partition holds <= slots / 2 groups
   const size_t lds_budget = 144 * 1024;
   uint32_t log2_slots = 14;
   while (log2_slots > 8 && ((size_t)(1u << log2_slots) + 2) * 8 * (1 + sh.n_aggs) > lds_budget) log2_slots--;
   if (((size_t)(1u << log2_slots) + 2) * 8 * (1 + sh.n_aggs) > lds_budget) return false;
-  const double per_part = (double)(1u << log2_slots) * 0.45;
+  const double per_part = (double)(1u << log2_slots) * 0.62;   // expected groups per partition (the caller passes 1.3 x its estimate): LDS table load <= ~0.62
   uint32_t log2_parts = 6;
   while (log2_parts < 10 && (double)(1u << log2_parts) * per_part < est_groups) log2_parts++;
   if ((double)(1u << log2_parts) * per_part < est_groups) return false;   // would need > 1024 partitions
@@ -374,7 +428,7 @@ bool partition_plan(const Shape& sh, double est_groups, bool any_nullable, Parti
   pp.log2_slots = log2_slots;
   // write-combining buffers of pass 2
   uint32_t B = 8;
-  auto scatter_lds = [&](uint32_t b) { return ((size_t)(1u << log2_parts) * b * pp.rec_words + 2 * (1u << log2_parts)) * 8 + (size_t)(1u << log2_parts) * 8 + 16; };
+  auto scatter_lds = [&](uint32_t b) { return ((size_t)(1u << log2_parts) * b * pp.rec.rec_words + 2 * (1u << log2_parts)) * 8 + (size_t)(1u << log2_parts) * 8 + 16; };
   while (B > 2 && scatter_lds(B) > lds_budget) B -= 2;
   if (scatter_lds(B) > lds_budget) return false;
   pp.buf_rows = B;
@@ -394,11 +448,11 @@ bool partition_plan(const Shape& sh, double est_groups, bool any_nullable, Parti
 // groups, or -1 if an LDS table overflowed (the caller falls back to the HBM-table sink).
 int64_t partitioned_agg(const Shape& sh, const Args& args, const PartitionPlan& pp, int static_id, Buf* out_keys, Buf* out_kvalid, Buf* out_acc, std::string* desc) {
   const uint32_t NP = 1u << pp.log2_parts;
-  const size_t slds = ((size_t)NP * pp.buf_rows * pp.rec_words + 2 * NP) * 8 + (size_t)NP * 8 + 16;
+  const size_t slds = ((size_t)NP * pp.buf_rows * pp.rec.rec_words + 2 * NP) * 8 + (size_t)NP * 8 + 16;
   const bool is_static = static_id == SHAPE_GB_SUM_CNT_I64 || static_id == SHAPE_GB_SUM_MEAN_U32_F64;   // the cases of PLX_PART_STATIC_CASES
   const int64_t rows_per_round = (int64_t)kBlock * kRows * (is_static ? kStaticRoundTiles : 1);
   const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
-  const int sgrid = (int)std::min<int64_t>(nrounds, (int64_t)device().cu_count * (slds > 76 * 1024 ? 1 : 2));   // the SAME grid for pass 1 and pass 2
+  const int sgrid = (int)std::min<int64_t>(nrounds, (int64_t)device().cu_count * (slds > 80 * 1024 ? 1 : 2));   // 2 workgroups per CU when two buffers sets fit the 160 KB LDS; the SAME grid for pass 1 and pass 2
   Buf hist = dev_alloc(sizeof(uint32_t) * (size_t)sgrid * NP);
   Buf wg_prefix = dev_alloc(sizeof(uint64_t) * (size_t)sgrid * NP);
   Buf totals = dev_alloc(sizeof(uint64_t) * (NP + 1));
@@ -419,9 +473,9 @@ int64_t partitioned_agg(const Shape& sh, const Args& args, const PartitionPlan& 
   uint64_t total = 0;
   d2h_sync(&total, part_off->as<uint64_t>() + NP, 8);
   if (total == 0) { *out_keys = dev_alloc(8); *out_kvalid = dev_alloc(8); *out_acc = dev_alloc(8); return 0; }
-  Buf recs = dev_alloc(sizeof(uint64_t) * (size_t)total * pp.rec_words + 64);
+  Buf recs = dev_alloc(sizeof(uint64_t) * (size_t)total * pp.rec.rec_words + 64);
   {
-    ProfileScope ps("part_scatter", scan_bytes(sh, args) + total * pp.rec_words * 8, (uint64_t)args.n_rows);
+    ProfileScope ps("part_scatter", scan_bytes(sh, args) + total * pp.rec.rec_words * 8, (uint64_t)args.n_rows);
     switch (static_id) {
       PLX_PART_STATIC_CASES(part_scatter_kernel, dim3(sgrid), dim3(kBlock), slds, stream(), sh, args, pp, part_off->as<unsigned long long>(), wg_prefix->as<unsigned long long>(), recs->as<unsigned long long>())
       default: { const DynLaunch d = dyn_launch(sh, args, slds); hipLaunchKernelGGL((part_scatter_kernel<DynProg>), dim3(sgrid), dim3(kBlock), d.lds, stream(), sh, d.args, pp, part_off->as<unsigned long long>(), wg_prefix->as<unsigned long long>(), recs->as<unsigned long long>()); } break;
@@ -439,16 +493,19 @@ int64_t partitioned_agg(const Shape& sh, const Args& args, const PartitionPlan& 
   ap.out_keys = (*out_keys)->as<unsigned long long>(); ap.out_kvalid = (*out_kvalid)->as<unsigned char>(); ap.out_acc = (*out_acc)->as<unsigned long long>();
   ap.log2_slots = pp.log2_slots; ap.max_groups = (uint32_t)std::min<uint64_t>(max_groups, 0xffffffffull);
   {
-    ProfileScope ps("part_agg_lds", total * pp.rec_words * 8, total);
+    ProfileScope ps("part_agg_lds", total * pp.rec.rec_words * 8, total);
     const size_t lds = (((size_t)1 << pp.log2_slots) + 2) * 8 * (1 + sh.n_aggs);
     const int agrid = (int)std::min<uint32_t>(NP, (uint32_t)device().cu_count);
-    hipLaunchKernelGGL(part_agg_kernel, dim3(agrid), dim3(kAggBlock), lds, stream(), sh, pp, ap);
+    switch (static_id) {
+      PLX_PART_STATIC_CASES(part_agg_kernel, dim3(agrid), dim3(kAggBlock), lds, stream(), sh, pp, ap)
+      default: hipLaunchKernelGGL((part_agg_kernel<DynProg>), dim3(agrid), dim3(kAggBlock), lds, stream(), sh, pp, ap); break;
+    }
     PLX_HIP(hipGetLastError());
   }
   uint64_t res[2] = {0, 0};
   d2h_sync(res, ctr->ptr, 16);
   if ((uint32_t)res[1]) return -1;
-  if (desc) *desc = "partitioned(P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec_words * 8) + "B,buf=" + std::to_string(pp.buf_rows) + ")+lds_hash_table(slots=" + std::to_string(1u << pp.log2_slots) + ")";
+  if (desc) *desc = "partitioned(P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec.rec_words * 8) + "B,buf=" + std::to_string(pp.buf_rows) + ")+lds_hash_table(slots=" + std::to_string(1u << pp.log2_slots) + ")";
   return (int64_t)res[0];
 }
 
