@@ -31,7 +31,8 @@ int g_compiled = 0;
 double g_ms = 0;
 
 const char* sink_type(Sink s) {
-  static const char* n[] = {"RegAggSink", "LdsAggSink", "DenseAggSink", "HashAggSink", "WideAggSink", "JoinBuildSink", "ProbeAggSink", "DirectBuildSink", "DirectProbeAggSink"};
+  static const char* n[] = {"RegAggSink", "LdsAggSink", "DenseAggSink", "HashAggSink", "WideAggSink", "JoinBuildSink", "ProbeAggSink", "DirectBuildSink", "DirectProbeAggSink",
+                            "part_count", "part_scatter", "part_agg"};
   return n[s];
 }
 
@@ -65,7 +66,7 @@ std::vector<std::string> compile_options() {
 
 std::string source_for(const Shape& sh, Sink sink) {
   std::ostringstream o;
-  o << "#include \"fused_sinks.hpp\"\nnamespace plx { namespace k {\n"
+  o << (sink >= PART_COUNT ? "#include \"partition_device.hpp\"\n" : "#include \"fused_sinks.hpp\"\n") << "namespace plx { namespace k {\n"
        "struct JitProg {\n  static constexpr bool kStatic = true; static constexpr int kId = -2;\n  static constexpr Shape shape() {\n    Shape s{};\n";
   o << "    s.n_inputs = " << (int)sh.n_inputs << "; s.n_ops = " << (int)sh.n_ops << "; s.n_aggs = " << (int)sh.n_aggs << "; s.pred = " << (int)sh.pred
     << "; s.key = " << (int)sh.key << "; s.n_keys = " << (int)sh.n_keys << ";\n";
@@ -74,9 +75,25 @@ std::string source_for(const Shape& sh, Sink sink) {
   for (int i = 0; i < sh.n_ops; i++)
     o << "    s.ops[" << i << "] = mkop(" << (int)sh.ops[i].code << ", " << (int)sh.ops[i].dst << ", " << (int)sh.ops[i].a << ", " << (int)sh.ops[i].b << ", " << (int)sh.ops[i].c << ");\n";
   for (int i = 0; i < sh.n_aggs; i++) o << "    s.aggs[" << i << "] = Agg{" << (int)sh.aggs[i].kind << ", " << (int)sh.aggs[i].src << "};\n";
-  o << "    return s;\n  }\n};\n"
-       "extern \"C\" __global__ __launch_bounds__(kBlock) void plx_jit_kernel(Shape dsh, Args args, "
-    << sink_type(sink) << "::Params sp) {\n  fused_scan_body<JitProg, " << sink_type(sink) << ">(dsh, args, sp);\n}\n}}\n";
+  o << "    return s;\n  }\n};\n";
+  switch (sink) {
+    case PART_COUNT:
+      o << "extern \"C\" __global__ __launch_bounds__(kBlock) void plx_jit_kernel(Shape dsh, Args args, uint32_t log2_parts, unsigned int* hist) {\n"
+           "  part_count_body<JitProg>(dsh, args, log2_parts, hist);\n}\n}}\n";
+      break;
+    case PART_SCATTER:
+      o << "extern \"C\" __global__ __launch_bounds__(kBlock) void plx_jit_kernel(Shape dsh, Args args, PartitionPlan pp, const unsigned long long* part_off, "
+           "const unsigned long long* wg_prefix, unsigned long long* out) {\n  part_scatter_body<JitProg>(dsh, args, pp, part_off, wg_prefix, out);\n}\n}}\n";
+      break;
+    case PART_AGG:
+      o << "extern \"C\" __global__ __launch_bounds__(kAggBlock) void plx_jit_kernel(Shape dsh, PartitionPlan pp, PartAggParams ap) {\n"
+           "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout cl = rec_layout(JitProg::shape());\n  part_agg_body(csh, cl, pp, ap);\n}\n}}\n";
+      break;
+    default:
+      o << "extern \"C\" __global__ __launch_bounds__(kBlock) void plx_jit_kernel(Shape dsh, Args args, " << sink_type(sink)
+        << "::Params sp) {\n  fused_scan_body<JitProg, " << sink_type(sink) << ">(dsh, args, sp);\n}\n}}\n";
+      break;
+  }
   return o.str();
 }
 
@@ -148,23 +165,30 @@ void stats(int* compiled, double* compile_ms) {
   if (compile_ms) *compile_ms = g_ms;
 }
 
-bool launch(const Shape& sh, const Args& args, Sink sink, const void* params, int grid, size_t lds_bytes) {
-  if (!enabled(args.n_rows)) return false;
+static hipFunction_t get_fn(const Shape& sh, Sink sink) {
   std::string key((const char*)&sh, sizeof(Shape));
   key.push_back((char)sink);
-  hipFunction_t fn = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_cache.find(key);
-    if (it == g_cache.end()) it = g_cache.emplace(key, compile(sh, sink)).first;
-    if (it->second.failed) return false;
-    fn = it->second.fn;
-  }
-  Shape shc = sh; Args ac = args;
-  void* kargs[] = {(void*)&shc, (void*)&ac, const_cast<void*>(params)};
-  const hipError_t rc = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, (unsigned)k::kBlock, 1, 1, (unsigned)lds_bytes, stream(), kargs, nullptr);
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_cache.find(key);
+  if (it == g_cache.end()) it = g_cache.emplace(key, compile(sh, sink)).first;
+  return it->second.failed ? nullptr : it->second.fn;
+}
+
+bool ensure(const Shape& sh, Sink kind, int64_t n_rows) { return enabled(n_rows) && get_fn(sh, kind) != nullptr; }
+
+bool launch_raw(const Shape& sh, Sink kind, void** kargs, int grid, int block, size_t lds_bytes) {
+  hipFunction_t fn = get_fn(sh, kind);
+  if (!fn) return false;
+  const hipError_t rc = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, (unsigned)block, 1, 1, (unsigned)lds_bytes, stream(), kargs, nullptr);
   if (rc != hipSuccess) { set_last_error(std::string("jit: launch failed: ") + hipGetErrorString(rc)); return false; }
   return true;
+}
+
+bool launch(const Shape& sh, const Args& args, Sink sink, const void* params, int grid, size_t lds_bytes) {
+  if (!enabled(args.n_rows)) return false;
+  Shape shc = sh; Args ac = args;
+  void* kargs[] = {(void*)&shc, (void*)&ac, const_cast<void*>(params)};
+  return launch_raw(sh, sink, kargs, grid, k::kBlock, lds_bytes);
 }
 
 }  // namespace jit

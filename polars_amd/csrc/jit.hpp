@@ -17,9 +17,16 @@
 namespace plx {
 namespace jit {
 
-enum Sink { REGAGG = 0, LDSAGG, DENSE, HASH, WIDE, JOIN_BUILD, PROBE_AGG, DIRECT_BUILD, DIRECT_PROBE, kNumSinks };
+enum Sink { REGAGG = 0, LDSAGG, DENSE, HASH, WIDE, JOIN_BUILD, PROBE_AGG, DIRECT_BUILD, DIRECT_PROBE,
+            // kernels of the partitioned group-by (partition_device.hpp); launched with launch_raw
+            PART_COUNT, PART_SCATTER, PART_AGG, kNumSinks };
 
 bool launch(const fused::Shape& sh, const fused::Args& args, Sink sink, const void* params, int grid, size_t lds_bytes);
+// Compile (or fetch) the specialised kernel of (shape, kind) without launching: lets a multi-kernel pipeline decide up
+// front whether every stage is available.  n_rows gates on PLX_JIT / PLX_JIT_MIN_ROWS like launch().
+bool ensure(const fused::Shape& sh, Sink kind, int64_t n_rows);
+// Launch with an explicit argument list (pointers to each kernel argument, in the wrapper's order).
+bool launch_raw(const fused::Shape& sh, Sink kind, void** kargs, int grid, int block, size_t lds_bytes);
 // compile-only check of the JIT toolchain for one (shape, sink): "" on success, else the compiler log (no GPU needed)
 std::string selftest(const fused::Shape& sh, Sink sink);
 // "aot" (pre-instantiated), "jit" (run-time specialised) or "generic" (interpreter): how a program of this size runs
