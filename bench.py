@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="q1", choices=["q1", "q3", "cfg2", "cfg3"])
+    ap.add_argument("--workload", default="q1", choices=["q1", "q3", "cfg2", "cfg3", "cfg5"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the SF100 / 1e9-row size of the workload)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -103,6 +103,18 @@ def make_workload(pl, name: str, rows: int, seed: int) -> Workload:
         def step():
             return {"groups": lf.collect().height}, (df, key, v)
         return Workload("cfg3_groupby_1e6_keys_1e9", n, n * 16 + 1_000_000 * 20, step, "fused_scan", f"config 3: {n} rows, 1e6 Int64 keys, group_by(key).agg(sum, count)")
+    if name == "cfg5":
+        n = rows or 1_000_000_000
+        g = torch.Generator(device="cuda"); g.manual_seed(seed)
+        codes = torch.randint(0, 1_000_000, (n,), generator=g, device="cuda", dtype=torch.int32)   # dictionary codes of "id%010d" keys (u32)
+        v = torch.rand((n,), generator=g, device="cuda", dtype=torch.float64) * 100.0
+        df = pl.DataFrame([pl.Series.from_torch("k", codes, dtype=pl.Categorical([], pl.UInt32)), pl.Series.from_torch("v", v)])
+        torch.cuda.synchronize()
+        lf = queries.cfg5(df.lazy())
+
+        def step():
+            return {"groups": lf.collect().height}, (df, codes, v)
+        return Workload("cfg5_dict_string_keys_1e9", n, n * 12 + 1_000_000 * 20, step, "part_scatter", f"config 5: {n} rows, 1e6 dictionary-encoded string keys (u32 codes), group_by(k).agg(sum, mean)")
     raise ValueError(name)
 
 
@@ -318,7 +330,7 @@ def main():
         extras = {}
         del wl
         torch.cuda.empty_cache()
-        for name in [w for w in ("q3", "cfg2", "cfg3", "q1") if w != args.workload]:
+        for name in [w for w in ("q3", "cfg2", "cfg3", "cfg5", "q1") if w != args.workload]:
             try:
                 w2 = make_workload(pl, name, 0, seed=20)
                 d2, s2, _ = timed(pl, w2, max(3, args.steps // 4), 1, False)

@@ -715,6 +715,23 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     res.key_valid = nullptr;  // packed keys carry their own null codes
     return;
   }
+  // large inputs over many (packed) group ids: per-row atomics on the dense HBM table are bound by the device atomic
+  // rate just like the hash table -> partition + LDS aggregation on the packed id (kernels_partition.hip)
+  if (kp.packed && kp.total_bits > 12 && !(c.plan.flags & PLX_PLAN_NO_PARTITION) && n >= ((int64_t)1 << 24)) {
+    PartitionPlan pp;
+    const double est = std::min((double)((uint64_t)1 << std::min(kp.total_bits, 40)), (double)n);
+    if (k::partition_plan(sh, est, false, &pp)) {
+      std::string pd;
+      Buf ok, okv, oacc;
+      const int64_t g = k::partitioned_agg(sh, args, pp, static_id, &ok, &okv, &oacc, &pd);
+      if (g >= 0) {
+        res.n_groups = g; res.n_aggs = sh.n_aggs; res.packed_keys = ok; res.key_valid = nullptr; res.acc = oacc;   // packed ids carry their own null codes
+        desc += std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+" + pd;
+        return;
+      }
+      desc += "lds-overflow+";
+    }
+  }
   if (kp.packed && kp.total_bits <= 28 && ((size_t)sh.n_aggs << (kp.total_bits + 3)) <= (size_t(8) << 30)) {
     const int64_t G = (int64_t)1 << kp.total_bits;
     Buf cells = dev_alloc(sizeof(uint64_t) * (size_t)(G + 1) * sh.n_aggs);

@@ -483,3 +483,23 @@ def test_grouped_agg_fuzz(pl, seed):
         else:
             assert math.isclose(m, float(x.astype(np.float64).mean()), rel_tol=RTOL, abs_tol=1e-9)
             assert mn == x.min().item() and mx == x.max().item()
+
+
+def test_partitioned_groupby_packed_dictionary_keys(pl):
+    """BASELINE config 5 shape at >= 2^24 rows: u32 dictionary codes (packed dense ids) -> partitioned LDS path."""
+    from polars_amd import queries
+    rng = np.random.default_rng(43)
+    n = 17_000_000
+    codes = rng.integers(0, 400_000, n).astype(np.uint32)
+    v = rng.uniform(0, 100, n)
+    df = pl.DataFrame([pl.Series("k", codes, dtype=pl.Categorical([], pl.UInt32)), pl.Series("v", v)])
+    out = queries.cfg5(df.lazy()).collect(); plan = pl.last_plan()
+    assert "partitioned(" in plan and "fused_scan[aot]" in plan, plan
+    ref = queries.cfg5(df.lazy()).collect(no_partition=True)
+    assert "dense_hbm_table" in pl.last_plan(), pl.last_plan()
+    k1, k2 = out["k"].to_numpy(), ref["k"].to_numpy()
+    o1, o2 = np.argsort(k1), np.argsort(k2)
+    assert np.array_equal(k1[o1], k2[o2]) and np.array_equal(k1[o1], np.unique(codes))
+    s = np.bincount(codes, v)[np.unique(codes)]; cnt = np.bincount(codes)[np.unique(codes)]
+    assert close(out["v_sum"].to_numpy()[o1], s) and close(out["v_mean"].to_numpy()[o1], s / cnt)
+    assert close(ref["v_sum"].to_numpy()[o2], s)
