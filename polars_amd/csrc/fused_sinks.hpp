@@ -360,7 +360,8 @@ struct DirectProbeAggSink {
 };
 
 template <class P, class Sink>
-__device__ __forceinline__ void fused_scan_body(const Shape& dsh, const Args& args, const typename Sink::Params& sp) {
+__device__ __forceinline__ void fused_scan_body(const Shape dsh, const Args args, const typename Sink::Params sp) {   // by value: kernel arguments passed by
+                                                                                                              // reference become addressable stack copies (spills)
   Sink sink;
   typename RegFileOf<P>::type rf = make_regfile<P>(args);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;

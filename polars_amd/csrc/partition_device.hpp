@@ -59,7 +59,7 @@ __device__ __forceinline__ int64_t round_row0(int64_t rd, int t, int wave_in_blo
 
 // ---- pass 1: per-workgroup partition histogram -----------------------------------------------------
 template <class P>
-__device__ __forceinline__ void part_count_body(const Shape& dsh, const Args& args, uint32_t log2_parts, unsigned int* __restrict__ hist /* [grid][NP] */) {
+__device__ __forceinline__ void part_count_body(const Shape dsh, const Args args, uint32_t log2_parts, unsigned int* __restrict__ hist /* [grid][NP] */) {
   extern __shared__ unsigned long long lds_raw[];
   unsigned int* cnt = reinterpret_cast<unsigned int*>(lds_raw);
   const uint32_t NP = 1u << log2_parts;
@@ -141,7 +141,7 @@ __device__ __forceinline__ void store_record(unsigned long long* dst, const RecL
 }
 
 template <class P>
-__device__ __forceinline__ void part_scatter_body(const Shape& dsh, const Args& args, const PartitionPlan& pp, const unsigned long long* __restrict__ part_off,
+__device__ __forceinline__ void part_scatter_body(const Shape dsh, const Args args, const PartitionPlan pp, const unsigned long long* __restrict__ part_off,
                                                               const unsigned long long* __restrict__ wg_prefix, unsigned long long* __restrict__ out) {
   extern __shared__ unsigned long long lds_raw[];
   const RecLayout L = LayoutOf<P>::get(pp);   // compile-time constant for AOT programs

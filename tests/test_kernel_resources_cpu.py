@@ -1,0 +1,40 @@
+"""Build-time guard: the pre-instantiated (AOT) hot kernels must not spill to scratch memory.  (Passing kernel arguments
+by reference into the inlined kernel body once turned them into stack copies: the partition scatter kernel spilled
+932 B/lane and ran 8x slower.)  Compiles the two kernel files with -Rpass-analysis=kernel-resource-usage; no GPU needed."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "polars_amd", "csrc")
+
+
+def resource_usage(src):
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-munsafe-fp-atomics",
+           "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", os.devnull]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC, timeout=900).stderr
+    res, cur = {}, None
+    for line in out.splitlines():
+        m = re.search(r"remark: (.*?) \[-Rpass", line)
+        if not m:
+            continue
+        t = m.group(1).strip()
+        if t.startswith("Function Name:"):
+            cur = t.split(": ", 1)[1]
+            res[cur] = {}
+        elif cur and ": " in t:
+            k, v = t.split(": ", 1)
+            res[cur][k.strip()] = v.strip()
+    return res
+
+
+def test_aot_kernels_do_not_spill():
+    checked = 0
+    for src in ("kernels_fused.hip", "kernels_partition.hip"):
+        for name, r in resource_usage(src).items():
+            if "StatProg" not in name:
+                continue          # the generic interpreter's kernels are not the hot path
+            checked += 1
+            assert int(r["ScratchSize [bytes/lane]"]) == 0, (name, r)
+            assert int(r["VGPRs"]) <= 256, (name, r)
+    assert checked >= 18, checked
