@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 namespace plx {
 
@@ -147,6 +148,23 @@ void h2d_async(void* dst, const void* src, size_t bytes) {
   PLX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream()));
 }
 
+// Host -> HBM copy of a caller-owned Arrow buffer.  Large buffers are page-locked in place (hipHostRegister) so the copy
+// is one DMA at PCIe rate instead of the runtime's staged pageable path; the registration is dropped once the copy is
+// done.  Synchronises (the caller may free the buffer on return).  PLX_PIN_UPLOADS=0 forces the pageable path.
+static const size_t kPinThreshold = size_t(32) << 20;
+void h2d_sync_pinned(void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return;
+  static const bool pin = [] { const char* e = getenv("PLX_PIN_UPLOADS"); return !(e && e[0] == '0'); }();
+  bool registered = false;
+  if (pin && bytes >= kPinThreshold) registered = hipHostRegister(const_cast<void*>(src), bytes, hipHostRegisterDefault) == hipSuccess;
+  if (!registered) (void)hipGetLastError();   // clear a failed registration (already-registered or unsupported memory)
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream());
+  const hipError_t e2 = hipStreamSynchronize(stream());
+  if (registered) (void)hipHostUnregister(const_cast<void*>(src));
+  PLX_HIP(e);
+  PLX_HIP(e2);
+}
+
 // --------------------------------------------------------------- columns ----
 ColumnPtr make_column(int dtype, int64_t len, bool with_validity) {
   auto c = std::make_shared<Column>();
@@ -181,7 +199,7 @@ ColumnPtr column_from_host(int dtype, const void* values, const uint8_t* validit
     if (len) { vbits = repack_bits((const uint8_t*)values, bit_offset, len); h2d_async(c->values->ptr, vbits.data(), vbits.size()); }
   } else {
     c->values = dev_alloc(values_bytes(dtype, len));
-    h2d_async(c->values->ptr, values, (size_t)len * dtype_width(dtype));
+    h2d_sync_pinned(c->values->ptr, values, (size_t)len * dtype_width(dtype));
   }
   if (validity) {
     nbits = repack_bits(validity, bit_offset, len);

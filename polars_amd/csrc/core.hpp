@@ -147,5 +147,6 @@ void profile_clear();
 // small host<->device helpers (async on the current stream + sync where noted)
 void d2h_sync(void* dst, const void* src, size_t bytes);
 void h2d_async(void* dst, const void* src, size_t bytes);  // src must stay alive until sync
+void h2d_sync_pinned(void* dst, const void* src, size_t bytes);  // large buffers: page-locked in place, one DMA; synchronises
 
 }  // namespace plx
