@@ -119,7 +119,7 @@ typedef enum plx_agg_op {
   PLX_AGG_FIRST = 6  /* first row of each group (group_by only; used for key columns) */
 } plx_agg_op;
 
-typedef enum plx_join_how { PLX_JOIN_INNER = 0, PLX_JOIN_LEFT = 1 } plx_join_how;
+typedef enum plx_join_how { PLX_JOIN_INNER = 0, PLX_JOIN_LEFT = 1, PLX_JOIN_SEMI = 2, PLX_JOIN_ANTI = 3 } plx_join_how;
 
 /* A 64-bit scalar passed by bit pattern; interpreted according to a plx_dtype. */
 typedef union plx_scalar {
@@ -263,9 +263,20 @@ int plx_groupby_agg(const plx_column* keys, int32_t n_keys, const plx_column* va
 
 /* Equi-join on one key column pair -> row-index pairs (PLX_U32). For LEFT joins the
  * right index column carries nulls for unmatched left rows. Null keys never match.
- * Pair order is unspecified (sort before comparing), as in the reference. */
+ * Pair order is unspecified (sort before comparing), as in the reference.
+ * SEMI / ANTI (single_keys_semi_anti.rs): *out_left_idx = the left rows with (without) a match on the right, in
+ * left order; *out_right_idx = 0 (no column).  A null left key never matches (kept by ANTI, dropped by SEMI). */
 int plx_join_indices(plx_join_how how, plx_column left_key, plx_column right_key,
                      plx_column* out_left_idx, plx_column* out_right_idx);
+
+/* Stable multi-key arg-sort (arg_sort_multiple; polars-core/src/chunked_array/ops/sort/arg_sort_multiple.rs,
+ * SortExec polars-mem-engine/src/executors/sort.rs).  descending / nulls_last: n_by flags each, NULL = all 0.
+ * nulls_last is an absolute position (not flipped by descending); floats in total order (NaN greatest,
+ * -0.0 == +0.0); ties keep input order.  limit >= 0 returns only the first `limit` indices of that order
+ * (sort + slice -> top-k, slice_pushdown_lp.rs / polars-stream top_k.rs) without sorting the whole input.
+ * *out_idx: PLX_U32 row indices. */
+int plx_sort_indices(const plx_column* by, int32_t n_by, const uint8_t* descending, const uint8_t* nulls_last, int64_t limit,
+                     plx_column* out_idx);
 
 /* Key-hash partitioning for the multi-GPU exchange: partition p of row i is
  * mulhi(dirty_hash(key[i]) * seed', n_partitions) (HashPartitioner; nulls -> 0).
@@ -322,7 +333,9 @@ typedef enum plx_ir_kind {
   PLX_IR_SELECT = 2,  /* input, exprs */
   PLX_IR_HSTACK = 3,  /* input, exprs (with_columns) */
   PLX_IR_GROUPBY = 4, /* input, keys, exprs (aggs), maintain_order */
-  PLX_IR_JOIN = 5     /* input, input_right, keys (left_on), keys_right (right_on), how, suffix */
+  PLX_IR_JOIN = 5,    /* input, input_right, keys (left_on), keys_right (right_on), how, suffix */
+  PLX_IR_SORT = 6,    /* input, keys (by), sort_descending[n_keys], sort_nulls_last[n_keys] (IR::Sort; always stable) */
+  PLX_IR_SLICE = 7    /* input, slice_offset (negative: from the end), slice_len (IR::Slice); directly above a Sort it becomes top-k */
 } plx_ir_kind;
 
 typedef struct plx_ir {
@@ -340,6 +353,10 @@ typedef struct plx_ir {
   int32_t how; /* plx_join_how */
   int32_t maintain_order;
   const char* suffix; /* join suffix, NULL = "_right" */
+  const uint8_t* sort_descending; /* PLX_IR_SORT: n_keys flags, NULL = ascending */
+  const uint8_t* sort_nulls_last; /* PLX_IR_SORT: n_keys flags, NULL = nulls first */
+  int64_t slice_offset;           /* PLX_IR_SLICE */
+  int64_t slice_len;              /* PLX_IR_SLICE: rows kept (clamped to the input; slice_offsets, polars-core/src/utils/mod.rs:340-358) */
 } plx_ir;
 
 /* plan flags */

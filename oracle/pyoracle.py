@@ -253,6 +253,82 @@ def join(how: int, lk: np.ndarray, lv: Optional[np.ndarray], rk: np.ndarray, rv:
     return li, ri, (unpack(rvb, m) if how == JOIN_LEFT else None)
 
 
+JOIN_SEMI, JOIN_ANTI = 2, 3
+
+
+def semi_anti_join(how: int, lk: np.ndarray, lv: Optional[np.ndarray], rk: np.ndarray, rv: Optional[np.ndarray]) -> np.ndarray:
+    """Left row indices kept by a SEMI (how=2) / ANTI (how=3) join, in left order.
+    Restates polars-ops/src/frame/join/hash_join/single_keys_semi_anti.rs: a hash SET of the valid right keys is
+    built, every left row is probed in order; a null left key never matches (kept by ANTI, dropped by SEMI)."""
+    a, b = key_bits(lk), key_bits(rk)
+    if rv is not None:
+        b = b[rv]
+    matched = np.isin(a, b)
+    if lv is not None:
+        matched &= lv
+    keep = matched if how == JOIN_SEMI else ~matched
+    return np.nonzero(keep)[0].astype(np.uint32)
+
+
+def _tot_cmp(a, b) -> int:
+    """TotalOrd for one non-null value pair (polars-utils/src/total_ord.rs): NaN == NaN, NaN greatest, -0.0 == 0.0."""
+    an, bn = isinstance(a, float) and a != a, isinstance(b, float) and b != b
+    if an or bn:
+        return 0 if (an and bn) else (1 if an else -1)
+    return (a > b) - (a < b)
+
+
+def sort_indices_cmp(keys, limit: Optional[int] = None) -> np.ndarray:
+    """arg_sort_multiple restated with the reference's comparator, for SMALL inputs (pure Python).
+    keys = [(values, valid or None, descending, nulls_last)].  Per key reorder_cmp (polars-utils/src/sort.rs:113-130):
+    equal -> next key (ordering_other_columns, polars-core/src/chunked_array/ops/sort/mod.rs:350-367); a null is
+    Greater when nulls_last else Less (NOT flipped by descending); otherwise the total order, reversed if descending.
+    Ties keep input order (maintain_order / stable, arg_sort_multiple.rs:64-75)."""
+    import functools
+    n = len(keys[0][0])
+    cols = [(v.tolist(), None if m is None else m.tolist(), bool(d), bool(nl)) for v, m, d, nl in keys]
+
+    def cmp_rows(i, j):
+        for v, m, d, nl in cols:
+            a_null, b_null = m is not None and not m[i], m is not None and not m[j]
+            if a_null and b_null:
+                continue
+            if a_null:
+                return 1 if nl else -1
+            if b_null:
+                return -1 if nl else 1
+            c = _tot_cmp(v[i], v[j])
+            if c:
+                return -c if d else c
+        return 0
+    order = sorted(range(n), key=functools.cmp_to_key(cmp_rows))
+    return np.array(order[:limit] if limit is not None else order, dtype=np.uint32)
+
+
+def sort_indices(keys, limit: Optional[int] = None) -> np.ndarray:
+    """Same order as sort_indices_cmp, vectorised: every key becomes (null rank, dense value rank) and the stable
+    np.lexsort applies them last key first.  Dense ranks come from np.unique, which orders NaN last (greatest) and
+    treats -0.0 == 0.0, i.e. the reference's TotalOrd."""
+    lex = []   # np.lexsort: LAST entry is the primary key
+    for v, m, d, nl in reversed(list(keys)):
+        v = np.asarray(v)
+        if v.dtype == np.bool_:
+            v = v.astype(np.uint8)
+        _, rank = np.unique(v, return_inverse=True)
+        rank = rank.astype(np.int64)
+        if d:
+            rank = -rank
+        if m is not None:
+            rank = np.where(m, rank, 0)                    # all nulls tie within a key
+            null_rank = np.where(m, 0, 1) if nl else np.where(m, 1, 0)
+            lex.append(rank)
+            lex.append(null_rank)
+        else:
+            lex.append(rank)
+    order = np.lexsort(lex).astype(np.uint32)
+    return order[:limit] if limit is not None else order
+
+
 def hash_partition(keys: np.ndarray, valid: Optional[np.ndarray], n_parts: int, seed: int = 0) -> np.ndarray:
     kb = np.ascontiguousarray(key_bits(keys))
     out = np.zeros(len(kb), dtype=np.uint32)

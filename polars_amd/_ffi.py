@@ -20,11 +20,11 @@ EQ, NE, LT, LE, GT, GE = range(6)
 ADD, SUB, MUL, TRUE_DIV, FLOOR_DIV, MOD = range(6)
 AND, OR, XOR = range(3)
 AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT, AGG_LEN, AGG_FIRST = range(7)
-JOIN_INNER, JOIN_LEFT = range(2)
+JOIN_INNER, JOIN_LEFT, JOIN_SEMI, JOIN_ANTI = range(4)
 AE_COLUMN, AE_LITERAL, AE_BINARY, AE_CAST, AE_AGG, AE_LEN, AE_ALIAS, AE_NOT = range(8)
 (OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE, OP_PLUS, OP_MINUS, OP_MULTIPLY, OP_TRUE_DIVIDE,
  OP_FLOOR_DIVIDE, OP_MODULUS, OP_AND, OP_OR, OP_XOR) = range(15)
-IR_SCAN, IR_FILTER, IR_SELECT, IR_HSTACK, IR_GROUPBY, IR_JOIN = range(6)
+IR_SCAN, IR_FILTER, IR_SELECT, IR_HSTACK, IR_GROUPBY, IR_JOIN, IR_SORT, IR_SLICE = range(8)
 PLAN_NO_FUSION = 1
 PLAN_NO_DIRECT_JOIN = 2
 PLAN_NO_PARTITION = 4
@@ -71,7 +71,9 @@ class IR(C.Structure):
     _fields_ = [("kind", C.c_int32), ("input", C.c_int32), ("input_right", C.c_int32), ("predicate", C.c_int32),
                 ("frame", C.c_uint64), ("exprs", C.POINTER(C.c_int32)), ("n_exprs", C.c_int32),
                 ("keys", C.POINTER(C.c_int32)), ("n_keys", C.c_int32), ("keys_right", C.POINTER(C.c_int32)),
-                ("n_keys_right", C.c_int32), ("how", C.c_int32), ("maintain_order", C.c_int32), ("suffix", C.c_char_p)]
+                ("n_keys_right", C.c_int32), ("how", C.c_int32), ("maintain_order", C.c_int32), ("suffix", C.c_char_p),
+                ("sort_descending", C.POINTER(C.c_uint8)), ("sort_nulls_last", C.POINTER(C.c_uint8)), ("slice_offset", C.c_int64),
+                ("slice_len", C.c_int64)]
 
 
 class ProfileRecord(C.Structure):
@@ -132,6 +134,7 @@ SIGNATURES = {
     "plx_reduce": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(Scalar), _i32p, _i32p]),
     "plx_groupby_agg": (C.c_int, [_u64p, C.c_int32, _u64p, _i32p, C.c_int32, C.c_int32, _u64p, _u64p]),
     "plx_join_indices": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, _u64p, _u64p]),
+    "plx_sort_indices": (C.c_int, [_u64p, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int64, _u64p]),
     "plx_hash_partition": (C.c_int, [C.c_uint64, C.c_int32, C.c_uint64, _u64p, _i64p]),
     "plx_frame_new": (C.c_int, [C.POINTER(C.c_char_p), _u64p, C.c_int32, _u64p]),
     "plx_frame_free": (C.c_int, [C.c_uint64]),

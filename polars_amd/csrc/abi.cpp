@@ -12,6 +12,7 @@
 #include "join.hpp"
 #include "kernels.hpp"
 #include "ops.hpp"
+#include "sort.hpp"
 
 namespace plx {
 void init_device(int ordinal);
@@ -286,7 +287,23 @@ int plx_join_indices(plx_join_how how, plx_column left_key, plx_column right_key
   join::join_indices(how, get_column(left_key), get_column(right_key), li, ri, &d);
   t_plan_desc = d;
   *out_left_idx = register_column(li);
-  *out_right_idx = register_column(ri);
+  *out_right_idx = ri ? register_column(ri) : 0;
+  PLX_CATCH
+}
+
+int plx_sort_indices(const plx_column* by, int32_t n_by, const uint8_t* descending, const uint8_t* nulls_last, int64_t limit, plx_column* out_idx) {
+  PLX_TRY
+  PLX_REQUIRE(by && n_by > 0 && out_idx, PLX_ERR_INVALID, "sort_indices: need at least one key column");
+  std::vector<sort::SortKey> keys;
+  for (int i = 0; i < n_by; i++) {
+    sort::SortKey k;
+    k.col = get_column(by[i]); k.descending = descending && descending[i]; k.nulls_last = nulls_last && nulls_last[i];
+    keys.push_back(k);
+  }
+  std::string d;
+  ColumnPtr idx = sort::sort_indices(keys, limit, &d);
+  t_plan_desc = d;
+  *out_idx = register_column(idx);
   PLX_CATCH
 }
 

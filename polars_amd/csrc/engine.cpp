@@ -14,6 +14,7 @@
 #include "kernels.hpp"
 #include "kernels_fused.hpp"
 #include "ops.hpp"
+#include "sort.hpp"
 
 namespace plx {
 namespace engine {
@@ -46,6 +47,13 @@ Plan import_plan(const plx_ir* ir, int n_ir, const plx_aexpr* ae, int n_ae, uint
     for (int j = 0; j < ir[i].n_keys_right; j++) n.keys_right.push_back(ir[i].keys_right[j]);
     n.how = ir[i].how; n.maintain_order = ir[i].maintain_order;
     if (ir[i].suffix) n.suffix = ir[i].suffix;
+    if (n.kind == PLX_IR_SORT) {
+      for (int j = 0; j < ir[i].n_keys; j++) {
+        n.sort_descending.push_back(ir[i].sort_descending ? ir[i].sort_descending[j] : 0);
+        n.sort_nulls_last.push_back(ir[i].sort_nulls_last ? ir[i].sort_nulls_last[j] : 0);
+      }
+    }
+    n.slice_offset = ir[i].slice_offset; n.slice_len = ir[i].slice_len;
     auto chk = [&](int e) { PLX_REQUIRE(e >= 0 && e < n_ae, PLX_ERR_INVALID, "IR node references an expression outside the arena"); };
     for (int e : n.exprs) chk(e);
     for (int e : n.keys) chk(e);
@@ -1213,6 +1221,14 @@ static FramePtr exec_join(Plan& plan, const IRN& n) {
   ColumnPtr li, ri;
   std::string d;
   join::join_indices(n.how, lk, rk, li, ri, &d);
+  if (n.how == PLX_JOIN_SEMI || n.how == PLX_JOIN_ANTI) {
+    // left columns only, left order (single_keys_semi_anti.rs; _finish_join is not involved)
+    plan.desc += "Join{" + d + ", gather x" + std::to_string(left->cols.size()) + "}; ";
+    auto out = std::make_shared<Frame>();
+    out->height = li->len; out->names = left->names;
+    for (auto& c : left->cols) out->cols.push_back(ops::gather(c, li));
+    return out;
+  }
   plan.desc += "Join{" + d + ", gather x" + std::to_string(left->cols.size() + right->cols.size()) + "}; ";
   // _finish_join (polars-ops/src/frame/join/general.rs:17-49): left columns, then right columns
   // except the right key when it is a plain column coalesced into the left key; name clashes get the suffix.
@@ -1230,6 +1246,49 @@ static FramePtr exec_join(Plan& plan, const IRN& n) {
     out->names.push_back(name);
     out->cols.push_back(ops::gather(right->cols[i], ri));
   }
+  return out;
+}
+
+// IR::Sort (+ a Slice directly above it: only the first offset+len rows of the order are produced, top-k)
+static FramePtr exec_sort(Plan& plan, const IRN& n, int64_t limit) {
+  FramePtr in = exec_node(plan, n.input);
+  PLX_REQUIRE(!n.keys.empty(), PLX_ERR_INVALID, "sort needs at least one key");
+  std::vector<sort::SortKey> keys;
+  for (size_t j = 0; j < n.keys.size(); j++) {
+    sort::SortKey sk;
+    sk.col = broadcast(eval(plan, n.keys[j], *in, nullptr), in->height);
+    sk.descending = n.sort_descending.size() > j && n.sort_descending[j];
+    sk.nulls_last = n.sort_nulls_last.size() > j && n.sort_nulls_last[j];
+    keys.push_back(sk);
+  }
+  std::string d;
+  ColumnPtr idx = sort::sort_indices(keys, limit, &d);
+  auto out = std::make_shared<Frame>();
+  out->names = in->names; out->height = idx->len;
+  for (auto& c : in->cols) out->cols.push_back(ops::gather(c, idx));
+  plan.desc += "Sort{" + d + ", gather x" + std::to_string(in->cols.size()) + "}; ";
+  return out;
+}
+
+static FramePtr exec_slice(Plan& plan, const IRN& n) {
+  PLX_REQUIRE(n.slice_len >= 0, PLX_ERR_INVALID, "slice length must be non-negative");
+  FramePtr in;
+  const IRN* src = n.input >= 0 ? &plan.ir[n.input] : nullptr;
+  PLX_REQUIRE(src, PLX_ERR_INVALID, "slice without an input");
+  if (src->kind == PLX_IR_SORT && n.slice_offset >= 0 && n.slice_offset <= (int64_t)1 << 40 && n.slice_len <= (int64_t)1 << 40) {
+    check_cancel();
+    in = exec_sort(plan, *src, n.slice_offset + n.slice_len);
+  } else in = exec_node(plan, n.input);
+  // slice_offsets (polars-core/src/utils/mod.rs:340-358): negative offsets count from the end, both ends clamped
+  const int64_t h = in->height;
+  int64_t start = n.slice_offset < 0 ? n.slice_offset + h : n.slice_offset;
+  int64_t stop = start + n.slice_len;   // offsets are far below the i64 range here (h < 2^32, len checked by the caller)
+  start = std::min(std::max<int64_t>(start, 0), h); stop = std::min(std::max<int64_t>(stop, 0), h);
+  if (start == 0 && stop == h) { plan.desc += "Slice{no-op}; "; return in; }
+  auto out = std::make_shared<Frame>();
+  out->names = in->names; out->height = stop - start;
+  for (auto& c : in->cols) out->cols.push_back(ops::slice_copy(c, start, stop - start));
+  plan.desc += "Slice{" + std::to_string(start) + ", " + std::to_string(stop - start) + "}; ";
   return out;
 }
 
@@ -1275,6 +1334,8 @@ static FramePtr exec_node(Plan& plan, int node_id) {
       return exec_groupby_materialised(plan, n, in);
     }
     case PLX_IR_JOIN: return exec_join(plan, n);
+    case PLX_IR_SORT: return exec_sort(plan, n, -1);
+    case PLX_IR_SLICE: return exec_slice(plan, n);
     default: fail(PLX_ERR_UNSUPPORTED, "IR node kind " + std::to_string(n.kind) + " is outside the hot path (run it on the CPU engine)");
   }
 }

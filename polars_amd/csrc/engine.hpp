@@ -32,6 +32,8 @@ struct IRN {
   std::vector<int> exprs, keys, keys_right;
   int how = 0, maintain_order = 0;
   std::string suffix = "_right";
+  std::vector<uint8_t> sort_descending, sort_nulls_last;
+  int64_t slice_offset = 0, slice_len = 0;
 };
 struct Plan {
   std::vector<IRN> ir;

@@ -97,15 +97,22 @@ __global__ __launch_bounds__(kBlock) void join_build_kernel(KeyCol build, Table 
 }
 
 // counts[i] = number of build matches of probe row i (left join: at least 1)
-__global__ __launch_bounds__(kBlock) void join_count_kernel(KeyCol probe, Table t, int left_join, uint32_t* __restrict__ counts) {
+__global__ __launch_bounds__(kBlock) void join_count_kernel(KeyCol probe, Table t, int how, uint32_t* __restrict__ counts) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < probe.n; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t c = 0;
     if (key_valid(probe, i)) {
       const int64_t slot = find_slot(t, load_key(probe, i));
       if (slot >= 0) { for (unsigned int r = t.head[slot]; r != kNoRow; r = t.next[r]) c++; }
     }
-    counts[i] = (left_join && c == 0) ? 1u : c;
+    // how: 0 inner, 1 left (unmatched rows emit one pair), 2 semi (row kept once if matched), 3 anti (kept if unmatched; null keys never match)
+    counts[i] = how == 2 ? (c ? 1u : 0u) : how == 3 ? (c ? 0u : 1u) : (how == 1 && c == 0) ? 1u : c;
   }
+}
+
+// semi / anti: the kept probe rows, in probe order (single_keys_semi_anti.rs keeps left order the same way)
+__global__ __launch_bounds__(kBlock) void join_emit_kept_kernel(const uint32_t* __restrict__ counts, const uint64_t* __restrict__ offsets, int64_t n, uint32_t* __restrict__ out_probe) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (counts[i]) out_probe[offsets[i]] = (uint32_t)i;
 }
 
 __global__ __launch_bounds__(kBlock) void join_emit_kernel(KeyCol probe, Table t, int left_join, const uint64_t* __restrict__ offsets,
@@ -129,13 +136,14 @@ static int ceil_log2(uint64_t x) { int b = 0; while ((1ull << b) < x) b++; retur
 void join_indices(int how, const ColumnPtr& left_key, const ColumnPtr& right_key, ColumnPtr& left_idx, ColumnPtr& right_idx, std::string* desc) {
   PLX_REQUIRE(left_key->dtype == right_key->dtype, PLX_ERR_INVALID,
               std::string("join keys have different dtypes (") + dtype_name(left_key->dtype) + ", " + dtype_name(right_key->dtype) + ")");
-  PLX_REQUIRE(how == PLX_JOIN_INNER || how == PLX_JOIN_LEFT, PLX_ERR_UNSUPPORTED, "join type outside the hot path");
+  PLX_REQUIRE(how == PLX_JOIN_INNER || how == PLX_JOIN_LEFT || how == PLX_JOIN_SEMI || how == PLX_JOIN_ANTI, PLX_ERR_UNSUPPORTED, "join type outside the hot path");
   PLX_REQUIRE(left_key->len < 0xffffffffll && right_key->len < 0xffffffffll, PLX_ERR_UNSUPPORTED, "join side exceeds u32 IdxSize");
   const bool left_join = how == PLX_JOIN_LEFT;
-  // det_hash_prone_order (hash_join/mod.rs:41-50): build on the shorter relation; left join builds on the right
-  const bool swapped = !left_join && !(left_key->len > right_key->len);
-  const ColumnPtr& probe = left_join ? left_key : (swapped ? right_key : left_key);
-  const ColumnPtr& build = left_join ? right_key : (swapped ? left_key : right_key);
+  const bool semi_anti = how == PLX_JOIN_SEMI || how == PLX_JOIN_ANTI;
+  // det_hash_prone_order (hash_join/mod.rs:41-50): build on the shorter relation; left / semi / anti joins build on the right
+  const bool swapped = !left_join && !semi_anti && !(left_key->len > right_key->len);
+  const ColumnPtr& probe = (left_join || semi_anti) ? left_key : (swapped ? right_key : left_key);
+  const ColumnPtr& build = (left_join || semi_anti) ? right_key : (swapped ? left_key : right_key);
   const int log2_cap = std::max(4, ceil_log2((uint64_t)std::max<int64_t>(build->len, 1) * 2));
   const uint64_t cap = 1ull << log2_cap;
   Buf keys = dev_alloc(sizeof(uint64_t) * (cap + 1));
@@ -156,13 +164,25 @@ void join_indices(int how, const ColumnPtr& left_key, const ColumnPtr& right_key
   Buf offsets = dev_alloc(sizeof(uint64_t) * (size_t)(np + 1));
   if (np) {
     ProfileScope ps("join_probe_count", (uint64_t)np * (kw + 4), (uint64_t)np);
-    hipLaunchKernelGGL(join_count_kernel, dim3(k::grid_for(np, kBlock * 2)), dim3(kBlock), 0, stream(), key_col(probe), t, left_join ? 1 : 0, counts->as<uint32_t>());
+    hipLaunchKernelGGL(join_count_kernel, dim3(k::grid_for(np, kBlock * 2)), dim3(kBlock), 0, stream(), key_col(probe), t, how, counts->as<uint32_t>());
     PLX_HIP(hipGetLastError());
   }
   k::exclusive_scan_u32(counts->as<uint32_t>(), offsets->as<uint64_t>(), np);
   uint64_t total = 0;
   d2h_sync(&total, offsets->as<uint64_t>() + np, 8);
   auto mk_idx = [&](int64_t n) { auto c = std::make_shared<Column>(); c->dtype = PLX_U32; c->len = n; c->values = dev_alloc(values_bytes(PLX_U32, n)); c->null_count = 0; return c; };
+  if (semi_anti) {
+    ColumnPtr kept = mk_idx((int64_t)total);
+    if (total) {
+      ProfileScope ps("join_emit_kept", (uint64_t)np * 12 + total * 4, (uint64_t)np);
+      hipLaunchKernelGGL(join_emit_kept_kernel, dim3(k::grid_for(np, kBlock * 2)), dim3(kBlock), 0, stream(), counts->as<uint32_t>(), offsets->as<uint64_t>(), np, kept->values->as<uint32_t>());
+      PLX_HIP(hipGetLastError());
+    }
+    if (desc) *desc = std::string(how == PLX_JOIN_SEMI ? "hash_semi_join" : "hash_anti_join") + "[build=right rows=" + std::to_string(build->len) + " cap=2^" + std::to_string(log2_cap) +
+                      ", probe rows=" + std::to_string(np) + ", kept=" + std::to_string(total) + "]";
+    left_idx = kept; right_idx = nullptr;
+    return;
+  }
   ColumnPtr pidx = mk_idx((int64_t)total), bidx = mk_idx((int64_t)total);
   if (total) {
     ProfileScope ps("join_probe_emit", (uint64_t)np * (kw + 8) + total * 8, (uint64_t)np);

@@ -1,0 +1,334 @@
+// kernels_sort.hip -- stable multi-key arg-sort (LSD radix) and top-k selection (MSD radix select).
+//
+// Reference behaviour (restated, not ported): arg_sort_multiple compares row-encoded keys with a stable
+// comparison sort on the CPU thread pool (polars-core/src/chunked_array/ops/sort/arg_sort_multiple.rs,
+// arg_sort.rs); sort followed by a slice keeps only the first rows (slice_pushdown_lp.rs -> SortExec slice /
+// streaming top_k.rs).  GPU shape:
+//   encode : every key column is turned into an order-preserving u64 (sign flip for ints, the IEEE total-order
+//            flip for floats with NaN canonicalised to the greatest value and -0 -> +0, bitwise NOT for
+//            descending) read THROUGH the current permutation, so narrow dtypes are never widened in HBM twice.
+//   rounds : keys are processed last to first (LSD over keys); within a key, 8-bit digits least significant
+//            first.  One pass over the encoded keys builds all 8 digit histograms; digits on which every row
+//            agrees are skipped (an i32-range key costs 4 passes, a dictionary code 1-3).
+//   pass   : per-workgroup digit histogram -> device exclusive scan (digit-major) -> stable scatter.  The scatter
+//            ranks the 256 keys of a sub-tile with wave64 ballots (8 ballots = match-any on the digit), per-wave
+//            digit counts meet in LDS, so ties keep input order without any atomics.
+//   nulls  : one extra 1-bit pass per nullable key (null rank is an absolute position: nulls_last is not flipped
+//            by `descending`, arg_sort.rs).
+//   top-k  : `limit` << n: MSD radix select on the first key finds the smallest prefix bucket that contains the
+//            limit-th row; rows at or below it (ties included) are compacted in row order and only those are
+//            sorted -- same result as the full stable sort followed by head(limit).
+// Everything is HBM-streaming integer work: 12 B read + 12 B written per row and pass.
+#include <algorithm>
+
+#include "dev.hpp"
+#include "kernels.hpp"
+#include "ops.hpp"
+#include "scan.hpp"
+#include "sort.hpp"
+
+namespace plx {
+namespace sort {
+
+using namespace dev;
+using k::kBlock;
+
+constexpr int kItems = 16;                 // sub-tiles of kBlock keys per workgroup
+constexpr int kTile = kBlock * kItems;     // 4096 keys per workgroup and pass
+constexpr int kWaves = kBlock / kWave;
+
+struct KeyCol {
+  const void* values;
+  const uint64_t* validity;
+  int dtype;
+};
+
+enum EncodeMode { ENC_VALUE = 0, ENC_NULL_RANK = 1, ENC_SELECT = 2 };
+
+__device__ __forceinline__ uint64_t flip_f64(double d) {
+  const uint64_t b = (d != d) ? 0x7ff8000000000000ull : (uint64_t)__double_as_longlong(d + 0.0);   // one NaN, -0 -> +0
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ uint64_t encode_value(const KeyCol& kc, int64_t r) {
+  constexpr uint64_t kSign = 0x8000000000000000ull;
+  switch (kc.dtype) {
+    case PLX_I8: return (uint64_t)(long long)reinterpret_cast<const int8_t*>(kc.values)[r] ^ kSign;
+    case PLX_I16: return (uint64_t)(long long)reinterpret_cast<const int16_t*>(kc.values)[r] ^ kSign;
+    case PLX_I32: return (uint64_t)(long long)reinterpret_cast<const int32_t*>(kc.values)[r] ^ kSign;
+    case PLX_I64: return reinterpret_cast<const uint64_t*>(kc.values)[r] ^ kSign;
+    case PLX_U8: return reinterpret_cast<const uint8_t*>(kc.values)[r];
+    case PLX_U16: return reinterpret_cast<const uint16_t*>(kc.values)[r];
+    case PLX_U32: return reinterpret_cast<const uint32_t*>(kc.values)[r];
+    case PLX_F32: return flip_f64((double)reinterpret_cast<const float*>(kc.values)[r]);
+    case PLX_F64: return flip_f64(reinterpret_cast<const double*>(kc.values)[r]);
+    case PLX_BOOL: return (reinterpret_cast<const uint64_t*>(kc.values)[r >> 6] >> (r & 63)) & 1;
+    default: return reinterpret_cast<const uint64_t*>(kc.values)[r];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void encode_kernel(KeyCol kc, const uint32_t* __restrict__ perm, int64_t n, int descending, int nulls_last, int mode,
+                                                        uint64_t* __restrict__ enc) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = perm ? (int64_t)perm[i] : i;
+    const bool valid = !kc.validity || ((kc.validity[r >> 6] >> (r & 63)) & 1);
+    uint64_t e;
+    if (mode == ENC_NULL_RANK) e = (valid == (nulls_last != 0)) ? 0ull : 1ull;   // nulls_last: valid rows rank 0; nulls first: nulls rank 0
+    else if (!valid) e = (mode == ENC_SELECT && nulls_last) ? ~0ull : 0ull;       // all nulls tie within a key
+    else { e = encode_value(kc, r); if (descending) e = ~e; }
+    enc[i] = e;
+  }
+}
+
+// hist[d * 256 + v] = rows whose digit d (bits 8d..8d+7) equals v
+__global__ __launch_bounds__(kBlock) void digit_hist_kernel(const uint64_t* __restrict__ enc, int64_t n, unsigned int* __restrict__ hist) {
+  __shared__ unsigned int h[8 * 256];
+  for (int j = threadIdx.x; j < 8 * 256; j += kBlock) h[j] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t e = enc[i];
+#pragma unroll
+    for (int d = 0; d < 8; d++) atomicAdd(&h[d * 256 + (int)((e >> (8 * d)) & 255)], 1u);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 8 * 256; j += kBlock) if (h[j]) atomicAdd(&hist[j], h[j]);
+}
+
+// block_hist[v * nblocks + b] = keys of tile b with digit v
+__global__ __launch_bounds__(kBlock) void radix_count_kernel(const uint64_t* __restrict__ enc, int64_t n, int shift, unsigned int* __restrict__ block_hist, uint32_t nblocks) {
+  __shared__ unsigned int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+#pragma unroll 4
+  for (int r = 0; r < kItems; r++) {
+    const int64_t i = base + (int64_t)r * kBlock + threadIdx.x;
+    if (i < n) atomicAdd(&h[(int)((enc[i] >> shift) & 255)], 1u);
+  }
+  __syncthreads();
+  block_hist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint64_t* __restrict__ enc_in, const uint32_t* __restrict__ idx_in, int64_t n, int shift,
+                                                               const uint64_t* __restrict__ offsets, uint32_t nblocks, uint64_t* __restrict__ enc_out,
+                                                               uint32_t* __restrict__ idx_out) {
+  __shared__ uint64_t running[256];            // next output slot of every digit value for this tile
+  __shared__ unsigned int wave_cnt[kWaves][256];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+  running[tid] = offsets[(uint64_t)tid * nblocks + blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) wave_cnt[w][tid] = 0;
+  __syncthreads();
+  for (int r = 0; r < kItems; r++) {
+    const int64_t i = base + (int64_t)r * kBlock + tid;
+    if (base + (int64_t)r * kBlock >= n) break;   // uniform
+    const bool valid = i < n;
+    const uint64_t e = valid ? enc_in[i] : 0ull;
+    const uint32_t idx = valid ? (idx_in ? idx_in[i] : (uint32_t)i) : 0u;
+    const uint32_t d = (uint32_t)((e >> shift) & 255);
+    uint64_t same = ballot(valid);               // lanes of this wave holding the same digit
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const bool bit = (d >> b) & 1;
+      const uint64_t bal = ballot(bit);
+      same &= bit ? bal : ~bal;
+    }
+    const uint32_t rank = (uint32_t)prefix_rank(same);
+    if (valid && rank == 0) wave_cnt[wave][d] = (uint32_t)popc64(same);
+    __syncthreads();
+    uint64_t pos = 0;
+    if (valid) {
+      uint32_t before = 0;
+      for (int w = 0; w < wave; w++) before += wave_cnt[w][d];
+      pos = running[d] + before + rank;
+    }
+    __syncthreads();
+    {
+      uint32_t tot = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; w++) { tot += wave_cnt[w][tid]; wave_cnt[w][tid] = 0; }
+      running[tid] += tot;
+    }
+    if (valid) { enc_out[pos] = e; idx_out[pos] = idx; }
+    __syncthreads();
+  }
+}
+
+// top-k: histogram of the digit at `shift` among rows whose higher bits equal `prefix`
+__global__ __launch_bounds__(kBlock) void select_hist_kernel(const uint64_t* __restrict__ enc, int64_t n, int shift, uint64_t prefix, int have_prefix,
+                                                             unsigned int* __restrict__ hist) {
+  __shared__ unsigned int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t e = enc[i];
+    if (!have_prefix || (e >> (shift + 8)) == prefix) atomicAdd(&h[(int)((e >> shift) & 255)], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// mask bit i = (enc[i] >> shift) <= bound
+__global__ __launch_bounds__(kBlock) void select_mask_kernel(const uint64_t* __restrict__ enc, int64_t n, int shift, uint64_t bound, uint64_t* __restrict__ mask) {
+  const int64_t n_round = (n + 63) & ~63ll;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool keep = i < n && (enc[i] >> shift) <= bound;
+    const uint64_t m = ballot(keep);
+    if ((threadIdx.x & 63) == 0) mask[i >> 6] = m;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- host side ---
+static KeyCol key_col(const ColumnPtr& c) { KeyCol kc; kc.values = c->data(); kc.validity = c->valid_words(); kc.dtype = c->dtype; return kc; }
+
+struct Work {
+  int64_t m = 0;                 // rows being sorted
+  Buf enc[2], idx[2];            // ping-pong buffers
+  int cur = 0;                   // idx[cur] holds the current permutation (when have_perm)
+  bool have_perm = false;        // false: identity
+  Buf hist, block_hist, offsets;
+  uint32_t nblocks = 0;
+  int passes = 0, skipped = 0;
+};
+
+static void encode(const SortKey& key, const uint32_t* perm, int64_t m, int mode, uint64_t* out) {
+  if (!m) return;
+  ProfileScope ps("sort_encode", (uint64_t)m * ((dtype_width(key.col->dtype) ? dtype_width(key.col->dtype) : 1) + 8 + (perm ? 4 : 0)), (uint64_t)m);
+  hipLaunchKernelGGL(encode_kernel, dim3(k::grid_for(m, kBlock * 4)), dim3(kBlock), 0, stream(), key_col(key.col), perm, m, key.descending ? 1 : 0,
+                     key.nulls_last ? 1 : 0, mode, out);
+  PLX_HIP(hipGetLastError());
+}
+
+static void radix_pass(Work& w, int shift) {
+  const int64_t m = w.m;
+  {
+    ProfileScope ps("sort_radix_count", (uint64_t)m * 8, (uint64_t)m);
+    hipLaunchKernelGGL(radix_count_kernel, dim3(w.nblocks), dim3(kBlock), 0, stream(), w.enc[w.cur]->as<uint64_t>(), m, shift, w.block_hist->as<unsigned int>(), w.nblocks);
+    PLX_HIP(hipGetLastError());
+  }
+  k::exclusive_scan_u32(w.block_hist->as<uint32_t>(), w.offsets->as<uint64_t>(), (int64_t)w.nblocks * 256);
+  {
+    ProfileScope ps("sort_radix_scatter", (uint64_t)m * 24, (uint64_t)m);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(w.nblocks), dim3(kBlock), 0, stream(), w.enc[w.cur]->as<uint64_t>(),
+                       w.have_perm ? w.idx[w.cur]->as<uint32_t>() : (const uint32_t*)nullptr, m, shift, w.offsets->as<uint64_t>(), w.nblocks,
+                       w.enc[w.cur ^ 1]->as<uint64_t>(), w.idx[w.cur ^ 1]->as<uint32_t>());
+    PLX_HIP(hipGetLastError());
+  }
+  w.cur ^= 1;
+  w.have_perm = true;
+  w.passes++;
+}
+
+// stable sort of the current permutation by the digits of enc[cur] on which rows differ (max_digits least significant digits)
+static void sort_encoded(Work& w, int max_digits) {
+  PLX_HIP(hipMemsetAsync(w.hist->ptr, 0, 8 * 256 * sizeof(unsigned int), stream()));
+  hipLaunchKernelGGL(digit_hist_kernel, dim3(k::grid_for(w.m, kBlock * 8, 4)), dim3(kBlock), 0, stream(), w.enc[w.cur]->as<uint64_t>(), w.m, w.hist->as<unsigned int>());
+  PLX_HIP(hipGetLastError());
+  std::vector<unsigned int> h(8 * 256);
+  d2h_sync(h.data(), w.hist->ptr, h.size() * sizeof(unsigned int));
+  for (int d = 0; d < max_digits; d++) {
+    bool uniform = false;
+    for (int v = 0; v < 256; v++) if ((int64_t)h[d * 256 + v] == w.m) { uniform = true; break; }
+    if (uniform) { w.skipped++; continue; }
+    // the next pass reads enc[cur]; enc must travel with the permutation, which radix_pass does
+    radix_pass(w, 8 * d);
+  }
+}
+
+static void sort_by_key(Work& w, const SortKey& key) {
+  const uint32_t* perm = w.have_perm ? w.idx[w.cur]->as<uint32_t>() : nullptr;
+  encode(key, perm, w.m, ENC_VALUE, w.enc[w.cur]->as<uint64_t>());
+  const int wd = dtype_width(key.col->dtype);
+  // unsigned / bool keys only populate their own width; signed and float keys use all 8 bytes (the histogram skips the uniform ones)
+  const int digits = key.descending ? 8 : (key.col->dtype == PLX_BOOL ? 1 : (dtype_is_unsigned(key.col->dtype) ? wd : 8));
+  sort_encoded(w, digits);
+  if (key.col->validity && column_null_count(key.col) > 0) {
+    perm = w.have_perm ? w.idx[w.cur]->as<uint32_t>() : nullptr;
+    encode(key, perm, w.m, ENC_NULL_RANK, w.enc[w.cur]->as<uint64_t>());
+    sort_encoded(w, 1);
+  }
+}
+
+static void init_work(Work& w, int64_t m, Buf initial_perm) {
+  w.m = m;
+  const size_t m1 = (size_t)std::max<int64_t>(m, 1);
+  for (int i = 0; i < 2; i++) { w.enc[i] = dev_alloc(m1 * 8); w.idx[i] = dev_alloc(m1 * 4); }
+  if (initial_perm) { w.idx[0] = initial_perm; w.have_perm = true; }
+  w.nblocks = (uint32_t)((m + kTile - 1) / kTile);
+  if (!w.nblocks) w.nblocks = 1;
+  w.hist = dev_alloc(8 * 256 * sizeof(unsigned int));
+  w.block_hist = dev_alloc((size_t)w.nblocks * 256 * sizeof(unsigned int));
+  w.offsets = dev_alloc(((size_t)w.nblocks * 256 + 1) * sizeof(uint64_t));
+}
+
+static ColumnPtr make_idx(int64_t n) {
+  auto c = std::make_shared<Column>();
+  c->dtype = PLX_U32; c->len = n; c->values = dev_alloc(values_bytes(PLX_U32, std::max<int64_t>(n, 1))); c->null_count = 0;
+  return c;
+}
+
+ColumnPtr sort_indices(const std::vector<SortKey>& keys, int64_t limit, std::string* desc) {
+  PLX_REQUIRE(!keys.empty(), PLX_ERR_INVALID, "sort needs at least one key");
+  const int64_t n = keys[0].col->len;
+  for (auto& kx : keys) PLX_REQUIRE(kx.col->len == n, PLX_ERR_SHAPE, "sort: key columns have different lengths");
+  PLX_REQUIRE(n < 0xffffffffll, PLX_ERR_UNSUPPORTED, "sort: more rows than u32 IdxSize");
+  const int64_t n_out = limit < 0 ? n : std::min(limit, n);
+  ColumnPtr out = make_idx(n_out);
+  if (n_out == 0) { if (desc) *desc = "sort[empty]"; return out; }
+  std::string d;
+  Buf cand;            // candidate rows of the top-k selection (row order)
+  int64_t m = n;
+  if (limit >= 0 && limit < n / 4 && n > 65536) {
+    // ---- MSD radix select on the first key: smallest prefix bucket holding the limit-th row
+    Buf enc0 = dev_alloc((size_t)n * 8);
+    encode(keys[0], nullptr, n, ENC_SELECT, enc0->as<uint64_t>());
+    Buf hist = dev_alloc(256 * sizeof(unsigned int));
+    std::vector<unsigned int> h(256);
+    uint64_t prefix = 0, need = (uint64_t)limit, below = 0, cand_rows = (uint64_t)n;
+    int shift = 56, rounds = 0;
+    bool have = false;
+    const uint64_t good_enough = std::max<uint64_t>(4 * (uint64_t)limit, 65536);
+    for (;; shift -= 8) {
+      PLX_HIP(hipMemsetAsync(hist->ptr, 0, 256 * sizeof(unsigned int), stream()));
+      {
+        ProfileScope ps("topk_select_hist", (uint64_t)n * 8, (uint64_t)n);
+        hipLaunchKernelGGL(select_hist_kernel, dim3(k::grid_for(n, kBlock * 8, 4)), dim3(kBlock), 0, stream(), enc0->as<uint64_t>(), n, shift, prefix, have ? 1 : 0, hist->as<unsigned int>());
+        PLX_HIP(hipGetLastError());
+      }
+      d2h_sync(h.data(), hist->ptr, 256 * sizeof(unsigned int));
+      rounds++;
+      uint64_t c = 0; int b = 0;
+      for (; b < 255; b++) { if (c + h[b] >= need) break; c += h[b]; }
+      below += c; need -= c;
+      prefix = (prefix << 8) | (uint64_t)b; have = true;
+      cand_rows = below + h[b];
+      if (cand_rows <= good_enough || shift == 0) break;
+    }
+    if (cand_rows < (uint64_t)n / 2) {
+      Buf mask = dev_alloc(bitmap_bytes(n));
+      {
+        ProfileScope ps("topk_select_mask", (uint64_t)n * 8 + (uint64_t)n / 8, (uint64_t)n);
+        hipLaunchKernelGGL(select_mask_kernel, dim3(k::grid_for(n, kBlock * 8, 4)), dim3(kBlock), 0, stream(), enc0->as<uint64_t>(), n, shift, prefix, mask->as<uint64_t>());
+        PLX_HIP(hipGetLastError());
+      }
+      k::FilterPlan fp = k::filter_prepare(mask->as<uint64_t>(), n);
+      PLX_REQUIRE((uint64_t)fp.n_out == cand_rows, PLX_ERR_INVALID, "top-k: candidate count mismatch");
+      Buf iota = dev_alloc((size_t)n * 4);
+      k::fill_iota_u32(iota->as<uint32_t>(), n);
+      cand = dev_alloc((size_t)std::max<int64_t>(fp.n_out, 1) * 4);
+      k::filter_apply(fp, 4, iota->ptr, nullptr, cand->ptr, nullptr);
+      m = fp.n_out;
+      d += "top_k_select[" + std::to_string(rounds) + " digit rounds, candidates=" + std::to_string(m) + "] -> ";
+    }
+  }
+  Work w;
+  init_work(w, m, cand);
+  for (size_t j = keys.size(); j-- > 0;) sort_by_key(w, keys[j]);
+  if (w.have_perm) PLX_HIP(hipMemcpyAsync(out->values->ptr, w.idx[w.cur]->ptr, (size_t)n_out * 4, hipMemcpyDeviceToDevice, stream()));
+  else k::fill_iota_u32(out->values->as<uint32_t>(), n_out);   // every digit of every key was uniform
+  d += "radix_sort[rows=" + std::to_string(m) + ", keys=" + std::to_string(keys.size()) + ", passes=" + std::to_string(w.passes) + ", uniform digits skipped=" + std::to_string(w.skipped) + "]";
+  if (desc) *desc = d;
+  return out;
+}
+
+}  // namespace sort
+}  // namespace plx

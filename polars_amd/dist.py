@@ -204,3 +204,91 @@ def groupby_agg(ops: LocalOps, keys: Dict[str, object], values: Dict[str, object
         else:
             res[out] = part[f"{out}__p0"]
     return res
+
+
+def allgather_columns(cols: Dict[str, object], group=None) -> Dict[str, object]:
+    """Replicate a (small) frame on every rank: one variable-length all-gather per column."""
+    return {k: allgather_concat(v, group) for k, v in cols.items()}
+
+
+def join_groupby(ops: LocalOps, probe: Dict[str, object], build: Dict[str, object], probe_key: str, build_key: str, local_fn,
+                 merge: Sequence[Tuple[str, str]], result_key: str, *, mode: str = "auto", build_bytes_limit: int = 2 << 30,
+                 build_prefilter=None, probe_prefilter=None, group=None) -> Dict[str, object]:
+    """Sharded `probe JOIN build ON key -> GROUP BY (key, build columns) -> aggregates` (TPC-H Q3 shape).
+
+    Every rank holds a row shard of both inputs.  `local_fn(probe_cols, build_cols) -> {column: tensor}` runs the
+    single-GPU fused pipeline on what the rank holds after the exchange and returns per-group partial rows; `merge`
+    lists (column, "sum" | "min" | "max") for the partial aggregates, the remaining columns are group attributes
+    (functionally determined by `result_key`).
+
+    mode "broadcast": the build side is all-gathered (it is the small relation: filtered TPC-H orders at SF100 is
+                      ~0.35 GB), the probe side never moves; rows of one key may sit on several ranks, so the partial
+                      groups are merged by key with one small all-to-all.
+    mode "shuffle"  : both sides are routed by key hash with one all-to-all per input (grace hash join); every key is
+                      then owned by one rank and the local result is final.
+    mode "auto"     : broadcast when the global build side is below `build_bytes_limit`.
+    `build_prefilter` / `probe_prefilter` (cols -> cols) are the single-input predicates pushed below the exchange, so
+    only surviving rows cross xGMI (the reference pushes them below the join the same way, predicate_pushdown/mod.rs).
+    The result stays sharded by key (disjoint key sets across ranks)."""
+    import torch
+    import torch.distributed as dist
+    distributed = dist.is_initialized() and dist.get_world_size(group) > 1
+    if not distributed:
+        return local_fn(probe, build)
+    if build_prefilter is not None:
+        build = build_prefilter(build)
+    if mode == "auto":
+        local_bytes = sum(int(t.numel()) * t.element_size() for t in build.values())
+        tot = torch.tensor([local_bytes], dtype=torch.int64, device=next(iter(build.values())).device)
+        dist.all_reduce(tot, group=group)
+        mode = "broadcast" if int(tot.item()) <= build_bytes_limit else "shuffle"
+    if mode == "shuffle":
+        if probe_prefilter is not None:
+            probe = probe_prefilter(probe)
+        probe2 = exchange_by_key(ops, probe[probe_key], probe, group=group)
+        build2 = exchange_by_key(ops, build[build_key], build, group=group)
+        return local_fn(probe2, build2)
+    # broadcast
+    part = local_fn(probe, allgather_columns(build, group))
+    moved = exchange_by_key(ops, part[result_key], part, group=group)
+    # merge partial groups of equal key with the local group-by operator; the attribute columns are functionally
+    # determined by the key, so grouping by (key, attributes) yields one row per key
+    merge_ops = dict(merge)
+    keys = {n: t for n, t in moved.items() if n not in merge_ops}
+    vals = {n: t for n, t in moved.items() if n in merge_ops}
+    if result_key not in keys:
+        raise ValueError("result_key must not be one of the merged aggregates")
+    return ops.groupby_partial(keys, vals, [(n, n, op) for n, op in merge])
+
+
+class Q3Local:
+    """The per-rank pieces of sharded TPC-H Q3 on libpolars_amd (device tensors in/out): the orders predicate pushed
+    below the exchange and the fused filter -> join -> group-by pipeline (polars_amd/queries.py q3)."""
+
+    def __init__(self, pl):
+        from . import datagen, queries
+        self.pl, self.datagen, self.queries = pl, datagen, queries
+        self.ops = HipLocalOps(pl)
+
+    @staticmethod
+    def _cols(df):
+        return {n: df[n].to_torch() for n in df.columns}
+
+    def build_prefilter(self, bc):
+        pl, c = self.pl, self.pl.col
+        f = self.datagen.frame_from_torch(pl, bc, self.datagen.ORDERS_Q3_COLS)
+        return self._cols(f.lazy().filter((c("o_orderdate") < self.queries.Q3_DATE) & ((c("o_custkey") % 5) == 0)).collect())
+
+    def probe_prefilter(self, pc):
+        pl, c = self.pl, self.pl.col
+        f = self.datagen.frame_from_torch(pl, pc, self.datagen.LINEITEM_Q3_COLS)
+        return self._cols(f.lazy().filter(c("l_shipdate") > self.queries.Q3_DATE).collect())
+
+    def local(self, pc, bc):
+        L = self.datagen.frame_from_torch(self.pl, pc, self.datagen.LINEITEM_Q3_COLS)
+        O = self.datagen.frame_from_torch(self.pl, bc, self.datagen.ORDERS_Q3_COLS)
+        return self._cols(self.queries.q3(L.lazy(), O.lazy()).collect())
+
+    def run(self, lineitem, orders, mode: str = "broadcast", group=None):
+        return join_groupby(self.ops, lineitem, orders, "l_orderkey", "o_orderkey", self.local, [("revenue", "sum")], "l_orderkey", mode=mode,
+                            build_prefilter=self.build_prefilter, probe_prefilter=self.probe_prefilter, group=group)

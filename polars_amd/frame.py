@@ -244,6 +244,24 @@ class Series:
         F.check(F.lib().plx_gather(self._h, idx._h, C.byref(h)))
         return Series._from_handle(self.name, h.value, self.dtype)
 
+    def arg_sort(self, *, descending: bool = False, nulls_last: bool = False, limit: int = -1) -> "Series":
+        """Stable arg-sort (Series.arg_sort); limit >= 0 keeps the first `limit` indices (top-k selection)."""
+        F.ensure_init()
+        h = C.c_uint64()
+        by = (C.c_uint64 * 1)(self._h)
+        d, nl = (C.c_uint8 * 1)(int(descending)), (C.c_uint8 * 1)(int(nulls_last))
+        F.check(F.lib().plx_sort_indices(by, 1, d, nl, int(limit), C.byref(h)))
+        return Series._from_handle(self.name, h.value, T.UInt32)
+
+    def sort(self, *, descending: bool = False, nulls_last: bool = False) -> "Series":
+        return self.gather(self.arg_sort(descending=descending, nulls_last=nulls_last))
+
+    def top_k(self, k: int = 5) -> "Series":
+        return self.gather(self.arg_sort(descending=True, nulls_last=True, limit=k))
+
+    def bottom_k(self, k: int = 5) -> "Series":
+        return self.gather(self.arg_sort(descending=False, nulls_last=True, limit=k))
+
     def _reduce(self, op: int):
         v, dt, ok = F.Scalar(), C.c_int32(), C.c_int32()
         F.check(F.lib().plx_reduce(op, self._h, C.byref(v), C.byref(dt), C.byref(ok)))
@@ -271,6 +289,17 @@ class Series:
 
     def __repr__(self) -> str:
         return f"Series({self.name!r}, {self.dtype}, len={len(self)})"
+
+
+def arg_sort_by(by: Sequence["Series"], descending=False, nulls_last=False, limit: int = -1) -> "Series":
+    """pl.arg_sort_by over device columns: stable multi-key arg-sort through plx_sort_indices (limit >= 0: top-k)."""
+    F.ensure_init()
+    n = len(by)
+    d, nl = _per_key(descending, n, "descending", "exprs"), _per_key(nulls_last, n, "nulls_last", "exprs")
+    h = C.c_uint64()
+    F.check(F.lib().plx_sort_indices((C.c_uint64 * n)(*[s._h for s in by]), n, (C.c_uint8 * n)(*map(int, d)), (C.c_uint8 * n)(*map(int, nl)),
+                                     int(limit), C.byref(h)))
+    return Series._from_handle(by[0].name, h.value, T.UInt32)
 
 
 def _upload(values: Any, dtype: Optional[T.DataType], validity: Any):
@@ -432,6 +461,24 @@ class DataFrame:
     def join(self, other: "DataFrame", on=None, how: str = "inner", left_on=None, right_on=None, suffix: str = "_right") -> "DataFrame":
         return self.lazy().join(other.lazy(), on=on, how=how, left_on=left_on, right_on=right_on, suffix=suffix).collect()
 
+    def sort(self, by, *more_by, descending=False, nulls_last=False, maintain_order: bool = False) -> "DataFrame":
+        return self.lazy().sort(by, *more_by, descending=descending, nulls_last=nulls_last, maintain_order=maintain_order).collect()
+
+    def slice(self, offset: int, length: Optional[int] = None) -> "DataFrame":
+        return self.lazy().slice(offset, length).collect()
+
+    def head(self, n: int = 5) -> "DataFrame":
+        return self.lazy().head(n).collect()
+
+    def tail(self, n: int = 5) -> "DataFrame":
+        return self.lazy().tail(n).collect()
+
+    def top_k(self, k: int, *, by, reverse=False) -> "DataFrame":
+        return self.lazy().top_k(k, by=by, reverse=reverse).collect()
+
+    def bottom_k(self, k: int, *, by, reverse=False) -> "DataFrame":
+        return self.lazy().bottom_k(k, by=by, reverse=reverse).collect()
+
     # -- host export --------------------------------------------------------------------------------
     def _download_all(self):
         """[(values, validity or None)] for every column with ONE device synchronisation
@@ -506,6 +553,14 @@ def _as_exprs(items: Iterable[Any]) -> List[Expr]:
     return out
 
 
+def _per_key(flag, n: int, what: str, keys_name: str) -> List[bool]:
+    if isinstance(flag, (list, tuple)):
+        if len(flag) != n:
+            raise ValueError(f"the length of `{what}` ({len(flag)}) does not match the length of `{keys_name}` ({n})")
+        return [bool(x) for x in flag]
+    return [bool(flag)] * n
+
+
 class LazyFrame:
     def __init__(self, node: P.Node):
         self._node = node
@@ -529,6 +584,39 @@ class LazyFrame:
             left_on = right_on = on
         lo, ro = _as_exprs([left_on]), _as_exprs([right_on])
         return LazyFrame(P.Node("join", left=self._node, right=other._node, left_on=lo, right_on=ro, how=how, suffix=suffix))
+
+    def sort(self, by, *more_by, descending=False, nulls_last=False, maintain_order: bool = False) -> "LazyFrame":
+        """LazyFrame.sort (py-polars lazyframe/frame.py sort): `descending` / `nulls_last` are one flag or one per key.
+        The GPU sort is always stable, which satisfies maintain_order either way."""
+        keys = _as_exprs([by, *more_by])
+        return LazyFrame(P.Node("sort", input=self._node, by=keys, descending=_per_key(descending, len(keys), "descending", "by"),
+                                nulls_last=_per_key(nulls_last, len(keys), "nulls_last", "by"), maintain_order=maintain_order))
+
+    def slice(self, offset: int, length: Optional[int] = None) -> "LazyFrame":
+        if length is not None and length < 0:
+            raise ValueError(f"negative slice lengths ({length!r}) are invalid for LazyFrame")
+        return LazyFrame(P.Node("slice", input=self._node, offset=int(offset), length=(1 << 40) if length is None else int(length)))
+
+    def head(self, n: int = 5) -> "LazyFrame":
+        return self.slice(0, n)
+
+    def limit(self, n: int = 5) -> "LazyFrame":
+        return self.head(n)
+
+    def tail(self, n: int = 5) -> "LazyFrame":
+        return self.slice(-n, n)
+
+    def top_k(self, k: int, *, by, reverse=False) -> "LazyFrame":
+        """The k largest rows by `by` (nulls are the smallest), as sort(descending).head(k): the engine turns a Slice
+        directly above a Sort into a radix select (polars-stream/src/nodes/top_k.rs)."""
+        keys = _as_exprs([by])
+        rev = _per_key(reverse, len(keys), "reverse", "by")
+        return self.sort(keys, descending=[not r for r in rev], nulls_last=True).head(k)
+
+    def bottom_k(self, k: int, *, by, reverse=False) -> "LazyFrame":
+        keys = _as_exprs([by])
+        rev = _per_key(reverse, len(keys), "reverse", "by")
+        return self.sort(keys, descending=rev, nulls_last=True).head(k)
 
     # -- execution -----------------------------------------------------------------------------------
     def _lower(self):

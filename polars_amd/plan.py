@@ -192,7 +192,7 @@ class Lowering:
     def lower_node(self, n: Node) -> Tuple[int, Schema]:
         def push(**kw) -> int:
             node = dict(kind=0, input=-1, input_right=-1, predicate=-1, frame=None, exprs=[], keys=[], keys_right=[], how=0,
-                        maintain_order=0, suffix="_right")
+                        maintain_order=0, suffix="_right", sort_descending=[], sort_nulls_last=[], slice_offset=0, slice_len=0)
             node.update(kw)
             self.irs.append(node)
             return len(self.irs) - 1
@@ -239,14 +239,24 @@ class Lowering:
                     bi = self._cast(bi, bdt, st)
                 lk.append(ai)
                 rk.append(bi)
+            how = {"inner": F.JOIN_INNER, "left": F.JOIN_LEFT, "semi": F.JOIN_SEMI, "anti": F.JOIN_ANTI}[n.how]
+            if n.how in ("semi", "anti"):   # left columns only (single_keys_semi_anti.rs)
+                return push(kind=F.IR_JOIN, input=li, input_right=ri, keys=lk, keys_right=rk, how=how, suffix=n.suffix), dict(ls)
             out_schema = dict(ls)
             right_key_names = {b.name for a, b in zip(n.left_on, n.right_on) if b.kind == "col" and a.kind == "col"}
             for name, dt in rs.items():
                 if name in right_key_names:
                     continue
                 out_schema[name + n.suffix if name in out_schema else name] = dt
-            how = {"inner": F.JOIN_INNER, "left": F.JOIN_LEFT}[n.how]
             return push(kind=F.IR_JOIN, input=li, input_right=ri, keys=lk, keys_right=rk, how=how, suffix=n.suffix), out_schema
+        if k == "sort":
+            inp, schema = self.lower_node(n.input)
+            keys = [self.lower_expr(e, schema)[0] for e in n.by]
+            return push(kind=F.IR_SORT, input=inp, keys=keys, sort_descending=[int(bool(x)) for x in n.descending],
+                        sort_nulls_last=[int(bool(x)) for x in n.nulls_last], maintain_order=int(n.maintain_order)), schema
+        if k == "slice":
+            inp, schema = self.lower_node(n.input)
+            return push(kind=F.IR_SLICE, input=inp, slice_offset=int(n.offset), slice_len=int(n.length)), schema
         raise TypeError(f"unsupported plan node {k}")
 
     # -- marshalling to the C structs -----------------------------------------------------------
@@ -287,6 +297,12 @@ class Lowering:
             sb = d["suffix"].encode()
             keep.append(sb)
             r.suffix = sb
+            if d["kind"] == F.IR_SORT:
+                for field in ("sort_descending", "sort_nulls_last"):
+                    arr = (C.c_uint8 * max(len(d[field]), 1))(*d[field])
+                    keep.append(arr)
+                    setattr(r, field, C.cast(arr, C.POINTER(C.c_uint8)))
+            r.slice_offset, r.slice_len = d["slice_offset"], d["slice_len"]
         return ir, n_ir, ae, n_ae, keep
 
 

@@ -56,3 +56,14 @@ def q3(lineitem, orders, date=Q3_DATE, seg_mod=5):
     return (li.join(o, left_on="l_orderkey", right_on="o_orderkey")
             .group_by("l_orderkey", "o_orderdate", "o_shippriority")
             .agg((c("l_extendedprice") * (1 - c("l_discount"))).sum().alias("revenue")))
+
+
+def q1_sorted(lineitem, cutoff=Q1_CUTOFF):
+    """TPC-H Q1 including its ORDER BY l_returnflag, l_linestatus (device radix sort of the <= 6 result rows)."""
+    return q1(lineitem, cutoff).sort("l_returnflag", "l_linestatus")
+
+
+def q3_top10(lineitem, orders, date=Q3_DATE, seg_mod=5):
+    """TPC-H Q3 including its ORDER BY revenue DESC, o_orderdate LIMIT 10: the Slice directly above the Sort becomes a
+    radix select over the ~1e6 groups."""
+    return q3(lineitem, orders, date, seg_mod).sort("revenue", "o_orderdate", descending=[True, False]).head(10)

@@ -73,6 +73,32 @@ def main():
     mine = {c: a.tolist() for c, a in orc.q1_native(qcols, datagen.us(1998, 9, 2), streaming=True).items()}
     merged = bench.combine_q1_results(bench.allgather_q1(mine, ws))
     np.savez(os.path.join(out_dir, f"q1_rank{rank}.npz"), **{c: np.asarray(a) for c, a in qcols.items()}, **{"m_" + c: np.asarray(a) for c, a in merged.items()})
+    # (e) sharded join -> group-by (Q3 shape), broadcast and shuffle modes; the local pipeline is the oracle's q3
+    orders, li = datagen.orders_lineitem_host(30000 + 300 * rank, seed=300 + rank)
+    # make order keys globally unique across ranks (each rank generated its own key space)
+    off = rank * 10_000_000
+    orders["o_orderkey"] = orders["o_orderkey"] + off; li["l_orderkey"] = li["l_orderkey"] + off
+    # scatter this rank's lineitem rows so that keys of one order also live on OTHER ranks' probe shards
+    allkeys = [torch.from_numpy(li[c]) for c in datagen.LINEITEM_Q3_COLS]
+    probe = {c: pdist.allgather_concat(t)[rank::ws].contiguous() for c, t in zip(datagen.LINEITEM_Q3_COLS, allkeys)}
+    build = {c: torch.from_numpy(orders[c]) for c in datagen.ORDERS_Q3_COLS}
+    date = datagen.us(1995, 3, 15)
+
+    def local_q3(pc, bc):
+        r = orc.q3({c: t.numpy() for c, t in pc.items()}, {c: t.numpy() for c, t in bc.items()}, date)
+        return {c: torch.from_numpy(np.ascontiguousarray(a)) for c, a in r.items()}
+    def build_pre(bc):
+        m = torch.from_numpy((bc["o_orderdate"].numpy() < date) & (bc["o_custkey"].numpy() % 5 == 0))
+        return {c: t[m] for c, t in bc.items()}
+
+    def probe_pre(pc):
+        m = pc["l_shipdate"] > date
+        return {c: t[m] for c, t in pc.items()}
+    for mode in ("broadcast", "shuffle", "auto"):
+        r = pdist.join_groupby(ops, probe, build, "l_orderkey", "o_orderkey", local_q3, [("revenue", "sum")], "l_orderkey", mode=mode,
+                               build_prefilter=build_pre if mode != "broadcast" else None, probe_prefilter=probe_pre if mode == "shuffle" else None)
+        np.savez(os.path.join(out_dir, f"q3_{mode}_rank{rank}.npz"), **{c: t.numpy() for c, t in r.items()})
+    np.savez(os.path.join(out_dir, f"q3_in_rank{rank}.npz"), **{"p_" + c: t.numpy() for c, t in probe.items()}, **{"b_" + c: t.numpy() for c, t in build.items()})
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), key=key.numpy(), flag=flag.numpy(), v=v.numpy(), x=x.numpy(),
              **{f"g_{k}": t.numpy() for k, t in g.items()}, **{f"s_{k}": t.numpy() for k, t in s.items()})
     dist.barrier()

@@ -118,6 +118,89 @@ C.append(dict(id="int_wrapping", kind="arith", source="crates/polars-compute/src
               expect={"add": [-9223372036854775808, 9223372036854775807, 4611686018427387906], "mul": [9223372036854775807, -9223372036854775808, -9223372036854775808],
                       "sub": [9223372036854775806, -9223372036854775807, 4611686018427387902]}))
 
+# ---- sort / top-k -----------------------------------------------------------------
+# frame columns + by / descending / nulls_last (+ limit = head after the sort); `expect` is the full output in order
+# unless "unordered": true (the reference test uses check_row_order=False / check_order=False there).
+TS = "py-polars/tests/unit/operations/test_sort.py"
+TK = "py-polars/tests/unit/operations/test_top_k.py"
+C.append(dict(id="sort_dates_multiples", kind="sort", source=TS + ":50-76", note="datetimes as their physical i64 (day index)",
+              frame={"date": [0, 0, 1, 1, 2], "values": [5, 4, 3, 2, 1]}, dtypes={"date": "i64", "values": "i64"},
+              by=["date", "values"], descending=[False, False], nulls_last=[False, False],
+              expect={"values": [4, 5, 2, 3, 1]}))
+for i, (nl, desc, ex, ey) in enumerate([
+        ([False, True], [False, False], [None, None, 1, 3], [3, None, 2, 1]),
+        ([True, False], [False, False], [1, 3, None, None], [2, 1, None, 3]),
+        ([True, False], [True, True], [3, 1, None, None], [1, 2, None, 3]),
+        ([False, True], [True, True], [None, None, 3, 1], [3, None, 1, 2]),
+        ([False, True], [True, False], [None, None, 3, 1], [3, None, 1, 2])]):
+    C.append(dict(id=f"sort_multi_nulls_last_{i}", kind="sort", source=TS + ":159-191",
+                  frame={"x": [None, 1, None, 3], "y": [3, 2, None, 1]}, dtypes={"x": "i64", "y": "i64"},
+                  by=["x", "y"], descending=desc, nulls_last=nl, expect={"x": ex, "y": ey}))
+C.append(dict(id="sort_nans_3740", kind="sort", source=TS + ":301-310",
+              frame={"key": [1, 2, 3, 4, 5], "val": [0.0, None, "nan", "-inf", "inf"]}, dtypes={"key": "i64", "val": "f64"},
+              by=["val"], descending=[False], nulls_last=[False], expect={"key": [2, 4, 1, 5, 3]}))
+C.append(dict(id="sort_args_nulls_first", kind="sort", source=TS + ":686-709",
+              frame={"a": [1, 2, None], "b": [6.0, 5.0, 4.0]}, dtypes={"a": "i64", "b": "f64"},
+              by=["a", "b"], descending=[False, False], nulls_last=[False, False], expect={"a": [None, 1, 2], "b": [4.0, 6.0, 5.0]}))
+C.append(dict(id="sort_args_nulls_last", kind="sort", source=TS + ":714-716",
+              frame={"a": [1, 2, None], "b": [6.0, 5.0, 4.0]}, dtypes={"a": "i64", "b": "f64"},
+              by=["a"], descending=[False], nulls_last=[True], expect={"a": [1, 2, None], "b": [6.0, 5.0, 4.0]}))
+C.append(dict(id="sort_descending", kind="sort", source=TS + ":803-808",
+              frame={"a": [1, 2, 3], "b": [4, 5, 6]}, dtypes={"a": "i64", "b": "i64"},
+              by=["a", "b"], descending=[True, True], nulls_last=[False, False], expect={"a": [3, 2, 1], "b": [6, 5, 4]}))
+for desc, nl, eb, ef in [(False, False, [None, False, False, True, True], [3.0, 2.0, 5.0, 1.0, 4.0]),
+                         (False, True, [False, False, True, True, None], [2.0, 5.0, 1.0, 4.0, 3.0]),
+                         (True, True, [True, True, False, False, None], [1.0, 4.0, 2.0, 5.0, 3.0]),
+                         (True, False, [None, True, True, False, False], [3.0, 1.0, 4.0, 2.0, 5.0])]:
+    C.append(dict(id=f"sort_bool_with_null_12139_desc{int(desc)}_nl{int(nl)}", kind="sort", source=TS + ":925-961",
+                  frame={"bool": [True, False, None, True, False], "float": [1.0, 2.0, 3.0, 4.0, 5.0]}, dtypes={"bool": "bool", "float": "f64"},
+                  by=["bool"], descending=[desc], nulls_last=[nl], expect={"bool": eb, "float": ef}))
+for desc in (True, False):
+    for nl in (True, False):
+        # the reference test builds its expectation with this rule (test_sort.py:1013-1018)
+        sentinel = 100 if desc ^ nl else -100
+        rx = sorted([1, 3, None, 2, None], key=lambda k: sentinel if k is None else k, reverse=desc)
+        ry = sorted([1, 3, 0, 2, 0], key=lambda k: sentinel if k == 0 else k, reverse=desc)
+        for by in (["x"], ["x", "y"]):
+            C.append(dict(id=f"sort_descending_nulls_last_desc{int(desc)}_nl{int(nl)}_{len(by)}key", kind="sort", source=TS + ":1005-1027",
+                          frame={"x": [1, 3, None, 2, None], "y": [1, 3, 0, 2, 0]}, dtypes={"x": "i64", "y": "i64"},
+                          by=by, descending=[desc] * len(by), nulls_last=[nl] * len(by), expect={"x": rx, "y": ry}))
+C.append(dict(id="sort_top_k_fast_path", kind="sort", source=TS + ":858-871",
+              frame={"a": [1, 2, None], "b": [6.0, 5.0, 4.0]}, dtypes={"a": "i64", "b": "f64"},
+              by=["b"], descending=[False], nulls_last=[False], limit=3, expect={"a": [None, 2, 1], "b": [4.0, 5.0, 6.0]}))
+C.append(dict(id="sort_head_maintain_order", kind="sort", source=TK + ":609-616",
+              frame={"x": [2, 0, 8, 0, 0, 0, 7, 0, 9, 0], "y": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]}, dtypes={"x": "i64", "y": "i64"},
+              by=["x"], descending=[False], nulls_last=[False], limit=4, expect={"x": [0, 0, 0, 0], "y": [1, 3, 4, 5]}))
+C.append(dict(id="top_k_9385_bool_sort_slice", kind="sort", source=TK + ":393-396",
+              frame={"b": [True, False]}, dtypes={"b": "bool"}, by=["b"], descending=[False], nulls_last=[False], limit=1, expect={"b": [False]}))
+C.append(dict(id="top_k_series", kind="top_k", source=TK + ":35-39", k=3, reverse=[False], bottom=False, unordered=True,
+              frame={"a": [3, 8, 1, 5, 2]}, dtypes={"a": "i64"}, by=["a"], expect={"a": [8, 5, 3]}))
+C.append(dict(id="bottom_k_series", kind="top_k", source=TK + ":35-40", k=4, reverse=[False], bottom=True, unordered=True,
+              frame={"a": [3, 8, 1, 5, 2]}, dtypes={"a": "i64"}, by=["a"], expect={"a": [3, 2, 1, 5]}))
+C.append(dict(id="top_k_more_than_rows", kind="top_k", source=TK + ":51-55", k=10, reverse=[False], bottom=False, unordered=True,
+              frame={"test": [2, 4, 1, 3]}, dtypes={"test": "i64"}, by=["test"], expect={"test": [4, 3, 2, 1]}))
+TKDF = dict(frame={"a": [1, 2, 3, 4, 2, 2, None], "b": [None, 2, 1, 4, 3, 2, None]}, dtypes={"a": "i64", "b": "i64"}, by=["a", "b"], unordered=True)
+C.append(dict(id="top_k_df_two_keys", kind="top_k", source=TK + ":94-106", k=3, reverse=[False, False], bottom=False, expect={"a": [4, 3, 2], "b": [4, 1, 3]}, **TKDF))
+C.append(dict(id="top_k_df_two_keys_reverse", kind="top_k", source=TK + ":108-112", k=3, reverse=[True, True], bottom=False, expect={"a": [1, 2, 2], "b": [None, 2, 2]}, **TKDF))
+C.append(dict(id="bottom_k_df_two_keys_reverse", kind="top_k", source=TK + ":113-117", k=4, reverse=[True, True], bottom=True, expect={"a": [4, 3, 2, 2], "b": [4, 1, 3, 2]}, **TKDF))
+C.append(dict(id="top_k_reverse", kind="top_k", source=TK + ":379-383", k=1, reverse=[True, True], bottom=False, unordered=True,
+              frame={"a": [1, 2, 3], "b": [4, 5, 6]}, dtypes={"a": "i64", "b": "i64"}, by=["a", "b"], expect={"a": [1], "b": [4]}))
+
+# ---- semi / anti joins: left rows kept, left order --------------------------------------------------------------
+TJ = "py-polars/tests/unit/operations/test_join.py"
+for how, ek, ep in (("anti", [1, 2], ["f", "i"]), ("semi", [3], [None])):
+    C.append(dict(id=f"{how}_join_null_in_right", kind="semi_anti", how=how, source=TJ + ":29-41",
+                  left={"key": [1, 2, 3], "payload": ["f", "i", None]}, left_dtypes={"key": "i64", "payload": "str"},
+                  right={"key": [3, 4, 5, None]}, right_dtypes={"key": "i64"}, on="key", expect={"key": ek, "payload": ep}))
+for how, ex in (("anti", [1]), ("semi", [0, 0])):
+    C.append(dict(id=f"{how}_join_sorted_null", kind="semi_anti", how=how, source=TJ + ":676-688",
+                  left={"x": [0, 0, 1]}, left_dtypes={"x": "i64"}, right={"x": [0, None], "y": [0, 1]}, right_dtypes={"x": "i64", "y": "i64"},
+                  on="x", expect={"x": ex}))
+for how, ea, ex in (("semi", [1, 9], [10, 90]), ("anti", [], [])):
+    C.append(dict(id=f"{how}_join_28264", kind="semi_anti", how=how, source=TJ + ":4325-4350",
+                  left={"a": [1, 9], "x": [10, 90]}, left_dtypes={"a": "i64", "x": "i64"}, right={"a": [1, 9], "y": [100, 900]}, right_dtypes={"a": "i64", "y": "i64"},
+                  on="a", expect={"a": ea, "x": ex}))
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")
 with open(out, "w") as f:
     json.dump(C, f, indent=1)

@@ -10,7 +10,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 NP = {"i8": np.int8, "i16": np.int16, "i32": np.int32, "i64": np.int64, "u8": np.uint8, "u16": np.uint16, "u32": np.uint32,
-      "u64": np.uint64, "f32": np.float32, "f64": np.float64}
+      "u64": np.uint64, "f32": np.float32, "f64": np.float64, "bool": np.bool_}
 
 
 def load_cases(kind=None):

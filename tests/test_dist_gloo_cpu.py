@@ -31,6 +31,24 @@ def test_sharded_groupby_and_exchange(tmp_path, ws):
         for c, v in whole.items():
             got = q["m_" + c]
             assert np.allclose(got.astype(np.float64), v.astype(np.float64), rtol=1e-9), c
+    # sharded join -> group-by: both modes equal the oracle's q3 on the concatenated inputs; results disjoint by key
+    ins = [np.load(f) for f in sorted(glob.glob(str(tmp_path / "q3_in_rank*.npz")))]
+    li_all = {c: np.concatenate([i["p_" + c] for i in ins]) for c in datagen.LINEITEM_Q3_COLS}
+    or_all = {c: np.concatenate([i["b_" + c] for i in ins]) for c in datagen.ORDERS_Q3_COLS}
+    exp = orc.q3(li_all, or_all, datagen.us(1995, 3, 15))
+    assert len(exp["l_orderkey"]) > 100
+    for mode in ("broadcast", "shuffle", "auto"):
+        outs = [np.load(f) for f in sorted(glob.glob(str(tmp_path / f"q3_{mode}_rank*.npz")))]
+        assert len(outs) == ws
+        keys = [set(o["l_orderkey"].tolist()) for o in outs]
+        for i in range(ws):
+            for j in range(i + 1, ws):
+                assert not (keys[i] & keys[j]), mode
+        got = {c: np.concatenate([o[c] for o in outs]) for c in exp}
+        order = np.argsort(got["l_orderkey"], kind="stable")
+        assert np.array_equal(got["l_orderkey"][order], exp["l_orderkey"]), mode
+        assert np.array_equal(got["o_orderdate"][order], exp["o_orderdate"]) and np.array_equal(got["o_shippriority"][order], exp["o_shippriority"]), mode
+        assert np.allclose(got["revenue"][order], exp["revenue"], rtol=1e-9), mode
     files = sorted(glob.glob(str(tmp_path / "rank*.npz")))
     assert len(files) == ws
     parts = [np.load(f) for f in files]

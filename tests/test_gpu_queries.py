@@ -503,3 +503,38 @@ def test_partitioned_groupby_packed_dictionary_keys(pl):
     s = np.bincount(codes, v)[np.unique(codes)]; cnt = np.bincount(codes)[np.unique(codes)]
     assert close(out["v_sum"].to_numpy()[o1], s) and close(out["v_mean"].to_numpy()[o1], s / cnt)
     assert close(ref["v_sum"].to_numpy()[o2], s)
+
+
+def test_sharded_q3_per_rank_pieces(pl, orc):
+    """The per-rank operators of the sharded Q3 (polars_amd/dist.py Q3Local) composed the way join_groupby composes them,
+    with concatenation standing in for the collectives: 2 virtual ranks, keys of one order on both ranks."""
+    import torch
+    from polars_amd import datagen, dist as pdist
+    orders, li = datagen.orders_lineitem_host(60_000, seed=77)
+    exp = orc.q3({k: li[k] for k in datagen.LINEITEM_Q3_COLS}, {k: orders[k] for k in datagen.ORDERS_Q3_COLS}, datagen.us(1995, 3, 15))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    q = pdist.Q3Local(pl)
+    probes = [{c: dev(li[c][r::2]) for c in datagen.LINEITEM_Q3_COLS} for r in range(2)]
+    half = len(orders["o_orderkey"]) // 2
+    builds = [{c: dev(orders[c][:half] if r == 0 else orders[c][half:]) for c in datagen.ORDERS_Q3_COLS} for r in range(2)]
+    # broadcast mode: prefilter -> all-gather(build) -> local pipeline -> merge partial groups by key
+    fb = [q.build_prefilter(b) for b in builds]
+    assert sum(int(f["o_orderkey"].numel()) for f in fb) < len(orders["o_orderkey"]) // 3
+    gathered = {c: torch.cat([f[c] for f in fb]) for c in datagen.ORDERS_Q3_COLS}
+    parts = [q.local(p, gathered) for p in probes]
+    assert sum(int(p["l_orderkey"].numel()) for p in parts) > len(exp["l_orderkey"])     # keys split over both ranks
+    allp = {c: torch.cat([p[c] for p in parts]) for c in parts[0]}
+    keys = {c: allp[c] for c in ("l_orderkey", "o_orderdate", "o_shippriority")}
+    merged = q.ops.groupby_partial(keys, {"revenue": allp["revenue"]}, [("revenue", "revenue", "sum")])
+    order = torch.argsort(merged["l_orderkey"])
+    assert torch.equal(merged["l_orderkey"][order].cpu(), torch.from_numpy(exp["l_orderkey"]))
+    assert torch.equal(merged["o_orderdate"][order].cpu(), torch.from_numpy(exp["o_orderdate"]))
+    assert np.allclose(merged["revenue"][order].cpu().numpy(), exp["revenue"], rtol=1e-9)
+    # shuffle mode pieces: probe prefilter + hash routing keep every surviving row exactly once
+    fp = [q.probe_prefilter(p) for p in probes]
+    assert sum(int(f["l_orderkey"].numel()) for f in fp) == int((li["l_shipdate"] > datagen.us(1995, 3, 15)).sum())
+    perm, counts = q.ops.hash_partition(fp[0]["l_orderkey"], 2)
+    assert sum(counts) == fp[0]["l_orderkey"].numel() and torch.equal(torch.sort(perm)[0].cpu(), torch.arange(sum(counts)))
+    # single-process run() is the plain local pipeline
+    full = q.run({c: dev(li[c]) for c in datagen.LINEITEM_Q3_COLS}, {c: dev(orders[c]) for c in datagen.ORDERS_Q3_COLS})
+    assert sorted(full["l_orderkey"].cpu().tolist()) == exp["l_orderkey"].tolist()

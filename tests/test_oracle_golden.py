@@ -271,3 +271,71 @@ def test_q1_native_drivers_agree(orc):
                 else:
                     assert np.array_equal(got[k], ref[k]), (k, streaming, threads)
     orc.set_threads(1)
+
+
+def _kat_keys(case, by, desc, nl):
+    cols = {n: kat.column(spec, case["dtypes"][n]) for n, spec in case["frame"].items()}
+    keys = [(cols[b][0], cols[b][1], bool(d), bool(x)) for b, d, x in zip(by, desc, nl)]
+    return cols, keys
+
+
+def _check_sorted_frame(case, cols, idx):
+    exp = case["expect"]
+    names = list(exp.keys())
+    got = []
+    for i in idx:
+        got.append(tuple(_to_py(cols[c][0][i], cols[c][1] is None or cols[c][1][i]) for c in names))
+    want = [tuple(exp[c][i] for c in names) for i in range(len(exp[names[0]]))]
+    if case.get("unordered"):
+        srt = lambda rows: sorted(rows, key=lambda r: tuple((x is None, x) for x in r))
+        got, want = srt(got), srt(want)
+    assert len(got) == len(want), (got, want)
+    for g, e in zip(got, want):
+        for a, b in zip(g, e):
+            assert kat.same_value(a, b), (case["id"], got, want)
+
+
+@pytest.mark.parametrize("case", kat.load_cases("sort"), ids=lambda c: c["id"])
+@pytest.mark.parametrize("impl", ["cmp", "lexsort"])
+def test_sort_kats(orc, case, impl):
+    """Both restatements of arg_sort_multiple (comparator and vectorised) against the reference's sort tests."""
+    cols, keys = _kat_keys(case, case["by"], case["descending"], case["nulls_last"])
+    fn = orc.sort_indices_cmp if impl == "cmp" else orc.sort_indices
+    _check_sorted_frame(case, cols, fn(keys, case.get("limit")))
+
+
+@pytest.mark.parametrize("case", kat.load_cases("top_k"), ids=lambda c: c["id"])
+def test_top_k_kats(orc, case):
+    # top_k(k, by, reverse) == sort(by, descending = not reverse, nulls_last).head(k); bottom_k: descending = reverse
+    desc = [bool(r) if case["bottom"] else (not r) for r in case["reverse"]]
+    cols, keys = _kat_keys(case, case["by"], desc, [True] * len(desc))
+    _check_sorted_frame(case, cols, orc.sort_indices(keys, case["k"]))
+    _check_sorted_frame(case, cols, orc.sort_indices_cmp(keys, case["k"]))
+
+
+@pytest.mark.parametrize("case", kat.load_cases("semi_anti"), ids=lambda c: c["id"])
+def test_semi_anti_kats(orc, case):
+    L, R, cats = _join_frames(orc, case)
+    on = case["on"]
+    idx = orc.semi_anti_join(orc.JOIN_SEMI if case["how"] == "semi" else orc.JOIN_ANTI, L[on][0], L[on][1], R[on][0], R[on][1])
+    for name, expv in case["expect"].items():
+        a, v = L[name]
+        got = [_to_py(a[i], v is None or v[i]) for i in idx]
+        if name in cats:
+            got = [None if g is None else cats[name][g] for g in got]
+        assert len(got) == len(expv) and all(kat.same_value(g, e) for g, e in zip(got, expv)), (case["id"], name, got, expv)
+
+
+def test_sort_restatements_agree_on_random_inputs(orc):
+    rng = np.random.default_rng(5)
+    for t in range(120):
+        n = int(rng.integers(0, 80))
+        keys = []
+        for _ in range(int(rng.integers(1, 4))):
+            kind = int(rng.integers(0, 3))
+            v = (rng.integers(-3, 4, n).astype(np.int64) if kind == 0 else
+                 rng.choice([0.0, -0.0, 1.5, -2.0, np.nan, np.inf, -np.inf], n) if kind == 1 else rng.integers(0, 2, n).astype(bool))
+            m = None if rng.random() < 0.4 else rng.random(n) < 0.7
+            keys.append((v, m, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
+        lim = None if rng.random() < 0.5 else int(rng.integers(0, n + 2))
+        assert np.array_equal(orc.sort_indices(keys, lim), orc.sort_indices_cmp(keys, lim)), t

@@ -101,3 +101,32 @@ def test_join_schema_and_suffix():
     root, schema = low.lower_node(L.lazy().join(R.lazy(), on="k")._node)
     assert list(schema) == ["k", "rain", "rain_right", "z"]      # general.rs:17-49 _finish_join
     assert low.irs[root]["kind"] == F.IR_JOIN and low.irs[root]["suffix"] == "_right"
+
+
+def test_sort_slice_and_semi_anti_lowering():
+    """IR::Sort / IR::Slice / semi+anti joins reach the C ABI as PLX_IR_SORT / PLX_IR_SLICE / how (no GPU needed)."""
+    df = pl.DataFrame([ph("a", pl.Int64), ph("b", pl.Float64, nullable=True)])
+    lf = df.lazy().sort("a", pl.col("b") * 2, descending=[True, False], nulls_last=[False, True]).slice(-5, 3)
+    low, root, schema = lf._lower()
+    kinds = [n["kind"] for n in low.irs]
+    assert kinds == [F.IR_SCAN, F.IR_SORT, F.IR_SLICE] and root == 2 and list(schema) == ["a", "b"]
+    s = low.irs[1]
+    assert s["sort_descending"] == [1, 0] and s["sort_nulls_last"] == [0, 1] and len(s["keys"]) == 2
+    assert (low.irs[2]["slice_offset"], low.irs[2]["slice_len"]) == (-5, 3)
+    (ir, n_ir, ae, n_ae, keep), *_ = lf._lowered_c()
+    assert n_ir == 3 and ir[1].sort_descending[0] == 1 and ir[1].sort_nulls_last[1] == 1 and ir[2].slice_offset == -5 and ir[2].slice_len == 3
+    # top_k(k, by) == sort(descending, nulls last).head(k); bottom_k: ascending
+    low, _, _ = df.lazy().top_k(7, by=["a", "b"], reverse=[False, True])._lower()
+    assert low.irs[1]["sort_descending"] == [1, 0] and low.irs[1]["sort_nulls_last"] == [1, 1] and low.irs[2]["slice_len"] == 7
+    low, _, _ = df.lazy().bottom_k(2, by="a")._lower()
+    assert low.irs[1]["sort_descending"] == [0] and low.irs[2]["slice_len"] == 2
+    with pytest.raises(ValueError, match=r"the length of `descending` \(1\) does not match the length of `by` \(2\)"):
+        df.lazy().sort("a", "b", descending=[True])
+    with pytest.raises(ValueError, match=r"the length of `reverse` \(1\) does not match the length of `by` \(2\)"):
+        df.lazy().top_k(1, by=["a", "b"], reverse=[True])
+    with pytest.raises(ValueError, match="negative slice lengths"):
+        df.lazy().slice(0, -1)
+    other = pl.DataFrame([ph("a", pl.Int64), ph("z", pl.Int64)])
+    for how, code in (("semi", F.JOIN_SEMI), ("anti", F.JOIN_ANTI)):
+        low, root, schema = df.lazy().join(other.lazy(), on="a", how=how)._lower()
+        assert low.irs[root]["how"] == code and list(schema) == ["a", "b"]      # left columns only
