@@ -45,8 +45,9 @@ def parse():
 class Workload:
     """name, rows, algorithmic bytes per step, build(pl) -> callable step() returning a host result."""
 
-    def __init__(self, name, rows, algo_bytes, step, kernel, desc):
+    def __init__(self, name, rows, algo_bytes, step, kernel, desc, variants=None):
         self.name, self.rows, self.algo_bytes, self.step, self.kernel, self.desc = name, rows, algo_bytes, step, kernel, desc
+        self.variants = variants or {}   # name -> step(): the same data through a longer query (extras only)
 
 
 def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
@@ -62,8 +63,14 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
         def step():
             out = lf.collect()
             return out.to_dict(), (df, cols)
+        lf_sorted = queries.q1_sorted(df.lazy())
+
+        def step_sorted():
+            out = lf_sorted.collect()
+            return out.to_dict(), (df, cols)
         return Workload("tpch_q1_sf100", n, n * datagen.Q1_BYTES_PER_ROW, step, "fused_scan_ldsagg_static",
-                        f"TPC-H Q1, lineitem {n} rows x 42 B (SF100 = 6.0e8), filter -> 2-key group_by -> 8 aggregates")
+                        f"TPC-H Q1, lineitem {n} rows x 42 B (SF100 = 6.0e8), filter -> 2-key group_by -> 8 aggregates",
+                        variants={"tpch_q1_sf100_order_by": step_sorted})
     if name == "q3":
         no = (rows // 4) if rows else SF100_ORDERS
         orders, li = datagen.orders_lineitem_device(no, seed=seed)
@@ -89,8 +96,14 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
             def step():   # noqa: F811
                 r = q3s.run(li, orders, mode=os.environ.get("PLX_Q3_MODE", "broadcast"))
                 return {"groups": int(r["l_orderkey"].numel())}, (li, orders)
+        lf_top = queries.q3_top10(L.lazy(), O.lazy())
+
+        def step_top10():
+            out = lf_top.collect()
+            return out.to_dict(), (L, O, li, orders)
         return Workload("tpch_q3_sf100", nl + no, nl * datagen.Q3_LINEITEM_BYTES_PER_ROW + no * datagen.Q3_ORDERS_BYTES_PER_ROW, step, "join_probe_emit",
-                        f"TPC-H Q3 (orders {no} x lineitem {nl}), filter both -> hash join -> group_by(orderkey, orderdate, shippriority)")
+                        f"TPC-H Q3 (orders {no} x lineitem {nl}), filter both -> hash join -> group_by(orderkey, orderdate, shippriority)",
+                        variants={} if ws > 1 else {"tpch_q3_sf100_order_by_limit10": step_top10})
     if name == "cfg2":
         n = rows or 1_000_000_000
         g = torch.Generator(device="cuda"); g.manual_seed(seed)
@@ -353,6 +366,11 @@ def main():
                 extras[w2.name] = {"rows_per_s": round(w2.rows * k2 / d2, 1), "ms_per_step": round(d2 / k2 * 1e3, 3),
                                    "whole_query_GBps": round(w2.algo_bytes * k2 / d2 / 1e9, 1), "roofline": roofline(s2, w2),
                                    "kernels": {k: {"launches": v[0], "avg_us": round(v[1] / v[0], 2)} for k, v in sorted(s2.items(), key=lambda kv: -kv[1][1])[:6]}}
+                for vname, vstep in w2.variants.items():
+                    wv = Workload(vname, w2.rows, w2.algo_bytes, vstep, w2.kernel, w2.desc)
+                    dv, sv, _ = timed(pl, wv, k2, 1, False)
+                    extras[vname] = {"rows_per_s": round(w2.rows * k2 / dv, 1), "ms_per_step": round(dv / k2 * 1e3, 3),
+                                     "kernels": {k: {"launches": v[0], "avg_us": round(v[1] / v[0], 2)} for k, v in sorted(sv.items(), key=lambda kv: -kv[1][1])[:6]}}
                 del w2
             except Exception as e:  # a secondary workload must never take the headline line down
                 extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -270,6 +270,24 @@ def semi_anti_join(how: int, lk: np.ndarray, lv: Optional[np.ndarray], rk: np.nd
     return np.nonzero(keep)[0].astype(np.uint32)
 
 
+def encode_key_rows(lkeys, rkeys):
+    """Multi-column join keys -> one id per distinct key tuple, shared by both sides (the role polars-row's row
+    encoding plays at polars-ops/src/frame/join/mod.rs:367-370): returns (left ids i64, left valid, right ids, right valid).
+    lkeys / rkeys = [(values, valid or None)] per key column; a null in any column makes the row's key null."""
+    nl = len(lkeys[0][0])
+    cols = [np.concatenate([key_bits(a), key_bits(b)]) for (a, _), (b, _) in zip(lkeys, rkeys)]
+    _, inv = np.unique(np.stack(cols, axis=1), axis=0, return_inverse=True)
+    inv = np.asarray(inv).reshape(-1).astype(np.int64)
+
+    def all_valid(keys, n):
+        v = np.ones(n, dtype=bool)
+        for _, m in keys:
+            if m is not None:
+                v &= m
+        return None if v.all() else v
+    return inv[:nl], all_valid(lkeys, nl), inv[nl:], all_valid(rkeys, len(rkeys[0][0]))
+
+
 def _tot_cmp(a, b) -> int:
     """TotalOrd for one non-null value pair (polars-utils/src/total_ord.rs): NaN == NaN, NaN greatest, -0.0 == 0.0."""
     an, bn = isinstance(a, float) and a != a, isinstance(b, float) and b != b

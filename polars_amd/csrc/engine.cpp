@@ -1215,12 +1215,55 @@ static FramePtr exec_groupby_materialised(Plan& plan, const IRN& n, const FrameP
 static FramePtr exec_join(Plan& plan, const IRN& n) {
   FramePtr left = exec_node(plan, n.input);
   FramePtr right = exec_node(plan, n.input_right);
-  PLX_REQUIRE(n.keys.size() == 1 && n.keys_right.size() == 1, PLX_ERR_UNSUPPORTED, "multi-key joins need row encoding (polars-row), not on this path yet");
-  ColumnPtr lk = broadcast(eval(plan, n.keys[0], *left, nullptr), left->height);
-  ColumnPtr rk = broadcast(eval(plan, n.keys_right[0], *right, nullptr), right->height);
+  PLX_REQUIRE(!n.keys.empty() && n.keys.size() == n.keys_right.size(), PLX_ERR_INVALID, "join: left_on / right_on length mismatch");
+  ColumnPtr lk, rk;
+  std::string packed_desc;
+  if (n.keys.size() == 1) {
+    lk = broadcast(eval(plan, n.keys[0], *left, nullptr), left->height);
+    rk = broadcast(eval(plan, n.keys_right[0], *right, nullptr), right->height);
+  } else {
+    // Multi-column keys: the reference row-encodes them (polars-row via join/mod.rs:367-370).  Integer / boolean
+    // keys are instead packed into ONE Int64 using the joint value range of both sides:
+    //   packed = sum_j (key_j - min_j) * stride_j,  stride_j = prod_{i>j} (max_i - min_i + 1)
+    // A null in any key column makes the packed key null, i.e. the row never matches (nulls_equal = false).
+    std::vector<ColumnPtr> lks, rks;
+    std::vector<int64_t> mins, spans;
+    for (size_t j = 0; j < n.keys.size(); j++) {
+      ColumnPtr a = broadcast(eval(plan, n.keys[j], *left, nullptr), left->height);
+      ColumnPtr b = broadcast(eval(plan, n.keys_right[j], *right, nullptr), right->height);
+      PLX_REQUIRE(a->dtype == b->dtype, PLX_ERR_INVALID, "join keys have different dtypes");
+      PLX_REQUIRE(dtype_is_int(a->dtype) || a->dtype == PLX_BOOL, PLX_ERR_UNSUPPORTED, "multi-column join keys must be integer / boolean / dictionary codes on this path");
+      if (a->dtype != PLX_I64) { PLX_REQUIRE(a->dtype != PLX_U64, PLX_ERR_UNSUPPORTED, "multi-column join on UInt64 keys"); a = ops::cast(a, PLX_I64); b = ops::cast(b, PLX_I64); }
+      int64_t amn = 0, amx = 0, bmn = 0, bmx = 0;
+      const bool ha = ops::int_range(a, &amn, &amx), hb = ops::int_range(b, &bmn, &bmx);
+      int64_t mn = ha ? amn : bmn, mx = ha ? amx : bmx;
+      if (ha && hb) { mn = std::min(amn, bmn); mx = std::max(amx, bmx); }
+      if (!ha && !hb) { mn = 0; mx = 0; }
+      PLX_REQUIRE((double)mx - (double)mn < 9e18, PLX_ERR_UNSUPPORTED, "multi-column join keys span more than 63 bits");
+      lks.push_back(a); rks.push_back(b); mins.push_back(mn); spans.push_back(mx - mn + 1);
+    }
+    double total = 1;
+    for (int64_t sp : spans) total *= (double)sp;
+    PLX_REQUIRE(total < 9.0e18, PLX_ERR_UNSUPPORTED, "multi-column join keys do not pack into 63 bits (needs row encoding)");
+    auto pack = [&](std::vector<ColumnPtr>& ks) {
+      ColumnPtr acc;
+      int64_t stride = 1;
+      for (size_t j = ks.size(); j-- > 0;) {
+        plx_scalar s; s.i = mins[j];
+        ColumnPtr t = ops::arith_scalar(PLX_SUB, ks[j], s, false);
+        if (stride != 1) { plx_scalar m; m.i = stride; t = ops::arith_scalar(PLX_MUL, t, m, false); }
+        acc = acc ? ops::arith(PLX_ADD, acc, t) : t;
+        stride *= spans[j];
+      }
+      return acc;
+    };
+    lk = pack(lks); rk = pack(rks);
+    packed_desc = "packed " + std::to_string(n.keys.size()) + " key columns into Int64; ";
+  }
   ColumnPtr li, ri;
   std::string d;
   join::join_indices(n.how, lk, rk, li, ri, &d);
+  d = packed_desc + d;
   if (n.how == PLX_JOIN_SEMI || n.how == PLX_JOIN_ANTI) {
     // left columns only, left order (single_keys_semi_anti.rs; _finish_join is not involved)
     plan.desc += "Join{" + d + ", gather x" + std::to_string(left->cols.size()) + "}; ";
@@ -1235,12 +1278,16 @@ static FramePtr exec_join(Plan& plan, const IRN& n) {
   auto out = std::make_shared<Frame>();
   out->height = li->len;
   for (size_t i = 0; i < left->cols.size(); i++) { out->names.push_back(left->names[i]); out->cols.push_back(ops::gather(left->cols[i], li)); }
-  const AE* rkx = &plan.ae[n.keys_right[0]];
-  while (rkx->kind == PLX_AE_ALIAS) rkx = &plan.ae[rkx->lhs];
-  const AE* lkx = &plan.ae[n.keys[0]];
-  while (lkx->kind == PLX_AE_ALIAS) lkx = &plan.ae[lkx->lhs];
+  std::vector<std::string> coalesced;   // right key columns merged into the left key (both sides plain columns)
+  for (size_t j = 0; j < n.keys.size(); j++) {
+    const AE* rkx = &plan.ae[n.keys_right[j]];
+    while (rkx->kind == PLX_AE_ALIAS) rkx = &plan.ae[rkx->lhs];
+    const AE* lkx = &plan.ae[n.keys[j]];
+    while (lkx->kind == PLX_AE_ALIAS) lkx = &plan.ae[lkx->lhs];
+    if (rkx->kind == PLX_AE_COLUMN && lkx->kind == PLX_AE_COLUMN) coalesced.push_back(rkx->name);
+  }
   for (size_t i = 0; i < right->cols.size(); i++) {
-    if (rkx->kind == PLX_AE_COLUMN && lkx->kind == PLX_AE_COLUMN && right->names[i] == rkx->name) continue;  // coalesced key
+    if (std::find(coalesced.begin(), coalesced.end(), right->names[i]) != coalesced.end()) continue;  // coalesced key
     std::string name = right->names[i];
     if (out->find(name) >= 0) name += n.suffix;
     out->names.push_back(name);

@@ -201,6 +201,12 @@ for how, ea, ex in (("semi", [1, 9], [10, 90]), ("anti", [], [])):
                   left={"a": [1, 9], "x": [10, 90]}, left_dtypes={"a": "i64", "x": "i64"}, right={"a": [1, 9], "y": [100, 900]}, right_dtypes={"a": "i64", "y": "i64"},
                   on="a", expect={"a": ea, "x": ex}))
 
+for how, ea, eb, ep in (("anti", [1, 2, 1], ["a", "b", "a"], [10, 20, 40]), ("semi", [3], ["c"], [30])):
+    C.append(dict(id=f"{how}_join_two_keys", kind="semi_anti", how=how, source=TJ + ":50-67",
+                  left={"a": [1, 2, 3, 1], "b": ["a", "b", "c", "a"], "payload": [10, 20, 30, 40]}, left_dtypes={"a": "i64", "b": "str", "payload": "i64"},
+                  right={"a": [3, 3, 4, 5], "b": ["c", "c", "d", "e"]}, right_dtypes={"a": "i64", "b": "str"},
+                  on=["a", "b"], expect={"a": ea, "b": eb, "payload": ep}))
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")
 with open(out, "w") as f:
     json.dump(C, f, indent=1)

@@ -189,3 +189,31 @@ def test_q1_sorted_and_q3_top10(pl, orc, n_orders):
     assert top["o_orderdate"].to_numpy().tolist() == e3["o_orderdate"][o3].tolist()
     if len(np.unique(e3["revenue"][o3])) == len(o3):
         assert top["l_orderkey"].to_numpy().tolist() == e3["l_orderkey"][o3].tolist()
+
+
+@pytest.mark.parametrize("how", ["inner", "left", "semi", "anti"])
+def test_multi_key_join_matches_row_encoded_oracle(pl, orc, how):
+    """Two / three key columns (ints of different widths, a boolean, nulls): the engine packs them into one Int64,
+    the oracle row-encodes them (oracle/pyoracle.py encode_key_rows); same pairs."""
+    rng = np.random.default_rng(21)
+    nl, nr = 40_000, 9_000
+    la, ra = rng.integers(-50, 50, nl).astype(np.int32), rng.integers(-60, 40, nr).astype(np.int32)
+    lb, rb = rng.integers(0, 300, nl).astype(np.int64) * 1_000_003, rng.integers(0, 300, nr).astype(np.int64) * 1_000_003
+    lc, rc = rng.integers(0, 2, nl).astype(bool), rng.integers(0, 2, nr).astype(bool)
+    lam, rbm = rng.random(nl) < 0.97, rng.random(nr) < 0.9
+    L = pl.DataFrame([pl.Series("a", la, validity=lam), pl.Series("b", lb), pl.Series("c", lc), pl.Series("lrow", np.arange(nl, dtype=np.int64))])
+    R = pl.DataFrame([pl.Series("a", ra), pl.Series("b", rb, validity=rbm), pl.Series("c", rc), pl.Series("rrow", np.arange(nr, dtype=np.int64))])
+    lk, lv, rk, rv = orc.encode_key_rows([(la, lam), (lb, None), (lc.astype(np.uint8), None)], [(ra, None), (rb, rbm), (rc.astype(np.uint8), None)])
+    out = L.join(R, on=["a", "b", "c"], how=how)
+    assert "packed 3 key columns" in pl.last_plan(), pl.last_plan()
+    if how in ("semi", "anti"):
+        exp = orc.semi_anti_join(orc.JOIN_SEMI if how == "semi" else orc.JOIN_ANTI, lk, lv, rk, rv)
+        assert out.columns == ["a", "b", "c", "lrow"] and np.array_equal(out["lrow"].to_numpy(), exp)
+        return
+    li, ri, rvalid = orc.join(orc.JOIN_LEFT if how == "left" else orc.JOIN_INNER, lk, lv, rk, rv)
+    assert out.columns == ["a", "b", "c", "lrow", "rrow"]          # all three right key columns are coalesced away
+    d = out.to_dict()
+    got = sorted(zip(d["lrow"], [(-1 if x is None else x) for x in d["rrow"]]))
+    want = sorted(zip(li.tolist(), [int(r) if (rvalid is None or rvalid[i]) else -1 for i, r in enumerate(ri.tolist())]))
+    assert got == want
+    assert out.height > nl // 4

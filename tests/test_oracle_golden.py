@@ -317,7 +317,12 @@ def test_top_k_kats(orc, case):
 def test_semi_anti_kats(orc, case):
     L, R, cats = _join_frames(orc, case)
     on = case["on"]
-    idx = orc.semi_anti_join(orc.JOIN_SEMI if case["how"] == "semi" else orc.JOIN_ANTI, L[on][0], L[on][1], R[on][0], R[on][1])
+    how = orc.JOIN_SEMI if case["how"] == "semi" else orc.JOIN_ANTI
+    if isinstance(on, list):
+        lk, lv, rk, rv = orc.encode_key_rows([L[c] for c in on], [R[c] for c in on])
+        idx = orc.semi_anti_join(how, lk, lv, rk, rv)
+    else:
+        idx = orc.semi_anti_join(how, L[on][0], L[on][1], R[on][0], R[on][1])
     for name, expv in case["expect"].items():
         a, v = L[name]
         got = [_to_py(a[i], v is None or v[i]) for i in idx]
