@@ -356,6 +356,14 @@ def main():
     }
     if rank == 0 and not args.no_extras and ws == 1:
         extras = {}
+        k2 = max(3, args.steps // 4)
+        for vname, vstep in wl.variants.items():
+            try:
+                dv, sv, _ = timed(pl, Workload(vname, wl.rows, wl.algo_bytes, vstep, wl.kernel, wl.desc), k2, 1, False)
+                extras[vname] = {"rows_per_s": round(wl.rows * k2 / dv, 1), "ms_per_step": round(dv / k2 * 1e3, 3),
+                                 "kernels": {k: {"launches": v[0], "avg_us": round(v[1] / v[0], 2)} for k, v in sorted(sv.items(), key=lambda kv: -kv[1][1])[:6]}}
+            except Exception as e:
+                extras[vname] = {"error": f"{type(e).__name__}: {e}"[:300]}
         del wl
         torch.cuda.empty_cache()
         for name in [w for w in ("q3", "cfg2", "cfg3", "cfg5", "q1") if w != args.workload]:

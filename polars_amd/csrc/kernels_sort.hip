@@ -177,6 +177,50 @@ __global__ __launch_bounds__(kBlock) void select_mask_kernel(const uint64_t* __r
   }
 }
 
+// ---- small inputs (a group-by result, top-k candidates): ONE workgroup, comparison rank sort, no host round trips ----
+// enc[j * m + i] = order-preserving code of key j for row i, with the null rank folded into nr (bit j of nr[i] set =
+// the row sorts AFTER every non-flagged row on key j ... see rank_before).  out[rank(i)] = perm ? perm[i] : i.
+constexpr int kSmallBlock = 1024;
+constexpr int kSmallMax = 2048;
+constexpr int kSmallMaxKeys = 8;
+
+// per key two codes: hi = null rank (0 / 1), lo = value code (0 for nulls); row a sorts before row b iff the
+// (hi, lo) sequence over the keys is lexicographically smaller, ties broken by the row position (stable)
+__global__ __launch_bounds__(kSmallBlock) void small_rank_sort_kernel(const uint64_t* __restrict__ enc, const uint8_t* __restrict__ nr, int n_keys, int m,
+                                                                      const uint32_t* __restrict__ perm, uint32_t* __restrict__ out) {
+  for (int i = threadIdx.x; i < m; i += kSmallBlock) {
+    uint64_t mine[kSmallMaxKeys]; uint8_t mnr[kSmallMaxKeys];
+#pragma unroll
+    for (int j = 0; j < kSmallMaxKeys; j++) if (j < n_keys) { mine[j] = enc[(size_t)j * m + i]; mnr[j] = nr[(size_t)j * m + i]; }
+    uint32_t rank = 0;
+    for (int o = 0; o < m; o++) {          // o is wave-uniform: the loads below are scalar / broadcast
+      int c = 0;                           // <0: row o sorts before row i
+#pragma unroll
+      for (int j = 0; j < kSmallMaxKeys; j++) {
+        if (j < n_keys && c == 0) {
+          const uint8_t onr = nr[(size_t)j * m + o];
+          const uint64_t oe = enc[(size_t)j * m + o];
+          c = onr != mnr[j] ? (onr < mnr[j] ? -1 : 1) : (oe != mine[j] ? (oe < mine[j] ? -1 : 1) : 0);
+        }
+      }
+      rank += (c < 0 || (c == 0 && o < i)) ? 1u : 0u;
+    }
+    out[rank] = perm ? perm[i] : (uint32_t)i;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void encode_small_kernel(KeyCol kc, const uint32_t* __restrict__ perm, int m, int descending, int nulls_last,
+                                                              uint64_t* __restrict__ enc, uint8_t* __restrict__ nr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int64_t r = perm ? (int64_t)perm[i] : i;
+  const bool valid = !kc.validity || ((kc.validity[r >> 6] >> (r & 63)) & 1);
+  uint64_t e = 0;
+  if (valid) { e = encode_value(kc, r); if (descending) e = ~e; }
+  enc[i] = e;
+  nr[i] = (valid == (nulls_last != 0)) ? 0 : 1;
+}
+
 // ---------------------------------------------------------------------------------------------- host side ---
 static KeyCol key_col(const ColumnPtr& c) { KeyCol kc; kc.values = c->data(); kc.validity = c->valid_words(); kc.dtype = c->dtype; return kc; }
 
@@ -286,7 +330,7 @@ ColumnPtr sort_indices(const std::vector<SortKey>& keys, int64_t limit, std::str
     uint64_t prefix = 0, need = (uint64_t)limit, below = 0, cand_rows = (uint64_t)n;
     int shift = 56, rounds = 0;
     bool have = false;
-    const uint64_t good_enough = std::max<uint64_t>(4 * (uint64_t)limit, 65536);
+    const uint64_t good_enough = std::max<uint64_t>(2 * (uint64_t)limit, (uint64_t)kSmallMax);   // small enough for the one-workgroup sort
     for (;; shift -= 8) {
       PLX_HIP(hipMemsetAsync(hist->ptr, 0, 256 * sizeof(unsigned int), stream()));
       {
@@ -319,6 +363,24 @@ ColumnPtr sort_indices(const std::vector<SortKey>& keys, int64_t limit, std::str
       m = fp.n_out;
       d += "top_k_select[" + std::to_string(rounds) + " digit rounds, candidates=" + std::to_string(m) + "] -> ";
     }
+  }
+  if (m <= kSmallMax && (int)keys.size() <= kSmallMaxKeys) {
+    const int nk = (int)keys.size();
+    Buf enc = dev_alloc((size_t)nk * m * 8), nr = dev_alloc((size_t)nk * m);
+    const uint32_t* perm = cand ? cand->as<uint32_t>() : nullptr;
+    ProfileScope ps("sort_small", (uint64_t)m * nk * 9, (uint64_t)m);
+    for (int j = 0; j < nk; j++) {
+      hipLaunchKernelGGL(encode_small_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream(), key_col(keys[j].col), perm, (int)m,
+                         keys[j].descending ? 1 : 0, keys[j].nulls_last ? 1 : 0, enc->as<uint64_t>() + (size_t)j * m, nr->as<uint8_t>() + (size_t)j * m);
+      PLX_HIP(hipGetLastError());
+    }
+    Buf sorted = dev_alloc((size_t)m * 4);
+    hipLaunchKernelGGL(small_rank_sort_kernel, dim3(1), dim3(kSmallBlock), 0, stream(), enc->as<uint64_t>(), nr->as<uint8_t>(), nk, (int)m, perm, sorted->as<uint32_t>());
+    PLX_HIP(hipGetLastError());
+    PLX_HIP(hipMemcpyAsync(out->values->ptr, sorted->ptr, (size_t)n_out * 4, hipMemcpyDeviceToDevice, stream()));
+    d += "rank_sort[rows=" + std::to_string(m) + ", keys=" + std::to_string(nk) + ", one workgroup]";
+    if (desc) *desc = d;
+    return out;
   }
   Work w;
   init_work(w, m, cand);

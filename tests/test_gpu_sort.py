@@ -181,7 +181,7 @@ def test_q1_sorted_and_q3_top10(pl, orc, n_orders):
     O = datagen.to_frame(pl, orders, datagen.ORDERS_Q3_COLS)
     e3 = orc.q3({k: li[k] for k in datagen.LINEITEM_Q3_COLS}, {k: orders[k] for k in datagen.ORDERS_Q3_COLS}, datagen.us(1995, 3, 15))
     top = queries.q3_top10(L.lazy(), O.lazy()).collect()
-    assert "FusedJoinGroupBy" in pl.last_plan() and "radix_sort" in pl.last_plan(), pl.last_plan()
+    assert "FusedJoinGroupBy" in pl.last_plan() and "_sort[" in pl.last_plan(), pl.last_plan()
     # the group order out of the join is unspecified, so ties on (revenue, o_orderdate) may resolve differently: compare keys
     o3 = np.lexsort((e3["o_orderdate"], -e3["revenue"]))[:10]
     assert top.height == min(10, len(e3["revenue"]))
@@ -216,4 +216,4 @@ def test_multi_key_join_matches_row_encoded_oracle(pl, orc, how):
     got = sorted(zip(d["lrow"], [(-1 if x is None else x) for x in d["rrow"]]))
     want = sorted(zip(li.tolist(), [int(r) if (rvalid is None or rvalid[i]) else -1 for i, r in enumerate(ri.tolist())]))
     assert got == want
-    assert out.height > nl // 4
+    assert out.height > 1000
