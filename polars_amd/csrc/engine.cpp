@@ -1045,50 +1045,54 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   if (compile_only) return true;
   // ---- run
   uint64_t nb = 0;
-  if (B->height > 0) { std::vector<uint64_t> host(kMaxAggs, 0); k::fused_regagg(cnt.shape, cnt.args, find_static_shape(cnt.shape), host.data()); nb = host[0]; }
   const int probe_static_id = find_static_shape(cp.shape);
   FusedAggResult r; r.n_aggs = cp.shape.n_aggs;
   auto rows = std::make_shared<Column>();
   rows->dtype = PLX_U32; rows->null_count = 0;
   int64_t G = 0;
   bool done = false;
-  // -- direct-address table when the build key range is small (cached column statistics)
+  // -- direct-address table when the build key range is small (cached column statistics); needs no count pass
   int64_t kmn = 0, kmx = 0;
-  if (!(plan.flags & PLX_PLAN_NO_DIRECT_JOIN) && nb > 0 && kdt != PLX_U64 && ops::int_range(B->cols[bki], &kmn, &kmx)) {
+  if (!(plan.flags & PLX_PLAN_NO_DIRECT_JOIN) && B->height > 0 && kdt != PLX_U64 && ops::int_range(B->cols[bki], &kmn, &kmx)) {
     const unsigned __int128 range128 = (unsigned __int128)((__int128)kmx - (__int128)kmn) + 1;
-    if (range128 <= ((unsigned __int128)1 << 32) && range128 <= (unsigned __int128)B->height * 64 && nb < 0xfffffff0ull) {
+    // pair list capacity: every build row may pass + one ordinal chunk (1024, kOrdChunk) per wave
+    const uint64_t ord_cap = (uint64_t)B->height + (uint64_t)k::scan_waves(B->height) * 1024 + 1024;
+    if (range128 <= ((unsigned __int128)1 << 34) && range128 <= (unsigned __int128)B->height * 256 && ord_cap < 0xfffffff0ull) {
       const uint64_t range = (uint64_t)range128;
-      // ordinals are reserved in per-wave chunks of 1024 (kOrdChunk): capacity = passing rows + one chunk per wave
-      const uint64_t ord_cap = nb + (uint64_t)k::scan_waves(B->height) * 1024 + 1024;
-      PLX_REQUIRE(ord_cap < 0xfffffff0ull, PLX_ERR_UNSUPPORTED, "direct join: too many build rows");
-      Buf dir = dev_alloc(sizeof(uint32_t) * range), okey = dev_alloc(sizeof(uint64_t) * ord_cap), orow = dev_alloc(sizeof(uint32_t) * ord_cap), ctr = dev_alloc_zero(16), fl2 = dev_alloc_zero(16);
-      Buf acc2 = dev_alloc(sizeof(uint64_t) * ord_cap * cp.shape.n_aggs);
-      PLX_HIP(hipMemsetAsync(dir->ptr, 0xff, sizeof(uint32_t) * range, stream()));
-      DirectJoinTable dt; dt.dir = dir->as<unsigned int>(); dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>();
-      dt.counter = ctr->as<unsigned int>(); dt.flags = fl2->as<unsigned int>(); dt.acc = acc2->as<unsigned long long>(); dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)ord_cap;
-      k::init_agg_cells(acc2->as<uint64_t>(), (int64_t)ord_cap, cp.shape);   // LEN = 0 everywhere: unused ordinals never show up
+      const size_t n_words = (size_t)(range / 64 + 1);
+      Buf bits = dev_alloc_zero(sizeof(uint64_t) * n_words), rank = dev_alloc(sizeof(uint64_t) * (n_words + 1));
+      Buf okey = dev_alloc(sizeof(uint64_t) * ord_cap), orow = dev_alloc(sizeof(uint32_t) * ord_cap), used = dev_alloc_zero(sizeof(uint32_t) * (ord_cap / 1024 + 2));
+      Buf ctr = dev_alloc_zero(16), fl2 = dev_alloc_zero(16);
+      DirectJoinTable dt; dt.bits = bits->as<unsigned long long>(); dt.rank = rank->as<unsigned long long>(); dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>();
+      dt.chunk_used = used->as<unsigned int>(); dt.counter = ctr->as<unsigned int>(); dt.flags = fl2->as<unsigned int>(); dt.acc = nullptr; dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)ord_cap;
       k::fused_direct_build(cb.shape, cb.args, dt, find_static_shape(cb.shape));
-      uint32_t f2[2] = {0, 0};
+      nb = k::direct_rank(dt, rank->as<uint64_t>());              // synchronises: flags and the ordinal counter are final too
+      uint32_t f2[2] = {0, 0}, n_used = 0;
       d2h_sync(f2, fl2->ptr, 8);
       if (f2[0]) return no("build keys are not unique");
       PLX_REQUIRE(!f2[1], PLX_ERR_INVALID, "direct join build: ordinal overflow");
-      uint32_t n_used = 0;
       d2h_sync(&n_used, ctr->ptr, 4);
-      const int64_t n_ord_used = (int64_t)std::min<uint64_t>(n_used, ord_cap);
+      const int64_t n_slots = (int64_t)nb, s1 = std::max<int64_t>(n_slots, 1);
+      Buf skey = dev_alloc(sizeof(uint64_t) * (size_t)s1), srow = dev_alloc(sizeof(uint32_t) * (size_t)s1);
+      k::direct_place(dt, (int64_t)std::min<uint64_t>(n_used, ord_cap), skey->as<uint64_t>(), srow->as<uint32_t>());
+      Buf acc2 = dev_alloc(sizeof(uint64_t) * (size_t)s1 * cp.shape.n_aggs);
+      k::init_agg_cells(acc2->as<uint64_t>(), s1, cp.shape);   // LEN = 0: build rows no probe row matched never show up
+      dt.ord_key = skey->as<unsigned long long>(); dt.ord_row = srow->as<unsigned int>(); dt.acc = acc2->as<unsigned long long>();
       k::fused_direct_probe_agg(cp.shape, cp.args, dt, probe_static_id);
-      G = k::direct_agg_compact(dt, n_ord_used, r.n_aggs, len_idx, nullptr, nullptr, nullptr);
-      const int64_t g1 = std::max<int64_t>(G, 1);
+      // one compaction pass into buffers sized for every slot (G <= n_slots)
+      r.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)s1);
+      r.acc = dev_alloc(sizeof(uint64_t) * (size_t)s1 * r.n_aggs);
+      rows->values = dev_alloc(values_bytes(PLX_U32, s1));
+      G = n_slots ? k::direct_agg_compact(dt, n_slots, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>()) : 0;
       r.n_groups = G;
-      r.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)g1);
-      r.acc = dev_alloc(sizeof(uint64_t) * (size_t)g1 * r.n_aggs);
-      rows->len = G; rows->values = dev_alloc(values_bytes(PLX_U32, g1));
-      if (G) k::direct_agg_compact(dt, n_ord_used, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
+      rows->len = G;
       plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " direct-address table range=" +
-                   std::to_string(range) + " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+probe_agg, aggs=" +
+                   std::to_string(range) + " (bitmap + rank) unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+probe_agg, aggs=" +
                    std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
       done = true;
     }
   }
+  if (!done && B->height > 0) { std::vector<uint64_t> host(kMaxAggs, 0); k::fused_regagg(cnt.shape, cnt.args, find_static_shape(cnt.shape), host.data()); nb = host[0]; }
   if (!done) {
   const int log2_cap = std::max(4, ceil_log2_u64(std::max<uint64_t>(nb, 1) * 2));
   const uint64_t cap = 1ull << log2_cap;

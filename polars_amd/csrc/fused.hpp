@@ -245,19 +245,28 @@ struct JoinAggTable {
 };
 
 // Direct-address ("perfect hash") variant of the fused join -> aggregate table, used when the build
-// key range is small (max - min + 1 <= a few x the build rows, e.g. TPC-H orderkeys): dir[key - kmin]
-// holds the ordinal of the build row, so probes of a key-ordered probe side are sequential reads
-// instead of one ~128-B fabric transfer per random probe.  ord_key / ord_row / acc are indexed by ordinal.
+// key range is small (max - min + 1 <= a few x the build rows, e.g. TPC-H orderkeys).  One BIT per key of the
+// range says whether a build row with that key passed the build predicate; rank[w] = number of set bits
+// before word w, so slot(key) = rank[w] + popc(bits[w] below the key's bit) numbers the build rows in key
+// order.  bits + rank are range/8 + range/8 bytes (150 MB for the 6e8 TPC-H SF100 orderkeys: resident in the
+// 256 MB Infinity Cache), where one u32 per key was 2.4 GB to memset and to miss in.
+//   build : the scan appends (key, row) pairs in per-wave ordinal chunks and sets the key's bit (a bit that was
+//           already set = duplicate build key -> the caller falls back);
+//   rank  : popcount per word -> device exclusive scan;
+//   place : pairs move to their slot (slot_key / slot_row, key order);
+//   probe : bit test + rank -> the row's aggregates land in acc[slot].
 struct DirectJoinTable {
-  unsigned int* dir;             // [range] ordinal or kNoRow32
-  unsigned long long* ord_key;   // [n_build_passing]
-  unsigned int* ord_row;         // [n_build_passing]
-  unsigned int* counter;         // [0] next ordinal
+  unsigned long long* bits;      // [range / 64 + 1]
+  const unsigned long long* rank; // [range / 64 + 2] exclusive prefix of popcounts (valid after the rank step)
+  unsigned long long* ord_key;   // build: pair list [n_ord]; probe / compact: slot_key [n_slots]
+  unsigned int* ord_row;         // same, build row
+  unsigned int* chunk_used;      // [n_ord / kOrdChunk + 1] ordinals handed out of each reserved chunk
+  unsigned int* counter;         // [0] next ordinal chunk base
   unsigned int* flags;           // [0] duplicate build key, [1] ordinal overflow
-  unsigned long long* acc;       // [n_build_passing * n_aggs]
+  unsigned long long* acc;       // [n_slots * n_aggs] (probe)
   long long kmin;
   unsigned long long range;
-  unsigned int n_ord;            // capacity of the ordinal arrays
+  unsigned int n_ord;            // capacity of the pair list
 };
 
 // Direct-address aggregation (dense keys in [key_min, key_min + n_groups)): acc[(G+1)*n_aggs],

@@ -310,11 +310,18 @@ struct ProbeAggSink {
 // and sub-allocates from them (one atomic per wave-row on a single counter word took 26 ms for the 1.5e8-row
 // TPC-H orders scan; ~12 k atomics this way).  Unused tails of chunks stay empty (LEN cell 0).
 constexpr unsigned int kOrdChunk = 1024;
+// slot of key index idx (its bit is set in `word` = bits[idx >> 6]): build rows numbered in key order
+__device__ __forceinline__ unsigned long long direct_slot(const DirectJoinTable& t, unsigned long long idx, unsigned long long word) {
+  return t.rank[idx >> 6] + (unsigned long long)__popcll(word & ((1ull << (idx & 63)) - 1ull));
+}
 struct DirectBuildSink {
   using Params = DirectJoinTable;
   unsigned int next = 0, end = 0;   // wave-uniform
   template <class S> __device__ __forceinline__ void init(const S&, const Params&) { next = 0; end = 0; }
-  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  __device__ __forceinline__ void close_chunk(const Params& p) {
+    if (end != 0 && lane_id() == 0) p.chunk_used[(end - kOrdChunk) / kOrdChunk] = next - (end - kOrdChunk);
+  }
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params& p) { close_chunk(p); }
   template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
@@ -323,6 +330,7 @@ struct DirectBuildSink {
       if (m == 0) continue;
       const unsigned int need = (unsigned int)popc64(m);
       if (next + need > end) {   // wave-uniform: reserve a fresh chunk
+        close_chunk(p);
         unsigned int base = 0;
         if (lane_id() == 0) base = atomicAdd(p.counter, kOrdChunk);
         next = __shfl(base, 0, 64);
@@ -336,8 +344,9 @@ struct DirectBuildSink {
       const uint64_t idx = key - (uint64_t)p.kmin;       // < range by construction (kmin/kmax cover the whole build column)
       p.ord_key[ord] = key;
       p.ord_row[ord] = (unsigned int)(row0 + r);
-      const unsigned int old = atomicCAS(&p.dir[idx], kNoRow32, ord);
-      if (old != kNoRow32) p.flags[0] = 1u;               // duplicate build key -> the caller falls back
+      const unsigned long long bit = 1ull << (idx & 63);
+      const unsigned long long old = atomicOr(&p.bits[idx >> 6], bit);
+      if (old & bit) p.flags[0] = 1u;                     // duplicate build key -> the caller falls back
     }
   }
 };
@@ -352,9 +361,9 @@ struct DirectProbeAggSink {
       if (!pass[r] || !((rf.getv(sh.key) >> r) & 1)) continue;
       const uint64_t idx = rf.get(r, sh.key) - (uint64_t)p.kmin;
       if (idx >= p.range) continue;
-      const unsigned int ord = p.dir[idx];
-      if (ord == kNoRow32) continue;
-      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)ord * sh.n_aggs);
+      const unsigned long long w = p.bits[idx >> 6];
+      if (!((w >> (idx & 63)) & 1ull)) continue;
+      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)direct_slot(p, idx, w) * sh.n_aggs);
     }
   }
 };

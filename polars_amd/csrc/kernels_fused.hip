@@ -25,6 +25,7 @@
 #include "fused_sinks.hpp"
 #include "kernels.hpp"
 #include "kernels_fused.hpp"
+#include "scan.hpp"
 #include "jit.hpp"
 #include <cstring>
 #include <vector>
@@ -308,6 +309,39 @@ void fused_direct_probe_agg(const Shape& sh, const Args& args, const DirectJoinT
   }
   PLX_HIP(hipGetLastError());
 }
+// rank step of the direct-address join table: popcount per bitmap word (scanned by exclusive_scan_u32)
+__global__ __launch_bounds__(kBlock) void direct_popc_kernel(const unsigned long long* __restrict__ bits, int64_t n_words, uint32_t* __restrict__ counts) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) counts[i] = (uint32_t)__popcll(bits[i]);
+}
+// place step: the (key, row) pairs appended by the build scan move to their key-ordered slot
+__global__ __launch_bounds__(kBlock) void direct_place_kernel(DirectJoinTable t, int64_t n_used, unsigned long long* __restrict__ slot_key, unsigned int* __restrict__ slot_row) {
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_used; o += (int64_t)gridDim.x * blockDim.x) {
+    if ((unsigned int)(o % kOrdChunk) >= t.chunk_used[o / kOrdChunk]) continue;   // unused tail of a reserved chunk
+    const unsigned long long key = t.ord_key[o];
+    const unsigned long long idx = key - (unsigned long long)t.kmin;
+    const unsigned long long s = direct_slot(t, idx, t.bits[idx >> 6]);
+    slot_key[s] = key;
+    slot_row[s] = t.ord_row[o];
+  }
+}
+uint64_t direct_rank(const DirectJoinTable& t, uint64_t* rank_out) {
+  const int64_t n_words = (int64_t)(t.range / 64 + 1);
+  Buf counts = dev_alloc(sizeof(uint32_t) * (size_t)n_words);
+  ProfileScope ps("direct_rank", (uint64_t)n_words * 20, (uint64_t)n_words);
+  hipLaunchKernelGGL(direct_popc_kernel, dim3(grid_for(n_words, kBlock * 4)), dim3(kBlock), 0, stream(), t.bits, n_words, counts->as<uint32_t>());
+  PLX_HIP(hipGetLastError());
+  exclusive_scan_u32(counts->as<uint32_t>(), rank_out, n_words);
+  uint64_t total = 0;
+  d2h_sync(&total, rank_out + n_words, 8);
+  return total;
+}
+void direct_place(const DirectJoinTable& t, int64_t n_used, uint64_t* slot_key, uint32_t* slot_row) {
+  if (n_used == 0) return;
+  ProfileScope ps("direct_place", (uint64_t)n_used * 24, (uint64_t)n_used);
+  hipLaunchKernelGGL(direct_place_kernel, dim3(grid_for(n_used, kBlock * 2)), dim3(kBlock), 0, stream(), t, n_used, (unsigned long long*)slot_key, (unsigned int*)slot_row);
+  PLX_HIP(hipGetLastError());
+}
+
 __global__ __launch_bounds__(kBlock) void direct_agg_compact_kernel(DirectJoinTable t, int64_t n_ord, int n_aggs, int len_idx, unsigned long long* __restrict__ counter,
                                                                     unsigned long long* __restrict__ out_keys, unsigned int* __restrict__ out_rows,
                                                                     unsigned long long* __restrict__ out_acc) {
