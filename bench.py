@@ -73,7 +73,7 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
                         variants={"tpch_q1_sf100_order_by": step_sorted})
     if name == "q3":
         no = (rows // 4) if rows else SF100_ORDERS
-        orders, li = datagen.orders_lineitem_device(no, seed=seed)
+        orders, li = datagen.orders_lineitem_device(no, seed=seed, ordered=os.environ.get("PLX_Q3_SHUFFLED", "0") != "1")   # dbgen row order by default
         L = datagen.frame_from_torch(pl, li, datagen.LINEITEM_Q3_COLS)
         O = datagen.frame_from_torch(pl, orders, datagen.ORDERS_Q3_COLS)
         torch.cuda.synchronize()

@@ -358,6 +358,49 @@ int plx_frame_dtypes(plx_frame f, int32_t* dtypes_out) {
 int plx_frame_to_host(plx_frame f, void* const* values_out, uint8_t* const* validity_out, int32_t* has_validity_out) {
   PLX_TRY
   FramePtr fr = get_frame(f);
+  // small results (a group-by / top-k output): one pack launch + ONE page-locked D2H copy instead of a staged pageable copy per buffer
+  {
+    struct Piece { const void* src; void* dst; size_t bytes; };
+    std::vector<Piece> pieces;
+    size_t total = 0;
+    bool ok = pinned_bounce() != nullptr;
+    for (size_t i = 0; ok && i < fr->cols.size(); i++) {
+      const ColumnPtr& c = fr->cols[i];
+      if (!(c->values || c->len == 0)) { ok = false; break; }
+      const size_t vb = c->dtype == PLX_BOOL ? (size_t)((c->len + 7) / 8) : (size_t)c->len * dtype_width(c->dtype);
+      const size_t nb = (size_t)((c->len + 7) / 8);
+      if (values_out && values_out[i] && vb) { pieces.push_back({c->values->ptr, values_out[i], vb}); total += (vb + 15) & ~size_t(15); }
+      if (validity_out && validity_out[i] && nb && c->validity) { pieces.push_back({c->validity->ptr, validity_out[i], nb}); total += (nb + 15) & ~size_t(15); }
+      if (total > kBounceBytes) ok = false;
+    }
+    if (ok && !pieces.empty()) {
+      Buf staging = dev_alloc(total);
+      std::vector<size_t> offs(pieces.size());
+      size_t at = 0;
+      for (size_t j = 0; j < pieces.size(); j++) { offs[j] = at; at += (pieces[j].bytes + 15) & ~size_t(15); }
+      for (size_t base = 0; base < pieces.size(); base += k::kPackMax) {
+        k::PackBatch b{}; b.n = (int)std::min<size_t>(k::kPackMax, pieces.size() - base);
+        for (int j = 0; j < b.n; j++) { b.src[j] = pieces[base + j].src; b.bytes[j] = (uint32_t)pieces[base + j].bytes; b.off[j] = (uint32_t)offs[base + j]; }
+        k::pack_buffers(b, staging->ptr);
+      }
+      std::lock_guard<std::mutex> lk(bounce_mutex());
+      uint8_t* host = reinterpret_cast<uint8_t*>(pinned_bounce());
+      PLX_HIP(hipMemcpyAsync(host, staging->ptr, total, hipMemcpyDeviceToHost, stream()));
+      PLX_HIP(hipStreamSynchronize(stream()));
+      for (size_t j = 0; j < pieces.size(); j++) memcpy(pieces[j].dst, host + offs[j], pieces[j].bytes);
+      for (size_t i = 0; i < fr->cols.size(); i++) {
+        const ColumnPtr& c = fr->cols[i];
+        const size_t nb = (size_t)((c->len + 7) / 8);
+        if (validity_out && validity_out[i] && nb && !c->validity) memset(validity_out[i], 0xff, nb);
+        if (has_validity_out) has_validity_out[i] = c->validity ? 1 : 0;
+      }
+      return PLX_OK;
+    }
+    if (ok && pieces.empty() && !fr->cols.empty()) {   // zero-row frame: nothing to copy
+      for (size_t i = 0; i < fr->cols.size(); i++) if (has_validity_out) has_validity_out[i] = fr->cols[i]->validity ? 1 : 0;
+      return PLX_OK;
+    }
+  }
   for (size_t i = 0; i < fr->cols.size(); i++) {
     const ColumnPtr& c = fr->cols[i];
     PLX_REQUIRE(c->values || c->len == 0, PLX_ERR_INVALID, "placeholder column has no data");

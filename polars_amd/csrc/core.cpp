@@ -138,8 +138,22 @@ void pool_trim() {
 }
 
 // --------------------------------------------------------------- helpers ----
+void* pinned_bounce() {
+  static void* buf = [] { void* p = nullptr; if (hipHostMalloc(&p, kBounceBytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; } return p; }();
+  return buf;
+}
+static std::mutex g_bounce_mu;
+std::mutex& bounce_mutex() { return g_bounce_mu; }
 void d2h_sync(void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return;
+  void* b = bytes <= 4096 ? pinned_bounce() : nullptr;
+  if (b) {
+    std::lock_guard<std::mutex> lk(g_bounce_mu);
+    PLX_HIP(hipMemcpyAsync(b, src, bytes, hipMemcpyDeviceToHost, stream()));
+    PLX_HIP(hipStreamSynchronize(stream()));
+    memcpy(dst, b, bytes);
+    return;
+  }
   PLX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream()));
   PLX_HIP(hipStreamSynchronize(stream()));
 }

@@ -145,7 +145,11 @@ int profile_fetch(plx_profile_record* out, int cap);
 void profile_clear();
 
 // small host<->device helpers (async on the current stream + sync where noted)
-void d2h_sync(void* dst, const void* src, size_t bytes);
+void d2h_sync(void* dst, const void* src, size_t bytes);   // small copies go through a page-locked bounce buffer (one DMA, no staged pageable path)
+// library-owned page-locked host buffer of kBounceBytes (nullptr if it could not be allocated); one user at a time (the library stream)
+constexpr size_t kBounceBytes = size_t(1) << 20;
+void* pinned_bounce();
+std::mutex& bounce_mutex();
 void h2d_async(void* dst, const void* src, size_t bytes);  // src must stay alive until sync
 void h2d_sync_pinned(void* dst, const void* src, size_t bytes);  // large buffers: page-locked in place, one DMA; synchronises
 

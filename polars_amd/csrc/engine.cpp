@@ -1062,19 +1062,19 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       const size_t n_words = (size_t)(range / 64 + 1);
       Buf bits = dev_alloc_zero(sizeof(uint64_t) * n_words), rank = dev_alloc(sizeof(uint64_t) * (n_words + 1));
       Buf okey = dev_alloc(sizeof(uint64_t) * ord_cap), orow = dev_alloc(sizeof(uint32_t) * ord_cap), used = dev_alloc_zero(sizeof(uint32_t) * (ord_cap / 1024 + 2));
-      Buf ctr = dev_alloc_zero(16), fl2 = dev_alloc_zero(16);
+      Buf meta = dev_alloc_zero(32);   // [0] ordinal counter, [2..3] flags, [4..5] pairs placed (u64)
       DirectJoinTable dt; dt.bits = bits->as<unsigned long long>(); dt.rank = rank->as<unsigned long long>(); dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>();
-      dt.chunk_used = used->as<unsigned int>(); dt.counter = ctr->as<unsigned int>(); dt.flags = fl2->as<unsigned int>(); dt.acc = nullptr; dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)ord_cap;
+      dt.chunk_used = used->as<unsigned int>(); dt.counter = meta->as<unsigned int>(); dt.flags = meta->as<unsigned int>() + 2; dt.acc = nullptr; dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)ord_cap;
       k::fused_direct_build(cb.shape, cb.args, dt, find_static_shape(cb.shape));
       nb = k::direct_rank(dt, rank->as<uint64_t>());              // synchronises: flags and the ordinal counter are final too
-      uint32_t f2[2] = {0, 0}, n_used = 0;
-      d2h_sync(f2, fl2->ptr, 8);
-      if (f2[0]) return no("build keys are not unique");
-      PLX_REQUIRE(!f2[1], PLX_ERR_INVALID, "direct join build: ordinal overflow");
-      d2h_sync(&n_used, ctr->ptr, 4);
+      uint32_t m4[4] = {0, 0, 0, 0};
+      d2h_sync(m4, meta->ptr, 16);
+      PLX_REQUIRE(!m4[3], PLX_ERR_INVALID, "direct join build: ordinal overflow");
+      const uint32_t n_used = m4[0];
       const int64_t n_slots = (int64_t)nb, s1 = std::max<int64_t>(n_slots, 1);
       Buf skey = dev_alloc(sizeof(uint64_t) * (size_t)s1), srow = dev_alloc(sizeof(uint32_t) * (size_t)s1);
-      k::direct_place(dt, (int64_t)std::min<uint64_t>(n_used, ord_cap), skey->as<uint64_t>(), srow->as<uint32_t>());
+      uint64_t* n_pairs_dev = meta->as<uint64_t>() + 2;
+      k::direct_place(dt, (int64_t)std::min<uint64_t>(n_used, ord_cap), skey->as<uint64_t>(), srow->as<uint32_t>(), n_pairs_dev);
       Buf acc2 = dev_alloc(sizeof(uint64_t) * (size_t)s1 * cp.shape.n_aggs);
       k::init_agg_cells(acc2->as<uint64_t>(), s1, cp.shape);   // LEN = 0: build rows no probe row matched never show up
       dt.ord_key = skey->as<unsigned long long>(); dt.ord_row = srow->as<unsigned int>(); dt.acc = acc2->as<unsigned long long>();
@@ -1084,6 +1084,9 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       r.acc = dev_alloc(sizeof(uint64_t) * (size_t)s1 * r.n_aggs);
       rows->values = dev_alloc(values_bytes(PLX_U32, s1));
       G = n_slots ? k::direct_agg_compact(dt, n_slots, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>()) : 0;
+      uint64_t pairs = 0;
+      d2h_sync(&pairs, n_pairs_dev, 8);          // the stream is idle after the compaction's own sync: no extra wait
+      if (pairs != nb) return no("build keys are not unique");   // two pairs shared a bit: the hash-table pipeline handles (and reports) duplicates
       r.n_groups = G;
       rows->len = G;
       plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " direct-address table range=" +

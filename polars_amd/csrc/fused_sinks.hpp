@@ -344,9 +344,9 @@ struct DirectBuildSink {
       const uint64_t idx = key - (uint64_t)p.kmin;       // < range by construction (kmin/kmax cover the whole build column)
       p.ord_key[ord] = key;
       p.ord_row[ord] = (unsigned int)(row0 + r);
-      const unsigned long long bit = 1ull << (idx & 63);
-      const unsigned long long old = atomicOr(&p.bits[idx >> 6], bit);
-      if (old & bit) p.flags[0] = 1u;                     // duplicate build key -> the caller falls back
+      // fire-and-forget (no-return) atomic: a duplicate build key shows up as popcount(bits) < number of pairs,
+      // which the place step counts (the caller then falls back)
+      __hip_atomic_fetch_or(&p.bits[idx >> 6], 1ull << (idx & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 };

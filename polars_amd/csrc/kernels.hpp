@@ -32,6 +32,10 @@ void bitmap_blit(uint64_t* dst, int64_t dst_off, const uint64_t* src, int64_t n_
 // out[i] = pattern (width 1/2/4/8 bytes)
 void fill(int width, void* out, uint64_t pattern, int64_t n);
 void fill_iota_u32(uint32_t* out, int64_t n);
+// result download of small frames: up to kPackMax device buffers are copied into one staging buffer by ONE launch
+constexpr int kPackMax = 32;
+struct PackBatch { const void* src[kPackMax]; uint32_t bytes[kPackMax]; uint32_t off[kPackMax]; int n; };
+void pack_buffers(const PackBatch& b, void* staging);
 
 // ---- reductions (kernels_reduce.hip) ------------------------------------------
 struct ReduceResult {

@@ -407,5 +407,17 @@ void fill_iota_u32(uint32_t* out, int64_t n) {
   PLX_HIP(hipGetLastError());
 }
 
+__global__ __launch_bounds__(kBlock) void pack_kernel(PackBatch b, uint8_t* __restrict__ out) {
+  const int j = blockIdx.x;
+  const uint8_t* src = reinterpret_cast<const uint8_t*>(b.src[j]);
+  uint8_t* dst = out + b.off[j];
+  for (uint32_t i = threadIdx.x; i < b.bytes[j]; i += kBlock) dst[i] = src[i];
+}
+void pack_buffers(const PackBatch& b, void* staging) {
+  if (b.n == 0) return;
+  hipLaunchKernelGGL(pack_kernel, dim3(b.n), dim3(kBlock), 0, stream(), b, reinterpret_cast<uint8_t*>(staging));
+  PLX_HIP(hipGetLastError());
+}
+
 }  // namespace k
 }  // namespace plx

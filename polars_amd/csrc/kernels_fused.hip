@@ -314,7 +314,10 @@ __global__ __launch_bounds__(kBlock) void direct_popc_kernel(const unsigned long
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) counts[i] = (uint32_t)__popcll(bits[i]);
 }
 // place step: the (key, row) pairs appended by the build scan move to their key-ordered slot
-__global__ __launch_bounds__(kBlock) void direct_place_kernel(DirectJoinTable t, int64_t n_used, unsigned long long* __restrict__ slot_key, unsigned int* __restrict__ slot_row) {
+// n_pairs[0] += pairs placed: fewer set bits than pairs = duplicate build keys
+__global__ __launch_bounds__(kBlock) void direct_place_kernel(DirectJoinTable t, int64_t n_used, unsigned long long* __restrict__ slot_key, unsigned int* __restrict__ slot_row,
+                                                              unsigned long long* __restrict__ n_pairs) {
+  unsigned int mine = 0;
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_used; o += (int64_t)gridDim.x * blockDim.x) {
     if ((unsigned int)(o % kOrdChunk) >= t.chunk_used[o / kOrdChunk]) continue;   // unused tail of a reserved chunk
     const unsigned long long key = t.ord_key[o];
@@ -322,7 +325,10 @@ __global__ __launch_bounds__(kBlock) void direct_place_kernel(DirectJoinTable t,
     const unsigned long long s = direct_slot(t, idx, t.bits[idx >> 6]);
     slot_key[s] = key;
     slot_row[s] = t.ord_row[o];
+    mine++;
   }
+  const uint64_t w = wave_sum_u64(mine);
+  if (lane_id() == 0 && w) atomicAdd(n_pairs, (unsigned long long)w);
 }
 uint64_t direct_rank(const DirectJoinTable& t, uint64_t* rank_out) {
   const int64_t n_words = (int64_t)(t.range / 64 + 1);
@@ -335,10 +341,11 @@ uint64_t direct_rank(const DirectJoinTable& t, uint64_t* rank_out) {
   d2h_sync(&total, rank_out + n_words, 8);
   return total;
 }
-void direct_place(const DirectJoinTable& t, int64_t n_used, uint64_t* slot_key, uint32_t* slot_row) {
+void direct_place(const DirectJoinTable& t, int64_t n_used, uint64_t* slot_key, uint32_t* slot_row, uint64_t* n_pairs_dev) {
   if (n_used == 0) return;
   ProfileScope ps("direct_place", (uint64_t)n_used * 24, (uint64_t)n_used);
-  hipLaunchKernelGGL(direct_place_kernel, dim3(grid_for(n_used, kBlock * 2)), dim3(kBlock), 0, stream(), t, n_used, (unsigned long long*)slot_key, (unsigned int*)slot_row);
+  hipLaunchKernelGGL(direct_place_kernel, dim3(grid_for(n_used, kBlock * 2)), dim3(kBlock), 0, stream(), t, n_used, (unsigned long long*)slot_key, (unsigned int*)slot_row,
+                     (unsigned long long*)n_pairs_dev);
   PLX_HIP(hipGetLastError());
 }
 

@@ -39,7 +39,8 @@ void fused_direct_probe_agg(const fused::Shape& sh, const fused::Args& args, con
 // rank step (popcount per bitmap word + exclusive scan into rank_out[range/64 + 2]); returns the number of set bits (synchronises)
 uint64_t direct_rank(const fused::DirectJoinTable& t, uint64_t* rank_out);
 // place step: pair list (t.ord_key / t.ord_row / t.chunk_used, first n_used ordinals) -> key-ordered slots
-void direct_place(const fused::DirectJoinTable& t, int64_t n_used, uint64_t* slot_key, uint32_t* slot_row);
+// n_pairs_dev[0] (zeroed by the caller) receives the number of pairs placed: more pairs than set bits = duplicate build keys
+void direct_place(const fused::DirectJoinTable& t, int64_t n_used, uint64_t* slot_key, uint32_t* slot_row, uint64_t* n_pairs_dev);
 int64_t direct_agg_compact(const fused::DirectJoinTable& t, int64_t n_ord, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc);
 void fill_u64(uint64_t* p, int64_t n, uint64_t v);
 void init_agg_cells(uint64_t* acc, int64_t n_slots, const fused::Shape& sh);
