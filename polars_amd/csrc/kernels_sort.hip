@@ -108,49 +108,69 @@ __global__ __launch_bounds__(kBlock) void radix_count_kernel(const uint64_t* __r
   block_hist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
+// Stable scatter of one tile.  A round covers kIPT * kBlock keys (key j of lane t = tile_base + round * kIPT * kBlock +
+// j * kBlock + t): every (item j, wave w) pair ranks its 64 keys with ballots and publishes one count per digit; after
+// ONE barrier thread d turns the kIPT * kWaves counts of digit d into exclusive prefixes (order: item-major, then wave =
+// input order) and advances the digit's running output position; after a second barrier every key knows its slot.
+constexpr int kIPT = 4;                          // keys per thread and round
+constexpr int kGroups = kIPT * kWaves;           // (item, wave) pairs of a round, in input order
+static_assert(kItems % kIPT == 0, "a tile is a whole number of rounds");
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint64_t* __restrict__ enc_in, const uint32_t* __restrict__ idx_in, int64_t n, int shift,
                                                                const uint64_t* __restrict__ offsets, uint32_t nblocks, uint64_t* __restrict__ enc_out,
                                                                uint32_t* __restrict__ idx_out) {
-  __shared__ uint64_t running[256];            // next output slot of every digit value for this tile
-  __shared__ unsigned int wave_cnt[kWaves][256];
+  __shared__ uint64_t running[256];              // next output slot of every digit value for this tile
+  __shared__ uint64_t round_base[256];           // running[] as it was at the start of the round
+  __shared__ unsigned int cnt[kGroups][256];     // keys of (item, wave) with the digit (zero between rounds)
+  __shared__ unsigned int pre[kGroups][256];     // exclusive prefix of cnt over the (item, wave) pairs
   const int tid = threadIdx.x, wave = tid >> 6;
   const int64_t base = (int64_t)blockIdx.x * kTile;
   running[tid] = offsets[(uint64_t)tid * nblocks + blockIdx.x];
 #pragma unroll
-  for (int w = 0; w < kWaves; w++) wave_cnt[w][tid] = 0;
+  for (int q = 0; q < kGroups; q++) cnt[q][tid] = 0;
   __syncthreads();
-  for (int r = 0; r < kItems; r++) {
-    const int64_t i = base + (int64_t)r * kBlock + tid;
-    if (base + (int64_t)r * kBlock >= n) break;   // uniform
-    const bool valid = i < n;
-    const uint64_t e = valid ? enc_in[i] : 0ull;
-    const uint32_t idx = valid ? (idx_in ? idx_in[i] : (uint32_t)i) : 0u;
-    const uint32_t d = (uint32_t)((e >> shift) & 255);
-    uint64_t same = ballot(valid);               // lanes of this wave holding the same digit
+  for (int r = 0; r < kItems / kIPT; r++) {
+    const int64_t rbase = base + (int64_t)r * kIPT * kBlock;
+    if (rbase >= n) break;   // uniform
+    uint64_t e[kIPT]; uint32_t idx[kIPT], d[kIPT], rank[kIPT]; bool valid[kIPT];
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
-      const bool bit = (d >> b) & 1;
-      const uint64_t bal = ballot(bit);
-      same &= bit ? bal : ~bal;
+    for (int j = 0; j < kIPT; j++) {
+      const int64_t i = rbase + (int64_t)j * kBlock + tid;
+      valid[j] = i < n;
+      e[j] = valid[j] ? enc_in[i] : 0ull;
+      idx[j] = valid[j] ? (idx_in ? idx_in[i] : (uint32_t)i) : 0u;
     }
-    const uint32_t rank = (uint32_t)prefix_rank(same);
-    if (valid && rank == 0) wave_cnt[wave][d] = (uint32_t)popc64(same);
-    __syncthreads();
-    uint64_t pos = 0;
-    if (valid) {
-      uint32_t before = 0;
-      for (int w = 0; w < wave; w++) before += wave_cnt[w][d];
-      pos = running[d] + before + rank;
+#pragma unroll
+    for (int j = 0; j < kIPT; j++) {
+      d[j] = (uint32_t)((e[j] >> shift) & 255);
+      uint64_t same = ballot(valid[j]);            // lanes of this wave holding the same digit
+#pragma unroll
+      for (int b = 0; b < 8; b++) {
+        const bool bit = (d[j] >> b) & 1;
+        const uint64_t bal = ballot(bit);
+        same &= bit ? bal : ~bal;
+      }
+      rank[j] = (uint32_t)prefix_rank(same);
+      if (valid[j] && rank[j] == 0) cnt[j * kWaves + wave][d[j]] = (uint32_t)popc64(same);
     }
     __syncthreads();
     {
-      uint32_t tot = 0;
+      uint32_t run = 0;
 #pragma unroll
-      for (int w = 0; w < kWaves; w++) { tot += wave_cnt[w][tid]; wave_cnt[w][tid] = 0; }
-      running[tid] += tot;
+      for (int q = 0; q < kGroups; q++) { const uint32_t c = cnt[q][tid]; cnt[q][tid] = 0; pre[q][tid] = run; run += c; }
+      const uint64_t rb = running[tid];
+      round_base[tid] = rb;
+      running[tid] = rb + run;
     }
-    if (valid) { enc_out[pos] = e; idx_out[pos] = idx; }
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kIPT; j++) {
+      if (!valid[j]) continue;
+      const uint64_t pos = round_base[d[j]] + pre[j * kWaves + wave][d[j]] + rank[j];
+      enc_out[pos] = e[j];
+      idx_out[pos] = idx[j];
+    }
+    // no third barrier: the next round's leaders write cnt (already zeroed), its scan step writes pre / round_base only after
+    // the next barrier, which every lane reaches after finishing the reads above
   }
 }
 
