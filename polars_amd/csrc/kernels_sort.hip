@@ -108,40 +108,65 @@ __global__ __launch_bounds__(kBlock) void radix_count_kernel(const uint64_t* __r
   block_hist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// Stable scatter of one tile.  A round covers kIPT * kBlock keys (key j of lane t = tile_base + round * kIPT * kBlock +
-// j * kBlock + t): every (item j, wave w) pair ranks its 64 keys with ballots and publishes one count per digit; after
-// ONE barrier thread d turns the kIPT * kWaves counts of digit d into exclusive prefixes (order: item-major, then wave =
-// input order) and advances the digit's running output position; after a second barrier every key knows its slot.
-constexpr int kIPT = 4;                          // keys per thread and round
+// Stable scatter of one tile, staged through LDS so that HBM sees whole runs instead of 12-byte fragments:
+//   0. the tile's keys are loaded once into registers and histogrammed (LDS atomics) -> local start of every digit value;
+//   1. ranking rounds of kIPT * kBlock keys (key j of lane t = tile_base + round * kIPT * kBlock + j * kBlock + t): every
+//      (item j, wave w) pair ranks its 64 keys with ballots (match-any on the digit) and publishes one count per digit;
+//      after ONE barrier thread d turns the kIPT * kWaves counts of digit d into exclusive prefixes (item-major, then
+//      wave = input order) and advances the digit's running position; after a second barrier every key knows its slot
+//      in the LDS copy of the tile, which ends up sorted by digit with ties in input order;
+//   2. the LDS copy is written out linearly: neighbouring lanes hold neighbouring keys of the same digit run, so the
+//      stores of a run (4096 / 256 = 16 keys = 128 B of codes on average) coalesce.
+constexpr int kIPT = 4;                          // keys per thread and ranking round
 constexpr int kGroups = kIPT * kWaves;           // (item, wave) pairs of a round, in input order
 static_assert(kItems % kIPT == 0, "a tile is a whole number of rounds");
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint64_t* __restrict__ enc_in, const uint32_t* __restrict__ idx_in, int64_t n, int shift,
                                                                const uint64_t* __restrict__ offsets, uint32_t nblocks, uint64_t* __restrict__ enc_out,
                                                                uint32_t* __restrict__ idx_out) {
-  __shared__ uint64_t running[256];              // next output slot of every digit value for this tile
-  __shared__ uint64_t round_base[256];           // running[] as it was at the start of the round
-  __shared__ unsigned int cnt[kGroups][256];     // keys of (item, wave) with the digit (zero between rounds)
-  __shared__ unsigned int pre[kGroups][256];     // exclusive prefix of cnt over the (item, wave) pairs
-  const int tid = threadIdx.x, wave = tid >> 6;
+  __shared__ uint64_t s_enc[kTile];              // the tile, sorted by digit (32 KB)
+  __shared__ uint32_t s_idx[kTile];              // 16 KB
+  __shared__ uint64_t gbase[256];                // global slot of the digit's first key of this tile minus its local start
+  __shared__ unsigned int hist[256];             // tile histogram, then the running local position of every digit value
+  __shared__ unsigned int round_base[256];       // hist[] as it was at the start of the round
+  __shared__ uint8_t cnt[kGroups][256];          // keys of (item, wave) with the digit (<= 64; zero between rounds)
+  __shared__ uint16_t pre[kGroups][256];         // exclusive prefix of cnt over the (item, wave) pairs (<= kIPT * kBlock)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t base = (int64_t)blockIdx.x * kTile;
-  running[tid] = offsets[(uint64_t)tid * nblocks + blockIdx.x];
+  uint64_t e[kItems]; uint32_t idx[kItems];
+  hist[tid] = 0;
 #pragma unroll
   for (int q = 0; q < kGroups; q++) cnt[q][tid] = 0;
+#pragma unroll
+  for (int k = 0; k < kItems; k++) {
+    const int64_t i = base + (int64_t)k * kBlock + tid;
+    e[k] = i < n ? enc_in[i] : 0ull;
+    idx[k] = i < n ? (idx_in ? idx_in[i] : (uint32_t)i) : 0u;
+  }
   __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kItems; k++) if (base + (int64_t)k * kBlock + tid < n) atomicAdd(&hist[(int)((e[k] >> shift) & 255)], 1u);
+  __syncthreads();
+  if (wave == 0) {   // exclusive scan of the 256 counts: 4 per lane + a wave scan of the lane totals
+    unsigned int v[4], tot = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) { v[c] = hist[lane * 4 + c]; tot += v[c]; }
+    unsigned int incl = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+    unsigned int run = incl - tot;
+#pragma unroll
+    for (int c = 0; c < 4; c++) { hist[lane * 4 + c] = run; run += v[c]; }
+  }
+  __syncthreads();
+  gbase[tid] = offsets[(uint64_t)tid * nblocks + blockIdx.x] - hist[tid];
+#pragma unroll
   for (int r = 0; r < kItems / kIPT; r++) {
-    const int64_t rbase = base + (int64_t)r * kIPT * kBlock;
-    if (rbase >= n) break;   // uniform
-    uint64_t e[kIPT]; uint32_t idx[kIPT], d[kIPT], rank[kIPT]; bool valid[kIPT];
+    uint32_t d[kIPT], rank[kIPT]; bool valid[kIPT];
 #pragma unroll
     for (int j = 0; j < kIPT; j++) {
-      const int64_t i = rbase + (int64_t)j * kBlock + tid;
-      valid[j] = i < n;
-      e[j] = valid[j] ? enc_in[i] : 0ull;
-      idx[j] = valid[j] ? (idx_in ? idx_in[i] : (uint32_t)i) : 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < kIPT; j++) {
-      d[j] = (uint32_t)((e[j] >> shift) & 255);
+      const int k = r * kIPT + j;
+      valid[j] = base + (int64_t)k * kBlock + tid < n;
+      d[j] = (uint32_t)((e[k] >> shift) & 255);
       uint64_t same = ballot(valid[j]);            // lanes of this wave holding the same digit
 #pragma unroll
       for (int b = 0; b < 8; b++) {
@@ -150,27 +175,38 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint64_t* _
         same &= bit ? bal : ~bal;
       }
       rank[j] = (uint32_t)prefix_rank(same);
-      if (valid[j] && rank[j] == 0) cnt[j * kWaves + wave][d[j]] = (uint32_t)popc64(same);
+      if (valid[j] && rank[j] == 0) cnt[j * kWaves + wave][d[j]] = (uint8_t)popc64(same);
     }
     __syncthreads();
     {
       uint32_t run = 0;
 #pragma unroll
-      for (int q = 0; q < kGroups; q++) { const uint32_t c = cnt[q][tid]; cnt[q][tid] = 0; pre[q][tid] = run; run += c; }
-      const uint64_t rb = running[tid];
+      for (int q = 0; q < kGroups; q++) { const uint32_t c = cnt[q][tid]; cnt[q][tid] = 0; pre[q][tid] = (uint16_t)run; run += c; }
+      const unsigned int rb = hist[tid];
       round_base[tid] = rb;
-      running[tid] = rb + run;
+      hist[tid] = rb + run;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kIPT; j++) {
       if (!valid[j]) continue;
-      const uint64_t pos = round_base[d[j]] + pre[j * kWaves + wave][d[j]] + rank[j];
-      enc_out[pos] = e[j];
-      idx_out[pos] = idx[j];
+      const uint32_t pos = round_base[d[j]] + pre[j * kWaves + wave][d[j]] + rank[j];
+      s_enc[pos] = e[r * kIPT + j];
+      s_idx[pos] = idx[r * kIPT + j];
     }
-    // no third barrier: the next round's leaders write cnt (already zeroed), its scan step writes pre / round_base only after
-    // the next barrier, which every lane reaches after finishing the reads above
+    // no third barrier: the next round's leaders write cnt (already zeroed); pre / round_base are rewritten only after the next
+    // round's first barrier, which every lane reaches after the reads above
+  }
+  __syncthreads();
+  const int64_t tile_n = n - base < kTile ? n - base : kTile;
+#pragma unroll 4
+  for (int k = 0; k < kItems; k++) {
+    const int p = k * kBlock + tid;
+    if (p >= tile_n) break;
+    const uint64_t ev = s_enc[p];
+    const uint64_t out = gbase[(int)((ev >> shift) & 255)] + (uint64_t)p;
+    enc_out[out] = ev;
+    idx_out[out] = s_idx[p];
   }
 }
 

@@ -362,7 +362,7 @@ def test_dist_hip_local_ops_single_rank(pl, orc):
     assert counts == np.bincount(exp, minlength=8).tolist()
     assert np.array_equal(exp[perm.cpu().numpy()], np.sort(exp))
     res = pdist.groupby_agg(ops, {"key": tk}, {"v": tv, "x": tx}, [("s", "v", "sum"), ("m", "x", "mean"), ("mn", "v", "min"), ("n", "", "len")], mode="gather")
-    order = torch.argsort(res["key"]).cpu().numpy()
+    order = np.argsort(res["key"].cpu().numpy())          # host-side: torch's device sort loads slowly on a cold box
     uk, inv = np.unique(key, return_inverse=True)
     assert np.array_equal(res["key"].cpu().numpy()[order], uk)
     assert np.array_equal(res["s"].cpu().numpy()[order], np.bincount(inv, v).astype(np.int64))

@@ -118,32 +118,30 @@ def test_series_sort_and_top_k(pl):
 
 
 def test_large_sort_properties(pl):
-    """Full-size style property check (no oracle): output is a permutation and the keys are non-decreasing.  Only plain
-    elementwise / reduction torch ops (cold GPU boxes load exotic torch kernels very slowly)."""
-    import torch
-    n = 30_000_000
-    g = torch.Generator(device="cuda"); g.manual_seed(5)
-    k = torch.randint(-2 ** 62, 2 ** 62, (n,), device="cuda", dtype=torch.int64, generator=g)
-    s = pl.Series.from_torch("k", k)
+    """Size-independent properties at 2e7 rows (no oracle): the output is a permutation, keys come out non-decreasing and
+    ties keep input order.  Host side is numpy only (torch kernels load very slowly on a cold GPU box)."""
+    n = 20_000_000
+    rng = np.random.default_rng(5)
+    k = rng.integers(-2 ** 62, 2 ** 62, n, dtype=np.int64)
+    s = pl.Series("k", k)
     idxs = s.arg_sort()
     assert "passes=8" in pl.last_plan(), pl.last_plan()
-    idx = idxs.to_torch().to(torch.int64)
-    sk = s.gather(idxs).to_torch()
+    idx = idxs.to_numpy()
+    sk = s.gather(idxs).to_numpy()
+    assert np.array_equal(sk, k[idx])                         # gather agrees with the host
     assert bool((sk[1:] >= sk[:-1]).all())
-    # permutation: index sums match 0..n-1 (first two power sums, mod 2^64) and the key multiset checksum is unchanged
-    ar = torch.arange(n, device="cuda", dtype=torch.int64)
-    assert int(idx.sum()) == int(ar.sum()) and int((idx * idx).sum()) == int((ar * ar).sum())
-    assert int(sk.sum()) == int(k.sum()) and int((sk * sk).sum()) == int((k * k).sum())
-    # narrow key range: most digit passes are skipped
-    k2 = (k & 1023).to(torch.int32)
-    s2 = pl.Series.from_torch("k2", k2)
-    idx2s = s2.arg_sort(descending=True)
+    seen = np.zeros(n, dtype=bool); seen[idx] = True
+    assert bool(seen.all())                                   # permutation
+    # narrow key range: most digit passes are skipped; descending; many ties
+    k2 = (k & 1023).astype(np.int32)
+    s2 = pl.Series("k2", k2)
+    idx2 = s2.arg_sort(descending=True).to_numpy().astype(np.int64)
     assert "passes=2" in pl.last_plan(), pl.last_plan()
-    idx2 = idx2s.to_torch().to(torch.int64)
-    sk2 = s2.gather(idx2s).to_torch()
+    sk2 = k2[idx2]
     assert bool((sk2[1:] <= sk2[:-1]).all())
     assert bool(((idx2[1:] > idx2[:-1]) | (sk2[1:] != sk2[:-1])).all())    # stable: ties in input order
-    assert int(idx2.sum()) == int(ar.sum())
+    seen[:] = False; seen[idx2] = True
+    assert bool(seen.all())
 
 
 @pytest.mark.parametrize("how", ["semi", "anti"])
