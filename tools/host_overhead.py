@@ -21,7 +21,5 @@ for name, rows in [("cfg2", 200_000_000), ("q1", 200_000_000), ("cfg3", 100_000_
     ksum = sum(v[1] for v in st.values()) / n
     print(f"{name}: {dt*1e3:.3f} ms/step, traced kernels {ksum/1e3:.3f} ms/step")
     for k, v in sorted(st.items(), key=lambda kv: -kv[1][1]): print(f"   {k:32s} x{v[0]/n:.0f}  {v[1]/v[0]:.1f} us")
-    # python-side split: plan lowering vs execute vs download
-    lf = queries.cfg2  # noqa
     del wl
     F.lib().plx_memory_trim(); torch.cuda.empty_cache()
