@@ -1,0 +1,76 @@
+"""Parity at BASELINE.json's full sizes (TPC-H SF100: 6.0e8 lineitem rows, 1.5e8 orders) through size-independent
+properties -- the oracle cannot cover these sizes in seconds: additivity over a row split, agreement of independent
+kernel pipelines (fused vs one-kernel-per-node, direct-address vs hash join table), avg = sum / count, count
+conservation against a plain filter.  Inputs are generated on the device (same generators as bench.py)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6          # float aggregates: 1e-6 relative (BASELINE.json north_star); integer results bit-exact
+
+
+def test_q1_sf100_properties(pl):
+    import torch
+    from polars_amd import datagen, queries
+    n = 600_000_000
+    cols = datagen.lineitem_device(n, seed=3)
+    torch.cuda.synchronize()
+    df = datagen.frame_from_torch(pl, cols, datagen.LINEITEM_Q1_COLS)
+    keys = ["l_returnflag", "l_linestatus"]
+    g = queries.q1(df.lazy()).collect().sort_host(keys)
+    assert "fused_scan[aot]" in pl.last_plan(), pl.last_plan()
+    # count conservation: an independent pipeline (compare kernel -> bitmap popcount) counts the rows the filter keeps
+    kept = df.lazy().filter(pl.col("l_shipdate") <= queries.Q1_CUTOFF).select(pl.len().alias("n")).collect(no_fusion=True).to_dict()["n"][0]
+    assert sum(g["count_order"]) == kept and 0 < kept < n
+    for i in range(len(g["count_order"])):
+        assert math.isclose(g["avg_qty"][i], g["sum_qty"][i] / g["count_order"][i], rel_tol=1e-12)
+        assert math.isclose(g["avg_price"][i], g["sum_base_price"][i] / g["count_order"][i], rel_tol=1e-9)
+        # discount in [0, 0.10], tax in [0, 0.08]:  disc_price <= base_price,  disc_price <= charge <= 1.08 * disc_price
+        assert 0.9 * g["sum_base_price"][i] * (1 - 1e-9) <= g["sum_disc_price"][i] <= g["sum_base_price"][i]
+        assert g["sum_disc_price"][i] <= g["sum_charge"][i] <= 1.08 * g["sum_disc_price"][i] * (1 + 1e-9)
+    # additivity over an unequal row split with an odd boundary (views of the same device buffers)
+    cut = 233_333_333
+    tot = {}
+    for lo, hi in ((0, cut), (cut, n)):
+        sub = {k: v[lo:hi] for k, v in cols.items()}
+        p = queries.q1(datagen.frame_from_torch(pl, sub, datagen.LINEITEM_Q1_COLS).lazy()).collect().sort_host(keys)
+        for j, kk in enumerate(zip(p["l_returnflag"], p["l_linestatus"])):
+            for c in ("count_order", "sum_qty", "sum_base_price", "sum_disc_price", "sum_charge"):
+                tot[(kk, c)] = tot.get((kk, c), 0) + p[c][j]
+    for j, kk in enumerate(zip(g["l_returnflag"], g["l_linestatus"])):
+        assert tot[(kk, "count_order")] == g["count_order"][j] and tot[(kk, "sum_qty")] == g["sum_qty"][j]      # integers: bit-exact
+        for c in ("sum_base_price", "sum_disc_price", "sum_charge"):
+            assert math.isclose(tot[(kk, c)], g[c][j], rel_tol=RTOL), (kk, c)
+    # ORDER BY on the device gives the host-sorted order
+    s = queries.q1_sorted(df.lazy()).collect().to_dict()
+    assert s["l_returnflag"] == g["l_returnflag"] and s["l_linestatus"] == g["l_linestatus"] and s["count_order"] == g["count_order"]
+
+
+def test_q3_sf100_properties(pl):
+    import torch
+    from polars_amd import datagen, queries
+    orders, li = datagen.orders_lineitem_device(150_000_000, seed=4)
+    torch.cuda.synchronize()
+    L = datagen.frame_from_torch(pl, li, datagen.LINEITEM_Q3_COLS)
+    O = datagen.frame_from_torch(pl, orders, datagen.ORDERS_Q3_COLS)
+    q = queries.q3(L.lazy(), O.lazy())
+    a = q.collect()
+    assert "direct-address table" in pl.last_plan(), pl.last_plan()
+    b = q.collect(no_direct_join=True)                      # independent pipeline: open-addressing hash table
+    assert "hash table cap" in pl.last_plan(), pl.last_plan()
+    assert a.height == b.height and a.height > 1_000_000
+    ka, kb = a["l_orderkey"].to_numpy(), b["l_orderkey"].to_numpy()
+    oa, ob = np.argsort(ka), np.argsort(kb)
+    assert np.array_equal(ka[oa], kb[ob]) and len(np.unique(ka)) == len(ka)            # same groups, one row per order
+    assert np.array_equal(a["o_orderdate"].to_numpy()[oa], b["o_orderdate"].to_numpy()[ob])
+    ra, rb = a["revenue"].to_numpy()[oa], b["revenue"].to_numpy()[ob]
+    assert np.allclose(ra, rb, rtol=RTOL, atol=0)
+    assert (a["o_orderdate"].to_numpy() < datagen.us(1995, 3, 15)).all()
+    # ORDER BY revenue DESC, o_orderdate LIMIT 10 on the device == the host's top 10 of the full result
+    top = queries.q3_top10(L.lazy(), O.lazy()).collect()
+    d = a["o_orderdate"].to_numpy()[oa]
+    best = np.lexsort((d, -ra))[:10]
+    assert np.allclose(top["revenue"].to_numpy(), ra[best], rtol=RTOL, atol=0)
+    assert top["l_orderkey"].to_numpy().tolist() == ka[oa][best].tolist()
