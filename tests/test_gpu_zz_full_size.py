@@ -3,11 +3,15 @@ properties -- the oracle cannot cover these sizes in seconds: additivity over a 
 kernel pipelines (fused vs one-kernel-per-node, direct-address vs hash join table), avg = sum / count, count
 conservation against a plain filter.  Inputs are generated on the device (same generators as bench.py)."""
 import math
+import os
 
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+# Opt-in (PLX_FULL_SIZE=1): each test generates 20-25 GB on the device with the torch generators of bench.py, which can take
+# minutes on a GPU box whose torch kernels are not yet paged in; the default GPU suite keeps the 3e7-row versions of the
+# same properties (tests/test_gpu_queries.py::test_full_size_properties_q1, test_q3, tests/test_gpu_sort.py).
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("PLX_FULL_SIZE") != "1", reason="full-size run is opt-in: PLX_FULL_SIZE=1")]
 RTOL = 1e-6          # float aggregates: 1e-6 relative (BASELINE.json north_star); integer results bit-exact
 
 
