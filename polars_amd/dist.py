@@ -52,6 +52,12 @@ def init_process_group(backend: Optional[str] = None):
     dist.init_process_group(backend=backend, rank=rank, world_size=ws)
 
 
+def torch_sync():
+    """Work queued on torch's current stream must be visible to the library's stream before it reads the tensors."""
+    import torch
+    torch.cuda.current_stream().synchronize()
+
+
 class LocalOps:
     """Per-rank compute used by the exchange layer (tensors in, tensors out)."""
 
@@ -65,6 +71,11 @@ class LocalOps:
     def groupby_partial(self, keys: Dict[str, object], values: Dict[str, object], aggs: Sequence[Tuple[str, str, str]]):
         """aggs = [(out_name, value column, partial op)] -> dict of tensors, one row per local group (keys + outs)."""
         raise NotImplementedError
+
+    def mean_from_partials(self, total, count):
+        """f64 sum / count of the mean decomposition (reduce/mean.rs:82-132)."""
+        import torch
+        return total.to(torch.float64) / count.to(torch.float64)
 
 
 class HipLocalOps(LocalOps):
@@ -87,7 +98,12 @@ class HipLocalOps(LocalOps):
         counts = (C.c_int64 * n_parts)()
         F.check(F.lib().plx_hash_partition(s._h, n_parts, seed, C.byref(h), counts))
         perm = self.pl.Series._from_handle("perm", h.value, self.pl.UInt32)
-        return perm.to_torch().to(torch.int64), list(counts)
+        return perm.cast(self.pl.Int64).to_torch(), list(counts)     # widened by the library's cast kernel (index tensors are int64 in torch)
+
+    def mean_from_partials(self, total, count):
+        pl = self.pl
+        torch_sync()
+        return (self._series("s", total).cast(pl.Float64) / self._series("c", count).cast(pl.Float64)).to_torch()
 
     def groupby_partial(self, keys, values, aggs):
         import torch
@@ -200,7 +216,7 @@ def groupby_agg(ops: LocalOps, keys: Dict[str, object], values: Dict[str, object
     res = {k: part[k] for k in keys}
     for out, col, op in aggs:
         if op == "mean":
-            res[out] = part[f"{out}__p0"].to(torch.float64) / part[f"{out}__p1"].to(torch.float64)
+            res[out] = ops.mean_from_partials(part[f"{out}__p0"], part[f"{out}__p1"])
         else:
             res[out] = part[f"{out}__p0"]
     return res

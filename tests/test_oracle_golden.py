@@ -344,3 +344,19 @@ def test_sort_restatements_agree_on_random_inputs(orc):
             keys.append((v, m, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
         lim = None if rng.random() < 0.5 else int(rng.integers(0, n + 2))
         assert np.array_equal(orc.sort_indices(keys, lim), orc.sort_indices_cmp(keys, lim)), t
+
+
+def test_numpy_q1_reference_matches_oracle(orc):
+    """tests/refs.py q1_numpy (the GPU tests' large-size reference) against the oracle's operator-by-operator Q1."""
+    from polars_amd import datagen
+    from tests import refs
+    cols = datagen.lineitem_host(300_000, seed=9)
+    cutoff = datagen.us(1998, 9, 2)
+    want = orc.q1({k: cols[k] for k in datagen.LINEITEM_Q1_COLS}, cutoff)
+    got = refs.q1_numpy(cols, cutoff)
+    assert len(got) == len(want["l_returnflag"]) >= 4
+    for i, key in enumerate(zip(want["l_returnflag"].tolist(), want["l_linestatus"].tolist())):
+        g = got[key]
+        assert g["count_order"] == want["count_order"][i] and g["sum_qty"] == want["sum_qty"][i]
+        for c in ("sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc"):
+            assert math.isclose(g[c], want[c][i], rel_tol=1e-9), (key, c)
