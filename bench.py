@@ -12,6 +12,11 @@ timed region starts.
 N > 1: one process per GPU, every rank holds its own SF100-sized shard (weak scaling); Q1's
 six-group partials are combined with an all-gather of a few hundred bytes (polars_amd/dist.py),
 no row crosses xGMI.  Prints ONE JSON line on rank 0.
+
+Order of work at N = 1: headline (Q1; its input comes from the library's own generator kernel, spot-checked against the
+generator's host twin, with the torch generators as fallback) -> CPU baseline -> secondary workloads (`extras`).  The
+line is complete after the first two; the extras only add to it, and a guard process prints the line as it stands if
+they have not finished PLX_BENCH_DEADLINE_S (300) seconds after the start (run_guarded).
 """
 from __future__ import annotations
 
@@ -50,14 +55,41 @@ class Workload:
         self.variants = variants or {}   # name -> step(): the same data through a longer query (extras only)
 
 
+def check_native_lineitem(pl, df, n: int, seed: int) -> None:
+    """Spot check of the device table against the generator's host twin (plx_datagen_lineitem_q1_host): three blocks of
+    rows, every column, bit-exact; raises on any difference."""
+    import numpy as np
+    from polars_amd import datagen
+    if df.height != n:
+        raise RuntimeError(f"generated {df.height} rows, wanted {n}")
+    blk = min(4096, n)
+    for row0 in sorted({0, max(0, n // 2 - 1234), n - blk}):
+        got = df.slice(row0, blk)
+        want = datagen.lineitem_native_host(row0, blk, seed)
+        for c in datagen.LINEITEM_Q1_COLS:
+            if not np.array_equal(got[c].to_numpy(), want[c]):
+                raise RuntimeError(f"device generator differs from its host twin in {c} at rows [{row0}, {row0 + blk})")
+
+
 def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
     import torch
     from polars_amd import datagen, queries
     if name == "q1":
         n = rows or SF100_LINEITEM
-        cols = datagen.lineitem_device(n, seed=seed)
-        df = datagen.frame_from_torch(pl, cols, datagen.LINEITEM_Q1_COLS)
-        torch.cuda.synchronize()
+        df, cols, gen = None, None, "library kernel (plx_datagen_lineitem_q1)"
+        if os.environ.get("PLX_BENCH_DATAGEN", "native") == "native":
+            # the library's own generator: 25 GB written straight into HBM columns, no torch kernels on the headline path
+            try:
+                df = datagen.lineitem_native(pl, n, seed)
+                check_native_lineitem(pl, df, n, seed)
+            except Exception as e:   # fall back to the torch generators rather than lose the measurement
+                print(f"[bench] native data generator unavailable ({type(e).__name__}: {e}); using the torch generators", file=sys.stderr)
+                df = None
+        if df is None:
+            gen = "torch generators (polars_amd/datagen.py lineitem_device)"
+            cols = datagen.lineitem_device(n, seed=seed)
+            df = datagen.frame_from_torch(pl, cols, datagen.LINEITEM_Q1_COLS)
+            torch.cuda.synchronize()
         lf = queries.q1(df.lazy())
 
         def step():
@@ -69,7 +101,7 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
             out = lf_sorted.collect()
             return out.to_dict(), (df, cols)
         return Workload("tpch_q1_sf100", n, n * datagen.Q1_BYTES_PER_ROW, step, "fused_scan_ldsagg_static",
-                        f"TPC-H Q1, lineitem {n} rows x 42 B (SF100 = 6.0e8), filter -> 2-key group_by -> 8 aggregates",
+                        f"TPC-H Q1, lineitem {n} rows x 42 B (SF100 = 6.0e8), filter -> 2-key group_by -> 8 aggregates; input: {gen}",
                         variants={"tpch_q1_sf100_order_by": step_sorted})
     if name == "q3":
         no = (rows // 4) if rows else SF100_ORDERS
@@ -320,8 +352,80 @@ def combine_q1_results(per_rank):
     return out
 
 
+def run_guarded(worker, deadline_s: float, poll_s: float = 0.25) -> int:
+    """Runs worker(emit) in a forked child and prints the LAST line it emitted exactly once, from this process.
+
+    The headline measurement comes first; the secondary workloads (`extras`) only refine the same JSON line.  On a GPU box
+    whose caches are cold, another library's kernels (torch's generators behind the extras' inputs) can take minutes to
+    load, so the worker hands every improved version of the line to `emit`; if it has not finished `deadline_s` seconds
+    after the start but a line exists, the child is stopped and the line printed as it stands.  A worker that dies
+    after the headline was measured still gets its line printed.  Forking happens before torch / HIP are imported, so
+    the child initialises the GPU on its own.  Returns the process exit code."""
+    import signal
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="plx_bench_")
+    path = os.path.join(tmp, "line.json")
+
+    def emit(line: dict):
+        with open(path + ".tmp", "w") as f:
+            f.write(json.dumps(line))
+        os.replace(path + ".tmp", path)
+
+    sys.stdout.flush(); sys.stderr.flush()
+    pid = os.fork()
+    if pid == 0:
+        code = 1
+        try:
+            worker(emit)
+            code = 0
+        except BaseException:  # noqa: BLE001 -- the parent decides what to print
+            import traceback
+            traceback.print_exc()
+        finally:
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(code)
+    t_end = time.monotonic() + deadline_s
+    status, stopped = None, False
+    while True:
+        done, st = os.waitpid(pid, os.WNOHANG)
+        if done:
+            status = st
+            break
+        if time.monotonic() >= t_end and os.path.exists(path):
+            os.kill(pid, signal.SIGKILL)
+            os.waitpid(pid, 0)
+            stopped = True
+            break
+        time.sleep(poll_s)
+    line = open(path).read() if os.path.exists(path) else None
+    for f in (path, path + ".tmp"):
+        if os.path.exists(f):
+            os.remove(f)
+    os.rmdir(tmp)
+    if line is not None:
+        if stopped:
+            d = json.loads(line)
+            d["note"] = f"secondary workloads stopped at the {deadline_s:.0f} s deadline; headline unaffected"
+            line = json.dumps(d)
+        print(line, flush=True)
+        return 0
+    return os.waitstatus_to_exitcode(status) if status is not None else 1
+
+
 def main():
     args = parse()
+    rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    # single-GPU runs with secondary workloads go through the guard; torchrun ranks and --no-extras runs (rocprofv3 wraps those) do not
+    if ws == 1 and not args.no_extras and os.environ.get("PLX_BENCH_GUARD", "1") != "0":
+        sys.exit(run_guarded(lambda emit: run(args, emit), float(os.environ.get("PLX_BENCH_DEADLINE_S", "300"))))
+    final = {}
+    run(args, final.update)
+    if rank == 0:
+        print(json.dumps(final), flush=True)
+
+
+def run(args, emit):
+    """The benchmark proper; emit(line) is called with every improved version of the JSON line (rank 0)."""
     import torch
     rank, local_rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     distributed = ws > 1
@@ -354,8 +458,17 @@ def main():
         "roofline": roofline(stats, wl),
         "kernels": {k: {"launches": v[0], "avg_us": round(v[1] / v[0], 2)} for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])[:8]},
     }
+    if rank == 0:
+        emit(line)                               # the headline is safe from here on
+    if rank == 0 and ws == 1 and not args.no_cpu:
+        try:
+            line["cpu_baseline"] = cpu_baseline_q1(args.cpu_seconds)
+        except Exception as e:
+            line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        emit(line)
     if rank == 0 and not args.no_extras and ws == 1:
         extras = {}
+        line["extras"] = extras
         k2 = max(3, args.steps // 4)
         for vname, vstep in wl.variants.items():
             try:
@@ -364,6 +477,7 @@ def main():
                                  "kernels": {k: {"launches": v[0], "avg_us": round(v[1] / v[0], 2)} for k, v in sorted(sv.items(), key=lambda kv: -kv[1][1])[:6]}}
             except Exception as e:
                 extras[vname] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            emit(line)
         del wl
         torch.cuda.empty_cache()
         for name in [w for w in ("q3", "cfg2", "cfg3", "cfg5", "q1") if w != args.workload]:
@@ -384,14 +498,9 @@ def main():
                 extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
             pl._ffi.lib().plx_memory_trim()
             torch.cuda.empty_cache()
-        line["extras"] = extras
-    if rank == 0 and ws == 1 and not args.no_cpu:
-        try:
-            line["cpu_baseline"] = cpu_baseline_q1(args.cpu_seconds)
-        except Exception as e:
-            line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            emit(line)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if distributed:
         import torch.distributed as dist
         dist.barrier()

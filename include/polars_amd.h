@@ -389,6 +389,18 @@ int plx_jit_set_min_rows(int64_t min_rows);
  * last plx_execute_plan on this thread. */
 const char* plx_last_plan_description(void);
 
+/* ---- synthetic benchmark data (no reference counterpart: dbgen lives outside the reference tree) -------
+ * Fills n_rows of the TPC-H Q1 lineitem columns directly in HBM with a counter-based generator (row i is a pure
+ * function of (seed, i): polars_amd/csrc/datagen_device.hpp), so bench.py gets its 25 GB SF100 input without
+ * depending on another library's kernels.  out_cols[7], in this order: l_shipdate (PLX_I64, Datetime[us]),
+ * l_returnflag (PLX_U8, codes 0..2 = A,N,R), l_linestatus (PLX_U8, 0..1 = F,O), l_quantity (PLX_I64, 1..50),
+ * l_extendedprice (PLX_F64), l_discount (PLX_F64, 0..0.10), l_tax (PLX_F64, 0..0.08). */
+int plx_datagen_lineitem_q1(int64_t n_rows, uint64_t seed, plx_column* out_cols);
+/* The same generator evaluated on the host for rows [row0, row0 + n) (no GPU needed): pins the kernel's arithmetic
+ * in the CPU tests and lets callers spot-check a device table.  Plain host arrays, any may be NULL. */
+int plx_datagen_lineitem_q1_host(int64_t row0, int64_t n, uint64_t seed, int64_t* shipdate, uint8_t* returnflag, uint8_t* linestatus,
+                                 int64_t* quantity, double* extendedprice, double* discount, double* tax);
+
 /* ---- tracing (NodeTimer equivalent) --------------------------------------- */
 typedef struct plx_profile_record {
   char name[48];      /* kernel / node name */

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "core.hpp"
+#include "datagen_device.hpp"
 #include "engine.hpp"
 #include "fused_shapes.hpp"
 #include "jit.hpp"
@@ -414,6 +415,35 @@ int plx_frame_to_host(plx_frame f, void* const* values_out, uint8_t* const* vali
     if (has_validity_out) has_validity_out[i] = c->validity ? 1 : 0;
   }
   PLX_HIP(hipStreamSynchronize(stream()));
+  PLX_CATCH
+}
+
+// ---- synthetic benchmark data --------------------------------------------------------
+int plx_datagen_lineitem_q1(int64_t n_rows, uint64_t seed, plx_column* out_cols) {
+  PLX_TRY
+  PLX_REQUIRE(n_rows >= 0 && out_cols, PLX_ERR_INVALID, "datagen: bad arguments");
+  static const int dts[7] = {PLX_I64, PLX_U8, PLX_U8, PLX_I64, PLX_F64, PLX_F64, PLX_F64};
+  ColumnPtr c[7];
+  for (int i = 0; i < 7; i++) { c[i] = make_column(dts[i], n_rows, false); c[i]->null_count = 0; }
+  k::datagen_lineitem_q1(n_rows, seed, c[0]->values->as<int64_t>(), c[1]->values->as<uint8_t>(), c[2]->values->as<uint8_t>(), c[3]->values->as<int64_t>(),
+                         c[4]->values->as<double>(), c[5]->values->as<double>(), c[6]->values->as<double>());
+  for (int i = 0; i < 7; i++) out_cols[i] = register_column(c[i]);
+  PLX_CATCH
+}
+int plx_datagen_lineitem_q1_host(int64_t row0, int64_t n, uint64_t seed, int64_t* shipdate, uint8_t* returnflag, uint8_t* linestatus, int64_t* quantity,
+                                 double* extendedprice, double* discount, double* tax) {
+  PLX_TRY
+  PLX_REQUIRE(row0 >= 0 && n >= 0, PLX_ERR_INVALID, "datagen: bad arguments");
+  for (int64_t j = 0; j < n; j++) {
+    const datagen::LineitemRow r = datagen::lineitem_row(seed, (uint64_t)(row0 + j));
+    if (shipdate) shipdate[j] = r.shipdate;
+    if (returnflag) returnflag[j] = r.returnflag;
+    if (linestatus) linestatus[j] = r.linestatus;
+    if (quantity) quantity[j] = r.quantity;
+    if (extendedprice) extendedprice[j] = r.extendedprice;
+    if (discount) discount[j] = r.discount;
+    if (tax) tax[j] = r.tax;
+  }
   PLX_CATCH
 }
 

@@ -1,0 +1,55 @@
+// datagen_device.hpp -- counter-based synthetic TPC-H lineitem rows (benchmark / test support, not part of the hot path).
+// Row i is a pure function of (seed, i): the device kernel and the host reference evaluate the same code, so the table is
+// identical for any launch geometry and the CPU tests can pin the kernel's arithmetic without a GPU.
+// Distributions follow polars_amd/datagen.py (_line_columns_host): TPC-H-like value ranges, Q1's filter keeps ~98 % of the rows
+// and the (returnflag, linestatus) pairs are (A,F), (N,F), (N,O), (R,F).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define PLX_HD __host__ __device__
+#else
+#define PLX_HD
+#endif
+
+namespace plx {
+namespace datagen {
+
+constexpr int64_t kDayUs = 86400000000ll;
+constexpr int64_t kStart = 8035ll * kDayUs;      // 1992-01-01 as Datetime[us]
+constexpr int64_t kCurrent = 9298ll * kDayUs;    // 1995-06-17
+
+struct LineitemRow {
+  int64_t shipdate, quantity;
+  uint8_t returnflag, linestatus;
+  double extendedprice, discount, tax;
+};
+
+PLX_HD inline uint64_t mix64(uint64_t z) {       // splitmix64 output function
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+PLX_HD inline uint64_t mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }   // v_mul_hi_u32 chain on the device
+// uniform integer in [lo, hi) from stream s of row i
+PLX_HD inline int64_t rand_range(uint64_t key, uint64_t i, uint32_t s, int64_t lo, int64_t hi) {
+  return lo + (int64_t)mulhi64(mix64(key + i * 8 + s), (uint64_t)(hi - lo));
+}
+PLX_HD inline LineitemRow lineitem_row(uint64_t seed, uint64_t i) {
+  const uint64_t key = mix64(seed);
+  LineitemRow r;
+  r.shipdate = kStart + rand_range(key, i, 0, 1, 2526 + 121) * kDayUs;
+  r.quantity = rand_range(key, i, 1, 1, 51);
+  r.extendedprice = (double)(r.quantity * rand_range(key, i, 2, 90000, 210000)) / 100.0;   // two decimals, correctly rounded
+  r.discount = (double)rand_range(key, i, 3, 0, 11) / 100.0;
+  r.tax = (double)rand_range(key, i, 4, 0, 9) / 100.0;
+  const int64_t receipt = r.shipdate + rand_range(key, i, 5, 1, 31) * kDayUs;
+  const bool coin = (mix64(key + i * 8 + 6) >> 63) != 0;
+  r.returnflag = receipt <= kCurrent ? (coin ? 0 : 2) : 1;     // A / R before the current date, N after
+  r.linestatus = r.shipdate > kCurrent ? 1 : 0;                // F / O
+  return r;
+}
+
+}  // namespace datagen
+}  // namespace plx

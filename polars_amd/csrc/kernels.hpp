@@ -37,6 +37,9 @@ constexpr int kPackMax = 32;
 struct PackBatch { const void* src[kPackMax]; uint32_t bytes[kPackMax]; uint32_t off[kPackMax]; int n; };
 void pack_buffers(const PackBatch& b, void* staging);
 
+// ---- synthetic data (kernels_datagen.hip; benchmark / test support) ------------------------------
+void datagen_lineitem_q1(int64_t n, uint64_t seed, int64_t* shipdate, uint8_t* flag, uint8_t* status, int64_t* qty, double* price, double* disc, double* tax);
+
 // ---- reductions (kernels_reduce.hip) ------------------------------------------
 struct ReduceResult {
   uint64_t isum;      // wrapping 64-bit sum of sign/zero-extended values (ints)

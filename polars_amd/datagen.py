@@ -118,6 +118,36 @@ def cfg5_host(n: int, n_keys: int = 1_000_000):
     return codes, v
 
 
+# ----------------------------------------------------------------------- native ----
+def lineitem_native_host(row0: int, n: int, seed: int = 10) -> Dict[str, np.ndarray]:
+    """Rows [row0, row0 + n) of the library's counter-based lineitem generator, evaluated on the host (no GPU):
+    plx_datagen_lineitem_q1_host, the CPU twin of the kernel behind lineitem_native."""
+    import ctypes as C
+
+    from . import _ffi as F
+    out = {"l_shipdate": np.zeros(n, np.int64), "l_returnflag": np.zeros(n, np.uint8), "l_linestatus": np.zeros(n, np.uint8),
+           "l_quantity": np.zeros(n, np.int64), "l_extendedprice": np.zeros(n, np.float64), "l_discount": np.zeros(n, np.float64),
+           "l_tax": np.zeros(n, np.float64)}
+    ptrs = [C.c_void_p(out[c].ctypes.data) if n else C.c_void_p(0) for c in LINEITEM_Q1_COLS]
+    F.check(F.lib().plx_datagen_lineitem_q1_host(row0, n, seed, *ptrs))
+    return out
+
+
+def lineitem_native(pl, n_rows: int, seed: int = 10):
+    """TPC-H Q1 lineitem columns generated straight into HBM by the library's own kernel (kernels_datagen.hip): no
+    torch kernels, no host staging.  Returns a DataFrame with the logical dtypes of the TPC-H schema."""
+    import ctypes as C
+
+    from . import _ffi as F
+    F.ensure_init()
+    hs = (C.c_uint64 * 7)()
+    F.check(F.lib().plx_datagen_lineitem_q1(n_rows, seed, hs))
+    lt = logical_dtypes(pl)
+    phys = {"l_shipdate": pl.Int64, "l_returnflag": pl.UInt8, "l_linestatus": pl.UInt8, "l_quantity": pl.Int64, "l_extendedprice": pl.Float64,
+            "l_discount": pl.Float64, "l_tax": pl.Float64}
+    return pl.DataFrame([pl.Series._from_handle(c, hs[i], lt.get(c, phys[c])) for i, c in enumerate(LINEITEM_Q1_COLS)])
+
+
 # ------------------------------------------------------------------------ torch ----
 def _line_columns_device(torch, g, shipdate):
     n = shipdate.numel()

@@ -1,0 +1,61 @@
+"""bench.py's line guard without a GPU: the ONE JSON line reaches stdout exactly once whether the worker finishes, stalls in a
+secondary workload past the deadline, or dies after the headline; nothing is printed if no headline was ever measured."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def _lines(capsys):
+    return [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+
+
+def test_worker_finishes_last_emitted_line_wins(capsys):
+    def worker(emit):
+        emit({"value": 1})
+        emit({"value": 1, "extras": {"q3": 2}})
+    assert bench.run_guarded(worker, deadline_s=30) == 0
+    out = _lines(capsys)
+    assert len(out) == 1 and json.loads(out[0]) == {"value": 1, "extras": {"q3": 2}}
+
+
+def test_stalled_secondary_workload_is_cut_at_the_deadline(capsys):
+    def worker(emit):
+        emit({"value": 7})
+        time.sleep(60)            # a secondary workload that never comes back
+        emit({"value": -1})
+    t0 = time.monotonic()
+    assert bench.run_guarded(worker, deadline_s=1.0, poll_s=0.05) == 0
+    assert time.monotonic() - t0 < 10
+    out = _lines(capsys)
+    assert len(out) == 1
+    d = json.loads(out[0])
+    assert d["value"] == 7 and "deadline" in d["note"]
+
+
+def test_no_deadline_cut_before_a_headline_exists(capsys):
+    def worker(emit):
+        time.sleep(1.0)           # slow headline: the guard must keep waiting past the deadline
+        emit({"value": 3})
+    assert bench.run_guarded(worker, deadline_s=0.2, poll_s=0.05) == 0
+    out = _lines(capsys)
+    assert len(out) == 1 and json.loads(out[0])["value"] == 3
+
+
+def test_worker_dying_after_the_headline_still_reports_it(capsys):
+    def worker(emit):
+        emit({"value": 5})
+        raise RuntimeError("secondary workload crashed")
+    assert bench.run_guarded(worker, deadline_s=30) == 0
+    out = _lines(capsys)
+    assert len(out) == 1 and json.loads(out[0]) == {"value": 5}
+
+
+def test_worker_dying_before_the_headline_prints_nothing_and_fails(capsys):
+    def worker(emit):
+        raise RuntimeError("no GPU")
+    assert bench.run_guarded(worker, deadline_s=30) != 0
+    assert _lines(capsys) == []
