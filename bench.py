@@ -71,6 +71,54 @@ def check_native_lineitem(pl, df, n: int, seed: int) -> None:
                 raise RuntimeError(f"device generator differs from its host twin in {c} at rows [{row0}, {row0 + blk})")
 
 
+def _blocks(n: int, blk: int = 4096):
+    blk = min(blk, n)
+    return [(r, blk) for r in sorted({0, max(0, n // 2 - 1234), n - blk})] if n else []
+
+
+def native_uniform_column(pl, name: str, dtype, np_name: str, n: int, seed: int, stream: int, lo: int, hi: int, scale: float = 1.0):
+    """A uniform device column from the library's generator, spot-checked against the generator's host twin."""
+    import numpy as np
+    from polars_amd import datagen
+    s = datagen.uniform_native(pl, name, dtype, n, seed, stream, lo, hi, scale)
+    df = pl.DataFrame([s])
+    for row0, blk in _blocks(n):
+        if not np.array_equal(df.slice(row0, blk)[name].to_numpy(), datagen.uniform_native_host(np_name, row0, blk, seed, stream, lo, hi, scale)):
+            raise RuntimeError(f"device generator differs from its host twin in {name} at rows [{row0}, {row0 + blk})")
+    return s
+
+
+def check_native_q3(pl, O, L, n_orders: int, seed: int) -> None:
+    """First and last 2048 orders (and their lines) of the device tables against the generator's host twin, bit-exact."""
+    import numpy as np
+    from polars_amd import datagen
+    if O.height != n_orders:
+        raise RuntimeError(f"generated {O.height} orders, wanted {n_orders}")
+    blk = min(2048, n_orders)
+    for order0 in sorted({0, n_orders - blk}):
+        wo, wl, _cnt = datagen.orders_lineitem_native_host(order0, blk, n_orders, seed)
+        go = O.slice(order0, blk)
+        for c in datagen.ORDERS_Q3_COLS:
+            if not np.array_equal(go[c].to_numpy(), wo[c]):
+                raise RuntimeError(f"device generator differs from its host twin in {c} at orders [{order0}, {order0 + blk})")
+        m = len(wl["l_orderkey"])
+        gl = L.slice(0, m) if order0 == 0 else L.slice(L.height - m, m)
+        for c in datagen.LINEITEM_Q3_COLS:
+            if not np.array_equal(gl[c].to_numpy(), wl[c]):
+                raise RuntimeError(f"device generator differs from its host twin in {c} (lines of orders [{order0}, {order0 + blk}))")
+
+
+def _native_or_none(what: str, build):
+    """build() -> inputs from the library's generators, or None (with a note on stderr) so the caller uses the torch generators."""
+    if os.environ.get("PLX_BENCH_DATAGEN", "native") != "native":
+        return None
+    try:
+        return build()
+    except Exception as e:
+        print(f"[bench] native data generator unavailable for {what} ({type(e).__name__}: {e}); using the torch generators", file=sys.stderr)
+        return None
+
+
 def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
     import torch
     from polars_amd import datagen, queries
@@ -105,12 +153,24 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
                         variants={"tpch_q1_sf100_order_by": step_sorted})
     if name == "q3":
         no = (rows // 4) if rows else SF100_ORDERS
-        orders, li = datagen.orders_lineitem_device(no, seed=seed, ordered=os.environ.get("PLX_Q3_SHUFFLED", "0") != "1")   # dbgen row order by default
-        L = datagen.frame_from_torch(pl, li, datagen.LINEITEM_Q3_COLS)
-        O = datagen.frame_from_torch(pl, orders, datagen.ORDERS_Q3_COLS)
-        torch.cuda.synchronize()
+        shuffled = os.environ.get("PLX_Q3_SHUFFLED", "0") == "1"
+        orders = li = None
+
+        def build_native():
+            O_, L_ = datagen.orders_lineitem_native(pl, no, seed)
+            check_native_q3(pl, O_, L_, no, seed)
+            return O_, L_
+        nat = _native_or_none("q3", build_native) if (ws == 1 and not shuffled) else None   # the sharded path exchanges torch tensors
+        if nat is not None:
+            O, L = nat
+            nl = L.height
+        else:
+            orders, li = datagen.orders_lineitem_device(no, seed=seed, ordered=not shuffled)   # dbgen row order by default
+            L = datagen.frame_from_torch(pl, li, datagen.LINEITEM_Q3_COLS)
+            O = datagen.frame_from_torch(pl, orders, datagen.ORDERS_Q3_COLS)
+            torch.cuda.synchronize()
+            nl = li["l_orderkey"].numel()
         lf = queries.q3(L.lazy(), O.lazy())
-        nl = li["l_orderkey"].numel()
 
         def step():
             out = lf.collect()
@@ -138,12 +198,17 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
                         variants={} if ws > 1 else {"tpch_q3_sf100_order_by_limit10": step_top10})
     if name == "cfg2":
         n = rows or 1_000_000_000
-        g = torch.Generator(device="cuda"); g.manual_seed(seed)
-        a = torch.randint(0, 2 ** 31, (n,), generator=g, device="cuda", dtype=torch.int64)
-        x = torch.rand((n,), generator=g, device="cuda", dtype=torch.float64) * 100.0
-        y = torch.rand((n,), generator=g, device="cuda", dtype=torch.float64)
-        df = pl.DataFrame([pl.Series.from_torch("a", a), pl.Series.from_torch("x", x), pl.Series.from_torch("y", y)])
-        torch.cuda.synchronize()
+        a = x = y = None
+        df = _native_or_none("cfg2", lambda: pl.DataFrame([native_uniform_column(pl, "a", pl.Int64, "Int64", n, seed, 0, 0, 2 ** 31),
+                                                           native_uniform_column(pl, "x", pl.Float64, "Float64", n, seed, 1, 0, 10 ** 9, 1e-7),
+                                                           native_uniform_column(pl, "y", pl.Float64, "Float64", n, seed, 2, 0, 10 ** 9, 1e-9)]))
+        if df is None:
+            g = torch.Generator(device="cuda"); g.manual_seed(seed)
+            a = torch.randint(0, 2 ** 31, (n,), generator=g, device="cuda", dtype=torch.int64)
+            x = torch.rand((n,), generator=g, device="cuda", dtype=torch.float64) * 100.0
+            y = torch.rand((n,), generator=g, device="cuda", dtype=torch.float64)
+            df = pl.DataFrame([pl.Series.from_torch("a", a), pl.Series.from_torch("x", x), pl.Series.from_torch("y", y)])
+            torch.cuda.synchronize()
         lf = queries.cfg2(df.lazy())
 
         def step():
@@ -151,11 +216,15 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
         return Workload("cfg2_filter_arith_agg_1e9", n, n * 24, step, "fused_scan_regagg_static", f"config 2: {n}-row Int64/Float64 frame, filter + arithmetic + sum/mean")
     if name == "cfg3":
         n = rows or 1_000_000_000
-        g = torch.Generator(device="cuda"); g.manual_seed(seed)
-        key = torch.randint(0, 1_000_000, (n,), generator=g, device="cuda", dtype=torch.int64)
-        v = torch.randint(0, 1000, (n,), generator=g, device="cuda", dtype=torch.int64)
-        df = pl.DataFrame([pl.Series.from_torch("key", key), pl.Series.from_torch("v", v)])
-        torch.cuda.synchronize()
+        key = v = None
+        df = _native_or_none("cfg3", lambda: pl.DataFrame([native_uniform_column(pl, "key", pl.Int64, "Int64", n, seed, 0, 0, 1_000_000),
+                                                           native_uniform_column(pl, "v", pl.Int64, "Int64", n, seed, 1, 0, 1000)]))
+        if df is None:
+            g = torch.Generator(device="cuda"); g.manual_seed(seed)
+            key = torch.randint(0, 1_000_000, (n,), generator=g, device="cuda", dtype=torch.int64)
+            v = torch.randint(0, 1000, (n,), generator=g, device="cuda", dtype=torch.int64)
+            df = pl.DataFrame([pl.Series.from_torch("key", key), pl.Series.from_torch("v", v)])
+            torch.cuda.synchronize()
         lf = queries.cfg3(df.lazy())
 
         def step():
@@ -163,11 +232,15 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
         return Workload("cfg3_groupby_1e6_keys_1e9", n, n * 16 + 1_000_000 * 20, step, "fused_scan", f"config 3: {n} rows, 1e6 Int64 keys, group_by(key).agg(sum, count)")
     if name == "cfg5":
         n = rows or 1_000_000_000
-        g = torch.Generator(device="cuda"); g.manual_seed(seed)
-        codes = torch.randint(0, 1_000_000, (n,), generator=g, device="cuda", dtype=torch.int32)   # dictionary codes of "id%010d" keys (u32)
-        v = torch.rand((n,), generator=g, device="cuda", dtype=torch.float64) * 100.0
-        df = pl.DataFrame([pl.Series.from_torch("k", codes, dtype=pl.Categorical([], pl.UInt32)), pl.Series.from_torch("v", v)])
-        torch.cuda.synchronize()
+        codes = v = None
+        df = _native_or_none("cfg5", lambda: pl.DataFrame([native_uniform_column(pl, "k", pl.Categorical([], pl.UInt32), "UInt32", n, seed, 0, 0, 1_000_000),
+                                                           native_uniform_column(pl, "v", pl.Float64, "Float64", n, seed, 1, 0, 10 ** 9, 1e-7)]))
+        if df is None:
+            g = torch.Generator(device="cuda"); g.manual_seed(seed)
+            codes = torch.randint(0, 1_000_000, (n,), generator=g, device="cuda", dtype=torch.int32)   # dictionary codes of "id%010d" keys (u32)
+            v = torch.rand((n,), generator=g, device="cuda", dtype=torch.float64) * 100.0
+            df = pl.DataFrame([pl.Series.from_torch("k", codes, dtype=pl.Categorical([], pl.UInt32)), pl.Series.from_torch("v", v)])
+            torch.cuda.synchronize()
         lf = queries.cfg5(df.lazy())
 
         def step():

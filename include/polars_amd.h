@@ -401,6 +401,22 @@ int plx_datagen_lineitem_q1(int64_t n_rows, uint64_t seed, plx_column* out_cols)
 int plx_datagen_lineitem_q1_host(int64_t row0, int64_t n, uint64_t seed, int64_t* shipdate, uint8_t* returnflag, uint8_t* linestatus,
                                  int64_t* quantity, double* extendedprice, double* discount, double* tax);
 
+/* TPC-H Q3 inputs in dbgen row order (both tables ascending in orderkey; sparse keys: 8 of every 32 used; 1-7 lines per
+ * order; l_shipdate = o_orderdate + 1..121 days).  out_orders[4]: o_orderkey, o_custkey, o_orderdate (Datetime[us]),
+ * o_shippriority (all PLX_I64); out_lineitem[4]: l_orderkey (I64), l_extendedprice (F64), l_discount (F64), l_shipdate (I64). */
+int plx_datagen_orders_lineitem(int64_t n_orders, uint64_t seed, plx_column* out_orders, plx_column* out_lineitem);
+/* Host twin for orders [order0, order0 + n) of a table of n_orders_total orders: per-order arrays (n entries, n_lines = lines
+ * of each order) and the lines of those orders in order (line_cap = capacity of the line arrays; *n_lines_out = lines written,
+ * PLX_ERR_INVALID if they do not fit).  Any output may be NULL. */
+int plx_datagen_orders_lineitem_host(int64_t order0, int64_t n, int64_t n_orders_total, uint64_t seed, int64_t* orderkey, int64_t* custkey,
+                                     int64_t* orderdate, uint32_t* n_lines, int64_t line_cap, int64_t* l_orderkey, double* l_extendedprice,
+                                     double* l_discount, int64_t* l_shipdate, int64_t* n_lines_out);
+/* One uniform column of n rows: value i = lo + floor(U_i * (hi - lo)), U_i from stream `stream` (0..7) of row i;
+ * dtype PLX_I64 / PLX_U32: the integer; PLX_F64: the integer times `scale`.  plx_datagen_uniform_host: rows
+ * [row0, row0 + n) into a host array of that dtype. */
+int plx_datagen_uniform(int32_t dtype, int64_t n_rows, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, double scale, plx_column* out);
+int plx_datagen_uniform_host(int32_t dtype, int64_t row0, int64_t n, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, double scale, void* out);
+
 /* ---- tracing (NodeTimer equivalent) --------------------------------------- */
 typedef struct plx_profile_record {
   char name[48];      /* kernel / node name */

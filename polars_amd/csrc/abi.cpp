@@ -13,6 +13,7 @@
 #include "join.hpp"
 #include "kernels.hpp"
 #include "ops.hpp"
+#include "scan.hpp"
 #include "sort.hpp"
 
 namespace plx {
@@ -443,6 +444,75 @@ int plx_datagen_lineitem_q1_host(int64_t row0, int64_t n, uint64_t seed, int64_t
     if (extendedprice) extendedprice[j] = r.extendedprice;
     if (discount) discount[j] = r.discount;
     if (tax) tax[j] = r.tax;
+  }
+  PLX_CATCH
+}
+
+int plx_datagen_orders_lineitem(int64_t n_orders, uint64_t seed, plx_column* out_orders, plx_column* out_lineitem) {
+  PLX_TRY
+  PLX_REQUIRE(n_orders >= 0 && out_orders && out_lineitem, PLX_ERR_INVALID, "datagen: bad arguments");
+  const int64_t cust_hi = std::max<int64_t>(2, n_orders / 10) + 1;
+  ColumnPtr o[4];
+  for (auto& c : o) { c = make_column(PLX_I64, n_orders, false); c->null_count = 0; }
+  Buf cnt = dev_alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(n_orders, 1));
+  Buf offsets = dev_alloc(sizeof(uint64_t) * (size_t)(n_orders + 1));
+  k::datagen_orders(n_orders, seed, cust_hi, o[0]->values->as<int64_t>(), o[1]->values->as<int64_t>(), o[2]->values->as<int64_t>(), o[3]->values->as<int64_t>(), cnt->as<uint32_t>());
+  k::exclusive_scan_u32(cnt->as<uint32_t>(), offsets->as<uint64_t>(), n_orders);
+  uint64_t n_lines = 0;
+  d2h_sync(&n_lines, offsets->as<uint64_t>() + n_orders, 8);
+  static const int ldt[4] = {PLX_I64, PLX_F64, PLX_F64, PLX_I64};
+  ColumnPtr l[4];
+  for (int i = 0; i < 4; i++) { l[i] = make_column(ldt[i], (int64_t)n_lines, false); l[i]->null_count = 0; }
+  k::datagen_lines(n_orders, seed, offsets->as<uint64_t>(), o[0]->values->as<int64_t>(), o[2]->values->as<int64_t>(), l[0]->values->as<int64_t>(), l[1]->values->as<double>(),
+                   l[2]->values->as<double>(), l[3]->values->as<int64_t>());
+  for (int i = 0; i < 4; i++) { out_orders[i] = register_column(o[i]); out_lineitem[i] = register_column(l[i]); }
+  PLX_CATCH
+}
+int plx_datagen_orders_lineitem_host(int64_t order0, int64_t n, int64_t n_orders_total, uint64_t seed, int64_t* orderkey, int64_t* custkey, int64_t* orderdate,
+                                     uint32_t* n_lines, int64_t line_cap, int64_t* l_orderkey, double* l_extendedprice, double* l_discount, int64_t* l_shipdate,
+                                     int64_t* n_lines_out) {
+  PLX_TRY
+  PLX_REQUIRE(order0 >= 0 && n >= 0 && n_orders_total >= order0 + n, PLX_ERR_INVALID, "datagen: bad arguments");
+  const int64_t cust_hi = std::max<int64_t>(2, n_orders_total / 10) + 1;
+  int64_t at = 0;
+  for (int64_t j = 0; j < n; j++) {
+    const datagen::OrderRow r = datagen::order_row(seed, (uint64_t)(order0 + j), cust_hi);
+    if (orderkey) orderkey[j] = r.orderkey;
+    if (custkey) custkey[j] = r.custkey;
+    if (orderdate) orderdate[j] = r.orderdate;
+    if (n_lines) n_lines[j] = r.n_lines;
+    const bool want_lines = l_orderkey || l_extendedprice || l_discount || l_shipdate;
+    for (uint32_t q = 0; q < r.n_lines; q++, at++) {
+      if (!want_lines) continue;
+      PLX_REQUIRE(at < line_cap, PLX_ERR_INVALID, "datagen: line arrays too small");
+      const datagen::Q3LineRow lr = datagen::q3_line_row(seed, (uint64_t)(order0 + j), q, r.orderdate);
+      if (l_orderkey) l_orderkey[at] = r.orderkey;
+      if (l_extendedprice) l_extendedprice[at] = lr.extendedprice;
+      if (l_discount) l_discount[at] = lr.discount;
+      if (l_shipdate) l_shipdate[at] = lr.shipdate;
+    }
+  }
+  if (n_lines_out) *n_lines_out = at;
+  PLX_CATCH
+}
+int plx_datagen_uniform(int32_t dtype, int64_t n_rows, uint64_t seed, uint32_t stream_id, int64_t lo, int64_t hi, double scale, plx_column* out) {
+  PLX_TRY
+  PLX_REQUIRE(n_rows >= 0 && out && hi > lo && stream_id < 8, PLX_ERR_INVALID, "datagen: bad arguments");
+  PLX_REQUIRE(dtype == PLX_I64 || dtype == PLX_U32 || dtype == PLX_F64, PLX_ERR_UNSUPPORTED, "datagen_uniform: dtype must be Int64, UInt32 or Float64");
+  ColumnPtr c = make_column(dtype, n_rows, false); c->null_count = 0;
+  k::datagen_uniform(dtype, n_rows, seed, stream_id, lo, hi, scale, c->values->ptr);
+  *out = register_column(c);
+  PLX_CATCH
+}
+int plx_datagen_uniform_host(int32_t dtype, int64_t row0, int64_t n, uint64_t seed, uint32_t stream_id, int64_t lo, int64_t hi, double scale, void* out) {
+  PLX_TRY
+  PLX_REQUIRE(row0 >= 0 && n >= 0 && (out || n == 0) && hi > lo && stream_id < 8, PLX_ERR_INVALID, "datagen: bad arguments");
+  PLX_REQUIRE(dtype == PLX_I64 || dtype == PLX_U32 || dtype == PLX_F64, PLX_ERR_UNSUPPORTED, "datagen_uniform: dtype must be Int64, UInt32 or Float64");
+  for (int64_t j = 0; j < n; j++) {
+    const int64_t v = datagen::uniform_value(seed, stream_id, (uint64_t)(row0 + j), lo, hi);
+    if (dtype == PLX_I64) reinterpret_cast<int64_t*>(out)[j] = v;
+    else if (dtype == PLX_U32) reinterpret_cast<uint32_t*>(out)[j] = (uint32_t)v;
+    else reinterpret_cast<double*>(out)[j] = (double)v * scale;
   }
   PLX_CATCH
 }

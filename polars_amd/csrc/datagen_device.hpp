@@ -51,5 +51,41 @@ PLX_HD inline LineitemRow lineitem_row(uint64_t seed, uint64_t i) {
   return r;
 }
 
+// ---- orders + their lineitem rows (TPC-H Q3 columns), dbgen row order: both tables ascending in orderkey ------------
+// Sparse order keys (8 of every 32 used), 1-7 lines per order, l_shipdate = o_orderdate + U[1, 121] days
+// (polars_amd/datagen.py orders_lineitem_host / _device restated as a pure function of (seed, order, line)).
+constexpr int64_t kOrderDays = 2406;             // days in [1992-01-01, 1998-08-02]
+struct OrderRow {
+  int64_t orderkey, custkey, orderdate;
+  uint32_t n_lines;
+};
+struct Q3LineRow {
+  int64_t shipdate;
+  double extendedprice, discount;
+};
+PLX_HD inline OrderRow order_row(uint64_t seed, uint64_t i, int64_t cust_hi) {
+  const uint64_t key = mix64(seed ^ 0x6f72646572730000ull);
+  OrderRow r;
+  r.orderkey = (int64_t)((i / 8) * 32 + (i % 8) + 1);
+  r.orderdate = kStart + rand_range(key, i, 0, 0, kOrderDays) * kDayUs;
+  r.custkey = rand_range(key, i, 1, 1, cust_hi);
+  r.n_lines = (uint32_t)rand_range(key, i, 2, 1, 8);
+  return r;
+}
+PLX_HD inline Q3LineRow q3_line_row(uint64_t seed, uint64_t order, uint32_t line, int64_t orderdate) {
+  const uint64_t key = mix64(mix64(seed ^ 0x6c696e6573000000ull) + order);   // one stream family per order
+  Q3LineRow r;
+  r.shipdate = orderdate + rand_range(key, line, 0, 1, 122) * kDayUs;
+  const int64_t qty = rand_range(key, line, 1, 1, 51);
+  r.extendedprice = (double)(qty * rand_range(key, line, 2, 90000, 210000)) / 100.0;
+  r.discount = (double)rand_range(key, line, 3, 0, 11) / 100.0;
+  return r;
+}
+
+// ---- one uniform column: lo + floor(U * (hi - lo)), optionally scaled to a double (BASELINE configs 2 / 3 / 5) -------
+PLX_HD inline int64_t uniform_value(uint64_t seed, uint32_t stream, uint64_t i, int64_t lo, int64_t hi) {
+  return rand_range(mix64(seed), i, stream & 7u, lo, hi);
+}
+
 }  // namespace datagen
 }  // namespace plx

@@ -148,6 +148,61 @@ def lineitem_native(pl, n_rows: int, seed: int = 10):
     return pl.DataFrame([pl.Series._from_handle(c, hs[i], lt.get(c, phys[c])) for i, c in enumerate(LINEITEM_Q1_COLS)])
 
 
+def orders_lineitem_native_host(order0: int, n: int, n_orders_total: int, seed: int = 10):
+    """Orders [order0, order0 + n) of the library's Q3 generator and their lines, on the host (no GPU)."""
+    import ctypes as C
+
+    from . import _ffi as F
+    o = {"o_orderkey": np.zeros(n, np.int64), "o_custkey": np.zeros(n, np.int64), "o_orderdate": np.zeros(n, np.int64), "o_shippriority": np.zeros(n, np.int64)}
+    cnt = np.zeros(n, np.uint32)
+    cap = 7 * n
+    li = {"l_orderkey": np.zeros(cap, np.int64), "l_extendedprice": np.zeros(cap, np.float64), "l_discount": np.zeros(cap, np.float64), "l_shipdate": np.zeros(cap, np.int64)}
+    nl = C.c_int64()
+    p = lambda a: C.c_void_p(a.ctypes.data) if a.size else C.c_void_p(0)
+    F.check(F.lib().plx_datagen_orders_lineitem_host(order0, n, n_orders_total, seed, p(o["o_orderkey"]), p(o["o_custkey"]), p(o["o_orderdate"]), p(cnt), cap,
+                                                     p(li["l_orderkey"]), p(li["l_extendedprice"]), p(li["l_discount"]), p(li["l_shipdate"]), C.byref(nl)))
+    return o, {k: v[:nl.value] for k, v in li.items()}, cnt
+
+
+def orders_lineitem_native(pl, n_orders: int, seed: int = 10):
+    """TPC-H Q3 orders / lineitem generated in HBM by the library (dbgen row order) -> (orders frame, lineitem frame)."""
+    import ctypes as C
+
+    from . import _ffi as F
+    F.ensure_init()
+    ho, hl = (C.c_uint64 * 4)(), (C.c_uint64 * 4)()
+    F.check(F.lib().plx_datagen_orders_lineitem(n_orders, seed, ho, hl))
+    lt = logical_dtypes(pl)
+    O = pl.DataFrame([pl.Series._from_handle(c, ho[i], lt.get(c, pl.Int64)) for i, c in enumerate(ORDERS_Q3_COLS)])
+    ldt = {"l_orderkey": pl.Int64, "l_extendedprice": pl.Float64, "l_discount": pl.Float64, "l_shipdate": pl.Datetime}
+    L = pl.DataFrame([pl.Series._from_handle(c, hl[i], lt.get(c, ldt[c])) for i, c in enumerate(LINEITEM_Q3_COLS)])
+    return O, L
+
+
+_NP_OF = {"Int64": np.int64, "UInt32": np.uint32, "Float64": np.float64}
+
+
+def uniform_native_host(dtype_name: str, row0: int, n: int, seed: int, stream: int, lo: int, hi: int, scale: float = 1.0) -> np.ndarray:
+    import ctypes as C
+
+    from . import _ffi as F
+    phys = {"Int64": F.I64, "UInt32": F.U32, "Float64": F.F64}[dtype_name]
+    out = np.zeros(n, _NP_OF[dtype_name])
+    F.check(F.lib().plx_datagen_uniform_host(phys, row0, n, seed, stream, lo, hi, scale, C.c_void_p(out.ctypes.data) if n else C.c_void_p(0)))
+    return out
+
+
+def uniform_native(pl, name: str, dtype, n: int, seed: int, stream: int, lo: int, hi: int, scale: float = 1.0):
+    """One uniform device column from the library's generator: lo + floor(U * (hi - lo)) (Float64: times `scale`)."""
+    import ctypes as C
+
+    from . import _ffi as F
+    F.ensure_init()
+    h = C.c_uint64()
+    F.check(F.lib().plx_datagen_uniform(dtype.physical, n, seed, stream, lo, hi, scale, C.byref(h)))
+    return pl.Series._from_handle(name, h.value, dtype)
+
+
 # ------------------------------------------------------------------------ torch ----
 def _line_columns_device(torch, g, shipdate):
     n = shipdate.numel()

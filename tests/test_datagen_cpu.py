@@ -70,3 +70,46 @@ def test_distributions_and_q1_group_structure(orc):
     ref = orc.q1(datagen.lineitem_host(n, seed=10), cutoff)
     assert sorted(zip(ref["l_returnflag"].tolist(), ref["l_linestatus"].tolist())) == pairs
     assert np.allclose(np.sort(ref["count_order"]) / n, np.sort(r["count_order"]) / n, atol=0.01)
+
+
+def test_q3_generator_host_twin(orc):
+    n = 20_000
+    orders, li, cnt = datagen.orders_lineitem_native_host(0, n, n, seed=5)
+    i = np.arange(n)
+    assert np.array_equal(orders["o_orderkey"], (i // 8) * 32 + (i % 8) + 1)            # sparse dbgen keys, ascending
+    assert cnt.min() == 1 and cnt.max() == 7 and len(li["l_orderkey"]) == int(cnt.sum())
+    assert np.array_equal(li["l_orderkey"], np.repeat(orders["o_orderkey"], cnt))       # dbgen row order
+    odate = np.repeat(orders["o_orderdate"], cnt)
+    lag = (li["l_shipdate"] - odate) // DAY
+    assert lag.min() >= 1 and lag.max() <= 121 and np.all((li["l_shipdate"] - odate) % DAY == 0)
+    d = (orders["o_orderdate"] - datagen.START) // DAY
+    assert d.min() >= 0 and d.max() <= 2405 and orders["o_orderdate"].max() <= datagen.END_ORDERS
+    assert orders["o_custkey"].min() >= 1 and orders["o_custkey"].max() <= max(2, n // 10)
+    assert np.all(orders["o_shippriority"] == 0)
+    # a sub-range is the same table (pure function of seed / order / line)
+    o2, l2, c2 = datagen.orders_lineitem_native_host(5000, 300, n, seed=5)
+    lo = int(cnt[:5000].sum())
+    assert np.array_equal(o2["o_orderdate"], orders["o_orderdate"][5000:5300]) and np.array_equal(c2, cnt[5000:5300])
+    for c in datagen.LINEITEM_Q3_COLS:
+        assert np.array_equal(l2[c], li[c][lo:lo + len(l2[c])])
+    # Q3 over it has the shape the benchmark relies on: ~10 % of the orders pass the build filter, a few per cent of them end up as groups
+    r = orc.q3(li, orders, datagen.us(1995, 3, 15))
+    assert 0.003 * n < len(r["l_orderkey"]) < 0.03 * n and np.all(r["revenue"] > 0)
+    ref_o, ref_l = datagen.orders_lineitem_host(n, seed=5, ordered=True)
+    ref = orc.q3(ref_l, ref_o, datagen.us(1995, 3, 15))
+    assert 0.7 < len(r["l_orderkey"]) / len(ref["l_orderkey"]) < 1.4                    # same selectivities as the numpy generator
+
+
+def test_uniform_generator_host_twin():
+    a = datagen.uniform_native_host("Int64", 0, 100_000, 7, 0, 0, 2 ** 31)
+    assert a.min() >= 0 and a.max() < 2 ** 31 and abs(a.mean() / 2 ** 30 - 1) < 0.02
+    k = datagen.uniform_native_host("UInt32", 0, 100_000, 7, 1, 0, 1_000_000)
+    assert k.dtype == np.uint32 and k.max() < 1_000_000 and len(np.unique(k)) > 90_000
+    x = datagen.uniform_native_host("Float64", 0, 100_000, 7, 2, 0, 10 ** 9, 1e-7)
+    assert 0.0 <= x.min() and x.max() < 100.0 and abs(x.mean() - 50.0) < 0.5
+    assert np.array_equal(datagen.uniform_native_host("Int64", 500, 100, 7, 0, 0, 2 ** 31), a[500:600])
+    assert not np.array_equal(datagen.uniform_native_host("Int64", 0, 1000, 7, 3, 0, 2 ** 31), a[:1000])       # streams are independent
+    # restated: lo + ((mix(mix(seed) + i * 8 + stream) * span) >> 64)
+    key = _mix(7)
+    for i in (0, 1, 99_999):
+        assert a[i] == (_mix((key + i * 8 + 0) & M64) * 2 ** 31) >> 64

@@ -29,3 +29,23 @@ def test_q1_over_generated_table_matches_oracle(pl, orc):
     assert g["count_order"] == want["count_order"].tolist() and g["sum_qty"] == want["sum_qty"].tolist()
     for c in ("sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc"):
         assert np.allclose(np.array(g[c]), want[c], rtol=1e-6, atol=0), c
+
+
+@pytest.mark.parametrize("n_orders", [0, 1, 5000, 300_001])
+def test_q3_device_generator_equals_host_twin(pl, n_orders):
+    from polars_amd import datagen
+    O, L = datagen.orders_lineitem_native(pl, n_orders, seed=8)
+    wo, wl, cnt = datagen.orders_lineitem_native_host(0, n_orders, n_orders, 8)
+    assert O.height == n_orders and L.height == int(cnt.sum())
+    for c in datagen.ORDERS_Q3_COLS:
+        assert np.array_equal(O[c].to_numpy(), wo[c]), c
+    for c in datagen.LINEITEM_Q3_COLS:
+        assert np.array_equal(L[c].to_numpy(), wl[c]), c
+
+
+def test_uniform_device_generator_equals_host_twin(pl):
+    from polars_amd import datagen
+    n = 1_000_003
+    for name, dt, args in (("Int64", pl.Int64, (3, 0, 0, 2 ** 31, 1.0)), ("UInt32", pl.UInt32, (3, 1, 0, 1_000_000, 1.0)), ("Float64", pl.Float64, (3, 2, 0, 10 ** 9, 1e-7))):
+        s = datagen.uniform_native(pl, "c", dt, n, *args)
+        assert np.array_equal(s.to_numpy(), datagen.uniform_native_host(name, 0, n, *args)), name
