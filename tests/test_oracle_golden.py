@@ -360,3 +360,43 @@ def test_numpy_q1_reference_matches_oracle(orc):
         assert g["count_order"] == want["count_order"][i] and g["sum_qty"] == want["sum_qty"][i]
         for c in ("sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc"):
             assert math.isclose(g[c], want[c][i], rel_tol=1e-9), (key, c)
+
+
+def test_sort_oracle_against_pyarrow():
+    """Independent implementation check (the reference cross-checks against pandas the same way): pyarrow's stable
+    sort_indices with one null placement for all keys, integer / NaN-free float / boolean keys, per-key direction."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(12)
+    for trial in range(60):
+        n = int(rng.integers(1, 400))
+        nk = int(rng.integers(1, 4))
+        nulls_last = bool(rng.integers(0, 2))
+        keys, arrays, sort_keys = [], {}, []
+        for j in range(nk):
+            kind = int(rng.integers(0, 3))
+            v = (rng.integers(-5, 6, n).astype(np.int64) if kind == 0 else rng.integers(-8, 9, n).astype(np.float64) / 4 if kind == 1 else rng.integers(0, 2, n).astype(bool))
+            m = None if rng.random() < 0.4 else rng.random(n) < 0.75
+            desc = bool(rng.integers(0, 2))
+            keys.append((v, m, desc, nulls_last))
+            arrays[f"k{j}"] = pa.array(v, mask=None if m is None else ~m)
+            sort_keys.append((f"k{j}", "descending" if desc else "ascending"))
+        want = pc.sort_indices(pa.table(arrays), sort_keys=sort_keys, null_placement="at_end" if nulls_last else "at_start").to_numpy()
+        assert np.array_equal(orc.sort_indices(keys), want), (trial, sort_keys, nulls_last)
+
+
+def test_semi_anti_oracle_against_pandas():
+    import pandas as pd
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(13)
+    for trial in range(20):
+        nl, nr = int(rng.integers(0, 300)), int(rng.integers(0, 200))
+        lk, rk = rng.integers(0, 60, nl).astype(np.int64), rng.integers(0, 60, nr).astype(np.int64)
+        lm, rm = rng.random(nl) < 0.9, rng.random(nr) < 0.8
+        left = pd.DataFrame({"k": pd.array(np.where(lm, lk, 0), dtype="Int64")})
+        left.loc[~lm, "k"] = pd.NA
+        right_keys = set(rk[rm].tolist())
+        matched = left["k"].map(lambda x: (x is not pd.NA) and (x in right_keys)).to_numpy(dtype=bool) if nl else np.zeros(0, bool)
+        assert np.array_equal(orc.semi_anti_join(orc.JOIN_SEMI, lk, lm, rk, rm), np.nonzero(matched)[0])
+        assert np.array_equal(orc.semi_anti_join(orc.JOIN_ANTI, lk, lm, rk, rm), np.nonzero(~matched)[0])
