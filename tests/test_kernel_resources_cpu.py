@@ -38,3 +38,16 @@ def test_aot_kernels_do_not_spill():
             assert int(r["ScratchSize [bytes/lane]"]) == 0, (name, r)
             assert int(r["VGPRs"]) <= 256, (name, r)
     assert checked >= 18, checked
+
+
+def test_sort_join_datagen_kernels_do_not_spill():
+    """The radix-sort, hash-join and generator kernels keep everything in registers / LDS (the sort scatter stages its tile in
+    exactly 64 KB of LDS: two workgroups per CU)."""
+    checked = 0
+    for src in ("kernels_sort.hip", "kernels_join.hip", "kernels_datagen.hip"):
+        for name, r in resource_usage(src).items():
+            checked += 1
+            assert int(r["ScratchSize [bytes/lane]"]) == 0, (name, r)
+            if "radix_scatter" in name:
+                assert int(r["LDS Size [bytes/block]"]) <= 80 * 1024, (name, r)
+    assert checked >= 15, checked
