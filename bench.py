@@ -325,6 +325,19 @@ def roofline(stats, wl):
             "avg_kernel_us": round(avg_us, 2), "launches": cnt, "algo_bytes_per_launch": algo, "traffic": pmc_traffic(wl.name, name, wl.rows)}
 
 
+def pyarrow_q1(cols, cutoff):
+    """TPC-H Q1 with pyarrow (compute kernels + Acero group_by, its own thread pool): a third-party CPU yardstick next to
+    the oracle; returns the result table."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    t = pa.table({k: pa.array(v) for k, v in cols.items()})
+    t = t.filter(pc.less_equal(t["l_shipdate"], pa.scalar(cutoff, pa.int64())))
+    disc_price = pc.multiply(t["l_extendedprice"], pc.subtract(pa.scalar(1.0), t["l_discount"]))
+    t = t.append_column("disc_price", disc_price).append_column("charge", pc.multiply(disc_price, pc.add(pa.scalar(1.0), t["l_tax"])))
+    return t.group_by(["l_returnflag", "l_linestatus"]).aggregate([("l_quantity", "sum"), ("l_extendedprice", "sum"), ("disc_price", "sum"), ("charge", "sum"),
+                                                                   ("l_quantity", "mean"), ("l_extendedprice", "mean"), ("l_discount", "mean"), ([], "count_all")])
+
+
 def cpu_baseline_q1(seconds: float):
     """TPC-H Q1 on the host cores with the CPU oracle -- a C++ restatement of the reference's algorithms
     (NOT Polars itself: no polars wheel / rustc in the image), on a bounded sample of the same workload.
@@ -351,11 +364,19 @@ def cpu_baseline_q1(seconds: float):
     cm = {k: v[:n_mem] for k, v in cols.items()}
     t0 = time.perf_counter(); orc.q1_native(cm, cutoff, streaming=False); dt_mem = time.perf_counter() - t0
     orc.set_threads(1)
+    n_pa, pa_rate = min(n, 50_000_000), None
+    try:
+        cp = {k: v[:n_pa] for k, v in cols.items()}
+        pyarrow_q1(cp, cutoff)
+        t0 = time.perf_counter(); pyarrow_q1(cp, cutoff); pa_rate = round(n_pa / (time.perf_counter() - t0), 1)
+    except Exception:   # a yardstick only
+        pa_rate = None
     return {"value": round(n / best, 1), "unit": "rows/s", "cores": cores, "kind": "port", "seconds": round(best, 3),
-            "in_memory_engine_rows_per_s": round(n_mem / dt_mem, 1),
+            "in_memory_engine_rows_per_s": round(n_mem / dt_mem, 1), "pyarrow_acero_rows_per_s": pa_rate,
             "sample": f"TPC-H Q1 on {n} synthetic lineitem rows (same generator, best of 3), oracle/plx_oracle.cpp orc_q1_streaming with {cores} threads: "
                       "C++ restatement of the reference's streaming/partitioned group-by path (morsels, thread-local hot tables), not Polars itself; "
-                      f"in_memory_engine_rows_per_s = orc_q1 (FilterExec -> GroupByExec with per-group index lists) on {n_mem} rows"}
+                      f"in_memory_engine_rows_per_s = orc_q1 (FilterExec -> GroupByExec with per-group index lists) on {n_mem} rows; "
+                      f"pyarrow_acero_rows_per_s = the same query with pyarrow compute + Acero group_by on {n_pa} rows (third-party yardstick)"}
 
 
 Q1_FIELDS = ("l_returnflag", "l_linestatus", "sum_qty", "count_order", "sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc")

@@ -59,3 +59,18 @@ def test_worker_dying_before_the_headline_prints_nothing_and_fails(capsys):
         raise RuntimeError("no GPU")
     assert bench.run_guarded(worker, deadline_s=30) != 0
     assert _lines(capsys) == []
+
+
+def test_pyarrow_yardstick_computes_q1(orc):
+    """The third-party CPU yardstick of bench.py's cpu_baseline evaluates the same query as the oracle."""
+    import numpy as np
+    from polars_amd import datagen
+    cols = datagen.lineitem_host(200_000, seed=4)
+    cutoff = datagen.us(1998, 9, 2)
+    t = bench.pyarrow_q1({k: cols[k] for k in datagen.LINEITEM_Q1_COLS}, cutoff).to_pydict()
+    want = orc.q1(cols, cutoff)
+    order = sorted(range(len(t["l_returnflag"])), key=lambda i: (t["l_returnflag"][i], t["l_linestatus"][i]))
+    assert [t["l_returnflag"][i] for i in order] == want["l_returnflag"].tolist()
+    assert [t["count_all"][i] for i in order] == want["count_order"].tolist() and [t["l_quantity_sum"][i] for i in order] == want["sum_qty"].tolist()
+    assert np.allclose([t["charge_sum"][i] for i in order], want["sum_charge"], rtol=1e-9)
+    assert np.allclose([t["l_discount_mean"][i] for i in order], want["avg_disc"], rtol=1e-9)
