@@ -529,6 +529,17 @@ int plx_execute_plan(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int
 }
 const char* plx_last_plan_description(void) { return t_plan_desc.c_str(); }
 
+int plx_debug_program_json(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int32_t n_exprs, int32_t root, char* buf, size_t cap) {
+  PLX_TRY
+  PLX_REQUIRE(buf && cap > 0, PLX_ERR_INVALID, "null buffer");
+  engine::Plan p = engine::import_plan(ir, n_ir, exprs, n_exprs, 0);
+  std::string json, why;
+  if (!engine::dump_program_json(p, root, &json, &why)) fail(PLX_ERR_UNSUPPORTED, "not a fusable pipeline: " + why);
+  PLX_REQUIRE(json.size() + 1 <= cap, PLX_ERR_INVALID, "buffer too small for the program dump (" + std::to_string(json.size() + 1) + " bytes)");
+  memcpy(buf, json.c_str(), json.size() + 1);
+  PLX_CATCH
+}
+
 int plx_describe_fusion(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int32_t n_exprs, int32_t root, int32_t* fusable, int32_t* static_shape_id,
                         char* why_not, size_t why_cap) {
   PLX_TRY

@@ -846,6 +846,57 @@ static ColumnPtr first_row_permutation(const FusedAggResult& r, int first_idx) {
   return column_from_host(PLX_U32, perm.data(), nullptr, 0, G);
 }
 
+// ---- machine-readable dump of a compiled pipeline (dump_program_json) ----
+struct ProgramDump {
+  std::string json;
+};
+static thread_local ProgramDump* t_program_dump = nullptr;   // set only for the duration of a dump_program_json call
+static std::string jstr(const std::string& x) { std::string o = "\""; for (char ch : x) { if (ch == '"' || ch == '\\') o += '\\'; o += ch; } return o + "\""; }
+static void dump_compiled(ProgramDump* dump, const char* kind, const Plan& plan, const Compiler& c, const KeyPlan* kp, const std::vector<int>& agg_nodes,
+                          const std::vector<FinalSpec>& specs, const std::vector<int>& out_exprs, int len_idx, int first_idx, bool maintain_order) {
+  if (!dump) return;
+  std::ostringstream o;
+  const Shape& sh = c.shape;
+  o << "{\"kind\":\"" << kind << "\",\"n_rows\":" << c.args.n_rows << ",\"inputs\":[";
+  auto name_of = [&](int col_id) -> std::string {   // input_cols holds the compiler's own column ids: map the buffer back to its frame column
+    const ColumnPtr& buf = c.cols[col_id];
+    for (size_t j = 0; j < c.df->cols.size(); j++) if (c.df->cols[j] == buf) return c.df->names[j];
+    return "?";
+  };
+  for (int i = 0; i < sh.n_inputs; i++)
+    o << (i ? "," : "") << "{\"name\":" << jstr(name_of(c.input_cols[i])) << ",\"dtype\":" << (int)sh.in_dtype[i] << ",\"nullable\":" << (int)sh.in_nullable[i] << "}";
+  o << "],\"ops\":[";
+  for (int i = 0; i < sh.n_ops; i++)
+    o << (i ? "," : "") << "[" << (int)sh.ops[i].code << "," << (int)sh.ops[i].dst << "," << (int)sh.ops[i].a << "," << (int)sh.ops[i].b << "," << (int)sh.ops[i].c << ",\"" << c.args.imm[i] << "\"]";
+  o << "],\"pred\":" << (int)sh.pred << ",\"key\":" << (int)sh.key << ",\"keys\":[";
+  for (int i = 0; i < sh.n_keys; i++) o << (i ? "," : "") << (int)sh.keys[i];
+  o << "],\"aggs\":[";
+  for (int i = 0; i < sh.n_aggs; i++) o << (i ? "," : "") << "[" << (int)sh.aggs[i].kind << "," << (int)sh.aggs[i].src << "]";
+  o << "],\"len_idx\":" << len_idx << ",\"first_idx\":" << first_idx << ",\"maintain_order\":" << (maintain_order ? 1 : 0);
+  if (kp) {
+    o << ",\"key_plan\":{\"packed\":" << (kp->packed ? 1 : 0) << ",\"wide\":" << (kp->wide ? 1 : 0) << ",\"parts\":[";
+    for (size_t i = 0; i < kp->parts.size(); i++) {
+      const KeyPart& kpart = kp->parts[i];
+      o << (i ? "," : "") << "{\"name\":" << jstr(output_name(plan, kpart.expr)) << ",\"dtype\":" << kpart.dtype << ",\"nullable\":" << (kpart.nullable ? 1 : 0) << ",\"shift\":" << kpart.dec.shift
+        << ",\"mask\":\"" << kpart.dec.mask << "\",\"min\":\"" << kpart.dec.min << "\",\"null_code\":\"" << kpart.dec.null_code << "\"}";
+    }
+    o << "]}";
+  }
+  o << ",\"finals\":[";
+  for (size_t i = 0; i < specs.size(); i++)
+    o << (i ? "," : "") << "{\"kind\":" << (int)specs[i].kind << ",\"a\":" << (int)specs[i].a << ",\"b\":" << (int)specs[i].b << ",\"c\":" << (int)specs[i].c << ",\"out_dtype\":" << (int)specs[i].out_dtype << "}";
+  o << "],\"outputs\":[";
+  for (size_t i = 0; i < out_exprs.size(); i++) {
+    int e = out_exprs[i];
+    while (plan.ae[e].kind == PLX_AE_ALIAS) e = plan.ae[e].lhs;
+    int idx = -1;                                   // index into finals when the output IS one aggregate (else: a row expression over aggregates)
+    for (size_t j = 0; j < agg_nodes.size(); j++) if (agg_nodes[j] == e) idx = (int)j;
+    o << (i ? "," : "") << "{\"name\":" << jstr(output_name(plan, out_exprs[i])) << ",\"final\":" << idx << "}";
+  }
+  o << "]}";
+  dump->json = o.str();
+}
+
 // Select(aggregations) over [Filter]* over `src`
 static bool fused_select(Plan& plan, const IRN& node, const std::vector<int>& preds, const FramePtr& src, FramePtr& out, Shape* shape_out, int* sid_out,
                          std::string* why, bool compile_only) {
@@ -864,7 +915,7 @@ static bool fused_select(Plan& plan, const IRN& node, const std::vector<int>& pr
   const int static_id = find_static_shape(c.shape);
   if (shape_out) *shape_out = c.shape;
   if (sid_out) *sid_out = static_id;
-  if (compile_only) return true;
+  if (compile_only) { dump_compiled(t_program_dump, "select", plan, c, nullptr, agg_nodes, specs, node.exprs, -1, -1, false); return true; }
   FusedAggResult r; r.n_groups = 1; r.n_aggs = c.shape.n_aggs;
   std::vector<uint64_t> host(kMaxAggs, 0);
   if (src->height == 0) { for (int k2 = 0; k2 < c.shape.n_aggs; k2++) host[k2] = agg_identity(c.shape.aggs[k2].kind); }
@@ -910,7 +961,7 @@ static bool fused_groupby(Plan& plan, const IRN& node, const std::vector<int>& p
   } catch (const Unsupported& u) { if (why) *why = u.why; return false; }
   if (shape_out) *shape_out = c.shape;
   if (sid_out) *sid_out = find_static_shape(c.shape);
-  if (compile_only) return true;
+  if (compile_only) { dump_compiled(t_program_dump, "group_by", plan, c, &kp, agg_nodes, specs, node.exprs, len_idx, first_idx, node.maintain_order != 0); return true; }
   FusedAggResult r;
   std::string d;
   run_fused_groupby(c, kp, len_idx, r, d);
@@ -1416,6 +1467,16 @@ bool describe_fusion(Plan& plan, int root, Shape* shape, int* static_id, std::st
   if (n.kind == PLX_IR_GROUPBY) return fused_groupby(plan, n, preds, src, out, shape, static_id, why_not, true);
   if (why_not) *why_not = "root is neither Select nor GroupBy";
   return false;
+}
+
+bool dump_program_json(Plan& plan, int root, std::string* json, std::string* why_not) {
+  ProgramDump d;
+  t_program_dump = &d;
+  bool ok = false;
+  try { ok = describe_fusion(plan, root, nullptr, nullptr, why_not); } catch (...) { t_program_dump = nullptr; throw; }
+  t_program_dump = nullptr;
+  if (ok && json) *json = d.json;
+  return ok && !d.json.empty();
 }
 
 // generic grouped aggregation over already materialised columns: builds a LOAD-only

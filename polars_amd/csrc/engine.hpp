@@ -57,6 +57,10 @@ void groupby_columns(const std::vector<ColumnPtr>& keys, const std::vector<Colum
 // `root` and reports the fused shape (and whether an AOT specialisation matches)
 // without touching the GPU.  Returns false if the plan is not fusable.
 bool describe_fusion(Plan& plan, int root, fused::Shape* shape, int* static_id, std::string* why_not);
+// The complete compiled form of a fusable `[Filter]* -> Select | GroupBy` pipeline as JSON (register program with its
+// immediates, input columns, aggregate cells, key packing / decoding, finalisation of every output): what the GPU will
+// execute, in a form the CPU tests interpret row by row against the oracle (tests/program_eval.py).  Compile only.
+bool dump_program_json(Plan& plan, int root, std::string* json, std::string* why_not);
 // GroupBy directly over an inner Join: the three programs (count, build, probe) of the fused
 // join->aggregate pipeline, or false + reason when the per-node path would run.
 bool describe_join_fusion(Plan& plan, int root, std::vector<fused::Shape>* shapes, std::string* why_not);

@@ -654,6 +654,17 @@ class LazyFrame:
         F.check(F.lib().plx_jit_selftest(ir, n_ir, ae, n_ae, root))
         del keep
 
+    def debug_program(self) -> dict:
+        """The complete compiled form of this (fusable) pipeline -- register program, immediates, aggregate cells, key
+        packing, finalisation -- as a dict (plx_debug_program_json).  Compile only: works on placeholder columns, no GPU."""
+        import json
+        low, root, _ = self._lower()
+        ir, n_ir, ae, n_ae, keep = low.to_c()
+        buf = C.create_string_buffer(1 << 16)
+        F.check(F.lib().plx_debug_program_json(ir, n_ir, ae, n_ae, root, buf, len(buf)))
+        del keep
+        return json.loads(buf.value.decode())
+
     def describe_fusion(self):
         """(fusable, static_shape_id, reason, program dump) -- compile only, no kernel launch."""
         low, root, _ = self._lower()

@@ -1,0 +1,234 @@
+"""Row-level interpreter of the engine's compiled pipelines (plx_debug_program_json), in numpy.
+
+Test infrastructure: the C++ expression compiler (polars_amd/csrc/engine.cpp, class Compiler + lower_keys + lower_agg)
+turns `[Filter]* -> Select | GroupBy` plans into a register program, aggregate cells, a key packing and a finalisation
+recipe; the GPU kernels execute exactly that (fused_device.hpp exec_op / agg_row_value, kernels_fused.hip finalize).
+This module restates those device semantics over whole numpy columns, so the CPU tests can run what the compiler
+emitted against the oracle without a GPU.  Opcodes / kinds mirror polars_amd/csrc/fused.hpp.
+"""
+import numpy as np
+
+(OP_NOP, OP_LOAD, OP_CONST, OP_ADD_F, OP_SUB_F, OP_MUL_F, OP_DIV_F, OP_ADD_I, OP_SUB_I, OP_MUL_I, OP_I2F, OP_U2F, OP_CMP_I, OP_CMP_U, OP_CMP_F,
+ OP_AND, OP_OR, OP_XOR, OP_NOT, OP_IFNULL, OP_MOV, OP_CANON_F, OP_FDIV_I, OP_MOD_I, OP_FDIV_U, OP_MOD_U) = range(26)
+(AGG_NONE, AGG_SUM_F, AGG_SUM_I, AGG_COUNT, AGG_COUNT_ORD, AGG_LEN, AGG_MIN_F, AGG_MAX_F, AGG_MIN_I, AGG_MAX_I, AGG_MIN_U, AGG_MAX_U, AGG_FIRST_ROW) = range(13)
+FIN_COPY64, FIN_TRUNC32, FIN_MEAN, FIN_MINMAX_I, FIN_MINMAX_F, FIN_NARROW = range(6)
+# plx_dtype (include/polars_amd.h)
+BOOL, I8, I16, I32, I64, U8, U16, U32, U64, F32, F64 = range(11)
+NP = {I8: np.int8, I16: np.int16, I32: np.int32, I64: np.int64, U8: np.uint8, U16: np.uint16, U32: np.uint32, U64: np.uint64, F32: np.float32, F64: np.float64}
+NONE = 255
+U = np.uint64
+
+
+def _f(a):
+    return a.view(np.float64)
+
+
+def _u(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _cmp(op, a, b, floats):
+    if floats:   # total order: NaN == NaN, NaN greatest (dev.hpp tot_*)
+        an, bn = np.isnan(a), np.isnan(b)
+        eq = (an & bn) | (a == b)
+        lt = ~an & (bn | (a < b)) & ~eq
+    else:
+        eq, lt = a == b, a < b
+    return [eq, ~eq, lt, lt | eq, ~(lt | eq), ~lt][op]
+
+
+def _floor_div_mod(x, y, want_div, signed):
+    nz = y != 0
+    ys = np.where(nz, y, 1)
+    with np.errstate(over="ignore"):
+        if signed:
+            xs, yy = x.view(np.int64), ys.view(np.int64)
+            q, m = np.floor_divide(xs, yy), np.mod(xs, yy)          # numpy = Python sign rules = the reference's floor semantics
+            neg1 = yy == -1                                          # wrapping_div(MIN, -1) = MIN, remainder 0
+            q = np.where(neg1, (U(0) - x).view(np.int64), q); m = np.where(neg1, 0, m)
+            r = (q if want_div else m).astype(np.int64).view(np.uint64)
+        else:
+            r = (x // ys) if want_div else (x % ys)
+    return np.where(nz, r, U(0)), nz
+
+
+def run_rows(prog, cols):
+    """Executes the register program over all rows.  cols: {name: (values ndarray, valid bool ndarray or None)}.
+    Returns (slots {slot: (u64 values, bool valid)}, pass mask)."""
+    n = len(next(iter(cols.values()))[0]) if cols else 0
+    slots = {}
+    ones = np.ones(n, dtype=bool)
+    for op in prog["ops"]:
+        code, dst, a, b, c, imm = op[0], op[1], op[2], op[3], op[4], U(int(op[5]))
+        if code == OP_LOAD:
+            inp = prog["inputs"][a]
+            v, m = cols[inp["name"]]
+            dt = inp["dtype"]
+            if dt == BOOL:
+                d = v.astype(np.uint64)
+            elif dt == F64:
+                d = _u(v)
+            elif dt in (I8, I16, I32, I64):
+                d = v.astype(np.int64).view(np.uint64)
+            elif dt in (U8, U16, U32, U64):
+                d = v.astype(np.uint64)
+            else:
+                raise NotImplementedError(f"input dtype {dt}")
+            vd = ones.copy() if m is None else m.copy()
+        elif code == OP_CONST:
+            d, vd = np.full(n, imm, dtype=np.uint64), ones.copy()
+        else:
+            (x, vx), (y, vy) = slots[a], slots[b]
+            vd = vx & vy
+            with np.errstate(all="ignore"):
+                if code == OP_ADD_F: d = _u(_f(x) + _f(y))
+                elif code == OP_SUB_F: d = _u(_f(x) - _f(y))
+                elif code == OP_MUL_F: d = _u(_f(x) * _f(y))
+                elif code == OP_DIV_F: d = _u(_f(x) / _f(y))
+                elif code == OP_ADD_I: d = x + y
+                elif code == OP_SUB_I: d = x - y
+                elif code == OP_MUL_I: d = x * y
+                elif code == OP_I2F: d, vd = _u(x.view(np.int64).astype(np.float64)), vx
+                elif code == OP_U2F: d, vd = _u(x.astype(np.float64)), vx
+                elif code == OP_CMP_I: d = _cmp(c, x.view(np.int64), y.view(np.int64), False).astype(np.uint64)
+                elif code == OP_CMP_U: d = _cmp(c, x, y, False).astype(np.uint64)
+                elif code == OP_CMP_F: d = _cmp(c, _f(x), _f(y), True).astype(np.uint64)
+                elif code in (OP_AND, OP_OR):
+                    ta, tb = (x & U(1)).astype(bool), (y & U(1)).astype(bool)
+                    if code == OP_AND:   # Kleene: false wins over null
+                        d = (ta & tb).astype(np.uint64); vd = (~tb & vy) | (~ta & vx) | (ta & vx & tb & vy)
+                    else:                # Kleene: true wins over null
+                        d = (ta | tb).astype(np.uint64); vd = (ta & vx) | (tb & vy) | (~ta & vx & ~tb & vy)
+                elif code == OP_XOR: d = (x ^ y) & U(1)
+                elif code == OP_NOT: d, vd = (~x) & U(1), vx
+                elif code == OP_CANON_F:
+                    f = _f(x)
+                    d, vd = np.where(np.isnan(f), U(0x7ff8000000000000), _u(f + 0.0)), vx
+                elif code in (OP_FDIV_I, OP_MOD_I):
+                    d, nz = _floor_div_mod(x, y, code == OP_FDIV_I, True); vd = vd & nz
+                elif code in (OP_FDIV_U, OP_MOD_U):
+                    d, nz = _floor_div_mod(x, y, code == OP_FDIV_U, False); vd = vd & nz
+                elif code == OP_IFNULL: d, vd = np.where(vx, x, imm), ones.copy()
+                elif code in (OP_MOV, OP_NOP): d, vd = x, vx
+                else:
+                    raise NotImplementedError(f"opcode {code}")
+        slots[dst] = (np.ascontiguousarray(d, dtype=np.uint64), vd)
+        # snapshot semantics: a later op may overwrite a slot; consumers read the value current at their turn
+    if prog["pred"] == NONE:
+        passed = ones
+    else:
+        pv, pm = slots[prog["pred"]]
+        passed = (pv & U(1)).astype(bool) & pm
+    return slots, passed
+
+
+def _snapshot_sources(prog, cols):
+    """Aggregate / key sources must be read when the program ends; a slot can be reused, so re-run and capture the
+    final contents (the compiler guarantees sources stay live until the end)."""
+    return run_rows(prog, cols)
+
+
+def _cells(prog, slots, passed, rows, group_of, n_groups):
+    """Aggregate cells [n_groups][n_aggs] as uint64 bit patterns (agg_row_value + agg_combine)."""
+    out = np.zeros((n_groups, len(prog["aggs"])), dtype=np.uint64)
+    for k, (kind, src) in enumerate(prog["aggs"]):
+        v, valid = slots[src] if src != NONE else (np.zeros(len(passed), np.uint64), np.ones(len(passed), bool))
+        sel = passed & valid if kind not in (AGG_LEN, AGG_FIRST_ROW) else passed
+        g = group_of[sel]
+        if kind in (AGG_LEN, AGG_COUNT):
+            out[:, k] = np.bincount(g, minlength=n_groups).astype(np.uint64)
+        elif kind == AGG_COUNT_ORD:
+            ok = sel & ~np.isnan(_f(v))
+            out[:, k] = np.bincount(group_of[ok], minlength=n_groups).astype(np.uint64)
+        elif kind == AGG_SUM_I:
+            acc = np.zeros(n_groups, np.uint64); np.add.at(acc, g, v[sel]); out[:, k] = acc
+        elif kind == AGG_SUM_F:
+            acc = np.zeros(n_groups, np.float64); np.add.at(acc, g, _f(v)[sel]); out[:, k] = _u(acc)
+        elif kind in (AGG_MIN_F, AGG_MAX_F):
+            f = _f(v); ok = sel & ~np.isnan(f)
+            acc = np.full(n_groups, np.inf if kind == AGG_MIN_F else -np.inf)
+            (np.minimum if kind == AGG_MIN_F else np.maximum).at(acc, group_of[ok], f[ok]); out[:, k] = _u(acc)
+        elif kind in (AGG_MIN_I, AGG_MAX_I):
+            acc = np.full(n_groups, np.iinfo(np.int64).max if kind == AGG_MIN_I else np.iinfo(np.int64).min, dtype=np.int64)
+            (np.minimum if kind == AGG_MIN_I else np.maximum).at(acc, g, v.view(np.int64)[sel]); out[:, k] = acc.view(np.uint64)
+        elif kind in (AGG_MIN_U, AGG_MAX_U):
+            acc = np.full(n_groups, np.iinfo(np.uint64).max if kind == AGG_MIN_U else 0, dtype=np.uint64)
+            (np.minimum if kind == AGG_MIN_U else np.maximum).at(acc, g, v[sel]); out[:, k] = acc
+        elif kind == AGG_FIRST_ROW:
+            acc = np.full(n_groups, np.iinfo(np.uint64).max, dtype=np.uint64)
+            np.minimum.at(acc, g, rows[sel].astype(np.uint64)); out[:, k] = acc
+        else:
+            raise NotImplementedError(f"aggregate kind {kind}")
+    return out
+
+
+def _finalise(fs, cells):
+    """One output column from the cells (finalize_batch_kernel): -> (values, valid or None)."""
+    kind, a, b, c, dt = fs["kind"], fs["a"], fs["b"], fs["c"], fs["out_dtype"]
+    ca = cells[:, a]
+    if kind in (FIN_COPY64, FIN_NARROW, FIN_TRUNC32):
+        if dt == F64:
+            return _f(np.ascontiguousarray(ca)).copy(), None
+        return ca.astype(NP[dt]) if dt in (U8, U16, U32, U64) else ca.view(np.int64).astype(NP[dt]), None   # wrapping narrow
+    cnt = cells[:, b]
+    if kind == FIN_MEAN:
+        with np.errstate(all="ignore"):
+            return _f(np.ascontiguousarray(ca)) / cnt.astype(np.float64), cnt != 0
+    if kind == FIN_MINMAX_I:
+        vals = ca.astype(NP[dt]) if dt in (U8, U16, U32, U64) else ca.view(np.int64).astype(NP[dt])
+        return vals, cnt != 0
+    if kind == FIN_MINMAX_F:
+        vals = _f(np.ascontiguousarray(ca)).copy()
+        vals[(cells[:, c] == 0) & (cnt != 0)] = np.nan              # only NaNs among the valid rows
+        return vals, cnt != 0
+    raise NotImplementedError(f"final kind {kind}")
+
+
+def evaluate(prog, cols):
+    """-> {output name: (values, valid or None)}; group_by results carry one row per group, in unspecified order."""
+    slots, passed = run_rows(prog, cols)
+    n = len(passed)
+    rows = np.arange(n)
+    res = {}
+    if prog["kind"] == "select":
+        cells = _cells(prog, slots, passed, rows, np.zeros(n, dtype=np.int64), 1)
+    else:
+        kp = prog["key_plan"]
+        if kp["wide"]:
+            words = [np.where(slots[s][1], slots[s][0], U(0)) for s in prog["keys"]]
+            valids = [slots[s][1] for s in prog["keys"]]
+            ident = np.stack(words + [v.astype(np.uint64) for v in valids], axis=1)
+        else:
+            kv, km = slots[prog["key"]]
+            ident = np.stack([np.where(km, kv, U(0)), km.astype(np.uint64)], axis=1)
+        sel_rows = np.nonzero(passed)[0]
+        uniq, inv = np.unique(ident[sel_rows], axis=0, return_inverse=True)
+        group_of = np.zeros(n, dtype=np.int64); group_of[sel_rows] = np.asarray(inv).reshape(-1)
+        G = len(uniq)
+        cells = _cells(prog, slots, passed, rows, group_of, G)
+        nk = len(kp["parts"])
+        for i, part in enumerate(kp["parts"]):
+            dt = part["dtype"]
+            if kp["wide"]:
+                word, valid = uniq[:, i], uniq[:, nk + i].astype(bool)
+            elif kp["packed"]:
+                code = (uniq[:, 0] >> U(part["shift"])) & U(int(part["mask"]))
+                null_code = int(part["null_code"])
+                valid = code != U(null_code) if null_code != (1 << 64) - 1 else np.ones(G, bool)
+                word = code + np.int64(int(part["min"])).astype(np.uint64) if int(part["min"]) >= 0 else code - U(-int(part["min"]))
+            else:
+                word, valid = uniq[:, 0], uniq[:, 1].astype(bool)
+            if dt == F64:
+                vals = _f(np.ascontiguousarray(word)).copy()
+            elif dt == BOOL:
+                vals = (word & U(1)).astype(bool)
+            elif dt in (U8, U16, U32, U64):
+                vals = word.astype(NP[dt])
+            else:
+                vals = word.view(np.int64).astype(NP[dt])
+            res[part["name"]] = (vals, None if valid.all() else valid)
+    for o in prog["outputs"]:
+        if o["final"] < 0:
+            raise NotImplementedError(f"output {o['name']} is a row expression over aggregates (evaluated by the per-node kernels)")
+        res[o["name"]] = _finalise(prog["finals"][o["final"]], cells)
+    return res

@@ -1,0 +1,165 @@
+"""The C++ expression compiler without a GPU: the pipelines it emits (plx_debug_program_json: register program, aggregate
+cells, key packing, finalisation) are interpreted row by row in numpy (tests/program_eval.py restates the device
+semantics of fused_device.hpp) and compared with the oracle / plain numpy on real data.  This pins predicate lowering
+(Kleene logic over nulls), arithmetic / casts / literal folding, floor-div and mod by zero, the aggregate decompositions
+(mean = f64 sum / count, min / max with NaN and null handling), key packing with null codes, wide keys and float key
+canonicalisation -- everything between the IR arenas and the kernels."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import polars_amd as pl
+from polars_amd import _ffi as F
+from polars_amd import datagen
+from polars_amd import queries as Q
+from tests import program_eval as pe
+
+NPDT = {np.int8: "Int8", np.int16: "Int16", np.int32: "Int32", np.int64: "Int64", np.uint8: "UInt8", np.uint16: "UInt16", np.uint32: "UInt32", np.uint64: "UInt64",
+        np.float64: "Float64", np.bool_: "Boolean"}
+
+
+def ph_like(name, values, valid=None, dtype=None, stats=True):
+    """Placeholder column (schema + min/max statistics, no device memory) mirroring a host array."""
+    dt = dtype or getattr(pl, NPDT[values.dtype.type])
+    rng = None
+    if stats and values.dtype.kind in "iu" and len(values):
+        sel = values if valid is None else values[valid]
+        if len(sel):
+            rng = (int(sel.min()), int(sel.max()))
+    h = C.c_uint64()
+    F.check(F.lib().plx_column_placeholder(dt.physical, len(values), int(valid is not None), 1 if rng else 0, rng[0] if rng else 0, rng[1] if rng else 0, C.byref(h)))
+    return pl.Series._from_handle(name, h.value, dt)
+
+
+def frame_like(cols, dtypes=None, stats=True):
+    return pl.DataFrame([ph_like(n, v, m, (dtypes or {}).get(n), stats) for n, (v, m) in cols.items()])
+
+
+def by_key(res, key_names):
+    """Rows of a group_by result as {key tuple: {column: value}} (None = null, NaN keys canonical)."""
+    n = len(next(iter(res.values()))[0])
+    def cell(c, i):
+        v, m = res[c]
+        if m is not None and not m[i]:
+            return None
+        x = v[i].item()
+        return "nan" if isinstance(x, float) and math.isnan(x) else x
+    return {tuple(cell(k, i) for k in key_names): {c: cell(c, i) for c in res if c not in key_names} for i in range(n)}
+
+
+def close(a, b, rtol=1e-9):
+    if a is None or b is None or isinstance(a, str) or isinstance(b, str):
+        return a == b
+    return a == b or math.isclose(a, b, rel_tol=rtol)
+
+
+def test_cfg2_program_matches_oracle(orc):
+    for null_frac in (0.0, 0.3):
+        a, x, y, xv = datagen.cfg2_host(200_000, null_frac)
+        cols = {"a": (a, None), "x": (x, xv), "y": (y, None)}
+        prog = Q.cfg2(frame_like(cols).lazy()).debug_program()
+        got = pe.evaluate(prog, cols)
+        want = orc.q_filter_agg_cfg2(a, x, y, 2 ** 30, xv)
+        assert got["a_sum"][0][0] == want["a_sum"]
+        assert math.isclose(got["xy"][0][0], want["xy"], rel_tol=1e-9) and math.isclose(got["x_mean"][0][0], want["x_mean"], rel_tol=1e-9)
+
+
+def test_q1_program_matches_oracle(orc):
+    li = datagen.lineitem_host(150_000, seed=2)
+    cols = {k: (li[k], None) for k in datagen.LINEITEM_Q1_COLS}
+    lt = datagen.logical_dtypes(pl)
+    prog = Q.q1(frame_like(cols, lt).lazy()).debug_program()
+    assert prog["key_plan"]["packed"] and len(prog["inputs"]) == 7
+    got = by_key(pe.evaluate(prog, cols), ["l_returnflag", "l_linestatus"])
+    want = orc.q1(li, datagen.us(1998, 9, 2))
+    assert len(got) == len(want["l_returnflag"])
+    for i, key in enumerate(zip(want["l_returnflag"].tolist(), want["l_linestatus"].tolist())):
+        g = got[key]
+        assert g["count_order"] == want["count_order"][i] and g["sum_qty"] == want["sum_qty"][i]
+        for c in ("sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc"):
+            assert close(g[c], float(want[c][i])), (key, c)
+
+
+@pytest.mark.parametrize("shape", ["packed_nullable_keys", "wide_keys", "raw_float_key", "raw_i64_key"])
+def test_group_by_programs_match_oracle(orc, shape):
+    rng = np.random.default_rng(hash(shape) % 1000)
+    n = 60_000
+    v = rng.integers(-1000, 1000, n).astype(np.int64); vm = rng.random(n) < 0.9
+    x = rng.normal(size=n); x[rng.random(n) < 0.02] = np.nan; xm = rng.random(n) < 0.85
+    u = rng.integers(0, 2 ** 40, n).astype(np.uint64)
+    if shape == "packed_nullable_keys":
+        keys = {"k0": (rng.integers(-5, 20, n).astype(np.int32), rng.random(n) < 0.9), "k1": (rng.integers(0, 3, n).astype(np.uint8), None),
+                "k2": (rng.integers(0, 2, n).astype(bool), rng.random(n) < 0.95)}
+    elif shape == "wide_keys":
+        keys = {"k0": (rng.integers(-2 ** 62, 2 ** 62, 40).astype(np.int64)[rng.integers(0, 40, n)], rng.random(n) < 0.9),
+                "k1": (rng.integers(-2 ** 62, 2 ** 62, 30).astype(np.int64)[rng.integers(0, 30, n)], None)}
+    elif shape == "raw_float_key":
+        kf = rng.choice([0.0, -0.0, 1.5, -2.25, np.nan, np.inf, 3.0, 7.5], n)
+        keys = {"k0": (kf, rng.random(n) < 0.9)}
+    else:
+        keys = {"k0": (rng.integers(-2 ** 62, 2 ** 62, 500).astype(np.int64)[rng.integers(0, 500, n)], rng.random(n) < 0.97)}
+    cols = dict(keys); cols.update({"v": (v, vm), "x": (x, xm), "u": (u, None)})
+    lf = (frame_like(cols, stats=shape != "wide_keys").lazy().filter(pl.col("u") > 2 ** 20)
+          .group_by(*keys.keys()).agg(pl.col("v").sum().alias("v_sum"), pl.col("v").mean().alias("v_mean"), pl.col("v").min().alias("v_min"), pl.col("v").max().alias("v_max"),
+                                      pl.col("v").count().alias("v_count"), pl.len().alias("n"), pl.col("x").sum().alias("x_sum"), pl.col("x").min().alias("x_min"),
+                                      pl.col("x").max().alias("x_max"), pl.col("x").mean().alias("x_mean"), pl.col("u").max().alias("u_max")))
+    prog = lf.debug_program()
+    kp = prog["key_plan"]
+    assert (kp["packed"], kp["wide"]) == {"packed_nullable_keys": (1, 0), "wide_keys": (0, 1), "raw_float_key": (0, 0), "raw_i64_key": (0, 0)}[shape]
+    got = by_key(pe.evaluate(prog, cols), list(keys))
+    sel = u > 2 ** 20
+    fk = [np.ascontiguousarray(kv[sel]) for kv, _ in keys.values()]
+    fm = [None if km is None else km[sel] for _, km in keys.values()]
+    A = orc
+    spec = [("v_sum", A.AGG_SUM, v[sel], vm[sel]), ("v_mean", A.AGG_MEAN, v[sel], vm[sel]), ("v_min", A.AGG_MIN, v[sel], vm[sel]), ("v_max", A.AGG_MAX, v[sel], vm[sel]),
+            ("v_count", A.AGG_COUNT, v[sel], vm[sel]), ("n", A.AGG_LEN, None, None), ("x_sum", A.AGG_SUM, x[sel], xm[sel]), ("x_min", A.AGG_MIN, x[sel], xm[sel]),
+            ("x_max", A.AGG_MAX, x[sel], xm[sel]), ("x_mean", A.AGG_MEAN, x[sel], xm[sel]), ("u_max", A.AGG_MAX, u[sel], None)]
+    r = orc.q_groupby(fk, fm, spec)
+    want = {}
+    names = list(keys)
+    res_named = {names[i]: r[f"key_{i}"] for i in range(len(names))}
+    res_named.update({s[0]: r[s[0]] for s in spec})
+    want = by_key(res_named, names)
+    assert set(got) == set(want), (len(got), len(want))
+    for k, row in want.items():
+        for c, wv in row.items():
+            assert close(got[k][c], wv, 1e-9), (shape, k, c, got[k][c], wv)
+
+
+def test_predicate_logic_and_integer_division(orc):
+    """Kleene and / or / not over nullable booleans, comparisons of nullable columns, int floor-div / mod (divisor 0 -> null),
+    literal folding (x / 4.0 == x * 0.25) -- against three-valued logic written out in numpy."""
+    rng = np.random.default_rng(77)
+    n = 80_000
+    a = rng.integers(-50, 50, n).astype(np.int64); am = rng.random(n) < 0.8
+    b = rng.integers(-5, 6, n).astype(np.int64); bm = rng.random(n) < 0.9
+    x = rng.normal(size=n); xm = rng.random(n) < 0.85
+    cols = {"a": (a, am), "b": (b, bm), "x": (x, xm)}
+    c = pl.col
+    pred = ((c("a") // c("b") > 2) | ~(c("x") / 4.0 < 0.1)) & ((c("a") % c("b") != 1) | (c("b") >= 0))
+    lf = frame_like(cols).lazy().filter(pred).select(pl.len().alias("n"), c("a").sum().alias("a_sum"), (c("x") / 4.0).sum().alias("x4"), c("x").count().alias("xc"))
+    got = pe.evaluate(lf.debug_program(), cols)
+
+    def kleene_or(p, pv, q, qv):    # value, valid
+        return (p & pv) | (q & qv), (p & pv) | (q & qv) | (pv & qv)
+
+    def kleene_and(p, pv, q, qv):
+        return p & q & pv & qv | False, (~p & pv) | (~q & qv) | (pv & qv)
+    nz = b != 0
+    bs = np.where(nz, b, 1)
+    dv, dvalid = np.floor_divide(a, bs), am & bm & nz
+    mv = np.mod(a, bs)
+    t1, t1v = dv > 2, dvalid
+    t2, t2v = ~(x * 0.25 < 0.1), xm
+    l, lv = kleene_or(t1, t1v, t2, t2v)
+    t3, t3v = mv != 1, dvalid
+    t4, t4v = b >= 0, bm
+    r_, rv = kleene_or(t3, t3v, t4, t4v)
+    p, pv = kleene_and(l & lv, lv, r_ & rv, rv)
+    keep = p & pv
+    assert got["n"][0][0] == int(keep.sum()) and 0 < keep.sum() < n
+    assert got["a_sum"][0][0] == int(a[keep & am].sum())
+    assert got["xc"][0][0] == int((keep & xm).sum())
+    assert math.isclose(got["x4"][0][0], float((x * 0.25)[keep & xm].sum()), rel_tol=1e-9)
