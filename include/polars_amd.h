@@ -379,7 +379,7 @@ int plx_describe_fusion(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, 
 /* Compile-only, no GPU needed: the complete compiled form of the fusable pipeline rooted at `root` (same arguments as
  * plx_describe_fusion) as a JSON document in buf (NUL-terminated, truncated to cap): register program with immediates,
  * input columns, aggregate cells, key packing / decoding, finalisation of every output.  The CPU tests interpret it row by
- * row against the oracle (tests/program_eval.py).  PLX_ERR_UNSUPPORTED with the reason in plx_last_error() if not fusable. */
+ * row (tests/program_eval.py).  PLX_ERR_UNSUPPORTED with the reason in plx_last_error() if not fusable. */
 int plx_debug_program_json(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int32_t n_exprs, int32_t root, char* buf, size_t cap);
 /* Run-time kernel specialisation (hiprtc): query shapes without a pre-instantiated kernel get one compiled on
  * first use (inputs of >= PLX_JIT_MIN_ROWS rows, default 2^22; PLX_JIT=0 disables; failures fall back to the

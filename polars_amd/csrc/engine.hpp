@@ -59,7 +59,7 @@ void groupby_columns(const std::vector<ColumnPtr>& keys, const std::vector<Colum
 bool describe_fusion(Plan& plan, int root, fused::Shape* shape, int* static_id, std::string* why_not);
 // The complete compiled form of a fusable `[Filter]* -> Select | GroupBy` pipeline as JSON (register program with its
 // immediates, input columns, aggregate cells, key packing / decoding, finalisation of every output): what the GPU will
-// execute, in a form the CPU tests interpret row by row against the oracle (tests/program_eval.py).  Compile only.
+// execute, in a form the CPU tests interpret row by row (tests/program_eval.py).  Compile only.
 bool dump_program_json(Plan& plan, int root, std::string* json, std::string* why_not);
 // GroupBy directly over an inner Join: the three programs (count, build, probe) of the fused
 // join->aggregate pipeline, or false + reason when the per-node path would run.
