@@ -163,3 +163,118 @@ def test_predicate_logic_and_integer_division(orc):
     assert got["a_sum"][0][0] == int(a[keep & am].sum())
     assert got["xc"][0][0] == int((keep & xm).sum())
     assert math.isclose(got["x4"][0][0], float((x * 0.25)[keep & xm].sum()), rel_tol=1e-9)
+
+
+# ---- random expression trees: compiler output (interpreted) vs a direct three-valued numpy evaluation of the same tree ----
+class _Gen:
+    """Random typed expression trees over four columns; every node carries its mirror-API expression and a numpy
+    evaluation (values, valid) that follows the reference's rules: nulls propagate through arithmetic and comparisons,
+    and / or are Kleene, integer + - * wrap, / is float division (col / literal = col * (1 / literal)), // and % follow
+    Python sign rules with divisor 0 -> null."""
+
+    def __init__(self, rng, cols):
+        self.rng, self.cols = rng, cols
+
+    def leaf(self, ty):
+        r = self.rng
+        if ty == "i":
+            if r.random() < 0.7:
+                name = ["a", "b"][int(r.integers(0, 2))]
+                v, m = self.cols[name]
+                return pl.col(name), (v, np.ones(len(v), bool) if m is None else m)
+            k = int(r.integers(-7, 8))
+            return pl.lit(k, dtype=pl.Int64), (np.full(self.n, k, np.int64), np.ones(self.n, bool))
+        if r.random() < 0.7:
+            name = ["x", "y"][int(r.integers(0, 2))]
+            v, m = self.cols[name]
+            return pl.col(name), (v, np.ones(len(v), bool) if m is None else m)
+        k = float(r.integers(-6, 7)) / 2 + 0.25
+        return pl.lit(k, dtype=pl.Float64), (np.full(self.n, k, np.float64), np.ones(self.n, bool))
+
+    @property
+    def n(self):
+        return len(self.cols["a"][0])
+
+    def num(self, ty, depth):
+        r = self.rng
+        if depth == 0 or r.random() < 0.25:
+            return self.leaf(ty)
+        with np.errstate(all="ignore"):
+            if ty == "f" and r.random() < 0.2:          # int -> float through true division
+                (ea, (va, ma)), (eb, (vb, mb)) = self.num("i", depth - 1), self.num("i", depth - 1)
+                return ea / eb, (va.astype(np.float64) / vb.astype(np.float64), ma & mb)
+            (ea, (va, ma)), (eb, (vb, mb)) = self.num(ty, depth - 1), self.num(ty, depth - 1)
+            op = int(r.integers(0, 5 if ty == "i" else 4))
+            if op == 0: return ea + eb, (va + vb, ma & mb)
+            if op == 1: return ea - eb, (va - vb, ma & mb)
+            if op == 2: return ea * eb, (va * vb, ma & mb)
+            if ty == "f":
+                return ea / eb, (va / vb, ma & mb)
+            nz = vb != 0
+            vs = np.where(nz, vb, 1)
+            if op == 3: return ea // eb, (np.floor_divide(va, vs), ma & mb & nz)
+            return ea % eb, (np.mod(va, vs), ma & mb & nz)
+
+    def boolean(self, depth):
+        r = self.rng
+        if depth == 0 or r.random() < 0.35:
+            ty = "i" if r.random() < 0.5 else "f"
+            (ea, (va, ma)), (eb, (vb, mb)) = self.num(ty, 1), self.num(ty, 1)
+            op = int(r.integers(0, 6))
+            if ty == "f":      # total order: NaN == NaN, NaN greatest
+                an, bn = np.isnan(va), np.isnan(vb)
+                eq = (an & bn) | (va == vb)
+                lt = ~an & (bn | (va < vb)) & ~eq
+            else:
+                eq, lt = va == vb, va < vb
+            val = [eq, ~eq, lt, lt | eq, ~(lt | eq), ~lt][op]
+            e = [ea == eb, ea != eb, ea < eb, ea <= eb, ea > eb, ea >= eb][op]
+            return e, (val, ma & mb)
+        if r.random() < 0.2:
+            e, (v, m) = self.boolean(depth - 1)
+            return ~e, (~v, m)
+        (ea, (va, ma)), (eb, (vb, mb)) = self.boolean(depth - 1), self.boolean(depth - 1)
+        if r.random() < 0.5:
+            return ea & eb, (va & vb, (~va & ma) | (~vb & mb) | (ma & mb))
+        return ea | eb, (va | vb, (va & ma) | (vb & mb) | (ma & mb))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_expression_trees(seed):
+    rng = np.random.default_rng(9000 + seed)
+    n = 4000
+    cols = {"a": (rng.integers(-40, 40, n).astype(np.int64), rng.random(n) < 0.85), "b": (rng.integers(-4, 5, n).astype(np.int64), None),
+            "x": (np.round(rng.normal(size=n) * 8) / 4, rng.random(n) < 0.9), "y": (rng.integers(-3, 4, n).astype(np.float64) / 2, None)}
+    g = _Gen(rng, cols)
+    pe_, (pv, pm) = g.boolean(3)
+    fe, (fv, fm) = g.num("f", 3)
+    ie, (iv, im) = g.num("i", 3)
+    lf = frame_like(cols).lazy().filter(pe_).select(pl.len().alias("n"), fe.sum().alias("fs"), fe.count().alias("fc"), fe.min().alias("fmin"),
+                                                    ie.sum().alias("isum"), ie.max().alias("imax"), ie.mean().alias("imean"))
+    try:
+        prog = lf.debug_program()
+    except pl.UnsupportedError as e:      # e.g. more than 16 live values / 32 ops: the engine runs such trees on the per-node path
+        assert "fusable" in str(e) or "program" in str(e) or "live values" in str(e), str(e)
+        return
+    got = pe.evaluate(prog, cols)
+    keep = pv & pm
+    assert got["n"][0][0] == int(keep.sum())
+    fsel = keep & fm
+    assert got["fc"][0][0] == int(fsel.sum())
+    with np.errstate(all="ignore"):
+        want_fs = float(fv[fsel].sum())
+    assert (math.isnan(want_fs) and math.isnan(got["fs"][0][0])) or close(float(got["fs"][0][0]), want_fs, 1e-9)
+    ford = fsel & ~np.isnan(fv)
+    fmin_v, fmin_m = got["fmin"]
+    if not fsel.any():
+        assert not fmin_m[0]
+    elif not ford.any():
+        assert fmin_m[0] and math.isnan(fmin_v[0])
+    else:
+        assert fmin_m[0] and fmin_v[0] == fv[ford].min()
+    isel = keep & im
+    assert got["isum"][0][0] == int(iv[isel].sum())            # wrapping sums coincide with exact ones at these magnitudes
+    imax_v, imax_m = got["imax"]
+    assert bool(imax_m[0]) == bool(isel.any()) and (not isel.any() or imax_v[0] == iv[isel].max())
+    imean_v, imean_m = got["imean"]
+    assert bool(imean_m[0]) == bool(isel.any()) and (not isel.any() or close(float(imean_v[0]), float(iv[isel].mean()), 1e-9))
