@@ -852,15 +852,14 @@ struct ProgramDump {
 };
 static thread_local ProgramDump* t_program_dump = nullptr;   // set only for the duration of a dump_program_json call
 static std::string jstr(const std::string& x) { std::string o = "\""; for (char ch : x) { if (ch == '"' || ch == '\\') o += '\\'; o += ch; } return o + "\""; }
-static void dump_compiled(ProgramDump* dump, const char* kind, const Plan& plan, const Compiler& c, const KeyPlan* kp, const std::vector<int>& agg_nodes,
-                          const std::vector<FinalSpec>& specs, const std::vector<int>& out_exprs, int len_idx, int first_idx, bool maintain_order) {
-  if (!dump) return;
+// the register program of one compiled scan as JSON fields (no braces); input names are looked up in `frame` by buffer identity
+static std::string program_fields(const Compiler& c, const Frame& frame) {
   std::ostringstream o;
   const Shape& sh = c.shape;
-  o << "{\"kind\":\"" << kind << "\",\"n_rows\":" << c.args.n_rows << ",\"inputs\":[";
+  o << "\"n_rows\":" << c.args.n_rows << ",\"inputs\":[";
   auto name_of = [&](int col_id) -> std::string {   // input_cols holds the compiler's own column ids: map the buffer back to its frame column
     const ColumnPtr& buf = c.cols[col_id];
-    for (size_t j = 0; j < c.df->cols.size(); j++) if (c.df->cols[j] == buf) return c.df->names[j];
+    for (size_t j = 0; j < frame.cols.size(); j++) if (frame.cols[j] == buf) return frame.names[j];
     return "?";
   };
   for (int i = 0; i < sh.n_inputs; i++)
@@ -872,17 +871,12 @@ static void dump_compiled(ProgramDump* dump, const char* kind, const Plan& plan,
   for (int i = 0; i < sh.n_keys; i++) o << (i ? "," : "") << (int)sh.keys[i];
   o << "],\"aggs\":[";
   for (int i = 0; i < sh.n_aggs; i++) o << (i ? "," : "") << "[" << (int)sh.aggs[i].kind << "," << (int)sh.aggs[i].src << "]";
-  o << "],\"len_idx\":" << len_idx << ",\"first_idx\":" << first_idx << ",\"maintain_order\":" << (maintain_order ? 1 : 0);
-  if (kp) {
-    o << ",\"key_plan\":{\"packed\":" << (kp->packed ? 1 : 0) << ",\"wide\":" << (kp->wide ? 1 : 0) << ",\"parts\":[";
-    for (size_t i = 0; i < kp->parts.size(); i++) {
-      const KeyPart& kpart = kp->parts[i];
-      o << (i ? "," : "") << "{\"name\":" << jstr(output_name(plan, kpart.expr)) << ",\"dtype\":" << kpart.dtype << ",\"nullable\":" << (kpart.nullable ? 1 : 0) << ",\"shift\":" << kpart.dec.shift
-        << ",\"mask\":\"" << kpart.dec.mask << "\",\"min\":\"" << kpart.dec.min << "\",\"null_code\":\"" << kpart.dec.null_code << "\"}";
-    }
-    o << "]}";
-  }
-  o << ",\"finals\":[";
+  o << "]";
+  return o.str();
+}
+static std::string finals_outputs_fields(const Plan& plan, const std::vector<int>& agg_nodes, const std::vector<FinalSpec>& specs, const std::vector<int>& out_exprs) {
+  std::ostringstream o;
+  o << "\"finals\":[";
   for (size_t i = 0; i < specs.size(); i++)
     o << (i ? "," : "") << "{\"kind\":" << (int)specs[i].kind << ",\"a\":" << (int)specs[i].a << ",\"b\":" << (int)specs[i].b << ",\"c\":" << (int)specs[i].c << ",\"out_dtype\":" << (int)specs[i].out_dtype << "}";
   o << "],\"outputs\":[";
@@ -893,7 +887,25 @@ static void dump_compiled(ProgramDump* dump, const char* kind, const Plan& plan,
     for (size_t j = 0; j < agg_nodes.size(); j++) if (agg_nodes[j] == e) idx = (int)j;
     o << (i ? "," : "") << "{\"name\":" << jstr(output_name(plan, out_exprs[i])) << ",\"final\":" << idx << "}";
   }
-  o << "]}";
+  o << "]";
+  return o.str();
+}
+static void dump_compiled(ProgramDump* dump, const char* kind, const Plan& plan, const Compiler& c, const KeyPlan* kp, const std::vector<int>& agg_nodes,
+                          const std::vector<FinalSpec>& specs, const std::vector<int>& out_exprs, int len_idx, int first_idx, bool maintain_order) {
+  if (!dump) return;
+  std::ostringstream o;
+  o << "{\"kind\":\"" << kind << "\"," << program_fields(c, *c.df);
+  o << ",\"len_idx\":" << len_idx << ",\"first_idx\":" << first_idx << ",\"maintain_order\":" << (maintain_order ? 1 : 0);
+  if (kp) {
+    o << ",\"key_plan\":{\"packed\":" << (kp->packed ? 1 : 0) << ",\"wide\":" << (kp->wide ? 1 : 0) << ",\"parts\":[";
+    for (size_t i = 0; i < kp->parts.size(); i++) {
+      const KeyPart& kpart = kp->parts[i];
+      o << (i ? "," : "") << "{\"name\":" << jstr(output_name(plan, kpart.expr)) << ",\"dtype\":" << kpart.dtype << ",\"nullable\":" << (kpart.nullable ? 1 : 0) << ",\"shift\":" << kpart.dec.shift
+        << ",\"mask\":\"" << kpart.dec.mask << "\",\"min\":\"" << kpart.dec.min << "\",\"null_code\":\"" << kpart.dec.null_code << "\"}";
+    }
+    o << "]}";
+  }
+  o << "," << finals_outputs_fields(plan, agg_nodes, specs, out_exprs) << "}";
   dump->json = o.str();
 }
 
@@ -1093,7 +1105,19 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     cp.finish();
   } catch (const Unsupported& u) { if (why) *why = u.why; return false; }
   if (shapes_out) { shapes_out->push_back(cnt.shape); shapes_out->push_back(cb.shape); shapes_out->push_back(cp.shape); }
-  if (compile_only) return true;
+  if (compile_only) {
+    if (t_program_dump) {   // the three scans + how groups, group keys and outputs are derived from them (tests/program_eval.py evaluate_join)
+      std::ostringstream o;
+      o << "{\"kind\":\"join_group_by\",\"build_side\":\"" << (build_right ? "right" : "left") << "\",\"build_key\":" << jstr(B->names[bki]) << ",\"probe_key\":" << jstr(P->names[pki])
+        << ",\"count\":{" << program_fields(cnt, *B) << "},\"build\":{" << program_fields(cb, *B) << "},\"probe\":{" << program_fields(cp, *P) << "},\"len_idx\":" << len_idx << ",\"group_keys\":[";
+      for (size_t i = 0; i < gkeys.size(); i++)
+        o << (i ? "," : "") << "{\"name\":" << jstr(output_name(plan, gkeys[i].expr)) << ",\"is_join_key\":" << (gkeys[i].is_join_key ? 1 : 0) << ",\"build_col\":"
+          << (gkeys[i].is_join_key ? std::string("null") : jstr(B->names[gkeys[i].build_col])) << ",\"dtype\":" << gkeys[i].dtype << "}";
+      o << "]," << finals_outputs_fields(plan, agg_nodes, specs, gb.exprs) << "}";
+      t_program_dump->json = o.str();
+    }
+    return true;
+  }
   // ---- run
   uint64_t nb = 0;
   const int probe_static_id = find_static_shape(cp.shape);
@@ -1473,7 +1497,11 @@ bool dump_program_json(Plan& plan, int root, std::string* json, std::string* why
   ProgramDump d;
   t_program_dump = &d;
   bool ok = false;
-  try { ok = describe_fusion(plan, root, nullptr, nullptr, why_not); } catch (...) { t_program_dump = nullptr; throw; }
+  try {
+    const IRN& n = plan.ir.at(root);
+    if (n.kind == PLX_IR_GROUPBY && n.input >= 0 && plan.ir[n.input].kind == PLX_IR_JOIN) ok = describe_join_fusion(plan, root, nullptr, why_not);
+    else ok = describe_fusion(plan, root, nullptr, nullptr, why_not);
+  } catch (...) { t_program_dump = nullptr; throw; }
   t_program_dump = nullptr;
   if (ok && json) *json = d.json;
   return ok && !d.json.empty();

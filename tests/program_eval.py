@@ -132,7 +132,10 @@ def _cells(prog, slots, passed, rows, group_of, n_groups):
     """Aggregate cells [n_groups][n_aggs] as uint64 bit patterns (agg_row_value + agg_combine)."""
     out = np.zeros((n_groups, len(prog["aggs"])), dtype=np.uint64)
     for k, (kind, src) in enumerate(prog["aggs"]):
-        v, valid = slots[src] if src != NONE else (np.zeros(len(passed), np.uint64), np.ones(len(passed), bool))
+        if kind in (AGG_LEN, AGG_FIRST_ROW) or src == NONE:     # these kinds read no source slot (the compiler stores src = 0 for them)
+            v, valid = np.zeros(len(passed), np.uint64), np.ones(len(passed), bool)
+        else:
+            v, valid = slots[src]
         sel = passed & valid if kind not in (AGG_LEN, AGG_FIRST_ROW) else passed
         g = group_of[sel]
         if kind in (AGG_LEN, AGG_COUNT):
@@ -230,5 +233,53 @@ def evaluate(prog, cols):
     for o in prog["outputs"]:
         if o["final"] < 0:
             raise NotImplementedError(f"output {o['name']} is a row expression over aggregates (evaluated by the per-node kernels)")
+        res[o["name"]] = _finalise(prog["finals"][o["final"]], cells)
+    return res
+
+
+def evaluate_join(prog, build_cols, probe_cols):
+    """The fused join -> group-by pipeline (engine.cpp fused_join_groupby): build scan (predicate + key) -> probe scan
+    (predicate + key + aggregates landing in the matching build row's cells) -> groups with at least one probe row.
+    build_cols / probe_cols: {original column name of that frame: (values, valid or None)}.
+    Returns {output name: (values, valid or None)}, or None when the surviving build keys are not unique (the engine then
+    falls back to the per-node join)."""
+    b_slots, b_pass = run_rows(prog["build"], build_cols)
+    bk, bkm = b_slots[prog["build"]["key"]]
+    ins = b_pass & bkm                                   # null build keys are never inserted
+    rows_b = np.nonzero(ins)[0]
+    keys_b = bk[rows_b]
+    # the count scan sizes the tables: it must count exactly the inserted rows
+    c_slots, c_pass = run_rows(prog["count"], build_cols)
+    ccells = _cells(prog["count"], c_slots, c_pass, np.arange(len(c_pass)), np.zeros(len(c_pass), dtype=np.int64), 1)
+    assert int(ccells[0, 0]) == len(rows_b), (int(ccells[0, 0]), len(rows_b))
+    order = np.argsort(keys_b, kind="stable")
+    skeys, srows = keys_b[order], rows_b[order]
+    if len(skeys) > 1 and (skeys[1:] == skeys[:-1]).any():
+        return None
+    p_slots, p_pass = run_rows(prog["probe"], probe_cols)
+    pk, pkm = p_slots[prog["probe"]["key"]]
+    pos = np.searchsorted(skeys, pk)
+    pos_c = np.minimum(pos, max(len(skeys) - 1, 0))
+    hit = (len(skeys) > 0) & (skeys[pos_c] == pk) if len(skeys) else np.zeros(len(pk), bool)
+    sel = p_pass & pkm & hit
+    n = len(sel)
+    group_of = np.where(sel, pos_c, 0).astype(np.int64)
+    cells = _cells(prog["probe"], p_slots, sel, np.arange(n), group_of, len(skeys))
+    live = cells[:, prog["len_idx"]] != 0 if len(skeys) else np.zeros(0, bool)
+    cells = cells[live]
+    res = {}
+    for gk in prog["group_keys"]:
+        if gk["is_join_key"]:
+            word = skeys[live]
+            dt = gk["dtype"]
+            vals = word.astype(NP[dt]) if dt in (U8, U16, U32, U64) else word.view(np.int64).astype(NP[dt])
+            res[gk["name"]] = (vals, None)
+        else:
+            v, m = build_cols[gk["build_col"]]
+            rows = srows[live]
+            res[gk["name"]] = (v[rows], None if m is None or m[rows].all() else m[rows])
+    for o in prog["outputs"]:
+        if o["final"] < 0:
+            raise NotImplementedError(f"output {o['name']} is a row expression over aggregates")
         res[o["name"]] = _finalise(prog["finals"][o["final"]], cells)
     return res
