@@ -39,6 +39,18 @@ static uint64_t scan_bytes(const Shape& sh, const Args& args) {
   return b;
 }
 
+// Tuning knobs for experiments (unset = the defaults below): PLX_PART_LOG2_PARTS (6..10), PLX_PART_BUF_ROWS (even, 2..16),
+// PLX_PART_WGS_PER_CU (1 | 2).  Read once per process.
+static int env_int(const char* name, int lo, int hi) {
+  const char* e = getenv(name);
+  if (!e || !*e) return -1;
+  const int v = atoi(e);
+  return (v >= lo && v <= hi) ? v : -1;
+}
+static const int kEnvLog2Parts = env_int("PLX_PART_LOG2_PARTS", 6, 10);
+static const int kEnvBufRows = env_int("PLX_PART_BUF_ROWS", 2, 16);
+static const int kEnvWgsPerCu = env_int("PLX_PART_WGS_PER_CU", 1, 2);
+
 bool partition_plan(const Shape& sh, double est_groups, bool any_nullable, PartitionPlan* out) {
   PartitionPlan pp{};
   pp.rec = rec_layout(sh);     // the layout AOT / JIT kernels derive at compile time from the same shape
@@ -53,11 +65,13 @@ bool partition_plan(const Shape& sh, double est_groups, bool any_nullable, Parti
   uint32_t log2_parts = 6;
   while (log2_parts < 10 && (double)(1u << log2_parts) * per_part < est_groups) log2_parts++;
   if ((double)(1u << log2_parts) * per_part < est_groups) return false;   // would need > 1024 partitions
+  if (kEnvLog2Parts > (int)log2_parts) log2_parts = (uint32_t)kEnvLog2Parts;   // only more partitions than needed: fewer would overflow the LDS tables
   pp.log2_parts = log2_parts;
   pp.log2_slots = log2_slots;
   // write-combining buffers of pass 2
   uint32_t B = 8;
   auto scatter_lds = [&](uint32_t b) { return ((size_t)(1u << log2_parts) * b * pp.rec.rec_words + 2 * (1u << log2_parts)) * 8 + (size_t)(1u << log2_parts) * 8 + 16; };
+  if (kEnvBufRows > 0) B = (uint32_t)(kEnvBufRows & ~1);
   while (B > 2 && scatter_lds(B) > lds_budget) B -= 2;
   if (scatter_lds(B) > lds_budget) return false;
   pp.buf_rows = B;
@@ -84,7 +98,8 @@ int64_t partitioned_agg(const Shape& sh, const Args& args, const PartitionPlan& 
   const bool use_jit = !is_static && jit::ensure(sh, jit::PART_COUNT, args.n_rows) && jit::ensure(sh, jit::PART_SCATTER, args.n_rows) && jit::ensure(sh, jit::PART_AGG, args.n_rows);
   const int64_t rows_per_round = (int64_t)kBlock * kRows * ((is_static || use_jit) ? kStaticRoundTiles : 1);
   const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
-  const int sgrid = (int)std::min<int64_t>(nrounds, (int64_t)device().cu_count * (slds > 80 * 1024 ? 1 : 2));   // 2 workgroups per CU when two buffers sets fit the 160 KB LDS; the SAME grid for pass 1 and pass 2
+  const int wgs_per_cu = slds > 80 * 1024 ? 1 : (kEnvWgsPerCu > 0 ? kEnvWgsPerCu : 2);
+  const int sgrid = (int)std::min<int64_t>(nrounds, (int64_t)device().cu_count * wgs_per_cu);   // 2 workgroups per CU when two buffers sets fit the 160 KB LDS; the SAME grid for pass 1 and pass 2
   Buf hist = dev_alloc(sizeof(uint32_t) * (size_t)sgrid * NP);
   Buf wg_prefix = dev_alloc(sizeof(uint64_t) * (size_t)sgrid * NP);
   Buf totals = dev_alloc(sizeof(uint64_t) * (NP + 1));
