@@ -73,6 +73,16 @@ C.append(dict(id="sum_empty_f32", kind="reduce", source="py-polars/tests/unit/op
 C.append(dict(id="sum_all_null_f32", kind="reduce", source="py-polars/tests/unit/operations/aggregation/test_aggregations.py:480-481",
               values=[None], dtype="f32", op="sum", expect=0.0))
 
+# perfect-hash (categorical) keys with nulls, groups in first-appearance order: the reference collects the group members, pinned here by their count
+_PH_VALUES = ["3", "41", "17", "5", "26", "27", "43", "45", "41", "13", "45", "48", "17", "22", "31", "25", "28", "13", "7", "26", "17", "4", "43", "47", "30", "28", "8", "27", "6", "7", "26", "11", "37", "29", "49", "20", "29", "28", "23", "9", None, "38", "19", "7", "38", "3", "30", "37", "41", "5", "16", "26", "31", "6", "25", "11", "17", "31", "31", "20", "26", None, "39", "10", "38", "4", "39", "15", "13", "35", "38", "11", "39", "11", "48", "36", "18", "11", "34", "16", "28", "9", "37", "8", "17", "48", "44", "28", "25", "30", "37", "30", "18", "12", None, "27", "10", "3", "16", "27", "6"]
+_PH_GROUPS = ["3", "41", "17", "5", "26", "27", "43", "45", "13", "48", "22", "31", "25", "28", "7", "4", "47", "30", "8", "6", "11", "37", "29", "49", "20", "23", "9", None, "38", "19", "16", "39", "10", "15", "35", "36", "18", "34", "44", "12"]
+_PH_COUNTS = [3, 3, 5, 2, 5, 4, 2, 2, 3, 3, 1, 4, 3, 5, 3, 2, 1, 4, 2, 3, 5, 4, 2, 1, 2, 1, 2, 3, 4, 1, 3, 3, 2, 1, 1, 1, 2, 1, 1, 1]
+assert sum(_PH_COUNTS) == len(_PH_VALUES) and len(_PH_GROUPS) == len(_PH_COUNTS)
+C.append(dict(id="perfect_hash_table_null_values", kind="groupby", source="py-polars/tests/unit/operations/test_group_by.py:948-1010",
+              keys={"a": _PH_VALUES}, key_dtypes={"a": "str"}, values={"c": [1] * len(_PH_VALUES)}, value_dtypes={"c": "i64"},
+              aggs=[["c", "len"]], maintain_order=True, expect={"a": _PH_GROUPS, "c_len": _PH_COUNTS},
+              note="the reference aggregates the key column itself into lists; the list lengths (and the group order, null group included) are what is pinned"))
+
 # ---- joins -------------------------------------------------------------------------------
 C.append(dict(id="inner_join_days", kind="join", how="inner", source="crates/polars/tests/it/core/joins.rs:40-78",
               left={"days": [0, 1, 2], "temp": [22.1, 19.9, 7.0], "rain": [0.2, 0.1, 0.3]}, left_dtypes={"days": "i32", "temp": "f64", "rain": "f64"},

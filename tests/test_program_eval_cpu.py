@@ -348,3 +348,43 @@ def test_join_pipeline_reports_duplicate_build_keys():
     pcols = {"k": (np.array([2, 3, 3, 9, 1, 2], dtype=np.int64), None), "v": (np.arange(6, dtype=np.int64), None)}
     lf = frame_like(pcols).lazy().join(frame_like(bcols).lazy(), on="k").group_by("k", "attr").agg(pl.col("v").sum().alias("s"))
     assert pe.evaluate_join(lf.debug_program(), bcols, pcols) is None      # the engine detects this at run time and takes the per-node join
+
+
+@pytest.mark.parametrize("case", [c for c in __import__("tests.kat", fromlist=["kat"]).load_cases("groupby")], ids=lambda c: c["id"])
+def test_reference_group_by_kats_through_the_compiler(case):
+    """The reference's group_by known-answer vectors, run through the C++ compiler + the numpy interpreter (no GPU): the same
+    cases tests/test_gpu_golden.py runs on the hardware."""
+    from tests import kat
+    cols, key_names = {}, list(case["keys"])
+    cats = {}
+    for name, spec in case["keys"].items():
+        a, v, c = kat.column(spec, case["key_dtypes"][name])
+        cols[name] = (a, v); cats[name] = c
+    aggs = []
+    for col, op in case["aggs"]:
+        if col not in cols:
+            a, v, _ = kat.column(case["values"][col], case["value_dtypes"][col])
+            if a.dtype == np.float32:
+                pytest.skip("f32 values aggregate on the per-node f32 path, not in the f64 fused program")
+            cols[col] = (a, v)
+        e = pl.col(col)
+        aggs.append({"sum": e.sum, "mean": e.mean, "min": e.min, "max": e.max, "count": e.count, "len": e.len}[op]().alias(f"{col}_{op}"))
+    try:
+        prog = frame_like(cols).lazy().group_by(*key_names, maintain_order=case["maintain_order"]).agg(*aggs).debug_program()
+    except pl.UnsupportedError:
+        pytest.skip("not a fused shape (runs on the per-node path on the GPU)")
+    got = by_key(pe.evaluate(prog, cols), key_names)
+    exp = case["expect"]
+    n = len(exp[key_names[0]])
+    assert len(got) == n, (len(got), n)
+    for i in range(n):
+        key = []
+        for k in key_names:
+            v = exp[k][i]
+            key.append(None if v is None else (cats[k].index(v) if cats[k] is not None else kat.scalar(v)))
+        row = got[tuple(key)]
+        for c, vals in exp.items():
+            if c in key_names:
+                continue
+            g = row[c]
+            assert kat.same_value(float("nan") if g == "nan" else g, vals[i], case.get("rtol", 1e-12)), (case["id"], key, c, g, vals[i])
