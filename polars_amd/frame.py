@@ -620,6 +620,9 @@ class LazyFrame:
 
     # -- execution -----------------------------------------------------------------------------------
     def _lower(self):
+        from . import io as _io
+        _io.reset_scans(self._node)          # file scans: tell them which columns / row groups this plan reads (io.push_down)
+        _io.push_down(self._node)
         low = P.Lowering()
         root, schema = low.lower_node(self._node)
         return low, root, schema
@@ -630,7 +633,11 @@ class LazyFrame:
         cached = getattr(self, "_c_cache", None)
         if cached is None:
             low, root, schema = self._lower()
-            cached = (low.to_c(), root, schema, low)
+            c_arenas = low.to_c()            # file scans are decoded and uploaded here (their frame handles are taken)
+            from . import io as _io
+            if _io.has_file_scan(self._node):   # dictionaries of string columns are only known now: refresh the result schema hints
+                _, schema = P.Lowering().lower_node(self._node)
+            cached = (c_arenas, root, schema, low)
             self._c_cache = cached
         return cached
 

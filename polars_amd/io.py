@@ -1,0 +1,299 @@
+"""Parquet scan -> device columns: the step BEFORE the hot path, host-decoded.
+
+The reference reads Parquet with its own decoder and pushes projections and predicates into the scan
+(crates/polars-io/src/parquet/read, crates/polars-plan/src/plans/optimizer/{projection_pushdown, predicate_pushdown},
+row-group skipping by statistics: crates/polars-io/src/predicates.rs).  Here the decoder is pyarrow on the host; what this
+module adds is the part that decides HOW MUCH crosses PCIe:
+
+* projection pushdown -- only the columns the plan reads are decoded and uploaded (TPC-H Q1 touches 7 of lineitem's 16),
+* predicate pushdown to row groups -- conjuncts `column <cmp> literal` of the filters directly above the scan skip the row
+  groups whose min / max statistics cannot match (the filter itself still runs on the GPU, exactly),
+* the upload goes through the Arrow C Data Interface import of the C ABI (buffers >= 32 MB are page-locked in place, one DMA).
+
+A device-side Parquet decoder (no host staging) is what row 3 ultimately asks for; this is the drop-in API with the traffic
+reduction, not that decoder.
+"""
+from __future__ import annotations
+
+import datetime as _dt
+from typing import Any, Dict, List, Optional, Sequence, Set, Tuple
+
+from . import _ffi as F
+from . import datatypes as T
+from . import plan as P
+from .expr import Expr
+
+Pred = Tuple[str, int, Any]          # (column, plx comparison operator, python literal)
+
+
+def _mirror_dtype(t) -> T.DataType:
+    import pyarrow as pa
+    if pa.types.is_dictionary(t) or pa.types.is_string(t) or pa.types.is_large_string(t):
+        return T.Categorical([])          # dictionary codes on the device; the dictionary is known after the read
+    if pa.types.is_timestamp(t):
+        if t.unit != "us":
+            raise TypeError(f"timestamp unit {t.unit} (only us is on the hot path)")
+        return T.Datetime
+    if pa.types.is_date32(t):
+        return T.Date
+    m = {pa.int8(): T.Int8, pa.int16(): T.Int16, pa.int32(): T.Int32, pa.int64(): T.Int64, pa.uint8(): T.UInt8, pa.uint16(): T.UInt16, pa.uint32(): T.UInt32,
+         pa.uint64(): T.UInt64, pa.float32(): T.Float32, pa.float64(): T.Float64, pa.bool_(): T.Boolean}
+    if t in m:
+        return m[t]
+    raise TypeError(f"parquet column type {t} is outside the hot path")
+
+
+class ParquetFrame:
+    """A scan source: looks like a DataFrame to the plan lowering (`schema`, `_frame_handle()`), materialises lazily."""
+
+    def __init__(self, path: str, columns: Optional[Sequence[str]] = None):
+        import pyarrow.parquet as pq
+        self.path = path
+        self._pf = pq.ParquetFile(path)
+        names = list(columns) if columns is not None else list(self._pf.schema_arrow.names)
+        self._schema: Dict[str, T.DataType] = {n: _mirror_dtype(self._pf.schema_arrow.field(n).type) for n in names}
+        self._need: Optional[Set[str]] = set()          # None = every column of the schema
+        self._preds: Optional[List[Pred]] = None        # None = not requested yet; [] = no pushdown
+        self._df = None
+        self._loaded: Optional[Tuple[frozenset, Tuple[int, ...]]] = None
+        self.last_read: Dict[str, Any] = {}
+
+    @property
+    def schema(self) -> Dict[str, T.DataType]:
+        out = dict(self._schema)
+        if self._df is not None:          # loaded columns know their dictionaries
+            out.update({n: d for n, d in self._df.schema.items() if n in out})
+        return out
+
+    @property
+    def num_rows(self) -> int:
+        return self._pf.metadata.num_rows
+
+    # -- what the plan needs (called by LazyFrame._lower through plan.push_down) ------------------------------------
+    def request(self, columns: Optional[Set[str]], predicates: List[Pred]) -> None:
+        """One call per use of this scan in a plan; uses are merged: union of the columns, the predicates only if every use
+        carries the same ones."""
+        if columns is None or self._need is None:
+            self._need = None
+        else:
+            self._need |= set(columns)
+        preds = sorted(predicates, key=repr)
+        if self._preds is None:
+            self._preds = preds
+        elif self._preds != preds:
+            self._preds = []
+
+    def reset_requests(self) -> None:
+        self._need, self._preds = set(), None
+
+    def selected_columns(self) -> List[str]:
+        return [n for n in self._schema if self._need is None or n in self._need]
+
+    def selected_row_groups(self) -> List[int]:
+        """Row groups that can contain a matching row according to their column statistics."""
+        md = self._pf.metadata
+        preds = self._preds or []
+        col_index = {md.schema.column(i).name: i for i in range(md.num_columns)}
+        keep = []
+        for g in range(md.num_row_groups):
+            rg = md.row_group(g)
+            ok = True
+            for name, op, value in preds:
+                st = rg.column(col_index[name]).statistics if name in col_index else None
+                if st is None or not st.has_min_max:
+                    continue
+                lo, hi = st.min, st.max
+                try:
+                    v = _comparable(value, lo)
+                    possible = {F.OP_GT: hi > v, F.OP_GE: hi >= v, F.OP_LT: lo < v, F.OP_LE: lo <= v, F.OP_EQ: lo <= v <= hi, F.OP_NE: not (lo == hi == v)}[op]
+                except TypeError:
+                    possible = True
+                if not possible:
+                    ok = False
+                    break
+            if ok:
+                keep.append(g)
+        return keep
+
+    # -- materialisation ---------------------------------------------------------------------------------------------------
+    def materialise(self):
+        from .frame import DataFrame, Series
+        cols, rgs = self.selected_columns(), self.selected_row_groups()
+        key = (frozenset(cols), tuple(rgs))
+        if self._df is not None and self._loaded == key:
+            return self._df
+        md = self._pf.metadata
+        tbl = self._pf.read_row_groups(rgs, columns=cols) if rgs else self._pf.schema_arrow.empty_table().select(cols)
+        self._df = DataFrame([Series.from_arrow(n, tbl.column(n)) for n in cols])
+        self._loaded = key
+        self.last_read = {"columns": cols, "row_groups": len(rgs), "of_row_groups": md.num_row_groups, "rows": tbl.num_rows, "of_rows": md.num_rows,
+                          "bytes": tbl.nbytes}
+        return self._df
+
+    def _frame_handle(self) -> int:
+        return self.materialise()._frame_handle()
+
+
+def _comparable(value: Any, like: Any) -> Any:
+    """The literal in the domain of the statistics (pyarrow reports timestamps as datetime, dates as date)."""
+    if isinstance(like, _dt.datetime):
+        if isinstance(value, _dt.datetime):
+            return value.replace(tzinfo=like.tzinfo) if value.tzinfo is None else value
+        if isinstance(value, _dt.date):
+            return _dt.datetime(value.year, value.month, value.day, tzinfo=like.tzinfo)
+        if isinstance(value, int):
+            return _dt.datetime(1970, 1, 1, tzinfo=like.tzinfo) + _dt.timedelta(microseconds=value)
+    if isinstance(like, _dt.date) and isinstance(value, _dt.datetime):
+        return value.date()
+    if isinstance(value, (bool, int, float)) and isinstance(like, (bool, int, float)):
+        return value
+    if type(value) is type(like):
+        return value
+    raise TypeError("statistics and literal are not comparable")
+
+
+def scan_parquet(path: str, columns: Optional[Sequence[str]] = None):
+    """LazyFrame over a Parquet file (mirrors polars.scan_parquet for the path's dtypes).  Nothing is read until collect()."""
+    from .frame import LazyFrame
+    return LazyFrame(P.Node("scan", frame=ParquetFrame(path, columns)))
+
+
+def read_parquet(path: str, columns: Optional[Sequence[str]] = None):
+    """Eager variant: decode (only `columns`) and upload."""
+    pf = ParquetFrame(path, columns)
+    pf.request(None, [])
+    return pf.materialise()
+
+
+# ---- plan analysis: which columns / predicates reach which scan (projection_pushdown / predicate_pushdown restated) --------------
+def expr_columns(e: Optional[Expr], out: Optional[Set[str]] = None) -> Set[str]:
+    out = set() if out is None else out
+    if e is None:
+        return out
+    if e.kind == "col":
+        out.add(e.name)
+    for child in (e.lhs, e.rhs):
+        if isinstance(child, Expr):
+            expr_columns(child, out)
+    return out
+
+
+def output_names(n: P.Node) -> List[str]:
+    k = n.kind
+    if k == "scan":
+        return list(n.frame.schema)
+    if k in ("filter", "sort", "slice"):
+        return output_names(n.input)
+    if k == "select":
+        return [P.expr_output_name(e) for e in n.exprs]
+    if k == "with_columns":
+        names = output_names(n.input)
+        return names + [x for x in (P.expr_output_name(e) for e in n.exprs) if x not in names]
+    if k == "group_by":
+        return [P.expr_output_name(e) for e in n.keys] + [P.expr_output_name(e) for e in n.aggs]
+    if k == "join":
+        left = output_names(n.left)
+        if n.how in ("semi", "anti"):
+            return left
+        rkeys = {b.name for a, b in zip(n.left_on, n.right_on) if a.kind == "col" and b.kind == "col"}
+        return left + [(r + n.suffix if r in left else r) for r in output_names(n.right) if r not in rkeys]
+    raise TypeError(k)
+
+
+def _conjuncts(e: Expr, out: List[Expr]) -> List[Expr]:
+    if e.kind == "binary" and e.op == F.OP_AND:
+        _conjuncts(e.lhs, out); _conjuncts(e.rhs, out)
+    else:
+        out.append(e)
+    return out
+
+
+_FLIP = {F.OP_LT: F.OP_GT, F.OP_GT: F.OP_LT, F.OP_LE: F.OP_GE, F.OP_GE: F.OP_LE, F.OP_EQ: F.OP_EQ, F.OP_NE: F.OP_NE}
+
+
+def simple_predicates(e: Expr) -> List[Pred]:
+    """Conjuncts of the form column <cmp> literal (either side)."""
+    out: List[Pred] = []
+    for c in _conjuncts(e, []):
+        if c.kind != "binary" or c.op not in _FLIP:
+            continue
+        l, r = c.lhs, c.rhs
+        if l.kind == "col" and r.kind == "lit" and r.value is not None:
+            out.append((l.name, c.op, r.value))
+        elif r.kind == "col" and l.kind == "lit" and l.value is not None:
+            out.append((r.name, _FLIP[c.op], l.value))
+    return out
+
+
+def push_down(node: P.Node, needed: Optional[Set[str]] = None, preds: Optional[List[Pred]] = None) -> None:
+    """Tells every ParquetFrame under `node` which columns the plan reads and which simple predicates sit directly above it."""
+    k = node.kind
+    if k == "scan":
+        if isinstance(node.frame, ParquetFrame):
+            node.frame.request(needed, preds or [])
+        return
+    if k == "filter":
+        cols = expr_columns(node.predicate)
+        below = preds if preds is not None else []
+        push_down(node.input, None if needed is None else needed | cols, below + simple_predicates(node.predicate))
+        return
+    if k == "select":
+        cols: Set[str] = set()
+        for e in node.exprs:
+            expr_columns(e, cols)
+        push_down(node.input, cols, None)
+        return
+    if k == "with_columns":
+        new = {P.expr_output_name(e) for e in node.exprs}
+        cols = set()
+        for e in node.exprs:
+            expr_columns(e, cols)
+        push_down(node.input, None if needed is None else (needed - new) | cols, None)
+        return
+    if k == "group_by":
+        cols = set()
+        for e in list(node.keys) + list(node.aggs):
+            expr_columns(e, cols)
+        push_down(node.input, cols, None)
+        return
+    if k == "sort":
+        cols = set()
+        for e in node.by:
+            expr_columns(e, cols)
+        push_down(node.input, None if needed is None else needed | cols, None)
+        return
+    if k == "slice":
+        push_down(node.input, needed, None)
+        return
+    if k == "join":
+        lnames, rnames = output_names(node.left), output_names(node.right)
+        lk, rk = set(), set()
+        for e in node.left_on:
+            expr_columns(e, lk)
+        for e in node.right_on:
+            expr_columns(e, rk)
+        if needed is None:
+            push_down(node.left, None, None); push_down(node.right, None, None)
+            return
+        lneed = {n for n in needed if n in lnames} | lk
+        rneed = rk | {n for n in rnames if n in needed or (n + node.suffix) in needed}
+        push_down(node.left, lneed, None); push_down(node.right, rneed, None)
+        return
+    raise TypeError(f"unsupported plan node {k}")
+
+
+def has_file_scan(node: P.Node) -> bool:
+    if node.kind == "scan":
+        return isinstance(node.frame, ParquetFrame)
+    return any(isinstance(getattr(node, a, None), P.Node) and has_file_scan(getattr(node, a)) for a in ("input", "left", "right"))
+
+
+def reset_scans(node: P.Node) -> None:
+    if node.kind == "scan":
+        if isinstance(node.frame, ParquetFrame):
+            node.frame.reset_requests()
+        return
+    for attr in ("input", "left", "right"):
+        child = getattr(node, attr, None)
+        if isinstance(child, P.Node):
+            reset_scans(child)

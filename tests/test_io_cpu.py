@@ -1,0 +1,117 @@
+"""polars_amd/io.py without a GPU: what a Parquet scan decides to read.  Projection pushdown (only the columns the plan touches),
+row-group skipping from min / max statistics for the simple conjuncts above the scan, merging of several uses of one scan."""
+import datetime as dt
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+import pytest
+
+import polars_amd as pl
+from polars_amd import datagen, io
+from polars_amd import queries as Q
+
+
+@pytest.fixture(scope="module")
+def lineitem_file(tmp_path_factory):
+    """A 16-column lineitem (the PDS-H schema of examples/datasets/pds_heads/lineitem.feather), sorted by l_shipdate, 40 row groups."""
+    n = 40_000
+    li = datagen.lineitem_host(n, seed=6)
+    order = np.argsort(li["l_shipdate"], kind="stable")
+    rng = np.random.default_rng(1)
+    t = pa.table({
+        "l_orderkey": pa.array(rng.integers(1, 10_000, n)), "l_partkey": pa.array(rng.integers(1, 1000, n)), "l_suppkey": pa.array(rng.integers(1, 100, n)),
+        "l_linenumber": pa.array(rng.integers(1, 8, n)), "l_quantity": pa.array(li["l_quantity"][order]), "l_extendedprice": pa.array(li["l_extendedprice"][order]),
+        "l_discount": pa.array(li["l_discount"][order]), "l_tax": pa.array(li["l_tax"][order]),
+        "l_returnflag": pa.array([datagen.FLAGS[c] for c in li["l_returnflag"][order]], pa.large_string()),
+        "l_linestatus": pa.array([datagen.STATUS[c] for c in li["l_linestatus"][order]], pa.large_string()),
+        "l_shipdate": pa.array(li["l_shipdate"][order], pa.timestamp("us")), "l_commitdate": pa.array(li["l_shipdate"][order], pa.timestamp("us")),
+        "l_receiptdate": pa.array(li["l_shipdate"][order], pa.timestamp("us")), "l_shipinstruct": pa.array(["NONE"] * n, pa.large_string()),
+        "l_shipmode": pa.array(["AIR"] * n, pa.large_string()), "l_comment": pa.array(["x"] * n, pa.large_string())})
+    path = str(tmp_path_factory.mktemp("pq") / "lineitem.parquet")
+    pq.write_table(t, path, row_group_size=1000)
+    return path, li, order
+
+
+def test_schema_and_laziness(lineitem_file):
+    path, _, _ = lineitem_file
+    lf = pl.scan_parquet(path)
+    src = lf._node.frame
+    assert isinstance(src, io.ParquetFrame) and src.num_rows == 40_000 and len(src.schema) == 16
+    assert src.schema["l_shipdate"] == pl.Datetime and src.schema["l_quantity"] == pl.Int64 and src.schema["l_extendedprice"] == pl.Float64
+    assert src.schema["l_returnflag"].physical == pl.UInt32.physical and src._df is None       # strings arrive as dictionary codes; nothing read yet
+
+
+def test_q1_reads_seven_of_sixteen_columns(lineitem_file):
+    path, _, _ = lineitem_file
+    lf = Q.q1(pl.scan_parquet(path))
+    io.reset_scans(lf._node); io.push_down(lf._node)
+    src = lf._node.input.input.frame if lf._node.kind != "scan" else None
+    node = lf._node
+    while node.kind != "scan":
+        node = node.input
+    src = node.frame
+    assert sorted(src.selected_columns()) == sorted(datagen.LINEITEM_Q1_COLS)
+    # Q1's predicate keeps ~98 % of a table sorted by ship date: only the last row groups can be skipped
+    rgs = src.selected_row_groups()
+    assert 35 <= len(rgs) < 40 and rgs == list(range(len(rgs)))
+    assert src._preds == [("l_shipdate", pl._ffi.OP_LE, Q.Q1_CUTOFF)]
+
+
+def test_row_group_skipping_follows_the_statistics(lineitem_file):
+    path, li, order = lineitem_file
+    ship = li["l_shipdate"][order]
+    lo, hi = dt.datetime(1994, 1, 1), dt.datetime(1994, 3, 1)
+    c = pl.col
+    lf = pl.scan_parquet(path).filter((c("l_shipdate") >= lo) & (c("l_shipdate") < hi) & (c("l_quantity") > 0)).select(c("l_extendedprice").sum())
+    io.reset_scans(lf._node); io.push_down(lf._node)
+    node = lf._node
+    while node.kind != "scan":
+        node = node.input
+    src = node.frame
+    assert sorted(src.selected_columns()) == ["l_extendedprice", "l_quantity", "l_shipdate"]
+    rgs = src.selected_row_groups()
+    us = lambda d: int((d - dt.datetime(1970, 1, 1)).total_seconds()) * 1_000_000
+    rows = np.nonzero((ship >= us(lo)) & (ship < us(hi)))[0]
+    want = sorted(set((rows // 1000).tolist()))
+    assert set(want) <= set(rgs) and len(rgs) <= len(want) + 2 and len(rgs) < 6        # every matching group is read, at most the two boundary groups extra
+    # literal on the left, != and ==, and a predicate that nothing can satisfy
+    lf2 = pl.scan_parquet(path).filter((dt.datetime(2030, 1, 1) < c("l_shipdate"))).select(pl.len())
+    io.reset_scans(lf2._node); io.push_down(lf2._node)
+    n2 = lf2._node
+    while n2.kind != "scan":
+        n2 = n2.input
+    assert n2.frame.selected_row_groups() == [] and n2.frame.selected_columns() == ["l_shipdate"]
+
+
+def test_plans_without_pruning_opportunities(lineitem_file):
+    path, _, _ = lineitem_file
+    c = pl.col
+    # no select: every column is needed; an OR predicate is not a conjunct of simple comparisons
+    lf = pl.scan_parquet(path).filter((c("l_quantity") > 49) | (c("l_tax") > 0.07))
+    io.reset_scans(lf._node); io.push_down(lf._node)
+    src = lf._node.input.frame
+    assert len(src.selected_columns()) == 16 and len(src.selected_row_groups()) == 40
+    # the same file scanned twice in one plan with different needs: union of columns, no predicate pushdown
+    a = pl.scan_parquet(path)
+    shared = a._node.frame
+    left = a.filter(c("l_quantity") > 10).select("l_orderkey", "l_quantity")
+    right = pl.LazyFrame(a._node).filter(c("l_tax") > 0.01).select("l_orderkey", "l_tax")
+    j = left.join(right, on="l_orderkey").group_by("l_orderkey").agg(c("l_quantity").sum(), c("l_tax").max())
+    io.reset_scans(j._node); io.push_down(j._node)
+    assert sorted(shared.selected_columns()) == ["l_orderkey", "l_quantity", "l_tax"] and len(shared.selected_row_groups()) == 40 and shared._preds == []
+    # join: each side only reads its own columns
+    orders = pa.table({"o_orderkey": pa.array(np.arange(100)), "o_custkey": pa.array(np.arange(100)), "o_orderdate": pa.array(np.arange(100), pa.timestamp("us")),
+                       "o_shippriority": pa.array(np.zeros(100, np.int64)), "o_comment": pa.array(["c"] * 100, pa.large_string())})
+    opath = path.replace("lineitem", "orders")
+    pq.write_table(orders, opath)
+    q3 = Q.q3(pl.scan_parquet(path), pl.scan_parquet(opath))
+    io.reset_scans(q3._node); io.push_down(q3._node)
+    jn = q3._node.input
+    lsrc, rsrc = jn.left, jn.right
+    while lsrc.kind != "scan":
+        lsrc = lsrc.input
+    while rsrc.kind != "scan":
+        rsrc = rsrc.input
+    assert sorted(lsrc.frame.selected_columns()) == sorted(datagen.LINEITEM_Q3_COLS)
+    assert sorted(rsrc.frame.selected_columns()) == sorted(datagen.ORDERS_Q3_COLS)
