@@ -621,8 +621,9 @@ class LazyFrame:
     # -- execution -----------------------------------------------------------------------------------
     def _lower(self):
         from . import io as _io
-        _io.reset_scans(self._node)          # file scans: tell them which columns / row groups this plan reads (io.push_down)
-        _io.push_down(self._node)
+        if _io.has_file_scan(self._node):    # file scans: tell them which columns / row groups this plan reads (io.push_down)
+            _io.reset_scans(self._node)
+            _io.push_down(self._node)
         low = P.Lowering()
         root, schema = low.lower_node(self._node)
         return low, root, schema
