@@ -16,7 +16,7 @@ no row crosses xGMI.  Prints ONE JSON line on rank 0.
 Order of work at N = 1: headline (Q1; its input comes from the library's own generator kernel, spot-checked against the
 generator's host twin, with the torch generators as fallback) -> CPU baseline -> secondary workloads (`extras`).  The
 line is complete after the first two; the extras only add to it, and a guard process prints the line as it stands if
-they have not finished PLX_BENCH_DEADLINE_S (300) seconds after the start (run_guarded).
+they have not finished PLX_BENCH_DEADLINE_S (180) seconds after the start (run_guarded).
 """
 from __future__ import annotations
 
@@ -511,7 +511,7 @@ def main():
     rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     # single-GPU runs with secondary workloads go through the guard; torchrun ranks and --no-extras runs (rocprofv3 wraps those) do not
     if ws == 1 and not args.no_extras and os.environ.get("PLX_BENCH_GUARD", "1") != "0":
-        sys.exit(run_guarded(lambda emit: run(args, emit), float(os.environ.get("PLX_BENCH_DEADLINE_S", "300"))))
+        sys.exit(run_guarded(lambda emit: run(args, emit), float(os.environ.get("PLX_BENCH_DEADLINE_S", "180"))))
     final = {}
     run(args, final.update)
     if rank == 0:
