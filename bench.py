@@ -460,10 +460,15 @@ def run_guarded(worker, deadline_s: float, poll_s: float = 0.25) -> int:
     tmp = tempfile.mkdtemp(prefix="plx_bench_")
     path = os.path.join(tmp, "line.json")
 
-    def emit(line: dict):
+    ready_path = path + ".ready"
+
+    def emit(line: dict, ready: bool = True):
+        """ready=False: the line lacks mandatory parts (the CPU baseline): never cut the worker while only such a version exists."""
         with open(path + ".tmp", "w") as f:
             f.write(json.dumps(line))
         os.replace(path + ".tmp", path)
+        if ready and not os.path.exists(ready_path):
+            open(ready_path, "w").close()
 
     sys.stdout.flush(); sys.stderr.flush()
     pid = os.fork()
@@ -485,14 +490,14 @@ def run_guarded(worker, deadline_s: float, poll_s: float = 0.25) -> int:
         if done:
             status = st
             break
-        if time.monotonic() >= t_end and os.path.exists(path):
+        if time.monotonic() >= t_end and os.path.exists(ready_path):
             os.kill(pid, signal.SIGKILL)
             os.waitpid(pid, 0)
             stopped = True
             break
         time.sleep(poll_s)
     line = open(path).read() if os.path.exists(path) else None
-    for f in (path, path + ".tmp"):
+    for f in (path, path + ".tmp", ready_path):
         if os.path.exists(f):
             os.remove(f)
     os.rmdir(tmp)
@@ -513,7 +518,7 @@ def main():
     if ws == 1 and not args.no_extras and os.environ.get("PLX_BENCH_GUARD", "1") != "0":
         sys.exit(run_guarded(lambda emit: run(args, emit), float(os.environ.get("PLX_BENCH_DEADLINE_S", "180"))))
     final = {}
-    run(args, final.update)
+    run(args, lambda line, ready=True: final.update(line))
     if rank == 0:
         print(json.dumps(final), flush=True)
 
@@ -552,14 +557,15 @@ def run(args, emit):
         "roofline": roofline(stats, wl),
         "kernels": {k: {"launches": v[0], "avg_us": round(v[1] / v[0], 2)} for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])[:8]},
     }
+    want_cpu = rank == 0 and ws == 1 and not args.no_cpu
     if rank == 0:
-        emit(line)                               # the headline is safe from here on
-    if rank == 0 and ws == 1 and not args.no_cpu:
+        emit(line, not want_cpu)                 # the headline is safe from here on (a guard cut waits for the CPU baseline)
+    if want_cpu:
         try:
             line["cpu_baseline"] = cpu_baseline_q1(args.cpu_seconds)
         except Exception as e:
             line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        emit(line)
+        emit(line, True)
     if rank == 0 and not args.no_extras and ws == 1:
         extras = {}
         line["extras"] = extras

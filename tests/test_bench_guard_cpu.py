@@ -45,6 +45,19 @@ def test_no_deadline_cut_before_a_headline_exists(capsys):
     assert len(out) == 1 and json.loads(out[0])["value"] == 3
 
 
+def test_no_cut_while_mandatory_parts_are_missing(capsys):
+    def worker(emit):
+        emit({"value": 9}, False)            # headline measured, CPU baseline still running when the deadline passes
+        time.sleep(1.0)
+        emit({"value": 9, "cpu_baseline": {"value": 1}}, True)
+        time.sleep(60)                       # a stalled secondary workload
+    t0 = time.monotonic()
+    assert bench.run_guarded(worker, deadline_s=0.3, poll_s=0.05) == 0
+    assert 0.9 < time.monotonic() - t0 < 10
+    out = _lines(capsys)
+    assert len(out) == 1 and json.loads(out[0])["cpu_baseline"] == {"value": 1}
+
+
 def test_worker_dying_after_the_headline_still_reports_it(capsys):
     def worker(emit):
         emit({"value": 5})
