@@ -115,3 +115,29 @@ def test_plans_without_pruning_opportunities(lineitem_file):
         rsrc = rsrc.input
     assert sorted(lsrc.frame.selected_columns()) == sorted(datagen.LINEITEM_Q3_COLS)
     assert sorted(rsrc.frame.selected_columns()) == sorted(datagen.ORDERS_Q3_COLS)
+
+
+def test_benchmark_tables_follow_the_reference_sample_schemas(tmp_path):
+    """The synthetic TPC-H columns (polars_amd/datagen.py) and the scan's dtype mapping agree with the Arrow schemas of the
+    reference's own sample tables (examples/datasets/pds_heads/*.feather, recorded by tests/golden/make_pds_schema.py)."""
+    import json
+    import os
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pds_heads_schema.json")))
+    arrow = {"int64": pa.int64(), "double": pa.float64(), "large_string": pa.large_string(), "timestamp[us]": pa.timestamp("us")}
+    lt = datagen.logical_dtypes(pl)
+    for table, needed in (("lineitem", set(datagen.LINEITEM_Q1_COLS) | set(datagen.LINEITEM_Q3_COLS)), ("orders", set(datagen.ORDERS_Q3_COLS))):
+        cols = dict(ref[table]["columns"])
+        assert needed <= set(cols), (table, needed - set(cols))
+        # a file with the reference's schema maps to the dtypes the generators use
+        t = pa.table({n: pa.array([], arrow[ty]) for n, ty in cols.items()})
+        path = str(tmp_path / f"{table}.parquet")
+        pq.write_table(t, path)
+        schema = pl.scan_parquet(path)._node.frame.schema
+        for n in needed:
+            if cols[n] == "large_string":
+                assert schema[n].physical == pl.UInt32.physical and lt[n].name == "Categorical"      # strings = dictionary codes on the device
+            else:
+                want = {"int64": pl.Int64, "double": pl.Float64, "timestamp[us]": pl.Datetime}[cols[n]]
+                assert schema[n] == want and lt.get(n, want) == want, (table, n)
+    li = datagen.lineitem_host(10, seed=1)
+    assert li["l_quantity"].dtype == np.int64 and li["l_extendedprice"].dtype == np.float64 and li["l_shipdate"].dtype == np.int64
