@@ -79,3 +79,50 @@ def test_product_never_imports_the_oracle():
     assert not bad, bad
     txt = open(os.path.join(ROOT, "polars_amd", "dist.py")).read()
     assert "import oracle" not in txt and "pyoracle" not in txt
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/polars_amd.h must be consumable by a C compiler (the boundary a cgo / JNI / Rust-FFI binding sees): a C11 program
+    using the kernel-level and plan-level entry points compiles with -Wall -Werror, links against the built library and, on a box
+    without a GPU, gets a clean error code + message instead of a crash."""
+    import subprocess
+    src = tmp_path / "abi_example.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "polars_amd.h"
+
+int main(void) {
+  if (plx_version() != ((PLX_ABI_MAJOR << 16) | PLX_ABI_MINOR)) return 10;
+  int rc = plx_init(0);
+  if (rc != PLX_OK) {                       /* no GPU here: a status code and a message, nothing else */
+    const char* msg = plx_last_error();
+    if (!msg || !strlen(msg)) return 11;
+    printf("init failed as expected: %d\n", rc);
+    /* the rest must fail the same way, not crash */
+    int64_t v[4] = {1, 2, 3, 4};
+    plx_column col = 0;
+    if (plx_column_from_host(PLX_I64, v, NULL, 0, 4, &col) == PLX_OK) return 12;
+    return 0;
+  }
+  /* with a GPU: filter(a > 2).select(sum(a)) through the kernel-level entry points */
+  int64_t v[4] = {1, 2, 3, 4};
+  plx_column a = 0, mask = 0, kept = 0;
+  plx_scalar two; two.i = 2;
+  plx_scalar out; plx_dtype out_dtype = PLX_I64; int32_t out_valid = 0;
+  if (plx_column_from_host(PLX_I64, v, NULL, 0, 4, &a)) return 20;
+  if (plx_cmp_scalar(PLX_GT, a, two, &mask)) return 21;
+  if (plx_filter(a, mask, &kept)) return 22;
+  if (plx_reduce(PLX_AGG_SUM, kept, &out, &out_dtype, &out_valid)) return 23;
+  printf("sum = %lld\n", (long long)out.i);
+  plx_column_free(a); plx_column_free(mask); plx_column_free(kept);
+  return out.i == 7 ? 0 : 24;
+}
+''')
+    exe = tmp_path / "abi_example"
+    inc, libdir = os.path.join(ROOT, "include"), os.path.join(ROOT, "polars_amd")
+    cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lpolars_amd", f"-Wl,-rpath,{libdir}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
