@@ -51,6 +51,15 @@ class Expr:
     def __invert__(self): return Expr("not", lhs=self)
     def __hash__(self): return id(self)
 
+    def __neg__(self): return lit(0)._bin(F.OP_MINUS, self)                      # 0 - x, as the reference lowers unary minus for integers / floats
+    def is_between(self, lower, upper, closed: str = "both") -> "Expr":
+        """lower <= x <= upper (py-polars expr.is_between); closed in {"both", "left", "right", "none"}."""
+        if closed not in ("both", "left", "right", "none"):
+            raise ValueError(f"closed must be one of 'both', 'left', 'right', 'none', got {closed!r}")
+        lo = self.__ge__(lower) if closed in ("both", "left") else self.__gt__(lower)
+        hi = self.__le__(upper) if closed in ("both", "right") else self.__lt__(upper)
+        return lo & hi
+
     def eq(self, o): return self.__eq__(o)
     def ne(self, o): return self.__ne__(o)
     def not_(self): return self.__invert__()

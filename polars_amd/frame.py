@@ -692,3 +692,24 @@ class GroupBy:
         es = _as_exprs(aggs) + [e.alias(k) for k, e in named.items()]
         out = LazyFrame(P.Node("group_by", input=self._lf._node, keys=self._keys, aggs=es, maintain_order=self._mo))
         return out.collect() if self._eager else out
+
+    # -- shorthands of polars' GroupBy / LazyGroupBy (py-polars dataframe/group_by.py, lazyframe/group_by.py) --------------
+    def len(self, name: Optional[str] = None):
+        """Rows per group (column "len")."""
+        from .expr import len as _len
+        return self.agg(_len().alias(name or "len"))
+
+    def _value_columns(self) -> List[str]:
+        """Every input column that is not a (plain-column) group key."""
+        from . import io as _io
+        keys = {k.name for k in self._keys if k.kind == "col"}
+        return [c for c in _io.output_names(self._lf._node) if c not in keys]
+
+    def _all(self, method: str):
+        return self.agg(*[getattr(_col(c), method)() for c in self._value_columns()])
+
+    def sum(self): return self._all("sum")
+    def mean(self): return self._all("mean")
+    def min(self): return self._all("min")
+    def max(self): return self._all("max")
+    def count(self): return self._all("count")

@@ -388,3 +388,26 @@ def test_reference_group_by_kats_through_the_compiler(case):
                 continue
             g = row[c]
             assert kat.same_value(float("nan") if g == "nan" else g, vals[i], case.get("rtol", 1e-12)), (case["id"], key, c, g, vals[i])
+
+
+def test_api_shorthands_lower_to_the_same_programs():
+    """is_between / unary minus / GroupBy.len / GroupBy.sum are sugar over the existing IR: they must compile and evaluate like the spelled-out forms."""
+    rng = np.random.default_rng(4)
+    n = 5000
+    cols = {"k": (rng.integers(0, 7, n).astype(np.int64), None), "a": (rng.integers(-50, 50, n).astype(np.int64), rng.random(n) < 0.9), "x": (rng.normal(size=n), None)}
+    c = pl.col
+    f = frame_like(cols)
+    short = f.lazy().filter(c("a").is_between(-10, 20, closed="left")).select((-c("x")).sum().alias("s"), pl.len().alias("n"))
+    long_ = f.lazy().filter((c("a") >= -10) & (c("a") < 20)).select((0.0 - c("x")).sum().alias("s"), pl.len().alias("n"))
+    a, b = pe.evaluate(short.debug_program(), cols), pe.evaluate(long_.debug_program(), cols)
+    keep = (cols["a"][0] >= -10) & (cols["a"][0] < 20) & cols["a"][1]
+    assert a["n"][0][0] == b["n"][0][0] == int(keep.sum()) and close(float(a["s"][0][0]), float(-cols["x"][0][keep].sum()), 1e-9) and a["s"][0][0] == b["s"][0][0]
+    with pytest.raises(ValueError, match="closed must be"):
+        c("a").is_between(0, 1, closed="sideways")
+    g1 = by_key(pe.evaluate(f.lazy().group_by("k").len().debug_program(), cols), ["k"])
+    assert {k[0]: v["len"] for k, v in g1.items()} == {int(k): int((cols["k"][0] == k).sum()) for k in np.unique(cols["k"][0])}
+    g2 = by_key(pe.evaluate(f.lazy().group_by("k").sum().debug_program(), cols), ["k"])
+    for k, row in g2.items():
+        m = cols["k"][0] == k[0]
+        assert row["a"] == int(cols["a"][0][m & cols["a"][1]].sum()) and close(row["x"], float(cols["x"][0][m].sum()), 1e-9)
+    assert list(f.lazy().group_by("k").mean()._lower()[2]) == ["k", "a", "x"]
