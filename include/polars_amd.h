@@ -306,7 +306,10 @@ typedef enum plx_aexpr_kind {
   PLX_AE_AGG = 4,     /* op = plx_agg_op, lhs */
   PLX_AE_LEN = 5,     /* pl.len() */
   PLX_AE_ALIAS = 6,   /* lhs, name */
-  PLX_AE_NOT = 7      /* lhs (boolean) */
+  PLX_AE_NOT = 7,     /* lhs (boolean) */
+  PLX_AE_IS_NULL = 8,     /* lhs -> Boolean, never null (FunctionExpr::Boolean(IsNull)) */
+  PLX_AE_IS_NOT_NULL = 9, /* lhs -> Boolean, never null */
+  PLX_AE_FILL_NULL = 10   /* lhs, rhs = non-null literal of the same dtype (fill_null(literal)); inside fused pipelines only */
 } plx_aexpr_kind;
 
 /* polars_plan::dsl::Operator subset */

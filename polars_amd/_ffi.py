@@ -21,7 +21,7 @@ ADD, SUB, MUL, TRUE_DIV, FLOOR_DIV, MOD = range(6)
 AND, OR, XOR = range(3)
 AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT, AGG_LEN, AGG_FIRST = range(7)
 JOIN_INNER, JOIN_LEFT, JOIN_SEMI, JOIN_ANTI = range(4)
-AE_COLUMN, AE_LITERAL, AE_BINARY, AE_CAST, AE_AGG, AE_LEN, AE_ALIAS, AE_NOT = range(8)
+AE_COLUMN, AE_LITERAL, AE_BINARY, AE_CAST, AE_AGG, AE_LEN, AE_ALIAS, AE_NOT, AE_IS_NULL, AE_IS_NOT_NULL, AE_FILL_NULL = range(11)
 (OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE, OP_PLUS, OP_MINUS, OP_MULTIPLY, OP_TRUE_DIVIDE,
  OP_FLOOR_DIVIDE, OP_MODULUS, OP_AND, OP_OR, OP_XOR) = range(15)
 IR_SCAN, IR_FILTER, IR_SELECT, IR_HSTACK, IR_GROUPBY, IR_JOIN, IR_SORT, IR_SLICE = range(8)

@@ -88,7 +88,8 @@ int infer_dtype(const Plan& plan, int e, const Frame& schema) {
     case PLX_AE_LITERAL: return x.dtype;
     case PLX_AE_ALIAS: return infer_dtype(plan, x.lhs, schema);
     case PLX_AE_CAST: return x.dtype;
-    case PLX_AE_NOT: return PLX_BOOL;
+    case PLX_AE_NOT: case PLX_AE_IS_NULL: case PLX_AE_IS_NOT_NULL: return PLX_BOOL;
+    case PLX_AE_FILL_NULL: return infer_dtype(plan, x.lhs, schema);
     case PLX_AE_LEN: return PLX_U32;
     case PLX_AE_AGG: {
       int in = infer_dtype(plan, x.lhs, schema);
@@ -171,6 +172,20 @@ static Evaluated eval(const Plan& plan, int e, const Frame& df, const std::map<i
     case PLX_AE_ALIAS: return eval(plan, x.lhs, df, overrides);
     case PLX_AE_CAST: { Evaluated c = eval(plan, x.lhs, df, overrides); return {ops::cast(c.col, x.dtype), c.scalar}; }
     case PLX_AE_NOT: { Evaluated c = eval(plan, x.lhs, df, overrides); return {ops::bool_not(c.col), c.scalar}; }
+    case PLX_AE_IS_NULL: case PLX_AE_IS_NOT_NULL: {
+      // the validity bitmap IS the answer: a Boolean column that shares it as its values (no kernel), never null itself
+      Evaluated c = eval(plan, x.lhs, df, overrides);
+      ColumnPtr b;
+      if (c.col->validity && column_null_count(c.col) > 0) {
+        b = std::make_shared<Column>();
+        b->dtype = PLX_BOOL; b->len = c.col->len; b->values = c.col->validity; b->null_count = 0;
+      } else {
+        plx_scalar one; one.u = 1;
+        b = ops::full_column(PLX_BOOL, one, true, c.col->len);
+      }
+      return {x.kind == PLX_AE_IS_NULL ? ops::bool_not(b) : b, c.scalar};
+    }
+    case PLX_AE_FILL_NULL: fail(PLX_ERR_UNSUPPORTED, "fill_null outside a fused pipeline (no per-node select kernel on this path yet)");
     case PLX_AE_LEN: { ops::ScalarValue s; s.dtype = PLX_U32; s.valid = true; s.v.u = (uint32_t)df.height; return {ops::scalar_column(s), true}; }
     case PLX_AE_AGG: {
       Evaluated c = eval(plan, x.lhs, df, overrides);
@@ -324,6 +339,22 @@ class Compiler {
       }
       case PLX_AE_ALIAS: return lower(x.lhs);
       case PLX_AE_NOT: { int a = lower(x.lhs); if (nodes[a].ty != 'b') throw Unsupported("not on non-boolean"); return mk(OP_NOT, a, a, 'b'); }
+      case PLX_AE_IS_NULL: case PLX_AE_IS_NOT_NULL: {
+        // valid(a) as a value, with the opcodes the kernels already have: (a ==bits a) is 1 with a's validity; IFNULL(.., 0) turns
+        // the null into 0.  A source that cannot be null folds to a constant.
+        int a = lower(x.lhs);
+        int nn = nodes[a].nullable ? ifnull(mk(OP_CMP_U, a, a, 'b', (uint8_t)PLX_EQ), 0) : konst(1, 'b');
+        return x.kind == PLX_AE_IS_NOT_NULL ? nn : mk(OP_NOT, nn, nn, 'b');
+      }
+      case PLX_AE_FILL_NULL: {
+        const int dt = infer_dtype(plan, x.lhs, *df);
+        const AE& l = plan.ae.at(x.rhs);
+        if (l.kind != PLX_AE_LITERAL || l.is_null) throw Unsupported("fill_null with a non-literal value");
+        if (l.dtype != dt) fail(PLX_ERR_INVALID, std::string("fill_null literal dtype ") + dtype_name(l.dtype) + " differs from the column's " + dtype_name(dt));
+        if (dt == PLX_F32) throw Unsupported("f32 fill_null");
+        int a = lower(x.lhs);
+        return nodes[a].nullable ? ifnull(a, widen_literal(l.dtype, l.lit)) : a;
+      }
       case PLX_AE_CAST: {
         int from = infer_dtype(plan, x.lhs, *df), to = x.dtype;
         int a = lower(x.lhs);

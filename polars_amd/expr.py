@@ -60,6 +60,14 @@ class Expr:
         hi = self.__le__(upper) if closed in ("both", "right") else self.__lt__(upper)
         return lo & hi
 
+    def is_null(self) -> "Expr": return Expr("is_null", lhs=self)
+    def is_not_null(self) -> "Expr": return Expr("is_not_null", lhs=self)
+    def fill_null(self, value: Any) -> "Expr":
+        """Replace nulls by a literal (py-polars expr.fill_null(value)); strategies are outside the hot path."""
+        if value is None or isinstance(value, Expr) and value.kind != "lit":
+            raise TypeError("fill_null takes a non-null literal on this path")
+        return Expr("fill_null", lhs=self, rhs=value if isinstance(value, Expr) else lit(value))
+
     def eq(self, o): return self.__eq__(o)
     def ne(self, o): return self.__ne__(o)
     def not_(self): return self.__invert__()
@@ -84,6 +92,8 @@ class Expr:
         if self.kind == "alias": return f"{self.lhs!r}.alias({self.name!r})"
         if self.kind == "cast": return f"{self.lhs!r}.cast({self.dtype})"
         if self.kind == "not": return f"~{self.lhs!r}"
+        if self.kind in ("is_null", "is_not_null"): return f"{self.lhs!r}.{self.kind}()"
+        if self.kind == "fill_null": return f"{self.lhs!r}.fill_null({self.rhs!r})"
         return self.kind
 
     def __bool__(self):

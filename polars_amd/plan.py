@@ -123,6 +123,15 @@ class Lowering:
             if dt != T.Boolean:
                 raise TypeError("~ needs a boolean expression")
             return self._push(kind=F.AE_NOT, lhs=idx), T.Boolean
+        if k in ("is_null", "is_not_null"):
+            idx, _ = self.lower_expr(e.lhs, schema)
+            return self._push(kind=F.AE_IS_NULL if k == "is_null" else F.AE_IS_NOT_NULL, lhs=idx), T.Boolean
+        if k == "fill_null":
+            idx, dt = self.lower_expr(e.lhs, schema)
+            li, ldt = self.lower_expr(e.rhs, schema, dt)        # the literal takes the column's dtype (python ints / floats are dynamic)
+            if ldt.physical != dt.physical:
+                raise TypeError(f"fill_null value of type {ldt} for a {dt} column")
+            return self._push(kind=F.AE_FILL_NULL, lhs=idx, rhs=li), dt
         if k == "len":
             return self._push(kind=F.AE_LEN), T.UInt32
         if k == "agg":

@@ -1,0 +1,33 @@
+"""is_null / is_not_null / fill_null(literal) on the GPU: fused (compare-with-self + IFNULL, opcodes the kernels already ran) and,
+for the two predicates, the per-node path (the validity bitmap shared as a Boolean column).  The lowering is pinned on the CPU
+(tests/test_program_eval_cpu.py::test_is_null_is_not_null_fill_null); written after this round's GPU budget was spent."""
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="null-handling expressions not yet run on a GPU (added after this round's GPU budget was spent)")]
+
+
+def test_null_expressions_fused_and_per_node(pl):
+    rng = np.random.default_rng(8)
+    n = 300_000
+    a, am = rng.integers(-20, 20, n).astype(np.int64), rng.random(n) < 0.7
+    x, xm = rng.normal(size=n), rng.random(n) < 0.6
+    k = rng.integers(0, 5, n).astype(np.int64)
+    df = pl.DataFrame([pl.Series("a", a, validity=am), pl.Series("x", x, validity=xm), pl.Series("k", k)])
+    c = pl.col
+    q = (df.lazy().filter(c("a").is_not_null() & (c("x").is_null() | (c("x").fill_null(2.5) > 0.0)))
+         .select(pl.len().alias("n"), c("a").fill_null(7).sum().alias("a7"), c("x").fill_null(-1.0).sum().alias("xf")))
+    out = q.collect().to_dict()
+    assert "FusedFilterAgg" in pl.last_plan(), pl.last_plan()
+    keep = am & (~xm | (np.where(xm, x, 2.5) > 0.0))
+    assert out["n"][0] == int(keep.sum()) and out["a7"][0] == int(np.where(am, a, 7)[keep].sum())
+    assert np.isclose(out["xf"][0], np.where(xm, x, -1.0)[keep].sum(), rtol=1e-9)
+    # per-node path for the predicates (fill_null has no per-node kernel: reported as unsupported)
+    cnt = df.lazy().filter(c("a").is_null()).select(pl.len().alias("n")).collect(no_fusion=True).to_dict()["n"][0]
+    assert cnt == int((~am).sum())
+    cnt = df.lazy().filter(c("x").is_not_null() & c("k").is_not_null()).select(pl.len().alias("n")).collect(no_fusion=True).to_dict()["n"][0]
+    assert cnt == int(xm.sum())
+    with pytest.raises(pl.UnsupportedError):
+        df.lazy().select(c("a").fill_null(0).sum()).collect(no_fusion=True)
+    g = df.lazy().filter(c("a").is_null()).group_by("k").agg(pl.len().alias("nulls")).collect().sort_host("k")
+    assert g["nulls"] == [int(((k == i) & ~am).sum()) for i in g["k"]]

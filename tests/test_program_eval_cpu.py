@@ -411,3 +411,44 @@ def test_api_shorthands_lower_to_the_same_programs():
         m = cols["k"][0] == k[0]
         assert row["a"] == int(cols["a"][0][m & cols["a"][1]].sum()) and close(row["x"], float(cols["x"][0][m].sum()), 1e-9)
     assert list(f.lazy().group_by("k").mean()._lower()[2]) == ["k", "a", "x"]
+
+
+def test_is_null_is_not_null_fill_null():
+    """Null handling expressions compile to opcodes the kernels already run (compare-with-self + IFNULL) and mean what
+    py-polars' is_null / is_not_null / fill_null(literal) mean."""
+    rng = np.random.default_rng(8)
+    n = 20_000
+    a, am = rng.integers(-20, 20, n).astype(np.int64), rng.random(n) < 0.7
+    x, xm = rng.normal(size=n), rng.random(n) < 0.6
+    x[rng.random(n) < 0.05] = np.nan
+    b, bm = rng.integers(0, 2, n).astype(bool), rng.random(n) < 0.8
+    k = rng.integers(0, 5, n).astype(np.int64)
+    cols = {"a": (a, am), "x": (x, xm), "b": (b, bm), "k": (k, None)}
+    c = pl.col
+    f = frame_like(cols)
+    lf = (f.lazy().filter(c("a").is_not_null() & (c("x").is_null() | (c("x").fill_null(2.5) > 0.0)) & c("b").fill_null(True))
+          .select(pl.len().alias("n"), c("a").fill_null(7).sum().alias("a7"), c("x").fill_null(-1.0).sum().alias("xf"), c("x").count().alias("xc"),
+                  (c("a").fill_null(0) + 1).max().alias("amax")))
+    prog = lf.debug_program()
+    got = pe.evaluate(prog, cols)
+    xf = np.where(xm, x, 2.5)
+    with np.errstate(invalid="ignore"):
+        keep = am & (~xm | (np.isnan(xf) | (xf > 0.0))) & np.where(bm, b, True)        # NaN > 0.0 in the total order
+    assert got["n"][0][0] == int(keep.sum()) and 0 < keep.sum() < n
+    assert got["a7"][0][0] == int(np.where(am, a, 7)[keep].sum())
+    want_xf = float(np.where(xm, x, -1.0)[keep].sum())
+    assert (math.isnan(want_xf) and math.isnan(got["xf"][0][0])) or close(float(got["xf"][0][0]), want_xf)
+    assert got["xc"][0][0] == int((keep & xm).sum()) and got["amax"][0][0] == int((np.where(am, a, 0) + 1)[keep].max())
+    # a filled column is no longer nullable: its count is the group length; is_null of a non-nullable column folds to a constant
+    g = f.lazy().group_by("k").agg(c("a").fill_null(0).count().alias("cnt"), c("a").count().alias("valid"))
+    by = by_key(pe.evaluate(g.debug_program(), cols), ["k"])
+    gn = f.lazy().filter(c("a").is_null() & c("k").is_not_null()).group_by("k").agg(pl.len().alias("nulls"))
+    byn = by_key(pe.evaluate(gn.debug_program(), cols), ["k"])
+    assert pe.evaluate(f.lazy().filter(c("k").is_null()).select(pl.len().alias("n")).debug_program(), cols)["n"][0][0] == 0
+    for kv, row in by.items():
+        m = k == kv[0]
+        assert row["cnt"] == int(m.sum()) and row["valid"] == int((m & am).sum()) and byn[kv]["nulls"] == int((m & ~am).sum())
+    with pytest.raises(TypeError):
+        c("a").fill_null(None)
+    with pytest.raises((TypeError, OverflowError)):
+        f.lazy().select(c("a").fill_null("zero").sum())._lower()
