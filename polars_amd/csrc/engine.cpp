@@ -429,7 +429,9 @@ class Compiler {
     if (x.kind == PLX_AE_LEN) { fs.kind = FIN_TRUNC32; fs.a = (uint8_t)add_agg(AGG_LEN, -1); fs.out_dtype = PLX_U32; return fs; }
     const int in_dt = infer_dtype(plan, x.lhs, *df);
     if (x.op == PLX_AGG_LEN) { fs.kind = FIN_TRUNC32; fs.a = (uint8_t)add_agg(AGG_LEN, -1); fs.out_dtype = PLX_U32; return fs; }
-    if (in_dt == PLX_BOOL && x.op != PLX_AGG_COUNT) throw Unsupported("aggregating a boolean expression");
+    // Boolean inputs: sum = number of true values (UInt32, sum_output_dtype) and mean = their fraction; a boolean slot holds 0 / 1,
+    // so both reuse the integer cells.  min / max of booleans would need a bit-packed finalisation: per-node path.
+    if (in_dt == PLX_BOOL && x.op != PLX_AGG_COUNT && x.op != PLX_AGG_SUM && x.op != PLX_AGG_MEAN) throw Unsupported("min / max of a boolean expression");
     int src = lower(x.lhs);
     switch (x.op) {
       case PLX_AGG_SUM:

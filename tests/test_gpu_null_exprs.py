@@ -31,3 +31,19 @@ def test_null_expressions_fused_and_per_node(pl):
         df.lazy().select(c("a").fill_null(0).sum()).collect(no_fusion=True)
     g = df.lazy().filter(c("a").is_null()).group_by("k").agg(pl.len().alias("nulls")).collect().sort_host("k")
     assert g["nulls"] == [int(((k == i) & ~am).sum()) for i in g["k"]]
+
+
+def test_boolean_sum_and_mean(pl):
+    rng = np.random.default_rng(10)
+    n = 200_000
+    a, am = rng.integers(-20, 20, n).astype(np.int64), rng.random(n) < 0.7
+    k = rng.integers(0, 6, n).astype(np.int64)
+    df = pl.DataFrame([pl.Series("a", a, validity=am), pl.Series("k", k)])
+    c = pl.col
+    g = df.lazy().group_by("k").agg(c("a").is_null().sum().alias("nulls"), (c("a") > 3).sum().alias("gt3"), (c("a") > 3).mean().alias("frac")).collect()
+    assert "FusedFilterGroupBy" in pl.last_plan() and g.schema["nulls"] == pl.UInt32 and g.schema["frac"] == pl.Float64
+    d = g.sort_host("k")
+    for i, kv in enumerate(d["k"]):
+        m = k == kv
+        assert d["nulls"][i] == int((m & ~am).sum()) and d["gt3"][i] == int((m & am & (a > 3)).sum())
+        assert np.isclose(d["frac"][i], (a > 3)[m & am].mean(), rtol=1e-12)

@@ -452,3 +452,25 @@ def test_is_null_is_not_null_fill_null():
         c("a").fill_null(None)
     with pytest.raises((TypeError, OverflowError)):
         f.lazy().select(c("a").fill_null("zero").sum())._lower()
+
+
+def test_boolean_sum_and_mean_in_fused_programs():
+    """sum / mean of a boolean expression (e.g. null counts per group: col.is_null().sum()) reuse the integer / float cells."""
+    rng = np.random.default_rng(10)
+    n = 30_000
+    a, am = rng.integers(-20, 20, n).astype(np.int64), rng.random(n) < 0.7
+    b, bm = rng.integers(0, 2, n).astype(bool), rng.random(n) < 0.85
+    k = rng.integers(0, 6, n).astype(np.int64)
+    cols = {"a": (a, am), "b": (b, bm), "k": (k, None)}
+    c = pl.col
+    lf = frame_like(cols).lazy().group_by("k").agg(c("a").is_null().sum().alias("nulls"), (c("a") > 3).sum().alias("gt3"), c("b").sum().alias("b_true"),
+                                                    c("b").mean().alias("b_frac"), (c("a") > 3).mean().alias("gt3_frac"))
+    prog = lf.debug_program()
+    assert [f["out_dtype"] for f in prog["finals"]][:3] == [pe.U32, pe.U32, pe.U32]
+    got = by_key(pe.evaluate(prog, cols), ["k"])
+    for kv, row in got.items():
+        m = k == kv[0]
+        assert row["nulls"] == int((m & ~am).sum()) and row["gt3"] == int((m & am & (a > 3)).sum()) and row["b_true"] == int((m & bm & b).sum())
+        assert close(row["b_frac"], float(b[m & bm].mean())) and close(row["gt3_frac"], float((a > 3)[m & am].mean()))
+    with pytest.raises(pl.UnsupportedError, match="min / max of a boolean"):
+        frame_like(cols).lazy().select(c("b").max()).debug_program()

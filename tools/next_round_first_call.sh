@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/first_call
 mkdir -p $OUT
 cd $R
 # 1. the tests marked non-strict xfail (generator kernels, parquet scan): run them for real
-timeout 120 python -m pytest tests/test_gpu_datagen.py tests/test_gpu_io.py --runxfail -q --timeout 100 > $OUT/unverified_tests.log 2>&1; echo "unverified tests exit $?" | tee -a $OUT/summary.txt
+timeout 120 python -m pytest tests/test_gpu_datagen.py tests/test_gpu_io.py tests/test_gpu_null_exprs.py --runxfail -q --timeout 100 > $OUT/unverified_tests.log 2>&1; echo "unverified tests exit $?" | tee -a $OUT/summary.txt
 # 2. the whole GPU suite
 timeout 300 python -m pytest tests -m gpu -q --timeout 120 --durations=8 > $OUT/pytest_gpu.log 2>&1; echo "gpu suite exit $?" | tee -a $OUT/summary.txt
 tail -4 $OUT/pytest_gpu.log
