@@ -474,3 +474,51 @@ def test_boolean_sum_and_mean_in_fused_programs():
         assert close(row["b_frac"], float(b[m & bm].mean())) and close(row["gt3_frac"], float((a > 3)[m & am].mean()))
     with pytest.raises(pl.UnsupportedError, match="min / max of a boolean"):
         frame_like(cols).lazy().select(c("b").max()).debug_program()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_group_by_shapes(orc, seed):
+    """Random key sets (dtypes, ranges up to the packing limits, nullability, 1-3 keys) and aggregates through lower_keys / lower_agg:
+    packed, wide and raw keys must all decode back to the oracle's groups."""
+    rng = np.random.default_rng(7000 + seed)
+    n = 8000
+    nk = int(rng.integers(1, 4))
+    keys = {}
+    for j in range(nk):
+        kind = int(rng.integers(0, 7))
+        card = int(rng.integers(2, 40))
+        if kind == 0: v = rng.integers(0, 2, n).astype(bool)
+        elif kind == 1: v = rng.integers(-card, card, n).astype(np.int8)
+        elif kind == 2: v = (rng.integers(0, card, n) * 1000 - 2 ** 31 + 5).astype(np.int32)                       # large negative offset
+        elif kind == 3: v = rng.integers(2 ** 62 - card, 2 ** 62, n).astype(np.int64)                             # near the top of the range
+        elif kind == 4: v = (rng.integers(0, card, n).astype(np.uint64) * np.uint64(2 ** 58)).astype(np.uint64)   # UInt64: never packed
+        elif kind == 5: v = rng.choice([0.0, -0.0, 1.25, -3.5, np.nan, np.inf], n)
+        else: v = rng.integers(-2 ** 40, 2 ** 40, card).astype(np.int64)[rng.integers(0, card, n)]                # sparse wide range
+        m = None if rng.random() < 0.5 else rng.random(n) < 0.85
+        keys[f"k{j}"] = (v, m)
+    val = rng.integers(-500, 500, n).astype(np.int64); vm = rng.random(n) < 0.9
+    x = rng.normal(size=n); xm = None
+    cols = dict(keys); cols.update({"v": (val, vm), "x": (x, xm)})
+    c = pl.col
+    lf = frame_like(cols, stats=bool(rng.integers(0, 2)) or True).lazy().group_by(*keys).agg(c("v").sum().alias("s"), c("v").min().alias("mn"), c("v").count().alias("cnt"),
+                                                                                                pl.len().alias("n"), c("x").mean().alias("xm"), c("x").max().alias("xx"))
+    try:
+        prog = lf.debug_program()
+    except pl.UnsupportedError as e:
+        assert "group keys" in str(e) or "fusable" in str(e), str(e)
+        return
+    got = by_key(pe.evaluate(prog, cols), list(keys))
+    A = orc
+    spec = [("s", A.AGG_SUM, val, vm), ("mn", A.AGG_MIN, val, vm), ("cnt", A.AGG_COUNT, val, vm), ("n", A.AGG_LEN, None, None), ("xm", A.AGG_MEAN, x, xm), ("xx", A.AGG_MAX, x, xm)]
+    kv = [np.ascontiguousarray(a.astype(np.uint8) if a.dtype == np.bool_ else a) for a, _ in keys.values()]
+    r = orc.q_groupby(kv, [m for _, m in keys.values()], spec)
+    named = {name: r[f"key_{i}"] for i, name in enumerate(keys)}
+    for name, (a, _) in keys.items():
+        if a.dtype == np.bool_:
+            named[name] = (named[name][0].astype(bool), named[name][1])
+    named.update({s[0]: r[s[0]] for s in spec})
+    want = by_key(named, list(keys))
+    assert set(got) == set(want), (seed, prog["key_plan"]["packed"], prog["key_plan"]["wide"], len(got), len(want))
+    for key, row in want.items():
+        for col, wv in row.items():
+            assert close(got[key][col], wv), (seed, key, col, got[key][col], wv)
