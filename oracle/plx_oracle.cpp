@@ -1022,3 +1022,94 @@ extern "C" int64_t orc_q1_streaming(const int64_t* shipdate, const uint8_t* flag
   }
   return G;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Full-size checkers for bench.py / tests (BASELINE configs 2, 3, 5 at 1e9 rows): the same queries as
+// pyoracle.q_filter_agg_cfg2 / q_groupby, executed the way the reference's streaming engine does -- morsels pulled by
+// worker threads, thread-local reduction state combined at the end (polars-stream/src/nodes/group_by.rs:140-250 local
+// phase, :252-497 combine_locals; reductions `+=` per group: polars-expr/src/reduce/sum.rs:15-112, mean.rs:82-132
+// keeps (f64 sum, count), count.rs:6-128) -- so a 1e9-row input is checked in seconds.  They return PARTIAL STATES
+// (sums and counts), which add across row blocks: the caller streams blocks of the host-twin generator through them.
+// ---------------------------------------------------------------------------------------------
+
+// filter(a > k).select((x*(1-y)).sum(), x.mean(), a.sum()): out = {sum_xy, sum_x} (f64), iout = {count_x_valid, sum_a (wrapping), rows_selected}
+extern "C" int orc_cfg2_partial(const int64_t* a, const double* x, const double* y, const uint8_t* x_valid, int64_t n, int64_t k, int64_t morsel,
+                                double* out, int64_t* iout) {
+  if (morsel <= 0) morsel = 100000;
+  const int nt = std::max(1, g_threads);
+  struct St { double sxy = 0, sx = 0; int64_t cx = 0, rows = 0; uint64_t sa = 0; };
+  std::vector<St> local((size_t)nt);
+  std::atomic<int64_t> next{0};
+  auto worker = [&](int tid) {
+    St& s = local[(size_t)tid];
+    std::vector<double> fx((size_t)morsel), fy((size_t)morsel), t1((size_t)morsel), pr((size_t)morsel);
+    std::vector<uint8_t> fv((size_t)morsel);
+    for (;;) {
+      const int64_t b = next.fetch_add(morsel);
+      if (b >= n) break;
+      const int64_t len = std::min<int64_t>(morsel, n - b);
+      int64_t m = 0;
+      for (int64_t i = 0; i < len; i++) {            // filter node: mask, then every column compacted
+        if (a[b + i] > k) { fx[m] = x[b + i]; fy[m] = y[b + i]; fv[m] = x_valid ? (uint8_t)getbit(x_valid, b + i) : 1; s.sa += (uint64_t)a[b + i]; m++; }
+      }
+      for (int64_t i = 0; i < m; i++) t1[i] = 1.0 - fy[i];        // one column per BinaryExpr node
+      for (int64_t i = 0; i < m; i++) pr[i] = fx[i] * t1[i];
+      for (int64_t i = 0; i < m; i++) if (fv[i]) { s.sxy += pr[i]; s.sx += fx[i]; s.cx++; }
+      s.rows += m;
+    }
+  };
+  if (nt == 1) worker(0);
+  else { std::vector<std::thread> ts; for (int t = 0; t < nt; t++) ts.emplace_back(worker, t); for (auto& t : ts) t.join(); }
+  St tot;
+  for (auto& s : local) { tot.sxy += s.sxy; tot.sx += s.sx; tot.cx += s.cx; tot.rows += s.rows; tot.sa += s.sa; }
+  out[0] = tot.sxy; out[1] = tot.sx;
+  iout[0] = tot.cx; iout[1] = (int64_t)tot.sa; iout[2] = tot.rows;
+  return 0;
+}
+
+// group_by(key).agg(v.sum(), v.count()) partial states for keys known to lie in [0, n_slots): thread-local tables indexed by
+// the key (the role of the per-thread Grouper + VecGroupedReduction), combined at the end.  key_dt: I64 | U32; val_dt: I64 | F64.
+// sums: int64 (wrapping) or double per slot, counts: rows per slot (all values valid); both are ADDED to (the caller zeroes them).
+// Returns 0, or 2 if a key falls outside [0, n_slots).
+extern "C" int orc_groupby_dense_partial(int key_dt, const void* keys, int val_dt, const void* vals, int64_t n, int64_t n_slots, int64_t morsel,
+                                         void* sums, int64_t* counts) {
+  if (morsel <= 0) morsel = 100000;
+  if ((key_dt != I64 && key_dt != U32) || (val_dt != I64 && val_dt != F64)) return 1;
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(g_threads, (n + morsel - 1) / morsel));
+  std::vector<std::vector<int64_t>> lcnt((size_t)nt);
+  std::vector<std::vector<uint64_t>> lsum((size_t)nt);   // int64 sums as wrapping u64, f64 sums as bit patterns of doubles
+  std::atomic<int64_t> next{0};
+  std::atomic<int> bad{0};
+  auto worker = [&](int tid) {
+    lcnt[(size_t)tid].assign((size_t)n_slots, 0);
+    lsum[(size_t)tid].assign((size_t)n_slots, 0);
+    int64_t* c = lcnt[(size_t)tid].data();
+    uint64_t* su = lsum[(size_t)tid].data();
+    double* sd = reinterpret_cast<double*>(su);
+    for (;;) {
+      const int64_t b = next.fetch_add(morsel);
+      if (b >= n) break;
+      const int64_t e = std::min<int64_t>(n, b + morsel);
+      for (int64_t i = b; i < e; i++) {
+        const int64_t key = key_dt == I64 ? ((const int64_t*)keys)[i] : (int64_t)((const uint32_t*)keys)[i];
+        if (key < 0 || key >= n_slots) { bad.store(1); continue; }
+        c[key]++;
+        if (val_dt == I64) su[key] += (uint64_t)((const int64_t*)vals)[i];
+        else sd[key] += ((const double*)vals)[i];
+      }
+    }
+  };
+  if (nt == 1) worker(0);
+  else { std::vector<std::thread> ts; for (int t = 0; t < nt; t++) ts.emplace_back(worker, t); for (auto& t : ts) t.join(); }
+  if (bad.load()) return 2;
+  parallel_ranges(n_slots, 64, [&](int64_t b, int64_t e, int) {
+    for (int64_t s = b; s < e; s++) {
+      for (int t = 0; t < nt; t++) {
+        counts[s] += lcnt[(size_t)t][(size_t)s];
+        if (val_dt == I64) ((uint64_t*)sums)[s] += lsum[(size_t)t][(size_t)s];
+        else ((double*)sums)[s] += reinterpret_cast<const double*>(lsum[(size_t)t].data())[s];
+      }
+    }
+  });
+  return 0;
+}

@@ -451,3 +451,60 @@ def q1_native(cols: Dict[str, np.ndarray], cutoff: int, streaming: bool = False,
     assert G >= 0
     order = np.lexsort((o["l_linestatus"][:G], o["l_returnflag"][:G]))
     return {k: v[:G][order] for k, v in o.items()}
+
+
+# ------------------------------------------ block-wise (partial-state) checkers for the full-size runs ----
+def cfg2_partial(a: np.ndarray, x: np.ndarray, y: np.ndarray, k: int, x_valid: Optional[np.ndarray] = None, morsel: int = 100_000) -> Dict[str, object]:
+    """Partial states of BASELINE config 2 over one row block (orc_cfg2_partial, multi-threaded): they ADD across blocks.
+    -> {"sum_xy", "sum_x", "count_x", "sum_a" (wrapping int64), "rows"}."""
+    out = np.zeros(2, np.float64)
+    iout = np.zeros(3, np.int64)
+    rc = lib().orc_cfg2_partial(_p(np.ascontiguousarray(a, np.int64)), _p(np.ascontiguousarray(x, np.float64)), _p(np.ascontiguousarray(y, np.float64)),
+                                _p(pack(x_valid)), C.c_int64(len(a)), C.c_int64(k), C.c_int64(morsel), _p(out), _p(iout))
+    assert rc == 0
+    return {"sum_xy": float(out[0]), "sum_x": float(out[1]), "count_x": int(iout[0]), "sum_a": int(iout[1]), "rows": int(iout[2])}
+
+
+def cfg2_combine(parts) -> Dict[str, object]:
+    """Block partials -> the query's result row (x_mean = sum / count, null when count == 0; a_sum wraps like Int64)."""
+    sxy = sum(p["sum_xy"] for p in parts); sx = sum(p["sum_x"] for p in parts); cx = sum(p["count_x"] for p in parts)
+    sa = sum(p["sum_a"] for p in parts)
+    sa = (sa + 2 ** 63) % 2 ** 64 - 2 ** 63
+    return {"xy": sxy, "x_mean": (sx / cx) if cx else None, "a_sum": sa, "rows": sum(p["rows"] for p in parts)}
+
+
+def groupby_dense_partial(keys: np.ndarray, vals: np.ndarray, sums: np.ndarray, counts: np.ndarray, morsel: int = 100_000) -> None:
+    """group_by(key).agg(v.sum(), v.count()) partial states of one row block, ADDED into sums[n_slots] (int64 or float64)
+    and counts[n_slots] (int64); keys (Int64 or UInt32) must lie in [0, n_slots) (orc_groupby_dense_partial)."""
+    keys, vals = np.ascontiguousarray(keys), np.ascontiguousarray(vals)
+    assert keys.dtype in (np.int64, np.uint32) and vals.dtype in (np.int64, np.float64) and sums.dtype == vals.dtype and counts.dtype == np.int64
+    rc = lib().orc_groupby_dense_partial(_dt(keys), _p(keys), _dt(vals), _p(vals), C.c_int64(len(keys)), C.c_int64(len(sums)), C.c_int64(morsel), _p(sums), _p(counts))
+    assert rc == 0, f"orc_groupby_dense_partial rc={rc}"
+
+
+Q1_SUMS = ("sum_qty", "sum_base_price", "sum_disc_price", "sum_charge", "count_order")
+
+
+def q1_combine(parts) -> Dict[str, np.ndarray]:
+    """Q1 results of disjoint row blocks (q1 / q1_native layout) -> the result over their union: sums and counts add,
+    the averages are recombined from (avg x count) -- the partial / final split of reduce/mean.rs:82-132."""
+    acc: Dict[Tuple[int, int], Dict[str, float]] = {}
+    for p in parts:
+        for i in range(len(p["l_returnflag"])):
+            m = acc.setdefault((int(p["l_returnflag"][i]), int(p["l_linestatus"][i])), {k: 0 for k in Q1_SUMS} | {"_disc": 0.0})
+            c = int(p["count_order"][i])
+            m["sum_qty"] += int(p["sum_qty"][i]); m["count_order"] += c
+            for k in ("sum_base_price", "sum_disc_price", "sum_charge"):
+                m[k] += float(p[k][i])
+            m["_disc"] += float(p["avg_disc"][i]) * c
+    ks = sorted(acc)
+    out = {"l_returnflag": np.array([k[0] for k in ks], np.uint8), "l_linestatus": np.array([k[1] for k in ks], np.uint8)}
+    for k in ("sum_qty", "count_order"):
+        out[k] = np.array([acc[g][k] for g in ks], np.int64)
+    for k in ("sum_base_price", "sum_disc_price", "sum_charge"):
+        out[k] = np.array([acc[g][k] for g in ks], np.float64)
+    cnt = out["count_order"].astype(np.float64)
+    out["avg_qty"] = out["sum_qty"].astype(np.float64) / cnt
+    out["avg_price"] = out["sum_base_price"] / cnt
+    out["avg_disc"] = np.array([acc[g]["_disc"] for g in ks], np.float64) / cnt
+    return out

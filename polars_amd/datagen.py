@@ -203,6 +203,71 @@ def uniform_native(pl, name: str, dtype, n: int, seed: int, stream: int, lo: int
     return pl.Series._from_handle(name, h.value, dtype)
 
 
+# ---- multi-threaded host twins (ctypes releases the GIL): full-size checks in bench.py / tests -------------------------
+def _host_threads(threads=None) -> int:
+    import os
+    return max(1, int(threads or min(64, os.cpu_count() or 1)))
+
+
+def _split(n: int, parts: int, align: int = 1):
+    per = max(align, -(-n // max(1, parts)))
+    per = -(-per // align) * align
+    return [(b, min(per, n - b)) for b in range(0, n, per)]
+
+
+def lineitem_native_host_mt(row0: int, n: int, seed: int = 10, threads=None) -> Dict[str, np.ndarray]:
+    """lineitem_native_host evaluated by `threads` host threads writing disjoint slices of the same arrays."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    from . import _ffi as F
+    out = {"l_shipdate": np.empty(n, np.int64), "l_returnflag": np.empty(n, np.uint8), "l_linestatus": np.empty(n, np.uint8),
+           "l_quantity": np.empty(n, np.int64), "l_extendedprice": np.empty(n, np.float64), "l_discount": np.empty(n, np.float64),
+           "l_tax": np.empty(n, np.float64)}
+    lib = F.lib()
+
+    def work(bl):
+        b, m = bl
+        ptrs = [C.c_void_p(out[c].ctypes.data + b * out[c].itemsize) for c in LINEITEM_Q1_COLS]
+        F.check(lib.plx_datagen_lineitem_q1_host(row0 + b, m, seed, *ptrs))
+    nt = _host_threads(threads)
+    with ThreadPoolExecutor(nt) as ex:
+        list(ex.map(work, _split(n, nt * 4, 4096)))
+    return out
+
+
+def uniform_native_host_mt(dtype_name: str, row0: int, n: int, seed: int, stream: int, lo: int, hi: int, scale: float = 1.0, threads=None) -> np.ndarray:
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    from . import _ffi as F
+    phys = {"Int64": F.I64, "UInt32": F.U32, "Float64": F.F64}[dtype_name]
+    out = np.empty(n, _NP_OF[dtype_name])
+    lib = F.lib()
+
+    def work(bl):
+        b, m = bl
+        F.check(lib.plx_datagen_uniform_host(phys, row0 + b, m, seed, stream, lo, hi, scale, C.c_void_p(out.ctypes.data + b * out.itemsize)))
+    nt = _host_threads(threads)
+    with ThreadPoolExecutor(nt) as ex:
+        list(ex.map(work, _split(n, nt * 4, 4096)))
+    return out
+
+
+def orders_lineitem_native_host_mt(order0: int, n: int, n_orders_total: int, seed: int = 10, threads=None):
+    """orders_lineitem_native_host over sub-blocks of orders in parallel, concatenated in order: (orders, lineitem, n_lines)."""
+    from concurrent.futures import ThreadPoolExecutor
+    nt = _host_threads(threads)
+    blocks = _split(n, nt * 2, 1024)
+    with ThreadPoolExecutor(nt) as ex:
+        parts = list(ex.map(lambda bl: orders_lineitem_native_host(order0 + bl[0], bl[1], n_orders_total, seed), blocks))
+    if not parts:
+        return orders_lineitem_native_host(order0, 0, n_orders_total, seed)
+    o = {k: np.concatenate([p[0][k] for p in parts]) for k in parts[0][0]}
+    li = {k: np.concatenate([p[1][k] for p in parts]) for k in parts[0][1]}
+    return o, li, np.concatenate([p[2] for p in parts])
+
+
 # ------------------------------------------------------------------------ torch ----
 def _line_columns_device(torch, g, shipdate):
     n = shipdate.numel()

@@ -1,0 +1,92 @@
+"""bench.py's checks of the timed results (`verified`), exercised without a GPU: a stand-in "library result" computed with
+plain numpy from the generators' host twins must pass, the same result with one perturbed cell must fail.  The checks
+themselves compare against the CPU oracle (oracle/pyoracle.py) evaluated block by block over the host twin."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from polars_amd import datagen  # noqa: E402
+
+
+class Col:
+    def __init__(self, a): self.a = np.asarray(a)
+    def to_numpy(self): return self.a
+
+
+class Frame(dict):
+    def __getitem__(self, k): return Col(dict.__getitem__(self, k))
+    def raw(self, k): return dict.__getitem__(self, k)
+
+
+def test_q1_blocks_match_single_pass_and_detect_corruption():
+    from oracle import pyoracle as orc
+    orc.set_threads(4)
+    n, seed = 300_000, 10
+    want, done, t, first = bench.q1_oracle_blocks(n, seed, budget_s=60, block=70_000)     # 5 blocks, ragged tail
+    assert done == n and t > 0 and len(first["l_shipdate"]) == 70_000
+    cols = datagen.lineitem_native_host(0, n, seed)
+    one = orc.q1({k: cols[k] for k in datagen.LINEITEM_Q1_COLS}, datagen.us(1998, 9, 2))
+    got = {k: one[k].tolist() for k in one}
+    got["l_returnflag"] = [datagen.FLAGS[c] for c in got["l_returnflag"]]               # the library returns categories
+    got["l_linestatus"] = [datagen.STATUS[c] for c in got["l_linestatus"]]
+    v = bench.compare_q1(got, want)
+    assert v["ok"] and v["max_rel_err"] < 1e-9, v
+    bad = dict(got); bad["sum_qty"] = list(got["sum_qty"]); bad["sum_qty"][0] += 1
+    assert not bench.compare_q1(bad, want)["ok"]
+    bad = dict(got); bad["sum_charge"] = [x * (1 + 3e-6) for x in got["sum_charge"]]
+    assert not bench.compare_q1(bad, want)["ok"]
+    # the baseline leg on the same rows: returns the verification with it
+    base, ver = bench.cpu_baseline_q1(1.0, rows=n, seed=seed, gpu_result=got)
+    assert ver["ok"] and ver["rows"] == n and base["kind"] in ("port", "reference") and "SAME rows" in base["sample"]
+
+
+def test_cfg2_check():
+    n, seed = 250_000, 20
+    a = datagen.uniform_native_host("Int64", 0, n, seed, 0, 0, 2 ** 31)
+    x = datagen.uniform_native_host("Float64", 0, n, seed, 1, 0, 10 ** 9, 1e-7)
+    y = datagen.uniform_native_host("Float64", 0, n, seed, 2, 0, 10 ** 9, 1e-9)
+    m = a > 2 ** 30
+    got = {"xy": [float((x[m] * (1 - y[m])).sum())], "x_mean": [float(x[m].mean())], "a_sum": [int(a[m].sum())]}
+    v = bench.verify_cfg2(got, n, seed, 60, block=100_000)
+    assert v["ok"] and v["rows"] == n, v
+    got["a_sum"][0] += 1
+    assert bench.verify_cfg2(got, n, seed, 60, block=100_000)["ok"] is False
+    assert bench.verify_cfg2(got, n, seed, 0.0)["ok"] is None          # no budget: reported as not covered, never as passed
+
+
+def test_groupby_checks_cfg3_cfg5():
+    n, seed, nk = 400_000, 20, 1000
+    key = datagen.uniform_native_host("Int64", 0, n, seed, 0, 0, nk)
+    v = datagen.uniform_native_host("Int64", 0, n, seed, 1, 0, 1000)
+    perm = np.random.default_rng(0).permutation(nk)                    # the library's group order is arbitrary
+    f = Frame(key=np.arange(nk)[perm], v_sum=np.bincount(key, weights=v, minlength=nk).astype(np.int64)[perm], v_count=np.bincount(key, minlength=nk).astype(np.uint32)[perm])
+    r = bench.verify_groupby_dense(f, "key", "v_sum", n, seed, nk, "Int64", "Int64", (0, 1000), ("count", "v_count"), 60, block=150_000)
+    assert r["ok"] and r["groups"] == nk, r
+    f.raw("v_sum")[3] += 1
+    assert bench.verify_groupby_dense(f, "key", "v_sum", n, seed, nk, "Int64", "Int64", (0, 1000), ("count", "v_count"), 60, block=150_000)["ok"] is False
+    codes = datagen.uniform_native_host("UInt32", 0, n, seed, 0, 0, nk)
+    w = datagen.uniform_native_host("Float64", 0, n, seed, 1, 0, 10 ** 9, 1e-7)
+    s, c = np.bincount(codes, weights=w, minlength=nk), np.bincount(codes, minlength=nk)
+    f = Frame(k=np.arange(nk, dtype=np.uint32)[perm], v_sum=s[perm], v_mean=(s / c)[perm])
+    r = bench.verify_groupby_dense(f, "k", "v_sum", n, seed, nk, "UInt32", "Float64", (0, 10 ** 9, 1e-7), ("mean", "v_mean"), 60, block=150_000)
+    assert r["ok"], r
+    f.raw("v_mean")[5] *= 1.00001
+    assert bench.verify_groupby_dense(f, "k", "v_sum", n, seed, nk, "UInt32", "Float64", (0, 10 ** 9, 1e-7), ("mean", "v_mean"), 60, block=150_000)["ok"] is False
+
+
+def test_q3_check():
+    from oracle import pyoracle as orc
+    orc.set_threads(4)
+    no, seed = 60_000, 20
+    o, li, cnt = datagen.orders_lineitem_native_host(0, no, no, seed)
+    o["o_shippriority"] = np.zeros(no, np.int64)
+    w = orc.q3({k: li[k] for k in datagen.LINEITEM_Q3_COLS}, {k: o[k] for k in datagen.ORDERS_Q3_COLS}, datagen.us(1995, 3, 15))
+    perm = np.random.default_rng(1).permutation(len(w["l_orderkey"]))
+    f = Frame({k: w[k][perm] for k in w})
+    r = bench.verify_q3(f, no, seed, 60, block=25_000, oracle_orders=20_000)
+    assert r["ok"] and r["covers_whole_input"] and r["groups_checked"] == len(perm) and r["rows"] == no + len(li["l_orderkey"]), r
+    f.raw("revenue")[0] *= 1.001
+    assert bench.verify_q3(f, no, seed, 60, block=25_000, oracle_orders=20_000)["ok"] is False
