@@ -52,8 +52,13 @@
  *   plx_profile_*
  *       crates/polars-expr/src/state/node_timer.rs:14-70 (NodeTimer)
  *
- * Threading: every call is thread-safe.  Errors never unwind across the ABI;
- * a non-zero status means `plx_last_error()` (thread-local) holds the message.
+ * Threading: every call is thread-safe (the reference calls plugins from rayon workers,
+ * crates/polars-ffi/src/version_0.rs:136-162).  A thread that wants its own HIP stream installs it
+ * with plx_set_stream; device buffers recycled by the library's pool between threads are ordered
+ * behind the releasing stream (event recorded at release, waited for on re-use).  A column handed
+ * to another thread must only be used there after the producing thread synchronised
+ * (plx_synchronize) -- the same rule a SeriesExport hand-over obeys.  Errors never unwind across
+ * the ABI; a non-zero status means `plx_last_error()` (thread-local) holds the message.
  */
 #ifndef POLARS_AMD_H
 #define POLARS_AMD_H
@@ -437,6 +442,34 @@ int plx_profile_enable(int on);
 /* Resolves pending events (synchronises), copies up to cap records, returns count in *n. */
 int plx_profile_fetch(plx_profile_record* out, int32_t cap, int32_t* n);
 int plx_profile_clear(void);
+
+/* ---- the reference's expression-plugin entry points ------------------------------------
+ * What an UNMODIFIED Polars dlopens (crates/polars-plan/src/plans/aexpr/function_expr/plugin.rs:23-137
+ * call_plugin, :139-227 plugin_field; normally generated by pyo3-polars-derive/src/lib.rs:140-163):
+ *   _polars_plugin_get_version()                 (major << 16) | minor, here (0, 1)   [pyo3-polars derive.rs:56-66]
+ *   _polars_plugin_get_last_error_message()      thread-local C string of the last failure   [derive.rs:26-45]
+ *   _polars_plugin_<name>(inputs, n, kwargs, kwargs_len, out, ctx)
+ *       inputs: n SeriesExport values (crates/polars-ffi/src/version_0.rs:7-16) the CALLEE takes ownership of and
+ *       releases (plugin.rs:122-125); out: written on success, out->private_data == NULL on failure; kwargs: pickled
+ *       dict (only the key "op" is read); ctx: CallerContext (version_0.rs:136-162), bit 0 = the caller is already
+ *       parallel -> the call runs on a HIP stream private to the calling thread.  A length-1 input is a broadcast literal.
+ *   _polars_plugin_field_<name>(fields, n, out, kwargs, kwargs_len)   output field (minor 1 signature, plugin.rs:186-207)
+ * Functions: plx_cmp / plx_arith (kwargs {"op": "gt" | ... | "add" | ...}) and one symbol per operator for callers
+ * without kwargs: plx_eq ne lt le gt ge, plx_add sub mul truediv floordiv mod, plx_filter(values, mask),
+ * plx_sum mean min max (length-1 result).  Python side: polars.plugins.register_plugin_function(
+ *     plugin_path=".../libpolars_amd.so", function_name="plx_gt", args=[pl.col("a"), pl.lit(3)]).           */
+typedef struct plx_caller_context { uint64_t bitflags; } plx_caller_context;
+uint32_t _polars_plugin_get_version(void);
+char* _polars_plugin_get_last_error_message(void);
+#define PLX_DECLARE_PLUGIN(name)                                                                                            \
+  void _polars_plugin_##name(const plx_series_export* inputs, size_t n_inputs, const uint8_t* kwargs, size_t kwargs_len,    \
+                             plx_series_export* out, const void* ctx);                                                      \
+  void _polars_plugin_field_##name(const struct ArrowSchema* fields, size_t n_fields, struct ArrowSchema* out,              \
+                                   const uint8_t* kwargs, size_t kwargs_len);
+PLX_DECLARE_PLUGIN(plx_cmp) PLX_DECLARE_PLUGIN(plx_arith) PLX_DECLARE_PLUGIN(plx_filter)
+PLX_DECLARE_PLUGIN(plx_eq) PLX_DECLARE_PLUGIN(plx_ne) PLX_DECLARE_PLUGIN(plx_lt) PLX_DECLARE_PLUGIN(plx_le) PLX_DECLARE_PLUGIN(plx_gt) PLX_DECLARE_PLUGIN(plx_ge)
+PLX_DECLARE_PLUGIN(plx_add) PLX_DECLARE_PLUGIN(plx_sub) PLX_DECLARE_PLUGIN(plx_mul) PLX_DECLARE_PLUGIN(plx_truediv) PLX_DECLARE_PLUGIN(plx_floordiv) PLX_DECLARE_PLUGIN(plx_mod)
+PLX_DECLARE_PLUGIN(plx_sum) PLX_DECLARE_PLUGIN(plx_mean) PLX_DECLARE_PLUGIN(plx_min) PLX_DECLARE_PLUGIN(plx_max)
 
 #ifdef __cplusplus
 }

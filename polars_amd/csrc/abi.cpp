@@ -419,6 +419,213 @@ int plx_frame_to_host(plx_frame f, void* const* values_out, uint8_t* const* vali
   PLX_CATCH
 }
 
+// ---- the reference's expression-plugin ABI -----------------------------------------------------
+// An UNMODIFIED Polars can dlopen this library as an expression plugin: its loader resolves
+//   _polars_plugin_get_version, _polars_plugin_get_last_error_message, _polars_plugin_<name>, _polars_plugin_field_<name>
+// (crates/polars-plan/src/plans/aexpr/function_expr/plugin.rs:23-137,139-227; the plugin side is normally generated by
+// pyo3-polars-derive/src/lib.rs:140-163).  Convention restated here: the callee takes ownership of the input SeriesExports
+// and calls their release (plugin.rs:122-125); the output is written to *out, a null out->private_data means failure and the
+// caller then fetches the thread-local message; kwargs are a pickled dict (serde-pickle) -- the only key read here is "op".
+// CallerContext bit 0 = the caller is already parallel (version_0.rs:136-162): such calls come from rayon workers at the same
+// time, so each of those threads gets its own HIP stream (no host threads are ever spawned here).
+extern "C++" {
+namespace {
+thread_local std::string t_plugin_error;
+struct PluginCtx { uint64_t bitflags; };
+
+hipStream_t plugin_thread_stream() {
+  static thread_local hipStream_t s = nullptr;
+  if (!s) PLX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return s;
+}
+// value of a string-valued key in a pickled {str: str} dict: scans SHORT_BINUNICODE (0x8c), BINUNICODE ('X') and
+// SHORT_BINSTRING ('U') tokens, which is how every pickle protocol >= 2 writes short str items
+std::string pickle_str_value(const uint8_t* kw, size_t n, const char* key) {
+  std::vector<std::string> toks;
+  for (size_t i = 0; i < n;) {
+    const uint8_t c = kw[i];
+    size_t len = 0, hdr = 0;
+    if ((c == 0x8c || c == 'U') && i + 1 < n) { len = kw[i + 1]; hdr = 2; }
+    else if (c == 'X' && i + 4 < n) { len = (size_t)kw[i + 1] | ((size_t)kw[i + 2] << 8) | ((size_t)kw[i + 3] << 16) | ((size_t)kw[i + 4] << 24); hdr = 5; }
+    if (hdr && i + hdr + len <= n) { toks.emplace_back((const char*)kw + i + hdr, len); i += hdr + len; }
+    else i++;
+  }
+  for (size_t i = 0; i + 1 < toks.size(); i++) if (toks[i] == key) return toks[i + 1];
+  return "";
+}
+// a length-1 input is a literal (Polars broadcasts it): read it on the host instead of uploading it
+bool series_scalar(const plx_series_export& s, int dt, plx_scalar* out, bool* valid) {
+  int64_t total = 0; const ArrowArray* one = nullptr;
+  for (size_t i = 0; i < s.len; i++) { total += s.arrays[i]->length; if (s.arrays[i]->length) one = s.arrays[i]; }
+  if (total != 1 || !one || one->n_buffers < 2) return false;
+  const uint8_t* vb = (const uint8_t*)one->buffers[0];
+  *valid = one->null_count == 0 || !vb || ((vb[one->offset >> 3] >> (one->offset & 7)) & 1);
+  out->u = 0;
+  const uint8_t* p = (const uint8_t*)one->buffers[1];
+  if (!*valid || !p) return true;
+  if (dt == PLX_BOOL) { out->u = (p[one->offset >> 3] >> (one->offset & 7)) & 1; return true; }
+  const int w = dtype_width(dt);
+  p += (size_t)one->offset * w;
+  switch (dt) {
+    case PLX_I8: out->i = *(const int8_t*)p; break;
+    case PLX_I16: { int16_t v; memcpy(&v, p, 2); out->i = v; } break;
+    case PLX_I32: { int32_t v; memcpy(&v, p, 4); out->i = v; } break;
+    case PLX_F32: memcpy(&out->f32, p, 4); break;
+    default: memcpy(&out->u, p, (size_t)w); break;
+  }
+  return true;
+}
+struct PluginInput { ColumnPtr col; bool is_scalar = false; plx_scalar scalar{}; bool scalar_valid = true; int dtype = 0; std::string name; };
+
+// takes ownership of every input (also on failure), runs body(inputs) -> column, exports it under the first input's name
+template <class Body>
+void plugin_call(const plx_series_export* inputs, size_t n, plx_series_export* out, const void* ctx, size_t want_inputs, Body body) {
+  std::vector<plx_series_export> own;
+  for (size_t i = 0; i < n; i++) own.push_back(inputs[i]);        // moved out of the caller's slice (the caller forgets it)
+  auto release_all = [&] { for (auto& s : own) if (s.release) s.release(&s); };
+  hipStream_t prev = nullptr; bool switched = false;
+  try {
+    PLX_REQUIRE(out, PLX_ERR_INVALID, "null output SeriesExport");
+    PLX_REQUIRE(n == want_inputs, PLX_ERR_INVALID, "expected " + std::to_string(want_inputs) + " input series, got " + std::to_string(n));
+    device();
+    if (ctx && (reinterpret_cast<const PluginCtx*>(ctx)->bitflags & 1)) { prev = stream(); set_thread_stream(plugin_thread_stream()); switched = true; }
+    std::vector<PluginInput> in(n);
+    for (size_t i = 0; i < n; i++) {
+      plx_series_export& s = own[i];
+      PLX_REQUIRE(s.field, PLX_ERR_INVALID, "input series without a field");
+      in[i].dtype = dtype_from_format(s.field->format);
+      in[i].name = s.field->name ? s.field->name : "";
+      if (in[i].dtype < 0) fail(PLX_ERR_UNSUPPORTED, std::string("plugin input: unsupported Arrow format '") + (s.field->format ? s.field->format : "") + "'");
+      if (n > 1 && series_scalar(s, in[i].dtype, &in[i].scalar, &in[i].scalar_valid)) in[i].is_scalar = true;
+      if (i + 1 == n && n > 1) { bool all = true; for (size_t j = 0; j < n; j++) all = all && in[j].is_scalar; if (all) { in[0].is_scalar = false; if (!in[0].col) {
+        std::vector<ColumnPtr> ch0; for (size_t c = 0; c < own[0].len; c++) ch0.push_back(import_one(own[0].arrays[c], in[0].dtype)); in[0].col = ops::concat(ch0); } } }
+      if (!in[i].is_scalar) {
+        std::vector<ColumnPtr> chunks;
+        for (size_t c = 0; c < s.len; c++) chunks.push_back(import_one(s.arrays[c], in[i].dtype));
+        in[i].col = chunks.empty() ? column_from_host(in[i].dtype, nullptr, nullptr, 0, 0) : ops::concat(chunks);
+        in[i].is_scalar = false;
+      }
+    }
+    release_all();                                                // host buffers are no longer referenced (uploads synchronise)
+    ColumnPtr res = body(in);
+    plx_series_export tmp{};
+    tmp.field = new ArrowSchema();
+    tmp.arrays = new ArrowArray*[1];
+    tmp.arrays[0] = new ArrowArray();
+    tmp.len = 1;
+    fill_export(res, in[0].name.c_str(), tmp.arrays[0], tmp.field);
+    tmp.release = release_series;
+    tmp.private_data = tmp.arrays;
+    *out = tmp;
+    if (switched) set_thread_stream(prev == device().own_stream ? nullptr : prev);
+    return;
+  } catch (const plx::Error& e) { t_plugin_error = e.msg; }
+  catch (const std::exception& e) { t_plugin_error = std::string("PANIC: ") + e.what(); }
+  catch (...) { t_plugin_error = "PANIC"; }
+  release_all();
+  if (switched) { try { set_thread_stream(prev == device().own_stream ? nullptr : prev); } catch (...) {} }
+  if (out) out->private_data = nullptr;
+}
+int cmp_op_of(const std::string& s) {
+  static const char* n[] = {"eq", "ne", "lt", "le", "gt", "ge"};
+  for (int i = 0; i < 6; i++) if (s == n[i]) return i;
+  return -1;
+}
+int arith_op_of(const std::string& s) {
+  static const char* n[] = {"add", "sub", "mul", "truediv", "floordiv", "mod"};
+  for (int i = 0; i < 6; i++) if (s == n[i]) return i;
+  return -1;
+}
+ColumnPtr plugin_cmp(int op, std::vector<PluginInput>& in) {
+  PLX_REQUIRE(op >= 0, PLX_ERR_INVALID, "plx_cmp: kwargs must carry op in {eq, ne, lt, le, gt, ge}");
+  PLX_REQUIRE(in[0].dtype == in[1].dtype, PLX_ERR_INVALID, "plx_cmp: operands differ in dtype (type coercion happens in the optimizer)");
+  static const int flip[] = {PLX_EQ, PLX_NE, PLX_GT, PLX_GE, PLX_LT, PLX_LE};
+  if (in[1].is_scalar) return ops::cmp_scalar(op, in[0].col, in[1].scalar, !in[1].scalar_valid);
+  if (in[0].is_scalar) return ops::cmp_scalar(flip[op], in[1].col, in[0].scalar, !in[0].scalar_valid);
+  return ops::cmp(op, in[0].col, in[1].col);
+}
+ColumnPtr plugin_arith(int op, std::vector<PluginInput>& in) {
+  PLX_REQUIRE(op >= 0, PLX_ERR_INVALID, "plx_arith: kwargs must carry op in {add, sub, mul, truediv, floordiv, mod}");
+  PLX_REQUIRE(in[0].dtype == in[1].dtype, PLX_ERR_INVALID, "plx_arith: operands differ in dtype (type coercion happens in the optimizer)");
+  auto null_like = [&](const ColumnPtr& c) { const int odt = (op == PLX_TRUE_DIV && dtype_is_int(c->dtype)) ? PLX_F64 : c->dtype; plx_scalar z; z.u = 0; return ops::full_column(odt, z, false, c->len); };
+  if (in[1].is_scalar) return in[1].scalar_valid ? ops::arith_scalar(op, in[0].col, in[1].scalar, false) : null_like(in[0].col);
+  if (in[0].is_scalar) return in[0].scalar_valid ? ops::arith_scalar(op, in[1].col, in[0].scalar, true) : null_like(in[1].col);
+  return ops::arith(op, in[0].col, in[1].col);
+}
+ColumnPtr plugin_reduce(int agg, std::vector<PluginInput>& in) { return ops::scalar_column(ops::reduce(agg, in[0].col)); }
+
+// output field of a plugin function: name of the first input, dtype by the rule of the operator
+enum FieldRule { FIELD_BOOL, FIELD_SAME, FIELD_ARITH, FIELD_SUM, FIELD_MEAN };
+void plugin_field(const ArrowSchema* fields, size_t n, ArrowSchema* out, FieldRule rule, int arith_op) {
+  try {
+    PLX_REQUIRE(fields && n >= 1 && out, PLX_ERR_INVALID, "plugin field: bad arguments");
+    const int dt = dtype_from_format(fields[0].format);
+    if (dt < 0) fail(PLX_ERR_UNSUPPORTED, std::string("plugin field: unsupported Arrow format '") + (fields[0].format ? fields[0].format : "") + "'");
+    int odt = dt;
+    switch (rule) {
+      case FIELD_BOOL: odt = PLX_BOOL; break;
+      case FIELD_SAME: break;
+      case FIELD_ARITH: odt = (arith_op == PLX_TRUE_DIV && dtype_is_int(dt)) ? PLX_F64 : dt; break;
+      case FIELD_SUM: odt = (dt == PLX_I8 || dt == PLX_I16 || dt == PLX_U8 || dt == PLX_U16) ? PLX_I64 : (dt == PLX_BOOL ? PLX_U32 : dt); break;   // sum_output_dtype, aggregate/mod.rs:55-64
+      case FIELD_MEAN: odt = dt == PLX_F32 ? PLX_F32 : PLX_F64; break;
+    }
+    memset(out, 0, sizeof(*out));
+    auto* nm = new std::string(fields[0].name ? fields[0].name : "");
+    // temporal formats keep their logical type when the physical type is unchanged
+    const bool keep = (rule == FIELD_SAME) && fields[0].format && fields[0].format[0] == 't';
+    auto* fmt = new std::string(keep ? fields[0].format : format_of_dtype(odt));
+    struct Holder { std::string* name; std::string* fmt; };
+    out->format = fmt->c_str(); out->name = nm->c_str(); out->flags = 2;
+    out->private_data = new Holder{nm, fmt};
+    out->release = [](ArrowSchema* s) { if (!s || !s->release) return; auto* h = (Holder*)s->private_data; delete h->name; delete h->fmt; delete h; s->release = nullptr; };
+    return;
+  } catch (const plx::Error& e) { t_plugin_error = e.msg; }
+  catch (...) { t_plugin_error = "PANIC"; }
+  if (out) out->release = nullptr;     // ArrowSchema::is_null(): no release callback = failure
+}
+}  // namespace
+}  // extern "C++"
+
+uint32_t _polars_plugin_get_version(void) { return ((uint32_t)PLX_ABI_MAJOR << 16) | (uint32_t)PLX_ABI_MINOR; }
+char* _polars_plugin_get_last_error_message(void) { return const_cast<char*>(t_plugin_error.c_str()); }
+
+#define PLX_PLUGIN_SIG const plx_series_export* inputs, size_t n_inputs, const uint8_t* kwargs, size_t kwargs_len, plx_series_export* out, const void* ctx
+#define PLX_FIELD_SIG const struct ArrowSchema* fields, size_t n_fields, struct ArrowSchema* out, const uint8_t* kwargs, size_t kwargs_len
+void _polars_plugin_plx_cmp(PLX_PLUGIN_SIG) {
+  const int op = cmp_op_of(pickle_str_value(kwargs, kwargs_len, "op"));
+  plugin_call(inputs, n_inputs, out, ctx, 2, [&](std::vector<PluginInput>& in) { return plugin_cmp(op, in); });
+}
+void _polars_plugin_field_plx_cmp(PLX_FIELD_SIG) { (void)kwargs; (void)kwargs_len; plugin_field(fields, n_fields, out, FIELD_BOOL, 0); }
+void _polars_plugin_plx_arith(PLX_PLUGIN_SIG) {
+  const int op = arith_op_of(pickle_str_value(kwargs, kwargs_len, "op"));
+  plugin_call(inputs, n_inputs, out, ctx, 2, [&](std::vector<PluginInput>& in) { return plugin_arith(op, in); });
+}
+void _polars_plugin_field_plx_arith(PLX_FIELD_SIG) { plugin_field(fields, n_fields, out, FIELD_ARITH, arith_op_of(pickle_str_value(kwargs, kwargs_len, "op"))); }
+// one symbol per operator as well, for callers that pass no kwargs
+#define PLX_PLUGIN_CMP(NAME, OP)                                                                                                                  \
+  void _polars_plugin_plx_##NAME(PLX_PLUGIN_SIG) { (void)kwargs; (void)kwargs_len; plugin_call(inputs, n_inputs, out, ctx, 2, [&](std::vector<PluginInput>& in) { return plugin_cmp(OP, in); }); } \
+  void _polars_plugin_field_plx_##NAME(PLX_FIELD_SIG) { (void)kwargs; (void)kwargs_len; plugin_field(fields, n_fields, out, FIELD_BOOL, 0); }
+#define PLX_PLUGIN_ARITH(NAME, OP)                                                                                                                \
+  void _polars_plugin_plx_##NAME(PLX_PLUGIN_SIG) { (void)kwargs; (void)kwargs_len; plugin_call(inputs, n_inputs, out, ctx, 2, [&](std::vector<PluginInput>& in) { return plugin_arith(OP, in); }); } \
+  void _polars_plugin_field_plx_##NAME(PLX_FIELD_SIG) { (void)kwargs; (void)kwargs_len; plugin_field(fields, n_fields, out, FIELD_ARITH, OP); }
+#define PLX_PLUGIN_REDUCE(NAME, AGG, RULE)                                                                                                        \
+  void _polars_plugin_plx_##NAME(PLX_PLUGIN_SIG) { (void)kwargs; (void)kwargs_len; plugin_call(inputs, n_inputs, out, ctx, 1, [&](std::vector<PluginInput>& in) { return plugin_reduce(AGG, in); }); } \
+  void _polars_plugin_field_plx_##NAME(PLX_FIELD_SIG) { (void)kwargs; (void)kwargs_len; plugin_field(fields, n_fields, out, RULE, 0); }
+PLX_PLUGIN_CMP(eq, PLX_EQ) PLX_PLUGIN_CMP(ne, PLX_NE) PLX_PLUGIN_CMP(lt, PLX_LT) PLX_PLUGIN_CMP(le, PLX_LE) PLX_PLUGIN_CMP(gt, PLX_GT) PLX_PLUGIN_CMP(ge, PLX_GE)
+PLX_PLUGIN_ARITH(add, PLX_ADD) PLX_PLUGIN_ARITH(sub, PLX_SUB) PLX_PLUGIN_ARITH(mul, PLX_MUL) PLX_PLUGIN_ARITH(truediv, PLX_TRUE_DIV)
+PLX_PLUGIN_ARITH(floordiv, PLX_FLOOR_DIV) PLX_PLUGIN_ARITH(mod, PLX_MOD)
+PLX_PLUGIN_REDUCE(sum, PLX_AGG_SUM, FIELD_SUM) PLX_PLUGIN_REDUCE(mean, PLX_AGG_MEAN, FIELD_MEAN) PLX_PLUGIN_REDUCE(min, PLX_AGG_MIN, FIELD_SAME) PLX_PLUGIN_REDUCE(max, PLX_AGG_MAX, FIELD_SAME)
+void _polars_plugin_plx_filter(PLX_PLUGIN_SIG) {
+  (void)kwargs; (void)kwargs_len;
+  plugin_call(inputs, n_inputs, out, ctx, 2, [&](std::vector<PluginInput>& in) {
+    PLX_REQUIRE(in[1].dtype == PLX_BOOL, PLX_ERR_INVALID, "plx_filter: the mask must be Boolean");
+    ColumnPtr mask = in[1].col;
+    if (in[1].is_scalar) { plx_scalar v = in[1].scalar; mask = ops::full_column(PLX_BOOL, v, in[1].scalar_valid, in[0].col->len); }
+    return ops::filter(in[0].col, mask);
+  });
+}
+void _polars_plugin_field_plx_filter(PLX_FIELD_SIG) { (void)kwargs; (void)kwargs_len; plugin_field(fields, n_fields, out, FIELD_SAME, 0); }
+
 // ---- synthetic benchmark data --------------------------------------------------------
 int plx_datagen_lineitem_q1(int64_t n_rows, uint64_t seed, plx_column* out_cols) {
   PLX_TRY

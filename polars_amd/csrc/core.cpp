@@ -2,6 +2,7 @@
 #include "core.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -46,11 +47,12 @@ void init_device(int ordinal) {
   g_dev.ordinal = ordinal;
 }
 hipStream_t stream() { return t_stream_set ? t_stream : device().own_stream; }
+static std::atomic<bool> g_multi_stream{false};   // a caller stream was installed at least once: freed blocks carry an event
 void set_thread_stream(hipStream_t s) {
-  // keep the pool's stream-order invariant: drain the old stream before switching
+  // drain the calling thread's old stream before switching (its pending frees are then safe on any stream)
   if (device_ready()) (void)hipStreamSynchronize(stream());
   if (s == nullptr) { t_stream_set = false; t_stream = nullptr; }
-  else { t_stream_set = true; t_stream = s; }
+  else { t_stream_set = true; t_stream = s; g_multi_stream.store(true, std::memory_order_release); }
 }
 void check_cancel() {
   if (g_dev.cancel.load(std::memory_order_relaxed)) fail(PLX_ERR_CANCELLED, "query cancelled");
@@ -58,9 +60,14 @@ void check_cancel() {
 
 // ------------------------------------------------------------ HBM pool ------
 namespace {
+// A cached block remembers the stream its last owner released it on and (once more than one stream is in use: one stream
+// per calling thread, include/polars_amd.h) an event recorded on that stream at release time.  Re-use on the SAME stream
+// is ordered by the stream itself; re-use on another stream first waits for the event, so a block is never handed to
+// stream B while kernels the releasing thread submitted on stream A can still touch it.
+struct FreeBlock { void* ptr; hipStream_t stream; hipEvent_t ev; };
 struct Pool {
   std::mutex mu;
-  std::multimap<size_t, void*> free_blocks;  // cap -> ptr
+  std::multimap<size_t, FreeBlock> free_blocks;  // cap -> block
   uint64_t in_use = 0, high = 0, cached = 0;
 } g_pool;
 
@@ -81,7 +88,18 @@ DevBuf::~DevBuf() {
   // costs tens of milliseconds (page-table work + an implicit device sync), far more than the
   // kernels that fill it, and 288 GB of HBM leaves room.  dev_alloc trims the cache on OOM and
   // when it grows past half of the device memory.
-  g_pool.free_blocks.emplace(cap, ptr);
+  FreeBlock fb{ptr, nullptr, nullptr};
+  if (device_ready()) {
+    fb.stream = stream();
+    if (g_multi_stream.load(std::memory_order_acquire)) {
+      if (hipEventCreateWithFlags(&fb.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(fb.ev, fb.stream) != hipSuccess) {
+        (void)hipGetLastError();
+        if (fb.ev) { (void)hipEventDestroy(fb.ev); fb.ev = nullptr; }
+        (void)hipStreamSynchronize(fb.stream);   // no event: make the release point a hard one
+      }
+    }
+  }
+  g_pool.free_blocks.emplace(cap, fb);
   g_pool.cached += cap;
 }
 
@@ -90,15 +108,23 @@ Buf dev_alloc(size_t bytes) {
   size_t cap = size_class(bytes);
   void* p = nullptr;
   bool over = false;
+  FreeBlock reused{nullptr, nullptr, nullptr};
   {
     std::lock_guard<std::mutex> lk(g_pool.mu);
     auto it = g_pool.free_blocks.lower_bound(cap);
     // exact class below 2 MiB; best fit within +25% above (large blocks rarely repeat their exact size)
     if (it != g_pool.free_blocks.end() && (it->first == cap || (cap > (size_t(1) << 21) && it->first <= cap + cap / 4))) {
-      p = it->second; cap = it->first; g_pool.free_blocks.erase(it); g_pool.cached -= cap;
+      reused = it->second; p = reused.ptr; cap = it->first; g_pool.free_blocks.erase(it); g_pool.cached -= cap;
     }
     over = g_pool.cached > dev.hbm_bytes / 2;
   }
+  if (p && reused.stream != stream()) {
+    // released on another stream: order this stream behind the release point (event), or drain the other stream when the
+    // block was released before a second stream existed
+    if (reused.ev) (void)hipStreamWaitEvent(stream(), reused.ev, 0);
+    else if (reused.stream) (void)hipStreamSynchronize(reused.stream);
+  }
+  if (reused.ev) (void)hipEventDestroy(reused.ev);
   if (over) pool_trim();
   if (!p) {
     hipError_t e = hipMalloc(&p, cap);
@@ -133,7 +159,11 @@ void pool_trim() {
   if (!device_ready()) return;
   (void)hipStreamSynchronize(stream());
   std::lock_guard<std::mutex> lk(g_pool.mu);
-  for (auto& kv : g_pool.free_blocks) (void)hipFree(kv.second);
+  for (auto& kv : g_pool.free_blocks) {
+    if (kv.second.ev) { (void)hipEventSynchronize(kv.second.ev); (void)hipEventDestroy(kv.second.ev); }
+    else if (kv.second.stream && kv.second.stream != stream()) (void)hipStreamSynchronize(kv.second.stream);
+    (void)hipFree(kv.second.ptr);
+  }
   g_pool.free_blocks.clear(); g_pool.cached = 0;
 }
 

@@ -87,7 +87,13 @@ class ParquetFrame:
         self._need, self._preds = set(), None
 
     def selected_columns(self) -> List[str]:
-        return [n for n in self._schema if self._need is None or n in self._need]
+        cols = [n for n in self._schema if self._need is None or n in self._need]
+        if not cols and self._schema:
+            # a plan that reads no column (select(len())) still needs the row count: keep the narrowest column, so the
+            # uploaded frame has the scan's height instead of 0
+            width = lambda n: getattr(getattr(self._schema[n], "np_dtype", None), "itemsize", None) or 64
+            cols = [min(self._schema, key=lambda n: (width(n), list(self._schema).index(n)))]
+        return cols
 
     def selected_row_groups(self) -> List[int]:
         """Row groups that can contain a matching row according to their column statistics."""
@@ -105,7 +111,17 @@ class ParquetFrame:
                 lo, hi = st.min, st.max
                 try:
                     v = _comparable(value, lo)
-                    possible = {F.OP_GT: hi > v, F.OP_GE: hi >= v, F.OP_LT: lo < v, F.OP_LE: lo <= v, F.OP_EQ: lo <= v <= hi, F.OP_NE: not (lo == hi == v)}[op]
+                    if isinstance(lo, float) or isinstance(hi, float) or isinstance(v, float):
+                        # Parquet min/max exclude NaN, but the engine compares floats in TOTAL order (NaN == NaN, NaN greatest:
+                        # comparisons/simd.rs:171-275), so a group may hold a NaN row that satisfies >, >=, != or == NaN although
+                        # the statistics say otherwise.  Only the "below" predicates can be pruned from [min, max] (NaN is never
+                        # below a non-NaN literal); a NaN literal prunes nothing.
+                        if v != v:
+                            possible = True
+                        else:
+                            possible = {F.OP_LT: lo < v, F.OP_LE: lo <= v}.get(op, True)
+                    else:
+                        possible = {F.OP_GT: hi > v, F.OP_GE: hi >= v, F.OP_LT: lo < v, F.OP_LE: lo <= v, F.OP_EQ: lo <= v <= hi, F.OP_NE: not (lo == hi == v)}[op]
                 except TypeError:
                     possible = True
                 if not possible:

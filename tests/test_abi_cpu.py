@@ -126,3 +126,41 @@ int main(void) {
     assert r.returncode == 0, r.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+
+
+def test_reference_plugin_entry_points_are_exported_and_fail_loudly_without_a_gpu():
+    """_polars_plugin_* are what an unmodified Polars resolves after dlopen (plugin.rs:23-137): version (0, 1), every declared
+    function + its field function exported, output fields correct without any GPU work, and -- on a box without a GPU -- a call
+    releases its inputs (the callee owns them, plugin.rs:122-125), leaves out.private_data NULL and sets the thread-local message."""
+    import pyarrow as pa
+    import torch
+
+    from polars_amd import _ffi
+    from tests import plugin_abi as P
+    lib = _ffi.lib()
+    src = open(os.path.join(ROOT, "include", "polars_amd.h")).read()
+    names = re.findall(r"PLX_DECLARE_PLUGIN\((plx_[a-z]+)\)", src)
+    assert len(names) == 19
+    for n in names:
+        assert hasattr(lib, "_polars_plugin_" + n) and hasattr(lib, "_polars_plugin_field_" + n), n
+    lib._polars_plugin_get_version.restype = C.c_uint32
+    v = lib._polars_plugin_get_version()
+    assert (v >> 16, v & 0xFFFF) == (0, 1)
+    # output fields (no device work)
+    assert P.field("plx_gt", pa.int64()).type == pa.bool_()
+    assert P.field("plx_cmp", pa.float64(), {"op": "le"}).type == pa.bool_()
+    assert P.field("plx_arith", pa.int32(), {"op": "truediv"}).type == pa.float64()
+    assert P.field("plx_arith", pa.int32(), {"op": "add"}).type == pa.int32()
+    assert P.field("plx_truediv", pa.float32()).type == pa.float32()
+    assert P.field("plx_sum", pa.int16()).type == pa.int64() and P.field("plx_sum", pa.uint32()).type == pa.uint32()
+    assert P.field("plx_mean", pa.int64()).type == pa.float64() and P.field("plx_mean", pa.float32()).type == pa.float32()
+    f = P.field("plx_filter", pa.timestamp("us"), col_name="ts")
+    assert f.type == pa.timestamp("us") and f.name == "ts"
+    assert P.field("plx_sum", pa.large_string()) is None and "unsupported Arrow format" in P.last_error()
+    if torch.cuda.is_available():
+        return
+    res, inp = P.call("plx_gt", [pa.array([1, 2, 3], pa.int64()), pa.array([2], pa.int64())])
+    assert res is None and inp.released == 2
+    assert "no HIP device" in P.last_error() or "plx_init" in P.last_error()
+    res, inp = P.call("plx_sum", [pa.array([1.0, 2.0]), pa.array([1.0])])       # wrong arity: still releases what it was given
+    assert res is None and inp.released == 2

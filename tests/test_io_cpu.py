@@ -141,3 +141,36 @@ def test_benchmark_tables_follow_the_reference_sample_schemas(tmp_path):
                 assert schema[n] == want and lt.get(n, want) == want, (table, n)
     li = datagen.lineitem_host(10, seed=1)
     assert li["l_quantity"].dtype == np.int64 and li["l_extendedprice"].dtype == np.float64 and li["l_shipdate"].dtype == np.int64
+
+
+def test_float_statistics_never_prune_a_group_that_may_hold_nan(tmp_path):
+    """Parquet min / max ignore NaN, the engine's float comparisons are a total order with NaN greatest
+    (comparisons/simd.rs:171-275): `x > 5` must keep a row group [1.0, NaN, 2.0] whose statistics say max = 2."""
+    c = pl.col
+    t = pa.table({"x": pa.array([1.0, float("nan"), 2.0, 10.0, 11.0, 12.0]), "k": pa.array([1, 2, 3, 4, 5, 6])})
+    path = str(tmp_path / "nan.parquet")
+    pq.write_table(t, path, row_group_size=3)
+
+    def groups(pred):
+        lf = pl.scan_parquet(path).filter(pred).select(c("k").sum())
+        io.reset_scans(lf._node); io.push_down(lf._node)
+        n = lf._node
+        while n.kind != "scan":
+            n = n.input
+        return n.frame.selected_row_groups()
+    assert groups(c("x") > 5.0) == [0, 1]            # the NaN row of group 0 is > 5 in total order
+    assert groups(c("x") >= 5.0) == [0, 1]
+    assert groups(c("x") != 1.5) == [0, 1]
+    assert groups(c("x") == float("nan")) == [0, 1]
+    assert groups(c("x") < 5.0) == [0]               # NaN is never below a number: pruning from min stays valid
+    assert groups(c("x") <= 0.5) == []
+    assert groups(c("k") > 3) == [1]                 # integer statistics prune as before
+
+
+def test_a_plan_that_reads_no_column_keeps_one_for_the_row_count(lineitem_file):
+    path, _, _ = lineitem_file
+    lf = pl.scan_parquet(path).select(pl.len())
+    io.reset_scans(lf._node); io.push_down(lf._node)
+    src = lf._node.input.frame
+    cols = src.selected_columns()
+    assert len(cols) == 1 and src.schema[cols[0]].np_dtype.itemsize <= 8      # COUNT(*) must see num_rows rows, not an empty frame
