@@ -432,13 +432,16 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
     if name == "cfg5":
         n = rows or 1_000_000_000
         codes = v = None
-        df = _native_or_none("cfg5", lambda: pl.DataFrame([native_uniform_column(pl, "k", pl.Categorical([], pl.UInt32), "UInt32", n, seed, 0, 0, 1_000_000),
+        # the dictionary of the 1e6 distinct "id%010d" strings (H2O id3 style) stays on the host; the column holds their u32 codes and
+        # knows the dictionary size (code bounds), like any dictionary-encoded string column
+        cats = ["id%010d" % i for i in range(1, 1_000_001)]
+        df = _native_or_none("cfg5", lambda: pl.DataFrame([native_uniform_column(pl, "k", pl.Categorical(cats, pl.UInt32), "UInt32", n, seed, 0, 0, 1_000_000),
                                                            native_uniform_column(pl, "v", pl.Float64, "Float64", n, seed, 1, 0, 10 ** 9, 1e-7)]))
         if df is None:
             g = torch.Generator(device="cuda"); g.manual_seed(seed)
             codes = torch.randint(0, 1_000_000, (n,), generator=g, device="cuda", dtype=torch.int32)   # dictionary codes of "id%010d" keys (u32)
             v = torch.rand((n,), generator=g, device="cuda", dtype=torch.float64) * 100.0
-            df = pl.DataFrame([pl.Series.from_torch("k", codes, dtype=pl.Categorical([], pl.UInt32)), pl.Series.from_torch("v", v)])
+            df = pl.DataFrame([pl.Series.from_torch("k", codes, dtype=pl.Categorical(cats, pl.UInt32)), pl.Series.from_torch("v", v)])
             torch.cuda.synchronize()
         lf = queries.cfg5(df.lazy())
 

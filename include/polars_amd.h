@@ -212,6 +212,11 @@ int plx_column_from_device(plx_dtype dtype, void* dev_values, void* dev_validity
  * rejects it. */
 int plx_column_placeholder(plx_dtype dtype, int64_t len, int nullable, int has_range, int64_t range_min, int64_t range_max,
                            plx_column* out);
+/* Caller-provided value bounds of an integer column (dictionary size of a Categorical, Parquet column-chunk min / max
+ * statistics): every valid value lies in [lo, hi].  The planner uses them the way the reference uses sortedness flags and
+ * metadata statistics -- to choose dense / direct-address group tables without a pass over the data.  Kernels that rely on
+ * the bounds check them per row and fail the query (PLX_ERR_INVALID) if a value lies outside. */
+int plx_column_set_bounds(plx_column col, int64_t lo, int64_t hi);
 /* Arrow C Data Interface import: copies to HBM, then calls array->release and
  * schema->release (callee takes ownership: plugin.rs:122-125 convention). */
 int plx_column_import_arrow(struct ArrowArray* array, struct ArrowSchema* schema, plx_column* out);

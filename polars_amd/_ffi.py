@@ -112,6 +112,7 @@ SIGNATURES = {
     "plx_column_from_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, _u64p]),
     "plx_column_from_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, _u64p]),
     "plx_column_placeholder": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _u64p]),
+    "plx_column_set_bounds": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64]),
     "plx_column_import_arrow": (C.c_int, [C.POINTER(ArrowArray), C.POINTER(ArrowSchema), _u64p]),
     "plx_column_import_series": (C.c_int, [C.POINTER(SeriesExport), _u64p]),
     "plx_column_export_arrow": (C.c_int, [C.c_uint64, C.POINTER(ArrowArray), C.POINTER(ArrowSchema)]),

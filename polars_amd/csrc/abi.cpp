@@ -90,6 +90,14 @@ int plx_column_placeholder(plx_dtype dtype, int64_t len, int nullable, int has_r
   PLX_CATCH
 }
 
+int plx_column_set_bounds(plx_column col, int64_t lo, int64_t hi) {
+  PLX_TRY
+  ColumnPtr c = get_column(col);
+  PLX_REQUIRE(dtype_is_int(c->dtype) && lo <= hi, PLX_ERR_INVALID, "set_bounds: integer columns only, lo <= hi");
+  c->range_state = 1; c->range_min = lo; c->range_max = hi; c->range_trusted = false;
+  PLX_CATCH
+}
+
 static int dtype_from_format(const char* f) {
   if (!f) return -1;
   if (!strcmp(f, "b")) return PLX_BOOL;
@@ -798,7 +806,8 @@ int plx_jit_selftest(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int
     fused::Shape sh{}; int sid = -1;
     PLX_REQUIRE(engine::describe_fusion(p, root, &sh, &sid, &why), PLX_ERR_UNSUPPORTED, "not fusable: " + why);
     if (rn.kind == PLX_IR_SELECT) jobs = {{sh, jit::REGAGG}};
-    else jobs = {{sh, jit::LDSAGG}, {sh, jit::DENSE}, {sh, jit::HASH}, {sh, jit::PART_COUNT}, {sh, jit::PART_SCATTER}, {sh, jit::PART_AGG}};
+    else jobs = {{sh, jit::LDSAGG}, {sh, jit::DENSE}, {sh, jit::HASH}, {sh, jit::PART_COUNT}, {sh, jit::PART_SCATTER}, {sh, jit::PART_AGG},
+                  {sh, jit::PART2_SCATTER_HASH}, {sh, jit::PART2_SCATTER_DIRECT}, {sh, jit::PART2_AGG_HASH}, {sh, jit::PART2_AGG_DIRECT}};
     if (sh.n_keys >= 2) jobs = {{sh, jit::WIDE}};
   }
   for (auto& j : jobs) {

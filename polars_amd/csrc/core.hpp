@@ -104,6 +104,7 @@ struct Column {
   // cached statistics of integer columns (zone-map style), filled lazily by ops::int_range
   int range_state = 0;      // 0 unknown, 1 known, 2 no valid rows
   int64_t range_min = 0, range_max = 0;
+  bool range_trusted = true;   // computed by the library (exact); false: caller-provided bounds (plx_column_set_bounds)
   const void* data() const { return values ? values->ptr : nullptr; }
   const uint64_t* valid_words() const { return validity ? validity->as<uint64_t>() : nullptr; }
 };

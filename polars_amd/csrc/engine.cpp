@@ -740,6 +740,42 @@ static int64_t run_wide_agg(const Shape& sh, const Args& args, int log2_cap, boo
   return g;
 }
 
+// Sample of the input for the group-by planner: kSampleBlocks evenly spaced blocks of rows (a prefix alone says nothing about
+// clustered data) aggregated into one HBM hash table.  -> number of distinct keys in the sample (-1: table overflow) and the
+// heavy hitters (keys holding >= 1/1024 of the sampled rows), which the partitioned path pre-aggregates instead of scattering.
+constexpr int kSampleBlocks = 8;
+static Args offset_args(const Shape& sh, const Args& a, int64_t row0, int64_t rows) {
+  Args o = a;
+  for (int i = 0; i < sh.n_inputs; i++) {
+    if (o.in[i].values) o.in[i].values = (const uint8_t*)o.in[i].values + (sh.in_dtype[i] == PLX_BOOL ? (size_t)(row0 / 8) : (size_t)row0 * dtype_width(sh.in_dtype[i]));
+    if (o.in[i].validity) o.in[i].validity = o.in[i].validity + row0 / 64;
+  }
+  o.n_rows = rows;
+  return o;
+}
+static int64_t sample_keys(const Shape& sh, const Args& args, int static_id, int len_idx, int64_t S, std::vector<uint64_t>* hot) {
+  const int log2_cap = 23;
+  const uint64_t cap = 1ull << log2_cap;
+  const int64_t slots = (int64_t)cap + 2;
+  Buf keys = dev_alloc(sizeof(uint64_t) * (size_t)slots), acc = dev_alloc(sizeof(uint64_t) * (size_t)slots * sh.n_aggs), ovf = dev_alloc_zero(8);
+  k::fill_u64(keys->as<uint64_t>(), slots, kEmptyKey);
+  k::init_agg_cells(acc->as<uint64_t>(), slots, sh);
+  HashTable t; t.keys = keys->as<unsigned long long>(); t.acc = acc->as<unsigned long long>(); t.overflow = ovf->as<unsigned int>();
+  t.log2_cap = (uint32_t)log2_cap; t.max_probe = 1u << 14;
+  const int64_t n = args.n_rows, per = (S / kSampleBlocks) & ~(int64_t)127, stride = (n / kSampleBlocks) & ~(int64_t)127;
+  for (int b = 0; b < kSampleBlocks; b++) {
+    const int64_t row0 = (int64_t)b * stride;
+    const int64_t rows = std::min<int64_t>(per, n - row0);
+    if (rows > 0) k::fused_hash_agg(sh, offset_args(sh, args, row0, rows), t, static_id);
+  }
+  uint32_t o = 0; d2h_sync(&o, ovf->ptr, 4);
+  if (o) return -1;
+  if (hot) k::select_hot_keys(t, sh.n_aggs, len_idx, (uint64_t)std::max<int64_t>(64, (per * kSampleBlocks) / 1024), hot);
+  return k::table_compact(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, nullptr, nullptr, nullptr);
+}
+static int part_version() { static const int v = [] { const char* e = getenv("PLX_PART_V"); return (e && e[0] == '1') ? 1 : 2; }(); return v; }
+static bool hot_keys_enabled() { static const bool v = [] { const char* e = getenv("PLX_PART_HOT"); return !(e && e[0] == '0'); }(); return v; }
+
 static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, FusedAggResult& res, std::string& desc) {
   const Shape& sh = c.shape;
   const Args& args = c.args;
@@ -759,8 +795,32 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
   // large inputs over many (packed) group ids: per-row atomics on the dense HBM table are bound by the device atomic
   // rate just like the hash table -> partition + LDS aggregation on the packed id (kernels_partition.hip)
   if (kp.packed && kp.total_bits > 12 && !(c.plan.flags & PLX_PLAN_NO_PARTITION) && n >= ((int64_t)1 << 24)) {
-    PartitionPlan pp;
     const double est = std::min((double)((uint64_t)1 << std::min(kp.total_bits, 40)), (double)n);
+    if (part_version() == 2) {
+      // second generation: direct-address LDS tables over the dense id when they fit (hash tables otherwise); a strided sample
+      // finds the heavy hitters, which are aggregated in the scatter pass instead of being scattered
+      std::vector<uint64_t> hot;
+      double est2 = est;
+      if (hot_keys_enabled() || kp.total_bits > 25) {
+        const int64_t S = (int64_t)1 << 22;
+        const int64_t d = sample_keys(sh, args, static_id, len_idx, S, hot_keys_enabled() ? &hot : nullptr);
+        if (d >= 0) est2 = std::min(est, std::min(estimate_groups((double)d, (double)S), (double)n) * 1.3);
+        desc += "sample(distinct=" + std::to_string(d) + ",hot=" + std::to_string(hot.size()) + ")+";
+      }
+      PartPlan2 p2;
+      if (k::partition_plan2(sh, est2, kp.total_bits, len_idx, n, (int)hot.size(), &p2)) {
+        std::string pd;
+        Buf ok, okv, oacc;
+        const int64_t g = k::partitioned_agg2(sh, args, p2, static_id, hot, &ok, &okv, &oacc, &pd);
+        if (g >= 0) {
+          res.n_groups = g; res.n_aggs = sh.n_aggs; res.packed_keys = ok; res.key_valid = nullptr; res.acc = oacc;   // packed ids carry their own null codes
+          desc += std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+" + pd;
+          return;
+        }
+        desc += "v2-unavailable+";
+      }
+    }
+    PartitionPlan pp;
     if (k::partition_plan(sh, est, false, &pp)) {
       std::string pd;
       Buf ok, okv, oacc;
@@ -791,7 +851,10 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
   else {
     Args sa = args; sa.n_rows = S;
     FusedAggResult tmp;
-    int64_t d = kp.wide ? run_wide_agg(sh, sa, 23, kp.wide_nullable, tmp, true) : run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true);
+    std::vector<uint64_t> hot;
+    const bool may_partition = !kp.wide && !(c.plan.flags & PLX_PLAN_NO_PARTITION) && n >= ((int64_t)1 << 24);
+    int64_t d = kp.wide ? run_wide_agg(sh, sa, 23, kp.wide_nullable, tmp, true)
+                        : (may_partition && part_version() == 2 ? sample_keys(sh, args, static_id, len_idx, S, hot_keys_enabled() ? &hot : nullptr) : run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true));
     double G = d < 0 ? 1e18 : estimate_groups((double)d, (double)S);
     G = std::min(G, (double)n);
     log2_cap = std::max(12, ceil_log2_u64((uint64_t)(G * 2.0) + 1));
@@ -801,6 +864,20 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     if (!kp.wide && !(c.plan.flags & PLX_PLAN_NO_PARTITION) && G >= 4096.0 && n >= ((int64_t)1 << 24)) {
       bool any_null = c.key >= 0 && c.nodes[c.key].nullable;
       for (auto& a : c.aggs) if (a.second >= 0 && c.nodes[a.second].nullable) any_null = true;
+      if (part_version() == 2) {
+        PartPlan2 p2;
+        if (k::partition_plan2(sh, G * 1.3, -1, len_idx, n, (int)hot.size(), &p2)) {
+          std::string pd;
+          Buf ok, okv, oacc;
+          const int64_t g = k::partitioned_agg2(sh, args, p2, static_id, hot, &ok, &okv, &oacc, &pd);
+          if (g >= 0) {
+            res.n_groups = g; res.n_aggs = sh.n_aggs; res.packed_keys = ok; res.key_valid = okv; res.acc = oacc;
+            desc += "hot=" + std::to_string(hot.size()) + "+" + std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+" + pd;
+            return;
+          }
+          desc += "v2-unavailable+";
+        }
+      }
       PartitionPlan pp;
       if (k::partition_plan(sh, G * 1.3, any_null, &pp)) {
         std::string pd;

@@ -181,6 +181,85 @@ struct PartitionPlan {
   RecLayout rec;               // == rec_layout(shape)
 };
 
+// ---- partitioned group-by, second generation (partition2_device.hpp, kernels_partition.hip) -------------------------
+// No counting pass: every scatter workgroup owns a private region of fixed-size CHUNKS and hands them to partitions on
+// demand; records are packed dword streams (32-bit keys / sources stay 32-bit); partitions are aggregated either in an LDS
+// open-addressing table (hash mode) or, for dense packed ids, in an LDS direct-address table (direct mode: the partition is
+// the id's high bits, the record carries only the low bits).
+constexpr uint32_t kP2Hash = 0, kP2Direct = 1;
+constexpr uint32_t kP2ChunkRecs = 256;        // records per chunk: chunk bytes = 256 * rec_words * 4 (a multiple of the 128-B line)
+constexpr uint32_t kP2MaxHot = 256;           // hot keys pre-aggregated in the scatter pass
+constexpr uint32_t kNoChunk = 0xffffffffu;
+struct RecLayout2 {
+  uint8_t key_words;             // 1 | 2 dwords
+  uint8_t key_kind;              // 0: 64-bit, 1: i32 (sign-extended on read), 2: u32 (zero-extended)
+  uint8_t n_src;
+  uint8_t has_valid, valid_off;  // one dword: bit j = source j valid, bit 31 = key valid
+  uint8_t has_rowid, rowid_off;  // two dwords
+  uint8_t rec_words;
+  uint8_t src_kind[kMaxSrc], src_off[kMaxSrc];
+  uint8_t src_slot[kMaxAggs];    // program slot of source j
+  uint8_t agg_src[kMaxAggs];     // aggregate k reads source agg_src[k] (kNone: LEN / FIRST_ROW)
+};
+// a slot whose only writer is the LOAD of a <= 32-bit integer column holds a sign- / zero-extended 32-bit value
+PLX_FHD constexpr uint8_t narrow_kind(const Shape& sh, uint8_t slot) {
+  int writers = 0, input = -1;
+  for (int i = 0; i < sh.n_ops; i++) {
+    if (sh.ops[i].dst != slot) continue;
+    writers++;
+    input = sh.ops[i].code == OP_LOAD ? (int)sh.ops[i].a : -1;
+  }
+  if (writers != 1 || input < 0) return 0;
+  switch (sh.in_dtype[input]) {
+    case 1: case 2: case 3: return 1;            // PLX_I8, PLX_I16, PLX_I32
+    case 0: case 5: case 6: case 7: return 2;    // PLX_BOOL, PLX_U8, PLX_U16, PLX_U32
+    default: return 0;
+  }
+}
+PLX_FHD constexpr RecLayout2 rec_layout2(const Shape& sh, uint32_t mode) {
+  RecLayout2 L{};
+  for (int k = 0; k < kMaxAggs; k++) { L.agg_src[k] = kNone; L.src_slot[k] = 0; }
+  for (int j = 0; j < kMaxSrc; j++) { L.src_kind[j] = 0; L.src_off[j] = 0; }
+  uint32_t w = 0, n_src = 0;
+  L.key_kind = mode == kP2Direct ? 2 : narrow_kind(sh, sh.key);
+  L.key_words = L.key_kind ? 1 : 2;
+  w += L.key_words;
+  for (int k = 0; k < sh.n_aggs; k++) {
+    const uint8_t kind = sh.aggs[k].kind;
+    if (kind == AGG_LEN) continue;
+    if (kind == AGG_FIRST_ROW) { L.has_rowid = 1; continue; }
+    int j = -1;
+    for (uint32_t t = 0; t < n_src; t++) if (L.src_slot[t] == sh.aggs[k].src) j = (int)t;
+    if (j < 0) { j = (int)n_src; if (n_src < (uint32_t)kMaxAggs) L.src_slot[n_src] = sh.aggs[k].src; n_src++; }
+    L.agg_src[k] = (uint8_t)j;
+  }
+  L.n_src = (uint8_t)n_src;
+  for (uint32_t j = 0; j < n_src && j < (uint32_t)kMaxSrc; j++) {
+    L.src_kind[j] = narrow_kind(sh, L.src_slot[j]);
+    L.src_off[j] = (uint8_t)w;
+    w += L.src_kind[j] ? 1 : 2;
+  }
+  L.has_valid = shape_may_have_nulls(sh) ? 1 : 0;
+  L.valid_off = (uint8_t)w; w += L.has_valid;
+  L.rowid_off = (uint8_t)w; w += 2 * L.has_rowid;
+  L.rec_words = (uint8_t)w;
+  return L;
+}
+struct PartPlan2 {
+  uint32_t mode;               // kP2Hash | kP2Direct
+  uint32_t log2_parts;         // P = 1 << log2_parts partitions
+  uint32_t log2_slots;         // slots of a partition's LDS table (direct mode: == key_shift)
+  uint32_t key_shift;          // direct mode: partition = id >> key_shift, table slot = id & ((1 << key_shift) - 1)
+  uint32_t ring_lines;         // 128-B lines of LDS staging per partition (power of two)
+  uint32_t block;              // threads of a scatter workgroup
+  uint32_t chunks_per_wg;      // chunks in each scatter workgroup's private region
+  uint32_t scatter_grid;
+  uint32_t n_hot;              // hot keys (0 = none), log2_hot_slots = slots of their LDS lookup table, hot_copies = accumulator copies
+  uint32_t log2_hot_slots, hot_copies;
+  uint32_t len_idx;            // the aggregate that counts rows (occupancy of a direct-address slot)
+  uint32_t rec_words;          // == rec_layout2(shape, mode).rec_words
+};
+
 // ---- batched result finalisation: every output column of a query in ONE launch ---------------
 constexpr int kMaxFinJobs = 24;
 struct FinJob {

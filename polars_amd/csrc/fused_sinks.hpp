@@ -76,7 +76,9 @@ struct LdsAggSink {
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
       if (!pass[r]) continue;
-      const uint32_t gid = (uint32_t)rf.get(r, sh.key);
+      const uint64_t gid64 = rf.get(r, sh.key);
+      if (gid64 >= (uint64_t)p.n_groups) continue;   // only possible when caller-declared column bounds (plx_column_set_bounds) were wrong: stay inside the table
+      const uint32_t gid = (uint32_t)gid64;
       unsigned long long* cells = lds_tbl + (size_t)gid * sh.n_aggs * p.copies + copy;
 #pragma unroll
       for (int k = 0; k < kMaxAggs; k++) {
@@ -116,6 +118,7 @@ struct DenseAggSink {
       if (!pass[r]) continue;
       bool kvalid = (rf.getv(sh.key) >> r) & 1;
       int64_t g = kvalid ? ((int64_t)rf.get(r, sh.key) - p.key_min) : p.n_groups;
+      if ((uint64_t)g > (uint64_t)p.n_groups) continue;   // see LdsAggSink: wrong caller-declared bounds must not leave the table
       atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)g * sh.n_aggs);
     }
   }

@@ -32,7 +32,7 @@ double g_ms = 0;
 
 const char* sink_type(Sink s) {
   static const char* n[] = {"RegAggSink", "LdsAggSink", "DenseAggSink", "HashAggSink", "WideAggSink", "JoinBuildSink", "ProbeAggSink", "DirectBuildSink", "DirectProbeAggSink",
-                            "part_count", "part_scatter", "part_agg"};
+                            "part_count", "part_scatter", "part_agg", "part2_scatter_hash", "part2_scatter_direct", "part2_agg_hash", "part2_agg_direct"};
   return n[s];
 }
 
@@ -66,7 +66,7 @@ std::vector<std::string> compile_options() {
 
 std::string source_for(const Shape& sh, Sink sink) {
   std::ostringstream o;
-  o << (sink >= PART_COUNT ? "#include \"partition_device.hpp\"\n" : "#include \"fused_sinks.hpp\"\n") << "namespace plx { namespace k {\n"
+  o << (sink >= PART2_SCATTER_HASH ? "#include \"partition2_device.hpp\"\n" : sink >= PART_COUNT ? "#include \"partition_device.hpp\"\n" : "#include \"fused_sinks.hpp\"\n") << "namespace plx { namespace k {\n"
        "struct JitProg {\n  static constexpr bool kStatic = true; static constexpr int kId = -2;\n  static constexpr Shape shape() {\n    Shape s{};\n";
   o << "    s.n_inputs = " << (int)sh.n_inputs << "; s.n_ops = " << (int)sh.n_ops << "; s.n_aggs = " << (int)sh.n_aggs << "; s.pred = " << (int)sh.pred
     << "; s.key = " << (int)sh.key << "; s.n_keys = " << (int)sh.n_keys << ";\n";
@@ -88,6 +88,15 @@ std::string source_for(const Shape& sh, Sink sink) {
     case PART_AGG:
       o << "extern \"C\" __global__ __launch_bounds__(kAggBlock) void plx_jit_kernel(Shape dsh, PartitionPlan pp, PartAggParams ap) {\n"
            "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout cl = rec_layout(JitProg::shape());\n  part_agg_body(csh, cl, pp, ap);\n}\n}}\n";
+      break;
+    case PART2_SCATTER_HASH: case PART2_SCATTER_DIRECT:
+      o << "extern \"C\" __global__ __launch_bounds__(kP2MaxBlock) void plx_jit_kernel(Shape dsh, Args args, PartPlan2 pp, ScatterParams2 sp) {\n"
+           "  part2_scatter_body<JitProg, " << (sink == PART2_SCATTER_DIRECT ? 1 : 0) << ">(dsh, args, pp, sp);\n}\n}}\n";
+      break;
+    case PART2_AGG_HASH: case PART2_AGG_DIRECT:
+      o << "extern \"C\" __global__ __launch_bounds__(kP2AggBlock) void plx_jit_kernel(PartPlan2 pp, AggParams2 ap) {\n"
+           "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout2 cl = rec_layout2(JitProg::shape(), " << (sink == PART2_AGG_DIRECT ? 1 : 0) << "u);\n"
+           "  part2_agg_body<Shape, " << (sink == PART2_AGG_DIRECT ? 1 : 0) << ">(csh, cl, pp, ap);\n}\n}}\n";
       break;
     default:
       o << "extern \"C\" __global__ __launch_bounds__(kBlock) void plx_jit_kernel(Shape dsh, Args args, " << sink_type(sink)

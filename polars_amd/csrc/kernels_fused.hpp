@@ -2,6 +2,7 @@
 // the join kernels (kernels_join.hip).
 #pragma once
 #include <string>
+#include <vector>
 
 #include "core.hpp"
 #include "fused.hpp"
@@ -58,6 +59,12 @@ void finalize_aggs(const uint64_t* acc, int n_aggs, int64_t G, const fused::Fina
 bool partition_plan(const fused::Shape& sh, double est_groups, bool any_nullable, fused::PartitionPlan* out);
 int64_t partitioned_agg(const fused::Shape& sh, const fused::Args& args, const fused::PartitionPlan& pp, int static_id, Buf* out_keys, Buf* out_kvalid,
                         Buf* out_acc, std::string* desc);
+// second generation (partition2_device.hpp): packed_bits > 0 = the key is a dense packed id of that many bits (direct-address
+// LDS tables when they fit); hot_keys = heavy hitters pre-aggregated in the scatter pass (select_hot_keys on a sample table)
+bool partition_plan2(const fused::Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, fused::PartPlan2* out);
+void select_hot_keys(const fused::HashTable& t, int n_aggs, int len_idx, uint64_t threshold, std::vector<uint64_t>* out);
+int64_t partitioned_agg2(const fused::Shape& sh, const fused::Args& args, const fused::PartPlan2& pp, int static_id, const std::vector<uint64_t>& hot_keys, Buf* out_keys,
+                         Buf* out_kvalid, Buf* out_acc, std::string* desc);
 // all jobs of a batch (key decodes + aggregate finalisations) in one launch
 void finalize_batch(const uint64_t* acc, int n_aggs, int64_t G, const fused::FinBatch& b);
 // packed group keys -> one key column

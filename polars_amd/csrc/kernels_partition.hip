@@ -21,6 +21,9 @@
 // HBM traffic: (1) reads the key/predicate columns, (2) reads all inputs + writes the records, (3) reads the
 // records: ~3x the algorithmic bytes instead of a fraction of the atomic rate.
 #include "partition_device.hpp"
+#include "partition2_device.hpp"
+#include <algorithm>
+#include <vector>
 #include "kernels.hpp"
 #include "kernels_fused.hpp"
 #include "jit.hpp"
@@ -173,6 +176,281 @@ int64_t partitioned_agg(const Shape& sh, const Args& args, const PartitionPlan& 
   if ((uint32_t)res[1]) return -1;
   if (desc) *desc = "partitioned(P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec.rec_words * 8) + "B,buf=" + std::to_string(pp.buf_rows) + ")+lds_hash_table(slots=" + std::to_string(1u << pp.log2_slots) + ")";
   return (int64_t)res[0];
+}
+
+
+// ======================================================================================================================
+// Second generation (partition2_device.hpp): no counting pass, packed records, chunked private output regions, hot-key
+// pre-aggregation, hash or direct-address LDS tables.  HBM traffic: inputs read ONCE + records written once + records
+// read once (e.g. 16 + 12 + 12 B/row for an i64 key column of dense ids and an i64 value, against 8 + 32 + 16 before).
+// ======================================================================================================================
+static const int kEnvP2Block = env_int("PLX_PART_BLOCK", 256, 1024);
+static const int kEnvP2Ring = env_int("PLX_PART_RING_LINES", 1, 16);
+static const int kEnvP2Direct = env_int("PLX_PART_DIRECT", 0, 1);        // 0: never use the direct-address mode
+
+static uint32_t floor_pow2(uint32_t x) { uint32_t p = 1; while (p * 2 <= x) p *= 2; return p; }
+static uint32_t ceil_log2(uint64_t x) { uint32_t b = 0; while ((1ull << b) < x) b++; return b; }
+
+bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, PartPlan2* out) {
+  PartPlan2 pp{};
+  if (sh.key == kNone || sh.n_keys) return false;
+  const size_t lds_total = 160 * 1024 - 2048;      // leave room for the kernels' static shared variables
+  pp.len_idx = (uint32_t)(len_idx < 0 ? 0 : len_idx);
+  // ---- table geometry
+  bool direct = false;
+  if (packed_bits > 0 && packed_bits <= 25 && kEnvP2Direct != 0 && len_idx >= 0) {
+    // direct-address LDS table: slots = low bits of the id; as many partitions as give every CU work, tables as large as fit
+    uint32_t max_shift = 0;
+    while (((size_t)1 << (max_shift + 1)) * sh.n_aggs * 8 <= 128 * 1024) max_shift++;
+    int shift = packed_bits - 9;                      // 512 partitions when the id range allows
+    if (shift > (int)max_shift) shift = (int)max_shift;
+    if (shift < 6) shift = 6;
+    const int lp = packed_bits - shift;
+    if (lp >= 4 && lp <= 9) { direct = true; pp.mode = kP2Direct; pp.key_shift = (uint32_t)shift; pp.log2_slots = (uint32_t)shift; pp.log2_parts = (uint32_t)lp; }
+  }
+  if (!direct) {
+    pp.mode = kP2Hash;
+    uint32_t log2_slots = 14;
+    auto tbl_bytes = [&](uint32_t ls) { return (((size_t)1 << ls) + 2) * 8 * (1 + sh.n_aggs); };
+    while (log2_slots > 8 && tbl_bytes(log2_slots) > 144 * 1024) log2_slots--;
+    if (tbl_bytes(log2_slots) > 144 * 1024) return false;
+    const double per_part = (double)(1u << log2_slots) * 0.62;     // LDS table load <= ~0.62 (the caller passes 1.3 x its estimate)
+    uint32_t lp = 6;
+    while (lp < 9 && (double)(1u << lp) * per_part < est_groups) lp++;
+    if ((double)(1u << lp) * per_part < est_groups) return false;  // more than 512 partitions: the rings would not fit the LDS
+    if (kEnvLog2Parts > (int)lp && kEnvLog2Parts <= 9) lp = (uint32_t)kEnvLog2Parts;
+    pp.log2_parts = lp; pp.log2_slots = log2_slots; pp.key_shift = 0;
+  }
+  const RecLayout2 L = rec_layout2(sh, pp.mode);
+  if (L.n_src > (uint32_t)kMaxSrc || L.rec_words > 13) return false;
+  pp.rec_words = L.rec_words;
+  const uint32_t NP = 1u << pp.log2_parts;
+  // ---- hot keys
+  pp.n_hot = (uint32_t)std::min<int>(n_hot, (int)kP2MaxHot);
+  pp.log2_hot_slots = pp.n_hot ? std::max<uint32_t>(3, ceil_log2((uint64_t)pp.n_hot * 2)) : 0;
+  pp.hot_copies = 1;
+  if (pp.n_hot) { uint32_t c = 16; while (c > 1 && (size_t)pp.n_hot * sh.n_aggs * 8 * c > 8 * 1024) c >>= 1; pp.hot_copies = c; }
+  // ---- rings: as many 128-B lines per partition as the LDS holds (power of two)
+  const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0;
+  const size_t fixed = part2_scatter_lds(NP, 0, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies);
+  if (fixed + (size_t)NP * 256 > lds_total) return false;
+  uint32_t lines = floor_pow2((uint32_t)((lds_total - fixed) / ((size_t)NP * 128)));
+  if (lines > 16) lines = 16;
+  if (kEnvP2Ring > 0 && (uint32_t)kEnvP2Ring <= lines) lines = floor_pow2((uint32_t)kEnvP2Ring);
+  if (lines < 2) return false;
+  pp.ring_lines = lines;
+  // ---- workgroup size: rows per round so that a partition receives well under its ring's free space per round
+  const double cap_recs = (double)(lines * 32) / L.rec_words, line_recs = 32.0 / L.rec_words;
+  const double lambda_max = std::max(1.0, (cap_recs - line_recs) * 0.55);
+  uint32_t block = kP2MaxBlock;
+  while (block > 256 && (double)block * kRows / NP > lambda_max) block >>= 1;
+  if (kEnvP2Block > 0) block = floor_pow2((uint32_t)kEnvP2Block);
+  pp.block = block;
+  const int64_t rows_per_round = (int64_t)block * kRows;
+  const int64_t nrounds = (n_rows + rows_per_round - 1) / rows_per_round;
+  pp.scatter_grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(nrounds, (int64_t)device().cu_count));
+  const int64_t rounds_per_wg = (nrounds + pp.scatter_grid - 1) / pp.scatter_grid;
+  pp.chunks_per_wg = (uint32_t)(rounds_per_wg * rows_per_round / kP2ChunkRecs + NP + 2);
+  *out = pp;
+  return true;
+}
+
+// ---- hot keys: heavy hitters of a sample aggregation table --------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void hot_candidates_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ acc, int64_t cap, int n_aggs,
+                                                                int len_idx, unsigned long long threshold, unsigned int* __restrict__ counter, unsigned long long* __restrict__ out /* [cap_out][2] */,
+                                                                unsigned int cap_out) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long k = keys[s];
+    if (k == kEmptyKey) continue;
+    const unsigned long long c = acc[(size_t)s * n_aggs + len_idx];
+    if (c < threshold) continue;
+    const unsigned int i = atomicAdd(counter, 1u);
+    if (i < cap_out) { out[(size_t)i * 2] = k; out[(size_t)i * 2 + 1] = c; }
+  }
+}
+// keys of the sample table `t` (regular slots only: never the null key or the EMPTY-pattern key) whose row count is at least
+// `threshold`, heaviest first, at most kP2MaxHot.  Synchronises.
+void select_hot_keys(const HashTable& t, int n_aggs, int len_idx, uint64_t threshold, std::vector<uint64_t>* out) {
+  out->clear();
+  if (len_idx < 0) return;
+  const unsigned int cap_out = 2048;
+  Buf cand = dev_alloc(sizeof(uint64_t) * 2 * cap_out);
+  Buf ctr = dev_alloc_zero(8);
+  const int64_t cap = (int64_t)1 << t.log2_cap;
+  hipLaunchKernelGGL(hot_candidates_kernel, dim3(grid_for(cap, kBlock * 4)), dim3(kBlock), 0, stream(), t.keys, t.acc, cap, n_aggs, len_idx, (unsigned long long)threshold,
+                     ctr->as<unsigned int>(), cand->as<unsigned long long>(), cap_out);
+  PLX_HIP(hipGetLastError());
+  uint32_t n = 0;
+  d2h_sync(&n, ctr->ptr, 4);
+  n = std::min<uint32_t>(n, cap_out);
+  if (!n) return;
+  std::vector<uint64_t> host((size_t)n * 2);
+  d2h_sync(host.data(), cand->ptr, host.size() * 8);
+  std::vector<std::pair<uint64_t, uint64_t>> v;   // (count, key)
+  for (uint32_t i = 0; i < n; i++) v.emplace_back(host[(size_t)i * 2 + 1], host[(size_t)i * 2]);
+  std::sort(v.begin(), v.end(), [](const std::pair<uint64_t, uint64_t>& a, const std::pair<uint64_t, uint64_t>& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+  for (size_t i = 0; i < v.size() && i < kP2MaxHot; i++) out->push_back(v[i].second);
+}
+
+// ---- chunk -> partition map -> per-partition chunk lists (counting sort) ----------------------------------------------
+__global__ __launch_bounds__(kBlock) void chunk_hist_kernel(const unsigned int* __restrict__ chunk_part, int64_t n_chunks, uint32_t NP, unsigned int* __restrict__ counts) {
+  extern __shared__ unsigned long long lds_raw[];
+  unsigned int* h = reinterpret_cast<unsigned int*>(lds_raw);
+  for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned int p = chunk_part[c];
+    if (p != kNoChunk) atomicAdd(&h[p], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) if (h[i]) atomicAdd(&counts[i], h[i]);
+}
+// every workgroup takes a contiguous block of chunk slots: local histogram -> one reservation per (workgroup, partition) -> placement
+__global__ __launch_bounds__(kBlock) void chunk_place_kernel(const unsigned int* __restrict__ chunk_part, int64_t n_chunks, uint32_t NP, const unsigned long long* __restrict__ cl_off,
+                                                             unsigned int* __restrict__ cursor, unsigned int* __restrict__ cl_ids) {
+  extern __shared__ unsigned long long lds_raw[];
+  unsigned int* h = reinterpret_cast<unsigned int*>(lds_raw);     // [NP] counts, then running positions
+  unsigned int* base = h + NP;                                     // [NP] reserved start within the partition's list
+  const int64_t per = (n_chunks + gridDim.x - 1) / gridDim.x;
+  const int64_t beg = (int64_t)blockIdx.x * per, end = beg + per < n_chunks ? beg + per : n_chunks;
+  for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  for (int64_t c = beg + threadIdx.x; c < end; c += blockDim.x) { const unsigned int p = chunk_part[c]; if (p != kNoChunk) atomicAdd(&h[p], 1u); }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) { base[i] = h[i] ? atomicAdd(&cursor[i], h[i]) : 0u; h[i] = 0; }
+  __syncthreads();
+  for (int64_t c = beg + threadIdx.x; c < end; c += blockDim.x) {
+    const unsigned int p = chunk_part[c];
+    if (p == kNoChunk) continue;
+    cl_ids[cl_off[p] + base[p] + atomicAdd(&h[p], 1u)] = (unsigned int)c;
+  }
+}
+// groups of the hot keys -> appended to the dense output (a hot key whose rows were all filtered out has LEN == 0: no group)
+__global__ __launch_bounds__(kBlock) void hot_emit_kernel(const unsigned long long* __restrict__ hot_keys, const unsigned long long* __restrict__ hot_out, uint32_t n_hot, int n_aggs,
+                                                          int len_idx, unsigned long long* __restrict__ counter, unsigned int* __restrict__ overflow, uint32_t max_groups,
+                                                          unsigned long long* __restrict__ out_keys, unsigned char* __restrict__ out_kvalid, unsigned long long* __restrict__ out_acc) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= n_hot || hot_out[(size_t)h * n_aggs + len_idx] == 0) return;
+  const unsigned long long o = atomicAdd(counter, 1ull);
+  if (o >= max_groups) { atomicExch(overflow, 2u); return; }
+  out_keys[o] = hot_keys[h]; out_kvalid[o] = 1;
+  for (int k = 0; k < n_aggs; k++) out_acc[o * n_aggs + k] = hot_out[(size_t)h * n_aggs + k];
+}
+
+#ifdef PLX_HAVE_Q3_SHAPES
+#define PLX_PART2_STATIC_CASES(KERNEL, MODE, ...)                                                                                        \
+  case SHAPE_GB_SUM_CNT_I64: hipLaunchKernelGGL((KERNEL<StatProg<SHAPE_GB_SUM_CNT_I64>, MODE>), __VA_ARGS__); break;                      \
+  case SHAPE_GB_SUM_MEAN_U32_F64: hipLaunchKernelGGL((KERNEL<StatProg<SHAPE_GB_SUM_MEAN_U32_F64>, MODE>), __VA_ARGS__); break;
+#else
+#define PLX_PART2_STATIC_CASES(KERNEL, MODE, ...)
+#endif
+
+// Runs scatter -> chunk sort -> aggregate (+ hot groups).  Outputs (allocated here): dense keys / valid flags / cells.
+// Returns the number of groups, -1 if an LDS table overflowed or no specialised kernel is available (the caller falls back).
+int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pp, int static_id, const std::vector<uint64_t>& hot_keys, Buf* out_keys, Buf* out_kvalid,
+                         Buf* out_acc, std::string* desc) {
+  const uint32_t NP = 1u << pp.log2_parts;
+  const bool direct = pp.mode == kP2Direct;
+  const bool is_static = static_id == SHAPE_GB_SUM_CNT_I64 || static_id == SHAPE_GB_SUM_MEAN_U32_F64;   // the cases of PLX_PART2_STATIC_CASES
+  const jit::Sink jk_scatter = direct ? jit::PART2_SCATTER_DIRECT : jit::PART2_SCATTER_HASH, jk_agg = direct ? jit::PART2_AGG_DIRECT : jit::PART2_AGG_HASH;
+  const bool use_jit = !is_static && jit::ensure(sh, jk_scatter, args.n_rows) && jit::ensure(sh, jk_agg, args.n_rows);
+  if (!is_static && !use_jit) return -1;
+  PLX_REQUIRE(pp.n_hot == hot_keys.size(), PLX_ERR_INVALID, "partitioned_agg2: plan / hot key list mismatch");
+  const uint32_t chunk_dw = kP2ChunkRecs * pp.rec_words;
+  const int64_t n_chunks = (int64_t)pp.scatter_grid * pp.chunks_per_wg;
+  Buf recs = dev_alloc((size_t)n_chunks * chunk_dw * 4 + 256);
+  Buf chunk_part = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks), chunk_fill = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks);
+  PLX_HIP(hipMemsetAsync(chunk_part->ptr, 0xff, sizeof(uint32_t) * (size_t)n_chunks, stream()));
+  Buf meta = dev_alloc_zero(64);             // [0..1] group counter (u64), [2] aggregation overflow, [3..4] scatter flags
+  // hot-key lookup table (host-built open addressing, same hash as the kernel) and their accumulators
+  const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0;
+  std::vector<uint64_t> h_keys(std::max<uint32_t>(hot_slots, 1), kEmptyKey), h_list(hot_keys);
+  std::vector<uint32_t> h_idx(std::max<uint32_t>(hot_slots, 1), 0);
+  Buf hot_tbl_keys, hot_tbl_idx, hot_out, hot_list;
+  if (pp.n_hot) {
+    for (uint32_t i = 0; i < pp.n_hot; i++) {
+      uint32_t s = (uint32_t)((hot_keys[i] * 0x9e3779b97f4a7c15ull) >> (64 - pp.log2_hot_slots));
+      while (h_keys[s] != kEmptyKey) s = (s + 1) & (hot_slots - 1);
+      h_keys[s] = hot_keys[i]; h_idx[s] = i;
+    }
+    hot_tbl_keys = dev_alloc(sizeof(uint64_t) * hot_slots); hot_tbl_idx = dev_alloc(sizeof(uint32_t) * hot_slots);
+    hot_list = dev_alloc(sizeof(uint64_t) * pp.n_hot);
+    hot_out = dev_alloc(sizeof(uint64_t) * (size_t)pp.n_hot * sh.n_aggs);
+    h2d_async(hot_tbl_keys->ptr, h_keys.data(), sizeof(uint64_t) * hot_slots);
+    h2d_async(hot_tbl_idx->ptr, h_idx.data(), sizeof(uint32_t) * hot_slots);
+    h2d_async(hot_list->ptr, h_list.data(), sizeof(uint64_t) * pp.n_hot);
+    init_agg_cells(hot_out->as<uint64_t>(), pp.n_hot, sh);
+  }
+  ScatterParams2 sp{};
+  sp.recs = recs->as<unsigned int>(); sp.chunk_part = chunk_part->as<unsigned int>(); sp.chunk_fill = chunk_fill->as<unsigned int>();
+  sp.flags = meta->as<unsigned int>() + 3;
+  sp.hot_tbl_keys = pp.n_hot ? hot_tbl_keys->as<unsigned long long>() : nullptr; sp.hot_tbl_idx = pp.n_hot ? hot_tbl_idx->as<unsigned int>() : nullptr;
+  sp.hot_out = pp.n_hot ? hot_out->as<unsigned long long>() : nullptr;
+  const size_t slds = part2_scatter_lds(NP, pp.ring_lines, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies);
+  {
+    // pass traffic: inputs read once + every surviving row written as one record (upper bound: all rows)
+    ProfileScope ps("part2_scatter", scan_bytes(sh, args) + (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
+    if (use_jit) {
+      Shape shc = sh; Args ac = args; PartPlan2 ppc = pp; ScatterParams2 spc = sp;
+      void* ka[] = {&shc, &ac, &ppc, &spc};
+      PLX_REQUIRE(jit::launch_raw(sh, jk_scatter, ka, (int)pp.scatter_grid, (int)pp.block, slds), PLX_ERR_HIP, "jit launch failed (part2_scatter)");
+    } else if (direct) {
+      switch (static_id) { PLX_PART2_STATIC_CASES(part2_scatter_kernel, (int)kP2Direct, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; }
+    } else {
+      switch (static_id) { PLX_PART2_STATIC_CASES(part2_scatter_kernel, (int)kP2Hash, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; }
+    }
+    PLX_HIP(hipGetLastError());
+  }
+  // chunk lists
+  Buf counts = dev_alloc_zero(sizeof(uint32_t) * (NP + 1)), cursor = dev_alloc_zero(sizeof(uint32_t) * (NP + 1));
+  Buf cl_off = dev_alloc(sizeof(uint64_t) * (NP + 2)), cl_ids = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks);
+  {
+    ProfileScope ps("part2_chunk_sort", (uint64_t)n_chunks * 12, (uint64_t)n_chunks);
+    const int g = grid_for(n_chunks, kBlock * 16, 2);
+    hipLaunchKernelGGL(chunk_hist_kernel, dim3(g), dim3(kBlock), sizeof(unsigned int) * NP, stream(), chunk_part->as<unsigned int>(), n_chunks, NP, counts->as<unsigned int>());
+    PLX_HIP(hipGetLastError());
+    exclusive_scan_u32(counts->as<uint32_t>(), cl_off->as<uint64_t>(), NP);
+    hipLaunchKernelGGL(chunk_place_kernel, dim3(g), dim3(kBlock), sizeof(unsigned int) * NP * 2, stream(), chunk_part->as<unsigned int>(), n_chunks, NP,
+                       cl_off->as<unsigned long long>(), cursor->as<unsigned int>(), cl_ids->as<unsigned int>());
+    PLX_HIP(hipGetLastError());
+  }
+  const uint64_t n_slots = direct ? ((uint64_t)1 << pp.log2_slots) : (((uint64_t)1 << pp.log2_slots) + 2);
+  const uint64_t max_groups = std::min<uint64_t>((uint64_t)NP * n_slots + pp.n_hot, (uint64_t)args.n_rows + 1);
+  *out_keys = dev_alloc(sizeof(uint64_t) * max_groups);
+  *out_kvalid = dev_alloc(max_groups);
+  *out_acc = dev_alloc(sizeof(uint64_t) * max_groups * sh.n_aggs);
+  AggParams2 ap{};
+  ap.recs = recs->as<unsigned int>(); ap.chunk_fill = chunk_fill->as<unsigned int>(); ap.cl_off = cl_off->as<unsigned long long>(); ap.cl_ids = cl_ids->as<unsigned int>();
+  ap.counter = meta->as<unsigned long long>(); ap.overflow = meta->as<unsigned int>() + 2;
+  ap.out_keys = (*out_keys)->as<unsigned long long>(); ap.out_kvalid = (*out_kvalid)->as<unsigned char>(); ap.out_acc = (*out_acc)->as<unsigned long long>();
+  ap.max_groups = (uint32_t)std::min<uint64_t>(max_groups, 0xffffffffull);
+  {
+    ProfileScope ps("part2_agg_lds", (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
+    const size_t lds = n_slots * 8 * ((direct ? 0 : 1) + sh.n_aggs);
+    if (use_jit) {
+      PartPlan2 ppc = pp; AggParams2 apc = ap;
+      void* ka[] = {&ppc, &apc};
+      PLX_REQUIRE(jit::launch_raw(sh, jk_agg, ka, (int)NP, kP2AggBlock, lds), PLX_ERR_HIP, "jit launch failed (part2_agg)");
+    } else if (direct) {
+      switch (static_id) { PLX_PART2_STATIC_CASES(part2_agg_kernel, (int)kP2Direct, dim3(NP), dim3(kP2AggBlock), lds, stream(), pp, ap) default: break; }
+    } else {
+      switch (static_id) { PLX_PART2_STATIC_CASES(part2_agg_kernel, (int)kP2Hash, dim3(NP), dim3(kP2AggBlock), lds, stream(), pp, ap) default: break; }
+    }
+    PLX_HIP(hipGetLastError());
+  }
+  if (pp.n_hot) {
+    hipLaunchKernelGGL(hot_emit_kernel, dim3((pp.n_hot + kBlock - 1) / kBlock), dim3(kBlock), 0, stream(), hot_list->as<unsigned long long>(), hot_out->as<unsigned long long>(), pp.n_hot,
+                       (int)sh.n_aggs, (int)pp.len_idx, ap.counter, ap.overflow, ap.max_groups, ap.out_keys, ap.out_kvalid, ap.out_acc);
+    PLX_HIP(hipGetLastError());
+  }
+  uint32_t res[5] = {0, 0, 0, 0, 0};
+  d2h_sync(res, meta->ptr, 20);
+  PLX_REQUIRE(!res[3], PLX_ERR_INVALID, "partitioned group-by: a scatter workgroup ran out of chunks");
+  PLX_REQUIRE(!res[4], PLX_ERR_INVALID, "group key outside the bounds declared for its column (plx_column_set_bounds)");
+  if (res[2]) return -1;
+  if (desc) *desc = std::string("partitioned(v2,") + (direct ? "direct" : "hash") + ",P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec_words * 4) + "B,ring=" + std::to_string(pp.ring_lines * 128) +
+                    "B,block=" + std::to_string(pp.block) + ",hot=" + std::to_string(pp.n_hot) + ")+" + (direct ? "lds_direct_table(slots=" : "lds_hash_table(slots=") + std::to_string(1u << pp.log2_slots) + ")";
+  return (int64_t)(((uint64_t)res[1] << 32) | res[0]);
 }
 
 }  // namespace k

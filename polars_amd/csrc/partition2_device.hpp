@@ -1,0 +1,431 @@
+// partition2_device.hpp -- device side of the partitioned high-cardinality group-by, second generation (see
+// kernels_partition.hip for the pipeline).  Device-only header: compiled ahead of time by kernels_partition.hip for the
+// benchmark shapes and at run time by hiprtc (jit.cpp) for any other program shape.
+//
+//   scatter  one 1024-thread workgroup per CU streams its rounds of the input (the fused program: predicate, key,
+//            aggregate sources), turns every surviving row into a packed dword record and appends it to its partition's
+//            LDS ring (one returning ds_add_u64 on {limit:fill} per row); after a barrier the waves write every COMPLETE
+//            128-B line of every ring to the partition's current chunk (8 lanes x 16 B per line, 8 lines per store
+//            instruction: full aligned lines only).  Chunks (256 records) come from the workgroup's PRIVATE region, handed
+//            out by an LDS counter: no counting pass, no global atomics, no cross-workgroup coordination.  Rows of hot keys
+//            (heavy hitters found in a sample) never reach the rings: they are aggregated in LDS accumulators on the spot.
+//   sort     the chunk -> partition map is counting-sorted into per-partition chunk lists (three tiny kernels).
+//   agg      one workgroup per partition (launched as a grid of P: the hardware balances them) walks the partition's
+//            chunk list, double-buffered, into an LDS open-addressing table (hash mode) or an LDS direct-address table
+//            (direct mode: dense packed ids, no key compare at all) and writes its groups straight to the dense output.
+#pragma once
+#include "fused_device.hpp"
+
+namespace plx {
+namespace k {
+
+constexpr int kP2MaxBlock = 1024;
+constexpr int kP2AggBlock = 1024;
+
+struct ScatterParams2 {
+  unsigned int* recs;                       // record pool: chunk c = dwords [c * chunk_dw, (c + 1) * chunk_dw)
+  unsigned int* chunk_part;                 // [scatter_grid * chunks_per_wg] partition of a chunk (kNoChunk: never handed out)
+  unsigned int* chunk_fill;                 // records in the chunk
+  unsigned int* flags;                      // [0] a workgroup ran out of chunks (cannot happen by construction; checked), [1] a dense id outside its declared range
+  const unsigned long long* hot_tbl_keys;   // [1 << log2_hot_slots] open-addressing lookup of the hot keys (kEmptyKey = free)
+  const unsigned int* hot_tbl_idx;          // hot-key ordinal of the slot
+  unsigned long long* hot_out;              // [n_hot][n_aggs] cells, device-scope atomics at the end of the kernel
+};
+
+struct AggParams2 {
+  const unsigned int* recs;
+  const unsigned int* chunk_fill;
+  const unsigned long long* cl_off;         // [P + 1] offsets into cl_ids
+  const unsigned int* cl_ids;               // chunk ids grouped by partition
+  unsigned long long* counter;              // [0] groups written so far
+  unsigned int* overflow;                   // [0] 1: an LDS table filled up, 2: output capacity exceeded
+  unsigned long long* out_keys;
+  unsigned char* out_kvalid;
+  unsigned long long* out_acc;
+  uint32_t max_groups;
+};
+
+__device__ __forceinline__ uint32_t part2_of(uint64_t key, bool kvalid, uint32_t log2_parts) {
+  if (!kvalid) return 0;   // null_partition() == 0 (hashing.rs:111-115)
+  return (uint32_t)((key * 0x55fbfd6bfc5458e9ull) >> (64 - log2_parts));
+}
+
+// LDS layout of the scatter kernel (dynamic shared memory), in this order:
+//   ring    [P][ring_dw] u32        staging rings (ring_dw = ring_lines * 32)
+//   fl      [P] u64                 {limit : fill}: records appended to the current chunk so far (low), most that fit (high)
+//   hot_k   [hot_slots] u64, hot_acc [n_hot * n_aggs * copies] u64
+//   fdw     [P] u32                 dwords of the current chunk already written to HBM
+//   chunk   [P] u32                 current chunk (kNoChunk: none yet)
+//   hot_i   [hot_slots] u32
+//   misc    [4] u32                 [0] next chunk of this workgroup's region
+__host__ __device__ inline size_t part2_scatter_lds(uint32_t P, uint32_t ring_lines, uint32_t hot_slots, uint32_t n_hot, uint32_t n_aggs, uint32_t copies) {
+  return (size_t)P * ring_lines * 128 + (size_t)P * 8 + (size_t)hot_slots * 8 + (size_t)n_hot * n_aggs * copies * 8 + (size_t)P * 4 * 2 + (size_t)hot_slots * 4 + 16;
+}
+
+// ---- one row -> record dwords ---------------------------------------------------------------------------------------
+template <int MODE, class S, class RF>
+__device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, const PartPlan2& pp, const RF& rf, int r, int64_t row, unsigned int* rec /* [L.rec_words] */,
+                                             uint32_t& part, bool& kvalid, uint64_t& key64) {
+  kvalid = (rf.getv(sh.key) >> r) & 1;
+  key64 = kvalid ? rf.get(r, sh.key) : 0ull;
+  if constexpr (MODE == (int)kP2Direct) {
+    part = (uint32_t)(key64 >> pp.key_shift);
+    rec[0] = (uint32_t)key64 & ((1u << pp.key_shift) - 1u);
+  } else {
+    part = part2_of(key64, kvalid, pp.log2_parts);
+    rec[0] = (uint32_t)key64;
+    if (L.key_words == 2) rec[1] = (uint32_t)(key64 >> 32);
+  }
+  uint32_t vbits = kvalid ? (1u << 31) : 0u;
+#pragma unroll
+  for (int j = 0; j < kMaxSrc; j++) {
+    if (j < (int)L.n_src) {
+      const uint64_t v = rf.get(r, L.src_slot[j]);
+      rec[L.src_off[j]] = (uint32_t)v;
+      if (!L.src_kind[j]) rec[L.src_off[j] + 1] = (uint32_t)(v >> 32);
+      if ((rf.getv(L.src_slot[j]) >> r) & 1) vbits |= 1u << j;
+    }
+  }
+  if (L.has_valid) rec[L.valid_off] = vbits;
+  if (L.has_rowid) { rec[L.rowid_off] = (uint32_t)(uint64_t)row; rec[L.rowid_off + 1] = (uint32_t)((uint64_t)row >> 32); }
+}
+
+// ---- the scatter kernel ------------------------------------------------------------------------------------------------
+template <class P, int MODE>
+__device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args args, const PartPlan2 pp, const ScatterParams2 sp) {
+  static_assert(P::kStatic, "the partitioned group-by runs specialised programs only (AOT or JIT)");
+  extern __shared__ unsigned long long p2_lds[];
+  constexpr Shape sh = P::shape();
+  constexpr RecLayout2 L = rec_layout2(P::shape(), (uint32_t)MODE);
+  constexpr uint32_t RW = L.rec_words;
+  constexpr uint32_t chunk_dw = kP2ChunkRecs * RW;
+  const uint32_t NP = 1u << pp.log2_parts, ring_dw = pp.ring_lines * 32u, ring_mask = ring_dw - 1u;
+  const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0u;
+  unsigned int* ring = reinterpret_cast<unsigned int*>(p2_lds);
+  unsigned long long* fl = p2_lds + (size_t)NP * ring_dw / 2;
+  unsigned long long* hot_k = fl + NP;
+  unsigned long long* hot_acc = hot_k + hot_slots;
+  unsigned int* fdw = reinterpret_cast<unsigned int*>(hot_acc + (size_t)pp.n_hot * sh.n_aggs * pp.hot_copies);
+  unsigned int* chunk = fdw + NP;
+  unsigned int* hot_i = chunk + NP;
+  unsigned int* misc = hot_i + hot_slots;
+  const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const uint32_t first_limit = ring_dw / RW < kP2ChunkRecs ? ring_dw / RW : kP2ChunkRecs;
+  for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) { fl[i] = (unsigned long long)first_limit << 32; fdw[i] = 0; chunk[i] = kNoChunk; }
+  for (uint32_t i = threadIdx.x; i < hot_slots; i += blockDim.x) { hot_k[i] = sp.hot_tbl_keys[i]; hot_i[i] = sp.hot_tbl_idx[i]; }
+  for (uint32_t i = threadIdx.x; i < pp.n_hot * sh.n_aggs * pp.hot_copies; i += blockDim.x) hot_acc[i] = agg_identity_dev(sh.aggs[(i / pp.hot_copies) % sh.n_aggs].kind);
+  if (threadIdx.x == 0) misc[0] = 0;
+  __syncthreads();
+  const uint32_t chunk0 = blockIdx.x * pp.chunks_per_wg;     // this workgroup's private chunk region
+  // partitions a lane owns in the flush phase: wave w, lane l < lanes_per_wave owns partition w * lanes_per_wave + l
+  const uint32_t lanes_per_wave = NP >= (uint32_t)nwaves ? NP / (uint32_t)nwaves : 1u;
+  const bool owner = NP >= (uint32_t)nwaves ? ((uint32_t)lane < lanes_per_wave) : ((uint32_t)wave < NP && lane == 0);
+  const uint32_t own_p = NP >= (uint32_t)nwaves ? (uint32_t)wave * lanes_per_wave + (uint32_t)lane : (uint32_t)wave;
+
+  const int64_t rows_per_round = (int64_t)blockDim.x * kRows;
+  const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
+  auto row0_of = [&](int64_t rd) { return (rd * nwaves + wave) * (int64_t)kTileRows + (int64_t)lane * kRows; };
+  auto round_full = [&](int64_t rd) { return (rd + 1) * rows_per_round <= args.n_rows; };
+  RegFile rf{};
+  unsigned int rec[kRows][RW];
+  uint32_t part[kRows];
+  bool pending[kRows];
+  // evaluates round rd (its column loads may already be in flight) and leaves its rows in rec / part / pending; rows of hot
+  // keys are aggregated here and never become pending
+  auto finish_round = [&](int64_t rd, bool preloaded) {
+    bool pass[kRows];
+    const int64_t row0 = row0_of(rd);
+    if (preloaded) {
+      run_rest_full<P>(args, row0, rf);
+#pragma unroll
+      for (int r = 0; r < kRows; r++) pass[r] = sh.pred == kNone || ((rf.get(r, sh.pred) & 1) && ((rf.getv(sh.pred) >> r) & 1));
+    } else {
+      int64_t r0;
+      tile_rows<P>(dsh, args, rd * nwaves + wave, rf, pass, r0);
+    }
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      bool kvalid; uint64_t key64;
+      make_record2<MODE>(sh, L, pp, rf, r, row0 + r, rec[r], part[r], kvalid, key64);
+      pending[r] = pass[r];
+      if (MODE == (int)kP2Direct && part[r] >= NP) { if (pass[r]) sp.flags[1] = 1u; pending[r] = false; }   // id outside the declared range: the query fails
+      if (pp.n_hot && pass[r] && kvalid && key64 != kEmptyKey) {
+        uint32_t s = (uint32_t)((key64 * 0x9e3779b97f4a7c15ull) >> (64 - pp.log2_hot_slots));
+        int hot = -1;
+        for (;;) {
+          const unsigned long long hk = hot_k[s];
+          if (hk == key64) { hot = (int)hot_i[s]; break; }
+          if (hk == kEmptyKey) break;
+          s = (s + 1) & (hot_slots - 1);
+        }
+        if (hot >= 0) {
+          pending[r] = false;
+          unsigned long long* cell = hot_acc + (size_t)hot * sh.n_aggs * pp.hot_copies + ((uint32_t)lane & (pp.hot_copies - 1));
+#pragma unroll
+          for (int k = 0; k < kMaxAggs; k++) {
+            if (k < sh.n_aggs) {
+              const Agg ag = sh.aggs[k];
+              const uint64_t v = ag.src != kNone ? rf.get(r, ag.src) : 0ull;
+              const bool valid = ag.src != kNone ? ((rf.getv(ag.src) >> r) & 1) : true;
+              const uint64_t x = agg_row_value(ag.kind, v, true, valid, (uint64_t)(row0 + r));
+              if ((x != agg_identity_dev(ag.kind) || ag.kind == AGG_SUM_F) && !(ag.kind == AGG_SUM_F && !valid)) lds_atomic_agg(ag.kind, cell + (size_t)k * pp.hot_copies, x);
+            }
+          }
+        }
+      }
+    }
+  };
+  auto issue_loads = [&](int64_t rd) -> bool {
+    if (rd < nrounds && round_full(rd)) { run_loads_full<P>(args, row0_of(rd), rf); return true; }
+    return false;
+  };
+  // writes every complete line of the rings this lane owns to HBM and opens / closes chunks; `final_pass` also writes the
+  // partial tail and records the fill of the last chunk
+  auto flush_phase = [&](bool final_pass) {
+    uint32_t fill = 0, lim = 0, f_dw = 0, ch = kNoChunk, nl = 0;
+    if (owner) {
+      const unsigned long long f = fl[own_p];
+      lim = (uint32_t)(f >> 32);
+      fill = (uint32_t)f < lim ? (uint32_t)f : lim;          // appends past the limit failed: they stay pending and come back
+      f_dw = fdw[own_p]; ch = chunk[own_p];
+      const uint32_t avail = fill * RW;
+      const uint32_t target = fill >= kP2ChunkRecs ? chunk_dw : (avail & ~31u);
+      nl = (target - f_dw) >> 5;
+      if ((nl || (final_pass && avail > f_dw)) && ch == kNoChunk) {
+        const uint32_t local = atomicAdd(&misc[0], 1u);
+        if (local >= pp.chunks_per_wg) { sp.flags[0] = 1u; nl = 0; fill = 0; }
+        else { ch = chunk0 + local; sp.chunk_part[ch] = own_p; }
+      }
+    }
+    uint32_t done = 0;
+    for (;;) {
+      const uint64_t m = ballot(done < nl);
+      if (!m) break;
+      const int rank = prefix_rank(m);
+      const int g = lane >> 3, sub = lane & 7;
+      int src_lane = -1;
+      {
+        uint64_t mm = m;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          if (mm) { const int o = (int)__builtin_ctzll(mm); mm &= mm - 1; if (g == i) src_lane = o; }
+        }
+      }
+      const uint32_t my_src = own_p * ring_dw + ((((f_dw >> 5) + done) & (pp.ring_lines - 1u)) << 5);
+      const uint64_t my_dst = (uint64_t)ch * chunk_dw + f_dw + done * 32u;
+      const int from = src_lane < 0 ? 0 : src_lane;
+      const uint32_t src = (uint32_t)__shfl((int)my_src, from, 64);
+      const uint64_t dst = shfl_u64(my_dst, from);
+      if (src_lane >= 0) {
+        const uint4 v = *reinterpret_cast<const uint4*>(ring + src + sub * 4);
+        *reinterpret_cast<uint4*>(sp.recs + dst + sub * 4) = v;
+      }
+      if (done < nl && rank < 8) done++;
+    }
+    if (owner) {
+      f_dw += nl * 32u;
+      if (final_pass && ch != kNoChunk) {
+        const uint32_t avail = fill * RW;
+        for (uint32_t w = f_dw; w < avail; w++) sp.recs[(uint64_t)ch * chunk_dw + w] = ring[own_p * ring_dw + (w & ring_mask)];
+        sp.chunk_fill[ch] = fill;
+      } else if (fill >= kP2ChunkRecs && f_dw == chunk_dw) {       // chunk complete: the next flush opens a new one
+        sp.chunk_fill[ch] = kP2ChunkRecs;
+        ch = kNoChunk; f_dw = 0; fill = 0;
+      }
+      uint32_t nlim = (f_dw + ring_dw) / RW;
+      if (nlim > kP2ChunkRecs) nlim = kP2ChunkRecs;
+      fl[own_p] = ((unsigned long long)nlim << 32) | fill;
+      fdw[own_p] = f_dw; chunk[own_p] = ch;
+    }
+  };
+
+  if ((int64_t)blockIdx.x < nrounds) finish_round(blockIdx.x, issue_loads(blockIdx.x));
+  for (int64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
+    const int64_t rd_next = rd + gridDim.x;
+    // round rd's rows sit in rec[]: the register file is free, so the NEXT round's column loads are issued now and only
+    // consumed after this round's appends and flushes (barriers do not drain vmcnt)
+    const bool preloaded = issue_loads(rd_next);
+    int any;
+    do {
+      bool mine = false;
+#pragma unroll
+      for (int r = 0; r < kRows; r++) {
+        if (!pending[r]) continue;
+        const unsigned long long old = atomicAdd(&fl[part[r]], 1ull);
+        const uint32_t pos = (uint32_t)old, lim = (uint32_t)(old >> 32);
+        if (pos < lim) {
+          unsigned int* base = ring + (size_t)part[r] * ring_dw;
+          const uint32_t d0 = pos * RW;
+#pragma unroll
+          for (uint32_t w = 0; w < RW; w++) base[(d0 + w) & ring_mask] = rec[r][w];
+          pending[r] = false;
+        } else mine = true;
+      }
+      any = __syncthreads_or(mine ? 1 : 0);
+      flush_phase(false);
+      __syncthreads();
+    } while (any);
+    if (rd_next < nrounds) finish_round(rd_next, preloaded);
+  }
+  flush_phase(true);
+  if (pp.n_hot) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < pp.n_hot * sh.n_aggs; i += blockDim.x) {
+      const uint8_t kind = sh.aggs[i % sh.n_aggs].kind;
+      uint64_t x = hot_acc[(size_t)i * pp.hot_copies];
+      for (uint32_t c = 1; c < pp.hot_copies; c++) x = agg_combine(kind, x, hot_acc[(size_t)i * pp.hot_copies + c]);
+      if (x != agg_identity_dev(kind) || kind == AGG_SUM_F) atomic_agg(kind, sp.hot_out + i, x);
+    }
+  }
+}
+
+template <class P, int MODE>
+__global__ __launch_bounds__(kP2MaxBlock) void part2_scatter_kernel(Shape dsh, Args args, PartPlan2 pp, ScatterParams2 sp) {
+  part2_scatter_body<P, MODE>(dsh, args, pp, sp);
+}
+
+// ---- the aggregation kernel --------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) RecWords3 { unsigned int a, b, c; };
+template <uint32_t RW>
+__device__ __forceinline__ void load_rec2(const unsigned int* p, unsigned int* r) {
+  if constexpr (RW == 4) { const uint4 v = *reinterpret_cast<const uint4*>(p); r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+  else if constexpr (RW == 3) { const RecWords3 v = *reinterpret_cast<const RecWords3*>(p); r[0] = v.a; r[1] = v.b; r[2] = v.c; }
+  else if constexpr (RW == 2) { const uint2 v = *reinterpret_cast<const uint2*>(p); r[0] = v.x; r[1] = v.y; }
+  else {
+#pragma unroll
+    for (uint32_t w = 0; w < RW; w++) r[w] = p[w];
+  }
+}
+
+template <class S, int MODE>
+__device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L, const PartPlan2& pp, const AggParams2& ap) {
+  extern __shared__ unsigned long long p2_lds[];
+  constexpr uint32_t kPerLane = kP2ChunkRecs / 64;    // records of a chunk per lane
+  const uint32_t NS = 1u << pp.log2_slots, n_aggs = sh.n_aggs, RW = L.rec_words, chunk_dw = kP2ChunkRecs * RW;
+  const bool direct = MODE == (int)kP2Direct;
+  unsigned long long* keys = p2_lds;                                    // hash mode: [NS + 2] (NS = null key, NS + 1 = the key equal to EMPTY)
+  unsigned long long* cells = direct ? p2_lds : keys + NS + 2;          // [(NS (+2)) * n_aggs]
+  const uint32_t n_slots = direct ? NS : NS + 2;
+  __shared__ unsigned int n_occ, cursor_l, full;
+  __shared__ unsigned long long gbase;
+  const uint32_t p = blockIdx.x;
+  if (!direct) for (uint32_t i = threadIdx.x; i < n_slots; i += blockDim.x) keys[i] = kEmptyKey;
+  for (uint32_t i = threadIdx.x; i < n_slots * n_aggs; i += blockDim.x) cells[i] = agg_identity_dev(sh.aggs[i % n_aggs].kind);
+  if (threadIdx.x == 0) { n_occ = 0; cursor_l = 0; full = 0; }
+  __syncthreads();
+  const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const uint64_t c_beg = ap.cl_off[p], c_end = ap.cl_off[p + 1];
+  unsigned int cur[kPerLane][16], nxt[kPerLane][16];   // [..][RW] (RW <= 13); unused words are never touched
+  uint32_t cnt_cur = 0, cnt_nxt = 0;
+  auto load_chunk = [&](uint64_t j, unsigned int (*dst)[16], uint32_t& cnt) {
+    cnt = 0;
+    if (j >= c_end) return;
+    const uint32_t id = ap.cl_ids[j];
+    cnt = ap.chunk_fill[id];
+    const unsigned int* base = ap.recs + (uint64_t)id * chunk_dw;
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      const uint32_t i = (uint32_t)lane + u * 64u;
+      if (i < cnt) {
+        switch (RW) {
+          case 2: load_rec2<2>(base + (size_t)i * 2, dst[u]); break;
+          case 3: load_rec2<3>(base + (size_t)i * 3, dst[u]); break;
+          case 4: load_rec2<4>(base + (size_t)i * 4, dst[u]); break;
+          default:
+#pragma unroll
+            for (uint32_t w = 0; w < 16; w++) if (w < RW) dst[u][w] = base[(size_t)i * RW + w];
+            break;
+        }
+      }
+    }
+  };
+  load_chunk(c_beg + (uint64_t)wave, nxt, cnt_nxt);
+  for (uint64_t j = c_beg + (uint64_t)wave; j < c_end; j += (uint64_t)nwaves) {
+    cnt_cur = cnt_nxt;
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+#pragma unroll
+      for (uint32_t w = 0; w < 16; w++) if (w < RW) cur[u][w] = nxt[u][w];
+    }
+    load_chunk(j + (uint64_t)nwaves, nxt, cnt_nxt);
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      const uint32_t i = (uint32_t)lane + u * 64u;
+      if (i >= cnt_cur) continue;
+      const unsigned int* rec = cur[u];
+      const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
+      const uint64_t rowid = L.has_rowid ? ((uint64_t)rec[L.rowid_off] | ((uint64_t)rec[L.rowid_off + 1] << 32)) : 0ull;
+      uint32_t slot;
+      if (direct) slot = rec[0];
+      else {
+        uint64_t key;
+        if (L.key_words == 2) key = (uint64_t)rec[0] | ((uint64_t)rec[1] << 32);
+        else key = L.key_kind == 1 ? (uint64_t)(long long)(int)rec[0] : (uint64_t)rec[0];
+        if (!(vbits >> 31)) { slot = NS; keys[NS] = 0; }
+        else if (key == kEmptyKey) { slot = NS + 1; keys[NS + 1] = 0; }
+        else {
+          slot = (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> (64 - pp.log2_slots));   // a second hash: the partition consumed the top bits of the first
+          uint32_t probe = 0;
+          for (;; probe++) {
+            const unsigned long long c = keys[slot];
+            if (c == key) break;
+            if (c == kEmptyKey) {
+              const unsigned long long old = atomicCAS(&keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
+              if (old == kEmptyKey || old == key) break;
+            }
+            slot = (slot + 1) & (NS - 1);
+            if (probe >= NS) { full = 1; break; }
+          }
+          if (probe >= NS) continue;
+        }
+      }
+      unsigned long long* cell = cells + (size_t)slot * n_aggs;
+#pragma unroll
+      for (uint32_t k = 0; k < (uint32_t)kMaxAggs; k++) {
+        if (k >= n_aggs) break;
+        const uint8_t kind = sh.aggs[k].kind;
+        const uint8_t sj = L.agg_src[k];
+        uint64_t v = 0ull;
+        bool valid = true;
+        if (sj != kNone) {
+          const uint32_t lo = rec[L.src_off[sj]];
+          v = L.src_kind[sj] == 0 ? ((uint64_t)lo | ((uint64_t)rec[L.src_off[sj] + 1] << 32)) : (L.src_kind[sj] == 1 ? (uint64_t)(long long)(int)lo : (uint64_t)lo);
+          valid = (vbits >> sj) & 1;
+        }
+        const uint64_t x = agg_row_value(kind, v, true, valid, rowid);
+        if (x != agg_identity_dev(kind) || kind == AGG_SUM_F) {
+          if (kind == AGG_SUM_F && !valid) continue;
+          lds_atomic_agg(kind, cell + k, x);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (full) { if (threadIdx.x == 0) atomicExch(ap.overflow, 1u); return; }
+  // emit the partition's groups: count, reserve once, write
+  uint32_t mine = 0;
+  for (uint32_t s = threadIdx.x; s < n_slots; s += blockDim.x) mine += direct ? (cells[(size_t)s * n_aggs + pp.len_idx] != 0) : (keys[s] != kEmptyKey);
+  if (mine) atomicAdd(&n_occ, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) gbase = n_occ ? atomicAdd(ap.counter, (unsigned long long)n_occ) : 0ull;
+  __syncthreads();
+  if (gbase + n_occ > ap.max_groups) { if (threadIdx.x == 0) atomicExch(ap.overflow, 2u); return; }
+  for (uint32_t s = threadIdx.x; s < n_slots; s += blockDim.x) {
+    if (direct ? (cells[(size_t)s * n_aggs + pp.len_idx] == 0) : (keys[s] == kEmptyKey)) continue;
+    const uint64_t o = gbase + atomicAdd(&cursor_l, 1u);
+    if (direct) { ap.out_keys[o] = ((uint64_t)p << pp.key_shift) | s; ap.out_kvalid[o] = 1; }
+    else { ap.out_keys[o] = s < NS ? keys[s] : (s == NS ? 0ull : kEmptyKey); ap.out_kvalid[o] = s == NS ? 0 : 1; }
+    for (uint32_t k = 0; k < n_aggs; k++) ap.out_acc[o * n_aggs + k] = cells[(size_t)s * n_aggs + k];
+  }
+}
+
+template <class P, int MODE>
+__global__ __launch_bounds__(kP2AggBlock) void part2_agg_kernel(PartPlan2 pp, AggParams2 ap) {
+  static_assert(P::kStatic, "the partitioned group-by runs specialised programs only (AOT or JIT)");
+  constexpr Shape csh = P::shape();
+  constexpr RecLayout2 cl = rec_layout2(P::shape(), (uint32_t)MODE);
+  part2_agg_body<Shape, MODE>(csh, cl, pp, ap);
+}
+
+}  // namespace k
+}  // namespace plx

@@ -32,9 +32,17 @@ class Series:
         if _handle:
             self._h = _handle
             self.dtype = _dtype if _dtype is not None else self._query_dtype()
+            self._declare_dictionary_bounds()
             return
         F.ensure_init()
         self._h, self.dtype = _upload(values, dtype, validity)
+        self._declare_dictionary_bounds()
+
+    def _declare_dictionary_bounds(self) -> None:
+        """Dictionary codes lie in [0, len(categories)): tell the planner (plx_column_set_bounds), which then groups / joins
+        on them with dense tables without a statistics pass over the column."""
+        if isinstance(self.dtype, T.Categorical) and self.dtype.categories:
+            F.check(F.lib().plx_column_set_bounds(self._h, 0, len(self.dtype.categories) - 1))
 
     # -- construction ----------------------------------------------------------------------
     @classmethod

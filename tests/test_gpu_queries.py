@@ -537,3 +537,79 @@ def test_sharded_q3_per_rank_pieces(pl, orc):
     # single-process run() is the plain local pipeline
     full = q.run({c: dev(li[c]) for c in datagen.LINEITEM_Q3_COLS}, {c: dev(orders[c]) for c in datagen.ORDERS_Q3_COLS})
     assert sorted(full["l_orderkey"].cpu().tolist()) == exp["l_orderkey"].tolist()
+
+
+@pytest.mark.parametrize("case", ["zipf", "one_hot_key"])
+def test_partitioned_groupby_skewed_keys(pl, case):
+    """Skew THROUGH the partitioned path (>= 2^25 rows, ~1e6 distinct keys): zipf s = 1.1 and one key holding half of the rows.
+    The heavy hitters found in the strided sample are aggregated in the scatter pass (the role of the reference's HotGrouper,
+    polars-expr/src/hot_groups/fixed_index_table.rs:19-165) and never reach a partition; the result must match numpy exactly."""
+    rng = np.random.default_rng(44)
+    n = 1 << 25
+    if case == "zipf":
+        key = ((rng.zipf(1.1, n) - 1) % 1_000_000).astype(np.int64)
+    else:
+        key = rng.integers(0, 1_000_000, n).astype(np.int64)
+        key[rng.random(n) < 0.5] = 777_777
+    key = key * 1_000_003 - 5                                   # not a dense range: the hash path, raw 64-bit keys
+    v = rng.integers(-1000, 1000, n).astype(np.int64)
+    df = pl.DataFrame({"key": key, "v": v})
+    out = df.lazy().group_by("key").agg(pl.col("v").sum().alias("s"), pl.col("v").count().alias("c")).collect()
+    plan = pl.last_plan()
+    assert "partitioned(v2,hash" in plan and "hot=0" not in plan, plan      # hot keys were found and used
+    gk = out["key"].to_numpy(); order = np.argsort(gk)
+    uk, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+    assert np.array_equal(gk[order], uk)
+    assert np.array_equal(out["s"].to_numpy()[order], np.bincount(inv, weights=v).astype(np.int64))
+    assert np.array_equal(out["c"].to_numpy()[order].astype(np.int64), cnt)
+
+
+def test_partitioned_groupby_direct_mode_dense_ids(pl):
+    """Dense packed ids (two narrow key columns + a dictionary column with declared bounds) at >= 2^24 rows: range partitions and
+    direct-address LDS tables (no key compare, 4-byte keys in the records); null keys travel as their own code."""
+    rng = np.random.default_rng(45)
+    n = 17_500_000
+    a = rng.integers(0, 300, n).astype(np.int16)
+    b = rng.integers(-20, 20, n).astype(np.int8)
+    bv = rng.random(n) > 0.01
+    x = rng.uniform(-1, 1, n)
+    xv = rng.random(n) > 0.2
+    df = pl.DataFrame([pl.Series("a", a), pl.Series("b", b, validity=bv), pl.Series("x", x, validity=xv)])
+    q = df.lazy().group_by("a", "b").agg(pl.col("x").sum().alias("s"), pl.col("x").count().alias("c"), pl.col("x").max().alias("mx"), pl.len().alias("n"))
+    out = q.collect(); plan = pl.last_plan()
+    assert "partitioned(v2,direct" in plan and "lds_direct_table" in plan, plan
+    ref = q.collect(no_partition=True)
+    assert "hbm_table" in pl.last_plan() or "lds_table" in pl.last_plan(), pl.last_plan()
+    d1, d2 = out.to_dict(), ref.to_dict()
+    kf = lambda d, i: (d["a"][i], d["b"][i] is None, d["b"][i] or 0)
+    o1 = sorted(range(out.height), key=lambda i: kf(d1, i)); o2 = sorted(range(ref.height), key=lambda i: kf(d2, i))
+    assert out.height == ref.height == 300 * 41                 # every (a, b) pair incl. b = null occurs in 1.75e7 rows
+    for c in ("a", "b", "c", "n"):
+        assert [d1[c][i] for i in o1] == [d2[c][i] for i in o2], c
+    for c in ("s", "mx"):
+        fa = np.array([np.nan if z is None else z for z in (d1[c][i] for i in o1)]); fb = np.array([np.nan if z is None else z for z in (d2[c][i] for i in o2)])
+        assert np.allclose(fa, fb, rtol=RTOL, atol=1e-9, equal_nan=True), c
+    # numpy check of one aggregate
+    sel = bv & (a == 7) & (b == 3)
+    i = next(j for j in range(out.height) if d1["a"][j] == 7 and d1["b"][j] == 3)
+    assert d1["n"][i] == int(sel.sum()) and d1["c"][i] == int((sel & xv).sum()) and math.isclose(d1["s"][i], float(x[sel & xv].sum()), rel_tol=1e-9, abs_tol=1e-9)
+
+
+def test_declared_bounds_are_checked_not_trusted_blindly(pl):
+    """plx_column_set_bounds (dictionary size, Parquet statistics): a value outside the declared bounds must fail the query (or be
+    kept out of every table), never write outside a table."""
+    from polars_amd import queries
+    rng = np.random.default_rng(46)
+    n = 17_000_000
+    codes = rng.integers(0, 500_000, n).astype(np.uint32)
+    v = rng.uniform(0, 100, n)
+    ok = pl.DataFrame([pl.Series("k", codes, dtype=pl.Categorical(["c%d" % i for i in range(500_000)], pl.UInt32)), pl.Series("v", v)])
+    out = queries.cfg5(ok.lazy()).collect(); plan = pl.last_plan()
+    assert "partitioned(v2,direct" in plan, plan
+    k1 = out["k"].to_numpy(); o1 = np.argsort(k1)
+    s = np.bincount(codes, v); cnt = np.bincount(codes); present = np.nonzero(cnt)[0]
+    assert np.array_equal(k1[o1], present) and close(out["v_sum"].to_numpy()[o1], s[present]) and close(out["v_mean"].to_numpy()[o1], s[present] / cnt[present])
+    bad_codes = codes.copy(); bad_codes[12345] = 3_000_000        # not a code of the 500 000-entry dictionary
+    bad = pl.DataFrame([pl.Series("k", bad_codes, dtype=pl.Categorical(["c%d" % i for i in range(500_000)], pl.UInt32)), pl.Series("v", v)])
+    with pytest.raises(pl.PlxError):
+        queries.cfg5(bad.lazy()).collect()

@@ -37,7 +37,9 @@ def test_aot_kernels_do_not_spill():
             checked += 1
             assert int(r["ScratchSize [bytes/lane]"]) == 0, (name, r)
             assert int(r["VGPRs"]) <= 256, (name, r)
-    assert checked >= 18, checked
+            if "part2_" in name:       # 1024-thread workgroups (16 waves per CU): 128 VGPRs at most
+                assert int(r["VGPRs"]) <= 128, (name, r)
+    assert checked >= 26, checked
 
 
 def test_sort_join_datagen_kernels_do_not_spill():
