@@ -1244,34 +1244,32 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     const uint64_t ord_cap = (uint64_t)B->height + (uint64_t)k::scan_waves(B->height) * 1024 + 1024;
     if (range128 <= ((unsigned __int128)1 << 34) && range128 <= (unsigned __int128)B->height * 256 && ord_cap < 0xfffffff0ull) {
       const uint64_t range = (uint64_t)range128;
-      const size_t n_words = (size_t)(range / 64 + 1);
-      Buf bits = dev_alloc_zero(sizeof(uint64_t) * n_words), rank = dev_alloc(sizeof(uint64_t) * (n_words + 1));
+      const size_t n_blocks = (size_t)(range / 512 + 1), n_words = n_blocks * 8;
+      Buf bits = dev_alloc_zero(sizeof(uint64_t) * n_words), rank = dev_alloc(sizeof(uint64_t) * (n_blocks + 1));
       Buf okey = dev_alloc(sizeof(uint64_t) * ord_cap), orow = dev_alloc(sizeof(uint32_t) * ord_cap), used = dev_alloc_zero(sizeof(uint32_t) * (ord_cap / 1024 + 2));
-      Buf meta = dev_alloc_zero(32);   // [0] ordinal counter, [2..3] flags, [4..5] pairs placed (u64)
+      Buf meta = dev_alloc_zero(32);   // [0] ordinal counter, [2..3] flags, [4..5] pairs appended (u64)
       DirectJoinTable dt; dt.bits = bits->as<unsigned long long>(); dt.rank = rank->as<unsigned long long>(); dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>();
       dt.chunk_used = used->as<unsigned int>(); dt.counter = meta->as<unsigned int>(); dt.flags = meta->as<unsigned int>() + 2; dt.acc = nullptr; dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)ord_cap;
       k::fused_direct_build(cb.shape, cb.args, dt, find_static_shape(cb.shape));
-      nb = k::direct_rank(dt, rank->as<uint64_t>());              // synchronises: flags and the ordinal counter are final too
+      // every wave closes its last chunk when it finishes, so chunk_used is final once the build scan is: the rank launch counts
+      // the pairs over the whole reserved capacity (the ordinal counter itself is only read back with the rank's sync)
+      uint64_t pairs = 0;
+      nb = k::direct_rank(dt, rank->as<uint64_t>(), (int64_t)ord_cap, meta->as<uint64_t>() + 2, &pairs);   // synchronises: flags and the ordinal counter are final too
       uint32_t m4[4] = {0, 0, 0, 0};
       d2h_sync(m4, meta->ptr, 16);
       PLX_REQUIRE(!m4[3], PLX_ERR_INVALID, "direct join build: ordinal overflow");
+      if (pairs != nb) return no("build keys are not unique");   // two pairs shared a bit: the hash-table pipeline handles (and reports) duplicates
       const uint32_t n_used = m4[0];
       const int64_t n_slots = (int64_t)nb, s1 = std::max<int64_t>(n_slots, 1);
-      Buf skey = dev_alloc(sizeof(uint64_t) * (size_t)s1), srow = dev_alloc(sizeof(uint32_t) * (size_t)s1);
-      uint64_t* n_pairs_dev = meta->as<uint64_t>() + 2;
-      k::direct_place(dt, (int64_t)std::min<uint64_t>(n_used, ord_cap), skey->as<uint64_t>(), srow->as<uint32_t>(), n_pairs_dev);
       Buf acc2 = dev_alloc(sizeof(uint64_t) * (size_t)s1 * cp.shape.n_aggs);
       k::init_agg_cells(acc2->as<uint64_t>(), s1, cp.shape);   // LEN = 0: build rows no probe row matched never show up
-      dt.ord_key = skey->as<unsigned long long>(); dt.ord_row = srow->as<unsigned int>(); dt.acc = acc2->as<unsigned long long>();
+      dt.acc = acc2->as<unsigned long long>();
       k::fused_direct_probe_agg(cp.shape, cp.args, dt, probe_static_id);
-      // one compaction pass into buffers sized for every slot (G <= n_slots)
+      // one pass over the pair list into buffers sized for every slot (G <= n_slots)
       r.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)s1);
       r.acc = dev_alloc(sizeof(uint64_t) * (size_t)s1 * r.n_aggs);
       rows->values = dev_alloc(values_bytes(PLX_U32, s1));
-      G = n_slots ? k::direct_agg_compact(dt, n_slots, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>()) : 0;
-      uint64_t pairs = 0;
-      d2h_sync(&pairs, n_pairs_dev, 8);          // the stream is idle after the compaction's own sync: no extra wait
-      if (pairs != nb) return no("build keys are not unique");   // two pairs shared a bit: the hash-table pipeline handles (and reports) duplicates
+      G = n_slots ? k::direct_agg_compact(dt, (int64_t)std::min<uint64_t>(n_used, ord_cap), r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>()) : 0;
       r.n_groups = G;
       rows->len = G;
       plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " direct-address table range=" +

@@ -325,19 +325,21 @@ struct JoinAggTable {
 
 // Direct-address ("perfect hash") variant of the fused join -> aggregate table, used when the build
 // key range is small (max - min + 1 <= a few x the build rows, e.g. TPC-H orderkeys).  One BIT per key of the
-// range says whether a build row with that key passed the build predicate; rank[w] = number of set bits
-// before word w, so slot(key) = rank[w] + popc(bits[w] below the key's bit) numbers the build rows in key
-// order.  bits + rank are range/8 + range/8 bytes (150 MB for the 6e8 TPC-H SF100 orderkeys: resident in the
-// 256 MB Infinity Cache), where one u32 per key was 2.4 GB to memset and to miss in.
-//   build : the scan appends (key, row) pairs in per-wave ordinal chunks and sets the key's bit (a bit that was
-//           already set = duplicate build key -> the caller falls back);
-//   rank  : popcount per word -> device exclusive scan;
-//   place : pairs move to their slot (slot_key / slot_row, key order);
-//   probe : bit test + rank -> the row's aggregates land in acc[slot].
+// range says whether a build row with that key passed the build predicate; rank[b] = number of set bits before the
+// 512-bit block b (8 words = one 64-B line), so slot(key) = rank[b] + popc(words of the block before the key's word) +
+// popc(bits below the key's bit) numbers the build rows in key order.  bits + rank are range/8 + range/64 bytes (75 + 9 MB
+// for the 6e8 TPC-H SF100 orderkeys: resident in the 256 MB Infinity Cache, the rank array in the L2s), where one u32
+// per key was 2.4 GB to memset and to miss in.
+//   build  : the scan appends (key, row) pairs in per-wave ordinal chunks and sets the key's bit;
+//   rank   : popcount per block -> device exclusive scan; the pairs are counted too: more pairs than set bits = a
+//            duplicate build key -> the caller falls back BEFORE the probe;
+//   probe  : bit test + rank -> the row's aggregates land in acc[slot];
+//   output : ONE pass over the pair list: pairs whose slot was hit by a probe row are compacted together with their cells
+//            (no key-ordered copy of the pairs, no pass over the slots).
 struct DirectJoinTable {
-  unsigned long long* bits;      // [range / 64 + 1]
-  const unsigned long long* rank; // [range / 64 + 2] exclusive prefix of popcounts (valid after the rank step)
-  unsigned long long* ord_key;   // build: pair list [n_ord]; probe / compact: slot_key [n_slots]
+  unsigned long long* bits;      // [(range / 512 + 1) * 8] bitmap words, padded to whole blocks
+  const unsigned long long* rank; // [range / 512 + 2] exclusive prefix of the per-block popcounts (valid after the rank step)
+  unsigned long long* ord_key;   // pair list [n_ord]
   unsigned int* ord_row;         // same, build row
   unsigned int* chunk_used;      // [n_ord / kOrdChunk + 1] ordinals handed out of each reserved chunk
   unsigned int* counter;         // [0] next ordinal chunk base

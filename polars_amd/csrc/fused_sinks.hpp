@@ -313,9 +313,22 @@ struct ProbeAggSink {
 // and sub-allocates from them (one atomic per wave-row on a single counter word took 26 ms for the 1.5e8-row
 // TPC-H orders scan; ~12 k atomics this way).  Unused tails of chunks stay empty (LEN cell 0).
 constexpr unsigned int kOrdChunk = 1024;
-// slot of key index idx (its bit is set in `word` = bits[idx >> 6]): build rows numbered in key order
+// slot of key index idx (its bit is set in `word` = bits[idx >> 6]): build rows numbered in key order.  The block's other
+// words share the 64-B line of `word`: the extra loads hit the line that is already on its way.
 __device__ __forceinline__ unsigned long long direct_slot(const DirectJoinTable& t, unsigned long long idx, unsigned long long word) {
-  return t.rank[idx >> 6] + (unsigned long long)__popcll(word & ((1ull << (idx & 63)) - 1ull));
+  const unsigned long long w = idx >> 6, blk = w >> 3;
+  const unsigned int in_blk = (unsigned int)(w & 7);
+  const ulonglong2* line = reinterpret_cast<const ulonglong2*>(t.bits + (blk << 3));
+  const ulonglong2 a = line[0], b = line[1], c = line[2], d = line[3];
+  unsigned int before = 0;
+  before += in_blk > 0 ? (unsigned int)__popcll(a.x) : 0u;
+  before += in_blk > 1 ? (unsigned int)__popcll(a.y) : 0u;
+  before += in_blk > 2 ? (unsigned int)__popcll(b.x) : 0u;
+  before += in_blk > 3 ? (unsigned int)__popcll(b.y) : 0u;
+  before += in_blk > 4 ? (unsigned int)__popcll(c.x) : 0u;
+  before += in_blk > 5 ? (unsigned int)__popcll(c.y) : 0u;
+  before += in_blk > 6 ? (unsigned int)__popcll(d.x) : 0u;
+  return t.rank[blk] + before + (unsigned long long)__popcll(word & ((1ull << (idx & 63)) - 1ull));
 }
 struct DirectBuildSink {
   using Params = DirectJoinTable;
@@ -348,7 +361,7 @@ struct DirectBuildSink {
       p.ord_key[ord] = key;
       p.ord_row[ord] = (unsigned int)(row0 + r);
       // fire-and-forget (no-return) atomic: a duplicate build key shows up as popcount(bits) < number of pairs,
-      // which the place step counts (the caller then falls back)
+      // which the rank step counts (the caller then falls back)
       __hip_atomic_fetch_or(&p.bits[idx >> 6], 1ull << (idx & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

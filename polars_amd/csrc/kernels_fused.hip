@@ -309,62 +309,62 @@ void fused_direct_probe_agg(const Shape& sh, const Args& args, const DirectJoinT
   }
   PLX_HIP(hipGetLastError());
 }
-// rank step of the direct-address join table: popcount per bitmap word (scanned by exclusive_scan_u32)
-__global__ __launch_bounds__(kBlock) void direct_popc_kernel(const unsigned long long* __restrict__ bits, int64_t n_words, uint32_t* __restrict__ counts) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) counts[i] = (uint32_t)__popcll(bits[i]);
-}
-// place step: the (key, row) pairs appended by the build scan move to their key-ordered slot
-// n_pairs[0] += pairs placed: fewer set bits than pairs = duplicate build keys
-__global__ __launch_bounds__(kBlock) void direct_place_kernel(DirectJoinTable t, int64_t n_used, unsigned long long* __restrict__ slot_key, unsigned int* __restrict__ slot_row,
-                                                              unsigned long long* __restrict__ n_pairs) {
-  unsigned int mine = 0;
-  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_used; o += (int64_t)gridDim.x * blockDim.x) {
-    if ((unsigned int)(o % kOrdChunk) >= t.chunk_used[o / kOrdChunk]) continue;   // unused tail of a reserved chunk
-    const unsigned long long key = t.ord_key[o];
-    const unsigned long long idx = key - (unsigned long long)t.kmin;
-    const unsigned long long s = direct_slot(t, idx, t.bits[idx >> 6]);
-    slot_key[s] = key;
-    slot_row[s] = t.ord_row[o];
-    mine++;
+// rank step of the direct-address join table: popcount per 512-bit block (one 64-B line per thread), scanned by
+// exclusive_scan_u32; the same launch adds up the ordinals handed out of the pair-list chunks (pairs appended by the build scan)
+__global__ __launch_bounds__(kBlock) void direct_popc_kernel(const unsigned long long* __restrict__ bits, int64_t n_blocks, uint32_t* __restrict__ counts,
+                                                             const unsigned int* __restrict__ chunk_used, int64_t n_chunks, unsigned long long* __restrict__ n_pairs) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks; i += (int64_t)gridDim.x * blockDim.x) {
+    const ulonglong2* line = reinterpret_cast<const ulonglong2*>(bits + (i << 3));
+    const ulonglong2 a = line[0], b = line[1], c = line[2], d = line[3];
+    counts[i] = (uint32_t)(__popcll(a.x) + __popcll(a.y) + __popcll(b.x) + __popcll(b.y) + __popcll(c.x) + __popcll(c.y) + __popcll(d.x) + __popcll(d.y));
   }
+  unsigned long long mine = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_chunks; i += (int64_t)gridDim.x * blockDim.x) mine += chunk_used[i];
   const uint64_t w = wave_sum_u64(mine);
   if (lane_id() == 0 && w) atomicAdd(n_pairs, (unsigned long long)w);
 }
-uint64_t direct_rank(const DirectJoinTable& t, uint64_t* rank_out) {
-  const int64_t n_words = (int64_t)(t.range / 64 + 1);
-  Buf counts = dev_alloc(sizeof(uint32_t) * (size_t)n_words);
-  ProfileScope ps("direct_rank", (uint64_t)n_words * 20, (uint64_t)n_words);
-  hipLaunchKernelGGL(direct_popc_kernel, dim3(grid_for(n_words, kBlock * 4)), dim3(kBlock), 0, stream(), t.bits, n_words, counts->as<uint32_t>());
-  PLX_HIP(hipGetLastError());
-  exclusive_scan_u32(counts->as<uint32_t>(), rank_out, n_words);
-  uint64_t total = 0;
-  d2h_sync(&total, rank_out + n_words, 8);
-  return total;
-}
-void direct_place(const DirectJoinTable& t, int64_t n_used, uint64_t* slot_key, uint32_t* slot_row, uint64_t* n_pairs_dev) {
-  if (n_used == 0) return;
-  ProfileScope ps("direct_place", (uint64_t)n_used * 24, (uint64_t)n_used);
-  hipLaunchKernelGGL(direct_place_kernel, dim3(grid_for(n_used, kBlock * 2)), dim3(kBlock), 0, stream(), t, n_used, (unsigned long long*)slot_key, (unsigned int*)slot_row,
+// -> set bits (= distinct build keys that passed); *pairs_out = pairs appended by the build scan (synchronises)
+uint64_t direct_rank(const DirectJoinTable& t, uint64_t* rank_out, int64_t n_used, uint64_t* n_pairs_dev, uint64_t* pairs_out) {
+  const int64_t n_blocks = (int64_t)(t.range / 512 + 1);
+  const int64_t n_chunks = (n_used + kOrdChunk - 1) / kOrdChunk;
+  Buf counts = dev_alloc(sizeof(uint32_t) * (size_t)n_blocks);
+  ProfileScope ps("direct_rank", (uint64_t)n_blocks * 76, (uint64_t)n_blocks);
+  hipLaunchKernelGGL(direct_popc_kernel, dim3(grid_for(n_blocks, kBlock * 2)), dim3(kBlock), 0, stream(), t.bits, n_blocks, counts->as<uint32_t>(), t.chunk_used, n_chunks,
                      (unsigned long long*)n_pairs_dev);
   PLX_HIP(hipGetLastError());
+  exclusive_scan_u32(counts->as<uint32_t>(), rank_out, n_blocks);
+  uint64_t total = 0;
+  d2h_sync(&total, rank_out + n_blocks, 8);
+  if (pairs_out) d2h_sync(pairs_out, n_pairs_dev, 8);     // the stream is idle: no extra wait
+  return total;
 }
 
-__global__ __launch_bounds__(kBlock) void direct_agg_compact_kernel(DirectJoinTable t, int64_t n_ord, int n_aggs, int len_idx, unsigned long long* __restrict__ counter,
-                                                                    unsigned long long* __restrict__ out_keys, unsigned int* __restrict__ out_rows,
-                                                                    unsigned long long* __restrict__ out_acc) {
-  compact_slots(n_ord, counter, [&](int64_t s) { return t.acc[(size_t)s * n_aggs + len_idx] != 0; },
-                [&](int64_t s, uint64_t o) {
+// output step: pairs whose slot received at least one probe row (LEN cell != 0) -> dense (key, build row, cells)
+__global__ __launch_bounds__(kBlock) void direct_pairs_compact_kernel(DirectJoinTable t, int64_t n_used, int n_aggs, int len_idx, unsigned long long* __restrict__ counter,
+                                                                      unsigned long long* __restrict__ out_keys, unsigned int* __restrict__ out_rows,
+                                                                      unsigned long long* __restrict__ out_acc) {
+  auto slot_of = [&](int64_t o) -> unsigned long long {
+    const unsigned long long idx = t.ord_key[o] - (unsigned long long)t.kmin;
+    return direct_slot(t, idx, t.bits[idx >> 6]);
+  };
+  compact_slots(n_used, counter,
+                [&](int64_t o) {
+                  if ((unsigned int)(o % kOrdChunk) >= t.chunk_used[o / kOrdChunk]) return false;   // unused tail of a reserved chunk
+                  return t.acc[(size_t)slot_of(o) * n_aggs + len_idx] != 0;
+                },
+                [&](int64_t o, uint64_t out) {
                   if (!out_keys) return;
-                  out_keys[o] = t.ord_key[s];
-                  out_rows[o] = t.ord_row[s];
-                  for (int k = 0; k < n_aggs; k++) out_acc[o * n_aggs + k] = t.acc[(size_t)s * n_aggs + k];
+                  const unsigned long long s = slot_of(o);
+                  out_keys[out] = t.ord_key[o];
+                  out_rows[out] = t.ord_row[o];
+                  for (int k = 0; k < n_aggs; k++) out_acc[out * n_aggs + k] = t.acc[(size_t)s * n_aggs + k];
                 });
 }
-int64_t direct_agg_compact(const DirectJoinTable& t, int64_t n_ord, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc) {
-  if (n_ord == 0) return 0;
+int64_t direct_agg_compact(const DirectJoinTable& t, int64_t n_used, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc) {
+  if (n_used == 0) return 0;
   Buf counter = dev_alloc_zero(8);
-  ProfileScope ps("table_compact", (uint64_t)n_ord * 8 * (uint64_t)(2 + n_aggs), (uint64_t)n_ord);
-  hipLaunchKernelGGL(direct_agg_compact_kernel, dim3(compact_grid(n_ord)), dim3(kBlock), 0, stream(), t, n_ord, n_aggs, len_idx, counter->as<unsigned long long>(),
+  ProfileScope ps("table_compact", (uint64_t)n_used * 8 * (uint64_t)(2 + n_aggs), (uint64_t)n_used);
+  hipLaunchKernelGGL(direct_pairs_compact_kernel, dim3(compact_grid(n_used)), dim3(kBlock), 0, stream(), t, n_used, n_aggs, len_idx, counter->as<unsigned long long>(),
                      (unsigned long long*)out_keys, (unsigned int*)out_rows, (unsigned long long*)out_acc);
   PLX_HIP(hipGetLastError());
   uint64_t n = 0;

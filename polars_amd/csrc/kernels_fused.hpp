@@ -37,12 +37,11 @@ int64_t scan_waves(int64_t n_rows);
 // direct-address variants (DirectJoinTable)
 void fused_direct_build(const fused::Shape& sh, const fused::Args& args, const fused::DirectJoinTable& t, int static_id);
 void fused_direct_probe_agg(const fused::Shape& sh, const fused::Args& args, const fused::DirectJoinTable& t, int static_id);
-// rank step (popcount per bitmap word + exclusive scan into rank_out[range/64 + 2]); returns the number of set bits (synchronises)
-uint64_t direct_rank(const fused::DirectJoinTable& t, uint64_t* rank_out);
-// place step: pair list (t.ord_key / t.ord_row / t.chunk_used, first n_used ordinals) -> key-ordered slots
-// n_pairs_dev[0] (zeroed by the caller) receives the number of pairs placed: more pairs than set bits = duplicate build keys
-void direct_place(const fused::DirectJoinTable& t, int64_t n_used, uint64_t* slot_key, uint32_t* slot_row, uint64_t* n_pairs_dev);
-int64_t direct_agg_compact(const fused::DirectJoinTable& t, int64_t n_ord, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc);
+// rank step (popcount per 512-bit block + exclusive scan into rank_out[range/512 + 2]); returns the number of set bits and, in
+// *pairs_out, the pairs the build scan appended (n_pairs_dev: a zeroed device word); more pairs than bits = duplicate build keys (synchronises)
+uint64_t direct_rank(const fused::DirectJoinTable& t, uint64_t* rank_out, int64_t n_used, uint64_t* n_pairs_dev, uint64_t* pairs_out);
+// output step: one pass over the first n_used ordinals of the pair list: pairs whose slot has a non-zero AGG_LEN cell -> out_keys / out_rows / out_acc
+int64_t direct_agg_compact(const fused::DirectJoinTable& t, int64_t n_used, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc);
 void fill_u64(uint64_t* p, int64_t n, uint64_t v);
 void init_agg_cells(uint64_t* acc, int64_t n_slots, const fused::Shape& sh);
 // Gather occupied table slots into dense arrays; returns the group count (synchronises).

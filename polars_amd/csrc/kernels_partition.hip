@@ -341,9 +341,14 @@ __global__ __launch_bounds__(kBlock) void hot_emit_kernel(const unsigned long lo
 #define PLX_PART2_STATIC_CASES(KERNEL, MODE, ...)                                                                                        \
   case SHAPE_GB_SUM_CNT_I64: hipLaunchKernelGGL((KERNEL<StatProg<SHAPE_GB_SUM_CNT_I64>, MODE>), __VA_ARGS__); break;                      \
   case SHAPE_GB_SUM_MEAN_U32_F64: hipLaunchKernelGGL((KERNEL<StatProg<SHAPE_GB_SUM_MEAN_U32_F64>, MODE>), __VA_ARGS__); break;
+#define PLX_PART2_STATIC_SCATTER_CASES(MODE, DEPTH, ...)                                                                                 \
+  case SHAPE_GB_SUM_CNT_I64: hipLaunchKernelGGL((part2_scatter_kernel<StatProg<SHAPE_GB_SUM_CNT_I64>, MODE, DEPTH>), __VA_ARGS__); break; \
+  case SHAPE_GB_SUM_MEAN_U32_F64: hipLaunchKernelGGL((part2_scatter_kernel<StatProg<SHAPE_GB_SUM_MEAN_U32_F64>, MODE, DEPTH>), __VA_ARGS__); break;
 #else
 #define PLX_PART2_STATIC_CASES(KERNEL, MODE, ...)
+#define PLX_PART2_STATIC_SCATTER_CASES(MODE, DEPTH, ...)
 #endif
+static const int kEnvP2Depth = env_int("PLX_PART_PREFETCH", 1, 2);       // rounds of column loads in flight (AOT shapes; default 2)
 
 // Runs scatter -> chunk sort -> aggregate (+ hot groups).  Outputs (allocated here): dense keys / valid flags / cells.
 // Returns the number of groups, -1 if an LDS table overflowed or no specialised kernel is available (the caller falls back).
@@ -394,10 +399,12 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pp,
       Shape shc = sh; Args ac = args; PartPlan2 ppc = pp; ScatterParams2 spc = sp;
       void* ka[] = {&shc, &ac, &ppc, &spc};
       PLX_REQUIRE(jit::launch_raw(sh, jk_scatter, ka, (int)pp.scatter_grid, (int)pp.block, slds), PLX_ERR_HIP, "jit launch failed (part2_scatter)");
-    } else if (direct) {
-      switch (static_id) { PLX_PART2_STATIC_CASES(part2_scatter_kernel, (int)kP2Direct, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; }
+    } else if (kEnvP2Depth == 1) {
+      if (direct) { switch (static_id) { PLX_PART2_STATIC_SCATTER_CASES((int)kP2Direct, 1, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; } }
+      else { switch (static_id) { PLX_PART2_STATIC_SCATTER_CASES((int)kP2Hash, 1, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; } }
     } else {
-      switch (static_id) { PLX_PART2_STATIC_CASES(part2_scatter_kernel, (int)kP2Hash, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; }
+      if (direct) { switch (static_id) { PLX_PART2_STATIC_SCATTER_CASES((int)kP2Direct, 2, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; } }
+      else { switch (static_id) { PLX_PART2_STATIC_SCATTER_CASES((int)kP2Hash, 2, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; } }
     }
     PLX_HIP(hipGetLastError());
   }

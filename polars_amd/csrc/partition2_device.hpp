@@ -91,7 +91,8 @@ __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, c
 }
 
 // ---- the scatter kernel ------------------------------------------------------------------------------------------------
-template <class P, int MODE>
+// DEPTH = rounds whose column loads are in flight while a round is appended and flushed (one register file per round in flight)
+template <class P, int MODE, int DEPTH = 1>
 __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args args, const PartPlan2 pp, const ScatterParams2 sp) {
   static_assert(P::kStatic, "the partitioned group-by runs specialised programs only (AOT or JIT)");
   extern __shared__ unsigned long long p2_lds[];
@@ -126,13 +127,13 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
   auto row0_of = [&](int64_t rd) { return (rd * nwaves + wave) * (int64_t)kTileRows + (int64_t)lane * kRows; };
   auto round_full = [&](int64_t rd) { return (rd + 1) * rows_per_round <= args.n_rows; };
-  RegFile rf{};
+  RegFile rfs[DEPTH] = {};
   unsigned int rec[kRows][RW];
   uint32_t part[kRows];
   bool pending[kRows];
   // evaluates round rd (its column loads may already be in flight) and leaves its rows in rec / part / pending; rows of hot
   // keys are aggregated here and never become pending
-  auto finish_round = [&](int64_t rd, bool preloaded) {
+  auto finish_round = [&](int64_t rd, bool preloaded, RegFile& rf) {
     bool pass[kRows];
     const int64_t row0 = row0_of(rd);
     if (preloaded) {
@@ -175,7 +176,7 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
       }
     }
   };
-  auto issue_loads = [&](int64_t rd) -> bool {
+  auto issue_loads = [&](int64_t rd, RegFile& rf) -> bool {
     if (rd < nrounds && round_full(rd)) { run_loads_full<P>(args, row0_of(rd), rf); return true; }
     return false;
   };
@@ -239,33 +240,40 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
     }
   };
 
-  if ((int64_t)blockIdx.x < nrounds) finish_round(blockIdx.x, issue_loads(blockIdx.x));
-  for (int64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
-    const int64_t rd_next = rd + gridDim.x;
-    // round rd's rows sit in rec[]: the register file is free, so the NEXT round's column loads are issued now and only
-    // consumed after this round's appends and flushes (barriers do not drain vmcnt)
-    const bool preloaded = issue_loads(rd_next);
-    int any;
-    do {
-      bool mine = false;
+  // Round k of this workgroup lives in register file k % DEPTH.  Per round: its rows are evaluated (loads issued DEPTH rounds
+  // ago) and copied into rec[]; the register file is then free, so the loads of round k + DEPTH are issued at once and stay
+  // in flight while round k is appended and flushed (barriers do not drain vmcnt).
+  bool pre[DEPTH];
 #pragma unroll
-      for (int r = 0; r < kRows; r++) {
-        if (!pending[r]) continue;
-        const unsigned long long old = atomicAdd(&fl[part[r]], 1ull);
-        const uint32_t pos = (uint32_t)old, lim = (uint32_t)(old >> 32);
-        if (pos < lim) {
-          unsigned int* base = ring + (size_t)part[r] * ring_dw;
-          const uint32_t d0 = pos * RW;
+  for (int d = 0; d < DEPTH; d++) pre[d] = issue_loads((int64_t)blockIdx.x + (int64_t)d * gridDim.x, rfs[d]);
+  for (int64_t rd0 = blockIdx.x; rd0 < nrounds; rd0 += (int64_t)DEPTH * gridDim.x) {
 #pragma unroll
-          for (uint32_t w = 0; w < RW; w++) base[(d0 + w) & ring_mask] = rec[r][w];
-          pending[r] = false;
-        } else mine = true;
-      }
-      any = __syncthreads_or(mine ? 1 : 0);
-      flush_phase(false);
-      __syncthreads();
-    } while (any);
-    if (rd_next < nrounds) finish_round(rd_next, preloaded);
+    for (int d = 0; d < DEPTH; d++) {
+      const int64_t rd = rd0 + (int64_t)d * gridDim.x;
+      if (rd >= nrounds) break;                      // uniform across the workgroup
+      finish_round(rd, pre[d], rfs[d]);
+      pre[d] = issue_loads(rd + (int64_t)DEPTH * gridDim.x, rfs[d]);
+      int any;
+      do {
+        bool mine = false;
+#pragma unroll
+        for (int r = 0; r < kRows; r++) {
+          if (!pending[r]) continue;
+          const unsigned long long old = atomicAdd(&fl[part[r]], 1ull);
+          const uint32_t pos = (uint32_t)old, lim = (uint32_t)(old >> 32);
+          if (pos < lim) {
+            unsigned int* base = ring + (size_t)part[r] * ring_dw;
+            const uint32_t d0 = pos * RW;
+#pragma unroll
+            for (uint32_t w = 0; w < RW; w++) base[(d0 + w) & ring_mask] = rec[r][w];
+            pending[r] = false;
+          } else mine = true;
+        }
+        any = __syncthreads_or(mine ? 1 : 0);
+        flush_phase(false);
+        __syncthreads();
+      } while (any);
+    }
   }
   flush_phase(true);
   if (pp.n_hot) {
@@ -279,9 +287,9 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   }
 }
 
-template <class P, int MODE>
+template <class P, int MODE, int DEPTH = 1>
 __global__ __launch_bounds__(kP2MaxBlock) void part2_scatter_kernel(Shape dsh, Args args, PartPlan2 pp, ScatterParams2 sp) {
-  part2_scatter_body<P, MODE>(dsh, args, pp, sp);
+  part2_scatter_body<P, MODE, DEPTH>(dsh, args, pp, sp);
 }
 
 // ---- the aggregation kernel --------------------------------------------------------------------------------------------

@@ -149,8 +149,31 @@ class Lowering:
             return self._lower_binary(e, schema)
         raise TypeError(f"unsupported expression {e!r}")
 
+    def _lower_string_compare(self, e: Expr, schema: Schema):
+        """Categorical column ==/!= string literal: the string is looked up in the column's dictionary and the physical codes
+        are compared -- what the reference does for a Categorical against a string scalar
+        (crates/polars-core/src/chunked_array/comparison/categorical.rs: the rev-map lookup, then `equal` on the physical).
+        A string that is not in the dictionary equals no row.  Returns None when `e` is not such a comparison."""
+        for col_side, lit_side in ((e.lhs, e.rhs), (e.rhs, e.lhs)):
+            if lit_side.kind == "lit" and isinstance(lit_side.value, str):
+                ci, cdt = self._lower_maybe_dyn(col_side, schema)
+                if isinstance(ci, tuple) or not isinstance(cdt, T.Categorical):
+                    raise TypeError("a string literal can only be compared with a dictionary-encoded (Categorical) column on this path")
+                if e.op not in (F.OP_EQ, F.OP_NE):
+                    raise TypeError("only == and != are supported between a Categorical column and a string")
+                cats = cdt.categories
+                code = cats.index(lit_side.value) if lit_side.value in cats else len(cats)
+                phys = T.PHYSICAL_TO_DTYPE[cdt.physical]
+                if code > int(__import__("numpy").iinfo(phys.np_dtype).max):      # absent string and a full code space: no row can match
+                    return self._lit_node(e.op == F.OP_NE, T.Boolean), T.Boolean
+                lit = self._lit_node(code, phys)
+                return self._push(kind=F.AE_BINARY, op=e.op, lhs=ci, rhs=lit), T.Boolean
+        return None
+
     def _lower_binary(self, e: Expr, schema: Schema):
         op = e.op
+        if (e.lhs.kind == "lit" and isinstance(e.lhs.value, str)) or (e.rhs.kind == "lit" and isinstance(e.rhs.value, str)):
+            return self._lower_string_compare(e, schema)
         li, ldt = self._lower_maybe_dyn(e.lhs, schema)
         ri, rdt = self._lower_maybe_dyn(e.rhs, schema)
         ldyn, rdyn = isinstance(li, tuple), isinstance(ri, tuple)

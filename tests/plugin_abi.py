@@ -72,10 +72,10 @@ def call(name: str, arrays, kwargs=None, parallel=False, names=None):
     if not out.private_data:
         return None, inp
     assert out.len == 1
+    name_out = bytes(out.field.contents.name or b"")          # copied before the schema is consumed by the import below
     res = pa.Array._import_from_c(C.addressof(out.arrays[0].contents), C.addressof(out.field.contents))
-    name_out = out.field.contents.name
-    C.CFUNCTYPE(None, C.POINTER(F.SeriesExport))(out.release)(C.byref(out))
     inp.out_name = name_out
+    C.CFUNCTYPE(None, C.POINTER(F.SeriesExport))(out.release)(C.byref(out))
     return res, inp
 
 
