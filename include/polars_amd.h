@@ -432,6 +432,10 @@ int plx_datagen_orders_lineitem_host(int64_t order0, int64_t n, int64_t n_orders
 /* One uniform column of n rows: value i = lo + floor(U_i * (hi - lo)), U_i from stream `stream` (0..7) of row i;
  * dtype PLX_I64 / PLX_U32: the integer; PLX_F64: the integer times `scale`.  plx_datagen_uniform_host: rows
  * [row0, row0 + n) into a host array of that dtype. */
+/* customer (TPC-H Q3 columns): out_cols[2] = c_custkey (PLX_I64, 1..n in order), c_mktsegment (PLX_U8 codes 0..4 =
+ * AUTOMOBILE, BUILDING, FURNITURE, HOUSEHOLD, MACHINERY); plx_datagen_customer_host: rows [row0, row0 + n) on the CPU. */
+int plx_datagen_customer(int64_t n_customers, uint64_t seed, plx_column* out_cols);
+int plx_datagen_customer_host(int64_t row0, int64_t n, uint64_t seed, int64_t* custkey, uint8_t* segment);
 int plx_datagen_uniform(int32_t dtype, int64_t n_rows, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, double scale, plx_column* out);
 int plx_datagen_uniform_host(int32_t dtype, int64_t row0, int64_t n, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, double scale, void* out);
 

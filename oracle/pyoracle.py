@@ -430,6 +430,31 @@ def q3(li: Dict[str, np.ndarray], orders: Dict[str, np.ndarray], date: int, seg_
             "revenue": r["revenue"][0][order]}
 
 
+def q3_full(customer: Dict[str, np.ndarray], orders: Dict[str, np.ndarray], li: Dict[str, np.ndarray], date: int, segment_code: int) -> Dict[str, np.ndarray]:
+    """TPC-H Q3 with all three tables in the reference's operator order (predicates already pushed below the joins, as the
+    optimizer does): FilterExec on each scan, JoinExec customer x orders on custkey (inner; the joined frame is materialised
+    by gathers, hash_join/single_keys_inner.rs + frame/join/mod.rs:564-652), JoinExec with lineitem on orderkey, the revenue
+    column, GroupByExec on (o_orderkey, o_orderdate, o_shippriority).  Returns rows sorted by o_orderkey."""
+    mc = cmp(EQ, customer["c_mktsegment"], np.array(segment_code, dtype=customer["c_mktsegment"].dtype).item())
+    c = {k: filter(v, None, mc)[0] for k, v in customer.items()}
+    mo = cmp(LT, orders["o_orderdate"], date)
+    o = {k: filter(v, None, mo)[0] for k, v in orders.items()}
+    cidx, oidx, _ = join(JOIN_INNER, c["c_custkey"], None, o["o_custkey"], None)
+    co = {k: gather(v, None, oidx)[0] for k, v in o.items() if k != "o_custkey"}     # right key coalesced into c_custkey
+    co.update({k: gather(v, None, cidx)[0] for k, v in c.items()})
+    ml = cmp(GT, li["l_shipdate"], date)
+    l = {k: filter(v, None, ml)[0] for k, v in li.items()}
+    a_idx, l_idx, _ = join(JOIN_INNER, co["o_orderkey"], None, l["l_orderkey"], None)
+    j = {k: gather(v, None, a_idx)[0] for k, v in co.items()}
+    j.update({k: gather(v, None, l_idx)[0] for k, v in l.items() if k != "l_orderkey"})
+    one_minus, _ = arith(SUB, 1.0, j["l_discount"], mode=2)
+    rev, _ = arith(MUL, j["l_extendedprice"], one_minus)
+    r = q_groupby([j["o_orderkey"], j["o_orderdate"], j["o_shippriority"]], [None, None, None], [("revenue", AGG_SUM, rev, None)])
+    order = np.argsort(r["key_0"][0], kind="stable")
+    return {"o_orderkey": r["key_0"][0][order], "o_orderdate": r["key_1"][0][order], "o_shippriority": r["key_2"][0][order],
+            "revenue": r["revenue"][0][order]}
+
+
 def q1_native(cols: Dict[str, np.ndarray], cutoff: int, streaming: bool = False, morsel: int = 100_000) -> Dict[str, np.ndarray]:
     """TPC-H Q1 end to end in C++ (multi-threaded per orc_set_threads), no Python between the steps.
     streaming=False: orc_q1, the in-memory FilterExec -> GroupByExec sequence (index lists per group);

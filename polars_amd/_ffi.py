@@ -141,6 +141,8 @@ SIGNATURES = {
     "plx_datagen_orders_lineitem_host": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _i64p]),
     "plx_datagen_uniform": (C.c_int, [C.c_int32, C.c_int64, C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, C.c_double, _u64p]),
+    "plx_datagen_customer": (C.c_int, [C.c_int64, C.c_uint64, _u64p]),
+    "plx_datagen_customer_host": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "plx_datagen_uniform_host": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, C.c_double, C.c_void_p]),
     "plx_debug_program_json": (C.c_int, [C.POINTER(IR), C.c_int32, C.POINTER(AExpr), C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
     "plx_sort_indices": (C.c_int, [_u64p, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int64, _u64p]),

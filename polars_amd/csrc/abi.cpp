@@ -710,6 +710,24 @@ int plx_datagen_orders_lineitem_host(int64_t order0, int64_t n, int64_t n_orders
   if (n_lines_out) *n_lines_out = at;
   PLX_CATCH
 }
+int plx_datagen_customer(int64_t n_customers, uint64_t seed, plx_column* out_cols) {
+  PLX_TRY
+  PLX_REQUIRE(n_customers >= 0 && out_cols, PLX_ERR_INVALID, "datagen: bad arguments");
+  ColumnPtr k = make_column(PLX_I64, n_customers, false), sgm = make_column(PLX_U8, n_customers, false);
+  k->null_count = 0; sgm->null_count = 0;
+  k::datagen_customer(n_customers, seed, k->values->as<int64_t>(), sgm->values->as<uint8_t>());
+  out_cols[0] = register_column(k); out_cols[1] = register_column(sgm);
+  PLX_CATCH
+}
+int plx_datagen_customer_host(int64_t row0, int64_t n, uint64_t seed, int64_t* custkey, uint8_t* segment) {
+  PLX_TRY
+  PLX_REQUIRE(row0 >= 0 && n >= 0, PLX_ERR_INVALID, "datagen: bad arguments");
+  for (int64_t j = 0; j < n; j++) {
+    if (custkey) custkey[j] = row0 + j + 1;
+    if (segment) segment[j] = datagen::customer_segment(seed, (uint64_t)(row0 + j + 1));
+  }
+  PLX_CATCH
+}
 int plx_datagen_uniform(int32_t dtype, int64_t n_rows, uint64_t seed, uint32_t stream_id, int64_t lo, int64_t hi, double scale, plx_column* out) {
   PLX_TRY
   PLX_REQUIRE(n_rows >= 0 && out && hi > lo && stream_id < 8, PLX_ERR_INVALID, "datagen: bad arguments");
@@ -779,7 +797,11 @@ int plx_describe_fusion(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, 
     // fused join -> aggregate: three programs (count, build, probe), one per line; the id is the probe program's
     std::vector<fused::Shape> shapes;
     ok = engine::describe_join_fusion(p, root, &shapes, &why);
-    if (ok) { sid = fused::find_static_shape(shapes[2]); t_plan_desc = dump(shapes[0]) + "\n" + dump(shapes[1]) + "\n" + dump(shapes[2]); }
+    if (ok) {   // count, build, probe, then one program per nested filter join (semi filter)
+      sid = fused::find_static_shape(shapes[2]);
+      t_plan_desc = dump(shapes[0]);
+      for (size_t i = 1; i < shapes.size(); i++) t_plan_desc += "\n" + dump(shapes[i]);
+    }
   } else {
     fused::Shape sh{};
     ok = engine::describe_fusion(p, root, &sh, &sid, &why);
@@ -802,6 +824,7 @@ int plx_jit_selftest(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int
     std::vector<fused::Shape> shapes;
     PLX_REQUIRE(engine::describe_join_fusion(p, root, &shapes, &why), PLX_ERR_UNSUPPORTED, "not fusable: " + why);
     jobs = {{shapes[0], jit::REGAGG}, {shapes[1], jit::JOIN_BUILD}, {shapes[1], jit::DIRECT_BUILD}, {shapes[2], jit::PROBE_AGG}, {shapes[2], jit::DIRECT_PROBE}};
+    for (size_t i = 3; i < shapes.size(); i++) jobs.push_back({shapes[i], jit::BITMAP_BUILD});
   } else {
     fused::Shape sh{}; int sid = -1;
     PLX_REQUIRE(engine::describe_fusion(p, root, &sh, &sid, &why), PLX_ERR_UNSUPPORTED, "not fusable: " + why);

@@ -82,6 +82,12 @@ PLX_HD inline Q3LineRow q3_line_row(uint64_t seed, uint64_t order, uint32_t line
   return r;
 }
 
+// ---- customer (TPC-H Q3 columns): dense keys 1..n in dbgen order, one of five market segments per customer ------------
+constexpr int kSegments = 5;   // AUTOMOBILE, BUILDING, FURNITURE, HOUSEHOLD, MACHINERY (dictionary codes 0..4)
+PLX_HD inline uint8_t customer_segment(uint64_t seed, uint64_t custkey) {
+  return (uint8_t)rand_range(mix64(seed ^ 0x637573746f6d6572ull), custkey, 0, 0, kSegments);
+}
+
 // ---- one uniform column: lo + floor(U * (hi - lo)), optionally scaled to a double (BASELINE configs 2 / 3 / 5) -------
 PLX_HD inline int64_t uniform_value(uint64_t seed, uint32_t stream, uint64_t i, int64_t lo, int64_t hi) {
   return rand_range(mix64(seed), i, stream & 7u, lo, hi);

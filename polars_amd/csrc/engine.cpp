@@ -5,7 +5,9 @@
 #include <algorithm>
 #include <cmath>
 #include <functional>
+#include <memory>
 #include <numeric>
+#include <set>
 #include <sstream>
 
 #include "fused_shapes.hpp"
@@ -279,6 +281,8 @@ class Compiler {
   int konst(uint64_t bits, char ty) { DNode n; n.code = OP_CONST; n.imm = bits; n.ty = ty; return add(n); }
   int konst_f(double d) { uint64_t b; memcpy(&b, &d, 8); return konst(b, 'f'); }
   int ifnull(int a, uint64_t code) { DNode n; n.code = OP_IFNULL; n.a = a; n.b = a; n.imm = code; n.ty = nodes[a].ty; n.nullable = false; return add(n); }
+  // membership of integer node `a` in lookup bitmap `lut` (args.lut[lut] is filled in by the caller before the launch)
+  int bit_lookup(int a, int lut, int64_t kmin) { DNode n; n.code = OP_BITLOOKUP; n.a = a; n.b = a; n.c = (uint8_t)lut; n.imm = (uint64_t)kmin; n.ty = 'b'; n.nullable = nodes[a].nullable; return add(n); }
   int col_id(const ColumnPtr& c) {
     for (size_t i = 0; i < cols.size(); i++) if (cols[i].get() == c.get()) return (int)i;
     cols.push_back(c);
@@ -510,7 +514,7 @@ class Compiler {
       args.imm[pc] = d.imm;
     } else {
       op.a = (uint8_t)sa; op.b = (uint8_t)sb;
-      if (d.code == OP_IFNULL) args.imm[pc] = d.imm;
+      if (d.code == OP_IFNULL || d.code == OP_BITLOOKUP) args.imm[pc] = d.imm;
     }
     shape.ops[pc] = op;
     d.slot = slot; d.emitted = true;
@@ -1126,6 +1130,68 @@ static int peel_filters(const Plan& plan, int input, std::vector<int>& preds) {
 // TPC-H Q3 has this shape.  Pipeline: count build rows -> build scan (predicate fused) -> probe scan
 // (predicate + expressions fused, aggregates land in the matching slot) -> compact -> gather the
 // build-side key columns.  Anything else returns false and the caller runs the per-node path.
+// ---- inner joins that only FILTER (semi-join rewrite) ---------------------------------------------------------------------
+// `X JOIN Y ON x = y` where one side (the filter side) has unique join keys and contributes no column to anything above the
+// join is a semi join of the other (payload) side: TPC-H Q3's `customer[c_mktsegment == ..] JOIN orders` only restricts orders.
+// The filter side becomes a membership bitmap over its key range (one fused scan of the filter side), the payload side's
+// scan tests `bit(key)` as one more conjunct of its predicate (OP_BITLOOKUP) -- no join output is materialised.
+struct SemiFilter {
+  FramePtr F;                 // filter side
+  std::vector<int> fpreds;    // its predicates
+  int fkey = -1;              // join key column of F
+  int pkey = -1;              // join key column of the payload frame
+};
+static void collect_columns(const Plan& plan, int e, std::set<std::string>& out) {
+  if (e < 0) return;
+  const AE& x = plan.ae.at(e);
+  if (x.kind == PLX_AE_COLUMN) { out.insert(x.name); return; }
+  collect_columns(plan, x.lhs, out);
+  collect_columns(plan, x.rhs, out);
+}
+// Resolves one input of the outer join to a scan node: [Filter]* Scan, or [Filter]* Join(inner; A, B) with A, B = [Filter]* Scan
+// where one of A / B is a pure filter with respect to `used` (the column names referenced above).  Appends the payload side's
+// predicates to `preds` and the filter to `semis`; returns the payload scan node or -1 (why set).
+static int resolve_join_side(const Plan& plan, int node, std::set<std::string> used, std::vector<int>& preds, std::vector<SemiFilter>& semis, std::string* why) {
+  auto no = [&](const char* m) { if (why) *why = m; return -1; };
+  const int n = peel_filters(plan, node, preds);
+  if (plan.ir[n].kind == PLX_IR_SCAN) return n;
+  if (plan.ir[n].kind != PLX_IR_JOIN) return no("join inputs are not filtered scans");
+  const IRN& j = plan.ir[n];
+  if (j.how != PLX_JOIN_INNER || j.keys.size() != 1 || j.keys_right.size() != 1) return no("nested join is not a single-key inner join");
+  auto plain = [&](int e) -> const AE* { const AE* x = &plan.ae[e]; while (x->kind == PLX_AE_ALIAS) x = &plan.ae[x->lhs]; return x->kind == PLX_AE_COLUMN ? x : nullptr; };
+  const AE* ka = plain(j.keys[0]);
+  const AE* kb = plain(j.keys_right[0]);
+  if (!ka || !kb) return no("nested join keys are expressions");
+  std::vector<int> ap, bp;
+  const int a = peel_filters(plan, j.input, ap), b = peel_filters(plan, j.input_right, bp);
+  if (plan.ir[a].kind != PLX_IR_SCAN || plan.ir[b].kind != PLX_IR_SCAN) return no("nested join inputs are not filtered scans");
+  FramePtr A = get_frame(plan.ir[a].frame), B = get_frame(plan.ir[b].frame);
+  const int kai = A->find(ka->name), kbi = B->find(kb->name);
+  if (kai < 0 || kbi < 0) return no("nested join key column not found");
+  if (A->cols[kai]->dtype != B->cols[kbi]->dtype || !dtype_is_int(A->cols[kai]->dtype) || A->cols[kai]->dtype == PLX_U64) return no("nested join key is not a signed / narrow integer column pair of one dtype");
+  for (size_t i = 0; i < B->names.size(); i++) if ((int)i != kbi && A->find(B->names[i]) >= 0) return no("nested join sides share a column name (suffix renaming is not modelled)");
+  for (int pe : preds) collect_columns(plan, pe, used);        // predicates above the nested join see the joined frame
+  bool used_a = false, used_b = false;
+  for (auto& nm : A->names) used_a = used_a || used.count(nm);
+  for (size_t i = 0; i < B->names.size(); i++) if ((int)i != kbi) used_b = used_b || used.count(B->names[i]);
+  if (used.count(kb->name) && kb->name != ka->name) return no("the right key of the nested join is referenced above it (coalesced away)");
+  SemiFilter sf;
+  int payload = -1;
+  if (!used_a) { sf.F = A; sf.fpreds = ap; sf.fkey = kai; sf.pkey = kbi; payload = b; preds.insert(preds.begin(), bp.begin(), bp.end()); }
+  else if (!used_b) { sf.F = B; sf.fpreds = bp; sf.fkey = kbi; sf.pkey = kai; payload = a; preds.insert(preds.begin(), ap.begin(), ap.end()); }
+  else return no("both sides of the nested join are referenced above it");
+  semis.push_back(sf);
+  return payload;
+}
+// key range of a semi filter's key column: exact statistics when the column has data, the declared range of a placeholder
+static bool semi_key_range(const SemiFilter& sf, int64_t* mn, int64_t* mx) {
+  const ColumnPtr& c = sf.F->cols[sf.fkey];
+  if (c->values) return ops::int_range(c, mn, mx);
+  if (c->range_state == 1) { *mn = c->range_min; *mx = c->range_max; return true; }
+  *mn = 0; *mx = 0;
+  return true;
+}
+
 static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::string* why, std::vector<Shape>* shapes_out = nullptr, bool compile_only = false) {
   auto no = [&](const char* m) { if (why) *why = m; return false; };
   if (gb.input < 0 || plan.ir[gb.input].kind != PLX_IR_JOIN) return no("input is not a join");
@@ -1137,8 +1203,16 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   const AE* rkx = plain(jn.keys_right[0]);
   if (!lkx || !rkx) return no("join keys are expressions");
   std::vector<int> lpreds, rpreds;
-  const int lsrc = peel_filters(plan, jn.input, lpreds), rsrc = peel_filters(plan, jn.input_right, rpreds);
-  if (plan.ir[lsrc].kind != PLX_IR_SCAN || plan.ir[rsrc].kind != PLX_IR_SCAN) return no("join inputs are not filtered scans");
+  std::vector<SemiFilter> lsemis, rsemis;
+  std::set<std::string> used;                       // column names referenced above the join inputs
+  for (int e : gb.keys) collect_columns(plan, e, used);
+  for (int e : gb.exprs) collect_columns(plan, e, used);
+  used.insert(lkx->name); used.insert(rkx->name);
+  const int lsrc = resolve_join_side(plan, jn.input, used, lpreds, lsemis, why);
+  if (lsrc < 0) return false;
+  const int rsrc = resolve_join_side(plan, jn.input_right, used, rpreds, rsemis, why);
+  if (rsrc < 0) return false;
+  if (lsemis.size() + rsemis.size() > (size_t)kMaxLuts) return no("more nested filter joins than lookup bitmaps");
   FramePtr L = get_frame(plan.ir[lsrc].frame), R = get_frame(plan.ir[rsrc].frame);
   const int lki = L->find(lkx->name), rki = R->find(rkx->name);
   if (lki < 0 || rki < 0) return no("join key column not found");
@@ -1151,6 +1225,8 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   const int bki = build_right ? rki : lki, pki = build_right ? lki : rki;
   const std::vector<int>& bpreds = build_right ? rpreds : lpreds;
   const std::vector<int>& ppreds = build_right ? lpreds : rpreds;
+  const std::vector<SemiFilter>& bsemis = build_right ? rsemis : lsemis;
+  const std::vector<SemiFilter>& psemis = build_right ? lsemis : rsemis;
   // joined-frame naming (_finish_join, general.rs:17-49): left columns, then right columns except the coalesced right key
   struct Src { int side; int idx; };   // side 0 = left, 1 = right
   std::map<std::string, Src> joined;
@@ -1195,26 +1271,47 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   }
   // ---- compile the three programs
   Compiler cnt(plan, *B), cb(plan, *B), cp(plan, *P);
+  std::vector<std::unique_ptr<Compiler>> csemi;      // one program per semi filter: build-side filters first, then probe-side
   std::vector<int> agg_nodes; std::vector<FinalSpec> specs;
   int len_idx = -1;
   try {
-    auto and_preds = [&](Compiler& c, const std::vector<int>& preds) { int p = -1; for (int pe : preds) { int n = c.lower(pe); if (c.nodes[n].ty != 'b') throw Unsupported("predicate is not boolean"); p = p < 0 ? n : c.mk(OP_AND, p, n, 'b'); } return p; };
-    cnt.pred = and_preds(cnt, bpreds);
+    // conjunction of the side's predicates and of the membership tests of its semi filters (lookup bitmap i = args.lut[lut0 + i])
+    auto and_preds = [&](Compiler& c, const std::vector<int>& preds, const std::vector<SemiFilter>& semis, int lut0) {
+      int p = -1;
+      for (int pe : preds) { int n = c.lower(pe); if (c.nodes[n].ty != 'b') throw Unsupported("predicate is not boolean"); p = p < 0 ? n : c.mk(OP_AND, p, n, 'b'); }
+      for (size_t i = 0; i < semis.size(); i++) {
+        int64_t mn = 0, mx = 0;
+        if (!semi_key_range(semis[i], &mn, &mx)) mn = mx = 0;      // empty filter side: the bitmap is empty, nothing matches
+        const int n = c.bit_lookup(c.load(semis[i].pkey), lut0 + (int)i, mn);
+        p = p < 0 ? n : c.mk(OP_AND, p, n, 'b');
+      }
+      return p;
+    };
+    cnt.pred = and_preds(cnt, bpreds, bsemis, 0);
     const int bk_cnt = cnt.load(bki);
     cnt.add_agg(cnt.nodes[bk_cnt].nullable ? AGG_COUNT : AGG_LEN, cnt.nodes[bk_cnt].nullable ? bk_cnt : -1);
     cnt.finish();
-    cb.pred = and_preds(cb, bpreds);
+    cb.pred = and_preds(cb, bpreds, bsemis, 0);
     cb.key = cb.load(bki);
     cb.finish();
-    cp.pred = and_preds(cp, ppreds);
+    cp.pred = and_preds(cp, ppreds, psemis, (int)bsemis.size());
     cp.key = cp.load(pki);
     cp.df = &pview;
     len_idx = cp.add_agg(AGG_LEN, -1);
     for (int e : gb.exprs) collect_aggs(plan, e, agg_nodes);
     for (int a : agg_nodes) specs.push_back(cp.lower_agg(a));
     cp.finish();
+    for (const std::vector<SemiFilter>* sv : {&bsemis, &psemis}) {
+      for (const SemiFilter& sf : *sv) {
+        csemi.emplace_back(new Compiler(plan, *sf.F));
+        Compiler& cf = *csemi.back();
+        cf.pred = and_preds(cf, sf.fpreds, {}, 0);
+        cf.key = cf.load(sf.fkey);
+        cf.finish();
+      }
+    }
   } catch (const Unsupported& u) { if (why) *why = u.why; return false; }
-  if (shapes_out) { shapes_out->push_back(cnt.shape); shapes_out->push_back(cb.shape); shapes_out->push_back(cp.shape); }
+  if (shapes_out) { shapes_out->push_back(cnt.shape); shapes_out->push_back(cb.shape); shapes_out->push_back(cp.shape); for (auto& cf : csemi) shapes_out->push_back(cf->shape); }
   if (compile_only) {
     if (t_program_dump) {   // the three scans + how groups, group keys and outputs are derived from them (tests/program_eval.py evaluate_join)
       std::ostringstream o;
@@ -1223,12 +1320,55 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       for (size_t i = 0; i < gkeys.size(); i++)
         o << (i ? "," : "") << "{\"name\":" << jstr(output_name(plan, gkeys[i].expr)) << ",\"is_join_key\":" << (gkeys[i].is_join_key ? 1 : 0) << ",\"build_col\":"
           << (gkeys[i].is_join_key ? std::string("null") : jstr(B->names[gkeys[i].build_col])) << ",\"dtype\":" << gkeys[i].dtype << "}";
-      o << "]," << finals_outputs_fields(plan, agg_nodes, specs, gb.exprs) << "}";
+      o << "]," << finals_outputs_fields(plan, agg_nodes, specs, gb.exprs) << ",\"semis\":[";
+      {
+        size_t ci = 0;
+        for (int side = 0; side < 2; side++) {
+          const std::vector<SemiFilter>& sv = side == 0 ? bsemis : psemis;
+          for (size_t i = 0; i < sv.size(); i++, ci++) {
+            int64_t mn = 0, mx = 0; semi_key_range(sv[i], &mn, &mx);
+            o << (ci ? "," : "") << "{\"side\":\"" << (side == 0 ? "build" : "probe") << "\",\"lut\":" << (side == 0 ? i : bsemis.size() + i) << ",\"kmin\":\"" << mn << "\",\"kmax\":\"" << mx
+              << "\",\"filter_key\":" << jstr(sv[i].F->names[sv[i].fkey]) << ",\"payload_key\":" << jstr((side == 0 ? B : P)->names[sv[i].pkey]) << ",\"filter\":{" << program_fields(*csemi[ci], *sv[i].F) << "}}";
+          }
+        }
+      }
+      o << "]}";
       t_program_dump->json = o.str();
     }
     return true;
   }
   // ---- run
+  // semi filters first: one fused scan of each filter side -> membership bitmap; its set bits must equal the rows that passed
+  // (unique filter keys), otherwise the nested join multiplies rows and the per-node path has to run it
+  std::vector<Buf> lut_bits;
+  {
+    size_t ci = 0;
+    for (int side = 0; side < 2; side++) {
+      const std::vector<SemiFilter>& sv = side == 0 ? bsemis : psemis;
+      for (size_t i = 0; i < sv.size(); i++, ci++) {
+        const SemiFilter& sf = sv[i];
+        int64_t mn = 0, mx = 0;
+        const bool have = sf.F->height > 0 && semi_key_range(sf, &mn, &mx);
+        const unsigned __int128 range128 = have ? (unsigned __int128)((__int128)mx - (__int128)mn) + 1 : 1;
+        if (range128 > ((unsigned __int128)1 << 34) || (have && range128 > (unsigned __int128)sf.F->height * 256 + 4096)) return no("nested filter join: key range too wide for a bitmap");
+        const uint64_t range = (uint64_t)range128;
+        Buf bits = dev_alloc_zero(sizeof(uint64_t) * (size_t)(range / 64 + 2)), rows_dev = dev_alloc_zero(8);
+        if (have) {
+          BitmapBuild bb; bb.bits = bits->as<unsigned long long>(); bb.count = rows_dev->as<unsigned long long>(); bb.kmin = mn; bb.range = range;
+          Compiler& cf = *csemi[ci];
+          k::fused_bitmap_build(cf.shape, cf.args, bb, find_static_shape(cf.shape));
+          uint64_t rows_in = 0;
+          d2h_sync(&rows_in, rows_dev->ptr, 8);
+          if ((uint64_t)k::bitmap_popcount(bits->as<uint64_t>(), (int64_t)range) != rows_in) return no("nested filter join: the filter side's keys are not unique");
+          plan.desc += "SemiFilter{" + sf.F->names[sf.fkey] + " -> bitmap range=" + std::to_string(range) + " rows=" + std::to_string(rows_in) + "/" + std::to_string(sf.F->height) + "}; ";
+        }
+        const Lut lut{bits->as<unsigned long long>(), range};
+        const int li = side == 0 ? (int)i : (int)(bsemis.size() + i);
+        if (side == 0) { cnt.args.lut[li] = lut; cb.args.lut[li] = lut; } else cp.args.lut[li] = lut;
+        lut_bits.push_back(bits);
+      }
+    }
+  }
   uint64_t nb = 0;
   const int probe_static_id = find_static_shape(cp.shape);
   FusedAggResult r; r.n_aggs = cp.shape.n_aggs;
@@ -1245,16 +1385,16 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     if (range128 <= ((unsigned __int128)1 << 34) && range128 <= (unsigned __int128)B->height * 256 && ord_cap < 0xfffffff0ull) {
       const uint64_t range = (uint64_t)range128;
       const size_t n_blocks = (size_t)(range / 512 + 1), n_words = n_blocks * 8;
-      Buf bits = dev_alloc_zero(sizeof(uint64_t) * n_words), rank = dev_alloc(sizeof(uint64_t) * (n_blocks + 1));
+      Buf bits = dev_alloc_zero(sizeof(uint64_t) * n_words), rank = dev_alloc(sizeof(uint32_t) * n_words);
       Buf okey = dev_alloc(sizeof(uint64_t) * ord_cap), orow = dev_alloc(sizeof(uint32_t) * ord_cap), used = dev_alloc_zero(sizeof(uint32_t) * (ord_cap / 1024 + 2));
       Buf meta = dev_alloc_zero(32);   // [0] ordinal counter, [2..3] flags, [4..5] pairs appended (u64)
-      DirectJoinTable dt; dt.bits = bits->as<unsigned long long>(); dt.rank = rank->as<unsigned long long>(); dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>();
+      DirectJoinTable dt; dt.bits = bits->as<unsigned long long>(); dt.rank = rank->as<unsigned int>(); dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>();
       dt.chunk_used = used->as<unsigned int>(); dt.counter = meta->as<unsigned int>(); dt.flags = meta->as<unsigned int>() + 2; dt.acc = nullptr; dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)ord_cap;
       k::fused_direct_build(cb.shape, cb.args, dt, find_static_shape(cb.shape));
       // every wave closes its last chunk when it finishes, so chunk_used is final once the build scan is: the rank launch counts
       // the pairs over the whole reserved capacity (the ordinal counter itself is only read back with the rank's sync)
       uint64_t pairs = 0;
-      nb = k::direct_rank(dt, rank->as<uint64_t>(), (int64_t)ord_cap, meta->as<uint64_t>() + 2, &pairs);   // synchronises: flags and the ordinal counter are final too
+      nb = k::direct_rank(dt, rank->as<uint32_t>(), (int64_t)ord_cap, meta->as<uint64_t>() + 2, &pairs);   // synchronises: flags and the ordinal counter are final too
       uint32_t m4[4] = {0, 0, 0, 0};
       d2h_sync(m4, meta->ptr, 16);
       PLX_REQUIRE(!m4[3], PLX_ERR_INVALID, "direct join build: ordinal overflow");

@@ -42,7 +42,10 @@ enum OpCode : uint8_t {
   OP_MOV,
   OP_CANON_F,  // float key canonicalisation: -0 -> +0, any NaN -> 0x7ff8000000000000 (total_ord.rs:40-48)
   // 64-bit integer floor division / modulo, Python sign rules; divisor 0 -> null (signed.rs:35-70)
-  OP_FDIV_I, OP_MOD_I, OP_FDIV_U, OP_MOD_U
+  OP_FDIV_I, OP_MOD_I, OP_FDIV_U, OP_MOD_U,
+  // dst <- bit (a - imm[pc]) of lookup bitmap args.lut[c] (0 outside [0, range)); validity of a.  The membership test of a
+  // semi-join whose filter side was reduced to a bitmap over its (dense) key range.
+  OP_BITLOOKUP
 };
 
 struct Op {
@@ -81,10 +84,16 @@ struct Input {
   const void* values;
   const uint64_t* validity;
 };
+constexpr int kMaxLuts = 2;
+struct Lut {
+  const unsigned long long* bits;   // [range / 64 + 1] words
+  uint64_t range;
+};
 
 struct Args {
   Input in[kMaxInputs];
   uint64_t imm[kMaxOps];
+  Lut lut[kMaxLuts];
   int64_t n_rows;
   // generic interpreter only: its register file lives in dynamic LDS behind the sink's own LDS (set by the launcher)
   uint32_t rf_lds_offset;
@@ -155,7 +164,7 @@ struct RecLayout {
 };
 PLX_FHD constexpr bool shape_may_have_nulls(const Shape& sh) {
   for (int i = 0; i < sh.n_inputs; i++) if (sh.in_nullable[i]) return true;
-  for (int i = 0; i < sh.n_ops; i++) if (sh.ops[i].code >= OP_FDIV_I) return true;   // integer div / mod: divisor 0 -> null
+  for (int i = 0; i < sh.n_ops; i++) if (sh.ops[i].code >= OP_FDIV_I && sh.ops[i].code <= OP_MOD_U) return true;   // integer div / mod: divisor 0 -> null
   return false;
 }
 PLX_FHD constexpr RecLayout rec_layout(const Shape& sh) {
@@ -325,20 +334,19 @@ struct JoinAggTable {
 
 // Direct-address ("perfect hash") variant of the fused join -> aggregate table, used when the build
 // key range is small (max - min + 1 <= a few x the build rows, e.g. TPC-H orderkeys).  One BIT per key of the
-// range says whether a build row with that key passed the build predicate; rank[b] = number of set bits before the
-// 512-bit block b (8 words = one 64-B line), so slot(key) = rank[b] + popc(words of the block before the key's word) +
-// popc(bits below the key's bit) numbers the build rows in key order.  bits + rank are range/8 + range/64 bytes (75 + 9 MB
-// for the 6e8 TPC-H SF100 orderkeys: resident in the 256 MB Infinity Cache, the rank array in the L2s), where one u32
-// per key was 2.4 GB to memset and to miss in.
+// range says whether a build row with that key passed the build predicate; rank[w] (u32) = number of set bits before
+// 64-bit word w, so slot(key) = rank[w] + popc(bits of the word below the key's bit) numbers the build rows in key order.
+// bits + rank are range/8 + range/16 bytes (75 + 37 MB for the 6e8 TPC-H SF100 orderkeys: resident in the 256 MB Infinity
+// Cache), where one u32 per key was 2.4 GB to memset and to miss in.
 //   build  : the scan appends (key, row) pairs in per-wave ordinal chunks and sets the key's bit;
-//   rank   : popcount per block -> device exclusive scan; the pairs are counted too: more pairs than set bits = a
-//            duplicate build key -> the caller falls back BEFORE the probe;
+//   rank   : popcount per 512-bit block -> device exclusive scan over the blocks -> per-word ranks; the pairs are counted
+//            too: more pairs than set bits = a duplicate build key -> the caller falls back BEFORE the probe;
 //   probe  : bit test + rank -> the row's aggregates land in acc[slot];
 //   output : ONE pass over the pair list: pairs whose slot was hit by a probe row are compacted together with their cells
 //            (no key-ordered copy of the pairs, no pass over the slots).
 struct DirectJoinTable {
   unsigned long long* bits;      // [(range / 512 + 1) * 8] bitmap words, padded to whole blocks
-  const unsigned long long* rank; // [range / 512 + 2] exclusive prefix of the per-block popcounts (valid after the rank step)
+  const unsigned int* rank;      // [(range / 512 + 1) * 8] set bits before each bitmap word (valid after the rank step)
   unsigned long long* ord_key;   // pair list [n_ord]
   unsigned int* ord_row;         // same, build row
   unsigned int* chunk_used;      // [n_ord / kOrdChunk + 1] ordinals handed out of each reserved chunk
@@ -348,6 +356,16 @@ struct DirectJoinTable {
   long long kmin;
   unsigned long long range;
   unsigned int n_ord;            // capacity of the pair list
+};
+
+// Semi-join filter side reduced to a bitmap over its key range (an inner join whose one side has unique keys and contributes
+// no column downstream only FILTERS the other side): the scan of the filter side sets bit (key - kmin) of every row that passes
+// its predicate and counts those rows (fewer set bits than rows = duplicate keys: the rewrite does not apply).
+struct BitmapBuild {
+  unsigned long long* bits;      // [range / 64 + 1], zeroed
+  unsigned long long* count;     // [0] rows inserted
+  long long kmin;
+  unsigned long long range;
 };
 
 // Direct-address aggregation (dense keys in [key_min, key_min + n_groups)): acc[(G+1)*n_aggs],

@@ -24,8 +24,11 @@ typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
 //    kernel was 28.8 k instructions and ran at 0.7 TB/s); in LDS a slot access is one ds_read/ds_write_b64 at
 //    base + ((slot * kRows + row) * 64 + lane) * 8 -- wave-private, consecutive lanes on consecutive banks.
 struct RegFile {
-  u64x16 v[kRows];
-  u32x16 valid;  // bit r of element s: row r of slot s is valid
+  // plain arrays, not ext_vector types: every index is a compile-time constant (AOT / JIT programs), so each (row, slot) is its
+  // own scalar value and the slots a program never touches cost no register (a 16-wide vector is kept alive as a whole
+  // across loop back-edges: 80 VGPRs per register file whatever the program uses)
+  uint64_t v[kRows][kSlots];
+  uint32_t valid[kSlots];  // bit r of element s: row r of slot s is valid
   __device__ __forceinline__ uint64_t get(int r, int s) const { return v[r][s]; }
   __device__ __forceinline__ uint32_t getv(int s) const { return valid[s]; }
   __device__ __forceinline__ void set(int r, int s, uint64_t x) { v[r][s] = x; }
@@ -303,6 +306,15 @@ __device__ __forceinline__ void exec_op(const Op op, const Shape& sh, const Args
         for (int r = 0; r < kRows; r++) d[r] = ((va >> r) & 1) ? a[r] : args.imm[pc];
         vd = (1u << kRows) - 1;
         break;
+      case OP_BITLOOKUP: {
+        const Lut& lut = args.lut[op.c < kMaxLuts ? op.c : 0];
+#pragma unroll
+        for (int r = 0; r < kRows; r++) {
+          const uint64_t idx = a[r] - args.imm[pc];
+          d[r] = (((va >> r) & 1) && idx < lut.range) ? ((lut.bits[idx >> 6] >> (idx & 63)) & 1ull) : 0ull;
+        }
+        vd = va;
+      } break;
       default:  // OP_MOV / OP_NOP
 #pragma unroll
         for (int r = 0; r < kRows; r++) d[r] = a[r];

@@ -313,22 +313,9 @@ struct ProbeAggSink {
 // and sub-allocates from them (one atomic per wave-row on a single counter word took 26 ms for the 1.5e8-row
 // TPC-H orders scan; ~12 k atomics this way).  Unused tails of chunks stay empty (LEN cell 0).
 constexpr unsigned int kOrdChunk = 1024;
-// slot of key index idx (its bit is set in `word` = bits[idx >> 6]): build rows numbered in key order.  The block's other
-// words share the 64-B line of `word`: the extra loads hit the line that is already on its way.
+// slot of key index idx (its bit is set in `word` = bits[idx >> 6]): build rows numbered in key order
 __device__ __forceinline__ unsigned long long direct_slot(const DirectJoinTable& t, unsigned long long idx, unsigned long long word) {
-  const unsigned long long w = idx >> 6, blk = w >> 3;
-  const unsigned int in_blk = (unsigned int)(w & 7);
-  const ulonglong2* line = reinterpret_cast<const ulonglong2*>(t.bits + (blk << 3));
-  const ulonglong2 a = line[0], b = line[1], c = line[2], d = line[3];
-  unsigned int before = 0;
-  before += in_blk > 0 ? (unsigned int)__popcll(a.x) : 0u;
-  before += in_blk > 1 ? (unsigned int)__popcll(a.y) : 0u;
-  before += in_blk > 2 ? (unsigned int)__popcll(b.x) : 0u;
-  before += in_blk > 3 ? (unsigned int)__popcll(b.y) : 0u;
-  before += in_blk > 4 ? (unsigned int)__popcll(c.x) : 0u;
-  before += in_blk > 5 ? (unsigned int)__popcll(c.y) : 0u;
-  before += in_blk > 6 ? (unsigned int)__popcll(d.x) : 0u;
-  return t.rank[blk] + before + (unsigned long long)__popcll(word & ((1ull << (idx & 63)) - 1ull));
+  return (unsigned long long)t.rank[idx >> 6] + (unsigned long long)__popcll(word & ((1ull << (idx & 63)) - 1ull));
 }
 struct DirectBuildSink {
   using Params = DirectJoinTable;
@@ -380,6 +367,27 @@ struct DirectProbeAggSink {
       const unsigned long long w = p.bits[idx >> 6];
       if (!((w >> (idx & 63)) & 1ull)) continue;
       atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)direct_slot(p, idx, w) * sh.n_aggs);
+    }
+  }
+};
+
+// ---- sink: membership bitmap of a semi-join's filter side -------------------------------------------
+struct BitmapBuildSink {
+  using Params = BitmapBuild;
+  unsigned long long n = 0;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) { n = 0; }
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params& p) {
+    const uint64_t w = wave_sum_u64(n);
+    if (lane_id() == 0 && w) atomicAdd(p.count, (unsigned long long)w);
+  }
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t, const Params& p) {
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      if (!pass[r] || !((rf.getv(sh.key) >> r) & 1)) continue;   // null keys never match
+      const uint64_t idx = rf.get(r, sh.key) - (uint64_t)p.kmin;
+      if (idx >= p.range) continue;
+      n++;
+      __hip_atomic_fetch_or(&p.bits[idx >> 6], 1ull << (idx & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 };

@@ -17,7 +17,7 @@
 namespace plx {
 namespace jit {
 
-enum Sink { REGAGG = 0, LDSAGG, DENSE, HASH, WIDE, JOIN_BUILD, PROBE_AGG, DIRECT_BUILD, DIRECT_PROBE,
+enum Sink { REGAGG = 0, LDSAGG, DENSE, HASH, WIDE, JOIN_BUILD, PROBE_AGG, DIRECT_BUILD, DIRECT_PROBE, BITMAP_BUILD,
             // kernels of the partitioned group-by (partition_device.hpp); launched with launch_raw
             PART_COUNT, PART_SCATTER, PART_AGG,
             // second generation (partition2_device.hpp)

@@ -59,6 +59,19 @@ void datagen_lines(int64_t n_orders, uint64_t seed, const uint64_t* offsets, con
   PLX_HIP(hipGetLastError());
 }
 
+__global__ __launch_bounds__(kBlock) void datagen_customer_kernel(int64_t n, uint64_t seed, int64_t* __restrict__ custkey, uint8_t* __restrict__ segment) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    custkey[i] = i + 1;
+    segment[i] = datagen::customer_segment(seed, (uint64_t)(i + 1));
+  }
+}
+void datagen_customer(int64_t n, uint64_t seed, int64_t* custkey, uint8_t* segment) {
+  if (n <= 0) return;
+  ProfileScope ps("datagen_customer", (uint64_t)n * 9, (uint64_t)n);
+  hipLaunchKernelGGL(datagen_customer_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, stream(), n, seed, custkey, segment);
+  PLX_HIP(hipGetLastError());
+}
+
 template <class T>
 __global__ __launch_bounds__(kBlock) void datagen_uniform_kernel(int64_t n, uint64_t seed, uint32_t strm, int64_t lo, int64_t hi, double scale, T* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

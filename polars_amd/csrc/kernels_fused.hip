@@ -42,7 +42,26 @@
   case SHAPE_Q3_BUILD: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_BUILD>, DirectBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
 #define PLX_STATIC_DIRECT_PROBE_CASES \
   case SHAPE_Q3_PROBE: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_PROBE>, DirectProbeAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+#ifdef PLX_HAVE_Q3FULL_SHAPES
+#define PLX_STATIC_BITMAP_BUILD_CASES \
+  case SHAPE_Q3F_SEMI: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3F_SEMI>, BitmapBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+#define PLX_STATIC_Q3F_JOIN_BUILD_CASES \
+  case SHAPE_Q3F_BUILD: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3F_BUILD>, JoinBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+#define PLX_STATIC_Q3F_DIRECT_BUILD_CASES \
+  case SHAPE_Q3F_BUILD: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3F_BUILD>, DirectBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+#define PLX_STATIC_Q3F_REGAGG_CASES \
+  case SHAPE_Q3F_COUNT: PLX_LAUNCH_SCAN(StatProg<SHAPE_Q3F_COUNT>, RegAggSink, grid, 0, sh, args, sp); break;
 #else
+#define PLX_STATIC_BITMAP_BUILD_CASES
+#define PLX_STATIC_Q3F_JOIN_BUILD_CASES
+#define PLX_STATIC_Q3F_DIRECT_BUILD_CASES
+#define PLX_STATIC_Q3F_REGAGG_CASES
+#endif
+#else
+#define PLX_STATIC_BITMAP_BUILD_CASES
+#define PLX_STATIC_Q3F_JOIN_BUILD_CASES
+#define PLX_STATIC_Q3F_DIRECT_BUILD_CASES
+#define PLX_STATIC_Q3F_REGAGG_CASES
 #define PLX_STATIC_DIRECT_BUILD_CASES
 #define PLX_STATIC_DIRECT_PROBE_CASES
 #define PLX_STATIC_JOIN_BUILD_CASES
@@ -101,6 +120,7 @@ void fused_regagg(const Shape& sh, const Args& args, int static_id, uint64_t* ou
       case SHAPE_CFG2_NULLX: PLX_LAUNCH_SCAN(StatProg<SHAPE_CFG2_NULLX>, RegAggSink, grid, 0, sh, args, sp); break;
       case SHAPE_CFG1: PLX_LAUNCH_SCAN(StatProg<SHAPE_CFG1>, RegAggSink, grid, 0, sh, args, sp); break;
       PLX_STATIC_REGAGG_EXTRA_CASES
+      PLX_STATIC_Q3F_REGAGG_CASES
       default: if (!jit::launch(sh, args, jit::REGAGG, &sp, grid, 0)) { const DynLaunch d = dyn_launch(sh, args, 0); PLX_LAUNCH_SCAN(DynProg, RegAggSink, grid, d.lds, sh, d.args, sp); } break;
     }
     PLX_HIP(hipGetLastError());
@@ -274,6 +294,7 @@ void fused_join_build(const Shape& sh, const Args& args, const JoinAggTable& t, 
   const int grid = scan_grid(args.n_rows, 8);
   switch (static_id) {
     PLX_STATIC_JOIN_BUILD_CASES
+    PLX_STATIC_Q3F_JOIN_BUILD_CASES
     default: if (!jit::launch(sh, args, jit::JOIN_BUILD, &t, grid, 0)) { const DynLaunch d = dyn_launch(sh, args, 0); hipLaunchKernelGGL((fused_scan_kernel<DynProg, JoinBuildSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, t); } break;
   }
   PLX_HIP(hipGetLastError());
@@ -289,12 +310,23 @@ void fused_probe_agg(const Shape& sh, const Args& args, const JoinAggTable& t, i
   PLX_HIP(hipGetLastError());
 }
 
+void fused_bitmap_build(const Shape& sh, const Args& args, const BitmapBuild& t, int static_id) {
+  if (args.n_rows == 0) return;
+  ProfileScope ps(static_id >= 0 ? "fused_scan_bitmap_build_static" : "fused_scan_bitmap_build", algo_bytes(sh, args), (uint64_t)args.n_rows);
+  const int grid = scan_grid(args.n_rows, 8);
+  switch (static_id) {
+    PLX_STATIC_BITMAP_BUILD_CASES
+    default: if (!jit::launch(sh, args, jit::BITMAP_BUILD, &t, grid, 0)) { const DynLaunch d = dyn_launch(sh, args, 0); hipLaunchKernelGGL((fused_scan_kernel<DynProg, BitmapBuildSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, t); } break;
+  }
+  PLX_HIP(hipGetLastError());
+}
 void fused_direct_build(const Shape& sh, const Args& args, const DirectJoinTable& t, int static_id) {
   if (args.n_rows == 0) return;
   ProfileScope ps(static_id >= 0 ? "fused_scan_direct_build_static" : "fused_scan_direct_build", algo_bytes(sh, args), (uint64_t)args.n_rows);
   const int grid = scan_grid(args.n_rows, 8);
   switch (static_id) {
     PLX_STATIC_DIRECT_BUILD_CASES
+    PLX_STATIC_Q3F_DIRECT_BUILD_CASES
     default: if (!jit::launch(sh, args, jit::DIRECT_BUILD, &t, grid, 0)) { const DynLaunch d = dyn_launch(sh, args, 0); hipLaunchKernelGGL((fused_scan_kernel<DynProg, DirectBuildSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, t); } break;
   }
   PLX_HIP(hipGetLastError());
@@ -323,18 +355,40 @@ __global__ __launch_bounds__(kBlock) void direct_popc_kernel(const unsigned long
   const uint64_t w = wave_sum_u64(mine);
   if (lane_id() == 0 && w) atomicAdd(n_pairs, (unsigned long long)w);
 }
+// second half of the rank step: block prefix + popcounts of the block's earlier words -> one u32 rank per bitmap word
+__global__ __launch_bounds__(kBlock) void direct_word_rank_kernel(const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ block_rank, int64_t n_blocks,
+                                                                  unsigned int* __restrict__ rank) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks; i += (int64_t)gridDim.x * blockDim.x) {
+    const ulonglong2* line = reinterpret_cast<const ulonglong2*>(bits + (i << 3));
+    const ulonglong2 a = line[0], b = line[1], c = line[2], d = line[3];
+    unsigned int r = (unsigned int)block_rank[i];
+    uint4 lo, hi;
+    lo.x = r; r += (unsigned int)__popcll(a.x);
+    lo.y = r; r += (unsigned int)__popcll(a.y);
+    lo.z = r; r += (unsigned int)__popcll(b.x);
+    lo.w = r; r += (unsigned int)__popcll(b.y);
+    hi.x = r; r += (unsigned int)__popcll(c.x);
+    hi.y = r; r += (unsigned int)__popcll(c.y);
+    hi.z = r; r += (unsigned int)__popcll(d.x);
+    hi.w = r;
+    reinterpret_cast<uint4*>(rank + (i << 3))[0] = lo;
+    reinterpret_cast<uint4*>(rank + (i << 3))[1] = hi;
+  }
+}
 // -> set bits (= distinct build keys that passed); *pairs_out = pairs appended by the build scan (synchronises)
-uint64_t direct_rank(const DirectJoinTable& t, uint64_t* rank_out, int64_t n_used, uint64_t* n_pairs_dev, uint64_t* pairs_out) {
+uint64_t direct_rank(const DirectJoinTable& t, uint32_t* rank_out, int64_t n_used, uint64_t* n_pairs_dev, uint64_t* pairs_out) {
   const int64_t n_blocks = (int64_t)(t.range / 512 + 1);
   const int64_t n_chunks = (n_used + kOrdChunk - 1) / kOrdChunk;
-  Buf counts = dev_alloc(sizeof(uint32_t) * (size_t)n_blocks);
-  ProfileScope ps("direct_rank", (uint64_t)n_blocks * 76, (uint64_t)n_blocks);
+  Buf counts = dev_alloc(sizeof(uint32_t) * (size_t)n_blocks), block_rank = dev_alloc(sizeof(uint64_t) * (size_t)(n_blocks + 1));
+  ProfileScope ps("direct_rank", (uint64_t)n_blocks * (64 + 4 + 8 + 64 + 8 + 32), (uint64_t)n_blocks);
   hipLaunchKernelGGL(direct_popc_kernel, dim3(grid_for(n_blocks, kBlock * 2)), dim3(kBlock), 0, stream(), t.bits, n_blocks, counts->as<uint32_t>(), t.chunk_used, n_chunks,
                      (unsigned long long*)n_pairs_dev);
   PLX_HIP(hipGetLastError());
-  exclusive_scan_u32(counts->as<uint32_t>(), rank_out, n_blocks);
+  exclusive_scan_u32(counts->as<uint32_t>(), block_rank->as<uint64_t>(), n_blocks);
+  hipLaunchKernelGGL(direct_word_rank_kernel, dim3(grid_for(n_blocks, kBlock * 2)), dim3(kBlock), 0, stream(), t.bits, block_rank->as<unsigned long long>(), n_blocks, (unsigned int*)rank_out);
+  PLX_HIP(hipGetLastError());
   uint64_t total = 0;
-  d2h_sync(&total, rank_out + n_blocks, 8);
+  d2h_sync(&total, block_rank->as<uint64_t>() + n_blocks, 8);
   if (pairs_out) d2h_sync(pairs_out, n_pairs_dev, 8);     // the stream is idle: no extra wait
   return total;
 }

@@ -34,12 +34,15 @@ void fused_probe_agg(const fused::Shape& sh, const fused::Args& args, const fuse
 int64_t join_agg_compact(const fused::JoinAggTable& t, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc);
 // number of waves a fused scan over n_rows launches (sizes per-wave reservations)
 int64_t scan_waves(int64_t n_rows);
+// semi-join filter side -> membership bitmap (BitmapBuild)
+void fused_bitmap_build(const fused::Shape& sh, const fused::Args& args, const fused::BitmapBuild& t, int static_id);
 // direct-address variants (DirectJoinTable)
 void fused_direct_build(const fused::Shape& sh, const fused::Args& args, const fused::DirectJoinTable& t, int static_id);
 void fused_direct_probe_agg(const fused::Shape& sh, const fused::Args& args, const fused::DirectJoinTable& t, int static_id);
-// rank step (popcount per 512-bit block + exclusive scan into rank_out[range/512 + 2]); returns the number of set bits and, in
-// *pairs_out, the pairs the build scan appended (n_pairs_dev: a zeroed device word); more pairs than bits = duplicate build keys (synchronises)
-uint64_t direct_rank(const fused::DirectJoinTable& t, uint64_t* rank_out, int64_t n_used, uint64_t* n_pairs_dev, uint64_t* pairs_out);
+// rank step (popcount per 512-bit block, exclusive scan over the blocks, u32 rank per word into rank_out[(range/512 + 1) * 8]);
+// returns the number of set bits and, in *pairs_out, the pairs the build scan appended (n_pairs_dev: a zeroed device word); more
+// pairs than bits = duplicate build keys (synchronises)
+uint64_t direct_rank(const fused::DirectJoinTable& t, uint32_t* rank_out, int64_t n_used, uint64_t* n_pairs_dev, uint64_t* pairs_out);
 // output step: one pass over the first n_used ordinals of the pair list: pairs whose slot has a non-zero AGG_LEN cell -> out_keys / out_rows / out_acc
 int64_t direct_agg_compact(const fused::DirectJoinTable& t, int64_t n_used, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc);
 void fill_u64(uint64_t* p, int64_t n, uint64_t v);

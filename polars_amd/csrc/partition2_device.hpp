@@ -127,13 +127,14 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
   auto row0_of = [&](int64_t rd) { return (rd * nwaves + wave) * (int64_t)kTileRows + (int64_t)lane * kRows; };
   auto round_full = [&](int64_t rd) { return (rd + 1) * rows_per_round <= args.n_rows; };
-  RegFile rfs[DEPTH] = {};
+  RegFile rfA{}, rfB{};       // one register file per round in flight (rfB only with DEPTH == 2); named variables, never an
+                              // array: a dynamically indexed or address-taken register file is spilled to scratch
   unsigned int rec[kRows][RW];
   uint32_t part[kRows];
   bool pending[kRows];
   // evaluates round rd (its column loads may already be in flight) and leaves its rows in rec / part / pending; rows of hot
   // keys are aggregated here and never become pending
-  auto finish_round = [&](int64_t rd, bool preloaded, RegFile& rf) {
+  auto finish_round = [&](int64_t rd, bool preloaded, RegFile& rf) __attribute__((always_inline)) {
     bool pass[kRows];
     const int64_t row0 = row0_of(rd);
     if (preloaded) {
@@ -176,13 +177,13 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
       }
     }
   };
-  auto issue_loads = [&](int64_t rd, RegFile& rf) -> bool {
+  auto issue_loads = [&](int64_t rd, RegFile& rf) __attribute__((always_inline)) -> bool {
     if (rd < nrounds && round_full(rd)) { run_loads_full<P>(args, row0_of(rd), rf); return true; }
     return false;
   };
   // writes every complete line of the rings this lane owns to HBM and opens / closes chunks; `final_pass` also writes the
   // partial tail and records the fill of the last chunk
-  auto flush_phase = [&](bool final_pass) {
+  auto flush_phase = [&](bool final_pass) __attribute__((always_inline)) {
     uint32_t fill = 0, lim = 0, f_dw = 0, ch = kNoChunk, nl = 0;
     if (owner) {
       const unsigned long long f = fl[own_p];
@@ -243,36 +244,49 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   // Round k of this workgroup lives in register file k % DEPTH.  Per round: its rows are evaluated (loads issued DEPTH rounds
   // ago) and copied into rec[]; the register file is then free, so the loads of round k + DEPTH are issued at once and stay
   // in flight while round k is appended and flushed (barriers do not drain vmcnt).
-  bool pre[DEPTH];
+  auto append_and_flush = [&]() __attribute__((always_inline)) {
+    int any;
+    do {
+      bool mine = false;
 #pragma unroll
-  for (int d = 0; d < DEPTH; d++) pre[d] = issue_loads((int64_t)blockIdx.x + (int64_t)d * gridDim.x, rfs[d]);
-  for (int64_t rd0 = blockIdx.x; rd0 < nrounds; rd0 += (int64_t)DEPTH * gridDim.x) {
+      for (int r = 0; r < kRows; r++) {
+        if (!pending[r]) continue;
+        const unsigned long long old = atomicAdd(&fl[part[r]], 1ull);
+        const uint32_t pos = (uint32_t)old, lim = (uint32_t)(old >> 32);
+        if (pos < lim) {
+          unsigned int* base = ring + (size_t)part[r] * ring_dw;
+          const uint32_t d0 = pos * RW;
 #pragma unroll
-    for (int d = 0; d < DEPTH; d++) {
-      const int64_t rd = rd0 + (int64_t)d * gridDim.x;
-      if (rd >= nrounds) break;                      // uniform across the workgroup
-      finish_round(rd, pre[d], rfs[d]);
-      pre[d] = issue_loads(rd + (int64_t)DEPTH * gridDim.x, rfs[d]);
-      int any;
-      do {
-        bool mine = false;
-#pragma unroll
-        for (int r = 0; r < kRows; r++) {
-          if (!pending[r]) continue;
-          const unsigned long long old = atomicAdd(&fl[part[r]], 1ull);
-          const uint32_t pos = (uint32_t)old, lim = (uint32_t)(old >> 32);
-          if (pos < lim) {
-            unsigned int* base = ring + (size_t)part[r] * ring_dw;
-            const uint32_t d0 = pos * RW;
-#pragma unroll
-            for (uint32_t w = 0; w < RW; w++) base[(d0 + w) & ring_mask] = rec[r][w];
-            pending[r] = false;
-          } else mine = true;
-        }
-        any = __syncthreads_or(mine ? 1 : 0);
-        flush_phase(false);
-        __syncthreads();
-      } while (any);
+          for (uint32_t w = 0; w < RW; w++) base[(d0 + w) & ring_mask] = rec[r][w];
+          pending[r] = false;
+        } else mine = true;
+      }
+      any = __syncthreads_or(mine ? 1 : 0);
+      flush_phase(false);
+      __syncthreads();
+    } while (any);
+  };
+  const int64_t stride = (int64_t)gridDim.x;
+  if constexpr (DEPTH == 1) {
+    if ((int64_t)blockIdx.x < nrounds) finish_round(blockIdx.x, issue_loads(blockIdx.x, rfA), rfA);
+    for (int64_t rd = blockIdx.x; rd < nrounds; rd += stride) {
+      const int64_t rd_next = rd + stride;
+      const bool preloaded = issue_loads(rd_next, rfA);
+      append_and_flush();
+      if (rd_next < nrounds) finish_round(rd_next, preloaded, rfA);
+    }
+  } else {
+    bool preA = issue_loads((int64_t)blockIdx.x, rfA), preB = issue_loads((int64_t)blockIdx.x + stride, rfB);
+    for (int64_t rd0 = blockIdx.x; rd0 < nrounds; rd0 += 2 * stride) {
+      finish_round(rd0, preA, rfA);
+      preA = issue_loads(rd0 + 2 * stride, rfA);
+      append_and_flush();
+      const int64_t rd1 = rd0 + stride;
+      if (rd1 < nrounds) {                          // uniform across the workgroup
+        finish_round(rd1, preB, rfB);
+        preB = issue_loads(rd1 + 2 * stride, rfB);
+        append_and_flush();
+      }
     }
   }
   flush_phase(true);

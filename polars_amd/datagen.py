@@ -17,6 +17,8 @@ import numpy as np
 DAY_US = 86_400_000_000
 FLAGS = ["A", "N", "R"]      # l_returnflag dictionary (codes 0,1,2)
 STATUS = ["F", "O"]          # l_linestatus dictionary (codes 0,1)
+SEGMENTS = ["AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY"]   # c_mktsegment dictionary (codes 0..4)
+CUSTOMER_Q3_COLS = ["c_custkey", "c_mktsegment"]
 LINEITEM_Q1_COLS = ["l_shipdate", "l_returnflag", "l_linestatus", "l_quantity", "l_extendedprice", "l_discount", "l_tax"]
 LINEITEM_Q3_COLS = ["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"]
 ORDERS_Q3_COLS = ["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"]
@@ -37,7 +39,18 @@ CURRENT = us(1995, 6, 17)
 
 def logical_dtypes(pl) -> Dict[str, object]:
     return {"l_shipdate": pl.Datetime, "o_orderdate": pl.Datetime, "l_returnflag": pl.Categorical(FLAGS, pl.UInt8),
-            "l_linestatus": pl.Categorical(STATUS, pl.UInt8)}
+            "l_linestatus": pl.Categorical(STATUS, pl.UInt8), "c_mktsegment": pl.Categorical(SEGMENTS, pl.UInt8)}
+
+
+def n_customers_for(n_orders: int) -> int:
+    """Customers referenced by `n_orders` orders (o_custkey is uniform in [1, n_customers]; TPC-H: 10 orders per customer)."""
+    return max(2, n_orders // 10)
+
+
+def customer_host(n_customers: int, seed: int = 10) -> Dict[str, np.ndarray]:
+    """numpy customer table (parity tests): dense keys 1..n, uniform market segment codes."""
+    rng = np.random.Generator(np.random.PCG64(seed + 1000))
+    return {"c_custkey": np.arange(1, n_customers + 1, dtype=np.int64), "c_mktsegment": rng.integers(0, len(SEGMENTS), n_customers).astype(np.uint8)}
 
 
 def to_frame(pl, cols: Dict[str, np.ndarray], names):
@@ -177,6 +190,28 @@ def orders_lineitem_native(pl, n_orders: int, seed: int = 10):
     ldt = {"l_orderkey": pl.Int64, "l_extendedprice": pl.Float64, "l_discount": pl.Float64, "l_shipdate": pl.Datetime}
     L = pl.DataFrame([pl.Series._from_handle(c, hl[i], lt.get(c, ldt[c])) for i, c in enumerate(LINEITEM_Q3_COLS)])
     return O, L
+
+
+def customer_native_host(row0: int, n: int, seed: int = 10) -> Dict[str, np.ndarray]:
+    """Rows [row0, row0 + n) of the library's customer generator on the host (plx_datagen_customer_host)."""
+    import ctypes as C
+
+    from . import _ffi as F
+    out = {"c_custkey": np.zeros(n, np.int64), "c_mktsegment": np.zeros(n, np.uint8)}
+    F.check(F.lib().plx_datagen_customer_host(row0, n, seed, C.c_void_p(out["c_custkey"].ctypes.data if n else 0), C.c_void_p(out["c_mktsegment"].ctypes.data if n else 0)))
+    return out
+
+
+def customer_native(pl, n_customers: int, seed: int = 10):
+    """customer (c_custkey, c_mktsegment) generated in HBM by the library -> DataFrame."""
+    import ctypes as C
+
+    from . import _ffi as F
+    F.ensure_init()
+    hs = (C.c_uint64 * 2)()
+    F.check(F.lib().plx_datagen_customer(n_customers, seed, hs))
+    lt = logical_dtypes(pl)
+    return pl.DataFrame([pl.Series._from_handle("c_custkey", hs[0], pl.Int64), pl.Series._from_handle("c_mktsegment", hs[1], lt["c_mktsegment"])])
 
 
 _NP_OF = {"Int64": np.int64, "UInt32": np.uint32, "Float64": np.float64}

@@ -58,6 +58,23 @@ def q3(lineitem, orders, date=Q3_DATE, seg_mod=5):
             .agg((c("l_extendedprice") * (1 - c("l_discount"))).sum().alias("revenue")))
 
 
+def q3_full(customer, orders, lineitem, date=Q3_DATE, segment="BUILDING"):
+    """TPC-H Q3 with all three tables, in the form the optimizer hands the physical planner (single-table
+    predicates pushed below the joins): customer[c_mktsegment == segment] JOIN orders[o_orderdate < date] ON custkey, then
+    JOIN lineitem[l_shipdate > date] ON orderkey, grouped by (o_orderkey, o_orderdate, o_shippriority)."""
+    c = E.col
+    cust = customer.filter(c("c_mktsegment") == segment)
+    o = cust.join(orders.filter(c("o_orderdate") < date), left_on="c_custkey", right_on="o_custkey")
+    j = o.join(lineitem.filter(c("l_shipdate") > date), left_on="o_orderkey", right_on="l_orderkey")
+    return (j.group_by("o_orderkey", "o_orderdate", "o_shippriority")
+            .agg((c("l_extendedprice") * (1 - c("l_discount"))).sum().alias("revenue")))
+
+
+def q3_full_top10(customer, orders, lineitem, date=Q3_DATE, segment="BUILDING"):
+    """... ORDER BY revenue DESC, o_orderdate LIMIT 10"""
+    return q3_full(customer, orders, lineitem, date, segment).sort("revenue", "o_orderdate", descending=[True, False]).head(10)
+
+
 def q1_sorted(lineitem, cutoff=Q1_CUTOFF):
     """TPC-H Q1 including its ORDER BY l_returnflag, l_linestatus (device radix sort of the <= 6 result rows)."""
     return q1(lineitem, cutoff).sort("l_returnflag", "l_linestatus")

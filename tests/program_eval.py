@@ -9,7 +9,7 @@ emitted against the oracle without a GPU.  Opcodes / kinds mirror polars_amd/csr
 import numpy as np
 
 (OP_NOP, OP_LOAD, OP_CONST, OP_ADD_F, OP_SUB_F, OP_MUL_F, OP_DIV_F, OP_ADD_I, OP_SUB_I, OP_MUL_I, OP_I2F, OP_U2F, OP_CMP_I, OP_CMP_U, OP_CMP_F,
- OP_AND, OP_OR, OP_XOR, OP_NOT, OP_IFNULL, OP_MOV, OP_CANON_F, OP_FDIV_I, OP_MOD_I, OP_FDIV_U, OP_MOD_U) = range(26)
+ OP_AND, OP_OR, OP_XOR, OP_NOT, OP_IFNULL, OP_MOV, OP_CANON_F, OP_FDIV_I, OP_MOD_I, OP_FDIV_U, OP_MOD_U, OP_BITLOOKUP) = range(27)
 (AGG_NONE, AGG_SUM_F, AGG_SUM_I, AGG_COUNT, AGG_COUNT_ORD, AGG_LEN, AGG_MIN_F, AGG_MAX_F, AGG_MIN_I, AGG_MAX_I, AGG_MIN_U, AGG_MAX_U, AGG_FIRST_ROW) = range(13)
 FIN_COPY64, FIN_TRUNC32, FIN_MEAN, FIN_MINMAX_I, FIN_MINMAX_F, FIN_NARROW = range(6)
 # plx_dtype (include/polars_amd.h)
@@ -52,9 +52,10 @@ def _floor_div_mod(x, y, want_div, signed):
     return np.where(nz, r, U(0)), nz
 
 
-def run_rows(prog, cols):
+def run_rows(prog, cols, luts=None):
     """Executes the register program over all rows.  cols: {name: (values ndarray, valid bool ndarray or None)}.
-    Returns (slots {slot: (u64 values, bool valid)}, pass mask)."""
+    luts: {index: bool array over the lookup bitmap's key range} for OP_BITLOOKUP (fused_device.hpp: bit (a - imm) of lut c, 0
+    outside the range, validity of a).  Returns (slots {slot: (u64 values, bool valid)}, pass mask)."""
     n = len(next(iter(cols.values()))[0]) if cols else 0
     slots = {}
     ones = np.ones(n, dtype=bool)
@@ -109,6 +110,13 @@ def run_rows(prog, cols):
                 elif code in (OP_FDIV_U, OP_MOD_U):
                     d, nz = _floor_div_mod(x, y, code == OP_FDIV_U, False); vd = vd & nz
                 elif code == OP_IFNULL: d, vd = np.where(vx, x, imm), ones.copy()
+                elif code == OP_BITLOOKUP:
+                    bits = luts[c]
+                    idx = x - imm                                     # wrapping u64: below the range -> huge -> outside
+                    inside = vx & (idx < U(len(bits)))
+                    d = np.zeros(n, np.uint64)
+                    d[inside] = bits[idx[inside].astype(np.int64)].astype(np.uint64)
+                    vd = vx
                 elif code in (OP_MOV, OP_NOP): d, vd = x, vx
                 else:
                     raise NotImplementedError(f"opcode {code}")
@@ -237,26 +245,48 @@ def evaluate(prog, cols):
     return res
 
 
-def evaluate_join(prog, build_cols, probe_cols):
+def build_luts(prog, filter_cols):
+    """Membership bitmaps of the pipeline's semi filters (engine.cpp: nested inner joins that only filter): for each entry of
+    prog["semis"] the filter program runs over its frame (filter_cols[i]) and sets bit (key - kmin) of every passing row with a
+    valid key.  Returns {lut index: bool array}, or None when a filter side's keys are not unique (the rewrite does not apply)."""
+    luts = {}
+    for sm, cols in zip(prog.get("semis", []), filter_cols):
+        slots, passed = run_rows(sm["filter"], cols)
+        kv, km = slots[sm["filter"]["key"]]
+        kmin, kmax = int(sm["kmin"]), int(sm["kmax"])
+        bits = np.zeros(max(kmax - kmin + 1, 1), bool)
+        idx = (kv[passed & km].view(np.int64) - kmin)
+        idx = idx[(idx >= 0) & (idx < len(bits))]
+        if len(np.unique(idx)) != len(idx):
+            return None
+        bits[idx] = True
+        luts[sm["lut"]] = bits
+    return luts
+
+
+def evaluate_join(prog, build_cols, probe_cols, filter_cols=()):
     """The fused join -> group-by pipeline (engine.cpp fused_join_groupby): build scan (predicate + key) -> probe scan
     (predicate + key + aggregates landing in the matching build row's cells) -> groups with at least one probe row.
-    build_cols / probe_cols: {original column name of that frame: (values, valid or None)}.
-    Returns {output name: (values, valid or None)}, or None when the surviving build keys are not unique (the engine then
-    falls back to the per-node join)."""
-    b_slots, b_pass = run_rows(prog["build"], build_cols)
+    build_cols / probe_cols: {original column name of that frame: (values, valid or None)}; filter_cols: the frames of
+    prog["semis"] in order.  Returns {output name: (values, valid or None)}, or None when the surviving build keys (or a
+    semi filter's keys) are not unique (the engine then falls back to the per-node join)."""
+    luts = build_luts(prog, filter_cols)
+    if luts is None:
+        return None
+    b_slots, b_pass = run_rows(prog["build"], build_cols, luts)
     bk, bkm = b_slots[prog["build"]["key"]]
     ins = b_pass & bkm                                   # null build keys are never inserted
     rows_b = np.nonzero(ins)[0]
     keys_b = bk[rows_b]
     # the count scan sizes the tables: it must count exactly the inserted rows
-    c_slots, c_pass = run_rows(prog["count"], build_cols)
+    c_slots, c_pass = run_rows(prog["count"], build_cols, luts)
     ccells = _cells(prog["count"], c_slots, c_pass, np.arange(len(c_pass)), np.zeros(len(c_pass), dtype=np.int64), 1)
     assert int(ccells[0, 0]) == len(rows_b), (int(ccells[0, 0]), len(rows_b))
     order = np.argsort(keys_b, kind="stable")
     skeys, srows = keys_b[order], rows_b[order]
     if len(skeys) > 1 and (skeys[1:] == skeys[:-1]).any():
         return None
-    p_slots, p_pass = run_rows(prog["probe"], probe_cols)
+    p_slots, p_pass = run_rows(prog["probe"], probe_cols, luts)
     pk, pkm = p_slots[prog["probe"]["key"]]
     pos = np.searchsorted(skeys, pk)
     pos_c = np.minimum(pos, max(len(skeys) - 1, 0))

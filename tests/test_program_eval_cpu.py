@@ -298,6 +298,46 @@ def test_q3_pipeline_matches_oracle(orc):
     assert np.allclose(got["revenue"][0][order], want["revenue"], rtol=1e-9)
 
 
+def test_q3_three_tables_pipeline_matches_oracle(orc):
+    """TPC-H Q3 with customer: the nested inner join customer x orders only FILTERS orders (no customer column is used above
+    it, c_custkey is unique), so the compiler reduces it to a membership bitmap tested inside the build scan (OP_BITLOOKUP);
+    the dictionary compare c_mktsegment == "BUILDING" is a compare of codes."""
+    no = 30_000
+    orders, li = datagen.orders_lineitem_host(no, seed=15, ordered=True)
+    cust = datagen.customer_host(datagen.n_customers_for(no), seed=15)
+    lt = datagen.logical_dtypes(pl)
+    lcols = {k: (li[k], None) for k in datagen.LINEITEM_Q3_COLS}
+    ocols = {k: (orders[k], None) for k in datagen.ORDERS_Q3_COLS}
+    ccols = {k: (cust[k], None) for k in datagen.CUSTOMER_Q3_COLS}
+    lf = Q.q3_full(frame_like(ccols, lt).lazy(), frame_like(ocols, lt).lazy(), frame_like(lcols, lt).lazy())
+    ok, sid, why, dump = lf.describe_fusion()
+    assert ok and dump.count("\n") == 3, (why, dump)                       # count / build / probe / semi filter
+    prog = lf.debug_program()
+    assert prog["kind"] == "join_group_by" and prog["build_key"] == "o_orderkey" and prog["probe_key"] == "l_orderkey"
+    assert [g["name"] for g in prog["group_keys"]] == ["o_orderkey", "o_orderdate", "o_shippriority"]
+    (sm,) = prog["semis"]
+    assert sm["side"] == "build" and sm["filter_key"] == "c_custkey" and sm["payload_key"] == "o_custkey" and (int(sm["kmin"]), int(sm["kmax"])) == (1, len(cust["c_custkey"]))
+    assert any(op[0] == pe.OP_BITLOOKUP for op in prog["build"]["ops"]) and any(op[0] == pe.OP_BITLOOKUP for op in prog["count"]["ops"])
+    got = pe.evaluate_join(prog, ocols, lcols, [ccols])
+    want = orc.q3_full(cust, {k: orders[k] for k in datagen.ORDERS_Q3_COLS}, {k: li[k] for k in datagen.LINEITEM_Q3_COLS}, datagen.us(1995, 3, 15), datagen.SEGMENTS.index("BUILDING"))
+    order = np.argsort(got["o_orderkey"][0])
+    assert len(order) == len(want["o_orderkey"]) > 100
+    assert np.array_equal(got["o_orderkey"][0][order], want["o_orderkey"]) and np.array_equal(got["o_orderdate"][0][order], want["o_orderdate"])
+    assert np.allclose(got["revenue"][0][order], want["revenue"], rtol=1e-9)
+    # a segment that is not in the dictionary matches no customer: empty result, not an error
+    none = Q.q3_full(frame_like(ccols, lt).lazy(), frame_like(ocols, lt).lazy(), frame_like(lcols, lt).lazy(), segment="NOSUCH").debug_program()
+    assert len(pe.evaluate_join(none, ocols, lcols, [ccols])["o_orderkey"][0]) == 0
+    # duplicate customer keys: the join would multiply rows -> the rewrite must refuse (engine: per-node path)
+    dup = {"c_custkey": (np.concatenate([cust["c_custkey"], cust["c_custkey"][:50]]), None), "c_mktsegment": (np.concatenate([cust["c_mktsegment"], np.ones(50, np.uint8)]), None)}
+    progd = Q.q3_full(frame_like(dup, lt).lazy(), frame_like(ocols, lt).lazy(), frame_like(lcols, lt).lazy()).debug_program()
+    seg1 = cust["c_mktsegment"][:50] == 1
+    assert (pe.evaluate_join(progd, ocols, lcols, [dup]) is None) == bool(seg1.any())
+    # a customer column used above the join: not a pure filter -> not fused
+    bad = (frame_like(ccols, lt).lazy().join(frame_like(ocols, lt).lazy(), left_on="c_custkey", right_on="o_custkey")
+           .join(frame_like(lcols, lt).lazy(), left_on="o_orderkey", right_on="l_orderkey").group_by("o_orderkey", "c_mktsegment").agg(pl.len()))
+    assert bad.describe_fusion()[0] is False
+
+
 @pytest.mark.parametrize("build", ["right", "left"])
 def test_join_group_by_pipeline_matches_numpy(build):
     """Both build sides, nullable keys on both sides, predicates on both inputs, several aggregates incl. mean / min / count of a
