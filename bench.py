@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="q1", choices=["q1", "q3", "cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--workload", default="q1", choices=["q1", "q3", "q3f", "cfg2", "cfg3", "cfg5"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the SF100 / 1e9-row size of the workload)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -236,12 +236,13 @@ def verify_groupby_dense(frame, key: str, sum_col: str, n: int, seed: int, n_key
             "max_rel_err": err, "rtol": VERIFY_RTOL, "groups": int(len(present))}
 
 
-def q3_expected_block(o: dict, li: dict, cnt, date: int, seg_mod: int = 5):
+def q3_expected_block(o: dict, li: dict, cnt, date: int, seg_mod: int = 5, cust_ok=None):
     """Q3 over one self-contained block of orders and their lines (dbgen order keeps an order's lines next to each other):
-    numpy restatement -> (orderkeys, orderdates, revenue) of the result groups, ascending in orderkey."""
+    numpy restatement -> (orderkeys, orderdates, revenue) of the result groups, ascending in orderkey.  cust_ok (bool per
+    custkey) = the three-table query's customer filter; otherwise the two-table stand-in o_custkey % seg_mod == 0."""
     import numpy as np
     nb = len(cnt)
-    om = (o["o_orderdate"] < date) & ((o["o_custkey"] % seg_mod) == 0)
+    om = (o["o_orderdate"] < date) & (cust_ok[o["o_custkey"]] if cust_ok is not None else ((o["o_custkey"] % seg_mod) == 0))
     oidx = np.repeat(np.arange(nb, dtype=np.int64), cnt)
     lm = (li["l_shipdate"] > date) & om[oidx]
     rev = li["l_extendedprice"][lm] * (1.0 - li["l_discount"][lm])
@@ -251,17 +252,25 @@ def q3_expected_block(o: dict, li: dict, cnt, date: int, seg_mod: int = 5):
     return o["o_orderkey"][has], o["o_orderdate"][has], sums[has]
 
 
-def verify_q3(frame, n_orders: int, seed: int, budget_s: float, block: int = 8_000_000, oracle_orders: int = 4_000_000) -> dict:
+def verify_q3(frame, n_orders: int, seed: int, budget_s: float, block: int = 8_000_000, oracle_orders: int = 4_000_000, customer_seed=None) -> dict:
     """The timed Q3 result against (a) the oracle's Q3 (reference operator order: filter, hash join, gather, group_by) on the
     first `oracle_orders` orders and (b) a numpy restatement over every block of orders the time budget allows; groups are
-    compared up to the last order key covered."""
+    compared up to the last order key covered.  customer_seed: the three-table query (customer host twin, segment BUILDING)."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle as orc
     from polars_amd import datagen
     date = datagen.us(1995, 3, 15)
     t0 = time.perf_counter()
-    gk = frame["l_orderkey"].to_numpy().astype(np.int64)
+    full3 = customer_seed is not None
+    key_name = "o_orderkey" if full3 else "l_orderkey"
+    cust = cust_ok = None
+    if full3:
+        ncust = datagen.n_customers_for(n_orders)
+        cust = datagen.customer_native_host(0, ncust, customer_seed)
+        cust_ok = np.zeros(ncust + 2, bool)
+        cust_ok[cust["c_custkey"][cust["c_mktsegment"] == datagen.SEGMENTS.index("BUILDING")]] = True
+    gk = frame[key_name].to_numpy().astype(np.int64)
     order = np.argsort(gk, kind="stable")
     gk, gd, gr = gk[order], frame["o_orderdate"].to_numpy().astype(np.int64)[order], frame["revenue"].to_numpy()[order]
     gp = frame["o_shippriority"].to_numpy()
@@ -269,12 +278,15 @@ def verify_q3(frame, n_orders: int, seed: int, budget_s: float, block: int = 8_0
     no = min(oracle_orders, n_orders)
     o, li, cnt = datagen.orders_lineitem_native_host_mt(0, no, n_orders, seed)
     o["o_shippriority"] = np.zeros(no, np.int64)
-    w = orc.q3({k: li[k] for k in datagen.LINEITEM_Q3_COLS}, {k: o[k] for k in datagen.ORDERS_Q3_COLS}, date)
+    if full3:
+        w = orc.q3_full(cust, {k: o[k] for k in datagen.ORDERS_Q3_COLS}, {k: li[k] for k in datagen.LINEITEM_Q3_COLS}, date, datagen.SEGMENTS.index("BUILDING"))
+    else:
+        w = orc.q3({k: li[k] for k in datagen.LINEITEM_Q3_COLS}, {k: o[k] for k in datagen.ORDERS_Q3_COLS}, date)
     hi = int(o["o_orderkey"][-1])
     m = gk <= hi
-    ok_oracle = bool(np.array_equal(gk[m], w["l_orderkey"]) and np.array_equal(gd[m], w["o_orderdate"]) and _rel_err(gr[m], w["revenue"]) <= VERIFY_RTOL)
-    rk, rd, rr = q3_expected_block(o, li, cnt, date)
-    ok_oracle = ok_oracle and bool(np.array_equal(rk, w["l_orderkey"]) and _rel_err(rr, w["revenue"]) <= 1e-12)   # the restatement agrees with the oracle
+    ok_oracle = bool(np.array_equal(gk[m], w[key_name]) and np.array_equal(gd[m], w["o_orderdate"]) and _rel_err(gr[m], w["revenue"]) <= VERIFY_RTOL)
+    rk, rd, rr = q3_expected_block(o, li, cnt, date, cust_ok=cust_ok)
+    ok_oracle = ok_oracle and bool(np.array_equal(rk, w[key_name]) and _rel_err(rr, w["revenue"]) <= 1e-12)   # the restatement agrees with the oracle
     lines_oracle = len(li["l_orderkey"])
     del o, li, cnt, w
     # (b) numpy restatement over all blocks
@@ -283,7 +295,7 @@ def verify_q3(frame, n_orders: int, seed: int, budget_s: float, block: int = 8_0
 
     def work(bl):
         o, li, cnt = datagen.orders_lineitem_native_host_mt(bl[0], bl[1], n_orders, seed, threads=16)
-        return q3_expected_block(o, li, cnt, date), len(li["l_orderkey"]), int(o["o_orderkey"][-1])
+        return q3_expected_block(o, li, cnt, date, cust_ok=cust_ok), len(li["l_orderkey"]), int(o["o_orderkey"][-1])
     last_key = -1
     with ThreadPoolExecutor(4) as ex:
         for i in range(0, len(blocks), 4):
@@ -298,7 +310,7 @@ def verify_q3(frame, n_orders: int, seed: int, budget_s: float, block: int = 8_0
     ok = bool(int(m.sum()) == len(wk) and np.array_equal(gk[m], wk) and np.array_equal(gd[m], wd) and err <= VERIFY_RTOL and not np.any(gp))
     full = done_orders >= n_orders
     return {"rows": int(done_orders + lines), "orders": int(done_orders), "lineitem_rows": int(lines), "covers_whole_input": bool(full),
-            "against": f"oracle Q3 (filter -> hash join -> gather -> group_by) on the first {no} orders / {lines_oracle} lines + numpy restatement over "
+            "against": f"oracle Q3 ({'customer x orders x lineitem' if full3 else 'orders x lineitem'}: filter -> hash join(s) -> gather -> group_by) on the first {no} orders / {lines_oracle} lines + numpy restatement over "
                        f"{'all' if full else done_orders} orders of the generator's host twin",
             "ok": bool(ok and ok_oracle and (full or done_orders > 0)), "ok_oracle_prefix": ok_oracle, "max_rel_err": err, "rtol": VERIFY_RTOL, "groups_checked": int(len(wk)),
             "groups_total": int(len(gk))}
@@ -392,6 +404,24 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
         return Workload("tpch_q3_sf100", nl + no, nl * datagen.Q3_LINEITEM_BYTES_PER_ROW + no * datagen.Q3_ORDERS_BYTES_PER_ROW, step, "join_probe_emit",
                         f"TPC-H Q3 (orders {no} x lineitem {nl}), filter both -> hash join -> group_by(orderkey, orderdate, shippriority)",
                         variants={} if ws > 1 else {"tpch_q3_sf100_order_by_limit10": step_top10}, verify=verify, scope="operator")
+    if name == "q3f":
+        # TPC-H Q3 with all three tables: customer[c_mktsegment == "BUILDING"] JOIN orders JOIN lineitem
+        no = (rows // 4) if rows else SF100_ORDERS
+        nc = datagen.n_customers_for(no)
+        O, L = datagen.orders_lineitem_native(pl, no, seed)
+        Cst = datagen.customer_native(pl, nc, seed)
+        nl = L.height
+        lf = queries.q3_full(Cst.lazy(), O.lazy(), L.lazy())
+
+        def step():
+            return lf.collect(), (Cst, O, L)
+        lf_top = queries.q3_full_top10(Cst.lazy(), O.lazy(), L.lazy())
+
+        def step_top10():
+            return lf_top.collect().to_dict(), (Cst, O, L)
+        return Workload("tpch_q3_three_tables_sf100", nl + no + nc, nl * datagen.Q3_LINEITEM_BYTES_PER_ROW + no * datagen.Q3_ORDERS_BYTES_PER_ROW + nc * 9, step, "join_probe_emit",
+                        f"TPC-H Q3 with customer ({nc}) x orders ({no}) x lineitem ({nl}): c_mktsegment == 'BUILDING', two joins, group_by(orderkey, orderdate, shippriority)",
+                        variants={"tpch_q3_three_tables_sf100_order_by_limit10": step_top10}, verify=lambda res, budget: verify_q3(res, no, seed, budget, customer_seed=seed), scope="operator")
     if name == "cfg2":
         n = rows or 1_000_000_000
         a = x = y = None
@@ -522,7 +552,7 @@ def pmc_traffic(workload_name: str, kernel: str, rows: int):
             "cfg5_dict_string_keys_1e9": 1_000_000_000}
     if workload_name in full and rows != full[workload_name]:
         return None
-    short = {"tpch_q1_sf100": "q1", "tpch_q3_sf100": "q3", "cfg2_filter_arith_agg_1e9": "cfg2", "cfg3_groupby_1e6_keys_1e9": "cfg3", "cfg5_dict_string_keys_1e9": "cfg5"}.get(workload_name)
+    short = {"tpch_q1_sf100": "q1", "tpch_q3_sf100": "q3", "tpch_q3_three_tables_sf100": "q3f", "cfg2_filter_arith_agg_1e9": "cfg2", "cfg3_groupby_1e6_keys_1e9": "cfg3", "cfg5_dict_string_keys_1e9": "cfg5"}.get(workload_name)
     for rnd in ("r02", "r01"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", rnd, f"{short}_pmc.json" if rnd != "r01" else f"{short}_sf100_pmc.json")))
@@ -905,7 +935,7 @@ def run(args, emit):
             emit(line)
         del wl, res
         torch.cuda.empty_cache()
-        for name in [w for w in ("q3", "cfg2", "cfg3", "cfg5", "q1") if w != args.workload]:
+        for name in [w for w in ("q3", "q3f", "cfg2", "cfg3", "cfg5", "q1") if w != args.workload]:
             try:
                 w2 = make_workload(pl, name, 0, seed=20)
                 d2, s2, r2, c2 = timed(pl, w2, k2, 1, False)

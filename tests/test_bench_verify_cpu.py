@@ -90,3 +90,21 @@ def test_q3_check():
     assert r["ok"] and r["covers_whole_input"] and r["groups_checked"] == len(perm) and r["rows"] == no + len(li["l_orderkey"]), r
     f.raw("revenue")[0] *= 1.001
     assert bench.verify_q3(f, no, seed, 60, block=25_000, oracle_orders=20_000)["ok"] is False
+
+
+def test_q3_three_tables_check():
+    from oracle import pyoracle as orc
+    orc.set_threads(4)
+    no, seed = 60_000, 21
+    o, li, cnt = datagen.orders_lineitem_native_host(0, no, no, seed)
+    o["o_shippriority"] = np.zeros(no, np.int64)
+    cust = datagen.customer_native_host(0, datagen.n_customers_for(no), seed)
+    w = orc.q3_full(cust, {k: o[k] for k in datagen.ORDERS_Q3_COLS}, {k: li[k] for k in datagen.LINEITEM_Q3_COLS}, datagen.us(1995, 3, 15), datagen.SEGMENTS.index("BUILDING"))
+    assert len(w["o_orderkey"]) > 50
+    perm = np.random.default_rng(2).permutation(len(w["o_orderkey"]))
+    f = Frame({k: w[k][perm] for k in w})
+    r = bench.verify_q3(f, no, seed, 60, block=25_000, oracle_orders=20_000, customer_seed=seed)
+    assert r["ok"] and r["covers_whole_input"] and r["groups_checked"] == len(perm), r
+    # the two-table stand-in (o_custkey % 5 == 0) is a different query: its check must reject this result
+    f2 = Frame({("l_orderkey" if k == "o_orderkey" else k): w[k][perm] for k in w})
+    assert bench.verify_q3(f2, no, seed, 60, block=25_000, oracle_orders=20_000)["ok"] is False

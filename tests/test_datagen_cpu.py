@@ -113,3 +113,14 @@ def test_uniform_generator_host_twin():
     key = _mix(7)
     for i in (0, 1, 99_999):
         assert a[i] == (_mix((key + i * 8 + 0) & M64) * 2 ** 31) >> 64
+
+
+def test_customer_host_twin_properties():
+    """plx_datagen_customer_host: dense keys in order, five market segments roughly uniform, a pure function of (seed, key)."""
+    a = datagen.customer_native_host(0, 50_000, seed=9)
+    assert np.array_equal(a["c_custkey"], np.arange(1, 50_001)) and a["c_mktsegment"].dtype == np.uint8 and a["c_mktsegment"].max() == 4
+    frac = np.bincount(a["c_mktsegment"], minlength=5) / 50_000
+    assert np.all(np.abs(frac - 0.2) < 0.01)
+    b = datagen.customer_native_host(12_345, 1000, seed=9)
+    assert np.array_equal(b["c_custkey"], a["c_custkey"][12_345:13_345]) and np.array_equal(b["c_mktsegment"], a["c_mktsegment"][12_345:13_345])
+    assert not np.array_equal(datagen.customer_native_host(0, 1000, seed=10)["c_mktsegment"], a["c_mktsegment"][:1000])

@@ -1,11 +1,10 @@
 """The library's lineitem generator kernel against its host twin, and TPC-H Q1 over a generated table against the oracle.
 bench.py performs the same spot check before every headline measurement (and falls back to the torch generators if it
-fails), so a defect here cannot corrupt a measurement; the kernel was written after this round's GPU budget was spent,
-hence the non-strict xfail: a pass shows up as XPASS, a failure does not mask the rest of the suite."""
+fails), so a defect here cannot corrupt a measurement."""
 import numpy as np
 import pytest
 
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="generator kernel not yet validated on a GPU (added after this round's GPU budget was spent)")]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("n", [0, 1, 4097, 1_000_003])
@@ -49,3 +48,11 @@ def test_uniform_device_generator_equals_host_twin(pl):
     for name, dt, args in (("Int64", pl.Int64, (3, 0, 0, 2 ** 31, 1.0)), ("UInt32", pl.UInt32, (3, 1, 0, 1_000_000, 1.0)), ("Float64", pl.Float64, (3, 2, 0, 10 ** 9, 1e-7))):
         s = datagen.uniform_native(pl, "c", dt, n, *args)
         assert np.array_equal(s.to_numpy(), datagen.uniform_native_host(name, 0, n, *args)), name
+
+
+def test_customer_generator_matches_host_twin(pl):
+    from polars_amd import datagen
+    n = 300_001
+    df = datagen.customer_native(pl, n, seed=5)
+    want = datagen.customer_native_host(0, n, seed=5)
+    assert np.array_equal(df["c_custkey"].to_numpy(), want["c_custkey"]) and np.array_equal(df["c_mktsegment"].to_numpy(), want["c_mktsegment"])

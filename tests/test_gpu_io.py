@@ -1,12 +1,11 @@
 """Parquet scan end to end on the GPU: TPC-H Q1 straight from a 16-column lineitem file equals the oracle on the same rows, only
-the needed columns / row groups cross PCIe.  The scan planning is pinned on the CPU (tests/test_io_cpu.py); this file was written
-after this round's GPU budget was spent, hence the non-strict xfail."""
+the needed columns / row groups cross PCIe.  The scan planning is pinned on the CPU (tests/test_io_cpu.py)."""
 import numpy as np
 import pyarrow as pa
 import pyarrow.parquet as pq
 import pytest
 
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="parquet scan not yet run on a GPU (added after this round's GPU budget was spent)")]
+pytestmark = pytest.mark.gpu
 
 
 def test_q1_from_parquet(pl, orc, tmp_path):

@@ -1,10 +1,10 @@
 """is_null / is_not_null / fill_null(literal) on the GPU: fused (compare-with-self + IFNULL, opcodes the kernels already ran) and,
 for the two predicates, the per-node path (the validity bitmap shared as a Boolean column).  The lowering is pinned on the CPU
-(tests/test_program_eval_cpu.py::test_is_null_is_not_null_fill_null); written after this round's GPU budget was spent."""
+(tests/test_program_eval_cpu.py::test_is_null_is_not_null_fill_null)."""
 import numpy as np
 import pytest
 
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="null-handling expressions not yet run on a GPU (added after this round's GPU budget was spent)")]
+pytestmark = pytest.mark.gpu
 
 
 def test_null_expressions_fused_and_per_node(pl):

@@ -613,3 +613,34 @@ def test_declared_bounds_are_checked_not_trusted_blindly(pl):
     bad = pl.DataFrame([pl.Series("k", bad_codes, dtype=pl.Categorical(["c%d" % i for i in range(500_000)], pl.UInt32)), pl.Series("v", v)])
     with pytest.raises(pl.PlxError):
         queries.cfg5(bad.lazy()).collect()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_q3_three_tables(pl, orc, fused):
+    """TPC-H Q3 with customer: the dictionary compare c_mktsegment == "BUILDING", customer x orders
+    (a pure filter: reduced to a membership bitmap tested inside the orders scan) and orders x lineitem, against the oracle's
+    three-table Q3; also through the one-kernel-per-node path."""
+    from polars_amd import datagen, queries
+    no = 150_000
+    orders, li = datagen.orders_lineitem_host(no, seed=17, ordered=True)
+    cust = datagen.customer_host(datagen.n_customers_for(no), seed=17)
+    C = datagen.to_frame(pl, cust, datagen.CUSTOMER_Q3_COLS); O = datagen.to_frame(pl, orders, datagen.ORDERS_Q3_COLS); L = datagen.to_frame(pl, li, datagen.LINEITEM_Q3_COLS)
+    out = queries.q3_full(C.lazy(), O.lazy(), L.lazy()).collect(no_fusion=not fused)
+    plan = pl.last_plan()
+    if fused:
+        assert "SemiFilter{c_custkey -> bitmap" in plan and "FusedJoinGroupBy" in plan, plan
+    else:
+        assert "Fused" not in plan, plan
+    want = orc.q3_full(cust, {k: orders[k] for k in datagen.ORDERS_Q3_COLS}, {k: li[k] for k in datagen.LINEITEM_Q3_COLS}, datagen.us(1995, 3, 15), datagen.SEGMENTS.index("BUILDING"))
+    k = out["o_orderkey"].to_numpy(); order = np.argsort(k)
+    assert len(k) == len(want["o_orderkey"]) > 500
+    assert np.array_equal(k[order], want["o_orderkey"]) and np.array_equal(out["o_orderdate"].to_numpy()[order], want["o_orderdate"])
+    assert np.array_equal(out["o_shippriority"].to_numpy()[order], want["o_shippriority"])
+    assert close(out["revenue"].to_numpy()[order], want["revenue"])
+    if fused:
+        # ORDER BY revenue DESC, o_orderdate LIMIT 10 on top of the fused pipeline
+        top = queries.q3_full_top10(C.lazy(), O.lazy(), L.lazy()).collect()
+        best = np.lexsort((want["o_orderdate"], -want["revenue"]))[:10]
+        assert top["o_orderkey"].to_numpy().tolist() == want["o_orderkey"][best].tolist()
+        # a segment missing from the dictionary: empty result
+        assert queries.q3_full(C.lazy(), O.lazy(), L.lazy(), segment="NOSUCH").collect().height == 0
