@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--dry-run", action="store_true", help="sharded workloads only: numpy frames + gloo instead of the library + RCCL (control-flow check without GPUs)")
     return ap.parse_args()
 
 
@@ -841,6 +842,145 @@ def main():
         print(json.dumps(final), flush=True)
 
 
+# ---- sharded high-cardinality group-by (cfg3 / cfg5 at N > 1) ------------------------------------------------------------
+# Every rank holds its own row shard (weak scaling); a step = ONE exchange of all rows by key hash (polars_amd/dist.py
+# sharded_groupby: plx_exchange_by_key = hash partition + gather + one grouped ncclSend / ncclRecv all-to-all(v) inside the
+# library) + the single-GPU partitioned group-by over the keys the rank owns.  The result stays sharded.  `--dry-run` swaps the
+# library and RCCL for numpy frames and gloo so the control flow (barriers, accounting, the JSON line) can be exercised
+# without GPUs (tests/test_dist_gloo_cpu.py); nothing of it is measured.
+class DryFrame:
+    """numpy stand-in for a device DataFrame (dry run only)."""
+
+    def __init__(self, cols):
+        self.cols = cols
+
+    @property
+    def height(self):
+        return len(next(iter(self.cols.values())))
+
+
+class DryComm:
+    """gloo stand-in for dist.LibComm (dry run only): same routing rule shape (a hash of the key modulo world size), one
+    all_to_all per column."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+        self.rows_sent = self.bytes_sent = 0
+
+    def exchange_by_key(self, df, key, seed=0):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        ws = self.world_size
+        k = df.cols[key].astype(np.uint64)
+        part = ((k * np.uint64(0x55fbfd6bfc5458e9)) >> np.uint64(40)) % np.uint64(ws)
+        order = np.argsort(part, kind="stable")
+        counts = np.bincount(part.astype(np.int64), minlength=ws).astype(np.int64)
+        send = torch.from_numpy(counts.copy()); recv = torch.zeros_like(send)
+        dist.all_to_all_single(recv, send)
+        rc = [int(x) for x in recv.tolist()]
+        out = {}
+        for name, v in df.cols.items():
+            src = torch.from_numpy(np.ascontiguousarray(v[order]).view(np.uint8).reshape(-1))
+            w = v.dtype.itemsize
+            dst = torch.empty(sum(rc) * w, dtype=torch.uint8)
+            dist.all_to_all_single(dst, src, output_split_sizes=[c * w for c in rc], input_split_sizes=[int(c) * w for c in counts])
+            out[name] = dst.numpy().view(v.dtype)
+            self.bytes_sent += int(sum(int(c) for i, c in enumerate(counts) if i != self.rank)) * w
+        self.rows_sent += int(sum(int(c) for i, c in enumerate(counts) if i != self.rank))
+        return DryFrame(out)
+
+
+def run_sharded(args, emit):
+    """bench.py --gpus N --workload cfg3 | cfg5: the sharded operator, one rank per GPU."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from polars_amd import dist as pdist
+    rank, local_rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dry = args.dry_run
+    cfg5 = args.workload == "cfg5"
+    n = args.rows or 1_000_000_000
+    n_keys = 1_000_000
+    seed = 10 + rank
+    key_name, val_name = ("k", "v")if cfg5 else ("key", "v")
+    if dry:
+        from polars_amd import datagen
+        pdist.init_process_group("gloo")
+        k = datagen.uniform_native_host("UInt32" if cfg5 else "Int64", 0, n, seed, 0, 0, n_keys)
+        v = datagen.uniform_native_host("Float64", 0, n, seed, 1, 0, 10 ** 9, 1e-7) if cfg5 else datagen.uniform_native_host("Int64", 0, n, seed, 1, 0, 1000)
+        df = DryFrame({key_name: k, val_name: v})
+        comm = DryComm()
+
+        def query(d):
+            kk = d.cols[key_name].astype(np.int64)
+            s = np.bincount(kk, weights=d.cols[val_name], minlength=n_keys); c = np.bincount(kk, minlength=n_keys)
+            keep = np.nonzero(c)[0]
+            return DryFrame({key_name: keep, "v_sum": s[keep] if cfg5 else s[keep].astype(np.int64), "v_count": c[keep]})
+        sync = lambda: None
+        stats_fn = lambda: {}
+    else:
+        torch.cuda.set_device(local_rank)
+        import polars_amd as pl
+        from polars_amd import queries
+        pl.init(local_rank)
+        pdist.init_process_group("nccl")
+        wl0 = make_workload(pl, args.workload, n, seed=seed)      # this rank's shard, from the library's generator
+        df = wl0.step()[1][0]
+        comm = pdist.LibComm(pl)
+        q = queries.cfg5 if cfg5 else queries.cfg3
+        query = lambda d: q(d.lazy()).collect()
+        F = pl._ffi
+        sync = lambda: (torch.cuda.synchronize(), F.check(F.lib().plx_synchronize()))
+        stats_fn = lambda: kernel_stats(pl)
+    res = None
+    for _ in range(max(args.warmup, 1)):
+        res = pdist.sharded_groupby(comm, df, key_name, query)
+    if not dry:
+        F.check(F.lib().plx_profile_clear()); F.check(F.lib().plx_profile_enable(1))
+    comm.rows_sent = comm.bytes_sent = 0
+    dist.barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = pdist.sharded_groupby(comm, df, key_name, query)
+    sync(); dist.barrier()
+    dt = time.perf_counter() - t0
+    stats = stats_fn()
+    # max over ranks of the timed region; totals of the exchange accounting and of the (sharded) result
+    t = torch.tensor([dt, float(comm.rows_sent), float(comm.bytes_sent), float(res.height)], dtype=torch.float64)
+    if not dry:
+        t = t.cuda()
+    tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    dt = float(tmax[0].item())
+    rec_bytes = (4 + 8) if cfg5 else 16
+    algo = n * rec_bytes + n_keys * 20 // ws
+    line = {
+        "metric": "rows/sec + achieved HBM GB/s, TPC-H Q1/Q3 SF100, 1/2/4/8 GPU vs CPU",
+        "value": round(n * ws * args.steps / dt, 1), "unit": "rows/s", "n_gpus": ws, "steps": args.steps, "warmup": max(args.warmup, 1),
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64" if cfg5 else "int64", "data": "synthetic",
+        "config": {"workload": ("cfg5_dict_string_keys" if cfg5 else "cfg3_groupby_1e6_keys") + f"_sharded_x{ws}", "rows_per_gpu": n, "algorithmic_bytes_per_gpu_step": algo,
+                   "description": f"{n} rows per rank, 1e6 keys over all ranks, group_by(key).agg(...): rows exchanged by key hash (one grouped all-to-all(v) of every column), "
+                                  "then the single-GPU partitioned group-by over the rank's keys; result sharded by key",
+                   "parallelism": f"row-sharded x{ws}, rows exchanged by key hash (all-to-all), per-rank group-by over disjoint key sets",
+                   "backend": "numpy + gloo DRY RUN (control flow only, nothing measured)" if dry else "libpolars_amd + RCCL (plx_exchange_by_key)"},
+        "shuffle": {"rows_sent_per_rank_per_step": round(float(tsum[1].item()) / ws / args.steps, 1), "bytes_sent_per_rank_per_step": round(float(tsum[2].item()) / ws / args.steps, 1),
+                    "fabric_GBps_per_rank": round(float(tsum[2].item()) / ws / dt / 1e9, 2)},
+        "groups_total": int(tsum[3].item()),
+        "whole_query_GBps_per_gpu": round(algo * args.steps / dt / 1e9, 1),
+        "kernels": _kernels(stats, 8) if stats else {},
+    }
+    if dry:
+        line["dry_run"] = True
+    if rank == 0:
+        emit(line)
+    dist.barrier()
+    dist.destroy_process_group()
+    return res
+
+
 def _kernels(stats, top: int):
     return {k: {"launches": v[0], "avg_us": round(v[1] / v[0], 2), "pass_bytes_per_launch": int(v[2])} for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])[:top]}
 
@@ -863,6 +1003,9 @@ def run(args, emit):
     import torch
     rank, local_rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     distributed = ws > 1
+    if (distributed or args.dry_run) and args.workload in ("cfg3", "cfg5"):
+        run_sharded(args, emit)
+        return
     torch.cuda.set_device(local_rank)
     import polars_amd as pl
     from polars_amd import dist as pdist

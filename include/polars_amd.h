@@ -439,6 +439,24 @@ int plx_datagen_customer_host(int64_t row0, int64_t n, uint64_t seed, int64_t* c
 int plx_datagen_uniform(int32_t dtype, int64_t n_rows, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, double scale, plx_column* out);
 int plx_datagen_uniform_host(int32_t dtype, int64_t row0, int64_t n, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, double scale, void* out);
 
+/* ---- multi-GPU exchange (one process per GPU, RCCL over xGMI) -----------------------------
+ * The exchange step of the sharded operators; shape of the reference's in-process exchange:
+ * crates/polars-utils/src/hashing.rs:72-121 (HashPartitioner), crates/polars-stream/src/nodes/group_by.rs:252-497
+ * (combine_locals).  A communicator wraps an RCCL communicator created from a 128-byte unique id that rank 0 obtains
+ * (plx_comm_unique_id) and hands to the other ranks by any means (torch.distributed / MPI / a file).  librccl is
+ * loaded with dlopen on first use.
+ *   plx_exchange_by_key  every row of `frame` goes to rank plx_hash_partition(key); all columns travel in ONE grouped
+ *                        ncclSend / ncclRecv all-to-all(v) on the library's stream; *out = the rows this rank received.
+ *                        rows_sent / bytes_sent: what left this rank over the fabric.
+ *   plx_allgather_frame  concatenation of every rank's (small) frame in rank order, on every rank.                     */
+typedef uint64_t plx_comm;
+int plx_comm_unique_id(uint8_t* out_128_bytes);
+int plx_comm_init(const uint8_t* unique_id_128_bytes, int32_t rank, int32_t world_size, plx_comm* out);
+int plx_comm_info(plx_comm comm, int32_t* rank, int32_t* world_size);
+int plx_comm_free(plx_comm comm);
+int plx_exchange_by_key(plx_comm comm, plx_frame frame, const char* key, uint64_t seed, plx_frame* out, uint64_t* rows_sent, uint64_t* bytes_sent);
+int plx_allgather_frame(plx_comm comm, plx_frame frame, plx_frame* out);
+
 /* ---- tracing (NodeTimer equivalent) --------------------------------------- */
 typedef struct plx_profile_record {
   char name[48];      /* kernel / node name */

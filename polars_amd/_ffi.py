@@ -113,6 +113,12 @@ SIGNATURES = {
     "plx_column_from_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, _u64p]),
     "plx_column_placeholder": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _u64p]),
     "plx_column_set_bounds": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64]),
+    "plx_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "plx_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _u64p]),
+    "plx_comm_info": (C.c_int, [C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "plx_comm_free": (C.c_int, [C.c_uint64]),
+    "plx_exchange_by_key": (C.c_int, [C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint64, _u64p, _u64p, _u64p]),
+    "plx_allgather_frame": (C.c_int, [C.c_uint64, C.c_uint64, _u64p]),
     "plx_column_import_arrow": (C.c_int, [C.POINTER(ArrowArray), C.POINTER(ArrowSchema), _u64p]),
     "plx_column_import_series": (C.c_int, [C.POINTER(SeriesExport), _u64p]),
     "plx_column_export_arrow": (C.c_int, [C.c_uint64, C.POINTER(ArrowArray), C.POINTER(ArrowSchema)]),

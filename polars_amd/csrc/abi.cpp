@@ -20,6 +20,14 @@ namespace plx {
 void init_device(int ordinal);
 void clear_handles();
 const std::string& last_error_ref();
+namespace comm {
+void unique_id(uint8_t* out128);
+uint64_t init(const uint8_t* id128, int rank, int ws);
+void destroy(uint64_t h);
+void info(uint64_t h, int* rank, int* ws);
+FramePtr exchange_by_key(uint64_t h, const FramePtr& in, const std::string& key, uint64_t seed, uint64_t* rows_sent, uint64_t* bytes_sent);
+FramePtr allgather_frame(uint64_t h, const FramePtr& in);
+}  // namespace comm
 }  // namespace plx
 
 using namespace plx;
@@ -846,6 +854,24 @@ int plx_jit_stats(int32_t* compiled, double* compile_ms) {
   jit::stats(&c, &ms);
   if (compiled) *compiled = c;
   if (compile_ms) *compile_ms = ms;
+  PLX_CATCH
+}
+
+// ---- multi-GPU exchange (comm.cpp) -----------------------------------------------------
+int plx_comm_unique_id(uint8_t* out) { PLX_TRY PLX_REQUIRE(out, PLX_ERR_INVALID, "null pointer"); comm::unique_id(out); PLX_CATCH }
+int plx_comm_init(const uint8_t* id, int32_t rank, int32_t world_size, plx_comm* out) { PLX_TRY PLX_REQUIRE(out, PLX_ERR_INVALID, "null pointer"); *out = comm::init(id, rank, world_size); PLX_CATCH }
+int plx_comm_info(plx_comm c, int32_t* rank, int32_t* world_size) { PLX_TRY int r = 0, w = 0; comm::info(c, &r, &w); if (rank) *rank = r; if (world_size) *world_size = w; PLX_CATCH }
+int plx_comm_free(plx_comm c) { PLX_TRY comm::destroy(c); PLX_CATCH }
+int plx_exchange_by_key(plx_comm c, plx_frame frame, const char* key, uint64_t seed, plx_frame* out, uint64_t* rows_sent, uint64_t* bytes_sent) {
+  PLX_TRY
+  PLX_REQUIRE(key && out, PLX_ERR_INVALID, "null pointer");
+  *out = register_frame(comm::exchange_by_key(c, get_frame(frame), key, seed, rows_sent, bytes_sent));
+  PLX_CATCH
+}
+int plx_allgather_frame(plx_comm c, plx_frame frame, plx_frame* out) {
+  PLX_TRY
+  PLX_REQUIRE(out, PLX_ERR_INVALID, "null pointer");
+  *out = register_frame(comm::allgather_frame(c, get_frame(frame)));
   PLX_CATCH
 }
 

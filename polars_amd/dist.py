@@ -124,6 +124,76 @@ class HipLocalOps(LocalOps):
         return {c: df[c].to_torch() for c in df.columns}
 
 
+class LibComm:
+    """RCCL communicator owned by libpolars_amd (include/polars_amd.h plx_comm_*): the exchange runs inside the library --
+    hash partition, gather and ONE grouped ncclSend / ncclRecv all-to-all(v) on the library's stream, no torch kernels.
+    torch.distributed is only the bootstrap: rank 0's 128-byte RCCL id travels through it once.  world size 1 needs no
+    process group at all (a self-exchange: what the single-GPU test exercises)."""
+
+    def __init__(self, pl, group=None):
+        import ctypes as C
+        F = pl._ffi
+        F.ensure_init()
+        self.pl, self._F = pl, F
+        rank, ws = 0, 1
+        try:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                rank, ws = dist.get_rank(group), dist.get_world_size(group)
+        except ImportError:
+            dist = None
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            F.check(F.lib().plx_comm_unique_id(ident))
+        if ws > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        h = C.c_uint64()
+        F.check(F.lib().plx_comm_init(ident, rank, ws, C.byref(h)))
+        self._h, self.rank, self.world_size = h.value, rank, ws
+        self.rows_sent = self.bytes_sent = 0          # over the fabric, accumulated
+
+    def exchange_by_key(self, df, key: str, seed: int = 0):
+        """Every row of `df` goes to rank hash_partition(key); returns the rows this rank now owns (a DataFrame with the same
+        columns / logical dtypes)."""
+        import ctypes as C
+        F = self._F
+        out, rows, nbytes = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        F.check(F.lib().plx_exchange_by_key(self._h, df._frame_handle(), key.encode(), seed, C.byref(out), C.byref(rows), C.byref(nbytes)))
+        self.rows_sent += rows.value; self.bytes_sent += nbytes.value
+        return self.pl.DataFrame._from_frame_handle(out.value, df.schema)
+
+    def allgather(self, df):
+        """Concatenation of every rank's frame (rank order) on every rank."""
+        import ctypes as C
+        F = self._F
+        out = C.c_uint64()
+        F.check(F.lib().plx_allgather_frame(self._h, df._frame_handle(), C.byref(out)))
+        return self.pl.DataFrame._from_frame_handle(out.value, df.schema)
+
+    def close(self):
+        if getattr(self, "_h", 0):
+            self._F.lib().plx_comm_free(self._h)
+            self._h = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sharded_groupby(comm, df, key: str, query, always_exchange: bool = False):
+    """High-cardinality group-by over row shards: one exchange by key hash (all columns in one grouped
+    all-to-all), then the single-GPU operator over the disjoint key set this rank owns -- `query(frame)` runs it (e.g.
+    lambda d: queries.cfg3(d.lazy()).collect()).  The result stays sharded by key: the concatenation over the ranks is the
+    global result.  `comm`: a LibComm (RCCL inside the library) or any object with world_size and exchange_by_key(df, key)
+    (bench.py's dry-run double under gloo).  always_exchange: run the exchange at world size 1 too (a self-exchange)."""
+    owned = comm.exchange_by_key(df, key) if comm is not None and (comm.world_size > 1 or always_exchange) else df
+    return query(owned)
+
+
 def allgather_concat(t, group=None):
     """Variable-length all-gather of a 1-D tensor (sizes first, then padded payload)."""
     import torch

@@ -106,3 +106,35 @@ def test_bench_q1_rank_combine_matches_single_shard():
             assert np.allclose(np.array(merged[k]), v, rtol=1e-9), k
         else:
             assert merged[k] == v.tolist(), k
+
+
+def test_sharded_groupby_bench_dry_run_prints_a_complete_line():
+    """bench.py --gpus 2 --workload cfg3 --dry-run under gloo: the sharded operator's control flow (exchange by key hash, per-rank
+    group-by over disjoint key sets, barriers, max-over-ranks timing, shuffle accounting) with numpy frames standing in for the
+    library -- so the first multi-GPU run is a measurement, not a debug session.  The key sets of the ranks must be disjoint and
+    cover the union: groups_total == distinct keys of both shards together."""
+    import json
+    import subprocess
+    import sys
+
+    import numpy as np
+
+    from polars_amd import datagen
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = 200_000
+    for wl, kdt in (("cfg3", "Int64"), ("cfg5", "UInt32")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", wl, "--rows", str(rows), "--dry-run"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "shuffle"):
+            assert k in d, k
+        assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dry_run"] is True and d["config"]["rows_per_gpu"] == rows
+        keys = np.concatenate([datagen.uniform_native_host(kdt, 0, rows, 10 + rank, 0, 0, 1_000_000) for rank in range(2)])
+        assert d["groups_total"] == len(np.unique(keys))
+        # about half of every shard's rows leave the rank; every row carries key + value
+        assert 0.4 * rows < d["shuffle"]["rows_sent_per_rank_per_step"] < 0.6 * rows
+        assert d["shuffle"]["bytes_sent_per_rank_per_step"] == d["shuffle"]["rows_sent_per_rank_per_step"] * (12 if wl == "cfg5" else 16)
