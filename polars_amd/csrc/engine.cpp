@@ -873,8 +873,18 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
         if (k::partition_plan2(sh, G * 1.3, -1, len_idx, n, (int)hot.size(), &p2)) {
           std::string pd;
           Buf ok, okv, oacc;
-          const int64_t g = k::partitioned_agg2(sh, args, p2, static_id, hot, &ok, &okv, &oacc, &pd);
+          // A raw signed-integer key column scanned without a predicate: the scatter pass also records the exact key range, which is
+          // cached on the column like any other statistic -- the NEXT group-by / join on it can plan dense (direct-address) tables.
+          ColumnPtr stat_col;
+          if (sh.pred == kNone && kp.parts.size() == 1 && dtype_is_int(kp.parts[0].dtype) && kp.parts[0].dtype != PLX_U64) {
+            const AE* x = &c.plan.ae[kp.parts[0].expr];
+            while (x->kind == PLX_AE_ALIAS) x = &c.plan.ae[x->lhs];
+            if (x->kind == PLX_AE_COLUMN) { const int ci = c.df->find(x->name); if (ci >= 0 && c.df->cols[ci]->range_state == 0 && c.df->cols[ci]->len == n) stat_col = c.df->cols[ci]; }
+          }
+          int64_t key_range[2] = {1, 0};
+          const int64_t g = k::partitioned_agg2(sh, args, p2, static_id, hot, &ok, &okv, &oacc, &pd, stat_col ? key_range : nullptr);
           if (g >= 0) {
+            if (stat_col && key_range[0] <= key_range[1]) { stat_col->range_state = 1; stat_col->range_min = key_range[0]; stat_col->range_max = key_range[1]; stat_col->range_trusted = true; pd += "+key_range_learned"; }
             res.n_groups = g; res.n_aggs = sh.n_aggs; res.packed_keys = ok; res.key_valid = okv; res.acc = oacc;
             desc += "hot=" + std::to_string(hot.size()) + "+" + std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+" + pd;
             return;

@@ -65,8 +65,10 @@ int64_t partitioned_agg(const fused::Shape& sh, const fused::Args& args, const f
 // LDS tables when they fit); hot_keys = heavy hitters pre-aggregated in the scatter pass (select_hot_keys on a sample table)
 bool partition_plan2(const fused::Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, fused::PartPlan2* out);
 void select_hot_keys(const fused::HashTable& t, int n_aggs, int len_idx, uint64_t threshold, std::vector<uint64_t>* out);
+// key_range_out (may be null): [2] receives the exact signed min / max of the valid keys the scatter pass streamed (hash mode
+// only; min > max when it saw none) -- statistics gathered as a by-product
 int64_t partitioned_agg2(const fused::Shape& sh, const fused::Args& args, const fused::PartPlan2& pp, int static_id, const std::vector<uint64_t>& hot_keys, Buf* out_keys,
-                         Buf* out_kvalid, Buf* out_acc, std::string* desc);
+                         Buf* out_kvalid, Buf* out_acc, std::string* desc, int64_t* key_range_out = nullptr);
 // all jobs of a batch (key decodes + aggregate finalisations) in one launch
 void finalize_batch(const uint64_t* acc, int n_aggs, int64_t G, const fused::FinBatch& b);
 // packed group keys -> one key column

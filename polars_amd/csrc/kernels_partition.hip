@@ -353,7 +353,7 @@ static const int kEnvP2Depth = env_int("PLX_PART_PREFETCH", 1, 2);       // roun
 // Runs scatter -> chunk sort -> aggregate (+ hot groups).  Outputs (allocated here): dense keys / valid flags / cells.
 // Returns the number of groups, -1 if an LDS table overflowed or no specialised kernel is available (the caller falls back).
 int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pp, int static_id, const std::vector<uint64_t>& hot_keys, Buf* out_keys, Buf* out_kvalid,
-                         Buf* out_acc, std::string* desc) {
+                         Buf* out_acc, std::string* desc, int64_t* key_range_out) {
   const uint32_t NP = 1u << pp.log2_parts;
   const bool direct = pp.mode == kP2Direct;
   const bool is_static = static_id == SHAPE_GB_SUM_CNT_I64 || static_id == SHAPE_GB_SUM_MEAN_U32_F64;   // the cases of PLX_PART2_STATIC_CASES
@@ -391,6 +391,15 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pp,
   sp.flags = meta->as<unsigned int>() + 3;
   sp.hot_tbl_keys = pp.n_hot ? hot_tbl_keys->as<unsigned long long>() : nullptr; sp.hot_tbl_idx = pp.n_hot ? hot_tbl_idx->as<unsigned int>() : nullptr;
   sp.hot_out = pp.n_hot ? hot_out->as<unsigned long long>() : nullptr;
+  // by-product statistics (hash mode, signed keys): exact min / max of the keys this scan streams anyway
+  Buf minmax;
+  if (key_range_out && !direct) {
+    minmax = dev_alloc(16);
+    const long long init[2] = {0x7fffffffffffffffll, (long long)0x8000000000000000ull};
+    h2d_async(minmax->ptr, init, 16);
+    PLX_HIP(hipStreamSynchronize(stream()));     // `init` is a stack object
+    sp.key_minmax = minmax->as<long long>();
+  }
   const size_t slds = part2_scatter_lds(NP, pp.ring_lines, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies);
   {
     // pass traffic: inputs read once + every surviving row written as one record (upper bound: all rows)
@@ -455,6 +464,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pp,
   PLX_REQUIRE(!res[3], PLX_ERR_INVALID, "partitioned group-by: a scatter workgroup ran out of chunks");
   PLX_REQUIRE(!res[4], PLX_ERR_INVALID, "group key outside the bounds declared for its column (plx_column_set_bounds)");
   if (res[2]) return -1;
+  if (minmax) { long long mm[2]; d2h_sync(mm, minmax->ptr, 16); key_range_out[0] = mm[0]; key_range_out[1] = mm[1]; }
   if (desc) *desc = std::string("partitioned(v2,") + (direct ? "direct" : "hash") + ",P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec_words * 4) + "B,ring=" + std::to_string(pp.ring_lines * 128) +
                     "B,block=" + std::to_string(pp.block) + ",hot=" + std::to_string(pp.n_hot) + ")+" + (direct ? "lds_direct_table(slots=" : "lds_hash_table(slots=") + std::to_string(1u << pp.log2_slots) + ")";
   return (int64_t)(((uint64_t)res[1] << 32) | res[0]);

@@ -30,6 +30,7 @@ struct ScatterParams2 {
   const unsigned long long* hot_tbl_keys;   // [1 << log2_hot_slots] open-addressing lookup of the hot keys (kEmptyKey = free)
   const unsigned int* hot_tbl_idx;          // hot-key ordinal of the slot
   unsigned long long* hot_out;              // [n_hot][n_aggs] cells, device-scope atomics at the end of the kernel
+  long long* key_minmax;                    // [2] signed min / max of the valid keys the scan saw (by-product statistics; null: not wanted)
 };
 
 struct AggParams2 {
@@ -57,7 +58,7 @@ __device__ __forceinline__ uint32_t part2_of(uint64_t key, bool kvalid, uint32_t
 //   fdw     [P] u32                 dwords of the current chunk already written to HBM
 //   chunk   [P] u32                 current chunk (kNoChunk: none yet)
 //   hot_i   [hot_slots] u32
-//   misc    [4] u32                 [0] next chunk of this workgroup's region
+//   misc    [4] u32                 [0] next chunk of this workgroup's region, [1], [2] "some row is still pending" flags (alternating)
 __host__ __device__ inline size_t part2_scatter_lds(uint32_t P, uint32_t ring_lines, uint32_t hot_slots, uint32_t n_hot, uint32_t n_aggs, uint32_t copies) {
   return (size_t)P * ring_lines * 128 + (size_t)P * 8 + (size_t)hot_slots * 8 + (size_t)n_hot * n_aggs * copies * 8 + (size_t)P * 4 * 2 + (size_t)hot_slots * 4 + 16;
 }
@@ -91,7 +92,8 @@ __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, c
 }
 
 // ---- the scatter kernel ------------------------------------------------------------------------------------------------
-// DEPTH = rounds whose column loads are in flight while a round is appended and flushed (one register file per round in flight)
+// DEPTH is kept for launch-table compatibility: one round of column loads is in flight while a round is appended and flushed
+// (two rounds measured no faster: the scatter pass is not bound by load latency)
 template <class P, int MODE, int DEPTH = 1>
 __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args args, const PartPlan2 pp, const ScatterParams2 sp) {
   static_assert(P::kStatic, "the partitioned group-by runs specialised programs only (AOT or JIT)");
@@ -115,7 +117,7 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) { fl[i] = (unsigned long long)first_limit << 32; fdw[i] = 0; chunk[i] = kNoChunk; }
   for (uint32_t i = threadIdx.x; i < hot_slots; i += blockDim.x) { hot_k[i] = sp.hot_tbl_keys[i]; hot_i[i] = sp.hot_tbl_idx[i]; }
   for (uint32_t i = threadIdx.x; i < pp.n_hot * sh.n_aggs * pp.hot_copies; i += blockDim.x) hot_acc[i] = agg_identity_dev(sh.aggs[(i / pp.hot_copies) % sh.n_aggs].kind);
-  if (threadIdx.x == 0) misc[0] = 0;
+  if (threadIdx.x < 4) misc[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t chunk0 = blockIdx.x * pp.chunks_per_wg;     // this workgroup's private chunk region
   // partitions a lane owns in the flush phase: wave w, lane l < lanes_per_wave owns partition w * lanes_per_wave + l
@@ -127,8 +129,8 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
   auto row0_of = [&](int64_t rd) { return (rd * nwaves + wave) * (int64_t)kTileRows + (int64_t)lane * kRows; };
   auto round_full = [&](int64_t rd) { return (rd + 1) * rows_per_round <= args.n_rows; };
-  RegFile rfA{}, rfB{};       // one register file per round in flight (rfB only with DEPTH == 2); named variables, never an
-                              // array: a dynamically indexed or address-taken register file is spilled to scratch
+  RegFile rfA{};              // a named variable, never an array: a dynamically indexed register file is spilled to scratch
+  long long kmin_seen = 0x7fffffffffffffffll, kmax_seen = (long long)0x8000000000000000ull;   // by-product statistics of the key
   unsigned int rec[kRows][RW];
   uint32_t part[kRows];
   bool pending[kRows];
@@ -150,6 +152,10 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
       bool kvalid; uint64_t key64;
       make_record2<MODE>(sh, L, pp, rf, r, row0 + r, rec[r], part[r], kvalid, key64);
       pending[r] = pass[r];
+      if (MODE == (int)kP2Hash && sp.key_minmax && pass[r] && kvalid) {
+        kmin_seen = (long long)key64 < kmin_seen ? (long long)key64 : kmin_seen;
+        kmax_seen = (long long)key64 > kmax_seen ? (long long)key64 : kmax_seen;
+      }
       if (MODE == (int)kP2Direct && part[r] >= NP) { if (pass[r]) sp.flags[1] = 1u; pending[r] = false; }   // id outside the declared range: the query fails
       if (pp.n_hot && pass[r] && kvalid && key64 != kEmptyKey) {
         uint32_t s = (uint32_t)((key64 * 0x9e3779b97f4a7c15ull) >> (64 - pp.log2_hot_slots));
@@ -244,52 +250,73 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   // Round k of this workgroup lives in register file k % DEPTH.  Per round: its rows are evaluated (loads issued DEPTH rounds
   // ago) and copied into rec[]; the register file is then free, so the loads of round k + DEPTH are issued at once and stay
   // in flight while round k is appended and flushed (barriers do not drain vmcnt).
-  auto append_and_flush = [&]() __attribute__((always_inline)) {
-    int any;
-    do {
-      bool mine = false;
+  // appends this lane's pending rows; true = some are still pending (their partition's ring / chunk was full)
+  auto append_pending = [&]() __attribute__((always_inline)) -> bool {
+    bool mine = false;
 #pragma unroll
-      for (int r = 0; r < kRows; r++) {
-        if (!pending[r]) continue;
-        const unsigned long long old = atomicAdd(&fl[part[r]], 1ull);
-        const uint32_t pos = (uint32_t)old, lim = (uint32_t)(old >> 32);
-        if (pos < lim) {
-          unsigned int* base = ring + (size_t)part[r] * ring_dw;
-          const uint32_t d0 = pos * RW;
+    for (int r = 0; r < kRows; r++) {
+      if (!pending[r]) continue;
+      const unsigned long long old = atomicAdd(&fl[part[r]], 1ull);
+      const uint32_t pos = (uint32_t)old, lim = (uint32_t)(old >> 32);
+      if (pos < lim) {
+        unsigned int* base = ring + (size_t)part[r] * ring_dw;
+        const uint32_t d0 = pos * RW;
 #pragma unroll
-          for (uint32_t w = 0; w < RW; w++) base[(d0 + w) & ring_mask] = rec[r][w];
-          pending[r] = false;
-        } else mine = true;
-      }
-      any = __syncthreads_or(mine ? 1 : 0);
+        for (uint32_t w = 0; w < RW; w++) base[(d0 + w) & ring_mask] = rec[r][w];
+        pending[r] = false;
+      } else mine = true;
+    }
+    return mine;
+  };
+  // Order of a round (the vector-memory counter of gfx9 counts loads AND stores, and the number of line stores of a flush is
+  // not a compile-time constant, so a wait for loaded data is a wait for every store issued before it):
+  //   append(rd) | barrier | evaluate round rd+1 from its loads (the stores still in flight are a whole round old by now) |
+  //   issue the loads of round rd+2 | flush(rd): line stores | barrier
+  // -- the fresh stores of a flush are never waited for before the next round's rows are needed.  Rows that did not fit
+  // (rare: the rings are sized for the arrival rate) take the slow path first: flush, barrier, append again.
+  const int64_t stride = (int64_t)gridDim.x;
+  const int64_t rd_first = (int64_t)blockIdx.x;
+  bool pre = false;
+  if (rd_first < nrounds) {
+    finish_round(rd_first, issue_loads(rd_first, rfA), rfA);
+    pre = issue_loads(rd_first + stride, rfA);
+  }
+  // "does any lane still hold a pending row?" with ONE barrier (__syncthreads_or costs two): lanes raise one of two alternating LDS
+  // flags before the barrier, everybody reads it after; lane 0 clears the other flag, which nobody touches until the next use
+  uint32_t sync_points = 0;
+  auto any_pending = [&](bool mine) __attribute__((always_inline)) -> bool {
+    const uint32_t par = sync_points & 1u;
+    sync_points++;
+    if (mine) misc[1 + par] = 1u;
+    __syncthreads();
+    const bool any = misc[1 + par] != 0;
+    if (threadIdx.x == 0) misc[2 - par] = 0u;
+    return any;
+  };
+  for (int64_t rd = rd_first; rd < nrounds; rd += stride) {
+    bool any = any_pending(append_pending());
+    while (any) {
       flush_phase(false);
       __syncthreads();
-    } while (any);
-  };
-  const int64_t stride = (int64_t)gridDim.x;
-  if constexpr (DEPTH == 1) {
-    if ((int64_t)blockIdx.x < nrounds) finish_round(blockIdx.x, issue_loads(blockIdx.x, rfA), rfA);
-    for (int64_t rd = blockIdx.x; rd < nrounds; rd += stride) {
-      const int64_t rd_next = rd + stride;
-      const bool preloaded = issue_loads(rd_next, rfA);
-      append_and_flush();
-      if (rd_next < nrounds) finish_round(rd_next, preloaded, rfA);
+      any = any_pending(append_pending());
     }
-  } else {
-    bool preA = issue_loads((int64_t)blockIdx.x, rfA), preB = issue_loads((int64_t)blockIdx.x + stride, rfB);
-    for (int64_t rd0 = blockIdx.x; rd0 < nrounds; rd0 += 2 * stride) {
-      finish_round(rd0, preA, rfA);
-      preA = issue_loads(rd0 + 2 * stride, rfA);
-      append_and_flush();
-      const int64_t rd1 = rd0 + stride;
-      if (rd1 < nrounds) {                          // uniform across the workgroup
-        finish_round(rd1, preB, rfB);
-        preB = issue_loads(rd1 + 2 * stride, rfB);
-        append_and_flush();
-      }
+    const int64_t rd_next = rd + stride;
+    if (rd_next < nrounds) {                          // uniform across the workgroup
+      finish_round(rd_next, pre, rfA);
+      pre = issue_loads(rd_next + stride, rfA);
     }
+    flush_phase(false);
+    __syncthreads();
   }
   flush_phase(true);
+  if (MODE == (int)kP2Hash && sp.key_minmax) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const long long a = (long long)shfl_xor_u64((uint64_t)kmin_seen, m), b = (long long)shfl_xor_u64((uint64_t)kmax_seen, m);
+      kmin_seen = a < kmin_seen ? a : kmin_seen; kmax_seen = b > kmax_seen ? b : kmax_seen;
+    }
+    if (lane == 0 && kmin_seen <= kmax_seen) { atomicMin(sp.key_minmax, kmin_seen); atomicMax(sp.key_minmax + 1, kmax_seen); }
+  }
   if (pp.n_hot) {
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < pp.n_hot * sh.n_aggs; i += blockDim.x) {
@@ -370,38 +397,58 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
       for (uint32_t w = 0; w < 16; w++) if (w < RW) cur[u][w] = nxt[u][w];
     }
     load_chunk(j + (uint64_t)nwaves, nxt, cnt_nxt);
+    // the lane's records of the chunk are handled in three passes so that their LDS round trips overlap: (1) decode the key and
+    // read the table word of its home slot for every record, (2) resolve the slot (hit on the first probe in the common case; the
+    // CAS / linear-probe loop otherwise), (3) update the cells
+    uint32_t slot[kPerLane];
+    uint64_t key[kPerLane];
+    unsigned long long first[kPerLane];
+    bool live[kPerLane];
 #pragma unroll
     for (uint32_t u = 0; u < kPerLane; u++) {
       const uint32_t i = (uint32_t)lane + u * 64u;
-      if (i >= cnt_cur) continue;
+      live[u] = i < cnt_cur;
+      slot[u] = 0; key[u] = 0; first[u] = 0;
+      if (!live[u]) continue;
+      const unsigned int* rec = cur[u];
+      if (direct) { slot[u] = rec[0]; continue; }
+      const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
+      if (L.key_words == 2) key[u] = (uint64_t)rec[0] | ((uint64_t)rec[1] << 32);
+      else key[u] = L.key_kind == 1 ? (uint64_t)(long long)(int)rec[0] : (uint64_t)rec[0];
+      if (!(vbits >> 31)) { slot[u] = NS; first[u] = kEmptyKey - 1; }                 // resolved below without probing
+      else if (key[u] == kEmptyKey) { slot[u] = NS + 1; first[u] = kEmptyKey - 1; }
+      else {
+        slot[u] = (uint32_t)((key[u] * 0x9e3779b97f4a7c15ull) >> (64 - pp.log2_slots));   // a second hash: the partition consumed the top bits of the first
+        first[u] = keys[slot[u]];
+      }
+    }
+    if (!direct) {
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) {
+        if (!live[u]) continue;
+        if (slot[u] >= NS) { keys[slot[u]] = 0; continue; }          // null-key / EMPTY-pattern groups: mark the slot occupied
+        unsigned long long c = first[u];
+        uint32_t sl = slot[u], probe = 0;
+        for (;; probe++) {
+          if (c == key[u]) break;
+          if (c == kEmptyKey) {
+            const unsigned long long old = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)key[u]);
+            if (old == kEmptyKey || old == key[u]) break;
+          }
+          sl = (sl + 1) & (NS - 1);
+          if (probe >= NS) { full = 1; live[u] = false; break; }
+          c = keys[sl];
+        }
+        slot[u] = sl;
+      }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      if (!live[u]) continue;
       const unsigned int* rec = cur[u];
       const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
       const uint64_t rowid = L.has_rowid ? ((uint64_t)rec[L.rowid_off] | ((uint64_t)rec[L.rowid_off + 1] << 32)) : 0ull;
-      uint32_t slot;
-      if (direct) slot = rec[0];
-      else {
-        uint64_t key;
-        if (L.key_words == 2) key = (uint64_t)rec[0] | ((uint64_t)rec[1] << 32);
-        else key = L.key_kind == 1 ? (uint64_t)(long long)(int)rec[0] : (uint64_t)rec[0];
-        if (!(vbits >> 31)) { slot = NS; keys[NS] = 0; }
-        else if (key == kEmptyKey) { slot = NS + 1; keys[NS + 1] = 0; }
-        else {
-          slot = (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> (64 - pp.log2_slots));   // a second hash: the partition consumed the top bits of the first
-          uint32_t probe = 0;
-          for (;; probe++) {
-            const unsigned long long c = keys[slot];
-            if (c == key) break;
-            if (c == kEmptyKey) {
-              const unsigned long long old = atomicCAS(&keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
-              if (old == kEmptyKey || old == key) break;
-            }
-            slot = (slot + 1) & (NS - 1);
-            if (probe >= NS) { full = 1; break; }
-          }
-          if (probe >= NS) continue;
-        }
-      }
-      unsigned long long* cell = cells + (size_t)slot * n_aggs;
+      unsigned long long* cell = cells + (size_t)slot[u] * n_aggs;
 #pragma unroll
       for (uint32_t k = 0; k < (uint32_t)kMaxAggs; k++) {
         if (k >= n_aggs) break;

@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""rocprofv3 counter-collection CSVs (FETCH_SIZE and WRITE_SIZE passes of tools/pmc_all.sh) -> profiles/<round>/<workload>_pmc.json:
+HBM bytes per launch of every library kernel, keyed by the name bench.py's HIP-event tracer uses for it (ProfileScope), with the
+gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts 128-B requests as 64 B: x2 for wide coalesced reads) and a write
+calibration on the library's own generator kernel (datagen_uniform writes exactly 8 B per row).
+usage: pmc_summarise.py <workload> <fetch counter csv> <write counter csv> <out json> [steps]"""
+import collections
+import csv
+import json
+import re
+import sys
+
+SCOPES = [  # (regex on the demangled kernel name, ProfileScope name in bench.py)
+    (r"fused_scan_kernel<.*LdsAggSink", "fused_scan_ldsagg_static"), (r"fused_scan_kernel<.*RegAggSink", "fused_scan_regagg_static"),
+    (r"fused_scan_kernel<.*DirectProbeAggSink", "fused_scan_direct_probe_agg_static"), (r"fused_scan_kernel<.*DirectBuildSink", "fused_scan_direct_build_static"),
+    (r"fused_scan_kernel<.*BitmapBuildSink", "fused_scan_bitmap_build_static"), (r"fused_scan_kernel<.*HashAggSink", "fused_scan_hashagg"),
+    (r"fused_scan_kernel<.*ProbeAggSink", "fused_scan_probe_agg_static"), (r"fused_scan_kernel<.*JoinBuildSink", "fused_scan_join_build_static"),
+    (r"part2_scatter_kernel", "part2_scatter"), (r"part2_agg_kernel", "part2_agg_lds"), (r"chunk_hist_kernel|chunk_place_kernel", "part2_chunk_sort"),
+    (r"part_scatter_kernel", "part_scatter"), (r"part_agg_kernel", "part_agg_lds"), (r"part_count_kernel", "part_count"),
+    (r"direct_popc_kernel|direct_word_rank_kernel", "direct_rank"), (r"direct_pairs_compact_kernel|hash_compact_kernel|join_agg_compact_kernel", "table_compact"),
+    (r"scan_block_kernel|scan_add_kernel|scan_", "exclusive_scan"), (r"gather_kernel", "gather_u32"), (r"finalize_batch_kernel", "finalize_batch"),
+    (r"datagen_uniform_kernel<long", "datagen_uniform_i64"), (r"datagen_", "datagen_other"), (r"hot_candidates_kernel|hot_emit_kernel", "hot_keys"),
+    (r"init_acc_kernel|fill_u64_kernel", "table_init"),
+]
+
+
+def scope_of(kernel: str):
+    for rx, name in SCOPES:
+        if re.search(rx, kernel):
+            return name
+    return None
+
+
+def read(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") != counter:
+            continue
+        k = r["Kernel_Name"]
+        agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    wl, fetch_csv, write_csv, out = sys.argv[1:5]
+    fetch, write = read(fetch_csv, "FETCH_SIZE"), read(write_csv, "WRITE_SIZE")
+    kernels = {}
+    for src, field in ((fetch, "fetch_KB"), (write, "write_KB")):
+        for k, (n, tot) in src.items():
+            sc = scope_of(k)
+            if sc is None:
+                continue
+            e = kernels.setdefault(sc, {"fetch_KB": 0.0, "write_KB": 0.0, "launches": 0, "kernel_names": []})
+            e[field] += tot
+            if field == "fetch_KB":
+                e["launches"] += n
+            if k[:100] not in e["kernel_names"]:
+                e["kernel_names"].append(k[:100])
+    res = {}
+    for sc, e in kernels.items():
+        n = max(e["launches"], 1)
+        if sc == "part2_chunk_sort":
+            n = max(n // 2, 1)          # two kernels per pass of the chunk sort
+        if sc == "direct_rank":
+            n = max(n // 2, 1)
+        f, w = e["fetch_KB"] / n, e["write_KB"] / n
+        res[sc] = {"fetch_KB": round(f, 1), "write_KB": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024), "launches_seen": e["launches"], "kernel_names": e["kernel_names"]}
+    cal = res.get("datagen_uniform_i64")
+    doc = {"workload": wl,
+           "command": f"rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) --kernel-trace -- python bench.py --workload {wl} --steps 3 --warmup 1 --no-extras --no-cpu  (tools/pmc_all.sh)",
+           "correction": "gfx950: FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies 128-B requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported, calibrated on datagen_uniform_i64 "
+                         "(the library's generator writes exactly 8 B per row): see `calibration`",
+           "calibration": cal, "kernels": res}
+    json.dump(doc, open(out, "w"), indent=1)
+    for sc, e in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]:
+        print(f"{wl:6s} {sc:38s} hbm {e['hbm_bytes_per_launch'] / 1e9:8.3f} GB  (fetch {e['fetch_KB'] * 1024 * 2 / 1e9:7.3f}  write {e['write_KB'] * 1024 / 1e9:7.3f})")
+
+
+if __name__ == "__main__":
+    main()
