@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="q1", choices=["q1", "q3", "q3f", "cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--workload", default="q1", choices=["q1", "q3", "q3f", "cfg2", "cfg3", "cfg5", "cfg5s"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the SF100 / 1e9-row size of the workload)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -199,7 +199,7 @@ def verify_cfg2(got: dict, n: int, seed: int, budget_s: float, block: int = 100_
 
 
 def verify_groupby_dense(frame, key: str, sum_col: str, n: int, seed: int, n_keys: int, key_np: str, val_np: str, val_args, second, budget_s: float,
-                         block: int = 100_000_000) -> dict:
+                         block: int = 100_000_000, key_args=None, key_shift: int = 0) -> dict:
     """cfg3 / cfg5: per-key (sum, count) of the host twin through the oracle's streaming group-by (thread-local tables, combined)
     against the library's result frame.  second = ("count", name) or ("mean", name)."""
     import numpy as np
@@ -210,7 +210,9 @@ def verify_groupby_dense(frame, key: str, sum_col: str, n: int, seed: int, n_key
     done, t0 = 0, time.perf_counter()
     while done < n and time.perf_counter() - t0 < budget_s:
         m = min(block, n - done)
-        k = datagen.uniform_native_host_mt(key_np, done, m, seed, 0, 0, n_keys)
+        k = datagen.uniform_native_host_mt(key_np, done, m, seed, 0, *(key_args or (0, n_keys)))
+        if key_shift:
+            k = k + key_shift
         v = datagen.uniform_native_host_mt(val_np, done, m, seed, 1, *val_args)
         orc.groupby_dense_partial(k, v, sums, counts)
         done += m
@@ -481,6 +483,31 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
         verify = (lambda res, budget: verify_groupby_dense(res, "k", "v_sum", n, seed, 1_000_000, "UInt32", "Float64", (0, 10 ** 9, 1e-7), ("mean", "v_mean"), budget)) if codes is None else None
         return Workload("cfg5_dict_string_keys_1e9", n, n * 12 + 1_000_000 * 20, step, "part_scatter", f"config 5: {n} rows, 1e6 dictionary-encoded string keys (u32 codes), group_by(k).agg(sum, mean)",
                         verify=verify, scope="operator")
+    if name == "cfg5s":
+        # config 5 starting from RAW Utf8View keys (16-byte views of the 12-byte strings "id%010d", generated in HBM): every step encodes
+        # the views into dictionary codes on the device (plx_strview_dict_encode_device) and then runs the dense-id group-by
+        n = rows or 1_000_000_000
+        views = datagen.id_views_native(pl, "k", n, seed, 0, 1, 1_000_001)
+        v = native_uniform_column(pl, "v", pl.Float64, "Float64", n, seed, 1, 0, 10 ** 9, 1e-7)
+
+        def step():
+            k = pl.Series.from_device_views("k", views)
+            return queries.cfg5(pl.DataFrame([k, v]).lazy()).collect(), (views, v, k)
+
+        def verify(res, budget):
+            import numpy as np
+            cats = list(res["k"].dtype.categories)                      # the device-built dictionary, downloaded here (outside the timed region)
+            ids = np.array([int(c[2:]) for c in cats], dtype=np.int64)
+
+            class Mapped:
+                def __init__(self, a): self.a = a
+                def to_numpy(self): return self.a
+            codes = res["k"].to_numpy()
+            frame = {"k": Mapped(ids[codes] - 1), "v_sum": res["v_sum"], "v_mean": res["v_mean"]}
+            return verify_groupby_dense(frame, "k", "v_sum", n, seed, 1_000_000, "Int64", "Float64", (0, 10 ** 9, 1e-7), ("mean", "v_mean"), budget, key_args=(1, 1_000_001), key_shift=-1)
+        return Workload("cfg5_utf8view_keys_1e9", n, n * 24 + 1_000_000 * 28, step, "strview_dict_encode",
+                        f"config 5 from raw strings: {n} rows, Utf8View keys (16-byte views of 1e6 distinct 12-byte strings) -> device-side dictionary encoding -> group_by(k).agg(sum, mean)",
+                        verify=verify, scope="operator")
     raise ValueError(name)
 
 
@@ -553,7 +580,7 @@ def pmc_traffic(workload_name: str, kernel: str, rows: int):
             "cfg5_dict_string_keys_1e9": 1_000_000_000}
     if workload_name in full and rows != full[workload_name]:
         return None
-    short = {"tpch_q1_sf100": "q1", "tpch_q3_sf100": "q3", "tpch_q3_three_tables_sf100": "q3f", "cfg2_filter_arith_agg_1e9": "cfg2", "cfg3_groupby_1e6_keys_1e9": "cfg3", "cfg5_dict_string_keys_1e9": "cfg5"}.get(workload_name)
+    short = {"tpch_q1_sf100": "q1", "tpch_q3_sf100": "q3", "tpch_q3_three_tables_sf100": "q3f", "cfg2_filter_arith_agg_1e9": "cfg2", "cfg3_groupby_1e6_keys_1e9": "cfg3", "cfg5_dict_string_keys_1e9": "cfg5", "cfg5_utf8view_keys_1e9": "cfg5s"}.get(workload_name)
     for rnd in ("r02", "r01"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", rnd, f"{short}_pmc.json" if rnd != "r01" else f"{short}_sf100_pmc.json")))
@@ -1078,7 +1105,7 @@ def run(args, emit):
             emit(line)
         del wl, res
         torch.cuda.empty_cache()
-        for name in [w for w in ("q3", "q3f", "cfg2", "cfg3", "cfg5", "q1") if w != args.workload]:
+        for name in [w for w in ("q3", "q3f", "cfg2", "cfg3", "cfg5", "cfg5s", "q1") if w != args.workload]:
             try:
                 w2 = make_workload(pl, name, 0, seed=20)
                 d2, s2, r2, c2 = timed(pl, w2, k2, 1, False)

@@ -439,6 +439,26 @@ int plx_datagen_customer_host(int64_t row0, int64_t n, uint64_t seed, int64_t* c
 int plx_datagen_uniform(int32_t dtype, int64_t n_rows, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, double scale, plx_column* out);
 int plx_datagen_uniform_host(int32_t dtype, int64_t row0, int64_t n, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, double scale, void* out);
 
+/* ---- raw Utf8View / BinaryView keys: device-side dictionary encoding -----------------------------
+ * The reference hashes and compares the 16-byte views directly (crates/polars-expr/src/hash_keys.rs:413-452 BinviewKeys,
+ * crates/polars-compute/src/binview_index_map.rs; view layout crates/polars-arrow/src/array/binview/view.rs:20-29,55:
+ * {len u32, 12 inline bytes} or {len u32, prefix u32, buffer index u32, offset u32}).  plx_strview_dict_encode builds that
+ * index map on the device once, when the column enters: `views` = n 16-byte views (host), `data_buffers` = the array's variadic
+ * data buffers (host; may be empty when every string is <= 12 bytes).  out_codes = a PLX_U32 column of dictionary codes (validity
+ * = the input's; bounds [0, n_distinct) declared), out_dict = the dictionary (code -> string), kept on the device.
+ * plx_strview_dict_encode_device: the same for views already in HBM (a PLX_U64 column of 2 n words; `data` a PLX_U8 column or 0).
+ * plx_strdict_to_host: offsets[n_strings + 1] + the concatenated bytes, in code order. */
+typedef uint64_t plx_strdict;
+int plx_strview_dict_encode(const void* views, const uint8_t* validity, int64_t bit_offset, int64_t n, const void* const* data_buffers, const int64_t* data_sizes,
+                            int32_t n_data_buffers, plx_column* out_codes, plx_strdict* out_dict);
+int plx_strview_dict_encode_device(plx_column views_u64_pairs, plx_column data_u8, plx_column* out_codes, plx_strdict* out_dict);
+int plx_strdict_info(plx_strdict dict, int64_t* n_strings, int64_t* total_bytes);
+int plx_strdict_to_host(plx_strdict dict, int64_t* offsets, uint8_t* bytes);
+int plx_strdict_free(plx_strdict dict);
+/* synthetic Utf8View column (benchmark support, BASELINE config 5 from raw strings): 2 n PLX_U64 words = the inline views of
+ * "id%010d" % (lo + floor(U * (hi - lo))) with the same counter-based U as plx_datagen_uniform(stream) */
+int plx_datagen_id_views(int64_t n_rows, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, plx_column* out_views);
+
 /* ---- multi-GPU exchange (one process per GPU, RCCL over xGMI) -----------------------------
  * The exchange step of the sharded operators; shape of the reference's in-process exchange:
  * crates/polars-utils/src/hashing.rs:72-121 (HashPartitioner), crates/polars-stream/src/nodes/group_by.rs:252-497

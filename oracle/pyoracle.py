@@ -533,3 +533,33 @@ def q1_combine(parts) -> Dict[str, np.ndarray]:
     out["avg_price"] = out["sum_base_price"] / cnt
     out["avg_disc"] = np.array([acc[g]["_disc"] for g in ks], np.float64) / cnt
     return out
+
+
+# ------------------------------------------------------------ raw string keys (Utf8View) ----
+def binview_parts(s: bytes):
+    """(len, prefix u32, inline?) of a string's 16-byte view (crates/polars-arrow/src/array/binview/view.rs:20-29,55: strings of
+    <= 12 bytes live inside the view, zero padded; longer ones keep a 4-byte prefix + buffer index + offset)."""
+    n = len(s)
+    return n, int.from_bytes(s[:4].ljust(4, b"\0"), "little"), n <= 12
+
+
+def binview_dict_encode(strings):
+    """The reference's view index map restated (crates/polars-compute/src/binview_index_map.rs; used by BinviewKeys,
+    crates/polars-expr/src/hash_keys.rs:413-452): every distinct string gets a dense index in first-appearance order, equality
+    is by length + bytes (inline views compare as the 16-byte value, long ones prefix first, then the bytes); nulls get no index.
+    strings: list of str | bytes | None -> (codes u32 (0 for null), valid bool array or None, categories in index order)."""
+    index, cats = {}, []
+    codes = np.zeros(len(strings), np.uint32)
+    valid = np.ones(len(strings), bool)
+    for i, s in enumerate(strings):
+        if s is None:
+            valid[i] = False
+            continue
+        b = s.encode() if isinstance(s, str) else bytes(s)
+        key = (binview_parts(b)[:2], b)            # (len, prefix) first, then the bytes: what the view compare does
+        j = index.get(key)
+        if j is None:
+            j = index[key] = len(cats)
+            cats.append(s)
+        codes[i] = j
+    return codes, (None if valid.all() else valid), cats

@@ -4,6 +4,8 @@
 // nothing unwinds across the ABI.
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
 
 #include "core.hpp"
 #include "datagen_device.hpp"
@@ -854,6 +856,105 @@ int plx_jit_stats(int32_t* compiled, double* compile_ms) {
   jit::stats(&c, &ms);
   if (compiled) *compiled = c;
   if (compile_ms) *compile_ms = ms;
+  PLX_CATCH
+}
+
+// ---- raw string keys: device-side dictionary (kernels_strview.hip) ------------------------------------
+extern "C++" {
+namespace {
+struct StrDict { Buf views, data, offsets, bytes; int64_t n = 0; uint64_t total = 0; bool materialised = false; };
+std::mutex g_strdict_mu;
+std::vector<std::unique_ptr<StrDict>> g_strdicts;     // handle = index + 1
+StrDict& get_strdict(uint64_t h) {
+  std::lock_guard<std::mutex> lk(g_strdict_mu);
+  if (h == 0 || h > g_strdicts.size() || !g_strdicts[h - 1]) fail(PLX_ERR_INVALID, "invalid string dictionary handle");
+  return *g_strdicts[h - 1];
+}
+uint64_t register_strdict(std::unique_ptr<StrDict> d) { std::lock_guard<std::mutex> lk(g_strdict_mu); g_strdicts.push_back(std::move(d)); return (uint64_t)g_strdicts.size(); }
+void materialise(StrDict& d) {
+  if (d.materialised) return;
+  k::strdict_materialise(d.views->as<uint64_t>(), d.data ? d.data->as<uint8_t>() : nullptr, d.n, &d.offsets, &d.bytes, &d.total);
+  d.materialised = true;
+}
+// shared tail of both entry points: views / validity / data are on the device
+void encode_on_device(const uint64_t* views, const ColumnPtr& validity_holder, Buf data, Buf buf_base, int64_t n, plx_column* out_codes, plx_strdict* out_dict) {
+  Buf codes, dviews;
+  int64_t nd = 0;
+  k::strview_dict_encode(views, validity_holder ? validity_holder->valid_words() : nullptr, data ? data->as<uint8_t>() : nullptr, buf_base ? buf_base->as<uint64_t>() : nullptr, n, &codes, &dviews, &nd);
+  auto c = std::make_shared<Column>();
+  c->dtype = PLX_U32; c->len = n; c->values = codes;
+  if (validity_holder && validity_holder->validity) c->validity = validity_holder->validity; else c->null_count = 0;
+  if (nd > 0) { c->range_state = 1; c->range_min = 0; c->range_max = nd - 1; c->range_trusted = true; }   // codes are dense by construction
+  auto d = std::make_unique<StrDict>();
+  d->views = dviews; d->data = data; d->n = nd;
+  *out_codes = register_column(c);
+  *out_dict = register_strdict(std::move(d));
+}
+}  // namespace
+}  // extern "C++"
+
+int plx_strview_dict_encode(const void* views, const uint8_t* validity, int64_t bit_offset, int64_t n, const void* const* data_buffers, const int64_t* data_sizes,
+                            int32_t n_data_buffers, plx_column* out_codes, plx_strdict* out_dict) {
+  PLX_TRY
+  PLX_REQUIRE(out_codes && out_dict && n >= 0 && (views || n == 0) && n_data_buffers >= 0 && (n_data_buffers == 0 || (data_buffers && data_sizes)), PLX_ERR_INVALID, "strview_dict_encode: bad arguments");
+  device();
+  Buf dv = dev_alloc((size_t)std::max<int64_t>(n, 1) * 16);
+  if (n) h2d_sync_pinned(dv->ptr, views, (size_t)n * 16);
+  // validity rides on a throw-away byte column so that bit offsets are normalised by the usual import path
+  ColumnPtr vh;
+  if (validity) {
+    std::vector<uint8_t> zeros((size_t)n);
+    vh = column_from_host(PLX_U8, zeros.data(), validity, bit_offset, n);
+  }
+  uint64_t total = 0;
+  std::vector<uint64_t> base((size_t)std::max(n_data_buffers, 1), 0);
+  for (int i = 0; i < n_data_buffers; i++) { base[i] = total; total += (uint64_t)data_sizes[i]; }
+  Buf data = dev_alloc((size_t)total + 64), bb = dev_alloc(sizeof(uint64_t) * base.size());
+  for (int i = 0; i < n_data_buffers; i++) if (data_sizes[i]) h2d_sync_pinned((uint8_t*)data->ptr + base[i], data_buffers[i], (size_t)data_sizes[i]);
+  h2d_async(bb->ptr, base.data(), sizeof(uint64_t) * base.size());
+  PLX_HIP(hipStreamSynchronize(stream()));
+  encode_on_device(dv->as<uint64_t>(), vh, data, bb, n, out_codes, out_dict);
+  PLX_CATCH
+}
+int plx_strview_dict_encode_device(plx_column views_u64_pairs, plx_column data_u8, plx_column* out_codes, plx_strdict* out_dict) {
+  PLX_TRY
+  PLX_REQUIRE(out_codes && out_dict, PLX_ERR_INVALID, "null pointer");
+  ColumnPtr v = get_column(views_u64_pairs);
+  PLX_REQUIRE(v->dtype == PLX_U64 && v->len % 2 == 0 && (v->values || v->len == 0), PLX_ERR_INVALID, "views must be a UInt64 column of 2 n words");
+  Buf data, bb = dev_alloc_zero(8);
+  if (data_u8) { ColumnPtr d = get_column(data_u8); PLX_REQUIRE(d->dtype == PLX_U8, PLX_ERR_INVALID, "data must be a UInt8 column"); data = d->values; }
+  encode_on_device(v->values ? v->values->as<uint64_t>() : nullptr, nullptr, data, bb, v->len / 2, out_codes, out_dict);
+  // the dictionary's views point into nothing else than `data`; inline strings need no buffer at all
+  PLX_CATCH
+}
+int plx_strdict_info(plx_strdict dict, int64_t* n_strings, int64_t* total_bytes) {
+  PLX_TRY
+  StrDict& d = get_strdict(dict);
+  if (total_bytes) materialise(d);
+  if (n_strings) *n_strings = d.n;
+  if (total_bytes) *total_bytes = (int64_t)d.total;
+  PLX_CATCH
+}
+int plx_strdict_to_host(plx_strdict dict, int64_t* offsets, uint8_t* bytes) {
+  PLX_TRY
+  StrDict& d = get_strdict(dict);
+  materialise(d);
+  if (offsets) d2h_sync(offsets, d.offsets->ptr, sizeof(int64_t) * (size_t)(d.n + 1));
+  if (bytes && d.total) d2h_sync(bytes, d.bytes->ptr, (size_t)d.total);
+  PLX_CATCH
+}
+int plx_strdict_free(plx_strdict dict) {
+  PLX_TRY
+  std::lock_guard<std::mutex> lk(g_strdict_mu);
+  if (dict && dict <= g_strdicts.size()) g_strdicts[dict - 1].reset();
+  PLX_CATCH
+}
+int plx_datagen_id_views(int64_t n_rows, uint64_t seed, uint32_t stream_id, int64_t lo, int64_t hi, plx_column* out_views) {
+  PLX_TRY
+  PLX_REQUIRE(n_rows >= 0 && out_views && hi > lo && lo >= 0 && hi <= 10000000000ll && stream_id < 8, PLX_ERR_INVALID, "datagen_id_views: bad arguments");
+  ColumnPtr c = make_column(PLX_U64, n_rows * 2, false); c->null_count = 0;
+  k::datagen_id_views(n_rows, seed, stream_id, lo, hi, c->values->as<uint64_t>());
+  *out_views = register_column(c);
   PLX_CATCH
 }
 

@@ -93,5 +93,17 @@ PLX_HD inline int64_t uniform_value(uint64_t seed, uint32_t stream, uint64_t i, 
   return rand_range(mix64(seed), i, stream & 7u, lo, hi);
 }
 
+// ---- Utf8View of the string "id%010d" % v (12 bytes: always inline; view layout polars-arrow/src/array/binview/view.rs:20-29) --------
+// w0 = length (12) | bytes 0..3 << 32, w1 = bytes 4..11, little-endian
+PLX_HD inline void id_view(uint64_t v, uint64_t* w0, uint64_t* w1) {
+  unsigned char s[12];
+  s[0] = 'i'; s[1] = 'd';
+  for (int d = 11; d >= 2; d--) { s[d] = (unsigned char)('0' + v % 10); v /= 10; }
+  uint64_t a = 12, b = 0;
+  for (int i = 0; i < 4; i++) a |= (uint64_t)s[i] << (32 + 8 * i);
+  for (int i = 0; i < 8; i++) b |= (uint64_t)s[4 + i] << (8 * i);
+  *w0 = a; *w1 = b;
+}
+
 }  // namespace datagen
 }  // namespace plx

@@ -44,6 +44,16 @@ void datagen_lines(int64_t n_orders, uint64_t seed, const uint64_t* offsets, con
 void datagen_uniform(int dtype, int64_t n, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, double scale, void* out);
 void datagen_customer(int64_t n, uint64_t seed, int64_t* custkey, uint8_t* segment);
 
+// ---- raw Utf8View / BinaryView keys (kernels_strview.hip) ---------------------------------------
+// device-side dictionary encoding of 16-byte views (+ concatenated data buffers): u32 code per row (first-claim order), the number
+// of distinct strings and their views ([n_distinct][2] u64; long strings carry their absolute offset into `data`).  Synchronises.
+void strview_dict_encode(const uint64_t* views, const uint64_t* validity, const uint8_t* data, const uint64_t* buf_base, int64_t n, Buf* out_codes, Buf* out_dict_views,
+                         int64_t* n_distinct);
+// dictionary -> offsets[n + 1] (u64) + contiguous bytes on the device
+void strdict_materialise(const uint64_t* dict_views, const uint8_t* data, int64_t n, Buf* out_offsets, Buf* out_bytes, uint64_t* total_bytes);
+// synthetic Utf8View column (benchmark support): the inline view of "id%010d" % value for value = lo + floor(U * (hi - lo)) of row i
+void datagen_id_views(int64_t n, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, uint64_t* out_views);
+
 // ---- reductions (kernels_reduce.hip) ------------------------------------------
 struct ReduceResult {
   uint64_t isum;      // wrapping 64-bit sum of sign/zero-extended values (ints)

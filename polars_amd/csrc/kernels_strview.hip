@@ -1,0 +1,215 @@
+// kernels_strview.hip -- raw Utf8View / BinaryView keys: device-side dictionary encoding.
+//
+// The reference groups / joins on string keys by hashing the 16-byte views (crates/polars-expr/src/hash_keys.rs:413-452
+// BinviewKeys; crates/polars-compute/src/binview_index_map.rs: an index map view -> dense index that compares inline views
+// by value and long strings by bytes; view layout crates/polars-arrow/src/array/binview/view.rs:20-29,55: {len u32, then 12 inline
+// bytes, or prefix u32 + buffer index u32 + offset u32}).  Here the same index map is built ONCE, on the device, when a string
+// column enters: every row's view is looked up / inserted in an open-addressing table in HBM (63-bit tag CAS: EMPTY -> tag|BUSY ->
+// tag, the claimer publishes the view and its code before the tag, as the wide-key aggregation sink does) and the row gets the
+// u32 code of its string; from then on the column is a dictionary column (codes in [0, n_distinct): dense ids, so group-bys on it
+// plan direct-address tables).  Strings of <= 12 bytes never touch the data buffers: the view IS the string (Arrow pads inline
+// views with zeros), which is the whole of BASELINE config 5's "id%010d" keys.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "core.hpp"
+#include "dev.hpp"
+#include "kernels.hpp"
+#include "scan.hpp"
+
+namespace plx {
+namespace k {
+
+using namespace dev;
+
+namespace {
+constexpr unsigned long long kEmptyTag = ~0ull, kBusy = 1ull << 63;
+
+struct StrTable {
+  unsigned long long* tags;     // [cap]
+  unsigned long long* w0;       // [cap] len | prefix << 32 (bytes 0..7 of the view)
+  unsigned long long* w1;       // [cap] inline: bytes 8..15; long: absolute byte offset of the first-seen string in `data`
+  unsigned int* code;           // [cap]
+  unsigned int* counter;        // [0] next code, [1] overflow flag
+  uint32_t log2_cap, max_probe;
+};
+struct StrEncode {
+  const unsigned long long* views;    // [n][2]
+  const uint64_t* validity;           // may be null
+  const unsigned char* data;          // all data buffers, concatenated
+  const unsigned long long* buf_base; // [n_buffers] offset of each original data buffer inside `data`
+  int64_t n;
+  unsigned int* out_codes;            // [n] (null for a counting-only sample pass)
+  unsigned long long* dict_views;     // [max_codes][2] view of every code's string (long strings rebased: absolute offset in w1's high half)
+  uint32_t max_codes;
+};
+
+__device__ __forceinline__ unsigned long long ld(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned int ld32(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st32(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t mix(uint64_t h, uint64_t w) { h ^= w; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; return h; }
+// up to 8 bytes at p (any alignment) as a little-endian word
+__device__ __forceinline__ uint64_t load_bytes(const unsigned char* p, uint32_t n) {
+  uint64_t w = 0;
+  for (uint32_t i = 0; i < n; i++) w |= (uint64_t)p[i] << (8 * i);
+  return w;
+}
+__device__ __forceinline__ uint64_t hash_long(const unsigned char* s, uint32_t len) {
+  uint64_t h = 0x9e3779b97f4a7c15ull ^ len;
+  uint32_t i = 0;
+  for (; i + 8 <= len; i += 8) h = mix(h, load_bytes(s + i, 8));
+  if (i < len) h = mix(h, load_bytes(s + i, len - i));
+  return h;
+}
+__device__ __forceinline__ bool same_bytes(const unsigned char* a, const unsigned char* b, uint32_t len) {
+  uint32_t i = 0;
+  for (; i + 8 <= len; i += 8) if (load_bytes(a + i, 8) != load_bytes(b + i, 8)) return false;
+  return i >= len || load_bytes(a + i, len - i) == load_bytes(b + i, len - i);
+}
+
+__global__ __launch_bounds__(kBlock) void strview_encode_kernel(StrEncode e, StrTable t) {
+  const uint64_t cap = 1ull << t.log2_cap;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < e.n; row += (int64_t)gridDim.x * blockDim.x) {
+    const bool valid = !e.validity || ((e.validity[row >> 6] >> (row & 63)) & 1);
+    const ulonglong2 v = reinterpret_cast<const ulonglong2*>(e.views)[row];
+    const uint32_t len = (uint32_t)v.x;
+    const bool is_long = len > 12;
+    uint64_t w0 = v.x, w1 = v.y, h;
+    const unsigned char* bytes = nullptr;
+    if (is_long) {
+      const uint32_t buf = (uint32_t)v.y, off = (uint32_t)(v.y >> 32);
+      const uint64_t abs_off = e.buf_base[buf] + off;
+      bytes = e.data + abs_off;
+      w1 = abs_off;
+      h = valid ? hash_long(bytes, len) : 0;
+    } else h = mix(mix(0x9e3779b97f4a7c15ull, w0), w1);
+    h *= 0x55fbfd6bfc5458e9ull;
+    uint64_t tag = h & ~kBusy;
+    if (tag == (kEmptyTag & ~kBusy)) tag ^= 1;
+    uint64_t slot = h >> (64 - t.log2_cap);
+    int64_t code = valid ? -1 : 0;
+    bool failed = false;
+    for (uint32_t probe = 0; code < 0 && !failed; probe++) {
+      if (probe >= t.max_probe) { failed = true; break; }
+      unsigned long long cur = ld(&t.tags[slot]);
+      bool claimed = false;
+      if (cur == kEmptyTag) {
+        const unsigned long long old = atomicCAS(&t.tags[slot], kEmptyTag, tag | kBusy);
+        if (old == kEmptyTag) claimed = true; else cur = old;
+      }
+      if (claimed) {   // publish: view words + code (write-through) -> drain -> tag
+        const unsigned int c = atomicAdd(t.counter, 1u);
+        st(&t.w0[slot], w0); st(&t.w1[slot], w1); st32(&t.code[slot], c);
+        if (e.dict_views && c < e.max_codes) { e.dict_views[(size_t)c * 2] = w0; e.dict_views[(size_t)c * 2 + 1] = w1; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st(&t.tags[slot], tag);
+        code = (int64_t)c;
+      }
+      // every lane of the wave is past its publish before any lane starts to wait (a lane must never wait for a slot that a
+      // lane of its own wave has claimed but not yet published)
+      __builtin_amdgcn_wave_barrier();
+      if (!claimed && (cur & ~kBusy) == tag) {
+        while (cur & kBusy) { __builtin_amdgcn_s_sleep(1); cur = ld(&t.tags[slot]); }
+        asm volatile("" ::: "memory");
+        bool same = ld(&t.w0[slot]) == w0;
+        if (same) {
+          const unsigned long long s1 = ld(&t.w1[slot]);
+          same = is_long ? (s1 == w1 || same_bytes(e.data + s1, bytes, len)) : (s1 == w1);
+        }
+        if (same) code = (int64_t)ld32(&t.code[slot]);
+      }
+      slot = (slot + 1) & (cap - 1);
+    }
+    if (failed) { atomicExch(t.counter + 1, 1u); code = 0; }
+    if (e.out_codes) e.out_codes[row] = (unsigned int)code;
+  }
+}
+
+// dictionary materialisation: byte length of every code's string, then the bytes, contiguously in code order
+__global__ __launch_bounds__(kBlock) void strdict_len_kernel(const unsigned long long* __restrict__ dict_views, int64_t n, uint32_t* __restrict__ lens) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) lens[i] = (uint32_t)dict_views[(size_t)i * 2];
+}
+__global__ __launch_bounds__(kBlock) void strdict_copy_kernel(const unsigned long long* __restrict__ dict_views, const unsigned char* __restrict__ data, int64_t n,
+                                                              const unsigned long long* __restrict__ offsets, unsigned char* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long w0 = dict_views[(size_t)i * 2], w1 = dict_views[(size_t)i * 2 + 1];
+    const uint32_t len = (uint32_t)w0;
+    unsigned char* dst = out + offsets[i];
+    if (len <= 12) {
+      for (uint32_t b = 0; b < len; b++) dst[b] = (unsigned char)(b < 4 ? (w0 >> (32 + 8 * b)) : (w1 >> (8 * (b - 4))));
+    } else {
+      const unsigned char* src = data + w1;
+      for (uint32_t b = 0; b < len; b++) dst[b] = src[b];
+    }
+  }
+}
+}  // namespace
+
+// views / validity / data: device buffers.  Returns the codes (device, u32 per row), the number of distinct strings and the
+// dictionary's views (device, [n_distinct][2], long strings carrying their absolute data offset).
+void strview_dict_encode(const uint64_t* views, const uint64_t* validity, const uint8_t* data, const uint64_t* buf_base, int64_t n, Buf* out_codes, Buf* out_dict_views,
+                         int64_t* n_distinct) {
+  *out_codes = dev_alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1));
+  if (n == 0) { *out_dict_views = dev_alloc(16); *n_distinct = 0; return; }
+  auto run = [&](int64_t rows, uint32_t log2_cap, uint32_t max_codes, unsigned int* codes, Buf* dict, uint32_t* distinct) -> bool {
+    const uint64_t cap = 1ull << log2_cap;
+    Buf tags = dev_alloc(8 * cap), w0 = dev_alloc(8 * cap), w1 = dev_alloc(8 * cap), code = dev_alloc(4 * cap), ctr = dev_alloc_zero(8);
+    PLX_HIP(hipMemsetAsync(tags->ptr, 0xff, 8 * cap, stream()));
+    if (dict) *dict = dev_alloc(16 * (size_t)std::max<uint32_t>(max_codes, 1));
+    StrTable t{tags->as<unsigned long long>(), w0->as<unsigned long long>(), w1->as<unsigned long long>(), code->as<unsigned int>(), ctr->as<unsigned int>(), log2_cap,
+               (uint32_t)std::min<uint64_t>(cap, 1u << 12)};
+    StrEncode e{(const unsigned long long*)views, validity, data, (const unsigned long long*)buf_base, rows, codes, dict ? (*dict)->as<unsigned long long>() : nullptr, max_codes};
+    {
+      ProfileScope ps("strview_dict_encode", (uint64_t)rows * (16 + (codes ? 4 : 0)), (uint64_t)rows);
+      hipLaunchKernelGGL(strview_encode_kernel, dim3(grid_for(rows, kBlock, 8)), dim3(kBlock), 0, stream(), e, t);
+      PLX_HIP(hipGetLastError());
+    }
+    uint32_t res[2] = {0, 0};
+    d2h_sync(res, ctr->ptr, 8);
+    *distinct = res[0];
+    return res[1] == 0;
+  };
+  // table size from a sample of the first rows: d distinct in S rows -> G ~ solution of d = G (1 - exp(-S / G))
+  uint32_t log2_cap = 16;
+  {
+    const int64_t S = std::min<int64_t>(n, (int64_t)1 << 20);
+    uint32_t d = 0;
+    if (run(S, 22, 0, nullptr, nullptr, &d)) {
+      double G = (double)d;
+      if (S < n && d > 0) {
+        if ((double)d >= 0.999 * (double)S) G = (double)n;
+        else { double lo = d, hi = 1e15; for (int it = 0; it < 200; it++) { const double mid = std::sqrt(lo * hi); (mid * (1.0 - std::exp(-(double)S / mid)) < (double)d ? lo : hi) = mid; } G = std::min(hi, (double)n); }
+      }
+      while (log2_cap < 34 && (double)(1ull << log2_cap) < 2.5 * G) log2_cap++;
+    } else log2_cap = 24;
+  }
+  for (int attempt = 0; attempt < 8; attempt++) {
+    uint32_t d = 0;
+    const uint32_t max_codes = (uint32_t)std::min<uint64_t>((uint64_t)n, 1ull << log2_cap);
+    if (run(n, log2_cap, max_codes, (*out_codes)->as<unsigned int>(), out_dict_views, &d)) { *n_distinct = d; return; }
+    log2_cap += 2;
+    PLX_REQUIRE(log2_cap <= 34, PLX_ERR_OOM, "string dictionary table would exceed 2^34 slots");
+  }
+  fail(PLX_ERR_OOM, "string dictionary table kept overflowing");
+}
+
+// dictionary -> contiguous bytes + offsets[n + 1] on the device
+void strdict_materialise(const uint64_t* dict_views, const uint8_t* data, int64_t n, Buf* out_offsets, Buf* out_bytes, uint64_t* total_bytes) {
+  *out_offsets = dev_alloc(sizeof(uint64_t) * (size_t)(n + 2));
+  if (n == 0) { PLX_HIP(hipMemsetAsync((*out_offsets)->ptr, 0, 16, stream())); *out_bytes = dev_alloc(16); *total_bytes = 0; return; }
+  Buf lens = dev_alloc(sizeof(uint32_t) * (size_t)n);
+  hipLaunchKernelGGL(strdict_len_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, stream(), (const unsigned long long*)dict_views, n, lens->as<uint32_t>());
+  PLX_HIP(hipGetLastError());
+  exclusive_scan_u32(lens->as<uint32_t>(), (*out_offsets)->as<uint64_t>(), n);
+  d2h_sync(total_bytes, (*out_offsets)->as<uint64_t>() + n, 8);
+  *out_bytes = dev_alloc((size_t)*total_bytes + 16);
+  hipLaunchKernelGGL(strdict_copy_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, stream(), (const unsigned long long*)dict_views, (const unsigned char*)data, n,
+                     (*out_offsets)->as<unsigned long long>(), (*out_bytes)->as<unsigned char>());
+  PLX_HIP(hipGetLastError());
+}
+
+}  // namespace k
+}  // namespace plx

@@ -238,6 +238,19 @@ def uniform_native(pl, name: str, dtype, n: int, seed: int, stream: int, lo: int
     return pl.Series._from_handle(name, h.value, dtype)
 
 
+def id_views_native(pl, name: str, n: int, seed: int, stream: int, lo: int, hi: int):
+    """A Utf8View key column generated in HBM: row i holds the (inline, 12-byte) view of "id%010d" % uniform_value(seed, stream, i, lo, hi)
+    -> UInt64 Series of 2 n words (feed it to pl.Series.from_device_views).  Host twin: uniform_native_host("Int64", ...) gives the
+    values, the strings are "id%010d" % value."""
+    import ctypes as C
+
+    from . import _ffi as F
+    F.ensure_init()
+    h = C.c_uint64()
+    F.check(F.lib().plx_datagen_id_views(n, seed, stream, lo, hi, C.byref(h)))
+    return pl.Series._from_handle(name, h.value, pl.UInt64)
+
+
 # ---- multi-threaded host twins (ctypes releases the GIL): full-size checks in bench.py / tests -------------------------
 def _host_threads(threads=None) -> int:
     import os

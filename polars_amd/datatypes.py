@@ -60,7 +60,7 @@ class Categorical(DataType):
         phys = index_dtype.physical if index_dtype is not None else F.U32
         npdt = index_dtype.np_dtype if index_dtype is not None else np.uint32
         super().__init__("Categorical", phys, npdt)
-        self.categories = list(categories)
+        self.categories = categories if hasattr(categories, "_load") else list(categories)   # a device-built dictionary stays lazy
 
     def __eq__(self, other) -> bool:
         return isinstance(other, Categorical)

@@ -73,6 +73,8 @@ class Series:
         if isinstance(arr, pa.ChunkedArray):
             arr = arr.combine_chunks()
         logical = None
+        if hasattr(pa.types, "is_string_view") and (pa.types.is_string_view(arr.type) or pa.types.is_binary_view(arr.type)):
+            return cls._from_string_views(name, arr)
         if pa.types.is_dictionary(arr.type) or pa.types.is_string(arr.type) or pa.types.is_large_string(arr.type):
             d = arr if pa.types.is_dictionary(arr.type) else arr.dictionary_encode()
             logical = T.Categorical(d.dictionary.to_pylist())
@@ -87,6 +89,41 @@ class Series:
         h = C.c_uint64()
         F.check(F.lib().plx_column_import_arrow(C.byref(a), C.byref(s), C.byref(h)))
         return cls(name, _handle=h.value, _dtype=logical)
+
+    @classmethod
+    def _from_string_views(cls, name: str, arr) -> "Series":
+        """Utf8View / BinaryView array -> dictionary column encoded ON THE DEVICE (plx_strview_dict_encode: the 16-byte views and
+        the data buffers are uploaded as they are, the library hashes / compares the views the way the reference's BinviewKeys
+        do and hands back u32 codes + the dictionary).  Codes are in first-claim order, not sorted."""
+        import pyarrow as pa
+        F.ensure_init()
+        a, s = F.ArrowArray(), F.ArrowSchema()
+        arr._export_to_c(C.addressof(a), C.addressof(s))
+        try:
+            n, nb = a.length, a.n_buffers
+            views = a.buffers[1]
+            views = (views or 0) + 16 * a.offset
+            n_data = max(nb - 3, 0)                       # [validity, views, data..., variadic sizes]
+            sizes_ptr = C.cast(a.buffers[nb - 1], C.POINTER(C.c_int64)) if n_data else None
+            data_ptrs = (C.c_void_p * max(n_data, 1))(*[a.buffers[2 + i] for i in range(n_data)])
+            data_sizes = (C.c_int64 * max(n_data, 1))(*[sizes_ptr[i] for i in range(n_data)])
+            validity = a.buffers[0] if a.null_count != 0 else None
+            codes, d = C.c_uint64(), C.c_uint64()
+            F.check(F.lib().plx_strview_dict_encode(C.c_void_p(views), C.c_void_p(validity), a.offset, n, data_ptrs, data_sizes, n_data, C.byref(codes), C.byref(d)))
+        finally:
+            for st, ty in ((a, F.ArrowArray), (s, F.ArrowSchema)):
+                if st.release:
+                    C.CFUNCTYPE(None, C.POINTER(ty))(st.release)(C.byref(st))
+        return cls(name, _handle=codes.value, _dtype=T.Categorical(DeviceDictionary(d.value, binary=pa.types.is_binary_view(arr.type)), T.UInt32))
+
+    @classmethod
+    def from_device_views(cls, name: str, views: "Series", data: "Optional[Series]" = None) -> "Series":
+        """Utf8View column whose views already sit in HBM (a UInt64 Series of 2 n words; `data`: a UInt8 Series with the long
+        strings' bytes, or None when every string is <= 12 bytes) -> dictionary column, encoded on the device."""
+        F.ensure_init()
+        codes, d = C.c_uint64(), C.c_uint64()
+        F.check(F.lib().plx_strview_dict_encode_device(views._h, data._h if data is not None else 0, C.byref(codes), C.byref(d)))
+        return cls(name, _handle=codes.value, _dtype=T.Categorical(DeviceDictionary(d.value), T.UInt32))
 
     def _query_dtype(self) -> T.DataType:
         dt = C.c_int32()
@@ -150,7 +187,8 @@ class Series:
         values, valid = self._download()
         out = values.tolist()
         if isinstance(self.dtype, T.Categorical) and self.dtype.categories:
-            out = [self.dtype.categories[c] if c < len(self.dtype.categories) else None for c in out]
+            cats = list(self.dtype.categories)
+            out = [cats[c] if c < len(cats) else None for c in out]
         if valid is not None:
             out = [v if ok else None for v, ok in zip(out, valid.tolist())]
         return out
@@ -308,6 +346,54 @@ def arg_sort_by(by: Sequence["Series"], descending=False, nulls_last=False, limi
     F.check(F.lib().plx_sort_indices((C.c_uint64 * n)(*[s._h for s in by]), n, (C.c_uint8 * n)(*map(int, d)), (C.c_uint8 * n)(*map(int, nl)),
                                      int(limit), C.byref(h)))
     return Series._from_handle(by[0].name, h.value, T.UInt32)
+
+
+class DeviceDictionary:
+    """Categories of a dictionary built on the device (plx_strview_dict_encode): a list-like whose strings are downloaded on
+    first use only -- a group-by on the codes never needs them, so a 1e6-entry dictionary costs nothing until results are
+    printed.  len() is known without a download."""
+
+    def __init__(self, handle: int, binary: bool = False):
+        n = C.c_int64()
+        F.check(F.lib().plx_strdict_info(handle, C.byref(n), None))
+        self._h, self._n, self._binary, self._items = handle, n.value, binary, None
+
+    def _load(self) -> list:
+        if self._items is None:
+            self._items = _download_dictionary(self._h, self._binary)
+            F.lib().plx_strdict_free(self._h)
+            self._h = 0
+        return self._items
+
+    def __len__(self): return self._n
+    def __bool__(self): return self._n > 0
+    def __iter__(self): return iter(self._load())
+    def __getitem__(self, i): return self._load()[i]
+    def __contains__(self, x): return x in self._load()
+    def index(self, x): return self._load().index(x)
+    def __eq__(self, other): return list(self) == list(other)
+    def __repr__(self): return f"DeviceDictionary({self._n} strings)"
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", 0) and F._lib is not None:
+                F._lib.plx_strdict_free(self._h)
+        except Exception:
+            pass
+
+
+def _download_dictionary(dict_handle: int, binary: bool = False) -> list:
+    """Strings of a device-built dictionary (plx_strdict_to_host), in code order."""
+    n, total = C.c_int64(), C.c_int64()
+    F.check(F.lib().plx_strdict_info(dict_handle, C.byref(n), C.byref(total)))
+    offsets = np.zeros(n.value + 1, np.int64)
+    raw = np.zeros(max(total.value, 1), np.uint8)
+    F.check(F.lib().plx_strdict_to_host(dict_handle, offsets.ctypes.data_as(C.c_void_p), raw.ctypes.data_as(C.c_void_p)))
+    blob = raw.tobytes()
+    o = offsets.tolist()
+    if binary:
+        return [blob[o[i]:o[i + 1]] for i in range(n.value)]
+    return [blob[o[i]:o[i + 1]].decode("utf-8", errors="surrogateescape") for i in range(n.value)]
 
 
 def _upload(values: Any, dtype: Optional[T.DataType], validity: Any):
@@ -521,7 +607,8 @@ class DataFrame:
         for c, (values, valid) in zip(self._cols, self._download_all()):
             out = values.tolist()
             if isinstance(c.dtype, T.Categorical) and c.dtype.categories:
-                out = [c.dtype.categories[x] if x < len(c.dtype.categories) else None for x in out]
+                cats = list(c.dtype.categories)
+                out = [cats[x] if x < len(cats) else None for x in out]
             if valid is not None:
                 out = [v if ok else None for v, ok in zip(out, valid.tolist())]
             res[c.name] = out

@@ -400,3 +400,16 @@ def test_semi_anti_oracle_against_pandas():
         matched = left["k"].map(lambda x: (x is not pd.NA) and (x in right_keys)).to_numpy(dtype=bool) if nl else np.zeros(0, bool)
         assert np.array_equal(orc.semi_anti_join(orc.JOIN_SEMI, lk, lm, rk, rm), np.nonzero(matched)[0])
         assert np.array_equal(orc.semi_anti_join(orc.JOIN_ANTI, lk, lm, rk, rm), np.nonzero(~matched)[0])
+
+
+def test_binview_index_map_restatement(orc):
+    """The oracle's view index map (binview_index_map.rs restated): dense indices in first-appearance order, equality by length +
+    bytes -- strings that share the 4-byte prefix or the length stay distinct, the empty string is a value, nulls get no index."""
+    s = ["abcd_x", "abcd_y", "abcd_x", "", None, "abcd", "a much longer string than twelve bytes A", "a much longer string than twelve bytes B", "", "abcd_y"]
+    codes, valid, cats = orc.binview_dict_encode(s)
+    assert cats == ["abcd_x", "abcd_y", "", "abcd", "a much longer string than twelve bytes A", "a much longer string than twelve bytes B"]
+    assert codes.tolist() == [0, 1, 0, 2, 0, 3, 4, 5, 2, 1] and valid.tolist() == [True, True, True, True, False, True, True, True, True, True]
+    assert orc.binview_parts(b"twelve bytes") == (12, int.from_bytes(b"twel", "little"), True) and orc.binview_parts(b"thirteen byte")[2] is False
+    # the reference's own string-key vector (test_group_by.py:32-52): a, b, a, b, b, c -> three groups in first-appearance order
+    c2, v2, k2 = orc.binview_dict_encode(["a", "b", "a", "b", "b", "c"])
+    assert k2 == ["a", "b", "c"] and v2 is None and np.bincount(c2, weights=[1, 2, 3, 4, 5, 6]).tolist() == [4.0, 11.0, 6.0]
