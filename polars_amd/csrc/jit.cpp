@@ -2,6 +2,8 @@
 #include "jit.hpp"
 
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <hip/hip_runtime_api.h>
 #include <hip/hiprtc.h>
 
@@ -118,10 +120,80 @@ bool enabled(int64_t n_rows) {
   return m >= 0 && n_rows >= m;
 }
 
+// ---- disk cache of compiled code objects ------------------------------------------------------------------------------
+// A shape without an AOT kernel costs 260-290 ms of hiprtc per process; the code object only depends on the generated source, the
+// compile options and the device headers, so it is kept in $PLX_JIT_CACHE_DIR (default ~/.cache/polars_amd/jit; PLX_JIT_CACHE=0
+// disables it) under a hash of exactly those inputs.  A cold process then loads the kernel in ~1 ms.
+uint64_t fnv1a(const std::string& s, uint64_t h = 0xcbf29ce484222325ull) { for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ull; } return h; }
+std::string cache_dir() {
+  const char* off = getenv("PLX_JIT_CACHE");
+  if (off && off[0] == '0') return "";
+  if (const char* d = getenv("PLX_JIT_CACHE_DIR")) return d;
+  const char* home = getenv("HOME");
+  return home && *home ? std::string(home) + "/.cache/polars_amd/jit" : std::string("/tmp/polars_amd_jit");
+}
+std::string headers_fingerprint() {   // the device headers the generated source includes: a stale cache entry must never survive an upgrade
+  static const std::string fp = [] {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (const char* f : {"fused.hpp", "fused_device.hpp", "fused_sinks.hpp", "fused_shapes.hpp", "partition_device.hpp", "partition2_device.hpp", "dev.hpp", "kconfig.hpp"}) {
+      if (FILE* fp2 = fopen((include_dir() + "/" + f).c_str(), "rb")) {
+        char buf[65536]; size_t n;
+        while ((n = fread(buf, 1, sizeof buf, fp2)) > 0) h = fnv1a(std::string(buf, n), h);
+        fclose(fp2);
+      }
+    }
+    char out[32]; snprintf(out, sizeof out, "%016llx", (unsigned long long)h);
+    return std::string(out);
+  }();
+  return fp;
+}
+std::string cache_path(const std::string& src) {
+  const std::string dir = cache_dir();
+  if (dir.empty()) return "";
+  std::string key = src + "|" + headers_fingerprint();
+  for (auto& o : compile_options()) if (o.compare(0, 2, "-I") != 0) key += "|" + o;
+  char name[64]; snprintf(name, sizeof name, "/%016llx%016llx.hsaco", (unsigned long long)fnv1a(key), (unsigned long long)fnv1a(key, 0x9e3779b97f4a7c15ull));
+  return dir + name;
+}
+bool load_cached(const std::string& path, std::vector<char>* code) {
+  if (path.empty()) return false;
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+  bool ok = n > 0;
+  if (ok) { code->resize((size_t)n); ok = fread(code->data(), 1, (size_t)n, f) == (size_t)n; }
+  fclose(f);
+  return ok;
+}
+void store_cached(const std::string& path, const std::vector<char>& code) {
+  if (path.empty()) return;
+  const std::string dir = path.substr(0, path.rfind('/'));
+  std::string acc;
+  for (size_t i = 1; i <= dir.size(); i++) if (i == dir.size() || dir[i] == '/') { acc = dir.substr(0, i); (void)mkdir(acc.c_str(), 0755); }
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  if (FILE* f = fopen(tmp.c_str(), "wb")) {
+    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());     // atomic publish: readers never see a partial file
+  }
+}
+int g_cache_hits = 0;
+
 Entry compile(const Shape& sh, Sink sink) {
   Entry e;
   const auto t0 = std::chrono::steady_clock::now();
   const std::string src = source_for(sh, sink);
+  const std::string cpath = cache_path(src);
+  {
+    std::vector<char> cached;
+    if (load_cached(cpath, &cached) && hipModuleLoadData(&e.mod, cached.data()) == hipSuccess && hipModuleGetFunction(&e.fn, e.mod, "plx_jit_kernel") == hipSuccess) {
+      g_cache_hits++; g_compiled++;      // stats(): specialised kernels made available, compiled or loaded
+      if (getenv("PLX_JIT_VERBOSE")) fprintf(stderr, "[plx jit] %s: loaded from %s\n", sink_type(sink), cpath.c_str());
+      return e;
+    }
+    (void)hipGetLastError();
+    e = Entry{};
+  }
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, src.c_str(), "plx_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { e.failed = true; return e; }
   const std::vector<std::string> optv = compile_options();

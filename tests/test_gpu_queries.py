@@ -644,3 +644,25 @@ def test_q3_three_tables(pl, orc, fused):
         assert top["o_orderkey"].to_numpy().tolist() == want["o_orderkey"][best].tolist()
         # a segment missing from the dictionary: empty result
         assert queries.q3_full(C.lazy(), O.lazy(), L.lazy(), segment="NOSUCH").collect().height == 0
+
+
+def test_float_sums_of_cancelling_values_stay_within_tolerance(pl, orc):
+    """Zero-mean data: |sum| is ~1e3 times smaller than sum(|x|), so summation error is amplified by that condition number.  The
+    reference's in-memory group sums are Kahan-compensated (aggregations/mod.rs:867-870, restated by the oracle), the library
+    accumulates plain f64 per lane / per LDS cell in arbitrary order; the results must still agree to 1e-6 relative (whole-column
+    and grouped), which f64 accumulation does with ~6 digits to spare.  (Inputs whose true sum is ~0 have no meaningful relative
+    error in any engine: the reference's own streaming and in-memory engines disagree there.)"""
+    rng = np.random.default_rng(47)
+    n = 8_000_000
+    x = rng.uniform(-1.0, 1.0, n) * rng.choice([1.0, 1e3, 1e-3], n)
+    g = rng.integers(0, 64, n).astype(np.int64)
+    df = pl.DataFrame({"g": g, "x": x})
+    tot = df.lazy().select(pl.col("x").sum().alias("s")).collect().to_dict()["s"][0]
+    want_tot = orc.reduce(orc.AGG_SUM, x)[0]
+    assert abs(want_tot) * 1e3 < np.abs(x).sum()                      # the data really cancels
+    assert math.isclose(tot, want_tot, rel_tol=RTOL)
+    out = df.lazy().group_by("g").agg(pl.col("x").sum().alias("s"), pl.col("x").mean().alias("m")).collect().sort_host("g")
+    w = orc.q_groupby([g], [None], [("s", orc.AGG_SUM, x, None), ("m", orc.AGG_MEAN, x, None)])
+    order = np.argsort(w["key_0"][0])
+    assert out["g"] == w["key_0"][0][order].tolist()
+    assert np.allclose(np.array(out["s"]), w["s"][0][order], rtol=RTOL, atol=0) and np.allclose(np.array(out["m"]), w["m"][0][order], rtol=RTOL, atol=0)
