@@ -198,13 +198,6 @@ struct PartitionPlan {
 constexpr uint32_t kP2Hash = 0, kP2Direct = 1;
 constexpr uint32_t kP2ChunkRecs = 256;        // records per chunk: chunk bytes = 256 * rec_words * 4 (a multiple of the 128-B line)
 constexpr uint32_t kP2MaxHot = 256;           // hot keys pre-aggregated in the scatter pass
-// LDS staging ring of a partition: a power-of-two number of RECORD slots whose dwords are a whole number (>= 2) of 128-B lines,
-// so that a record never straddles the wrap-around (one address computation per record) and lines map to the chunk's lines
-PLX_FHD constexpr uint32_t p2_ring_recs(uint32_t rec_words) {
-  uint32_t r = 16;
-  while ((r * rec_words) % 32 != 0 || (r * rec_words) / 32 < 2) r *= 2;
-  return r;
-}
 constexpr uint32_t kNoChunk = 0xffffffffu;
 struct RecLayout2 {
   uint8_t key_words;             // 1 | 2 dwords
@@ -266,7 +259,7 @@ struct PartPlan2 {
   uint32_t log2_parts;         // P = 1 << log2_parts partitions
   uint32_t log2_slots;         // slots of a partition's LDS table (direct mode: == key_shift)
   uint32_t key_shift;          // direct mode: partition = id >> key_shift, table slot = id & ((1 << key_shift) - 1)
-  uint32_t ring_lines;         // 128-B lines of LDS staging per partition == p2_ring_recs(rec_words) * rec_words / 32
+  uint32_t ring_lines;         // 128-B lines of LDS staging per partition (power of two)
   uint32_t block;              // threads of a scatter workgroup
   uint32_t chunks_per_wg;      // chunks in each scatter workgroup's private region
   uint32_t scatter_grid;

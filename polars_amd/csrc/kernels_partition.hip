@@ -185,6 +185,7 @@ int64_t partitioned_agg(const Shape& sh, const Args& args, const PartitionPlan& 
 // read once (e.g. 16 + 12 + 12 B/row for an i64 key column of dense ids and an i64 value, against 8 + 32 + 16 before).
 // ======================================================================================================================
 static const int kEnvP2Block = env_int("PLX_PART_BLOCK", 256, 1024);
+static const int kEnvP2Ring = env_int("PLX_PART_RING_LINES", 1, 16);
 static const int kEnvP2Direct = env_int("PLX_PART_DIRECT", 0, 1);        // 0: never use the direct-address mode
 
 static uint32_t floor_pow2(uint32_t x) { uint32_t p = 1; while (p * 2 <= x) p *= 2; return p; }
@@ -201,16 +202,11 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
     // direct-address LDS table: slots = low bits of the id; as many partitions as give every CU work, tables as large as fit
     uint32_t max_shift = 0;
     while (((size_t)1 << (max_shift + 1)) * sh.n_aggs * 8 <= 128 * 1024) max_shift++;
-    // as many partitions as the scatter workgroup's LDS holds rings for (512 with 16-byte records, 256 with 12-byte ones), at
-    // least 16: every CU gets partitions to aggregate
-    const RecLayout2 Ld = rec_layout2(sh, kP2Direct);
-    int lp_max = 9;
-    while (lp_max > 4 && part2_scatter_lds(1u << lp_max, p2_ring_recs(Ld.rec_words) * Ld.rec_words / 32, n_hot ? 512 : 0, (uint32_t)std::min<int>(n_hot, (int)kP2MaxHot), sh.n_aggs, 1) + 8192 > lds_total) lp_max--;
-    int shift = packed_bits - lp_max;
+    int shift = packed_bits - 9;                      // 512 partitions when the id range allows
     if (shift > (int)max_shift) shift = (int)max_shift;
     if (shift < 6) shift = 6;
     const int lp = packed_bits - shift;
-    if (lp >= 4 && lp <= lp_max) { direct = true; pp.mode = kP2Direct; pp.key_shift = (uint32_t)shift; pp.log2_slots = (uint32_t)shift; pp.log2_parts = (uint32_t)lp; }
+    if (lp >= 4 && lp <= 9) { direct = true; pp.mode = kP2Direct; pp.key_shift = (uint32_t)shift; pp.log2_slots = (uint32_t)shift; pp.log2_parts = (uint32_t)lp; }
   }
   if (!direct) {
     pp.mode = kP2Hash;
@@ -234,19 +230,21 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
   pp.log2_hot_slots = pp.n_hot ? std::max<uint32_t>(3, ceil_log2((uint64_t)pp.n_hot * 2)) : 0;
   pp.hot_copies = 1;
   if (pp.n_hot) { uint32_t c = 16; while (c > 1 && (size_t)pp.n_hot * sh.n_aggs * 8 * c > 8 * 1024) c >>= 1; pp.hot_copies = c; }
-  // ---- rings: p2_ring_recs(rec_words) record slots per partition (a whole number of 128-B lines); they must fit the LDS next to the
-  // per-partition state, the flush list and the hot-key tables
+  // ---- rings: as many 128-B lines per partition as the LDS holds (power of two)
   const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0;
-  const uint32_t lines = p2_ring_recs(L.rec_words) * L.rec_words / 32;
-  if (part2_scatter_lds(NP, lines, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies) > lds_total) return false;
+  const size_t fixed = part2_scatter_lds(NP, 0, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies);
+  if (fixed + (size_t)NP * 256 > lds_total) return false;
+  uint32_t lines = floor_pow2((uint32_t)((lds_total - fixed) / ((size_t)NP * 128)));
+  if (lines > 16) lines = 16;
+  if (kEnvP2Ring > 0 && (uint32_t)kEnvP2Ring <= lines) lines = floor_pow2((uint32_t)kEnvP2Ring);
+  if (lines < 2) return false;
   pp.ring_lines = lines;
   // ---- workgroup size: rows per round so that a partition receives well under its ring's free space per round
-  const double cap_recs = (double)p2_ring_recs(L.rec_words), line_recs = 32.0 / L.rec_words;
+  const double cap_recs = (double)(lines * 32) / L.rec_words, line_recs = 32.0 / L.rec_words;
   const double lambda_max = std::max(1.0, (cap_recs - line_recs) * 0.55);
   uint32_t block = kP2MaxBlock;
   while (block > 256 && (double)block * kRows / NP > lambda_max) block >>= 1;
   if (kEnvP2Block > 0) block = floor_pow2((uint32_t)kEnvP2Block);
-  if (block < NP) block = NP;                       // thread t < P owns partition t in the flush phase
   pp.block = block;
   const int64_t rows_per_round = (int64_t)block * kRows;
   const int64_t nrounds = (n_rows + rows_per_round - 1) / rows_per_round;

@@ -52,17 +52,15 @@ __device__ __forceinline__ uint32_t part2_of(uint64_t key, bool kvalid, uint32_t
 }
 
 // LDS layout of the scatter kernel (dynamic shared memory), in this order:
-//   ring    [P][ring_dw] u32        staging rings: p2_ring_recs(RW) record slots = ring_lines whole 128-B lines (ring_dw = ring_lines * 32)
+//   ring    [P][ring_dw] u32        staging rings (ring_dw = ring_lines * 32)
 //   fl      [P] u64                 {limit : fill}: records appended to the current chunk so far (low), most that fit (high)
 //   hot_k   [hot_slots] u64, hot_acc [n_hot * n_aggs * copies] u64
 //   fdw     [P] u32                 dwords of the current chunk already written to HBM
 //   chunk   [P] u32                 current chunk (kNoChunk: none yet)
 //   hot_i   [hot_slots] u32
-//   misc    [4] u32                 [0] next chunk of this workgroup's region, [1], [2] "some row is still pending" flags (alternating), [3] lines in flist
-//   flist   [P * ring_lines] u64    lines to write this round: (destination line in the record pool << 16) | ring line
+//   misc    [4] u32                 [0] next chunk of this workgroup's region, [1], [2] "some row is still pending" flags (alternating)
 __host__ __device__ inline size_t part2_scatter_lds(uint32_t P, uint32_t ring_lines, uint32_t hot_slots, uint32_t n_hot, uint32_t n_aggs, uint32_t copies) {
-  return (size_t)P * ring_lines * 128 + (size_t)P * 8 + (size_t)hot_slots * 8 + (size_t)n_hot * n_aggs * copies * 8 + (size_t)P * ring_lines * 8 + (size_t)P * 4 * 2 +
-         (size_t)hot_slots * 4 + 16;
+  return (size_t)P * ring_lines * 128 + (size_t)P * 8 + (size_t)hot_slots * 8 + (size_t)n_hot * n_aggs * copies * 8 + (size_t)P * 4 * 2 + (size_t)hot_slots * 4 + 16;
 }
 
 // ---- one row -> record dwords ---------------------------------------------------------------------------------------
@@ -104,29 +102,29 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   constexpr RecLayout2 L = rec_layout2(P::shape(), (uint32_t)MODE);
   constexpr uint32_t RW = L.rec_words;
   constexpr uint32_t chunk_dw = kP2ChunkRecs * RW;
-  constexpr uint32_t ring_recs = p2_ring_recs(RW), ring_dw = ring_recs * RW, ring_lines = ring_dw / 32;
-  const uint32_t NP = 1u << pp.log2_parts;
+  const uint32_t NP = 1u << pp.log2_parts, ring_dw = pp.ring_lines * 32u, ring_mask = ring_dw - 1u;
   const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0u;
   unsigned int* ring = reinterpret_cast<unsigned int*>(p2_lds);
   unsigned long long* fl = p2_lds + (size_t)NP * ring_dw / 2;
   unsigned long long* hot_k = fl + NP;
   unsigned long long* hot_acc = hot_k + hot_slots;
-  unsigned long long* flist = hot_acc + (size_t)pp.n_hot * sh.n_aggs * pp.hot_copies;
-  unsigned int* fdw = reinterpret_cast<unsigned int*>(flist + (size_t)NP * ring_lines);
+  unsigned int* fdw = reinterpret_cast<unsigned int*>(hot_acc + (size_t)pp.n_hot * sh.n_aggs * pp.hot_copies);
   unsigned int* chunk = fdw + NP;
   unsigned int* hot_i = chunk + NP;
   unsigned int* misc = hot_i + hot_slots;
   const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const uint32_t first_limit = ring_recs < kP2ChunkRecs ? ring_recs : kP2ChunkRecs;
+  const uint32_t first_limit = ring_dw / RW < kP2ChunkRecs ? ring_dw / RW : kP2ChunkRecs;
   for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) { fl[i] = (unsigned long long)first_limit << 32; fdw[i] = 0; chunk[i] = kNoChunk; }
   for (uint32_t i = threadIdx.x; i < hot_slots; i += blockDim.x) { hot_k[i] = sp.hot_tbl_keys[i]; hot_i[i] = sp.hot_tbl_idx[i]; }
   for (uint32_t i = threadIdx.x; i < pp.n_hot * sh.n_aggs * pp.hot_copies; i += blockDim.x) hot_acc[i] = agg_identity_dev(sh.aggs[(i / pp.hot_copies) % sh.n_aggs].kind);
   if (threadIdx.x < 4) misc[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t chunk0 = blockIdx.x * pp.chunks_per_wg;     // this workgroup's private chunk region
-  // flush phase: thread t < P owns partition t (P <= the workgroup size); every thread then copies lines
-  const bool owner = threadIdx.x < NP;
-  const uint32_t own_p = threadIdx.x;
+  // partitions a lane owns in the flush phase: wave w, lane l < lanes_per_wave owns partition w * lanes_per_wave + l
+  const uint32_t lanes_per_wave = NP >= (uint32_t)nwaves ? NP / (uint32_t)nwaves : 1u;
+  const bool owner = NP >= (uint32_t)nwaves ? ((uint32_t)lane < lanes_per_wave) : ((uint32_t)wave < NP && lane == 0);
+  const uint32_t own_p = NP >= (uint32_t)nwaves ? (uint32_t)wave * lanes_per_wave + (uint32_t)lane : (uint32_t)wave;
+
   const int64_t rows_per_round = (int64_t)blockDim.x * kRows;
   const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
   auto row0_of = [&](int64_t rd) { return (rd * nwaves + wave) * (int64_t)kTileRows + (int64_t)lane * kRows; };
@@ -189,54 +187,69 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
     if (rd < nrounds && round_full(rd)) { run_loads_full<P>(args, row0_of(rd), rf); return true; }
     return false;
   };
-  // Flush, part 1 (owners): which lines of the partition's ring are complete?  They are queued in `flist` (one LDS atomic per
-  // owner with work), chunks are opened / closed, the partition's state advances.  `final_pass` also writes the partial tail
-  // and records the fill of the last chunk.  Part 2 (flush_copy, after a barrier): ALL threads write the queued lines, 8 lanes
-  // x 16 B per line -- a handful of instructions per thread instead of a per-wave owner loop.
-  auto flush_queue = [&](bool final_pass) __attribute__((always_inline)) {
-    if (!owner) return;
-    const unsigned long long f = fl[own_p];
-    const uint32_t lim = (uint32_t)(f >> 32);
-    uint32_t fill = (uint32_t)f < lim ? (uint32_t)f : lim;          // appends past the limit failed: they stay pending and come back
-    uint32_t f_dw = fdw[own_p], ch = chunk[own_p];
-    const uint32_t avail = fill * RW;
-    const uint32_t target = fill >= kP2ChunkRecs ? chunk_dw : (avail & ~31u);
-    uint32_t nl = (target - f_dw) >> 5;
-    if ((nl || (final_pass && avail > f_dw)) && ch == kNoChunk) {
-      const uint32_t local = atomicAdd(&misc[0], 1u);
-      if (local >= pp.chunks_per_wg) { sp.flags[0] = 1u; nl = 0; fill = 0; }
-      else { ch = chunk0 + local; sp.chunk_part[ch] = own_p; }
-    }
-    if (nl) {
-      const uint32_t at = atomicAdd(&misc[3], nl);
-      const uint32_t line0 = f_dw >> 5;
-      for (uint32_t j = 0; j < nl; j++) {
-        const unsigned long long dst_line = (unsigned long long)ch * (chunk_dw / 32) + line0 + j;
-        flist[at + j] = (dst_line << 16) | (own_p * ring_lines + (line0 + j) % ring_lines);
+  // writes every complete line of the rings this lane owns to HBM and opens / closes chunks; `final_pass` also writes the
+  // partial tail and records the fill of the last chunk
+  auto flush_phase = [&](bool final_pass) __attribute__((always_inline)) {
+    uint32_t fill = 0, lim = 0, f_dw = 0, ch = kNoChunk, nl = 0;
+    if (owner) {
+      const unsigned long long f = fl[own_p];
+      lim = (uint32_t)(f >> 32);
+      fill = (uint32_t)f < lim ? (uint32_t)f : lim;          // appends past the limit failed: they stay pending and come back
+      f_dw = fdw[own_p]; ch = chunk[own_p];
+      const uint32_t avail = fill * RW;
+      const uint32_t target = fill >= kP2ChunkRecs ? chunk_dw : (avail & ~31u);
+      nl = (target - f_dw) >> 5;
+      if ((nl || (final_pass && avail > f_dw)) && ch == kNoChunk) {
+        const uint32_t local = atomicAdd(&misc[0], 1u);
+        if (local >= pp.chunks_per_wg) { sp.flags[0] = 1u; nl = 0; fill = 0; }
+        else { ch = chunk0 + local; sp.chunk_part[ch] = own_p; }
       }
+    }
+    uint32_t done = 0;
+    for (;;) {
+      const uint64_t m = ballot(done < nl);
+      if (!m) break;
+      const int rank = prefix_rank(m);
+      const int g = lane >> 3, sub = lane & 7;
+      int src_lane = -1;
+      {
+        uint64_t mm = m;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          if (mm) { const int o = (int)__builtin_ctzll(mm); mm &= mm - 1; if (g == i) src_lane = o; }
+        }
+      }
+      const uint32_t my_src = own_p * ring_dw + ((((f_dw >> 5) + done) & (pp.ring_lines - 1u)) << 5);
+      const uint64_t my_dst = (uint64_t)ch * chunk_dw + f_dw + done * 32u;
+      const int from = src_lane < 0 ? 0 : src_lane;
+      const uint32_t src = (uint32_t)__shfl((int)my_src, from, 64);
+      const uint64_t dst = shfl_u64(my_dst, from);
+      if (src_lane >= 0) {
+        const uint4 v = *reinterpret_cast<const uint4*>(ring + src + sub * 4);
+        *reinterpret_cast<uint4*>(sp.recs + dst + sub * 4) = v;
+      }
+      if (done < nl && rank < 8) done++;
+    }
+    if (owner) {
       f_dw += nl * 32u;
-    }
-    if (final_pass && ch != kNoChunk) {
-      for (uint32_t w = f_dw; w < avail; w++) sp.recs[(uint64_t)ch * chunk_dw + w] = ring[own_p * ring_dw + (w % ring_dw)];
-      sp.chunk_fill[ch] = fill;
-    } else if (fill >= kP2ChunkRecs && f_dw == chunk_dw) {       // chunk complete: the next flush opens a new one
-      sp.chunk_fill[ch] = kP2ChunkRecs;
-      ch = kNoChunk; f_dw = 0; fill = 0;
-    }
-    uint32_t nlim = f_dw / RW + ring_recs;                         // record i may be written once record i - ring_recs is flushed
-    if (nlim > kP2ChunkRecs) nlim = kP2ChunkRecs;
-    fl[own_p] = ((unsigned long long)nlim << 32) | fill;
-    fdw[own_p] = f_dw; chunk[own_p] = ch;
-  };
-  auto flush_copy = [&]() __attribute__((always_inline)) {
-    const uint32_t n_lines = misc[3];
-    const uint32_t sub = threadIdx.x & 7u;
-    for (uint32_t i = threadIdx.x >> 3; i < n_lines; i += blockDim.x >> 3) {
-      const unsigned long long e = flist[i];
-      const uint4 v = *reinterpret_cast<const uint4*>(ring + ((uint32_t)(e & 0xffffu) << 5) + sub * 4);
-      *reinterpret_cast<uint4*>(sp.recs + ((e >> 16) << 5) + sub * 4) = v;
+      if (final_pass && ch != kNoChunk) {
+        const uint32_t avail = fill * RW;
+        for (uint32_t w = f_dw; w < avail; w++) sp.recs[(uint64_t)ch * chunk_dw + w] = ring[own_p * ring_dw + (w & ring_mask)];
+        sp.chunk_fill[ch] = fill;
+      } else if (fill >= kP2ChunkRecs && f_dw == chunk_dw) {       // chunk complete: the next flush opens a new one
+        sp.chunk_fill[ch] = kP2ChunkRecs;
+        ch = kNoChunk; f_dw = 0; fill = 0;
+      }
+      uint32_t nlim = (f_dw + ring_dw) / RW;
+      if (nlim > kP2ChunkRecs) nlim = kP2ChunkRecs;
+      fl[own_p] = ((unsigned long long)nlim << 32) | fill;
+      fdw[own_p] = f_dw; chunk[own_p] = ch;
     }
   };
+
+  // Round k of this workgroup lives in register file k % DEPTH.  Per round: its rows are evaluated (loads issued DEPTH rounds
+  // ago) and copied into rec[]; the register file is then free, so the loads of round k + DEPTH are issued at once and stay
+  // in flight while round k is appended and flushed (barriers do not drain vmcnt).
   // appends this lane's pending rows; true = some are still pending (their partition's ring / chunk was full)
   auto append_pending = [&]() __attribute__((always_inline)) -> bool {
     bool mine = false;
@@ -246,20 +259,21 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
       const unsigned long long old = atomicAdd(&fl[part[r]], 1ull);
       const uint32_t pos = (uint32_t)old, lim = (uint32_t)(old >> 32);
       if (pos < lim) {
-        unsigned int* dst = ring + (size_t)part[r] * ring_dw + (pos & (ring_recs - 1u)) * RW;      // a record never straddles the wrap-around
+        unsigned int* base = ring + (size_t)part[r] * ring_dw;
+        const uint32_t d0 = pos * RW;
 #pragma unroll
-        for (uint32_t w = 0; w < RW; w++) dst[w] = rec[r][w];
+        for (uint32_t w = 0; w < RW; w++) base[(d0 + w) & ring_mask] = rec[r][w];
         pending[r] = false;
       } else mine = true;
     }
     return mine;
   };
-  // Order of a round (three barriers):
-  //   append(rd) | B | owners queue the complete lines; everybody evaluates round rd+1 from its loads and issues the loads of
-  //   round rd+2 | B | all threads write the queued lines | B
-  // The line stores come last: the vector-memory counter of gfx9 counts loads AND stores, so the wait for round rd+1's loads
-  // sees only stores that are a whole round old.  Rows that did not fit (rare: the rings are sized for the arrival rate) take
-  // the slow path first: queue, copy, append again.
+  // Order of a round (the vector-memory counter of gfx9 counts loads AND stores, and the number of line stores of a flush is
+  // not a compile-time constant, so a wait for loaded data is a wait for every store issued before it):
+  //   append(rd) | barrier | evaluate round rd+1 from its loads (the stores still in flight are a whole round old by now) |
+  //   issue the loads of round rd+2 | flush(rd): line stores | barrier
+  // -- the fresh stores of a flush are never waited for before the next round's rows are needed.  Rows that did not fit
+  // (rare: the rings are sized for the arrival rate) take the slow path first: flush, barrier, append again.
   const int64_t stride = (int64_t)gridDim.x;
   const int64_t rd_first = (int64_t)blockIdx.x;
   bool pre = false;
@@ -274,7 +288,6 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
     const uint32_t par = sync_points & 1u;
     sync_points++;
     if (mine) misc[1 + par] = 1u;
-    if (threadIdx.x == 0) misc[3] = 0u;        // the flush list is empty again: the previous copy finished a barrier ago
     __syncthreads();
     const bool any = misc[1 + par] != 0;
     if (threadIdx.x == 0) misc[2 - par] = 0u;
@@ -283,9 +296,7 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   for (int64_t rd = rd_first; rd < nrounds; rd += stride) {
     bool any = any_pending(append_pending());
     while (any) {
-      flush_queue(false);
-      __syncthreads();
-      flush_copy();
+      flush_phase(false);
       __syncthreads();
       any = any_pending(append_pending());
     }
@@ -294,16 +305,10 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
       finish_round(rd_next, pre, rfA);
       pre = issue_loads(rd_next + stride, rfA);
     }
-    flush_queue(false);
-    __syncthreads();
-    flush_copy();
+    flush_phase(false);
     __syncthreads();
   }
-  if (threadIdx.x == 0) misc[3] = 0u;
-  __syncthreads();
-  flush_queue(true);
-  __syncthreads();
-  flush_copy();
+  flush_phase(true);
   if (MODE == (int)kP2Hash && sp.key_minmax) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {

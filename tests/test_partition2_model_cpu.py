@@ -11,24 +11,14 @@ CHUNK_RECS = 256
 NO_CHUNK = 0xFFFFFFFF
 
 
-def ring_recs_for(rec_words):
-    """fused.hpp p2_ring_recs: a power-of-two number of record slots whose dwords are a whole number (>= 2) of 128-B lines"""
-    r = 16
-    while (r * rec_words) % 32 != 0 or (r * rec_words) // 32 < 2:
-        r *= 2
-    return r
-
-
 class Model:
-    def __init__(self, n_parts, rec_words, chunks_per_wg):
-        self.NP, self.RW = n_parts, rec_words
-        self.ring_recs = ring_recs_for(rec_words)
-        self.ring_dw = self.ring_recs * rec_words
-        self.ring_lines = self.ring_dw // 32
+    def __init__(self, n_parts, rec_words, ring_lines, chunks_per_wg):
+        self.NP, self.RW, self.ring_lines = n_parts, rec_words, ring_lines
+        self.ring_dw = ring_lines * 32
         self.chunk_dw = CHUNK_RECS * rec_words
         self.ring = np.full((n_parts, self.ring_dw), -1, np.int64)
         self.ring_dirty = np.zeros((n_parts, self.ring_dw), bool)          # written and not yet flushed
-        first_limit = min(self.ring_recs, CHUNK_RECS)
+        first_limit = min(self.ring_dw // rec_words, CHUNK_RECS)
         self.fill = np.zeros(n_parts, np.int64); self.limit = np.full(n_parts, first_limit, np.int64)
         self.fdw = np.zeros(n_parts, np.int64); self.chunk = np.full(n_parts, NO_CHUNK, np.int64)
         self.next_chunk = 0
@@ -42,9 +32,9 @@ class Model:
         pos = self.fill[p]; self.fill[p] += 1
         if pos >= self.limit[p]:
             return False
-        d0 = (pos & (self.ring_recs - 1)) * self.RW                     # a record never straddles the wrap-around
+        d0 = pos * self.RW
         for w in range(self.RW):
-            i = d0 + w
+            i = (d0 + w) & (self.ring_dw - 1)
             assert not self.ring_dirty[p, i], "ring position overwritten before it was flushed"
             self.ring[p, i] = rec[w]; self.ring_dirty[p, i] = True
         return True
@@ -63,7 +53,7 @@ class Model:
                 ch = self.next_chunk; self.next_chunk += 1
                 self.chunk_part[ch] = p
             for done in range(nl):
-                src = (((f_dw >> 5) + done) % self.ring_lines) << 5
+                src = (((f_dw >> 5) + done) & (self.ring_lines - 1)) << 5
                 dst = f_dw + done * 32
                 assert dst % 32 == 0 and dst + 32 <= self.chunk_dw
                 assert self.ring_dirty[p, src:src + 32].all(), "flushing a line that is not completely written"
@@ -73,27 +63,25 @@ class Model:
             f_dw += nl * 32
             if final and ch != NO_CHUNK:
                 for w in range(f_dw, avail):
-                    i = w % self.ring_dw
+                    i = w & (self.ring_dw - 1)
                     self.recs[ch, w] = self.ring[p, i]; self.ring_dirty[p, i] = False
                 self.chunk_fill[ch] = fill
             elif fill >= CHUNK_RECS and f_dw == self.chunk_dw:
                 self.chunk_fill[ch] = CHUNK_RECS
                 ch, f_dw, fill = NO_CHUNK, 0, 0
-            self.limit[p] = min(f_dw // self.RW + self.ring_recs, CHUNK_RECS)
+            self.limit[p] = min((f_dw + self.ring_dw) // self.RW, CHUNK_RECS)
             self.fill[p] = fill; self.fdw[p] = f_dw; self.chunk[p] = ch
 
 
-@pytest.mark.parametrize("rec_words,n_parts,skew", [(4, 64, 0.0), (3, 64, 0.0), (3, 32, 0.0), (2, 16, 0.0), (5, 8, 0.0), (13, 8, 0.0), (6, 16, 0.0), (8, 16, 0.2),
-                                                    (4, 64, 0.7), (3, 32, 0.95), (7, 4, 1.0), (1, 128, 0.3)])
-def test_every_record_lands_exactly_once(rec_words, n_parts, skew):
-    rng = np.random.default_rng(rec_words * 100 + n_parts)
+@pytest.mark.parametrize("rec_words,ring_lines,n_parts,skew", [(4, 2, 64, 0.0), (3, 2, 64, 0.0), (3, 4, 32, 0.0), (2, 2, 16, 0.0), (5, 2, 8, 0.0), (13, 2, 8, 0.0),
+                                                              (4, 2, 64, 0.7), (3, 4, 32, 0.95), (7, 8, 4, 1.0), (1, 2, 128, 0.3)])
+def test_every_record_lands_exactly_once(rec_words, ring_lines, n_parts, skew):
+    rng = np.random.default_rng(rec_words * 100 + ring_lines * 10 + n_parts)
     rows_per_round, rounds = 512, 40
     n = rows_per_round * rounds
     parts = rng.integers(0, n_parts, n)
     parts[rng.random(n) < skew] = 3 % n_parts                                # a hot partition
-    m = Model(n_parts, rec_words, chunks_per_wg=n // CHUNK_RECS + n_parts + 2)
-    ring_lines = m.ring_lines
-    assert m.ring_recs & (m.ring_recs - 1) == 0 and m.ring_dw % 32 == 0 and ring_lines >= 2
+    m = Model(n_parts, rec_words, ring_lines, chunks_per_wg=n // CHUNK_RECS + n_parts + 2)
     iters = 0
     for rd in range(rounds):
         pending = list(range(rd * rows_per_round, (rd + 1) * rows_per_round))
@@ -118,5 +106,5 @@ def test_every_record_lands_exactly_once(rec_words, n_parts, skew):
     assert seen.all()
     assert (m.chunk_part[m.next_chunk:] == NO_CHUNK).all()
     # rings sized for the arrival rate rarely retry; a hot partition does (that is what the hot-key path is for)
-    if skew == 0.0 and rows_per_round / n_parts <= (m.ring_recs - 32 / rec_words) * 0.55:
+    if skew == 0.0 and rows_per_round / n_parts <= (ring_lines * 32 / rec_words - 32 / rec_words) * 0.55:
         assert iters <= rounds * 1.5, iters
