@@ -6,10 +6,12 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#ifndef PLX_HD
+#if defined(__HIPCC__) || defined(__HIP__)
 #define PLX_HD __host__ __device__
 #else
 #define PLX_HD
+#endif
 #endif
 
 namespace plx {

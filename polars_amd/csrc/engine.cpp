@@ -748,6 +748,9 @@ static int64_t run_wide_agg(const Shape& sh, const Args& args, int log2_cap, boo
 // clustered data) aggregated into one HBM hash table.  -> number of distinct keys in the sample (-1: table overflow) and the
 // heavy hitters (keys holding >= 1/1024 of the sampled rows), which the partitioned path pre-aggregates instead of scattering.
 constexpr int kSampleBlocks = 8;
+// rows the partitioned group-by samples per query (distinct-count estimate + heavy hitters): 2^20 strided rows cost ~0.15 ms at
+// 1e9 rows; a key is "hot" from 1/1024 of the sample up, i.e. 1024 occurrences
+constexpr int64_t kPartSampleRows = (int64_t)1 << 20;
 static Args offset_args(const Shape& sh, const Args& a, int64_t row0, int64_t rows) {
   Args o = a;
   for (int i = 0; i < sh.n_inputs; i++) {
@@ -758,7 +761,7 @@ static Args offset_args(const Shape& sh, const Args& a, int64_t row0, int64_t ro
   return o;
 }
 static int64_t sample_keys(const Shape& sh, const Args& args, int static_id, int len_idx, int64_t S, std::vector<uint64_t>* hot) {
-  const int log2_cap = 23;
+  const int log2_cap = ceil_log2_u64((uint64_t)S) + 1;
   const uint64_t cap = 1ull << log2_cap;
   const int64_t slots = (int64_t)cap + 2;
   Buf keys = dev_alloc(sizeof(uint64_t) * (size_t)slots), acc = dev_alloc(sizeof(uint64_t) * (size_t)slots * sh.n_aggs), ovf = dev_alloc_zero(8);
@@ -777,6 +780,7 @@ static int64_t sample_keys(const Shape& sh, const Args& args, int static_id, int
   if (hot) k::select_hot_keys(t, sh.n_aggs, len_idx, (uint64_t)std::max<int64_t>(64, (per * kSampleBlocks) / 1024), hot);
   return k::table_compact(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, nullptr, nullptr, nullptr);
 }
+static bool probe_late_loads() { static const bool v = [] { const char* e = getenv("PLX_PROBE_LATE"); return !(e && e[0] == '0'); }(); return v; }
 static int part_version() { static const int v = [] { const char* e = getenv("PLX_PART_V"); return (e && e[0] == '1') ? 1 : 2; }(); return v; }
 static bool hot_keys_enabled() { static const bool v = [] { const char* e = getenv("PLX_PART_HOT"); return !(e && e[0] == '0'); }(); return v; }
 
@@ -806,7 +810,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
       std::vector<uint64_t> hot;
       double est2 = est;
       if (hot_keys_enabled() || kp.total_bits > 25) {
-        const int64_t S = (int64_t)1 << 22;
+        const int64_t S = kPartSampleRows;
         const int64_t d = sample_keys(sh, args, static_id, len_idx, S, hot_keys_enabled() ? &hot : nullptr);
         if (d >= 0) est2 = std::min(est, std::min(estimate_groups((double)d, (double)S), (double)n) * 1.3);
         desc += "sample(distinct=" + std::to_string(d) + ",hot=" + std::to_string(hot.size()) + ")+";
@@ -857,12 +861,14 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     FusedAggResult tmp;
     std::vector<uint64_t> hot;
     const bool may_partition = !kp.wide && !(c.plan.flags & PLX_PLAN_NO_PARTITION) && n >= ((int64_t)1 << 24);
+    const bool strided = may_partition && part_version() == 2;
+    const int64_t Sd = strided ? kPartSampleRows : S;
     int64_t d = kp.wide ? run_wide_agg(sh, sa, 23, kp.wide_nullable, tmp, true)
-                        : (may_partition && part_version() == 2 ? sample_keys(sh, args, static_id, len_idx, S, hot_keys_enabled() ? &hot : nullptr) : run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true));
-    double G = d < 0 ? 1e18 : estimate_groups((double)d, (double)S);
+                        : (strided ? sample_keys(sh, args, static_id, len_idx, Sd, hot_keys_enabled() ? &hot : nullptr) : run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true));
+    double G = d < 0 ? 1e18 : estimate_groups((double)d, (double)Sd);
     G = std::min(G, (double)n);
     log2_cap = std::max(12, ceil_log2_u64((uint64_t)(G * 2.0) + 1));
-    desc += "sample(distinct=" + std::to_string(d) + "/" + std::to_string(S) + ")+";
+    desc += "sample(distinct=" + std::to_string(d) + "/" + std::to_string(Sd) + ")+";
     // many rows, many groups: per-row global atomics are bound by the ~24 G/s device atomic rate; partition the
     // rows and aggregate each partition in LDS instead (kernels_partition.hip)
     if (!kp.wide && !(c.plan.flags & PLX_PLAN_NO_PARTITION) && G >= 4096.0 && n >= ((int64_t)1 << 24)) {
@@ -996,6 +1002,9 @@ static std::string program_fields(const Compiler& c, const Frame& frame) {
   o << "],\"aggs\":[";
   for (int i = 0; i < sh.n_aggs; i++) o << (i ? "," : "") << "[" << (int)sh.aggs[i].kind << "," << (int)sh.aggs[i].src << "]";
   o << "]";
+  // ops the predicate / key depend on (a probe scan runs the others only for the lanes that find a build row)
+  const ProgramSplit split = split_program(sh);
+  o << ",\"early_mask\":" << split.early << ",\"any_late\":" << (split.any_late ? 1 : 0);
   return o.str();
 }
 static std::string finals_outputs_fields(const Plan& plan, const std::vector<int>& agg_nodes, const std::vector<FinalSpec>& specs, const std::vector<int>& out_exprs) {
@@ -1400,6 +1409,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       Buf meta = dev_alloc_zero(32);   // [0] ordinal counter, [2..3] flags, [4..5] pairs appended (u64)
       DirectJoinTable dt; dt.bits = bits->as<unsigned long long>(); dt.rank = rank->as<unsigned int>(); dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>();
       dt.chunk_used = used->as<unsigned int>(); dt.counter = meta->as<unsigned int>(); dt.flags = meta->as<unsigned int>() + 2; dt.acc = nullptr; dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)ord_cap;
+      dt.late_loads = probe_late_loads() ? 1u : 0u;
       k::fused_direct_build(cb.shape, cb.args, dt, find_static_shape(cb.shape));
       // every wave closes its last chunk when it finishes, so chunk_used is final once the build scan is: the rank launch counts
       // the pairs over the whole reserved capacity (the ordinal counter itself is only read back with the rank's sync)

@@ -17,6 +17,14 @@
 #pragma once
 #include <stdint.h>
 
+#ifndef PLX_HD
+#if defined(__HIPCC__) || defined(__HIP__)
+#define PLX_HD __host__ __device__
+#else
+#define PLX_HD
+#endif
+#endif
+
 namespace plx {
 namespace fused {
 
@@ -79,6 +87,52 @@ struct Shape {
   Op ops[kMaxOps];
   Agg aggs[kMaxAggs];
 };
+
+// late materialisation split of a program (fused_device.hpp run_split): bit pc of `early` = op pc feeds the predicate / key
+struct ProgramSplit { uint32_t early; bool any_late; };
+PLX_HD constexpr uint32_t op_src_slots(const Op& op) {
+  if (op.code == OP_LOAD || op.code == OP_CONST || op.code == OP_NOP) return 0;
+  return (1u << op.a) | (1u << op.b);
+}
+PLX_HD constexpr ProgramSplit split_program(const Shape& s) {
+  const uint32_t all = s.n_ops >= 32 ? ~0u : ((1u << s.n_ops) - 1u);
+  uint32_t live_out = 0;
+  if (s.pred != kNone) live_out |= 1u << s.pred;
+  if (s.key != kNone) live_out |= 1u << s.key;
+  for (int i = 0; i < s.n_keys; i++) live_out |= 1u << s.keys[i];
+  uint32_t need = live_out, early = 0;
+  for (int pc = s.n_ops - 1; pc >= 0; pc--) {
+    const Op op = s.ops[pc];
+    if (op.code == OP_NOP || !(need & (1u << op.dst))) continue;
+    early |= 1u << pc;
+    need &= ~(1u << op.dst);
+    need |= op_src_slots(op);
+  }
+  for (int k = 0; k < s.n_aggs; k++) live_out |= 1u << s.aggs[k].src;
+  bool ok = true;
+  // a late op must still read the value its (early) producer wrote: no early op further down may reuse that slot
+  for (int pl = 0; pl < s.n_ops; pl++) {
+    if ((early >> pl) & 1u) continue;
+    const uint32_t srcs = op_src_slots(s.ops[pl]);
+    for (int sl = 0; sl < kSlots; sl++) {
+      if (!((srcs >> sl) & 1u)) continue;
+      int def = -1;
+      for (int pc = 0; pc < pl; pc++) if (s.ops[pc].code != OP_NOP && s.ops[pc].dst == sl) def = pc;
+      if (def < 0 || !((early >> def) & 1u)) continue;
+      for (int pc = def + 1; pc < s.n_ops; pc++) if (((early >> pc) & 1u) && s.ops[pc].dst == sl) ok = false;
+    }
+  }
+  // a value the sink reads whose final producer is early must not be overwritten by a late op
+  for (int sl = 0; sl < kSlots; sl++) {
+    if (!((live_out >> sl) & 1u)) continue;
+    int def = -1;
+    for (int pc = 0; pc < s.n_ops; pc++) if (s.ops[pc].code != OP_NOP && s.ops[pc].dst == sl) def = pc;
+    if (def < 0 || !((early >> def) & 1u)) continue;
+    for (int pc = 0; pc < s.n_ops; pc++) if (!((early >> pc) & 1u) && s.ops[pc].code != OP_NOP && s.ops[pc].dst == sl) ok = false;
+  }
+  if (!ok) early = all;
+  return ProgramSplit{early, (early & all) != all};
+}
 
 struct Input {
   const void* values;
@@ -356,6 +410,7 @@ struct DirectJoinTable {
   long long kmin;
   unsigned long long range;
   unsigned int n_ord;            // capacity of the pair list
+  unsigned int late_loads;       // probe: columns only the aggregates read are loaded under the hit mask (fused_device.hpp split_program)
 };
 
 // Semi-join filter side reduced to a bitmap over its key range (an inner join whose one side has unique keys and contributes

@@ -375,6 +375,21 @@ __device__ __forceinline__ void run_rest_full(const Args& args, int64_t row0, RF
   for (int pc = nl; pc < sh.n_ops; pc++) exec_op<true>(sh.ops[pc], sh, args, pc, row0, rf);
 }
 
+// ---- late materialisation (AOT / JIT programs) -------------------------------------------------------------------------
+// A probe scan needs the predicate and the join key of EVERY row but the aggregate inputs only of the rows that find a build
+// row, and in a selective join those are few and far between.  The ops are split at compile time into the ones the predicate /
+// key depend on (run for the whole tile) and the rest (run under the lanes' hit mask: a lane without a hit issues no load, so
+// 64-byte segments without a hit are never fetched).  Slots are reused by the host compiler, so the split is only taken when
+// running all "early" ops before all "late" ones provably reads and leaves the same values as program order.
+template <class P, bool FULL, bool EARLY, class RF>
+__device__ __forceinline__ void run_split(const Args& args, int64_t row0, RF& rf) {
+  constexpr Shape sh = P::shape();
+  constexpr ProgramSplit sp = split_program(sh);
+#pragma unroll
+  for (int pc = 0; pc < sh.n_ops; pc++)
+    if (((sp.early >> pc) & 1u) == (EARLY ? 1u : 0u)) exec_op<FULL>(sh.ops[pc], sh, args, pc, row0, rf);
+}
+
 // Register file of a kernel running program provider P: VGPRs for AOT programs, the wave's slice of dynamic LDS
 // (at args.rf_lds_offset, after the sink's own LDS) for the generic interpreter.
 template <class P> struct RegFileOf { using type = RegFile; };

@@ -2,6 +2,8 @@
 // ahead of time by kernels_fused.hip for the benchmark shapes and the generic interpreter, and at run time by
 // hiprtc (jit.cpp) for any other program shape).  See kernels_fused.hip for the design notes.
 #pragma once
+#include <type_traits>
+
 #include "fused_device.hpp"
 
 namespace plx {
@@ -392,6 +394,44 @@ struct BitmapBuildSink {
   }
 };
 
+// AOT / JIT probe scan with late materialisation: predicate + key for the tile, bitmap test, then the rest of the program for
+// the lanes that hit (DirectJoinTable::late_loads; 0 runs the whole program up front like every other sink)
+template <class P, bool FULL>
+__device__ __forceinline__ void direct_probe_tile(const Args& args, const DirectJoinTable& p, int64_t base, RegFile& rf) {
+  constexpr Shape sh = P::shape();
+  const int64_t row0 = base + (int64_t)lane_id() * kRows;
+  run_split<P, FULL, true>(args, row0, rf);
+  if (!p.late_loads) run_split<P, FULL, false>(args, row0, rf);
+  bool hit[kRows], any = false;
+  unsigned long long slot[kRows];
+#pragma unroll
+  for (int r = 0; r < kRows; r++) {
+    bool ok = FULL || (row0 + r < args.n_rows);
+    if (sh.pred != kNone) ok = ok && (rf.get(r, sh.pred) & 1) && ((rf.getv(sh.pred) >> r) & 1);
+    ok = ok && ((rf.getv(sh.key) >> r) & 1);
+    const uint64_t idx = rf.get(r, sh.key) - (uint64_t)p.kmin;
+    ok = ok && idx < p.range;
+    slot[r] = 0;
+    if (ok) {
+      const unsigned long long w = p.bits[idx >> 6];
+      ok = (w >> (idx & 63)) & 1ull;
+      if (ok) slot[r] = direct_slot(p, idx, w);
+    }
+    hit[r] = ok; any = any || ok;
+  }
+  if (any) {
+    if (p.late_loads) run_split<P, FULL, false>(args, row0, rf);
+#pragma unroll
+    for (int r = 0; r < kRows; r++)
+      if (hit[r]) atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot[r] * sh.n_aggs);
+  }
+}
+
+template <class P, class Sink>
+__host__ __device__ constexpr bool late_probe() {
+  if constexpr (P::kStatic && std::is_same<Sink, DirectProbeAggSink>::value) return split_program(P::shape()).any_late;
+  else return false;
+}
 template <class P, class Sink>
 __device__ __forceinline__ void fused_scan_body(const Shape dsh, const Args args, const typename Sink::Params sp) {   // by value: kernel arguments passed by
                                                                                                               // reference become addressable stack copies (spills)
@@ -400,7 +440,13 @@ __device__ __forceinline__ void fused_scan_body(const Shape dsh, const Args args
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t ntiles = (args.n_rows + kTileRows - 1) / kTileRows;
-  if constexpr (P::kStatic) {
+  if constexpr (late_probe<P, Sink>()) {
+    for (int64_t t = wave; t < ntiles; t += nwaves) {
+      const int64_t base = t * kTileRows;
+      if (base + kTileRows <= args.n_rows) direct_probe_tile<P, true>(args, sp, base, rf);   // wave-uniform
+      else direct_probe_tile<P, false>(args, sp, base, rf);
+    }
+  } else if constexpr (P::kStatic) {
     constexpr Shape sh = P::shape();
     sink.init(sh, sp);
     for (int64_t t = wave; t < ntiles; t += nwaves) {

@@ -4,8 +4,8 @@
 // BinviewKeys; crates/polars-compute/src/binview_index_map.rs: an index map view -> dense index that compares inline views
 // by value and long strings by bytes; view layout crates/polars-arrow/src/array/binview/view.rs:20-29,55: {len u32, then 12 inline
 // bytes, or prefix u32 + buffer index u32 + offset u32}).  Here the same index map is built ONCE, on the device, when a string
-// column enters: every row's view is looked up / inserted in an open-addressing table in HBM (63-bit tag CAS: EMPTY -> tag|BUSY ->
-// tag, the claimer publishes the view and its code before the tag, as the wide-key aggregation sink does) and the row gets the
+// column enters: every row's view is looked up / inserted in an open-addressing table of 32-byte slots in HBM (63-bit tag CAS:
+// EMPTY -> tag|BUSY -> tag, the claimer publishes the view and its code before the tag, as the wide-key aggregation sink does) and the row gets the
 // u32 code of its string; from then on the column is a dictionary column (codes in [0, n_distinct): dense ids, so group-bys on it
 // plan direct-address tables).  Strings of <= 12 bytes never touch the data buffers: the view IS the string (Arrow pads inline
 // views with zeros), which is the whole of BASELINE config 5's "id%010d" keys.
@@ -27,11 +27,15 @@ using namespace dev;
 namespace {
 constexpr unsigned long long kEmptyTag = ~0ull, kBusy = 1ull << 63;
 
+// one slot = 32 bytes, so a probe touches one 128-B line: tag, the view words the tag stands for, and the code
+struct alignas(32) StrSlot {
+  unsigned long long tag;      // kEmptyTag | tag|BUSY (claimed, being published) | tag (published: the slot never changes again)
+  unsigned long long w0;       // len | prefix << 32 (bytes 0..7 of the view)
+  unsigned long long w1;       // inline: bytes 8..15; long: absolute byte offset of the first-seen string in `data`
+  unsigned int code, pad;
+};
 struct StrTable {
-  unsigned long long* tags;     // [cap]
-  unsigned long long* w0;       // [cap] len | prefix << 32 (bytes 0..7 of the view)
-  unsigned long long* w1;       // [cap] inline: bytes 8..15; long: absolute byte offset of the first-seen string in `data`
-  unsigned int* code;           // [cap]
+  StrSlot* slots;               // [cap]
   unsigned int* counter;        // [0] next code, [1] overflow flag
   uint32_t log2_cap, max_probe;
 };
@@ -70,61 +74,127 @@ __device__ __forceinline__ bool same_bytes(const unsigned char* a, const unsigne
   return i >= len || load_bytes(a + i, len - i) == load_bytes(b + i, len - i);
 }
 
+// Rows per thread in flight: the table probe is a dependent random access (one 128-B line per row out of a table that does not
+// fit L2), so the kernel is bound by how many probes are outstanding, not by bytes.
+constexpr int kStrRows = 4;
+
+struct StrKey { uint64_t w0, w1, tag, slot; const unsigned char* bytes; uint32_t len; bool is_long, valid; };
+
+__device__ __forceinline__ StrKey str_key(const StrEncode& e, const StrTable& t, int64_t row, ulonglong2 v) {
+  StrKey k;
+  k.valid = !e.validity || ((e.validity[row >> 6] >> (row & 63)) & 1);
+  k.len = (uint32_t)v.x;
+  k.is_long = k.len > 12;
+  k.w0 = v.x; k.w1 = v.y; k.bytes = nullptr;
+  uint64_t h;
+  if (k.is_long) {
+    const uint32_t buf = (uint32_t)v.y, off = (uint32_t)(v.y >> 32);
+    const uint64_t abs_off = e.buf_base[buf] + off;
+    k.bytes = e.data + abs_off;
+    k.w1 = abs_off;
+    h = k.valid ? hash_long(k.bytes, k.len) : 0;
+  } else h = mix(mix(0x9e3779b97f4a7c15ull, k.w0), k.w1);
+  h *= 0x55fbfd6bfc5458e9ull;
+  k.tag = h & ~kBusy;
+  if (k.tag == (kEmptyTag & ~kBusy)) k.tag ^= 1;
+  k.slot = h >> (64 - t.log2_cap);
+  return k;
+}
+
+__device__ __forceinline__ bool same_string(const StrEncode& e, const StrKey& k, unsigned long long s0, unsigned long long s1) {
+  if (s0 != k.w0) return false;
+  return k.is_long ? (s1 == k.w1 || same_bytes(e.data + s1, k.bytes, k.len)) : (s1 == k.w1);
+}
+
+// Two ways to read a slot.  The PLAIN read goes through this XCD's L2 and may be stale, but a published slot never changes and
+// its tag is written after (and drained behind) its other words, so a plain read that shows a published tag shows that slot's
+// final contents: it can answer "this is my string" and "this is some other string, go on".  Only a read that shows EMPTY or
+// BUSY has to be repeated coherently (device scope), and that is where claiming happens.  Once the dictionary is warm (n_distinct
+// << n, the case worth encoding) almost every row ends on plain reads.
 __global__ __launch_bounds__(kBlock) void strview_encode_kernel(StrEncode e, StrTable t) {
-  const uint64_t cap = 1ull << t.log2_cap;
-  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < e.n; row += (int64_t)gridDim.x * blockDim.x) {
-    const bool valid = !e.validity || ((e.validity[row >> 6] >> (row & 63)) & 1);
-    const ulonglong2 v = reinterpret_cast<const ulonglong2*>(e.views)[row];
-    const uint32_t len = (uint32_t)v.x;
-    const bool is_long = len > 12;
-    uint64_t w0 = v.x, w1 = v.y, h;
-    const unsigned char* bytes = nullptr;
-    if (is_long) {
-      const uint32_t buf = (uint32_t)v.y, off = (uint32_t)(v.y >> 32);
-      const uint64_t abs_off = e.buf_base[buf] + off;
-      bytes = e.data + abs_off;
-      w1 = abs_off;
-      h = valid ? hash_long(bytes, len) : 0;
-    } else h = mix(mix(0x9e3779b97f4a7c15ull, w0), w1);
-    h *= 0x55fbfd6bfc5458e9ull;
-    uint64_t tag = h & ~kBusy;
-    if (tag == (kEmptyTag & ~kBusy)) tag ^= 1;
-    uint64_t slot = h >> (64 - t.log2_cap);
-    int64_t code = valid ? -1 : 0;
-    bool failed = false;
-    for (uint32_t probe = 0; code < 0 && !failed; probe++) {
-      if (probe >= t.max_probe) { failed = true; break; }
-      unsigned long long cur = ld(&t.tags[slot]);
-      bool claimed = false;
-      if (cur == kEmptyTag) {
-        const unsigned long long old = atomicCAS(&t.tags[slot], kEmptyTag, tag | kBusy);
-        if (old == kEmptyTag) claimed = true; else cur = old;
-      }
-      if (claimed) {   // publish: view words + code (write-through) -> drain -> tag
-        const unsigned int c = atomicAdd(t.counter, 1u);
-        st(&t.w0[slot], w0); st(&t.w1[slot], w1); st32(&t.code[slot], c);
-        if (e.dict_views && c < e.max_codes) { e.dict_views[(size_t)c * 2] = w0; e.dict_views[(size_t)c * 2 + 1] = w1; }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st(&t.tags[slot], tag);
-        code = (int64_t)c;
-      }
-      // every lane of the wave is past its publish before any lane starts to wait (a lane must never wait for a slot that a
-      // lane of its own wave has claimed but not yet published)
-      __builtin_amdgcn_wave_barrier();
-      if (!claimed && (cur & ~kBusy) == tag) {
-        while (cur & kBusy) { __builtin_amdgcn_s_sleep(1); cur = ld(&t.tags[slot]); }
-        asm volatile("" ::: "memory");
-        bool same = ld(&t.w0[slot]) == w0;
-        if (same) {
-          const unsigned long long s1 = ld(&t.w1[slot]);
-          same = is_long ? (s1 == w1 || same_bytes(e.data + s1, bytes, len)) : (s1 == w1);
-        }
-        if (same) code = (int64_t)ld32(&t.code[slot]);
-      }
-      slot = (slot + 1) & (cap - 1);
+  const uint64_t mask = (1ull << t.log2_cap) - 1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; base < e.n; base += stride * kStrRows) {
+    StrKey key[kStrRows];
+    int64_t code[kStrRows];
+    uint32_t probes[kStrRows];
+    ulonglong2 a[kStrRows], b[kStrRows];
+#pragma unroll
+    for (int r = 0; r < kStrRows; r++) {
+      const int64_t row = base + (int64_t)r * stride;
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      ulonglong2 v = make_ulonglong2(0, 0);
+      if (row < e.n) { const u64x2 t2 = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(e.views) + row); v.x = t2.x; v.y = t2.y; }
+      key[r] = str_key(e, t, row < e.n ? row : 0, v);
+      if (row >= e.n) key[r].valid = false;
+      code[r] = key[r].valid ? -1 : 0;
+      probes[r] = 0;
     }
-    if (failed) { atomicExch(t.counter + 1, 1u); code = 0; }
-    if (e.out_codes) e.out_codes[row] = (unsigned int)code;
+    // plain probes, kStrRows independent lines in flight
+    bool any = true;
+    while (any) {
+#pragma unroll
+      for (int r = 0; r < kStrRows; r++) {
+        const ulonglong2* s = reinterpret_cast<const ulonglong2*>(t.slots + key[r].slot);
+        a[r] = s[0]; b[r] = s[1];
+      }
+      any = false;
+#pragma unroll
+      for (int r = 0; r < kStrRows; r++) {
+        if (code[r] != -1) continue;
+        const unsigned long long tg = a[r].x;
+        if (tg == kEmptyTag || (tg & kBusy)) { code[r] = -2; continue; }     // needs the coherent path, at this slot
+        if (tg == key[r].tag && same_string(e, key[r], a[r].y, b[r].x)) { code[r] = (int64_t)(unsigned int)b[r].y; continue; }
+        key[r].slot = (key[r].slot + 1) & mask;
+        if (++probes[r] >= t.max_probe) { code[r] = -3; continue; }
+        any = true;
+      }
+    }
+    // coherent path: claim / wait / compare
+#pragma unroll
+    for (int r = 0; r < kStrRows; r++) {
+      const StrKey k = key[r];
+      uint64_t slot = k.slot;
+      int64_t c = code[r];
+      uint32_t probe = probes[r];
+      bool failed = c == -3;
+      while (c == -2 && !failed) {
+        if (probe++ >= t.max_probe) { failed = true; break; }
+        StrSlot* s = t.slots + slot;
+        unsigned long long cur = ld(&s->tag);
+        bool claimed = false;
+        if (cur == kEmptyTag) {
+          const unsigned long long old = atomicCAS(&s->tag, kEmptyTag, k.tag | kBusy);
+          if (old == kEmptyTag) claimed = true; else cur = old;
+        }
+        if (claimed) {   // publish: view words + code (write-through) -> drain -> tag
+          const unsigned int nc = atomicAdd(t.counter, 1u);
+          st(&s->w0, k.w0); st(&s->w1, k.w1); st32(&s->code, nc);
+          if (e.dict_views && nc < e.max_codes) { e.dict_views[(size_t)nc * 2] = k.w0; e.dict_views[(size_t)nc * 2 + 1] = k.w1; }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          st(&s->tag, k.tag);
+          c = (int64_t)nc;
+        }
+        // every lane of the wave is past its publish before any lane starts to wait (a lane must never wait for a slot that a
+        // lane of its own wave has claimed but not yet published)
+        __builtin_amdgcn_wave_barrier();
+        if (!claimed && (cur & ~kBusy) == k.tag) {
+          while (cur & kBusy) { __builtin_amdgcn_s_sleep(1); cur = ld(&s->tag); }
+          asm volatile("" ::: "memory");
+          if (same_string(e, k, ld(&s->w0), ld(&s->w1))) c = (int64_t)ld32(&s->code);
+        }
+        slot = (slot + 1) & mask;
+      }
+      if (failed) { atomicExch(t.counter + 1, 1u); c = 0; }
+      code[r] = c;
+    }
+    if (e.out_codes) {
+#pragma unroll
+      for (int r = 0; r < kStrRows; r++) {
+        const int64_t row = base + (int64_t)r * stride;
+        if (row < e.n) __builtin_nontemporal_store((unsigned int)code[r], e.out_codes + row);
+      }
+    }
   }
 }
 
@@ -156,15 +226,15 @@ void strview_dict_encode(const uint64_t* views, const uint64_t* validity, const 
   if (n == 0) { *out_dict_views = dev_alloc(16); *n_distinct = 0; return; }
   auto run = [&](int64_t rows, uint32_t log2_cap, uint32_t max_codes, unsigned int* codes, Buf* dict, uint32_t* distinct) -> bool {
     const uint64_t cap = 1ull << log2_cap;
-    Buf tags = dev_alloc(8 * cap), w0 = dev_alloc(8 * cap), w1 = dev_alloc(8 * cap), code = dev_alloc(4 * cap), ctr = dev_alloc_zero(8);
-    PLX_HIP(hipMemsetAsync(tags->ptr, 0xff, 8 * cap, stream()));
+    Buf slots = dev_alloc(sizeof(StrSlot) * cap), ctr = dev_alloc_zero(8);
+    PLX_HIP(hipMemsetAsync(slots->ptr, 0xff, sizeof(StrSlot) * cap, stream()));
     if (dict) *dict = dev_alloc(16 * (size_t)std::max<uint32_t>(max_codes, 1));
-    StrTable t{tags->as<unsigned long long>(), w0->as<unsigned long long>(), w1->as<unsigned long long>(), code->as<unsigned int>(), ctr->as<unsigned int>(), log2_cap,
+    StrTable t{slots->as<StrSlot>(), ctr->as<unsigned int>(), log2_cap,
                (uint32_t)std::min<uint64_t>(cap, 1u << 12)};
     StrEncode e{(const unsigned long long*)views, validity, data, (const unsigned long long*)buf_base, rows, codes, dict ? (*dict)->as<unsigned long long>() : nullptr, max_codes};
     {
       ProfileScope ps("strview_dict_encode", (uint64_t)rows * (16 + (codes ? 4 : 0)), (uint64_t)rows);
-      hipLaunchKernelGGL(strview_encode_kernel, dim3(grid_for(rows, kBlock, 8)), dim3(kBlock), 0, stream(), e, t);
+      hipLaunchKernelGGL(strview_encode_kernel, dim3(grid_for(rows, kBlock * kStrRows, 8)), dim3(kBlock), 0, stream(), e, t);
       PLX_HIP(hipGetLastError());
     }
     uint32_t res[2] = {0, 0};

@@ -52,14 +52,45 @@ def _floor_div_mod(x, y, want_div, signed):
     return np.where(nz, r, U(0)), nz
 
 
-def run_rows(prog, cols, luts=None):
+def split_order(prog):
+    """Op order of the late-materialisation split (fused.hpp split_program / fused_device.hpp run_split): every op the predicate
+    and the key depend on (bit pc of early_mask), then the rest, each group in program order."""
+    m = int(prog.get("early_mask", (1 << len(prog["ops"])) - 1))
+    idx = range(len(prog["ops"]))
+    return [i for i in idx if (m >> i) & 1] + [i for i in idx if not (m >> i) & 1]
+
+
+def live_out_slots(prog):
+    out = {a[1] for a in prog["aggs"]} | set(prog.get("keys", []))
+    for k in ("pred", "key"):
+        if prog[k] != NONE:
+            out.add(prog[k])
+    return out
+
+
+def split_matches(prog, cols, luts=None):
+    """True when running the program in split order leaves the predicate, key and aggregate sources exactly as program order does
+    (what the engine's compile-time check promises whenever it reports any_late)."""
+    a, pa = run_rows(prog, cols, luts)
+    b, pb = run_rows(prog, cols, luts, split=True)
+    if not np.array_equal(pa, pb):
+        return False
+    for s in live_out_slots(prog):
+        (va, ma), (vb, mb) = a[s], b[s]
+        if not np.array_equal(ma, mb) or not np.array_equal(va[ma], vb[mb]):
+            return False
+    return True
+
+
+def run_rows(prog, cols, luts=None, split=False):
     """Executes the register program over all rows.  cols: {name: (values ndarray, valid bool ndarray or None)}.
+    split: run the ops in split_order (the probe kernel's order) instead of program order.
     luts: {index: bool array over the lookup bitmap's key range} for OP_BITLOOKUP (fused_device.hpp: bit (a - imm) of lut c, 0
     outside the range, validity of a).  Returns (slots {slot: (u64 values, bool valid)}, pass mask)."""
     n = len(next(iter(cols.values()))[0]) if cols else 0
     slots = {}
     ones = np.ones(n, dtype=bool)
-    for op in prog["ops"]:
+    for op in ([prog["ops"][i] for i in split_order(prog)] if split else prog["ops"]):
         code, dst, a, b, c, imm = op[0], op[1], op[2], op[3], op[4], U(int(op[5]))
         if code == OP_LOAD:
             inp = prog["inputs"][a]
@@ -286,7 +317,7 @@ def evaluate_join(prog, build_cols, probe_cols, filter_cols=()):
     skeys, srows = keys_b[order], rows_b[order]
     if len(skeys) > 1 and (skeys[1:] == skeys[:-1]).any():
         return None
-    p_slots, p_pass = run_rows(prog["probe"], probe_cols, luts)
+    p_slots, p_pass = run_rows(prog["probe"], probe_cols, luts, split=True)     # the probe kernel's op order
     pk, pkm = p_slots[prog["probe"]["key"]]
     pos = np.searchsorted(skeys, pk)
     pos_c = np.minimum(pos, max(len(skeys) - 1, 0))

@@ -257,6 +257,7 @@ def test_random_expression_trees(seed):
         assert "fusable" in str(e) or "program" in str(e) or "live values" in str(e), str(e)
         return
     got = pe.evaluate(prog, cols)
+    assert pe.split_matches(prog, cols)          # late-materialisation order is safe whenever the engine says so (slots are reused)
     keep = pv & pm
     assert got["n"][0][0] == int(keep.sum())
     fsel = keep & fm
@@ -289,6 +290,11 @@ def test_q3_pipeline_matches_oracle(orc):
     prog = Q.q3(frame_like(lcols, lt).lazy(), frame_like(ocols, lt).lazy()).debug_program()
     assert prog["kind"] == "join_group_by" and prog["build_side"] == "right" and prog["build_key"] == "o_orderkey" and prog["probe_key"] == "l_orderkey"
     assert [g["name"] for g in prog["group_keys"]] == ["l_orderkey", "o_orderdate", "o_shippriority"]
+    # late materialisation: the probe scan loads l_extendedprice / l_discount only for rows that find an order
+    pp = prog["probe"]
+    late = [pp["ops"][i] for i in range(len(pp["ops"])) if not (pp["early_mask"] >> i) & 1]
+    assert pp["any_late"] == 1 and sorted(pp["inputs"][op[2]]["name"] for op in late if op[0] == pe.OP_LOAD) == ["l_discount", "l_extendedprice"]
+    assert pe.split_matches(pp, lcols)
     got = pe.evaluate_join(prog, ocols, lcols)
     want = orc.q3(li, orders, datagen.us(1995, 3, 15))
     order = np.argsort(got["l_orderkey"][0])
