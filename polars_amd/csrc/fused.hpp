@@ -321,6 +321,7 @@ struct PartPlan2 {
   uint32_t log2_hot_slots, hot_copies;
   uint32_t len_idx;            // the aggregate that counts rows (occupancy of a direct-address slot)
   uint32_t rec_words;          // == rec_layout2(shape, mode).rec_words
+  uint32_t ablate;             // measurement only (PLX_PART_ABLATE, results are WRONG when set): 1 = flush without the HBM stores, 2 = append without the ring writes
 };
 
 // ---- batched result finalisation: every output column of a query in ONE launch ---------------
@@ -410,8 +411,10 @@ struct DirectJoinTable {
   long long kmin;
   unsigned long long range;
   unsigned int n_ord;            // capacity of the pair list
-  unsigned int late_loads;       // probe: columns only the aggregates read are loaded under the hit mask (fused_device.hpp split_program)
+  unsigned int opts;             // kDirectLateLoads | kDirectMergeOrs
 };
+constexpr unsigned int kDirectLateLoads = 1u;   // probe: columns only the aggregates read are loaded under the hit mask (split_program)
+constexpr unsigned int kDirectMergeOrs = 2u;    // build: bits of neighbouring lanes that fall into one bitmap word are OR-ed in the wave first
 
 // Semi-join filter side reduced to a bitmap over its key range (an inner join whose one side has unique keys and contributes
 // no column downstream only FILTERS the other side): the scan of the filter side sets bit (key - kmin) of every row that passes

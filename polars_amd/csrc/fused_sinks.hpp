@@ -328,8 +328,12 @@ struct DirectBuildSink {
   }
   template <class S> __device__ __forceinline__ void finish(const S&, const Params& p) { close_chunk(p); }
   template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+    bool part[kRows];
+    unsigned int word[kRows];
+    unsigned long long bit[kRows];
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
+      part[r] = false; word[r] = 0; bit[r] = 0;
       const bool ins = pass[r] && ((rf.getv(sh.key) >> r) & 1);
       const uint64_t m = ballot(ins);
       if (m == 0) continue;
@@ -349,10 +353,28 @@ struct DirectBuildSink {
       const uint64_t idx = key - (uint64_t)p.kmin;       // < range by construction (kmin/kmax cover the whole build column)
       p.ord_key[ord] = key;
       p.ord_row[ord] = (unsigned int)(row0 + r);
-      // fire-and-forget (no-return) atomic: a duplicate build key shows up as popcount(bits) < number of pairs,
-      // which the rank step counts (the caller then falls back)
-      __hip_atomic_fetch_or(&p.bits[idx >> 6], 1ull << (idx & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      part[r] = true; word[r] = (unsigned int)(idx >> 6); bit[r] = 1ull << (idx & 63);     // range <= 2^34: the word index fits 28 bits
     }
+    // fire-and-forget (no-return) atomics: a duplicate build key shows up as popcount(bits) < number of pairs, which the rank step
+    // counts (the caller then falls back).  Build tables are usually scanned in key order, where the 128 rows of a tile land in
+    // a handful of bitmap words: rows of one lane and runs of neighbouring lanes that share a word are OR-ed together first
+    // (segmented scan over the lanes; lanes that share a word without being neighbours just issue separately).
+    static_assert(kRows == 2, "pairwise merge below");
+    if (part[0] && part[1] && word[0] == word[1]) { bit[0] |= bit[1]; part[1] = false; }
+    if (part[1]) __hip_atomic_fetch_or(&p.bits[word[1]], bit[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p.opts & kDirectMergeOrs) {
+      const int lane = lane_id();
+      const unsigned int w = part[0] ? word[0] : 0xffffffffu - (unsigned int)lane;   // a word of its own
+      unsigned long long v = part[0] ? bit[0] : 0ull;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int wo = __shfl_up(w, d, 64);
+        const unsigned long long vo = __shfl_up(v, d, 64);
+        if (lane >= d && wo == w) v |= vo;
+      }
+      const unsigned int wn = __shfl_down(w, 1, 64);
+      if (part[0] && (lane == 63 || wn != w)) __hip_atomic_fetch_or(&p.bits[word[0]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (part[0]) __hip_atomic_fetch_or(&p.bits[word[0]], bit[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 };
 
@@ -395,13 +417,13 @@ struct BitmapBuildSink {
 };
 
 // AOT / JIT probe scan with late materialisation: predicate + key for the tile, bitmap test, then the rest of the program for
-// the lanes that hit (DirectJoinTable::late_loads; 0 runs the whole program up front like every other sink)
+// the lanes that hit (DirectJoinTable::opts & kDirectLateLoads; without it runs the whole program up front like every other sink)
 template <class P, bool FULL>
 __device__ __forceinline__ void direct_probe_tile(const Args& args, const DirectJoinTable& p, int64_t base, RegFile& rf) {
   constexpr Shape sh = P::shape();
   const int64_t row0 = base + (int64_t)lane_id() * kRows;
   run_split<P, FULL, true>(args, row0, rf);
-  if (!p.late_loads) run_split<P, FULL, false>(args, row0, rf);
+  if (!(p.opts & kDirectLateLoads)) run_split<P, FULL, false>(args, row0, rf);
   bool hit[kRows], any = false;
   unsigned long long slot[kRows];
 #pragma unroll
@@ -420,7 +442,7 @@ __device__ __forceinline__ void direct_probe_tile(const Args& args, const Direct
     hit[r] = ok; any = any || ok;
   }
   if (any) {
-    if (p.late_loads) run_split<P, FULL, false>(args, row0, rf);
+    if (p.opts & kDirectLateLoads) run_split<P, FULL, false>(args, row0, rf);
 #pragma unroll
     for (int r = 0; r < kRows; r++)
       if (hit[r]) atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot[r] * sh.n_aggs);

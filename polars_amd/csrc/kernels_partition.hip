@@ -187,6 +187,9 @@ int64_t partitioned_agg(const Shape& sh, const Args& args, const PartitionPlan& 
 static const int kEnvP2Block = env_int("PLX_PART_BLOCK", 256, 1024);
 static const int kEnvP2Ring = env_int("PLX_PART_RING_LINES", 1, 16);
 static const int kEnvP2Direct = env_int("PLX_PART_DIRECT", 0, 1);        // 0: never use the direct-address mode
+static const int kEnvP2DirectLp = env_int("PLX_PART_DIRECT_LOG2_PARTS", 4, 9);   // direct mode: partitions when the id range allows (default 2^9)
+static const int kEnvP2Wgs = env_int("PLX_PART2_WGS_PER_CU", 1, 4);       // scatter workgroups per CU (they must fit the LDS together)
+static const int kEnvP2Ablate = env_int("PLX_PART_ABLATE", 0, 3);
 
 static uint32_t floor_pow2(uint32_t x) { uint32_t p = 1; while (p * 2 <= x) p *= 2; return p; }
 static uint32_t ceil_log2(uint64_t x) { uint32_t b = 0; while ((1ull << b) < x) b++; return b; }
@@ -202,7 +205,7 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
     // direct-address LDS table: slots = low bits of the id; as many partitions as give every CU work, tables as large as fit
     uint32_t max_shift = 0;
     while (((size_t)1 << (max_shift + 1)) * sh.n_aggs * 8 <= 128 * 1024) max_shift++;
-    int shift = packed_bits - 9;                      // 512 partitions when the id range allows
+    int shift = packed_bits - (kEnvP2DirectLp > 0 ? kEnvP2DirectLp : 9);   // 512 partitions when the id range allows
     if (shift > (int)max_shift) shift = (int)max_shift;
     if (shift < 6) shift = 6;
     const int lp = packed_bits - shift;
@@ -248,7 +251,8 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
   pp.block = block;
   const int64_t rows_per_round = (int64_t)block * kRows;
   const int64_t nrounds = (n_rows + rows_per_round - 1) / rows_per_round;
-  pp.scatter_grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(nrounds, (int64_t)device().cu_count));
+  pp.scatter_grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(nrounds, (int64_t)device().cu_count * std::max(1, kEnvP2Wgs)));
+  pp.ablate = kEnvP2Ablate > 0 ? (uint32_t)kEnvP2Ablate : 0u;
   const int64_t rounds_per_wg = (nrounds + pp.scatter_grid - 1) / pp.scatter_grid;
   pp.chunks_per_wg = (uint32_t)(rounds_per_wg * rows_per_round / kP2ChunkRecs + NP + 2);
   *out = pp;
@@ -417,6 +421,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pp,
     }
     PLX_HIP(hipGetLastError());
   }
+  if (pp.ablate) PLX_HIP(hipMemsetAsync(chunk_fill->ptr, 0, sizeof(uint32_t) * (size_t)n_chunks, stream()));   // measurement mode: the records are garbage, aggregate none of them
   // chunk lists
   Buf counts = dev_alloc_zero(sizeof(uint32_t) * (NP + 1)), cursor = dev_alloc_zero(sizeof(uint32_t) * (NP + 1));
   Buf cl_off = dev_alloc(sizeof(uint64_t) * (NP + 2)), cl_ids = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks);

@@ -106,10 +106,10 @@ __device__ __forceinline__ bool same_string(const StrEncode& e, const StrKey& k,
   return k.is_long ? (s1 == k.w1 || same_bytes(e.data + s1, k.bytes, k.len)) : (s1 == k.w1);
 }
 
-// Two ways to read a slot.  The PLAIN read goes through this XCD's L2 and may be stale, but a published slot never changes and
-// its tag is written after (and drained behind) its other words, so a plain read that shows a published tag shows that slot's
-// final contents: it can answer "this is my string" and "this is some other string, go on".  Only a read that shows EMPTY or
-// BUSY has to be repeated coherently (device scope), and that is where claiming happens.  Once the dictionary is warm (n_distinct
+// Two ways to read a slot.  The PLAIN read goes through this CU's L1 and this XCD's L2 and may be stale, but a published slot
+// never changes, so a plain read that shows a published tag of ANOTHER string is final ("go on"), and one that shows this
+// string's tag with matching words and a written code is a hit.  Anything else (EMPTY, BUSY, or halves that disagree) is
+// repeated coherently (device scope), and that is where claiming happens.  Once the dictionary is warm (n_distinct
 // << n, the case worth encoding) almost every row ends on plain reads.
 __global__ __launch_bounds__(kBlock) void strview_encode_kernel(StrEncode e, StrTable t) {
   const uint64_t mask = (1ull << t.log2_cap) - 1;
@@ -144,7 +144,14 @@ __global__ __launch_bounds__(kBlock) void strview_encode_kernel(StrEncode e, Str
         if (code[r] != -1) continue;
         const unsigned long long tg = a[r].x;
         if (tg == kEmptyTag || (tg & kBusy)) { code[r] = -2; continue; }     // needs the coherent path, at this slot
-        if (tg == key[r].tag && same_string(e, key[r], a[r].y, b[r].x)) { code[r] = (int64_t)(unsigned int)b[r].y; continue; }
+        if (tg == key[r].tag) {
+          // the slot's two 16-byte halves are two loads, and under cache thrash they can come from different moments (the half
+          // with w1 / code OLDER than the half that shows the published tag): a hit needs every word to agree and a written
+          // code; a disagreement is not "another string" (63-bit tags do not collide in practice) but a reason to look again
+          const unsigned int c = (unsigned int)b[r].y;
+          if (c != 0xffffffffu && same_string(e, key[r], a[r].y, b[r].x)) code[r] = (int64_t)c; else code[r] = -2;
+          continue;
+        }
         key[r].slot = (key[r].slot + 1) & mask;
         if (++probes[r] >= t.max_probe) { code[r] = -3; continue; }
         any = true;

@@ -226,7 +226,7 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
       const uint64_t dst = shfl_u64(my_dst, from);
       if (src_lane >= 0) {
         const uint4 v = *reinterpret_cast<const uint4*>(ring + src + sub * 4);
-        *reinterpret_cast<uint4*>(sp.recs + dst + sub * 4) = v;
+        if (!(pp.ablate & 1u)) *reinterpret_cast<uint4*>(sp.recs + dst + sub * 4) = v;
       }
       if (done < nl && rank < 8) done++;
     }
@@ -262,7 +262,7 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
         unsigned int* base = ring + (size_t)part[r] * ring_dw;
         const uint32_t d0 = pos * RW;
 #pragma unroll
-        for (uint32_t w = 0; w < RW; w++) base[(d0 + w) & ring_mask] = rec[r][w];
+        for (uint32_t w = 0; w < RW; w++) if (!(pp.ablate & 2u)) base[(d0 + w) & ring_mask] = rec[r][w];
         pending[r] = false;
       } else mine = true;
     }
