@@ -315,6 +315,7 @@ struct PartPlan2 {
   uint32_t key_shift;          // direct mode: partition = id >> key_shift, table slot = id & ((1 << key_shift) - 1)
   uint32_t ring_lines;         // 128-B lines of LDS staging per partition (power of two)
   uint32_t block;              // threads of a scatter workgroup
+  uint32_t tiles;              // tiles each wave loads per round (template parameter of the scatter kernel)
   uint32_t chunks_per_wg;      // chunks in each scatter workgroup's private region
   uint32_t scatter_grid;
   uint32_t n_hot;              // hot keys (0 = none), log2_hot_slots = slots of their LDS lookup table, hot_copies = accumulator copies

@@ -190,9 +190,20 @@ static const int kEnvP2Direct = env_int("PLX_PART_DIRECT", 0, 1);        // 0: n
 static const int kEnvP2DirectLp = env_int("PLX_PART_DIRECT_LOG2_PARTS", 4, 9);   // direct mode: partitions when the id range allows (default 2^9)
 static const int kEnvP2Wgs = env_int("PLX_PART2_WGS_PER_CU", 1, 4);       // scatter workgroups per CU (they must fit the LDS together)
 static const int kEnvP2Ablate = env_int("PLX_PART_ABLATE", 0, 3);
+static const int kEnvP2Tiles = env_int("PLX_PART_TILES", 1, 4);           // tiles per wave and round (AOT shapes: 1 | 2 | 4)
 
 static uint32_t floor_pow2(uint32_t x) { uint32_t p = 1; while (p * 2 <= x) p *= 2; return p; }
 static uint32_t ceil_log2(uint64_t x) { uint32_t b = 0; while ((1ull << b) < x) b++; return b; }
+
+// grid and chunk regions of the scatter pass for `tiles` tiles per wave and round
+static void plan2_geometry(PartPlan2& pp, int64_t n_rows, uint32_t tiles) {
+  pp.tiles = tiles;
+  const int64_t rows_per_round = (int64_t)pp.block * kRows * tiles;
+  const int64_t nrounds = (n_rows + rows_per_round - 1) / rows_per_round;
+  pp.scatter_grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(nrounds, (int64_t)device().cu_count * std::max(1, kEnvP2Wgs)));
+  const int64_t rounds_per_wg = (nrounds + pp.scatter_grid - 1) / pp.scatter_grid;
+  pp.chunks_per_wg = (uint32_t)(rounds_per_wg * rows_per_round / kP2ChunkRecs + (1u << pp.log2_parts) + 2);
+}
 
 bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, PartPlan2* out) {
   PartPlan2 pp{};
@@ -249,12 +260,8 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
   while (block > 256 && (double)block * kRows / NP > lambda_max) block >>= 1;
   if (kEnvP2Block > 0) block = floor_pow2((uint32_t)kEnvP2Block);
   pp.block = block;
-  const int64_t rows_per_round = (int64_t)block * kRows;
-  const int64_t nrounds = (n_rows + rows_per_round - 1) / rows_per_round;
-  pp.scatter_grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(nrounds, (int64_t)device().cu_count * std::max(1, kEnvP2Wgs)));
   pp.ablate = kEnvP2Ablate > 0 ? (uint32_t)kEnvP2Ablate : 0u;
-  const int64_t rounds_per_wg = (nrounds + pp.scatter_grid - 1) / pp.scatter_grid;
-  pp.chunks_per_wg = (uint32_t)(rounds_per_wg * rows_per_round / kP2ChunkRecs + NP + 2);
+  plan2_geometry(pp, n_rows, kEnvP2Tiles > 0 ? (uint32_t)kEnvP2Tiles : (uint32_t)kP2JitTiles);
   *out = pp;
   return true;
 }
@@ -345,25 +352,27 @@ __global__ __launch_bounds__(kBlock) void hot_emit_kernel(const unsigned long lo
 #define PLX_PART2_STATIC_CASES(KERNEL, MODE, ...)                                                                                        \
   case SHAPE_GB_SUM_CNT_I64: hipLaunchKernelGGL((KERNEL<StatProg<SHAPE_GB_SUM_CNT_I64>, MODE>), __VA_ARGS__); break;                      \
   case SHAPE_GB_SUM_MEAN_U32_F64: hipLaunchKernelGGL((KERNEL<StatProg<SHAPE_GB_SUM_MEAN_U32_F64>, MODE>), __VA_ARGS__); break;
-#define PLX_PART2_STATIC_SCATTER_CASES(MODE, DEPTH, ...)                                                                                 \
-  case SHAPE_GB_SUM_CNT_I64: hipLaunchKernelGGL((part2_scatter_kernel<StatProg<SHAPE_GB_SUM_CNT_I64>, MODE, DEPTH>), __VA_ARGS__); break; \
-  case SHAPE_GB_SUM_MEAN_U32_F64: hipLaunchKernelGGL((part2_scatter_kernel<StatProg<SHAPE_GB_SUM_MEAN_U32_F64>, MODE, DEPTH>), __VA_ARGS__); break;
+#define PLX_PART2_STATIC_SCATTER_CASES(MODE, TILES, ...)                                                                                 \
+  case SHAPE_GB_SUM_CNT_I64: hipLaunchKernelGGL((part2_scatter_kernel<StatProg<SHAPE_GB_SUM_CNT_I64>, MODE, TILES>), __VA_ARGS__); break; \
+  case SHAPE_GB_SUM_MEAN_U32_F64: hipLaunchKernelGGL((part2_scatter_kernel<StatProg<SHAPE_GB_SUM_MEAN_U32_F64>, MODE, TILES>), __VA_ARGS__); break;
 #else
 #define PLX_PART2_STATIC_CASES(KERNEL, MODE, ...)
-#define PLX_PART2_STATIC_SCATTER_CASES(MODE, DEPTH, ...)
+#define PLX_PART2_STATIC_SCATTER_CASES(MODE, TILES, ...)
 #endif
-static const int kEnvP2Depth = env_int("PLX_PART_PREFETCH", 1, 2);       // rounds of column loads in flight (AOT shapes; default 2)
 
 // Runs scatter -> chunk sort -> aggregate (+ hot groups).  Outputs (allocated here): dense keys / valid flags / cells.
 // Returns the number of groups, -1 if an LDS table overflowed or no specialised kernel is available (the caller falls back).
-int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pp, int static_id, const std::vector<uint64_t>& hot_keys, Buf* out_keys, Buf* out_kvalid,
+int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& plan, int static_id, const std::vector<uint64_t>& hot_keys, Buf* out_keys, Buf* out_kvalid,
                          Buf* out_acc, std::string* desc, int64_t* key_range_out) {
+  PartPlan2 pp = plan;
   const uint32_t NP = 1u << pp.log2_parts;
   const bool direct = pp.mode == kP2Direct;
   const bool is_static = static_id == SHAPE_GB_SUM_CNT_I64 || static_id == SHAPE_GB_SUM_MEAN_U32_F64;   // the cases of PLX_PART2_STATIC_CASES
   const jit::Sink jk_scatter = direct ? jit::PART2_SCATTER_DIRECT : jit::PART2_SCATTER_HASH, jk_agg = direct ? jit::PART2_AGG_DIRECT : jit::PART2_AGG_HASH;
   const bool use_jit = !is_static && jit::ensure(sh, jk_scatter, args.n_rows) && jit::ensure(sh, jk_agg, args.n_rows);
   if (!is_static && !use_jit) return -1;
+  if (pp.tiles == 3) plan2_geometry(pp, args.n_rows, 4);                                        // only 1 | 2 | 4 are instantiated
+  if (use_jit && pp.tiles != (uint32_t)kP2JitTiles) plan2_geometry(pp, args.n_rows, (uint32_t)kP2JitTiles);   // run-time specialised kernels have one geometry
   PLX_REQUIRE(pp.n_hot == hot_keys.size(), PLX_ERR_INVALID, "partitioned_agg2: plan / hot key list mismatch");
   const uint32_t chunk_dw = kP2ChunkRecs * pp.rec_words;
   const int64_t n_chunks = (int64_t)pp.scatter_grid * pp.chunks_per_wg;
@@ -412,12 +421,12 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pp,
       Shape shc = sh; Args ac = args; PartPlan2 ppc = pp; ScatterParams2 spc = sp;
       void* ka[] = {&shc, &ac, &ppc, &spc};
       PLX_REQUIRE(jit::launch_raw(sh, jk_scatter, ka, (int)pp.scatter_grid, (int)pp.block, slds), PLX_ERR_HIP, "jit launch failed (part2_scatter)");
-    } else if (kEnvP2Depth == 1) {
-      if (direct) { switch (static_id) { PLX_PART2_STATIC_SCATTER_CASES((int)kP2Direct, 1, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; } }
-      else { switch (static_id) { PLX_PART2_STATIC_SCATTER_CASES((int)kP2Hash, 1, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; } }
     } else {
-      if (direct) { switch (static_id) { PLX_PART2_STATIC_SCATTER_CASES((int)kP2Direct, 2, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; } }
-      else { switch (static_id) { PLX_PART2_STATIC_SCATTER_CASES((int)kP2Hash, 2, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; } }
+#define PLX_P2_SCATTER(MODE, T) \
+  switch (static_id) { PLX_PART2_STATIC_SCATTER_CASES((int)MODE, T, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; }
+      if (direct) { if (pp.tiles == 1) { PLX_P2_SCATTER(kP2Direct, 1) } else if (pp.tiles == 2) { PLX_P2_SCATTER(kP2Direct, 2) } else { PLX_P2_SCATTER(kP2Direct, 4) } }
+      else { if (pp.tiles == 1) { PLX_P2_SCATTER(kP2Hash, 1) } else if (pp.tiles == 2) { PLX_P2_SCATTER(kP2Hash, 2) } else { PLX_P2_SCATTER(kP2Hash, 4) } }
+#undef PLX_P2_SCATTER
     }
     PLX_HIP(hipGetLastError());
   }

@@ -14,6 +14,8 @@
 //            chunk list, double-buffered, into an LDS open-addressing table (hash mode) or an LDS direct-address table
 //            (direct mode: dense packed ids, no key compare at all) and writes its groups straight to the dense output.
 #pragma once
+#include <type_traits>
+
 #include "fused_device.hpp"
 
 namespace plx {
@@ -92,9 +94,19 @@ __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, c
 }
 
 // ---- the scatter kernel ------------------------------------------------------------------------------------------------
-// DEPTH is kept for launch-table compatibility: one round of column loads is in flight while a round is appended and flushed
-// (two rounds measured no faster: the scatter pass is not bound by load latency)
-template <class P, int MODE, int DEPTH = 1>
+// compile-time loop over the tiles of a round (their register files and record stashes must be indexed by constants)
+template <int N, class F>
+__device__ __forceinline__ void p2_static_for(F&& f) {
+  if constexpr (N > 0) { p2_static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+constexpr int kP2JitTiles = 2;       // tiles per wave and round of the run-time specialised kernels (the host plans with the same value)
+
+// TILES: tiles (kTileRows rows) each wave loads per round.  The pass is bound by load latency, not by bytes: the line stores of a
+// flush and the column loads share the vector-memory counter, the number of stores is not a compile-time constant, so every wait
+// for loaded data is a wait for everything (vmcnt(0)) and only ONE batch of loads can be in flight per wave.  The batch is
+// therefore made TILES tiles wide: all of a round's rows are evaluated into records at once (one wait), the loads of the next
+// round are issued immediately, and the round is then appended / flushed tile by tile (TILES sub-rounds of barriers) while they fly.
+template <class P, int MODE, int TILES = kP2JitTiles>
 __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args args, const PartPlan2 pp, const ScatterParams2 sp) {
   static_assert(P::kStatic, "the partitioned group-by runs specialised programs only (AOT or JIT)");
   extern __shared__ unsigned long long p2_lds[];
@@ -118,6 +130,7 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   for (uint32_t i = threadIdx.x; i < hot_slots; i += blockDim.x) { hot_k[i] = sp.hot_tbl_keys[i]; hot_i[i] = sp.hot_tbl_idx[i]; }
   for (uint32_t i = threadIdx.x; i < pp.n_hot * sh.n_aggs * pp.hot_copies; i += blockDim.x) hot_acc[i] = agg_identity_dev(sh.aggs[(i / pp.hot_copies) % sh.n_aggs].kind);
   if (threadIdx.x < 4) misc[threadIdx.x] = 0;
+  if (threadIdx.x == 0 && pp.tiles != (uint32_t)TILES) sp.flags[0] = 1u;     // host and kernel disagree about the round geometry: fail the query
   __syncthreads();
   const uint32_t chunk0 = blockIdx.x * pp.chunks_per_wg;     // this workgroup's private chunk region
   // partitions a lane owns in the flush phase: wave w, lane l < lanes_per_wave owns partition w * lanes_per_wave + l
@@ -125,66 +138,75 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   const bool owner = NP >= (uint32_t)nwaves ? ((uint32_t)lane < lanes_per_wave) : ((uint32_t)wave < NP && lane == 0);
   const uint32_t own_p = NP >= (uint32_t)nwaves ? (uint32_t)wave * lanes_per_wave + (uint32_t)lane : (uint32_t)wave;
 
-  const int64_t rows_per_round = (int64_t)blockDim.x * kRows;
+  const int64_t rows_per_round = (int64_t)blockDim.x * kRows * TILES;
   const int64_t nrounds = (args.n_rows + rows_per_round - 1) / rows_per_round;
-  auto row0_of = [&](int64_t rd) { return (rd * nwaves + wave) * (int64_t)kTileRows + (int64_t)lane * kRows; };
+  auto tile_of = [&](int64_t rd, int t) { return (rd * TILES + t) * (int64_t)nwaves + wave; };
   auto round_full = [&](int64_t rd) { return (rd + 1) * rows_per_round <= args.n_rows; };
-  RegFile rfA{};              // a named variable, never an array: a dynamically indexed register file is spilled to scratch
+  RegFile rf[TILES];          // indexed by compile-time constants only (p2_static_for): a dynamically indexed register file is spilled to scratch
   long long kmin_seen = 0x7fffffffffffffffll, kmax_seen = (long long)0x8000000000000000ull;   // by-product statistics of the key
-  unsigned int rec[kRows][RW];
-  uint32_t part[kRows];
-  bool pending[kRows];
-  // evaluates round rd (its column loads may already be in flight) and leaves its rows in rec / part / pending; rows of hot
-  // keys are aggregated here and never become pending
-  auto finish_round = [&](int64_t rd, bool preloaded, RegFile& rf) __attribute__((always_inline)) {
-    bool pass[kRows];
-    const int64_t row0 = row0_of(rd);
-    if (preloaded) {
-      run_rest_full<P>(args, row0, rf);
+  unsigned int rec[TILES][kRows][RW];
+  uint32_t part[TILES][kRows];
+  bool pending[TILES][kRows];
+  // evaluates the TILES tiles of round rd (their column loads may already be in flight) and leaves the rows in rec / part /
+  // pending; rows of hot keys are aggregated here and never become pending
+  auto finish_round = [&](int64_t rd, bool preloaded) __attribute__((always_inline)) {
+    p2_static_for<TILES>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      bool pass[kRows];
+      const int64_t row0 = tile_of(rd, t) * (int64_t)kTileRows + (int64_t)lane * kRows;
+      if (preloaded) {
+        run_rest_full<P>(args, row0, rf[t]);
 #pragma unroll
-      for (int r = 0; r < kRows; r++) pass[r] = sh.pred == kNone || ((rf.get(r, sh.pred) & 1) && ((rf.getv(sh.pred) >> r) & 1));
-    } else {
-      int64_t r0;
-      tile_rows<P>(dsh, args, rd * nwaves + wave, rf, pass, r0);
-    }
-#pragma unroll
-    for (int r = 0; r < kRows; r++) {
-      bool kvalid; uint64_t key64;
-      make_record2<MODE>(sh, L, pp, rf, r, row0 + r, rec[r], part[r], kvalid, key64);
-      pending[r] = pass[r];
-      if (MODE == (int)kP2Hash && sp.key_minmax && pass[r] && kvalid) {
-        kmin_seen = (long long)key64 < kmin_seen ? (long long)key64 : kmin_seen;
-        kmax_seen = (long long)key64 > kmax_seen ? (long long)key64 : kmax_seen;
+        for (int r = 0; r < kRows; r++) pass[r] = sh.pred == kNone || ((rf[t].get(r, sh.pred) & 1) && ((rf[t].getv(sh.pred) >> r) & 1));
+      } else {
+        int64_t r0;
+        tile_rows<P>(dsh, args, tile_of(rd, t), rf[t], pass, r0);
       }
-      if (MODE == (int)kP2Direct && part[r] >= NP) { if (pass[r]) sp.flags[1] = 1u; pending[r] = false; }   // id outside the declared range: the query fails
-      if (pp.n_hot && pass[r] && kvalid && key64 != kEmptyKey) {
-        uint32_t s = (uint32_t)((key64 * 0x9e3779b97f4a7c15ull) >> (64 - pp.log2_hot_slots));
-        int hot = -1;
-        for (;;) {
-          const unsigned long long hk = hot_k[s];
-          if (hk == key64) { hot = (int)hot_i[s]; break; }
-          if (hk == kEmptyKey) break;
-          s = (s + 1) & (hot_slots - 1);
-        }
-        if (hot >= 0) {
-          pending[r] = false;
-          unsigned long long* cell = hot_acc + (size_t)hot * sh.n_aggs * pp.hot_copies + ((uint32_t)lane & (pp.hot_copies - 1));
 #pragma unroll
-          for (int k = 0; k < kMaxAggs; k++) {
-            if (k < sh.n_aggs) {
-              const Agg ag = sh.aggs[k];
-              const uint64_t v = ag.src != kNone ? rf.get(r, ag.src) : 0ull;
-              const bool valid = ag.src != kNone ? ((rf.getv(ag.src) >> r) & 1) : true;
-              const uint64_t x = agg_row_value(ag.kind, v, true, valid, (uint64_t)(row0 + r));
-              if ((x != agg_identity_dev(ag.kind) || ag.kind == AGG_SUM_F) && !(ag.kind == AGG_SUM_F && !valid)) lds_atomic_agg(ag.kind, cell + (size_t)k * pp.hot_copies, x);
+      for (int r = 0; r < kRows; r++) {
+        bool kvalid; uint64_t key64;
+        make_record2<MODE>(sh, L, pp, rf[t], r, row0 + r, rec[t][r], part[t][r], kvalid, key64);
+        pending[t][r] = pass[r];
+        if (MODE == (int)kP2Hash && sp.key_minmax && pass[r] && kvalid) {
+          kmin_seen = (long long)key64 < kmin_seen ? (long long)key64 : kmin_seen;
+          kmax_seen = (long long)key64 > kmax_seen ? (long long)key64 : kmax_seen;
+        }
+        if (MODE == (int)kP2Direct && part[t][r] >= NP) { if (pass[r]) sp.flags[1] = 1u; pending[t][r] = false; }   // id outside the declared range: the query fails
+        if (pp.n_hot && pass[r] && kvalid && key64 != kEmptyKey) {
+          uint32_t s = (uint32_t)((key64 * 0x9e3779b97f4a7c15ull) >> (64 - pp.log2_hot_slots));
+          int hot = -1;
+          for (;;) {
+            const unsigned long long hk = hot_k[s];
+            if (hk == key64) { hot = (int)hot_i[s]; break; }
+            if (hk == kEmptyKey) break;
+            s = (s + 1) & (hot_slots - 1);
+          }
+          if (hot >= 0) {
+            pending[t][r] = false;
+            unsigned long long* cell = hot_acc + (size_t)hot * sh.n_aggs * pp.hot_copies + ((uint32_t)lane & (pp.hot_copies - 1));
+#pragma unroll
+            for (int k = 0; k < kMaxAggs; k++) {
+              if (k < sh.n_aggs) {
+                const Agg ag = sh.aggs[k];
+                const uint64_t v = ag.src != kNone ? rf[t].get(r, ag.src) : 0ull;
+                const bool valid = ag.src != kNone ? ((rf[t].getv(ag.src) >> r) & 1) : true;
+                const uint64_t x = agg_row_value(ag.kind, v, true, valid, (uint64_t)(row0 + r));
+                if ((x != agg_identity_dev(ag.kind) || ag.kind == AGG_SUM_F) && !(ag.kind == AGG_SUM_F && !valid)) lds_atomic_agg(ag.kind, cell + (size_t)k * pp.hot_copies, x);
+              }
             }
           }
         }
       }
-    }
+    });
   };
-  auto issue_loads = [&](int64_t rd, RegFile& rf) __attribute__((always_inline)) -> bool {
-    if (rd < nrounds && round_full(rd)) { run_loads_full<P>(args, row0_of(rd), rf); return true; }
+  auto issue_loads = [&](int64_t rd) __attribute__((always_inline)) -> bool {
+    if (rd < nrounds && round_full(rd)) {
+      p2_static_for<TILES>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        run_loads_full<P>(args, tile_of(rd, t) * (int64_t)kTileRows + (int64_t)lane * kRows, rf[t]);
+      });
+      return true;
+    }
     return false;
   };
   // writes every complete line of the rings this lane owns to HBM and opens / closes chunks; `final_pass` also writes the
@@ -246,41 +268,25 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
       fdw[own_p] = f_dw; chunk[own_p] = ch;
     }
   };
-
-  // Round k of this workgroup lives in register file k % DEPTH.  Per round: its rows are evaluated (loads issued DEPTH rounds
-  // ago) and copied into rec[]; the register file is then free, so the loads of round k + DEPTH are issued at once and stay
-  // in flight while round k is appended and flushed (barriers do not drain vmcnt).
-  // appends this lane's pending rows; true = some are still pending (their partition's ring / chunk was full)
-  auto append_pending = [&]() __attribute__((always_inline)) -> bool {
+  // appends this lane's pending rows of tile t; true = some are still pending (their partition's ring / chunk was full)
+  auto append_pending = [&](auto tc) __attribute__((always_inline)) -> bool {
+    constexpr int t = decltype(tc)::value;
     bool mine = false;
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
-      if (!pending[r]) continue;
-      const unsigned long long old = atomicAdd(&fl[part[r]], 1ull);
+      if (!pending[t][r]) continue;
+      const unsigned long long old = atomicAdd(&fl[part[t][r]], 1ull);
       const uint32_t pos = (uint32_t)old, lim = (uint32_t)(old >> 32);
       if (pos < lim) {
-        unsigned int* base = ring + (size_t)part[r] * ring_dw;
+        unsigned int* base = ring + (size_t)part[t][r] * ring_dw;
         const uint32_t d0 = pos * RW;
 #pragma unroll
-        for (uint32_t w = 0; w < RW; w++) if (!(pp.ablate & 2u)) base[(d0 + w) & ring_mask] = rec[r][w];
-        pending[r] = false;
+        for (uint32_t w = 0; w < RW; w++) if (!(pp.ablate & 2u)) base[(d0 + w) & ring_mask] = rec[t][r][w];
+        pending[t][r] = false;
       } else mine = true;
     }
     return mine;
   };
-  // Order of a round (the vector-memory counter of gfx9 counts loads AND stores, and the number of line stores of a flush is
-  // not a compile-time constant, so a wait for loaded data is a wait for every store issued before it):
-  //   append(rd) | barrier | evaluate round rd+1 from its loads (the stores still in flight are a whole round old by now) |
-  //   issue the loads of round rd+2 | flush(rd): line stores | barrier
-  // -- the fresh stores of a flush are never waited for before the next round's rows are needed.  Rows that did not fit
-  // (rare: the rings are sized for the arrival rate) take the slow path first: flush, barrier, append again.
-  const int64_t stride = (int64_t)gridDim.x;
-  const int64_t rd_first = (int64_t)blockIdx.x;
-  bool pre = false;
-  if (rd_first < nrounds) {
-    finish_round(rd_first, issue_loads(rd_first, rfA), rfA);
-    pre = issue_loads(rd_first + stride, rfA);
-  }
   // "does any lane still hold a pending row?" with ONE barrier (__syncthreads_or costs two): lanes raise one of two alternating LDS
   // flags before the barrier, everybody reads it after; lane 0 clears the other flag, which nobody touches until the next use
   uint32_t sync_points = 0;
@@ -293,20 +299,36 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
     if (threadIdx.x == 0) misc[2 - par] = 0u;
     return any;
   };
+  // Order of a round: its TILES tiles sit in rec[] (evaluated during the previous round's last sub-round), the loads of the next
+  // round are in flight.  Sub-round t: append(t) | barrier | [last t: evaluate the next round from its loads, issue the loads of
+  // the round after] | flush: line stores | barrier.  Rows that did not fit (rare: the rings are sized for the arrival rate) take
+  // the slow path first: flush, barrier, append again.
+  const int64_t stride = (int64_t)gridDim.x;
+  const int64_t rd_first = (int64_t)blockIdx.x;
+  bool pre = false;
+  if (rd_first < nrounds) {
+    finish_round(rd_first, issue_loads(rd_first));
+    pre = issue_loads(rd_first + stride);
+  }
   for (int64_t rd = rd_first; rd < nrounds; rd += stride) {
-    bool any = any_pending(append_pending());
-    while (any) {
+    p2_static_for<TILES>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      bool any = any_pending(append_pending(tc));
+      while (any) {
+        flush_phase(false);
+        __syncthreads();
+        any = any_pending(append_pending(tc));
+      }
+      if (t == TILES - 1) {
+        const int64_t rd_next = rd + stride;
+        if (rd_next < nrounds) {                          // uniform across the workgroup
+          finish_round(rd_next, pre);
+          pre = issue_loads(rd_next + stride);
+        }
+      }
       flush_phase(false);
       __syncthreads();
-      any = any_pending(append_pending());
-    }
-    const int64_t rd_next = rd + stride;
-    if (rd_next < nrounds) {                          // uniform across the workgroup
-      finish_round(rd_next, pre, rfA);
-      pre = issue_loads(rd_next + stride, rfA);
-    }
-    flush_phase(false);
-    __syncthreads();
+    });
   }
   flush_phase(true);
   if (MODE == (int)kP2Hash && sp.key_minmax) {
@@ -328,9 +350,9 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   }
 }
 
-template <class P, int MODE, int DEPTH = 1>
+template <class P, int MODE, int TILES = kP2JitTiles>
 __global__ __launch_bounds__(kP2MaxBlock) void part2_scatter_kernel(Shape dsh, Args args, PartPlan2 pp, ScatterParams2 sp) {
-  part2_scatter_body<P, MODE, DEPTH>(dsh, args, pp, sp);
+  part2_scatter_body<P, MODE, TILES>(dsh, args, pp, sp);
 }
 
 // ---- the aggregation kernel --------------------------------------------------------------------------------------------

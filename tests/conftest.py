@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
 
 
+def pytest_collection_finish(session):
+    """On a fresh GPU box the very first `import torch` pages the image in and can take minutes: do it here, outside any test's
+    timeout, when a selected test is going to need it (the product itself never imports torch)."""
+    if any(item.get_closest_marker("gpu") for item in session.items):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+
+
 @pytest.fixture(scope="session")
 def orc():
     """The CPU oracle (test infrastructure)."""
