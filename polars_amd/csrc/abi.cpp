@@ -840,7 +840,8 @@ int plx_jit_selftest(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int
     PLX_REQUIRE(engine::describe_fusion(p, root, &sh, &sid, &why), PLX_ERR_UNSUPPORTED, "not fusable: " + why);
     if (rn.kind == PLX_IR_SELECT) jobs = {{sh, jit::REGAGG}};
     else jobs = {{sh, jit::LDSAGG}, {sh, jit::DENSE}, {sh, jit::HASH}, {sh, jit::PART_COUNT}, {sh, jit::PART_SCATTER}, {sh, jit::PART_AGG},
-                  {sh, jit::PART2_SCATTER_HASH}, {sh, jit::PART2_SCATTER_DIRECT}, {sh, jit::PART2_AGG_HASH}, {sh, jit::PART2_AGG_DIRECT}};
+                  {sh, jit::PART2_SCATTER_HASH}, {sh, jit::PART2_SCATTER_DIRECT}, {sh, jit::PART2_AGG_HASH}, {sh, jit::PART2_AGG_DIRECT},
+                  {sh, jit::PART2_SCATTER_HASH_T2}, {sh, jit::PART2_SCATTER_DIRECT_T2}};
     if (sh.n_keys >= 2) jobs = {{sh, jit::WIDE}};
   }
   for (auto& j : jobs) {

@@ -34,7 +34,7 @@ double g_ms = 0;
 
 const char* sink_type(Sink s) {
   static const char* n[] = {"RegAggSink", "LdsAggSink", "DenseAggSink", "HashAggSink", "WideAggSink", "JoinBuildSink", "ProbeAggSink", "DirectBuildSink", "DirectProbeAggSink", "BitmapBuildSink",
-                            "part_count", "part_scatter", "part_agg", "part2_scatter_hash", "part2_scatter_direct", "part2_agg_hash", "part2_agg_direct"};
+                            "part_count", "part_scatter", "part_agg", "part2_scatter_hash", "part2_scatter_direct", "part2_agg_hash", "part2_agg_direct", "part2_scatter_hash_t2", "part2_scatter_direct_t2"};
   return n[s];
 }
 
@@ -91,9 +91,10 @@ std::string source_for(const Shape& sh, Sink sink) {
       o << "extern \"C\" __global__ __launch_bounds__(kAggBlock) void plx_jit_kernel(Shape dsh, PartitionPlan pp, PartAggParams ap) {\n"
            "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout cl = rec_layout(JitProg::shape());\n  part_agg_body(csh, cl, pp, ap);\n}\n}}\n";
       break;
-    case PART2_SCATTER_HASH: case PART2_SCATTER_DIRECT:
+    case PART2_SCATTER_HASH: case PART2_SCATTER_DIRECT: case PART2_SCATTER_HASH_T2: case PART2_SCATTER_DIRECT_T2:
       o << "extern \"C\" __global__ __launch_bounds__(kP2MaxBlock) void plx_jit_kernel(Shape dsh, Args args, PartPlan2 pp, ScatterParams2 sp) {\n"
-           "  part2_scatter_body<JitProg, " << (sink == PART2_SCATTER_DIRECT ? 1 : 0) << ">(dsh, args, pp, sp);\n}\n}}\n";
+           "  part2_scatter_body<JitProg, " << ((sink == PART2_SCATTER_DIRECT || sink == PART2_SCATTER_DIRECT_T2) ? 1 : 0) << ", "
+        << ((sink == PART2_SCATTER_HASH_T2 || sink == PART2_SCATTER_DIRECT_T2) ? 2 : 1) << ">(dsh, args, pp, sp);\n}\n}}\n";
       break;
     case PART2_AGG_HASH: case PART2_AGG_DIRECT:
       o << "extern \"C\" __global__ __launch_bounds__(kP2AggBlock) void plx_jit_kernel(PartPlan2 pp, AggParams2 ap) {\n"

@@ -21,7 +21,9 @@ enum Sink { REGAGG = 0, LDSAGG, DENSE, HASH, WIDE, JOIN_BUILD, PROBE_AGG, DIRECT
             // kernels of the partitioned group-by (partition_device.hpp); launched with launch_raw
             PART_COUNT, PART_SCATTER, PART_AGG,
             // second generation (partition2_device.hpp)
-            PART2_SCATTER_HASH, PART2_SCATTER_DIRECT, PART2_AGG_HASH, PART2_AGG_DIRECT, kNumSinks };
+            PART2_SCATTER_HASH, PART2_SCATTER_DIRECT, PART2_AGG_HASH, PART2_AGG_DIRECT,
+            PART2_SCATTER_HASH_T2, PART2_SCATTER_DIRECT_T2,      // two tiles per wave and round
+            kNumSinks };
 
 bool launch(const fused::Shape& sh, const fused::Args& args, Sink sink, const void* params, int grid, size_t lds_bytes);
 // Compile (or fetch) the specialised kernel of (shape, kind) without launching: lets a multi-kernel pipeline decide up

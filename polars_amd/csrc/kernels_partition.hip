@@ -190,7 +190,7 @@ static const int kEnvP2Direct = env_int("PLX_PART_DIRECT", 0, 1);        // 0: n
 static const int kEnvP2DirectLp = env_int("PLX_PART_DIRECT_LOG2_PARTS", 4, 9);   // direct mode: partitions when the id range allows (default 2^9)
 static const int kEnvP2Wgs = env_int("PLX_PART2_WGS_PER_CU", 1, 4);       // scatter workgroups per CU (they must fit the LDS together)
 static const int kEnvP2Ablate = env_int("PLX_PART_ABLATE", 0, 3);
-static const int kEnvP2Tiles = env_int("PLX_PART_TILES", 1, 4);           // tiles per wave and round (AOT shapes: 1 | 2 | 4)
+static const int kEnvP2Tiles = env_int("PLX_PART_TILES", 1, 2);           // tiles per wave and round (default: 2 when the rings absorb them)
 
 static uint32_t floor_pow2(uint32_t x) { uint32_t p = 1; while (p * 2 <= x) p *= 2; return p; }
 static uint32_t ceil_log2(uint64_t x) { uint32_t b = 0; while ((1ull << b) < x) b++; return b; }
@@ -261,7 +261,10 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
   if (kEnvP2Block > 0) block = floor_pow2((uint32_t)kEnvP2Block);
   pp.block = block;
   pp.ablate = kEnvP2Ablate > 0 ? (uint32_t)kEnvP2Ablate : 0u;
-  plan2_geometry(pp, n_rows, kEnvP2Tiles > 0 ? (uint32_t)kEnvP2Tiles : (uint32_t)kP2JitTiles);
+  // two tiles per round when the rings absorb them (same arrival-rate rule): half the barriers and ring scans per row
+  uint32_t tiles = ((double)block * kRows * 2 / NP <= lambda_max) ? 2u : 1u;
+  if (kEnvP2Tiles > 0) tiles = kEnvP2Tiles >= 2 ? 2u : 1u;
+  plan2_geometry(pp, n_rows, tiles);
   *out = pp;
   return true;
 }
@@ -368,11 +371,10 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   const uint32_t NP = 1u << pp.log2_parts;
   const bool direct = pp.mode == kP2Direct;
   const bool is_static = static_id == SHAPE_GB_SUM_CNT_I64 || static_id == SHAPE_GB_SUM_MEAN_U32_F64;   // the cases of PLX_PART2_STATIC_CASES
-  const jit::Sink jk_scatter = direct ? jit::PART2_SCATTER_DIRECT : jit::PART2_SCATTER_HASH, jk_agg = direct ? jit::PART2_AGG_DIRECT : jit::PART2_AGG_HASH;
+  const jit::Sink jk_scatter = pp.tiles == 2 ? (direct ? jit::PART2_SCATTER_DIRECT_T2 : jit::PART2_SCATTER_HASH_T2) : (direct ? jit::PART2_SCATTER_DIRECT : jit::PART2_SCATTER_HASH), jk_agg = direct ? jit::PART2_AGG_DIRECT : jit::PART2_AGG_HASH;
   const bool use_jit = !is_static && jit::ensure(sh, jk_scatter, args.n_rows) && jit::ensure(sh, jk_agg, args.n_rows);
   if (!is_static && !use_jit) return -1;
-  if (pp.tiles == 3) plan2_geometry(pp, args.n_rows, 4);                                        // only 1 | 2 | 4 are instantiated
-  if (use_jit && pp.tiles != (uint32_t)kP2JitTiles) plan2_geometry(pp, args.n_rows, (uint32_t)kP2JitTiles);   // run-time specialised kernels have one geometry
+  PLX_REQUIRE(pp.tiles == 1 || pp.tiles == 2, PLX_ERR_INVALID, "partitioned_agg2: 1 or 2 tiles per round");
   PLX_REQUIRE(pp.n_hot == hot_keys.size(), PLX_ERR_INVALID, "partitioned_agg2: plan / hot key list mismatch");
   const uint32_t chunk_dw = kP2ChunkRecs * pp.rec_words;
   const int64_t n_chunks = (int64_t)pp.scatter_grid * pp.chunks_per_wg;
@@ -424,8 +426,8 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
     } else {
 #define PLX_P2_SCATTER(MODE, T) \
   switch (static_id) { PLX_PART2_STATIC_SCATTER_CASES((int)MODE, T, dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp) default: break; }
-      if (direct) { if (pp.tiles == 1) { PLX_P2_SCATTER(kP2Direct, 1) } else if (pp.tiles == 2) { PLX_P2_SCATTER(kP2Direct, 2) } else { PLX_P2_SCATTER(kP2Direct, 4) } }
-      else { if (pp.tiles == 1) { PLX_P2_SCATTER(kP2Hash, 1) } else if (pp.tiles == 2) { PLX_P2_SCATTER(kP2Hash, 2) } else { PLX_P2_SCATTER(kP2Hash, 4) } }
+      if (direct) { if (pp.tiles == 1) { PLX_P2_SCATTER(kP2Direct, 1) } else { PLX_P2_SCATTER(kP2Direct, 2) } }
+      else { if (pp.tiles == 1) { PLX_P2_SCATTER(kP2Hash, 1) } else { PLX_P2_SCATTER(kP2Hash, 2) } }
 #undef PLX_P2_SCATTER
     }
     PLX_HIP(hipGetLastError());

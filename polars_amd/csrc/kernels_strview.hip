@@ -135,6 +135,7 @@ __global__ __launch_bounds__(kBlock) void strview_encode_kernel(StrEncode e, Str
     while (any) {
 #pragma unroll
       for (int r = 0; r < kStrRows; r++) {
+        if (code[r] != -1) continue;          // resolved rows fetch nothing: the loop runs for the slowest row of the wave
         const ulonglong2* s = reinterpret_cast<const ulonglong2*>(t.slots + key[r].slot);
         a[r] = s[0]; b[r] = s[1];
       }

@@ -99,14 +99,13 @@ template <int N, class F>
 __device__ __forceinline__ void p2_static_for(F&& f) {
   if constexpr (N > 0) { p2_static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
 }
-constexpr int kP2JitTiles = 2;       // tiles per wave and round of the run-time specialised kernels (the host plans with the same value)
 
-// TILES: tiles (kTileRows rows) each wave loads per round.  The pass is bound by load latency, not by bytes: the line stores of a
-// flush and the column loads share the vector-memory counter, the number of stores is not a compile-time constant, so every wait
-// for loaded data is a wait for everything (vmcnt(0)) and only ONE batch of loads can be in flight per wave.  The batch is
-// therefore made TILES tiles wide: all of a round's rows are evaluated into records at once (one wait), the loads of the next
-// round are issued immediately, and the round is then appended / flushed tile by tile (TILES sub-rounds of barriers) while they fly.
-template <class P, int MODE, int TILES = kP2JitTiles>
+// TILES: tiles (kTileRows rows) each wave handles per round.  A round costs two barriers and one scan of the rings whatever it
+// appends (measured: the pass is bound by instruction issue and barrier latency, not by bytes -- without ring writes AND without
+// line stores it still takes 80 % of its time), so a round is made as wide as the rings allow: all TILES tiles are evaluated into
+// records at once (one wait for their loads), the loads of the next round are issued at once, then everything is appended and
+// the complete lines are flushed.  The host picks TILES / ring size / partition count together (partition_plan2).
+template <class P, int MODE, int TILES = 1>
 __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args args, const PartPlan2 pp, const ScatterParams2 sp) {
   static_assert(P::kStatic, "the partitioned group-by runs specialised programs only (AOT or JIT)");
   extern __shared__ unsigned long long p2_lds[];
@@ -299,10 +298,11 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
     if (threadIdx.x == 0) misc[2 - par] = 0u;
     return any;
   };
-  // Order of a round: its TILES tiles sit in rec[] (evaluated during the previous round's last sub-round), the loads of the next
-  // round are in flight.  Sub-round t: append(t) | barrier | [last t: evaluate the next round from its loads, issue the loads of
-  // the round after] | flush: line stores | barrier.  Rows that did not fit (rare: the rings are sized for the arrival rate) take
-  // the slow path first: flush, barrier, append again.
+  // Order of a round (the vector-memory counter of gfx9 counts loads AND stores, and the number of line stores of a flush is
+  // not a compile-time constant, so a wait for loaded data is a wait for every store issued before it):
+  //   append(rd) | barrier | evaluate round rd+1 from its loads (the stores still in flight are a whole round old by now) |
+  //   issue the loads of round rd+2 | flush(rd): line stores | barrier
+  // Rows that did not fit (rare: the rings are sized for the arrival rate) take the slow path first: flush, barrier, append again.
   const int64_t stride = (int64_t)gridDim.x;
   const int64_t rd_first = (int64_t)blockIdx.x;
   bool pre = false;
@@ -310,25 +310,25 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
     finish_round(rd_first, issue_loads(rd_first));
     pre = issue_loads(rd_first + stride);
   }
+  auto append_round = [&]() __attribute__((always_inline)) -> bool {
+    bool mine = false;
+    p2_static_for<TILES>([&](auto tc) __attribute__((always_inline)) { mine = append_pending(tc) || mine; });
+    return mine;
+  };
   for (int64_t rd = rd_first; rd < nrounds; rd += stride) {
-    p2_static_for<TILES>([&](auto tc) __attribute__((always_inline)) {
-      constexpr int t = decltype(tc)::value;
-      bool any = any_pending(append_pending(tc));
-      while (any) {
-        flush_phase(false);
-        __syncthreads();
-        any = any_pending(append_pending(tc));
-      }
-      if (t == TILES - 1) {
-        const int64_t rd_next = rd + stride;
-        if (rd_next < nrounds) {                          // uniform across the workgroup
-          finish_round(rd_next, pre);
-          pre = issue_loads(rd_next + stride);
-        }
-      }
+    bool any = any_pending(append_round());
+    while (any) {
       flush_phase(false);
       __syncthreads();
-    });
+      any = any_pending(append_round());
+    }
+    const int64_t rd_next = rd + stride;
+    if (rd_next < nrounds) {                          // uniform across the workgroup
+      finish_round(rd_next, pre);
+      pre = issue_loads(rd_next + stride);
+    }
+    flush_phase(false);
+    __syncthreads();
   }
   flush_phase(true);
   if (MODE == (int)kP2Hash && sp.key_minmax) {
@@ -350,7 +350,7 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   }
 }
 
-template <class P, int MODE, int TILES = kP2JitTiles>
+template <class P, int MODE, int TILES = 1>
 __global__ __launch_bounds__(kP2MaxBlock) void part2_scatter_kernel(Shape dsh, Args args, PartPlan2 pp, ScatterParams2 sp) {
   part2_scatter_body<P, MODE, TILES>(dsh, args, pp, sp);
 }
@@ -386,39 +386,36 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   __syncthreads();
   const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const uint64_t c_beg = ap.cl_off[p], c_end = ap.cl_off[p + 1];
-  unsigned int cur[kPerLane][16], nxt[kPerLane][16];   // [..][RW] (RW <= 13); unused words are never touched
-  uint32_t cnt_cur = 0, cnt_nxt = 0;
-  auto load_chunk = [&](uint64_t j, unsigned int (*dst)[16], uint32_t& cnt) {
-    cnt = 0;
-    if (j >= c_end) return;
-    const uint32_t id = ap.cl_ids[j];
-    cnt = ap.chunk_fill[id];
+  // Three chunks per wave are in flight: the chunk being aggregated and the next two (a partition count that gives every CU only
+  // one workgroup leaves 16 waves to cover the HBM latency).  Every lane ALWAYS loads its kPerLane records of a chunk -- past
+  // the fill, or past the end of the list (clamped to the last chunk), the words are simply ignored -- so the number of loads per
+  // chunk is a constant and the wait for the oldest chunk leaves the younger two in flight; the chunk id and fill come through
+  // the scalar cache (wave-uniform address).
+  unsigned int b0[kPerLane][16], b1[kPerLane][16], b2[kPerLane][16];   // [..][RW] (RW <= 13); unused words are never touched
+  uint32_t n0 = 0, n1 = 0, n2 = 0;
+  auto load_chunk = [&](uint64_t j, unsigned int (*dst)[16], uint32_t& cnt) __attribute__((always_inline)) {
+    const uint64_t jc = j < c_end ? j : c_end - 1;
+    const uint32_t jlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)jc), jhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(jc >> 32));
+    const uint64_t ju = ((uint64_t)jhi << 32) | jlo;
+    const uint32_t id = ap.cl_ids[ju];
+    const uint32_t fill = ap.chunk_fill[id];
+    cnt = j < c_end ? fill : 0u;
     const unsigned int* base = ap.recs + (uint64_t)id * chunk_dw;
 #pragma unroll
     for (uint32_t u = 0; u < kPerLane; u++) {
       const uint32_t i = (uint32_t)lane + u * 64u;
-      if (i < cnt) {
-        switch (RW) {
-          case 2: load_rec2<2>(base + (size_t)i * 2, dst[u]); break;
-          case 3: load_rec2<3>(base + (size_t)i * 3, dst[u]); break;
-          case 4: load_rec2<4>(base + (size_t)i * 4, dst[u]); break;
-          default:
+      switch (RW) {
+        case 2: load_rec2<2>(base + (size_t)i * 2, dst[u]); break;
+        case 3: load_rec2<3>(base + (size_t)i * 3, dst[u]); break;
+        case 4: load_rec2<4>(base + (size_t)i * 4, dst[u]); break;
+        default:
 #pragma unroll
-            for (uint32_t w = 0; w < 16; w++) if (w < RW) dst[u][w] = base[(size_t)i * RW + w];
-            break;
-        }
+          for (uint32_t w = 0; w < 16; w++) if (w < RW) dst[u][w] = base[(size_t)i * RW + w];
+          break;
       }
     }
   };
-  load_chunk(c_beg + (uint64_t)wave, nxt, cnt_nxt);
-  for (uint64_t j = c_beg + (uint64_t)wave; j < c_end; j += (uint64_t)nwaves) {
-    cnt_cur = cnt_nxt;
-#pragma unroll
-    for (uint32_t u = 0; u < kPerLane; u++) {
-#pragma unroll
-      for (uint32_t w = 0; w < 16; w++) if (w < RW) cur[u][w] = nxt[u][w];
-    }
-    load_chunk(j + (uint64_t)nwaves, nxt, cnt_nxt);
+  auto process = [&](unsigned int (*cur)[16], uint32_t cnt_cur) __attribute__((always_inline)) {
     // the lane's records of the chunk are handled in three passes so that their LDS round trips overlap: (1) decode the key and
     // read the table word of its home slot for every record, (2) resolve the slot (hit on the first probe in the common case; the
     // CAS / linear-probe loop otherwise), (3) update the cells
@@ -489,6 +486,20 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
           lds_atomic_agg(kind, cell + k, x);
         }
       }
+    }
+  };
+  if (c_beg < c_end) {
+    const uint64_t step = (uint64_t)nwaves;
+    uint64_t j = c_beg + (uint64_t)wave;
+    load_chunk(j, b0, n0);
+    load_chunk(j + step, b1, n1);
+    for (;;) {     // the three buffers rotate by name: copying a buffer would wait for its loads
+      if (j >= c_end) break;
+      load_chunk(j + 2 * step, b2, n2); process(b0, n0); j += step;
+      if (j >= c_end) break;
+      load_chunk(j + 2 * step, b0, n0); process(b1, n1); j += step;
+      if (j >= c_end) break;
+      load_chunk(j + 2 * step, b1, n1); process(b2, n2); j += step;
     }
   }
   __syncthreads();
