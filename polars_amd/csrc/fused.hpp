@@ -409,13 +409,13 @@ struct DirectJoinTable {
   unsigned int* counter;         // [0] next ordinal chunk base
   unsigned int* flags;           // [0] duplicate build key, [1] ordinal overflow
   unsigned long long* acc;       // [n_slots * n_aggs] (probe)
+  unsigned long long* touched;   // [n_slots / 64 + 1] bit per slot: some probe row landed there (what the output step scans instead of the cells)
   long long kmin;
   unsigned long long range;
   unsigned int n_ord;            // capacity of the pair list
-  unsigned int opts;             // kDirectLateLoads | kDirectMergeOrs
+  unsigned int opts;             // kDirectLateLoads
 };
 constexpr unsigned int kDirectLateLoads = 1u;   // probe: columns only the aggregates read are loaded under the hit mask (split_program)
-constexpr unsigned int kDirectMergeOrs = 2u;    // build: bits of neighbouring lanes that fall into one bitmap word are OR-ed in the wave first
 
 // Semi-join filter side reduced to a bitmap over its key range (an inner join whose one side has unique keys and contributes
 // no column downstream only FILTERS the other side): the scan of the filter side sets bit (key - kmin) of every row that passes

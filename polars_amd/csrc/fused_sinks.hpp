@@ -319,6 +319,11 @@ constexpr unsigned int kOrdChunk = 1024;
 __device__ __forceinline__ unsigned long long direct_slot(const DirectJoinTable& t, unsigned long long idx, unsigned long long word) {
   return (unsigned long long)t.rank[idx >> 6] + (unsigned long long)__popcll(word & ((1ull << (idx & 63)) - 1ull));
 }
+// marks a slot as hit; the plain (possibly stale) read only saves atomics when a join is unselective
+__device__ __forceinline__ void direct_touch(const DirectJoinTable& t, unsigned long long slot) {
+  const unsigned long long bit = 1ull << (slot & 63);
+  if (!(t.touched[slot >> 6] & bit)) __hip_atomic_fetch_or(&t.touched[slot >> 6], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 struct DirectBuildSink {
   using Params = DirectJoinTable;
   unsigned int next = 0, end = 0;   // wave-uniform
@@ -356,25 +361,14 @@ struct DirectBuildSink {
       part[r] = true; word[r] = (unsigned int)(idx >> 6); bit[r] = 1ull << (idx & 63);     // range <= 2^34: the word index fits 28 bits
     }
     // fire-and-forget (no-return) atomics: a duplicate build key shows up as popcount(bits) < number of pairs, which the rank step
-    // counts (the caller then falls back).  Build tables are usually scanned in key order, where the 128 rows of a tile land in
-    // a handful of bitmap words: rows of one lane and runs of neighbouring lanes that share a word are OR-ed together first
-    // (segmented scan over the lanes; lanes that share a word without being neighbours just issue separately).
+    // counts (the caller then falls back).  The two rows of a lane usually share a bitmap word when the build table is scanned in
+    // key order: one atomic then.  (Merging across lanes with a segmented wave scan was measured: no faster, the scan is not
+    // bound by the atomic rate.)
     static_assert(kRows == 2, "pairwise merge below");
     if (part[0] && part[1] && word[0] == word[1]) { bit[0] |= bit[1]; part[1] = false; }
-    if (part[1]) __hip_atomic_fetch_or(&p.bits[word[1]], bit[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (p.opts & kDirectMergeOrs) {
-      const int lane = lane_id();
-      const unsigned int w = part[0] ? word[0] : 0xffffffffu - (unsigned int)lane;   // a word of its own
-      unsigned long long v = part[0] ? bit[0] : 0ull;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned int wo = __shfl_up(w, d, 64);
-        const unsigned long long vo = __shfl_up(v, d, 64);
-        if (lane >= d && wo == w) v |= vo;
-      }
-      const unsigned int wn = __shfl_down(w, 1, 64);
-      if (part[0] && (lane == 63 || wn != w)) __hip_atomic_fetch_or(&p.bits[word[0]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (part[0]) __hip_atomic_fetch_or(&p.bits[word[0]], bit[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int r = 0; r < kRows; r++)
+      if (part[r]) __hip_atomic_fetch_or(&p.bits[word[r]], bit[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 };
 
@@ -390,7 +384,9 @@ struct DirectProbeAggSink {
       if (idx >= p.range) continue;
       const unsigned long long w = p.bits[idx >> 6];
       if (!((w >> (idx & 63)) & 1ull)) continue;
-      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)direct_slot(p, idx, w) * sh.n_aggs);
+      const unsigned long long slot = direct_slot(p, idx, w);
+      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
+      direct_touch(p, slot);
     }
   }
 };
@@ -445,7 +441,7 @@ __device__ __forceinline__ void direct_probe_tile(const Args& args, const Direct
     if (p.opts & kDirectLateLoads) run_split<P, FULL, false>(args, row0, rf);
 #pragma unroll
     for (int r = 0; r < kRows; r++)
-      if (hit[r]) atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot[r] * sh.n_aggs);
+      if (hit[r]) { atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot[r] * sh.n_aggs); direct_touch(p, slot[r]); }
   }
 }
 

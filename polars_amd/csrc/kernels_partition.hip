@@ -216,7 +216,9 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
     // direct-address LDS table: slots = low bits of the id; as many partitions as give every CU work, tables as large as fit
     uint32_t max_shift = 0;
     while (((size_t)1 << (max_shift + 1)) * sh.n_aggs * 8 <= 128 * 1024) max_shift++;
-    int shift = packed_bits - (kEnvP2DirectLp > 0 ? kEnvP2DirectLp : 9);   // 512 partitions when the id range allows
+    // 256 partitions when the id range allows: one aggregation workgroup per CU (three chunks in flight per wave keep it fed) and
+    // rings of four lines, which absorb two tiles per scatter round
+    int shift = packed_bits - (kEnvP2DirectLp > 0 ? kEnvP2DirectLp : 8);
     if (shift > (int)max_shift) shift = (int)max_shift;
     if (shift < 6) shift = 6;
     const int lp = packed_bits - shift;
