@@ -1408,7 +1408,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       Buf okey = dev_alloc(sizeof(uint64_t) * ord_cap), orow = dev_alloc(sizeof(uint32_t) * ord_cap), used = dev_alloc_zero(sizeof(uint32_t) * (ord_cap / 1024 + 2));
       Buf meta = dev_alloc_zero(32);   // [0] ordinal counter, [2..3] flags, [4..5] pairs appended (u64)
       DirectJoinTable dt; dt.bits = bits->as<unsigned long long>(); dt.rank = rank->as<unsigned int>(); dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>();
-      dt.chunk_used = used->as<unsigned int>(); dt.counter = meta->as<unsigned int>(); dt.flags = meta->as<unsigned int>() + 2; dt.acc = nullptr; dt.touched = nullptr; dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)ord_cap;
+      dt.chunk_used = used->as<unsigned int>(); dt.counter = meta->as<unsigned int>(); dt.flags = meta->as<unsigned int>() + 2; dt.acc = nullptr; dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)ord_cap;
       dt.opts = probe_late_loads() ? kDirectLateLoads : 0u;
       k::fused_direct_build(cb.shape, cb.args, dt, find_static_shape(cb.shape));
       // every wave closes its last chunk when it finishes, so chunk_used is final once the build scan is: the rank launch counts
@@ -1424,8 +1424,6 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       Buf acc2 = dev_alloc(sizeof(uint64_t) * (size_t)s1 * cp.shape.n_aggs);
       k::init_agg_cells(acc2->as<uint64_t>(), s1, cp.shape);   // LEN = 0: build rows no probe row matched never show up
       dt.acc = acc2->as<unsigned long long>();
-      Buf touched = dev_alloc_zero(sizeof(uint64_t) * (size_t)(s1 / 64 + 1));
-      dt.touched = touched->as<unsigned long long>();
       k::fused_direct_probe_agg(cp.shape, cp.args, dt, probe_static_id);
       // one pass over the pair list into buffers sized for every slot (G <= n_slots)
       r.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)s1);

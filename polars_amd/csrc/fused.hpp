@@ -409,7 +409,6 @@ struct DirectJoinTable {
   unsigned int* counter;         // [0] next ordinal chunk base
   unsigned int* flags;           // [0] duplicate build key, [1] ordinal overflow
   unsigned long long* acc;       // [n_slots * n_aggs] (probe)
-  unsigned long long* touched;   // [n_slots / 64 + 1] bit per slot: some probe row landed there (what the output step scans instead of the cells)
   long long kmin;
   unsigned long long range;
   unsigned int n_ord;            // capacity of the pair list

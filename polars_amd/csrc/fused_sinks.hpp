@@ -319,11 +319,6 @@ constexpr unsigned int kOrdChunk = 1024;
 __device__ __forceinline__ unsigned long long direct_slot(const DirectJoinTable& t, unsigned long long idx, unsigned long long word) {
   return (unsigned long long)t.rank[idx >> 6] + (unsigned long long)__popcll(word & ((1ull << (idx & 63)) - 1ull));
 }
-// marks a slot as hit; the plain (possibly stale) read only saves atomics when a join is unselective
-__device__ __forceinline__ void direct_touch(const DirectJoinTable& t, unsigned long long slot) {
-  const unsigned long long bit = 1ull << (slot & 63);
-  if (!(t.touched[slot >> 6] & bit)) __hip_atomic_fetch_or(&t.touched[slot >> 6], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 struct DirectBuildSink {
   using Params = DirectJoinTable;
   unsigned int next = 0, end = 0;   // wave-uniform
@@ -384,9 +379,7 @@ struct DirectProbeAggSink {
       if (idx >= p.range) continue;
       const unsigned long long w = p.bits[idx >> 6];
       if (!((w >> (idx & 63)) & 1ull)) continue;
-      const unsigned long long slot = direct_slot(p, idx, w);
-      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
-      direct_touch(p, slot);
+      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)direct_slot(p, idx, w) * sh.n_aggs);
     }
   }
 };
@@ -441,7 +434,7 @@ __device__ __forceinline__ void direct_probe_tile(const Args& args, const Direct
     if (p.opts & kDirectLateLoads) run_split<P, FULL, false>(args, row0, rf);
 #pragma unroll
     for (int r = 0; r < kRows; r++)
-      if (hit[r]) { atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot[r] * sh.n_aggs); direct_touch(p, slot[r]); }
+      if (hit[r]) atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot[r] * sh.n_aggs);
   }
 }
 
