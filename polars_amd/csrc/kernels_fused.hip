@@ -69,6 +69,8 @@
 #define PLX_STATIC_REGAGG_EXTRA_CASES
 #endif
 
+#include <cstdlib>
+
 namespace plx {
 namespace k {
 
@@ -94,7 +96,13 @@ __global__ __launch_bounds__(kBlock) void partials_finish_kernel(Shape sh, const
 }
 
 // ---- host launchers ----------------------------------------------------------------------
-static int scan_grid(int64_t n_rows, int blocks_per_cu) {
+// workgroups per CU of a scan; `knob` names an environment variable that overrides the default (measurement runs only).
+// The defaults are measured, and not monotonic in occupancy: on SF100 inputs the streaming scans run 8-10 % faster with 5 or 7
+// workgroups per CU than with 4, 6 or 8 (Q1 4.15 vs 4.61 / 4.40 / 4.46 ms, config 2 3.82 vs 4.12 / 4.05 ms, Q3 build 0.85 vs
+// 0.91 / 0.90 / 0.98 ms; gpurun_out/r02m, same box, repeated), while the probe scan wants 8 or 16 (1.83 ms; 2.34 with 10, 2.13
+// with 12): the grid-stride distance between a wave's consecutive tiles decides which HBM channels its columns land on together.
+static int scan_grid(int64_t n_rows, int blocks_per_cu, const char* knob = nullptr) {
+  if (knob) { const char* e = getenv(knob); const int v = e ? atoi(e) : 0; if (v >= 1 && v <= 32) blocks_per_cu = v; }
   int64_t ntiles = (n_rows + kTileRows - 1) / kTileRows;
   return grid_for(ntiles, kBlock / 64, blocks_per_cu);
 }
@@ -109,7 +117,7 @@ static uint64_t algo_bytes(const Shape& sh, const Args& args) {
   hipLaunchKernelGGL((fused_scan_kernel<PROG, SINK>), dim3(grid), dim3(kBlock), (lds), stream(), sh, args, sp)
 
 void fused_regagg(const Shape& sh, const Args& args, int static_id, uint64_t* out_host) {
-  const int grid = scan_grid(args.n_rows, 4);
+  const int grid = scan_grid(args.n_rows, 5, "PLX_BPC_REGAGG");
   Buf partials = dev_alloc(sizeof(uint64_t) * (size_t)(grid + 1) * kMaxAggs);
   unsigned long long* pp = partials->as<unsigned long long>();
   RegAggSink::Params sp{pp};
@@ -144,7 +152,7 @@ void fused_lds_agg(const Shape& sh, const Args& args, int n_groups, int static_i
   PLX_REQUIRE(copies > 0, PLX_ERR_INVALID, "fused_lds_agg: group table does not fit LDS");
   const int cells = n_groups * sh.n_aggs;
   const size_t lds = (size_t)cells * copies * 8;
-  const int grid = scan_grid(args.n_rows, 4);
+  const int grid = scan_grid(args.n_rows, 5, "PLX_BPC_LDSAGG");
   const bool use_partials = n_groups <= 64;
   Buf partials;
   LdsAggSink::Params sp{};
@@ -323,7 +331,7 @@ void fused_bitmap_build(const Shape& sh, const Args& args, const BitmapBuild& t,
 void fused_direct_build(const Shape& sh, const Args& args, const DirectJoinTable& t, int static_id) {
   if (args.n_rows == 0) return;
   ProfileScope ps(static_id >= 0 ? "fused_scan_direct_build_static" : "fused_scan_direct_build", algo_bytes(sh, args), (uint64_t)args.n_rows);
-  const int grid = scan_grid(args.n_rows, 8);
+  const int grid = scan_grid(args.n_rows, 5, "PLX_BPC_DIRECT_BUILD");
   switch (static_id) {
     PLX_STATIC_DIRECT_BUILD_CASES
     PLX_STATIC_Q3F_DIRECT_BUILD_CASES
@@ -334,7 +342,7 @@ void fused_direct_build(const Shape& sh, const Args& args, const DirectJoinTable
 void fused_direct_probe_agg(const Shape& sh, const Args& args, const DirectJoinTable& t, int static_id) {
   if (args.n_rows == 0) return;
   ProfileScope ps(static_id >= 0 ? "fused_scan_direct_probe_agg_static" : "fused_scan_direct_probe_agg", algo_bytes(sh, args), (uint64_t)args.n_rows);
-  const int grid = scan_grid(args.n_rows, 8);
+  const int grid = scan_grid(args.n_rows, 8, "PLX_BPC_DIRECT_PROBE");
   switch (static_id) {
     PLX_STATIC_DIRECT_PROBE_CASES
     default: if (!jit::launch(sh, args, jit::DIRECT_PROBE, &t, grid, 0)) { const DynLaunch d = dyn_launch(sh, args, 0); hipLaunchKernelGGL((fused_scan_kernel<DynProg, DirectProbeAggSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, t); } break;

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "core.hpp"
@@ -261,7 +262,8 @@ void strview_dict_encode(const uint64_t* views, const uint64_t* validity, const 
         if ((double)d >= 0.999 * (double)S) G = (double)n;
         else { double lo = d, hi = 1e15; for (int it = 0; it < 200; it++) { const double mid = std::sqrt(lo * hi); (mid * (1.0 - std::exp(-(double)S / mid)) < (double)d ? lo : hi) = mid; } G = std::min(hi, (double)n); }
       }
-      while (log2_cap < 34 && (double)(1ull << log2_cap) < 2.5 * G) log2_cap++;
+      static const double slack = [] { const char* e = getenv("PLX_STRVIEW_SLACK"); const double v = e ? atof(e) : 0.0; return (v >= 1.2 && v <= 8.0) ? v : 2.5; }();   // slots per expected string
+      while (log2_cap < 34 && (double)(1ull << log2_cap) < slack * G) log2_cap++;
     } else log2_cap = 24;
   }
   for (int attempt = 0; attempt < 8; attempt++) {
