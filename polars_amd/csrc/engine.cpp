@@ -707,7 +707,7 @@ static int64_t run_hash_agg(const Shape& sh, const Args& args, int static_id, in
   Buf ovf = dev_alloc_zero(8);
   k::fill_u64(keys->as<uint64_t>(), slots, kEmptyKey);
   k::init_agg_cells(acc->as<uint64_t>(), slots, sh);
-  HashTable t; t.keys = keys->as<unsigned long long>(); t.acc = acc->as<unsigned long long>(); t.overflow = ovf->as<unsigned int>();
+  HashTable t; t.keys = keys->as<unsigned long long>(); t.acc = acc->as<unsigned long long>(); t.overflow = ovf->as<unsigned int>(); t.wave_combine = 0;
   t.log2_cap = (uint32_t)log2_cap; t.max_probe = (uint32_t)std::min<uint64_t>(cap, 1u << 14);
   k::fused_hash_agg(sh, args, t, static_id);
   uint32_t o = 0; d2h_sync(&o, ovf->ptr, 4);
@@ -767,7 +767,7 @@ static int64_t sample_keys(const Shape& sh, const Args& args, int static_id, int
   Buf keys = dev_alloc(sizeof(uint64_t) * (size_t)slots), acc = dev_alloc(sizeof(uint64_t) * (size_t)slots * sh.n_aggs), ovf = dev_alloc_zero(8);
   k::fill_u64(keys->as<uint64_t>(), slots, kEmptyKey);
   k::init_agg_cells(acc->as<uint64_t>(), slots, sh);
-  HashTable t; t.keys = keys->as<unsigned long long>(); t.acc = acc->as<unsigned long long>(); t.overflow = ovf->as<unsigned int>();
+  HashTable t; t.keys = keys->as<unsigned long long>(); t.acc = acc->as<unsigned long long>(); t.overflow = ovf->as<unsigned int>(); t.wave_combine = 1;
   t.log2_cap = (uint32_t)log2_cap; t.max_probe = 1u << 14;
   const int64_t n = args.n_rows, per = (S / kSampleBlocks) & ~(int64_t)127, stride = (n / kSampleBlocks) & ~(int64_t)127;
   for (int b = 0; b < kSampleBlocks; b++) {

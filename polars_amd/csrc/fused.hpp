@@ -356,6 +356,8 @@ struct HashTable {
   unsigned int* overflow;  // set when a probe sequence exceeds max_probe
   uint32_t log2_cap;
   uint32_t max_probe;
+  uint32_t wave_combine;   // 1: rows of a wave that share a key are combined in registers first, ONE lane updates the table (the
+                           // planner's sample pass: a key holding half of the rows must not cost half a million atomics on one address)
 };
 
 // Wide-key hash aggregation table (group keys that do not pack into one 64-bit word; the

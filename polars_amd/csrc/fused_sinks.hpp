@@ -149,7 +149,49 @@ struct HashAggSink {
     atomicExch(p.overflow, 1u);
     return -1;
   }
+  // wave_combine: groups the wave's rows by key (leader = first unprocessed lane, members = ballot of equal keys), reduces every
+  // aggregate across the members with a shuffle tree and lets the leader alone touch the table.  64 rounds when all keys differ:
+  // only for small inputs where same-address device atomics would dominate (the 2^20-row sample).
+  template <class S, class RF> __device__ __forceinline__ void consume_combined(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+    const uint64_t cap = 1ull << p.log2_cap;
+    const int lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      const bool kvalid = (rf.getv(sh.key) >> r) & 1;
+      const uint64_t key = kvalid ? rf.get(r, sh.key) : 0ull;
+      uint64_t xv[kMaxAggs];      // this row's contribution to every aggregate (the program is a compile-time constant out here)
+#pragma unroll
+      for (int k = 0; k < kMaxAggs; k++) {
+        xv[k] = 0;
+        if (k < sh.n_aggs) { const Agg ag = sh.aggs[k]; xv[k] = agg_row_value(ag.kind, rf.get(r, ag.src), true, (rf.getv(ag.src) >> r) & 1, (uint64_t)(row0 + r)); }
+      }
+      uint64_t todo = ballot(pass[r]);
+      while (todo) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const uint64_t lkey = shfl_u64(key, leader);
+        const bool lvalid = __shfl((int)kvalid, leader, 64) != 0;
+        const bool member = pass[r] && kvalid == lvalid && key == lkey;
+        todo &= ~ballot(member);
+        int64_t slot = -1;
+        if (lane == leader) {
+          if (!kvalid) { slot = (int64_t)cap; p.keys[cap] = 0; }
+          else if (key == kEmptyKey) { slot = (int64_t)cap + 1; p.keys[cap + 1] = 0; }
+          else slot = find_slot(p, key);
+        }
+#pragma unroll
+        for (int k = 0; k < kMaxAggs; k++) {
+          if (k < sh.n_aggs) {
+            uint64_t x = member ? xv[k] : agg_identity_dev(sh.aggs[k].kind);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) x = agg_combine(sh.aggs[k].kind, x, shfl_xor_u64(x, m));
+            if (lane == leader && slot >= 0 && (x != agg_identity_dev(sh.aggs[k].kind) || sh.aggs[k].kind == AGG_SUM_F)) atomic_agg(sh.aggs[k].kind, p.acc + (size_t)slot * sh.n_aggs + k, x);
+          }
+        }
+      }
+    }
+  }
   template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+    if (p.wave_combine) { consume_combined(sh, rf, pass, row0, p); return; }      // uniform branch (kernel argument)
     const uint64_t cap = 1ull << p.log2_cap;
 #pragma unroll
     for (int r = 0; r < kRows; r++) {

@@ -233,7 +233,11 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
     const double per_part = (double)(1u << log2_slots) * 0.62;     // LDS table load <= ~0.62 (the caller passes 1.3 x its estimate)
     uint32_t lp = 6;
     while (lp < 9 && (double)(1u << lp) * per_part < est_groups) lp++;
-    if ((double)(1u << lp) * per_part < est_groups) return false;  // more than 512 partitions: the rings would not fit the LDS
+    // more than 512 partitions: the rings would not fit the LDS.  The estimate already carries the caller's 1.3x, so at 512 partitions
+    // a table load of up to 0.8 is accepted before giving up (1e6 groups sit exactly on the 0.62 boundary: whether the sample's
+    // estimate came out at 0.999e6 or 1.001e6 must not decide which generation of kernels runs); a table that does fill up is
+    // reported by the aggregation pass and the caller falls back
+    if ((double)(1u << lp) * per_part < est_groups && (lp < 9 || (double)(1u << lp) * (double)(1u << log2_slots) * 0.8 < est_groups)) return false;
     if (kEnvLog2Parts > (int)lp && kEnvLog2Parts <= 9) lp = (uint32_t)kEnvLog2Parts;
     pp.log2_parts = lp; pp.log2_slots = log2_slots; pp.key_shift = 0;
   }

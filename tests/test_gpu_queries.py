@@ -564,6 +564,28 @@ def test_partitioned_groupby_skewed_keys(pl, case):
     assert np.array_equal(out["c"].to_numpy()[order].astype(np.int64), cnt)
 
 
+@pytest.mark.parametrize("seed", [10, 20, 31])
+def test_partitioned_v2_is_planned_for_1e6_uniform_keys_whatever_the_sample_says(pl, seed):
+    """BASELINE config 3's shape (1e6 uniform keys) sits exactly on the 512-partition capacity of the LDS hash tables (1.3 x estimate vs
+    512 x 4096 x 0.62): whether the 2^20-row sample estimates 0.999e6 or 1.001e6 groups must not decide which generation of kernels
+    runs (seed 20 estimated just above and fell back to the round-1 three-pass kernels: 18.7 instead of 9.7 ms at 1e9 rows)."""
+    from polars_amd import datagen
+    n = 1 << 25
+    key = datagen.uniform_native(pl, "key", pl.Int64, n, seed, 0, 0, 1_000_000)
+    val = datagen.uniform_native(pl, "val", pl.Int64, n, seed, 1, 0, 1000)
+    df = pl.DataFrame([key, val])
+    out = df.lazy().group_by("key").agg(pl.col("val").sum().alias("s"), pl.len().alias("n")).collect()
+    plan = pl.last_plan()
+    assert "partitioned(v2,hash" in plan, plan
+    k = key.to_numpy(); v = val.to_numpy()
+    gk = out["key"].to_numpy(); order = np.argsort(gk)
+    assert np.array_equal(gk[order], np.unique(k))
+    assert np.array_equal(out["s"].to_numpy()[order], np.bincount(k, weights=v, minlength=1_000_000)[np.unique(k)].astype(np.int64))
+    # the scan also learned the key range: the second run plans dense ids
+    df.lazy().group_by("key").agg(pl.col("val").sum().alias("s"), pl.len().alias("n")).collect()
+    assert "partitioned(v2,direct" in pl.last_plan(), pl.last_plan()
+
+
 def test_partitioned_groupby_direct_mode_dense_ids(pl):
     """Dense packed ids (two narrow key columns + a dictionary column with declared bounds) at >= 2^24 rows: range partitions and
     direct-address LDS tables (no key compare, 4-byte keys in the records); null keys travel as their own code."""
