@@ -149,9 +149,13 @@ struct HashAggSink {
     atomicExch(p.overflow, 1u);
     return -1;
   }
-  // wave_combine: groups the wave's rows by key (leader = first unprocessed lane, members = ballot of equal keys), reduces every
-  // aggregate across the members with a shuffle tree and lets the leader alone touch the table.  64 rounds when all keys differ:
-  // only for small inputs where same-address device atomics would dominate (the 2^20-row sample).
+  // wave_combine: up to kCombineRounds times the first unprocessed lane's key is broadcast, the lanes holding the same key reduce
+  // every aggregate with a shuffle tree and ONE of them keeps the total; then all such leaders update the table together, and
+  // the rows no round reached go the ordinary way.  A key that holds a large share of the rows is almost surely picked in the
+  // first rounds (share f: missed with probability (1 - f)^rounds), which is all this is for: the planner's 2^20-row sample must
+  // not issue half a million device atomics on one address.  No memory operation inside the rounds (a table probe there would
+  // serialise its latency round after round).
+  static constexpr int kCombineRounds = 4;
   template <class S, class RF> __device__ __forceinline__ void consume_combined(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
     const uint64_t cap = 1ull << p.log2_cap;
     const int lane = lane_id();
@@ -165,33 +169,46 @@ struct HashAggSink {
         xv[k] = 0;
         if (k < sh.n_aggs) { const Agg ag = sh.aggs[k]; xv[k] = agg_row_value(ag.kind, rf.get(r, ag.src), true, (rf.getv(ag.src) >> r) & 1, (uint64_t)(row0 + r)); }
       }
+      bool reached = false, keeps_total = false;
       uint64_t todo = ballot(pass[r]);
-      while (todo) {
+#pragma unroll 1
+      for (int round = 0; round < kCombineRounds && todo; round++) {
         const int leader = (int)__builtin_ctzll(todo);
         const uint64_t lkey = shfl_u64(key, leader);
         const bool lvalid = __shfl((int)kvalid, leader, 64) != 0;
-        const bool member = pass[r] && kvalid == lvalid && key == lkey;
+        const bool member = pass[r] && !reached && kvalid == lvalid && key == lkey;
         todo &= ~ballot(member);
-        int64_t slot = -1;
-        if (lane == leader) {
-          if (!kvalid) { slot = (int64_t)cap; p.keys[cap] = 0; }
-          else if (key == kEmptyKey) { slot = (int64_t)cap + 1; p.keys[cap + 1] = 0; }
-          else slot = find_slot(p, key);
-        }
 #pragma unroll
         for (int k = 0; k < kMaxAggs; k++) {
           if (k < sh.n_aggs) {
             uint64_t x = member ? xv[k] : agg_identity_dev(sh.aggs[k].kind);
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) x = agg_combine(sh.aggs[k].kind, x, shfl_xor_u64(x, m));
-            if (lane == leader && slot >= 0 && (x != agg_identity_dev(sh.aggs[k].kind) || sh.aggs[k].kind == AGG_SUM_F)) atomic_agg(sh.aggs[k].kind, p.acc + (size_t)slot * sh.n_aggs + k, x);
+            if (lane == leader) xv[k] = x;          // the leader's own contribution becomes the group's
           }
+        }
+        if (member) reached = true;
+        if (lane == leader) keeps_total = true;
+      }
+      if (!pass[r] || (reached && !keeps_total)) continue;      // another lane carries this row
+      int64_t slot;
+      if (!kvalid) { slot = (int64_t)cap; p.keys[cap] = 0; }
+      else if (key == kEmptyKey) { slot = (int64_t)cap + 1; p.keys[cap + 1] = 0; }
+      else slot = find_slot(p, key);
+      if (slot < 0) continue;
+#pragma unroll
+      for (int k = 0; k < kMaxAggs; k++) {
+        if (k < sh.n_aggs) {
+          const uint8_t kind = sh.aggs[k].kind;
+          if (xv[k] != agg_identity_dev(kind) || kind == AGG_SUM_F) atomic_agg(kind, p.acc + (size_t)slot * sh.n_aggs + k, xv[k]);
         }
       }
     }
   }
   template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
-    if (p.wave_combine) { consume_combined(sh, rf, pass, row0, p); return; }      // uniform branch (kernel argument)
+    if constexpr (std::is_same<RF, RegFile>::value) {      // specialised programs only (the partitioned group-by, whose planner samples, never runs the interpreter)
+      if (p.wave_combine) { consume_combined(sh, rf, pass, row0, p); return; }      // uniform branch (kernel argument)
+    }
     const uint64_t cap = 1ull << p.log2_cap;
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
