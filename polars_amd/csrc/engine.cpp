@@ -760,7 +760,15 @@ static Args offset_args(const Shape& sh, const Args& a, int64_t row0, int64_t ro
   o.n_rows = rows;
   return o;
 }
-static int64_t sample_keys(const Shape& sh, const Args& args, int static_id, int len_idx, int64_t S, std::vector<uint64_t>* hot) {
+// Returns the number of distinct keys in the sample (-1: table overflow).  *groups_est (if given): estimated number of groups of the
+// whole input -- the heavy hitters are taken out of the sample first (estimate_groups assumes equally likely keys: one key holding
+// half of the rows would halve the estimate and the LDS tables planned from it would run at twice their load).
+static int64_t sample_keys(const Shape& full, const Args& args, int static_id, int full_len_idx, int64_t S, std::vector<uint64_t>* hot, double* groups_est = nullptr) {
+  // the sample only counts rows per key: the query's other aggregates are dropped (half the table atomics for a two-aggregate
+  // query), which makes it a different program shape -- 2^20 rows in blocks below the JIT threshold run the interpreter, fast enough
+  Shape sh = full;
+  int len_idx = full_len_idx;
+  if (full_len_idx >= 0 && full.n_aggs > 1) { sh.n_aggs = 1; sh.aggs[0] = full.aggs[full_len_idx]; len_idx = 0; static_id = -1; }
   const int log2_cap = ceil_log2_u64((uint64_t)S) + 1;
   const uint64_t cap = 1ull << log2_cap;
   const int64_t slots = (int64_t)cap + 2;
@@ -777,8 +785,14 @@ static int64_t sample_keys(const Shape& sh, const Args& args, int static_id, int
   }
   uint32_t o = 0; d2h_sync(&o, ovf->ptr, 4);
   if (o) return -1;
-  if (hot) k::select_hot_keys(t, sh.n_aggs, len_idx, (uint64_t)std::max<int64_t>(64, (per * kSampleBlocks) / 1024), hot);
-  return k::table_compact(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, nullptr, nullptr, nullptr);
+  uint64_t hot_rows = 0;
+  if (hot) k::select_hot_keys(t, sh.n_aggs, len_idx, (uint64_t)std::max<int64_t>(64, (per * kSampleBlocks) / 1024), hot, &hot_rows);
+  const int64_t d = k::table_compact(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, nullptr, nullptr, nullptr);
+  if (groups_est) {
+    const double n_hot = hot ? (double)hot->size() : 0.0, s_rest = std::max(1.0, (double)(per * kSampleBlocks) - (double)hot_rows), d_rest = std::max(0.0, (double)d - n_hot);
+    *groups_est = d < 0 ? 1e18 : (d_rest > 0 ? estimate_groups(d_rest, s_rest) : 0.0) + n_hot;
+  }
+  return d;
 }
 static bool probe_late_loads() { static const bool v = [] { const char* e = getenv("PLX_PROBE_LATE"); return !(e && e[0] == '0'); }(); return v; }
 static int part_version() { static const int v = [] { const char* e = getenv("PLX_PART_V"); return (e && e[0] == '1') ? 1 : 2; }(); return v; }
@@ -811,8 +825,9 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
       double est2 = est;
       if (hot_keys_enabled() || kp.total_bits > 25) {
         const int64_t S = kPartSampleRows;
-        const int64_t d = sample_keys(sh, args, static_id, len_idx, S, hot_keys_enabled() ? &hot : nullptr);
-        if (d >= 0) est2 = std::min(est, std::min(estimate_groups((double)d, (double)S), (double)n) * 1.3);
+        double g_est = 1e18;
+        const int64_t d = sample_keys(sh, args, static_id, len_idx, S, hot_keys_enabled() ? &hot : nullptr, &g_est);
+        if (d >= 0) est2 = std::min(est, std::min(g_est, (double)n) * 1.3);
         desc += "sample(distinct=" + std::to_string(d) + ",hot=" + std::to_string(hot.size()) + ")+";
       }
       PartPlan2 p2;
@@ -863,9 +878,10 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     const bool may_partition = !kp.wide && !(c.plan.flags & PLX_PLAN_NO_PARTITION) && n >= ((int64_t)1 << 24);
     const bool strided = may_partition && part_version() == 2;
     const int64_t Sd = strided ? kPartSampleRows : S;
+    double g_est = -1.0;
     int64_t d = kp.wide ? run_wide_agg(sh, sa, 23, kp.wide_nullable, tmp, true)
-                        : (strided ? sample_keys(sh, args, static_id, len_idx, Sd, hot_keys_enabled() ? &hot : nullptr) : run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true));
-    double G = d < 0 ? 1e18 : estimate_groups((double)d, (double)Sd);
+                        : (strided ? sample_keys(sh, args, static_id, len_idx, Sd, hot_keys_enabled() ? &hot : nullptr, &g_est) : run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true));
+    double G = d < 0 ? 1e18 : (g_est >= 0.0 ? g_est : estimate_groups((double)d, (double)Sd));
     G = std::min(G, (double)n);
     log2_cap = std::max(12, ceil_log2_u64((uint64_t)(G * 2.0) + 1));
     desc += "sample(distinct=" + std::to_string(d) + "/" + std::to_string(Sd) + ")+";

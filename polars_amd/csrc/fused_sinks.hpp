@@ -149,13 +149,13 @@ struct HashAggSink {
     atomicExch(p.overflow, 1u);
     return -1;
   }
-  // wave_combine: up to kCombineRounds times the first unprocessed lane's key is broadcast, the lanes holding the same key reduce
+  // wave_combine: up to kCombineRounds (8) times the first unprocessed lane's key is broadcast, the lanes holding the same key reduce
   // every aggregate with a shuffle tree and ONE of them keeps the total; then all such leaders update the table together, and
   // the rows no round reached go the ordinary way.  A key that holds a large share of the rows is almost surely picked in the
   // first rounds (share f: missed with probability (1 - f)^rounds), which is all this is for: the planner's 2^20-row sample must
   // not issue half a million device atomics on one address.  No memory operation inside the rounds (a table probe there would
   // serialise its latency round after round).
-  static constexpr int kCombineRounds = 4;
+  static constexpr int kCombineRounds = 8;
   template <class S, class RF> __device__ __forceinline__ void consume_combined(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
     const uint64_t cap = 1ull << p.log2_cap;
     const int lane = lane_id();
@@ -206,9 +206,7 @@ struct HashAggSink {
     }
   }
   template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
-    if constexpr (std::is_same<RF, RegFile>::value) {      // specialised programs only (the partitioned group-by, whose planner samples, never runs the interpreter)
-      if (p.wave_combine) { consume_combined(sh, rf, pass, row0, p); return; }      // uniform branch (kernel argument)
-    }
+    if (p.wave_combine) { consume_combined(sh, rf, pass, row0, p); return; }      // uniform branch (kernel argument); also in the interpreter: a sample block is below the JIT's row threshold
     const uint64_t cap = 1ull << p.log2_cap;
 #pragma unroll
     for (int r = 0; r < kRows; r++) {

@@ -64,7 +64,8 @@ int64_t partitioned_agg(const fused::Shape& sh, const fused::Args& args, const f
 // second generation (partition2_device.hpp): packed_bits > 0 = the key is a dense packed id of that many bits (direct-address
 // LDS tables when they fit); hot_keys = heavy hitters pre-aggregated in the scatter pass (select_hot_keys on a sample table)
 bool partition_plan2(const fused::Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, fused::PartPlan2* out);
-void select_hot_keys(const fused::HashTable& t, int n_aggs, int len_idx, uint64_t threshold, std::vector<uint64_t>* out);
+// hot_rows: sample rows the returned keys account for
+void select_hot_keys(const fused::HashTable& t, int n_aggs, int len_idx, uint64_t threshold, std::vector<uint64_t>* out, uint64_t* hot_rows = nullptr);
 // key_range_out (may be null): [2] receives the exact signed min / max of the valid keys the scatter pass streamed (hash mode
 // only; min > max when it saw none) -- statistics gathered as a by-product
 int64_t partitioned_agg2(const fused::Shape& sh, const fused::Args& args, const fused::PartPlan2& pp, int static_id, const std::vector<uint64_t>& hot_keys, Buf* out_keys,

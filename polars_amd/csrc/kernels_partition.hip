@@ -290,8 +290,9 @@ __global__ __launch_bounds__(kBlock) void hot_candidates_kernel(const unsigned l
 }
 // keys of the sample table `t` (regular slots only: never the null key or the EMPTY-pattern key) whose row count is at least
 // `threshold`, heaviest first, at most kP2MaxHot.  Synchronises.
-void select_hot_keys(const HashTable& t, int n_aggs, int len_idx, uint64_t threshold, std::vector<uint64_t>* out) {
+void select_hot_keys(const HashTable& t, int n_aggs, int len_idx, uint64_t threshold, std::vector<uint64_t>* out, uint64_t* hot_rows) {
   out->clear();
+  if (hot_rows) *hot_rows = 0;
   if (len_idx < 0) return;
   const unsigned int cap_out = 2048;
   Buf cand = dev_alloc(sizeof(uint64_t) * 2 * cap_out);
@@ -309,7 +310,7 @@ void select_hot_keys(const HashTable& t, int n_aggs, int len_idx, uint64_t thres
   std::vector<std::pair<uint64_t, uint64_t>> v;   // (count, key)
   for (uint32_t i = 0; i < n; i++) v.emplace_back(host[(size_t)i * 2 + 1], host[(size_t)i * 2]);
   std::sort(v.begin(), v.end(), [](const std::pair<uint64_t, uint64_t>& a, const std::pair<uint64_t, uint64_t>& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
-  for (size_t i = 0; i < v.size() && i < kP2MaxHot; i++) out->push_back(v[i].second);
+  for (size_t i = 0; i < v.size() && i < kP2MaxHot; i++) { out->push_back(v[i].second); if (hot_rows) *hot_rows += v[i].first; }
 }
 
 // ---- chunk -> partition map -> per-partition chunk lists (counting sort) ----------------------------------------------

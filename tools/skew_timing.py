@@ -32,10 +32,16 @@ def main():
         q.collect(); q.collect()
         pl.synchronize() if hasattr(pl, "synchronize") else None
         ts = []
+        F = pl._ffi
+        F.check(F.lib().plx_profile_clear()); F.check(F.lib().plx_profile_enable(1))
         for _ in range(7):
             t0 = time.perf_counter(); r = q.collect(); ts.append(time.perf_counter() - t0)
+        F.check(F.lib().plx_synchronize())
+        import bench
+        ks = {k: round(v[1] / 7) for k, v in bench.kernel_stats(pl).items()}      # us per query
+        F.check(F.lib().plx_profile_enable(0))
         ts.sort()
-        out[name] = {"ms_median": round(ts[len(ts) // 2] * 1e3, 3), "ms_min": round(ts[0] * 1e3, 3), "groups": r.height, "plan": pl.last_plan()[:160]}
+        out[name] = {"ms_median": round(ts[len(ts) // 2] * 1e3, 3), "ms_min": round(ts[0] * 1e3, 3), "groups": r.height, "kernel_us": ks, "plan": pl.last_plan()[:160]}
         del df, q, r
     base = out["uniform"]["ms_median"]
     for name in ("zipf_1.1", "one_hot_key_50pct"):
