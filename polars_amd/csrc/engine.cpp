@@ -882,6 +882,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     int64_t d = kp.wide ? run_wide_agg(sh, sa, 23, kp.wide_nullable, tmp, true)
                         : (strided ? sample_keys(sh, args, static_id, len_idx, Sd, hot_keys_enabled() ? &hot : nullptr, &g_est) : run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true));
     double G = d < 0 ? 1e18 : (g_est >= 0.0 ? g_est : estimate_groups((double)d, (double)Sd));
+    if (!hot.empty() && G < 1e17) G *= 2.0;      // heavy hitters mean a heavy tail: the sample undercounts the rare keys (zipf 1.1: by ~2x), and LDS tables at twice their planned load probe long
     G = std::min(G, (double)n);
     log2_cap = std::max(12, ceil_log2_u64((uint64_t)(G * 2.0) + 1));
     desc += "sample(distinct=" + std::to_string(d) + "/" + std::to_string(Sd) + ")+";
