@@ -187,7 +187,13 @@ static Evaluated eval(const Plan& plan, int e, const Frame& df, const std::map<i
       }
       return {x.kind == PLX_AE_IS_NULL ? ops::bool_not(b) : b, c.scalar};
     }
-    case PLX_AE_FILL_NULL: fail(PLX_ERR_UNSUPPORTED, "fill_null outside a fused pipeline (no per-node select kernel on this path yet)");
+    case PLX_AE_FILL_NULL: {
+      Evaluated c = eval(plan, x.lhs, df, overrides);
+      const AE& l = plan.ae.at(x.rhs);
+      PLX_REQUIRE(l.kind == PLX_AE_LITERAL && !l.is_null, PLX_ERR_UNSUPPORTED, "fill_null with a non-literal value");
+      PLX_REQUIRE(l.dtype == c.col->dtype, PLX_ERR_INVALID, std::string("fill_null literal dtype ") + dtype_name(l.dtype) + " differs from the column's " + dtype_name(c.col->dtype));
+      return {ops::fill_null(c.col, l.lit), c.scalar};
+    }
     case PLX_AE_LEN: { ops::ScalarValue s; s.dtype = PLX_U32; s.valid = true; s.v.u = (uint32_t)df.height; return {ops::scalar_column(s), true}; }
     case PLX_AE_AGG: {
       Evaluated c = eval(plan, x.lhs, df, overrides);
@@ -1711,6 +1717,7 @@ static FramePtr exec_node(Plan& plan, int node_id) {
   PLX_REQUIRE(node_id >= 0 && node_id < (int)plan.ir.size(), PLX_ERR_INVALID, "bad IR node index");
   const IRN& n = plan.ir[node_id];
   const bool fuse = !(plan.flags & PLX_PLAN_NO_FUSION);
+  { auto it = plan.memo.find(node_id); if (it != plan.memo.end()) return it->second; }
   switch (n.kind) {
     case PLX_IR_SCAN: return get_frame(n.frame);
     case PLX_IR_FILTER: return exec_filter(plan, n);
@@ -1726,6 +1733,7 @@ static FramePtr exec_node(Plan& plan, int node_id) {
           FramePtr out; std::string why;
           if (fused_select(plan, n, preds, src, out, nullptr, nullptr, &why, false)) return out;
           plan.desc += "(not fused: " + why + ") ";
+          plan.memo[src_node] = src;      // the per-node path below runs the same subtree: once is enough
         }
       }
       return exec_select(plan, n, false);
@@ -1743,6 +1751,7 @@ static FramePtr exec_node(Plan& plan, int node_id) {
         FramePtr out; std::string why;
         if (fused_groupby(plan, n, preds, src, out, nullptr, nullptr, &why, false)) return out;
         plan.desc += "(not fused: " + why + ") ";
+        plan.memo[src_node] = src;
       }
       FramePtr in = exec_node(plan, n.input);
       return exec_groupby_materialised(plan, n, in);

@@ -40,6 +40,7 @@ struct Plan {
   std::vector<AE> ae;
   uint32_t flags = 0;
   std::string desc;  // physical plan description (which kernels / pipelines ran)
+  std::map<int, FramePtr> memo;  // subtrees already executed for a fusion attempt that then fell back: the per-node path reuses them
 };
 
 Plan import_plan(const plx_ir* ir, int n_ir, const plx_aexpr* ae, int n_ae, uint32_t flags);

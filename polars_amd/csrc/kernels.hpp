@@ -31,6 +31,7 @@ void bool_kleene(int op, const uint64_t* lv, const uint64_t* lvalid, const uint6
 void bitmap_blit(uint64_t* dst, int64_t dst_off, const uint64_t* src, int64_t n_bits);
 // out[i] = pattern (width 1/2/4/8 bytes)
 void fill(int width, void* out, uint64_t pattern, int64_t n);
+void fill_null(int width /* 0: bitmap */, const void* in, const uint64_t* validity, uint64_t pattern, int64_t n, void* out);
 void fill_iota_u32(uint32_t* out, int64_t n);
 // result download of small frames: up to kPackMax device buffers are copied into one staging buffer by ONE launch
 constexpr int kPackMax = 32;

@@ -376,6 +376,30 @@ void fill(int width, void* out, uint64_t pattern, int64_t n) {
   PLX_HIP(hipGetLastError());
 }
 
+// fill_null(literal): out[i] = valid(i) ? in[i] : v   (per-node path; fused programs use OP_IFNULL)
+template <class W>
+__global__ __launch_bounds__(kBlock) void fill_null_kernel(const W* __restrict__ in, const uint64_t* __restrict__ validity, W v, int64_t n, W* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = ((validity[i >> 6] >> (i & 63)) & 1) ? in[i] : v;
+}
+__global__ __launch_bounds__(kBlock) void fill_null_bool_kernel(const uint64_t* __restrict__ in, const uint64_t* __restrict__ validity, int v, int64_t n_words, uint64_t* __restrict__ out) {
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * blockDim.x)
+    out[w] = (in[w] & validity[w]) | (v ? ~validity[w] : 0ull);
+}
+void fill_null(int width, const void* in, const uint64_t* validity, uint64_t pattern, int64_t n, void* out) {
+  if (n == 0) return;
+  const int grid = grid_for(n, kBlock * 4);
+  switch (width) {
+    case 0: hipLaunchKernelGGL(fill_null_bool_kernel, dim3(grid_for((n + 63) / 64, kBlock * 4)), dim3(kBlock), 0, stream(), (const uint64_t*)in, validity, (int)(pattern & 1), (n + 63) / 64, (uint64_t*)out); break;
+    case 1: hipLaunchKernelGGL((fill_null_kernel<uint8_t>), dim3(grid), dim3(kBlock), 0, stream(), (const uint8_t*)in, validity, (uint8_t)pattern, n, (uint8_t*)out); break;
+    case 2: hipLaunchKernelGGL((fill_null_kernel<uint16_t>), dim3(grid), dim3(kBlock), 0, stream(), (const uint16_t*)in, validity, (uint16_t)pattern, n, (uint16_t*)out); break;
+    case 4: hipLaunchKernelGGL((fill_null_kernel<uint32_t>), dim3(grid), dim3(kBlock), 0, stream(), (const uint32_t*)in, validity, (uint32_t)pattern, n, (uint32_t*)out); break;
+    case 8: hipLaunchKernelGGL((fill_null_kernel<uint64_t>), dim3(grid), dim3(kBlock), 0, stream(), (const uint64_t*)in, validity, (uint64_t)pattern, n, (uint64_t*)out); break;
+    default: fail(PLX_ERR_INVALID, "fill_null: bad width");
+  }
+  PLX_HIP(hipGetLastError());
+}
+
 __global__ __launch_bounds__(kBlock) void popcount_kernel(const uint64_t* __restrict__ a, int64_t n_bits, unsigned long long* __restrict__ out) {
   const int64_t nwords = (n_bits + 63) >> 6;
   uint64_t acc = 0;

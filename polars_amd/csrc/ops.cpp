@@ -307,6 +307,23 @@ ColumnPtr full_column(int dtype, plx_scalar v, bool valid, int64_t len) {
 }
 ColumnPtr scalar_column(const ScalarValue& s) { return full_column(s.dtype, s.v, s.valid, 1); }
 
+// fill_null(literal) per node (reference: ChunkFillNullValue, polars-core/src/chunked_array/ops/fill_null.rs): same dtype, no nulls left
+ColumnPtr fill_null(const ColumnPtr& c, plx_scalar v) {
+  if (!c->validity || column_null_count(c) == 0) {
+    if (!c->validity) return c;
+    auto same = std::make_shared<Column>(*c);
+    same->validity = nullptr; same->null_count = 0;
+    return same;
+  }
+  auto out = std::make_shared<Column>();
+  out->dtype = c->dtype; out->len = c->len; out->null_count = 0;
+  const int w = dtype_width(c->dtype);
+  out->values = w ? dev_alloc(values_bytes(c->dtype, c->len)) : dev_alloc_zero(bitmap_bytes(c->len));
+  k::fill_null(w, c->values->ptr, c->validity->as<uint64_t>(), v.u, c->len, out->values->ptr);
+  if (c->range_state == 1) out->range_state = 0;      // the literal may lie outside the cached range: recompute on demand
+  return out;
+}
+
 ColumnPtr concat(const std::vector<ColumnPtr>& chunks) {
   PLX_REQUIRE(!chunks.empty(), PLX_ERR_INVALID, "concat: no chunks");
   if (chunks.size() == 1) return chunks[0];

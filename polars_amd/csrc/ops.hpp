@@ -30,6 +30,7 @@ struct ScalarValue { plx_scalar v; int dtype; bool valid; };
 ScalarValue reduce(int agg_op, const ColumnPtr& c);
 ColumnPtr scalar_column(const ScalarValue& s);                 // length-1 column
 ColumnPtr full_column(int dtype, plx_scalar v, bool valid, int64_t len);  // broadcast literal
+ColumnPtr fill_null(const ColumnPtr& c, plx_scalar v);                     // valid ? value : literal (same dtype)
 ColumnPtr concat(const std::vector<ColumnPtr>& chunks);
 ColumnPtr slice_copy(const ColumnPtr& c, int64_t offset, int64_t len);
 

@@ -728,13 +728,17 @@ class LazyFrame:
         (the benchmark loop, a served query) skip the ~125 us of Python lowering."""
         cached = getattr(self, "_c_cache", None)
         if cached is None:
+            from . import io as _io
+            scan = _io.has_file_scan(self._node)
             low, root, schema = self._lower()
             c_arenas = low.to_c()            # file scans are decoded and uploaded here (their frame handles are taken)
-            from . import io as _io
-            if _io.has_file_scan(self._node):   # dictionaries of string columns are only known now: refresh the result schema hints
+            if scan:                         # dictionaries of string columns are only known now: refresh the result schema hints
                 _, schema = P.Lowering().lower_node(self._node)
             cached = (c_arenas, root, schema, low)
-            self._c_cache = cached
+            # A scan source is shared by every LazyFrame derived from the same scan_parquet(): a sibling plan's collect() re-materialises it
+            # (other columns / row groups) and frees the frame this plan's arenas point at -- plans over file scans are lowered afresh.
+            if not scan:
+                self._c_cache = cached
         return cached
 
     def collect(self, *, no_fusion: bool = False, no_direct_join: bool = False, no_partition: bool = False) -> DataFrame:

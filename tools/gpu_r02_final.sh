@@ -20,6 +20,7 @@ for k, v in (d.get("extras") or {}).items():
     if isinstance(v, dict) and "ms_per_step" in v:
         print(" ", k, v["ms_per_step"], "frac", (v.get("roofline") or {}).get("frac"), "cold", v.get("cold_first_step_ms"), "verified", (v.get("verified") or {}).get("ok"))
 PY
+python tools/skew_timing.py 26 2>/dev/null | tail -1 > $OUT/skew_timing_2p26.json; python tools/skew_timing.py 28 2>/dev/null | tail -1 > $OUT/skew_timing_2p28.json; el "skew timing done"
 bash tools/pmc_all.sh r02z q1 q3 q3f cfg2 cfg3 cfg5 cfg5s > $OUT/pmc_all.log 2>&1; el "pmc_all exit $?"
 grep -E "hbm|exit" $OUT/pmc_all.log | head -80
 el "end"
