@@ -888,7 +888,6 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     int64_t d = kp.wide ? run_wide_agg(sh, sa, 23, kp.wide_nullable, tmp, true)
                         : (strided ? sample_keys(sh, args, static_id, len_idx, Sd, hot_keys_enabled() ? &hot : nullptr, &g_est) : run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true));
     double G = d < 0 ? 1e18 : (g_est >= 0.0 ? g_est : estimate_groups((double)d, (double)Sd));
-    if (!hot.empty() && G < 1e17) G *= 2.0;      // heavy hitters mean a heavy tail: the sample undercounts the rare keys (zipf 1.1: by ~2x), and LDS tables at twice their planned load probe long
     G = std::min(G, (double)n);
     log2_cap = std::max(12, ceil_log2_u64((uint64_t)(G * 2.0) + 1));
     desc += "sample(distinct=" + std::to_string(d) + "/" + std::to_string(Sd) + ")+";
@@ -899,7 +898,11 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
       for (auto& a : c.aggs) if (a.second >= 0 && c.nodes[a.second].nullable) any_null = true;
       if (part_version() == 2) {
         PartPlan2 p2;
-        if (k::partition_plan2(sh, G * 1.3, -1, len_idx, n, (int)hot.size(), &p2)) {
+        // heavy hitters mean a heavy tail: the sample undercounts the rare keys (zipf 1.1: by ~2x) and LDS tables at twice their planned
+        // load probe long -- plan for twice the estimate when that still fits the 512-partition limit
+        const bool planned = (!hot.empty() && G < 1e17 && k::partition_plan2(sh, G * 2.6, -1, len_idx, n, (int)hot.size(), &p2)) ||
+                             k::partition_plan2(sh, G * 1.3, -1, len_idx, n, (int)hot.size(), &p2);
+        if (planned) {
           std::string pd;
           Buf ok, okv, oacc;
           // A raw signed-integer key column scanned without a predicate: the scatter pass also records the exact key range, which is

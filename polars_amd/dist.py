@@ -37,6 +37,16 @@ def world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def single_node_rccl_env():
+    """RCCL bootstrap defaults for ONE node (what bench.py and the tests run): the rendezvous sockets go over loopback and the
+    InfiniBand transport is not probed -- a GPU box without a usable NIC otherwise spends minutes (or forever) looking for one.
+    Data never uses these sockets: ranks of one node talk over xGMI.  Only defaults: an explicit environment wins, and nothing is
+    set when MASTER_ADDR names another host."""
+    if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
+
+
 def init_process_group(backend: Optional[str] = None):
     """Rendezvous from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
     import torch
@@ -49,6 +59,8 @@ def init_process_group(backend: Optional[str] = None):
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        single_node_rccl_env()
     dist.init_process_group(backend=backend, rank=rank, world_size=ws)
 
 
@@ -142,6 +154,7 @@ class LibComm:
                 rank, ws = dist.get_rank(group), dist.get_world_size(group)
         except ImportError:
             dist = None
+        single_node_rccl_env()
         ident = (C.c_uint8 * 128)()
         if rank == 0:
             F.check(F.lib().plx_comm_unique_id(ident))
