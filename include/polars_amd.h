@@ -459,6 +459,38 @@ int plx_strdict_free(plx_strdict dict);
  * "id%010d" % (lo + floor(U * (hi - lo))) with the same counter-based U as plx_datagen_uniform(stream) */
 int plx_datagen_id_views(int64_t n_rows, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, plx_column* out_views);
 
+/* ---- Parquet scan -> device columns ------------------------------------
+ * The scan in front of the hot path: the reference decodes Parquet on the CPU (crates/polars-parquet/src/parquet/read/page/reader.rs:183-300
+ * page walk, parquet/read/compression.rs:70-135 decompress, arrow/read/deserialize/{primitive,boolean,dictionary_encoded,binview} decode;
+ * driven by crates/polars-io/src/parquet/read/read_impl.rs and crates/polars-stream/src/nodes/io_sources/parquet).  Here the host reads
+ * METADATA only (footer, page headers, string dictionary pages); the column-chunk bytes travel to HBM as stored -- compressed and
+ * encoded, one DMA per chunk -- and are decoded by kernels: Snappy, RLE / bit-packed hybrid levels and dictionary indices, PLAIN
+ * values, null expansion, integer narrowing.
+ *   plx_parquet_open            footer + schema; works without a GPU (planning / row-group pruning on any machine)
+ *   plx_parquet_column_info     leaf column -> name, plx_dtype (-1: outside the hot path's dtypes: nested, decimal, INT96, ...),
+ *                               logical kind (0 none, 1 Date = days in PLX_I32, 2 Datetime[us] in PLX_I64, 3 String / 4 Binary =
+ *                               PLX_U32 dictionary codes + plx_parquet_categories), nullable.  `name` stays valid until the next
+ *                               call on the same thread.
+ *   plx_parquet_chunk_info      codec, bit mask of the page encodings, sizes, and the chunk statistics as scalars of the column's
+ *                               dtype (has_min_max = 0 when absent or not usable, e.g. strings); null_count -1 = unknown
+ *   plx_parquet_read            row_groups x columns -> frame (rows in row-group order as given).  Codecs: UNCOMPRESSED, SNAPPY;
+ *                               encodings: PLAIN, PLAIN_DICTIONARY / RLE_DICTIONARY, RLE levels; data pages v1 and v2; anything else
+ *                               is PLX_ERR_UNSUPPORTED naming what it met (the caller decodes that file on the host), a malformed
+ *                               file is PLX_ERR_INVALID.  Needs plx_init: there is no host decode path in the library.
+ *   plx_parquet_categories*     dictionary of a String / Binary column as of its last read: offsets[n + 1] + concatenated bytes,
+ *                               index = code (first-appearance order over the chunk dictionaries read) */
+typedef uint64_t plx_parquet;
+int plx_parquet_open(const char* path, plx_parquet* out);
+int plx_parquet_close(plx_parquet file);
+int plx_parquet_shape(plx_parquet file, int64_t* num_rows, int32_t* num_row_groups, int32_t* num_columns);
+int plx_parquet_column_info(plx_parquet file, int32_t column, const char** name, int32_t* dtype, int32_t* logical, int32_t* nullable);
+int plx_parquet_row_group_info(plx_parquet file, int32_t row_group, int64_t* num_rows, int64_t* compressed_bytes);
+int plx_parquet_chunk_info(plx_parquet file, int32_t row_group, int32_t column, int32_t* codec, uint32_t* encodings, int64_t* compressed_bytes,
+                           int64_t* uncompressed_bytes, int32_t* has_min_max, plx_scalar* min, plx_scalar* max, int64_t* null_count);
+int plx_parquet_read(plx_parquet file, const int32_t* row_groups, int32_t n_row_groups, const int32_t* columns, int32_t n_columns, plx_frame* out);
+int plx_parquet_categories(plx_parquet file, int32_t column, int64_t* n_strings, int64_t* total_bytes);
+int plx_parquet_categories_to_host(plx_parquet file, int32_t column, int64_t* offsets, uint8_t* bytes);
+
 /* ---- multi-GPU exchange (one process per GPU, RCCL over xGMI) -----------------------------
  * The exchange step of the sharded operators; shape of the reference's in-process exchange:
  * crates/polars-utils/src/hashing.rs:72-121 (HashPartitioner), crates/polars-stream/src/nodes/group_by.rs:252-497

@@ -1,0 +1,151 @@
+// kernels_parquet.hip -- launch shells of the device Parquet decoder.  The per-thread / per-wavefront bodies live in
+// parquet_device.hpp (host + device, also executed by the CPU harness of the tests); this file only maps them onto the grid.
+//
+//   pq_snappy          one wavefront (64-thread workgroup) per compressed stream: LDS window + element batch, see parquet_device.hpp
+//   pq_page_prepare    one thread per page: split the payload into level / value streams
+//   pq_count_runs      one thread per (page, stream): entries its run table needs       } the only serial walks: run HEADERS of one
+//   pq_fill_runs       one thread per (page, stream): the run table                      } stream of one page
+//   pq_validity        one thread per 64 rows: validity word + its popcount
+//   pq_page_valid0     one thread per page: valid rows before the page (dense-slot base)
+//   pq_decode          one thread per row (coalesced stores), pq_decode_bool one thread per 64 rows
+//
+// Bound: HBM / PCIe -- the decoded column is written once, the encoded bytes are read once or twice (Snappy output is re-read by the
+// decode pass); nothing here is arithmetic.
+#include "dev.hpp"
+#include "kernels.hpp"
+#include "parquet_kernels.hpp"
+
+namespace plx {
+namespace k {
+using namespace pq;
+
+__global__ __launch_bounds__(64) void pq_snappy_kernel(const DecompJob* __restrict__ jobs, uint32_t n_jobs, uint32_t* __restrict__ err) {
+  __shared__ SnapShared sh;
+  if (blockIdx.x >= n_jobs) return;
+  const DecompJob job = jobs[blockIdx.x];
+  const uint32_t lane = threadIdx.x;
+  if (lane == 0) snappy_begin(sh, job);
+  __syncthreads();
+  while (sh.done == 0) {
+    snappy_stage(sh, job, lane);
+    __syncthreads();
+    if (lane == 0) snappy_parse(sh, job);
+    __syncthreads();
+    snappy_copy(sh, job, lane);
+    __threadfence();        // the next round's back-references read what this round's other lanes wrote (stores done, L1 dropped)
+    __syncthreads();
+  }
+  if (lane == 0 && sh.done == 2) atomicOr(err, (uint32_t)PE_SNAPPY);
+}
+
+__global__ __launch_bounds__(kBlock) void pq_page_prepare_kernel(PageDesc* __restrict__ pages, uint32_t n_pages, uint32_t* __restrict__ err) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_pages) return;
+  PageDesc p = pages[i];
+  const uint32_t e = page_prepare(p);
+  pages[i] = p;
+  if (e) atomicOr(err, e);
+}
+
+__global__ __launch_bounds__(kBlock) void pq_count_runs_kernel(const PageDesc* __restrict__ pages, uint32_t n_pages, int levels, uint32_t* __restrict__ counts,
+                                                               uint32_t* __restrict__ err) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= 2 * n_pages) return;
+  uint32_t e = 0;
+  const int s = (int)(t & 1);
+  counts[t] = (s == 0 && !levels) ? 0u : stream_entries(pages[t >> 1], s, &e);
+  if (e) atomicOr(err, e);
+}
+
+__global__ __launch_bounds__(kBlock) void pq_fill_runs_kernel(const PageDesc* __restrict__ pages, uint32_t n_pages, const uint64_t* __restrict__ offs,
+                                                              RunEntry* __restrict__ runs) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= 2 * n_pages) return;
+  const uint32_t n = (uint32_t)(offs[t + 1] - offs[t]);
+  if (n) stream_fill(pages[t >> 1], (int)(t & 1), runs + offs[t], n);
+}
+
+__global__ __launch_bounds__(kBlock) void pq_validity_kernel(const PageDesc* __restrict__ pages, uint32_t n_pages, const RunEntry* __restrict__ runs,
+                                                             const uint64_t* __restrict__ offs, uint64_t n_rows, uint64_t* __restrict__ validity,
+                                                             uint32_t* __restrict__ popc, uint32_t* __restrict__ err) {
+  const uint64_t n_words = (n_rows + 63) >> 6;
+  for (uint64_t w = (uint64_t)blockIdx.x * kBlock + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * kBlock) {
+    uint32_t e = 0;
+    const uint64_t word = validity_word(pages, n_pages, runs, offs, n_rows, w, &e);
+    validity[w] = word;
+    popc[w] = (uint32_t)__popcll(word);
+    if (e) atomicOr(err, e);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void pq_page_valid0_kernel(PageDesc* __restrict__ pages, uint32_t n_pages, const uint64_t* __restrict__ validity,
+                                                                const uint64_t* __restrict__ word_prefix) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_pages) return;
+  pages[i].valid0 = valid_before(validity, word_prefix, pages[i].row0);
+}
+
+__global__ __launch_bounds__(kBlock) void pq_decode_kernel(ColumnDecode c, void* __restrict__ out, uint32_t out_width, uint32_t* __restrict__ err) {
+  uint32_t e = 0;
+  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < c.n_rows; r += (uint64_t)gridDim.x * kBlock) decode_rows(c, out, out_width, r, r + 1, &e);
+  if (e) atomicOr(err, e);
+}
+
+__global__ __launch_bounds__(kBlock) void pq_decode_bool_kernel(ColumnDecode c, uint64_t* __restrict__ out, uint32_t* __restrict__ err) {
+  const uint64_t n_words = (c.n_rows + 63) >> 6;
+  uint32_t e = 0;
+  for (uint64_t w = (uint64_t)blockIdx.x * kBlock + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * kBlock) out[w] = decode_bool_word(c, w, &e);
+  if (e) atomicOr(err, e);
+}
+
+static unsigned blocks_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+void pq_snappy(const DecompJob* jobs, uint32_t n_jobs, uint64_t bytes_out, uint32_t* err) {
+  if (!n_jobs) return;
+  ProfileScope ps("pq_snappy", bytes_out * 2, n_jobs);
+  hipLaunchKernelGGL(pq_snappy_kernel, dim3(n_jobs), dim3(64), 0, stream(), jobs, n_jobs, err);
+  PLX_HIP(hipGetLastError());
+}
+void pq_page_prepare(PageDesc* pages, uint32_t n_pages, uint32_t* err) {
+  if (!n_pages) return;
+  hipLaunchKernelGGL(pq_page_prepare_kernel, dim3(blocks_for(n_pages)), dim3(kBlock), 0, stream(), pages, n_pages, err);
+  PLX_HIP(hipGetLastError());
+}
+void pq_count_runs(const PageDesc* pages, uint32_t n_pages, bool levels, uint32_t* counts, uint32_t* err) {
+  if (!n_pages) return;
+  ProfileScope ps("pq_count_runs", 0, n_pages);
+  hipLaunchKernelGGL(pq_count_runs_kernel, dim3(blocks_for(2ull * n_pages)), dim3(kBlock), 0, stream(), pages, n_pages, levels ? 1 : 0, counts, err);
+  PLX_HIP(hipGetLastError());
+}
+void pq_fill_runs(const PageDesc* pages, uint32_t n_pages, const uint64_t* offs, RunEntry* runs) {
+  if (!n_pages) return;
+  ProfileScope ps("pq_fill_runs", 0, n_pages);
+  hipLaunchKernelGGL(pq_fill_runs_kernel, dim3(blocks_for(2ull * n_pages)), dim3(kBlock), 0, stream(), pages, n_pages, offs, runs);
+  PLX_HIP(hipGetLastError());
+}
+void pq_validity(const PageDesc* pages, uint32_t n_pages, const RunEntry* runs, const uint64_t* offs, uint64_t n_rows, uint64_t* validity, uint32_t* popc, uint32_t* err) {
+  const uint64_t n_words = (n_rows + 63) >> 6;
+  if (!n_words) return;
+  ProfileScope ps("pq_validity", n_words * 12, n_rows);
+  hipLaunchKernelGGL(pq_validity_kernel, dim3(grid_for((int64_t)n_words, kBlock)), dim3(kBlock), 0, stream(), pages, n_pages, runs, offs, n_rows, validity, popc, err);
+  PLX_HIP(hipGetLastError());
+}
+void pq_page_valid0(PageDesc* pages, uint32_t n_pages, const uint64_t* validity, const uint64_t* word_prefix) {
+  if (!n_pages) return;
+  hipLaunchKernelGGL(pq_page_valid0_kernel, dim3(blocks_for(n_pages)), dim3(kBlock), 0, stream(), pages, n_pages, validity, word_prefix);
+  PLX_HIP(hipGetLastError());
+}
+void pq_decode(const ColumnDecode& c, void* out, uint32_t out_width, uint64_t encoded_bytes, uint32_t* err) {
+  if (!c.n_rows) return;
+  if (out_width == 0) {
+    ProfileScope ps("pq_decode_bool", encoded_bytes + c.n_rows / 8, c.n_rows);
+    hipLaunchKernelGGL(pq_decode_bool_kernel, dim3(grid_for((int64_t)((c.n_rows + 63) >> 6), kBlock)), dim3(kBlock), 0, stream(), c, (uint64_t*)out, err);
+  } else {
+    ProfileScope ps("pq_decode", encoded_bytes + c.n_rows * out_width, c.n_rows);
+    hipLaunchKernelGGL(pq_decode_kernel, dim3(grid_for((int64_t)c.n_rows, kBlock, 16)), dim3(kBlock), 0, stream(), c, out, out_width, err);
+  }
+  PLX_HIP(hipGetLastError());
+}
+
+}  // namespace k
+}  // namespace plx

@@ -1,0 +1,245 @@
+// parquet.cpp -- device-side Parquet scan behind the C ABI ("Parquet/IPC scan -> device").
+//
+// plx_parquet_open parses the footer on the host (no GPU needed: metadata, schema and row-group statistics are available for
+// planning / pruning on any machine).  plx_parquet_read moves the selected column chunks to HBM AS STORED (one read + one DMA per
+// chunk through a page-locked double buffer) and decodes them there (parquet_reader.hpp orchestrates, kernels_parquet.hip runs
+// the bodies of parquet_device.hpp).  Reference: crates/polars-io/src/parquet/read/read_impl.rs (row groups x projection),
+// crates/polars-parquet/src/{parquet/read,arrow/read/deserialize}; crates/polars-stream/src/nodes/io_sources/parquet.
+#include <memory>
+#include <mutex>
+
+#include "core.hpp"
+#include "kernels.hpp"
+#include "parquet_kernels.hpp"
+#include "parquet_reader.hpp"
+#include "scan.hpp"
+
+using namespace plx;
+
+namespace {
+
+// HBM + kernel launches on the calling thread's stream
+struct HipBackend {
+  using Mem = Buf;
+  struct Stage { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+  Stage stage_[2];
+  int next_ = 0;
+  uint64_t encoded_bytes = 0;
+
+  ~HipBackend() {
+    for (Stage& s : stage_) {
+      if (s.pending) (void)hipEventSynchronize(s.ev);
+      if (s.ev) (void)hipEventDestroy(s.ev);
+      if (s.p) (void)hipHostFree(s.p);
+    }
+  }
+  Mem alloc(size_t bytes) { return dev_alloc(bytes ? bytes : 8); }
+  uint64_t addr(const Mem& m) { return m ? (uint64_t)m->ptr : 0; }
+  // page-locked staging, two buffers: chunk k + 1 is read from the file while chunk k is on its way to HBM
+  uint8_t* host_stage(size_t bytes) {
+    Stage& s = stage_[next_];
+    next_ ^= 1;
+    if (s.pending) { PLX_HIP(hipEventSynchronize(s.ev)); s.pending = false; }
+    if (s.cap < bytes) {
+      if (s.p) { PLX_HIP(hipHostFree(s.p)); s.p = nullptr; s.cap = 0; }
+      size_t cap = std::max(bytes, size_t(8) << 20);
+      PLX_HIP(hipHostMalloc(&s.p, cap, hipHostMallocDefault));
+      s.cap = cap;
+    }
+    if (!s.ev) PLX_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    return (uint8_t*)s.p;
+  }
+  void upload(uint64_t dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    encoded_bytes += bytes;
+    PLX_HIP(hipMemcpyAsync((void*)dst, src, bytes, hipMemcpyHostToDevice, stream()));
+    for (Stage& s : stage_)
+      if (s.p == src) { PLX_HIP(hipEventRecord(s.ev, stream())); s.pending = true; }
+  }
+  // descriptor arrays from pageable memory: done when this returns
+  void upload_small(uint64_t dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    PLX_HIP(hipMemcpyAsync((void*)dst, src, bytes, hipMemcpyHostToDevice, stream()));
+    PLX_HIP(hipStreamSynchronize(stream()));
+  }
+  void zero(uint64_t dst, size_t bytes) { PLX_HIP(hipMemsetAsync((void*)dst, 0, bytes, stream())); }
+  uint64_t read_u64(uint64_t a) { uint64_t v = 0; d2h_sync(&v, (const void*)a, 8); return v; }
+  uint32_t read_u32(uint64_t a) { uint32_t v = 0; d2h_sync(&v, (const void*)a, 4); return v; }
+  void scan_u32(const uint32_t* in, uint64_t* out, int64_t n) { k::exclusive_scan_u32(in, out, n); }
+
+  void run_snappy(const pq::DecompJob* jobs, uint32_t n, uint64_t bytes_out, uint32_t* err) { k::pq_snappy(jobs, n, bytes_out, err); }
+  void run_page_prepare(pq::PageDesc* pages, uint32_t n, uint32_t* err) { k::pq_page_prepare(pages, n, err); }
+  void run_count_runs(const pq::PageDesc* pages, uint32_t n, bool with_levels, uint32_t* counts, uint32_t* err) { k::pq_count_runs(pages, n, with_levels, counts, err); }
+  void run_fill_runs(const pq::PageDesc* pages, uint32_t n, const uint64_t* offs, pq::RunEntry* runs) { k::pq_fill_runs(pages, n, offs, runs); }
+  void run_validity(const pq::PageDesc* pages, uint32_t n, const pq::RunEntry* runs, const uint64_t* offs, uint64_t n_rows, uint64_t* validity, uint32_t* popc,
+                    uint32_t* err) {
+    k::pq_validity(pages, n, runs, offs, n_rows, validity, popc, err);
+  }
+  void run_page_valid0(pq::PageDesc* pages, uint32_t n, const uint64_t* validity, const uint64_t* prefix) { k::pq_page_valid0(pages, n, validity, prefix); }
+  void run_decode(const pq::ColumnDecode& c, void* out, uint32_t out_width, uint32_t* err) { k::pq_decode(c, out, out_width, encoded_bytes, err); }
+};
+
+std::mutex g_mu;
+std::vector<std::unique_ptr<pq::File>> g_files;   // handle = index + 1
+
+pq::File& get_file(uint64_t h) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (h == 0 || h > g_files.size() || !g_files[h - 1]) fail(PLX_ERR_INVALID, "invalid parquet handle");
+  return *g_files[h - 1];
+}
+
+// per-thread copy of the last column name handed out (the pointer stays valid until the next call on this thread)
+thread_local std::string t_name;
+
+}  // namespace
+
+#define PQ_TRY try {
+#define PQ_CATCH                                                                                   \
+  }                                                                                                \
+  catch (const plx::Error& e) { plx::set_last_error(e.msg); return e.code; }                        \
+  catch (const pq::Unsupported& e) { plx::set_last_error(std::string("parquet: ") + e.what()); return PLX_ERR_UNSUPPORTED; } \
+  catch (const pq::FormatError& e) { plx::set_last_error(std::string("parquet: ") + e.what()); return PLX_ERR_INVALID; }     \
+  catch (const std::bad_alloc&) { plx::set_last_error("host out of memory"); return PLX_ERR_OOM; } \
+  catch (const std::exception& e) { plx::set_last_error(std::string("PANIC: ") + e.what()); return PLX_ERR_INVALID; }        \
+  catch (...) { plx::set_last_error("PANIC"); return PLX_ERR_INVALID; }                             \
+  return PLX_OK;
+
+extern "C" {
+
+int plx_parquet_open(const char* path, plx_parquet* out) {
+  PQ_TRY
+  PLX_REQUIRE(path && out, PLX_ERR_INVALID, "null argument");
+  std::unique_ptr<pq::File> f = pq::open_file(path);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_files.push_back(std::move(f));
+  *out = (plx_parquet)g_files.size();
+  PQ_CATCH
+}
+
+int plx_parquet_close(plx_parquet file) {
+  PQ_TRY
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (file && file <= g_files.size()) g_files[file - 1].reset();
+  PQ_CATCH
+}
+
+int plx_parquet_shape(plx_parquet file, int64_t* num_rows, int32_t* num_row_groups, int32_t* num_columns) {
+  PQ_TRY
+  pq::File& f = get_file(file);
+  if (num_rows) *num_rows = f.md.num_rows;
+  if (num_row_groups) *num_row_groups = (int32_t)f.md.row_groups.size();
+  if (num_columns) *num_columns = (int32_t)f.md.leaves.size();
+  PQ_CATCH
+}
+
+int plx_parquet_column_info(plx_parquet file, int32_t column, const char** name, int32_t* dtype, int32_t* logical, int32_t* nullable) {
+  PQ_TRY
+  pq::File& f = get_file(file);
+  PLX_REQUIRE(column >= 0 && (size_t)column < f.md.leaves.size(), PLX_ERR_INVALID, "parquet column index out of range");
+  const pq::Leaf& l = f.md.leaves[column];
+  const pq::LeafType t = pq::leaf_type(l);
+  if (name) { t_name = l.name; *name = t_name.c_str(); }
+  if (dtype) *dtype = t.dtype;
+  if (logical) *logical = t.logical;
+  if (nullable) *nullable = l.repetition == pq::REP_OPTIONAL ? 1 : 0;
+  PQ_CATCH
+}
+
+int plx_parquet_row_group_info(plx_parquet file, int32_t row_group, int64_t* num_rows, int64_t* compressed_bytes) {
+  PQ_TRY
+  pq::File& f = get_file(file);
+  PLX_REQUIRE(row_group >= 0 && (size_t)row_group < f.md.row_groups.size(), PLX_ERR_INVALID, "parquet row group index out of range");
+  const pq::RowGroup& g = f.md.row_groups[row_group];
+  if (num_rows) *num_rows = g.num_rows;
+  if (compressed_bytes) {
+    int64_t b = 0;
+    for (const pq::ColumnChunk& c : g.columns) b += c.total_compressed_size;
+    *compressed_bytes = b;
+  }
+  PQ_CATCH
+}
+
+int plx_parquet_chunk_info(plx_parquet file, int32_t row_group, int32_t column, int32_t* codec, uint32_t* encodings, int64_t* compressed_bytes,
+                           int64_t* uncompressed_bytes, int32_t* has_min_max, plx_scalar* min, plx_scalar* max, int64_t* null_count) {
+  PQ_TRY
+  pq::File& f = get_file(file);
+  PLX_REQUIRE(row_group >= 0 && (size_t)row_group < f.md.row_groups.size(), PLX_ERR_INVALID, "parquet row group index out of range");
+  PLX_REQUIRE(column >= 0 && (size_t)column < f.md.leaves.size(), PLX_ERR_INVALID, "parquet column index out of range");
+  const pq::ColumnChunk& c = f.md.row_groups[row_group].columns[column];
+  if (codec) *codec = c.codec;
+  if (encodings) *encodings = c.encodings;
+  if (compressed_bytes) *compressed_bytes = c.total_compressed_size;
+  if (uncompressed_bytes) *uncompressed_bytes = c.total_uncompressed_size;
+  plx_scalar mn, mx;
+  mn.u = mx.u = 0;
+  const bool has = pq::chunk_min_max(f.md.leaves[column], c, &mn, &mx);
+  if (has_min_max) *has_min_max = has ? 1 : 0;
+  if (min) *min = mn;
+  if (max) *max = mx;
+  if (null_count) *null_count = c.stats.has_null_count ? c.stats.null_count : -1;
+  PQ_CATCH
+}
+
+int plx_parquet_read(plx_parquet file, const int32_t* row_groups, int32_t n_row_groups, const int32_t* columns, int32_t n_columns, plx_frame* out) {
+  PQ_TRY
+  PLX_REQUIRE(out && (columns || n_columns == 0) && (row_groups || n_row_groups == 0), PLX_ERR_INVALID, "null argument");
+  pq::File& f = get_file(file);
+  device();   // fails loudly without a GPU: there is no host decode path in the library
+  std::vector<int> rgs(row_groups, row_groups + n_row_groups);
+  auto frame = std::make_shared<Frame>();
+  try {
+    for (int32_t i = 0; i < n_columns; i++) {
+      check_cancel();
+      HipBackend be;
+      pq::ReadStats st;
+      pq::ColumnResult<HipBackend> r = pq::read_column(be, f, rgs, columns[i], &st);
+      auto col = std::make_shared<Column>();
+      col->dtype = r.dtype; col->len = r.len; col->values = r.values;
+      if (r.has_validity) col->validity = r.validity;
+      col->null_count = r.null_count;
+      frame->names.push_back(f.md.leaves[columns[i]].name);
+      frame->cols.push_back(col);
+      frame->height = r.len;
+    }
+  } catch (...) {
+    (void)hipStreamSynchronize(stream());   // descriptor vectors / staging of the failed column may still be in flight
+    throw;
+  }
+  if (n_columns == 0) {
+    int64_t n = 0;
+    for (int g : rgs) { PLX_REQUIRE(g >= 0 && (size_t)g < f.md.row_groups.size(), PLX_ERR_INVALID, "parquet row group index out of range"); n += f.md.row_groups[g].num_rows; }
+    frame->height = n;
+  }
+  *out = register_frame(frame);
+  PQ_CATCH
+}
+
+int plx_parquet_categories(plx_parquet file, int32_t column, int64_t* n_strings, int64_t* total_bytes) {
+  PQ_TRY
+  pq::File& f = get_file(file);
+  auto it = f.categories.find(column);
+  PLX_REQUIRE(it != f.categories.end(), PLX_ERR_NOT_FOUND, "no string dictionary: the column has not been read (or is not a string column)");
+  int64_t b = 0;
+  for (const std::string& s : it->second) b += (int64_t)s.size();
+  if (n_strings) *n_strings = (int64_t)it->second.size();
+  if (total_bytes) *total_bytes = b;
+  PQ_CATCH
+}
+
+int plx_parquet_categories_to_host(plx_parquet file, int32_t column, int64_t* offsets, uint8_t* bytes) {
+  PQ_TRY
+  pq::File& f = get_file(file);
+  auto it = f.categories.find(column);
+  PLX_REQUIRE(it != f.categories.end(), PLX_ERR_NOT_FOUND, "no string dictionary: the column has not been read (or is not a string column)");
+  PLX_REQUIRE(offsets, PLX_ERR_INVALID, "null offsets pointer");
+  int64_t off = 0, i = 0;
+  for (const std::string& s : it->second) {
+    offsets[i++] = off;
+    if (!s.empty()) { PLX_REQUIRE(bytes, PLX_ERR_INVALID, "null bytes pointer"); memcpy(bytes + off, s.data(), s.size()); }
+    off += (int64_t)s.size();
+  }
+  offsets[i] = off;
+  PQ_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,486 @@
+// parquet_reader.hpp -- Parquet column chunks -> device columns, host orchestration.
+//
+// The host only touches METADATA: the footer (parquet_format.hpp), the Thrift page headers inside each column chunk, and the
+// dictionary pages of string columns (a few KB each, unified into one column-wide dictionary).  The chunk bytes themselves go to HBM
+// exactly as they are in the file -- compressed, encoded -- in one copy per chunk, and everything else happens there
+// (parquet_device.hpp): Snappy, level / index run tables, validity, dense -> row expansion, dictionary lookup, integer narrowing.
+//
+// `read_column<B>` is a template over the execution backend B (HBM + kernel launches in parquet.cpp; host memory + the same bodies
+// run thread by thread in tests/emu/parquet_emu.cpp), so the page walk, the stream planning and the dictionary handling below are
+// what the CPU tests execute.
+//
+// Reference shape: crates/polars-parquet/src/parquet/read/page/reader.rs:183-300 (page iteration of a chunk),
+// parquet/read/compression.rs:70-135 (decompress per page), arrow/read/deserialize/{primitive,boolean,dictionary_encoded,binview}
+// (decode per page into an Arrow array), crates/polars-io/src/parquet/read/read_impl.rs (row groups x projected columns).
+#pragma once
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/polars_amd.h"
+#include "parquet_device.hpp"
+#include "parquet_format.hpp"
+
+namespace plx {
+namespace pq {
+
+struct Unsupported : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+// ---- file ---------------------------------------------------------------------------------------------------------------------------
+struct File {
+  std::string path;
+  int fd = -1;
+  int64_t size = 0;
+  FileMetaData md;
+  // column-wide dictionaries of the string columns read last (leaf index -> categories)
+  std::unordered_map<int, std::vector<std::string>> categories;
+  ~File() { if (fd >= 0) ::close(fd); }
+
+  void pread_exact(void* dst, size_t n, int64_t off) const {
+    uint8_t* p = (uint8_t*)dst;
+    while (n) {
+      ssize_t got = ::pread(fd, p, n, off);
+      if (got <= 0) throw FormatError("short read from " + path);
+      p += got; off += got; n -= (size_t)got;
+    }
+  }
+};
+
+inline std::unique_ptr<File> open_file(const std::string& path) {
+  auto f = std::make_unique<File>();
+  f->path = path;
+  f->fd = ::open(path.c_str(), O_RDONLY);
+  if (f->fd < 0) throw FormatError("cannot open " + path);
+  struct stat st;
+  if (::fstat(f->fd, &st) != 0) throw FormatError("cannot stat " + path);
+  f->size = st.st_size;
+  if (f->size < 12) throw FormatError(path + " is too small to be a Parquet file");
+  uint8_t tail[8];
+  f->pread_exact(tail, 8, f->size - 8);
+  if (memcmp(tail + 4, "PAR1", 4) != 0) {
+    if (memcmp(tail + 4, "PARE", 4) == 0) throw Unsupported("encrypted Parquet footer");
+    throw FormatError(path + " does not end with the PAR1 magic");
+  }
+  uint32_t flen = load_u32(tail);
+  if ((int64_t)flen + 12 > f->size) throw FormatError("footer length past the start of the file");
+  std::vector<uint8_t> footer(flen);
+  f->pread_exact(footer.data(), flen, f->size - 8 - flen);
+  f->md = parse_file_metadata(footer.data(), flen);
+  return f;
+}
+
+// ---- leaf -> device dtype -------------------------------------------------------------------------------------------------------------
+enum LogicalOut { LO_NONE = 0, LO_DATE = 1, LO_DATETIME_US = 2, LO_STRING = 3, LO_BINARY = 4 };
+
+struct LeafType {
+  int dtype = -1;          // plx_dtype, -1: outside the hot path (why says what it is)
+  int logical = LO_NONE;
+  uint32_t src_width = 0;  // bytes per PLAIN value in the file (0: bit-packed booleans / byte arrays)
+  std::string why;
+};
+
+inline LeafType leaf_type(const Leaf& l) {
+  LeafType t;
+  if (l.nested) { t.why = "nested / repeated column"; return t; }
+  switch (l.type) {
+    case PT_BOOLEAN: t.dtype = PLX_BOOL; t.src_width = 0; return t;
+    case PT_INT32:
+      t.src_width = 4;
+      if (l.logical == LG_NONE) { t.dtype = PLX_I32; return t; }
+      if (l.logical == LG_DATE) { t.dtype = PLX_I32; t.logical = LO_DATE; return t; }
+      if (l.logical == LG_INT && l.int_bits <= 32) {
+        t.dtype = l.int_bits == 8 ? (l.int_signed ? PLX_I8 : PLX_U8) : l.int_bits == 16 ? (l.int_signed ? PLX_I16 : PLX_U16) : (l.int_signed ? PLX_I32 : PLX_U32);
+        return t;
+      }
+      t.why = l.logical == LG_DECIMAL ? "decimal" : "annotated INT32";
+      return t;
+    case PT_INT64:
+      t.src_width = 8;
+      if (l.logical == LG_NONE) { t.dtype = PLX_I64; return t; }
+      if (l.logical == LG_INT && l.int_bits == 64) { t.dtype = l.int_signed ? PLX_I64 : PLX_U64; return t; }
+      if (l.logical == LG_TIMESTAMP_MICROS) { t.dtype = PLX_I64; t.logical = LO_DATETIME_US; return t; }
+      t.why = l.logical == LG_DECIMAL ? "decimal" : (l.logical == LG_TIMESTAMP_MILLIS || l.logical == LG_TIMESTAMP_NANOS) ? "timestamp unit other than us" : "annotated INT64";
+      return t;
+    case PT_FLOAT: t.dtype = PLX_F32; t.src_width = 4; return t;
+    case PT_DOUBLE: t.dtype = PLX_F64; t.src_width = 8; return t;
+    case PT_BYTE_ARRAY:
+      if (l.logical == LG_STRING || l.logical == LG_NONE) { t.dtype = PLX_U32; t.logical = l.logical == LG_STRING ? LO_STRING : LO_BINARY; return t; }
+      t.why = "annotated BYTE_ARRAY";
+      return t;
+    case PT_INT96: t.why = "INT96 timestamp"; return t;
+    default: t.why = "FIXED_LEN_BYTE_ARRAY"; return t;
+  }
+}
+
+inline uint32_t out_width_of(int dtype) {
+  switch (dtype) {
+    case PLX_BOOL: return 0;
+    case PLX_I8: case PLX_U8: return 1;
+    case PLX_I16: case PLX_U16: return 2;
+    case PLX_I32: case PLX_U32: case PLX_F32: return 4;
+    default: return 8;
+  }
+}
+
+// ---- host Snappy (string dictionary pages only: a few KB per chunk) ---------------------------------------------------------------------------
+inline std::vector<uint8_t> snappy_decompress_host(const uint8_t* in, size_t n, size_t expect) {
+  size_t pos = 0, out_len = 0;
+  for (int shift = 0;; shift += 7) {
+    if (pos >= n || shift > 28) throw FormatError("snappy: bad preamble");
+    uint8_t b = in[pos++];
+    out_len |= (size_t)(b & 0x7f) << shift;
+    if (!(b & 0x80)) break;
+  }
+  if (out_len != expect) throw FormatError("snappy: uncompressed length differs from the page header");
+  std::vector<uint8_t> out(out_len);
+  size_t o = 0;
+  while (pos < n) {
+    uint8_t tag = in[pos++];
+    size_t len, off = 0;
+    if ((tag & 3) == 0) {
+      len = (tag >> 2) + 1;
+      if (len > 60) {
+        size_t nb = len - 60;
+        if (pos + nb > n) throw FormatError("snappy: truncated literal length");
+        len = 0;
+        for (size_t b = 0; b < nb; b++) len |= (size_t)in[pos + b] << (8 * b);
+        len += 1; pos += nb;
+      }
+      if (len > n - pos || len > out_len - o) throw FormatError("snappy: literal past the end");
+      memcpy(out.data() + o, in + pos, len);
+      pos += len; o += len;
+      continue;
+    }
+    if ((tag & 3) == 1) {
+      if (pos + 1 > n) throw FormatError("snappy: truncated copy");
+      len = ((tag >> 2) & 7) + 4; off = ((size_t)(tag >> 5) << 8) | in[pos]; pos += 1;
+    } else if ((tag & 3) == 2) {
+      if (pos + 2 > n) throw FormatError("snappy: truncated copy");
+      len = (tag >> 2) + 1; off = in[pos] | ((size_t)in[pos + 1] << 8); pos += 2;
+    } else {
+      if (pos + 4 > n) throw FormatError("snappy: truncated copy");
+      len = (tag >> 2) + 1; off = load_u32(in + pos); pos += 4;
+    }
+    if (off == 0 || off > o || len > out_len - o) throw FormatError("snappy: bad back-reference");
+    for (size_t i = 0; i < len; i++) out[o + i] = out[o - off + i];
+    o += len;
+  }
+  if (o != out_len) throw FormatError("snappy: stream ends early");
+  return out;
+}
+
+// ---- read one column --------------------------------------------------------------------------------------------------------------------
+struct ReadStats {
+  uint64_t file_bytes = 0, data_pages = 0, dict_pages = 0, snappy_streams = 0, snappy_bytes_out = 0, run_entries = 0;
+};
+
+template <class B> struct ColumnResult {
+  typename B::Mem values;
+  typename B::Mem validity;      // empty: no nulls
+  bool has_validity = false;
+  int dtype = PLX_I64;
+  int logical = LO_NONE;
+  int64_t len = 0;
+  int64_t null_count = 0;
+};
+
+inline std::string error_bits_text(uint32_t e) {
+  std::string s;
+  auto add = [&](uint32_t bit, const char* t) { if (e & bit) { if (!s.empty()) s += ", "; s += t; } };
+  add(PE_LEVELS, "definition levels do not cover the page");
+  add(PE_RUNS, "malformed RLE / bit-packed run header");
+  add(PE_VALUES, "value bytes missing");
+  add(PE_DICT_INDEX, "dictionary index out of range");
+  add(PE_SNAPPY, "malformed Snappy stream");
+  add(PE_DEF_LEVEL, "definition level > 1 in a flat column");
+  return s;
+}
+
+inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector<int>& row_groups, int leaf_idx, ReadStats* stats) {
+  const FileMetaData& md = f.md;
+  if (leaf_idx < 0 || (size_t)leaf_idx >= md.leaves.size()) throw FormatError("column index out of range");
+  const Leaf& leaf = md.leaves[leaf_idx];
+  const LeafType lt = leaf_type(leaf);
+  if (lt.dtype < 0) throw Unsupported("column '" + leaf.name + "': " + lt.why + " is outside the hot path's dtypes");
+  const bool is_bytes = leaf.type == PT_BYTE_ARRAY;
+  const bool optional = leaf.repetition == REP_OPTIONAL;
+
+  ColumnResult<B> res;
+  res.dtype = lt.dtype; res.logical = lt.logical;
+
+  // -- plan: chunk placement in the blob ------------------------------------------------------------------------------------------------
+  struct ChunkRef { const ColumnChunk* c; int64_t rows; size_t blob_off; };
+  std::vector<ChunkRef> chunks;
+  size_t blob_bytes = 0;
+  int64_t n_rows = 0;
+  bool nulls_possible = false;
+  for (int g : row_groups) {
+    if (g < 0 || (size_t)g >= md.row_groups.size()) throw FormatError("row group index out of range");
+    const RowGroup& rg = md.row_groups[g];
+    const ColumnChunk& c = rg.columns[leaf_idx];
+    if (!c.has_meta) throw FormatError("column chunk without metadata");
+    if (c.external_file) throw Unsupported("column chunk stored in another file");
+    if (c.type != leaf.type) throw FormatError("column chunk type differs from the schema");
+    if (c.codec != CODEC_UNCOMPRESSED && c.codec != CODEC_SNAPPY)
+      throw Unsupported(std::string("column '") + leaf.name + "': codec " + codec_name(c.codec) + " has no device decompressor (UNCOMPRESSED and SNAPPY do)");
+    if (c.num_values != rg.num_rows) throw FormatError("flat column chunk whose value count differs from the row group's rows");
+    if (c.start() < 4 || c.total_compressed_size < 0 || c.start() + c.total_compressed_size > f.size - 8) throw FormatError("column chunk outside the file");
+    chunks.push_back({&c, rg.num_rows, blob_bytes});
+    blob_bytes += align16((size_t)c.total_compressed_size);
+    n_rows += rg.num_rows;
+    if (optional && !(c.stats.has_null_count && c.stats.null_count == 0)) nulls_possible = true;
+  }
+  res.len = n_rows;
+  if (n_rows >= (int64_t)1 << 40) throw Unsupported("more than 2^40 rows in one read");
+  const uint32_t out_width = out_width_of(lt.dtype);
+  auto out_bytes = [&](int64_t n) { return lt.dtype == PLX_BOOL ? (size_t)(((n + 63) / 64) * 8 + 8) : (size_t)n * out_width; };
+  if (n_rows == 0) {
+    res.values = be.alloc(out_bytes(0));
+    if (is_bytes) f.categories[leaf_idx].clear();
+    return res;
+  }
+
+  typename B::Mem blob = be.alloc(blob_bytes + 64);
+  const uint64_t blob_addr = be.addr(blob);
+
+  // -- page walk (host, headers only) + upload of the chunk bytes as they are -------------------------------------------------------------
+  std::vector<PageDesc> pages;
+  std::vector<DictDesc> dicts;
+  std::vector<DecompJob> jobs;
+  std::vector<size_t> job_of_page;            // per page: index into jobs or npos
+  std::vector<size_t> job_of_dict;            // per dict
+  std::vector<uint32_t> remap;                // string columns: concatenated chunk-dictionary -> column code tables
+  std::vector<size_t> remap_base_of_dict;     // per dict (strings)
+  std::vector<std::string> categories;
+  std::unordered_map<std::string, uint32_t> cat_index;
+  const size_t npos = (size_t)-1;
+  uint64_t row0 = 0;
+  for (const ChunkRef& ch : chunks) {
+    const ColumnChunk& c = *ch.c;
+    const size_t sz = (size_t)c.total_compressed_size;
+    uint8_t* host = be.host_stage(sz + 16);
+    f.pread_exact(host, sz, c.start());
+    if (stats) stats->file_bytes += sz;
+    const bool codec_on = c.codec != CODEC_UNCOMPRESSED;
+    size_t pos = 0;
+    int64_t seen = 0;
+    size_t chunk_dict = npos;
+    while (seen < c.num_values) {
+      if (pos >= sz) throw FormatError("column chunk ends before all its values were found");
+      PageHeader h = parse_page_header(host + pos, sz - pos);
+      pos += h.header_bytes;
+      if ((size_t)h.compressed_size > sz - pos) throw FormatError("page runs past its column chunk");
+      const uint64_t payload = blob_addr + ch.blob_off + pos;
+      if (h.type == PAGE_DICTIONARY) {
+        if (chunk_dict != npos) throw FormatError("two dictionary pages in one column chunk");
+        if (h.encoding != ENC_PLAIN && h.encoding != ENC_PLAIN_DICTIONARY) throw Unsupported(std::string("dictionary page encoding ") + encoding_name(h.encoding));
+        DictDesc d{};
+        d.n = (uint32_t)h.num_values;
+        chunk_dict = dicts.size();
+        if (is_bytes) {
+          // strings: the host reads the (small) dictionary, assigns column-wide codes in first-appearance order
+          std::vector<uint8_t> plain;
+          const uint8_t* p = host + pos;
+          size_t n = (size_t)h.compressed_size;
+          if (codec_on) { plain = snappy_decompress_host(p, n, (size_t)h.uncompressed_size); p = plain.data(); n = plain.size(); }
+          remap_base_of_dict.push_back(remap.size());
+          size_t q = 0;
+          for (uint32_t i = 0; i < d.n; i++) {
+            if (q + 4 > n) throw FormatError("string dictionary page ends early");
+            uint32_t len = load_u32(p + q);
+            q += 4;
+            if (len > n - q) throw FormatError("string dictionary entry runs past the page");
+            std::string s((const char*)p + q, len);
+            q += len;
+            auto it = cat_index.find(s);
+            uint32_t code;
+            if (it == cat_index.end()) { code = (uint32_t)categories.size(); cat_index.emplace(s, code); categories.push_back(std::move(s)); }
+            else code = it->second;
+            remap.push_back(code);
+          }
+          job_of_dict.push_back(npos);
+        } else {
+          if ((uint64_t)d.n * lt.src_width > (uint64_t)h.uncompressed_size && lt.src_width) throw FormatError("dictionary page smaller than its entry count");
+          if (lt.src_width == 0) throw Unsupported("dictionary-encoded booleans");
+          d.values = payload;
+          if (codec_on) {
+            job_of_dict.push_back(jobs.size());
+            jobs.push_back(DecompJob{payload, 0, (uint32_t)h.compressed_size, (uint32_t)h.uncompressed_size});
+          } else job_of_dict.push_back(npos);
+          remap_base_of_dict.push_back(npos);
+        }
+        dicts.push_back(d);
+        if (stats) stats->dict_pages++;
+      } else if (h.type == PAGE_DATA || h.type == PAGE_DATA_V2) {
+        PageDesc p{};
+        const bool v2 = h.type == PAGE_DATA_V2;
+        p.src = payload; p.comp_size = (uint32_t)h.compressed_size; p.uncomp_size = (uint32_t)h.uncompressed_size;
+        p.num_values = (uint32_t)h.num_values; p.row0 = row0 + (uint64_t)seen;
+        p.flags = (v2 ? PF_V2 : 0u) | (optional ? PF_HAS_DEF : 0u);
+        if (h.encoding == ENC_PLAIN_DICTIONARY || h.encoding == ENC_RLE_DICTIONARY) {
+          if (chunk_dict == npos) throw FormatError("dictionary-encoded page without a dictionary page");
+          p.flags |= PF_DICT; p.dict = (uint32_t)chunk_dict;
+        } else if (h.encoding == ENC_PLAIN) {
+          if (is_bytes) throw Unsupported("column '" + leaf.name + "': PLAIN (not dictionary-encoded) string pages");
+        } else {
+          throw Unsupported("column '" + leaf.name + "': page encoding " + encoding_name(h.encoding));
+        }
+        size_t job = npos;
+        if (v2) {
+          if (h.rep_len != 0) throw Unsupported("repetition levels in a flat column");
+          if (h.def_len < 0 || h.def_len > h.compressed_size) throw FormatError("v2 level bytes exceed the page");
+          if (!optional && h.def_len != 0) throw FormatError("definition levels in a required column");
+          p.v2_def_len = (uint32_t)h.def_len;
+          if (codec_on && h.is_compressed) {
+            p.flags |= PF_COMPRESSED;
+            job = jobs.size();
+            jobs.push_back(DecompJob{payload + (uint64_t)h.def_len, 0, (uint32_t)(h.compressed_size - h.def_len), (uint32_t)(h.uncompressed_size - h.def_len)});
+            if (h.uncompressed_size < h.def_len) throw FormatError("v2 page smaller than its level bytes");
+          }
+        } else {
+          if (optional && h.def_encoding != ENC_RLE) throw Unsupported(std::string("definition levels encoded as ") + encoding_name(h.def_encoding));
+          if (codec_on) {
+            p.flags |= PF_COMPRESSED;
+            job = jobs.size();
+            jobs.push_back(DecompJob{payload, 0, (uint32_t)h.compressed_size, (uint32_t)h.uncompressed_size});
+          }
+        }
+        if (!codec_on && h.compressed_size != h.uncompressed_size) throw FormatError("uncompressed page whose two sizes differ");
+        job_of_page.push_back(job);
+        pages.push_back(p);
+        seen += h.num_values;
+        if (stats) stats->data_pages++;
+      }  // index pages and unknown page types are skipped
+      pos += (size_t)h.compressed_size;
+    }
+    if (seen != c.num_values) throw FormatError("pages of a column chunk hold more values than its metadata says");
+    be.upload(blob_addr + ch.blob_off, host, sz);
+    row0 += (uint64_t)ch.rows;
+  }
+
+  // -- scratch for the decompressed streams ---------------------------------------------------------------------------------------------
+  typename B::Mem scratch{};
+  if (!jobs.empty()) {
+    size_t total = 0;
+    std::vector<size_t> off(jobs.size());
+    for (size_t j = 0; j < jobs.size(); j++) { off[j] = total; total += align16((size_t)jobs[j].uncomp_size + 16); }
+    scratch = be.alloc(total + 64);
+    const uint64_t base = be.addr(scratch);
+    for (size_t j = 0; j < jobs.size(); j++) jobs[j].dst = base + off[j];
+    for (size_t i = 0; i < pages.size(); i++) if (job_of_page[i] != npos) pages[i].dst = jobs[job_of_page[i]].dst;
+    for (size_t i = 0; i < dicts.size(); i++) if (job_of_dict[i] != npos) dicts[i].values = jobs[job_of_dict[i]].dst;
+    if (stats) { stats->snappy_streams += jobs.size(); for (auto& j : jobs) stats->snappy_bytes_out += j.uncomp_size; }
+  }
+  typename B::Mem remap_mem{};
+  if (is_bytes) {
+    remap_mem = be.alloc(remap.size() * 4 + 64);
+    if (!remap.empty()) be.upload_small(be.addr(remap_mem), remap.data(), remap.size() * 4);
+    for (size_t i = 0; i < dicts.size(); i++) dicts[i].values = be.addr(remap_mem) + remap_base_of_dict[i] * 4;
+    f.categories[leaf_idx] = std::move(categories);
+  }
+
+  const uint32_t n_pages = (uint32_t)pages.size();
+  typename B::Mem pages_mem = be.alloc(pages.size() * sizeof(PageDesc) + 64);
+  typename B::Mem dicts_mem = be.alloc(dicts.size() * sizeof(DictDesc) + 64);
+  typename B::Mem jobs_mem = be.alloc(jobs.size() * sizeof(DecompJob) + 64);
+  typename B::Mem err_mem = be.alloc(64);
+  be.upload_small(be.addr(pages_mem), pages.data(), pages.size() * sizeof(PageDesc));
+  if (!dicts.empty()) be.upload_small(be.addr(dicts_mem), dicts.data(), dicts.size() * sizeof(DictDesc));
+  if (!jobs.empty()) be.upload_small(be.addr(jobs_mem), jobs.data(), jobs.size() * sizeof(DecompJob));
+  be.zero(be.addr(err_mem), 64);
+  uint32_t* err = (uint32_t*)be.addr(err_mem);
+
+  // -- device passes ----------------------------------------------------------------------------------------------------------------------
+  if (!jobs.empty()) {
+    uint64_t bytes_out = 0;
+    for (const DecompJob& j : jobs) bytes_out += j.uncomp_size;
+    be.run_snappy((const DecompJob*)be.addr(jobs_mem), (uint32_t)jobs.size(), bytes_out, err);
+  }
+  PageDesc* d_pages = (PageDesc*)be.addr(pages_mem);
+  be.run_page_prepare(d_pages, n_pages, err);
+  // run tables: entries per (page, stream) -> exclusive prefix -> fill
+  typename B::Mem counts = be.alloc((size_t)n_pages * 2 * 4 + 64);
+  typename B::Mem offs = be.alloc(((size_t)n_pages * 2 + 1) * 8 + 64);
+  be.run_count_runs(d_pages, n_pages, nulls_possible, (uint32_t*)be.addr(counts), err);   // level tables only when nulls are possible
+  be.scan_u32((const uint32_t*)be.addr(counts), (uint64_t*)be.addr(offs), (int64_t)n_pages * 2);
+  const uint64_t n_entries = be.read_u64(be.addr(offs) + (uint64_t)n_pages * 2 * 8);
+  if (stats) stats->run_entries += n_entries;
+  typename B::Mem runs = be.alloc((size_t)n_entries * sizeof(RunEntry) + 64);
+  be.run_fill_runs(d_pages, n_pages, (const uint64_t*)be.addr(offs), (RunEntry*)be.addr(runs));
+
+  const uint64_t n_words = ((uint64_t)n_rows + 63) / 64;
+  typename B::Mem word_prefix{};
+  const uint64_t* d_validity = nullptr;
+  const uint64_t* d_prefix = nullptr;
+  if (nulls_possible) {
+    res.validity = be.alloc((size_t)n_words * 8 + 8);
+    res.has_validity = true;
+    typename B::Mem popc = be.alloc((size_t)n_words * 4 + 64);
+    word_prefix = be.alloc(((size_t)n_words + 1) * 8 + 64);
+    be.zero(be.addr(res.validity) + n_words * 8, 8);
+    be.run_validity(d_pages, n_pages, (const RunEntry*)be.addr(runs), (const uint64_t*)be.addr(offs), (uint64_t)n_rows, (uint64_t*)be.addr(res.validity),
+                    (uint32_t*)be.addr(popc), err);
+    be.scan_u32((const uint32_t*)be.addr(popc), (uint64_t*)be.addr(word_prefix), (int64_t)n_words);
+    d_validity = (const uint64_t*)be.addr(res.validity);
+    d_prefix = (const uint64_t*)be.addr(word_prefix);
+    be.run_page_valid0(d_pages, n_pages, d_validity, d_prefix);
+  }
+
+  res.values = be.alloc(out_bytes(n_rows));
+  ColumnDecode cd{};
+  cd.pages = d_pages; cd.n_pages = n_pages; cd.dicts = (const DictDesc*)be.addr(dicts_mem); cd.runs = (const RunEntry*)be.addr(runs);
+  cd.run_off = (const uint64_t*)be.addr(offs); cd.validity = d_validity; cd.word_prefix = d_prefix; cd.n_rows = (uint64_t)n_rows;
+  cd.src_width = lt.src_width; cd.dict_width = is_bytes ? 4u : lt.src_width;
+  if (lt.dtype == PLX_BOOL) be.zero(be.addr(res.values) + n_words * 8, 8);
+  be.run_decode(cd, (void*)be.addr(res.values), out_width, err);
+
+  // -- one synchronisation: error word (+ the valid-row total) ---------------------------------------------------------------------------
+  uint32_t e = be.read_u32(be.addr(err_mem));
+  if (e) throw FormatError("column '" + leaf.name + "' of " + f.path + ": " + error_bits_text(e));
+  if (nulls_possible) {
+    uint64_t valid = be.read_u64(be.addr(word_prefix) + n_words * 8);
+    res.null_count = n_rows - (int64_t)valid;
+    if (res.null_count == 0) { res.validity = typename B::Mem{}; res.has_validity = false; }
+  }
+  return res;
+}
+
+// ---- statistics of a chunk as typed scalars (row-group pruning) ---------------------------------------------------------------------------
+// PLAIN-encoded single values: little-endian of the physical type.  Returns false when the chunk has none usable for the dtype
+// (strings: byte-wise order says nothing about dictionary codes; deprecated fields are only right for signed types).
+inline bool chunk_min_max(const Leaf& leaf, const ColumnChunk& c, plx_scalar* mn, plx_scalar* mx) {
+  const LeafType lt = leaf_type(leaf);
+  if (lt.dtype < 0 || leaf.type == PT_BYTE_ARRAY || !c.stats.has_min || !c.stats.has_max) return false;
+  const bool is_unsigned = lt.dtype == PLX_U8 || lt.dtype == PLX_U16 || lt.dtype == PLX_U32 || lt.dtype == PLX_U64;
+  if (c.stats.from_deprecated && is_unsigned) return false;
+  auto one = [&](const std::string& raw, plx_scalar* out) {
+    out->u = 0;
+    switch (leaf.type) {
+      case PT_BOOLEAN: if (raw.size() < 1) return false; out->u = raw[0] & 1; return true;
+      case PT_INT32: {
+        if (raw.size() < 4) return false;
+        int32_t v; memcpy(&v, raw.data(), 4);
+        if (is_unsigned) out->u = (uint32_t)v; else out->i = v;
+        return true;
+      }
+      case PT_INT64: if (raw.size() < 8) return false; memcpy(&out->i, raw.data(), 8); return true;
+      case PT_FLOAT: if (raw.size() < 4) return false; memcpy(&out->f32, raw.data(), 4); return true;
+      case PT_DOUBLE: if (raw.size() < 8) return false; memcpy(&out->f64, raw.data(), 8); return true;
+      default: return false;
+    }
+  };
+  return one(c.stats.min, mn) && one(c.stats.max, mx);
+}
+
+}  // namespace pq
+}  // namespace plx

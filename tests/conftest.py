@@ -15,6 +15,8 @@ def pytest_configure(config):
 def pytest_collection_finish(session):
     """On a fresh GPU box the very first `import torch` pages the image in and can take minutes: do it here, outside any test's
     timeout, when a selected test is going to need it (the product itself never imports torch)."""
+    if os.environ.get("PLX_SKIP_TORCH_PREIMPORT") == "1":      # short targeted GPU sessions whose selected tests never touch torch
+        return
     if any(item.get_closest_marker("gpu") for item in session.items):
         try:
             import torch  # noqa: F401

@@ -1,0 +1,175 @@
+// parquet_emu.cpp -- CPU harness of the device Parquet decoder (TEST INFRASTRUCTURE: never linked into libpolars_amd.so).
+//
+// It instantiates the product's own orchestration (polars_amd/csrc/parquet_reader.hpp: read_column<B>) with a backend whose "device
+// memory" is host memory and whose "kernel launches" run the product's own per-thread / per-wavefront bodies
+// (polars_amd/csrc/parquet_device.hpp) one thread after another -- the grid mapping of kernels_parquet.hip restated as loops.  What the
+// CPU tests therefore cover: footer / page-header parsing, page planning, dictionary unification, Snappy (stage / parse / copy rounds
+// of one wavefront), run tables, validity words, dense-slot ranks, value decode.  What they cannot cover: the launch shells and the
+// memory-ordering of the real wavefront (the GPU tests do).
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../polars_amd/csrc/parquet_reader.hpp"
+
+using namespace plx::pq;
+
+namespace {
+
+struct HostBackend {
+  using Mem = std::shared_ptr<std::vector<uint8_t>>;
+  std::vector<uint8_t> stage_[2];
+  int next_ = 0;
+  int order = 0;   // 0: threads ascending, 1: descending (results must not depend on the order threads run in)
+
+  Mem alloc(size_t bytes) { return std::make_shared<std::vector<uint8_t>>(bytes + 64, (uint8_t)0xA5); }   // device memory is not zeroed
+  uint64_t addr(const Mem& m) { return m ? (uint64_t)m->data() : 0; }
+  uint8_t* host_stage(size_t bytes) {
+    std::vector<uint8_t>& s = stage_[next_];
+    next_ ^= 1;
+    s.assign(bytes, 0xEE);
+    return s.data();
+  }
+  void upload(uint64_t dst, const void* src, size_t bytes) { memcpy((void*)dst, src, bytes); }
+  void upload_small(uint64_t dst, const void* src, size_t bytes) { memcpy((void*)dst, src, bytes); }
+  void zero(uint64_t dst, size_t bytes) { memset((void*)dst, 0, bytes); }
+  uint64_t read_u64(uint64_t a) { uint64_t v; memcpy(&v, (const void*)a, 8); return v; }
+  uint32_t read_u32(uint64_t a) { uint32_t v; memcpy(&v, (const void*)a, 4); return v; }
+  void scan_u32(const uint32_t* in, uint64_t* out, int64_t n) {
+    uint64_t run = 0;
+    for (int64_t i = 0; i < n; i++) { out[i] = run; run += in[i]; }
+    out[n] = run;
+  }
+  template <class F> void for_threads(uint64_t n, F&& f) {
+    if (order == 0) for (uint64_t t = 0; t < n; t++) f(t);
+    else for (uint64_t t = n; t-- > 0;) f(t);
+  }
+
+  // one wavefront per stream: the loop of pq_snappy_kernel with the lanes of a phase run one after another
+  void run_snappy(const DecompJob* jobs, uint32_t n, uint64_t, uint32_t* err) {
+    for_threads(n, [&](uint64_t j) {
+      SnapShared sh;
+      const DecompJob job = jobs[j];
+      snappy_begin(sh, job);
+      while (sh.done == 0) {
+        for (uint32_t lane = 0; lane < 64; lane++) snappy_stage(sh, job, lane);
+        snappy_parse(sh, job);
+        if (order == 0) for (uint32_t lane = 0; lane < 64; lane++) snappy_copy(sh, job, lane);
+        else for (uint32_t lane = 64; lane-- > 0;) snappy_copy(sh, job, lane);
+      }
+      if (sh.done == 2) *err |= PE_SNAPPY;
+    });
+  }
+  void run_page_prepare(PageDesc* pages, uint32_t n, uint32_t* err) { for_threads(n, [&](uint64_t i) { *err |= page_prepare(pages[i]); }); }
+  void run_count_runs(const PageDesc* pages, uint32_t n, bool levels, uint32_t* counts, uint32_t* err) {
+    for_threads(2ull * n, [&](uint64_t t) {
+      int s = (int)(t & 1);
+      counts[t] = (s == 0 && !levels) ? 0u : stream_entries(pages[t >> 1], s, err);
+    });
+  }
+  void run_fill_runs(const PageDesc* pages, uint32_t n, const uint64_t* offs, RunEntry* runs) {
+    for_threads(2ull * n, [&](uint64_t t) {
+      uint32_t cnt = (uint32_t)(offs[t + 1] - offs[t]);
+      if (cnt) stream_fill(pages[t >> 1], (int)(t & 1), runs + offs[t], cnt);
+    });
+  }
+  void run_validity(const PageDesc* pages, uint32_t n, const RunEntry* runs, const uint64_t* offs, uint64_t n_rows, uint64_t* validity, uint32_t* popc, uint32_t* err) {
+    for_threads((n_rows + 63) >> 6, [&](uint64_t w) {
+      uint64_t word = validity_word(pages, n, runs, offs, n_rows, w, err);
+      validity[w] = word;
+      popc[w] = (uint32_t)__builtin_popcountll(word);
+    });
+  }
+  void run_page_valid0(PageDesc* pages, uint32_t n, const uint64_t* validity, const uint64_t* prefix) {
+    for_threads(n, [&](uint64_t i) { pages[i].valid0 = valid_before(validity, prefix, pages[i].row0); });
+  }
+  void run_decode(const ColumnDecode& c, void* out, uint32_t out_width, uint32_t* err) {
+    if (out_width == 0) for_threads((c.n_rows + 63) >> 6, [&](uint64_t w) { ((uint64_t*)out)[w] = decode_bool_word(c, w, err); });
+    else for_threads(c.n_rows, [&](uint64_t r) { decode_rows(c, out, out_width, r, r + 1, err); });
+  }
+};
+
+struct EmuResult {
+  ColumnResult<HostBackend> col;
+  std::vector<std::string> categories;
+  ReadStats stats;
+};
+
+thread_local std::string t_err;
+
+}  // namespace
+
+extern "C" {
+
+const char* pqemu_last_error() { return t_err.c_str(); }
+
+// returns 0 ok, 3 unsupported, 1 invalid
+int pqemu_read_column(const char* path, const int* row_groups, int n_row_groups, int column, int thread_order, void** out) {
+  try {
+    std::unique_ptr<File> f = open_file(path);
+    HostBackend be;
+    be.order = thread_order;
+    auto r = std::make_unique<EmuResult>();
+    std::vector<int> rgs(row_groups, row_groups + n_row_groups);
+    r->col = read_column(be, *f, rgs, column, &r->stats);
+    auto it = f->categories.find(column);
+    if (it != f->categories.end()) r->categories = it->second;
+    *out = r.release();
+    return 0;
+  } catch (const Unsupported& e) { t_err = e.what(); return 3;
+  } catch (const std::exception& e) { t_err = e.what(); return 1; }
+}
+void pqemu_free(void* h) { delete (EmuResult*)h; }
+void pqemu_info(void* h, int* dtype, int* logical, int64_t* len, int64_t* null_count, int* has_validity, int64_t* n_categories, uint64_t* stats6) {
+  EmuResult* r = (EmuResult*)h;
+  *dtype = r->col.dtype; *logical = r->col.logical; *len = r->col.len; *null_count = r->col.null_count; *has_validity = r->col.has_validity ? 1 : 0;
+  *n_categories = (int64_t)r->categories.size();
+  stats6[0] = r->stats.file_bytes; stats6[1] = r->stats.data_pages; stats6[2] = r->stats.dict_pages; stats6[3] = r->stats.snappy_streams;
+  stats6[4] = r->stats.snappy_bytes_out; stats6[5] = r->stats.run_entries;
+}
+void pqemu_copy(void* h, void* values, size_t values_bytes, void* validity, size_t validity_bytes) {
+  EmuResult* r = (EmuResult*)h;
+  if (values_bytes) memcpy(values, r->col.values->data(), values_bytes);
+  if (validity_bytes && r->col.has_validity) memcpy(validity, r->col.validity->data(), validity_bytes);
+}
+int64_t pqemu_category(void* h, int64_t i, char* buf, int64_t cap) {
+  EmuResult* r = (EmuResult*)h;
+  const std::string& s = r->categories[(size_t)i];
+  if ((int64_t)s.size() <= cap) memcpy(buf, s.data(), s.size());
+  return (int64_t)s.size();
+}
+
+// Snappy alone: the wavefront rounds against an arbitrary compressed buffer (fuzzed by the tests against a reference decoder)
+int pqemu_snappy(const uint8_t* in, uint32_t n_in, uint8_t* out, uint32_t n_out, int thread_order, uint32_t* rounds) {
+  HostBackend be;
+  be.order = thread_order;
+  std::vector<uint8_t> src(in, in + n_in);
+  src.resize(n_in + 64, 0xCC);
+  DecompJob job{(uint64_t)src.data(), (uint64_t)out, n_in, n_out};
+  uint32_t err = 0, nr = 0;
+  SnapShared sh;
+  snappy_begin(sh, job);
+  while (sh.done == 0) {
+    for (uint32_t lane = 0; lane < 64; lane++) snappy_stage(sh, job, lane);
+    snappy_parse(sh, job);
+    if (thread_order == 0) for (uint32_t lane = 0; lane < 64; lane++) snappy_copy(sh, job, lane);
+    else for (uint32_t lane = 64; lane-- > 0;) snappy_copy(sh, job, lane);
+    nr++;
+  }
+  if (sh.done == 2) err = PE_SNAPPY;
+  if (rounds) *rounds = nr;
+  return (int)err;
+}
+
+// the host Snappy of the product (string dictionary pages)
+int pqemu_snappy_host(const uint8_t* in, uint32_t n_in, uint8_t* out, uint32_t n_out) {
+  try {
+    std::vector<uint8_t> v = snappy_decompress_host(in, n_in, n_out);
+    memcpy(out, v.data(), v.size());
+    return 0;
+  } catch (const std::exception& e) { t_err = e.what(); return 1; }
+}
+
+}  // extern "C"
