@@ -1,7 +1,7 @@
 // kernels_parquet.hip -- launch shells of the device Parquet decoder.  The per-thread / per-wavefront bodies live in
 // parquet_device.hpp (host + device, also executed by the CPU harness of the tests); this file only maps them onto the grid.
 //
-//   pq_snappy          one wavefront (64-thread workgroup) per compressed stream: LDS window + element batch, see parquet_device.hpp
+//   pq_snappy          one 256-thread workgroup per compressed stream: parquet_snappy.hpp
 //   pq_page_prepare    one thread per page: split the payload into level / value streams
 //   pq_count_runs      one thread per (page, stream): entries its run table needs       } the only serial walks: run HEADERS of one
 //   pq_fill_runs       one thread per (page, stream): the run table                      } stream of one page
@@ -11,6 +11,9 @@
 //
 // Bound: HBM / PCIe -- the decoded column is written once, the encoded bytes are read once or twice (Snappy output is re-read by the
 // decode pass); nothing here is arithmetic.
+#include <cstdio>
+#include <cstdlib>
+
 #include "dev.hpp"
 #include "kernels.hpp"
 #include "parquet_kernels.hpp"
@@ -19,23 +22,63 @@ namespace plx {
 namespace k {
 using namespace pq;
 
-__global__ __launch_bounds__(64) void pq_snappy_kernel(const DecompJob* __restrict__ jobs, uint32_t n_jobs, uint32_t* __restrict__ err) {
+// phase clock (PLX_SNAPPY_TIMING=1): thread 0 of every workgroup adds the cycles it spent per phase to dbg[0..7]
+// (stage, next, mark, rank + place, point, jump, gather/direct, fence), dbg[8] = rounds, dbg[9] = elements, dbg[10] = jump sweeps
+#define PQ_TICK(slot)                                      \
+  if (dbg && lane == 0) {                                  \
+    const uint64_t now = wall_clock64();                   \
+    t_acc[slot] += now - t_last;                           \
+    t_last = now;                                          \
+  }
+
+__global__ __launch_bounds__(kSnapLanes) void pq_snappy_kernel(const DecompJob* __restrict__ jobs, uint32_t n_jobs, uint32_t* __restrict__ err,
+                                                               unsigned long long* __restrict__ dbg) {
   __shared__ SnapShared sh;
   if (blockIdx.x >= n_jobs) return;
   const DecompJob job = jobs[blockIdx.x];
   const uint32_t lane = threadIdx.x;
+  uint64_t t_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = dbg ? wall_clock64() : 0;
   if (lane == 0) snappy_begin(sh, job);
   __syncthreads();
   while (sh.done == 0) {
     snappy_stage(sh, job, lane);
     __syncthreads();
-    if (lane == 0) snappy_parse(sh, job);
+    PQ_TICK(0)
+    snappy_next(sh, job, lane);
     __syncthreads();
-    snappy_copy(sh, job, lane);
-    __threadfence();        // the next round's back-references read what this round's other lanes wrote (stores done, L1 dropped)
+    PQ_TICK(1)
+    for (uint32_t it = 0; it < kSnapSweeps && __syncthreads_or(snappy_mark(sh, it, lane) ? 1 : 0); it++) {}   // barrier + "does any node still have a successor"
     __syncthreads();
+    PQ_TICK(2)
+    snappy_rank(sh, lane);
+    __syncthreads();
+    if (lane == 0) snappy_scan(sh);
+    __syncthreads();
+    snappy_place(sh, job, lane);
+    __syncthreads();
+    if (lane == 0) snappy_finish(sh, job);
+    __syncthreads();
+    PQ_TICK(3)
+    if (sh.done == 2 || sh.bad) break;      // uniform: every lane reads the flags after the barrier
+    t_acc[8] += 1; t_acc[9] += sh.n_el;
+    if (sh.direct) {
+      snappy_direct(sh, job, lane);
+    } else {
+      snappy_point(sh, lane);
+      __syncthreads();
+      PQ_TICK(4)
+      while (__syncthreads_or(snappy_jump(sh, lane) ? 1 : 0)) { t_acc[10] += 1; }   // barrier + "did any lane still follow a pointer"
+      PQ_TICK(5)
+      snappy_gather(sh, job, lane);
+    }
+    PQ_TICK(6)
+    __threadfence();        // later rounds read this output from HBM: stores complete, L1 dropped
+    __syncthreads();
+    PQ_TICK(7)
   }
-  if (lane == 0 && sh.done == 2) atomicOr(err, (uint32_t)PE_SNAPPY);
+  if (lane == 0 && (sh.done == 2 || sh.bad)) atomicOr(err, (uint32_t)PE_SNAPPY);
+  if (dbg && lane == 0)
+    for (int i = 0; i < 11; i++) atomicAdd(dbg + i, (unsigned long long)t_acc[i]);
 }
 
 __global__ __launch_bounds__(kBlock) void pq_page_prepare_kernel(PageDesc* __restrict__ pages, uint32_t n_pages, uint32_t* __restrict__ err) {
@@ -102,9 +145,25 @@ static unsigned blocks_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kB
 
 void pq_snappy(const DecompJob* jobs, uint32_t n_jobs, uint64_t bytes_out, uint32_t* err) {
   if (!n_jobs) return;
-  ProfileScope ps("pq_snappy", bytes_out * 2, n_jobs);
-  hipLaunchKernelGGL(pq_snappy_kernel, dim3(n_jobs), dim3(64), 0, stream(), jobs, n_jobs, err);
-  PLX_HIP(hipGetLastError());
+  static const bool timing = [] { const char* e = getenv("PLX_SNAPPY_TIMING"); return e && e[0] == '1'; }();
+  Buf dbg;
+  if (timing) dbg = dev_alloc_zero(11 * 8);
+  {
+    ProfileScope ps("pq_snappy", bytes_out * 2, n_jobs);
+    hipLaunchKernelGGL(pq_snappy_kernel, dim3(n_jobs), dim3(kSnapLanes), 0, stream(), jobs, n_jobs, err, timing ? dbg->as<unsigned long long>() : nullptr);
+    PLX_HIP(hipGetLastError());
+  }
+  if (timing) {
+    int per_cu = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pq_snappy_kernel, (int)kSnapLanes, 0);
+    fprintf(stderr, "[pq_snappy] workgroups per CU: %d; ", per_cu);
+    unsigned long long h[11];
+    d2h_sync(h, dbg->ptr, sizeof h);
+    static const char* names[8] = {"stage", "next", "mark", "rank_place", "point", "jump", "gather", "fence"};
+    fprintf(stderr, "[pq_snappy] streams=%u out=%.1f MB rounds=%llu elements=%llu jump_sweeps=%llu; 100 MHz ticks summed over streams:", n_jobs, bytes_out / 1e6, h[8], h[9], h[10]);
+    for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
+    fprintf(stderr, "\n");
+  }
 }
 void pq_page_prepare(PageDesc* pages, uint32_t n_pages, uint32_t* err) {
   if (!n_pages) return;

@@ -26,13 +26,8 @@ struct HipBackend {
   int next_ = 0;
   uint64_t encoded_bytes = 0;
 
-  ~HipBackend() {
-    for (Stage& s : stage_) {
-      if (s.pending) (void)hipEventSynchronize(s.ev);
-      if (s.ev) (void)hipEventDestroy(s.ev);
-      if (s.p) (void)hipHostFree(s.p);
-    }
-  }
+  // No destructor: the backend lives as long as its host thread, and at process exit the HIP runtime may already be gone -- the
+  // staging buffers are left to the OS, like the library's bounce buffer (core.cpp).
   Mem alloc(size_t bytes) { return dev_alloc(bytes ? bytes : 8); }
   uint64_t addr(const Mem& m) { return m ? (uint64_t)m->ptr : 0; }
   // page-locked staging, two buffers: chunk k + 1 is read from the file while chunk k is on its way to HBM
@@ -190,7 +185,10 @@ int plx_parquet_read(plx_parquet file, const int32_t* row_groups, int32_t n_row_
   try {
     for (int32_t i = 0; i < n_columns; i++) {
       check_cancel();
-      HipBackend be;
+      // one backend per host thread, kept: its two page-locked staging buffers cost milliseconds to allocate (hipHostMalloc), a
+      // column chunk takes about as long to upload
+      static thread_local HipBackend be;
+      be.encoded_bytes = 0;
       pq::ReadStats st;
       pq::ColumnResult<HipBackend> r = pq::read_column(be, f, rgs, columns[i], &st);
       auto col = std::make_shared<Column>();

@@ -17,7 +17,7 @@
 // GPU shape: nothing here is sequential over a column.  The only serial walks are per page: one thread reads the run headers of one
 // level / index stream into a run table (a few hundred to a few thousand headers per 1 MB page), after which every row is decoded
 // independently by binary search in that table; Snappy is one wavefront per page (serial tag parse by lane 0 from an LDS window,
-// byte copies by all 64 lanes).
+// bytes produced by all 64 lanes through pointer jumping: parquet_snappy.hpp).
 #pragma once
 #include <stdint.h>
 #include <string.h>
@@ -37,6 +37,7 @@ enum PageFlags : uint32_t {
   PF_COMPRESSED = 2u,   // the values part went through the decompressor: it sits at `dst`
   PF_DICT = 4u,         // values are dictionary indices
   PF_HAS_DEF = 8u,      // the page carries definition levels (optional column)
+  PF_RLE_VALUES = 16u,  // boolean values as u32 length + 1-bit hybrid runs (Encoding RLE; what v2 writers emit for booleans)
 };
 
 struct PageDesc {
@@ -123,6 +124,16 @@ PLX_HD uint32_t page_prepare(PageDesc& p) {
       if (p.bit_width > 32) { err |= PE_RUNS; p.bit_width = 0; }
     }
   }
+  if ((p.flags & PF_RLE_VALUES) && !err) {
+    if (p.val_len < 4) {
+      if (p.num_values) err |= PE_VALUES;
+      p.val_len = 0;
+    } else {
+      uint32_t n = load_u32((const uint8_t*)p.val_ptr);
+      if (n > p.val_len - 4) { err |= PE_VALUES; n = p.val_len - 4; }
+      p.val_ptr += 4; p.val_len = n; p.bit_width = 1;
+    }
+  }
   p.valid0 = 0;
   return err;
 }
@@ -163,15 +174,15 @@ template <class Emit> PLX_HD uint32_t walk_runs(const uint8_t* s, uint32_t len, 
   return k;
 }
 
-// stream s of page p: 0 = definition levels (1 bit, exactly num_values of them), 1 = dictionary indices (bit_width bits; one per
-// non-null row, which only the levels know: the walk stops at the end of the stream)
+// stream s of page p: 0 = definition levels (1 bit, exactly num_values of them), 1 = dictionary indices / RLE booleans (bit_width
+// bits; one per non-null row, which only the levels know: the walk stops at the end of the stream)
 PLX_HD bool stream_params(const PageDesc& p, int s, const uint8_t** ptr, uint32_t* len, uint32_t* bits) {
   if (s == 0) {
     if (!(p.flags & PF_HAS_DEF)) return false;
     *ptr = (const uint8_t*)p.def_ptr; *len = p.def_len; *bits = 1;
     return true;
   }
-  if (!(p.flags & PF_DICT)) return false;
+  if (!(p.flags & (PF_DICT | PF_RLE_VALUES))) return false;
   *ptr = (const uint8_t*)p.val_ptr; *len = p.val_len; *bits = p.bit_width;
   return true;
 }
@@ -326,7 +337,7 @@ PLX_HD bool decode_row(const ColumnDecode& c, uint32_t pg, uint64_t r, uint64_t*
   } else {
     dense = r - p.row0;
   }
-  if (p.flags & PF_DICT) {
+  if (p.flags & (PF_DICT | PF_RLE_VALUES)) {
     uint32_t idx = 0;
     if (p.bit_width) {
       const RunEntry* pr = c.runs + c.run_off[2 * pg + 1];
@@ -335,6 +346,7 @@ PLX_HD bool decode_row(const ColumnDecode& c, uint32_t pg, uint64_t r, uint64_t*
       uint32_t k = find_run(pr, n_ent - 1, (uint32_t)dense);
       idx = run_value((const uint8_t*)p.val_ptr, pr[k], p.bit_width, (uint32_t)dense);
     }
+    if (p.flags & PF_RLE_VALUES) { *out_bits = idx; return true; }
     const DictDesc& d = c.dicts[p.dict];
     if (idx >= d.n) { *err |= PE_DICT_INDEX; *out_bits = 0; return true; }
     const uint8_t* e = (const uint8_t*)d.values + (uint64_t)idx * c.dict_width;
@@ -395,136 +407,7 @@ PLX_HD uint64_t decode_bool_word(const ColumnDecode& c, uint64_t w, uint32_t* er
   return word;
 }
 
-// ---- Snappy: one wavefront per stream -------------------------------------------------------------------------------------------------
-// Each round: (stage) all lanes copy the next kSnapWindow input bytes into LDS; (parse) lane 0 decodes up to kSnapBatch elements
-// from the window -- it stops early at an element whose copy source lies inside this round's own output, so the elements of a round
-// are independent of each other; (copy) the lanes share the round's output bytes in 16-byte slots.
-constexpr uint32_t kSnapWindow = 1024;   // 64 lanes x 16 B
-constexpr uint32_t kSnapBatch = 64;
-
-struct SnapElem {
-  uint32_t dst;     // output position
-  uint32_t len;     // bit 31: copy (else literal)
-  uint32_t src;     // literal: input position of the bytes; copy: offset back from dst
-};
-struct SnapShared {
-  uint8_t win[kSnapWindow + 16];
-  SnapElem el[kSnapBatch];
-  uint32_t n_el;
-  uint32_t in_pos;      // next unparsed input byte
-  uint32_t out_pos;     // bytes produced after this round
-  uint32_t round_out0;  // bytes produced before this round
-  uint32_t done;        // 1: finished, 2: error
-};
-
-PLX_HD void snappy_begin(SnapShared& sh, const DecompJob& job) {
-  // preamble: uncompressed length as a varint
-  const uint8_t* in = (const uint8_t*)job.src;
-  uint32_t pos = 0, n = 0;
-  bool ok = false;
-  for (uint32_t shift = 0; shift <= 28 && pos < job.comp_size; shift += 7) {
-    uint32_t b = in[pos++];
-    n |= (b & 0x7f) << shift;
-    if (!(b & 0x80)) { ok = true; break; }
-  }
-  sh.n_el = 0; sh.in_pos = pos; sh.out_pos = 0; sh.round_out0 = 0;
-  sh.done = (!ok || n != job.uncomp_size) ? 2u : (n == 0 ? 1u : 0u);
-}
-
-// stage: lane copies 16 input bytes of the window
-PLX_HD void snappy_stage(SnapShared& sh, const DecompJob& job, uint32_t lane) {
-  const uint8_t* in = (const uint8_t*)job.src;
-  uint32_t base = sh.in_pos + lane * 16;
-  for (uint32_t b = 0; b < 16; b++) {
-    uint32_t pos = base + b;
-    sh.win[lane * 16 + b] = pos < job.comp_size ? in[pos] : 0;
-  }
-}
-
-// parse: lane 0 only.  Reads tags from the window, writes the round's elements.
-PLX_HD void snappy_parse(SnapShared& sh, const DecompJob& job) {
-  const uint32_t win0 = sh.in_pos;
-  uint32_t pos = sh.in_pos, out = sh.out_pos, n = 0;
-  const uint32_t round0 = out;
-  sh.round_out0 = round0;
-  uint32_t done = 0;
-  while (n < kSnapBatch) {
-    if (pos >= job.comp_size) { done = 1; break; }
-    if (pos - win0 + 5 > kSnapWindow) break;             // tag + up to 4 length / offset bytes must be inside the window
-    const uint8_t* t = sh.win + (pos - win0);
-    uint32_t tag = t[0], kind = tag & 3, len, src, used;
-    bool copy = kind != 0;
-    if (!copy) {
-      uint32_t l = tag >> 2;
-      if (l < 60) { len = l + 1; used = 1; }
-      else {
-        uint32_t nb = l - 59;                             // 1..4 length bytes
-        uint32_t v = 0;
-        for (uint32_t b = 0; b < nb; b++) v |= (uint32_t)t[1 + b] << (8 * b);
-        len = v + 1; used = 1 + nb;
-        if (v == 0xffffffffu) { done = 2; break; }
-      }
-      src = pos + used;
-      if (src > job.comp_size || len > job.comp_size - src) { done = 2; break; }
-      used += len;
-    } else if (kind == 1) {
-      len = ((tag >> 2) & 7) + 4; src = ((tag >> 5) << 8) | t[1]; used = 2;
-    } else if (kind == 2) {
-      len = (tag >> 2) + 1; src = t[1] | ((uint32_t)t[2] << 8); used = 3;
-    } else {
-      len = (tag >> 2) + 1; src = t[1] | ((uint32_t)t[2] << 8) | ((uint32_t)t[3] << 16) | ((uint32_t)t[4] << 24); used = 5;
-    }
-    if (copy) {
-      if (pos + used > job.comp_size || src == 0 || src > out) { done = 2; break; }
-      // the source [out - src, out - src + min(len, src)) must have been written by EARLIER rounds
-      uint32_t span = len < src ? len : src;
-      if (n > 0 && out - src + span > round0) break;
-    }
-    if (len > job.uncomp_size - out) { done = 2; break; }
-    sh.el[n].dst = out; sh.el[n].len = len | (copy ? 0x80000000u : 0u); sh.el[n].src = src;
-    n++;
-    pos += used; out += len;
-  }
-  if (!done && pos >= job.comp_size) done = 1;
-  if (done == 1 && out != job.uncomp_size) done = 2;
-  sh.n_el = n; sh.in_pos = pos; sh.out_pos = out; sh.done = done;
-}
-
-// copy: lane handles the 16-byte slots lane, lane + 64, ... of the round's output
-PLX_HD void snappy_copy(const SnapShared& sh, const DecompJob& job, uint32_t lane) {
-  const uint8_t* in = (const uint8_t*)job.src;
-  uint8_t* out = (uint8_t*)job.dst;
-  const uint32_t b0 = sh.round_out0, b1 = sh.out_pos, n = sh.n_el;
-  if (!n) return;
-  for (uint64_t s0 = (uint64_t)b0 + (uint64_t)lane * 16; s0 < b1; s0 += 64 * 16) {
-    uint32_t pos = (uint32_t)s0, end = s0 + 16 < b1 ? (uint32_t)s0 + 16 : b1;
-    uint32_t lo = 0, hi = n;                              // last element with dst <= pos
-    while (hi - lo > 1) {
-      uint32_t mid = (lo + hi) >> 1;
-      if (sh.el[mid].dst <= pos) lo = mid; else hi = mid;
-    }
-    uint32_t e = lo;
-    while (pos < end) {
-      const SnapElem el = sh.el[e];
-      uint32_t len = el.len & 0x7fffffffu, el_end = el.dst + len;
-      uint32_t seg_end = el_end < end ? el_end : end;
-      if (!(el.len >> 31)) {
-        const uint8_t* s = in + el.src + (pos - el.dst);
-        if (seg_end - pos == 16) memcpy(out + pos, s, 16);
-        else for (uint32_t i = 0; pos + i < seg_end; i++) out[pos + i] = s[i];
-      } else if (el.src >= len) {                         // plain back-reference
-        const uint8_t* s = out + pos - el.src;
-        if (seg_end - pos == 16) { uint8_t tmp[16]; memcpy(tmp, s, 16); memcpy(out + pos, tmp, 16); }
-        else for (uint32_t i = 0; pos + i < seg_end; i++) out[pos + i] = s[i];
-      } else {                                            // overlapping: the pattern of `src` bytes before dst repeats
-        const uint8_t* pat = out + el.dst - el.src;
-        for (uint32_t q = pos; q < seg_end; q++) out[q] = pat[(q - el.dst) % el.src];
-      }
-      pos = seg_end;
-      e++;
-    }
-  }
-}
-
 }  // namespace pq
 }  // namespace plx
+
+#include "parquet_snappy.hpp"   // Snappy: one wavefront per stream (stage / parse / point / jump / gather rounds)

@@ -159,7 +159,9 @@ struct ColumnChunk {
   bool external_file = false;        // file_path set: the chunk lives in another file
   Statistics stats;
   // byte range of the chunk in the file: [start, start + total_compressed_size)
-  int64_t start() const { return dictionary_page_offset > 0 && dictionary_page_offset < data_page_offset ? dictionary_page_offset : data_page_offset; }
+  int64_t start() const {
+    return dictionary_page_offset > 0 && (data_page_offset <= 0 || dictionary_page_offset < data_page_offset) ? dictionary_page_offset : data_page_offset;
+  }
 };
 
 struct RowGroup {

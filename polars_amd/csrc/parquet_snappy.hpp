@@ -1,0 +1,342 @@
+// parquet_snappy.hpp -- raw Snappy on the device, one 256-thread workgroup per stream (part of parquet_device.hpp: host + device bodies).
+//
+// A Snappy stream is a chain twice over: every element's position depends on all earlier tags, and a copy may read bytes the
+// previous element produced (sorted keys: each 8-byte value copies 5-6 bytes of its predecessor at offset 8, so an "element-parallel"
+// LZ decoder degenerates to one element at a time).  Measured on MI355X (2e7-row lineitem-like file, tools/parquet_bench.py): decoding
+// element after element through HBM 1060 ms, through LDS 475 ms, a full tag parse on one lane + pointer jumping 257 ms, a one-LDS-read
+// chain walk on one lane 139 ms, of which the walk was 85 % (in-kernel phase clock, PLX_SNAPPY_TIMING=1: 166 ns per element).  A GPU
+// lane is a poor serial machine, so NOTHING here follows the chain element by element -- both chains are resolved by pointer doubling:
+//
+//   stage   the next kSnapWindow input bytes -> LDS
+//   next    every window position b is decoded AS IF a tag started there: nl[b] = {output length, position of the following tag};
+//           positions a chain cannot continue from (tag not complete in the window, end of input, a long literal) are STOP nodes
+//   mark    which positions are real tags?  Those reachable from the round's first tag.  Jacobi pointer doubling: sweep k holds
+//           jmp[b] = the 2^k-th successor of b; a marked node marks its 2^k-th successor; log2(chain length) sweeps
+//   rank    marked positions in ascending order ARE the elements in stream order: element index and output offset are prefix sums
+//           over the marked positions (each thread scans its 19 consecutive positions, thread 0 scans the 256 partial sums)
+//   place   every thread decodes and validates the elements of its positions -> el[rank] = {source, dst, len}; the round ends
+//           (`cut`) at the first STOP node on the chain or the first element that no longer fits (kSnapRound bytes, kSnapElems)
+//   point   every output byte i of the round gets a POINTER: literal byte -> its input position; copy byte -> the output byte
+//           `offset` earlier (in this round: an LDS index; before it: an absolute output position).  "byte i = byte i - offset" is
+//           exactly Snappy's copy semantics, overlapping copies included.
+//   jump    pointer jumping in LDS: ptr[i] = ptr[ptr[i]] while ptr[i] is a byte of this round -- a dependency chain of depth d
+//           resolves in log2(d) sweeps instead of d steps
+//   gather  byte i is loaded from the input (literal) or from the output of EARLIER rounds in HBM (made visible by the fence that ends
+//           every round) and stored; threads handle bytes i = t, t + 256, ..., so a wavefront's loads and stores are 64 consecutive bytes
+//
+// A literal longer than kSnapDirect is a round of its own, copied input -> output 16 bytes per thread (incompressible pages are one
+// 64 KB literal per Snappy block).  Every phase is a pure function of the previous one (double-buffered jmp, monotone marks, atomic
+// min), so the result does not depend on the order threads run in -- which is what lets the CPU harness execute the same bodies.
+// Format: snap crate / google snappy format_description.txt, used by the reference through
+// crates/polars-parquet/src/parquet/compression.rs:144-230.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+namespace plx {
+namespace pq {
+
+constexpr uint32_t kSnapLanes = 256;         // threads per stream: one workgroup of 4 wavefronts ("lane" below = thread of the workgroup)
+constexpr uint32_t kSnapWindow = 4096;       // input bytes staged per round: 256 lanes x 16 B
+constexpr uint32_t kSnapRound = 4096;        // output bytes per round
+constexpr uint32_t kSnapElems = 1024;        // elements per round
+constexpr uint32_t kSnapDirect = 512;        // literals longer than this bypass the pointer machinery
+constexpr uint32_t kSnapChunk = 19;          // positions per thread in rank / place (odd: conflict-free LDS strides)
+constexpr uint32_t kSnapNodes = kSnapLanes * kSnapChunk;   // 4864 >= kSnapWindow + 5 + kSnapDirect + 1: every position a chain can reach
+// Sweep k marks the chain nodes at distance < 2^(k+1) from the round's first tag.  A round takes at most kSnapElems elements, and the node
+// right behind them must be seen (it cuts the round): distance kSnapElems < 2^11, so 11 sweeps always suffice.
+constexpr uint32_t kSnapSweeps = 11;
+constexpr uint32_t kSnapKindFar = 1u << 30;  // pointer kinds (bits 31:30): 0 = byte of this round (LDS index), 1 = earlier output, 2 = input
+constexpr uint32_t kSnapKindLit = 2u << 30;
+constexpr uint32_t kSnapPosMask = (1u << 30) - 1;
+constexpr uint32_t kSnapStop = 0xffffffffu;  // nl[] of a STOP node
+constexpr uint32_t kSnapLongNode = 0xfffffffeu;   // nl[] of a literal > kSnapDirect (or with a malformed length)
+constexpr uint16_t kSnapEnd = 0xffffu;       // jmp[] of a node without successor
+static_assert(kSnapNodes >= kSnapWindow + 5 + kSnapDirect + 1, "chain positions must fit the node arrays");
+static_assert((1u << kSnapSweeps) > kSnapElems, "the node behind a full round must get its mark");
+
+struct SnapElem {
+  uint32_t src;     // bit 31: literal, bits 0..30 = input position of its bytes; else copy offset (>= 1)
+  uint16_t dst;     // first output byte, relative to the round
+  uint16_t len;
+};
+struct SnapShared {
+  alignas(16) uint8_t win[kSnapWindow + 16];
+  uint32_t nl[kSnapNodes];       // element nodes: output length << 16 | position of the next tag; else kSnapStop / kSnapLongNode
+  union {
+    uint16_t jmp[2][kSnapNodes]; // mark phase: 2^k-th successor, double-buffered
+    uint32_t ptr[kSnapRound];    // point / jump / gather phases
+  };
+  uint8_t mark[kSnapNodes];
+  uint32_t part_cnt[kSnapLanes + 1], part_len[kSnapLanes + 1];   // per thread chunk: marked elements, their output bytes (then exclusive prefixes)
+  SnapElem el[kSnapElems];
+  uint32_t cut;         // first position of the chain that is not part of this round
+  uint32_t n_el;
+  uint32_t direct;      // 1: the round is one long literal {direct_src, direct_len} copied input -> output
+  uint32_t direct_src, direct_len;
+  uint32_t in_pos;      // next unparsed input byte
+  uint32_t win_pos;     // input position of win[0]
+  uint32_t out_pos;     // bytes produced after this round
+  uint32_t round_out0;  // bytes produced before this round
+  uint32_t done;        // 1: finished, 2: error
+  uint32_t bad;         // set by any lane that meets a malformed element: the round is abandoned, the stream is in error
+};
+
+PLX_HD void snap_min(uint32_t* p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // compiler builtin: no runtime header needed
+#else
+  if (v < *p) *p = v;
+#endif
+}
+
+// the tag at t (4 more bytes readable): literal -> kind 0, *len = its length (0xffffffff: malformed); copy -> kind 1..3, *val = offset,
+// *len = 4..64; *hdr = bytes of the tag itself (literal: incl. its length bytes)
+PLX_HD uint32_t snappy_tag(const uint8_t* t, uint32_t* len, uint32_t* val, uint32_t* hdr) {
+  const uint32_t tag = t[0], kind = tag & 3;
+  if (kind == 0) {
+    const uint32_t l = tag >> 2;
+    if (l < 60) { *len = l + 1; *hdr = 1; }
+    else {
+      const uint32_t nb = l - 59;                         // 1..4 length bytes
+      uint32_t v = 0;
+      for (uint32_t b = 0; b < nb; b++) v |= (uint32_t)t[1 + b] << (8 * b);
+      *len = v >= kSnapPosMask ? 0xffffffffu : v + 1;
+      *hdr = 1 + nb;
+    }
+    *val = 0;
+  } else if (kind == 1) { *len = ((tag >> 2) & 7) + 4; *val = ((tag >> 5) << 8) | t[1]; *hdr = 2; }
+  else if (kind == 2) { *len = (tag >> 2) + 1; *val = t[1] | ((uint32_t)t[2] << 8); *hdr = 3; }
+  else { *len = (tag >> 2) + 1; *val = t[1] | ((uint32_t)t[2] << 8) | ((uint32_t)t[3] << 16) | ((uint32_t)t[4] << 24); *hdr = 5; }
+  return kind;
+}
+
+PLX_HD void snappy_begin(SnapShared& sh, const DecompJob& job) {
+  // preamble: uncompressed length as a varint
+  const uint8_t* in = (const uint8_t*)job.src;
+  uint32_t pos = 0, n = 0;
+  bool ok = false;
+  for (uint32_t shift = 0; shift <= 28 && pos < job.comp_size; shift += 7) {
+    uint32_t b = in[pos++];
+    n |= (b & 0x7f) << shift;
+    if (!(b & 0x80)) { ok = true; break; }
+  }
+  sh.n_el = 0; sh.direct = 0; sh.direct_src = 0; sh.direct_len = 0; sh.in_pos = pos; sh.win_pos = pos; sh.out_pos = 0; sh.round_out0 = 0; sh.bad = 0;
+  sh.cut = kSnapStop;
+  // positions carry two kind bits: streams of 1 GiB and more are refused (Parquet pages are a few MB)
+  if (job.comp_size > kSnapPosMask || job.uncomp_size > kSnapPosMask) ok = false;
+  sh.done = (!ok || n != job.uncomp_size) ? 2u : (n == 0 ? 1u : 0u);
+}
+
+// stage: the window, 16 input bytes per lane (the 16 pad bytes behind it are cleared by lane 0)
+PLX_HD void snappy_stage(SnapShared& sh, const DecompJob& job, uint32_t lane) {
+  const uint8_t* in = (const uint8_t*)job.src;
+  constexpr uint32_t kPieces = kSnapWindow / 16 / kSnapLanes;     // 16-byte pieces per lane (1 with 256 lanes)
+  uint8_t tmp[kPieces][16];
+  for (uint32_t c = 0; c < kPieces; c++) {                // all loads are issued before the first LDS write waits for one
+    const uint32_t base = sh.in_pos + (c * kSnapLanes + lane) * 16;   // consecutive lanes -> consecutive pieces
+    if (base + 16 <= job.comp_size) memcpy(tmp[c], in + base, 16);
+    else for (uint32_t b = 0; b < 16; b++) tmp[c][b] = base + b < job.comp_size ? in[base + b] : 0;
+  }
+  for (uint32_t c = 0; c < kPieces; c++) memcpy(sh.win + (c * kSnapLanes + lane) * 16, tmp[c], 16);
+  if (lane == 0) {
+    memset(sh.win + kSnapWindow, 0, 16);
+    sh.win_pos = sh.in_pos; sh.round_out0 = sh.out_pos; sh.direct = 0; sh.cut = kSnapStop;
+  }
+}
+
+// next: classify the nodes lane, lane + kSnapLanes, ...: element {length, successor} or STOP; start of the mark phase
+PLX_HD void snappy_next(SnapShared& sh, const DecompJob& job, uint32_t lane) {
+  const uint32_t avail = job.comp_size - sh.in_pos;       // input bytes left (in_pos <= comp_size)
+  for (uint32_t b = lane; b < kSnapNodes; b += kSnapLanes) {
+    uint32_t v = kSnapStop;
+    uint16_t j = kSnapEnd;
+    if (b + 5 <= kSnapWindow && b < avail) {              // tag + up to 4 length / offset bytes inside the window, inside the input
+      uint32_t len, val, hdr;
+      const uint32_t kind = snappy_tag(sh.win + b, &len, &val, &hdr);
+      if (kind == 0 && len > kSnapDirect) v = kSnapLongNode;
+      else {
+        const uint32_t nxt = b + hdr + (kind == 0 ? len : 0);
+        v = (len << 16) | nxt;
+        j = (uint16_t)nxt;                                // < kSnapNodes; may be a STOP node, which then ends the chain
+      }
+    }
+    sh.nl[b] = v;
+    sh.jmp[0][b] = j;
+    sh.mark[b] = b == 0;
+  }
+}
+
+// mark: sweep `it` of the pointer doubling; returns whether this lane still saw a node with a successor
+PLX_HD bool snappy_mark(SnapShared& sh, uint32_t it, uint32_t lane) {
+  const uint16_t* src = sh.jmp[it & 1];
+  uint16_t* dst = sh.jmp[(it & 1) ^ 1];
+  bool changed = false;
+  for (uint32_t b = lane; b < kSnapNodes; b += kSnapLanes) {
+    const uint16_t j = src[b];
+    if (j == kSnapEnd) { dst[b] = kSnapEnd; continue; }
+    if (sh.mark[b]) sh.mark[j] = 1;                       // marks only ever land on nodes of the real chain
+    dst[b] = src[j];
+    changed = true;
+  }
+  return changed;
+}
+
+// rank, step 1: per thread chunk of kSnapChunk consecutive positions: marked elements, their output bytes; the first marked STOP
+PLX_HD void snappy_rank(SnapShared& sh, uint32_t lane) {
+  uint32_t cnt = 0, len = 0;
+  for (uint32_t b = lane * kSnapChunk; b < (lane + 1) * kSnapChunk; b++) {
+    if (!sh.mark[b]) continue;
+    const uint32_t v = sh.nl[b];
+    if (v >= kSnapLongNode) { snap_min(&sh.cut, b); break; }      // the chain ends here (nothing behind a STOP is marked)
+    cnt++; len += v >> 16;
+  }
+  sh.part_cnt[lane] = cnt; sh.part_len[lane] = len;
+}
+
+// rank, step 2: lane 0 turns the partial sums into exclusive prefixes (256 independent LDS reads, a chain of adds)
+PLX_HD void snappy_scan(SnapShared& sh) {
+  uint32_t c = 0, l = 0;
+  for (uint32_t t = 0; t < kSnapLanes; t++) {
+    const uint32_t pc = sh.part_cnt[t], pl = sh.part_len[t];
+    sh.part_cnt[t] = c; sh.part_len[t] = l;
+    c += pc; l += pl;
+  }
+  sh.part_cnt[kSnapLanes] = c; sh.part_len[kSnapLanes] = l;
+}
+
+// place: decode and validate the marked elements of this thread's positions into el[rank]; the first one that does not fit cuts the round
+PLX_HD void snappy_place(SnapShared& sh, const DecompJob& job, uint32_t lane) {
+  uint32_t r = sh.part_cnt[lane], d = sh.part_len[lane];
+  const uint32_t win0 = sh.win_pos, round0 = sh.round_out0;
+  for (uint32_t b = lane * kSnapChunk; b < (lane + 1) * kSnapChunk; b++) {
+    if (!sh.mark[b]) continue;
+    const uint32_t v = sh.nl[b];
+    if (v >= kSnapLongNode) break;
+    const uint32_t olen = v >> 16;
+    if (r >= kSnapElems || d + olen > kSnapRound) { snap_min(&sh.cut, b); break; }   // monotone: everything behind it fails too
+    uint32_t len, val, hdr;
+    const uint32_t kind = snappy_tag(sh.win + b, &len, &val, &hdr);
+    SnapElem el;
+    el.dst = (uint16_t)d; el.len = (uint16_t)len;
+    bool ok = len <= job.uncomp_size - (round0 + d);
+    if (kind == 0) {
+      const uint32_t src = win0 + b + hdr;
+      ok = ok && src <= job.comp_size && len <= job.comp_size - src;
+      el.src = 0x80000000u | src;
+    } else {
+      ok = ok && win0 + b + hdr <= job.comp_size && val >= 1 && val <= round0 + d;
+      el.src = val;
+    }
+    if (!ok) sh.bad = 1;                                  // the round is abandoned before any pointer is formed
+    sh.el[r] = el;
+    r++; d += olen;
+  }
+}
+
+// finish: lane 0 closes the round at `cut` (element count, bytes, where the next round starts, end of stream, a direct literal)
+PLX_HD void snappy_finish(SnapShared& sh, const DecompJob& job) {
+  const uint32_t c = sh.cut, win0 = sh.win_pos;
+  const uint32_t avail = job.comp_size - win0;
+  if (c >= kSnapNodes) { sh.done = 2; return; }           // cannot happen (every chain ends in a STOP node); never spin
+  // elements and bytes in front of the cut: prefix of its chunk + the marked elements of the chunk before it
+  const uint32_t t = c / kSnapChunk;
+  uint32_t n = sh.part_cnt[t], bytes = sh.part_len[t];
+  for (uint32_t b = t * kSnapChunk; b < c; b++)
+    if (sh.mark[b]) { n++; bytes += sh.nl[b] >> 16; }
+  uint32_t done = 0, next = c;
+  if (c >= avail) {
+    done = c == avail ? 1u : 2u;                          // a literal running past the end of the input
+  } else if (sh.nl[c] == kSnapLongNode && n == 0) {
+    uint32_t l, val, hdr;
+    snappy_tag(sh.win + c, &l, &val, &hdr);
+    const uint32_t src = win0 + c + hdr;
+    if (l == 0xffffffffu || src > job.comp_size || l > job.comp_size - src || l > job.uncomp_size - sh.out_pos) { sh.done = 2; return; }
+    sh.direct = 1; sh.direct_src = src; sh.direct_len = l;
+    next = c + hdr + l; bytes = l;
+    if (next >= avail) done = next == avail ? 1u : 2u;
+  }
+  if (done == 1 && sh.out_pos + bytes != job.uncomp_size) done = 2;     // the stream ends, the promised length is not reached
+  if (!done && next == 0) done = 2;                       // no progress is impossible for a well-formed stream; never spin
+  sh.n_el = n; sh.in_pos = win0 + next; sh.out_pos += bytes; sh.done = done;
+}
+
+// direct: the round's single long literal, 16 bytes per lane and step
+PLX_HD void snappy_direct(const SnapShared& sh, const DecompJob& job, uint32_t lane) {
+  const uint8_t* s = (const uint8_t*)job.src + sh.direct_src;
+  uint8_t* d = (uint8_t*)job.dst + sh.round_out0;
+  const uint32_t n = sh.direct_len;
+  // four 16-byte pieces per lane and step, loaded before any is stored (input and output never overlap, which the compiler cannot know)
+  for (uint32_t o0 = 0; o0 < n; o0 += 4 * kSnapLanes * 16) {
+    uint8_t tmp[4][16];
+    for (uint32_t c = 0; c < 4; c++) {
+      const uint32_t o = o0 + (c * kSnapLanes + lane) * 16;
+      if (o + 16 <= n) memcpy(tmp[c], s + o, 16);
+      else for (uint32_t b = 0; b < 16; b++) tmp[c][b] = o + b < n ? s[o + b] : 0;
+    }
+    for (uint32_t c = 0; c < 4; c++) {
+      const uint32_t o = o0 + (c * kSnapLanes + lane) * 16;
+      if (o + 16 <= n) memcpy(d + o, tmp[c], 16);
+      else for (uint32_t b = 0; o + b < n && b < 16; b++) d[o + b] = tmp[c][b];
+    }
+  }
+}
+
+// point: pointer of every output byte of the round
+PLX_HD void snappy_point(SnapShared& sh, uint32_t lane) {
+  const uint32_t n = sh.n_el, round0 = sh.round_out0;
+  for (uint32_t k = lane; k < n; k += kSnapLanes) {       // element-major: no search, the element knows its bytes
+    const SnapElem e = sh.el[k];
+    const uint32_t end = (uint32_t)e.dst + e.len;
+    if (e.src >> 31) {
+      const uint32_t base = kSnapKindLit | (e.src & 0x7fffffffu);
+      for (uint32_t i = e.dst; i < end; i++) sh.ptr[i] = base + (i - e.dst);
+    } else {
+      for (uint32_t i = e.dst; i < end; i++)
+        sh.ptr[i] = e.src <= i ? i - e.src                // a byte of this round (strictly earlier: offset >= 1)
+                               : kSnapKindFar | (round0 + i - e.src);   // place checked offset <= absolute position
+    }
+  }
+}
+
+// jump: one sweep of pointer jumping; returns whether this lane still followed a pointer into the round
+PLX_HD bool snappy_jump(SnapShared& sh, uint32_t lane) {
+  const uint32_t n_bytes = sh.out_pos - sh.round_out0;
+  bool changed = false;
+  for (uint32_t i = lane; i < n_bytes; i += kSnapLanes) {
+    const uint32_t p = sh.ptr[i];
+    if (p >> 30) continue;                                // resolved: input byte or earlier output
+    sh.ptr[i] = sh.ptr[p];                                // p < i: any value found there is an ancestor of byte i
+    changed = true;
+  }
+  return changed;
+}
+
+// gather: load every byte through its resolved pointer and store it
+PLX_HD void snappy_gather(const SnapShared& sh, const DecompJob& job, uint32_t lane) {
+  const uint8_t* in = (const uint8_t*)job.src;
+  uint8_t* gout = (uint8_t*)job.dst;
+  const uint32_t n_bytes = sh.out_pos - sh.round_out0, round0 = sh.round_out0;
+  // Every resolved pointer leads outside the round (input, or output of earlier rounds), so the loads never alias the stores --
+  // which the compiler cannot know: taken one byte at a time each load would wait for the previous store.  16 loads in flight,
+  // then 16 stores.
+  constexpr uint32_t kBatch = 16;
+  for (uint32_t i0 = lane; i0 < n_bytes; i0 += kSnapLanes * kBatch) {
+    uint8_t v[kBatch] = {};
+    for (uint32_t k = 0; k < kBatch; k++) {
+      const uint32_t i = i0 + kSnapLanes * k;
+      if (i < n_bytes) {
+        const uint32_t p = sh.ptr[i];
+        const uint32_t at = p & kSnapPosMask;
+        v[k] = (p >> 30) == 2 ? in[at] : gout[at];
+      }
+    }
+    for (uint32_t k = 0; k < kBatch; k++) {
+      const uint32_t i = i0 + kSnapLanes * k;
+      if (i < n_bytes) gout[round0 + i] = v[k];
+    }
+  }
+}
+
+}  // namespace pq
+}  // namespace plx

@@ -1,17 +1,16 @@
-"""Parquet scan -> device columns: the step BEFORE the hot path, host-decoded.
+"""Parquet scan -> device columns: the step BEFORE the hot path.
 
 The reference reads Parquet with its own decoder and pushes projections and predicates into the scan
 (crates/polars-io/src/parquet/read, crates/polars-plan/src/plans/optimizer/{projection_pushdown, predicate_pushdown},
-row-group skipping by statistics: crates/polars-io/src/predicates.rs).  Here the decoder is pyarrow on the host; what this
-module adds is the part that decides HOW MUCH crosses PCIe:
+row-group skipping by statistics: crates/polars-io/src/predicates.rs).  Here:
 
-* projection pushdown -- only the columns the plan reads are decoded and uploaded (TPC-H Q1 touches 7 of lineitem's 16),
+* the DECODER is on the device (decoder="device", the default): the library parses the footer itself, the selected column chunks
+  cross PCIe exactly as they are stored -- compressed and encoded -- and are decompressed / decoded in HBM
+  (`plx_parquet_*`, polars_amd/csrc/parquet*.{hpp,cpp} + kernels_parquet.hip).  decoder="host" keeps the round-1 path (pyarrow
+  decodes, Arrow buffers are uploaded) for files outside the device decoder's codecs / encodings,
+* projection pushdown -- only the columns the plan reads are fetched (TPC-H Q1 touches 7 of lineitem's 16),
 * predicate pushdown to row groups -- conjuncts `column <cmp> literal` of the filters directly above the scan skip the row
-  groups whose min / max statistics cannot match (the filter itself still runs on the GPU, exactly),
-* the upload goes through the Arrow C Data Interface import of the C ABI (buffers >= 32 MB are page-locked in place, one DMA).
-
-A device-side Parquet decoder (no host staging) is what row 3 ultimately asks for; this is the drop-in API with the traffic
-reduction, not that decoder.
+  groups whose min / max statistics cannot match (the filter itself still runs on the GPU, exactly).
 """
 from __future__ import annotations
 
@@ -24,6 +23,8 @@ from . import plan as P
 from .expr import Expr
 
 Pred = Tuple[str, int, Any]          # (column, plx comparison operator, python literal)
+
+_EPOCH = _dt.datetime(1970, 1, 1)
 
 
 def _mirror_dtype(t) -> T.DataType:
@@ -43,20 +44,176 @@ def _mirror_dtype(t) -> T.DataType:
     raise TypeError(f"parquet column type {t} is outside the hot path")
 
 
+class _HostDecoder:
+    """decoder="host": pyarrow reads and decodes on the CPU, the decoded Arrow buffers are uploaded (the round-1 path; kept for files
+    the device decoder does not cover: zstd / gzip pages, PLAIN string pages, delta encodings)."""
+    name = "host"
+
+    def __init__(self, path: str):
+        import pyarrow.parquet as pq
+        self._pf = pq.ParquetFile(path)
+        md = self._pf.metadata
+        self.names = list(self._pf.schema_arrow.names)
+        self.num_rows, self.num_row_groups = md.num_rows, md.num_row_groups
+        self._col_index = {md.schema.column(i).name: i for i in range(md.num_columns)}
+
+    def dtype(self, name: str) -> T.DataType:
+        return _mirror_dtype(self._pf.schema_arrow.field(name).type)
+
+    def stats(self, g: int, name: str):
+        """(min, max) in the domain pyarrow reports statistics in, or None"""
+        if name not in self._col_index:
+            return None
+        st = self._pf.metadata.row_group(g).column(self._col_index[name]).statistics
+        if st is None or not st.has_min_max:
+            return None
+        return st.min, st.max
+
+    def literal(self, name: str, value: Any, like: Any) -> Any:
+        return _comparable(value, like)
+
+    def read(self, rgs: List[int], cols: List[str]):
+        from .frame import DataFrame, Series
+        tbl = self._pf.read_row_groups(rgs, columns=cols) if rgs else self._pf.schema_arrow.empty_table().select(cols)
+        return DataFrame([Series.from_arrow(n, tbl.column(n)) for n in cols]), tbl.num_rows, tbl.nbytes
+
+
+class _DeviceDecoder:
+    """decoder="device" (default): the library parses the footer itself (plx_parquet_open: no pyarrow anywhere on this path), the
+    selected column chunks are copied to HBM as stored and decoded by kernels (plx_parquet_read; polars_amd/csrc/parquet*.{hpp,cpp},
+    kernels_parquet.hip).  Metadata and statistics are available without a GPU."""
+    name = "device"
+    _LOGICAL = {1: "date", 2: "datetime", 3: "string", 4: "binary"}
+
+    def __init__(self, path: str):
+        import ctypes as C
+        h = C.c_uint64()
+        F.check(F.lib().plx_parquet_open(path.encode(), C.byref(h)))
+        self._h = h.value
+        n, g, c = C.c_int64(), C.c_int32(), C.c_int32()
+        F.check(F.lib().plx_parquet_shape(self._h, C.byref(n), C.byref(g), C.byref(c)))
+        self.num_rows, self.num_row_groups = n.value, g.value
+        self.names, self._info = [], {}
+        for i in range(c.value):
+            nm, dt, lg, nl = C.c_char_p(), C.c_int32(), C.c_int32(), C.c_int32()
+            F.check(F.lib().plx_parquet_column_info(self._h, i, C.byref(nm), C.byref(dt), C.byref(lg), C.byref(nl)))
+            name = nm.value.decode()
+            self.names.append(name)
+            self._info[name] = (i, dt.value, lg.value, bool(nl.value))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", 0) and F._lib is not None:
+                F._lib.plx_parquet_close(self._h)
+        except Exception:
+            pass
+
+    def dtype(self, name: str) -> T.DataType:
+        _, dt, lg, _ = self._info[name]
+        if dt < 0:
+            raise TypeError(f"parquet column {name!r} has a type outside the hot path (nested, decimal, INT96, non-us timestamp, ...)")
+        if lg == 1:
+            return T.Date
+        if lg == 2:
+            return T.Datetime
+        if lg in (3, 4):
+            return T.Categorical([])
+        return T.PHYSICAL_TO_DTYPE[dt]
+
+    def stats(self, g: int, name: str):
+        import ctypes as C
+        if name not in self._info:
+            return None
+        i, dt, lg, _ = self._info[name]
+        has, mn, mx = C.c_int32(), F.Scalar(), F.Scalar()
+        F.check(F.lib().plx_parquet_chunk_info(self._h, g, i, None, None, None, None, C.byref(has), C.byref(mn), C.byref(mx), None))
+        if not has.value:
+            return None
+        pick = (lambda s: s.f64) if dt == F.F64 else (lambda s: float(s.f32)) if dt == F.F32 else (lambda s: s.u) if dt in (F.U8, F.U16, F.U32, F.U64) else \
+               (lambda s: bool(s.u)) if dt == F.BOOL else (lambda s: s.i)
+        return pick(mn), pick(mx)
+
+    def literal(self, name: str, value: Any, like: Any) -> Any:
+        """The literal in the PHYSICAL domain the library reports statistics in (Date = days, Datetime = microseconds)."""
+        lg = self._info[name][2]
+        if lg == 2:
+            if isinstance(value, _dt.datetime):
+                v = value.replace(tzinfo=None) if value.tzinfo is None else value.astimezone(_dt.timezone.utc).replace(tzinfo=None)
+                d = v - _EPOCH
+                return (d.days * 86400 + d.seconds) * 1_000_000 + d.microseconds
+            if isinstance(value, _dt.date):
+                return (value - _EPOCH.date()).days * 86_400_000_000
+        if lg == 1:
+            if isinstance(value, _dt.datetime):
+                return (value.date() - _EPOCH.date()).days
+            if isinstance(value, _dt.date):
+                return (value - _EPOCH.date()).days
+        if isinstance(value, (bool, int, float)):
+            return value
+        raise TypeError("statistics and literal are not comparable")
+
+    def chunk_info(self, g: int, name: str) -> Dict[str, Any]:
+        import ctypes as C
+        i = self._info[name][0]
+        codec, enc, cb, ub, nc = C.c_int32(), C.c_uint32(), C.c_int64(), C.c_int64(), C.c_int64()
+        F.check(F.lib().plx_parquet_chunk_info(self._h, g, i, C.byref(codec), C.byref(enc), C.byref(cb), C.byref(ub), None, None, None, C.byref(nc)))
+        return {"codec": codec.value, "encodings": enc.value, "compressed_bytes": cb.value, "uncompressed_bytes": ub.value, "null_count": nc.value}
+
+    def read(self, rgs: List[int], cols: List[str]):
+        import ctypes as C
+        from .frame import DataFrame
+        F.ensure_init()
+        idx = [self._info[n][0] for n in cols]
+        a_rg = (C.c_int32 * max(len(rgs), 1))(*rgs)
+        a_col = (C.c_int32 * max(len(idx), 1))(*idx)
+        fh = C.c_uint64()
+        F.check(F.lib().plx_parquet_read(self._h, a_rg, len(rgs), a_col, len(idx), C.byref(fh)))
+        hint = {}
+        for n in cols:
+            i, dt, lg, _ = self._info[n]
+            if lg in (3, 4):
+                hint[n] = T.Categorical(self._categories(i, binary=lg == 4), T.UInt32)
+            elif lg:
+                hint[n] = T.Date if lg == 1 else T.Datetime
+        df = DataFrame._from_frame_handle(fh.value, hint)
+        for s in df.get_columns():
+            s._declare_dictionary_bounds()
+        nbytes = sum(self.chunk_info(g, n)["compressed_bytes"] for g in rgs for n in cols)
+        return df, df.height, nbytes
+
+    def _categories(self, col: int, binary: bool) -> list:
+        import ctypes as C
+
+        import numpy as np
+        n, tb = C.c_int64(), C.c_int64()
+        F.check(F.lib().plx_parquet_categories(self._h, col, C.byref(n), C.byref(tb)))
+        off = np.zeros(n.value + 1, np.int64)
+        raw = np.zeros(max(tb.value, 1), np.uint8)
+        F.check(F.lib().plx_parquet_categories_to_host(self._h, col, off.ctypes.data_as(C.c_void_p), raw.ctypes.data_as(C.c_void_p)))
+        b = raw.tobytes()
+        items = [b[off[i]:off[i + 1]] for i in range(n.value)]
+        return items if binary else [x.decode("utf-8", "replace") for x in items]
+
+
 class ParquetFrame:
     """A scan source: looks like a DataFrame to the plan lowering (`schema`, `_frame_handle()`), materialises lazily."""
 
-    def __init__(self, path: str, columns: Optional[Sequence[str]] = None):
-        import pyarrow.parquet as pq
+    def __init__(self, path: str, columns: Optional[Sequence[str]] = None, decoder: str = "device"):
+        if decoder not in ("device", "host"):
+            raise ValueError("decoder must be 'device' or 'host'")
         self.path = path
-        self._pf = pq.ParquetFile(path)
-        names = list(columns) if columns is not None else list(self._pf.schema_arrow.names)
-        self._schema: Dict[str, T.DataType] = {n: _mirror_dtype(self._pf.schema_arrow.field(n).type) for n in names}
+        self._dec = _DeviceDecoder(path) if decoder == "device" else _HostDecoder(path)
+        names = list(columns) if columns is not None else list(self._dec.names)
+        self._schema: Dict[str, T.DataType] = {n: self._dec.dtype(n) for n in names}
         self._need: Optional[Set[str]] = set()          # None = every column of the schema
         self._preds: Optional[List[Pred]] = None        # None = not requested yet; [] = no pushdown
         self._df = None
         self._loaded: Optional[Tuple[frozenset, Tuple[int, ...]]] = None
         self.last_read: Dict[str, Any] = {}
+
+    @property
+    def decoder(self) -> str:
+        return self._dec.name
 
     @property
     def schema(self) -> Dict[str, T.DataType]:
@@ -67,7 +224,11 @@ class ParquetFrame:
 
     @property
     def num_rows(self) -> int:
-        return self._pf.metadata.num_rows
+        return self._dec.num_rows
+
+    @property
+    def num_row_groups(self) -> int:
+        return self._dec.num_row_groups
 
     # -- what the plan needs (called by LazyFrame._lower through plan.push_down) ------------------------------------
     def request(self, columns: Optional[Set[str]], predicates: List[Pred]) -> None:
@@ -97,20 +258,17 @@ class ParquetFrame:
 
     def selected_row_groups(self) -> List[int]:
         """Row groups that can contain a matching row according to their column statistics."""
-        md = self._pf.metadata
         preds = self._preds or []
-        col_index = {md.schema.column(i).name: i for i in range(md.num_columns)}
         keep = []
-        for g in range(md.num_row_groups):
-            rg = md.row_group(g)
+        for g in range(self._dec.num_row_groups):
             ok = True
             for name, op, value in preds:
-                st = rg.column(col_index[name]).statistics if name in col_index else None
-                if st is None or not st.has_min_max:
+                st = self._dec.stats(g, name)
+                if st is None:
                     continue
-                lo, hi = st.min, st.max
+                lo, hi = st
                 try:
-                    v = _comparable(value, lo)
+                    v = self._dec.literal(name, value, lo)
                     if isinstance(lo, float) or isinstance(hi, float) or isinstance(v, float):
                         # Parquet min/max exclude NaN, but the engine compares floats in TOTAL order (NaN == NaN, NaN greatest:
                         # comparisons/simd.rs:171-275), so a group may hold a NaN row that satisfies >, >=, != or == NaN although
@@ -133,17 +291,14 @@ class ParquetFrame:
 
     # -- materialisation ---------------------------------------------------------------------------------------------------
     def materialise(self):
-        from .frame import DataFrame, Series
         cols, rgs = self.selected_columns(), self.selected_row_groups()
         key = (frozenset(cols), tuple(rgs))
         if self._df is not None and self._loaded == key:
             return self._df
-        md = self._pf.metadata
-        tbl = self._pf.read_row_groups(rgs, columns=cols) if rgs else self._pf.schema_arrow.empty_table().select(cols)
-        self._df = DataFrame([Series.from_arrow(n, tbl.column(n)) for n in cols])
+        self._df, rows, nbytes = self._dec.read(rgs, cols)
         self._loaded = key
-        self.last_read = {"columns": cols, "row_groups": len(rgs), "of_row_groups": md.num_row_groups, "rows": tbl.num_rows, "of_rows": md.num_rows,
-                          "bytes": tbl.nbytes}
+        self.last_read = {"columns": cols, "row_groups": len(rgs), "of_row_groups": self._dec.num_row_groups, "rows": rows, "of_rows": self._dec.num_rows,
+                          "bytes": nbytes, "decoder": self._dec.name}
         return self._df
 
     def _frame_handle(self) -> int:
@@ -168,15 +323,16 @@ def _comparable(value: Any, like: Any) -> Any:
     raise TypeError("statistics and literal are not comparable")
 
 
-def scan_parquet(path: str, columns: Optional[Sequence[str]] = None):
-    """LazyFrame over a Parquet file (mirrors polars.scan_parquet for the path's dtypes).  Nothing is read until collect()."""
+def scan_parquet(path: str, columns: Optional[Sequence[str]] = None, decoder: str = "device"):
+    """LazyFrame over a Parquet file (mirrors polars.scan_parquet for the path's dtypes).  Nothing is read until collect().
+    decoder="device": column chunks are decoded on the GPU (UNCOMPRESSED / SNAPPY, PLAIN / dictionary pages); "host": pyarrow."""
     from .frame import LazyFrame
-    return LazyFrame(P.Node("scan", frame=ParquetFrame(path, columns)))
+    return LazyFrame(P.Node("scan", frame=ParquetFrame(path, columns, decoder)))
 
 
-def read_parquet(path: str, columns: Optional[Sequence[str]] = None):
-    """Eager variant: decode (only `columns`) and upload."""
-    pf = ParquetFrame(path, columns)
+def read_parquet(path: str, columns: Optional[Sequence[str]] = None, decoder: str = "device"):
+    """Eager variant: decode (only `columns`) into device columns."""
+    pf = ParquetFrame(path, columns, decoder)
     pf.request(None, [])
     return pf.materialise()
 

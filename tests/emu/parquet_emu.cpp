@@ -18,6 +18,44 @@ using namespace plx::pq;
 
 namespace {
 
+// the part of a round after the parse, lanes of a phase one after another (ascending or descending: the result must not depend on it)
+template <class F> void for_lanes(int order, F&& f) {
+  if (order == 0) for (uint32_t lane = 0; lane < kSnapLanes; lane++) f(lane);
+  else for (uint32_t lane = kSnapLanes; lane-- > 0;) f(lane);
+}
+// one wavefront decompressing one stream: the loop of pq_snappy_kernel, every barrier-separated phase run lane after lane
+uint32_t snappy_stream(const DecompJob& job, int order, uint32_t* rounds) {
+  SnapShared sh;
+  memset(&sh, 0xA5, sizeof sh);     // LDS is not zeroed
+  snappy_begin(sh, job);
+  uint32_t nr = 0;
+  while (sh.done == 0) {
+    nr++;
+    for_lanes(order, [&](uint32_t lane) { snappy_stage(sh, job, lane); });
+    for_lanes(order, [&](uint32_t lane) { snappy_next(sh, job, lane); });
+    for (uint32_t it = 0; it < kSnapSweeps; it++) {   // __syncthreads_or(snappy_mark(...)) of the kernel
+      bool any = false;
+      for_lanes(order, [&](uint32_t lane) { any |= snappy_mark(sh, it, lane); });
+      if (!any) break;
+    }
+    for_lanes(order, [&](uint32_t lane) { snappy_rank(sh, lane); });
+    snappy_scan(sh);
+    for_lanes(order, [&](uint32_t lane) { snappy_place(sh, job, lane); });
+    snappy_finish(sh, job);
+    if (sh.done == 2 || sh.bad) break;
+    if (sh.direct) { for_lanes(order, [&](uint32_t lane) { snappy_direct(sh, job, lane); }); continue; }
+    for_lanes(order, [&](uint32_t lane) { snappy_point(sh, lane); });
+    for (;;) {                                   // __syncthreads_or(snappy_jump(...)) of the kernel
+      bool any = false;
+      for_lanes(order, [&](uint32_t lane) { any |= snappy_jump(sh, lane); });
+      if (!any) break;
+    }
+    for_lanes(order, [&](uint32_t lane) { snappy_gather(sh, job, lane); });
+  }
+  if (rounds) *rounds = nr;
+  return (sh.done == 2 || sh.bad) ? (uint32_t)PE_SNAPPY : 0u;
+}
+
 struct HostBackend {
   using Mem = std::shared_ptr<std::vector<uint8_t>>;
   std::vector<uint8_t> stage_[2];
@@ -49,18 +87,7 @@ struct HostBackend {
 
   // one wavefront per stream: the loop of pq_snappy_kernel with the lanes of a phase run one after another
   void run_snappy(const DecompJob* jobs, uint32_t n, uint64_t, uint32_t* err) {
-    for_threads(n, [&](uint64_t j) {
-      SnapShared sh;
-      const DecompJob job = jobs[j];
-      snappy_begin(sh, job);
-      while (sh.done == 0) {
-        for (uint32_t lane = 0; lane < 64; lane++) snappy_stage(sh, job, lane);
-        snappy_parse(sh, job);
-        if (order == 0) for (uint32_t lane = 0; lane < 64; lane++) snappy_copy(sh, job, lane);
-        else for (uint32_t lane = 64; lane-- > 0;) snappy_copy(sh, job, lane);
-      }
-      if (sh.done == 2) *err |= PE_SNAPPY;
-    });
+    for_threads(n, [&](uint64_t j) { *err |= snappy_stream(jobs[j], order, nullptr); });
   }
   void run_page_prepare(PageDesc* pages, uint32_t n, uint32_t* err) { for_threads(n, [&](uint64_t i) { *err |= page_prepare(pages[i]); }); }
   void run_count_runs(const PageDesc* pages, uint32_t n, bool levels, uint32_t* counts, uint32_t* err) {
@@ -148,17 +175,8 @@ int pqemu_snappy(const uint8_t* in, uint32_t n_in, uint8_t* out, uint32_t n_out,
   std::vector<uint8_t> src(in, in + n_in);
   src.resize(n_in + 64, 0xCC);
   DecompJob job{(uint64_t)src.data(), (uint64_t)out, n_in, n_out};
-  uint32_t err = 0, nr = 0;
-  SnapShared sh;
-  snappy_begin(sh, job);
-  while (sh.done == 0) {
-    for (uint32_t lane = 0; lane < 64; lane++) snappy_stage(sh, job, lane);
-    snappy_parse(sh, job);
-    if (thread_order == 0) for (uint32_t lane = 0; lane < 64; lane++) snappy_copy(sh, job, lane);
-    else for (uint32_t lane = 64; lane-- > 0;) snappy_copy(sh, job, lane);
-    nr++;
-  }
-  if (sh.done == 2) err = PE_SNAPPY;
+  uint32_t nr = 0;
+  uint32_t err = snappy_stream(job, thread_order, &nr);
   if (rounds) *rounds = nr;
   return (int)err;
 }

@@ -20,7 +20,7 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in _DEPS):
-            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", SO, SRC], check=True)
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", SO, SRC, "-lpthread"], check=True)
         l = C.CDLL(SO)
         l.pqemu_last_error.restype = C.c_char_p
         l.pqemu_read_column.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]

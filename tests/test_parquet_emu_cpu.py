@@ -1,0 +1,389 @@
+"""The device Parquet decoder, checked on the CPU.
+
+tests/emu/parquet_emu.cpp instantiates the PRODUCT's reader (polars_amd/csrc/parquet_reader.hpp) with a backend that runs the
+product's per-thread / per-wavefront kernel bodies (parquet_device.hpp) one thread after another on host memory.  Ground truth:
+pyarrow's own decode of the same file (files are written here with pyarrow: codecs, page versions, dictionary on / off, page and row
+group sizes, nulls).  Snappy is additionally fuzzed on hand-built streams (every element kind, overlapping copies, long literals)
+against a 20-line Python decoder, and on corrupt streams, which must yield an error code and never touch bytes past the output.
+"""
+import datetime as dt
+import os
+import struct
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+import pytest
+
+import parquet_emu as E
+
+RNG = np.random.default_rng(20260923)
+
+
+def check_column(path, table, name, row_groups=None, order=0):
+    ci = table.column_names.index(name)
+    nrg = pq.ParquetFile(path).metadata.num_row_groups
+    rgs = list(range(nrg)) if row_groups is None else row_groups
+    r = E.read_column(path, rgs, ci, order)
+    want = pq.ParquetFile(path).read_row_groups(rgs, columns=[name]).column(0).combine_chunks() if rgs else table.column(name).combine_chunks().slice(0, 0)
+    n = len(want)
+    assert len(r["values"]) == n
+    wvalid = np.array([v is not None for v in want.to_pylist()], bool) if want.null_count else np.ones(n, bool)
+    if r["valid"] is None:
+        assert want.null_count == 0 and r["null_count"] == 0
+    else:
+        assert np.array_equal(r["valid"], wvalid) and r["null_count"] == want.null_count
+        # pad bits of the last validity word are zero
+        if n % 64:
+            assert int(r["raw_validity_words"][-1]) >> (n % 64) == 0
+    t = want.type
+    if pa.types.is_string(t) or pa.types.is_large_string(t) or pa.types.is_binary(t) or pa.types.is_large_binary(t):
+        wl = want.to_pylist()
+        cats = r["categories"]
+        assert len(set(cats)) == len(cats)
+        for i in np.nonzero(wvalid)[0]:
+            w = wl[i] if isinstance(wl[i], bytes) else wl[i].encode()
+            assert cats[r["values"][i]] == w
+        assert set(cats) >= {(x if isinstance(x, bytes) else x.encode()) for x in wl if x is not None}
+        return r
+    if pa.types.is_timestamp(t):
+        exp = want.cast(pa.int64()).to_numpy(zero_copy_only=False)
+    elif pa.types.is_date32(t):
+        exp = want.cast(pa.int32()).to_numpy(zero_copy_only=False)
+    else:
+        exp = want.to_numpy(zero_copy_only=False)
+    got = r["values"]
+    if pa.types.is_boolean(t):
+        exp = np.array([bool(x) if x is not None else False for x in want.to_pylist()])
+        assert np.array_equal(got[wvalid], exp[wvalid])
+        if n % 64:
+            assert int(r["raw_value_words"][-1]) >> (n % 64) == 0
+    elif pa.types.is_floating(t):
+        e = np.asarray(exp, dtype=got.dtype)
+        assert np.array_equal(got[wvalid].view(np.uint32 if got.dtype == np.float32 else np.uint64), e[wvalid].view(np.uint32 if got.dtype == np.float32 else np.uint64))   # bit-exact, NaN payloads included
+    else:
+        if pa.types.is_timestamp(t) or pa.types.is_date32(t):
+            want = want.cast(pa.int64() if pa.types.is_timestamp(t) else pa.int32())
+        e = np.fromiter((x if x is not None else 0 for x in want.to_pylist()), dtype=got.dtype, count=n)
+        assert np.array_equal(got[wvalid], e[wvalid])
+    assert np.all(got[~wvalid] == 0)       # null slots are written (as zero), never left uninitialised
+    return r
+
+
+def mixed_table(n, null_frac=0.2):
+    m = lambda: RNG.random(n) < null_frac
+    words = np.array(["", "a", "bb", "BUILDING", "AUTOMOBILE", "a much longer string that does not fit in twelve bytes", "ünïcödé"])
+    return pa.table({
+        "i8": pa.array(RNG.integers(-128, 128, n).astype(np.int8)), "i16": pa.array(RNG.integers(-30000, 30000, n).astype(np.int16), mask=m()),
+        "i32": pa.array(RNG.integers(-2**31, 2**31, n).astype(np.int32), mask=m()), "i64": pa.array(RNG.integers(-2**62, 2**62, n), mask=m()),
+        "u8": pa.array(RNG.integers(0, 256, n).astype(np.uint8), mask=m()), "u16": pa.array(RNG.integers(0, 65536, n).astype(np.uint16)),
+        "u32": pa.array(RNG.integers(0, 2**32, n).astype(np.uint32), mask=m()), "u64": pa.array(RNG.integers(0, 2**63, n).astype(np.uint64) * 2 + 1, mask=m()),
+        "f32": pa.array(RNG.normal(size=n).astype(np.float32), mask=m()), "f64": pa.array(np.where(RNG.random(n) < 0.05, np.nan, RNG.normal(size=n)), mask=m()),
+        "b": pa.array(RNG.random(n) < 0.5, mask=m()), "b_req": pa.array(RNG.random(n) < 0.1),
+        "date": pa.array(RNG.integers(0, 20000, n).astype(np.int32), pa.date32(), mask=m()),
+        "ts": pa.array(RNG.integers(0, 2**50, n), pa.timestamp("us"), mask=m()),
+        "s": pa.array(words[RNG.integers(0, len(words), n)], mask=m()), "ls": pa.array(words[RNG.integers(0, 3, n)], pa.large_string()),
+        "bin": pa.array([bytes([i % 7, 0, 255]) for i in range(n)], pa.binary()),
+        "low_card": pa.array(RNG.integers(0, 3, n)), "const": pa.array(np.full(n, 42, np.int64)), "all_null": pa.array(np.zeros(n, np.int64), mask=np.ones(n, bool)),
+        "runs": pa.array(np.repeat(RNG.integers(0, 5, (n + 99) // 100), 100)[:n], mask=np.repeat(RNG.random((n + 49) // 50) < 0.3, 50)[:n]),
+    })
+
+
+@pytest.mark.parametrize("compression", ["none", "snappy"])
+@pytest.mark.parametrize("version,dictionary", [("1.0", True), ("2.0", True), ("1.0", False), ("2.0", False)])
+def test_every_dtype_against_pyarrow(tmp_path, compression, version, dictionary):
+    n = 5000
+    t = mixed_table(n)
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression=compression, data_page_version=version, use_dictionary=dictionary, row_group_size=1700, data_page_size=2048)
+    for name in t.column_names:
+        if not dictionary and name in ("s", "ls", "bin"):
+            with pytest.raises(E.EmuError) as ei:          # PLAIN string pages: reported as unsupported, naming the column
+                E.read_column(path, [0], t.column_names.index(name))
+            assert ei.value.code == 3 and name in str(ei.value)
+            continue
+        check_column(path, t, name)
+
+
+def test_thread_order_does_not_matter(tmp_path):
+    t = mixed_table(3000)
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression="snappy", row_group_size=1000, data_page_size=1024)
+    for name in ("i64", "f64", "s", "b", "runs", "u8"):
+        check_column(path, t, name, order=1)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 127, 128, 129, 4096])
+def test_sizes_around_word_boundaries(tmp_path, n):
+    t = pa.table({"a": pa.array(RNG.integers(0, 100, n), mask=RNG.random(n) < 0.5), "b": pa.array(RNG.random(n) < 0.5, mask=RNG.random(n) < 0.5),
+                  "s": pa.array(np.array(["x", "y"])[RNG.integers(0, 2, n)] if n else [], pa.string()), "f": pa.array(RNG.normal(size=n))})
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression="snappy", data_page_size=64, row_group_size=50)
+    for name in t.column_names:
+        check_column(path, t, name)
+
+
+def test_row_group_subsets_in_any_order(tmp_path):
+    n = 10_000
+    t = pa.table({"k": pa.array(np.arange(n)), "v": pa.array(RNG.normal(size=n), mask=RNG.random(n) < 0.1), "s": pa.array(np.array(["a", "b", "c", "d"])[np.arange(n) // 2600])})
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, row_group_size=1000, compression="snappy")
+    for rgs in ([3], [9, 0], [2, 3, 4, 7], [], [5, 5]):
+        for name in t.column_names:
+            check_column(path, t, name, row_groups=rgs)
+    # the dictionary of a subset only holds what those chunks' dictionaries hold, in first-appearance order
+    r = E.read_column(path, [9, 0], 2)
+    assert r["categories"] == [b"d", b"a"]
+
+
+def test_nulls_at_page_boundaries_and_long_runs(tmp_path):
+    n = 20_000
+    valid = np.ones(n, bool)
+    valid[1000:3000] = False; valid[4095:4097] = False; valid[-1] = False; valid[0] = False
+    vals = RNG.integers(0, 1 << 40, n)
+    t = pa.table({"a": pa.array(vals, mask=~valid), "d": pa.array(vals % 7, mask=~valid)})
+    path = str(tmp_path / "t.parquet")
+    for ver in ("1.0", "2.0"):
+        pq.write_table(t, path, data_page_size=512, row_group_size=7000, data_page_version=ver, compression="snappy")
+        ra = check_column(path, t, "a"); check_column(path, t, "d")
+        assert ra["stats"]["data_pages"] >= 15 and ra["null_count"] == int((~valid).sum())
+
+
+def test_optional_column_without_nulls_skips_the_level_tables(tmp_path):
+    n = 8000
+    t = pa.table({"a": pa.array(RNG.integers(0, 50, n))})      # pyarrow writes OPTIONAL + null_count = 0 statistics
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, data_page_size=1024)
+    r = check_column(path, t, "a")
+    pages = r["stats"]["data_pages"]
+    assert r["valid"] is None and r["stats"]["run_entries"] < 40 * pages      # only index-stream tables, no level tables
+    # without statistics the levels are decoded, and the validity is dropped again when it turns out to be all ones
+    pq.write_table(t, path, data_page_size=1024, write_statistics=False)
+    r2 = check_column(path, t, "a")
+    assert r2["valid"] is None and r2["null_count"] == 0
+
+
+def test_snappy_sees_real_back_references(tmp_path):
+    """Columns whose pages compress well (periodic PLAIN values): copies, overlapping copies and multi-round streams."""
+    n = 60_000
+    t = pa.table({"period7": pa.array(np.tile(np.arange(7, dtype=np.int64) * 1_000_003, n // 7 + 1)[:n]), "zeros": pa.array(np.zeros(n)),
+                  "ramp": pa.array(np.arange(n, dtype=np.int32) // 16), "text": pa.array(np.tile(np.array(["lorem ipsum dolor", "sit amet", "consectetur"]), n // 3 + 1)[:n])})
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression="snappy", use_dictionary=["text"], data_page_size=1 << 16)
+    for name in t.column_names:
+        r = check_column(path, t, name)
+        if name != "text":
+            assert r["stats"]["snappy_bytes_out"] > 4 * r["stats"]["file_bytes"]
+
+
+def test_unsupported_files_say_what_they_are(tmp_path):
+    n = 100
+    t = pa.table({"a": pa.array(np.arange(n)), "dec": pa.array([None] * n, pa.decimal128(10, 2)), "lst": pa.array([[1, 2]] * n), "ms": pa.array(np.arange(n), pa.timestamp("ms")),
+                  "z": pa.array(np.arange(n))})
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression={"a": "zstd", "dec": "none", "lst.list.element": "none", "ms": "none", "z": "gzip"}, use_dictionary=False,
+                   column_encoding={"z": "DELTA_BINARY_PACKED"})
+    for col, word in ((0, "ZSTD"), (1, "decimal"), (2, "nested"), (3, "timestamp unit"), (4, "GZIP")):
+        with pytest.raises(E.EmuError) as ei:
+            E.read_column(path, [0], col)
+        assert ei.value.code == 3 and word in str(ei.value), str(ei.value)
+    pq.write_table(t.select(["z"]), path, compression="none", use_dictionary=False, column_encoding={"z": "DELTA_BINARY_PACKED"})
+    with pytest.raises(E.EmuError) as ei:
+        E.read_column(path, [0], 0)
+    assert ei.value.code == 3 and "DELTA_BINARY_PACKED" in str(ei.value)
+
+
+def test_corrupt_files_are_errors_not_crashes(tmp_path):
+    n = 4000
+    t = pa.table({"a": pa.array(RNG.integers(0, 9, n), mask=RNG.random(n) < 0.3), "s": pa.array(np.array(["p", "q"])[RNG.integers(0, 2, n)])})
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression="snappy", data_page_size=512)
+    raw = bytearray(open(path, "rb").read())
+    bad = str(tmp_path / "bad.parquet")
+    outcomes = set()
+    for trial in range(60):
+        b = bytearray(raw)
+        md_len = struct.unpack("<I", b[-8:-4])[0]
+        lo, hi = (4, len(b) - 8 - md_len) if trial % 3 else (len(b) - 8 - md_len, len(b) - 8)      # page bytes or footer bytes
+        for _ in range(1 + trial % 4):
+            b[int(RNG.integers(lo, hi))] ^= 1 << int(RNG.integers(0, 8))
+        open(bad, "wb").write(b)
+        for col in (0, 1):
+            try:
+                E.read_column(bad, [0], col)
+                outcomes.add("ok")            # a flipped value bit is still a well-formed file
+            except E.EmuError as e:
+                assert e.code in (1, 3)
+                outcomes.add("error")
+    assert outcomes == {"ok", "error"}
+    open(bad, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(E.EmuError):
+        E.read_column(bad, [0], 0)
+
+
+# ---- Snappy on hand-built streams -------------------------------------------------------------------------------------------------------
+def py_unsnap(data: bytes) -> bytes:
+    pos, n, shift = 0, 0, 0
+    while True:
+        b = data[pos]; pos += 1
+        n |= (b & 0x7f) << shift; shift += 7
+        if not b & 0x80:
+            break
+    out = bytearray()
+    while pos < len(data):
+        tag = data[pos]; pos += 1
+        kind = tag & 3
+        if kind == 0:
+            ln = tag >> 2
+            if ln >= 60:
+                nb = ln - 59
+                ln = int.from_bytes(data[pos:pos + nb], "little"); pos += nb
+            ln += 1
+            out += data[pos:pos + ln]; pos += ln
+            continue
+        if kind == 1:
+            ln, off = ((tag >> 2) & 7) + 4, ((tag >> 5) << 8) | data[pos]; pos += 1
+        elif kind == 2:
+            ln, off = (tag >> 2) + 1, int.from_bytes(data[pos:pos + 2], "little"); pos += 2
+        else:
+            ln, off = (tag >> 2) + 1, int.from_bytes(data[pos:pos + 4], "little"); pos += 4
+        for _ in range(ln):
+            out.append(out[-off])
+    assert len(out) == n
+    return bytes(out)
+
+
+def varint(n):
+    out = bytearray()
+    while True:
+        b = n & 0x7f; n >>= 7
+        out.append(b | (0x80 if n else 0))
+        if not n:
+            return bytes(out)
+
+
+def lit(payload: bytes) -> bytes:
+    n = len(payload) - 1
+    if n < 60:
+        return bytes([n << 2]) + payload
+    nb = max(1, (n.bit_length() + 7) // 8)
+    return bytes([(59 + nb) << 2]) + n.to_bytes(nb, "little") + payload
+
+
+def copy(off, ln, kind=None):
+    if kind is None:
+        kind = 1 if (4 <= ln <= 11 and off < 2048) else 2 if off < 65536 else 3
+    if kind == 1:
+        return bytes([1 | ((ln - 4) << 2) | ((off >> 8) << 5), off & 255])
+    if kind == 2:
+        return bytes([2 | ((ln - 1) << 2)]) + off.to_bytes(2, "little")
+    return bytes([3 | ((ln - 1) << 2)]) + off.to_bytes(4, "little")
+
+
+def random_stream(rng, target):
+    body, out_len = bytearray(), 0
+    while out_len < target:
+        k = rng.integers(0, 10)
+        if out_len == 0 or k < 3:
+            n = int(rng.choice([1, 2, 5, 59, 60, 61, 255, 256, 257, 3000, 70000])) if k < 2 else int(rng.integers(1, 40))
+            body += lit(rng.integers(0, 256, n, dtype=np.uint8).tobytes()); out_len += n
+        else:
+            off = int(rng.integers(1, min(out_len, 70000) + 1)) if k < 8 else int(rng.integers(1, min(out_len, 8) + 1))    # small offsets: overlapping copies
+            ln = int(rng.integers(4, 12)) if k % 2 else int(rng.integers(1, 65))
+            kind = None if rng.random() < 0.7 else (3 if True else 2)
+            if kind is None and not (4 <= ln <= 11 and off < 2048) and off >= 65536:
+                kind = 3
+            body += copy(off, ln, kind); out_len += ln
+    return varint(out_len) + bytes(body), out_len
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_snappy_rounds_on_random_element_streams(seed):
+    rng = np.random.default_rng(seed)
+    data, n = random_stream(rng, int(rng.choice([1, 50, 1000, 5000, 200_000])))
+    want = py_unsnap(data)
+    for order in (0, 1):
+        err, got, rounds, tail = E.snappy(data, n, order)
+        assert err == 0 and got == want and rounds >= 1
+        assert tail == bytes([0x5A]) * 64           # nothing written past the output
+    rc, got = E.snappy_host(data, n)
+    assert rc == 0 and got == want
+
+
+def test_snappy_on_pyarrow_compressed_buffers():
+    for payload in (b"", b"a", b"abc" * 10000, RNG.integers(0, 256, 100_000, dtype=np.uint8).tobytes(), np.arange(50_000, dtype=np.int64).tobytes(),
+                    (b"x" * 70000 + b"y") * 3):
+        data = pa.compress(payload, codec="snappy", asbytes=True)
+        err, got, rounds, tail = E.snappy(data, len(payload))
+        assert err == 0 and got == payload and tail == bytes([0x5A]) * 64
+        rc, got = E.snappy_host(data, len(payload))
+        assert rc == 0 and got == payload
+
+
+def test_snappy_corrupt_streams_fail_cleanly():
+    payload = (b"hello world, " * 500) + RNG.integers(0, 256, 3000, dtype=np.uint8).tobytes()
+    good = pa.compress(payload, codec="snappy", asbytes=True)
+    n = len(payload)
+    cases = [good[:len(good) // 2], good[:-1], varint(n + 1) + good[len(varint(n)):], varint(n) + copy(5, 10, 2), varint(n) + lit(b"ab") + copy(3, 10, 2),
+             varint(10) + lit(b"0123456789abcdef"), varint(10) + bytes([63 << 2, 0xff, 0xff, 0xff, 0xff]), b"\xff\xff\xff\xff\xff\xff", varint(4) + bytes([0x01 | (0 << 2)])]
+    for trial in range(200):
+        b = bytearray(good)
+        b[int(RNG.integers(0, len(b)))] ^= 1 << int(RNG.integers(0, 8))
+        cases.append(bytes(b))
+    errors = 0
+    for data in cases:
+        err, got, _, tail = E.snappy(data, n)
+        assert tail == bytes([0x5A]) * 64
+        rc, got_h = E.snappy_host(data, n)
+        if err == 0:
+            assert rc == 0 and got == got_h        # a flipped literal byte still decodes: both decoders agree on the bytes
+        else:
+            errors += 1
+            assert rc != 0
+    assert errors > 20
+
+
+def test_reader_under_address_sanitizer(tmp_path):
+    """The same reader, built with -fsanitize=address,undefined as a stand-alone program (tests/emu/parquet_emu_main.cpp), over
+    well-formed files, ~150 bit-flipped / truncated copies and corrupt Snappy streams: error codes, never an out-of-bounds access."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "pq_asan")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-o", exe,
+                    os.path.join(here, "emu", "parquet_emu_main.cpp")], check=True)
+    files = []
+    t = mixed_table(3000)
+    for i, (comp, ver, dic) in enumerate((("snappy", "1.0", True), ("none", "2.0", True), ("snappy", "2.0", False))):
+        p = str(tmp_path / f"good{i}.parquet")
+        pq.write_table(t, p, compression=comp, data_page_version=ver, use_dictionary=dic, row_group_size=1100, data_page_size=700)
+        files.append(p)
+        raw = open(p, "rb").read()
+        md_len = struct.unpack("<I", raw[-8:-4])[0]
+        for k in range(50):
+            b = bytearray(raw)
+            lo, hi = (4, len(b) - 8 - md_len) if k % 3 else (len(b) - 8 - md_len, len(b) - 4)
+            for _ in range(1 + k % 5):
+                b[int(RNG.integers(lo, hi))] ^= 1 << int(RNG.integers(0, 8))
+            q = str(tmp_path / f"bad{i}_{k}.parquet")
+            open(q, "wb").write(b if k % 10 else b[:int(RNG.integers(8, len(b)))])
+            files.append(q)
+    payload = (b"hello world, " * 300) + RNG.integers(0, 256, 2000, dtype=np.uint8).tobytes()
+    good = pa.compress(payload, codec="snappy", asbytes=True)
+    for k in range(120):
+        b = bytearray(good)
+        if k:
+            b[int(RNG.integers(0, len(b)))] ^= 1 << int(RNG.integers(0, 8))
+        if k % 7 == 3:
+            b = b[:int(RNG.integers(1, len(b)))]
+        q = str(tmp_path / f"s{k}.snappy")
+        open(q, "wb").write(struct.pack("<I", len(payload)) + bytes(b))
+        files.append(q)
+    for seed in range(6):
+        data, n = random_stream(np.random.default_rng(100 + seed), 20_000)
+        q = str(tmp_path / f"r{seed}.snappy")
+        open(q, "wb").write(struct.pack("<I", n) + data)
+        files.append(q)
+    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600, env={**os.environ, "ASAN_OPTIONS": "detect_leaks=0"})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    counts = dict(kv.split("=") for kv in r.stdout.split())
+    assert int(counts["ok"]) > 100 and int(counts["invalid"]) > 30, r.stdout

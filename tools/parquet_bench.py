@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Device Parquet decode rate: a lineitem-like file (PLAIN doubles / int64 keys, dictionary-encoded low-cardinality ints and
+strings, a nullable column) written by pyarrow, read with polars_amd.read_parquet (decoder="device"), per-kernel times from the
+library's HIP-event profile, pyarrow's own multi-threaded decode of the same file as the CPU yardstick.
+usage (GPU box): python tools/parquet_bench.py [rows] -> one JSON line per codec"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import polars_amd as pl  # noqa: E402
+
+
+def main():
+    n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
+    rng = np.random.default_rng(3)
+    t = pa.table({"l_orderkey": pa.array(np.sort(rng.integers(1, 4 * n, n))), "l_quantity": pa.array(rng.integers(1, 51, n)),
+                  "l_extendedprice": pa.array(rng.random(n) * 1e5), "l_discount": pa.array(rng.integers(0, 11, n) / 100.0),
+                  "l_returnflag": pa.array(np.array(["R", "A", "N"])[rng.integers(0, 3, n)]),
+                  "l_shipdate": pa.array(rng.integers(694224000, 912470400, n) * 1_000_000, pa.timestamp("us")),
+                  "l_nullable": pa.array(rng.integers(0, 1 << 30, n), mask=rng.random(n) < 0.1)})
+    decoded = sum(c.nbytes for c in t.columns)
+    pl.init(0)
+    F = pl._ffi
+    import bench
+    d = tempfile.mkdtemp()
+    for codec in ("none", "snappy"):
+        path = os.path.join(d, f"li_{codec}.parquet")
+        pq.write_table(t, path, compression=codec, row_group_size=1 << 20)
+        fbytes = os.path.getsize(path)
+        pl.read_parquet(path)        # warm: page cache, pool, pinned staging
+        F.check(F.lib().plx_profile_clear()); F.check(F.lib().plx_profile_enable(1))
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); df = pl.read_parquet(path); F.check(F.lib().plx_synchronize()); ts.append(time.perf_counter() - t0)
+        ks = {k: round(v[1] / 3) for k, v in bench.kernel_stats(pl).items()}
+        F.check(F.lib().plx_profile_enable(0))
+        t0 = time.perf_counter(); pq.read_table(path); t_pa = time.perf_counter() - t0
+        best = min(ts)
+        print(json.dumps({"rows": n, "codec": codec, "file_bytes": fbytes, "decoded_bytes": decoded, "read_s": round(best, 4), "file_GBps": round(fbytes / best / 1e9, 2),
+                          "decoded_GBps": round(decoded / best / 1e9, 2), "rows_per_s": round(n / best), "kernel_us_per_read": ks, "kernel_ms_total": round(sum(ks.values()) / 1e3, 2),
+                          "pyarrow_read_table_s": round(t_pa, 4), "pyarrow_threads": pa.cpu_count()}))
+        del df
+
+
+if __name__ == "__main__":
+    main()
