@@ -53,3 +53,14 @@ def test_sort_join_datagen_kernels_do_not_spill():
             if "radix_scatter" in name:
                 assert int(r["LDS Size [bytes/block]"]) <= 80 * 1024, (name, r)
     assert checked >= 15, checked
+
+
+def test_parquet_kernels_do_not_spill_and_fit_two_snappy_workgroups_per_cu():
+    """The Parquet decode kernels keep their state in registers; the Snappy workgroup's LDS (window, node tables, pointers, elements)
+    stays under 80 KB so that two streams share a CU's 160 KB."""
+    res = resource_usage("kernels_parquet.hip")
+    assert len(res) >= 8
+    for name, r in res.items():
+        assert int(r["ScratchSize [bytes/lane]"]) == 0, (name, r)
+        if "pq_snappy" in name:
+            assert int(r["LDS Size [bytes/block]"]) <= 80 * 1024, (name, r)
