@@ -491,6 +491,29 @@ int plx_parquet_read(plx_parquet file, const int32_t* row_groups, int32_t n_row_
 int plx_parquet_categories(plx_parquet file, int32_t column, int64_t* n_strings, int64_t* total_bytes);
 int plx_parquet_categories_to_host(plx_parquet file, int32_t column, int64_t* offsets, uint8_t* bytes);
 
+/* ---- Arrow IPC file (Feather V2) scan -> device columns -------------------------
+ * The reference reads IPC files with crates/polars-arrow/src/io/ipc/read/{file.rs,common.rs,read_basic.rs,schema.rs} (driven by
+ * crates/polars-io/src/ipc/ipc_file.rs and crates/polars-stream/src/nodes/io_sources/ipc.rs): FlatBuffers footer + one message per
+ * record batch whose body holds the column buffers in Arrow layout.  An uncompressed file needs no decoding at all: the host parses
+ * the metadata, every selected buffer goes file -> page-locked staging -> HBM in one DMA, record batches are concatenated in place.
+ *   plx_ipc_open / _shape / _column_info / _batch_info   metadata; work without a GPU.  dtype / logical as for plx_parquet_column_info.
+ *   plx_ipc_read                batches x columns -> frame.  LZ4 / ZSTD compressed bodies, nested columns, non-us timestamps ->
+ *                               PLX_ERR_UNSUPPORTED naming what it met.
+ *   strings                     dictionary-encoded in the file: indices become PLX_U32 codes (widened on the device), values through
+ *                               plx_ipc_categories*.  Utf8 / LargeUtf8 / Utf8View columns: views are assembled on the host, the
+ *                               dictionary is built on the device (plx_strview_dict_encode); plx_ipc_column_strdict hands its handle
+ *                               over (caller frees it with plx_strdict_free). */
+typedef uint64_t plx_ipc;
+int plx_ipc_open(const char* path, plx_ipc* out);
+int plx_ipc_close(plx_ipc file);
+int plx_ipc_shape(plx_ipc file, int64_t* num_rows, int32_t* num_batches, int32_t* num_columns);
+int plx_ipc_column_info(plx_ipc file, int32_t column, const char** name, int32_t* dtype, int32_t* logical, int32_t* nullable);
+int plx_ipc_batch_info(plx_ipc file, int32_t batch, int64_t* num_rows, int64_t* body_bytes, int32_t* compressed);
+int plx_ipc_read(plx_ipc file, const int32_t* batches, int32_t n_batches, const int32_t* columns, int32_t n_columns, plx_frame* out);
+int plx_ipc_categories(plx_ipc file, int32_t column, int64_t* n_strings, int64_t* total_bytes);
+int plx_ipc_categories_to_host(plx_ipc file, int32_t column, int64_t* offsets, uint8_t* bytes);
+int plx_ipc_column_strdict(plx_ipc file, int32_t column, plx_strdict* out);
+
 /* ---- multi-GPU exchange (one process per GPU, RCCL over xGMI) -----------------------------
  * The exchange step of the sharded operators; shape of the reference's in-process exchange:
  * crates/polars-utils/src/hashing.rs:72-121 (HashPartitioner), crates/polars-stream/src/nodes/group_by.rs:252-497

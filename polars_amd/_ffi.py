@@ -128,6 +128,15 @@ SIGNATURES = {
     "plx_parquet_read": (C.c_int, [C.c_uint64, _i32p, C.c_int32, _i32p, C.c_int32, _u64p]),
     "plx_parquet_categories": (C.c_int, [C.c_uint64, C.c_int32, _i64p, _i64p]),
     "plx_parquet_categories_to_host": (C.c_int, [C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "plx_ipc_open": (C.c_int, [C.c_char_p, _u64p]),
+    "plx_ipc_close": (C.c_int, [C.c_uint64]),
+    "plx_ipc_shape": (C.c_int, [C.c_uint64, _i64p, _i32p, _i32p]),
+    "plx_ipc_column_info": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_char_p), _i32p, _i32p, _i32p]),
+    "plx_ipc_batch_info": (C.c_int, [C.c_uint64, C.c_int32, _i64p, _i64p, _i32p]),
+    "plx_ipc_read": (C.c_int, [C.c_uint64, _i32p, C.c_int32, _i32p, C.c_int32, _u64p]),
+    "plx_ipc_categories": (C.c_int, [C.c_uint64, C.c_int32, _i64p, _i64p]),
+    "plx_ipc_categories_to_host": (C.c_int, [C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "plx_ipc_column_strdict": (C.c_int, [C.c_uint64, C.c_int32, _u64p]),
     "plx_comm_unique_id": (C.c_int, [C.c_void_p]),
     "plx_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _u64p]),
     "plx_comm_info": (C.c_int, [C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

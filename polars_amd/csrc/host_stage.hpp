@@ -1,0 +1,42 @@
+// host_stage.hpp -- file bytes -> HBM through two page-locked staging buffers: buffer k + 1 is filled from the file while buffer k
+// is on its way over PCIe (one DMA each, on the calling thread's stream).  One instance per host thread, kept for the thread's life:
+// hipHostMalloc costs milliseconds, a column chunk takes about as long to upload.  No destructor on purpose (at process exit the
+// HIP runtime may already be gone; the buffers are left to the OS like the library's bounce buffer in core.cpp).
+#pragma once
+#include "core.hpp"
+
+namespace plx {
+
+struct PinnedStage {
+  struct Slot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+  Slot slot_[2];
+  int next_ = 0;
+
+  // a host buffer of at least `bytes`, valid until the next-but-one call
+  uint8_t* get(size_t bytes) {
+    Slot& s = slot_[next_];
+    next_ ^= 1;
+    if (s.pending) { PLX_HIP(hipEventSynchronize(s.ev)); s.pending = false; }
+    if (s.cap < bytes) {
+      if (s.p) { PLX_HIP(hipHostFree(s.p)); s.p = nullptr; s.cap = 0; }
+      size_t cap = std::max(bytes, size_t(8) << 20);
+      PLX_HIP(hipHostMalloc(&s.p, cap, hipHostMallocDefault));
+      s.cap = cap;
+    }
+    if (!s.ev) PLX_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    return (uint8_t*)s.p;
+  }
+  // asynchronous copy of a buffer obtained from get(); the slot is reusable once the copy has run
+  void upload(void* dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    PLX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream()));
+    for (Slot& s : slot_)
+      if (s.p == src) { PLX_HIP(hipEventRecord(s.ev, stream())); s.pending = true; }
+  }
+  static PinnedStage& for_this_thread() {
+    static thread_local PinnedStage* st = new PinnedStage();    // never destroyed (see above)
+    return *st;
+  }
+};
+
+}  // namespace plx

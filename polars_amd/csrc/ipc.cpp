@@ -1,0 +1,359 @@
+// ipc.cpp -- Arrow IPC file (Feather V2) scan -> device columns behind the C ABI ("Parquet/IPC scan -> device").
+//
+// An uncompressed IPC file already holds the hot path's layout: a primitive column of a record batch is a values buffer + a validity
+// bitmap, exactly what a device column is.  So there is nothing to decode: the host parses the FlatBuffers metadata (ipc_format.hpp),
+// every selected buffer travels file -> page-locked staging -> HBM in one DMA, batches are concatenated in place (bitmaps that do not
+// start on a word boundary are merged by the bitmap blit kernel), dictionary indices are widened to u32 codes by the cast kernel, and
+// string columns that are not dictionary-encoded (Utf8 / LargeUtf8 / Utf8View) go through the device-side dictionary encoder of
+// kernels_strview.hip.  Reference: crates/polars-arrow/src/io/ipc/read/{file.rs,common.rs,read_basic.rs,schema.rs},
+// crates/polars-io/src/ipc/ipc_file.rs, crates/polars-stream/src/nodes/io_sources/ipc.rs.
+#include <map>
+#include <memory>
+#include <mutex>
+
+#include "core.hpp"
+#include "host_stage.hpp"
+#include "ipc_reader.hpp"
+#include "kernels.hpp"
+
+using namespace plx;
+
+namespace {
+
+using ipc::ColType; using ipc::File; using ipc::Slot; using ipc::Unsupported; using ipc::col_type; using ipc::decode_strings; using ipc::load_dictionaries;
+using ipc::open_file; using ipc::read_block_meta; using ipc::read_buffer; using ipc::slot_of;
+using ipc::LO_NONE; using ipc::LO_DATE; using ipc::LO_DATETIME_US; using ipc::LO_STRING; using ipc::LO_BINARY;
+
+int idx_dtype(int bits, bool is_signed) {
+  switch (bits) {
+    case 8: return is_signed ? PLX_I8 : PLX_U8;
+    case 16: return is_signed ? PLX_I16 : PLX_U16;
+    case 32: return is_signed ? PLX_I32 : PLX_U32;
+    default: return is_signed ? PLX_I64 : PLX_U64;
+  }
+}
+
+// one bitmap of a batch (n bits at body + r) OR-ed into dst at bit dst_off; dst is zeroed
+void blit_bitmap(const File& f, PinnedStage& st, int64_t body, const ipc::BufferRef& r, int64_t n, uint64_t* dst, int64_t dst_off) {
+  const size_t bytes = (size_t)((n + 7) / 8);
+  if ((int64_t)bytes > r.length) throw ipc::FormatError("bitmap buffer shorter than the array");
+  Buf tmp = dev_alloc(bitmap_bytes(n));
+  uint8_t* h = st.get(bytes);
+  f.pread_sliced(h, bytes, body + r.offset);
+  st.upload(tmp->ptr, h, bytes);
+  k::bitmap_blit(dst, dst_off, tmp->as<uint64_t>(), n);
+}
+void blit_ones(int64_t n, uint64_t* dst, int64_t dst_off) {
+  Buf ones = dev_alloc(bitmap_bytes(n));
+  k::fill(8, ones->ptr, ~0ull, (n + 63) / 64);
+  k::bitmap_blit(dst, dst_off, ones->as<uint64_t>(), n);
+}
+
+ColumnPtr read_fixed_column(File& f, const std::vector<int>& bsel, int col, const ColType& ct, int64_t total) {
+  PinnedStage& st = PinnedStage::for_this_thread();
+  const ipc::Field& fl = f.footer.fields[col];
+  bool any_nulls = false;
+  for (int b : bsel) {
+    const ipc::BatchMeta& bm = f.batches[b];
+    Slot s = slot_of(f, bm, col);
+    if (s.node >= bm.nodes.size() || s.buf + 2 > bm.buffers.size()) throw ipc::FormatError("record batch without the column's buffers");
+    if (bm.nodes[s.node].length != bm.length) throw ipc::FormatError("column length differs from its record batch");
+    if (bm.nodes[s.node].null_count > 0) any_nulls = true;
+  }
+  const int file_dtype = fl.has_dictionary ? idx_dtype(fl.index_bits, fl.index_signed) : ct.dtype;
+  auto c = std::make_shared<Column>();
+  c->dtype = file_dtype; c->len = total;
+  c->values = dev_alloc(values_bytes(file_dtype, total) + 8);
+  if (file_dtype == PLX_BOOL) PLX_HIP(hipMemsetAsync(c->values->ptr, 0, bitmap_bytes(total), stream()));
+  if (any_nulls) { c->validity = dev_alloc_zero(bitmap_bytes(total)); } else c->null_count = 0;
+  int64_t row = 0, nulls = 0;
+  for (int b : bsel) {
+    const ipc::BatchMeta& bm = f.batches[b];
+    const Slot s = slot_of(f, bm, col);
+    const int64_t n = bm.length, body = f.body_off[b];
+    const ipc::BufferRef& vb = bm.buffers[s.buf + 1];
+    if (n == 0) continue;
+    if (file_dtype == PLX_BOOL) {
+      blit_bitmap(f, st, body, vb, n, c->values->as<uint64_t>(), row);
+    } else {
+      const size_t bytes = (size_t)n * (size_t)ct.width;
+      if ((int64_t)bytes > vb.length) throw ipc::FormatError("values buffer shorter than the array");
+      uint8_t* h = st.get(bytes);
+      f.pread_sliced(h, bytes, body + vb.offset);
+      st.upload((uint8_t*)c->values->ptr + (size_t)row * (size_t)ct.width, h, bytes);
+    }
+    if (any_nulls) {
+      const int64_t nc = bm.nodes[s.node].null_count;
+      nulls += nc;
+      if (nc > 0) blit_bitmap(f, st, body, bm.buffers[s.buf], n, c->validity->as<uint64_t>(), row);
+      else blit_ones(n, c->validity->as<uint64_t>(), row);
+    }
+    row += n;
+  }
+  if (any_nulls) c->null_count = nulls;
+  if (fl.has_dictionary && file_dtype != PLX_U32) {
+    // dictionary indices -> u32 codes on the device
+    auto out = std::make_shared<Column>();
+    out->dtype = PLX_U32; out->len = total; out->validity = c->validity; out->null_count = c->null_count;
+    out->values = dev_alloc(values_bytes(PLX_U32, total) + 8);
+    k::cast(file_dtype, PLX_U32, c->values->ptr, total, out->values->ptr, nullptr);
+    return out;
+  }
+  c->dtype = ct.dtype;
+  return c;
+}
+
+// Utf8 / LargeUtf8 / Utf8View (+ binary twins) that are not dictionary-encoded: 16-byte views are assembled on the host (offsets ->
+// {len, inline bytes | prefix, buffer, offset}; view buffer indices rebased across batches), hashing / comparing / encoding happens
+// on the device (plx_strview_dict_encode: kernels_strview.hip)
+ColumnPtr read_string_column(File& f, const std::vector<int>& bsel, int col, int64_t total, plx_strdict* dict_out) {
+  const ipc::Field& fl = f.footer.fields[col];
+  const bool is_view = fl.type == ipc::TY_UTF8_VIEW || fl.type == ipc::TY_BINARY_VIEW;
+  const bool large = fl.type == ipc::TY_LARGE_UTF8 || fl.type == ipc::TY_LARGE_BINARY;
+  std::vector<uint8_t> views((size_t)total * 16 + 16, 0), validity((size_t)(total + 7) / 8 + 8, 0);
+  std::vector<std::vector<uint8_t>> data;
+  bool any_nulls = false;
+  int64_t row = 0;
+  for (int b : bsel) {
+    const ipc::BatchMeta& bm = f.batches[b];
+    const Slot s = slot_of(f, bm, col);
+    const int64_t n = bm.length, body = f.body_off[b];
+    if (s.node >= bm.nodes.size() || s.buf + (is_view ? 2 : 3) > bm.buffers.size()) throw ipc::FormatError("record batch without the column's buffers");
+    if (bm.nodes[s.node].length != n) throw ipc::FormatError("column length differs from its record batch");
+    const int64_t nc = bm.nodes[s.node].null_count;
+    std::vector<uint8_t> vbits;
+    if (nc > 0) {
+      any_nulls = true;
+      vbits = read_buffer(f, body, bm.buffers[s.buf]);
+      if ((int64_t)vbits.size() - 16 < (n + 7) / 8) throw ipc::FormatError("bitmap buffer shorter than the array");
+    }
+    for (int64_t i = 0; i < n; i++) {
+      const bool ok = nc == 0 || ((vbits[(size_t)i >> 3] >> (i & 7)) & 1);
+      if (ok) validity[(size_t)(row + i) >> 3] |= (uint8_t)(1u << ((row + i) & 7));
+    }
+    const uint32_t base = (uint32_t)data.size();
+    if (is_view) {
+      const int64_t nvar = s.variadic < bm.variadic_counts.size() ? bm.variadic_counts[s.variadic] : 0;
+      if (s.buf + 2 + (size_t)nvar > bm.buffers.size()) throw ipc::FormatError("view array without its data buffers");
+      std::vector<uint8_t> v = read_buffer(f, body, bm.buffers[s.buf + 1]);
+      if ((int64_t)v.size() - 16 < n * 16) throw ipc::FormatError("views buffer shorter than the array");
+      for (int64_t k = 0; k < nvar; k++) data.push_back(read_buffer(f, body, bm.buffers[s.buf + 2 + (size_t)k]));
+      for (int64_t i = 0; i < n; i++) {
+        uint8_t* dst = views.data() + 16 * (size_t)(row + i);
+        memcpy(dst, v.data() + 16 * i, 16);
+        uint32_t len, bi, off;
+        memcpy(&len, dst, 4);
+        const bool ok = nc == 0 || ((vbits[(size_t)i >> 3] >> (i & 7)) & 1);
+        if (!ok) { memset(dst, 0, 16); continue; }
+        if (len > 12) {
+          memcpy(&bi, dst + 8, 4); memcpy(&off, dst + 12, 4);
+          if ((int64_t)bi >= nvar || (uint64_t)off + len > data[base + bi].size() - 16) throw ipc::FormatError("view points outside its data buffer");
+          bi += base;
+          memcpy(dst + 8, &bi, 4);
+        }
+      }
+    } else {
+      std::vector<uint8_t> offs = read_buffer(f, body, bm.buffers[s.buf + 1]);
+      data.push_back(read_buffer(f, body, bm.buffers[s.buf + 2]));
+      const std::vector<uint8_t>& d = data.back();
+      const size_t ow = large ? 8 : 4;
+      if (n && (int64_t)offs.size() - 16 < (n + 1) * (int64_t)ow) throw ipc::FormatError("offsets buffer shorter than the array");
+      if ((int64_t)d.size() - 16 >= ((int64_t)1 << 32)) throw Unsupported("string data buffer of 4 GiB or more in one record batch");
+      for (int64_t i = 0; i < n; i++) {
+        int64_t a, e;
+        if (large) { memcpy(&a, offs.data() + 8 * i, 8); memcpy(&e, offs.data() + 8 * (i + 1), 8); }
+        else { int32_t a32, e32; memcpy(&a32, offs.data() + 4 * i, 4); memcpy(&e32, offs.data() + 4 * (i + 1), 4); a = a32; e = e32; }
+        if (a < 0 || e < a || e > (int64_t)d.size() - 16 || e - a > 0x7fffffff) throw ipc::FormatError("string offsets outside the data buffer");
+        const bool ok = nc == 0 || ((vbits[(size_t)i >> 3] >> (i & 7)) & 1);
+        if (!ok) continue;
+        uint8_t* dst = views.data() + 16 * (size_t)(row + i);
+        const uint32_t len = (uint32_t)(e - a), off = (uint32_t)a;
+        memcpy(dst, &len, 4);
+        if (len <= 12) memcpy(dst + 4, d.data() + a, len);
+        else { memcpy(dst + 4, d.data() + a, 4); memcpy(dst + 8, &base, 4); memcpy(dst + 12, &off, 4); }
+      }
+    }
+    row += n;
+  }
+  std::vector<const void*> ptrs;
+  std::vector<int64_t> sizes;
+  for (const std::vector<uint8_t>& d : data) { ptrs.push_back(d.data()); sizes.push_back((int64_t)d.size() - 16); }
+  plx_column codes = 0;
+  plx_strdict dict = 0;
+  int rc = plx_strview_dict_encode(views.data(), any_nulls ? validity.data() : nullptr, 0, total, ptrs.empty() ? nullptr : ptrs.data(), sizes.empty() ? nullptr : sizes.data(),
+                                   (int32_t)ptrs.size(), &codes, &dict);
+  if (rc != PLX_OK) fail(rc, plx_last_error());
+  ColumnPtr c = get_column(codes);
+  free_column(codes);       // the frame keeps the column alive
+  *dict_out = dict;
+  return c;
+}
+
+std::mutex g_mu;
+std::vector<std::unique_ptr<File>> g_files;   // handle = index + 1
+File& get_file(uint64_t h) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (h == 0 || h > g_files.size() || !g_files[h - 1]) fail(PLX_ERR_INVALID, "invalid ipc handle");
+  return *g_files[h - 1];
+}
+thread_local std::string t_name;
+
+}  // namespace
+
+#define IPC_TRY try {
+#define IPC_CATCH                                                                                   \
+  }                                                                                                 \
+  catch (const plx::Error& e) { plx::set_last_error(e.msg); return e.code; }                         \
+  catch (const Unsupported& e) { plx::set_last_error(std::string("ipc: ") + e.what()); return PLX_ERR_UNSUPPORTED; }   \
+  catch (const ipc::FormatError& e) { plx::set_last_error(std::string("ipc: ") + e.what()); return PLX_ERR_INVALID; } \
+  catch (const plx::IoError& e) { plx::set_last_error(std::string("ipc: ") + e.what()); return PLX_ERR_INVALID; }     \
+  catch (const std::bad_alloc&) { plx::set_last_error("host out of memory"); return PLX_ERR_OOM; }  \
+  catch (const std::exception& e) { plx::set_last_error(std::string("PANIC: ") + e.what()); return PLX_ERR_INVALID; } \
+  catch (...) { plx::set_last_error("PANIC"); return PLX_ERR_INVALID; }                              \
+  return PLX_OK;
+
+extern "C" {
+
+int plx_ipc_open(const char* path, plx_ipc* out) {
+  IPC_TRY
+  PLX_REQUIRE(path && out, PLX_ERR_INVALID, "null argument");
+  std::unique_ptr<File> f = open_file(path);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_files.push_back(std::move(f));
+  *out = (plx_ipc)g_files.size();
+  IPC_CATCH
+}
+
+int plx_ipc_close(plx_ipc file) {
+  IPC_TRY
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (file && file <= g_files.size()) g_files[file - 1].reset();
+  IPC_CATCH
+}
+
+int plx_ipc_shape(plx_ipc file, int64_t* num_rows, int32_t* num_batches, int32_t* num_columns) {
+  IPC_TRY
+  File& f = get_file(file);
+  if (num_rows) *num_rows = f.num_rows;
+  if (num_batches) *num_batches = (int32_t)f.batches.size();
+  if (num_columns) *num_columns = (int32_t)f.footer.fields.size();
+  IPC_CATCH
+}
+
+int plx_ipc_column_info(plx_ipc file, int32_t column, const char** name, int32_t* dtype, int32_t* logical, int32_t* nullable) {
+  IPC_TRY
+  File& f = get_file(file);
+  PLX_REQUIRE(column >= 0 && (size_t)column < f.footer.fields.size(), PLX_ERR_INVALID, "ipc column index out of range");
+  const ipc::Field& fl = f.footer.fields[column];
+  const ColType t = col_type(fl);
+  if (name) { t_name = fl.name; *name = t_name.c_str(); }
+  if (dtype) *dtype = t.dtype;
+  if (logical) *logical = t.logical;
+  if (nullable) *nullable = fl.nullable ? 1 : 0;
+  IPC_CATCH
+}
+
+int plx_ipc_batch_info(plx_ipc file, int32_t batch, int64_t* num_rows, int64_t* body_bytes, int32_t* compressed) {
+  IPC_TRY
+  File& f = get_file(file);
+  PLX_REQUIRE(batch >= 0 && (size_t)batch < f.batches.size(), PLX_ERR_INVALID, "ipc record batch index out of range");
+  if (num_rows) *num_rows = f.batches[batch].length;
+  if (body_bytes) *body_bytes = f.footer.batches[batch].body_len;
+  if (compressed) *compressed = f.batches[batch].compressed ? 1 + f.batches[batch].codec : 0;
+  IPC_CATCH
+}
+
+int plx_ipc_read(plx_ipc file, const int32_t* batches, int32_t n_batches, const int32_t* columns, int32_t n_columns, plx_frame* out) {
+  IPC_TRY
+  PLX_REQUIRE(out && (columns || n_columns == 0) && (batches || n_batches == 0), PLX_ERR_INVALID, "null argument");
+  File& f = get_file(file);
+  device();   // fails loudly without a GPU
+  std::vector<int> bsel(batches, batches + n_batches);
+  int64_t total = 0;
+  for (int b : bsel) {
+    PLX_REQUIRE(b >= 0 && (size_t)b < f.batches.size(), PLX_ERR_INVALID, "ipc record batch index out of range");
+    if (f.batches[b].compressed) throw Unsupported(std::string("record batch body compressed with ") + (f.batches[b].codec == 0 ? "LZ4_FRAME" : "ZSTD"));
+    total += f.batches[b].length;
+  }
+  auto frame = std::make_shared<Frame>();
+  frame->height = total;
+  try {
+    for (int32_t i = 0; i < n_columns; i++) {
+      check_cancel();
+      const int col = columns[i];
+      PLX_REQUIRE(col >= 0 && (size_t)col < f.footer.fields.size(), PLX_ERR_INVALID, "ipc column index out of range");
+      const ipc::Field& fl = f.footer.fields[col];
+      const ColType ct = col_type(fl);
+      if (ct.dtype < 0) throw Unsupported("column '" + fl.name + "': " + ct.why + " is outside the hot path's dtypes");
+      ColumnPtr c;
+      if (ct.strings && !fl.has_dictionary) {
+        plx_strdict d = 0;
+        c = read_string_column(f, bsel, col, total, &d);
+        auto it = f.strdicts.find(col);
+        if (it != f.strdicts.end() && it->second) plx_strdict_free(it->second);
+        f.strdicts[col] = d;
+      } else {
+        if (fl.has_dictionary) load_dictionaries(f);
+        c = read_fixed_column(f, bsel, col, ct, total);
+        if (fl.has_dictionary) {
+          auto it = f.dicts.find(fl.dict_id);
+          const int64_t nd = it == f.dicts.end() ? 0 : (int64_t)it->second.size();
+          if (nd > 0) { c->range_state = 1; c->range_min = 0; c->range_max = nd - 1; c->range_trusted = false; }   // declared, checked by the kernels
+        }
+      }
+      frame->names.push_back(fl.name);
+      frame->cols.push_back(c);
+    }
+    PLX_HIP(hipStreamSynchronize(stream()));     // staging buffers and temporaries of the last column are done
+  } catch (...) {
+    (void)hipStreamSynchronize(stream());
+    throw;
+  }
+  *out = register_frame(frame);
+  IPC_CATCH
+}
+
+int plx_ipc_categories(plx_ipc file, int32_t column, int64_t* n_strings, int64_t* total_bytes) {
+  IPC_TRY
+  File& f = get_file(file);
+  PLX_REQUIRE(column >= 0 && (size_t)column < f.footer.fields.size(), PLX_ERR_INVALID, "ipc column index out of range");
+  const ipc::Field& fl = f.footer.fields[column];
+  PLX_REQUIRE(fl.has_dictionary && col_type(fl).dtype >= 0, PLX_ERR_NOT_FOUND, "not a dictionary-encoded string column (strings encoded on the device: plx_ipc_column_strdict)");
+  load_dictionaries(f);
+  const std::vector<std::string>& d = f.dicts[fl.dict_id];
+  int64_t b = 0;
+  for (const std::string& s : d) b += (int64_t)s.size();
+  if (n_strings) *n_strings = (int64_t)d.size();
+  if (total_bytes) *total_bytes = b;
+  IPC_CATCH
+}
+
+int plx_ipc_categories_to_host(plx_ipc file, int32_t column, int64_t* offsets, uint8_t* bytes) {
+  IPC_TRY
+  File& f = get_file(file);
+  PLX_REQUIRE(column >= 0 && (size_t)column < f.footer.fields.size(), PLX_ERR_INVALID, "ipc column index out of range");
+  const ipc::Field& fl = f.footer.fields[column];
+  PLX_REQUIRE(fl.has_dictionary && col_type(fl).dtype >= 0 && offsets, PLX_ERR_NOT_FOUND, "not a dictionary-encoded string column");
+  load_dictionaries(f);
+  int64_t off = 0, i = 0;
+  for (const std::string& s : f.dicts[fl.dict_id]) {
+    offsets[i++] = off;
+    if (!s.empty()) { PLX_REQUIRE(bytes, PLX_ERR_INVALID, "null bytes pointer"); memcpy(bytes + off, s.data(), s.size()); }
+    off += (int64_t)s.size();
+  }
+  offsets[i] = off;
+  IPC_CATCH
+}
+
+int plx_ipc_column_strdict(plx_ipc file, int32_t column, plx_strdict* out) {
+  IPC_TRY
+  File& f = get_file(file);
+  PLX_REQUIRE(out, PLX_ERR_INVALID, "null out pointer");
+  auto it = f.strdicts.find(column);
+  PLX_REQUIRE(it != f.strdicts.end() && it->second, PLX_ERR_NOT_FOUND, "no device dictionary: the column has not been read (or is dictionary-encoded in the file: plx_ipc_categories)");
+  *out = it->second;
+  it->second = 0;       // ownership moves to the caller (plx_strdict_free)
+  IPC_CATCH
+}
+
+}  // extern "C"

@@ -9,6 +9,7 @@
 #include <mutex>
 
 #include "core.hpp"
+#include "host_stage.hpp"
 #include "kernels.hpp"
 #include "parquet_kernels.hpp"
 #include "parquet_reader.hpp"
@@ -21,35 +22,16 @@ namespace {
 // HBM + kernel launches on the calling thread's stream
 struct HipBackend {
   using Mem = Buf;
-  struct Stage { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
-  Stage stage_[2];
-  int next_ = 0;
+  PinnedStage& stage_ = PinnedStage::for_this_thread();
   uint64_t encoded_bytes = 0;
 
-  // No destructor: the backend lives as long as its host thread, and at process exit the HIP runtime may already be gone -- the
-  // staging buffers are left to the OS, like the library's bounce buffer (core.cpp).
   Mem alloc(size_t bytes) { return dev_alloc(bytes ? bytes : 8); }
   uint64_t addr(const Mem& m) { return m ? (uint64_t)m->ptr : 0; }
-  // page-locked staging, two buffers: chunk k + 1 is read from the file while chunk k is on its way to HBM
-  uint8_t* host_stage(size_t bytes) {
-    Stage& s = stage_[next_];
-    next_ ^= 1;
-    if (s.pending) { PLX_HIP(hipEventSynchronize(s.ev)); s.pending = false; }
-    if (s.cap < bytes) {
-      if (s.p) { PLX_HIP(hipHostFree(s.p)); s.p = nullptr; s.cap = 0; }
-      size_t cap = std::max(bytes, size_t(8) << 20);
-      PLX_HIP(hipHostMalloc(&s.p, cap, hipHostMallocDefault));
-      s.cap = cap;
-    }
-    if (!s.ev) PLX_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
-    return (uint8_t*)s.p;
-  }
+  // page-locked staging, two buffers: chunk k + 1 is read from the file while chunk k is on its way to HBM (host_stage.hpp)
+  uint8_t* host_stage(size_t bytes) { return stage_.get(bytes); }
   void upload(uint64_t dst, const void* src, size_t bytes) {
-    if (!bytes) return;
     encoded_bytes += bytes;
-    PLX_HIP(hipMemcpyAsync((void*)dst, src, bytes, hipMemcpyHostToDevice, stream()));
-    for (Stage& s : stage_)
-      if (s.p == src) { PLX_HIP(hipEventRecord(s.ev, stream())); s.pending = true; }
+    stage_.upload((void*)dst, src, bytes);
   }
   // descriptor arrays from pageable memory: done when this returns
   void upload_small(uint64_t dst, const void* src, size_t bytes) {
@@ -94,6 +76,7 @@ thread_local std::string t_name;
   catch (const plx::Error& e) { plx::set_last_error(e.msg); return e.code; }                        \
   catch (const pq::Unsupported& e) { plx::set_last_error(std::string("parquet: ") + e.what()); return PLX_ERR_UNSUPPORTED; } \
   catch (const pq::FormatError& e) { plx::set_last_error(std::string("parquet: ") + e.what()); return PLX_ERR_INVALID; }     \
+  catch (const plx::IoError& e) { plx::set_last_error(std::string("parquet: ") + e.what()); return PLX_ERR_INVALID; }        \
   catch (const std::bad_alloc&) { plx::set_last_error("host out of memory"); return PLX_ERR_OOM; } \
   catch (const std::exception& e) { plx::set_last_error(std::string("PANIC: ") + e.what()); return PLX_ERR_INVALID; }        \
   catch (...) { plx::set_last_error("PANIC"); return PLX_ERR_INVALID; }                             \
@@ -185,10 +168,7 @@ int plx_parquet_read(plx_parquet file, const int32_t* row_groups, int32_t n_row_
   try {
     for (int32_t i = 0; i < n_columns; i++) {
       check_cancel();
-      // one backend per host thread, kept: its two page-locked staging buffers cost milliseconds to allocate (hipHostMalloc), a
-      // column chunk takes about as long to upload
-      static thread_local HipBackend be;
-      be.encoded_bytes = 0;
+      HipBackend be;       // the page-locked staging buffers behind it belong to the host thread and are kept (host_stage.hpp)
       pq::ReadStats st;
       pq::ColumnResult<HipBackend> r = pq::read_column(be, f, rgs, columns[i], &st);
       auto col = std::make_shared<Column>();

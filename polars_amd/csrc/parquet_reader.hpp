@@ -13,10 +13,6 @@
 // parquet/read/compression.rs:70-135 (decompress per page), arrow/read/deserialize/{primitive,boolean,dictionary_encoded,binview}
 // (decode per page into an Arrow array), crates/polars-io/src/parquet/read/read_impl.rs (row groups x projected columns).
 #pragma once
-#include <fcntl.h>
-#include <sys/stat.h>
-#include <unistd.h>
-
 #include <algorithm>
 #include <memory>
 #include <exception>
@@ -26,6 +22,7 @@
 #include <vector>
 
 #include "../../include/polars_amd.h"
+#include "file_io.hpp"
 #include "parquet_device.hpp"
 #include "parquet_format.hpp"
 
@@ -37,51 +34,15 @@ struct Unsupported : std::runtime_error {
 };
 
 // ---- file ---------------------------------------------------------------------------------------------------------------------------
-struct File {
-  std::string path;
-  int fd = -1;
-  int64_t size = 0;
+struct File : FileReader {
   FileMetaData md;
   // column-wide dictionaries of the string columns read last (leaf index -> categories)
   std::unordered_map<int, std::vector<std::string>> categories;
-  ~File() { if (fd >= 0) ::close(fd); }
-
-  void pread_exact(void* dst, size_t n, int64_t off) const {
-    uint8_t* p = (uint8_t*)dst;
-    while (n) {
-      ssize_t got = ::pread(fd, p, n, off);
-      if (got <= 0) throw FormatError("short read from " + path);
-      p += got; off += got; n -= (size_t)got;
-    }
-  }
-  // A column chunk out of the page cache is a memcpy: one thread moves ~10 GB/s, PCIe takes ~56 GB/s.  Large reads are cut into
-  // slices read concurrently (positional reads on one descriptor are independent).
-  void pread_sliced(void* dst, size_t n, int64_t off) const {
-    const size_t kSlice = size_t(2) << 20;
-    size_t threads = std::min<size_t>(8, n / kSlice);
-    if (threads < 2) { pread_exact(dst, n, off); return; }
-    std::vector<std::thread> pool;
-    std::vector<std::exception_ptr> errs(threads);
-    const size_t per = (n / threads + 4095) & ~size_t(4095);
-    for (size_t t = 0; t < threads; t++) {
-      const size_t b = std::min(n, t * per), e = std::min(n, (t + 1) * per);
-      pool.emplace_back([this, dst, off, b, e, t, &errs] {
-        try { if (e > b) pread_exact((uint8_t*)dst + b, e - b, off + (int64_t)b); } catch (...) { errs[t] = std::current_exception(); }
-      });
-    }
-    for (std::thread& th : pool) th.join();
-    for (std::exception_ptr& ep : errs) if (ep) std::rethrow_exception(ep);
-  }
 };
 
 inline std::unique_ptr<File> open_file(const std::string& path) {
   auto f = std::make_unique<File>();
-  f->path = path;
-  f->fd = ::open(path.c_str(), O_RDONLY);
-  if (f->fd < 0) throw FormatError("cannot open " + path);
-  struct stat st;
-  if (::fstat(f->fd, &st) != 0) throw FormatError("cannot stat " + path);
-  f->size = st.st_size;
+  f->open(path);
   if (f->size < 12) throw FormatError(path + " is too small to be a Parquet file");
   uint8_t tail[8];
   f->pread_exact(tail, 8, f->size - 8);

@@ -1,0 +1,150 @@
+"""plx_ipc_* without a GPU: the library's own Arrow IPC metadata reader (polars_amd/csrc/ipc_format.hpp: FlatBuffers footer, schema,
+record-batch and dictionary messages) against pyarrow's view of the same files; the host half of the reader under AddressSanitizer
+over corrupted files; the loud failure of plx_ipc_read when no device is bound."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.ipc as ipc
+import pytest
+
+import polars_amd as pl
+from polars_amd import _ffi as F
+from polars_amd import ipc_io
+
+RNG = np.random.default_rng(9)
+
+
+def sample(n):
+    m = RNG.random(n) < 0.2
+    words = np.array(["", "a", "BUILDING", "a much longer string that does not fit in twelve bytes", "ünï"])
+    return pa.table({
+        "i8": pa.array(RNG.integers(-100, 100, n).astype(np.int8)), "u16": pa.array(RNG.integers(0, 60000, n).astype(np.uint16), mask=m),
+        "i32": pa.array(RNG.integers(-10**9, 10**9, n).astype(np.int32)), "u32": pa.array(RNG.integers(0, 2**32, n).astype(np.uint32)),
+        "i64": pa.array(RNG.integers(-10**15, 10**15, n), mask=m), "u64": pa.array(RNG.integers(0, 2**63, n).astype(np.uint64)),
+        "f32": pa.array(RNG.normal(size=n).astype(np.float32)), "f64": pa.array(RNG.normal(size=n), mask=m), "b": pa.array(RNG.random(n) < 0.5, mask=m),
+        "date": pa.array(RNG.integers(0, 20000, n).astype(np.int32), pa.date32()), "ts": pa.array(RNG.integers(0, 2**50, n), pa.timestamp("us")),
+        "s": pa.array(words[RNG.integers(0, 5, n)], mask=m), "ls": pa.array(words[RNG.integers(0, 5, n)], pa.large_string()),
+        "sv": pa.array(words[RNG.integers(0, 5, n)], pa.string_view()), "bin": pa.array([b"\x00\x01"] * n, pa.binary()),
+        "d8": pa.array(words[RNG.integers(0, 5, n)]).dictionary_encode().cast(pa.dictionary(pa.int8(), pa.string())),
+        "d32": pa.array(words[RNG.integers(0, 3, n)], mask=m).dictionary_encode(),
+        # outside the hot path
+        "ts_ms": pa.array(RNG.integers(0, 2**40, n), pa.timestamp("ms")), "dec": pa.array([None] * n, pa.decimal128(12, 2)), "lst": pa.array([[1, 2]] * n),
+        "st": pa.array([{"p": 1, "q": "z"}] * n), "tail": pa.array(np.arange(n)),
+    })
+
+
+def write(path, t, chunk=None, **opts):
+    with ipc.new_file(path, t.schema, options=ipc.IpcWriteOptions(**opts)) as w:
+        for b in t.to_batches(max_chunksize=chunk):
+            w.write_batch(b)
+
+
+def test_schema_batches_and_dictionaries_match_pyarrow(tmp_path):
+    n = 2500
+    t = sample(n)
+    path = str(tmp_path / "t.arrow")
+    write(path, t, chunk=700)
+    rd = ipc.open_file(path)
+    src = ipc_io._IpcDecoder(path)
+    assert src.num_rows == n and src.num_row_groups == rd.num_record_batches == 4 and src.names == t.column_names
+    want = {"i8": pl.Int8, "u16": pl.UInt16, "i32": pl.Int32, "u32": pl.UInt32, "i64": pl.Int64, "u64": pl.UInt64, "f32": pl.Float32, "f64": pl.Float64,
+            "b": pl.Boolean, "date": pl.Date, "ts": pl.Datetime, "tail": pl.Int64}
+    for name, dt in want.items():
+        assert src.dtype(name) == dt and src.dtype(name).physical == dt.physical, name
+    for name in ("s", "ls", "sv", "bin", "d8", "d32"):
+        assert isinstance(src.dtype(name), pl.Categorical)
+    for name in ("ts_ms", "dec", "lst", "st"):
+        with pytest.raises(TypeError):
+            src.dtype(name)
+    assert src._info["bin"][2] == 4 and src._info["s"][2] == 3 and src._info["i8"][3] is True
+    for b in range(4):
+        info = src.batch_info(b)
+        assert info["rows"] == rd.get_batch(b).num_rows and info["compression"] is None and info["body_bytes"] > 0
+    # dictionaries of the dictionary-encoded columns: the values the file holds, in the file's order (pyarrow unifies across batches when writing)
+    for name in ("d8", "d32"):
+        col = rd.read_all().column(name).combine_chunks()
+        assert src.categories(name) == col.dictionary.to_pylist()
+    with pytest.raises(pl.PlxError):
+        src.categories("s")             # not dictionary-encoded in the file: its dictionary is built on the device at read time
+
+
+def test_compressed_files_are_recognised(tmp_path):
+    t = pa.table({"a": np.arange(1000)})
+    for codec, name in (("lz4", "lz4"), ("zstd", "zstd")):
+        path = str(tmp_path / f"{codec}.arrow")
+        write(path, t, compression=codec)
+        src = ipc_io._IpcDecoder(path)
+        assert src.batch_info(0)["compression"] == name and src.num_rows == 1000
+
+
+def test_not_an_ipc_file(tmp_path):
+    p = tmp_path / "junk.arrow"
+    p.write_bytes(b"ARROW1\x00\x00" + b"\x00" * 64 + b"NOPE!!")
+    h = C.c_uint64()
+    assert F.lib().plx_ipc_open(str(p).encode(), C.byref(h)) == 1 and "ARROW1" in F.lib().plx_last_error().decode()
+    assert F.lib().plx_ipc_open(str(tmp_path / "absent").encode(), C.byref(h)) == 1 and "cannot open" in F.lib().plx_last_error().decode()
+    # a stream-format file (no footer) is not a file-format file
+    sink = str(tmp_path / "stream.arrows")
+    t = pa.table({"a": np.arange(10)})
+    with ipc.new_stream(sink, t.schema) as w:
+        w.write_table(t)
+    assert F.lib().plx_ipc_open(sink.encode(), C.byref(h)) == 1
+
+
+def test_read_needs_a_gpu_and_says_so(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by tests/test_gpu_ipc.py")
+    path = str(tmp_path / "t.arrow")
+    write(path, pa.table({"a": np.arange(10)}))
+    h = C.c_uint64()
+    F.check(F.lib().plx_ipc_open(path.encode(), C.byref(h)))
+    b, col, fh = (C.c_int32 * 1)(0), (C.c_int32 * 1)(0), C.c_uint64()
+    assert F.lib().plx_ipc_read(h.value, b, 1, col, 1, C.byref(fh)) == 2          # PLX_ERR_HIP
+    assert "GPU" in F.lib().plx_last_error().decode()
+
+
+def test_projection_reaches_the_ipc_scan(tmp_path):
+    n = 1000
+    t = pa.table({"k": np.arange(n) % 7, "v": RNG.normal(size=n), "w": RNG.normal(size=n), "s": pa.array(["x"] * n)})
+    path = str(tmp_path / "t.arrow")
+    write(path, t, chunk=300)
+    from polars_amd import io
+    c = pl.col
+    lf = pl.scan_ipc(path).filter(c("v") > 0).group_by("k").agg(c("v").sum())
+    io.reset_scans(lf._node); io.push_down(lf._node)
+    node = lf._node
+    while node.kind != "scan":
+        node = node.input
+    assert sorted(node.frame.selected_columns()) == ["k", "v"] and node.frame.selected_row_groups() == [0, 1, 2, 3]
+
+
+def test_host_reader_under_address_sanitizer(tmp_path):
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "ipc_asan")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-o", exe,
+                    os.path.join(here, "emu", "ipc_meta_main.cpp"), "-lpthread"], check=True)
+    t = sample(800)
+    files = []
+    for i, chunk in enumerate((None, 150)):
+        p = str(tmp_path / f"good{i}.arrow")
+        write(p, t, chunk=chunk)
+        files.append(p)
+        raw = open(p, "rb").read()
+        flen = struct.unpack("<i", raw[-10:-6])[0]
+        for k in range(80):
+            b = bytearray(raw)
+            lo, hi = (len(b) - 10 - flen, len(b) - 6) if k % 2 else (8, len(b) - 10 - flen)        # footer bytes or message / body bytes
+            for _ in range(1 + k % 4):
+                b[int(RNG.integers(lo, hi))] ^= 1 << int(RNG.integers(0, 8))
+            q = str(tmp_path / f"bad{i}_{k}.arrow")
+            open(q, "wb").write(b if k % 9 else b[:int(RNG.integers(16, len(b)))])
+            files.append(q)
+    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600, env={**os.environ, "ASAN_OPTIONS": "detect_leaks=0"})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    counts = dict(kv.split("=") for kv in r.stdout.split())
+    assert int(counts["ok"]) >= 2 and int(counts["invalid"]) > 20 and int(counts["strings"]) > 0, r.stdout
