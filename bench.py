@@ -554,15 +554,25 @@ def timed(pl, wl: Workload, steps: int, warmup: int, distributed: bool, combine=
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(); F.check(F.lib().plx_synchronize())
+    # The harness process must not garbage-collect inside the timed region (what timeit does too): with torch / numpy / pyarrow loaded
+    # a generation-2 collection walks a few million objects, ~40 ms, and its allocation-count trigger put it on timed step 4 of the
+    # headline every single run (step_ms showed 4.3, 4.3, 4.3, 40, 4.5, 4.3 ... = 6.1 ms/step "measured" for a 4.3 ms step).
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
+    marks = [t0]
     for _ in range(steps):
         res, _keep = wl.step()
         if combine:
             res = combine(res)
+        marks.append(time.perf_counter())      # host-side return times (a step ends with its result download, so these are real step times)
     torch.cuda.synchronize(); F.check(F.lib().plx_synchronize())
+    timed.last_step_ms = [round((b - a) * 1e3, 3) for a, b in zip(marks, marks[1:])]
     if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     stats = kernel_stats(pl)
     F.check(F.lib().plx_profile_enable(0))
     if distributed:
@@ -1061,6 +1071,7 @@ def run(args, emit):
                                    f"row-sharded x{ws}, rows exchanged by key hash (all-to-all), per-rank group-by over disjoint key sets")},
         "whole_query_GBps_per_gpu": round(wl.algo_bytes * args.steps / dt / 1e9, 1),
         "cold_first_step_ms": None if cold_ms is None else round(cold_ms, 2),
+        "step_ms": getattr(timed, "last_step_ms", None),      # every timed step, in order: a stall of the box shows here, not only in the mean
         "roofline": roofline(stats, wl, args.steps),
         "kernels": _kernels(stats, 8),
     }

@@ -7,9 +7,11 @@
 // string columns that are not dictionary-encoded (Utf8 / LargeUtf8 / Utf8View) go through the device-side dictionary encoder of
 // kernels_strview.hip.  Reference: crates/polars-arrow/src/io/ipc/read/{file.rs,common.rs,read_basic.rs,schema.rs},
 // crates/polars-io/src/ipc/ipc_file.rs, crates/polars-stream/src/nodes/io_sources/ipc.rs.
+#include <exception>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include "core.hpp"
 #include "host_stage.hpp"
@@ -103,6 +105,30 @@ ColumnPtr read_fixed_column(File& f, const std::vector<int>& bsel, int col, cons
   return c;
 }
 
+// rows [0, n) in parallel slices (the 16-byte views of a string column are independent of each other; one host thread assembles
+// ~2e8 of them per second, a 2e7-row column would otherwise cost more than its upload and its device encode together)
+template <class Fn> void parallel_rows(int64_t n, Fn&& fn) {
+  const int64_t kMinRows = int64_t(1) << 16;
+  const int threads = (int)std::min<int64_t>(16, n / kMinRows);
+  if (threads < 2) { fn((int64_t)0, n); return; }
+  std::vector<std::thread> pool;
+  std::vector<std::exception_ptr> errs((size_t)threads);
+  const int64_t per = (n + threads - 1) / threads;
+  for (int t = 0; t < threads; t++) {
+    const int64_t b = std::min(n, t * per), e = std::min(n, b + per);
+    pool.emplace_back([&fn, &errs, t, b, e] { try { if (e > b) fn(b, e); } catch (...) { errs[(size_t)t] = std::current_exception(); } });
+  }
+  for (std::thread& th : pool) th.join();
+  for (std::exception_ptr& ep : errs) if (ep) std::rethrow_exception(ep);
+}
+// bits [off, off + n) of a little-endian bitmap := 1
+void set_bits(uint8_t* bits, int64_t off, int64_t n) {
+  int64_t i = off, end = off + n;
+  for (; i < end && (i & 7); i++) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
+  if (end - i >= 8) { memset(bits + (i >> 3), 0xff, (size_t)((end - i) >> 3)); i += (end - i) & ~int64_t(7); }
+  for (; i < end; i++) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
+}
+
 // Utf8 / LargeUtf8 / Utf8View (+ binary twins) that are not dictionary-encoded: 16-byte views are assembled on the host (offsets ->
 // {len, inline bytes | prefix, buffer, offset}; view buffer indices rebased across batches), hashing / comparing / encoding happens
 // on the device (plx_strview_dict_encode: kernels_strview.hip)
@@ -110,7 +136,10 @@ ColumnPtr read_string_column(File& f, const std::vector<int>& bsel, int col, int
   const ipc::Field& fl = f.footer.fields[col];
   const bool is_view = fl.type == ipc::TY_UTF8_VIEW || fl.type == ipc::TY_BINARY_VIEW;
   const bool large = fl.type == ipc::TY_LARGE_UTF8 || fl.type == ipc::TY_LARGE_BINARY;
-  std::vector<uint8_t> views((size_t)total * 16 + 16, 0), validity((size_t)(total + 7) / 8 + 8, 0);
+  // views are written row by row below (every row, in parallel slices): no 16 B/row zero fill by one thread first
+  std::unique_ptr<uint8_t[]> views_mem(new uint8_t[(size_t)total * 16 + 16]);
+  uint8_t* const views = views_mem.get();
+  std::vector<uint8_t> validity((size_t)(total + 7) / 8 + 8, 0);
   std::vector<std::vector<uint8_t>> data;
   bool any_nulls = false;
   int64_t row = 0;
@@ -127,10 +156,10 @@ ColumnPtr read_string_column(File& f, const std::vector<int>& bsel, int col, int
       vbits = read_buffer(f, body, bm.buffers[s.buf]);
       if ((int64_t)vbits.size() - 16 < (n + 7) / 8) throw ipc::FormatError("bitmap buffer shorter than the array");
     }
-    for (int64_t i = 0; i < n; i++) {
-      const bool ok = nc == 0 || ((vbits[(size_t)i >> 3] >> (i & 7)) & 1);
-      if (ok) validity[(size_t)(row + i) >> 3] |= (uint8_t)(1u << ((row + i) & 7));
-    }
+    if (nc == 0) set_bits(validity.data(), row, n);
+    else
+      for (int64_t i = 0; i < n; i++)
+        if ((vbits[(size_t)i >> 3] >> (i & 7)) & 1) validity[(size_t)(row + i) >> 3] |= (uint8_t)(1u << ((row + i) & 7));
     const uint32_t base = (uint32_t)data.size();
     if (is_view) {
       const int64_t nvar = s.variadic < bm.variadic_counts.size() ? bm.variadic_counts[s.variadic] : 0;
@@ -138,8 +167,9 @@ ColumnPtr read_string_column(File& f, const std::vector<int>& bsel, int col, int
       std::vector<uint8_t> v = read_buffer(f, body, bm.buffers[s.buf + 1]);
       if ((int64_t)v.size() - 16 < n * 16) throw ipc::FormatError("views buffer shorter than the array");
       for (int64_t k = 0; k < nvar; k++) data.push_back(read_buffer(f, body, bm.buffers[s.buf + 2 + (size_t)k]));
-      for (int64_t i = 0; i < n; i++) {
-        uint8_t* dst = views.data() + 16 * (size_t)(row + i);
+      parallel_rows(n, [&](int64_t i0, int64_t i1) {
+      for (int64_t i = i0; i < i1; i++) {
+        uint8_t* dst = views + 16 * (size_t)(row + i);
         memcpy(dst, v.data() + 16 * i, 16);
         uint32_t len, bi, off;
         memcpy(&len, dst, 4);
@@ -152,6 +182,7 @@ ColumnPtr read_string_column(File& f, const std::vector<int>& bsel, int col, int
           memcpy(dst + 8, &bi, 4);
         }
       }
+      });
     } else {
       std::vector<uint8_t> offs = read_buffer(f, body, bm.buffers[s.buf + 1]);
       data.push_back(read_buffer(f, body, bm.buffers[s.buf + 2]));
@@ -159,19 +190,22 @@ ColumnPtr read_string_column(File& f, const std::vector<int>& bsel, int col, int
       const size_t ow = large ? 8 : 4;
       if (n && (int64_t)offs.size() - 16 < (n + 1) * (int64_t)ow) throw ipc::FormatError("offsets buffer shorter than the array");
       if ((int64_t)d.size() - 16 >= ((int64_t)1 << 32)) throw Unsupported("string data buffer of 4 GiB or more in one record batch");
-      for (int64_t i = 0; i < n; i++) {
+      parallel_rows(n, [&](int64_t i0, int64_t i1) {
+      for (int64_t i = i0; i < i1; i++) {
         int64_t a, e;
         if (large) { memcpy(&a, offs.data() + 8 * i, 8); memcpy(&e, offs.data() + 8 * (i + 1), 8); }
         else { int32_t a32, e32; memcpy(&a32, offs.data() + 4 * i, 4); memcpy(&e32, offs.data() + 4 * (i + 1), 4); a = a32; e = e32; }
         if (a < 0 || e < a || e > (int64_t)d.size() - 16 || e - a > 0x7fffffff) throw ipc::FormatError("string offsets outside the data buffer");
         const bool ok = nc == 0 || ((vbits[(size_t)i >> 3] >> (i & 7)) & 1);
+        uint8_t* dst = views + 16 * (size_t)(row + i);
+        memset(dst, 0, 16);                     // null rows and the unused inline bytes of short strings are zero (views are compared whole)
         if (!ok) continue;
-        uint8_t* dst = views.data() + 16 * (size_t)(row + i);
         const uint32_t len = (uint32_t)(e - a), off = (uint32_t)a;
         memcpy(dst, &len, 4);
         if (len <= 12) memcpy(dst + 4, d.data() + a, len);
         else { memcpy(dst + 4, d.data() + a, 4); memcpy(dst + 8, &base, 4); memcpy(dst + 12, &off, 4); }
       }
+      });
     }
     row += n;
   }
@@ -180,7 +214,7 @@ ColumnPtr read_string_column(File& f, const std::vector<int>& bsel, int col, int
   for (const std::vector<uint8_t>& d : data) { ptrs.push_back(d.data()); sizes.push_back((int64_t)d.size() - 16); }
   plx_column codes = 0;
   plx_strdict dict = 0;
-  int rc = plx_strview_dict_encode(views.data(), any_nulls ? validity.data() : nullptr, 0, total, ptrs.empty() ? nullptr : ptrs.data(), sizes.empty() ? nullptr : sizes.data(),
+  int rc = plx_strview_dict_encode(views, any_nulls ? validity.data() : nullptr, 0, total, ptrs.empty() ? nullptr : ptrs.data(), sizes.empty() ? nullptr : sizes.data(),
                                    (int32_t)ptrs.size(), &codes, &dict);
   if (rc != PLX_OK) fail(rc, plx_last_error());
   ColumnPtr c = get_column(codes);

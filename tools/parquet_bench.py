@@ -47,6 +47,24 @@ def main():
                           "decoded_GBps": round(decoded / best / 1e9, 2), "rows_per_s": round(n / best), "kernel_us_per_read": ks, "kernel_ms_total": round(sum(ks.values()) / 1e3, 2),
                           "pyarrow_read_table_s": round(t_pa, 4), "pyarrow_threads": pa.cpu_count()}))
         del df
+    # the same table as an uncompressed Arrow IPC file: no decode at all, buffers are DMA'd into place (strings: device dictionary encode)
+    import pyarrow.ipc as ipc
+    path = os.path.join(d, "li.arrow")
+    with ipc.new_file(path, t.schema) as w:
+        for b in t.to_batches(max_chunksize=1 << 20):
+            w.write_batch(b)
+    fbytes = os.path.getsize(path)
+    pl.read_ipc(path)
+    F.check(F.lib().plx_profile_clear()); F.check(F.lib().plx_profile_enable(1))
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); df = pl.read_ipc(path); F.check(F.lib().plx_synchronize()); ts.append(time.perf_counter() - t0)
+    ks = {k: round(v[1] / 3) for k, v in bench.kernel_stats(pl).items()}
+    F.check(F.lib().plx_profile_enable(0))
+    t0 = time.perf_counter(); ipc.open_file(path).read_all(); t_pa = time.perf_counter() - t0
+    best = min(ts)
+    print(json.dumps({"rows": n, "format": "arrow_ipc_uncompressed", "file_bytes": fbytes, "read_s": round(best, 4), "file_GBps": round(fbytes / best / 1e9, 2),
+                      "rows_per_s": round(n / best), "kernel_us_per_read": ks, "pyarrow_read_all_s_mmap_zero_copy": round(t_pa, 4)}))
 
 
 if __name__ == "__main__":
