@@ -1,0 +1,504 @@
+// host_codecs.hpp -- page decompressors that run on HOST threads: Zstandard (RFC 8878) and LZ4 raw blocks, written from the format
+// specifications, bounds-checked, no third-party code.  No HIP.
+//
+// Why they exist: Snappy pages are decompressed on the device (parquet_snappy.hpp).  Zstandard is what Polars itself writes by default
+// (crates/polars-parquet/src/parquet/compression.rs:144-230 dispatches to the zstd crate), and its entropy stages (FSE-coded sequences
+// on a backward bit stream, 4-way Huffman literals) are a different kernel family that is not written yet.  Until it is, such pages are
+// decompressed by a pool of host threads, one page each, into the page-locked staging buffer, and from there everything is the
+// uncompressed device path (levels, dictionary indices, values, nulls: kernels_parquet.hip) -- so a file written by Polars is still
+// read without pyarrow and decoded on the device, only its decompression is not.
+//
+// zstd_decompress follows RFC 8878 section by section: frames (3.1.1), blocks (3.1.1.2), literals section with raw / RLE / Huffman
+// literals in 1 or 4 streams (3.1.1.3.1, 4.2), Huffman weights direct or FSE-compressed (4.2.1), sequences section with predefined /
+// RLE / FSE / repeat tables (3.1.1.3.2, 4.1), sequence execution with the three repeat offsets (3.1.1.5).  Dictionaries are refused.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace plx {
+namespace codec {
+
+struct CodecError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+// ---- LZ4 raw block (Parquet codec LZ4_RAW) -------------------------------------------------------------------------------------------
+// sequences of: token (hi nibble literal length, lo nibble match length - 4; 15 = more length bytes of 255 follow), literals,
+// 2-byte little-endian offset, [match length bytes].  The last sequence ends after its literals.
+inline void lz4_raw_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t out_len) {
+  size_t ip = 0, op = 0;
+  while (ip < n) {
+    const uint8_t token = in[ip++];
+    size_t lit = token >> 4;
+    if (lit == 15) {
+      uint8_t b;
+      do {
+        if (ip >= n) throw CodecError("lz4: truncated literal length");
+        b = in[ip++];
+        lit += b;
+      } while (b == 255);
+    }
+    if (lit > n - ip || lit > out_len - op) throw CodecError("lz4: literals past the end");
+    memcpy(out + op, in + ip, lit);
+    ip += lit; op += lit;
+    if (ip >= n) break;                       // last sequence: literals only
+    if (n - ip < 2) throw CodecError("lz4: truncated offset");
+    const size_t off = in[ip] | ((size_t)in[ip + 1] << 8);
+    ip += 2;
+    size_t ml = (token & 15);
+    if (ml == 15) {
+      uint8_t b;
+      do {
+        if (ip >= n) throw CodecError("lz4: truncated match length");
+        b = in[ip++];
+        ml += b;
+      } while (b == 255);
+    }
+    ml += 4;
+    if (off == 0 || off > op || ml > out_len - op) throw CodecError("lz4: bad match");
+    for (size_t i = 0; i < ml; i++) out[op + i] = out[op - off + i];
+    op += ml;
+  }
+  if (op != out_len) throw CodecError("lz4: block decodes to a different length than the page header says");
+}
+
+// ---- Zstandard ------------------------------------------------------------------------------------------------------------------------
+namespace zstd_detail {
+
+inline int highest_bit(uint64_t v) { return v ? 63 - __builtin_clzll(v) : -1; }
+
+// forward little-endian bit reader (FSE table descriptions)
+struct FwdBits {
+  const uint8_t* p; size_t n; size_t bit = 0;
+  uint32_t read(int nb) {
+    uint32_t v = 0;
+    for (int i = 0; i < nb; i++) {
+      size_t byte = (bit + i) >> 3;
+      if (byte >= n) throw CodecError("zstd: table description runs past its section");
+      v |= (uint32_t)((p[byte] >> ((bit + i) & 7)) & 1) << i;
+    }
+    bit += nb;
+    return v;
+  }
+  void rewind(int nb) { bit -= nb; }
+  size_t bytes_used() const { return (bit + 7) >> 3; }
+};
+
+// backward bit stream (4.1 / 4.2.2): starts at the highest set bit of the last byte; bits before the start read as zero
+struct BackBits {
+  const uint8_t* p; int64_t off;        // bit offset of the next bit to hand out (counting down)
+  BackBits(const uint8_t* src, size_t n) : p(src) {
+    if (n == 0 || src[n - 1] == 0) throw CodecError("zstd: backward bit stream without its end mark");
+    off = (int64_t)n * 8 - (8 - highest_bit(src[n - 1]));      // drop the padding and the mark itself
+  }
+  uint64_t read(int nb) {
+    if (nb == 0) return 0;
+    off -= nb;
+    int64_t at = off; int take = nb;
+    if (at < 0) { take += (int)at; at = 0; }
+    uint64_t v = 0;
+    if (take > 0) {
+      // bits [at, at + take) little-endian
+      size_t byte = (size_t)(at >> 3);
+      int sh = (int)(at & 7), got = 0;
+      while (got < take) {
+        uint64_t b = p[byte++] >> sh;
+        int can = 8 - sh;
+        v |= b << got;
+        got += can; sh = 0;
+      }
+      if (take < 64) v &= ((uint64_t)1 << take) - 1;
+    }
+    if (off < 0) v = (-off >= 64) ? 0 : v << (-off);
+    return v;
+  }
+};
+
+struct FseTable {
+  int log = 0;
+  std::vector<uint8_t> symbol, nbits;
+  std::vector<uint16_t> base;
+  bool set = false;
+};
+
+inline void fse_build(const int16_t* freq, int nsym, int log, FseTable& t) {
+  const int size = 1 << log;
+  t.log = log; t.symbol.assign(size, 0); t.nbits.assign(size, 0); t.base.assign(size, 0); t.set = true;
+  std::vector<uint16_t> desc(nsym, 0);
+  int high = size;
+  for (int s = 0; s < nsym; s++)
+    if (freq[s] == -1) { t.symbol[--high] = (uint8_t)s; desc[s] = 1; }
+  const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+  int pos = 0;
+  for (int s = 0; s < nsym; s++) {
+    if (freq[s] <= 0) continue;
+    desc[s] = (uint16_t)freq[s];
+    for (int i = 0; i < freq[s]; i++) {
+      t.symbol[pos] = (uint8_t)s;
+      do { pos = (pos + step) & mask; } while (pos >= high);
+    }
+  }
+  if (pos != 0) throw CodecError("zstd: FSE distribution does not fill its table");
+  for (int i = 0; i < size; i++) {
+    const int s = t.symbol[i];
+    const uint16_t next = desc[s]++;
+    t.nbits[i] = (uint8_t)(log - highest_bit(next));
+    t.base[i] = (uint16_t)(((uint32_t)next << t.nbits[i]) - size);
+  }
+}
+
+// 4.1.1: FSE table description -> table; returns the bytes it took
+inline size_t fse_read(const uint8_t* p, size_t n, int max_log, int max_sym, FseTable& t) {
+  FwdBits br{p, n};
+  const int log = 5 + (int)br.read(4);
+  if (log > max_log) throw CodecError("zstd: FSE accuracy log too large");
+  int remaining = 1 << log, sym = 0;
+  int16_t freq[256];
+  while (remaining > 0 && sym <= max_sym) {
+    int bits = highest_bit((uint64_t)remaining + 1) + 1;
+    uint32_t val = br.read(bits);
+    const uint32_t lower = ((uint32_t)1 << (bits - 1)) - 1;
+    const uint32_t threshold = ((uint32_t)1 << bits) - 1 - (uint32_t)(remaining + 1);
+    if ((val & lower) < threshold) { br.rewind(1); val &= lower; }
+    else if (val > lower) val -= threshold;
+    const int proba = (int)val - 1;
+    remaining -= proba < 0 ? -proba : proba;
+    freq[sym++] = (int16_t)proba;
+    if (proba == 0) {
+      uint32_t rep = br.read(2);
+      for (;;) {
+        for (uint32_t i = 0; i < rep && sym <= max_sym; i++) freq[sym++] = 0;
+        if (rep == 3) rep = br.read(2); else break;
+      }
+    }
+  }
+  if (remaining != 0 || sym > max_sym + 1) throw CodecError("zstd: malformed FSE distribution");
+  fse_build(freq, sym, log, t);
+  return br.bytes_used();
+}
+
+struct HufTable {
+  int max_bits = 0;
+  std::vector<uint8_t> symbol, nbits;
+  bool set = false;
+};
+
+inline void huf_build(const uint8_t* bits, int nsym, HufTable& t) {
+  int max_bits = 0;
+  uint32_t rank_count[17] = {0};
+  for (int i = 0; i < nsym; i++) {
+    if (bits[i] > 11) throw CodecError("zstd: Huffman code longer than 11 bits");
+    max_bits = bits[i] > max_bits ? bits[i] : max_bits;
+    rank_count[bits[i]]++;
+  }
+  if (max_bits == 0) throw CodecError("zstd: empty Huffman tree");
+  const uint32_t size = 1u << max_bits;
+  t.max_bits = max_bits; t.symbol.assign(size, 0); t.nbits.assign(size, 0); t.set = true;
+  uint32_t rank_idx[18];
+  rank_idx[max_bits] = 0;
+  for (int i = max_bits; i >= 1; i--) {
+    rank_idx[i - 1] = rank_idx[i] + rank_count[i] * (1u << (max_bits - i));
+    if (rank_idx[i - 1] > size) throw CodecError("zstd: Huffman weights overflow the table");
+    for (uint32_t k = rank_idx[i]; k < rank_idx[i - 1]; k++) t.nbits[k] = (uint8_t)i;
+  }
+  if (rank_idx[0] != size) throw CodecError("zstd: Huffman weights do not fill the table");
+  for (int s = 0; s < nsym; s++) {
+    if (!bits[s]) continue;
+    const uint32_t code = rank_idx[bits[s]], len = 1u << (max_bits - bits[s]);
+    for (uint32_t k = 0; k < len; k++) t.symbol[code + k] = (uint8_t)s;
+    rank_idx[bits[s]] += len;
+  }
+}
+
+// 4.2.1: Huffman tree description -> table; returns the bytes it took
+inline size_t huf_read(const uint8_t* p, size_t n, HufTable& t) {
+  if (n < 1) throw CodecError("zstd: missing Huffman tree description");
+  const int hb = p[0];
+  uint8_t weights[260];
+  int nw = 0;
+  size_t used;
+  if (hb >= 128) {
+    nw = hb - 127;
+    const size_t bytes = (size_t)(nw + 1) / 2;
+    if (bytes > n - 1) throw CodecError("zstd: Huffman weights run past the literals section");
+    for (int i = 0; i < nw; i++) weights[i] = (i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4);
+    used = 1 + bytes;
+  } else {
+    if ((size_t)hb > n - 1 || hb == 0) throw CodecError("zstd: FSE-compressed Huffman weights run past the literals section");
+    const uint8_t* q = p + 1;
+    FseTable ft;
+    const size_t th = fse_read(q, (size_t)hb, 6, 255, ft);
+    if (th >= (size_t)hb) throw CodecError("zstd: no room for the Huffman weight stream");
+    BackBits bs(q + th, (size_t)hb - th);
+    uint32_t s1 = (uint32_t)bs.read(ft.log), s2 = (uint32_t)bs.read(ft.log);
+    for (;;) {
+      if (nw >= 254) throw CodecError("zstd: too many Huffman weights");     // two more may follow below: 255 weights + the implied one = 256 symbols
+      weights[nw++] = ft.symbol[s1];
+      s1 = ft.base[s1] + (uint32_t)bs.read(ft.nbits[s1]);
+      if (bs.off < 0) { weights[nw++] = ft.symbol[s2]; break; }
+      if (nw >= 254) throw CodecError("zstd: too many Huffman weights");
+      weights[nw++] = ft.symbol[s2];
+      s2 = ft.base[s2] + (uint32_t)bs.read(ft.nbits[s2]);
+      if (bs.off < 0) { weights[nw++] = ft.symbol[s1]; break; }
+    }
+    used = 1 + (size_t)hb;
+  }
+  // weights -> code lengths; the last symbol's weight is implied (the sum of 2^(w-1) is a power of two)
+  uint64_t sum = 0;
+  for (int i = 0; i < nw; i++) {
+    if (weights[i] > 11) throw CodecError("zstd: Huffman weight above 11");
+    sum += weights[i] ? (uint64_t)1 << (weights[i] - 1) : 0;
+  }
+  if (sum == 0) throw CodecError("zstd: all Huffman weights are zero");
+  const int max_bits = highest_bit(sum) + 1;
+  const uint64_t left = ((uint64_t)1 << max_bits) - sum;
+  if (left & (left - 1)) throw CodecError("zstd: Huffman weights do not leave a power of two");
+  const int last_weight = highest_bit(left) + 1;
+  uint8_t bits[260];
+  for (int i = 0; i < nw; i++) bits[i] = weights[i] ? (uint8_t)(max_bits + 1 - weights[i]) : 0;
+  bits[nw] = (uint8_t)(max_bits + 1 - last_weight);
+  huf_build(bits, nw + 1, t);
+  return used;
+}
+
+inline void huf_stream(const HufTable& t, const uint8_t* p, size_t n, uint8_t* out, size_t out_len) {
+  BackBits bs(p, n);
+  const int mb = t.max_bits;
+  const uint32_t mask = (1u << mb) - 1;
+  uint32_t state = (uint32_t)bs.read(mb);
+  size_t o = 0;
+  while (bs.off > -mb) {
+    if (o >= out_len) throw CodecError("zstd: Huffman stream longer than its regenerated size");
+    out[o++] = t.symbol[state];
+    const int nb = t.nbits[state];
+    state = ((state << nb) + (uint32_t)bs.read(nb)) & mask;
+  }
+  if (bs.off != -mb || o != out_len) throw CodecError("zstd: Huffman stream does not end where it should");
+}
+
+const uint32_t kLLBase[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+const uint8_t kLLBits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+const uint32_t kMLBase[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41, 43, 47, 51, 59,
+                              67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
+const uint8_t kMLBits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+const int16_t kLLDefault[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+const int16_t kOFDefault[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+const int16_t kMLDefault[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+
+struct FrameState {
+  HufTable huf;
+  FseTable ll, of, ml;
+  uint64_t rep[3] = {1, 4, 8};
+};
+
+// one of the three sequence tables (3.1.1.3.2.1): mode 0 predefined, 1 RLE, 2 FSE description, 3 repeat
+inline size_t seq_table(int mode, const uint8_t* p, size_t n, int max_log, int max_sym, const int16_t* dflt, int ndflt, int dflt_log, FseTable& t) {
+  switch (mode) {
+    case 0: fse_build(dflt, ndflt, dflt_log, t); return 0;
+    case 1: {
+      if (n < 1) throw CodecError("zstd: missing RLE symbol");
+      if (p[0] > max_sym) throw CodecError("zstd: RLE symbol out of range");
+      t.log = 0; t.symbol.assign(1, p[0]); t.nbits.assign(1, 0); t.base.assign(1, 0); t.set = true;
+      return 1;
+    }
+    case 2: return fse_read(p, n, max_log, max_sym, t);
+    default:
+      if (!t.set) throw CodecError("zstd: repeat mode without a previous table");
+      return 0;
+  }
+}
+
+inline void block_compressed(FrameState& fs, const uint8_t* p, size_t n, std::vector<uint8_t>& lit_buf, uint8_t* out, size_t out_cap, size_t* op_io) {
+  // ---- literals section (3.1.1.3.1) ----
+  if (n < 1) throw CodecError("zstd: empty compressed block");
+  const int ltype = p[0] & 3, sf = (p[0] >> 2) & 3;
+  size_t regen = 0, comp = 0, hdr = 0;
+  int streams = 1;
+  if (ltype < 2) {
+    if (sf == 0 || sf == 2) { regen = p[0] >> 3; hdr = 1; }
+    else if (sf == 1) { if (n < 2) throw CodecError("zstd: truncated literals header"); regen = (p[0] >> 4) | ((size_t)p[1] << 4); hdr = 2; }
+    else { if (n < 3) throw CodecError("zstd: truncated literals header"); regen = (p[0] >> 4) | ((size_t)p[1] << 4) | ((size_t)p[2] << 12); hdr = 3; }
+  } else {
+    if (sf == 0 || sf == 1) {
+      if (n < 3) throw CodecError("zstd: truncated literals header");
+      const uint32_t v = p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+      regen = (v >> 4) & 0x3ff; comp = (v >> 14) & 0x3ff; hdr = 3; streams = sf == 0 ? 1 : 4;
+    } else if (sf == 2) {
+      if (n < 4) throw CodecError("zstd: truncated literals header");
+      const uint32_t v = p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+      regen = (v >> 4) & 0x3fff; comp = v >> 18; hdr = 4; streams = 4;
+    } else {
+      if (n < 5) throw CodecError("zstd: truncated literals header");
+      const uint64_t v = p[0] | ((uint64_t)p[1] << 8) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 24) | ((uint64_t)p[4] << 32);
+      regen = (size_t)((v >> 4) & 0x3ffff); comp = (size_t)(v >> 22); hdr = 5; streams = 4;
+    }
+  }
+  if (regen > (size_t)128 * 1024) throw CodecError("zstd: literals larger than a block");
+  lit_buf.resize(regen + 8);
+  uint8_t* lits = lit_buf.data();
+  size_t pos = hdr;
+  if (ltype == 0) {
+    if (regen > n - pos) throw CodecError("zstd: raw literals past the block");
+    memcpy(lits, p + pos, regen); pos += regen;
+  } else if (ltype == 1) {
+    if (pos >= n) throw CodecError("zstd: RLE literal missing");
+    memset(lits, p[pos], regen); pos += 1;
+  } else {
+    if (comp > n - pos) throw CodecError("zstd: compressed literals past the block");
+    const uint8_t* q = p + pos;
+    size_t left = comp;
+    if (ltype == 2) { const size_t th = huf_read(q, left, fs.huf); q += th; left -= th; }
+    else if (!fs.huf.set) throw CodecError("zstd: treeless literals without a previous Huffman table");
+    if (streams == 1) huf_stream(fs.huf, q, left, lits, regen);
+    else {
+      if (left < 6) throw CodecError("zstd: missing Huffman jump table");
+      const size_t s1 = q[0] | ((size_t)q[1] << 8), s2 = q[2] | ((size_t)q[3] << 8), s3 = q[4] | ((size_t)q[5] << 8);
+      if (s1 + s2 + s3 > left - 6) throw CodecError("zstd: Huffman streams past the literals section");
+      const size_t s4 = left - 6 - s1 - s2 - s3, each = (regen + 3) / 4;
+      if (each * 3 > regen) throw CodecError("zstd: regenerated size too small for four streams");
+      const uint8_t* d = q + 6;
+      huf_stream(fs.huf, d, s1, lits, each);
+      huf_stream(fs.huf, d + s1, s2, lits + each, each);
+      huf_stream(fs.huf, d + s1 + s2, s3, lits + 2 * each, each);
+      huf_stream(fs.huf, d + s1 + s2 + s3, s4, lits + 3 * each, regen - 3 * each);
+    }
+    pos += comp;
+  }
+  // ---- sequences section (3.1.1.3.2) ----
+  if (pos >= n) throw CodecError("zstd: missing sequences section");
+  size_t nseq = p[pos++];
+  if (nseq >= 128) {
+    if (nseq < 255) { if (pos >= n) throw CodecError("zstd: truncated sequence count"); nseq = ((nseq - 128) << 8) + p[pos++]; }
+    else { if (n - pos < 2) throw CodecError("zstd: truncated sequence count"); nseq = p[pos] + ((size_t)p[pos + 1] << 8) + 0x7f00; pos += 2; }
+  }
+  size_t op = *op_io, lp = 0;
+  if (nseq == 0) {
+    if (pos != n) throw CodecError("zstd: bytes after an empty sequences section");
+    if (regen > out_cap - op) throw CodecError("zstd: output larger than the page header says");
+    memcpy(out + op, lits, regen);
+    *op_io = op + regen;
+    return;
+  }
+  if (pos >= n) throw CodecError("zstd: missing compression modes");
+  const int modes = p[pos++];
+  if (modes & 3) throw CodecError("zstd: reserved bits set in the compression modes");
+  pos += seq_table((modes >> 6) & 3, p + pos, n - pos, 9, 35, kLLDefault, 36, 6, fs.ll);
+  pos += seq_table((modes >> 4) & 3, p + pos, n - pos, 8, 31, kOFDefault, 29, 5, fs.of);
+  pos += seq_table((modes >> 2) & 3, p + pos, n - pos, 9, 52, kMLDefault, 53, 6, fs.ml);
+  if (pos >= n) throw CodecError("zstd: missing sequence bit stream");
+  BackBits bs(p + pos, n - pos);
+  uint32_t sl = (uint32_t)bs.read(fs.ll.log), so = (uint32_t)bs.read(fs.of.log), sm = (uint32_t)bs.read(fs.ml.log);
+  for (size_t i = 0; i < nseq; i++) {
+    const int oc = fs.of.symbol[so], lc = fs.ll.symbol[sl], mc = fs.ml.symbol[sm];
+    if (oc > 31 || lc > 35 || mc > 52) throw CodecError("zstd: sequence code out of range");
+    const uint64_t ov = ((uint64_t)1 << oc) + bs.read(oc);
+    const uint64_t ml = kMLBase[mc] + bs.read(kMLBits[mc]);
+    const uint64_t ll = kLLBase[lc] + bs.read(kLLBits[lc]);
+    if (i + 1 < nseq) {
+      sl = fs.ll.base[sl] + (uint32_t)bs.read(fs.ll.nbits[sl]);
+      sm = fs.ml.base[sm] + (uint32_t)bs.read(fs.ml.nbits[sm]);
+      so = fs.of.base[so] + (uint32_t)bs.read(fs.of.nbits[so]);
+    }
+    if (bs.off < 0) throw CodecError("zstd: sequence bit stream ends early");
+    uint64_t offset;
+    if (ov > 3) {
+      offset = ov - 3;
+      fs.rep[2] = fs.rep[1]; fs.rep[1] = fs.rep[0]; fs.rep[0] = offset;
+    } else {
+      uint64_t idx = ov - 1;
+      if (ll == 0) idx++;
+      if (idx == 0) offset = fs.rep[0];
+      else {
+        offset = idx < 3 ? fs.rep[idx] : fs.rep[0] - 1;
+        if (idx > 1) fs.rep[2] = fs.rep[1];
+        fs.rep[1] = fs.rep[0]; fs.rep[0] = offset;
+      }
+    }
+    if (ll > regen - lp || ll > out_cap - op) throw CodecError("zstd: sequence literals past their section / the output");
+    memcpy(out + op, lits + lp, ll);
+    op += ll; lp += ll;
+    if (offset == 0 || offset > op || ml > out_cap - op) throw CodecError("zstd: match outside the output (dictionaries are not supported)");
+    if (offset >= ml) memcpy(out + op, out + op - offset, ml);
+    else for (uint64_t k = 0; k < ml; k++) out[op + k] = out[op - offset + k];
+    op += ml;
+  }
+  if (bs.off != 0) throw CodecError("zstd: sequence bit stream not consumed exactly");
+  const size_t rest = regen - lp;
+  if (rest > out_cap - op) throw CodecError("zstd: output larger than the page header says");
+  memcpy(out + op, lits + lp, rest);
+  *op_io = op + rest;
+}
+
+}  // namespace zstd_detail
+
+// every frame of [in, in + n) into out[0, out_len); throws unless exactly out_len bytes result
+inline void zstd_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t out_len) {
+  using namespace zstd_detail;
+  size_t ip = 0, op = 0;
+  std::vector<uint8_t> lit_buf;
+  while (ip < n) {
+    if (n - ip < 4) throw CodecError("zstd: truncated frame magic");
+    uint32_t magic;
+    memcpy(&magic, in + ip, 4);
+    if ((magic & 0xfffffff0u) == 0x184d2a50u) {            // skippable frame
+      if (n - ip < 8) throw CodecError("zstd: truncated skippable frame");
+      uint32_t len;
+      memcpy(&len, in + ip + 4, 4);
+      if (len > n - ip - 8) throw CodecError("zstd: skippable frame past the end");
+      ip += 8 + len;
+      continue;
+    }
+    if (magic != 0xfd2fb528u) throw CodecError("zstd: not a Zstandard frame");
+    ip += 4;
+    if (ip >= n) throw CodecError("zstd: truncated frame header");
+    const uint8_t fhd = in[ip++];
+    const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, did_flag = fhd & 3;
+    if (fhd & 8) throw CodecError("zstd: reserved bit set in the frame header");
+    if (!single) { if (ip >= n) throw CodecError("zstd: truncated frame header"); ip++; }       // window descriptor: the whole output is the window here
+    const int did_bytes = did_flag == 3 ? 4 : did_flag;
+    if ((size_t)did_bytes > n - ip) throw CodecError("zstd: truncated frame header");
+    uint32_t did = 0;
+    for (int i = 0; i < did_bytes; i++) did |= (uint32_t)in[ip + i] << (8 * i);
+    if (did) throw CodecError("zstd: frame needs a dictionary");
+    ip += did_bytes;
+    const int fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : fcs_flag == 1 ? 2 : fcs_flag == 2 ? 4 : 8;
+    if ((size_t)fcs_bytes > n - ip) throw CodecError("zstd: truncated frame header");
+    ip += fcs_bytes;                                        // the page header is the authority on the size
+    FrameState fs;
+    const size_t frame_start = op;
+    for (;;) {
+      if (n - ip < 3) throw CodecError("zstd: truncated block header");
+      const uint32_t bh = in[ip] | ((uint32_t)in[ip + 1] << 8) | ((uint32_t)in[ip + 2] << 16);
+      ip += 3;
+      const int last = bh & 1, type = (bh >> 1) & 3;
+      const size_t bsize = bh >> 3;
+      if (type == 0) {
+        if (bsize > n - ip || bsize > out_len - op) throw CodecError("zstd: raw block past the end");
+        memcpy(out + op, in + ip, bsize);
+        ip += bsize; op += bsize;
+      } else if (type == 1) {
+        if (ip >= n || bsize > out_len - op) throw CodecError("zstd: RLE block past the end");
+        memset(out + op, in[ip], bsize);
+        ip += 1; op += bsize;
+      } else if (type == 2) {
+        if (bsize > n - ip) throw CodecError("zstd: compressed block past the end");
+        // matches may reach back to the start of the frame only: hand the block a view that starts there
+        size_t rel = op - frame_start;
+        block_compressed(fs, in + ip, bsize, lit_buf, out + frame_start, out_len - frame_start, &rel);
+        op = frame_start + rel;
+        ip += bsize;
+      } else {
+        throw CodecError("zstd: reserved block type");
+      }
+      if (last) break;
+    }
+    if (checksum) { if (n - ip < 4) throw CodecError("zstd: truncated checksum"); ip += 4; }
+  }
+  if (op != out_len) throw CodecError("zstd: frames decode to a different length than the page header says");
+}
+
+}  // namespace codec
+}  // namespace plx

@@ -1,6 +1,7 @@
 // parquet_reader.hpp -- Parquet column chunks -> device columns, host orchestration.
 //
-// The host only touches METADATA: the footer (parquet_format.hpp), the Thrift page headers inside each column chunk, and the
+// The host only touches METADATA (and, for the two codecs without a device kernel yet -- ZSTD, LZ4_RAW -- decompresses pages on a pool of
+// threads: host_codecs.hpp): the footer (parquet_format.hpp), the Thrift page headers inside each column chunk, and the
 // dictionary pages of string columns (a few KB each, unified into one column-wide dictionary).  The chunk bytes themselves go to HBM
 // exactly as they are in the file -- compressed, encoded -- in one copy per chunk, and everything else happens there
 // (parquet_device.hpp): Snappy, level / index run tables, validity, dense -> row expansion, dictionary lookup, integer narrowing.
@@ -23,6 +24,7 @@
 
 #include "../../include/polars_amd.h"
 #include "file_io.hpp"
+#include "host_codecs.hpp"
 #include "parquet_device.hpp"
 #include "parquet_format.hpp"
 
@@ -160,7 +162,7 @@ inline std::vector<uint8_t> snappy_decompress_host(const uint8_t* in, size_t n, 
 
 // ---- read one column --------------------------------------------------------------------------------------------------------------------
 struct ReadStats {
-  uint64_t file_bytes = 0, data_pages = 0, dict_pages = 0, snappy_streams = 0, snappy_bytes_out = 0, run_entries = 0;
+  uint64_t file_bytes = 0, data_pages = 0, dict_pages = 0, snappy_streams = 0, snappy_bytes_out = 0, run_entries = 0, host_inflated_pages = 0, host_inflated_bytes = 0;
 };
 
 template <class B> struct ColumnResult {
@@ -200,7 +202,7 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
   res.dtype = lt.dtype; res.logical = lt.logical;
 
   // -- plan: chunk placement in the blob ------------------------------------------------------------------------------------------------
-  struct ChunkRef { const ColumnChunk* c; int64_t rows; size_t blob_off; };
+  struct ChunkRef { const ColumnChunk* c; int64_t rows; size_t blob_off, blob_cap; };
   std::vector<ChunkRef> chunks;
   size_t blob_bytes = 0;
   int64_t n_rows = 0;
@@ -212,13 +214,18 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
     if (!c.has_meta) throw FormatError("column chunk without metadata");
     if (c.external_file) throw Unsupported("column chunk stored in another file");
     if (c.type != leaf.type) throw FormatError("column chunk type differs from the schema");
-    if (c.codec != CODEC_UNCOMPRESSED && c.codec != CODEC_SNAPPY)
-      throw Unsupported(std::string("column '") + leaf.name + "': codec " + codec_name(c.codec) + " has no device decompressor (UNCOMPRESSED and SNAPPY do)");
+    const bool host_codec = c.codec == CODEC_ZSTD || c.codec == CODEC_LZ4_RAW;       // decompressed by host threads (host_codecs.hpp)
+    if (c.codec != CODEC_UNCOMPRESSED && c.codec != CODEC_SNAPPY && !host_codec)
+      throw Unsupported(std::string("column '") + leaf.name + "': codec " + codec_name(c.codec) + " has no decompressor here (UNCOMPRESSED, SNAPPY, ZSTD and LZ4_RAW do)");
     if (c.num_values != rg.num_rows) throw FormatError("flat column chunk whose value count differs from the row group's rows");
     if (rg.num_rows == 0) continue;            // an empty row group has nothing to fetch (writers leave its data page offset at 0)
     if (c.start() < 4 || c.total_compressed_size < 0 || c.start() + c.total_compressed_size > f.size - 8) throw FormatError("column chunk outside the file");
-    chunks.push_back({&c, rg.num_rows, blob_bytes});
-    blob_bytes += align16((size_t)c.total_compressed_size);
+    // what goes to HBM: the chunk as stored, or -- host codecs -- its image with every page payload decompressed (the metadata's
+    // uncompressed total, page headers included, bounds it)
+    if (host_codec && (c.total_uncompressed_size < 0 || c.total_uncompressed_size > ((int64_t)1 << 40))) throw FormatError("column chunk with an absurd uncompressed size");
+    const size_t cap = align16((size_t)(host_codec ? c.total_uncompressed_size : c.total_compressed_size));
+    chunks.push_back({&c, rg.num_rows, blob_bytes, cap});
+    blob_bytes += cap;
     n_rows += rg.num_rows;
     if (optional && !(c.stats.has_null_count && c.stats.null_count == 0)) nulls_possible = true;
   }
@@ -250,10 +257,21 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
   for (const ChunkRef& ch : chunks) {
     const ColumnChunk& c = *ch.c;
     const size_t sz = (size_t)c.total_compressed_size;
-    uint8_t* host = be.host_stage(sz + 16);
+    const bool host_codec = c.codec == CODEC_ZSTD || c.codec == CODEC_LZ4_RAW;
+    const bool codec_on = c.codec == CODEC_SNAPPY;          // pages decompressed on the device
+    // Device codec / none: the stored bytes are staged and uploaded as they are.  Host codec: the stored bytes stay in pageable memory;
+    // what is staged and uploaded is the chunk's IMAGE -- the page payloads decompressed, back to back -- and the pages then look
+    // like pages of an uncompressed file to every kernel.
+    std::vector<uint8_t> stored;
+    uint8_t* host = nullptr;
+    uint8_t* image = nullptr;
+    size_t ipos = 0;
+    if (host_codec) { stored.resize(sz + 16); host = stored.data(); image = be.host_stage(ch.blob_cap + 16); }
+    else host = be.host_stage(sz + 16);
     f.pread_sliced(host, sz, c.start());
     if (stats) stats->file_bytes += sz;
-    const bool codec_on = c.codec != CODEC_UNCOMPRESSED;
+    struct Inflate { const uint8_t* src; size_t n; uint8_t* dst; size_t out; bool copy; };
+    std::vector<Inflate> inflate;
     size_t pos = 0;
     int64_t seen = 0;
     size_t chunk_dict = npos;
@@ -262,7 +280,27 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
       PageHeader h = parse_page_header(host + pos, sz - pos);
       pos += h.header_bytes;
       if ((size_t)h.compressed_size > sz - pos) throw FormatError("page runs past its column chunk");
-      const uint64_t payload = blob_addr + ch.blob_off + pos;
+      const bool data_page = h.type == PAGE_DATA || h.type == PAGE_DATA_V2;
+      size_t place = pos;                                     // offset of the payload inside what is uploaded
+      if (host_codec && (data_page || (h.type == PAGE_DICTIONARY && !is_bytes))) {
+        const size_t out = (size_t)h.uncompressed_size;
+        if (out > ch.blob_cap - ipos) throw FormatError("pages decompress to more than the chunk metadata says");
+        place = ipos;
+        if (h.type == PAGE_DATA_V2) {
+          // v2: level bytes are stored uncompressed in front of the (optionally compressed) values
+          if (h.def_len < 0 || h.rep_len < 0 || (int64_t)h.def_len + h.rep_len > h.compressed_size || (int64_t)h.def_len + h.rep_len > h.uncompressed_size)
+            throw FormatError("v2 level bytes exceed the page");
+          const size_t lv = (size_t)h.def_len + (size_t)h.rep_len;
+          inflate.push_back({host + pos, lv, image + ipos, lv, true});
+          inflate.push_back({host + pos + lv, (size_t)h.compressed_size - lv, image + ipos + lv, out - lv, !h.is_compressed});
+        } else {
+          inflate.push_back({host + pos, (size_t)h.compressed_size, image + ipos, out, false});
+        }
+        ipos += out;
+      }
+      const uint64_t payload = blob_addr + ch.blob_off + place;
+      // sizes of the payload as the kernels will see it
+      const uint32_t seen_comp = host_codec ? (uint32_t)h.uncompressed_size : (uint32_t)h.compressed_size;
       if (h.type == PAGE_DICTIONARY) {
         if (chunk_dict != npos) throw FormatError("two dictionary pages in one column chunk");
         if (h.encoding != ENC_PLAIN && h.encoding != ENC_PLAIN_DICTIONARY) throw Unsupported(std::string("dictionary page encoding ") + encoding_name(h.encoding));
@@ -275,6 +313,14 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
           const uint8_t* p = host + pos;
           size_t n = (size_t)h.compressed_size;
           if (codec_on) { plain = snappy_decompress_host(p, n, (size_t)h.uncompressed_size); p = plain.data(); n = plain.size(); }
+          else if (host_codec) {
+            plain.resize((size_t)h.uncompressed_size);
+            try {
+              if (c.codec == CODEC_ZSTD) codec::zstd_decompress(p, n, plain.data(), plain.size());
+              else codec::lz4_raw_decompress(p, n, plain.data(), plain.size());
+            } catch (const codec::CodecError& e) { throw FormatError(std::string("dictionary page: ") + e.what()); }
+            p = plain.data(); n = plain.size();
+          }
           remap_base_of_dict.push_back(remap.size());
           size_t q = 0;
           for (uint32_t i = 0; i < d.n; i++) {
@@ -303,10 +349,10 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
         }
         dicts.push_back(d);
         if (stats) stats->dict_pages++;
-      } else if (h.type == PAGE_DATA || h.type == PAGE_DATA_V2) {
+      } else if (data_page) {
         PageDesc p{};
         const bool v2 = h.type == PAGE_DATA_V2;
-        p.src = payload; p.comp_size = (uint32_t)h.compressed_size; p.uncomp_size = (uint32_t)h.uncompressed_size;
+        p.src = payload; p.comp_size = seen_comp; p.uncomp_size = (uint32_t)h.uncompressed_size;
         p.num_values = (uint32_t)h.num_values; p.row0 = row0 + (uint64_t)seen;
         p.flags = (v2 ? PF_V2 : 0u) | (optional ? PF_HAS_DEF : 0u);
         if (h.encoding == ENC_PLAIN_DICTIONARY || h.encoding == ENC_RLE_DICTIONARY) {
@@ -339,7 +385,7 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
             jobs.push_back(DecompJob{payload, 0, (uint32_t)h.compressed_size, (uint32_t)h.uncompressed_size});
           }
         }
-        if (!codec_on && h.compressed_size != h.uncompressed_size) throw FormatError("uncompressed page whose two sizes differ");
+        if (c.codec == CODEC_UNCOMPRESSED && h.compressed_size != h.uncompressed_size) throw FormatError("uncompressed page whose two sizes differ");
         job_of_page.push_back(job);
         pages.push_back(p);
         seen += h.num_values;
@@ -348,7 +394,36 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
       pos += (size_t)h.compressed_size;
     }
     if (seen != c.num_values) throw FormatError("pages of a column chunk hold more values than its metadata says");
-    be.upload(blob_addr + ch.blob_off, host, sz);
+    if (host_codec) {
+      // one page per host thread at a time; errors of any of them fail the read
+      const size_t threads = std::min<size_t>(16, inflate.size());
+      std::vector<std::exception_ptr> errs(std::max<size_t>(threads, 1));
+      auto work = [&](size_t t) {
+        try {
+          for (size_t i = t; i < inflate.size(); i += std::max<size_t>(threads, 1)) {
+            const Inflate& j = inflate[i];
+            if (j.copy) { if (j.n != j.out) throw FormatError("uncompressed part of a page whose two sizes differ"); if (j.n) memcpy(j.dst, j.src, j.n); }
+            else if (c.codec == CODEC_ZSTD) codec::zstd_decompress(j.src, j.n, j.dst, j.out);
+            else codec::lz4_raw_decompress(j.src, j.n, j.dst, j.out);
+          }
+        } catch (...) { errs[t] = std::current_exception(); }
+      };
+      if (threads <= 1) { if (!inflate.empty()) work(0); }
+      else {
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < threads; t++) pool.emplace_back(work, t);
+        for (std::thread& th : pool) th.join();
+      }
+      for (std::exception_ptr& ep : errs)
+        if (ep) {
+          try { std::rethrow_exception(ep); }
+          catch (const codec::CodecError& e) { throw FormatError(std::string("column '") + leaf.name + "': " + e.what()); }
+        }
+      if (stats) { stats->host_inflated_pages += inflate.size(); stats->host_inflated_bytes += ipos; }
+      be.upload(blob_addr + ch.blob_off, image, ipos);
+    } else {
+      be.upload(blob_addr + ch.blob_off, host, sz);
+    }
     row0 += (uint64_t)ch.rows;
   }
 

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "../../polars_amd/csrc/host_codecs.hpp"
 #include "../../polars_amd/csrc/parquet_reader.hpp"
 
 using namespace plx::pq;
@@ -179,6 +180,18 @@ int pqemu_snappy(const uint8_t* in, uint32_t n_in, uint8_t* out, uint32_t n_out,
   uint32_t err = snappy_stream(job, thread_order, &nr);
   if (rounds) *rounds = nr;
   return (int)err;
+}
+
+// the host page decompressors of the product (polars_amd/csrc/host_codecs.hpp): codec 0 = zstd, 1 = lz4 raw block
+int pqemu_host_codec(int codec, const uint8_t* in, uint32_t n_in, uint8_t* out, uint32_t n_out) {
+  try {
+    std::vector<uint8_t> src(in, in + n_in);          // exact-size heap blocks: a sanitizer build sees any access past either end
+    std::vector<uint8_t> dst(n_out);
+    if (codec == 0) plx::codec::zstd_decompress(src.data(), src.size(), dst.data(), dst.size());
+    else plx::codec::lz4_raw_decompress(src.data(), src.size(), dst.data(), dst.size());
+    if (n_out) memcpy(out, dst.data(), n_out);
+    return 0;
+  } catch (const std::exception& e) { t_err = e.what(); return 1; }
 }
 
 // the host Snappy of the product (string dictionary pages)

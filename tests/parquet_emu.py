@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "emu", "parquet_emu.cpp")
 SO = os.path.join(HERE, "emu", "libparquet_emu.so")
 CSRC = os.path.join(os.path.dirname(HERE), "polars_amd", "csrc")
-_DEPS = [SRC] + [os.path.join(CSRC, h) for h in ("parquet_reader.hpp", "parquet_device.hpp", "parquet_format.hpp")]
+_DEPS = [SRC] + [os.path.join(CSRC, h) for h in ("parquet_reader.hpp", "parquet_device.hpp", "parquet_snappy.hpp", "parquet_format.hpp", "host_codecs.hpp", "file_io.hpp")]
 NP = {0: None, 1: np.int8, 2: np.int16, 3: np.int32, 4: np.int64, 5: np.uint8, 6: np.uint16, 7: np.uint32, 8: np.uint64, 9: np.float32, 10: np.float64}
 
 _lib = None
@@ -32,6 +32,7 @@ def lib():
         l.pqemu_category.restype = C.c_int64
         l.pqemu_snappy.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
         l.pqemu_snappy_host.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        l.pqemu_host_codec.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32]
         _lib = l
     return _lib
 
@@ -88,3 +89,10 @@ def snappy_host(data: bytes, n_out: int):
     out = np.zeros(max(n_out, 1), np.uint8)
     rc = lib().pqemu_snappy_host(data, len(data), out.ctypes.data_as(C.c_void_p), n_out)
     return rc, out[:n_out].tobytes()
+
+
+def host_codec(codec: str, data: bytes, n_out: int):
+    """The product's host page decompressors ("zstd" / "lz4_raw") -> (rc, bytes, error text)."""
+    out = np.zeros(max(n_out, 1), np.uint8)
+    rc = lib().pqemu_host_codec({"zstd": 0, "lz4_raw": 1}[codec], data, len(data), out.ctypes.data_as(C.c_void_p), n_out)
+    return rc, out[:n_out].tobytes(), lib().pqemu_last_error().decode() if rc else ""

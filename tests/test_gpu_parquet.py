@@ -58,7 +58,7 @@ def compare(df, want_table, names):
         assert np.all(values[~wvalid] == 0), name
 
 
-@pytest.mark.parametrize("compression", ["none", "snappy"])
+@pytest.mark.parametrize("compression", ["none", "snappy", "zstd"])      # zstd: pages inflated by host threads (host_codecs.hpp), then the uncompressed device path
 @pytest.mark.parametrize("version,dictionary", [("1.0", True), ("2.0", True), ("1.0", False)])
 def test_device_decode_matches_pyarrow(pl, tmp_path, compression, version, dictionary):
     n = 20_000
@@ -110,10 +110,10 @@ def test_unsupported_and_corrupt_files_are_status_codes(pl, tmp_path):
     n = 5000
     t = pa.table({"a": pa.array(RNG.integers(0, 9, n), mask=RNG.random(n) < 0.3), "z": pa.array(np.arange(n))})
     path = str(tmp_path / "t.parquet")
-    pq.write_table(t, path, compression={"a": "snappy", "z": "zstd"})
+    pq.write_table(t, path, compression={"a": "snappy", "z": "gzip"})
     with pytest.raises(pl.UnsupportedError) as ei:
         pl.read_parquet(path, columns=["z"])
-    assert "ZSTD" in str(ei.value)
+    assert "GZIP" in str(ei.value)
     compare(pl.read_parquet(path, columns=["a"]), t, ["a"])
     # flip bits inside the page bytes: an error (or a well-formed different value), never a hang or a crash; the library stays usable
     raw = bytearray(open(path, "rb").read())
