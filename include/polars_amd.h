@@ -498,8 +498,8 @@ int plx_parquet_categories_to_host(plx_parquet file, int32_t column, int64_t* of
  * record batch whose body holds the column buffers in Arrow layout.  An uncompressed file needs no decoding at all: the host parses
  * the metadata, every selected buffer goes file -> page-locked staging -> HBM in one DMA, record batches are concatenated in place.
  *   plx_ipc_open / _shape / _column_info / _batch_info   metadata; work without a GPU.  dtype / logical as for plx_parquet_column_info.
- *   plx_ipc_read                batches x columns -> frame.  LZ4 / ZSTD compressed bodies, nested columns, non-us timestamps ->
- *                               PLX_ERR_UNSUPPORTED naming what it met.
+ *   plx_ipc_read                batches x columns -> frame.  LZ4_FRAME / ZSTD compressed bodies are inflated per buffer by host threads
+ *                               (the library's own decoders); nested columns, non-us timestamps -> PLX_ERR_UNSUPPORTED naming what it met.
  *   strings                     dictionary-encoded in the file: indices become PLX_U32 codes (widened on the device), values through
  *                               plx_ipc_categories*.  Utf8 / LargeUtf8 / Utf8View columns: views are assembled on the host, the
  *                               dictionary is built on the device (plx_strview_dict_encode); plx_ipc_column_strdict hands its handle

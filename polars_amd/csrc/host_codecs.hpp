@@ -1,5 +1,5 @@
-// host_codecs.hpp -- page decompressors that run on HOST threads: Zstandard (RFC 8878) and LZ4 raw blocks, written from the format
-// specifications, bounds-checked, no third-party code.  No HIP.
+// host_codecs.hpp -- page / buffer decompressors that run on HOST threads: Zstandard (RFC 8878), LZ4 raw blocks and LZ4 frames, written
+// from the format specifications, bounds-checked, no third-party code.  No HIP.
 //
 // Why they exist: Snappy pages are decompressed on the device (parquet_snappy.hpp).  Zstandard is what Polars itself writes by default
 // (crates/polars-parquet/src/parquet/compression.rs:144-230 dispatches to the zstd crate), and its entropy stages (FSE-coded sequences
@@ -25,11 +25,12 @@ struct CodecError : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
-// ---- LZ4 raw block (Parquet codec LZ4_RAW) -------------------------------------------------------------------------------------------
-// sequences of: token (hi nibble literal length, lo nibble match length - 4; 15 = more length bytes of 255 follow), literals,
-// 2-byte little-endian offset, [match length bytes].  The last sequence ends after its literals.
-inline void lz4_raw_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t out_len) {
-  size_t ip = 0, op = 0;
+// ---- LZ4 ------------------------------------------------------------------------------------------------------------------------------
+// One LZ4 block: sequences of token (hi nibble literal length, lo nibble match length - 4; 15 = more length bytes of 255 follow),
+// literals, 2-byte little-endian offset, [match length bytes]; the last sequence ends after its literals.  Appends to out at *op;
+// matches may reach back into what out already holds (dependent blocks of a frame).
+inline void lz4_block(const uint8_t* in, size_t n, uint8_t* out, size_t* op_io, size_t out_cap) {
+  size_t ip = 0, op = *op_io;
   while (ip < n) {
     const uint8_t token = in[ip++];
     size_t lit = token >> 4;
@@ -41,7 +42,7 @@ inline void lz4_raw_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t
         lit += b;
       } while (b == 255);
     }
-    if (lit > n - ip || lit > out_len - op) throw CodecError("lz4: literals past the end");
+    if (lit > n - ip || lit > out_cap - op) throw CodecError("lz4: literals past the end");
     memcpy(out + op, in + ip, lit);
     ip += lit; op += lit;
     if (ip >= n) break;                       // last sequence: literals only
@@ -58,11 +59,64 @@ inline void lz4_raw_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t
       } while (b == 255);
     }
     ml += 4;
-    if (off == 0 || off > op || ml > out_len - op) throw CodecError("lz4: bad match");
+    if (off == 0 || off > op || ml > out_cap - op) throw CodecError("lz4: bad match");
     for (size_t i = 0; i < ml; i++) out[op + i] = out[op - off + i];
     op += ml;
   }
+  *op_io = op;
+}
+
+// Parquet codec LZ4_RAW: the page is one block
+inline void lz4_raw_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t out_len) {
+  size_t op = 0;
+  lz4_block(in, n, out, &op, out_len);
   if (op != out_len) throw CodecError("lz4: block decodes to a different length than the page header says");
+}
+
+// LZ4 frame format (Arrow IPC body compression LZ4_FRAME): magic, FLG / BD [content size] [dictionary id] HC, blocks {u32 size, high bit =
+// stored; 0 = end mark} [block checksum], [content checksum]; skippable frames are skipped.  Checksums are not verified.
+inline void lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t out_len) {
+  size_t ip = 0, op = 0;
+  auto rd32 = [&](size_t at) { uint32_t v; if (n - at < 4 || at > n) throw CodecError("lz4: truncated frame"); memcpy(&v, in + at, 4); return v; };
+  while (ip < n) {
+    const uint32_t magic = rd32(ip);
+    if ((magic & 0xfffffff0u) == 0x184d2a50u) {
+      const uint32_t len = rd32(ip + 4);
+      if (len > n - ip - 8) throw CodecError("lz4: skippable frame past the end");
+      ip += 8 + len;
+      continue;
+    }
+    if (magic != 0x184d2204u) throw CodecError("lz4: not an LZ4 frame");
+    ip += 4;
+    if (n - ip < 3) throw CodecError("lz4: truncated frame descriptor");
+    const uint8_t flg = in[ip];
+    if ((flg >> 6) != 1) throw CodecError("lz4: unknown frame version");
+    const bool block_checksum = flg & 0x10, content_size = flg & 0x08, content_checksum = flg & 0x04, dict_id = flg & 0x01;
+    if (dict_id) throw CodecError("lz4: frame needs a dictionary");
+    ip += 2 + (content_size ? 8 : 0) + 1;                 // FLG, BD, [content size], HC
+    if (ip > n) throw CodecError("lz4: truncated frame descriptor");
+    const size_t frame_start = op;
+    for (;;) {
+      const uint32_t bs = rd32(ip);
+      ip += 4;
+      if (bs == 0) break;
+      const size_t len = bs & 0x7fffffffu;
+      if (len > n - ip) throw CodecError("lz4: block past the end of the frame");
+      if (bs & 0x80000000u) {
+        if (len > out_len - op) throw CodecError("lz4: stored block past the output");
+        memcpy(out + op, in + ip, len);
+        op += len;
+      } else {
+        size_t rel = op - frame_start;                    // matches reach back to the start of the frame at most
+        lz4_block(in + ip, len, out + frame_start, &rel, out_len - frame_start);
+        op = frame_start + rel;
+      }
+      ip += len + (block_checksum ? 4 : 0);
+      if (ip > n) throw CodecError("lz4: truncated block checksum");
+    }
+    if (content_checksum) { if (n - ip < 4) throw CodecError("lz4: truncated content checksum"); ip += 4; }
+  }
+  if (op != out_len) throw CodecError("lz4: frame decodes to a different length than its buffer header says");
 }
 
 // ---- Zstandard ------------------------------------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 // ipc.cpp -- Arrow IPC file (Feather V2) scan -> device columns behind the C ABI ("Parquet/IPC scan -> device").
 //
-// An uncompressed IPC file already holds the hot path's layout: a primitive column of a record batch is a values buffer + a validity
+// An IPC file already holds the hot path's layout (LZ4_FRAME / ZSTD compressed bodies are inflated buffer by buffer on the host first,
+// host_codecs.hpp): a primitive column of a record batch is a values buffer + a validity
 // bitmap, exactly what a device column is.  So there is nothing to decode: the host parses the FlatBuffers metadata (ipc_format.hpp),
 // every selected buffer travels file -> page-locked staging -> HBM in one DMA, batches are concatenated in place (bitmaps that do not
 // start on a word boundary are merged by the bitmap blit kernel), dictionary indices are widened to u32 codes by the cast kernel, and
@@ -36,12 +37,11 @@ int idx_dtype(int bits, bool is_signed) {
 }
 
 // one bitmap of a batch (n bits at body + r) OR-ed into dst at bit dst_off; dst is zeroed
-void blit_bitmap(const File& f, PinnedStage& st, int64_t body, const ipc::BufferRef& r, int64_t n, uint64_t* dst, int64_t dst_off) {
+void blit_bitmap(const File& f, PinnedStage& st, const ipc::BatchMeta& bm, int64_t body, const ipc::BufferRef& r, int64_t n, uint64_t* dst, int64_t dst_off) {
   const size_t bytes = (size_t)((n + 7) / 8);
-  if ((int64_t)bytes > r.length) throw ipc::FormatError("bitmap buffer shorter than the array");
   Buf tmp = dev_alloc(bitmap_bytes(n));
   uint8_t* h = st.get(bytes);
-  f.pread_sliced(h, bytes, body + r.offset);
+  ipc::load_buffer(f, bm, body, r, h, bytes);       // stored, or LZ4-frame / zstd decompressed by this host thread (host_codecs.hpp)
   st.upload(tmp->ptr, h, bytes);
   k::bitmap_blit(dst, dst_off, tmp->as<uint64_t>(), n);
 }
@@ -76,18 +76,17 @@ ColumnPtr read_fixed_column(File& f, const std::vector<int>& bsel, int col, cons
     const ipc::BufferRef& vb = bm.buffers[s.buf + 1];
     if (n == 0) continue;
     if (file_dtype == PLX_BOOL) {
-      blit_bitmap(f, st, body, vb, n, c->values->as<uint64_t>(), row);
+      blit_bitmap(f, st, bm, body, vb, n, c->values->as<uint64_t>(), row);
     } else {
       const size_t bytes = (size_t)n * (size_t)ct.width;
-      if ((int64_t)bytes > vb.length) throw ipc::FormatError("values buffer shorter than the array");
       uint8_t* h = st.get(bytes);
-      f.pread_sliced(h, bytes, body + vb.offset);
+      ipc::load_buffer(f, bm, body, vb, h, bytes);
       st.upload((uint8_t*)c->values->ptr + (size_t)row * (size_t)ct.width, h, bytes);
     }
     if (any_nulls) {
       const int64_t nc = bm.nodes[s.node].null_count;
       nulls += nc;
-      if (nc > 0) blit_bitmap(f, st, body, bm.buffers[s.buf], n, c->validity->as<uint64_t>(), row);
+      if (nc > 0) blit_bitmap(f, st, bm, body, bm.buffers[s.buf], n, c->validity->as<uint64_t>(), row);
       else blit_ones(n, c->validity->as<uint64_t>(), row);
     }
     row += n;
@@ -153,7 +152,7 @@ ColumnPtr read_string_column(File& f, const std::vector<int>& bsel, int col, int
     std::vector<uint8_t> vbits;
     if (nc > 0) {
       any_nulls = true;
-      vbits = read_buffer(f, body, bm.buffers[s.buf]);
+      vbits = read_buffer(f, bm, body, bm.buffers[s.buf]);
       if ((int64_t)vbits.size() - 16 < (n + 7) / 8) throw ipc::FormatError("bitmap buffer shorter than the array");
     }
     if (nc == 0) set_bits(validity.data(), row, n);
@@ -164,9 +163,9 @@ ColumnPtr read_string_column(File& f, const std::vector<int>& bsel, int col, int
     if (is_view) {
       const int64_t nvar = s.variadic < bm.variadic_counts.size() ? bm.variadic_counts[s.variadic] : 0;
       if (s.buf + 2 + (size_t)nvar > bm.buffers.size()) throw ipc::FormatError("view array without its data buffers");
-      std::vector<uint8_t> v = read_buffer(f, body, bm.buffers[s.buf + 1]);
+      std::vector<uint8_t> v = read_buffer(f, bm, body, bm.buffers[s.buf + 1]);
       if ((int64_t)v.size() - 16 < n * 16) throw ipc::FormatError("views buffer shorter than the array");
-      for (int64_t k = 0; k < nvar; k++) data.push_back(read_buffer(f, body, bm.buffers[s.buf + 2 + (size_t)k]));
+      for (int64_t k = 0; k < nvar; k++) data.push_back(read_buffer(f, bm, body, bm.buffers[s.buf + 2 + (size_t)k]));
       parallel_rows(n, [&](int64_t i0, int64_t i1) {
       for (int64_t i = i0; i < i1; i++) {
         uint8_t* dst = views + 16 * (size_t)(row + i);
@@ -184,8 +183,8 @@ ColumnPtr read_string_column(File& f, const std::vector<int>& bsel, int col, int
       }
       });
     } else {
-      std::vector<uint8_t> offs = read_buffer(f, body, bm.buffers[s.buf + 1]);
-      data.push_back(read_buffer(f, body, bm.buffers[s.buf + 2]));
+      std::vector<uint8_t> offs = read_buffer(f, bm, body, bm.buffers[s.buf + 1]);
+      data.push_back(read_buffer(f, bm, body, bm.buffers[s.buf + 2]));
       const std::vector<uint8_t>& d = data.back();
       const size_t ow = large ? 8 : 4;
       if (n && (int64_t)offs.size() - 16 < (n + 1) * (int64_t)ow) throw ipc::FormatError("offsets buffer shorter than the array");
@@ -306,7 +305,7 @@ int plx_ipc_read(plx_ipc file, const int32_t* batches, int32_t n_batches, const 
   int64_t total = 0;
   for (int b : bsel) {
     PLX_REQUIRE(b >= 0 && (size_t)b < f.batches.size(), PLX_ERR_INVALID, "ipc record batch index out of range");
-    if (f.batches[b].compressed) throw Unsupported(std::string("record batch body compressed with ") + (f.batches[b].codec == 0 ? "LZ4_FRAME" : "ZSTD"));
+    if (f.batches[b].compressed && f.batches[b].codec != 0 && f.batches[b].codec != 1) throw Unsupported("record batch body compressed with an unknown codec");
     total += f.batches[b].length;
   }
   auto frame = std::make_shared<Frame>();

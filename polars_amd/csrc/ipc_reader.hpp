@@ -9,6 +9,7 @@
 
 #include "../../include/polars_amd.h"
 #include "file_io.hpp"
+#include "host_codecs.hpp"
 #include "ipc_format.hpp"
 
 namespace plx {
@@ -140,9 +141,52 @@ inline Slot slot_of(const File& f, const BatchMeta& bm, int col) {
   return s;
 }
 
-inline std::vector<uint8_t> read_buffer(const File& f, int64_t body, const BufferRef& r) {
-  std::vector<uint8_t> v((size_t)r.length + 16, 0);
-  if (r.length) f.pread_sliced(v.data(), (size_t)r.length, body + r.offset);
+// Body compression (Message.fbs BodyCompression): every buffer of a compressed record batch starts with its uncompressed length as an
+// int64 (-1: the bytes that follow are stored as they are), then one LZ4 frame / Zstandard frame.
+inline int64_t compressed_buffer_length(const File& f, int64_t body, const BufferRef& r) {
+  if (r.length == 0) return 0;
+  if (r.length < 8) throw FormatError("compressed buffer shorter than its length prefix");
+  int64_t ulen;
+  f.pread_exact(&ulen, 8, body + r.offset);
+  if (ulen < -1 || ulen > ((int64_t)1 << 40)) throw FormatError("compressed buffer with an absurd uncompressed length");
+  return ulen == -1 ? r.length - 8 : ulen;
+}
+// the bytes of one buffer, decompressed when the batch is compressed, into dst[0, need) (need <= its uncompressed length)
+inline void load_buffer(const File& f, const BatchMeta& bm, int64_t body, const BufferRef& r, uint8_t* dst, size_t need) {
+  if (!need) return;
+  if (!bm.compressed) {
+    if ((int64_t)need > r.length) throw FormatError("buffer shorter than the array needs");
+    f.pread_sliced(dst, need, body + r.offset);
+    return;
+  }
+  if (r.length < 8) throw FormatError("compressed buffer shorter than its length prefix");
+  std::vector<uint8_t> raw((size_t)r.length);
+  f.pread_sliced(raw.data(), raw.size(), body + r.offset);
+  int64_t ulen;
+  memcpy(&ulen, raw.data(), 8);
+  if (ulen == -1) {
+    if ((int64_t)need > r.length - 8) throw FormatError("buffer shorter than the array needs");
+    memcpy(dst, raw.data() + 8, need);
+    return;
+  }
+  if (ulen < 0 || (int64_t)need > ulen) throw FormatError("buffer shorter than the array needs");
+  try {
+    if ((size_t)ulen == need) {
+      if (bm.codec == 0) codec::lz4_frame_decompress(raw.data() + 8, raw.size() - 8, dst, need);
+      else codec::zstd_decompress(raw.data() + 8, raw.size() - 8, dst, need);
+    } else {                                       // padded buffers: decompress all of it, hand out the front
+      std::vector<uint8_t> full((size_t)ulen);
+      if (bm.codec == 0) codec::lz4_frame_decompress(raw.data() + 8, raw.size() - 8, full.data(), full.size());
+      else codec::zstd_decompress(raw.data() + 8, raw.size() - 8, full.data(), full.size());
+      memcpy(dst, full.data(), need);
+    }
+  } catch (const codec::CodecError& e) { throw FormatError(std::string("compressed buffer: ") + e.what()); }
+}
+// a whole buffer (+ 16 readable pad bytes behind it)
+inline std::vector<uint8_t> read_buffer(const File& f, const BatchMeta& bm, int64_t body, const BufferRef& r) {
+  const int64_t n = bm.compressed ? compressed_buffer_length(f, body, r) : r.length;
+  std::vector<uint8_t> v((size_t)n + 16, 0);
+  load_buffer(f, bm, body, r, v.data(), (size_t)n);
   return v;
 }
 
@@ -153,10 +197,10 @@ inline void decode_strings(const File& f, const Field& fl, const BatchMeta& bm, 
   if (fl.type == TY_UTF8_VIEW || fl.type == TY_BINARY_VIEW) {
     const int64_t nvar = var0 < bm.variadic_counts.size() ? bm.variadic_counts[var0] : 0;
     if (buf0 + 2 + (size_t)nvar > bm.buffers.size()) throw FormatError("view array without its data buffers");
-    std::vector<uint8_t> views = read_buffer(f, body, bm.buffers[buf0 + 1]);
+    std::vector<uint8_t> views = read_buffer(f, bm, body, bm.buffers[buf0 + 1]);
     if ((int64_t)views.size() - 16 < n * 16) throw FormatError("views buffer shorter than the array");
     std::vector<std::vector<uint8_t>> data;
-    for (int64_t k = 0; k < nvar; k++) data.push_back(read_buffer(f, body, bm.buffers[buf0 + 2 + (size_t)k]));
+    for (int64_t k = 0; k < nvar; k++) data.push_back(read_buffer(f, bm, body, bm.buffers[buf0 + 2 + (size_t)k]));
     for (int64_t i = 0; i < n; i++) {
       const uint8_t* v = views.data() + 16 * i;
       uint32_t len, bi, off;
@@ -170,7 +214,7 @@ inline void decode_strings(const File& f, const Field& fl, const BatchMeta& bm, 
   }
   if (buf0 + 3 > bm.buffers.size()) throw FormatError("string array without its buffers");
   const bool large = fl.type == TY_LARGE_UTF8 || fl.type == TY_LARGE_BINARY;
-  std::vector<uint8_t> offs = read_buffer(f, body, bm.buffers[buf0 + 1]), data = read_buffer(f, body, bm.buffers[buf0 + 2]);
+  std::vector<uint8_t> offs = read_buffer(f, bm, body, bm.buffers[buf0 + 1]), data = read_buffer(f, bm, body, bm.buffers[buf0 + 2]);
   const size_t ow = large ? 8 : 4;
   if (n && (int64_t)offs.size() - 16 < (n + 1) * (int64_t)ow) throw FormatError("offsets buffer shorter than the array");
   auto off_at = [&](int64_t i) -> int64_t {
@@ -190,7 +234,7 @@ inline void load_dictionaries(File& f) {
     int64_t body = 0;
     BatchMeta bm = read_block_meta(f, b, &body);
     if (!bm.is_dictionary) throw FormatError("record batch listed as a dictionary");
-    if (bm.compressed) throw Unsupported("compressed dictionary batch");
+    if (bm.compressed && bm.codec != 0 && bm.codec != 1) throw Unsupported("dictionary batch compressed with an unknown codec");
     const Field* fl = nullptr;
     for (const Field& x : f.footer.fields) if (x.has_dictionary && x.dict_id == bm.dict_id) { fl = &x; break; }
     if (!fl || col_type(*fl).dtype < 0) continue;       // dictionary of a column outside the hot path

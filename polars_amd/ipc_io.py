@@ -121,7 +121,7 @@ class IpcFrame(ParquetFrame):
 
 
 def scan_ipc(path: str, columns: Optional[Sequence[str]] = None):
-    """LazyFrame over an Arrow IPC (Feather V2) file (mirrors polars.scan_ipc for the path's dtypes); uncompressed bodies only."""
+    """LazyFrame over an Arrow IPC (Feather V2) file (mirrors polars.scan_ipc for the path's dtypes); uncompressed, LZ4-frame and Zstandard bodies."""
     from .frame import LazyFrame
     return LazyFrame(P.Node("scan", frame=IpcFrame(path, columns)))
 

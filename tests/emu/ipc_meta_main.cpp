@@ -21,13 +21,13 @@ int main(int argc, char** argv) {
         for (size_t b = 0; b < f->batches.size(); b++) {
           const BatchMeta& bm = f->batches[b];
           Slot s = slot_of(*f, bm, (int)c);
-          if (ct.dtype < 0 || bm.compressed) continue;
+          if (ct.dtype < 0) continue;
           if (ct.strings && !fl.has_dictionary) {
             std::vector<std::string> out;
             decode_strings(*f, fl, bm, f->body_off[b], s.buf, s.node, s.variadic, &out);
             strings += (long)out.size();
           } else if (s.buf + 2 <= bm.buffers.size()) {
-            read_buffer(*f, f->body_off[b], bm.buffers[s.buf + 1]);
+            read_buffer(*f, bm, f->body_off[b], bm.buffers[s.buf + 1]);
           }
         }
       }

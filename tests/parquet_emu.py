@@ -94,5 +94,5 @@ def snappy_host(data: bytes, n_out: int):
 def host_codec(codec: str, data: bytes, n_out: int):
     """The product's host page decompressors ("zstd" / "lz4_raw") -> (rc, bytes, error text)."""
     out = np.zeros(max(n_out, 1), np.uint8)
-    rc = lib().pqemu_host_codec({"zstd": 0, "lz4_raw": 1}[codec], data, len(data), out.ctypes.data_as(C.c_void_p), n_out)
+    rc = lib().pqemu_host_codec({"zstd": 0, "lz4_raw": 1, "lz4_frame": 2}[codec], data, len(data), out.ctypes.data_as(C.c_void_p), n_out)
     return rc, out[:n_out].tobytes(), lib().pqemu_last_error().decode() if rc else ""

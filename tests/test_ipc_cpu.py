@@ -130,9 +130,9 @@ def test_host_reader_under_address_sanitizer(tmp_path):
                     os.path.join(here, "emu", "ipc_meta_main.cpp"), "-lpthread"], check=True)
     t = sample(800)
     files = []
-    for i, chunk in enumerate((None, 150)):
+    for i, (chunk, codec) in enumerate(((None, None), (150, None), (300, "lz4"), (300, "zstd"))):
         p = str(tmp_path / f"good{i}.arrow")
-        write(p, t, chunk=chunk)
+        write(p, t, chunk=chunk, **({"compression": codec} if codec else {}))
         files.append(p)
         raw = open(p, "rb").read()
         flen = struct.unpack("<i", raw[-10:-6])[0]
@@ -147,4 +147,53 @@ def test_host_reader_under_address_sanitizer(tmp_path):
     r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600, env={**os.environ, "ASAN_OPTIONS": "detect_leaks=0"})
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     counts = dict(kv.split("=") for kv in r.stdout.split())
-    assert int(counts["ok"]) >= 2 and int(counts["invalid"]) > 20 and int(counts["strings"]) > 0, r.stdout
+    assert int(counts["ok"]) >= 4 and int(counts["invalid"]) > 20 and int(counts["strings"]) > 0, r.stdout
+
+
+def _ipc_emu():
+    here = os.path.dirname(os.path.abspath(__file__))
+    so, src = os.path.join(here, "emu", "libipc_emu.so"), os.path.join(here, "emu", "ipc_emu.cpp")
+    csrc = os.path.join(os.path.dirname(here), "polars_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, h) for h in ("ipc_reader.hpp", "ipc_format.hpp", "host_codecs.hpp", "file_io.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", so, src, "-lpthread"], check=True)
+    l = C.CDLL(so)
+    l.ipcemu_buffer.restype = C.c_int64
+    l.ipcemu_buffer.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+    l.ipcemu_last_error.restype = C.c_char_p
+    return l
+
+
+@pytest.mark.parametrize("codec", [None, "lz4", "zstd"])
+def test_buffers_as_uploaded_match_pyarrow(tmp_path, codec):
+    """Every buffer of every hot-path column in every record batch, as the product's host half hands it to the upload (body compression
+    undone by host_codecs.hpp: LZ4 frames are what pyarrow's feather writer produces by default), equals pyarrow's buffer."""
+    n = 3000
+    t = sample(n).select(["i8", "u16", "i32", "i64", "f32", "f64", "b", "date", "ts", "s", "ls", "sv", "d8", "d32", "tail"])
+    path = str(tmp_path / "t.arrow")
+    write(path, t, chunk=1100, **({"compression": codec} if codec else {}))
+    l = _ipc_emu()
+    rd = ipc.open_file(path)
+    checked = 0
+    for b in range(rd.num_record_batches):
+        batch = rd.get_batch(b)
+        for ci, name in enumerate(t.column_names):
+            arr = batch.column(ci)
+            arr = arr.indices if pa.types.is_dictionary(arr.type) else arr
+            for which, buf in enumerate(arr.buffers()):
+                if buf is None or which > 2 or (pa.types.is_string_view(arr.type) and which >= 2 and buf.size == 0):
+                    continue
+                out = np.zeros(buf.size + 64, np.uint8)
+                got = l.ipcemu_buffer(path.encode(), b, ci, which, out.ctypes.data_as(C.c_void_p), out.nbytes)
+                assert got >= 0, l.ipcemu_last_error().decode()
+                want = np.frombuffer(buf, np.uint8)
+                if which == 0:          # validity: the file may pad differently; compare the bits that matter
+                    nb = (len(arr) + 7) // 8
+                    w = np.unpackbits(want[:nb], bitorder="little")[arr.offset:arr.offset + len(arr)]
+                    g = np.unpackbits(out[:nb], bitorder="little")[:len(arr)]
+                    assert np.array_equal(w, g), (name, b)
+                else:
+                    k = min(got, len(want))
+                    assert k > 0 and np.array_equal(out[:k], want[:k]), (name, b, which)
+                checked += 1
+    assert checked > 60
