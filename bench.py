@@ -582,6 +582,70 @@ def timed(pl, wl: Workload, steps: int, warmup: int, distributed: bool, combine=
     return dt, stats, res, cold_ms
 
 
+def scan_extra(pl, n: int):
+    """File -> device columns (no query): a lineitem-like table of n rows written by pyarrow as Parquet (uncompressed / Snappy /
+    Zstandard) and as an Arrow IPC file, read with the library's own scan (metadata parsed by the library, Snappy and all page decoding
+    on the device, zstd inflated by the library's host threads); every read is checked against the source columns; pyarrow's own
+    multi-threaded read of the same file is the CPU yardstick.  Files live in a temporary directory (page cache)."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.ipc as ipc
+    import pyarrow.parquet as pq
+    F = pl._ffi
+    rng = np.random.default_rng(3)
+    key = np.sort(rng.integers(1, 4 * n, n))
+    qty = rng.integers(1, 51, n)
+    price = rng.random(n) * 1e5
+    flag = rng.integers(0, 3, n)
+    ship = rng.integers(694224000, 912470400, n) * 1_000_000
+    nmask = rng.random(n) < 0.1
+    nval = rng.integers(0, 1 << 30, n)
+    t = pa.table({"l_orderkey": pa.array(key), "l_quantity": pa.array(qty), "l_extendedprice": pa.array(price),
+                  "l_returnflag": pa.array(np.array(["R", "A", "N"])[flag]), "l_shipdate": pa.array(ship, pa.timestamp("us")), "l_nullable": pa.array(nval, mask=nmask)})
+    decoded = sum(c.nbytes for c in t.columns)
+    want = {"l_orderkey": int(key.sum()), "l_quantity": int(qty.sum()), "l_nullable": int(nval[~nmask].sum())}      # none of these sums leaves int64
+    out = {"rows": n, "decoded_bytes": decoded, "columns": t.column_names, "pyarrow_threads": pa.cpu_count(), "files": {}}
+    d = tempfile.mkdtemp(prefix="plx_scan_")
+    try:
+        def check(df):
+            try:
+                ok = df.height == n and all(int(df[c].sum()) == v for c, v in want.items()) and df["l_nullable"].null_count() == int(nmask.sum())
+                ok = ok and int(df["l_shipdate"].min()) == int(ship.min()) and int(df["l_shipdate"].max()) == int(ship.max())
+                ok = ok and abs(float(df["l_extendedprice"].sum()) - float(price.sum())) <= 1e-9 * abs(float(price.sum()))
+                counts = df.lazy().group_by("l_returnflag").agg(pl.len().alias("n")).collect().sort_host("l_returnflag")
+                return bool(ok and dict(zip(counts["l_returnflag"], counts["n"])) == {k: int((flag == i).sum()) for i, k in enumerate(["R", "A", "N"])})
+            except Exception as e:      # the timing stands on its own; say why the check could not be made
+                return f"check failed to run: {type(e).__name__}: {e}"[:200]
+
+        def measure(read, path, py_read):
+            read(path)                                          # warm: page cache, pool, staging buffers
+            ts = []
+            F.check(F.lib().plx_profile_clear()); F.check(F.lib().plx_profile_enable(1))
+            for _ in range(3):
+                t0 = time.perf_counter(); df = read(path); F.check(F.lib().plx_synchronize()); ts.append(time.perf_counter() - t0)
+            ks = {k: round(v[1] / 3) for k, v in kernel_stats(pl).items()}
+            F.check(F.lib().plx_profile_enable(0))
+            t0 = time.perf_counter(); py_read(path); t_pa = time.perf_counter() - t0
+            fb, best = os.path.getsize(path), min(ts)
+            return {"file_bytes": fb, "read_ms": round(best * 1e3, 2), "file_GBps": round(fb / best / 1e9, 2), "decoded_GBps": round(decoded / best / 1e9, 2),
+                    "rows_per_s": round(n / best), "kernel_us": ks, "pyarrow_read_ms": round(t_pa * 1e3, 2), "verified": check(df)}
+        for codec in ("none", "snappy", "zstd"):
+            path = os.path.join(d, f"li_{codec}.parquet")
+            pq.write_table(t, path, compression=codec, row_group_size=1 << 20)
+            out["files"][f"parquet_{codec}"] = measure(pl.read_parquet, path, pq.read_table)
+            os.remove(path)
+        path = os.path.join(d, "li.arrow")
+        with ipc.new_file(path, t.schema) as w:
+            for b in t.to_batches(max_chunksize=1 << 20):
+                w.write_batch(b)
+        out["files"]["arrow_ipc"] = measure(pl.read_ipc, path, lambda p: ipc.open_file(p).read_all())
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def pmc_traffic(workload_name: str, kernel: str, rows: int):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; separate
     passes, tools/pmc_round.sh).  bench.py cannot run rocprofv3 on itself, so this is the number measured on the same workload at
@@ -1137,6 +1201,13 @@ def run(args, emit):
                 extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
             pl._ffi.lib().plx_memory_trim()
             torch.cuda.empty_cache()
+            emit(line)
+        # last (nothing after it can be cut short by it): the scan in front of the path, SURVEY.md 8(f) row 3
+        if os.environ.get("PLX_BENCH_SCAN", "1") != "0":
+            try:
+                extras["parquet_ipc_scan_2e7_rows"] = scan_extra(pl, 20_000_000)
+            except Exception as e:
+                extras["parquet_ipc_scan_2e7_rows"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             emit(line)
     if rank == 0:
         emit(line)
