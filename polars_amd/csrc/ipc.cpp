@@ -224,6 +224,12 @@ ColumnPtr read_string_column(File& f, const std::vector<int>& bsel, int col, int
 
 std::mutex g_mu;
 std::vector<std::unique_ptr<File>> g_files;   // handle = index + 1
+std::vector<std::unique_ptr<std::mutex>> g_file_mu;   // one reader at a time per handle (reads fill the handle's dictionary caches)
+std::mutex& file_mutex(uint64_t h) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (h == 0 || h > g_file_mu.size() || !g_file_mu[h - 1]) fail(PLX_ERR_INVALID, "invalid ipc handle");
+  return *g_file_mu[h - 1];
+}
 File& get_file(uint64_t h) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (h == 0 || h > g_files.size() || !g_files[h - 1]) fail(PLX_ERR_INVALID, "invalid ipc handle");
@@ -253,6 +259,7 @@ int plx_ipc_open(const char* path, plx_ipc* out) {
   std::unique_ptr<File> f = open_file(path);
   std::lock_guard<std::mutex> lk(g_mu);
   g_files.push_back(std::move(f));
+  g_file_mu.push_back(std::make_unique<std::mutex>());
   *out = (plx_ipc)g_files.size();
   IPC_CATCH
 }
@@ -300,6 +307,7 @@ int plx_ipc_read(plx_ipc file, const int32_t* batches, int32_t n_batches, const 
   IPC_TRY
   PLX_REQUIRE(out && (columns || n_columns == 0) && (batches || n_batches == 0), PLX_ERR_INVALID, "null argument");
   File& f = get_file(file);
+  std::lock_guard<std::mutex> reading(file_mutex(file));
   device();   // fails loudly without a GPU
   std::vector<int> bsel(batches, batches + n_batches);
   int64_t total = 0;
@@ -349,6 +357,7 @@ int plx_ipc_read(plx_ipc file, const int32_t* batches, int32_t n_batches, const 
 int plx_ipc_categories(plx_ipc file, int32_t column, int64_t* n_strings, int64_t* total_bytes) {
   IPC_TRY
   File& f = get_file(file);
+  std::lock_guard<std::mutex> reading(file_mutex(file));
   PLX_REQUIRE(column >= 0 && (size_t)column < f.footer.fields.size(), PLX_ERR_INVALID, "ipc column index out of range");
   const ipc::Field& fl = f.footer.fields[column];
   PLX_REQUIRE(fl.has_dictionary && col_type(fl).dtype >= 0, PLX_ERR_NOT_FOUND, "not a dictionary-encoded string column (strings encoded on the device: plx_ipc_column_strdict)");
@@ -364,6 +373,7 @@ int plx_ipc_categories(plx_ipc file, int32_t column, int64_t* n_strings, int64_t
 int plx_ipc_categories_to_host(plx_ipc file, int32_t column, int64_t* offsets, uint8_t* bytes) {
   IPC_TRY
   File& f = get_file(file);
+  std::lock_guard<std::mutex> reading(file_mutex(file));
   PLX_REQUIRE(column >= 0 && (size_t)column < f.footer.fields.size(), PLX_ERR_INVALID, "ipc column index out of range");
   const ipc::Field& fl = f.footer.fields[column];
   PLX_REQUIRE(fl.has_dictionary && col_type(fl).dtype >= 0 && offsets, PLX_ERR_NOT_FOUND, "not a dictionary-encoded string column");
@@ -381,6 +391,7 @@ int plx_ipc_categories_to_host(plx_ipc file, int32_t column, int64_t* offsets, u
 int plx_ipc_column_strdict(plx_ipc file, int32_t column, plx_strdict* out) {
   IPC_TRY
   File& f = get_file(file);
+  std::lock_guard<std::mutex> reading(file_mutex(file));
   PLX_REQUIRE(out, PLX_ERR_INVALID, "null out pointer");
   auto it = f.strdicts.find(column);
   PLX_REQUIRE(it != f.strdicts.end() && it->second, PLX_ERR_NOT_FOUND, "no device dictionary: the column has not been read (or is dictionary-encoded in the file: plx_ipc_categories)");

@@ -58,6 +58,12 @@ struct HipBackend {
 
 std::mutex g_mu;
 std::vector<std::unique_ptr<pq::File>> g_files;   // handle = index + 1
+std::vector<std::unique_ptr<std::mutex>> g_file_mu;   // one reader at a time per handle (a read rewrites the handle's string dictionaries)
+std::mutex& file_mutex(uint64_t h) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (h == 0 || h > g_file_mu.size() || !g_file_mu[h - 1]) fail(PLX_ERR_INVALID, "invalid parquet handle");
+  return *g_file_mu[h - 1];
+}
 
 pq::File& get_file(uint64_t h) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -90,6 +96,7 @@ int plx_parquet_open(const char* path, plx_parquet* out) {
   std::unique_ptr<pq::File> f = pq::open_file(path);
   std::lock_guard<std::mutex> lk(g_mu);
   g_files.push_back(std::move(f));
+  g_file_mu.push_back(std::make_unique<std::mutex>());
   *out = (plx_parquet)g_files.size();
   PQ_CATCH
 }
@@ -162,6 +169,7 @@ int plx_parquet_read(plx_parquet file, const int32_t* row_groups, int32_t n_row_
   PQ_TRY
   PLX_REQUIRE(out && (columns || n_columns == 0) && (row_groups || n_row_groups == 0), PLX_ERR_INVALID, "null argument");
   pq::File& f = get_file(file);
+  std::lock_guard<std::mutex> reading(file_mutex(file));
   device();   // fails loudly without a GPU: there is no host decode path in the library
   std::vector<int> rgs(row_groups, row_groups + n_row_groups);
   auto frame = std::make_shared<Frame>();
@@ -195,6 +203,7 @@ int plx_parquet_read(plx_parquet file, const int32_t* row_groups, int32_t n_row_
 int plx_parquet_categories(plx_parquet file, int32_t column, int64_t* n_strings, int64_t* total_bytes) {
   PQ_TRY
   pq::File& f = get_file(file);
+  std::lock_guard<std::mutex> reading(file_mutex(file));
   auto it = f.categories.find(column);
   PLX_REQUIRE(it != f.categories.end(), PLX_ERR_NOT_FOUND, "no string dictionary: the column has not been read (or is not a string column)");
   int64_t b = 0;
@@ -207,6 +216,7 @@ int plx_parquet_categories(plx_parquet file, int32_t column, int64_t* n_strings,
 int plx_parquet_categories_to_host(plx_parquet file, int32_t column, int64_t* offsets, uint8_t* bytes) {
   PQ_TRY
   pq::File& f = get_file(file);
+  std::lock_guard<std::mutex> reading(file_mutex(file));
   auto it = f.categories.find(column);
   PLX_REQUIRE(it != f.categories.end(), PLX_ERR_NOT_FOUND, "no string dictionary: the column has not been read (or is not a string column)");
   PLX_REQUIRE(offsets, PLX_ERR_INVALID, "null offsets pointer");
