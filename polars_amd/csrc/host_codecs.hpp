@@ -1,5 +1,5 @@
-// host_codecs.hpp -- page / buffer decompressors that run on HOST threads: Zstandard (RFC 8878), LZ4 raw blocks and LZ4 frames, written
-// from the format specifications, bounds-checked, no third-party code.  No HIP.
+// host_codecs.hpp -- page / buffer decompressors that run on HOST threads: Zstandard (RFC 8878), LZ4 raw blocks and LZ4 frames, DEFLATE in
+// gzip / zlib wrappers (RFC 1950-1952), written from the format specifications, bounds-checked, no third-party code.  No HIP.
 //
 // Why they exist: Snappy pages are decompressed on the device (parquet_snappy.hpp).  Zstandard is what Polars itself writes by default
 // (crates/polars-parquet/src/parquet/compression.rs:144-230 dispatches to the zstd crate), and its entropy stages (FSE-coded sequences
@@ -117,6 +117,179 @@ inline void lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size
     if (content_checksum) { if (n - ip < 4) throw CodecError("lz4: truncated content checksum"); ip += 4; }
   }
   if (op != out_len) throw CodecError("lz4: frame decodes to a different length than its buffer header says");
+}
+
+// ---- DEFLATE / gzip (Parquet codec GZIP) ---------------------------------------------------------------------------------------------------
+// RFC 1951 blocks (stored, fixed Huffman, dynamic Huffman) inside RFC 1952 members (header with optional extra / name / comment / header
+// CRC, trailer CRC32 + ISIZE; the CRC is not verified) or a zlib wrapper (RFC 1950).  Canonical Huffman codes are decoded length by length
+// from the per-length symbol counts -- slow next to table-driven decoders, plenty for pages that then cross PCIe.
+namespace inflate_detail {
+
+struct Bits {
+  const uint8_t* p; size_t n; size_t pos = 0; uint32_t hold = 0; int cnt = 0;
+  uint32_t get(int need) {
+    while (cnt < need) {
+      if (pos >= n) throw CodecError("deflate: stream ends inside a block");
+      hold |= (uint32_t)p[pos++] << cnt;
+      cnt += 8;
+    }
+    const uint32_t v = need ? hold & ((1u << need) - 1) : 0;
+    hold >>= need; cnt -= need;
+    return v;
+  }
+  void align() { hold = 0; cnt = 0; }      // the bytes already pulled in are whole bytes: drop the rest of the current one
+};
+
+struct Huff { uint16_t count[16]; uint16_t symbol[288]; };
+
+inline void build(Huff& h, const uint8_t* lens, int n) {
+  memset(h.count, 0, sizeof h.count);
+  for (int i = 0; i < n; i++) h.count[lens[i]]++;
+  // over-subscribed sets are malformed; incomplete ones are allowed only in the degenerate single-code case (checked by the caller's decode)
+  int left = 1;
+  for (int len = 1; len <= 15; len++) { left = (left << 1) - h.count[len]; if (left < 0) throw CodecError("deflate: over-subscribed Huffman code"); }
+  uint16_t offs[16];
+  offs[1] = 0;
+  for (int len = 1; len < 15; len++) offs[len + 1] = (uint16_t)(offs[len] + h.count[len]);
+  for (int i = 0; i < n; i++) if (lens[i]) h.symbol[offs[lens[i]]++] = (uint16_t)i;
+}
+
+inline int decode(Bits& b, const Huff& h) {
+  int code = 0, first = 0, index = 0;
+  for (int len = 1; len <= 15; len++) {
+    code |= (int)b.get(1);
+    const int count = h.count[len];
+    if (code - count < first) return h.symbol[index + (code - first)];
+    index += count; first += count;
+    first <<= 1; code <<= 1;
+  }
+  throw CodecError("deflate: invalid Huffman code");
+}
+
+const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t kLenBits[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t kDistBits[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+inline void codes(Bits& b, const Huff& lit, const Huff& dist, uint8_t* out, size_t* op_io, size_t cap) {
+  size_t op = *op_io;
+  for (;;) {
+    const int sym = decode(b, lit);
+    if (sym < 256) {
+      if (op >= cap) throw CodecError("deflate: output larger than the page header says");
+      out[op++] = (uint8_t)sym;
+    } else if (sym == 256) {
+      break;
+    } else {
+      if (sym > 285) throw CodecError("deflate: invalid length code");
+      const size_t len = kLenBase[sym - 257] + b.get(kLenBits[sym - 257]);
+      const int ds = decode(b, dist);
+      if (ds > 29) throw CodecError("deflate: invalid distance code");
+      const size_t d = kDistBase[ds] + b.get(kDistBits[ds]);
+      if (d > op || len > cap - op) throw CodecError("deflate: match outside the output");
+      for (size_t i = 0; i < len; i++) out[op + i] = out[op - d + i];
+      op += len;
+    }
+  }
+  *op_io = op;
+}
+
+// one DEFLATE stream starting at in[*ip_io]; appends to out
+inline void inflate(const uint8_t* in, size_t n, size_t* ip_io, uint8_t* out, size_t* op_io, size_t cap) {
+  Bits b{in + *ip_io, n - *ip_io};
+  size_t op = *op_io;
+  const size_t start = op;          // matches may not reach before this member's own output
+  for (;;) {
+    const uint32_t last = b.get(1), type = b.get(2);
+    if (type == 0) {
+      b.align();
+      if (b.n - b.pos < 4) throw CodecError("deflate: truncated stored block");
+      const uint32_t len = b.p[b.pos] | ((uint32_t)b.p[b.pos + 1] << 8), nlen = b.p[b.pos + 2] | ((uint32_t)b.p[b.pos + 3] << 8);
+      b.pos += 4;
+      if ((len ^ 0xffff) != nlen) throw CodecError("deflate: stored block length check failed");
+      if (len > b.n - b.pos || len > cap - op) throw CodecError("deflate: stored block past the end");
+      memcpy(out + op, b.p + b.pos, len);
+      b.pos += len; op += len;
+    } else if (type == 1) {
+      uint8_t lens[288];
+      for (int i = 0; i < 144; i++) lens[i] = 8;
+      for (int i = 144; i < 256; i++) lens[i] = 9;
+      for (int i = 256; i < 280; i++) lens[i] = 7;
+      for (int i = 280; i < 288; i++) lens[i] = 8;
+      Huff lit, dist;
+      build(lit, lens, 288);
+      uint8_t dl[30];
+      memset(dl, 5, 30);
+      build(dist, dl, 30);
+      size_t rel = op - start;
+      codes(b, lit, dist, out + start, &rel, cap - start);
+      op = start + rel;
+    } else if (type == 2) {
+      const int nlen = (int)b.get(5) + 257, ndist = (int)b.get(5) + 1, ncode = (int)b.get(4) + 4;
+      if (nlen > 286 || ndist > 30) throw CodecError("deflate: too many codes in a dynamic block");
+      static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+      uint8_t lens[320];
+      memset(lens, 0, sizeof lens);
+      for (int i = 0; i < ncode; i++) lens[order[i]] = (uint8_t)b.get(3);
+      Huff lencode;
+      build(lencode, lens, 19);
+      uint8_t ll[320];
+      int idx = 0;
+      while (idx < nlen + ndist) {
+        const int sym = decode(b, lencode);
+        if (sym < 16) ll[idx++] = (uint8_t)sym;
+        else {
+          int rep; uint8_t val = 0;
+          if (sym == 16) { if (idx == 0) throw CodecError("deflate: repeat without a previous length"); val = ll[idx - 1]; rep = 3 + (int)b.get(2); }
+          else if (sym == 17) rep = 3 + (int)b.get(3);
+          else rep = 11 + (int)b.get(7);
+          if (idx + rep > nlen + ndist) throw CodecError("deflate: code lengths overrun");
+          while (rep--) ll[idx++] = val;
+        }
+      }
+      if (ll[256] == 0) throw CodecError("deflate: no end-of-block code");
+      Huff lit, dist;
+      build(lit, ll, nlen);
+      build(dist, ll + nlen, ndist);
+      size_t rel = op - start;
+      codes(b, lit, dist, out + start, &rel, cap - start);
+      op = start + rel;
+    } else {
+      throw CodecError("deflate: reserved block type");
+    }
+    if (last) break;
+  }
+  *ip_io += b.pos - (size_t)(b.cnt / 8);      // whole bytes pulled in but not used belong to what follows
+  *op_io = op;
+}
+
+}  // namespace inflate_detail
+
+// every gzip member (or one zlib stream, or a bare DEFLATE stream when neither header is there) of [in, in + n) into out[0, out_len)
+inline void gzip_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t out_len) {
+  size_t ip = 0, op = 0;
+  if (n >= 2 && in[0] == 0x1f && in[1] == 0x8b) {
+    while (ip < n) {
+      if (n - ip < 10 || in[ip] != 0x1f || in[ip + 1] != 0x8b) throw CodecError("gzip: bad member header");
+      if (in[ip + 2] != 8) throw CodecError("gzip: compression method is not deflate");
+      const uint8_t flg = in[ip + 3];
+      ip += 10;
+      if (flg & 4) { if (n - ip < 2) throw CodecError("gzip: truncated extra field"); const size_t xl = in[ip] | ((size_t)in[ip + 1] << 8); ip += 2; if (xl > n - ip) throw CodecError("gzip: extra field past the end"); ip += xl; }
+      for (int f = 3; f <= 4; f++)                        // FNAME (bit 3), FCOMMENT (bit 4): zero-terminated
+        if (flg & (1 << f)) { while (ip < n && in[ip]) ip++; if (ip >= n) throw CodecError("gzip: unterminated header string"); ip++; }
+      if (flg & 2) { if (n - ip < 2) throw CodecError("gzip: truncated header crc"); ip += 2; }
+      inflate_detail::inflate(in, n, &ip, out, &op, out_len);
+      if (n - ip < 8) throw CodecError("gzip: truncated trailer");
+      ip += 8;                                            // CRC32, ISIZE: the page header is the authority on the size
+    }
+  } else if (n >= 2 && (in[0] & 0x0f) == 8 && ((in[0] << 8 | in[1]) % 31) == 0) {
+    if (in[1] & 0x20) throw CodecError("zlib: stream needs a preset dictionary");
+    ip = 2;
+    inflate_detail::inflate(in, n, &ip, out, &op, out_len);
+  } else {
+    inflate_detail::inflate(in, n, &ip, out, &op, out_len);
+  }
+  if (op != out_len) throw CodecError("gzip: stream decodes to a different length than the page header says");
 }
 
 // ---- Zstandard ------------------------------------------------------------------------------------------------------------------------

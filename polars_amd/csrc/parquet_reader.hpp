@@ -1,6 +1,6 @@
 // parquet_reader.hpp -- Parquet column chunks -> device columns, host orchestration.
 //
-// The host only touches METADATA (and, for the two codecs without a device kernel yet -- ZSTD, LZ4_RAW -- decompresses pages on a pool of
+// The host only touches METADATA (and, for the codecs without a device kernel yet -- ZSTD, GZIP, LZ4_RAW -- decompresses pages on a pool of
 // threads: host_codecs.hpp): the footer (parquet_format.hpp), the Thrift page headers inside each column chunk, and the
 // dictionary pages of string columns (a few KB each, unified into one column-wide dictionary).  The chunk bytes themselves go to HBM
 // exactly as they are in the file -- compressed, encoded -- in one copy per chunk, and everything else happens there
@@ -189,6 +189,13 @@ inline std::string error_bits_text(uint32_t e) {
 
 inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
+// pages of the codecs without a device kernel are inflated by host threads (host_codecs.hpp)
+inline void host_inflate(int codec_id, const uint8_t* src, size_t n, uint8_t* dst, size_t out) {
+  if (codec_id == CODEC_ZSTD) codec::zstd_decompress(src, n, dst, out);
+  else if (codec_id == CODEC_GZIP) codec::gzip_decompress(src, n, dst, out);
+  else codec::lz4_raw_decompress(src, n, dst, out);
+}
+
 template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector<int>& row_groups, int leaf_idx, ReadStats* stats) {
   const FileMetaData& md = f.md;
   if (leaf_idx < 0 || (size_t)leaf_idx >= md.leaves.size()) throw FormatError("column index out of range");
@@ -214,9 +221,9 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
     if (!c.has_meta) throw FormatError("column chunk without metadata");
     if (c.external_file) throw Unsupported("column chunk stored in another file");
     if (c.type != leaf.type) throw FormatError("column chunk type differs from the schema");
-    const bool host_codec = c.codec == CODEC_ZSTD || c.codec == CODEC_LZ4_RAW;       // decompressed by host threads (host_codecs.hpp)
+    const bool host_codec = c.codec == CODEC_ZSTD || c.codec == CODEC_LZ4_RAW || c.codec == CODEC_GZIP;       // decompressed by host threads (host_codecs.hpp)
     if (c.codec != CODEC_UNCOMPRESSED && c.codec != CODEC_SNAPPY && !host_codec)
-      throw Unsupported(std::string("column '") + leaf.name + "': codec " + codec_name(c.codec) + " has no decompressor here (UNCOMPRESSED, SNAPPY, ZSTD and LZ4_RAW do)");
+      throw Unsupported(std::string("column '") + leaf.name + "': codec " + codec_name(c.codec) + " has no decompressor here (UNCOMPRESSED, SNAPPY, ZSTD, GZIP and LZ4_RAW do)");
     if (c.num_values != rg.num_rows) throw FormatError("flat column chunk whose value count differs from the row group's rows");
     if (rg.num_rows == 0) continue;            // an empty row group has nothing to fetch (writers leave its data page offset at 0)
     if (c.start() < 4 || c.total_compressed_size < 0 || c.start() + c.total_compressed_size > f.size - 8) throw FormatError("column chunk outside the file");
@@ -257,7 +264,7 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
   for (const ChunkRef& ch : chunks) {
     const ColumnChunk& c = *ch.c;
     const size_t sz = (size_t)c.total_compressed_size;
-    const bool host_codec = c.codec == CODEC_ZSTD || c.codec == CODEC_LZ4_RAW;
+    const bool host_codec = c.codec == CODEC_ZSTD || c.codec == CODEC_LZ4_RAW || c.codec == CODEC_GZIP;
     const bool codec_on = c.codec == CODEC_SNAPPY;          // pages decompressed on the device
     // Device codec / none: the stored bytes are staged and uploaded as they are.  Host codec: the stored bytes stay in pageable memory;
     // what is staged and uploaded is the chunk's IMAGE -- the page payloads decompressed, back to back -- and the pages then look
@@ -316,8 +323,7 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
           else if (host_codec) {
             plain.resize((size_t)h.uncompressed_size);
             try {
-              if (c.codec == CODEC_ZSTD) codec::zstd_decompress(p, n, plain.data(), plain.size());
-              else codec::lz4_raw_decompress(p, n, plain.data(), plain.size());
+              host_inflate(c.codec, p, n, plain.data(), plain.size());
             } catch (const codec::CodecError& e) { throw FormatError(std::string("dictionary page: ") + e.what()); }
             p = plain.data(); n = plain.size();
           }
@@ -403,8 +409,7 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
           for (size_t i = t; i < inflate.size(); i += std::max<size_t>(threads, 1)) {
             const Inflate& j = inflate[i];
             if (j.copy) { if (j.n != j.out) throw FormatError("uncompressed part of a page whose two sizes differ"); if (j.n) memcpy(j.dst, j.src, j.n); }
-            else if (c.codec == CODEC_ZSTD) codec::zstd_decompress(j.src, j.n, j.dst, j.out);
-            else codec::lz4_raw_decompress(j.src, j.n, j.dst, j.out);
+            else host_inflate(c.codec, j.src, j.n, j.dst, j.out);
           }
         } catch (...) { errs[t] = std::current_exception(); }
       };

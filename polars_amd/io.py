@@ -6,9 +6,9 @@ row-group skipping by statistics: crates/polars-io/src/predicates.rs).  Here:
 
 * the DECODER is on the device (decoder="device", the default): the library parses the footer itself, the selected column chunks
   cross PCIe exactly as they are stored -- compressed and encoded -- and are decompressed / decoded in HBM
-  (`plx_parquet_*`, polars_amd/csrc/parquet*.{hpp,cpp} + kernels_parquet.hip; Snappy on the device, zstd / lz4-raw pages inflated by the
+  (`plx_parquet_*`, polars_amd/csrc/parquet*.{hpp,cpp} + kernels_parquet.hip; Snappy on the device, zstd / gzip / lz4-raw pages inflated by the
   library's own host threads first).  decoder="host" keeps the round-1 path (pyarrow decodes, Arrow buffers are uploaded) for files
-  outside the device decoder's codecs / encodings (gzip, brotli, PLAIN string pages, delta encodings),
+  outside the device decoder's codecs / encodings (brotli, PLAIN string pages, delta encodings),
 * projection pushdown -- only the columns the plan reads are fetched (TPC-H Q1 touches 7 of lineitem's 16),
 * predicate pushdown to row groups -- conjuncts `column <cmp> literal` of the filters directly above the scan skip the row
   groups whose min / max statistics cannot match (the filter itself still runs on the GPU, exactly).
@@ -47,7 +47,7 @@ def _mirror_dtype(t) -> T.DataType:
 
 class _HostDecoder:
     """decoder="host": pyarrow reads and decodes on the CPU, the decoded Arrow buffers are uploaded (the round-1 path; kept for files
-    the device decoder does not cover: gzip / brotli pages, PLAIN string pages, delta encodings)."""
+    the device decoder does not cover: brotli pages, PLAIN string pages, delta encodings)."""
     name = "host"
 
     def __init__(self, path: str):
@@ -326,7 +326,7 @@ def _comparable(value: Any, like: Any) -> Any:
 
 def scan_parquet(path: str, columns: Optional[Sequence[str]] = None, decoder: str = "device"):
     """LazyFrame over a Parquet file (mirrors polars.scan_parquet for the path's dtypes).  Nothing is read until collect().
-    decoder="device": column chunks are decoded on the GPU (UNCOMPRESSED / SNAPPY / ZSTD / LZ4_RAW, PLAIN / dictionary pages); "host": pyarrow."""
+    decoder="device": column chunks are decoded on the GPU (UNCOMPRESSED / SNAPPY / ZSTD / GZIP / LZ4_RAW, PLAIN / dictionary pages); "host": pyarrow."""
     from .frame import LazyFrame
     return LazyFrame(P.Node("scan", frame=ParquetFrame(path, columns, decoder)))
 

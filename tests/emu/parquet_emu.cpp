@@ -182,14 +182,15 @@ int pqemu_snappy(const uint8_t* in, uint32_t n_in, uint8_t* out, uint32_t n_out,
   return (int)err;
 }
 
-// the host decompressors of the product (polars_amd/csrc/host_codecs.hpp): codec 0 = zstd, 1 = lz4 raw block, 2 = lz4 frame
+// the host decompressors of the product (polars_amd/csrc/host_codecs.hpp): codec 0 = zstd, 1 = lz4 raw block, 2 = lz4 frame, 3 = gzip / zlib / raw deflate
 int pqemu_host_codec(int codec, const uint8_t* in, uint32_t n_in, uint8_t* out, uint32_t n_out) {
   try {
     std::vector<uint8_t> src(in, in + n_in);          // exact-size heap blocks: a sanitizer build sees any access past either end
     std::vector<uint8_t> dst(n_out);
     if (codec == 0) plx::codec::zstd_decompress(src.data(), src.size(), dst.data(), dst.size());
     else if (codec == 1) plx::codec::lz4_raw_decompress(src.data(), src.size(), dst.data(), dst.size());
-    else plx::codec::lz4_frame_decompress(src.data(), src.size(), dst.data(), dst.size());
+    else if (codec == 2) plx::codec::lz4_frame_decompress(src.data(), src.size(), dst.data(), dst.size());
+    else plx::codec::gzip_decompress(src.data(), src.size(), dst.data(), dst.size());
     if (n_out) memcpy(out, dst.data(), n_out);
     return 0;
   } catch (const std::exception& e) { t_err = e.what(); return 1; }

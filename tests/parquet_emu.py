@@ -16,11 +16,20 @@ NP = {0: None, 1: np.int8, 2: np.int16, 3: np.int32, 4: np.int64, 5: np.uint8, 6
 _lib = None
 
 
+def build_if_stale(so, src, deps):
+    """g++ -shared into a private temporary file, then an atomic rename: pytest-xdist workers may all find the library stale at once,
+    and none of them may ever dlopen a half-written file."""
+    if os.path.exists(so) and all(os.path.getmtime(d) <= os.path.getmtime(so) for d in deps):
+        return
+    tmp = f"{so}.{os.getpid()}.tmp"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", tmp, src, "-lpthread"], check=True)
+    os.replace(tmp, so)
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in _DEPS):
-            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", SO, SRC, "-lpthread"], check=True)
+        build_if_stale(SO, SRC, _DEPS)
         l = C.CDLL(SO)
         l.pqemu_last_error.restype = C.c_char_p
         l.pqemu_read_column.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -94,5 +103,5 @@ def snappy_host(data: bytes, n_out: int):
 def host_codec(codec: str, data: bytes, n_out: int):
     """The product's host page decompressors ("zstd" / "lz4_raw") -> (rc, bytes, error text)."""
     out = np.zeros(max(n_out, 1), np.uint8)
-    rc = lib().pqemu_host_codec({"zstd": 0, "lz4_raw": 1, "lz4_frame": 2}[codec], data, len(data), out.ctypes.data_as(C.c_void_p), n_out)
+    rc = lib().pqemu_host_codec({"zstd": 0, "lz4_raw": 1, "lz4_frame": 2, "gzip": 3}[codec], data, len(data), out.ctypes.data_as(C.c_void_p), n_out)
     return rc, out[:n_out].tobytes(), lib().pqemu_last_error().decode() if rc else ""

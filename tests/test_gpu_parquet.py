@@ -110,10 +110,10 @@ def test_unsupported_and_corrupt_files_are_status_codes(pl, tmp_path):
     n = 5000
     t = pa.table({"a": pa.array(RNG.integers(0, 9, n), mask=RNG.random(n) < 0.3), "z": pa.array(np.arange(n))})
     path = str(tmp_path / "t.parquet")
-    pq.write_table(t, path, compression={"a": "snappy", "z": "gzip"})
+    pq.write_table(t, path, compression={"a": "snappy", "z": "brotli"})
     with pytest.raises(pl.UnsupportedError) as ei:
         pl.read_parquet(path, columns=["z"])
-    assert "GZIP" in str(ei.value)
+    assert "BROTLI" in str(ei.value)
     compare(pl.read_parquet(path, columns=["a"]), t, ["a"])
     # flip bits inside the page bytes: an error (or a well-formed different value), never a hang or a crash; the library stays usable
     raw = bytearray(open(path, "rb").read())

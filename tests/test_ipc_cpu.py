@@ -155,8 +155,8 @@ def _ipc_emu():
     so, src = os.path.join(here, "emu", "libipc_emu.so"), os.path.join(here, "emu", "ipc_emu.cpp")
     csrc = os.path.join(os.path.dirname(here), "polars_amd", "csrc")
     deps = [src] + [os.path.join(csrc, h) for h in ("ipc_reader.hpp", "ipc_format.hpp", "host_codecs.hpp", "file_io.hpp")]
-    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", so, src, "-lpthread"], check=True)
+    import parquet_emu
+    parquet_emu.build_if_stale(so, src, deps)
     l = C.CDLL(so)
     l.ipcemu_buffer.restype = C.c_int64
     l.ipcemu_buffer.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]

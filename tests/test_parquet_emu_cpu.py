@@ -89,7 +89,7 @@ def mixed_table(n, null_frac=0.2):
     })
 
 
-@pytest.mark.parametrize("compression", ["none", "snappy", "zstd", "lz4"])       # snappy: device kernel; zstd / lz4 (raw): host threads, then the uncompressed device path
+@pytest.mark.parametrize("compression", ["none", "snappy", "zstd", "lz4", "gzip"])       # snappy: device kernel; zstd / lz4 (raw) / gzip: host threads, then the uncompressed device path
 @pytest.mark.parametrize("version,dictionary", [("1.0", True), ("2.0", True), ("1.0", False), ("2.0", False)])
 def test_every_dtype_against_pyarrow(tmp_path, compression, version, dictionary):
     n = 5000
@@ -181,9 +181,9 @@ def test_unsupported_files_say_what_they_are(tmp_path):
     t = pa.table({"a": pa.array(np.arange(n)), "dec": pa.array([None] * n, pa.decimal128(10, 2)), "lst": pa.array([[1, 2]] * n), "ms": pa.array(np.arange(n), pa.timestamp("ms")),
                   "z": pa.array(np.arange(n))})
     path = str(tmp_path / "t.parquet")
-    pq.write_table(t, path, compression={"a": "brotli", "dec": "none", "lst.list.element": "none", "ms": "none", "z": "gzip"}, use_dictionary=False,
+    pq.write_table(t, path, compression={"a": "brotli", "dec": "none", "lst.list.element": "none", "ms": "none", "z": "brotli"}, use_dictionary=False,
                    column_encoding={"z": "DELTA_BINARY_PACKED"})
-    for col, word in ((0, "BROTLI"), (1, "decimal"), (2, "nested"), (3, "timestamp unit"), (4, "GZIP")):
+    for col, word in ((0, "BROTLI"), (1, "decimal"), (2, "nested"), (3, "timestamp unit"), (4, "BROTLI")):
         with pytest.raises(E.EmuError) as ei:
             E.read_column(path, [0], col)
         assert ei.value.code == 3 and word in str(ei.value), str(ei.value)
@@ -215,6 +215,17 @@ def test_host_zstd_and_lz4_against_the_real_codecs(name):
     c = pa.Codec("lz4_raw").compress(p, asbytes=True)
     rc, out, err = E.host_codec("lz4_raw", c, len(p))
     assert rc == 0 and out == p, err
+    rc, out, err = E.host_codec("lz4_frame", pa.Codec("lz4").compress(p, asbytes=True), len(p))
+    assert rc == 0 and out == p, err
+    # DEFLATE: gzip members (one and two), zlib wrapper, bare stream, stored blocks, fixed and dynamic Huffman blocks
+    import gzip
+    import zlib
+    raw = zlib.compressobj(6, zlib.DEFLATED, -15)
+    fixed = zlib.compressobj(1, zlib.DEFLATED, -15, strategy=zlib.Z_FIXED)
+    for c in (pa.Codec("gzip", compression_level=1).compress(p, asbytes=True), pa.Codec("gzip", compression_level=9).compress(p, asbytes=True), zlib.compress(p, 6),
+              zlib.compress(p, 0), gzip.compress(p[:len(p) // 2]) + gzip.compress(p[len(p) // 2:]), raw.compress(p) + raw.flush(), fixed.compress(p) + fixed.flush()):
+        rc, out, err = E.host_codec("gzip", c, len(p))
+        assert rc == 0 and out == p, err
     # two frames back to back decode as their concatenation; a skippable frame in between is skipped
     if p:
         z = pa.Codec("zstd").compress(p, asbytes=True)
@@ -226,7 +237,8 @@ def test_host_zstd_and_lz4_against_the_real_codecs(name):
 def test_host_codecs_reject_corrupt_streams():
     rng = np.random.default_rng(77)
     p = PAYLOADS["mixed"]
-    for codec, good in (("zstd", pa.Codec("zstd", compression_level=9).compress(p, asbytes=True)), ("lz4_raw", pa.Codec("lz4_raw").compress(p, asbytes=True))):
+    for codec, good in (("zstd", pa.Codec("zstd", compression_level=9).compress(p, asbytes=True)), ("lz4_raw", pa.Codec("lz4_raw").compress(p, asbytes=True)),
+                        ("lz4_frame", pa.Codec("lz4").compress(p, asbytes=True)), ("gzip", pa.Codec("gzip").compress(p, asbytes=True))):
         outcomes = set()
         for trial in range(300):
             b = bytearray(good)
@@ -237,7 +249,7 @@ def test_host_codecs_reject_corrupt_streams():
             rc, out, err = E.host_codec(codec, bytes(b), len(p))
             outcomes.add("error" if rc else "ok")
             if rc:
-                assert err.startswith(codec.split("_")[0])
+                assert err.split(":")[0] in (codec.split("_")[0], "deflate", "zlib")
         assert "error" in outcomes
         rc, _, _ = E.host_codec(codec, good, len(p) + 1)          # the page header's size is the authority
         assert rc != 0
@@ -404,7 +416,7 @@ def test_reader_under_address_sanitizer(tmp_path):
                     os.path.join(here, "emu", "parquet_emu_main.cpp")], check=True)
     files = []
     t = mixed_table(3000)
-    for i, (comp, ver, dic) in enumerate((("snappy", "1.0", True), ("none", "2.0", True), ("snappy", "2.0", False), ("zstd", "2.0", True), ("lz4", "1.0", True))):
+    for i, (comp, ver, dic) in enumerate((("snappy", "1.0", True), ("none", "2.0", True), ("snappy", "2.0", False), ("zstd", "2.0", True), ("lz4", "1.0", True), ("gzip", "1.0", True))):
         p = str(tmp_path / f"good{i}.parquet")
         pq.write_table(t, p, compression=comp, data_page_version=ver, use_dictionary=dic, row_group_size=1100, data_page_size=700)
         files.append(p)
