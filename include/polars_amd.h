@@ -475,7 +475,8 @@ int plx_datagen_id_views(int64_t n_rows, uint64_t seed, uint32_t stream, int64_t
  *                               dtype (has_min_max = 0 when absent or not usable, e.g. strings); null_count -1 = unknown
  *   plx_parquet_read            row_groups x columns -> frame (rows in row-group order as given).  Codecs: UNCOMPRESSED, SNAPPY (device
  *                               kernel), ZSTD, GZIP and LZ4_RAW (pages inflated by host threads with the library's own decoders, then the same kernels);
- *                               encodings: PLAIN, PLAIN_DICTIONARY / RLE_DICTIONARY, RLE levels; data pages v1 and v2; anything else
+ *                               encodings: PLAIN (strings: see plx_parquet_column_strdict), PLAIN_DICTIONARY / RLE_DICTIONARY, RLE levels;
+ *                               data pages v1 and v2; anything else
  *                               is PLX_ERR_UNSUPPORTED naming what it met (the caller decodes that file on the host), a malformed
  *                               file is PLX_ERR_INVALID.  Needs plx_init: there is no host decode path in the library.
  *   plx_parquet_categories*     dictionary of a String / Binary column as of its last read: offsets[n + 1] + concatenated bytes,
@@ -491,6 +492,10 @@ int plx_parquet_chunk_info(plx_parquet file, int32_t row_group, int32_t column, 
 int plx_parquet_read(plx_parquet file, const int32_t* row_groups, int32_t n_row_groups, const int32_t* columns, int32_t n_columns, plx_frame* out);
 int plx_parquet_categories(plx_parquet file, int32_t column, int64_t* n_strings, int64_t* total_bytes);
 int plx_parquet_categories_to_host(plx_parquet file, int32_t column, int64_t* offsets, uint8_t* bytes);
+/* String columns holding PLAIN (not dictionary-encoded) pages: host threads assemble 16-byte views over the page payloads, the dictionary is
+ * built on the device (plx_strview_dict_encode); this hands its handle over (caller frees it with plx_strdict_free).  PLX_ERR_NOT_FOUND
+ * when the column's last read went through the chunk dictionaries (plx_parquet_categories*). */
+int plx_parquet_column_strdict(plx_parquet file, int32_t column, plx_strdict* out);
 
 /* ---- Arrow IPC file (Feather V2) scan -> device columns -------------------------
  * The reference reads IPC files with crates/polars-arrow/src/io/ipc/read/{file.rs,common.rs,read_basic.rs,schema.rs} (driven by

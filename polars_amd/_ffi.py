@@ -128,6 +128,7 @@ SIGNATURES = {
     "plx_parquet_read": (C.c_int, [C.c_uint64, _i32p, C.c_int32, _i32p, C.c_int32, _u64p]),
     "plx_parquet_categories": (C.c_int, [C.c_uint64, C.c_int32, _i64p, _i64p]),
     "plx_parquet_categories_to_host": (C.c_int, [C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "plx_parquet_column_strdict": (C.c_int, [C.c_uint64, C.c_int32, _u64p]),
     "plx_ipc_open": (C.c_int, [C.c_char_p, _u64p]),
     "plx_ipc_close": (C.c_int, [C.c_uint64]),
     "plx_ipc_shape": (C.c_int, [C.c_uint64, _i64p, _i32p, _i32p]),

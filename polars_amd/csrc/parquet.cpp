@@ -33,6 +33,24 @@ struct HipBackend {
     encoded_bytes += bytes;
     stage_.upload((void*)dst, src, bytes);
   }
+  void discard_pending() { (void)hipStreamSynchronize(stream()); }
+  // string columns with PLAIN pages: the views assembled by the reader's host threads go through the device dictionary encoder
+  void encode_string_views(pq::File& f, int leaf, const uint8_t* views, const uint8_t* validity, int64_t n, const std::vector<const void*>& ptrs,
+                           const std::vector<int64_t>& sizes, pq::ColumnResult<HipBackend>* res) {
+    plx_column codes = 0;
+    plx_strdict dict = 0;
+    const int rc = plx_strview_dict_encode(views, validity, 0, n, ptrs.empty() ? nullptr : ptrs.data(), sizes.empty() ? nullptr : sizes.data(), (int32_t)ptrs.size(), &codes, &dict);
+    if (rc != PLX_OK) fail(rc, plx_last_error());
+    ColumnPtr c = get_column(codes);
+    free_column(codes);
+    res->values = c->values;
+    res->validity = c->validity;
+    res->has_validity = (bool)c->validity;
+    auto it = f.strdicts.find(leaf);
+    if (it != f.strdicts.end() && it->second) plx_strdict_free(it->second);
+    f.strdicts[leaf] = dict;
+    f.categories.erase(leaf);
+  }
   // descriptor arrays from pageable memory: done when this returns
   void upload_small(uint64_t dst, const void* src, size_t bytes) {
     if (!bytes) return;
@@ -197,6 +215,18 @@ int plx_parquet_read(plx_parquet file, const int32_t* row_groups, int32_t n_row_
     frame->height = n;
   }
   *out = register_frame(frame);
+  PQ_CATCH
+}
+
+int plx_parquet_column_strdict(plx_parquet file, int32_t column, plx_strdict* out) {
+  PQ_TRY
+  pq::File& f = get_file(file);
+  std::lock_guard<std::mutex> reading(file_mutex(file));
+  PLX_REQUIRE(out, PLX_ERR_INVALID, "null out pointer");
+  auto it = f.strdicts.find(column);
+  PLX_REQUIRE(it != f.strdicts.end() && it->second, PLX_ERR_NOT_FOUND, "no device dictionary: the column's pages were dictionary-encoded (plx_parquet_categories) or it has not been read");
+  *out = it->second;
+  it->second = 0;       // ownership moves to the caller (plx_strdict_free)
   PQ_CATCH
 }
 

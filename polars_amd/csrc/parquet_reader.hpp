@@ -15,6 +15,7 @@
 // (decode per page into an Arrow array), crates/polars-io/src/parquet/read/read_impl.rs (row groups x projected columns).
 #pragma once
 #include <algorithm>
+#include <map>
 #include <memory>
 #include <exception>
 #include <string>
@@ -40,6 +41,8 @@ struct File : FileReader {
   FileMetaData md;
   // column-wide dictionaries of the string columns read last (leaf index -> categories)
   std::unordered_map<int, std::vector<std::string>> categories;
+  // ... or, for string columns with PLAIN pages (dictionary built on the device), the handle of that dictionary (plx_strdict; 0: none)
+  std::unordered_map<int, uint64_t> strdicts;
 };
 
 inline std::unique_ptr<File> open_file(const std::string& path) {
@@ -196,7 +199,11 @@ inline void host_inflate(int codec_id, const uint8_t* src, size_t n, uint8_t* ds
   else codec::lz4_raw_decompress(src, n, dst, out);
 }
 
-template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector<int>& row_groups, int leaf_idx, ReadStats* stats) {
+// thrown by the device reader when a string column turns out to hold PLAIN (not dictionary-encoded) data pages: read_column then
+// takes the host-views path below
+struct NeedsHostStrings {};
+
+template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std::vector<int>& row_groups, int leaf_idx, ReadStats* stats) {
   const FileMetaData& md = f.md;
   if (leaf_idx < 0 || (size_t)leaf_idx >= md.leaves.size()) throw FormatError("column index out of range");
   const Leaf& leaf = md.leaves[leaf_idx];
@@ -365,7 +372,7 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
           if (chunk_dict == npos) throw FormatError("dictionary-encoded page without a dictionary page");
           p.flags |= PF_DICT; p.dict = (uint32_t)chunk_dict;
         } else if (h.encoding == ENC_PLAIN) {
-          if (is_bytes) throw Unsupported("column '" + leaf.name + "': PLAIN (not dictionary-encoded) string pages");
+          if (is_bytes) throw NeedsHostStrings{};
         } else if (h.encoding == ENC_RLE && leaf.type == PT_BOOLEAN) {
           p.flags |= PF_RLE_VALUES;
         } else {
@@ -523,6 +530,249 @@ template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector
     if (res.null_count == 0) { res.validity = typename B::Mem{}; res.has_validity = false; }
   }
   return res;
+}
+
+// ---- string columns with PLAIN pages: views assembled on the host, dictionary built on the device ------------------------------------------
+// Variable-length values are a chain (each length prefix says where the next one starts), and a column that is not dictionary-encoded
+// has as many distinct values as it likes -- so there is no per-chunk dictionary to remap.  Host threads (one page at a time each)
+// decompress the page, decode its definition levels and -- for the dictionary-encoded pages such a chunk may start with -- its
+// indices, and write one 16-byte view per row ({len, inline bytes} or {len, prefix, buffer, offset}: the reference's own layout,
+// crates/polars-arrow/src/array/binview/view.rs:20-29) pointing into the page payloads, which become the column's data buffers.  The
+// views then go through the device-side dictionary encoder (backend: plx_strview_dict_encode, kernels_strview.hip) exactly like a
+// Utf8View column handed over by the caller.  Reference: arrow/read/deserialize/binview/{required,optional}.rs, parquet/encoding/plain_byte_array.rs.
+inline std::vector<uint32_t> decode_hybrid_host(const uint8_t* s, size_t len, uint32_t bits, size_t count) {
+  std::vector<uint32_t> out;
+  out.reserve(count);
+  if (bits == 0) { out.assign(count, 0); return out; }
+  if (bits > 32) throw FormatError("hybrid stream with more than 32 bits per value");
+  const size_t vbytes = (bits + 7) / 8;
+  const uint32_t mask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1);
+  size_t pos = 0;
+  while (out.size() < count) {
+    if (pos >= len) throw FormatError("hybrid stream ends before the page's values");
+    uint32_t h = 0;
+    for (uint32_t shift = 0;; shift += 7) {
+      if (pos >= len || shift > 28) throw FormatError("malformed run header");
+      uint32_t b = s[pos++];
+      h |= (b & 0x7f) << shift;
+      if (!(b & 0x80)) break;
+    }
+    if (h & 1) {
+      size_t bytes = (size_t)(h >> 1) * bits;
+      if (bytes > len - pos) bytes = len - pos;
+      size_t n = bytes * 8 / bits;
+      if (n > count - out.size()) n = count - out.size();
+      if (n == 0) throw FormatError("empty bit-packed run");
+      for (size_t i = 0; i < n; i++) {
+        const size_t bit = i * bits;
+        uint64_t w = 0;
+        const size_t at = pos + (bit >> 3), avail = len - at < 8 ? len - at : 8;
+        memcpy(&w, s + at, avail);
+        out.push_back((uint32_t)(w >> (bit & 7)) & mask);
+      }
+      pos += bytes;
+    } else {
+      size_t n = h >> 1;
+      if (vbytes > len - pos) throw FormatError("run value past the stream");
+      uint32_t v = 0;
+      for (size_t b = 0; b < vbytes; b++) v |= (uint32_t)s[pos + b] << (8 * b);
+      pos += vbytes;
+      if (n > count - out.size()) n = count - out.size();
+      if (n == 0 && pos >= len) throw FormatError("hybrid stream ends before the page's values");
+      out.insert(out.end(), n, v & mask);
+    }
+  }
+  return out;
+}
+
+inline void make_view(uint8_t* dst, const uint8_t* bytes, uint32_t len, uint32_t buffer, uint32_t offset) {
+  memset(dst, 0, 16);
+  memcpy(dst, &len, 4);
+  if (len <= 12) { if (len) memcpy(dst + 4, bytes, len); }
+  else { memcpy(dst + 4, bytes, 4); memcpy(dst + 8, &buffer, 4); memcpy(dst + 12, &offset, 4); }
+}
+
+inline void page_inflate(int codec_id, const uint8_t* src, size_t n, uint8_t* dst, size_t out) {
+  try {
+    if (codec_id == CODEC_UNCOMPRESSED) { if (n != out) throw FormatError("uncompressed page whose two sizes differ"); if (n) memcpy(dst, src, n); }
+    else if (codec_id == CODEC_SNAPPY) { std::vector<uint8_t> v = snappy_decompress_host(src, n, out); if (out) memcpy(dst, v.data(), out); }
+    else host_inflate(codec_id, src, n, dst, out);
+  } catch (const codec::CodecError& e) { throw FormatError(e.what()); }
+}
+
+template <class B> ColumnResult<B> read_string_column_host(B& be, File& f, const std::vector<int>& row_groups, int leaf_idx, ReadStats* stats) {
+  const FileMetaData& md = f.md;
+  const Leaf& leaf = md.leaves[leaf_idx];
+  const LeafType lt = leaf_type(leaf);
+  const bool optional = leaf.repetition == REP_OPTIONAL;
+  ColumnResult<B> res;
+  res.dtype = lt.dtype; res.logical = lt.logical;
+  struct ChunkRef { const ColumnChunk* c; int64_t rows; };
+  std::vector<ChunkRef> chunks;
+  int64_t n_rows = 0;
+  for (int g : row_groups) {
+    const RowGroup& rg = md.row_groups[g];          // indices, metadata and codec were validated by the device reader before it gave up
+    const ColumnChunk& c = rg.columns[leaf_idx];
+    if (rg.num_rows == 0) continue;
+    chunks.push_back({&c, rg.num_rows});
+    n_rows += rg.num_rows;
+  }
+  res.len = n_rows;
+  std::unique_ptr<uint8_t[]> views(new uint8_t[(size_t)n_rows * 16 + 16]);
+  std::vector<uint8_t> validity((size_t)(n_rows + 7) / 8 + 8, 0);
+  std::vector<std::vector<uint8_t>> data;           // one per page payload / dictionary page: the column's data buffers
+  int64_t nulls = 0;
+  uint64_t row0 = 0;
+  struct Task { PageHeader h; const uint8_t* stored; uint64_t row0; size_t buffer; };
+  for (const ChunkRef& ch : chunks) {
+    const ColumnChunk& c = *ch.c;
+    const size_t sz = (size_t)c.total_compressed_size;
+    std::vector<uint8_t> stored(sz + 16);
+    f.pread_sliced(stored.data(), sz, c.start());
+    if (stats) stats->file_bytes += sz;
+    std::vector<uint8_t> dict_views;                // 16 bytes per dictionary entry
+    bool have_dict = false;
+    std::vector<Task> tasks;
+    size_t pos = 0;
+    int64_t seen = 0;
+    while (seen < c.num_values) {
+      if (pos >= sz) throw FormatError("column chunk ends before all its values were found");
+      PageHeader h = parse_page_header(stored.data() + pos, sz - pos);
+      pos += h.header_bytes;
+      if ((size_t)h.compressed_size > sz - pos) throw FormatError("page runs past its column chunk");
+      if (h.type == PAGE_DICTIONARY) {
+        if (have_dict) throw FormatError("two dictionary pages in one column chunk");
+        if (h.encoding != ENC_PLAIN && h.encoding != ENC_PLAIN_DICTIONARY) throw Unsupported(std::string("dictionary page encoding ") + encoding_name(h.encoding));
+        const size_t buf = data.size();
+        data.emplace_back((size_t)h.uncompressed_size + 16);
+        page_inflate(c.codec, stored.data() + pos, (size_t)h.compressed_size, data[buf].data(), (size_t)h.uncompressed_size);
+        const uint8_t* p = data[buf].data();
+        const size_t n = (size_t)h.uncompressed_size;
+        dict_views.resize((size_t)h.num_values * 16);
+        size_t q = 0;
+        for (int32_t i = 0; i < h.num_values; i++) {
+          if (q + 4 > n) throw FormatError("string dictionary page ends early");
+          const uint32_t len = load_u32(p + q);
+          q += 4;
+          if (len > n - q) throw FormatError("string dictionary entry runs past the page");
+          make_view(dict_views.data() + 16 * (size_t)i, p + q, len, (uint32_t)buf, (uint32_t)q);
+          q += len;
+        }
+        have_dict = true;
+        if (stats) stats->dict_pages++;
+      } else if (h.type == PAGE_DATA || h.type == PAGE_DATA_V2) {
+        tasks.push_back({h, stored.data() + pos, row0 + (uint64_t)seen, data.size()});
+        data.emplace_back();
+        seen += h.num_values;
+        if (stats) stats->data_pages++;
+      }
+      pos += (size_t)h.compressed_size;
+    }
+    if (seen != c.num_values) throw FormatError("pages of a column chunk hold more values than its metadata says");
+    // pages in parallel: each writes the views of its own rows and a byte per row of validity
+    std::vector<std::vector<uint8_t>> page_valid(tasks.size());
+    const size_t threads = std::min<size_t>(16, tasks.size());
+    std::vector<std::exception_ptr> errs(std::max<size_t>(threads, 1));
+    auto work = [&](size_t t) {
+      try {
+        for (size_t k = t; k < tasks.size(); k += std::max<size_t>(threads, 1)) {
+          const Task& tk = tasks[k];
+          const PageHeader& h = tk.h;
+          const bool v2 = h.type == PAGE_DATA_V2;
+          const size_t nvals = (size_t)h.num_values;
+          std::vector<uint8_t>& payload = data[tk.buffer];
+          payload.resize((size_t)h.uncompressed_size + 16);
+          const uint8_t* levels = nullptr; size_t levels_len = 0, values_off = 0;
+          if (v2) {
+            if (h.rep_len != 0) throw Unsupported("repetition levels in a flat column");
+            if (h.def_len < 0 || h.def_len > h.compressed_size || h.def_len > h.uncompressed_size) throw FormatError("v2 level bytes exceed the page");
+            const size_t lv = (size_t)h.def_len;
+            if (lv) memcpy(payload.data(), tk.stored, lv);
+            page_inflate(h.is_compressed ? c.codec : (int)CODEC_UNCOMPRESSED, tk.stored + lv, (size_t)h.compressed_size - lv, payload.data() + lv, (size_t)h.uncompressed_size - lv);
+            levels = payload.data(); levels_len = lv; values_off = lv;
+          } else {
+            page_inflate(c.codec, tk.stored, (size_t)h.compressed_size, payload.data(), (size_t)h.uncompressed_size);
+            if (optional) {
+              if (h.def_encoding != ENC_RLE) throw Unsupported(std::string("definition levels encoded as ") + encoding_name(h.def_encoding));
+              if (h.uncompressed_size < 4) throw FormatError("page too small for its level length");
+              const uint32_t ll = load_u32(payload.data());
+              if (ll > (uint32_t)h.uncompressed_size - 4) throw FormatError("level bytes exceed the page");
+              levels = payload.data() + 4; levels_len = ll; values_off = 4 + (size_t)ll;
+            }
+          }
+          std::vector<uint8_t>& valid = page_valid[k];
+          valid.assign(nvals, 1);
+          size_t present = nvals;
+          if (optional) {
+            std::vector<uint32_t> lv = decode_hybrid_host(levels, levels_len, 1, nvals);
+            present = 0;
+            for (size_t i = 0; i < nvals; i++) { if (lv[i] > 1) throw FormatError("definition level > 1 in a flat column"); valid[i] = (uint8_t)lv[i]; present += lv[i]; }
+          }
+          const uint8_t* vals = payload.data() + values_off;
+          const size_t vlen = (size_t)h.uncompressed_size - values_off;
+          uint8_t* out = views.get() + 16 * (size_t)tk.row0;
+          if (h.encoding == ENC_PLAIN) {
+            size_t q = 0;
+            for (size_t i = 0; i < nvals; i++) {
+              if (!valid[i]) { memset(out + 16 * i, 0, 16); continue; }
+              if (q + 4 > vlen) throw FormatError("string page ends before its values");
+              const uint32_t len = load_u32(vals + q);
+              q += 4;
+              if (len > vlen - q) throw FormatError("string value runs past the page");
+              make_view(out + 16 * i, vals + q, len, (uint32_t)tk.buffer, (uint32_t)(values_off + q));
+              q += len;
+            }
+          } else if (h.encoding == ENC_PLAIN_DICTIONARY || h.encoding == ENC_RLE_DICTIONARY) {
+            if (!have_dict) throw FormatError("dictionary-encoded page without a dictionary page");
+            if (vlen < 1 && present) throw FormatError("dictionary-encoded page without its bit width");
+            const uint32_t bw = vlen ? vals[0] : 0;
+            std::vector<uint32_t> idx = decode_hybrid_host(vals + (vlen ? 1 : 0), vlen ? vlen - 1 : 0, bw, present);
+            const size_t nd = dict_views.size() / 16;
+            size_t d = 0;
+            for (size_t i = 0; i < nvals; i++) {
+              if (!valid[i]) { memset(out + 16 * i, 0, 16); continue; }
+              const uint32_t ix = idx[d++];
+              if (ix >= nd) throw FormatError("dictionary index out of range");
+              memcpy(out + 16 * i, dict_views.data() + 16 * (size_t)ix, 16);
+            }
+          } else {
+            throw Unsupported("column '" + leaf.name + "': page encoding " + encoding_name(h.encoding));
+          }
+        }
+      } catch (...) { errs[t] = std::current_exception(); }
+    };
+    if (threads <= 1) { if (!tasks.empty()) work(0); }
+    else {
+      std::vector<std::thread> pool;
+      for (size_t t = 0; t < threads; t++) pool.emplace_back(work, t);
+      for (std::thread& th : pool) th.join();
+    }
+    for (std::exception_ptr& ep : errs) if (ep) std::rethrow_exception(ep);
+    for (size_t k = 0; k < tasks.size(); k++) {
+      const std::vector<uint8_t>& valid = page_valid[k];
+      uint64_t r = tasks[k].row0;
+      for (size_t i = 0; i < valid.size(); i++, r++) {
+        if (valid[i]) validity[(size_t)(r >> 3)] |= (uint8_t)(1u << (r & 7));
+        else nulls++;
+      }
+    }
+    row0 += (uint64_t)ch.rows;
+  }
+  res.null_count = nulls;
+  std::vector<const void*> ptrs;
+  std::vector<int64_t> sizes;
+  for (const std::vector<uint8_t>& d : data) { ptrs.push_back(d.data()); sizes.push_back(d.size() >= 16 ? (int64_t)d.size() - 16 : 0); }
+  be.encode_string_views(f, leaf_idx, views.get(), nulls ? validity.data() : nullptr, n_rows, ptrs, sizes, &res);
+  return res;
+}
+
+template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector<int>& row_groups, int leaf_idx, ReadStats* stats) {
+  try {
+    return read_column_device(be, f, row_groups, leaf_idx, stats);
+  } catch (const NeedsHostStrings&) {
+    be.discard_pending();          // uploads of the abandoned attempt
+    return read_string_column_host(be, f, row_groups, leaf_idx, stats);
+  }
 }
 
 // ---- statistics of a chunk as typed scalars (row-group pruning) ---------------------------------------------------------------------------

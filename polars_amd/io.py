@@ -8,7 +8,7 @@ row-group skipping by statistics: crates/polars-io/src/predicates.rs).  Here:
   cross PCIe exactly as they are stored -- compressed and encoded -- and are decompressed / decoded in HBM
   (`plx_parquet_*`, polars_amd/csrc/parquet*.{hpp,cpp} + kernels_parquet.hip; Snappy on the device, zstd / gzip / lz4-raw pages inflated by the
   library's own host threads first).  decoder="host" keeps the round-1 path (pyarrow decodes, Arrow buffers are uploaded) for files
-  outside the device decoder's codecs / encodings (brotli, PLAIN string pages, delta encodings),
+  outside the device decoder's codecs / encodings (brotli, delta encodings),
 * projection pushdown -- only the columns the plan reads are fetched (TPC-H Q1 touches 7 of lineitem's 16),
 * predicate pushdown to row groups -- conjuncts `column <cmp> literal` of the filters directly above the scan skip the row
   groups whose min / max statistics cannot match (the filter itself still runs on the GPU, exactly).
@@ -47,7 +47,7 @@ def _mirror_dtype(t) -> T.DataType:
 
 class _HostDecoder:
     """decoder="host": pyarrow reads and decodes on the CPU, the decoded Arrow buffers are uploaded (the round-1 path; kept for files
-    the device decoder does not cover: brotli pages, PLAIN string pages, delta encodings)."""
+    the device decoder does not cover: brotli pages, delta encodings)."""
     name = "host"
 
     def __init__(self, path: str):
@@ -173,7 +173,12 @@ class _DeviceDecoder:
         for n in cols:
             i, dt, lg, _ = self._info[n]
             if lg in (3, 4):
-                hint[n] = T.Categorical(self._categories(i, binary=lg == 4), T.UInt32)
+                sd = C.c_uint64()
+                if F.lib().plx_parquet_column_strdict(self._h, i, C.byref(sd)) == 0:   # PLAIN string pages: dictionary built on the device, downloaded lazily
+                    from .frame import DeviceDictionary
+                    hint[n] = T.Categorical(DeviceDictionary(sd.value, binary=lg == 4), T.UInt32)
+                else:
+                    hint[n] = T.Categorical(self._categories(i, binary=lg == 4), T.UInt32)
             elif lg:
                 hint[n] = T.Date if lg == 1 else T.Datetime
         df = DataFrame._from_frame_handle(fh.value, hint)

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../polars_amd/csrc/host_codecs.hpp"
@@ -73,6 +74,40 @@ struct HostBackend {
   }
   void upload(uint64_t dst, const void* src, size_t bytes) { memcpy((void*)dst, src, bytes); }
   void upload_small(uint64_t dst, const void* src, size_t bytes) { memcpy((void*)dst, src, bytes); }
+  void discard_pending() {}
+  // stand-in for the device dictionary encoder (plx_strview_dict_encode): codes in first-appearance order, categories into the file
+  void encode_string_views(File& f, int leaf, const uint8_t* views, const uint8_t* validity, int64_t n, const std::vector<const void*>& ptrs,
+                           const std::vector<int64_t>& sizes, ColumnResult<HostBackend>* res) {
+    std::unordered_map<std::string, uint32_t> index;
+    std::vector<std::string> cats;
+    res->values = alloc((size_t)n * 4 + 8);
+    uint32_t* codes = (uint32_t*)res->values->data();
+    for (int64_t i = 0; i < n; i++) {
+      const bool ok = !validity || ((validity[(size_t)i >> 3] >> (i & 7)) & 1);
+      if (!ok) { codes[i] = 0; continue; }
+      const uint8_t* v = views + 16 * (size_t)i;
+      uint32_t len, bi, off;
+      memcpy(&len, v, 4);
+      std::string s;
+      if (len <= 12) s.assign((const char*)v + 4, len);
+      else {
+        memcpy(&bi, v + 8, 4); memcpy(&off, v + 12, 4);
+        if (bi >= ptrs.size() || (int64_t)off + len > sizes[bi]) throw FormatError("view points outside its data buffer");
+        if (memcmp((const uint8_t*)ptrs[bi] + off, v + 4, 4) != 0) throw FormatError("view prefix differs from its data");
+        s.assign((const char*)ptrs[bi] + off, len);
+      }
+      auto it = index.find(s);
+      if (it == index.end()) { it = index.emplace(s, (uint32_t)cats.size()).first; cats.push_back(s); }
+      codes[i] = it->second;
+    }
+    if (validity) {
+      res->validity = alloc((size_t)((n + 63) / 64) * 8 + 8);
+      memset(res->validity->data(), 0, res->validity->size());
+      memcpy(res->validity->data(), validity, (size_t)(n + 7) / 8);
+      res->has_validity = true;
+    }
+    f.categories[leaf] = std::move(cats);
+  }
   void zero(uint64_t dst, size_t bytes) { memset((void*)dst, 0, bytes); }
   uint64_t read_u64(uint64_t a) { uint64_t v; memcpy(&v, (const void*)a, 8); return v; }
   uint32_t read_u32(uint64_t a) { uint32_t v; memcpy(&v, (const void*)a, 4); return v; }

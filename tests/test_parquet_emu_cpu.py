@@ -97,12 +97,7 @@ def test_every_dtype_against_pyarrow(tmp_path, compression, version, dictionary)
     path = str(tmp_path / "t.parquet")
     pq.write_table(t, path, compression=compression, data_page_version=version, use_dictionary=dictionary, row_group_size=1700, data_page_size=2048)
     for name in t.column_names:
-        if not dictionary and name in ("s", "ls", "bin"):
-            with pytest.raises(E.EmuError) as ei:          # PLAIN string pages: reported as unsupported, naming the column
-                E.read_column(path, [0], t.column_names.index(name))
-            assert ei.value.code == 3 and name in str(ei.value)
-            continue
-        check_column(path, t, name)
+        check_column(path, t, name)         # strings without a dictionary (PLAIN pages): views assembled by host threads, encoded by the backend
 
 
 def test_thread_order_does_not_matter(tmp_path):
@@ -450,3 +445,26 @@ def test_reader_under_address_sanitizer(tmp_path):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     counts = dict(kv.split("=") for kv in r.stdout.split())
     assert int(counts["ok"]) > 100 and int(counts["invalid"]) > 30, r.stdout
+
+
+@pytest.mark.parametrize("compression", ["none", "snappy", "zstd"])
+def test_string_chunks_that_fall_back_from_dictionary_to_plain(tmp_path, compression):
+    """A high-cardinality string column: the writer starts every chunk dictionary-encoded and falls back to PLAIN pages once the
+    dictionary is full -- both page kinds in one chunk, nulls, long and short (inline) strings, an empty string."""
+    rng = np.random.default_rng(12)
+    n = 30_000
+    vals = np.array([("k%d" % i) if i % 3 else ("a considerably longer key number %d" % i) for i in rng.integers(0, 20_000, n)], dtype=object)
+    vals[::97] = ""
+    t = pa.table({"s": pa.array(vals, pa.string(), mask=rng.random(n) < 0.15), "b": pa.array([v.encode() for v in vals], pa.binary())})
+    path = str(tmp_path / "t.parquet")
+    for ver in ("1.0", "2.0"):
+        pq.write_table(t, path, compression=compression, data_page_version=ver, dictionary_pagesize_limit=4096, data_page_size=2048, row_group_size=11_000)
+        encs = set()
+        md = pq.ParquetFile(path).metadata
+        for g in range(md.num_row_groups):
+            encs |= set(md.row_group(g).column(0).encodings)
+        assert "PLAIN" in encs and ("RLE_DICTIONARY" in encs or "PLAIN_DICTIONARY" in encs)
+        for name in ("s", "b"):
+            r = check_column(path, t, name)
+            assert len(r["categories"]) > 5000
+        check_column(path, t, "s", row_groups=[2, 0])
