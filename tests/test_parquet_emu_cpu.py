@@ -468,3 +468,60 @@ def test_string_chunks_that_fall_back_from_dictionary_to_plain(tmp_path, compres
             r = check_column(path, t, name)
             assert len(r["categories"]) > 5000
         check_column(path, t, "s", row_groups=[2, 0])
+
+
+def test_snappy_streams_built_around_the_kernel_constants():
+    """Hand-built streams whose elements land on the decoder's internal boundaries: tags in the last bytes of the 4096-byte input
+    window, rounds that fill exactly (4096 output bytes / 1024 elements), literals of 511 / 512 / 513 bytes (the direct-copy
+    threshold), every literal header width, copies whose source ends exactly at a round boundary, long runs of 1-byte literals and
+    of offset-1 copies (the deepest pointer chains), 4-byte-offset copies reaching back further than any LDS window."""
+    rng = np.random.default_rng(99)
+    streams = []
+
+    def build(parts):
+        body, out = bytearray(), bytearray()
+        for kind, a, b in parts:
+            if kind == "lit":
+                payload = bytes(a)
+                body += lit(payload); out += payload
+            else:
+                off, ln = a, b
+                assert 1 <= off <= len(out)
+                body += copy(off, ln, None if (4 <= ln <= 11 and off < 2048) or off < 65536 else 3)
+                for _ in range(ln):
+                    out.append(out[-off])
+        return varint(len(out)) + bytes(body), bytes(out)
+
+    r = lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    # 1. tags at every offset of the window's tail: a literal sized so that the next tag starts at 4096 - k
+    for k in range(1, 9):
+        for after in ("copy2", "copy4", "lit60"):
+            first = 4096 - k - 3          # header of a literal this long takes 3 bytes (nb = 2)
+            parts = [("lit", r(first), 0)]
+            parts.append(("copy", 7, 9) if after == "copy2" else ("copy", 70000 % first + 1, 33) if after == "copy4" else ("lit", r(61), 0))
+            parts += [("lit", r(5), 0), ("copy", 3, 20)]
+            streams.append(build(parts))
+    # 2. rounds that fill exactly: 1024 elements of 4 output bytes; 4096 one-byte literals; then more
+    streams.append(build([("lit", r(8), 0)] + [("copy", 8, 4)] * 3000))
+    streams.append(build([("lit", r(1), 0) for _ in range(9000)]))
+    streams.append(build([("lit", b"ab", 0)] + [("copy", 1, 64)] * 500))          # offset-1 runs: chains as deep as a round
+    streams.append(build([("lit", b"xyz", 0)] + [("copy", 3, 5), ("copy", 2, 4), ("copy", 1, 4)] * 2000))
+    # 3. literal lengths around the direct-copy threshold and the header widths
+    for n in (59, 60, 61, 255, 256, 257, 511, 512, 513, 4095, 4096, 4097, 65535, 65536, 65537, 70001):
+        streams.append(build([("lit", r(7), 0), ("copy", 7, 11), ("lit", r(n), 0), ("copy", n, 13), ("lit", r(3), 0)]))
+    # 4. copies whose source ends exactly where a round starts / reaches far back (4-byte offsets)
+    base = [("lit", r(4096), 0)]
+    streams.append(build(base + [("copy", 4096, 64), ("copy", 64, 64), ("copy", 4096 + 128, 64)] * 40))
+    streams.append(build([("lit", r(100_000), 0)] + [("copy", 99_000, 64), ("lit", r(2), 0), ("copy", 70_000, 5)] * 300))
+    # 5. a stream that alternates long (direct) literals with element-dense stretches
+    parts = []
+    for i in range(6):
+        parts += [("lit", r(3000 + 1111 * i), 0)] + [("copy", 1 + (j % 50), 4 + (j % 60)) for j in range(700)]
+    streams.append(build(parts))
+    for data, want in streams:
+        assert py_unsnap(data) == want
+        for order in (0, 1):
+            err, got, rounds, tail = E.snappy(data, len(want), order)
+            assert err == 0 and got == want and tail == bytes([0x5A]) * 64
+        rc, got = E.snappy_host(data, len(want))
+        assert rc == 0 and got == want

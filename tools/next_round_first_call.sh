@@ -1,32 +1,39 @@
 #!/bin/bash
-# First GPU session of the next round: validates on hardware everything that was written after round 1's GPU budget ran out,
-# then collects the measurements the next kernel work starts from.  Everything lands in gpurun_out/first_call/.
-# usage: /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/next_round_first_call.sh'
+# First GPU session of the next round: validates what round 2 could only check on the CPU (no GPU minutes were left), then collects the
+# starting measurements.  ~2 GPU-minutes.  usage: gpurun --timeout 400 -- 'bash tools/next_round_first_call.sh'
+#
+# CPU-verified only at the end of round 2 (the device paths they reuse had run on hardware; the new code in them is host code):
+#   * Parquet: ZSTD / GZIP / LZ4_RAW pages (host_codecs.hpp -> chunk image -> the uncompressed device path)   tests/test_gpu_parquet.py [zstd-*]
+#   * Parquet: string columns with PLAIN pages (host views -> plx_strview_dict_encode)                          tests/test_gpu_parquet.py [*-False-*]
+#   * Arrow IPC: LZ4-frame / ZSTD bodies                                                                         tests/test_gpu_ipc.py::test_compressed_bodies
+#   * bench.py extras.parquet_ipc_scan_2e7_rows (scan_extra)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/first_call
+OUT=$R/gpurun_out/r03a
 mkdir -p $OUT
 cd $R
-# 1. the tests marked non-strict xfail (generator kernels, parquet scan): run them for real
-timeout 120 python -m pytest tests/test_gpu_datagen.py tests/test_gpu_io.py tests/test_gpu_null_exprs.py --runxfail -q --timeout 100 > $OUT/unverified_tests.log 2>&1; echo "unverified tests exit $?" | tee -a $OUT/summary.txt
-# 2. the whole GPU suite
-timeout 300 python -m pytest tests -m gpu -q --timeout 120 --durations=8 > $OUT/pytest_gpu.log 2>&1; echo "gpu suite exit $?" | tee -a $OUT/summary.txt
-tail -4 $OUT/pytest_gpu.log
-# 3. bench through the guard with the library's generators, then with the torch generators (same kernels, different inputs)
-timeout 240 python bench.py > $OUT/bench_native.json 2> $OUT/bench_native.err; echo "bench (native datagen, guarded) exit $?" | tee -a $OUT/summary.txt
-grep -c "native data generator unavailable" $OUT/bench_native.err | sed 's/^/fallbacks to torch generators: /' | tee -a $OUT/summary.txt
-PLX_BENCH_DATAGEN=torch PLX_BENCH_GUARD=0 timeout 240 python bench.py --no-extras > $OUT/bench_torch.json 2> $OUT/bench_torch.err; echo "bench (torch datagen) exit $?" | tee -a $OUT/summary.txt
-python - <<'PY' | tee -a $OUT/summary.txt
-import json, os
-o = os.environ.get("GRAFT_REPO_ROOT", os.getcwd()) + "/gpurun_out/first_call/"
-for f in ("bench_native.json", "bench_torch.json"):
-    try:
-        d = json.load(open(o + f))
-        print(f, d["ms_per_step"], d["roofline"]["frac"], d["config"]["description"][-60:], {k: v.get("ms_per_step") for k, v in d.get("extras", {}).items()}, d.get("note"))
-    except Exception as e:
-        print(f, "unreadable:", e)
+t0=$(date +%s)
+el() { echo "[+$(( $(date +%s) - t0 ))s] $*" | tee -a $OUT/summary.txt; }
+export PLX_SKIP_TORCH_PREIMPORT=1
+timeout 120 python -m pytest tests/test_gpu_parquet.py tests/test_gpu_ipc.py tests/test_gpu_io.py -m gpu -q --timeout 90 --durations=5 > $OUT/pytest_scan.log 2>&1; el "scan gpu tests exit $?"
+tail -15 $OUT/pytest_scan.log | cut -c1-250
+unset PLX_SKIP_TORCH_PREIMPORT
+PLX_SNAPPY_TIMING=1 timeout 60 python tools/parquet_bench.py 2e7 > $OUT/parquet_bench.jsonl 2> $OUT/parquet_bench.err; el "scan bench exit $?"
+cut -c1-330 $OUT/parquet_bench.jsonl; grep pq_snappy $OUT/parquet_bench.err | tail -3 | cut -c1-400
+timeout 200 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err; el "bench exit $?"
+python - $OUT/bench_full.json <<'PY' | tee -a $OUT/summary.txt
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+print("headline", d["config"]["workload"], "ms/step", d["ms_per_step"], "value", d["value"], "frac", d["roofline"]["frac"], "verified", (d.get("verified") or {}).get("ok"))
+print("step_ms", d.get("step_ms"))
+for k, v in (d.get("extras") or {}).items():
+    if isinstance(v, dict) and "ms_per_step" in v:
+        print(" ", k, v["ms_per_step"], "frac", (v.get("roofline") or {}).get("frac"), "verified", (v.get("verified") or {}).get("ok"))
+    elif isinstance(v, dict) and "files" in v:
+        for fk, fv in v["files"].items():
+            print("  scan", fk, fv.get("read_ms"), "ms", fv.get("file_GBps"), "GB/s file; pyarrow", fv.get("pyarrow_read_ms"), "ms; verified", fv.get("verified"))
+    elif isinstance(v, dict) and "error" in v:
+        print(" ", k, "ERROR", v["error"])
 PY
-# 4. optional full-size properties, partition sweep, sort
-PLX_FULL_SIZE=1 timeout 200 python -m pytest tests/test_gpu_zz_full_size.py -q --timeout 180 > $OUT/full_size.log 2>&1; echo "full-size tests exit $?" | tee -a $OUT/summary.txt
-timeout 300 bash tools/part_sweep.sh cfg3 > $OUT/part_sweep.log 2>&1; cp $R/gpurun_out/part_sweep.txt $OUT/ 2>/dev/null
-timeout 100 python tools/sort_bench.py > $OUT/sort_bench.json 2>/dev/null
-cat $OUT/summary.txt
+timeout 400 python -m pytest tests -m gpu -q --timeout 300 -x > $OUT/pytest_gpu_all.log 2>&1; el "whole gpu suite exit $?"
+tail -4 $OUT/pytest_gpu_all.log
+el "end"
