@@ -82,6 +82,40 @@ class Translator:
         tbl = df.to_arrow()
         return DataFrame([Series.from_arrow(name, tbl.column(name)) for name in tbl.column_names])
 
+    def _file_scan(self, node: Any) -> LazyFrame:
+        """IR::Scan (visitor/nodes.rs:199-215, filled at :451-499): paths, predicate, file_options (UnifiedScanArgs: with_columns = the
+        optimizer's projection pushdown, n_rows = slice pushdown, row_index), scan_type = ("parquet", options json, cloud options json).
+        A single local Parquet file becomes this package's device scan (io.scan_parquet: metadata parsed by the library, pages decoded on
+        the GPU); the pushed-down predicate is re-applied as a filter, whose simple conjuncts prune row groups by statistics."""
+        from .io import scan_parquet
+        paths = [str(p) for p in (node.paths or [])]
+        if len(paths) != 1:
+            raise NotSupported(f"scan over {len(paths)} files")
+        if "://" in paths[0] and not paths[0].startswith("file://"):
+            raise NotSupported("scan of a remote object")
+        st = node.scan_type
+        fmt = st[0] if isinstance(st, (tuple, list)) else str(st)
+        if fmt != "parquet":
+            raise NotSupported(f"{fmt} scan")
+        if isinstance(st, (tuple, list)) and len(st) > 2 and st[2] not in (None, "null"):
+            raise NotSupported("scan with cloud options")
+        if getattr(node, "hive_parts", None) is not None:
+            raise NotSupported("hive-partitioned scan")
+        fo = node.file_options
+        if getattr(fo, "row_index", None) is not None:
+            raise NotSupported("scan with a row index")
+        cols = getattr(fo, "with_columns", None)
+        try:
+            lf = scan_parquet(paths[0][7:] if paths[0].startswith("file://") else paths[0], columns=list(cols) if cols is not None else None)
+        except F.PlxError as e:                      # unreadable / malformed file: the CPU engine reports it its own way
+            raise NotSupported(f"parquet file: {e.msg}")
+        if getattr(node, "predicate", None) is not None:
+            lf = lf.filter(self.named(node.predicate))
+        nr = getattr(fo, "n_rows", None)
+        if nr is not None:
+            lf = lf.slice(int(nr[0]), int(nr[1]))
+        return lf
+
     # -- expressions -------------------------------------------------------------------------------------------
     def expr(self, node_id: int) -> E.Expr:
         x = self.nt.view_expression(node_id)
@@ -135,6 +169,8 @@ class Translator:
             if getattr(node, "selection", None) is not None:
                 raise NotSupported("scan with a pushed-down selection")
             return self.frame_of(node).lazy()
+        if kind == "Scan":
+            return self._file_scan(node)
         if kind == "Filter":
             return self.plan(node.input).filter(self.named(node.predicate))
         if kind in ("Select", "Reduce"):

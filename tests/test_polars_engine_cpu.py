@@ -187,3 +187,72 @@ def test_callback_commits_supported_plans_and_leaves_the_rest_to_the_cpu_engine(
     nt4 = FullJoin(jl, jr)
     eng.execute_with_amd(nt4, None, frame_of=lambda node: node.df)
     assert nt4.udf is None
+
+
+# ---- IR::Scan of a Parquet file -> this package's device scan --------------------------------------------------------------------------
+Scan = _cls("Scan", "paths", "file_info", "hive_parts", "predicate", "file_options", "scan_type")
+FileOptions = _cls("FileOptions", "n_rows", "with_columns", "cache", "row_index", "rechunk")
+
+
+class MapTraverser:
+    """A hand-built optimized plan: node id -> plan node, expression id -> expression node (same protocol as FakeTraverser)."""
+
+    def __init__(self, nodes, exprs, root):
+        self.nodes, self.exprs, self.cur, self.udf = nodes, exprs, root, None
+
+    def get_node(self): return self.cur
+    def set_node(self, n): self.cur = n
+    def set_udf(self, fn, is_pure): self.udf = (fn, is_pure)
+    def view_current_node(self): return self.nodes[self.cur]
+    def view_expression(self, i): return self.exprs[i]
+
+
+def test_file_scan_node_becomes_a_device_parquet_scan(tmp_path):
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from polars_amd import io
+    n = 10_000
+    t = pa.table({"k": np.arange(n) % 5, "v": np.arange(n), "d": pa.array(np.arange(n).astype(np.int32), pa.date32()), "unused": np.zeros(n),
+                  "nested": pa.array([[1]] * n)})
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, row_group_size=1000, compression="zstd")
+    # SELECT k, sum(v) FROM scan(path, columns=[k, v], predicate: v >= 7500 on an integer column) GROUP BY k   -- as the optimizer leaves it: projection and
+    # predicate pushed into the scan node
+    exprs = {0: Column(name="v"), 1: Literal(value=7500, dtype=pl.Int64), 2: BinaryExpr(left=0, op=Operator.GtEq, right=1), 3: Column(name="k"),
+             4: Agg(name="sum", arguments=[0], options=None)}
+    nodes = {0: Scan(paths=[path], file_info=None, hive_parts=None, predicate=PyExprIR(node=2, output_name="v"),
+                     file_options=FileOptions(n_rows=None, with_columns=["k", "v"], cache=True, row_index=None, rechunk=False), scan_type=("parquet", "{}", "null")),
+             1: GroupBy(input=0, keys=[PyExprIR(node=3, output_name="k")], aggs=[PyExprIR(node=4, output_name="v")], apply=None, maintain_order=False, options=None)}
+    lf = eng.Translator(MapTraverser(nodes, exprs, 1)).plan()
+    kinds = []
+    node = lf._node
+    while True:
+        kinds.append(node.kind)
+        if node.kind == "scan":
+            break
+        node = node.input
+    assert kinds == ["group_by", "filter", "scan"]
+    src = node.frame
+    assert isinstance(src, io.ParquetFrame) and src.decoder == "device" and list(src.schema) == ["k", "v"]        # the nested column was projected away: no TypeError
+    io.reset_scans(lf._node); io.push_down(lf._node)
+    assert sorted(src.selected_columns()) == ["k", "v"] and src.selected_row_groups() == [7, 8, 9]              # statistics prune what the predicate excludes
+    # what cannot be taken: several files, other formats, cloud options, a row index; a missing file is left to the CPU engine too
+    for change, word in (({"paths": [path, path]}, "2 files"), ({"scan_type": ("csv", "{}", "null")}, "csv scan"), ({"scan_type": ("parquet", "{}", '{"aws": 1}')}, "cloud"),
+                         ({"file_options": FileOptions(n_rows=None, with_columns=None, cache=True, row_index=("idx", 0), rechunk=False)}, "row index"),
+                         ({"paths": [str(tmp_path / "absent.parquet")]}, "parquet file")):
+        kw = dict(paths=[path], file_info=None, hive_parts=None, predicate=None, file_options=FileOptions(n_rows=None, with_columns=["k"], cache=True, row_index=None, rechunk=False),
+                  scan_type=("parquet", "{}", "null"))
+        kw.update(change)
+        with pytest.raises(eng.NotSupported) as ei:
+            eng.Translator(MapTraverser({0: Scan(**kw)}, {}, 0)).plan()
+        assert word in str(ei.value)
+    # all columns requested -> the nested one makes the schema unbuildable: TypeError, which execute_with_amd turns into "CPU engine runs it"
+    nt = MapTraverser({0: Scan(paths=[path], file_info=None, hive_parts=None, predicate=None, file_options=FileOptions(n_rows=(0, 10), with_columns=None, cache=True, row_index=None, rechunk=False),
+                               scan_type=("parquet", "{}", "null"))}, {}, 0)
+    eng.execute_with_amd(nt)
+    assert nt.udf is None
+    # a slice pushed into the scan comes back as a Slice node
+    kw["paths"] = [path]; kw["file_options"] = FileOptions(n_rows=(5, 10), with_columns=["k"], cache=True, row_index=None, rechunk=False)
+    lf2 = eng.Translator(MapTraverser({0: Scan(**kw)}, {}, 0)).plan()
+    assert lf2._node.kind == "slice" and lf2._node.input.kind == "scan"
