@@ -316,25 +316,33 @@ struct FwdBits {
 
 // backward bit stream (4.1 / 4.2.2): starts at the highest set bit of the last byte; bits before the start read as zero
 struct BackBits {
-  const uint8_t* p; int64_t off;        // bit offset of the next bit to hand out (counting down)
-  BackBits(const uint8_t* src, size_t n) : p(src) {
-    if (n == 0 || src[n - 1] == 0) throw CodecError("zstd: backward bit stream without its end mark");
-    off = (int64_t)n * 8 - (8 - highest_bit(src[n - 1]));      // drop the padding and the mark itself
+  const uint8_t* p; size_t n; int64_t off;        // bit offset of the next bit to hand out (counting down)
+  BackBits(const uint8_t* src, size_t len) : p(src), n(len) {
+    if (len == 0 || src[len - 1] == 0) throw CodecError("zstd: backward bit stream without its end mark");
+    off = (int64_t)len * 8 - (8 - highest_bit(src[len - 1]));      // drop the padding and the mark itself
   }
   uint64_t read(int nb) {
     if (nb == 0) return 0;
     off -= nb;
+    if (off >= 0) {
+      const size_t byte = (size_t)(off >> 3);
+      if (byte + 8 <= n && nb <= 56) {                  // the common case: one unaligned 8-byte load covers shift (<= 7) + nb bits
+        uint64_t w;
+        memcpy(&w, p + byte, 8);
+        return (w >> (off & 7)) & (((uint64_t)1 << nb) - 1);
+      }
+    }
+    // near either end of the stream: byte by byte, bits before the start are zero
     int64_t at = off; int take = nb;
     if (at < 0) { take += (int)at; at = 0; }
     uint64_t v = 0;
     if (take > 0) {
-      // bits [at, at + take) little-endian
       size_t byte = (size_t)(at >> 3);
       int sh = (int)(at & 7), got = 0;
       while (got < take) {
-        uint64_t b = p[byte++] >> sh;
+        uint64_t bb = p[byte++] >> sh;
         int can = 8 - sh;
-        v |= b << got;
+        v |= bb << got;
         got += can; sh = 0;
       }
       if (take < 64) v &= ((uint64_t)1 << take) - 1;
@@ -491,19 +499,59 @@ inline size_t huf_read(const uint8_t* p, size_t n, HufTable& t) {
   return used;
 }
 
-inline void huf_stream(const HufTable& t, const uint8_t* p, size_t n, uint8_t* out, size_t out_len) {
-  BackBits bs(p, n);
-  const int mb = t.max_bits;
-  const uint32_t mask = (1u << mb) - 1;
-  uint32_t state = (uint32_t)bs.read(mb);
-  size_t o = 0;
-  while (bs.off > -mb) {
-    if (o >= out_len) throw CodecError("zstd: Huffman stream longer than its regenerated size");
-    out[o++] = t.symbol[state];
-    const int nb = t.nbits[state];
-    state = ((state << nb) + (uint32_t)bs.read(nb)) & mask;
+// one Huffman-coded stream: the next max_bits bits (the first-read bit most significant) index the table; a symbol consumes its code length
+struct HufCursor {
+  const uint8_t* p; size_t n; int64_t off; uint8_t* out; size_t o, out_len;
+  HufCursor(const uint8_t* src, size_t len, uint8_t* dst, size_t dst_len) : p(src), n(len), out(dst), o(0), out_len(dst_len) {
+    if (len == 0 || src[len - 1] == 0) throw CodecError("zstd: backward bit stream without its end mark");
+    off = (int64_t)len * 8 - (8 - highest_bit(src[len - 1]));
   }
-  if (bs.off != -mb || o != out_len) throw CodecError("zstd: Huffman stream does not end where it should");
+  // bits [off - mb, off) with zero fill below the start of the stream
+  uint32_t peek(int mb) const {
+    const int64_t lo = off - mb;
+    if (lo >= 0) {
+      const size_t byte = (size_t)(lo >> 3);
+      if (byte + 8 <= n) { uint64_t w; memcpy(&w, p + byte, 8); return (uint32_t)(w >> (lo & 7)) & ((1u << mb) - 1); }
+    }
+    uint32_t v = 0;
+    for (int i = 0; i < mb; i++) {
+      const int64_t bit = lo + i;
+      if (bit >= 0 && (size_t)(bit >> 3) < n) v |= (uint32_t)((p[bit >> 3] >> (bit & 7)) & 1) << i;
+    }
+    return v;
+  }
+};
+
+inline void huf_finish(const HufTable& t, HufCursor& c) {
+  const int mb = t.max_bits;
+  // the stream is exhausted exactly when every bit has been consumed: the last symbol's code ends at bit 0
+  while (c.off > 0) {
+    if (c.o >= c.out_len) throw CodecError("zstd: Huffman stream longer than its regenerated size");
+    const uint32_t idx = c.peek(mb);
+    c.out[c.o++] = t.symbol[idx];
+    c.off -= t.nbits[idx];
+  }
+  if (c.off != 0 || c.o != c.out_len) throw CodecError("zstd: Huffman stream does not end where it should");
+}
+
+inline void huf_stream(const HufTable& t, const uint8_t* p, size_t n, uint8_t* out, size_t out_len) {
+  HufCursor c(p, n, out, out_len);
+  huf_finish(t, c);
+}
+
+// the four streams of a literals section side by side: four independent dependency chains per loop iteration
+inline void huf_streams4(const HufTable& t, const uint8_t* const src[4], const size_t len[4], uint8_t* const dst[4], const size_t dst_len[4]) {
+  HufCursor c0(src[0], len[0], dst[0], dst_len[0]), c1(src[1], len[1], dst[1], dst_len[1]), c2(src[2], len[2], dst[2], dst_len[2]), c3(src[3], len[3], dst[3], dst_len[3]);
+  const int mb = t.max_bits;
+  const uint8_t* sym = t.symbol.data();
+  const uint8_t* nbt = t.nbits.data();
+  // while every stream has at least 64 bits and 1 output slot left, no bounds can be crossed: peek() takes its fast path
+  while (c0.off >= 64 && c1.off >= 64 && c2.off >= 64 && c3.off >= 64 && c0.o < c0.out_len && c1.o < c1.out_len && c2.o < c2.out_len && c3.o < c3.out_len) {
+    const uint32_t i0 = c0.peek(mb), i1 = c1.peek(mb), i2 = c2.peek(mb), i3 = c3.peek(mb);
+    c0.out[c0.o++] = sym[i0]; c1.out[c1.o++] = sym[i1]; c2.out[c2.o++] = sym[i2]; c3.out[c3.o++] = sym[i3];
+    c0.off -= nbt[i0]; c1.off -= nbt[i1]; c2.off -= nbt[i2]; c3.off -= nbt[i3];
+  }
+  huf_finish(t, c0); huf_finish(t, c1); huf_finish(t, c2); huf_finish(t, c3);
 }
 
 const uint32_t kLLBase[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
@@ -587,10 +635,11 @@ inline void block_compressed(FrameState& fs, const uint8_t* p, size_t n, std::ve
       const size_t s4 = left - 6 - s1 - s2 - s3, each = (regen + 3) / 4;
       if (each * 3 > regen) throw CodecError("zstd: regenerated size too small for four streams");
       const uint8_t* d = q + 6;
-      huf_stream(fs.huf, d, s1, lits, each);
-      huf_stream(fs.huf, d + s1, s2, lits + each, each);
-      huf_stream(fs.huf, d + s1 + s2, s3, lits + 2 * each, each);
-      huf_stream(fs.huf, d + s1 + s2 + s3, s4, lits + 3 * each, regen - 3 * each);
+      const uint8_t* const src4[4] = {d, d + s1, d + s1 + s2, d + s1 + s2 + s3};
+      const size_t len4[4] = {s1, s2, s3, s4};
+      uint8_t* const dst4[4] = {lits, lits + each, lits + 2 * each, lits + 3 * each};
+      const size_t dlen4[4] = {each, each, each, regen - 3 * each};
+      huf_streams4(fs.huf, src4, len4, dst4, dlen4);
     }
     pos += comp;
   }

@@ -409,7 +409,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     if (seen != c.num_values) throw FormatError("pages of a column chunk hold more values than its metadata says");
     if (host_codec) {
       // one page per host thread at a time; errors of any of them fail the read
-      const size_t threads = std::min<size_t>(16, inflate.size());
+      const size_t threads = std::min<size_t>(std::min<size_t>(32, std::max(2u, std::thread::hardware_concurrency() / 2)), inflate.size());
       std::vector<std::exception_ptr> errs(std::max<size_t>(threads, 1));
       auto work = [&](size_t t) {
         try {
