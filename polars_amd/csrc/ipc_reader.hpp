@@ -148,7 +148,9 @@ inline int64_t compressed_buffer_length(const File& f, int64_t body, const Buffe
   if (r.length < 8) throw FormatError("compressed buffer shorter than its length prefix");
   int64_t ulen;
   f.pread_exact(&ulen, 8, body + r.offset);
-  if (ulen < -1 || ulen > ((int64_t)1 << 40)) throw FormatError("compressed buffer with an absurd uncompressed length");
+  // no LZ4 / zstd stream expands more than ~32768 : 1 (a zstd RLE block: 4 bytes -> 128 KB): anything beyond is a corrupt length, and
+  // must not become an allocation
+  if (ulen < -1 || ulen > ((int64_t)1 << 31) || ulen > 65536 * (r.length - 8) + 1024) throw FormatError("compressed buffer with an absurd uncompressed length");
   return ulen == -1 ? r.length - 8 : ulen;
 }
 // the bytes of one buffer, decompressed when the batch is compressed, into dst[0, need) (need <= its uncompressed length)
@@ -170,6 +172,7 @@ inline void load_buffer(const File& f, const BatchMeta& bm, int64_t body, const 
     return;
   }
   if (ulen < 0 || (int64_t)need > ulen) throw FormatError("buffer shorter than the array needs");
+  if (ulen > ((int64_t)1 << 31) || ulen > 65536 * (r.length - 8) + 1024) throw FormatError("compressed buffer with an absurd uncompressed length");
   try {
     if ((size_t)ulen == need) {
       if (bm.codec == 0) codec::lz4_frame_decompress(raw.data() + 8, raw.size() - 8, dst, need);

@@ -461,6 +461,8 @@ inline PageHeader parse_page_header(const uint8_t* p, size_t n) {
   });
   h.header_bytes = r.consumed();
   if (h.compressed_size < 0 || h.uncompressed_size < 0 || h.num_values < 0) throw FormatError("page header with negative sizes");
+  // no codec expands more than ~32768 : 1 (a zstd RLE block); a corrupt size must not become an allocation
+  if ((int64_t)h.uncompressed_size > 65536 * (int64_t)h.compressed_size + 4096) throw FormatError("page header with an absurd uncompressed size");
   return h;
 }
 

@@ -236,7 +236,9 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     if (c.start() < 4 || c.total_compressed_size < 0 || c.start() + c.total_compressed_size > f.size - 8) throw FormatError("column chunk outside the file");
     // what goes to HBM: the chunk as stored, or -- host codecs -- its image with every page payload decompressed (the metadata's
     // uncompressed total, page headers included, bounds it)
-    if (host_codec && (c.total_uncompressed_size < 0 || c.total_uncompressed_size > ((int64_t)1 << 40))) throw FormatError("column chunk with an absurd uncompressed size");
+    // (no codec here expands more than ~32768 : 1; a corrupt total must not become an allocation)
+    if (host_codec && (c.total_uncompressed_size < 0 || c.total_uncompressed_size > ((int64_t)1 << 36) || c.total_uncompressed_size > 65536 * c.total_compressed_size + 4096))
+      throw FormatError("column chunk with an absurd uncompressed size");
     const size_t cap = align16((size_t)(host_codec ? c.total_uncompressed_size : c.total_compressed_size));
     chunks.push_back({&c, rg.num_rows, blob_bytes, cap});
     blob_bytes += cap;
