@@ -126,21 +126,34 @@ inline void lz4_frame_decompress(const uint8_t* in, size_t n, uint8_t* out, size
 namespace inflate_detail {
 
 struct Bits {
-  const uint8_t* p; size_t n; size_t pos = 0; uint32_t hold = 0; int cnt = 0;
+  const uint8_t* p; size_t n; size_t pos = 0; uint64_t hold = 0; int cnt = 0;
   uint32_t get(int need) {
     while (cnt < need) {
       if (pos >= n) throw CodecError("deflate: stream ends inside a block");
-      hold |= (uint32_t)p[pos++] << cnt;
+      hold |= (uint64_t)p[pos++] << cnt;
       cnt += 8;
     }
-    const uint32_t v = need ? hold & ((1u << need) - 1) : 0;
+    const uint32_t v = need ? (uint32_t)(hold & (((uint64_t)1 << need) - 1)) : 0;
     hold >>= need; cnt -= need;
     return v;
   }
-  void align() { hold = 0; cnt = 0; }      // the bytes already pulled in are whole bytes: drop the rest of the current one
+  // the next `need` (<= 16) bits without consuming them; past the end of the stream they read as zero (a code that needs them fails in drop)
+  uint32_t peek(int need) {
+    while (cnt < need && pos < n) { hold |= (uint64_t)p[pos++] << cnt; cnt += 8; }
+    return (uint32_t)(hold & (((uint64_t)1 << need) - 1));
+  }
+  void drop(int used) {
+    if (used > cnt) throw CodecError("deflate: stream ends inside a block");
+    hold >>= used; cnt -= used;
+  }
+  void align() { const int whole = cnt / 8; pos -= (size_t)whole; hold = 0; cnt = 0; }      // back to the byte boundary: bytes pulled in ahead are handed back
 };
 
-struct Huff { uint16_t count[16]; uint16_t symbol[288]; };
+constexpr int kFastBits = 10;
+struct Huff {
+  uint16_t count[16]; uint16_t symbol[288];
+  uint16_t fast[1 << kFastBits];      // code (bit-reversed: DEFLATE codes arrive most significant bit first) -> length << 9 | symbol; 0: longer than kFastBits
+};
 
 inline void build(Huff& h, const uint8_t* lens, int n) {
   memset(h.count, 0, sizeof h.count);
@@ -152,9 +165,22 @@ inline void build(Huff& h, const uint8_t* lens, int n) {
   offs[1] = 0;
   for (int len = 1; len < 15; len++) offs[len + 1] = (uint16_t)(offs[len] + h.count[len]);
   for (int i = 0; i < n; i++) if (lens[i]) h.symbol[offs[lens[i]]++] = (uint16_t)i;
+  // first-level table: every code of at most kFastBits bits, replicated over the bits that follow it
+  memset(h.fast, 0, sizeof h.fast);
+  int code = 0, index = 0;
+  for (int len = 1; len <= kFastBits; len++) {
+    for (int k = 0; k < h.count[len]; k++, code++, index++) {
+      uint32_t rev = 0;
+      for (int b = 0; b < len; b++) rev |= ((uint32_t)(code >> b) & 1) << (len - 1 - b);
+      for (uint32_t fill = rev; fill < (1u << kFastBits); fill += 1u << len) h.fast[fill] = (uint16_t)((len << 9) | h.symbol[index]);
+    }
+    code <<= 1;
+  }
 }
 
 inline int decode(Bits& b, const Huff& h) {
+  const uint16_t f = h.fast[b.peek(kFastBits)];
+  if (f) { b.drop(f >> 9); return f & 511; }
   int code = 0, first = 0, index = 0;
   for (int len = 1; len <= 15; len++) {
     code |= (int)b.get(1);
@@ -259,7 +285,7 @@ inline void inflate(const uint8_t* in, size_t n, size_t* ip_io, uint8_t* out, si
     }
     if (last) break;
   }
-  *ip_io += b.pos - (size_t)(b.cnt / 8);      // whole bytes pulled in but not used belong to what follows
+  *ip_io += b.pos - (size_t)(b.cnt / 8);      // whole bytes pulled in ahead but not used belong to what follows
   *op_io = op;
 }
 
