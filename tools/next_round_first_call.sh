@@ -34,6 +34,7 @@ for k, v in (d.get("extras") or {}).items():
     elif isinstance(v, dict) and "error" in v:
         print(" ", k, "ERROR", v["error"])
 PY
+bash tools/pmc_all.sh r03a q3 q3f cfg3 cfg5 > $OUT/pmc_all.log 2>&1; el "pmc refresh exit $? (copy gpurun_out/r03a/profiles/* to profiles/)"
 timeout 400 python -m pytest tests -m gpu -q --timeout 300 -x > $OUT/pytest_gpu_all.log 2>&1; el "whole gpu suite exit $?"
 tail -4 $OUT/pytest_gpu_all.log
 el "end"
