@@ -1202,6 +1202,33 @@ def run(args, emit):
             pl._ffi.lib().plx_memory_trim()
             torch.cuda.empty_cache()
             emit(line)
+        # Q3 on SHUFFLED inputs (round-1 review, item 6): the headline Q3 runs on dbgen row order, where an order's lines are adjacent and the
+        # probe's late materialisation skips whole cache lines; shuffled rows are the adversarial case for both.  Torch generators (the
+        # library's generator has no shuffled mode), so no host-twin verification: the group count is compared with the ordered run's.
+        if os.environ.get("PLX_BENCH_Q3_SHUFFLED", "1") != "0":
+            prev = os.environ.get("PLX_Q3_SHUFFLED")
+            try:
+                os.environ["PLX_Q3_SHUFFLED"] = "1"
+                w3 = make_workload(pl, "q3", 0, seed=20)
+                w3.name = "tpch_q3_sf100_shuffled_inputs"          # (also keeps the ordered run's PMC traffic figure off this line)
+                d3, s3, r3, c3 = timed(pl, w3, k2, 2, False)
+                ordered = extras.get("tpch_q3_sf100", {})
+                extras["tpch_q3_sf100_shuffled_inputs"] = {
+                    "rows_per_s": round(w3.rows * k2 / d3, 1), "ms_per_step": round(d3 / k2 * 1e3, 3), "cold_first_step_ms": None if c3 is None else round(c3, 2),
+                    "vs_ordered_inputs": (round(d3 / k2 * 1e3 / ordered["ms_per_step"], 2) if ordered.get("ms_per_step") else None),
+                    "groups": int(r3.height) if hasattr(r3, "height") else None, "roofline": roofline(s3, w3, k2), "kernels": _kernels(s3, 6),
+                    "note": "same query, same row counts, both tables in random row order (torch generators); not oracle-verified"}
+                del w3, r3
+            except Exception as e:
+                extras["tpch_q3_sf100_shuffled_inputs"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            finally:
+                if prev is None:
+                    os.environ.pop("PLX_Q3_SHUFFLED", None)
+                else:
+                    os.environ["PLX_Q3_SHUFFLED"] = prev
+            pl._ffi.lib().plx_memory_trim()
+            torch.cuda.empty_cache()
+            emit(line)
         # last (nothing after it can be cut short by it): the scan in front of the path, SURVEY.md 8(f) row 3
         if os.environ.get("PLX_BENCH_SCAN", "1") != "0":
             try:
