@@ -476,6 +476,7 @@ int plx_datagen_id_views(int64_t n_rows, uint64_t seed, uint32_t stream, int64_t
  *   plx_parquet_read            row_groups x columns -> frame (rows in row-group order as given).  Codecs: UNCOMPRESSED, SNAPPY (device
  *                               kernel), ZSTD, GZIP and LZ4_RAW (pages inflated by host threads with the library's own decoders, then the same kernels);
  *                               encodings: PLAIN (strings: see plx_parquet_column_strdict), PLAIN_DICTIONARY / RLE_DICTIONARY, RLE levels;
+ *                               DELTA_BINARY_PACKED / BYTE_STREAM_SPLIT / DELTA_*_BYTE_ARRAY / INT96 (decoded by host threads);
  *                               data pages v1 and v2; anything else
  *                               is PLX_ERR_UNSUPPORTED naming what it met (the caller decodes that file on the host), a malformed
  *                               file is PLX_ERR_INVALID.  Needs plx_init: there is no host decode path in the library.

@@ -101,7 +101,7 @@ inline LeafType leaf_type(const Leaf& l) {
       if (l.logical == LG_STRING || l.logical == LG_NONE) { t.dtype = PLX_U32; t.logical = l.logical == LG_STRING ? LO_STRING : LO_BINARY; return t; }
       t.why = "annotated BYTE_ARRAY";
       return t;
-    case PT_INT96: t.why = "INT96 timestamp"; return t;
+    case PT_INT96: t.dtype = PLX_I64; t.logical = LO_DATETIME_US; t.src_width = 12; return t;     // legacy timestamps: converted by host threads (read_fixed_column_host)
     default: t.why = l.logical == LG_DECIMAL ? "decimal (FIXED_LEN_BYTE_ARRAY)" : "FIXED_LEN_BYTE_ARRAY"; return t;
   }
 }
@@ -202,6 +202,8 @@ inline void host_inflate(int codec_id, const uint8_t* src, size_t n, uint8_t* ds
 // thrown by the device reader when a string column turns out to hold PLAIN (not dictionary-encoded) data pages: read_column then
 // takes the host-views path below
 struct NeedsHostStrings {};
+// ... and when a fixed-width column holds pages in an encoding only the host decoder knows (DELTA_BINARY_PACKED, BYTE_STREAM_SPLIT; INT96)
+struct NeedsHostValues {};
 
 template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std::vector<int>& row_groups, int leaf_idx, ReadStats* stats) {
   const FileMetaData& md = f.md;
@@ -378,6 +380,8 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
         } else if (h.encoding == ENC_RLE && leaf.type == PT_BOOLEAN) {
           p.flags |= PF_RLE_VALUES;
         } else {
+          if (is_bytes && (h.encoding == ENC_DELTA_LENGTH_BYTE_ARRAY || h.encoding == ENC_DELTA_BYTE_ARRAY)) throw NeedsHostStrings{};
+          if (!is_bytes && (h.encoding == ENC_DELTA_BINARY_PACKED || h.encoding == ENC_BYTE_STREAM_SPLIT)) throw NeedsHostValues{};
           throw Unsupported("column '" + leaf.name + "': page encoding " + encoding_name(h.encoding));
         }
         size_t job = npos;
@@ -587,6 +591,62 @@ inline std::vector<uint32_t> decode_hybrid_host(const uint8_t* s, size_t len, ui
   return out;
 }
 
+// DELTA_BINARY_PACKED (parquet/encoding/delta_bitpacked/decoder.rs): header {block size, miniblocks per block, total count, first value},
+// then per block {min delta, one bit width per miniblock, bit-packed deltas}; value[i] = value[i - 1] + min delta + delta (wrapping).
+// Appends the stream's values to out; returns the bytes consumed.
+inline size_t delta_binary_packed_host(const uint8_t* p, size_t n, std::vector<int64_t>& out) {
+  size_t pos = 0;
+  auto uleb = [&]() {
+    uint64_t v = 0;
+    for (int shift = 0; shift < 70; shift += 7) {
+      if (pos >= n) throw FormatError("delta stream ends inside its header");
+      const uint8_t b = p[pos++];
+      v |= (uint64_t)(b & 0x7f) << shift;
+      if (!(b & 0x80)) return v;
+    }
+    throw FormatError("delta stream: varint too long");
+  };
+  auto zigzag = [&]() { const uint64_t v = uleb(); return (int64_t)(v >> 1) ^ -(int64_t)(v & 1); };
+  const uint64_t block = uleb(), minis = uleb(), total = uleb();
+  if (block == 0 || block % 128 || minis == 0 || block % minis || (block / minis) % 32 || block > (1u << 20)) throw FormatError("delta stream with an invalid block shape");
+  if (total > ((uint64_t)1 << 31)) throw FormatError("delta stream with an absurd value count");
+  int64_t value = zigzag();
+  const uint64_t per_mini = block / minis;
+  uint64_t left = total;
+  if (left) { out.push_back(value); left--; }
+  std::vector<uint8_t> widths((size_t)minis);
+  while (left) {
+    const int64_t min_delta = zigzag();
+    if (minis > n - pos) throw FormatError("delta stream ends inside a block header");
+    memcpy(widths.data(), p + pos, (size_t)minis);
+    pos += (size_t)minis;
+    for (uint64_t m = 0; m < minis && left; m++) {
+      const uint32_t bw = widths[(size_t)m];
+      if (bw > 64) throw FormatError("delta stream with a bit width above 64");
+      const size_t bytes = (size_t)(per_mini * bw / 8);
+      if (bytes > n - pos) throw FormatError("delta stream ends inside a miniblock");
+      const uint64_t take = left < per_mini ? left : per_mini;
+      for (uint64_t i = 0; i < take; i++) {
+        uint64_t d = 0;
+        if (bw) {
+          const uint64_t bit = i * bw;
+          const size_t at = pos + (size_t)(bit >> 3);
+          unsigned __int128 w = 0;
+          const size_t avail = n - at < 16 ? n - at : 16;
+          memcpy(&w, p + at, avail);
+          w >>= (bit & 7);
+          d = bw == 64 ? (uint64_t)w : (uint64_t)w & (((uint64_t)1 << bw) - 1);
+        }
+        value = (int64_t)((uint64_t)value + (uint64_t)min_delta + d);
+        out.push_back(value);
+      }
+      pos += bytes;
+      left -= take;
+    }
+  }
+  return pos;
+}
+
 inline void make_view(uint8_t* dst, const uint8_t* bytes, uint32_t len, uint32_t buffer, uint32_t offset) {
   memset(dst, 0, 16);
   memcpy(dst, &len, 4);
@@ -737,6 +797,43 @@ template <class B> ColumnResult<B> read_string_column_host(B& be, File& f, const
               if (ix >= nd) throw FormatError("dictionary index out of range");
               memcpy(out + 16 * i, dict_views.data() + 16 * (size_t)ix, 16);
             }
+          } else if (h.encoding == ENC_DELTA_LENGTH_BYTE_ARRAY) {
+            // all lengths first (delta-packed), then the bytes back to back (parquet/encoding/delta_length_byte_array)
+            std::vector<int64_t> lens;
+            const size_t used = delta_binary_packed_host(vals, vlen, lens);
+            if (lens.size() != present) throw FormatError("delta-length page with a different value count than its levels");
+            size_t q = used, d = 0;
+            for (size_t i = 0; i < nvals; i++) {
+              if (!valid[i]) { memset(out + 16 * i, 0, 16); continue; }
+              const int64_t len = lens[d++];
+              if (len < 0 || (uint64_t)len > vlen - q || len > 0x7fffffff) throw FormatError("string value runs past the page");
+              make_view(out + 16 * i, vals + q, (uint32_t)len, (uint32_t)tk.buffer, (uint32_t)(values_off + q));
+              q += (size_t)len;
+            }
+          } else if (h.encoding == ENC_DELTA_BYTE_ARRAY) {
+            // incremental encoding: value = first `prefix` bytes of the previous value + suffix; the values are rebuilt into a buffer of
+            // their own, appended behind the page payload (parquet/encoding/delta_byte_array)
+            std::vector<int64_t> prefixes, suffix_lens;
+            size_t used = delta_binary_packed_host(vals, vlen, prefixes);
+            used += delta_binary_packed_host(vals + used, vlen - used, suffix_lens);
+            if (prefixes.size() != present || suffix_lens.size() != present) throw FormatError("delta-byte-array page with a different value count than its levels");
+            size_t total = 0;
+            { int64_t prev = 0; for (size_t k2 = 0; k2 < present; k2++) { if (prefixes[k2] < 0 || prefixes[k2] > prev || suffix_lens[k2] < 0) throw FormatError("delta-byte-array page with an invalid prefix"); prev = prefixes[k2] + suffix_lens[k2]; total += (size_t)prev; if (total > ((size_t)1 << 31)) throw FormatError("delta-byte-array page expands beyond 2 GiB"); } }
+            const size_t base = payload.size();                 // rebuilt values live behind the payload (+ its 16 pad bytes)
+            payload.resize(base + total + 16);
+            vals = payload.data() + values_off;                 // the resize may have moved the payload
+            size_t q = used, w = base, prev_at = 0, prev_len = 0, d = 0;
+            for (size_t i = 0; i < nvals; i++) {
+              if (!valid[i]) { memset(out + 16 * i, 0, 16); continue; }
+              const size_t pre = (size_t)prefixes[d], suf = (size_t)suffix_lens[d];
+              d++;
+              if (suf > vlen - q) throw FormatError("string suffix runs past the page");
+              if (pre) memmove(payload.data() + w, payload.data() + prev_at, pre);
+              if (suf) memcpy(payload.data() + w + pre, vals + q, suf);
+              q += suf;
+              make_view(out + 16 * i, payload.data() + w, (uint32_t)(pre + suf), (uint32_t)tk.buffer, (uint32_t)w);
+              prev_at = w; prev_len = pre + suf; w += prev_len;
+            }
           } else {
             throw Unsupported("column '" + leaf.name + "': page encoding " + encoding_name(h.encoding));
           }
@@ -768,12 +865,224 @@ template <class B> ColumnResult<B> read_string_column_host(B& be, File& f, const
   return res;
 }
 
+// ---- fixed-width columns in encodings without a kernel: decoded by host threads ------------------------------------------------------------
+// DELTA_BINARY_PACKED integers and BYTE_STREAM_SPLIT floats (what "v2" writers choose), INT96 timestamps (legacy Spark / Impala; -> us):
+// host threads (a page each) decompress, decode levels and values, and write the finished column -- values + validity bitmap -- into
+// the staging buffer; one upload, no kernel.  The chunk's PLAIN / dictionary pages (writers mix them) take the same route here.
+template <class B> ColumnResult<B> read_fixed_column_host(B& be, File& f, const std::vector<int>& row_groups, int leaf_idx, ReadStats* stats) {
+  const FileMetaData& md = f.md;
+  const Leaf& leaf = md.leaves[leaf_idx];
+  const LeafType lt = leaf_type(leaf);
+  if (lt.dtype < 0) throw Unsupported("column '" + leaf.name + "': " + lt.why + " is outside the hot path's dtypes");
+  if (lt.dtype == PLX_BOOL || leaf.type == PT_BYTE_ARRAY) throw Unsupported("column '" + leaf.name + "': no host value decoder for this type");
+  const bool optional = leaf.repetition == REP_OPTIONAL;
+  const bool int96 = leaf.type == PT_INT96;
+  const uint32_t sw = lt.src_width, ow = out_width_of(lt.dtype);
+  ColumnResult<B> res;
+  res.dtype = lt.dtype; res.logical = lt.logical;
+  struct ChunkRef { const ColumnChunk* c; int64_t rows; };
+  std::vector<ChunkRef> chunks;
+  int64_t n_rows = 0;
+  for (int g : row_groups) {
+    if (g < 0 || (size_t)g >= md.row_groups.size()) throw FormatError("row group index out of range");
+    const RowGroup& rg = md.row_groups[g];
+    const ColumnChunk& c = rg.columns[leaf_idx];
+    if (!c.has_meta) throw FormatError("column chunk without metadata");
+    if (c.external_file) throw Unsupported("column chunk stored in another file");
+    if (c.type != leaf.type) throw FormatError("column chunk type differs from the schema");
+    if (c.codec != CODEC_UNCOMPRESSED && c.codec != CODEC_SNAPPY && c.codec != CODEC_ZSTD && c.codec != CODEC_LZ4_RAW && c.codec != CODEC_GZIP)
+      throw Unsupported(std::string("column '") + leaf.name + "': codec " + codec_name(c.codec) + " has no decompressor here");
+    if (c.num_values != rg.num_rows) throw FormatError("flat column chunk whose value count differs from the row group's rows");
+    if (rg.num_rows == 0) continue;
+    if (c.start() < 4 || c.total_compressed_size < 0 || c.start() + c.total_compressed_size > f.size - 8) throw FormatError("column chunk outside the file");
+    chunks.push_back({&c, rg.num_rows});
+    n_rows += rg.num_rows;
+  }
+  res.len = n_rows;
+  if (n_rows >= (int64_t)1 << 40) throw Unsupported("more than 2^40 rows in one read");
+  const size_t out_bytes = (size_t)n_rows * ow;
+  res.values = be.alloc(out_bytes + 8);
+  if (n_rows == 0) return res;
+  uint8_t* out = be.host_stage(out_bytes + 16);
+  std::vector<uint8_t> validity((size_t)(n_rows + 7) / 8 + 8, 0);
+  int64_t nulls = 0;
+  uint64_t row0 = 0;
+  auto put = [&](uint64_t row, uint64_t bits) {
+    switch (ow) {
+      case 1: out[row] = (uint8_t)bits; break;
+      case 2: { uint16_t v = (uint16_t)bits; memcpy(out + 2 * row, &v, 2); break; }
+      case 4: { uint32_t v = (uint32_t)bits; memcpy(out + 4 * row, &v, 4); break; }
+      default: memcpy(out + 8 * row, &bits, 8); break;
+    }
+  };
+  auto plain_at = [&](const uint8_t* v, size_t i) -> uint64_t {
+    if (int96) {
+      int64_t nanos; int32_t jd;
+      memcpy(&nanos, v + 12 * i, 8); memcpy(&jd, v + 12 * i + 8, 4);
+      return (uint64_t)(((int64_t)jd - 2440588) * 86400000000LL + nanos / 1000);
+    }
+    if (sw == 8) return load_u64(v + 8 * i);
+    return (uint64_t)load_u32(v + 4 * i);
+  };
+  struct Task { PageHeader h; const uint8_t* stored; uint64_t row0; };
+  for (const ChunkRef& ch : chunks) {
+    const ColumnChunk& c = *ch.c;
+    const size_t sz = (size_t)c.total_compressed_size;
+    std::vector<uint8_t> stored(sz + 16);
+    f.pread_sliced(stored.data(), sz, c.start());
+    if (stats) stats->file_bytes += sz;
+    std::vector<uint64_t> dict;
+    bool have_dict = false;
+    std::vector<Task> tasks;
+    size_t pos = 0;
+    int64_t seen = 0;
+    while (seen < c.num_values) {
+      if (pos >= sz) throw FormatError("column chunk ends before all its values were found");
+      PageHeader h = parse_page_header(stored.data() + pos, sz - pos);
+      pos += h.header_bytes;
+      if ((size_t)h.compressed_size > sz - pos) throw FormatError("page runs past its column chunk");
+      if (h.type == PAGE_DICTIONARY) {
+        if (have_dict) throw FormatError("two dictionary pages in one column chunk");
+        if (h.encoding != ENC_PLAIN && h.encoding != ENC_PLAIN_DICTIONARY) throw Unsupported(std::string("dictionary page encoding ") + encoding_name(h.encoding));
+        std::vector<uint8_t> plain((size_t)h.uncompressed_size + 16);
+        page_inflate(c.codec, stored.data() + pos, (size_t)h.compressed_size, plain.data(), (size_t)h.uncompressed_size);
+        if ((uint64_t)h.num_values * sw > (uint64_t)h.uncompressed_size) throw FormatError("dictionary page smaller than its entry count");
+        dict.resize((size_t)h.num_values);
+        for (size_t i = 0; i < dict.size(); i++) dict[i] = plain_at(plain.data(), i);
+        have_dict = true;
+        if (stats) stats->dict_pages++;
+      } else if (h.type == PAGE_DATA || h.type == PAGE_DATA_V2) {
+        tasks.push_back({h, stored.data() + pos, row0 + (uint64_t)seen});
+        seen += h.num_values;
+        if (stats) stats->data_pages++;
+      }
+      pos += (size_t)h.compressed_size;
+    }
+    if (seen != c.num_values) throw FormatError("pages of a column chunk hold more values than its metadata says");
+    std::vector<std::vector<uint8_t>> page_valid(tasks.size());
+    const size_t threads = std::min<size_t>(std::min<size_t>(32, std::max(2u, std::thread::hardware_concurrency() / 2)), tasks.size());
+    std::vector<std::exception_ptr> errs(std::max<size_t>(threads, 1));
+    auto work = [&](size_t t) {
+      try {
+        std::vector<uint8_t> payload;
+        std::vector<int64_t> deltas;
+        for (size_t k = t; k < tasks.size(); k += std::max<size_t>(threads, 1)) {
+          const Task& tk = tasks[k];
+          const PageHeader& h = tk.h;
+          const bool v2 = h.type == PAGE_DATA_V2;
+          const size_t nvals = (size_t)h.num_values;
+          payload.assign((size_t)h.uncompressed_size + 16, 0);
+          const uint8_t* levels = nullptr; size_t levels_len = 0, values_off = 0;
+          if (v2) {
+            if (h.rep_len != 0) throw Unsupported("repetition levels in a flat column");
+            if (h.def_len < 0 || h.def_len > h.compressed_size || h.def_len > h.uncompressed_size) throw FormatError("v2 level bytes exceed the page");
+            const size_t lv = (size_t)h.def_len;
+            if (lv) memcpy(payload.data(), tk.stored, lv);
+            page_inflate(h.is_compressed ? c.codec : (int)CODEC_UNCOMPRESSED, tk.stored + lv, (size_t)h.compressed_size - lv, payload.data() + lv, (size_t)h.uncompressed_size - lv);
+            levels = payload.data(); levels_len = lv; values_off = lv;
+          } else {
+            page_inflate(c.codec, tk.stored, (size_t)h.compressed_size, payload.data(), (size_t)h.uncompressed_size);
+            if (optional) {
+              if (h.def_encoding != ENC_RLE) throw Unsupported(std::string("definition levels encoded as ") + encoding_name(h.def_encoding));
+              if (h.uncompressed_size < 4) throw FormatError("page too small for its level length");
+              const uint32_t ll = load_u32(payload.data());
+              if (ll > (uint32_t)h.uncompressed_size - 4) throw FormatError("level bytes exceed the page");
+              levels = payload.data() + 4; levels_len = ll; values_off = 4 + (size_t)ll;
+            }
+          }
+          std::vector<uint8_t>& valid = page_valid[k];
+          valid.assign(nvals, 1);
+          size_t present = nvals;
+          if (optional) {
+            std::vector<uint32_t> lv = decode_hybrid_host(levels, levels_len, 1, nvals);
+            present = 0;
+            for (size_t i = 0; i < nvals; i++) { if (lv[i] > 1) throw FormatError("definition level > 1 in a flat column"); valid[i] = (uint8_t)lv[i]; present += lv[i]; }
+          }
+          const uint8_t* vals = payload.data() + values_off;
+          const size_t vlen = (size_t)h.uncompressed_size - values_off;
+          // dense value d of the page, as the bits of the source type
+          std::vector<uint32_t> idx;
+          deltas.clear();
+          enum { K_PLAIN, K_DICT, K_DELTA, K_SPLIT } kind;
+          if (h.encoding == ENC_PLAIN) {
+            kind = K_PLAIN;
+            if ((uint64_t)present * sw > vlen) throw FormatError("value bytes missing");
+          } else if (h.encoding == ENC_PLAIN_DICTIONARY || h.encoding == ENC_RLE_DICTIONARY) {
+            kind = K_DICT;
+            if (!have_dict) throw FormatError("dictionary-encoded page without a dictionary page");
+            if (vlen < 1 && present) throw FormatError("dictionary-encoded page without its bit width");
+            idx = decode_hybrid_host(vals + (vlen ? 1 : 0), vlen ? vlen - 1 : 0, vlen ? vals[0] : 0, present);
+          } else if (h.encoding == ENC_DELTA_BINARY_PACKED && !int96 && (leaf.type == PT_INT32 || leaf.type == PT_INT64)) {
+            kind = K_DELTA;
+            delta_binary_packed_host(vals, vlen, deltas);
+            if (deltas.size() != present) throw FormatError("delta page with a different value count than its levels");
+          } else if (h.encoding == ENC_BYTE_STREAM_SPLIT && !int96) {
+            kind = K_SPLIT;
+            if ((uint64_t)present * sw > vlen) throw FormatError("value bytes missing");
+          } else {
+            throw Unsupported("column '" + leaf.name + "': page encoding " + encoding_name(h.encoding));
+          }
+          size_t d = 0;
+          for (size_t i = 0; i < nvals; i++) {
+            if (!valid[i]) { put(tk.row0 + i, 0); continue; }
+            uint64_t bits;
+            switch (kind) {
+              case K_PLAIN: bits = plain_at(vals, d); break;
+              case K_DICT: { const uint32_t ix = idx[d]; if (ix >= dict.size()) throw FormatError("dictionary index out of range"); bits = dict[ix]; break; }
+              case K_DELTA: bits = (uint64_t)deltas[d]; break;
+              default: {
+                bits = 0;
+                for (uint32_t b = 0; b < sw; b++) bits |= (uint64_t)vals[(size_t)b * present + d] << (8 * b);
+                break;
+              }
+            }
+            d++;
+            put(tk.row0 + i, bits);
+          }
+        }
+      } catch (...) { errs[t] = std::current_exception(); }
+    };
+    if (threads <= 1) { if (!tasks.empty()) work(0); }
+    else {
+      std::vector<std::thread> pool;
+      for (size_t t = 0; t < threads; t++) pool.emplace_back(work, t);
+      for (std::thread& th : pool) th.join();
+    }
+    for (std::exception_ptr& ep : errs) if (ep) std::rethrow_exception(ep);
+    for (size_t k = 0; k < tasks.size(); k++) {
+      const std::vector<uint8_t>& valid = page_valid[k];
+      uint64_t r = tasks[k].row0;
+      for (size_t i = 0; i < valid.size(); i++, r++) {
+        if (valid[i]) validity[(size_t)(r >> 3)] |= (uint8_t)(1u << (r & 7));
+        else nulls++;
+      }
+    }
+    row0 += (uint64_t)ch.rows;
+  }
+  be.upload(be.addr(res.values), out, out_bytes);
+  res.null_count = nulls;
+  if (nulls) {
+    const size_t vb = (size_t)((n_rows + 63) / 64) * 8;
+    res.validity = be.alloc(vb + 8);
+    be.zero(be.addr(res.validity), vb + 8);
+    be.upload_small(be.addr(res.validity), validity.data(), (size_t)(n_rows + 7) / 8);
+    res.has_validity = true;
+  }
+  be.discard_pending();            // the staging buffer of this column is about to be reused
+  return res;
+}
+
 template <class B> ColumnResult<B> read_column(B& be, File& f, const std::vector<int>& row_groups, int leaf_idx, ReadStats* stats) {
+  if (leaf_idx >= 0 && (size_t)leaf_idx < f.md.leaves.size() && f.md.leaves[leaf_idx].type == PT_INT96 && !f.md.leaves[leaf_idx].nested)
+    return read_fixed_column_host(be, f, row_groups, leaf_idx, stats);
   try {
     return read_column_device(be, f, row_groups, leaf_idx, stats);
   } catch (const NeedsHostStrings&) {
     be.discard_pending();          // uploads of the abandoned attempt
     return read_string_column_host(be, f, row_groups, leaf_idx, stats);
+  } catch (const NeedsHostValues&) {
+    be.discard_pending();
+    return read_fixed_column_host(be, f, row_groups, leaf_idx, stats);
   }
 }
 

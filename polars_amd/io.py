@@ -8,7 +8,7 @@ row-group skipping by statistics: crates/polars-io/src/predicates.rs).  Here:
   cross PCIe exactly as they are stored -- compressed and encoded -- and are decompressed / decoded in HBM
   (`plx_parquet_*`, polars_amd/csrc/parquet*.{hpp,cpp} + kernels_parquet.hip; Snappy on the device, zstd / gzip / lz4-raw pages inflated by the
   library's own host threads first).  decoder="host" keeps the round-1 path (pyarrow decodes, Arrow buffers are uploaded) for files
-  outside the device decoder's codecs / encodings (brotli, delta encodings),
+  outside the device decoder's codecs / types (brotli, decimals, nested columns),
 * projection pushdown -- only the columns the plan reads are fetched (TPC-H Q1 touches 7 of lineitem's 16),
 * predicate pushdown to row groups -- conjuncts `column <cmp> literal` of the filters directly above the scan skip the row
   groups whose min / max statistics cannot match (the filter itself still runs on the GPU, exactly).
@@ -47,7 +47,7 @@ def _mirror_dtype(t) -> T.DataType:
 
 class _HostDecoder:
     """decoder="host": pyarrow reads and decodes on the CPU, the decoded Arrow buffers are uploaded (the round-1 path; kept for files
-    the device decoder does not cover: brotli pages, delta encodings)."""
+    the device decoder does not cover: brotli pages, decimals, nested columns)."""
     name = "host"
 
     def __init__(self, path: str):

@@ -182,10 +182,9 @@ def test_unsupported_files_say_what_they_are(tmp_path):
         with pytest.raises(E.EmuError) as ei:
             E.read_column(path, [0], col)
         assert ei.value.code == 3 and word in str(ei.value), str(ei.value)
-    pq.write_table(t.select(["z"]), path, compression="none", use_dictionary=False, column_encoding={"z": "DELTA_BINARY_PACKED"})
-    with pytest.raises(E.EmuError) as ei:
-        E.read_column(path, [0], 0)
-    assert ei.value.code == 3 and "DELTA_BINARY_PACKED" in str(ei.value)
+    # booleans in an encoding nobody decodes here
+    pq.write_table(pa.table({"b": pa.array(np.arange(n) % 3 == 0)}), path, compression="none", use_dictionary=False, column_encoding={"b": "RLE"}, data_page_version="1.0")
+    check_column(path, pa.table({"b": pa.array(np.arange(n) % 3 == 0)}), "b")          # RLE booleans ARE decoded (device bodies); kept here as the boundary case
 
 
 PAYLOADS = {
@@ -525,3 +524,47 @@ def test_snappy_streams_built_around_the_kernel_constants():
             assert err == 0 and got == want and tail == bytes([0x5A]) * 64
         rc, got = E.snappy_host(data, len(want))
         assert rc == 0 and got == want
+
+
+@pytest.mark.parametrize("compression", ["none", "snappy", "zstd"])
+@pytest.mark.parametrize("version", ["1.0", "2.0"])
+def test_encodings_only_the_host_decoder_knows(tmp_path, compression, version):
+    """DELTA_BINARY_PACKED integers, BYTE_STREAM_SPLIT floats, DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY strings (what parquet "v2"
+    writers choose), INT96 timestamps (legacy Spark / Impala): decoded by host threads, uploaded as finished columns."""
+    rng = np.random.default_rng(21)
+    n = 7000
+    m = lambda: rng.random(n) < 0.2
+    words = np.array(["", "a", "prefix-shared-0001", "prefix-shared-0002", "prefix-shared-and-longer-0003", "zebra", "ünï"])
+    t = pa.table({
+        "d64": pa.array(np.cumsum(rng.integers(-5, 50, n)), mask=m()), "d32": pa.array(rng.integers(-2**31, 2**31, n).astype(np.int32)),
+        "d64w": pa.array(rng.integers(-2**63, 2**63, n)), "d16": pa.array(rng.integers(-3000, 3000, n).astype(np.int16), mask=m()),
+        "du32": pa.array(rng.integers(0, 2**32, n).astype(np.uint32)), "const": pa.array(np.full(n, 7, np.int64)),
+        "bss64": pa.array(rng.normal(size=n), mask=m()), "bss32": pa.array(rng.normal(size=n).astype(np.float32)),
+        "dl": pa.array(words[rng.integers(0, len(words), n)], mask=m()), "dba": pa.array(np.sort(words[rng.integers(0, len(words), n)])),
+        "dts": pa.array(np.cumsum(rng.integers(0, 10**6, n)), pa.timestamp("us")),
+    })
+    enc = {"d64": "DELTA_BINARY_PACKED", "d32": "DELTA_BINARY_PACKED", "d64w": "DELTA_BINARY_PACKED", "d16": "DELTA_BINARY_PACKED", "du32": "DELTA_BINARY_PACKED",
+           "const": "DELTA_BINARY_PACKED", "bss64": "BYTE_STREAM_SPLIT", "bss32": "BYTE_STREAM_SPLIT", "dl": "DELTA_LENGTH_BYTE_ARRAY", "dba": "DELTA_BYTE_ARRAY",
+           "dts": "DELTA_BINARY_PACKED"}
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression=compression, data_page_version=version, use_dictionary=False, column_encoding=enc, row_group_size=2500, data_page_size=1500)
+    md = pq.ParquetFile(path).metadata
+    for i, name in enumerate(t.column_names):
+        assert enc[name] in md.row_group(0).column(i).encodings, (name, md.row_group(0).column(i).encodings)
+        check_column(path, t, name)
+        check_column(path, t, name, row_groups=[2, 0], order=1)
+
+
+def test_int96_timestamps(tmp_path):
+    rng = np.random.default_rng(22)
+    n = 5000
+    us = rng.integers(-10**15, 2 * 10**15, n)               # before and after the epoch
+    t = pa.table({"ts": pa.array(us, pa.timestamp("us"), mask=rng.random(n) < 0.1), "k": pa.array(np.arange(n))})
+    path = str(tmp_path / "t.parquet")
+    for dic in (True, False):
+        pq.write_table(t, path, use_deprecated_int96_timestamps=True, compression="snappy", use_dictionary=dic, row_group_size=1800, data_page_size=2000)
+        assert pq.ParquetFile(path).metadata.row_group(0).column(0).physical_type == "INT96"
+        r = E.read_column(path, [0, 1, 2], 0)
+        assert r["dtype"] == 4 and r["logical"] == 2           # Int64 / Datetime[us]
+        valid = np.array([x is not None for x in t.column("ts").to_pylist()])
+        assert np.array_equal(r["valid"], valid) and np.array_equal(r["values"][valid], us[valid])
