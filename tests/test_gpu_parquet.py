@@ -147,3 +147,29 @@ def test_q1_from_parquet_both_decoders(pl, orc, tmp_path):
         assert out["count_order"] == want["count_order"].tolist() and out["sum_qty"] == want["sum_qty"].tolist(), decoder
         for c in ("sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc"):
             assert np.allclose(np.array(out[c]), want[c], rtol=1e-6, atol=0), (decoder, c)
+
+
+def test_host_decoded_encodings_arrive_on_the_device(pl, tmp_path):
+    """DELTA_BINARY_PACKED / BYTE_STREAM_SPLIT / DELTA_*_BYTE_ARRAY / INT96 columns: decoded by the library's host threads
+    (parquet_reader.hpp: read_fixed_column_host, read_string_column_host), uploaded as finished columns / views."""
+    n = 30_000
+    words = np.array(["", "a", "prefix-shared-0001", "prefix-shared-0002", "prefix-shared-and-longer-0003", "zebra"])
+    m = lambda: RNG.random(n) < 0.2
+    t = pa.table({"d64": pa.array(np.cumsum(RNG.integers(-5, 50, n)), mask=m()), "d32": pa.array(RNG.integers(-2**31, 2**31, n).astype(np.int32)),
+                  "bss64": pa.array(RNG.normal(size=n), mask=m()), "bss32": pa.array(RNG.normal(size=n).astype(np.float32)),
+                  "dl": pa.array(words[RNG.integers(0, len(words), n)], mask=m()), "dba": pa.array(np.sort(words[RNG.integers(0, len(words), n)])),
+                  "plain_i64": pa.array(RNG.integers(0, 1 << 40, n))})
+    enc = {"d64": "DELTA_BINARY_PACKED", "d32": "DELTA_BINARY_PACKED", "bss64": "BYTE_STREAM_SPLIT", "bss32": "BYTE_STREAM_SPLIT", "dl": "DELTA_LENGTH_BYTE_ARRAY",
+           "dba": "DELTA_BYTE_ARRAY", "plain_i64": "PLAIN"}
+    path = str(tmp_path / "v2.parquet")
+    pq.write_table(t, path, compression="zstd", data_page_version="2.0", use_dictionary=False, column_encoding=enc, row_group_size=11_000, data_page_size=4096)
+    df = pl.read_parquet(path)
+    compare(df, t, t.column_names)
+    us = RNG.integers(-10**15, 2 * 10**15, n)
+    t96 = pa.table({"ts": pa.array(us, pa.timestamp("us"), mask=RNG.random(n) < 0.1)})
+    path96 = str(tmp_path / "int96.parquet")
+    pq.write_table(t96, path96, use_deprecated_int96_timestamps=True, compression="snappy")
+    s = pl.read_parquet(path96)["ts"]
+    values, valid = s._download()
+    want_valid = np.array([x is not None for x in t96.column("ts").to_pylist()])
+    assert s.dtype == pl.Datetime and np.array_equal(valid, want_valid) and np.array_equal(values[want_valid], us[want_valid])
