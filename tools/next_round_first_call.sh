@@ -5,6 +5,7 @@
 # CPU-verified only at the end of round 2 (the device paths they reuse had run on hardware; the new code in them is host code):
 #   * Parquet: ZSTD / GZIP / LZ4_RAW pages (host_codecs.hpp -> chunk image -> the uncompressed device path)   tests/test_gpu_parquet.py [zstd-*]
 #   * Parquet: string columns with PLAIN pages (host views -> plx_strview_dict_encode)                          tests/test_gpu_parquet.py [*-False-*]
+#   * Parquet: DELTA_* / BYTE_STREAM_SPLIT / INT96 columns (host decode, one upload)                           tests/test_gpu_parquet.py::test_host_decoded_encodings_arrive_on_the_device
 #   * Arrow IPC: LZ4-frame / ZSTD bodies                                                                         tests/test_gpu_ipc.py::test_compressed_bodies
 #   * bench.py extras.parquet_ipc_scan_2e7_rows (scan_extra)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
