@@ -298,6 +298,9 @@ int plx_hash_partition(plx_column key, int32_t n_partitions, uint64_t seed, plx_
 /* ---- frames ------------------------------------------------------------- */
 int plx_frame_new(const char* const* names, const plx_column* cols, int32_t n_cols, plx_frame* out);
 int plx_frame_free(plx_frame f);
+/* Vertical concatenation (polars.concat(how="vertical"), crates/polars-core/src/frame/mod.rs:609 vstack_mut): same column names and dtypes in
+ * every frame; columns are copied device-to-device, validity bitmaps merged at bit granularity.  Used by multi-file scans. */
+int plx_frame_concat(const plx_frame* frames, int32_t n_frames, plx_frame* out);
 int plx_frame_shape(plx_frame f, int64_t* height, int32_t* width);
 /* name_out points into library-owned storage valid until the frame is freed. */
 int plx_frame_column(plx_frame f, int32_t i, const char** name_out, plx_column* col_out);

@@ -180,6 +180,7 @@ SIGNATURES = {
     "plx_hash_partition": (C.c_int, [C.c_uint64, C.c_int32, C.c_uint64, _u64p, _i64p]),
     "plx_frame_new": (C.c_int, [C.POINTER(C.c_char_p), _u64p, C.c_int32, _u64p]),
     "plx_frame_free": (C.c_int, [C.c_uint64]),
+    "plx_frame_concat": (C.c_int, [_u64p, C.c_int32, _u64p]),
     "plx_frame_shape": (C.c_int, [C.c_uint64, _i64p, _i32p]),
     "plx_frame_column": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_char_p), _u64p]),
     "plx_frame_dtypes": (C.c_int, [C.c_uint64, _i32p]),

@@ -352,6 +352,25 @@ int plx_frame_new(const char* const* names, const plx_column* cols, int32_t n_co
   PLX_CATCH
 }
 int plx_frame_free(plx_frame f) { PLX_TRY free_frame(f); PLX_CATCH }
+int plx_frame_concat(const plx_frame* frames, int32_t n_frames, plx_frame* out) {
+  PLX_TRY
+  PLX_REQUIRE(frames && out && n_frames >= 1, PLX_ERR_INVALID, "frame_concat: bad arguments");
+  std::vector<FramePtr> fs;
+  for (int32_t i = 0; i < n_frames; i++) fs.push_back(get_frame(frames[i]));
+  auto o = std::make_shared<Frame>();
+  o->names = fs[0]->names;
+  for (const FramePtr& f : fs) {
+    PLX_REQUIRE(f->names == o->names, PLX_ERR_SHAPE, "frame_concat: frames have different columns");
+    o->height += f->height;
+  }
+  for (size_t c = 0; c < o->names.size(); c++) {
+    std::vector<ColumnPtr> chunks;
+    for (const FramePtr& f : fs) chunks.push_back(f->cols[c]);
+    o->cols.push_back(ops::concat(chunks));        // dtype mismatches are reported by the op
+  }
+  *out = register_frame(o);
+  PLX_CATCH
+}
 int plx_frame_shape(plx_frame f, int64_t* height, int32_t* width) {
   PLX_TRY
   FramePtr fr = get_frame(f);

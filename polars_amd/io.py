@@ -201,14 +201,141 @@ class _DeviceDecoder:
         return items if binary else [x.decode("utf-8", "replace") for x in items]
 
 
+def concat_frames(dfs):
+    """Vertical concatenation of device frames with equal schemas (plx_frame_concat: device-to-device copies, bitmaps merged at bit
+    granularity).  Dictionary columns are first brought onto one dictionary: codes of frame i go through remap_i (a gather on the
+    device), the union keeps first-appearance order across the frames."""
+    import ctypes as C
+
+    import numpy as np
+    from .frame import DataFrame, Series
+    dfs = [d for d in dfs]
+    if len(dfs) == 1:
+        return dfs[0]
+    names = dfs[0].columns
+    for d in dfs:
+        if d.columns != names:
+            raise ValueError(f"frames to concatenate have different columns: {d.columns} vs {names}")
+    hint = {}
+    for n in names:
+        if not isinstance(dfs[0][n].dtype, T.Categorical):
+            continue
+        union, index = [], {}
+        parts = []
+        for d in dfs:
+            cats = list(d[n].dtype.categories)
+            remap = np.empty(max(len(cats), 1), np.uint32)
+            for i, c in enumerate(cats):
+                j = index.get(c)
+                if j is None:
+                    j = index[c] = len(union)
+                    union.append(c)
+                remap[i] = j
+            parts.append(remap[:len(cats)] if cats else remap[:0])
+        new = []
+        for d, remap in zip(dfs, parts):
+            s = d[n]
+            if s.dtype.physical != F.U32:                               # narrow codes (u8 / u16 dictionaries built by the caller): one width for all frames
+                s = s.cast(T.UInt32)
+            if len(remap) and not np.array_equal(remap, np.arange(len(remap), dtype=np.uint32)):
+                s = Series("remap", remap, T.UInt32).gather(s)          # null codes stay null (gather honours the index validity)
+                s.name = n
+            new.append(s)
+        hint[n] = T.Categorical(union, T.UInt32)
+        dfs = [DataFrame([new[i] if c.name == n else c for c in d.get_columns()]) for i, d in enumerate(dfs)]
+    handles = (C.c_uint64 * len(dfs))(*[d._frame_handle() for d in dfs])
+    out = C.c_uint64()
+    F.check(F.lib().plx_frame_concat(handles, len(dfs), C.byref(out)))
+    for n in names:
+        dt = dfs[0][n].dtype
+        if n not in hint and dt.name in ("Date", "Datetime"):
+            hint[n] = dt
+    res = DataFrame._from_frame_handle(out.value, hint)
+    for s in res.get_columns():
+        s._declare_dictionary_bounds()
+    return res
+
+
+class _MultiDecoder:
+    """Several files behind one scan (a glob or a list of paths: TPC-H tables usually come as directories of files).  Row groups are
+    numbered across the files in path order; statistics come from the file a row group lives in; a read fetches file by file (each
+    through the device decoder) and concatenates on the device."""
+
+    def __init__(self, paths: Sequence[str], make):
+        self.paths = list(paths)
+        self.parts = [make(p) for p in self.paths]
+        first = self.parts[0]
+        self.name = first.name
+        self.names = list(first.names)
+        for p, part in zip(self.paths[1:], self.parts[1:]):
+            if list(part.names) != self.names:
+                raise ValueError(f"{p}: columns differ from {self.paths[0]}")
+        self.num_rows = sum(p.num_rows for p in self.parts)
+        self._map = [(i, g) for i, p in enumerate(self.parts) for g in range(p.num_row_groups)]
+        self.num_row_groups = len(self._map)
+
+    def dtype(self, name: str) -> T.DataType:
+        dts = [p.dtype(name) for p in self.parts]
+        for p, d in zip(self.paths, dts):
+            if d != dts[0] or d.physical != dts[0].physical:
+                raise TypeError(f"{p}: column {name!r} is {d}, {self.paths[0]} has {dts[0]}")
+        return dts[0]
+
+    def stats(self, g: int, name: str):
+        i, lg = self._map[g]
+        return self.parts[i].stats(lg, name)
+
+    def literal(self, name: str, value: Any, like: Any) -> Any:
+        return self.parts[0].literal(name, value, like)
+
+    def read(self, rgs: List[int], cols: List[str]):
+        runs: List[Tuple[int, List[int]]] = []                 # consecutive row groups of one file are one read
+        for g in rgs:
+            i, lg = self._map[g]
+            if runs and runs[-1][0] == i:
+                runs[-1][1].append(lg)
+            else:
+                runs.append((i, [lg]))
+        if not runs:
+            return self.parts[0].read([], cols)
+        dfs, rows, nbytes = [], 0, 0
+        for i, lgs in runs:
+            df, r, b = self.parts[i].read(lgs, cols)
+            dfs.append(df); rows += r; nbytes += b
+        return concat_frames(dfs), rows, nbytes
+
+
+def expand_paths(source, suffixes=(".parquet",)) -> List[str]:
+    """str (a file, a directory, or a glob pattern) or a sequence of paths -> the sorted list of files, as polars.scan_parquet accepts."""
+    import glob
+    import os
+    if isinstance(source, (list, tuple)):
+        out: List[str] = []
+        for s in source:
+            out += expand_paths(s, suffixes)
+        return out
+    source = os.fspath(source)
+    if os.path.isdir(source):
+        found = sorted(f for sfx in suffixes for f in glob.glob(os.path.join(source, "**", "*" + sfx), recursive=True))
+    elif any(ch in source for ch in "*?["):
+        found = sorted(glob.glob(source, recursive=True))
+    else:
+        found = [source]
+    if not found:
+        raise FileNotFoundError(f"no files match {source!r}")
+    return found
+
+
 class ParquetFrame:
     """A scan source: looks like a DataFrame to the plan lowering (`schema`, `_frame_handle()`), materialises lazily."""
 
-    def __init__(self, path: str, columns: Optional[Sequence[str]] = None, decoder: str = "device"):
+    def __init__(self, path, columns: Optional[Sequence[str]] = None, decoder: str = "device"):
         if decoder not in ("device", "host"):
             raise ValueError("decoder must be 'device' or 'host'")
-        self.path = path
-        self._dec = _DeviceDecoder(path) if decoder == "device" else _HostDecoder(path)
+        paths = expand_paths(path)
+        self.path = paths[0] if len(paths) == 1 else paths
+        make = _DeviceDecoder if decoder == "device" else _HostDecoder
+        self._dec = make(paths[0]) if len(paths) == 1 else _MultiDecoder(paths, make)
         names = list(columns) if columns is not None else list(self._dec.names)
         self._schema: Dict[str, T.DataType] = {n: self._dec.dtype(n) for n in names}
         self._need: Optional[Set[str]] = set()          # None = every column of the schema
@@ -329,14 +456,15 @@ def _comparable(value: Any, like: Any) -> Any:
     raise TypeError("statistics and literal are not comparable")
 
 
-def scan_parquet(path: str, columns: Optional[Sequence[str]] = None, decoder: str = "device"):
-    """LazyFrame over a Parquet file (mirrors polars.scan_parquet for the path's dtypes).  Nothing is read until collect().
+def scan_parquet(path, columns: Optional[Sequence[str]] = None, decoder: str = "device"):
+    """LazyFrame over a Parquet file, a directory / glob of files or a list of them (mirrors polars.scan_parquet for the path's dtypes).
+    Nothing is read until collect().
     decoder="device": column chunks are decoded on the GPU (UNCOMPRESSED / SNAPPY / ZSTD / GZIP / LZ4_RAW, PLAIN / dictionary pages); "host": pyarrow."""
     from .frame import LazyFrame
     return LazyFrame(P.Node("scan", frame=ParquetFrame(path, columns, decoder)))
 
 
-def read_parquet(path: str, columns: Optional[Sequence[str]] = None, decoder: str = "device"):
+def read_parquet(path, columns: Optional[Sequence[str]] = None, decoder: str = "device"):
     """Eager variant: decode (only `columns`) into device columns."""
     pf = ParquetFrame(path, columns, decoder)
     pf.request(None, [])

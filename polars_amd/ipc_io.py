@@ -16,7 +16,7 @@ import numpy as np
 from . import _ffi as F
 from . import datatypes as T
 from . import plan as P
-from .io import ParquetFrame
+from .io import ParquetFrame, _MultiDecoder, expand_paths
 
 
 class _IpcDecoder:
@@ -108,9 +108,10 @@ class _IpcDecoder:
 class IpcFrame(ParquetFrame):
     """Scan source over an Arrow IPC file: the same lazy materialisation and projection pushdown as ParquetFrame."""
 
-    def __init__(self, path: str, columns: Optional[Sequence[str]] = None):
-        self.path = path
-        self._dec = _IpcDecoder(path)
+    def __init__(self, path, columns: Optional[Sequence[str]] = None):
+        paths = expand_paths(path, suffixes=(".arrow", ".feather", ".ipc"))
+        self.path = paths[0] if len(paths) == 1 else paths
+        self._dec = _IpcDecoder(paths[0]) if len(paths) == 1 else _MultiDecoder(paths, _IpcDecoder)
         names = list(columns) if columns is not None else list(self._dec.names)
         self._schema = {n: self._dec.dtype(n) for n in names}
         self._need = set()
@@ -120,13 +121,13 @@ class IpcFrame(ParquetFrame):
         self.last_read = {}
 
 
-def scan_ipc(path: str, columns: Optional[Sequence[str]] = None):
+def scan_ipc(path, columns: Optional[Sequence[str]] = None):
     """LazyFrame over an Arrow IPC (Feather V2) file (mirrors polars.scan_ipc for the path's dtypes); uncompressed, LZ4-frame and Zstandard bodies."""
     from .frame import LazyFrame
     return LazyFrame(P.Node("scan", frame=IpcFrame(path, columns)))
 
 
-def read_ipc(path: str, columns: Optional[Sequence[str]] = None):
+def read_ipc(path, columns: Optional[Sequence[str]] = None):
     pf = IpcFrame(path, columns)
     pf.request(None, [])
     return pf.materialise()

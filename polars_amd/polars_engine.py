@@ -85,17 +85,19 @@ class Translator:
     def _file_scan(self, node: Any) -> LazyFrame:
         """IR::Scan (visitor/nodes.rs:199-215, filled at :451-499): paths, predicate, file_options (UnifiedScanArgs: with_columns = the
         optimizer's projection pushdown, n_rows = slice pushdown, row_index), scan_type = ("parquet", options json, cloud options json).
-        A single local Parquet file becomes this package's device scan (io.scan_parquet: metadata parsed by the library, pages decoded on
-        the GPU); the pushed-down predicate is re-applied as a filter, whose simple conjuncts prune row groups by statistics."""
+        Local Parquet / Arrow IPC files (one or several with the same schema) become this package's device scan (io.scan_parquet /
+        ipc_io.scan_ipc: metadata parsed by the library, pages decoded on the GPU, files concatenated on the device); the pushed-down predicate is re-applied as a filter, whose simple conjuncts prune row groups by statistics."""
         from .io import scan_parquet
+        from .ipc_io import scan_ipc
         paths = [str(p) for p in (node.paths or [])]
-        if len(paths) != 1:
-            raise NotSupported(f"scan over {len(paths)} files")
-        if "://" in paths[0] and not paths[0].startswith("file://"):
+        if not paths:
+            raise NotSupported("scan over no files")
+        if any("://" in p and not p.startswith("file://") for p in paths):
             raise NotSupported("scan of a remote object")
+        paths = [p[7:] if p.startswith("file://") else p for p in paths]
         st = node.scan_type
         fmt = st[0] if isinstance(st, (tuple, list)) else str(st)
-        if fmt != "parquet":
+        if fmt not in ("parquet", "ipc"):
             raise NotSupported(f"{fmt} scan")
         if isinstance(st, (tuple, list)) and len(st) > 2 and st[2] not in (None, "null"):
             raise NotSupported("scan with cloud options")
@@ -106,9 +108,11 @@ class Translator:
             raise NotSupported("scan with a row index")
         cols = getattr(fo, "with_columns", None)
         try:
-            lf = scan_parquet(paths[0][7:] if paths[0].startswith("file://") else paths[0], columns=list(cols) if cols is not None else None)
+            lf = (scan_parquet if fmt == "parquet" else scan_ipc)(paths if len(paths) > 1 else paths[0], columns=list(cols) if cols is not None else None)
         except F.PlxError as e:                      # unreadable / malformed file: the CPU engine reports it its own way
-            raise NotSupported(f"parquet file: {e.msg}")
+            raise NotSupported(f"{fmt} file: {e.msg}")
+        except (TypeError, ValueError) as e:         # a type outside the hot path, or files whose schemas differ (the CPU engine has its own rules for those)
+            raise NotSupported(f"{fmt} scan: {e}")
         if getattr(node, "predicate", None) is not None:
             lf = lf.filter(self.named(node.predicate))
         nr = getattr(fo, "n_rows", None)

@@ -173,3 +173,31 @@ def test_host_decoded_encodings_arrive_on_the_device(pl, tmp_path):
     values, valid = s._download()
     want_valid = np.array([x is not None for x in t96.column("ts").to_pylist()])
     assert s.dtype == pl.Datetime and np.array_equal(valid, want_valid) and np.array_equal(values[want_valid], us[want_valid])
+
+
+def test_scan_over_several_files_unifies_dictionaries(pl, tmp_path):
+    """A directory of files with one schema is one scan: frames are read file by file and concatenated on the device
+    (plx_frame_concat); string columns, whose dictionaries differ from file to file, are first brought onto one dictionary."""
+    rng = np.random.default_rng(5)
+    parts, paths = [], []
+    for f, (n, words) in enumerate([(3001, ["a", "b", "c"]), (1999, ["c", "zz", "a", "only here"]), (2500, ["b"])]):
+        t = pa.table({"i": pa.array(rng.integers(0, 10**9, n), mask=rng.random(n) < 0.1), "f": rng.normal(size=n), "b": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.3),
+                      "s": pa.array(np.array(words)[rng.integers(0, len(words), n)], mask=rng.random(n) < 0.2),
+                      "d": pa.array(rng.integers(0, 20000, n).astype(np.int32), pa.date32())})
+        paths.append(str(tmp_path / f"part-{f}.parquet"))
+        pq.write_table(t, paths[-1], row_group_size=777, compression=["none", "snappy", "zstd"][f], use_dictionary=f != 1)
+        parts.append(t)
+    want = pa.concat_tables(parts)
+    df = pl.read_parquet(str(tmp_path))
+    assert df.height == want.num_rows
+    compare(df, want, want.column_names)
+    cats = list(df["s"].dtype.categories)
+    assert sorted(cats) == ["a", "b", "c", "only here", "zz"] and len(set(cats)) == 5
+    # pruning across files, then a group-by on the unified string column
+    c = pl.col
+    out = pl.scan_parquet(paths).filter(c("d") >= 0).group_by("s").agg(pl.len().alias("n"), c("f").sum().alias("sf")).collect().sort_host("s")
+    s = np.array([x if x is not None else "\0" for x in want.column("s").to_pylist()]); fv = want.column("f").to_numpy()
+    for i, key in enumerate(out["s"]):
+        mk = s == (key if key is not None else "\0")
+        assert out["n"][i] == int(mk.sum()) and abs(out["sf"][i] - fv[mk].sum()) < 1e-9 * max(1.0, np.abs(fv[mk]).sum())
+    assert len(out["s"]) == 6

@@ -237,8 +237,10 @@ def test_file_scan_node_becomes_a_device_parquet_scan(tmp_path):
     assert isinstance(src, io.ParquetFrame) and src.decoder == "device" and list(src.schema) == ["k", "v"]        # the nested column was projected away: no TypeError
     io.reset_scans(lf._node); io.push_down(lf._node)
     assert sorted(src.selected_columns()) == ["k", "v"] and src.selected_row_groups() == [7, 8, 9]              # statistics prune what the predicate excludes
-    # what cannot be taken: several files, other formats, cloud options, a row index; a missing file is left to the CPU engine too
-    for change, word in (({"paths": [path, path]}, "2 files"), ({"scan_type": ("csv", "{}", "null")}, "csv scan"), ({"scan_type": ("parquet", "{}", '{"aws": 1}')}, "cloud"),
+    # what cannot be taken: files whose schemas differ, other formats, cloud options, a row index; a missing file is left to the CPU engine too
+    other = str(tmp_path / "other.parquet")
+    pq.write_table(pa.table({"k": np.arange(10).astype(np.float64)}), other)
+    for change, word in (({"paths": [path, other]}, "columns differ"), ({"scan_type": ("csv", "{}", "null")}, "csv scan"), ({"paths": []}, "no files"), ({"scan_type": ("parquet", "{}", '{"aws": 1}')}, "cloud"),
                          ({"file_options": FileOptions(n_rows=None, with_columns=None, cache=True, row_index=("idx", 0), rechunk=False)}, "row index"),
                          ({"paths": [str(tmp_path / "absent.parquet")]}, "parquet file")):
         kw = dict(paths=[path], file_info=None, hive_parts=None, predicate=None, file_options=FileOptions(n_rows=None, with_columns=["k"], cache=True, row_index=None, rechunk=False),
@@ -256,3 +258,55 @@ def test_file_scan_node_becomes_a_device_parquet_scan(tmp_path):
     kw["paths"] = [path]; kw["file_options"] = FileOptions(n_rows=(5, 10), with_columns=["k"], cache=True, row_index=None, rechunk=False)
     lf2 = eng.Translator(MapTraverser({0: Scan(**kw)}, {}, 0)).plan()
     assert lf2._node.kind == "slice" and lf2._node.input.kind == "scan"
+
+
+def test_file_scan_over_several_files_and_ipc(tmp_path):
+    """The optimizer hands over the expanded path list: several local files with one schema are one device scan whose row groups are
+    numbered across the files (statistics pruning picks row groups out of every file); scan_type "ipc" goes to the IPC reader."""
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.ipc as ipc
+    import pyarrow.parquet as pq
+    from polars_amd import io, ipc_io
+    paths = []
+    for f in range(3):
+        n = 4000
+        t = pa.table({"v": np.arange(n) + 10_000 * f, "s": pa.array(np.array(["a", "b", "c" + str(f)])[np.arange(n) % 3])})
+        paths.append(str(tmp_path / f"part-{f}.parquet"))
+        pq.write_table(t, paths[-1], row_group_size=1000)
+    exprs = {0: Column(name="v"), 1: Literal(value=12_500, dtype=pl.Int64), 2: BinaryExpr(left=0, op=Operator.GtEq, right=1),
+             3: Literal(value=21_000, dtype=pl.Int64), 4: BinaryExpr(left=0, op=Operator.Lt, right=3), 5: BinaryExpr(left=2, op=Operator.And, right=4)}
+    fo = FileOptions(n_rows=None, with_columns=None, cache=True, row_index=None, rechunk=False)
+    nodes = {0: Scan(paths=["file://" + paths[0]] + paths[1:], file_info=None, hive_parts=None, predicate=PyExprIR(node=5, output_name="v"), file_options=fo,
+                     scan_type=("parquet", "{}", "null"))}
+    lf = eng.Translator(MapTraverser(nodes, exprs, 0)).plan()
+    src = lf._node.input.frame
+    assert isinstance(src, io.ParquetFrame) and src.path == paths and src.num_row_groups == 12 and src.num_rows == 12_000
+    io.reset_scans(lf._node); io.push_down(lf._node)
+    assert src.selected_row_groups() == [6, 7, 8]                    # file 1: v in [12000, 14000); file 2: v in [20000, 21000)
+    runs = []
+    for i, part in enumerate(src._dec.parts):                        # the read goes file by file: record what each file is asked for (no GPU here)
+        part.read = (lambda i: lambda rgs, cols: runs.append((i, list(rgs), list(cols))) or (f"frame{i}", 1000 * len(rgs), 8000 * len(rgs)))(i)
+    joined = []
+    real, io.concat_frames = io.concat_frames, lambda dfs: joined.append(list(dfs)) or "all"
+    try:
+        assert src._dec.read(src.selected_row_groups(), ["v"]) == ("all", 3000, 24000)
+    finally:
+        io.concat_frames = real
+    assert runs == [(1, [2, 3], ["v"]), (2, [0], ["v"])] and joined == [["frame1", "frame2"]]
+    # the same directory through the user-facing entry points: a directory, a glob, a list
+    for source in (str(tmp_path), str(tmp_path / "part-*.parquet"), paths):
+        assert io.ParquetFrame(source).path == paths
+    with pytest.raises(FileNotFoundError):
+        io.ParquetFrame(str(tmp_path / "nothing-*.parquet"))
+    # Arrow IPC files
+    ipaths = []
+    for f in range(2):
+        ipaths.append(str(tmp_path / f"b{f}.arrow"))
+        with ipc.new_file(ipaths[-1], pa.schema([("v", pa.int64())])) as w:
+            for lo in (0, 100):
+                w.write_batch(pa.record_batch({"v": np.arange(lo, lo + 100)}))
+    nodes = {0: Scan(paths=ipaths, file_info=None, hive_parts=None, predicate=None, file_options=fo, scan_type=("ipc", "{}", "null"))}
+    lf = eng.Translator(MapTraverser(nodes, {}, 0)).plan()
+    src = lf._node.frame
+    assert isinstance(src, ipc_io.IpcFrame) and src.num_row_groups == 4 and src.num_rows == 400 and list(src.schema) == ["v"]

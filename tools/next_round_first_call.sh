@@ -7,6 +7,7 @@
 #   * Parquet: string columns with PLAIN pages (host views -> plx_strview_dict_encode)                          tests/test_gpu_parquet.py [*-False-*]
 #   * Parquet: DELTA_* / BYTE_STREAM_SPLIT / INT96 columns (host decode, one upload)                           tests/test_gpu_parquet.py::test_host_decoded_encodings_arrive_on_the_device
 #   * Arrow IPC: LZ4-frame / ZSTD bodies                                                                         tests/test_gpu_ipc.py::test_compressed_bodies
+#   * scans over several files (plx_frame_concat + dictionary unification)                                       tests/test_gpu_parquet.py::test_scan_over_several_files_unifies_dictionaries
 #   * bench.py extras.parquet_ipc_scan_2e7_rows (scan_extra)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r03a
