@@ -101,18 +101,6 @@ def test_batch_subsets_and_lazy_scan(pl, tmp_path):
         assert out["n"][i] == int(mk.sum()) and out["su"][i] == int(u32[mk].sum()) & 0xffffffff       # a UInt32 sum stays UInt32 (wrapping), as in Polars
 
 
-@pytest.mark.parametrize("codec", ["lz4", "zstd"])
-def test_compressed_bodies(pl, tmp_path, codec):
-    """LZ4-frame (pyarrow's feather default) and Zstandard bodies: buffers are inflated by the library's own host decoders
-    (host_codecs.hpp), then uploaded like any other."""
-    n = 3001
-    t = table(n)
-    path = str(tmp_path / "t.arrow")
-    write(path, t, chunk=1000, compression=codec)
-    df = pl.read_ipc(path)
-    compare(df, t, t.column_names)
-
-
 def test_unsupported_ipc_files_are_status_codes(pl, tmp_path):
     t = pa.table({"a": np.arange(1000), "l": pa.array([[1]] * 1000), "ms": pa.array(np.arange(1000), pa.timestamp("ms"))})
     path2 = str(tmp_path / "nested.arrow")

@@ -58,9 +58,7 @@ def compare(df, want_table, names):
         assert np.all(values[~wvalid] == 0), name
 
 
-@pytest.mark.parametrize("compression", ["none", "snappy", "zstd"])      # zstd: pages inflated by host threads (host_codecs.hpp), then the uncompressed device path
-@pytest.mark.parametrize("version,dictionary", [("1.0", True), ("2.0", True), ("1.0", False)])
-def test_device_decode_matches_pyarrow(pl, tmp_path, compression, version, dictionary):
+def decode_and_compare(pl, tmp_path, compression, version, dictionary):
     n = 20_000
     t = table(n)
     path = str(tmp_path / "t.parquet")
@@ -71,6 +69,14 @@ def test_device_decode_matches_pyarrow(pl, tmp_path, compression, version, dicti
     compare(df, pq.read_table(path), names)
     if not dictionary:
         assert pl.read_parquet(path, columns=["s"], decoder="host")["s"].to_list() == df["s"].to_list()
+
+
+@pytest.mark.parametrize("compression", ["none", "snappy"])
+@pytest.mark.parametrize("version", ["1.0", "2.0"])
+def test_device_decode_matches_pyarrow(pl, tmp_path, compression, version):
+    """Everything decoded by kernels: Snappy, levels, dictionary and PLAIN values.  (Pages of other codecs and string columns without a
+    dictionary take host threads first: tests/test_gpu_zzz_scan_host_paths.py.)"""
+    decode_and_compare(pl, tmp_path, compression, version, True)
 
 
 def test_many_pages_many_row_groups_and_subsets(pl, tmp_path):
@@ -147,57 +153,3 @@ def test_q1_from_parquet_both_decoders(pl, orc, tmp_path):
         assert out["count_order"] == want["count_order"].tolist() and out["sum_qty"] == want["sum_qty"].tolist(), decoder
         for c in ("sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc"):
             assert np.allclose(np.array(out[c]), want[c], rtol=1e-6, atol=0), (decoder, c)
-
-
-def test_host_decoded_encodings_arrive_on_the_device(pl, tmp_path):
-    """DELTA_BINARY_PACKED / BYTE_STREAM_SPLIT / DELTA_*_BYTE_ARRAY / INT96 columns: decoded by the library's host threads
-    (parquet_reader.hpp: read_fixed_column_host, read_string_column_host), uploaded as finished columns / views."""
-    n = 30_000
-    words = np.array(["", "a", "prefix-shared-0001", "prefix-shared-0002", "prefix-shared-and-longer-0003", "zebra"])
-    m = lambda: RNG.random(n) < 0.2
-    t = pa.table({"d64": pa.array(np.cumsum(RNG.integers(-5, 50, n)), mask=m()), "d32": pa.array(RNG.integers(-2**31, 2**31, n).astype(np.int32)),
-                  "bss64": pa.array(RNG.normal(size=n), mask=m()), "bss32": pa.array(RNG.normal(size=n).astype(np.float32)),
-                  "dl": pa.array(words[RNG.integers(0, len(words), n)], mask=m()), "dba": pa.array(np.sort(words[RNG.integers(0, len(words), n)])),
-                  "plain_i64": pa.array(RNG.integers(0, 1 << 40, n))})
-    enc = {"d64": "DELTA_BINARY_PACKED", "d32": "DELTA_BINARY_PACKED", "bss64": "BYTE_STREAM_SPLIT", "bss32": "BYTE_STREAM_SPLIT", "dl": "DELTA_LENGTH_BYTE_ARRAY",
-           "dba": "DELTA_BYTE_ARRAY", "plain_i64": "PLAIN"}
-    path = str(tmp_path / "v2.parquet")
-    pq.write_table(t, path, compression="zstd", data_page_version="2.0", use_dictionary=False, column_encoding=enc, row_group_size=11_000, data_page_size=4096)
-    df = pl.read_parquet(path)
-    compare(df, t, t.column_names)
-    us = RNG.integers(-10**15, 2 * 10**15, n)
-    t96 = pa.table({"ts": pa.array(us, pa.timestamp("us"), mask=RNG.random(n) < 0.1)})
-    path96 = str(tmp_path / "int96.parquet")
-    pq.write_table(t96, path96, use_deprecated_int96_timestamps=True, compression="snappy")
-    s = pl.read_parquet(path96)["ts"]
-    values, valid = s._download()
-    want_valid = np.array([x is not None for x in t96.column("ts").to_pylist()])
-    assert s.dtype == pl.Datetime and np.array_equal(valid, want_valid) and np.array_equal(values[want_valid], us[want_valid])
-
-
-def test_scan_over_several_files_unifies_dictionaries(pl, tmp_path):
-    """A directory of files with one schema is one scan: frames are read file by file and concatenated on the device
-    (plx_frame_concat); string columns, whose dictionaries differ from file to file, are first brought onto one dictionary."""
-    rng = np.random.default_rng(5)
-    parts, paths = [], []
-    for f, (n, words) in enumerate([(3001, ["a", "b", "c"]), (1999, ["c", "zz", "a", "only here"]), (2500, ["b"])]):
-        t = pa.table({"i": pa.array(rng.integers(0, 10**9, n), mask=rng.random(n) < 0.1), "f": rng.normal(size=n), "b": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.3),
-                      "s": pa.array(np.array(words)[rng.integers(0, len(words), n)], mask=rng.random(n) < 0.2),
-                      "d": pa.array(rng.integers(0, 20000, n).astype(np.int32), pa.date32())})
-        paths.append(str(tmp_path / f"part-{f}.parquet"))
-        pq.write_table(t, paths[-1], row_group_size=777, compression=["none", "snappy", "zstd"][f], use_dictionary=f != 1)
-        parts.append(t)
-    want = pa.concat_tables(parts)
-    df = pl.read_parquet(str(tmp_path))
-    assert df.height == want.num_rows
-    compare(df, want, want.column_names)
-    cats = list(df["s"].dtype.categories)
-    assert sorted(cats) == ["a", "b", "c", "only here", "zz"] and len(set(cats)) == 5
-    # pruning across files, then a group-by on the unified string column
-    c = pl.col
-    out = pl.scan_parquet(paths).filter(c("d") >= 0).group_by("s").agg(pl.len().alias("n"), c("f").sum().alias("sf")).collect().sort_host("s")
-    s = np.array([x if x is not None else "\0" for x in want.column("s").to_pylist()]); fv = want.column("f").to_numpy()
-    for i, key in enumerate(out["s"]):
-        mk = s == (key if key is not None else "\0")
-        assert out["n"][i] == int(mk.sum()) and abs(out["sf"][i] - fv[mk].sum()) < 1e-9 * max(1.0, np.abs(fv[mk]).sum())
-    assert len(out["s"]) == 6

@@ -1,0 +1,132 @@
+"""Scan paths whose newest code is HOST code feeding device paths that had already run on hardware: pages of host-inflated codecs
+(zstd; host_codecs.hpp), string columns without a dictionary (host threads assemble Utf8Views, the device dictionary encoder takes
+over), whole-column host decodes (DELTA_*, BYTE_STREAM_SPLIT, INT96), compressed Arrow IPC bodies, scans over several files
+(plx_frame_concat + dictionary unification), and the reference's own TPC-H sample files (tests/golden/pds_heads).  Their host halves
+are pinned on the CPU (tests/test_parquet_emu_cpu.py, tests/test_ipc_cpu.py, tests/test_polars_engine_cpu.py); they were written
+after round 2's GPU minutes were spent, so this file sorts last: a surprise here cannot hide the rest of the suite behind `-x`."""
+import datetime as dt
+import os
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.ipc as ipc
+import pyarrow.parquet as pq
+import pytest
+
+import test_gpu_ipc as I
+from test_gpu_parquet import compare, decode_and_compare
+
+pytestmark = pytest.mark.gpu
+
+RNG = np.random.default_rng(78)
+PDS_HEADS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pds_heads")
+
+
+@pytest.mark.parametrize("compression,version,dictionary", [("zstd", "1.0", True), ("zstd", "2.0", True), ("zstd", "1.0", False), ("none", "1.0", False), ("snappy", "1.0", False)])
+def test_host_inflated_pages_and_plain_strings(pl, tmp_path, compression, version, dictionary):
+    decode_and_compare(pl, tmp_path, compression, version, dictionary)
+
+
+def test_host_decoded_encodings_arrive_on_the_device(pl, tmp_path):
+    """DELTA_BINARY_PACKED / BYTE_STREAM_SPLIT / DELTA_*_BYTE_ARRAY / INT96 columns: decoded by the library's host threads
+    (parquet_reader.hpp: read_fixed_column_host, read_string_column_host), uploaded as finished columns / views."""
+    n = 30_000
+    words = np.array(["", "a", "prefix-shared-0001", "prefix-shared-0002", "prefix-shared-and-longer-0003", "zebra"])
+    m = lambda: RNG.random(n) < 0.2
+    t = pa.table({"d64": pa.array(np.cumsum(RNG.integers(-5, 50, n)), mask=m()), "d32": pa.array(RNG.integers(-2**31, 2**31, n).astype(np.int32)),
+                  "bss64": pa.array(RNG.normal(size=n), mask=m()), "bss32": pa.array(RNG.normal(size=n).astype(np.float32)),
+                  "dl": pa.array(words[RNG.integers(0, len(words), n)], mask=m()), "dba": pa.array(np.sort(words[RNG.integers(0, len(words), n)])),
+                  "plain_i64": pa.array(RNG.integers(0, 1 << 40, n))})
+    enc = {"d64": "DELTA_BINARY_PACKED", "d32": "DELTA_BINARY_PACKED", "bss64": "BYTE_STREAM_SPLIT", "bss32": "BYTE_STREAM_SPLIT", "dl": "DELTA_LENGTH_BYTE_ARRAY",
+           "dba": "DELTA_BYTE_ARRAY", "plain_i64": "PLAIN"}
+    path = str(tmp_path / "v2.parquet")
+    pq.write_table(t, path, compression="zstd", data_page_version="2.0", use_dictionary=False, column_encoding=enc, row_group_size=11_000, data_page_size=4096)
+    df = pl.read_parquet(path)
+    compare(df, t, t.column_names)
+    us = RNG.integers(-10**15, 2 * 10**15, n)
+    t96 = pa.table({"ts": pa.array(us, pa.timestamp("us"), mask=RNG.random(n) < 0.1)})
+    path96 = str(tmp_path / "int96.parquet")
+    pq.write_table(t96, path96, use_deprecated_int96_timestamps=True, compression="snappy")
+    s = pl.read_parquet(path96)["ts"]
+    values, valid = s._download()
+    want_valid = np.array([x is not None for x in t96.column("ts").to_pylist()])
+    assert s.dtype == pl.Datetime and np.array_equal(valid, want_valid) and np.array_equal(values[want_valid], us[want_valid])
+
+
+def test_scan_over_several_files_unifies_dictionaries(pl, tmp_path):
+    """A directory of files with one schema is one scan: frames are read file by file and concatenated on the device
+    (plx_frame_concat); string columns, whose dictionaries differ from file to file, are first brought onto one dictionary."""
+    rng = np.random.default_rng(5)
+    parts, paths = [], []
+    for f, (n, words) in enumerate([(3001, ["a", "b", "c"]), (1999, ["c", "zz", "a", "only here"]), (2500, ["b"])]):
+        t = pa.table({"i": pa.array(rng.integers(0, 10**9, n), mask=rng.random(n) < 0.1), "f": rng.normal(size=n), "b": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.3),
+                      "s": pa.array(np.array(words)[rng.integers(0, len(words), n)], mask=rng.random(n) < 0.2),
+                      "d": pa.array(rng.integers(0, 20000, n).astype(np.int32), pa.date32())})
+        paths.append(str(tmp_path / f"part-{f}.parquet"))
+        pq.write_table(t, paths[-1], row_group_size=777, compression=["none", "snappy", "zstd"][f], use_dictionary=f != 1)
+        parts.append(t)
+    want = pa.concat_tables(parts)
+    df = pl.read_parquet(str(tmp_path))
+    assert df.height == want.num_rows
+    compare(df, want, want.column_names)
+    cats = list(df["s"].dtype.categories)
+    assert sorted(cats) == ["a", "b", "c", "only here", "zz"] and len(set(cats)) == 5
+    # pruning across files, then a group-by on the unified string column
+    c = pl.col
+    out = pl.scan_parquet(paths).filter(c("d") >= 0).group_by("s").agg(pl.len().alias("n"), c("f").sum().alias("sf")).collect().sort_host("s")
+    s = np.array([x if x is not None else "\0" for x in want.column("s").to_pylist()]); fv = want.column("f").to_numpy()
+    for i, key in enumerate(out["s"]):
+        mk = s == (key if key is not None else "\0")
+        assert out["n"][i] == int(mk.sum()) and abs(out["sf"][i] - fv[mk].sum()) < 1e-9 * max(1.0, np.abs(fv[mk]).sum())
+    assert len(out["s"]) == 6
+
+
+@pytest.mark.parametrize("codec", ["lz4", "zstd"])
+def test_compressed_bodies(pl, tmp_path, codec):
+    """LZ4-frame (pyarrow's feather default) and Zstandard bodies: buffers are inflated by the library's own host decoders
+    (host_codecs.hpp), then uploaded like any other."""
+    n = 3001
+    t = I.table(n)
+    path = str(tmp_path / "t.arrow")
+    I.write(path, t, chunk=1000, compression=codec)
+    df = pl.read_ipc(path)
+    I.compare(df, t, t.column_names)
+
+
+def test_tpch_queries_over_the_reference_sample_files(pl):
+    """Q1 and the two-table Q3 straight from the files the reference ships (written by its IPC writer: int64 / double / timestamp[us] /
+    large_string columns), through scan_ipc; expected values computed with numpy from pyarrow's read of the same files."""
+    from polars_amd import queries
+    li = ipc.open_file(os.path.join(PDS_HEADS, "lineitem.feather")).read_all()
+    od = ipc.open_file(os.path.join(PDS_HEADS, "orders.feather")).read_all()
+    col = lambda t, n: np.array(t.column(n).to_pylist()) if pa.types.is_large_string(t.column(n).type) else t.column(n).to_numpy()
+    cutoff = dt.datetime(1996, 4, 1)                                # inside the 10 rows' ship dates: the filter removes some of them
+    out = queries.q1(pl.scan_ipc(os.path.join(PDS_HEADS, "lineitem.feather")), cutoff).collect().sort_host(["l_returnflag", "l_linestatus"])
+    keep = col(li, "l_shipdate") <= np.datetime64(cutoff, "us")
+    fl, st, q, p, d, x = (col(li, n)[keep] for n in ("l_returnflag", "l_linestatus", "l_quantity", "l_extendedprice", "l_discount", "l_tax"))
+    groups = sorted(set(zip(fl.tolist(), st.tolist())))
+    assert list(zip(out["l_returnflag"], out["l_linestatus"])) == groups and len(groups) >= 2
+    for i, (a, b) in enumerate(groups):
+        m = (fl == a) & (st == b)
+        assert out["count_order"][i] == int(m.sum()) and out["sum_qty"][i] == int(q[m].sum())
+        for name, want in (("sum_base_price", p[m].sum()), ("sum_disc_price", (p[m] * (1 - d[m])).sum()), ("sum_charge", (p[m] * (1 - d[m]) * (1 + x[m])).sum()),
+                           ("avg_qty", q[m].mean()), ("avg_price", p[m].mean()), ("avg_disc", d[m].mean())):
+            assert abs(out[name][i] - want) <= 1e-6 * abs(want), (name, a, b)           # float sums: rel-tol 1e-6 (SURVEY.md 8(c) semantics 5)
+    # Q3 on (lineitem, orders): every customer passes the segment stand-in (seg_mod = 1); the date splits the ten orders
+    date = dt.datetime(1996, 2, 1)
+    lf = queries.q3(pl.scan_ipc(os.path.join(PDS_HEADS, "lineitem.feather")), pl.scan_ipc(os.path.join(PDS_HEADS, "orders.feather")), date, seg_mod=1)
+    got = lf.collect().sort_host("l_orderkey")
+    d64 = np.datetime64(date, "us")
+    odate, oprio = col(od, "o_orderdate"), col(od, "o_shippriority")
+    ok = {int(k): (int(odate[i].astype("datetime64[us]").astype(np.int64)), int(oprio[i])) for i, k in enumerate(col(od, "o_orderkey")) if odate[i] < d64}      # Datetime columns download as microseconds
+    want = {}
+    for k, sd, p, d in zip(col(li, "l_orderkey"), col(li, "l_shipdate"), col(li, "l_extendedprice"), col(li, "l_discount")):
+        if sd > d64 and int(k) in ok:
+            want[int(k)] = want.get(int(k), 0.0) + p * (1 - d)
+    assert got["l_orderkey"] == sorted(want) and len(want) >= 1
+    for i, k in enumerate(got["l_orderkey"]):
+        assert abs(got["revenue"][i] - want[k]) <= 1e-9 * want[k] and got["o_shippriority"][i] == ok[k][1] and got["o_orderdate"][i] == ok[k][0]
+    # the three-table form on these heads has no customer for any of the ten orders: an empty result with the right columns
+    empty = queries.q3_full(pl.scan_ipc(os.path.join(PDS_HEADS, "customer.feather")), pl.scan_ipc(os.path.join(PDS_HEADS, "orders.feather")),
+                            pl.scan_ipc(os.path.join(PDS_HEADS, "lineitem.feather")), date).collect()
+    assert empty.height == 0 and empty.columns == ["o_orderkey", "o_orderdate", "o_shippriority", "revenue"]

@@ -164,20 +164,14 @@ def _ipc_emu():
     return l
 
 
-@pytest.mark.parametrize("codec", [None, "lz4", "zstd"])
-def test_buffers_as_uploaded_match_pyarrow(tmp_path, codec):
-    """Every buffer of every hot-path column in every record batch, as the product's host half hands it to the upload (body compression
-    undone by host_codecs.hpp: LZ4 frames are what pyarrow's feather writer produces by default), equals pyarrow's buffer."""
-    n = 3000
-    t = sample(n).select(["i8", "u16", "i32", "i64", "f32", "f64", "b", "date", "ts", "s", "ls", "sv", "d8", "d32", "tail"])
-    path = str(tmp_path / "t.arrow")
-    write(path, t, chunk=1100, **({"compression": codec} if codec else {}))
+def _check_buffers(path, names):
+    """every buffer of the named columns in every record batch, as the host half hands it to the upload, against pyarrow's; returns the count"""
     l = _ipc_emu()
     rd = ipc.open_file(path)
     checked = 0
     for b in range(rd.num_record_batches):
         batch = rd.get_batch(b)
-        for ci, name in enumerate(t.column_names):
+        for ci, name in enumerate(names):
             arr = batch.column(ci)
             arr = arr.indices if pa.types.is_dictionary(arr.type) else arr
             for which, buf in enumerate(arr.buffers()):
@@ -196,4 +190,38 @@ def test_buffers_as_uploaded_match_pyarrow(tmp_path, codec):
                     k = min(got, len(want))
                     assert k > 0 and np.array_equal(out[:k], want[:k]), (name, b, which)
                 checked += 1
-    assert checked > 60
+    return checked
+
+
+@pytest.mark.parametrize("codec", [None, "lz4", "zstd"])
+def test_buffers_as_uploaded_match_pyarrow(tmp_path, codec):
+    """Every buffer of every hot-path column in every record batch, as the product's host half hands it to the upload (body compression
+    undone by host_codecs.hpp: LZ4 frames are what pyarrow's feather writer produces by default), equals pyarrow's buffer."""
+    n = 3000
+    t = sample(n).select(["i8", "u16", "i32", "i64", "f32", "f64", "b", "date", "ts", "s", "ls", "sv", "d8", "d32", "tail"])
+    path = str(tmp_path / "t.arrow")
+    write(path, t, chunk=1100, **({"compression": codec} if codec else {}))
+    assert _check_buffers(path, t.column_names) > 60
+
+
+PDS_HEADS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pds_heads")
+
+
+@pytest.mark.parametrize("name", ["lineitem", "orders", "customer"])
+def test_files_written_by_the_reference(name):
+    """tests/golden/pds_heads/*.feather are the reference's own TPC-H sample tables, written by ITS IPC writer (copied by
+    tests/golden/make_pds_heads.py): the library's metadata reader agrees with pyarrow on them, every column maps to
+    a hot-path dtype (int64, double, timestamp[us], large_string), and the host half delivers every buffer as pyarrow sees it."""
+    import hashlib
+    import json
+    path = os.path.join(PDS_HEADS, name + ".feather")
+    want_sum = json.load(open(os.path.join(PDS_HEADS, "SHA256.json")))["sha256"][name + ".feather"]
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == want_sum
+    t = ipc.open_file(path).read_all()
+    src = ipc_io.IpcFrame(path)
+    assert src.num_rows == t.num_rows == 10 and list(src.schema) == t.column_names
+    for f in t.schema:
+        got = src.schema[f.name]
+        want = "Categorical" if pa.types.is_large_string(f.type) else "Datetime" if pa.types.is_timestamp(f.type) else {"int64": "Int64", "double": "Float64"}[str(f.type)]
+        assert got.name == want, (f.name, got, f.type)
+    assert _check_buffers(path, t.column_names) >= t.num_columns + sum(pa.types.is_large_string(f.type) for f in t.schema)      # no nulls in these files: values (+ data) buffers only

@@ -3,11 +3,13 @@
 # starting measurements.  ~2 GPU-minutes.  usage: gpurun --timeout 400 -- 'bash tools/next_round_first_call.sh'
 #
 # CPU-verified only at the end of round 2 (the device paths they reuse had run on hardware; the new code in them is host code):
-#   * Parquet: ZSTD / GZIP / LZ4_RAW pages (host_codecs.hpp -> chunk image -> the uncompressed device path)   tests/test_gpu_parquet.py [zstd-*]
-#   * Parquet: string columns with PLAIN pages (host views -> plx_strview_dict_encode)                          tests/test_gpu_parquet.py [*-False-*]
-#   * Parquet: DELTA_* / BYTE_STREAM_SPLIT / INT96 columns (host decode, one upload)                           tests/test_gpu_parquet.py::test_host_decoded_encodings_arrive_on_the_device
-#   * Arrow IPC: LZ4-frame / ZSTD bodies                                                                         tests/test_gpu_ipc.py::test_compressed_bodies
-#   * scans over several files (plx_frame_concat + dictionary unification)                                       tests/test_gpu_parquet.py::test_scan_over_several_files_unifies_dictionaries
+#   * Parquet: ZSTD / GZIP / LZ4_RAW pages (host_codecs.hpp -> chunk image -> the uncompressed device path)
+#   * Parquet: string columns with PLAIN pages (host views -> plx_strview_dict_encode)
+#   * Parquet: DELTA_* / BYTE_STREAM_SPLIT / INT96 columns (host decode, one upload)
+#   * Arrow IPC: LZ4-frame / ZSTD bodies
+#   * scans over several files (plx_frame_concat + dictionary unification)
+#   * Q1 / Q3 over the reference's own TPC-H sample files (tests/golden/pds_heads, through scan_ipc)
+#   all of the above: tests/test_gpu_zzz_scan_host_paths.py (sorted last on purpose)
 #   * bench.py extras.parquet_ipc_scan_2e7_rows (scan_extra)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r03a
@@ -16,7 +18,7 @@ cd $R
 t0=$(date +%s)
 el() { echo "[+$(( $(date +%s) - t0 ))s] $*" | tee -a $OUT/summary.txt; }
 export PLX_SKIP_TORCH_PREIMPORT=1
-timeout 120 python -m pytest tests/test_gpu_parquet.py tests/test_gpu_ipc.py tests/test_gpu_io.py -m gpu -q --timeout 90 --durations=5 > $OUT/pytest_scan.log 2>&1; el "scan gpu tests exit $?"
+timeout 120 python -m pytest tests/test_gpu_parquet.py tests/test_gpu_ipc.py tests/test_gpu_io.py tests/test_gpu_zzz_scan_host_paths.py -m gpu -q --timeout 90 --durations=5 > $OUT/pytest_scan.log 2>&1; el "scan gpu tests exit $?"
 tail -15 $OUT/pytest_scan.log | cut -c1-250
 unset PLX_SKIP_TORCH_PREIMPORT
 PLX_SNAPPY_TIMING=1 timeout 60 python tools/parquet_bench.py 2e7 > $OUT/parquet_bench.jsonl 2> $OUT/parquet_bench.err; el "scan bench exit $?"
