@@ -64,6 +64,48 @@ def init_process_group(backend: Optional[str] = None):
     dist.init_process_group(backend=backend, rank=rank, world_size=ws)
 
 
+def scan_shard(group=None) -> Tuple[int, int]:
+    """(rank, world) for scan_parquet / scan_ipc(..., shard=...): the initialised process group's, else the torchrun environment's."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(group), dist.get_world_size(group)
+    except ImportError:
+        pass
+    rank, _, ws = world()
+    return rank, ws
+
+
+def unify_dictionaries(df, group=None, remap=None):
+    """Every rank of a sharded scan decodes ITS row groups, so a string column's codes index a per-rank dictionary.  Before codes
+    of different ranks meet (an all-gather of partial aggregates keyed by the column, an exchange by it), all ranks agree on one
+    dictionary: the category lists are all-gathered (host objects, a few KB for the TPC-H flags), the union is taken in rank order,
+    and the local codes go through a u32 remap table on the device (io.remap_codes).  Returns the frame with the remapped columns;
+    a no-op without a process group.  `remap(series, table, union)` is injectable for the CPU tests."""
+    from . import datatypes as T
+    from . import io
+    try:
+        import torch.distributed as dist
+        on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    except ImportError:
+        on = False
+    names = [c.name for c in df.get_columns() if isinstance(c.dtype, T.Categorical)]
+    if not on or not names:
+        return df
+    rank, ws = dist.get_rank(group), dist.get_world_size(group)
+    mine = {n: list(df[n].dtype.categories) for n in names}
+    every: List[Optional[dict]] = [None] * ws
+    dist.all_gather_object(every, mine, group=group)
+    remap = remap or io.remap_codes
+    cols = []
+    for c in df.get_columns():
+        if c.name in mine:
+            union, tables = io.dictionary_union([r[c.name] for r in every])
+            c = remap(c, tables[rank], union)
+        cols.append(c)
+    return type(df)(cols)
+
+
 def torch_sync():
     """Work queued on torch's current stream must be visible to the library's stream before it reads the tensors."""
     import torch

@@ -73,6 +73,9 @@ class _HostDecoder:
     def literal(self, name: str, value: Any, like: Any) -> Any:
         return _comparable(value, like)
 
+    def rows_of(self, g: int) -> int:
+        return self._pf.metadata.row_group(g).num_rows
+
     def read(self, rgs: List[int], cols: List[str]):
         from .frame import DataFrame, Series
         tbl = self._pf.read_row_groups(rgs, columns=cols) if rgs else self._pf.schema_arrow.empty_table().select(cols)
@@ -120,6 +123,12 @@ class _DeviceDecoder:
         if lg in (3, 4):
             return T.Categorical([])
         return T.PHYSICAL_TO_DTYPE[dt]
+
+    def rows_of(self, g: int) -> int:
+        import ctypes as C
+        n = C.c_int64()
+        F.check(F.lib().plx_parquet_row_group_info(self._h, g, C.byref(n), None))
+        return n.value
 
     def stats(self, g: int, name: str):
         import ctypes as C
@@ -201,14 +210,47 @@ class _DeviceDecoder:
         return items if binary else [x.decode("utf-8", "replace") for x in items]
 
 
+def dictionary_union(dictionaries):
+    """[categories of part 0, categories of part 1, ...] -> (union in first-appearance order, [u32 remap table of part i: old code -> union code])."""
+    import numpy as np
+    union, index, remaps = [], {}, []
+    for cats in dictionaries:
+        cats = list(cats)
+        remap = np.empty(len(cats), np.uint32)
+        for i, c in enumerate(cats):
+            j = index.get(c)
+            if j is None:
+                j = index[c] = len(union)
+                union.append(c)
+            remap[i] = j
+        remaps.append(remap)
+    return union, remaps
+
+
+def remap_codes(s, remap, union):
+    """Dictionary column `s` re-expressed in the dictionary `union`: its codes go through the u32 table `remap` (a gather on the device;
+    null codes stay null, the gather honours the index validity)."""
+    import numpy as np
+    from .frame import Series
+    if s.dtype.physical != F.U32:                                   # narrow codes (u8 / u16 dictionaries built by the caller): one width everywhere
+        s = s.cast(T.UInt32)
+    if len(remap) and not np.array_equal(remap, np.arange(len(remap), dtype=np.uint32)):
+        name = s.name
+        s = Series("remap", np.ascontiguousarray(remap, np.uint32), T.UInt32).gather(s)
+        s.name = name
+    else:
+        s = s.rename(s.name)
+    s.dtype = T.Categorical(union, T.UInt32)
+    s._declare_dictionary_bounds()
+    return s
+
+
 def concat_frames(dfs):
     """Vertical concatenation of device frames with equal schemas (plx_frame_concat: device-to-device copies, bitmaps merged at bit
-    granularity).  Dictionary columns are first brought onto one dictionary: codes of frame i go through remap_i (a gather on the
-    device), the union keeps first-appearance order across the frames."""
+    granularity).  Dictionary columns are first brought onto one dictionary (dictionary_union / remap_codes)."""
     import ctypes as C
 
-    import numpy as np
-    from .frame import DataFrame, Series
+    from .frame import DataFrame
     dfs = [d for d in dfs]
     if len(dfs) == 1:
         return dfs[0]
@@ -220,27 +262,8 @@ def concat_frames(dfs):
     for n in names:
         if not isinstance(dfs[0][n].dtype, T.Categorical):
             continue
-        union, index = [], {}
-        parts = []
-        for d in dfs:
-            cats = list(d[n].dtype.categories)
-            remap = np.empty(max(len(cats), 1), np.uint32)
-            for i, c in enumerate(cats):
-                j = index.get(c)
-                if j is None:
-                    j = index[c] = len(union)
-                    union.append(c)
-                remap[i] = j
-            parts.append(remap[:len(cats)] if cats else remap[:0])
-        new = []
-        for d, remap in zip(dfs, parts):
-            s = d[n]
-            if s.dtype.physical != F.U32:                               # narrow codes (u8 / u16 dictionaries built by the caller): one width for all frames
-                s = s.cast(T.UInt32)
-            if len(remap) and not np.array_equal(remap, np.arange(len(remap), dtype=np.uint32)):
-                s = Series("remap", remap, T.UInt32).gather(s)          # null codes stay null (gather honours the index validity)
-                s.name = n
-            new.append(s)
+        union, remaps = dictionary_union([d[n].dtype.categories for d in dfs])
+        new = [remap_codes(d[n], remap, union) for d, remap in zip(dfs, remaps)]
         hint[n] = T.Categorical(union, T.UInt32)
         dfs = [DataFrame([new[i] if c.name == n else c for c in d.get_columns()]) for i, d in enumerate(dfs)]
     handles = (C.c_uint64 * len(dfs))(*[d._frame_handle() for d in dfs])
@@ -254,6 +277,20 @@ def concat_frames(dfs):
     for s in res.get_columns():
         s._declare_dictionary_bounds()
     return res
+
+
+def split_by_rows(rows: Sequence[int], parts: int) -> List[List[int]]:
+    """Indices 0..len(rows)-1 cut into `parts` CONTIGUOUS runs of about equal row totals (entry i goes to the run in which the middle
+    of its row range falls): the row-group shards of a scan that several GPUs share (independent row ranges).  Runs
+    may be empty when there are fewer row groups than parts."""
+    total = sum(rows)
+    out: List[List[int]] = [[] for _ in range(parts)]
+    acc = 0
+    for i, r in enumerate(rows):
+        k = min(parts - 1, int((2 * acc + r) * parts // (2 * total))) if total > 0 else 0
+        out[k].append(i)
+        acc += r
+    return out
 
 
 class _MultiDecoder:
@@ -284,6 +321,10 @@ class _MultiDecoder:
     def stats(self, g: int, name: str):
         i, lg = self._map[g]
         return self.parts[i].stats(lg, name)
+
+    def rows_of(self, g: int) -> int:
+        i, lg = self._map[g]
+        return self.parts[i].rows_of(lg)
 
     def literal(self, name: str, value: Any, like: Any) -> Any:
         return self.parts[0].literal(name, value, like)
@@ -329,9 +370,10 @@ def expand_paths(source, suffixes=(".parquet",)) -> List[str]:
 class ParquetFrame:
     """A scan source: looks like a DataFrame to the plan lowering (`schema`, `_frame_handle()`), materialises lazily."""
 
-    def __init__(self, path, columns: Optional[Sequence[str]] = None, decoder: str = "device"):
+    def __init__(self, path, columns: Optional[Sequence[str]] = None, decoder: str = "device", shard: Optional[Tuple[int, int]] = None):
         if decoder not in ("device", "host"):
             raise ValueError("decoder must be 'device' or 'host'")
+        self._set_shard(shard)
         paths = expand_paths(path)
         self.path = paths[0] if len(paths) == 1 else paths
         make = _DeviceDecoder if decoder == "device" else _HostDecoder
@@ -343,6 +385,16 @@ class ParquetFrame:
         self._df = None
         self._loaded: Optional[Tuple[frozenset, Tuple[int, ...]]] = None
         self.last_read: Dict[str, Any] = {}
+
+    def _set_shard(self, shard) -> None:
+        """shard = (rank, world): this process reads the rank-th of `world` contiguous runs of the row groups that survive pruning
+        (split_by_rows); None = all of them."""
+        if shard is not None:
+            rank, world = int(shard[0]), int(shard[1])
+            if not (world >= 1 and 0 <= rank < world):
+                raise ValueError(f"shard {shard!r}: need 0 <= rank < world")
+            shard = (rank, world)
+        self._shard = shard
 
     @property
     def decoder(self) -> str:
@@ -420,6 +472,9 @@ class ParquetFrame:
                     break
             if ok:
                 keep.append(g)
+        if getattr(self, "_shard", None) is not None and self._shard[1] > 1:
+            rank, world = self._shard
+            keep = [keep[i] for i in split_by_rows([self._dec.rows_of(g) for g in keep], world)[rank]]
         return keep
 
     # -- materialisation ---------------------------------------------------------------------------------------------------
@@ -456,12 +511,14 @@ def _comparable(value: Any, like: Any) -> Any:
     raise TypeError("statistics and literal are not comparable")
 
 
-def scan_parquet(path, columns: Optional[Sequence[str]] = None, decoder: str = "device"):
+def scan_parquet(path, columns: Optional[Sequence[str]] = None, decoder: str = "device", shard: Optional[Tuple[int, int]] = None):
     """LazyFrame over a Parquet file, a directory / glob of files or a list of them (mirrors polars.scan_parquet for the path's dtypes).
     Nothing is read until collect().
-    decoder="device": column chunks are decoded on the GPU (UNCOMPRESSED / SNAPPY / ZSTD / GZIP / LZ4_RAW, PLAIN / dictionary pages); "host": pyarrow."""
+    decoder="device": column chunks are decoded on the GPU (UNCOMPRESSED / SNAPPY / ZSTD / GZIP / LZ4_RAW, PLAIN / dictionary pages); "host": pyarrow.
+    shard=(rank, world): one process per GPU, each reading its own run of row groups (polars_amd.dist.scan_shard() gives the pair of the
+    running process group; string columns then need dist.unify_dictionaries before their codes meet another rank's)."""
     from .frame import LazyFrame
-    return LazyFrame(P.Node("scan", frame=ParquetFrame(path, columns, decoder)))
+    return LazyFrame(P.Node("scan", frame=ParquetFrame(path, columns, decoder, shard)))
 
 
 def read_parquet(path, columns: Optional[Sequence[str]] = None, decoder: str = "device"):

@@ -59,6 +59,9 @@ class _IpcDecoder:
     def stats(self, g: int, name: str):
         return None
 
+    def rows_of(self, g: int) -> int:
+        return self.batch_info(g)["rows"]
+
     def literal(self, name: str, value: Any, like: Any) -> Any:
         raise TypeError("ipc files carry no statistics")
 
@@ -108,7 +111,8 @@ class _IpcDecoder:
 class IpcFrame(ParquetFrame):
     """Scan source over an Arrow IPC file: the same lazy materialisation and projection pushdown as ParquetFrame."""
 
-    def __init__(self, path, columns: Optional[Sequence[str]] = None):
+    def __init__(self, path, columns: Optional[Sequence[str]] = None, shard=None):
+        self._set_shard(shard)
         paths = expand_paths(path, suffixes=(".arrow", ".feather", ".ipc"))
         self.path = paths[0] if len(paths) == 1 else paths
         self._dec = _IpcDecoder(paths[0]) if len(paths) == 1 else _MultiDecoder(paths, _IpcDecoder)
@@ -121,10 +125,10 @@ class IpcFrame(ParquetFrame):
         self.last_read = {}
 
 
-def scan_ipc(path, columns: Optional[Sequence[str]] = None):
+def scan_ipc(path, columns: Optional[Sequence[str]] = None, shard=None):
     """LazyFrame over an Arrow IPC (Feather V2) file (mirrors polars.scan_ipc for the path's dtypes); uncompressed, LZ4-frame and Zstandard bodies."""
     from .frame import LazyFrame
-    return LazyFrame(P.Node("scan", frame=IpcFrame(path, columns)))
+    return LazyFrame(P.Node("scan", frame=IpcFrame(path, columns, shard)))
 
 
 def read_ipc(path, columns: Optional[Sequence[str]] = None):

@@ -101,6 +101,48 @@ def main():
     np.savez(os.path.join(out_dir, f"q3_in_rank{rank}.npz"), **{"p_" + c: t.numpy() for c, t in probe.items()}, **{"b_" + c: t.numpy() for c, t in build.items()})
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), key=key.numpy(), flag=flag.numpy(), v=v.numpy(), x=x.numpy(),
              **{f"g_{k}": t.numpy() for k, t in g.items()}, **{f"s_{k}": t.numpy() for k, t in s.items()})
+    # (f) a scan shared by the ranks: every rank takes its run of row groups (io.split_by_rows through scan_shard()), decodes them --
+    # here with pyarrow, the planning and the dictionary agreement are what is under test -- and the per-rank dictionaries of the
+    # string column are unified (dist.unify_dictionaries; the device remap is replaced by its numpy twin)
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from polars_amd import datatypes as T
+    from polars_amd import io
+    ds = os.path.join(out_dir, "dataset")
+    if rank == 0:
+        os.makedirs(ds)
+        r2 = np.random.default_rng(77)
+        for f, n_f in enumerate((5000, 12000, 3000)):
+            words = np.array([f"w{f}", "shared", f"only{f}", "zz"])
+            pq.write_table(pa.table({"k": np.arange(n_f) + 100_000 * f, "s": pa.array(words[r2.integers(0, 4, n_f)], mask=r2.random(n_f) < 0.1)}),
+                           os.path.join(ds, f"part-{f}.parquet"), row_group_size=1000 + 500 * f)
+    dist.barrier()
+    assert pdist.scan_shard() == (rank, ws)
+    src = io.ParquetFrame(ds, shard=pdist.scan_shard())
+    src.request(None, [("k", io.F.OP_GE, 2000)])                    # prunes the first two row groups of part-0 on every rank alike
+    rgs = src.selected_row_groups()
+    tables = []
+    for g in rgs:
+        i, lg = src._dec._map[g]
+        tables.append(pq.ParquetFile(src._dec.paths[i]).read_row_group(lg))
+    tbl = pa.concat_tables(tables) if tables else pa.table({"k": pa.array([], pa.int64()), "s": pa.array([], pa.string())})
+    enc = tbl.column("s").combine_chunks().dictionary_encode()
+
+    class Col:
+        def __init__(self, name, codes, valid, dtype):
+            self.name, self.codes, self.valid, self.dtype = name, codes, valid, dtype
+
+    class Frame:
+        def __init__(self, cols): self.cols = list(cols)
+        def get_columns(self): return list(self.cols)
+        def __getitem__(self, n): return next(c for c in self.cols if c.name == n)
+
+    valid = np.array([x is not None for x in enc.indices.to_pylist()], bool)
+    codes = np.array([x or 0 for x in enc.indices.to_pylist()], np.uint32)
+    local = Frame([Col("k", tbl.column("k").to_numpy(), None, T.Int64), Col("s", codes, valid, T.Categorical(enc.dictionary.to_pylist(), T.UInt32))])
+    one = pdist.unify_dictionaries(local, remap=lambda c, table, union: Col(c.name, table[c.codes] if len(table) else c.codes, c.valid, T.Categorical(union, T.UInt32)))
+    np.savez(os.path.join(out_dir, f"scan_rank{rank}.npz"), rgs=np.array(rgs, np.int64), k=one["k"].codes, codes=one["s"].codes, valid=one["s"].valid,
+             union=np.array(list(one["s"].dtype.categories), dtype=object), allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -49,6 +49,26 @@ def test_sharded_groupby_and_exchange(tmp_path, ws):
         assert np.array_equal(got["l_orderkey"][order], exp["l_orderkey"]), mode
         assert np.array_equal(got["o_orderdate"][order], exp["o_orderdate"]) and np.array_equal(got["o_shippriority"][order], exp["o_shippriority"]), mode
         assert np.allclose(got["revenue"][order], exp["revenue"], rtol=1e-9), mode
+    # the shared scan: shards are disjoint contiguous runs covering every row group the predicate keeps, every rank ends up with the
+    # SAME dictionary, and codes decoded through it give back the file's strings
+    import pyarrow.parquet as pq
+    scans = [np.load(f, allow_pickle=True) for f in sorted(glob.glob(str(tmp_path / "scan_rank*.npz")))]
+    assert len(scans) == ws
+    got_rgs = [s["rgs"].tolist() for s in scans]
+    flat = [g for r in got_rgs for g in r]
+    n_groups = 5 + 8 + 2                                              # 5000 / 1000, 12000 / 1500, 3000 / 2000 (rounded up)
+    assert flat == list(range(2, n_groups)), got_rgs                  # in rank order: contiguous, disjoint, complete; k >= 2000 dropped two
+    rows = [len(s["k"]) for s in scans]
+    assert max(rows) - min(rows) <= 2000 + 1000, rows                 # balanced to within about a row group
+    union = scans[0]["union"].tolist()
+    assert all(s["union"].tolist() == union for s in scans) and len(set(union)) == len(union) == 8
+    whole = pq.read_table(str(tmp_path / "dataset")).to_pandas().sort_values("k")
+    whole = whole[whole["k"] >= 2000 - 0]                              # row groups 0 and 1 of part-0 hold k < 2000 exactly
+    k = np.concatenate([s["k"] for s in scans]); order = np.argsort(k, kind="stable")
+    words = np.array([union[c] if ok else None for s in scans for c, ok in zip(s["codes"].tolist(), s["valid"].tolist())], dtype=object)[order]
+    assert np.array_equal(k[order], whole["k"].to_numpy())
+    want = whole["s"].to_numpy()
+    assert all((a is None and (b is None or b != b)) or a == b for a, b in zip(words.tolist(), want.tolist()))
     files = sorted(glob.glob(str(tmp_path / "rank*.npz")))
     assert len(files) == ws
     parts = [np.load(f) for f in files]

@@ -130,3 +130,26 @@ def test_tpch_queries_over_the_reference_sample_files(pl):
     empty = queries.q3_full(pl.scan_ipc(os.path.join(PDS_HEADS, "customer.feather")), pl.scan_ipc(os.path.join(PDS_HEADS, "orders.feather")),
                             pl.scan_ipc(os.path.join(PDS_HEADS, "lineitem.feather")), date).collect()
     assert empty.height == 0 and empty.columns == ["o_orderkey", "o_orderdate", "o_shippriority", "revenue"]
+
+
+def test_row_group_shards_of_one_scan_add_up(pl, tmp_path):
+    """scan_parquet(..., shard=(rank, world)): what each of `world` processes would read, here one after the other in one process --
+    the shards' frames concatenated (dictionaries unified on the way) are the whole file, and per-shard partial aggregates add up."""
+    rng = np.random.default_rng(6)
+    n = 50_000
+    t = pa.table({"k": np.arange(n), "v": pa.array(rng.integers(0, 1000, n), mask=rng.random(n) < 0.1), "s": pa.array(np.array(["x", "y", "z", "w"])[(np.arange(n) // 9000) % 4])})
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, row_group_size=3000, compression="snappy")
+    from polars_amd import io
+    world = 3
+    shards = []
+    for rank in range(world):
+        src = io.ParquetFrame(path, shard=(rank, world))
+        src.request(None, [])
+        shards.append(src.materialise())
+    assert sum(d.height for d in shards) == n and min(d.height for d in shards) >= n // world - 3000
+    compare(io.concat_frames(shards), t, t.column_names)
+    c = pl.col
+    total = sum(pl.scan_parquet(path, shard=(rank, world)).filter(c("k") >= 10_000).select(c("v").sum().alias("sv")).collect()["sv"].to_list()[0] for rank in range(world))
+    v = t.column("v").to_numpy(zero_copy_only=False)
+    assert total == int(np.nansum(v[10_000:]))

@@ -174,3 +174,22 @@ def test_a_plan_that_reads_no_column_keeps_one_for_the_row_count(lineitem_file):
     src = lf._node.input.frame
     cols = src.selected_columns()
     assert len(cols) == 1 and src.schema[cols[0]].np_dtype.itemsize <= 8      # COUNT(*) must see num_rows rows, not an empty frame
+
+
+def test_split_by_rows_and_dictionary_union():
+    """The two pure pieces under a scan that several processes share: contiguous, balanced row-group runs and one dictionary for all."""
+    from polars_amd import io
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        rows = rng.integers(0, 1000, int(rng.integers(0, 40))).tolist()
+        parts = int(rng.integers(1, 10))
+        runs = io.split_by_rows(rows, parts)
+        assert len(runs) == parts and [i for r in runs for i in r] == list(range(len(rows)))          # contiguous, in order, complete
+        if rows and sum(rows):
+            loads = [sum(rows[i] for i in r) for r in runs]
+            assert max(loads) <= sum(rows) / parts + max(rows)                                         # never more than one row group over the fair share
+    assert io.split_by_rows([10] * 8, 4) == [[0, 1], [2, 3], [4, 5], [6, 7]] and io.split_by_rows([1, 1, 1, 1, 1, 100], 3) == [[0, 1, 2, 3, 4], [5], []]
+    union, remaps = io.dictionary_union([["a", "b"], ["b", "c", "a", "b"], [], ["d"]])
+    assert union == ["a", "b", "c", "d"] and [r.tolist() for r in remaps] == [[0, 1], [1, 2, 0, 1], [], [3]] and all(r.dtype == np.uint32 for r in remaps)
+    with pytest.raises(ValueError):
+        io.ParquetFrame.__new__(io.ParquetFrame)._set_shard((2, 2))
