@@ -470,8 +470,9 @@ int plx_datagen_id_views(int64_t n_rows, uint64_t seed, uint32_t stream, int64_t
  * encoded, one DMA per chunk -- and are decoded by kernels: Snappy, RLE / bit-packed hybrid levels and dictionary indices, PLAIN
  * values, null expansion, integer narrowing.
  *   plx_parquet_open            footer + schema; works without a GPU (planning / row-group pruning on any machine)
- *   plx_parquet_column_info     leaf column -> name, plx_dtype (-1: outside the hot path's dtypes: nested, decimal, INT96, ...),
- *                               logical kind (0 none, 1 Date = days in PLX_I32, 2 Datetime[us] in PLX_I64, 3 String / 4 Binary =
+ *   plx_parquet_column_info     leaf column -> name, plx_dtype (-1: outside the hot path's dtypes: nested, decimal, ...),
+ *                               logical kind (0 none, 1 Date = days in PLX_I32, 2 / 5 / 6 Datetime[us / ms / ns] in PLX_I64 -- the stored
+ *                               unit is kept; INT96 columns come out as ns like the reference's default --, 3 String / 4 Binary =
  *                               PLX_U32 dictionary codes + plx_parquet_categories), nullable.  `name` stays valid until the next
  *                               call on the same thread.
  *   plx_parquet_chunk_info      codec, bit mask of the page encodings, sizes, and the chunk statistics as scalars of the column's

@@ -19,7 +19,7 @@ struct Unsupported : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
-enum LogicalOut { LO_NONE = 0, LO_DATE = 1, LO_DATETIME_US = 2, LO_STRING = 3, LO_BINARY = 4 };
+enum LogicalOut { LO_NONE = 0, LO_DATE = 1, LO_DATETIME_US = 2, LO_STRING = 3, LO_BINARY = 4, LO_DATETIME_MS = 5, LO_DATETIME_NS = 6 };
 
 struct ColType {
   int dtype = -1;           // plx_dtype; -1: outside the hot path
@@ -63,7 +63,9 @@ inline ColType col_type(const Field& f) {
       return t;
     case TY_TIMESTAMP:
       if (f.unit == 2) { t.dtype = PLX_I64; t.logical = LO_DATETIME_US; t.width = 8; return t; }
-      t.why = "timestamp unit other than us";
+      if (f.unit == 1) { t.dtype = PLX_I64; t.logical = LO_DATETIME_MS; t.width = 8; return t; }
+      if (f.unit == 3) { t.dtype = PLX_I64; t.logical = LO_DATETIME_NS; t.width = 8; return t; }
+      t.why = "timestamp in seconds";                    // the reference multiplies these into milliseconds on import: not on this path
       return t;
     case TY_UTF8: case TY_LARGE_UTF8: case TY_UTF8_VIEW:
       t.dtype = PLX_U32; t.logical = LO_STRING; t.strings = true; return t;

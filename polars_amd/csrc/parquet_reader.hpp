@@ -64,7 +64,7 @@ inline std::unique_ptr<File> open_file(const std::string& path) {
 }
 
 // ---- leaf -> device dtype -------------------------------------------------------------------------------------------------------------
-enum LogicalOut { LO_NONE = 0, LO_DATE = 1, LO_DATETIME_US = 2, LO_STRING = 3, LO_BINARY = 4 };
+enum LogicalOut { LO_NONE = 0, LO_DATE = 1, LO_DATETIME_US = 2, LO_STRING = 3, LO_BINARY = 4, LO_DATETIME_MS = 5, LO_DATETIME_NS = 6 };
 
 struct LeafType {
   int dtype = -1;          // plx_dtype, -1: outside the hot path (why says what it is)
@@ -93,7 +93,9 @@ inline LeafType leaf_type(const Leaf& l) {
       if (l.logical == LG_NONE) { t.dtype = PLX_I64; return t; }
       if (l.logical == LG_INT && l.int_bits == 64) { t.dtype = l.int_signed ? PLX_I64 : PLX_U64; return t; }
       if (l.logical == LG_TIMESTAMP_MICROS) { t.dtype = PLX_I64; t.logical = LO_DATETIME_US; return t; }
-      t.why = l.logical == LG_DECIMAL ? "decimal" : (l.logical == LG_TIMESTAMP_MILLIS || l.logical == LG_TIMESTAMP_NANOS) ? "timestamp unit other than us" : "annotated INT64";
+      if (l.logical == LG_TIMESTAMP_MILLIS) { t.dtype = PLX_I64; t.logical = LO_DATETIME_MS; return t; }       // the stored unit is kept, as the reference keeps it
+      if (l.logical == LG_TIMESTAMP_NANOS) { t.dtype = PLX_I64; t.logical = LO_DATETIME_NS; return t; }        // (Datetime("ms" | "us" | "ns"): schema/convert.rs)
+      t.why = l.logical == LG_DECIMAL ? "decimal" : "annotated INT64";
       return t;
     case PT_FLOAT: t.dtype = PLX_F32; t.src_width = 4; return t;
     case PT_DOUBLE: t.dtype = PLX_F64; t.src_width = 8; return t;
@@ -101,7 +103,9 @@ inline LeafType leaf_type(const Leaf& l) {
       if (l.logical == LG_STRING || l.logical == LG_NONE) { t.dtype = PLX_U32; t.logical = l.logical == LG_STRING ? LO_STRING : LO_BINARY; return t; }
       t.why = "annotated BYTE_ARRAY";
       return t;
-    case PT_INT96: t.dtype = PLX_I64; t.logical = LO_DATETIME_US; t.src_width = 12; return t;     // legacy timestamps: converted by host threads (read_fixed_column_host)
+    // legacy timestamps, converted by host threads (read_fixed_column_host) to NANOSECONDS like the reference's default
+    // (int96_coerce_to_timeunit = Nanosecond, crates/polars-parquet/src/arrow/read/schema/mod.rs:32)
+    case PT_INT96: t.dtype = PLX_I64; t.logical = LO_DATETIME_NS; t.src_width = 12; return t;
     default: t.why = l.logical == LG_DECIMAL ? "decimal (FIXED_LEN_BYTE_ARRAY)" : "FIXED_LEN_BYTE_ARRAY"; return t;
   }
 }
@@ -310,7 +314,9 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
             throw FormatError("v2 level bytes exceed the page");
           const size_t lv = (size_t)h.def_len + (size_t)h.rep_len;
           inflate.push_back({host + pos, lv, image + ipos, lv, true});
-          inflate.push_back({host + pos + lv, (size_t)h.compressed_size - lv, image + ipos + lv, out - lv, !h.is_compressed});
+          const bool no_values = (size_t)h.compressed_size == lv;     // all-null page without value bytes: nothing to inflate, whatever is_compressed says
+          if (no_values && out != lv) throw FormatError("v2 page without value bytes whose sizes differ");
+          inflate.push_back({host + pos + lv, (size_t)h.compressed_size - lv, image + ipos + lv, out - lv, !h.is_compressed || no_values});
         } else {
           inflate.push_back({host + pos, (size_t)h.compressed_size, image + ipos, out, false});
         }
@@ -390,7 +396,10 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
           if (h.def_len < 0 || h.def_len > h.compressed_size) throw FormatError("v2 level bytes exceed the page");
           if (!optional && h.def_len != 0) throw FormatError("definition levels in a required column");
           p.v2_def_len = (uint32_t)h.def_len;
-          if (codec_on && h.is_compressed) {
+          // an all-null v2 page may carry NO value bytes at all although is_compressed is set (parquet-mr writes them; the reference's
+          // fixture empty_datapage_v2.snappy.parquet, py-polars/tests/unit/io/test_parquet.py:848): nothing to inflate
+          if (h.is_compressed && h.compressed_size == h.def_len && h.uncompressed_size != h.def_len) throw FormatError("v2 page without value bytes whose sizes differ");
+          if (codec_on && h.is_compressed && h.compressed_size > h.def_len) {
             p.flags |= PF_COMPRESSED;
             job = jobs.size();
             jobs.push_back(DecompJob{payload + (uint64_t)h.def_len, 0, (uint32_t)(h.compressed_size - h.def_len), (uint32_t)(h.uncompressed_size - h.def_len)});
@@ -655,6 +664,7 @@ inline void make_view(uint8_t* dst, const uint8_t* bytes, uint32_t len, uint32_t
 }
 
 inline void page_inflate(int codec_id, const uint8_t* src, size_t n, uint8_t* dst, size_t out) {
+  if (n == 0 && out == 0) return;        // the value section of an all-null v2 page
   try {
     if (codec_id == CODEC_UNCOMPRESSED) { if (n != out) throw FormatError("uncompressed page whose two sizes differ"); if (n) memcpy(dst, src, n); }
     else if (codec_id == CODEC_SNAPPY) { std::vector<uint8_t> v = snappy_decompress_host(src, n, out); if (out) memcpy(dst, v.data(), out); }
@@ -917,9 +927,14 @@ template <class B> ColumnResult<B> read_fixed_column_host(B& be, File& f, const 
   };
   auto plain_at = [&](const uint8_t* v, size_t i) -> uint64_t {
     if (int96) {
-      int64_t nanos; int32_t jd;
+      // int96_to_i64_ns (crates/polars-parquet/src/parquet/types.rs:222-234): Julian day (unsigned) and nanoseconds of the day ->
+      // nanoseconds since the epoch, i64::MAX where that does not fit (simple.rs:731-733)
+      int64_t nanos; uint32_t jd;
       memcpy(&nanos, v + 12 * i, 8); memcpy(&jd, v + 12 * i + 8, 4);
-      return (uint64_t)(((int64_t)jd - 2440588) * 86400000000LL + nanos / 1000);
+      const int64_t seconds = ((int64_t)jd - 2440588) * 86400;
+      int64_t ns, sum;
+      if (__builtin_mul_overflow(seconds, (int64_t)1000000000, &ns) || __builtin_add_overflow(ns, nanos, &sum)) return (uint64_t)INT64_MAX;
+      return (uint64_t)sum;
     }
     if (sw == 8) return load_u64(v + 8 * i);
     return (uint64_t)load_u32(v + 4 * i);

@@ -48,7 +48,32 @@ UInt64 = DataType("UInt64", F.U64, np.uint64)
 Float32 = DataType("Float32", F.F32, np.float32)
 Float64 = DataType("Float64", F.F64, np.float64)
 Date = DataType("Date", F.I32, np.int32)          # days since epoch
-Datetime = DataType("Datetime", F.I64, np.int64)  # microseconds since epoch
+
+
+class DatetimeType(DataType):
+    """Datetime(time_unit, time_zone): i64 ticks since the epoch in "ms" | "us" | "ns" (crates/polars-core/src/datatypes/time_unit.rs).
+    `Datetime` is the "us" instance (what python datetimes and TPC-H dates become); `Datetime("ns")` makes another, as
+    polars.Datetime("ns") does.  All compare equal as dtypes (`dt == Datetime` asks "is this a Datetime"); `time_unit` tells them apart.
+    The time zone is carried, never interpreted: the physical values are UTC instants either way."""
+    UNITS = ("ms", "us", "ns")
+
+    def __init__(self, time_unit: str = "us", time_zone=None):
+        if time_unit not in self.UNITS:
+            raise ValueError(f"time unit {time_unit!r} (ms, us or ns)")
+        super().__init__("Datetime", F.I64, np.int64)
+        self.time_unit, self.time_zone = time_unit, time_zone
+
+    def __call__(self, time_unit: str = "us", time_zone=None) -> "DatetimeType":
+        return DatetimeType(time_unit, time_zone)
+
+    def __repr__(self) -> str:
+        return "Datetime" if self.time_unit == "us" and self.time_zone is None else f"Datetime(time_unit={self.time_unit!r}, time_zone={self.time_zone!r})"
+
+    def ticks_per_second(self) -> int:
+        return {"ms": 1_000, "us": 1_000_000, "ns": 1_000_000_000}[self.time_unit]
+
+
+Datetime = DatetimeType("us")  # microseconds since epoch
 
 
 class Categorical(DataType):
@@ -61,6 +86,7 @@ class Categorical(DataType):
         npdt = index_dtype.np_dtype if index_dtype is not None else np.uint32
         super().__init__("Categorical", phys, npdt)
         self.categories = categories if hasattr(categories, "_load") else list(categories)   # a device-built dictionary stays lazy
+        self.from_strings = False          # True: the column was plain strings where it came from (a file scan); to_arrow() gives strings back
 
     def __eq__(self, other) -> bool:
         return isinstance(other, Categorical)

@@ -78,12 +78,14 @@ class Series:
         if pa.types.is_dictionary(arr.type) or pa.types.is_string(arr.type) or pa.types.is_large_string(arr.type):
             d = arr if pa.types.is_dictionary(arr.type) else arr.dictionary_encode()
             logical = T.Categorical(d.dictionary.to_pylist())
+            logical.from_strings = not pa.types.is_dictionary(arr.type)
             arr = d.indices.cast(pa.uint32())
         elif pa.types.is_date32(arr.type):
             logical = T.Date
         elif pa.types.is_timestamp(arr.type):
-            logical = T.Datetime
-            arr = arr.cast(pa.timestamp("us"))
+            if arr.type.unit == "s":                      # the reference has no seconds unit: such arrays become milliseconds on import
+                arr = arr.cast(pa.timestamp("ms", arr.type.tz))
+            logical = T.Datetime if arr.type.unit == "us" and arr.type.tz is None else T.Datetime(arr.type.unit, arr.type.tz)
         a, s = F.ArrowArray(), F.ArrowSchema()
         arr._export_to_c(C.addressof(a), C.addressof(s))
         h = C.c_uint64()
@@ -208,10 +210,13 @@ class Series:
         return t
 
     def to_arrow(self):
+        """Arrow array with the LOGICAL type: the library exports the physical buffers (plx_column_export_arrow), the annotations are put
+        back here -- Date -> date32, Datetime -> timestamp[unit, tz], dictionary codes -> a dictionary array (or, for columns that were
+        strings in the file they were scanned from, large_string: what the reference's scan of that file yields)."""
         import pyarrow as pa
         a, s = F.ArrowArray(), F.ArrowSchema()
         F.check(F.lib().plx_column_export_arrow(self._h, C.byref(a), C.byref(s)))
-        return pa.Array._import_from_c(C.addressof(a), C.addressof(s))
+        return logical_arrow(pa.Array._import_from_c(C.addressof(a), C.addressof(s)), self.dtype)
 
     # -- kernel-level operators (one reference kernel family each) ------------------------------
     def _binary_col(self, fn, op: int, other: "Series") -> "Series":
@@ -335,6 +340,24 @@ class Series:
 
     def __repr__(self) -> str:
         return f"Series({self.name!r}, {self.dtype}, len={len(self)})"
+
+
+def logical_arrow(arr, dtype: T.DataType):
+    """physical Arrow array + mirror dtype -> Arrow array of the logical type (host side, no copy for Date / Datetime)"""
+    import pyarrow as pa
+    if isinstance(dtype, T.Categorical):
+        cats = list(dtype.categories)
+        if not cats and arr.null_count != len(arr):
+            return arr                                    # codes without a known dictionary stay codes
+        binary = any(isinstance(c, bytes) for c in cats)
+        values = pa.array(cats, pa.large_binary() if binary else pa.large_string())
+        d = pa.DictionaryArray.from_arrays(arr.cast(pa.uint32()), values)
+        return d.cast(values.type) if getattr(dtype, "from_strings", False) else d
+    if dtype.name == "Date":
+        return arr.cast(pa.date32())
+    if isinstance(dtype, T.DatetimeType):
+        return arr.cast(pa.timestamp(dtype.time_unit, dtype.time_zone))
+    return arr
 
 
 def arg_sort_by(by: Sequence["Series"], descending=False, nulls_last=False, limit: int = -1) -> "Series":

@@ -33,9 +33,9 @@ def _mirror_dtype(t) -> T.DataType:
     if pa.types.is_dictionary(t) or pa.types.is_string(t) or pa.types.is_large_string(t):
         return T.Categorical([])          # dictionary codes on the device; the dictionary is known after the read
     if pa.types.is_timestamp(t):
-        if t.unit != "us":
-            raise TypeError(f"timestamp unit {t.unit} (only us is on the hot path)")
-        return T.Datetime
+        if t.unit == "s":
+            raise TypeError("timestamp in seconds (ms, us and ns are on the hot path)")
+        return T.Datetime if t.unit == "us" and t.tz is None else T.Datetime(t.unit, t.tz)
     if pa.types.is_date32(t):
         return T.Date
     m = {pa.int8(): T.Int8, pa.int16(): T.Int16, pa.int32(): T.Int32, pa.int64(): T.Int64, pa.uint8(): T.UInt8, pa.uint16(): T.UInt16, pa.uint32(): T.UInt32,
@@ -82,6 +82,16 @@ class _HostDecoder:
         return DataFrame([Series.from_arrow(n, tbl.column(n)) for n in cols]), tbl.num_rows, tbl.nbytes
 
 
+def string_column_dtype(categories=()) -> T.Categorical:
+    """dtype of a column that is plain strings in the file: u32 dictionary codes here, strings again in to_arrow()"""
+    dt = T.Categorical(categories, T.UInt32)
+    dt.from_strings = True
+    return dt
+
+
+DATETIME_UNITS = {2: "us", 5: "ms", 6: "ns"}      # the library's logical kinds of Datetime columns (include/polars_amd.h: plx_parquet_column_info)
+
+
 class _DeviceDecoder:
     """decoder="device" (default): the library parses the footer itself (plx_parquet_open: no pyarrow anywhere on this path), the
     selected column chunks are copied to HBM as stored and decoded by kernels (plx_parquet_read; polars_amd/csrc/parquet*.{hpp,cpp},
@@ -115,13 +125,13 @@ class _DeviceDecoder:
     def dtype(self, name: str) -> T.DataType:
         _, dt, lg, _ = self._info[name]
         if dt < 0:
-            raise TypeError(f"parquet column {name!r} has a type outside the hot path (nested, decimal, INT96, non-us timestamp, ...)")
+            raise TypeError(f"parquet column {name!r} has a type outside the hot path (nested, decimal, ...)")
         if lg == 1:
             return T.Date
-        if lg == 2:
-            return T.Datetime
+        if lg in DATETIME_UNITS:
+            return T.Datetime if lg == 2 else T.Datetime(DATETIME_UNITS[lg])
         if lg in (3, 4):
-            return T.Categorical([])
+            return string_column_dtype()
         return T.PHYSICAL_TO_DTYPE[dt]
 
     def rows_of(self, g: int) -> int:
@@ -140,19 +150,24 @@ class _DeviceDecoder:
         if not has.value:
             return None
         pick = (lambda s: s.f64) if dt == F.F64 else (lambda s: float(s.f32)) if dt == F.F32 else (lambda s: s.u) if dt in (F.U8, F.U16, F.U32, F.U64) else \
-               (lambda s: bool(s.u)) if dt == F.BOOL else (lambda s: s.i)
+               (lambda s: bool(s.u)) if dt == F.BOOL else (lambda s: s.i // 1000) if lg == 6 else (lambda s: s.i)       # Datetime[ns]: in microseconds, see literal()
         return pick(mn), pick(mx)
 
     def literal(self, name: str, value: Any, like: Any) -> Any:
         """The literal in the PHYSICAL domain the library reports statistics in (Date = days, Datetime = microseconds)."""
         lg = self._info[name][2]
-        if lg == 2:
+        if lg in DATETIME_UNITS:
+            us = None
             if isinstance(value, _dt.datetime):
                 v = value.replace(tzinfo=None) if value.tzinfo is None else value.astimezone(_dt.timezone.utc).replace(tzinfo=None)
                 d = v - _EPOCH
-                return (d.days * 86400 + d.seconds) * 1_000_000 + d.microseconds
-            if isinstance(value, _dt.date):
-                return (value - _EPOCH.date()).days * 86_400_000_000
+                us = (d.days * 86400 + d.seconds) * 1_000_000 + d.microseconds
+            elif isinstance(value, _dt.date):
+                us = (value - _EPOCH.date()).days * 86_400_000_000
+            if us is not None:
+                # the comparison happens in the coarser of the two units (plan.Lowering._lower_mixed_time_units): ms columns against the
+                # floor-divided literal; ns columns are floor-divided into microseconds -- stats() does that to their min / max
+                return us // 1000 if lg == 5 else us
         if lg == 1:
             if isinstance(value, _dt.datetime):
                 return (value.date() - _EPOCH.date()).days
@@ -185,11 +200,11 @@ class _DeviceDecoder:
                 sd = C.c_uint64()
                 if F.lib().plx_parquet_column_strdict(self._h, i, C.byref(sd)) == 0:   # PLAIN string pages: dictionary built on the device, downloaded lazily
                     from .frame import DeviceDictionary
-                    hint[n] = T.Categorical(DeviceDictionary(sd.value, binary=lg == 4), T.UInt32)
+                    hint[n] = string_column_dtype(DeviceDictionary(sd.value, binary=lg == 4))
                 else:
-                    hint[n] = T.Categorical(self._categories(i, binary=lg == 4), T.UInt32)
+                    hint[n] = string_column_dtype(self._categories(i, binary=lg == 4))
             elif lg:
-                hint[n] = T.Date if lg == 1 else T.Datetime
+                hint[n] = self.dtype(n)
         df = DataFrame._from_frame_handle(fh.value, hint)
         for s in df.get_columns():
             s._declare_dictionary_bounds()
@@ -240,7 +255,9 @@ def remap_codes(s, remap, union):
         s.name = name
     else:
         s = s.rename(s.name)
+    from_strings = getattr(s.dtype, "from_strings", False)
     s.dtype = T.Categorical(union, T.UInt32)
+    s.dtype.from_strings = from_strings
     s._declare_dictionary_bounds()
     return s
 
@@ -264,7 +281,7 @@ def concat_frames(dfs):
             continue
         union, remaps = dictionary_union([d[n].dtype.categories for d in dfs])
         new = [remap_codes(d[n], remap, union) for d, remap in zip(dfs, remaps)]
-        hint[n] = T.Categorical(union, T.UInt32)
+        hint[n] = new[0].dtype
         dfs = [DataFrame([new[i] if c.name == n else c for c in d.get_columns()]) for i, d in enumerate(dfs)]
     handles = (C.c_uint64 * len(dfs))(*[d._frame_handle() for d in dfs])
     out = C.c_uint64()

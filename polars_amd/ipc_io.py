@@ -16,7 +16,7 @@ import numpy as np
 from . import _ffi as F
 from . import datatypes as T
 from . import plan as P
-from .io import ParquetFrame, _MultiDecoder, expand_paths
+from .io import DATETIME_UNITS, ParquetFrame, _MultiDecoder, expand_paths, string_column_dtype
 
 
 class _IpcDecoder:
@@ -47,14 +47,20 @@ class _IpcDecoder:
     def dtype(self, name: str) -> T.DataType:
         _, dt, lg, _ = self._info[name]
         if dt < 0:
-            raise TypeError(f"ipc column {name!r} has a type outside the hot path (nested, decimal, non-us timestamp, ...)")
+            raise TypeError(f"ipc column {name!r} has a type outside the hot path (nested, decimal, timestamp in seconds, ...)")
         if lg == 1:
             return T.Date
-        if lg == 2:
-            return T.Datetime
+        if lg in DATETIME_UNITS:
+            return T.Datetime if lg == 2 else T.Datetime(DATETIME_UNITS[lg])
         if lg in (3, 4):
-            return T.Categorical([])
+            return string_column_dtype() if self._plain_strings(name) else T.Categorical([])
         return T.PHYSICAL_TO_DTYPE[dt]
+
+    def _plain_strings(self, name: str) -> bool:
+        """True for Utf8 / LargeUtf8 / Utf8View (and binary) columns, False for columns that are dictionary-encoded in the file (those
+        stay dictionaries, as the reference reads them: Categorical)."""
+        n, tb = C.c_int64(), C.c_int64()
+        return F.lib().plx_ipc_categories(self._h, self._info[name][0], C.byref(n), C.byref(tb)) != 0
 
     def stats(self, g: int, name: str):
         return None
@@ -84,11 +90,11 @@ class _IpcDecoder:
             if lg in (3, 4):
                 sd = C.c_uint64()
                 if F.lib().plx_ipc_column_strdict(self._h, i, C.byref(sd)) == 0:       # encoded on the device: the dictionary stays there until asked for
-                    hint[n] = T.Categorical(DeviceDictionary(sd.value, binary=lg == 4), T.UInt32)
+                    hint[n] = string_column_dtype(DeviceDictionary(sd.value, binary=lg == 4))
                 else:
                     hint[n] = T.Categorical(self.categories(n), T.UInt32)
             elif lg:
-                hint[n] = T.Date if lg == 1 else T.Datetime
+                hint[n] = self.dtype(n)
         df = DataFrame._from_frame_handle(fh.value, hint)
         for s in df.get_columns():
             s._declare_dictionary_bounds()

@@ -115,6 +115,8 @@ class Lowering:
             return self._push(kind=F.AE_ALIAS, lhs=idx, name=e.name), dt
         if k == "cast":
             idx, dt = self.lower_expr(e.lhs, schema, e.dtype)
+            if isinstance(dt, T.DatetimeType) and isinstance(e.dtype, T.DatetimeType) and dt.time_unit != e.dtype.time_unit:
+                raise TypeError(f"cast Datetime[{dt.time_unit}] -> Datetime[{e.dtype.time_unit}] (a multiply / floor-divide of the ticks) is not on this path")
             if dt == e.dtype:
                 return idx, dt
             return self._push(kind=F.AE_CAST, lhs=idx, dtype=e.dtype.physical), e.dtype
@@ -170,6 +172,45 @@ class Lowering:
                 return self._push(kind=F.AE_BINARY, op=e.op, lhs=ci, rhs=lit), T.Boolean
         return None
 
+    def _lower_mixed_time_units(self, op: int, li: int, ldt, ri: int, rdt):
+        """Datetime column <cmp> Datetime literal of another time unit (a python datetime is "us").  The reference coerces both sides to
+        the COARSER unit (get_time_units, crates/polars-core/src/utils/mod.rs:804-811) and casts the finer side by floor division
+        (chunked_array/logical/datetime.rs:59-66: `v.div_euclid(d)`).  No cast kernel runs here: the comparison is rewritten, exactly,
+        into the column's own unit.  Column coarser than the literal: the literal is floor-divided.  Column finer by the factor f:
+        floor(x / f) <= L  <=>  x <= f L + f - 1;  floor(x / f) >= L  <=>  x >= f L;  < and > shift L by one; == is both bounds, != neither."""
+        cmp_ops = (F.OP_EQ, F.OP_NE, F.OP_LT, F.OP_LE, F.OP_GT, F.OP_GE)
+        is_lit = lambda i: self.aexprs[i]["kind"] == F.AE_LITERAL and not self.aexprs[i]["is_null"]
+        if op not in cmp_ops or is_lit(li) == is_lit(ri):
+            raise TypeError(f"Datetime[{ldt.time_unit}] with Datetime[{rdt.time_unit}]: only comparisons of a column with a literal cross time units on this path")
+        if is_lit(li):                                              # literal <op> column  ->  column <flipped op> literal
+            li, ldt, ri, rdt = ri, rdt, li, ldt
+            op = {F.OP_LT: F.OP_GT, F.OP_LE: F.OP_GE, F.OP_GT: F.OP_LT, F.OP_GE: F.OP_LE}.get(op, op)
+        L = int(self.aexprs[ri]["lit"])
+        cu, lu = ldt.ticks_per_second(), rdt.ticks_per_second()
+        cmp = lambda o, v: self._push(kind=F.AE_BINARY, op=o, lhs=li, rhs=self._lit_node(int(v), ldt))
+        if cu < lu:                                                 # the column's unit is the coarser one: only the literal is cast
+            return cmp(op, L // (lu // cu)), T.Boolean
+        f = cu // lu
+        i64_min, i64_max = -(1 << 63), (1 << 63) - 1
+        # x <= hi / x >= lo with bounds that may lie outside i64: then the comparison is constant for every non-null x (and stays null for nulls)
+        le = lambda hi: cmp(F.OP_LE, i64_max) if hi >= i64_max else cmp(F.OP_LT, i64_min) if hi < i64_min else cmp(F.OP_LE, hi)
+        ge = lambda lo: cmp(F.OP_GE, i64_min) if lo <= i64_min else cmp(F.OP_GT, i64_max) if lo > i64_max else cmp(F.OP_GE, lo)
+        gt = lambda hi: cmp(F.OP_GT, i64_max) if hi >= i64_max else cmp(F.OP_GE, i64_min) if hi < i64_min else cmp(F.OP_GT, hi)
+        lt = lambda lo: cmp(F.OP_LT, i64_min) if lo <= i64_min else cmp(F.OP_LE, i64_max) if lo > i64_max else cmp(F.OP_LT, lo)
+        upper = lambda l: f * l + f - 1                             # floor(x / f) <= l  <=>  x <= upper(l)
+        lower = lambda l: f * l                                     # floor(x / f) >= l  <=>  x >= lower(l)
+        if op == F.OP_LE:
+            return le(upper(L)), T.Boolean
+        if op == F.OP_LT:
+            return le(upper(L - 1)), T.Boolean
+        if op == F.OP_GE:
+            return ge(lower(L)), T.Boolean
+        if op == F.OP_GT:
+            return ge(lower(L + 1)), T.Boolean
+        if op == F.OP_EQ:
+            return self._push(kind=F.AE_BINARY, op=F.OP_AND, lhs=ge(lower(L)), rhs=le(upper(L))), T.Boolean
+        return self._push(kind=F.AE_BINARY, op=F.OP_OR, lhs=lt(lower(L)), rhs=gt(upper(L))), T.Boolean
+
     def _lower_binary(self, e: Expr, schema: Schema):
         op = e.op
         if (e.lhs.kind == "lit" and isinstance(e.lhs.value, str)) or (e.rhs.kind == "lit" and isinstance(e.rhs.value, str)):
@@ -177,6 +218,8 @@ class Lowering:
         li, ldt = self._lower_maybe_dyn(e.lhs, schema)
         ri, rdt = self._lower_maybe_dyn(e.rhs, schema)
         ldyn, rdyn = isinstance(li, tuple), isinstance(ri, tuple)
+        if not ldyn and not rdyn and isinstance(ldt, T.DatetimeType) and isinstance(rdt, T.DatetimeType) and ldt.time_unit != rdt.time_unit:
+            return self._lower_mixed_time_units(op, li, ldt, ri, rdt)
         if op in (F.OP_AND, F.OP_OR, F.OP_XOR):
             if ldyn or rdyn or ldt != T.Boolean or rdt != T.Boolean:
                 raise TypeError("& | ^ need boolean operands on this path")
@@ -265,6 +308,8 @@ class Lowering:
             for a, b in zip(n.left_on, n.right_on):
                 ai, adt = self.lower_expr(a, ls)
                 bi, bdt = self.lower_expr(b, rs)
+                if isinstance(adt, T.DatetimeType) and isinstance(bdt, T.DatetimeType) and adt.time_unit != bdt.time_unit:
+                    raise TypeError(f"join keys Datetime[{adt.time_unit}] and Datetime[{bdt.time_unit}]: casts between time units are not on this path")
                 if adt.physical != bdt.physical:
                     st = T.supertype(adt, bdt)
                     ai = self._cast(ai, adt, st)

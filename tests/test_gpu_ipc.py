@@ -102,7 +102,7 @@ def test_batch_subsets_and_lazy_scan(pl, tmp_path):
 
 
 def test_unsupported_ipc_files_are_status_codes(pl, tmp_path):
-    t = pa.table({"a": np.arange(1000), "l": pa.array([[1]] * 1000), "ms": pa.array(np.arange(1000), pa.timestamp("ms"))})
+    t = pa.table({"a": np.arange(1000), "l": pa.array([[1]] * 1000), "ms": pa.array(np.arange(1000), pa.timestamp("s"))})
     path2 = str(tmp_path / "nested.arrow")
     write(path2, t)
     with pytest.raises(TypeError):
@@ -113,4 +113,4 @@ def test_unsupported_ipc_files_are_status_codes(pl, tmp_path):
     h, fh = C.c_uint64(), C.c_uint64()
     F.check(F.lib().plx_ipc_open(path2.encode(), C.byref(h)))
     b, cols = (C.c_int32 * 1)(0), (C.c_int32 * 1)(2)
-    assert F.lib().plx_ipc_read(h.value, b, 1, cols, 1, C.byref(fh)) == 3 and "timestamp unit" in F.lib().plx_last_error().decode()
+    assert F.lib().plx_ipc_read(h.value, b, 1, cols, 1, C.byref(fh)) == 3 and "timestamp in seconds" in F.lib().plx_last_error().decode()

@@ -50,7 +50,8 @@ def test_host_decoded_encodings_arrive_on_the_device(pl, tmp_path):
     s = pl.read_parquet(path96)["ts"]
     values, valid = s._download()
     want_valid = np.array([x is not None for x in t96.column("ts").to_pylist()])
-    assert s.dtype == pl.Datetime and np.array_equal(valid, want_valid) and np.array_equal(values[want_valid], us[want_valid])
+    assert s.dtype == pl.Datetime and s.dtype.time_unit == "ns"                # INT96 -> Datetime[ns], the reference's default
+    assert np.array_equal(valid, want_valid) and np.array_equal(values[want_valid], us[want_valid] * 1000)
 
 
 def test_scan_over_several_files_unifies_dictionaries(pl, tmp_path):
@@ -153,3 +154,48 @@ def test_row_group_shards_of_one_scan_add_up(pl, tmp_path):
     total = sum(pl.scan_parquet(path, shard=(rank, world)).filter(c("k") >= 10_000).select(c("v").sum().alias("sv")).collect()["sv"].to_list()[0] for rank in range(world))
     v = t.column("v").to_numpy(zero_copy_only=False)
     assert total == int(np.nansum(v[10_000:]))
+
+
+IO_FILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "io_files")
+
+
+@pytest.mark.parametrize("name", sorted(f for f in os.listdir(IO_FILES) if f.endswith(".parquet") and not f.startswith("nested")))
+def test_the_reference_s_own_parquet_fixtures_on_the_device(pl, name):
+    """The files the reference's I/O tests read (tests/golden/io_files, see tests/test_parquet_emu_cpu.py for what each one is about),
+    decoded on the device."""
+    path = os.path.join(IO_FILES, name)
+    want = pq.read_table(path)
+    df = pl.read_parquet(path)
+    assert df.columns == want.column_names and df.height == want.num_rows
+    for n in want.column_names:
+        w = want.column(n).combine_chunks()
+        s = df[n]
+        assert s.null_count() == w.null_count, n
+        if pa.types.is_binary(w.type) or pa.types.is_string(w.type) or pa.types.is_large_string(w.type):
+            assert s.to_list() == w.to_pylist(), n
+            continue
+        if pa.types.is_timestamp(w.type):
+            assert s.dtype.time_unit == w.type.unit, n                     # ns for INT96 and for tz_aware.parquet
+            w = w.cast(pa.int64())
+        values, valid = s._download()
+        wl = w.to_pylist()
+        ok = np.array([x is not None for x in wl], bool)
+        assert (valid is None and ok.all()) or np.array_equal(valid, ok), n
+        got = values[ok].tolist()
+        exp = [x for x in wl if x is not None]
+        assert got == exp or np.allclose(got, exp, rtol=0, atol=0, equal_nan=True), n
+
+
+def test_logical_types_survive_the_arrow_export(pl, tmp_path):
+    """Series.to_arrow(): Date / Datetime[unit] / string columns of a scan come back with their Arrow types (what the Polars attachment
+    hands to polars.from_arrow), dictionaries stay dictionaries."""
+    t = pa.table({"d": pa.array([1, None, 3], pa.date32()), "ns": pa.array([1, 2, None], pa.timestamp("ns")), "ms": pa.array([5, 6, 7], pa.timestamp("ms")),
+                  "s": pa.array(["x", None, "y"]), "i": pa.array([1, 2, 3])})
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path)
+    back = pl.read_parquet(path).to_arrow()
+    assert back.schema.types == [pa.date32(), pa.timestamp("ns"), pa.timestamp("ms"), pa.large_string(), pa.int64()]
+    for n in t.column_names:
+        assert back.column(n).to_pylist() == t.column(n).to_pylist(), n
+    cat = pl.Series.from_arrow("c", pa.array(["a", "b", "a"]).dictionary_encode()).to_arrow()
+    assert pa.types.is_dictionary(cat.type) and cat.to_pylist() == ["a", "b", "a"]

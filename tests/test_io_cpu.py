@@ -193,3 +193,25 @@ def test_split_by_rows_and_dictionary_union():
     assert union == ["a", "b", "c", "d"] and [r.tolist() for r in remaps] == [[0, 1], [1, 2, 0, 1], [], [3]] and all(r.dtype == np.uint32 for r in remaps)
     with pytest.raises(ValueError):
         io.ParquetFrame.__new__(io.ParquetFrame)._set_shard((2, 2))
+
+
+def test_logical_arrow_types():
+    """frame.logical_arrow: the host half of Series.to_arrow() -- physical export + mirror dtype -> Arrow logical type."""
+    import pyarrow as pa
+    from polars_amd.frame import logical_arrow
+    from polars_amd.io import string_column_dtype
+    assert logical_arrow(pa.array([1, None], pa.int32()), pl.Date).type == pa.date32()
+    a = logical_arrow(pa.array([1_000, None], pa.int64()), pl.Datetime("ns", "UTC"))
+    assert a.type == pa.timestamp("ns", "UTC") and a.null_count == 1
+    assert logical_arrow(pa.array([5], pa.int64()), pl.Datetime).type == pa.timestamp("us")
+    codes = pa.array([1, 0, None, 1], pa.uint32())
+    d = logical_arrow(codes, pl.Categorical(["x", "y"]))
+    assert pa.types.is_dictionary(d.type) and d.to_pylist() == ["y", "x", None, "y"]
+    s = logical_arrow(codes, string_column_dtype(["x", "y"]))
+    assert s.type == pa.large_string() and s.to_pylist() == ["y", "x", None, "y"]
+    b = logical_arrow(codes, string_column_dtype([b"\x00", b"\xff\x01"]))
+    assert b.type == pa.large_binary() and b.to_pylist() == [b"\xff\x01", b"\x00", None, b"\xff\x01"]
+    assert logical_arrow(pa.array([1.5]), pl.Float64).type == pa.float64()
+    assert pl.Datetime("ms") == pl.Datetime and pl.Datetime("ms").time_unit == "ms" and repr(pl.Datetime) == "Datetime"
+    with pytest.raises(ValueError):
+        pl.Datetime("s")

@@ -31,8 +31,9 @@ def sample(n):
         "sv": pa.array(words[RNG.integers(0, 5, n)], pa.string_view()), "bin": pa.array([b"\x00\x01"] * n, pa.binary()),
         "d8": pa.array(words[RNG.integers(0, 5, n)]).dictionary_encode().cast(pa.dictionary(pa.int8(), pa.string())),
         "d32": pa.array(words[RNG.integers(0, 3, n)], mask=m).dictionary_encode(),
+        "ts_ms": pa.array(RNG.integers(0, 2**40, n), pa.timestamp("ms")),
         # outside the hot path
-        "ts_ms": pa.array(RNG.integers(0, 2**40, n), pa.timestamp("ms")), "dec": pa.array([None] * n, pa.decimal128(12, 2)), "lst": pa.array([[1, 2]] * n),
+        "dec": pa.array([None] * n, pa.decimal128(12, 2)), "lst": pa.array([[1, 2]] * n),
         "st": pa.array([{"p": 1, "q": "z"}] * n), "tail": pa.array(np.arange(n)),
     })
 
@@ -57,7 +58,9 @@ def test_schema_batches_and_dictionaries_match_pyarrow(tmp_path):
         assert src.dtype(name) == dt and src.dtype(name).physical == dt.physical, name
     for name in ("s", "ls", "sv", "bin", "d8", "d32"):
         assert isinstance(src.dtype(name), pl.Categorical)
-    for name in ("ts_ms", "dec", "lst", "st"):
+    assert src.dtype("ts_ms").time_unit == "ms" and src.dtype("ts").time_unit == "us" and src.dtype("ts_ms") == pl.Datetime       # the file's unit is kept
+    assert src.dtype("s").from_strings and src.dtype("sv").from_strings and not src.dtype("d8").from_strings      # plain strings vs dictionaries in the file
+    for name in ("dec", "lst", "st"):
         with pytest.raises(TypeError):
             src.dtype(name)
     assert src._info["bin"][2] == 4 and src._info["s"][2] == 3 and src._info["i8"][3] is True
@@ -225,3 +228,14 @@ def test_files_written_by_the_reference(name):
         want = "Categorical" if pa.types.is_large_string(f.type) else "Datetime" if pa.types.is_timestamp(f.type) else {"int64": "Int64", "double": "Float64"}[str(f.type)]
         assert got.name == want, (f.name, got, f.type)
     assert _check_buffers(path, t.column_names) >= t.num_columns + sum(pa.types.is_large_string(f.type) for f in t.schema)      # no nulls in these files: values (+ data) buffers only
+
+
+@pytest.mark.parametrize("name", ["foods1.ipc", "foods2.ipc"])
+def test_the_reference_s_own_ipc_fixtures(name):
+    """py-polars/tests/unit/io/files/foods{1,2}.ipc (copied by tests/golden/make_io_files.py): written by the reference's IPC writer."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "io_files", name)
+    t = ipc.open_file(path).read_all()
+    src = ipc_io.IpcFrame(path)
+    assert src.num_rows == t.num_rows == 27 and list(src.schema) == t.column_names == ["category", "calories", "fats_g", "sugars_g"]
+    assert src.schema["category"].from_strings and src.schema["fats_g"] == pl.Float64
+    assert _check_buffers(path, t.column_names) >= 5

@@ -20,8 +20,8 @@ import parquet_emu as E
 RNG = np.random.default_rng(20260923)
 
 
-def check_column(path, table, name, row_groups=None, order=0):
-    ci = table.column_names.index(name)
+def check_column(path, table, name, row_groups=None, order=0, ci=None):
+    ci = table.column_names.index(name) if ci is None else ci           # ci: the LEAF index when the file also has nested columns
     nrg = pq.ParquetFile(path).metadata.num_row_groups
     rgs = list(range(nrg)) if row_groups is None else row_groups
     r = E.read_column(path, rgs, ci, order)
@@ -178,10 +178,12 @@ def test_unsupported_files_say_what_they_are(tmp_path):
     path = str(tmp_path / "t.parquet")
     pq.write_table(t, path, compression={"a": "brotli", "dec": "none", "lst.list.element": "none", "ms": "none", "z": "brotli"}, use_dictionary=False,
                    column_encoding={"z": "DELTA_BINARY_PACKED"})
-    for col, word in ((0, "BROTLI"), (1, "decimal"), (2, "nested"), (3, "timestamp unit"), (4, "BROTLI")):
+    for col, word in ((0, "BROTLI"), (1, "decimal"), (2, "nested"), (4, "BROTLI")):
         with pytest.raises(E.EmuError) as ei:
             E.read_column(path, [0], col)
         assert ei.value.code == 3 and word in str(ei.value), str(ei.value)
+    r = E.read_column(path, [0], 3)                     # millisecond timestamps keep their unit (logical kind 5), as the reference keeps it
+    assert r["logical"] == 5 and r["dtype"] == 4 and np.array_equal(r["values"], np.arange(n))
     # booleans in an encoding nobody decodes here
     pq.write_table(pa.table({"b": pa.array(np.arange(n) % 3 == 0)}), path, compression="none", use_dictionary=False, column_encoding={"b": "RLE"}, data_page_version="1.0")
     check_column(path, pa.table({"b": pa.array(np.arange(n) % 3 == 0)}), "b")          # RLE booleans ARE decoded (device bodies); kept here as the boundary case
@@ -559,12 +561,53 @@ def test_int96_timestamps(tmp_path):
     rng = np.random.default_rng(22)
     n = 5000
     us = rng.integers(-10**15, 2 * 10**15, n)               # before and after the epoch
+    us[7] = 32_503_680_000_000_000                          # year 3000: does not fit nanoseconds
     t = pa.table({"ts": pa.array(us, pa.timestamp("us"), mask=rng.random(n) < 0.1), "k": pa.array(np.arange(n))})
     path = str(tmp_path / "t.parquet")
     for dic in (True, False):
         pq.write_table(t, path, use_deprecated_int96_timestamps=True, compression="snappy", use_dictionary=dic, row_group_size=1800, data_page_size=2000)
         assert pq.ParquetFile(path).metadata.row_group(0).column(0).physical_type == "INT96"
         r = E.read_column(path, [0, 1, 2], 0)
-        assert r["dtype"] == 4 and r["logical"] == 2           # Int64 / Datetime[us]
+        assert r["dtype"] == 4 and r["logical"] == 6           # Int64 / Datetime[ns]: the reference's default for INT96 (schema/mod.rs:32)
         valid = np.array([x is not None for x in t.column("ts").to_pylist()])
-        assert np.array_equal(r["valid"], valid) and np.array_equal(r["values"][valid], us[valid])
+        want = us * 1000
+        want[7] = np.iinfo(np.int64).max                       # int96_to_i64_ns(..).unwrap_or(i64::MAX), simple.rs:731-733
+        assert np.array_equal(r["valid"], valid) and np.array_equal(r["values"][valid], want[valid])
+
+
+IO_FILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "io_files")
+REFERENCE_FILES = sorted(f for f in os.listdir(IO_FILES) if f.endswith(".parquet"))
+
+
+@pytest.mark.parametrize("name", REFERENCE_FILES)
+def test_the_reference_s_own_parquet_fixtures(name):
+    """tests/golden/io_files: the Parquet files the reference's I/O tests read (py-polars/tests/unit/io/files, docs/assets/data; copied by
+    tests/golden/make_io_files.py), written by Polars' own writer, parquet-mr, parquet-cpp and Impala -- zstd, gzip, snappy and LZ4_RAW pages, v2 pages, an all-null v2 page without value bytes (test_parquet.py:848), INT96 and nanosecond timestamps,
+    un-annotated binary strings, deprecated BIT_PACKED levels in the encoding lists.  Every flat column through the product's reader
+    (kernel bodies run on the CPU) equals pyarrow's decode; nested columns are refused by name."""
+    import hashlib
+    import json
+    from polars_amd import io
+    path = os.path.join(IO_FILES, name)
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == json.load(open(os.path.join(IO_FILES, "INDEX.json")))[name]["sha256"]
+    table = pq.read_table(path)
+    dec = io._DeviceDecoder(path)                               # the library's metadata reader: leaf names and indices
+    assert dec.num_rows == table.num_rows
+    flat = [n for n in table.column_names if n in dec._info]
+    assert flat or name.startswith("nested")
+    for n in flat:
+        check_column(path, table, n, ci=dec._info[n][0])
+        for order in (1,):                                      # lanes in descending order too
+            check_column(path, table, n, order=order, ci=dec._info[n][0])
+    nested = [n for n in dec.names if n not in table.column_names]
+    for n in nested:
+        with pytest.raises(E.EmuError) as ei:
+            E.read_column(path, [0], dec._info[n][0])
+        assert ei.value.code == 3 and "nested" in str(ei.value)
+    if name == "tz_aware.parquet":
+        assert dec.dtype("UTC_DATETIME_ID").time_unit == "ns"
+    if name == "alltypes_plain.parquet":
+        assert dec.dtype("timestamp_col").time_unit == "ns" and dec._info["string_col"][2] == 4      # INT96 -> Datetime[ns]; BYTE_ARRAY without annotation -> Binary
+    if name == "empty_datapage_v2.snappy.parquet":
+        r = E.read_column(path, [0], 0)
+        assert r["null_count"] == 1 and r["valid"].tolist() == [False]

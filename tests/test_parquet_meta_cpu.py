@@ -47,7 +47,7 @@ def test_schema_shape_and_statistics_match_pyarrow(tmp_path):
     F.check(F.lib().plx_parquet_shape(h, C.byref(rows), C.byref(groups), C.byref(cols)))
     assert (rows.value, groups.value, cols.value) == (md.num_rows, md.num_row_groups, md.num_columns)      # leaf columns, nested ones included
     want = {"i8": (F.I8, 0), "u16": (F.U16, 0), "i32": (F.I32, 0), "u32": (F.U32, 0), "i64": (F.I64, 0), "u64": (F.U64, 0), "f32": (F.F32, 0), "f64": (F.F64, 0),
-            "b": (F.BOOL, 0), "date": (F.I32, 1), "ts": (F.I64, 2), "ts_ms": (-1, 0), "s": (F.U32, 3), "bin": (F.U32, 4), "dec": (-1, 0)}
+            "b": (F.BOOL, 0), "date": (F.I32, 1), "ts": (F.I64, 2), "ts_ms": (F.I64, 5), "s": (F.U32, 3), "bin": (F.U32, 4), "dec": (-1, 0)}
     names = []
     for i in range(cols.value):
         nm, dtp, lg, nl = C.c_char_p(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -83,8 +83,8 @@ def test_schema_shape_and_statistics_match_pyarrow(tmp_path):
             lo, hi = st.min, st.max
             if name == "date":
                 lo, hi = (lo - dt.date(1970, 1, 1)).days, (hi - dt.date(1970, 1, 1)).days
-            if name == "ts":
-                us = lambda d: (d.replace(tzinfo=None) - dt.datetime(1970, 1, 1)) // dt.timedelta(microseconds=1)
+            if name in ("ts", "ts_ms"):              # statistics come in the column's own unit
+                us = lambda d: (d.replace(tzinfo=None) - dt.datetime(1970, 1, 1)) // dt.timedelta(microseconds=1 if name == "ts" else 1000)
                 lo, hi = us(lo), us(hi)
             pick = {"f64": lambda s: s.f64, "f32": lambda s: s.f32, "b": lambda s: bool(s.u)}.get(name, (lambda s: s.u) if name.startswith("u") else (lambda s: s.i))
             assert pick(mn) == lo and pick(mx) == hi, (name, pick(mn), lo)

@@ -568,3 +568,48 @@ def test_random_group_by_shapes(orc, seed):
     for key, row in want.items():
         for col, wv in row.items():
             assert close(got[key][col], wv), (seed, key, col, got[key][col], wv)
+
+
+@pytest.mark.parametrize("unit", ["ms", "ns"])
+def test_datetime_literal_against_columns_of_other_time_units(unit):
+    """A python datetime (Datetime[us]) compared with a Datetime[ms] / Datetime[ns] column.  The reference coerces to the coarser unit
+    and casts the finer side by floor division (utils/mod.rs:804-811, logical/datetime.rs:59-66); the lowering rewrites the comparison
+    into the column's unit instead of casting.  Checked for all six operators, on both sides of the epoch, with nulls, through the
+    compiled program."""
+    import datetime as dtm
+    rng = np.random.default_rng(7)
+    n = 4000
+    per_us = {"ms": None, "ns": 1000}[unit]
+    lits = [dtm.datetime(1970, 1, 1), dtm.datetime(1970, 1, 1, 0, 0, 0, 1), dtm.datetime(1969, 12, 31, 23, 59, 59, 999_999), dtm.datetime(1995, 3, 15, 12, 0, 0, 123_456),
+            dtm.datetime(1960, 6, 1, 1, 2, 3, 999)]
+    us_of = lambda d: ((d - dtm.datetime(1970, 1, 1)) // dtm.timedelta(microseconds=1))
+    centres = np.array([us_of(d) for d in lits], np.int64)
+    if unit == "ns":
+        t = (centres[rng.integers(0, len(lits), n)] * 1000 + rng.integers(-2500, 2500, n)).astype(np.int64)          # a few microseconds around every literal
+    else:
+        t = (centres[rng.integers(0, len(lits), n)] // 1000 + rng.integers(-3, 4, n)).astype(np.int64)
+    valid = rng.random(n) > 0.1
+    cols = {"t": (t, valid)}
+    df = frame_like(cols, {"t": pl.Datetime(unit)})
+    assert df.schema["t"].time_unit == unit
+    npop = {"<": np.less, "<=": np.less_equal, ">": np.greater, ">=": np.greater_equal, "==": np.equal, "!=": np.not_equal}
+    for d in lits:
+        L = us_of(d)
+        for name, fn in npop.items():
+            c = pl.col("t")
+            e = {"<": c < d, "<=": c <= d, ">": c > d, ">=": c >= d, "==": c.eq(d), "!=": c.ne(d)}[name]
+            if unit == "ns":
+                want = fn(t // per_us, L)                     # column floor-divided into microseconds
+            else:
+                want = fn(t, L // 1000)                       # literal floor-divided into milliseconds
+            got = pe.evaluate(df.lazy().filter(e).select(pl.len().alias("n")).debug_program(), cols)["n"][0][0]
+            assert got == int((want & valid).sum()), (unit, name, d)
+            flipped = {"<": d > c, "<=": d >= c, ">": d < c, ">=": d <= c, "==": c.eq(d), "!=": c.ne(d)}[name]      # literal on the left
+            assert pe.evaluate(df.lazy().filter(flipped).select(pl.len().alias("n")).debug_program(), cols)["n"][0][0] == got
+    with pytest.raises(TypeError):                            # two columns of different units would need the cast kernel
+        frame_like({"a": (t, None), "b": (t, None)}, {"a": pl.Datetime("ns"), "b": pl.Datetime("us")}).lazy().filter(pl.col("a") < pl.col("b")).debug_program()
+    # bounds beyond i64 in the column's unit: constant comparisons, nulls stay out
+    if unit == "ns":
+        far = dtm.datetime(9999, 1, 1)
+        assert pe.evaluate(df.lazy().filter(pl.col("t") < far).select(pl.len().alias("n")).debug_program(), cols)["n"][0][0] == int(valid.sum())
+        assert pe.evaluate(df.lazy().filter(pl.col("t") >= far).select(pl.len().alias("n")).debug_program(), cols)["n"][0][0] == 0
