@@ -399,6 +399,7 @@ class ParquetFrame:
         self._schema: Dict[str, T.DataType] = {n: self._dec.dtype(n) for n in names}
         self._need: Optional[Set[str]] = set()          # None = every column of the schema
         self._preds: Optional[List[Pred]] = None        # None = not requested yet; [] = no pushdown
+        self._window: Any = None                        # None = not requested yet; (offset, length) of a slice directly above; False = every row
         self._df = None
         self._loaded: Optional[Tuple[frozenset, Tuple[int, ...]]] = None
         self.last_read: Dict[str, Any] = {}
@@ -433,9 +434,12 @@ class ParquetFrame:
         return self._dec.num_row_groups
 
     # -- what the plan needs (called by LazyFrame._lower through plan.push_down) ------------------------------------
-    def request(self, columns: Optional[Set[str]], predicates: List[Pred]) -> None:
+    def request(self, columns: Optional[Set[str]], predicates: List[Pred], window: Optional[Tuple[int, int]] = None) -> None:
         """One call per use of this scan in a plan; uses are merged: union of the columns, the predicates only if every use
-        carries the same ones."""
+        carries the same ones, the row window (a slice directly above the scan: slice pushdown, crates/polars-plan/src/plans/optimizer/
+        slice_pushdown_lp.rs) only if every use carries the same one."""
+        first = self._preds is None
+        self._window = (window or False) if first else (self._window if self._window == (window or False) else False)
         if columns is None or self._need is None:
             self._need = None
         else:
@@ -447,7 +451,7 @@ class ParquetFrame:
             self._preds = []
 
     def reset_requests(self) -> None:
-        self._need, self._preds = set(), None
+        self._need, self._preds, self._window = set(), None, None
 
     def selected_columns(self) -> List[str]:
         cols = [n for n in self._schema if self._need is None or n in self._need]
@@ -492,7 +496,38 @@ class ParquetFrame:
         if getattr(self, "_shard", None) is not None and self._shard[1] > 1:
             rank, world = self._shard
             keep = [keep[i] for i in split_by_rows([self._dec.rows_of(g) for g in keep], world)[rank]]
-        return keep
+        return self._windowed(keep)[0]
+
+    def _windowed(self, keep: List[int]) -> Tuple[List[int], int]:
+        """(row groups that overlap the pushed-down slice, rows of `keep` in front of the first of them)"""
+        w = getattr(self, "_window", None)
+        if not w or self._preds:
+            return keep, 0
+        rows = [self._dec.rows_of(g) for g in keep]
+        total = sum(rows)
+        off, length = w
+        lo = max(0, total + off) if off < 0 else min(off, total)
+        hi = total if off < 0 else min(total, lo + max(length, 0))          # a slice counted from the end keeps the end: its offset is not rebased
+        out, skipped, acc = [], 0, 0
+        for g, r in zip(keep, rows):
+            if acc + r > lo and acc < hi:
+                out.append(g)
+            elif not out and acc + r <= lo:
+                skipped += r
+            acc += r
+        return out, (skipped if out else 0)
+
+    def window_skip(self, offset: int, length: int) -> int:
+        """Rows the scan leaves out in front of the slice (offset, length) it was asked to cover: the plan's Slice node subtracts them
+        from its offset.  0 when that slice was not pushed down (another use of the scan needs other rows) or counts from the end."""
+        if getattr(self, "_window", None) != (offset, length) or offset < 0:
+            return 0
+        saved, self._window = self._window, None
+        try:
+            keep = self.selected_row_groups()
+        finally:
+            self._window = saved
+        return self._windowed(keep)[1]
 
     # -- materialisation ---------------------------------------------------------------------------------------------------
     def materialise(self):
@@ -605,12 +640,35 @@ def simple_predicates(e: Expr) -> List[Pred]:
     return out
 
 
-def push_down(node: P.Node, needed: Optional[Set[str]] = None, preds: Optional[List[Pred]] = None) -> None:
-    """Tells every ParquetFrame under `node` which columns the plan reads and which simple predicates sit directly above it."""
+def _row_preserving(exprs) -> bool:
+    """no aggregate anywhere: the node maps row i to row i"""
+    def walk(e) -> bool:
+        if e is None:
+            return True
+        if e.kind in ("agg", "len"):
+            return False
+        return all(walk(c) for c in (e.lhs, e.rhs) if isinstance(c, Expr))
+    return all(walk(e) for e in exprs) and any(expr_columns(e) for e in exprs)
+
+
+def scan_under(node: P.Node):
+    """The file scan a Slice node's window reaches: through row-preserving select / with_columns nodes only."""
+    while True:
+        if node.kind == "scan":
+            return node.frame if isinstance(node.frame, ParquetFrame) else None
+        if node.kind in ("select", "with_columns") and _row_preserving(node.exprs):
+            node = node.input
+            continue
+        return None
+
+
+def push_down(node: P.Node, needed: Optional[Set[str]] = None, preds: Optional[List[Pred]] = None, window: Optional[Tuple[int, int]] = None) -> None:
+    """Tells every ParquetFrame under `node` which columns the plan reads, which simple predicates sit directly above it and which
+    rows a slice directly above it keeps."""
     k = node.kind
     if k == "scan":
         if isinstance(node.frame, ParquetFrame):
-            node.frame.request(needed, preds or [])
+            node.frame.request(needed, preds or [], window)
         return
     if k == "filter":
         cols = expr_columns(node.predicate)
@@ -621,14 +679,14 @@ def push_down(node: P.Node, needed: Optional[Set[str]] = None, preds: Optional[L
         cols: Set[str] = set()
         for e in node.exprs:
             expr_columns(e, cols)
-        push_down(node.input, cols, None)
+        push_down(node.input, cols, None, window if _row_preserving(node.exprs) else None)
         return
     if k == "with_columns":
         new = {P.expr_output_name(e) for e in node.exprs}
         cols = set()
         for e in node.exprs:
             expr_columns(e, cols)
-        push_down(node.input, None if needed is None else (needed - new) | cols, None)
+        push_down(node.input, None if needed is None else (needed - new) | cols, None, window if _row_preserving(node.exprs) else None)
         return
     if k == "group_by":
         cols = set()
@@ -643,7 +701,7 @@ def push_down(node: P.Node, needed: Optional[Set[str]] = None, preds: Optional[L
         push_down(node.input, None if needed is None else needed | cols, None)
         return
     if k == "slice":
-        push_down(node.input, needed, None)
+        push_down(node.input, needed, None, (int(node.offset), int(node.length)))
         return
     if k == "join":
         lnames, rnames = output_names(node.left), output_names(node.right)

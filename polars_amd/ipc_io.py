@@ -126,6 +126,7 @@ class IpcFrame(ParquetFrame):
         self._schema = {n: self._dec.dtype(n) for n in names}
         self._need = set()
         self._preds = None
+        self._window = None
         self._df = None
         self._loaded = None
         self.last_read = {}

@@ -333,7 +333,12 @@ class Lowering:
                         sort_nulls_last=[int(bool(x)) for x in n.nulls_last], maintain_order=int(n.maintain_order)), schema
         if k == "slice":
             inp, schema = self.lower_node(n.input)
-            return push(kind=F.IR_SLICE, input=inp, slice_offset=int(n.offset), slice_len=int(n.length)), schema
+            offset = int(n.offset)
+            from . import io as _io
+            src = _io.scan_under(n.input)
+            if src is not None:                  # the scan below reads only the row groups this slice overlaps: the offset counts from its first row
+                offset -= src.window_skip(int(n.offset), int(n.length))
+            return push(kind=F.IR_SLICE, input=inp, slice_offset=offset, slice_len=int(n.length)), schema
         raise TypeError(f"unsupported plan node {k}")
 
     # -- marshalling to the C structs -----------------------------------------------------------

@@ -199,3 +199,24 @@ def test_logical_types_survive_the_arrow_export(pl, tmp_path):
         assert back.column(n).to_pylist() == t.column(n).to_pylist(), n
     cat = pl.Series.from_arrow("c", pa.array(["a", "b", "a"]).dictionary_encode()).to_arrow()
     assert pa.types.is_dictionary(cat.type) and cat.to_pylist() == ["a", "b", "a"]
+
+
+def test_slice_pushed_into_the_scan(pl, tmp_path):
+    """head / slice directly above a scan read only the overlapping row groups (tests/test_io_cpu.py pins the planning); the rows that
+    come back are the same as slicing the whole table."""
+    n = 20_000
+    t = pa.table({"k": np.arange(n), "s": pa.array(np.array(["a", "b", "c"])[np.arange(n) % 3]), "v": pa.array(np.arange(n) * 0.5, mask=np.arange(n) % 7 == 0)})
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, row_group_size=1500, compression="snappy")
+    for off, ln in [(0, 5), (1499, 3), (4000, 6000), (19_990, 100), (-10, 4), (25_000, 3)]:
+        lf = pl.scan_parquet(path).slice(off, ln)
+        df = lf.collect()
+        want = t.slice(off, ln) if off >= 0 else t.slice(max(0, n + off), ln)
+        if off >= n:
+            want = t.slice(0, 0)
+        assert df.height == want.num_rows, (off, ln)
+        compare(df, want, t.column_names)
+        read = lf._node.input.frame.last_read
+        assert read["row_groups"] <= (ln + 1499) // 1500 + 1 or off < 0, (off, ln, read)
+    out = pl.scan_parquet(path).select(pl.col("k"), (pl.col("v") * 2).alias("w")).head(7).collect()
+    assert out["k"].to_list() == list(range(7)) and out["w"].to_list() == [None, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0]

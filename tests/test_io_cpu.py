@@ -215,3 +215,52 @@ def test_logical_arrow_types():
     assert pl.Datetime("ms") == pl.Datetime and pl.Datetime("ms").time_unit == "ms" and repr(pl.Datetime) == "Datetime"
     with pytest.raises(ValueError):
         pl.Datetime("s")
+
+
+def test_slice_pushdown_reads_only_the_row_groups_it_overlaps(tmp_path):
+    """head / slice directly above a scan (also through row-preserving projections): only the overlapping row groups are read and
+    the Slice node's offset is rebased to the first of them (slice_pushdown_lp.rs); a filter in between, an aggregate in between or
+    a second use of the scan with other rows switch it off.  Checked by replaying the plan's arithmetic on row indices."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from polars_amd import _ffi as F
+    n = 10_000
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(pa.table({"k": np.arange(n), "v": np.arange(n) * 2}), path, row_group_size=1000)
+    c = pl.col
+
+    def plan_of(lf):
+        low, root, _ = lf._lower()
+        node = lf._node
+        while node.kind != "scan":
+            node = node.input
+        ir = next(d for d in low.irs if d["kind"] == F.IR_SLICE)
+        return node.frame, ir["slice_offset"], ir["slice_len"]
+
+    def rows_read(src):
+        return np.concatenate([np.arange(g * 1000, (g + 1) * 1000) for g in src.selected_row_groups()] or [np.arange(0)])
+
+    for off, ln in [(0, 5), (0, 1000), (999, 2), (1000, 1), (2500, 4000), (9990, 100), (10_000, 5), (20_000, 5), (3000, 0), (-5, 5), (-1500, 10), (-20_000, 3)]:
+        for build in (lambda: pl.scan_parquet(path).slice(off, ln), lambda: pl.scan_parquet(path).select(c("k"), (c("v") + 1).alias("w")).slice(off, ln),
+                      lambda: pl.scan_parquet(path).with_columns((c("v") * 2).alias("w")).slice(off, ln)):
+            src, o2, l2 = plan_of(build())
+            got = rows_read(src)
+            m = len(got)
+            start = max(0, m + o2) if o2 < 0 else min(o2, m)
+            want = np.arange(n)[off:off + ln] if off >= 0 else np.arange(n)[max(0, n + off):][:ln]
+            assert np.array_equal(got[start:start + l2], want), (off, ln)
+            assert len(src.selected_row_groups()) <= (ln + 999) // 1000 + 1 or off < 0, (off, ln)
+    assert len(plan_of(pl.scan_parquet(path).head(5))[0].selected_row_groups()) == 1
+    # not pushed: a filter between slice and scan (the slice counts FILTERED rows), an aggregate, a sort
+    for lf in (pl.scan_parquet(path).filter(c("k") >= 0).slice(2500, 10), pl.scan_parquet(path).sort("k").slice(2500, 10)):
+        src, o2, _ = plan_of(lf)
+        assert len(src.selected_row_groups()) == 10 and o2 == 2500
+    # a filter ABOVE the slice does not matter
+    src, o2, _ = plan_of(pl.scan_parquet(path).slice(2500, 10).filter(c("k") > 0))
+    assert src.selected_row_groups() == [2] and o2 == 500
+    # two uses of one scan with different windows: all rows, offsets untouched
+    base = pl.scan_parquet(path)
+    j = base.slice(2500, 10).join(base.slice(7000, 10), on="k")
+    low, _, _ = j._lower()
+    assert sorted(d["slice_offset"] for d in low.irs if d["kind"] == F.IR_SLICE) == [2500, 7000]
+    assert len(base._node.frame.selected_row_groups()) == 10
