@@ -645,6 +645,19 @@ class DataFrame:
         import pyarrow as pa
         return pa.table({c.name: c.to_arrow() for c in self._cols})
 
+    def write_parquet(self, path: str, *, compression: str = "zstd", row_group_size: Optional[int] = None) -> None:
+        """Results to a Parquet file (DataFrame.write_parquet; zstd like the reference's default).  The encoder is pyarrow's, on the host:
+        writing is the step after the path (result frames are small), only the download is this library's."""
+        import pyarrow.parquet as pq
+        pq.write_table(self.to_arrow(), path, compression=compression, row_group_size=row_group_size)
+
+    def write_ipc(self, path: str, *, compression: Optional[str] = None) -> None:
+        """Results to an Arrow IPC (Feather V2) file (DataFrame.write_ipc); compression: None, "lz4" or "zstd"."""
+        import pyarrow as pa
+        t = self.to_arrow()
+        with pa.ipc.new_file(path, t.schema, options=pa.ipc.IpcWriteOptions(compression=compression)) as w:
+            w.write_table(t)
+
     def sort_host(self, by: Union[str, Sequence[str]]) -> Dict[str, list]:
         """Host-side ordering helper for comparing unordered results (sort / top-k are out
         of scope on the GPU: SURVEY.md section 8e)."""

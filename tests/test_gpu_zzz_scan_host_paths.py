@@ -220,3 +220,18 @@ def test_slice_pushed_into_the_scan(pl, tmp_path):
         assert read["row_groups"] <= (ln + 1499) // 1500 + 1 or off < 0, (off, ln, read)
     out = pl.scan_parquet(path).select(pl.col("k"), (pl.col("v") * 2).alias("w")).head(7).collect()
     assert out["k"].to_list() == list(range(7)) and out["w"].to_list() == [None, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0]
+
+
+def test_results_written_and_scanned_again(pl, tmp_path):
+    """write_parquet / write_ipc of a result frame (host encoder) and a scan of what was written: logical types make the round trip."""
+    t = pa.table({"d": pa.array([1, None, 3, 4], pa.date32()), "ts": pa.array([10, 20, None, 40], pa.timestamp("us")), "s": pa.array(["x", None, "y", "x"]),
+                  "f": pa.array([0.5, 1.5, None, 2.5]), "b": pa.array([True, None, False, True])})
+    src = str(tmp_path / "in.parquet")
+    pq.write_table(t, src)
+    df = pl.read_parquet(src)
+    p2, p3 = str(tmp_path / "out.parquet"), str(tmp_path / "out.arrow")
+    df.write_parquet(p2)
+    df.write_ipc(p3, compression="zstd")
+    assert pq.read_table(p2).to_pydict() == t.to_pydict()
+    for again in (pl.read_parquet(p2), pl.read_ipc(p3)):
+        compare(again, t, t.column_names)
