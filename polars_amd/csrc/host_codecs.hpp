@@ -25,6 +25,20 @@ struct CodecError : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
+inline void copy16(uint8_t* d, const uint8_t* s) { uint64_t a, b; memcpy(&a, s, 8); memcpy(&b, s + 8, 8); memcpy(d, &a, 8); memcpy(d + 8, &b, 8); }
+
+// match copy of an LZ77 decoder: n bytes from off bytes back, byte-sequential semantics (a match may overlap itself).  With
+// `slack` >= 16 writable bytes behind the match it goes word by word (what is written past the match is overwritten by what follows).
+inline void match_copy(uint8_t* d, size_t off, size_t n, size_t slack) {
+  const uint8_t* m = d - off;
+  if (slack >= 16 && off >= 8) {
+    if (off >= 16) for (size_t k = 0; k < n; k += 16) copy16(d + k, m + k);
+    else for (size_t k = 0; k < n; k += 8) { uint64_t w; memcpy(&w, m + k, 8); memcpy(d + k, &w, 8); }
+  } else if (off >= n) memcpy(d, m, n);
+  else if (off == 1) memset(d, m[0], n);
+  else for (size_t k = 0; k < n; k++) d[k] = m[k];
+}
+
 // ---- LZ4 ------------------------------------------------------------------------------------------------------------------------------
 // One LZ4 block: sequences of token (hi nibble literal length, lo nibble match length - 4; 15 = more length bytes of 255 follow),
 // literals, 2-byte little-endian offset, [match length bytes]; the last sequence ends after its literals.  Appends to out at *op;
@@ -43,7 +57,8 @@ inline void lz4_block(const uint8_t* in, size_t n, uint8_t* out, size_t* op_io, 
       } while (b == 255);
     }
     if (lit > n - ip || lit > out_cap - op) throw CodecError("lz4: literals past the end");
-    memcpy(out + op, in + ip, lit);
+    if (lit <= 16 && n - ip >= 16 && out_cap - op >= 16) copy16(out + op, in + ip);
+    else memcpy(out + op, in + ip, lit);
     ip += lit; op += lit;
     if (ip >= n) break;                       // last sequence: literals only
     if (n - ip < 2) throw CodecError("lz4: truncated offset");
@@ -60,7 +75,7 @@ inline void lz4_block(const uint8_t* in, size_t n, uint8_t* out, size_t* op_io, 
     }
     ml += 4;
     if (off == 0 || off > op || ml > out_cap - op) throw CodecError("lz4: bad match");
-    for (size_t i = 0; i < ml; i++) out[op + i] = out[op - off + i];
+    match_copy(out + op, off, ml, out_cap - op - ml);
     op += ml;
   }
   *op_io = op;
@@ -127,7 +142,18 @@ namespace inflate_detail {
 
 struct Bits {
   const uint8_t* p; size_t n; size_t pos = 0; uint64_t hold = 0; int cnt = 0;
+  // at least 56 valid bits in one go while 8 input bytes remain (cnt stays a multiple of 8 short of 64: whole bytes only)
+  void refill() {
+    if (cnt < 48 && n - pos >= 8) {
+      uint64_t w;
+      memcpy(&w, p + pos, 8);
+      hold |= w << cnt;
+      const int take = (63 - cnt) >> 3;      // whole bytes that fit
+      pos += (size_t)take; cnt += take * 8;
+    }
+  }
   uint32_t get(int need) {
+    refill();
     while (cnt < need) {
       if (pos >= n) throw CodecError("deflate: stream ends inside a block");
       hold |= (uint64_t)p[pos++] << cnt;
@@ -139,6 +165,7 @@ struct Bits {
   }
   // the next `need` (<= 16) bits without consuming them; past the end of the stream they read as zero (a code that needs them fails in drop)
   uint32_t peek(int need) {
+    refill();
     while (cnt < need && pos < n) { hold |= (uint64_t)p[pos++] << cnt; cnt += 8; }
     return (uint32_t)(hold & (((uint64_t)1 << need) - 1));
   }
@@ -213,7 +240,7 @@ inline void codes(Bits& b, const Huff& lit, const Huff& dist, uint8_t* out, size
       if (ds > 29) throw CodecError("deflate: invalid distance code");
       const size_t d = kDistBase[ds] + b.get(kDistBits[ds]);
       if (d > op || len > cap - op) throw CodecError("deflate: match outside the output");
-      for (size_t i = 0; i < len; i++) out[op + i] = out[op - d + i];
+      match_copy(out + op, d, len, cap - op - len);
       op += len;
     }
   }
@@ -378,10 +405,15 @@ struct BackBits {
   }
 };
 
+// one state of a sequence table with everything the decoder needs in 8 bytes: the symbol's base value and extra-bit count
+// (literal length / match length / offset code) and the state transition
+struct SeqEntry { uint32_t base_value; uint16_t next_base; uint8_t extra_bits; uint8_t nbits; };
+
 struct FseTable {
   int log = 0;
   std::vector<uint8_t> symbol, nbits;
   std::vector<uint16_t> base;
+  std::vector<SeqEntry> seq;            // sequence tables only (seq_entries)
   bool set = false;
 };
 
@@ -444,6 +476,7 @@ inline size_t fse_read(const uint8_t* p, size_t n, int max_log, int max_sym, Fse
 struct HufTable {
   int max_bits = 0;
   std::vector<uint8_t> symbol, nbits;
+  std::vector<uint16_t> entry;          // (code length << 8) | symbol: one load per decoded byte in the fast loop
   bool set = false;
 };
 
@@ -472,6 +505,8 @@ inline void huf_build(const uint8_t* bits, int nsym, HufTable& t) {
     for (uint32_t k = 0; k < len; k++) t.symbol[code + k] = (uint8_t)s;
     rank_idx[bits[s]] += len;
   }
+  t.entry.resize(size);
+  for (uint32_t k = 0; k < size; k++) t.entry[k] = (uint16_t)((uint16_t)t.nbits[k] << 8 | t.symbol[k]);
 }
 
 // 4.2.1: Huffman tree description -> table; returns the bytes it took
@@ -568,14 +603,29 @@ inline void huf_stream(const HufTable& t, const uint8_t* p, size_t n, uint8_t* o
 // the four streams of a literals section side by side: four independent dependency chains per loop iteration
 inline void huf_streams4(const HufTable& t, const uint8_t* const src[4], const size_t len[4], uint8_t* const dst[4], const size_t dst_len[4]) {
   HufCursor c0(src[0], len[0], dst[0], dst_len[0]), c1(src[1], len[1], dst[1], dst_len[1]), c2(src[2], len[2], dst[2], dst_len[2]), c3(src[3], len[3], dst[3], dst_len[3]);
-  const int mb = t.max_bits;
-  const uint8_t* sym = t.symbol.data();
-  const uint8_t* nbt = t.nbits.data();
-  // while every stream has at least 64 bits and 1 output slot left, no bounds can be crossed: peek() takes its fast path
-  while (c0.off >= 64 && c1.off >= 64 && c2.off >= 64 && c3.off >= 64 && c0.o < c0.out_len && c1.o < c1.out_len && c2.o < c2.out_len && c3.o < c3.out_len) {
-    const uint32_t i0 = c0.peek(mb), i1 = c1.peek(mb), i2 = c2.peek(mb), i3 = c3.peek(mb);
-    c0.out[c0.o++] = sym[i0]; c1.out[c1.o++] = sym[i1]; c2.out[c2.o++] = sym[i2]; c3.out[c3.o++] = sym[i3];
-    c0.off -= nbt[i0]; c1.off -= nbt[i1]; c2.off -= nbt[i2]; c3.off -= nbt[i3];
+  const int mb = t.max_bits, top = 64 - mb;
+  const uint16_t* tbl = t.entry.data();
+  // Four independent dependency chains per iteration.  Each stream refills a 64-bit container once (an unaligned load whose top
+  // >= 56 bits are the next bits of the stream, first-read bit most significant) and takes five symbols from it: 5 x 11 bits fit.
+  // While every stream has >= 64 bits and 5 output slots left, no bound can be crossed.
+  auto refill = [](const HufCursor& c) -> uint64_t {
+    const int64_t lo = c.off - 56;
+    const size_t byte = (size_t)(lo >> 3);
+    uint64_t w;
+    memcpy(&w, c.p + byte, 8);
+    return w << (64 - (c.off - (int64_t)byte * 8));
+  };
+  while (c0.off >= 64 && c1.off >= 64 && c2.off >= 64 && c3.off >= 64 && c0.o + 5 <= c0.out_len && c1.o + 5 <= c1.out_len && c2.o + 5 <= c2.out_len && c3.o + 5 <= c3.out_len) {
+    uint64_t b0 = refill(c0), b1 = refill(c1), b2 = refill(c2), b3 = refill(c3);
+    int u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+    for (int k = 0; k < 5; k++) {
+      const uint16_t e0 = tbl[b0 >> top], e1 = tbl[b1 >> top], e2 = tbl[b2 >> top], e3 = tbl[b3 >> top];
+      c0.out[c0.o + k] = (uint8_t)e0; c1.out[c1.o + k] = (uint8_t)e1; c2.out[c2.o + k] = (uint8_t)e2; c3.out[c3.o + k] = (uint8_t)e3;
+      b0 <<= e0 >> 8; b1 <<= e1 >> 8; b2 <<= e2 >> 8; b3 <<= e3 >> 8;
+      u0 += e0 >> 8; u1 += e1 >> 8; u2 += e2 >> 8; u3 += e3 >> 8;
+    }
+    c0.o += 5; c1.o += 5; c2.o += 5; c3.o += 5;
+    c0.off -= u0; c1.off -= u1; c2.off -= u2; c3.off -= u3;
   }
   huf_finish(t, c0); huf_finish(t, c1); huf_finish(t, c2); huf_finish(t, c3);
 }
@@ -612,6 +662,21 @@ inline size_t seq_table(int mode, const uint8_t* p, size_t n, int max_log, int m
   }
 }
 
+// kind 0: literal lengths, 1: offsets (base 2^code, code extra bits), 2: match lengths
+inline void seq_entries(FseTable& t, int kind) {
+  const size_t size = t.symbol.size();
+  t.seq.resize(size);
+  for (size_t i = 0; i < size; i++) {
+    const int c = t.symbol[i];
+    SeqEntry e;
+    if (kind == 0) { if (c > 35) throw CodecError("zstd: sequence code out of range"); e.base_value = kLLBase[c]; e.extra_bits = kLLBits[c]; }
+    else if (kind == 2) { if (c > 52) throw CodecError("zstd: sequence code out of range"); e.base_value = kMLBase[c]; e.extra_bits = kMLBits[c]; }
+    else { if (c > 31) throw CodecError("zstd: sequence code out of range"); e.base_value = (uint32_t)1 << c; e.extra_bits = (uint8_t)c; }
+    e.next_base = t.base[i]; e.nbits = t.nbits[i];
+    t.seq[i] = e;
+  }
+}
+
 inline void block_compressed(FrameState& fs, const uint8_t* p, size_t n, std::vector<uint8_t>& lit_buf, uint8_t* out, size_t out_cap, size_t* op_io) {
   // ---- literals section (3.1.1.3.1) ----
   if (n < 1) throw CodecError("zstd: empty compressed block");
@@ -638,7 +703,7 @@ inline void block_compressed(FrameState& fs, const uint8_t* p, size_t n, std::ve
     }
   }
   if (regen > (size_t)128 * 1024) throw CodecError("zstd: literals larger than a block");
-  lit_buf.resize(regen + 8);
+  lit_buf.resize(regen + 32);            // slack: literals are copied 16 bytes at a time
   uint8_t* lits = lit_buf.data();
   size_t pos = hdr;
   if (ltype == 0) {
@@ -687,46 +752,66 @@ inline void block_compressed(FrameState& fs, const uint8_t* p, size_t n, std::ve
   if (pos >= n) throw CodecError("zstd: missing compression modes");
   const int modes = p[pos++];
   if (modes & 3) throw CodecError("zstd: reserved bits set in the compression modes");
-  pos += seq_table((modes >> 6) & 3, p + pos, n - pos, 9, 35, kLLDefault, 36, 6, fs.ll);
-  pos += seq_table((modes >> 4) & 3, p + pos, n - pos, 8, 31, kOFDefault, 29, 5, fs.of);
-  pos += seq_table((modes >> 2) & 3, p + pos, n - pos, 9, 52, kMLDefault, 53, 6, fs.ml);
+  { const int m = (modes >> 6) & 3; pos += seq_table(m, p + pos, n - pos, 9, 35, kLLDefault, 36, 6, fs.ll); if (m != 3 || fs.ll.seq.empty()) seq_entries(fs.ll, 0); }
+  { const int m = (modes >> 4) & 3; pos += seq_table(m, p + pos, n - pos, 8, 31, kOFDefault, 29, 5, fs.of); if (m != 3 || fs.of.seq.empty()) seq_entries(fs.of, 1); }
+  { const int m = (modes >> 2) & 3; pos += seq_table(m, p + pos, n - pos, 9, 52, kMLDefault, 53, 6, fs.ml); if (m != 3 || fs.ml.seq.empty()) seq_entries(fs.ml, 2); }
   if (pos >= n) throw CodecError("zstd: missing sequence bit stream");
   BackBits bs(p + pos, n - pos);
   uint32_t sl = (uint32_t)bs.read(fs.ll.log), so = (uint32_t)bs.read(fs.of.log), sm = (uint32_t)bs.read(fs.ml.log);
+  const SeqEntry* const tl = fs.ll.seq.data();
+  const SeqEntry* const to = fs.of.seq.data();
+  const SeqEntry* const tm = fs.ml.seq.data();
+  const uint8_t* const sp = bs.p;
+  const int64_t fast_hi = (int64_t)bs.n * 8 - 64;        // below this bit offset an 8-byte load never passes the end of the stream
+  uint64_t rep0 = fs.rep[0], rep1 = fs.rep[1], rep2 = fs.rep[2];
   for (size_t i = 0; i < nseq; i++) {
-    const int oc = fs.of.symbol[so], lc = fs.ll.symbol[sl], mc = fs.ml.symbol[sm];
-    if (oc > 31 || lc > 35 || mc > 52) throw CodecError("zstd: sequence code out of range");
-    const uint64_t ov = ((uint64_t)1 << oc) + bs.read(oc);
-    const uint64_t ml = kMLBase[mc] + bs.read(kMLBits[mc]);
-    const uint64_t ll = kLLBase[lc] + bs.read(kLLBits[lc]);
-    if (i + 1 < nseq) {
-      sl = fs.ll.base[sl] + (uint32_t)bs.read(fs.ll.nbits[sl]);
-      sm = fs.ml.base[sm] + (uint32_t)bs.read(fs.ml.nbits[sm]);
-      so = fs.of.base[so] + (uint32_t)bs.read(fs.of.nbits[so]);
+    const SeqEntry el = tl[sl], eo = to[so], em = tm[sm];
+    uint64_t ov, ml, ll;
+    if (bs.off <= fast_hi && bs.off >= 160 && i + 1 < nseq) {
+      // <= 89 bits per sequence, far from both ends of the stream: unchecked 8-byte loads (a zero-bit read masks to 0)
+      int64_t off = bs.off;
+      auto rd = [&](int nb) -> uint64_t { off -= nb; uint64_t w; memcpy(&w, sp + (off >> 3), 8); return (w >> (off & 7)) & (((uint64_t)1 << nb) - 1); };
+      ov = eo.base_value + rd(eo.extra_bits);
+      ml = em.base_value + rd(em.extra_bits);
+      ll = el.base_value + rd(el.extra_bits);
+      sl = el.next_base + (uint32_t)rd(el.nbits);
+      sm = em.next_base + (uint32_t)rd(em.nbits);
+      so = eo.next_base + (uint32_t)rd(eo.nbits);
+      bs.off = off;
+    } else {
+      ov = eo.base_value + bs.read(eo.extra_bits);
+      ml = em.base_value + bs.read(em.extra_bits);
+      ll = el.base_value + bs.read(el.extra_bits);
+      if (i + 1 < nseq) {
+        sl = el.next_base + (uint32_t)bs.read(el.nbits);
+        sm = em.next_base + (uint32_t)bs.read(em.nbits);
+        so = eo.next_base + (uint32_t)bs.read(eo.nbits);
+      }
+      if (bs.off < 0) throw CodecError("zstd: sequence bit stream ends early");
     }
-    if (bs.off < 0) throw CodecError("zstd: sequence bit stream ends early");
     uint64_t offset;
     if (ov > 3) {
       offset = ov - 3;
-      fs.rep[2] = fs.rep[1]; fs.rep[1] = fs.rep[0]; fs.rep[0] = offset;
+      rep2 = rep1; rep1 = rep0; rep0 = offset;
     } else {
       uint64_t idx = ov - 1;
       if (ll == 0) idx++;
-      if (idx == 0) offset = fs.rep[0];
+      if (idx == 0) offset = rep0;
       else {
-        offset = idx < 3 ? fs.rep[idx] : fs.rep[0] - 1;
-        if (idx > 1) fs.rep[2] = fs.rep[1];
-        fs.rep[1] = fs.rep[0]; fs.rep[0] = offset;
+        offset = idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
+        if (idx > 1) rep2 = rep1;
+        rep1 = rep0; rep0 = offset;
       }
     }
     if (ll > regen - lp || ll > out_cap - op) throw CodecError("zstd: sequence literals past their section / the output");
-    memcpy(out + op, lits + lp, ll);
+    if (ll <= 16 && out_cap - op >= 16) copy16(out + op, lits + lp);       // lit_buf has 32 bytes of slack
+    else memcpy(out + op, lits + lp, ll);
     op += ll; lp += ll;
     if (offset == 0 || offset > op || ml > out_cap - op) throw CodecError("zstd: match outside the output (dictionaries are not supported)");
-    if (offset >= ml) memcpy(out + op, out + op - offset, ml);
-    else for (uint64_t k = 0; k < ml; k++) out[op + k] = out[op - offset + k];
+    match_copy(out + op, offset, ml, out_cap - op - ml);
     op += ml;
   }
+  fs.rep[0] = rep0; fs.rep[1] = rep1; fs.rep[2] = rep2;
   if (bs.off != 0) throw CodecError("zstd: sequence bit stream not consumed exactly");
   const size_t rest = regen - lp;
   if (rest > out_cap - op) throw CodecError("zstd: output larger than the page header says");

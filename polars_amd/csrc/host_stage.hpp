@@ -30,8 +30,8 @@ struct PinnedStage {
   void upload(void* dst, const void* src, size_t bytes) {
     if (!bytes) return;
     PLX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream()));
-    for (Slot& s : slot_)
-      if (s.p == src) { PLX_HIP(hipEventRecord(s.ev, stream())); s.pending = true; }
+    for (Slot& s : slot_)          // any part of a staging buffer: the buffer is busy until this copy (and those queued before it) has run
+      if (s.p && (const uint8_t*)src >= (const uint8_t*)s.p && (const uint8_t*)src < (const uint8_t*)s.p + s.cap) { PLX_HIP(hipEventRecord(s.ev, stream())); s.pending = true; }
   }
   static PinnedStage& for_this_thread() {
     static thread_local PinnedStage* st = new PinnedStage();    // never destroyed (see above)

@@ -15,10 +15,12 @@
 // (decode per page into an Arrow array), crates/polars-io/src/parquet/read/read_impl.rs (row groups x projected columns).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <exception>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -108,6 +110,11 @@ inline LeafType leaf_type(const Leaf& l) {
     case PT_INT96: t.dtype = PLX_I64; t.logical = LO_DATETIME_NS; t.src_width = 12; return t;
     default: t.why = l.logical == LG_DECIMAL ? "decimal (FIXED_LEN_BYTE_ARRAY)" : "FIXED_LEN_BYTE_ARRAY"; return t;
   }
+}
+
+// host threads for page-sized tasks: half the hardware threads (the other half is the caller's: other columns, the GPU driver), 2 .. 64
+inline size_t host_threads(size_t tasks) {
+  return std::min<size_t>(std::min<size_t>(64, std::max(2u, std::thread::hardware_concurrency() / 2)), tasks);
 }
 
 inline uint32_t out_width_of(int dtype) {
@@ -276,23 +283,79 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
   std::unordered_map<std::string, uint32_t> cat_index;
   const size_t npos = (size_t)-1;
   uint64_t row0 = 0;
-  for (const ChunkRef& ch : chunks) {
+  // Host codecs: pages are inflated by host threads.  When every chunk of the read uses one (the normal case: a file has one codec), the
+  // pages of ALL chunks are inflated in one parallel pass after the page walk -- a chunk alone has too few pages to keep the cores busy --
+  // into one page-locked image of the column, laid out like the device blob.  Mixed columns fall back to chunk-by-chunk.
+  struct Inflate { const uint8_t* src; size_t n; uint8_t* dst; size_t out; bool copy; int codec; };
+  auto run_inflate = [&](const std::vector<Inflate>& tasks) {
+    const size_t threads = host_threads(tasks.size());
+    std::vector<std::exception_ptr> errs(std::max<size_t>(threads, 1));
+    std::atomic<size_t> next{0};
+    auto work = [&](size_t t) {
+      try {
+        for (size_t i = next.fetch_add(1); i < tasks.size(); i = next.fetch_add(1)) {
+          const Inflate& j = tasks[i];
+          if (j.copy) { if (j.n != j.out) throw FormatError("uncompressed part of a page whose two sizes differ"); if (j.n) memcpy(j.dst, j.src, j.n); }
+          else host_inflate(j.codec, j.src, j.n, j.dst, j.out);
+        }
+      } catch (...) { errs[t] = std::current_exception(); }
+    };
+    if (threads <= 1) { if (!tasks.empty()) work(0); }
+    else {
+      std::vector<std::thread> pool;
+      for (size_t t = 0; t < threads; t++) pool.emplace_back(work, t);
+      for (std::thread& th : pool) th.join();
+    }
+    for (std::exception_ptr& ep : errs)
+      if (ep) {
+        try { std::rethrow_exception(ep); }
+        catch (const codec::CodecError& e) { throw FormatError(std::string("column '") + leaf.name + "': " + e.what()); }
+      }
+  };
+  bool all_host = !chunks.empty();
+  for (const ChunkRef& ch : chunks) all_host = all_host && (ch.c->codec == CODEC_ZSTD || ch.c->codec == CODEC_LZ4_RAW || ch.c->codec == CODEC_GZIP);
+  // ... in batches of consecutive chunks of about kInflateBatch image bytes: the page-locked image stays bounded, and batch k is on its
+  // way over PCIe (the other staging buffer) while batch k + 1 is inflated
+  const char* batch_env = getenv("PLX_PARQUET_INFLATE_BATCH");       // bytes; the tests shrink it to cross batch borders with small files
+  const size_t kInflateBatch = batch_env && atoll(batch_env) > 0 ? (size_t)atoll(batch_env) : (size_t)256 << 20;
+  std::vector<size_t> batch_last(chunks.size(), 0);       // per chunk: index of the last chunk of its batch
+  for (size_t i = 0; i < chunks.size();) {
+    size_t j = i, bytes = 0;
+    while (j < chunks.size() && (j == i || bytes + chunks[j].blob_cap <= kInflateBatch)) bytes += chunks[j++].blob_cap;
+    for (size_t k = i; k < j; k++) batch_last[k] = j - 1;
+    i = j;
+  }
+  uint8_t* batch_image = nullptr;
+  size_t batch_base = 0;
+  std::vector<Inflate> inflate_all;
+  std::vector<std::vector<uint8_t>> stored_all;          // the stored bytes of a batch's chunks stay alive until its pass has run
+  struct ImageUpload { size_t blob_off, bytes; };
+  std::vector<ImageUpload> image_uploads;
+  for (size_t ci = 0; ci < chunks.size(); ci++) {
+    const ChunkRef& ch = chunks[ci];
     const ColumnChunk& c = *ch.c;
+    if (all_host && (ci == 0 || batch_last[ci - 1] != batch_last[ci])) {      // first chunk of a batch
+      const ChunkRef& last = chunks[batch_last[ci]];
+      batch_base = ch.blob_off;
+      batch_image = be.host_stage(last.blob_off + last.blob_cap - batch_base + 64);
+    }
     const size_t sz = (size_t)c.total_compressed_size;
     const bool host_codec = c.codec == CODEC_ZSTD || c.codec == CODEC_LZ4_RAW || c.codec == CODEC_GZIP;
     const bool codec_on = c.codec == CODEC_SNAPPY;          // pages decompressed on the device
     // Device codec / none: the stored bytes are staged and uploaded as they are.  Host codec: the stored bytes stay in pageable memory;
     // what is staged and uploaded is the chunk's IMAGE -- the page payloads decompressed, back to back -- and the pages then look
     // like pages of an uncompressed file to every kernel.
-    std::vector<uint8_t> stored;
+    std::vector<uint8_t> stored_here;
     uint8_t* host = nullptr;
     uint8_t* image = nullptr;
     size_t ipos = 0;
-    if (host_codec) { stored.resize(sz + 16); host = stored.data(); image = be.host_stage(ch.blob_cap + 16); }
-    else host = be.host_stage(sz + 16);
+    if (host_codec) {
+      std::vector<uint8_t>& stored = all_host ? (stored_all.emplace_back(), stored_all.back()) : stored_here;
+      stored.resize(sz + 16); host = stored.data();
+      image = all_host ? batch_image + (ch.blob_off - batch_base) : be.host_stage(ch.blob_cap + 16);
+    } else host = be.host_stage(sz + 16);
     f.pread_sliced(host, sz, c.start());
     if (stats) stats->file_bytes += sz;
-    struct Inflate { const uint8_t* src; size_t n; uint8_t* dst; size_t out; bool copy; };
     std::vector<Inflate> inflate;
     size_t pos = 0;
     int64_t seen = 0;
@@ -313,12 +376,12 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
           if (h.def_len < 0 || h.rep_len < 0 || (int64_t)h.def_len + h.rep_len > h.compressed_size || (int64_t)h.def_len + h.rep_len > h.uncompressed_size)
             throw FormatError("v2 level bytes exceed the page");
           const size_t lv = (size_t)h.def_len + (size_t)h.rep_len;
-          inflate.push_back({host + pos, lv, image + ipos, lv, true});
+          inflate.push_back({host + pos, lv, image + ipos, lv, true, c.codec});
           const bool no_values = (size_t)h.compressed_size == lv;     // all-null page without value bytes: nothing to inflate, whatever is_compressed says
           if (no_values && out != lv) throw FormatError("v2 page without value bytes whose sizes differ");
-          inflate.push_back({host + pos + lv, (size_t)h.compressed_size - lv, image + ipos + lv, out - lv, !h.is_compressed || no_values});
+          inflate.push_back({host + pos + lv, (size_t)h.compressed_size - lv, image + ipos + lv, out - lv, !h.is_compressed || no_values, c.codec});
         } else {
-          inflate.push_back({host + pos, (size_t)h.compressed_size, image + ipos, out, false});
+          inflate.push_back({host + pos, (size_t)h.compressed_size, image + ipos, out, false, c.codec});
         }
         ipos += out;
       }
@@ -423,37 +486,24 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     }
     if (seen != c.num_values) throw FormatError("pages of a column chunk hold more values than its metadata says");
     if (host_codec) {
-      // one page per host thread at a time; errors of any of them fail the read
-      const size_t threads = std::min<size_t>(std::min<size_t>(32, std::max(2u, std::thread::hardware_concurrency() / 2)), inflate.size());
-      std::vector<std::exception_ptr> errs(std::max<size_t>(threads, 1));
-      auto work = [&](size_t t) {
-        try {
-          for (size_t i = t; i < inflate.size(); i += std::max<size_t>(threads, 1)) {
-            const Inflate& j = inflate[i];
-            if (j.copy) { if (j.n != j.out) throw FormatError("uncompressed part of a page whose two sizes differ"); if (j.n) memcpy(j.dst, j.src, j.n); }
-            else host_inflate(c.codec, j.src, j.n, j.dst, j.out);
-          }
-        } catch (...) { errs[t] = std::current_exception(); }
-      };
-      if (threads <= 1) { if (!inflate.empty()) work(0); }
-      else {
-        std::vector<std::thread> pool;
-        for (size_t t = 0; t < threads; t++) pool.emplace_back(work, t);
-        for (std::thread& th : pool) th.join();
-      }
-      for (std::exception_ptr& ep : errs)
-        if (ep) {
-          try { std::rethrow_exception(ep); }
-          catch (const codec::CodecError& e) { throw FormatError(std::string("column '") + leaf.name + "': " + e.what()); }
-        }
       if (stats) { stats->host_inflated_pages += inflate.size(); stats->host_inflated_bytes += ipos; }
-      be.upload(blob_addr + ch.blob_off, image, ipos);
+      if (all_host) {
+        inflate_all.insert(inflate_all.end(), inflate.begin(), inflate.end());
+        image_uploads.push_back({ch.blob_off, ipos});
+        if (ci == batch_last[ci]) {
+          run_inflate(inflate_all);
+          for (const ImageUpload& u : image_uploads) be.upload(blob_addr + u.blob_off, batch_image + (u.blob_off - batch_base), u.bytes);
+          inflate_all.clear(); image_uploads.clear(); stored_all.clear();
+        }
+      } else {
+        run_inflate(inflate);
+        be.upload(blob_addr + ch.blob_off, image, ipos);
+      }
     } else {
       be.upload(blob_addr + ch.blob_off, host, sz);
     }
     row0 += (uint64_t)ch.rows;
   }
-
   // -- scratch for the decompressed streams ---------------------------------------------------------------------------------------------
   typename B::Mem scratch{};
   if (!jobs.empty()) {
@@ -743,7 +793,7 @@ template <class B> ColumnResult<B> read_string_column_host(B& be, File& f, const
     if (seen != c.num_values) throw FormatError("pages of a column chunk hold more values than its metadata says");
     // pages in parallel: each writes the views of its own rows and a byte per row of validity
     std::vector<std::vector<uint8_t>> page_valid(tasks.size());
-    const size_t threads = std::min<size_t>(16, tasks.size());
+    const size_t threads = host_threads(tasks.size());
     std::vector<std::exception_ptr> errs(std::max<size_t>(threads, 1));
     auto work = [&](size_t t) {
       try {
@@ -975,7 +1025,7 @@ template <class B> ColumnResult<B> read_fixed_column_host(B& be, File& f, const 
     }
     if (seen != c.num_values) throw FormatError("pages of a column chunk hold more values than its metadata says");
     std::vector<std::vector<uint8_t>> page_valid(tasks.size());
-    const size_t threads = std::min<size_t>(std::min<size_t>(32, std::max(2u, std::thread::hardware_concurrency() / 2)), tasks.size());
+    const size_t threads = host_threads(tasks.size());
     std::vector<std::exception_ptr> errs(std::max<size_t>(threads, 1));
     auto work = [&](size_t t) {
       try {

@@ -611,3 +611,18 @@ def test_the_reference_s_own_parquet_fixtures(name):
     if name == "empty_datapage_v2.snappy.parquet":
         r = E.read_column(path, [0], 0)
         assert r["null_count"] == 1 and r["valid"].tolist() == [False]
+
+
+@pytest.mark.parametrize("compression", ["zstd", "gzip", "lz4"])
+def test_host_inflate_batches(tmp_path, compression, monkeypatch):
+    """Host-codec pages are inflated column-wide, in batches of consecutive chunks (parquet_reader.hpp: kInflateBatch).  With the batch
+    shrunk to 40 KB a 12-row-group file crosses many batch borders (single-chunk batches, multi-chunk batches, the last partial one)."""
+    monkeypatch.setenv("PLX_PARQUET_INFLATE_BATCH", "40000")
+    n = 60_000
+    t = mixed_table(n)
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression=compression, row_group_size=5000, data_page_size=3000)
+    for name in ("i64", "f64", "s", "b", "i8"):
+        if name in t.column_names:
+            check_column(path, t, name)
+    check_column(path, t, t.column_names[0], row_groups=[11, 0, 5, 6, 7])
