@@ -12,6 +12,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <atomic>
 #include <thread>
 
 #include "core.hpp"
@@ -69,6 +70,52 @@ ColumnPtr read_fixed_column(File& f, const std::vector<int>& bsel, int col, cons
   if (file_dtype == PLX_BOOL) PLX_HIP(hipMemsetAsync(c->values->ptr, 0, bitmap_bytes(total), stream()));
   if (any_nulls) { c->validity = dev_alloc_zero(bitmap_bytes(total)); } else c->null_count = 0;
   int64_t row = 0, nulls = 0;
+  // Compressed bodies: a values buffer is one LZ4 frame / zstd stream of up to a whole record batch -- inflating them one after the
+  // other on this thread would leave the host idle.  The buffers of all selected batches are inflated in parallel straight into a
+  // page-locked image of the column (groups of ~256 MB: group k is on its way over PCIe while group k + 1 is inflated).
+  bool any_compressed = false;
+  for (int b : bsel) any_compressed = any_compressed || f.batches[b].compressed;
+  const bool values_in_parallel = any_compressed && file_dtype != PLX_BOOL;
+  if (values_in_parallel) {
+    struct Task { const ipc::BatchMeta* bm; int64_t body; const ipc::BufferRef* vb; size_t off, bytes; };
+    const size_t kGroup = (size_t)256 << 20;
+    size_t i = 0;
+    int64_t row0 = 0;
+    while (i < bsel.size()) {
+      std::vector<Task> tasks;
+      size_t bytes = 0, j = i;
+      int64_t rows = 0;
+      while (j < bsel.size() && (j == i || bytes + (size_t)f.batches[bsel[j]].length * (size_t)ct.width <= kGroup)) {
+        const ipc::BatchMeta& bm = f.batches[bsel[j]];
+        const Slot s = slot_of(f, bm, col);
+        const size_t nb = (size_t)bm.length * (size_t)ct.width;
+        if (nb) tasks.push_back({&bm, f.body_off[bsel[j]], &bm.buffers[s.buf + 1], bytes, nb});
+        bytes += nb; rows += bm.length; j++;
+      }
+      if (bytes) {
+        uint8_t* img = st.get(bytes);
+        const size_t threads = std::min<size_t>(std::min<size_t>(64, std::max(2u, std::thread::hardware_concurrency() / 2)), tasks.size());
+        std::vector<std::exception_ptr> errs(std::max<size_t>(threads, 1));
+        std::atomic<size_t> next{0};
+        auto work = [&](size_t t) {
+          try {
+            for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1))
+              ipc::load_buffer(f, *tasks[k].bm, tasks[k].body, *tasks[k].vb, img + tasks[k].off, tasks[k].bytes);
+          } catch (...) { errs[t] = std::current_exception(); }
+        };
+        if (threads <= 1) work(0);
+        else {
+          std::vector<std::thread> pool;
+          for (size_t t = 0; t < threads; t++) pool.emplace_back(work, t);
+          for (std::thread& th : pool) th.join();
+        }
+        for (std::exception_ptr& ep : errs) if (ep) std::rethrow_exception(ep);
+        st.upload((uint8_t*)c->values->ptr + (size_t)row0 * (size_t)ct.width, img, bytes);
+      }
+      row0 += rows;
+      i = j;
+    }
+  }
   for (int b : bsel) {
     const ipc::BatchMeta& bm = f.batches[b];
     const Slot s = slot_of(f, bm, col);
@@ -77,6 +124,8 @@ ColumnPtr read_fixed_column(File& f, const std::vector<int>& bsel, int col, cons
     if (n == 0) continue;
     if (file_dtype == PLX_BOOL) {
       blit_bitmap(f, st, bm, body, vb, n, c->values->as<uint64_t>(), row);
+    } else if (values_in_parallel) {
+      // done above
     } else {
       const size_t bytes = (size_t)n * (size_t)ct.width;
       uint8_t* h = st.get(bytes);
