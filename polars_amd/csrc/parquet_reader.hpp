@@ -127,7 +127,7 @@ inline uint32_t out_width_of(int dtype) {
   }
 }
 
-// ---- host Snappy (string dictionary pages only: a few KB per chunk) ---------------------------------------------------------------------------
+// ---- host Snappy (string dictionary pages; pages of the columns that host threads decode) ---------------------------------------------------------------------------
 inline std::vector<uint8_t> snappy_decompress_host(const uint8_t* in, size_t n, size_t expect) {
   size_t pos = 0, out_len = 0;
   for (int shift = 0;; shift += 7) {
@@ -152,7 +152,8 @@ inline std::vector<uint8_t> snappy_decompress_host(const uint8_t* in, size_t n, 
         len += 1; pos += nb;
       }
       if (len > n - pos || len > out_len - o) throw FormatError("snappy: literal past the end");
-      memcpy(out.data() + o, in + pos, len);
+      if (len <= 16 && n - pos >= 16 && out_len - o >= 16) codec::copy16(out.data() + o, in + pos);
+      else memcpy(out.data() + o, in + pos, len);
       pos += len; o += len;
       continue;
     }
@@ -167,7 +168,7 @@ inline std::vector<uint8_t> snappy_decompress_host(const uint8_t* in, size_t n, 
       len = (tag >> 2) + 1; off = load_u32(in + pos); pos += 4;
     }
     if (off == 0 || off > o || len > out_len - o) throw FormatError("snappy: bad back-reference");
-    for (size_t i = 0; i < len; i++) out[o + i] = out[o - off + i];
+    codec::match_copy(out.data() + o, off, len, out_len - o - len);
     o += len;
   }
   if (o != out_len) throw FormatError("snappy: stream ends early");
