@@ -769,14 +769,18 @@ inline void block_compressed(FrameState& fs, const uint8_t* p, size_t n, std::ve
     uint64_t ov, ml, ll;
     if (bs.off <= fast_hi && bs.off >= 160 && i + 1 < nseq) {
       // <= 89 bits per sequence, far from both ends of the stream: unchecked 8-byte loads (a zero-bit read masks to 0)
+      // three loads: the offset's extra bits (<= 31), both lengths' (<= 32 together), the three state updates (<= 26 together)
       int64_t off = bs.off;
-      auto rd = [&](int nb) -> uint64_t { off -= nb; uint64_t w; memcpy(&w, sp + (off >> 3), 8); return (w >> (off & 7)) & (((uint64_t)1 << nb) - 1); };
-      ov = eo.base_value + rd(eo.extra_bits);
-      ml = em.base_value + rd(em.extra_bits);
-      ll = el.base_value + rd(el.extra_bits);
-      sl = el.next_base + (uint32_t)rd(el.nbits);
-      sm = em.next_base + (uint32_t)rd(em.nbits);
-      so = eo.next_base + (uint32_t)rd(eo.nbits);
+      auto window = [&](int nb) -> uint64_t { off -= nb; uint64_t w; memcpy(&w, sp + (off >> 3), 8); return w >> (off & 7); };
+      auto low = [](uint64_t v, int nb) -> uint64_t { return v & (((uint64_t)1 << nb) - 1); };
+      ov = eo.base_value + low(window(eo.extra_bits), eo.extra_bits);
+      const uint64_t w2 = window(em.extra_bits + el.extra_bits);            // [ll extra | ml extra] from the low end up: ll was written last
+      ll = el.base_value + low(w2, el.extra_bits);
+      ml = em.base_value + low(w2 >> el.extra_bits, em.extra_bits);
+      const uint64_t w3 = window(el.nbits + em.nbits + eo.nbits);
+      so = eo.next_base + (uint32_t)low(w3, eo.nbits);
+      sm = em.next_base + (uint32_t)low(w3 >> eo.nbits, em.nbits);
+      sl = el.next_base + (uint32_t)low(w3 >> (eo.nbits + em.nbits), el.nbits);
       bs.off = off;
     } else {
       ov = eo.base_value + bs.read(eo.extra_bits);
