@@ -21,7 +21,7 @@ export PLX_SKIP_TORCH_PREIMPORT=1
 timeout 120 python -m pytest tests/test_gpu_parquet.py tests/test_gpu_ipc.py tests/test_gpu_io.py tests/test_gpu_zzz_scan_host_paths.py -m gpu -q --timeout 90 --durations=5 > $OUT/pytest_scan.log 2>&1; el "scan gpu tests exit $?"
 tail -15 $OUT/pytest_scan.log | cut -c1-250
 unset PLX_SKIP_TORCH_PREIMPORT
-PLX_SNAPPY_TIMING=1 timeout 60 python tools/parquet_bench.py 2e7 > $OUT/parquet_bench.jsonl 2> $OUT/parquet_bench.err; el "scan bench exit $?"
+PLX_SNAPPY_TIMING=1 timeout 120 python tools/parquet_bench.py 2e7 > $OUT/parquet_bench.jsonl 2> $OUT/parquet_bench.err; el "scan bench exit $?"
 cut -c1-330 $OUT/parquet_bench.jsonl; grep pq_snappy $OUT/parquet_bench.err | tail -3 | cut -c1-400
 timeout 200 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err; el "bench exit $?"
 python - $OUT/bench_full.json <<'PY' | tee -a $OUT/summary.txt
