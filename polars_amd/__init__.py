@@ -12,10 +12,10 @@ from .datatypes import (Boolean, Categorical, DataType, Date, Datetime, Float32,
                         UInt16, UInt32, UInt64)
 from .expr import Expr, col, count, len, lit, max, mean, min, sum  # noqa: A004
 from .frame import DataFrame, GroupBy, LazyFrame, Series, arg_sort_by
-from .io import read_parquet, scan_parquet
+from .io import concat, read_parquet, scan_parquet
 from .ipc_io import read_ipc, scan_ipc
 
-__all__ = ["init", "last_plan", "PlxError", "UnsupportedError", "DataFrame", "LazyFrame", "GroupBy", "Series", "arg_sort_by", "scan_parquet", "read_parquet", "scan_ipc", "read_ipc", "Expr", "col", "lit",
+__all__ = ["init", "last_plan", "PlxError", "UnsupportedError", "DataFrame", "LazyFrame", "GroupBy", "Series", "arg_sort_by", "scan_parquet", "read_parquet", "concat", "scan_ipc", "read_ipc", "Expr", "col", "lit",
            "len", "sum", "mean", "min", "max", "count", "DataType", "Boolean", "Int8", "Int16", "Int32", "Int64", "UInt8", "UInt16",
            "UInt32", "UInt64", "Float32", "Float64", "Date", "Datetime", "Categorical"]
 __version__ = "0.1.0"

@@ -296,6 +296,52 @@ def concat_frames(dfs):
     return res
 
 
+class ConcatFrame:
+    """Scan source of concat([...]) (IR::Union; executors/union.rs): the inputs are collected -- each its own plan -- and concatenated on
+    the device (concat_frames).  It looks like an in-memory frame to the lowering; projections above it are not pushed into the inputs
+    (for several FILES with one schema, scan_parquet / scan_ipc over the list is the tool: it prunes and projects per file)."""
+
+    def __init__(self, lfs):
+        self._lfs = list(lfs)
+        if not self._lfs:
+            raise ValueError("concat of no frames")
+        schemas = [lf._lower()[2] for lf in self._lfs]
+        first = schemas[0]
+        for sc in schemas[1:]:
+            if list(sc) != list(first):
+                raise ValueError(f"concat: frames have different columns: {list(sc)} vs {list(first)}")
+            for n in first:
+                a, b = first[n], sc[n]
+                if a != b or a.physical != b.physical or getattr(a, "time_unit", None) != getattr(b, "time_unit", None):
+                    raise TypeError(f"concat: column {n!r} is {a} in one frame and {b} in another (no supertype casting on this path)")
+        self._schema = dict(first)
+        self._df = None
+
+    @property
+    def schema(self) -> Dict[str, T.DataType]:
+        return dict(self._df.schema) if self._df is not None else dict(self._schema)
+
+    def materialise(self):
+        if self._df is None:
+            self._df = concat_frames([lf.collect() for lf in self._lfs])
+        return self._df
+
+    def _frame_handle(self) -> int:
+        return self.materialise()._frame_handle()
+
+
+def concat(items, how: str = "vertical"):
+    """polars.concat(items, how="vertical"): DataFrames -> DataFrame (device-to-device copies, dictionaries unified); if any item is a
+    LazyFrame -> LazyFrame over a deferred source."""
+    from .frame import DataFrame, LazyFrame
+    if how != "vertical":
+        raise NotImplementedError(f"concat how={how!r} (vertical is on this path)")
+    items = list(items)
+    if items and all(isinstance(x, DataFrame) for x in items):
+        return concat_frames(items)
+    return LazyFrame(P.Node("scan", frame=ConcatFrame([x.lazy() if isinstance(x, DataFrame) else x for x in items])))
+
+
 def split_by_rows(rows: Sequence[int], parts: int) -> List[List[int]]:
     """Indices 0..len(rows)-1 cut into `parts` CONTIGUOUS runs of about equal row totals (entry i goes to the run in which the middle
     of its row range falls): the row-group shards of a scan that several GPUs share (independent row ranges).  Runs

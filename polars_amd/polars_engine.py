@@ -175,6 +175,15 @@ class Translator:
             return self.frame_of(node).lazy()
         if kind == "Scan":
             return self._file_scan(node)
+        if kind == "Union":                                 # visitor/nodes.rs:361-370, filled at :783-790
+            from .io import concat
+            try:
+                out = concat([self.plan(i) for i in node.inputs])
+            except (TypeError, ValueError) as e:                # differing schemas: the CPU engine applies its own supertype rules
+                raise NotSupported(f"union: {e}")
+            if getattr(node, "slice", None) is not None:
+                out = out.slice(int(node.slice[0]), int(node.slice[1]))
+            return out
         if kind == "Filter":
             return self.plan(node.input).filter(self.named(node.predicate))
         if kind in ("Select", "Reduce"):

@@ -235,3 +235,15 @@ def test_results_written_and_scanned_again(pl, tmp_path):
     assert pq.read_table(p2).to_pydict() == t.to_pydict()
     for again in (pl.read_parquet(p2), pl.read_ipc(p3)):
         compare(again, t, t.column_names)
+
+
+def test_concat_of_frames_and_plans(pl):
+    """polars.concat(how="vertical"): eager frames and lazy plans; string dictionaries of the parts are unified."""
+    a = pl.DataFrame({"k": np.arange(5), "s": pl.Series.from_arrow("s", pa.array(["x", "y", None, "x", "y"])), "f": np.arange(5) * 0.5})
+    b = pl.DataFrame({"k": np.arange(5, 9), "s": pl.Series.from_arrow("s", pa.array(["z", "y", "z", None])), "f": np.arange(4) * 2.0})
+    both = pl.concat([a, b])
+    assert both.height == 9 and both["k"].to_list() == list(range(9)) and both["s"].to_list() == ["x", "y", None, "x", "y", "z", "y", "z", None]
+    assert both["f"].to_list() == [0.0, 0.5, 1.0, 1.5, 2.0, 0.0, 2.0, 4.0, 6.0]
+    c = pl.col
+    out = pl.concat([a.lazy().filter(c("k") >= 3), b.lazy()]).group_by("s").agg(c("f").sum().alias("sf"), pl.len().alias("n")).collect().sort_host("s")
+    assert out["s"] == ["x", "y", "z", None] and out["n"] == [1, 2, 2, 1] and out["sf"] == [1.5, 4.0, 4.0, 6.0]

@@ -310,3 +310,37 @@ def test_file_scan_over_several_files_and_ipc(tmp_path):
     lf = eng.Translator(MapTraverser(nodes, {}, 0)).plan()
     src = lf._node.frame
     assert isinstance(src, ipc_io.IpcFrame) and src.num_row_groups == 4 and src.num_rows == 400 and list(src.schema) == ["v"]
+
+
+Union = _cls("Union", "inputs", "slice", "rows", "maintain_order")
+
+
+def test_union_node_becomes_a_device_concat():
+    """IR::Union (visitor/nodes.rs:361-370): the inputs are translated one by one, the node becomes a scan over a deferred source that
+    collects them and concatenates on the device (io.ConcatFrame); a slice carried by the node stays a Slice; inputs whose schemas
+    differ are left to the CPU engine (which has supertype rules for them)."""
+    from polars_amd import io
+    a = pl.DataFrame([ph("k", pl.Int64), ph("s", pl.Categorical(["x", "y"]), rng=(0, 1)), ph("t", pl.Datetime("ns"))])
+    b = pl.DataFrame([ph("k", pl.Int64, n=1000), ph("s", pl.Categorical(["y", "z"]), rng=(0, 1), n=1000), ph("t", pl.Datetime("ns"), n=1000)])
+    exprs = {0: Column(name="k"), 1: Literal(value=5, dtype=pl.Int64), 2: BinaryExpr(left=0, op=Operator.Gt, right=1)}
+    nodes = {0: DataFrameScan(df=a, projection=None, selection=None), 1: DataFrameScan(df=b, projection=None, selection=None),
+             2: Filter(input=1, predicate=PyExprIR(node=2, output_name="k")), 3: Union(inputs=[0, 2], slice=(3, 10), rows=(None, 0), maintain_order=True)}
+    lf = eng.Translator(MapTraverser(nodes, exprs, 3), frame_of=lambda node: node.df).plan()
+    assert lf._node.kind == "slice" and (lf._node.offset, lf._node.length) == (3, 10) and lf._node.input.kind == "scan"
+    src = lf._node.input.frame
+    assert isinstance(src, io.ConcatFrame) and list(src.schema) == ["k", "s", "t"] and src.schema["t"].time_unit == "ns" and len(src._lfs) == 2
+    assert src._lfs[1]._node.kind == "filter"
+    low, root, schema = lf._lower()                            # lowers without touching a GPU: the source is only a schema until collect()
+    assert list(schema) == ["k", "s", "t"]
+    # the user-facing spelling
+    assert isinstance(pl.concat([a.lazy(), b.lazy().filter(pl.col("k") > 5)])._node.frame, io.ConcatFrame)
+    # schemas that differ: names, dtypes, time units
+    for other in (pl.DataFrame([ph("k", pl.Int64), ph("s2", pl.Categorical(["x"]))]), pl.DataFrame([ph("k", pl.Int32), ph("s", pl.Categorical(["x"])), ph("t", pl.Datetime("ns"))]),
+                  pl.DataFrame([ph("k", pl.Int64), ph("s", pl.Categorical(["x"])), ph("t", pl.Datetime("us"))])):
+        bad = {0: DataFrameScan(df=a, projection=None, selection=None), 1: DataFrameScan(df=other, projection=None, selection=None),
+               2: Union(inputs=[0, 1], slice=None, rows=(None, 0), maintain_order=True)}
+        with pytest.raises(eng.NotSupported) as ei:
+            eng.Translator(MapTraverser(bad, {}, 2), frame_of=lambda node: node.df).plan()
+        assert "union" in str(ei.value)
+    with pytest.raises(NotImplementedError):
+        pl.concat([a, b], how="horizontal")
