@@ -55,8 +55,14 @@ def _dtype(dt: Any) -> Optional[T.DataType]:
         return None
     for key, val in _DTYPES.items():
         if name == key or text == key or text.startswith(key + "("):
-            if key == "Datetime" and "time_unit='us'" not in text and text != "Datetime" and "time_unit" in text:
-                raise NotSupported(f"Datetime time unit other than us: {text}")
+            if key == "Datetime" and "time_unit" in text:
+                import re
+                unit = re.search(r"time_unit='(\w+)'", text)
+                zone = re.search(r"time_zone='([^']+)'", text)
+                if unit is None or unit.group(1) not in T.DatetimeType.UNITS:
+                    raise NotSupported(f"Datetime time unit: {text}")
+                if unit.group(1) != "us" or zone is not None:
+                    return T.Datetime(unit.group(1), zone.group(1) if zone else None)      # casts between units are refused when the plan is lowered (plan.py)
             return val
     raise NotSupported(f"dtype {text}")
 
