@@ -128,7 +128,13 @@ inline uint32_t out_width_of(int dtype) {
 }
 
 // ---- host Snappy (string dictionary pages; pages of the columns that host threads decode) ---------------------------------------------------------------------------
+inline void snappy_decompress_into(const uint8_t* in, size_t n, uint8_t* out, size_t expect);
 inline std::vector<uint8_t> snappy_decompress_host(const uint8_t* in, size_t n, size_t expect) {
+  std::vector<uint8_t> out(expect);
+  snappy_decompress_into(in, n, out.data(), expect);
+  return out;
+}
+inline void snappy_decompress_into(const uint8_t* in, size_t n, uint8_t* out, size_t expect) {
   size_t pos = 0, out_len = 0;
   for (int shift = 0;; shift += 7) {
     if (pos >= n || shift > 28) throw FormatError("snappy: bad preamble");
@@ -137,7 +143,6 @@ inline std::vector<uint8_t> snappy_decompress_host(const uint8_t* in, size_t n, 
     if (!(b & 0x80)) break;
   }
   if (out_len != expect) throw FormatError("snappy: uncompressed length differs from the page header");
-  std::vector<uint8_t> out(out_len);
   size_t o = 0;
   while (pos < n) {
     uint8_t tag = in[pos++];
@@ -152,8 +157,8 @@ inline std::vector<uint8_t> snappy_decompress_host(const uint8_t* in, size_t n, 
         len += 1; pos += nb;
       }
       if (len > n - pos || len > out_len - o) throw FormatError("snappy: literal past the end");
-      if (len <= 16 && n - pos >= 16 && out_len - o >= 16) codec::copy16(out.data() + o, in + pos);
-      else memcpy(out.data() + o, in + pos, len);
+      if (len <= 16 && n - pos >= 16 && out_len - o >= 16) codec::copy16(out + o, in + pos);
+      else memcpy(out + o, in + pos, len);
       pos += len; o += len;
       continue;
     }
@@ -168,11 +173,10 @@ inline std::vector<uint8_t> snappy_decompress_host(const uint8_t* in, size_t n, 
       len = (tag >> 2) + 1; off = load_u32(in + pos); pos += 4;
     }
     if (off == 0 || off > o || len > out_len - o) throw FormatError("snappy: bad back-reference");
-    codec::match_copy(out.data() + o, off, len, out_len - o - len);
+    codec::match_copy(out + o, off, len, out_len - o - len);
     o += len;
   }
   if (o != out_len) throw FormatError("snappy: stream ends early");
-  return out;
 }
 
 // ---- read one column --------------------------------------------------------------------------------------------------------------------
@@ -205,8 +209,20 @@ inline std::string error_bits_text(uint32_t e) {
 inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // pages of the codecs without a device kernel are inflated by host threads (host_codecs.hpp)
+// Which codecs are inflated by host threads.  ZSTD / GZIP / LZ4_RAW always (no device kernel).  SNAPPY has one (pq_snappy), the default;
+// PLX_PARQUET_SNAPPY=host sends Snappy pages through the host threads too -- on a many-core host the column-wide parallel inflate may
+// outrun the device kernel, whose time is set by the longest single stream; an experiment switch until both are timed.
+inline bool snappy_on_host() {
+  const char* e = getenv("PLX_PARQUET_SNAPPY");        // read per column chunk: cheap, and a test can flip it
+  return e && !strcmp(e, "host");
+}
+inline bool is_host_codec(int codec_id) {
+  return codec_id == CODEC_ZSTD || codec_id == CODEC_LZ4_RAW || codec_id == CODEC_GZIP || (codec_id == CODEC_SNAPPY && snappy_on_host());
+}
+
 inline void host_inflate(int codec_id, const uint8_t* src, size_t n, uint8_t* dst, size_t out) {
-  if (codec_id == CODEC_ZSTD) codec::zstd_decompress(src, n, dst, out);
+  if (codec_id == CODEC_SNAPPY) { if (out || n) snappy_decompress_into(src, n, dst, out); }
+  else if (codec_id == CODEC_ZSTD) codec::zstd_decompress(src, n, dst, out);
   else if (codec_id == CODEC_GZIP) codec::gzip_decompress(src, n, dst, out);
   else codec::lz4_raw_decompress(src, n, dst, out);
 }
@@ -242,7 +258,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     if (!c.has_meta) throw FormatError("column chunk without metadata");
     if (c.external_file) throw Unsupported("column chunk stored in another file");
     if (c.type != leaf.type) throw FormatError("column chunk type differs from the schema");
-    const bool host_codec = c.codec == CODEC_ZSTD || c.codec == CODEC_LZ4_RAW || c.codec == CODEC_GZIP;       // decompressed by host threads (host_codecs.hpp)
+    const bool host_codec = is_host_codec(c.codec);       // decompressed by host threads (host_codecs.hpp)
     if (c.codec != CODEC_UNCOMPRESSED && c.codec != CODEC_SNAPPY && !host_codec)
       throw Unsupported(std::string("column '") + leaf.name + "': codec " + codec_name(c.codec) + " has no decompressor here (UNCOMPRESSED, SNAPPY, ZSTD, GZIP and LZ4_RAW do)");
     if (c.num_values != rg.num_rows) throw FormatError("flat column chunk whose value count differs from the row group's rows");
@@ -314,7 +330,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
       }
   };
   bool all_host = !chunks.empty();
-  for (const ChunkRef& ch : chunks) all_host = all_host && (ch.c->codec == CODEC_ZSTD || ch.c->codec == CODEC_LZ4_RAW || ch.c->codec == CODEC_GZIP);
+  for (const ChunkRef& ch : chunks) all_host = all_host && is_host_codec(ch.c->codec);
   // ... in batches of consecutive chunks of about kInflateBatch image bytes: the page-locked image stays bounded, and batch k is on its
   // way over PCIe (the other staging buffer) while batch k + 1 is inflated
   const char* batch_env = getenv("PLX_PARQUET_INFLATE_BATCH");       // bytes; the tests shrink it to cross batch borders with small files
@@ -341,8 +357,8 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
       batch_image = be.host_stage(last.blob_off + last.blob_cap - batch_base + 64);
     }
     const size_t sz = (size_t)c.total_compressed_size;
-    const bool host_codec = c.codec == CODEC_ZSTD || c.codec == CODEC_LZ4_RAW || c.codec == CODEC_GZIP;
-    const bool codec_on = c.codec == CODEC_SNAPPY;          // pages decompressed on the device
+    const bool host_codec = is_host_codec(c.codec);
+    const bool codec_on = c.codec == CODEC_SNAPPY && !host_codec;          // pages decompressed on the device
     // Device codec / none: the stored bytes are staged and uploaded as they are.  Host codec: the stored bytes stay in pageable memory;
     // what is staged and uploaded is the chunk's IMAGE -- the page payloads decompressed, back to back -- and the pages then look
     // like pages of an uncompressed file to every kernel.

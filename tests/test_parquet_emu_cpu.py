@@ -626,3 +626,19 @@ def test_host_inflate_batches(tmp_path, compression, monkeypatch):
         if name in t.column_names:
             check_column(path, t, name)
     check_column(path, t, t.column_names[0], row_groups=[11, 0, 5, 6, 7])
+
+
+@pytest.mark.parametrize("version,dictionary", [("1.0", True), ("2.0", True), ("2.0", False)])
+def test_snappy_pages_through_the_host_threads(tmp_path, monkeypatch, version, dictionary):
+    """PLX_PARQUET_SNAPPY=host: Snappy pages take the column-wide host inflate like zstd pages (an experiment switch: which side wins
+    depends on the host's core count); same results, no device Snappy stream."""
+    monkeypatch.setenv("PLX_PARQUET_SNAPPY", "host")
+    n = 9000
+    t = mixed_table(n)
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression="snappy", data_page_version=version, use_dictionary=dictionary, row_group_size=2500, data_page_size=2000)
+    for name in t.column_names:
+        r = check_column(path, t, name)
+        assert r["stats"]["snappy_streams"] == 0, name
+    monkeypatch.delenv("PLX_PARQUET_SNAPPY")
+    assert check_column(path, t, "const")["stats"]["snappy_streams"] > 0       # a compressible column: its pages are Snappy streams for the kernel again

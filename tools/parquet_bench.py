@@ -30,9 +30,14 @@ def main():
     F = pl._ffi
     import bench
     d = tempfile.mkdtemp()
-    for codec in ("none", "snappy", "zstd", "lz4", "gzip"):          # zstd / lz4 (raw) / gzip: pages inflated by host threads, then the uncompressed device path
-        path = os.path.join(d, f"li_{codec}.parquet")
-        pq.write_table(t, path, compression=codec, row_group_size=1 << 20)
+    for codec in ("none", "snappy", "snappy@host", "zstd", "lz4", "gzip"):          # zstd / lz4 (raw) / gzip: pages inflated by host threads, then the uncompressed device path
+        os.environ.pop("PLX_PARQUET_SNAPPY", None)
+        if codec == "snappy@host":           # the same file, Snappy pages inflated by the host threads instead of pq_snappy (experiment switch)
+            os.environ["PLX_PARQUET_SNAPPY"] = "host"
+            path = os.path.join(d, "li_snappy.parquet")
+        else:
+            path = os.path.join(d, f"li_{codec}.parquet")
+            pq.write_table(t, path, compression=codec, row_group_size=1 << 20)
         fbytes = os.path.getsize(path)
         pl.read_parquet(path)        # warm: page cache, pool, pinned staging
         F.check(F.lib().plx_profile_clear()); F.check(F.lib().plx_profile_enable(1))
@@ -47,6 +52,7 @@ def main():
                           "decoded_GBps": round(decoded / best / 1e9, 2), "rows_per_s": round(n / best), "kernel_us_per_read": ks, "kernel_ms_total": round(sum(ks.values()) / 1e3, 2),
                           "pyarrow_read_table_s": round(t_pa, 4), "pyarrow_threads": pa.cpu_count()}))
         del df
+    os.environ.pop("PLX_PARQUET_SNAPPY", None)
     # the same table as an uncompressed Arrow IPC file: no decode at all, buffers are DMA'd into place (strings: device dictionary encode)
     import pyarrow.ipc as ipc
     path = os.path.join(d, "li.arrow")
