@@ -1,6 +1,6 @@
 #!/bin/bash
 # First GPU session of the next round: validates what round 2 could only check on the CPU (no GPU minutes were left), then collects the
-# starting measurements.  ~2 GPU-minutes.  usage: gpurun --timeout 400 -- 'bash tools/next_round_first_call.sh'
+# starting measurements.  ~4 GPU-minutes.  usage: gpurun --timeout 700 -- 'bash tools/next_round_first_call.sh'
 #
 # CPU-verified only at the end of round 2 (the device paths they reuse had run on hardware; the new code in them is host code):
 #   * Parquet: ZSTD / GZIP / LZ4_RAW pages (host_codecs.hpp -> chunk image -> the uncompressed device path)
@@ -23,6 +23,8 @@ tail -15 $OUT/pytest_scan.log | cut -c1-250
 unset PLX_SKIP_TORCH_PREIMPORT
 PLX_SNAPPY_TIMING=1 timeout 120 python tools/parquet_bench.py 2e7 > $OUT/parquet_bench.jsonl 2> $OUT/parquet_bench.err; el "scan bench exit $?"
 cut -c1-330 $OUT/parquet_bench.jsonl; grep pq_snappy $OUT/parquet_bench.err | tail -3 | cut -c1-400
+timeout 240 python tools/q1_from_files.py 3e7 8 > $OUT/q1_from_files.jsonl 2> $OUT/q1_from_files.err; el "q1 from parquet files exit $?"
+cut -c1-400 $OUT/q1_from_files.jsonl
 timeout 200 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err; el "bench exit $?"
 python - $OUT/bench_full.json <<'PY' | tee -a $OUT/summary.txt
 import json, sys
