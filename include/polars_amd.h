@@ -491,6 +491,9 @@ int plx_parquet_open(const char* path, plx_parquet* out);
 int plx_parquet_close(plx_parquet file);
 int plx_parquet_shape(plx_parquet file, int64_t* num_rows, int32_t* num_row_groups, int32_t* num_columns);
 int plx_parquet_column_info(plx_parquet file, int32_t column, const char** name, int32_t* dtype, int32_t* logical, int32_t* nullable);
+/* time zone of a Datetime column: "UTC" when the file marks the timestamps as instants (isAdjustedToUTC; the reference then reads
+ * Datetime(unit, "UTC"), crates/polars-parquet/src/arrow/read/schema/convert.rs), "" otherwise.  Valid until the next call on the thread. */
+int plx_parquet_column_timezone(plx_parquet file, int32_t column, const char** timezone);
 int plx_parquet_row_group_info(plx_parquet file, int32_t row_group, int64_t* num_rows, int64_t* compressed_bytes);
 int plx_parquet_chunk_info(plx_parquet file, int32_t row_group, int32_t column, int32_t* codec, uint32_t* encodings, int64_t* compressed_bytes,
                            int64_t* uncompressed_bytes, int32_t* has_min_max, plx_scalar* min, plx_scalar* max, int64_t* null_count);
@@ -519,6 +522,7 @@ int plx_ipc_open(const char* path, plx_ipc* out);
 int plx_ipc_close(plx_ipc file);
 int plx_ipc_shape(plx_ipc file, int64_t* num_rows, int32_t* num_batches, int32_t* num_columns);
 int plx_ipc_column_info(plx_ipc file, int32_t column, const char** name, int32_t* dtype, int32_t* logical, int32_t* nullable);
+int plx_ipc_column_timezone(plx_ipc file, int32_t column, const char** timezone);      /* the Timestamp type's timezone string, "" = none */
 int plx_ipc_batch_info(plx_ipc file, int32_t batch, int64_t* num_rows, int64_t* body_bytes, int32_t* compressed);
 int plx_ipc_read(plx_ipc file, const int32_t* batches, int32_t n_batches, const int32_t* columns, int32_t n_columns, plx_frame* out);
 int plx_ipc_categories(plx_ipc file, int32_t column, int64_t* n_strings, int64_t* total_bytes);

@@ -123,6 +123,7 @@ SIGNATURES = {
     "plx_parquet_close": (C.c_int, [C.c_uint64]),
     "plx_parquet_shape": (C.c_int, [C.c_uint64, _i64p, _i32p, _i32p]),
     "plx_parquet_column_info": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_char_p), _i32p, _i32p, _i32p]),
+    "plx_parquet_column_timezone": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_char_p)]),
     "plx_parquet_row_group_info": (C.c_int, [C.c_uint64, C.c_int32, _i64p, _i64p]),
     "plx_parquet_chunk_info": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, _i32p, C.POINTER(C.c_uint32), _i64p, _i64p, _i32p, C.POINTER(Scalar), C.POINTER(Scalar), _i64p]),
     "plx_parquet_read": (C.c_int, [C.c_uint64, _i32p, C.c_int32, _i32p, C.c_int32, _u64p]),
@@ -133,6 +134,7 @@ SIGNATURES = {
     "plx_ipc_close": (C.c_int, [C.c_uint64]),
     "plx_ipc_shape": (C.c_int, [C.c_uint64, _i64p, _i32p, _i32p]),
     "plx_ipc_column_info": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_char_p), _i32p, _i32p, _i32p]),
+    "plx_ipc_column_timezone": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_char_p)]),
     "plx_ipc_batch_info": (C.c_int, [C.c_uint64, C.c_int32, _i64p, _i64p, _i32p]),
     "plx_ipc_read": (C.c_int, [C.c_uint64, _i32p, C.c_int32, _i32p, C.c_int32, _u64p]),
     "plx_ipc_categories": (C.c_int, [C.c_uint64, C.c_int32, _i64p, _i64p]),

@@ -342,6 +342,15 @@ int plx_ipc_column_info(plx_ipc file, int32_t column, const char** name, int32_t
   IPC_CATCH
 }
 
+int plx_ipc_column_timezone(plx_ipc file, int32_t column, const char** timezone) {
+  IPC_TRY
+  File& f = get_file(file);
+  PLX_REQUIRE(column >= 0 && (size_t)column < f.footer.fields.size() && timezone, PLX_ERR_INVALID, "ipc column index out of range");
+  t_name = f.footer.fields[column].timezone;
+  *timezone = t_name.c_str();
+  IPC_CATCH
+}
+
 int plx_ipc_batch_info(plx_ipc file, int32_t batch, int64_t* num_rows, int64_t* body_bytes, int32_t* compressed) {
   IPC_TRY
   File& f = get_file(file);

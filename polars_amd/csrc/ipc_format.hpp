@@ -94,6 +94,7 @@ struct Field {
   bool is_signed = true;
   int precision = 0;         // TY_FLOAT: 0 half, 1 single, 2 double
   int unit = 0;              // TY_DATE: 0 day, 1 millisecond; TY_TIMESTAMP / TY_DURATION: 0 s, 1 ms, 2 us, 3 ns
+  std::string timezone;      // TY_TIMESTAMP: "" = none
   bool has_dictionary = false;
   int64_t dict_id = -1;
   int index_bits = 32;
@@ -139,7 +140,7 @@ inline Field parse_field(const Flat& fb, size_t t, int depth) {
       case TY_INT: f.bit_width = fb.scalar<int32_t>(ty, 0, 0); f.is_signed = fb.scalar<uint8_t>(ty, 1, 0) != 0; break;
       case TY_FLOAT: f.precision = fb.scalar<int16_t>(ty, 0, 0); break;
       case TY_DATE: f.unit = fb.scalar<int16_t>(ty, 0, 1); break;
-      case TY_TIMESTAMP: f.unit = fb.scalar<int16_t>(ty, 0, 0); break;
+      case TY_TIMESTAMP: f.unit = fb.scalar<int16_t>(ty, 0, 0); f.timezone = fb.str(ty, 1); break;
       case TY_DURATION: f.unit = fb.scalar<int16_t>(ty, 0, 1); break;
       default: break;
     }

@@ -148,6 +148,18 @@ int plx_parquet_column_info(plx_parquet file, int32_t column, const char** name,
   PQ_CATCH
 }
 
+int plx_parquet_column_timezone(plx_parquet file, int32_t column, const char** timezone) {
+  PQ_TRY
+  pq::File& f = get_file(file);
+  PLX_REQUIRE(column >= 0 && (size_t)column < f.md.leaves.size() && timezone, PLX_ERR_INVALID, "parquet column index out of range");
+  const pq::Leaf& l = f.md.leaves[column];
+  // Parquet has no zone names: isAdjustedToUTC = instants, which the reference reads as Datetime(unit, "UTC") (schema/convert.rs)
+  const bool ts = l.logical == pq::LG_TIMESTAMP_MILLIS || l.logical == pq::LG_TIMESTAMP_MICROS || l.logical == pq::LG_TIMESTAMP_NANOS;
+  t_name = ts && l.utc ? "UTC" : "";
+  *timezone = t_name.c_str();
+  PQ_CATCH
+}
+
 int plx_parquet_row_group_info(plx_parquet file, int32_t row_group, int64_t* num_rows, int64_t* compressed_bytes) {
   PQ_TRY
   pq::File& f = get_file(file);

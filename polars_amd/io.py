@@ -129,7 +129,11 @@ class _DeviceDecoder:
         if lg == 1:
             return T.Date
         if lg in DATETIME_UNITS:
-            return T.Datetime if lg == 2 else T.Datetime(DATETIME_UNITS[lg])
+            import ctypes as C
+            tz = C.c_char_p()
+            F.check(F.lib().plx_parquet_column_timezone(self._h, self._info[name][0], C.byref(tz)))
+            zone = tz.value.decode() if tz.value else None
+            return T.Datetime if lg == 2 and not zone else T.Datetime(DATETIME_UNITS[lg], zone)
         if lg in (3, 4):
             return string_column_dtype()
         return T.PHYSICAL_TO_DTYPE[dt]

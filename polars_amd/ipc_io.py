@@ -51,7 +51,10 @@ class _IpcDecoder:
         if lg == 1:
             return T.Date
         if lg in DATETIME_UNITS:
-            return T.Datetime if lg == 2 else T.Datetime(DATETIME_UNITS[lg])
+            tz = C.c_char_p()
+            F.check(F.lib().plx_ipc_column_timezone(self._h, self._info[name][0], C.byref(tz)))
+            zone = tz.value.decode() if tz.value else None
+            return T.Datetime if lg == 2 and not zone else T.Datetime(DATETIME_UNITS[lg], zone)
         if lg in (3, 4):
             return string_column_dtype() if self._plain_strings(name) else T.Categorical([])
         return T.PHYSICAL_TO_DTYPE[dt]

@@ -31,7 +31,7 @@ def sample(n):
         "sv": pa.array(words[RNG.integers(0, 5, n)], pa.string_view()), "bin": pa.array([b"\x00\x01"] * n, pa.binary()),
         "d8": pa.array(words[RNG.integers(0, 5, n)]).dictionary_encode().cast(pa.dictionary(pa.int8(), pa.string())),
         "d32": pa.array(words[RNG.integers(0, 3, n)], mask=m).dictionary_encode(),
-        "ts_ms": pa.array(RNG.integers(0, 2**40, n), pa.timestamp("ms")),
+        "ts_ms": pa.array(RNG.integers(0, 2**40, n), pa.timestamp("ms", "Europe/Vienna")),
         # outside the hot path
         "dec": pa.array([None] * n, pa.decimal128(12, 2)), "lst": pa.array([[1, 2]] * n),
         "st": pa.array([{"p": 1, "q": "z"}] * n), "tail": pa.array(np.arange(n)),
@@ -59,6 +59,7 @@ def test_schema_batches_and_dictionaries_match_pyarrow(tmp_path):
     for name in ("s", "ls", "sv", "bin", "d8", "d32"):
         assert isinstance(src.dtype(name), pl.Categorical)
     assert src.dtype("ts_ms").time_unit == "ms" and src.dtype("ts").time_unit == "us" and src.dtype("ts_ms") == pl.Datetime       # the file's unit is kept
+    assert src.dtype("ts_ms").time_zone == "Europe/Vienna" and src.dtype("ts").time_zone is None                                     # ... and its zone
     assert src.dtype("s").from_strings and src.dtype("sv").from_strings and not src.dtype("d8").from_strings      # plain strings vs dictionaries in the file
     for name in ("dec", "lst", "st"):
         with pytest.raises(TypeError):

@@ -605,7 +605,7 @@ def test_the_reference_s_own_parquet_fixtures(name):
             E.read_column(path, [0], dec._info[n][0])
         assert ei.value.code == 3 and "nested" in str(ei.value)
     if name == "tz_aware.parquet":
-        assert dec.dtype("UTC_DATETIME_ID").time_unit == "ns"
+        assert dec.dtype("UTC_DATETIME_ID").time_unit == "ns" and dec.dtype("UTC_DATETIME_ID").time_zone == "UTC"        # Datetime("ns", "UTC"), as the reference reads it
     if name == "alltypes_plain.parquet":
         assert dec.dtype("timestamp_col").time_unit == "ns" and dec._info["string_col"][2] == 4      # INT96 -> Datetime[ns]; BYTE_ARRAY without annotation -> Binary
     if name == "empty_datapage_v2.snappy.parquet":
