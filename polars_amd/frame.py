@@ -786,8 +786,14 @@ class LazyFrame:
         return DataFrame._from_frame_handle(out.value, schema)
 
     def explain(self) -> str:
-        """Physical plan chosen by the last collect() on this thread."""
-        return F.last_plan()
+        """Physical plan chosen by the last collect() on this thread; for plans over file scans also what each scan reads (projection,
+        row groups left by statistics / slice / shard -- known before anything is read, no GPU needed)."""
+        from . import io as _io
+        lines = [F.last_plan()] if F._lib is not None and F.last_plan() else []
+        if _io.has_file_scan(self._node):
+            self._lower()
+            lines += _io.describe_scans(self._node)
+        return "\n".join(lines)
 
     def jit_selftest(self) -> None:
         """Compile (not run) the run-time specialised kernels of this query with hiprtc; raises PlxError with the

@@ -579,6 +579,24 @@ class ParquetFrame:
             self._window = saved
         return self._windowed(keep)[1]
 
+    def describe(self) -> str:
+        """What the current plan makes this scan read (after push_down): the shape of the reference's explain() line for a scan --
+        `Parquet SCAN [paths] / PROJECT k/n COLUMNS / SELECTION` -- plus the row groups the statistics, the slice and the shard leave."""
+        paths = self.path if isinstance(self.path, list) else [self.path]
+        shown = ", ".join(paths[:2]) + (f", ... {len(paths) - 2} more" if len(paths) > 2 else "")
+        cols, rgs = self.selected_columns(), self.selected_row_groups()
+        ops = {F.OP_EQ: "==", F.OP_NE: "!=", F.OP_LT: "<", F.OP_LE: "<=", F.OP_GT: ">", F.OP_GE: ">="}
+        kind = type(self).__name__.replace("Frame", "")
+        lines = [f"{kind} SCAN [{shown}] decoder={self.decoder}", f"  PROJECT {len(cols)}/{len(self._dec.names)} COLUMNS: {', '.join(cols)}",
+                 f"  ROW GROUPS {len(rgs)}/{self._dec.num_row_groups}"]
+        if self._preds:
+            lines.append("  STATISTICS PRUNING: " + " & ".join(f"[{n} {ops.get(o, o)} {v!r}]" for n, o, v in self._preds))
+        if getattr(self, "_window", None):
+            lines.append(f"  SLICE: offset {self._window[0]}, length {self._window[1]}")
+        if getattr(self, "_shard", None) and self._shard[1] > 1:
+            lines.append(f"  SHARD: {self._shard[0]} of {self._shard[1]}")
+        return "\n".join(lines)
+
     # -- materialisation ---------------------------------------------------------------------------------------------------
     def materialise(self):
         cols, rgs = self.selected_columns(), self.selected_row_groups()
@@ -768,6 +786,18 @@ def push_down(node: P.Node, needed: Optional[Set[str]] = None, preds: Optional[L
         push_down(node.left, lneed, None); push_down(node.right, rneed, None)
         return
     raise TypeError(f"unsupported plan node {k}")
+
+
+def describe_scans(node: P.Node) -> List[str]:
+    """describe() of every file scan under `node`, left to right (requests must have been pushed down: LazyFrame._lower does)."""
+    if node.kind == "scan":
+        return [node.frame.describe()] if isinstance(node.frame, ParquetFrame) else []
+    out: List[str] = []
+    for attr in ("input", "left", "right"):
+        child = getattr(node, attr, None)
+        if isinstance(child, P.Node):
+            out += describe_scans(child)
+    return out
 
 
 def has_file_scan(node: P.Node) -> bool:

@@ -264,3 +264,15 @@ def test_slice_pushdown_reads_only_the_row_groups_it_overlaps(tmp_path):
     low, _, _ = j._lower()
     assert sorted(d["slice_offset"] for d in low.irs if d["kind"] == F.IR_SLICE) == [2500, 7000]
     assert len(base._node.frame.selected_row_groups()) == 10
+
+
+def test_explain_reports_what_each_scan_reads(tmp_path):
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    for i in range(3):
+        pq.write_table(pa.table({"k": np.arange(5000) + 5000 * i, "v": np.arange(5000) * 1.0, "s": ["a"] * 5000}), str(tmp_path / f"p{i}.parquet"), row_group_size=1000)
+    c = pl.col
+    text = pl.scan_parquet(str(tmp_path), shard=(1, 2)).filter(c("k") >= 7000).select(c("v").sum()).explain()
+    assert "Parquet SCAN [" in text and "PROJECT 2/3 COLUMNS: k, v" in text and "ROW GROUPS 4/15" in text and "[k >= 7000]" in text and "SHARD: 1 of 2" in text
+    text = pl.scan_parquet(str(tmp_path / "p0.parquet")).select("k").slice(1500, 10).explain()
+    assert "PROJECT 1/3 COLUMNS: k" in text and "ROW GROUPS 1/5" in text and "SLICE: offset 1500, length 10" in text
