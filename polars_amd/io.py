@@ -365,7 +365,7 @@ class _MultiDecoder:
     numbered across the files in path order; statistics come from the file a row group lives in; a read fetches file by file (each
     through the device decoder) and concatenates on the device."""
 
-    def __init__(self, paths: Sequence[str], make):
+    def __init__(self, paths: Sequence[str], make, hive: Optional[List[Dict[str, str]]] = None):
         self.paths = list(paths)
         self.parts = [make(p) for p in self.paths]
         first = self.parts[0]
@@ -374,11 +374,30 @@ class _MultiDecoder:
         for p, part in zip(self.paths[1:], self.parts[1:]):
             if list(part.names) != self.names:
                 raise ValueError(f"{p}: columns differ from {self.paths[0]}")
+        # hive partitions (key=value directories under the scanned directory; crates/polars-io/src/hive.rs, crates/polars-plan/src/plans/hive.rs):
+        # one constant column per key, after the file's columns; integers when every value parses as one, strings otherwise.  Their
+        # "statistics" are exact (min = max = the value), so a predicate on a partition column skips whole files.
+        self._hive: Dict[str, list] = {}
+        if hive and any(hive):
+            keys = list(hive[0])
+            if any(list(h) != keys for h in hive):
+                raise ValueError("hive partition keys differ between files")
+            for k in keys:
+                if k in self.names:
+                    raise ValueError(f"hive partition key {k!r} is also a column of the files")
+                raw = [h[k] for h in hive]
+                try:
+                    self._hive[k] = [int(v) for v in raw]
+                except ValueError:
+                    self._hive[k] = raw
+            self.names += keys
         self.num_rows = sum(p.num_rows for p in self.parts)
         self._map = [(i, g) for i, p in enumerate(self.parts) for g in range(p.num_row_groups)]
         self.num_row_groups = len(self._map)
 
     def dtype(self, name: str) -> T.DataType:
+        if name in self._hive:
+            return T.Int64 if isinstance(self._hive[name][0], int) else string_column_dtype()
         dts = [p.dtype(name) for p in self.parts]
         for p, d in zip(self.paths, dts):
             if d != dts[0] or d.physical != dts[0].physical:
@@ -387,6 +406,9 @@ class _MultiDecoder:
 
     def stats(self, g: int, name: str):
         i, lg = self._map[g]
+        if name in self._hive:
+            v = self._hive[name][i]
+            return (v, v) if isinstance(v, int) else None
         return self.parts[i].stats(lg, name)
 
     def rows_of(self, g: int) -> int:
@@ -394,7 +416,28 @@ class _MultiDecoder:
         return self.parts[i].rows_of(lg)
 
     def literal(self, name: str, value: Any, like: Any) -> Any:
+        if name in self._hive:
+            if isinstance(value, int) and not isinstance(value, bool):
+                return value
+            raise TypeError("statistics and literal are not comparable")
         return self.parts[0].literal(name, value, like)
+
+    def _with_hive(self, df, i: int, rows: int, cols: List[str]):
+        """the frame of file i with its partition columns appended (constant columns uploaded once per read), in `cols` order"""
+        import numpy as np
+        from .frame import DataFrame, Series
+        have = {c.name: c for c in df.get_columns()} if df is not None else {}
+        out = []
+        for n in cols:
+            if n in self._hive:
+                v = self._hive[n][i]
+                if isinstance(v, int):
+                    out.append(Series(n, np.full(rows, v, np.int64), T.Int64))
+                else:
+                    out.append(Series(n, np.zeros(rows, np.uint32), string_column_dtype([v])))
+            else:
+                out.append(have[n])
+        return DataFrame(out)
 
     def read(self, rgs: List[int], cols: List[str]):
         runs: List[Tuple[int, List[int]]] = []                 # consecutive row groups of one file are one read
@@ -404,12 +447,17 @@ class _MultiDecoder:
                 runs[-1][1].append(lg)
             else:
                 runs.append((i, [lg]))
+        file_cols = [c for c in cols if c not in self._hive]
         if not runs:
-            return self.parts[0].read([], cols)
+            df, r, b = self.parts[0].read([], file_cols)
+            return (self._with_hive(df, 0, 0, cols) if self._hive else df), r, b
         dfs, rows, nbytes = [], 0, 0
         for i, lgs in runs:
-            df, r, b = self.parts[i].read(lgs, cols)
-            dfs.append(df); rows += r; nbytes += b
+            if file_cols:
+                df, r, b = self.parts[i].read(lgs, file_cols)
+            else:                                               # only partition columns are wanted: the row count comes from the metadata
+                df, r, b = None, sum(self.parts[i].rows_of(g) for g in lgs), 0
+            dfs.append(self._with_hive(df, i, r, cols) if self._hive else df); rows += r; nbytes += b
         return concat_frames(dfs), rows, nbytes
 
 
@@ -434,6 +482,25 @@ def expand_paths(source, suffixes=(".parquet",)) -> List[str]:
     return found
 
 
+def hive_parts(source, files: List[str]) -> Optional[List[Dict[str, str]]]:
+    """key=value directory names between a scanned DIRECTORY and each of its files (the reference enables hive partitioning by
+    default exactly then: a single directory as the source); None for any other source or when no such directory exists."""
+    import os
+    if isinstance(source, (list, tuple)) or not os.path.isdir(os.fspath(source)):
+        return None
+    root = os.path.abspath(os.fspath(source))
+    out = []
+    for f in files:
+        rel = os.path.relpath(os.path.dirname(os.path.abspath(f)), root)
+        parts = {}
+        for seg in ([] if rel == "." else rel.split(os.sep)):
+            if "=" in seg:
+                k, v = seg.split("=", 1)
+                parts[k] = v
+        out.append(parts)
+    return out if any(out) else None
+
+
 class ParquetFrame:
     """A scan source: looks like a DataFrame to the plan lowering (`schema`, `_frame_handle()`), materialises lazily."""
 
@@ -444,7 +511,8 @@ class ParquetFrame:
         paths = expand_paths(path)
         self.path = paths[0] if len(paths) == 1 else paths
         make = _DeviceDecoder if decoder == "device" else _HostDecoder
-        self._dec = make(paths[0]) if len(paths) == 1 else _MultiDecoder(paths, make)
+        hive = hive_parts(path, paths)
+        self._dec = make(paths[0]) if len(paths) == 1 and not hive else _MultiDecoder(paths, make, hive)
         names = list(columns) if columns is not None else list(self._dec.names)
         self._schema: Dict[str, T.DataType] = {n: self._dec.dtype(n) for n in names}
         self._need: Optional[Set[str]] = set()          # None = every column of the schema

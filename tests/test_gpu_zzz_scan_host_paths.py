@@ -247,3 +247,24 @@ def test_concat_of_frames_and_plans(pl):
     c = pl.col
     out = pl.concat([a.lazy().filter(c("k") >= 3), b.lazy()]).group_by("s").agg(c("f").sum().alias("sf"), pl.len().alias("n")).collect().sort_host("s")
     assert out["s"] == ["x", "y", "z", None] and out["n"] == [1, 2, 2, 1] and out["sf"] == [1.5, 4.0, 4.0, 6.0]
+
+
+def test_hive_partition_columns(pl, tmp_path):
+    """Partition columns of a hive-style directory arrive as constant columns per file; a predicate on one skips files."""
+    want_rows = []
+    for y in (1994, 1995):
+        for seg in ("A", "B"):
+            os.makedirs(tmp_path / f"year={y}" / f"seg={seg}")
+            k = np.arange(2500) + (y - 1994) * 10_000 + (seg == "B") * 5000
+            pq.write_table(pa.table({"k": k, "v": k * 0.5}), str(tmp_path / f"year={y}" / f"seg={seg}" / "part-0.parquet"), row_group_size=1000)
+            want_rows += [(int(x), y, seg) for x in k]
+    df = pl.read_parquet(str(tmp_path))
+    assert df.columns == ["k", "v", "year", "seg"] and df.height == 10_000
+    assert list(zip(df["k"].to_list(), df["year"].to_list(), df["seg"].to_list())) == want_rows
+    c = pl.col
+    lf = pl.scan_parquet(str(tmp_path)).filter(c("year") == 1995).group_by("seg").agg(c("v").sum().alias("sv"), pl.len().alias("n"))
+    out = lf.collect().sort_host("seg")
+    assert out["seg"] == ["A", "B"] and out["n"] == [2500, 2500]
+    assert out["sv"] == [sum(x * 0.5 for x, y, s in want_rows if y == 1995 and s == seg) for seg in ("A", "B")]
+    only = pl.scan_parquet(str(tmp_path)).select(c("year").sum().alias("sy")).collect()          # partition columns only: no file column is read
+    assert only["sy"].to_list() == [(1994 + 1995) * 5000]

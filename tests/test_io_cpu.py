@@ -2,6 +2,8 @@
 row-group skipping from min / max statistics for the simple conjuncts above the scan, merging of several uses of one scan."""
 import datetime as dt
 
+import os
+
 import numpy as np
 import pyarrow as pa
 import pyarrow.parquet as pq
@@ -276,3 +278,33 @@ def test_explain_reports_what_each_scan_reads(tmp_path):
     assert "Parquet SCAN [" in text and "PROJECT 2/3 COLUMNS: k, v" in text and "ROW GROUPS 4/15" in text and "[k >= 7000]" in text and "SHARD: 1 of 2" in text
     text = pl.scan_parquet(str(tmp_path / "p0.parquet")).select("k").slice(1500, 10).explain()
     assert "PROJECT 1/3 COLUMNS: k" in text and "ROW GROUPS 1/5" in text and "SLICE: offset 1500, length 10" in text
+
+
+def test_hive_partitioned_directory(tmp_path):
+    """key=value directories under a scanned directory become columns (after the file's own; integers when every value parses as
+    one), predicates on them skip whole files -- crates/polars-io/src/hive.rs; the reference turns this on by default for a directory
+    source and for nothing else (a list of the same files has no partition columns)."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from polars_amd import io
+    files = []
+    for y in (1994, 1995, 1996):
+        for seg in ("A", "B"):
+            os.makedirs(tmp_path / f"year={y}" / f"seg={seg}")
+            files.append(str(tmp_path / f"year={y}" / f"seg={seg}" / "part-0.parquet"))
+            pq.write_table(pa.table({"k": np.arange(3000), "v": np.arange(3000) * 1.0}), files[-1], row_group_size=1000)
+    src = io.ParquetFrame(str(tmp_path))
+    assert list(src.schema) == ["k", "v", "year", "seg"] and src.schema["year"] == pl.Int64 and src.schema["seg"].from_strings
+    c = pl.col
+    lf = pl.scan_parquet(str(tmp_path)).filter((c("year") >= 1995) & (c("year") < 1996)).select(c("v").sum())
+    text = lf.explain()
+    assert "ROW GROUPS 6/18" in text and "PROJECT 2/4 COLUMNS: v, year" in text
+    node = lf._node
+    while node.kind != "scan":
+        node = node.input
+    assert node.frame.selected_row_groups() == list(range(6, 12))
+    assert list(io.ParquetFrame(files).schema) == ["k", "v"]                       # an explicit list: no partition columns
+    with pytest.raises(ValueError):                                               # a key that is also a column of the files
+        os.makedirs(tmp_path / "bad" / "k=1")
+        pq.write_table(pa.table({"k": np.arange(3)}), str(tmp_path / "bad" / "k=1" / "f.parquet"))
+        io.ParquetFrame(str(tmp_path / "bad"))
