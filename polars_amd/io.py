@@ -408,7 +408,7 @@ class _MultiDecoder:
         i, lg = self._map[g]
         if name in self._hive:
             v = self._hive[name][i]
-            return (v, v) if isinstance(v, int) else None
+            return (v, v)                                       # exact: strings too (only == and != reach them, see literal())
         return self.parts[i].stats(lg, name)
 
     def rows_of(self, g: int) -> int:
@@ -417,7 +417,9 @@ class _MultiDecoder:
 
     def literal(self, name: str, value: Any, like: Any) -> Any:
         if name in self._hive:
-            if isinstance(value, int) and not isinstance(value, bool):
+            if isinstance(like, int) and isinstance(value, int) and not isinstance(value, bool):
+                return value
+            if isinstance(like, str) and isinstance(value, str):
                 return value
             raise TypeError("statistics and literal are not comparable")
         return self.parts[0].literal(name, value, like)

@@ -303,6 +303,8 @@ def test_hive_partitioned_directory(tmp_path):
     while node.kind != "scan":
         node = node.input
     assert node.frame.selected_row_groups() == list(range(6, 12))
+    lf = pl.scan_parquet(str(tmp_path)).filter((c("seg") == "B") & (c("year") != 1994)).select(c("v").sum())
+    assert "ROW GROUPS 6/18" in lf.explain()                                      # string partition values prune on == / != as well
     assert list(io.ParquetFrame(files).schema) == ["k", "v"]                       # an explicit list: no partition columns
     with pytest.raises(ValueError):                                               # a key that is also a column of the files
         os.makedirs(tmp_path / "bad" / "k=1")
