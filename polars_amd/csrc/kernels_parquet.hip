@@ -81,6 +81,58 @@ __global__ __launch_bounds__(kSnapLanes) void pq_snappy_kernel(const DecompJob* 
     for (int i = 0; i < 11; i++) atomicAdd(dbg + i, (unsigned long long)t_acc[i]);
 }
 
+// second generation (PLX_SNAPPY_KERNEL=2): the same rounds with the batched-load bodies of next / mark / rank (parquet_snappy.hpp); not the default
+// until it has been timed against the first on hardware
+__global__ __launch_bounds__(kSnapLanes) void pq_snappy_kernel_v2(const DecompJob* __restrict__ jobs, uint32_t n_jobs, uint32_t* __restrict__ err,
+                                                               unsigned long long* __restrict__ dbg) {
+  __shared__ SnapShared sh;
+  if (blockIdx.x >= n_jobs) return;
+  const DecompJob job = jobs[blockIdx.x];
+  const uint32_t lane = threadIdx.x;
+  uint64_t t_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = dbg ? wall_clock64() : 0;
+  if (lane == 0) snappy_begin(sh, job);
+  __syncthreads();
+  while (sh.done == 0) {
+    snappy_stage(sh, job, lane);
+    __syncthreads();
+    PQ_TICK(0)
+    snappy_next_v2(sh, job, lane);
+    __syncthreads();
+    PQ_TICK(1)
+    for (uint32_t it = 0; it < kSnapSweeps && __syncthreads_or(snappy_mark_v2(sh, it, lane) ? 1 : 0); it++) {}   // barrier + "does any node still have a successor"
+    __syncthreads();
+    PQ_TICK(2)
+    snappy_rank_v2(sh, lane);
+    __syncthreads();
+    if (lane == 0) snappy_scan(sh);
+    __syncthreads();
+    snappy_place(sh, job, lane);
+    __syncthreads();
+    if (lane == 0) snappy_finish(sh, job);
+    __syncthreads();
+    PQ_TICK(3)
+    if (sh.done == 2 || sh.bad) break;      // uniform: every lane reads the flags after the barrier
+    t_acc[8] += 1; t_acc[9] += sh.n_el;
+    if (sh.direct) {
+      snappy_direct(sh, job, lane);
+    } else {
+      snappy_point(sh, lane);
+      __syncthreads();
+      PQ_TICK(4)
+      while (__syncthreads_or(snappy_jump(sh, lane) ? 1 : 0)) { t_acc[10] += 1; }   // barrier + "did any lane still follow a pointer"
+      PQ_TICK(5)
+      snappy_gather(sh, job, lane);
+    }
+    PQ_TICK(6)
+    __threadfence();        // later rounds read this output from HBM: stores complete, L1 dropped
+    __syncthreads();
+    PQ_TICK(7)
+  }
+  if (lane == 0 && (sh.done == 2 || sh.bad)) atomicOr(err, (uint32_t)PE_SNAPPY);
+  if (dbg && lane == 0)
+    for (int i = 0; i < 11; i++) atomicAdd(dbg + i, (unsigned long long)t_acc[i]);
+}
+
 __global__ __launch_bounds__(kBlock) void pq_page_prepare_kernel(PageDesc* __restrict__ pages, uint32_t n_pages, uint32_t* __restrict__ err) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_pages) return;
@@ -150,7 +202,9 @@ void pq_snappy(const DecompJob* jobs, uint32_t n_jobs, uint64_t bytes_out, uint3
   if (timing) dbg = dev_alloc_zero(11 * 8);
   {
     ProfileScope ps("pq_snappy", bytes_out * 2, n_jobs);
-    hipLaunchKernelGGL(pq_snappy_kernel, dim3(n_jobs), dim3(kSnapLanes), 0, stream(), jobs, n_jobs, err, timing ? dbg->as<unsigned long long>() : nullptr);
+    static const bool v2 = [] { const char* e = getenv("PLX_SNAPPY_KERNEL"); return e && e[0] == '2'; }();
+    if (v2) hipLaunchKernelGGL(pq_snappy_kernel_v2, dim3(n_jobs), dim3(kSnapLanes), 0, stream(), jobs, n_jobs, err, timing ? dbg->as<unsigned long long>() : nullptr);
+    else hipLaunchKernelGGL(pq_snappy_kernel, dim3(n_jobs), dim3(kSnapLanes), 0, stream(), jobs, n_jobs, err, timing ? dbg->as<unsigned long long>() : nullptr);
     PLX_HIP(hipGetLastError());
   }
   if (timing) {

@@ -182,6 +182,68 @@ PLX_HD bool snappy_mark(SnapShared& sh, uint32_t it, uint32_t lane) {
   return changed;
 }
 
+// ---- second-generation bodies of next / mark / rank (pq_snappy_kernel_v2; PLX_SNAPPY_KERNEL=2) ------------------------------------------
+// The first-generation loops above touch LDS in program order: a store (which the compiler must assume may alias the next
+// iteration's load -- the two halves of jmp[][], or the byte window against anything) sits between the loads of consecutive nodes, so every
+// one of a lane's kSnapChunk = 19 nodes pays the full LDS latency, twice in mark (src[b], then src[src[b]]): ~290 cycles per node measured
+// (profiles/r02/parquet_snappy_phase_clock.txt: mark is 38 % of the kernel).  Here all loads of a lane's nodes are issued before the first
+// store -- 19 loads in flight, one wait -- which is also the weakest ordering the mark phase allows (a lane sees the marks as of the
+// start of the sweep, what the any-order argument of the first generation already assumes).  Same results, checked by the CPU harness.
+PLX_HD void snappy_next_v2(SnapShared& sh, const DecompJob& job, uint32_t lane) {
+  const uint32_t avail = job.comp_size - sh.in_pos;
+  uint32_t v[kSnapChunk];
+  uint16_t j[kSnapChunk];
+  for (uint32_t k = 0; k < kSnapChunk; k++) {
+    const uint32_t b = lane + k * kSnapLanes;
+    v[k] = kSnapStop; j[k] = kSnapEnd;
+    if (b + 5 <= kSnapWindow && b < avail) {
+      uint32_t len, val, hdr;
+      const uint32_t kind = snappy_tag(sh.win + b, &len, &val, &hdr);
+      if (kind == 0 && len > kSnapDirect) v[k] = kSnapLongNode;
+      else {
+        const uint32_t nxt = b + hdr + (kind == 0 ? len : 0);
+        v[k] = (len << 16) | nxt;
+        j[k] = (uint16_t)nxt;
+      }
+    }
+  }
+  for (uint32_t k = 0; k < kSnapChunk; k++) {
+    const uint32_t b = lane + k * kSnapLanes;
+    sh.nl[b] = v[k];
+    sh.jmp[0][b] = j[k];
+    sh.mark[b] = b == 0;
+  }
+}
+
+PLX_HD bool snappy_mark_v2(SnapShared& sh, uint32_t it, uint32_t lane) {
+  const uint16_t* src = sh.jmp[it & 1];
+  uint16_t* dst = sh.jmp[(it & 1) ^ 1];
+  uint16_t j[kSnapChunk], jj[kSnapChunk];
+  uint8_t m[kSnapChunk];
+  for (uint32_t k = 0; k < kSnapChunk; k++) { const uint32_t b = lane + k * kSnapLanes; j[k] = src[b]; m[k] = sh.mark[b]; }
+  for (uint32_t k = 0; k < kSnapChunk; k++) jj[k] = j[k] == kSnapEnd ? kSnapEnd : src[j[k]];
+  bool changed = false;
+  for (uint32_t k = 0; k < kSnapChunk; k++) {
+    const uint32_t b = lane + k * kSnapLanes;
+    dst[b] = jj[k];
+    if (j[k] != kSnapEnd) { changed = true; if (m[k]) sh.mark[j[k]] = 1; }
+  }
+  return changed;
+}
+
+PLX_HD void snappy_rank_v2(SnapShared& sh, uint32_t lane) {
+  uint8_t m[kSnapChunk];
+  uint32_t v[kSnapChunk];
+  for (uint32_t k = 0; k < kSnapChunk; k++) { const uint32_t b = lane * kSnapChunk + k; m[k] = sh.mark[b]; v[k] = sh.nl[b]; }
+  uint32_t cnt = 0, len = 0;
+  for (uint32_t k = 0; k < kSnapChunk; k++) {
+    if (!m[k]) continue;
+    if (v[k] >= kSnapLongNode) { snap_min(&sh.cut, lane * kSnapChunk + k); break; }
+    cnt++; len += v[k] >> 16;
+  }
+  sh.part_cnt[lane] = cnt; sh.part_len[lane] = len;
+}
+
 // rank, step 1: per thread chunk of kSnapChunk consecutive positions: marked elements, their output bytes; the first marked STOP
 PLX_HD void snappy_rank(SnapShared& sh, uint32_t lane) {
   uint32_t cnt = 0, len = 0;

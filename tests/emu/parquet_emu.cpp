@@ -31,16 +31,18 @@ uint32_t snappy_stream(const DecompJob& job, int order, uint32_t* rounds) {
   memset(&sh, 0xA5, sizeof sh);     // LDS is not zeroed
   snappy_begin(sh, job);
   uint32_t nr = 0;
+  const char* gen = getenv("PLX_SNAPPY_KERNEL");      // "2": the bodies of pq_snappy_kernel_v2
+  const bool v2 = gen && gen[0] == '2';
   while (sh.done == 0) {
     nr++;
     for_lanes(order, [&](uint32_t lane) { snappy_stage(sh, job, lane); });
-    for_lanes(order, [&](uint32_t lane) { snappy_next(sh, job, lane); });
+    for_lanes(order, [&](uint32_t lane) { if (v2) snappy_next_v2(sh, job, lane); else snappy_next(sh, job, lane); });
     for (uint32_t it = 0; it < kSnapSweeps; it++) {   // __syncthreads_or(snappy_mark(...)) of the kernel
       bool any = false;
-      for_lanes(order, [&](uint32_t lane) { any |= snappy_mark(sh, it, lane); });
+      for_lanes(order, [&](uint32_t lane) { any |= v2 ? snappy_mark_v2(sh, it, lane) : snappy_mark(sh, it, lane); });
       if (!any) break;
     }
-    for_lanes(order, [&](uint32_t lane) { snappy_rank(sh, lane); });
+    for_lanes(order, [&](uint32_t lane) { if (v2) snappy_rank_v2(sh, lane); else snappy_rank(sh, lane); });
     snappy_scan(sh);
     for_lanes(order, [&](uint32_t lane) { snappy_place(sh, job, lane); });
     snappy_finish(sh, job);

@@ -642,3 +642,40 @@ def test_snappy_pages_through_the_host_threads(tmp_path, monkeypatch, version, d
         assert r["stats"]["snappy_streams"] == 0, name
     monkeypatch.delenv("PLX_PARQUET_SNAPPY")
     assert check_column(path, t, "const")["stats"]["snappy_streams"] > 0       # a compressible column: its pages are Snappy streams for the kernel again
+
+
+def test_second_generation_snappy_bodies(tmp_path, monkeypatch):
+    """pq_snappy_kernel_v2 (PLX_SNAPPY_KERNEL=2; batched LDS loads in next / mark / rank, parquet_snappy.hpp): the same streams, both
+    lane orders, the same results as the first generation -- random element streams, real Snappy output, corrupt streams, a whole file."""
+    monkeypatch.setenv("PLX_SNAPPY_KERNEL", "2")
+    for seed in range(12):
+        data, n = random_stream(np.random.default_rng(500 + seed), 30_000)
+        want = py_unsnap(data)
+        for order in (0, 1):
+            err, got, rounds, tail = E.snappy(data, n, order)
+            assert err == 0 and got == want and tail == bytes([0x5A]) * 64, (seed, order)
+    rng = np.random.default_rng(77)
+    for payload in (b"", b"a", b"abc" * 10000, rng.integers(0, 256, 100_000, dtype=np.uint8).tobytes(), np.arange(50_000, dtype=np.int64).tobytes(), (b"x" * 70000 + b"y") * 3):
+        data = pa.compress(payload, codec="snappy", asbytes=True)
+        err, got, _, tail = E.snappy(data, len(payload))
+        assert err == 0 and got == payload and tail == bytes([0x5A]) * 64
+    good = pa.compress((b"hello world, " * 500) + rng.integers(0, 256, 3000, dtype=np.uint8).tobytes(), codec="snappy", asbytes=True)
+    n = 13 * 500 + 3000
+    outcomes = []
+    for trial in range(150):
+        b = bytearray(good)
+        b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        monkeypatch.setenv("PLX_SNAPPY_KERNEL", "2")
+        e2, g2, _, tail = E.snappy(bytes(b), n)
+        assert tail == bytes([0x5A]) * 64
+        monkeypatch.setenv("PLX_SNAPPY_KERNEL", "1")
+        e1, g1, _, _ = E.snappy(bytes(b), n)
+        assert (e1 == 0) == (e2 == 0) and (e1 != 0 or g1 == g2)          # the same verdict, and the same bytes when there is no error
+        outcomes.append(e2 != 0)
+    assert sum(outcomes) >= 3                                           # most flips land in literal bytes: wrong bytes, no error
+    monkeypatch.setenv("PLX_SNAPPY_KERNEL", "2")
+    t = mixed_table(7000)
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression="snappy", row_group_size=3000, data_page_size=2500)
+    for name in t.column_names:
+        check_column(path, t, name, order=1)

@@ -10,6 +10,7 @@
 #   * scans over several files (plx_frame_concat + dictionary unification)
 #   * Q1 / Q3 over the reference's own TPC-H sample files (tests/golden/pds_heads, through scan_ipc)
 #   all of the above: tests/test_gpu_zzz_scan_host_paths.py (sorted last on purpose)
+#   * pq_snappy_kernel_v2 (PLX_SNAPPY_KERNEL=2: batched LDS loads in next / mark / rank) and PLX_PARQUET_SNAPPY=host, timed beside the default by tools/parquet_bench.py
 #   * bench.py extras.parquet_ipc_scan_2e7_rows (scan_extra)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r03a
@@ -20,6 +21,8 @@ el() { echo "[+$(( $(date +%s) - t0 ))s] $*" | tee -a $OUT/summary.txt; }
 export PLX_SKIP_TORCH_PREIMPORT=1
 timeout 120 python -m pytest tests/test_gpu_parquet.py tests/test_gpu_ipc.py tests/test_gpu_io.py tests/test_gpu_zzz_scan_host_paths.py -m gpu -q --timeout 90 --durations=5 > $OUT/pytest_scan.log 2>&1; el "scan gpu tests exit $?"
 tail -15 $OUT/pytest_scan.log | cut -c1-250
+PLX_SNAPPY_KERNEL=2 timeout 120 python -m pytest tests/test_gpu_parquet.py -m gpu -q --timeout 90 > $OUT/pytest_snappy_v2.log 2>&1; el "snappy kernel v2 gpu tests exit $?"
+tail -3 $OUT/pytest_snappy_v2.log | cut -c1-250
 unset PLX_SKIP_TORCH_PREIMPORT
 PLX_SNAPPY_TIMING=1 timeout 120 python tools/parquet_bench.py 2e7 > $OUT/parquet_bench.jsonl 2> $OUT/parquet_bench.err; el "scan bench exit $?"
 cut -c1-330 $OUT/parquet_bench.jsonl; grep pq_snappy $OUT/parquet_bench.err | tail -3 | cut -c1-400

@@ -17,7 +17,26 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import polars_amd as pl  # noqa: E402
 
 
+def only_snappy(path):
+    """child process of main(): time one existing Snappy file (with whatever PLX_SNAPPY_KERNEL the parent set) and check it against pyarrow"""
+    pl.init(0)
+    F = pl._ffi
+    import bench
+    want = pq.read_table(path)
+    df = pl.read_parquet(path)
+    ok = all(np.array_equal(df[c].to_numpy(), want.column(c).to_numpy()) for c in ("l_orderkey", "l_quantity", "l_extendedprice", "l_discount", "l_shipdate") if c in want.column_names and c != "l_shipdate") \
+        and df["l_returnflag"].to_list()[:1000] == want.column("l_returnflag").to_pylist()[:1000]
+    F.check(F.lib().plx_profile_clear()); F.check(F.lib().plx_profile_enable(1))
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); df = pl.read_parquet(path); F.check(F.lib().plx_synchronize()); ts.append(time.perf_counter() - t0)
+    ks = {k: round(v[1] / 3) for k, v in bench.kernel_stats(pl).items()}
+    print(json.dumps({"codec": "snappy@kernel" + os.environ.get("PLX_SNAPPY_KERNEL", "1"), "read_s": round(min(ts), 4), "kernel_us_per_read": ks, "matches_pyarrow": bool(ok)}))
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[2] == "--only-snappy":
+        return only_snappy(sys.argv[3])
     n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
     rng = np.random.default_rng(3)
     t = pa.table({"l_orderkey": pa.array(np.sort(rng.integers(1, 4 * n, n))), "l_quantity": pa.array(rng.integers(1, 51, n)),
@@ -30,8 +49,15 @@ def main():
     F = pl._ffi
     import bench
     d = tempfile.mkdtemp()
-    for codec in ("none", "snappy", "snappy@host", "zstd", "lz4", "gzip"):          # zstd / lz4 (raw) / gzip: pages inflated by host threads, then the uncompressed device path
+    for codec in ("none", "snappy", "snappy@kernel2", "snappy@host", "zstd", "lz4", "gzip"):          # zstd / lz4 (raw) / gzip: pages inflated by host threads, then the uncompressed device path
         os.environ.pop("PLX_PARQUET_SNAPPY", None)
+        if codec == "snappy@kernel2":        # the same file through pq_snappy_kernel_v2 (batched LDS loads); needs its own process: the switch is read once
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), str(n), "--only-snappy", os.path.join(d, "li_snappy.parquet")], capture_output=True, text=True,
+                               env={**os.environ, "PLX_SNAPPY_KERNEL": "2"})
+            print((r.stdout.strip().splitlines() or [json.dumps({"codec": codec, "error": r.stderr[-300:]})])[-1])
+            sys.stderr.write(r.stderr[-2000:])
+            continue
         if codec == "snappy@host":           # the same file, Snappy pages inflated by the host threads instead of pq_snappy (experiment switch)
             os.environ["PLX_PARQUET_SNAPPY"] = "host"
             path = os.path.join(d, "li_snappy.parquet")
