@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kSnapLanes) void pq_snappy_kernel(const DecompJob* 
     for (int i = 0; i < 11; i++) atomicAdd(dbg + i, (unsigned long long)t_acc[i]);
 }
 
-// second generation (PLX_SNAPPY_KERNEL=2): the same rounds with the batched-load bodies of next / mark / rank (parquet_snappy.hpp); not the default
+// second generation (PLX_SNAPPY_KERNEL=2): the same rounds with the batched-load bodies of next / mark / rank / jump (parquet_snappy.hpp); not the default
 // until it has been timed against the first on hardware
 __global__ __launch_bounds__(kSnapLanes) void pq_snappy_kernel_v2(const DecompJob* __restrict__ jobs, uint32_t n_jobs, uint32_t* __restrict__ err,
                                                                unsigned long long* __restrict__ dbg) {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kSnapLanes) void pq_snappy_kernel_v2(const DecompJo
       snappy_point(sh, lane);
       __syncthreads();
       PQ_TICK(4)
-      while (__syncthreads_or(snappy_jump(sh, lane) ? 1 : 0)) { t_acc[10] += 1; }   // barrier + "did any lane still follow a pointer"
+      while (__syncthreads_or(snappy_jump_v2(sh, lane) ? 1 : 0)) { t_acc[10] += 1; }   // barrier + "did any lane still follow a pointer"
       PQ_TICK(5)
       snappy_gather(sh, job, lane);
     }

@@ -374,6 +374,21 @@ PLX_HD bool snappy_jump(SnapShared& sh, uint32_t lane) {
   return changed;
 }
 
+// second generation (pq_snappy_kernel_v2): the loads of all of a lane's bytes, then the dependent loads, then the stores -- ptr[] is
+// updated in place, so in program order every load would wait for the store before it.  Reading ptr[p] before or after another
+// update of it makes no difference to the result: whatever is found there is an ancestor of byte i (see snappy_jump).
+PLX_HD bool snappy_jump_v2(SnapShared& sh, uint32_t lane) {
+  const uint32_t n_bytes = sh.out_pos - sh.round_out0;
+  constexpr uint32_t kPer = kSnapRound / kSnapLanes;
+  uint32_t p[kPer], q[kPer];
+  for (uint32_t k = 0; k < kPer; k++) { const uint32_t i = lane + k * kSnapLanes; p[k] = i < n_bytes ? sh.ptr[i] : (1u << 30); }
+  for (uint32_t k = 0; k < kPer; k++) q[k] = (p[k] >> 30) ? p[k] : sh.ptr[p[k]];
+  bool changed = false;
+  for (uint32_t k = 0; k < kPer; k++)
+    if (!(p[k] >> 30)) { sh.ptr[lane + k * kSnapLanes] = q[k]; changed = true; }
+  return changed;
+}
+
 // gather: load every byte through its resolved pointer and store it
 PLX_HD void snappy_gather(const SnapShared& sh, const DecompJob& job, uint32_t lane) {
   const uint8_t* in = (const uint8_t*)job.src;

@@ -51,7 +51,7 @@ uint32_t snappy_stream(const DecompJob& job, int order, uint32_t* rounds) {
     for_lanes(order, [&](uint32_t lane) { snappy_point(sh, lane); });
     for (;;) {                                   // __syncthreads_or(snappy_jump(...)) of the kernel
       bool any = false;
-      for_lanes(order, [&](uint32_t lane) { any |= snappy_jump(sh, lane); });
+      for_lanes(order, [&](uint32_t lane) { any |= v2 ? snappy_jump_v2(sh, lane) : snappy_jump(sh, lane); });
       if (!any) break;
     }
     for_lanes(order, [&](uint32_t lane) { snappy_gather(sh, job, lane); });
