@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kSnapLanes) void pq_snappy_kernel_v2(const DecompJo
     __syncthreads();
     if (lane == 0) snappy_scan(sh);
     __syncthreads();
-    snappy_place(sh, job, lane);
+    snappy_place_v2(sh, job, lane);
     __syncthreads();
     if (lane == 0) snappy_finish(sh, job);
     __syncthreads();

@@ -33,6 +33,14 @@
 #include <stdint.h>
 #include <string.h>
 
+// full unrolling keeps the per-position register arrays of the second-generation bodies in registers (a loop left rolled indexes them
+// dynamically: scratch); the host compiler of the CPU harness does not need it
+#if defined(__clang__)
+#define PLX_UNROLL _Pragma("unroll")
+#else
+#define PLX_UNROLL
+#endif
+
 namespace plx {
 namespace pq {
 
@@ -294,6 +302,49 @@ PLX_HD void snappy_place(SnapShared& sh, const DecompJob& job, uint32_t lane) {
     sh.el[r] = el;
     r++; d += olen;
   }
+}
+
+// second generation (pq_snappy_kernel_v2): marks and node words of the chunk loaded up front, elements kept in registers (indexed by
+// the position in the chunk, a compile-time constant once unrolled) and stored after the last window byte has been read
+PLX_HD void snappy_place_v2(SnapShared& sh, const DecompJob& job, uint32_t lane) {
+  uint8_t m[kSnapChunk];
+  uint32_t v[kSnapChunk];
+  PLX_UNROLL
+  for (uint32_t k = 0; k < kSnapChunk; k++) { const uint32_t b = lane * kSnapChunk + k; m[k] = sh.mark[b]; v[k] = sh.nl[b]; }
+  uint32_t r = sh.part_cnt[lane], d = sh.part_len[lane];
+  const uint32_t win0 = sh.win_pos, round0 = sh.round_out0;
+  SnapElem e[kSnapChunk];
+  uint32_t at[kSnapChunk];
+  bool stopped = false, bad = false;
+  PLX_UNROLL
+  for (uint32_t k = 0; k < kSnapChunk; k++) {
+    at[k] = 0xffffffffu;
+    if (stopped || !m[k]) continue;
+    const uint32_t b = lane * kSnapChunk + k;
+    if (v[k] >= kSnapLongNode) { stopped = true; continue; }
+    const uint32_t olen = v[k] >> 16;
+    if (r >= kSnapElems || d + olen > kSnapRound) { snap_min(&sh.cut, b); stopped = true; continue; }
+    uint32_t len, val, hdr;
+    const uint32_t kind = snappy_tag(sh.win + b, &len, &val, &hdr);
+    SnapElem el;
+    el.dst = (uint16_t)d; el.len = (uint16_t)len;
+    bool ok = len <= job.uncomp_size - (round0 + d);
+    if (kind == 0) {
+      const uint32_t src = win0 + b + hdr;
+      ok = ok && src <= job.comp_size && len <= job.comp_size - src;
+      el.src = 0x80000000u | src;
+    } else {
+      ok = ok && win0 + b + hdr <= job.comp_size && val >= 1 && val <= round0 + d;
+      el.src = val;
+    }
+    if (!ok) bad = true;
+    e[k] = el; at[k] = r;
+    r++; d += olen;
+  }
+  PLX_UNROLL
+  for (uint32_t k = 0; k < kSnapChunk; k++)
+    if (at[k] != 0xffffffffu) sh.el[at[k]] = e[k];
+  if (bad) sh.bad = 1;
 }
 
 // finish: lane 0 closes the round at `cut` (element count, bytes, where the next round starts, end of stream, a direct literal)

@@ -64,3 +64,5 @@ def test_parquet_kernels_do_not_spill_and_fit_two_snappy_workgroups_per_cu():
         assert int(r["ScratchSize [bytes/lane]"]) == 0, (name, r)
         if "pq_snappy" in name:
             assert int(r["LDS Size [bytes/block]"]) <= 80 * 1024, (name, r)
+            assert int(r["VGPRs"]) <= 256, (name, r)          # two 256-thread workgroups per CU = two waves per SIMD: 256 registers each at most
+    assert sum("pq_snappy" in n for n in res) == 2           # generation 1 (default) and the opt-in generation 2 (PLX_SNAPPY_KERNEL=2)
