@@ -1,6 +1,6 @@
 #!/bin/bash
 # First GPU session of the next round: validates what round 2 could only check on the CPU (no GPU minutes were left), then collects the
-# starting measurements.  ~4 GPU-minutes.  usage: gpurun --timeout 700 -- 'bash tools/next_round_first_call.sh'
+# starting measurements.  ~8 GPU-minutes.  usage: gpurun --timeout 1300 -- 'bash tools/next_round_first_call.sh'
 #
 # CPU-verified only at the end of round 2 (the device paths they reuse had run on hardware; the new code in them is host code):
 #   * Parquet: ZSTD / GZIP / LZ4_RAW pages (host_codecs.hpp -> chunk image -> the uncompressed device path)
@@ -19,12 +19,12 @@ cd $R
 t0=$(date +%s)
 el() { echo "[+$(( $(date +%s) - t0 ))s] $*" | tee -a $OUT/summary.txt; }
 export PLX_SKIP_TORCH_PREIMPORT=1
-timeout 120 python -m pytest tests/test_gpu_parquet.py tests/test_gpu_ipc.py tests/test_gpu_io.py tests/test_gpu_zzz_scan_host_paths.py -m gpu -q --timeout 90 --durations=5 > $OUT/pytest_scan.log 2>&1; el "scan gpu tests exit $?"
+timeout 300 python -m pytest tests/test_gpu_parquet.py tests/test_gpu_ipc.py tests/test_gpu_io.py tests/test_gpu_zzz_scan_host_paths.py -m gpu -q --timeout 90 --durations=5 > $OUT/pytest_scan.log 2>&1; el "scan gpu tests exit $?"
 tail -15 $OUT/pytest_scan.log | cut -c1-250
 PLX_SNAPPY_KERNEL=2 timeout 120 python -m pytest tests/test_gpu_parquet.py -m gpu -q --timeout 90 > $OUT/pytest_snappy_v2.log 2>&1; el "snappy kernel v2 gpu tests exit $?"
 tail -3 $OUT/pytest_snappy_v2.log | cut -c1-250
 unset PLX_SKIP_TORCH_PREIMPORT
-PLX_SNAPPY_TIMING=1 timeout 120 python tools/parquet_bench.py 2e7 > $OUT/parquet_bench.jsonl 2> $OUT/parquet_bench.err; el "scan bench exit $?"
+PLX_SNAPPY_TIMING=1 timeout 360 python tools/parquet_bench.py 2e7 > $OUT/parquet_bench.jsonl 2> $OUT/parquet_bench.err; el "scan bench exit $?"
 cut -c1-330 $OUT/parquet_bench.jsonl; grep pq_snappy $OUT/parquet_bench.err | tail -3 | cut -c1-400
 timeout 240 python tools/q1_from_files.py 3e7 8 > $OUT/q1_from_files.jsonl 2> $OUT/q1_from_files.err; el "q1 from parquet files exit $?"
 cut -c1-400 $OUT/q1_from_files.jsonl
