@@ -723,6 +723,27 @@ class LazyFrame:
         return LazyFrame(P.Node("sort", input=self._node, by=keys, descending=_per_key(descending, len(keys), "descending", "by"),
                                 nulls_last=_per_key(nulls_last, len(keys), "nulls_last", "by"), maintain_order=maintain_order))
 
+    def collect_schema(self) -> Dict[str, T.DataType]:
+        """Output columns and dtypes of the plan (LazyFrame.collect_schema); nothing is executed."""
+        return dict(self._lower()[2])
+
+    def drop(self, *columns) -> "LazyFrame":
+        """All columns but the named ones (LazyFrame.drop): a projection."""
+        gone = {c for x in columns for c in ([x] if isinstance(x, str) else list(x))}
+        have = list(self.collect_schema())
+        missing = gone - set(have)
+        if missing:
+            raise KeyError(f"column not found: {sorted(missing)[0]}")
+        return self.select(*[_col(n) for n in have if n not in gone])
+
+    def rename(self, mapping: Dict[str, str]) -> "LazyFrame":
+        """Columns renamed old -> new, order kept (LazyFrame.rename): a projection with aliases."""
+        have = list(self.collect_schema())
+        missing = set(mapping) - set(have)
+        if missing:
+            raise KeyError(f"column not found: {sorted(missing)[0]}")
+        return self.select(*[_col(n).alias(mapping[n]) if n in mapping else _col(n) for n in have])
+
     def slice(self, offset: int, length: Optional[int] = None) -> "LazyFrame":
         if length is not None and length < 0:
             raise ValueError(f"negative slice lengths ({length!r}) are invalid for LazyFrame")

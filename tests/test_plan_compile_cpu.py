@@ -130,3 +130,15 @@ def test_sort_slice_and_semi_anti_lowering():
     for how, code in (("semi", F.JOIN_SEMI), ("anti", F.JOIN_ANTI)):
         low, root, schema = df.lazy().join(other.lazy(), on="a", how=how)._lower()
         assert low.irs[root]["how"] == code and list(schema) == ["a", "b"]      # left columns only
+
+
+def test_drop_rename_and_collect_schema_are_projections():
+    df = pl.DataFrame([ph("a", pl.Int64), ph("b", pl.Float64), ph("c", pl.Int16)])
+    lf = df.lazy()
+    assert lf.collect_schema() == {"a": pl.Int64, "b": pl.Float64, "c": pl.Int16}
+    assert list(lf.drop("b").collect_schema()) == ["a", "c"] and list(lf.drop(["a", "b"]).collect_schema()) == ["c"]
+    assert lf.rename({"a": "k", "c": "z"}).collect_schema() == {"k": pl.Int64, "b": pl.Float64, "z": pl.Int16}
+    assert lf.drop("b")._node.kind == "select" and lf.rename({"a": "k"})._node.kind == "select"
+    for bad in (lambda: lf.drop("nope"), lambda: lf.rename({"nope": "x"})):
+        with pytest.raises(KeyError):
+            bad()
