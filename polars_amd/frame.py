@@ -584,6 +584,15 @@ class DataFrame:
     def slice(self, offset: int, length: Optional[int] = None) -> "DataFrame":
         return self.lazy().slice(offset, length).collect()
 
+    def drop(self, *columns) -> "DataFrame":
+        return self.lazy().drop(*columns).collect()
+
+    def rename(self, mapping: Dict[str, str]) -> "DataFrame":
+        return self.lazy().rename(mapping).collect()
+
+    def drop_nulls(self, subset=None) -> "DataFrame":
+        return self.lazy().drop_nulls(subset).collect()
+
     def head(self, n: int = 5) -> "DataFrame":
         return self.lazy().head(n).collect()
 
@@ -735,6 +744,16 @@ class LazyFrame:
         if missing:
             raise KeyError(f"column not found: {sorted(missing)[0]}")
         return self.select(*[_col(n) for n in have if n not in gone])
+
+    def drop_nulls(self, subset=None) -> "LazyFrame":
+        """Rows without a null in the named columns (all columns by default) -- LazyFrame.drop_nulls: a filter on the AND of is_not_null."""
+        names = list(self.collect_schema()) if subset is None else ([subset] if isinstance(subset, str) else list(subset))
+        if not names:
+            return self
+        pred = _col(names[0]).is_not_null()
+        for n in names[1:]:
+            pred = pred & _col(n).is_not_null()
+        return self.filter(pred)
 
     def rename(self, mapping: Dict[str, str]) -> "LazyFrame":
         """Columns renamed old -> new, order kept (LazyFrame.rename): a projection with aliases."""

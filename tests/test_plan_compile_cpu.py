@@ -142,3 +142,15 @@ def test_drop_rename_and_collect_schema_are_projections():
     for bad in (lambda: lf.drop("nope"), lambda: lf.rename({"nope": "x"})):
         with pytest.raises(KeyError):
             bad()
+
+
+def test_drop_nulls_is_a_filter_on_is_not_null():
+    df = pl.DataFrame([ph("a", pl.Int64, nullable=True), ph("b", pl.Float64, nullable=True), ph("c", pl.Int16)])
+    lf = df.lazy().drop_nulls(["a", "b"])
+    assert lf._node.kind == "filter"
+    low, root, schema = lf._lower()
+    pred = low.aexprs[low.irs[root]["predicate"]]
+    assert pred["kind"] == F.AE_BINARY and pred["op"] == F.OP_AND and low.aexprs[pred["lhs"]]["kind"] == F.AE_IS_NOT_NULL and low.aexprs[pred["rhs"]]["kind"] == F.AE_IS_NOT_NULL
+    assert df.lazy().drop_nulls("a")._node.kind == "filter" and list(schema) == ["a", "b", "c"]
+    fusable, _, why, _ = df.lazy().drop_nulls().select(pl.col("c").sum()).describe_fusion()
+    assert fusable, why
