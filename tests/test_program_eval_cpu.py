@@ -613,3 +613,24 @@ def test_datetime_literal_against_columns_of_other_time_units(unit):
         far = dtm.datetime(9999, 1, 1)
         assert pe.evaluate(df.lazy().filter(pl.col("t") < far).select(pl.len().alias("n")).debug_program(), cols)["n"][0][0] == int(valid.sum())
         assert pe.evaluate(df.lazy().filter(pl.col("t") >= far).select(pl.len().alias("n")).debug_program(), cols)["n"][0][0] == 0
+
+
+def test_is_between_all_closures():
+    rng = np.random.default_rng(11)
+    n = 5000
+    x = rng.integers(-20, 20, n).astype(np.int64)
+    valid = rng.random(n) > 0.15
+    cols = {"x": (x, valid)}
+    df = frame_like(cols)
+    for closed, fn in (("both", lambda v: (v >= -3) & (v <= 7)), ("left", lambda v: (v >= -3) & (v < 7)), ("right", lambda v: (v > -3) & (v <= 7)), ("none", lambda v: (v > -3) & (v < 7))):
+        got = pe.evaluate(df.lazy().filter(pl.col("x").is_between(-3, 7, closed=closed)).select(pl.len().alias("n")).debug_program(), cols)["n"][0][0]
+        assert got == int((fn(x) & valid).sum()), closed
+    import datetime as dtm
+    t = (rng.integers(0, 3000, n) * 86_400_000_000).astype(np.int64)
+    tdf = frame_like({"t": (t, None)}, {"t": pl.Datetime})
+    lo, hi = dtm.datetime(1972, 1, 1), dtm.datetime(1975, 6, 1)
+    us = lambda d: (d - dtm.datetime(1970, 1, 1)) // dtm.timedelta(microseconds=1)
+    got = pe.evaluate(tdf.lazy().filter(pl.col("t").is_between(lo, hi)).select(pl.len().alias("n")).debug_program(), {"t": (t, None)})["n"][0][0]
+    assert got == int(((t >= us(lo)) & (t <= us(hi))).sum())
+    with pytest.raises(ValueError):
+        pl.col("x").is_between(0, 1, closed="sideways")
