@@ -9,6 +9,8 @@
 #   * Arrow IPC: LZ4-frame / ZSTD bodies
 #   * scans over several files (plx_frame_concat + dictionary unification)
 #   * Q1 / Q3 over the reference's own TPC-H sample files (tests/golden/pds_heads, through scan_ipc)
+#   * slice pushdown into scans, Datetime ms / ns / time zones, INT96 -> ns, logical Arrow export, write_parquet / write_ipc, concat / IR::Union,
+#     hive-partitioned directories, row-group shards, the reference's own Parquet / IPC fixture files (tests/golden/io_files)
 #   all of the above: tests/test_gpu_zzz_scan_host_paths.py (sorted last on purpose)
 #   * pq_snappy_kernel_v2 (PLX_SNAPPY_KERNEL=2: batched LDS loads in next / mark / rank) and PLX_PARQUET_SNAPPY=host, timed beside the default by tools/parquet_bench.py
 #   * bench.py extras.parquet_ipc_scan_2e7_rows (scan_extra)
