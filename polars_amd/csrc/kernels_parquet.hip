@@ -104,7 +104,11 @@ __global__ __launch_bounds__(kSnapLanes) void pq_snappy_kernel_v2(const DecompJo
     PQ_TICK(2)
     snappy_rank_v2(sh, lane);
     __syncthreads();
-    if (lane == 0) snappy_scan(sh);
+    snappy_scan_v2_blocks(sh, lane);
+    __syncthreads();
+    if (lane == 0) snappy_scan_v2_totals(sh);
+    __syncthreads();
+    snappy_scan_v2_offsets(sh, lane);
     __syncthreads();
     snappy_place_v2(sh, job, lane);
     __syncthreads();

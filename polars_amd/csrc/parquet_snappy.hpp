@@ -275,6 +275,45 @@ PLX_HD void snappy_scan(SnapShared& sh) {
   sh.part_cnt[kSnapLanes] = c; sh.part_len[kSnapLanes] = l;
 }
 
+// second generation (pq_snappy_kernel_v2) of the scan: lane 0 alone walks 256 pairs in the first generation, each read waiting for the
+// write before it (~100 cycles a step: ~12 us a round, two thirds of "rank_place" on the phase clock).  Three short steps instead:
+// a) lanes 0..15 scan 16 pairs each (loads first, then stores) and leave their block totals, b) lane 0 scans the 16 totals, c) every
+// lane adds its block's offset.  Scratch for the totals: the element array, which is dead between two rounds' place phases.
+constexpr uint32_t kSnapScanBlocks = 16, kSnapScanPer = kSnapLanes / kSnapScanBlocks;
+PLX_HD void snappy_scan_v2_blocks(SnapShared& sh, uint32_t lane) {
+  if (lane >= kSnapScanBlocks) return;
+  uint32_t* tmp = (uint32_t*)sh.el;
+  uint32_t pc[kSnapScanPer], pl[kSnapScanPer];
+  PLX_UNROLL
+  for (uint32_t t = 0; t < kSnapScanPer; t++) { pc[t] = sh.part_cnt[lane * kSnapScanPer + t]; pl[t] = sh.part_len[lane * kSnapScanPer + t]; }
+  uint32_t c = 0, l = 0;
+  PLX_UNROLL
+  for (uint32_t t = 0; t < kSnapScanPer; t++) {
+    sh.part_cnt[lane * kSnapScanPer + t] = c; sh.part_len[lane * kSnapScanPer + t] = l;
+    c += pc[t]; l += pl[t];
+  }
+  tmp[lane] = c; tmp[kSnapScanBlocks + lane] = l;
+}
+PLX_HD void snappy_scan_v2_totals(SnapShared& sh) {
+  uint32_t* tmp = (uint32_t*)sh.el;
+  uint32_t bc[kSnapScanBlocks], bl[kSnapScanBlocks];
+  PLX_UNROLL
+  for (uint32_t b = 0; b < kSnapScanBlocks; b++) { bc[b] = tmp[b]; bl[b] = tmp[kSnapScanBlocks + b]; }
+  uint32_t c = 0, l = 0;
+  PLX_UNROLL
+  for (uint32_t b = 0; b < kSnapScanBlocks; b++) {
+    tmp[2 * kSnapScanBlocks + b] = c; tmp[3 * kSnapScanBlocks + b] = l;
+    c += bc[b]; l += bl[b];
+  }
+  sh.part_cnt[kSnapLanes] = c; sh.part_len[kSnapLanes] = l;
+}
+PLX_HD void snappy_scan_v2_offsets(SnapShared& sh, uint32_t lane) {
+  const uint32_t* tmp = (const uint32_t*)sh.el;
+  const uint32_t b = lane / kSnapScanPer;
+  const uint32_t oc = tmp[2 * kSnapScanBlocks + b], ol = tmp[3 * kSnapScanBlocks + b];
+  sh.part_cnt[lane] += oc; sh.part_len[lane] += ol;
+}
+
 // place: decode and validate the marked elements of this thread's positions into el[rank]; the first one that does not fit cuts the round
 PLX_HD void snappy_place(SnapShared& sh, const DecompJob& job, uint32_t lane) {
   uint32_t r = sh.part_cnt[lane], d = sh.part_len[lane];

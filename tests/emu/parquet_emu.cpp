@@ -43,7 +43,11 @@ uint32_t snappy_stream(const DecompJob& job, int order, uint32_t* rounds) {
       if (!any) break;
     }
     for_lanes(order, [&](uint32_t lane) { if (v2) snappy_rank_v2(sh, lane); else snappy_rank(sh, lane); });
-    snappy_scan(sh);
+    if (v2) {
+      for_lanes(order, [&](uint32_t lane) { snappy_scan_v2_blocks(sh, lane); });
+      snappy_scan_v2_totals(sh);
+      for_lanes(order, [&](uint32_t lane) { snappy_scan_v2_offsets(sh, lane); });
+    } else snappy_scan(sh);
     for_lanes(order, [&](uint32_t lane) { if (v2) snappy_place_v2(sh, job, lane); else snappy_place(sh, job, lane); });
     snappy_finish(sh, job);
     if (sh.done == 2 || sh.bad) break;
