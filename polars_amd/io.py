@@ -484,13 +484,17 @@ def expand_paths(source, suffixes=(".parquet",)) -> List[str]:
     return found
 
 
-def hive_parts(source, files: List[str]) -> Optional[List[Dict[str, str]]]:
+def hive_parts(source, files: List[str], force: Optional[bool] = None) -> Optional[List[Dict[str, str]]]:
     """key=value directory names between a scanned DIRECTORY and each of its files (the reference enables hive partitioning by
-    default exactly then: a single directory as the source); None for any other source or when no such directory exists."""
+    default exactly then: a single directory as the source); None for any other source or when no such directory exists.
+    force=False: never; force=True: for any source, every key=value directory of the absolute path counts."""
     import os
-    if isinstance(source, (list, tuple)) or not os.path.isdir(os.fspath(source)):
+    if force is False:
         return None
-    root = os.path.abspath(os.fspath(source))
+    is_dir = not isinstance(source, (list, tuple)) and os.path.isdir(os.fspath(source))
+    if not is_dir and not force:
+        return None
+    root = os.path.abspath(os.fspath(source)) if is_dir else os.sep
     out = []
     for f in files:
         rel = os.path.relpath(os.path.dirname(os.path.abspath(f)), root)
@@ -506,14 +510,18 @@ def hive_parts(source, files: List[str]) -> Optional[List[Dict[str, str]]]:
 class ParquetFrame:
     """A scan source: looks like a DataFrame to the plan lowering (`schema`, `_frame_handle()`), materialises lazily."""
 
-    def __init__(self, path, columns: Optional[Sequence[str]] = None, decoder: str = "device", shard: Optional[Tuple[int, int]] = None):
+    def __init__(self, path, columns: Optional[Sequence[str]] = None, decoder: str = "device", shard: Optional[Tuple[int, int]] = None, *,
+                 hive_partitioning: Optional[bool] = None, use_statistics: bool = True, include_file_paths: Optional[str] = None):
         if decoder not in ("device", "host"):
             raise ValueError("decoder must be 'device' or 'host'")
         self._set_shard(shard)
+        self._use_statistics = bool(use_statistics)
         paths = expand_paths(path)
         self.path = paths[0] if len(paths) == 1 else paths
         make = _DeviceDecoder if decoder == "device" else _HostDecoder
-        hive = hive_parts(path, paths)
+        hive = hive_parts(path, paths, hive_partitioning)
+        if include_file_paths:                              # one more constant string column per file (scan_parquet(include_file_paths=...))
+            hive = [dict(h, **{include_file_paths: p}) for h, p in zip(hive or [{} for _ in paths], paths)]
         self._dec = make(paths[0]) if len(paths) == 1 and not hive else _MultiDecoder(paths, make, hive)
         names = list(columns) if columns is not None else list(self._dec.names)
         self._schema: Dict[str, T.DataType] = {n: self._dec.dtype(n) for n in names}
@@ -584,7 +592,7 @@ class ParquetFrame:
 
     def selected_row_groups(self) -> List[int]:
         """Row groups that can contain a matching row according to their column statistics."""
-        preds = self._preds or []
+        preds = (self._preds or []) if getattr(self, "_use_statistics", True) else []
         keep = []
         for g in range(self._dec.num_row_groups):
             ok = True
@@ -659,7 +667,7 @@ class ParquetFrame:
         kind = type(self).__name__.replace("Frame", "")
         lines = [f"{kind} SCAN [{shown}] decoder={self.decoder}", f"  PROJECT {len(cols)}/{len(self._dec.names)} COLUMNS: {', '.join(cols)}",
                  f"  ROW GROUPS {len(rgs)}/{self._dec.num_row_groups}"]
-        if self._preds:
+        if self._preds and getattr(self, "_use_statistics", True):
             lines.append("  STATISTICS PRUNING: " + " & ".join(f"[{n} {ops.get(o, o)} {v!r}]" for n, o, v in self._preds))
         if getattr(self, "_window", None):
             lines.append(f"  SLICE: offset {self._window[0]}, length {self._window[1]}")
@@ -701,14 +709,18 @@ def _comparable(value: Any, like: Any) -> Any:
     raise TypeError("statistics and literal are not comparable")
 
 
-def scan_parquet(path, columns: Optional[Sequence[str]] = None, decoder: str = "device", shard: Optional[Tuple[int, int]] = None):
+def scan_parquet(path, columns: Optional[Sequence[str]] = None, decoder: str = "device", shard: Optional[Tuple[int, int]] = None, *, n_rows: Optional[int] = None,
+                 hive_partitioning: Optional[bool] = None, use_statistics: bool = True, include_file_paths: Optional[str] = None):
     """LazyFrame over a Parquet file, a directory / glob of files or a list of them (mirrors polars.scan_parquet for the path's dtypes).
     Nothing is read until collect().
     decoder="device": column chunks are decoded on the GPU (UNCOMPRESSED / SNAPPY / ZSTD / GZIP / LZ4_RAW, PLAIN / dictionary pages); "host": pyarrow.
+    n_rows / hive_partitioning / use_statistics / include_file_paths: as in polars.scan_parquet.
     shard=(rank, world): one process per GPU, each reading its own run of row groups (polars_amd.dist.scan_shard() gives the pair of the
     running process group; string columns then need dist.unify_dictionaries before their codes meet another rank's)."""
     from .frame import LazyFrame
-    return LazyFrame(P.Node("scan", frame=ParquetFrame(path, columns, decoder, shard)))
+    lf = LazyFrame(P.Node("scan", frame=ParquetFrame(path, columns, decoder, shard, hive_partitioning=hive_partitioning, use_statistics=use_statistics,
+                                                      include_file_paths=include_file_paths)))
+    return lf if n_rows is None else lf.head(int(n_rows))        # n_rows: a slice, pushed into the scan (only the row groups it overlaps are read)
 
 
 def read_parquet(path, columns: Optional[Sequence[str]] = None, decoder: str = "device"):

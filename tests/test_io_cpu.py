@@ -310,3 +310,23 @@ def test_hive_partitioned_directory(tmp_path):
         os.makedirs(tmp_path / "bad" / "k=1")
         pq.write_table(pa.table({"k": np.arange(3)}), str(tmp_path / "bad" / "k=1" / "f.parquet"))
         io.ParquetFrame(str(tmp_path / "bad"))
+
+
+def test_scan_parquet_keyword_arguments(tmp_path):
+    """n_rows (a pushed-down slice), hive_partitioning on / off, use_statistics, include_file_paths -- polars.scan_parquet's keywords."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    for y in (1, 2):
+        os.makedirs(tmp_path / f"y={y}")
+        pq.write_table(pa.table({"k": np.arange(4000) + 4000 * (y - 1)}), str(tmp_path / f"y={y}" / "f.parquet"), row_group_size=1000)
+    files = sorted(str(p) for p in tmp_path.glob("y=*/f.parquet"))
+    c = pl.col
+    lf = pl.scan_parquet(str(tmp_path), n_rows=1500)
+    assert lf._node.kind == "slice" and "ROW GROUPS 2/8" in lf.explain()
+    assert list(pl.scan_parquet(str(tmp_path), hive_partitioning=False).collect_schema()) == ["k"]
+    assert list(pl.scan_parquet(files, hive_partitioning=True).collect_schema()) == ["k", "y"]
+    sc = pl.scan_parquet(files, include_file_paths="path").collect_schema()
+    assert list(sc) == ["k", "path"] and sc["path"].from_strings
+    assert "ROW GROUPS 4/8" in pl.scan_parquet(files, include_file_paths="path").filter(c("path") == files[1]).explain()
+    q = lambda **kw: pl.scan_parquet(str(tmp_path), **kw).filter(c("k") >= 7000).select(c("k").sum()).explain()
+    assert "ROW GROUPS 1/8" in q() and "ROW GROUPS 8/8" in q(use_statistics=False)
