@@ -268,3 +268,15 @@ def test_hive_partition_columns(pl, tmp_path):
     assert out["sv"] == [sum(x * 0.5 for x, y, s in want_rows if y == 1995 and s == seg) for seg in ("A", "B")]
     only = pl.scan_parquet(str(tmp_path)).select(c("year").sum().alias("sy")).collect()          # partition columns only: no file column is read
     assert only["sy"].to_list() == [(1994 + 1995) * 5000]
+
+
+def test_scan_keywords_n_rows_and_file_paths(pl, tmp_path):
+    paths = []
+    for i in range(3):
+        paths.append(str(tmp_path / f"f{i}.parquet"))
+        pq.write_table(pa.table({"k": np.arange(2000) + 2000 * i}), paths[-1], row_group_size=500)
+    df = pl.scan_parquet(paths, include_file_paths="path", n_rows=2500).collect()
+    assert df.height == 2500 and df["k"].to_list() == list(range(2500))
+    assert df["path"].to_list() == [paths[0]] * 2000 + [paths[1]] * 500
+    out = pl.scan_parquet(paths, include_file_paths="path").group_by("path").agg(pl.len().alias("n")).collect().sort_host("path")
+    assert out["path"] == sorted(paths) and out["n"] == [2000, 2000, 2000]
