@@ -60,6 +60,19 @@ class Expr:
         hi = self.__le__(upper) if closed in ("both", "right") else self.__lt__(upper)
         return lo & hi
 
+    def is_in(self, values) -> "Expr":
+        """x is one of a short list of literals (Expr.is_in with a literal list): OR of equalities; a null x gives null, as the
+        reference's is_in does with nulls_equal=False.  Strings compare through the column's dictionary like ==."""
+        vals = list(values)
+        if any(v is None for v in vals):
+            raise TypeError("is_in with a null in the list is outside this path")
+        if not vals:
+            raise ValueError("is_in with an empty list")
+        out = self.eq(vals[0])
+        for v in vals[1:]:
+            out = out | self.eq(v)
+        return out
+
     def is_null(self) -> "Expr": return Expr("is_null", lhs=self)
     def is_not_null(self) -> "Expr": return Expr("is_not_null", lhs=self)
     def fill_null(self, value: Any) -> "Expr":

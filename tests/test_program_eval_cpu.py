@@ -634,3 +634,20 @@ def test_is_between_all_closures():
     assert got == int(((t >= us(lo)) & (t <= us(hi))).sum())
     with pytest.raises(ValueError):
         pl.col("x").is_between(0, 1, closed="sideways")
+
+
+def test_is_in_a_literal_list():
+    rng = np.random.default_rng(12)
+    n = 4000
+    x = rng.integers(0, 12, n).astype(np.int64)
+    valid = rng.random(n) > 0.2
+    codes = rng.integers(0, 4, n).astype(np.uint32)
+    cols = {"x": (x, valid), "s": (codes, None)}
+    df = frame_like(cols, {"s": pl.Categorical(["AIR", "MAIL", "RAIL", "SHIP"], pl.UInt32)})
+    got = pe.evaluate(df.lazy().filter(pl.col("x").is_in([3, 5, 11])).select(pl.len().alias("n")).debug_program(), cols)["n"][0][0]
+    assert got == int((np.isin(x, [3, 5, 11]) & valid).sum())
+    got = pe.evaluate(df.lazy().filter(pl.col("s").is_in(["MAIL", "SHIP", "TRUCK"])).select(pl.len().alias("n")).debug_program(), cols)["n"][0][0]
+    assert got == int(np.isin(codes, [1, 3]).sum())                      # a string absent from the dictionary matches nothing
+    for bad in ([], [1, None]):
+        with pytest.raises((TypeError, ValueError)):
+            pl.col("x").is_in(bad)
