@@ -47,6 +47,16 @@ def q1(lineitem, cutoff=Q1_CUTOFF):
                  E.len().alias("count_order")))
 
 
+def q6(lineitem, year: int = 1994, discount: float = 0.06, quantity: int = 24):
+    """TPC-H Q6 (forecasting revenue change): one filter + one sum, the shape of BASELINE config 2 on lineitem's columns --
+    sum(l_extendedprice * l_discount) over shipdate in [year, year + 1), discount within +-0.01, quantity below the bound."""
+    c = E.col
+    lo, hi = dt.datetime(year, 1, 1), dt.datetime(year + 1, 1, 1)
+    return (lineitem.filter(c("l_shipdate").is_between(lo, hi, closed="left") & c("l_discount").is_between(round(discount - 0.01, 2), round(discount + 0.01, 2))
+                            & (c("l_quantity") < quantity))
+            .select((c("l_extendedprice") * c("l_discount")).sum().alias("revenue")))
+
+
 def q3(lineitem, orders, date=Q3_DATE, seg_mod=5):
     """TPC-H Q3 restated on the two big tables (SURVEY.md 8(d) cfg 4): the customer
     market-segment filter is approximated by o_custkey % seg_mod == 0."""

@@ -280,3 +280,14 @@ def test_scan_keywords_n_rows_and_file_paths(pl, tmp_path):
     assert df["path"].to_list() == [paths[0]] * 2000 + [paths[1]] * 500
     out = pl.scan_parquet(paths, include_file_paths="path").group_by("path").agg(pl.len().alias("n")).collect().sort_host("path")
     assert out["path"] == sorted(paths) and out["n"] == [2000, 2000, 2000]
+
+
+def test_tpch_q6_on_the_device(pl):
+    """TPC-H Q6 (queries.q6: is_between on dates and discounts, a quantity bound, one product sum) against numpy on the generator's host twin."""
+    from polars_amd import datagen, queries
+    li = datagen.lineitem_host(500_000, seed=6)
+    names = ["l_shipdate", "l_discount", "l_quantity", "l_extendedprice"]
+    out = queries.q6(datagen.to_frame(pl, li, names).lazy()).collect()
+    m = (li["l_shipdate"] >= datagen.us(1994, 1, 1)) & (li["l_shipdate"] < datagen.us(1995, 1, 1)) & (li["l_discount"] >= 0.05) & (li["l_discount"] <= 0.07) & (li["l_quantity"] < 24)
+    want = float((li["l_extendedprice"][m] * li["l_discount"][m]).sum())
+    assert abs(out["revenue"].to_list()[0] - want) <= 1e-6 * want          # float sum: 1e-6 relative (BASELINE.json north_star)

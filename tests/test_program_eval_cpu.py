@@ -651,3 +651,16 @@ def test_is_in_a_literal_list():
     for bad in ([], [1, None]):
         with pytest.raises((TypeError, ValueError)):
             pl.col("x").is_in(bad)
+
+
+def test_q6_program_matches_numpy():
+    li = datagen.lineitem_host(200_000, seed=5)
+    names = ["l_shipdate", "l_discount", "l_quantity", "l_extendedprice"]
+    cols = {k: (li[k], None) for k in names}
+    lf = Q.q6(frame_like(cols, datagen.logical_dtypes(pl)).lazy())
+    fusable, _, why, _ = lf.describe_fusion()
+    assert fusable, why
+    got = pe.evaluate(lf.debug_program(), cols)["revenue"][0][0]
+    m = (li["l_shipdate"] >= datagen.us(1994, 1, 1)) & (li["l_shipdate"] < datagen.us(1995, 1, 1)) & (li["l_discount"] >= 0.05) & (li["l_discount"] <= 0.07) & (li["l_quantity"] < 24)
+    want = float((li["l_extendedprice"][m] * li["l_discount"][m]).sum())
+    assert m.sum() > 1000 and math.isclose(got, want, rel_tol=1e-9)
