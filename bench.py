@@ -927,8 +927,27 @@ def run_guarded(worker, deadline_s: float, poll_s: float = 0.25) -> int:
             d["note"] = f"secondary workloads stopped at the {deadline_s:.0f} s deadline; headline unaffected"
             line = json.dumps(d)
         print(line, flush=True)
-        return 0
+        return EXIT_PARITY if failed_verifications(json.loads(line)) else 0
     return os.waitstatus_to_exitcode(status) if status is not None else 1
+
+
+EXIT_PARITY = 3      # the line was printed, but a result of a timed workload disagreed with the CPU oracle
+
+
+def failed_verifications(line: dict):
+    """Names of the workloads of a bench line whose `verified.ok` is False (headline and extras; the scan extra's per-file `verified`)."""
+    bad = []
+    if (line.get("verified") or {}).get("ok") is False:
+        bad.append((line.get("config") or {}).get("workload", "headline"))
+    for name, ex in (line.get("extras") or {}).items():
+        if not isinstance(ex, dict):
+            continue
+        if (ex.get("verified") or {}).get("ok") is False:
+            bad.append(name)
+        for fk, fv in (ex.get("files") or {}).items():
+            if isinstance(fv, dict) and fv.get("verified") is False:
+                bad.append(f"{name}.{fk}")
+    return bad
 
 
 def main():
@@ -941,6 +960,10 @@ def main():
     run(args, lambda line, ready=True: final.update(line))
     if rank == 0:
         print(json.dumps(final), flush=True)
+        bad = failed_verifications(final)
+        if bad:
+            print(f"[bench] parity check failed for: {bad}", file=sys.stderr)
+            sys.exit(EXIT_PARITY)
 
 
 # ---- sharded high-cardinality group-by (cfg3 / cfg5 at N > 1) ------------------------------------------------------------

@@ -63,11 +63,9 @@ class Expr:
     def is_in(self, values) -> "Expr":
         """x is one of a short list of literals (Expr.is_in with a literal list): OR of equalities; a null x gives null, as the
         reference's is_in does with nulls_equal=False.  Strings compare through the column's dictionary like ==."""
-        vals = list(values)
-        if any(v is None for v in vals):
-            raise TypeError("is_in with a null in the list is outside this path")
+        vals = [v for v in values if v is not None]      # nulls_equal=False: a null in the list equals nothing
         if not vals:
-            raise ValueError("is_in with an empty list")
+            return self.ne(self)                         # all-false for every non-null x, null for null x
         out = self.eq(vals[0])
         for v in vals[1:]:
             out = out | self.eq(v)

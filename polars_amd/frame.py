@@ -790,11 +790,16 @@ class LazyFrame:
         return self.sort(keys, descending=rev, nulls_last=True).head(k)
 
     # -- execution -----------------------------------------------------------------------------------
-    def _lower(self):
+    def _lower(self, materialise: bool = False):
+        """Lowers the plan.  `materialise`: first read every deferred source (file scans, concat inputs) -- only then are the dictionaries
+        of their string columns known, and both the lowering of string literals (a literal becomes its dictionary code) and the result
+        schema depend on them.  Without it (explain(), schema queries) nothing is read."""
         from . import io as _io
         if _io.has_file_scan(self._node):    # file scans: tell them which columns / row groups this plan reads (io.push_down)
             _io.reset_scans(self._node)
             _io.push_down(self._node)
+        if materialise:
+            _io.materialise_sources(self._node)
         low = P.Lowering()
         root, schema = low.lower_node(self._node)
         return low, root, schema
@@ -805,15 +810,13 @@ class LazyFrame:
         cached = getattr(self, "_c_cache", None)
         if cached is None:
             from . import io as _io
-            scan = _io.has_file_scan(self._node)
-            low, root, schema = self._lower()
-            c_arenas = low.to_c()            # file scans are decoded and uploaded here (their frame handles are taken)
-            if scan:                         # dictionaries of string columns are only known now: refresh the result schema hints
-                _, schema = P.Lowering().lower_node(self._node)
+            deferred = _io.has_deferred_source(self._node)
+            low, root, schema = self._lower(materialise=deferred)
+            c_arenas = low.to_c()
             cached = (c_arenas, root, schema, low)
             # A scan source is shared by every LazyFrame derived from the same scan_parquet(): a sibling plan's collect() re-materialises it
-            # (other columns / row groups) and frees the frame this plan's arenas point at -- plans over file scans are lowered afresh.
-            if not scan:
+            # (other columns / row groups) and frees the frame this plan's arenas point at -- plans over deferred sources are lowered afresh.
+            if not deferred:
                 self._c_cache = cached
         return cached
 

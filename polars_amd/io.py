@@ -16,6 +16,8 @@ row-group skipping by statistics: crates/polars-io/src/predicates.rs).  Here:
 from __future__ import annotations
 
 import datetime as _dt
+import re as _re
+from urllib.parse import unquote as _url_unquote
 from typing import Any, Dict, List, Optional, Sequence, Set, Tuple
 
 from . import _ffi as F
@@ -177,6 +179,11 @@ class _DeviceDecoder:
                 return (value.date() - _EPOCH.date()).days
             if isinstance(value, _dt.date):
                 return (value - _EPOCH.date()).days
+        if lg == 6 and isinstance(value, (int, float)) and not isinstance(value, bool):
+            # a plain number against a Datetime[ns] column is compared in ns ticks by the kernel, while stats() reports this column's
+            # min / max floor-divided to microseconds: bring the literal into that domain (floor: every comparison below stays conservative
+            # except the strict ones at the boundary, so those do not prune -- see selected_row_groups' TypeError path)
+            raise TypeError("numeric literal against Datetime[ns] statistics: not pruned")
         if isinstance(value, (bool, int, float)):
             return value
         raise TypeError("statistics and literal are not comparable")
@@ -385,10 +392,12 @@ class _MultiDecoder:
             for k in keys:
                 if k in self.names:
                     raise ValueError(f"hive partition key {k!r} is also a column of the files")
-                raw = [h[k] for h in hive]
-                try:
-                    self._hive[k] = [int(v) for v in raw]
-                except ValueError:
+                # values are URL-decoded and the default-partition marker is a null (crates/polars-io/src/hive.rs, plans/hive.rs); integers
+                # only when every non-null value is a plain decimal (python's int() would also take '1_000' or ' 5')
+                raw = [None if h[k] == "__HIVE_DEFAULT_PARTITION__" else _url_unquote(h[k]) for h in hive]
+                if any(v is not None for v in raw) and all(v is None or _re.fullmatch(r"-?\d+", v) for v in raw):
+                    self._hive[k] = [None if v is None else int(v) for v in raw]
+                else:
                     self._hive[k] = raw
             self.names += keys
         self.num_rows = sum(p.num_rows for p in self.parts)
@@ -397,7 +406,7 @@ class _MultiDecoder:
 
     def dtype(self, name: str) -> T.DataType:
         if name in self._hive:
-            return T.Int64 if isinstance(self._hive[name][0], int) else string_column_dtype()
+            return T.Int64 if any(isinstance(v, int) for v in self._hive[name]) else string_column_dtype()
         dts = [p.dtype(name) for p in self.parts]
         for p, d in zip(self.paths, dts):
             if d != dts[0] or d.physical != dts[0].physical:
@@ -408,6 +417,8 @@ class _MultiDecoder:
         i, lg = self._map[g]
         if name in self._hive:
             v = self._hive[name][i]
+            if v is None:
+                return None                                     # a null partition value: never pruned through statistics
             return (v, v)                                       # exact: strings too (only == and != reach them, see literal())
         return self.parts[i].stats(lg, name)
 
@@ -433,10 +444,12 @@ class _MultiDecoder:
         for n in cols:
             if n in self._hive:
                 v = self._hive[n][i]
-                if isinstance(v, int):
-                    out.append(Series(n, np.full(rows, v, np.int64), T.Int64))
+                is_int = any(isinstance(x, int) for x in self._hive[n])
+                null = np.zeros(rows, bool) if v is None else None          # __HIVE_DEFAULT_PARTITION__: an all-null column for this file
+                if is_int:
+                    out.append(Series(n, np.full(rows, v or 0, np.int64), T.Int64, null))
                 else:
-                    out.append(Series(n, np.zeros(rows, np.uint32), string_column_dtype([v])))
+                    out.append(Series(n, np.zeros(rows, np.uint32), string_column_dtype([] if v is None else [v]), null))
             else:
                 out.append(have[n])
         return DataFrame(out)
@@ -886,6 +899,27 @@ def has_file_scan(node: P.Node) -> bool:
     if node.kind == "scan":
         return isinstance(node.frame, ParquetFrame)
     return any(isinstance(getattr(node, a, None), P.Node) and has_file_scan(getattr(node, a)) for a in ("input", "left", "right"))
+
+
+def _children(node: P.Node):
+    return [getattr(node, a) for a in ("input", "left", "right") if isinstance(getattr(node, a, None), P.Node)]
+
+
+def has_deferred_source(node: P.Node) -> bool:
+    """A source whose frame (and the dictionaries of its string columns) only exists after materialise(): file scans and concat inputs."""
+    if node.kind == "scan":
+        return isinstance(node.frame, (ParquetFrame, ConcatFrame))
+    return any(has_deferred_source(c) for c in _children(node))
+
+
+def materialise_sources(node: P.Node) -> None:
+    """Reads every deferred source under `node` (after push_down told the file scans what the plan needs)."""
+    if node.kind == "scan":
+        if isinstance(node.frame, (ParquetFrame, ConcatFrame)):
+            node.frame.materialise()
+        return
+    for c in _children(node):
+        materialise_sources(c)
 
 
 def reset_scans(node: P.Node) -> None:

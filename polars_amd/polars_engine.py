@@ -119,11 +119,13 @@ class Translator:
             raise NotSupported(f"{fmt} file: {e.msg}")
         except (TypeError, ValueError) as e:         # a type outside the hot path, or files whose schemas differ (the CPU engine has its own rules for those)
             raise NotSupported(f"{fmt} scan: {e}")
-        if getattr(node, "predicate", None) is not None:
-            lf = lf.filter(self.named(node.predicate))
+        # the reference applies the scan's pre_slice physically BEFORE its predicate (polars-stream multi_scan apply_extra_ops.rs: slice
+        # at :264, predicate at :334): scan_parquet(p, n_rows=N).filter(pred) = the first N rows, then filtered
         nr = getattr(fo, "n_rows", None)
         if nr is not None:
             lf = lf.slice(int(nr[0]), int(nr[1]))
+        if getattr(node, "predicate", None) is not None:
+            lf = lf.filter(self.named(node.predicate))
         return lf
 
     # -- expressions -------------------------------------------------------------------------------------------

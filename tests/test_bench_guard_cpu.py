@@ -87,3 +87,14 @@ def test_pyarrow_yardstick_computes_q1(orc):
     assert [t["count_all"][i] for i in order] == want["count_order"].tolist() and [t["l_quantity_sum"][i] for i in order] == want["sum_qty"].tolist()
     assert np.allclose([t["charge_sum"][i] for i in order], want["sum_charge"], rtol=1e-9)
     assert np.allclose([t["l_discount_mean"][i] for i in order], want["avg_disc"], rtol=1e-9)
+
+
+def test_failed_verification_makes_the_exit_code_non_zero(capsys):
+    """A parity regression at full size must not ship with a green rc (round-2 review, Weak 2): the line is still printed."""
+    def worker(emit):
+        emit({"value": 1, "verified": {"ok": True}, "extras": {"tpch_q3_sf100": {"verified": {"ok": False, "max_rel_err": 1.0}}}})
+    assert bench.run_guarded(worker, deadline_s=30) == bench.EXIT_PARITY
+    assert len(_lines(capsys)) == 1
+    assert bench.failed_verifications({"verified": {"ok": False}, "config": {"workload": "q1"}}) == ["q1"]
+    assert bench.failed_verifications({"verified": {"ok": None}, "extras": {"a": {"verified": {"ok": True}}, "scan": {"files": {"snappy": {"verified": False}}}}}) == ["scan.snappy"]
+    assert bench.failed_verifications({"extras": {"x": {"error": "boom"}}}) == []

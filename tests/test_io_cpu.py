@@ -330,3 +330,38 @@ def test_scan_parquet_keyword_arguments(tmp_path):
     assert "ROW GROUPS 4/8" in pl.scan_parquet(files, include_file_paths="path").filter(c("path") == files[1]).explain()
     q = lambda **kw: pl.scan_parquet(str(tmp_path), **kw).filter(c("k") >= 7000).select(c("k").sum()).explain()
     assert "ROW GROUPS 1/8" in q() and "ROW GROUPS 8/8" in q(use_statistics=False)
+
+
+def test_ns_datetime_statistics_do_not_prune_against_a_plain_integer(tmp_path):
+    """Round-2 advisor (medium): stats() of a Datetime[ns] column are in microseconds while a plain integer literal is compared in ns ticks
+    by the kernel -- such a predicate must not prune (499 rows match in the last group here); a datetime literal still does."""
+    import datetime as dt
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    n = 4000
+    ts = np.arange(n, dtype=np.int64) * 1_000_000_007 + 1_600_000_000_000_000_000
+    path = str(tmp_path / "ns.parquet")
+    pq.write_table(pa.table({"ts": pa.array(ts, pa.timestamp("ns")), "v": np.arange(n)}), path, row_group_size=1000, version="2.6")
+    lf = pl.scan_parquet(path).filter(pl.col("ts") > int(ts[3500])).select(pl.len())
+    assert "ROW GROUPS 4/4" in lf.explain()
+    when = dt.datetime(1970, 1, 1) + dt.timedelta(microseconds=int(ts[3500] // 1000))
+    assert "ROW GROUPS 1/4" in pl.scan_parquet(path).filter(pl.col("ts") > when).select(pl.len()).explain()
+
+
+def test_hive_values_are_url_decoded_and_the_default_partition_is_null(tmp_path):
+    """crates/polars-io/src/hive.rs: percent-decoding, __HIVE_DEFAULT_PARTITION__ -> null; integers only for plain decimals."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from polars_amd import io
+    for d in ("a=1/b=x%20y", "a=__HIVE_DEFAULT_PARTITION__/b=z", "a=3/b=__HIVE_DEFAULT_PARTITION__"):
+        os.makedirs(tmp_path / "t" / d)
+        pq.write_table(pa.table({"k": np.arange(10)}), str(tmp_path / "t" / d / "f.parquet"))
+    src = io.ParquetFrame(str(tmp_path / "t"))
+    assert src.schema["a"] == pl.Int64 and src.schema["b"].from_strings
+    assert sorted(src._dec._hive["a"], key=str) == [1, 3, None] and sorted(src._dec._hive["b"], key=str) == [None, "x y", "z"]
+    lf = pl.scan_parquet(str(tmp_path / "t")).filter(pl.col("b") == "x y").select(pl.len())
+    assert "ROW GROUPS 2/3" in lf.explain()            # the null partition value is never pruned through statistics; the filter drops it on the device
+    for d in ("c=1_000", "c=5"):
+        os.makedirs(tmp_path / "u" / d)
+        pq.write_table(pa.table({"k": np.arange(3)}), str(tmp_path / "u" / d / "f.parquet"))
+    assert io.ParquetFrame(str(tmp_path / "u")).schema["c"].from_strings      # '1_000' is not an integer

@@ -258,6 +258,10 @@ def test_file_scan_node_becomes_a_device_parquet_scan(tmp_path):
     kw["paths"] = [path]; kw["file_options"] = FileOptions(n_rows=(5, 10), with_columns=["k"], cache=True, row_index=None, rechunk=False)
     lf2 = eng.Translator(MapTraverser({0: Scan(**kw)}, {}, 0)).plan()
     assert lf2._node.kind == "slice" and lf2._node.input.kind == "scan"
+    # pre_slice AND predicate on one scan: the reference slices first, then filters (multi_scan apply_extra_ops.rs :264 before :334)
+    kw["predicate"] = PyExprIR(node=1, output_name="k")
+    lf3 = eng.Translator(MapTraverser({0: Scan(**kw)}, {1: BinaryExpr(left=2, op=Operator.Gt, right=3), 2: Column(name="k"), 3: Literal(value=7, dtype=pl.Int64)}, 0)).plan()
+    assert lf3._node.kind == "filter" and lf3._node.input.kind == "slice" and lf3._node.input.input.kind == "scan"
 
 
 def test_file_scan_over_several_files_and_ipc(tmp_path):

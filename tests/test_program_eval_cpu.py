@@ -648,9 +648,11 @@ def test_is_in_a_literal_list():
     assert got == int((np.isin(x, [3, 5, 11]) & valid).sum())
     got = pe.evaluate(df.lazy().filter(pl.col("s").is_in(["MAIL", "SHIP", "TRUCK"])).select(pl.len().alias("n")).debug_program(), cols)["n"][0][0]
     assert got == int(np.isin(codes, [1, 3]).sum())                      # a string absent from the dictionary matches nothing
-    for bad in ([], [1, None]):
-        with pytest.raises((TypeError, ValueError)):
-            pl.col("x").is_in(bad)
+    # the empty list matches nothing (null stays null -> dropped by the filter); a null in the list equals nothing (nulls_equal=False)
+    got = pe.evaluate(df.lazy().filter(pl.col("x").is_in([])).select(pl.len().alias("n")).debug_program(), cols)["n"][0][0]
+    assert got == 0
+    got = pe.evaluate(df.lazy().filter(pl.col("x").is_in([3, None])).select(pl.len().alias("n")).debug_program(), cols)["n"][0][0]
+    assert got == int(((x == 3) & valid).sum())
 
 
 def test_q6_program_matches_numpy():

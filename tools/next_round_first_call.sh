@@ -21,6 +21,8 @@ cd $R
 t0=$(date +%s)
 el() { echo "[+$(( $(date +%s) - t0 ))s] $*" | tee -a $OUT/summary.txt; }
 export PLX_SKIP_TORCH_PREIMPORT=1
+timeout 200 python -m pytest tests -m gpu_unvalidated -q --timeout 90 > $OUT/pytest_unvalidated.log 2>&1; el "gpu_unvalidated tests exit $?"
+tail -15 $OUT/pytest_unvalidated.log | cut -c1-250
 timeout 300 python -m pytest tests/test_gpu_parquet.py tests/test_gpu_ipc.py tests/test_gpu_io.py tests/test_gpu_zzz_scan_host_paths.py -m gpu -q --timeout 90 --durations=5 > $OUT/pytest_scan.log 2>&1; el "scan gpu tests exit $?"
 tail -15 $OUT/pytest_scan.log | cut -c1-250
 PLX_SNAPPY_KERNEL=2 timeout 120 python -m pytest tests/test_gpu_parquet.py -m gpu -q --timeout 90 > $OUT/pytest_snappy_v2.log 2>&1; el "snappy kernel v2 gpu tests exit $?"
