@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = every rank holds the full single-GPU configuration (SF100 / 1e9 rows per rank); "
+                    "strong = that configuration in TOTAL, split over the ranks (BASELINE config 4: SF100 over 8 GPUs)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "preagg", "rows"], help="sharded cfg3 / cfg5: what crosses the fabric (dist.sharded_groupby)")
     ap.add_argument("--dry-run", action="store_true", help="sharded workloads only: numpy frames + gloo instead of the library + RCCL (control-flow check without GPUs)")
     return ap.parse_args()
 
@@ -967,53 +970,219 @@ def main():
 
 
 # ---- sharded high-cardinality group-by (cfg3 / cfg5 at N > 1) ------------------------------------------------------------
-# Every rank holds its own row shard (weak scaling); a step = ONE exchange of all rows by key hash (polars_amd/dist.py
-# sharded_groupby: plx_exchange_by_key = hash partition + gather + one grouped ncclSend / ncclRecv all-to-all(v) inside the
-# library) + the single-GPU partitioned group-by over the keys the rank owns.  The result stays sharded.  `--dry-run` swaps the
-# library and RCCL for numpy frames and gloo so the control flow (barriers, accounting, the JSON line) can be exercised
-# without GPUs (tests/test_dist_gloo_cpu.py); nothing of it is measured.
+# Every rank holds a row shard; a step = polars_amd.dist.sharded_groupby: the local partitioned group-by (every rank reduces its rows to
+# one partial row per local group), ONE exchange of the PARTIAL rows by key hash (plx_exchange_by_key: hash partition + gather + one
+# grouped ncclSend / ncclRecv all-to-all(v) inside the library), and the merge of the partials on the rank that owns the key
+# (crates/polars-stream/src/nodes/group_by.rs:140-497).  Raw rows are exchanged instead only when the local group-by would not shrink
+# the shard (mode "rows").  The result stays sharded.  `--dry-run` swaps the library and RCCL for numpy frames and gloo so the control
+# flow (mode choice, barriers, accounting, the JSON line) can be exercised without GPUs (tests/test_dist_gloo_cpu.py); nothing of it is
+# measured.
 class DryFrame:
-    """numpy stand-in for a device DataFrame (dry run only)."""
+    """numpy stand-in for a device DataFrame (dry run only): name -> values, plus name -> validity (bool array) for nullable columns."""
 
-    def __init__(self, cols):
-        self.cols = cols
+    def __init__(self, cols, valid=None, schema=None):
+        self.cols = dict(cols)
+        self.valid = {k: v for k, v in (valid or {}).items() if v is not None}
+        self.schema = schema
 
     @property
     def height(self):
-        return len(next(iter(self.cols.values())))
+        return len(next(iter(self.cols.values()))) if self.cols else 0
+
+    def validity(self, name):
+        import numpy as np
+        v = self.valid.get(name)
+        return np.ones(self.height, bool) if v is None else v
 
 
 class DryComm:
-    """gloo stand-in for dist.LibComm (dry run only): same routing rule shape (a hash of the key modulo world size), one
-    all_to_all per column."""
+    """gloo stand-in for dist.LibComm (dry run only): same routing rule shape (a hash of the key modulo world size, null keys to rank 0:
+    hashing.rs:111-115), one all_to_all per column, validity as one byte per row."""
 
     def __init__(self):
         import torch.distributed as dist
         self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
         self.rows_sent = self.bytes_sent = 0
 
+    def agree(self, value):
+        import torch.distributed as dist
+        box = [float(value)]
+        dist.broadcast_object_list(box, src=0)
+        return float(box[0])
+
     def exchange_by_key(self, df, key, seed=0):
         import numpy as np
         import torch
         import torch.distributed as dist
         ws = self.world_size
-        k = df.cols[key].astype(np.uint64)
+        kv = df.cols[key]
+        k = (kv.view(np.uint64) if kv.dtype.itemsize == 8 else kv.astype(np.uint64))
         part = ((k * np.uint64(0x55fbfd6bfc5458e9)) >> np.uint64(40)) % np.uint64(ws)
+        part = np.where(df.validity(key), part, np.uint64(0)).astype(np.int64)
         order = np.argsort(part, kind="stable")
-        counts = np.bincount(part.astype(np.int64), minlength=ws).astype(np.int64)
+        counts = np.bincount(part, minlength=ws).astype(np.int64)
         send = torch.from_numpy(counts.copy()); recv = torch.zeros_like(send)
         dist.all_to_all_single(recv, send)
         rc = [int(x) for x in recv.tolist()]
-        out = {}
-        for name, v in df.cols.items():
+        # a column travels with a validity byte per row when ANY rank holds nulls in it (the sends and receives must pair up)
+        has = torch.tensor([1 if n in df.valid else 0 for n in df.cols], dtype=torch.int64)
+        dist.all_reduce(has, op=dist.ReduceOp.MAX)
+        out, out_valid = {}, {}
+        away = int(sum(int(c) for i, c in enumerate(counts) if i != self.rank))
+
+        def a2a(v):
             src = torch.from_numpy(np.ascontiguousarray(v[order]).view(np.uint8).reshape(-1))
             w = v.dtype.itemsize
             dst = torch.empty(sum(rc) * w, dtype=torch.uint8)
             dist.all_to_all_single(dst, src, output_split_sizes=[c * w for c in rc], input_split_sizes=[int(c) * w for c in counts])
-            out[name] = dst.numpy().view(v.dtype)
-            self.bytes_sent += int(sum(int(c) for i, c in enumerate(counts) if i != self.rank)) * w
-        self.rows_sent += int(sum(int(c) for i, c in enumerate(counts) if i != self.rank))
-        return DryFrame(out)
+            self.bytes_sent += away * w
+            return dst.numpy().view(v.dtype)
+        for (name, v), nullable in zip(df.cols.items(), has.tolist()):
+            out[name] = a2a(v)
+            if nullable:
+                out_valid[name] = a2a(df.validity(name).astype(np.uint8)).astype(bool)
+        self.rows_sent += away
+        return DryFrame(out, out_valid, df.schema)
+
+
+class DryOps:
+    """numpy stand-in for dist.LibFrameOps (dry run only): the same four local queries over DryFrames, null-aware (null key = its own
+    group; sum / count / min / max / mean skip null values; min / max / mean of no value = null)."""
+
+    @staticmethod
+    def _groups(df, key):
+        import numpy as np
+        kv, valid = df.cols[key], df.validity(key)
+        uniq, inv = np.unique(kv[valid], return_inverse=True)
+        gid = np.full(df.height, len(uniq), np.int64)
+        gid[valid] = inv
+        has_null = bool((~valid).any())
+        keys = np.concatenate([uniq, np.zeros(1, kv.dtype)]) if has_null else uniq
+        kvalid = np.concatenate([np.ones(len(uniq), bool), np.zeros(1, bool)]) if has_null else None
+        return gid, len(keys), keys, kvalid
+
+    def _aggregate(self, df, key, aggs):
+        import numpy as np
+        gid, ng, keys, kvalid = self._groups(df, key)
+        cols, valid = {key: keys}, {key: kvalid}
+        for out, col, op in aggs:
+            if op == "len":
+                cols[out] = np.bincount(gid, minlength=ng).astype(np.uint32)
+                continue
+            v, ok = df.cols[col], df.validity(col)
+            g = gid[ok]
+            if op == "count":
+                cols[out] = np.bincount(g, minlength=ng).astype(np.uint32)
+            elif op in ("sum", "sum_f64"):
+                x = v[ok].astype(np.float64) if op == "sum_f64" or v.dtype.kind == "f" else v[ok].astype(np.uint32 if v.dtype == np.uint32 else np.int64)
+                acc = np.zeros(ng, x.dtype)
+                np.add.at(acc, g, x)
+                cols[out] = acc
+            elif op in ("min", "max"):
+                fn, init = (np.minimum, np.inf) if op == "min" else (np.maximum, -np.inf)
+                if v.dtype.kind == "f":
+                    acc = np.full(ng, init, v.dtype)
+                else:
+                    info = np.iinfo(v.dtype)
+                    acc = np.full(ng, info.max if op == "min" else info.min, v.dtype)
+                fn.at(acc, g, v[ok])
+                seen = np.bincount(g, minlength=ng) > 0
+                cols[out] = np.where(seen, acc, np.zeros(1, v.dtype))
+                valid[out] = None if seen.all() else seen
+            else:
+                raise ValueError(op)
+        return DryFrame(cols, valid, df.schema)
+
+    def final(self, df, spec):
+        import numpy as np
+        from polars_amd.dist import PARTIALS
+        part = self._aggregate(df, spec.key, [(f"{o}__p{i}", c, pop) for o, c, op in spec.aggs for i, (pop, _) in enumerate(PARTIALS[op])])
+        return self._finish(part, spec)
+
+    def partial(self, df, spec):
+        return self._aggregate(df, spec.key, spec.partial_aggs())
+
+    def merge(self, part, spec, source_schema=None):
+        return self._finish(self._aggregate(part, spec.key, spec.merge_aggs()), spec)
+
+    @staticmethod
+    def _finish(part, spec):
+        import numpy as np
+        cols, valid = {spec.key: part.cols[spec.key]}, {spec.key: part.valid.get(spec.key)}
+        for o, c, op in spec.aggs:
+            if op == "mean":
+                n = part.cols[f"{o}__p1"].astype(np.float64)
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    cols[o] = np.where(n > 0, part.cols[f"{o}__p0"] / np.where(n > 0, n, 1.0), 0.0)
+                valid[o] = None if (n > 0).all() else n > 0
+            else:
+                cols[o] = part.cols[f"{o}__p0"]
+                valid[o] = part.valid.get(f"{o}__p0")
+        return DryFrame(cols, valid, part.schema)
+
+    def distinct_in_prefix(self, df, key, n):
+        import numpy as np
+        return len(np.unique(df.cols[key][:n][df.validity(key)[:n]])) + int((~df.validity(key)[:n]).any())
+
+
+def verify_sharded_groupby(res_cols, key_name, sum_name, second, total_rows, input_sum, ranks_rows_seeds, n_keys, key_np, val_np, val_args, budget_s):
+    """Rank 0's check of a sharded cfg3 / cfg5 result (all ranks' result rows gathered): size-independent properties always -- the key sets
+    of the ranks are disjoint (no key twice), the counts add up to the rows of all shards, the sums add up to the column sums every rank
+    computed with a different kernel (the whole-column reduction) -- and, when the host twin of ALL shards fits the time budget, the full
+    comparison against the oracle's streaming group-by."""
+    import numpy as np
+    k = np.asarray(res_cols[key_name]).astype(np.int64)
+    out = {"groups": int(len(k)), "checks": {}}
+    out["checks"]["keys_disjoint_across_ranks"] = bool(len(np.unique(k)) == len(k))
+    if second[0] == "count":
+        out["checks"]["counts_add_up_to_all_rows"] = bool(int(np.asarray(res_cols[second[1]]).astype(np.int64).sum()) == int(total_rows))
+    s = np.asarray(res_cols[sum_name])
+    if s.dtype.kind == "f":
+        tot = float(np.sum(s.astype(np.float64)))
+        out["checks"]["sums_add_up_to_column_sums"] = bool(abs(tot - float(input_sum)) <= 1e-9 * max(1.0, abs(float(input_sum))))
+    else:
+        out["checks"]["sums_add_up_to_column_sums"] = bool(int(s.astype(np.int64).sum()) == int(input_sum))
+    ok = all(out["checks"].values())
+    out["against"] = "linearity: disjoint key sets, counts == rows of all shards, sums == whole-column sums (independent reduction kernel)"
+    if ok and budget_s > 0:
+        from oracle import pyoracle as orc
+        from polars_amd import datagen
+        vdt = np.int64 if val_np == "Int64" else np.float64
+        sums, counts = np.zeros(n_keys, vdt), np.zeros(n_keys, np.int64)
+        t0, complete = time.perf_counter(), True
+        for n, seed in ranks_rows_seeds:
+            done = 0
+            while done < n:
+                if time.perf_counter() - t0 > budget_s:
+                    complete = False
+                    break
+                m = min(100_000_000, n - done)
+                orc.groupby_dense_partial(datagen.uniform_native_host_mt(key_np, done, m, seed, 0, 0, n_keys), datagen.uniform_native_host_mt(val_np, done, m, seed, 1, *val_args), sums, counts)
+                done += m
+            if not complete:
+                break
+        if complete:
+            order = np.argsort(k, kind="stable")
+            present = np.nonzero(counts)[0]
+            good = np.array_equal(k[order], present)
+            err = 0.0
+            if good:
+                gs, g2 = s[order], np.asarray(res_cols[second[1]])[order]
+                if vdt is np.int64:
+                    good = np.array_equal(gs.astype(np.int64), sums[present])
+                else:
+                    err = _rel_err(gs, sums[present]); good = err <= VERIFY_RTOL
+                if second[0] == "count":
+                    good = good and np.array_equal(g2.astype(np.int64), counts[present])
+                else:
+                    e2 = _rel_err(g2, sums[present] / counts[present]); err = max(err, e2); good = good and e2 <= VERIFY_RTOL
+            ok = bool(good)
+            out.update(against="oracle (orc_groupby_dense_partial over the host twin of EVERY rank's shard, all rows) + " + out["against"], max_rel_err=err, rtol=VERIFY_RTOL,
+                       rows=int(total_rows))
+        else:
+            out["note"] = "the oracle did not cover all shards within its time budget: properties only"
+    out["ok"] = bool(ok)
+    return out
 
 
 def run_sharded(args, emit):
@@ -1025,42 +1194,41 @@ def run_sharded(args, emit):
     rank, local_rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     dry = args.dry_run
     cfg5 = args.workload == "cfg5"
-    n = args.rows or 1_000_000_000
+    strong = args.scaling == "strong"
+    n = args.rows or (1_000_000_000 // ws if strong else 1_000_000_000)      # strong: the 1e9-row configuration split over the ranks
     n_keys = 1_000_000
     seed = 10 + rank
-    key_name, val_name = ("k", "v")if cfg5 else ("key", "v")
+    key_name, val_name = ("k", "v") if cfg5 else ("key", "v")
+    spec = pdist.GroupBySpec(key_name, [("v_sum", val_name, "sum"), ("v_mean", val_name, "mean")] if cfg5 else [("v_sum", val_name, "sum"), ("v_count", val_name, "count")])
+    second = ("mean", "v_mean") if cfg5 else ("count", "v_count")
+    val_np, val_args = ("Float64", (0, 10 ** 9, 1e-7)) if cfg5 else ("Int64", (0, 1000))
     if dry:
         from polars_amd import datagen
         pdist.init_process_group("gloo")
         k = datagen.uniform_native_host("UInt32" if cfg5 else "Int64", 0, n, seed, 0, 0, n_keys)
-        v = datagen.uniform_native_host("Float64", 0, n, seed, 1, 0, 10 ** 9, 1e-7) if cfg5 else datagen.uniform_native_host("Int64", 0, n, seed, 1, 0, 1000)
+        v = datagen.uniform_native_host(val_np, 0, n, seed, 1, *val_args)
         df = DryFrame({key_name: k, val_name: v})
-        comm = DryComm()
-
-        def query(d):
-            kk = d.cols[key_name].astype(np.int64)
-            s = np.bincount(kk, weights=d.cols[val_name], minlength=n_keys); c = np.bincount(kk, minlength=n_keys)
-            keep = np.nonzero(c)[0]
-            return DryFrame({key_name: keep, "v_sum": s[keep] if cfg5 else s[keep].astype(np.int64), "v_count": c[keep]})
+        comm, ops = DryComm(), DryOps()
         sync = lambda: None
         stats_fn = lambda: {}
+        column_sum = lambda: float(v.sum()) if cfg5 else int(v.sum())
+        result_cols = lambda r: dict(r.cols)
     else:
         torch.cuda.set_device(local_rank)
         import polars_amd as pl
-        from polars_amd import queries
         pl.init(local_rank)
         pdist.init_process_group("nccl")
         wl0 = make_workload(pl, args.workload, n, seed=seed)      # this rank's shard, from the library's generator
         df = wl0.step()[1][0]
-        comm = pdist.LibComm(pl)
-        q = queries.cfg5 if cfg5 else queries.cfg3
-        query = lambda d: q(d.lazy()).collect()
+        comm, ops = pdist.LibComm(pl), pdist.LibFrameOps(pl)
         F = pl._ffi
         sync = lambda: (torch.cuda.synchronize(), F.check(F.lib().plx_synchronize()))
         stats_fn = lambda: kernel_stats(pl)
-    res = None
+        column_sum = lambda: df.lazy().select(pl.col(val_name).sum().alias("s")).collect()["s"].to_list()[0]
+        result_cols = lambda r: {c: r[c].to_numpy() for c in r.columns}
+    res, info = None, {}
     for _ in range(max(args.warmup, 1)):
-        res = pdist.sharded_groupby(comm, df, key_name, query)
+        res = pdist.sharded_groupby(comm, df, spec, ops, mode=args.mode, info=info)
     if not dry:
         F.check(F.lib().plx_profile_clear()); F.check(F.lib().plx_profile_enable(1))
     comm.rows_sent = comm.bytes_sent = 0
@@ -1069,34 +1237,50 @@ def run_sharded(args, emit):
     gc.collect(); gc.disable()          # see timed(): the harness must not collect inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = pdist.sharded_groupby(comm, df, key_name, query)
+        res = pdist.sharded_groupby(comm, df, spec, ops, mode=args.mode, info=info)
     sync(); dist.barrier()
     dt = time.perf_counter() - t0
     gc.enable()
     stats = stats_fn()
     # max over ranks of the timed region; totals of the exchange accounting and of the (sharded) result
-    t = torch.tensor([dt, float(comm.rows_sent), float(comm.bytes_sent), float(res.height)], dtype=torch.float64)
+    t = torch.tensor([dt, float(comm.rows_sent), float(comm.bytes_sent), float(res.height), float(n), float(column_sum())], dtype=torch.float64)
     if not dry:
         t = t.cuda()
     tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
     dt = float(tmax[0].item())
+    total_rows = int(tsum[4].item())
+    # rank 0 gathers the (small) sharded result and checks it
+    mine = result_cols(res)
+    every = [None] * ws
+    dist.all_gather_object(every, {c: np.asarray(a) for c, a in mine.items()})
+    verified = None
+    if rank == 0:
+        allc = {c: np.concatenate([e[c] for e in every]) for c in mine}
+        isum = tsum[5].item()
+        verified = verify_sharded_groupby(allc, key_name, "v_sum", second, total_rows, isum if cfg5 else int(round(isum)), [(n, 10 + r) for r in range(ws)], n_keys,
+                                          "UInt32" if cfg5 else "Int64", val_np, val_args, 0.0 if os.environ.get("PLX_BENCH_VERIFY", "1") == "0" else float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40")))
+        if verified.get("ok") is False:
+            print(f"[bench] VERIFICATION FAILED for the sharded {args.workload}: {verified}", file=sys.stderr)
     rec_bytes = (4 + 8) if cfg5 else 16
     algo = n * rec_bytes + n_keys * 20 // ws
+    how = {"preagg": "local partitioned group-by -> partial rows exchanged by key hash (one grouped all-to-all(v)) -> merge on the owner",
+           "rows": "raw rows exchanged by key hash (one grouped all-to-all(v)) -> single-GPU partitioned group-by over the owned keys", "local": "single rank"}[info.get("mode", "local")]
     line = {
         "metric": "rows/sec + achieved HBM GB/s, TPC-H Q1/Q3 SF100, 1/2/4/8 GPU vs CPU",
-        "value": round(n * ws * args.steps / dt, 1), "unit": "rows/s", "n_gpus": ws, "steps": args.steps, "warmup": max(args.warmup, 1),
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": round(total_rows * args.steps / dt, 1), "unit": "rows/s", "n_gpus": ws, "steps": args.steps, "warmup": max(args.warmup, 1),
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f64" if cfg5 else "int64", "data": "synthetic",
         "config": {"workload": ("cfg5_dict_string_keys" if cfg5 else "cfg3_groupby_1e6_keys") + f"_sharded_x{ws}", "rows_per_gpu": n, "algorithmic_bytes_per_gpu_step": algo,
-                   "description": f"{n} rows per rank, 1e6 keys over all ranks, group_by(key).agg(...): rows exchanged by key hash (one grouped all-to-all(v) of every column), "
-                                  "then the single-GPU partitioned group-by over the rank's keys; result sharded by key",
-                   "parallelism": f"row-sharded x{ws}, rows exchanged by key hash (all-to-all), per-rank group-by over disjoint key sets",
+                   "description": f"{n} rows per rank, 1e6 keys over all ranks, group_by(key).agg(...): {how}; result sharded by key",
+                   "parallelism": f"row-sharded x{ws}; {how}",
                    "backend": "numpy + gloo DRY RUN (control flow only, nothing measured)" if dry else "libpolars_amd + RCCL (plx_exchange_by_key)"},
+        "exchange_mode": info.get("mode"), "shrink_estimate": info.get("shrink_estimate"), "partial_rows_per_rank": info.get("partial_rows"),
         "shuffle": {"rows_sent_per_rank_per_step": round(float(tsum[1].item()) / ws / args.steps, 1), "bytes_sent_per_rank_per_step": round(float(tsum[2].item()) / ws / args.steps, 1),
                     "fabric_GBps_per_rank": round(float(tsum[2].item()) / ws / dt / 1e9, 2)},
         "groups_total": int(tsum[3].item()),
         "whole_query_GBps_per_gpu": round(algo * args.steps / dt / 1e9, 1),
+        "verified": verified,
         "kernels": _kernels(stats, 8) if stats else {},
     }
     if dry:

@@ -206,7 +206,7 @@ class LibComm:
             ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
         h = C.c_uint64()
         F.check(F.lib().plx_comm_init(ident, rank, ws, C.byref(h)))
-        self._h, self.rank, self.world_size = h.value, rank, ws
+        self._h, self.rank, self.world_size, self._group = h.value, rank, ws, group
         self.rows_sent = self.bytes_sent = 0          # over the fabric, accumulated
 
     def exchange_by_key(self, df, key: str, seed: int = 0):
@@ -218,6 +218,15 @@ class LibComm:
         F.check(F.lib().plx_exchange_by_key(self._h, df._frame_handle(), key.encode(), seed, C.byref(out), C.byref(rows), C.byref(nbytes)))
         self.rows_sent += rows.value; self.bytes_sent += nbytes.value
         return self.pl.DataFrame._from_frame_handle(out.value, df.schema)
+
+    def agree(self, value: float) -> float:
+        """Rank 0's value on every rank (plan decisions every rank must take alike); host-side, through the bootstrap process group."""
+        if self.world_size == 1:
+            return float(value)
+        import torch.distributed as dist
+        box = [float(value)]
+        dist.broadcast_object_list(box, src=0, group=self._group)
+        return float(box[0])
 
     def allgather(self, df):
         """Concatenation of every rank's frame (rank order) on every rank."""
@@ -239,14 +248,130 @@ class LibComm:
             pass
 
 
-def sharded_groupby(comm, df, key: str, query, always_exchange: bool = False):
-    """High-cardinality group-by over row shards: one exchange by key hash (all columns in one grouped
-    all-to-all), then the single-GPU operator over the disjoint key set this rank owns -- `query(frame)` runs it (e.g.
-    lambda d: queries.cfg3(d.lazy()).collect()).  The result stays sharded by key: the concatenation over the ranks is the
-    global result.  `comm`: a LibComm (RCCL inside the library) or any object with world_size and exchange_by_key(df, key)
-    (bench.py's dry-run double under gloo).  always_exchange: run the exchange at world size 1 too (a self-exchange)."""
-    owned = comm.exchange_by_key(df, key) if comm is not None and (comm.world_size > 1 or always_exchange) else df
-    return query(owned)
+class GroupBySpec:
+    """group_by(key).agg(...) in the form the sharded operator splits it: aggs = [(out_name, value column or "" for len, op)], op in
+    PARTIALS.  The split is the reference's own (crates/polars-stream/src/nodes/group_by.rs:140-250 local pre-aggregation, :252-497
+    combine_locals; reduce/mean.rs:82-132 keeps (f64 sum, count)): every rank reduces its rows to one partial row per local group,
+    partial rows are routed by key hash, the owner of a key combines them."""
+
+    def __init__(self, key: str, aggs: Sequence[Tuple[str, str, str]]):
+        self.key, self.aggs = key, [(o, c or "", op) for o, c, op in aggs]
+        for _, _, op in self.aggs:
+            if op not in PARTIALS:
+                raise ValueError(f"aggregate {op!r} has no partial / combine decomposition on this path")
+
+    def partial_aggs(self) -> List[Tuple[str, str, str]]:
+        return [(f"{o}__p{i}", c, pop) for o, c, op in self.aggs for i, (pop, _) in enumerate(PARTIALS[op])]
+
+    def merge_aggs(self) -> List[Tuple[str, str, str]]:
+        return [(f"{o}__p{i}", f"{o}__p{i}", cop) for o, c, op in self.aggs for i, (_, cop) in enumerate(PARTIALS[op])]
+
+
+class LibFrameOps:
+    """The local queries of a sharded group-by as libpolars_amd plans (each one is the single-GPU operator: the fused scan into LDS /
+    partitioned tables); tests/ and bench.py --dry-run inject a numpy double with the same four methods."""
+
+    def __init__(self, pl):
+        self.pl = pl
+
+    def _expr(self, col: str, op: str):
+        pl = self.pl
+        if op == "len":
+            return pl.len()
+        if op == "sum_f64":
+            return pl.col(col).cast(pl.Float64).sum()
+        return getattr(pl.col(col), op)()
+
+    def final(self, df, spec: GroupBySpec):
+        return df.lazy().group_by(spec.key).agg(*[self._expr(c, op).alias(o) for o, c, op in spec.aggs]).collect()
+
+    def partial(self, df, spec: GroupBySpec):
+        return df.lazy().group_by(spec.key).agg(*[self._expr(c, op).alias(o) for o, c, op in spec.partial_aggs()]).collect()
+
+    def merge(self, part, spec: GroupBySpec, source_schema=None):
+        """partial rows of the keys this rank owns -> the final rows.  mean = sum of the f64 partial sums / sum of the counts, null when
+        no value was counted (count % count is null exactly then: integer mod by zero, arithmetic/signed.rs:35-70)."""
+        pl = self.pl
+        lf = part.lazy().group_by(spec.key).agg(*[self._expr(c, op).alias(o) for o, c, op in spec.merge_aggs()])
+        outs = [pl.col(spec.key)]
+        for o, c, op in spec.aggs:
+            if op == "mean":
+                n = pl.col(f"{o}__p1")
+                m = pl.col(f"{o}__p0") / (n + n % n).cast(pl.Float64)
+                if source_schema is not None and source_schema.get(c) == pl.Float32:      # Float32.mean() stays Float32 (reduce/mean.rs:29-80)
+                    m = m.cast(pl.Float32)
+                outs.append(m.alias(o))
+            else:
+                outs.append(pl.col(f"{o}__p0").alias(o))
+        return lf.select(*outs).collect()
+
+    def distinct_in_prefix(self, df, key: str, n: int) -> int:
+        return self.pl.DataFrame([df[key]]).slice(0, n).lazy().group_by(key).agg(self.pl.len().alias("n")).collect().height
+
+
+def estimate_shrink(rows: int, sample_rows: int, sample_distinct: int) -> float:
+    """How much a local group-by shrinks `rows` rows, from the number of distinct keys in a sample: with G equally likely keys a sample of
+    n rows holds u = G (1 - exp(-n / G)) distinct ones; G is solved by bisection and pushed through the same formula for the whole shard
+    (skew only makes the true shrink larger).  Returns rows / expected local groups; 1.0 when every sampled key was distinct."""
+    import math
+    n, u = float(sample_rows), float(sample_distinct)
+    if rows <= 0 or n <= 0 or u <= 0:
+        return 1.0
+    if u >= 0.995 * n:                      # (nearly) all distinct: G is not identifiable from this sample, assume no shrink
+        return 1.0
+    lo, hi = u, 1e15
+    for _ in range(200):
+        g = math.sqrt(lo * hi)
+        if g * -math.expm1(-n / g) < u:
+            lo = g
+        else:
+            hi = g
+    g = math.sqrt(lo * hi)
+    return rows / max(1.0, g * -math.expm1(-rows / g))
+
+
+PREAGG_MIN_SHRINK = 8.0          # pre-aggregate before the exchange when the local group-by shrinks the shard at least this much
+PREAGG_SAMPLE_ROWS = 1 << 20
+
+
+def sharded_groupby(comm, df, spec, ops=None, *, mode: str = "auto", always_exchange: bool = False, info: Optional[dict] = None):
+    """group_by(key).agg(...) over row shards; the result stays sharded by key (the concatenation over the ranks is
+    the global result; null keys live on rank 0: hashing.rs:111-115).
+
+    mode "preagg": local group-by -> ONE exchange of the partial rows by key hash (G x state bytes cross xGMI, not the rows) ->
+                   the owner combines the partials (group_by.rs:140-497).  BASELINE configs 3 / 5 (1e9 rows, 1e6 keys per rank): ~20 MB
+                   per rank instead of ~14 GB.
+    mode "rows"  : ONE exchange of the raw rows by key hash -> the single-GPU operator over the disjoint key set; right when almost
+                   every row is its own group (the local aggregate would not shrink anything).
+    mode "auto"  : "preagg" when the distinct keys of a 2^20-row sample predict a local shrink >= 8x (estimate_shrink); the choice is
+                   agreed across ranks (rank 0's estimate is broadcast through the communicator's agree()).
+    `spec`: a GroupBySpec.
+    `comm`: LibComm (RCCL inside the library) or any object with world_size, exchange_by_key(df, key) and agree(value);
+    `ops`: LibFrameOps or a double.  `info`, if given, receives {"mode", "shrink_estimate", "partial_rows"}."""
+    alone = comm is None or (comm.world_size == 1 and not always_exchange)
+    if alone:
+        if info is not None:
+            info.update(mode="local", shrink_estimate=None, partial_rows=None)
+        return ops.final(df, spec)
+    if mode == "auto":
+        n = min(int(df.height), PREAGG_SAMPLE_ROWS)
+        shrink = estimate_shrink(int(df.height), n, ops.distinct_in_prefix(df, spec.key, n)) if n else 1.0
+        shrink = comm.agree(shrink)                    # every rank must take the same branch (the exchanges must pair up)
+        mode = "preagg" if shrink >= PREAGG_MIN_SHRINK else "rows"
+    else:
+        shrink = None
+    if mode == "rows":
+        out = ops.final(comm.exchange_by_key(df, spec.key), spec)
+        if info is not None:
+            info.update(mode="rows", shrink_estimate=shrink, partial_rows=None)
+        return out
+    if mode != "preagg":
+        raise ValueError(f"sharded_groupby mode {mode!r}")
+    part = ops.partial(df, spec)
+    owned = comm.exchange_by_key(part, spec.key)
+    if info is not None:
+        info.update(mode="preagg", shrink_estimate=shrink, partial_rows=int(part.height))
+    return ops.merge(owned, spec, getattr(df, "schema", None))
 
 
 def allgather_concat(t, group=None):

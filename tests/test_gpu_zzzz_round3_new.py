@@ -7,7 +7,7 @@ import pyarrow as pa
 import pyarrow.parquet as pq
 import pytest
 
-pytestmark = pytest.mark.gpu_unvalidated
+pytestmark = pytest.mark.gpu          # validated on hardware: gpurun_out/r03a (round 3, first call)
 
 
 def test_string_literal_filter_on_a_scanned_column_first_collect(pl, tmp_path):

@@ -1,0 +1,272 @@
+// micro_part3 -- third-generation partition scatter for the high-cardinality group-by (BASELINE configs 3 and 5), standalone.
+// Question: does a TILE-SORT scatter (rank rows by partition inside a workgroup tile with one LDS atomic per row, sort the tile's
+// records in LDS, write every partition's run contiguously to the partition's current chunk -- partial 128-B lines are left to the L2
+// to merge with the next round's run) beat the ring + complete-line flush of partition2_device.hpp (7.0 ms per 1e9 rows)?  And how
+// does the two-pass time depend on the record width (4 / 8 / 12 B)?
+//
+//   scatter3<REC, R, BLOCK>   rounds of BLOCK * R rows per workgroup: loads (prefetched one round ahead) -> partition + rank
+//                             (ds_add_rtn_u32) | barrier | one wave scans the 256 counts, assigns the runs' destinations (private
+//                             chunks, no global atomics) | barrier | records into the sorted LDS tile | barrier | 16-lane groups copy
+//                             the runs out
+//   agg3<REC>                 one workgroup per partition walks its chunk list into an LDS direct-address table
+// Records:  REC=4: {key_low:12 | value:20}   REC=8: {key_low:u32, value:u32}   REC=12: {key_low:u32, value:u64}
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/micro_part3.bin tools/micro_part3.hip      run: tools/micro_part3.bin [rows]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+constexpr uint32_t kNP = 256, kShift = 12;            // 1e6 keys < 2^20: partition = key >> 12, slot = key & 4095
+constexpr uint32_t kChunk = 2048;                     // records per chunk
+constexpr uint32_t kNoChunk = 0xffffffffu;
+
+__device__ __forceinline__ uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
+__global__ void gen(int64_t* keys, int64_t* vals, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    keys[i] = (int64_t)(mix((uint64_t)i * 2 + 1) % 1000000ull);
+    vals[i] = (int64_t)(mix((uint64_t)i * 2 + 2) % 1000ull);
+  }
+}
+__global__ void ref_agg(const int64_t* keys, const int64_t* vals, int64_t n, unsigned long long* sum, unsigned int* cnt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    atomicAdd(&sum[keys[i]], (unsigned long long)vals[i]); atomicAdd(&cnt[keys[i]], 1u);
+  }
+}
+
+template <int REC> struct RecT;
+template <> struct RecT<4> { using T = uint32_t; };
+template <> struct RecT<8> { using T = uint2; };
+struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
+template <> struct RecT<12> { using T = U3; };
+template <int REC> __device__ __forceinline__ typename RecT<REC>::T make_rec(uint32_t klow, uint64_t v) {
+  if constexpr (REC == 4) return klow | ((uint32_t)v << 12);
+  else if constexpr (REC == 8) return make_uint2(klow, (uint32_t)v);
+  else { U3 r; r.a = klow; r.b = (uint32_t)v; r.c = (uint32_t)(v >> 32); return r; }
+}
+template <int REC> __device__ __forceinline__ void split_rec(const typename RecT<REC>::T& r, uint32_t& klow, uint64_t& v) {
+  if constexpr (REC == 4) { klow = r & 4095u; v = r >> 12; }
+  else if constexpr (REC == 8) { klow = r.x; v = r.y; }
+  else { klow = r.a; v = (uint64_t)r.b | ((uint64_t)r.c << 32); }
+}
+
+// LDS: sorted[T] records | cnt[NP] | off[NP + 1] | gdst_chunk[NP] | gdst_fill[NP] | cur_chunk[NP] | cur_fill[NP] | misc[4]
+template <int REC, int R, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void scatter3(const int64_t* __restrict__ keys, const int64_t* __restrict__ vals, int64_t n, typename RecT<REC>::T* __restrict__ recs,
+                                                  uint32_t* __restrict__ chunk_part, uint32_t* __restrict__ chunk_fill, uint32_t chunks_per_wg, uint32_t* __restrict__ flags, int ablate) {
+  using Rec = typename RecT<REC>::T;
+  constexpr int T = BLOCK * R;
+  extern __shared__ unsigned long long lds_raw[];
+  Rec* sorted = reinterpret_cast<Rec*>(lds_raw);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds_raw) + (size_t)T * REC);
+  uint32_t* off = cnt + kNP;
+  uint32_t* gchunk = off + kNP + 1;
+  uint32_t* gfill = gchunk + kNP;
+  uint32_t* cur_chunk = gfill + kNP;
+  uint32_t* cur_fill = cur_chunk + kNP;
+  uint32_t* misc = cur_fill + kNP;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < (int)kNP; i += BLOCK) { cnt[i] = 0; cur_chunk[i] = kNoChunk; cur_fill[i] = 0; }
+  if (tid == 0) misc[0] = 0;
+  __syncthreads();
+  const uint32_t chunk0 = blockIdx.x * chunks_per_wg;
+  const int64_t nrounds = (n + T - 1) / T;
+  // a thread's rows of a round: R / 2 pairs; pair k = rows base + (k * BLOCK + tid) * 2, +1 (one 16-B load per column)
+  longlong2 kq[R / 2], vq[R / 2], kn[R / 2], vn[R / 2];
+  auto load = [&](int64_t rd, longlong2* k, longlong2* v) __attribute__((always_inline)) {
+    const int64_t base = rd * T;
+#pragma unroll
+    for (int j = 0; j < R / 2; j++) {
+      const int64_t row = base + ((int64_t)j * BLOCK + tid) * 2;
+      if (row + 1 < n) { k[j] = *reinterpret_cast<const longlong2*>(keys + row); v[j] = *reinterpret_cast<const longlong2*>(vals + row); }
+      else { k[j].x = row < n ? keys[row] : -1; k[j].y = -1; v[j].x = row < n ? vals[row] : 0; v[j].y = 0; }
+    }
+  };
+  int64_t rd = blockIdx.x;
+  if (rd < nrounds) load(rd, kn, vn);
+  for (; rd < nrounds; rd += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < R / 2; j++) { kq[j] = kn[j]; vq[j] = vn[j]; }
+    if (rd + gridDim.x < nrounds) load(rd + gridDim.x, kn, vn);
+    uint32_t part[R], rank[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      const int64_t key = (j & 1) ? kq[j / 2].y : kq[j / 2].x;
+      part[j] = key < 0 ? kNP : (uint32_t)((uint64_t)key >> kShift);
+      rank[j] = part[j] < kNP ? atomicAdd(&cnt[part[j]], 1u) : 0u;
+    }
+    __syncthreads();                                                                  // A: counts complete
+    if (tid < 64) {                                                                   // one wave: scan + destinations for 4 partitions per lane
+      uint32_t c[4], s = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { c[q] = cnt[lane * 4 + q]; s += c[q]; }
+      uint32_t incl = s;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+      uint32_t o = incl - s;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t p = lane * 4 + q;
+        off[p] = o; o += c[q];
+        cnt[p] = 0;
+        uint32_t ch = cur_chunk[p], fill = cur_fill[p];
+        if (c[q]) {
+          if (ch == kNoChunk || fill + c[q] > kChunk) {
+            if (ch != kNoChunk) chunk_fill[ch] = fill;
+            const uint32_t need = (c[q] + kChunk - 1) / kChunk;
+            const uint32_t local = atomicAdd(&misc[0], need);
+            if (local + need > chunks_per_wg) { flags[0] = 1; ch = chunk0; gchunk[p] = ch; gfill[p] = 0; fill = 0; }    // cannot happen by construction; results flagged wrong
+            else {
+              ch = chunk0 + local;
+              for (uint32_t e = 0; e < need; e++) { chunk_part[ch + e] = p; if (e + 1 < need) chunk_fill[ch + e] = kChunk; }
+              gchunk[p] = ch; gfill[p] = 0;
+              ch += need - 1; fill = c[q] - (need - 1) * kChunk;
+            }
+          } else { gchunk[p] = ch; gfill[p] = fill; fill += c[q]; }
+          cur_chunk[p] = ch; cur_fill[p] = fill;
+        }
+      }
+      if (lane == 63) off[kNP] = o;
+    }
+    __syncthreads();                                                                  // B: offsets known
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      if (part[j] >= kNP) continue;
+      const int64_t key = (j & 1) ? kq[j / 2].y : kq[j / 2].x;
+      const int64_t val = (j & 1) ? vq[j / 2].y : vq[j / 2].x;
+      if (!(ablate & 2)) sorted[off[part[j]] + rank[j]] = make_rec<REC>((uint32_t)key & ((1u << kShift) - 1u), (uint64_t)val);
+    }
+    __syncthreads();                                                                  // C: tile sorted
+    {
+      const int g = tid >> 4, l16 = tid & 15;
+      for (uint32_t p = g; p < kNP; p += BLOCK / 16) {
+        const uint32_t o = off[p], c = off[p + 1] - o;
+        Rec* dst = recs + (uint64_t)gchunk[p] * kChunk + gfill[p];
+        for (uint32_t j = l16; j < c; j += 16) { const Rec r = sorted[o + j]; if (!(ablate & 1)) dst[j] = r; }
+      }
+    }
+    // no barrier here: the next round touches cnt (reset before B) and, only after its own barriers A and B, off / sorted
+  }
+  __syncthreads();
+  for (int p = tid; p < (int)kNP; p += BLOCK) if (cur_chunk[p] != kNoChunk) chunk_fill[cur_chunk[p]] = cur_fill[p];
+}
+
+// chunk lists per partition: one workgroup, counting sort of the chunk -> partition map (micro-benchmark plumbing)
+__global__ __launch_bounds__(1024) void chunk_lists(const uint32_t* chunk_part, uint32_t n_chunks, uint32_t* cl_off /* [NP + 1] */, uint32_t* cl_ids) {
+  __shared__ uint32_t cnt[kNP + 1], cur[kNP];
+  for (int i = threadIdx.x; i <= (int)kNP; i += 1024) cnt[i] = 0;
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < n_chunks; c += 1024) if (chunk_part[c] != kNoChunk) atomicAdd(&cnt[chunk_part[c]], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t s = 0; for (uint32_t p = 0; p < kNP; p++) { const uint32_t c = cnt[p]; cl_off[p] = s; cur[p] = s; s += c; } cl_off[kNP] = s; }
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < n_chunks; c += 1024) if (chunk_part[c] != kNoChunk) cl_ids[atomicAdd(&cur[chunk_part[c]], 1u)] = c;
+}
+
+template <int REC>
+__global__ __launch_bounds__(1024) void agg3(const typename RecT<REC>::T* __restrict__ recs, const uint32_t* __restrict__ chunk_fill, const uint32_t* __restrict__ cl_off,
+                                             const uint32_t* __restrict__ cl_ids, unsigned long long* __restrict__ out_sum, unsigned int* __restrict__ out_cnt) {
+  using Rec = typename RecT<REC>::T;
+  __shared__ unsigned long long sum[1u << kShift];
+  __shared__ unsigned int cnt[1u << kShift];
+  const uint32_t p = blockIdx.x;
+  for (int i = threadIdx.x; i < (1 << kShift); i += 1024) { sum[i] = 0; cnt[i] = 0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int PER = kChunk / 64;               // records of a chunk per lane
+  constexpr int B = 8;                           // records per lane per batch in flight
+  for (uint32_t j = cl_off[p] + wave; j < cl_off[p + 1]; j += 16) {
+    const uint32_t id = cl_ids[j], fill = chunk_fill[id];
+    const Rec* base = recs + (uint64_t)id * kChunk;
+    for (int b0 = 0; b0 < PER; b0 += B) {
+      Rec r[B];
+#pragma unroll
+      for (int u = 0; u < B; u++) { const uint32_t i = (uint32_t)(b0 + u) * 64 + lane; r[u] = base[i < fill ? i : 0]; }
+#pragma unroll
+      for (int u = 0; u < B; u++) {
+        const uint32_t i = (uint32_t)(b0 + u) * 64 + lane;
+        if (i < fill) { uint32_t kl; uint64_t v; split_rec<REC>(r[u], kl, v); atomicAdd(&sum[kl], (unsigned long long)v); atomicAdd(&cnt[kl], 1u); }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (1 << kShift); i += 1024) { out_sum[((uint64_t)p << kShift) + i] = sum[i]; out_cnt[((uint64_t)p << kShift) + i] = cnt[i]; }
+}
+__global__ void compare(const unsigned long long* a, const unsigned long long* b, const unsigned int* ca, const unsigned int* cb, int n, unsigned int* bad) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) if (a[i] != b[i] || ca[i] != cb[i]) atomicAdd(bad, 1u);
+}
+
+template <class F> static float time_ms(F f, int reps = 4) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  f(); CK(hipDeviceSynchronize());
+  hipEventRecord(a);
+  for (int i = 0; i < reps; i++) f();
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms = 0; hipEventElapsedTime(&ms, a, b);
+  return ms / reps;
+}
+
+struct Ctx {
+  int64_t n; int64_t *keys, *vals; void* recs; uint32_t *chunk_part, *chunk_fill, *flags, *cl_off, *cl_ids; unsigned long long *ref_sum, *out_sum; unsigned int *ref_cnt, *out_cnt, *bad;
+  uint32_t max_chunks;
+};
+
+template <int REC, int R, int BLOCK>
+static void run_variant(Ctx& c, int wg_per_cu, int ablate = 0) {
+  using Rec = typename RecT<REC>::T;
+  constexpr int T = BLOCK * R;
+  const int grid = 256 * wg_per_cu;
+  const size_t lds = (size_t)T * REC + (size_t)(kNP * 6 + 1 + 4) * 4;
+  const uint32_t chunks_per_wg = (uint32_t)((c.n / grid + kChunk - 1) / kChunk * 102 / 100 + kNP + 8);
+  const uint32_t n_chunks = chunks_per_wg * grid;
+  if (n_chunks > c.max_chunks) { printf("REC=%d: chunk table too small\n", REC); return; }
+  auto kern = scatter3<REC, R, BLOCK>;
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto scatter = [&] {
+    hipMemsetAsync(c.chunk_part, 0xff, (size_t)n_chunks * 4, 0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, 0, c.keys, c.vals, c.n, (Rec*)c.recs, c.chunk_part, c.chunk_fill, chunks_per_wg, c.flags, ablate);
+  };
+  const float t_sc = time_ms(scatter);
+  auto lists = [&] { hipLaunchKernelGGL(chunk_lists, dim3(1), dim3(1024), 0, 0, c.chunk_part, n_chunks, c.cl_off, c.cl_ids); };
+  const float t_ls = time_ms(lists, 2);
+  auto agg = [&] { hipLaunchKernelGGL(agg3<REC>, dim3(kNP), dim3(1024), 0, 0, (const Rec*)c.recs, c.chunk_fill, c.cl_off, c.cl_ids, c.out_sum, c.out_cnt); };
+  const float t_ag = time_ms(agg);
+  CK(hipMemset(c.bad, 0, 4));
+  hipLaunchKernelGGL(compare, dim3(256), dim3(256), 0, 0, c.ref_sum, c.out_sum, c.ref_cnt, c.out_cnt, 1 << 20, c.bad);
+  unsigned int bad = 0, flag = 0; CK(hipMemcpy(&bad, c.bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&flag, c.flags, 4, hipMemcpyDeviceToHost));
+  const double gb_sc = (double)c.n * (16 + REC) / 1e9, gb_ag = (double)c.n * REC / 1e9;
+  printf("REC=%2d R=%d BLOCK=%4d wg/cu=%d ablate=%d lds=%6zu: scatter %7.3f ms (%6.0f GB/s)  lists %5.3f ms  agg %6.3f ms (%6.0f GB/s)  total %7.3f ms  mismatches=%u overflow=%u\n", REC, R, BLOCK,
+         wg_per_cu, ablate, lds, t_sc, gb_sc / t_sc * 1e3, t_ls, t_ag, gb_ag / t_ag * 1e3, t_sc + t_ls + t_ag, ablate ? 0u : bad, flag);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  Ctx c{};
+  c.n = argc > 1 ? (int64_t)atof(argv[1]) : 1000000000ll;
+  CK(hipMalloc(&c.keys, c.n * 8)); CK(hipMalloc(&c.vals, c.n * 8));
+  c.max_chunks = (uint32_t)(c.n / kChunk * 11 / 10 + 1024 * (kNP + 16));
+  CK(hipMalloc(&c.recs, (size_t)c.max_chunks * kChunk * 12));
+  CK(hipMalloc(&c.chunk_part, (size_t)c.max_chunks * 4)); CK(hipMalloc(&c.chunk_fill, (size_t)c.max_chunks * 4)); CK(hipMalloc(&c.cl_ids, (size_t)c.max_chunks * 4));
+  CK(hipMalloc(&c.cl_off, (kNP + 1) * 4)); CK(hipMalloc(&c.flags, 16)); CK(hipMalloc(&c.bad, 4)); CK(hipMemset(c.flags, 0, 16));
+  CK(hipMalloc(&c.ref_sum, 8 << 20)); CK(hipMalloc(&c.out_sum, 8 << 20)); CK(hipMalloc(&c.ref_cnt, 4 << 20)); CK(hipMalloc(&c.out_cnt, 4 << 20));
+  CK(hipMemset(c.ref_sum, 0, 8 << 20)); CK(hipMemset(c.ref_cnt, 0, 4 << 20));
+  hipLaunchKernelGGL(gen, dim3(2048), dim3(256), 0, 0, c.keys, c.vals, c.n);
+  hipLaunchKernelGGL(ref_agg, dim3(2048), dim3(256), 0, 0, c.keys, c.vals, c.n, c.ref_sum, c.ref_cnt);
+  CK(hipDeviceSynchronize());
+  printf("rows %lld\n", (long long)c.n);
+  run_variant<8, 8, 1024>(c, 1);
+  run_variant<8, 8, 1024>(c, 1, 1);
+  run_variant<8, 8, 1024>(c, 1, 3);
+  run_variant<8, 4, 1024>(c, 1);
+  run_variant<8, 8, 512>(c, 2);
+  run_variant<8, 8, 512>(c, 3);
+  run_variant<8, 16, 512>(c, 2);
+  run_variant<8, 8, 256>(c, 4);
+  run_variant<4, 8, 1024>(c, 1);
+  run_variant<4, 8, 512>(c, 2);
+  run_variant<4, 16, 512>(c, 2);
+  run_variant<12, 8, 1024>(c, 1);
+  run_variant<12, 8, 512>(c, 2);
+  return 0;
+}
