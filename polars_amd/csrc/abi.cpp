@@ -861,6 +861,17 @@ int plx_jit_selftest(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int
     else jobs = {{sh, jit::LDSAGG}, {sh, jit::DENSE}, {sh, jit::HASH}, {sh, jit::PART_COUNT}, {sh, jit::PART_SCATTER}, {sh, jit::PART_AGG},
                   {sh, jit::PART2_SCATTER_HASH}, {sh, jit::PART2_SCATTER_DIRECT}, {sh, jit::PART2_AGG_HASH}, {sh, jit::PART2_AGG_DIRECT},
                   {sh, jit::PART2_SCATTER_HASH_T2}, {sh, jit::PART2_SCATTER_DIRECT_T2}};
+    if (rn.kind != PLX_IR_SELECT && sh.n_keys < 2) {
+      // third generation scatter: hash / direct x 1 / 2 / 4 tiles, and every packing the shape admits, with the matching aggregation kernels
+      for (uint32_t mode = 0; mode < 2; mode++) {
+        const uint32_t best = fused::best_static_pack(sh, mode);
+        for (uint32_t pack = 0; pack <= best; pack++) {
+          if (pack == fused::kPackNarrow && fused::rec_layout2(sh, mode, fused::kPackNarrow).rec_words == fused::rec_layout2(sh, mode, fused::kPackNone).rec_words) continue;
+          for (uint32_t tiles : {1u, 2u, 4u}) { jobs.push_back({sh, jit::part3_scatter_sink(mode, tiles, pack, false)}); jobs.push_back({sh, jit::part3_scatter_sink(mode, tiles, pack, true)}); }
+          jobs.push_back({sh, jit::part3_agg_sink(mode, pack)});
+        }
+      }
+    }
     if (sh.n_keys >= 2) jobs = {{sh, jit::WIDE}};
   }
   for (auto& j : jobs) {

@@ -76,15 +76,54 @@ Comm& get_comm(uint64_t h) {
   return *g_comms[h - 1];
 }
 
-// per-destination row counts of every rank -> [ws][ws] on the host (one ncclAllGather of ws int64 each + one D2H)
-std::vector<int64_t> exchange_counts(Comm& c, const std::vector<int64_t>& mine) {
+// One ncclAllGather of `n` int64 per rank + ONE D2H: all[r * n + i] = value i of rank r.  `send` is a device buffer of n int64.
+std::vector<int64_t> allgather_i64(Comm& c, const Buf& send, size_t n) {
   const int ws = c.ws;
-  Buf send = dev_alloc(sizeof(int64_t) * ws), all = dev_alloc(sizeof(int64_t) * ws * ws);
-  h2d_async(send->ptr, mine.data(), sizeof(int64_t) * ws);
-  nccl_check(rccl().AllGather(send->ptr, all->ptr, (size_t)ws, kNcclInt64, c.nccl, stream()), "ncclAllGather(counts)");
-  std::vector<int64_t> host((size_t)ws * ws);
+  Buf all = dev_alloc(sizeof(int64_t) * n * (size_t)ws);
+  nccl_check(rccl().AllGather(send->ptr, all->ptr, n, kNcclInt64, c.nccl, stream()), "ncclAllGather(counts)");
+  std::vector<int64_t> host(n * (size_t)ws);
   d2h_sync(host.data(), all->ptr, host.size() * 8);
   return host;
+}
+
+// What crosses the fabric for one column: fixed-width, null-free byte arrays ("wires").  Bit-packed buffers cannot be sliced per
+// destination at arbitrary row offsets, so Boolean values and validity bitmaps travel as one byte per row and are re-packed on receipt
+// (the reference's partitioner hands out row index lists and gathers, crates/polars-expr/src/hash_keys.rs:263-314: there is no bit
+// slicing there either).
+struct Wire { ColumnPtr data; size_t width; };
+ColumnPtr bitmap_as_bytes(const Buf& bits, int64_t n) {
+  auto b = std::make_shared<Column>();
+  b->dtype = PLX_BOOL; b->len = n; b->values = bits; b->null_count = 0;
+  return ops::cast(b, PLX_U8);
+}
+Buf bytes_as_bitmap(const ColumnPtr& bytes) {
+  plx_scalar zero; zero.u = 0;
+  return ops::cmp_scalar(PLX_NE, bytes, zero)->values;
+}
+// the wires of column `col` (already in its final row order): values, then validity when `with_validity`
+void column_wires(const ColumnPtr& col, bool with_validity, std::vector<Wire>& out) {
+  if (col->dtype == PLX_BOOL) out.push_back({bitmap_as_bytes(col->values, col->len), 1});
+  else {
+    auto v = std::make_shared<Column>(*col);
+    v->validity = nullptr;
+    out.push_back({v, (size_t)dtype_width(col->dtype)});
+  }
+  if (with_validity) {
+    if (col->validity) out.push_back({bitmap_as_bytes(col->validity, col->len), 1});
+    else { plx_scalar one; one.u = 1; out.push_back({ops::full_column(PLX_U8, one, true, col->len), 1}); }
+  }
+}
+// received wires -> column
+ColumnPtr column_from_wires(int dtype, int64_t n, bool with_validity, const std::vector<ColumnPtr>& recv, size_t& wi) {
+  ColumnPtr o;
+  if (dtype == PLX_BOOL) {
+    o = std::make_shared<Column>();
+    o->dtype = PLX_BOOL; o->len = n; o->values = bytes_as_bitmap(recv[wi++]);
+  } else o = recv[wi++];
+  o->dtype = dtype;
+  if (with_validity) { o->validity = bytes_as_bitmap(recv[wi++]); o->null_count = -1; }
+  else { o->validity = nullptr; o->null_count = 0; }
+  return o;
 }
 
 }  // namespace
@@ -123,88 +162,102 @@ void destroy(uint64_t h) {
 
 void info(uint64_t h, int* rank, int* ws) { Comm& c = get_comm(h); if (rank) *rank = c.rank; if (ws) *ws = c.ws; }
 
-// Routes every row of `in` to rank hash_partition(key); returns the rows this rank received (all columns, same names) and,
-// in *rows_sent / *bytes_sent, what left this rank over the fabric (rows kept locally do not count).
+// Routes every row of `in` to rank hash_partition(key) -- null keys to rank 0 (null_partition(), hashing.rs:111-115) -- and returns
+// the rows this rank received (all columns, same names; nullable and Boolean columns included); in *rows_sent / *bytes_sent what
+// left this rank over the fabric (rows kept locally do not count).  Host round trips: ONE (the [ws x ws] counts + the per-column
+// "some rank has nulls here" flags, needed for the receive allocations); the transfers are one ncclGroup = one fused RCCL kernel over
+// all seven xGMI links, so columns are not packed into a per-peer staging buffer (that would add two D2D passes over the payload and
+// save nothing on the wire).  Everything is ordered on the library's stream: no synchronisation at the end.
 FramePtr exchange_by_key(uint64_t h, const FramePtr& in, const std::string& key, uint64_t seed, uint64_t* rows_sent, uint64_t* bytes_sent) {
   Comm& c = get_comm(h);
   const int ws = c.ws;
   const int ki = in->find(key);
   PLX_REQUIRE(ki >= 0, PLX_ERR_NOT_FOUND, "exchange_by_key: key column not found: " + key);
-  for (size_t i = 0; i < in->cols.size(); i++) {
-    const ColumnPtr& col = in->cols[i];
-    PLX_REQUIRE(col->dtype != PLX_BOOL, PLX_ERR_UNSUPPORTED, "exchange_by_key: bit-packed Boolean columns cannot be sliced per destination (cast to UInt8 first)");
-    PLX_REQUIRE(!col->validity || column_null_count(col) == 0, PLX_ERR_UNSUPPORTED, "exchange_by_key: nullable columns are not exchanged yet (" + in->names[i] + ")");
-  }
-  // destination of every row and the permutation that groups rows by destination (plx_hash_partition)
+  const size_t nc = in->cols.size();
+  // destination of every row and the permutation that groups rows by destination (plx_hash_partition); counts stay on the device
   ColumnPtr perm;
-  std::vector<int64_t> send_cnt((size_t)ws, 0);
-  join::hash_partition(in->cols[ki], ws, seed, perm, send_cnt.data());
-  const std::vector<int64_t> all = exchange_counts(c, send_cnt);     // all[r * ws + d] = rows rank r sends to rank d
-  std::vector<int64_t> recv_cnt((size_t)ws), send_off((size_t)ws + 1, 0), recv_off((size_t)ws + 1, 0);
-  for (int r = 0; r < ws; r++) recv_cnt[r] = all[(size_t)r * ws + c.rank];
+  Buf counts_dev;
+  join::hash_partition_dev(in->cols[ki], ws, seed, perm, counts_dev);
+  Buf send = dev_alloc(sizeof(int64_t) * ((size_t)ws + nc));
+  PLX_HIP(hipMemcpyAsync(send->ptr, counts_dev->ptr, sizeof(int64_t) * (size_t)ws, hipMemcpyDeviceToDevice, stream()));
+  std::vector<int64_t> flags(nc, 0);
+  for (size_t i = 0; i < nc; i++) flags[i] = (in->cols[i]->validity && column_null_count(in->cols[i]) != 0) ? 1 : 0;
+  if (nc) h2d_async((uint8_t*)send->ptr + sizeof(int64_t) * (size_t)ws, flags.data(), sizeof(int64_t) * nc);
+  const size_t stride = (size_t)ws + nc;
+  const std::vector<int64_t> all = allgather_i64(c, send, stride);    // all[r * stride + d] = rows rank r sends to rank d; [.. + ws + i] = rank r has nulls in column i
+  std::vector<int64_t> send_cnt((size_t)ws), recv_cnt((size_t)ws), send_off((size_t)ws + 1, 0), recv_off((size_t)ws + 1, 0);
+  for (int r = 0; r < ws; r++) { send_cnt[r] = all[(size_t)c.rank * stride + r]; recv_cnt[r] = all[(size_t)r * stride + c.rank]; }
   for (int r = 0; r < ws; r++) { send_off[r + 1] = send_off[r] + send_cnt[r]; recv_off[r + 1] = recv_off[r] + recv_cnt[r]; }
+  PLX_REQUIRE(send_off[ws] == in->height, PLX_ERR_INVALID, "exchange_by_key: partition counts do not add up to the frame height");
   const int64_t n_out = recv_off[ws];
-  auto out = std::make_shared<Frame>();
-  out->height = n_out; out->names = in->names;
-  std::vector<ColumnPtr> staged;
-  for (const ColumnPtr& col : in->cols) {
-    ColumnPtr g = ops::gather(col, perm);                             // destination order, contiguous per rank
-    staged.push_back(g);
-    ColumnPtr o = make_column(col->dtype, n_out, false);
-    o->null_count = 0;
-    out->cols.push_back(o);
-  }
+  std::vector<char> nullable(nc, 0);
+  for (size_t i = 0; i < nc; i++) for (int r = 0; r < ws; r++) if (all[(size_t)r * stride + ws + i]) nullable[i] = 1;
+  std::vector<Wire> wires;
+  for (size_t i = 0; i < nc; i++) column_wires(ops::gather(in->cols[i], perm), nullable[i], wires);     // destination order, contiguous per rank
+  std::vector<ColumnPtr> recv;
+  for (const Wire& w : wires) { ColumnPtr o = make_column(w.width == 1 ? PLX_U8 : w.width == 2 ? PLX_U16 : w.width == 4 ? PLX_U32 : PLX_U64, n_out, false); o->null_count = 0; recv.push_back(o); }
   uint64_t moved_rows = 0, moved_bytes = 0;
   {
     ProfileScope ps("rccl_all_to_all_v", 0, (uint64_t)in->height);
     nccl_check(rccl().GroupStart(), "ncclGroupStart");
-    for (size_t ci = 0; ci < staged.size(); ci++) {
-      const size_t w = (size_t)dtype_width(staged[ci]->dtype);
-      const uint8_t* src = (const uint8_t*)staged[ci]->values->ptr;
-      uint8_t* dst = (uint8_t*)out->cols[ci]->values->ptr;
+    for (size_t wi = 0; wi < wires.size(); wi++) {
+      const size_t w = wires[wi].width;
+      const uint8_t* src = (const uint8_t*)wires[wi].data->values->ptr;
+      uint8_t* dst = (uint8_t*)recv[wi]->values->ptr;
       for (int p = 0; p < ws; p++) {
         if (send_cnt[p]) nccl_check(rccl().Send(src + (size_t)send_off[p] * w, (size_t)send_cnt[p] * w, kNcclUint8, p, c.nccl, stream()), "ncclSend");
         if (recv_cnt[p]) nccl_check(rccl().Recv(dst + (size_t)recv_off[p] * w, (size_t)recv_cnt[p] * w, kNcclUint8, p, c.nccl, stream()), "ncclRecv");
-        if (p != c.rank) { moved_bytes += (uint64_t)send_cnt[p] * w; }
+        if (p != c.rank) moved_bytes += (uint64_t)send_cnt[p] * w;
       }
     }
     nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
   }
   for (int p = 0; p < ws; p++) if (p != c.rank) moved_rows += (uint64_t)send_cnt[p];
-  PLX_HIP(hipStreamSynchronize(stream()));   // the staged buffers go back to the pool when this returns
+  auto out = std::make_shared<Frame>();
+  out->height = n_out; out->names = in->names;
+  size_t wi = 0;
+  for (size_t i = 0; i < nc; i++) out->cols.push_back(column_from_wires(in->cols[i]->dtype, n_out, nullable[i], recv, wi));
   if (rows_sent) *rows_sent = moved_rows;
   if (bytes_sent) *bytes_sent = moved_bytes;
   return out;
 }
 
 // Concatenation of every rank's frame, in rank order, on every rank (variable lengths: counts first, then one grouped
-// send / recv per column -- an all-gather(v)).
+// send / recv per wire -- an all-gather(v)); nullable and Boolean columns travel like in exchange_by_key.
 FramePtr allgather_frame(uint64_t h, const FramePtr& in) {
   Comm& c = get_comm(h);
   const int ws = c.ws;
-  for (size_t i = 0; i < in->cols.size(); i++) {
-    PLX_REQUIRE(in->cols[i]->dtype != PLX_BOOL && (!in->cols[i]->validity || column_null_count(in->cols[i]) == 0), PLX_ERR_UNSUPPORTED,
-                "allgather_frame: Boolean / nullable columns are not supported yet (" + in->names[i] + ")");
-  }
-  std::vector<int64_t> mine((size_t)ws, in->height);
-  const std::vector<int64_t> all = exchange_counts(c, mine);          // all[r * ws + *] = height of rank r
+  const size_t nc = in->cols.size();
+  std::vector<int64_t> mine(1 + nc, 0);
+  mine[0] = in->height;
+  for (size_t i = 0; i < nc; i++) mine[1 + i] = (in->cols[i]->validity && column_null_count(in->cols[i]) != 0) ? 1 : 0;
+  Buf send = dev_alloc(sizeof(int64_t) * mine.size());
+  h2d_async(send->ptr, mine.data(), sizeof(int64_t) * mine.size());
+  const size_t stride = mine.size();
+  const std::vector<int64_t> all = allgather_i64(c, send, stride);
   std::vector<int64_t> off((size_t)ws + 1, 0);
-  for (int r = 0; r < ws; r++) off[r + 1] = off[r] + all[(size_t)r * ws];
-  auto out = std::make_shared<Frame>();
-  out->height = off[ws]; out->names = in->names;
-  for (const ColumnPtr& col : in->cols) { ColumnPtr o = make_column(col->dtype, off[ws], false); o->null_count = 0; out->cols.push_back(o); }
+  for (int r = 0; r < ws; r++) off[r + 1] = off[r] + all[(size_t)r * stride];
+  std::vector<char> nullable(nc, 0);
+  for (size_t i = 0; i < nc; i++) for (int r = 0; r < ws; r++) if (all[(size_t)r * stride + 1 + i]) nullable[i] = 1;
+  std::vector<Wire> wires;
+  for (size_t i = 0; i < nc; i++) column_wires(in->cols[i], nullable[i], wires);
+  std::vector<ColumnPtr> recv;
+  for (const Wire& w : wires) { ColumnPtr o = make_column(w.width == 1 ? PLX_U8 : w.width == 2 ? PLX_U16 : w.width == 4 ? PLX_U32 : PLX_U64, off[ws], false); o->null_count = 0; recv.push_back(o); }
   nccl_check(rccl().GroupStart(), "ncclGroupStart");
-  for (size_t ci = 0; ci < in->cols.size(); ci++) {
-    const size_t w = (size_t)dtype_width(in->cols[ci]->dtype);
-    uint8_t* dst = (uint8_t*)out->cols[ci]->values->ptr;
+  for (size_t wi = 0; wi < wires.size(); wi++) {
+    const size_t w = wires[wi].width;
+    uint8_t* dst = (uint8_t*)recv[wi]->values->ptr;
     for (int p = 0; p < ws; p++) {
-      if (in->height) nccl_check(rccl().Send(in->cols[ci]->values->ptr, (size_t)in->height * w, kNcclUint8, p, c.nccl, stream()), "ncclSend");
-      const int64_t n = all[(size_t)p * ws];
+      if (in->height) nccl_check(rccl().Send(wires[wi].data->values->ptr, (size_t)in->height * w, kNcclUint8, p, c.nccl, stream()), "ncclSend");
+      const int64_t n = all[(size_t)p * stride];
       if (n) nccl_check(rccl().Recv(dst + (size_t)off[p] * w, (size_t)n * w, kNcclUint8, p, c.nccl, stream()), "ncclRecv");
     }
   }
   nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
-  PLX_HIP(hipStreamSynchronize(stream()));
+  auto out = std::make_shared<Frame>();
+  out->height = off[ws]; out->names = in->names;
+  size_t wi = 0;
+  for (size_t i = 0; i < nc; i++) out->cols.push_back(column_from_wires(in->cols[i]->dtype, off[ws], nullable[i], recv, wi));
   return out;
 }
 

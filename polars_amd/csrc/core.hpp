@@ -105,6 +105,9 @@ struct Column {
   int range_state = 0;      // 0 unknown, 1 known, 2 no valid rows
   int64_t range_min = 0, range_max = 0;
   bool range_trusted = true;   // computed by the library (exact); false: caller-provided bounds (plx_column_set_bounds)
+  // what the group-by planner learned from its strided sample of this column AS A KEY (engine.cpp KeySample: heavy hitters, distinct count,
+  // group estimate): a column is immutable, so the next group-by on it with no predicate skips the 8 sample launches (0.3 ms per query)
+  std::shared_ptr<void> key_sample;
   const void* data() const { return values ? values->ptr : nullptr; }
   const uint64_t* valid_words() const { return validity ? validity->as<uint64_t>() : nullptr; }
 };

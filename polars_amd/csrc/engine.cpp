@@ -769,7 +769,7 @@ static Args offset_args(const Shape& sh, const Args& a, int64_t row0, int64_t ro
 // Returns the number of distinct keys in the sample (-1: table overflow).  *groups_est (if given): estimated number of groups of the
 // whole input -- the heavy hitters are taken out of the sample first (estimate_groups assumes equally likely keys: one key holding
 // half of the rows would halve the estimate and the LDS tables planned from it would run at twice their load).
-static int64_t sample_keys(const Shape& full, const Args& args, int static_id, int full_len_idx, int64_t S, std::vector<uint64_t>* hot, double* groups_est = nullptr) {
+static int64_t sample_keys(const Shape& full, const Args& args, int static_id, int full_len_idx, int64_t S, std::vector<uint64_t>* hot, double* groups_est) {
   // the sample only counts rows per key: the query's other aggregates are dropped (half the table atomics for a two-aggregate
   // query), which makes it a different program shape -- 2^20 rows in blocks below the JIT threshold run the interpreter, fast enough
   Shape sh = full;
@@ -804,6 +804,58 @@ static bool probe_late_loads() { static const bool v = [] { const char* e = gete
 static int part_version() { static const int v = [] { const char* e = getenv("PLX_PART_V"); return (e && e[0] == '1') ? 1 : 2; }(); return v; }
 static bool hot_keys_enabled() { static const bool v = [] { const char* e = getenv("PLX_PART_HOT"); return !(e && e[0] == '0'); }(); return v; }
 
+// Value ranges of the record sources that are plain integer columns (cached column statistics, one reduction pass the first time a
+// column is asked): the partitioned group-by packs its records with them (fused::kPackNarrow / kPackFused).
+static void source_ranges(const Compiler& c, k::SrcRange out[kMaxSrc]) {
+  const Shape& sh = c.shape;
+  const RecLayout2 L = rec_layout2(sh, kP2Hash, kPackNarrow);
+  for (uint32_t j = 0; j < L.n_src && j < (uint32_t)kMaxSrc; j++) {
+    out[j] = k::SrcRange{};
+    const int in = slot_input(sh, L.src_slot[j]);
+    if (in < 0 || in >= (int)c.input_cols.size()) continue;
+    const ColumnPtr& col = c.cols[c.input_cols[in]];
+    if (!dtype_is_int(col->dtype) || col->dtype == PLX_U64) continue;
+    int64_t mn = 0, mx = 0;
+    if (ops::int_range(col, &mn, &mx)) { out[j].known = true; out[j].mn = mn; out[j].mx = mx; }
+  }
+}
+
+// The planner's sample of a key column (see Column::key_sample).
+struct KeySample { int64_t n_rows = 0, distinct = -1; double groups_est = 1e18; std::vector<uint64_t> hot; bool with_hot = false; };
+// the frame column a single-column group key reads directly, when the query has no predicate (then the sample depends on nothing else)
+static ColumnPtr plain_key_column(const Compiler& c, const KeyPlan& kp) {
+  if (c.shape.pred != kNone || kp.parts.size() != 1) return nullptr;
+  const AE* x = &c.plan.ae[kp.parts[0].expr];
+  while (x->kind == PLX_AE_ALIAS) x = &c.plan.ae[x->lhs];
+  if (x->kind != PLX_AE_COLUMN) return nullptr;
+  const int ci = c.df->find(x->name);
+  return ci >= 0 && c.df->cols[ci]->len == c.args.n_rows ? c.df->cols[ci] : nullptr;
+}
+static bool sample_cache_enabled() { static const bool v = [] { const char* e = getenv("PLX_SAMPLE_CACHE"); return !(e && e[0] == '0'); }(); return v; }
+static int64_t sample_keys(const Shape& full, const Args& args, int static_id, int full_len_idx, int64_t S, std::vector<uint64_t>* hot, double* groups_est);
+static int64_t sample_keys_cached(const ColumnPtr& key_col, const Shape& sh, const Args& args, int static_id, int len_idx, int64_t S, std::vector<uint64_t>* hot, double* groups_est,
+                                  std::string& desc) {
+  if (key_col && sample_cache_enabled() && key_col->key_sample) {
+    const KeySample& ks = *std::static_pointer_cast<KeySample>(key_col->key_sample);
+    if (ks.n_rows == args.n_rows && (ks.with_hot || !hot)) {
+      if (hot) *hot = ks.hot;
+      if (groups_est) *groups_est = ks.groups_est;
+      desc += "cached_";
+      return ks.distinct;
+    }
+  }
+  double g = 1e18;
+  const int64_t d = sample_keys(sh, args, static_id, len_idx, S, hot, &g);
+  if (groups_est) *groups_est = g;
+  if (key_col && sample_cache_enabled() && d >= 0) {
+    auto ks = std::make_shared<KeySample>();
+    ks->n_rows = args.n_rows; ks->distinct = d; ks->groups_est = g; ks->with_hot = hot != nullptr;
+    if (hot) ks->hot = *hot;
+    key_col->key_sample = ks;
+  }
+  return d;
+}
+
 static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, FusedAggResult& res, std::string& desc) {
   const Shape& sh = c.shape;
   const Args& args = c.args;
@@ -832,12 +884,14 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
       if (hot_keys_enabled() || kp.total_bits > 25) {
         const int64_t S = kPartSampleRows;
         double g_est = 1e18;
-        const int64_t d = sample_keys(sh, args, static_id, len_idx, S, hot_keys_enabled() ? &hot : nullptr, &g_est);
+        const int64_t d = sample_keys_cached(plain_key_column(c, kp), sh, args, static_id, len_idx, S, hot_keys_enabled() ? &hot : nullptr, &g_est, desc);
         if (d >= 0) est2 = std::min(est, std::min(g_est, (double)n) * 1.3);
         desc += "sample(distinct=" + std::to_string(d) + ",hot=" + std::to_string(hot.size()) + ")+";
       }
       PartPlan2 p2;
-      if (k::partition_plan2(sh, est2, kp.total_bits, len_idx, n, (int)hot.size(), &p2)) {
+      k::SrcRange ranges[kMaxSrc];
+      source_ranges(c, ranges);
+      if (k::partition_plan2(sh, est2, kp.total_bits, len_idx, n, (int)hot.size(), &p2, ranges)) {
         std::string pd;
         Buf ok, okv, oacc;
         const int64_t g = k::partitioned_agg2(sh, args, p2, static_id, hot, &ok, &okv, &oacc, &pd);
@@ -886,7 +940,8 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     const int64_t Sd = strided ? kPartSampleRows : S;
     double g_est = -1.0;
     int64_t d = kp.wide ? run_wide_agg(sh, sa, 23, kp.wide_nullable, tmp, true)
-                        : (strided ? sample_keys(sh, args, static_id, len_idx, Sd, hot_keys_enabled() ? &hot : nullptr, &g_est) : run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true));
+                        : (strided ? sample_keys_cached(plain_key_column(c, kp), sh, args, static_id, len_idx, Sd, hot_keys_enabled() ? &hot : nullptr, &g_est, desc)
+                                   : run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true));
     double G = d < 0 ? 1e18 : (g_est >= 0.0 ? g_est : estimate_groups((double)d, (double)Sd));
     G = std::min(G, (double)n);
     log2_cap = std::max(12, ceil_log2_u64((uint64_t)(G * 2.0) + 1));
@@ -898,10 +953,12 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
       for (auto& a : c.aggs) if (a.second >= 0 && c.nodes[a.second].nullable) any_null = true;
       if (part_version() == 2) {
         PartPlan2 p2;
+        k::SrcRange ranges[kMaxSrc];
+        source_ranges(c, ranges);
         // heavy hitters mean a heavy tail: the sample undercounts the rare keys (zipf 1.1: by ~2x) and LDS tables at twice their planned
         // load probe long -- plan for twice the estimate when that still fits the 512-partition limit
-        const bool planned = (!hot.empty() && G < 1e17 && k::partition_plan2(sh, G * 2.6, -1, len_idx, n, (int)hot.size(), &p2)) ||
-                             k::partition_plan2(sh, G * 1.3, -1, len_idx, n, (int)hot.size(), &p2);
+        const bool planned = (!hot.empty() && G < 1e17 && k::partition_plan2(sh, G * 2.6, -1, len_idx, n, (int)hot.size(), &p2, ranges)) ||
+                             k::partition_plan2(sh, G * 1.3, -1, len_idx, n, (int)hot.size(), &p2, ranges);
         if (planned) {
           std::string pd;
           Buf ok, okv, oacc;

@@ -253,17 +253,40 @@ constexpr uint32_t kP2Hash = 0, kP2Direct = 1;
 constexpr uint32_t kP2ChunkRecs = 256;        // records per chunk: chunk bytes = 256 * rec_words * 4 (a multiple of the 128-B line)
 constexpr uint32_t kP2MaxHot = 256;           // hot keys pre-aggregated in the scatter pass
 constexpr uint32_t kNoChunk = 0xffffffffu;
+// Record packing (third generation scatter, partition3_device.hpp; 0 everywhere else):
+//   kPackNone    sources keep their column width
+//   kPackNarrow  every 64-bit INTEGER source that is a plain column load is stored as a u32 offset from a run-time base
+//                (PartPlan2::src_base: the column's cached minimum; the planner checks max - min < 2^32)
+//   kPackFused   direct mode, ONE integer source, no validity / row id: the whole record is one dword, key_low | (v - base) << key_shift
+//                (the planner checks key_shift + bits(max - min) <= 32)
+constexpr uint32_t kPackNone = 0, kPackNarrow = 1, kPackFused = 2;
 struct RecLayout2 {
   uint8_t key_words;             // 1 | 2 dwords
   uint8_t key_kind;              // 0: 64-bit, 1: i32 (sign-extended on read), 2: u32 (zero-extended)
+  uint8_t pack;                  // kPack*
   uint8_t n_src;
   uint8_t has_valid, valid_off;  // one dword: bit j = source j valid, bit 31 = key valid
   uint8_t has_rowid, rowid_off;  // two dwords
   uint8_t rec_words;
-  uint8_t src_kind[kMaxSrc], src_off[kMaxSrc];
+  uint8_t src_kind[kMaxSrc], src_off[kMaxSrc];   // kind 0: 64-bit, 1: i32, 2: u32, 3: u32 offset from PartPlan2::src_base[j] (packing)
   uint8_t src_slot[kMaxAggs];    // program slot of source j
   uint8_t agg_src[kMaxAggs];     // aggregate k reads source agg_src[k] (kNone: LEN / FIRST_ROW)
 };
+// the input column a slot is loaded from when its only writer is a LOAD, else -1
+PLX_FHD constexpr int slot_input(const Shape& sh, uint8_t slot) {
+  int writers = 0, input = -1;
+  for (int i = 0; i < sh.n_ops; i++) {
+    if (sh.ops[i].dst != slot) continue;
+    writers++;
+    input = sh.ops[i].code == OP_LOAD ? (int)sh.ops[i].a : -1;
+  }
+  return writers == 1 ? input : -1;
+}
+// a slot that holds a plain 64-bit INTEGER column (candidates for kPackNarrow / kPackFused)
+PLX_FHD constexpr bool slot_is_int64_column(const Shape& sh, uint8_t slot) {
+  const int in = slot_input(sh, slot);
+  return in >= 0 && (sh.in_dtype[in] == 4 || sh.in_dtype[in] == 8);     // PLX_I64, PLX_U64
+}
 // a slot whose only writer is the LOAD of a <= 32-bit integer column holds a sign- / zero-extended 32-bit value
 PLX_FHD constexpr uint8_t narrow_kind(const Shape& sh, uint8_t slot) {
   int writers = 0, input = -1;
@@ -279,8 +302,9 @@ PLX_FHD constexpr uint8_t narrow_kind(const Shape& sh, uint8_t slot) {
     default: return 0;
   }
 }
-PLX_FHD constexpr RecLayout2 rec_layout2(const Shape& sh, uint32_t mode) {
+PLX_FHD constexpr RecLayout2 rec_layout2(const Shape& sh, uint32_t mode, uint32_t pack = kPackNone) {
   RecLayout2 L{};
+  L.pack = (uint8_t)pack;
   for (int k = 0; k < kMaxAggs; k++) { L.agg_src[k] = kNone; L.src_slot[k] = 0; }
   for (int j = 0; j < kMaxSrc; j++) { L.src_kind[j] = 0; L.src_off[j] = 0; }
   uint32_t w = 0, n_src = 0;
@@ -299,9 +323,11 @@ PLX_FHD constexpr RecLayout2 rec_layout2(const Shape& sh, uint32_t mode) {
   L.n_src = (uint8_t)n_src;
   for (uint32_t j = 0; j < n_src && j < (uint32_t)kMaxSrc; j++) {
     L.src_kind[j] = narrow_kind(sh, L.src_slot[j]);
+    if (pack != kPackNone && slot_is_int64_column(sh, L.src_slot[j])) L.src_kind[j] = 3;
     L.src_off[j] = (uint8_t)w;
     w += L.src_kind[j] ? 1 : 2;
   }
+  if (pack == kPackFused) { w = 1; L.src_off[0] = 0; }      // planner-checked: direct mode, one integer source, no validity, no row id
   L.has_valid = shape_may_have_nulls(sh) ? 1 : 0;
   L.valid_off = (uint8_t)w; w += L.has_valid;
   L.rowid_off = (uint8_t)w; w += 2 * L.has_rowid;
@@ -323,7 +349,18 @@ struct PartPlan2 {
   uint32_t len_idx;            // the aggregate that counts rows (occupancy of a direct-address slot)
   uint32_t rec_words;          // == rec_layout2(shape, mode).rec_words
   uint32_t ablate;             // measurement only (PLX_PART_ABLATE, results are WRONG when set): 1 = flush without the HBM stores, 2 = append without the ring writes
+  uint32_t gen;                // scatter generation: 2 = rings + line flush (partition2_device.hpp), 3 = tile sort + carry lines (partition3_device.hpp)
+  uint32_t pack;               // kPack* (gen 3 only): == rec_layout2(shape, mode, pack).pack
+  int64_t src_base[kMaxSrc];   // packing: value a kind-3 source is stored relative to
 };
+// which packing a shape admits at all (the planner still has to check the value ranges): kPackFused / kPackNarrow / kPackNone
+PLX_FHD constexpr uint32_t best_static_pack(const Shape& sh, uint32_t mode) {
+  const RecLayout2 L = rec_layout2(sh, mode, kPackNarrow);
+  bool any = false;
+  for (uint32_t j = 0; j < L.n_src && j < (uint32_t)kMaxSrc; j++) any = any || L.src_kind[j] == 3;
+  if (mode == kP2Direct && L.n_src == 1 && L.src_kind[0] != 0 && !L.has_valid && !L.has_rowid) return kPackFused;
+  return any ? kPackNarrow : kPackNone;
+}
 
 // ---- batched result finalisation: every output column of a query in ONE launch ---------------
 constexpr int kMaxFinJobs = 24;

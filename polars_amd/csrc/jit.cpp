@@ -35,6 +35,8 @@ double g_ms = 0;
 const char* sink_type(Sink s) {
   static const char* n[] = {"RegAggSink", "LdsAggSink", "DenseAggSink", "HashAggSink", "WideAggSink", "JoinBuildSink", "ProbeAggSink", "DirectBuildSink", "DirectProbeAggSink", "BitmapBuildSink",
                             "part_count", "part_scatter", "part_agg", "part2_scatter_hash", "part2_scatter_direct", "part2_agg_hash", "part2_agg_direct", "part2_scatter_hash_t2", "part2_scatter_direct_t2"};
+  if (s >= PART3_AGG) return "part3_agg";
+  if (s >= PART3_SCATTER) return "part3_scatter";
   return n[s];
 }
 
@@ -68,7 +70,7 @@ std::vector<std::string> compile_options() {
 
 std::string source_for(const Shape& sh, Sink sink) {
   std::ostringstream o;
-  o << (sink >= PART2_SCATTER_HASH ? "#include \"partition2_device.hpp\"\n" : sink >= PART_COUNT ? "#include \"partition_device.hpp\"\n" : "#include \"fused_sinks.hpp\"\n") << "namespace plx { namespace k {\n"
+  o << (sink >= PART3_SCATTER ? "#include \"partition3_device.hpp\"\n" : sink >= PART2_SCATTER_HASH ? "#include \"partition2_device.hpp\"\n" : sink >= PART_COUNT ? "#include \"partition_device.hpp\"\n" : "#include \"fused_sinks.hpp\"\n") << "namespace plx { namespace k {\n"
        "struct JitProg {\n  static constexpr bool kStatic = true; static constexpr int kId = -2;\n  static constexpr Shape shape() {\n    Shape s{};\n";
   o << "    s.n_inputs = " << (int)sh.n_inputs << "; s.n_ops = " << (int)sh.n_ops << "; s.n_aggs = " << (int)sh.n_aggs << "; s.pred = " << (int)sh.pred
     << "; s.key = " << (int)sh.key << "; s.n_keys = " << (int)sh.n_keys << ";\n";
@@ -102,6 +104,19 @@ std::string source_for(const Shape& sh, Sink sink) {
            "  part2_agg_body<Shape, " << (sink == PART2_AGG_DIRECT ? 1 : 0) << ">(csh, cl, pp, ap);\n}\n}}\n";
       break;
     default:
+      if (sink >= PART3_AGG) {
+        const int v = (int)sink - (int)PART3_AGG, mode = v & 1, pack = v >> 1;
+        o << "extern \"C\" __global__ __launch_bounds__(kP2AggBlock) void plx_jit_kernel(PartPlan2 pp, AggParams2 ap) {\n"
+             "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout2 cl = rec_layout2(JitProg::shape(), " << mode << "u, " << pack << "u);\n"
+             "  part2_agg_body<Shape, " << mode << ">(csh, cl, pp, ap);\n}\n}}\n";
+        break;
+      }
+      if (sink >= PART3_SCATTER) {
+        const int v = (int)sink - (int)PART3_SCATTER, mode = v & 1, tiles = 1 << ((v >> 1) % 3), pack = (v / 6) % 3, hot = v / 18;
+        o << "extern \"C\" __global__ __launch_bounds__(kP2MaxBlock) void plx_jit_kernel(Shape dsh, Args args, PartPlan2 pp, ScatterParams2 sp) {\n"
+             "  part3_scatter_body<JitProg, " << mode << ", " << tiles << ", " << pack << ", " << (hot ? "true" : "false") << ">(dsh, args, pp, sp);\n}\n}}\n";
+        break;
+      }
       o << "extern \"C\" __global__ __launch_bounds__(kBlock) void plx_jit_kernel(Shape dsh, Args args, " << sink_type(sink)
         << "::Params sp) {\n  fused_scan_body<JitProg, " << sink_type(sink) << ">(dsh, args, sp);\n}\n}}\n";
       break;
@@ -136,7 +151,7 @@ std::string cache_dir() {
 std::string headers_fingerprint() {   // the device headers the generated source includes: a stale cache entry must never survive an upgrade
   static const std::string fp = [] {
     uint64_t h = 0xcbf29ce484222325ull;
-    for (const char* f : {"fused.hpp", "fused_device.hpp", "fused_sinks.hpp", "fused_shapes.hpp", "partition_device.hpp", "partition2_device.hpp", "dev.hpp", "kconfig.hpp"}) {
+    for (const char* f : {"fused.hpp", "fused_device.hpp", "fused_sinks.hpp", "fused_shapes.hpp", "partition_device.hpp", "partition2_device.hpp", "partition3_device.hpp", "dev.hpp", "kconfig.hpp"}) {
       if (FILE* fp2 = fopen((include_dir() + "/" + f).c_str(), "rb")) {
         char buf[65536]; size_t n;
         while ((n = fread(buf, 1, sizeof buf, fp2)) > 0) h = fnv1a(std::string(buf, n), h);

@@ -15,6 +15,8 @@ void join_indices(int how, const ColumnPtr& left_key, const ColumnPtr& right_key
 
 // HashPartitioner (polars-utils/src/hashing.rs:72-121): rows grouped by partition.
 void hash_partition(const ColumnPtr& key, int n_partitions, uint64_t seed, ColumnPtr& perm, int64_t* counts_out);
+// same, the per-partition row counts stay on the device ([n_partitions] u64): no host round trip (the exchange all-gathers them)
+void hash_partition_dev(const ColumnPtr& key, int n_partitions, uint64_t seed, ColumnPtr& perm, Buf& counts_dev);
 
 }  // namespace join
 }  // namespace plx

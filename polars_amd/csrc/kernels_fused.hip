@@ -74,6 +74,11 @@
 namespace plx {
 namespace k {
 
+// name of a fused scan in the HIP-event profile: AOT kernels carry their shape id ("fused_scan_ldsagg_static#3" = fused_scan_kernel<StatProg<3>, LdsAggSink>), so
+// a counter file collected on another instantiation is never read as this one's (bench.py pmc_traffic matches the full name)
+static std::string scope_name(const char* aot, const char* other, int static_id) { return static_id >= 0 ? std::string(aot) + "#" + std::to_string(static_id) : std::string(other); }
+
+
 using namespace dev;
 using namespace fused;
 
@@ -122,7 +127,7 @@ void fused_regagg(const Shape& sh, const Args& args, int static_id, uint64_t* ou
   unsigned long long* pp = partials->as<unsigned long long>();
   RegAggSink::Params sp{pp};
   {
-    ProfileScope ps(static_id >= 0 ? "fused_scan_regagg_static" : "fused_scan_regagg_generic", algo_bytes(sh, args), (uint64_t)args.n_rows);
+    ProfileScope ps(scope_name("fused_scan_regagg_static", "fused_scan_regagg_generic", static_id).c_str(), algo_bytes(sh, args), (uint64_t)args.n_rows);
     switch (static_id) {
       case SHAPE_CFG2: PLX_LAUNCH_SCAN(StatProg<SHAPE_CFG2>, RegAggSink, grid, 0, sh, args, sp); break;
       case SHAPE_CFG2_NULLX: PLX_LAUNCH_SCAN(StatProg<SHAPE_CFG2_NULLX>, RegAggSink, grid, 0, sh, args, sp); break;
@@ -160,7 +165,7 @@ void fused_lds_agg(const Shape& sh, const Args& args, int n_groups, int static_i
   if (use_partials) { partials = dev_alloc(sizeof(uint64_t) * (size_t)grid * cells); sp.partials = partials->as<unsigned long long>(); }
   else { init_agg_cells(out_dev, n_groups, sh); sp.global_acc = (unsigned long long*)out_dev; }
   {
-    ProfileScope ps(static_id >= 0 ? "fused_scan_ldsagg_static" : "fused_scan_ldsagg_generic", algo_bytes(sh, args), (uint64_t)args.n_rows);
+    ProfileScope ps(scope_name("fused_scan_ldsagg_static", "fused_scan_ldsagg_generic", static_id).c_str(), algo_bytes(sh, args), (uint64_t)args.n_rows);
     switch (static_id) {
       case SHAPE_Q1: PLX_LAUNCH_SCAN(StatProg<SHAPE_Q1>, LdsAggSink, grid, lds, sh, args, sp); break;
       default: if (!jit::launch(sh, args, jit::LDSAGG, &sp, grid, lds)) { const DynLaunch d = dyn_launch(sh, args, lds); PLX_LAUNCH_SCAN(DynProg, LdsAggSink, grid, d.lds, sh, d.args, sp); } break;
@@ -298,7 +303,7 @@ int64_t wide_compact(const WideTable& t, int n_keys, int n_aggs, int64_t out_str
 
 void fused_join_build(const Shape& sh, const Args& args, const JoinAggTable& t, int static_id) {
   if (args.n_rows == 0) return;
-  ProfileScope ps(static_id >= 0 ? "fused_scan_join_build_static" : "fused_scan_join_build", algo_bytes(sh, args), (uint64_t)args.n_rows);
+  ProfileScope ps(scope_name("fused_scan_join_build_static", "fused_scan_join_build", static_id).c_str(), algo_bytes(sh, args), (uint64_t)args.n_rows);
   const int grid = scan_grid(args.n_rows, 8);
   switch (static_id) {
     PLX_STATIC_JOIN_BUILD_CASES
@@ -309,7 +314,7 @@ void fused_join_build(const Shape& sh, const Args& args, const JoinAggTable& t, 
 }
 void fused_probe_agg(const Shape& sh, const Args& args, const JoinAggTable& t, int static_id) {
   if (args.n_rows == 0) return;
-  ProfileScope ps(static_id >= 0 ? "fused_scan_probe_agg_static" : "fused_scan_probe_agg", algo_bytes(sh, args), (uint64_t)args.n_rows);
+  ProfileScope ps(scope_name("fused_scan_probe_agg_static", "fused_scan_probe_agg", static_id).c_str(), algo_bytes(sh, args), (uint64_t)args.n_rows);
   const int grid = scan_grid(args.n_rows, 8);
   switch (static_id) {
     PLX_STATIC_PROBE_AGG_CASES
@@ -320,7 +325,7 @@ void fused_probe_agg(const Shape& sh, const Args& args, const JoinAggTable& t, i
 
 void fused_bitmap_build(const Shape& sh, const Args& args, const BitmapBuild& t, int static_id) {
   if (args.n_rows == 0) return;
-  ProfileScope ps(static_id >= 0 ? "fused_scan_bitmap_build_static" : "fused_scan_bitmap_build", algo_bytes(sh, args), (uint64_t)args.n_rows);
+  ProfileScope ps(scope_name("fused_scan_bitmap_build_static", "fused_scan_bitmap_build", static_id).c_str(), algo_bytes(sh, args), (uint64_t)args.n_rows);
   const int grid = scan_grid(args.n_rows, 8);
   switch (static_id) {
     PLX_STATIC_BITMAP_BUILD_CASES
@@ -330,7 +335,7 @@ void fused_bitmap_build(const Shape& sh, const Args& args, const BitmapBuild& t,
 }
 void fused_direct_build(const Shape& sh, const Args& args, const DirectJoinTable& t, int static_id) {
   if (args.n_rows == 0) return;
-  ProfileScope ps(static_id >= 0 ? "fused_scan_direct_build_static" : "fused_scan_direct_build", algo_bytes(sh, args), (uint64_t)args.n_rows);
+  ProfileScope ps(scope_name("fused_scan_direct_build_static", "fused_scan_direct_build", static_id).c_str(), algo_bytes(sh, args), (uint64_t)args.n_rows);
   const int grid = scan_grid(args.n_rows, 5, "PLX_BPC_DIRECT_BUILD");
   switch (static_id) {
     PLX_STATIC_DIRECT_BUILD_CASES
@@ -341,7 +346,7 @@ void fused_direct_build(const Shape& sh, const Args& args, const DirectJoinTable
 }
 void fused_direct_probe_agg(const Shape& sh, const Args& args, const DirectJoinTable& t, int static_id) {
   if (args.n_rows == 0) return;
-  ProfileScope ps(static_id >= 0 ? "fused_scan_direct_probe_agg_static" : "fused_scan_direct_probe_agg", algo_bytes(sh, args), (uint64_t)args.n_rows);
+  ProfileScope ps(scope_name("fused_scan_direct_probe_agg_static", "fused_scan_direct_probe_agg", static_id).c_str(), algo_bytes(sh, args), (uint64_t)args.n_rows);
   const int grid = scan_grid(args.n_rows, 8, "PLX_BPC_DIRECT_PROBE");
   switch (static_id) {
     PLX_STATIC_DIRECT_PROBE_CASES

@@ -63,7 +63,11 @@ int64_t partitioned_agg(const fused::Shape& sh, const fused::Args& args, const f
                         Buf* out_acc, std::string* desc);
 // second generation (partition2_device.hpp): packed_bits > 0 = the key is a dense packed id of that many bits (direct-address
 // LDS tables when they fit); hot_keys = heavy hitters pre-aggregated in the scatter pass (select_hot_keys on a sample table)
-bool partition_plan2(const fused::Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, fused::PartPlan2* out);
+// value range of a record source (rec_layout2(...).src_slot[j]) when it is a plain integer column with cached statistics: lets the third
+// generation scatter pack records (fused::kPackNarrow / kPackFused)
+struct SrcRange { bool known = false; int64_t mn = 0, mx = 0; };
+bool partition_plan2(const fused::Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, fused::PartPlan2* out,
+                     const SrcRange* src_ranges = nullptr /* [fused::kMaxSrc] */);
 // hot_rows: sample rows the returned keys account for
 void select_hot_keys(const fused::HashTable& t, int n_aggs, int len_idx, uint64_t threshold, std::vector<uint64_t>* out, uint64_t* hot_rows = nullptr);
 // key_range_out (may be null): [2] receives the exact signed min / max of the valid keys the scatter pass streamed (hash mode

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void partition_scatter_kernel(KeyCol kc, ui
   }
 }
 
-void hash_partition(const ColumnPtr& key, int n_partitions, uint64_t seed, ColumnPtr& perm, int64_t* counts_out) {
+void hash_partition_dev(const ColumnPtr& key, int n_partitions, uint64_t seed, ColumnPtr& perm, Buf& counts) {
   PLX_REQUIRE(n_partitions >= 1 && n_partitions <= 4096, PLX_ERR_INVALID, "hash_partition: 1..4096 partitions");
   // HashPartitioner::new seed mixing (hashing.rs:81-96)
   auto fold = [](uint64_t a, uint64_t b) { unsigned __int128 r = (unsigned __int128)a * b; return (uint64_t)r ^ (uint64_t)(r >> 64); };
@@ -251,9 +251,8 @@ void hash_partition(const ColumnPtr& key, int n_partitions, uint64_t seed, Colum
   const int64_t n = key->len;
   perm = std::make_shared<Column>();
   perm->dtype = PLX_U32; perm->len = n; perm->values = dev_alloc(values_bytes(PLX_U32, n)); perm->null_count = 0;
-  Buf counts = dev_alloc_zero(sizeof(uint64_t) * (size_t)n_partitions);
+  counts = dev_alloc_zero(sizeof(uint64_t) * (size_t)n_partitions);
   Buf cursors = dev_alloc(sizeof(uint64_t) * (size_t)(n_partitions + 1));
-  std::vector<uint64_t> h((size_t)n_partitions, 0);
   if (n) {
     ProfileScope ps("hash_partition", (uint64_t)n * (dtype_width(key->dtype) * 2 + 4), (uint64_t)n);
     const int grid = k::grid_for(n, kBlock * 8);
@@ -264,8 +263,14 @@ void hash_partition(const ColumnPtr& key, int n_partitions, uint64_t seed, Colum
     hipLaunchKernelGGL(partition_scatter_kernel, dim3(grid), dim3(kBlock), 0, stream(), key_col(key), s, (uint32_t)n_partitions, cursors->as<unsigned long long>(),
                        perm->values->as<uint32_t>());
     PLX_HIP(hipGetLastError());
-    d2h_sync(h.data(), counts->ptr, sizeof(uint64_t) * (size_t)n_partitions);
   }
+}
+
+void hash_partition(const ColumnPtr& key, int n_partitions, uint64_t seed, ColumnPtr& perm, int64_t* counts_out) {
+  Buf counts;
+  hash_partition_dev(key, n_partitions, seed, perm, counts);
+  std::vector<uint64_t> h((size_t)n_partitions, 0);
+  if (key->len) d2h_sync(h.data(), counts->ptr, sizeof(uint64_t) * (size_t)n_partitions);
   for (int p = 0; p < n_partitions; p++) counts_out[p] = (int64_t)h[p];
 }
 

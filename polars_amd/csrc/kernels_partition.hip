@@ -21,7 +21,7 @@
 // HBM traffic: (1) reads the key/predicate columns, (2) reads all inputs + writes the records, (3) reads the
 // records: ~3x the algorithmic bytes instead of a fraction of the atomic rate.
 #include "partition_device.hpp"
-#include "partition2_device.hpp"
+#include "partition3_device.hpp"
 #include <algorithm>
 #include <vector>
 #include "kernels.hpp"
@@ -190,7 +190,8 @@ static const int kEnvP2Direct = env_int("PLX_PART_DIRECT", 0, 1);        // 0: n
 static const int kEnvP2DirectLp = env_int("PLX_PART_DIRECT_LOG2_PARTS", 4, 9);   // direct mode: partitions when the id range allows (default 2^9)
 static const int kEnvP2Wgs = env_int("PLX_PART2_WGS_PER_CU", 1, 4);       // scatter workgroups per CU (they must fit the LDS together)
 static const int kEnvP2Ablate = env_int("PLX_PART_ABLATE", 0, 3);
-static const int kEnvP2Tiles = env_int("PLX_PART_TILES", 1, 2);           // tiles per wave and round (default: 2 when the rings absorb them)
+static const int kEnvP2Tiles = env_int("PLX_PART_TILES", 1, 4);           // tiles per wave and round (gen 2: default 2 when the rings absorb them; gen 3: 4 / 2 / 1 by LDS)
+static const int kEnvP2Gen = env_int("PLX_PART_GEN", 2, 3);               // scatter generation (default 3: tile sort + carry lines; 2: rings + line flush)
 
 static uint32_t floor_pow2(uint32_t x) { uint32_t p = 1; while (p * 2 <= x) p *= 2; return p; }
 static uint32_t ceil_log2(uint64_t x) { uint32_t b = 0; while ((1ull << b) < x) b++; return b; }
@@ -205,8 +206,45 @@ static void plan2_geometry(PartPlan2& pp, int64_t n_rows, uint32_t tiles) {
   pp.chunks_per_wg = (uint32_t)(rounds_per_wg * rows_per_round / kP2ChunkRecs + (1u << pp.log2_parts) + 2);
 }
 
-bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, PartPlan2* out) {
+static uint32_t bits_for(uint64_t span) { uint32_t b = 0; while (b < 64 && (span >> b)) b++; return b; }     // bits that hold 0..span
+
+// third generation: packing from the value ranges, tile size from the LDS budget.  false: this shape / geometry stays on generation 2
+static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange* ranges, size_t lds_total) {
+  const uint32_t NP = 1u << pp.log2_parts;
+  if (NP < 64) return false;                                                   // the scan wave owns NP / 64 partitions per lane
+  uint32_t pack = kPackNone;
+  const char* pe = getenv("PLX_PART_PACK");
+  const uint32_t pack_cap = pe ? (uint32_t)std::max(0, std::min(2, atoi(pe))) : 2u;
+  if (ranges && pack_cap > 0) {
+    const RecLayout2 Ln = rec_layout2(sh, pp.mode, kPackNarrow);
+    bool narrow_ok = false, all_ok = true;
+    for (uint32_t j = 0; j < Ln.n_src && j < (uint32_t)kMaxSrc; j++) {
+      if (Ln.src_kind[j] != 3) continue;
+      if (ranges[j].known && ranges[j].mx >= ranges[j].mn && (uint64_t)ranges[j].mx - (uint64_t)ranges[j].mn < 0xffffffffull) narrow_ok = true; else all_ok = false;
+    }
+    if (narrow_ok && all_ok) pack = kPackNarrow;
+    if (pack_cap >= 2 && best_static_pack(sh, pp.mode) == kPackFused && ranges[0].known && ranges[0].mx >= ranges[0].mn &&
+        pp.key_shift + bits_for((uint64_t)ranges[0].mx - (uint64_t)ranges[0].mn) <= 32) pack = kPackFused;
+  }
+  const RecLayout2 L = rec_layout2(sh, pp.mode, pack);
+  if (L.n_src > (uint32_t)kMaxSrc || L.rec_words > 13) return false;
+  for (int j = 0; j < kMaxSrc; j++) pp.src_base[j] = (pack != kPackNone && ranges && ranges[j].known && (L.src_kind[j] == 3 || pack == kPackFused)) ? ranges[j].mn : 0;
+  const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0;
+  uint32_t tiles = 0;
+  for (uint32_t t : {4u, 2u, 1u}) {
+    if (kEnvP2Tiles > 0 && t > (uint32_t)kEnvP2Tiles) continue;
+    if (part3_scatter_lds(kP2MaxBlock * kRows * t, L.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies) <= lds_total) { tiles = t; break; }
+  }
+  if (!tiles) return false;
+  pp.gen = 3; pp.pack = pack; pp.rec_words = L.rec_words; pp.block = kP2MaxBlock; pp.ring_lines = 0;
+  plan2_geometry(pp, n_rows, tiles);
+  // chunks are filled completely (the carry line keeps the remainder): whole chunks of the rows + one partial chunk per partition + slack
+  return true;
+}
+
+bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, PartPlan2* out, const SrcRange* src_ranges) {
   PartPlan2 pp{};
+  pp.gen = 2;
   if (sh.key == kNone || sh.n_keys) return false;
   const size_t lds_total = 160 * 1024 - 2048;      // leave room for the kernels' static shared variables
   pp.len_idx = (uint32_t)(len_idx < 0 ? 0 : len_idx);
@@ -250,7 +288,9 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
   pp.log2_hot_slots = pp.n_hot ? std::max<uint32_t>(3, ceil_log2((uint64_t)pp.n_hot * 2)) : 0;
   pp.hot_copies = 1;
   if (pp.n_hot) { uint32_t c = 16; while (c > 1 && (size_t)pp.n_hot * sh.n_aggs * 8 * c > 8 * 1024) c >>= 1; pp.hot_copies = c; }
-  // ---- rings: as many 128-B lines per partition as the LDS holds (power of two)
+  pp.ablate = kEnvP2Ablate > 0 ? (uint32_t)kEnvP2Ablate : 0u;
+  if (kEnvP2Gen != 2 && plan3(sh, pp, n_rows, src_ranges, lds_total)) { *out = pp; return true; }
+  // ---- generation 2.  rings: as many 128-B lines per partition as the LDS holds (power of two)
   const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0;
   const size_t fixed = part2_scatter_lds(NP, 0, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies);
   if (fixed + (size_t)NP * 256 > lds_total) return false;
@@ -370,6 +410,45 @@ __global__ __launch_bounds__(kBlock) void hot_emit_kernel(const unsigned long lo
 #define PLX_PART2_STATIC_SCATTER_CASES(MODE, TILES, ...)
 #endif
 
+// ---- third generation: the AOT instantiations of the benchmark shapes (anything else goes through the JIT) -------------------
+// config 3 (Int64 key, Int64 value): first run hash mode (key range unknown), then direct mode; records 16 / 12 B unpacked, 12 / 8 B with
+// the value narrowed to a u32 offset, 4 B with key_low and value fused into one dword.  config 5 (u32 dictionary codes, Float64 value): 12 B.
+#ifdef PLX_HAVE_Q3_SHAPES
+#define PLX_P3_COMBOS(X)                                                                                                              \
+  X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 2, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 2, kPackNarrow)                                      \
+  X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackFused) \
+  X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Hash, 2, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackNone)
+#else
+#define PLX_P3_COMBOS(X)
+#endif
+static bool part3_static_available(int static_id, uint32_t mode, uint32_t tiles, uint32_t pack) {
+#define X(ID, MODE, TILES, PACK) if (static_id == ID && mode == (uint32_t)MODE && tiles == (uint32_t)TILES && pack == (uint32_t)PACK) return true;
+  PLX_P3_COMBOS(X)
+#undef X
+  return false;
+}
+static void part3_static_scatter(int static_id, const Shape& sh, const Args& args, const PartPlan2& pp, const ScatterParams2& sp, size_t lds) {
+#define X(ID, MODE, TILES, PACK)                                                                                                       \
+  if (static_id == ID && pp.mode == (uint32_t)MODE && pp.tiles == (uint32_t)TILES && pp.pack == (uint32_t)PACK) {                        \
+    auto kern = part3_scatter_kernel<StatProg<ID>, (int)MODE, TILES, (int)PACK, false>;                                                        \
+    static bool attr_set = false;                                                                                                      \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); attr_set = true; } \
+    hipLaunchKernelGGL(kern, dim3(pp.scatter_grid), dim3(pp.block), lds, stream(), sh, args, pp, sp);                                   \
+    return;                                                                                                                            \
+  }
+  PLX_P3_COMBOS(X)
+#undef X
+}
+static void part3_static_agg(int static_id, const PartPlan2& pp, const AggParams2& ap, uint32_t NP, size_t lds) {
+#define X(ID, MODE, TILES, PACK)                                                                                                       \
+  if (static_id == ID && pp.mode == (uint32_t)MODE && pp.pack == (uint32_t)PACK) {                                                       \
+    hipLaunchKernelGGL((part2_agg_kernel<StatProg<ID>, (int)MODE, (int)PACK>), dim3(NP), dim3(kP2AggBlock), lds, stream(), pp, ap);     \
+    return;                                                                                                                            \
+  }
+  PLX_P3_COMBOS(X)
+#undef X
+}
+
 // Runs scatter -> chunk sort -> aggregate (+ hot groups).  Outputs (allocated here): dense keys / valid flags / cells.
 // Returns the number of groups, -1 if an LDS table overflowed or no specialised kernel is available (the caller falls back).
 int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& plan, int static_id, const std::vector<uint64_t>& hot_keys, Buf* out_keys, Buf* out_kvalid,
@@ -377,11 +456,20 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   PartPlan2 pp = plan;
   const uint32_t NP = 1u << pp.log2_parts;
   const bool direct = pp.mode == kP2Direct;
-  const bool is_static = static_id == SHAPE_GB_SUM_CNT_I64 || static_id == SHAPE_GB_SUM_MEAN_U32_F64;   // the cases of PLX_PART2_STATIC_CASES
-  const jit::Sink jk_scatter = pp.tiles == 2 ? (direct ? jit::PART2_SCATTER_DIRECT_T2 : jit::PART2_SCATTER_HASH_T2) : (direct ? jit::PART2_SCATTER_DIRECT : jit::PART2_SCATTER_HASH), jk_agg = direct ? jit::PART2_AGG_DIRECT : jit::PART2_AGG_HASH;
+  const bool gen3 = pp.gen == 3;
+  const bool is_static = gen3 ? (pp.n_hot == 0 && part3_static_available(static_id, pp.mode, pp.tiles, pp.pack))      // the AOT builds leave the hot-key path out
+                              : (static_id == SHAPE_GB_SUM_CNT_I64 || static_id == SHAPE_GB_SUM_MEAN_U32_F64);   // the cases of PLX_PART2_STATIC_CASES
+  const jit::Sink jk_scatter = gen3 ? jit::part3_scatter_sink(pp.mode, pp.tiles, pp.pack, pp.n_hot != 0)
+                                    : pp.tiles == 2 ? (direct ? jit::PART2_SCATTER_DIRECT_T2 : jit::PART2_SCATTER_HASH_T2) : (direct ? jit::PART2_SCATTER_DIRECT : jit::PART2_SCATTER_HASH);
+  const jit::Sink jk_agg = gen3 ? jit::part3_agg_sink(pp.mode, pp.pack) : (direct ? jit::PART2_AGG_DIRECT : jit::PART2_AGG_HASH);
   const bool use_jit = !is_static && jit::ensure(sh, jk_scatter, args.n_rows) && jit::ensure(sh, jk_agg, args.n_rows);
   if (!is_static && !use_jit) return -1;
-  PLX_REQUIRE(pp.tiles == 1 || pp.tiles == 2, PLX_ERR_INVALID, "partitioned_agg2: 1 or 2 tiles per round");
+  PLX_REQUIRE(pp.tiles == 1 || pp.tiles == 2 || (gen3 && pp.tiles == 4), PLX_ERR_INVALID, "partitioned_agg2: tiles per round");
+  // the kernels' names in the HIP-event profile carry the variant (mode, tiles, packing, record dwords): a counter file of another variant must never
+  // be read as this one's (bench.py pmc_traffic matches the full name)
+  const std::string sid = use_jit ? "jit" : "#" + std::to_string(static_id);
+  const std::string scatter_name = std::string(gen3 ? "part3_scatter[" : "part2_scatter[") + sid + (direct ? ",d,t" : ",h,t") + std::to_string(pp.tiles) + (gen3 ? ",p" + std::to_string(pp.pack) : "") + "]";
+  const std::string agg_name = "part_agg_lds[" + sid + (direct ? ",d,p" : ",h,p") + std::to_string(pp.pack) + "]";
   PLX_REQUIRE(pp.n_hot == hot_keys.size(), PLX_ERR_INVALID, "partitioned_agg2: plan / hot key list mismatch");
   const uint32_t chunk_dw = kP2ChunkRecs * pp.rec_words;
   const int64_t n_chunks = (int64_t)pp.scatter_grid * pp.chunks_per_wg;
@@ -422,11 +510,13 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
     PLX_HIP(hipStreamSynchronize(stream()));     // `init` is a stack object
     sp.key_minmax = minmax->as<long long>();
   }
-  const size_t slds = part2_scatter_lds(NP, pp.ring_lines, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies);
+  const size_t slds = gen3 ? part3_scatter_lds(pp.block * kRows * pp.tiles, pp.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies)
+                           : part2_scatter_lds(NP, pp.ring_lines, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies);
   {
     // pass traffic: inputs read once + every surviving row written as one record (upper bound: all rows)
-    ProfileScope ps("part2_scatter", scan_bytes(sh, args) + (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
-    if (use_jit) {
+    ProfileScope ps(scatter_name.c_str(), scan_bytes(sh, args) + (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
+    if (!use_jit && gen3) part3_static_scatter(static_id, sh, args, pp, sp, slds);
+    else if (use_jit) {
       Shape shc = sh; Args ac = args; PartPlan2 ppc = pp; ScatterParams2 spc = sp;
       void* ka[] = {&shc, &ac, &ppc, &spc};
       PLX_REQUIRE(jit::launch_raw(sh, jk_scatter, ka, (int)pp.scatter_grid, (int)pp.block, slds), PLX_ERR_HIP, "jit launch failed (part2_scatter)");
@@ -464,9 +554,10 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   ap.out_keys = (*out_keys)->as<unsigned long long>(); ap.out_kvalid = (*out_kvalid)->as<unsigned char>(); ap.out_acc = (*out_acc)->as<unsigned long long>();
   ap.max_groups = (uint32_t)std::min<uint64_t>(max_groups, 0xffffffffull);
   {
-    ProfileScope ps("part2_agg_lds", (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
+    ProfileScope ps(agg_name.c_str(), (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
     const size_t lds = n_slots * 8 * ((direct ? 0 : 1) + sh.n_aggs);
-    if (use_jit) {
+    if (!use_jit && gen3) part3_static_agg(static_id, pp, ap, NP, lds);
+    else if (use_jit) {
       PartPlan2 ppc = pp; AggParams2 apc = ap;
       void* ka[] = {&ppc, &apc};
       PLX_REQUIRE(jit::launch_raw(sh, jk_agg, ka, (int)NP, kP2AggBlock, lds), PLX_ERR_HIP, "jit launch failed (part2_agg)");
@@ -488,8 +579,9 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   PLX_REQUIRE(!res[4], PLX_ERR_INVALID, "group key outside the bounds declared for its column (plx_column_set_bounds)");
   if (res[2]) return -1;
   if (minmax) { long long mm[2]; d2h_sync(mm, minmax->ptr, 16); key_range_out[0] = mm[0]; key_range_out[1] = mm[1]; }
-  if (desc) *desc = std::string("partitioned(v2,") + (direct ? "direct" : "hash") + ",P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec_words * 4) + "B,ring=" + std::to_string(pp.ring_lines * 128) +
-                    "B,block=" + std::to_string(pp.block) + ",hot=" + std::to_string(pp.n_hot) + ")+" + (direct ? "lds_direct_table(slots=" : "lds_hash_table(slots=") + std::to_string(1u << pp.log2_slots) + ")";
+  if (desc) *desc = std::string(gen3 ? "partitioned(v3," : "partitioned(v2,") + (direct ? "direct" : "hash") + ",P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec_words * 4) +
+                    (gen3 ? "B,pack=" + std::to_string(pp.pack) + ",tile=" + std::to_string(pp.block * kRows * pp.tiles) : "B,ring=" + std::to_string(pp.ring_lines * 128) + "B") +
+                    ",block=" + std::to_string(pp.block) + ",hot=" + std::to_string(pp.n_hot) + ")+" + (direct ? "lds_direct_table(slots=" : "lds_hash_table(slots=") + std::to_string(1u << pp.log2_slots) + ")";
   return (int64_t)(((uint64_t)res[1] << 32) | res[0]);
 }
 

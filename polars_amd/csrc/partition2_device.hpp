@@ -84,8 +84,12 @@ __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, c
   for (int j = 0; j < kMaxSrc; j++) {
     if (j < (int)L.n_src) {
       const uint64_t v = rf.get(r, L.src_slot[j]);
-      rec[L.src_off[j]] = (uint32_t)v;
-      if (!L.src_kind[j]) rec[L.src_off[j] + 1] = (uint32_t)(v >> 32);
+      if (L.pack == kPackFused) rec[0] |= (uint32_t)(v - (uint64_t)pp.src_base[0]) << pp.key_shift;      // one dword: key_low | (v - base) << key_shift
+      else if (L.src_kind[j] == 3) rec[L.src_off[j]] = (uint32_t)(v - (uint64_t)pp.src_base[j]);
+      else {
+        rec[L.src_off[j]] = (uint32_t)v;
+        if (!L.src_kind[j]) rec[L.src_off[j] + 1] = (uint32_t)(v >> 32);
+      }
       if ((rf.getv(L.src_slot[j]) >> r) & 1) vbits |= 1u << j;
     }
   }
@@ -405,6 +409,7 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
     for (uint32_t u = 0; u < kPerLane; u++) {
       const uint32_t i = (uint32_t)lane + u * 64u;
       switch (RW) {
+        case 1: dst[u][0] = base[i]; break;
         case 2: load_rec2<2>(base + (size_t)i * 2, dst[u]); break;
         case 3: load_rec2<3>(base + (size_t)i * 3, dst[u]); break;
         case 4: load_rec2<4>(base + (size_t)i * 4, dst[u]); break;
@@ -430,7 +435,7 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
       slot[u] = 0; key[u] = 0; first[u] = 0;
       if (!live[u]) continue;
       const unsigned int* rec = cur[u];
-      if (direct) { slot[u] = rec[0]; continue; }
+      if (direct) { slot[u] = L.pack == kPackFused ? (rec[0] & ((1u << pp.key_shift) - 1u)) : rec[0]; continue; }
       const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
       if (L.key_words == 2) key[u] = (uint64_t)rec[0] | ((uint64_t)rec[1] << 32);
       else key[u] = L.key_kind == 1 ? (uint64_t)(long long)(int)rec[0] : (uint64_t)rec[0];
@@ -477,7 +482,9 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
         bool valid = true;
         if (sj != kNone) {
           const uint32_t lo = rec[L.src_off[sj]];
-          v = L.src_kind[sj] == 0 ? ((uint64_t)lo | ((uint64_t)rec[L.src_off[sj] + 1] << 32)) : (L.src_kind[sj] == 1 ? (uint64_t)(long long)(int)lo : (uint64_t)lo);
+          if (L.pack == kPackFused) v = (uint64_t)pp.src_base[0] + (uint64_t)(lo >> pp.key_shift);
+          else if (L.src_kind[sj] == 3) v = (uint64_t)pp.src_base[sj] + (uint64_t)lo;
+          else v = L.src_kind[sj] == 0 ? ((uint64_t)lo | ((uint64_t)rec[L.src_off[sj] + 1] << 32)) : (L.src_kind[sj] == 1 ? (uint64_t)(long long)(int)lo : (uint64_t)lo);
           valid = (vbits >> sj) & 1;
         }
         const uint64_t x = agg_row_value(kind, v, true, valid, rowid);
@@ -521,11 +528,11 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   }
 }
 
-template <class P, int MODE>
+template <class P, int MODE, int PACK = 0>
 __global__ __launch_bounds__(kP2AggBlock) void part2_agg_kernel(PartPlan2 pp, AggParams2 ap) {
   static_assert(P::kStatic, "the partitioned group-by runs specialised programs only (AOT or JIT)");
   constexpr Shape csh = P::shape();
-  constexpr RecLayout2 cl = rec_layout2(P::shape(), (uint32_t)MODE);
+  constexpr RecLayout2 cl = rec_layout2(P::shape(), (uint32_t)MODE, (uint32_t)PACK);
   part2_agg_body<Shape, MODE>(csh, cl, pp, ap);
 }
 

@@ -101,6 +101,33 @@ def main():
     np.savez(os.path.join(out_dir, f"q3_in_rank{rank}.npz"), **{"p_" + c: t.numpy() for c, t in probe.items()}, **{"b_" + c: t.numpy() for c, t in build.items()})
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), key=key.numpy(), flag=flag.numpy(), v=v.numpy(), x=x.numpy(),
              **{f"g_{k}": t.numpy() for k, t in g.items()}, **{f"s_{k}": t.numpy() for k, t in s.items()})
+    # (g) the frame-level sharded group-by (dist.sharded_groupby: what bench.py --gpus N --workload cfg3 runs): pre-aggregation before the
+    # exchange vs raw-row exchange vs the sample-driven choice, with NULL keys (one group, owned by rank 0) and null values; numpy doubles
+    # stand in for the library frames and the RCCL communicator (bench.DryFrame / DryComm / DryOps)
+    r3 = np.random.default_rng(4000 + rank)
+    m = 30_000 + 700 * rank
+    gk = r3.integers(0, 2500, m).astype(np.int64); gk_valid = r3.random(m) > 0.02
+    gv = r3.integers(-1000, 1000, m).astype(np.int64); gv_valid = r3.random(m) > 0.1
+    gv_valid[gk == 7] = False                                     # a group whose values are ALL null: sum 0, count 0, mean / min null
+    gx = r3.uniform(-1, 1, m)
+    shard = bench.DryFrame({"key": gk, "v": gv, "x": gx}, {"key": gk_valid, "v": gv_valid})
+    spec = pdist.GroupBySpec("key", [("v_sum", "v", "sum"), ("v_count", "v", "count"), ("v_mean", "v", "mean"), ("v_min", "v", "min"), ("x_max", "x", "max"), ("n", "", "len")])
+    comm, fops = bench.DryComm(), bench.DryOps()
+    save = {"in_key": gk, "in_key_valid": gk_valid, "in_v": gv, "in_v_valid": gv_valid, "in_x": gx}
+    for mode in ("preagg", "rows", "auto"):
+        comm.rows_sent = comm.bytes_sent = 0
+        info = {}
+        out = pdist.sharded_groupby(comm, shard, spec, fops, mode=mode, info=info)
+        for c, a in out.cols.items():
+            save[f"{mode}_{c}"] = a
+            save[f"{mode}_{c}__valid"] = out.validity(c)
+        save[f"{mode}_rows_sent"] = np.array([comm.rows_sent]); save[f"{mode}_mode"] = np.array([info["mode"]])
+    # a high-cardinality shard (every key distinct): the sample says the local aggregate shrinks nothing -> "auto" must exchange rows
+    uniq = bench.DryFrame({"key": (np.arange(5000, dtype=np.int64) * ws + rank), "v": np.ones(5000, np.int64), "x": np.zeros(5000)})
+    info = {}
+    pdist.sharded_groupby(comm, uniq, spec, fops, mode="auto", info=info)
+    save["auto_unique_mode"] = np.array([info["mode"]])
+    np.savez(os.path.join(out_dir, f"sgb_rank{rank}.npz"), **save)
     # (f) a scan shared by the ranks: every rank takes its run of row groups (io.split_by_rows through scan_shard()), decodes them --
     # here with pyarrow, the planning and the dictionary agreement are what is under test -- and the per-rank dictionaries of the
     # string column are unified (dist.unify_dictionaries; the device remap is replaced by its numpy twin)

@@ -69,6 +69,35 @@ def test_sharded_groupby_and_exchange(tmp_path, ws):
     assert np.array_equal(k[order], whole["k"].to_numpy())
     want = whole["s"].to_numpy()
     assert all((a is None and (b is None or b != b)) or a == b for a, b in zip(words.tolist(), want.tolist()))
+    # the frame-level sharded group-by: every mode gives the pandas answer on the concatenated shards (null key = one group, on rank 0;
+    # all-null groups: sum 0, count 0, mean / min null); pre-aggregation moves far fewer rows than the raw-row exchange
+    sg = [np.load(f) for f in sorted(glob.glob(str(tmp_path / "sgb_rank*.npz")))]
+    assert len(sg) == ws
+    kk = np.concatenate([s["in_key"] for s in sg]).astype(np.float64); kk[~np.concatenate([s["in_key_valid"] for s in sg])] = np.nan
+    vv = np.concatenate([s["in_v"] for s in sg]).astype(np.float64); vv[~np.concatenate([s["in_v_valid"] for s in sg])] = np.nan
+    whole_df = pd.DataFrame({"key": kk, "v": vv, "x": np.concatenate([s["in_x"] for s in sg])})
+    gb = whole_df.groupby("key", dropna=False)
+    want = pd.DataFrame({"v_sum": gb["v"].sum(), "v_count": gb["v"].count(), "v_mean": gb["v"].mean(), "v_min": gb["v"].min(), "x_max": gb["x"].max(), "n": gb.size()}).reset_index()
+    want = want.sort_values("key", na_position="last").reset_index(drop=True)
+    for mode in ("preagg", "rows", "auto"):
+        got_k = np.concatenate([s[f"{mode}_key"] for s in sg]).astype(np.float64)
+        got_kv = np.concatenate([s[f"{mode}_key__valid"] for s in sg])
+        assert sum(int((~s[f"{mode}_key__valid"]).sum()) for s in sg[1:]) == 0 and int((~sg[0][f"{mode}_key__valid"]).sum()) == 1, mode     # the null group lives on rank 0 only
+        got_k[~got_kv] = np.inf
+        order = np.argsort(got_k, kind="stable")
+        assert len(got_k) == len(want) and len(np.unique(got_k)) == len(got_k), mode                       # disjoint key sets
+        wk = want["key"].to_numpy().copy(); wk[np.isnan(wk)] = np.inf
+        assert np.array_equal(got_k[order], wk), mode
+        col = lambda c: np.concatenate([s[f"{mode}_{c}"] for s in sg])[order]
+        colv = lambda c: np.concatenate([s[f"{mode}_{c}__valid"] for s in sg])[order]
+        assert np.array_equal(col("v_sum"), want["v_sum"].to_numpy().astype(np.int64)) and np.array_equal(col("v_count"), want["v_count"].to_numpy()), mode
+        assert np.array_equal(col("n"), want["n"].to_numpy()) and np.array_equal(col("x_max"), want["x_max"].to_numpy()), mode
+        has = want["v_count"].to_numpy() > 0
+        assert np.array_equal(colv("v_mean"), has) and np.array_equal(colv("v_min"), has) and not has.all(), mode
+        assert np.allclose(col("v_mean")[has], want["v_mean"].to_numpy()[has], rtol=1e-12) and np.array_equal(col("v_min")[has], want["v_min"].to_numpy()[has].astype(np.int64)), mode
+    pre, raw = sum(int(s["preagg_rows_sent"][0]) for s in sg), sum(int(s["rows_rows_sent"][0]) for s in sg)
+    assert pre < raw / 5 and raw > 0.4 * len(whole_df) * (ws - 1) / ws                                     # ~2500 groups per rank instead of ~30000 rows
+    assert all(str(s["auto_mode"][0]) == "preagg" and str(s["auto_unique_mode"][0]) == "rows" for s in sg)   # the sample-driven choice, agreed across ranks
     files = sorted(glob.glob(str(tmp_path / "rank*.npz")))
     assert len(files) == ws
     parts = [np.load(f) for f in files]
@@ -158,3 +187,16 @@ def test_sharded_groupby_bench_dry_run_prints_a_complete_line():
         # about half of every shard's rows leave the rank; every row carries key + value
         assert 0.4 * rows < d["shuffle"]["rows_sent_per_rank_per_step"] < 0.6 * rows
         assert d["shuffle"]["bytes_sent_per_rank_per_step"] == d["shuffle"]["rows_sent_per_rank_per_step"] * (12 if wl == "cfg5" else 16)
+        assert d["exchange_mode"] == "rows" and d["shrink_estimate"] < 2          # 2e5 rows over 1e6 keys: the local group-by would shrink nothing
+        assert d["verified"]["ok"] is True and all(d["verified"]["checks"].values()) and "oracle" in d["verified"]["against"]
+    # few keys per rank (keys 0..1e6 but 2e6 rows would be slow here: force the mode instead): partial rows cross the fabric, not rows; strong scaling label
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29542",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg3", "--rows", str(rows), "--dry-run", "--mode", "preagg", "--scaling", "strong"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["exchange_mode"] == "preagg" and d["scaling"] == "strong" and d["verified"]["ok"] is True
+    local_groups = [len(np.unique(datagen.uniform_native_host("Int64", 0, rows, 10 + rank, 0, 0, 1_000_000))) for rank in range(2)]
+    assert d["partial_rows_per_rank"] in local_groups
+    assert 0.4 * min(local_groups) < d["shuffle"]["rows_sent_per_rank_per_step"] < 0.6 * max(local_groups)
+    assert d["shuffle"]["bytes_sent_per_rank_per_step"] == d["shuffle"]["rows_sent_per_rank_per_step"] * (8 + 8 + 4)     # key + i64 partial sum + u32 partial count

@@ -5,6 +5,8 @@ reference's execution shape), (c) the CPU oracle -- the reference's own engine-p
 frame-equal with check_row_order=False).  Integer results bit-exact, float aggregates 1e-6 rel."""
 import math
 
+import re
+
 import numpy as np
 import pytest
 
@@ -556,7 +558,7 @@ def test_partitioned_groupby_skewed_keys(pl, case):
     df = pl.DataFrame({"key": key, "v": v})
     out = df.lazy().group_by("key").agg(pl.col("v").sum().alias("s"), pl.col("v").count().alias("c")).collect()
     plan = pl.last_plan()
-    assert "partitioned(v2,hash" in plan and "hot=0" not in plan, plan      # hot keys were found and used
+    assert re.search(r"partitioned\(v[23],hash", plan) and "hot=0" not in plan, plan      # hot keys were found and used
     gk = out["key"].to_numpy(); order = np.argsort(gk)
     uk, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
     assert np.array_equal(gk[order], uk)
@@ -576,14 +578,14 @@ def test_partitioned_v2_is_planned_for_1e6_uniform_keys_whatever_the_sample_says
     df = pl.DataFrame([key, val])
     out = df.lazy().group_by("key").agg(pl.col("val").sum().alias("s"), pl.len().alias("n")).collect()
     plan = pl.last_plan()
-    assert "partitioned(v2,hash" in plan, plan
+    assert re.search(r"partitioned\(v[23],hash", plan), plan
     k = key.to_numpy(); v = val.to_numpy()
     gk = out["key"].to_numpy(); order = np.argsort(gk)
     assert np.array_equal(gk[order], np.unique(k))
     assert np.array_equal(out["s"].to_numpy()[order], np.bincount(k, weights=v, minlength=1_000_000)[np.unique(k)].astype(np.int64))
     # the scan also learned the key range: the second run plans dense ids
     df.lazy().group_by("key").agg(pl.col("val").sum().alias("s"), pl.len().alias("n")).collect()
-    assert "partitioned(v2,direct" in pl.last_plan(), pl.last_plan()
+    assert re.search(r"partitioned\(v[23],direct", pl.last_plan()), pl.last_plan()
 
 
 def test_partitioned_groupby_direct_mode_dense_ids(pl):
@@ -599,7 +601,7 @@ def test_partitioned_groupby_direct_mode_dense_ids(pl):
     df = pl.DataFrame([pl.Series("a", a), pl.Series("b", b, validity=bv), pl.Series("x", x, validity=xv)])
     q = df.lazy().group_by("a", "b").agg(pl.col("x").sum().alias("s"), pl.col("x").count().alias("c"), pl.col("x").max().alias("mx"), pl.len().alias("n"))
     out = q.collect(); plan = pl.last_plan()
-    assert "partitioned(v2,direct" in plan and "lds_direct_table" in plan, plan
+    assert re.search(r"partitioned\(v[23],direct", plan) and "lds_direct_table" in plan, plan
     ref = q.collect(no_partition=True)
     assert "hbm_table" in pl.last_plan() or "lds_table" in pl.last_plan(), pl.last_plan()
     d1, d2 = out.to_dict(), ref.to_dict()
@@ -627,7 +629,7 @@ def test_declared_bounds_are_checked_not_trusted_blindly(pl):
     v = rng.uniform(0, 100, n)
     ok = pl.DataFrame([pl.Series("k", codes, dtype=pl.Categorical(["c%d" % i for i in range(500_000)], pl.UInt32)), pl.Series("v", v)])
     out = queries.cfg5(ok.lazy()).collect(); plan = pl.last_plan()
-    assert "partitioned(v2,direct" in plan, plan
+    assert re.search(r"partitioned\(v[23],direct", plan), plan
     k1 = out["k"].to_numpy(); o1 = np.argsort(k1)
     s = np.bincount(codes, v); cnt = np.bincount(codes); present = np.nonzero(cnt)[0]
     assert np.array_equal(k1[o1], present) and close(out["v_sum"].to_numpy()[o1], s[present]) and close(out["v_mean"].to_numpy()[o1], s[present] / cnt[present])

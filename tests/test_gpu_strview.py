@@ -3,6 +3,8 @@ crates/polars-compute/src/binview_index_map.rs): the library encodes the 16-byte
 Checked against the oracle's restatement of the view index map (codes up to renaming: first-claim order on the device is not
 first-appearance order), on inline strings, long strings (prefix + data buffer), shared prefixes / lengths, empty strings, nulls,
 chunk offsets; the reference's string-key group_by vectors run through it; group-bys on the encoded column use dense tables."""
+import re
+
 import numpy as np
 import pyarrow as pa
 import pytest
@@ -79,7 +81,7 @@ def test_config5_from_raw_strings(pl):
     assert len(k) == n and len(k.dtype.categories) <= n_keys
     v = datagen.uniform_native(pl, "v", pl.Float64, n, seed, 1, 0, 10 ** 9, 1e-7)
     out = queries.cfg5(pl.DataFrame([k, v]).lazy()).collect()
-    assert "partitioned(v2,direct" in pl.last_plan(), pl.last_plan()
+    assert re.search(r"partitioned\(v[23],direct", pl.last_plan()), pl.last_plan()
     ids = datagen.uniform_native_host("Int64", 0, n, seed, 0, 1, n_keys + 1)
     vals = datagen.uniform_native_host("Float64", 0, n, seed, 1, 0, 10 ** 9, 1e-7)
     s, c = np.bincount(ids, weights=vals, minlength=n_keys + 1), np.bincount(ids, minlength=n_keys + 1)

@@ -40,15 +40,18 @@ template <> struct RecT<4> { using T = uint32_t; };
 template <> struct RecT<8> { using T = uint2; };
 struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
 template <> struct RecT<12> { using T = U3; };
+template <> struct RecT<16> { using T = uint4; };
 template <int REC> __device__ __forceinline__ typename RecT<REC>::T make_rec(uint32_t klow, uint64_t v) {
   if constexpr (REC == 4) return klow | ((uint32_t)v << 12);
   else if constexpr (REC == 8) return make_uint2(klow, (uint32_t)v);
-  else { U3 r; r.a = klow; r.b = (uint32_t)v; r.c = (uint32_t)(v >> 32); return r; }
+  else if constexpr (REC == 12) { U3 r; r.a = klow; r.b = (uint32_t)v; r.c = (uint32_t)(v >> 32); return r; }
+  else return make_uint4(klow, (uint32_t)v, (uint32_t)(v >> 32), 0u);
 }
 template <int REC> __device__ __forceinline__ void split_rec(const typename RecT<REC>::T& r, uint32_t& klow, uint64_t& v) {
   if constexpr (REC == 4) { klow = r & 4095u; v = r >> 12; }
   else if constexpr (REC == 8) { klow = r.x; v = r.y; }
-  else { klow = r.a; v = (uint64_t)r.b | ((uint64_t)r.c << 32); }
+  else if constexpr (REC == 12) { klow = r.a; v = (uint64_t)r.b | ((uint64_t)r.c << 32); }
+  else { klow = r.x; v = (uint64_t)r.y | ((uint64_t)r.z << 32); }
 }
 
 // LDS: sorted[T] records | cnt[NP] | off[NP + 1] | gdst_chunk[NP] | gdst_fill[NP] | cur_chunk[NP] | cur_fill[NP] | misc[4]
@@ -152,6 +155,142 @@ __global__ __launch_bounds__(BLOCK) void scatter3(const int64_t* __restrict__ ke
   for (int p = tid; p < (int)kNP; p += BLOCK) if (cur_chunk[p] != kNoChunk) chunk_fill[cur_chunk[p]] = cur_fill[p];
 }
 
+// ---- variant C: tile sort + per-partition CARRY line in LDS: only whole, aligned 128-B lines are ever written ------------------------
+// A partition's output is a dword stream; the dwords that do not fill a line yet wait in the partition's carry line (LDS) for the next
+// round.  The scan wave turns (carry + run) into a number of lines and their destination (rest of the current chunk, then fresh
+// chunks, consecutive); a 16-lane group per partition writes them (8 B per lane = one line per group per store) and leaves the new carry.
+// LDS: sorted[T] | carry[NP][32] dwords | cnt | off[NP+1] | carry_dw | dstA | lines_left | dstB | cur_chunk | cur_lines | misc
+template <int REC, int R, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void scatter3c(const int64_t* __restrict__ keys, const int64_t* __restrict__ vals, int64_t n, uint32_t* __restrict__ recs,
+                                                   uint32_t* __restrict__ chunk_part, uint32_t* __restrict__ chunk_fill, uint32_t chunks_per_wg, uint32_t* __restrict__ flags, int ablate) {
+  using Rec = typename RecT<REC>::T;
+  constexpr int T = BLOCK * R;
+  constexpr uint32_t RW = REC / 4, chunk_dw = kChunk * RW, cap_lines = chunk_dw / 32;
+  extern __shared__ unsigned long long lds_raw[];
+  uint32_t* sorted_dw = reinterpret_cast<uint32_t*>(lds_raw);
+  Rec* sorted = reinterpret_cast<Rec*>(lds_raw);
+  uint32_t* carry = sorted_dw + (size_t)T * RW;
+  uint32_t* cnt = carry + kNP * 32;
+  uint32_t* off = cnt + kNP;
+  uint32_t* carry_dw = off + kNP + 1;
+  uint32_t* dstA = carry_dw + kNP;        // first destination, in lines (chunk * cap_lines + line)
+  uint32_t* lines_left = dstA + kNP;      // lines that still fit there
+  uint32_t* dstB = lines_left + kNP;      // then here (fresh consecutive chunks), in lines
+  uint32_t* cur_chunk = dstB + kNP;
+  uint32_t* cur_lines = cur_chunk + kNP;
+  uint32_t* misc = cur_lines + kNP;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < (int)kNP; i += BLOCK) { cnt[i] = 0; carry_dw[i] = 0; cur_chunk[i] = kNoChunk; cur_lines[i] = cap_lines; }
+  if (tid == 0) misc[0] = 0;
+  __syncthreads();
+  const uint32_t chunk0 = blockIdx.x * chunks_per_wg;
+  const int64_t nrounds = (n + T - 1) / T;
+  longlong2 kq[R / 2], vq[R / 2], kn[R / 2], vn[R / 2];
+  auto load = [&](int64_t rd, longlong2* k, longlong2* v) __attribute__((always_inline)) {
+    const int64_t base = rd * T;
+#pragma unroll
+    for (int j = 0; j < R / 2; j++) {
+      const int64_t row = base + ((int64_t)j * BLOCK + tid) * 2;
+      if (row + 1 < n) { k[j] = *reinterpret_cast<const longlong2*>(keys + row); v[j] = *reinterpret_cast<const longlong2*>(vals + row); }
+      else { k[j].x = row < n ? keys[row] : -1; k[j].y = -1; v[j].x = row < n ? vals[row] : 0; v[j].y = 0; }
+    }
+  };
+  // opens `need` fresh consecutive chunks for partition p; returns the first (or kNoChunk on overflow)
+  auto open_chunks = [&](uint32_t p, uint32_t need) -> uint32_t {
+    const uint32_t local = atomicAdd(&misc[0], need);
+    if (local + need > chunks_per_wg) { flags[0] = 1; return chunk0; }
+    for (uint32_t e = 0; e < need; e++) chunk_part[chunk0 + local + e] = p;
+    return chunk0 + local;
+  };
+  int64_t rd = blockIdx.x;
+  if (rd < nrounds) load(rd, kn, vn);
+  for (; rd < nrounds; rd += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < R / 2; j++) { kq[j] = kn[j]; vq[j] = vn[j]; }
+    if (rd + gridDim.x < nrounds) load(rd + gridDim.x, kn, vn);
+    uint32_t part[R], rank[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      const int64_t key = (j & 1) ? kq[j / 2].y : kq[j / 2].x;
+      part[j] = key < 0 ? kNP : (uint32_t)((uint64_t)key >> kShift);
+      rank[j] = part[j] < kNP ? atomicAdd(&cnt[part[j]], 1u) : 0u;
+    }
+    __syncthreads();                                                                  // A: counts complete
+    if (tid < 64) {
+      uint32_t c[4], s = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { c[q] = cnt[lane * 4 + q]; s += c[q]; }
+      uint32_t incl = s;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+      uint32_t o = incl - s;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t p = lane * 4 + q;
+        off[p] = o; o += c[q];
+        cnt[p] = 0;
+        const uint32_t nl = (carry_dw[p] + c[q] * RW) >> 5;
+        if (nl) {
+          uint32_t ch = cur_chunk[p], ln = cur_lines[p];
+          const uint32_t left = cap_lines - ln;
+          dstA[p] = ch * cap_lines + ln; lines_left[p] = left;           // (left == 0 when no chunk is open: ln == cap_lines)
+          if (nl > left) {
+            const uint32_t extra = nl - left, need = (extra + cap_lines - 1) / cap_lines;
+            if (ch != kNoChunk) chunk_fill[ch] = kChunk;
+            const uint32_t first = open_chunks(p, need);
+            for (uint32_t e = 0; e + 1 < need; e++) chunk_fill[first + e] = kChunk;
+            dstB[p] = first * cap_lines;
+            ch = first + need - 1; ln = extra - (need - 1) * cap_lines;
+          } else ln += nl;
+          cur_chunk[p] = ch; cur_lines[p] = ln;
+        }
+      }
+      if (lane == 63) off[kNP] = o;
+    }
+    __syncthreads();                                                                  // B: offsets and destinations known
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      if (part[j] >= kNP) continue;
+      const int64_t key = (j & 1) ? kq[j / 2].y : kq[j / 2].x;
+      const int64_t val = (j & 1) ? vq[j / 2].y : vq[j / 2].x;
+      if (!(ablate & 2)) sorted[off[part[j]] + rank[j]] = make_rec<REC>((uint32_t)key & ((1u << kShift) - 1u), (uint64_t)val);
+    }
+    __syncthreads();                                                                  // C: tile sorted
+    {
+      const int g = tid >> 4, l16 = tid & 15;
+      for (uint32_t p = g; p < kNP; p += BLOCK / 16) {
+        const uint32_t o_dw = off[p] * RW, r_dw = (off[p + 1] - off[p]) * RW, c_dw = carry_dw[p];
+        const uint32_t total = c_dw + r_dw, nl = total >> 5, rem = total & 31u;
+        const uint32_t* cy = carry + p * 32;
+        const uint32_t a = dstA[p], left = lines_left[p], b = dstB[p];
+        for (uint32_t i = 0; i < nl; i++) {
+          const uint32_t d = i * 32 + l16 * 2;
+          uint2 w;
+          w.x = d < c_dw ? cy[d] : sorted_dw[o_dw + d - c_dw];
+          w.y = d + 1 < c_dw ? cy[d + 1] : sorted_dw[o_dw + d + 1 - c_dw];
+          const uint64_t line = i < left ? (uint64_t)a + i : (uint64_t)b + (i - left);
+          if (!(ablate & 1)) *reinterpret_cast<uint2*>(recs + line * 32 + l16 * 2) = w;
+        }
+        // the new carry: dwords [nl * 32, total) of the stream
+        if (nl == 0) { for (uint32_t i = l16; i < r_dw; i += 16) carry[p * 32 + c_dw + i] = sorted_dw[o_dw + i]; }
+        else { for (uint32_t i = l16; i < rem; i += 16) carry[p * 32 + i] = sorted_dw[o_dw + nl * 32 + i - c_dw]; }
+        if (l16 == 0) carry_dw[p] = rem;
+      }
+    }
+  }
+  __syncthreads();
+  // tails: the carry dwords go behind the lines written so far; the last chunk's fill in records
+  for (int p = tid; p < (int)kNP; p += BLOCK) {
+    uint32_t ch = cur_chunk[p], ln = cur_lines[p];
+    const uint32_t rem = carry_dw[p];
+    if (rem) {
+      if (ln == cap_lines) { if (ch != kNoChunk) chunk_fill[ch] = kChunk; ch = open_chunks(p, 1); ln = 0; }
+      for (uint32_t i = 0; i < rem; i++) recs[((uint64_t)ch * cap_lines + ln) * 32 + i] = carry[p * 32 + i];
+    }
+    if (ch != kNoChunk) chunk_fill[ch] = (ln * 32 + rem) / RW;
+  }
+}
+
 // chunk lists per partition: one workgroup, counting sort of the chunk -> partition map (micro-benchmark plumbing)
 __global__ __launch_bounds__(1024) void chunk_lists(const uint32_t* chunk_part, uint32_t n_chunks, uint32_t* cl_off /* [NP + 1] */, uint32_t* cl_ids) {
   __shared__ uint32_t cnt[kNP + 1], cur[kNP];
@@ -212,41 +351,48 @@ struct Ctx {
   uint32_t max_chunks;
 };
 
-template <int REC, int R, int BLOCK>
+template <int REC, int R, int BLOCK, bool CARRY = false>
 static void run_variant(Ctx& c, int wg_per_cu, int ablate = 0) {
   using Rec = typename RecT<REC>::T;
   constexpr int T = BLOCK * R;
   const int grid = 256 * wg_per_cu;
-  const size_t lds = (size_t)T * REC + (size_t)(kNP * 6 + 1 + 4) * 4;
+  const size_t lds = CARRY ? (size_t)T * REC + (size_t)kNP * 128 + (size_t)(kNP * 8 + 1 + 4) * 4 : (size_t)T * REC + (size_t)(kNP * 6 + 1 + 4) * 4;
   const uint32_t chunks_per_wg = (uint32_t)((c.n / grid + kChunk - 1) / kChunk * 102 / 100 + kNP + 8);
   const uint32_t n_chunks = chunks_per_wg * grid;
   if (n_chunks > c.max_chunks) { printf("REC=%d: chunk table too small\n", REC); return; }
   auto kern = scatter3<REC, R, BLOCK>;
-  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto kern_c = scatter3c<REC, R, BLOCK>;
+  if (CARRY) CK(hipFuncSetAttribute((const void*)kern_c, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  else CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   auto scatter = [&] {
     hipMemsetAsync(c.chunk_part, 0xff, (size_t)n_chunks * 4, 0);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, 0, c.keys, c.vals, c.n, (Rec*)c.recs, c.chunk_part, c.chunk_fill, chunks_per_wg, c.flags, ablate);
+    if (CARRY) hipLaunchKernelGGL(kern_c, dim3(grid), dim3(BLOCK), lds, 0, c.keys, c.vals, c.n, (uint32_t*)c.recs, c.chunk_part, c.chunk_fill, chunks_per_wg, c.flags, ablate);
+    else hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, 0, c.keys, c.vals, c.n, (Rec*)c.recs, c.chunk_part, c.chunk_fill, chunks_per_wg, c.flags, ablate);
   };
+  printf("[%s REC=%d R=%d BLOCK=%d] scatter...\n", CARRY ? "carry" : "direct", REC, R, BLOCK);
   const float t_sc = time_ms(scatter);
+  printf("  lists...\n");
   auto lists = [&] { hipLaunchKernelGGL(chunk_lists, dim3(1), dim3(1024), 0, 0, c.chunk_part, n_chunks, c.cl_off, c.cl_ids); };
   const float t_ls = time_ms(lists, 2);
   auto agg = [&] { hipLaunchKernelGGL(agg3<REC>, dim3(kNP), dim3(1024), 0, 0, (const Rec*)c.recs, c.chunk_fill, c.cl_off, c.cl_ids, c.out_sum, c.out_cnt); };
+  printf("  agg...\n");
   const float t_ag = time_ms(agg);
   CK(hipMemset(c.bad, 0, 4));
   hipLaunchKernelGGL(compare, dim3(256), dim3(256), 0, 0, c.ref_sum, c.out_sum, c.ref_cnt, c.out_cnt, 1 << 20, c.bad);
   unsigned int bad = 0, flag = 0; CK(hipMemcpy(&bad, c.bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&flag, c.flags, 4, hipMemcpyDeviceToHost));
   const double gb_sc = (double)c.n * (16 + REC) / 1e9, gb_ag = (double)c.n * REC / 1e9;
-  printf("REC=%2d R=%d BLOCK=%4d wg/cu=%d ablate=%d lds=%6zu: scatter %7.3f ms (%6.0f GB/s)  lists %5.3f ms  agg %6.3f ms (%6.0f GB/s)  total %7.3f ms  mismatches=%u overflow=%u\n", REC, R, BLOCK,
+  printf("%s REC=%2d R=%d BLOCK=%4d wg/cu=%d ablate=%d lds=%6zu: scatter %7.3f ms (%6.0f GB/s)  lists %5.3f ms  agg %6.3f ms (%6.0f GB/s)  total %7.3f ms  mismatches=%u overflow=%u\n", CARRY ? "carry " : "direct", REC, R, BLOCK,
          wg_per_cu, ablate, lds, t_sc, gb_sc / t_sc * 1e3, t_ls, t_ag, gb_ag / t_ag * 1e3, t_sc + t_ls + t_ag, ablate ? 0u : bad, flag);
   fflush(stdout);
 }
 
 int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
   Ctx c{};
   c.n = argc > 1 ? (int64_t)atof(argv[1]) : 1000000000ll;
   CK(hipMalloc(&c.keys, c.n * 8)); CK(hipMalloc(&c.vals, c.n * 8));
   c.max_chunks = (uint32_t)(c.n / kChunk * 11 / 10 + 1024 * (kNP + 16));
-  CK(hipMalloc(&c.recs, (size_t)c.max_chunks * kChunk * 12));
+  CK(hipMalloc(&c.recs, (size_t)c.max_chunks * kChunk * 16));
   CK(hipMalloc(&c.chunk_part, (size_t)c.max_chunks * 4)); CK(hipMalloc(&c.chunk_fill, (size_t)c.max_chunks * 4)); CK(hipMalloc(&c.cl_ids, (size_t)c.max_chunks * 4));
   CK(hipMalloc(&c.cl_off, (kNP + 1) * 4)); CK(hipMalloc(&c.flags, 16)); CK(hipMalloc(&c.bad, 4)); CK(hipMemset(c.flags, 0, 16));
   CK(hipMalloc(&c.ref_sum, 8 << 20)); CK(hipMalloc(&c.out_sum, 8 << 20)); CK(hipMalloc(&c.ref_cnt, 4 << 20)); CK(hipMalloc(&c.out_cnt, 4 << 20));
@@ -256,17 +402,16 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   printf("rows %lld\n", (long long)c.n);
   run_variant<8, 8, 1024>(c, 1);
-  run_variant<8, 8, 1024>(c, 1, 1);
-  run_variant<8, 8, 1024>(c, 1, 3);
-  run_variant<8, 4, 1024>(c, 1);
-  run_variant<8, 8, 512>(c, 2);
-  run_variant<8, 8, 512>(c, 3);
-  run_variant<8, 16, 512>(c, 2);
-  run_variant<8, 8, 256>(c, 4);
-  run_variant<4, 8, 1024>(c, 1);
-  run_variant<4, 8, 512>(c, 2);
-  run_variant<4, 16, 512>(c, 2);
-  run_variant<12, 8, 1024>(c, 1);
-  run_variant<12, 8, 512>(c, 2);
+  run_variant<8, 8, 1024, true>(c, 1);
+  run_variant<8, 8, 1024, true>(c, 1, 1);
+  run_variant<8, 8, 1024, true>(c, 1, 3);
+  run_variant<8, 4, 1024, true>(c, 1);
+  run_variant<8, 8, 512, true>(c, 2);
+  run_variant<8, 16, 512, true>(c, 2);
+  run_variant<4, 8, 1024, true>(c, 1);
+  run_variant<4, 16, 512, true>(c, 2);
+  run_variant<12, 8, 1024, true>(c, 1);
+  run_variant<12, 4, 1024, true>(c, 1);
+  run_variant<16, 8, 1024, true>(c, 1);
   return 0;
 }

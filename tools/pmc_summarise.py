@@ -25,9 +25,23 @@ SCOPES = [  # (regex on the demangled kernel name, ProfileScope name in bench.py
 
 
 def scope_of(kernel: str):
+    """The name the library's HIP-event profile gives a launch of this kernel SYMBOL: AOT instantiations carry their template
+    arguments (kernels_fused.hip scope_name, kernels_partition.hip partitioned_agg2), so bench.py only ever pairs a counter figure
+    with the very instantiation it timed."""
+    m = re.search(r"fused_scan_kernel<.*StatProg<(\d+)>", kernel)
+    sid = m.group(1) if m else None
+    m = re.search(r"part3_scatter_kernel<.*StatProg<(\d+)>\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*>", kernel)
+    if m:
+        return f"part3_scatter[#{m.group(1)},{'d' if m.group(2) == '1' else 'h'},t{m.group(3)},p{m.group(4)}]"
+    m = re.search(r"part2_scatter_kernel<.*StatProg<(\d+)>\s*,\s*(\d+)\s*,\s*(\d+)\s*>", kernel)
+    if m:
+        return f"part2_scatter[#{m.group(1)},{'d' if m.group(2) == '1' else 'h'},t{m.group(3)}]"
+    m = re.search(r"part2_agg_kernel<.*StatProg<(\d+)>\s*,\s*(\d+)\s*,\s*(\d+)\s*>", kernel)
+    if m:
+        return f"part_agg_lds[#{m.group(1)},{'d' if m.group(2) == '1' else 'h'},p{m.group(3)}]"
     for rx, name in SCOPES:
         if re.search(rx, kernel):
-            return name
+            return f"{name}#{sid}" if sid is not None and name.endswith("_static") else name
     return None
 
 
@@ -66,7 +80,7 @@ def main():
         f, w = e["fetch_KB"] / n, e["write_KB"] / n
         res[sc] = {"fetch_KB": round(f, 1), "write_KB": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024), "launches_seen": e["launches"], "kernel_names": e["kernel_names"]}
     cal = res.get("datagen_uniform_i64")
-    doc = {"workload": wl,
+    doc = {"workload": wl, "keyed_by": "kernel symbol",
            "command": f"rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) --kernel-trace -- python bench.py --workload {wl} --steps 3 --warmup 1 --no-extras --no-cpu  (tools/pmc_all.sh)",
            "correction": "gfx950: FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies 128-B requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported, calibrated on datagen_uniform_i64 "
                          "(the library's generator writes exactly 8 B per row): see `calibration`",
