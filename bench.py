@@ -585,6 +585,41 @@ def timed(pl, wl: Workload, steps: int, warmup: int, distributed: bool, combine=
     return dt, stats, res, cold_ms
 
 
+def step_spread(step_ms, rows_per_step: int) -> dict:
+    """BASELINE.md 2.3 reports min / median / max of the timed steps; `value` / `ms_per_step` stay the K-step mean the driver's contract
+    defines (total rows / the bracketed wall time), the median-based rate is given beside them."""
+    if not step_ms:
+        return {}
+    v = sorted(step_ms)
+    med = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+    return {"ms_per_step_min": v[0], "ms_per_step_median": round(med, 4), "ms_per_step_max": v[-1], "value_median_based": round(rows_per_step / (med * 1e-3), 1) if med > 0 else None}
+
+
+def end_to_end_q1(pl, n: int, reps: int = 3) -> dict:
+    """TPC-H Q1 END TO END from host memory (BASELINE.md 2.3 "also report end-to-end with H2D/D2H"): the seven lineitem columns start as numpy
+    arrays in pageable host memory, a step = hand them to the boundary (plx_column_from_host: page-locked in place, one DMA per column), run the
+    query, download the result.  PCIe-inclusive, so it is never `value`; n rows of the same generator as the headline."""
+    import numpy as np
+    from polars_amd import datagen, queries
+    host = {c: np.ascontiguousarray(a) for c, a in datagen.lineitem_native_host_mt(0, n, 10).items()}
+    nbytes = sum(a.nbytes for a in host.values())
+    times, up_times, res = [], [], None
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        df = datagen.to_frame(pl, host, datagen.LINEITEM_Q1_COLS)
+        t1 = time.perf_counter()
+        res = queries.q1(df.lazy()).collect().to_dict()
+        times.append(time.perf_counter() - t0); up_times.append(t1 - t0)
+        del df
+    times, up_times = sorted(times[1:]), sorted(up_times[1:])           # the first pass page-locks the host arrays for the first time
+    med, up = times[len(times) // 2], up_times[len(up_times) // 2]
+    want = q1_oracle_blocks(n, 10, 30.0, block=n)[0] if n <= 100_000_000 else None
+    ver = dict(compare_q1(res, want), rows=n, rtol=VERIFY_RTOL) if want is not None else None
+    return {"rows": n, "host_bytes": nbytes, "ms_per_step_median": round(med * 1e3, 3), "upload_ms_median": round(up * 1e3, 3), "rows_per_s": round(n / med, 1),
+            "pcie_inclusive_GBps": round(nbytes / med / 1e9, 2), "upload_GBps": round(nbytes / up / 1e9, 2),
+            "what": "numpy columns in host memory -> plx_column_from_host (7 columns) -> Q1 -> result download; median of %d" % reps, "verified": ver}
+
+
 def scan_extra(pl, n: int):
     """File -> device columns (no query): a lineitem-like table of n rows written by pyarrow as Parquet (uncompressed / Snappy /
     Zstandard) and as an Arrow IPC file, read with the library's own scan (metadata parsed by the library, Snappy and all page decoding
@@ -1357,6 +1392,7 @@ def run(args, emit):
         "whole_query_GBps_per_gpu": round(wl.algo_bytes * args.steps / dt / 1e9, 1),
         "cold_first_step_ms": None if cold_ms is None else round(cold_ms, 2),
         "step_ms": getattr(timed, "last_step_ms", None),      # every timed step, in order: a stall of the box shows here, not only in the mean
+        **step_spread(getattr(timed, "last_step_ms", None), wl.rows * ws),
         "roofline": roofline(stats, wl, args.steps),
         "kernels": _kernels(stats, 8),
     }
@@ -1446,6 +1482,12 @@ def run(args, emit):
                     os.environ["PLX_Q3_SHUFFLED"] = prev
             pl._ffi.lib().plx_memory_trim()
             torch.cuda.empty_cache()
+            emit(line)
+        if os.environ.get("PLX_BENCH_E2E", "1") != "0":
+            try:
+                extras["end_to_end_with_h2d"] = end_to_end_q1(pl, 60_000_000)
+            except Exception as e:
+                extras["end_to_end_with_h2d"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             emit(line)
         # last (nothing after it can be cut short by it): the scan in front of the path, SURVEY.md 8(f) row 3
         if os.environ.get("PLX_BENCH_SCAN", "1") != "0":

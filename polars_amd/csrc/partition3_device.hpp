@@ -147,7 +147,17 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
 
   const int64_t stride = (int64_t)gridDim.x;
   const int64_t rd_first = (int64_t)blockIdx.x;
-  if (rd_first < nrounds) finish_round(rd_first, issue_loads(rd_first));
+  // When do the next round's column loads go out?  One-dword records leave room in the register file for the loaded columns of a whole round
+  // next to the records of the current one: the loads are issued a full round ahead (kEarly).  Wider records do not: with both live the kernel
+  // spilled, and every scratch reload is a vmcnt(0) that also waits for these very loads (measured, 1e9 rows: 12-B records 6.96 -> 6.09 ms,
+  // 8-B 6.07 -> 5.62 with the late issue; 4-B 4.81 early vs 5.07 late) -- there they go out after the sort step, when the records have left
+  // the registers, and land during the copy-out.
+  constexpr bool kEarly = RW == 1 || TILES <= 2;
+  bool pre_early = false;
+  if (rd_first < nrounds) {
+    finish_round(rd_first, issue_loads(rd_first));
+    if (kEarly) pre_early = issue_loads(rd_first + stride);
+  }
   const uint32_t per_lane = NP >> 6;          // partitions per lane of the scan wave (NP is a power of two >= 64)
   for (int64_t rd = rd_first; rd < nrounds; rd += stride) {
     // ---- rank: one LDS atomic per surviving row (kept in the row's `part` word: partition in the low 10 bits, rank above them)
@@ -200,11 +210,9 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
         for (uint32_t w = 0; w < RW; w++) if (!(pp.ablate & 2u)) dst[w] = rec[t][r][w];
       }
     });
-    // the next round's column loads go out HERE: the records of this round have just left the registers (the loaded columns and the records
-    // are never live together: with both, the kernel spilled, and every scratch reload is a vmcnt(0) that also waits for these very loads),
-    // and they have the whole copy-out phase to land
     const int64_t rd_next = rd + stride;
-    const bool pre = issue_loads(rd_next);
+    bool pre = pre_early;
+    if (!kEarly) pre = issue_loads(rd_next);
     __syncthreads();                                                                  // C: the tile is sorted
     // ---- copy-out: whole lines to HBM, the rest into the carry lines
     {
@@ -230,7 +238,10 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
     }
     // ---- the next round's rows, evaluated from the loads issued before the copy-out
     // (no barrier here: the next round touches cnt -- reset before B -- and, only after its own barriers A and B, off / sorted / carry)
-    if (rd_next < nrounds) finish_round(rd_next, pre);       // uniform across the workgroup
+    if (rd_next < nrounds) {                                 // uniform across the workgroup
+      finish_round(rd_next, pre);
+      if (kEarly) pre_early = issue_loads(rd_next + stride);
+    }
   }
   __syncthreads();
   // tails: the carry dwords go behind the lines written so far; the fill of every partition's last chunk, in records
