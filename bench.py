@@ -373,7 +373,18 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
             O_, L_ = datagen.orders_lineitem_native(pl, no, seed)
             check_native_q3(pl, O_, L_, no, seed)
             return O_, L_
-        nat = _native_or_none("q3", build_native) if (ws == 1 and not shuffled) else None   # the sharded path exchanges torch tensors
+        nat = _native_or_none("q3", build_native) if ws == 1 else None   # the sharded path exchanges torch tensors
+        if nat is not None and shuffled:
+            # the SAME rows as the ordered run (the library's generator, host twin available: the oracle can check the result) in a seeded
+            # random row order, both tables: one device gather per column
+            def permuted(df, gseed):
+                g = torch.Generator(device="cuda"); g.manual_seed(gseed)
+                perm = pl.Series.from_torch("perm", torch.randperm(df.height, generator=g, device="cuda", dtype=torch.int32), dtype=pl.UInt32)
+                torch.cuda.synchronize()
+                out = pl.DataFrame([df[c].gather(perm) for c in df.columns])
+                pl._ffi.check(pl._ffi.lib().plx_synchronize())
+                return out
+            nat = (permuted(nat[0], seed * 2 + 1), permuted(nat[1], seed * 2 + 2))
         if nat is not None:
             O, L = nat
             nl = L.height
@@ -1471,7 +1482,9 @@ def run(args, emit):
                     "rows_per_s": round(w3.rows * k2 / d3, 1), "ms_per_step": round(d3 / k2 * 1e3, 3), "cold_first_step_ms": None if c3 is None else round(c3, 2),
                     "vs_ordered_inputs": (round(d3 / k2 * 1e3 / ordered["ms_per_step"], 2) if ordered.get("ms_per_step") else None),
                     "groups": int(r3.height) if hasattr(r3, "height") else None, "roofline": roofline(s3, w3, k2), "kernels": _kernels(s3, 6),
-                    "note": "same query, same row counts, both tables in random row order (torch generators); not oracle-verified"}
+                    "note": "same query over the SAME rows as tpch_q3_sf100 (the library's generator), both tables in a seeded random row order (device gather)"}
+                if os.environ.get("PLX_BENCH_VERIFY", "1") != "0":
+                    extras["tpch_q3_sf100_shuffled_inputs"]["verified"] = _verify(w3, r3, float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40")))
                 del w3, r3
             except Exception as e:
                 extras["tpch_q3_sf100_shuffled_inputs"] = {"error": f"{type(e).__name__}: {e}"[:300]}

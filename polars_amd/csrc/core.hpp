@@ -108,6 +108,7 @@ struct Column {
   // what the group-by planner learned from its strided sample of this column AS A KEY (engine.cpp KeySample: heavy hitters, distinct count,
   // group estimate): a column is immutable, so the next group-by on it with no predicate skips the 8 sample launches (0.3 ms per query)
   std::shared_ptr<void> key_sample;
+  int order_state = 0;         // 0 unknown, 1 (roughly) ascending, 2 unordered: sampled once when the column is the probe key of a large join (k::sample_sortedness)
   const void* data() const { return values ? values->ptr : nullptr; }
   const uint64_t* valid_words() const { return validity ? validity->as<uint64_t>() : nullptr; }
 };

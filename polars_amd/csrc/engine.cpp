@@ -800,6 +800,8 @@ static int64_t sample_keys(const Shape& full, const Args& args, int static_id, i
   }
   return d;
 }
+// PLX_PROBE_PARTITIONED: 0 = never, 2 = whenever the kernels are available (tests: small inputs, any key order), default = by size / density / key order
+static int partitioned_probe_mode() { const char* e = getenv("PLX_PROBE_PARTITIONED"); return e && e[0] == '0' ? 0 : e && e[0] == '2' ? 2 : 1; }
 static bool probe_late_loads() { static const bool v = [] { const char* e = getenv("PLX_PROBE_LATE"); return !(e && e[0] == '0'); }(); return v; }
 static int part_version() { static const int v = [] { const char* e = getenv("PLX_PART_V"); return (e && e[0] == '1') ? 1 : 2; }(); return v; }
 static bool hot_keys_enabled() { static const bool v = [] { const char* e = getenv("PLX_PART_HOT"); return !(e && e[0] == '0'); }(); return v; }
@@ -1372,7 +1374,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     if (!probe_only(e)) return no("aggregate reads a build-side column");
   }
   // ---- compile the three programs
-  Compiler cnt(plan, *B), cb(plan, *B), cp(plan, *P);
+  Compiler cnt(plan, *B), cb(plan, *B), cp(plan, *P), cs(plan, *P);
   std::vector<std::unique_ptr<Compiler>> csemi;      // one program per semi filter: build-side filters first, then probe-side
   std::vector<int> agg_nodes; std::vector<FinalSpec> specs;
   int len_idx = -1;
@@ -1403,6 +1405,12 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     for (int e : gb.exprs) collect_aggs(plan, e, agg_nodes);
     for (int a : agg_nodes) specs.push_back(cp.lower_agg(a));
     cp.finish();
+    // the probe side's predicate + key alone, row id as payload: the program of the partitioned probe's scatter (k::partitioned_probe_hits)
+    cs.pred = and_preds(cs, ppreds, psemis, (int)bsemis.size());
+    cs.key = cs.load(pki);
+    cs.df = &pview;
+    cs.add_agg(AGG_FIRST_ROW, -1);
+    cs.finish();
     for (const std::vector<SemiFilter>* sv : {&bsemis, &psemis}) {
       for (const SemiFilter& sf : *sv) {
         csemi.emplace_back(new Compiler(plan, *sf.F));
@@ -1466,7 +1474,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
         }
         const Lut lut{bits->as<unsigned long long>(), range};
         const int li = side == 0 ? (int)i : (int)(bsemis.size() + i);
-        if (side == 0) { cnt.args.lut[li] = lut; cb.args.lut[li] = lut; } else cp.args.lut[li] = lut;
+        if (side == 0) { cnt.args.lut[li] = lut; cb.args.lut[li] = lut; } else { cp.args.lut[li] = lut; cs.args.lut[li] = lut; }
         lut_bits.push_back(bits);
       }
     }
@@ -1507,7 +1515,35 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       Buf acc2 = dev_alloc(sizeof(uint64_t) * (size_t)s1 * cp.shape.n_aggs);
       k::init_agg_cells(acc2->as<uint64_t>(), s1, cp.shape);   // LEN = 0: build rows no probe row matched never show up
       dt.acc = acc2->as<unsigned long long>();
-      k::fused_direct_probe_agg(cp.shape, cp.args, dt, probe_static_id);
+      // Probe.  Keys in (rough) key order walk the bitmap out of the L2; keys in no order fetch one line per row across the fabric: those
+      // are partitioned by key range first and probed against LDS-resident bitmap slices, and the ordinary probe kernel then runs over
+      // the matching rows only (gathered).  Worth it when the bitmap is far larger than an L2 (4 MB) and few rows can match.
+      std::string probe_how = "probe_agg";
+      bool probed = false;
+      const int pmode = partitioned_probe_mode();
+      if (pmode == 2 || (pmode == 1 && P->height >= ((int64_t)1 << 24) && range >= ((uint64_t)1 << 28) && nb * 8 <= range)) {
+        const ColumnPtr& pk = P->cols[pki];
+        if (pk->order_state == 0) pk->order_state = k::sample_sortedness(pk) >= 0.9 ? 1 : 2;
+        ColumnPtr hits;
+        std::string pd;
+        if ((pmode == 2 || pk->order_state == 2) && k::partitioned_probe_hits(cs.shape, cs.args, dt, nb, &hits, &pd)) {
+          if (hits->len > 0) {
+            Args a2 = cp.args;
+            a2.n_rows = hits->len;
+            std::vector<ColumnPtr> keep;
+            for (int i = 0; i < cp.shape.n_inputs; i++) {
+              ColumnPtr g = ops::gather(cp.cols[cp.input_cols[i]], hits);
+              a2.in[i].values = g->data(); a2.in[i].validity = cp.shape.in_nullable[i] ? g->valid_words() : nullptr;
+              keep.push_back(g);
+            }
+            k::fused_direct_probe_agg(cp.shape, a2, dt, probe_static_id);
+            PLX_HIP(hipStreamSynchronize(stream()));       // the gathered columns live until the kernel has read them
+          }
+          probe_how = pd + "+gather+probe_agg";
+          probed = true;
+        }
+      }
+      if (!probed) k::fused_direct_probe_agg(cp.shape, cp.args, dt, probe_static_id);
       // one pass over the pair list into buffers sized for every slot (G <= n_slots)
       r.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)s1);
       r.acc = dev_alloc(sizeof(uint64_t) * (size_t)s1 * r.n_aggs);
@@ -1516,7 +1552,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       r.n_groups = G;
       rows->len = G;
       plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " direct-address table range=" +
-                   std::to_string(range) + " (bitmap + rank) unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+probe_agg, aggs=" +
+                   std::to_string(range) + " (bitmap + rank) unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+" + probe_how + ", aggs=" +
                    std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
       done = true;
     }

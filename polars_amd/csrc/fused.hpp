@@ -259,7 +259,9 @@ constexpr uint32_t kNoChunk = 0xffffffffu;
 //                (PartPlan2::src_base: the column's cached minimum; the planner checks max - min < 2^32)
 //   kPackFused   direct mode, ONE integer source, no validity / row id: the whole record is one dword, key_low | (v - base) << key_shift
 //                (the planner checks key_shift + bits(max - min) <= 32)
-constexpr uint32_t kPackNone = 0, kPackNarrow = 1, kPackFused = 2;
+//   kPackRowid   direct mode, no source, row id payload (the partitioned join probe): two dwords, key_low | row << key_shift (a 64-bit
+//                field: key_shift + 32 row bits always fit); null keys never become records, so there is no validity dword
+constexpr uint32_t kPackNone = 0, kPackNarrow = 1, kPackFused = 2, kPackRowid = 3;
 struct RecLayout2 {
   uint8_t key_words;             // 1 | 2 dwords
   uint8_t key_kind;              // 0: 64-bit, 1: i32 (sign-extended on read), 2: u32 (zero-extended)
@@ -329,6 +331,7 @@ PLX_FHD constexpr RecLayout2 rec_layout2(const Shape& sh, uint32_t mode, uint32_
   }
   if (pack == kPackFused) { w = 1; L.src_off[0] = 0; }      // planner-checked: direct mode, one integer source, no validity, no row id
   L.has_valid = shape_may_have_nulls(sh) ? 1 : 0;
+  if (pack == kPackRowid) { L.has_valid = 0; L.valid_off = 0; L.rowid_off = 0; L.rec_words = 2; return L; }
   L.valid_off = (uint8_t)w; w += L.has_valid;
   L.rowid_off = (uint8_t)w; w += 2 * L.has_rowid;
   L.rec_words = (uint8_t)w;
@@ -352,6 +355,8 @@ struct PartPlan2 {
   uint32_t gen;                // scatter generation: 2 = rings + line flush (partition2_device.hpp), 3 = tile sort + carry lines (partition3_device.hpp)
   uint32_t pack;               // kPack* (gen 3 only): == rec_layout2(shape, mode, pack).pack
   int64_t src_base[kMaxSrc];   // packing: value a kind-3 source is stored relative to
+  int64_t key_base;            // direct mode: the dense id is key - key_base (0: the program already produces dense ids)
+  uint32_t oob_drop;           // direct mode: 1 = rows whose id lies outside the partitions are dropped (join probe: such keys match nothing); 0 = the query fails
 };
 // which packing a shape admits at all (the planner still has to check the value ranges): kPackFused / kPackNarrow / kPackNone
 PLX_FHD constexpr uint32_t best_static_pack(const Shape& sh, uint32_t mode) {

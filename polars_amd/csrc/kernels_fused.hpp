@@ -74,6 +74,20 @@ void select_hot_keys(const fused::HashTable& t, int n_aggs, int len_idx, uint64_
 // only; min > max when it saw none) -- statistics gathered as a by-product
 int64_t partitioned_agg2(const fused::Shape& sh, const fused::Args& args, const fused::PartPlan2& pp, int static_id, const std::vector<uint64_t>& hot_keys, Buf* out_keys,
                          Buf* out_kvalid, Buf* out_acc, std::string* desc, int64_t* key_range_out = nullptr);
+// ---- partitioned join probe (probe keys in no particular order) ----------------------------------------------------------------
+// A direct-address join table is a bitmap over the build key range: 75 MB for TPC-H SF100 orders.  Probe keys that arrive in key
+// order walk it line by line out of the L2; probe keys in RANDOM order fetch one 128-B line from the Infinity Cache per row -- the
+// fabric, not HBM, then bounds the probe (SF100 Q3 on shuffled inputs: 7.0 ms against 1.9 ms).  So unordered probe rows are first
+// radix-partitioned by the high bits of (key - kmin) with the scatter of the partitioned group-by (records = key low bits + row id,
+// predicate fused), and every partition is then probed by ONE workgroup against LDS only: its slice of the bitmap when that fits, else a
+// Bloom filter built from the slice's set bits in the kernel's prologue; the CANDIDATE row ids (hits + < 1-2 % false positives) come back as
+// one u32 column and the caller runs the ordinary probe kernel -- which tests the exact bitmap -- over just those rows (the reference's partitioned build/probe:
+// crates/polars-ops/src/frame/join/hash_join/single_keys.rs:16-167, single_keys_inner.rs:11-149).
+// `sh` / `args`: the probe side's predicate + key program with ONE aggregate AGG_FIRST_ROW (its row id is the record payload).
+// Returns false when the geometry or the JIT is not available (the caller probes directly); *hits: PLX_U32 column of matching probe rows.
+bool partitioned_probe_hits(const fused::Shape& sh, const fused::Args& args, const fused::DirectJoinTable& dt, uint64_t n_build, ColumnPtr* hits, std::string* desc);
+// fraction of adjacent pairs (strided sample) of an integer column that are non-decreasing: 1.0 = sorted ascending
+double sample_sortedness(const ColumnPtr& c);
 // all jobs of a batch (key decodes + aggregate finalisations) in one launch
 void finalize_batch(const uint64_t* acc, int n_aggs, int64_t G, const fused::FinBatch& b);
 // packed group keys -> one key column

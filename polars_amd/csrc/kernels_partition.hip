@@ -585,5 +585,229 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   return (int64_t)(((uint64_t)res[1] << 32) | res[0]);
 }
 
+
+// ======================================================================================================================
+// Partitioned join probe (kernels_fused.hpp: partitioned_probe_hits)
+// ======================================================================================================================
+// One workgroup per partition.  Its slice of the build bitmap (2^key_shift bits: up to 512 KB) does not fit the LDS, but the build keys in
+// it are few (the planner requires a sparse bitmap): the prologue turns the slice's set bits into a Bloom filter in LDS (kBloomK probes over
+// `bloom_bits` bits: ~10 bits per build key at TPC-H SF100 -> under 1 % false positives), and the partition's records are then streamed against
+// LDS alone -- no access outside the chip per record, no dependent load chain (the first version re-checked positives of a FOLDED slice in
+// HBM: every chunk waited ~3 us for that load, 1.7 ms per 3.2e8 records).  What comes out are CANDIDATE row ids: the ordinary probe kernel the
+// caller runs over them tests the exact bitmap anyway.  Output slots are reserved with an LDS counter in the partition's private region (a
+// million returning atomics on one global counter serialise: 9 ms).
+constexpr uint32_t kBloomK = 4;
+__device__ __forceinline__ uint32_t bloom_pos(uint32_t low, uint32_t i, uint32_t log2_bits) {
+  constexpr uint32_t mult[kBloomK] = {0x9e3779b1u, 0x85ebca77u, 0xc2b2ae3du, 0x27d4eb2fu};
+  return ((low + 1u) * mult[i]) >> (32u - log2_bits);
+}
+__global__ __launch_bounds__(kP2AggBlock) void probe_pass_kernel(const unsigned int* __restrict__ recs, const unsigned int* __restrict__ chunk_fill, const unsigned long long* __restrict__ cl_off,
+                                                                 const unsigned int* __restrict__ cl_ids, const unsigned long long* __restrict__ bits, unsigned long long range,
+                                                                 unsigned long long n_words, uint32_t key_shift, uint32_t log2_bloom_bits, uint32_t exact,
+                                                                 unsigned int* __restrict__ hits /* a region of (chunks x 256) slots per partition */, unsigned int* __restrict__ part_hits) {
+  extern __shared__ unsigned long long lds_raw[];
+  unsigned int* bloom = reinterpret_cast<unsigned int*>(lds_raw);          // exact != 0: the slice itself (it fits), bit = key low bits
+  __shared__ unsigned int wg_hits;
+  const uint32_t p = blockIdx.x;
+  const uint32_t W = 1u << (key_shift - 6);                                // 64-bit words of the slice
+  const uint32_t bloom_words = 1u << (log2_bloom_bits - 5);
+  if (threadIdx.x == 0) wg_hits = 0;
+  for (uint32_t i = threadIdx.x; i < bloom_words; i += blockDim.x) bloom[i] = 0;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < W; i += blockDim.x) {
+    const unsigned long long wi = (unsigned long long)p * W + i;
+    unsigned long long w = wi < n_words ? bits[wi] : 0ull;
+    if (exact) { if (w) { bloom[i * 2] = (unsigned int)w; bloom[i * 2 + 1] = (unsigned int)(w >> 32); } continue; }
+    while (w) {
+      const uint32_t b = (uint32_t)__builtin_ctzll(w); w &= w - 1;
+      const uint32_t low = i * 64u + b;
+#pragma unroll
+      for (uint32_t q = 0; q < kBloomK; q++) { const uint32_t pos = bloom_pos(low, q, log2_bloom_bits); atomicOr(&bloom[pos >> 5], 1u << (pos & 31u)); }
+    }
+  }
+  __syncthreads();
+  const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  constexpr uint32_t kPerLane = kP2ChunkRecs / 64;
+  const uint64_t c_beg = cl_off[p], c_end = cl_off[p + 1];
+  const unsigned long long region = c_beg * kP2ChunkRecs;                  // this partition's output region: one slot per record it may hold
+  // Three chunks per wave are in flight and the chunk IDS run one more step ahead: a chunk's records can only be addressed once its id has
+  // arrived, so loading id and records in the same step made every step wait for two dependent memory round trips (3 us per chunk).
+  unsigned long long ra[kPerLane], rb[kPerLane], rc[kPerLane];             // raw 8-B records {key_low | row << key_shift}
+  uint32_t fill_a = 0, fill_b = 0, fill_c = 0;
+  const uint32_t low_mask = (1u << key_shift) - 1u;
+  auto load_id = [&](uint64_t j) -> uint32_t { return cl_ids[j < c_end ? j : c_end - 1]; };   // past the end: the last chunk again, ignored (fill 0)
+  auto load_chunk = [&](uint64_t j, uint32_t id, unsigned long long* r, uint32_t& fill) __attribute__((always_inline)) {
+    fill = j < c_end ? chunk_fill[id] : 0u;
+    const unsigned long long* base = reinterpret_cast<const unsigned long long*>(recs) + (uint64_t)id * kP2ChunkRecs;
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) r[u] = base[(uint32_t)lane + u * 64u];              // the chunk is allocated in full
+  };
+  auto process = [&](const unsigned long long* r, uint32_t fill) __attribute__((always_inline)) {
+    uint64_t m[kPerLane];
+    unsigned int lo[kPerLane], rid[kPerLane];
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) { lo[u] = (unsigned int)r[u] & low_mask; rid[u] = (unsigned int)(r[u] >> key_shift); }
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      const uint32_t i = (uint32_t)lane + u * 64u;
+      bool pos = i < fill && (((unsigned long long)p << key_shift) | lo[u]) < range;
+      if (exact) pos = pos && ((bloom[lo[u] >> 5] >> (lo[u] & 31u)) & 1u);
+      else {
+#pragma unroll
+        for (uint32_t q = 0; q < kBloomK; q++) { const uint32_t b = bloom_pos(lo[u], q, log2_bloom_bits); pos = pos && ((bloom[b >> 5] >> (b & 31u)) & 1u); }
+      }
+      m[u] = ballot(pos); total += (uint32_t)popc64(m[u]);
+    }
+    if (!total) return;                                                                      // wave-uniform
+    unsigned int o32 = 0;
+    if (lane == 0) o32 = atomicAdd(&wg_hits, total);
+    unsigned long long o = region + (unsigned long long)(unsigned int)__shfl((int)o32, 0, 64);
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      if ((m[u] >> lane) & 1ull) hits[o + (uint64_t)prefix_rank(m[u])] = rid[u];             // row id (the caller guarantees < 2^32 rows)
+      o += (uint64_t)popc64(m[u]);
+    }
+  };
+  if (c_beg < c_end) {
+    const uint64_t step = (uint64_t)nwaves;
+    uint64_t j = c_beg + (uint64_t)wave;
+    uint32_t id_next;
+    load_chunk(j, load_id(j), ra, fill_a);
+    load_chunk(j + step, load_id(j + step), rb, fill_b);
+    id_next = load_id(j + 2 * step);
+    for (;;) {                                                                               // the three buffers rotate by name
+      if (j >= c_end) break;
+      { const uint32_t id = id_next; id_next = load_id(j + 3 * step); load_chunk(j + 2 * step, id, rc, fill_c); } process(ra, fill_a); j += step;
+      if (j >= c_end) break;
+      { const uint32_t id = id_next; id_next = load_id(j + 3 * step); load_chunk(j + 2 * step, id, ra, fill_a); } process(rb, fill_b); j += step;
+      if (j >= c_end) break;
+      { const uint32_t id = id_next; id_next = load_id(j + 3 * step); load_chunk(j + 2 * step, id, rb, fill_b); } process(rc, fill_c); j += step;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) part_hits[p] = wg_hits;
+}
+// the partitions' hit regions -> one dense list
+__global__ __launch_bounds__(kBlock) void probe_hits_compact_kernel(const unsigned int* __restrict__ regions, const unsigned long long* __restrict__ cl_off, const unsigned int* __restrict__ part_hits,
+                                                                    const unsigned long long* __restrict__ out_off, unsigned int* __restrict__ out) {
+  const uint32_t p = blockIdx.x;
+  const unsigned int* src = regions + cl_off[p] * kP2ChunkRecs;
+  unsigned int* dst = out + out_off[p];
+  for (uint32_t i = threadIdx.x; i < part_hits[p]; i += blockDim.x) dst[i] = src[i];
+}
+
+bool partitioned_probe_hits(const Shape& sh, const Args& args, const DirectJoinTable& dt, uint64_t n_build, ColumnPtr* hits_out, std::string* desc) {
+  if (args.n_rows >= (int64_t)0xfffffff0ll || sh.n_aggs != 1 || sh.aggs[0].kind != AGG_FIRST_ROW || sh.key == kNone || sh.n_keys) return false;
+  const uint32_t bits_total = std::max<uint32_t>(ceil_log2(dt.range), 15);
+  PartPlan2 pp{};
+  pp.mode = kP2Direct; pp.gen = 3; pp.pack = kPackRowid; pp.n_hot = 0; pp.hot_copies = 1; pp.len_idx = 0; pp.oob_drop = 1; pp.key_base = dt.kmin;
+  pp.log2_parts = std::min<uint32_t>(8, bits_total - 9);                       // 256 partitions (the scatter's best geometry: 8192-row tiles), slices of >= 2^9 keys
+  if (pp.log2_parts < 6) return false;
+  pp.key_shift = bits_total - pp.log2_parts; pp.log2_slots = pp.key_shift;
+  const RecLayout2 L = rec_layout2(sh, kP2Direct, kPackRowid);
+  if (!L.has_rowid || L.n_src != 0 || L.rec_words != 2 || pp.key_shift > 32) return false;     // one 64-bit field: key low bits | row id << key_shift
+  pp.rec_words = L.rec_words; pp.block = kP2MaxBlock;
+  const uint32_t NP = 1u << pp.log2_parts;
+  const size_t lds_total = 160 * 1024 - 2048;
+  uint32_t tiles = 0;
+  for (uint32_t t : {4u, 2u, 1u}) if (part3_scatter_lds(kP2MaxBlock * kRows * t, L.rec_words, NP, 0, 0, sh.n_aggs, 1) <= lds_total) { tiles = t; break; }
+  if (!tiles) return false;
+  plan2_geometry(pp, args.n_rows, tiles);
+  // LDS of the probe pass: the partition's bitmap slice itself when it fits (exact), else a Bloom filter of 2^20 bits (128 KB)
+  const bool exact = pp.key_shift <= 20;
+  const uint32_t log2_bloom = exact ? std::max<uint32_t>(pp.key_shift, 6) : 20;
+  // a Bloom filter of 2^20 bits with 4 probes stays under ~2 % false positives up to 2^17 keys: denser slices would flood the caller with candidates
+  if (!exact && (double)n_build * (double)((uint64_t)1 << pp.key_shift) / (double)dt.range > (double)(1u << 17)) return false;
+  const jit::Sink jk = jit::part3_scatter_sink(pp.mode, pp.tiles, pp.pack, false);
+  if (!jit::ensure(sh, jk, args.n_rows)) return false;
+  const uint32_t chunk_dw = kP2ChunkRecs * pp.rec_words;
+  const int64_t n_chunks = (int64_t)pp.scatter_grid * pp.chunks_per_wg;
+  Buf recs = dev_alloc((size_t)n_chunks * chunk_dw * 4 + 256);
+  Buf chunk_part = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks), chunk_fill = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks);
+  PLX_HIP(hipMemsetAsync(chunk_part->ptr, 0xff, sizeof(uint32_t) * (size_t)n_chunks, stream()));
+  Buf meta = dev_alloc_zero(64);             // [0..1] hit counter (u64), [3..4] scatter flags
+  ScatterParams2 sp{};
+  sp.recs = recs->as<unsigned int>(); sp.chunk_part = chunk_part->as<unsigned int>(); sp.chunk_fill = chunk_fill->as<unsigned int>(); sp.flags = meta->as<unsigned int>() + 3;
+  {
+    ProfileScope ps("probe_scatter[jit]", scan_bytes(sh, args) + (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
+    const size_t slds = part3_scatter_lds(pp.block * kRows * pp.tiles, pp.rec_words, NP, 0, 0, sh.n_aggs, 1);
+    Shape shc = sh; Args ac = args; PartPlan2 ppc = pp; ScatterParams2 spc = sp;
+    void* ka[] = {&shc, &ac, &ppc, &spc};
+    PLX_REQUIRE(jit::launch_raw(sh, jk, ka, (int)pp.scatter_grid, (int)pp.block, slds), PLX_ERR_HIP, "jit launch failed (probe scatter)");
+  }
+  Buf counts = dev_alloc_zero(sizeof(uint32_t) * (NP + 1)), cursor = dev_alloc_zero(sizeof(uint32_t) * (NP + 1));
+  Buf cl_off = dev_alloc(sizeof(uint64_t) * (NP + 2)), cl_ids = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks);
+  {
+    ProfileScope ps("part2_chunk_sort", (uint64_t)n_chunks * 12, (uint64_t)n_chunks);
+    const int g = grid_for(n_chunks, kBlock * 16, 2);
+    hipLaunchKernelGGL(chunk_hist_kernel, dim3(g), dim3(kBlock), sizeof(unsigned int) * NP, stream(), chunk_part->as<unsigned int>(), n_chunks, NP, counts->as<unsigned int>());
+    PLX_HIP(hipGetLastError());
+    exclusive_scan_u32(counts->as<uint32_t>(), cl_off->as<uint64_t>(), NP);
+    hipLaunchKernelGGL(chunk_place_kernel, dim3(g), dim3(kBlock), sizeof(unsigned int) * NP * 2, stream(), chunk_part->as<unsigned int>(), n_chunks, NP,
+                       cl_off->as<unsigned long long>(), cursor->as<unsigned int>(), cl_ids->as<unsigned int>());
+    PLX_HIP(hipGetLastError());
+  }
+  auto hits = std::make_shared<Column>();
+  hits->dtype = PLX_U32; hits->null_count = 0;
+  Buf regions = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks * kP2ChunkRecs + 16);          // a slot per record a partition may hold
+  Buf part_hits = dev_alloc_zero(sizeof(uint32_t) * (NP + 1)), hit_off = dev_alloc(sizeof(uint64_t) * (NP + 2));
+  {
+    ProfileScope ps("probe_pass_lds_bitmap", (uint64_t)args.n_rows * pp.rec_words * 4 + dt.range / 8, (uint64_t)args.n_rows);
+    const unsigned long long n_words = (dt.range / 512 + 1) * 8;
+    hipLaunchKernelGGL(probe_pass_kernel, dim3(NP), dim3(kP2AggBlock), ((size_t)1 << (log2_bloom - 3)), stream(), recs->as<unsigned int>(), chunk_fill->as<unsigned int>(),
+                       cl_off->as<unsigned long long>(), cl_ids->as<unsigned int>(), dt.bits, dt.range, n_words, pp.key_shift, log2_bloom, exact ? 1u : 0u,
+                       regions->as<unsigned int>(), part_hits->as<unsigned int>());
+    PLX_HIP(hipGetLastError());
+    exclusive_scan_u32(part_hits->as<uint32_t>(), hit_off->as<uint64_t>(), NP);              // hit_off[NP] = total
+  }
+  uint32_t res[5] = {0, 0, 0, 0, 0};
+  d2h_sync(res, meta->ptr, 20);
+  PLX_REQUIRE(!res[3], PLX_ERR_INVALID, "partitioned probe: a scatter workgroup ran out of chunks");
+  uint64_t total_hits = 0;
+  d2h_sync(&total_hits, hit_off->as<uint64_t>() + NP, 8);
+  hits->len = (int64_t)total_hits;
+  hits->values = dev_alloc(values_bytes(PLX_U32, std::max<int64_t>(hits->len, 1)));
+  if (hits->len) {
+    hipLaunchKernelGGL(probe_hits_compact_kernel, dim3(NP), dim3(kBlock), 0, stream(), regions->as<unsigned int>(), cl_off->as<unsigned long long>(), part_hits->as<unsigned int>(),
+                       hit_off->as<unsigned long long>(), hits->values->as<unsigned int>());
+    PLX_HIP(hipGetLastError());
+  }
+  *hits_out = hits;
+  if (desc) *desc = "partitioned_probe(P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec_words * 4) + "B,tile=" + std::to_string(pp.block * kRows * pp.tiles) + (exact ? ",lds_bitmap=" : ",lds_bloom=") + std::to_string(((size_t)1 << (log2_bloom - 3)) >> 10) +
+                    "KB,candidates=" + std::to_string(hits->len) + ")";
+  return true;
+}
+
+// ---- is a key column (roughly) sorted?  fraction of non-decreasing adjacent pairs over 64 evenly spaced runs of 1024 rows ----------------
+__global__ __launch_bounds__(kBlock) void sortedness_kernel(const void* __restrict__ values, int width, int is_signed, int64_t n, int64_t run, int64_t stride, unsigned int* __restrict__ out /* [2]: pairs, ordered */) {
+  unsigned int pairs = 0, ordered = 0;
+  const int64_t base = (int64_t)blockIdx.x * stride;
+  for (int64_t i = threadIdx.x; i + 1 < run && base + i + 1 < n; i += blockDim.x) {
+    long long a, b;
+    const int64_t j = base + i;
+    switch (width) {
+      case 1: a = is_signed ? (long long)((const signed char*)values)[j] : (long long)((const unsigned char*)values)[j]; b = is_signed ? (long long)((const signed char*)values)[j + 1] : (long long)((const unsigned char*)values)[j + 1]; break;
+      case 2: a = is_signed ? (long long)((const short*)values)[j] : (long long)((const unsigned short*)values)[j]; b = is_signed ? (long long)((const short*)values)[j + 1] : (long long)((const unsigned short*)values)[j + 1]; break;
+      case 4: a = is_signed ? (long long)((const int*)values)[j] : (long long)((const unsigned int*)values)[j]; b = is_signed ? (long long)((const int*)values)[j + 1] : (long long)((const unsigned int*)values)[j + 1]; break;
+      default: a = ((const long long*)values)[j]; b = ((const long long*)values)[j + 1]; break;
+    }
+    pairs++; ordered += a <= b;
+  }
+  if (pairs) { atomicAdd(&out[0], pairs); atomicAdd(&out[1], ordered); }
+}
+double sample_sortedness(const ColumnPtr& c) {
+  if (!c || !dtype_is_int(c->dtype) || c->dtype == PLX_U64 || c->len < 2) return 1.0;
+  const int64_t n = c->len, run = 1024;
+  const int blocks = (int)std::min<int64_t>(64, (n + run - 1) / run);
+  const int64_t stride = blocks > 1 ? (n - run) / (blocks - 1) : 0;
+  Buf out = dev_alloc_zero(8);
+  hipLaunchKernelGGL(sortedness_kernel, dim3(blocks), dim3(kBlock), 0, stream(), c->data(), dtype_width(c->dtype), dtype_is_signed(c->dtype) ? 1 : 0, n, run, stride, out->as<unsigned int>());
+  PLX_HIP(hipGetLastError());
+  uint32_t h[2] = {0, 0};
+  d2h_sync(h, out->ptr, 8);
+  return h[0] ? (double)h[1] / (double)h[0] : 1.0;
+}
+
 }  // namespace k
 }  // namespace plx

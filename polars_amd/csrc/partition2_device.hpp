@@ -72,8 +72,10 @@ __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, c
   kvalid = (rf.getv(sh.key) >> r) & 1;
   key64 = kvalid ? rf.get(r, sh.key) : 0ull;
   if constexpr (MODE == (int)kP2Direct) {
-    part = (uint32_t)(key64 >> pp.key_shift);
-    rec[0] = (uint32_t)key64 & ((1u << pp.key_shift) - 1u);
+    const uint64_t id = key64 - (uint64_t)pp.key_base;
+    const uint64_t hi = id >> pp.key_shift;
+    part = hi > 0xfffffffeull ? 0xfffffffeu : (uint32_t)hi;           // far outside the id range: still "outside" after the narrowing
+    rec[0] = (uint32_t)id & ((1u << pp.key_shift) - 1u);
   } else {
     part = part2_of(key64, kvalid, pp.log2_parts);
     rec[0] = (uint32_t)key64;
@@ -92,6 +94,11 @@ __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, c
       }
       if ((rf.getv(L.src_slot[j]) >> r) & 1) vbits |= 1u << j;
     }
+  }
+  if (L.pack == kPackRowid) {              // {key_low | row << key_shift} as one 64-bit field
+    const uint64_t f = (uint64_t)rec[0] | ((uint64_t)row << pp.key_shift);
+    rec[0] = (uint32_t)f; rec[1] = (uint32_t)(f >> 32);
+    return;
   }
   if (L.has_valid) rec[L.valid_off] = vbits;
   if (L.has_rowid) { rec[L.rowid_off] = (uint32_t)(uint64_t)row; rec[L.rowid_off + 1] = (uint32_t)((uint64_t)row >> 32); }

@@ -105,7 +105,8 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
           kmin_seen = (long long)key64 < kmin_seen ? (long long)key64 : kmin_seen;
           kmax_seen = (long long)key64 > kmax_seen ? (long long)key64 : kmax_seen;
         }
-        if (MODE == (int)kP2Direct && part[t][r] >= NP) { if (pass[r]) sp.flags[1] = 1u; pend = false; }   // id outside the declared range: the query fails
+        if (MODE == (int)kP2Direct && pp.oob_drop && !kvalid) pend = false;                                      // join probe: a null key matches nothing
+        if (MODE == (int)kP2Direct && part[t][r] >= NP) { if (pass[r] && !pp.oob_drop) sp.flags[1] = 1u; pend = false; }   // id outside the declared range: the query fails (group-by) / the row matches nothing (join probe)
         if (HOT && pp.n_hot && pass[r] && kvalid && key64 != kEmptyKey) {
           uint32_t s = (uint32_t)((key64 * 0x9e3779b97f4a7c15ull) >> (64 - pp.log2_hot_slots));
           int hot = -1;
