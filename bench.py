@@ -9,9 +9,10 @@ timed region starts.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload q1|q3|cfg2|cfg3] [--rows R]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, every rank holds its own SF100-sized shard (weak scaling); Q1's
-six-group partials are combined with an all-gather of a few hundred bytes (polars_amd/dist.py),
-no row crosses xGMI.  Prints ONE JSON line on rank 0.
+N > 1: one process per GPU.  --scaling weak (default): every rank holds its own SF100-sized shard; --scaling strong: the SF100 /
+1e9-row configuration in TOTAL, split over the ranks (BASELINE config 4).  Q1's six-group partials are combined with an all-gather
+of a few hundred bytes (polars_amd/dist.py), no row crosses xGMI; cfg3 / cfg5 pre-aggregate locally and exchange the PARTIAL rows
+by key hash (--mode rows exchanges raw rows instead).  Prints ONE JSON line on rank 0; exits 3 if a result disagreed with the oracle.
 
 Order of work at N = 1: headline (Q1; its input comes from the library's own generator kernel, spot-checked against the
 generator's host twin, with the torch generators as fallback) -> CPU baseline -> secondary workloads (`extras`).  The
@@ -1381,7 +1382,11 @@ def run(args, emit):
     if distributed:
         pdist.init_process_group("nccl")
     seed = 10 + rank
-    wl = make_workload(pl, args.workload, args.rows, seed=seed, ws=ws)
+    rows = args.rows
+    if distributed and args.scaling == "strong" and not rows:
+        # strong scaling (BASELINE config 4: SF100 in TOTAL over the ranks): every rank generates 1/ws of the single-GPU configuration
+        rows = {"q1": SF100_LINEITEM, "q3": 4 * SF100_ORDERS, "q3f": 4 * SF100_ORDERS, "cfg2": 10 ** 9}.get(args.workload, 0) // ws
+    wl = make_workload(pl, args.workload, rows, seed=seed, ws=ws)
 
     combine = None
     if distributed and args.workload == "q1":
@@ -1394,7 +1399,7 @@ def run(args, emit):
     line = {
         "metric": "rows/sec + achieved HBM GB/s, TPC-H Q1/Q3 SF100, 1/2/4/8 GPU vs CPU",
         "value": round(total_rows / dt, 1), "unit": "rows/s", "n_gpus": ws, "steps": args.steps, "warmup": max(args.warmup, 1),
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if (distributed and args.scaling == "strong") else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": wl.name, "description": wl.desc, "rows_per_gpu": wl.rows, "algorithmic_bytes_per_gpu_step": wl.algo_bytes,
                    "parallelism": ("single GPU" if ws == 1 else f"row-sharded x{ws}, all-gather of group partials" if args.workload == "q1" else

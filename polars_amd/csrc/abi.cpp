@@ -922,6 +922,14 @@ void encode_on_device(const uint64_t* views, const ColumnPtr& validity_holder, B
   *out_dict = register_strdict(std::move(d));
 }
 }  // namespace
+namespace plx {
+// views (and the long strings' bytes, one buffer, absolute offsets) already in HBM -> dictionary codes + dictionary handle; the scan sources
+// that build their views on the device (ipc.cpp) end here
+void strview_encode_device(const uint64_t* views, const ColumnPtr& validity_holder, Buf data, int64_t n, plx_column* out_codes, plx_strdict* out_dict) {
+  Buf bb = dev_alloc_zero(8);
+  encode_on_device(views, validity_holder, data, bb, n, out_codes, out_dict);
+}
+}  // namespace plx
 }  // extern "C++"
 
 int plx_strview_dict_encode(const void* views, const uint8_t* validity, int64_t bit_offset, int64_t n, const void* const* data_buffers, const int64_t* data_sizes,

@@ -15,10 +15,12 @@
 #include <atomic>
 #include <thread>
 
+#include <chrono>
 #include "core.hpp"
 #include "host_stage.hpp"
 #include "ipc_reader.hpp"
 #include "kernels.hpp"
+#include "ops.hpp"
 
 using namespace plx;
 
@@ -75,7 +77,10 @@ ColumnPtr read_fixed_column(File& f, const std::vector<int>& bsel, int col, cons
   // page-locked image of the column (groups of ~256 MB: group k is on its way over PCIe while group k + 1 is inflated).
   bool any_compressed = false;
   for (int b : bsel) any_compressed = any_compressed || f.batches[b].compressed;
-  const bool values_in_parallel = any_compressed && file_dtype != PLX_BOOL;
+  // Uncompressed bodies of MANY batches take the same route: one positional read per (batch, column) buffer on the calling thread -- each
+  // spawning its own few slice threads -- left a 1 GB file at 8 GB/s (pyarrow's mmap "read": 2x faster); a pool over all the column's buffers
+  // fills the page-locked image at memory speed and the column crosses PCIe in one DMA while the next column is read.
+  const bool values_in_parallel = (any_compressed || bsel.size() > 1) && file_dtype != PLX_BOOL;
   if (values_in_parallel) {
     struct Task { const ipc::BatchMeta* bm; int64_t body; const ipc::BufferRef* vb; size_t off, bytes; };
     const size_t kGroup = (size_t)256 << 20;
@@ -99,8 +104,13 @@ ColumnPtr read_fixed_column(File& f, const std::vector<int>& bsel, int col, cons
         std::atomic<size_t> next{0};
         auto work = [&](size_t t) {
           try {
-            for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1))
-              ipc::load_buffer(f, *tasks[k].bm, tasks[k].body, *tasks[k].vb, img + tasks[k].off, tasks[k].bytes);
+            for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1)) {
+              const Task& tk = tasks[k];
+              if (!tk.bm->compressed) {               // stored: one positional read by this pool thread (no nested slice threads)
+                if ((int64_t)tk.bytes > tk.vb->length) throw ipc::FormatError("buffer shorter than the array needs");
+                f.pread_exact(img + tk.off, tk.bytes, tk.body + tk.vb->offset);
+              } else ipc::load_buffer(f, *tk.bm, tk.body, *tk.vb, img + tk.off, tk.bytes);
+            }
           } catch (...) { errs[t] = std::current_exception(); }
         };
         if (threads <= 1) work(0);
@@ -177,13 +187,102 @@ void set_bits(uint8_t* bits, int64_t off, int64_t n) {
   for (; i < end; i++) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
 }
 
-// Utf8 / LargeUtf8 / Utf8View (+ binary twins) that are not dictionary-encoded: 16-byte views are assembled on the host (offsets ->
+// Utf8 / LargeUtf8 (+ binary twins), not dictionary-encoded: offsets and bytes of every selected batch cross PCIe as they are stored (a pool
+// of host threads fills two page-locked images: 4-8 B of offsets per row instead of 16 B of host-assembled views out of pageable memory -- the
+// 1-character l_returnflag column of a 2e7-row file took 115 of the file's 150 ms that way), the views are built by a kernel
+// (k::strviews_from_offsets) and encoded on the device like every other string column.
+ColumnPtr read_offset_string_column(File& f, const std::vector<int>& bsel, int col, int64_t total, bool large, plx_strdict* dict_out) {
+  PinnedStage& st = PinnedStage::for_this_thread();
+  const size_t ow = large ? 8 : 4;
+  struct Part { const ipc::BatchMeta* bm; int64_t body, n, row0; const ipc::BufferRef *vbits, *offs, *data; size_t off_at, data_at, data_len; };
+  std::vector<Part> parts;
+  std::vector<uint8_t> validity((size_t)(total + 7) / 8 + 8, 0);
+  bool any_nulls = false;
+  size_t off_bytes = 0, data_bytes = 0;
+  int64_t row = 0;
+  for (int b : bsel) {
+    const ipc::BatchMeta& bm = f.batches[b];
+    const Slot s = slot_of(f, bm, col);
+    const int64_t n = bm.length, body = f.body_off[b];
+    if (s.node >= bm.nodes.size() || s.buf + 3 > bm.buffers.size()) throw ipc::FormatError("record batch without the column's buffers");
+    if (bm.nodes[s.node].length != n) throw ipc::FormatError("column length differs from its record batch");
+    const int64_t nc = bm.nodes[s.node].null_count;
+    if (nc > 0) {
+      any_nulls = true;
+      const std::vector<uint8_t> vbits = read_buffer(f, bm, body, bm.buffers[s.buf]);
+      if ((int64_t)vbits.size() - 16 < (n + 7) / 8) throw ipc::FormatError("bitmap buffer shorter than the array");
+      for (int64_t i = 0; i < n; i++)
+        if ((vbits[(size_t)i >> 3] >> (i & 7)) & 1) validity[(size_t)(row + i) >> 3] |= (uint8_t)(1u << ((row + i) & 7));
+    } else set_bits(validity.data(), row, n);
+    const int64_t dlen = bm.compressed ? ipc::compressed_buffer_length(f, body, bm.buffers[s.buf + 2]) : bm.buffers[s.buf + 2].length;
+    if (dlen < 0) throw ipc::FormatError("string data buffer with a negative length");
+    if (n) parts.push_back({&bm, body, n, row, &bm.buffers[s.buf], &bm.buffers[s.buf + 1], &bm.buffers[s.buf + 2], off_bytes, data_bytes, (size_t)dlen});
+    if (n) { off_bytes += (size_t)(n + 1) * ow; data_bytes += ((size_t)dlen + 15) & ~size_t(15); }
+    row += n;
+  }
+  if (data_bytes >= ((size_t)1 << 32)) throw Unsupported("string column with 4 GiB or more of bytes in one read");
+  Buf d_offs = dev_alloc(std::max<size_t>(off_bytes, 8) + 64), d_data = dev_alloc(std::max<size_t>(data_bytes, 8) + 64), d_views = dev_alloc((size_t)std::max<int64_t>(total, 1) * 16);
+  Buf err = dev_alloc_zero(8);
+  // both images through the pool: tasks = (part, which buffer)
+  for (int which = 0; which < 2; which++) {
+    const size_t bytes = which == 0 ? off_bytes : data_bytes;
+    if (!bytes) continue;
+    uint8_t* img = st.get(bytes);
+    const size_t threads = std::min<size_t>(std::min<size_t>(64, std::max(2u, std::thread::hardware_concurrency() / 2)), parts.size());
+    std::vector<std::exception_ptr> errs(std::max<size_t>(threads, 1));
+    std::atomic<size_t> next{0};
+    auto work = [&](size_t t) {
+      try {
+        for (size_t k = next.fetch_add(1); k < parts.size(); k = next.fetch_add(1)) {
+          const Part& p = parts[k];
+          const ipc::BufferRef& r = which == 0 ? *p.offs : *p.data;
+          const size_t need = which == 0 ? (size_t)(p.n + 1) * ow : p.data_len;
+          uint8_t* dst = img + (which == 0 ? p.off_at : p.data_at);
+          if (!need) continue;
+          if (!p.bm->compressed) {
+            if ((int64_t)need > r.length) throw ipc::FormatError("buffer shorter than the array needs");
+            f.pread_exact(dst, need, p.body + r.offset);
+          } else ipc::load_buffer(f, *p.bm, p.body, r, dst, need);
+        }
+      } catch (...) { errs[t] = std::current_exception(); }
+    };
+    if (threads <= 1) work(0);
+    else {
+      std::vector<std::thread> pool;
+      for (size_t t = 0; t < threads; t++) pool.emplace_back(work, t);
+      for (std::thread& th : pool) th.join();
+    }
+    for (std::exception_ptr& ep : errs) if (ep) std::rethrow_exception(ep);
+    st.upload(which == 0 ? d_offs->ptr : d_data->ptr, img, bytes);
+  }
+  ColumnPtr vh;
+  if (any_nulls) {
+    std::vector<uint8_t> zeros((size_t)total);
+    vh = column_from_host(PLX_U8, zeros.data(), validity.data(), 0, total);
+  }
+  for (const Part& p : parts)
+    k::strviews_from_offsets((const uint8_t*)d_offs->ptr + p.off_at, large, d_data->as<uint8_t>(), (uint64_t)p.data_at, (int64_t)p.data_len, p.n, d_views->as<uint64_t>() + (size_t)p.row0 * 2,
+                             vh ? vh->valid_words() : nullptr, p.row0, err->as<unsigned int>());
+  uint32_t bad = 0;
+  d2h_sync(&bad, err->ptr, 4);
+  if (bad) throw ipc::FormatError("string offsets outside the data buffer");
+  plx_column codes = 0;
+  uint64_t dict = 0;
+  strview_encode_device(d_views->as<uint64_t>(), vh, d_data, total, &codes, &dict);
+  ColumnPtr c = get_column(codes);
+  free_column(codes);       // the frame keeps the column alive
+  *dict_out = (plx_strdict)dict;
+  return c;
+}
+
+// Utf8View (+ binary twin; also the fallback shape of the function above), not dictionary-encoded: 16-byte views are assembled on the host (offsets ->
 // {len, inline bytes | prefix, buffer, offset}; view buffer indices rebased across batches), hashing / comparing / encoding happens
 // on the device (plx_strview_dict_encode: kernels_strview.hip)
 ColumnPtr read_string_column(File& f, const std::vector<int>& bsel, int col, int64_t total, plx_strdict* dict_out) {
   const ipc::Field& fl = f.footer.fields[col];
   const bool is_view = fl.type == ipc::TY_UTF8_VIEW || fl.type == ipc::TY_BINARY_VIEW;
   const bool large = fl.type == ipc::TY_LARGE_UTF8 || fl.type == ipc::TY_LARGE_BINARY;
+  if (!is_view && !getenv("PLX_IPC_HOST_VIEWS")) return read_offset_string_column(f, bsel, col, total, large, dict_out);
   // views are written row by row below (every row, in parallel slices): no 16 B/row zero fill by one thread first
   std::unique_ptr<uint8_t[]> views_mem(new uint8_t[(size_t)total * 16 + 16]);
   uint8_t* const views = views_mem.get();
@@ -384,6 +483,10 @@ int plx_ipc_read(plx_ipc file, const int32_t* batches, int32_t n_batches, const 
       const ipc::Field& fl = f.footer.fields[col];
       const ColType ct = col_type(fl);
       if (ct.dtype < 0) throw Unsupported("column '" + fl.name + "': " + ct.why + " is outside the hot path's dtypes");
+      static const bool timing = getenv("PLX_IPC_TIMING") != nullptr;      // per-column host time on stderr (measurement only)
+      const auto t_col = std::chrono::steady_clock::now();
+      struct Report { bool on; const std::string& name; std::chrono::steady_clock::time_point t0; int64_t rows;
+                      ~Report() { if (on) fprintf(stderr, "[plx ipc] column %-20s %8.2f ms host (%lld rows)\n", name.c_str(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), (long long)rows); } } report{timing, fl.name, t_col, total};
       ColumnPtr c;
       if (ct.strings && !fl.has_dictionary) {
         plx_strdict d = 0;

@@ -51,6 +51,11 @@ void datagen_customer(int64_t n, uint64_t seed, int64_t* custkey, uint8_t* segme
 void strview_dict_encode(const uint64_t* views, const uint64_t* validity, const uint8_t* data, const uint64_t* buf_base, int64_t n, Buf* out_codes, Buf* out_dict_views,
                          int64_t* n_distinct);
 // dictionary -> offsets[n + 1] (u64) + contiguous bytes on the device
+// Utf8 / LargeUtf8 arrays (offsets + bytes, already in HBM) -> 16-byte views: {len, 12 inline bytes} or {len, 4-byte prefix, buffer 0, offset
+// data_base + start}; null rows (validity bit row0 + i clear) become all-zero views.  *err (device u32) is set when an offset pair is not
+// monotonic, leaves the data buffer or a long string starts beyond 4 GiB.
+void strviews_from_offsets(const void* offsets, bool large, const uint8_t* data, uint64_t data_base, int64_t data_len, int64_t n, uint64_t* views_out, const uint64_t* validity, int64_t row0,
+                           unsigned int* err);
 void strdict_materialise(const uint64_t* dict_views, const uint8_t* data, int64_t n, Buf* out_offsets, Buf* out_bytes, uint64_t* total_bytes);
 // synthetic Utf8View column (benchmark support): the inline view of "id%010d" % value for value = lo + floor(U * (hi - lo)) of row i
 void datagen_id_views(int64_t n, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, uint64_t* out_views);

@@ -276,6 +276,44 @@ void strview_dict_encode(const uint64_t* views, const uint64_t* validity, const 
   fail(PLX_ERR_OOM, "string dictionary table kept overflowing");
 }
 
+namespace {
+template <class OFF>
+__global__ __launch_bounds__(kBlock) void strviews_from_offsets_kernel(const OFF* __restrict__ offs, const unsigned char* __restrict__ data, unsigned long long data_base, long long data_len,
+                                                                       int64_t n, unsigned long long* __restrict__ views, const uint64_t* __restrict__ validity, int64_t row0, unsigned int* __restrict__ err) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const long long a = (long long)offs[i], e = (long long)offs[i + 1];
+    unsigned long long w0 = 0, w1 = 0;
+    const bool ok = !validity || ((validity[(row0 + i) >> 6] >> ((row0 + i) & 63)) & 1);
+    if (a < 0 || e < a || e > data_len || e - a > 0x7fffffffll) { *err = 1u; }
+    else if (ok) {
+      const uint32_t len = (uint32_t)(e - a);
+      const unsigned char* p = data + data_base + (unsigned long long)a;
+      if (len <= 12) {
+        w0 = (unsigned long long)len | (load_bytes(p, len < 4 ? len : 4) << 32);
+        if (len > 4) w1 = load_bytes(p + 4, len - 4);
+      } else {
+        const unsigned long long off = data_base + (unsigned long long)a;
+        if (off > 0xffffffffull) *err = 1u;
+        w0 = (unsigned long long)len | (load_bytes(p, 4) << 32);
+        w1 = (off & 0xffffffffull) << 32;                 // buffer index 0, offset in the high half
+      }
+    }
+    views[(size_t)i * 2] = w0; views[(size_t)i * 2 + 1] = w1;
+  }
+}
+}  // namespace
+void strviews_from_offsets(const void* offsets, bool large, const uint8_t* data, uint64_t data_base, int64_t data_len, int64_t n, uint64_t* views_out, const uint64_t* validity, int64_t row0,
+                           unsigned int* err) {
+  if (n == 0) return;
+  ProfileScope ps("strviews_from_offsets", (uint64_t)n * ((large ? 8 : 4) + 16), (uint64_t)n);
+  const int grid = grid_for(n, kBlock * 4);
+  if (large) hipLaunchKernelGGL((strviews_from_offsets_kernel<long long>), dim3(grid), dim3(kBlock), 0, stream(), (const long long*)offsets, (const unsigned char*)data, (unsigned long long)data_base,
+                                (long long)data_len, n, (unsigned long long*)views_out, validity, row0, err);
+  else hipLaunchKernelGGL((strviews_from_offsets_kernel<int>), dim3(grid), dim3(kBlock), 0, stream(), (const int*)offsets, (const unsigned char*)data, (unsigned long long)data_base,
+                          (long long)data_len, n, (unsigned long long*)views_out, validity, row0, err);
+  PLX_HIP(hipGetLastError());
+}
+
 // dictionary -> contiguous bytes + offsets[n + 1] on the device
 void strdict_materialise(const uint64_t* dict_views, const uint8_t* data, int64_t n, Buf* out_offsets, Buf* out_bytes, uint64_t* total_bytes) {
   *out_offsets = dev_alloc(sizeof(uint64_t) * (size_t)(n + 2));

@@ -38,4 +38,5 @@ ColumnPtr slice_copy(const ColumnPtr& c, int64_t offset, int64_t len);
 bool int_range(const ColumnPtr& c, int64_t* mn, int64_t* mx);
 
 }  // namespace ops
+void strview_encode_device(const uint64_t* views, const ColumnPtr& validity_holder, Buf data, int64_t n, plx_column* out_codes, uint64_t* out_dict);   // abi.cpp
 }  // namespace plx
