@@ -535,10 +535,15 @@ int plx_ipc_column_strdict(plx_ipc file, int32_t column, plx_strdict* out);
  * (combine_locals).  A communicator wraps an RCCL communicator created from a 128-byte unique id that rank 0 obtains
  * (plx_comm_unique_id) and hands to the other ranks by any means (torch.distributed / MPI / a file).  librccl is
  * loaded with dlopen on first use.
- *   plx_exchange_by_key  every row of `frame` goes to rank plx_hash_partition(key); all columns travel in ONE grouped
- *                        ncclSend / ncclRecv all-to-all(v) on the library's stream; *out = the rows this rank received.
- *                        rows_sent / bytes_sent: what left this rank over the fabric.
- *   plx_allgather_frame  concatenation of every rank's (small) frame in rank order, on every rank.                     */
+ *   plx_exchange_by_key  every row of `frame` goes to rank plx_hash_partition(key) -- rows with a NULL key to rank 0
+ *                        (null_partition(), hashing.rs:111-115); all columns travel in ONE grouped ncclSend / ncclRecv
+ *                        all-to-all(v) on the library's stream (nullable and Boolean columns included: validity bitmaps and
+ *                        bit-packed values cross as one byte per row and are re-packed on receipt); ONE host round trip
+ *                        (the [world x world] row counts, for the receive allocations), no synchronisation at the end;
+ *                        *out = the rows this rank received.  rows_sent / bytes_sent: what left this rank over the fabric.
+ *                        The sharded group-by calls it on PARTIAL aggregate rows (polars_amd/dist.py sharded_groupby:
+ *                        local pre-aggregation first, group_by.rs:140-497), the sharded join on rows.
+ *   plx_allgather_frame  concatenation of every rank's (small) frame in rank order, on every rank (same column kinds).  */
 typedef uint64_t plx_comm;
 int plx_comm_unique_id(uint8_t* out_128_bytes);
 int plx_comm_init(const uint8_t* unique_id_128_bytes, int32_t rank, int32_t world_size, plx_comm* out);

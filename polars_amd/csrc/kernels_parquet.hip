@@ -81,8 +81,8 @@ __global__ __launch_bounds__(kSnapLanes) void pq_snappy_kernel(const DecompJob* 
     for (int i = 0; i < 11; i++) atomicAdd(dbg + i, (unsigned long long)t_acc[i]);
 }
 
-// second generation (PLX_SNAPPY_KERNEL=2): the same rounds with the batched-load bodies of next / mark / rank / jump (parquet_snappy.hpp); not the default
-// until it has been timed against the first on hardware
+// second generation (the default; PLX_SNAPPY_KERNEL=1 selects the first): the same rounds with the batched-load bodies of next / mark / rank / jump
+// (parquet_snappy.hpp); timed against the first on hardware in round 3: 42.6 vs 51.4 ms
 __global__ __launch_bounds__(kSnapLanes) void pq_snappy_kernel_v2(const DecompJob* __restrict__ jobs, uint32_t n_jobs, uint32_t* __restrict__ err,
                                                                unsigned long long* __restrict__ dbg) {
   __shared__ SnapShared sh;
@@ -206,7 +206,9 @@ void pq_snappy(const DecompJob* jobs, uint32_t n_jobs, uint64_t bytes_out, uint3
   if (timing) dbg = dev_alloc_zero(11 * 8);
   {
     ProfileScope ps("pq_snappy", bytes_out * 2, n_jobs);
-    static const bool v2 = [] { const char* e = getenv("PLX_SNAPPY_KERNEL"); return e && e[0] == '2'; }();
+    // generation 2 (batched LDS loads) is the default since round 3: 42.6 vs 51.4 ms of pq_snappy on the 2e7-row file (gpurun_out/r03a), bit-identical
+    // output on every stream of the GPU and CPU suites; PLX_SNAPPY_KERNEL=1 selects the first generation
+    static const bool v2 = [] { const char* e = getenv("PLX_SNAPPY_KERNEL"); return !(e && e[0] == '1'); }();
     if (v2) hipLaunchKernelGGL(pq_snappy_kernel_v2, dim3(n_jobs), dim3(kSnapLanes), 0, stream(), jobs, n_jobs, err, timing ? dbg->as<unsigned long long>() : nullptr);
     else hipLaunchKernelGGL(pq_snappy_kernel, dim3(n_jobs), dim3(kSnapLanes), 0, stream(), jobs, n_jobs, err, timing ? dbg->as<unsigned long long>() : nullptr);
     PLX_HIP(hipGetLastError());

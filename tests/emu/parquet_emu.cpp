@@ -31,8 +31,8 @@ uint32_t snappy_stream(const DecompJob& job, int order, uint32_t* rounds) {
   memset(&sh, 0xA5, sizeof sh);     // LDS is not zeroed
   snappy_begin(sh, job);
   uint32_t nr = 0;
-  const char* gen = getenv("PLX_SNAPPY_KERNEL");      // "2": the bodies of pq_snappy_kernel_v2
-  const bool v2 = gen && gen[0] == '2';
+  const char* gen = getenv("PLX_SNAPPY_KERNEL");      // default (as in the product): the bodies of pq_snappy_kernel_v2; "1": the first generation
+  const bool v2 = !(gen && gen[0] == '1');
   while (sh.done == 0) {
     nr++;
     for_lanes(order, [&](uint32_t lane) { snappy_stage(sh, job, lane); });

@@ -3,19 +3,21 @@
 # (FETCH_SIZE and WRITE_SIZE in SEPARATE passes: they do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"; never
 # combined with sys/hip/hsa tracing).  usage (GPU box): bash tools/pmc_all.sh <tag> [workloads...]  -> gpurun_out/<tag>/profiles/
 TAG=${1:-r02p}; shift
-WLS=${@:-q1 q3 q3f cfg2 cfg3 cfg5}
+WLS=${@:-q1 q3 q3s q3f cfg2 cfg3 cfg5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 P=$OUT/profiles
 mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
 for WL in $WLS; do
-  PLX_BENCH_VERIFY=0 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -o $WL -- python $R/bench.py --workload $WL --steps 10 --warmup 2 --no-extras --no-cpu > $OUT/stats_$WL.json 2> $OUT/stats_$WL.err
+  BWL=$WL; unset PLX_Q3_SHUFFLED
+  if [ "$WL" = "q3s" ]; then BWL=q3; export PLX_Q3_SHUFFLED=1; fi      # Q3 over both tables in a seeded random row order (the partitioned probe)
+  PLX_BENCH_VERIFY=0 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -o $WL -- python $R/bench.py --workload $BWL --steps 10 --warmup 2 --no-extras --no-cpu > $OUT/stats_$WL.json 2> $OUT/stats_$WL.err
   echo "stats $WL exit $?"
   f=$(find $OUT/stats_$WL -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $P/${WL}_kernel_stats.csv && head -5 $f | cut -c1-160
   grep -h '^{' $OUT/stats_$WL.json | tail -1 > $P/${WL}_bench_line_same_session.json
   for C in FETCH_SIZE WRITE_SIZE; do
-    PLX_BENCH_VERIFY=0 timeout 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${WL}_$C -o pmc -- python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-extras --no-cpu > $OUT/pmc_${WL}_$C.log 2>&1
+    PLX_BENCH_VERIFY=0 timeout 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${WL}_$C -o pmc -- python $R/bench.py --workload $BWL --steps 3 --warmup 1 --no-extras --no-cpu > $OUT/pmc_${WL}_$C.log 2>&1
     echo "pmc $WL $C exit $?"
   done
   ff=$(find $OUT/pmc_${WL}_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(find $OUT/pmc_${WL}_WRITE_SIZE -name "*counter_collection.csv" | head -1)

@@ -30,7 +30,7 @@ def scope_of(kernel: str):
     with the very instantiation it timed."""
     m = re.search(r"fused_scan_kernel<.*StatProg<(\d+)>", kernel)
     sid = m.group(1) if m else None
-    m = re.search(r"part3_scatter_kernel<.*StatProg<(\d+)>\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*>", kernel)
+    m = re.search(r"part3_scatter_kernel<.*StatProg<(\d+)>\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*(?:,\s*(?:true|false)\s*)?>", kernel)
     if m:
         return f"part3_scatter[#{m.group(1)},{'d' if m.group(2) == '1' else 'h'},t{m.group(3)},p{m.group(4)}]"
     m = re.search(r"part2_scatter_kernel<.*StatProg<(\d+)>\s*,\s*(\d+)\s*,\s*(\d+)\s*>", kernel)
