@@ -591,7 +591,7 @@ def timed(pl, wl: Workload, steps: int, warmup: int, distributed: bool, combine=
     stats = kernel_stats(pl)
     F.check(F.lib().plx_profile_enable(0))
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, stats, res, cold_ms
@@ -1375,12 +1375,15 @@ def run(args, emit):
     if (distributed or args.dry_run) and args.workload in ("cfg3", "cfg5"):
         run_sharded(args, emit)
         return
-    torch.cuda.set_device(local_rank)
+    # PLX_BENCH_DEVICE / PLX_DIST_BACKEND: smoke runs of the N > 1 control flow on a ONE-GPU box (every rank on device 0, torch.distributed over gloo);
+    # never set by the driver: one rank per GPU over RCCL is the measured configuration
+    dev = int(os.environ.get("PLX_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev)
     import polars_amd as pl
     from polars_amd import dist as pdist
-    pl.init(local_rank)
+    pl.init(dev)
     if distributed:
-        pdist.init_process_group("nccl")
+        pdist.init_process_group(os.environ.get("PLX_DIST_BACKEND", "nccl"))
     seed = 10 + rank
     rows = args.rows
     if distributed and args.scaling == "strong" and not rows:

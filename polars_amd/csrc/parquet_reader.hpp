@@ -112,9 +112,9 @@ inline LeafType leaf_type(const Leaf& l) {
   }
 }
 
-// host threads for page-sized tasks: half the hardware threads (the other half is the caller's: other columns, the GPU driver), 2 .. 128 (PLX_HOST_THREADS overrides the cap)
+// host threads for page-sized tasks: half the hardware threads (the other half is the caller's: other columns, the GPU driver), 2 .. 64 (PLX_HOST_THREADS overrides the cap; 128 measured no faster on a 256-thread host)
 inline size_t host_threads(size_t tasks) {
-  static const size_t cap = [] { const char* e = getenv("PLX_HOST_THREADS"); const long v = e ? atol(e) : 0; return v >= 1 && v <= 1024 ? (size_t)v : (size_t)128; }();
+  static const size_t cap = [] { const char* e = getenv("PLX_HOST_THREADS"); const long v = e ? atol(e) : 0; return v >= 1 && v <= 1024 ? (size_t)v : (size_t)64; }();
   return std::min<size_t>(std::min<size_t>(cap, std::max(2u, std::thread::hardware_concurrency() / 2)), tasks);
 }
 
