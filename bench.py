@@ -1276,6 +1276,9 @@ def run_sharded(args, emit):
         import polars_amd as pl
         pl.init(local_rank)
         pdist.init_process_group("nccl")
+        if not dist.is_initialized():                            # world size 1 (smoke run): the barriers / reductions below still want a group
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+            dist.init_process_group("nccl", rank=0, world_size=1)
         wl0 = make_workload(pl, args.workload, n, seed=seed)      # this rank's shard, from the library's generator
         df = wl0.step()[1][0]
         comm, ops = pdist.LibComm(pl), pdist.LibFrameOps(pl)
@@ -1285,8 +1288,9 @@ def run_sharded(args, emit):
         column_sum = lambda: df.lazy().select(pl.col(val_name).sum().alias("s")).collect()["s"].to_list()[0]
         result_cols = lambda r: {c: r[c].to_numpy() for c in r.columns}
     res, info = None, {}
+    force = os.environ.get("PLX_BENCH_FORCE_SHARDED") == "1"
     for _ in range(max(args.warmup, 1)):
-        res = pdist.sharded_groupby(comm, df, spec, ops, mode=args.mode, info=info)
+        res = pdist.sharded_groupby(comm, df, spec, ops, mode=args.mode, info=info, always_exchange=force)
     if not dry:
         F.check(F.lib().plx_profile_clear()); F.check(F.lib().plx_profile_enable(1))
     comm.rows_sent = comm.bytes_sent = 0
@@ -1295,7 +1299,7 @@ def run_sharded(args, emit):
     gc.collect(); gc.disable()          # see timed(): the harness must not collect inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = pdist.sharded_groupby(comm, df, spec, ops, mode=args.mode, info=info)
+        res = pdist.sharded_groupby(comm, df, spec, ops, mode=args.mode, info=info, always_exchange=force)
     sync(); dist.barrier()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -1372,8 +1376,8 @@ def run(args, emit):
     import torch
     rank, local_rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     distributed = ws > 1
-    if (distributed or args.dry_run) and args.workload in ("cfg3", "cfg5"):
-        run_sharded(args, emit)
+    if (distributed or args.dry_run or os.environ.get("PLX_BENCH_FORCE_SHARDED") == "1") and args.workload in ("cfg3", "cfg5"):
+        run_sharded(args, emit)      # PLX_BENCH_FORCE_SHARDED=1: the sharded operator at world size 1 (a self-exchange through RCCL: smoke run on a one-GPU box)
         return
     # PLX_BENCH_DEVICE / PLX_DIST_BACKEND: smoke runs of the N > 1 control flow on a ONE-GPU box (every rank on device 0, torch.distributed over gloo);
     # never set by the driver: one rank per GPU over RCCL is the measured configuration

@@ -15,6 +15,7 @@
 // which is why rows are exchanged in one grouped operation rather than rank by rank.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -67,6 +68,17 @@ void nccl_check(int rc, const char* what) {
 }
 
 struct Comm { NcclComm nccl = nullptr; int rank = 0, ws = 1; };
+
+// One ncclSend / ncclRecv carries at most kP2PChunk bytes.  Measured on RCCL 2.26.6 (MI355X, gpurun_out/r03x, tools/debug_exchange2.py): a transfer of more than
+// 2^30 bytes delivers only its first half -- 134e6 rows x 8 B arrive whole, 135e6 rows leave 67.5e6 zero rows behind, no error code.  Larger transfers
+// are cut into pieces of 2^29 bytes inside the same group; both sides derive the piece count from the same byte count, so sends and receives pair up.
+constexpr size_t kP2PChunk = size_t(1) << 29;
+void send_chunked(const uint8_t* src, size_t bytes, int peer, Comm& c) {
+  for (size_t o = 0; o < bytes; o += kP2PChunk) nccl_check(rccl().Send(src + o, std::min(kP2PChunk, bytes - o), kNcclUint8, peer, c.nccl, stream()), "ncclSend");
+}
+void recv_chunked(uint8_t* dst, size_t bytes, int peer, Comm& c) {
+  for (size_t o = 0; o < bytes; o += kP2PChunk) nccl_check(rccl().Recv(dst + o, std::min(kP2PChunk, bytes - o), kNcclUint8, peer, c.nccl, stream()), "ncclRecv");
+}
 std::mutex g_comm_mu;
 std::vector<std::unique_ptr<Comm>> g_comms;   // handle = index + 1
 
@@ -167,7 +179,7 @@ void info(uint64_t h, int* rank, int* ws) { Comm& c = get_comm(h); if (rank) *ra
 // left this rank over the fabric (rows kept locally do not count).  Host round trips: ONE (the [ws x ws] counts + the per-column
 // "some rank has nulls here" flags, needed for the receive allocations); the transfers are one ncclGroup = one fused RCCL kernel over
 // all seven xGMI links, so columns are not packed into a per-peer staging buffer (that would add two D2D passes over the payload and
-// save nothing on the wire).  Everything is ordered on the library's stream: no synchronisation at the end.
+// save nothing on the wire).  One stream synchronisation at the end (the staged buffers are recycled by the pool after it).
 FramePtr exchange_by_key(uint64_t h, const FramePtr& in, const std::string& key, uint64_t seed, uint64_t* rows_sent, uint64_t* bytes_sent) {
   Comm& c = get_comm(h);
   const int ws = c.ws;
@@ -205,14 +217,19 @@ FramePtr exchange_by_key(uint64_t h, const FramePtr& in, const std::string& key,
       const uint8_t* src = (const uint8_t*)wires[wi].data->values->ptr;
       uint8_t* dst = (uint8_t*)recv[wi]->values->ptr;
       for (int p = 0; p < ws; p++) {
-        if (send_cnt[p]) nccl_check(rccl().Send(src + (size_t)send_off[p] * w, (size_t)send_cnt[p] * w, kNcclUint8, p, c.nccl, stream()), "ncclSend");
-        if (recv_cnt[p]) nccl_check(rccl().Recv(dst + (size_t)recv_off[p] * w, (size_t)recv_cnt[p] * w, kNcclUint8, p, c.nccl, stream()), "ncclRecv");
+        if (send_cnt[p]) send_chunked(src + (size_t)send_off[p] * w, (size_t)send_cnt[p] * w, p, c);
+        if (recv_cnt[p]) recv_chunked(dst + (size_t)recv_off[p] * w, (size_t)recv_cnt[p] * w, p, c);
         if (p != c.rank) moved_bytes += (uint64_t)send_cnt[p] * w;
       }
     }
     nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
   }
   for (int p = 0; p < ws; p++) if (p != c.rank) moved_rows += (uint64_t)send_cnt[p];
+  // The staged (gathered) wires go back to the pool when this returns.  The pool recycles in stream order, but whether every transfer of an RCCL group
+  // is ordered on the caller's stream alone is RCCL's business (proxy threads, internal streams for local copies): wait for the exchange before the
+  // buffers can be handed out again.  The consumer of the exchanged frame needs it finished anyway; PLX_COMM_NO_SYNC=1 skips the wait (measurement only).
+  static const bool no_sync = getenv("PLX_COMM_NO_SYNC") != nullptr;
+  if (!no_sync) PLX_HIP(hipStreamSynchronize(stream()));
   auto out = std::make_shared<Frame>();
   out->height = n_out; out->names = in->names;
   size_t wi = 0;
@@ -248,12 +265,13 @@ FramePtr allgather_frame(uint64_t h, const FramePtr& in) {
     const size_t w = wires[wi].width;
     uint8_t* dst = (uint8_t*)recv[wi]->values->ptr;
     for (int p = 0; p < ws; p++) {
-      if (in->height) nccl_check(rccl().Send(wires[wi].data->values->ptr, (size_t)in->height * w, kNcclUint8, p, c.nccl, stream()), "ncclSend");
+      if (in->height) send_chunked((const uint8_t*)wires[wi].data->values->ptr, (size_t)in->height * w, p, c);
       const int64_t n = all[(size_t)p * stride];
-      if (n) nccl_check(rccl().Recv(dst + (size_t)off[p] * w, (size_t)n * w, kNcclUint8, p, c.nccl, stream()), "ncclRecv");
+      if (n) recv_chunked(dst + (size_t)off[p] * w, (size_t)n * w, p, c);
     }
   }
   nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+  PLX_HIP(hipStreamSynchronize(stream()));       // as in exchange_by_key: the wires are recycled after this
   auto out = std::make_shared<Frame>();
   out->height = off[ws]; out->names = in->names;
   size_t wi = 0;

@@ -823,7 +823,17 @@ static void source_ranges(const Compiler& c, k::SrcRange out[kMaxSrc]) {
 }
 
 // The planner's sample of a key column (see Column::key_sample).
-struct KeySample { int64_t n_rows = 0, distinct = -1; double groups_est = 1e18; std::vector<uint64_t> hot; bool with_hot = false; };
+// `sig`: the program that produced the sampled key VALUES (ops + immediates): the same column enters as raw values on its first group-by and -- once its range has
+// been learned -- as packed ids (key - min) on the next; hot keys of one encoding never match rows of the other (a stale list is harmless for the result
+// -- the rows simply take the scatter -- but one key holding half of the rows then costs 28 ms of same-address LDS atomics instead of 0.1 ms)
+struct KeySample { int64_t n_rows = 0, distinct = -1; double groups_est = 1e18; std::vector<uint64_t> hot; bool with_hot = false; uint64_t sig = 0; };
+static uint64_t key_program_signature(const Shape& sh, const Args& args) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; } };
+  mix(&sh, sizeof(Shape));
+  mix(args.imm, sizeof(args.imm));
+  return h;
+}
 // the frame column a single-column group key reads directly, when the query has no predicate (then the sample depends on nothing else)
 static ColumnPtr plain_key_column(const Compiler& c, const KeyPlan& kp) {
   if (c.shape.pred != kNone || kp.parts.size() != 1) return nullptr;
@@ -839,7 +849,7 @@ static int64_t sample_keys_cached(const ColumnPtr& key_col, const Shape& sh, con
                                   std::string& desc) {
   if (key_col && sample_cache_enabled() && key_col->key_sample) {
     const KeySample& ks = *std::static_pointer_cast<KeySample>(key_col->key_sample);
-    if (ks.n_rows == args.n_rows && (ks.with_hot || !hot)) {
+    if (ks.n_rows == args.n_rows && (ks.with_hot || !hot) && ks.sig == key_program_signature(sh, args)) {
       if (hot) *hot = ks.hot;
       if (groups_est) *groups_est = ks.groups_est;
       desc += "cached_";
@@ -851,7 +861,7 @@ static int64_t sample_keys_cached(const ColumnPtr& key_col, const Shape& sh, con
   if (groups_est) *groups_est = g;
   if (key_col && sample_cache_enabled() && d >= 0) {
     auto ks = std::make_shared<KeySample>();
-    ks->n_rows = args.n_rows; ks->distinct = d; ks->groups_est = g; ks->with_hot = hot != nullptr;
+    ks->n_rows = args.n_rows; ks->distinct = d; ks->groups_est = g; ks->with_hot = hot != nullptr; ks->sig = key_program_signature(sh, args);
     if (hot) ks->hot = *hot;
     key_col->key_sample = ks;
   }

@@ -84,5 +84,15 @@ assert want3["v_mean"][i11] is None and want3["v_min"][i11] is None and want3["v
 info = {}
 pdist.sharded_groupby(comm, df, spec, fops, mode="auto", always_exchange=True, info=info)     # 1e6 rows over 5e4 keys: the sample predicts a 20x shrink
 assert info["mode"] == "preagg" and info["shrink_estimate"] > 8, info
+# a transfer of more than 2^30 bytes: RCCL 2.26 delivers only its first half in one ncclSend / ncclRecv (found by the round-3 smoke run's rank-0 check:
+# 135e6 rows x 8 B left 67.5e6 zero rows behind); comm.cpp cuts transfers into 2^29-byte pieces
+stage("exchange of > 2^30 bytes per column")
+big_n = 140_000_000
+big = pl.DataFrame([pl.Series("key", np.arange(big_n, dtype=np.int64) % 1_000_003), pl.Series("v", np.arange(big_n, dtype=np.int64))])
+moved = comm.exchange_by_key(big, "key")
+want_v, want_k = big_n * (big_n - 1) // 2, int((np.arange(big_n, dtype=np.int64) % 1_000_003).sum())
+chk = moved.lazy().select(pl.col("v").sum().alias("sv"), pl.col("key").sum().alias("sk"), pl.len().alias("n")).collect()
+assert chk["n"].to_list() == [big_n] and chk["sv"].to_list() == [want_v] and chk["sk"].to_list() == [want_k], chk.to_dict()
+del big, moved
 comm.close()
 print("RCCL_WORKER_OK")
