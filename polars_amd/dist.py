@@ -330,6 +330,7 @@ def estimate_shrink(rows: int, sample_rows: int, sample_distinct: int) -> float:
     return rows / max(1.0, g * -math.expm1(-rows / g))
 
 
+P2P_CHUNK_BYTES = 1 << 29        # largest per-peer segment of one all-to-all round on the torch path (exchange_by_key); the library path: comm.cpp kP2PChunk
 PREAGG_MIN_SHRINK = 8.0          # pre-aggregate before the exchange when the local group-by shrinks the shard at least this much
 PREAGG_SAMPLE_ROWS = 1 << 20
 
@@ -406,11 +407,32 @@ def exchange_by_key(ops: LocalOps, key, cols: Dict[str, object], seed: int = 0, 
     recv = torch.zeros_like(send)
     dist.all_to_all_single(recv, send, group=group)
     recv_counts = [int(x) for x in recv.tolist()]
+    # RCCL 2.26 delivers only the first half of a point-to-point transfer above 2^30 bytes (measured on MI355X, see comm.cpp kP2PChunk): a column whose
+    # per-peer segment is larger than P2P_CHUNK_BYTES goes in several rounds of row slabs; the round count is agreed across ranks
+    biggest = torch.tensor([max(counts + recv_counts + [0])], dtype=torch.int64, device=key.device)
+    dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
+    biggest = int(biggest.item())
+    send_off = [0] + list(np.cumsum(counts)); recv_off = [0] + list(np.cumsum(recv_counts))
     out = {}
     for name, t in cols.items():
         src = ops.take(t, perm).contiguous()
         dst = torch.empty(sum(recv_counts), dtype=t.dtype, device=t.device)
-        dist.all_to_all_single(dst, src, output_split_sizes=recv_counts, input_split_sizes=counts, group=group)
+        lim = max(1, P2P_CHUNK_BYTES // max(1, t.element_size()))
+        rounds = max(1, -(-biggest // lim))
+        if rounds == 1:
+            dist.all_to_all_single(dst, src, output_split_sizes=recv_counts, input_split_sizes=counts, group=group)
+        else:
+            for r in range(rounds):
+                ins = [min(max(c - r * lim, 0), lim) for c in counts]
+                outs = [min(max(c - r * lim, 0), lim) for c in recv_counts]
+                src_r = torch.cat([src[int(send_off[p]) + r * lim: int(send_off[p]) + r * lim + ins[p]] for p in range(ws)]) if sum(ins) else src[:0]
+                dst_r = torch.empty(sum(outs), dtype=t.dtype, device=t.device)
+                dist.all_to_all_single(dst_r, src_r.contiguous(), output_split_sizes=outs, input_split_sizes=ins, group=group)
+                at = 0
+                for p in range(ws):
+                    if outs[p]:
+                        dst[int(recv_off[p]) + r * lim: int(recv_off[p]) + r * lim + outs[p]] = dst_r[at: at + outs[p]]
+                    at += outs[p]
         out[name] = dst
     return out
 

@@ -61,6 +61,12 @@ def main():
     mine = torch.tensor([n, int(v.sum())], dtype=torch.int64)
     dist.all_reduce(tot); dist.all_reduce(mine)
     assert torch.equal(tot, mine), "rows or values lost in the all-to-all"
+    # (a') the same exchange in several rounds of row slabs (what a per-peer segment above 2^29 bytes triggers on RCCL): identical result
+    saved = pdist.P2P_CHUNK_BYTES
+    pdist.P2P_CHUNK_BYTES = 8 * 1000                              # 1000 rows of an int64 column per peer and round
+    moved2 = pdist.exchange_by_key(ops, key, {"key": key, "v": v})
+    pdist.P2P_CHUNK_BYTES = saved
+    assert torch.equal(moved2["key"], moved["key"]) and torch.equal(moved2["v"], moved["v"]), "chunked exchange differs from the single-round exchange"
     # (b) low-cardinality group-by: local partials + all-gather + combine (replicated result)
     g = pdist.groupby_agg(ops, {"flag": flag}, {"v": v, "x": x}, aggs, mode="gather")
     # (c) high-cardinality group-by: shuffle by key hash, result sharded by key
