@@ -193,7 +193,7 @@ FramePtr exchange_by_key(uint64_t h, const FramePtr& in, const std::string& key,
   Buf send = dev_alloc(sizeof(int64_t) * ((size_t)ws + nc));
   PLX_HIP(hipMemcpyAsync(send->ptr, counts_dev->ptr, sizeof(int64_t) * (size_t)ws, hipMemcpyDeviceToDevice, stream()));
   std::vector<int64_t> flags(nc, 0);
-  for (size_t i = 0; i < nc; i++) flags[i] = (in->cols[i]->validity && column_null_count(in->cols[i]) != 0) ? 1 : 0;
+  for (size_t i = 0; i < nc; i++) flags[i] = (in->cols[i]->validity && in->cols[i]->null_count != 0) ? 1 : 0;   // an unknown null count (-1) counts as "may have nulls": no popcount + host sync here
   if (nc) h2d_async((uint8_t*)send->ptr + sizeof(int64_t) * (size_t)ws, flags.data(), sizeof(int64_t) * nc);
   const size_t stride = (size_t)ws + nc;
   const std::vector<int64_t> all = allgather_i64(c, send, stride);    // all[r * stride + d] = rows rank r sends to rank d; [.. + ws + i] = rank r has nulls in column i
@@ -247,7 +247,7 @@ FramePtr allgather_frame(uint64_t h, const FramePtr& in) {
   const size_t nc = in->cols.size();
   std::vector<int64_t> mine(1 + nc, 0);
   mine[0] = in->height;
-  for (size_t i = 0; i < nc; i++) mine[1 + i] = (in->cols[i]->validity && column_null_count(in->cols[i]) != 0) ? 1 : 0;
+  for (size_t i = 0; i < nc; i++) mine[1 + i] = (in->cols[i]->validity && in->cols[i]->null_count != 0) ? 1 : 0;
   Buf send = dev_alloc(sizeof(int64_t) * mine.size());
   h2d_async(send->ptr, mine.data(), sizeof(int64_t) * mine.size());
   const size_t stride = mine.size();

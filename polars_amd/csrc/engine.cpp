@@ -847,8 +847,10 @@ static bool sample_cache_enabled() { static const bool v = [] { const char* e = 
 static int64_t sample_keys(const Shape& full, const Args& args, int static_id, int full_len_idx, int64_t S, std::vector<uint64_t>* hot, double* groups_est);
 static int64_t sample_keys_cached(const ColumnPtr& key_col, const Shape& sh, const Args& args, int static_id, int len_idx, int64_t S, std::vector<uint64_t>* hot, double* groups_est,
                                   std::string& desc) {
-  if (key_col && sample_cache_enabled() && key_col->key_sample) {
-    const KeySample& ks = *std::static_pointer_cast<KeySample>(key_col->key_sample);
+  // (atomic_load / atomic_store: two host threads may plan group-bys over the same column at once -- each on its own stream, core.cpp)
+  const std::shared_ptr<void> held = key_col && sample_cache_enabled() ? std::atomic_load(&key_col->key_sample) : nullptr;
+  if (held) {
+    const KeySample& ks = *std::static_pointer_cast<KeySample>(held);
     if (ks.n_rows == args.n_rows && (ks.with_hot || !hot) && ks.sig == key_program_signature(sh, args)) {
       if (hot) *hot = ks.hot;
       if (groups_est) *groups_est = ks.groups_est;
@@ -863,7 +865,7 @@ static int64_t sample_keys_cached(const ColumnPtr& key_col, const Shape& sh, con
     auto ks = std::make_shared<KeySample>();
     ks->n_rows = args.n_rows; ks->distinct = d; ks->groups_est = g; ks->with_hot = hot != nullptr; ks->sig = key_program_signature(sh, args);
     if (hot) ks->hot = *hot;
-    key_col->key_sample = ks;
+    std::atomic_store(&key_col->key_sample, std::shared_ptr<void>(ks));
   }
   return d;
 }
