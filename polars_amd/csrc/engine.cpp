@@ -1433,7 +1433,8 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       }
     }
   } catch (const Unsupported& u) { if (why) *why = u.why; return false; }
-  if (shapes_out) { shapes_out->push_back(cnt.shape); shapes_out->push_back(cb.shape); shapes_out->push_back(cp.shape); for (auto& cf : csemi) shapes_out->push_back(cf->shape); }
+  // count, build, probe, the semi filters' scans, and LAST the probe side's predicate + key program of the partitioned probe's scatter
+  if (shapes_out) { shapes_out->push_back(cnt.shape); shapes_out->push_back(cb.shape); shapes_out->push_back(cp.shape); for (auto& cf : csemi) shapes_out->push_back(cf->shape); shapes_out->push_back(cs.shape); }
   if (compile_only) {
     if (t_program_dump) {   // the three scans + how groups, group keys and outputs are derived from them (tests/program_eval.py evaluate_join)
       std::ostringstream o;
@@ -1538,7 +1539,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
         if (pk->order_state == 0) pk->order_state = k::sample_sortedness(pk) >= 0.9 ? 1 : 2;
         ColumnPtr hits;
         std::string pd;
-        if ((pmode == 2 || pk->order_state == 2) && k::partitioned_probe_hits(cs.shape, cs.args, dt, nb, &hits, &pd)) {
+        if ((pmode == 2 || pk->order_state == 2) && k::partitioned_probe_hits(cs.shape, cs.args, dt, nb, find_static_shape(cs.shape), &hits, &pd)) {
           if (hits->len > 0) {
             Args a2 = cp.args;
             a2.n_rows = hits->len;

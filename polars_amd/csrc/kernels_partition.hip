@@ -697,7 +697,7 @@ __global__ __launch_bounds__(kBlock) void probe_hits_compact_kernel(const unsign
   for (uint32_t i = threadIdx.x; i < part_hits[p]; i += blockDim.x) dst[i] = src[i];
 }
 
-bool partitioned_probe_hits(const Shape& sh, const Args& args, const DirectJoinTable& dt, uint64_t n_build, ColumnPtr* hits_out, std::string* desc) {
+bool partitioned_probe_hits(const Shape& sh, const Args& args, const DirectJoinTable& dt, uint64_t n_build, int static_id, ColumnPtr* hits_out, std::string* desc) {
   if (args.n_rows >= (int64_t)0xfffffff0ll || sh.n_aggs != 1 || sh.aggs[0].kind != AGG_FIRST_ROW || sh.key == kNone || sh.n_keys) return false;
   const uint32_t bits_total = std::max<uint32_t>(ceil_log2(dt.range), 15);
   PartPlan2 pp{};
@@ -720,7 +720,12 @@ bool partitioned_probe_hits(const Shape& sh, const Args& args, const DirectJoinT
   // a Bloom filter of 2^20 bits with 4 probes stays under ~2 % false positives up to 2^17 keys: denser slices would flood the caller with candidates
   if (!exact && (double)n_build * (double)((uint64_t)1 << pp.key_shift) / (double)dt.range > (double)(1u << 17)) return false;
   const jit::Sink jk = jit::part3_scatter_sink(pp.mode, pp.tiles, pp.pack, false);
-  if (!jit::ensure(sh, jk, args.n_rows)) return false;
+#ifdef PLX_HAVE_Q3_PROBE_SCATTER
+  const bool aot = static_id == SHAPE_Q3_PROBE_SCATTER && pp.tiles == 4;       // TPC-H Q3's probe side (two- and three-table variants share it)
+#else
+  const bool aot = false;
+#endif
+  if (!aot && !jit::ensure(sh, jk, args.n_rows)) return false;
   const uint32_t chunk_dw = kP2ChunkRecs * pp.rec_words;
   const int64_t n_chunks = (int64_t)pp.scatter_grid * pp.chunks_per_wg;
   Buf recs = dev_alloc((size_t)n_chunks * chunk_dw * 4 + 256);
@@ -730,11 +735,19 @@ bool partitioned_probe_hits(const Shape& sh, const Args& args, const DirectJoinT
   ScatterParams2 sp{};
   sp.recs = recs->as<unsigned int>(); sp.chunk_part = chunk_part->as<unsigned int>(); sp.chunk_fill = chunk_fill->as<unsigned int>(); sp.flags = meta->as<unsigned int>() + 3;
   {
-    ProfileScope ps("probe_scatter[jit]", scan_bytes(sh, args) + (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
+    const std::string name = aot ? "probe_scatter[#" + std::to_string(static_id) + ",d,t4,p3]" : std::string("probe_scatter[jit]");
+    ProfileScope ps(name.c_str(), scan_bytes(sh, args) + (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
     const size_t slds = part3_scatter_lds(pp.block * kRows * pp.tiles, pp.rec_words, NP, 0, 0, sh.n_aggs, 1);
-    Shape shc = sh; Args ac = args; PartPlan2 ppc = pp; ScatterParams2 spc = sp;
-    void* ka[] = {&shc, &ac, &ppc, &spc};
-    PLX_REQUIRE(jit::launch_raw(sh, jk, ka, (int)pp.scatter_grid, (int)pp.block, slds), PLX_ERR_HIP, "jit launch failed (probe scatter)");
+    if (aot) {
+#ifdef PLX_HAVE_Q3_PROBE_SCATTER
+      hipLaunchKernelGGL((part3_scatter_kernel<StatProg<SHAPE_Q3_PROBE_SCATTER>, (int)kP2Direct, 4, (int)kPackRowid, false>), dim3(pp.scatter_grid), dim3(pp.block), slds, stream(), sh, args, pp, sp);
+      PLX_HIP(hipGetLastError());
+#endif
+    } else {
+      Shape shc = sh; Args ac = args; PartPlan2 ppc = pp; ScatterParams2 spc = sp;
+      void* ka[] = {&shc, &ac, &ppc, &spc};
+      PLX_REQUIRE(jit::launch_raw(sh, jk, ka, (int)pp.scatter_grid, (int)pp.block, slds), PLX_ERR_HIP, "jit launch failed (probe scatter)");
+    }
   }
   Buf counts = dev_alloc_zero(sizeof(uint32_t) * (NP + 1)), cursor = dev_alloc_zero(sizeof(uint32_t) * (NP + 1));
   Buf cl_off = dev_alloc(sizeof(uint64_t) * (NP + 2)), cl_ids = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks);

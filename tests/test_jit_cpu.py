@@ -40,7 +40,7 @@ def test_join_groupby_pipeline():
     q = (t.lazy().filter(pl.col("a") > 0).join(small.lazy().filter(pl.col("pay") < 3), on="k").group_by("k", "pay")
          .agg((pl.col("x") * 0.5).sum().alias("s"), pl.len()))
     fusable, sid, why, dump = q.describe_fusion()
-    assert fusable and sid == -1 and dump.count("\n") == 2, (why, dump)     # count / build / probe programs
+    assert fusable and sid == -1 and dump.count("\n") == 3, (why, dump)     # count / build / probe programs + the scatter program of the partitioned probe
     q.jit_selftest()
 
 

@@ -317,7 +317,7 @@ def test_q3_three_tables_pipeline_matches_oracle(orc):
     ccols = {k: (cust[k], None) for k in datagen.CUSTOMER_Q3_COLS}
     lf = Q.q3_full(frame_like(ccols, lt).lazy(), frame_like(ocols, lt).lazy(), frame_like(lcols, lt).lazy())
     ok, sid, why, dump = lf.describe_fusion()
-    assert ok and dump.count("\n") == 3, (why, dump)                       # count / build / probe / semi filter
+    assert ok and dump.count("\n") == 4, (why, dump)                       # count / build / probe / semi filter / the partitioned probe's scatter
     prog = lf.debug_program()
     assert prog["kind"] == "join_group_by" and prog["build_key"] == "o_orderkey" and prog["probe_key"] == "l_orderkey"
     assert [g["name"] for g in prog["group_keys"]] == ["o_orderkey", "o_orderdate", "o_shippriority"]

@@ -54,6 +54,7 @@ def shapes():
         ("SHAPE_Q3F_COUNT", "TPC-H Q3 (three tables) build side count: o_orderdate predicate AND membership of o_custkey in the BUILDING customers' bitmap", q3f, 0),
         ("SHAPE_Q3F_BUILD", "TPC-H Q3 (three tables) build scan: same predicate, o_orderkey -> row", q3f, 1),
         ("SHAPE_Q3F_SEMI", "TPC-H Q3 (three tables) customer scan: c_mktsegment == code -> membership bitmap over c_custkey", q3f, 3),
+        ("SHAPE_Q3_PROBE_SCATTER", "TPC-H Q3 probe side, predicate + key only, row id as payload: the scatter of the partitioned probe (unordered probe keys)", q3, 3),
     ]
 
 
@@ -110,7 +111,7 @@ def main():
     items = shapes()
     for i, (name, doc, _, _) in enumerate(items):
         out.append(f"  {name} = {i},  // {doc}\n")
-    out.append("  kNumStaticShapes\n};\n#define PLX_HAVE_Q3_SHAPES 1\n#define PLX_HAVE_Q3FULL_SHAPES 1\n\nPLX_HD constexpr Shape static_shape(int id) {\n  Shape s{};\n  s.pred = kNone;\n  s.key = kNone;\n  switch (id) {\n")
+    out.append("  kNumStaticShapes\n};\n#define PLX_HAVE_Q3_SHAPES 1\n#define PLX_HAVE_Q3FULL_SHAPES 1\n#define PLX_HAVE_Q3_PROBE_SCATTER 1\n\nPLX_HD constexpr Shape static_shape(int id) {\n  Shape s{};\n  s.pred = kNone;\n  s.key = kNone;\n  switch (id) {\n")
     for name, doc, q, which in items:
         ok, sid, why, dump = q.describe_fusion()
         if not ok:
