@@ -499,14 +499,17 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
         return Workload("cfg5_dict_string_keys_1e9", n, n * 12 + 1_000_000 * 20, step, "part_scatter", f"config 5: {n} rows, 1e6 dictionary-encoded string keys (u32 codes), group_by(k).agg(sum, mean)",
                         verify=verify, scope="operator")
     if name == "cfg5s":
-        # config 5 starting from RAW Utf8View keys (16-byte views of the 12-byte strings "id%010d", generated in HBM): every step encodes
-        # the views into dictionary codes on the device (plx_strview_dict_encode_device) and then runs the dense-id group-by
+        # config 5 starting from RAW Utf8View keys (16-byte views of the 12-byte strings "id%010d", generated in HBM): every step groups on the
+        # views themselves (plx_strview_groupby: rows partitioned by the view's hash, LDS tables keyed by the view; the distinct views are the
+        # result's dictionary).  PLX_BENCH_CFG5S_ENCODE=1: the route of rounds 2-3 -- encode the views to dictionary codes on the device
+        # (plx_strview_dict_encode_device), then the dense-id group-by.
         n = rows or 1_000_000_000
         views = datagen.id_views_native(pl, "k", n, seed, 0, 1, 1_000_001)
         v = native_uniform_column(pl, "v", pl.Float64, "Float64", n, seed, 1, 0, 10 ** 9, 1e-7)
+        encode_first = os.environ.get("PLX_BENCH_CFG5S_ENCODE") == "1"
 
         def step():
-            k = pl.Series.from_device_views("k", views)
+            k = pl.Series.from_device_views("k", views, encode="eager" if encode_first else "deferred")
             return queries.cfg5(pl.DataFrame([k, v]).lazy()).collect(), (views, v, k)
 
         def verify(res, budget):
@@ -520,8 +523,9 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
             codes = res["k"].to_numpy()
             frame = {"k": Mapped(ids[codes] - 1), "v_sum": res["v_sum"], "v_mean": res["v_mean"]}
             return verify_groupby_dense(frame, "k", "v_sum", n, seed, 1_000_000, "Int64", "Float64", (0, 10 ** 9, 1e-7), ("mean", "v_mean"), budget, key_args=(1, 1_000_001), key_shift=-1)
-        return Workload("cfg5_utf8view_keys_1e9", n, n * 24 + 1_000_000 * 28, step, "strview_dict_encode",
-                        f"config 5 from raw strings: {n} rows, Utf8View keys (16-byte views of 1e6 distinct 12-byte strings) -> device-side dictionary encoding -> group_by(k).agg(sum, mean)",
+        return Workload("cfg5_utf8view_keys_1e9", n, n * 24 + 1_000_000 * 28, step, "strview_dict_encode" if encode_first else "strgroup_scatter",
+                        f"config 5 from raw strings: {n} rows, Utf8View keys (16-byte views of 1e6 distinct 12-byte strings) -> " +
+                        ("device-side dictionary encoding -> group_by(k).agg(sum, mean)" if encode_first else "group_by(k).agg(sum, mean) on the views (string-key operator)"),
                         verify=verify, scope="operator")
     raise ValueError(name)
 

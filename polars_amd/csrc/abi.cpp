@@ -967,6 +967,32 @@ int plx_strview_dict_encode_device(plx_column views_u64_pairs, plx_column data_u
   // the dictionary's views point into nothing else than `data`; inline strings need no buffer at all
   PLX_CATCH
 }
+int plx_strview_groupby(plx_column views_u64_pairs, plx_column value, plx_column* out_codes, plx_strdict* out_dict, plx_column* out_sum, plx_column* out_count, plx_column* out_len) {
+  PLX_TRY
+  PLX_REQUIRE(out_codes && out_dict && out_sum && out_count && out_len, PLX_ERR_INVALID, "null pointer");
+  ColumnPtr v = get_column(views_u64_pairs), x = get_column(value);
+  PLX_REQUIRE(v->dtype == PLX_U64 && v->len % 2 == 0, PLX_ERR_INVALID, "views must be a UInt64 column of 2 n words");
+  const int64_t n = v->len / 2;
+  PLX_REQUIRE(x->len == n, PLX_ERR_SHAPE, "value column and views differ in length");
+  if (n == 0 || (x->dtype != PLX_F64 && x->dtype != PLX_I64)) fail(PLX_ERR_UNSUPPORTED, "string group-by fast path: one Float64 / Int64 value column over a non-empty key");
+  Buf gviews, gsum, gcnt, glen;
+  std::string desc;
+  const int64_t G = k::strview_groupby(v->values->as<uint64_t>(), x->values->as<uint64_t>(), x->validity ? x->valid_words() : nullptr, n, x->dtype == PLX_F64, &gviews, &gsum, &gcnt, &glen, &desc);
+  if (G < 0) fail(PLX_ERR_UNSUPPORTED, "string group-by fast path not applicable (a string longer than 12 bytes, or more distinct strings than its LDS tables hold)");
+  auto col = [&](int dtype, const Buf& b) { auto c = std::make_shared<Column>(); c->dtype = dtype; c->len = G; c->values = b; c->null_count = 0; return c; };
+  ColumnPtr codes = make_column(PLX_U32, G, false);
+  codes->null_count = 0;
+  if (G) { k::fill_iota_u32(codes->values->as<uint32_t>(), G); codes->range_state = 1; codes->range_min = 0; codes->range_max = G - 1; codes->range_trusted = true; }
+  auto d = std::make_unique<StrDict>();
+  d->views = gviews; d->data = nullptr; d->n = G;
+  *out_codes = register_column(codes);
+  *out_dict = register_strdict(std::move(d));
+  *out_sum = register_column(col(x->dtype, gsum));
+  *out_count = register_column(col(PLX_U32, gcnt));
+  *out_len = register_column(col(PLX_U32, glen));
+  t_plan_desc = "StringViewGroupBy{" + desc + ", rows=" + std::to_string(n) + ", groups=" + std::to_string(G) + "}; ";
+  PLX_CATCH
+}
 int plx_strdict_info(plx_strdict dict, int64_t* n_strings, int64_t* total_bytes) {
   PLX_TRY
   StrDict& d = get_strdict(dict);

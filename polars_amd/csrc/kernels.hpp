@@ -1,6 +1,7 @@
 // kernels.hpp -- host-callable launchers of the hand-written gfx950 kernels.
 // Every launcher enqueues on plx::stream() and returns immediately unless noted.
 #pragma once
+#include <string>
 #include "core.hpp"
 #include "kconfig.hpp"
 
@@ -56,6 +57,9 @@ void strview_dict_encode(const uint64_t* views, const uint64_t* validity, const 
 // monotonic, leaves the data buffer or a long string starts beyond 4 GiB.
 void strviews_from_offsets(const void* offsets, bool large, const uint8_t* data, uint64_t data_base, int64_t data_len, int64_t n, uint64_t* views_out, const uint64_t* validity, int64_t row0,
                            unsigned int* err);
+// group_by(raw Utf8View key).agg(sum / count / len of one 8-byte numeric column) without a dictionary-encode pass (kernels_strgroup.hip); -1 = not on the fast path
+int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uint64_t* val_validity, int64_t n, bool is_f64, Buf* out_views, Buf* out_sum, Buf* out_cnt, Buf* out_len,
+                        std::string* desc);
 void strdict_materialise(const uint64_t* dict_views, const uint8_t* data, int64_t n, Buf* out_offsets, Buf* out_bytes, uint64_t* total_bytes);
 // synthetic Utf8View column (benchmark support): the inline view of "id%010d" % value for value = lo + floor(U * (hi - lo)) of row i
 void datagen_id_views(int64_t n, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, uint64_t* out_views);

@@ -26,9 +26,14 @@ class Series:
     """A named device-resident column (handle into libpolars_amd)."""
 
     def __init__(self, name: str = "", values: Any = None, dtype: Optional[T.DataType] = None, validity: Any = None, *, _handle: int = 0,
-                 _dtype: Optional[T.DataType] = None, _keepalive: Any = None):
+                 _dtype: Optional[T.DataType] = None, _keepalive: Any = None, _raw: Any = None):
         self.name = name
         self._keepalive = _keepalive
+        self._raw = None                  # (views, data) of a Utf8View column whose dictionary encoding is deferred (from_device_views(encode="deferred"))
+        self._hh, self._dt = 0, None
+        if _raw is not None:
+            self._raw = _raw
+            return
         if _handle:
             self._h = _handle
             self.dtype = _dtype if _dtype is not None else self._query_dtype()
@@ -37,6 +42,40 @@ class Series:
         F.ensure_init()
         self._h, self.dtype = _upload(values, dtype, validity)
         self._declare_dictionary_bounds()
+
+    # The column handle and the dtype are attributes of every Series; for a Utf8View column with deferred encoding they come into being
+    # (plx_strview_dict_encode_device) the first time anything asks for them -- a group-by keyed on the column that the string-key operator
+    # can serve (LazyFrame.collect -> _string_key_group_by) never does.
+    @property
+    def _h(self) -> int:
+        if not self._hh and self._raw is not None:
+            self._encode_raw()
+        return self._hh
+
+    @_h.setter
+    def _h(self, v: int) -> None:
+        self._hh = v
+
+    @property
+    def dtype(self) -> T.DataType:
+        if self._dt is None and self._raw is not None:
+            self._encode_raw()
+        return self._dt
+
+    @dtype.setter
+    def dtype(self, v) -> None:
+        self._dt = v
+
+    def _encode_raw(self) -> None:
+        views, data = self._raw
+        codes, d = C.c_uint64(), C.c_uint64()
+        F.check(F.lib().plx_strview_dict_encode_device(views._h, data._h if data is not None else 0, C.byref(codes), C.byref(d)))
+        self._hh, self._dt = codes.value, T.Categorical(DeviceDictionary(d.value), T.UInt32)
+        self._declare_dictionary_bounds()
+
+    def _is_raw_views(self) -> bool:
+        """A Utf8View column not (yet) dictionary-encoded."""
+        return self._raw is not None and not self._hh
 
     def _declare_dictionary_bounds(self) -> None:
         """Dictionary codes lie in [0, len(categories)): tell the planner (plx_column_set_bounds), which then groups / joins
@@ -119,10 +158,18 @@ class Series:
         return cls(name, _handle=codes.value, _dtype=T.Categorical(DeviceDictionary(d.value, binary=pa.types.is_binary_view(arr.type)), T.UInt32))
 
     @classmethod
-    def from_device_views(cls, name: str, views: "Series", data: "Optional[Series]" = None) -> "Series":
+    def from_device_views(cls, name: str, views: "Series", data: "Optional[Series]" = None, *, encode: str = "eager") -> "Series":
         """Utf8View column whose views already sit in HBM (a UInt64 Series of 2 n words; `data`: a UInt8 Series with the long
-        strings' bytes, or None when every string is <= 12 bytes) -> dictionary column, encoded on the device."""
+        strings' bytes, or None when every string is <= 12 bytes) -> dictionary column, encoded on the device.
+        encode="deferred": the column stays a column of views until an operator needs dictionary codes; group_by(<this column>).agg(sum /
+        mean / count / len of one Float64 / Int64 column) then runs on the views themselves (plx_strview_groupby) and never encodes."""
         F.ensure_init()
+        if encode not in ("eager", "deferred"):
+            raise ValueError(f"encode must be 'eager' or 'deferred', not {encode!r}")
+        if encode == "deferred":
+            if len(views) % 2:
+                raise ValueError("views must hold 2 n UInt64 words")
+            return cls(name, _raw=(views, data))
         codes, d = C.c_uint64(), C.c_uint64()
         F.check(F.lib().plx_strview_dict_encode_device(views._h, data._h if data is not None else 0, C.byref(codes), C.byref(d)))
         return cls(name, _handle=codes.value, _dtype=T.Categorical(DeviceDictionary(d.value), T.UInt32))
@@ -134,13 +181,15 @@ class Series:
 
     def __del__(self):
         try:
-            if getattr(self, "_h", 0) and F._lib is not None:
-                F._lib.plx_column_free(self._h)
+            if getattr(self, "_hh", 0) and F._lib is not None:
+                F._lib.plx_column_free(self._hh)
         except Exception:
             pass
 
     # -- metadata -----------------------------------------------------------------------------
     def __len__(self) -> int:
+        if self._is_raw_views():
+            return len(self._raw[0]) // 2
         n = C.c_int64()
         F.check(F.lib().plx_column_info(self._h, None, C.byref(n), None))
         return n.value
@@ -151,6 +200,8 @@ class Series:
         return n.value
 
     def rename(self, name: str) -> "Series":
+        if self._is_raw_views():
+            return Series(name, _raw=self._raw)
         F.check(F.lib().plx_column_retain(self._h))
         return Series(name, _handle=self._h, _dtype=self.dtype, _keepalive=self._keepalive)
 
@@ -822,6 +873,10 @@ class LazyFrame:
 
     def collect(self, *, no_fusion: bool = False, no_direct_join: bool = False, no_partition: bool = False) -> DataFrame:
         F.ensure_init()
+        if not (no_fusion or no_partition):
+            fast = _string_key_group_by(self._node)
+            if fast is not None:
+                return fast
         (ir, n_ir, ae, n_ae, keep), root, schema, _low = self._lowered_c()
         out = C.c_uint64()
         flags = (F.PLAN_NO_FUSION if no_fusion else 0) | (F.PLAN_NO_DIRECT_JOIN if no_direct_join else 0) | (F.PLAN_NO_PARTITION if no_partition else 0)
@@ -866,6 +921,54 @@ class LazyFrame:
         F.check(F.lib().plx_describe_fusion(ir, n_ir, ae, n_ae, root, C.byref(fus), C.byref(sid), why, 512))
         del keep
         return bool(fus.value), sid.value, why.value.decode(), F.last_plan()
+
+
+def _string_key_group_by(node: P.Node) -> Optional[DataFrame]:
+    """group_by(<Utf8View column still held as views>).agg(sum / mean / count / len of ONE Float64 / Int64 column) straight over a DataFrame:
+    the string-key operator (plx_strview_groupby: rows partitioned by the view's hash, per-partition LDS tables keyed by the view) instead of
+    encode-then-group.  None when the plan is anything else or the operator declines (PLX_ERR_UNSUPPORTED: a string over 12 bytes, too many
+    distinct strings) -- collect() then goes the usual way, which encodes the column.  Semantics as the reference's group-by on a String
+    key (crates/polars-expr/src/hash_keys.rs:413-452): one row per distinct string, sum of an all-null group 0, its mean null."""
+    if node.kind != "group_by" or node.maintain_order or len(node.keys) != 1 or node.keys[0].kind != "col" or not node.aggs:
+        return None
+    src = node.input
+    if src.kind != "scan" or type(src.frame) is not DataFrame:
+        return None
+    cols = {c.name: c for c in src.frame._cols}
+    key = cols.get(node.keys[0].name)
+    if key is None or not key._is_raw_views() or key._raw[1] is not None:
+        return None
+    plan, value = [], None                   # (output name, "sum" | "mean" | "count" | "len")
+    for e in node.aggs:
+        out = P.expr_output_name(e)
+        while e.kind == "alias":
+            e = e.lhs
+        if e.kind == "len":
+            plan.append((out, "len"))
+            continue
+        kinds = {F.AGG_SUM: "sum", F.AGG_MEAN: "mean", F.AGG_COUNT: "count", F.AGG_LEN: "len"}
+        if e.kind != "agg" or e.op not in kinds or e.lhs.kind != "col" or e.lhs.name == key.name or e.lhs.name not in cols:
+            return None
+        if value is not None and value.name != e.lhs.name:
+            return None
+        value = cols[e.lhs.name]
+        plan.append((out, kinds[e.op]))
+    if value is None or value._is_raw_views() or value.dtype not in (T.Float64, T.Int64) or len({o for o, _ in plan} | {key.name}) != len(plan) + 1:
+        return None
+    hs = [C.c_uint64() for _ in range(5)]
+    try:
+        F.check(F.lib().plx_strview_groupby(key._raw[0]._h, value._h, *[C.byref(h) for h in hs]))
+    except F.UnsupportedError:
+        return None
+    codes, d, s_sum, s_cnt, s_len = (h.value for h in hs)
+    parts = {"sum": Series("__sum", _handle=s_sum, _dtype=value.dtype), "count": Series("__count", _handle=s_cnt, _dtype=T.UInt32), "len": Series("__len", _handle=s_len, _dtype=T.UInt32)}
+    k = Series(key.name, _handle=codes, _dtype=T.Categorical(DeviceDictionary(d), T.UInt32))
+    if not any(a == "mean" for _, a in plan):
+        return DataFrame([k] + [parts[a].rename(o) for o, a in plan])
+    # mean = sum / count, null for a group without a valid value (count % count is null exactly then), computed by the library over the G result rows
+    n = _col("__count")
+    outs = [_col(key.name)] + [((_col("__sum").cast(T.Float64) / (n + n % n).cast(T.Float64)) if a == "mean" else _col("__" + a)).alias(o) for o, a in plan]
+    return DataFrame([k, parts["sum"], parts["count"], parts["len"]]).lazy().select(*outs).collect()
 
 
 class GroupBy:

@@ -1,0 +1,117 @@
+"""Round 3, third batch: the string-key group-by operator (plx_strview_groupby; kernels_strgroup.hip) -- group_by(<Utf8View column held as
+views>).agg(sum / mean / count / len) without a dictionary-encode pass.  Reference semantics: crates/polars-expr/src/hash_keys.rs:413-452
+(BinviewKeys), crates/polars-compute/src/binview_index_map.rs.  Checked against numpy on the generator's host twin and against the
+encode-then-group route of the same library (which the earlier rounds pinned to the oracle)."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+pytestmark = pytest.mark.gpu_unvalidated
+
+
+def _views_series(pl, strings):
+    """Host strings (all <= 12 bytes) -> UInt64 Series of 2 n view words in HBM, as a scan source would leave them."""
+    arr = pa.array(strings, pa.string_view())
+    assert arr.null_count == 0
+    raw = np.frombuffer(arr.buffers()[1], dtype=np.uint64, count=2 * len(strings), offset=16 * arr.offset)
+    return pl.Series("views", raw.copy(), pl.UInt64)
+
+
+def _by_key(out, key="k"):
+    d = out.to_dict()
+    order = sorted(range(len(d[key])), key=lambda i: d[key][i])
+    return {c: [d[c][i] for i in order] for c in d}
+
+
+def test_string_key_group_by_on_views_matches_numpy_and_the_encoded_route(pl):
+    from polars_amd import datagen
+    n, seed, n_keys = 9_000_001, 12, 200_000
+    views = datagen.id_views_native(pl, "k", n, seed, 0, 1, n_keys + 1)
+    v = datagen.uniform_native(pl, "v", pl.Float64, n, seed, 1, 0, 10 ** 9, 1e-7)
+    k = pl.Series.from_device_views("k", views, encode="deferred")
+    assert k._is_raw_views() and len(k) == n
+    q = lambda key: pl.DataFrame([key, v]).lazy().group_by("k").agg(pl.col("v").sum().alias("v_sum"), pl.col("v").mean().alias("v_mean"), pl.col("v").count().alias("c"), pl.len())
+    out = q(k).collect()
+    assert "StringViewGroupBy" in pl.last_plan(), pl.last_plan()
+    assert k._is_raw_views()                                                      # the key column was never encoded
+    assert list(out.schema) == ["k", "v_sum", "v_mean", "c", "len"] and out.schema["v_sum"] == pl.Float64 and out.schema["len"] == pl.UInt32
+    ids = datagen.uniform_native_host("Int64", 0, n, seed, 0, 1, n_keys + 1)
+    vals = datagen.uniform_native_host("Float64", 0, n, seed, 1, 0, 10 ** 9, 1e-7)
+    s, c = np.bincount(ids, weights=vals, minlength=n_keys + 1), np.bincount(ids, minlength=n_keys + 1)
+    present = np.nonzero(c)[0]
+    got = _by_key(out)
+    assert got["k"] == ["id%010d" % i for i in present]
+    assert np.allclose(got["v_sum"], s[present], rtol=1e-9) and np.allclose(got["v_mean"], s[present] / c[present], rtol=1e-9)
+    assert got["c"] == c[present].tolist() and got["len"] == c[present].tolist()
+    # the same query through dictionary encoding + the dense-id group-by
+    ref = _by_key(q(pl.Series.from_device_views("k", views)).collect())
+    assert "StringViewGroupBy" not in pl.last_plan()
+    assert ref["k"] == got["k"] and ref["c"] == got["c"] and ref["len"] == got["len"] and np.allclose(ref["v_sum"], got["v_sum"], rtol=1e-9)
+
+
+def test_string_key_group_by_nulls_int_values_short_and_empty_strings(pl):
+    rng = np.random.default_rng(5)
+    words = ["", "a", "b", "ab", "ba", "a\0", "abcdefghijkl", "abcdefghijkm", "Abcdefghijkl", "xbcdefghijkl", "ünï", "twelve bytes", "0", "00"]
+    n = 300_011
+    idx = rng.integers(0, len(words), n)
+    idx[rng.random(n) < 0.3] = 6                                                 # a hot key: same-address LDS atomics
+    strings = [words[i] for i in idx]
+    x = rng.integers(-10 ** 12, 10 ** 12, n)
+    valid = rng.random(n) > 0.2
+    valid[idx == 3] = False                                                       # one group without a single valid value
+    v = pl.Series("v", x, pl.Int64, validity=valid)
+    k = pl.Series.from_device_views("k", _views_series(pl, strings), encode="deferred")
+    out = pl.DataFrame([k, v]).lazy().group_by("k").agg(pl.col("v").sum(), pl.col("v").mean().alias("m"), pl.col("v").count().alias("c"), pl.len().alias("n")).collect()
+    assert "StringViewGroupBy" in pl.last_plan(), pl.last_plan()
+    assert out.schema["v"] == pl.Int64
+    got = _by_key(out)
+    want = sorted(set(strings))
+    assert got["k"] == want
+    for j, w in enumerate(want):
+        m = np.array([s == w for s in strings])
+        assert got["n"][j] == int(m.sum()) and got["c"][j] == int((m & valid).sum())
+        assert got["v"][j] == int(x[m & valid].sum())                             # integer sums are exact; 0 for the all-null group
+        if (m & valid).any():
+            assert abs(got["m"][j] - x[m & valid].mean()) <= 1e-9 * max(1.0, abs(x[m & valid].mean()))
+        else:
+            assert got["m"][j] is None
+    # len only needs no value column in the reference; here the operator wants one -> the usual route, same rows
+    out2 = pl.DataFrame([pl.Series.from_device_views("k", _views_series(pl, strings), encode="deferred"), v]).lazy().group_by("k").agg(pl.len().alias("n")).collect()
+    assert "StringViewGroupBy" not in pl.last_plan()
+    assert _by_key(out2)["n"] == got["n"]
+
+
+def test_string_key_group_by_declines_long_strings_and_many_groups(pl):
+    F = pl._ffi
+    import ctypes as C
+    # a string of 13 bytes: the view is not the string -> PLX_ERR_UNSUPPORTED from the ABI, and the deferred column encodes instead
+    strings = ["short", "thirteen byte", "short", "x"] * 1000
+    arr = pa.array(strings, pa.string_view())
+    raw = np.frombuffer(arr.buffers()[1], dtype=np.uint64, count=2 * len(strings)).copy()
+    views = pl.Series("views", raw, pl.UInt64)
+    v = pl.Series("v", np.arange(len(strings), dtype=np.float64), pl.Float64)
+    hs = [C.c_uint64() for _ in range(5)]
+    st = F.lib().plx_strview_groupby(views._h, v._h, *[C.byref(h) for h in hs])
+    assert st == F.ERR_UNSUPPORTED and b"12 bytes" in F.lib().plx_last_error()
+    # more distinct strings than the LDS tables hold (512 partitions x 4096 slots at 60 %): declined on the sample estimate, the usual route answers
+    from polars_amd import datagen
+    n, n_keys = 4_000_000, 3_000_000
+    views = datagen.id_views_native(pl, "k", n, 3, 0, 1, n_keys + 1)
+    vv = datagen.uniform_native(pl, "v", pl.Float64, n, 3, 1, 0, 1000, 1e-3)
+    k = pl.Series.from_device_views("k", views, encode="deferred")
+    out = pl.DataFrame([k, vv]).lazy().group_by("k").agg(pl.col("v").sum(), pl.len()).collect()
+    assert "StringViewGroupBy" not in pl.last_plan() and not k._is_raw_views()
+    ids = datagen.uniform_native_host("Int64", 0, n, 3, 0, 1, n_keys + 1)
+    assert out.height == len(np.unique(ids)) and sum(out["len"].to_list()) == n
+
+
+def test_deferred_views_column_behaves_like_the_encoded_one_elsewhere(pl):
+    strings = ["b", "a", "c", "a", "b", "a"]
+    k = pl.Series.from_device_views("k", _views_series(pl, strings), encode="deferred")
+    assert len(k) == 6 and k.rename("z").name == "z" and k._is_raw_views()
+    df = pl.DataFrame([k, pl.Series("v", [1.0, 2.0, 3.0, 4.0, 5.0, 6.0])])
+    assert df.height == 6 and k._is_raw_views()
+    assert df.lazy().filter(pl.col("k") == "a").select(pl.col("v").sum()).collect().to_dict() == {"v": [12.0]}       # any other operator encodes on first use
+    assert not k._is_raw_views() and isinstance(k.dtype, pl.Categorical) and k.to_list() == strings
+    with pytest.raises(ValueError):
+        pl.Series.from_device_views("k", _views_series(pl, strings), encode="later")
