@@ -245,8 +245,11 @@ def ensure_init() -> None:
         init()
 
 
+_plan_note = None          # description of a collect() that was served by more than one library call (frame._string_key_group_by); reset by every collect()
+
+
 def last_plan() -> str:
-    return lib().plx_last_plan_description().decode()
+    return _plan_note if _plan_note is not None else lib().plx_last_plan_description().decode()
 
 
 def jit_set_min_rows(min_rows: int) -> None:

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -33,7 +34,7 @@ namespace {
 constexpr uint32_t kSgBlock = 1024;
 constexpr uint32_t kSgRows = 3;                        // rows per thread and round: tiles of 3072 rows
 constexpr uint32_t kSgTile = kSgBlock * kSgRows;
-constexpr uint32_t kSgRW = 6;                          // record dwords: view (4) + value (2); bit 31 of dword 0 (above the 4-bit length): value is null
+constexpr uint32_t kSgRW = 6;                          // record dwords: view (4) + value (2); dword 0 = length (4 bits) | value is null << 4 | 27 hash bits << 5
 constexpr uint32_t kSgChunkRecs = 256;
 constexpr uint32_t kSgChunkDw = kSgChunkRecs * kSgRW, kSgCapLines = kSgChunkDw / 32;
 constexpr uint32_t kSgNoChunk = 0xffffffffu;
@@ -50,143 +51,232 @@ struct SgScatter {
   unsigned int* recs;
   unsigned int* chunk_part;
   unsigned int* chunk_fill;
-  unsigned int* flags;               // [0] ran out of chunks, [1] a string longer than 12 bytes, [2] a view whose second word is the EMPTY pattern
+  unsigned int* flags;               // [0] ran out of chunks, [1] a string longer than 12 bytes, [2] unused
+  unsigned long long* timing;        // PLX_STRGROUP_TIMING=1: [9] 100 MHz ticks of thread 0 summed over workgroups, by phase; [8] rounds
   uint32_t chunks_per_wg, log2_parts;
+  uint32_t variant;                  // PLX_STRGROUP_VARIANT (experiments; results are wrong): 1 no line stores, 2 rows made up from the row index instead of loaded
 };
 
-// LDS: sorted [tile * 6] u32 | carry [NP][32] u32 | cnt, off[NP + 1], carry_dw, dstA, lines_left, dstB, cur_chunk, cur_lines [NP] u32 | misc [4]
-__host__ __device__ inline size_t sg_scatter_lds(uint32_t NP) { return (size_t)kSgTile * kSgRW * 4 + (size_t)NP * 128 + ((size_t)NP * 8 + 1) * 4 + 16; }
+// LDS: sorted [tile * 6] u32 | carry [NP][32] u32 | cnt, off [NP + 1], desc, dstA, lines_left, dstB, state [NP] u32 | misc [4]
+__host__ __device__ inline size_t sg_scatter_lds(uint32_t NP) { return (size_t)kSgTile * kSgRW * 4 + (size_t)NP * 128 + ((size_t)NP * 7 + 1) * 4 + 16; }
 
+// One round = one tile of 3072 rows.  What shapes the schedule (measured with PLX_STRGROUP_TIMING on the first version, 12.6 us per round):
+//  * loads and stores share one counter per wave (vmcnt): a wave that waits for its rows right after it has written lines waits for the
+//    WRITES to be acknowledged.  So rows are consumed (hashed, ranked) BEFORE the round's lines go out, one full round after their loads
+//    were issued, and the stores have until the same point of the next round to drain;
+//  * every per-partition step is an LDS round trip: the scan wave and the flush fetch the words of several partitions at once and only
+//    then act on them; chunk allocation is one wave prefix sum, not one atomic per partition;
+//  * a partition receives 36 dwords per round on average: the flush gives it a 32-lane group that writes up to two lines at once.
+template <bool TIMING>
 __global__ __launch_bounds__(kSgBlock) void strgroup_scatter_kernel(SgScatter p) {
   extern __shared__ unsigned long long sg_lds[];
-  const uint32_t NP = 1u << p.log2_parts;
+  constexpr uint32_t NP = 512;
   unsigned int* sorted = reinterpret_cast<unsigned int*>(sg_lds);
   unsigned int* carry = sorted + (size_t)kSgTile * kSgRW;
   unsigned int* cnt = carry + (size_t)NP * 32;
   unsigned int* off = cnt + NP;
-  unsigned int* carry_dw = off + NP + 1;
-  unsigned int* dstA = carry_dw + NP;
-  unsigned int* lines_left = dstA + NP;
+  unsigned int* desc = off + NP + 1;       // this round: first row in the tile | rows << 12 | carried dwords << 24 | (lines continue in a new chunk) << 31
+  unsigned int* dstA = desc + NP;          // line index of the partition's first line of this round
+  unsigned int* lines_left = dstA + NP;    // lines that still fit the current chunk / first line of the newly opened chunk(s): read only when bit 31 is set
   unsigned int* dstB = lines_left + NP;
-  unsigned int* cur_chunk = dstB + NP;
-  unsigned int* cur_lines = cur_chunk + NP;
-  unsigned int* misc = cur_lines + NP;
+  unsigned int* state = dstB + NP;         // carried dwords | lines used in the current chunk << 5 | (workgroup-local index of the current chunk + 1) << 11
+  unsigned int* misc = state + NP;         // [0] chunks this workgroup has opened
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (uint32_t i = tid; i < NP; i += kSgBlock) { cnt[i] = 0; carry_dw[i] = 0; cur_chunk[i] = kSgNoChunk; cur_lines[i] = kSgCapLines; }
+  for (uint32_t i = tid; i < NP; i += kSgBlock) { cnt[i] = 0; state[i] = kSgCapLines << 5; }
   if (tid < 4) misc[tid] = 0;
   __syncthreads();
   const uint32_t chunk0 = blockIdx.x * p.chunks_per_wg;
-  auto open_chunks = [&](uint32_t part, uint32_t need) -> uint32_t {
-    const uint32_t local = atomicAdd(&misc[0], need);
-    if (local + need > p.chunks_per_wg) { p.flags[0] = 1u; return chunk0; }
-    for (uint32_t e = 0; e < need; e++) p.chunk_part[chunk0 + local + e] = part;
-    return chunk0 + local;
-  };
   const int64_t nrounds = (p.n + kSgTile - 1) / kSgTile;
-  const uint32_t per_lane = NP >> 6;
-  ulonglong2 vn[kSgRows];
-  unsigned long long xn[kSgRows];
-  auto load = [&](int64_t rd, ulonglong2* v, unsigned long long* x) __attribute__((always_inline)) {
+  ulonglong2 v[kSgRows], vn[kSgRows];
+  unsigned long long x[kSgRows], xn[kSgRows];
+  uint32_t part[kSgRows];
+  bool vnull[kSgRows];
+  auto load = [&](int64_t rd, ulonglong2* vv, unsigned long long* xx) __attribute__((always_inline)) {
 #pragma unroll
     for (uint32_t j = 0; j < kSgRows; j++) {
       const int64_t row = rd * kSgTile + (int64_t)j * kSgBlock + tid;
-      if (row < p.n) { v[j] = reinterpret_cast<const ulonglong2*>(p.views)[row]; x[j] = p.values[row]; }
-      else { v[j] = make_ulonglong2(kSgEmpty, kSgEmpty); x[j] = 0; }
+      if (row < p.n) {
+        if (p.variant & 2u) { vv[j] = make_ulonglong2(12ull | (uint64_t)row << 32, sg_mix(row, 77)); xx[j] = row; }
+        else { vv[j] = reinterpret_cast<const ulonglong2*>(p.views)[row]; xx[j] = p.values[row]; }
+      } else { vv[j] = make_ulonglong2(kSgEmpty, kSgEmpty); xx[j] = 0; }
     }
   };
-  int64_t rd = blockIdx.x;
-  if (rd < nrounds) load(rd, vn, xn);
-  for (; rd < nrounds; rd += gridDim.x) {
-    ulonglong2 v[kSgRows];
-    unsigned long long x[kSgRows];
-#pragma unroll
-    for (uint32_t j = 0; j < kSgRows; j++) { v[j] = vn[j]; x[j] = xn[j]; }
-    if (rd + gridDim.x < nrounds) load(rd + gridDim.x, vn, xn);
-    uint32_t part[kSgRows];
-    bool live[kSgRows], vnull[kSgRows];
+  // rows of round rd (in v, x) -> partition and rank within (tile, partition): part = partition | rank << 10, all ones for a row that is not there
+  auto rank = [&](int64_t rd) __attribute__((always_inline)) {
 #pragma unroll
     for (uint32_t j = 0; j < kSgRows; j++) {
       const int64_t row = rd * kSgTile + (int64_t)j * kSgBlock + tid;
-      live[j] = row < p.n;
-      vnull[j] = live[j] && p.val_validity && !((p.val_validity[row >> 6] >> (row & 63)) & 1);
-      if (live[j] && (uint32_t)v[j].x > 12u) { p.flags[1] = 1u; live[j] = false; }          // a long string: the view is not the string -> the caller falls back
-      if (live[j] && v[j].y == kSgEmpty) { p.flags[2] = 1u; live[j] = false; }
-      part[j] = live[j] ? (uint32_t)(sg_hash(v[j].x, v[j].y) >> (64 - p.log2_parts)) : 0xffffffffu;
-      if (live[j]) part[j] |= atomicAdd(&cnt[part[j]], 1u) << 10;                            // rank within (tile, partition) above the partition's 10 bits
+      bool live = row < p.n;
+      vnull[j] = live && p.val_validity && !((p.val_validity[row >> 6] >> (row & 63)) & 1);
+      if (live && (uint32_t)v[j].x > 12u) { p.flags[1] = 1u; live = false; }          // a long string: the view is not the string -> the caller falls back
+      part[j] = 0xffffffffu;
+      if (live) {
+        const uint64_t h = sg_hash(v[j].x, v[j].y);
+        const uint32_t q = (uint32_t)(h >> (64 - 9));
+        part[j] = q | atomicAdd(&cnt[q], 1u) << 10;
+        // the record's first dword: length (4 bits) | value is null | the 27 hash bits below the partition's, which the aggregation kernel probes with
+        v[j].x = (v[j].x & 0xffffffff0000000full) | (vnull[j] ? 16u : 0u) | ((uint64_t)((uint32_t)(h >> (64 - 9 - 27)) & 0x7ffffffu) << 5);
+      }
     }
-    __syncthreads();                                                                          // A
+  };
+  unsigned long long t_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = TIMING ? wall_clock64() : 0;
+#define SG_TICK(i) do { if (TIMING && tid == 0) { const unsigned long long now = wall_clock64(); t_acc[i] += now - t_last; t_last = now; } } while (0)
+  int64_t rd = blockIdx.x;
+  if (rd < nrounds) { load(rd, v, x); rank(rd); }
+  if (rd + gridDim.x < nrounds) load(rd + gridDim.x, vn, xn);
+  for (; rd < nrounds; rd += gridDim.x) {
+    __syncthreads();                                                                          // A: the tile's ranks are complete, the previous flush is done with off / desc
+    SG_TICK(0);
     if (wave == 0) {
-      uint32_t s = 0;
-      for (uint32_t q = 0; q < per_lane; q++) s += cnt[(uint32_t)lane * per_lane + q];
-      uint32_t incl = s;
+      // eight consecutive partitions per lane, their words read and written as 16-byte vectors
+      const uint4* cnt4 = reinterpret_cast<const uint4*>(cnt) + lane * 2;
+      const uint4* st4 = reinterpret_cast<const uint4*>(state) + lane * 2;
+      uint32_t s = 0, lane_need = 0;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
-      uint32_t o = incl - s;
-      for (uint32_t q = 0; q < per_lane; q++) {
-        const uint32_t pp = (uint32_t)lane * per_lane + q;
-        const uint32_t c = cnt[pp];
-        off[pp] = o; o += c;
-        cnt[pp] = 0;
-        const uint32_t nl = (carry_dw[pp] + c * kSgRW) >> 5;
-        if (nl) {
-          uint32_t ch = cur_chunk[pp], ln = cur_lines[pp];
-          const uint32_t left = kSgCapLines - ln;
-          dstA[pp] = ch * kSgCapLines + ln; lines_left[pp] = left;
-          if (nl > left) {
-            const uint32_t extra = nl - left, need = (extra + kSgCapLines - 1) / kSgCapLines;
-            if (ch != kSgNoChunk) p.chunk_fill[ch] = kSgChunkRecs;
-            const uint32_t first = open_chunks(pp, need);
-            for (uint32_t e = 0; e + 1 < need; e++) p.chunk_fill[first + e] = kSgChunkRecs;
-            dstB[pp] = first * kSgCapLines;
-            ch = first + need - 1; ln = extra - (need - 1) * kSgCapLines;
-          } else ln += nl;
-          cur_chunk[pp] = ch; cur_lines[pp] = ln;
+      for (uint32_t h = 0; h < 2; h++) {
+        const uint4 cc = cnt4[h], ss = st4[h];
+        const uint32_t c[4] = {cc.x, cc.y, cc.z, cc.w}, st[4] = {ss.x, ss.y, ss.z, ss.w};
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+          const uint32_t nl = ((st[q] & 31u) + c[q] * kSgRW) >> 5, left = kSgCapLines - ((st[q] >> 5) & 63u);
+          s += c[q];
+          lane_need += nl > left ? (nl - left + kSgCapLines - 1) / kSgCapLines : 0u;
         }
       }
-      if (lane == 63) off[NP] = o;
+      const uint32_t opened = misc[0];
+      uint32_t incl = s, incl_need = lane_need;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64), o2 = (uint32_t)__shfl_up((int)incl_need, d, 64);
+        if (lane >= d) { incl += o; incl_need += o2; }
+      }
+      uint32_t o = incl - s, base = opened + incl_need - lane_need;
+      if (lane == 63) { misc[0] = opened + incl_need; off[NP] = incl; if (opened + incl_need > p.chunks_per_wg) p.flags[0] = 1u; }
+      if (base + lane_need > p.chunks_per_wg) base = 0;                                       // flagged above: the host raises; stay inside the workgroup's chunks
+#pragma unroll 1
+      for (uint32_t h = 0; h < 2; h++) {
+        const uint4 cc = cnt4[h], ss = st4[h];
+        const uint32_t c[4] = {cc.x, cc.y, cc.z, cc.w}, st[4] = {ss.x, ss.y, ss.z, ss.w};
+        uint32_t ov[4], av[4], sv[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+          const uint32_t pp = (uint32_t)lane * 8 + h * 4 + q;
+          const uint32_t cd = st[q] & 31u;
+          uint32_t ln = (st[q] >> 5) & 63u, lc = st[q] >> 11;
+          const uint32_t total = cd + c[q] * kSgRW, nl = total >> 5, left = kSgCapLines - ln;
+          uint32_t a = o | c[q] << 12 | cd << 24;
+          ov[q] = o; o += c[q];
+          if (nl) {
+            uint32_t first_line = (chunk0 + lc - 1) * kSgCapLines + ln;
+            if (nl > left) {
+              const uint32_t extra = nl - left, need = (extra + kSgCapLines - 1) / kSgCapLines, first = base;
+              base += need;
+              if (lc) p.chunk_fill[chunk0 + lc - 1] = kSgChunkRecs;
+              for (uint32_t e = 0; e < need; e++) { p.chunk_part[chunk0 + first + e] = pp; if (e + 1 < need) p.chunk_fill[chunk0 + first + e] = kSgChunkRecs; }
+              if (left == 0) first_line = (chunk0 + first) * kSgCapLines;                     // everything goes to the new chunk(s), which are consecutive
+              else { a |= 0x80000000u; lines_left[pp] = left; dstB[pp] = (chunk0 + first) * kSgCapLines; }
+              lc = first + need; ln = extra - (need - 1) * kSgCapLines;
+            } else ln += nl;
+            dstA[pp] = first_line;
+          }
+          av[q] = a;
+          sv[q] = (total & 31u) | ln << 5 | lc << 11;
+        }
+        reinterpret_cast<uint4*>(off)[lane * 2 + h] = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+        reinterpret_cast<uint4*>(cnt)[lane * 2 + h] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4*>(desc)[lane * 2 + h] = make_uint4(av[0], av[1], av[2], av[3]);
+        reinterpret_cast<uint4*>(state)[lane * 2 + h] = make_uint4(sv[0], sv[1], sv[2], sv[3]);
+      }
     }
+    SG_TICK(1);
     __syncthreads();                                                                          // B
+    SG_TICK(2);
 #pragma unroll
     for (uint32_t j = 0; j < kSgRows; j++) {
-      if (!live[j]) continue;
-      unsigned int* dst = sorted + (size_t)(off[part[j] & 1023u] + (part[j] >> 10)) * kSgRW;
-      dst[0] = (uint32_t)v[j].x | (vnull[j] ? 0x80000000u : 0u); dst[1] = (uint32_t)(v[j].x >> 32);
-      dst[2] = (uint32_t)v[j].y; dst[3] = (uint32_t)(v[j].y >> 32);
-      dst[4] = (uint32_t)x[j]; dst[5] = (uint32_t)(x[j] >> 32);
+      if (part[j] == 0xffffffffu) continue;
+      uint2* dst = reinterpret_cast<uint2*>(sorted + (size_t)(off[part[j] & 1023u] + (part[j] >> 10)) * kSgRW);
+      dst[0] = make_uint2((uint32_t)v[j].x, (uint32_t)(v[j].x >> 32));
+      dst[1] = make_uint2((uint32_t)v[j].y, (uint32_t)(v[j].y >> 32));
+      dst[2] = make_uint2((uint32_t)x[j], (uint32_t)(x[j] >> 32));
     }
-    __syncthreads();                                                                          // C
+    // the next round's rows arrived a round ago: rank them now (cnt is zero again since the scan), then send for the rows after them
+    SG_TICK(3);
+    if (rd + gridDim.x < nrounds) {
+      if (TIMING) { __builtin_amdgcn_s_waitcnt(0x0F70); SG_TICK(4); }                         // vmcnt(0): the rows' arrival, apart from the work on them
+#pragma unroll
+      for (uint32_t j = 0; j < kSgRows; j++) { v[j] = vn[j]; x[j] = xn[j]; }
+      rank(rd + gridDim.x);
+      SG_TICK(5);
+      if (rd + 2 * (int64_t)gridDim.x < nrounds) load(rd + 2 * (int64_t)gridDim.x, vn, xn);
+    }
+    __syncthreads();                                                                          // C: the tile is complete
+    SG_TICK(6);
     {
-      const uint32_t g = (uint32_t)tid >> 4, l16 = (uint32_t)tid & 15u;
-      for (uint32_t pp = g; pp < NP; pp += kSgBlock >> 4) {
-        const uint32_t o_dw = off[pp] * kSgRW, r_dw = (off[pp + 1] - off[pp]) * kSgRW, c_dw = carry_dw[pp];
-        const uint32_t total = c_dw + r_dw, nl = total >> 5, rem = total & 31u;
-        const unsigned int* cy = carry + (size_t)pp * 32;
-        const uint32_t a = dstA[pp], left = lines_left[pp], b = dstB[pp];
-        for (uint32_t i = 0; i < nl; i++) {
-          const uint32_t d = i * 32 + l16 * 2;
-          uint2 w;
-          w.x = d < c_dw ? cy[d] : sorted[o_dw + d - c_dw];
-          w.y = d + 1 < c_dw ? cy[d + 1] : sorted[o_dw + d + 1 - c_dw];
-          const uint64_t line = i < left ? (uint64_t)a + i : (uint64_t)b + (i - left);
-          *reinterpret_cast<uint2*>(p.recs + line * 32 + l16 * 2) = w;
+      const uint32_t g = (uint32_t)tid >> 5, l32 = (uint32_t)tid & 31u, d = l32 * 2;         // lanes 0-15: the first line, 16-31: the second
+#pragma unroll 1
+      for (uint32_t b4 = 0; b4 < 4; b4++) {
+        uint32_t a[4], da[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) { const uint32_t pp = g + (b4 * 4 + q) * 32u; a[q] = desc[pp]; da[q] = dstA[pp]; }
+        uint2 w[4];
+        uint32_t r[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+          const uint32_t pp = g + (b4 * 4 + q) * 32u;
+          const uint32_t o_dw = (a[q] & 4095u) * kSgRW, r_dw = ((a[q] >> 12) & 4095u) * kSgRW, c_dw = (a[q] >> 24) & 31u, nl = (c_dw + r_dw) >> 5;
+          // dword d of the partition's stream (carry first, then its rows of the tile); d, c_dw and o_dw are even: one 8-byte read
+          w[q] = *reinterpret_cast<const uint2*>(d < c_dw ? carry + (size_t)pp * 32 + d : sorted + o_dw + d - c_dw);
+          // the new carry's dword l32 = dword nl * 32 + l32 of the stream
+          const uint32_t sd = nl * 32 + l32;
+          r[q] = sd < c_dw ? carry[(size_t)pp * 32 + sd] : sorted[o_dw + sd - c_dw];
         }
-        if (nl == 0) { for (uint32_t i = l16; i < r_dw; i += 16) carry[(size_t)pp * 32 + c_dw + i] = sorted[o_dw + i]; }
-        else { for (uint32_t i = l16; i < rem; i += 16) carry[(size_t)pp * 32 + i] = sorted[o_dw + nl * 32 + i - c_dw]; }
-        if (l16 == 0) carry_dw[pp] = rem;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+          const uint32_t pp = g + (b4 * 4 + q) * 32u;
+          const uint32_t r_dw = ((a[q] >> 12) & 4095u) * kSgRW, c_dw = (a[q] >> 24) & 31u, total = c_dw + r_dw, nl = total >> 5, rem = total & 31u;
+          const uint32_t li = l32 >> 4;
+          if (li < nl && !(p.variant & 1u)) {
+            uint64_t line = (uint64_t)da[q] + li;
+            if ((a[q] >> 31) && li >= lines_left[pp]) line = (uint64_t)dstB[pp] + (li - lines_left[pp]);
+            *reinterpret_cast<uint2*>(p.recs + line * 32 + (l32 & 15u) * 2) = w[q];
+          }
+          if (r_dw && l32 < rem) carry[(size_t)pp * 32 + l32] = r[q];
+          if (nl > 2) {
+            // three or more lines for one partition in one round (skew): the rest of its lines, two at a time
+            const uint32_t o_dw = (a[q] & 4095u) * kSgRW;
+            const uint32_t left = (a[q] >> 31) ? lines_left[pp] : 0xffffffffu, b = (a[q] >> 31) ? dstB[pp] : 0u;
+            for (uint32_t i = 2 + li; i < nl; i += 2) {
+              const uint32_t dd = i * 32 + (l32 & 15u) * 2;
+              const uint2 ww = *reinterpret_cast<const uint2*>(sorted + o_dw + dd - c_dw);
+              const uint64_t line = i < left ? (uint64_t)da[q] + i : (uint64_t)b + (i - left);
+              *reinterpret_cast<uint2*>(p.recs + line * 32 + (l32 & 15u) * 2) = ww;
+            }
+          }
+        }
       }
     }
+    SG_TICK(7);
+    if (TIMING && tid == 0) t_acc[8]++;
   }
+  if (TIMING && tid == 0) { for (int i = 0; i < 9; i++) atomicAdd(&p.timing[i], t_acc[i]); }
   __syncthreads();
   for (uint32_t pp = tid; pp < NP; pp += kSgBlock) {
-    uint32_t ch = cur_chunk[pp], ln = cur_lines[pp];
-    const uint32_t rem = carry_dw[pp];
+    const uint32_t st = state[pp], rem = st & 31u;
+    uint32_t ln = (st >> 5) & 63u, lc = st >> 11;
     if (rem) {
-      if (ln == kSgCapLines) { if (ch != kSgNoChunk) p.chunk_fill[ch] = kSgChunkRecs; ch = open_chunks(pp, 1); ln = 0; }
-      for (uint32_t i = 0; i < rem; i++) p.recs[((uint64_t)ch * kSgCapLines + ln) * 32 + i] = carry[(size_t)pp * 32 + i];
+      if (ln == kSgCapLines) {
+        if (lc) p.chunk_fill[chunk0 + lc - 1] = kSgChunkRecs;
+        const uint32_t local = atomicAdd(&misc[0], 1u);
+        if (local >= p.chunks_per_wg) { p.flags[0] = 1u; continue; }
+        p.chunk_part[chunk0 + local] = pp;
+        lc = local + 1; ln = 0;
+      }
+      for (uint32_t i = 0; i < rem; i++) p.recs[((uint64_t)(chunk0 + lc - 1) * kSgCapLines + ln) * 32 + i] = carry[(size_t)pp * 32 + i];
     }
-    if (ch != kSgNoChunk) p.chunk_fill[ch] = (ln * 32 + rem) / kSgRW;
+    if (lc) p.chunk_fill[chunk0 + lc - 1] = (ln * 32 + rem) / kSgRW;
   }
 }
+#undef SG_TICK
 
 // chunk -> partition map -> per-partition chunk lists (counting sort; the same three steps as kernels_partition.hip)
 __global__ __launch_bounds__(kBlock) void sg_chunk_hist_kernel(const unsigned int* __restrict__ chunk_part, int64_t n_chunks, uint32_t NP, unsigned int* __restrict__ counts) {
@@ -224,28 +314,41 @@ struct SgAgg {
   const unsigned long long* cl_off;
   const unsigned int* cl_ids;
   unsigned long long* counter;       // [0] groups written so far
-  unsigned int* overflow;            // [0] 1: an LDS table filled up, 2: more groups than the output holds
+  unsigned int* overflow;            // [0] 1: a partition has more groups than its LDS storage, 2: more groups than the output holds
   unsigned long long* out_views;     // [max_groups][2]
   unsigned long long* out_sum;       // [max_groups] f64 or i64 bits
   unsigned int* out_cnt;             // valid values per group
   unsigned int* out_len;             // rows per group
-  uint32_t log2_slots, log2_parts, max_groups, is_f64;
+  uint32_t max_groups, is_f64;
+  uint32_t variant;                  // PLX_STRGROUP_VARIANT (experiments; results are wrong): 16 no accumulation, 32 no probing, 64 loads only
 };
 
-// LDS: w1 [NS] u64 (the claim word) | w0 [NS] u64 | sum [NS] u64 | cnt [NS] u32 | len [NS] u32
+constexpr uint32_t kSgTagSlots = 8192, kSgGroupCap = 3584;      // per partition: 32 KB of tag words + 3584 groups x 32 B = 144 KB of LDS
+constexpr uint32_t kSgPending = 0xfffu;
+
+// One workgroup per partition.  The probe loop is VALU- and LDS-issue bound, not latency bound (measured: with the probe loop 13 ms, without it
+// 4.3 ms = the time of the record loads alone), so the loop body is as small as it can be:
+//  * the record carries 27 bits of its view's hash (written by the scatter): no hashing here;
+//  * tag table: 8192 words {14-bit tag | 12-bit group index}, at most 35 % full -- a probe is ONE 4-byte LDS read and two compares; a matching tag is
+//    confirmed once against the group's 16-byte view (a false match, ~1e-5 of the lookups, just probes on);
+//  * groups get dense indices in claim order (keys and cells live in [group] arrays): the output needs no compaction.
+// Claim: CAS empty -> {tag | pending}; the winner takes the next group index, writes the view, then publishes {tag | index} (LDS operations of one
+// wave complete in order); whoever sees {tag | pending} looks again.
+// LDS: tags [8192] u32 | w0 [cap] u64 | w1 [cap] u64 | sum [cap] u64 | cnt [cap] u32 | len [cap] u32
 __global__ __launch_bounds__(kSgBlock) void strgroup_agg_kernel(SgAgg a) {
   extern __shared__ unsigned long long sg_lds[];
-  const uint32_t NS = 1u << a.log2_slots, mask = NS - 1u;
-  unsigned long long* w1s = sg_lds;
-  unsigned long long* w0s = w1s + NS;
-  unsigned long long* sums = w0s + NS;
-  unsigned int* cnts = reinterpret_cast<unsigned int*>(sums + NS);
-  unsigned int* lens = cnts + NS;
-  __shared__ unsigned int n_occ, cursor_l, full;
+  unsigned int* tags = reinterpret_cast<unsigned int*>(sg_lds);
+  unsigned long long* w0s = sg_lds + kSgTagSlots / 2;
+  unsigned long long* w1s = w0s + kSgGroupCap;
+  unsigned long long* sums = w1s + kSgGroupCap;
+  unsigned int* cnts = reinterpret_cast<unsigned int*>(sums + kSgGroupCap);
+  unsigned int* lens = cnts + kSgGroupCap;
+  __shared__ unsigned int n_groups, full;
   __shared__ unsigned long long gbase;
   const uint32_t p = blockIdx.x;
-  for (uint32_t i = threadIdx.x; i < NS; i += blockDim.x) { w1s[i] = kSgEmpty; w0s[i] = kSgEmpty; sums[i] = 0ull; cnts[i] = 0; lens[i] = 0; }
-  if (threadIdx.x == 0) { n_occ = 0; cursor_l = 0; full = 0; }
+  for (uint32_t i = threadIdx.x; i < kSgTagSlots; i += blockDim.x) tags[i] = 0xffffffffu;
+  for (uint32_t i = threadIdx.x; i < kSgGroupCap; i += blockDim.x) { sums[i] = 0ull; cnts[i] = 0; lens[i] = 0; }
+  if (threadIdx.x == 0) { n_groups = 0; full = 0; }
   __syncthreads();
   const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const uint64_t c_beg = a.cl_off[p], c_end = a.cl_off[p + 1];
@@ -263,47 +366,61 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_agg_kernel(SgAgg a) {
     }
   };
   auto process = [&](uint2 (*r)[3], uint32_t fill) __attribute__((always_inline)) {
+    if (a.variant & 64u) {
+      unsigned int acc = 0;
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) acc ^= r[u][0].x ^ r[u][1].y ^ r[u][2].x;
+      if (acc == 0x12345677u && fill == 77777u) full = 1;
+      return;
+    }
+    uint32_t ts[kPerLane], g[kPerLane];          // tag slot; group index once found (kPending: not yet)
 #pragma unroll
     for (uint32_t u = 0; u < kPerLane; u++) {
-      const uint32_t i = (uint32_t)lane + u * 64u;
-      const bool live = i < fill;
-      const bool vnull = (r[u][0].x >> 31) & 1u;
-      const unsigned long long w0 = ((unsigned long long)r[u][0].y << 32) | (r[u][0].x & 0x7fffffffu);
-      const unsigned long long w1 = ((unsigned long long)r[u][1].y << 32) | r[u][1].x;
-      const unsigned long long x = ((unsigned long long)r[u][2].y << 32) | r[u][2].x;
-      uint32_t sl = (uint32_t)(sg_hash(w0, w1) >> (64 - a.log2_parts - a.log2_slots)) & mask;      // the bits below the partition's
-      bool found = !live;
-      // every lane runs the same number of rounds of {look, claim, publish} | wave barrier | {compare}: a lane never WAITS inside a round for a word
-      // that a lane of its own wave is about to publish -- it looks again in the next round
-      for (uint32_t it = 0; it < 4 * NS + 64; it++) {
-        if (__all(found)) break;
-        bool again = false;
-        unsigned long long cur = kSgEmpty;
-        if (!found) {
-          cur = w1s[sl];
-          if (cur == kSgEmpty) {
-            const unsigned long long old = atomicCAS(&w1s[sl], kSgEmpty, w1);
-            if (old == kSgEmpty) { w0s[sl] = w0; found = true; }
-            else cur = old;
+      ts[u] = (r[u][0].x >> 5) & (kSgTagSlots - 1u);
+      g[u] = ((uint32_t)lane + u * 64u < fill) && !(a.variant & 32u) ? kSgPending : 0u;
+    }
+    for (uint32_t it = 0; it < 4 * kSgTagSlots; it++) {
+      bool all = true;
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) all = all && g[u] != kSgPending;
+      if (__all(all)) break;
+      uint32_t e[kPerLane];
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) if (g[u] == kSgPending) e[u] = *reinterpret_cast<volatile unsigned int*>(&tags[ts[u]]);
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) {
+        if (g[u] != kSgPending) continue;
+        const uint32_t tag = r[u][0].x >> 18;                                 // the 14 hash bits above the slot's 13
+        if (e[u] == 0xffffffffu) {
+          if (atomicCAS(&tags[ts[u]], 0xffffffffu, tag << 12 | kSgPending) == 0xffffffffu) {
+            const uint32_t idx = atomicAdd(&n_groups, 1u);
+            if (idx >= kSgGroupCap) { full = 1; g[u] = 0; *reinterpret_cast<volatile unsigned int*>(&tags[ts[u]]) = tag << 12; continue; }
+            *reinterpret_cast<volatile unsigned long long*>(&w0s[idx]) = ((unsigned long long)r[u][0].y << 32) | (r[u][0].x & 15u);
+            *reinterpret_cast<volatile unsigned long long*>(&w1s[idx]) = ((unsigned long long)r[u][1].y << 32) | r[u][1].x;
+            *reinterpret_cast<volatile unsigned int*>(&tags[ts[u]]) = tag << 12 | idx;
+            g[u] = idx;
           }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (!found) {
-          if (cur == w1) {
-            const unsigned long long k0 = *reinterpret_cast<volatile unsigned long long*>(&w0s[sl]);
-            if (k0 == kSgEmpty) again = true;             // claimed, first word not published yet: same slot, next round
-            else if (k0 == w0) found = true;
+          // lost the race: the winner's word next round, same slot
+        } else if ((e[u] >> 12) == tag) {
+          const uint32_t idx = e[u] & kSgPending;
+          if (idx != kSgPending) {
+            const unsigned long long k0 = *reinterpret_cast<volatile unsigned long long*>(&w0s[idx]), k1 = *reinterpret_cast<volatile unsigned long long*>(&w1s[idx]);
+            if (k0 == (((unsigned long long)r[u][0].y << 32) | (r[u][0].x & 15u)) && k1 == (((unsigned long long)r[u][1].y << 32) | r[u][1].x)) g[u] = idx;
+            else ts[u] = (ts[u] + 1) & (kSgTagSlots - 1u);                    // same tag, another string
           }
-          if (!found && !again) sl = (sl + 1) & mask;
-        }
+          // pending: the group's view is being written -- the same slot again next round
+        } else ts[u] = (ts[u] + 1) & (kSgTagSlots - 1u);
       }
-      if (live && !found) { full = 1; continue; }
-      if (!live) continue;
-      atomicAdd(&lens[sl], 1u);
-      if (!vnull) {
-        atomicAdd(&cnts[sl], 1u);
-        if (a.is_f64) atomicAdd(reinterpret_cast<double*>(&sums[sl]), __longlong_as_double((long long)x));
-        else atomicAdd(&sums[sl], x);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      if ((uint32_t)lane + u * 64u >= fill || g[u] == kSgPending || (a.variant & 16u)) continue;
+      atomicAdd(&lens[g[u]], 1u);
+      if (!((r[u][0].x >> 4) & 1u)) {
+        atomicAdd(&cnts[g[u]], 1u);
+        const unsigned long long x = ((unsigned long long)r[u][2].y << 32) | r[u][2].x;
+        if (a.is_f64) atomicAdd(reinterpret_cast<double*>(&sums[g[u]]), __longlong_as_double((long long)x));
+        else atomicAdd(&sums[g[u]], x);
       }
     }
   };
@@ -322,20 +439,17 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_agg_kernel(SgAgg a) {
   }
   __syncthreads();
   if (full) { if (threadIdx.x == 0) atomicExch(a.overflow, 1u); return; }
-  uint32_t mine = 0;
-  for (uint32_t s = threadIdx.x; s < NS; s += blockDim.x) mine += w1s[s] != kSgEmpty;
-  if (mine) atomicAdd(&n_occ, mine);
+  const uint32_t ng = n_groups;
+  if (threadIdx.x == 0) gbase = ng ? atomicAdd(a.counter, (unsigned long long)ng) : 0ull;
   __syncthreads();
-  if (threadIdx.x == 0) gbase = n_occ ? atomicAdd(a.counter, (unsigned long long)n_occ) : 0ull;
-  __syncthreads();
-  if (gbase + n_occ > a.max_groups) { if (threadIdx.x == 0) atomicExch(a.overflow, 2u); return; }
-  for (uint32_t s = threadIdx.x; s < NS; s += blockDim.x) {
-    if (w1s[s] == kSgEmpty) continue;
-    const uint64_t o = gbase + atomicAdd(&cursor_l, 1u);
-    a.out_views[o * 2] = w0s[s]; a.out_views[o * 2 + 1] = w1s[s];
-    a.out_sum[o] = sums[s]; a.out_cnt[o] = cnts[s]; a.out_len[o] = lens[s];
+  if (gbase + ng > a.max_groups) { if (threadIdx.x == 0) atomicExch(a.overflow, 2u); return; }
+  for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) {
+    const uint64_t o = gbase + i;
+    a.out_views[o * 2] = w0s[i]; a.out_views[o * 2 + 1] = w1s[i];
+    a.out_sum[o] = sums[i]; a.out_cnt[o] = cnts[i]; a.out_len[o] = lens[i];
   }
 }
+
 // distinct views among the first S rows: one 64-bit hash per row into a table of 4 S slots (a sample; hash collisions undercount by ~S / 2^64)
 __global__ __launch_bounds__(kBlock) void sg_sample_kernel(const unsigned long long* __restrict__ views, int64_t S, unsigned long long* __restrict__ slots, uint32_t log2_cap,
                                                            unsigned int* __restrict__ res) {
@@ -379,13 +493,15 @@ double sg_estimate_groups(const uint64_t* views, int64_t n) {
 int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uint64_t* val_validity, int64_t n, bool is_f64, Buf* out_views, Buf* out_sum, Buf* out_cnt, Buf* out_len,
                         std::string* desc) {
   if (n <= 0) return -1;
-  const uint32_t log2_parts = 9, NP = 1u << log2_parts, log2_slots = 12;                    // 512 x 4096 slots of 32 B = 128 KB of LDS per partition
+  const uint32_t log2_parts = 9, NP = 1u << log2_parts;
+  static_assert(kSgBlock == 1024, "the scatter kernel's scan wave and flush step take eight partitions per lane / sixteen per 32-lane group: 512 partitions, 1024 threads");
   const double est_groups = sg_estimate_groups(views, n);
-  if (est_groups < 0 || est_groups > (double)NP * (double)(1u << log2_slots) * 0.6) return -1;
+  if (est_groups < 0 || est_groups > (double)NP * (double)kSgGroupCap * 0.8) return -1;      // a partition's groups must fit its LDS storage (3584) with room for the spread
   const int64_t nrounds = (n + kSgTile - 1) / kSgTile;
   const uint32_t grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(nrounds, device().cu_count));
   const int64_t rounds_per_wg = (nrounds + grid - 1) / grid;
   const uint32_t chunks_per_wg = (uint32_t)(rounds_per_wg * kSgTile / kSgChunkRecs + NP + 2);
+  if (chunks_per_wg >= (1u << 21)) return -1;                                              // the scatter packs workgroup-local chunk indices into 21 bits
   const int64_t n_chunks = (int64_t)grid * chunks_per_wg;
   Buf recs = dev_alloc((size_t)n_chunks * kSgChunkDw * 4 + 256);
   Buf chunk_part = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks), chunk_fill = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks);
@@ -395,11 +511,21 @@ int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uin
   sp.views = (const unsigned long long*)views; sp.values = (const unsigned long long*)values; sp.val_validity = val_validity; sp.n = n;
   sp.recs = recs->as<unsigned int>(); sp.chunk_part = chunk_part->as<unsigned int>(); sp.chunk_fill = chunk_fill->as<unsigned int>(); sp.flags = meta->as<unsigned int>() + 3;
   sp.chunks_per_wg = chunks_per_wg; sp.log2_parts = log2_parts;
+  static const uint32_t variant = std::getenv("PLX_STRGROUP_VARIANT") ? (uint32_t)atoi(std::getenv("PLX_STRGROUP_VARIANT")) : 0u;
+  sp.variant = variant;
+  static const bool timing = std::getenv("PLX_STRGROUP_TIMING") && std::getenv("PLX_STRGROUP_TIMING")[0] == '1';
+  Buf tbuf;
+  if (timing) { tbuf = dev_alloc_zero(128); sp.timing = tbuf->as<unsigned long long>(); }
   {
     ProfileScope ps("strgroup_scatter", (uint64_t)n * (24 + 24), (uint64_t)n);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)strgroup_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); attr = true; }
-    hipLaunchKernelGGL(strgroup_scatter_kernel, dim3(grid), dim3(kSgBlock), sg_scatter_lds(NP), stream(), sp);
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)strgroup_scatter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)strgroup_scatter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipGetLastError(); attr = true;
+    }
+    if (timing) hipLaunchKernelGGL(strgroup_scatter_kernel<true>, dim3(grid), dim3(kSgBlock), sg_scatter_lds(NP), stream(), sp);
+    else hipLaunchKernelGGL(strgroup_scatter_kernel<false>, dim3(grid), dim3(kSgBlock), sg_scatter_lds(NP), stream(), sp);
     PLX_HIP(hipGetLastError());
   }
   Buf counts = dev_alloc_zero(sizeof(uint32_t) * (NP + 1)), cursor = dev_alloc_zero(sizeof(uint32_t) * (NP + 1));
@@ -414,7 +540,7 @@ int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uin
                        cl_off->as<unsigned long long>(), cursor->as<unsigned int>(), cl_ids->as<unsigned int>());
     PLX_HIP(hipGetLastError());
   }
-  const uint64_t max_groups = std::min<uint64_t>((uint64_t)NP << log2_slots, (uint64_t)n);
+  const uint64_t max_groups = std::min<uint64_t>((uint64_t)NP * kSgGroupCap, (uint64_t)n);
   *out_views = dev_alloc(16 * (size_t)max_groups + 16);
   *out_sum = dev_alloc(8 * (size_t)max_groups + 8);
   *out_cnt = dev_alloc(4 * (size_t)max_groups + 8);
@@ -423,10 +549,11 @@ int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uin
   ap.recs = recs->as<unsigned int>(); ap.chunk_fill = chunk_fill->as<unsigned int>(); ap.cl_off = cl_off->as<unsigned long long>(); ap.cl_ids = cl_ids->as<unsigned int>();
   ap.counter = meta->as<unsigned long long>(); ap.overflow = meta->as<unsigned int>() + 2;
   ap.out_views = (*out_views)->as<unsigned long long>(); ap.out_sum = (*out_sum)->as<unsigned long long>(); ap.out_cnt = (*out_cnt)->as<unsigned int>(); ap.out_len = (*out_len)->as<unsigned int>();
-  ap.log2_slots = log2_slots; ap.log2_parts = log2_parts; ap.max_groups = (uint32_t)std::min<uint64_t>(max_groups, 0xffffffffull); ap.is_f64 = is_f64 ? 1u : 0u;
+  ap.variant = variant;
+  ap.max_groups = (uint32_t)std::min<uint64_t>(max_groups, 0xffffffffull); ap.is_f64 = is_f64 ? 1u : 0u;
   {
     ProfileScope ps("strgroup_agg_lds", (uint64_t)n * 24, (uint64_t)n);
-    const size_t lds = ((size_t)1 << log2_slots) * 32;
+    const size_t lds = (size_t)kSgTagSlots * 4 + (size_t)kSgGroupCap * 32;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)strgroup_agg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); attr = true; }
     hipLaunchKernelGGL(strgroup_agg_kernel, dim3(NP), dim3(kSgBlock), lds, stream(), ap);
@@ -434,9 +561,16 @@ int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uin
   }
   uint32_t res[6] = {0, 0, 0, 0, 0, 0};
   d2h_sync(res, meta->ptr, 24);
+  if (timing) {
+    unsigned long long t[9];
+    d2h_sync(t, tbuf->ptr, 72);
+    const double g = (double)grid * 100.0;              // 100 MHz ticks -> microseconds per workgroup
+    fprintf(stderr, "[plx strgroup] scatter thread 0, us per workgroup: barrier A %.0f | scan %.0f | barrier B %.0f | tile %.0f | rows arrive %.0f | rank %.0f | load issue + barrier C %.0f | flush %.0f  (%.0f rounds)\n",
+            t[0] / g, t[1] / g, t[2] / g, t[3] / g, t[4] / g, t[5] / g, t[6] / g, t[7] / g, (double)t[8] / grid);
+  }
   PLX_REQUIRE(!res[3], PLX_ERR_INVALID, "string group-by: a scatter workgroup ran out of chunks");
-  if (res[2] || res[4] || res[5]) return -1;               // table overflow / long strings / the EMPTY pattern: the usual route
-  if (desc) *desc = "strview_groupby(partitioned by view hash, P=512, rec=24B, tile=3072)+lds_view_table(slots=4096), est_groups=" + std::to_string((long long)est_groups);
+  if ((res[2] || res[4] || res[5]) && !variant) return -1;               // table overflow / long strings / the EMPTY pattern: the usual route
+  if (desc) *desc = "strview_groupby(partitioned by view hash, P=512, rec=24B, tile=3072)+lds_tag_table(slots=8192, groups<=3584), est_groups=" + std::to_string((long long)est_groups);
   return (int64_t)(((uint64_t)res[1] << 32) | res[0]);
 }
 

@@ -873,6 +873,7 @@ class LazyFrame:
 
     def collect(self, *, no_fusion: bool = False, no_direct_join: bool = False, no_partition: bool = False) -> DataFrame:
         F.ensure_init()
+        F._plan_note = None
         if not (no_fusion or no_partition):
             fast = _string_key_group_by(self._node)
             if fast is not None:
@@ -968,7 +969,10 @@ def _string_key_group_by(node: P.Node) -> Optional[DataFrame]:
     # mean = sum / count, null for a group without a valid value (count % count is null exactly then), computed by the library over the G result rows
     n = _col("__count")
     outs = [_col(key.name)] + [((_col("__sum").cast(T.Float64) / (n + n % n).cast(T.Float64)) if a == "mean" else _col("__" + a)).alias(o) for o, a in plan]
-    return DataFrame([k, parts["sum"], parts["count"], parts["len"]]).lazy().select(*outs).collect()
+    desc = F.last_plan()
+    out = DataFrame([k, parts["sum"], parts["count"], parts["len"]]).lazy().select(*outs).collect()
+    F._plan_note = desc + F.last_plan()
+    return out
 
 
 class GroupBy:

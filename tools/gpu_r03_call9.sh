@@ -7,6 +7,7 @@ cd $R
 export PLX_SKIP_TORCH_PREIMPORT=1
 timeout 300 python -m pytest tests/test_gpu_zzzz_round3_c.py -m gpu_unvalidated -q --timeout 120 > $OUT/pytest_strgroup.log 2>&1; echo "strgroup tests exit $?"; tail -25 $OUT/pytest_strgroup.log | cut -c1-400
 unset PLX_SKIP_TORCH_PREIMPORT
+PLX_STRGROUP_TIMING=1 timeout 200 python bench.py --workload cfg5s --steps 2 --warmup 1 --no-extras --no-cpu 2>&1 | grep "plx strgroup" | tail -2
 timeout 300 python bench.py --workload cfg5s --steps 6 --warmup 2 --no-extras --no-cpu > $OUT/cfg5s_views.json 2> $OUT/cfg5s_views.err; echo "cfg5s (views) exit $?"
 python - <<'PY' $OUT/cfg5s_views.json
 import json, sys
@@ -17,5 +18,3 @@ for l in open(sys.argv[1]):
         print(json.dumps(d.get("kernels", d.get("kernel_breakdown")), indent=None)[:1500])
 PY
 tail -5 $OUT/cfg5s_views.err | cut -c1-300
-PLX_BENCH_CFG5S_ENCODE=1 timeout 300 python bench.py --workload cfg5s --steps 4 --warmup 2 --no-extras --no-cpu > $OUT/cfg5s_encode.json 2> $OUT/cfg5s_encode.err; echo "cfg5s (encode) exit $?"
-grep -o '"ms_per_step": [0-9.]*' $OUT/cfg5s_encode.json | head -2
