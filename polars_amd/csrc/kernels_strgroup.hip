@@ -57,15 +57,26 @@ struct SgScatter {
   uint32_t variant;                  // PLX_STRGROUP_VARIANT (experiments; results are wrong): 1 no line stores, 2 rows made up from the row index instead of loaded
 };
 
-// LDS: sorted [tile * 6] u32 | carry [NP][32] u32 | cnt, off [NP + 1], desc, dstA, lines_left, dstB, state [NP] u32 | misc [4]
-__host__ __device__ inline size_t sg_scatter_lds(uint32_t NP) { return (size_t)kSgTile * kSgRW * 4 + (size_t)NP * 128 + ((size_t)NP * 7 + 1) * 4 + 16; }
+// the scatter's hash: three 32x32->64 multiply-adds over the string's bytes and its length (multilinear, so the high half is well mixed), folded
+// and multiplied once more -- five quarter-rate instructions where a 64-bit finaliser costs a dozen; 36 bits are used (partition 9 + tag table 27)
+__device__ __forceinline__ uint64_t sg_hash36(uint64_t w0, uint64_t w1) {
+  uint64_t h = (uint64_t)(uint32_t)(w0 >> 32) * 0x9e3779b1u + (uint64_t)((uint32_t)w0 & 15u) * 0x85ebca6bc2b2ae35ull;
+  h += (uint64_t)(uint32_t)w1 * 0xc2b2ae3du;
+  h += (uint64_t)(uint32_t)(w1 >> 32) * 0x27d4eb2fu;
+  const uint32_t g = (uint32_t)(h >> 32) ^ (uint32_t)h * 0x165667b1u;
+  return (uint64_t)g * 0x9e3779b97f4a7c15ull;
+}
 
-// One round = one tile of 3072 rows.  What shapes the schedule (measured with PLX_STRGROUP_TIMING on the first version, 12.6 us per round):
-//  * loads and stores share one counter per wave (vmcnt): a wave that waits for its rows right after it has written lines waits for the
-//    WRITES to be acknowledged.  So rows are consumed (hashed, ranked) BEFORE the round's lines go out, one full round after their loads
-//    were issued, and the stores have until the same point of the next round to drain;
-//  * every per-partition step is an LDS round trip: the scan wave and the flush fetch the words of several partitions at once and only
-//    then act on them; chunk allocation is one wave prefix sum, not one atomic per partition;
+// LDS: sorted [tile * 6] u32 | carry [NP][32] u32 | desc4 [NP] uint4 | cnt, off [NP + 1], lines_left, dstB, state [NP] u32 | wtot [8] | misc [4]
+__host__ __device__ inline size_t sg_scatter_lds(uint32_t NP) { return (size_t)kSgTile * kSgRW * 4 + (size_t)NP * 128 + (size_t)NP * 16 + ((size_t)NP * 5 + 1) * 4 + 32 + 16 + 12; }
+
+// One round = one tile of 3072 rows.  What shapes the schedule (measured phase by phase with PLX_STRGROUP_TIMING; the first version took 12.6 us a round):
+//  * loads and stores share one counter per wave (vmcnt): rows are consumed (hashed, ranked) BEFORE the round's lines go out, one full round
+//    after their loads were issued -- they have always arrived, and the stores have a round to drain;
+//  * with no memory traffic at all the first version still took 8.7 us a round: the kernel is bound by VALU issue (two cycles per wave-instruction,
+//    four waves per SIMD) and LDS round trips, not by HBM.  Hence: the scan is one partition per thread over eight waves (not eight per lane of
+//    one wave while fifteen waves wait); it leaves the flush a ready-made descriptor per partition (one 16-byte read, no decoding arithmetic to
+//    speak of); the flush fetches the words of four partitions before it acts on any; the hash is five multiply-adds;
 //  * a partition receives 36 dwords per round on average: the flush gives it a 32-lane group that writes up to two lines at once.
 template <bool TIMING>
 __global__ __launch_bounds__(kSgBlock) void strgroup_scatter_kernel(SgScatter p) {
@@ -73,14 +84,16 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_scatter_kernel(SgScatter p)
   constexpr uint32_t NP = 512;
   unsigned int* sorted = reinterpret_cast<unsigned int*>(sg_lds);
   unsigned int* carry = sorted + (size_t)kSgTile * kSgRW;
-  unsigned int* cnt = carry + (size_t)NP * 32;
+  // per partition, for the flush: x = (first dword of its rows in the tile) - (carried dwords) [may be negative], y = carried dwords | new carry << 5 |
+  // lines << 10 | has rows << 20 | lines continue in a newly opened chunk << 21, z = line index of its first line
+  uint4* desc4 = reinterpret_cast<uint4*>(carry + (size_t)NP * 32);
+  unsigned int* cnt = reinterpret_cast<unsigned int*>(desc4 + NP);
   unsigned int* off = cnt + NP;
-  unsigned int* desc = off + NP + 1;       // this round: first row in the tile | rows << 12 | carried dwords << 24 | (lines continue in a new chunk) << 31
-  unsigned int* dstA = desc + NP;          // line index of the partition's first line of this round
-  unsigned int* lines_left = dstA + NP;    // lines that still fit the current chunk / first line of the newly opened chunk(s): read only when bit 31 is set
+  unsigned int* lines_left = off + NP + 1; // lines that still fit the current chunk / first line of the newly opened chunk(s): read only when bit 21 is set
   unsigned int* dstB = lines_left + NP;
   unsigned int* state = dstB + NP;         // carried dwords | lines used in the current chunk << 5 | (workgroup-local index of the current chunk + 1) << 11
-  unsigned int* misc = state + NP;         // [0] chunks this workgroup has opened
+  unsigned int* wtot = state + NP + 3;     // (16-byte aligned) per scan wave: rows | chunks needed << 16
+  unsigned int* misc = wtot + 8;           // [0] chunks this workgroup has opened
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (uint32_t i = tid; i < NP; i += kSgBlock) { cnt[i] = 0; state[i] = kSgCapLines << 5; }
   if (tid < 4) misc[tid] = 0;
@@ -90,7 +103,6 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_scatter_kernel(SgScatter p)
   ulonglong2 v[kSgRows], vn[kSgRows];
   unsigned long long x[kSgRows], xn[kSgRows];
   uint32_t part[kSgRows];
-  bool vnull[kSgRows];
   auto load = [&](int64_t rd, ulonglong2* vv, unsigned long long* xx) __attribute__((always_inline)) {
 #pragma unroll
     for (uint32_t j = 0; j < kSgRows; j++) {
@@ -107,15 +119,15 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_scatter_kernel(SgScatter p)
     for (uint32_t j = 0; j < kSgRows; j++) {
       const int64_t row = rd * kSgTile + (int64_t)j * kSgBlock + tid;
       bool live = row < p.n;
-      vnull[j] = live && p.val_validity && !((p.val_validity[row >> 6] >> (row & 63)) & 1);
+      const bool vnull = live && p.val_validity && !((p.val_validity[row >> 6] >> (row & 63)) & 1);
       if (live && (uint32_t)v[j].x > 12u) { p.flags[1] = 1u; live = false; }          // a long string: the view is not the string -> the caller falls back
       part[j] = 0xffffffffu;
       if (live) {
-        const uint64_t h = sg_hash(v[j].x, v[j].y);
+        const uint64_t h = sg_hash36(v[j].x, v[j].y);
         const uint32_t q = (uint32_t)(h >> (64 - 9));
         part[j] = q | atomicAdd(&cnt[q], 1u) << 10;
         // the record's first dword: length (4 bits) | value is null | the 27 hash bits below the partition's, which the aggregation kernel probes with
-        v[j].x = (v[j].x & 0xffffffff0000000full) | (vnull[j] ? 16u : 0u) | ((uint64_t)((uint32_t)(h >> (64 - 9 - 27)) & 0x7ffffffu) << 5);
+        v[j].x = (v[j].x & 0xffffffff0000000full) | (vnull ? 16u : 0u) | ((uint64_t)((uint32_t)(h >> (64 - 9 - 27)) & 0x7ffffffu) << 5);
       }
     }
   };
@@ -125,68 +137,50 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_scatter_kernel(SgScatter p)
   if (rd < nrounds) { load(rd, v, x); rank(rd); }
   if (rd + gridDim.x < nrounds) load(rd + gridDim.x, vn, xn);
   for (; rd < nrounds; rd += gridDim.x) {
-    __syncthreads();                                                                          // A: the tile's ranks are complete, the previous flush is done with off / desc
+    __syncthreads();                                                                          // A: the tile's ranks are complete, the previous flush is done with off / desc4
     SG_TICK(0);
-    if (wave == 0) {
-      // eight consecutive partitions per lane, their words read and written as 16-byte vectors
-      const uint4* cnt4 = reinterpret_cast<const uint4*>(cnt) + lane * 2;
-      const uint4* st4 = reinterpret_cast<const uint4*>(state) + lane * 2;
-      uint32_t s = 0, lane_need = 0;
+    // scan, one partition per thread of waves 0-7
+    uint32_t sc_c = 0, sc_st = 0, sc_v = 0, sc_incl = 0, sc_opened = 0;
+    if (tid < (int)NP) {
+      sc_c = cnt[tid]; sc_st = state[tid]; sc_opened = misc[0];
+      const uint32_t nl = ((sc_st & 31u) + sc_c * kSgRW) >> 5, left = kSgCapLines - ((sc_st >> 5) & 63u);
+      sc_v = sc_c | (nl > left ? (nl - left + kSgCapLines - 1) / kSgCapLines : 0u) << 16;   // rows (<= 3072 in all) and chunks to open, scanned together
+      sc_incl = sc_v;
 #pragma unroll
-      for (uint32_t h = 0; h < 2; h++) {
-        const uint4 cc = cnt4[h], ss = st4[h];
-        const uint32_t c[4] = {cc.x, cc.y, cc.z, cc.w}, st[4] = {ss.x, ss.y, ss.z, ss.w};
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)sc_incl, d, 64); if (lane >= d) sc_incl += o; }
+      if (lane == 63) wtot[wave] = sc_incl;
+    }
+    __syncthreads();                                                                          // A2
+    if (tid < (int)NP) {
+      const uint4 t0 = reinterpret_cast<const uint4*>(wtot)[0], t1 = reinterpret_cast<const uint4*>(wtot)[1];
+      const uint32_t wt[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+      uint32_t pre = 0, tot = 0;
 #pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
-          const uint32_t nl = ((st[q] & 31u) + c[q] * kSgRW) >> 5, left = kSgCapLines - ((st[q] >> 5) & 63u);
-          s += c[q];
-          lane_need += nl > left ? (nl - left + kSgCapLines - 1) / kSgCapLines : 0u;
-        }
+      for (int w = 0; w < 8; w++) { if (w < wave) pre += wt[w]; tot += wt[w]; }
+      const uint32_t excl = pre + sc_incl - sc_v;
+      const uint32_t o = excl & 0xffffu, c = sc_c, pp = (uint32_t)tid;
+      uint32_t base = sc_opened + (excl >> 16);
+      if (tid == (int)NP - 1) { misc[0] = sc_opened + (tot >> 16); off[NP] = tot & 0xffffu; }
+      if (sc_opened + (tot >> 16) > p.chunks_per_wg) { if (tid == 0) p.flags[0] = 1u; base = 0; }      // the host raises; stay inside the workgroup's chunks
+      const uint32_t cd = sc_st & 31u;
+      uint32_t ln = (sc_st >> 5) & 63u, lc = sc_st >> 11;
+      const uint32_t total = cd + c * kSgRW, nl = total >> 5, rem = total & 31u, left = kSgCapLines - ln;
+      uint32_t y = cd | rem << 5 | nl << 10 | (c ? 1u << 20 : 0u), first_line = 0;
+      off[pp] = o;
+      cnt[pp] = 0;
+      if (nl) {
+        first_line = (chunk0 + lc - 1) * kSgCapLines + ln;
+        if (nl > left) {
+          const uint32_t extra = nl - left, need = (extra + kSgCapLines - 1) / kSgCapLines, first = base;
+          if (lc) p.chunk_fill[chunk0 + lc - 1] = kSgChunkRecs;
+          for (uint32_t e = 0; e < need; e++) { p.chunk_part[chunk0 + first + e] = pp; if (e + 1 < need) p.chunk_fill[chunk0 + first + e] = kSgChunkRecs; }
+          if (left == 0) first_line = (chunk0 + first) * kSgCapLines;                         // everything goes to the new chunk(s), which are consecutive
+          else { y |= 1u << 21; lines_left[pp] = left; dstB[pp] = (chunk0 + first) * kSgCapLines; }
+          lc = first + need; ln = extra - (need - 1) * kSgCapLines;
+        } else ln += nl;
       }
-      const uint32_t opened = misc[0];
-      uint32_t incl = s, incl_need = lane_need;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64), o2 = (uint32_t)__shfl_up((int)incl_need, d, 64);
-        if (lane >= d) { incl += o; incl_need += o2; }
-      }
-      uint32_t o = incl - s, base = opened + incl_need - lane_need;
-      if (lane == 63) { misc[0] = opened + incl_need; off[NP] = incl; if (opened + incl_need > p.chunks_per_wg) p.flags[0] = 1u; }
-      if (base + lane_need > p.chunks_per_wg) base = 0;                                       // flagged above: the host raises; stay inside the workgroup's chunks
-#pragma unroll 1
-      for (uint32_t h = 0; h < 2; h++) {
-        const uint4 cc = cnt4[h], ss = st4[h];
-        const uint32_t c[4] = {cc.x, cc.y, cc.z, cc.w}, st[4] = {ss.x, ss.y, ss.z, ss.w};
-        uint32_t ov[4], av[4], sv[4];
-#pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
-          const uint32_t pp = (uint32_t)lane * 8 + h * 4 + q;
-          const uint32_t cd = st[q] & 31u;
-          uint32_t ln = (st[q] >> 5) & 63u, lc = st[q] >> 11;
-          const uint32_t total = cd + c[q] * kSgRW, nl = total >> 5, left = kSgCapLines - ln;
-          uint32_t a = o | c[q] << 12 | cd << 24;
-          ov[q] = o; o += c[q];
-          if (nl) {
-            uint32_t first_line = (chunk0 + lc - 1) * kSgCapLines + ln;
-            if (nl > left) {
-              const uint32_t extra = nl - left, need = (extra + kSgCapLines - 1) / kSgCapLines, first = base;
-              base += need;
-              if (lc) p.chunk_fill[chunk0 + lc - 1] = kSgChunkRecs;
-              for (uint32_t e = 0; e < need; e++) { p.chunk_part[chunk0 + first + e] = pp; if (e + 1 < need) p.chunk_fill[chunk0 + first + e] = kSgChunkRecs; }
-              if (left == 0) first_line = (chunk0 + first) * kSgCapLines;                     // everything goes to the new chunk(s), which are consecutive
-              else { a |= 0x80000000u; lines_left[pp] = left; dstB[pp] = (chunk0 + first) * kSgCapLines; }
-              lc = first + need; ln = extra - (need - 1) * kSgCapLines;
-            } else ln += nl;
-            dstA[pp] = first_line;
-          }
-          av[q] = a;
-          sv[q] = (total & 31u) | ln << 5 | lc << 11;
-        }
-        reinterpret_cast<uint4*>(off)[lane * 2 + h] = make_uint4(ov[0], ov[1], ov[2], ov[3]);
-        reinterpret_cast<uint4*>(cnt)[lane * 2 + h] = make_uint4(0, 0, 0, 0);
-        reinterpret_cast<uint4*>(desc)[lane * 2 + h] = make_uint4(av[0], av[1], av[2], av[3]);
-        reinterpret_cast<uint4*>(state)[lane * 2 + h] = make_uint4(sv[0], sv[1], sv[2], sv[3]);
-      }
+      desc4[pp] = make_uint4(o * kSgRW - cd, y, first_line, 0u);
+      state[pp] = rem | ln << 5 | lc << 11;
     }
     SG_TICK(1);
     __syncthreads();                                                                          // B
@@ -212,43 +206,41 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_scatter_kernel(SgScatter p)
     __syncthreads();                                                                          // C: the tile is complete
     SG_TICK(6);
     {
-      const uint32_t g = (uint32_t)tid >> 5, l32 = (uint32_t)tid & 31u, d = l32 * 2;         // lanes 0-15: the first line, 16-31: the second
+      const uint32_t g = (uint32_t)tid >> 5, l32 = (uint32_t)tid & 31u, d = l32 * 2, li = l32 >> 4;   // lanes 0-15: the first line, 16-31: the second
+      const int sorted_d = (int)d, sorted_r = (int)l32;
 #pragma unroll 1
       for (uint32_t b4 = 0; b4 < 4; b4++) {
-        uint32_t a[4], da[4];
+        uint4 D[4];
 #pragma unroll
-        for (uint32_t q = 0; q < 4; q++) { const uint32_t pp = g + (b4 * 4 + q) * 32u; a[q] = desc[pp]; da[q] = dstA[pp]; }
+        for (uint32_t q = 0; q < 4; q++) D[q] = desc4[g + (b4 * 4 + q) * 32u];
         uint2 w[4];
         uint32_t r[4];
 #pragma unroll
         for (uint32_t q = 0; q < 4; q++) {
           const uint32_t pp = g + (b4 * 4 + q) * 32u;
-          const uint32_t o_dw = (a[q] & 4095u) * kSgRW, r_dw = ((a[q] >> 12) & 4095u) * kSgRW, c_dw = (a[q] >> 24) & 31u, nl = (c_dw + r_dw) >> 5;
-          // dword d of the partition's stream (carry first, then its rows of the tile); d, c_dw and o_dw are even: one 8-byte read
-          w[q] = *reinterpret_cast<const uint2*>(d < c_dw ? carry + (size_t)pp * 32 + d : sorted + o_dw + d - c_dw);
-          // the new carry's dword l32 = dword nl * 32 + l32 of the stream
-          const uint32_t sd = nl * 32 + l32;
-          r[q] = sd < c_dw ? carry[(size_t)pp * 32 + sd] : sorted[o_dw + sd - c_dw];
+          const uint32_t c_dw = D[q].y & 31u, nl32 = (D[q].y >> 5) & (1023u << 5);            // lines * 32
+          // dword d of the partition's stream (carry first, then its rows of the tile); d, the carry length and the row offset are even: one 8-byte read
+          w[q] = *reinterpret_cast<const uint2*>(d < c_dw ? carry + (size_t)pp * 32 + d : sorted + ((int)D[q].x + sorted_d));
+          // the new carry's dword l32 = dword lines * 32 + l32 of the stream
+          const uint32_t sd = nl32 + l32;
+          r[q] = sd < c_dw ? carry[(size_t)pp * 32 + sd] : sorted[(int)D[q].x + (int)nl32 + sorted_r];
         }
 #pragma unroll
         for (uint32_t q = 0; q < 4; q++) {
           const uint32_t pp = g + (b4 * 4 + q) * 32u;
-          const uint32_t r_dw = ((a[q] >> 12) & 4095u) * kSgRW, c_dw = (a[q] >> 24) & 31u, total = c_dw + r_dw, nl = total >> 5, rem = total & 31u;
-          const uint32_t li = l32 >> 4;
+          const uint32_t y = D[q].y, nl = (y >> 10) & 1023u;
           if (li < nl && !(p.variant & 1u)) {
-            uint64_t line = (uint64_t)da[q] + li;
-            if ((a[q] >> 31) && li >= lines_left[pp]) line = (uint64_t)dstB[pp] + (li - lines_left[pp]);
+            uint64_t line = (uint64_t)D[q].z + li;
+            if ((y >> 21) & 1u) { const uint32_t left = lines_left[pp]; if (li >= left) line = (uint64_t)dstB[pp] + (li - left); }
             *reinterpret_cast<uint2*>(p.recs + line * 32 + (l32 & 15u) * 2) = w[q];
           }
-          if (r_dw && l32 < rem) carry[(size_t)pp * 32 + l32] = r[q];
+          if (((y >> 20) & 1u) && l32 < ((y >> 5) & 31u)) carry[(size_t)pp * 32 + l32] = r[q];
           if (nl > 2) {
             // three or more lines for one partition in one round (skew): the rest of its lines, two at a time
-            const uint32_t o_dw = (a[q] & 4095u) * kSgRW;
-            const uint32_t left = (a[q] >> 31) ? lines_left[pp] : 0xffffffffu, b = (a[q] >> 31) ? dstB[pp] : 0u;
+            const uint32_t left = ((y >> 21) & 1u) ? lines_left[pp] : 0xffffffffu, b = ((y >> 21) & 1u) ? dstB[pp] : 0u;
             for (uint32_t i = 2 + li; i < nl; i += 2) {
-              const uint32_t dd = i * 32 + (l32 & 15u) * 2;
-              const uint2 ww = *reinterpret_cast<const uint2*>(sorted + o_dw + dd - c_dw);
-              const uint64_t line = i < left ? (uint64_t)da[q] + i : (uint64_t)b + (i - left);
+              const uint2 ww = *reinterpret_cast<const uint2*>(sorted + ((int)D[q].x + (int)(i * 32 + (l32 & 15u) * 2)));
+              const uint64_t line = i < left ? (uint64_t)D[q].z + i : (uint64_t)b + (i - left);
               *reinterpret_cast<uint2*>(p.recs + line * 32 + (l32 & 15u) * 2) = ww;
             }
           }
@@ -323,18 +315,18 @@ struct SgAgg {
   uint32_t variant;                  // PLX_STRGROUP_VARIANT (experiments; results are wrong): 16 no accumulation, 32 no probing, 64 loads only
 };
 
-constexpr uint32_t kSgTagSlots = 8192, kSgGroupCap = 3584;      // per partition: 32 KB of tag words + 3584 groups x 32 B = 144 KB of LDS
+constexpr uint32_t kSgTagSlots = 16384, kSgGroupCap = 2816;     // per partition: 64 KB of tag words + 2816 groups x 32 B = 152 KB of LDS
 constexpr uint32_t kSgPending = 0xfffu;
 
 // One workgroup per partition.  The probe loop is VALU- and LDS-issue bound, not latency bound (measured: with the probe loop 13 ms, without it
 // 4.3 ms = the time of the record loads alone), so the loop body is as small as it can be:
 //  * the record carries 27 bits of its view's hash (written by the scatter): no hashing here;
-//  * tag table: 8192 words {14-bit tag | 12-bit group index}, at most 35 % full -- a probe is ONE 4-byte LDS read and two compares; a matching tag is
-//    confirmed once against the group's 16-byte view (a false match, ~1e-5 of the lookups, just probes on);
+//  * tag table: 16384 words {13-bit tag | 12-bit group index}, at most 14 % full -- a probe is ONE 4-byte LDS read and two compares; a matching tag is
+//    confirmed once against the group's 16-byte view (a false match, ~2e-5 of the lookups, just probes on);
 //  * groups get dense indices in claim order (keys and cells live in [group] arrays): the output needs no compaction.
 // Claim: CAS empty -> {tag | pending}; the winner takes the next group index, writes the view, then publishes {tag | index} (LDS operations of one
 // wave complete in order); whoever sees {tag | pending} looks again.
-// LDS: tags [8192] u32 | w0 [cap] u64 | w1 [cap] u64 | sum [cap] u64 | cnt [cap] u32 | len [cap] u32
+// LDS: tags [16384] u32 | w0 [cap] u64 | w1 [cap] u64 | sum [cap] u64 | cnt [cap] u32 | len [cap] u32
 __global__ __launch_bounds__(kSgBlock) void strgroup_agg_kernel(SgAgg a) {
   extern __shared__ unsigned long long sg_lds[];
   unsigned int* tags = reinterpret_cast<unsigned int*>(sg_lds);
@@ -390,7 +382,7 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_agg_kernel(SgAgg a) {
 #pragma unroll
       for (uint32_t u = 0; u < kPerLane; u++) {
         if (g[u] != kSgPending) continue;
-        const uint32_t tag = r[u][0].x >> 18;                                 // the 14 hash bits above the slot's 13
+        const uint32_t tag = r[u][0].x >> 19;                                 // the 13 hash bits above the slot's 14
         if (e[u] == 0xffffffffu) {
           if (atomicCAS(&tags[ts[u]], 0xffffffffu, tag << 12 | kSgPending) == 0xffffffffu) {
             const uint32_t idx = atomicAdd(&n_groups, 1u);
@@ -496,7 +488,7 @@ int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uin
   const uint32_t log2_parts = 9, NP = 1u << log2_parts;
   static_assert(kSgBlock == 1024, "the scatter kernel's scan wave and flush step take eight partitions per lane / sixteen per 32-lane group: 512 partitions, 1024 threads");
   const double est_groups = sg_estimate_groups(views, n);
-  if (est_groups < 0 || est_groups > (double)NP * (double)kSgGroupCap * 0.8) return -1;      // a partition's groups must fit its LDS storage (3584) with room for the spread
+  if (est_groups < 0 || est_groups > (double)NP * (double)kSgGroupCap * 0.8) return -1;      // a partition's groups must fit its LDS storage (2816) with room for the spread
   const int64_t nrounds = (n + kSgTile - 1) / kSgTile;
   const uint32_t grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(nrounds, device().cu_count));
   const int64_t rounds_per_wg = (nrounds + grid - 1) / grid;
@@ -570,7 +562,7 @@ int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uin
   }
   PLX_REQUIRE(!res[3], PLX_ERR_INVALID, "string group-by: a scatter workgroup ran out of chunks");
   if ((res[2] || res[4] || res[5]) && !variant) return -1;               // table overflow / long strings / the EMPTY pattern: the usual route
-  if (desc) *desc = "strview_groupby(partitioned by view hash, P=512, rec=24B, tile=3072)+lds_tag_table(slots=8192, groups<=3584), est_groups=" + std::to_string((long long)est_groups);
+  if (desc) *desc = "strview_groupby(partitioned by view hash, P=512, rec=24B, tile=3072)+lds_tag_table(slots=16384, groups<=2816), est_groups=" + std::to_string((long long)est_groups);
   return (int64_t)(((uint64_t)res[1] << 32) | res[0]);
 }
 

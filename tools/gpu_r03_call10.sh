@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r03j
 mkdir -p $OUT
 cd $R
-for V in 0 3 32 64; do
+for V in 3; do
   PLX_BENCH_VERIFY=0 PLX_STRGROUP_VARIANT=$V timeout 120 python bench.py --workload cfg5s --steps 3 --warmup 1 --no-extras --no-cpu > $OUT/v$V.json 2> $OUT/v$V.err
   python - $OUT/v$V.json $V <<'PY'
 import json, sys
