@@ -6,7 +6,7 @@ import numpy as np
 import pyarrow as pa
 import pytest
 
-pytestmark = pytest.mark.gpu_unvalidated
+pytestmark = pytest.mark.gpu
 
 
 def _views_series(pl, strings):
@@ -25,7 +25,7 @@ def _by_key(out, key="k"):
 
 def test_string_key_group_by_on_views_matches_numpy_and_the_encoded_route(pl):
     from polars_amd import datagen
-    n, seed, n_keys = 9_000_001, 12, 200_000
+    n, seed, n_keys = 60_000_001, 12, 200_000          # ~76 tiles per workgroup: every partition's lines cross into a second chunk
     views = datagen.id_views_native(pl, "k", n, seed, 0, 1, n_keys + 1)
     v = datagen.uniform_native(pl, "v", pl.Float64, n, seed, 1, 0, 10 ** 9, 1e-7)
     k = pl.Series.from_device_views("k", views, encode="deferred")
@@ -93,7 +93,7 @@ def test_string_key_group_by_declines_long_strings_and_many_groups(pl):
     hs = [C.c_uint64() for _ in range(5)]
     st = F.lib().plx_strview_groupby(views._h, v._h, *[C.byref(h) for h in hs])
     assert st == F.ERR_UNSUPPORTED and b"12 bytes" in F.lib().plx_last_error()
-    # more distinct strings than the LDS tables hold (512 partitions x 4096 slots at 60 %): declined on the sample estimate, the usual route answers
+    # more distinct strings than the LDS tables hold (512 partitions x 2816 groups at 80 %): declined on the sample estimate, the usual route answers
     from polars_amd import datagen
     n, n_keys = 4_000_000, 3_000_000
     views = datagen.id_views_native(pl, "k", n, 3, 0, 1, n_keys + 1)

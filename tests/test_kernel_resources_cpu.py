@@ -70,3 +70,14 @@ def test_parquet_kernels_do_not_spill_and_fit_two_snappy_workgroups_per_cu():
             assert int(r["LDS Size [bytes/block]"]) <= 80 * 1024, (name, r)
             assert int(r["VGPRs"]) <= 256, (name, r)          # two 256-thread workgroups per CU = two waves per SIMD: 256 registers each at most
     assert sum("pq_snappy" in n for n in res) == 2           # generation 2 (the default since round 3) and generation 1 (PLX_SNAPPY_KERNEL=1)
+
+
+def test_string_group_by_kernels_do_not_spill():
+    """kernels_strgroup.hip: 1024-thread workgroups (128 registers at most); the scatter's first version with batched LDS reads spilled 648 B / lane.
+    (The <true> instantiation is the PLX_STRGROUP_TIMING build with its phase clocks: diagnostics, allowed a few spilled registers.)"""
+    res = resource_usage("kernels_strgroup.hip")
+    assert len(res) >= 6
+    for name, r in res.items():
+        timing_build = "strgroup_scatter_kernelILb1" in name
+        assert int(r["ScratchSize [bytes/lane]"]) <= (64 if timing_build else 0), (name, r)
+        assert int(r["VGPRs"]) <= 128, (name, r)
