@@ -211,7 +211,7 @@ static uint32_t bits_for(uint64_t span) { uint32_t b = 0; while (b < 64 && (span
 // third generation: packing from the value ranges, tile size from the LDS budget.  false: this shape / geometry stays on generation 2
 static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange* ranges, size_t lds_total) {
   const uint32_t NP = 1u << pp.log2_parts;
-  if (NP < 64) return false;                                                   // the scan wave owns NP / 64 partitions per lane
+  if (NP < 64 || NP > (uint32_t)kP2MaxBlock) return false;                    // the scan takes one partition per thread, in whole waves
   uint32_t pack = kPackNone;
   const char* pe = getenv("PLX_PART_PACK");
   const uint32_t pack_cap = pe ? (uint32_t)std::max(0, std::min(2, atoi(pe))) : 2u;

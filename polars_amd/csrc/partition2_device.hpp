@@ -119,7 +119,7 @@ __device__ __forceinline__ void p2_static_for(F&& f) {
 template <class P, int MODE, int TILES = 1>
 __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args args, const PartPlan2 pp, const ScatterParams2 sp) {
   static_assert(P::kStatic, "the partitioned group-by runs specialised programs only (AOT or JIT)");
-  extern __shared__ unsigned long long p2_lds[];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long p2_lds[];
   constexpr Shape sh = P::shape();
   constexpr RecLayout2 L = rec_layout2(P::shape(), (uint32_t)MODE);
   constexpr uint32_t RW = L.rec_words;
@@ -381,7 +381,7 @@ __device__ __forceinline__ void load_rec2(const unsigned int* p, unsigned int* r
 
 template <class S, int MODE>
 __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L, const PartPlan2& pp, const AggParams2& ap) {
-  extern __shared__ unsigned long long p2_lds[];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long p2_lds[];
   constexpr uint32_t kPerLane = kP2ChunkRecs / 64;    // records of a chunk per lane
   const uint32_t NS = 1u << pp.log2_slots, n_aggs = sh.n_aggs, RW = L.rec_words, chunk_dw = kP2ChunkRecs * RW;
   const bool direct = MODE == (int)kP2Direct;

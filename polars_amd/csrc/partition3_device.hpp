@@ -7,14 +7,17 @@
 // bytes.  This one sorts a whole TILE of rows by partition inside the workgroup and writes whole lines only:
 //
 //   rank      one returning ds_add_u32 per row on the partition's counter: the row's rank within (tile, partition)
-//   scan      one wave turns the counts into offsets of the sorted tile and, per partition, (carry + run) dwords into a number of whole
-//             128-B lines and their destination: the rest of the partition's current chunk, then fresh chunks (consecutive, from the
-//             workgroup's PRIVATE region: no counting pass, no global atomics)
+//   scan      one partition per thread (NP / 64 waves, one prefix sum for the tile offsets AND the chunk allocation): per partition, (carry + run)
+//             dwords become a number of whole 128-B lines and their destination -- the rest of the partition's current chunk, then fresh chunks
+//             (consecutive, from the workgroup's PRIVATE region: no counting pass, no global atomics) -- left behind as ONE 16-byte descriptor
 //   sort      every row's packed record goes to its slot of the LDS tile
-//   copy-out  a 16-lane group per partition streams carry + run out as aligned 128-B lines (8 B per lane) and leaves the dwords that do
-//             not fill a line in the partition's CARRY line for the next round: partial lines never reach HBM (a partial line is a
-//             read-modify-write at the DRAM: 6.1 ms per 1e9 rows with them, 5.0 ms without)
-// Three barriers per round of blockDim * 2 * TILES rows (8192 for the benchmark shapes).  Rows of hot keys (heavy hitters of the sample)
+//   copy-out  a 16-lane group per partition reads the descriptor (one ds_read_b128), streams carry + run out as aligned 128-B lines (8 B per
+//             lane, one two-dword LDS read per line) and leaves the dwords that do not fill a line in the partition's CARRY line for the next
+//             round: partial lines never reach HBM (a partial line is a read-modify-write at the DRAM: 6.1 ms per 1e9 rows with them, 5.0 without)
+// The per-round cost is the LDS instruction stream, not HBM (kernels_strgroup.hip has the measurements): the scan used to be four to sixteen
+// partitions per lane of ONE wave with an LDS atomic per chunk opening, the copy-out seven dword reads of per-partition words and two reads per
+// line -- tools/micro_part3.hip scatter3c vs scatter3d, 1e9 rows: 4-B records 4.45 -> 3.93 ms, 12-B 6.45 -> 5.53 (profiles/r03/micro_part3_descriptor_flush.txt).
+// Four barriers per round of blockDim * 2 * TILES rows (8192 for the benchmark shapes).  Rows of hot keys (heavy hitters of the sample)
 // never become records: they are aggregated in LDS accumulators on the spot, as before.
 #pragma once
 #include "partition2_device.hpp"
@@ -22,19 +25,21 @@
 namespace plx {
 namespace k {
 
-// LDS of the scatter kernel (dynamic shared memory), in this order (u64 arrays first):
+// LDS of the scatter kernel (dynamic shared memory, 16-byte aligned), in this order:
+//   desc [NP] uint4               per partition and round, written by the scan for the copy-out: x = (first dword of its rows in the tile) - (carried dwords),
+//                                 y = carried dwords | new carry << 5 | whole lines << 10 | has rows << 24 | lines continue in newly opened chunks << 25, z = its first line
 //   hot_k [hot_slots] u64, hot_acc [n_hot * n_aggs * copies] u64
 //   sorted [T * RW] u32           the tile, sorted by partition (T = block * kRows * TILES rows)
 //   carry  [NP][32] u32           dwords of a partition that do not fill a line yet
-//   cnt, off[NP + 1], carry_dw, dstA, lines_left, dstB, cur_chunk, cur_lines [NP] u32 each; hot_i [hot_slots] u32; misc [4] u32
+//   cnt, off[NP + 1], carry_dw, lines_left, dstB, cur_chunk, cur_lines [NP] u32 each; hot_i [hot_slots] u32; wtot [16] u32; misc [4] u32
 __host__ __device__ inline size_t part3_scatter_lds(uint32_t T, uint32_t RW, uint32_t NP, uint32_t hot_slots, uint32_t n_hot, uint32_t n_aggs, uint32_t copies) {
-  return (size_t)hot_slots * 8 + (size_t)n_hot * n_aggs * copies * 8 + (size_t)T * RW * 4 + (size_t)NP * 128 + ((size_t)NP * 8 + 1) * 4 + (size_t)hot_slots * 4 + 16;
+  return (size_t)NP * 16 + (size_t)hot_slots * 8 + (size_t)n_hot * n_aggs * copies * 8 + (size_t)T * RW * 4 + (size_t)NP * 128 + ((size_t)NP * 7 + 1) * 4 + (size_t)hot_slots * 4 + 64 + 16;
 }
 
 template <class P, int MODE, int TILES, int PACK, bool HOT = true>
 __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args args, const PartPlan2 pp, const ScatterParams2 sp) {
   static_assert(P::kStatic, "the partitioned group-by runs specialised programs only (AOT or JIT)");
-  extern __shared__ unsigned long long p2_lds[];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long p2_lds[];
   constexpr Shape sh = P::shape();
   constexpr RecLayout2 L = rec_layout2(P::shape(), (uint32_t)MODE, (uint32_t)PACK);
   constexpr uint32_t RW = L.rec_words;
@@ -42,20 +47,21 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
   const uint32_t NP = 1u << pp.log2_parts;
   const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0u;
   const uint32_t T = blockDim.x * kRows * TILES;
-  unsigned long long* hot_k = p2_lds;
+  uint4* desc = reinterpret_cast<uint4*>(p2_lds);
+  unsigned long long* hot_k = p2_lds + (size_t)NP * 2;
   unsigned long long* hot_acc = hot_k + hot_slots;
   unsigned int* sorted = reinterpret_cast<unsigned int*>(hot_acc + (size_t)pp.n_hot * sh.n_aggs * pp.hot_copies);
   unsigned int* carry = sorted + (size_t)T * RW;
   unsigned int* cnt = carry + (size_t)NP * 32;
   unsigned int* off = cnt + NP;
   unsigned int* carry_dw = off + NP + 1;
-  unsigned int* dstA = carry_dw + NP;         // first destination of a partition's lines this round, in lines (chunk * cap_lines + line)
-  unsigned int* lines_left = dstA + NP;       // lines that still fit there
-  unsigned int* dstB = lines_left + NP;       // the rest goes here (fresh consecutive chunks), in lines
+  unsigned int* lines_left = carry_dw + NP;   // read only for a partition whose lines continue in newly opened chunks: lines that still fit the current chunk ...
+  unsigned int* dstB = lines_left + NP;       // ... and where the rest goes (fresh consecutive chunks), in lines
   unsigned int* cur_chunk = dstB + NP;
   unsigned int* cur_lines = cur_chunk + NP;   // lines of the current chunk already written (cap_lines: none open / full)
   unsigned int* hot_i = cur_lines + NP;
-  unsigned int* misc = hot_i + hot_slots;     // [0] next chunk of this workgroup's region
+  unsigned int* wtot = hot_i + hot_slots;     // [16] per scan wave: rows | chunks to open << 16
+  unsigned int* misc = wtot + 16;             // [0] next chunk of this workgroup's region
   const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   for (uint32_t i = threadIdx.x; i < NP; i += blockDim.x) { cnt[i] = 0; carry_dw[i] = 0; cur_chunk[i] = kNoChunk; cur_lines[i] = cap_lines; }
   for (uint32_t i = threadIdx.x; i < hot_slots; i += blockDim.x) { hot_k[i] = sp.hot_tbl_keys[i]; hot_i[i] = sp.hot_tbl_idx[i]; }
@@ -159,7 +165,6 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
     finish_round(rd_first, issue_loads(rd_first));
     if (kEarly) pre_early = issue_loads(rd_first + stride);
   }
-  const uint32_t per_lane = NP >> 6;          // partitions per lane of the scan wave (NP is a power of two >= 64)
   for (int64_t rd = rd_first; rd < nrounds; rd += stride) {
     // ---- rank: one LDS atomic per surviving row (kept in the row's `part` word: partition in the low 10 bits, rank above them)
     p2_static_for<TILES>([&](auto tc) __attribute__((always_inline)) {
@@ -168,36 +173,43 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
       for (int r = 0; r < kRows; r++) if (part[t][r] != kNotPending) part[t][r] |= atomicAdd(&cnt[part[t][r]], 1u) << 10;
     });
     __syncthreads();                                                                  // A: the counts are complete
-    // ---- scan (one wave): tile offsets, lines and destinations of every partition
-    if (wave == 0) {
-      uint32_t s = 0;
-      for (uint32_t q = 0; q < per_lane; q++) s += cnt[(uint32_t)lane * per_lane + q];
-      uint32_t incl = s;
+    // ---- scan, one partition per thread: tile offsets, lines and destinations of every partition
+    uint32_t sc_c = 0, sc_cd = 0, sc_ln = 0, sc_ch = 0, sc_v = 0, sc_incl = 0, sc_opened = 0;
+    if (threadIdx.x < NP) {
+      const uint32_t p = threadIdx.x;
+      sc_c = cnt[p]; sc_cd = carry_dw[p]; sc_ln = cur_lines[p]; sc_ch = cur_chunk[p]; sc_opened = misc[0];
+      const uint32_t nl = (sc_cd + sc_c * RW) >> 5, left = cap_lines - sc_ln;          // left: 0 when no chunk is open (cur_lines == cap_lines)
+      sc_v = sc_c | (nl > left ? (nl - left + cap_lines - 1) / cap_lines : 0u) << 16;   // rows (<= T < 2^16 in all) and chunks to open, scanned together
+      sc_incl = sc_v;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
-      uint32_t o = incl - s;
-      for (uint32_t q = 0; q < per_lane; q++) {
-        const uint32_t p = (uint32_t)lane * per_lane + q;
-        const uint32_t c = cnt[p];
-        off[p] = o; o += c;
-        cnt[p] = 0;
-        const uint32_t nl = (carry_dw[p] + c * RW) >> 5;
-        if (nl) {
-          uint32_t ch = cur_chunk[p], ln = cur_lines[p];
-          const uint32_t left = cap_lines - ln;                                        // 0 when no chunk is open (ln == cap_lines)
-          dstA[p] = ch * cap_lines + ln; lines_left[p] = left;
-          if (nl > left) {
-            const uint32_t extra = nl - left, need = (extra + cap_lines - 1) / cap_lines;
-            if (ch != kNoChunk) sp.chunk_fill[ch] = kP2ChunkRecs;
-            const uint32_t first = open_chunks(p, need);
-            for (uint32_t e = 0; e + 1 < need; e++) sp.chunk_fill[first + e] = kP2ChunkRecs;
-            dstB[p] = first * cap_lines;
-            ch = first + need - 1; ln = extra - (need - 1) * cap_lines;
-          } else ln += nl;
-          cur_chunk[p] = ch; cur_lines[p] = ln;
-        }
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)sc_incl, d, 64); if (lane >= d) sc_incl += o; }
+      if (lane == 63) wtot[wave] = sc_incl;
+    }
+    __syncthreads();                                                                  // A2: the scan waves' totals
+    if (threadIdx.x < NP) {
+      const uint32_t p = threadIdx.x;
+      uint32_t pre = 0, tot = 0;
+      for (uint32_t w = 0; w < (NP >> 6); w++) { const uint32_t x = wtot[w]; if (w < (uint32_t)wave) pre += x; tot += x; }
+      const uint32_t excl = pre + sc_incl - sc_v, o = excl & 0xffffu, c = sc_c;
+      uint32_t local = sc_opened + (excl >> 16);                                       // this partition's first fresh chunk, within the workgroup's region
+      if (p == NP - 1) { misc[0] = sc_opened + (tot >> 16); off[NP] = tot & 0xffffu; }
+      if (sc_opened + (tot >> 16) > pp.chunks_per_wg) { if (p == 0) sp.flags[0] = 1u; local = 0; }   // cannot happen by construction; the query fails if it does
+      const uint32_t cd = sc_cd, total = cd + c * RW, nl = total >> 5, rem = total & 31u, left = cap_lines - sc_ln;
+      uint32_t ln = sc_ln, ch = sc_ch, y = cd | rem << 5 | nl << 10 | (c ? 1u << 24 : 0u), first_line = 0;
+      off[p] = o; cnt[p] = 0; carry_dw[p] = rem;
+      if (nl) {
+        first_line = ch * cap_lines + ln;
+        if (nl > left) {
+          const uint32_t extra = nl - left, need = (extra + cap_lines - 1) / cap_lines, first = chunk0 + local;
+          if (ch != kNoChunk) sp.chunk_fill[ch] = kP2ChunkRecs;
+          for (uint32_t e = 0; e < need; e++) { sp.chunk_part[first + e] = p; if (e + 1 < need) sp.chunk_fill[first + e] = kP2ChunkRecs; }
+          if (left == 0) first_line = first * cap_lines;                                // everything goes to the new chunk(s), which are consecutive
+          else { y |= 1u << 25; lines_left[p] = left; dstB[p] = first * cap_lines; }
+          ch = first + need - 1; ln = extra - (need - 1) * cap_lines;
+        } else ln += nl;
+        cur_chunk[p] = ch; cur_lines[p] = ln;
       }
-      if (lane == 63) off[NP] = o;
+      desc[p] = make_uint4(o * RW - cd, y, first_line, 0u);
     }
     __syncthreads();                                                                  // B: offsets and destinations are known
     // ---- sort: every record to its slot of the tile
@@ -217,24 +229,35 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
     __syncthreads();                                                                  // C: the tile is sorted
     // ---- copy-out: whole lines to HBM, the rest into the carry lines
     {
-      const uint32_t g = threadIdx.x >> 4, l16 = threadIdx.x & 15u;
+      const uint32_t g = threadIdx.x >> 4, l16 = threadIdx.x & 15u, d = l16 * 2;
       for (uint32_t p = g; p < NP; p += blockDim.x >> 4) {
-        const uint32_t o_dw = off[p] * RW, r_dw = (off[p + 1] - off[p]) * RW, c_dw = carry_dw[p];
-        const uint32_t total = c_dw + r_dw, nl = total >> 5, rem = total & 31u;
-        const unsigned int* cy = carry + (size_t)p * 32;
-        const uint32_t a = dstA[p], left = lines_left[p], b = dstB[p];
-        for (uint32_t i = 0; i < nl; i++) {
-          const uint32_t d = i * 32 + l16 * 2;
-          uint2 w;
-          w.x = d < c_dw ? cy[d] : sorted[o_dw + d - c_dw];
-          w.y = d + 1 < c_dw ? cy[d + 1] : sorted[o_dw + d + 1 - c_dw];
-          const uint64_t line = i < left ? (uint64_t)a + i : (uint64_t)b + (i - left);
-          if (!(pp.ablate & 1u)) *reinterpret_cast<uint2*>(sp.recs + line * 32 + l16 * 2) = w;
+        const uint4 D = desc[p];
+        const int s0 = (int)D.x;                                                       // dword i of the partition's stream (carry first) = sorted[s0 + i] for i >= c_dw
+        const uint32_t y = D.y, c_dw = y & 31u, rem = (y >> 5) & 31u, nl = (y >> 10) & 0x3fffu;
+        uint32_t left = 0xffffffffu, b = 0;
+        if ((y >> 25) & 1u) { left = lines_left[p]; b = dstB[p]; }
+        if (nl) {
+          // the first line may start in the carry; a lane's two dwords come from ONE base (a two-dword read), and the one lane whose pair straddles the
+          // end of the carry takes its second dword from the tile
+          const unsigned int* src = d < c_dw ? carry + (size_t)p * 32 + d : sorted + (s0 + (int)d);
+          uint2 w = make_uint2(src[0], src[1]);
+          if (d < c_dw && d + 1 >= c_dw) w.y = sorted[s0 + (int)d + 1];
+          if (!(pp.ablate & 1u)) *reinterpret_cast<uint2*>(sp.recs + (uint64_t)D.z * 32 + d) = w;
+          for (uint32_t i = 1; i < nl; i++) {
+            const unsigned int* s2 = sorted + (s0 + (int)(i * 32 + d));
+            const uint2 w2 = make_uint2(s2[0], s2[1]);
+            const uint64_t line = i < left ? (uint64_t)D.z + i : (uint64_t)b + (i - left);
+            if (!(pp.ablate & 1u)) *reinterpret_cast<uint2*>(sp.recs + line * 32 + d) = w2;
+          }
         }
-        // the new carry = dwords [nl * 32, total) of the stream (16 lanes of one wave: the reads above happen before these writes)
-        if (nl == 0) { for (uint32_t i = l16; i < r_dw; i += 16) carry[(size_t)p * 32 + c_dw + i] = sorted[o_dw + i]; }
-        else { for (uint32_t i = l16; i < rem; i += 16) carry[(size_t)p * 32 + i] = sorted[o_dw + nl * 32 + i - c_dw]; }
-        if (l16 == 0) carry_dw[p] = rem;
+        // the new carry = dwords [nl * 32, nl * 32 + rem) of the stream; without a whole line the old carry stays and the run is appended
+        // (16 lanes of one wave: the reads above happen before these writes)
+        if ((y >> 24) & 1u) {
+          const unsigned int* s3 = sorted + (s0 + (int)(nl * 32 + d));
+          const uint32_t r0 = s3[0], r1 = s3[1], lo = nl ? 0u : c_dw;
+          if (d >= lo && d < rem) carry[(size_t)p * 32 + d] = r0;
+          if (d + 1 >= lo && d + 1 < rem) carry[(size_t)p * 32 + d + 1] = r1;
+        }
       }
     }
     // ---- the next round's rows, evaluated from the loads issued before the copy-out

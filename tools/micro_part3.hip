@@ -292,6 +292,157 @@ __global__ __launch_bounds__(BLOCK) void scatter3c(const int64_t* __restrict__ k
 }
 
 // chunk lists per partition: one workgroup, counting sort of the chunk -> partition map (micro-benchmark plumbing)
+// scatter3d: scatter3c with what the string-key scatter (kernels_strgroup.hip) taught -- the per-round cost is the LDS instruction stream:
+//  * scan: one partition per thread (NP / 64 waves) with one prefix sum for offsets AND chunk allocation, instead of four partitions per lane of one wave
+//  * the scan leaves a 16-byte descriptor per partition; the copy-out reads it with ONE ds_read_b128 instead of seven dword reads
+//  * the copy-out reads a lane's two dwords of a line with one two-dword read from ONE base (carry or tile; the one lane per partition where the
+//    stream changes from carry to tile inside its pair fixes its second dword up), the leftover likewise
+template <int REC, int R, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void scatter3d(const int64_t* __restrict__ keys, const int64_t* __restrict__ vals, int64_t n, uint32_t* __restrict__ recs,
+                                                   uint32_t* __restrict__ chunk_part, uint32_t* __restrict__ chunk_fill, uint32_t chunks_per_wg, uint32_t* __restrict__ flags, int ablate) {
+  using Rec = typename RecT<REC>::T;
+  constexpr int T = BLOCK * R;
+  constexpr uint32_t RW = REC / 4, chunk_dw = kChunk * RW, cap_lines = chunk_dw / 32;
+  extern __shared__ unsigned long long lds_raw[];
+  uint32_t* sorted_dw = reinterpret_cast<uint32_t*>(lds_raw);
+  Rec* sorted = reinterpret_cast<Rec*>(lds_raw);
+  uint32_t* carry = sorted_dw + (size_t)T * RW;
+  uint4* desc4 = reinterpret_cast<uint4*>(carry + kNP * 32);   // x = first tile dword - carried dwords, y = carried | new carry << 5 | lines << 10 | rows << 20 | crosses << 21, z = first line
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(desc4 + kNP);
+  uint32_t* off = cnt + kNP;
+  uint32_t* carry_dw = off + kNP + 1;
+  uint32_t* lines_left = carry_dw + kNP;
+  uint32_t* dstB = lines_left + kNP;
+  uint32_t* cur_chunk = dstB + kNP;
+  uint32_t* cur_lines = cur_chunk + kNP;
+  uint32_t* wtot = cur_lines + kNP;       // [16]
+  uint32_t* misc = wtot + 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < (int)kNP; i += BLOCK) { cnt[i] = 0; carry_dw[i] = 0; cur_chunk[i] = kNoChunk; cur_lines[i] = cap_lines; }
+  if (tid == 0) misc[0] = 0;
+  __syncthreads();
+  const uint32_t chunk0 = blockIdx.x * chunks_per_wg;
+  const int64_t nrounds = (n + T - 1) / T;
+  longlong2 kq[R / 2], vq[R / 2], kn[R / 2], vn[R / 2];
+  auto load = [&](int64_t rd, longlong2* k, longlong2* v) __attribute__((always_inline)) {
+    const int64_t base = rd * T;
+#pragma unroll
+    for (int j = 0; j < R / 2; j++) {
+      const int64_t row = base + ((int64_t)j * BLOCK + tid) * 2;
+      if (row + 1 < n) { k[j] = *reinterpret_cast<const longlong2*>(keys + row); v[j] = *reinterpret_cast<const longlong2*>(vals + row); }
+      else { k[j].x = row < n ? keys[row] : -1; k[j].y = -1; v[j].x = row < n ? vals[row] : 0; v[j].y = 0; }
+    }
+  };
+  int64_t rd = blockIdx.x;
+  if (rd < nrounds) load(rd, kn, vn);
+  for (; rd < nrounds; rd += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < R / 2; j++) { kq[j] = kn[j]; vq[j] = vn[j]; }
+    if (rd + gridDim.x < nrounds) load(rd + gridDim.x, kn, vn);
+    uint32_t part[R], rank[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      const int64_t key = (j & 1) ? kq[j / 2].y : kq[j / 2].x;
+      part[j] = key < 0 ? kNP : (uint32_t)((uint64_t)key >> kShift);
+      rank[j] = part[j] < kNP ? atomicAdd(&cnt[part[j]], 1u) : 0u;
+    }
+    __syncthreads();                                                                  // A: counts complete
+    uint32_t sc_c = 0, sc_cd = 0, sc_ln = 0, sc_ch = 0, sc_v = 0, sc_incl = 0, sc_opened = 0;
+    if (tid < (int)kNP) {
+      sc_c = cnt[tid]; sc_cd = carry_dw[tid]; sc_ln = cur_lines[tid]; sc_ch = cur_chunk[tid]; sc_opened = misc[0];
+      const uint32_t nl = (sc_cd + sc_c * RW) >> 5, left = cap_lines - sc_ln;
+      sc_v = sc_c | (nl > left ? (nl - left + cap_lines - 1) / cap_lines : 0u) << 16;
+      sc_incl = sc_v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(sc_incl, d, 64); if (lane >= d) sc_incl += o; }
+      if (lane == 63) wtot[wave] = sc_incl;
+    }
+    __syncthreads();                                                                  // A2
+    if (tid < (int)kNP) {
+      uint32_t pre = 0, tot = 0;
+#pragma unroll
+      for (int w = 0; w < (int)kNP / 64; w++) { const uint32_t x = wtot[w]; if (w < wave) pre += x; tot += x; }
+      const uint32_t excl = pre + sc_incl - sc_v, o = excl & 0xffffu, c = sc_c, p = (uint32_t)tid;
+      uint32_t base = sc_opened + (excl >> 16);
+      if (tid == (int)kNP - 1) { misc[0] = sc_opened + (tot >> 16); off[kNP] = tot & 0xffffu; }
+      if (sc_opened + (tot >> 16) > chunks_per_wg) { if (tid == 0) flags[0] = 1; base = 0; }
+      const uint32_t cd = sc_cd, total = cd + c * RW, nl = total >> 5, rem = total & 31u, left = cap_lines - sc_ln;
+      uint32_t ln = sc_ln, ch = sc_ch, y = cd | rem << 5 | nl << 10 | (c ? 1u << 20 : 0u), first_line = 0;
+      off[p] = o; cnt[p] = 0; carry_dw[p] = rem;
+      if (nl) {
+        first_line = ch * cap_lines + ln;
+        if (nl > left) {
+          const uint32_t extra = nl - left, need = (extra + cap_lines - 1) / cap_lines, first = chunk0 + base;
+          if (ch != kNoChunk) chunk_fill[ch] = kChunk;
+          for (uint32_t e = 0; e < need; e++) { chunk_part[first + e] = p; if (e + 1 < need) chunk_fill[first + e] = kChunk; }
+          if (left == 0) first_line = first * cap_lines;
+          else { y |= 1u << 21; lines_left[p] = left; dstB[p] = first * cap_lines; }
+          ch = first + need - 1; ln = extra - (need - 1) * cap_lines;
+        } else ln += nl;
+        cur_chunk[p] = ch; cur_lines[p] = ln;
+      }
+      desc4[p] = make_uint4(o * RW - cd, y, first_line, 0u);
+    }
+    __syncthreads();                                                                  // B: offsets and destinations known
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      if (part[j] >= kNP) continue;
+      const int64_t key = (j & 1) ? kq[j / 2].y : kq[j / 2].x;
+      const int64_t val = (j & 1) ? vq[j / 2].y : vq[j / 2].x;
+      if (!(ablate & 2)) sorted[off[part[j]] + rank[j]] = make_rec<REC>((uint32_t)key & ((1u << kShift) - 1u), (uint64_t)val);
+    }
+    __syncthreads();                                                                  // C: tile sorted
+    {
+      const uint32_t g = (uint32_t)tid >> 4, l16 = (uint32_t)tid & 15u, d = l16 * 2;
+      constexpr uint32_t kPer = kNP / (BLOCK / 16);
+      uint4 D[kPer];
+#pragma unroll
+      for (uint32_t q = 0; q < kPer; q++) D[q] = desc4[g + q * (BLOCK / 16)];
+#pragma unroll
+      for (uint32_t q = 0; q < kPer; q++) {
+        const uint32_t p = g + q * (BLOCK / 16);
+        const int s0 = (int)D[q].x;
+        const uint32_t y = D[q].y, c_dw = y & 31u, rem = (y >> 5) & 31u, nl = (y >> 10) & 1023u;
+        uint32_t left = 0xffffffffu, b = 0;
+        if ((y >> 21) & 1u) { left = lines_left[p]; b = dstB[p]; }
+        if (nl) {
+          const uint32_t* src = d < c_dw ? carry + p * 32 + d : sorted_dw + (s0 + (int)d);
+          uint2 w = make_uint2(src[0], src[1]);
+          if (d < c_dw && d + 1 >= c_dw) w.y = sorted_dw[s0 + (int)d + 1];
+          if (!(ablate & 1)) *reinterpret_cast<uint2*>(recs + (uint64_t)(0 < left ? D[q].z : b) * 32 + d) = w;
+          for (uint32_t i = 1; i < nl; i++) {
+            const uint32_t* s2 = sorted_dw + (s0 + (int)(i * 32 + d));
+            const uint2 w2 = make_uint2(s2[0], s2[1]);
+            const uint64_t line = i < left ? (uint64_t)D[q].z + i : (uint64_t)b + (i - left);
+            if (!(ablate & 1)) *reinterpret_cast<uint2*>(recs + line * 32 + d) = w2;
+          }
+        }
+        if ((y >> 20) & 1u) {
+          const uint32_t* s3 = sorted_dw + (s0 + (int)(nl * 32 + d));
+          const uint32_t r0 = s3[0], r1 = s3[1], lo = nl ? 0u : c_dw;
+          if (d >= lo && d < rem) carry[p * 32 + d] = r0;
+          if (d + 1 >= lo && d + 1 < rem) carry[p * 32 + d + 1] = r1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int p = tid; p < (int)kNP; p += BLOCK) {
+    uint32_t ch = cur_chunk[p], ln = cur_lines[p];
+    const uint32_t rem = carry_dw[p];
+    if (rem) {
+      if (ln == cap_lines) {
+        if (ch != kNoChunk) chunk_fill[ch] = kChunk;
+        const uint32_t local = atomicAdd(&misc[0], 1u);
+        if (local >= chunks_per_wg) { flags[0] = 1; continue; }
+        ch = chunk0 + local; chunk_part[ch] = p; ln = 0;
+      }
+      for (uint32_t i = 0; i < rem; i++) recs[((uint64_t)ch * cap_lines + ln) * 32 + i] = carry[p * 32 + i];
+    }
+    if (ch != kNoChunk) chunk_fill[ch] = (ln * 32 + rem) / RW;
+  }
+}
+
 __global__ __launch_bounds__(1024) void chunk_lists(const uint32_t* chunk_part, uint32_t n_chunks, uint32_t* cl_off /* [NP + 1] */, uint32_t* cl_ids) {
   __shared__ uint32_t cnt[kNP + 1], cur[kNP];
   for (int i = threadIdx.x; i <= (int)kNP; i += 1024) cnt[i] = 0;
@@ -351,25 +502,29 @@ struct Ctx {
   uint32_t max_chunks;
 };
 
-template <int REC, int R, int BLOCK, bool CARRY = false>
+template <int REC, int R, int BLOCK, int CARRY = 0>
 static void run_variant(Ctx& c, int wg_per_cu, int ablate = 0) {
   using Rec = typename RecT<REC>::T;
   constexpr int T = BLOCK * R;
   const int grid = 256 * wg_per_cu;
-  const size_t lds = CARRY ? (size_t)T * REC + (size_t)kNP * 128 + (size_t)(kNP * 8 + 1 + 4) * 4 : (size_t)T * REC + (size_t)(kNP * 6 + 1 + 4) * 4;
+  const size_t lds = CARRY == 2 ? (size_t)T * REC + (size_t)kNP * 128 + (size_t)kNP * 16 + (size_t)(kNP * 7 + 1 + 16 + 4) * 4
+                     : CARRY ? (size_t)T * REC + (size_t)kNP * 128 + (size_t)(kNP * 8 + 1 + 4) * 4 : (size_t)T * REC + (size_t)(kNP * 6 + 1 + 4) * 4;
   const uint32_t chunks_per_wg = (uint32_t)((c.n / grid + kChunk - 1) / kChunk * 102 / 100 + kNP + 8);
   const uint32_t n_chunks = chunks_per_wg * grid;
   if (n_chunks > c.max_chunks) { printf("REC=%d: chunk table too small\n", REC); return; }
   auto kern = scatter3<REC, R, BLOCK>;
   auto kern_c = scatter3c<REC, R, BLOCK>;
-  if (CARRY) CK(hipFuncSetAttribute((const void*)kern_c, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto kern_d = scatter3d<REC, R, BLOCK>;
+  if (CARRY == 2) CK(hipFuncSetAttribute((const void*)kern_d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  else if (CARRY) CK(hipFuncSetAttribute((const void*)kern_c, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   else CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   auto scatter = [&] {
     hipMemsetAsync(c.chunk_part, 0xff, (size_t)n_chunks * 4, 0);
-    if (CARRY) hipLaunchKernelGGL(kern_c, dim3(grid), dim3(BLOCK), lds, 0, c.keys, c.vals, c.n, (uint32_t*)c.recs, c.chunk_part, c.chunk_fill, chunks_per_wg, c.flags, ablate);
+    if (CARRY == 2) hipLaunchKernelGGL(kern_d, dim3(grid), dim3(BLOCK), lds, 0, c.keys, c.vals, c.n, (uint32_t*)c.recs, c.chunk_part, c.chunk_fill, chunks_per_wg, c.flags, ablate);
+    else if (CARRY) hipLaunchKernelGGL(kern_c, dim3(grid), dim3(BLOCK), lds, 0, c.keys, c.vals, c.n, (uint32_t*)c.recs, c.chunk_part, c.chunk_fill, chunks_per_wg, c.flags, ablate);
     else hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, 0, c.keys, c.vals, c.n, (Rec*)c.recs, c.chunk_part, c.chunk_fill, chunks_per_wg, c.flags, ablate);
   };
-  printf("[%s REC=%d R=%d BLOCK=%d] scatter...\n", CARRY ? "carry" : "direct", REC, R, BLOCK);
+  printf("[%s REC=%d R=%d BLOCK=%d] scatter...\n", CARRY == 2 ? "carry+desc" : CARRY ? "carry" : "direct", REC, R, BLOCK);
   const float t_sc = time_ms(scatter);
   printf("  lists...\n");
   auto lists = [&] { hipLaunchKernelGGL(chunk_lists, dim3(1), dim3(1024), 0, 0, c.chunk_part, n_chunks, c.cl_off, c.cl_ids); };
@@ -381,7 +536,7 @@ static void run_variant(Ctx& c, int wg_per_cu, int ablate = 0) {
   hipLaunchKernelGGL(compare, dim3(256), dim3(256), 0, 0, c.ref_sum, c.out_sum, c.ref_cnt, c.out_cnt, 1 << 20, c.bad);
   unsigned int bad = 0, flag = 0; CK(hipMemcpy(&bad, c.bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&flag, c.flags, 4, hipMemcpyDeviceToHost));
   const double gb_sc = (double)c.n * (16 + REC) / 1e9, gb_ag = (double)c.n * REC / 1e9;
-  printf("%s REC=%2d R=%d BLOCK=%4d wg/cu=%d ablate=%d lds=%6zu: scatter %7.3f ms (%6.0f GB/s)  lists %5.3f ms  agg %6.3f ms (%6.0f GB/s)  total %7.3f ms  mismatches=%u overflow=%u\n", CARRY ? "carry " : "direct", REC, R, BLOCK,
+  printf("%s REC=%2d R=%d BLOCK=%4d wg/cu=%d ablate=%d lds=%6zu: scatter %7.3f ms (%6.0f GB/s)  lists %5.3f ms  agg %6.3f ms (%6.0f GB/s)  total %7.3f ms  mismatches=%u overflow=%u\n", CARRY == 2 ? "carry+desc" : CARRY ? "carry " : "direct", REC, R, BLOCK,
          wg_per_cu, ablate, lds, t_sc, gb_sc / t_sc * 1e3, t_ls, t_ag, gb_ag / t_ag * 1e3, t_sc + t_ls + t_ag, ablate ? 0u : bad, flag);
   fflush(stdout);
 }
@@ -401,17 +556,25 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(ref_agg, dim3(2048), dim3(256), 0, 0, c.keys, c.vals, c.n, c.ref_sum, c.ref_cnt);
   CK(hipDeviceSynchronize());
   printf("rows %lld\n", (long long)c.n);
-  run_variant<8, 8, 1024>(c, 1);
-  run_variant<8, 8, 1024, true>(c, 1);
-  run_variant<8, 8, 1024, true>(c, 1, 1);
-  run_variant<8, 8, 1024, true>(c, 1, 3);
-  run_variant<8, 4, 1024, true>(c, 1);
-  run_variant<8, 8, 512, true>(c, 2);
-  run_variant<8, 16, 512, true>(c, 2);
-  run_variant<4, 8, 1024, true>(c, 1);
-  run_variant<4, 16, 512, true>(c, 2);
-  run_variant<12, 8, 1024, true>(c, 1);
-  run_variant<12, 4, 1024, true>(c, 1);
-  run_variant<16, 8, 1024, true>(c, 1);
+  const bool all = argc > 2;
+  if (all) {
+    run_variant<8, 8, 1024>(c, 1);
+    run_variant<8, 8, 1024, 1>(c, 1, 1);
+    run_variant<8, 8, 1024, 1>(c, 1, 3);
+    run_variant<8, 4, 1024, 1>(c, 1);
+    run_variant<8, 8, 512, 1>(c, 2);
+    run_variant<8, 16, 512, 1>(c, 2);
+    run_variant<4, 16, 512, 1>(c, 2);
+  }
+  run_variant<4, 8, 1024, 1>(c, 1);
+  run_variant<4, 8, 1024, 2>(c, 1);
+  run_variant<8, 8, 1024, 1>(c, 1);
+  run_variant<8, 8, 1024, 2>(c, 1);
+  run_variant<12, 8, 1024, 1>(c, 1);
+  run_variant<12, 8, 1024, 2>(c, 1);
+  run_variant<12, 4, 1024, 1>(c, 1);
+  run_variant<12, 4, 1024, 2>(c, 1);
+  run_variant<12, 8, 1024, 2>(c, 1, 1);
+  run_variant<12, 8, 1024, 2>(c, 1, 3);
   return 0;
 }
