@@ -79,7 +79,7 @@ __host__ __device__ inline size_t sg_scatter_lds(uint32_t NP) { return (size_t)k
 //    four waves per SIMD) and LDS round trips, not by HBM.  Hence: the scan is one partition per thread over eight waves (not eight per lane of
 //    one wave while fifteen waves wait); it leaves the flush a ready-made descriptor per partition (one 16-byte read, no decoding arithmetic to
 //    speak of); the flush fetches the words of four partitions before it acts on any; the hash is five multiply-adds;
-//  * a partition receives 36 dwords per round on average: the flush gives it a 32-lane group that writes up to two lines at once.
+//  * the copy-out: a 16-lane group per partition, four LDS instructions plus one per line beyond the first (a partition receives 36 dwords a round).
 template <bool TIMING>
 __global__ __launch_bounds__(kSgBlock) void strgroup_scatter_kernel(SgScatter p) {
   extern __shared__ unsigned long long sg_lds[];
@@ -208,44 +208,40 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_scatter_kernel(SgScatter p)
     // start on its share of the flush while the others are still queueing -- ahead of barrier C everybody would wait for the last one
     if (rd + 2 * (int64_t)gridDim.x < nrounds) load(rd + 2 * (int64_t)gridDim.x, vn, xn);
     {
-      const uint32_t g = (uint32_t)tid >> 5, l32 = (uint32_t)tid & 31u, d = l32 * 2, li = l32 >> 4;   // lanes 0-15: the first line, 16-31: the second
-      const int sorted_d = (int)d, sorted_r = (int)l32;
+      // copy-out: a 16-lane group per partition (64 groups, eight partitions each, in two batches of four whose LDS reads are issued together): one
+      // 16-byte descriptor read, one 8-byte read per line and lane (every offset here is even), one for the leftover, one 8-byte write into the carry
+      const uint32_t g = (uint32_t)tid >> 4, l16 = (uint32_t)tid & 15u, d = l16 * 2;
 #pragma unroll 1
-      for (uint32_t b4 = 0; b4 < 4; b4++) {
+      for (uint32_t b4 = 0; b4 < 2; b4++) {
         uint4 D[4];
 #pragma unroll
-        for (uint32_t q = 0; q < 4; q++) D[q] = desc4[g + (b4 * 4 + q) * 32u];
-        uint2 w[4];
-        uint32_t r[4];
+        for (uint32_t q = 0; q < 4; q++) D[q] = desc4[g + (b4 * 4 + q) * 64u];
+        uint2 w[4], r[4];
 #pragma unroll
         for (uint32_t q = 0; q < 4; q++) {
-          const uint32_t pp = g + (b4 * 4 + q) * 32u;
+          const uint32_t pp = g + (b4 * 4 + q) * 64u;
           const uint32_t c_dw = D[q].y & 31u, nl32 = (D[q].y >> 5) & (1023u << 5);            // lines * 32
-          // dword d of the partition's stream (carry first, then its rows of the tile); d, the carry length and the row offset are even: one 8-byte read
-          w[q] = *reinterpret_cast<const uint2*>(d < c_dw ? carry + (size_t)pp * 32 + d : sorted + ((int)D[q].x + sorted_d));
-          // the new carry's dword l32 = dword lines * 32 + l32 of the stream
-          const uint32_t sd = nl32 + l32;
-          r[q] = sd < c_dw ? carry[(size_t)pp * 32 + sd] : sorted[(int)D[q].x + (int)nl32 + sorted_r];
+          // dword d of the partition's stream (carry first, then its rows of the tile)
+          w[q] = *reinterpret_cast<const uint2*>(d < c_dw ? carry + (size_t)pp * 32 + d : sorted + ((int)D[q].x + (int)d));
+          // the new carry's dwords d, d + 1 = dwords lines * 32 + d of the stream (without a whole line the old carry stays and the rows are appended)
+          const int ri = (int)D[q].x + (int)(nl32 + d);                                        // negative only where the value is not used (a dword that stays in the carry)
+          r[q] = *reinterpret_cast<const uint2*>(sorted + (ri < 0 ? 0 : ri));
         }
 #pragma unroll
         for (uint32_t q = 0; q < 4; q++) {
-          const uint32_t pp = g + (b4 * 4 + q) * 32u;
-          const uint32_t y = D[q].y, nl = (y >> 10) & 1023u;
-          if (li < nl) {
-            uint64_t line = (uint64_t)D[q].z + li;
-            if ((y >> 21) & 1u) { const uint32_t left = lines_left[pp]; if (li >= left) line = (uint64_t)dstB[pp] + (li - left); }
-            *reinterpret_cast<uint2*>(p.recs + line * 32 + (l32 & 15u) * 2) = w[q];
-          }
-          if (((y >> 20) & 1u) && l32 < ((y >> 5) & 31u)) carry[(size_t)pp * 32 + l32] = r[q];
-          if (nl > 2) {
-            // three or more lines for one partition in one round (skew): the rest of its lines, two at a time
-            const uint32_t left = ((y >> 21) & 1u) ? lines_left[pp] : 0xffffffffu, b = ((y >> 21) & 1u) ? dstB[pp] : 0u;
-            for (uint32_t i = 2 + li; i < nl; i += 2) {
-              const uint2 ww = *reinterpret_cast<const uint2*>(sorted + ((int)D[q].x + (int)(i * 32 + (l32 & 15u) * 2)));
+          const uint32_t pp = g + (b4 * 4 + q) * 64u;
+          const uint32_t y = D[q].y, c_dw = y & 31u, rem = (y >> 5) & 31u, nl = (y >> 10) & 1023u;
+          if (nl) {
+            uint32_t left = 0xffffffffu, b = 0;
+            if ((y >> 21) & 1u) { left = lines_left[pp]; b = dstB[pp]; }
+            *reinterpret_cast<uint2*>(p.recs + (uint64_t)D[q].z * 32 + d) = w[q];
+            for (uint32_t i = 1; i < nl; i++) {
+              const uint2 ww = *reinterpret_cast<const uint2*>(sorted + ((int)D[q].x + (int)(i * 32 + d)));
               const uint64_t line = i < left ? (uint64_t)D[q].z + i : (uint64_t)b + (i - left);
-              *reinterpret_cast<uint2*>(p.recs + line * 32 + (l32 & 15u) * 2) = ww;
+              *reinterpret_cast<uint2*>(p.recs + line * 32 + d) = ww;
             }
           }
+          if (((y >> 20) & 1u) && d >= (nl ? 0u : c_dw) && d < rem) *reinterpret_cast<uint2*>(carry + (size_t)pp * 32 + d) = r[q];
         }
       }
     }
