@@ -7,8 +7,8 @@ mkdir -p $OUT
 cd $R
 t0=$(date +%s)
 el() { echo "[+$(( $(date +%s) - t0 ))s] $*" | tee -a $OUT/summary.txt; }
-bash tools/pmc_all.sh r03w cfg5s > $OUT/pmc_all.log 2>&1; el "pmc cfg5s exit $?"
-grep -E "^cfg5s " $OUT/pmc_all.log | head -8
+bash tools/pmc_all.sh r03w cfg3 cfg5 q3s cfg5s > $OUT/pmc_all.log 2>&1; el "pmc refresh exit $?"
+grep -E "^(cfg3|cfg5|q3s|cfg5s) " $OUT/pmc_all.log | head -8
 timeout 600 python -m pytest tests -m gpu -q --timeout 300 -x > $OUT/pytest_gpu_all.log 2>&1; el "whole gpu suite exit $?"
 tail -4 $OUT/pytest_gpu_all.log | cut -c1-300
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; el "smoke exit $?"; tail -2 $OUT/smoke.log | cut -c1-300
