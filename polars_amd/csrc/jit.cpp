@@ -101,14 +101,14 @@ std::string source_for(const Shape& sh, Sink sink) {
     case PART2_AGG_HASH: case PART2_AGG_DIRECT:
       o << "extern \"C\" __global__ __launch_bounds__(kP2AggBlock) void plx_jit_kernel(PartPlan2 pp, AggParams2 ap) {\n"
            "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout2 cl = rec_layout2(JitProg::shape(), " << (sink == PART2_AGG_DIRECT ? 1 : 0) << "u);\n"
-           "  part2_agg_body<Shape, " << (sink == PART2_AGG_DIRECT ? 1 : 0) << ">(csh, cl, pp, ap);\n}\n}}\n";
+           "  part2_agg_body<Shape, " << (sink == PART2_AGG_DIRECT ? 1 : 0) << ", (cl.rec_words <= 1 ? 6 : 3)>(csh, cl, pp, ap);\n}\n}}\n";
       break;
     default:
       if (sink >= PART3_AGG) {
         const int v = (int)sink - (int)PART3_AGG, mode = v & 1, pack = v >> 1;
         o << "extern \"C\" __global__ __launch_bounds__(kP2AggBlock) void plx_jit_kernel(PartPlan2 pp, AggParams2 ap) {\n"
              "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout2 cl = rec_layout2(JitProg::shape(), " << mode << "u, " << pack << "u);\n"
-             "  part2_agg_body<Shape, " << mode << ">(csh, cl, pp, ap);\n}\n}}\n";
+             "  part2_agg_body<Shape, " << mode << ", (cl.rec_words <= 1 ? 6 : 3)>(csh, cl, pp, ap);\n}\n}}\n";
         break;
       }
       if (sink >= PART3_SCATTER) {

@@ -310,6 +310,7 @@ struct SgAgg {
   unsigned int* out_cnt;             // valid values per group
   unsigned int* out_len;             // rows per group
   uint32_t max_groups, is_f64;
+  uint32_t has_nulls;                // 0: the value column has no validity bitmap -- valid values = rows, one LDS atomic less per record
 };
 
 constexpr uint32_t kSgTagSlots = 16384, kSgGroupCap = 2816;     // per partition: 64 KB of tag words + 2816 groups x 32 B = 152 KB of LDS
@@ -342,24 +343,27 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_agg_kernel(SgAgg a) {
   const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const uint64_t c_beg = a.cl_off[p], c_end = a.cl_off[p + 1];
   constexpr uint32_t kPerLane = kSgChunkRecs / 64;
+  static_assert(kPerLane == 4, "load_chunk unpacks four records per lane");
   uint2 ra[kPerLane][3], rb[kPerLane][3];
   uint32_t fill_a = 0, fill_b = 0;
   auto load_id = [&](uint64_t j) -> uint32_t { return a.cl_ids[j < c_end ? j : c_end - 1]; };
+  // a lane takes FOUR CONSECUTIVE records of the chunk (96 bytes: six 16-byte loads) -- the order of records within a chunk means nothing to an
+  // aggregation, and the memory pipeline accepts a wave-load every ~40 cycles whatever its width: twelve 8-byte loads per chunk cost twice the issue slots
   auto load_chunk = [&](uint64_t j, uint32_t id, uint2 (*r)[3], uint32_t& fill) __attribute__((always_inline)) {
     fill = j < c_end ? a.chunk_fill[id] : 0u;
-    const uint2* base = reinterpret_cast<const uint2*>(a.recs + (uint64_t)id * kSgChunkDw);
-#pragma unroll
-    for (uint32_t u = 0; u < kPerLane; u++) {
-      const uint2* q = base + (size_t)((uint32_t)lane + u * 64u) * 3;
-      r[u][0] = q[0]; r[u][1] = q[1]; r[u][2] = q[2];
-    }
+    const uint4* base = reinterpret_cast<const uint4*>(a.recs + (uint64_t)id * kSgChunkDw) + (size_t)lane * 6;
+    const uint4 q0 = base[0], q1 = base[1], q2 = base[2], q3 = base[3], q4 = base[4], q5 = base[5];
+    r[0][0] = make_uint2(q0.x, q0.y); r[0][1] = make_uint2(q0.z, q0.w); r[0][2] = make_uint2(q1.x, q1.y);
+    r[1][0] = make_uint2(q1.z, q1.w); r[1][1] = make_uint2(q2.x, q2.y); r[1][2] = make_uint2(q2.z, q2.w);
+    r[2][0] = make_uint2(q3.x, q3.y); r[2][1] = make_uint2(q3.z, q3.w); r[2][2] = make_uint2(q4.x, q4.y);
+    r[3][0] = make_uint2(q4.z, q4.w); r[3][1] = make_uint2(q5.x, q5.y); r[3][2] = make_uint2(q5.z, q5.w);
   };
   auto process = [&](uint2 (*r)[3], uint32_t fill) __attribute__((always_inline)) {
     uint32_t ts[kPerLane], g[kPerLane];          // tag slot; group index once found (kPending: not yet)
 #pragma unroll
     for (uint32_t u = 0; u < kPerLane; u++) {
       ts[u] = (r[u][0].x >> 5) & (kSgTagSlots - 1u);
-      g[u] = (uint32_t)lane + u * 64u < fill ? kSgPending : 0u;
+      g[u] = (uint32_t)lane * 4u + u < fill ? kSgPending : 0u;
     }
     for (uint32_t it = 0; it < 4 * kSgTagSlots; it++) {
       bool all = true;
@@ -396,10 +400,10 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_agg_kernel(SgAgg a) {
     }
 #pragma unroll
     for (uint32_t u = 0; u < kPerLane; u++) {
-      if ((uint32_t)lane + u * 64u >= fill || g[u] == kSgPending) continue;
+      if ((uint32_t)lane * 4u + u >= fill || g[u] == kSgPending) continue;
       atomicAdd(&lens[g[u]], 1u);
       if (!((r[u][0].x >> 4) & 1u)) {
-        atomicAdd(&cnts[g[u]], 1u);
+        if (a.has_nulls) atomicAdd(&cnts[g[u]], 1u);
         const unsigned long long x = ((unsigned long long)r[u][2].y << 32) | r[u][2].x;
         if (a.is_f64) atomicAdd(reinterpret_cast<double*>(&sums[g[u]]), __longlong_as_double((long long)x));
         else atomicAdd(&sums[g[u]], x);
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_agg_kernel(SgAgg a) {
   for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) {
     const uint64_t o = gbase + i;
     a.out_views[o * 2] = w0s[i]; a.out_views[o * 2 + 1] = w1s[i];
-    a.out_sum[o] = sums[i]; a.out_cnt[o] = cnts[i]; a.out_len[o] = lens[i];
+    a.out_sum[o] = sums[i]; a.out_cnt[o] = a.has_nulls ? cnts[i] : lens[i]; a.out_len[o] = lens[i];
   }
 }
 
@@ -529,6 +533,7 @@ int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uin
   ap.recs = recs->as<unsigned int>(); ap.chunk_fill = chunk_fill->as<unsigned int>(); ap.cl_off = cl_off->as<unsigned long long>(); ap.cl_ids = cl_ids->as<unsigned int>();
   ap.counter = meta->as<unsigned long long>(); ap.overflow = meta->as<unsigned int>() + 2;
   ap.out_views = (*out_views)->as<unsigned long long>(); ap.out_sum = (*out_sum)->as<unsigned long long>(); ap.out_cnt = (*out_cnt)->as<unsigned int>(); ap.out_len = (*out_len)->as<unsigned int>();
+  ap.has_nulls = val_validity ? 1u : 0u;
   ap.max_groups = (uint32_t)std::min<uint64_t>(max_groups, 0xffffffffull); ap.is_f64 = is_f64 ? 1u : 0u;
   {
     ProfileScope ps("strgroup_agg_lds", (uint64_t)n * 24, (uint64_t)n);

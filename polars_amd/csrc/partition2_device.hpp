@@ -379,8 +379,9 @@ __device__ __forceinline__ void load_rec2(const unsigned int* p, unsigned int* r
   }
 }
 
-template <class S, int MODE>
+template <class S, int MODE, int NB = 3>
 __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L, const PartPlan2& pp, const AggParams2& ap) {
+  static_assert(NB >= 2 && NB <= 8, "chunks in flight per wave");
   extern __shared__ __attribute__((aligned(16))) unsigned long long p2_lds[];
   constexpr uint32_t kPerLane = kP2ChunkRecs / 64;    // records of a chunk per lane
   const uint32_t NS = 1u << pp.log2_slots, n_aggs = sh.n_aggs, RW = L.rec_words, chunk_dw = kP2ChunkRecs * RW;
@@ -397,13 +398,15 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   __syncthreads();
   const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const uint64_t c_beg = ap.cl_off[p], c_end = ap.cl_off[p + 1];
-  // Three chunks per wave are in flight: the chunk being aggregated and the next two (a partition count that gives every CU only
-  // one workgroup leaves 16 waves to cover the HBM latency).  Every lane ALWAYS loads its kPerLane records of a chunk -- past
-  // the fill, or past the end of the list (clamped to the last chunk), the words are simply ignored -- so the number of loads per
-  // chunk is a constant and the wait for the oldest chunk leaves the younger two in flight; the chunk id and fill come through
-  // the scalar cache (wave-uniform address).
-  unsigned int b0[kPerLane][16], b1[kPerLane][16], b2[kPerLane][16];   // [..][RW] (RW <= 13); unused words are never touched
-  uint32_t n0 = 0, n1 = 0, n2 = 0;
+  // NB chunks per wave are in flight: the chunk being aggregated and the next NB - 1 (a partition count that gives every CU only one workgroup
+  // leaves 16 waves to cover the HBM latency; three 3-KB chunks per wave do for 12-byte records, one-dword records -- 1 KB a chunk -- want six:
+  // config 3's aggregation pass ran at 4.1 TB/s with three).  Every lane ALWAYS loads its kPerLane records of a chunk -- past the fill, or past
+  // the end of the list (clamped to the last chunk), the words are simply ignored -- so the number of loads per chunk is a constant and the wait
+  // for the oldest chunk leaves the younger ones in flight; the chunk id and fill come through the scalar cache (wave-uniform address).
+  unsigned int bufs[NB][kPerLane][16];   // [..][RW] (RW <= 13); unused words are never touched
+  uint32_t nn[NB];
+#pragma unroll
+  for (int s = 0; s < NB; s++) nn[s] = 0;
   auto load_chunk = [&](uint64_t j, unsigned int (*dst)[16], uint32_t& cnt) __attribute__((always_inline)) {
     const uint64_t jc = j < c_end ? j : c_end - 1;
     const uint32_t jlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)jc), jhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(jc >> 32));
@@ -412,6 +415,12 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
     const uint32_t fill = ap.chunk_fill[id];
     cnt = j < c_end ? fill : 0u;
     const unsigned int* base = ap.recs + (uint64_t)id * chunk_dw;
+    if (RW == 1) {     // one-dword records: the lane takes four consecutive ones with ONE 16-byte load (the memory pipeline accepts a wave-load every ~40 cycles whatever its width)
+      static_assert(kPerLane == 4, "four records per lane");
+      const uint4 q = reinterpret_cast<const uint4*>(base)[lane];
+      dst[0][0] = q.x; dst[1][0] = q.y; dst[2][0] = q.z; dst[3][0] = q.w;
+      return;
+    }
 #pragma unroll
     for (uint32_t u = 0; u < kPerLane; u++) {
       const uint32_t i = (uint32_t)lane + u * 64u;
@@ -437,7 +446,7 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
     bool live[kPerLane];
 #pragma unroll
     for (uint32_t u = 0; u < kPerLane; u++) {
-      const uint32_t i = (uint32_t)lane + u * 64u;
+      const uint32_t i = RW == 1 ? (uint32_t)lane * 4u + u : (uint32_t)lane + u * 64u;     // as load_chunk dealt the chunk's records out
       live[u] = i < cnt_cur;
       slot[u] = 0; key[u] = 0; first[u] = 0;
       if (!live[u]) continue;
@@ -505,15 +514,16 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   if (c_beg < c_end) {
     const uint64_t step = (uint64_t)nwaves;
     uint64_t j = c_beg + (uint64_t)wave;
-    load_chunk(j, b0, n0);
-    load_chunk(j + step, b1, n1);
-    for (;;) {     // the three buffers rotate by name: copying a buffer would wait for its loads
-      if (j >= c_end) break;
-      load_chunk(j + 2 * step, b2, n2); process(b0, n0); j += step;
-      if (j >= c_end) break;
-      load_chunk(j + 2 * step, b0, n0); process(b1, n1); j += step;
-      if (j >= c_end) break;
-      load_chunk(j + 2 * step, b1, n1); process(b2, n2); j += step;
+#pragma unroll
+    for (int s = 0; s + 1 < NB; s++) load_chunk(j + (uint64_t)s * step, bufs[s], nn[s]);
+    for (bool done = false; !done;) {     // the buffers rotate by (compile-time) index: copying a buffer would wait for its loads
+#pragma unroll
+      for (int s = 0; s < NB; s++) {
+        if (j >= c_end) { done = true; break; }
+        load_chunk(j + (uint64_t)(NB - 1) * step, bufs[(s + NB - 1) % NB], nn[(s + NB - 1) % NB]);
+        process(bufs[s], nn[s]);
+        j += step;
+      }
     }
   }
   __syncthreads();
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(kP2AggBlock) void part2_agg_kernel(PartPlan2 pp, Ag
   static_assert(P::kStatic, "the partitioned group-by runs specialised programs only (AOT or JIT)");
   constexpr Shape csh = P::shape();
   constexpr RecLayout2 cl = rec_layout2(P::shape(), (uint32_t)MODE, (uint32_t)PACK);
-  part2_agg_body<Shape, MODE>(csh, cl, pp, ap);
+  part2_agg_body<Shape, MODE, (cl.rec_words <= 1 ? 6 : 3)>(csh, cl, pp, ap);
 }
 
 }  // namespace k
