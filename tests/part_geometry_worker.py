@@ -1,0 +1,50 @@
+"""One partitioned group-by under the geometry the environment dictates (PLX_PART_LOG2_PARTS / PLX_PART_DIRECT_LOG2_PARTS / PLX_PART_TILES /
+PLX_PART_PACK are read once per process: tests/test_gpu_zzzz_round3_d.py starts this script once per geometry).  argv: mode (hash | direct), input
+(hot: a stretch of rows from 48 keys, which the sample makes heavy hitters -- the scatter's hot-key build; flat: uniform keys) and the substrings the
+plan description of the second run must contain.  Checks the result against numpy and prints the plan."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import polars_amd as pl  # noqa: E402
+
+
+def main():
+    mode, shape, want = sys.argv[1], sys.argv[2], sys.argv[3:]
+    pl.init(0)
+    rng = np.random.default_rng(97)
+    n, G = 17_300_001, 200_000
+    ids = rng.integers(0, G, n)
+    if shape == "hot":
+        ids[n // 2: n // 2 + n // 50] = rng.integers(0, 48, n // 50)
+    v = rng.integers(-10 ** 6, 10 ** 6, n).astype(np.int64)
+    x = rng.uniform(-1, 1, n)
+    if mode == "hash":
+        key = ids.astype(np.int64) * 1_000_003 - 10 ** 12           # sparse 64-bit keys: hash partitions
+        df = pl.DataFrame({"k": key, "v": v, "x": x})
+    else:
+        key = ids.astype(np.uint32)                                 # dense ids: direct-address partitions
+        df = pl.DataFrame([pl.Series("k", key, dtype=pl.Categorical([], pl.UInt32)), pl.Series("v", v), pl.Series("x", x)])
+    q = df.lazy().group_by("k").agg(pl.col("v").sum().alias("s"), pl.col("x").sum().alias("xs"), pl.len().alias("n"))
+    for run in range(2):                                            # the second run knows the key range (packed / fused records)
+        out = q.collect()
+        plan = pl.last_plan()
+        print(f"run {run}: {plan}")
+        assert "partitioned(v3," in plan, plan
+        if run == 1:                                                # (the first run of dense ids has no key range yet and takes hash partitions)
+            for w in want:
+                assert w in plan, (w, plan)
+        k = out["k"].to_numpy()
+        order = np.argsort(k)
+        present = np.unique(ids)
+        assert np.array_equal(k[order], np.unique(key)), "keys"
+        assert np.array_equal(out["n"].to_numpy()[order], np.bincount(ids, minlength=G)[present]), "len"
+        assert np.array_equal(out["s"].to_numpy()[order], np.bincount(ids, v, minlength=G)[present].astype(np.int64)), "int sum"       # |sums| < 2^53: exact in the float accumulator of bincount
+        assert np.allclose(out["xs"].to_numpy()[order], np.bincount(ids, x, minlength=G)[present], rtol=1e-9, atol=1e-9), "float sum"
+    print("OK")
+
+
+if __name__ == "__main__":
+    main()

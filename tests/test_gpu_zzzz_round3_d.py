@@ -1,0 +1,30 @@
+"""Round 3, fourth batch: the generation-3 scatter (one-partition-per-thread scan, descriptor copy-out) under every geometry the planner can choose,
+not only the benchmark's 256 partitions / 8192-row tiles: 64 to 512 partitions (one to eight scan waves), 2048- to 8192-row tiles, hash and direct
+partitions, plain and packed records, with and without the hot-key build.  The knobs are read once per process, so each geometry runs tests/part_geometry_worker.py in its own."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+GEOMETRIES = [      # (what the second run -- key range known -- must report; the planner never takes fewer partitions than the group estimate needs: 128 here)
+    ("hash", "hot", {"PLX_PART_LOG2_PARTS": "6"}, ["hash,P=128,", "hot=48)"]),
+    ("hash", "flat", {"PLX_PART_LOG2_PARTS": "7", "PLX_PART_TILES": "2"}, ["hash,P=128,", "tile=4096,", "hot=0)"]),
+    ("hash", "flat", {"PLX_PART_LOG2_PARTS": "9", "PLX_PART_TILES": "1"}, ["hash,P=512,", "tile=2048,"]),
+    ("hash", "hot", {"PLX_PART_LOG2_PARTS": "9", "PLX_PART_PACK": "0"}, ["hash,P=512,", "pack=0,"]),
+    ("direct", "flat", {"PLX_PART_DIRECT_LOG2_PARTS": "6"}, ["direct,P=64,", "tile=8192,"]),
+    ("direct", "hot", {"PLX_PART_DIRECT_LOG2_PARTS": "9", "PLX_PART_TILES": "2"}, ["direct,P=512,", "tile=4096,"]),
+    ("direct", "flat", {"PLX_PART_DIRECT_LOG2_PARTS": "8", "PLX_PART_PACK": "1"}, ["direct,P=256,"]),
+]
+
+
+@pytest.mark.parametrize("mode,shape,env,want", GEOMETRIES, ids=[f"{m}-{sh}-" + "-".join(f"{k[9:].lower()}{v}" for k, v in e.items()) for m, sh, e, _ in GEOMETRIES])
+def test_generation3_scatter_geometries(mode, shape, env, want):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "part_geometry_worker.py"), mode, shape, *want], capture_output=True, text=True, timeout=240, cwd=ROOT, env=e)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-1500:], r.stderr[-2500:])
