@@ -115,3 +115,41 @@ def test_deferred_views_column_behaves_like_the_encoded_one_elsewhere(pl):
     assert not k._is_raw_views() and isinstance(k.dtype, pl.Categorical) and k.to_list() == strings
     with pytest.raises(ValueError):
         pl.Series.from_device_views("k", _views_series(pl, strings), encode="later")
+
+
+def _operator_cases():
+    """The reference's own string-key group_by vectors (tests/golden, from py-polars/tests/unit/operations/test_group_by.py and aggregation/
+    test_aggregations.py) that the operator can serve: one string key without nulls, strings of at most 12 bytes, one Int64 / Float64 value column; of
+    the case's aggregates those the operator knows (sum / mean / count / len) -- the others are checked on the encoded route by test_gpu_strview.py."""
+    from tests import kat
+    out = []
+    for c in kat.load_cases("groupby"):
+        if list(c["key_dtypes"].values()) != ["str"] or len(c["values"]) != 1:
+            continue
+        (vname, vdt), = c["value_dtypes"].items()
+        strings = kat.expand(next(iter(c["keys"].values())))
+        aggs = [(col, op) for col, op in c["aggs"] if op in ("sum", "mean", "count", "len")]
+        if vdt not in ("i64", "f64") or not aggs or any(s is None or len(s.encode()) > 12 for s in strings):
+            continue
+        out.append((c, aggs))
+    return out
+
+
+@pytest.mark.parametrize("case,aggs", _operator_cases(), ids=lambda x: x["id"] if isinstance(x, dict) else "")
+def test_reference_string_key_group_by_vectors_through_the_operator(pl, case, aggs):
+    from tests import kat
+    from tests.test_gpu_golden import _agg, _series
+    (kname, kspec), = case["keys"].items()
+    (vname, vspec), = case["values"].items()
+    k = pl.Series.from_device_views(kname, _views_series(pl, kat.expand(kspec)), encode="deferred")
+    v = _series(pl, vname, vspec, case["value_dtypes"][vname])
+    out = pl.DataFrame([k, v]).lazy().group_by(kname).agg(*[_agg(pl, c, o) for c, o in aggs]).collect()      # (no maintain_order: the operator's groups come in no particular order)
+    assert "StringViewGroupBy" in pl.last_plan(), pl.last_plan()
+    names = [kname] + [f"{c}_{o}" for c, o in aggs]
+    assert out.columns == names
+    rows = sorted(out.rows(), key=lambda r: r[0])
+    exp = sorted((tuple(case["expect"][c][g] for c in names) for g in range(len(case["expect"][kname]))), key=lambda r: r[0])
+    assert len(rows) == len(exp), (rows, exp)
+    for got, want in zip(rows, exp):
+        for g, e in zip(got, want):
+            assert kat.same_value(g, e, 1e-12), (case["id"], rows, exp)
