@@ -460,7 +460,7 @@ int plx_strview_dict_encode_device(plx_column views_u64_pairs, plx_column data_u
  * HBM (inline strings: <= 12 bytes each); value: a PLX_F64 / PLX_I64 column of n rows, nulls allowed.  Outputs, one row per distinct string, in no particular
  * order: out_codes = 0 .. G-1 (PLX_U32) with *out_dict holding the G strings in that order; out_sum (the value's dtype; 0 for a group without a valid value),
  * out_count (valid values, PLX_U32), out_len (rows, PLX_U32) -- mean = sum / count.  Returns PLX_ERR_UNSUPPORTED when the input is outside the fast path (a
- * string longer than 12 bytes, more distinct strings than the LDS tables hold): the caller then encodes (plx_strview_dict_encode_device) and groups on the codes. */
+ * string longer than 12 bytes, more distinct strings than the LDS tables hold, fewer than ~4096 of them): the caller then encodes (plx_strview_dict_encode_device) and groups on the codes. */
 int plx_strview_groupby(plx_column views_u64_pairs, plx_column value, plx_column* out_codes, plx_strdict* out_dict, plx_column* out_sum, plx_column* out_count, plx_column* out_len);
 int plx_strdict_info(plx_strdict dict, int64_t* n_strings, int64_t* total_bytes);
 int plx_strdict_to_host(plx_strdict dict, int64_t* offsets, uint8_t* bytes);

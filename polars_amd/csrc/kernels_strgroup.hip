@@ -57,7 +57,15 @@ struct SgScatter {
   unsigned int* flags;               // [0] ran out of chunks, [1] a string longer than 12 bytes, [2] unused
   unsigned long long* timing;        // PLX_STRGROUP_TIMING=1: [9] 100 MHz ticks of thread 0 summed over workgroups, by phase; [8] rounds
   uint32_t chunks_per_wg, log2_parts;
+  // heavy hitters of the sample (sg_hot_kernel): their rows never become records -- one string with half of the rows would put half of the rows into ONE
+  // aggregation workgroup, every update on the same LDS address (measured: 76 ms instead of 1.6 for 2^26 rows) -- but are summed in LDS cells right here
+  uint32_t n_hot;                    // <= kSgMaxHot
+  const unsigned long long* hot_views;   // [n_hot][2]
+  unsigned long long* hot_acc;       // [kSgMaxHot][3] sum bits, valid values, rows (global, zeroed): every workgroup adds its LDS cells at its end
+  uint32_t is_f64;
 };
+constexpr uint32_t kSgMaxHot = 64, kSgHotSlots = 128, kSgHotCopies = 4;
+constexpr size_t kSgHotLds = (size_t)kSgMaxHot * 16 + (size_t)kSgHotSlots * 4 + (size_t)kSgMaxHot * kSgHotCopies * 16;     // views | slot -> index | cells {sum, valid | rows << 32}
 
 // the scatter's hash: three 32x32->64 multiply-adds over the string's bytes and its length (multilinear, so the high half is well mixed), folded
 // and multiplied once more -- five quarter-rate instructions where a 64-bit finaliser costs a dozen; 36 bits are used (partition 9 + tag table 27)
@@ -69,8 +77,8 @@ __device__ __forceinline__ uint64_t sg_hash36(uint64_t w0, uint64_t w1) {
   return (uint64_t)g * 0x9e3779b97f4a7c15ull;
 }
 
-// LDS: sorted [tile * 6] u32 | carry [NP][32] u32 | desc4 [NP] uint4 | cnt, off [NP + 1], lines_left, dstB, state [NP] u32 | wtot [8] | misc [4]
-__host__ __device__ inline size_t sg_scatter_lds(uint32_t NP) { return (size_t)kSgTile * kSgRW * 4 + (size_t)NP * 128 + (size_t)NP * 16 + ((size_t)NP * 5 + 1) * 4 + 32 + 16 + 12; }
+// LDS: sorted [tile * 6] u32 | carry [NP][32] u32 | desc4 [NP] uint4 | cnt, off [NP + 1], lines_left, dstB, state [NP] u32 | wtot [8] | misc [4] | hot views [64][2] u64, hot slots [128] u32, hot cells [64][4][2] u64
+__host__ __device__ inline size_t sg_scatter_lds(uint32_t NP) { return (size_t)kSgTile * kSgRW * 4 + (size_t)NP * 128 + (size_t)NP * 16 + ((size_t)NP * 5 + 1) * 4 + 32 + 16 + 12 + kSgHotLds; }
 
 // One round = one tile of 3072 rows.  What shapes the schedule (measured phase by phase with PLX_STRGROUP_TIMING; the first version took 12.6 us a round):
 //  * loads and stores share one counter per wave (vmcnt): rows are consumed (hashed, ranked) BEFORE the round's lines go out, one full round
@@ -96,9 +104,24 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_scatter_kernel(SgScatter p)
   unsigned int* state = dstB + NP;         // carried dwords | lines used in the current chunk << 5 | (workgroup-local index of the current chunk + 1) << 11
   unsigned int* wtot = state + NP + 3;     // (16-byte aligned) per scan wave: rows | chunks needed << 16
   unsigned int* misc = wtot + 8;           // [0] chunks this workgroup has opened
+  unsigned long long* hot_v = reinterpret_cast<unsigned long long*>(misc + 4);       // (misc is 16-byte aligned like wtot)
+  unsigned int* hot_slot = reinterpret_cast<unsigned int*>(hot_v + kSgMaxHot * 2);   // hash slot -> hot index + 1 (0: empty), linear probing
+  unsigned long long* hot_cell = reinterpret_cast<unsigned long long*>(hot_slot + kSgHotSlots);   // [hot][copy]{sum bits, valid values | rows << 32}
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (uint32_t i = tid; i < NP; i += kSgBlock) { cnt[i] = 0; state[i] = kSgCapLines << 5; }
   if (tid < 4) misc[tid] = 0;
+  if (p.n_hot) {
+    for (uint32_t i = tid; i < kSgHotSlots; i += kSgBlock) hot_slot[i] = 0;
+    for (uint32_t i = tid; i < kSgMaxHot * kSgHotCopies * 2; i += kSgBlock) hot_cell[i] = 0ull;
+    for (uint32_t i = tid; i < p.n_hot * 2; i += kSgBlock) hot_v[i] = p.hot_views[i];
+    __syncthreads();
+    if (tid == 0)
+      for (uint32_t i = 0; i < p.n_hot; i++) {
+        uint32_t sl = (uint32_t)(sg_hash36(hot_v[i * 2], hot_v[i * 2 + 1]) >> 20) & (kSgHotSlots - 1u);
+        while (hot_slot[sl]) sl = (sl + 1) & (kSgHotSlots - 1u);
+        hot_slot[sl] = i + 1;
+      }
+  }
   __syncthreads();
   const uint32_t chunk0 = blockIdx.x * p.chunks_per_wg;
   const int64_t nrounds = (p.n + kSgTile - 1) / kSgTile;
@@ -122,8 +145,24 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_scatter_kernel(SgScatter p)
       const bool vnull = live && p.val_validity && !((p.val_validity[row >> 6] >> (row & 63)) & 1);
       if (live && (uint32_t)v[j].x > 12u) { p.flags[1] = 1u; live = false; }          // a long string: the view is not the string -> the caller falls back
       part[j] = 0xffffffffu;
+      uint64_t h = 0;
       if (live) {
-        const uint64_t h = sg_hash36(v[j].x, v[j].y);
+        h = sg_hash36(v[j].x, v[j].y);
+        if (p.n_hot) {
+          for (uint32_t sl = (uint32_t)(h >> 20) & (kSgHotSlots - 1u);; sl = (sl + 1) & (kSgHotSlots - 1u)) {
+            const uint32_t e = hot_slot[sl];
+            if (!e) break;
+            if (hot_v[(e - 1) * 2] == v[j].x && hot_v[(e - 1) * 2 + 1] == v[j].y) {
+              unsigned long long* cell = hot_cell + ((size_t)(e - 1) * kSgHotCopies + ((uint32_t)wave & (kSgHotCopies - 1u))) * 2;
+              atomicAdd(cell + 1, (1ull << 32) | (vnull ? 0ull : 1ull));
+              if (!vnull) { if (p.is_f64) atomicAdd(reinterpret_cast<double*>(cell), __longlong_as_double((long long)x[j])); else atomicAdd(cell, x[j]); }
+              live = false;
+              break;
+            }
+          }
+        }
+      }
+      if (live) {
         const uint32_t q = (uint32_t)(h >> (64 - 9));
         part[j] = q | atomicAdd(&cnt[q], 1u) << 10;
         // the record's first dword: length (4 bits) | value is null | the 27 hash bits below the partition's, which the aggregation kernel probes with
@@ -250,6 +289,14 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_scatter_kernel(SgScatter p)
   }
   if (TIMING && tid == 0) { for (int i = 0; i < 9; i++) atomicAdd(&p.timing[i], t_acc[i]); }
   __syncthreads();
+  for (uint32_t i = tid; i < p.n_hot * kSgHotCopies; i += kSgBlock) {
+    const unsigned long long sum = hot_cell[(size_t)i * 2], cl = hot_cell[(size_t)i * 2 + 1];
+    unsigned long long* g = p.hot_acc + (size_t)(i / kSgHotCopies) * 3;
+    if (!cl) continue;
+    if (p.is_f64) atomicAdd(reinterpret_cast<double*>(g), __longlong_as_double((long long)sum)); else atomicAdd(g, sum);
+    atomicAdd(g + 1, cl & 0xffffffffull);
+    atomicAdd(g + 2, cl >> 32);
+  }
   for (uint32_t pp = tid; pp < NP; pp += kSgBlock) {
     const uint32_t st = state[pp], rem = st & 31u;
     uint32_t ln = (st >> 5) & 63u, lc = st >> 11;
@@ -471,6 +518,61 @@ double sg_estimate_groups(const uint64_t* views, int64_t n) {
   for (int it = 0; it < 200; it++) { const double mid = std::sqrt(lo * hi); (mid * (1.0 - std::exp(-(double)S / mid)) < d ? lo : hi) = mid; }
   return std::min(hi, (double)n);
 }
+// heavy hitters: 8192 rows spread evenly over the input, counted by their 64-bit hash in an LDS table; a string with >= 1/512 of the sample (16 rows) is
+// hot; the 64 most frequent of those go to the scatter.  One workgroup; res = {n_hot, hottest count, distinct hashes in the sample, sample size}
+constexpr uint32_t kSgHotSample = 8192, kSgHotTable = 8192, kSgHotMinCount = kSgHotSample / 512;
+__global__ __launch_bounds__(kSgBlock) void sg_hot_kernel(const unsigned long long* __restrict__ views, int64_t n, unsigned long long* __restrict__ hot_views, unsigned int* __restrict__ res) {
+  extern __shared__ unsigned long long sg_lds[];                   // hashes [8192] u64 | counts [8192] u32 | first sample index [8192] u32 | candidates [256] u32
+  unsigned long long* hs = sg_lds;
+  unsigned int* hc = reinterpret_cast<unsigned int*>(hs + kSgHotTable);
+  unsigned int* hrow = hc + kSgHotTable;
+  unsigned int* cand = hrow + kSgHotTable;
+  __shared__ unsigned int n_cand, n_distinct;
+  const int64_t S = n < (int64_t)kSgHotSample ? n : (int64_t)kSgHotSample;
+  for (uint32_t i = threadIdx.x; i < kSgHotTable; i += blockDim.x) { hs[i] = kSgEmpty; hc[i] = 0; }
+  if (threadIdx.x == 0) { n_cand = 0; n_distinct = 0; }
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < S; i += blockDim.x) {
+    const int64_t row = (int64_t)((__int128)i * n / S);
+    const ulonglong2 v = reinterpret_cast<const ulonglong2*>(views)[row];
+    unsigned long long h = sg_hash(v.x, v.y);
+    if (h == kSgEmpty) h = 0;
+    uint32_t sl = (uint32_t)(h >> 20) & (kSgHotTable - 1u);
+    for (uint32_t probe = 0; probe < 256; probe++, sl = (sl + 1) & (kSgHotTable - 1u)) {
+      const unsigned long long old = atomicCAS(&hs[sl], kSgEmpty, h);
+      if (old == kSgEmpty) { hrow[sl] = (unsigned int)i; atomicAdd(&n_distinct, 1u); }
+      if (old == kSgEmpty || old == h) { atomicAdd(&hc[sl], 1u); break; }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < kSgHotTable; i += blockDim.x)
+    if (hc[i] >= kSgHotMinCount && S >= (int64_t)kSgHotSample / 4) { const uint32_t o = atomicAdd(&n_cand, 1u); if (o < 256) cand[o] = i; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t nc = n_cand < 256u ? n_cand : 256u, top = 0;
+    for (uint32_t a = 0; a < nc; a++)          // selection sort by count, descending: at most 256 entries
+      for (uint32_t b = a + 1; b < nc; b++) if (hc[cand[b]] > hc[cand[a]]) { const unsigned int t = cand[a]; cand[a] = cand[b]; cand[b] = t; }
+    if (nc) top = hc[cand[0]];
+    if (nc > kSgMaxHot) nc = kSgMaxHot;
+    for (uint32_t a = 0; a < nc; a++) {
+      const int64_t row = (int64_t)((__int128)hrow[cand[a]] * n / S);
+      hot_views[a * 2] = views[row * 2]; hot_views[a * 2 + 1] = views[row * 2 + 1];
+    }
+    res[0] = nc; res[1] = top; res[2] = n_distinct; res[3] = (unsigned int)S;
+  }
+}
+// the hot strings' groups behind the partitions' groups
+__global__ void sg_hot_emit_kernel(uint32_t n_hot, const unsigned long long* __restrict__ hot_views, const unsigned long long* __restrict__ hot_acc, unsigned long long* counter, uint32_t max_groups,
+                                   unsigned int* overflow, unsigned long long* out_views, unsigned long long* out_sum, unsigned int* out_cnt, unsigned int* out_len) {
+  __shared__ unsigned long long base;
+  if (threadIdx.x == 0) base = atomicAdd(counter, (unsigned long long)n_hot);
+  __syncthreads();
+  if (base + n_hot > max_groups) { if (threadIdx.x == 0) atomicExch(overflow, 2u); return; }
+  const uint32_t i = threadIdx.x;
+  if (i >= n_hot) return;
+  out_views[(base + i) * 2] = hot_views[i * 2]; out_views[(base + i) * 2 + 1] = hot_views[i * 2 + 1];
+  out_sum[base + i] = hot_acc[i * 3]; out_cnt[base + i] = (unsigned int)hot_acc[i * 3 + 1]; out_len[base + i] = (unsigned int)hot_acc[i * 3 + 2];
+}
 }  // namespace
 
 // views [n][2] / values [n] (8-byte, f64 when is_f64 else i64) / value validity (may be null) on the device.
@@ -483,6 +585,21 @@ int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uin
   static_assert(kSgBlock == 1024, "the scatter kernel's scan wave and flush step take eight partitions per lane / sixteen per 32-lane group: 512 partitions, 1024 threads");
   const double est_groups = sg_estimate_groups(views, n);
   if (est_groups < 0 || est_groups > (double)NP * (double)kSgGroupCap * 0.8) return -1;      // a partition's groups must fit its LDS storage (2816) with room for the spread
+  // few groups: a partition holds a handful of strings and every update of its workgroup lands on the same few LDS addresses (measured, 2^26 rows:
+  // 100 strings 2.9 ms against 0.95 ms for encode-then-group, 1e4 strings 1.5 against 2.0) -- the usual route is the better one there
+  const char* force = std::getenv("PLX_STRGROUP_FORCE");                                   // tests of the operator's semantics on small inputs
+  if (est_groups < 4096.0 && !(force && force[0] == '1')) return -1;
+  Buf hot_views = dev_alloc(16 * kSgMaxHot), hot_acc = dev_alloc_zero(24 * kSgMaxHot), hot_res = dev_alloc_zero(16);
+  {
+    const size_t lds = (size_t)kSgHotTable * 16 + 256 * 4;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)sg_hot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); attr = true; }
+    hipLaunchKernelGGL(sg_hot_kernel, dim3(1), dim3(kSgBlock), lds, stream(), (const unsigned long long*)views, n, hot_views->as<unsigned long long>(), hot_res->as<unsigned int>());
+  }
+  PLX_HIP(hipGetLastError());
+  uint32_t hot[4] = {0, 0, 0, 0};
+  d2h_sync(hot, hot_res->ptr, 16);
+  const uint32_t n_hot = hot[0];
   const int64_t nrounds = (n + kSgTile - 1) / kSgTile;
   const uint32_t grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(nrounds, device().cu_count));
   const int64_t rounds_per_wg = (nrounds + grid - 1) / grid;
@@ -497,6 +614,7 @@ int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uin
   sp.views = (const unsigned long long*)views; sp.values = (const unsigned long long*)values; sp.val_validity = val_validity; sp.n = n;
   sp.recs = recs->as<unsigned int>(); sp.chunk_part = chunk_part->as<unsigned int>(); sp.chunk_fill = chunk_fill->as<unsigned int>(); sp.flags = meta->as<unsigned int>() + 3;
   sp.chunks_per_wg = chunks_per_wg; sp.log2_parts = log2_parts;
+  sp.n_hot = n_hot; sp.hot_views = hot_views->as<unsigned long long>(); sp.hot_acc = hot_acc->as<unsigned long long>(); sp.is_f64 = is_f64 ? 1u : 0u;
   static const bool timing = std::getenv("PLX_STRGROUP_TIMING") && std::getenv("PLX_STRGROUP_TIMING")[0] == '1';
   Buf tbuf;
   if (timing) { tbuf = dev_alloc_zero(128); sp.timing = tbuf->as<unsigned long long>(); }
@@ -524,7 +642,7 @@ int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uin
                        cl_off->as<unsigned long long>(), cursor->as<unsigned int>(), cl_ids->as<unsigned int>());
     PLX_HIP(hipGetLastError());
   }
-  const uint64_t max_groups = std::min<uint64_t>((uint64_t)NP * kSgGroupCap, (uint64_t)n);
+  const uint64_t max_groups = std::min<uint64_t>((uint64_t)NP * kSgGroupCap + kSgMaxHot, (uint64_t)n);
   *out_views = dev_alloc(16 * (size_t)max_groups + 16);
   *out_sum = dev_alloc(8 * (size_t)max_groups + 8);
   *out_cnt = dev_alloc(4 * (size_t)max_groups + 8);
@@ -543,6 +661,11 @@ int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uin
     hipLaunchKernelGGL(strgroup_agg_kernel, dim3(NP), dim3(kSgBlock), lds, stream(), ap);
     PLX_HIP(hipGetLastError());
   }
+  if (n_hot) {
+    hipLaunchKernelGGL(sg_hot_emit_kernel, dim3(1), dim3(kSgMaxHot), 0, stream(), n_hot, hot_views->as<unsigned long long>(), hot_acc->as<unsigned long long>(), ap.counter, ap.max_groups, ap.overflow,
+                       ap.out_views, ap.out_sum, ap.out_cnt, ap.out_len);
+    PLX_HIP(hipGetLastError());
+  }
   uint32_t res[6] = {0, 0, 0, 0, 0, 0};
   d2h_sync(res, meta->ptr, 24);
   if (timing) {
@@ -554,7 +677,7 @@ int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uin
   }
   PLX_REQUIRE(!res[3], PLX_ERR_INVALID, "string group-by: a scatter workgroup ran out of chunks");
   if (res[2] || res[4] || res[5]) return -1;               // a partition with more groups than its LDS storage / long strings: the usual route
-  if (desc) *desc = "strview_groupby(partitioned by view hash, P=512, rec=24B, tile=3072)+lds_tag_table(slots=16384, groups<=2816), est_groups=" + std::to_string((long long)est_groups);
+  if (desc) *desc = "strview_groupby(partitioned by view hash, P=512, rec=24B, tile=3072)+lds_tag_table(slots=16384, groups<=2816), est_groups=" + std::to_string((long long)est_groups) + ", hot=" + std::to_string(n_hot);
   return (int64_t)(((uint64_t)res[1] << 32) | res[0]);
 }
 

@@ -49,7 +49,8 @@ def test_string_key_group_by_on_views_matches_numpy_and_the_encoded_route(pl):
     assert ref["k"] == got["k"] and ref["c"] == got["c"] and ref["len"] == got["len"] and np.allclose(ref["v_sum"], got["v_sum"], rtol=1e-9)
 
 
-def test_string_key_group_by_nulls_int_values_short_and_empty_strings(pl):
+def test_string_key_group_by_nulls_int_values_short_and_empty_strings(pl, monkeypatch):
+    monkeypatch.setenv("PLX_STRGROUP_FORCE", "1")           # 14 distinct strings: the operator would leave so few groups to the usual route
     rng = np.random.default_rng(5)
     words = ["", "a", "b", "ab", "ba", "a\0", "abcdefghijkl", "abcdefghijkm", "Abcdefghijkl", "xbcdefghijkl", "ünï", "twelve bytes", "0", "00"]
     n = 300_011
@@ -136,7 +137,8 @@ def _operator_cases():
 
 
 @pytest.mark.parametrize("case,aggs", _operator_cases(), ids=lambda x: x["id"] if isinstance(x, dict) else "")
-def test_reference_string_key_group_by_vectors_through_the_operator(pl, case, aggs):
+def test_reference_string_key_group_by_vectors_through_the_operator(pl, case, aggs, monkeypatch):
+    monkeypatch.setenv("PLX_STRGROUP_FORCE", "1")           # a handful of groups: without this the operator declines (few groups -> the usual route)
     from tests import kat
     from tests.test_gpu_golden import _agg, _series
     (kname, kspec), = case["keys"].items()
@@ -153,3 +155,66 @@ def test_reference_string_key_group_by_vectors_through_the_operator(pl, case, ag
     for got, want in zip(rows, exp):
         for g, e in zip(got, want):
             assert kat.same_value(g, e, 1e-12), (case["id"], rows, exp)
+
+
+def _id_views(pl, ids):
+    """Inline views of "id%010d" % id, built on the host (tools/strgroup_sweep.py has the same)."""
+    digits = np.zeros((len(ids), 10), np.uint8)
+    x = np.asarray(ids, np.int64).copy()
+    for j in range(9, -1, -1):
+        digits[:, j] = 48 + x % 10
+        x //= 10
+    raw = np.zeros((len(ids), 16), np.uint8)
+    raw[:, 0] = 12
+    raw[:, 4] = ord("i"); raw[:, 5] = ord("d")
+    raw[:, 6:16] = digits
+    return pl.Series("views", raw.reshape(-1).view(np.uint64), pl.UInt64)
+
+
+@pytest.mark.parametrize("shape", ["one_string_half_of_the_rows", "zipf_1.1", "hot_with_null_values_int"])
+def test_string_key_group_by_heavy_hitters(pl, shape):
+    """Strings that hold a large share of the rows are summed in the scatter's LDS cells (sampled: sg_hot_kernel) and never reach a partition: without
+    that, one string with half of the rows cost 76 ms instead of 1.6 at 2^26 rows.  Exact for Int64, 1e-9 for Float64; the plan reports hot > 0."""
+    import re
+    rng = np.random.default_rng(23)
+    n, G = 6_000_011, 300_000
+    if shape == "zipf_1.1":
+        ids = (rng.zipf(1.1, n) - 1) % G
+    else:
+        ids = rng.integers(0, G, n)
+        ids[rng.random(n) < 0.5] = 123_456
+    k = pl.Series.from_device_views("k", _id_views(pl, ids), encode="deferred")
+    if shape == "hot_with_null_values_int":
+        x = rng.integers(-10 ** 9, 10 ** 9, n)
+        valid = rng.random(n) > 0.25
+        v = pl.Series("v", x, pl.Int64, validity=valid)
+    else:
+        x = rng.uniform(-1, 1, n)
+        valid = np.ones(n, bool)
+        v = pl.Series("v", x)
+    out = pl.DataFrame([k, v]).lazy().group_by("k").agg(pl.col("v").sum().alias("s"), pl.col("v").count().alias("c"), pl.len().alias("n")).collect()
+    plan = pl.last_plan()
+    m = re.search(r"StringViewGroupBy\{.*hot=(\d+)", plan)
+    assert m and int(m.group(1)) > 0, plan
+    got = _by_key(out)
+    present = np.unique(ids)
+    assert got["k"] == ["id%010d" % i for i in present]
+    assert got["n"] == np.bincount(ids, minlength=G)[present].tolist()
+    assert got["c"] == np.bincount(ids, valid.astype(np.float64), minlength=G)[present].astype(np.int64).tolist()
+    want = np.bincount(ids, np.where(valid, x, 0), minlength=G)[present]
+    if shape == "hot_with_null_values_int":
+        assert got["s"] == want.astype(np.int64).tolist()                      # |sums| < 2^53: bincount's float accumulator is exact
+    else:
+        assert np.allclose(got["s"], want, rtol=1e-9, atol=1e-9)
+
+
+def test_string_key_group_by_leaves_few_groups_to_the_usual_route(pl):
+    rng = np.random.default_rng(29)
+    n = 3_000_000
+    ids = rng.integers(0, 100, n)
+    x = rng.uniform(0, 1, n)
+    k = pl.Series.from_device_views("k", _id_views(pl, ids), encode="deferred")
+    out = pl.DataFrame([k, pl.Series("v", x)]).lazy().group_by("k").agg(pl.col("v").sum().alias("s"), pl.len().alias("n")).collect()
+    assert "StringViewGroupBy" not in pl.last_plan() and not k._is_raw_views()
+    got = _by_key(out)
+    assert got["k"] == ["id%010d" % i for i in range(100)] and got["n"] == np.bincount(ids).tolist() and np.allclose(got["s"], np.bincount(ids, x), rtol=1e-9)
