@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd $R
 t0=$(date +%s)
 el() { echo "[+$(( $(date +%s) - t0 ))s] $*" | tee -a $OUT/summary.txt; }
-bash tools/pmc_all.sh r03w cfg3 cfg5 cfg5s > $OUT/pmc_all.log 2>&1; el "pmc refresh exit $?"
+bash tools/pmc_all.sh r03w cfg5s > $OUT/pmc_all.log 2>&1; el "pmc refresh exit $?"
 grep -E "^(cfg3|cfg5|q3s|cfg5s) " $OUT/pmc_all.log | head -8
 timeout 600 python -m pytest tests -m gpu -q --timeout 300 -x > $OUT/pytest_gpu_all.log 2>&1; el "whole gpu suite exit $?"
 tail -4 $OUT/pytest_gpu_all.log | cut -c1-300
