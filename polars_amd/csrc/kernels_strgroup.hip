@@ -521,9 +521,9 @@ double sg_estimate_groups(const uint64_t* views, int64_t n) {
   for (int it = 0; it < 200; it++) { const double mid = std::sqrt(lo * hi); (mid * (1.0 - std::exp(-(double)S / mid)) < d ? lo : hi) = mid; }
   return std::min(hi, (double)n);
 }
-// heavy hitters: 8192 rows spread evenly over the input, counted by their 64-bit hash in an LDS table; a string with >= 1/512 of the sample (16 rows) is
+// heavy hitters: 4096 rows spread evenly over the input, counted by their 64-bit hash in an LDS table; a string with >= 1/512 of the sample (8 rows) is
 // hot; the 64 most frequent of those go to the scatter.  One workgroup; res = {n_hot, hottest count, distinct hashes in the sample, sample size}
-constexpr uint32_t kSgHotSample = 8192, kSgHotTable = 8192, kSgHotMinCount = kSgHotSample / 512;
+constexpr uint32_t kSgHotSample = 4096, kSgHotTable = 8192, kSgHotMinCount = kSgHotSample / 512;     // (a table as large as the sample is FULL when every string is different: 256-step probe chains)
 __global__ __launch_bounds__(kSgBlock) void sg_hot_kernel(const unsigned long long* __restrict__ views, int64_t n, unsigned long long* __restrict__ hot_views, unsigned int* __restrict__ res) {
   extern __shared__ unsigned long long sg_lds[];                   // hashes [8192] u64 | counts [8192] u32 | first sample index [8192] u32 | candidates [256] u32
   unsigned long long* hs = sg_lds;
