@@ -163,13 +163,13 @@ class Series:
         strings' bytes, or None when every string is <= 12 bytes) -> dictionary column, encoded on the device.
         encode="deferred": the column stays a column of views until an operator needs dictionary codes; group_by(<this column>).agg(sum /
         mean / count / len of one Float64 / Int64 column) then runs on the views themselves (plx_strview_groupby) and never encodes."""
-        F.ensure_init()
         if encode not in ("eager", "deferred"):
             raise ValueError(f"encode must be 'eager' or 'deferred', not {encode!r}")
         if encode == "deferred":
             if len(views) % 2:
                 raise ValueError("views must hold 2 n UInt64 words")
             return cls(name, _raw=(views, data))
+        F.ensure_init()
         codes, d = C.c_uint64(), C.c_uint64()
         F.check(F.lib().plx_strview_dict_encode_device(views._h, data._h if data is not None else 0, C.byref(codes), C.byref(d)))
         return cls(name, _handle=codes.value, _dtype=T.Categorical(DeviceDictionary(d.value), T.UInt32))
