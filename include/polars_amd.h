@@ -532,6 +532,12 @@ int plx_ipc_column_info(plx_ipc file, int32_t column, const char** name, int32_t
 int plx_ipc_column_timezone(plx_ipc file, int32_t column, const char** timezone);      /* the Timestamp type's timezone string, "" = none */
 int plx_ipc_batch_info(plx_ipc file, int32_t batch, int64_t* num_rows, int64_t* body_bytes, int32_t* compressed);
 int plx_ipc_read(plx_ipc file, const int32_t* batches, int32_t n_batches, const int32_t* columns, int32_t n_columns, plx_frame* out);
+/* One Utf8 / LargeUtf8 / Binary column of the selected record batches as it is needed for a group-by ON THE VIEWS (plx_strview_groupby): *out_views = a PLX_U64 column of
+ * 2 n words (16-byte views built on the device from the file's offsets + bytes), *out_data = the bytes behind the views of strings over 12 bytes (PLX_U8; the pair is what
+ * plx_strview_dict_encode_device takes when the column has to be encoded after all).  PLX_ERR_UNSUPPORTED: a column with nulls, a Utf8View column, a column that is
+ * dictionary-encoded in the file -- read those through plx_ipc_read.  (The reference reads string columns as views and hashes them per operator:
+ * crates/polars-io/src/ipc/ipc_file.rs, crates/polars-expr/src/hash_keys.rs:413-452.) */
+int plx_ipc_read_string_views(plx_ipc file, const int32_t* batches, int32_t n_batches, int32_t column, plx_column* out_views, plx_column* out_data);
 int plx_ipc_categories(plx_ipc file, int32_t column, int64_t* n_strings, int64_t* total_bytes);
 int plx_ipc_categories_to_host(plx_ipc file, int32_t column, int64_t* offsets, uint8_t* bytes);
 int plx_ipc_column_strdict(plx_ipc file, int32_t column, plx_strdict* out);

@@ -138,6 +138,7 @@ SIGNATURES = {
     "plx_ipc_column_timezone": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_char_p)]),
     "plx_ipc_batch_info": (C.c_int, [C.c_uint64, C.c_int32, _i64p, _i64p, _i32p]),
     "plx_ipc_read": (C.c_int, [C.c_uint64, _i32p, C.c_int32, _i32p, C.c_int32, _u64p]),
+    "plx_ipc_read_string_views": (C.c_int, [C.c_uint64, _i32p, C.c_int32, C.c_int32, _u64p, _u64p]),
     "plx_ipc_categories": (C.c_int, [C.c_uint64, C.c_int32, _i64p, _i64p]),
     "plx_ipc_categories_to_host": (C.c_int, [C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
     "plx_ipc_column_strdict": (C.c_int, [C.c_uint64, C.c_int32, _u64p]),

@@ -191,7 +191,10 @@ void set_bits(uint8_t* bits, int64_t off, int64_t n) {
 // of host threads fills two page-locked images: 4-8 B of offsets per row instead of 16 B of host-assembled views out of pageable memory -- the
 // 1-character l_returnflag column of a 2e7-row file took 115 of the file's 150 ms that way), the views are built by a kernel
 // (k::strviews_from_offsets) and encoded on the device like every other string column.
-ColumnPtr read_offset_string_column(File& f, const std::vector<int>& bsel, int col, int64_t total, bool large, plx_strdict* dict_out) {
+// raw != nullptr: the column is NOT dictionary-encoded -- its views (2 x total UInt64 words) and the bytes behind them are handed back as they sit in HBM
+// (plx_ipc_read_string_views: a group-by keyed on the column runs on the views, kernels_strgroup.hip); a column with nulls is refused there
+struct RawViews { ColumnPtr views, data; };
+ColumnPtr read_offset_string_column(File& f, const std::vector<int>& bsel, int col, int64_t total, bool large, plx_strdict* dict_out, RawViews* raw = nullptr) {
   PinnedStage& st = PinnedStage::for_this_thread();
   const size_t ow = large ? 8 : 4;
   struct Part { const ipc::BatchMeta* bm; int64_t body, n, row0; const ipc::BufferRef *vbits, *offs, *data; size_t off_at, data_at, data_len; };
@@ -266,6 +269,13 @@ ColumnPtr read_offset_string_column(File& f, const std::vector<int>& bsel, int c
   uint32_t bad = 0;
   d2h_sync(&bad, err->ptr, 4);
   if (bad) throw ipc::FormatError("string offsets outside the data buffer");
+  if (raw) {
+    if (any_nulls) throw Unsupported("string column with nulls: its views are not handed out (read it dictionary-encoded)");
+    auto col_of = [](int dtype, int64_t len, const Buf& b) { auto c = std::make_shared<Column>(); c->dtype = dtype; c->len = len; c->values = b; c->null_count = 0; return c; };
+    raw->views = col_of(PLX_U64, total * 2, d_views);
+    raw->data = col_of(PLX_U8, (int64_t)data_bytes, d_data);
+    return nullptr;
+  }
   plx_column codes = 0;
   uint64_t dict = 0;
   strview_encode_device(d_views->as<uint64_t>(), vh, d_data, total, &codes, &dict);
@@ -512,6 +522,37 @@ int plx_ipc_read(plx_ipc file, const int32_t* batches, int32_t n_batches, const 
     throw;
   }
   *out = register_frame(frame);
+  IPC_CATCH
+}
+
+int plx_ipc_read_string_views(plx_ipc file, const int32_t* batches, int32_t n_batches, int32_t column, plx_column* out_views, plx_column* out_data) {
+  IPC_TRY
+  PLX_REQUIRE(out_views && out_data && (batches || n_batches == 0), PLX_ERR_INVALID, "null argument");
+  File& f = get_file(file);
+  std::lock_guard<std::mutex> reading(file_mutex(file));
+  device();   // fails loudly without a GPU
+  PLX_REQUIRE(column >= 0 && (size_t)column < f.footer.fields.size(), PLX_ERR_INVALID, "ipc column index out of range");
+  const ipc::Field& fl = f.footer.fields[column];
+  const ColType ct = col_type(fl);
+  const bool is_view = fl.type == ipc::TY_UTF8_VIEW || fl.type == ipc::TY_BINARY_VIEW;
+  if (!ct.strings || fl.has_dictionary || is_view) throw Unsupported("column '" + fl.name + "': views are handed out for Utf8 / LargeUtf8 / Binary columns that are not dictionary-encoded in the file");
+  std::vector<int> bsel(batches, batches + n_batches);
+  int64_t total = 0;
+  for (int b : bsel) {
+    PLX_REQUIRE(b >= 0 && (size_t)b < f.batches.size(), PLX_ERR_INVALID, "ipc record batch index out of range");
+    if (f.batches[b].compressed && f.batches[b].codec != 0 && f.batches[b].codec != 1) throw Unsupported("record batch body compressed with an unknown codec");
+    total += f.batches[b].length;
+  }
+  RawViews raw;
+  try {
+    read_offset_string_column(f, bsel, column, total, fl.type == ipc::TY_LARGE_UTF8 || fl.type == ipc::TY_LARGE_BINARY, nullptr, &raw);
+    PLX_HIP(hipStreamSynchronize(stream()));
+  } catch (...) {
+    (void)hipStreamSynchronize(stream());
+    throw;
+  }
+  *out_views = register_column(raw.views);
+  *out_data = register_column(raw.data);
   IPC_CATCH
 }
 

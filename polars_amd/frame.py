@@ -933,11 +933,20 @@ def _string_key_group_by(node: P.Node) -> Optional[DataFrame]:
     if node.kind != "group_by" or node.maintain_order or len(node.keys) != 1 or node.keys[0].kind != "col" or not node.aggs:
         return None
     src = node.input
-    if src.kind != "scan" or type(src.frame) is not DataFrame:
+    if src.kind != "scan":
         return None
-    cols = {c.name: c for c in src.frame._cols}
+    frame = src.frame
+    if type(frame) is not DataFrame:
+        # a single-file IPC scan that hands its string columns out as views (scan_ipc(string_keys="deferred")): read what THIS plan needs, then look at the columns
+        if getattr(getattr(frame, "_dec", None), "string_keys", "encoded") != "deferred":
+            return None
+        from . import io as _io
+        _io.reset_scans(node)
+        _io.push_down(node)
+        frame = frame.materialise()
+    cols = {c.name: c for c in frame._cols}
     key = cols.get(node.keys[0].name)
-    if key is None or not key._is_raw_views() or key._raw[1] is not None:
+    if key is None or not key._is_raw_views():       # (bytes behind the views -- strings over 12 bytes -- do not matter here: the operator declines such a column itself)
         return None
     plan, value = [], None                   # (output name, "sum" | "mean" | "count" | "len")
     for e in node.aggs:

@@ -22,10 +22,11 @@ from .io import DATETIME_UNITS, ParquetFrame, _MultiDecoder, expand_paths, strin
 class _IpcDecoder:
     name = "device"
 
-    def __init__(self, path: str):
+    def __init__(self, path: str, string_keys: str = "encoded"):
         h = C.c_uint64()
         F.check(F.lib().plx_ipc_open(path.encode(), C.byref(h)))
         self._h = h.value
+        self.string_keys = string_keys
         n, g, c = C.c_int64(), C.c_int32(), C.c_int32()
         F.check(F.lib().plx_ipc_shape(self._h, C.byref(n), C.byref(g), C.byref(c)))
         self.num_rows, self.num_row_groups = n.value, g.value
@@ -82,8 +83,24 @@ class _IpcDecoder:
     def read(self, rgs: List[int], cols: List[str]):
         from .frame import DataFrame, DeviceDictionary
         F.ensure_init()
-        idx = [self._info[n][0] for n in cols]
+        from .frame import Series
         a_b = (C.c_int32 * max(len(rgs), 1))(*rgs)
+        # string_keys="deferred": Utf8 / LargeUtf8 columns come as the views the device builds from offsets + bytes, not dictionary-encoded -- a group-by keyed on such
+        # a column runs on the views (plx_strview_groupby), anything else encodes the column on first use.  Columns the library does not hand out as views
+        # (nulls, Utf8View, dictionary-encoded in the file) are read the usual way.
+        raw = {}
+        if self.string_keys == "deferred":
+            for n in cols:
+                i, dt, lg, _ = self._info[n]
+                if lg == 3 and self._plain_strings(n):
+                    v, d = C.c_uint64(), C.c_uint64()
+                    st = F.lib().plx_ipc_read_string_views(self._h, a_b, len(rgs), i, C.byref(v), C.byref(d))
+                    if st == F.ERR_UNSUPPORTED:
+                        continue
+                    F.check(st)
+                    raw[n] = Series(n, _raw=(Series._from_handle("views", v.value, T.UInt64), Series._from_handle("data", d.value, T.UInt8)))
+        all_cols, cols = cols, [n for n in cols if n not in raw]
+        idx = [self._info[n][0] for n in cols]
         a_col = (C.c_int32 * max(len(idx), 1))(*idx)
         fh = C.c_uint64()
         F.check(F.lib().plx_ipc_read(self._h, a_b, len(rgs), a_col, len(idx), C.byref(fh)))
@@ -101,6 +118,9 @@ class _IpcDecoder:
         df = DataFrame._from_frame_handle(fh.value, hint)
         for s in df.get_columns():
             s._declare_dictionary_bounds()
+        if raw:
+            have = {s.name: s for s in df.get_columns()}
+            df = DataFrame([raw[n] if n in raw else have[n] for n in all_cols])
         nbytes = sum(self.batch_info(b)["body_bytes"] for b in rgs)
         return df, df.height, nbytes
 
@@ -120,11 +140,14 @@ class _IpcDecoder:
 class IpcFrame(ParquetFrame):
     """Scan source over an Arrow IPC file: the same lazy materialisation and projection pushdown as ParquetFrame."""
 
-    def __init__(self, path, columns: Optional[Sequence[str]] = None, shard=None):
+    def __init__(self, path, columns: Optional[Sequence[str]] = None, shard=None, string_keys: str = "encoded"):
+        if string_keys not in ("encoded", "deferred"):
+            raise ValueError(f"string_keys must be 'encoded' or 'deferred', not {string_keys!r}")
         self._set_shard(shard)
         paths = expand_paths(path, suffixes=(".arrow", ".feather", ".ipc"))
         self.path = paths[0] if len(paths) == 1 else paths
-        self._dec = _IpcDecoder(paths[0]) if len(paths) == 1 else _MultiDecoder(paths, _IpcDecoder)
+        # (several files are concatenated on the device, which needs their dictionaries: deferral is a single-file matter)
+        self._dec = _IpcDecoder(paths[0], string_keys) if len(paths) == 1 else _MultiDecoder(paths, _IpcDecoder)
         names = list(columns) if columns is not None else list(self._dec.names)
         self._schema = {n: self._dec.dtype(n) for n in names}
         self._need = set()
@@ -135,10 +158,12 @@ class IpcFrame(ParquetFrame):
         self.last_read = {}
 
 
-def scan_ipc(path, columns: Optional[Sequence[str]] = None, shard=None):
-    """LazyFrame over an Arrow IPC (Feather V2) file (mirrors polars.scan_ipc for the path's dtypes); uncompressed, LZ4-frame and Zstandard bodies."""
+def scan_ipc(path, columns: Optional[Sequence[str]] = None, shard=None, *, string_keys: str = "encoded"):
+    """LazyFrame over an Arrow IPC (Feather V2) file (mirrors polars.scan_ipc for the path's dtypes); uncompressed, LZ4-frame and Zstandard bodies.
+    string_keys="deferred" (one file): Utf8 / LargeUtf8 columns without nulls stay columns of views until an operator needs dictionary codes;
+    scan_ipc(...).group_by(<such a column>).agg(sum / mean / count / len of one Float64 / Int64 column) then never encodes (plx_strview_groupby)."""
     from .frame import LazyFrame
-    return LazyFrame(P.Node("scan", frame=IpcFrame(path, columns, shard)))
+    return LazyFrame(P.Node("scan", frame=IpcFrame(path, columns, shard, string_keys)))
 
 
 def read_ipc(path, columns: Optional[Sequence[str]] = None):

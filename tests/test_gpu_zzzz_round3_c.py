@@ -218,3 +218,54 @@ def test_string_key_group_by_leaves_few_groups_to_the_usual_route(pl):
     assert "StringViewGroupBy" not in pl.last_plan() and not k._is_raw_views()
     got = _by_key(out)
     assert got["k"] == ["id%010d" % i for i in range(100)] and got["n"] == np.bincount(ids).tolist() and np.allclose(got["s"], np.bincount(ids, x), rtol=1e-9)
+
+
+def test_scan_ipc_string_key_group_by_on_views(pl, tmp_path):
+    """scan_ipc(string_keys="deferred"): a Utf8 column comes out of the file as device-built views, group_by on it runs on the views; any other use of the
+    column, strings over 12 bytes and a key column with nulls take the encoded route -- same answers (against pandas)."""
+    import pyarrow.feather  # noqa: F401
+    import pyarrow.ipc as ipc
+    rng = np.random.default_rng(31)
+    n, G = 1_200_000, 60_000
+    ids = rng.integers(0, G, n)
+    keys = np.array(["id%010d" % i for i in range(G)])[ids]
+    v = rng.uniform(-5, 5, n)
+    w = rng.integers(-1000, 1000, n)
+    table = pa.table({"k": pa.array(keys, pa.string()), "v": v, "w": w, "long": pa.array(np.char.add(keys, "_and_some_more"), pa.large_string()),
+                      "kn": pa.array([None if i % 97 == 0 else s for i, s in enumerate(keys)], pa.string())})
+    path = str(tmp_path / "keys.arrow")
+    with ipc.new_file(path, table.schema) as wr:
+        for b in table.to_batches(max_chunksize=250_000):              # several record batches
+            wr.write_batch(b)
+    want = table.select(["k", "v"]).to_pandas().groupby("k")["v"].agg(["sum", "mean", "size"]).sort_index()
+
+    lf = pl.scan_ipc(path, string_keys="deferred")
+    out = lf.group_by("k").agg(pl.col("v").sum().alias("s"), pl.col("v").mean().alias("m"), pl.len().alias("n")).collect()
+    assert "StringViewGroupBy" in pl.last_plan(), pl.last_plan()
+    got = _by_key(out)
+    assert got["k"] == want.index.tolist() and got["n"] == want["size"].tolist()
+    assert np.allclose(got["s"], want["sum"], rtol=1e-9, atol=1e-9) and np.allclose(got["m"], want["mean"], rtol=1e-9, atol=1e-9)
+    # an Int64 value column of the same scan
+    out = lf.group_by("k").agg(pl.col("w").sum()).collect()
+    assert "StringViewGroupBy" in pl.last_plan()
+    assert _by_key(out)["w"] == table.select(["k", "w"]).to_pandas().groupby("k")["w"].sum().sort_index().tolist()
+    # the column used otherwise: encoded on first touch
+    one = lf.filter(pl.col("k") == "id0000000007").select(pl.col("v").sum().alias("s"), pl.len().alias("n")).collect().to_dict()
+    assert one["n"] == [int((ids == 7).sum())] and abs(one["s"][0] - v[ids == 7].sum()) < 1e-9
+    # strings over 12 bytes: the operator declines, the views + bytes are encoded, same groups
+    out = lf.group_by("long").agg(pl.col("v").sum().alias("s")).collect()
+    assert "StringViewGroupBy" not in pl.last_plan()
+    gl = _by_key(out, "long")
+    assert gl["long"] == [k + "_and_some_more" for k in want.index] and np.allclose(gl["s"], want["sum"], rtol=1e-9, atol=1e-9)
+    # a key column with nulls is read dictionary-encoded as before (null is its own group)
+    out = lf.group_by("kn").agg(pl.len().alias("n"), pl.col("v").sum().alias("s")).collect()
+    assert "StringViewGroupBy" not in pl.last_plan()
+    d = out.to_dict()
+    wn = table.select(["kn", "v"]).to_pandas().groupby("kn", dropna=False)["v"].agg(["sum", "size"])
+    assert len(d["kn"]) == len(wn) and sum(d["n"]) == n
+    i_null = d["kn"].index(None)
+    assert d["n"][i_null] == int(wn.loc[wn.index.isna(), "size"].iloc[0])
+    # and the default scan is unchanged
+    out = pl.scan_ipc(path).group_by("k").agg(pl.col("v").sum().alias("s")).collect()
+    assert "StringViewGroupBy" not in pl.last_plan()
+    assert np.allclose(_by_key(out)["s"], want["sum"], rtol=1e-9, atol=1e-9)
