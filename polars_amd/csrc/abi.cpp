@@ -975,6 +975,7 @@ int plx_strview_groupby(plx_column views_u64_pairs, plx_column value, plx_column
   const int64_t n = v->len / 2;
   PLX_REQUIRE(x->len == n, PLX_ERR_SHAPE, "value column and views differ in length");
   if (n == 0 || (x->dtype != PLX_F64 && x->dtype != PLX_I64)) fail(PLX_ERR_UNSUPPORTED, "string group-by fast path: one Float64 / Int64 value column over a non-empty key");
+  PLX_REQUIRE(v->values && x->values, PLX_ERR_INVALID, "placeholder column has no data");
   Buf gviews, gsum, gcnt, glen;
   std::string desc;
   const int64_t G = k::strview_groupby(v->values->as<uint64_t>(), x->values->as<uint64_t>(), x->validity ? x->valid_words() : nullptr, n, x->dtype == PLX_F64, &gviews, &gsum, &gcnt, &glen, &desc);

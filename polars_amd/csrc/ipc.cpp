@@ -530,7 +530,6 @@ int plx_ipc_read_string_views(plx_ipc file, const int32_t* batches, int32_t n_ba
   PLX_REQUIRE(out_views && out_data && (batches || n_batches == 0), PLX_ERR_INVALID, "null argument");
   File& f = get_file(file);
   std::lock_guard<std::mutex> reading(file_mutex(file));
-  device();   // fails loudly without a GPU
   PLX_REQUIRE(column >= 0 && (size_t)column < f.footer.fields.size(), PLX_ERR_INVALID, "ipc column index out of range");
   const ipc::Field& fl = f.footer.fields[column];
   const ColType ct = col_type(fl);
@@ -543,6 +542,7 @@ int plx_ipc_read_string_views(plx_ipc file, const int32_t* batches, int32_t n_ba
     if (f.batches[b].compressed && f.batches[b].codec != 0 && f.batches[b].codec != 1) throw Unsupported("record batch body compressed with an unknown codec");
     total += f.batches[b].length;
   }
+  device();   // (after the checks that need no device) fails loudly without a GPU
   RawViews raw;
   try {
     read_offset_string_column(f, bsel, column, total, fl.type == ipc::TY_LARGE_UTF8 || fl.type == ipc::TY_LARGE_BINARY, nullptr, &raw);

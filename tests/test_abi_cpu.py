@@ -164,3 +164,46 @@ def test_reference_plugin_entry_points_are_exported_and_fail_loudly_without_a_gp
     assert "no HIP device" in P.last_error() or "plx_init" in P.last_error()
     res, inp = P.call("plx_sum", [pa.array([1.0, 2.0]), pa.array([1.0])])       # wrong arity: still releases what it was given
     assert res is None and inp.released == 2
+
+
+def test_string_key_group_by_entry_checks_its_arguments_before_it_needs_a_device(tmp_path):
+    """plx_strview_groupby / plx_ipc_read_string_views: what can be refused from the handles alone is refused with the right status and message; only
+    then does the call need the GPU (and says so)."""
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.ipc as ipc
+    from polars_amd import _ffi as F
+    lib = F.lib()
+    ERR_INVALID, ERR_SHAPE = 1, 5                     # include/polars_amd.h
+
+    def ph(dtype, n):
+        h = C.c_uint64()
+        assert lib.plx_column_placeholder(dtype, n, 0, 0, 0, 0, C.byref(h)) == 0
+        return h.value
+    outs = [C.c_uint64() for _ in range(5)]
+    refs = [C.byref(o) for o in outs]
+    views, odd, v64, v32, short = ph(F.U64, 200), ph(F.U64, 201), ph(F.F64, 100), ph(F.I32, 100), ph(F.F64, 99)
+    assert lib.plx_strview_groupby(views, v64, None, *refs[1:]) == ERR_INVALID and b"null pointer" in lib.plx_last_error()
+    assert lib.plx_strview_groupby(odd, v64, *refs) == ERR_INVALID and b"2 n words" in lib.plx_last_error()
+    assert lib.plx_strview_groupby(v64, v64, *refs) == ERR_INVALID                                   # views must be UInt64
+    assert lib.plx_strview_groupby(views, short, *refs) == ERR_SHAPE and b"differ in length" in lib.plx_last_error()
+    assert lib.plx_strview_groupby(views, v32, *refs) == F.ERR_UNSUPPORTED and b"Float64 / Int64" in lib.plx_last_error()
+    st = lib.plx_strview_groupby(views, v64, *refs)                                                     # well-formed: now it needs the device
+    assert st != 0 and st != F.ERR_UNSUPPORTED and (b"HIP" in lib.plx_last_error() or b"placeholder" in lib.plx_last_error()), lib.plx_last_error()
+    # the IPC side: a Utf8 column, a dictionary-encoded one, a numeric one
+    path = str(tmp_path / "t.arrow")
+    t = pa.table({"s": pa.array(["a", "bb", "ccc"], pa.string()), "d": pa.array(["x", "y", "x"]).dictionary_encode(), "i": pa.array([1, 2, 3], pa.int64())})
+    with ipc.new_file(path, t.schema) as w:
+        w.write_table(t)
+    fh = C.c_uint64()
+    assert lib.plx_ipc_open(path.encode(), C.byref(fh)) == 0
+    b0 = (C.c_int32 * 1)(0)
+    o1, o2 = C.c_uint64(), C.c_uint64()
+    assert lib.plx_ipc_read_string_views(fh.value, b0, 1, 7, C.byref(o1), C.byref(o2)) == ERR_INVALID and b"column index" in lib.plx_last_error()
+    assert lib.plx_ipc_read_string_views(fh.value, b0, 1, 1, C.byref(o1), C.byref(o2)) == F.ERR_UNSUPPORTED and b"dictionary-encoded" in lib.plx_last_error()
+    assert lib.plx_ipc_read_string_views(fh.value, b0, 1, 2, C.byref(o1), C.byref(o2)) == F.ERR_UNSUPPORTED
+    assert lib.plx_ipc_read_string_views(fh.value, (C.c_int32 * 1)(5), 1, 0, C.byref(o1), C.byref(o2)) == ERR_INVALID and b"record batch index" in lib.plx_last_error()
+    assert lib.plx_ipc_read_string_views(fh.value, b0, 1, 0, None, C.byref(o2)) == ERR_INVALID
+    st = lib.plx_ipc_read_string_views(fh.value, b0, 1, 0, C.byref(o1), C.byref(o2))                   # well-formed: needs the device
+    assert st != 0 and st != F.ERR_UNSUPPORTED and b"HIP" in lib.plx_last_error(), lib.plx_last_error()
+    assert lib.plx_ipc_close(fh.value) == 0
