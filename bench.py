@@ -374,7 +374,7 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
             O_, L_ = datagen.orders_lineitem_native(pl, no, seed)
             check_native_q3(pl, O_, L_, no, seed)
             return O_, L_
-        nat = _native_or_none("q3", build_native) if ws == 1 else None   # the sharded path exchanges torch tensors
+        nat = _native_or_none("q3", build_native)
         if nat is not None and shuffled:
             # the SAME rows as the ordered run (the library's generator, host twin available: the oracle can check the result) in a seeded
             # random row order, both tables: one device gather per column
@@ -400,19 +400,6 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
         def step():
             out = lf.collect()
             return out, (L, O, li, orders)
-        if ws > 1:
-            # global problem = union of the per-rank tables: make the order keys globally unique, then run the sharded
-            # join -> group-by (polars_amd/dist.py join_groupby): filtered build side all-gathered, probe rows never move,
-            # partial groups merged by key with one small all-to-all.
-            from polars_amd import dist as pdist
-            import torch.distributed as dist
-            off = dist.get_rank() * (int(orders["o_orderkey"].max().item()) + 1)
-            orders["o_orderkey"] += off; li["l_orderkey"] += off
-            q3s = pdist.Q3Local(pl)
-
-            def step():   # noqa: F811
-                r = q3s.run(li, orders, mode=os.environ.get("PLX_Q3_MODE", "broadcast"))
-                return {"groups": int(r["l_orderkey"].numel())}, (li, orders)
         lf_top = queries.q3_top10(L.lazy(), O.lazy())
 
         def step_top10():
@@ -421,7 +408,7 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
         verify = (lambda res, budget: verify_q3(res, no, seed, budget)) if nat is not None else None
         return Workload("tpch_q3_sf100", nl + no, nl * datagen.Q3_LINEITEM_BYTES_PER_ROW + no * datagen.Q3_ORDERS_BYTES_PER_ROW, step, "join_probe_emit",
                         f"TPC-H Q3 (orders {no} x lineitem {nl}), filter both -> hash join -> group_by(orderkey, orderdate, shippriority)",
-                        variants={} if ws > 1 else {"tpch_q3_sf100_order_by_limit10": step_top10}, verify=verify, scope="operator")
+                        variants={"tpch_q3_sf100_order_by_limit10": step_top10}, verify=verify, scope="operator")
     if name == "q3f":
         # TPC-H Q3 with all three tables: customer[c_mktsegment == "BUILDING"] JOIN orders JOIN lineitem
         no = (rows // 4) if rows else SF100_ORDERS
@@ -931,7 +918,7 @@ def combine_q1_results(per_rank):
     return out
 
 
-def run_guarded(worker, deadline_s: float, poll_s: float = 0.25) -> int:
+def run_guarded(worker, deadline_s: float, poll_s: float = 0.25, prints: bool = True) -> int:
     """Runs worker(emit) in a forked child and prints the LAST line it emitted exactly once, from this process.
 
     The headline measurement comes first; the secondary workloads (`extras`) only refine the same JSON line.  On a GPU box
@@ -939,7 +926,8 @@ def run_guarded(worker, deadline_s: float, poll_s: float = 0.25) -> int:
     load, so the worker hands every improved version of the line to `emit`; if it has not finished `deadline_s` seconds
     after the start but a line exists, the child is stopped and the line printed as it stands.  A worker that dies
     after the headline was measured still gets its line printed.  Forking happens before torch / HIP are imported, so
-    the child initialises the GPU on its own.  Returns the process exit code."""
+    the child initialises the GPU on its own.  Returns the process exit code.  `prints=False` (ranks other than 0 of an N > 1 run): the
+    worker never emits; it is stopped `deadline_s` + 20 s after the start (rank 0 has printed or been cut by then) and that counts as success."""
     import signal
     import tempfile
     tmp = tempfile.mkdtemp(prefix="plx_bench_")
@@ -975,7 +963,7 @@ def run_guarded(worker, deadline_s: float, poll_s: float = 0.25) -> int:
         if done:
             status = st
             break
-        if time.monotonic() >= t_end and os.path.exists(ready_path):
+        if (time.monotonic() >= t_end and os.path.exists(ready_path)) or (not prints and time.monotonic() >= t_end + 20.0):
             os.kill(pid, signal.SIGKILL)
             os.waitpid(pid, 0)
             stopped = True
@@ -993,6 +981,8 @@ def run_guarded(worker, deadline_s: float, poll_s: float = 0.25) -> int:
             line = json.dumps(d)
         print(line, flush=True)
         return EXIT_PARITY if failed_verifications(json.loads(line)) else 0
+    if stopped and not prints:
+        return 0
     return os.waitstatus_to_exitcode(status) if status is not None else 1
 
 
@@ -1015,12 +1005,48 @@ def failed_verifications(line: dict):
     return bad
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE in the environment): start the N ranks here, one process per GPU,
+    with the environment torchrun would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT on 127.0.0.1).  Rank 0
+    prints the one JSON line on the inherited stdout.  A rank that dies takes the others down (they would wait in a collective
+    forever); the exit code is the first non-zero one."""
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    code, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and code == 0:
+                code = rc
+                print(f"[bench] rank {r} exited with code {rc}; stopping the other ranks", file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.2)
+    return code
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    # single-GPU runs with secondary workloads go through the guard; torchrun ranks and --no-extras runs (rocprofv3 wraps those) do not
-    if ws == 1 and not args.no_extras and os.environ.get("PLX_BENCH_GUARD", "1") != "0":
-        sys.exit(run_guarded(lambda emit: run(args, emit), float(os.environ.get("PLX_BENCH_DEADLINE_S", "420"))))
+    guard = os.environ.get("PLX_BENCH_GUARD", "1") != "0" and not args.no_extras
+    deadline = float(os.environ.get("PLX_BENCH_DEADLINE_S", "420"))
+    # runs with secondary workloads go through the guard (every rank of an N > 1 run: a rank whose line-printing peer was cut must not
+    # wait in a collective forever); --no-extras runs (rocprofv3 wraps those) do not
+    if guard:
+        sys.exit(run_guarded(lambda emit: run(args, emit), deadline, prints=rank == 0))
     final = {}
     run(args, lambda line, ready=True: final.update(line))
     if rank == 0:
@@ -1071,6 +1097,23 @@ class DryComm:
         box = [float(value)]
         dist.broadcast_object_list(box, src=0)
         return float(box[0])
+
+    def total(self, value):
+        import torch.distributed as dist
+        every = [None] * self.world_size
+        dist.all_gather_object(every, float(value))
+        return float(sum(every))
+
+    def allgather(self, df):
+        """concatenation of every rank's frame in rank order (pickled numpy over gloo: dry run only)"""
+        import numpy as np
+        import torch.distributed as dist
+        every = [None] * self.world_size
+        dist.all_gather_object(every, (df.cols, {n: df.validity(n) for n in df.valid}))
+        nullable = {n for _, v in every for n in v}
+        cols = {n: np.concatenate([c[n] for c, _ in every]) for n in df.cols}
+        valid = {n: np.concatenate([v[n] if n in v else np.ones(len(c[n]), bool) for c, v in every]) for n in nullable}
+        return DryFrame(cols, valid, df.schema)
 
     def exchange_by_key(self, df, key, seed=0):
         import numpy as np
@@ -1247,15 +1290,156 @@ def verify_sharded_groupby(res_cols, key_name, sum_name, second, total_rows, inp
     return out
 
 
-def run_sharded(args, emit):
-    """bench.py --gpus N --workload cfg3 | cfg5: the sharded operator, one rank per GPU."""
+class DryJoinOps:
+    """numpy stand-in for dist.LibJoinOps on TPC-H Q3's shape (dry run only): the two single-table predicates, the local
+    filter -> join -> group-by, the merge of partial groups."""
+
+    def __init__(self, date, seg_mod=5):
+        self.date, self.seg_mod = date, seg_mod
+
+    @staticmethod
+    def _take(df, m):
+        return DryFrame({c: v[m] for c, v in df.cols.items()}, None, df.schema)
+
+    def build_prefilter(self, df):
+        return self._take(df, (df.cols["o_orderdate"] < self.date) & (df.cols["o_custkey"] % self.seg_mod == 0))
+
+    def probe_prefilter(self, df):
+        return self._take(df, df.cols["l_shipdate"] > self.date)
+
+    def local(self, probe, build):
+        import numpy as np
+        b, p = self.build_prefilter(build), self.probe_prefilter(probe)
+        order = np.argsort(b.cols["o_orderkey"], kind="stable")
+        bk = b.cols["o_orderkey"][order]
+        pos = np.searchsorted(bk, p.cols["l_orderkey"])
+        hit = (pos < len(bk)) & (bk[np.minimum(pos, max(len(bk) - 1, 0))] == p.cols["l_orderkey"]) if len(bk) else np.zeros(p.height, bool)
+        slot = pos[hit]
+        rev = p.cols["l_extendedprice"][hit] * (1.0 - p.cols["l_discount"][hit])
+        sums = np.bincount(slot, weights=rev, minlength=len(bk))
+        has = np.bincount(slot, minlength=len(bk)) > 0
+        return DryFrame({"l_orderkey": bk[has], "o_orderdate": b.cols["o_orderdate"][order][has], "o_shippriority": b.cols["o_shippriority"][order][has], "revenue": sums[has]})
+
+    def merge(self, part, spec):
+        import numpy as np
+        uniq, first, inv = np.unique(part.cols[spec.result_key], return_index=True, return_inverse=True)
+        out = {c: v[first] for c, v in part.cols.items()}
+        for c, op in spec.merge:
+            assert op == "sum"
+            out[c] = np.bincount(inv, weights=part.cols[c], minlength=len(uniq))
+        return DryFrame(out)
+
+    def nbytes(self, df):
+        return int(sum(v.nbytes for v in df.cols.values()))
+
+
+class MultiCtx:
+    """What the N > 1 workloads share: the rank's device + library + RCCL communicator (plx_comm_*: the exchange runs inside the
+    library), or -- `--dry-run` -- numpy frames + gloo with the same methods.  torch.distributed is the bootstrap and carries the few
+    host-side numbers (timings, row totals, the gathered result for rank 0's check)."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from polars_amd import dist as pdist
+        self.rank, self.local_rank, self.ws = pdist.world()
+        self.dry, self.pl, self.torch, self.dist, self.pdist = args.dry_run, None, torch, dist, pdist
+        if self.dry:
+            pdist.init_process_group("gloo")
+            self._ensure_group("gloo")
+            self.comm = DryComm()
+        else:
+            dev = int(os.environ.get("PLX_BENCH_DEVICE", self.local_rank))
+            torch.cuda.set_device(dev)
+            import polars_amd as pl
+            pl.init(dev)
+            self.pl, self.F = pl, pl._ffi
+            pdist.init_process_group(os.environ.get("PLX_DIST_BACKEND", "nccl"))
+            self._ensure_group(os.environ.get("PLX_DIST_BACKEND", "nccl"))
+            self.comm = pdist.LibComm(pl)
+
+    def _ensure_group(self, backend):
+        # world size 1 (smoke run on a one-GPU box): the barriers / gathers below still want a group
+        if not self.dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+            self.dist.init_process_group(backend, rank=0, world_size=1)
+
+    def sync(self):
+        if not self.dry:
+            self.torch.cuda.synchronize(); self.F.check(self.F.lib().plx_synchronize())
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def gather(self, obj):
+        """every rank's host object, in rank order, on every rank"""
+        every = [None] * self.ws
+        self.dist.all_gather_object(every, obj)
+        return every
+
+    def profile_start(self):
+        if not self.dry:
+            self.F.check(self.F.lib().plx_profile_clear()); self.F.check(self.F.lib().plx_profile_enable(1))
+
+    def profile_stop(self):
+        if self.dry:
+            return {}
+        st = kernel_stats(self.pl)
+        self.F.check(self.F.lib().plx_profile_enable(0))
+        return st
+
+    def trim(self):
+        if not self.dry:
+            self.F.lib().plx_memory_trim(); self.torch.cuda.empty_cache()
+
+    def backend(self):
+        return "numpy + gloo DRY RUN (control flow only, nothing measured)" if self.dry else "libpolars_amd + RCCL (plx_exchange_by_key / plx_allgather_frame)"
+
+    def close(self):
+        self.barrier()
+        if hasattr(self.comm, "close"):
+            self.comm.close()
+        self.dist.destroy_process_group()
+
+
+def timed_multi(ctx, step, steps: int, warmup: int):
+    """`warmup` untimed steps, then exactly `steps` timed ones bracketed by barrier + device synchronisation on both sides; the time is the
+    MAX over the ranks.  -> (seconds, per-kernel stats of this rank, result of the last step, per-step ms of this rank)"""
+    import gc
+    res = None
+    for _ in range(max(warmup, 1)):
+        res = step()
+    ctx.profile_start()
+    ctx.barrier(); ctx.sync()
+    gc.collect(); gc.disable()          # see timed(): the harness must not collect inside the timed region
+    t0 = time.perf_counter()
+    marks = [t0]
+    for _ in range(steps):
+        res = step()
+        marks.append(time.perf_counter())
+    ctx.sync(); ctx.barrier()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    stats = ctx.profile_stop()
+    dt = max(ctx.gather(dt))
+    return dt, stats, res, [round((b - a) * 1e3, 3) for a, b in zip(marks, marks[1:])]
+
+
+METRIC = "rows/sec + achieved HBM GB/s, TPC-H Q1/Q3 SF100, 1/2/4/8 GPU vs CPU"
+
+
+def multi_line_base(ctx, args, steps, warmup, dt, total_rows, dtype, strong):
+    return {"metric": METRIC, "value": round(total_rows * steps / dt, 1), "unit": "rows/s", "n_gpus": ctx.ws, "steps": steps, "warmup": max(warmup, 1),
+            "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic"}
+
+
+def sharded_groupby_line(ctx, args, workload: str, steps: int, warmup: int) -> dict:
+    """cfg3 / cfg5 at N > 1 (dist.sharded_groupby), one rank per GPU: the local partitioned group-by, ONE exchange of the partial rows by
+    key hash inside the library, the merge on the owner of the key; rank 0 gathers the (small) sharded result and checks it."""
     import numpy as np
-    import torch
-    import torch.distributed as dist
-    from polars_amd import dist as pdist
-    rank, local_rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    dry = args.dry_run
-    cfg5 = args.workload == "cfg5"
+    pdist = ctx.pdist
+    rank, ws, dry = ctx.rank, ctx.ws, ctx.dry
+    cfg5 = workload == "cfg5"
     strong = args.scaling == "strong"
     n = args.rows or (1_000_000_000 // ws if strong else 1_000_000_000)      # strong: the 1e9-row configuration split over the ranks
     n_keys = 1_000_000
@@ -1266,96 +1450,274 @@ def run_sharded(args, emit):
     val_np, val_args = ("Float64", (0, 10 ** 9, 1e-7)) if cfg5 else ("Int64", (0, 1000))
     if dry:
         from polars_amd import datagen
-        pdist.init_process_group("gloo")
         k = datagen.uniform_native_host("UInt32" if cfg5 else "Int64", 0, n, seed, 0, 0, n_keys)
         v = datagen.uniform_native_host(val_np, 0, n, seed, 1, *val_args)
         df = DryFrame({key_name: k, val_name: v})
-        comm, ops = DryComm(), DryOps()
-        sync = lambda: None
-        stats_fn = lambda: {}
+        ops = DryOps()
         column_sum = lambda: float(v.sum()) if cfg5 else int(v.sum())
         result_cols = lambda r: dict(r.cols)
     else:
-        torch.cuda.set_device(local_rank)
-        import polars_amd as pl
-        pl.init(local_rank)
-        pdist.init_process_group("nccl")
-        if not dist.is_initialized():                            # world size 1 (smoke run): the barriers / reductions below still want a group
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
-            dist.init_process_group("nccl", rank=0, world_size=1)
-        wl0 = make_workload(pl, args.workload, n, seed=seed)      # this rank's shard, from the library's generator
+        pl = ctx.pl
+        wl0 = make_workload(pl, workload, n, seed=seed)      # this rank's shard, from the library's generator
         df = wl0.step()[1][0]
-        comm, ops = pdist.LibComm(pl), pdist.LibFrameOps(pl)
-        F = pl._ffi
-        sync = lambda: (torch.cuda.synchronize(), F.check(F.lib().plx_synchronize()))
-        stats_fn = lambda: kernel_stats(pl)
+        ops = pdist.LibFrameOps(pl)
         column_sum = lambda: df.lazy().select(pl.col(val_name).sum().alias("s")).collect()["s"].to_list()[0]
         result_cols = lambda r: {c: r[c].to_numpy() for c in r.columns}
-    res, info = None, {}
+    comm, info = ctx.comm, {}
     force = os.environ.get("PLX_BENCH_FORCE_SHARDED") == "1"
-    for _ in range(max(args.warmup, 1)):
-        res = pdist.sharded_groupby(comm, df, spec, ops, mode=args.mode, info=info, always_exchange=force)
-    if not dry:
-        F.check(F.lib().plx_profile_clear()); F.check(F.lib().plx_profile_enable(1))
+    step = lambda: pdist.sharded_groupby(comm, df, spec, ops, mode=args.mode, info=info, always_exchange=force)
+    step()                                                   # the first step also fills the per-column caches; the exchange accounting starts after it
     comm.rows_sent = comm.bytes_sent = 0
-    dist.barrier(); sync()
-    import gc
-    gc.collect(); gc.disable()          # see timed(): the harness must not collect inside the timed region
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = pdist.sharded_groupby(comm, df, spec, ops, mode=args.mode, info=info, always_exchange=force)
-    sync(); dist.barrier()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    stats = stats_fn()
-    # max over ranks of the timed region; totals of the exchange accounting and of the (sharded) result
-    t = torch.tensor([dt, float(comm.rows_sent), float(comm.bytes_sent), float(res.height), float(n), float(column_sum())], dtype=torch.float64)
-    if not dry:
-        t = t.cuda()
-    tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-    dt = float(tmax[0].item())
-    total_rows = int(tsum[4].item())
-    # rank 0 gathers the (small) sharded result and checks it
-    mine = result_cols(res)
-    every = [None] * ws
-    dist.all_gather_object(every, {c: np.asarray(a) for c, a in mine.items()})
+    dt, stats, res, step_ms = timed_multi(ctx, step, steps, max(warmup, 1))
+    sent_rows, sent_bytes = comm.rows_sent / (steps + max(warmup, 1)), comm.bytes_sent / (steps + max(warmup, 1))
+    every = ctx.gather({"sent_rows": sent_rows, "sent_bytes": sent_bytes, "groups": int(res.height), "rows": n, "sum": column_sum(), "cols": {c: np.asarray(a) for c, a in result_cols(res).items()}})
+    total_rows = sum(e["rows"] for e in every)
     verified = None
     if rank == 0:
-        allc = {c: np.concatenate([e[c] for e in every]) for c in mine}
-        isum = tsum[5].item()
+        allc = {c: np.concatenate([e["cols"][c] for e in every]) for c in every[0]["cols"]}
+        isum = sum(e["sum"] for e in every)
         verified = verify_sharded_groupby(allc, key_name, "v_sum", second, total_rows, isum if cfg5 else int(round(isum)), [(n, 10 + r) for r in range(ws)], n_keys,
                                           "UInt32" if cfg5 else "Int64", val_np, val_args, 0.0 if os.environ.get("PLX_BENCH_VERIFY", "1") == "0" else float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40")))
         if verified.get("ok") is False:
-            print(f"[bench] VERIFICATION FAILED for the sharded {args.workload}: {verified}", file=sys.stderr)
+            print(f"[bench] VERIFICATION FAILED for the sharded {workload}: {verified}", file=sys.stderr)
     rec_bytes = (4 + 8) if cfg5 else 16
     algo = n * rec_bytes + n_keys * 20 // ws
     how = {"preagg": "local partitioned group-by -> partial rows exchanged by key hash (one grouped all-to-all(v)) -> merge on the owner",
            "rows": "raw rows exchanged by key hash (one grouped all-to-all(v)) -> single-GPU partitioned group-by over the owned keys", "local": "single rank"}[info.get("mode", "local")]
-    line = {
-        "metric": "rows/sec + achieved HBM GB/s, TPC-H Q1/Q3 SF100, 1/2/4/8 GPU vs CPU",
-        "value": round(total_rows * args.steps / dt, 1), "unit": "rows/s", "n_gpus": ws, "steps": args.steps, "warmup": max(args.warmup, 1),
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": "f64" if cfg5 else "int64", "data": "synthetic",
+    line = multi_line_base(ctx, args, steps, warmup, dt, total_rows, "f64" if cfg5 else "int64", strong)
+    line.update({
         "config": {"workload": ("cfg5_dict_string_keys" if cfg5 else "cfg3_groupby_1e6_keys") + f"_sharded_x{ws}", "rows_per_gpu": n, "algorithmic_bytes_per_gpu_step": algo,
                    "description": f"{n} rows per rank, 1e6 keys over all ranks, group_by(key).agg(...): {how}; result sharded by key",
-                   "parallelism": f"row-sharded x{ws}; {how}",
-                   "backend": "numpy + gloo DRY RUN (control flow only, nothing measured)" if dry else "libpolars_amd + RCCL (plx_exchange_by_key)"},
+                   "parallelism": f"row-sharded x{ws}; {how}", "backend": ctx.backend()},
         "exchange_mode": info.get("mode"), "shrink_estimate": info.get("shrink_estimate"), "partial_rows_per_rank": info.get("partial_rows"),
-        "shuffle": {"rows_sent_per_rank_per_step": round(float(tsum[1].item()) / ws / args.steps, 1), "bytes_sent_per_rank_per_step": round(float(tsum[2].item()) / ws / args.steps, 1),
-                    "fabric_GBps_per_rank": round(float(tsum[2].item()) / ws / dt / 1e9, 2)},
-        "groups_total": int(tsum[3].item()),
-        "whole_query_GBps_per_gpu": round(algo * args.steps / dt / 1e9, 1),
+        "shuffle": {"rows_sent_per_rank_per_step": round(sum(e["sent_rows"] for e in every) / ws, 1), "bytes_sent_per_rank_per_step": round(sum(e["sent_bytes"] for e in every) / ws, 1),
+                    "fabric_GBps_per_rank": round(sum(e["sent_bytes"] for e in every) / ws * steps / dt / 1e9, 2)},
+        "groups_total": sum(e["groups"] for e in every),
+        "whole_query_GBps_per_gpu": round(algo * steps / dt / 1e9, 1), "step_ms": step_ms,
         "verified": verified,
         "kernels": _kernels(stats, 8) if stats else {},
-    }
+    })
     if dry:
         line["dry_run"] = True
-    if rank == 0:
+    return line
+
+
+def sharded_q3_line(ctx, args, steps: int, warmup: int) -> dict:
+    """TPC-H Q3 at N > 1 (BASELINE config 4: lineitem JOIN orders, key-hash sharded, RCCL all-to-all): dist.sharded_join_groupby over the
+    library's communicator.  Every rank generates its own orders and their lines (dbgen row order) and shifts the order keys into its own
+    key range, so the global tables are the union of the shards.  --scaling strong (what config 4 is quoted on): SF100 in TOTAL, 1/N per
+    rank; weak: SF100 per rank.  PLX_Q3_MODE = auto | broadcast | shuffle (default shuffle: the exchange config 4 names).  Rank 0 gathers
+    the sharded result and checks every rank's key range against the numpy restatement over that rank's host twin (+ the oracle's Q3 on
+    a prefix), within the verification budget."""
+    import numpy as np
+    from polars_amd import datagen, queries
+    pdist = ctx.pdist
+    rank, ws, dry = ctx.rank, ctx.ws, ctx.dry
+    strong = args.scaling == "strong"
+    no = (args.rows // 4) if args.rows else (SF100_ORDERS // ws if strong else SF100_ORDERS)
+    seed = 10 + rank
+    key_span = 4 * no + 64                                     # the generator uses 8 of every 32 key values: o_orderkey < 4 * n_orders
+    off = rank * key_span
+    date = datagen.us(1995, 3, 15)
+    if dry:
+        o, li, _cnt = datagen.orders_lineitem_native_host_mt(0, no, no, seed, threads=2)
+        o["o_shippriority"] = np.zeros(no, np.int64)
+        o["o_orderkey"] = o["o_orderkey"] + off; li["l_orderkey"] = li["l_orderkey"] + off
+        O, L = DryFrame({c: o[c] for c in datagen.ORDERS_Q3_COLS}), DryFrame({c: li[c] for c in datagen.LINEITEM_Q3_COLS})
+        ops, spec = DryJoinOps(date), pdist.JoinGroupBySpec("l_orderkey", "o_orderkey", "l_orderkey", [("revenue", "sum")])
+        result_cols = lambda r: dict(r.cols)
+    else:
+        pl = ctx.pl
+        O, L = datagen.orders_lineitem_native(pl, no, seed)
+        check_native_q3(pl, O, L, no, seed)
+        if off:
+            O = O.with_columns((pl.col("o_orderkey") + off).alias("o_orderkey"))
+            L = L.with_columns((pl.col("l_orderkey") + off).alias("l_orderkey"))
+        ops, spec = pdist.q3_ops(pl)
+        result_cols = lambda r: {c: r[c].to_numpy() for c in r.columns}
+    nl = int(L.height)
+    comm, info = ctx.comm, {}
+    force = os.environ.get("PLX_BENCH_FORCE_SHARDED") == "1"
+    mode = os.environ.get("PLX_Q3_MODE", "shuffle")
+    step = lambda: pdist.sharded_join_groupby(comm, ops, L, O, spec, mode=mode, info=info, always_exchange=force)
+    step()
+    comm.rows_sent = comm.bytes_sent = 0
+    dt, stats, res, step_ms = timed_multi(ctx, step, steps, max(warmup, 1))
+    sent_rows, sent_bytes = comm.rows_sent / (steps + max(warmup, 1)), comm.bytes_sent / (steps + max(warmup, 1))
+    every = ctx.gather({"sent_rows": sent_rows, "sent_bytes": sent_bytes, "groups": int(res.height), "rows": nl + no, "cols": {c: np.asarray(a) for c, a in result_cols(res).items()}})
+    total_rows = sum(e["rows"] for e in every)
+    verified = None
+    if rank == 0 and os.environ.get("PLX_BENCH_VERIFY", "1") != "0":
+        allc = {c: np.concatenate([e["cols"][c] for e in every]) for c in every[0]["cols"]}
+        k = allc["l_orderkey"].astype(np.int64)
+        budget = float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40"))
+        per, ok = [], bool(len(np.unique(k)) == len(k))               # the ranks' key sets are disjoint: no key twice in the gathered result
+
+        class Host:
+            def __init__(self, a): self.a = a
+            def to_numpy(self): return self.a
+        for r in range(ws):
+            m = (k >= r * key_span) & (k < (r + 1) * key_span)
+            frame = {"l_orderkey": Host(k[m] - r * key_span), "o_orderdate": Host(allc["o_orderdate"][m]), "o_shippriority": Host(allc["o_shippriority"][m]), "revenue": Host(allc["revenue"][m])}
+            v = verify_q3(frame, no, 10 + r, budget / ws, oracle_orders=min(no, 4_000_000 // ws))
+            per.append({"rank_keys": r, "ok": v["ok"], "orders": v["orders"], "covers_whole_input": v["covers_whole_input"], "groups_checked": v["groups_checked"], "max_rel_err": v["max_rel_err"]})
+            ok = ok and bool(v["ok"])
+        verified = {"ok": ok, "rows": int(sum(p["orders"] for p in per)), "keys_disjoint_across_ranks": bool(len(np.unique(k)) == len(k)), "groups_total": int(len(k)),
+                    "against": "per key range of every rank: oracle Q3 on a prefix + numpy restatement over the blocks of that rank's host twin the budget allows", "per_rank": per, "rtol": VERIFY_RTOL}
+        if not ok:
+            print(f"[bench] VERIFICATION FAILED for the sharded q3: {verified}", file=sys.stderr)
+    algo = nl * datagen.Q3_LINEITEM_BYTES_PER_ROW + no * datagen.Q3_ORDERS_BYTES_PER_ROW
+    how = {"shuffle": "both sides filtered, then routed by key hash (one grouped all-to-all(v) per input), local fused join -> group-by over the owned keys",
+           "broadcast": "filtered build side all-gathered, probe side stays, partial groups routed by key (one small all-to-all(v)) and merged by the owner", "local": "single rank"}[info.get("mode", "local")]
+    line = multi_line_base(ctx, args, steps, warmup, dt, total_rows, "f64", strong)
+    line.update({
+        "config": {"workload": f"tpch_q3_sf100_sharded_x{ws}", "rows_per_gpu": nl + no, "orders_per_gpu": no, "lineitem_rows_per_gpu": nl, "algorithmic_bytes_per_gpu_step": algo,
+                   "description": f"TPC-H Q3 (orders {no} x lineitem {nl} per rank), filter both -> hash join -> group_by(orderkey, orderdate, shippriority): {how}; result sharded by key",
+                   "parallelism": f"row-sharded x{ws}; {how}", "backend": ctx.backend()},
+        "exchange_mode": info.get("mode"), "build_rows_after_filter_per_rank": info.get("build_rows"), "probe_rows_after_filter_per_rank": info.get("probe_rows"),
+        "partial_rows_per_rank": info.get("partial_rows"),
+        "shuffle": {"rows_sent_per_rank_per_step": round(sum(e["sent_rows"] for e in every) / ws, 1), "bytes_sent_per_rank_per_step": round(sum(e["sent_bytes"] for e in every) / ws, 1),
+                    "fabric_GBps_per_rank": round(sum(e["sent_bytes"] for e in every) / ws * steps / dt / 1e9, 2)},
+        "groups_total": sum(e["groups"] for e in every),
+        "whole_query_GBps_per_gpu": round(algo * steps / dt / 1e9, 1), "step_ms": step_ms,
+        "verified": verified,
+        "kernels": _kernels(stats, 8) if stats else {},
+    })
+    if dry:
+        line["dry_run"] = True
+    return line
+
+
+def dry_q1_step(n: int, seed: int):
+    """numpy stand-in for the per-rank Q1 (dry run only): the result in the layout of DataFrame.to_dict()."""
+    import numpy as np
+    from polars_amd import datagen
+    li = datagen.lineitem_native_host_mt(0, n, seed, threads=2)
+    cutoff = datagen.us(1998, 9, 2)
+
+    def step():
+        m = li["l_shipdate"] <= cutoff
+        g = (li["l_returnflag"][m].astype(np.int64) * 2 + li["l_linestatus"][m].astype(np.int64))
+        cnt = np.bincount(g, minlength=6)
+        qty, price, disc, tax = (li[c][m] for c in ("l_quantity", "l_extendedprice", "l_discount", "l_tax"))
+        s = lambda w: np.bincount(g, weights=w, minlength=6)
+        dp = price * (1 - disc)
+        out = {f: [] for f in Q1_FIELDS}
+        for i in np.nonzero(cnt)[0]:
+            c = int(cnt[i])
+            out["l_returnflag"].append(int(i) // 2); out["l_linestatus"].append(int(i) % 2)
+            out["sum_qty"].append(int(qty[g == i].sum())); out["count_order"].append(c)
+            out["sum_base_price"].append(float(s(price)[i])); out["sum_disc_price"].append(float(s(dp)[i])); out["sum_charge"].append(float(s(dp * (1 + tax))[i]))
+            out["avg_qty"].append(float(s(qty.astype(np.float64))[i]) / c); out["avg_price"].append(float(s(price)[i]) / c); out["avg_disc"].append(float(s(disc)[i]) / c)
+        return out
+    return step
+
+
+def rowsharded_line(ctx, args, workload: str, steps: int, warmup: int) -> dict:
+    """q1 / cfg2 / q3f at N > 1: independent row shards (SURVEY.md 8(e) "scan / filter / arith / whole-column agg: contiguous row-range
+    split"); Q1's six-group partial results are combined with an all-gather of 1.25 KB per rank, no row crosses xGMI; cfg2 / q3f run as
+    replicas over their own shards.  Rank 0 checks ITS shard's result against the oracle over the shard's host twin (Q1: and that the
+    combined result equals the merge of the gathered per-rank results)."""
+    rank, ws, dry = ctx.rank, ctx.ws, ctx.dry
+    strong = args.scaling == "strong"
+    seed = 10 + rank
+    rows = args.rows
+    if strong and not rows:
+        rows = {"q1": SF100_LINEITEM, "q3f": 4 * SF100_ORDERS, "cfg2": 10 ** 9}.get(workload, 0) // ws
+    if dry:
+        if workload != "q1":
+            raise ValueError("--dry-run knows q1, q3, cfg3 and cfg5")
+        n = rows or 200_000
+        one = dry_q1_step(n, seed)
+        wl = Workload("tpch_q1_sf100", n, n * 42, None, "", f"TPC-H Q1, lineitem {n} rows per rank (numpy stand-in)")
+    else:
+        wl = make_workload(ctx.pl, workload, rows, seed=seed, ws=ws)
+        one = lambda: wl.step()[0]
+    local = {}
+
+    def step():
+        r = one()
+        local["res"] = r
+        return combine_q1_results(allgather_q1(r, ws)) if workload == "q1" else r
+    dt, stats, res, step_ms = timed_multi(ctx, step, steps, max(warmup, 1))
+    verified = None
+    if workload == "q1":
+        parts = ctx.gather(local["res"])
+        if rank == 0 and os.environ.get("PLX_BENCH_VERIFY", "1") != "0":
+            merged_ok = compare_q1_dicts(res, combine_q1_results(parts))
+            budget = float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40"))
+            want, done, _t, _f = q1_oracle_blocks(wl.rows, seed, budget, block=min(wl.rows, 100_000_000))
+            mine = compare_q1(local["res"], want) if done == wl.rows else {"ok": None, "note": "host check ran out of its time budget"}
+            verified = {"ok": bool(merged_ok and mine.get("ok") is not False) if mine.get("ok") is not None else (None if merged_ok else False), "rows": int(done),
+                        "combined_equals_merge_of_rank_results": bool(merged_ok), "rank0_shard_vs_oracle": mine,
+                        "against": "rank 0's shard: oracle (orc_q1_streaming over the shard's host twin); combined result: merge of the gathered per-rank results"}
+    elif rank == 0 and not dry and os.environ.get("PLX_BENCH_VERIFY", "1") != "0":
+        verified = _verify(wl, local["res"], float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40")))
+    line = multi_line_base(ctx, args, steps, warmup, dt, wl.rows * ws, "f64", strong)
+    line.update({
+        "config": {"workload": wl.name + f"_x{ws}", "description": wl.desc, "rows_per_gpu": wl.rows, "algorithmic_bytes_per_gpu_step": wl.algo_bytes,
+                   "parallelism": (f"row-sharded x{ws}, all-gather of group partials" if workload == "q1" else f"row-sharded x{ws}, independent replicas (no data-path collective)"),
+                   "backend": ctx.backend()},
+        "whole_query_GBps_per_gpu": round(wl.algo_bytes * steps / dt / 1e9, 1), "step_ms": step_ms, **step_spread(step_ms, wl.rows * ws),
+        "roofline": roofline(stats, wl, steps) if stats else None, "verified": verified,
+        "kernels": _kernels(stats, 8) if stats else {},
+    })
+    if dry:
+        line["dry_run"] = True
+    return line
+
+
+def compare_q1_dicts(a: dict, b: dict) -> bool:
+    """two Q1 results in to_dict() layout: same groups, integer columns equal, floats within 1e-9"""
+    import numpy as np
+    if sorted(zip(a["l_returnflag"], a["l_linestatus"])) != sorted(zip(b["l_returnflag"], b["l_linestatus"])):
+        return False
+    oa = sorted(range(len(a["count_order"])), key=lambda i: (a["l_returnflag"][i], a["l_linestatus"][i]))
+    ob = sorted(range(len(b["count_order"])), key=lambda i: (b["l_returnflag"][i], b["l_linestatus"][i]))
+    for f in Q1_FIELDS[2:]:
+        x, y = np.array([a[f][i] for i in oa], np.float64), np.array([b[f][i] for i in ob], np.float64)
+        if not np.allclose(x, y, rtol=1e-9, atol=0):
+            return False
+    return True
+
+
+MULTI_EXTRAS = ("q3", "cfg3", "cfg5", "q1")
+
+
+def run_multi(args, emit):
+    """bench.py at N > 1 (one process per GPU; also `--dry-run` and the world-size-1 smoke run PLX_BENCH_FORCE_SHARDED=1): the headline
+    workload, then -- unless --no-extras -- the other sharded workloads as `extras`, every rank taking part in each."""
+    ctx = MultiCtx(args)
+
+    def one(workload, steps, warmup):
+        if workload in ("cfg3", "cfg5"):
+            return sharded_groupby_line(ctx, args, workload, steps, warmup)
+        if workload == "q3":
+            return sharded_q3_line(ctx, args, steps, warmup)
+        return rowsharded_line(ctx, args, workload, steps, warmup)
+    line = one(args.workload, args.steps, args.warmup)
+    if ctx.rank == 0:
         emit(line)
-    dist.barrier()
-    dist.destroy_process_group()
-    return res
+    if not args.no_extras:
+        extras = {}
+        line["extras"] = extras
+        k2 = max(3, args.steps // 4)
+        scaling = args.scaling
+        for w in [w for w in MULTI_EXTRAS if w != args.workload]:
+            ctx.trim()
+            args.scaling = "strong" if w == "q3" else scaling    # BASELINE config 4 is SF100 in TOTAL over the ranks: the Q3 extra always runs it that way
+            try:
+                ex = one(w, k2, 2)
+                name = ex["config"]["workload"]
+                ex = {k: ex[k] for k in ("value", "unit", "ms_per_step", "scaling", "config", "exchange_mode", "shuffle", "groups_total", "whole_query_GBps_per_gpu", "step_ms",
+                                         "roofline", "verified", "kernels", "partial_rows_per_rank", "build_rows_after_filter_per_rank", "probe_rows_after_filter_per_rank") if k in ex}
+            except Exception as e:  # a secondary workload must never take the headline line down (the other ranks raise alike or the guard cuts the run)
+                name, ex = w, {"error": f"{type(e).__name__}: {e}"[:300]}
+            extras[name] = ex
+            if ctx.rank == 0:
+                emit(line)
+        args.scaling = scaling
+    ctx.close()
 
 
 def _kernels(stats, top: int):
@@ -1379,33 +1741,19 @@ def run(args, emit):
     """The benchmark proper; emit(line) is called with every improved version of the JSON line (rank 0)."""
     import torch
     rank, local_rank, ws = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = ws > 1
-    if (distributed or args.dry_run or os.environ.get("PLX_BENCH_FORCE_SHARDED") == "1") and args.workload in ("cfg3", "cfg5"):
-        run_sharded(args, emit)      # PLX_BENCH_FORCE_SHARDED=1: the sharded operator at world size 1 (a self-exchange through RCCL: smoke run on a one-GPU box)
+    if ws > 1 or args.dry_run or os.environ.get("PLX_BENCH_FORCE_SHARDED") == "1":
+        # N > 1, `--dry-run`, or the sharded operators at world size 1 (PLX_BENCH_FORCE_SHARDED=1: a self-exchange through RCCL, the smoke run a one-GPU box allows)
+        run_multi(args, emit)
         return
-    # PLX_BENCH_DEVICE / PLX_DIST_BACKEND: smoke runs of the N > 1 control flow on a ONE-GPU box (every rank on device 0, torch.distributed over gloo);
-    # never set by the driver: one rank per GPU over RCCL is the measured configuration
+    distributed = False
     dev = int(os.environ.get("PLX_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(dev)
     import polars_amd as pl
-    from polars_amd import dist as pdist
     pl.init(dev)
-    if distributed:
-        pdist.init_process_group(os.environ.get("PLX_DIST_BACKEND", "nccl"))
     seed = 10 + rank
     rows = args.rows
-    if distributed and args.scaling == "strong" and not rows:
-        # strong scaling (BASELINE config 4: SF100 in TOTAL over the ranks): every rank generates 1/ws of the single-GPU configuration
-        rows = {"q1": SF100_LINEITEM, "q3": 4 * SF100_ORDERS, "q3f": 4 * SF100_ORDERS, "cfg2": 10 ** 9}.get(args.workload, 0) // ws
     wl = make_workload(pl, args.workload, rows, seed=seed, ws=ws)
-
-    combine = None
-    if distributed and args.workload == "q1":
-        # per-rank result -> all-gather of the (tiny) per-group partial states -> combine (SURVEY.md 8(e))
-        def combine(res):
-            return combine_q1_results(allgather_q1(res, ws))
-
-    dt, stats, res, cold_ms = timed(pl, wl, args.steps, max(args.warmup, 1), distributed, combine)
+    dt, stats, res, cold_ms = timed(pl, wl, args.steps, max(args.warmup, 1), distributed)
     total_rows = wl.rows * ws * args.steps
     line = {
         "metric": "rows/sec + achieved HBM GB/s, TPC-H Q1/Q3 SF100, 1/2/4/8 GPU vs CPU",
@@ -1413,9 +1761,7 @@ def run(args, emit):
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if (distributed and args.scaling == "strong") else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": wl.name, "description": wl.desc, "rows_per_gpu": wl.rows, "algorithmic_bytes_per_gpu_step": wl.algo_bytes,
-                   "parallelism": ("single GPU" if ws == 1 else f"row-sharded x{ws}, all-gather of group partials" if args.workload == "q1" else
-                                   f"row-sharded x{ws}, filtered build side all-gathered, partial groups merged by key (all-to-all)" if args.workload == "q3" else
-                                   f"row-sharded x{ws}, rows exchanged by key hash (all-to-all), per-rank group-by over disjoint key sets")},
+                   "parallelism": "single GPU"},
         "whole_query_GBps_per_gpu": round(wl.algo_bytes * args.steps / dt / 1e9, 1),
         "cold_first_step_ms": None if cold_ms is None else round(cold_ms, 2),
         "step_ms": getattr(timed, "last_step_ms", None),      # every timed step, in order: a stall of the box shows here, not only in the mean
@@ -1527,10 +1873,6 @@ def run(args, emit):
             emit(line)
     if rank == 0:
         emit(line)
-    if distributed:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

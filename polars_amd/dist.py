@@ -15,9 +15,11 @@ two ideas with GPUs as the partitions:
   operator input (`exchange_by_key`), after which every rank owns a disjoint key set and runs
   the single-GPU operator unchanged; results stay sharded (concatenation of disjoint parts).
 
-Everything here moves `torch.Tensor`s; the per-rank compute is delegated to a `LocalOps`
-object.  The product `HipLocalOps` calls libpolars_amd through the C ABI on device memory; the
-CPU tests inject an oracle-backed LocalOps to exercise the exchange logic under gloo.
+Everything here moves FRAMES (device DataFrames of libpolars_amd): the exchange runs inside the
+library on RCCL (`LibComm`: plx_exchange_by_key / plx_allgather_frame), the per-rank compute is the
+single-GPU operator behind a small ops object (`LibFrameOps`, `LibJoinOps`).  torch.distributed is
+only the bootstrap (rank 0's RCCL id, a few host-side agreements).  The CPU tests and
+`bench.py --dry-run` inject numpy frames + a gloo communicator with the same methods.
 """
 from __future__ import annotations
 
@@ -106,78 +108,6 @@ def unify_dictionaries(df, group=None, remap=None):
     return type(df)(cols)
 
 
-def torch_sync():
-    """Work queued on torch's current stream must be visible to the library's stream before it reads the tensors."""
-    import torch
-    torch.cuda.current_stream().synchronize()
-
-
-class LocalOps:
-    """Per-rank compute used by the exchange layer (tensors in, tensors out)."""
-
-    def hash_partition(self, key, n_parts: int, seed: int = 0):
-        """-> (perm int64 tensor grouping rows by partition, counts list[int])"""
-        raise NotImplementedError
-
-    def take(self, col, perm):
-        return col[perm]
-
-    def groupby_partial(self, keys: Dict[str, object], values: Dict[str, object], aggs: Sequence[Tuple[str, str, str]]):
-        """aggs = [(out_name, value column, partial op)] -> dict of tensors, one row per local group (keys + outs)."""
-        raise NotImplementedError
-
-    def mean_from_partials(self, total, count):
-        """f64 sum / count of the mean decomposition (reduce/mean.rs:82-132)."""
-        import torch
-        return total.to(torch.float64) / count.to(torch.float64)
-
-
-class HipLocalOps(LocalOps):
-    """LocalOps on libpolars_amd (device tensors are wrapped zero-copy, results copied D2D)."""
-
-    def __init__(self, pl):
-        self.pl = pl
-
-    def _series(self, name, t):
-        return self.pl.Series.from_torch(name, t)
-
-    def hash_partition(self, key, n_parts: int, seed: int = 0):
-        import ctypes as C
-
-        import torch
-        F = self.pl._ffi
-        torch.cuda.current_stream().synchronize()
-        s = self._series("k", key)
-        h = C.c_uint64()
-        counts = (C.c_int64 * n_parts)()
-        F.check(F.lib().plx_hash_partition(s._h, n_parts, seed, C.byref(h), counts))
-        perm = self.pl.Series._from_handle("perm", h.value, self.pl.UInt32)
-        return perm.cast(self.pl.Int64).to_torch(), list(counts)     # widened by the library's cast kernel (index tensors are int64 in torch)
-
-    def mean_from_partials(self, total, count):
-        pl = self.pl
-        torch_sync()
-        return (self._series("s", total).cast(pl.Float64) / self._series("c", count).cast(pl.Float64)).to_torch()
-
-    def groupby_partial(self, keys, values, aggs):
-        import torch
-        pl = self.pl
-        torch.cuda.current_stream().synchronize()
-        cols = [self._series(n, t) for n, t in keys.items()] + [self._series(n, t) for n, t in values.items()]
-        exprs = []
-        for out, col, op in aggs:
-            e = pl.col(col) if col else None
-            if op == "sum_f64":
-                e = e.cast(pl.Float64).sum()
-            elif op == "len":
-                e = pl.len()
-            else:
-                e = getattr(e, op)()
-            exprs.append(e.alias(out))
-        df = pl.DataFrame(cols).lazy().group_by(*keys.keys()).agg(*exprs).collect()
-        return {c: df[c].to_torch() for c in df.columns}
-
-
 class LibComm:
     """RCCL communicator owned by libpolars_amd (include/polars_amd.h plx_comm_*): the exchange runs inside the library --
     hash partition, gather and ONE grouped ncclSend / ncclRecv all-to-all(v) on the library's stream, no torch kernels.
@@ -227,6 +157,15 @@ class LibComm:
         box = [float(value)]
         dist.broadcast_object_list(box, src=0, group=self._group)
         return float(box[0])
+
+    def total(self, value: float) -> float:
+        """Sum of one host number per rank, on every rank (sizes that decide a plan every rank must take alike)."""
+        if self.world_size == 1:
+            return float(value)
+        import torch.distributed as dist
+        every = [None] * self.world_size
+        dist.all_gather_object(every, float(value), group=self._group)
+        return float(sum(every))
 
     def allgather(self, df):
         """Concatenation of every rank's frame (rank order) on every rank."""
@@ -330,7 +269,6 @@ def estimate_shrink(rows: int, sample_rows: int, sample_distinct: int) -> float:
     return rows / max(1.0, g * -math.expm1(-rows / g))
 
 
-P2P_CHUNK_BYTES = 1 << 29        # largest per-peer segment of one all-to-all round on the torch path (exchange_by_key); the library path: comm.cpp kP2PChunk
 PREAGG_MIN_SHRINK = 8.0          # pre-aggregate before the exchange when the local group-by shrinks the shard at least this much
 PREAGG_SAMPLE_ROWS = 1 << 20
 
@@ -375,208 +313,92 @@ def sharded_groupby(comm, df, spec, ops=None, *, mode: str = "auto", always_exch
     return ops.merge(owned, spec, getattr(df, "schema", None))
 
 
-def allgather_concat(t, group=None):
-    """Variable-length all-gather of a 1-D tensor (sizes first, then padded payload)."""
-    import torch
-    import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return t
-    ws = dist.get_world_size(group)
-    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
-    sizes = [torch.zeros_like(n) for _ in range(ws)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    m = max(sizes + [1])
-    pad = torch.zeros(m, dtype=t.dtype, device=t.device)
-    pad[: t.numel()] = t
-    outs = [torch.zeros_like(pad) for _ in range(ws)]
-    dist.all_gather(outs, pad, group=group)
-    return torch.cat([o[:s] for o, s in zip(outs, sizes)])
+class JoinGroupBySpec:
+    """`probe JOIN build ON probe_key == build_key -> GROUP BY (result_key, attributes) -> aggregates` (TPC-H Q3's shape) in the form the
+    sharded operator needs: `merge` = [(aggregate column of the local result, "sum" | "min" | "max")], every other column of the local
+    result is a group attribute (result_key first; the attributes are functionally determined by it)."""
+
+    def __init__(self, probe_key: str, build_key: str, result_key: str, merge: Sequence[Tuple[str, str]]):
+        self.probe_key, self.build_key, self.result_key, self.merge = probe_key, build_key, result_key, list(merge)
+        for _, op in self.merge:
+            if op not in ("sum", "min", "max"):
+                raise ValueError(f"partial aggregate {op!r} cannot be merged across ranks")
 
 
-def exchange_by_key(ops: LocalOps, key, cols: Dict[str, object], seed: int = 0, group=None) -> Dict[str, object]:
-    """Route every row to rank hash_partition(key) with one all-to-all per column.
-    Nulls (none on this path yet) would go to partition 0 like the reference's null_partition()."""
-    import torch
-    import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return dict(cols)
-    ws = dist.get_world_size(group)
-    perm, counts = ops.hash_partition(key, ws, seed)
-    send = torch.tensor(counts, dtype=torch.int64, device=key.device)
-    recv = torch.zeros_like(send)
-    dist.all_to_all_single(recv, send, group=group)
-    recv_counts = [int(x) for x in recv.tolist()]
-    # RCCL 2.26 delivers only the first half of a point-to-point transfer above 2^30 bytes (measured on MI355X, see comm.cpp kP2PChunk): a column whose
-    # per-peer segment is larger than P2P_CHUNK_BYTES goes in several rounds of row slabs; the round count is agreed across ranks
-    biggest = torch.tensor([max(counts + recv_counts + [0])], dtype=torch.int64, device=key.device)
-    dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
-    biggest = int(biggest.item())
-    send_off = [0] + list(np.cumsum(counts)); recv_off = [0] + list(np.cumsum(recv_counts))
-    out = {}
-    for name, t in cols.items():
-        src = ops.take(t, perm).contiguous()
-        dst = torch.empty(sum(recv_counts), dtype=t.dtype, device=t.device)
-        lim = max(1, P2P_CHUNK_BYTES // max(1, t.element_size()))
-        rounds = max(1, -(-biggest // lim))
-        if rounds == 1:
-            dist.all_to_all_single(dst, src, output_split_sizes=recv_counts, input_split_sizes=counts, group=group)
-        else:
-            for r in range(rounds):
-                ins = [min(max(c - r * lim, 0), lim) for c in counts]
-                outs = [min(max(c - r * lim, 0), lim) for c in recv_counts]
-                src_r = torch.cat([src[int(send_off[p]) + r * lim: int(send_off[p]) + r * lim + ins[p]] for p in range(ws)]) if sum(ins) else src[:0]
-                dst_r = torch.empty(sum(outs), dtype=t.dtype, device=t.device)
-                dist.all_to_all_single(dst_r, src_r.contiguous(), output_split_sizes=outs, input_split_sizes=ins, group=group)
-                at = 0
-                for p in range(ws):
-                    if outs[p]:
-                        dst[int(recv_off[p]) + r * lim: int(recv_off[p]) + r * lim + outs[p]] = dst_r[at: at + outs[p]]
-                    at += outs[p]
-        out[name] = dst
-    return out
+class LibJoinOps:
+    """The per-rank queries of a sharded join -> group-by as libpolars_amd plans over device frames.  `local(probe, build)` is the
+    single-GPU fused filter -> join -> group-by (a LazyFrame builder such as queries.q3); `build_filter` / `probe_filter` are the
+    single-input predicates pushed below the exchange (the reference pushes them below the join the same way,
+    polars-plan predicate_pushdown), so only surviving rows cross xGMI.  bench.py --dry-run and the gloo tests inject a numpy double
+    with the same methods."""
+
+    def __init__(self, pl, local, build_filter=None, probe_filter=None):
+        self.pl, self._local, self._bf, self._pf = pl, local, build_filter, probe_filter
+
+    def build_prefilter(self, df):
+        return df if self._bf is None else df.lazy().filter(self._bf).collect()
+
+    def probe_prefilter(self, df):
+        return df if self._pf is None else df.lazy().filter(self._pf).collect()
+
+    def local(self, probe, build):
+        return self._local(probe.lazy(), build.lazy()).collect()
+
+    def merge(self, part, spec: JoinGroupBySpec):
+        """partial groups of the keys this rank owns -> one row per key (group_by(key, attributes).agg(merge ops))"""
+        pl = self.pl
+        ops = dict(spec.merge)
+        keys = [c for c in part.columns if c not in ops]
+        return part.lazy().group_by(*keys).agg(*[getattr(pl.col(c), op)().alias(c) for c, op in spec.merge]).collect()
+
+    def nbytes(self, df) -> int:
+        return int(sum(df.height * (t.np_dtype.itemsize if getattr(t, "np_dtype", None) is not None else 1) for t in df.schema.values()))
 
 
-def _combine(op: str, t, inverse, n_groups: int):
-    import torch
-    if t.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8):
-        t = t.to(torch.int64)   # counts / narrow partials combine in 64 bit
-    if op == "sum":
-        return torch.zeros(n_groups, dtype=t.dtype, device=t.device).index_add_(0, inverse, t)
-    red = "amin" if op == "min" else "amax"
-    init = torch.full((n_groups,), float("inf") if op == "min" else float("-inf"), dtype=torch.float64, device=t.device) if t.dtype.is_floating_point else \
-        torch.full((n_groups,), torch.iinfo(t.dtype).max if op == "min" else torch.iinfo(t.dtype).min, dtype=t.dtype, device=t.device)
-    return init.to(t.dtype).scatter_reduce_(0, inverse, t, reduce=red)
+BROADCAST_BUILD_BYTES = 2 << 30       # "auto": all-gather the filtered build side when it is at most this large over ALL ranks
 
 
-def groupby_agg(ops: LocalOps, keys: Dict[str, object], values: Dict[str, object], aggs: Sequence[Tuple[str, str, str]], *, mode: str = "auto",
-                group=None) -> Dict[str, object]:
-    """Sharded group_by(keys).agg(...): aggs = [(out_name, value column, op)], op in PARTIALS.
+def sharded_join_groupby(comm, ops, probe, build, spec: JoinGroupBySpec, *, mode: str = "auto", always_exchange: bool = False, info: Optional[dict] = None):
+    """Sharded `probe JOIN build -> GROUP BY -> aggregates` over row shards of both inputs (BASELINE config 4: SF100 lineitem JOIN orders
+    over 8 GPUs); the partitioned build / probe of crates/polars-stream/src/nodes/joins/equi_join.rs:446-760 with GPUs as the
+    partitions (HashPartitioner, null keys -> partition 0: crates/polars-utils/src/hashing.rs:72-121).  Frames in, frame out; every
+    exchange is the library's (comm.exchange_by_key / comm.allgather: one grouped RCCL all-to-all(v) / all-gather(v) per call).
 
-    mode "gather" : local aggregate -> all-gather partials -> every rank combines (replicated, tiny result)
-    mode "shuffle": all-to-all rows by key hash -> local aggregate -> result stays sharded by key
-    mode "auto"   : "gather" unless the local aggregate shrinks the data by less than 8x.
-    Result columns: keys + out_names.  mean is null-free here (count == 0 groups cannot exist without nulls).
-    """
-    import torch
-    import torch.distributed as dist
-    distributed = dist.is_initialized() and dist.get_world_size(group) > 1
-    partial_aggs: List[Tuple[str, str, str]] = []
-    for out, col, op in aggs:
-        for i, (pop, _) in enumerate(PARTIALS[op]):
-            partial_aggs.append((f"{out}__p{i}", col, pop))
-    if mode == "shuffle" and distributed:
-        if len(keys) != 1:
-            raise NotImplementedError("shuffle mode routes on a single key column")
-        kname = next(iter(keys))
-        moved = exchange_by_key(ops, keys[kname], {**keys, **values}, group=group)
-        keys = {k: moved[k] for k in keys}
-        values = {k: moved[k] for k in values}
-        distributed = False   # key sets are disjoint now: the local result is final
-    part = ops.groupby_partial(keys, values, partial_aggs)
-    if distributed:
-        part = {k: allgather_concat(v, group) for k, v in part.items()}
-        # combine partials of equal keys: pack the key tuple into rows and unique them
-        kt = torch.stack([part[k].to(torch.int64) for k in keys], dim=1)
-        uniq, inverse = torch.unique(kt, dim=0, return_inverse=True)
-        n = uniq.shape[0]
-        comb = {k: uniq[:, i].to(part[k].dtype) for i, k in enumerate(keys)}
-        for out, col, op in aggs:
-            for i, (_, cop) in enumerate(PARTIALS[op]):
-                comb[f"{out}__p{i}"] = _combine(cop, part[f"{out}__p{i}"], inverse, n)
-        part = comb
-    res = {k: part[k] for k in keys}
-    for out, col, op in aggs:
-        if op == "mean":
-            res[out] = ops.mean_from_partials(part[f"{out}__p0"], part[f"{out}__p1"])
-        else:
-            res[out] = part[f"{out}__p0"]
-    return res
-
-
-def allgather_columns(cols: Dict[str, object], group=None) -> Dict[str, object]:
-    """Replicate a (small) frame on every rank: one variable-length all-gather per column."""
-    return {k: allgather_concat(v, group) for k, v in cols.items()}
-
-
-def join_groupby(ops: LocalOps, probe: Dict[str, object], build: Dict[str, object], probe_key: str, build_key: str, local_fn,
-                 merge: Sequence[Tuple[str, str]], result_key: str, *, mode: str = "auto", build_bytes_limit: int = 2 << 30,
-                 build_prefilter=None, probe_prefilter=None, group=None) -> Dict[str, object]:
-    """Sharded `probe JOIN build ON key -> GROUP BY (key, build columns) -> aggregates` (TPC-H Q3 shape).
-
-    Every rank holds a row shard of both inputs.  `local_fn(probe_cols, build_cols) -> {column: tensor}` runs the
-    single-GPU fused pipeline on what the rank holds after the exchange and returns per-group partial rows; `merge`
-    lists (column, "sum" | "min" | "max") for the partial aggregates, the remaining columns are group attributes
-    (functionally determined by `result_key`).
-
-    mode "broadcast": the build side is all-gathered (it is the small relation: filtered TPC-H orders at SF100 is
-                      ~0.35 GB), the probe side never moves; rows of one key may sit on several ranks, so the partial
-                      groups are merged by key with one small all-to-all.
-    mode "shuffle"  : both sides are routed by key hash with one all-to-all per input (grace hash join); every key is
-                      then owned by one rank and the local result is final.
-    mode "auto"     : broadcast when the global build side is below `build_bytes_limit`.
-    `build_prefilter` / `probe_prefilter` (cols -> cols) are the single-input predicates pushed below the exchange, so
-    only surviving rows cross xGMI (the reference pushes them below the join the same way, predicate_pushdown/mod.rs).
-    The result stays sharded by key (disjoint key sets across ranks)."""
-    import torch
-    import torch.distributed as dist
-    distributed = dist.is_initialized() and dist.get_world_size(group) > 1
-    if not distributed:
-        return local_fn(probe, build)
-    if build_prefilter is not None:
-        build = build_prefilter(build)
+    mode "shuffle"  : both sides are filtered, then routed by key hash (one exchange per input: a grace hash join); every key is then
+                      owned by one rank and the local result is final.
+    mode "broadcast": the filtered build side is all-gathered (the small relation: filtered TPC-H orders at SF100 is ~0.5 GB in all),
+                      the probe side never moves; rows of one key may sit on several ranks, so the partial groups are routed by
+                      result key (one small exchange) and merged by their owner.
+    mode "auto"     : broadcast when the filtered build side of ALL ranks is at most BROADCAST_BUILD_BYTES (agreed across ranks).
+    The result stays sharded by key.  `info` receives {"mode", "build_rows", "probe_rows", "partial_rows"}."""
+    alone = comm is None or (comm.world_size == 1 and not always_exchange)
+    if alone:
+        if info is not None:
+            info.update(mode="local", build_rows=None, probe_rows=None, partial_rows=None)
+        return ops.local(probe, build)
+    build_f = ops.build_prefilter(build)
     if mode == "auto":
-        local_bytes = sum(int(t.numel()) * t.element_size() for t in build.values())
-        tot = torch.tensor([local_bytes], dtype=torch.int64, device=next(iter(build.values())).device)
-        dist.all_reduce(tot, group=group)
-        mode = "broadcast" if int(tot.item()) <= build_bytes_limit else "shuffle"
+        mode = "broadcast" if comm.total(ops.nbytes(build_f)) <= BROADCAST_BUILD_BYTES else "shuffle"
     if mode == "shuffle":
-        if probe_prefilter is not None:
-            probe = probe_prefilter(probe)
-        probe2 = exchange_by_key(ops, probe[probe_key], probe, group=group)
-        build2 = exchange_by_key(ops, build[build_key], build, group=group)
-        return local_fn(probe2, build2)
-    # broadcast
-    part = local_fn(probe, allgather_columns(build, group))
-    moved = exchange_by_key(ops, part[result_key], part, group=group)
-    # merge partial groups of equal key with the local group-by operator; the attribute columns are functionally
-    # determined by the key, so grouping by (key, attributes) yields one row per key
-    merge_ops = dict(merge)
-    keys = {n: t for n, t in moved.items() if n not in merge_ops}
-    vals = {n: t for n, t in moved.items() if n in merge_ops}
-    if result_key not in keys:
-        raise ValueError("result_key must not be one of the merged aggregates")
-    return ops.groupby_partial(keys, vals, [(n, n, op) for n, op in merge])
+        probe_f = ops.probe_prefilter(probe)
+        p2 = comm.exchange_by_key(probe_f, spec.probe_key)
+        b2 = comm.exchange_by_key(build_f, spec.build_key)
+        if info is not None:
+            info.update(mode="shuffle", build_rows=int(build_f.height), probe_rows=int(probe_f.height), partial_rows=None)
+        return ops.local(p2, b2)
+    if mode != "broadcast":
+        raise ValueError(f"sharded_join_groupby mode {mode!r}")
+    part = ops.local(probe, comm.allgather(build_f))
+    owned = comm.exchange_by_key(part, spec.result_key)
+    if info is not None:
+        info.update(mode="broadcast", build_rows=int(build_f.height), probe_rows=None, partial_rows=int(part.height))
+    return ops.merge(owned, spec)
 
 
-class Q3Local:
-    """The per-rank pieces of sharded TPC-H Q3 on libpolars_amd (device tensors in/out): the orders predicate pushed
-    below the exchange and the fused filter -> join -> group-by pipeline (polars_amd/queries.py q3)."""
-
-    def __init__(self, pl):
-        from . import datagen, queries
-        self.pl, self.datagen, self.queries = pl, datagen, queries
-        self.ops = HipLocalOps(pl)
-
-    @staticmethod
-    def _cols(df):
-        return {n: df[n].to_torch() for n in df.columns}
-
-    def build_prefilter(self, bc):
-        pl, c = self.pl, self.pl.col
-        f = self.datagen.frame_from_torch(pl, bc, self.datagen.ORDERS_Q3_COLS)
-        return self._cols(f.lazy().filter((c("o_orderdate") < self.queries.Q3_DATE) & ((c("o_custkey") % 5) == 0)).collect())
-
-    def probe_prefilter(self, pc):
-        pl, c = self.pl, self.pl.col
-        f = self.datagen.frame_from_torch(pl, pc, self.datagen.LINEITEM_Q3_COLS)
-        return self._cols(f.lazy().filter(c("l_shipdate") > self.queries.Q3_DATE).collect())
-
-    def local(self, pc, bc):
-        L = self.datagen.frame_from_torch(self.pl, pc, self.datagen.LINEITEM_Q3_COLS)
-        O = self.datagen.frame_from_torch(self.pl, bc, self.datagen.ORDERS_Q3_COLS)
-        return self._cols(self.queries.q3(L.lazy(), O.lazy()).collect())
-
-    def run(self, lineitem, orders, mode: str = "broadcast", group=None):
-        return join_groupby(self.ops, lineitem, orders, "l_orderkey", "o_orderkey", self.local, [("revenue", "sum")], "l_orderkey", mode=mode,
-                            build_prefilter=self.build_prefilter, probe_prefilter=self.probe_prefilter, group=group)
+def q3_ops(pl):
+    """(LibJoinOps, JoinGroupBySpec) of TPC-H Q3 on the two big tables (queries.q3): orders predicate and lineitem predicate pushed below
+    the exchange, the fused filter -> join -> group-by as the local operator."""
+    from . import queries
+    c = pl.col
+    ops = LibJoinOps(pl, queries.q3, build_filter=(c("o_orderdate") < queries.Q3_DATE) & ((c("o_custkey") % 5) == 0), probe_filter=c("l_shipdate") > queries.Q3_DATE)
+    return ops, JoinGroupBySpec("l_orderkey", "o_orderkey", "l_orderkey", [("revenue", "sum")])

@@ -1,7 +1,7 @@
-"""Worker of tests/test_dist_gloo_cpu.py: one process per rank, gloo backend, CPU tensors.
-The per-rank compute is an oracle-backed LocalOps (test infrastructure) -- what is under test
-is polars_amd.dist: key-hash routing with one all-to-all, partial/final aggregate
-decomposition, variable-length all-gather."""
+"""Worker of tests/test_dist_gloo_cpu.py: one process per rank, gloo backend, numpy frames.
+What is under test is polars_amd.dist -- the control flow of the sharded operators (mode choice agreed across ranks, partial / final
+aggregate decomposition, which frames cross the fabric, the merge on the owner) -- with bench.py's numpy doubles standing in for the
+device frames, the library's RCCL communicator and the per-rank operators."""
 import os
 import sys
 
@@ -14,99 +14,59 @@ sys.path.insert(0, ROOT)
 from oracle import pyoracle as orc  # noqa: E402
 from polars_amd import dist as pdist  # noqa: E402
 
-AGG = {"sum": orc.AGG_SUM, "count": orc.AGG_COUNT, "len": orc.AGG_LEN, "min": orc.AGG_MIN, "max": orc.AGG_MAX}
-
-
-class OracleLocalOps(pdist.LocalOps):
-    def hash_partition(self, key, n_parts, seed=0):
-        p = orc.hash_partition(key.numpy(), None, n_parts, seed)
-        perm = np.argsort(p, kind="stable")
-        return torch.from_numpy(perm.astype(np.int64)), np.bincount(p, minlength=n_parts).tolist()
-
-    def groupby_partial(self, keys, values, aggs):
-        ks = [k.numpy() for k in keys.values()]
-        spec = []
-        for out, col, op in aggs:
-            v = values[col].numpy() if col else None
-            if op == "sum_f64":
-                spec.append((out, orc.AGG_SUM, v.astype(np.float64), None))
-            else:
-                spec.append((out, AGG[op], v, None))
-        r = orc.q_groupby(ks, [None] * len(ks), spec)
-        res = {name: torch.from_numpy(np.ascontiguousarray(r[f"key_{i}"][0])) for i, name in enumerate(keys)}
-        for out, _, _ in aggs:
-            a = r[out][0]
-            res[out] = torch.from_numpy(np.ascontiguousarray(a.astype(np.int64) if a.dtype == np.uint32 else a))
-        return res
-
 
 def main():
     pdist.init_process_group("gloo")
     rank, ws = dist.get_rank(), dist.get_world_size()
-    ops = OracleLocalOps()
     out_dir = sys.argv[1]
-    # every rank owns a different row shard of the same logical table
+    import bench
+    # (a) the exchange double itself: every row lands on ONE rank per key, nothing lost, all-gather = concatenation in rank order
     rng = np.random.default_rng(1000 + rank)
     n = 20_000 + 1000 * rank
-    key = torch.from_numpy(rng.integers(0, 3000, n).astype(np.int64))
-    flag = torch.from_numpy(rng.integers(0, 3, n).astype(np.int64))
-    v = torch.from_numpy(rng.integers(-50, 50, n).astype(np.int64))
-    x = torch.from_numpy(rng.uniform(0, 1, n))
-    aggs = [("s", "v", "sum"), ("m", "x", "mean"), ("mn", "v", "min"), ("mx", "x", "max"), ("n", "", "len")]
-    # (a) exchange_by_key: every row lands on the rank its key hashes to, nothing lost
-    moved = pdist.exchange_by_key(ops, key, {"key": key, "v": v})
-    owner = orc.hash_partition(moved["key"].numpy(), None, ws, 0)
-    assert (owner == rank).all(), "row routed to the wrong rank"
-    tot = torch.tensor([moved["key"].numel(), int(moved["v"].sum())], dtype=torch.int64)
+    key = rng.integers(0, 3000, n).astype(np.int64)
+    v = rng.integers(-50, 50, n).astype(np.int64)
+    comm0 = bench.DryComm()
+    moved = comm0.exchange_by_key(bench.DryFrame({"key": key, "v": v}), "key")
+    owners = comm0.allgather(bench.DryFrame({"key": np.unique(moved.cols["key"]), "r": np.full(len(np.unique(moved.cols["key"])), rank, np.int64)}))
+    assert len(np.unique(owners.cols["key"])) == owners.height, "a key landed on two ranks"
+    tot = torch.tensor([moved.height, int(moved.cols["v"].sum())], dtype=torch.int64)
     mine = torch.tensor([n, int(v.sum())], dtype=torch.int64)
     dist.all_reduce(tot); dist.all_reduce(mine)
     assert torch.equal(tot, mine), "rows or values lost in the all-to-all"
-    # (a') the same exchange in several rounds of row slabs (what a per-peer segment above 2^29 bytes triggers on RCCL): identical result
-    saved = pdist.P2P_CHUNK_BYTES
-    pdist.P2P_CHUNK_BYTES = 8 * 1000                              # 1000 rows of an int64 column per peer and round
-    moved2 = pdist.exchange_by_key(ops, key, {"key": key, "v": v})
-    pdist.P2P_CHUNK_BYTES = saved
-    assert torch.equal(moved2["key"], moved["key"]) and torch.equal(moved2["v"], moved["v"]), "chunked exchange differs from the single-round exchange"
-    # (b) low-cardinality group-by: local partials + all-gather + combine (replicated result)
-    g = pdist.groupby_agg(ops, {"flag": flag}, {"v": v, "x": x}, aggs, mode="gather")
-    # (c) high-cardinality group-by: shuffle by key hash, result sharded by key
-    s = pdist.groupby_agg(ops, {"key": key}, {"v": v, "x": x}, aggs, mode="shuffle")
+    assert comm0.total(rank + 1) == ws * (ws + 1) / 2
     # (d) bench.py --gpus N: per-rank Q1 frames are all-gathered as one fixed-size tensor and merged on every rank
-    import bench
     from polars_amd import datagen
     li = datagen.lineitem_host(30_000 + 500 * rank, seed=200 + rank)
     qcols = {c: li[c] for c in datagen.LINEITEM_Q1_COLS}
     mine = {c: a.tolist() for c, a in orc.q1_native(qcols, datagen.us(1998, 9, 2), streaming=True).items()}
     merged = bench.combine_q1_results(bench.allgather_q1(mine, ws))
     np.savez(os.path.join(out_dir, f"q1_rank{rank}.npz"), **{c: np.asarray(a) for c, a in qcols.items()}, **{"m_" + c: np.asarray(a) for c, a in merged.items()})
-    # (e) sharded join -> group-by (Q3 shape), broadcast and shuffle modes; the local pipeline is the oracle's q3
+    # (e) sharded join -> group-by (Q3 shape; dist.sharded_join_groupby: what bench.py --gpus N --workload q3 runs), all three modes
     orders, li = datagen.orders_lineitem_host(30000 + 300 * rank, seed=300 + rank)
     # make order keys globally unique across ranks (each rank generated its own key space)
     off = rank * 10_000_000
     orders["o_orderkey"] = orders["o_orderkey"] + off; li["l_orderkey"] = li["l_orderkey"] + off
     # scatter this rank's lineitem rows so that keys of one order also live on OTHER ranks' probe shards
-    allkeys = [torch.from_numpy(li[c]) for c in datagen.LINEITEM_Q3_COLS]
-    probe = {c: pdist.allgather_concat(t)[rank::ws].contiguous() for c, t in zip(datagen.LINEITEM_Q3_COLS, allkeys)}
-    build = {c: torch.from_numpy(orders[c]) for c in datagen.ORDERS_Q3_COLS}
+    comm = bench.DryComm()
+    allrows = comm.allgather(bench.DryFrame({c: li[c] for c in datagen.LINEITEM_Q3_COLS}))
+    probe = bench.DryFrame({c: np.ascontiguousarray(allrows.cols[c][rank::ws]) for c in datagen.LINEITEM_Q3_COLS})
+    build = bench.DryFrame({c: orders[c] for c in datagen.ORDERS_Q3_COLS})
     date = datagen.us(1995, 3, 15)
-
-    def local_q3(pc, bc):
-        r = orc.q3({c: t.numpy() for c, t in pc.items()}, {c: t.numpy() for c, t in bc.items()}, date)
-        return {c: torch.from_numpy(np.ascontiguousarray(a)) for c, a in r.items()}
-    def build_pre(bc):
-        m = torch.from_numpy((bc["o_orderdate"].numpy() < date) & (bc["o_custkey"].numpy() % 5 == 0))
-        return {c: t[m] for c, t in bc.items()}
-
-    def probe_pre(pc):
-        m = pc["l_shipdate"] > date
-        return {c: t[m] for c, t in pc.items()}
-    for mode in ("broadcast", "shuffle", "auto"):
-        r = pdist.join_groupby(ops, probe, build, "l_orderkey", "o_orderkey", local_q3, [("revenue", "sum")], "l_orderkey", mode=mode,
-                               build_prefilter=build_pre if mode != "broadcast" else None, probe_prefilter=probe_pre if mode == "shuffle" else None)
-        np.savez(os.path.join(out_dir, f"q3_{mode}_rank{rank}.npz"), **{c: t.numpy() for c, t in r.items()})
-    np.savez(os.path.join(out_dir, f"q3_in_rank{rank}.npz"), **{"p_" + c: t.numpy() for c, t in probe.items()}, **{"b_" + c: t.numpy() for c, t in build.items()})
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), key=key.numpy(), flag=flag.numpy(), v=v.numpy(), x=x.numpy(),
-             **{f"g_{k}": t.numpy() for k, t in g.items()}, **{f"s_{k}": t.numpy() for k, t in s.items()})
+    jops, jspec = bench.DryJoinOps(date), pdist.JoinGroupBySpec("l_orderkey", "o_orderkey", "l_orderkey", [("revenue", "sum")])
+    # the numpy double of the local operator against the oracle's q3 on this rank's inputs
+    w = orc.q3(probe.cols, build.cols, date)
+    g = jops.local(probe, build)
+    o = np.argsort(g.cols["l_orderkey"])
+    assert np.array_equal(g.cols["l_orderkey"][o], w["l_orderkey"]) and np.allclose(g.cols["revenue"][o], w["revenue"], rtol=1e-12)
+    saved = pdist.BROADCAST_BUILD_BYTES
+    for mode in ("broadcast", "shuffle", "auto", "auto_small_limit"):
+        pdist.BROADCAST_BUILD_BYTES = 1000 if mode == "auto_small_limit" else saved      # a build side over the limit: "auto" must shuffle
+        comm.rows_sent = comm.bytes_sent = 0
+        info = {}
+        r = pdist.sharded_join_groupby(comm, jops, probe, build, jspec, mode=mode.split("_")[0], info=info)
+        np.savez(os.path.join(out_dir, f"q3_{mode}_rank{rank}.npz"), mode=np.array([info["mode"]]), rows_sent=np.array([comm.rows_sent]), **r.cols)
+    pdist.BROADCAST_BUILD_BYTES = saved
+    np.savez(os.path.join(out_dir, f"q3_in_rank{rank}.npz"), **{"p_" + c: a for c, a in probe.cols.items()}, **{"b_" + c: a for c, a in build.cols.items()})
     # (g) the frame-level sharded group-by (dist.sharded_groupby: what bench.py --gpus N --workload cfg3 runs): pre-aggregation before the
     # exchange vs raw-row exchange vs the sample-driven choice, with NULL keys (one group, owned by rank 0) and null values; numpy doubles
     # stand in for the library frames and the RCCL communicator (bench.DryFrame / DryComm / DryOps)

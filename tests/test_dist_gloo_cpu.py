@@ -37,9 +37,11 @@ def test_sharded_groupby_and_exchange(tmp_path, ws):
     or_all = {c: np.concatenate([i["b_" + c] for i in ins]) for c in datagen.ORDERS_Q3_COLS}
     exp = orc.q3(li_all, or_all, datagen.us(1995, 3, 15))
     assert len(exp["l_orderkey"]) > 100
-    for mode in ("broadcast", "shuffle", "auto"):
+    sent = {}
+    for mode, took in (("broadcast", "broadcast"), ("shuffle", "shuffle"), ("auto", "broadcast"), ("auto_small_limit", "shuffle")):
         outs = [np.load(f) for f in sorted(glob.glob(str(tmp_path / f"q3_{mode}_rank*.npz")))]
-        assert len(outs) == ws
+        assert len(outs) == ws and all(str(o["mode"][0]) == took for o in outs), mode      # the size-driven choice, agreed across ranks
+        sent[mode] = sum(int(o["rows_sent"][0]) for o in outs)
         keys = [set(o["l_orderkey"].tolist()) for o in outs]
         for i in range(ws):
             for j in range(i + 1, ws):
@@ -49,6 +51,8 @@ def test_sharded_groupby_and_exchange(tmp_path, ws):
         assert np.array_equal(got["l_orderkey"][order], exp["l_orderkey"]), mode
         assert np.array_equal(got["o_orderdate"][order], exp["o_orderdate"]) and np.array_equal(got["o_shippriority"][order], exp["o_shippriority"]), mode
         assert np.allclose(got["revenue"][order], exp["revenue"], rtol=1e-9), mode
+    # broadcast moves only partial groups (the build side is all-gathered, not counted as routed rows); shuffle moves the filtered rows of both sides
+    assert 0 < sent["broadcast"] < sent["shuffle"] and sent["auto"] == sent["broadcast"] and sent["auto_small_limit"] == sent["shuffle"]
     # the shared scan: shards are disjoint contiguous runs covering every row group the predicate keeps, every rank ends up with the
     # SAME dictionary, and codes decoded through it give back the file's strings
     import pyarrow.parquet as pq
@@ -98,30 +102,6 @@ def test_sharded_groupby_and_exchange(tmp_path, ws):
     pre, raw = sum(int(s["preagg_rows_sent"][0]) for s in sg), sum(int(s["rows_rows_sent"][0]) for s in sg)
     assert pre < raw / 5 and raw > 0.4 * len(whole_df) * (ws - 1) / ws                                     # ~2500 groups per rank instead of ~30000 rows
     assert all(str(s["auto_mode"][0]) == "preagg" and str(s["auto_unique_mode"][0]) == "rows" for s in sg)   # the sample-driven choice, agreed across ranks
-    files = sorted(glob.glob(str(tmp_path / "rank*.npz")))
-    assert len(files) == ws
-    parts = [np.load(f) for f in files]
-    df = pd.DataFrame({k: np.concatenate([p[k] for p in parts]) for k in ("key", "flag", "v", "x")})
-
-    def check(group_col, got):
-        g = df.groupby(group_col)
-        exp = pd.DataFrame({"s": g["v"].sum(), "m": g["x"].mean(), "mn": g["v"].min(), "mx": g["x"].max(), "n": g.size()}).sort_index()
-        order = np.argsort(got[group_col])
-        assert np.array_equal(got[group_col][order], exp.index.to_numpy())
-        assert np.array_equal(got["s"][order], exp["s"].to_numpy()) and np.array_equal(got["mn"][order], exp["mn"].to_numpy())
-        assert np.array_equal(got["n"][order], exp["n"].to_numpy()) and np.array_equal(got["mx"][order], exp["mx"].to_numpy())
-        assert np.allclose(got["m"][order], exp["m"].to_numpy(), rtol=1e-12)
-
-    # gather mode: every rank holds the full (replicated) result
-    for p in parts:
-        check("flag", {k[2:]: p[k] for k in p.files if k.startswith("g_")})
-    # shuffle mode: the result is sharded by key -- disjoint key sets whose union is the full answer
-    keysets = [set(p["s_key"].tolist()) for p in parts]
-    for i in range(ws):
-        for j in range(i + 1, ws):
-            assert not (keysets[i] & keysets[j])
-    union = {k[2:]: np.concatenate([p[k] for p in parts]) for k in parts[0].files if k.startswith("s_")}
-    check("key", union)
 
 
 def test_partial_final_decomposition_table():
@@ -155,6 +135,32 @@ def test_bench_q1_rank_combine_matches_single_shard():
             assert np.allclose(np.array(merged[k]), v, rtol=1e-9), k
         else:
             assert merged[k] == v.tolist(), k
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2 --dry-run` WITHOUT torchrun (the shape of the driver's N = 1 command with another N): bench.py starts the
+    two ranks itself and rank 0 prints ONE line with n_gpus = 2 -- the Q1 headline plus the sharded Q3 (BASELINE config 4, strong scaling,
+    both sides exchanged by key hash), cfg3 and cfg5 as extras, every one checked by rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1", "--rows", "120000"],
+                       capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["config"]["workload"] == "tpch_q1_sf100_x2" and d["verified"]["ok"] is True
+    ex = d["extras"]
+    assert set(ex) == {"tpch_q3_sf100_sharded_x2", "cfg3_groupby_1e6_keys_sharded_x2", "cfg5_dict_string_keys_sharded_x2"}, list(ex)
+    q3 = ex["tpch_q3_sf100_sharded_x2"]
+    assert q3["scaling"] == "strong" and q3["exchange_mode"] == "shuffle" and q3["verified"]["ok"] is True and q3["verified"]["keys_disjoint_across_ranks"] is True
+    assert all(p["covers_whole_input"] and p["ok"] for p in q3["verified"]["per_rank"]) and q3["shuffle"]["rows_sent_per_rank_per_step"] > 0
+    assert q3["shuffle"]["bytes_sent_per_rank_per_step"] == q3["shuffle"]["rows_sent_per_rank_per_step"] * 32        # four 8-byte columns on either side
+    for w in ("cfg3_groupby_1e6_keys_sharded_x2", "cfg5_dict_string_keys_sharded_x2"):
+        assert ex[w]["verified"]["ok"] is True and ex[w]["scaling"] == "weak", w
 
 
 def test_sharded_groupby_bench_dry_run_prints_a_complete_line():

@@ -345,31 +345,23 @@ def test_errors_are_status_codes_not_crashes(pl):
         pl.DataFrame([a]).lazy().select(pl.col("nope").sum()).collect()
 
 
-def test_dist_hip_local_ops_single_rank(pl, orc):
-    """polars_amd.dist on the product LocalOps (device tensors wrapped zero-copy, compute through the C ABI), world
-    size 1: hash_partition agrees with the oracle's HashPartitioner restatement and groupby_agg with numpy."""
-    import torch
-    from polars_amd import dist as pdist
-    ops = pdist.HipLocalOps(pl)
+def test_hash_partition_matches_the_partitioner_restatement(pl, orc):
+    """plx_hash_partition (what plx_exchange_by_key routes rows with) against the oracle's HashPartitioner restatement
+    (crates/polars-utils/src/hashing.rs:72-121): per-partition counts and a permutation that groups the rows by partition."""
+    import ctypes as C
+    F = pl._ffi
     rng = np.random.default_rng(61)
     n = 200_000
     key = rng.integers(-5000, 5000, n).astype(np.int64)
-    v = rng.integers(-50, 50, n).astype(np.int64)
-    x = rng.uniform(0, 1, n)
-    tk, tv, tx = torch.from_numpy(key).cuda(), torch.from_numpy(v).cuda(), torch.from_numpy(x).cuda()
-    perm, counts = ops.hash_partition(tk, 8, 0)
-    exp = orc.hash_partition(key, None, 8, 0)
-    assert counts == np.bincount(exp, minlength=8).tolist()
-    assert np.array_equal(exp[perm.cpu().numpy()], np.sort(exp))
-    res = pdist.groupby_agg(ops, {"key": tk}, {"v": tv, "x": tx}, [("s", "v", "sum"), ("m", "x", "mean"), ("mn", "v", "min"), ("n", "", "len")], mode="gather")
-    order = np.argsort(res["key"].cpu().numpy())          # host-side: torch's device sort loads slowly on a cold box
-    uk, inv = np.unique(key, return_inverse=True)
-    assert np.array_equal(res["key"].cpu().numpy()[order], uk)
-    assert np.array_equal(res["s"].cpu().numpy()[order], np.bincount(inv, v).astype(np.int64))
-    assert np.allclose(res["m"].cpu().numpy()[order], np.bincount(inv, x) / np.bincount(inv), rtol=1e-9)
-    mn = np.full(len(uk), 10**9); np.minimum.at(mn, inv, v)
-    assert np.array_equal(res["mn"].cpu().numpy()[order], mn)
-    assert np.array_equal(res["n"].cpu().numpy()[order].astype(np.int64), np.bincount(inv))
+    s = pl.Series("k", key)
+    for n_parts, seed in ((8, 0), (3, 7)):
+        h = C.c_uint64()
+        counts = (C.c_int64 * n_parts)()
+        F.check(F.lib().plx_hash_partition(s._h, n_parts, seed, C.byref(h), counts))
+        perm = pl.Series._from_handle("perm", h.value, pl.UInt32).to_numpy()
+        exp = orc.hash_partition(key, None, n_parts, seed)
+        assert list(counts) == np.bincount(exp, minlength=n_parts).tolist()
+        assert np.array_equal(np.sort(perm), np.arange(n)) and np.array_equal(exp[perm], np.sort(exp))
 
 
 def test_library_exchange_on_rccl_world_size_one():

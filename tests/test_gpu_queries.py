@@ -505,40 +505,35 @@ def test_partitioned_groupby_packed_dictionary_keys(pl):
 
 
 def test_sharded_q3_per_rank_pieces(pl, orc):
-    """The per-rank operators of the sharded Q3 (polars_amd/dist.py Q3Local) composed the way join_groupby composes them,
-    with concatenation standing in for the collectives: 2 virtual ranks, keys of one order on both ranks."""
-    import torch
+    """The per-rank operators of the sharded Q3 (polars_amd/dist.py q3_ops -> LibJoinOps) composed the way sharded_join_groupby
+    composes them, with a frame concatenation standing in for the collectives: 2 virtual ranks, keys of one order on both ranks."""
     from polars_amd import datagen, dist as pdist
     orders, li = datagen.orders_lineitem_host(60_000, seed=77)
     exp = orc.q3({k: li[k] for k in datagen.LINEITEM_Q3_COLS}, {k: orders[k] for k in datagen.ORDERS_Q3_COLS}, datagen.us(1995, 3, 15))
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    q = pdist.Q3Local(pl)
-    probes = [{c: dev(li[c][r::2]) for c in datagen.LINEITEM_Q3_COLS} for r in range(2)]
+    ops, spec = pdist.q3_ops(pl)
+    probes = [datagen.to_frame(pl, {c: np.ascontiguousarray(li[c][r::2]) for c in datagen.LINEITEM_Q3_COLS}, datagen.LINEITEM_Q3_COLS) for r in range(2)]
     half = len(orders["o_orderkey"]) // 2
-    builds = [{c: dev(orders[c][:half] if r == 0 else orders[c][half:]) for c in datagen.ORDERS_Q3_COLS} for r in range(2)]
+    builds = [datagen.to_frame(pl, {c: np.ascontiguousarray(orders[c][:half] if r == 0 else orders[c][half:]) for c in datagen.ORDERS_Q3_COLS}, datagen.ORDERS_Q3_COLS) for r in range(2)]
     # broadcast mode: prefilter -> all-gather(build) -> local pipeline -> merge partial groups by key
-    fb = [q.build_prefilter(b) for b in builds]
-    assert sum(int(f["o_orderkey"].numel()) for f in fb) < len(orders["o_orderkey"]) // 3
-    hcat = lambda ts: dev(np.concatenate([t.cpu().numpy() for t in ts]))     # stands in for the all-gather; no torch kernels
-    gathered = {c: hcat([f[c] for f in fb]) for c in datagen.ORDERS_Q3_COLS}
-    parts = [q.local(p, gathered) for p in probes]
-    assert sum(int(p["l_orderkey"].numel()) for p in parts) > len(exp["l_orderkey"])     # keys split over both ranks
-    allp = {c: hcat([p[c] for p in parts]) for c in parts[0]}
-    keys = {c: allp[c] for c in ("l_orderkey", "o_orderdate", "o_shippriority")}
-    merged = q.ops.groupby_partial(keys, {"revenue": allp["revenue"]}, [("revenue", "revenue", "sum")])
-    m = {c: t.cpu().numpy() for c, t in merged.items()}     # host-side checks (torch's device sort loads slowly on a cold box)
+    fb = [ops.build_prefilter(b) for b in builds]
+    assert sum(f.height for f in fb) < len(orders["o_orderkey"]) // 3
+    assert ops.nbytes(fb[0]) == fb[0].height * 8 * len(datagen.ORDERS_Q3_COLS)
+    gathered = pl.concat(fb)                                     # stands in for plx_allgather_frame
+    parts = [ops.local(p, gathered) for p in probes]
+    assert sum(p.height for p in parts) > len(exp["l_orderkey"])     # keys split over both ranks
+    merged = ops.merge(pl.concat(parts), spec)
+    assert merged.columns == ["l_orderkey", "o_orderdate", "o_shippriority", "revenue"]
+    m = {c: merged[c].to_numpy() for c in merged.columns}
     order = np.argsort(m["l_orderkey"])
     assert np.array_equal(m["l_orderkey"][order], exp["l_orderkey"])
-    assert np.array_equal(m["o_orderdate"][order], exp["o_orderdate"])
+    assert np.array_equal(m["o_orderdate"][order].astype(np.int64), exp["o_orderdate"])
     assert np.allclose(m["revenue"][order], exp["revenue"], rtol=1e-9)
-    # shuffle mode pieces: probe prefilter + hash routing keep every surviving row exactly once
-    fp = [q.probe_prefilter(p) for p in probes]
-    assert sum(int(f["l_orderkey"].numel()) for f in fp) == int((li["l_shipdate"] > datagen.us(1995, 3, 15)).sum())
-    perm, counts = q.ops.hash_partition(fp[0]["l_orderkey"], 2)
-    assert sum(counts) == fp[0]["l_orderkey"].numel() and np.array_equal(np.sort(perm.cpu().numpy()), np.arange(sum(counts)))
-    # single-process run() is the plain local pipeline
-    full = q.run({c: dev(li[c]) for c in datagen.LINEITEM_Q3_COLS}, {c: dev(orders[c]) for c in datagen.ORDERS_Q3_COLS})
-    assert sorted(full["l_orderkey"].cpu().tolist()) == exp["l_orderkey"].tolist()
+    # shuffle mode pieces: the probe prefilter keeps every surviving row exactly once
+    fp = [ops.probe_prefilter(p) for p in probes]
+    assert sum(f.height for f in fp) == int((li["l_shipdate"] > datagen.us(1995, 3, 15)).sum())
+    # a single rank without a communicator is the plain local pipeline
+    full = pdist.sharded_join_groupby(None, ops, datagen.to_frame(pl, li, datagen.LINEITEM_Q3_COLS), datagen.to_frame(pl, orders, datagen.ORDERS_Q3_COLS), spec)
+    assert sorted(full["l_orderkey"].to_numpy().tolist()) == exp["l_orderkey"].tolist()
 
 
 @pytest.mark.parametrize("case", ["zipf", "one_hot_key"])
