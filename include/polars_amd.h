@@ -217,6 +217,10 @@ int plx_column_placeholder(plx_dtype dtype, int64_t len, int nullable, int has_r
  * metadata statistics -- to choose dense / direct-address group tables without a pass over the data.  Kernels that rely on
  * the bounds check them per row and fail the query (PLX_ERR_INVALID) if a value lies outside. */
 int plx_column_set_bounds(plx_column col, int64_t lo, int64_t hi);
+/* Forgets what the library has LEARNED about the column (value range computed by a statistics pass or as a by-product of a scan, the group-by
+ * planner's key sample and heavy hitters, the sampled sortedness): the next query pays for them again, as the first query on a fresh column
+ * does.  Bounds declared with plx_column_set_bounds stay.  Measurement support (bench.py `one_shot_ms`); never changes a result. */
+int plx_column_drop_statistics(plx_column col);
 /* Arrow C Data Interface import: copies to HBM, then calls array->release and
  * schema->release (callee takes ownership: plugin.rs:122-125 convention). */
 int plx_column_import_arrow(struct ArrowArray* array, struct ArrowSchema* schema, plx_column* out);
@@ -441,6 +445,11 @@ int plx_datagen_customer(int64_t n_customers, uint64_t seed, plx_column* out_col
 int plx_datagen_customer_host(int64_t row0, int64_t n, uint64_t seed, int64_t* custkey, uint8_t* segment);
 int plx_datagen_uniform(int32_t dtype, int64_t n_rows, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, double scale, plx_column* out);
 int plx_datagen_uniform_host(int32_t dtype, int64_t row0, int64_t n, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, double scale, void* out);
+/* One heavy-tailed PLX_I64 key column in [0, n_keys) (BASELINE config 3's "Zipf s = 1.1" variant): key i = floor(1 / x_i^10) - 1, x_i uniform in
+ * [x0, 1) from stream `stream` of row i, x0 = n_keys^(-1/10) handed over as x0_q62 = round(x0 * 2^62); integer fixed-point arithmetic only, so
+ * plx_datagen_zipf_host (rows [row0, row0 + n) on the CPU) is bit-identical. */
+int plx_datagen_zipf(int64_t n_rows, uint64_t seed, uint32_t stream, uint64_t x0_q62, int64_t n_keys, plx_column* out);
+int plx_datagen_zipf_host(int64_t row0, int64_t n, uint64_t seed, uint32_t stream, uint64_t x0_q62, int64_t n_keys, int64_t* out);
 
 /* ---- raw Utf8View / BinaryView keys: device-side dictionary encoding -----------------------------
  * The reference hashes and compares the 16-byte views directly (crates/polars-expr/src/hash_keys.rs:413-452 BinviewKeys,

@@ -113,6 +113,7 @@ SIGNATURES = {
     "plx_column_from_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, _u64p]),
     "plx_column_placeholder": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _u64p]),
     "plx_column_set_bounds": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64]),
+    "plx_column_drop_statistics": (C.c_int, [C.c_uint64]),
     "plx_strview_dict_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, _u64p, _u64p]),
     "plx_strview_dict_encode_device": (C.c_int, [C.c_uint64, C.c_uint64, _u64p, _u64p]),
     "plx_strview_groupby": (C.c_int, [C.c_uint64, C.c_uint64, _u64p, _u64p, _u64p, _u64p, _u64p]),
@@ -179,6 +180,8 @@ SIGNATURES = {
     "plx_datagen_customer": (C.c_int, [C.c_int64, C.c_uint64, _u64p]),
     "plx_datagen_customer_host": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "plx_datagen_uniform_host": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, C.c_double, C.c_void_p]),
+    "plx_datagen_zipf": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int64, _u64p]),
+    "plx_datagen_zipf_host": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int64, C.c_void_p]),
     "plx_debug_program_json": (C.c_int, [C.POINTER(IR), C.c_int32, C.POINTER(AExpr), C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
     "plx_sort_indices": (C.c_int, [_u64p, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int64, _u64p]),
     "plx_hash_partition": (C.c_int, [C.c_uint64, C.c_int32, C.c_uint64, _u64p, _i64p]),

@@ -108,6 +108,15 @@ int plx_column_set_bounds(plx_column col, int64_t lo, int64_t hi) {
   PLX_CATCH
 }
 
+int plx_column_drop_statistics(plx_column col) {
+  PLX_TRY
+  ColumnPtr c = get_column(col);
+  if (c->range_trusted) { c->range_state = 0; c->range_min = c->range_max = 0; }       // bounds the caller declared are part of the column, not a cache
+  std::atomic_store(&c->key_sample, std::shared_ptr<void>());
+  c->order_state = 0;
+  PLX_CATCH
+}
+
 static int dtype_from_format(const char* f) {
   if (!f) return -1;
   if (!strcmp(f, "b")) return PLX_BOOL;
@@ -776,6 +785,21 @@ int plx_datagen_uniform_host(int32_t dtype, int64_t row0, int64_t n, uint64_t se
     else if (dtype == PLX_U32) reinterpret_cast<uint32_t*>(out)[j] = (uint32_t)v;
     else reinterpret_cast<double*>(out)[j] = (double)v * scale;
   }
+  PLX_CATCH
+}
+
+int plx_datagen_zipf(int64_t n_rows, uint64_t seed, uint32_t stream_id, uint64_t x0_q62, int64_t n_keys, plx_column* out) {
+  PLX_TRY
+  PLX_REQUIRE(n_rows >= 0 && out && n_keys > 0 && stream_id < 8 && x0_q62 > 0 && x0_q62 < (1ull << 62), PLX_ERR_INVALID, "datagen_zipf: bad arguments");
+  ColumnPtr c = make_column(PLX_I64, n_rows, false); c->null_count = 0;
+  k::datagen_zipf(n_rows, seed, stream_id, x0_q62, n_keys, c->values->as<int64_t>());
+  *out = register_column(c);
+  PLX_CATCH
+}
+int plx_datagen_zipf_host(int64_t row0, int64_t n, uint64_t seed, uint32_t stream_id, uint64_t x0_q62, int64_t n_keys, int64_t* out) {
+  PLX_TRY
+  PLX_REQUIRE(row0 >= 0 && n >= 0 && (out || n == 0) && n_keys > 0 && stream_id < 8 && x0_q62 > 0 && x0_q62 < (1ull << 62), PLX_ERR_INVALID, "datagen_zipf: bad arguments");
+  for (int64_t j = 0; j < n; j++) out[j] = datagen::zipf_value(seed, stream_id, (uint64_t)(row0 + j), x0_q62, n_keys);
   PLX_CATCH
 }
 

@@ -95,6 +95,20 @@ PLX_HD inline int64_t uniform_value(uint64_t seed, uint32_t stream, uint64_t i, 
   return rand_range(mix64(seed), i, stream & 7u, lo, hi);
 }
 
+// ---- one heavy-tailed key column (BASELINE config 3's "Zipf s = 1.1" variant): key = floor(1 / x^10) - 1 with x uniform in
+// [x0, 1), x0 = n_keys^(-1/10) -- a Pareto variable of tail index 0.1, whose density falls like k^(-1.1): key 0 holds ~9 % of the rows, key 1 ~5 %,
+// the tail thins out over [0, n_keys).  Fixed point (62 fractional bits, integer multiplies and ONE integer division): the device kernel and the
+// host twin agree bit for bit, which floating-point pow() would not guarantee.  x0_q62 = round(x0 * 2^62), computed once by the caller.
+PLX_HD inline uint64_t mul_q62(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 62); }
+PLX_HD inline int64_t zipf_value(uint64_t seed, uint32_t stream, uint64_t i, uint64_t x0_q62, int64_t n_keys) {
+  const uint64_t one = 1ull << 62;
+  const uint64_t x = x0_q62 + mulhi64(mix64(mix64(seed) + i * 8 + (stream & 7u)), one - x0_q62);
+  const uint64_t x2 = mul_q62(x, x), x4 = mul_q62(x2, x2), x8 = mul_q62(x4, x4), x10 = mul_q62(x8, x2);
+  const uint64_t k = x10 ? one / x10 : (uint64_t)n_keys;     // floor(1 / x^10)
+  const int64_t id = (int64_t)(k ? k - 1 : 0);
+  return id < n_keys ? id : n_keys - 1;
+}
+
 // ---- Utf8View of the string "id%010d" % v (12 bytes: always inline; view layout polars-arrow/src/array/binview/view.rs:20-29) --------
 // w0 = length (12) | bytes 0..3 << 32, w1 = bytes 4..11, little-endian
 PLX_HD inline void id_view(uint64_t v, uint64_t* w0, uint64_t* w1) {

@@ -817,6 +817,9 @@ static void source_ranges(const Compiler& c, k::SrcRange out[kMaxSrc]) {
     if (in < 0 || in >= (int)c.input_cols.size()) continue;
     const ColumnPtr& col = c.cols[c.input_cols[in]];
     if (!dtype_is_int(col->dtype) || col->dtype == PLX_U64) continue;
+    // make_record2 stores (v - base) in 32 bits WITHOUT a per-row range check: only ranges the library computed itself may narrow a value
+    // (bounds declared by the caller -- plx_column_set_bounds, IPC dictionary sizes -- are checked per row where they address tables, never trusted here)
+    if (col->range_state != 0 && !col->range_trusted) continue;
     int64_t mn = 0, mx = 0;
     if (ops::int_range(col, &mn, &mx)) { out[j].known = true; out[j].mn = mn; out[j].mx = mx; }
   }

@@ -44,6 +44,7 @@ void datagen_lineitem_q1(int64_t n, uint64_t seed, int64_t* shipdate, uint8_t* f
 void datagen_orders(int64_t n, uint64_t seed, int64_t cust_hi, int64_t* okey, int64_t* cust, int64_t* odate, int64_t* prio, uint32_t* n_lines);
 void datagen_lines(int64_t n_orders, uint64_t seed, const uint64_t* offsets, const int64_t* okey, const int64_t* odate, int64_t* lkey, double* price, double* disc, int64_t* ship);
 void datagen_uniform(int dtype, int64_t n, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, double scale, void* out);
+void datagen_zipf(int64_t n, uint64_t seed, uint32_t stream, uint64_t x0_q62, int64_t n_keys, int64_t* out);
 void datagen_customer(int64_t n, uint64_t seed, int64_t* custkey, uint8_t* segment);
 
 // ---- raw Utf8View / BinaryView keys (kernels_strview.hip) ---------------------------------------

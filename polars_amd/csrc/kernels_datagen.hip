@@ -108,5 +108,15 @@ void datagen_uniform(int dtype, int64_t n, uint64_t seed, uint32_t strm, int64_t
   PLX_HIP(hipGetLastError());
 }
 
+__global__ __launch_bounds__(kBlock) void datagen_zipf_kernel(int64_t n, uint64_t seed, uint32_t strm, uint64_t x0_q62, int64_t n_keys, int64_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = datagen::zipf_value(seed, strm, (uint64_t)i, x0_q62, n_keys);
+}
+void datagen_zipf(int64_t n, uint64_t seed, uint32_t strm, uint64_t x0_q62, int64_t n_keys, int64_t* out) {
+  if (n <= 0) return;
+  ProfileScope ps("datagen_zipf", (uint64_t)n * 8, (uint64_t)n);
+  hipLaunchKernelGGL(datagen_zipf_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, stream(), n, seed, strm, x0_q62, n_keys, out);
+  PLX_HIP(hipGetLastError());
+}
+
 }  // namespace k
 }  // namespace plx

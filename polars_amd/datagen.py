@@ -238,6 +238,40 @@ def uniform_native(pl, name: str, dtype, n: int, seed: int, stream: int, lo: int
     return pl.Series._from_handle(name, h.value, dtype)
 
 
+def zipf_x0_q62(n_keys: int) -> int:
+    """x0 = n_keys ** -0.1 as the 62-bit fixed-point integer the zipf generator takes (plx_datagen_zipf: key = floor(1 / x^10) - 1, x uniform in [x0, 1))."""
+    return int(round(float(n_keys) ** -0.1 * (1 << 62)))
+
+
+def zipf_native(pl, name: str, n: int, seed: int, stream: int, n_keys: int):
+    """A heavy-tailed Int64 key column in [0, n_keys) from the library's generator (density ~ k^-1.1: config 3's Zipf variant)."""
+    import ctypes as C
+
+    from . import _ffi as F
+    F.ensure_init()
+    h = C.c_uint64()
+    F.check(F.lib().plx_datagen_zipf(n, seed, stream, zipf_x0_q62(n_keys), n_keys, C.byref(h)))
+    return pl.Series._from_handle(name, h.value, pl.Int64)
+
+
+def zipf_native_host_mt(row0: int, n: int, seed: int, stream: int, n_keys: int, threads=None) -> np.ndarray:
+    """Host twin of zipf_native: rows [row0, row0 + n), bit-identical (integer fixed point), over the host threads."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    from . import _ffi as F
+    out = np.empty(n, np.int64)
+    lib, x0 = F.lib(), zipf_x0_q62(n_keys)
+
+    def work(bl):
+        b, m = bl
+        F.check(lib.plx_datagen_zipf_host(row0 + b, m, seed, stream, x0, n_keys, C.c_void_p(out.ctypes.data + b * 8)))
+    nt = _host_threads(threads)
+    with ThreadPoolExecutor(nt) as ex:
+        list(ex.map(work, _split(n, nt * 4, 4096)))
+    return out
+
+
 def id_views_native(pl, name: str, n: int, seed: int, stream: int, lo: int, hi: int):
     """A Utf8View key column generated in HBM: row i holds the (inline, 12-byte) view of "id%010d" % uniform_value(seed, stream, i, lo, hi)
     -> UInt64 Series of 2 n words (feed it to pl.Series.from_device_views).  Host twin: uniform_native_host("Int64", ...) gives the

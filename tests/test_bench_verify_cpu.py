@@ -57,6 +57,49 @@ def test_cfg2_check():
     assert bench.verify_cfg2(got, n, seed, 0.0)["ok"] is None          # no budget: reported as not covered, never as passed
 
 
+def test_cfg2_check_with_nulls():
+    """the nullable variant (cfg2_nulls5pct_1e9): x is null where the generator's stream-3 value is below 5; a result that ignored the bitmap fails"""
+    n, seed = 250_000, 20
+    a = datagen.uniform_native_host("Int64", 0, n, seed, 0, 0, 2 ** 31)
+    x = datagen.uniform_native_host("Float64", 0, n, seed, 1, 0, 10 ** 9, 1e-7)
+    y = datagen.uniform_native_host("Float64", 0, n, seed, 2, 0, 10 ** 9, 1e-9)
+    valid = datagen.uniform_native_host("UInt32", 0, n, seed, 3, 0, 100) >= bench.CFG2_NULL_PCT
+    assert 0.04 < 1 - valid.mean() < 0.06
+    m = a > 2 ** 30
+    got = {"xy": [float((x[m & valid] * (1 - y[m & valid])).sum())], "x_mean": [float(x[m & valid].mean())], "a_sum": [int(a[m].sum())]}
+    assert bench.verify_cfg2(got, n, seed, 60, block=100_000, null_pct=bench.CFG2_NULL_PCT)["ok"] is True
+    blind = {"xy": [float((x[m] * (1 - y[m])).sum())], "x_mean": [float(x[m].mean())], "a_sum": [int(a[m].sum())]}
+    assert bench.verify_cfg2(blind, n, seed, 60, block=100_000, null_pct=bench.CFG2_NULL_PCT)["ok"] is False
+
+
+def test_groupby_checks_zipf_and_sparse_keys():
+    """cfg3_zipf_1e9 (keys from the zipf generator's host twin) and cfg3_sparse_keys_1e9 (ids times an odd 64-bit constant: the result keys map back
+    through the inverse multiplier)"""
+    n, seed, nk = 300_000, 20, 5000
+    kz = datagen.zipf_native_host_mt(0, n, seed, 0, nk, threads=2)
+    v = datagen.uniform_native_host("Int64", 0, n, seed, 1, 0, 1000)
+    present = np.nonzero(np.bincount(kz, minlength=nk))[0]
+    f = Frame(key=present[::-1], v_sum=np.bincount(kz, weights=v, minlength=nk).astype(np.int64)[present][::-1], v_count=np.bincount(kz, minlength=nk).astype(np.uint32)[present][::-1])
+    gen = lambda r0, m: datagen.zipf_native_host_mt(r0, m, seed, 0, nk, threads=2)
+    r = bench.verify_groupby_dense(f, "key", "v_sum", n, seed, nk, "Int64", "Int64", (0, 1000), ("count", "v_count"), 60, block=110_000, key_gen=gen)
+    assert r["ok"] and r["groups"] == len(present) < nk, r
+    f.raw("v_count")[0] += 1
+    assert bench.verify_groupby_dense(f, "key", "v_sum", n, seed, nk, "Int64", "Int64", (0, 1000), ("count", "v_count"), 60, block=110_000, key_gen=gen)["ok"] is False
+    ids = datagen.uniform_native_host("Int64", 0, n, seed, 0, 0, nk)
+    w = datagen.uniform_native_host("Int64", 0, n, seed, 1, -(1 << 40), 1 << 40)
+    assert w.min() < -(1 << 39) and w.max() > (1 << 39)
+    sparse = (np.arange(nk).astype(np.uint64) * np.uint64(bench.HASHED_KEY_MULT % (1 << 64))).astype(np.int64)          # what the device multiply produces
+    assert len(np.unique(sparse)) == nk and np.array_equal((sparse.astype(np.uint64) * np.uint64(bench.HASHED_KEY_INV)).astype(np.int64), np.arange(nk))
+    sums = np.zeros(nk, np.int64); np.add.at(sums, ids, w)
+    perm = np.random.default_rng(1).permutation(nk)
+    f = Frame(key=sparse[perm], v_sum=sums[perm], v_count=np.bincount(ids, minlength=nk).astype(np.uint32)[perm])
+    unmap = lambda k: (k.astype(np.uint64) * np.uint64(bench.HASHED_KEY_INV)).astype(np.int64)
+    r = bench.verify_groupby_dense(f, "key", "v_sum", n, seed, nk, "Int64", "Int64", (-(1 << 40), 1 << 40), ("count", "v_count"), 60, block=110_000, key_unmap=unmap)
+    assert r["ok"], r
+    f.raw("v_sum")[7] -= 1
+    assert bench.verify_groupby_dense(f, "key", "v_sum", n, seed, nk, "Int64", "Int64", (-(1 << 40), 1 << 40), ("count", "v_count"), 60, block=110_000, key_unmap=unmap)["ok"] is False
+
+
 def test_groupby_checks_cfg3_cfg5():
     n, seed, nk = 400_000, 20, 1000
     key = datagen.uniform_native_host("Int64", 0, n, seed, 0, 0, nk)

@@ -115,6 +115,28 @@ def test_uniform_generator_host_twin():
         assert a[i] == (_mix((key + i * 8 + 0) & M64) * 2 ** 31) >> 64
 
 
+def test_zipf_generator_host_twin():
+    """plx_datagen_zipf_host: key = floor(1 / x^10) - 1 with x uniform in [n_keys^-0.1, 1) in 62-bit fixed point -- pinned against a Python big-integer
+    restatement; the density falls like k^-1.1 (P(key >= k) = ((k + 1)^-0.1 - x0) / (1 - x0))."""
+    nk, seed, strm = 1_000_000, 11, 0
+    k = datagen.zipf_native_host_mt(0, 400_000, seed, strm, nk, threads=2)
+    assert k.dtype == np.int64 and k.min() == 0 and k.max() < nk
+    x0 = datagen.zipf_x0_q62(nk)
+    one = 1 << 62
+    key = _mix(seed)
+    for i in (0, 1, 7, 399_999):
+        x = x0 + ((_mix((key + i * 8 + strm) & M64) * (one - x0)) >> 64)
+        x2 = (x * x) >> 62; x4 = (x2 * x2) >> 62; x8 = (x4 * x4) >> 62; x10 = (x8 * x2) >> 62
+        assert k[i] == min(one // x10 - 1, nk - 1), i
+    assert np.array_equal(datagen.zipf_native_host_mt(1234, 999, seed, strm, nk, threads=1), k[1234:2233])          # a pure function of (seed, row)
+    x0f = nk ** -0.1
+    for kk in (1, 2, 10, 1000):
+        want = ((kk) ** -0.1 - x0f) / (1 - x0f)                      # P(key >= kk) = P(K >= kk + 1 in units of floor(1 / x^10)) = P(x <= (kk + 1 - 1 ...))
+        got = float((k >= kk - 0).mean()) if kk == 0 else float((k + 1 >= kk).mean())
+        assert abs(got - want) < 0.01, (kk, got, want)
+    assert 0.08 < float((k == 0).mean()) < 0.10 and 0.04 < float((k == 1).mean()) < 0.06
+
+
 def test_customer_host_twin_properties():
     """plx_datagen_customer_host: dense keys in order, five market segments roughly uniform, a pure function of (seed, key)."""
     a = datagen.customer_native_host(0, 50_000, seed=9)

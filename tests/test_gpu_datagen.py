@@ -50,6 +50,35 @@ def test_uniform_device_generator_equals_host_twin(pl):
         assert np.array_equal(s.to_numpy(), datagen.uniform_native_host(name, 0, n, *args)), name
 
 
+def test_zipf_device_generator_equals_host_twin(pl):
+    from polars_amd import datagen
+    n = 1_000_003
+    s = datagen.zipf_native(pl, "key", n, 17, 0, 1_000_000)
+    assert np.array_equal(s.to_numpy(), datagen.zipf_native_host_mt(0, n, 17, 0, 1_000_000))
+
+
+def test_dropped_statistics_change_the_plan_not_the_result(pl):
+    """plx_column_drop_statistics (bench.py one_shot_ms): a group-by on a raw Int64 key learns the key range on its first run and plans dense ids on the
+    second; after the drop it plans like the first run again -- and gives the same groups every time."""
+    import re
+    from polars_amd import queries
+    rng = np.random.default_rng(5)
+    n = 17_000_000
+    key = rng.integers(1000, 301_000, n).astype(np.int64)
+    v = rng.integers(0, 1000, n).astype(np.int64)
+    df = pl.DataFrame({"key": key, "v": v})
+    plans, outs = [], []
+    for step in range(3):
+        if step == 2:
+            for c in df.get_columns():
+                pl._ffi.check(pl._ffi.lib().plx_column_drop_statistics(c._h))
+        outs.append(queries.cfg3(df.lazy()).collect().sort_host("key")); plans.append(pl.last_plan())
+    assert "hash" in plans[0] and "key_range_learned" in plans[0], plans[0]
+    assert re.search(r"partitioned\(v3,direct", plans[1]), plans[1]
+    assert "hash" in plans[2] and "direct" not in plans[2], plans[2]
+    assert outs[0] == outs[1] == outs[2]
+
+
 def test_customer_generator_matches_host_twin(pl):
     from polars_amd import datagen
     n = 300_001

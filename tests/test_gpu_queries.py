@@ -634,6 +634,25 @@ def test_declared_bounds_are_checked_not_trusted_blindly(pl):
         queries.cfg5(bad.lazy()).collect()
 
 
+def test_wrong_declared_bounds_on_a_value_column_never_narrow_it(pl):
+    """The record packer of the partitioned group-by stores an Int64 aggregate source as a u32 offset from the column's minimum WITHOUT a
+    per-row range check, so it may only use ranges the library computed itself.  A caller-declared range (plx_column_set_bounds) that is
+    too tight must not change a sum (round-3 advisor finding: values were truncated silently)."""
+    from polars_amd import queries
+    rng = np.random.default_rng(47)
+    n = 17_000_000
+    key = rng.integers(0, 300_000, n).astype(np.int64)
+    v = rng.integers(0, 1 << 40, n).astype(np.int64)
+    sv = pl.Series("v", v)
+    pl._ffi.check(pl._ffi.lib().plx_column_set_bounds(sv._h, 0, 999))       # a lie: the values span 2^40
+    out = queries.cfg3(pl.DataFrame([pl.Series("key", key), sv]).lazy()).collect(); plan = pl.last_plan()
+    assert "partitioned(" in plan and "pack=0" in plan, plan
+    o = np.argsort(out["key"].to_numpy())
+    want = np.zeros(300_000, np.int64); np.add.at(want, key, v)
+    present = np.nonzero(np.bincount(key, minlength=300_000))[0]
+    assert np.array_equal(out["key"].to_numpy()[o], present) and np.array_equal(out["v_sum"].to_numpy()[o], want[present])
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_q3_three_tables(pl, orc, fused):
     """TPC-H Q3 with customer: the dictionary compare c_mktsegment == "BUILDING", customer x orders
