@@ -1589,7 +1589,36 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   if (fl[0]) return no("build keys are not unique");
   PLX_REQUIRE(!fl[1], PLX_ERR_OOM, "join build: probe sequence overflow");
   k::init_agg_cells(acc->as<uint64_t>(), (int64_t)cap + 1, cp.shape);
-  k::fused_probe_agg(cp.shape, cp.args, t, probe_static_id);
+  // Probe.  A table beyond the caches (64 MB) probed by a much longer relation: every probe row would fetch a line across the fabric (SF100 Q3 on keys without
+  // a dense range: 3.2e8 random probes of a 400 MB table).  The probe side is partitioned by the key's HASH instead and each partition is tested against an
+  // LDS Bloom filter of the table's keys in it (k::partitioned_hash_probe_hits: the radix-partitioned probe of single_keys_inner.rs:11-149 with the partition's
+  // filter in LDS); the hash probe below then runs over the surviving candidates only and compares whole keys.
+  std::string hprobe_how = "probe_agg";
+  bool hprobed = false;
+  {
+    const int pmode = partitioned_probe_mode();
+    if (pmode == 2 || (pmode == 1 && P->height >= ((int64_t)1 << 24) && (cap + 1) * 12 > ((uint64_t)64 << 20) && nb * 16 <= (uint64_t)P->height)) {
+      ColumnPtr hits;
+      std::string pd;
+      if (k::partitioned_hash_probe_hits(cs.shape, cs.args, t, nb, find_static_shape(cs.shape), &hits, &pd)) {
+        if (hits->len > 0) {
+          Args a2 = cp.args;
+          a2.n_rows = hits->len;
+          std::vector<ColumnPtr> keep;
+          for (int i = 0; i < cp.shape.n_inputs; i++) {
+            ColumnPtr g = ops::gather(cp.cols[cp.input_cols[i]], hits);
+            a2.in[i].values = g->data(); a2.in[i].validity = cp.shape.in_nullable[i] ? g->valid_words() : nullptr;
+            keep.push_back(g);
+          }
+          k::fused_probe_agg(cp.shape, a2, t, probe_static_id);
+          PLX_HIP(hipStreamSynchronize(stream()));       // the gathered columns live until the kernel has read them
+        }
+        hprobe_how = pd + "+gather+probe_agg";
+        hprobed = true;
+      }
+    }
+  }
+  if (!hprobed) k::fused_probe_agg(cp.shape, cp.args, t, probe_static_id);
   G = k::join_agg_compact(t, r.n_aggs, len_idx, nullptr, nullptr, nullptr);
   r.n_groups = G;
   const int64_t g1 = std::max<int64_t>(G, 1);
@@ -1598,7 +1627,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   rows->len = G; rows->values = dev_alloc(values_bytes(PLX_U32, g1));
   if (G) k::join_agg_compact(t, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
   plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " hash table cap=2^" + std::to_string(log2_cap) +
-               " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+probe_agg, aggs=" + std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
+               " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+" + hprobe_how + ", aggs=" + std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
   }  // hash-table path
   // ---- output frame: keys, then aggregates
   out = std::make_shared<Frame>();

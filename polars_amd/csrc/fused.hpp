@@ -357,7 +357,9 @@ struct PartPlan2 {
   int64_t src_base[kMaxSrc];   // packing: value a kind-3 source is stored relative to
   int64_t key_base;            // direct mode: the dense id is key - key_base (0: the program already produces dense ids)
   uint32_t oob_drop;           // direct mode: 1 = rows whose id lies outside the partitions are dropped (join probe: such keys match nothing); 0 = the query fails
+  uint32_t hash_bits;          // direct mode, join probe on keys WITHOUT a usable range: the "dense id" is the top hash_bits bits of key * kP2HashMult (0: key - key_base)
 };
+constexpr unsigned long long kP2HashMult = 0x9e3779b97f4a7c15ull;   // odd: key -> key * kP2HashMult is a bijection on 64-bit keys
 // which packing a shape admits at all (the planner still has to check the value ranges): kPackFused / kPackNarrow / kPackNone
 PLX_FHD constexpr uint32_t best_static_pack(const Shape& sh, uint32_t mode) {
   const RecLayout2 L = rec_layout2(sh, mode, kPackNarrow);

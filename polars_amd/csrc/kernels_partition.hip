@@ -601,19 +601,37 @@ __device__ __forceinline__ uint32_t bloom_pos(uint32_t low, uint32_t i, uint32_t
   constexpr uint32_t mult[kBloomK] = {0x9e3779b1u, 0x85ebca77u, 0xc2b2ae3du, 0x27d4eb2fu};
   return ((low + 1u) * mult[i]) >> (32u - log2_bits);
 }
+// Keys WITHOUT a usable range (hash_bits != 0; `bits` is null): the build side is an open-addressing hash table in HBM (JoinAggTable); its occupied slots
+// were sorted by the partition of their key's hash (slot lists bl_ids[bl_off[p] .. bl_off[p + 1])), the prologue reads the partition's keys and puts the low
+// key_shift bits of their hashed ids -- what the records carry -- into the Bloom filter.  Everything after the prologue is the same.
+struct ProbeHashedBuild {
+  const unsigned long long* table_keys;    // [cap + 1] keys of the build table (slot `cap` = the key whose bits equal kEmptyKey, listed only when a build row holds it)
+  const unsigned long long* bl_off;        // [NP + 1]
+  const unsigned int* bl_ids;              // occupied table slots grouped by partition
+  uint32_t hash_bits;                      // 0: the bitmap source
+};
 __global__ __launch_bounds__(kP2AggBlock) void probe_pass_kernel(const unsigned int* __restrict__ recs, const unsigned int* __restrict__ chunk_fill, const unsigned long long* __restrict__ cl_off,
                                                                  const unsigned int* __restrict__ cl_ids, const unsigned long long* __restrict__ bits, unsigned long long range,
-                                                                 unsigned long long n_words, uint32_t key_shift, uint32_t log2_bloom_bits, uint32_t exact,
+                                                                 unsigned long long n_words, uint32_t key_shift, uint32_t log2_bloom_bits, uint32_t exact, ProbeHashedBuild hb,
                                                                  unsigned int* __restrict__ hits /* a region of (chunks x 256) slots per partition */, unsigned int* __restrict__ part_hits) {
   extern __shared__ unsigned long long lds_raw[];
   unsigned int* bloom = reinterpret_cast<unsigned int*>(lds_raw);          // exact != 0: the slice itself (it fits), bit = key low bits
   __shared__ unsigned int wg_hits;
   const uint32_t p = blockIdx.x;
-  const uint32_t W = 1u << (key_shift - 6);                                // 64-bit words of the slice
+  const uint32_t W = hb.hash_bits ? 0u : 1u << (key_shift - 6);           // 64-bit words of the slice
   const uint32_t bloom_words = 1u << (log2_bloom_bits - 5);
   if (threadIdx.x == 0) wg_hits = 0;
   for (uint32_t i = threadIdx.x; i < bloom_words; i += blockDim.x) bloom[i] = 0;
   __syncthreads();
+  if (hb.hash_bits) {
+    const uint32_t tag_mask = key_shift >= 32 ? 0xffffffffu : (1u << key_shift) - 1u;
+    for (unsigned long long j = hb.bl_off[p] + threadIdx.x; j < hb.bl_off[p + 1]; j += blockDim.x) {
+      const unsigned long long key = hb.table_keys[hb.bl_ids[j]];
+      const uint32_t low = (uint32_t)((key * kP2HashMult) >> (64u - hb.hash_bits)) & tag_mask;
+#pragma unroll
+      for (uint32_t q = 0; q < kBloomK; q++) { const uint32_t pos = bloom_pos(low, q, log2_bloom_bits); atomicOr(&bloom[pos >> 5], 1u << (pos & 31u)); }
+    }
+  }
   for (uint32_t i = threadIdx.x; i < W; i += blockDim.x) {
     const unsigned long long wi = (unsigned long long)p * W + i;
     unsigned long long w = wi < n_words ? bits[wi] : 0ull;
@@ -634,7 +652,7 @@ __global__ __launch_bounds__(kP2AggBlock) void probe_pass_kernel(const unsigned 
   // arrived, so loading id and records in the same step made every step wait for two dependent memory round trips (3 us per chunk).
   unsigned long long ra[kPerLane], rb[kPerLane], rc[kPerLane];             // raw 8-B records {key_low | row << key_shift}
   uint32_t fill_a = 0, fill_b = 0, fill_c = 0;
-  const uint32_t low_mask = (1u << key_shift) - 1u;
+  const uint32_t low_mask = key_shift >= 32 ? 0xffffffffu : (1u << key_shift) - 1u;
   auto load_id = [&](uint64_t j) -> uint32_t { return cl_ids[j < c_end ? j : c_end - 1]; };   // past the end: the last chunk again, ignored (fill 0)
   auto load_chunk = [&](uint64_t j, uint32_t id, unsigned long long* r, uint32_t& fill) __attribute__((always_inline)) {
     fill = j < c_end ? chunk_fill[id] : 0u;
@@ -651,7 +669,7 @@ __global__ __launch_bounds__(kP2AggBlock) void probe_pass_kernel(const unsigned 
 #pragma unroll
     for (uint32_t u = 0; u < kPerLane; u++) {
       const uint32_t i = (uint32_t)lane + u * 64u;
-      bool pos = i < fill && (((unsigned long long)p << key_shift) | lo[u]) < range;
+      bool pos = i < fill && (hb.hash_bits || (((unsigned long long)p << key_shift) | lo[u]) < range);
       if (exact) pos = pos && ((bloom[lo[u] >> 5] >> (lo[u] & 31u)) & 1u);
       else {
 #pragma unroll
@@ -697,11 +715,28 @@ __global__ __launch_bounds__(kBlock) void probe_hits_compact_kernel(const unsign
   for (uint32_t i = threadIdx.x; i < part_hits[p]; i += blockDim.x) dst[i] = src[i];
 }
 
-bool partitioned_probe_hits(const Shape& sh, const Args& args, const DirectJoinTable& dt, uint64_t n_build, int static_id, ColumnPtr* hits_out, std::string* desc) {
+// slot s of the build hash table -> the partition of its key's hashed id (kNoChunk: free slot).  Slot `cap` stands for the key whose bits equal kEmptyKey
+// (JoinBuildSink: head[cap] holds its row, keys[cap] keeps the EMPTY pattern -- which IS that key).
+__global__ __launch_bounds__(kBlock) void table_slot_parts_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ head, int64_t cap, uint32_t hash_bits,
+                                                                  uint32_t key_shift, unsigned int* __restrict__ part) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= cap; s += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long k = keys[s];
+    const bool used = s == cap ? head[cap] != kNoRow32 : k != kEmptyKey;
+    part[s] = used ? (unsigned int)(((k * kP2HashMult) >> (64u - hash_bits)) >> key_shift) : kNoChunk;
+  }
+}
+
+// dt: the direct-address bitmap of the build side (keys with a dense range); ht: the build side's open-addressing hash table (keys without one: partition and
+// record tag come from the key's hash, kP2HashMult).  Exactly one of them is given.
+static bool probe_hits_impl(const Shape& sh, const Args& args, const DirectJoinTable* dtp, const JoinAggTable* ht, uint64_t n_build, int static_id, ColumnPtr* hits_out, std::string* desc) {
   if (args.n_rows >= (int64_t)0xfffffff0ll || sh.n_aggs != 1 || sh.aggs[0].kind != AGG_FIRST_ROW || sh.key == kNone || sh.n_keys) return false;
-  const uint32_t bits_total = std::max<uint32_t>(ceil_log2(dt.range), 15);
+  const bool hashed = ht != nullptr;
+  constexpr uint32_t kHashBits = 39;                                           // 8 partition bits + a 31-bit tag: the record is tag | row << 31
+  const DirectJoinTable dt = dtp ? *dtp : DirectJoinTable{};
+  const uint32_t bits_total = hashed ? kHashBits : std::max<uint32_t>(ceil_log2(dt.range), 15);
   PartPlan2 pp{};
-  pp.mode = kP2Direct; pp.gen = 3; pp.pack = kPackRowid; pp.n_hot = 0; pp.hot_copies = 1; pp.len_idx = 0; pp.oob_drop = 1; pp.key_base = dt.kmin;
+  pp.mode = kP2Direct; pp.gen = 3; pp.pack = kPackRowid; pp.n_hot = 0; pp.hot_copies = 1; pp.len_idx = 0; pp.oob_drop = 1; pp.key_base = hashed ? 0 : dt.kmin;
+  pp.hash_bits = hashed ? kHashBits : 0u;
   pp.log2_parts = std::min<uint32_t>(8, bits_total - 9);                       // 256 partitions (the scatter's best geometry: 8192-row tiles), slices of >= 2^9 keys
   if (pp.log2_parts < 6) return false;
   pp.key_shift = bits_total - pp.log2_parts; pp.log2_slots = pp.key_shift;
@@ -715,10 +750,10 @@ bool partitioned_probe_hits(const Shape& sh, const Args& args, const DirectJoinT
   if (!tiles) return false;
   plan2_geometry(pp, args.n_rows, tiles);
   // LDS of the probe pass: the partition's bitmap slice itself when it fits (exact), else a Bloom filter of 2^20 bits (128 KB)
-  const bool exact = pp.key_shift <= 20;
+  const bool exact = !hashed && pp.key_shift <= 20;
   const uint32_t log2_bloom = exact ? std::max<uint32_t>(pp.key_shift, 6) : 20;
   // a Bloom filter of 2^20 bits with 4 probes stays under ~2 % false positives up to 2^17 keys: denser slices would flood the caller with candidates
-  if (!exact && (double)n_build * (double)((uint64_t)1 << pp.key_shift) / (double)dt.range > (double)(1u << 17)) return false;
+  if (!exact && (hashed ? (double)n_build / (double)NP : (double)n_build * (double)((uint64_t)1 << pp.key_shift) / (double)dt.range) > (double)(1u << 17)) return false;
   const jit::Sink jk = jit::part3_scatter_sink(pp.mode, pp.tiles, pp.pack, false);
 #ifdef PLX_HAVE_Q3_PROBE_SCATTER
   const bool aot = static_id == SHAPE_Q3_PROBE_SCATTER && pp.tiles == 4;       // TPC-H Q3's probe side (two- and three-table variants share it)
@@ -735,7 +770,7 @@ bool partitioned_probe_hits(const Shape& sh, const Args& args, const DirectJoinT
   ScatterParams2 sp{};
   sp.recs = recs->as<unsigned int>(); sp.chunk_part = chunk_part->as<unsigned int>(); sp.chunk_fill = chunk_fill->as<unsigned int>(); sp.flags = meta->as<unsigned int>() + 3;
   {
-    const std::string name = aot ? "probe_scatter[#" + std::to_string(static_id) + ",d,t4,p3]" : std::string("probe_scatter[jit]");
+    const std::string name = aot ? "probe_scatter[#" + std::to_string(static_id) + (hashed ? ",d,t4,p3,h]" : ",d,t4,p3]") : std::string(hashed ? "probe_scatter[jit,h]" : "probe_scatter[jit]");
     ProfileScope ps(name.c_str(), scan_bytes(sh, args) + (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
     const size_t slds = part3_scatter_lds(pp.block * kRows * pp.tiles, pp.rec_words, NP, 0, 0, sh.n_aggs, 1);
     if (aot) {
@@ -765,11 +800,31 @@ bool partitioned_probe_hits(const Shape& sh, const Args& args, const DirectJoinT
   hits->dtype = PLX_U32; hits->null_count = 0;
   Buf regions = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks * kP2ChunkRecs + 16);          // a slot per record a partition may hold
   Buf part_hits = dev_alloc_zero(sizeof(uint32_t) * (NP + 1)), hit_off = dev_alloc(sizeof(uint64_t) * (NP + 2));
+  // hashed build side: the occupied slots of its hash table, grouped by the partition of their key (the counting sort of the chunk lists, over table slots)
+  ProbeHashedBuild hb{};
+  Buf bl_part, bl_counts, bl_cursor, bl_off, bl_ids;
+  if (hashed) {
+    const int64_t n_slots = ((int64_t)1 << ht->log2_cap) + 1;                  // + slot `cap`: the key equal to kEmptyKey
+    bl_part = dev_alloc(sizeof(uint32_t) * (size_t)n_slots);
+    bl_counts = dev_alloc_zero(sizeof(uint32_t) * (NP + 1)); bl_cursor = dev_alloc_zero(sizeof(uint32_t) * (NP + 1));
+    bl_off = dev_alloc(sizeof(uint64_t) * (NP + 2)); bl_ids = dev_alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1));
+    ProfileScope ps("probe_build_slot_lists", (uint64_t)n_slots * 16, (uint64_t)n_slots);
+    hipLaunchKernelGGL(table_slot_parts_kernel, dim3(grid_for(n_slots, kBlock * 8)), dim3(kBlock), 0, stream(), ht->keys, ht->head, n_slots - 1, pp.hash_bits, pp.key_shift, bl_part->as<unsigned int>());
+    PLX_HIP(hipGetLastError());
+    const int g = grid_for(n_slots, kBlock * 16, 2);
+    hipLaunchKernelGGL(chunk_hist_kernel, dim3(g), dim3(kBlock), sizeof(unsigned int) * NP, stream(), bl_part->as<unsigned int>(), n_slots, NP, bl_counts->as<unsigned int>());
+    PLX_HIP(hipGetLastError());
+    exclusive_scan_u32(bl_counts->as<uint32_t>(), bl_off->as<uint64_t>(), NP);
+    hipLaunchKernelGGL(chunk_place_kernel, dim3(g), dim3(kBlock), sizeof(unsigned int) * NP * 2, stream(), bl_part->as<unsigned int>(), n_slots, NP,
+                       bl_off->as<unsigned long long>(), bl_cursor->as<unsigned int>(), bl_ids->as<unsigned int>());
+    PLX_HIP(hipGetLastError());
+    hb.table_keys = ht->keys; hb.bl_off = bl_off->as<unsigned long long>(); hb.bl_ids = bl_ids->as<unsigned int>(); hb.hash_bits = pp.hash_bits;
+  }
   {
-    ProfileScope ps("probe_pass_lds_bitmap", (uint64_t)args.n_rows * pp.rec_words * 4 + dt.range / 8, (uint64_t)args.n_rows);
-    const unsigned long long n_words = (dt.range / 512 + 1) * 8;
+    ProfileScope ps(hashed ? "probe_pass_lds_bloom_hashed" : "probe_pass_lds_bitmap", (uint64_t)args.n_rows * pp.rec_words * 4 + (hashed ? n_build * 12 : dt.range / 8), (uint64_t)args.n_rows);
+    const unsigned long long n_words = hashed ? 0ull : (dt.range / 512 + 1) * 8;
     hipLaunchKernelGGL(probe_pass_kernel, dim3(NP), dim3(kP2AggBlock), ((size_t)1 << (log2_bloom - 3)), stream(), recs->as<unsigned int>(), chunk_fill->as<unsigned int>(),
-                       cl_off->as<unsigned long long>(), cl_ids->as<unsigned int>(), dt.bits, dt.range, n_words, pp.key_shift, log2_bloom, exact ? 1u : 0u,
+                       cl_off->as<unsigned long long>(), cl_ids->as<unsigned int>(), hashed ? nullptr : dt.bits, hashed ? 0ull : dt.range, n_words, pp.key_shift, log2_bloom, exact ? 1u : 0u, hb,
                        regions->as<unsigned int>(), part_hits->as<unsigned int>());
     PLX_HIP(hipGetLastError());
     exclusive_scan_u32(part_hits->as<uint32_t>(), hit_off->as<uint64_t>(), NP);              // hit_off[NP] = total
@@ -787,9 +842,18 @@ bool partitioned_probe_hits(const Shape& sh, const Args& args, const DirectJoinT
     PLX_HIP(hipGetLastError());
   }
   *hits_out = hits;
-  if (desc) *desc = "partitioned_probe(P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec_words * 4) + "B,tile=" + std::to_string(pp.block * kRows * pp.tiles) + (exact ? ",lds_bitmap=" : ",lds_bloom=") + std::to_string(((size_t)1 << (log2_bloom - 3)) >> 10) +
+  if (desc) *desc = std::string(hashed ? "partitioned_hash_probe(P=" : "partitioned_probe(P=") + std::to_string(NP) + ",rec=" + std::to_string(pp.rec_words * 4) + "B,tile=" + std::to_string(pp.block * kRows * pp.tiles) + (exact ? ",lds_bitmap=" : ",lds_bloom=") + std::to_string(((size_t)1 << (log2_bloom - 3)) >> 10) +
                     "KB,candidates=" + std::to_string(hits->len) + ")";
   return true;
+}
+
+bool partitioned_probe_hits(const Shape& sh, const Args& args, const DirectJoinTable& dt, uint64_t n_build, int static_id, ColumnPtr* hits_out, std::string* desc) {
+  return probe_hits_impl(sh, args, &dt, nullptr, n_build, static_id, hits_out, desc);
+}
+// The same for a build side WITHOUT a dense key range (its open-addressing hash table `ht`, already built): rows -> partitions and 31-bit tags by the key's hash,
+// per-partition Bloom filters in LDS from the table's keys; the candidates then go through the ordinary hash probe (fused_probe_agg), which compares whole keys.
+bool partitioned_hash_probe_hits(const Shape& sh, const Args& args, const JoinAggTable& ht, uint64_t n_build, int static_id, ColumnPtr* hits_out, std::string* desc) {
+  return probe_hits_impl(sh, args, nullptr, &ht, n_build, static_id, hits_out, desc);
 }
 
 // ---- is a key column (roughly) sorted?  fraction of non-decreasing adjacent pairs over 64 evenly spaced runs of 1024 rows ----------------

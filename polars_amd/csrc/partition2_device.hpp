@@ -72,7 +72,8 @@ __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, c
   kvalid = (rf.getv(sh.key) >> r) & 1;
   key64 = kvalid ? rf.get(r, sh.key) : 0ull;
   if constexpr (MODE == (int)kP2Direct) {
-    const uint64_t id = key64 - (uint64_t)pp.key_base;
+    // (wave-uniform branch) keys without a usable range -- the hashed partitioned probe: partition and record carry bits of the key's hash instead
+    const uint64_t id = pp.hash_bits ? (key64 * kP2HashMult) >> (64u - pp.hash_bits) : key64 - (uint64_t)pp.key_base;
     const uint64_t hi = id >> pp.key_shift;
     part = hi > 0xfffffffeull ? 0xfffffffeu : (uint32_t)hi;           // far outside the id range: still "outside" after the narrowing
     rec[0] = (uint32_t)id & ((1u << pp.key_shift) - 1u);

@@ -1,0 +1,127 @@
+"""The radix-partitioned join probe (kernels_partition.hip: partitioned_probe_hits / partitioned_hash_probe_hits): probe rows partitioned by key range
+(build keys with a dense range: LDS bitmap slices) or by the key's hash (64-bit keys without one: LDS Bloom filters of the build hash table's keys), the
+ordinary probe over the surviving candidates.  Reference: crates/polars-ops/src/frame/join/hash_join/single_keys.rs:16-167, single_keys_inner.rs:11-149."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HASH_MULT = np.uint64(0x9E3779B97F4A7C15)      # odd: k -> k * HASH_MULT mod 2^64 is a bijection (bench.py's hashed-key Q3 uses the same)
+
+
+def hashed(a):
+    return (a.astype(np.uint64) * HASH_MULT).astype(np.int64)
+
+
+def close(a, b):
+    return np.allclose(np.array(a, dtype=np.float64), np.array(b, dtype=np.float64), rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("ordered", [False, True])
+def test_q3_partitioned_probe_matches_the_oracle(pl, orc, monkeypatch, ordered):
+    """TPC-H Q3 with the probe side radix-partitioned by key range and probed against LDS-resident bitmap slices (forced: the planner
+    only picks it for unordered keys over bitmaps far larger than an L2).  Same groups, same sums as the oracle and as the direct probe.
+    Reference: crates/polars-ops/src/frame/join/hash_join/single_keys_inner.rs:11-149 (partitioned probe_inner)."""
+    from polars_amd import datagen, queries
+    orders, li = datagen.orders_lineitem_host(1_200_000, seed=31, ordered=ordered)
+    assert len(li["l_orderkey"]) >= 1 << 22                     # the scatter's program is JIT-compiled: inputs below 2^22 rows would not take the path
+    L = datagen.to_frame(pl, li, datagen.LINEITEM_Q3_COLS)
+    O = datagen.to_frame(pl, orders, datagen.ORDERS_Q3_COLS)
+    exp = orc.q3({k: li[k] for k in datagen.LINEITEM_Q3_COLS}, {k: orders[k] for k in datagen.ORDERS_Q3_COLS}, datagen.us(1995, 3, 15))
+    monkeypatch.setenv("PLX_PROBE_PARTITIONED", "2")
+    out = queries.q3(L.lazy(), O.lazy()).collect()
+    plan = pl.last_plan()
+    assert "partitioned_probe(" in plan and "direct-address table" in plan, plan
+    g = out.sort_host("l_orderkey")
+    assert g["l_orderkey"] == exp["l_orderkey"].tolist(), plan
+    assert g["o_orderdate"] == exp["o_orderdate"].tolist() and g["o_shippriority"] == exp["o_shippriority"].tolist()
+    assert close(g["revenue"], exp["revenue"])
+    monkeypatch.setenv("PLX_PROBE_PARTITIONED", "0")
+    out0 = queries.q3(L.lazy(), O.lazy()).collect()
+    assert "partitioned_probe(" not in pl.last_plan()
+    g0 = out0.sort_host("l_orderkey")
+    assert g0["l_orderkey"] == g["l_orderkey"] and close(g0["revenue"], g["revenue"])
+
+
+def test_partitioned_probe_null_and_out_of_range_probe_keys(pl, monkeypatch):
+    """Probe keys that are null, below the build key range or above it match nothing (and must not fail the query); a probe key equal to
+    the smallest / largest build key matches."""
+    rng = np.random.default_rng(9)
+    nb, n = 200_000, (1 << 22) + 12345
+    bkey = (np.arange(nb, dtype=np.int64) * 7 + 1000)
+    battr = rng.integers(0, 100, nb).astype(np.int64)
+    pkey = rng.integers(0, nb * 7 + 3000, n).astype(np.int64)            # below 1000 and above the largest build key: out of range
+    pkey[:4] = [bkey[0], bkey[-1], bkey[0] - 1, bkey[-1] + 1]
+    valid = rng.random(n) > 0.05
+    x = rng.integers(-50, 50, n).astype(np.int64)
+    B = pl.DataFrame({"k": bkey, "a": battr})
+    P = pl.DataFrame([pl.Series("k", pkey, validity=valid), pl.Series("x", x)])
+    c = pl.col
+    q = lambda: P.lazy().join(B.lazy(), on="k").group_by("k", "a").agg(c("x").sum().alias("sx"), pl.len().alias("n")).collect()
+    monkeypatch.setenv("PLX_PROBE_PARTITIONED", "2")
+    got = q()
+    assert "partitioned_probe(" in pl.last_plan(), pl.last_plan()
+    g = got.sort_host("k")
+    inb = valid & (pkey >= 1000) & ((pkey - 1000) % 7 == 0) & (pkey <= bkey[-1])
+    keys, inv = np.unique(pkey[inb], return_inverse=True)
+    assert g["k"] == keys.tolist()
+    assert g["sx"] == np.bincount(inv, weights=x[inb]).astype(np.int64).tolist() and g["n"] == np.bincount(inv).tolist()
+    assert g["a"] == battr[(keys - 1000) // 7].tolist()
+
+
+@pytest.mark.parametrize("ordered", [False, True])
+def test_q3_on_hashed_keys_takes_the_partitioned_hash_probe(pl, orc, monkeypatch, ordered):
+    """TPC-H Q3 with orderkey * 0x9E3779B97F4A7C15 mod 2^64 on both sides: no dense key range, so the build side is an open-addressing hash table; the probe
+    side is partitioned by the key's hash, filtered against per-partition LDS Bloom filters of the table's keys, and the hash probe runs over the candidates
+    (forced here: the planner picks it for tables beyond the caches).  Same groups and sums as the oracle and as the plain hash probe."""
+    from polars_amd import datagen, queries
+    orders, li = datagen.orders_lineitem_host(1_200_000, seed=33, ordered=ordered)
+    orders["o_orderkey"] = hashed(orders["o_orderkey"]); li["l_orderkey"] = hashed(li["l_orderkey"])
+    assert len(li["l_orderkey"]) >= 1 << 22
+    L = datagen.to_frame(pl, li, datagen.LINEITEM_Q3_COLS)
+    O = datagen.to_frame(pl, orders, datagen.ORDERS_Q3_COLS)
+    exp = orc.q3({k: li[k] for k in datagen.LINEITEM_Q3_COLS}, {k: orders[k] for k in datagen.ORDERS_Q3_COLS}, datagen.us(1995, 3, 15))
+    assert len(exp["l_orderkey"]) > 1000
+    monkeypatch.setenv("PLX_PROBE_PARTITIONED", "2")
+    out = queries.q3(L.lazy(), O.lazy()).collect()
+    plan = pl.last_plan()
+    assert "partitioned_hash_probe(" in plan and "hash table cap=" in plan, plan
+    g = out.sort_host("l_orderkey")
+    assert g["l_orderkey"] == exp["l_orderkey"].tolist(), plan
+    assert g["o_orderdate"] == exp["o_orderdate"].tolist() and g["o_shippriority"] == exp["o_shippriority"].tolist()
+    assert close(g["revenue"], exp["revenue"])
+    monkeypatch.setenv("PLX_PROBE_PARTITIONED", "0")
+    out0 = queries.q3(L.lazy(), O.lazy()).collect()
+    assert "partitioned_hash_probe(" not in pl.last_plan()
+    g0 = out0.sort_host("l_orderkey")
+    assert g0["l_orderkey"] == g["l_orderkey"] and close(g0["revenue"], g["revenue"])
+
+
+def test_partitioned_hash_probe_edge_keys(pl, monkeypatch):
+    """Sparse 64-bit build keys including the key whose bits equal the table's EMPTY pattern (-1), 0, the smallest and the largest Int64; null probe keys and
+    probe keys absent from the build side match nothing; the Bloom filters' false positives are removed by the final key compare."""
+    rng = np.random.default_rng(10)
+    nb, n = 300_000, (1 << 22) + 4321
+    bkey = np.unique(np.concatenate([rng.integers(-(1 << 62), 1 << 62, nb).astype(np.int64), np.array([-1, 0, np.iinfo(np.int64).min, np.iinfo(np.int64).max], np.int64)]))
+    battr = rng.integers(0, 100, len(bkey)).astype(np.int64)
+    pkey = np.where(rng.random(n) < 0.3, bkey[rng.integers(0, len(bkey), n)], rng.integers(-(1 << 62), 1 << 62, n).astype(np.int64))
+    pkey[:4] = [-1, 0, np.iinfo(np.int64).min, np.iinfo(np.int64).max]
+    valid = rng.random(n) > 0.05
+    valid[:4] = True
+    x = rng.integers(-50, 50, n).astype(np.int64)
+    B = pl.DataFrame({"k": bkey, "a": battr})
+    P = pl.DataFrame([pl.Series("k", pkey, validity=valid), pl.Series("x", x)])
+    c = pl.col
+    q = lambda: P.lazy().join(B.lazy(), on="k").group_by("k", "a").agg(c("x").sum().alias("sx"), pl.len().alias("n")).collect()
+    monkeypatch.setenv("PLX_PROBE_PARTITIONED", "2")
+    got = q()
+    plan = pl.last_plan()
+    assert "partitioned_hash_probe(" in plan, plan
+    cand = int(plan.split("candidates=")[1].split(")")[0])
+    inb = valid & np.isin(pkey, bkey)
+    assert int(inb.sum()) <= cand <= int(inb.sum()) + int(0.05 * n), (cand, int(inb.sum()))       # every true match is a candidate; few false positives
+    g = got.sort_host("k")
+    keys, inv = np.unique(pkey[inb], return_inverse=True)
+    assert g["k"] == keys.tolist() and {-1, 0, int(np.iinfo(np.int64).min), int(np.iinfo(np.int64).max)} <= set(g["k"])
+    assert g["sx"] == np.bincount(inv, weights=x[inb]).astype(np.int64).tolist() and g["n"] == np.bincount(inv).tolist()
+    assert g["a"] == battr[np.searchsorted(bkey, keys)].tolist()
