@@ -757,6 +757,7 @@ constexpr int kSampleBlocks = 8;
 // rows the partitioned group-by samples per query (distinct-count estimate + heavy hitters): 2^20 strided rows cost ~0.15 ms at
 // 1e9 rows; a key is "hot" from 1/1024 of the sample up, i.e. 1024 occurrences
 constexpr int64_t kPartSampleRows = (int64_t)1 << 20;
+constexpr int64_t kHotFraction = 4096;
 static Args offset_args(const Shape& sh, const Args& a, int64_t row0, int64_t rows) {
   Args o = a;
   for (int i = 0; i < sh.n_inputs; i++) {
@@ -792,7 +793,9 @@ static int64_t sample_keys(const Shape& full, const Args& args, int static_id, i
   uint32_t o = 0; d2h_sync(&o, ovf->ptr, 4);
   if (o) return -1;
   uint64_t hot_rows = 0;
-  if (hot) k::select_hot_keys(t, sh.n_aggs, len_idx, (uint64_t)std::max<int64_t>(64, (per * kSampleBlocks) / 1024), hot, &hot_rows);
+  // a key is "hot" from 1/4096 of the sampled rows (256 of 2^20: a stable count) -- at 1e9 rows ~2.4e5 rows that would otherwise serialise on one LDS address
+  // in one aggregation workgroup (~0.5 ms); the kP2MaxHot heaviest are kept
+  if (hot) k::select_hot_keys(t, sh.n_aggs, len_idx, (uint64_t)std::max<int64_t>(64, (per * kSampleBlocks) / kHotFraction), hot, &hot_rows);
   const int64_t d = k::table_compact(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, nullptr, nullptr, nullptr);
   if (groups_est) {
     const double n_hot = hot ? (double)hot->size() : 0.0, s_rest = std::max(1.0, (double)(per * kSampleBlocks) - (double)hot_rows), d_rest = std::max(0.0, (double)d - n_hot);
@@ -1573,21 +1576,57 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       done = true;
     }
   }
-  if (!done && B->height > 0) { std::vector<uint64_t> host(kMaxAggs, 0); k::fused_regagg(cnt.shape, cnt.args, find_static_shape(cnt.shape), host.data()); nb = host[0]; }
+  // Size of the build table.  The number of build rows that pass the build side's predicate is a by-product of the build scan itself (JoinBuildSink counts what
+  // it inserts), so a large build side is sized from a strided sample of the count program (4 blocks of 2^18 rows, + 25 %) instead of a counting pass over the
+  // whole side; if the sample misjudged (table more than 0.7 full, or a probe sequence overflowed) the table is rebuilt once from the exact count.
+  auto exact_count = [&]() -> uint64_t { std::vector<uint64_t> host(kMaxAggs, 0); k::fused_regagg(cnt.shape, cnt.args, find_static_shape(cnt.shape), host.data()); return host[0]; };
+  bool sized_by_sample = false;
+  if (!done && B->height > 0) {
+    static const bool no_sample = getenv("PLX_JOIN_COUNT_SAMPLE") && getenv("PLX_JOIN_COUNT_SAMPLE")[0] == '0';
+    if (B->height >= ((int64_t)1 << 24) && !no_sample) {
+      constexpr int kCountBlocks = 4;                  // every block is a launch + a host round trip (~40 us)
+      const int64_t per = (int64_t)1 << 18, stride = (B->height / kCountBlocks) & ~(int64_t)127;
+      uint64_t hits = 0, seen = 0;
+      for (int b = 0; b < kCountBlocks; b++) {
+        const int64_t row0 = (int64_t)b * stride, rows_b = std::min<int64_t>(per, B->height - row0);
+        if (rows_b <= 0) continue;
+        std::vector<uint64_t> host(kMaxAggs, 0);
+        k::fused_regagg(cnt.shape, offset_args(cnt.shape, cnt.args, row0, rows_b), -1, host.data());
+        hits += host[0]; seen += (uint64_t)rows_b;
+      }
+      nb = (uint64_t)((double)hits / (double)std::max<uint64_t>(seen, 1) * (double)B->height * 1.25) + 4096;
+      sized_by_sample = true;
+    } else nb = exact_count();
+  }
   if (!done) {
-  const int log2_cap = std::max(4, ceil_log2_u64(std::max<uint64_t>(nb, 1) * 2));
-  const uint64_t cap = 1ull << log2_cap;
-  Buf keys = dev_alloc(sizeof(uint64_t) * (cap + 1)), head = dev_alloc(sizeof(uint32_t) * (cap + 1)), flags = dev_alloc_zero(16);
-  Buf acc = dev_alloc(sizeof(uint64_t) * (cap + 1) * cp.shape.n_aggs);
-  PLX_HIP(hipMemsetAsync(keys->ptr, 0xff, sizeof(uint64_t) * (cap + 1), stream()));
-  PLX_HIP(hipMemsetAsync(head->ptr, 0xff, sizeof(uint32_t) * (cap + 1), stream()));
-  JoinAggTable t; t.keys = keys->as<unsigned long long>(); t.head = head->as<unsigned int>(); t.flags = flags->as<unsigned int>(); t.acc = acc->as<unsigned long long>();
-  t.log2_cap = (uint32_t)log2_cap;
-  k::fused_join_build(cb.shape, cb.args, t, find_static_shape(cb.shape));
-  uint32_t fl[2] = {0, 0};
-  d2h_sync(fl, flags->ptr, 8);
-  if (fl[0]) return no("build keys are not unique");
-  PLX_REQUIRE(!fl[1], PLX_ERR_OOM, "join build: probe sequence overflow");
+  Buf keys, head, flags, acc;
+  JoinAggTable t{};
+  int log2_cap = 4;
+  uint64_t cap = 0;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    log2_cap = std::max(4, ceil_log2_u64(std::max<uint64_t>(nb, 1) * 2));
+    cap = 1ull << log2_cap;
+    keys = dev_alloc(sizeof(uint64_t) * (cap + 1)); head = dev_alloc(sizeof(uint32_t) * (cap + 1)); flags = dev_alloc_zero(32);
+    PLX_HIP(hipMemsetAsync(keys->ptr, 0xff, sizeof(uint64_t) * (cap + 1), stream()));
+    PLX_HIP(hipMemsetAsync(head->ptr, 0xff, sizeof(uint32_t) * (cap + 1), stream()));
+    t.keys = keys->as<unsigned long long>(); t.head = head->as<unsigned int>(); t.flags = flags->as<unsigned int>(); t.acc = nullptr;
+    t.count = flags->as<unsigned long long>() + 1; t.log2_cap = (uint32_t)log2_cap;
+    k::fused_join_build(cb.shape, cb.args, t, find_static_shape(cb.shape));
+    uint64_t fl64[2] = {0, 0};
+    d2h_sync(fl64, flags->ptr, 16);
+    const uint32_t dup = (uint32_t)fl64[0], ovf = (uint32_t)(fl64[0] >> 32);
+    if (dup) return no("build keys are not unique");
+    if (sized_by_sample && attempt == 0 && (ovf || fl64[1] * 10 > cap * 7)) {      // the sample misjudged: once more, from the exact count
+      nb = ovf ? exact_count() : fl64[1];
+      sized_by_sample = false;
+      continue;
+    }
+    PLX_REQUIRE(!ovf, PLX_ERR_OOM, "join build: probe sequence overflow");
+    nb = fl64[1];                                                                   // exact from here on
+    break;
+  }
+  acc = dev_alloc(sizeof(uint64_t) * (cap + 1) * cp.shape.n_aggs);
+  t.acc = acc->as<unsigned long long>();
   k::init_agg_cells(acc->as<uint64_t>(), (int64_t)cap + 1, cp.shape);
   // Probe.  A table beyond the caches (64 MB) probed by a much longer relation: every probe row would fetch a line across the fabric (SF100 Q3 on keys without
   // a dense range: 3.2e8 random probes of a 400 MB table).  The probe side is partitioned by the key's HASH instead and each partition is tested against an
@@ -1619,13 +1658,15 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     }
   }
   if (!hprobed) k::fused_probe_agg(cp.shape, cp.args, t, probe_static_id);
-  G = k::join_agg_compact(t, r.n_aggs, len_idx, nullptr, nullptr, nullptr);
-  r.n_groups = G;
-  const int64_t g1 = std::max<int64_t>(G, 1);
+  // ONE compaction pass into buffers sized for every build row (G <= nb): no counting pass over the table first
+  const int64_t g1 = std::max<int64_t>((int64_t)nb, 1);
   r.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)g1);
   r.acc = dev_alloc(sizeof(uint64_t) * (size_t)g1 * r.n_aggs);
-  rows->len = G; rows->values = dev_alloc(values_bytes(PLX_U32, g1));
-  if (G) k::join_agg_compact(t, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
+  rows->values = dev_alloc(values_bytes(PLX_U32, g1));
+  G = k::join_agg_compact(t, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
+  PLX_REQUIRE(G <= g1, PLX_ERR_INVALID, "join: more groups than build rows");
+  r.n_groups = G;
+  rows->len = G;
   plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " hash table cap=2^" + std::to_string(log2_cap) +
                " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+" + hprobe_how + ", aggs=" + std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
   }  // hash-table path

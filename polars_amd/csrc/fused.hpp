@@ -340,8 +340,9 @@ PLX_FHD constexpr RecLayout2 rec_layout2(const Shape& sh, uint32_t mode, uint32_
 struct PartPlan2 {
   uint32_t mode;               // kP2Hash | kP2Direct
   uint32_t log2_parts;         // P = 1 << log2_parts partitions
-  uint32_t log2_slots;         // slots of a partition's LDS table (direct mode: == key_shift)
-  uint32_t key_shift;          // direct mode: partition = id >> key_shift, table slot = id & ((1 << key_shift) - 1)
+  uint32_t log2_slots;         // slots of a partition's LDS table (direct mode: == key_shift; hash mode: 0 when n_slots is not a power of two)
+  uint32_t n_slots;            // hash mode: slots of the partition's LDS open-addressing table (any number: slot = mulhi(hash32, n_slots); + 2 special slots behind them)
+  uint32_t key_shift;          // direct mode: partition = id >> key_shift, table slot = id & ((1 << key_shift) - 1)  (interleave: see below; key_shift stays the slot bits)
   uint32_t ring_lines;         // 128-B lines of LDS staging per partition (power of two)
   uint32_t block;              // threads of a scatter workgroup
   uint32_t tiles;              // tiles each wave loads per round (template parameter of the scatter kernel)
@@ -357,9 +358,13 @@ struct PartPlan2 {
   int64_t src_base[kMaxSrc];   // packing: value a kind-3 source is stored relative to
   int64_t key_base;            // direct mode: the dense id is key - key_base (0: the program already produces dense ids)
   uint32_t oob_drop;           // direct mode: 1 = rows whose id lies outside the partitions are dropped (join probe: such keys match nothing); 0 = the query fails
+  uint32_t interleave;         // direct mode, group-by: partition = the id's LOW log2_parts bits, table slot = id >> log2_parts (ids are usually handed out in order of
+                               // first appearance or popularity -- dictionary codes, zipf-like keys: the high bits would put all popular ids into partition 0)
   uint32_t hash_bits;          // direct mode, join probe on keys WITHOUT a usable range: the "dense id" is the top hash_bits bits of key * kP2HashMult (0: key - key_base)
 };
-constexpr unsigned long long kP2HashMult = 0x9e3779b97f4a7c15ull;   // odd: key -> key * kP2HashMult is a bijection on 64-bit keys
+// the multiplier of the join hash tables' slot hash (JoinBuildSink / ProbeAggSink; the reference's DirtyHash, polars-utils/src/hashing.rs:62-69): the hashed
+// partitioned probe takes its partition from the SAME top bits, so partition p of the probe side meets exactly region p of the build table
+constexpr unsigned long long kP2HashMult = 0x55fbfd6bfc5458e9ull;
 // which packing a shape admits at all (the planner still has to check the value ranges): kPackFused / kPackNarrow / kPackNone
 PLX_FHD constexpr uint32_t best_static_pack(const Shape& sh, uint32_t mode) {
   const RecLayout2 L = rec_layout2(sh, mode, kPackNarrow);
@@ -432,6 +437,7 @@ struct JoinAggTable {
   unsigned int* flags;    // [0] = duplicate build key seen, [1] = probe sequence overflow
   unsigned long long* acc;
   uint32_t log2_cap;
+  unsigned long long* count;   // build: [0] += rows inserted (null: not wanted) -- the build side's row count after its predicate, a by-product of the build scan
 };
 
 // Direct-address ("perfect hash") variant of the fused join -> aggregate table, used when the build

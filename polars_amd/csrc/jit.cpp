@@ -112,7 +112,7 @@ std::string source_for(const Shape& sh, Sink sink) {
         break;
       }
       if (sink >= PART3_SCATTER) {
-        const int v = (int)sink - (int)PART3_SCATTER, mode = v & 1, tiles = 1 << ((v >> 1) % 3), pack = (v / 6) % 4, hot = v / 24;
+        const int v = (int)sink - (int)PART3_SCATTER, mode = v & 1, tiles = 1 + ((v >> 1) & 3), pack = (v >> 3) & 3, hot = v >> 5;
         o << "extern \"C\" __global__ __launch_bounds__(kP2MaxBlock) void plx_jit_kernel(Shape dsh, Args args, PartPlan2 pp, ScatterParams2 sp) {\n"
              "  part3_scatter_body<JitProg, " << mode << ", " << tiles << ", " << pack << ", " << (hot ? "true" : "false") << ">(dsh, args, pp, sp);\n}\n}}\n";
         break;

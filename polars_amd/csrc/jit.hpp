@@ -23,11 +23,11 @@ enum Sink { REGAGG = 0, LDSAGG, DENSE, HASH, WIDE, JOIN_BUILD, PROBE_AGG, DIRECT
             // second generation (partition2_device.hpp)
             PART2_SCATTER_HASH, PART2_SCATTER_DIRECT, PART2_AGG_HASH, PART2_AGG_DIRECT,
             PART2_SCATTER_HASH_T2, PART2_SCATTER_DIRECT_T2,      // two tiles per wave and round
-            // third generation scatter (partition3_device.hpp): PART3_SCATTER + mode + 2 * log2(tiles) + 6 * pack (18 kinds), and the
-            // aggregation pass over packed records: PART3_AGG + mode + 2 * pack (6 kinds)
-            PART3_SCATTER, PART3_AGG = PART3_SCATTER + 48,     // scatter: ... + 24 * (hot-key path compiled in); pack 0..3
-            kNumSinks = PART3_AGG + 6 };
-inline Sink part3_scatter_sink(uint32_t mode, uint32_t tiles, uint32_t pack, bool hot) { return (Sink)(PART3_SCATTER + mode + 2 * (tiles == 4 ? 2 : tiles == 2 ? 1 : 0) + 6 * pack + (hot ? 24 : 0)); }
+            // third generation scatter (partition3_device.hpp): PART3_SCATTER + mode + 2 * (tiles - 1) + 8 * pack (tiles 1..4, pack 0..3: 32 kinds), and the
+            // aggregation pass over packed records: PART3_AGG + mode + 2 * pack (8 kinds)
+            PART3_SCATTER, PART3_AGG = PART3_SCATTER + 64,     // scatter: ... + 32 * (hot-key path compiled in)
+            kNumSinks = PART3_AGG + 8 };
+inline Sink part3_scatter_sink(uint32_t mode, uint32_t tiles, uint32_t pack, bool hot) { return (Sink)(PART3_SCATTER + mode + 2 * (tiles - 1) + 8 * pack + (hot ? 32 : 0)); }
 inline Sink part3_agg_sink(uint32_t mode, uint32_t pack) { return (Sink)(PART3_AGG + mode + 2 * pack); }
 
 bool launch(const fused::Shape& sh, const fused::Args& args, Sink sink, const void* params, int grid, size_t lds_bytes);

@@ -231,8 +231,9 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
   for (int j = 0; j < kMaxSrc; j++) pp.src_base[j] = (pack != kPackNone && ranges && ranges[j].known && (L.src_kind[j] == 3 || pack == kPackFused)) ? ranges[j].mn : 0;
   const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0;
   uint32_t tiles = 0;
-  for (uint32_t t : {4u, 2u, 1u}) {
+  for (uint32_t t : {4u, 3u, 2u, 1u}) {
     if (kEnvP2Tiles > 0 && t > (uint32_t)kEnvP2Tiles) continue;
+    if (pp.mode == kP2Hash && t > 3) continue;      // hash partitions keep the 64-bit key and its hash live: four tiles spill (24 B / lane; a scratch reload waits for every load in flight)
     if (part3_scatter_lds(kP2MaxBlock * kRows * t, L.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies) <= lds_total) { tiles = t; break; }
   }
   if (!tiles) return false;
@@ -260,24 +261,26 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
     if (shift > (int)max_shift) shift = (int)max_shift;
     if (shift < 6) shift = 6;
     const int lp = packed_bits - shift;
-    if (lp >= 4 && lp <= 9) { direct = true; pp.mode = kP2Direct; pp.key_shift = (uint32_t)shift; pp.log2_slots = (uint32_t)shift; pp.log2_parts = (uint32_t)lp; }
+    if (lp >= 4 && lp <= 9) {
+      direct = true; pp.mode = kP2Direct; pp.key_shift = (uint32_t)shift; pp.log2_slots = (uint32_t)shift; pp.log2_parts = (uint32_t)lp;
+      static const bool no_interleave = getenv("PLX_PART_INTERLEAVE") && getenv("PLX_PART_INTERLEAVE")[0] == '0';
+      pp.interleave = no_interleave ? 0u : 1u;
+    }
   }
   if (!direct) {
     pp.mode = kP2Hash;
-    uint32_t log2_slots = 14;
-    auto tbl_bytes = [&](uint32_t ls) { return (((size_t)1 << ls) + 2) * 8 * (1 + sh.n_aggs); };
-    while (log2_slots > 8 && tbl_bytes(log2_slots) > 144 * 1024) log2_slots--;
-    if (tbl_bytes(log2_slots) > 144 * 1024) return false;
-    const double per_part = (double)(1u << log2_slots) * 0.62;     // LDS table load <= ~0.62 (the caller passes 1.3 x its estimate)
+    // LDS open-addressing table of a partition: keys + cells, ANY number of slots (slot = mulhi(hash32, n_slots)), as many as 144 KB hold.  Fewer partitions
+    // make the scatter faster (its per-round cost is per partition: 256 partitions of 16-byte records move two lines per partition and round, 512 one), so the
+    // smallest partition count whose tables stay at or below a load of 0.85 x the caller's padded estimate (it passes 1.3 x its own: a real load of ~0.65).
+    const uint32_t n_slots = (uint32_t)std::min<size_t>((144 * 1024) / (8 * (1 + (size_t)sh.n_aggs)) - 2, (size_t)1 << 14);
+    if (n_slots < 256) return false;
+    const double per_part = (double)n_slots * 0.85;
     uint32_t lp = 6;
     while (lp < 9 && (double)(1u << lp) * per_part < est_groups) lp++;
-    // more than 512 partitions: the rings would not fit the LDS.  The estimate already carries the caller's 1.3x, so at 512 partitions
-    // a table load of up to 0.8 is accepted before giving up (1e6 groups sit exactly on the 0.62 boundary: whether the sample's
-    // estimate came out at 0.999e6 or 1.001e6 must not decide which generation of kernels runs); a table that does fill up is
-    // reported by the aggregation pass and the caller falls back
-    if ((double)(1u << lp) * per_part < est_groups && (lp < 9 || (double)(1u << lp) * (double)(1u << log2_slots) * 0.8 < est_groups)) return false;
+    // more than 512 partitions: the carry lines would not fit the LDS.  A table that does fill up is reported by the aggregation pass and the caller falls back
+    if ((double)(1u << lp) * per_part < est_groups && (double)(1u << lp) * (double)n_slots * 0.95 < est_groups) return false;
     if (kEnvLog2Parts > (int)lp && kEnvLog2Parts <= 9) lp = (uint32_t)kEnvLog2Parts;
-    pp.log2_parts = lp; pp.log2_slots = log2_slots; pp.key_shift = 0;
+    pp.log2_parts = lp; pp.n_slots = n_slots; pp.log2_slots = 0; pp.key_shift = 0;
   }
   const RecLayout2 L = rec_layout2(sh, pp.mode);
   if (L.n_src > (uint32_t)kMaxSrc || L.rec_words > 13) return false;
@@ -415,9 +418,9 @@ __global__ __launch_bounds__(kBlock) void hot_emit_kernel(const unsigned long lo
 // the value narrowed to a u32 offset, 4 B with key_low and value fused into one dword.  config 5 (u32 dictionary codes, Float64 value): 12 B.
 #ifdef PLX_HAVE_Q3_SHAPES
 #define PLX_P3_COMBOS(X)                                                                                                              \
-  X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 2, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 2, kPackNarrow)                                      \
+  X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow)                                      \
   X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackFused) \
-  X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Hash, 2, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackNone)
+  X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackNone)
 #else
 #define PLX_P3_COMBOS(X)
 #endif
@@ -464,7 +467,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   const jit::Sink jk_agg = gen3 ? jit::part3_agg_sink(pp.mode, pp.pack) : (direct ? jit::PART2_AGG_DIRECT : jit::PART2_AGG_HASH);
   const bool use_jit = !is_static && jit::ensure(sh, jk_scatter, args.n_rows) && jit::ensure(sh, jk_agg, args.n_rows);
   if (!is_static && !use_jit) return -1;
-  PLX_REQUIRE(pp.tiles == 1 || pp.tiles == 2 || (gen3 && pp.tiles == 4), PLX_ERR_INVALID, "partitioned_agg2: tiles per round");
+  PLX_REQUIRE(pp.tiles == 1 || pp.tiles == 2 || (gen3 && (pp.tiles == 3 || pp.tiles == 4)), PLX_ERR_INVALID, "partitioned_agg2: tiles per round");
   // the kernels' names in the HIP-event profile carry the variant (mode, tiles, packing, record dwords): a counter file of another variant must never
   // be read as this one's (bench.py pmc_traffic matches the full name)
   const std::string sid = use_jit ? "jit" : "#" + std::to_string(static_id);
@@ -543,7 +546,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
                        cl_off->as<unsigned long long>(), cursor->as<unsigned int>(), cl_ids->as<unsigned int>());
     PLX_HIP(hipGetLastError());
   }
-  const uint64_t n_slots = direct ? ((uint64_t)1 << pp.log2_slots) : (((uint64_t)1 << pp.log2_slots) + 2);
+  const uint64_t n_slots = direct ? ((uint64_t)1 << pp.log2_slots) : ((uint64_t)pp.n_slots + 2);
   const uint64_t max_groups = std::min<uint64_t>((uint64_t)NP * n_slots + pp.n_hot, (uint64_t)args.n_rows + 1);
   *out_keys = dev_alloc(sizeof(uint64_t) * max_groups);
   *out_kvalid = dev_alloc(max_groups);
@@ -581,7 +584,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   if (minmax) { long long mm[2]; d2h_sync(mm, minmax->ptr, 16); key_range_out[0] = mm[0]; key_range_out[1] = mm[1]; }
   if (desc) *desc = std::string(gen3 ? "partitioned(v3," : "partitioned(v2,") + (direct ? "direct" : "hash") + ",P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec_words * 4) +
                     (gen3 ? "B,pack=" + std::to_string(pp.pack) + ",tile=" + std::to_string(pp.block * kRows * pp.tiles) : "B,ring=" + std::to_string(pp.ring_lines * 128) + "B") +
-                    ",block=" + std::to_string(pp.block) + ",hot=" + std::to_string(pp.n_hot) + ")+" + (direct ? "lds_direct_table(slots=" : "lds_hash_table(slots=") + std::to_string(1u << pp.log2_slots) + ")";
+                    ",block=" + std::to_string(pp.block) + ",hot=" + std::to_string(pp.n_hot) + ")+" + (direct ? "lds_direct_table(slots=" : "lds_hash_table(slots=") + std::to_string(direct ? 1u << pp.log2_slots : pp.n_slots) + ")";
   return (int64_t)(((uint64_t)res[1] << 32) | res[0]);
 }
 
@@ -601,13 +604,15 @@ __device__ __forceinline__ uint32_t bloom_pos(uint32_t low, uint32_t i, uint32_t
   constexpr uint32_t mult[kBloomK] = {0x9e3779b1u, 0x85ebca77u, 0xc2b2ae3du, 0x27d4eb2fu};
   return ((low + 1u) * mult[i]) >> (32u - log2_bits);
 }
-// Keys WITHOUT a usable range (hash_bits != 0; `bits` is null): the build side is an open-addressing hash table in HBM (JoinAggTable); its occupied slots
-// were sorted by the partition of their key's hash (slot lists bl_ids[bl_off[p] .. bl_off[p + 1])), the prologue reads the partition's keys and puts the low
-// key_shift bits of their hashed ids -- what the records carry -- into the Bloom filter.  Everything after the prologue is the same.
+// Keys WITHOUT a usable range (hash_bits != 0; `bits` is null): the build side is an open-addressing hash table in HBM (JoinAggTable) whose slot hash is
+// key * kP2HashMult -- the hash the scatter took partition and tag from -- so the keys of partition p sit in region p of the table: slots
+// [p * cap / NP, (p + 1) * cap / NP) plus, linear probing, the run of occupied slots behind the region's end (wrapping at the table's end).  The prologue
+// streams that region (coalesced) and puts the tag bits of every key that belongs to partition p into the Bloom filter; keys of partition p - 1 that spilled
+// into this region are skipped (they are not p's).  Everything after the prologue is the same.
 struct ProbeHashedBuild {
-  const unsigned long long* table_keys;    // [cap + 1] keys of the build table (slot `cap` = the key whose bits equal kEmptyKey, listed only when a build row holds it)
-  const unsigned long long* bl_off;        // [NP + 1]
-  const unsigned int* bl_ids;              // occupied table slots grouped by partition
+  const unsigned long long* table_keys;    // [cap + 1] keys of the build table; slot `cap` = the key whose bits equal kEmptyKey (present iff table_head[cap] holds a row)
+  const unsigned int* table_head;
+  uint32_t log2_cap;
   uint32_t hash_bits;                      // 0: the bitmap source
 };
 __global__ __launch_bounds__(kP2AggBlock) void probe_pass_kernel(const unsigned int* __restrict__ recs, const unsigned int* __restrict__ chunk_fill, const unsigned long long* __restrict__ cl_off,
@@ -625,11 +630,20 @@ __global__ __launch_bounds__(kP2AggBlock) void probe_pass_kernel(const unsigned 
   __syncthreads();
   if (hb.hash_bits) {
     const uint32_t tag_mask = key_shift >= 32 ? 0xffffffffu : (1u << key_shift) - 1u;
-    for (unsigned long long j = hb.bl_off[p] + threadIdx.x; j < hb.bl_off[p + 1]; j += blockDim.x) {
-      const unsigned long long key = hb.table_keys[hb.bl_ids[j]];
-      const uint32_t low = (uint32_t)((key * kP2HashMult) >> (64u - hb.hash_bits)) & tag_mask;
+    const uint32_t log2_parts = hb.hash_bits - key_shift;
+    const unsigned long long cap = 1ull << hb.log2_cap, region = cap >> log2_parts;       // the host guarantees cap >= NP
+    auto add = [&](unsigned long long key) {
+      const unsigned long long id = (key * kP2HashMult) >> (64u - hb.hash_bits);
+      if ((uint32_t)(id >> key_shift) != p) return;
+      const uint32_t low = (uint32_t)id & tag_mask;
 #pragma unroll
       for (uint32_t q = 0; q < kBloomK; q++) { const uint32_t pos = bloom_pos(low, q, log2_bloom_bits); atomicOr(&bloom[pos >> 5], 1u << (pos & 31u)); }
+    };
+    for (unsigned long long j = threadIdx.x; j < region; j += blockDim.x) { const unsigned long long key = hb.table_keys[(unsigned long long)p * region + j]; if (key != kEmptyKey) add(key); }
+    if (threadIdx.x == 0) {
+      // the run of occupied slots behind the region: keys of this partition that linear probing pushed past its end (short: the table is at most half full)
+      for (unsigned long long s = (((unsigned long long)p + 1) * region) & (cap - 1), n = 0; n < cap; s = (s + 1) & (cap - 1), n++) { const unsigned long long key = hb.table_keys[s]; if (key == kEmptyKey) break; add(key); }
+      if (hb.table_head[cap] != kNoRow32) add(kEmptyKey);                                  // the key equal to the EMPTY pattern lives in slot `cap`
     }
   }
   for (uint32_t i = threadIdx.x; i < W; i += blockDim.x) {
@@ -715,17 +729,6 @@ __global__ __launch_bounds__(kBlock) void probe_hits_compact_kernel(const unsign
   for (uint32_t i = threadIdx.x; i < part_hits[p]; i += blockDim.x) dst[i] = src[i];
 }
 
-// slot s of the build hash table -> the partition of its key's hashed id (kNoChunk: free slot).  Slot `cap` stands for the key whose bits equal kEmptyKey
-// (JoinBuildSink: head[cap] holds its row, keys[cap] keeps the EMPTY pattern -- which IS that key).
-__global__ __launch_bounds__(kBlock) void table_slot_parts_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ head, int64_t cap, uint32_t hash_bits,
-                                                                  uint32_t key_shift, unsigned int* __restrict__ part) {
-  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= cap; s += (int64_t)gridDim.x * blockDim.x) {
-    const unsigned long long k = keys[s];
-    const bool used = s == cap ? head[cap] != kNoRow32 : k != kEmptyKey;
-    part[s] = used ? (unsigned int)(((k * kP2HashMult) >> (64u - hash_bits)) >> key_shift) : kNoChunk;
-  }
-}
-
 // dt: the direct-address bitmap of the build side (keys with a dense range); ht: the build side's open-addressing hash table (keys without one: partition and
 // record tag come from the key's hash, kP2HashMult).  Exactly one of them is given.
 static bool probe_hits_impl(const Shape& sh, const Args& args, const DirectJoinTable* dtp, const JoinAggTable* ht, uint64_t n_build, int static_id, ColumnPtr* hits_out, std::string* desc) {
@@ -800,25 +803,10 @@ static bool probe_hits_impl(const Shape& sh, const Args& args, const DirectJoinT
   hits->dtype = PLX_U32; hits->null_count = 0;
   Buf regions = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks * kP2ChunkRecs + 16);          // a slot per record a partition may hold
   Buf part_hits = dev_alloc_zero(sizeof(uint32_t) * (NP + 1)), hit_off = dev_alloc(sizeof(uint64_t) * (NP + 2));
-  // hashed build side: the occupied slots of its hash table, grouped by the partition of their key (the counting sort of the chunk lists, over table slots)
   ProbeHashedBuild hb{};
-  Buf bl_part, bl_counts, bl_cursor, bl_off, bl_ids;
   if (hashed) {
-    const int64_t n_slots = ((int64_t)1 << ht->log2_cap) + 1;                  // + slot `cap`: the key equal to kEmptyKey
-    bl_part = dev_alloc(sizeof(uint32_t) * (size_t)n_slots);
-    bl_counts = dev_alloc_zero(sizeof(uint32_t) * (NP + 1)); bl_cursor = dev_alloc_zero(sizeof(uint32_t) * (NP + 1));
-    bl_off = dev_alloc(sizeof(uint64_t) * (NP + 2)); bl_ids = dev_alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(n_slots, 1));
-    ProfileScope ps("probe_build_slot_lists", (uint64_t)n_slots * 16, (uint64_t)n_slots);
-    hipLaunchKernelGGL(table_slot_parts_kernel, dim3(grid_for(n_slots, kBlock * 8)), dim3(kBlock), 0, stream(), ht->keys, ht->head, n_slots - 1, pp.hash_bits, pp.key_shift, bl_part->as<unsigned int>());
-    PLX_HIP(hipGetLastError());
-    const int g = grid_for(n_slots, kBlock * 16, 2);
-    hipLaunchKernelGGL(chunk_hist_kernel, dim3(g), dim3(kBlock), sizeof(unsigned int) * NP, stream(), bl_part->as<unsigned int>(), n_slots, NP, bl_counts->as<unsigned int>());
-    PLX_HIP(hipGetLastError());
-    exclusive_scan_u32(bl_counts->as<uint32_t>(), bl_off->as<uint64_t>(), NP);
-    hipLaunchKernelGGL(chunk_place_kernel, dim3(g), dim3(kBlock), sizeof(unsigned int) * NP * 2, stream(), bl_part->as<unsigned int>(), n_slots, NP,
-                       bl_off->as<unsigned long long>(), bl_cursor->as<unsigned int>(), bl_ids->as<unsigned int>());
-    PLX_HIP(hipGetLastError());
-    hb.table_keys = ht->keys; hb.bl_off = bl_off->as<unsigned long long>(); hb.bl_ids = bl_ids->as<unsigned int>(); hb.hash_bits = pp.hash_bits;
+    if (ht->log2_cap < pp.log2_parts) return false;                           // a table smaller than the partition count needs no partitioned probe
+    hb.table_keys = ht->keys; hb.table_head = ht->head; hb.log2_cap = ht->log2_cap; hb.hash_bits = pp.hash_bits;
   }
   {
     ProfileScope ps(hashed ? "probe_pass_lds_bloom_hashed" : "probe_pass_lds_bitmap", (uint64_t)args.n_rows * pp.rec_words * 4 + (hashed ? n_build * 12 : dt.range / 8), (uint64_t)args.n_rows);

@@ -74,9 +74,13 @@ __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, c
   if constexpr (MODE == (int)kP2Direct) {
     // (wave-uniform branch) keys without a usable range -- the hashed partitioned probe: partition and record carry bits of the key's hash instead
     const uint64_t id = pp.hash_bits ? (key64 * kP2HashMult) >> (64u - pp.hash_bits) : key64 - (uint64_t)pp.key_base;
-    const uint64_t hi = id >> pp.key_shift;
+    uint64_t hi = id >> pp.key_shift, low = id;
+    if (pp.interleave) {                                               // (wave-uniform) partition = low bits, slot = the bits above them
+      hi = (id >> (pp.key_shift + pp.log2_parts)) ? 0xfffffffeull : (id & ((1ull << pp.log2_parts) - 1ull));
+      low = id >> pp.log2_parts;
+    }
     part = hi > 0xfffffffeull ? 0xfffffffeu : (uint32_t)hi;           // far outside the id range: still "outside" after the narrowing
-    rec[0] = (uint32_t)id & ((1u << pp.key_shift) - 1u);
+    rec[0] = (uint32_t)low & ((1u << pp.key_shift) - 1u);
   } else {
     part = part2_of(key64, kvalid, pp.log2_parts);
     rec[0] = (uint32_t)key64;
@@ -385,8 +389,8 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   static_assert(NB >= 2 && NB <= 8, "chunks in flight per wave");
   extern __shared__ __attribute__((aligned(16))) unsigned long long p2_lds[];
   constexpr uint32_t kPerLane = kP2ChunkRecs / 64;    // records of a chunk per lane
-  const uint32_t NS = 1u << pp.log2_slots, n_aggs = sh.n_aggs, RW = L.rec_words, chunk_dw = kP2ChunkRecs * RW;
   const bool direct = MODE == (int)kP2Direct;
+  const uint32_t NS = direct ? 1u << pp.log2_slots : pp.n_slots, n_aggs = sh.n_aggs, RW = L.rec_words, chunk_dw = kP2ChunkRecs * RW;
   unsigned long long* keys = p2_lds;                                    // hash mode: [NS + 2] (NS = null key, NS + 1 = the key equal to EMPTY)
   unsigned long long* cells = direct ? p2_lds : keys + NS + 2;          // [(NS (+2)) * n_aggs]
   const uint32_t n_slots = direct ? NS : NS + 2;
@@ -459,7 +463,8 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
       if (!(vbits >> 31)) { slot[u] = NS; first[u] = kEmptyKey - 1; }                 // resolved below without probing
       else if (key[u] == kEmptyKey) { slot[u] = NS + 1; first[u] = kEmptyKey - 1; }
       else {
-        slot[u] = (uint32_t)((key[u] * 0x9e3779b97f4a7c15ull) >> (64 - pp.log2_slots));   // a second hash: the partition consumed the top bits of the first
+        // a second hash (the partition consumed the top bits of the first); the table has ANY number of slots: slot = floor(hash32 * NS / 2^32)
+        slot[u] = (uint32_t)((((key[u] * 0x9e3779b97f4a7c15ull) >> 32) * (uint64_t)NS) >> 32);
         first[u] = keys[slot[u]];
       }
     }
@@ -476,7 +481,7 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
             const unsigned long long old = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)key[u]);
             if (old == kEmptyKey || old == key[u]) break;
           }
-          sl = (sl + 1) & (NS - 1);
+          sl = sl + 1 == NS ? 0u : sl + 1;
           if (probe >= NS) { full = 1; live[u] = false; break; }
           c = keys[sl];
         }
@@ -540,7 +545,7 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   for (uint32_t s = threadIdx.x; s < n_slots; s += blockDim.x) {
     if (direct ? (cells[(size_t)s * n_aggs + pp.len_idx] == 0) : (keys[s] == kEmptyKey)) continue;
     const uint64_t o = gbase + atomicAdd(&cursor_l, 1u);
-    if (direct) { ap.out_keys[o] = ((uint64_t)p << pp.key_shift) | s; ap.out_kvalid[o] = 1; }
+    if (direct) { ap.out_keys[o] = pp.interleave ? (((uint64_t)s << pp.log2_parts) | p) : (((uint64_t)p << pp.key_shift) | s); ap.out_kvalid[o] = 1; }
     else { ap.out_keys[o] = s < NS ? keys[s] : (s == NS ? 0ull : kEmptyKey); ap.out_kvalid[o] = s == NS ? 0 : 1; }
     for (uint32_t k = 0; k < n_aggs; k++) ap.out_acc[o * n_aggs + k] = cells[(size_t)s * n_aggs + k];
   }

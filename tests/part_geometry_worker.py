@@ -1,5 +1,5 @@
 """One partitioned group-by under the geometry the environment dictates (PLX_PART_LOG2_PARTS / PLX_PART_DIRECT_LOG2_PARTS / PLX_PART_TILES /
-PLX_PART_PACK are read once per process: tests/test_gpu_zzzz_round3_d.py starts this script once per geometry).  argv: mode (hash | direct), input
+PLX_PART_PACK are read once per process: tests/test_gpu_partition_geometry.py starts this script once per geometry).  argv: mode (hash | direct), input
 (hot: a stretch of rows from 48 keys, which the sample makes heavy hitters -- the scatter's hot-key build; flat: uniform keys) and the substrings the
 plan description of the second run must contain.  Checks the result against numpy and prints the plan."""
 import os

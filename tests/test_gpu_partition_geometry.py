@@ -1,4 +1,4 @@
-"""Round 3, fourth batch: the generation-3 scatter (one-partition-per-thread scan, descriptor copy-out) under every geometry the planner can choose,
+"""The generation-3 scatter of the partitioned group-by (one-partition-per-thread scan, descriptor copy-out) under every geometry the planner can choose,
 not only the benchmark's 256 partitions / 8192-row tiles: 64 to 512 partitions (one to eight scan waves), 2048- to 8192-row tiles, hash and direct
 partitions, plain and packed records, with and without the hot-key build.  The knobs are read once per process, so each geometry runs tests/part_geometry_worker.py in its own."""
 import os
@@ -19,6 +19,8 @@ GEOMETRIES = [      # (what the second run -- key range known -- must report; th
     ("direct", "flat", {"PLX_PART_DIRECT_LOG2_PARTS": "6"}, ["direct,P=64,", "tile=8192,"]),
     ("direct", "hot", {"PLX_PART_DIRECT_LOG2_PARTS": "9", "PLX_PART_TILES": "2"}, ["direct,P=512,", "tile=4096,"]),
     ("direct", "flat", {"PLX_PART_DIRECT_LOG2_PARTS": "8", "PLX_PART_PACK": "1"}, ["direct,P=256,"]),
+    ("hash", "flat", {"PLX_PART_LOG2_PARTS": "8", "PLX_PART_TILES": "3"}, ["hash,P=256,", "tile=6144,"]),           # three tiles per round: 16-byte records at 256 partitions
+    ("direct", "hot", {"PLX_PART_DIRECT_LOG2_PARTS": "8", "PLX_PART_INTERLEAVE": "0"}, ["direct,P=256,"]),          # partition = the id's high bits (the join probe's mapping)
 ]
 
 
