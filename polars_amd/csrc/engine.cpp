@@ -920,11 +920,11 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
           desc += std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+" + pd;
           return;
         }
-        desc += "v2-unavailable+";
+        desc += g == -2 ? "v2-unavailable+" : "lds-overflow+";
       }
     }
     PartitionPlan pp;
-    if (k::partition_plan(sh, est, false, &pp)) {
+    if (part_version() == 1 && k::partition_plan(sh, est, false, &pp)) {
       std::string pd;
       Buf ok, okv, oacc;
       const int64_t g = k::partitioned_agg(sh, args, pp, static_id, &ok, &okv, &oacc, &pd);
@@ -972,24 +972,29 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
       bool any_null = c.key >= 0 && c.nodes[c.key].nullable;
       for (auto& a : c.aggs) if (a.second >= 0 && c.nodes[a.second].nullable) any_null = true;
       if (part_version() == 2) {
-        PartPlan2 p2;
         k::SrcRange ranges[kMaxSrc];
         source_ranges(c, ranges);
-        // heavy hitters mean a heavy tail: the sample undercounts the rare keys (zipf 1.1: by ~2x) and LDS tables at twice their planned
-        // load probe long -- plan for twice the estimate when that still fits the 512-partition limit
-        const bool planned = (!hot.empty() && G < 1e17 && k::partition_plan2(sh, G * 2.6, -1, len_idx, n, (int)hot.size(), &p2, ranges)) ||
-                             k::partition_plan2(sh, G * 1.3, -1, len_idx, n, (int)hot.size(), &p2, ranges);
-        if (planned) {
+        // A raw signed-integer key column scanned without a predicate: the scatter pass also records the exact key range, which is
+        // cached on the column like any other statistic -- the NEXT group-by / join on it can plan dense (direct-address) tables.
+        ColumnPtr stat_col;
+        if (sh.pred == kNone && kp.parts.size() == 1 && dtype_is_int(kp.parts[0].dtype) && kp.parts[0].dtype != PLX_U64) {
+          const AE* x = &c.plan.ae[kp.parts[0].expr];
+          while (x->kind == PLX_AE_ALIAS) x = &c.plan.ae[x->lhs];
+          if (x->kind == PLX_AE_COLUMN) { const int ci = c.df->find(x->name); if (ci >= 0 && c.df->cols[ci]->range_state == 0 && c.df->cols[ci]->len == n) stat_col = c.df->cols[ci]; }
+        }
+        // How many groups to plan for.  The estimate assumes equally likely keys; heavy hitters in the sample mean a heavy TAIL too, and a tail the sample
+        // undercounts badly (zipf 1.1 over 1e6 keys: 1.5e5 distinct keys in 2^20 sampled rows, 1e6 in 1e9 rows): with skew the tables are planned for 4 x the
+        // estimate.  A table that fills up anyway is reported by the aggregation pass; the plan is then doubled (more partitions) and the pass repeated -- never
+        // the per-row HBM-table path, which a skewed input turns into seconds of same-address atomics.
+        double plan_for = (!hot.empty() && G < 1e17) ? G * 4.0 : G * 1.3;
+        for (int attempt = 0; attempt < 3; attempt++) {
+          PartPlan2 p2;
+          if (!k::partition_plan2(sh, plan_for, -1, len_idx, n, (int)hot.size(), &p2, ranges)) {
+            if (attempt == 0 && !hot.empty() && k::partition_plan2(sh, G * 1.3, -1, len_idx, n, (int)hot.size(), &p2, ranges)) { /* 4 x does not fit 512 partitions: the plain estimate does */ }
+            else break;
+          }
           std::string pd;
           Buf ok, okv, oacc;
-          // A raw signed-integer key column scanned without a predicate: the scatter pass also records the exact key range, which is
-          // cached on the column like any other statistic -- the NEXT group-by / join on it can plan dense (direct-address) tables.
-          ColumnPtr stat_col;
-          if (sh.pred == kNone && kp.parts.size() == 1 && dtype_is_int(kp.parts[0].dtype) && kp.parts[0].dtype != PLX_U64) {
-            const AE* x = &c.plan.ae[kp.parts[0].expr];
-            while (x->kind == PLX_AE_ALIAS) x = &c.plan.ae[x->lhs];
-            if (x->kind == PLX_AE_COLUMN) { const int ci = c.df->find(x->name); if (ci >= 0 && c.df->cols[ci]->range_state == 0 && c.df->cols[ci]->len == n) stat_col = c.df->cols[ci]; }
-          }
           int64_t key_range[2] = {1, 0};
           const int64_t g = k::partitioned_agg2(sh, args, p2, static_id, hot, &ok, &okv, &oacc, &pd, stat_col ? key_range : nullptr);
           if (g >= 0) {
@@ -998,9 +1003,13 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
             desc += "hot=" + std::to_string(hot.size()) + "+" + std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+" + pd;
             return;
           }
-          desc += "v2-unavailable+";
+          if (g == -2) { desc += "v2-unavailable+"; break; }
+          desc += "lds-overflow(P=" + std::to_string(1u << p2.log2_parts) + ")+";
+          if (p2.log2_parts >= 9) break;
+          plan_for = std::max(plan_for * 2.0, (double)((uint64_t)p2.n_slots << p2.log2_parts) * 1.01);      // beyond what this plan's tables hold at all
         }
       }
+      if (part_version() == 1) {
       PartitionPlan pp;
       if (k::partition_plan(sh, G * 1.3, any_null, &pp)) {
         std::string pd;
@@ -1013,6 +1022,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
         }
         desc += "lds-overflow+";
       }
+      }   // first-generation kernels (PLX_PART_V=1 only)
     }
   }
   for (int attempt = 0; attempt < 8; attempt++) {

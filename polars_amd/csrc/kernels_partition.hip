@@ -453,7 +453,7 @@ static void part3_static_agg(int static_id, const PartPlan2& pp, const AggParams
 }
 
 // Runs scatter -> chunk sort -> aggregate (+ hot groups).  Outputs (allocated here): dense keys / valid flags / cells.
-// Returns the number of groups, -1 if an LDS table overflowed or no specialised kernel is available (the caller falls back).
+// Returns the number of groups, -1 if an LDS table overflowed (the caller plans more partitions or falls back), -2 if no specialised kernel is available.
 int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& plan, int static_id, const std::vector<uint64_t>& hot_keys, Buf* out_keys, Buf* out_kvalid,
                          Buf* out_acc, std::string* desc, int64_t* key_range_out) {
   PartPlan2 pp = plan;
@@ -466,7 +466,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
                                     : pp.tiles == 2 ? (direct ? jit::PART2_SCATTER_DIRECT_T2 : jit::PART2_SCATTER_HASH_T2) : (direct ? jit::PART2_SCATTER_DIRECT : jit::PART2_SCATTER_HASH);
   const jit::Sink jk_agg = gen3 ? jit::part3_agg_sink(pp.mode, pp.pack) : (direct ? jit::PART2_AGG_DIRECT : jit::PART2_AGG_HASH);
   const bool use_jit = !is_static && jit::ensure(sh, jk_scatter, args.n_rows) && jit::ensure(sh, jk_agg, args.n_rows);
-  if (!is_static && !use_jit) return -1;
+  if (!is_static && !use_jit) return -2;
   PLX_REQUIRE(pp.tiles == 1 || pp.tiles == 2 || (gen3 && (pp.tiles == 3 || pp.tiles == 4)), PLX_ERR_INVALID, "partitioned_agg2: tiles per round");
   // the kernels' names in the HIP-event profile carry the variant (mode, tiles, packing, record dwords): a counter file of another variant must never
   // be read as this one's (bench.py pmc_traffic matches the full name)

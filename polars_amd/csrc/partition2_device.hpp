@@ -525,7 +525,7 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
     for (bool done = false; !done;) {     // the buffers rotate by (compile-time) index: copying a buffer would wait for its loads
 #pragma unroll
       for (int s = 0; s < NB; s++) {
-        if (j >= c_end) { done = true; break; }
+        if (j >= c_end || *(volatile unsigned int*)&full) { done = true; break; }      // a full table: the result is discarded anyway; probing it record by record would take O(slots) each
         load_chunk(j + (uint64_t)(NB - 1) * step, bufs[(s + NB - 1) % NB], nn[(s + NB - 1) % NB]);
         process(bufs[s], nn[s]);
         j += step;

@@ -19,7 +19,8 @@ GEOMETRIES = [      # (what the second run -- key range known -- must report; th
     ("direct", "flat", {"PLX_PART_DIRECT_LOG2_PARTS": "6"}, ["direct,P=64,", "tile=8192,"]),
     ("direct", "hot", {"PLX_PART_DIRECT_LOG2_PARTS": "9", "PLX_PART_TILES": "2"}, ["direct,P=512,", "tile=4096,"]),
     ("direct", "flat", {"PLX_PART_DIRECT_LOG2_PARTS": "8", "PLX_PART_PACK": "1"}, ["direct,P=256,"]),
-    ("hash", "flat", {"PLX_PART_LOG2_PARTS": "8", "PLX_PART_TILES": "3"}, ["hash,P=256,", "tile=6144,"]),           # three tiles per round: 16-byte records at 256 partitions
+    ("hash", "flat", {"PLX_PART_LOG2_PARTS": "8", "PLX_PART_TILES": "3", "PLX_PART_PACK": "0"}, ["hash,P=256,", "rec=24B,pack=0,", "tile=4096,"]),
+    ("hash", "hot", {"PLX_PART_LOG2_PARTS": "8", "PLX_PART_TILES": "3"}, ["hash,P=256,", "rec=20B,", "tile=4096,", "slots=4606)"]),     # an LDS table that is not a power of two
     ("direct", "hot", {"PLX_PART_DIRECT_LOG2_PARTS": "8", "PLX_PART_INTERLEAVE": "0"}, ["direct,P=256,"]),          # partition = the id's high bits (the join probe's mapping)
 ]
 
