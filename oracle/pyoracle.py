@@ -91,6 +91,10 @@ def _dt(a: np.ndarray) -> int:
 def cmp(op: int, a: np.ndarray, b) -> np.ndarray:
     """Values only (validity = AND of inputs is the caller's business, arity.rs:203-214)."""
     a = np.ascontiguousarray(a)
+    if a.dtype == np.bool_:
+        # Boolean arrays compare as bitmaps, false < true (crates/polars-compute/src/comparisons/boolean.rs:9-70): eq !(l ^ r), ne l ^ r, lt !l & r, le !l | r
+        l, r = a, (np.full(len(a), bool(b)) if not isinstance(b, np.ndarray) else b.astype(bool))
+        return {EQ: ~(l ^ r), NE: l ^ r, LT: ~l & r, LE: ~l | r, GT: l & ~r, GE: l | ~r}[op]
     n = len(a)
     scalar = not isinstance(b, np.ndarray)
     bb = np.array([b], dtype=a.dtype) if scalar else np.ascontiguousarray(b.astype(a.dtype, copy=False))

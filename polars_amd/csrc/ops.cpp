@@ -41,10 +41,19 @@ ColumnPtr cmp(int op, const ColumnPtr& lhs, const ColumnPtr& rhs) {
   out->dtype = PLX_BOOL; out->len = lhs->len;
   out->values = dev_alloc_zero(bitmap_bytes(lhs->len));
   if (lhs->dtype == PLX_BOOL) {
-    // bool == bool / != via xor (the reference compares bitmaps the same way)
-    PLX_REQUIRE(op == PLX_EQ || op == PLX_NE, PLX_ERR_UNSUPPORTED, "cmp: only ==/!= on boolean columns");
-    k::bitmap_op(2, lhs->values->as<uint64_t>(), rhs->values->as<uint64_t>(), lhs->len, out->values->as<uint64_t>());
-    if (op == PLX_EQ) k::bitmap_op(3, out->values->as<uint64_t>(), nullptr, lhs->len, out->values->as<uint64_t>());
+    // Boolean columns compare as bitmaps, false < true (crates/polars-compute/src/comparisons/boolean.rs:9-70): == is !(l ^ r), != is l ^ r,
+    // < is !l & r, <= is !l | r, > and >= the same with the operands swapped
+    const uint64_t* a = lhs->values->as<uint64_t>();
+    const uint64_t* b = rhs->values->as<uint64_t>();
+    uint64_t* o = out->values->as<uint64_t>();
+    if (op == PLX_EQ || op == PLX_NE) {
+      k::bitmap_op(2, a, b, lhs->len, o);
+      if (op == PLX_EQ) k::bitmap_op(3, o, nullptr, lhs->len, o);
+    } else {
+      const bool swap = op == PLX_GT || op == PLX_GE;
+      k::bitmap_op(3, swap ? b : a, nullptr, lhs->len, o);                                  // !l
+      k::bitmap_op((op == PLX_LT || op == PLX_GT) ? 0 : 1, o, swap ? a : b, lhs->len, o);   // & r  /  | r
+    }
   } else {
     plx_scalar z; z.u = 0;
     k::cmp(lhs->dtype, op, lhs->data(), rhs->data(), z, lhs->len, out->values->as<uint64_t>());

@@ -217,6 +217,116 @@ for how, ea, eb, ep in (("anti", [1, 2, 1], ["a", "b", "a"], [10, 20, 40]), ("se
                   right={"a": [3, 3, 4, 5], "b": ["c", "c", "d", "e"]}, right_dtypes={"a": "i64", "b": "str"},
                   on=["a", "b"], expect={"a": ea, "b": eb, "payload": ep}))
 
+# ---- a3 arithmetic on primitive columns (round 4): kind "binary" = one operator, lhs / rhs = a column (list) or {"scalar": v}, nulls in / nulls out ----
+TA = "py-polars/tests/unit/operations/arithmetic/test_arithmetic.py"
+TL = "py-polars/tests/unit/lazyframe/test_lazyframe.py"
+TD = "py-polars/tests/unit/dataframe/test_df.py"
+
+
+def B(id, source, op, lhs, rhs, dtype, expect, expect_dtype=None, **kw):
+    C.append(dict(id=id, kind="binary", source=source, op=op, lhs=lhs, rhs=rhs, dtype=dtype, expect=expect, expect_dtype=expect_dtype or dtype, **kw))
+
+
+S = lambda v: {"scalar": v}
+# test_arithmetic (lazyframe): a = [1, 2, 3] against integer literals on either side
+for i, (op, lhs, rhs, exp) in enumerate([("mod", [1, 2, 3], S(2), [1, 0, 1]), ("mod", S(2), [1, 2, 3], [0, 0, 2]), ("floor_div", S(1), [1, 2, 3], [1, 0, 0]),
+                                         ("mul", S(1), [1, 2, 3], [1, 2, 3]), ("add", S(1), [1, 2, 3], [2, 3, 4]), ("sub", S(1), [1, 2, 3], [0, -1, -2]),
+                                         ("floor_div", [1, 2, 3], S(2), [0, 1, 1]), ("mul", [1, 2, 3], S(2), [2, 4, 6]), ("add", [1, 2, 3], S(2), [3, 4, 5]),
+                                         ("sub", [1, 2, 3], S(2), [-1, 0, 1])]):
+    B(f"lazy_arithmetic_{i + 1}", TL + ":910-941", op, lhs, rhs, "i64", exp)
+# test_arithmetic_series: s = [1, 2] as Int64 and as Float64
+for dt, one in (("i64", 1), ("f64", 1.0)):
+    fl = dt == "f64"
+    B(f"series_mul_{dt}", TA + ":446-456", "mul", [1, 2], [1, 2], dt, [1, 4])
+    B(f"series_truediv_{dt}", TA + ":446-456", "true_div", [1, 2], [1, 2], dt, [1.0, 1.0], "f64")
+    B(f"series_truediv_scalar_left_{dt}", TA + ":462", "true_div", S(one), [1, 2], dt, [1.0, 0.5], "f64")
+    B(f"series_floordiv_scalar_left_{dt}", TA + ":463-464", "floor_div", S(one), [1, 2], dt, [1.0, 0.0] if fl else [1, 0])
+    B(f"series_mod_scalar_left_{dt}", TA + ":466", "mod", S(one), [1, 2], dt, [0, 1])
+    B(f"series_mod_scalar_right_{dt}", TA + ":467", "mod", [1, 2], S(one), dt, [0, 0])
+    B(f"series_floordiv_scalar_right_{dt}", TA + ":457", "floor_div", [1, 2], S(2 * one), dt, [0, 1])
+# test_df_series_division: true division of ints is Float64, floor division stays Int64
+B("df_series_truediv_int", TA + ":425-443", "true_div", [2, 2, 10, 5, 6, 6], [2, 2, 2, 2, 2, 2], "i64", [1.0, 1.0, 5.0, 2.5, 3.0, 3.0], "f64")
+B("df_series_floordiv_int", TA + ":425-443", "floor_div", [2, 2, 10, 5, 6, 6], [2, 2, 2, 2, 2, 2], "i64", [1, 1, 5, 2, 3, 3])
+# test_arithmetic_on_df: Float64 columns against scalars
+B("df_mul_scalar_f64", TA + ":365-371", "mul", [1.0, 2.0], S(2.0), "f64", [2.0, 4.0])
+B("df_add_scalar_left_f64", TA + ":373-375", "add", S(2.0), [3.0, 4.0], "f64", [5.0, 6.0])
+B("df_div_scalar_f64", TA + ":377-379", "true_div", [1.0, 2.0], S(2.0), "f64", [0.5, 1.0])
+B("df_mod_scalar_f64", TA + ":385-387", "mod", [3.0, 4.0], S(2.0), "f64", [1.0, 0.0])
+# test_arithmetic_null_count: a null on either side is a null result
+B("null_propagation_col_col", TA + ":273-285", "add", [1, None, 2], [None, 2, 1], "i64", [None, None, 3])
+B("null_propagation_scalar_left", TA + ":273-285", "add", S(1), [None, 2, 1], "i64", [None, 3, 2])
+B("null_propagation_scalar_right", TA + ":273-285", "add", [1, None, 2], S(1), "i64", [2, None, 3])
+# test_integer_divide_scalar_zero_lhs_19142: 0 // [1, 0] and 0 % [1, 0]
+B("int_floordiv_scalar_zero_lhs", TA + ":840-842", "floor_div", S(0), [1, 0], "i64", [0, None])
+B("int_mod_scalar_zero_lhs", TA + ":840-842", "mod", S(0), [1, 0], "i64", [0, None])
+# test_floordiv_truediv (test_df.py): Python semantics for negative operands; x = [0, -1, -2, -3], y = [-0.0, -3.0, 5.0, -7.0], z = [10, 3, -5, 7]
+for n in (3, -3):
+    B(f"floordiv_python_semantics_int_by_{n}", TD + ":2972-2988", "floor_div", [0, -1, -2, -3, 10, 3, -5, 7], S(n), "i64", [v // n for v in (0, -1, -2, -3, 10, 3, -5, 7)])
+    B(f"truediv_python_semantics_int_by_{n}", TD + ":2972-2988", "true_div", [0, -1, -2, -3, 10, 3, -5, 7], S(n), "i64", [v / n for v in (0, -1, -2, -3, 10, 3, -5, 7)], "f64")
+    B(f"floordiv_python_semantics_f64_by_{n}", TD + ":2972-2988", "floor_div", [-0.0, -3.0, 5.0, -7.0], S(float(n)), "f64", [v // n for v in (-0.0, -3.0, 5.0, -7.0)])
+B("floordiv_int_frame_frame", TD + ":2990-3000", "floor_div", [0, -1, -2, -3], [2, -2, 2, 3], "i64", [0, 0, -1, -1])
+# test_int_operator_stability: small integer dtypes keep their dtype under + - * // (wrapping), / gives Float64
+for dt in ("i8", "u8", "i16", "u16", "i32", "u32", "u64"):
+    B(f"int_operator_stability_{dt}_add", TA + ":662-668", "add", [10], S(2), dt, [12])
+    B(f"int_operator_stability_{dt}_truediv", TA + ":662-668", "true_div", [10], S(2), dt, [5.0], "f64")
+B("float_floor_divide", TL + ":944-949", "floor_div", [10.4], S(0.5), "f64", [10.4 // 0.5])
+
+# ---- a1 comparisons: kind "compare" -----------------------------------------------------------------------------------------------
+TC = "py-polars/tests/unit/operations/test_comparison.py"
+RC = "crates/polars-core/src/chunked_array/comparison/mod.rs"
+
+
+def CMP(id, source, lhs, rhs, dtype, expect):
+    C.append(dict(id=id, kind="compare", source=source, lhs=lhs, rhs=rhs, dtype=dtype, expect=expect))
+
+
+CMP("comparison_expr_expr", TC + ":90-112", [1, 2, 3], [2, 1, 3], "i64",
+    {"eq": [False, False, True], "ne": [True, True, False], "lt": [True, False, False], "le": [True, False, True], "gt": [False, True, False], "ge": [False, True, True]})
+CMP("comparison_order_null_column", TC + ":22-43", [42, 42], [None, None], "i64", {op: [None, None] for op in ("lt", "le", "gt", "ge", "eq", "ne")})
+CMP("comparison_nulls_single", TC + ":46-62", [None], [None], "i64", {"eq": [None], "ne": [None]})
+CMP("null_handling_i32", RC + ":1214-1278", [1, None, 3], [1, 2, 3], "i32",
+    {"eq": [True, None, True], "ne": [False, None, False], "gt": [False, None, False], "ge": [True, None, True], "lt": [False, None, False], "le": [True, None, True]})
+# test_broadcasting_numeric: a = [1, 2, 3] against the unit-length columns [1] and [3], on either side
+for name, rhs, exp in (("one", S(1), {"eq": [True, False, False], "ne": [False, True, True], "gt": [False, True, True], "lt": [False, False, False], "ge": [True, True, True], "le": [True, False, False]}),
+                       ("three", S(3), {"eq": [False, False, True], "ne": [True, True, False], "gt": [False, False, False], "lt": [True, True, False], "ge": [False, False, True], "le": [True, True, True]})):
+    CMP(f"broadcasting_numeric_{name}_right", RC + ":1412-1468", [1, 2, 3], rhs, "i32", exp)
+CMP("broadcasting_numeric_one_left", RC + ":1412-1468", S(1), [1, 2, 3], "i32",
+    {"eq": [True, False, False], "ne": [False, True, True], "gt": [False, False, False], "lt": [False, True, True], "ge": [True, False, False], "le": [True, True, True]})
+CMP("broadcasting_numeric_three_left", RC + ":1412-1468", S(3), [1, 2, 3], "i32",
+    {"eq": [False, False, True], "ne": [True, True, False], "gt": [True, True, False], "lt": [False, False, False], "ge": [True, True, True], "le": [False, False, True]})
+# test_total_ordering_bool_series: false < true, null propagates
+CMP("total_ordering_bool", TC + ":455-468", [None, None, None, False, False, False, True, True, True], [None, False, True, None, False, True, None, False, True], "bool",
+    {"eq": [None, None, None, None, True, False, None, False, True], "ne": [None, None, None, None, False, True, None, True, False],
+     "lt": [None, None, None, None, False, True, None, False, False], "le": [None, None, None, None, True, True, None, False, True],
+     "gt": [None, None, None, None, False, False, None, True, False], "ge": [None, None, None, None, True, False, None, True, True]})
+
+# ---- a2 Boolean logic (Kleene): kind "bool_logic" ---------------------------------------------------------------------------------
+C.append(dict(id="bitwise_ops", kind="bool_logic", source=RC + ":1093-1103", lhs=[True, False, False], rhs=[True, True, None],
+              expect={"or": [True, True, None], "and": [True, False, False], "not_rhs": [False, False, None]}))
+C.append(dict(id="kleene_or_true", kind="bool_logic", source=RC + ":1305-1316", lhs=[True, False, None], rhs=[True, True, True], expect={"or": [True, True, True]}))
+C.append(dict(id="kleene_or_false", kind="bool_logic", source=RC + ":1305-1316", lhs=[True, False, None], rhs=[False, False, False], expect={"or": [True, False, None]}))
+
+# ---- a6 whole-column aggregates: kind "reduce" (more of them) -----------------------------------------------------------------------
+TG = "py-polars/tests/unit/operations/aggregation/test_aggregations.py"
+RA = "crates/polars-core/src/chunked_array/ops/aggregate/mod.rs"
+C.append(dict(id="boolean_mean", kind="reduce", source=TG + ":42-54", values=[True, False, None, True], dtype="bool", op="mean", expect=0.6666666666666666))
+C.append(dict(id="boolean_sum_is_index_type", kind="reduce", source=TA + ":244-254; " + TG + ":497-501", values=[True, False, True], dtype="bool", op="sum", expect=2, expect_dtype="u32"))
+for dt in ("i16", "u16", "i8", "u8", "i32", "u32", "i64", "u64"):
+    C.append(dict(id=f"int_min_max_skip_null_{dt}", kind="reduce", source=TG + ":605-611", values=[None, 1], dtype=dt, op="min", expect=1))
+    C.append(dict(id=f"int_max_skip_null_{dt}", kind="reduce", source=TG + ":605-611", values=[None, 1], dtype=dt, op="max", expect=1))
+IDS = [130352432, 130352277, 130352611, 130352833, 130352305, 130352258, 130352764, 130352475, 130352368, 130352346]
+C.append(dict(id="min_2850", kind="reduce", source=TG + ":746-774", values=IDS, dtype="i64", op="min", expect=130352258))
+C.append(dict(id="max_2850", kind="reduce", source=TG + ":746-774", values=IDS, dtype="i64", op="max", expect=130352833))
+C.append(dict(id="sum_inf_not_nan", kind="reduce", source=TG + ":1333-1336", values=[10.0, None, 10.0, 10.0, 10.0, 10.0, "inf", 10.0, 10.0], dtype="f64", op="sum", expect="inf"))
+C.append(dict(id="min_full_nan", kind="reduce", source="py-polars/tests/unit/series/test_series.py:2105-2107", values=["nan", "nan"], dtype="f64", op="min", expect="nan"))
+C.append(dict(id="max_full_nan", kind="reduce", source="py-polars/tests/unit/series/test_series.py:2105-2107", values=["nan", "nan"], dtype="f64", op="max", expect="nan"))
+for dt in ("f32", "f64"):
+    C.append(dict(id=f"agg_float_min_ignores_nan_{dt}", kind="reduce", source=RA + ":755-764", values=[1.0, "nan"], dtype=dt, op="min", expect=1.0))
+    C.append(dict(id=f"agg_float_min_ignores_nan_reversed_{dt}", kind="reduce", source=RA + ":755-764", values=["nan", 1.0], dtype=dt, op="min", expect=1.0))
+C.append(dict(id="mean_f32_with_null", kind="reduce", source=RA + ":802-814", values=[1.0, 2.0, None], dtype="f32", op="mean", expect=1.5))
+C.append(dict(id="mean_all_null_f32", kind="reduce", source=RA + ":815-825", values=[None, None, None], dtype="f32", op="mean", expect=None))
+C.append(dict(id="count_all_null_column", kind="reduce", source=TG + ":737-743", values=[None, None, None, None, None, None], dtype="i64", op="count", expect=0))
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")
 with open(out, "w") as f:
     json.dump(C, f, indent=1)

@@ -27,6 +27,14 @@ def _u(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
+def kleene(op, ta, va, tb, vb):
+    """Kleene and / or on nullable Booleans (values, validity) -> (values, validity): false wins over null in `and`, true wins over null in `or`
+    (crates/polars-core/src/chunked_array/comparison/mod.rs test_kleene; polars-compute bitwise kernels)."""
+    if op == "and":
+        return ta & tb, (~tb & vb) | (~ta & va) | (ta & va & tb & vb)
+    return ta | tb, (ta & va) | (tb & vb) | (~ta & va & ~tb & vb)
+
+
 def _cmp(op, a, b, floats):
     if floats:   # total order: NaN == NaN, NaN greatest (dev.hpp tot_*)
         an, bn = np.isnan(a), np.isnan(b)
@@ -127,10 +135,8 @@ def run_rows(prog, cols, luts=None, split=False):
                 elif code == OP_CMP_F: d = _cmp(c, _f(x), _f(y), True).astype(np.uint64)
                 elif code in (OP_AND, OP_OR):
                     ta, tb = (x & U(1)).astype(bool), (y & U(1)).astype(bool)
-                    if code == OP_AND:   # Kleene: false wins over null
-                        d = (ta & tb).astype(np.uint64); vd = (~tb & vy) | (~ta & vx) | (ta & vx & tb & vy)
-                    else:                # Kleene: true wins over null
-                        d = (ta | tb).astype(np.uint64); vd = (ta & vx) | (tb & vy) | (~ta & vx & ~tb & vy)
+                    t, vd = kleene("and" if code == OP_AND else "or", ta, vx, tb, vy)
+                    d = t.astype(np.uint64)
                 elif code == OP_XOR: d = (x ^ y) & U(1)
                 elif code == OP_NOT: d, vd = (~x) & U(1), vx
                 elif code == OP_CANON_F:

@@ -58,6 +58,64 @@ def test_reduce_kats(pl, case):
     # the same through a plan (fused register sink)
     out = pl.DataFrame([s]).lazy().select(getattr(pl.col("v"), case["op"])()).collect()
     assert kat.same_value(out.rows()[0][0], case["expect"], case.get("rtol", 1e-12))
+    if "expect_dtype" in case:
+        assert out.schema["v"] == getattr(pl, PLDT[case["expect_dtype"]]), out.schema
+
+
+def _operand(pl, name, spec, dtype):
+    if isinstance(spec, dict) and "scalar" in spec:
+        return kat.NP[dtype](kat.scalar(spec["scalar"])).item(), True
+    return _series(pl, name, spec, dtype), False
+
+
+@pytest.mark.parametrize("case", kat.load_cases("binary"), ids=lambda c: c["id"])
+def test_binary_arithmetic_kats(pl, case):
+    """One arithmetic operator through the per-kernel entry points (plx_arith / plx_arith_scalar) AND through a plan (the fused register program where the
+    operator fuses, the per-node kernels otherwise)."""
+    F = pl._ffi
+    OPS = {"add": F.ADD, "sub": F.SUB, "mul": F.MUL, "true_div": F.TRUE_DIV, "floor_div": F.FLOOR_DIV, "mod": F.MOD}
+    l, ls = _operand(pl, "l", case["lhs"], case["dtype"])
+    r, rs = _operand(pl, "r", case["rhs"], case["dtype"])
+    out = r.arith(OPS[case["op"]], l, True) if ls else l.arith(OPS[case["op"]], r)
+    assert out.dtype == getattr(pl, PLDT[case["expect_dtype"]]), (out.dtype, case["expect_dtype"])
+    got = out.to_list()
+    assert len(got) == len(case["expect"])
+    for g, e in zip(got, case["expect"]):
+        assert kat.same_value(g, e, 1e-15), (case["id"], got, case["expect"])
+    # through expressions
+    import operator
+    pyop = {"add": operator.add, "sub": operator.sub, "mul": operator.mul, "true_div": operator.truediv, "floor_div": operator.floordiv, "mod": operator.mod}[case["op"]]
+    cols = [x for x, is_s in ((l, ls), (r, rs)) if not is_s]
+    le = pl.lit(l, dtype=getattr(pl, PLDT[case["dtype"]])) if ls else pl.col("l")
+    re_ = pl.lit(r, dtype=getattr(pl, PLDT[case["dtype"]])) if rs else pl.col("r")
+    res = pl.DataFrame(cols).lazy().select(pyop(le, re_).alias("o")).collect()
+    got2 = res["o"].to_list()
+    assert res.schema["o"] == getattr(pl, PLDT[case["expect_dtype"]]), res.schema
+    for g, e in zip(got2, case["expect"]):
+        assert kat.same_value(g, e, 1e-15), (case["id"], "plan", got2, case["expect"])
+
+
+@pytest.mark.parametrize("case", kat.load_cases("compare"), ids=lambda c: c["id"])
+def test_compare_kats(pl, case):
+    F = pl._ffi
+    OPS = {"eq": F.EQ, "ne": F.NE, "lt": F.LT, "le": F.LE, "gt": F.GT, "ge": F.GE}
+    FLIP = {"eq": "eq", "ne": "ne", "lt": "gt", "le": "ge", "gt": "lt", "ge": "le"}
+    l, ls = _operand(pl, "l", case["lhs"], case["dtype"])
+    r, rs = _operand(pl, "r", case["rhs"], case["dtype"])
+    for name, exp in case["expect"].items():
+        got = r.cmp(OPS[FLIP[name]], l).to_list() if ls else l.cmp(OPS[name], r).to_list()
+        assert got == exp, (case["id"], name, got, exp)
+
+
+@pytest.mark.parametrize("case", kat.load_cases("bool_logic"), ids=lambda c: c["id"])
+def test_bool_logic_kats(pl, case):
+    l, r = _series(pl, "l", case["lhs"], "bool"), _series(pl, "r", case["rhs"], "bool")
+    for name, exp in case["expect"].items():
+        got = (~r).to_list() if name == "not_rhs" else (l & r).to_list() if name == "and" else (l | r).to_list()
+        assert got == exp, (case["id"], name, got, exp)
+        if name != "not_rhs":      # the same through a fused predicate program (Kleene OP_AND / OP_OR)
+            e = (pl.col("l") & pl.col("r")) if name == "and" else (pl.col("l") | pl.col("r"))
+            assert pl.DataFrame([l, r]).lazy().select(e.alias("o")).collect()["o"].to_list() == exp, (case["id"], name, "plan")
 
 
 @pytest.mark.parametrize("case", kat.load_cases("join"), ids=lambda c: c["id"])

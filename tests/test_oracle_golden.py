@@ -63,8 +63,77 @@ def test_groupby_kats(orc, case, threads):
 @pytest.mark.parametrize("case", kat.load_cases("reduce"), ids=lambda c: c["id"])
 def test_reduce_kats(orc, case):
     a, v, _ = kat.column(case["values"], case["dtype"])
-    got, _ = orc.reduce(AGG[case["op"]], a, v)
+    got, odt = orc.reduce(AGG[case["op"]], a, v)
     assert kat.same_value(got, case["expect"], case.get("rtol", 1e-12))
+    if "expect_dtype" in case:
+        assert odt == orc.DT_OF[np.dtype(kat.NP[case["expect_dtype"]])], (case["id"], odt)
+
+
+ARITH_OPS = {"add": "ADD", "sub": "SUB", "mul": "MUL", "true_div": "TRUE_DIV", "floor_div": "FLOOR_DIV", "mod": "MOD"}
+
+
+def _operand(spec, dtype):
+    """KAT operand -> (array or python scalar, validity or None, is_scalar)"""
+    if isinstance(spec, dict) and "scalar" in spec:
+        return kat.NP[dtype](kat.scalar(spec["scalar"])).item(), None, True
+    a, v, _ = kat.column(spec, dtype)
+    return a, v, False
+
+
+@pytest.mark.parametrize("case", kat.load_cases("binary"), ids=lambda c: c["id"])
+def test_binary_arithmetic_kats(orc, case):
+    """One arithmetic operator on primitive columns, column / scalar on either side, nulls in -> nulls out (the validity of a binary kernel's result is the AND
+    of its inputs' validities, crates/polars-core/src/chunked_array/ops/arity.rs:203-214, plus the divisor != 0 mask of integer floor-div / mod)."""
+    l, lv, ls = _operand(case["lhs"], case["dtype"])
+    r, rv, rs = _operand(case["rhs"], case["dtype"])
+    op = getattr(orc, ARITH_OPS[case["op"]])
+    vals, extra = orc.arith(op, l, r, mode=2 if ls else 1 if rs else 0)
+    assert vals.dtype == kat.NP[case["expect_dtype"]], (vals.dtype, case["expect_dtype"])
+    valid = np.ones(len(vals), bool)
+    for v in (lv, rv, extra):
+        if v is not None:
+            valid &= v
+    got = [vals[i].item() if valid[i] else None for i in range(len(vals))]
+    assert len(got) == len(case["expect"])
+    for g, e in zip(got, case["expect"]):
+        assert kat.same_value(g, e, 1e-15), (case["id"], got, case["expect"])
+
+
+CMP_OPS = {"eq": "EQ", "ne": "NE", "lt": "LT", "le": "LE", "gt": "GT", "ge": "GE"}
+FLIP = {"eq": "eq", "ne": "ne", "lt": "gt", "le": "ge", "gt": "lt", "ge": "le"}
+
+
+@pytest.mark.parametrize("case", kat.load_cases("compare"), ids=lambda c: c["id"])
+def test_compare_kats(orc, case):
+    l, lv, ls = _operand(case["lhs"], case["dtype"])
+    r, rv, rs = _operand(case["rhs"], case["dtype"])
+    for name, exp in case["expect"].items():
+        if ls:          # scalar on the left: the comparison is evaluated with the operands swapped (the broadcast kernels take the scalar on the right)
+            vals = orc.cmp(getattr(orc, CMP_OPS[FLIP[name]]), r, l)
+            valid = rv
+        else:
+            vals = orc.cmp(getattr(orc, CMP_OPS[name]), l, r)
+            valid = lv if rs else (None if lv is None and rv is None else (np.ones(len(vals), bool) if lv is None else lv) & (np.ones(len(vals), bool) if rv is None else rv))
+        got = [bool(vals[i]) if (valid is None or valid[i]) else None for i in range(len(vals))]
+        assert got == exp, (case["id"], name, got, exp)
+
+
+@pytest.mark.parametrize("case", kat.load_cases("bool_logic"), ids=lambda c: c["id"])
+def test_bool_logic_kats(case):
+    """Kleene and / or / not on nullable Booleans (crates/polars-core/src/chunked_array/comparison/mod.rs test_bitwise_ops, test_kleene) against the numpy
+    restatement the compiled-program interpreter uses (tests/program_eval.py)."""
+    from tests import program_eval as pe
+    l, lv, _ = kat.column(case["lhs"], "bool")
+    r, rv, _ = kat.column(case["rhs"], "bool")
+    lv = np.ones(len(l), bool) if lv is None else lv
+    rv = np.ones(len(r), bool) if rv is None else rv
+    for name, exp in case["expect"].items():
+        if name == "not_rhs":
+            vals, valid = ~r, rv
+        else:
+            vals, valid = pe.kleene(name, l, lv, r, rv)
+        got = [bool(vals[i]) if valid[i] else None for i in range(len(vals))]
+        assert got == exp, (case["id"], name, got, exp)
 
 
 def _join_frames(orc, case):
