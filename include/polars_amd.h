@@ -195,6 +195,10 @@ int plx_device_info(char* name_out, size_t name_cap, int32_t* cu_count, uint64_t
 int plx_memory_stats(uint64_t* in_use, uint64_t* high_water);
 /* return cached free blocks to the driver */
 int plx_memory_trim(void);
+/* Pre-grows the device memory pool: after the call its cache holds a free block of at least `bytes`.  Mapping device memory costs ~30 ms per GB
+ * (hipMalloc); an executor that expects queries with large intermediates (the record pool of a partitioned group-by over 1e9 rows: 12-25 GB) sizes the
+ * pool once at start-up, the way the reference's GPU engine sizes its RMM pool, instead of paying inside its first query. */
+int plx_memory_reserve(uint64_t bytes);
 
 /* ---- columns ----------------------------------------------------------- */
 /* Copy a host Arrow-layout buffer pair to HBM. `validity` may be NULL (no nulls);

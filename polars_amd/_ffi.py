@@ -109,6 +109,7 @@ SIGNATURES = {
     "plx_device_info": (C.c_int, [C.c_char_p, C.c_size_t, _i32p, _u64p]),
     "plx_memory_stats": (C.c_int, [_u64p, _u64p]),
     "plx_memory_trim": (C.c_int, []),
+    "plx_memory_reserve": (C.c_int, [C.c_uint64]),
     "plx_column_from_host": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, _u64p]),
     "plx_column_from_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, _u64p]),
     "plx_column_placeholder": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, _u64p]),

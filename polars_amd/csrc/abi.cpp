@@ -70,6 +70,7 @@ int plx_device_info(char* name_out, size_t name_cap, int32_t* cu_count, uint64_t
 }
 int plx_memory_stats(uint64_t* in_use, uint64_t* high_water) { PLX_TRY pool_stats(in_use, high_water); PLX_CATCH }
 int plx_memory_trim(void) { PLX_TRY pool_trim(); PLX_CATCH }
+int plx_memory_reserve(uint64_t bytes) { PLX_TRY device(); pool_reserve((size_t)bytes); PLX_CATCH }
 
 // ---- columns ---------------------------------------------------------------------
 int plx_column_from_host(plx_dtype dtype, const void* values, const uint8_t* validity, int64_t bit_offset, int64_t len, plx_column* out) {

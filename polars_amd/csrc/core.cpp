@@ -69,6 +69,7 @@ struct Pool {
   std::mutex mu;
   std::multimap<size_t, FreeBlock> free_blocks;  // cap -> block
   uint64_t in_use = 0, high = 0, cached = 0;
+  size_t reserve = 0;     // plx_memory_reserve: trims keep one cached block of at least this size
 } g_pool;
 
 size_t size_class(size_t bytes) {
@@ -103,7 +104,7 @@ DevBuf::~DevBuf() {
   g_pool.cached += cap;
 }
 
-Buf dev_alloc(size_t bytes) {
+static Buf dev_alloc_impl(size_t bytes, bool transient) {
   Device& dev = device();
   size_t cap = size_class(bytes);
   void* p = nullptr;
@@ -112,8 +113,10 @@ Buf dev_alloc(size_t bytes) {
   {
     std::lock_guard<std::mutex> lk(g_pool.mu);
     auto it = g_pool.free_blocks.lower_bound(cap);
-    // exact class below 2 MiB; best fit within +25% above (large blocks rarely repeat their exact size)
-    if (it != g_pool.free_blocks.end() && (it->first == cap || (cap > (size_t(1) << 21) && it->first <= cap + cap / 4))) {
+    // exact class below 2 MiB; best fit within +25% above (large blocks rarely repeat their exact size).  A TRANSIENT request (a query's record pool: gone when
+    // the query returns) takes the smallest cached block that holds it, however much larger: mapping fresh memory costs ~30 ms per GB (hipMalloc), and the block
+    // goes back to the cache in a moment
+    if (it != g_pool.free_blocks.end() && (it->first == cap || (cap > (size_t(1) << 21) && (it->first <= cap + cap / 4 || (transient && cap >= (size_t(64) << 20)))))) {
       reused = it->second; p = reused.ptr; cap = it->first; g_pool.free_blocks.erase(it); g_pool.cached -= cap;
     }
     over = g_pool.cached > dev.hbm_bytes / 2;
@@ -140,6 +143,13 @@ Buf dev_alloc(size_t bytes) {
   g_pool.in_use += cap; g_pool.high = std::max(g_pool.high, g_pool.in_use);
   return b;
 }
+Buf dev_alloc(size_t bytes) { return dev_alloc_impl(bytes, false); }
+Buf dev_alloc_transient(size_t bytes) { return dev_alloc_impl(bytes, true); }
+// A free block of at least `bytes` in the pool's cache (mapped now, so that no query pays for it): what an engine does when it sizes its memory pool at start-up.
+void pool_reserve(size_t bytes) {
+  { std::lock_guard<std::mutex> lk(g_pool.mu); g_pool.reserve = bytes ? size_class(bytes) : 0; }
+  if (bytes) { Buf b = dev_alloc_impl(bytes, true); }      // allocated (or found), released into the cache at once
+}
 Buf dev_alloc_zero(size_t bytes) {
   Buf b = dev_alloc(bytes);
   PLX_HIP(hipMemsetAsync(b->ptr, 0, b->cap, stream()));
@@ -159,12 +169,18 @@ void pool_trim() {
   if (!device_ready()) return;
   (void)hipStreamSynchronize(stream());
   std::lock_guard<std::mutex> lk(g_pool.mu);
-  for (auto& kv : g_pool.free_blocks) {
-    if (kv.second.ev) { (void)hipEventSynchronize(kv.second.ev); (void)hipEventDestroy(kv.second.ev); }
+  // the reserved block (plx_memory_reserve) survives: the smallest cached block that is at least that large
+  auto keep = g_pool.reserve ? g_pool.free_blocks.lower_bound(g_pool.reserve) : g_pool.free_blocks.end();
+  std::pair<size_t, FreeBlock> kept{0, FreeBlock{nullptr, nullptr, nullptr}};
+  for (auto it = g_pool.free_blocks.begin(); it != g_pool.free_blocks.end(); ++it) {
+    auto& kv = *it;
+    if (kv.second.ev) { (void)hipEventSynchronize(kv.second.ev); (void)hipEventDestroy(kv.second.ev); kv.second.ev = nullptr; }
     else if (kv.second.stream && kv.second.stream != stream()) (void)hipStreamSynchronize(kv.second.stream);
+    if (it == keep) { kept = {kv.first, kv.second}; continue; }
     (void)hipFree(kv.second.ptr);
   }
   g_pool.free_blocks.clear(); g_pool.cached = 0;
+  if (kept.second.ptr) { g_pool.free_blocks.emplace(kept.first, kept.second); g_pool.cached = kept.first; }
 }
 
 // --------------------------------------------------------------- helpers ----

@@ -90,6 +90,8 @@ struct DevBuf {
 using Buf = std::shared_ptr<DevBuf>;
 Buf dev_alloc(size_t bytes);               // uninitialised, 256-B aligned, padded by >= 64 B
 Buf dev_alloc_zero(size_t bytes);          // hipMemsetAsync 0 on the current stream
+Buf dev_alloc_transient(size_t bytes);     // a query's big scratch buffer (record pools): any cached block that holds it is taken, not only one within +25 %
+void pool_reserve(size_t bytes);           // make sure the cache holds a free block of at least `bytes`
 Buf dev_borrow(void* p, size_t bytes);
 void pool_stats(uint64_t* in_use, uint64_t* high_water);
 void pool_trim();

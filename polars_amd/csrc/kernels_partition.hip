@@ -476,7 +476,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   PLX_REQUIRE(pp.n_hot == hot_keys.size(), PLX_ERR_INVALID, "partitioned_agg2: plan / hot key list mismatch");
   const uint32_t chunk_dw = kP2ChunkRecs * pp.rec_words;
   const int64_t n_chunks = (int64_t)pp.scatter_grid * pp.chunks_per_wg;
-  Buf recs = dev_alloc((size_t)n_chunks * chunk_dw * 4 + 256);
+  Buf recs = dev_alloc_transient((size_t)n_chunks * chunk_dw * 4 + 256);
   Buf chunk_part = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks), chunk_fill = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks);
   PLX_HIP(hipMemsetAsync(chunk_part->ptr, 0xff, sizeof(uint32_t) * (size_t)n_chunks, stream()));
   Buf meta = dev_alloc_zero(64);             // [0..1] group counter (u64), [2] aggregation overflow, [3..4] scatter flags
@@ -766,7 +766,7 @@ static bool probe_hits_impl(const Shape& sh, const Args& args, const DirectJoinT
   if (!aot && !jit::ensure(sh, jk, args.n_rows)) return false;
   const uint32_t chunk_dw = kP2ChunkRecs * pp.rec_words;
   const int64_t n_chunks = (int64_t)pp.scatter_grid * pp.chunks_per_wg;
-  Buf recs = dev_alloc((size_t)n_chunks * chunk_dw * 4 + 256);
+  Buf recs = dev_alloc_transient((size_t)n_chunks * chunk_dw * 4 + 256);
   Buf chunk_part = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks), chunk_fill = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks);
   PLX_HIP(hipMemsetAsync(chunk_part->ptr, 0xff, sizeof(uint32_t) * (size_t)n_chunks, stream()));
   Buf meta = dev_alloc_zero(64);             // [0..1] hit counter (u64), [3..4] scatter flags

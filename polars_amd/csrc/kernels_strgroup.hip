@@ -614,7 +614,7 @@ int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uin
   const uint32_t chunks_per_wg = (uint32_t)(rounds_per_wg * kSgTile / kSgChunkRecs + NP + 2);
   if (chunks_per_wg >= (1u << 21)) return -1;                                              // the scatter packs workgroup-local chunk indices into 21 bits
   const int64_t n_chunks = (int64_t)grid * chunks_per_wg;
-  Buf recs = dev_alloc((size_t)n_chunks * kSgChunkDw * 4 + 256);
+  Buf recs = dev_alloc_transient((size_t)n_chunks * kSgChunkDw * 4 + 256);
   Buf chunk_part = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks), chunk_fill = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks);
   PLX_HIP(hipMemsetAsync(chunk_part->ptr, 0xff, sizeof(uint32_t) * (size_t)n_chunks, stream()));
   Buf meta = dev_alloc_zero(64);              // [0..1] group counter, [2] overflow, [3..5] scatter flags

@@ -154,8 +154,10 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["dry_run"] is True and d["config"]["workload"] == "tpch_q1_sf100_x2" and d["verified"]["ok"] is True
     ex = d["extras"]
-    assert set(ex) == {"tpch_q3_sf100_sharded_x2", "cfg3_groupby_1e6_keys_sharded_x2", "cfg5_dict_string_keys_sharded_x2"}, list(ex)
-    q3 = ex["tpch_q3_sf100_sharded_x2"]
+    assert set(ex) == {"tpch_q3_sf100_sharded_x2", "tpch_q3_sf100_sharded_x2_shuffle", "cfg3_groupby_1e6_keys_sharded_x2", "cfg5_dict_string_keys_sharded_x2"}, list(ex)
+    qa = ex["tpch_q3_sf100_sharded_x2"]
+    assert qa["scaling"] == "strong" and qa["exchange_mode"] == "broadcast" and qa["verified"]["ok"] is True and qa["partial_rows_per_rank"] > 0
+    q3 = ex["tpch_q3_sf100_sharded_x2_shuffle"]
     assert q3["scaling"] == "strong" and q3["exchange_mode"] == "shuffle" and q3["verified"]["ok"] is True and q3["verified"]["keys_disjoint_across_ranks"] is True
     assert all(p["covers_whole_input"] and p["ok"] for p in q3["verified"]["per_rank"]) and q3["shuffle"]["rows_sent_per_rank_per_step"] > 0
     assert q3["shuffle"]["bytes_sent_per_rank_per_step"] == q3["shuffle"]["rows_sent_per_rank_per_step"] * 32        # four 8-byte columns on either side
