@@ -233,7 +233,7 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
   uint32_t tiles = 0;
   for (uint32_t t : {4u, 3u, 2u, 1u}) {
     if (kEnvP2Tiles > 0 && t > (uint32_t)kEnvP2Tiles) continue;
-    if (pp.mode == kP2Hash && t > 3) continue;      // hash partitions keep the 64-bit key and its hash live: four tiles spill (24 B / lane; a scratch reload waits for every load in flight)
+    if ((pp.mode == kP2Hash || pp.n_hot) && t > 3) continue;      // hash partitions keep the 64-bit key and its hash live, the hot-key path its lookups: four tiles spill (12-24 B / lane; a scratch reload waits for every load in flight)
     if (part3_scatter_lds(kP2MaxBlock * kRows * t, L.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies) <= lds_total) { tiles = t; break; }
   }
   if (!tiles) return false;
@@ -421,11 +421,15 @@ __global__ __launch_bounds__(kBlock) void hot_emit_kernel(const unsigned long lo
   X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow)                                      \
   X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackFused) \
   X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackNone)
+// ... and with the hot-key path compiled in (skewed keys: heavy hitters are summed in the scatter), for config 3's two runs -- key range unknown / known
+#define PLX_P3_HOT_COMBOS(X) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 3, kPackFused)
 #else
 #define PLX_P3_COMBOS(X)
+#define PLX_P3_HOT_COMBOS(X)
 #endif
-static bool part3_static_available(int static_id, uint32_t mode, uint32_t tiles, uint32_t pack) {
+static bool part3_static_available(int static_id, uint32_t mode, uint32_t tiles, uint32_t pack, bool hot) {
 #define X(ID, MODE, TILES, PACK) if (static_id == ID && mode == (uint32_t)MODE && tiles == (uint32_t)TILES && pack == (uint32_t)PACK) return true;
+  if (hot) { PLX_P3_HOT_COMBOS(X) return false; }
   PLX_P3_COMBOS(X)
 #undef X
   return false;
@@ -439,7 +443,17 @@ static void part3_static_scatter(int static_id, const Shape& sh, const Args& arg
     hipLaunchKernelGGL(kern, dim3(pp.scatter_grid), dim3(pp.block), lds, stream(), sh, args, pp, sp);                                   \
     return;                                                                                                                            \
   }
-  PLX_P3_COMBOS(X)
+  if (!pp.n_hot) { PLX_P3_COMBOS(X) }
+#undef X
+#define X(ID, MODE, TILES, PACK)                                                                                                       \
+  if (static_id == ID && pp.mode == (uint32_t)MODE && pp.tiles == (uint32_t)TILES && pp.pack == (uint32_t)PACK) {                        \
+    auto kern = part3_scatter_kernel<StatProg<ID>, (int)MODE, TILES, (int)PACK, true>;                                                         \
+    static bool attr_set = false;                                                                                                      \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); attr_set = true; } \
+    hipLaunchKernelGGL(kern, dim3(pp.scatter_grid), dim3(pp.block), lds, stream(), sh, args, pp, sp);                                   \
+    return;                                                                                                                            \
+  }
+  if (pp.n_hot) { PLX_P3_HOT_COMBOS(X) }
 #undef X
 }
 static void part3_static_agg(int static_id, const PartPlan2& pp, const AggParams2& ap, uint32_t NP, size_t lds) {
@@ -449,6 +463,7 @@ static void part3_static_agg(int static_id, const PartPlan2& pp, const AggParams
     return;                                                                                                                            \
   }
   PLX_P3_COMBOS(X)
+  PLX_P3_HOT_COMBOS(X)       // (the aggregation pass is the same kernel with or without hot keys; its instantiations are among the plain combos: a no-op here)
 #undef X
 }
 
@@ -460,7 +475,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   const uint32_t NP = 1u << pp.log2_parts;
   const bool direct = pp.mode == kP2Direct;
   const bool gen3 = pp.gen == 3;
-  const bool is_static = gen3 ? (pp.n_hot == 0 && part3_static_available(static_id, pp.mode, pp.tiles, pp.pack))      // the AOT builds leave the hot-key path out
+  const bool is_static = gen3 ? part3_static_available(static_id, pp.mode, pp.tiles, pp.pack, pp.n_hot != 0)      // most AOT builds leave the hot-key path out
                               : (static_id == SHAPE_GB_SUM_CNT_I64 || static_id == SHAPE_GB_SUM_MEAN_U32_F64);   // the cases of PLX_PART2_STATIC_CASES
   const jit::Sink jk_scatter = gen3 ? jit::part3_scatter_sink(pp.mode, pp.tiles, pp.pack, pp.n_hot != 0)
                                     : pp.tiles == 2 ? (direct ? jit::PART2_SCATTER_DIRECT_T2 : jit::PART2_SCATTER_HASH_T2) : (direct ? jit::PART2_SCATTER_DIRECT : jit::PART2_SCATTER_HASH);
@@ -471,7 +486,8 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   // the kernels' names in the HIP-event profile carry the variant (mode, tiles, packing, record dwords): a counter file of another variant must never
   // be read as this one's (bench.py pmc_traffic matches the full name)
   const std::string sid = use_jit ? "jit" : "#" + std::to_string(static_id);
-  const std::string scatter_name = std::string(gen3 ? "part3_scatter[" : "part2_scatter[") + sid + (direct ? ",d,t" : ",h,t") + std::to_string(pp.tiles) + (gen3 ? ",p" + std::to_string(pp.pack) : "") + "]";
+  const std::string scatter_name = std::string(gen3 ? "part3_scatter[" : "part2_scatter[") + sid + (direct ? ",d,t" : ",h,t") + std::to_string(pp.tiles) + (gen3 ? ",p" + std::to_string(pp.pack) : "") +
+                                   (gen3 && pp.n_hot ? ",hot]" : "]");
   const std::string agg_name = "part_agg_lds[" + sid + (direct ? ",d,p" : ",h,p") + std::to_string(pp.pack) + "]";
   PLX_REQUIRE(pp.n_hot == hot_keys.size(), PLX_ERR_INVALID, "partitioned_agg2: plan / hot key list mismatch");
   const uint32_t chunk_dw = kP2ChunkRecs * pp.rec_words;
@@ -773,7 +789,7 @@ static bool probe_hits_impl(const Shape& sh, const Args& args, const DirectJoinT
   ScatterParams2 sp{};
   sp.recs = recs->as<unsigned int>(); sp.chunk_part = chunk_part->as<unsigned int>(); sp.chunk_fill = chunk_fill->as<unsigned int>(); sp.flags = meta->as<unsigned int>() + 3;
   {
-    const std::string name = aot ? "probe_scatter[#" + std::to_string(static_id) + (hashed ? ",d,t4,p3,h]" : ",d,t4,p3]") : std::string(hashed ? "probe_scatter[jit,h]" : "probe_scatter[jit]");
+    const std::string name = aot ? "probe_scatter[#" + std::to_string(static_id) + ",d,t4,p3]" : std::string("probe_scatter[jit]");     // (one kernel for range and hash partitions: PartPlan2::hash_bits)
     ProfileScope ps(name.c_str(), scan_bytes(sh, args) + (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
     const size_t slds = part3_scatter_lds(pp.block * kRows * pp.tiles, pp.rec_words, NP, 0, 0, sh.n_aggs, 1);
     if (aot) {
@@ -809,7 +825,8 @@ static bool probe_hits_impl(const Shape& sh, const Args& args, const DirectJoinT
     hb.table_keys = ht->keys; hb.table_head = ht->head; hb.log2_cap = ht->log2_cap; hb.hash_bits = pp.hash_bits;
   }
   {
-    ProfileScope ps(hashed ? "probe_pass_lds_bloom_hashed" : "probe_pass_lds_bitmap", (uint64_t)args.n_rows * pp.rec_words * 4 + (hashed ? n_build * 12 : dt.range / 8), (uint64_t)args.n_rows);
+    ProfileScope ps("probe_pass_lds",     // one kernel symbol for the bitmap-slice, Bloom-from-bitmap and Bloom-from-hash-table sources: one tracer name (the plan description says which)
+                    (uint64_t)args.n_rows * pp.rec_words * 4 + (hashed ? n_build * 12 : dt.range / 8), (uint64_t)args.n_rows);
     const unsigned long long n_words = hashed ? 0ull : (dt.range / 512 + 1) * 8;
     hipLaunchKernelGGL(probe_pass_kernel, dim3(NP), dim3(kP2AggBlock), ((size_t)1 << (log2_bloom - 3)), stream(), recs->as<unsigned int>(), chunk_fill->as<unsigned int>(),
                        cl_off->as<unsigned long long>(), cl_ids->as<unsigned int>(), hashed ? nullptr : dt.bits, hashed ? 0ull : dt.range, n_words, pp.key_shift, log2_bloom, exact ? 1u : 0u, hb,

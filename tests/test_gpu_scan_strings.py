@@ -1,5 +1,5 @@
-"""GPU tests added in round 3.  New tests start with the `gpu_unvalidated` marker (conftest.py keeps them out of `-m gpu`) and are
-promoted to `gpu` only after a gpurun session has passed them (`pytest -m gpu_unvalidated`)."""
+"""String columns of file scans in predicates and group keys: a literal compared with a scanned column on the first collect (the dictionary exists only after
+the scan was materialised), hive string partition keys, Datetime[ns] statistics against plain numbers, concat of lazy scans grouped by a string key."""
 import os
 
 import numpy as np
@@ -7,7 +7,7 @@ import pyarrow as pa
 import pyarrow.parquet as pq
 import pytest
 
-pytestmark = pytest.mark.gpu          # validated on hardware: gpurun_out/r03a (round 3, first call)
+pytestmark = pytest.mark.gpu
 
 
 def test_string_literal_filter_on_a_scanned_column_first_collect(pl, tmp_path):

@@ -1,4 +1,4 @@
-"""Round 3, third batch: the string-key group-by operator (plx_strview_groupby; kernels_strgroup.hip) -- group_by(<Utf8View column held as
+"""The string-key group-by operator (plx_strview_groupby; kernels_strgroup.hip) -- group_by(<Utf8View column held as
 views>).agg(sum / mean / count / len) without a dictionary-encode pass.  Reference semantics: crates/polars-expr/src/hash_keys.rs:413-452
 (BinviewKeys), crates/polars-compute/src/binview_index_map.rs.  Checked against numpy on the generator's host twin and against the
 encode-then-group route of the same library (which the earlier rounds pinned to the oracle)."""
