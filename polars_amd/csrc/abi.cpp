@@ -893,12 +893,19 @@ int plx_jit_selftest(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int
         const uint32_t best = fused::best_static_pack(sh, mode);
         for (uint32_t pack = 0; pack <= best; pack++) {
           if (pack == fused::kPackNarrow && fused::rec_layout2(sh, mode, fused::kPackNarrow).rec_words == fused::rec_layout2(sh, mode, fused::kPackNone).rec_words) continue;
-          for (uint32_t tiles : {1u, 2u, 4u}) { jobs.push_back({sh, jit::part3_scatter_sink(mode, tiles, pack, false)}); jobs.push_back({sh, jit::part3_scatter_sink(mode, tiles, pack, true)}); }
+          for (uint32_t tiles : {1u, 2u, 3u, 4u}) { jobs.push_back({sh, jit::part3_scatter_sink(mode, tiles, pack, false)}); jobs.push_back({sh, jit::part3_scatter_sink(mode, tiles, pack, true)}); }
           jobs.push_back({sh, jit::part3_agg_sink(mode, pack)});
         }
       }
     }
-    if (sh.n_keys >= 2) jobs = {{sh, jit::WIDE}};
+    if (sh.n_keys >= 2) {
+      // wide key: the HBM table sink, and the partitioned path -- hash partitions, plain or narrowed records, no hot keys
+      jobs = {{sh, jit::WIDE}};
+      for (uint32_t pack = 0; pack <= std::min<uint32_t>(fused::best_static_pack(sh, fused::kP2Hash), fused::kPackNarrow); pack++) {
+        for (uint32_t tiles : {1u, 2u, 3u}) jobs.push_back({sh, jit::part3_scatter_sink(fused::kP2Hash, tiles, pack, false)});
+        jobs.push_back({sh, jit::part3_agg_sink(fused::kP2Hash, pack)});
+      }
+    }
   }
   for (auto& j : jobs) {
     const std::string log = jit::selftest(j.first, j.second);

@@ -955,8 +955,8 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     Args sa = args; sa.n_rows = S;
     FusedAggResult tmp;
     std::vector<uint64_t> hot;
-    const bool may_partition = !kp.wide && !(c.plan.flags & PLX_PLAN_NO_PARTITION) && n >= ((int64_t)1 << 24);
-    const bool strided = may_partition && part_version() == 2;
+    const bool may_partition = !(c.plan.flags & PLX_PLAN_NO_PARTITION) && n >= ((int64_t)1 << 24);
+    const bool strided = may_partition && !kp.wide && part_version() == 2;
     const int64_t Sd = strided ? kPartSampleRows : S;
     double g_est = -1.0;
     int64_t d = kp.wide ? run_wide_agg(sh, sa, 23, kp.wide_nullable, tmp, true)
@@ -968,6 +968,30 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     desc += "sample(distinct=" + std::to_string(d) + "/" + std::to_string(Sd) + ")+";
     // many rows, many groups: per-row global atomics are bound by the ~24 G/s device atomic rate; partition the
     // rows and aggregate each partition in LDS instead (kernels_partition.hip)
+    // a wide (multi-column, unpackable) key takes the same partitioned path: records carry one word per key column, partitions come from the hash of the
+    // words + null mask, the LDS tables compare word by word (the reference row-encodes such keys: crates/polars-row, hash_keys.rs:334 RowEncodedKeys)
+    if (kp.wide && may_partition && part_version() == 2 && G >= 4096.0) {
+      k::SrcRange ranges[kMaxSrc];
+      source_ranges(c, ranges);
+      double plan_for = G * 1.3;
+      for (int attempt = 0; attempt < 3; attempt++) {
+        PartPlan2 p2;
+        if (!k::partition_plan2(sh, plan_for, -1, len_idx, n, 0, &p2, ranges)) break;
+        std::string pd;
+        Buf ok, okv, oacc;
+        int64_t stride = 0;
+        const int64_t g = k::partitioned_agg2(sh, args, p2, -1, {}, &ok, &okv, &oacc, &pd, nullptr, &stride);
+        if (g >= 0) {
+          res.n_groups = g; res.n_aggs = sh.n_aggs; res.wide_words = ok; res.wide_valid = okv; res.wide_stride = stride; res.acc = oacc;
+          desc += std::string("fused_scan[") + jit::program_mode(-1, args.n_rows) + "]+" + pd;
+          return;
+        }
+        if (g == -2) { desc += "v2-unavailable+"; break; }
+        desc += "lds-overflow(P=" + std::to_string(1u << p2.log2_parts) + ")+";
+        if (p2.log2_parts >= 9) break;
+        plan_for = std::max(plan_for * 2.0, (double)((uint64_t)p2.n_slots << p2.log2_parts) * 1.01);
+      }
+    }
     if (!kp.wide && !(c.plan.flags & PLX_PLAN_NO_PARTITION) && G >= 4096.0 && n >= ((int64_t)1 << 24)) {
       bool any_null = c.key >= 0 && c.nodes[c.key].nullable;
       for (auto& a : c.aggs) if (a.second >= 0 && c.nodes[a.second].nullable) any_null = true;

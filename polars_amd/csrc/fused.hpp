@@ -263,11 +263,12 @@ constexpr uint32_t kNoChunk = 0xffffffffu;
 //                field: key_shift + 32 row bits always fit); null keys never become records, so there is no validity dword
 constexpr uint32_t kPackNone = 0, kPackNarrow = 1, kPackFused = 2, kPackRowid = 3;
 struct RecLayout2 {
-  uint8_t key_words;             // 1 | 2 dwords
+  uint8_t n_key_cols;            // 0: one key slot (Shape::key); 2..kMaxKeys: a wide key -- Shape::keys, one 64-bit word per key column, null keys flagged in the validity dword
+  uint8_t key_words;             // 1 | 2 dwords (wide key: 2 per key column)
   uint8_t key_kind;              // 0: 64-bit, 1: i32 (sign-extended on read), 2: u32 (zero-extended)
   uint8_t pack;                  // kPack*
   uint8_t n_src;
-  uint8_t has_valid, valid_off;  // one dword: bit j = source j valid, bit 31 = key valid
+  uint8_t has_valid, valid_off;  // one dword: bit j = source j valid, bit 31 = key valid (wide key: bit 24 + i = key column i valid)
   uint8_t has_rowid, rowid_off;  // two dwords
   uint8_t rec_words;
   uint8_t src_kind[kMaxSrc], src_off[kMaxSrc];   // kind 0: 64-bit, 1: i32, 2: u32, 3: u32 offset from PartPlan2::src_base[j] (packing)
@@ -310,8 +311,12 @@ PLX_FHD constexpr RecLayout2 rec_layout2(const Shape& sh, uint32_t mode, uint32_
   for (int k = 0; k < kMaxAggs; k++) { L.agg_src[k] = kNone; L.src_slot[k] = 0; }
   for (int j = 0; j < kMaxSrc; j++) { L.src_kind[j] = 0; L.src_off[j] = 0; }
   uint32_t w = 0, n_src = 0;
-  L.key_kind = mode == kP2Direct ? 2 : narrow_kind(sh, sh.key);
-  L.key_words = L.key_kind ? 1 : 2;
+  L.n_key_cols = sh.n_keys;
+  if (sh.n_keys) { L.key_kind = 0; L.key_words = (uint8_t)(2 * sh.n_keys); }      // hash mode only (the planner never plans direct partitions for a wide key)
+  else {
+    L.key_kind = mode == kP2Direct ? 2 : narrow_kind(sh, sh.key);
+    L.key_words = L.key_kind ? 1 : 2;
+  }
   w += L.key_words;
   for (int k = 0; k < sh.n_aggs; k++) {
     const uint8_t kind = sh.aggs[k].kind;
@@ -358,6 +363,7 @@ struct PartPlan2 {
   int64_t src_base[kMaxSrc];   // packing: value a kind-3 source is stored relative to
   int64_t key_base;            // direct mode: the dense id is key - key_base (0: the program already produces dense ids)
   uint32_t oob_drop;           // direct mode: 1 = rows whose id lies outside the partitions are dropped (join probe: such keys match nothing); 0 = the query fails
+  uint32_t wide_null_word;     // wide key with a nullable key column: the LDS tables keep the null mask as one more key word
   uint32_t interleave;         // direct mode, group-by: partition = the id's LOW log2_parts bits, table slot = id >> log2_parts (ids are usually handed out in order of
                                // first appearance or popularity -- dictionary codes, zipf-like keys: the high bits would put all popular ids into partition 0)
   uint32_t hash_bits;          // direct mode, join probe on keys WITHOUT a usable range: the "dense id" is the top hash_bits bits of key * kP2HashMult (0: key - key_base)

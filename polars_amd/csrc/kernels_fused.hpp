@@ -73,7 +73,8 @@ void select_hot_keys(const fused::HashTable& t, int n_aggs, int len_idx, uint64_
 // key_range_out (may be null): [2] receives the exact signed min / max of the valid keys the scatter pass streamed (hash mode
 // only; min > max when it saw none) -- statistics gathered as a by-product
 int64_t partitioned_agg2(const fused::Shape& sh, const fused::Args& args, const fused::PartPlan2& pp, int static_id, const std::vector<uint64_t>& hot_keys, Buf* out_keys,
-                         Buf* out_kvalid, Buf* out_acc, std::string* desc, int64_t* key_range_out = nullptr);
+                         Buf* out_kvalid, Buf* out_acc, std::string* desc, int64_t* key_range_out = nullptr, int64_t* wide_stride_out = nullptr);
+// (wide key -- Shape::n_keys != 0: *out_keys = [n_keys][stride] key words, *out_kvalid = [n_keys][stride] valid flags, *wide_stride_out = stride)
 // ---- partitioned join probe (probe keys in no particular order) ----------------------------------------------------------------
 // A direct-address join table is a bitmap over the build key range: 75 MB for TPC-H SF100 orders.  Probe keys that arrive in key
 // order walk it line by line out of the L2; probe keys in RANDOM order fetch one 128-B line from the Infinity Cache per row -- the

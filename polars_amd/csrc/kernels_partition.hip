@@ -246,12 +246,14 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
 bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, PartPlan2* out, const SrcRange* src_ranges) {
   PartPlan2 pp{};
   pp.gen = 2;
-  if (sh.key == kNone || sh.n_keys) return false;
+  if (sh.key == kNone && !sh.n_keys) return false;
+  const bool wide = sh.n_keys != 0;                // a multi-column key compared word by word: hash partitions only, no hot keys
+  if (wide && n_hot) return false;
   const size_t lds_total = 160 * 1024 - 2048;      // leave room for the kernels' static shared variables
   pp.len_idx = (uint32_t)(len_idx < 0 ? 0 : len_idx);
   // ---- table geometry
   bool direct = false;
-  if (packed_bits > 0 && packed_bits <= 25 && kEnvP2Direct != 0 && len_idx >= 0) {
+  if (!wide && packed_bits > 0 && packed_bits <= 25 && kEnvP2Direct != 0 && len_idx >= 0) {
     // direct-address LDS table: slots = low bits of the id; as many partitions as give every CU work, tables as large as fit
     uint32_t max_shift = 0;
     while (((size_t)1 << (max_shift + 1)) * sh.n_aggs * 8 <= 128 * 1024) max_shift++;
@@ -272,7 +274,9 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
     // LDS open-addressing table of a partition: keys + cells, ANY number of slots (slot = mulhi(hash32, n_slots)), as many as 144 KB hold.  Fewer partitions
     // make the scatter faster (its per-round cost is per partition: 256 partitions of 16-byte records move two lines per partition and round, 512 one), so the
     // smallest partition count whose tables stay at or below a load of 0.85 x the caller's padded estimate (it passes 1.3 x its own: a real load of ~0.65).
-    const uint32_t n_slots = (uint32_t)std::min<size_t>((144 * 1024) / (8 * (1 + (size_t)sh.n_aggs)) - 2, (size_t)1 << 14);
+    pp.wide_null_word = wide && shape_may_have_nulls(sh) ? 1u : 0u;
+    const size_t slot_words = wide ? 1 + (size_t)sh.n_keys + pp.wide_null_word + (size_t)sh.n_aggs : 1 + (size_t)sh.n_aggs;      // wide: state word + key words (+ null mask) + cells
+    const uint32_t n_slots = (uint32_t)std::min<size_t>((144 * 1024) / (8 * slot_words) - 2, (size_t)1 << 14);
     if (n_slots < 256) return false;
     const double per_part = (double)n_slots * 0.85;
     uint32_t lp = 6;
@@ -470,7 +474,7 @@ static void part3_static_agg(int static_id, const PartPlan2& pp, const AggParams
 // Runs scatter -> chunk sort -> aggregate (+ hot groups).  Outputs (allocated here): dense keys / valid flags / cells.
 // Returns the number of groups, -1 if an LDS table overflowed (the caller plans more partitions or falls back), -2 if no specialised kernel is available.
 int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& plan, int static_id, const std::vector<uint64_t>& hot_keys, Buf* out_keys, Buf* out_kvalid,
-                         Buf* out_acc, std::string* desc, int64_t* key_range_out) {
+                         Buf* out_acc, std::string* desc, int64_t* key_range_out, int64_t* wide_stride_out) {
   PartPlan2 pp = plan;
   const uint32_t NP = 1u << pp.log2_parts;
   const bool direct = pp.mode == kP2Direct;
@@ -562,19 +566,21 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
                        cl_off->as<unsigned long long>(), cursor->as<unsigned int>(), cl_ids->as<unsigned int>());
     PLX_HIP(hipGetLastError());
   }
-  const uint64_t n_slots = direct ? ((uint64_t)1 << pp.log2_slots) : ((uint64_t)pp.n_slots + 2);
+  const bool wide = sh.n_keys != 0;
+  const uint64_t n_slots = direct ? ((uint64_t)1 << pp.log2_slots) : wide ? (uint64_t)pp.n_slots : ((uint64_t)pp.n_slots + 2);
   const uint64_t max_groups = std::min<uint64_t>((uint64_t)NP * n_slots + pp.n_hot, (uint64_t)args.n_rows + 1);
-  *out_keys = dev_alloc(sizeof(uint64_t) * max_groups);
-  *out_kvalid = dev_alloc(max_groups);
+  *out_keys = dev_alloc(sizeof(uint64_t) * max_groups * (wide ? sh.n_keys : 1));        // wide: [n_keys][max_groups] words, [n_keys][max_groups] valid flags
+  *out_kvalid = dev_alloc(max_groups * (wide ? sh.n_keys : 1));
   *out_acc = dev_alloc(sizeof(uint64_t) * max_groups * sh.n_aggs);
   AggParams2 ap{};
   ap.recs = recs->as<unsigned int>(); ap.chunk_fill = chunk_fill->as<unsigned int>(); ap.cl_off = cl_off->as<unsigned long long>(); ap.cl_ids = cl_ids->as<unsigned int>();
   ap.counter = meta->as<unsigned long long>(); ap.overflow = meta->as<unsigned int>() + 2;
   ap.out_keys = (*out_keys)->as<unsigned long long>(); ap.out_kvalid = (*out_kvalid)->as<unsigned char>(); ap.out_acc = (*out_acc)->as<unsigned long long>();
   ap.max_groups = (uint32_t)std::min<uint64_t>(max_groups, 0xffffffffull);
+  if (wide_stride_out) *wide_stride_out = (int64_t)ap.max_groups;
   {
     ProfileScope ps(agg_name.c_str(), (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
-    const size_t lds = n_slots * 8 * ((direct ? 0 : 1) + sh.n_aggs);
+    const size_t lds = n_slots * 8 * ((direct ? 0 : wide ? 1 + sh.n_keys + pp.wide_null_word : 1) + sh.n_aggs);
     if (!use_jit && gen3) part3_static_agg(static_id, pp, ap, NP, lds);
     else if (use_jit) {
       PartPlan2 ppc = pp; AggParams2 apc = ap;
@@ -600,7 +606,8 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   if (minmax) { long long mm[2]; d2h_sync(mm, minmax->ptr, 16); key_range_out[0] = mm[0]; key_range_out[1] = mm[1]; }
   if (desc) *desc = std::string(gen3 ? "partitioned(v3," : "partitioned(v2,") + (direct ? "direct" : "hash") + ",P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec_words * 4) +
                     (gen3 ? "B,pack=" + std::to_string(pp.pack) + ",tile=" + std::to_string(pp.block * kRows * pp.tiles) : "B,ring=" + std::to_string(pp.ring_lines * 128) + "B") +
-                    ",block=" + std::to_string(pp.block) + ",hot=" + std::to_string(pp.n_hot) + ")+" + (direct ? "lds_direct_table(slots=" : "lds_hash_table(slots=") + std::to_string(direct ? 1u << pp.log2_slots : pp.n_slots) + ")";
+                    ",block=" + std::to_string(pp.block) + ",hot=" + std::to_string(pp.n_hot) + ")+" + (direct ? "lds_direct_table(slots=" : wide ? "lds_wide_key_table(words=" + std::to_string(sh.n_keys + pp.wide_null_word) + ",slots=" : "lds_hash_table(slots=") +
+                    std::to_string(direct ? 1u << pp.log2_slots : pp.n_slots) + ")";
   return (int64_t)(((uint64_t)res[1] << 32) | res[0]);
 }
 

@@ -65,10 +65,53 @@ __host__ __device__ inline size_t part2_scatter_lds(uint32_t P, uint32_t ring_li
   return (size_t)P * ring_lines * 128 + (size_t)P * 8 + (size_t)hot_slots * 8 + (size_t)n_hot * n_aggs * copies * 8 + (size_t)P * 4 * 2 + (size_t)hot_slots * 4 + 16;
 }
 
+// hash of a wide (multi-column) key: its 64-bit words and the null mask of its columns (the reference row-encodes such keys and hashes the bytes,
+// crates/polars-row/src/encode.rs, crates/polars-expr/src/hash_keys.rs:334 RowEncodedKeys); the top bits pick the partition, lower bits the LDS slot
+__device__ __forceinline__ uint64_t wide_key_mix(uint64_t h, uint64_t w) { h ^= w; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; return h; }
+__device__ __forceinline__ uint64_t wide_key_hash(const uint64_t* w, uint32_t n_words, uint32_t nullmask) {
+  uint64_t h = 0x9e3779b97f4a7c15ull ^ nullmask;
+  for (uint32_t j = 0; j < n_words; j++) h = wide_key_mix(h, w[j]);
+  return h * 0x55fbfd6bfc5458e9ull;
+}
+
 // ---- one row -> record dwords ---------------------------------------------------------------------------------------
 template <int MODE, class S, class RF>
 __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, const PartPlan2& pp, const RF& rf, int r, int64_t row, unsigned int* rec /* [L.rec_words] */,
                                              uint32_t& part, bool& kvalid, uint64_t& key64) {
+  if (L.n_key_cols) {
+    // wide key (hash partitions): one 64-bit word per key column (0 for a null), the columns' null mask folded into the hash and kept in the validity dword
+    uint64_t w[kMaxKeys];
+    uint32_t nullmask = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxKeys; j++) {
+      w[j] = 0;
+      if (j < (int)L.n_key_cols) {
+        const bool kv = (rf.getv(sh.keys[j]) >> r) & 1;
+        w[j] = kv ? rf.get(r, sh.keys[j]) : 0ull;
+        if (!kv) nullmask |= 1u << j;
+        rec[2 * j] = (uint32_t)w[j]; rec[2 * j + 1] = (uint32_t)(w[j] >> 32);
+      }
+    }
+    const uint64_t h = wide_key_hash(w, L.n_key_cols, nullmask);
+    part = (uint32_t)(h >> (64 - pp.log2_parts));
+    kvalid = true; key64 = 0;                        // (a null key column makes a group of its own; no hot keys / key statistics on this path)
+    uint32_t vb = (nullmask ^ ((1u << L.n_key_cols) - 1u)) << 24;
+#pragma unroll
+    for (int j = 0; j < kMaxSrc; j++) {
+      if (j < (int)L.n_src) {
+        const uint64_t v = rf.get(r, L.src_slot[j]);
+        if (L.src_kind[j] == 3) rec[L.src_off[j]] = (uint32_t)(v - (uint64_t)pp.src_base[j]);
+        else {
+          rec[L.src_off[j]] = (uint32_t)v;
+          if (!L.src_kind[j]) rec[L.src_off[j] + 1] = (uint32_t)(v >> 32);
+        }
+        if ((rf.getv(L.src_slot[j]) >> r) & 1) vb |= 1u << j;
+      }
+    }
+    if (L.has_valid) rec[L.valid_off] = vb;
+    if (L.has_rowid) { rec[L.rowid_off] = (uint32_t)(uint64_t)row; rec[L.rowid_off + 1] = (uint32_t)((uint64_t)row >> 32); }
+    return;
+  }
   kvalid = (rf.getv(sh.key) >> r) & 1;
   key64 = kvalid ? rf.get(r, sh.key) : 0ull;
   if constexpr (MODE == (int)kP2Direct) {
@@ -391,9 +434,14 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   constexpr uint32_t kPerLane = kP2ChunkRecs / 64;    // records of a chunk per lane
   const bool direct = MODE == (int)kP2Direct;
   const uint32_t NS = direct ? 1u << pp.log2_slots : pp.n_slots, n_aggs = sh.n_aggs, RW = L.rec_words, chunk_dw = kP2ChunkRecs * RW;
+  // wide key (L.n_key_cols != 0, hash mode): state [NS] u64 (kEmptyKey | hash | hash + busy bit) | key words [KW][NS] u64 | cells [NS][n_aggs]; no special slots
+  // (a null key column is part of the key: its bit of the null mask is hashed and compared)
+  const bool wide = !direct && L.n_key_cols != 0;
+  const uint32_t KW = wide ? (uint32_t)L.n_key_cols + (pp.wide_null_word ? 1u : 0u) : 0u;
   unsigned long long* keys = p2_lds;                                    // hash mode: [NS + 2] (NS = null key, NS + 1 = the key equal to EMPTY)
-  unsigned long long* cells = direct ? p2_lds : keys + NS + 2;          // [(NS (+2)) * n_aggs]
-  const uint32_t n_slots = direct ? NS : NS + 2;
+  unsigned long long* kwords = keys + NS;                               // wide: [KW][NS]
+  unsigned long long* cells = direct ? p2_lds : wide ? kwords + (size_t)KW * NS : keys + NS + 2;          // [(NS (+2)) * n_aggs]
+  const uint32_t n_slots = (direct || wide) ? NS : NS + 2;
   __shared__ unsigned int n_occ, cursor_l, full;
   __shared__ unsigned long long gbase;
   const uint32_t p = blockIdx.x;
@@ -441,7 +489,104 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
       }
     }
   };
+  // wide keys: slot protocol kEmptyKey -> hash | busy (CAS) -> hash; the claimer writes the key words, then publishes the hash (LDS operations of a wave
+  // complete in order, so a reader that sees the published hash sees the words); a lane that meets a busy slot looks again in the next round of the loop
+  // -- never a spin inside a round: the claimer may be a lane of the same wave
+  constexpr unsigned long long kBusy = 1ull;
+  auto process_wide = [&](unsigned int (*cur)[16], uint32_t cnt_cur) __attribute__((always_inline)) {
+    uint32_t slot[kPerLane];
+    unsigned long long tag[kPerLane];
+    bool live[kPerLane], found[kPerLane];
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      const uint32_t i = (uint32_t)lane + u * 64u;
+      live[u] = i < cnt_cur; found[u] = !live[u];
+      slot[u] = 0; tag[u] = 0;
+      if (!live[u]) continue;
+      const unsigned int* rec = cur[u];
+      const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
+      uint64_t w[kMaxKeys];
+#pragma unroll
+      for (int j = 0; j < kMaxKeys; j++) w[j] = j < (int)L.n_key_cols ? ((uint64_t)rec[2 * j] | ((uint64_t)rec[2 * j + 1] << 32)) : 0ull;
+      const uint32_t nullmask = ((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u);
+      const uint64_t h = wide_key_hash(w, L.n_key_cols, nullmask);
+      tag[u] = h & ~kBusy;                                                              // busy bit clear: never the EMPTY pattern itself ...
+      if ((tag[u] | kBusy) == kEmptyKey) tag[u] ^= 2ull;                                // ... nor EMPTY once the busy bit is set
+      slot[u] = (uint32_t)((((h << pp.log2_parts) >> 32) * (uint64_t)NS) >> 32);        // the partition consumed the hash's top bits
+    }
+    for (uint32_t it = 0; it < 8u * NS + 64u; it++) {
+      bool all = true;
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) all = all && found[u];
+      if (__all(all)) break;
+      unsigned long long st[kPerLane];
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) if (!found[u]) st[u] = *reinterpret_cast<volatile unsigned long long*>(&keys[slot[u]]);
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) {
+        if (found[u]) continue;
+        const unsigned int* rec = cur[u];
+        if (st[u] == kEmptyKey) {
+          if (atomicCAS(&keys[slot[u]], (unsigned long long)kEmptyKey, tag[u] | kBusy) == kEmptyKey) {
+#pragma unroll
+            for (int j = 0; j < kMaxKeys; j++)
+              if (j < (int)L.n_key_cols) *reinterpret_cast<volatile unsigned long long*>(&kwords[(size_t)j * NS + slot[u]]) = (uint64_t)rec[2 * j] | ((uint64_t)rec[2 * j + 1] << 32);
+            if (pp.wide_null_word) {
+              const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
+              *reinterpret_cast<volatile unsigned long long*>(&kwords[(size_t)L.n_key_cols * NS + slot[u]]) = ((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u);
+            }
+            *reinterpret_cast<volatile unsigned long long*>(&keys[slot[u]]) = tag[u];
+            found[u] = true;
+          }
+          // lost the race: the winner's word in the next round, same slot
+        } else if ((st[u] & ~kBusy) == tag[u]) {
+          if (!(st[u] & kBusy)) {
+            bool same = true;
+#pragma unroll
+            for (int j = 0; j < kMaxKeys; j++)
+              if (j < (int)L.n_key_cols) same = same && *reinterpret_cast<volatile unsigned long long*>(&kwords[(size_t)j * NS + slot[u]]) == ((uint64_t)rec[2 * j] | ((uint64_t)rec[2 * j + 1] << 32));
+            if (pp.wide_null_word) {
+              const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
+              same = same && *reinterpret_cast<volatile unsigned long long*>(&kwords[(size_t)L.n_key_cols * NS + slot[u]]) == (unsigned long long)(((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u));
+            }
+            if (same) found[u] = true;
+            else slot[u] = slot[u] + 1 == NS ? 0u : slot[u] + 1;                     // same hash, another key
+          }
+          // busy: the key words are being written -- the same slot again next round
+        } else slot[u] = slot[u] + 1 == NS ? 0u : slot[u] + 1;
+      }
+      if (it >= 8u * NS) { full = 1; break; }                                          // a full table (the pass reports it; the caller plans more partitions)
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      if (!live[u] || !found[u]) continue;
+      const unsigned int* rec = cur[u];
+      const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
+      const uint64_t rowid = L.has_rowid ? ((uint64_t)rec[L.rowid_off] | ((uint64_t)rec[L.rowid_off + 1] << 32)) : 0ull;
+      unsigned long long* cell = cells + (size_t)slot[u] * n_aggs;
+#pragma unroll
+      for (uint32_t k = 0; k < (uint32_t)kMaxAggs; k++) {
+        if (k >= n_aggs) break;
+        const uint8_t kind = sh.aggs[k].kind;
+        const uint8_t sj = L.agg_src[k];
+        uint64_t v = 0ull;
+        bool valid = true;
+        if (sj != kNone) {
+          const uint32_t lo = rec[L.src_off[sj]];
+          if (L.src_kind[sj] == 3) v = (uint64_t)pp.src_base[sj] + (uint64_t)lo;
+          else v = L.src_kind[sj] == 0 ? ((uint64_t)lo | ((uint64_t)rec[L.src_off[sj] + 1] << 32)) : (L.src_kind[sj] == 1 ? (uint64_t)(long long)(int)lo : (uint64_t)lo);
+          valid = (vbits >> sj) & 1;
+        }
+        const uint64_t x = agg_row_value(kind, v, true, valid, rowid);
+        if (x != agg_identity_dev(kind) || kind == AGG_SUM_F) {
+          if (kind == AGG_SUM_F && !valid) continue;
+          lds_atomic_agg(kind, cell + k, x);
+        }
+      }
+    }
+  };
   auto process = [&](unsigned int (*cur)[16], uint32_t cnt_cur) __attribute__((always_inline)) {
+    if (wide) { process_wide(cur, cnt_cur); return; }
     // the lane's records of the chunk are handled in three passes so that their LDS round trips overlap: (1) decode the key and
     // read the table word of its home slot for every record, (2) resolve the slot (hit on the first probe in the common case; the
     // CAS / linear-probe loop otherwise), (3) update the cells
@@ -546,6 +691,13 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
     if (direct ? (cells[(size_t)s * n_aggs + pp.len_idx] == 0) : (keys[s] == kEmptyKey)) continue;
     const uint64_t o = gbase + atomicAdd(&cursor_l, 1u);
     if (direct) { ap.out_keys[o] = pp.interleave ? (((uint64_t)s << pp.log2_parts) | p) : (((uint64_t)p << pp.key_shift) | s); ap.out_kvalid[o] = 1; }
+    else if (wide) {       // key words and per-column valid flags, column-major with stride max_groups (the layout of the HBM-table path's result: FusedAggResult::wide_words / wide_valid)
+      const uint32_t nm = pp.wide_null_word ? (uint32_t)kwords[(size_t)L.n_key_cols * NS + s] : 0u;
+      for (uint32_t j = 0; j < (uint32_t)L.n_key_cols; j++) {
+        ap.out_keys[(size_t)j * ap.max_groups + o] = kwords[(size_t)j * NS + s];
+        ap.out_kvalid[(size_t)j * ap.max_groups + o] = (unsigned char)(((nm >> j) & 1u) ^ 1u);
+      }
+    }
     else { ap.out_keys[o] = s < NS ? keys[s] : (s == NS ? 0ull : kEmptyKey); ap.out_kvalid[o] = s == NS ? 0 : 1; }
     for (uint32_t k = 0; k < n_aggs; k++) ap.out_acc[o * n_aggs + k] = cells[(size_t)s * n_aggs + k];
   }
