@@ -1,7 +1,7 @@
 """The counter summaries under profiles/ are keyed by the name the library's HIP-event tracer gives a launch (bench.py pairs a counter figure with a timed
 kernel only on an exact match of that name): tools/pmc_summarise.py derives the same name from the kernel SYMBOL rocprofv3 reports.  This pins the mapping
-for the kernel families of the bench workloads, on symbols copied from profiles/r03/*_kernel_stats.csv, and checks that every committed summary's dominant
-kernels still resolve."""
+for the kernel families of the bench workloads, on symbols copied from profiles/*/*_kernel_stats.csv, and checks that in every committed summary of the current
+round EVERY kernel that takes >= 3 % of a step's kernel time has a counter figure under the name the same session's bench line gave it."""
 import csv
 import glob
 import importlib.util
@@ -19,6 +19,10 @@ CASES = [
     ("void plx::k::fused_scan_kernel<plx::k::StatProg<7>, plx::k::DirectBuildSink>(plx::fused::Shape, plx::fused::Args, plx::fused::DirectJoinTable)", "fused_scan_direct_build_static#7"),
     ("void plx::k::part3_scatter_kernel<plx::k::StatProg<4>, 1, 4, 2, false>(plx::fused::Shape, plx::fused::Args, plx::k::PartPlan2, plx::k::ScatterParams2)", "part3_scatter[#4,d,t4,p2]"),
     ("void plx::k::part3_scatter_kernel<plx::k::StatProg<4>, 0, 2, 1, false>(plx::fused::Shape, plx::fused::Args, plx::k::PartPlan2, plx::k::ScatterParams2)", "part3_scatter[#4,h,t2,p1]"),
+    ("void plx::k::part3_scatter_kernel<plx::k::StatProg<4>, 0, 3, 1, true>(plx::fused::Shape, plx::fused::Args, plx::k::PartPlan2, plx::k::ScatterParams2)", "part3_scatter[#4,h,t3,p1,hot]"),
+    ("void plx::k::part3_scatter_kernel<plx::k::StatProg<4>, 1, 3, 2, true>(plx::fused::Shape, plx::fused::Args, plx::k::PartPlan2, plx::k::ScatterParams2)", "part3_scatter[#4,d,t3,p2,hot]"),
+    ("plx::k::probe_pass_kernel(unsigned int const*, unsigned int const*, unsigned long long const*, unsigned int const*, unsigned long long const*, unsigned long long, unsigned long long, unsigned int, unsigned int, unsigned int, plx::k::ProbeHashedBuild, unsigned int*, unsigned int*)", "probe_pass_lds"),
+    ("void plx::k::fused_scan_kernel<plx::k::StatProg<7>, plx::k::JoinBuildSink>(plx::fused::Shape, plx::fused::Args, plx::fused::JoinAggTable)", "fused_scan_join_build_static#7"),
     ("void plx::k::part3_scatter_kernel<plx::k::StatProg<12>, 1, 4, 3, false>(plx::fused::Shape, plx::fused::Args, plx::k::PartPlan2, plx::k::ScatterParams2)", "probe_scatter[#12,d,t4,p3]"),
     ("void plx::k::part2_agg_kernel<plx::k::StatProg<5>, 1, 0>(plx::k::PartPlan2, plx::k::AggParams2)", "part_agg_lds[#5,d,p0]"),
     ("void plx::k::(anonymous namespace)::strgroup_scatter_kernel<false>(plx::k::(anonymous namespace)::SgScatter)", "strgroup_scatter"),
@@ -35,16 +39,26 @@ def test_kernel_symbols_map_to_the_tracer_names():
         assert pmc.scope_of(symbol) == name, (symbol, pmc.scope_of(symbol), name)
 
 
-def test_committed_summaries_are_keyed_by_symbol_and_cover_their_dominant_kernels():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03", "*_pmc.json")))
-    assert len(files) >= 8
+ROUND = "r04"
+
+
+def test_committed_summaries_are_keyed_by_symbol_and_cover_every_kernel_that_matters():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", ROUND, "*_pmc.json")))
+    assert len(files) >= 12
     for f in files:
         d = json.load(open(f))
         assert d.get("keyed_by") == "kernel symbol", f
         wl = os.path.basename(f)[:-len("_pmc.json")]
-        stats = os.path.join(ROOT, "profiles", "r03", wl + "_kernel_stats.csv")
+        # (a) by symbol: the kernel that takes most of the workload's time resolves to a name with a counter figure
+        stats = os.path.join(ROOT, "profiles", ROUND, wl + "_kernel_stats.csv")
         rows = [r for r in csv.DictReader(open(stats)) if "plx::" in r["Name"] and "datagen" not in r["Name"] and "gather_kernel" not in r["Name"]]
         rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-        top = pmc.scope_of(rows[0]["Name"])                    # the kernel that takes most of the workload's time has a counter figure under its own name
+        top = pmc.scope_of(rows[0]["Name"])
         assert top is not None and top in d["kernels"], (f, rows[0]["Name"][:80], top, list(d["kernels"])[:6])
         assert d["kernels"][top]["hbm_bytes_per_launch"] > 0
+        # (b) by tracer name: every kernel of the same session's bench line with >= 3 % of the step's kernel time has a counter figure under that very name
+        line = json.load(open(os.path.join(ROOT, "profiles", ROUND, wl + "_bench_line_same_session.json")))
+        total = sum(v["avg_us"] * v["launches"] for v in line["kernels"].values())
+        for name, v in line["kernels"].items():
+            if v["avg_us"] * v["launches"] >= 0.03 * total:
+                assert name in d["kernels"], (wl, name, sorted(d["kernels"]))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """rocprofv3 counter-collection CSVs (FETCH_SIZE and WRITE_SIZE passes of tools/pmc_all.sh) -> profiles/<round>/<workload>_pmc.json:
-HBM bytes per launch of every library kernel, keyed by the name bench.py's HIP-event tracer uses for it (ProfileScope), with the
+HBM bytes per (median) launch of every library kernel, keyed by the name bench.py's HIP-event tracer uses for it (ProfileScope), with the
 gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts 128-B requests as 64 B: x2 for wide coalesced reads) and a write
 calibration on the library's own generator kernel (datagen_uniform writes exactly 8 B per row).
 usage: pmc_summarise.py <workload> <fetch counter csv> <write counter csv> <out json> [steps]"""
@@ -49,12 +49,19 @@ def scope_of(kernel: str):
 
 
 def read(path, counter):
-    agg = collections.defaultdict(lambda: [0, 0.0])
+    """kernel symbol -> [launches, launches x MEDIAN counter value per launch].  The median, not the mean: a process also launches a kernel outside the steps
+    it measures (the q3s workload PREPARES its input with eight SF100-sized gathers; the same gather kernel then runs sixty times on a few million rows inside
+    the steps) -- the typical launch is what a step's traffic is made of."""
+    vals = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r.get("Counter_Name") != counter:
             continue
-        k = r["Kernel_Name"]
-        agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
+        vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    agg = {}
+    for k, v in vals.items():
+        v.sort()
+        med = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+        agg[k] = [len(v), med * len(v)]
     return agg
 
 
