@@ -565,7 +565,8 @@ int plx_ipc_column_strdict(plx_ipc file, int32_t column, plx_strdict* out);
  *                        (null_partition(), hashing.rs:111-115); all columns travel in ONE grouped ncclSend / ncclRecv
  *                        all-to-all(v) on the library's stream (nullable and Boolean columns included: validity bitmaps and
  *                        bit-packed values cross as one byte per row and are re-packed on receipt); ONE host round trip
- *                        (the [world x world] row counts, for the receive allocations), no synchronisation at the end;
+ *                        (the [world x world] row counts, for the receive allocations) and ONE stream synchronisation at the end
+ *                        (the gathered per-destination buffers return to the pool only after RCCL is done with them);
  *                        *out = the rows this rank received.  rows_sent / bytes_sent: what left this rank over the fabric.
  *                        The sharded group-by calls it on PARTIAL aggregate rows (polars_amd/dist.py sharded_groupby:
  *                        local pre-aggregation first, group_by.rs:140-497), the sharded join on rows.

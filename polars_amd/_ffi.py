@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -250,11 +251,17 @@ def ensure_init() -> None:
         init()
 
 
-_plan_note = None          # description of a collect() that was served by more than one library call (frame._string_key_group_by); reset by every collect()
+_tls = threading.local()    # per calling thread, like plx_last_plan_description itself: the description of a collect() that was served by more than one
+                            # library call (frame._string_key_group_by); reset by every collect()
+
+
+def set_plan_note(note) -> None:
+    _tls.plan_note = note
 
 
 def last_plan() -> str:
-    return _plan_note if _plan_note is not None else lib().plx_last_plan_description().decode()
+    note = getattr(_tls, "plan_note", None)
+    return note if note is not None else lib().plx_last_plan_description().decode()
 
 
 def jit_set_min_rows(min_rows: int) -> None:

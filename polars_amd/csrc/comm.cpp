@@ -227,9 +227,8 @@ FramePtr exchange_by_key(uint64_t h, const FramePtr& in, const std::string& key,
   for (int p = 0; p < ws; p++) if (p != c.rank) moved_rows += (uint64_t)send_cnt[p];
   // The staged (gathered) wires go back to the pool when this returns.  The pool recycles in stream order, but whether every transfer of an RCCL group
   // is ordered on the caller's stream alone is RCCL's business (proxy threads, internal streams for local copies): wait for the exchange before the
-  // buffers can be handed out again.  The consumer of the exchanged frame needs it finished anyway; PLX_COMM_NO_SYNC=1 skips the wait (measurement only).
-  static const bool no_sync = getenv("PLX_COMM_NO_SYNC") != nullptr;
-  if (!no_sync) PLX_HIP(hipStreamSynchronize(stream()));
+  // buffers can be handed out again.  The consumer of the exchanged frame needs it finished anyway.
+  PLX_HIP(hipStreamSynchronize(stream()));
   auto out = std::make_shared<Frame>();
   out->height = n_out; out->names = in->names;
   size_t wi = 0;

@@ -1551,7 +1551,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       Buf bits = dev_alloc_zero(sizeof(uint64_t) * n_words), rank = dev_alloc(sizeof(uint32_t) * n_words);
       Buf okey = dev_alloc(sizeof(uint64_t) * ord_cap), orow = dev_alloc(sizeof(uint32_t) * ord_cap), used = dev_alloc_zero(sizeof(uint32_t) * (ord_cap / 1024 + 2));
       Buf meta = dev_alloc_zero(32);   // [0] ordinal counter, [2..3] flags, [4..5] pairs appended (u64)
-      DirectJoinTable dt; dt.bits = bits->as<unsigned long long>(); dt.rank = rank->as<unsigned int>(); dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>();
+      DirectJoinTable dt{}; dt.bits = bits->as<unsigned long long>(); dt.rank = rank->as<unsigned int>(); dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>();
       dt.chunk_used = used->as<unsigned int>(); dt.counter = meta->as<unsigned int>(); dt.flags = meta->as<unsigned int>() + 2; dt.acc = nullptr; dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)ord_cap;
       dt.opts = probe_late_loads() ? kDirectLateLoads : 0u;
       k::fused_direct_build(cb.shape, cb.args, dt, find_static_shape(cb.shape));
@@ -1573,6 +1573,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       // the matching rows only (gathered).  Worth it when the bitmap is far larger than an L2 (4 MB) and few rows can match.
       std::string probe_how = "probe_agg";
       bool probed = false;
+      Buf touch;
       const int pmode = partitioned_probe_mode();
       if (pmode == 2 || (pmode == 1 && P->height >= ((int64_t)1 << 24) && range >= ((uint64_t)1 << 28) && nb * 8 <= range)) {
         const ColumnPtr& pk = P->cols[pki];
@@ -1590,7 +1591,17 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
               keep.push_back(g);
             }
             k::fused_direct_probe_agg(cp.shape, a2, dt, probe_static_id);
-            PLX_HIP(hipStreamSynchronize(stream()));       // the gathered columns live until the kernel has read them
+            // the pair-list compaction below looks every build pair up in bitmap, rank and LEN cells -- random lines for a shuffled build side.  Only keys
+            // among the candidates can have been matched: a 2^26-bit filter of their hashes (8 MB: cache-resident) lets the compaction skip the rest
+            const int key_in = slot_input(cp.shape, cp.shape.key);
+            if (key_in >= 0 && (size_t)key_in < keep.size()) {
+              constexpr unsigned int kLog2TouchBits = 26;
+              touch = dev_alloc_zero(sizeof(uint64_t) * ((size_t)1 << (kLog2TouchBits - 6)));
+              ColumnPtr k64 = keep[key_in]->dtype == PLX_I64 ? keep[key_in] : ops::cast(keep[key_in], PLX_I64);
+              k::touch_filter_set(k64->values->as<int64_t>(), k64->valid_words(), hits->len, kLog2TouchBits, touch->as<uint64_t>());
+              dt.touch_filter = touch->as<unsigned long long>(); dt.log2_touch_bits = kLog2TouchBits;
+            }
+            PLX_HIP(hipStreamSynchronize(stream()));       // the gathered columns live until the kernels have read them
           }
           probe_how = pd + "+gather+probe_agg";
           probed = true;
@@ -1638,7 +1649,8 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   int log2_cap = 4;
   uint64_t cap = 0;
   for (int attempt = 0; attempt < 2; attempt++) {
-    log2_cap = std::max(4, ceil_log2_u64(std::max<uint64_t>(nb, 1) * 2));
+    // (the sampled count already carries 25 %: x1.6 keeps the load at or below ~0.6 without doubling a table that x2 would push over the next power of two)
+    log2_cap = std::max(4, ceil_log2_u64((uint64_t)((double)std::max<uint64_t>(nb, 1) * (sized_by_sample ? 1.6 : 2.0))));
     cap = 1ull << log2_cap;
     keys = dev_alloc(sizeof(uint64_t) * (cap + 1)); head = dev_alloc(sizeof(uint32_t) * (cap + 1)); flags = dev_alloc_zero(32);
     PLX_HIP(hipMemsetAsync(keys->ptr, 0xff, sizeof(uint64_t) * (cap + 1), stream()));

@@ -471,6 +471,10 @@ struct DirectJoinTable {
   unsigned long long range;
   unsigned int n_ord;            // capacity of the pair list
   unsigned int opts;             // kDirectLateLoads
+  // output step after a PARTITIONED probe: bit (key * kP2HashMult) >> (64 - log2_touch_bits) is set for every candidate key the final probe ran over; a pair whose
+  // bit is clear cannot have been matched, so the compaction skips its three random lookups (bitmap word, rank, LEN cell).  null: every pair is looked up.
+  const unsigned long long* touch_filter;
+  unsigned int log2_touch_bits;
 };
 constexpr unsigned int kDirectLateLoads = 1u;   // probe: columns only the aggregates read are loaded under the hit mask (split_program)
 

@@ -418,6 +418,10 @@ __global__ __launch_bounds__(kBlock) void direct_pairs_compact_kernel(DirectJoin
   compact_slots(n_used, counter,
                 [&](int64_t o) {
                   if ((unsigned int)(o % kOrdChunk) >= t.chunk_used[o / kOrdChunk]) return false;   // unused tail of a reserved chunk
+                  if (t.touch_filter) {     // (a few MB: stays in the caches) no candidate of the partitioned probe had this key's bit -> no probe row matched it
+                    const unsigned long long h = (t.ord_key[o] * kP2HashMult) >> (64u - t.log2_touch_bits);
+                    if (!((t.touch_filter[h >> 6] >> (h & 63)) & 1ull)) return false;
+                  }
                   return t.acc[(size_t)slot_of(o) * n_aggs + len_idx] != 0;
                 },
                 [&](int64_t o, uint64_t out) {
@@ -428,6 +432,22 @@ __global__ __launch_bounds__(kBlock) void direct_pairs_compact_kernel(DirectJoin
                   for (int k = 0; k < n_aggs; k++) out_acc[out * n_aggs + k] = t.acc[(size_t)s * n_aggs + k];
                 });
 }
+// sets the touch-filter bit of every valid key of `keys` (the join key column gathered at the partitioned probe's candidate rows, widened to 64 bits)
+__global__ __launch_bounds__(kBlock) void touch_filter_kernel(const long long* __restrict__ keys, const uint64_t* __restrict__ validity, int64_t n, unsigned int log2_bits,
+                                                              unsigned long long* __restrict__ filter) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (validity && !((validity[i >> 6] >> (i & 63)) & 1ull)) continue;
+    const unsigned long long h = ((unsigned long long)keys[i] * kP2HashMult) >> (64u - log2_bits);
+    __hip_atomic_fetch_or(&filter[h >> 6], 1ull << (h & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+void touch_filter_set(const int64_t* keys, const uint64_t* validity, int64_t n, unsigned int log2_bits, uint64_t* filter) {
+  if (n <= 0) return;
+  ProfileScope ps("touch_filter", (uint64_t)n * 16, (uint64_t)n);
+  hipLaunchKernelGGL(touch_filter_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, stream(), (const long long*)keys, validity, n, log2_bits, (unsigned long long*)filter);
+  PLX_HIP(hipGetLastError());
+}
+
 int64_t direct_agg_compact(const DirectJoinTable& t, int64_t n_used, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc) {
   if (n_used == 0) return 0;
   Buf counter = dev_alloc_zero(8);

@@ -86,6 +86,7 @@ int64_t partitioned_agg2(const fused::Shape& sh, const fused::Args& args, const 
 // crates/polars-ops/src/frame/join/hash_join/single_keys.rs:16-167, single_keys_inner.rs:11-149).
 // `sh` / `args`: the probe side's predicate + key program with ONE aggregate AGG_FIRST_ROW (its row id is the record payload).
 // Returns false when the geometry or the JIT is not available (the caller probes directly); *hits: PLX_U32 column of matching probe rows.
+void touch_filter_set(const int64_t* keys, const uint64_t* validity, int64_t n, unsigned int log2_bits, uint64_t* filter);
 bool partitioned_probe_hits(const fused::Shape& sh, const fused::Args& args, const fused::DirectJoinTable& dt, uint64_t n_build, int static_id, ColumnPtr* hits, std::string* desc);
 bool partitioned_hash_probe_hits(const fused::Shape& sh, const fused::Args& args, const fused::JoinAggTable& ht, uint64_t n_build, int static_id, ColumnPtr* hits, std::string* desc);
 // fraction of adjacent pairs (strided sample) of an integer column that are non-decreasing: 1.0 = sorted ascending

@@ -450,7 +450,8 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_agg_kernel(SgAgg a) {
     }
 #pragma unroll
     for (uint32_t u = 0; u < kPerLane; u++) {
-      if ((uint32_t)lane * 4u + u >= fill || g[u] == kSgPending) continue;
+      if ((uint32_t)lane * 4u + u >= fill) continue;
+      if (g[u] == kSgPending) { full = 1; continue; }       // the probe loop gave up on a record (cannot happen below the planned load): never drop a row silently -- the caller falls back
       atomicAdd(&lens[g[u]], 1u);
       if (!((r[u][0].x >> 4) & 1u)) {
         if (a.has_nulls) atomicAdd(&cnts[g[u]], 1u);
@@ -486,12 +487,16 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_agg_kernel(SgAgg a) {
   }
 }
 
-// distinct views among the first S = 2^18 rows: one 64-bit hash per row into a table of 4 S slots (a sample; hash collisions undercount by ~S / 2^64)
-__global__ __launch_bounds__(kBlock) void sg_sample_kernel(const unsigned long long* __restrict__ views, int64_t S, unsigned long long* __restrict__ slots, uint32_t log2_cap,
+// distinct views among S = 2^18 sampled rows: one 64-bit hash per row into a table of 4 S slots (a sample; hash collisions undercount by ~S / 2^64)
+__global__ __launch_bounds__(kBlock) void sg_sample_kernel(const unsigned long long* __restrict__ views, int64_t n, int64_t S, unsigned long long* __restrict__ slots, uint32_t log2_cap,
                                                            unsigned int* __restrict__ res) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S) return;
-  const ulonglong2 v = reinterpret_cast<const ulonglong2*>(views)[i];
+  // 64 evenly spaced runs of S / 64 rows (a prefix alone says nothing about clustered or sorted input; single strided rows would fetch a line each)
+  const int64_t run = S / 64 > 0 ? S / 64 : 1, r = i / run, within = i % run;
+  const int64_t n_runs = (S + run - 1) / run;
+  const int64_t row = S >= n ? i : (int64_t)((__int128)r * (n - run) / (n_runs > 1 ? n_runs - 1 : 1)) + within;
+  const ulonglong2 v = reinterpret_cast<const ulonglong2*>(views)[row < n ? row : n - 1];
   if ((uint32_t)v.x > 12u) { res[1] = 1u; return; }
   unsigned long long h = sg_hash(v.x, v.y);
   if (h == kSgEmpty) h = 0;
@@ -513,7 +518,7 @@ double sg_estimate_groups(const uint64_t* views, int64_t n) {
   const uint32_t log2_cap = 20;
   Buf slots = dev_alloc(8ull << log2_cap), res = dev_alloc_zero(8);
   PLX_HIP(hipMemsetAsync(slots->ptr, 0xff, 8ull << log2_cap, stream()));
-  hipLaunchKernelGGL(sg_sample_kernel, dim3((unsigned)((S + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream(), (const unsigned long long*)views, S, slots->as<unsigned long long>(), log2_cap,
+  hipLaunchKernelGGL(sg_sample_kernel, dim3((unsigned)((S + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream(), (const unsigned long long*)views, n, S, slots->as<unsigned long long>(), log2_cap,
                      res->as<unsigned int>());
   PLX_HIP(hipGetLastError());
   uint32_t r[2] = {0, 0};

@@ -873,7 +873,7 @@ class LazyFrame:
 
     def collect(self, *, no_fusion: bool = False, no_direct_join: bool = False, no_partition: bool = False) -> DataFrame:
         F.ensure_init()
-        F._plan_note = None
+        F.set_plan_note(None)
         if not (no_fusion or no_partition):
             fast = _string_key_group_by(self._node)
             if fast is not None:
@@ -980,7 +980,7 @@ def _string_key_group_by(node: P.Node) -> Optional[DataFrame]:
     outs = [_col(key.name)] + [((_col("__sum").cast(T.Float64) / (n + n % n).cast(T.Float64)) if a == "mean" else _col("__" + a)).alias(o) for o, a in plan]
     desc = F.last_plan()
     out = DataFrame([k, parts["sum"], parts["count"], parts["len"]]).lazy().select(*outs).collect()
-    F._plan_note = desc + F.last_plan()
+    F.set_plan_note(desc + F.last_plan())
     return out
 
 
