@@ -367,6 +367,9 @@ struct PartPlan2 {
   uint32_t interleave;         // direct mode, group-by: partition = the id's LOW log2_parts bits, table slot = id >> log2_parts (ids are usually handed out in order of
                                // first appearance or popularity -- dictionary codes, zipf-like keys: the high bits would put all popular ids into partition 0)
   uint32_t hash_bits;          // direct mode, join probe on keys WITHOUT a usable range: the "dense id" is the top hash_bits bits of key * kP2HashMult (0: key - key_base)
+  uint32_t slice;              // direct mode, join probe on a key range: partition = id / slice, record low = id % slice (slice = range / P rounded up to a multiple of 64, so
+                               // every partition is populated whatever the range; 0: partition = id >> key_shift).  slice_magic = floor(2^64 / slice); key_shift = bits of `low`
+  unsigned long long slice_magic;
 };
 // the multiplier of the join hash tables' slot hash (JoinBuildSink / ProbeAggSink; the reference's DirtyHash, polars-utils/src/hashing.rs:62-69): the hashed
 // partitioned probe takes its partition from the SAME top bits, so partition p of the probe side meets exactly region p of the build table
@@ -438,13 +441,16 @@ struct WideTable {
 // acc[(cap+1) * n_aggs].
 constexpr uint32_t kNoRow32 = 0xffffffffu;
 struct JoinAggTable {
-  unsigned long long* keys;
-  unsigned int* head;     // build row of the slot
+  // [cap + 1] slots of 16 bytes: {key, build row (low 32 bits of the second word)}.  Key and row share a line: an insert is ONE line across the fabric (the CAS on the
+  // key; the row store merges into the line the CAS just brought in), and so is a probe.  Slot `cap` = the key whose bits equal kEmptyKey (present iff its row is set).
+  unsigned long long* slots;
   unsigned int* flags;    // [0] = duplicate build key seen, [1] = probe sequence overflow
   unsigned long long* acc;
   uint32_t log2_cap;
   unsigned long long* count;   // build: [0] += rows inserted (null: not wanted) -- the build side's row count after its predicate, a by-product of the build scan
 };
+PLX_HD inline unsigned long long* jt_key(const JoinAggTable& t, uint64_t s) { return t.slots + 2 * s; }
+PLX_HD inline unsigned int* jt_row(const JoinAggTable& t, uint64_t s) { return reinterpret_cast<unsigned int*>(t.slots + 2 * s + 1); }
 
 // Direct-address ("perfect hash") variant of the fused join -> aggregate table, used when the build
 // key range is small (max - min + 1 <= a few x the build rows, e.g. TPC-H orderkeys).  One BIT per key of the

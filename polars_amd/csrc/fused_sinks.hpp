@@ -326,7 +326,7 @@ struct JoinBuildSink {
       // One atomic per build row: the CAS winner owns the slot and stores its row with a plain store;
       // meeting the same key again means the build keys are not unique -> flag, the caller falls back.
       if (key == kEmptyKey) {
-        const unsigned int old = atomicExch(&p.head[cap], (unsigned int)(row0 + r));
+        const unsigned int old = atomicExch(jt_row(p, cap), (unsigned int)(row0 + r));
         if (old != kNoRow32) p.flags[0] = 1u;
         continue;
       }
@@ -334,8 +334,8 @@ struct JoinBuildSink {
       // CAS first: the table is at most half full and build keys are (expected to be) unique, so the home slot is usually free -- a read before the CAS
       // would be a second trip across the fabric for nothing (SF100 Q3 on hashed keys: 1.5e7 inserts into a 400 MB table)
       for (uint32_t probe = 0;; probe++) {
-        const unsigned long long old = atomicCAS(&p.keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
-        if (old == kEmptyKey) { p.head[slot] = (unsigned int)(row0 + r); break; }
+        const unsigned long long old = atomicCAS(jt_key(p, slot), (unsigned long long)kEmptyKey, (unsigned long long)key);
+        if (old == kEmptyKey) { *jt_row(p, slot) = (unsigned int)(row0 + r); break; }
         if (old == key) { p.flags[0] = 1u; break; }
         slot = (slot + 1) & (cap - 1);
         if (probe > (1u << 16)) { p.flags[1] = 1u; break; }
@@ -352,21 +352,21 @@ struct ProbeAggSink {
     const uint64_t cap = 1ull << p.log2_cap;
 #pragma unroll
     for (int r = 0; r < kRows; r++) {
-      if (!pass[r] || !((rf.getv(sh.key) >> r) & 1)) continue;
-      const uint64_t key = rf.get(r, sh.key);
       int64_t slot = -1;
-      if (key == kEmptyKey) { if (p.head[cap] != kNoRow32) slot = (int64_t)cap; }
-      else {
-        uint64_t s = (key * kP2HashMult) >> (64 - p.log2_cap);
-        for (;;) {
-          const unsigned long long cur = p.keys[s];
-          if (cur == key) { slot = (int64_t)s; break; }
-          if (cur == kEmptyKey) break;
-          s = (s + 1) & (cap - 1);
+      if (pass[r] && ((rf.getv(sh.key) >> r) & 1)) {
+        const uint64_t key = rf.get(r, sh.key);
+        if (key == kEmptyKey) { if (*jt_row(p, cap) != kNoRow32) slot = (int64_t)cap; }
+        else {
+          uint64_t s = (key * kP2HashMult) >> (64 - p.log2_cap);
+          for (;;) {
+            const unsigned long long cur = *jt_key(p, s);
+            if (cur == key) { slot = (int64_t)s; break; }
+            if (cur == kEmptyKey) break;
+            s = (s + 1) & (cap - 1);
+          }
         }
+        if (slot >= 0) atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
       }
-      if (slot < 0) continue;
-      atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
     }
   }
 };

@@ -467,8 +467,8 @@ __global__ __launch_bounds__(kBlock) void join_agg_compact_kernel(JoinAggTable t
   compact_slots(cap + 1, counter, [&](int64_t s) { return t.acc[(size_t)s * n_aggs + len_idx] != 0; },
                 [&](int64_t s, uint64_t o) {
                   if (!out_keys) return;
-                  out_keys[o] = s < cap ? t.keys[s] : kEmptyKey;
-                  out_rows[o] = t.head[s];
+                  out_keys[o] = s < cap ? *jt_key(t, (uint64_t)s) : kEmptyKey;
+                  out_rows[o] = *jt_row(t, (uint64_t)s);
                   for (int k = 0; k < n_aggs; k++) out_acc[o * n_aggs + k] = t.acc[(size_t)s * n_aggs + k];
                 });
 }

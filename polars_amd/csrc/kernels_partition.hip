@@ -633,20 +633,19 @@ __device__ __forceinline__ uint32_t bloom_pos(uint32_t low, uint32_t i, uint32_t
 // streams that region (coalesced) and puts the tag bits of every key that belongs to partition p into the Bloom filter; keys of partition p - 1 that spilled
 // into this region are skipped (they are not p's).  Everything after the prologue is the same.
 struct ProbeHashedBuild {
-  const unsigned long long* table_keys;    // [cap + 1] keys of the build table; slot `cap` = the key whose bits equal kEmptyKey (present iff table_head[cap] holds a row)
-  const unsigned int* table_head;
+  const unsigned long long* table_slots;   // [cap + 1][2] {key, build row} slots of the build table (JoinAggTable); slot `cap` = the key whose bits equal kEmptyKey (present iff its row is set)
   uint32_t log2_cap;
   uint32_t hash_bits;                      // 0: the bitmap source
 };
 __global__ __launch_bounds__(kP2AggBlock) void probe_pass_kernel(const unsigned int* __restrict__ recs, const unsigned int* __restrict__ chunk_fill, const unsigned long long* __restrict__ cl_off,
                                                                  const unsigned int* __restrict__ cl_ids, const unsigned long long* __restrict__ bits, unsigned long long range,
-                                                                 unsigned long long n_words, uint32_t key_shift, uint32_t log2_bloom_bits, uint32_t exact, ProbeHashedBuild hb,
+                                                                 unsigned long long n_words, uint32_t key_shift, uint32_t slice /* keys per partition (a multiple of 64) */, uint32_t log2_bloom_bits, uint32_t exact, ProbeHashedBuild hb,
                                                                  unsigned int* __restrict__ hits /* a region of (chunks x 256) slots per partition */, unsigned int* __restrict__ part_hits) {
   extern __shared__ unsigned long long lds_raw[];
   unsigned int* bloom = reinterpret_cast<unsigned int*>(lds_raw);          // exact != 0: the slice itself (it fits), bit = key low bits
   __shared__ unsigned int wg_hits;
   const uint32_t p = blockIdx.x;
-  const uint32_t W = hb.hash_bits ? 0u : 1u << (key_shift - 6);           // 64-bit words of the slice
+  const uint32_t W = hb.hash_bits ? 0u : slice >> 6;                      // 64-bit words of the slice
   const uint32_t bloom_words = 1u << (log2_bloom_bits - 5);
   if (threadIdx.x == 0) wg_hits = 0;
   for (uint32_t i = threadIdx.x; i < bloom_words; i += blockDim.x) bloom[i] = 0;
@@ -662,11 +661,11 @@ __global__ __launch_bounds__(kP2AggBlock) void probe_pass_kernel(const unsigned 
 #pragma unroll
       for (uint32_t q = 0; q < kBloomK; q++) { const uint32_t pos = bloom_pos(low, q, log2_bloom_bits); atomicOr(&bloom[pos >> 5], 1u << (pos & 31u)); }
     };
-    for (unsigned long long j = threadIdx.x; j < region; j += blockDim.x) { const unsigned long long key = hb.table_keys[(unsigned long long)p * region + j]; if (key != kEmptyKey) add(key); }
+    for (unsigned long long j = threadIdx.x; j < region; j += blockDim.x) { const unsigned long long key = hb.table_slots[((unsigned long long)p * region + j) * 2]; if (key != kEmptyKey) add(key); }
     if (threadIdx.x == 0) {
       // the run of occupied slots behind the region: keys of this partition that linear probing pushed past its end (short: the table is at most half full)
-      for (unsigned long long s = (((unsigned long long)p + 1) * region) & (cap - 1), n = 0; n < cap; s = (s + 1) & (cap - 1), n++) { const unsigned long long key = hb.table_keys[s]; if (key == kEmptyKey) break; add(key); }
-      if (hb.table_head[cap] != kNoRow32) add(kEmptyKey);                                  // the key equal to the EMPTY pattern lives in slot `cap`
+      for (unsigned long long s = (((unsigned long long)p + 1) * region) & (cap - 1), n = 0; n < cap; s = (s + 1) & (cap - 1), n++) { const unsigned long long key = hb.table_slots[s * 2]; if (key == kEmptyKey) break; add(key); }
+      if ((unsigned int)hb.table_slots[cap * 2 + 1] != kNoRow32) add(kEmptyKey);                                  // the key equal to the EMPTY pattern lives in slot `cap`
     }
   }
   for (uint32_t i = threadIdx.x; i < W; i += blockDim.x) {
@@ -706,7 +705,7 @@ __global__ __launch_bounds__(kP2AggBlock) void probe_pass_kernel(const unsigned 
 #pragma unroll
     for (uint32_t u = 0; u < kPerLane; u++) {
       const uint32_t i = (uint32_t)lane + u * 64u;
-      bool pos = i < fill && (hb.hash_bits || (((unsigned long long)p << key_shift) | lo[u]) < range);
+      bool pos = i < fill && (hb.hash_bits || (unsigned long long)p * slice + lo[u] < range);
       if (exact) pos = pos && ((bloom[lo[u] >> 5] >> (lo[u] & 31u)) & 1u);
       else {
 #pragma unroll
@@ -765,7 +764,16 @@ static bool probe_hits_impl(const Shape& sh, const Args& args, const DirectJoinT
   pp.hash_bits = hashed ? kHashBits : 0u;
   pp.log2_parts = std::min<uint32_t>(8, bits_total - 9);                       // 256 partitions (the scatter's best geometry: 8192-row tiles), slices of >= 2^9 keys
   if (pp.log2_parts < 6) return false;
-  pp.key_shift = bits_total - pp.log2_parts; pp.log2_slots = pp.key_shift;
+  pp.key_shift = bits_total - pp.log2_parts;
+  if (!hashed) {
+    // a key range is cut into P EQUAL slices (multiples of 64 keys: whole bitmap words), not at a power of two: SF100's 6.0e8-key range cut at 2^22 populated 143
+    // of 256 partitions -- the probe pass, one workgroup per partition, ran on 56 % of the chip
+    const uint64_t per = (dt.range + (((uint64_t)1 << pp.log2_parts) - 1)) >> pp.log2_parts;
+    pp.slice = (uint32_t)std::max<uint64_t>((per + 63) & ~(uint64_t)63, 512);
+    pp.slice_magic = ~0ull / pp.slice;                                          // floor((2^64 - 1) / slice): the quotient it gives is exact or one short (make_record2 corrects)
+    pp.key_shift = std::max<uint32_t>(ceil_log2(pp.slice), 9);
+  }
+  pp.log2_slots = pp.key_shift;
   const RecLayout2 L = rec_layout2(sh, kP2Direct, kPackRowid);
   if (!L.has_rowid || L.n_src != 0 || L.rec_words != 2 || pp.key_shift > 32) return false;     // one 64-bit field: key low bits | row id << key_shift
   pp.rec_words = L.rec_words; pp.block = kP2MaxBlock;
@@ -779,7 +787,7 @@ static bool probe_hits_impl(const Shape& sh, const Args& args, const DirectJoinT
   const bool exact = !hashed && pp.key_shift <= 20;
   const uint32_t log2_bloom = exact ? std::max<uint32_t>(pp.key_shift, 6) : 20;
   // a Bloom filter of 2^20 bits with 4 probes stays under ~2 % false positives up to 2^17 keys: denser slices would flood the caller with candidates
-  if (!exact && (hashed ? (double)n_build / (double)NP : (double)n_build * (double)((uint64_t)1 << pp.key_shift) / (double)dt.range) > (double)(1u << 17)) return false;
+  if (!exact && (hashed ? (double)n_build / (double)NP : (double)n_build * (double)pp.slice / (double)dt.range) > (double)(1u << 17)) return false;
   const jit::Sink jk = jit::part3_scatter_sink(pp.mode, pp.tiles, pp.pack, false);
 #ifdef PLX_HAVE_Q3_PROBE_SCATTER
   const bool aot = static_id == SHAPE_Q3_PROBE_SCATTER && pp.tiles == 4;       // TPC-H Q3's probe side (two- and three-table variants share it)
@@ -829,14 +837,14 @@ static bool probe_hits_impl(const Shape& sh, const Args& args, const DirectJoinT
   ProbeHashedBuild hb{};
   if (hashed) {
     if (ht->log2_cap < pp.log2_parts) return false;                           // a table smaller than the partition count needs no partitioned probe
-    hb.table_keys = ht->keys; hb.table_head = ht->head; hb.log2_cap = ht->log2_cap; hb.hash_bits = pp.hash_bits;
+    hb.table_slots = ht->slots; hb.log2_cap = ht->log2_cap; hb.hash_bits = pp.hash_bits;
   }
   {
     ProfileScope ps("probe_pass_lds",     // one kernel symbol for the bitmap-slice, Bloom-from-bitmap and Bloom-from-hash-table sources: one tracer name (the plan description says which)
-                    (uint64_t)args.n_rows * pp.rec_words * 4 + (hashed ? n_build * 12 : dt.range / 8), (uint64_t)args.n_rows);
+                    (uint64_t)args.n_rows * pp.rec_words * 4 + (hashed ? ((uint64_t)1 << ht->log2_cap) * 16 : dt.range / 8), (uint64_t)args.n_rows);
     const unsigned long long n_words = hashed ? 0ull : (dt.range / 512 + 1) * 8;
     hipLaunchKernelGGL(probe_pass_kernel, dim3(NP), dim3(kP2AggBlock), ((size_t)1 << (log2_bloom - 3)), stream(), recs->as<unsigned int>(), chunk_fill->as<unsigned int>(),
-                       cl_off->as<unsigned long long>(), cl_ids->as<unsigned int>(), hashed ? nullptr : dt.bits, hashed ? 0ull : dt.range, n_words, pp.key_shift, log2_bloom, exact ? 1u : 0u, hb,
+                       cl_off->as<unsigned long long>(), cl_ids->as<unsigned int>(), hashed ? nullptr : dt.bits, hashed ? 0ull : dt.range, n_words, pp.key_shift, pp.slice, log2_bloom, exact ? 1u : 0u, hb,
                        regions->as<unsigned int>(), part_hits->as<unsigned int>());
     PLX_HIP(hipGetLastError());
     exclusive_scan_u32(part_hits->as<uint32_t>(), hit_off->as<uint64_t>(), NP);              // hit_off[NP] = total

@@ -121,6 +121,10 @@ __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, c
     if (pp.interleave) {                                               // (wave-uniform) partition = low bits, slot = the bits above them
       hi = (id >> (pp.key_shift + pp.log2_parts)) ? 0xfffffffeull : (id & ((1ull << pp.log2_parts) - 1ull));
       low = id >> pp.log2_parts;
+    } else if (pp.slice) {                                             // (wave-uniform) equal slices of the id range: id / slice by the reciprocal, one correction step
+      hi = __umul64hi(id, pp.slice_magic);
+      low = id - hi * (uint64_t)pp.slice;
+      if (low >= (uint64_t)pp.slice) { hi++; low -= (uint64_t)pp.slice; }
     }
     part = hi > 0xfffffffeull ? 0xfffffffeu : (uint32_t)hi;           // far outside the id range: still "outside" after the narrowing
     rec[0] = (uint32_t)low & ((1u << pp.key_shift) - 1u);

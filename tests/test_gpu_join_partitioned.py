@@ -69,6 +69,46 @@ def test_partitioned_probe_null_and_out_of_range_probe_keys(pl, monkeypatch):
     assert g["a"] == battr[(keys - 1000) // 7].tolist()
 
 
+@pytest.mark.parametrize("stride,nb", [(1, 100_003), (37, 700_001), (251, 1_200_007), (131, 2_500_003)])
+def test_partitioned_probe_cuts_the_key_range_into_equal_slices(pl, monkeypatch, stride, nb):
+    """The key range is cut into P equal slices (range / P rounded up to whole bitmap words), whatever the range: ranges that are no power of two, slices
+    that fit the LDS as they are (exact) and slices that only fit as Bloom filters; keys on both sides of every slice boundary and the last key of the range
+    find their partition (id / slice through the reciprocal + one correction step, partition2_device.hpp make_record2)."""
+    rng = np.random.default_rng(stride)
+    n = (1 << 22) + 777
+    kmin = -12345
+    bkey = kmin + np.arange(nb, dtype=np.int64) * stride
+    battr = rng.integers(0, 1000, nb).astype(np.int64)
+    rng_keys = int(bkey[-1] - kmin) + 1
+    pkey = kmin + rng.integers(0, rng_keys, n).astype(np.int64)
+    hit = rng.random(n) < 0.4
+    pkey[hit] = bkey[rng.integers(0, nb, int(hit.sum()))]
+    per = -(-rng_keys // 256)
+    slice_ = max((per + 63) // 64 * 64, 512)
+    edges = kmin + np.arange(1, 256, dtype=np.int64) * slice_
+    edges = edges[edges < bkey[-1]]
+    m = len(edges)
+    pkey[:m] = edges; pkey[m:2 * m] = edges - 1; pkey[2 * m:3 * m] = edges + 1       # both sides of every slice boundary
+    pkey[3 * m:3 * m + 3] = [bkey[0], bkey[-1], bkey[-1] + 1]
+    x = rng.integers(-50, 50, n).astype(np.int64)
+    B = pl.DataFrame({"k": bkey, "a": battr})
+    P = pl.DataFrame({"k": pkey, "x": x})
+    c = pl.col
+    monkeypatch.setenv("PLX_PROBE_PARTITIONED", "2")
+    got = P.lazy().join(B.lazy(), on="k").group_by("k", "a").agg(c("x").sum().alias("sx"), pl.len().alias("n")).collect()
+    plan = pl.last_plan()
+    assert "partitioned_probe(" in plan, plan
+    assert ("lds_bitmap=" in plan) == (slice_ <= 1 << 20), plan
+    inb = (pkey >= kmin) & (pkey <= bkey[-1]) & ((pkey - kmin) % stride == 0)
+    cand = int(plan.split("candidates=")[1].split(")")[0])
+    assert int(inb.sum()) <= cand <= int(inb.sum()) + int(0.05 * n), (cand, int(inb.sum()))
+    g = got.sort_host("k")
+    keys, inv = np.unique(pkey[inb], return_inverse=True)
+    assert g["k"] == keys.tolist()
+    assert g["sx"] == np.bincount(inv, weights=x[inb]).astype(np.int64).tolist() and g["n"] == np.bincount(inv).tolist()
+    assert g["a"] == battr[(keys - kmin) // stride].tolist()
+
+
 @pytest.mark.parametrize("ordered", [False, True])
 def test_q3_on_hashed_keys_takes_the_partitioned_hash_probe(pl, orc, monkeypatch, ordered):
     """TPC-H Q3 with orderkey * 0x9E3779B97F4A7C15 mod 2^64 on both sides: no dense key range, so the build side is an open-addressing hash table; the probe
@@ -97,15 +137,18 @@ def test_q3_on_hashed_keys_takes_the_partitioned_hash_probe(pl, orc, monkeypatch
     assert g0["l_orderkey"] == g["l_orderkey"] and close(g0["revenue"], g["revenue"])
 
 
-def test_partitioned_hash_probe_edge_keys(pl, monkeypatch):
-    """Sparse 64-bit build keys including the key whose bits equal the table's EMPTY pattern (-1), 0, the smallest and the largest Int64; null probe keys and
-    probe keys absent from the build side match nothing; the Bloom filters' false positives are removed by the final key compare."""
+@pytest.mark.parametrize("dt", [np.int64, np.uint64])
+def test_partitioned_hash_probe_edge_keys(pl, monkeypatch, dt):
+    """Sparse 64-bit build keys including the key whose bits equal the table's EMPTY pattern (-1 / 2^64 - 1), 0, the smallest and the largest Int64 (UInt64: keys
+    above 2^63); null probe keys and probe keys absent from the build side match nothing; the Bloom filters' false positives are removed by the final key compare."""
     rng = np.random.default_rng(10)
     nb, n = 300_000, (1 << 22) + 4321
-    bkey = np.unique(np.concatenate([rng.integers(-(1 << 62), 1 << 62, nb).astype(np.int64), np.array([-1, 0, np.iinfo(np.int64).min, np.iinfo(np.int64).max], np.int64)]))
+    edge = np.array([-1, 0, np.iinfo(np.int64).min, np.iinfo(np.int64).max], np.int64)
+    bkey = np.unique(np.concatenate([rng.integers(-(1 << 62), 1 << 62, nb).astype(np.int64), edge])).view(dt)
+    bkey = np.sort(bkey)
     battr = rng.integers(0, 100, len(bkey)).astype(np.int64)
-    pkey = np.where(rng.random(n) < 0.3, bkey[rng.integers(0, len(bkey), n)], rng.integers(-(1 << 62), 1 << 62, n).astype(np.int64))
-    pkey[:4] = [-1, 0, np.iinfo(np.int64).min, np.iinfo(np.int64).max]
+    pkey = np.where(rng.random(n) < 0.3, bkey[rng.integers(0, len(bkey), n)], rng.integers(-(1 << 62), 1 << 62, n).astype(np.int64).view(dt))
+    pkey[:4] = edge.view(dt)
     valid = rng.random(n) > 0.05
     valid[:4] = True
     x = rng.integers(-50, 50, n).astype(np.int64)
@@ -122,6 +165,10 @@ def test_partitioned_hash_probe_edge_keys(pl, monkeypatch):
     assert int(inb.sum()) <= cand <= int(inb.sum()) + int(0.05 * n), (cand, int(inb.sum()))       # every true match is a candidate; few false positives
     g = got.sort_host("k")
     keys, inv = np.unique(pkey[inb], return_inverse=True)
-    assert g["k"] == keys.tolist() and {-1, 0, int(np.iinfo(np.int64).min), int(np.iinfo(np.int64).max)} <= set(g["k"])
+    assert g["k"] == keys.tolist() and {int(v) for v in edge.view(dt)} <= set(g["k"])
     assert g["sx"] == np.bincount(inv, weights=x[inb]).astype(np.int64).tolist() and g["n"] == np.bincount(inv).tolist()
     assert g["a"] == battr[np.searchsorted(bkey, keys)].tolist()
+    monkeypatch.setenv("PLX_PROBE_PARTITIONED", "0")                                             # the plain hash probe: the compaction without the candidates' filter
+    g0 = q().sort_host("k")
+    assert "partitioned_hash_probe(" not in pl.last_plan()
+    assert g0["k"] == g["k"] and g0["sx"] == g["sx"] and g0["n"] == g["n"] and g0["a"] == g["a"]
