@@ -1584,12 +1584,10 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
           if (hits->len > 0) {
             Args a2 = cp.args;
             a2.n_rows = hits->len;
-            std::vector<ColumnPtr> keep;
-            for (int i = 0; i < cp.shape.n_inputs; i++) {
-              ColumnPtr g = ops::gather(cp.cols[cp.input_cols[i]], hits);
-              a2.in[i].values = g->data(); a2.in[i].validity = cp.shape.in_nullable[i] ? g->valid_words() : nullptr;
-              keep.push_back(g);
-            }
+            std::vector<ColumnPtr> srcs;
+            for (int i = 0; i < cp.shape.n_inputs; i++) srcs.push_back(cp.cols[cp.input_cols[i]]);
+            std::vector<ColumnPtr> keep = ops::gather_columns(srcs, hits);
+            for (int i = 0; i < cp.shape.n_inputs; i++) { a2.in[i].values = keep[i]->data(); a2.in[i].validity = cp.shape.in_nullable[i] ? keep[i]->valid_words() : nullptr; }
             k::fused_direct_probe_agg(cp.shape, a2, dt, probe_static_id);
             // the pair-list compaction below looks every build pair up in bitmap, rank and LEN cells -- random lines for a shuffled build side.  Only keys
             // among the candidates can have been matched: a 2^26-bit filter of their hashes (8 MB: cache-resident) lets the compaction skip the rest
@@ -1688,12 +1686,10 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
         if (hits->len > 0) {
           Args a2 = cp.args;
           a2.n_rows = hits->len;
-          std::vector<ColumnPtr> keep;
-          for (int i = 0; i < cp.shape.n_inputs; i++) {
-            ColumnPtr g = ops::gather(cp.cols[cp.input_cols[i]], hits);
-            a2.in[i].values = g->data(); a2.in[i].validity = cp.shape.in_nullable[i] ? g->valid_words() : nullptr;
-            keep.push_back(g);
-          }
+          std::vector<ColumnPtr> srcs;
+          for (int i = 0; i < cp.shape.n_inputs; i++) srcs.push_back(cp.cols[cp.input_cols[i]]);
+          std::vector<ColumnPtr> keep = ops::gather_columns(srcs, hits);
+          for (int i = 0; i < cp.shape.n_inputs; i++) { a2.in[i].values = keep[i]->data(); a2.in[i].validity = cp.shape.in_nullable[i] ? keep[i]->valid_words() : nullptr; }
           k::fused_probe_agg(cp.shape, a2, t, probe_static_id);
           PLX_HIP(hipStreamSynchronize(stream()));       // the gathered columns live until the kernels have read them
         }

@@ -90,6 +90,9 @@ void filter_apply(const FilterPlan& p, int width, const void* values, const uint
                   uint64_t* out_validity);
 void gather(int width, const void* values, const uint64_t* validity, const uint32_t* idx, const uint64_t* idx_validity,
             int64_t n_idx, void* out, uint64_t* out_validity);
+constexpr int kGatherMultiMax = 8;
+// n_cols (<= kGatherMultiMax) columns of 4- or 8-byte values, no validity anywhere, gathered at the same indices in one launch
+void gather_multi(int n_cols, const int* widths, const void* const* values, const uint32_t* idx, int64_t n_idx, void* const* out);
 
 }  // namespace k
 }  // namespace plx

@@ -179,5 +179,40 @@ void gather(int width, const void* values, const uint64_t* validity, const uint3
   PLX_HIP(hipGetLastError());
 }
 
+// several columns at the same indices in ONE launch (the partitioned join probe gathers every probe-side input at its candidates: four launches of a latency-bound
+// kernel, each waiting for the one before; here a lane's loads of all columns are in flight together).  Columns of 4- or 8-byte values without validity.
+struct GatherMulti {
+  const void* values[kGatherMultiMax];
+  void* out[kGatherMultiMax];
+  uint8_t width[kGatherMultiMax];
+  int n_cols;
+};
+__global__ __launch_bounds__(kBlock) void gather_multi_kernel(GatherMulti g, const uint32_t* __restrict__ idx, int64_t n_idx) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_idx; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t j = idx[i];
+    uint64_t v[kGatherMultiMax];
+#pragma unroll
+    for (int c = 0; c < kGatherMultiMax; c++)
+      if (c < g.n_cols) v[c] = g.width[c] == 8 ? static_cast<const uint64_t*>(g.values[c])[j] : (uint64_t)static_cast<const uint32_t*>(g.values[c])[j];
+#pragma unroll
+    for (int c = 0; c < kGatherMultiMax; c++)
+      if (c < g.n_cols) { if (g.width[c] == 8) static_cast<uint64_t*>(g.out[c])[i] = v[c]; else static_cast<uint32_t*>(g.out[c])[i] = (uint32_t)v[c]; }
+  }
+}
+void gather_multi(int n_cols, const int* widths, const void* const* values, const uint32_t* idx, int64_t n_idx, void* const* out) {
+  if (n_idx == 0 || n_cols == 0) return;
+  PLX_REQUIRE(n_cols <= kGatherMultiMax, PLX_ERR_INVALID, "gather_multi: too many columns");
+  GatherMulti g{};
+  uint64_t bytes = 0;
+  g.n_cols = n_cols;
+  for (int c = 0; c < n_cols; c++) {
+    PLX_REQUIRE(widths[c] == 4 || widths[c] == 8, PLX_ERR_INVALID, "gather_multi: 4- and 8-byte values only");
+    g.values[c] = values[c]; g.out[c] = out[c]; g.width[c] = (uint8_t)widths[c]; bytes += 2 * (uint64_t)widths[c];
+  }
+  ProfileScope ps("gather_multi", (uint64_t)n_idx * (4 + bytes), (uint64_t)n_idx);
+  hipLaunchKernelGGL(gather_multi_kernel, dim3(grid_for(n_idx, kBlock)), dim3(kBlock), 0, stream(), g, idx, n_idx);
+  PLX_HIP(hipGetLastError());
+}
+
 }  // namespace k
 }  // namespace plx

@@ -188,6 +188,7 @@ static const int kEnvP2Block = env_int("PLX_PART_BLOCK", 256, 1024);
 static const int kEnvP2Ring = env_int("PLX_PART_RING_LINES", 1, 16);
 static const int kEnvP2Direct = env_int("PLX_PART_DIRECT", 0, 1);        // 0: never use the direct-address mode
 static const int kEnvP2DirectLp = env_int("PLX_PART_DIRECT_LOG2_PARTS", 4, 9);   // direct mode: partitions when the id range allows (default 2^9)
+static const int kEnvP3Block = env_int("PLX_P3_BLOCK", 0, 1024);         // measurement: threads of a gen-3 scatter workgroup (0 = 1024; a multiple of 64, >= the partition count)
 static const int kEnvP2Wgs = env_int("PLX_PART2_WGS_PER_CU", 1, 4);       // scatter workgroups per CU (they must fit the LDS together)
 static const int kEnvP2Ablate = env_int("PLX_PART_ABLATE", 0, 3);
 static const int kEnvP2Tiles = env_int("PLX_PART_TILES", 1, 4);           // tiles per wave and round (gen 2: default 2 when the rings absorb them; gen 3: 4 / 2 / 1 by LDS)
@@ -238,6 +239,7 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
   }
   if (!tiles) return false;
   pp.gen = 3; pp.pack = pack; pp.rec_words = L.rec_words; pp.block = kP2MaxBlock; pp.ring_lines = 0;
+  if (kEnvP3Block >= 64 && (uint32_t)kEnvP3Block >= NP && kEnvP3Block % 64 == 0) pp.block = (uint32_t)kEnvP3Block;
   plan2_geometry(pp, n_rows, tiles);
   // chunks are filled completely (the carry line keeps the remainder): whole chunks of the rows + one partial chunk per partition + slack
   return true;
@@ -778,6 +780,7 @@ static bool probe_hits_impl(const Shape& sh, const Args& args, const DirectJoinT
   if (!L.has_rowid || L.n_src != 0 || L.rec_words != 2 || pp.key_shift > 32) return false;     // one 64-bit field: key low bits | row id << key_shift
   pp.rec_words = L.rec_words; pp.block = kP2MaxBlock;
   const uint32_t NP = 1u << pp.log2_parts;
+  if (kEnvP3Block >= 64 && (uint32_t)kEnvP3Block >= NP && kEnvP3Block % 64 == 0) pp.block = (uint32_t)kEnvP3Block;
   const size_t lds_total = 160 * 1024 - 2048;
   uint32_t tiles = 0;
   for (uint32_t t : {4u, 2u, 1u}) if (part3_scatter_lds(kP2MaxBlock * kRows * t, L.rec_words, NP, 0, 0, sh.n_aggs, 1) <= lds_total) { tiles = t; break; }

@@ -235,6 +235,25 @@ ColumnPtr gather(const ColumnPtr& c, const ColumnPtr& idx) {
   return out;
 }
 
+// several columns at the same (valid) indices: one launch when every column is a plain 4- or 8-byte one, column by column otherwise
+std::vector<ColumnPtr> gather_columns(const std::vector<ColumnPtr>& cols, const ColumnPtr& idx) {
+  PLX_REQUIRE(idx->dtype == PLX_U32, PLX_ERR_INVALID, "gather: indices must be u32 (IdxSize)");
+  bool plain = !idx->validity && cols.size() >= 2 && cols.size() <= (size_t)k::kGatherMultiMax;
+  for (const ColumnPtr& c : cols) plain = plain && !c->validity && c->dtype != PLX_BOOL && (dtype_width(c->dtype) == 4 || dtype_width(c->dtype) == 8);
+  std::vector<ColumnPtr> out;
+  if (!plain) { for (const ColumnPtr& c : cols) out.push_back(gather(c, idx)); return out; }
+  std::vector<int> widths; std::vector<const void*> src; std::vector<void*> dst;
+  for (const ColumnPtr& c : cols) {
+    auto o = std::make_shared<Column>();
+    o->dtype = c->dtype; o->len = idx->len; o->null_count = 0;
+    o->values = dev_alloc(values_bytes(c->dtype, idx->len));
+    widths.push_back(dtype_width(c->dtype)); src.push_back(c->data()); dst.push_back(o->values->ptr);
+    out.push_back(o);
+  }
+  k::gather_multi((int)cols.size(), widths.data(), src.data(), idx->values->as<uint32_t>(), idx->len, dst.data());
+  return out;
+}
+
 // ------------------------------------------------------------------- reduce ---
 static int sum_out_dtype(int dt) {
   switch (dt) {

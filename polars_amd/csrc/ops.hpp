@@ -25,6 +25,7 @@ int64_t prepared_rows(const PreparedMask& m);
 ColumnPtr filter_prepared(const ColumnPtr& c, const PreparedMask& m);
 // gather/primitive.rs:9-78
 ColumnPtr gather(const ColumnPtr& c, const ColumnPtr& idx);
+std::vector<ColumnPtr> gather_columns(const std::vector<ColumnPtr>& cols, const ColumnPtr& idx);   // one launch for plain 4- / 8-byte columns
 // whole-column aggregate -> scalar (aggregate/mod.rs)
 struct ScalarValue { plx_scalar v; int dtype; bool valid; };
 ScalarValue reduce(int agg_op, const ColumnPtr& c);

@@ -159,7 +159,8 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
   // spilled, and every scratch reload is a vmcnt(0) that also waits for these very loads (measured, 1e9 rows: 12-B records 6.96 -> 6.09 ms,
   // 8-B 6.07 -> 5.62 with the late issue; 4-B 4.81 early vs 5.07 late) -- there they go out after the sort step, when the records have left
   // the registers, and land during the copy-out.
-  constexpr bool kEarly = RW == 1 || TILES <= 2;
+  // The join probe's scatter (row-id records: key + row, a predicate column or two) has the room as well: 121 registers, no scratch, with the loads a round ahead.
+  constexpr bool kEarly = RW == 1 || TILES <= 2 || (PACK == (int)kPackRowid && sh.n_inputs <= 2);
   bool pre_early = false;
   if (rd_first < nrounds) {
     finish_round(rd_first, issue_loads(rd_first));

@@ -19,7 +19,7 @@ SCOPES = [  # (regex on the demangled kernel name, ProfileScope name in bench.py
     (r"part_scatter_kernel", "part_scatter"), (r"part_agg_kernel", "part_agg_lds"), (r"part_count_kernel", "part_count"),
     (r"direct_popc_kernel|direct_word_rank_kernel", "direct_rank"), (r"direct_pairs_compact_kernel|hash_compact_kernel|join_agg_compact_kernel", "table_compact"),
     (r"probe_pass_kernel", "probe_pass_lds"), (r"probe_hits_compact_kernel", "probe_hits_compact"), (r"touch_filter_kernel", "touch_filter"),
-    (r"scan_block_kernel|scan_add_kernel|scan_", "exclusive_scan"), (r"gather_kernel", "gather_u32"), (r"finalize_batch_kernel", "finalize_batch"),
+    (r"scan_block_kernel|scan_add_kernel|scan_", "exclusive_scan"), (r"gather_multi_kernel", "gather_multi"), (r"gather_multi_kernel", "gather_multi"), (r"gather_kernel", "gather_u32"), (r"finalize_batch_kernel", "finalize_batch"),
     (r"datagen_uniform_kernel<long", "datagen_uniform_i64"), (r"datagen_", "datagen_other"), (r"hot_candidates_kernel|hot_emit_kernel", "hot_keys"),
     (r"strgroup_scatter_kernel", "strgroup_scatter"), (r"strgroup_agg_kernel", "strgroup_agg_lds"),
     (r"init_acc_kernel|fill_u64_kernel", "table_init"), (r"strview_encode_kernel", "strview_dict_encode"), (r"strdict_", "strdict_materialise"),
