@@ -16,6 +16,14 @@ __device__ __forceinline__ int prefix_rank(uint64_t m) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// Reads and writes of LDS words that other lanes update concurrently (slot protocols of the LDS tables).  NOT `volatile`: the compiler's address-space inference
+// skips volatile accesses, so a volatile access through a pointer derived from the dynamic LDS base became a FLAT instruction -- and every flat load is followed by
+// s_waitcnt vmcnt(0), which also waits for the chunk loads in flight (measured: the slot search of the wide-key aggregation was 15 of 18.5 ms this way).  A relaxed
+// workgroup-scope atomic access is a plain ds_read / ds_write; LDS operations of a wave are processed in order, lds_order() keeps the COMPILER from reordering them.
+template <class T> __device__ __forceinline__ T lds_ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <class T> __device__ __forceinline__ void lds_st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
   uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
   lo = __shfl_xor(lo, mask, 64);

@@ -101,14 +101,14 @@ std::string source_for(const Shape& sh, Sink sink) {
     case PART2_AGG_HASH: case PART2_AGG_DIRECT:
       o << "extern \"C\" __global__ __launch_bounds__(kP2AggBlock) void plx_jit_kernel(PartPlan2 pp, AggParams2 ap) {\n"
            "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout2 cl = rec_layout2(JitProg::shape(), " << (sink == PART2_AGG_DIRECT ? 1 : 0) << "u);\n"
-           "  part2_agg_body<Shape, " << (sink == PART2_AGG_DIRECT ? 1 : 0) << ", (cl.rec_words <= 1 ? 6 : 3)>(csh, cl, pp, ap);\n}\n}}\n";
+           "  part2_agg_body<Shape, " << (sink == PART2_AGG_DIRECT ? 1 : 0) << ", p2_agg_chunks_in_flight(cl.rec_words)>(csh, cl, pp, ap);\n}\n}}\n";
       break;
     default:
       if (sink >= PART3_AGG) {
         const int v = (int)sink - (int)PART3_AGG, mode = v & 1, pack = v >> 1;
         o << "extern \"C\" __global__ __launch_bounds__(kP2AggBlock) void plx_jit_kernel(PartPlan2 pp, AggParams2 ap) {\n"
              "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout2 cl = rec_layout2(JitProg::shape(), " << mode << "u, " << pack << "u);\n"
-             "  part2_agg_body<Shape, " << mode << ", (cl.rec_words <= 1 ? 6 : 3)>(csh, cl, pp, ap);\n}\n}}\n";
+             "  part2_agg_body<Shape, " << mode << ", p2_agg_chunks_in_flight(cl.rec_words)>(csh, cl, pp, ap);\n}\n}}\n";
         break;
       }
       if (sink >= PART3_SCATTER) {
@@ -248,6 +248,16 @@ std::string selftest(const Shape& sh, Sink sink) {
   const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   std::string log;
   if (rc != HIPRTC_SUCCESS) { size_t n = 0; hiprtcGetProgramLogSize(prog, &n); log.assign(n, 0); if (n) hiprtcGetProgramLog(prog, &log[0]); if (log.empty()) log = "hiprtc error"; }
+  else if (const char* dir = getenv("PLX_JIT_DUMP_DIR")) {
+    // the code object next to its source, one pair per sink: `llvm-readelf --notes` on it gives registers / scratch of a run-time-compiled kernel without a GPU
+    // (tests/test_kernel_resources_cpu.py)
+    size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    const std::string base = std::string(dir) + "/" + sink_type(sink) + "_" + std::to_string((int)sink);
+    if (FILE* f = fopen((base + ".hsaco").c_str(), "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
+    if (FILE* f = fopen((base + ".hip").c_str(), "wb")) { fwrite(src.data(), 1, src.size(), f); fclose(f); }
+  }
   hiprtcDestroyProgram(&prog);
   return log;
 }

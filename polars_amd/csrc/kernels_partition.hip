@@ -190,7 +190,7 @@ static const int kEnvP2Direct = env_int("PLX_PART_DIRECT", 0, 1);        // 0: n
 static const int kEnvP2DirectLp = env_int("PLX_PART_DIRECT_LOG2_PARTS", 4, 9);   // direct mode: partitions when the id range allows (default 2^9)
 static const int kEnvP3Block = env_int("PLX_P3_BLOCK", 0, 1024);         // measurement: threads of a gen-3 scatter workgroup (0 = 1024; a multiple of 64, >= the partition count)
 static const int kEnvP2Wgs = env_int("PLX_PART2_WGS_PER_CU", 1, 4);       // scatter workgroups per CU (they must fit the LDS together)
-static const int kEnvP2Ablate = env_int("PLX_PART_ABLATE", 0, 3);
+static const int kEnvP2Ablate = env_int("PLX_PART_ABLATE", 0, 15);     // measurement only, results WRONG: 1 / 2 scatter (fused.hpp PartPlan2::ablate), 4 = wide-key aggregation without the cell updates, 8 = without the slot search
 static const int kEnvP2Tiles = env_int("PLX_PART_TILES", 1, 4);           // tiles per wave and round (gen 2: default 2 when the rings absorb them; gen 3: 4 / 2 / 1 by LDS)
 static const int kEnvP2Gen = env_int("PLX_PART_GEN", 2, 3);               // scatter generation (default 3: tile sort + carry lines; 2: rings + line flush)
 
@@ -232,14 +232,14 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
   for (int j = 0; j < kMaxSrc; j++) pp.src_base[j] = (pack != kPackNone && ranges && ranges[j].known && (L.src_kind[j] == 3 || pack == kPackFused)) ? ranges[j].mn : 0;
   const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0;
   uint32_t tiles = 0;
+  const uint32_t block = kEnvP3Block >= 64 && (uint32_t)kEnvP3Block >= NP && kEnvP3Block % 64 == 0 ? (uint32_t)kEnvP3Block : (uint32_t)kP2MaxBlock;
   for (uint32_t t : {4u, 3u, 2u, 1u}) {
     if (kEnvP2Tiles > 0 && t > (uint32_t)kEnvP2Tiles) continue;
     if ((pp.mode == kP2Hash || pp.n_hot) && t > 3) continue;      // hash partitions keep the 64-bit key and its hash live, the hot-key path its lookups: four tiles spill (12-24 B / lane; a scratch reload waits for every load in flight)
-    if (part3_scatter_lds(kP2MaxBlock * kRows * t, L.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies) <= lds_total) { tiles = t; break; }
+    if (part3_scatter_lds(block * kRows * t, L.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies) <= lds_total) { tiles = t; break; }
   }
   if (!tiles) return false;
-  pp.gen = 3; pp.pack = pack; pp.rec_words = L.rec_words; pp.block = kP2MaxBlock; pp.ring_lines = 0;
-  if (kEnvP3Block >= 64 && (uint32_t)kEnvP3Block >= NP && kEnvP3Block % 64 == 0) pp.block = (uint32_t)kEnvP3Block;
+  pp.gen = 3; pp.pack = pack; pp.rec_words = L.rec_words; pp.block = block; pp.ring_lines = 0;
   plan2_geometry(pp, n_rows, tiles);
   // chunks are filled completely (the carry line keeps the remainder): whole chunks of the rows + one partial chunk per partition + slack
   return true;
@@ -554,7 +554,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
     }
     PLX_HIP(hipGetLastError());
   }
-  if (pp.ablate) PLX_HIP(hipMemsetAsync(chunk_fill->ptr, 0, sizeof(uint32_t) * (size_t)n_chunks, stream()));   // measurement mode: the records are garbage, aggregate none of them
+  if (pp.ablate & 3u) PLX_HIP(hipMemsetAsync(chunk_fill->ptr, 0, sizeof(uint32_t) * (size_t)n_chunks, stream()));   // measurement mode: the records are garbage, aggregate none of them
   // chunk lists
   Buf counts = dev_alloc_zero(sizeof(uint32_t) * (NP + 1)), cursor = dev_alloc_zero(sizeof(uint32_t) * (NP + 1));
   Buf cl_off = dev_alloc(sizeof(uint64_t) * (NP + 2)), cl_ids = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks);

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_agg_kernel(SgAgg a) {
       if (__all(all)) break;
       uint32_t e[kPerLane];
 #pragma unroll
-      for (uint32_t u = 0; u < kPerLane; u++) if (g[u] == kSgPending) e[u] = *reinterpret_cast<volatile unsigned int*>(&tags[ts[u]]);
+      for (uint32_t u = 0; u < kPerLane; u++) if (g[u] == kSgPending) e[u] = lds_ld(&tags[ts[u]]);
 #pragma unroll
       for (uint32_t u = 0; u < kPerLane; u++) {
         if (g[u] != kSgPending) continue;
@@ -430,17 +430,19 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_agg_kernel(SgAgg a) {
         if (e[u] == 0xffffffffu) {
           if (atomicCAS(&tags[ts[u]], 0xffffffffu, tag << 12 | kSgPending) == 0xffffffffu) {
             const uint32_t idx = atomicAdd(&n_groups, 1u);
-            if (idx >= kSgGroupCap) { full = 1; g[u] = 0; *reinterpret_cast<volatile unsigned int*>(&tags[ts[u]]) = tag << 12; continue; }
-            *reinterpret_cast<volatile unsigned long long*>(&w0s[idx]) = ((unsigned long long)r[u][0].y << 32) | (r[u][0].x & 15u);
-            *reinterpret_cast<volatile unsigned long long*>(&w1s[idx]) = ((unsigned long long)r[u][1].y << 32) | r[u][1].x;
-            *reinterpret_cast<volatile unsigned int*>(&tags[ts[u]]) = tag << 12 | idx;
+            if (idx >= kSgGroupCap) { full = 1; g[u] = 0; lds_st(&tags[ts[u]], tag << 12); continue; }
+            lds_st(&w0s[idx], ((unsigned long long)r[u][0].y << 32) | (r[u][0].x & 15u));
+            lds_st(&w1s[idx], ((unsigned long long)r[u][1].y << 32) | r[u][1].x);
+            lds_order();                                                      // the view first, then the tag word that announces it
+            lds_st(&tags[ts[u]], tag << 12 | idx);
             g[u] = idx;
           }
           // lost the race: the winner's word next round, same slot
         } else if ((e[u] >> 12) == tag) {
           const uint32_t idx = e[u] & kSgPending;
           if (idx != kSgPending) {
-            const unsigned long long k0 = *reinterpret_cast<volatile unsigned long long*>(&w0s[idx]), k1 = *reinterpret_cast<volatile unsigned long long*>(&w1s[idx]);
+            lds_order();                                                      // (after the tag word that announced it)
+            const unsigned long long k0 = lds_ld(&w0s[idx]), k1 = lds_ld(&w1s[idx]);
             if (k0 == (((unsigned long long)r[u][0].y << 32) | (r[u][0].x & 15u)) && k1 == (((unsigned long long)r[u][1].y << 32) | r[u][1].x)) g[u] = idx;
             else ts[u] = (ts[u] + 1) & (kSgTagSlots - 1u);                    // same tag, another string
           }

@@ -425,11 +425,21 @@ __device__ __forceinline__ void load_rec2(const unsigned int* p, unsigned int* r
   if constexpr (RW == 4) { const uint4 v = *reinterpret_cast<const uint4*>(p); r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
   else if constexpr (RW == 3) { const RecWords3 v = *reinterpret_cast<const RecWords3*>(p); r[0] = v.a; r[1] = v.b; r[2] = v.c; }
   else if constexpr (RW == 2) { const uint2 v = *reinterpret_cast<const uint2*>(p); r[0] = v.x; r[1] = v.y; }
-  else {
+  else if constexpr (RW % 4 == 0) {      // (records of 4k dwords in a 16-byte aligned chunk)
+#pragma unroll
+    for (uint32_t w = 0; w < RW; w += 4) { const uint4 v = *reinterpret_cast<const uint4*>(p + w); r[w] = v.x; r[w + 1] = v.y; r[w + 2] = v.z; r[w + 3] = v.w; }
+  } else if constexpr (RW % 2 == 0) {    // 8-byte aligned: two-dword loads (24-byte wide-key records: three instead of six)
+#pragma unroll
+    for (uint32_t w = 0; w < RW; w += 2) { const uint2 v = *reinterpret_cast<const uint2*>(p + w); r[w] = v.x; r[w + 1] = v.y; }
+  } else {
 #pragma unroll
     for (uint32_t w = 0; w < RW; w++) r[w] = p[w];
   }
 }
+
+// chunks a wave keeps in flight: one-dword records (1 KB a chunk) want six; up to four dwords three; wider records two -- their buffers are kPerLane x rec_words
+// registers EACH, and with three the wide-key aggregation spilled (7 registers; a scratch reload waits for every chunk load in flight)
+__host__ __device__ constexpr int p2_agg_chunks_in_flight(uint32_t rec_words) { return rec_words <= 1 ? 6 : rec_words <= 4 ? 3 : 2; }
 
 template <class S, int MODE, int NB = 3>
 __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L, const PartPlan2& pp, const AggParams2& ap) {
@@ -486,6 +496,12 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
         case 2: load_rec2<2>(base + (size_t)i * 2, dst[u]); break;
         case 3: load_rec2<3>(base + (size_t)i * 3, dst[u]); break;
         case 4: load_rec2<4>(base + (size_t)i * 4, dst[u]); break;
+        case 5: load_rec2<5>(base + (size_t)i * 5, dst[u]); break;
+        case 6: load_rec2<6>(base + (size_t)i * 6, dst[u]); break;
+        case 7: load_rec2<7>(base + (size_t)i * 7, dst[u]); break;
+        case 8: load_rec2<8>(base + (size_t)i * 8, dst[u]); break;
+        case 10: load_rec2<10>(base + (size_t)i * 10, dst[u]); break;
+        case 12: load_rec2<12>(base + (size_t)i * 12, dst[u]); break;
         default:
 #pragma unroll
           for (uint32_t w = 0; w < 16; w++) if (w < RW) dst[u][w] = base[(size_t)i * RW + w];
@@ -518,14 +534,33 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
       if ((tag[u] | kBusy) == kEmptyKey) tag[u] ^= 2ull;                                // ... nor EMPTY once the busy bit is set
       slot[u] = (uint32_t)((((h << pp.log2_parts) >> 32) * (uint64_t)NS) >> 32);        // the partition consumed the hash's top bits
     }
-    for (uint32_t it = 0; it < 8u * NS + 64u; it++) {
+    if (pp.ablate & 8u) {
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) found[u] = true;
+    }
+    // Slot search.  The pass is bound by the instructions it issues (sixteen waves share four 16-lane SIMDs) and a wave walks as long as its longest probe sequence
+    // (a dozen slots at load 0.5), so the walk itself is a per-lane loop of one state read and two compares; what is heavy or rare -- claiming an empty slot,
+    // comparing key words on a hash match, a slot whose words are still being written -- happens once per round behind it, and a second round is the exception.
+    // (Measured, 1e9 records of a two-column key: with one loop that did everything per probe step the search was 15 of the pass's 18.5 ms.)
+    for (uint32_t round = 0;; round++) {
       bool all = true;
 #pragma unroll
       for (uint32_t u = 0; u < kPerLane; u++) all = all && found[u];
       if (__all(all)) break;
+      if (round >= 4u * NS + 64u) { full = 1; break; }                                   // (slots that stay busy: cannot happen; the pass reports a full table)
       unsigned long long st[kPerLane];
 #pragma unroll
-      for (uint32_t u = 0; u < kPerLane; u++) if (!found[u]) st[u] = *reinterpret_cast<volatile unsigned long long*>(&keys[slot[u]]);
+      for (uint32_t u = 0; u < kPerLane; u++) {
+        st[u] = kEmptyKey;
+        if (found[u]) continue;
+        for (uint32_t n = 0;; n++) {
+          st[u] = lds_ld(&keys[slot[u]]);
+          if (st[u] == kEmptyKey || (st[u] & ~kBusy) == tag[u]) break;
+          if (n >= NS) { full = 1; found[u] = true; live[u] = false; break; }           // every slot holds another key: a full table (the caller plans more partitions)
+          slot[u] = slot[u] + 1 == NS ? 0u : slot[u] + 1;
+        }
+      }
+      lds_order();                                                                         // key words are read AFTER the state that announces them
 #pragma unroll
       for (uint32_t u = 0; u < kPerLane; u++) {
         if (found[u]) continue;
@@ -534,36 +569,34 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
           if (atomicCAS(&keys[slot[u]], (unsigned long long)kEmptyKey, tag[u] | kBusy) == kEmptyKey) {
 #pragma unroll
             for (int j = 0; j < kMaxKeys; j++)
-              if (j < (int)L.n_key_cols) *reinterpret_cast<volatile unsigned long long*>(&kwords[(size_t)j * NS + slot[u]]) = (uint64_t)rec[2 * j] | ((uint64_t)rec[2 * j + 1] << 32);
+              if (j < (int)L.n_key_cols) lds_st(&kwords[(size_t)j * NS + slot[u]], (unsigned long long)((uint64_t)rec[2 * j] | ((uint64_t)rec[2 * j + 1] << 32)));
             if (pp.wide_null_word) {
               const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
-              *reinterpret_cast<volatile unsigned long long*>(&kwords[(size_t)L.n_key_cols * NS + slot[u]]) = ((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u);
+              lds_st(&kwords[(size_t)L.n_key_cols * NS + slot[u]], (unsigned long long)(((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u)));
             }
-            *reinterpret_cast<volatile unsigned long long*>(&keys[slot[u]]) = tag[u];
+            lds_order();                                                                   // the words first, then the state that announces them
+            lds_st(&keys[slot[u]], tag[u]);
             found[u] = true;
           }
           // lost the race: the winner's word in the next round, same slot
-        } else if ((st[u] & ~kBusy) == tag[u]) {
-          if (!(st[u] & kBusy)) {
-            bool same = true;
+        } else if (st[u] == tag[u]) {                                                      // published, the same hash: compare the key words
+          bool same = true;
 #pragma unroll
-            for (int j = 0; j < kMaxKeys; j++)
-              if (j < (int)L.n_key_cols) same = same && *reinterpret_cast<volatile unsigned long long*>(&kwords[(size_t)j * NS + slot[u]]) == ((uint64_t)rec[2 * j] | ((uint64_t)rec[2 * j + 1] << 32));
-            if (pp.wide_null_word) {
-              const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
-              same = same && *reinterpret_cast<volatile unsigned long long*>(&kwords[(size_t)L.n_key_cols * NS + slot[u]]) == (unsigned long long)(((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u));
-            }
-            if (same) found[u] = true;
-            else slot[u] = slot[u] + 1 == NS ? 0u : slot[u] + 1;                     // same hash, another key
+          for (int j = 0; j < kMaxKeys; j++)
+            if (j < (int)L.n_key_cols) same = same && lds_ld(&kwords[(size_t)j * NS + slot[u]]) == (unsigned long long)((uint64_t)rec[2 * j] | ((uint64_t)rec[2 * j + 1] << 32));
+          if (pp.wide_null_word) {
+            const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
+            same = same && lds_ld(&kwords[(size_t)L.n_key_cols * NS + slot[u]]) == (unsigned long long)(((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u));
           }
-          // busy: the key words are being written -- the same slot again next round
-        } else slot[u] = slot[u] + 1 == NS ? 0u : slot[u] + 1;
+          if (same) found[u] = true;
+          else slot[u] = slot[u] + 1 == NS ? 0u : slot[u] + 1;                           // same hash, another key: the walk goes on next round
+        }
+        // (the same hash, busy: its key words are being written -- the same slot again next round)
       }
-      if (it >= 8u * NS) { full = 1; break; }                                          // a full table (the pass reports it; the caller plans more partitions)
     }
 #pragma unroll
     for (uint32_t u = 0; u < kPerLane; u++) {
-      if (!live[u] || !found[u]) continue;
+      if (!live[u] || !found[u] || (pp.ablate & 4u)) continue;
       const unsigned int* rec = cur[u];
       const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
       const uint64_t rowid = L.has_rowid ? ((uint64_t)rec[L.rowid_off] | ((uint64_t)rec[L.rowid_off + 1] << 32)) : 0ull;
@@ -674,7 +707,7 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
     for (bool done = false; !done;) {     // the buffers rotate by (compile-time) index: copying a buffer would wait for its loads
 #pragma unroll
       for (int s = 0; s < NB; s++) {
-        if (j >= c_end || *(volatile unsigned int*)&full) { done = true; break; }      // a full table: the result is discarded anyway; probing it record by record would take O(slots) each
+        if (j >= c_end || lds_ld(&full)) { done = true; break; }      // a full table: the result is discarded anyway; probing it record by record would take O(slots) each
         load_chunk(j + (uint64_t)(NB - 1) * step, bufs[(s + NB - 1) % NB], nn[(s + NB - 1) % NB]);
         process(bufs[s], nn[s]);
         j += step;
@@ -712,7 +745,7 @@ __global__ __launch_bounds__(kP2AggBlock) void part2_agg_kernel(PartPlan2 pp, Ag
   static_assert(P::kStatic, "the partitioned group-by runs specialised programs only (AOT or JIT)");
   constexpr Shape csh = P::shape();
   constexpr RecLayout2 cl = rec_layout2(P::shape(), (uint32_t)MODE, (uint32_t)PACK);
-  part2_agg_body<Shape, MODE, (cl.rec_words <= 1 ? 6 : 3)>(csh, cl, pp, ap);
+  part2_agg_body<Shape, MODE, p2_agg_chunks_in_flight(cl.rec_words)>(csh, cl, pp, ap);
 }
 
 }  // namespace k
