@@ -66,6 +66,16 @@ struct DictDesc {
   uint32_t pad;
 };
 
+// Addresses travel as 64-bit integers inside descriptors that the kernels load from memory; a pointer made from such an integer is a GENERIC pointer to the
+// compiler, and every access through it a FLAT instruction (counted by vmcnt AND lgkmcnt: each wait for an LDS operation then also waits for the global loads in
+// flight -- the Snappy kernel had 126 of them).  On the device the integer is first made a global-address-space pointer; on the host (the CPU twin the tests run)
+// it is a plain cast.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PQ_GPTR(T, x) ((T*)(__attribute__((address_space(1))) T*)(x))
+#else
+#define PQ_GPTR(T, x) ((T*)(x))
+#endif
+
 struct DecompJob {      // one Snappy stream
   uint64_t src, dst;
   uint32_t comp_size, uncomp_size;
@@ -92,7 +102,7 @@ PLX_HD int popc64_hd(uint64_t x) { return __builtin_popcountll(x); }
 // ---- page_prepare: one thread per page ----------------------------------------------------------------------------------------------
 // Splits the (decompressed) payload into level and value streams (page/mod.rs:372-450).  Returns error bits.
 PLX_HD uint32_t page_prepare(PageDesc& p) {
-  const uint8_t* body = (const uint8_t*)(p.flags & PF_COMPRESSED ? p.dst : p.src);
+  const uint8_t* body = PQ_GPTR(const uint8_t, p.flags & PF_COMPRESSED ? p.dst : p.src);
   uint32_t err = 0;
   if (p.flags & PF_V2) {
     // levels are never compressed and stay at src; the values part is what was (or was not) decompressed
@@ -119,7 +129,7 @@ PLX_HD uint32_t page_prepare(PageDesc& p) {
     if (p.val_len < 1) {
       if (p.num_values) err |= PE_VALUES;
     } else {
-      p.bit_width = *(const uint8_t*)p.val_ptr;
+      p.bit_width = *PQ_GPTR(const uint8_t, p.val_ptr);
       p.val_ptr += 1; p.val_len -= 1;
       if (p.bit_width > 32) { err |= PE_RUNS; p.bit_width = 0; }
     }
@@ -129,7 +139,7 @@ PLX_HD uint32_t page_prepare(PageDesc& p) {
       if (p.num_values) err |= PE_VALUES;
       p.val_len = 0;
     } else {
-      uint32_t n = load_u32((const uint8_t*)p.val_ptr);
+      uint32_t n = load_u32(PQ_GPTR(const uint8_t, p.val_ptr));
       if (n > p.val_len - 4) { err |= PE_VALUES; n = p.val_len - 4; }
       p.val_ptr += 4; p.val_len = n; p.bit_width = 1;
     }
@@ -179,11 +189,11 @@ template <class Emit> PLX_HD uint32_t walk_runs(const uint8_t* s, uint32_t len, 
 PLX_HD bool stream_params(const PageDesc& p, int s, const uint8_t** ptr, uint32_t* len, uint32_t* bits) {
   if (s == 0) {
     if (!(p.flags & PF_HAS_DEF)) return false;
-    *ptr = (const uint8_t*)p.def_ptr; *len = p.def_len; *bits = 1;
+    *ptr = PQ_GPTR(const uint8_t, p.def_ptr); *len = p.def_len; *bits = 1;
     return true;
   }
   if (!(p.flags & (PF_DICT | PF_RLE_VALUES))) return false;
-  *ptr = (const uint8_t*)p.val_ptr; *len = p.val_len; *bits = p.bit_width;
+  *ptr = PQ_GPTR(const uint8_t, p.val_ptr); *len = p.val_len; *bits = p.bit_width;
   return true;
 }
 
@@ -281,7 +291,7 @@ PLX_HD uint64_t validity_word(const PageDesc* pages, uint32_t n_pages, const Run
     uint32_t n_ent = (uint32_t)(run_off[2 * pg + 1] - run_off[2 * pg]);       // runs + sentinel
     if (n_ent < 2 || pr[n_ent - 1].start != p.num_values) { *err |= PE_LEVELS; r += take_page; continue; }
     uint32_t n_runs = n_ent - 1;
-    const uint8_t* s = (const uint8_t*)p.def_ptr;
+    const uint8_t* s = PQ_GPTR(const uint8_t, p.def_ptr);
     uint32_t i = (uint32_t)(r - p.row0), left = take_page;
     uint32_t k = find_run(pr, n_runs, i);
     while (left) {
@@ -344,16 +354,16 @@ PLX_HD bool decode_row(const ColumnDecode& c, uint32_t pg, uint64_t r, uint64_t*
       uint32_t n_ent = (uint32_t)(c.run_off[2 * pg + 2] - c.run_off[2 * pg + 1]);   // runs + sentinel {start = indices in the stream}
       if (n_ent < 2 || dense >= pr[n_ent - 1].start) { *err |= PE_VALUES; *out_bits = 0; return true; }
       uint32_t k = find_run(pr, n_ent - 1, (uint32_t)dense);
-      idx = run_value((const uint8_t*)p.val_ptr, pr[k], p.bit_width, (uint32_t)dense);
+      idx = run_value(PQ_GPTR(const uint8_t, p.val_ptr), pr[k], p.bit_width, (uint32_t)dense);
     }
     if (p.flags & PF_RLE_VALUES) { *out_bits = idx; return true; }
     const DictDesc& d = c.dicts[p.dict];
     if (idx >= d.n) { *err |= PE_DICT_INDEX; *out_bits = 0; return true; }
-    const uint8_t* e = (const uint8_t*)d.values + (uint64_t)idx * c.dict_width;
+    const uint8_t* e = PQ_GPTR(const uint8_t, d.values) + (uint64_t)idx * c.dict_width;
     *out_bits = c.dict_width == 8 ? load_u64(e) : c.dict_width == 4 ? (uint64_t)load_u32(e) : (uint64_t)*e;
     return true;
   }
-  const uint8_t* v = (const uint8_t*)p.val_ptr;
+  const uint8_t* v = PQ_GPTR(const uint8_t, p.val_ptr);
   if (c.src_width == 0) {
     if ((dense >> 3) >= p.val_len) { *err |= PE_VALUES; *out_bits = 0; return true; }
     *out_bits = (v[dense >> 3] >> (dense & 7)) & 1;

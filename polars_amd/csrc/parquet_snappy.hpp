@@ -121,7 +121,7 @@ PLX_HD uint32_t snappy_tag(const uint8_t* t, uint32_t* len, uint32_t* val, uint3
 
 PLX_HD void snappy_begin(SnapShared& sh, const DecompJob& job) {
   // preamble: uncompressed length as a varint
-  const uint8_t* in = (const uint8_t*)job.src;
+  const uint8_t* in = PQ_GPTR(const uint8_t, job.src);
   uint32_t pos = 0, n = 0;
   bool ok = false;
   for (uint32_t shift = 0; shift <= 28 && pos < job.comp_size; shift += 7) {
@@ -138,7 +138,7 @@ PLX_HD void snappy_begin(SnapShared& sh, const DecompJob& job) {
 
 // stage: the window, 16 input bytes per lane (the 16 pad bytes behind it are cleared by lane 0)
 PLX_HD void snappy_stage(SnapShared& sh, const DecompJob& job, uint32_t lane) {
-  const uint8_t* in = (const uint8_t*)job.src;
+  const uint8_t* in = PQ_GPTR(const uint8_t, job.src);
   constexpr uint32_t kPieces = kSnapWindow / 16 / kSnapLanes;     // 16-byte pieces per lane (1 with 256 lanes)
   uint8_t tmp[kPieces][16];
   for (uint32_t c = 0; c < kPieces; c++) {                // all loads are issued before the first LDS write waits for one
@@ -415,8 +415,8 @@ PLX_HD void snappy_finish(SnapShared& sh, const DecompJob& job) {
 
 // direct: the round's single long literal, 16 bytes per lane and step
 PLX_HD void snappy_direct(const SnapShared& sh, const DecompJob& job, uint32_t lane) {
-  const uint8_t* s = (const uint8_t*)job.src + sh.direct_src;
-  uint8_t* d = (uint8_t*)job.dst + sh.round_out0;
+  const uint8_t* s = PQ_GPTR(const uint8_t, job.src) + sh.direct_src;
+  uint8_t* d = PQ_GPTR(uint8_t, job.dst) + sh.round_out0;
   const uint32_t n = sh.direct_len;
   // four 16-byte pieces per lane and step, loaded before any is stored (input and output never overlap, which the compiler cannot know)
   for (uint32_t o0 = 0; o0 < n; o0 += 4 * kSnapLanes * 16) {
@@ -481,8 +481,8 @@ PLX_HD bool snappy_jump_v2(SnapShared& sh, uint32_t lane) {
 
 // gather: load every byte through its resolved pointer and store it
 PLX_HD void snappy_gather(const SnapShared& sh, const DecompJob& job, uint32_t lane) {
-  const uint8_t* in = (const uint8_t*)job.src;
-  uint8_t* gout = (uint8_t*)job.dst;
+  const uint8_t* in = PQ_GPTR(const uint8_t, job.src);
+  uint8_t* gout = PQ_GPTR(uint8_t, job.dst);
   const uint32_t n_bytes = sh.out_pos - sh.round_out0, round0 = sh.round_out0;
   // Every resolved pointer leads outside the round (input, or output of earlier rounds), so the loads never alias the stores --
   // which the compiler cannot know: taken one byte at a time each load would wait for the previous store.  16 loads in flight,

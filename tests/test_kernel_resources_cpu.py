@@ -81,3 +81,52 @@ def test_string_group_by_kernels_do_not_spill():
         timing_build = "strgroup_scatter_kernelILb1" in name
         assert int(r["ScratchSize [bytes/lane]"]) <= (64 if timing_build else 0), (name, r)
         assert int(r["VGPRs"]) <= 128, (name, r)
+
+
+def test_no_kernel_uses_flat_memory_instructions(tmp_path):
+    """Every memory access of every kernel in the built library is a global_*, ds_* or scalar instruction -- never flat_*.  A flat access is counted by vmcnt AND
+    lgkmcnt, so the wait behind it also waits for every global load in flight; it appears when the compiler cannot tell the address space: a `volatile` access
+    through a pointer derived from the dynamic LDS base (the LDS slot protocols used those: the wide-key aggregation's slot search was 15 of 18.5 ms), or a pointer
+    made from a 64-bit integer that was loaded from a descriptor (the Parquet page descriptors / Snappy jobs: 126 flat instructions in pq_snappy).  dev.hpp lds_ld /
+    lds_st and parquet_device.hpp PQ_GPTR are the two idioms that avoid them."""
+    import shutil
+    lib = os.path.join(ROOT, "polars_amd", "libpolars_amd.so")
+    assert os.path.exists(lib), "build the library first (__graft_entry__.build)"
+    work = tmp_path / "co"
+    work.mkdir()
+    shutil.copy(lib, work / "lib.so")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=work, capture_output=True, text=True, timeout=300)      # writes lib.so.<n>.hipv4-amdgcn-amd-amdhsa--gfx950
+    objs = sorted(f for f in os.listdir(work) if f.endswith("gfx950"))
+    assert len(objs) >= 10, objs
+    kernels, offenders = 0, {}
+    for f in objs:
+        name = None
+        for line in subprocess.run([objdump, "-d", f], cwd=work, capture_output=True, text=True, timeout=600).stdout.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+            if m:
+                name = m.group(1); kernels += 1
+            elif name and re.search(r"\bflat_(load|store|atomic)", line):
+                offenders[name] = offenders.get(name, 0) + 1
+    assert kernels >= 200, kernels
+    assert not offenders, offenders
+
+
+def test_jit_wide_key_aggregation_has_no_scratch_and_no_flat_access(tmp_path, monkeypatch):
+    """The run-time compiled kernels of the two-column-key group-by (bench.py cfg3w): the LDS aggregation pass keeps two chunks of 5- or 6-dword records in
+    flight next to its slot search -- three spilled -- and reads its table through ds_* instructions only (plx_jit_selftest + PLX_JIT_DUMP_DIR: no GPU needed)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import polars_amd as pl
+    from test_jit_cpu import ph
+    monkeypatch.setenv("PLX_JIT_DUMP_DIR", str(tmp_path))
+    t = pl.DataFrame([ph("id", pl.Int64), ph("id2", pl.Int64), ph("v", pl.Float64)])
+    t.lazy().group_by("id", "id2").agg(pl.col("v").sum().alias("s"), pl.len().alias("n")).jit_selftest()
+    objs = [f for f in os.listdir(tmp_path) if f.startswith("part3_agg") and f.endswith(".hsaco")]
+    assert objs, os.listdir(tmp_path)
+    for f in objs:
+        notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f], cwd=tmp_path, capture_output=True, text=True, timeout=120).stdout
+        assert int(re.search(r"\.vgpr_spill_count:\s*(\d+)", notes).group(1)) == 0, notes
+        assert int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", notes).group(1)) == 0, notes
+        isa = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", f], cwd=tmp_path, capture_output=True, text=True, timeout=120).stdout
+        assert "ds_cmpst_rtn_b64" in isa and not re.search(r"\bflat_(load|store|atomic)", isa)
