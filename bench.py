@@ -2005,7 +2005,7 @@ def run(args, emit):
                 w2 = make_workload(pl, name, int(os.environ.get("PLX_BENCH_EXTRAS_ROWS", "0")), seed=20)
                 d2, s2, r2, c2 = timed(pl, w2, k2, 2, False)       # two warm-up steps: config 3's second run is the first with learned key statistics (new buffer sizes)
                 extras[w2.name] = {"rows_per_s": round(w2.rows * k2 / d2, 1), "ms_per_step": round(d2 / k2 * 1e3, 3), "cold_first_step_ms": None if c2 is None else round(c2, 2),
-                                   "one_shot_ms": one_shot_ms(pl, w2),
+                                   "one_shot_ms": one_shot_ms(pl, w2), "step_ms": list(getattr(timed, "last_step_ms", [])), **step_spread(getattr(timed, "last_step_ms", []), w2.rows),
                                    "whole_query_GBps": round(w2.algo_bytes * k2 / d2 / 1e9, 1), "roofline": roofline(s2, w2, k2), "kernels": _kernels(s2, 6)}
                 emit(line)
                 for vname, vstep in w2.variants.items():
