@@ -20,6 +20,12 @@ __device__ __forceinline__ int prefix_rank(uint64_t m) {
 // skips volatile accesses, so a volatile access through a pointer derived from the dynamic LDS base became a FLAT instruction -- and every flat load is followed by
 // s_waitcnt vmcnt(0), which also waits for the chunk loads in flight (measured: the slot search of the wide-key aggregation was 15 of 18.5 ms this way).  A relaxed
 // workgroup-scope atomic access is a plain ds_read / ds_write; LDS operations of a wave are processed in order, lds_order() keeps the COMPILER from reordering them.
+// A wave-uniform read of memory this kernel never writes (chunk lists, fills: written by the kernel before), through the CONSTANT address space: the load is
+// invariant to the compiler whatever "memory" clobbers and atomics surround it, so with a uniform index it becomes an s_load (scalar cache) instead of a vector
+// load + s_waitcnt vmcnt(0) -- which would also wait for every record load in flight.
+template <class T> __device__ __forceinline__ T uniform_ld(const T* p, uint64_t i) {
+  return reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p))[i];
+}
 template <class T> __device__ __forceinline__ T lds_ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 template <class T> __device__ __forceinline__ void lds_st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }

@@ -478,8 +478,8 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
     const uint64_t jc = j < c_end ? j : c_end - 1;
     const uint32_t jlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)jc), jhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(jc >> 32));
     const uint64_t ju = ((uint64_t)jhi << 32) | jlo;
-    const uint32_t id = ap.cl_ids[ju];
-    const uint32_t fill = ap.chunk_fill[id];
+    const uint32_t id = uniform_ld(ap.cl_ids, ju);
+    const uint32_t fill = uniform_ld(ap.chunk_fill, (uint64_t)id);
     cnt = j < c_end ? fill : 0u;
     const unsigned int* base = ap.recs + (uint64_t)id * chunk_dw;
     if (RW == 1) {     // one-dword records: the lane takes four consecutive ones with ONE 16-byte load (the memory pipeline accepts a wave-load every ~40 cycles whatever its width)
