@@ -463,16 +463,22 @@ int plx_datagen_zipf_host(int64_t row0, int64_t n, uint64_t seed, uint32_t strea
  * data buffers (host; may be empty when every string is <= 12 bytes).  out_codes = a PLX_U32 column of dictionary codes (validity
  * = the input's; bounds [0, n_distinct) declared), out_dict = the dictionary (code -> string), kept on the device.
  * plx_strview_dict_encode_device: the same for views already in HBM (a PLX_U64 column of 2 n words; `data` a PLX_U8 column or 0).
+ * Nulls of a view column in HBM: the raw-view entry points (plx_strview_dict_encode_device, plx_strview_groupby, plx_ipc_read_string_views) carry no bitmap --
+ * a null entry is a view whose length word is 0xFFFFFFFF (no Arrow view has it: lengths are non-negative int32; the other 12 bytes zero).
+ * plx_strview_stamp_nulls(views, valid) writes those stamps in place from the array's validity (valid: a PLX_BOOL column of n rows, true = valid -- the
+ * BinaryViewArray's validity bitmap, crates/polars-arrow/src/array/binview/mod.rs, imported as Boolean values); encode gives such rows null codes.
  * plx_strdict_to_host: offsets[n_strings + 1] + the concatenated bytes, in code order. */
 typedef uint64_t plx_strdict;
 int plx_strview_dict_encode(const void* views, const uint8_t* validity, int64_t bit_offset, int64_t n, const void* const* data_buffers, const int64_t* data_sizes,
                             int32_t n_data_buffers, plx_column* out_codes, plx_strdict* out_dict);
 int plx_strview_dict_encode_device(plx_column views_u64_pairs, plx_column data_u8, plx_column* out_codes, plx_strdict* out_dict);
+int plx_strview_stamp_nulls(plx_column views_u64_pairs, plx_column valid_bool);
 /* group_by(<raw Utf8View key>).agg(sum, count, len of ONE numeric column), the key never dictionary-encoded first (kernels_strgroup.hip; the reference's
  * BinviewKeys group-by: crates/polars-expr/src/hash_keys.rs:413-452, crates/polars-compute/src/binview_index_map.rs).  views: a PLX_U64 column of 2 n words in
  * HBM (inline strings: <= 12 bytes each); value: a PLX_F64 / PLX_I64 column of n rows, nulls allowed.  Outputs, one row per distinct string, in no particular
  * order: out_codes = 0 .. G-1 (PLX_U32) with *out_dict holding the G strings in that order; out_sum (the value's dtype; 0 for a group without a valid value),
- * out_count (valid values, PLX_U32), out_len (rows, PLX_U32) -- mean = sum / count.  Returns PLX_ERR_UNSUPPORTED when the input is outside the fast path (a
+ * out_count (valid values, PLX_U32), out_len (rows, PLX_U32) -- mean = sum / count.  Rows with a null key (stamped views, above) form one group of their own,
+ * as in the reference (a null is a key: hash_keys.rs:413-452 keeps the validity in the key): that group's code is null, its dictionary entry empty.  Returns PLX_ERR_UNSUPPORTED when the input is outside the fast path (a
  * string longer than 12 bytes, more distinct strings than the LDS tables hold, fewer than ~4096 of them): the caller then encodes (plx_strview_dict_encode_device) and groups on the codes. */
 int plx_strview_groupby(plx_column views_u64_pairs, plx_column value, plx_column* out_codes, plx_strdict* out_dict, plx_column* out_sum, plx_column* out_count, plx_column* out_len);
 int plx_strdict_info(plx_strdict dict, int64_t* n_strings, int64_t* total_bytes);
@@ -547,7 +553,7 @@ int plx_ipc_batch_info(plx_ipc file, int32_t batch, int64_t* num_rows, int64_t* 
 int plx_ipc_read(plx_ipc file, const int32_t* batches, int32_t n_batches, const int32_t* columns, int32_t n_columns, plx_frame* out);
 /* One Utf8 / LargeUtf8 / Binary column of the selected record batches as it is needed for a group-by ON THE VIEWS (plx_strview_groupby): *out_views = a PLX_U64 column of
  * 2 n words (16-byte views built on the device from the file's offsets + bytes), *out_data = the bytes behind the views of strings over 12 bytes (PLX_U8; the pair is what
- * plx_strview_dict_encode_device takes when the column has to be encoded after all).  PLX_ERR_UNSUPPORTED: a column with nulls, a Utf8View column, a column that is
+ * plx_strview_dict_encode_device takes when the column has to be encoded after all); null entries are stamped views.  PLX_ERR_UNSUPPORTED: a Utf8View column, a column that is
  * dictionary-encoded in the file -- read those through plx_ipc_read.  (The reference reads string columns as views and hashes them per operator:
  * crates/polars-io/src/ipc/ipc_file.rs, crates/polars-expr/src/hash_keys.rs:413-452.) */
 int plx_ipc_read_string_views(plx_ipc file, const int32_t* batches, int32_t n_batches, int32_t column, plx_column* out_views, plx_column* out_data);

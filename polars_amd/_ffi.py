@@ -119,6 +119,7 @@ SIGNATURES = {
     "plx_strview_dict_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, _u64p, _u64p]),
     "plx_strview_dict_encode_device": (C.c_int, [C.c_uint64, C.c_uint64, _u64p, _u64p]),
     "plx_strview_groupby": (C.c_int, [C.c_uint64, C.c_uint64, _u64p, _u64p, _u64p, _u64p, _u64p]),
+    "plx_strview_stamp_nulls": (C.c_int, [C.c_uint64, C.c_uint64]),
     "plx_strdict_info": (C.c_int, [C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "plx_strdict_to_host": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p]),
     "plx_strdict_free": (C.c_int, [C.c_uint64]),

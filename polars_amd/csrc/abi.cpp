@@ -995,8 +995,26 @@ int plx_strview_dict_encode_device(plx_column views_u64_pairs, plx_column data_u
   PLX_REQUIRE(v->dtype == PLX_U64 && v->len % 2 == 0 && (v->values || v->len == 0), PLX_ERR_INVALID, "views must be a UInt64 column of 2 n words");
   Buf data, bb = dev_alloc_zero(8);
   if (data_u8) { ColumnPtr d = get_column(data_u8); PLX_REQUIRE(d->dtype == PLX_U8, PLX_ERR_INVALID, "data must be a UInt8 column"); data = d->values; }
-  encode_on_device(v->values ? v->values->as<uint64_t>() : nullptr, nullptr, data, bb, v->len / 2, out_codes, out_dict);
+  // nulls arrive as stamped views (plx_strview_stamp_nulls / plx_ipc_read_string_views): the bitmap the encoder and the code column want is read off the stamps
+  ColumnPtr vh;
+  const int64_t n = v->len / 2;
+  if (n > 0) {
+    Buf bits = dev_alloc(bitmap_bytes(n));
+    const int64_t nulls = k::strview_validity_from_stamps(v->values->as<uint64_t>(), n, bits->as<uint64_t>());
+    if (nulls > 0) { vh = std::make_shared<Column>(); vh->dtype = PLX_U8; vh->len = n; vh->validity = bits; vh->null_count = nulls; }
+  }
+  encode_on_device(v->values ? v->values->as<uint64_t>() : nullptr, vh, data, bb, n, out_codes, out_dict);
   // the dictionary's views point into nothing else than `data`; inline strings need no buffer at all
+  PLX_CATCH
+}
+int plx_strview_stamp_nulls(plx_column views_u64_pairs, plx_column valid_bool) {
+  PLX_TRY
+  ColumnPtr v = get_column(views_u64_pairs), m = get_column(valid_bool);
+  PLX_REQUIRE(v->dtype == PLX_U64 && v->len % 2 == 0, PLX_ERR_INVALID, "views must be a UInt64 column of 2 n words");
+  PLX_REQUIRE(m->dtype == PLX_BOOL, PLX_ERR_INVALID, "the validity of the views is a Boolean column (true = valid: the array's validity bitmap as its values)");
+  PLX_REQUIRE(m->len == v->len / 2, PLX_ERR_SHAPE, "validity column and views differ in length");
+  PLX_REQUIRE((v->values && m->values) || v->len == 0, PLX_ERR_INVALID, "placeholder column has no data");
+  if (v->len) k::strview_stamp_nulls(v->values->as<uint64_t>(), m->values->as<uint64_t>(), m->len);
   PLX_CATCH
 }
 int plx_strview_groupby(plx_column views_u64_pairs, plx_column value, plx_column* out_codes, plx_strdict* out_dict, plx_column* out_sum, plx_column* out_count, plx_column* out_len) {
@@ -1016,6 +1034,11 @@ int plx_strview_groupby(plx_column views_u64_pairs, plx_column value, plx_column
   ColumnPtr codes = make_column(PLX_U32, G, false);
   codes->null_count = 0;
   if (G) { k::fill_iota_u32(codes->values->as<uint32_t>(), G); codes->range_state = 1; codes->range_min = 0; codes->range_max = G - 1; codes->range_trusted = true; }
+  if (G) {      // the null key's group (stamped views): its code is null, its dictionary entry the empty string
+    Buf bits = dev_alloc(bitmap_bytes(G));
+    const int64_t nulls = k::strview_null_group(gviews->as<uint64_t>(), G, bits->as<uint64_t>());
+    if (nulls > 0) { codes->validity = bits; codes->null_count = nulls; }
+  }
   auto d = std::make_unique<StrDict>();
   d->views = gviews; d->data = nullptr; d->n = G;
   *out_codes = register_column(codes);

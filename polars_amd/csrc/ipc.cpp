@@ -192,7 +192,7 @@ void set_bits(uint8_t* bits, int64_t off, int64_t n) {
 // 1-character l_returnflag column of a 2e7-row file took 115 of the file's 150 ms that way), the views are built by a kernel
 // (k::strviews_from_offsets) and encoded on the device like every other string column.
 // raw != nullptr: the column is NOT dictionary-encoded -- its views (2 x total UInt64 words) and the bytes behind them are handed back as they sit in HBM
-// (plx_ipc_read_string_views: a group-by keyed on the column runs on the views, kernels_strgroup.hip); a column with nulls is refused there
+// (plx_ipc_read_string_views: a group-by keyed on the column runs on the views, kernels_strgroup.hip); nulls are stamped into the views
 struct RawViews { ColumnPtr views, data; };
 ColumnPtr read_offset_string_column(File& f, const std::vector<int>& bsel, int col, int64_t total, bool large, plx_strdict* dict_out, RawViews* raw = nullptr) {
   PinnedStage& st = PinnedStage::for_this_thread();
@@ -265,12 +265,12 @@ ColumnPtr read_offset_string_column(File& f, const std::vector<int>& bsel, int c
   }
   for (const Part& p : parts)
     k::strviews_from_offsets((const uint8_t*)d_offs->ptr + p.off_at, large, d_data->as<uint8_t>(), (uint64_t)p.data_at, (int64_t)p.data_len, p.n, d_views->as<uint64_t>() + (size_t)p.row0 * 2,
-                             vh ? vh->valid_words() : nullptr, p.row0, err->as<unsigned int>());
+                             vh ? vh->valid_words() : nullptr, p.row0, raw != nullptr, err->as<unsigned int>());
   uint32_t bad = 0;
   d2h_sync(&bad, err->ptr, 4);
   if (bad) throw ipc::FormatError("string offsets outside the data buffer");
   if (raw) {
-    if (any_nulls) throw Unsupported("string column with nulls: its views are not handed out (read it dictionary-encoded)");
+    // (nulls travel as stamped views: kernels.hpp kStrviewNullLen)
     auto col_of = [](int dtype, int64_t len, const Buf& b) { auto c = std::make_shared<Column>(); c->dtype = dtype; c->len = len; c->values = b; c->null_count = 0; return c; };
     raw->views = col_of(PLX_U64, total * 2, d_views);
     raw->data = col_of(PLX_U8, (int64_t)data_bytes, d_data);

@@ -54,13 +54,21 @@ void strview_dict_encode(const uint64_t* views, const uint64_t* validity, const 
                          int64_t* n_distinct);
 // dictionary -> offsets[n + 1] (u64) + contiguous bytes on the device
 // Utf8 / LargeUtf8 arrays (offsets + bytes, already in HBM) -> 16-byte views: {len, 12 inline bytes} or {len, 4-byte prefix, buffer 0, offset
-// data_base + start}; null rows (validity bit row0 + i clear) become all-zero views.  *err (device u32) is set when an offset pair is not
+// data_base + start}; null rows (validity bit row0 + i clear) become all-zero views, or null stamps (below) with stamp_nulls.  *err (device u32) is set when an offset pair is not
 // monotonic, leaves the data buffer or a long string starts beyond 4 GiB.
-void strviews_from_offsets(const void* offsets, bool large, const uint8_t* data, uint64_t data_base, int64_t data_len, int64_t n, uint64_t* views_out, const uint64_t* validity, int64_t row0,
+void strviews_from_offsets(const void* offsets, bool large, const uint8_t* data, uint64_t data_base, int64_t data_len, int64_t n, uint64_t* views_out, const uint64_t* validity, int64_t row0, bool stamp_nulls,
                            unsigned int* err);
-// group_by(raw Utf8View key).agg(sum / count / len of one 8-byte numeric column) without a dictionary-encode pass (kernels_strgroup.hip); -1 = not on the fast path
+// A null entry of a view column that travels WITHOUT a bitmap (plx_strview_groupby, plx_strview_dict_encode_device, plx_ipc_read_string_views) is a view whose length
+// word is kStrviewNullLen -- no Arrow view has it (lengths are non-negative int32).  strview_stamp_nulls writes the stamps from a bitmap (in place),
+// strview_validity_from_stamps gives the bitmap back ([ceil(n / 64)] words) and returns the number of nulls.
+constexpr uint32_t kStrviewNullLen = 0xffffffffu;
+void strview_stamp_nulls(uint64_t* views, const uint64_t* validity, int64_t n);
+int64_t strview_validity_from_stamps(const uint64_t* views, int64_t n, uint64_t* valid);
+// group_by(raw Utf8View key).agg(sum / count / len of one 8-byte numeric column) without a dictionary-encode pass (kernels_strgroup.hip); -1 = not on the fast path.
+// A stamped (null) key is a key of its own; strview_null_group finds its group among the G result views (-> 0 or 1), clears its bit of `valid` and empties its view.
 int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uint64_t* val_validity, int64_t n, bool is_f64, Buf* out_views, Buf* out_sum, Buf* out_cnt, Buf* out_len,
                         std::string* desc);
+int64_t strview_null_group(uint64_t* gviews, int64_t G, uint64_t* valid);
 void strdict_materialise(const uint64_t* dict_views, const uint8_t* data, int64_t n, Buf* out_offsets, Buf* out_bytes, uint64_t* total_bytes);
 // synthetic Utf8View column (benchmark support): the inline view of "id%010d" % value for value = lo + floor(U * (hi - lo)) of row i
 void datagen_id_views(int64_t n, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, uint64_t* out_views);

@@ -146,7 +146,10 @@ __global__ __launch_bounds__(kSgBlock) void strgroup_scatter_kernel(SgScatter p)
       const int64_t row = rd * kSgTile + (int64_t)j * kSgBlock + tid;
       bool live = row < p.n;
       const bool vnull = live && p.val_validity && !((p.val_validity[row >> 6] >> (row & 63)) & 1);
-      if (live && (uint32_t)v[j].x > 12u) { p.flags[1] = 1u; live = false; }          // a long string: the view is not the string -> the caller falls back
+      // a null key (the view stamped with the impossible length kStrviewNullLen: plx_strview_stamp_nulls) is a key of its own -- from here on the view {15, 0}:
+      // length nibble 15, which no string of the fast path has (<= 12 bytes); the result's group with that view becomes the null group
+      if (live && (uint32_t)v[j].x == kStrviewNullLen) v[j] = make_ulonglong2(15ull, 0ull);
+      else if (live && (uint32_t)v[j].x > 12u) { p.flags[1] = 1u; live = false; }     // a long string: the view is not the string -> the caller falls back
       part[j] = 0xffffffffu;
       uint64_t h = 0;
       if (live) {
@@ -498,8 +501,9 @@ __global__ __launch_bounds__(kBlock) void sg_sample_kernel(const unsigned long l
   const int64_t run = S / 64 > 0 ? S / 64 : 1, r = i / run, within = i % run;
   const int64_t n_runs = (S + run - 1) / run;
   const int64_t row = S >= n ? i : (int64_t)((__int128)r * (n - run) / (n_runs > 1 ? n_runs - 1 : 1)) + within;
-  const ulonglong2 v = reinterpret_cast<const ulonglong2*>(views)[row < n ? row : n - 1];
-  if ((uint32_t)v.x > 12u) { res[1] = 1u; return; }
+  ulonglong2 v = reinterpret_cast<const ulonglong2*>(views)[row < n ? row : n - 1];
+  if ((uint32_t)v.x == kStrviewNullLen) v = make_ulonglong2(15ull, 0ull);                 // a null key: one more distinct key (as the scatter sees it)
+  else if ((uint32_t)v.x > 12u) { res[1] = 1u; return; }
   unsigned long long h = sg_hash(v.x, v.y);
   if (h == kSgEmpty) h = 0;
   const uint64_t mask = (1ull << log2_cap) - 1;
@@ -549,7 +553,8 @@ __global__ __launch_bounds__(kSgBlock) void sg_hot_kernel(const unsigned long lo
   __syncthreads();
   for (int64_t i = threadIdx.x; i < S; i += blockDim.x) {
     const int64_t row = (int64_t)((__int128)i * n / S);
-    const ulonglong2 v = reinterpret_cast<const ulonglong2*>(views)[row];
+    ulonglong2 v = reinterpret_cast<const ulonglong2*>(views)[row];
+    if ((uint32_t)v.x == kStrviewNullLen) v = make_ulonglong2(15ull, 0ull);               // (a column that is mostly null: the null key is the heavy hitter)
     unsigned long long h = sg_hash(v.x, v.y);
     if (h == kSgEmpty) h = 0;
     uint32_t sl = (uint32_t)(h >> 20) & (kSgHotTable - 1u);
@@ -571,7 +576,8 @@ __global__ __launch_bounds__(kSgBlock) void sg_hot_kernel(const unsigned long lo
     if (nc > kSgMaxHot) nc = kSgMaxHot;
     for (uint32_t a = 0; a < nc; a++) {
       const int64_t row = (int64_t)((__int128)hrow[cand[a]] * n / S);
-      hot_views[a * 2] = views[row * 2]; hot_views[a * 2 + 1] = views[row * 2 + 1];
+      const bool knull = (uint32_t)views[row * 2] == kStrviewNullLen;
+      hot_views[a * 2] = knull ? 15ull : views[row * 2]; hot_views[a * 2 + 1] = knull ? 0ull : views[row * 2 + 1];
     }
     res[0] = nc; res[1] = top; res[2] = n_distinct; res[3] = (unsigned int)S;
   }
@@ -588,7 +594,30 @@ __global__ void sg_hot_emit_kernel(uint32_t n_hot, const unsigned long long* __r
   out_views[(base + i) * 2] = hot_views[i * 2]; out_views[(base + i) * 2 + 1] = hot_views[i * 2 + 1];
   out_sum[base + i] = hot_acc[i * 3]; out_cnt[base + i] = (unsigned int)hot_acc[i * 3 + 1]; out_len[base + i] = (unsigned int)hot_acc[i * 3 + 2];
 }
+// the result's group views: the null key's group carries the view {15, 0} (length nibble 15) -> its bit of `valid` stays clear and its view becomes the empty string
+__global__ __launch_bounds__(kBlock) void sg_null_group_kernel(unsigned long long* __restrict__ gviews, int64_t G, unsigned long long* __restrict__ valid, unsigned int* __restrict__ n_null) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;                        // one 64-bit validity word per thread
+  if (w * 64 >= G) return;
+  unsigned long long bits = 0;
+  for (int b = 0; b < 64 && w * 64 + b < G; b++) {
+    const int64_t i = w * 64 + b;
+    if (gviews[i * 2] == 15ull && gviews[i * 2 + 1] == 0ull) { gviews[i * 2] = 0ull; atomicAdd(n_null, 1u); }
+    else bits |= 1ull << b;
+  }
+  valid[w] = bits;
+}
 }  // namespace
+
+// -> number of null-key groups (0 or 1) among the G group views strview_groupby returned; `valid` ([ceil(G / 64)] words) gets the groups' validity
+int64_t strview_null_group(uint64_t* gviews, int64_t G, uint64_t* valid) {
+  if (G <= 0) return 0;
+  Buf cnt = dev_alloc_zero(8);
+  hipLaunchKernelGGL(sg_null_group_kernel, dim3((unsigned)(((G + 63) / 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream(), (unsigned long long*)gviews, G, (unsigned long long*)valid, cnt->as<unsigned int>());
+  PLX_HIP(hipGetLastError());
+  uint32_t n = 0;
+  d2h_sync(&n, cnt->ptr, 4);
+  return (int64_t)n;
+}
 
 // views [n][2] / values [n] (8-byte, f64 when is_f64 else i64) / value validity (may be null) on the device.
 // Returns the number of groups and fills *out_views ([G][2]), *out_sum ([G] u64 bits), *out_cnt / *out_len ([G] u32); -1: not on the fast path (a string longer

@@ -280,11 +280,11 @@ void strview_dict_encode(const uint64_t* views, const uint64_t* validity, const 
 namespace {
 template <class OFF>
 __global__ __launch_bounds__(kBlock) void strviews_from_offsets_kernel(const OFF* __restrict__ offs, const unsigned char* __restrict__ data, unsigned long long data_base, long long data_len,
-                                                                       int64_t n, unsigned long long* __restrict__ views, const uint64_t* __restrict__ validity, int64_t row0, unsigned int* __restrict__ err) {
+                                                                       int64_t n, unsigned long long* __restrict__ views, const uint64_t* __restrict__ validity, int64_t row0, bool stamp_nulls, unsigned int* __restrict__ err) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const long long a = (long long)offs[i], e = (long long)offs[i + 1];
-    unsigned long long w0 = 0, w1 = 0;
     const bool ok = !validity || ((validity[(row0 + i) >> 6] >> ((row0 + i) & 63)) & 1);
+    unsigned long long w0 = !ok && stamp_nulls ? (unsigned long long)kStrviewNullLen : 0ull, w1 = 0;      // views handed out as they are carry their nulls as stamps
     if (a < 0 || e < a || e > data_len || e - a > 0x7fffffffll) { *err = 1u; }
     else if (ok) {
       const uint32_t len = (uint32_t)(e - a);
@@ -304,15 +304,51 @@ __global__ __launch_bounds__(kBlock) void strviews_from_offsets_kernel(const OFF
 }
 }  // namespace
 void strviews_from_offsets(const void* offsets, bool large, const uint8_t* data, uint64_t data_base, int64_t data_len, int64_t n, uint64_t* views_out, const uint64_t* validity, int64_t row0,
-                           unsigned int* err) {
+                           bool stamp_nulls, unsigned int* err) {
   if (n == 0) return;
   ProfileScope ps("strviews_from_offsets", (uint64_t)n * ((large ? 8 : 4) + 16), (uint64_t)n);
   const int grid = grid_for(n, kBlock * 4);
   if (large) hipLaunchKernelGGL((strviews_from_offsets_kernel<long long>), dim3(grid), dim3(kBlock), 0, stream(), (const long long*)offsets, (const unsigned char*)data, (unsigned long long)data_base,
-                                (long long)data_len, n, (unsigned long long*)views_out, validity, row0, err);
+                                (long long)data_len, n, (unsigned long long*)views_out, validity, row0, stamp_nulls, err);
   else hipLaunchKernelGGL((strviews_from_offsets_kernel<int>), dim3(grid), dim3(kBlock), 0, stream(), (const int*)offsets, (const unsigned char*)data, (unsigned long long)data_base,
-                          (long long)data_len, n, (unsigned long long*)views_out, validity, row0, err);
+                          (long long)data_len, n, (unsigned long long*)views_out, validity, row0, stamp_nulls, err);
   PLX_HIP(hipGetLastError());
+}
+
+// ---- nulls of a view column that travels WITHOUT a bitmap (the raw-view interfaces: plx_strview_groupby, plx_strview_dict_encode_device, plx_ipc_read_string_views) ----
+namespace {
+__global__ __launch_bounds__(kBlock) void strview_stamp_kernel(unsigned long long* __restrict__ views, const uint64_t* __restrict__ validity, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (!((validity[i >> 6] >> (i & 63)) & 1)) { views[i * 2] = (unsigned long long)kStrviewNullLen; views[i * 2 + 1] = 0ull; }
+}
+__global__ __launch_bounds__(kBlock) void strview_unstamp_kernel(const unsigned long long* __restrict__ views, int64_t n, unsigned long long* __restrict__ valid, unsigned long long* __restrict__ n_null) {
+  const int lane = lane_id();
+  const int64_t nwords = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  unsigned long long mine = 0;
+  for (int64_t w = wave; w < nwords; w += nwaves) {
+    const int64_t i = w * 64 + lane;
+    const bool ok = i < n && (uint32_t)views[i * 2] != kStrviewNullLen;
+    const uint64_t m = ballot(ok);
+    if (lane == 0) { valid[w] = m; const int64_t rows = n - w * 64 < 64 ? n - w * 64 : 64; mine += (unsigned long long)(rows - popc64(m)); }
+  }
+  if (lane == 0 && mine) atomicAdd(n_null, mine);
+}
+}  // namespace
+void strview_stamp_nulls(uint64_t* views, const uint64_t* validity, int64_t n) {
+  if (n <= 0 || !validity) return;
+  hipLaunchKernelGGL(strview_stamp_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, stream(), (unsigned long long*)views, validity, n);
+  PLX_HIP(hipGetLastError());
+}
+int64_t strview_validity_from_stamps(const uint64_t* views, int64_t n, uint64_t* valid) {
+  if (n <= 0) return 0;
+  Buf cnt = dev_alloc_zero(8);
+  ProfileScope ps("strview_nulls", (uint64_t)n * 8, (uint64_t)n);
+  hipLaunchKernelGGL(strview_unstamp_kernel, dim3(grid_for(n, kBlock * 2)), dim3(kBlock), 0, stream(), (const unsigned long long*)views, n, (unsigned long long*)valid, cnt->as<unsigned long long>());
+  PLX_HIP(hipGetLastError());
+  uint64_t c = 0;
+  d2h_sync(&c, cnt->ptr, 8);
+  return (int64_t)c;
 }
 
 // dictionary -> contiguous bytes + offsets[n + 1] on the device

@@ -158,13 +158,20 @@ class Series:
         return cls(name, _handle=codes.value, _dtype=T.Categorical(DeviceDictionary(d.value, binary=pa.types.is_binary_view(arr.type)), T.UInt32))
 
     @classmethod
-    def from_device_views(cls, name: str, views: "Series", data: "Optional[Series]" = None, *, encode: str = "eager") -> "Series":
+    def from_device_views(cls, name: str, views: "Series", data: "Optional[Series]" = None, *, validity: "Optional[Series]" = None, encode: str = "eager") -> "Series":
         """Utf8View column whose views already sit in HBM (a UInt64 Series of 2 n words; `data`: a UInt8 Series with the long
         strings' bytes, or None when every string is <= 12 bytes) -> dictionary column, encoded on the device.
+        validity: a Boolean Series of n rows (True = valid), the array's validity bitmap; its nulls are stamped into `views` IN PLACE
+        (plx_strview_stamp_nulls: a null entry is a view with the length word 0xFFFFFFFF) -- the raw-view operators carry no bitmap.
         encode="deferred": the column stays a column of views until an operator needs dictionary codes; group_by(<this column>).agg(sum /
         mean / count / len of one Float64 / Int64 column) then runs on the views themselves (plx_strview_groupby) and never encodes."""
         if encode not in ("eager", "deferred"):
             raise ValueError(f"encode must be 'eager' or 'deferred', not {encode!r}")
+        if validity is not None:
+            if len(validity) * 2 != len(views):
+                raise ValueError("validity must have one entry per view")
+            F.ensure_init()
+            F.check(F.lib().plx_strview_stamp_nulls(views._h, validity._h))
         if encode == "deferred":
             if len(views) % 2:
                 raise ValueError("views must hold 2 n UInt64 words")

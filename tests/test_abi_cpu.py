@@ -190,6 +190,12 @@ def test_string_key_group_by_entry_checks_its_arguments_before_it_needs_a_device
     assert lib.plx_strview_groupby(views, v32, *refs) == F.ERR_UNSUPPORTED and b"Float64 / Int64" in lib.plx_last_error()
     st = lib.plx_strview_groupby(views, v64, *refs)                                                     # well-formed: now it needs the device
     assert st != 0 and st != F.ERR_UNSUPPORTED and (b"HIP" in lib.plx_last_error() or b"placeholder" in lib.plx_last_error()), lib.plx_last_error()
+    # nulls of a raw view column: plx_strview_stamp_nulls takes the views and a Boolean column of the same length
+    vb, vb_short = ph(F.BOOL, 100), ph(F.BOOL, 99)
+    assert lib.plx_strview_stamp_nulls(odd, vb) == ERR_INVALID and b"2 n words" in lib.plx_last_error()
+    assert lib.plx_strview_stamp_nulls(views, v64) == ERR_INVALID and b"Boolean" in lib.plx_last_error()
+    assert lib.plx_strview_stamp_nulls(views, vb_short) == ERR_SHAPE and b"differ in length" in lib.plx_last_error()
+    assert lib.plx_strview_stamp_nulls(views, vb) == ERR_INVALID and b"placeholder" in lib.plx_last_error()
     # the IPC side: a Utf8 column, a dictionary-encoded one, a numeric one
     path = str(tmp_path / "t.arrow")
     t = pa.table({"s": pa.array(["a", "bb", "ccc"], pa.string()), "d": pa.array(["x", "y", "x"]).dictionary_encode(), "i": pa.array([1, 2, 3], pa.int64())})

@@ -222,7 +222,7 @@ def test_string_key_group_by_leaves_few_groups_to_the_usual_route(pl):
 
 def test_scan_ipc_string_key_group_by_on_views(pl, tmp_path):
     """scan_ipc(string_keys="deferred"): a Utf8 column comes out of the file as device-built views, group_by on it runs on the views; any other use of the
-    column, strings over 12 bytes and a key column with nulls take the encoded route -- same answers (against pandas)."""
+    column and strings over 12 bytes take the encoded route; a key column with nulls is handed out as stamped views -- same answers (against pandas)."""
     import pyarrow.feather  # noqa: F401
     import pyarrow.ipc as ipc
     rng = np.random.default_rng(31)
@@ -257,15 +257,90 @@ def test_scan_ipc_string_key_group_by_on_views(pl, tmp_path):
     assert "StringViewGroupBy" not in pl.last_plan()
     gl = _by_key(out, "long")
     assert gl["long"] == [k + "_and_some_more" for k in want.index] and np.allclose(gl["s"], want["sum"], rtol=1e-9, atol=1e-9)
-    # a key column with nulls is read dictionary-encoded as before (null is its own group)
+    # a key column with nulls comes out as stamped views (round 4): the operator runs on them, null is a group of its own
     out = lf.group_by("kn").agg(pl.len().alias("n"), pl.col("v").sum().alias("s")).collect()
-    assert "StringViewGroupBy" not in pl.last_plan()
+    assert "StringViewGroupBy" in pl.last_plan(), pl.last_plan()
     d = out.to_dict()
     wn = table.select(["kn", "v"]).to_pandas().groupby("kn", dropna=False)["v"].agg(["sum", "size"])
-    assert len(d["kn"]) == len(wn) and sum(d["n"]) == n
+    assert len(d["kn"]) == len(wn) and sum(d["n"]) == n and d["kn"].count(None) == 1
     i_null = d["kn"].index(None)
-    assert d["n"][i_null] == int(wn.loc[wn.index.isna(), "size"].iloc[0])
+    assert d["n"][i_null] == int(wn.loc[wn.index.isna(), "size"].iloc[0]) and abs(d["s"][i_null] - float(wn.loc[wn.index.isna(), "sum"].iloc[0])) < 1e-6
+    present = {kk: (m, s) for kk, m, s in zip(d["kn"], d["n"], d["s"]) if kk is not None}
+    assert all(present[kk][0] == int(r["size"]) and abs(present[kk][1] - float(r["sum"])) < 1e-6 for kk, r in wn[~wn.index.isna()].iterrows())
     # and the default scan is unchanged
     out = pl.scan_ipc(path).group_by("k").agg(pl.col("v").sum().alias("s")).collect()
     assert "StringViewGroupBy" not in pl.last_plan()
     assert np.allclose(_by_key(out)["s"], want["sum"], rtol=1e-9, atol=1e-9)
+
+
+def _views_and_validity(pl, strings):
+    """Host strings with None entries -> (UInt64 Series of 2 n view words as Arrow holds them: null slots carry whatever the builder left, Boolean validity Series)."""
+    arr = pa.array(strings, pa.string_view())
+    raw = np.frombuffer(arr.buffers()[1], dtype=np.uint64, count=2 * len(strings), offset=16 * arr.offset).copy()
+    valid = np.array([s is not None for s in strings])
+    raw[np.repeat(~valid, 2)] = np.uint64(0x0123456789abcdef)                     # garbage behind null slots must not matter
+    return pl.Series("views", raw, pl.UInt64), pl.Series("valid", valid, pl.Boolean)
+
+
+@pytest.mark.parametrize("null_share", [0.03, 0.6])
+def test_null_string_keys_form_one_group_of_their_own(pl, monkeypatch, null_share):
+    """Rows whose key is null are one group (key null), exactly as group_by on a nullable String column in the reference (hash_keys.rs:413-452: the validity is
+    part of the key); with most rows null the null key is the heavy hitter the scatter sums on the spot.  The empty string is a different key."""
+    monkeypatch.setenv("PLX_STRGROUP_FORCE", "1")
+    rng = np.random.default_rng(17)
+    words = ["", "a", "b", "ab", "abcdefghijkl", "twelve bytes", "0"] + ["w%05d" % i for i in range(5000)]
+    n = 400_003
+    idx = rng.integers(0, len(words), n)
+    strings = [words[i] for i in idx]
+    isnull = rng.random(n) < null_share
+    strings = [None if z else s for s, z in zip(strings, isnull)]
+    x = rng.integers(-10 ** 9, 10 ** 9, n)
+    vvalid = rng.random(n) > 0.1
+    views, valid = _views_and_validity(pl, strings)
+    k = pl.Series.from_device_views("k", views, validity=valid, encode="deferred")
+    v = pl.Series("v", x, pl.Int64, validity=vvalid)
+    out = pl.DataFrame([k, v]).lazy().group_by("k").agg(pl.col("v").sum(), pl.col("v").count().alias("c"), pl.len().alias("n")).collect()
+    assert "StringViewGroupBy" in pl.last_plan(), pl.last_plan()
+    d = out.to_dict()
+    assert d["k"].count(None) == 1 and out["k"].null_count() == 1
+    got = {kk: (s, c, m) for kk, s, c, m in zip(d["k"], d["v"], d["c"], d["n"])}
+    want = {}
+    for sk, xv, ok in zip(strings, x.tolist(), vvalid.tolist()):
+        e = want.setdefault(sk, [0, 0, 0])
+        e[2] += 1
+        if ok:
+            e[0] += xv; e[1] += 1
+    assert set(got) == set(want) and "" in got and None in got
+    assert all(tuple(want[kk]) == got[kk] for kk in want)
+    # the encode route reads the same stamps: null codes for the same rows, the same groups
+    k2 = pl.Series.from_device_views("k", views, encode="eager")                  # (views are already stamped)
+    assert k2.null_count() == int(isnull.sum())
+    out2 = pl.DataFrame([k2, v]).lazy().group_by("k").agg(pl.col("v").sum(), pl.col("v").count().alias("c"), pl.len().alias("n")).collect()
+    assert "StringViewGroupBy" not in pl.last_plan()
+    d2 = out2.to_dict()
+    assert {kk: (s, c, m) for kk, s, c, m in zip(d2["k"], d2["v"], d2["c"], d2["n"])} == got
+
+
+def test_ipc_string_column_with_nulls_is_handed_out_as_stamped_views(pl, tmp_path, monkeypatch):
+    """scan_ipc(string_keys="deferred") over a Utf8 column WITH nulls: the views come out stamped, the group-by runs on them and has the null group."""
+    import pyarrow.ipc as ipc
+    monkeypatch.setenv("PLX_STRGROUP_FORCE", "1")
+    rng = np.random.default_rng(23)
+    n = 200_000
+    keys = np.array(["k%04d" % i for i in range(3000)])[rng.integers(0, 3000, n)].astype(object)
+    keys[rng.random(n) < 0.07] = None
+    v = rng.random(n)
+    t = pa.table({"k": pa.array(keys.tolist(), pa.string()), "v": pa.array(v)})
+    path = str(tmp_path / "nulls.arrow")
+    with ipc.new_file(path, t.schema) as w:
+        for b in t.to_batches(max_chunksize=1 << 16):
+            w.write_batch(b)
+    out = pl.scan_ipc(path, string_keys="deferred").group_by("k").agg(pl.col("v").sum().alias("s"), pl.len().alias("n")).collect()
+    assert "StringViewGroupBy" in pl.last_plan(), pl.last_plan()
+    d = out.to_dict()
+    import pandas as pd
+    ref = pd.DataFrame({"k": keys, "v": v}).groupby("k", dropna=False).agg(s=("v", "sum"), n=("v", "size"))
+    want = {(None if (isinstance(kk, float) and np.isnan(kk)) or kk is None else kk): (float(r.s), int(r.n)) for kk, r in ref.iterrows()}
+    assert set(d["k"]) == set(want) and None in want
+    for kk, s, m in zip(d["k"], d["s"], d["n"]):
+        assert m == want[kk][1] and abs(s - want[kk][0]) <= 1e-9 * max(1.0, abs(want[kk][0]))
