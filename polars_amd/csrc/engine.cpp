@@ -579,12 +579,14 @@ struct KeyPlan {
   bool wide_nullable = false;
   std::vector<int> wide_nodes;
   int total_bits = 64;
+  std::string note;      // what the planner did to get the key's range, for the plan description
 };
 
 static int ceil_log2_u64(uint64_t x) { int b = 0; while (b < 64 && (1ull << b) < x) b++; return b; }
 
 // Lowers the group keys into one 64-bit key node. Narrow / multi-column keys are packed
 // using column min/max statistics; a single wide key is used raw.
+static bool learn_dense_ranges() { const char* e = getenv("PLX_LEARN_DENSE_RANGE"); return !(e && e[0] == '0'); }   // (measurement / tests: 0 = the first run plans without a range pass)
 static KeyPlan lower_keys(Compiler& c, const std::vector<int>& key_exprs) {
   KeyPlan kp;
   const Plan& plan = c.plan;
@@ -604,7 +606,15 @@ static KeyPlan lower_keys(Compiler& c, const std::vector<int>& key_exprs) {
     if (part.dtype == PLX_BOOL) { info[i].have_range = true; info[i].mn = 0; info[i].mx = 1; }
     else if (dtype_is_int(part.dtype) && x->kind == PLX_AE_COLUMN) {
       ColumnPtr col = c.df->cols[c.df->find(x->name)];
-      const bool cheap = dtype_width(part.dtype) <= 2 || nk > 1 || col->range_state != 0;
+      bool cheap = dtype_width(part.dtype) <= 2 || nk > 1 || col->range_state != 0;
+      // A single wide key whose range nobody has looked at yet: the range pass over it costs 8 B / row (1.5 ms per 1e9 rows) -- worth it exactly when the keys are
+      // dense ids, which then take the direct-address tables at once instead of hash partitions on this run and direct ones on the next (1e9 rows over 1e6 dense ids:
+      // first run 10.2 -> 7 ms; zipf-distributed ones, whose sample undercounts the groups and overflowed the hash tables once: 22.8 -> 9 ms).  A sample of 65536
+      // rows says whether they LOOK dense (sparse 64-bit keys span far more than 2^26 in any sample: no pass for them).
+      if (!cheap && part.dtype != PLX_U64 && col->values && col->len >= ((int64_t)1 << 24) && learn_dense_ranges()) {
+        int64_t smn = 0, smx = 0;
+        if (k::sample_minmax(col, &smn, &smx) && (unsigned __int128)((__int128)smx - (__int128)smn) < ((unsigned __int128)1 << 26)) { cheap = true; kp.note += "KeyRange{" + std::string(x->name) + ": sample looks dense -> range pass}; "; }
+      }
       if (part.dtype == PLX_U64) all_packable = false;
       else if (cheap) {
         if (col->values && ops::int_range(col, &info[i].mn, &info[i].mx)) info[i].have_range = true;
@@ -1247,7 +1257,7 @@ static bool fused_groupby(Plan& plan, const IRN& node, const std::vector<int>& p
   FusedAggResult r;
   std::string d;
   run_fused_groupby(c, kp, len_idx, r, d);
-  plan.desc += "FusedFilterGroupBy{" + d + ", inputs=" + std::to_string(c.shape.n_inputs) + ", ops=" + std::to_string(c.shape.n_ops) + ", aggs=" + std::to_string(c.shape.n_aggs) + ", groups=" + std::to_string(r.n_groups) + "}; ";
+  plan.desc += kp.note + "FusedFilterGroupBy{" + d + ", inputs=" + std::to_string(c.shape.n_inputs) + ", ops=" + std::to_string(c.shape.n_ops) + ", aggs=" + std::to_string(c.shape.n_aggs) + ", groups=" + std::to_string(r.n_groups) + "}; ";
   out = std::make_shared<Frame>();
   out->height = r.n_groups;
   FinBatch batch{};

@@ -91,6 +91,8 @@ bool partitioned_probe_hits(const fused::Shape& sh, const fused::Args& args, con
 bool partitioned_hash_probe_hits(const fused::Shape& sh, const fused::Args& args, const fused::JoinAggTable& ht, uint64_t n_build, int static_id, ColumnPtr* hits, std::string* desc);
 // fraction of adjacent pairs (strided sample) of an integer column that are non-decreasing: 1.0 = sorted ascending
 double sample_sortedness(const ColumnPtr& c);
+// smallest / largest valid value among 65536 rows (64 evenly spaced runs); false: no valid value in the sample / not an integer column
+bool sample_minmax(const ColumnPtr& c, int64_t* mn, int64_t* mx);
 // all jobs of a batch (key decodes + aggregate finalisations) in one launch
 void finalize_batch(const uint64_t* acc, int n_aggs, int64_t G, const fused::FinBatch& b);
 // packed group keys -> one key column

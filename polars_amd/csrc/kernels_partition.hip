@@ -909,5 +909,46 @@ double sample_sortedness(const ColumnPtr& c) {
   return h[0] ? (double)h[1] / (double)h[0] : 1.0;
 }
 
+// ---- smallest / largest valid value over 64 evenly spaced runs of 1024 rows: does an integer key column LOOK dense? --------------------------------------
+__global__ __launch_bounds__(kBlock) void sample_minmax_kernel(const void* __restrict__ values, const uint64_t* __restrict__ validity, int width, int is_signed, int64_t n, int64_t run, int64_t stride,
+                                                               long long* __restrict__ out /* [2]: min, max */) {
+  long long lo = 0x7fffffffffffffffll, hi = (long long)0x8000000000000000ull;
+  const int64_t base = (int64_t)blockIdx.x * stride;
+  for (int64_t i = threadIdx.x; i < run && base + i < n; i += blockDim.x) {
+    const int64_t j = base + i;
+    if (validity && !((validity[j >> 6] >> (j & 63)) & 1)) continue;
+    long long a;
+    switch (width) {
+      case 1: a = is_signed ? (long long)((const signed char*)values)[j] : (long long)((const unsigned char*)values)[j]; break;
+      case 2: a = is_signed ? (long long)((const short*)values)[j] : (long long)((const unsigned short*)values)[j]; break;
+      case 4: a = is_signed ? (long long)((const int*)values)[j] : (long long)((const unsigned int*)values)[j]; break;
+      default: a = ((const long long*)values)[j]; break;
+    }
+    lo = a < lo ? a : lo; hi = a > hi ? a : hi;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const long long a = (long long)shfl_xor_u64((uint64_t)lo, m), b = (long long)shfl_xor_u64((uint64_t)hi, m);
+    lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+  }
+  if (lane_id() == 0 && lo <= hi) { atomicMin(out, lo); atomicMax(out + 1, hi); }
+}
+bool sample_minmax(const ColumnPtr& c, int64_t* mn, int64_t* mx) {
+  if (!c || !dtype_is_int(c->dtype) || c->dtype == PLX_U64 || c->len < 1 || !c->values) return false;
+  const int64_t n = c->len, run = 1024;
+  const int blocks = (int)std::min<int64_t>(64, (n + run - 1) / run);
+  const int64_t stride = blocks > 1 ? (n - run) / (blocks - 1) : 0;
+  Buf out = dev_alloc(16);
+  const long long init[2] = {0x7fffffffffffffffll, (long long)0x8000000000000000ull};
+  h2d_async(out->ptr, init, 16);
+  hipLaunchKernelGGL(sample_minmax_kernel, dim3(blocks), dim3(kBlock), 0, stream(), c->data(), c->valid_words(), dtype_width(c->dtype), dtype_is_signed(c->dtype) ? 1 : 0, n, run, stride, out->as<long long>());
+  PLX_HIP(hipGetLastError());
+  long long h[2] = {0, 0};
+  d2h_sync(h, out->ptr, 16);
+  if (h[0] > h[1]) return false;
+  *mn = h[0]; *mx = h[1];
+  return true;
+}
+
 }  // namespace k
 }  // namespace plx

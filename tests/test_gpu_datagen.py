@@ -57,10 +57,12 @@ def test_zipf_device_generator_equals_host_twin(pl):
     assert np.array_equal(s.to_numpy(), datagen.zipf_native_host_mt(0, n, 17, 0, 1_000_000))
 
 
-def test_dropped_statistics_change_the_plan_not_the_result(pl):
+def test_dropped_statistics_change_the_plan_not_the_result(pl, monkeypatch):
     """plx_column_drop_statistics (bench.py one_shot_ms): a group-by on a raw Int64 key learns the key range on its first run and plans dense ids on the
-    second; after the drop it plans like the first run again -- and gives the same groups every time."""
+    second; after the drop it plans like the first run again -- and gives the same groups every time.  (PLX_LEARN_DENSE_RANGE=0: without the range pass that
+    the planner now runs up front for keys whose sample looks dense -- the next test.)"""
     import re
+    monkeypatch.setenv("PLX_LEARN_DENSE_RANGE", "0")
     from polars_amd import queries
     rng = np.random.default_rng(5)
     n = 17_000_000
@@ -77,6 +79,33 @@ def test_dropped_statistics_change_the_plan_not_the_result(pl):
     assert re.search(r"partitioned\(v3,direct", plans[1]), plans[1]
     assert "hash" in plans[2] and "direct" not in plans[2], plans[2]
     assert outs[0] == outs[1] == outs[2]
+
+
+def test_dense_looking_keys_get_their_range_before_the_first_run(pl):
+    """A single Int64 key nobody has statistics for, >= 2^24 rows: a 65536-row sample says whether the keys LOOK dense; if so the exact range pass (8 B / row)
+    runs before planning and the FIRST run already takes direct-address partitions; sparse 64-bit keys get no pass and take hash partitions as before."""
+    import re
+    from polars_amd import queries
+    rng = np.random.default_rng(6)
+    n = 17_000_000
+    ids = rng.integers(0, 300_000, n)
+    v = rng.integers(0, 1000, n).astype(np.int64)
+    want_n = np.bincount(ids, minlength=300_000)
+    want_s = np.bincount(ids, v, minlength=300_000).astype(np.int64)
+    for name, key, unmap in (("dense", (ids + 1000).astype(np.int64), lambda k: k - 1000), ("sparse", ids.astype(np.int64) * 1_000_003 - 10 ** 12, lambda k: (k + 10 ** 12) // 1_000_003)):
+        df = pl.DataFrame({"key": key, "v": v})
+        out = queries.cfg3(df.lazy()).collect().sort_host("key")
+        plan = pl.last_plan()
+        if name == "dense":
+            assert "KeyRange{key: sample looks dense" in plan and re.search(r"partitioned\(v3,direct", plan), plan
+        else:
+            assert "KeyRange{" not in plan and re.search(r"partitioned\(v3,hash", plan), plan
+        k = unmap(np.array(out["key"], dtype=np.int64))                       # (sort_host: a dict of lists)
+        agg_cols = [c for c in out if c != "key"]
+        present = np.nonzero(want_n)[0]
+        assert np.array_equal(k, present), name
+        got = {c: np.array(out[c], dtype=np.int64) for c in agg_cols}
+        assert any(np.array_equal(g, want_s[present]) for g in got.values()) and any(np.array_equal(g, want_n[present]) for g in got.values()), (name, agg_cols)
 
 
 def test_customer_generator_matches_host_twin(pl):

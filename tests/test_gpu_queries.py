@@ -562,11 +562,12 @@ def test_partitioned_groupby_skewed_keys(pl, case):
 
 
 @pytest.mark.parametrize("seed", [10, 20, 31])
-def test_partitioned_v2_is_planned_for_1e6_uniform_keys_whatever_the_sample_says(pl, seed):
+def test_partitioned_v2_is_planned_for_1e6_uniform_keys_whatever_the_sample_says(pl, seed, monkeypatch):
     """BASELINE config 3's shape (1e6 uniform keys) sits exactly on the 512-partition capacity of the LDS hash tables (1.3 x estimate vs
     512 x 4096 x 0.62): whether the 2^20-row sample estimates 0.999e6 or 1.001e6 groups must not decide which generation of kernels
     runs (seed 20 estimated just above and fell back to the round-1 three-pass kernels: 18.7 instead of 9.7 ms at 1e9 rows)."""
     from polars_amd import datagen
+    monkeypatch.setenv("PLX_LEARN_DENSE_RANGE", "0")        # (the hash-mode plan of a first run WITHOUT the up-front range pass that dense-looking keys now get: tests/test_gpu_datagen.py)
     n = 1 << 25
     key = datagen.uniform_native(pl, "key", pl.Int64, n, seed, 0, 0, 1_000_000)
     val = datagen.uniform_native(pl, "val", pl.Int64, n, seed, 1, 0, 1000)
