@@ -764,6 +764,7 @@ static bool probe_hits_impl(const Shape& sh, const Args& args, const DirectJoinT
   PartPlan2 pp{};
   pp.mode = kP2Direct; pp.gen = 3; pp.pack = kPackRowid; pp.n_hot = 0; pp.hot_copies = 1; pp.len_idx = 0; pp.oob_drop = 1; pp.key_base = hashed ? 0 : dt.kmin;
   pp.hash_bits = hashed ? kHashBits : 0u;
+  pp.ablate = kEnvP2Ablate > 0 ? ((uint32_t)kEnvP2Ablate & 3u) : 0u;      // measurement only (the records are garbage: no partition keeps any of them, the join finds nothing)
   pp.log2_parts = std::min<uint32_t>(8, bits_total - 9);                       // 256 partitions (the scatter's best geometry: 8192-row tiles), slices of >= 2^9 keys
   if (pp.log2_parts < 6) return false;
   pp.key_shift = bits_total - pp.log2_parts;
@@ -821,6 +822,7 @@ static bool probe_hits_impl(const Shape& sh, const Args& args, const DirectJoinT
       PLX_REQUIRE(jit::launch_raw(sh, jk, ka, (int)pp.scatter_grid, (int)pp.block, slds), PLX_ERR_HIP, "jit launch failed (probe scatter)");
     }
   }
+  if (pp.ablate) PLX_HIP(hipMemsetAsync(chunk_fill->ptr, 0, sizeof(uint32_t) * (size_t)n_chunks, stream()));
   Buf counts = dev_alloc_zero(sizeof(uint32_t) * (NP + 1)), cursor = dev_alloc_zero(sizeof(uint32_t) * (NP + 1));
   Buf cl_off = dev_alloc(sizeof(uint64_t) * (NP + 2)), cl_ids = dev_alloc(sizeof(uint32_t) * (size_t)n_chunks);
   {

@@ -344,3 +344,26 @@ def test_ipc_string_column_with_nulls_is_handed_out_as_stamped_views(pl, tmp_pat
     assert set(d["k"]) == set(want) and None in want
     for kk, s, m in zip(d["k"], d["s"], d["n"]):
         assert m == want[kk][1] and abs(s - want[kk][0]) <= 1e-9 * max(1.0, abs(want[kk][0]))
+
+
+def test_reference_vector_null_string_key_group(pl, monkeypatch):
+    """py-polars/tests/unit/operations/test_group_by.py:948-1000 (test_perfect_hash_table_null_values): 101 string keys, three of them null, 40 groups in order of
+    first appearance with the null group in 28th place holding [None, None, None].  Here: the same keys as stamped views through the string-key operator (forced:
+    40 groups are far below its planning threshold) -- the same 40 groups, the same sizes, one null group of three rows."""
+    monkeypatch.setenv("PLX_STRGROUP_FORCE", "1")
+    # fmt: off
+    values = ["3", "41", "17", "5", "26", "27", "43", "45", "41", "13", "45", "48", "17", "22", "31", "25", "28", "13", "7", "26", "17", "4", "43", "47", "30", "28", "8", "27", "6", "7", "26", "11", "37", "29", "49", "20", "29", "28", "23", "9", None, "38", "19", "7", "38", "3", "30", "37", "41", "5", "16", "26", "31", "6", "25", "11", "17", "31", "31", "20", "26", None, "39", "10", "38", "4", "39", "15", "13", "35", "38", "11", "39", "11", "48", "36", "18", "11", "34", "16", "28", "9", "37", "8", "17", "48", "44", "28", "25", "30", "37", "30", "18", "12", None, "27", "10", "3", "16", "27", "6"]
+    groups = ["3", "41", "17", "5", "26", "27", "43", "45", "13", "48", "22", "31", "25", "28", "7", "4", "47", "30", "8", "6", "11", "37", "29", "49", "20", "23", "9", None, "38", "19", "16", "39", "10", "15", "35", "36", "18", "34", "44", "12"]
+    # fmt: on
+    sizes = {"3": 3, "41": 3, "17": 5, "5": 2, "26": 5, "27": 4, "43": 2, "45": 2, "13": 3, "48": 3, "22": 1, "31": 4, "25": 3, "28": 5, "7": 3, "4": 2, "47": 1, "30": 4, "8": 2, "6": 3,
+             "11": 5, "37": 4, "29": 2, "49": 1, "20": 2, "23": 1, "9": 2, None: 3, "38": 4, "19": 1}          # the first thirty of the reference's agg_values, by length
+    views, valid = _views_and_validity(pl, values)
+    k = pl.Series.from_device_views("a", views, validity=valid, encode="deferred")
+    ones = pl.Series("one", np.ones(len(values), dtype=np.int64), pl.Int64)
+    out = pl.DataFrame([k, ones]).lazy().group_by("a").agg(pl.col("one").sum().alias("n"), pl.len().alias("len")).collect()
+    assert "StringViewGroupBy" in pl.last_plan(), pl.last_plan()
+    d = out.to_dict()
+    got = dict(zip(d["a"], d["n"]))
+    assert set(got) == set(groups) and len(d["a"]) == 40 and got[None] == 3 and d["n"] == d["len"]
+    assert all(got[g] == c for g, c in sizes.items())
+    assert all(got[g] == sum(1 for v in values if v == g) for g in groups)
