@@ -682,6 +682,14 @@ def timed(pl, wl: Workload, steps: int, warmup: int, distributed: bool, combine=
     F = pl._ffi
     res = None
     cold_ms = None
+    # The harness process must not garbage-collect inside the timed region (what timeit does too): with torch / numpy / pyarrow loaded
+    # a generation-2 collection walks a few million objects, ~40 ms, and its allocation-count trigger put it on timed step 4 of the
+    # headline every single run (step_ms showed 4.3, 4.3, 4.3, 40, 4.5, 4.3 ... = 6.1 ms/step "measured" for a 4.3 ms step).  Collected
+    # BEFORE the warm-up steps: a 40 ms pause between warm-up and timed region lets the device drop its clocks, and the first timed step of
+    # every series then ran 5-10 % slow (3.80, 3.52, 3.55 ...).
+    import gc
+    gc.collect()
+    gc.disable()
     for i in range(warmup):
         if i == 0 and not getattr(wl, "_ran", False):
             torch.cuda.synchronize(); F.check(F.lib().plx_synchronize())
@@ -699,12 +707,6 @@ def timed(pl, wl: Workload, steps: int, warmup: int, distributed: bool, combine=
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(); F.check(F.lib().plx_synchronize())
-    # The harness process must not garbage-collect inside the timed region (what timeit does too): with torch / numpy / pyarrow loaded
-    # a generation-2 collection walks a few million objects, ~40 ms, and its allocation-count trigger put it on timed step 4 of the
-    # headline every single run (step_ms showed 4.3, 4.3, 4.3, 40, 4.5, 4.3 ... = 6.1 ms/step "measured" for a 4.3 ms step).
-    import gc
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     marks = [t0]
     for _ in range(steps):
@@ -1589,11 +1591,11 @@ def timed_multi(ctx, step, steps: int, warmup: int):
     MAX over the ranks.  -> (seconds, per-kernel stats of this rank, result of the last step, per-step ms of this rank)"""
     import gc
     res = None
+    gc.collect(); gc.disable()          # see timed(): the harness must not collect inside the timed region, nor pause between warm-up and timed steps
     for _ in range(max(warmup, 1)):
         res = step()
     ctx.profile_start()
     ctx.barrier(); ctx.sync()
-    gc.collect(); gc.disable()          # see timed(): the harness must not collect inside the timed region
     t0 = time.perf_counter()
     marks = [t0]
     for _ in range(steps):
