@@ -288,6 +288,8 @@ class Compiler {
   int konst_f(double d) { uint64_t b; memcpy(&b, &d, 8); return konst(b, 'f'); }
   int ifnull(int a, uint64_t code) { DNode n; n.code = OP_IFNULL; n.a = a; n.b = a; n.imm = code; n.ty = nodes[a].ty; n.nullable = false; return add(n); }
   // membership of integer node `a` in lookup bitmap `lut` (args.lut[lut] is filled in by the caller before the launch)
+  // node `a` with its validity cut down to the rows where boolean node `m` is valid and true (OP_MASKV)
+  int mask_valid(int a, int m) { DNode n; n.code = OP_MASKV; n.a = a; n.b = m; n.ty = nodes[a].ty; n.nullable = true; return add(n); }
   int bit_lookup(int a, int lut, int64_t kmin) { DNode n; n.code = OP_BITLOOKUP; n.a = a; n.b = a; n.c = (uint8_t)lut; n.imm = (uint64_t)kmin; n.ty = 'b'; n.nullable = nodes[a].nullable; return add(n); }
   int col_id(const ColumnPtr& c) {
     for (size_t i = 0; i < cols.size(); i++) if (cols[i].get() == c.get()) return (int)i;
@@ -1448,7 +1450,9 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       for (size_t i = 0; i < semis.size(); i++) {
         int64_t mn = 0, mx = 0;
         if (!semi_key_range(semis[i], &mn, &mx)) mn = mx = 0;      // empty filter side: the bitmap is empty, nothing matches
-        const int n = c.bit_lookup(c.load(semis[i].pkey), lut0 + (int)i, mn);
+        // (rows the cheaper conjuncts already rejected do not look the bitmap up: OP_MASKV; the conjunction is the same either way)
+        const int kn = c.load(semis[i].pkey);
+        const int n = c.bit_lookup(p < 0 ? kn : c.mask_valid(kn, p), lut0 + (int)i, mn);
         p = p < 0 ? n : c.mk(OP_AND, p, n, 'b');
       }
       return p;

@@ -53,7 +53,11 @@ enum OpCode : uint8_t {
   OP_FDIV_I, OP_MOD_I, OP_FDIV_U, OP_MOD_U,
   // dst <- bit (a - imm[pc]) of lookup bitmap args.lut[c] (0 outside [0, range)); validity of a.  The membership test of a
   // semi-join whose filter side was reduced to a bitmap over its (dense) key range.
-  OP_BITLOOKUP
+  OP_BITLOOKUP,
+  // dst <- a, valid only in rows where b is valid and true.  In front of a bitmap lookup it takes the rows an earlier, cheaper conjunct of the predicate already
+  // rejected out of the lookup: an invalid lane issues no load (a random lookup moves a whole line from the L2 to the CU: TPC-H Q3's orders scan with the customer
+  // filter was bound by those lines, not by HBM)
+  OP_MASKV
 };
 
 struct Op {
@@ -132,6 +136,11 @@ PLX_HD constexpr ProgramSplit split_program(const Shape& s) {
   }
   if (!ok) early = all;
   return ProgramSplit{early, (early & all) != all};
+}
+
+PLX_HD constexpr bool shape_has_op(const Shape& s, uint8_t code) {
+  for (int pc = 0; pc < s.n_ops; pc++) if (s.ops[pc].code == code) return true;
+  return false;
 }
 
 struct Input {

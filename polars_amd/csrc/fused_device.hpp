@@ -315,6 +315,12 @@ __device__ __forceinline__ void exec_op(const Op op, const Shape& sh, const Args
         }
         vd = va;
       } break;
+      case OP_MASKV: {
+        uint32_t tb = 0;
+#pragma unroll
+        for (int r = 0; r < kRows; r++) { d[r] = a[r]; tb |= (uint32_t)(b[r] & 1) << r; }
+        vd = va & vb & tb;
+      } break;
       default:  // OP_MOV / OP_NOP
 #pragma unroll
         for (int r = 0; r < kRows; r++) d[r] = a[r];

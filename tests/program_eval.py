@@ -9,7 +9,7 @@ emitted against the oracle without a GPU.  Opcodes / kinds mirror polars_amd/csr
 import numpy as np
 
 (OP_NOP, OP_LOAD, OP_CONST, OP_ADD_F, OP_SUB_F, OP_MUL_F, OP_DIV_F, OP_ADD_I, OP_SUB_I, OP_MUL_I, OP_I2F, OP_U2F, OP_CMP_I, OP_CMP_U, OP_CMP_F,
- OP_AND, OP_OR, OP_XOR, OP_NOT, OP_IFNULL, OP_MOV, OP_CANON_F, OP_FDIV_I, OP_MOD_I, OP_FDIV_U, OP_MOD_U, OP_BITLOOKUP) = range(27)
+ OP_AND, OP_OR, OP_XOR, OP_NOT, OP_IFNULL, OP_MOV, OP_CANON_F, OP_FDIV_I, OP_MOD_I, OP_FDIV_U, OP_MOD_U, OP_BITLOOKUP, OP_MASKV) = range(28)
 (AGG_NONE, AGG_SUM_F, AGG_SUM_I, AGG_COUNT, AGG_COUNT_ORD, AGG_LEN, AGG_MIN_F, AGG_MAX_F, AGG_MIN_I, AGG_MAX_I, AGG_MIN_U, AGG_MAX_U, AGG_FIRST_ROW) = range(13)
 FIN_COPY64, FIN_TRUNC32, FIN_MEAN, FIN_MINMAX_I, FIN_MINMAX_F, FIN_NARROW = range(6)
 # plx_dtype (include/polars_amd.h)
@@ -154,6 +154,7 @@ def run_rows(prog, cols, luts=None, split=False):
                     d = np.zeros(n, np.uint64)
                     d[inside] = bits[idx[inside].astype(np.int64)].astype(np.uint64)
                     vd = vx
+                elif code == OP_MASKV: d, vd = x, vx & vy & (y & U(1)).astype(bool)
                 elif code in (OP_MOV, OP_NOP): d, vd = x, vx
                 else:
                     raise NotImplementedError(f"opcode {code}")
