@@ -729,6 +729,17 @@ def timed(pl, wl: Workload, steps: int, warmup: int, distributed: bool, combine=
     return dt, stats, res, cold_ms
 
 
+def release_memory(pl) -> None:
+    """Between two secondary workloads: the library's pool and torch's cache go back to the driver, which unmaps tens of gigabytes in the
+    background for a while after the calls return -- kernels that run meanwhile are slowed and the odd one stalls for milliseconds (the
+    three-table Q3, whose small inputs are generated in 0.1 s, showed one 14 ms step in every full run and none on its own).  So: wait."""
+    import torch
+    pl._ffi.lib().plx_memory_trim()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    time.sleep(0.4)
+
+
 def step_spread(step_ms, rows_per_step: int) -> dict:
     """BASELINE.md 2.3 reports min / median / max of the timed steps; `value` / `ms_per_step` stay the K-step mean the driver's contract
     defines (total rows / the bracketed wall time), the median-based rate is given beside them."""
@@ -2001,7 +2012,7 @@ def run(args, emit):
                 extras[vname] = {"error": f"{type(e).__name__}: {e}"[:300]}
             emit(line)
         del wl, res
-        torch.cuda.empty_cache()
+        release_memory(pl)
         for name in [w for w in EXTRA_WORKLOADS if w != args.workload]:
             try:
                 w2 = make_workload(pl, name, int(os.environ.get("PLX_BENCH_EXTRAS_ROWS", "0")), seed=20)
@@ -2019,8 +2030,7 @@ def run(args, emit):
                 del w2, r2
             except Exception as e:  # a secondary workload must never take the headline line down
                 extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            pl._ffi.lib().plx_memory_trim()
-            torch.cuda.empty_cache()
+            release_memory(pl)
             emit(line)
         # Q3 on SHUFFLED inputs (round-1 review, item 6): the headline Q3 runs on dbgen row order, where an order's lines are adjacent and the
         # probe's late materialisation skips whole cache lines; shuffled rows are the adversarial case for both.  Torch generators (the
@@ -2048,8 +2058,7 @@ def run(args, emit):
                     os.environ.pop("PLX_Q3_SHUFFLED", None)
                 else:
                     os.environ["PLX_Q3_SHUFFLED"] = prev
-            pl._ffi.lib().plx_memory_trim()
-            torch.cuda.empty_cache()
+            release_memory(pl)
             emit(line)
         if os.environ.get("PLX_BENCH_E2E", "1") != "0":
             try:
