@@ -709,11 +709,14 @@ def timed(pl, wl: Workload, steps: int, warmup: int, distributed: bool, combine=
     torch.cuda.synchronize(); F.check(F.lib().plx_synchronize())
     t0 = time.perf_counter()
     marks = [t0]
+    trace = os.environ.get("PLX_BENCH_STEP_TRACE") == "1"          # measurement: a line per timed step on stderr (next to PLX_POOL_TRACE's)
     for _ in range(steps):
         res, _keep = wl.step()
         if combine:
             res = combine(res)
         marks.append(time.perf_counter())      # host-side return times (a step ends with its result download, so these are real step times)
+        if trace:
+            print(f"STEP {wl.name} {len(marks) - 1}: {(marks[-1] - marks[-2]) * 1e3:.3f} ms", file=sys.stderr, flush=True)
     torch.cuda.synchronize(); F.check(F.lib().plx_synchronize())
     timed.last_step_ms = [round((b - a) * 1e3, 3) for a, b in zip(marks, marks[1:])]
     if distributed:
@@ -2013,7 +2016,8 @@ def run(args, emit):
             emit(line)
         del wl, res
         release_memory(pl)
-        for name in [w for w in EXTRA_WORKLOADS if w != args.workload]:
+        only = [w for w in os.environ.get("PLX_BENCH_EXTRAS", "").split(",") if w]          # measurement: only these secondary workloads
+        for name in [w for w in EXTRA_WORKLOADS if w != args.workload and (not only or w in only)]:
             try:
                 w2 = make_workload(pl, name, int(os.environ.get("PLX_BENCH_EXTRAS_ROWS", "0")), seed=20)
                 d2, s2, r2, c2 = timed(pl, w2, k2, 2, False)       # two warm-up steps: config 3's second run is the first with learned key statistics (new buffer sizes)

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -130,7 +131,10 @@ static Buf dev_alloc_impl(size_t bytes, bool transient) {
   if (reused.ev) (void)hipEventDestroy(reused.ev);
   if (over) pool_trim();
   if (!p) {
+    static const bool trace = getenv("PLX_POOL_TRACE") && getenv("PLX_POOL_TRACE")[0] == '1';      // measurement: every mapping of fresh memory, with its cost
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, cap);
+    if (trace) fprintf(stderr, "[plx pool] hipMalloc %.1f MB%s: %.2f ms\n", cap / 1048576.0, transient ? " (transient)" : "", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e != hipSuccess) {
       pool_trim();
       e = hipMalloc(&p, cap);
