@@ -108,6 +108,24 @@ C.append(dict(id="join_null_keys_never_match", kind="join", how="inner", source=
               right={"a": [1, 1, None, 2], "b": [6, 7, 8, 9]}, right_dtypes={"a": "i64", "b": "i64"},
               on="a", expect={"a": [2, 1, 1, 1, 1], "b": [9, 6, 7, 6, 7]}))
 
+C.append(dict(id="left_join_dup_keys_strings_as_codes", kind="join", how="left", source="py-polars/tests/unit/operations/test_join.py:251-256",
+              left={"a": ["a", "b", "a", "z"], "b": [1, 2, 3, 4], "c": [6, 5, 4, 3]}, left_dtypes={"a": "str", "b": "i64", "c": "i64"},
+              right={"a": ["b", "c", "b", "a"], "k": [0, 3, 9, 6], "c": [1, 0, 2, 1]}, right_dtypes={"a": "str", "k": "i64", "c": "i64"},
+              on="a", expect_column_sorted_by_key={"b": [1, 3, 2, 2, 4]}, expect_null_count={"c_right": 1}))
+C.append(dict(id="left_join_keeps_every_left_row_nulls_included", kind="join", how="left", source="py-polars/tests/unit/operations/test_join.py:1316-1345",
+              left={"a": [None, 2, 1, 1, 5]}, left_dtypes={"a": "i64"},
+              right={"a": [1, None, 2, 6], "b": [6, 7, 8, 9]}, right_dtypes={"a": "i64", "b": "i64"},
+              on="a", expect={"a": [None, 2, 1, 1, 5]}))
+C.append(dict(id="left_join_three_keys_chunks_alignment_4720", kind="join", how="left", source="py-polars/tests/unit/operations/test_join.py:346-400",
+              left={"index1": [0, 0, 1, 1], "index2": [10, 10, 11, 11], "index3": [100, 101, 100, 101]}, left_dtypes={"index1": "i64", "index2": "i64", "index3": "i64"},
+              right={"index1": [0, 1], "index2": [10, 11], "index3": [100, 101]}, right_dtypes={"index1": "i64", "index2": "i64", "index3": "i64"},
+              on=["index1", "index2", "index3"], expect={"index1": [0, 0, 1, 1], "index2": [10, 10, 11, 11], "index3": [100, 101, 100, 101]},
+              note="the left side is the reference's df1 x df2 cross join, written out"))
+_J4 = [None if a % 6 == 0 else a for a in range(138)]
+C.append(dict(id="inner_join_four_keys_with_validity", kind="join", how="inner", source="py-polars/tests/unit/operations/test_join.py:980-1001",
+              left={c: _J4 for c in "abcd"}, left_dtypes={c: "i64" for c in "abcd"}, right={c: _J4 for c in "abcd"}, right_dtypes={c: "i64" for c in "abcd"},
+              on=["a", "b", "c", "d"], expect_rows=115, note="nulls_equal=False (the default): the 23 rows whose keys are null match nothing; 138 rows = two validity words and a remainder"))
+
 # ---- comparison total order -------------------------------------------------------------------
 C.append(dict(id="total_ordering_float", kind="cmp_total_order", source="py-polars/tests/unit/operations/test_comparison.py:209-226,343-371",
               values=[0.0, -0.0, -1.0, 1.0, "-nan", "nan", "-inf", "inf", None], dtypes=["f32", "f64"],

@@ -135,6 +135,10 @@ def test_join_kats(pl, case):
         return pl.DataFrame(cols)
     L, R = frame("left"), frame("right")
     out = L.join(R, on=case["on"], how=case["how"])
+    if "expect_rows" in case:
+        assert out.height == case["expect_rows"], (case["id"], out.height)
+    for c, n_null in case.get("expect_null_count", {}).items():
+        assert out[c].null_count() == n_null, (case["id"], c)
     if "expect" in case:
         exp = case["expect"]
         names = list(exp.keys())
@@ -147,7 +151,7 @@ def test_join_kats(pl, case):
             for a, b in zip(g, e):
                 assert kat.same_value(a, b), (case["id"], got_rows, exp_rows)
         assert [c for c in out.columns if c in names] == names   # column order / `_right` suffix rule
-    else:
+    elif "expect_column_sorted_by_key" in case:
         d = out.to_dict()
         on = case["on"]
         for c, expv in case["expect_column_sorted_by_key"].items():

@@ -164,13 +164,28 @@ def test_join_kats(orc, case, threads):
     L, R, cats = _join_frames(orc, case)
     on = case["on"]
     how = orc.JOIN_LEFT if case["how"] == "left" else orc.JOIN_INNER
-    li, ri, rvalid = orc.join(how, L[on][0], L[on][1], R[on][0], R[on][1])
+    if isinstance(on, list):
+        # several key columns: the rows' key tuples numbered over both sides (what the engine's key packing amounts to); a null in any column = a null key
+        def tuples(F):
+            valid = np.ones(len(F[on[0]][0]), bool)
+            for c in on:
+                if F[c][1] is not None:
+                    valid &= F[c][1]
+            return [tuple(int(F[c][0][i]) for c in on) if valid[i] else None for i in range(len(valid))], valid
+        lt, lvalid = tuples(L); rt, rvalid_k = tuples(R)
+        ids = {t: i for i, t in enumerate(sorted({t for t in lt + rt if t is not None}))}
+        lk = np.array([ids[t] if t is not None else 0 for t in lt], dtype=np.int64); rk = np.array([ids[t] if t is not None else 0 for t in rt], dtype=np.int64)
+        li, ri, rvalid = orc.join(how, lk, None if lvalid.all() else lvalid, rk, None if rvalid_k.all() else rvalid_k)
+    else:
+        li, ri, rvalid = orc.join(how, L[on][0], L[on][1], R[on][0], R[on][1])
+    if "expect_rows" in case:
+        assert len(li) == case["expect_rows"], (case["id"], len(li))
     out = {}
     for name, (a, v) in L.items():
         vals, ok = orc.gather(a, v, li)
         out[name] = [(_to_py(x, o)) for x, o in zip(vals, ok)]
     for name, (a, v) in R.items():
-        if name == on:
+        if name == on or (isinstance(on, list) and name in on):
             continue
         vals, ok = orc.gather(a, v, ri, rvalid)
         nm = name + "_right" if name in out else name
@@ -184,11 +199,13 @@ def test_join_kats(orc, case, threads):
         for g, e in zip(got_rows, exp_rows):
             for a, b in zip(g, e):
                 assert kat.same_value(a, b), (case["id"], got_rows, exp_rows)
-    else:
+    elif "expect_column_sorted_by_key" in case:
         for c, expv in case["expect_column_sorted_by_key"].items():
             order = sorted(range(len(li)), key=lambda i: (out[on][i], i))
             # probe order (left rows in order, build duplicates in insertion order) == maintain_order="left_right"
             assert [out[c][i] for i in order] == expv
+    for c, n_null in case.get("expect_null_count", {}).items():
+        assert sum(x is None for x in out[c]) == n_null, (case["id"], c, out[c])
     orc.set_threads(1)
 
 
