@@ -2020,7 +2020,9 @@ def run(args, emit):
         for name in [w for w in EXTRA_WORKLOADS if w != args.workload and (not only or w in only)]:
             try:
                 w2 = make_workload(pl, name, int(os.environ.get("PLX_BENCH_EXTRAS_ROWS", "0")), seed=20)
-                d2, s2, r2, c2 = timed(pl, w2, k2, 2, False)       # two warm-up steps: config 3's second run is the first with learned key statistics (new buffer sizes)
+                # three warm-up steps: config 3's second run is the first with learned key statistics (new buffer sizes), and the three-table Q3's THIRD run still maps
+                # fresh result buffers (the two before it hold theirs): one 10 ms kernel on first touch, in every full run, on the first timed step
+                d2, s2, r2, c2 = timed(pl, w2, k2, 3, False)
                 extras[w2.name] = {"rows_per_s": round(w2.rows * k2 / d2, 1), "ms_per_step": round(d2 / k2 * 1e3, 3), "cold_first_step_ms": None if c2 is None else round(c2, 2),
                                    "one_shot_ms": one_shot_ms(pl, w2), "step_ms": list(getattr(timed, "last_step_ms", [])), **step_spread(getattr(timed, "last_step_ms", []), w2.rows),
                                    "whole_query_GBps": round(w2.algo_bytes * k2 / d2 / 1e9, 1), "roofline": roofline(s2, w2, k2), "kernels": _kernels(s2, 6)}
@@ -2045,7 +2047,7 @@ def run(args, emit):
                 os.environ["PLX_Q3_SHUFFLED"] = "1"
                 w3 = make_workload(pl, "q3", 0, seed=20)
                 w3.name = "tpch_q3_sf100_shuffled_inputs"          # (also keeps the ordered run's PMC traffic figure off this line)
-                d3, s3, r3, c3 = timed(pl, w3, k2, 2, False)
+                d3, s3, r3, c3 = timed(pl, w3, k2, 3, False)
                 ordered = extras.get("tpch_q3_sf100", {})
                 extras["tpch_q3_sf100_shuffled_inputs"] = {
                     "rows_per_s": round(w3.rows * k2 / d3, 1), "ms_per_step": round(d3 / k2 * 1e3, 3), "cold_first_step_ms": None if c3 is None else round(c3, 2),
