@@ -740,7 +740,13 @@ def release_memory(pl) -> None:
     pl._ffi.lib().plx_memory_trim()
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
-    time.sleep(0.4)
+    # ... until the device's free memory has stopped growing (three equal readings 100 ms apart; at most 4 s)
+    last, same, t_end = -1, 0, time.perf_counter() + 4.0
+    while same < 3 and time.perf_counter() < t_end:
+        time.sleep(0.1)
+        free = torch.cuda.mem_get_info()[0]
+        same = same + 1 if free == last else 0
+        last = free
 
 
 def step_spread(step_ms, rows_per_step: int) -> dict:
