@@ -736,10 +736,20 @@ def release_memory(pl) -> None:
     """Between two secondary workloads: the library's pool and torch's cache go back to the driver, which unmaps tens of gigabytes in the
     background for a while after the calls return -- kernels that run meanwhile are slowed and the odd one stalls for milliseconds (the
     three-table Q3, whose small inputs are generated in 0.1 s, showed one 14 ms step in every full run and none on its own).  So: wait."""
+    import ctypes
+    import gc
     import torch
     pl._ffi.lib().plx_memory_trim()
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
+    # The host side too: the all-rows verification of a workload leaves tens of gigabytes of freed numpy arrays behind; handed back to the kernel lazily they
+    # cost the NEXT workload a 10-20 ms stall of the main thread in one of its first steps (the three-table Q3, whose inputs take 0.1 s to generate, showed it in
+    # every full run; with PLX_BENCH_VERIFY=0 never).  Collect, and return the freed heap to the kernel now.
+    gc.collect()
+    try:
+        ctypes.CDLL("libc.so.6").malloc_trim(0)
+    except OSError:
+        pass
     # ... until the device's free memory has stopped growing (three equal readings 100 ms apart; at most 4 s)
     last, same, t_end = -1, 0, time.perf_counter() + 4.0
     while same < 3 and time.perf_counter() < t_end:
@@ -2022,6 +2032,11 @@ def run(args, emit):
             emit(line)
         del wl, res
         release_memory(pl)
+        # The all-rows host checks of the secondary workloads run AFTER all of them have been timed: a check builds the workload's host twin (tens of gigabytes
+        # of numpy arrays, all host threads in the oracle) and what it leaves behind in the host's memory management cost the NEXT workload a 10-20 ms stall
+        # of the main thread in one of its first steps and ~5 % on the others (the three-table Q3 behind the hashed-key Q3's check: one step of 13-22 ms in
+        # every full run, none with PLX_BENCH_VERIFY=0).  The results wait on the device (a few MB each) until then.
+        pending_checks = []
         only = [w for w in os.environ.get("PLX_BENCH_EXTRAS", "").split(",") if w]          # measurement: only these secondary workloads
         for name in [w for w in EXTRA_WORKLOADS if w != args.workload and (not only or w in only)]:
             try:
@@ -2038,7 +2053,7 @@ def run(args, emit):
                     dv, sv, _, _ = timed(pl, wv, k2, 1, False)
                     extras[vname] = {"rows_per_s": round(w2.rows * k2 / dv, 1), "ms_per_step": round(dv / k2 * 1e3, 3), "kernels": _kernels(sv, 6)}
                 if os.environ.get("PLX_BENCH_VERIFY", "1") != "0":
-                    extras[w2.name]["verified"] = _verify(w2, r2, float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40")))
+                    pending_checks.append((w2.name, w2.verify, r2))       # checked after every secondary workload has been timed (below)
                 del w2, r2
             except Exception as e:  # a secondary workload must never take the headline line down
                 extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -2061,7 +2076,7 @@ def run(args, emit):
                     "groups": int(r3.height) if hasattr(r3, "height") else None, "roofline": roofline(s3, w3, k2), "kernels": _kernels(s3, 6),
                     "note": "same query over the SAME rows as tpch_q3_sf100 (the library's generator), both tables in a seeded random row order (device gather)"}
                 if os.environ.get("PLX_BENCH_VERIFY", "1") != "0":
-                    extras["tpch_q3_sf100_shuffled_inputs"]["verified"] = _verify(w3, r3, float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40")))
+                    pending_checks.append(("tpch_q3_sf100_shuffled_inputs", w3.verify, r3))
                 del w3, r3
             except Exception as e:
                 extras["tpch_q3_sf100_shuffled_inputs"] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -2072,6 +2087,13 @@ def run(args, emit):
                     os.environ["PLX_Q3_SHUFFLED"] = prev
             release_memory(pl)
             emit(line)
+        for cname, cfn, cres in pending_checks:
+            if cname in extras and "error" not in extras[cname]:
+                shim = Workload(cname, 0, 0, None, "", "", verify=cfn)
+                extras[cname]["verified"] = _verify(shim, cres, float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40")))
+                emit(line)
+        del pending_checks
+        release_memory(pl)
         if os.environ.get("PLX_BENCH_E2E", "1") != "0":
             try:
                 extras["end_to_end_with_h2d"] = end_to_end_q1(pl, 60_000_000)
