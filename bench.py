@@ -1603,8 +1603,17 @@ class MultiCtx:
         return st
 
     def trim(self):
+        """Between two workloads: device pool and torch cache back to the driver, and the host heap a verification left behind back to the kernel (see
+        release_memory: lazily reclaimed host memory stalled the next workload's main thread)."""
+        import ctypes
+        import gc
         if not self.dry:
             self.F.lib().plx_memory_trim(); self.torch.cuda.empty_cache()
+        gc.collect()
+        try:
+            ctypes.CDLL("libc.so.6").malloc_trim(0)
+        except OSError:
+            pass
 
     def backend(self):
         return "numpy + gloo DRY RUN (control flow only, nothing measured)" if self.dry else "libpolars_amd + RCCL (plx_exchange_by_key / plx_allgather_frame)"
