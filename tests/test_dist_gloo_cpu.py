@@ -208,3 +208,25 @@ def test_sharded_groupby_bench_dry_run_prints_a_complete_line():
     assert d["partial_rows_per_rank"] in local_groups
     assert 0.4 * min(local_groups) < d["shuffle"]["rows_sent_per_rank_per_step"] < 0.6 * max(local_groups)
     assert d["shuffle"]["bytes_sent_per_rank_per_step"] == d["shuffle"]["rows_sent_per_rank_per_step"] * (8 + 8 + 4)     # key + i64 partial sum + u32 partial count
+
+
+def test_bench_eight_ranks_dry_run_is_quiet_and_complete():
+    """`python bench.py --gpus 8 --dry-run` (the largest N the driver launches): eight ranks under gloo, the headline plus all four sharded workloads verified,
+    and nothing on stderr that looks like a failure -- the farewell barrier tolerates a peer that has already left."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1", "--rows", "120000"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Traceback" not in r.stderr, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["dry_run"] is True and d["verified"]["ok"] is True
+    ex = d["extras"]
+    assert set(ex) == {"tpch_q3_sf100_sharded_x8", "tpch_q3_sf100_sharded_x8_shuffle", "cfg3_groupby_1e6_keys_sharded_x8", "cfg5_dict_string_keys_sharded_x8"}
+    assert all(v["verified"]["ok"] is True for v in ex.values())
+    assert ex["tpch_q3_sf100_sharded_x8"]["scaling"] == "strong" and ex["tpch_q3_sf100_sharded_x8_shuffle"]["exchange_mode"] == "shuffle"
