@@ -1632,6 +1632,26 @@ class MultiCtx:
             pass
 
 
+# The all-rows host checks of the SECONDARY sharded workloads are deferred until all of them have been timed (run_multi): a check leaves tens of gigabytes of
+# freed host arrays behind, and what the kernel does with them stalled the next workload's main thread on rank 0 -- whose time is the max over the ranks.
+DEFERRED_CHECKS = {"on": False, "pending": []}
+
+
+class PendingCheck(dict):
+    """Placeholder of a `verified` entry whose check has not run yet (serialises as a note should the line be printed before it has)."""
+    def __init__(self, fn):
+        super().__init__(ok=None, note="host check pending (it runs after every secondary workload has been timed)")
+        self.fn = fn
+
+
+def host_check(fn):
+    if DEFERRED_CHECKS["on"]:
+        p = PendingCheck(fn)
+        DEFERRED_CHECKS["pending"].append(p)
+        return p
+    return fn()
+
+
 def timed_multi(ctx, step, steps: int, warmup: int):
     """`warmup` untimed steps, then exactly `steps` timed ones bracketed by barrier + device synchronisation on both sides; the time is the
     MAX over the ranks.  -> (seconds, per-kernel stats of this rank, result of the last step, per-step ms of this rank)"""
@@ -1702,14 +1722,15 @@ def sharded_groupby_line(ctx, args, workload: str, steps: int, warmup: int) -> d
     sent_rows, sent_bytes = comm.rows_sent / (steps + max(warmup, 1)), comm.bytes_sent / (steps + max(warmup, 1))
     every = ctx.gather({"sent_rows": sent_rows, "sent_bytes": sent_bytes, "groups": int(res.height), "rows": n, "sum": column_sum(), "cols": {c: np.asarray(a) for c, a in result_cols(res).items()}})
     total_rows = sum(e["rows"] for e in every)
-    verified = None
-    if rank == 0:
+    def check():
         allc = {c: np.concatenate([e["cols"][c] for e in every]) for c in every[0]["cols"]}
         isum = sum(e["sum"] for e in every)
         verified = verify_sharded_groupby(allc, key_name, "v_sum", second, total_rows, isum if cfg5 else int(round(isum)), [(n, 10 + r) for r in range(ws)], n_keys,
                                           "UInt32" if cfg5 else "Int64", val_np, val_args, 0.0 if os.environ.get("PLX_BENCH_VERIFY", "1") == "0" else float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40")))
         if verified.get("ok") is False:
             print(f"[bench] VERIFICATION FAILED for the sharded {workload}: {verified}", file=sys.stderr)
+        return verified
+    verified = host_check(check) if rank == 0 else None
     rec_bytes = (4 + 8) if cfg5 else 16
     algo = n * rec_bytes + n_keys * 20 // ws
     how = {"preagg": "local partitioned group-by -> partial rows exchanged by key hash (one grouped all-to-all(v)) -> merge on the owner",
@@ -1778,8 +1799,7 @@ def sharded_q3_line(ctx, args, steps: int, warmup: int, mode=None) -> dict:
     sent_rows, sent_bytes = comm.rows_sent / (steps + max(warmup, 1)), comm.bytes_sent / (steps + max(warmup, 1))
     every = ctx.gather({"sent_rows": sent_rows, "sent_bytes": sent_bytes, "groups": int(res.height), "rows": nl + no, "cols": {c: np.asarray(a) for c, a in result_cols(res).items()}})
     total_rows = sum(e["rows"] for e in every)
-    verified = None
-    if rank == 0 and os.environ.get("PLX_BENCH_VERIFY", "1") != "0":
+    def check():
         allc = {c: np.concatenate([e["cols"][c] for e in every]) for c in every[0]["cols"]}
         k = allc["l_orderkey"].astype(np.int64)
         budget = float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40"))
@@ -1798,6 +1818,8 @@ def sharded_q3_line(ctx, args, steps: int, warmup: int, mode=None) -> dict:
                     "against": "per key range of every rank: oracle Q3 on a prefix + numpy restatement over the blocks of that rank's host twin the budget allows", "per_rank": per, "rtol": VERIFY_RTOL}
         if not ok:
             print(f"[bench] VERIFICATION FAILED for the sharded q3: {verified}", file=sys.stderr)
+        return verified
+    verified = host_check(check) if rank == 0 and os.environ.get("PLX_BENCH_VERIFY", "1") != "0" else None
     algo = nl * datagen.Q3_LINEITEM_BYTES_PER_ROW + no * datagen.Q3_ORDERS_BYTES_PER_ROW
     how = {"shuffle": "both sides filtered, then routed by key hash (one grouped all-to-all(v) per input), local fused join -> group-by over the owned keys",
            "broadcast": "filtered build side all-gathered, probe side stays, partial groups routed by key (one small all-to-all(v)) and merged by the owner", "local": "single rank"}[info.get("mode", "local")]
@@ -1876,15 +1898,20 @@ def rowsharded_line(ctx, args, workload: str, steps: int, warmup: int) -> dict:
     if workload == "q1":
         parts = ctx.gather(local["res"])
         if rank == 0 and os.environ.get("PLX_BENCH_VERIFY", "1") != "0":
-            merged_ok = compare_q1_dicts(res, combine_q1_results(parts))
-            budget = float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40"))
-            want, done, _t, _f = q1_oracle_blocks(wl.rows, seed, budget, block=min(wl.rows, 100_000_000))
-            mine = compare_q1(local["res"], want) if done == wl.rows else {"ok": None, "note": "host check ran out of its time budget"}
-            verified = {"ok": bool(merged_ok and mine.get("ok") is not False) if mine.get("ok") is not None else (None if merged_ok else False), "rows": int(done),
+            mine_res = local["res"]
+
+            def check():
+                merged_ok = compare_q1_dicts(res, combine_q1_results(parts))
+                budget = float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40"))
+                want, done, _t, _f = q1_oracle_blocks(wl.rows, seed, budget, block=min(wl.rows, 100_000_000))
+                mine = compare_q1(mine_res, want) if done == wl.rows else {"ok": None, "note": "host check ran out of its time budget"}
+                return {"ok": bool(merged_ok and mine.get("ok") is not False) if mine.get("ok") is not None else (None if merged_ok else False), "rows": int(done),
                         "combined_equals_merge_of_rank_results": bool(merged_ok), "rank0_shard_vs_oracle": mine,
                         "against": "rank 0's shard: oracle (orc_q1_streaming over the shard's host twin); combined result: merge of the gathered per-rank results"}
+            verified = host_check(check)
     elif rank == 0 and not dry and os.environ.get("PLX_BENCH_VERIFY", "1") != "0":
-        verified = _verify(wl, local["res"], float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40")))
+        last_res = local["res"]
+        verified = host_check(lambda: _verify(wl, last_res, float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40"))))
     line = multi_line_base(ctx, args, steps, warmup, dt, wl.rows * ws, "f64", strong)
     line.update({
         "config": {"workload": wl.name + f"_x{ws}", "description": wl.desc, "rows_per_gpu": wl.rows, "algorithmic_bytes_per_gpu_step": wl.algo_bytes,
@@ -1936,6 +1963,7 @@ def run_multi(args, emit):
         line["extras"] = extras
         k2 = max(3, args.steps // 4)
         scaling = args.scaling
+        DEFERRED_CHECKS["on"], DEFERRED_CHECKS["pending"] = True, []
         for w in [w for w in MULTI_EXTRAS if w != args.workload]:
             ctx.trim()
             args.scaling = "strong" if w.startswith("q3") else scaling    # BASELINE config 4 is SF100 in TOTAL over the ranks: the Q3 extras always run it that way
@@ -1950,6 +1978,16 @@ def run_multi(args, emit):
             if ctx.rank == 0:
                 emit(line)
         args.scaling = scaling
+        DEFERRED_CHECKS["on"] = False
+        for ex in extras.values():              # rank 0 only has any: the host checks, now that nothing is left to time
+            v = ex.get("verified")
+            if isinstance(v, PendingCheck):
+                try:
+                    ex["verified"] = v.fn()
+                except Exception as e:
+                    ex["verified"] = {"rows": 0, "ok": None, "error": f"{type(e).__name__}: {e}"[:300]}
+                emit(line)
+        DEFERRED_CHECKS["pending"] = []
     ctx.close()
 
 
