@@ -1929,10 +1929,15 @@ def rowsharded_line(ctx, args, workload: str, steps: int, warmup: int) -> dict:
 def compare_q1_dicts(a: dict, b: dict) -> bool:
     """two Q1 results in to_dict() layout: same groups, integer columns equal, floats within 1e-9"""
     import numpy as np
-    if sorted(zip(a["l_returnflag"], a["l_linestatus"])) != sorted(zip(b["l_returnflag"], b["l_linestatus"])):
+    from polars_amd import datagen
+
+    def codes(d):      # a result that went through pack_q1 / unpack_q1 carries the two keys as dictionary codes, one straight from to_dict() as strings
+        return ([datagen.FLAGS.index(v) if isinstance(v, str) else int(v) for v in d["l_returnflag"]], [datagen.STATUS.index(v) if isinstance(v, str) else int(v) for v in d["l_linestatus"]])
+    (fa, sa), (fb, sb) = codes(a), codes(b)
+    if sorted(zip(fa, sa)) != sorted(zip(fb, sb)):
         return False
-    oa = sorted(range(len(a["count_order"])), key=lambda i: (a["l_returnflag"][i], a["l_linestatus"][i]))
-    ob = sorted(range(len(b["count_order"])), key=lambda i: (b["l_returnflag"][i], b["l_linestatus"][i]))
+    oa = sorted(range(len(a["count_order"])), key=lambda i: (fa[i], sa[i]))
+    ob = sorted(range(len(b["count_order"])), key=lambda i: (fb[i], sb[i]))
     for f in Q1_FIELDS[2:]:
         x, y = np.array([a[f][i] for i in oa], np.float64), np.array([b[f][i] for i in ob], np.float64)
         if not np.allclose(x, y, rtol=1e-9, atol=0):

@@ -151,3 +151,21 @@ def test_q3_three_tables_check():
     # the two-table stand-in (o_custkey % 5 == 0) is a different query: its check must reject this result
     f2 = Frame({("l_orderkey" if k == "o_orderkey" else k): w[k][perm] for k in w})
     assert bench.verify_q3(f2, no, seed, 60, block=25_000, oracle_orders=20_000)["ok"] is False
+
+
+def test_q1_results_compare_across_key_representations():
+    """bench.py at N > 1: the combined Q1 result went through pack_q1 / unpack_q1 (the two keys as dictionary codes), the per-rank results come straight from
+    to_dict() (strings) -- compare_q1_dicts must see the same groups in both (it compared 0 with 'A' and reported a failed verification for every real
+    multi-GPU Q1 run; the gloo dry run's stand-in results carry codes on both sides and never showed it)."""
+    import bench
+    from polars_amd import datagen
+    a = {"l_returnflag": ["A", "N", "R"], "l_linestatus": ["F", "O", "F"], "sum_qty": [10, 20, 30], "count_order": [1, 2, 3], "sum_base_price": [1.5, 2.5, 3.5],
+         "sum_disc_price": [1.0, 2.0, 3.0], "sum_charge": [1.1, 2.2, 3.3], "avg_qty": [10.0, 10.0, 10.0], "avg_price": [1.5, 1.25, 3.5 / 3], "avg_disc": [0.1, 0.2, 0.3]}
+    packed = bench.unpack_q1(bench.pack_q1(a))
+    assert len(packed) == 1 and packed[0]["l_returnflag"] == [datagen.FLAGS.index(v) for v in a["l_returnflag"]]
+    combined = bench.combine_q1_results(packed)                                  # what every rank holds after the all-gather (codes)
+    assert bench.compare_q1_dicts(combined, bench.combine_q1_results([a]))       # ... against the merge of the ranks' own results (strings)
+    b = dict(a, sum_qty=[10, 21, 30])
+    assert not bench.compare_q1_dicts(combined, bench.combine_q1_results([b]))
+    c = dict(a, l_returnflag=["A", "N", "N"])
+    assert not bench.compare_q1_dicts(combined, bench.combine_q1_results([c]))
