@@ -9,8 +9,9 @@ timed region starts.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload q1|q3|cfg2|cfg3] [--rows R]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU.  --scaling weak (default): every rank holds its own SF100-sized shard; --scaling strong: the SF100 /
-1e9-row configuration in TOTAL, split over the ranks (BASELINE config 4).  Q1's six-group partials are combined with an all-gather
+N > 1: one process per GPU.  --scaling strong (the default at N > 1): the SF100 / 1e9-row configuration in TOTAL, split over the ranks, so the
+N-GPU lines sit on one curve with the N = 1 line (BASELINE: "SF100, 1/2/4/8 GPU"); --scaling weak: every rank holds its own SF100-sized shard (run
+as the extra `..._weak`).  Q1's six-group partials are combined with an all-gather
 of a few hundred bytes (polars_amd/dist.py), no row crosses xGMI; cfg3 / cfg5 pre-aggregate locally and exchange the PARTIAL rows
 by key hash (--mode rows exchanges raw rows instead).  Prints ONE JSON line on rank 0; exits 3 if a result disagreed with the oracle.
 
@@ -51,11 +52,14 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = every rank holds the full single-GPU configuration (SF100 / 1e9 rows per rank); "
-                    "strong = that configuration in TOTAL, split over the ranks (BASELINE config 4: SF100 over 8 GPUs)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: strong (default) = the single-GPU configuration in TOTAL, split over the ranks (BASELINE's metric: "
+                    "SF100 on 1/2/4/8 GPUs); weak = every rank holds the full single-GPU configuration (SF100 / 1e9 rows per rank)")
     ap.add_argument("--mode", default="auto", choices=["auto", "preagg", "rows"], help="sharded cfg3 / cfg5: what crosses the fabric (dist.sharded_groupby)")
     ap.add_argument("--dry-run", action="store_true", help="sharded workloads only: numpy frames + gloo instead of the library + RCCL (control-flow check without GPUs)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "strong" if max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1 else "weak"
+    return args
 
 
 class Workload:
@@ -1193,7 +1197,7 @@ def run_guarded(worker, deadline_s: float, poll_s: float = 0.25, prints: bool = 
             d = json.loads(line)
             d["note"] = f"secondary workloads stopped at the {deadline_s:.0f} s deadline; headline unaffected"
             line = json.dumps(d)
-        print(line, flush=True)
+        print_record(json.loads(line))
         return EXIT_PARITY if failed_verifications(json.loads(line)) else 0
     if stopped and not prints:
         return 0
@@ -1217,6 +1221,91 @@ def failed_verifications(line: dict):
             if isinstance(fv, dict) and fv.get("verified") is False:
                 bad.append(f"{name}.{fk}")
     return bad
+
+
+HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                 "roofline", "cpu_baseline", "verified", "cold_first_step_ms", "one_shot_ms", "ms_per_step_median", "comm", "note", "dry_run")
+HEADLINE_MAX_BYTES = 4096     # the driver parses the LAST stdout line out of an 8 KB tail: the line it must read stays far below that
+EXTRAS_FILE = os.environ.get("PLX_BENCH_EXTRAS_FILE", os.path.join(ROOT, "bench_extras.json"))
+
+
+def _clip(v, n: int):
+    return v if not isinstance(v, str) or len(v) <= n else v[: n - 3] + "..."
+
+
+def _slim(obj, text: int):
+    """a JSON object with its prose clipped to `text` characters and nested tables (per-kernel lists, step series) dropped"""
+    if not isinstance(obj, dict):
+        return obj
+    out = {}
+    for k, v in obj.items():
+        if isinstance(v, dict):
+            if k in ("dominant_kernel", "rank0_shard_vs_oracle", "polars"):
+                continue
+            v = {a: _clip(b, text) for a, b in v.items() if not isinstance(b, (dict, list))}
+        elif isinstance(v, list):
+            continue
+        out[k] = _clip(v, text)
+    return out
+
+
+def headline_line(full: dict, extras_file=None) -> dict:
+    """The ONE line the driver parses (the last stdout line): BASELINE's metric, the timing, `config`, `roofline`, `cpu_baseline`, `verified`, with the
+    prose clipped, plus one short row per secondary workload (`extras_summary`: ms per step, roofline fraction, counter traffic in GB, oracle verdict).
+    Everything else -- per-kernel tables, step series, the secondary workloads in full -- is the FULL record: written to `extras_file` and printed on
+    an earlier stdout line.  Always below HEADLINE_MAX_BYTES (round 4's 25 KB line was not parseable from the driver's 8 KB tail)."""
+    out = {}
+    for k in HEADLINE_KEYS:
+        if k in full:
+            v = full[k]
+            out[k] = _slim(v, 160) if isinstance(v, dict) else _clip(v, 200)
+    summ = {}
+    for name, ex in (full.get("extras") or {}).items():
+        if not isinstance(ex, dict):
+            continue
+        if "error" in ex:
+            summ[name] = {"error": _clip(ex["error"], 60)}
+            continue
+        r = ex.get("roofline") or {}
+        row = {"ms": ex.get("ms_per_step"), "frac": r.get("frac")}
+        if r.get("traffic") is not None:
+            row["traffic_GB"] = round(r["traffic"] / 1e9, 2)
+        ok = (ex.get("verified") or {}).get("ok") if isinstance(ex.get("verified"), dict) else None
+        files = ex.get("files")
+        if isinstance(files, dict) and files:
+            ok = all(isinstance(f, dict) and f.get("verified") is not False for f in files.values())
+        if "verified" in ex or files:
+            row["ok"] = ok
+        summ[name] = {a: b for a, b in row.items() if b is not None or a == "ok"}
+    if summ:
+        out["extras_summary"] = summ
+    if extras_file:
+        out["extras_file"] = os.path.relpath(extras_file, ROOT) if os.path.abspath(extras_file).startswith(ROOT + os.sep) else extras_file
+    bad = failed_verifications(full)
+    if bad:
+        out["failed_verifications"] = bad[:8]
+    for drop in ("extras_summary", "note"):           # cannot happen with the workloads of this file; the bound is unconditional all the same
+        if len(json.dumps(out)) < HEADLINE_MAX_BYTES:
+            break
+        out.pop(drop, None)
+    if len(json.dumps(out)) >= HEADLINE_MAX_BYTES:
+        out = {k: (_slim(v, 40) if isinstance(v, dict) else _clip(v, 80)) for k, v in out.items()}
+    return out
+
+
+def print_record(full: dict) -> None:
+    """stdout: the full record on an earlier line (prefixed, so that nothing mistakes it for the line), then the headline line LAST; the full record
+    also goes to EXTRAS_FILE."""
+    path = EXTRAS_FILE
+    try:
+        with open(path + ".tmp", "w") as f:
+            json.dump(full, f)
+        os.replace(path + ".tmp", path)
+    except OSError as e:
+        print(f"[bench] could not write {path}: {e}", file=sys.stderr)
+        path = None
+    print("[bench] full record: " + json.dumps(full), flush=True)
+    print(json.dumps(headline_line(full, path)), flush=True)
 
 
 def spawn_ranks(args) -> int:
@@ -1264,7 +1353,7 @@ def main():
     final = {}
     run(args, lambda line, ready=True: final.update(line))
     if rank == 0:
-        print(json.dumps(final), flush=True)
+        print_record(final)
         bad = failed_verifications(final)
         if bad:
             print(f"[bench] parity check failed for: {bad}", file=sys.stderr)
@@ -1279,171 +1368,6 @@ def main():
 # the shard (mode "rows").  The result stays sharded.  `--dry-run` swaps the library and RCCL for numpy frames and gloo so the control
 # flow (mode choice, barriers, accounting, the JSON line) can be exercised without GPUs (tests/test_dist_gloo_cpu.py); nothing of it is
 # measured.
-class DryFrame:
-    """numpy stand-in for a device DataFrame (dry run only): name -> values, plus name -> validity (bool array) for nullable columns."""
-
-    def __init__(self, cols, valid=None, schema=None):
-        self.cols = dict(cols)
-        self.valid = {k: v for k, v in (valid or {}).items() if v is not None}
-        self.schema = schema
-
-    @property
-    def height(self):
-        return len(next(iter(self.cols.values()))) if self.cols else 0
-
-    def validity(self, name):
-        import numpy as np
-        v = self.valid.get(name)
-        return np.ones(self.height, bool) if v is None else v
-
-
-class DryComm:
-    """gloo stand-in for dist.LibComm (dry run only): same routing rule shape (a hash of the key modulo world size, null keys to rank 0:
-    hashing.rs:111-115), one all_to_all per column, validity as one byte per row."""
-
-    def __init__(self):
-        import torch.distributed as dist
-        self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
-        self.rows_sent = self.bytes_sent = 0
-
-    def agree(self, value):
-        import torch.distributed as dist
-        box = [float(value)]
-        dist.broadcast_object_list(box, src=0)
-        return float(box[0])
-
-    def total(self, value):
-        import torch.distributed as dist
-        every = [None] * self.world_size
-        dist.all_gather_object(every, float(value))
-        return float(sum(every))
-
-    def allgather(self, df):
-        """concatenation of every rank's frame in rank order (pickled numpy over gloo: dry run only)"""
-        import numpy as np
-        import torch.distributed as dist
-        every = [None] * self.world_size
-        dist.all_gather_object(every, (df.cols, {n: df.validity(n) for n in df.valid}))
-        nullable = {n for _, v in every for n in v}
-        cols = {n: np.concatenate([c[n] for c, _ in every]) for n in df.cols}
-        valid = {n: np.concatenate([v[n] if n in v else np.ones(len(c[n]), bool) for c, v in every]) for n in nullable}
-        return DryFrame(cols, valid, df.schema)
-
-    def exchange_by_key(self, df, key, seed=0):
-        import numpy as np
-        import torch
-        import torch.distributed as dist
-        ws = self.world_size
-        kv = df.cols[key]
-        k = (kv.view(np.uint64) if kv.dtype.itemsize == 8 else kv.astype(np.uint64))
-        part = ((k * np.uint64(0x55fbfd6bfc5458e9)) >> np.uint64(40)) % np.uint64(ws)
-        part = np.where(df.validity(key), part, np.uint64(0)).astype(np.int64)
-        order = np.argsort(part, kind="stable")
-        counts = np.bincount(part, minlength=ws).astype(np.int64)
-        send = torch.from_numpy(counts.copy()); recv = torch.zeros_like(send)
-        dist.all_to_all_single(recv, send)
-        rc = [int(x) for x in recv.tolist()]
-        # a column travels with a validity byte per row when ANY rank holds nulls in it (the sends and receives must pair up)
-        has = torch.tensor([1 if n in df.valid else 0 for n in df.cols], dtype=torch.int64)
-        dist.all_reduce(has, op=dist.ReduceOp.MAX)
-        out, out_valid = {}, {}
-        away = int(sum(int(c) for i, c in enumerate(counts) if i != self.rank))
-
-        def a2a(v):
-            src = torch.from_numpy(np.ascontiguousarray(v[order]).view(np.uint8).reshape(-1))
-            w = v.dtype.itemsize
-            dst = torch.empty(sum(rc) * w, dtype=torch.uint8)
-            dist.all_to_all_single(dst, src, output_split_sizes=[c * w for c in rc], input_split_sizes=[int(c) * w for c in counts])
-            self.bytes_sent += away * w
-            return dst.numpy().view(v.dtype)
-        for (name, v), nullable in zip(df.cols.items(), has.tolist()):
-            out[name] = a2a(v)
-            if nullable:
-                out_valid[name] = a2a(df.validity(name).astype(np.uint8)).astype(bool)
-        self.rows_sent += away
-        return DryFrame(out, out_valid, df.schema)
-
-
-class DryOps:
-    """numpy stand-in for dist.LibFrameOps (dry run only): the same four local queries over DryFrames, null-aware (null key = its own
-    group; sum / count / min / max / mean skip null values; min / max / mean of no value = null)."""
-
-    @staticmethod
-    def _groups(df, key):
-        import numpy as np
-        kv, valid = df.cols[key], df.validity(key)
-        uniq, inv = np.unique(kv[valid], return_inverse=True)
-        gid = np.full(df.height, len(uniq), np.int64)
-        gid[valid] = inv
-        has_null = bool((~valid).any())
-        keys = np.concatenate([uniq, np.zeros(1, kv.dtype)]) if has_null else uniq
-        kvalid = np.concatenate([np.ones(len(uniq), bool), np.zeros(1, bool)]) if has_null else None
-        return gid, len(keys), keys, kvalid
-
-    def _aggregate(self, df, key, aggs):
-        import numpy as np
-        gid, ng, keys, kvalid = self._groups(df, key)
-        cols, valid = {key: keys}, {key: kvalid}
-        for out, col, op in aggs:
-            if op == "len":
-                cols[out] = np.bincount(gid, minlength=ng).astype(np.uint32)
-                continue
-            v, ok = df.cols[col], df.validity(col)
-            g = gid[ok]
-            if op == "count":
-                cols[out] = np.bincount(g, minlength=ng).astype(np.uint32)
-            elif op in ("sum", "sum_f64"):
-                x = v[ok].astype(np.float64) if op == "sum_f64" or v.dtype.kind == "f" else v[ok].astype(np.uint32 if v.dtype == np.uint32 else np.int64)
-                acc = np.zeros(ng, x.dtype)
-                np.add.at(acc, g, x)
-                cols[out] = acc
-            elif op in ("min", "max"):
-                fn, init = (np.minimum, np.inf) if op == "min" else (np.maximum, -np.inf)
-                if v.dtype.kind == "f":
-                    acc = np.full(ng, init, v.dtype)
-                else:
-                    info = np.iinfo(v.dtype)
-                    acc = np.full(ng, info.max if op == "min" else info.min, v.dtype)
-                fn.at(acc, g, v[ok])
-                seen = np.bincount(g, minlength=ng) > 0
-                cols[out] = np.where(seen, acc, np.zeros(1, v.dtype))
-                valid[out] = None if seen.all() else seen
-            else:
-                raise ValueError(op)
-        return DryFrame(cols, valid, df.schema)
-
-    def final(self, df, spec):
-        import numpy as np
-        from polars_amd.dist import PARTIALS
-        part = self._aggregate(df, spec.key, [(f"{o}__p{i}", c, pop) for o, c, op in spec.aggs for i, (pop, _) in enumerate(PARTIALS[op])])
-        return self._finish(part, spec)
-
-    def partial(self, df, spec):
-        return self._aggregate(df, spec.key, spec.partial_aggs())
-
-    def merge(self, part, spec, source_schema=None):
-        return self._finish(self._aggregate(part, spec.key, spec.merge_aggs()), spec)
-
-    @staticmethod
-    def _finish(part, spec):
-        import numpy as np
-        cols, valid = {spec.key: part.cols[spec.key]}, {spec.key: part.valid.get(spec.key)}
-        for o, c, op in spec.aggs:
-            if op == "mean":
-                n = part.cols[f"{o}__p1"].astype(np.float64)
-                with np.errstate(invalid="ignore", divide="ignore"):
-                    cols[o] = np.where(n > 0, part.cols[f"{o}__p0"] / np.where(n > 0, n, 1.0), 0.0)
-                valid[o] = None if (n > 0).all() else n > 0
-            else:
-                cols[o] = part.cols[f"{o}__p0"]
-                valid[o] = part.valid.get(f"{o}__p0")
-        return DryFrame(cols, valid, part.schema)
-
-    def distinct_in_prefix(self, df, key, n):
-        import numpy as np
-        return len(np.unique(df.cols[key][:n][df.validity(key)[:n]])) + int((~df.validity(key)[:n]).any())
-
-
 def verify_sharded_groupby(res_cols, key_name, sum_name, second, total_rows, input_sum, ranks_rows_seeds, n_keys, key_np, val_np, val_args, budget_s):
     """Rank 0's check of a sharded cfg3 / cfg5 result (all ranks' result rows gathered): size-independent properties always -- the key sets
     of the ranks are disjoint (no key twice), the counts add up to the rows of all shards, the sums add up to the column sums every rank
@@ -1504,47 +1428,13 @@ def verify_sharded_groupby(res_cols, key_name, sum_name, second, total_rows, inp
     return out
 
 
-class DryJoinOps:
-    """numpy stand-in for dist.LibJoinOps on TPC-H Q3's shape (dry run only): the two single-table predicates, the local
-    filter -> join -> group-by, the merge of partial groups."""
-
-    def __init__(self, date, seg_mod=5):
-        self.date, self.seg_mod = date, seg_mod
-
-    @staticmethod
-    def _take(df, m):
-        return DryFrame({c: v[m] for c, v in df.cols.items()}, None, df.schema)
-
-    def build_prefilter(self, df):
-        return self._take(df, (df.cols["o_orderdate"] < self.date) & (df.cols["o_custkey"] % self.seg_mod == 0))
-
-    def probe_prefilter(self, df):
-        return self._take(df, df.cols["l_shipdate"] > self.date)
-
-    def local(self, probe, build):
-        import numpy as np
-        b, p = self.build_prefilter(build), self.probe_prefilter(probe)
-        order = np.argsort(b.cols["o_orderkey"], kind="stable")
-        bk = b.cols["o_orderkey"][order]
-        pos = np.searchsorted(bk, p.cols["l_orderkey"])
-        hit = (pos < len(bk)) & (bk[np.minimum(pos, max(len(bk) - 1, 0))] == p.cols["l_orderkey"]) if len(bk) else np.zeros(p.height, bool)
-        slot = pos[hit]
-        rev = p.cols["l_extendedprice"][hit] * (1.0 - p.cols["l_discount"][hit])
-        sums = np.bincount(slot, weights=rev, minlength=len(bk))
-        has = np.bincount(slot, minlength=len(bk)) > 0
-        return DryFrame({"l_orderkey": bk[has], "o_orderdate": b.cols["o_orderdate"][order][has], "o_shippriority": b.cols["o_shippriority"][order][has], "revenue": sums[has]})
-
-    def merge(self, part, spec):
-        import numpy as np
-        uniq, first, inv = np.unique(part.cols[spec.result_key], return_index=True, return_inverse=True)
-        out = {c: v[first] for c, v in part.cols.items()}
-        for c, op in spec.merge:
-            assert op == "sum"
-            out[c] = np.bincount(inv, weights=part.cols[c], minlength=len(uniq))
-        return DryFrame(out)
-
-    def nbytes(self, df):
-        return int(sum(v.nbytes for v in df.cols.values()))
+def dry_doubles():
+    """`--dry-run` only: the numpy + gloo stand-ins for the library's frames / communicator / local operators live with the tests (tests/dry_multigpu.py)."""
+    import importlib
+    tdir = os.path.join(ROOT, "tests")
+    if tdir not in sys.path:
+        sys.path.insert(0, tdir)
+    return importlib.import_module("dry_multigpu")
 
 
 class MultiCtx:
@@ -1561,7 +1451,7 @@ class MultiCtx:
         if self.dry:
             pdist.init_process_group("gloo")
             self._ensure_group("gloo")
-            self.comm = DryComm()
+            self.comm = dry_doubles().DryComm()
         else:
             dev = int(os.environ.get("PLX_BENCH_DEVICE", self.local_rank))
             torch.cuda.set_device(dev)
@@ -1617,6 +1507,11 @@ class MultiCtx:
 
     def backend(self):
         return "numpy + gloo DRY RUN (control flow only, nothing measured)" if self.dry else "libpolars_amd + RCCL (plx_exchange_by_key / plx_allgather_frame)"
+
+    def comm_info(self):
+        """What the communicator itself says it is (RCCL: ncclCommUserRank / ncclCommCount through plx_comm_info) next to what the launcher's environment names."""
+        r, w = self.comm.info() if hasattr(self.comm, "info") else (self.comm.rank, self.comm.world_size)
+        return {"rank": r, "world_size": w, "env_world_size": int(os.environ.get("WORLD_SIZE", "1")), "library": "gloo (dry run)" if self.dry else "rccl"}
 
     def close(self):
         # (the measurements are done and rank 0's line is out: a peer that has already left must not turn the farewell barrier into a traceback)
@@ -1702,8 +1597,9 @@ def sharded_groupby_line(ctx, args, workload: str, steps: int, warmup: int) -> d
         from polars_amd import datagen
         k = datagen.uniform_native_host("UInt32" if cfg5 else "Int64", 0, n, seed, 0, 0, n_keys)
         v = datagen.uniform_native_host(val_np, 0, n, seed, 1, *val_args)
-        df = DryFrame({key_name: k, val_name: v})
-        ops = DryOps()
+        dry_m = dry_doubles()
+        df = dry_m.DryFrame({key_name: k, val_name: v})
+        ops = dry_m.DryOps()
         column_sum = lambda: float(v.sum()) if cfg5 else int(v.sum())
         result_cols = lambda r: dict(r.cols)
     else:
@@ -1737,7 +1633,7 @@ def sharded_groupby_line(ctx, args, workload: str, steps: int, warmup: int) -> d
            "rows": "raw rows exchanged by key hash (one grouped all-to-all(v)) -> single-GPU partitioned group-by over the owned keys", "local": "single rank"}[info.get("mode", "local")]
     line = multi_line_base(ctx, args, steps, warmup, dt, total_rows, "f64" if cfg5 else "int64", strong)
     line.update({
-        "config": {"workload": ("cfg5_dict_string_keys" if cfg5 else "cfg3_groupby_1e6_keys") + f"_sharded_x{ws}", "rows_per_gpu": n, "algorithmic_bytes_per_gpu_step": algo,
+        "config": {"workload": ("cfg5_dict_string_keys" if cfg5 else "cfg3_groupby_1e6_keys") + f"_sharded_x{ws}_{args.scaling}", "rows_per_gpu": n, "algorithmic_bytes_per_gpu_step": algo,
                    "description": f"{n} rows per rank, 1e6 keys over all ranks, group_by(key).agg(...): {how}; result sharded by key",
                    "parallelism": f"row-sharded x{ws}; {how}", "backend": ctx.backend()},
         "exchange_mode": info.get("mode"), "shrink_estimate": info.get("shrink_estimate"), "partial_rows_per_rank": info.get("partial_rows"),
@@ -1776,8 +1672,9 @@ def sharded_q3_line(ctx, args, steps: int, warmup: int, mode=None) -> dict:
         o, li, _cnt = datagen.orders_lineitem_native_host_mt(0, no, no, seed, threads=2)
         o["o_shippriority"] = np.zeros(no, np.int64)
         o["o_orderkey"] = o["o_orderkey"] + off; li["l_orderkey"] = li["l_orderkey"] + off
-        O, L = DryFrame({c: o[c] for c in datagen.ORDERS_Q3_COLS}), DryFrame({c: li[c] for c in datagen.LINEITEM_Q3_COLS})
-        ops, spec = DryJoinOps(date), pdist.JoinGroupBySpec("l_orderkey", "o_orderkey", "l_orderkey", [("revenue", "sum")])
+        dry_m = dry_doubles()
+        O, L = dry_m.DryFrame({c: o[c] for c in datagen.ORDERS_Q3_COLS}), dry_m.DryFrame({c: li[c] for c in datagen.LINEITEM_Q3_COLS})
+        ops, spec = dry_m.DryJoinOps(date), pdist.JoinGroupBySpec("l_orderkey", "o_orderkey", "l_orderkey", [("revenue", "sum")])
         result_cols = lambda r: dict(r.cols)
     else:
         pl = ctx.pl
@@ -1825,7 +1722,7 @@ def sharded_q3_line(ctx, args, steps: int, warmup: int, mode=None) -> dict:
            "broadcast": "filtered build side all-gathered, probe side stays, partial groups routed by key (one small all-to-all(v)) and merged by the owner", "local": "single rank"}[info.get("mode", "local")]
     line = multi_line_base(ctx, args, steps, warmup, dt, total_rows, "f64", strong)
     line.update({
-        "config": {"workload": f"tpch_q3_sf100_sharded_x{ws}" + ("_shuffle" if mode == "shuffle" else ""), "rows_per_gpu": nl + no, "orders_per_gpu": no, "lineitem_rows_per_gpu": nl, "algorithmic_bytes_per_gpu_step": algo,
+        "config": {"workload": f"tpch_q3_sf100_sharded_x{ws}" + ("_shuffle" if mode == "shuffle" else "") + f"_{args.scaling}", "rows_per_gpu": nl + no, "orders_per_gpu": no, "lineitem_rows_per_gpu": nl, "algorithmic_bytes_per_gpu_step": algo,
                    "description": f"TPC-H Q3 (orders {no} x lineitem {nl} per rank), filter both -> hash join -> group_by(orderkey, orderdate, shippriority): {how}; result sharded by key",
                    "parallelism": f"row-sharded x{ws}; {how}", "backend": ctx.backend()},
         "exchange_mode": info.get("mode"), "build_rows_after_filter_per_rank": info.get("build_rows"), "probe_rows_after_filter_per_rank": info.get("probe_rows"),
@@ -1840,31 +1737,6 @@ def sharded_q3_line(ctx, args, steps: int, warmup: int, mode=None) -> dict:
     if dry:
         line["dry_run"] = True
     return line
-
-
-def dry_q1_step(n: int, seed: int):
-    """numpy stand-in for the per-rank Q1 (dry run only): the result in the layout of DataFrame.to_dict()."""
-    import numpy as np
-    from polars_amd import datagen
-    li = datagen.lineitem_native_host_mt(0, n, seed, threads=2)
-    cutoff = datagen.us(1998, 9, 2)
-
-    def step():
-        m = li["l_shipdate"] <= cutoff
-        g = (li["l_returnflag"][m].astype(np.int64) * 2 + li["l_linestatus"][m].astype(np.int64))
-        cnt = np.bincount(g, minlength=6)
-        qty, price, disc, tax = (li[c][m] for c in ("l_quantity", "l_extendedprice", "l_discount", "l_tax"))
-        s = lambda w: np.bincount(g, weights=w, minlength=6)
-        dp = price * (1 - disc)
-        out = {f: [] for f in Q1_FIELDS}
-        for i in np.nonzero(cnt)[0]:
-            c = int(cnt[i])
-            out["l_returnflag"].append(int(i) // 2); out["l_linestatus"].append(int(i) % 2)
-            out["sum_qty"].append(int(qty[g == i].sum())); out["count_order"].append(c)
-            out["sum_base_price"].append(float(s(price)[i])); out["sum_disc_price"].append(float(s(dp)[i])); out["sum_charge"].append(float(s(dp * (1 + tax))[i]))
-            out["avg_qty"].append(float(s(qty.astype(np.float64))[i]) / c); out["avg_price"].append(float(s(price)[i]) / c); out["avg_disc"].append(float(s(disc)[i]) / c)
-        return out
-    return step
 
 
 def rowsharded_line(ctx, args, workload: str, steps: int, warmup: int) -> dict:
@@ -1882,7 +1754,7 @@ def rowsharded_line(ctx, args, workload: str, steps: int, warmup: int) -> dict:
         if workload != "q1":
             raise ValueError("--dry-run knows q1, q3, cfg3 and cfg5")
         n = rows or 200_000
-        one = dry_q1_step(n, seed)
+        one = dry_doubles().dry_q1_step(n, seed)
         wl = Workload("tpch_q1_sf100", n, n * 42, None, "", f"TPC-H Q1, lineitem {n} rows per rank (numpy stand-in)")
     else:
         wl = make_workload(ctx.pl, workload, rows, seed=seed, ws=ws)
@@ -1914,7 +1786,7 @@ def rowsharded_line(ctx, args, workload: str, steps: int, warmup: int) -> dict:
         verified = host_check(lambda: _verify(wl, last_res, float(os.environ.get("PLX_BENCH_VERIFY_BUDGET_S", "40"))))
     line = multi_line_base(ctx, args, steps, warmup, dt, wl.rows * ws, "f64", strong)
     line.update({
-        "config": {"workload": wl.name + f"_x{ws}", "description": wl.desc, "rows_per_gpu": wl.rows, "algorithmic_bytes_per_gpu_step": wl.algo_bytes,
+        "config": {"workload": wl.name + f"_x{ws}_{args.scaling}", "description": wl.desc, "rows_per_gpu": wl.rows, "algorithmic_bytes_per_gpu_step": wl.algo_bytes,
                    "parallelism": (f"row-sharded x{ws}, all-gather of group partials" if workload == "q1" else f"row-sharded x{ws}, independent replicas (no data-path collective)"),
                    "backend": ctx.backend()},
         "whole_query_GBps_per_gpu": round(wl.algo_bytes * steps / dt / 1e9, 1), "step_ms": step_ms, **step_spread(step_ms, wl.rows * ws),
@@ -1945,7 +1817,7 @@ def compare_q1_dicts(a: dict, b: dict) -> bool:
     return True
 
 
-MULTI_EXTRAS = ("q3", "q3:shuffle", "cfg3", "cfg5", "q1")
+MULTI_EXTRAS = ("q3", "q3:shuffle", "cfg3", "cfg5", "q1", "q1:weak")     # ":weak" = the per-rank SF100 shard (weak scaling), labelled so in its config.workload
 EXTRA_WORKLOADS = ("q3", "q3h", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "q1")      # the secondary workloads of the N = 1 line, in this order
 
 
@@ -1959,8 +1831,11 @@ def run_multi(args, emit):
             return sharded_groupby_line(ctx, args, workload, steps, warmup)
         if workload.startswith("q3") and workload != "q3f":
             return sharded_q3_line(ctx, args, steps, warmup, mode=workload.partition(":")[2] or None)
-        return rowsharded_line(ctx, args, workload, steps, warmup)
+        return rowsharded_line(ctx, args, workload.partition(":")[0], steps, warmup)
     line = one(args.workload, args.steps, args.warmup)
+    line["comm"] = ctx.comm_info()
+    if line["comm"]["world_size"] != line["comm"]["env_world_size"]:
+        raise RuntimeError(f"the communicator spans {line['comm']['world_size']} ranks, the launcher's environment names {line['comm']['env_world_size']}")
     if ctx.rank == 0:
         emit(line)
     if not args.no_extras:
@@ -1969,9 +1844,10 @@ def run_multi(args, emit):
         k2 = max(3, args.steps // 4)
         scaling = args.scaling
         DEFERRED_CHECKS["on"], DEFERRED_CHECKS["pending"] = True, []
-        for w in [w for w in MULTI_EXTRAS if w != args.workload]:
+        for w in [w for w in MULTI_EXTRAS if w != args.workload and not (w.endswith(":weak") and scaling == "weak")]:
             ctx.trim()
-            args.scaling = "strong" if w.startswith("q3") else scaling    # BASELINE config 4 is SF100 in TOTAL over the ranks: the Q3 extras always run it that way
+            # BASELINE config 4 is SF100 in TOTAL over the ranks: the Q3 extras always run it that way; "<workload>:weak" is the weak-scaling variant of a headline
+            args.scaling = "strong" if w.startswith("q3") else ("weak" if w.endswith(":weak") else scaling)
             try:
                 ex = one(w, k2, 2)
                 name = ex["config"]["workload"]

@@ -35,6 +35,8 @@ struct Rccl {
   int (*GetUniqueId)(NcclId*) = nullptr;
   int (*CommInitRank)(NcclComm*, int, NcclId, int) = nullptr;
   int (*CommDestroy)(NcclComm) = nullptr;
+  int (*CommCount)(const NcclComm, int*) = nullptr;      // optional: what RCCL itself says the communicator is (plx_comm_info)
+  int (*CommUserRank)(const NcclComm, int*) = nullptr;
   int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
   int (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
@@ -52,6 +54,8 @@ Rccl& rccl() {
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
     r.Send = (decltype(r.Send))sym("ncclSend");
     r.Recv = (decltype(r.Recv))sym("ncclRecv");
     r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
@@ -172,7 +176,19 @@ void destroy(uint64_t h) {
   if (c->nccl && rccl().CommDestroy) (void)rccl().CommDestroy(c->nccl);
 }
 
-void info(uint64_t h, int* rank, int* ws) { Comm& c = get_comm(h); if (rank) *rank = c.rank; if (ws) *ws = c.ws; }
+// rank / world size as RCCL reports them for the live communicator (ncclCommUserRank / ncclCommCount), checked against what init() was given
+void info(uint64_t h, int* rank, int* ws) {
+  Comm& c = get_comm(h);
+  int r = c.rank, w = c.ws;
+  if (c.nccl && rccl().CommCount && rccl().CommUserRank) {
+    nccl_check(rccl().CommCount(c.nccl, &w), "ncclCommCount");
+    nccl_check(rccl().CommUserRank(c.nccl, &r), "ncclCommUserRank");
+    PLX_REQUIRE(r == c.rank && w == c.ws, PLX_ERR_HIP, "communicator disagrees with its initialisation: rank " + std::to_string(r) + " of " + std::to_string(w) +
+                " (initialised as " + std::to_string(c.rank) + " of " + std::to_string(c.ws) + ")");
+  }
+  if (rank) *rank = r;
+  if (ws) *ws = w;
+}
 
 // Routes every row of `in` to rank hash_partition(key) -- null keys to rank 0 (null_partition(), hashing.rs:111-115) -- and returns
 // the rows this rank received (all columns, same names; nullable and Boolean columns included); in *rows_sent / *bytes_sent what

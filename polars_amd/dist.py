@@ -139,6 +139,13 @@ class LibComm:
         self._h, self.rank, self.world_size, self._group = h.value, rank, ws, group
         self.rows_sent = self.bytes_sent = 0          # over the fabric, accumulated
 
+    def info(self):
+        """(rank, world size) as RCCL reports them for the live communicator (plx_comm_info: ncclCommUserRank / ncclCommCount)"""
+        import ctypes as C
+        r, w = C.c_int32(), C.c_int32()
+        self._F.check(self._F.lib().plx_comm_info(self._h, C.byref(r), C.byref(w)))
+        return int(r.value), int(w.value)
+
     def exchange_by_key(self, df, key: str, seed: int = 0):
         """Every row of `df` goes to rank hash_partition(key); returns the rows this rank now owns (a DataFrame with the same
         columns / logical dtypes)."""

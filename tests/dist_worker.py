@@ -1,6 +1,6 @@
 """Worker of tests/test_dist_gloo_cpu.py: one process per rank, gloo backend, numpy frames.
 What is under test is polars_amd.dist -- the control flow of the sharded operators (mode choice agreed across ranks, partial / final
-aggregate decomposition, which frames cross the fabric, the merge on the owner) -- with bench.py's numpy doubles standing in for the
+aggregate decomposition, which frames cross the fabric, the merge on the owner) -- with the numpy doubles of tests/dry_multigpu.py standing in for the
 device frames, the library's RCCL communicator and the per-rank operators."""
 import os
 import sys
@@ -11,6 +11,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import pyoracle as orc  # noqa: E402
 from polars_amd import dist as pdist  # noqa: E402
 
@@ -19,15 +20,16 @@ def main():
     pdist.init_process_group("gloo")
     rank, ws = dist.get_rank(), dist.get_world_size()
     out_dir = sys.argv[1]
-    import bench
+    import bench  # noqa: F401 -- (the verification helpers)
+    import dry_multigpu as dry
     # (a) the exchange double itself: every row lands on ONE rank per key, nothing lost, all-gather = concatenation in rank order
     rng = np.random.default_rng(1000 + rank)
     n = 20_000 + 1000 * rank
     key = rng.integers(0, 3000, n).astype(np.int64)
     v = rng.integers(-50, 50, n).astype(np.int64)
-    comm0 = bench.DryComm()
-    moved = comm0.exchange_by_key(bench.DryFrame({"key": key, "v": v}), "key")
-    owners = comm0.allgather(bench.DryFrame({"key": np.unique(moved.cols["key"]), "r": np.full(len(np.unique(moved.cols["key"])), rank, np.int64)}))
+    comm0 = dry.DryComm()
+    moved = comm0.exchange_by_key(dry.DryFrame({"key": key, "v": v}), "key")
+    owners = comm0.allgather(dry.DryFrame({"key": np.unique(moved.cols["key"]), "r": np.full(len(np.unique(moved.cols["key"])), rank, np.int64)}))
     assert len(np.unique(owners.cols["key"])) == owners.height, "a key landed on two ranks"
     tot = torch.tensor([moved.height, int(moved.cols["v"].sum())], dtype=torch.int64)
     mine = torch.tensor([n, int(v.sum())], dtype=torch.int64)
@@ -47,12 +49,12 @@ def main():
     off = rank * 10_000_000
     orders["o_orderkey"] = orders["o_orderkey"] + off; li["l_orderkey"] = li["l_orderkey"] + off
     # scatter this rank's lineitem rows so that keys of one order also live on OTHER ranks' probe shards
-    comm = bench.DryComm()
-    allrows = comm.allgather(bench.DryFrame({c: li[c] for c in datagen.LINEITEM_Q3_COLS}))
-    probe = bench.DryFrame({c: np.ascontiguousarray(allrows.cols[c][rank::ws]) for c in datagen.LINEITEM_Q3_COLS})
-    build = bench.DryFrame({c: orders[c] for c in datagen.ORDERS_Q3_COLS})
+    comm = dry.DryComm()
+    allrows = comm.allgather(dry.DryFrame({c: li[c] for c in datagen.LINEITEM_Q3_COLS}))
+    probe = dry.DryFrame({c: np.ascontiguousarray(allrows.cols[c][rank::ws]) for c in datagen.LINEITEM_Q3_COLS})
+    build = dry.DryFrame({c: orders[c] for c in datagen.ORDERS_Q3_COLS})
     date = datagen.us(1995, 3, 15)
-    jops, jspec = bench.DryJoinOps(date), pdist.JoinGroupBySpec("l_orderkey", "o_orderkey", "l_orderkey", [("revenue", "sum")])
+    jops, jspec = dry.DryJoinOps(date), pdist.JoinGroupBySpec("l_orderkey", "o_orderkey", "l_orderkey", [("revenue", "sum")])
     # the numpy double of the local operator against the oracle's q3 on this rank's inputs
     w = orc.q3(probe.cols, build.cols, date)
     g = jops.local(probe, build)
@@ -69,16 +71,16 @@ def main():
     np.savez(os.path.join(out_dir, f"q3_in_rank{rank}.npz"), **{"p_" + c: a for c, a in probe.cols.items()}, **{"b_" + c: a for c, a in build.cols.items()})
     # (g) the frame-level sharded group-by (dist.sharded_groupby: what bench.py --gpus N --workload cfg3 runs): pre-aggregation before the
     # exchange vs raw-row exchange vs the sample-driven choice, with NULL keys (one group, owned by rank 0) and null values; numpy doubles
-    # stand in for the library frames and the RCCL communicator (bench.DryFrame / DryComm / DryOps)
+    # stand in for the library frames and the RCCL communicator (tests/dry_multigpu.py: DryFrame / DryComm / DryOps)
     r3 = np.random.default_rng(4000 + rank)
     m = 30_000 + 700 * rank
     gk = r3.integers(0, 2500, m).astype(np.int64); gk_valid = r3.random(m) > 0.02
     gv = r3.integers(-1000, 1000, m).astype(np.int64); gv_valid = r3.random(m) > 0.1
     gv_valid[gk == 7] = False                                     # a group whose values are ALL null: sum 0, count 0, mean / min null
     gx = r3.uniform(-1, 1, m)
-    shard = bench.DryFrame({"key": gk, "v": gv, "x": gx}, {"key": gk_valid, "v": gv_valid})
+    shard = dry.DryFrame({"key": gk, "v": gv, "x": gx}, {"key": gk_valid, "v": gv_valid})
     spec = pdist.GroupBySpec("key", [("v_sum", "v", "sum"), ("v_count", "v", "count"), ("v_mean", "v", "mean"), ("v_min", "v", "min"), ("x_max", "x", "max"), ("n", "", "len")])
-    comm, fops = bench.DryComm(), bench.DryOps()
+    comm, fops = dry.DryComm(), dry.DryOps()
     save = {"in_key": gk, "in_key_valid": gk_valid, "in_v": gv, "in_v_valid": gv_valid, "in_x": gx}
     for mode in ("preagg", "rows", "auto"):
         comm.rows_sent = comm.bytes_sent = 0
@@ -89,7 +91,7 @@ def main():
             save[f"{mode}_{c}__valid"] = out.validity(c)
         save[f"{mode}_rows_sent"] = np.array([comm.rows_sent]); save[f"{mode}_mode"] = np.array([info["mode"]])
     # a high-cardinality shard (every key distinct): the sample says the local aggregate shrinks nothing -> "auto" must exchange rows
-    uniq = bench.DryFrame({"key": (np.arange(5000, dtype=np.int64) * ws + rank), "v": np.ones(5000, np.int64), "x": np.zeros(5000)})
+    uniq = dry.DryFrame({"key": (np.arange(5000, dtype=np.int64) * ws + rank), "v": np.ones(5000, np.int64), "x": np.zeros(5000)})
     info = {}
     pdist.sharded_groupby(comm, uniq, spec, fops, mode="auto", info=info)
     save["auto_unique_mode"] = np.array([info["mode"]])

@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bench_lines  # noqa: E402
 
 
 @pytest.mark.parametrize("ws", [2, 3])
@@ -149,20 +151,24 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1", "--rows", "120000"],
                        capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["config"]["workload"] == "tpch_q1_sf100_x2" and d["verified"]["ok"] is True
+    head, d = bench_lines.split(r.stdout)
+    # the line the driver parses: SF100 in TOTAL (strong scaling) by default at N > 1, small, and it carries the verdicts of the extras
+    assert head["n_gpus"] == 2 and head["scaling"] == "strong" and head["config"]["workload"] == "tpch_q1_sf100_x2_strong" and head["verified"]["ok"] is True
+    assert "roofline" in head and "extras" not in head and head["extras_file"]
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["config"]["workload"] == "tpch_q1_sf100_x2_strong" and d["verified"]["ok"] is True
     ex = d["extras"]
-    assert set(ex) == {"tpch_q3_sf100_sharded_x2", "tpch_q3_sf100_sharded_x2_shuffle", "cfg3_groupby_1e6_keys_sharded_x2", "cfg5_dict_string_keys_sharded_x2"}, list(ex)
-    qa = ex["tpch_q3_sf100_sharded_x2"]
+    assert set(ex) == {"tpch_q3_sf100_sharded_x2_strong", "tpch_q3_sf100_sharded_x2_shuffle_strong", "cfg3_groupby_1e6_keys_sharded_x2_strong", "cfg5_dict_string_keys_sharded_x2_strong",
+                       "tpch_q1_sf100_x2_weak"}, list(ex)
+    assert set(head["extras_summary"]) == set(ex) and all(v["ok"] is True for v in head["extras_summary"].values())
+    assert ex["tpch_q1_sf100_x2_weak"]["scaling"] == "weak" and ex["tpch_q1_sf100_x2_weak"]["verified"]["ok"] is True
+    qa = ex["tpch_q3_sf100_sharded_x2_strong"]
     assert qa["scaling"] == "strong" and qa["exchange_mode"] == "broadcast" and qa["verified"]["ok"] is True and qa["partial_rows_per_rank"] > 0
-    q3 = ex["tpch_q3_sf100_sharded_x2_shuffle"]
+    q3 = ex["tpch_q3_sf100_sharded_x2_shuffle_strong"]
     assert q3["scaling"] == "strong" and q3["exchange_mode"] == "shuffle" and q3["verified"]["ok"] is True and q3["verified"]["keys_disjoint_across_ranks"] is True
     assert all(p["covers_whole_input"] and p["ok"] for p in q3["verified"]["per_rank"]) and q3["shuffle"]["rows_sent_per_rank_per_step"] > 0
     assert q3["shuffle"]["bytes_sent_per_rank_per_step"] == q3["shuffle"]["rows_sent_per_rank_per_step"] * 32        # four 8-byte columns on either side
-    for w in ("cfg3_groupby_1e6_keys_sharded_x2", "cfg5_dict_string_keys_sharded_x2"):
-        assert ex[w]["verified"]["ok"] is True and ex[w]["scaling"] == "weak", w
+    for w in ("cfg3_groupby_1e6_keys_sharded_x2_strong", "cfg5_dict_string_keys_sharded_x2_strong"):
+        assert ex[w]["verified"]["ok"] is True and ex[w]["scaling"] == "strong", w
 
 
 def test_sharded_groupby_bench_dry_run_prints_a_complete_line():
@@ -181,12 +187,11 @@ def test_sharded_groupby_bench_dry_run_prints_a_complete_line():
     rows = 200_000
     for wl, kdt in (("cfg3", "Int64"), ("cfg5", "UInt32")):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", wl, "--rows", str(rows), "--dry-run"]
+               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", wl, "--rows", str(rows), "--dry-run", "--scaling", "weak"]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
         assert r.returncode == 0, r.stderr[-2000:]
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        assert len(lines) == 1, r.stdout
-        d = json.loads(lines[0])
+        head, d = bench_lines.split(r.stdout)
+        assert all(k in head for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "scaling", "config", "verified")) and head["verified"]["ok"] is True
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "shuffle"):
             assert k in d, k
         assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dry_run"] is True and d["config"]["rows_per_gpu"] == rows
@@ -202,7 +207,7 @@ def test_sharded_groupby_bench_dry_run_prints_a_complete_line():
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg3", "--rows", str(rows), "--dry-run", "--mode", "preagg", "--scaling", "strong"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    _, d = bench_lines.split(r.stdout)
     assert d["exchange_mode"] == "preagg" and d["scaling"] == "strong" and d["verified"]["ok"] is True
     local_groups = [len(np.unique(datagen.uniform_native_host("Int64", 0, rows, 10 + rank, 0, 0, 1_000_000))) for rank in range(2)]
     assert d["partial_rows_per_rank"] in local_groups
@@ -222,11 +227,11 @@ def test_bench_eight_ranks_dry_run_is_quiet_and_complete():
                        capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Traceback" not in r.stderr, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    head, d = bench_lines.split(r.stdout)
+    assert head["n_gpus"] == 8 and head["scaling"] == "strong" and head["config"]["workload"] == "tpch_q1_sf100_x8_strong"
     assert d["n_gpus"] == 8 and d["dry_run"] is True and d["verified"]["ok"] is True
     ex = d["extras"]
-    assert set(ex) == {"tpch_q3_sf100_sharded_x8", "tpch_q3_sf100_sharded_x8_shuffle", "cfg3_groupby_1e6_keys_sharded_x8", "cfg5_dict_string_keys_sharded_x8"}
+    assert set(ex) == {"tpch_q3_sf100_sharded_x8_strong", "tpch_q3_sf100_sharded_x8_shuffle_strong", "cfg3_groupby_1e6_keys_sharded_x8_strong", "cfg5_dict_string_keys_sharded_x8_strong",
+                       "tpch_q1_sf100_x8_weak"}
     assert all(v["verified"]["ok"] is True for v in ex.values())
-    assert ex["tpch_q3_sf100_sharded_x8"]["scaling"] == "strong" and ex["tpch_q3_sf100_sharded_x8_shuffle"]["exchange_mode"] == "shuffle"
+    assert ex["tpch_q3_sf100_sharded_x8_strong"]["scaling"] == "strong" and ex["tpch_q3_sf100_sharded_x8_shuffle_strong"]["exchange_mode"] == "shuffle"

@@ -4,6 +4,7 @@ reference's execution shape), (c) the CPU oracle -- the reference's own engine-p
 (py-polars/tests/unit/streaming/test_streaming_group_by.py:149-196: same query, two executors,
 frame-equal with check_row_order=False).  Integer results bit-exact, float aggregates 1e-6 rel."""
 import math
+import os
 
 import re
 
@@ -705,3 +706,32 @@ def test_float_sums_of_cancelling_values_stay_within_tolerance(pl, orc):
     order = np.argsort(w["key_0"][0])
     assert out["g"] == w["key_0"][0][order].tolist()
     assert np.allclose(np.array(out["s"]), w["s"][0][order], rtol=RTOL, atol=0) and np.allclose(np.array(out["m"]), w["m"][0][order], rtol=RTOL, atol=0)
+
+
+def test_bench_multi_gpu_default_run_through_rccl_at_world_size_one(tmp_path):
+    """The WHOLE default N > 1 run of bench.py -- Q1 headline over the all-gather, then sharded Q3 (broadcast and shuffle), cfg3, cfg5 -- on the one GPU of
+    this box through RCCL (PLX_BENCH_FORCE_SHARDED=1: every exchange is a self-exchange), at small sizes: the code the driver's 2/4/8-GPU runs execute is
+    exercised by `pytest -m gpu` every round.  The communicator must span exactly the ranks the environment names (ncclCommCount through plx_comm_info), every
+    workload must be verified against the oracle, and the line the driver parses must be the small one."""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bench_lines
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(PLX_BENCH_FORCE_SHARDED="1", PLX_BENCH_EXTRAS_FILE=str(tmp_path / "extras.json"), MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    try:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--rows", "400000"], capture_output=True, text=True, timeout=420, cwd=root, env=env)
+    except subprocess.TimeoutExpired as e:
+        err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+        pytest.skip("the RCCL run did not finish within 420 s (seen on freshly provisioned boxes: ncclCommInitRank not returning); last lines: " + " | ".join(err.strip().splitlines()[-3:]))
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    head, full = bench_lines.split(r.stdout)
+    assert head["comm"] == {"rank": 0, "world_size": 1, "env_world_size": 1, "library": "rccl"}
+    assert head["n_gpus"] == 1 and head["verified"]["ok"] is True and head["roofline"]["frac"] > 0
+    ex = full["extras"]
+    assert {k.split("_sharded")[0].split("_x1")[0] for k in ex} == {"tpch_q3_sf100", "cfg3_groupby_1e6_keys", "cfg5_dict_string_keys"}, list(ex)
+    assert len(ex) == 4 and all("error" not in v and v["verified"]["ok"] is True for v in ex.values()), {k: v.get("error") or v.get("verified") for k, v in ex.items()}
+    assert {v.get("exchange_mode") for k, v in ex.items() if k.startswith("tpch_q3")} == {"broadcast", "shuffle"}
+    assert json.load(open(tmp_path / "extras.json"))["extras"].keys() == ex.keys()
