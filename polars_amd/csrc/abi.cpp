@@ -840,6 +840,7 @@ int plx_describe_fusion(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, 
     d += "] in_dtype=[";
     for (int i = 0; i < sh.n_inputs; i++) d += std::to_string(sh.in_dtype[i]) + (sh.in_nullable[i] ? "?" : "") + ",";
     d += "]";
+    if (sh.n_keys) { d += " keys=["; for (int i = 0; i < sh.n_keys; i++) d += std::to_string(sh.keys[i]) + ","; d += "]"; }     // a wide (multi-column) key: one slot per key column
     return d;
   };
   std::string why;

@@ -115,9 +115,10 @@ static Buf dev_alloc_impl(size_t bytes, bool transient) {
     std::lock_guard<std::mutex> lk(g_pool.mu);
     auto it = g_pool.free_blocks.lower_bound(cap);
     // exact class below 2 MiB; best fit within +25% above (large blocks rarely repeat their exact size).  A TRANSIENT request (a query's record pool: gone when
-    // the query returns) takes the smallest cached block that holds it, however much larger: mapping fresh memory costs ~30 ms per GB (hipMalloc), and the block
-    // goes back to the cache in a moment
-    if (it != g_pool.free_blocks.end() && (it->first == cap || (cap > (size_t(1) << 21) && (it->first <= cap + cap / 4 || (transient && cap >= (size_t(64) << 20)))))) {
+    // the query returns) takes the smallest cached block that holds it up to FOUR times its size: mapping fresh memory costs ~30 ms per GB (hipMalloc), and the
+    // block goes back to the cache in a moment.  Not beyond: a 64 MB record pool that checked out the 26 GB reserved block would leave the next large transient of
+    // the same query to map fresh memory after all (and count 26 GB as in use).
+    if (it != g_pool.free_blocks.end() && (it->first == cap || (cap > (size_t(1) << 21) && (it->first <= cap + cap / 4 || (transient && cap >= (size_t(64) << 20) && it->first / 4 <= cap))))) {
       reused = it->second; p = reused.ptr; cap = it->first; g_pool.free_blocks.erase(it); g_pool.cached -= cap;
     }
     over = g_pool.cached > dev.hbm_bytes / 2;
@@ -136,7 +137,8 @@ static Buf dev_alloc_impl(size_t bytes, bool transient) {
     hipError_t e = hipMalloc(&p, cap);
     if (trace) fprintf(stderr, "[plx pool] hipMalloc %.1f MB%s: %.2f ms\n", cap / 1048576.0, transient ? " (transient)" : "", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e != hipSuccess) {
-      pool_trim();
+      (void)hipGetLastError();
+      pool_trim(true);       // out of memory: every cached block goes back to the driver, the reserved one (plx_memory_reserve) included
       e = hipMalloc(&p, cap);
       if (e != hipSuccess) fail(PLX_ERR_OOM, "hipMalloc(" + std::to_string(cap) + ") failed: " + hipGetErrorString(e));
     }
@@ -169,12 +171,13 @@ void pool_stats(uint64_t* in_use, uint64_t* high_water) {
   if (in_use) *in_use = g_pool.in_use;
   if (high_water) *high_water = g_pool.high;
 }
-void pool_trim() {
+void pool_trim(bool force) {
   if (!device_ready()) return;
   (void)hipStreamSynchronize(stream());
   std::lock_guard<std::mutex> lk(g_pool.mu);
-  // the reserved block (plx_memory_reserve) survives: the smallest cached block that is at least that large
-  auto keep = g_pool.reserve ? g_pool.free_blocks.lower_bound(g_pool.reserve) : g_pool.free_blocks.end();
+  // the reserved block (plx_memory_reserve) survives an ordinary trim: the smallest cached block that is at least that large.  `force` (the allocator ran out of
+  // device memory) releases it too: idle cached memory must never be the reason a request fails.
+  auto keep = (g_pool.reserve && !force) ? g_pool.free_blocks.lower_bound(g_pool.reserve) : g_pool.free_blocks.end();
   std::pair<size_t, FreeBlock> kept{0, FreeBlock{nullptr, nullptr, nullptr}};
   for (auto it = g_pool.free_blocks.begin(); it != g_pool.free_blocks.end(); ++it) {
     auto& kv = *it;

@@ -94,7 +94,7 @@ Buf dev_alloc_transient(size_t bytes);     // a query's big scratch buffer (reco
 void pool_reserve(size_t bytes);           // make sure the cache holds a free block of at least `bytes`
 Buf dev_borrow(void* p, size_t bytes);
 void pool_stats(uint64_t* in_use, uint64_t* high_water);
-void pool_trim();
+void pool_trim(bool force = false);   // force: the reserved block (pool_reserve) is released as well
 
 // --------------------------------------------------------------- columns ----
 struct Column {

@@ -735,7 +735,11 @@ static int64_t run_hash_agg(const Shape& sh, const Args& args, int static_id, in
   return compact_into(keys->as<uint64_t>(), acc->as<uint64_t>(), slots, (int64_t)cap, sh.n_aggs, -1, out);
 }
 
-static int64_t run_wide_agg(const Shape& sh, const Args& args, int log2_cap, bool nullable, FusedAggResult& out, bool count_only) {
+static Args offset_args(const Shape& sh, const Args& a, int64_t row0, int64_t rows);
+// `sample_blocks` > 0 (the planner's distinct-count sample; count_only): only that many evenly spaced blocks of args.n_rows / ... rows are aggregated -- `sample_rows` in
+// all -- instead of the whole input: a prefix says nothing about clustered or sorted data (it undercounts, and the partitioned path then runs into full LDS tables).
+// Blocks stay below the JIT threshold, so the sample runs the interpreter: no run-time compilation for a pass over a million rows.
+static int64_t run_wide_agg(const Shape& sh, const Args& args, int log2_cap, bool nullable, FusedAggResult& out, bool count_only, int sample_blocks = 0, int64_t sample_rows = 0) {
   const uint64_t cap = 1ull << log2_cap;
   const int nw = sh.n_keys + (nullable ? 1 : 0);
   Buf tags = dev_alloc(sizeof(uint64_t) * cap);
@@ -747,7 +751,13 @@ static int64_t run_wide_agg(const Shape& sh, const Args& args, int log2_cap, boo
   WideTable t; t.tags = tags->as<unsigned long long>(); t.words = words->as<unsigned long long>(); t.acc = acc->as<unsigned long long>();
   t.overflow = ovf->as<unsigned int>(); t.log2_cap = (uint32_t)log2_cap; t.max_probe = (uint32_t)std::min<uint64_t>(cap, 1u << 14);
   t.n_words = (uint32_t)nw; t.has_null_word = nullable ? 1u : 0u;
-  k::fused_wide_agg(sh, args, t);
+  if (sample_blocks > 0) {
+    const int64_t n = args.n_rows, per = (sample_rows / sample_blocks) & ~(int64_t)127, stride = (n / sample_blocks) & ~(int64_t)127;
+    for (int b = 0; b < sample_blocks; b++) {
+      const int64_t row0 = (int64_t)b * stride, rows = std::min<int64_t>(per, n - row0);
+      if (rows > 0) k::fused_wide_agg(sh, offset_args(sh, args, row0, rows), t);
+    }
+  } else k::fused_wide_agg(sh, args, t);
   uint32_t o = 0; d2h_sync(&o, ovf->ptr, 4);
   if (o) return -1;
   int64_t g = k::wide_compact(t, sh.n_keys, sh.n_aggs, 0, nullptr, nullptr, nullptr);
@@ -969,9 +979,9 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     std::vector<uint64_t> hot;
     const bool may_partition = !(c.plan.flags & PLX_PLAN_NO_PARTITION) && n >= ((int64_t)1 << 24);
     const bool strided = may_partition && !kp.wide && part_version() == 2;
-    const int64_t Sd = strided ? kPartSampleRows : S;
+    const int64_t Sd = strided || kp.wide ? kPartSampleRows : S;
     double g_est = -1.0;
-    int64_t d = kp.wide ? run_wide_agg(sh, sa, 23, kp.wide_nullable, tmp, true)
+    int64_t d = kp.wide ? run_wide_agg(sh, args, 21, kp.wide_nullable, tmp, true, kSampleBlocks, Sd)
                         : (strided ? sample_keys_cached(plain_key_column(c, kp), sh, args, static_id, len_idx, Sd, hot_keys_enabled() ? &hot : nullptr, &g_est, desc)
                                    : run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true));
     double G = d < 0 ? 1e18 : (g_est >= 0.0 ? g_est : estimate_groups((double)d, (double)Sd));
@@ -992,16 +1002,18 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
         std::string pd;
         Buf ok, okv, oacc;
         int64_t stride = 0;
-        const int64_t g = k::partitioned_agg2(sh, args, p2, -1, {}, &ok, &okv, &oacc, &pd, nullptr, &stride);
+        const int64_t g = k::partitioned_agg2(sh, args, p2, static_id, {}, &ok, &okv, &oacc, &pd, nullptr, &stride);
         if (g >= 0) {
           res.n_groups = g; res.n_aggs = sh.n_aggs; res.wide_words = ok; res.wide_valid = okv; res.wide_stride = stride; res.acc = oacc;
-          desc += std::string("fused_scan[") + jit::program_mode(-1, args.n_rows) + "]+" + pd;
+          desc += std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+" + pd;
           return;
         }
         if (g == -2) { desc += "v2-unavailable+"; break; }
         desc += "lds-overflow(P=" + std::to_string(1u << p2.log2_parts) + ")+";
         if (p2.log2_parts >= 9) break;
-        plan_for = std::max(plan_for * 2.0, (double)((uint64_t)p2.n_slots << p2.log2_parts) * 1.01);
+        // a table filled up: the sample undercounted (clustered keys).  One more attempt at the LARGEST plan (512 partitions); if that overflows too the HBM table takes over --
+        // never a ladder of full scatter + aggregate passes over all rows
+        plan_for = std::max(plan_for * 2.0, (double)((uint64_t)p2.n_slots << 9) * 0.8);
       }
     }
     if (!kp.wide && !(c.plan.flags & PLX_PLAN_NO_PARTITION) && G >= 4096.0 && n >= ((int64_t)1 << 24)) {

@@ -68,8 +68,22 @@ std::vector<std::string> compile_options() {
           "-I" + include_dir(), "-I/opt/rocm/include", "-I" + resource_include()};
 }
 
+uint64_t fnv1a(const std::string& s, uint64_t h = 0xcbf29ce484222325ull) { for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ull; } return h; }
+
+// Every run-time-compiled kernel gets a symbol of its own: plx_jit_<kind>_<sink number>_<8 hex digits of the program shape>.  Tracers (rocprofv3 --kernel-trace /
+// --pmc) key their rows by symbol: under one shared name the scatter and the aggregation pass of a partitioned group-by were one row of the statistics.
+std::string kernel_symbol(const Shape& sh, Sink sink) {
+  std::string key((const char*)&sh, sizeof(Shape));
+  key.push_back((char)sink);
+  char out[96];
+  snprintf(out, sizeof out, "plx_jit_%s_%d_%08x", sink_type(sink), (int)sink, (unsigned)(fnv1a(key) & 0xffffffffu));
+  return out;
+}
+
 std::string source_for(const Shape& sh, Sink sink) {
   std::ostringstream o;
+  const std::string sym = kernel_symbol(sh, sink);
+  o << "#define plx_jit_kernel " << sym << "\n";
   o << (sink >= PART3_SCATTER ? "#include \"partition3_device.hpp\"\n" : sink >= PART2_SCATTER_HASH ? "#include \"partition2_device.hpp\"\n" : sink >= PART_COUNT ? "#include \"partition_device.hpp\"\n" : "#include \"fused_sinks.hpp\"\n") << "namespace plx { namespace k {\n"
        "struct JitProg {\n  static constexpr bool kStatic = true; static constexpr int kId = -2;\n  static constexpr Shape shape() {\n    Shape s{};\n";
   o << "    s.n_inputs = " << (int)sh.n_inputs << "; s.n_ops = " << (int)sh.n_ops << "; s.n_aggs = " << (int)sh.n_aggs << "; s.pred = " << (int)sh.pred
@@ -140,7 +154,6 @@ bool enabled(int64_t n_rows) {
 // A shape without an AOT kernel costs 260-290 ms of hiprtc per process; the code object only depends on the generated source, the
 // compile options and the device headers, so it is kept in $PLX_JIT_CACHE_DIR (default ~/.cache/polars_amd/jit; PLX_JIT_CACHE=0
 // disables it) under a hash of exactly those inputs.  A cold process then loads the kernel in ~1 ms.
-uint64_t fnv1a(const std::string& s, uint64_t h = 0xcbf29ce484222325ull) { for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ull; } return h; }
 std::string cache_dir() {
   const char* off = getenv("PLX_JIT_CACHE");
   if (off && off[0] == '0') return "";
@@ -202,7 +215,7 @@ Entry compile(const Shape& sh, Sink sink) {
   const std::string cpath = cache_path(src);
   {
     std::vector<char> cached;
-    if (load_cached(cpath, &cached) && hipModuleLoadData(&e.mod, cached.data()) == hipSuccess && hipModuleGetFunction(&e.fn, e.mod, "plx_jit_kernel") == hipSuccess) {
+    if (load_cached(cpath, &cached) && hipModuleLoadData(&e.mod, cached.data()) == hipSuccess && hipModuleGetFunction(&e.fn, e.mod, kernel_symbol(sh, sink).c_str()) == hipSuccess) {
       g_cache_hits++; g_compiled++;      // stats(): specialised kernels made available, compiled or loaded
       if (getenv("PLX_JIT_VERBOSE")) fprintf(stderr, "[plx jit] %s: loaded from %s\n", sink_type(sink), cpath.c_str());
       return e;
@@ -229,7 +242,7 @@ Entry compile(const Shape& sh, Sink sink) {
   std::vector<char> code(cs);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
-  if (hipModuleLoadData(&e.mod, code.data()) != hipSuccess || hipModuleGetFunction(&e.fn, e.mod, "plx_jit_kernel") != hipSuccess) { e.failed = true; return e; }
+  if (hipModuleLoadData(&e.mod, code.data()) != hipSuccess || hipModuleGetFunction(&e.fn, e.mod, kernel_symbol(sh, sink).c_str()) != hipSuccess) { e.failed = true; return e; }
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   g_compiled++; g_ms += ms;
   if (getenv("PLX_JIT_VERBOSE")) fprintf(stderr, "[plx jit] %s: %.0f ms, %zu bytes\n", sink_type(sink), ms, cs);

@@ -277,8 +277,9 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
     // make the scatter faster (its per-round cost is per partition: 256 partitions of 16-byte records move two lines per partition and round, 512 one), so the
     // smallest partition count whose tables stay at or below a load of 0.85 x the caller's padded estimate (it passes 1.3 x its own: a real load of ~0.65).
     pp.wide_null_word = wide && shape_may_have_nulls(sh) ? 1u : 0u;
-    const size_t slot_words = wide ? 1 + (size_t)sh.n_keys + pp.wide_null_word + (size_t)sh.n_aggs : 1 + (size_t)sh.n_aggs;      // wide: state word + key words (+ null mask) + cells
-    const uint32_t n_slots = (uint32_t)std::min<size_t>((144 * 1024) / (8 * slot_words) - 2, (size_t)1 << 14);
+    // wide: a 32-bit tag + key words (+ null mask) + cells per slot, slots in buckets of four tags
+    const size_t slot_bytes = wide ? 4 + 8 * ((size_t)sh.n_keys + pp.wide_null_word + (size_t)sh.n_aggs) : 8 * (1 + (size_t)sh.n_aggs);
+    const uint32_t n_slots = wide ? (uint32_t)std::min<size_t>(((144 * 1024) / slot_bytes) & ~(size_t)3, (size_t)1 << 14) : (uint32_t)std::min<size_t>((144 * 1024) / slot_bytes - 2, (size_t)1 << 14);
     if (n_slots < 256) return false;
     const double per_part = (double)n_slots * 0.85;
     uint32_t lp = 6;
@@ -426,7 +427,8 @@ __global__ __launch_bounds__(kBlock) void hot_emit_kernel(const unsigned long lo
 #define PLX_P3_COMBOS(X)                                                                                                              \
   X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow)                                      \
   X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackFused) \
-  X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackNone)
+  X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackNone)                              \
+  X(SHAPE_GB2_SUM_CNT_I64, kP2Hash, 1, kPackNarrow) X(SHAPE_GB2_SUM_CNT_I64, kP2Hash, 1, kPackNone)       /* two-column key at 512 partitions: 20- / 24-byte records, one 2048-row tile */
 // ... and with the hot-key path compiled in (skewed keys: heavy hitters are summed in the scatter), for config 3's two runs -- key range unknown / known
 #define PLX_P3_HOT_COMBOS(X) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 3, kPackFused)
 #else
@@ -582,7 +584,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   if (wide_stride_out) *wide_stride_out = (int64_t)ap.max_groups;
   {
     ProfileScope ps(agg_name.c_str(), (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
-    const size_t lds = n_slots * 8 * ((direct ? 0 : wide ? 1 + sh.n_keys + pp.wide_null_word : 1) + sh.n_aggs);
+    const size_t lds = wide ? n_slots * (4 + 8 * ((size_t)sh.n_keys + pp.wide_null_word + sh.n_aggs)) : n_slots * 8 * ((direct ? 0 : 1) + sh.n_aggs);
     if (!use_jit && gen3) part3_static_agg(static_id, pp, ap, NP, lds);
     else if (use_jit) {
       PartPlan2 ppc = pp; AggParams2 apc = ap;

@@ -420,6 +420,7 @@ __global__ __launch_bounds__(kP2MaxBlock) void part2_scatter_kernel(Shape dsh, A
 
 // ---- the aggregation kernel --------------------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(4))) RecWords3 { unsigned int a, b, c; };
+struct __attribute__((packed, aligned(4))) RecWords4 { unsigned int a, b, c, d; };
 template <uint32_t RW>
 __device__ __forceinline__ void load_rec2(const unsigned int* p, unsigned int* r) {
   if constexpr (RW == 4) { const uint4 v = *reinterpret_cast<const uint4*>(p); r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
@@ -432,8 +433,16 @@ __device__ __forceinline__ void load_rec2(const unsigned int* p, unsigned int* r
 #pragma unroll
     for (uint32_t w = 0; w < RW; w += 2) { const uint2 v = *reinterpret_cast<const uint2*>(p + w); r[w] = v.x; r[w + 1] = v.y; }
   } else {
+    // an odd number of dwords (20-byte wide-key records: five): the record is only 4-byte aligned, which a global_load_dwordx4 / x3 does not mind -- two load
+    // instructions per record instead of five (the memory pipeline takes a wave-load every few dozen cycles whatever its width)
+    uint32_t w = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < RW; w++) r[w] = p[w];
+    for (; w + 4 <= RW; w += 4) { const RecWords4 v = *reinterpret_cast<const RecWords4*>(p + w); r[w] = v.a; r[w + 1] = v.b; r[w + 2] = v.c; r[w + 3] = v.d; }
+    if constexpr (RW % 4 == 3) { const RecWords3 v = *reinterpret_cast<const RecWords3*>(p + w); r[w] = v.a; r[w + 1] = v.b; r[w + 2] = v.c; }
+    else {
+#pragma unroll
+      for (uint32_t x = RW / 4 * 4; x < RW; x++) r[x] = p[x];
+    }
   }
 }
 
@@ -448,18 +457,19 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   constexpr uint32_t kPerLane = kP2ChunkRecs / 64;    // records of a chunk per lane
   const bool direct = MODE == (int)kP2Direct;
   const uint32_t NS = direct ? 1u << pp.log2_slots : pp.n_slots, n_aggs = sh.n_aggs, RW = L.rec_words, chunk_dw = kP2ChunkRecs * RW;
-  // wide key (L.n_key_cols != 0, hash mode): state [NS] u64 (kEmptyKey | hash | hash + busy bit) | key words [KW][NS] u64 | cells [NS][n_aggs]; no special slots
-  // (a null key column is part of the key: its bit of the null mask is hashed and compared)
+  // wide key (L.n_key_cols != 0, hash mode): tags [NS] u32 (0 = empty | tag | tag + busy bit; NS a multiple of four: buckets of four tags) | key words [KW][NS] u64 |
+  // cells [NS][n_aggs]; no special slots (a null key column is part of the key: its bit of the null mask is hashed and compared)
   const bool wide = !direct && L.n_key_cols != 0;
   const uint32_t KW = wide ? (uint32_t)L.n_key_cols + (pp.wide_null_word ? 1u : 0u) : 0u;
   unsigned long long* keys = p2_lds;                                    // hash mode: [NS + 2] (NS = null key, NS + 1 = the key equal to EMPTY)
-  unsigned long long* kwords = keys + NS;                               // wide: [KW][NS]
+  unsigned long long* kwords = keys + NS / 2;                           // wide: [KW][NS], behind the NS 32-bit tags
   unsigned long long* cells = direct ? p2_lds : wide ? kwords + (size_t)KW * NS : keys + NS + 2;          // [(NS (+2)) * n_aggs]
   const uint32_t n_slots = (direct || wide) ? NS : NS + 2;
   __shared__ unsigned int n_occ, cursor_l, full;
   __shared__ unsigned long long gbase;
   const uint32_t p = blockIdx.x;
-  if (!direct) for (uint32_t i = threadIdx.x; i < n_slots; i += blockDim.x) keys[i] = kEmptyKey;
+  if (wide) { for (uint32_t i = threadIdx.x; i < NS; i += blockDim.x) reinterpret_cast<unsigned int*>(p2_lds)[i] = 0u; }
+  else if (!direct) for (uint32_t i = threadIdx.x; i < n_slots; i += blockDim.x) keys[i] = kEmptyKey;
   for (uint32_t i = threadIdx.x; i < n_slots * n_aggs; i += blockDim.x) cells[i] = agg_identity_dev(sh.aggs[i % n_aggs].kind);
   if (threadIdx.x == 0) { n_occ = 0; cursor_l = 0; full = 0; }
   __syncthreads();
@@ -509,19 +519,38 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
       }
     }
   };
-  // wide keys: slot protocol kEmptyKey -> hash | busy (CAS) -> hash; the claimer writes the key words, then publishes the hash (LDS operations of a wave
-  // complete in order, so a reader that sees the published hash sees the words); a lane that meets a busy slot looks again in the next round of the loop
-  // -- never a spin inside a round: the claimer may be a lane of the same wave
-  constexpr unsigned long long kBusy = 1ull;
+  // wide keys: a table of 32-bit TAGS in buckets of four (one 16-byte LDS read looks at four slots), key words and cells behind it.  Slot protocol on the tag word:
+  // 0 (empty) -> tag | busy (CAS) -> tag; the claimer writes the key words, then publishes the tag (LDS operations of a wave complete in order, so a reader that
+  // sees the published tag sees the words); a lane that meets a busy slot with its own tag looks again in the next round -- never a spin inside a round: the
+  // claimer may be a lane of the same wave.  A key sits at the first position of its probe sequence (bucket by bucket, position by position) that was empty when
+  // it arrived; nothing is ever removed, so a search may stop at the first empty position.
+  constexpr unsigned int kBusy = 1u;
+  unsigned int* tags = reinterpret_cast<unsigned int*>(p2_lds);
   auto process_wide = [&](unsigned int (*cur)[16], uint32_t cnt_cur) __attribute__((always_inline)) {
     uint32_t slot[kPerLane];
-    unsigned long long tag[kPerLane];
-    bool live[kPerLane], found[kPerLane];
+    unsigned int tag[kPerLane], st[kPerLane];
+    bool live[kPerLane], found[kPerLane], cand[kPerLane];
+    // one probe step: the bucket of `slot` in one read; the first position at or behind `slot` that is empty or carries the tag (busy or not) is a candidate
+    auto probe = [&](uint32_t u, const uint4& q) __attribute__((always_inline)) {
+      const uint32_t t = tag[u];
+      uint32_t m = (uint32_t)(q.x == 0u || (q.x & ~kBusy) == t) | ((uint32_t)(q.y == 0u || (q.y & ~kBusy) == t) << 1) | ((uint32_t)(q.z == 0u || (q.z & ~kBusy) == t) << 2) |
+                   ((uint32_t)(q.w == 0u || (q.w & ~kBusy) == t) << 3);
+      m &= 0xfu << (slot[u] & 3u);
+      if (m) {
+        const uint32_t i = (uint32_t)__builtin_ctz(m);
+        slot[u] = (slot[u] & ~3u) + i;
+        st[u] = i == 0 ? q.x : i == 1 ? q.y : i == 2 ? q.z : q.w;
+        cand[u] = true;
+      } else {
+        slot[u] = (slot[u] & ~3u) + 4u;
+        if (slot[u] >= NS) slot[u] = 0;
+      }
+    };
 #pragma unroll
     for (uint32_t u = 0; u < kPerLane; u++) {
       const uint32_t i = (uint32_t)lane + u * 64u;
-      live[u] = i < cnt_cur; found[u] = !live[u];
-      slot[u] = 0; tag[u] = 0;
+      live[u] = i < cnt_cur; found[u] = !live[u]; cand[u] = false;
+      slot[u] = 0; tag[u] = 0; st[u] = 0;
       if (!live[u]) continue;
       const unsigned int* rec = cur[u];
       const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
@@ -530,43 +559,52 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
       for (int j = 0; j < kMaxKeys; j++) w[j] = j < (int)L.n_key_cols ? ((uint64_t)rec[2 * j] | ((uint64_t)rec[2 * j + 1] << 32)) : 0ull;
       const uint32_t nullmask = ((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u);
       const uint64_t h = wide_key_hash(w, L.n_key_cols, nullmask);
-      tag[u] = h & ~kBusy;                                                              // busy bit clear: never the EMPTY pattern itself ...
-      if ((tag[u] | kBusy) == kEmptyKey) tag[u] ^= 2ull;                                // ... nor EMPTY once the busy bit is set
-      slot[u] = (uint32_t)((((h << pp.log2_parts) >> 32) * (uint64_t)NS) >> 32);        // the partition consumed the hash's top bits
+      uint32_t t31 = (uint32_t)h & 0x7fffffffu;                                           // the partition took the hash's top bits, the bucket takes the ones below: the tag is the low end
+      if (!t31) t31 = 1u;
+      tag[u] = t31 << 1;                                                                   // never 0 (empty), busy bit clear
+      slot[u] = (uint32_t)((((h << pp.log2_parts) >> 32) * (uint64_t)(NS >> 2)) >> 32) << 2;
     }
     if (pp.ablate & 8u) {
 #pragma unroll
       for (uint32_t u = 0; u < kPerLane; u++) found[u] = true;
     }
-    // Slot search.  The pass is bound by the instructions it issues (sixteen waves share four 16-lane SIMDs) and a wave walks as long as its longest probe sequence
-    // (a dozen slots at load 0.5), so the walk itself is a per-lane loop of one state read and two compares; what is heavy or rare -- claiming an empty slot,
-    // comparing key words on a hash match, a slot whose words are still being written -- happens once per round behind it, and a second round is the exception.
-    // (Measured, 1e9 records of a two-column key: with one loop that did everything per probe step the search was 15 of the pass's 18.5 ms.)
+    // Slot search.  The pass is bound by the instructions it issues (sixteen waves share four 16-lane SIMDs) and a wave walks as long as its longest lane, so (a) a
+    // probe step covers four slots, (b) the first step of the lane's four records is issued together (four reads in flight), (c) what is heavy or rare -- claiming an
+    // empty slot, comparing key words on a tag match, a slot whose words are still being written -- happens once per round behind the walk.  At a load of 0.5 nineteen
+    // searches in twenty end in their first bucket.  (Round 4: a table of 64-bit hash words walked slot by slot, the lane's records one after the other: the search
+    // was 8 of the pass's 11.5 ms at 1e9 records of a two-column key.)
+    {
+      uint4 q[kPerLane];
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) q[u] = *reinterpret_cast<const uint4*>(&tags[found[u] ? 0u : slot[u]]);
+      lds_order();
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) if (!found[u]) probe(u, q[u]);
+    }
     for (uint32_t round = 0;; round++) {
       bool all = true;
 #pragma unroll
       for (uint32_t u = 0; u < kPerLane; u++) all = all && found[u];
       if (__all(all)) break;
-      if (round >= 4u * NS + 64u) { full = 1; break; }                                   // (slots that stay busy: cannot happen; the pass reports a full table)
-      unsigned long long st[kPerLane];
+      if (round >= NS + 64u) { full = 1; break; }                                         // (slots that stay busy: cannot happen; the pass reports a full table)
 #pragma unroll
       for (uint32_t u = 0; u < kPerLane; u++) {
-        st[u] = kEmptyKey;
         if (found[u]) continue;
-        for (uint32_t n = 0;; n++) {
-          st[u] = lds_ld(&keys[slot[u]]);
-          if (st[u] == kEmptyKey || (st[u] & ~kBusy) == tag[u]) break;
-          if (n >= NS) { full = 1; found[u] = true; live[u] = false; break; }           // every slot holds another key: a full table (the caller plans more partitions)
-          slot[u] = slot[u] + 1 == NS ? 0u : slot[u] + 1;
+        for (uint32_t n = 0; !cand[u]; n++) {
+          if (n >= (NS >> 2) + 1u) { full = 1; found[u] = true; live[u] = false; break; }   // every slot holds another key: a full table (the caller plans more partitions)
+          const uint4 q = *reinterpret_cast<const uint4*>(&tags[slot[u] & ~3u]);
+          lds_order();
+          probe(u, q);
         }
       }
-      lds_order();                                                                         // key words are read AFTER the state that announces them
+      lds_order();                                                                         // key words are read AFTER the tag that announces them
 #pragma unroll
       for (uint32_t u = 0; u < kPerLane; u++) {
         if (found[u]) continue;
         const unsigned int* rec = cur[u];
-        if (st[u] == kEmptyKey) {
-          if (atomicCAS(&keys[slot[u]], (unsigned long long)kEmptyKey, tag[u] | kBusy) == kEmptyKey) {
+        cand[u] = false;
+        if (st[u] == 0u) {
+          if (atomicCAS(&tags[slot[u]], 0u, tag[u] | kBusy) == 0u) {
 #pragma unroll
             for (int j = 0; j < kMaxKeys; j++)
               if (j < (int)L.n_key_cols) lds_st(&kwords[(size_t)j * NS + slot[u]], (unsigned long long)((uint64_t)rec[2 * j] | ((uint64_t)rec[2 * j + 1] << 32)));
@@ -574,12 +612,12 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
               const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
               lds_st(&kwords[(size_t)L.n_key_cols * NS + slot[u]], (unsigned long long)(((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u)));
             }
-            lds_order();                                                                   // the words first, then the state that announces them
-            lds_st(&keys[slot[u]], tag[u]);
+            lds_order();                                                                   // the words first, then the tag that announces them
+            lds_st(&tags[slot[u]], tag[u]);
             found[u] = true;
           }
-          // lost the race: the winner's word in the next round, same slot
-        } else if (st[u] == tag[u]) {                                                      // published, the same hash: compare the key words
+          // lost the race: the winner's tag in the next round, same position
+        } else if (st[u] == tag[u]) {                                                      // published, the same tag: compare the key words
           bool same = true;
 #pragma unroll
           for (int j = 0; j < kMaxKeys; j++)
@@ -589,9 +627,9 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
             same = same && lds_ld(&kwords[(size_t)L.n_key_cols * NS + slot[u]]) == (unsigned long long)(((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u));
           }
           if (same) found[u] = true;
-          else slot[u] = slot[u] + 1 == NS ? 0u : slot[u] + 1;                           // same hash, another key: the walk goes on next round
+          else { slot[u] = slot[u] + 1 == NS ? 0u : slot[u] + 1; }                       // the same tag, another key: the walk goes on behind it
         }
-        // (the same hash, busy: its key words are being written -- the same slot again next round)
+        // (the same tag, busy: its key words are being written -- the same position again next round)
       }
     }
 #pragma unroll
@@ -718,14 +756,14 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   if (full) { if (threadIdx.x == 0) atomicExch(ap.overflow, 1u); return; }
   // emit the partition's groups: count, reserve once, write
   uint32_t mine = 0;
-  for (uint32_t s = threadIdx.x; s < n_slots; s += blockDim.x) mine += direct ? (cells[(size_t)s * n_aggs + pp.len_idx] != 0) : (keys[s] != kEmptyKey);
+  for (uint32_t s = threadIdx.x; s < n_slots; s += blockDim.x) mine += direct ? (cells[(size_t)s * n_aggs + pp.len_idx] != 0) : wide ? (tags[s] != 0u) : (keys[s] != kEmptyKey);
   if (mine) atomicAdd(&n_occ, mine);
   __syncthreads();
   if (threadIdx.x == 0) gbase = n_occ ? atomicAdd(ap.counter, (unsigned long long)n_occ) : 0ull;
   __syncthreads();
   if (gbase + n_occ > ap.max_groups) { if (threadIdx.x == 0) atomicExch(ap.overflow, 2u); return; }
   for (uint32_t s = threadIdx.x; s < n_slots; s += blockDim.x) {
-    if (direct ? (cells[(size_t)s * n_aggs + pp.len_idx] == 0) : (keys[s] == kEmptyKey)) continue;
+    if (direct ? (cells[(size_t)s * n_aggs + pp.len_idx] == 0) : wide ? (tags[s] == 0u) : (keys[s] == kEmptyKey)) continue;
     const uint64_t o = gbase + atomicAdd(&cursor_l, 1u);
     if (direct) { ap.out_keys[o] = pp.interleave ? (((uint64_t)s << pp.log2_parts) | p) : (((uint64_t)p << pp.key_shift) | s); ap.out_kvalid[o] = 1; }
     else if (wide) {       // key words and per-column valid flags, column-major with stride max_groups (the layout of the HBM-table path's result: FusedAggResult::wide_words / wide_valid)

@@ -26,6 +26,11 @@ def cfg3(lf):
     return lf.group_by("key").agg(E.col("v").sum().alias("v_sum"), E.col("v").count().alias("v_count"))
 
 
+def cfg3w(lf):
+    """group_by(k1, k2).agg(v.sum(), v.count())  -- config 3 on a two-column (wide) key: the reference row-encodes it (hash_keys.rs:334 RowEncodedKeys)"""
+    return lf.group_by("k1", "k2").agg(E.col("v").sum().alias("v_sum"), E.col("v").count().alias("v_count"))
+
+
 def cfg5(lf):
     """group_by(k).agg(v.sum(), v.mean()) on dictionary-encoded string keys -- BASELINE config 5"""
     return lf.group_by("k").agg(E.col("v").sum().alias("v_sum"), E.col("v").mean().alias("v_mean"))

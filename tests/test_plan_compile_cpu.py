@@ -29,7 +29,7 @@ def test_benchmark_queries_hit_aot_kernels():
     gb = pl.DataFrame([ph("key", pl.Int64), ph("v", pl.Int64)])
     gb5 = pl.DataFrame([ph("k", pl.Categorical([], pl.UInt32), rng=(0, 999_999)), ph("v", pl.Float64)])
     expect = [(Q.cfg2(cfg.lazy()), 0), (Q.cfg2(cfgn.lazy()), 1), (Q.cfg1(cfg.lazy()), 2), (Q.q1(lineitem().lazy()), 3), (Q.cfg3(gb.lazy()), 4),
-              (Q.cfg5(gb5.lazy()), 5)]
+              (Q.cfg5(gb5.lazy()), 5), (Q.cfg3w(pl.DataFrame([ph("k1", pl.Int64), ph("k2", pl.Int64), ph("v", pl.Int64)]).lazy()), 13)]
     for q, sid in expect:
         fusable, got, why, dump = q.describe_fusion()
         assert fusable and got == sid, (sid, got, why, dump)

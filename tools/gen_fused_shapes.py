@@ -55,6 +55,8 @@ def shapes():
         ("SHAPE_Q3F_BUILD", "TPC-H Q3 (three tables) build scan: same predicate, o_orderkey -> row", q3f, 1),
         ("SHAPE_Q3F_SEMI", "TPC-H Q3 (three tables) customer scan: c_mktsegment == code -> membership bitmap over c_custkey", q3f, 3),
         ("SHAPE_Q3_PROBE_SCATTER", "TPC-H Q3 probe side, predicate + key only, row id as payload: the scatter of the partitioned probe (unordered probe keys)", q3, 3),
+        ("SHAPE_GB2_SUM_CNT_I64", "group_by(k1:i64, k2:i64).agg(v.sum(), v.count())  [config 3 on a two-column key: word-by-word LDS tables]",
+         Q.cfg3w(pl.DataFrame([ph("k1", pl.Int64), ph("k2", pl.Int64), ph("v", pl.Int64)]).lazy()), 0),
     ]
 
 
@@ -75,7 +77,9 @@ def parse(dump):
     ops = [tuple(int(v) for v in t.split(",")) for t in re.findall(r"\(([^)]*)\)", m.group(4))]
     aggs = [tuple(int(v) for v in t.split(",")) for t in re.findall(r"\(([^)]*)\)", m.group(5))]
     ind = [t for t in m.group(6).split(",") if t]
-    return n_in, pred, key, ops, aggs, ind
+    mk = re.search(r" keys=\[(.*?)\]", dump)
+    keys = [int(t) for t in mk.group(1).split(",") if t] if mk else []
+    return n_in, pred, key, ops, aggs, ind, keys
 
 
 HEADER = '''// fused_shapes.hpp -- GENERATED by tools/gen_fused_shapes.py; do not edit by hand.
@@ -111,14 +115,16 @@ def main():
     items = shapes()
     for i, (name, doc, _, _) in enumerate(items):
         out.append(f"  {name} = {i},  // {doc}\n")
-    out.append("  kNumStaticShapes\n};\n#define PLX_HAVE_Q3_SHAPES 1\n#define PLX_HAVE_Q3FULL_SHAPES 1\n#define PLX_HAVE_Q3_PROBE_SCATTER 1\n\nPLX_HD constexpr Shape static_shape(int id) {\n  Shape s{};\n  s.pred = kNone;\n  s.key = kNone;\n  switch (id) {\n")
+    out.append("  kNumStaticShapes\n};\n#define PLX_HAVE_Q3_SHAPES 1\n#define PLX_HAVE_Q3FULL_SHAPES 1\n#define PLX_HAVE_Q3_PROBE_SCATTER 1\n#define PLX_HAVE_GB2_SHAPE 1\n\nPLX_HD constexpr Shape static_shape(int id) {\n  Shape s{};\n  s.pred = kNone;\n  s.key = kNone;\n  switch (id) {\n")
     for name, doc, q, which in items:
         ok, sid, why, dump = q.describe_fusion()
         if not ok:
             raise SystemExit(f"{name}: not fusable: {why}")
-        n_in, pred, key, ops, aggs, ind = parse(dump.split("\n")[which])
+        n_in, pred, key, ops, aggs, ind, keys = parse(dump.split("\n")[which])
         out.append(f"    case {name}: {{  // {doc}\n")
         out.append(f"      s.n_inputs = {n_in}; s.n_ops = {len(ops)}; s.n_aggs = {len(aggs)}; s.pred = {pred}; s.key = {key};\n")
+        if keys:
+            out.append(f"      s.n_keys = {len(keys)};" + "".join(f" s.keys[{j}] = {k};" for j, k in enumerate(keys)) + "\n")
         for j, t in enumerate(ind):
             nullable = t.endswith("?")
             out.append(f"      s.in_dtype[{j}] = {int(t.rstrip('?'))}; s.in_nullable[{j}] = {1 if nullable else 0};\n")
