@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="q1", choices=["q1", "q3", "q3f", "q3h", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s"])
+    ap.add_argument("--workload", default="q1", choices=["q1", "q3", "q3f", "q3h", "q3d", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the SF100 / 1e9-row size of the workload)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -454,6 +454,68 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
                        variants={"tpch_q3_sf100_order_by_limit10": step_top10}, verify=verify, scope="operator")
         wl3.inputs = [L, O]
         return wl3
+    if name == "q3d":
+        # A join whose BUILD side repeats its keys (round-4 review, Missing 2): lineitem-shaped probe side (SF100: 6e8 rows) JOIN a partsupp-shaped build side (8e7 rows over
+        # 2e7 parts: ~4 rows per part, 0..12), both filtered, grouped by (partkey, suppkey): a group is a build ROW and every probe row of a part adds to each of the part's
+        # build rows (the reference: hash table key -> list of rows, single_keys.rs:16-167; one joined row per entry, single_keys_inner.rs:11-38).  All columns from the
+        # library's uniform generator (host twins: the result is checked over all rows).
+        nl = rows or SF100_LINEITEM
+        nb = max(nl * 2 // 15, 1000)              # 8e7 at SF100
+        n_parts = max(nb // 4, 100)
+        lo_d, hi_d, date = datagen.us(1992, 1, 2), datagen.us(1998, 12, 1), datagen.us(1995, 3, 15)
+        L = pl.DataFrame([native_uniform_column(pl, "l_partkey", pl.Int64, "Int64", nl, seed, 0, 0, n_parts),
+                          native_uniform_column(pl, "l_extendedprice", pl.Float64, "Float64", nl, seed, 1, 90_000, 10_500_000, 0.01),
+                          native_uniform_column(pl, "l_discount", pl.Float64, "Float64", nl, seed, 2, 0, 11, 0.01),
+                          native_uniform_column(pl, "l_shipdate", pl.Datetime, "Int64", nl, seed, 3, lo_d, hi_d)])
+        PS = pl.DataFrame([native_uniform_column(pl, "ps_partkey", pl.Int64, "Int64", nb, seed + 1000, 0, 0, n_parts),
+                           native_uniform_column(pl, "ps_suppkey", pl.Int64, "Int64", nb, seed + 1000, 1, 0, 1_000_000)])
+        PS = PS.with_columns((pl.col("ps_partkey") % 32).alias("ps_group"))          # a property of the part, the same in all of its rows
+        PS = pl.DataFrame([PS["ps_partkey"], PS["ps_suppkey"], PS["ps_group"]])
+        pl._ffi.check(pl._ffi.lib().plx_synchronize())
+        lfd = queries.q3_partsupp(L.lazy(), PS.lazy())
+
+        def step_d():
+            return lfd.collect(), (L, PS)
+
+        def verify_d(res, budget):
+            from oracle import pyoracle as orc
+            t0 = time.perf_counter()
+            S, Cn = np.zeros(n_parts, np.float64), np.zeros(n_parts, np.int64)
+            done = 0
+            while done < nl and time.perf_counter() - t0 < budget:
+                m = min(100_000_000, nl - done)
+                k = datagen.uniform_native_host_mt("Int64", done, m, seed, 0, 0, n_parts)
+                keep = (datagen.uniform_native_host_mt("Int64", done, m, seed, 3, lo_d, hi_d) > date) & (k % 32 == 5)
+                k = k[keep]
+                rev = datagen.uniform_native_host_mt("Float64", done, m, seed, 1, 90_000, 10_500_000, 0.01)[keep] * (1.0 - datagen.uniform_native_host_mt("Float64", done, m, seed, 2, 0, 11, 0.01)[keep])
+                orc.groupby_dense_partial(np.ascontiguousarray(k), np.ascontiguousarray(rev), S, Cn)
+                done += m
+            if done < nl:
+                return {"rows": done, "ok": None, "note": "host check ran out of its time budget before covering the input"}
+            bk = datagen.uniform_native_host_mt("Int64", 0, nb, seed + 1000, 0, 0, n_parts)
+            bs = datagen.uniform_native_host_mt("Int64", 0, nb, seed + 1000, 1, 0, 1_000_000)
+            keep = (bk % 32 == 5)
+            bk, bs = bk[keep], bs[keep]
+            pairs, mult = np.unique(bk * 1_000_000 + bs, return_counts=True)           # build rows that are ONE group of (partkey, suppkey)
+            pk = pairs // 1_000_000
+            live = Cn[pk] > 0
+            pairs, mult, pk = pairs[live], mult[live], pk[live]
+            gk = res["l_partkey"].to_numpy().astype(np.int64) * 1_000_000 + res["ps_suppkey"].to_numpy().astype(np.int64)
+            order = np.argsort(gk, kind="stable")
+            ok = bool(np.array_equal(gk[order], pairs))
+            err = 0.0
+            if ok:
+                ok = bool(np.array_equal(res["n"].to_numpy().astype(np.int64)[order], mult * Cn[pk]))
+                err = _rel_err(res["revenue"].to_numpy()[order], mult * S[pk])
+                ok = ok and err <= VERIFY_RTOL
+            return {"rows": nl + nb, "against": "host twin of both tables: per-part revenue and row count of the filtered probe side through the oracle's streaming group-by, times the "
+                    "multiplicity of every (partkey, suppkey) build pair", "ok": ok, "max_rel_err": err, "rtol": VERIFY_RTOL, "groups": int(len(pairs)),
+                    "build_rows_after_filter": int(len(bk)), "duplicate_build_pairs": int((mult > 1).sum())}
+        wld = Workload("join_duplicate_build_keys_sf100", nl + nb, nl * 32 + nb * 24, step_d, "fused_scan",
+                       f"lineitem-shaped probe side ({nl} rows) JOIN partsupp-shaped build side ({nb} rows, ~4 per part: duplicate build keys), filter both, group_by(partkey, suppkey).agg(revenue, len)",
+                       verify=verify_d, scope="operator")
+        wld.inputs = [L, PS]
+        return wld
     if name == "q3f":
         # TPC-H Q3 with all three tables: customer[c_mktsegment == "BUILDING"] JOIN orders JOIN lineitem
         no = (rows // 4) if rows else SF100_ORDERS
@@ -1818,7 +1880,7 @@ def compare_q1_dicts(a: dict, b: dict) -> bool:
 
 
 MULTI_EXTRAS = ("q3", "q3:shuffle", "cfg3", "cfg5", "q1", "q1:weak")     # ":weak" = the per-rank SF100 shard (weak scaling), labelled so in its config.workload
-EXTRA_WORKLOADS = ("q3", "q3h", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "q1")      # the secondary workloads of the N = 1 line, in this order
+EXTRA_WORKLOADS = ("q3", "q3h", "q3d", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "q1")      # the secondary workloads of the N = 1 line, in this order
 
 
 def run_multi(args, emit):

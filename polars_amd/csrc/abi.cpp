@@ -115,6 +115,7 @@ int plx_column_drop_statistics(plx_column col) {
   if (c->range_trusted) { c->range_state = 0; c->range_min = c->range_max = 0; }       // bounds the caller declared are part of the column, not a cache
   std::atomic_store(&c->key_sample, std::shared_ptr<void>());
   c->order_state = 0;
+  c->repeats_as_build_key = false;
   PLX_CATCH
 }
 

@@ -111,6 +111,7 @@ struct Column {
   // group estimate): a column is immutable, so the next group-by on it with no predicate skips the 8 sample launches (0.3 ms per query)
   std::shared_ptr<void> key_sample;
   int order_state = 0;         // 0 unknown, 1 (roughly) ascending, 2 unordered: sampled once when the column is the probe key of a large join (k::sample_sortedness)
+  bool repeats_as_build_key = false;   // learned by a join that built on this column: some key occurs more than once (the next join skips the unique-key attempt; a fact about the column, whatever the predicate was)
   const void* data() const { return values ? values->ptr : nullptr; }
   const uint64_t* valid_words() const { return validity ? validity->as<uint64_t>() : nullptr; }
 };

@@ -726,7 +726,7 @@ static int64_t run_hash_agg(const Shape& sh, const Args& args, int static_id, in
   k::fill_u64(keys->as<uint64_t>(), slots, kEmptyKey);
   k::init_agg_cells(acc->as<uint64_t>(), slots, sh);
   HashTable t; t.keys = keys->as<unsigned long long>(); t.acc = acc->as<unsigned long long>(); t.overflow = ovf->as<unsigned int>(); t.wave_combine = 0;
-  t.log2_cap = (uint32_t)log2_cap; t.max_probe = (uint32_t)std::min<uint64_t>(cap, 1u << 14);
+  t.log2_cap = (uint32_t)log2_cap; t.max_probe = (uint32_t)std::min<uint64_t>(cap, 1u << 10);
   k::fused_hash_agg(sh, args, t, static_id);
   uint32_t o = 0; d2h_sync(&o, ovf->ptr, 4);
   if (o) return -1;
@@ -749,7 +749,7 @@ static int64_t run_wide_agg(const Shape& sh, const Args& args, int log2_cap, boo
   k::fill_u64(tags->as<uint64_t>(), (int64_t)cap, kEmptyKey);
   k::init_agg_cells(acc->as<uint64_t>(), (int64_t)cap, sh);
   WideTable t; t.tags = tags->as<unsigned long long>(); t.words = words->as<unsigned long long>(); t.acc = acc->as<unsigned long long>();
-  t.overflow = ovf->as<unsigned int>(); t.log2_cap = (uint32_t)log2_cap; t.max_probe = (uint32_t)std::min<uint64_t>(cap, 1u << 14);
+  t.overflow = ovf->as<unsigned int>(); t.log2_cap = (uint32_t)log2_cap; t.max_probe = (uint32_t)std::min<uint64_t>(cap, 1u << 10);
   t.n_words = (uint32_t)nw; t.has_null_word = nullable ? 1u : 0u;
   if (sample_blocks > 0) {
     const int64_t n = args.n_rows, per = (sample_rows / sample_blocks) & ~(int64_t)127, stride = (n / sample_blocks) & ~(int64_t)127;
@@ -1559,6 +1559,19 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     }
   }
   uint64_t nb = 0;
+  // Duplicate build keys (the reference's tables map a key to a LIST of build rows: single_keys.rs:16-167, probe_inner emits one pair per entry, single_keys_inner.rs:11-38):
+  // the hash-table pipeline then runs in multi-value mode -- chains of build rows per key, a group = a build ROW (or the rows of a key that agree on the build-side group
+  // columns: canonicalise_chains), every probe row adds to the cells of each row of its key's chain.  Possible when those group columns are integer-typed (compared bitwise).
+  bool known_dups = B->height > 0 && B->cols[bki]->repeats_as_build_key, multi = false;
+  RepCols rep_cols{};
+  bool multi_ok = !(getenv("PLX_JOIN_MULTI") && getenv("PLX_JOIN_MULTI")[0] == '0');
+  for (auto& gk : gkeys) {
+    if (gk.is_join_key) continue;
+    const ColumnPtr& col = B->cols[gk.build_col];
+    const int w = col->dtype == PLX_BOOL || col->dtype == PLX_F32 || col->dtype == PLX_F64 ? 0 : dtype_width(col->dtype);
+    if (!w || rep_cols.n >= kMaxRepCols) { multi_ok = false; break; }
+    rep_cols.vals[rep_cols.n] = col->data(); rep_cols.valid[rep_cols.n] = (const unsigned long long*)col->valid_words(); rep_cols.width[rep_cols.n] = w; rep_cols.n++;
+  }
   const int probe_static_id = find_static_shape(cp.shape);
   FusedAggResult r; r.n_aggs = cp.shape.n_aggs;
   auto rows = std::make_shared<Column>();
@@ -1567,7 +1580,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   bool done = false;
   // -- direct-address table when the build key range is small (cached column statistics); needs no count pass
   int64_t kmn = 0, kmx = 0;
-  if (!(plan.flags & PLX_PLAN_NO_DIRECT_JOIN) && B->height > 0 && kdt != PLX_U64 && ops::int_range(B->cols[bki], &kmn, &kmx)) {
+  if (!(plan.flags & PLX_PLAN_NO_DIRECT_JOIN) && !known_dups && B->height > 0 && kdt != PLX_U64 && ops::int_range(B->cols[bki], &kmn, &kmx)) {
     const unsigned __int128 range128 = (unsigned __int128)((__int128)kmx - (__int128)kmn) + 1;
     // pair list capacity: every build row may pass + one ordinal chunk (1024, kOrdChunk) per wave
     const uint64_t ord_cap = (uint64_t)B->height + (uint64_t)k::scan_waves(B->height) * 1024 + 1024;
@@ -1588,7 +1601,8 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       uint32_t m4[4] = {0, 0, 0, 0};
       d2h_sync(m4, meta->ptr, 16);
       PLX_REQUIRE(!m4[3], PLX_ERR_INVALID, "direct join build: ordinal overflow");
-      if (pairs != nb) return no("build keys are not unique");   // two pairs shared a bit: the hash-table pipeline handles (and reports) duplicates
+      if (pairs != nb) known_dups = true;                          // two pairs shared a bit: duplicate build keys -- the hash-table pipeline below runs them in multi-value mode
+      else {
       const uint32_t n_used = m4[0];
       const int64_t n_slots = (int64_t)nb, s1 = std::max<int64_t>(n_slots, 1);
       Buf acc2 = dev_alloc(sizeof(uint64_t) * (size_t)s1 * cp.shape.n_aggs);
@@ -1643,6 +1657,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
                    std::to_string(range) + " (bitmap + rank) unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+" + probe_how + ", aggs=" +
                    std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
       done = true;
+      }  // unique build keys
     }
   }
   // Size of the build table.  The number of build rows that pass the build side's predicate is a by-product of the build scan itself (JoinBuildSink counts what
@@ -1667,12 +1682,16 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       sized_by_sample = true;
     } else nb = exact_count();
   }
+  static const bool jtrace = getenv("PLX_JOIN_TRACE") && getenv("PLX_JOIN_TRACE")[0] == '1';
+#define JTRACE(...) do { if (jtrace) { PLX_HIP(hipStreamSynchronize(stream())); fprintf(stderr, "[plx join] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
   if (!done) {
-  Buf keys, flags, acc;
+  Buf keys, flags, acc, links;
   JoinAggTable t{};
   int log2_cap = 4;
   uint64_t cap = 0;
-  for (int attempt = 0; attempt < 2; attempt++) {
+  if (known_dups) { B->cols[bki]->repeats_as_build_key = true; if (!multi_ok) return no("build keys are not unique (and a build-side group column is not integer-typed)"); multi = true; }
+  for (int attempt = 0; attempt < 3; attempt++) {
+    if (multi && !links) links = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(B->height, 1));
     // (the sampled count already carries 25 %: x1.6 keeps the load at or below ~0.6 without doubling a table that x2 would push over the next power of two)
     log2_cap = std::max(4, ceil_log2_u64((uint64_t)((double)std::max<uint64_t>(nb, 1) * (sized_by_sample ? 1.6 : 2.0))));
     cap = 1ull << log2_cap;
@@ -1680,11 +1699,19 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     PLX_HIP(hipMemsetAsync(keys->ptr, 0xff, sizeof(uint64_t) * 2 * (cap + 1), stream()));
     t.slots = keys->as<unsigned long long>(); t.flags = flags->as<unsigned int>(); t.acc = nullptr;
     t.count = flags->as<unsigned long long>() + 1; t.log2_cap = (uint32_t)log2_cap;
+    t.links = multi ? links->as<unsigned long long>() : nullptr;
+    JTRACE("build attempt %d multi=%d cap=2^%d nb=%llu", attempt, (int)multi, log2_cap, (unsigned long long)nb);
     k::fused_join_build(cb.shape, cb.args, t, find_static_shape(cb.shape));
+    JTRACE("build done");
     uint64_t fl64[2] = {0, 0};
     d2h_sync(fl64, flags->ptr, 16);
     const uint32_t dup = (uint32_t)fl64[0], ovf = (uint32_t)(fl64[0] >> 32);
-    if (dup) return no("build keys are not unique");
+    if (dup) {
+      if (!multi_ok) return no("build keys are not unique (and a build-side group column is not integer-typed)");
+      B->cols[bki]->repeats_as_build_key = true;
+      multi = true;                                  // build once more, chaining the rows of a key (the table's size stays: it was planned for the rows, not the keys)
+      continue;
+    }
     if (sized_by_sample && attempt == 0 && (ovf || fl64[1] * 10 > cap * 7)) {      // the sample misjudged: once more, from the exact count
       nb = ovf ? exact_count() : fl64[1];
       sized_by_sample = false;
@@ -1694,9 +1721,20 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     nb = fl64[1];                                                                   // exact from here on
     break;
   }
-  acc = dev_alloc(sizeof(uint64_t) * (cap + 1) * cp.shape.n_aggs);
+  if (multi) {
+    Buf cflags = dev_alloc_zero(8);
+    constexpr unsigned int kMaxChain = 1024;
+    JTRACE("canonicalise: %d columns", rep_cols.n);
+    k::canonicalise_chains(t, rep_cols, kMaxChain, cflags->as<unsigned int>());
+    JTRACE("canonicalise done");
+    uint32_t too_long = 0;
+    d2h_sync(&too_long, cflags->ptr, 4);
+    if (too_long) return no("a build key repeats more than 1024 times");
+  }
+  const int64_t n_cells = multi ? std::max<int64_t>(B->height, 1) : (int64_t)cap + 1;      // multi-value mode: one cell set per build ROW
+  acc = dev_alloc(sizeof(uint64_t) * (size_t)n_cells * cp.shape.n_aggs);
   t.acc = acc->as<unsigned long long>();
-  k::init_agg_cells(acc->as<uint64_t>(), (int64_t)cap + 1, cp.shape);
+  k::init_agg_cells(acc->as<uint64_t>(), n_cells, cp.shape);
   // Probe.  A table beyond the caches (64 MB) probed by a much longer relation: every probe row would fetch a line across the fabric (SF100 Q3 on keys without
   // a dense range: 3.2e8 random probes of a 400 MB table).  The probe side is partitioned by the key's HASH instead and each partition is tested against an
   // LDS Bloom filter of the table's keys in it (k::partitioned_hash_probe_hits: the radix-partitioned probe of single_keys_inner.rs:11-149 with the partition's
@@ -1724,7 +1762,9 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       }
     }
   }
+  JTRACE("probe (partitioned: %d)", (int)hprobed);
   if (!hprobed) k::fused_probe_agg(cp.shape, cp.args, t, probe_static_id);
+  JTRACE("probe done");
   // ONE compaction pass into buffers sized for every build row (G <= nb): no counting pass over the table first
   const int64_t g1 = std::max<int64_t>((int64_t)nb, 1);
   r.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)g1);
@@ -1732,12 +1772,14 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   rows->values = dev_alloc(values_bytes(PLX_U32, g1));
   // (measured on SF100 Q3 with hashed keys: listing the touched slots from the candidates' probe -- one returning atomic per row -- costs that probe 0.5 ms, a
   // candidates' filter in front of the LEN cells 0.2 ms; streaming the LEN cells is 0.37 ms)
-  G = k::join_agg_compact(t, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
+  G = multi ? k::rows_agg_compact(acc->as<uint64_t>(), B->height, r.n_aggs, len_idx, rows->values->as<uint32_t>(), r.acc->as<uint64_t>())
+            : k::join_agg_compact(t, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
+  JTRACE("compacted: %lld groups", (long long)G);
   PLX_REQUIRE(G <= g1, PLX_ERR_INVALID, "join: more groups than build rows");
   r.n_groups = G;
   rows->len = G;
   plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " hash table cap=2^" + std::to_string(log2_cap) +
-               " unique-keys, probe rows=" + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+" + hprobe_how + ", aggs=" + std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
+               (multi ? " multi-value (row chains, a group = a build row), probe rows=" : " unique-keys, probe rows=") + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+" + hprobe_how + ", aggs=" + std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
   }  // hash-table path
   // ---- output frame: keys, then aggregates
   out = std::make_shared<Frame>();
@@ -1745,7 +1787,8 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   FinBatch batch{};
   for (auto& gk : gkeys) {
     out->names.push_back(output_name(plan, gk.expr));
-    if (gk.is_join_key) {
+    if (gk.is_join_key && multi) out->cols.push_back(ops::gather(B->cols[bki], rows));      // (inner join: the build row's key IS the group's key)
+    else if (gk.is_join_key) {
       KeyPart part; part.expr = gk.expr; part.dtype = gk.dtype;
       part.dec.shift = 0; part.dec.mask = ~0ull; part.dec.min = 0; part.dec.null_code = ~0ull; part.dec.dtype = gk.dtype;
       out->cols.push_back(decode_key_column(r, part, 0, batch));

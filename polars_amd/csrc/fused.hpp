@@ -379,6 +379,8 @@ struct PartPlan2 {
   uint32_t slice;              // direct mode, join probe on a key range: partition = id / slice, record low = id % slice (slice = range / P rounded up to a multiple of 64, so
                                // every partition is populated whatever the range; 0: partition = id >> key_shift).  slice_magic = floor(2^64 / slice); key_shift = bits of `low`
   unsigned long long slice_magic;
+  uint32_t n_tags;             // hash mode, wide keys: entries of the partition's LDS tag table (a multiple of 8: buckets of eight; ~4 per group the storage holds); n_slots = groups
+  uint32_t pad_;
 };
 // the multiplier of the join hash tables' slot hash (JoinBuildSink / ProbeAggSink; the reference's DirtyHash, polars-utils/src/hashing.rs:62-69): the hashed
 // partitioned probe takes its partition from the SAME top bits, so partition p of the probe side meets exactly region p of the build table
@@ -457,7 +459,16 @@ struct JoinAggTable {
   unsigned long long* acc;
   uint32_t log2_cap;
   unsigned long long* count;   // build: [0] += rows inserted (null: not wanted) -- the build side's row count after its predicate, a by-product of the build scan
+  // Multi-value mode (non-null): build keys may repeat (the reference's hash tables map a key to a LIST of build rows, single_keys.rs:16-167).  links[build row] =
+  // {next build row with the same key (low 32 bits; kNoRow32 ends the chain), representative row (high 32 bits)}; the slot's row word is the HEAD of its key's chain
+  // (exchanged in by every insert), the word above it counts the key's duplicate inserts (from its 0xffffffff fill).  A group of the fused join -> aggregate is then
+  // a build ROW: `acc` is [build rows][n_aggs] and a probe row adds to the cells of the representative of every row of its key's chain -- the representative of a
+  // row is the first row of the chain that agrees with it on the build-side group columns (canonicalise_chains), so build rows that are ONE group share one cell set.
+  unsigned long long* links;
 };
+// build-side columns on which two build rows of one key must agree to be ONE group (canonicalise_chains): plain fixed-width values + optional validity bitmap
+constexpr int kMaxRepCols = 6;
+struct RepCols { int n; const void* vals[kMaxRepCols]; const unsigned long long* valid[kMaxRepCols]; int width[kMaxRepCols]; };
 PLX_HD inline unsigned long long* jt_key(const JoinAggTable& t, uint64_t s) { return t.slots + 2 * s; }
 PLX_HD inline unsigned int* jt_row(const JoinAggTable& t, uint64_t s) { return reinterpret_cast<unsigned int*>(t.slots + 2 * s + 1); }
 

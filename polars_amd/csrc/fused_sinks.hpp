@@ -327,10 +327,26 @@ struct JoinBuildSink {
       // meeting the same key again means the build keys are not unique -> flag, the caller falls back.
       if (key == kEmptyKey) {
         const unsigned int old = atomicExch(jt_row(p, cap), (unsigned int)(row0 + r));
-        if (old != kNoRow32) p.flags[0] = 1u;
+        if (p.links) { p.links[row0 + r] = (unsigned long long)old | ((unsigned long long)(row0 + r) << 32); if (old != kNoRow32) atomicAdd(jt_row(p, cap) + 1, 1u); }
+        else if (old != kNoRow32) p.flags[0] = 1u;
         continue;
       }
       uint64_t slot = (key * kP2HashMult) >> (64 - p.log2_cap);
+      if (p.links) {
+        // multi-value mode (wave-uniform branch): find or claim the key's slot, then push this row onto the front of the key's chain
+        for (uint32_t probe = 0;; probe++) {
+          const unsigned long long old = atomicCAS(jt_key(p, slot), (unsigned long long)kEmptyKey, (unsigned long long)key);
+          if (old == kEmptyKey || old == key) {
+            const unsigned int prev = atomicExch(jt_row(p, slot), (unsigned int)(row0 + r));
+            p.links[row0 + r] = (unsigned long long)prev | ((unsigned long long)(row0 + r) << 32);      // its own representative until canonicalise_chains says otherwise
+            if (old == key) atomicAdd(jt_row(p, slot) + 1, 1u);                                           // marks the slot as one with duplicates (the word starts at 0xffffffff)
+            break;
+          }
+          slot = (slot + 1) & (cap - 1);
+          if (probe > (1u << 16)) { p.flags[1] = 1u; break; }
+        }
+        continue;
+      }
       // CAS first: the table is at most half full and build keys are (expected to be) unique, so the home slot is usually free -- a read before the CAS
       // would be a second trip across the fabric for nothing (SF100 Q3 on hashed keys: 1.5e7 inserts into a 400 MB table)
       for (uint32_t probe = 0;; probe++) {
@@ -365,7 +381,16 @@ struct ProbeAggSink {
             s = (s + 1) & (cap - 1);
           }
         }
-        if (slot >= 0) atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
+        if (slot >= 0) {
+          if (p.links) {      // multi-value mode (wave-uniform): one contribution per build row of the key, into the cells of that row's representative
+            unsigned int o = *jt_row(p, (uint64_t)slot);
+            for (uint32_t n = 0; o != kNoRow32 && n < (1u << 24); n++) {
+              const unsigned long long l = p.links[o];
+              atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)(l >> 32) * sh.n_aggs);
+              o = (unsigned int)l;
+            }
+          } else atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
+        }
       }
     }
   }

@@ -484,6 +484,76 @@ int64_t join_agg_compact(const JoinAggTable& t, int n_aggs, int len_idx, uint64_
   return (int64_t)n;
 }
 
+// ---- multi-value join table (duplicate build keys): representatives and row-indexed compaction --------------------------------
+// One thread per slot of the build table.  Slots whose key was inserted once are skipped by the duplicate counter in the slot itself (no access to the links).  For a
+// key with several build rows the thread walks the chain and gives every row its representative: the first row of the chain (in chain order) that agrees with it on all
+// `rc` columns -- the build-side group columns -- null == null, values bitwise (integer-typed columns only; the planner keeps float columns out of this path).  With no
+// such columns (the group key is the join key alone) every row of a key is one group: the chain's head represents them all.  A chain longer than `max_chain` raises
+// flags[0]: the pairwise search is quadratic in the classes of a chain and runs in one thread.
+__device__ __forceinline__ bool rep_cols_equal(const RepCols& rc, unsigned int a, unsigned int b) {
+  for (int j = 0; j < rc.n; j++) {
+    const bool va = !rc.valid[j] || ((rc.valid[j][a >> 6] >> (a & 63)) & 1ull), vb = !rc.valid[j] || ((rc.valid[j][b >> 6] >> (b & 63)) & 1ull);
+    if (va != vb) return false;
+    if (!va) continue;
+    switch (rc.width[j]) {
+      case 1: if (((const unsigned char*)rc.vals[j])[a] != ((const unsigned char*)rc.vals[j])[b]) return false; break;
+      case 2: if (((const unsigned short*)rc.vals[j])[a] != ((const unsigned short*)rc.vals[j])[b]) return false; break;
+      case 4: if (((const unsigned int*)rc.vals[j])[a] != ((const unsigned int*)rc.vals[j])[b]) return false; break;
+      default: if (((const unsigned long long*)rc.vals[j])[a] != ((const unsigned long long*)rc.vals[j])[b]) return false; break;
+    }
+  }
+  return true;
+}
+__global__ __launch_bounds__(kBlock) void canonicalise_chains_kernel(JoinAggTable t, RepCols rc, unsigned int max_chain, unsigned int* __restrict__ flags) {
+  const int64_t cap = (int64_t)1 << t.log2_cap;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= cap; s += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned int* rw = jt_row(t, (uint64_t)s);
+    const unsigned int head = rw[0];
+    if (head == kNoRow32 || rw[1] == 0xffffffffu) continue;          // empty, or a key with ONE build row (its link already names itself)
+    unsigned int len = 0;
+    for (unsigned int o = head; o != kNoRow32; len++) {
+      if (len >= max_chain) { flags[0] = 1u; break; }
+      const unsigned long long lo = t.links[o];
+      unsigned int rep = o;
+      unsigned int q = head;
+      for (unsigned int n = 0; q != o && n < len; n++) {                                        // (o is the len-th row of the chain: at most len steps)
+        const unsigned long long lq = t.links[q];
+        if ((unsigned int)(lq >> 32) == q && rep_cols_equal(rc, q, o)) { rep = q; break; }     // only representatives are candidates
+        q = (unsigned int)lq;
+      }
+      t.links[o] = (lo & 0xffffffffull) | ((unsigned long long)rep << 32);
+      o = (unsigned int)lo;
+    }
+  }
+}
+void canonicalise_chains(const JoinAggTable& t, const RepCols& rc, unsigned int max_chain, unsigned int* flags) {
+  const int64_t n_slots = ((int64_t)1 << t.log2_cap) + 1;
+  ProfileScope ps("join_chain_representatives", (uint64_t)n_slots * 16, (uint64_t)n_slots);
+  hipLaunchKernelGGL(canonicalise_chains_kernel, dim3(grid_for(n_slots, kBlock * 4)), dim3(kBlock), 0, stream(), t, rc, max_chain, flags);
+  PLX_HIP(hipGetLastError());
+}
+// groups of the multi-value table = build rows whose LEN cell is non-zero (a row that represents nobody, matched nobody or never passed the build predicate has none)
+__global__ __launch_bounds__(kBlock) void rows_agg_compact_kernel(const unsigned long long* __restrict__ acc, int64_t n_rows, int n_aggs, int len_idx, unsigned long long* __restrict__ counter,
+                                                                  unsigned int* __restrict__ out_rows, unsigned long long* __restrict__ out_acc) {
+  compact_slots(n_rows, counter, [&](int64_t s) { return acc[(size_t)s * n_aggs + len_idx] != 0; },
+                [&](int64_t s, uint64_t o) {
+                  if (!out_rows) return;
+                  out_rows[o] = (unsigned int)s;
+                  for (int k = 0; k < n_aggs; k++) out_acc[o * n_aggs + k] = acc[(size_t)s * n_aggs + k];
+                });
+}
+int64_t rows_agg_compact(const uint64_t* acc, int64_t n_rows, int n_aggs, int len_idx, uint32_t* out_rows, uint64_t* out_acc) {
+  if (n_rows == 0) return 0;
+  Buf counter = dev_alloc_zero(8);
+  ProfileScope ps("table_compact", (uint64_t)n_rows * 8 * (uint64_t)n_aggs, (uint64_t)n_rows);
+  hipLaunchKernelGGL(rows_agg_compact_kernel, dim3(compact_grid(n_rows)), dim3(kBlock), 0, stream(), (const unsigned long long*)acc, n_rows, n_aggs, len_idx, counter->as<unsigned long long>(),
+                     (unsigned int*)out_rows, (unsigned long long*)out_acc);
+  PLX_HIP(hipGetLastError());
+  uint64_t n = 0;
+  d2h_sync(&n, counter->ptr, 8);
+  return (int64_t)n;
+}
+
 // ---- table compaction: occupied slots -> dense output ----------------------------------
 // Wave-aggregated output allocation: ballot the occupied lanes, one atomicAdd per wave
 // reserves popcount slots, lanes write at base + prefix rank.

@@ -32,6 +32,9 @@ void fused_join_build(const fused::Shape& sh, const fused::Args& args, const fus
 void fused_probe_agg(const fused::Shape& sh, const fused::Args& args, const fused::JoinAggTable& t, int static_id);
 // slots whose AGG_LEN cell (len_idx) is non-zero -> out_keys (u64), out_rows (u32 build row), out_acc; nullptr outputs = count only
 int64_t join_agg_compact(const fused::JoinAggTable& t, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc);
+// multi-value join table (duplicate build keys; fused::JoinAggTable::links): representatives of the rows of every key's chain, and the compaction of row-indexed cells
+void canonicalise_chains(const fused::JoinAggTable& t, const fused::RepCols& rc, unsigned int max_chain, unsigned int* flags);
+int64_t rows_agg_compact(const uint64_t* acc, int64_t n_rows, int n_aggs, int len_idx, uint32_t* out_rows, uint64_t* out_acc);
 // number of waves a fused scan over n_rows launches (sizes per-wave reservations)
 int64_t scan_waves(int64_t n_rows);
 // semi-join filter side -> membership bitmap (BitmapBuild)

@@ -277,9 +277,11 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
     // make the scatter faster (its per-round cost is per partition: 256 partitions of 16-byte records move two lines per partition and round, 512 one), so the
     // smallest partition count whose tables stay at or below a load of 0.85 x the caller's padded estimate (it passes 1.3 x its own: a real load of ~0.65).
     pp.wide_null_word = wide && shape_may_have_nulls(sh) ? 1u : 0u;
-    // wide: a 32-bit tag + key words (+ null mask) + cells per slot, slots in buckets of four tags
-    const size_t slot_bytes = wide ? 4 + 8 * ((size_t)sh.n_keys + pp.wide_null_word + (size_t)sh.n_aggs) : 8 * (1 + (size_t)sh.n_aggs);
-    const uint32_t n_slots = wide ? (uint32_t)std::min<size_t>(((144 * 1024) / slot_bytes) & ~(size_t)3, (size_t)1 << 14) : (uint32_t)std::min<size_t>((144 * 1024) / slot_bytes - 2, (size_t)1 << 14);
+    // wide: group storage (key words (+ null mask) + cells) for n_slots groups, numbered in order of appearance, behind a tag table of FOUR 32-bit entries per group
+    // of capacity (buckets of eight; ordinals are 12 bits: at most 4096 groups a partition)
+    const size_t slot_bytes = wide ? 16 + 8 * ((size_t)sh.n_keys + pp.wide_null_word + (size_t)sh.n_aggs) : 8 * (1 + (size_t)sh.n_aggs);
+    const uint32_t n_slots = wide ? (uint32_t)std::min<size_t>(((144 * 1024) / slot_bytes) & ~(size_t)1, (size_t)4096) : (uint32_t)std::min<size_t>((144 * 1024) / slot_bytes - 2, (size_t)1 << 14);
+    pp.n_tags = wide ? n_slots * 4 : 0;
     if (n_slots < 256) return false;
     const double per_part = (double)n_slots * 0.85;
     uint32_t lp = 6;
@@ -584,7 +586,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   if (wide_stride_out) *wide_stride_out = (int64_t)ap.max_groups;
   {
     ProfileScope ps(agg_name.c_str(), (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
-    const size_t lds = wide ? n_slots * (4 + 8 * ((size_t)sh.n_keys + pp.wide_null_word + sh.n_aggs)) : n_slots * 8 * ((direct ? 0 : 1) + sh.n_aggs);
+    const size_t lds = wide ? (size_t)pp.n_tags * 4 + n_slots * 8 * ((size_t)sh.n_keys + pp.wide_null_word + sh.n_aggs) : n_slots * 8 * ((direct ? 0 : 1) + sh.n_aggs);
     if (!use_jit && gen3) part3_static_agg(static_id, pp, ap, NP, lds);
     else if (use_jit) {
       PartPlan2 ppc = pp; AggParams2 apc = ap;
@@ -610,7 +612,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   if (minmax) { long long mm[2]; d2h_sync(mm, minmax->ptr, 16); key_range_out[0] = mm[0]; key_range_out[1] = mm[1]; }
   if (desc) *desc = std::string(gen3 ? "partitioned(v3," : "partitioned(v2,") + (direct ? "direct" : "hash") + ",P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec_words * 4) +
                     (gen3 ? "B,pack=" + std::to_string(pp.pack) + ",tile=" + std::to_string(pp.block * kRows * pp.tiles) : "B,ring=" + std::to_string(pp.ring_lines * 128) + "B") +
-                    ",block=" + std::to_string(pp.block) + ",hot=" + std::to_string(pp.n_hot) + ")+" + (direct ? "lds_direct_table(slots=" : wide ? "lds_wide_key_table(words=" + std::to_string(sh.n_keys + pp.wide_null_word) + ",slots=" : "lds_hash_table(slots=") +
+                    ",block=" + std::to_string(pp.block) + ",hot=" + std::to_string(pp.n_hot) + (use_jit ? ",kernels=jit" : ",kernels=aot") + ")+" + (direct ? "lds_direct_table(slots=" : wide ? "lds_wide_key_table(words=" + std::to_string(sh.n_keys + pp.wide_null_word) + ",slots=" : "lds_hash_table(slots=") +
                     std::to_string(direct ? 1u << pp.log2_slots : pp.n_slots) + ")";
   return (int64_t)(((uint64_t)res[1] << 32) | res[0]);
 }

@@ -457,21 +457,23 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   constexpr uint32_t kPerLane = kP2ChunkRecs / 64;    // records of a chunk per lane
   const bool direct = MODE == (int)kP2Direct;
   const uint32_t NS = direct ? 1u << pp.log2_slots : pp.n_slots, n_aggs = sh.n_aggs, RW = L.rec_words, chunk_dw = kP2ChunkRecs * RW;
-  // wide key (L.n_key_cols != 0, hash mode): tags [NS] u32 (0 = empty | tag | tag + busy bit; NS a multiple of four: buckets of four tags) | key words [KW][NS] u64 |
-  // cells [NS][n_aggs]; no special slots (a null key column is part of the key: its bit of the null mask is hashed and compared)
+  // wide key (L.n_key_cols != 0, hash mode): tag entries [pp.n_tags] u32 | group keys [NS][KW] u64 | cells [NS][n_aggs] (NS = groups the partition's storage holds);
+  // no special slots (a null key column is part of the key: its bit of the null mask is hashed and compared) -- see process_wide
   const bool wide = !direct && L.n_key_cols != 0;
   const uint32_t KW = wide ? (uint32_t)L.n_key_cols + (pp.wide_null_word ? 1u : 0u) : 0u;
+  const uint32_t MAXG = NS;
   unsigned long long* keys = p2_lds;                                    // hash mode: [NS + 2] (NS = null key, NS + 1 = the key equal to EMPTY)
-  unsigned long long* kwords = keys + NS / 2;                           // wide: [KW][NS], behind the NS 32-bit tags
-  unsigned long long* cells = direct ? p2_lds : wide ? kwords + (size_t)KW * NS : keys + NS + 2;          // [(NS (+2)) * n_aggs]
+  unsigned long long* gkeys = p2_lds + pp.n_tags / 2;                   // wide: [NS][KW], behind the 32-bit tag entries
+  unsigned long long* cells = direct ? p2_lds : wide ? gkeys + (size_t)KW * NS : keys + NS + 2;          // [(NS (+2)) * n_aggs]
   const uint32_t n_slots = (direct || wide) ? NS : NS + 2;
+  __shared__ unsigned int n_groups;
   __shared__ unsigned int n_occ, cursor_l, full;
   __shared__ unsigned long long gbase;
   const uint32_t p = blockIdx.x;
-  if (wide) { for (uint32_t i = threadIdx.x; i < NS; i += blockDim.x) reinterpret_cast<unsigned int*>(p2_lds)[i] = 0u; }
+  if (wide) { for (uint32_t i = threadIdx.x; i < pp.n_tags; i += blockDim.x) reinterpret_cast<unsigned int*>(p2_lds)[i] = 0u; }
   else if (!direct) for (uint32_t i = threadIdx.x; i < n_slots; i += blockDim.x) keys[i] = kEmptyKey;
   for (uint32_t i = threadIdx.x; i < n_slots * n_aggs; i += blockDim.x) cells[i] = agg_identity_dev(sh.aggs[i % n_aggs].kind);
-  if (threadIdx.x == 0) { n_occ = 0; cursor_l = 0; full = 0; }
+  if (threadIdx.x == 0) { n_occ = 0; cursor_l = 0; full = 0; n_groups = 0; }
   __syncthreads();
   const int lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const uint64_t c_beg = ap.cl_off[p], c_end = ap.cl_off[p + 1];
@@ -519,143 +521,151 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
       }
     }
   };
-  // wide keys: a table of 32-bit TAGS in buckets of four (one 16-byte LDS read looks at four slots), key words and cells behind it.  Slot protocol on the tag word:
-  // 0 (empty) -> tag | busy (CAS) -> tag; the claimer writes the key words, then publishes the tag (LDS operations of a wave complete in order, so a reader that
-  // sees the published tag sees the words); a lane that meets a busy slot with its own tag looks again in the next round -- never a spin inside a round: the
-  // claimer may be a lane of the same wave.  A key sits at the first position of its probe sequence (bucket by bucket, position by position) that was empty when
-  // it arrived; nothing is ever removed, so a search may stop at the first empty position.
-  constexpr unsigned int kBusy = 1u;
+  // Wide keys.  LDS: tag entries [NT] u32 in buckets of EIGHT (two 16-byte reads look at a whole bucket; NT = pp.n_tags, a multiple of 8, about four entries per
+  // group of capacity: a load below 0.25, so a key sits in its home bucket but for ~1e-5 of them) | group keys [MAXG][KW] u64 | cells [MAXG][n_aggs]; MAXG = pp.n_slots
+  // groups per partition, numbered by an LDS counter in order of first appearance.  Entry = busy << 31 | tag19 << 12 | group ordinal (0 = empty; tag19 != 0).
+  //   fast path  straight-line, no divergent control flow: hash -> the bucket (2 x ds_read_b128) -> first entry with the record's tag -> the group's key words (one
+  //              ds_read_b128 for two key columns) -> compare -> the cell atomics under that predicate.  Every record of a key that is already in the table ends here.
+  //   slow path  only if some lane's record did not: a new key (claimed by CAS: empty -> busy | tag; ordinal from the counter; key words written; entry published --
+  //              LDS operations of a wave complete in order, so whoever sees the published entry sees the words), a key pushed out of a full home bucket (the search
+  //              goes on bucket by bucket), a tag that matched another key, an entry that is still busy (looked at again in the next round -- never a spin inside a
+  //              round: the claimer may be a lane of the same wave).
+  // Round 4 walked a table of 64-bit hash words slot by slot, every step behind a divergent branch: ~2500 instructions per 256-record chunk, most of them scalar
+  // mask bookkeeping, on a pass that is bound by the instruction stream of its sixteen waves (8 of the pass's 11.5 ms at 1e9 records of a two-column key).
   unsigned int* tags = reinterpret_cast<unsigned int*>(p2_lds);
-  auto process_wide = [&](unsigned int (*cur)[16], uint32_t cnt_cur) __attribute__((always_inline)) {
-    uint32_t slot[kPerLane];
-    unsigned int tag[kPerLane], st[kPerLane];
-    bool live[kPerLane], found[kPerLane], cand[kPerLane];
-    // one probe step: the bucket of `slot` in one read; the first position at or behind `slot` that is empty or carries the tag (busy or not) is a candidate
-    auto probe = [&](uint32_t u, const uint4& q) __attribute__((always_inline)) {
-      const uint32_t t = tag[u];
-      uint32_t m = (uint32_t)(q.x == 0u || (q.x & ~kBusy) == t) | ((uint32_t)(q.y == 0u || (q.y & ~kBusy) == t) << 1) | ((uint32_t)(q.z == 0u || (q.z & ~kBusy) == t) << 2) |
-                   ((uint32_t)(q.w == 0u || (q.w & ~kBusy) == t) << 3);
-      m &= 0xfu << (slot[u] & 3u);
-      if (m) {
-        const uint32_t i = (uint32_t)__builtin_ctz(m);
-        slot[u] = (slot[u] & ~3u) + i;
-        st[u] = i == 0 ? q.x : i == 1 ? q.y : i == 2 ? q.z : q.w;
-        cand[u] = true;
-      } else {
-        slot[u] = (slot[u] & ~3u) + 4u;
-        if (slot[u] >= NS) slot[u] = 0;
+  const uint32_t NT = pp.n_tags, n_buckets = NT >> 3;
+  auto wide_update = [&](const unsigned int* rec, uint32_t ord) __attribute__((always_inline)) {
+    const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
+    const uint64_t rowid = L.has_rowid ? ((uint64_t)rec[L.rowid_off] | ((uint64_t)rec[L.rowid_off + 1] << 32)) : 0ull;
+    unsigned long long* cell = cells + (size_t)ord * n_aggs;
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)kMaxAggs; k++) {
+      if (k >= n_aggs) break;
+      const uint8_t kind = sh.aggs[k].kind;
+      const uint8_t sj = L.agg_src[k];
+      uint64_t v = 0ull;
+      bool valid = true;
+      if (sj != kNone) {
+        const uint32_t lo = rec[L.src_off[sj]];
+        if (L.src_kind[sj] == 3) v = (uint64_t)pp.src_base[sj] + (uint64_t)lo;
+        else v = L.src_kind[sj] == 0 ? ((uint64_t)lo | ((uint64_t)rec[L.src_off[sj] + 1] << 32)) : (L.src_kind[sj] == 1 ? (uint64_t)(long long)(int)lo : (uint64_t)lo);
+        valid = (vbits >> sj) & 1;
       }
-    };
+      const uint64_t x = agg_row_value(kind, v, true, valid, rowid);
+      if (x != agg_identity_dev(kind) || kind == AGG_SUM_F) {
+        if (kind == AGG_SUM_F && !valid) continue;
+        lds_atomic_agg(kind, cell + k, x);
+      }
+    }
+  };
+  auto wide_word = [&](const unsigned int* rec, uint32_t j) __attribute__((always_inline)) -> unsigned long long {      // key word j of a record (j == n_key_cols: the null mask)
+    if (j < (uint32_t)L.n_key_cols) return (unsigned long long)rec[2 * j] | ((unsigned long long)rec[2 * j + 1] << 32);
+    const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
+    return (unsigned long long)(((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u));
+  };
+  auto process_wide = [&](unsigned int (*cur)[16], uint32_t cnt_cur) __attribute__((always_inline)) {
+    uint32_t bucket[kPerLane], tagf[kPerLane];
+    bool pending[kPerLane];
+    // ---- fast path
+    uint4 qa[kPerLane], qb[kPerLane];
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      const unsigned int* rec = cur[u];
+      // a hash of the key words for THIS table (the partition consumed the scatter's hash): 32-bit multiplies only
+      uint32_t x = 0x9e3779b9u;
+#pragma unroll
+      for (uint32_t j = 0; j < (uint32_t)kMaxKeys + 1u; j++) {
+        if (j >= KW) break;
+        const unsigned long long w = wide_word(rec, j);
+        x = (x ^ (uint32_t)w) * 0x85ebca77u;
+        x = (x ^ (uint32_t)(w >> 32)) * 0xc2b2ae3du;
+      }
+      x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 13;
+      bucket[u] = __umulhi(x, n_buckets);
+      uint32_t t19 = (x * 0x297a2d39u) >> 13;
+      if (!t19) t19 = 1u;
+      tagf[u] = t19 << 12;
+      qa[u] = *reinterpret_cast<const uint4*>(&tags[bucket[u] * 8u]);
+      qb[u] = *reinterpret_cast<const uint4*>(&tags[bucket[u] * 8u + 4u]);
+    }
+    lds_order();
+    uint32_t ord[kPerLane];
+    bool hit[kPerLane];
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      const uint32_t t = tagf[u];
+      const uint32_t e0 = qa[u].x, e1 = qa[u].y, e2 = qa[u].z, e3 = qa[u].w, e4 = qb[u].x, e5 = qb[u].y, e6 = qb[u].z, e7 = qb[u].w;
+      // the first entry of the bucket that carries the tag, published (busy bit clear): compare the upper twenty bits
+      uint32_t e = 0u;
+      e = ((e7 & 0xfffff000u) == t) ? e7 : e; e = ((e6 & 0xfffff000u) == t) ? e6 : e; e = ((e5 & 0xfffff000u) == t) ? e5 : e; e = ((e4 & 0xfffff000u) == t) ? e4 : e;
+      e = ((e3 & 0xfffff000u) == t) ? e3 : e; e = ((e2 & 0xfffff000u) == t) ? e2 : e; e = ((e1 & 0xfffff000u) == t) ? e1 : e; e = ((e0 & 0xfffff000u) == t) ? e0 : e;
+      hit[u] = e != 0u;
+      ord[u] = e & 0xfffu;
+    }
+    // the groups' key words (ordinal 0 for a miss: any valid address)
+    unsigned long long kw[kPerLane][kMaxKeys + 1];
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+      if (KW == 2u) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&gkeys[(size_t)ord[u] * 2u]);
+        kw[u][0] = v.x; kw[u][1] = v.y;
+      } else {
+#pragma unroll
+        for (uint32_t j = 0; j < (uint32_t)kMaxKeys + 1u; j++) if (j < KW) kw[u][j] = lds_ld(&gkeys[(size_t)ord[u] * KW + j]);
+      }
+    }
+    lds_order();
+    bool any_pending = false;
 #pragma unroll
     for (uint32_t u = 0; u < kPerLane; u++) {
       const uint32_t i = (uint32_t)lane + u * 64u;
-      live[u] = i < cnt_cur; found[u] = !live[u]; cand[u] = false;
-      slot[u] = 0; tag[u] = 0; st[u] = 0;
-      if (!live[u]) continue;
       const unsigned int* rec = cur[u];
-      const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
-      uint64_t w[kMaxKeys];
+      bool same = hit[u];
 #pragma unroll
-      for (int j = 0; j < kMaxKeys; j++) w[j] = j < (int)L.n_key_cols ? ((uint64_t)rec[2 * j] | ((uint64_t)rec[2 * j + 1] << 32)) : 0ull;
-      const uint32_t nullmask = ((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u);
-      const uint64_t h = wide_key_hash(w, L.n_key_cols, nullmask);
-      uint32_t t31 = (uint32_t)h & 0x7fffffffu;                                           // the partition took the hash's top bits, the bucket takes the ones below: the tag is the low end
-      if (!t31) t31 = 1u;
-      tag[u] = t31 << 1;                                                                   // never 0 (empty), busy bit clear
-      slot[u] = (uint32_t)((((h << pp.log2_parts) >> 32) * (uint64_t)(NS >> 2)) >> 32) << 2;
+      for (uint32_t j = 0; j < (uint32_t)kMaxKeys + 1u; j++) if (j < KW) same = same && kw[u][j] == wide_word(rec, j);
+      const bool live = i < cnt_cur && !(pp.ablate & 8u);
+      pending[u] = live && !same;
+      any_pending = any_pending || pending[u];
+      if (live && same && !(pp.ablate & 4u)) wide_update(rec, ord[u]);
     }
-    if (pp.ablate & 8u) {
+    if (!__any(any_pending)) return;
+    // ---- slow path (see above): record by record, position by position
 #pragma unroll
-      for (uint32_t u = 0; u < kPerLane; u++) found[u] = true;
-    }
-    // Slot search.  The pass is bound by the instructions it issues (sixteen waves share four 16-lane SIMDs) and a wave walks as long as its longest lane, so (a) a
-    // probe step covers four slots, (b) the first step of the lane's four records is issued together (four reads in flight), (c) what is heavy or rare -- claiming an
-    // empty slot, comparing key words on a tag match, a slot whose words are still being written -- happens once per round behind the walk.  At a load of 0.5 nineteen
-    // searches in twenty end in their first bucket.  (Round 4: a table of 64-bit hash words walked slot by slot, the lane's records one after the other: the search
-    // was 8 of the pass's 11.5 ms at 1e9 records of a two-column key.)
-    {
-      uint4 q[kPerLane];
+    for (uint32_t u = 0; u < kPerLane; u++) {      // (unrolled: the record buffers are registers, a run-time index would put them into scratch)
+      if (!__any(pending[u])) continue;
+      const unsigned int* rec = cur[u];
+      uint32_t pos = bucket[u] * 8u, steps = 0;
+      bool todo = pending[u];
+      for (uint32_t round = 0; __any(todo); round++) {
+        if (round > 4u * NT + 64u) { full = 1; break; }
+        if (lds_ld(&full)) break;                                                                // (a claimed entry may never be published once the storage is full)
+        if (todo) {
+          for (;;) {
+            if (steps > NT) { full = 1; todo = false; break; }                                 // every entry belongs to another key: a full table
+            const uint32_t e = lds_ld(&tags[pos]);
+            if (e == 0u) {
+              if (atomicCAS(&tags[pos], 0u, 0x80000000u | tagf[u]) != 0u) continue;           // somebody else took it: look at what is there now
+              const uint32_t o = atomicAdd(&n_groups, 1u);
+              if (o >= MAXG) { full = 1; todo = false; break; }                                // more groups than the partition's storage holds
 #pragma unroll
-      for (uint32_t u = 0; u < kPerLane; u++) q[u] = *reinterpret_cast<const uint4*>(&tags[found[u] ? 0u : slot[u]]);
-      lds_order();
-#pragma unroll
-      for (uint32_t u = 0; u < kPerLane; u++) if (!found[u]) probe(u, q[u]);
-    }
-    for (uint32_t round = 0;; round++) {
-      bool all = true;
-#pragma unroll
-      for (uint32_t u = 0; u < kPerLane; u++) all = all && found[u];
-      if (__all(all)) break;
-      if (round >= NS + 64u) { full = 1; break; }                                         // (slots that stay busy: cannot happen; the pass reports a full table)
-#pragma unroll
-      for (uint32_t u = 0; u < kPerLane; u++) {
-        if (found[u]) continue;
-        for (uint32_t n = 0; !cand[u]; n++) {
-          if (n >= (NS >> 2) + 1u) { full = 1; found[u] = true; live[u] = false; break; }   // every slot holds another key: a full table (the caller plans more partitions)
-          const uint4 q = *reinterpret_cast<const uint4*>(&tags[slot[u] & ~3u]);
-          lds_order();
-          probe(u, q);
-        }
-      }
-      lds_order();                                                                         // key words are read AFTER the tag that announces them
-#pragma unroll
-      for (uint32_t u = 0; u < kPerLane; u++) {
-        if (found[u]) continue;
-        const unsigned int* rec = cur[u];
-        cand[u] = false;
-        if (st[u] == 0u) {
-          if (atomicCAS(&tags[slot[u]], 0u, tag[u] | kBusy) == 0u) {
-#pragma unroll
-            for (int j = 0; j < kMaxKeys; j++)
-              if (j < (int)L.n_key_cols) lds_st(&kwords[(size_t)j * NS + slot[u]], (unsigned long long)((uint64_t)rec[2 * j] | ((uint64_t)rec[2 * j + 1] << 32)));
-            if (pp.wide_null_word) {
-              const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
-              lds_st(&kwords[(size_t)L.n_key_cols * NS + slot[u]], (unsigned long long)(((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u)));
+              for (uint32_t j = 0; j < (uint32_t)kMaxKeys + 1u; j++) if (j < KW) lds_st(&gkeys[(size_t)o * KW + j], wide_word(rec, j));
+              lds_order();                                                                       // the words first, then the entry that announces them
+              lds_st(&tags[pos], tagf[u] | o);
+              if (!(pp.ablate & 4u)) wide_update(rec, o);
+              todo = false;
+              break;
             }
-            lds_order();                                                                   // the words first, then the tag that announces them
-            lds_st(&tags[slot[u]], tag[u]);
-            found[u] = true;
+            if ((e & 0x7ffff000u) == tagf[u]) {
+              if (e & 0x80000000u) break;                                                        // its key words are being written: this entry again in the next round
+              const uint32_t o = e & 0xfffu;
+              bool same = true;
+#pragma unroll
+              for (uint32_t j = 0; j < (uint32_t)kMaxKeys + 1u; j++) if (j < KW) same = same && lds_ld(&gkeys[(size_t)o * KW + j]) == wide_word(rec, j);
+              if (same) { if (!(pp.ablate & 4u)) wide_update(rec, o); todo = false; break; }
+            }
+            pos = pos + 1u == NT ? 0u : pos + 1u;
+            steps++;
           }
-          // lost the race: the winner's tag in the next round, same position
-        } else if (st[u] == tag[u]) {                                                      // published, the same tag: compare the key words
-          bool same = true;
-#pragma unroll
-          for (int j = 0; j < kMaxKeys; j++)
-            if (j < (int)L.n_key_cols) same = same && lds_ld(&kwords[(size_t)j * NS + slot[u]]) == (unsigned long long)((uint64_t)rec[2 * j] | ((uint64_t)rec[2 * j + 1] << 32));
-          if (pp.wide_null_word) {
-            const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
-            same = same && lds_ld(&kwords[(size_t)L.n_key_cols * NS + slot[u]]) == (unsigned long long)(((vbits >> 24) & ((1u << L.n_key_cols) - 1u)) ^ ((1u << L.n_key_cols) - 1u));
-          }
-          if (same) found[u] = true;
-          else { slot[u] = slot[u] + 1 == NS ? 0u : slot[u] + 1; }                       // the same tag, another key: the walk goes on behind it
-        }
-        // (the same tag, busy: its key words are being written -- the same position again next round)
-      }
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < kPerLane; u++) {
-      if (!live[u] || !found[u] || (pp.ablate & 4u)) continue;
-      const unsigned int* rec = cur[u];
-      const uint32_t vbits = L.has_valid ? rec[L.valid_off] : 0xffffffffu;
-      const uint64_t rowid = L.has_rowid ? ((uint64_t)rec[L.rowid_off] | ((uint64_t)rec[L.rowid_off + 1] << 32)) : 0ull;
-      unsigned long long* cell = cells + (size_t)slot[u] * n_aggs;
-#pragma unroll
-      for (uint32_t k = 0; k < (uint32_t)kMaxAggs; k++) {
-        if (k >= n_aggs) break;
-        const uint8_t kind = sh.aggs[k].kind;
-        const uint8_t sj = L.agg_src[k];
-        uint64_t v = 0ull;
-        bool valid = true;
-        if (sj != kNone) {
-          const uint32_t lo = rec[L.src_off[sj]];
-          if (L.src_kind[sj] == 3) v = (uint64_t)pp.src_base[sj] + (uint64_t)lo;
-          else v = L.src_kind[sj] == 0 ? ((uint64_t)lo | ((uint64_t)rec[L.src_off[sj] + 1] << 32)) : (L.src_kind[sj] == 1 ? (uint64_t)(long long)(int)lo : (uint64_t)lo);
-          valid = (vbits >> sj) & 1;
-        }
-        const uint64_t x = agg_row_value(kind, v, true, valid, rowid);
-        if (x != agg_identity_dev(kind) || kind == AGG_SUM_F) {
-          if (kind == AGG_SUM_F && !valid) continue;
-          lds_atomic_agg(kind, cell + k, x);
         }
       }
     }
@@ -756,20 +766,20 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   if (full) { if (threadIdx.x == 0) atomicExch(ap.overflow, 1u); return; }
   // emit the partition's groups: count, reserve once, write
   uint32_t mine = 0;
-  for (uint32_t s = threadIdx.x; s < n_slots; s += blockDim.x) mine += direct ? (cells[(size_t)s * n_aggs + pp.len_idx] != 0) : wide ? (tags[s] != 0u) : (keys[s] != kEmptyKey);
+  for (uint32_t s = threadIdx.x; s < n_slots; s += blockDim.x) mine += direct ? (cells[(size_t)s * n_aggs + pp.len_idx] != 0) : wide ? (s < n_groups) : (keys[s] != kEmptyKey);      // wide: groups are numbered densely
   if (mine) atomicAdd(&n_occ, mine);
   __syncthreads();
   if (threadIdx.x == 0) gbase = n_occ ? atomicAdd(ap.counter, (unsigned long long)n_occ) : 0ull;
   __syncthreads();
   if (gbase + n_occ > ap.max_groups) { if (threadIdx.x == 0) atomicExch(ap.overflow, 2u); return; }
   for (uint32_t s = threadIdx.x; s < n_slots; s += blockDim.x) {
-    if (direct ? (cells[(size_t)s * n_aggs + pp.len_idx] == 0) : wide ? (tags[s] == 0u) : (keys[s] == kEmptyKey)) continue;
+    if (direct ? (cells[(size_t)s * n_aggs + pp.len_idx] == 0) : wide ? (s >= n_groups) : (keys[s] == kEmptyKey)) continue;
     const uint64_t o = gbase + atomicAdd(&cursor_l, 1u);
     if (direct) { ap.out_keys[o] = pp.interleave ? (((uint64_t)s << pp.log2_parts) | p) : (((uint64_t)p << pp.key_shift) | s); ap.out_kvalid[o] = 1; }
     else if (wide) {       // key words and per-column valid flags, column-major with stride max_groups (the layout of the HBM-table path's result: FusedAggResult::wide_words / wide_valid)
-      const uint32_t nm = pp.wide_null_word ? (uint32_t)kwords[(size_t)L.n_key_cols * NS + s] : 0u;
+      const uint32_t nm = pp.wide_null_word ? (uint32_t)gkeys[(size_t)s * KW + L.n_key_cols] : 0u;
       for (uint32_t j = 0; j < (uint32_t)L.n_key_cols; j++) {
-        ap.out_keys[(size_t)j * ap.max_groups + o] = kwords[(size_t)j * NS + s];
+        ap.out_keys[(size_t)j * ap.max_groups + o] = gkeys[(size_t)s * KW + j];
         ap.out_kvalid[(size_t)j * ap.max_groups + o] = (unsigned char)(((nm >> j) & 1u) ^ 1u);
       }
     }

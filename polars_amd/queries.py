@@ -73,6 +73,18 @@ def q3(lineitem, orders, date=Q3_DATE, seg_mod=5):
             .agg((c("l_extendedprice") * (1 - c("l_discount"))).sum().alias("revenue")))
 
 
+def q3_partsupp(lineitem, partsupp, date=Q3_DATE, group=5):
+    """A join whose BUILD side repeats its keys: lineitem[l_shipdate > date] JOIN partsupp[ps_group == group] ON partkey (dbgen's partsupp holds four rows per part;
+    the shape of TPC-H Q9 / Q20's partsupp joins), grouped by (l_partkey, ps_suppkey) -- a group is a build row, every lineitem row of a part contributes to each of the
+    part's suppliers.  ps_group is a property of the part (the same for all of its rows): the predicate keeps parts with ALL their partsupp rows."""
+    c = E.col
+    ps = partsupp.filter(c("ps_group") == group)
+    li = lineitem.filter(c("l_shipdate") > date)
+    return (li.join(ps, left_on="l_partkey", right_on="ps_partkey")
+            .group_by("l_partkey", "ps_suppkey")
+            .agg((c("l_extendedprice") * (1 - c("l_discount"))).sum().alias("revenue"), E.len().alias("n")))
+
+
 def q3_full(customer, orders, lineitem, date=Q3_DATE, segment="BUILDING"):
     """TPC-H Q3 with all three tables, in the form the optimizer hands the physical planner (single-table
     predicates pushed below the joins): customer[c_mktsegment == segment] JOIN orders[o_orderdate < date] ON custkey, then

@@ -82,15 +82,19 @@ def test_wide_keys_with_null_key_columns_and_a_float_key(pl):
 
 
 def test_wide_key_table_overflow_plans_more_partitions(pl, monkeypatch):
-    """An estimate that is far too low (the sample sees a prefix of few keys): the aggregation pass reports a full LDS table, the plan is doubled and the pass repeated."""
+    """An estimate that is far too low (every block of the planner's strided sample -- 8 blocks of 2^17 rows -- sees the same few keys): the aggregation pass reports a
+    full LDS table and the pass is repeated ONCE, at the largest plan."""
     rng = np.random.default_rng(203)
     n, G = 17_000_003, 900_000
-    g = np.concatenate([rng.integers(0, 5000, 1 << 22), rng.integers(0, G, n - (1 << 22))])      # the planner's prefix sample sees ~5000 groups
+    g = rng.integers(0, G, n)
+    per, stride = ((1 << 20) // 8) & ~127, (n // 8) & ~127
+    for b in range(8):
+        g[b * stride: b * stride + per] = rng.integers(0, 5000, per)                           # what the planner samples: ~5000 groups
     ka = rng.integers(-(1 << 62), 1 << 62, G).astype(np.int64)
     kb = rng.integers(-(1 << 62), 1 << 62, G).astype(np.int64)
     v = rng.integers(0, 100, n).astype(np.int64)
     df = pl.DataFrame({"a": ka[g], "b": kb[g], "v": v})
     out = df.lazy().group_by("a", "b").agg(pl.col("v").sum().alias("s"), pl.len().alias("len")).collect()
     plan = pl.last_plan()
-    assert "lds-overflow(P=" in plan and "lds_wide_key_table" in plan, plan
+    assert plan.count("lds-overflow(P=") == 1 and "P=512" in plan and "lds_wide_key_table" in plan, plan
     assert out.height == len(np.unique(g)) and int(out["s"].to_numpy().sum()) == int(v.sum()) and int(out["len"].to_numpy().sum()) == n

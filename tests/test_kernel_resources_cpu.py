@@ -129,4 +129,4 @@ def test_jit_wide_key_aggregation_has_no_scratch_and_no_flat_access(tmp_path, mo
         assert int(re.search(r"\.vgpr_spill_count:\s*(\d+)", notes).group(1)) == 0, notes
         assert int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", notes).group(1)) == 0, notes
         isa = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", f], cwd=tmp_path, capture_output=True, text=True, timeout=120).stdout
-        assert "ds_cmpst_rtn_b32" in isa and "ds_read_b128" in isa and not re.search(r"\bflat_(load|store|atomic)", isa)
+        assert "ds_cmpst_rtn_b32" in isa and "ds_read_b128" in isa and "scratch_" not in isa and not re.search(r"\bflat_(load|store|atomic)", isa)

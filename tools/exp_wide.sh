@@ -1,18 +1,32 @@
 #!/bin/bash
-# the two-column-key group-by (cfg3w) and the string-key group-by (cfg5s) after a change to the LDS slot protocols; PLX_PART_ABLATE 4 / 8 take parts of the wide-key
-# aggregation pass out (results wrong, not verified)
+# measurement session for the wide-key aggregation pass: ablations + SQ counters (gpurun: ./tools/exp_wide.sh <name>)
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
-mkdir -p gpurun_out/expw
-for spec in ${@:-cfg3w:0 cfg5s:0}; do
-  wl=${spec%%:*}; ab=${spec#*:}
-  v=1; [ "$ab" != "0" ] && v=0
-  PLX_PART_ABLATE=$ab PLX_BENCH_VERIFY=$v timeout 300 python bench.py --workload $wl --no-extras --no-cpu --steps 3 --warmup 1 > gpurun_out/expw/${wl}_ab$ab.json 2> gpurun_out/expw/${wl}_ab$ab.err
-  python - gpurun_out/expw/${wl}_ab$ab.json $wl $ab <<'PY'
+out="gpurun_out/$1"; mkdir -p "$out"; export TMPDIR=/tmp
+run() { tag="$1"; shift; env "$@" PLX_BENCH_VERIFY=0 timeout 300 python bench.py --workload cfg3w --no-extras --no-cpu --steps 4 --warmup 2 > "$out/$tag.json" 2> "$out/$tag.err"; echo "$tag rc=$?";
+        python - "$out/$tag.json" <<'P'
 import json,sys
-try:
-    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])
-    ks=sorted(d['kernels'].items(), key=lambda kv:-kv[1]['avg_us']*kv[1]['launches'])[:4]
-    print(sys.argv[2:], d['ms_per_step'], d.get('verified',{}).get('ok'), [(k,v['launches'],round(v['avg_us'])) for k,v in ks])
-except Exception as e: print(sys.argv[2:], 'failed', e); print(open(sys.argv[1].replace('.json','.err')).read()[-600:])
-PY
+l=[x for x in open(sys.argv[1]).read().splitlines() if x.startswith("[bench] full record: ")]
+d=json.loads(l[-1][21:]) if l else {}
+print("   ms", d.get("ms_per_step"), {k:v["avg_us"] for k,v in (d.get("kernels") or {}).items() if v["avg_us"]>100})
+P
+}
+run base X=1
+run abl8 PLX_PART_ABLATE=8
+run abl4 PLX_PART_ABLATE=4
+run abl12 PLX_PART_ABLATE=12
+for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT" \
+            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_SMEM SQ_WAVES"; do
+  tag=$(echo "$pass" | cut -d' ' -f1)
+  (cd /tmp && PLX_BENCH_VERIFY=0 timeout 400 rocprofv3 --pmc $pass --kernel-trace -d "$OLDPWD/$out/pmc_$tag" -o w -- python "$OLDPWD/bench.py" --workload cfg3w --no-extras --no-cpu --steps 2 --warmup 1 > /dev/null 2> "$OLDPWD/$out/pmc_$tag.err"); echo "pmc $tag rc=$?"
+  python - "$out/pmc_$tag" <<'P'
+import csv,glob,sys,collections
+f=glob.glob(sys.argv[1]+"/**/*counter_collection.csv",recursive=True)
+if not f: print("no csv"); sys.exit()
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f[0])):
+    k=r["Kernel_Name"]
+    if "part" in k: acc[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k,v in acc.items():
+    print(k, {c:(round(sorted(x)[len(x)//2]/1e6,2)) for c,x in v.items()}, "(median per launch, millions)")
+P
 done

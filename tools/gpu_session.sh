@@ -10,7 +10,7 @@ for step in "$@"; do
   echo "=== $step ($(date +%T))"
   case "$kind" in
     mall) ./tools/micro_mall.bin > "$out/micro_mall.txt" 2>&1; tail -12 "$out/micro_mall.txt" ;;
-    tests) timeout 1500 python -m pytest $rest -x -q -p no:cacheprovider > "$out/pytest_$(echo "$rest" | tr -c 'a-zA-Z0-9' '_' | cut -c1-40).log" 2>&1; tail -5 "$out"/pytest_*.log ;;
+    tests) timeout 1500 python -m pytest $rest -x -q -p no:cacheprovider --timeout 300 > "$out/pytest_$(echo "$rest" | tr -c 'a-zA-Z0-9' '_' | cut -c1-40).log" 2>&1; tail -5 "$out"/pytest_*.log ;;
     bench) wl="${rest%%:*}"; extra=""; [ "$rest" != "$wl" ] && extra="${rest#*:}"
            timeout 600 python bench.py --workload "$wl" --no-extras --no-cpu --steps 5 --warmup 2 $extra > "$out/bench_$wl.json" 2> "$out/bench_$wl.err"; echo "rc=$?"; cut -c1-1500 "$out/bench_$wl.json"; tail -3 "$out/bench_$wl.err" ;;
     sharded) wl="${rest%%:*}"; mode="shuffle"; [ "$rest" != "$wl" ] && mode="${rest#*:}"
