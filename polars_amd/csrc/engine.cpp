@@ -1376,7 +1376,12 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   auto no = [&](const char* m) { if (why) *why = m; return false; };
   if (gb.input < 0 || plan.ir[gb.input].kind != PLX_IR_JOIN) return no("input is not a join");
   const IRN& jn = plan.ir[gb.input];
-  if (jn.how != PLX_JOIN_INNER || jn.keys.size() != 1 || jn.keys_right.size() != 1) return no("not a single-key inner join");
+  if ((jn.how != PLX_JOIN_INNER && jn.how != PLX_JOIN_LEFT) || jn.keys.size() != 1 || jn.keys_right.size() != 1) return no("not a single-key inner or left join");
+  // LEFT join (single_keys_left.rs:106-195: every left row survives; rows without a match carry nulls in the right table's columns): the matched rows are the inner join's
+  // -- the same pipeline with the RIGHT table as the build side -- and the unmatched ones are a group-by of their own over the left table, keyed by the join key, behind
+  // the predicate "key not among the build keys" (a membership bitmap over the build key range, tested inside the scan: OP_BITLOOKUP); their groups carry nulls in the
+  // build-side group columns.  Needs a build key range a bitmap can cover; otherwise the per-node path runs the join.
+  const bool left_join = jn.how == PLX_JOIN_LEFT;
   if (gb.maintain_order) return no("maintain_order");
   auto plain = [&](int e) -> const AE* { const AE* x = &plan.ae[e]; while (x->kind == PLX_AE_ALIAS) x = &plan.ae[x->lhs]; return x->kind == PLX_AE_COLUMN ? x : nullptr; };
   const AE* lkx = plain(jn.keys[0]);
@@ -1399,7 +1404,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   const int kdt = L->cols[lki]->dtype;
   if (kdt != R->cols[rki]->dtype || !dtype_is_int(kdt)) return no("join key is not an integer column pair of one dtype");
   if (L->height >= 0xffffffffll || R->height >= 0xffffffffll) return no("side exceeds u32 row indices");
-  const bool build_right = L->height > R->height;   // det_hash_prone_order: probe = the longer relation
+  const bool build_right = left_join || L->height > R->height;   // det_hash_prone_order: probe = the longer relation; a left join probes with its left table (single_keys_left.rs)
   const FramePtr& B = build_right ? R : L;
   const FramePtr& P = build_right ? L : R;
   const int bki = build_right ? rki : lki, pki = build_right ? lki : rki;
@@ -1450,7 +1455,20 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     if (!probe_only(e)) return no("aggregate reads a build-side column");
   }
   // ---- compile the three programs
-  Compiler cnt(plan, *B), cb(plan, *B), cp(plan, *P), cs(plan, *P);
+  Compiler cnt(plan, *B), cb(plan, *B), cp(plan, *P), cs(plan, *P), ca(plan, *P);      // ca: the left join's unmatched rows (group-by over the probe side)
+  KeyPlan akp;
+  std::vector<FinalSpec> aspecs;
+  int a_len_idx = -1;
+  int64_t a_kmn = 0, a_kmx = 0;
+  uint64_t a_range = 0;
+  if (left_join) {
+    if (psemis.size() + 1 > (size_t)kMaxLuts) return no("left join: no lookup bitmap left for the membership test");
+    if (kdt == PLX_U64) return no("left join on UInt64 keys");
+    const bool have = B->height > 0 && ops::int_range(B->cols[bki], &a_kmn, &a_kmx);
+    const unsigned __int128 range128 = have ? (unsigned __int128)((__int128)a_kmx - (__int128)a_kmn) + 1 : 1;
+    if (range128 > ((unsigned __int128)1 << 34) || (have && range128 > (unsigned __int128)B->height * 256 + 4096)) return no("left join: build key range too wide for the membership bitmap");
+    a_range = (uint64_t)range128;
+  }
   std::vector<std::unique_ptr<Compiler>> csemi;      // one program per semi filter: build-side filters first, then probe-side
   std::vector<int> agg_nodes; std::vector<FinalSpec> specs;
   int len_idx = -1;
@@ -1489,6 +1507,20 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     cs.df = &pview;
     cs.add_agg(AGG_FIRST_ROW, -1);
     cs.finish();
+    if (left_join) {
+      ca.df = &pview;
+      int p = and_preds(ca, ppreds, psemis, 0);                                  // (its own lookup numbering: the probe side's semi filters, then the membership bitmap)
+      const int kn = ca.load(pki);
+      const int member = ca.ifnull(ca.bit_lookup(p < 0 ? kn : ca.mask_valid(kn, p), (int)psemis.size(), a_kmn), 0);      // a null key is among nobody's keys
+      const int unmatched = ca.mk(OP_NOT, member, member, 'b');
+      ca.pred = p < 0 ? unmatched : ca.mk(OP_AND, p, unmatched, 'b');
+      int jk_expr = -1;
+      for (auto& gk : gkeys) if (gk.is_join_key) jk_expr = gk.expr;
+      akp = lower_keys(ca, std::vector<int>{jk_expr});
+      a_len_idx = ca.add_agg(AGG_LEN, -1);
+      for (int a : agg_nodes) aspecs.push_back(ca.lower_agg(a));
+      ca.finish();
+    }
     for (const std::vector<SemiFilter>* sv : {&bsemis, &psemis}) {
       for (const SemiFilter& sf : *sv) {
         csemi.emplace_back(new Compiler(plan, *sf.F));
@@ -1553,7 +1585,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
         }
         const Lut lut{bits->as<unsigned long long>(), range};
         const int li = side == 0 ? (int)i : (int)(bsemis.size() + i);
-        if (side == 0) { cnt.args.lut[li] = lut; cb.args.lut[li] = lut; } else { cp.args.lut[li] = lut; cs.args.lut[li] = lut; }
+        if (side == 0) { cnt.args.lut[li] = lut; cb.args.lut[li] = lut; } else { cp.args.lut[li] = lut; cs.args.lut[li] = lut; if (left_join) ca.args.lut[i] = lut; }
         lut_bits.push_back(bits);
       }
     }
@@ -1563,6 +1595,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   // the hash-table pipeline then runs in multi-value mode -- chains of build rows per key, a group = a build ROW (or the rows of a key that agree on the build-side group
   // columns: canonicalise_chains), every probe row adds to the cells of each row of its key's chain.  Possible when those group columns are integer-typed (compared bitwise).
   bool known_dups = B->height > 0 && B->cols[bki]->repeats_as_build_key, multi = false;
+  uint32_t merged_rows = 0;      // multi-value mode: build rows that share their group with an earlier row of their key
   RepCols rep_cols{};
   bool multi_ok = !(getenv("PLX_JOIN_MULTI") && getenv("PLX_JOIN_MULTI")[0] == '0');
   for (auto& gk : gkeys) {
@@ -1727,9 +1760,10 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     JTRACE("canonicalise: %d columns", rep_cols.n);
     k::canonicalise_chains(t, rep_cols, kMaxChain, cflags->as<unsigned int>());
     JTRACE("canonicalise done");
-    uint32_t too_long = 0;
-    d2h_sync(&too_long, cflags->ptr, 4);
-    if (too_long) return no("a build key repeats more than 1024 times");
+    uint32_t cfl[2] = {0, 0};
+    d2h_sync(cfl, cflags->ptr, 8);
+    if (cfl[0]) return no("a build key repeats more than 1024 times");
+    merged_rows = cfl[1];
   }
   const int64_t n_cells = multi ? std::max<int64_t>(B->height, 1) : (int64_t)cap + 1;      // multi-value mode: one cell set per build ROW
   acc = dev_alloc(sizeof(uint64_t) * (size_t)n_cells * cp.shape.n_aggs);
@@ -1779,7 +1813,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   r.n_groups = G;
   rows->len = G;
   plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " hash table cap=2^" + std::to_string(log2_cap) +
-               (multi ? " multi-value (row chains, a group = a build row), probe rows=" : " unique-keys, probe rows=") + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+" + hprobe_how + ", aggs=" + std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
+               (multi ? " multi-value (row chains, a group = a build row; " + std::to_string(merged_rows) + " rows share another row's group), probe rows=" : " unique-keys, probe rows=") + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+" + hprobe_how + ", aggs=" + std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
   }  // hash-table path
   // ---- output frame: keys, then aggregates
   out = std::make_shared<Frame>();
@@ -1802,6 +1836,45 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     Evaluated ev = eval(plan, e, gframe, &overrides);
     out->names.push_back(output_name(plan, e));
     out->cols.push_back(broadcast(ev, G));
+  }
+  if (left_join) {
+    // the unmatched left rows: membership bitmap of the build keys that pass the build side's predicate, then a fused group-by over the left table
+    Buf bits = dev_alloc_zero(sizeof(uint64_t) * (size_t)(a_range / 64 + 2)), rows_dev = dev_alloc_zero(8);
+    if (B->height > 0) {
+      BitmapBuild bb; bb.bits = bits->as<unsigned long long>(); bb.count = rows_dev->as<unsigned long long>(); bb.kmin = a_kmn; bb.range = a_range;
+      k::fused_bitmap_build(cb.shape, cb.args, bb, find_static_shape(cb.shape));
+    }
+    ca.args.lut[psemis.size()] = Lut{bits->as<unsigned long long>(), a_range};
+    FusedAggResult ar;
+    std::string ad;
+    run_fused_groupby(ca, akp, a_len_idx, ar, ad);
+    plan.desc += "LeftJoinUnmatched{membership bitmap range=" + std::to_string(a_range) + ", " + akp.note + "FusedFilterGroupBy{" + ad + ", groups=" + std::to_string(ar.n_groups) + "}}; ";
+    const int64_t U = ar.n_groups;
+    auto tail = std::make_shared<Frame>();
+    tail->height = U;
+    FinBatch abatch{};
+    for (auto& gk : gkeys) {
+      tail->names.push_back(output_name(plan, gk.expr));
+      if (gk.is_join_key) tail->cols.push_back(decode_key_column(ar, akp.parts[0], 0, abatch));
+      else tail->cols.push_back(ops::full_column(B->cols[gk.build_col]->dtype, plx_scalar{0}, false, U));       // no build row: null
+    }
+    std::map<int, ColumnPtr> aover;
+    for (size_t i = 0; i < agg_nodes.size(); i++) aover[agg_nodes[i]] = finalize_column(ar, aspecs[i], abatch);
+    if (U > 0) k::finalize_batch(ar.acc->as<uint64_t>(), ar.n_aggs, U, abatch);
+    Frame aframe; aframe.height = U;
+    for (int e : gb.exprs) {
+      Evaluated ev = eval(plan, e, aframe, &aover);
+      tail->names.push_back(output_name(plan, e));
+      tail->cols.push_back(broadcast(ev, U));
+    }
+    if (U > 0) {
+      for (size_t i = 0; i < out->cols.size(); i++) {
+        ColumnPtr b = tail->cols[i];
+        if (b->dtype != out->cols[i]->dtype) b = ops::cast(b, out->cols[i]->dtype);
+        out->cols[i] = G > 0 ? ops::concat({out->cols[i], b}) : b;
+      }
+      out->height = G + U;
+    }
   }
   return true;
 }

@@ -510,20 +510,22 @@ __global__ __launch_bounds__(kBlock) void canonicalise_chains_kernel(JoinAggTabl
     const unsigned int* rw = jt_row(t, (uint64_t)s);
     const unsigned int head = rw[0];
     if (head == kNoRow32 || rw[1] == 0xffffffffu) continue;          // empty, or a key with ONE build row (its link already names itself)
-    unsigned int len = 0;
+    unsigned int len = 0, merged = 0;
     for (unsigned int o = head; o != kNoRow32; len++) {
       if (len >= max_chain) { flags[0] = 1u; break; }
       const unsigned long long lo = t.links[o];
       unsigned int rep = o;
       unsigned int q = head;
-      for (unsigned int n = 0; q != o && n < len; n++) {                                        // (o is the len-th row of the chain: at most len steps)
+      for (unsigned int n = 0; n < len; n++) {                                                   // o is the len-th row of the chain: the len rows before it, in chain order
         const unsigned long long lq = t.links[q];
-        if ((unsigned int)(lq >> 32) == q && rep_cols_equal(rc, q, o)) { rep = q; break; }     // only representatives are candidates
+        if (rep == o && (unsigned int)(lq >> 32) == q && rep_cols_equal(rc, q, o)) rep = q;      // the FIRST representative that agrees (only representatives are candidates)
         q = (unsigned int)lq;
       }
+      if (rep != o) merged++;
       t.links[o] = (lo & 0xffffffffull) | ((unsigned long long)rep << 32);
       o = (unsigned int)lo;
     }
+    if (merged) atomicAdd(&flags[1], merged);        // (statistics: build rows that joined another row's group)
   }
 }
 void canonicalise_chains(const JoinAggTable& t, const RepCols& rc, unsigned int max_chain, unsigned int* flags) {

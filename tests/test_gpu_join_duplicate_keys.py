@@ -130,3 +130,70 @@ def test_float_build_group_column_with_duplicate_keys_runs_unfused(pl):
     g = J.groupby(["k", "a"]).agg(sx=("x", "sum"), n=("x", "size")).reset_index().sort_values(["k", "a"])
     got = pd.DataFrame({"k": out["k"].to_numpy(), "a": out["a"].to_numpy(), "sx": out["sx"].to_numpy(), "n": out["n"].to_numpy().astype(np.int64)}).sort_values(["k", "a"])
     assert got["k"].tolist() == g["k"].tolist() and got["a"].tolist() == g["a"].tolist() and got["sx"].tolist() == g["sx"].tolist() and got["n"].tolist() == g["n"].tolist()
+
+
+# ---- LEFT joins on the fused path (single_keys_left.rs:106-195): matched rows as the inner join, unmatched rows grouped by their own key with nulls in the build columns ----
+def _expected_left(pkey, pvalid, x, w, bkey, battr, battr_valid, by_attr):
+    inner = _expected(pkey, pvalid, x, w, bkey, battr, battr_valid, by_attr)
+    P = pd.DataFrame({"k": pd.array(pkey, dtype="Int64"), "x": x, "w": w})
+    P.loc[~pvalid, "k"] = pd.NA
+    un = P[~(pvalid & np.isin(pkey, bkey))]                       # no build row with this key (a null key matches nothing)
+    g = un.groupby("k", dropna=False, sort=True).agg(sx=("x", "sum"), sw=("w", "sum"), n=("x", "size")).reset_index()
+    if by_attr:
+        g.insert(1, "a", pd.array([pd.NA] * len(g), dtype="Int64"))
+        inner["a"] = inner["a"].astype("Int64")
+    inner["k"] = inner["k"].astype("Int64")
+    if not by_attr:
+        # grouped by the key alone, a key's matched and unmatched rows cannot both exist: the two parts never share a group
+        pass
+    return pd.concat([inner, g], ignore_index=True)
+
+
+def _query_left(pl, P, B, by_attr, **kw):
+    c = pl.col
+    keys = ("k", "a") if by_attr else ("k",)
+    return P.lazy().join(B.lazy(), on="k", how="left").group_by(*keys).agg(c("x").sum().alias("sx"), c("w").sum().alias("sw"), pl.len().alias("n")).collect(**kw)
+
+
+@pytest.mark.parametrize("dups,by_attr", [(False, True), (True, True), (True, False)])
+def test_left_join_group_by_takes_the_fused_path(pl, dups, by_attr):
+    """LEFT JOIN -> group_by on the fused pipeline: unique and duplicate build keys, null probe keys (their own group, null key), probe keys beyond the build range."""
+    rng = np.random.default_rng(301 + 2 * dups + by_attr)
+    n, n_keys = (1 << 22) + 999, 120_000
+    B, P, host = _frames(pl, rng, n, n_keys, hashed=False, dense=True)
+    pkey, pvalid, x, w, bkey, battr, bvalid = host
+    if not dups:      # one row per key
+        bkey, first = np.unique(bkey, return_index=True)
+        battr = battr[first]
+        B = pl.DataFrame({"k": bkey, "a": battr})
+    out = _query_left(pl, P, B, by_attr)
+    plan = pl.last_plan()
+    assert "FusedJoinGroupBy{" in plan and "LeftJoinUnmatched{" in plan and ("multi-value" in plan) == dups, plan
+    exp = _expected_left(pkey, pvalid, x, w, bkey, battr, None, by_attr)
+    _check(out, exp, by_attr)
+    ref = _query_left(pl, P, B, by_attr, no_fusion=True)
+    assert "FusedJoinGroupBy" not in pl.last_plan()
+    _check(ref, exp, by_attr)
+
+
+def test_left_join_with_predicates_on_both_sides_and_every_row_unmatched(pl):
+    """Predicates below a left join: the left one filters rows, the right one only decides which rows MATCH (a left row whose partners all fail it is unmatched, not dropped);
+    and a build side that keeps no row at all: every left row is unmatched."""
+    rng = np.random.default_rng(77)
+    n, nb = (1 << 22) + 5, 200_000
+    bkey = rng.permutation(nb).astype(np.int64)
+    battr = rng.integers(0, 1000, nb).astype(np.int64)
+    pkey = rng.integers(0, nb + 50_000, n).astype(np.int64)
+    x = rng.integers(-9, 9, n).astype(np.int64)
+    w = rng.random(n)
+    B = pl.DataFrame({"k": bkey, "a": battr}); P = pl.DataFrame({"k": pkey, "x": x, "w": w})
+    c = pl.col
+    for cut in (500, -1):
+        q = (P.lazy().filter(c("x") > -5).join(B.lazy().filter(c("a") < cut), on="k", how="left").group_by("k", "a")
+             .agg(c("x").sum().alias("sx"), c("w").sum().alias("sw"), pl.len().alias("n")))
+        out = q.collect()
+        assert "LeftJoinUnmatched{" in pl.last_plan(), pl.last_plan()
+        keep = x > -5
+        bk = battr < cut
+        exp = _expected_left(pkey[keep], np.ones(int(keep.sum()), bool), x[keep], w[keep], bkey[bk], battr[bk], None, True)
+        _check(out, exp, True)
