@@ -465,8 +465,10 @@ int plx_datagen_zipf_host(int64_t row0, int64_t n, uint64_t seed, uint32_t strea
  * plx_strview_dict_encode_device: the same for views already in HBM (a PLX_U64 column of 2 n words; `data` a PLX_U8 column or 0).
  * Nulls of a view column in HBM: the raw-view entry points (plx_strview_dict_encode_device, plx_strview_groupby, plx_ipc_read_string_views) carry no bitmap --
  * a null entry is a view whose length word is 0xFFFFFFFF (no Arrow view has it: lengths are non-negative int32; the other 12 bytes zero).
- * plx_strview_stamp_nulls(views, valid) writes those stamps in place from the array's validity (valid: a PLX_BOOL column of n rows, true = valid -- the
- * BinaryViewArray's validity bitmap, crates/polars-arrow/src/array/binview/mod.rs, imported as Boolean values); encode gives such rows null codes.
+ * plx_strview_stamp_nulls(views, valid) writes those stamps into the column from the array's validity (valid: a PLX_BOOL column of n rows, true = valid -- the
+ * BinaryViewArray's validity bitmap, crates/polars-arrow/src/array/binview/mod.rs, imported as Boolean values; a NULL entry of `valid` itself counts as not valid);
+ * encode gives such rows null codes.  A view buffer the caller lent (plx_column_from_device) or that another column shares is copied first: the COLUMN behind the
+ * handle is stamped, never memory somebody else can see.
  * plx_strdict_to_host: offsets[n_strings + 1] + the concatenated bytes, in code order. */
 typedef uint64_t plx_strdict;
 int plx_strview_dict_encode(const void* views, const uint8_t* validity, int64_t bit_offset, int64_t n, const void* const* data_buffers, const int64_t* data_sizes,

@@ -1016,7 +1016,23 @@ int plx_strview_stamp_nulls(plx_column views_u64_pairs, plx_column valid_bool) {
   PLX_REQUIRE(m->dtype == PLX_BOOL, PLX_ERR_INVALID, "the validity of the views is a Boolean column (true = valid: the array's validity bitmap as its values)");
   PLX_REQUIRE(m->len == v->len / 2, PLX_ERR_SHAPE, "validity column and views differ in length");
   PLX_REQUIRE((v->values && m->values) || v->len == 0, PLX_ERR_INVALID, "placeholder column has no data");
-  if (v->len) k::strview_stamp_nulls(v->values->as<uint64_t>(), m->values->as<uint64_t>(), m->len);
+  if (!v->len) return PLX_OK;
+  // a null entry of the Boolean column itself means "not valid" (its value bit is whatever was stored): valid = value AND validity
+  ColumnPtr eff = m;
+  if (m->validity) {
+    auto a = std::make_shared<Column>(); a->dtype = PLX_BOOL; a->len = m->len; a->values = m->values; a->null_count = 0;
+    auto b = std::make_shared<Column>(); b->dtype = PLX_BOOL; b->len = m->len; b->values = m->validity; b->null_count = 0;
+    eff = ops::bool_binop(PLX_AND, a, b);
+  }
+  // the stamps are written INTO the view buffer: a buffer the caller lent (plx_column_from_device) or one that other columns share is copied first, so that nobody
+  // else's views change under them
+  if (!v->values->owned || v->values.use_count() > 1) {
+    Buf copy = dev_alloc(v->values->bytes);
+    PLX_HIP(hipMemcpyAsync(copy->ptr, v->values->ptr, v->values->bytes, hipMemcpyDeviceToDevice, stream()));
+    v->values = copy;
+  }
+  k::strview_stamp_nulls(v->values->as<uint64_t>(), eff->values->as<uint64_t>(), m->len);
+  PLX_HIP(hipStreamSynchronize(stream()));      // (`eff` may be a temporary)
   PLX_CATCH
 }
 int plx_strview_groupby(plx_column views_u64_pairs, plx_column value, plx_column* out_codes, plx_strdict* out_dict, plx_column* out_sum, plx_column* out_count, plx_column* out_len) {

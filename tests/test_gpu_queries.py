@@ -210,7 +210,7 @@ def _join_groupby_reference(lk, lx, rk, ry):
 
 @pytest.mark.parametrize("shape", ["build_right", "build_left", "dup_build_keys", "probe_side_group_key", "sentinel_key"])
 def test_join_groupby_fusion_and_fallbacks(pl, shape):
-    """The fused join->aggregate pipeline only fires when a group is one build row; every other
+    """The fused join->aggregate pipeline fires when a group is one build row (duplicate build keys included: row chains); every other
     shape must fall back to the per-node path and still agree with a plain numpy evaluation."""
     rng = np.random.default_rng(31)
     nl, nr = (40_000, 3_000) if shape != "build_left" else (3_000, 40_000)
@@ -234,7 +234,9 @@ def test_join_groupby_fusion_and_fallbacks(pl, shape):
          .group_by(*keys).agg(pl.col(val).sum().alias("s"), pl.len().alias("n")))
     out = q.collect()
     plan = pl.last_plan()
-    fused = shape in ("build_right", "build_left", "sentinel_key")
+    fused = shape in ("build_right", "build_left", "sentinel_key", "dup_build_keys")      # duplicate build keys: the multi-value mode of the fused pipeline (round 5)
+    if shape == "dup_build_keys":
+        assert "multi-value (row chains" in plan, plan
     if shape == "build_left":   # aggregate reads the probe (= right, longer) side: y; group keys k + ... y is probe side -> not a build column
         fused = False
     assert ("FusedJoinGroupBy" in plan) == fused, plan
