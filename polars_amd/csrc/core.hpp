@@ -106,7 +106,10 @@ struct Column {
   // cached statistics of integer columns (zone-map style), filled lazily by ops::int_range
   int range_state = 0;      // 0 unknown, 1 known, 2 no valid rows
   int64_t range_min = 0, range_max = 0;
-  bool range_trusted = true;   // computed by the library (exact); false: caller-provided bounds (plx_column_set_bounds)
+  bool range_trusted = true;   // computed by the library (exact); false: caller-provided bounds (plx_column_set_bounds) or bounds the planner ASSUMED from a sample
+  bool range_assumed = false;  // range_min / range_max are the planner's guess (a strided sample + slack; engine.cpp assume_range): used like declared bounds -- every kernel
+                               // that addresses a table or narrows a value with them checks each row -- and when a row falls outside them the query is planned again from an exact pass
+  bool no_assume = false;      // a guess about this column was wrong once: exact statistics only
   // what the group-by planner learned from its strided sample of this column AS A KEY (engine.cpp KeySample: heavy hitters, distinct count,
   // group estimate): a column is immutable, so the next group-by on it with no predicate skips the 8 sample launches (0.3 ms per query)
   std::shared_ptr<void> key_sample;

@@ -380,7 +380,7 @@ struct PartPlan2 {
                                // every partition is populated whatever the range; 0: partition = id >> key_shift).  slice_magic = floor(2^64 / slice); key_shift = bits of `low`
   unsigned long long slice_magic;
   uint32_t n_tags;             // hash mode, wide keys: entries of the partition's LDS tag table (a multiple of 8: buckets of eight; ~4 per group the storage holds); n_slots = groups
-  uint32_t pad_;
+  uint32_t check_src;          // 1: the value bases (src_base) come from unverified bounds: a value that does not fit its narrowed field raises the scatter's flag [2]
 };
 // the multiplier of the join hash tables' slot hash (JoinBuildSink / ProbeAggSink; the reference's DirtyHash, polars-utils/src/hashing.rs:62-69): the hashed
 // partitioned probe takes its partition from the SAME top bits, so partition p of the probe side meets exactly region p of the build table

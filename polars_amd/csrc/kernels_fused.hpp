@@ -68,7 +68,7 @@ int64_t partitioned_agg(const fused::Shape& sh, const fused::Args& args, const f
 // LDS tables when they fit); hot_keys = heavy hitters pre-aggregated in the scatter pass (select_hot_keys on a sample table)
 // value range of a record source (rec_layout2(...).src_slot[j]) when it is a plain integer column with cached statistics: lets the third
 // generation scatter pack records (fused::kPackNarrow / kPackFused)
-struct SrcRange { bool known = false; int64_t mn = 0, mx = 0; };
+struct SrcRange { bool known = false; int64_t mn = 0, mx = 0; bool check = false; /* bounds nobody verified (the planner's sample): narrow with a per-row check */ };
 bool partition_plan2(const fused::Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, fused::PartPlan2* out,
                      const SrcRange* src_ranges = nullptr /* [fused::kMaxSrc] */);
 // hot_rows: sample rows the returned keys account for
@@ -95,7 +95,7 @@ bool partitioned_hash_probe_hits(const fused::Shape& sh, const fused::Args& args
 // fraction of adjacent pairs (strided sample) of an integer column that are non-decreasing: 1.0 = sorted ascending
 double sample_sortedness(const ColumnPtr& c);
 // smallest / largest valid value among 65536 rows (64 evenly spaced runs); false: no valid value in the sample / not an integer column
-bool sample_minmax(const ColumnPtr& c, int64_t* mn, int64_t* mx);
+bool sample_minmax(const ColumnPtr& c, int64_t* mn, int64_t* mx, int blocks = 64);
 // all jobs of a batch (key decodes + aggregate finalisations) in one launch
 void finalize_batch(const uint64_t* acc, int n_aggs, int64_t G, const fused::FinBatch& b);
 // packed group keys -> one key column

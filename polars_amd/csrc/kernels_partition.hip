@@ -230,6 +230,8 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
   const RecLayout2 L = rec_layout2(sh, pp.mode, pack);
   if (L.n_src > (uint32_t)kMaxSrc || L.rec_words > 13) return false;
   for (int j = 0; j < kMaxSrc; j++) pp.src_base[j] = (pack != kPackNone && ranges && ranges[j].known && (L.src_kind[j] == 3 || pack == kPackFused)) ? ranges[j].mn : 0;
+  pp.check_src = 0;
+  for (uint32_t j = 0; j < L.n_src && j < (uint32_t)kMaxSrc; j++) if (pack != kPackNone && ranges && ranges[j].known && ranges[j].check && (L.src_kind[j] == 3 || pack == kPackFused)) pp.check_src = 1;
   const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0;
   uint32_t tiles = 0;
   const uint32_t block = kEnvP3Block >= 64 && (uint32_t)kEnvP3Block >= NP && kEnvP3Block % 64 == 0 ? (uint32_t)kEnvP3Block : (uint32_t)kP2MaxBlock;
@@ -604,10 +606,11 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
                        (int)sh.n_aggs, (int)pp.len_idx, ap.counter, ap.overflow, ap.max_groups, ap.out_keys, ap.out_kvalid, ap.out_acc);
     PLX_HIP(hipGetLastError());
   }
-  uint32_t res[5] = {0, 0, 0, 0, 0};
-  d2h_sync(res, meta->ptr, 20);
+  uint32_t res[6] = {0, 0, 0, 0, 0, 0};
+  d2h_sync(res, meta->ptr, 24);
   PLX_REQUIRE(!res[3], PLX_ERR_INVALID, "partitioned group-by: a scatter workgroup ran out of chunks");
   PLX_REQUIRE(!res[4], PLX_ERR_INVALID, "group key outside the bounds declared for its column (plx_column_set_bounds)");
+  PLX_REQUIRE(!res[5], PLX_ERR_INVALID, "aggregated value outside the bounds assumed for its column");
   if (res[2]) return -1;
   if (minmax) { long long mm[2]; d2h_sync(mm, minmax->ptr, 16); key_range_out[0] = mm[0]; key_range_out[1] = mm[1]; }
   if (desc) *desc = std::string(gen3 ? "partitioned(v3," : "partitioned(v2,") + (direct ? "direct" : "hash") + ",P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec_words * 4) +
@@ -939,10 +942,10 @@ __global__ __launch_bounds__(kBlock) void sample_minmax_kernel(const void* __res
   }
   if (lane_id() == 0 && lo <= hi) { atomicMin(out, lo); atomicMax(out + 1, hi); }
 }
-bool sample_minmax(const ColumnPtr& c, int64_t* mn, int64_t* mx) {
+bool sample_minmax(const ColumnPtr& c, int64_t* mn, int64_t* mx, int max_blocks) {
   if (!c || !dtype_is_int(c->dtype) || c->dtype == PLX_U64 || c->len < 1 || !c->values) return false;
   const int64_t n = c->len, run = 1024;
-  const int blocks = (int)std::min<int64_t>(64, (n + run - 1) / run);
+  const int blocks = (int)std::min<int64_t>(max_blocks, (n + run - 1) / run);
   const int64_t stride = blocks > 1 ? (n - run) / (blocks - 1) : 0;
   Buf out = dev_alloc(16);
   const long long init[2] = {0x7fffffffffffffffll, (long long)0x8000000000000000ull};

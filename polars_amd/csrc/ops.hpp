@@ -36,7 +36,8 @@ ColumnPtr concat(const std::vector<ColumnPtr>& chunks);
 ColumnPtr slice_copy(const ColumnPtr& c, int64_t offset, int64_t len);
 
 // min / max of an integer column over valid rows (cached on the column); false if no valid rows
-bool int_range(const ColumnPtr& c, int64_t* mn, int64_t* mx);
+// (allow_assumed: the caller checks every row against the bounds and can re-run -- the group-by planner; see Column::range_assumed)
+bool int_range(const ColumnPtr& c, int64_t* mn, int64_t* mx, bool allow_assumed = false);
 
 }  // namespace ops
 void strview_encode_device(const uint64_t* views, const ColumnPtr& validity_holder, Buf data, int64_t n, plx_column* out_codes, uint64_t* out_dict);   // abi.cpp

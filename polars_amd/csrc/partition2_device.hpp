@@ -77,7 +77,7 @@ __device__ __forceinline__ uint64_t wide_key_hash(const uint64_t* w, uint32_t n_
 // ---- one row -> record dwords ---------------------------------------------------------------------------------------
 template <int MODE, class S, class RF>
 __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, const PartPlan2& pp, const RF& rf, int r, int64_t row, unsigned int* rec /* [L.rec_words] */,
-                                             uint32_t& part, bool& kvalid, uint64_t& key64) {
+                                             uint32_t& part, bool& kvalid, uint64_t& key64, uint32_t& narrow_viol /* |= 1: a value did not fit the narrowed field (pp.check_src) */) {
   if (L.n_key_cols) {
     // wide key (hash partitions): one 64-bit word per key column (0 for a null), the columns' null mask folded into the hash and kept in the validity dword
     uint64_t w[kMaxKeys];
@@ -100,7 +100,7 @@ __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, c
     for (int j = 0; j < kMaxSrc; j++) {
       if (j < (int)L.n_src) {
         const uint64_t v = rf.get(r, L.src_slot[j]);
-        if (L.src_kind[j] == 3) rec[L.src_off[j]] = (uint32_t)(v - (uint64_t)pp.src_base[j]);
+        if (L.src_kind[j] == 3) { rec[L.src_off[j]] = (uint32_t)(v - (uint64_t)pp.src_base[j]); if (pp.check_src && ((v - (uint64_t)pp.src_base[j]) >> 32) && ((rf.getv(L.src_slot[j]) >> r) & 1)) narrow_viol |= 1u; }
         else {
           rec[L.src_off[j]] = (uint32_t)v;
           if (!L.src_kind[j]) rec[L.src_off[j] + 1] = (uint32_t)(v >> 32);
@@ -138,8 +138,9 @@ __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, c
   for (int j = 0; j < kMaxSrc; j++) {
     if (j < (int)L.n_src) {
       const uint64_t v = rf.get(r, L.src_slot[j]);
-      if (L.pack == kPackFused) rec[0] |= (uint32_t)(v - (uint64_t)pp.src_base[0]) << pp.key_shift;      // one dword: key_low | (v - base) << key_shift
-      else if (L.src_kind[j] == 3) rec[L.src_off[j]] = (uint32_t)(v - (uint64_t)pp.src_base[j]);
+      // (pp.check_src: the bases come from bounds nobody has verified -- the planner's sample, engine.cpp assume_range: a value outside them is reported, never truncated silently)
+      if (L.pack == kPackFused) { rec[0] |= (uint32_t)(v - (uint64_t)pp.src_base[0]) << pp.key_shift; if (pp.check_src && ((v - (uint64_t)pp.src_base[0]) >> (32u - pp.key_shift)) && ((rf.getv(L.src_slot[j]) >> r) & 1)) narrow_viol |= 1u; }      // one dword: key_low | (v - base) << key_shift
+      else if (L.src_kind[j] == 3) { rec[L.src_off[j]] = (uint32_t)(v - (uint64_t)pp.src_base[j]); if (pp.check_src && ((v - (uint64_t)pp.src_base[j]) >> 32) && ((rf.getv(L.src_slot[j]) >> r) & 1)) narrow_viol |= 1u; }
       else {
         rec[L.src_off[j]] = (uint32_t)v;
         if (!L.src_kind[j]) rec[L.src_off[j] + 1] = (uint32_t)(v >> 32);
@@ -227,7 +228,9 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
 #pragma unroll
       for (int r = 0; r < kRows; r++) {
         bool kvalid; uint64_t key64;
-        make_record2<MODE>(sh, L, pp, rf[t], r, row0 + r, rec[t][r], part[t][r], kvalid, key64);
+        uint32_t nviol = 0;
+        make_record2<MODE>(sh, L, pp, rf[t], r, row0 + r, rec[t][r], part[t][r], kvalid, key64, nviol);
+        if (nviol && pass[r]) sp.flags[2] = 1u;                                            // a value outside the bounds its narrowing assumed: the query is planned again
         pending[t][r] = pass[r];
         if (MODE == (int)kP2Hash && sp.key_minmax && pass[r] && kvalid) {
           kmin_seen = (long long)key64 < kmin_seen ? (long long)key64 : kmin_seen;

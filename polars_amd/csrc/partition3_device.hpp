@@ -105,7 +105,9 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
 #pragma unroll
       for (int r = 0; r < kRows; r++) {
         bool kvalid; uint64_t key64;
-        make_record2<MODE>(sh, L, pp, rf[t], r, row0 + r, rec[t][r], part[t][r], kvalid, key64);
+        uint32_t nviol = 0;
+        make_record2<MODE>(sh, L, pp, rf[t], r, row0 + r, rec[t][r], part[t][r], kvalid, key64, nviol);
+        if (nviol && pass[r]) sp.flags[2] = 1u;                                            // a value outside the bounds its narrowing assumed: the query is planned again
         bool pend = pass[r];
         if (MODE == (int)kP2Hash && sp.key_minmax && pass[r] && kvalid) {
           kmin_seen = (long long)key64 < kmin_seen ? (long long)key64 : kmin_seen;

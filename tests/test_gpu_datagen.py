@@ -114,3 +114,45 @@ def test_customer_generator_matches_host_twin(pl):
     df = datagen.customer_native(pl, n, seed=5)
     want = datagen.customer_native_host(0, n, seed=5)
     assert np.array_equal(df["c_custkey"].to_numpy(), want["c_custkey"]) and np.array_equal(df["c_mktsegment"].to_numpy(), want["c_mktsegment"])
+
+
+def _outside_the_sample(n, runs=1024, run=1024):
+    """row indices no run of the planner's strided range sample (k::sample_minmax: `runs` evenly spaced runs of `run` rows) looks at"""
+    stride = (n - run) // (runs - 1)
+    return stride // 2 + stride * np.arange(3, 9)            # the middle of six gaps between runs
+
+
+@pytest.mark.parametrize("violate", ["nothing", "key", "value"])
+def test_bounds_assumed_from_a_sample_are_checked_per_row_and_a_wrong_guess_runs_again(pl, violate):
+    """First group-by over columns nobody has statistics for: the planner GUESSES their bounds from a strided sample (engine.cpp assume_range) instead of two exact
+    min / max passes, plans direct-address tables and narrowed values with them, and every row is checked against them in the scatter.  A key or a value outside the guess
+    (placed where the sample does not look) must not produce a wrong answer: the query is planned again from exact statistics, and these columns are never guessed about again."""
+    import re
+    from polars_amd import queries
+    rng = np.random.default_rng(12)
+    n = 17_000_000
+    ids = rng.integers(0, 300_000, n).astype(np.int64)
+    v = rng.integers(0, 1000, n).astype(np.int64)
+    hole = _outside_the_sample(n)
+    if violate == "key":
+        ids[hole] = 5_000_000 + np.arange(len(hole))          # needs more key bits than the sampled span: beyond any free slack
+    if violate == "value":
+        v[hole] = (1 << 40) + np.arange(len(hole))            # does not fit a 32-bit offset from the sampled minimum
+    df = pl.DataFrame({"key": ids + 1000, "v": v})
+    out = queries.cfg3(df.lazy()).collect().sort_host("key")
+    plan = pl.last_plan()
+    assert "bounds assumed from the sample" in plan, plan
+    assert ("AssumedBoundsViolated{" in plan) == (violate != "nothing"), plan
+    assert re.search(r"partitioned\(v3,direct", plan), plan
+    keys, inv = np.unique(ids + 1000, return_inverse=True)
+    assert np.array_equal(np.array(out["key"], dtype=np.int64), keys)
+    cols = [c for c in out if c != "key"]
+    sums = np.zeros(len(keys), np.int64); np.add.at(sums, inv, v)
+    cnts = np.bincount(inv)
+    got = [np.array(out[c], dtype=np.int64) for c in cols]
+    assert any(np.array_equal(g, sums) for g in got) and any(np.array_equal(g, cnts) for g in got)
+    # the next run: the same plan without a guess when it was right (the bounds stay, checked per row), exact statistics when it was wrong
+    out2 = queries.cfg3(df.lazy()).collect().sort_host("key")
+    plan2 = pl.last_plan()
+    assert "AssumedBoundsViolated{" not in plan2 and re.search(r"partitioned\(v3,direct", plan2), plan2
+    assert out2 == out
