@@ -608,8 +608,14 @@ static bool assume_range(const ColumnPtr& col) {
     case PLX_I32: lo_lim = INT32_MIN; hi_lim = INT32_MAX; break; case PLX_U32: lo_lim = 0; hi_lim = 0xffffffffll; break;
     default: break;
   }
-  const __int128 lo = std::max<__int128>((__int128)smn - slack, lo_lim);
+  __int128 lo = std::max<__int128>((__int128)smn - slack, lo_lim);
   __int128 hi = std::min<__int128>((__int128)smx + slack, hi_lim);
+  // non-negative values whose span costs the same number of bits from 0 as from their minimum: from 0 (ids and counts usually start there, and a key program without
+  // the subtraction is the shape the ahead-of-time kernels were built for)
+  if (smn >= 0) {
+    auto bits_of = [](__int128 span) { int b = 1; while (b < 62 && ((__int128)1 << b) < span + 2) b++; return b; };
+    if (bits_of(hi) == bits_of(hi - lo)) lo = 0;
+  }
   // everything up to the next power of two above the span costs the same number of key bits (and value bits): take it -- a heavy-tailed id column (ids handed out by
   // popularity) shows its largest ids to no sample
   { int b = 1; while (b < 62 && ((__int128)1 << b) < hi - lo + 2) b++; hi = std::min<__int128>(lo + ((__int128)1 << b) - 2, hi_lim); }
@@ -649,7 +655,15 @@ static KeyPlan lower_keys(Compiler& c, const std::vector<int>& key_exprs) {
           else kp.note += "KeyRange{" + std::string(x->name) + ": sample looks dense -> range pass}; ";
         }
       }
-      if (part.dtype == PLX_U64) all_packable = false;
+      // several key columns: whether they bit-pack is decided from their ranges -- guessed from the sample like a single key's (a sampled span beyond 2^62 settles it
+      // without any pass: such a column packs with nothing)
+      bool hopeless = false;
+      if (cheap && nk > 1 && col->range_state == 0 && part.dtype != PLX_U64 && dtype_width(part.dtype) > 2 && col->values && col->len >= ((int64_t)1 << 24) && assume_ranges() && !col->no_assume) {
+        int64_t smn = 0, smx = 0;
+        if (k::sample_minmax(col, &smn, &smx, 1024) && (unsigned __int128)((__int128)smx - (__int128)smn) >= ((unsigned __int128)1 << 61)) hopeless = true;
+        else assume_range(col);
+      }
+      if (part.dtype == PLX_U64 || hopeless) all_packable = false;
       else if (cheap) {
         if (col->values && ops::int_range(col, &info[i].mn, &info[i].mx, true)) info[i].have_range = true;
         else if (col->range_state == 1) { info[i].have_range = true; info[i].mn = col->range_min; info[i].mx = col->range_max; }

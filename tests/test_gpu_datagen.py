@@ -141,9 +141,9 @@ def test_bounds_assumed_from_a_sample_are_checked_per_row_and_a_wrong_guess_runs
     df = pl.DataFrame({"key": ids + 1000, "v": v})
     out = queries.cfg3(df.lazy()).collect().sort_host("key")
     plan = pl.last_plan()
-    assert "bounds assumed from the sample" in plan, plan
+    assert ("bounds assumed from the sample" in plan) == (violate == "nothing"), plan          # (the plan string describes the run that produced the result)
     assert ("AssumedBoundsViolated{" in plan) == (violate != "nothing"), plan
-    assert re.search(r"partitioned\(v3,direct", plan), plan
+    assert re.search(r"partitioned\(v3,direct" if violate != "key" else r"partitioned\(v3,hash", plan), plan      # (the stray keys make the exact range a 23-bit one: hash partitions)
     keys, inv = np.unique(ids + 1000, return_inverse=True)
     assert np.array_equal(np.array(out["key"], dtype=np.int64), keys)
     cols = [c for c in out if c != "key"]
@@ -154,5 +154,5 @@ def test_bounds_assumed_from_a_sample_are_checked_per_row_and_a_wrong_guess_runs
     # the next run: the same plan without a guess when it was right (the bounds stay, checked per row), exact statistics when it was wrong
     out2 = queries.cfg3(df.lazy()).collect().sort_host("key")
     plan2 = pl.last_plan()
-    assert "AssumedBoundsViolated{" not in plan2 and re.search(r"partitioned\(v3,direct", plan2), plan2
+    assert "AssumedBoundsViolated{" not in plan2 and "bounds assumed" not in plan2, plan2
     assert out2 == out

@@ -8,6 +8,6 @@ python - "$out/$tag.json" <<'P'
 import json,sys
 l=[x for x in open(sys.argv[1]).read().splitlines() if x.startswith("[bench] full record: ")]
 d=json.loads(l[-1][21:]) if l else {}
-print("   ms", d.get("ms_per_step"), "verified", (d.get("verified") or {}).get("ok"), {k:v["avg_us"] for k,v in (d.get("kernels") or {}).items() if v["avg_us"]>80})
+print("   ms", d.get("ms_per_step"), "one_shot", d.get("one_shot_ms"), "cold", d.get("cold_first_step_ms"), "verified", (d.get("verified") or {}).get("ok"), {k:v["avg_us"] for k,v in (d.get("kernels") or {}).items() if v["avg_us"]>80})
 P
 tail -2 "$out/$tag.err"
