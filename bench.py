@@ -948,7 +948,7 @@ def scan_extra(pl, n: int):
     return out
 
 
-PMC_ROUND = "r04"
+PMC_ROUND = "r05"
 
 
 def pmc_traffic(workload_name: str, kernel: str, rows: int):
@@ -962,7 +962,7 @@ def pmc_traffic(workload_name: str, kernel: str, rows: int):
              "cfg2_filter_arith_agg_1e9": ("cfg2", 10 ** 9), "cfg3_groupby_1e6_keys_1e9": ("cfg3", 10 ** 9), "cfg5_dict_string_keys_1e9": ("cfg5", 10 ** 9),
              "tpch_q3_sf100_shuffled_inputs": ("q3s", SF100_ORDERS + SF100_LINEITEM), "cfg5_utf8view_keys_1e9": ("cfg5s", 10 ** 9),
              "tpch_q3_sf100_hashed_keys": ("q3h", SF100_ORDERS + SF100_LINEITEM), "cfg2_nulls5pct_1e9": ("cfg2n", 10 ** 9), "cfg3_zipf_1e9": ("cfg3z", 10 ** 9),
-             "cfg3_sparse_keys_1e9": ("cfg3s", 10 ** 9)}.get(workload_name)
+             "cfg3_sparse_keys_1e9": ("cfg3s", 10 ** 9), "cfg3_two_int64_keys_1e9": ("cfg3w", 10 ** 9), "join_duplicate_build_keys_sf100": ("q3d", SF100_LINEITEM + SF100_LINEITEM * 2 // 15)}.get(workload_name)
     if short is None or (short[1] is not None and abs(rows - short[1]) > 0.01 * short[1]):
         return None
     try:

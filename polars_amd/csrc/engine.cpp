@@ -1232,9 +1232,8 @@ static std::string finals_outputs_fields(const Plan& plan, const std::vector<int
   o << "]";
   return o.str();
 }
-static void dump_compiled(ProgramDump* dump, const char* kind, const Plan& plan, const Compiler& c, const KeyPlan* kp, const std::vector<int>& agg_nodes,
-                          const std::vector<FinalSpec>& specs, const std::vector<int>& out_exprs, int len_idx, int first_idx, bool maintain_order) {
-  if (!dump) return;
+static std::string compiled_json(const char* kind, const Plan& plan, const Compiler& c, const KeyPlan* kp, const std::vector<int>& agg_nodes,
+                                 const std::vector<FinalSpec>& specs, const std::vector<int>& out_exprs, int len_idx, int first_idx, bool maintain_order) {
   std::ostringstream o;
   o << "{\"kind\":\"" << kind << "\"," << program_fields(c, *c.df);
   o << ",\"len_idx\":" << len_idx << ",\"first_idx\":" << first_idx << ",\"maintain_order\":" << (maintain_order ? 1 : 0);
@@ -1248,7 +1247,11 @@ static void dump_compiled(ProgramDump* dump, const char* kind, const Plan& plan,
     o << "]}";
   }
   o << "," << finals_outputs_fields(plan, agg_nodes, specs, out_exprs) << "}";
-  dump->json = o.str();
+  return o.str();
+}
+static void dump_compiled(ProgramDump* dump, const char* kind, const Plan& plan, const Compiler& c, const KeyPlan* kp, const std::vector<int>& agg_nodes,
+                          const std::vector<FinalSpec>& specs, const std::vector<int>& out_exprs, int len_idx, int first_idx, bool maintain_order) {
+  if (dump) dump->json = compiled_json(kind, plan, c, kp, agg_nodes, specs, out_exprs, len_idx, first_idx, maintain_order);
 }
 
 // Select(aggregations) over [Filter]* over `src`
@@ -1522,7 +1525,9 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   if (left_join) {
     if (psemis.size() + 1 > (size_t)kMaxLuts) return no("left join: no lookup bitmap left for the membership test");
     if (kdt == PLX_U64) return no("left join on UInt64 keys");
-    const bool have = B->height > 0 && ops::int_range(B->cols[bki], &a_kmn, &a_kmx);
+    bool have = false;                                          // (a placeholder column -- compile-only callers -- has its declared range or none)
+    if (B->height > 0 && B->cols[bki]->values) have = ops::int_range(B->cols[bki], &a_kmn, &a_kmx);
+    else if (B->height > 0 && B->cols[bki]->range_state == 1) { a_kmn = B->cols[bki]->range_min; a_kmx = B->cols[bki]->range_max; have = true; }
     const unsigned __int128 range128 = have ? (unsigned __int128)((__int128)a_kmx - (__int128)a_kmn) + 1 : 1;
     if (range128 > ((unsigned __int128)1 << 34) || (have && range128 > (unsigned __int128)B->height * 256 + 4096)) return no("left join: build key range too wide for the membership bitmap");
     a_range = (uint64_t)range128;
@@ -1594,7 +1599,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   if (compile_only) {
     if (t_program_dump) {   // the three scans + how groups, group keys and outputs are derived from them (tests/program_eval.py evaluate_join)
       std::ostringstream o;
-      o << "{\"kind\":\"join_group_by\",\"build_side\":\"" << (build_right ? "right" : "left") << "\",\"build_key\":" << jstr(B->names[bki]) << ",\"probe_key\":" << jstr(P->names[pki])
+      o << "{\"kind\":\"join_group_by\",\"how\":\"" << (left_join ? "left" : "inner") << "\",\"build_side\":\"" << (build_right ? "right" : "left") << "\",\"build_key\":" << jstr(B->names[bki]) << ",\"probe_key\":" << jstr(P->names[pki])
         << ",\"count\":{" << program_fields(cnt, *B) << "},\"build\":{" << program_fields(cb, *B) << "},\"probe\":{" << program_fields(cp, *P) << "},\"len_idx\":" << len_idx << ",\"group_keys\":[";
       for (size_t i = 0; i < gkeys.size(); i++)
         o << (i ? "," : "") << "{\"name\":" << jstr(output_name(plan, gkeys[i].expr)) << ",\"is_join_key\":" << (gkeys[i].is_join_key ? 1 : 0) << ",\"build_col\":"
@@ -1611,7 +1616,11 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
           }
         }
       }
-      o << "]}";
+      o << "]";
+      // a left join's unmatched rows: a group-by program over the probe side whose predicate ends in NOT member(key) -- lookup bitmap `lut` = the build keys that pass the build program
+      if (left_join) o << ",\"unmatched\":{\"lut\":" << psemis.size() << ",\"kmin\":\"" << a_kmn << "\",\"range\":\"" << a_range << "\",\"program\":"
+                       << compiled_json("group_by", plan, ca, &akp, agg_nodes, aspecs, gb.exprs, a_len_idx, -1, false) << "}";
+      o << "}";
       t_program_dump->json = o.str();
     }
     return true;

@@ -233,9 +233,9 @@ def _finalise(fs, cells):
     raise NotImplementedError(f"final kind {kind}")
 
 
-def evaluate(prog, cols):
+def evaluate(prog, cols, luts=None):
     """-> {output name: (values, valid or None)}; group_by results carry one row per group, in unspecified order."""
-    slots, passed = run_rows(prog, cols)
+    slots, passed = run_rows(prog, cols, luts)
     n = len(passed)
     rows = np.arange(n)
     res = {}
@@ -304,10 +304,13 @@ def build_luts(prog, filter_cols):
 
 def evaluate_join(prog, build_cols, probe_cols, filter_cols=()):
     """The fused join -> group-by pipeline (engine.cpp fused_join_groupby): build scan (predicate + key) -> probe scan
-    (predicate + key + aggregates landing in the matching build row's cells) -> groups with at least one probe row.
+    (predicate + key + aggregates landing in the cells of the matching build rows) -> groups with at least one probe row.
+    Build keys may repeat (round 5, the multi-value mode of the table): every probe row then contributes once per build row of
+    its key, a group is a build row -- or the rows of a key that agree on all build-side group columns (one group of the
+    reference's group-by over the joined frame).  prog["how"] == "left": the probe rows without a partner are grouped by
+    their own key (prog["unmatched"]: a group_by program behind NOT member(key)), nulls in the build-side group columns.
     build_cols / probe_cols: {original column name of that frame: (values, valid or None)}; filter_cols: the frames of
-    prog["semis"] in order.  Returns {output name: (values, valid or None)}, or None when the surviving build keys (or a
-    semi filter's keys) are not unique (the engine then falls back to the per-node join)."""
+    prog["semis"] in order.  Returns {output name: (values, valid or None)}, or None when a semi filter's keys are not unique."""
     luts = build_luts(prog, filter_cols)
     if luts is None:
         return None
@@ -322,18 +325,30 @@ def evaluate_join(prog, build_cols, probe_cols, filter_cols=()):
     assert int(ccells[0, 0]) == len(rows_b), (int(ccells[0, 0]), len(rows_b))
     order = np.argsort(keys_b, kind="stable")
     skeys, srows = keys_b[order], rows_b[order]
-    if len(skeys) > 1 and (skeys[1:] == skeys[:-1]).any():
-        return None
+    nb = len(skeys)
+    # representatives: the first build row (in this order) among the rows of one key that agree on every build-side group column
+    ident = [skeys.astype(np.uint64)]
+    for gk in prog["group_keys"]:
+        if not gk["is_join_key"]:
+            v, m = build_cols[gk["build_col"]]
+            mm = np.ones(len(v), bool) if m is None else m
+            ident += [np.where(mm[srows], v[srows].astype(np.int64).view(np.uint64), U(0)), mm[srows].astype(np.uint64)]
+    if nb:
+        _, first, inv = np.unique(np.stack(ident, axis=1), axis=0, return_index=True, return_inverse=True)
+        rep = first[np.asarray(inv).reshape(-1)]
+    else:
+        rep = np.zeros(0, np.int64)
     p_slots, p_pass = run_rows(prog["probe"], probe_cols, luts, split=True)     # the probe kernel's op order
     pk, pkm = p_slots[prog["probe"]["key"]]
-    pos = np.searchsorted(skeys, pk)
-    pos_c = np.minimum(pos, max(len(skeys) - 1, 0))
-    hit = (len(skeys) > 0) & (skeys[pos_c] == pk) if len(skeys) else np.zeros(len(pk), bool)
-    sel = p_pass & pkm & hit
-    n = len(sel)
-    group_of = np.where(sel, pos_c, 0).astype(np.int64)
-    cells = _cells(prog["probe"], p_slots, sel, np.arange(n), group_of, len(skeys))
-    live = cells[:, prog["len_idx"]] != 0 if len(skeys) else np.zeros(0, bool)
+    lo, hi = np.searchsorted(skeys, pk, "left"), np.searchsorted(skeys, pk, "right")
+    sel = p_pass & pkm & (hi > lo)
+    prow = np.nonzero(sel)[0]
+    cnt = (hi - lo)[prow]
+    xrow = np.repeat(prow, cnt)                                                  # one entry per (probe row, build row of its key)
+    xpos = np.repeat(lo[prow], cnt) + (np.arange(len(xrow)) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+    x_slots = {s_: (v[xrow], m[xrow]) for s_, (v, m) in p_slots.items()}
+    cells = _cells(prog["probe"], x_slots, np.ones(len(xrow), bool), xrow, rep[xpos].astype(np.int64), nb)
+    live = cells[:, prog["len_idx"]] != 0 if nb else np.zeros(0, bool)
     cells = cells[live]
     res = {}
     for gk in prog["group_keys"]:
@@ -350,4 +365,23 @@ def evaluate_join(prog, build_cols, probe_cols, filter_cols=()):
         if o["final"] < 0:
             raise NotImplementedError(f"output {o['name']} is a row expression over aggregates")
         res[o["name"]] = _finalise(prog["finals"][o["final"]], cells)
+    if prog.get("how") == "left":
+        un = prog["unmatched"]
+        kmin, rng = int(un["kmin"]), int(un["range"])
+        bits = np.zeros(max(rng, 1), bool)
+        idx = skeys.view(np.int64) - kmin
+        bits[idx[(idx >= 0) & (idx < len(bits))]] = True
+        # (the unmatched program numbers its lookups on its own: the probe side's semi filters first, then the membership bitmap)
+        n_bsemi = sum(1 for sm in prog.get("semis", []) if sm["side"] == "build")
+        un_luts = {i - n_bsemi: b for i, b in luts.items() if i >= n_bsemi}
+        un_luts[un["lut"]] = bits
+        tail = evaluate(un["program"], probe_cols, un_luts)
+        n_t = len(next(iter(tail.values()))[0])
+        for name, (v, m) in list(res.items()):
+            if name in tail:
+                tv, tm = tail[name]
+            else:                                                                # a build-side group column: null for a row without a partner
+                tv, tm = np.zeros(n_t, v.dtype), np.zeros(n_t, bool)
+            mm = np.concatenate([np.ones(len(v), bool) if m is None else m, np.ones(n_t, bool) if tm is None else tm])
+            res[name] = (np.concatenate([v, tv.astype(v.dtype)]), None if mm.all() else mm)
     return res

@@ -30,6 +30,12 @@ CASES = [
     ("plx::k::(anonymous namespace)::sg_chunk_place_kernel(unsigned int const*, long, unsigned int, unsigned long long const*, unsigned int*, unsigned int*)", "part2_chunk_sort"),
     ("plx::k::direct_pairs_compact_kernel(plx::fused::DirectJoinTable, long, int, int, unsigned long long*, unsigned long long*, unsigned int*, unsigned long long*)", "table_compact"),
     ("void plx::k::datagen_uniform_kernel<long>(long, unsigned long, unsigned int, long, long, double, long*)", "datagen_uniform_i64"),
+    ("void plx::k::part3_scatter_kernel<plx::k::StatProg<13>, 0, 1, 1, false>(plx::fused::Shape, plx::fused::Args, plx::k::PartPlan2, plx::k::ScatterParams2)", "part3_scatter[#13,h,t1,p1]"),
+    ("void plx::k::part2_agg_kernel<plx::k::StatProg<13>, 0, 1>(plx::k::PartPlan2, plx::k::AggParams2)", "part_agg_lds[#13,h,p1]"),
+    ("plx::k::canonicalise_chains_kernel(plx::fused::JoinAggTable, plx::fused::RepCols, unsigned int, unsigned int*)", "join_chain_representatives"),
+    ("plx::k::rows_agg_compact_kernel(unsigned long long const*, long, int, int, unsigned long long*, unsigned int*, unsigned long long*)", "table_compact"),
+    ("plx_jit_part3_scatter_21_0a1b2c3d", "part3_scatter[jit,h,t2,p0]"), ("plx_jit_part3_scatter_60_0a1b2c3d", "part3_scatter[jit,d,t1,p1,hot]"), ("plx_jit_part3_agg_85_deadbeef", "part_agg_lds[jit,h,p1]"),
+    ("plx_jit_RegAggSink_0_0a1b2c3d", None),
     ("__amd_rocclr_fillBufferAligned", None),
 ]
 
@@ -39,7 +45,7 @@ def test_kernel_symbols_map_to_the_tracer_names():
         assert pmc.scope_of(symbol) == name, (symbol, pmc.scope_of(symbol), name)
 
 
-ROUND = "r04"
+ROUND = "r05"
 
 
 def test_committed_summaries_are_keyed_by_symbol_and_cover_every_kernel_that_matters():

@@ -389,11 +389,65 @@ def test_join_group_by_pipeline_matches_numpy(build):
             assert close(g[key][c], wv), (key, c, g[key][c], wv)
 
 
-def test_join_pipeline_reports_duplicate_build_keys():
-    bcols = {"k": (np.array([1, 2, 2, 3], dtype=np.int64), None), "attr": (np.arange(4, dtype=np.int64), None)}
-    pcols = {"k": (np.array([2, 3, 3, 9, 1, 2], dtype=np.int64), None), "v": (np.arange(6, dtype=np.int64), None)}
-    lf = frame_like(pcols).lazy().join(frame_like(bcols).lazy(), on="k").group_by("k", "attr").agg(pl.col("v").sum().alias("s"))
-    assert pe.evaluate_join(lf.debug_program(), bcols, pcols) is None      # the engine detects this at run time and takes the per-node join
+def _pandas_join_groupby(bcols, pcols, how, keys, bpred=None, ppred=None):
+    """pandas: [filter] both frames -> merge on k -> group by `keys` (nulls are groups) -> sum(v), len"""
+    pd = pytest.importorskip("pandas")
+    def frame(cols, pred):
+        d = {}
+        for n, (v, m) in cols.items():
+            a = pd.array(v, dtype="Int64")
+            if m is not None:
+                a[~m] = pd.NA
+            d[n] = a
+        f = pd.DataFrame(d)
+        return f if pred is None else f[pred(f)]
+    B, P = frame(bcols, bpred), frame(pcols, ppred)
+    # a null key matches nothing (pandas would match NA with NA): join the valid keys, keep the null-key probe rows of a left join as unmatched
+    J = P[P["k"].notna()].merge(B[B["k"].notna()], on="k", how=how)
+    if how == "left":
+        J = pd.concat([J, P[P["k"].isna()]], ignore_index=True)
+    g = J.groupby(keys, dropna=False).agg(s=("v", "sum"), n=("v", "size")).reset_index()
+    return {tuple(None if pd.isna(x) else int(x) for x in row[:len(keys)]): {"s": int(row[len(keys)]), "n": int(row[len(keys) + 1])} for row in g.itertuples(index=False)}
+
+
+def test_join_pipeline_with_duplicate_build_keys_groups_by_build_row():
+    """Duplicate build keys (round 5: the multi-value mode of the fused pipeline): every probe row contributes once per build row of its key; build rows of a key that
+    agree on the build-side group column are ONE group.  The compiled programs through the numpy interpreter against pandas merge -> groupby."""
+    bcols = {"k": (np.array([1, 2, 2, 3, 2, 7, 7], dtype=np.int64), None), "attr": (np.array([10, 20, 21, 30, 20, 70, 70], dtype=np.int64), None)}
+    pcols = {"k": (np.array([2, 3, 3, 9, 1, 2, 7, 8], dtype=np.int64), None), "v": (np.arange(8, dtype=np.int64), None)}      # (the longer side probes)
+    lf = frame_like(pcols).lazy().join(frame_like(bcols).lazy(), on="k").group_by("k", "attr").agg(pl.col("v").sum().alias("s"), pl.len().alias("n"))
+    got = by_key(pe.evaluate_join(lf.debug_program(), bcols, pcols), ["k", "attr"])
+    assert got == _pandas_join_groupby(bcols, pcols, "inner", ["k", "attr"])
+    assert got[(2, 20)] == {"s": 2 * (0 + 5), "n": 4} and got[(7, 70)] == {"s": 12, "n": 2}          # two build rows (2, 20): every probe row of key 2 counts twice
+    rng = np.random.default_rng(8)
+    nb, npr = 4_000, 30_000
+    bcols = {"k": (rng.integers(0, 1500, nb).astype(np.int64), rng.random(nb) < 0.97), "attr": (rng.integers(0, 3, nb).astype(np.int64), rng.random(nb) < 0.9),
+             "flag": (rng.integers(0, 100, nb).astype(np.int64), None)}
+    pcols = {"k": (rng.integers(0, 3000, npr).astype(np.int64), rng.random(npr) < 0.95), "v": (rng.integers(-50, 50, npr).astype(np.int64), None)}
+    for keys in (["k", "attr"], ["k"]):
+        lf = (frame_like(pcols).lazy().filter(pl.col("v") > -40).join(frame_like(bcols).lazy().filter(pl.col("flag") < 80), on="k").group_by(*keys)
+              .agg(pl.col("v").sum().alias("s"), pl.len().alias("n")))
+        got = by_key(pe.evaluate_join(lf.debug_program(), bcols, pcols), keys)
+        want = _pandas_join_groupby(bcols, pcols, "inner", keys, bpred=lambda f: f["flag"] < 80, ppred=lambda f: f["v"] > -40)
+        assert got == want and len(want) > 1000, keys
+
+
+def test_left_join_pipeline_keeps_the_unmatched_rows_as_groups_of_their_own():
+    """LEFT JOIN -> group_by: the matched rows as the inner join (duplicate build keys included), the rows without a partner grouped by their own key with nulls in the
+    build-side group column; a null probe key matches nothing and is a group of its own; a predicate on the right table decides who MATCHES, not who survives."""
+    rng = np.random.default_rng(9)
+    nb, npr = 3_000, 25_000
+    bcols = {"k": (rng.integers(100, 1600, nb).astype(np.int64), None), "attr": (rng.integers(0, 4, nb).astype(np.int64), None), "flag": (rng.integers(0, 100, nb).astype(np.int64), None)}
+    pcols = {"k": (rng.integers(0, 2500, npr).astype(np.int64), rng.random(npr) < 0.96), "v": (rng.integers(-50, 50, npr).astype(np.int64), None)}
+    for keys in (["k", "attr"], ["k"]):
+        lf = (frame_like(pcols).lazy().filter(pl.col("v") > -45).join(frame_like(bcols).lazy().filter(pl.col("flag") < 60), on="k", how="left").group_by(*keys)
+              .agg(pl.col("v").sum().alias("s"), pl.len().alias("n")))
+        prog = lf.debug_program()
+        assert prog["how"] == "left" and prog["build_side"] == "right" and "unmatched" in prog
+        got = by_key(pe.evaluate_join(prog, bcols, pcols), keys)
+        want = _pandas_join_groupby(bcols, pcols, "left", keys, bpred=lambda f: f["flag"] < 60, ppred=lambda f: f["v"] > -45)
+        assert got == want and len(want) > 1500, keys
+        assert any(k[0] is None for k in want) and (keys == ["k"] or any(k[1] is None and k[0] is not None for k in want))
 
 
 @pytest.mark.parametrize("case", [c for c in __import__("tests.kat", fromlist=["kat"]).load_cases("groupby")], ids=lambda c: c["id"])

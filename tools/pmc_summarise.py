@@ -22,6 +22,8 @@ SCOPES = [  # (regex on the demangled kernel name, ProfileScope name in bench.py
     (r"scan_block_kernel|scan_add_kernel|scan_", "exclusive_scan"), (r"gather_multi_kernel", "gather_multi"), (r"gather_multi_kernel", "gather_multi"), (r"gather_kernel", "gather_u32"), (r"finalize_batch_kernel", "finalize_batch"),
     (r"datagen_uniform_kernel<long", "datagen_uniform_i64"), (r"datagen_", "datagen_other"), (r"hot_candidates_kernel|hot_emit_kernel", "hot_keys"),
     (r"strgroup_scatter_kernel", "strgroup_scatter"), (r"strgroup_agg_kernel", "strgroup_agg_lds"),
+    (r"canonicalise_chains_kernel", "join_chain_representatives"), (r"rows_agg_compact_kernel|wide_compact_kernel", "table_compact"),
+    (r"fused_scan_kernel<.*WideAggSink", "fused_scan_wideagg"),
     (r"init_acc_kernel|fill_u64_kernel", "table_init"), (r"strview_encode_kernel", "strview_dict_encode"), (r"strdict_", "strdict_materialise"),
 ]
 
@@ -30,6 +32,16 @@ def scope_of(kernel: str):
     """The name the library's HIP-event profile gives a launch of this kernel SYMBOL: AOT instantiations carry their template
     arguments (kernels_fused.hip scope_name, kernels_partition.hip partitioned_agg2), so bench.py only ever pairs a counter figure
     with the very instantiation it timed."""
+    # run-time compiled kernels carry their kind in the symbol (jit.cpp kernel_symbol: plx_jit_<kind>_<sink number>_<shape hash>)
+    m = re.match(r"plx_jit_part3_scatter_(\d+)_", kernel)
+    if m:
+        v = int(m.group(1)) - 19
+        mode, tiles, pack, hot = v & 1, 1 + ((v >> 1) & 3), (v >> 3) & 3, v >> 5
+        return f"{'probe_scatter' if pack == 3 else 'part3_scatter'}[jit,{'d' if mode else 'h'},t{tiles},p{pack}{',hot' if hot else ''}]"
+    m = re.match(r"plx_jit_part3_agg_(\d+)_", kernel)
+    if m:
+        v = int(m.group(1)) - 83
+        return f"part_agg_lds[jit,{'d' if v & 1 else 'h'},p{v >> 1}]"
     m = re.search(r"fused_scan_kernel<.*StatProg<(\d+)>", kernel)
     sid = m.group(1) if m else None
     m = re.search(r"part3_scatter_kernel<.*StatProg<(\d+)>\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*(?:,\s*(true|false)\s*)?>", kernel)
