@@ -33,13 +33,15 @@
 // Launch cases of the join-pipeline AOT shapes; empty when fused_shapes.hpp was generated without them.
 #ifdef PLX_HAVE_Q3_SHAPES
 #define PLX_STATIC_JOIN_BUILD_CASES \
-  case SHAPE_Q3_BUILD: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_BUILD>, JoinBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+  case SHAPE_Q3_BUILD: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_BUILD>, JoinBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break; \
+  case SHAPE_Q3D_BUILD: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3D_BUILD>, JoinBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
 #define PLX_STATIC_PROBE_AGG_CASES \
   case SHAPE_Q3_PROBE: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_PROBE>, ProbeAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
 #define PLX_STATIC_REGAGG_EXTRA_CASES \
   case SHAPE_Q3_COUNT: PLX_LAUNCH_SCAN(StatProg<SHAPE_Q3_COUNT>, RegAggSink, grid, 0, sh, args, sp); break;
 #define PLX_STATIC_DIRECT_BUILD_CASES \
-  case SHAPE_Q3_BUILD: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_BUILD>, DirectBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
+  case SHAPE_Q3_BUILD: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_BUILD>, DirectBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break; \
+  case SHAPE_Q3D_BUILD: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3D_BUILD>, DirectBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
 #define PLX_STATIC_DIRECT_PROBE_CASES \
   case SHAPE_Q3_PROBE: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_PROBE>, DirectProbeAggSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;
 #ifdef PLX_HAVE_Q3FULL_SHAPES

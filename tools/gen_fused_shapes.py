@@ -57,6 +57,9 @@ def shapes():
         ("SHAPE_Q3_PROBE_SCATTER", "TPC-H Q3 probe side, predicate + key only, row id as payload: the scatter of the partitioned probe (unordered probe keys)", q3, 3),
         ("SHAPE_GB2_SUM_CNT_I64", "group_by(k1:i64, k2:i64).agg(v.sum(), v.count())  [config 3 on a two-column key: word-by-word LDS tables]",
          Q.cfg3w(pl.DataFrame([ph("k1", pl.Int64), ph("k2", pl.Int64), ph("v", pl.Int64)]).lazy()), 0),
+        ("SHAPE_Q3D_BUILD", "lineitem JOIN partsupp (duplicate build keys) build scan: ps_group predicate fused, ps_partkey -> row chains [bench workload q3d]",
+         Q.q3_partsupp(pl.DataFrame([ph("l_partkey", pl.Int64, n=1 << 22), ph("l_extendedprice", pl.Float64, n=1 << 22), ph("l_discount", pl.Float64, n=1 << 22), ph("l_shipdate", pl.Datetime, n=1 << 22)]).lazy(),
+                       pl.DataFrame([ph("ps_partkey", pl.Int64), ph("ps_suppkey", pl.Int64), ph("ps_group", pl.Int64)]).lazy()), 1),
     ]
 
 
@@ -115,7 +118,7 @@ def main():
     items = shapes()
     for i, (name, doc, _, _) in enumerate(items):
         out.append(f"  {name} = {i},  // {doc}\n")
-    out.append("  kNumStaticShapes\n};\n#define PLX_HAVE_Q3_SHAPES 1\n#define PLX_HAVE_Q3FULL_SHAPES 1\n#define PLX_HAVE_Q3_PROBE_SCATTER 1\n#define PLX_HAVE_GB2_SHAPE 1\n\nPLX_HD constexpr Shape static_shape(int id) {\n  Shape s{};\n  s.pred = kNone;\n  s.key = kNone;\n  switch (id) {\n")
+    out.append("  kNumStaticShapes\n};\n#define PLX_HAVE_Q3_SHAPES 1\n#define PLX_HAVE_Q3FULL_SHAPES 1\n#define PLX_HAVE_Q3_PROBE_SCATTER 1\n#define PLX_HAVE_GB2_SHAPE 1\n#define PLX_HAVE_Q3D_SHAPE 1\n\nPLX_HD constexpr Shape static_shape(int id) {\n  Shape s{};\n  s.pred = kNone;\n  s.key = kNone;\n  switch (id) {\n")
     for name, doc, q, which in items:
         ok, sid, why, dump = q.describe_fusion()
         if not ok:
