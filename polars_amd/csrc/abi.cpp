@@ -112,7 +112,7 @@ int plx_column_set_bounds(plx_column col, int64_t lo, int64_t hi) {
 int plx_column_drop_statistics(plx_column col) {
   PLX_TRY
   ColumnPtr c = get_column(col);
-  if (c->range_trusted || c->range_assumed) { c->range_state = 0; c->range_min = c->range_max = 0; c->range_trusted = true; c->range_assumed = false; }       // bounds the caller declared are part of the column, not a cache
+  if (c->range_trusted || c->range_assumed) { c->range_state = 0; c->range_min = c->range_max = 0; c->range_trusted = true; c->range_assumed = false; c->range_verified = false; }       // bounds the caller declared are part of the column, not a cache
   c->no_assume = false;
   std::atomic_store(&c->key_sample, std::shared_ptr<void>());
   c->order_state = 0;

@@ -109,6 +109,7 @@ struct Column {
   bool range_trusted = true;   // computed by the library (exact); false: caller-provided bounds (plx_column_set_bounds) or bounds the planner ASSUMED from a sample
   bool range_assumed = false;  // range_min / range_max are the planner's guess (a strided sample + slack; engine.cpp assume_range): used like declared bounds -- every kernel
                                // that addresses a table or narrows a value with them checks each row -- and when a row falls outside them the query is planned again from an exact pass
+  bool range_verified = false; // the assumed bounds have since been checked against EVERY row (a scan without a predicate that narrowed this column): valid, if not tight
   bool no_assume = false;      // a guess about this column was wrong once: exact statistics only
   // what the group-by planner learned from its strided sample of this column AS A KEY (engine.cpp KeySample: heavy hitters, distinct count,
   // group estimate): a column is immutable, so the next group-by on it with no predicate skips the 8 sample launches (0.3 ms per query)

@@ -894,7 +894,20 @@ static void source_ranges(const Compiler& c, k::SrcRange out[kMaxSrc]) {
     if (col->range_state == 0) assume_range(col);
     if (col->range_state != 0 && !col->range_trusted && !col->range_assumed) continue;
     int64_t mn = 0, mx = 0;
-    if (ops::int_range(col, &mn, &mx, true)) { out[j].known = true; out[j].mn = mn; out[j].mx = mx; out[j].check = col->range_assumed; }
+    if (ops::int_range(col, &mn, &mx, true)) { out[j].known = true; out[j].mn = mn; out[j].mx = mx; out[j].check = col->range_assumed && !col->range_verified; }
+  }
+}
+// A partitioned run WITHOUT a predicate put every row of its narrowed value columns through the per-row check (PartPlan2::check_src) and raised no flag: their assumed
+// bounds are now verified -- valid for every row, if not tight -- and later runs take the kernels without the check.
+static void mark_sources_verified(const Compiler& c) {
+  const Shape& sh = c.shape;
+  if (sh.pred != kNone) return;
+  const RecLayout2 L = rec_layout2(sh, kP2Hash, kPackNarrow);
+  for (uint32_t j = 0; j < L.n_src && j < (uint32_t)kMaxSrc; j++) {
+    const int in = slot_input(sh, L.src_slot[j]);
+    if (in < 0 || in >= (int)c.input_cols.size()) continue;
+    const ColumnPtr& col = c.cols[c.input_cols[in]];
+    if (col->range_assumed) col->range_verified = true;
   }
 }
 
@@ -986,6 +999,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
         Buf ok, okv, oacc;
         const int64_t g = k::partitioned_agg2(sh, args, p2, static_id, hot, &ok, &okv, &oacc, &pd);
         if (g >= 0) {
+          if (p2.check_src) mark_sources_verified(c);
           res.n_groups = g; res.n_aggs = sh.n_aggs; res.packed_keys = ok; res.key_valid = nullptr; res.acc = oacc;   // packed ids carry their own null codes
           desc += std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+" + pd;
           return;
@@ -1052,6 +1066,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
         int64_t stride = 0;
         const int64_t g = k::partitioned_agg2(sh, args, p2, static_id, {}, &ok, &okv, &oacc, &pd, nullptr, &stride);
         if (g >= 0) {
+          if (p2.check_src) mark_sources_verified(c);
           res.n_groups = g; res.n_aggs = sh.n_aggs; res.wide_words = ok; res.wide_valid = okv; res.wide_stride = stride; res.acc = oacc;
           desc += std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+" + pd;
           return;
@@ -1095,6 +1110,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
           const int64_t g = k::partitioned_agg2(sh, args, p2, static_id, hot, &ok, &okv, &oacc, &pd, stat_col ? key_range : nullptr);
           if (g >= 0) {
             if (stat_col && key_range[0] <= key_range[1]) { stat_col->range_state = 1; stat_col->range_min = key_range[0]; stat_col->range_max = key_range[1]; stat_col->range_trusted = true; pd += "+key_range_learned"; }
+            if (p2.check_src) mark_sources_verified(c);
             res.n_groups = g; res.n_aggs = sh.n_aggs; res.packed_keys = ok; res.key_valid = okv; res.acc = oacc;
             desc += "hot=" + std::to_string(hot.size()) + "+" + std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+" + pd;
             return;
@@ -1327,7 +1343,7 @@ static bool fused_groupby(Plan& plan, const IRN& node, const std::vector<int>& p
     // a row outside bounds the planner had only ASSUMED (assume_range): forget the guesses, never guess about these columns again, and run the query once more --
     // its statistics now come from exact passes.  (Bounds the caller declared are the caller's promise: that error stands.)
     bool guessed = false;
-    for (auto& col : c.cols) if (col->range_assumed) { col->range_state = 0; col->range_trusted = true; col->range_assumed = false; col->no_assume = true; std::atomic_store(&col->key_sample, std::shared_ptr<void>()); guessed = true; }
+    for (auto& col : c.cols) if (col->range_assumed) { col->range_state = 0; col->range_trusted = true; col->range_assumed = false; col->range_verified = false; col->no_assume = true; std::atomic_store(&col->key_sample, std::shared_ptr<void>()); guessed = true; }
     if (!guessed || e.code != PLX_ERR_INVALID) throw;
     plan.desc += "AssumedBoundsViolated{exact statistics, second run}; ";
     return fused_groupby(plan, node, preds, src, out, shape_out, sid_out, why, compile_only);

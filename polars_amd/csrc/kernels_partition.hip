@@ -449,9 +449,9 @@ static bool part3_static_available(int static_id, uint32_t mode, uint32_t tiles,
 static void part3_static_scatter(int static_id, const Shape& sh, const Args& args, const PartPlan2& pp, const ScatterParams2& sp, size_t lds) {
 #define X(ID, MODE, TILES, PACK)                                                                                                       \
   if (static_id == ID && pp.mode == (uint32_t)MODE && pp.tiles == (uint32_t)TILES && pp.pack == (uint32_t)PACK) {                        \
-    auto kern = part3_scatter_kernel<StatProg<ID>, (int)MODE, TILES, (int)PACK, false>;                                                        \
-    static bool attr_set = false;                                                                                                      \
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); attr_set = true; } \
+    auto kern = pp.check_src ? part3_scatter_kernel<StatProg<ID>, (int)MODE, TILES, (int)PACK, false, true> : part3_scatter_kernel<StatProg<ID>, (int)MODE, TILES, (int)PACK, false, false>;   \
+    static bool attr_set[2] = {false, false};                                                                                          \
+    if (!attr_set[pp.check_src ? 1 : 0]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); attr_set[pp.check_src ? 1 : 0] = true; } \
     hipLaunchKernelGGL(kern, dim3(pp.scatter_grid), dim3(pp.block), lds, stream(), sh, args, pp, sp);                                   \
     return;                                                                                                                            \
   }
@@ -459,9 +459,9 @@ static void part3_static_scatter(int static_id, const Shape& sh, const Args& arg
 #undef X
 #define X(ID, MODE, TILES, PACK)                                                                                                       \
   if (static_id == ID && pp.mode == (uint32_t)MODE && pp.tiles == (uint32_t)TILES && pp.pack == (uint32_t)PACK) {                        \
-    auto kern = part3_scatter_kernel<StatProg<ID>, (int)MODE, TILES, (int)PACK, true>;                                                         \
-    static bool attr_set = false;                                                                                                      \
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); attr_set = true; } \
+    auto kern = pp.check_src ? part3_scatter_kernel<StatProg<ID>, (int)MODE, TILES, (int)PACK, true, true> : part3_scatter_kernel<StatProg<ID>, (int)MODE, TILES, (int)PACK, true, false>;     \
+    static bool attr_set[2] = {false, false};                                                                                          \
+    if (!attr_set[pp.check_src ? 1 : 0]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); attr_set[pp.check_src ? 1 : 0] = true; } \
     hipLaunchKernelGGL(kern, dim3(pp.scatter_grid), dim3(pp.block), lds, stream(), sh, args, pp, sp);                                   \
     return;                                                                                                                            \
   }

@@ -389,7 +389,7 @@ bool int_range(const ColumnPtr& c, int64_t* mn, int64_t* mx, bool allow_assumed)
   PLX_REQUIRE(dtype_is_int(c->dtype), PLX_ERR_INVALID, "int_range: integer column required");
   // bounds the group-by planner only guessed (Column::range_assumed) are good for callers that check every row against them and can run again; everybody else gets
   // exact statistics (computed now, cached as such)
-  if (c->range_assumed && !allow_assumed) { c->range_state = 0; c->range_trusted = true; c->range_assumed = false; }
+  if (c->range_assumed && !allow_assumed) { c->range_state = 0; c->range_trusted = true; c->range_assumed = false; c->range_verified = false; }
   if (c->range_state == 0) {
     if (c->len == 0) c->range_state = 2;
     else {

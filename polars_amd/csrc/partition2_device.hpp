@@ -75,9 +75,9 @@ __device__ __forceinline__ uint64_t wide_key_hash(const uint64_t* w, uint32_t n_
 }
 
 // ---- one row -> record dwords ---------------------------------------------------------------------------------------
-template <int MODE, class S, class RF>
+template <int MODE, bool CHECK = true, class S, class RF>
 __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, const PartPlan2& pp, const RF& rf, int r, int64_t row, unsigned int* rec /* [L.rec_words] */,
-                                             uint32_t& part, bool& kvalid, uint64_t& key64, uint32_t& narrow_viol /* |= 1: a value did not fit the narrowed field (pp.check_src) */) {
+                                             uint32_t& part, bool& kvalid, uint64_t& key64, bool row_ok /* the row passed the predicate (and exists) */, uint64_t& narrow_viol /* wave-uniform: |= ballot(a valid value did not fit its narrowed field); only under pp.check_src */) {
   if (L.n_key_cols) {
     // wide key (hash partitions): one 64-bit word per key column (0 for a null), the columns' null mask folded into the hash and kept in the validity dword
     uint64_t w[kMaxKeys];
@@ -100,7 +100,7 @@ __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, c
     for (int j = 0; j < kMaxSrc; j++) {
       if (j < (int)L.n_src) {
         const uint64_t v = rf.get(r, L.src_slot[j]);
-        if (L.src_kind[j] == 3) { rec[L.src_off[j]] = (uint32_t)(v - (uint64_t)pp.src_base[j]); if (pp.check_src && ((v - (uint64_t)pp.src_base[j]) >> 32) && ((rf.getv(L.src_slot[j]) >> r) & 1)) narrow_viol |= 1u; }
+        if (L.src_kind[j] == 3) { rec[L.src_off[j]] = (uint32_t)(v - (uint64_t)pp.src_base[j]); if (CHECK && pp.check_src) narrow_viol |= __ballot(((v - (uint64_t)pp.src_base[j]) >> 32) != 0 && row_ok && ((rf.getv(L.src_slot[j]) >> r) & 1)); }
         else {
           rec[L.src_off[j]] = (uint32_t)v;
           if (!L.src_kind[j]) rec[L.src_off[j] + 1] = (uint32_t)(v >> 32);
@@ -139,8 +139,8 @@ __device__ __forceinline__ void make_record2(const S& sh, const RecLayout2& L, c
     if (j < (int)L.n_src) {
       const uint64_t v = rf.get(r, L.src_slot[j]);
       // (pp.check_src: the bases come from bounds nobody has verified -- the planner's sample, engine.cpp assume_range: a value outside them is reported, never truncated silently)
-      if (L.pack == kPackFused) { rec[0] |= (uint32_t)(v - (uint64_t)pp.src_base[0]) << pp.key_shift; if (pp.check_src && ((v - (uint64_t)pp.src_base[0]) >> (32u - pp.key_shift)) && ((rf.getv(L.src_slot[j]) >> r) & 1)) narrow_viol |= 1u; }      // one dword: key_low | (v - base) << key_shift
-      else if (L.src_kind[j] == 3) { rec[L.src_off[j]] = (uint32_t)(v - (uint64_t)pp.src_base[j]); if (pp.check_src && ((v - (uint64_t)pp.src_base[j]) >> 32) && ((rf.getv(L.src_slot[j]) >> r) & 1)) narrow_viol |= 1u; }
+      if (L.pack == kPackFused) { rec[0] |= (uint32_t)(v - (uint64_t)pp.src_base[0]) << pp.key_shift; if (CHECK && pp.check_src) narrow_viol |= __ballot(((v - (uint64_t)pp.src_base[0]) >> (32u - pp.key_shift)) != 0 && row_ok && ((rf.getv(L.src_slot[j]) >> r) & 1)); }      // one dword: key_low | (v - base) << key_shift
+      else if (L.src_kind[j] == 3) { rec[L.src_off[j]] = (uint32_t)(v - (uint64_t)pp.src_base[j]); if (CHECK && pp.check_src) narrow_viol |= __ballot(((v - (uint64_t)pp.src_base[j]) >> 32) != 0 && row_ok && ((rf.getv(L.src_slot[j]) >> r) & 1)); }
       else {
         rec[L.src_off[j]] = (uint32_t)v;
         if (!L.src_kind[j]) rec[L.src_off[j] + 1] = (uint32_t)(v >> 32);
@@ -207,6 +207,7 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
   auto round_full = [&](int64_t rd) { return (rd + 1) * rows_per_round <= args.n_rows; };
   RegFile rf[TILES];          // indexed by compile-time constants only (p2_static_for): a dynamically indexed register file is spilled to scratch
   long long kmin_seen = 0x7fffffffffffffffll, kmax_seen = (long long)0x8000000000000000ull;   // by-product statistics of the key
+  uint64_t narrow_viol = 0;     // wave-uniform (scalar registers): lanes whose value did not fit its narrowed field (make_record2, pp.check_src)
   unsigned int rec[TILES][kRows][RW];
   uint32_t part[TILES][kRows];
   bool pending[TILES][kRows];
@@ -228,9 +229,7 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
 #pragma unroll
       for (int r = 0; r < kRows; r++) {
         bool kvalid; uint64_t key64;
-        uint32_t nviol = 0;
-        make_record2<MODE>(sh, L, pp, rf[t], r, row0 + r, rec[t][r], part[t][r], kvalid, key64, nviol);
-        if (nviol && pass[r]) sp.flags[2] = 1u;                                            // a value outside the bounds its narrowing assumed: the query is planned again
+        make_record2<MODE>(sh, L, pp, rf[t], r, row0 + r, rec[t][r], part[t][r], kvalid, key64, pass[r], narrow_viol);
         pending[t][r] = pass[r];
         if (MODE == (int)kP2Hash && sp.key_minmax && pass[r] && kvalid) {
           kmin_seen = (long long)key64 < kmin_seen ? (long long)key64 : kmin_seen;
@@ -397,6 +396,7 @@ __device__ __forceinline__ void part2_scatter_body(const Shape dsh, const Args a
     __syncthreads();
   }
   flush_phase(true);
+  if (narrow_viol && lane == 0) sp.flags[2] = 1u;     // a value outside the bounds its narrowing assumed: the query is planned again (engine.cpp)
   if (MODE == (int)kP2Hash && sp.key_minmax) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {

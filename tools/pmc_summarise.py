@@ -44,7 +44,7 @@ def scope_of(kernel: str):
         return f"part_agg_lds[jit,{'d' if v & 1 else 'h'},p{v >> 1}]"
     m = re.search(r"fused_scan_kernel<.*StatProg<(\d+)>", kernel)
     sid = m.group(1) if m else None
-    m = re.search(r"part3_scatter_kernel<.*StatProg<(\d+)>\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*(?:,\s*(true|false)\s*)?>", kernel)
+    m = re.search(r"part3_scatter_kernel<.*StatProg<(\d+)>\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*(?:,\s*(true|false)\s*)?(?:,\s*(?:true|false)\s*)?>", kernel)      # (the last flag: the per-row check of narrowed values compiled in)
     if m:      # pack 3 (row-id records) is the probe side's scatter of the partitioned join probe: the library's tracer calls it probe_scatter
         hot = ",hot" if m.group(5) == "true" else ""
         return f"{'probe_scatter' if m.group(4) == '3' else 'part3_scatter'}[#{m.group(1)},{'d' if m.group(2) == '1' else 'h'},t{m.group(3)},p{m.group(4)}{hot}]"
