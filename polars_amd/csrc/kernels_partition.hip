@@ -234,13 +234,23 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
   for (uint32_t j = 0; j < L.n_src && j < (uint32_t)kMaxSrc; j++) if (pack != kPackNone && ranges && ranges[j].known && ranges[j].check && (L.src_kind[j] == 3 || pack == kPackFused)) pp.check_src = 1;
   const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0;
   uint32_t tiles = 0;
-  const uint32_t block = kEnvP3Block >= 64 && (uint32_t)kEnvP3Block >= NP && kEnvP3Block % 64 == 0 ? (uint32_t)kEnvP3Block : (uint32_t)kP2MaxBlock;
+  uint32_t block = kEnvP3Block >= 64 && (uint32_t)kEnvP3Block >= NP && kEnvP3Block % 64 == 0 ? (uint32_t)kEnvP3Block : (uint32_t)kP2MaxBlock;
   for (uint32_t t : {4u, 3u, 2u, 1u}) {
     if (kEnvP2Tiles > 0 && t > (uint32_t)kEnvP2Tiles) continue;
     if ((pp.mode == kP2Hash || pp.n_hot) && t > 3) continue;      // hash partitions keep the 64-bit key and its hash live, the hot-key path its lookups: four tiles spill (12-24 B / lane; a scratch reload waits for every load in flight)
     if (part3_scatter_lds(block * kRows * t, L.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies) <= lds_total) { tiles = t; break; }
   }
   if (!tiles) return false;
+  // The per-round cost of the scatter is per PARTITION, so what counts is rows per round.  When the LDS holds only one or two tiles of a full 1024-thread workgroup
+  // (wide records at 512 partitions: 88 KB of carry lines and bookkeeping before the tile), a SMALLER workgroup with one tile more stages more rows: 896 threads x 2 tiles
+  // of 20-byte records = 3584 rows a round instead of 2048 (measured at 1e9 rows of a two-column key, round 5: 12.9 -> 10.6 ms at 832 threads; 704: 12.1, 768: 11.2;
+  // 512 threads x 3 tiles: 19.0 -- the tile sort wants the threads).  At least 768 threads (and one per partition).
+  if (!(kEnvP3Block >= 64) && !(kEnvP2Tiles > 0) && tiles < ((pp.mode == kP2Hash || pp.n_hot) ? 3u : 4u)) {
+    for (uint32_t b = (uint32_t)kP2MaxBlock - 64; b >= 768 && b >= NP; b -= 64) {
+      if (b * (tiles + 1) <= block * tiles) break;                       // no more rows a round than what we have
+      if (part3_scatter_lds(b * kRows * (tiles + 1), L.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies) <= lds_total) { block = b; tiles = tiles + 1; break; }
+    }
+  }
   pp.gen = 3; pp.pack = pack; pp.rec_words = L.rec_words; pp.block = block; pp.ring_lines = 0;
   plan2_geometry(pp, n_rows, tiles);
   // chunks are filled completely (the carry line keeps the remainder): whole chunks of the rows + one partial chunk per partition + slack
@@ -432,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void hot_emit_kernel(const unsigned long lo
   X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow)                                      \
   X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackFused) \
   X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackNone)                              \
-  X(SHAPE_GB2_SUM_CNT_I64, kP2Hash, 1, kPackNarrow) X(SHAPE_GB2_SUM_CNT_I64, kP2Hash, 1, kPackNone)       /* two-column key at 512 partitions: 20- / 24-byte records, one 2048-row tile */
+  X(SHAPE_GB2_SUM_CNT_I64, kP2Hash, 2, kPackNarrow) X(SHAPE_GB2_SUM_CNT_I64, kP2Hash, 2, kPackNone)       /* two-column key at 512 partitions: 20- / 24-byte records, two tiles of an 896- / 704-thread workgroup */
 // ... and with the hot-key path compiled in (skewed keys: heavy hitters are summed in the scatter), for config 3's two runs -- key range unknown / known
 #define PLX_P3_HOT_COMBOS(X) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 3, kPackFused)
 #else
