@@ -31,6 +31,10 @@ CASES = [
     ("plx::k::direct_pairs_compact_kernel(plx::fused::DirectJoinTable, long, int, int, unsigned long long*, unsigned long long*, unsigned int*, unsigned long long*)", "table_compact"),
     ("void plx::k::datagen_uniform_kernel<long>(long, unsigned long, unsigned int, long, long, double, long*)", "datagen_uniform_i64"),
     ("void plx::k::part3_scatter_kernel<plx::k::StatProg<13>, 0, 1, 1, false>(plx::fused::Shape, plx::fused::Args, plx::k::PartPlan2, plx::k::ScatterParams2)", "part3_scatter[#13,h,t1,p1]"),
+    # (round 5: a sixth template flag -- the per-row check of narrowed values compiled in or not; both forms are one tracer name)
+    ("void plx::k::part3_scatter_kernel<plx::k::StatProg<13>, 0, 2, 1, false, false>(plx::fused::Shape, plx::fused::Args, plx::fused::PartPlan2, plx::k::ScatterParams2)", "part3_scatter[#13,h,t2,p1]"),
+    ("void plx::k::part3_scatter_kernel<plx::k::StatProg<13>, 0, 2, 1, false, true>(plx::fused::Shape, plx::fused::Args, plx::fused::PartPlan2, plx::k::ScatterParams2)", "part3_scatter[#13,h,t2,p1]"),
+    ("void plx::k::part3_scatter_kernel<plx::k::StatProg<4>, 1, 3, 2, true, true>(plx::fused::Shape, plx::fused::Args, plx::fused::PartPlan2, plx::k::ScatterParams2)", "part3_scatter[#4,d,t3,p2,hot]"),
     ("void plx::k::part2_agg_kernel<plx::k::StatProg<13>, 0, 1>(plx::k::PartPlan2, plx::k::AggParams2)", "part_agg_lds[#13,h,p1]"),
     ("plx::k::canonicalise_chains_kernel(plx::fused::JoinAggTable, plx::fused::RepCols, unsigned int, unsigned int*)", "join_chain_representatives"),
     ("plx::k::rows_agg_compact_kernel(unsigned long long const*, long, int, int, unsigned long long*, unsigned int*, unsigned long long*)", "table_compact"),
