@@ -1177,6 +1177,37 @@ def allgather_q1(res, ws):
     return unpack_q1(allt)
 
 
+def allgather_combine_q1(res, ws):
+    """The Q1 step's tail at N > 1, vectorised: one fixed-size tensor all-gather of the ranks' result frames (1.25 KB each) and their merge in numpy -- no per-row Python
+    (at eight ranks the row-by-row unpack + merge of 128 rows cost ~0.3 ms of a 0.9 ms step).  Same result as combine_q1_results(allgather_q1(...)), which the
+    verification still computes the slow way and compares with this one."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    mine = pack_q1(res)
+    if dist.get_backend() == "nccl":
+        mine = mine.cuda()
+    allt = torch.empty((ws * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(allt, mine.contiguous())
+    a = allt.cpu().numpy()
+    F = {f: j for j, f in enumerate(Q1_FIELDS)}
+    a = a[a[:, F["count_order"]] != 0]
+    key = a[:, F["l_returnflag"]] * 4 + a[:, F["l_linestatus"]]
+    uniq, inv = np.unique(key, return_inverse=True)
+    g = len(uniq)
+    cnt = np.zeros(g, np.int64); np.add.at(cnt, inv, a[:, F["count_order"]])
+    qty = np.zeros(g, np.int64); np.add.at(qty, inv, a[:, F["sum_qty"]])
+    def fsum(col, weight=None):           # sum per group of a bit-cast float column (times a weight)
+        x = np.ascontiguousarray(a[:, F[col]]).view(np.float64)
+        acc = np.zeros(g, np.float64)
+        np.add.at(acc, inv, x if weight is None else x * weight)
+        return acc
+    base, disc_p, charge = fsum("sum_base_price"), fsum("sum_disc_price"), fsum("sum_charge")
+    disc = fsum("avg_disc", a[:, F["count_order"]].astype(np.float64))
+    return {"l_returnflag": (uniq // 4).tolist(), "l_linestatus": (uniq % 4).tolist(), "sum_qty": qty.tolist(), "sum_base_price": base.tolist(), "sum_disc_price": disc_p.tolist(),
+            "sum_charge": charge.tolist(), "avg_qty": (qty / cnt).tolist(), "avg_price": (base / cnt).tolist(), "avg_disc": (disc / cnt).tolist(), "count_order": cnt.tolist()}
+
+
 def combine_q1_results(per_rank):
     """Merge the Q1 results of row-sharded ranks: sums and counts add, averages are recombined from
     (avg x count) -- the partial/final decomposition of polars_amd.dist.PARTIALS applied to the finished frames."""
@@ -1826,7 +1857,7 @@ def rowsharded_line(ctx, args, workload: str, steps: int, warmup: int) -> dict:
     def step():
         r = one()
         local["res"] = r
-        return combine_q1_results(allgather_q1(r, ws)) if workload == "q1" else r
+        return allgather_combine_q1(r, ws) if workload == "q1" else r
     dt, stats, res, step_ms = timed_multi(ctx, step, steps, max(warmup, 1))
     verified = None
     if workload == "q1":

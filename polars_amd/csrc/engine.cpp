@@ -651,7 +651,9 @@ static KeyPlan lower_keys(Compiler& c, const std::vector<int>& key_exprs) {
         int64_t smn = 0, smx = 0;
         if (k::sample_minmax(col, &smn, &smx) && (unsigned __int128)((__int128)smx - (__int128)smn) < ((unsigned __int128)1 << 26)) {
           cheap = true;
-          if (assume_range(col)) kp.note += "KeyRange{" + std::string(x->name) + ": sample looks dense -> bounds assumed from the sample, checked per row}; ";
+          // (a guess is safe for ONE non-nullable key: every id below 2^bits decodes to the right key whatever the bounds were, anything beyond is reported by the
+          //  tables; a nullable key's null code sits right above the assumed maximum, and the parts of a multi-column key overflow into each other: exact passes there)
+          if (nk == 1 && !info[i].nullable && assume_range(col)) kp.note += "KeyRange{" + std::string(x->name) + ": sample looks dense -> bounds assumed from the sample, checked per row}; ";
           else kp.note += "KeyRange{" + std::string(x->name) + ": sample looks dense -> range pass}; ";
         }
       }
@@ -661,7 +663,7 @@ static KeyPlan lower_keys(Compiler& c, const std::vector<int>& key_exprs) {
       if (cheap && nk > 1 && col->range_state == 0 && part.dtype != PLX_U64 && dtype_width(part.dtype) > 2 && col->values && col->len >= ((int64_t)1 << 24) && assume_ranges() && !col->no_assume) {
         int64_t smn = 0, smx = 0;
         if (k::sample_minmax(col, &smn, &smx, 1024) && (unsigned __int128)((__int128)smx - (__int128)smn) >= ((unsigned __int128)1 << 61)) hopeless = true;
-        else assume_range(col);
+        // (otherwise: the exact pass -- bounds that are only guessed must not pack several columns into one id: a value beyond its part's bits would spill into the next part)
       }
       if (part.dtype == PLX_U64 || hopeless) all_packable = false;
       else if (cheap) {
@@ -897,6 +899,18 @@ static void source_ranges(const Compiler& c, k::SrcRange out[kMaxSrc]) {
     if (ops::int_range(col, &mn, &mx, true)) { out[j].known = true; out[j].mn = mn; out[j].mx = mx; out[j].check = col->range_assumed && !col->range_verified; }
   }
 }
+// does any input column of the compiled query carry bounds nobody measured (declared by the caller, or assumed by the planner)?  Then the table sinks report ids outside
+// their tables (LdsAggSink / DenseAggSink `oob`) and the host looks at the flag.
+static bool untrusted_key_bounds(const Compiler& c) {
+  for (auto& col : c.cols) if (col->range_state == 1 && !col->range_trusted) return true;
+  return false;
+}
+static void check_oob_flag(const Buf& oob) {
+  if (!oob) return;
+  uint32_t f = 0;
+  d2h_sync(&f, oob->ptr, 4);
+  if (f) fail(PLX_ERR_INVALID, "group key outside the bounds declared or assumed for its column");
+}
 // A partitioned run WITHOUT a predicate put every row of its narrowed value columns through the per-row check (PartPlan2::check_src) and raised no flag: their assumed
 // bounds are now verified -- valid for every row, if not tight -- and later runs take the kernels without the check.
 static void mark_sources_verified(const Compiler& c) {
@@ -969,9 +983,11 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
   if (kp.packed && kp.total_bits <= 12 && k::lds_agg_copies(1 << kp.total_bits, sh.n_aggs) > 0) {
     const int G = 1 << kp.total_bits;
     Buf cells = dev_alloc(sizeof(uint64_t) * (size_t)G * sh.n_aggs);
-    k::fused_lds_agg(sh, args, G, static_id, cells->as<uint64_t>());
+    Buf oob = untrusted_key_bounds(c) ? dev_alloc_zero(8) : nullptr;      // key bounds nobody measured: the sink reports a group id outside the table
+    k::fused_lds_agg(sh, args, G, static_id, cells->as<uint64_t>(), oob ? oob->as<unsigned int>() : nullptr);
     desc += std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+lds_table(G=" + std::to_string(G) + ",copies=" + std::to_string(k::lds_agg_copies(G, sh.n_aggs)) + ")";
     compact_into(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, res);
+    check_oob_flag(oob);
     res.key_valid = nullptr;  // packed keys carry their own null codes
     return;
   }
@@ -1024,10 +1040,12 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     const int64_t G = (int64_t)1 << kp.total_bits;
     Buf cells = dev_alloc(sizeof(uint64_t) * (size_t)(G + 1) * sh.n_aggs);
     k::init_agg_cells(cells->as<uint64_t>(), G + 1, sh);
-    DenseTable t; t.acc = cells->as<unsigned long long>(); t.key_min = 0; t.n_groups = G;
+    Buf oob = untrusted_key_bounds(c) ? dev_alloc_zero(8) : nullptr;
+    DenseTable t; t.acc = cells->as<unsigned long long>(); t.key_min = 0; t.n_groups = G; t.oob = oob ? oob->as<unsigned int>() : nullptr;
     k::fused_dense_agg(sh, args, t, static_id);
     desc += std::string("fused_scan[") + jit::program_mode(static_id, args.n_rows) + "]+dense_hbm_table(G=" + std::to_string(G) + ")";
     compact_into(nullptr, cells->as<uint64_t>(), G, -1, sh.n_aggs, len_idx, res);
+    check_oob_flag(oob);
     res.key_valid = nullptr;
     return;
   }

@@ -520,6 +520,7 @@ struct DenseTable {
   unsigned long long* acc;
   int64_t key_min;
   int64_t n_groups;
+  unsigned int* oob;     // may be null: [0] = 1 when a key fell outside the table (see LdsAggSink::Params::oob)
 };
 
 }  // namespace fused

@@ -65,6 +65,7 @@ struct LdsAggSink {
     unsigned long long* global_acc;  // [G][n_aggs] device-scope atomics (large G)
     int n_groups;
     int copies;                      // power of two
+    unsigned int* oob;               // may be null: [0] = 1 when a group id fell outside the table (key bounds that were declared or assumed, not measured, and wrong)
   };
   template <class S> __device__ __forceinline__ void init(const S& sh, const Params& p) {
     extern __shared__ unsigned long long lds_tbl[];
@@ -79,7 +80,7 @@ struct LdsAggSink {
     for (int r = 0; r < kRows; r++) {
       if (!pass[r]) continue;
       const uint64_t gid64 = rf.get(r, sh.key);
-      if (gid64 >= (uint64_t)p.n_groups) continue;   // only possible when caller-declared column bounds (plx_column_set_bounds) were wrong: stay inside the table
+      if (gid64 >= (uint64_t)p.n_groups) { if (p.oob) *p.oob = 1u; continue; }   // only possible when declared / assumed column bounds were wrong: stay inside the table, tell the host (the query fails or is planned again)
       const uint32_t gid = (uint32_t)gid64;
       unsigned long long* cells = lds_tbl + (size_t)gid * sh.n_aggs * p.copies + copy;
 #pragma unroll
@@ -120,7 +121,7 @@ struct DenseAggSink {
       if (!pass[r]) continue;
       bool kvalid = (rf.getv(sh.key) >> r) & 1;
       int64_t g = kvalid ? ((int64_t)rf.get(r, sh.key) - p.key_min) : p.n_groups;
-      if ((uint64_t)g > (uint64_t)p.n_groups) continue;   // see LdsAggSink: wrong caller-declared bounds must not leave the table
+      if ((uint64_t)g > (uint64_t)p.n_groups) { if (p.oob) *p.oob = 1u; continue; }   // see LdsAggSink: wrong declared / assumed bounds must not leave the table
       atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)g * sh.n_aggs);
     }
   }

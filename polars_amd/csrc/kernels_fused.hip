@@ -154,7 +154,7 @@ int lds_agg_copies(int n_groups, int n_aggs) {
   return c;
 }
 
-void fused_lds_agg(const Shape& sh, const Args& args, int n_groups, int static_id, uint64_t* out_dev /* [G][n_aggs] */) {
+void fused_lds_agg(const Shape& sh, const Args& args, int n_groups, int static_id, uint64_t* out_dev /* [G][n_aggs] */, unsigned int* oob) {
   const int copies = lds_agg_copies(n_groups, sh.n_aggs);
   PLX_REQUIRE(copies > 0, PLX_ERR_INVALID, "fused_lds_agg: group table does not fit LDS");
   const int cells = n_groups * sh.n_aggs;
@@ -163,7 +163,7 @@ void fused_lds_agg(const Shape& sh, const Args& args, int n_groups, int static_i
   const bool use_partials = n_groups <= 64;
   Buf partials;
   LdsAggSink::Params sp{};
-  sp.n_groups = n_groups; sp.copies = copies;
+  sp.n_groups = n_groups; sp.copies = copies; sp.oob = oob;
   if (use_partials) { partials = dev_alloc(sizeof(uint64_t) * (size_t)grid * cells); sp.partials = partials->as<unsigned long long>(); }
   else { init_agg_cells(out_dev, n_groups, sh); sp.global_acc = (unsigned long long*)out_dev; }
   {

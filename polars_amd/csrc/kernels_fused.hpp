@@ -17,7 +17,7 @@ void fused_regagg(const fused::Shape& sh, const fused::Args& args, int static_id
 // filter -> exprs -> LDS-resident table for dense group ids in [0, n_groups); out_dev
 // [n_groups][n_aggs] 64-bit patterns in HBM.  lds_agg_copies() == 0 => does not fit.
 int lds_agg_copies(int n_groups, int n_aggs);
-void fused_lds_agg(const fused::Shape& sh, const fused::Args& args, int n_groups, int static_id, uint64_t* out_dev);
+void fused_lds_agg(const fused::Shape& sh, const fused::Args& args, int n_groups, int static_id, uint64_t* out_dev, unsigned int* oob = nullptr /* device flag: a group id outside the table */);
 
 // filter -> exprs -> atomics into an HBM table. Tables must be initialised with
 // fill_u64(keys, cap + 2, kEmptyKey) / init_agg_cells(acc, slots, sh).

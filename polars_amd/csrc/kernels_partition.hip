@@ -442,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void hot_emit_kernel(const unsigned long lo
   X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow)                                      \
   X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackFused) \
   X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackNone)                              \
-  X(SHAPE_GB2_SUM_CNT_I64, kP2Hash, 2, kPackNarrow) X(SHAPE_GB2_SUM_CNT_I64, kP2Hash, 2, kPackNone)       /* two-column key at 512 partitions: 20- / 24-byte records, two tiles of an 896- / 704-thread workgroup */
+  X(SHAPE_GB2_SUM_CNT_I64, kP2Hash, 2, kPackNarrow)       /* two-column key at 512 partitions: 20-byte records, two tiles of an 896-thread workgroup (values that do not narrow: 24-byte records, run-time compiled) */
 // ... and with the hot-key path compiled in (skewed keys: heavy hitters are summed in the scatter), for config 3's two runs -- key range unknown / known
 #define PLX_P3_HOT_COMBOS(X) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 3, kPackFused)
 #else

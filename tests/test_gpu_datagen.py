@@ -122,6 +122,32 @@ def _outside_the_sample(n, runs=1024, run=1024):
     return stride // 2 + stride * np.arange(3, 9)            # the middle of six gaps between runs
 
 
+def test_a_wrong_guess_about_a_small_key_range_is_caught_by_the_lds_table(pl):
+    """Keys whose sampled range fits an LDS table (<= 12 bits): ids below 2^bits decode to the right key whatever the guess was; a key beyond them is reported by the table
+    sink (LdsAggSink `oob`) and the query runs again from exact statistics.  Nullable keys and multi-column keys are never guessed about (exact passes)."""
+    from polars_amd import queries
+    rng = np.random.default_rng(13)
+    n = 17_000_000
+    ids = rng.integers(0, 3000, n).astype(np.int64)
+    v = rng.integers(0, 1000, n).astype(np.int64)
+    ids[_outside_the_sample(n)] = 5000 + np.arange(6)
+    df = pl.DataFrame({"key": ids, "v": v})
+    out = queries.cfg3(df.lazy()).collect().sort_host("key")
+    plan = pl.last_plan()
+    assert "AssumedBoundsViolated{" in plan, plan
+    keys, inv = np.unique(ids, return_inverse=True)
+    assert np.array_equal(np.array(out["key"], dtype=np.int64), keys)
+    sums = np.zeros(len(keys), np.int64); np.add.at(sums, inv, v)
+    assert any(np.array_equal(np.array(out[c], dtype=np.int64), sums) for c in out if c != "key")
+    # a nullable key: no guess (the null code sits right above the assumed maximum)
+    valid = rng.random(n) > 0.01
+    dfn = pl.DataFrame([pl.Series("key", ids, validity=valid), pl.Series("v", v)])
+    outn = queries.cfg3(dfn.lazy()).collect()
+    plan = pl.last_plan()
+    assert "bounds assumed from the sample" not in plan.split("FusedFilterGroupBy")[0].split("KeyRange{key")[-1] or "range pass" in plan, plan
+    assert outn.height == len(np.unique(ids[valid])) + 1
+
+
 @pytest.mark.parametrize("violate", ["nothing", "key", "value"])
 def test_bounds_assumed_from_a_sample_are_checked_per_row_and_a_wrong_guess_runs_again(pl, violate):
     """First group-by over columns nobody has statistics for: the planner GUESSES their bounds from a strided sample (engine.cpp assume_range) instead of two exact
