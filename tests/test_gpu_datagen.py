@@ -144,7 +144,7 @@ def test_a_wrong_guess_about_a_small_key_range_is_caught_by_the_lds_table(pl):
     dfn = pl.DataFrame([pl.Series("key", ids, validity=valid), pl.Series("v", v)])
     outn = queries.cfg3(dfn.lazy()).collect()
     plan = pl.last_plan()
-    assert "bounds assumed from the sample" not in plan.split("FusedFilterGroupBy")[0].split("KeyRange{key")[-1] or "range pass" in plan, plan
+    assert "KeyRange{key: sample looks dense -> range pass}" in plan and "AssumedBoundsViolated{" not in plan, plan
     assert outn.height == len(np.unique(ids[valid])) + 1
 
 

@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 out="gpurun_out/$1"; mkdir -p "$out"; wl="$2"; shift 2
 tag="${wl}_$(echo "$*" | tr -c 'a-zA-Z0-9=' '_' | cut -c1-40)"
-env "$@" PLX_BENCH_VERIFY=${PLX_BENCH_VERIFY:-0} timeout 400 python bench.py --workload "$wl" --no-extras --no-cpu --steps 4 --warmup 2 > "$out/$tag.json" 2> "$out/$tag.err"; echo "$tag rc=$?"
+env "$@" PLX_BENCH_VERIFY=${PLX_BENCH_VERIFY:-0} timeout 400 python bench.py --workload "$wl" --no-extras --no-cpu --steps ${STEPS:-4} --warmup 2 > "$out/$tag.json" 2> "$out/$tag.err"; echo "$tag rc=$?"
 python - "$out/$tag.json" <<'P'
 import json,sys
 l=[x for x in open(sys.argv[1]).read().splitlines() if x.startswith("[bench] full record: ")]
