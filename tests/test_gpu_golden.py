@@ -158,6 +158,62 @@ def test_join_kats(pl, case):
             assert sorted(zip(d[on], d[c])) == sorted(zip(sorted(d[on]), expv))
 
 
+def _single_key_join_cases():
+    out = []
+    for c in kat.load_cases("join"):
+        if isinstance(c["on"], str) and "expect" in c and c["how"] in ("inner", "left"):
+            out.append(c)
+    return out
+
+
+@pytest.mark.parametrize("case", _single_key_join_cases(), ids=lambda c: c["id"])
+def test_join_kats_through_the_fused_join_group_by(pl, case):
+    """The reference's single-key inner / left join vectors once more, through the FUSED join -> group-by pipeline (duplicate build keys: row chains; left joins: the
+    unmatched rows as groups of their own): group the reference's expected joined frame by (key, one column of the build side) and count -- the same query on the
+    device must give exactly those groups, with the fused path where its preconditions hold (integer key; integer build-side group column when build keys repeat)."""
+    key = case["on"]
+    def frame(side):
+        return pl.DataFrame([_series(pl, n, spec, case[side + "_dtypes"][n]) for n, spec in case[side].items()])
+    if any(dt == "str" for side in ("left", "right") for dt in case[side + "_dtypes"].values()):
+        pytest.skip("string columns travel as dictionary codes in the other join KAT test")
+    L, R = frame("left"), frame("right")
+    nl, nr = len(next(iter(case["left"].values()))), len(next(iter(case["right"].values())))
+    build = "right" if (case["how"] == "left" or nl > nr) else "left"          # the engine's rule: a left join builds on the right table, an inner join on the shorter one
+    exp = case["expect"]
+    names = list(exp.keys())
+    # a non-key column of the build side as it is named in the joined frame (`_right` suffix when both sides have it)
+    gcol = None
+    for n in case[build]:
+        if n == key:
+            continue
+        joined = n + "_right" if (build == "right" and n in case["left"]) else n
+        if joined in names:
+            gcol = joined
+            break
+    gkeys = [key] + ([gcol] if gcol is not None else [])          # (no other build column in the expected frame: the join key alone)
+    n_exp = len(exp[names[0]])
+    want = {}
+    for i in range(n_exp):
+        k = tuple(kat.scalar(exp[c][i]) for c in gkeys)
+        k = tuple("nan" if isinstance(x, float) and x != x else x for x in k)
+        want[k] = want.get(k, 0) + 1
+    out = L.lazy().join(R.lazy(), on=key, how=case["how"]).group_by(*gkeys).agg(pl.len().alias("n")).collect()
+    plan = pl.last_plan()
+    d = out.to_dict()
+    got = {}
+    for i in range(out.height):
+        k = tuple("nan" if isinstance(x, float) and x != x else x for x in (d[c][i] for c in gkeys))
+        assert k not in got, (case["id"], k)
+        got[k] = d["n"][i]
+    assert got == want, (case["id"], plan, got, want)
+    bdt = "i64" if gcol is None else case[build + "_dtypes"][[n for n in case[build] if (n + "_right" if (build == "right" and n in case["left"]) else n) == gcol][0]]
+    bkeys = [v for v in case[build][key] if v is not None]
+    dup = len(set(bkeys)) != len(bkeys)
+    if case[build + "_dtypes"][key] not in ("f32", "f64", "str") and not (dup and bdt in ("f32", "f64")):
+        assert "FusedJoinGroupBy{" in plan, (case["id"], plan)
+        assert ("multi-value" in plan) == dup and ("LeftJoinUnmatched{" in plan) == (case["how"] == "left"), (case["id"], plan)
+
+
 def test_total_ordering_floats(pl):
     case = kat.load_cases("cmp_total_order")[0]
     vals = [kat.scalar(v) for v in case["values"]]
