@@ -98,3 +98,22 @@ def test_wide_key_table_overflow_plans_more_partitions(pl, monkeypatch):
     plan = pl.last_plan()
     assert plan.count("lds-overflow(P=") == 1 and "P=512" in plan and "lds_wide_key_table" in plan, plan
     assert out.height == len(np.unique(g)) and int(out["s"].to_numpy().sum()) == int(v.sum()) and int(out["len"].to_numpy().sum()) == n
+
+
+def test_wide_keys_with_one_heavy_group(pl):
+    """Half of the rows share ONE (a, b) pair (the wide-key path has no hot-key cells: they all meet in one partition, on one group's LDS cells), the rest spread over
+    200 000 pairs: same groups and sums as numpy."""
+    rng = np.random.default_rng(204)
+    n, G = 17_000_000, 200_000
+    g = rng.integers(0, G, n)
+    g[rng.random(n) < 0.5] = 7
+    ka = rng.integers(-(1 << 62), 1 << 62, G).astype(np.int64)
+    kb = rng.integers(-(1 << 62), 1 << 62, G).astype(np.int64)
+    v = rng.integers(0, 1000, n).astype(np.int64)
+    out = pl.DataFrame({"a": ka[g], "b": kb[g], "v": v}).lazy().group_by("a", "b").agg(pl.col("v").sum().alias("s"), pl.len().alias("len")).collect()
+    assert "lds_wide_key_table" in pl.last_plan(), pl.last_plan()
+    cnt = np.bincount(g, minlength=G); sums = np.bincount(g, weights=v, minlength=G).astype(np.int64)
+    present = np.nonzero(cnt)[0]
+    got = {(int(a), int(b)): (int(s), int(c)) for a, b, s, c in zip(out["a"].to_numpy(), out["b"].to_numpy(), out["s"].to_numpy(), out["len"].to_numpy())}
+    assert len(got) == len(present)
+    assert got == {(int(ka[i]), int(kb[i])): (int(sums[i]), int(cnt[i])) for i in present}
