@@ -1816,6 +1816,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       sized_by_sample = true;
     } else nb = exact_count();
   }
+  // PLX_JOIN_TRACE=1 (debugging aid): every stage of the hash-table pipeline announced on stderr behind a stream synchronisation -- a stage that hangs is the last one named
   static const bool jtrace = getenv("PLX_JOIN_TRACE") && getenv("PLX_JOIN_TRACE")[0] == '1';
 #define JTRACE(...) do { if (jtrace) { PLX_HIP(hipStreamSynchronize(stream())); fprintf(stderr, "[plx join] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
   if (!done) {
@@ -1979,6 +1980,8 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   }
   return true;
 }
+
+#undef JTRACE
 
 // ----------------------------------------------------------------- executors ----
 static FramePtr exec_node(Plan& plan, int node_id);
