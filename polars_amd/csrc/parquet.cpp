@@ -7,6 +7,11 @@
 // crates/polars-parquet/src/{parquet/read,arrow/read/deserialize}; crates/polars-stream/src/nodes/io_sources/parquet.
 #include <memory>
 #include <mutex>
+#include <exception>
+#include <thread>
+#include <functional>
+#include <deque>
+#include <condition_variable>
 
 #include "core.hpp"
 #include "host_stage.hpp"
@@ -46,6 +51,7 @@ struct HipBackend {
     res->values = c->values;
     res->validity = c->validity;
     res->has_validity = (bool)c->validity;
+    std::lock_guard<std::mutex> lk(f.meta_mu);
     auto it = f.strdicts.find(leaf);
     if (it != f.strdicts.end() && it->second) plx_strdict_free(it->second);
     f.strdicts[leaf] = dict;
@@ -72,6 +78,64 @@ struct HipBackend {
   }
   void run_page_valid0(pq::PageDesc* pages, uint32_t n, const uint64_t* validity, const uint64_t* prefix) { k::pq_page_valid0(pages, n, validity, prefix); }
   void run_decode(const pq::ColumnDecode& c, void* out, uint32_t out_width, uint32_t* err) { k::pq_decode(c, out, out_width, encoded_bytes, err); }
+};
+
+// The columns of one plx_parquet_read run on a few persistent host threads, each with a HIP stream of its own (core.cpp: one stream per calling thread; freed blocks carry
+// events across streams).  A column is a chain upload -> decompress -> decode with host round trips in between (descriptor uploads, error words, run counts), and the
+// Snappy kernel runs one workgroup per page: alone, a column's ~1000 pages fill the chip twice and its tail runs on a few CUs -- with several columns in flight the chip stays
+// full and one column's uploads overlap another's kernels (2e7-row lineitem-like file: Snappy read 68 -> see DESIGN.md 4.5).  The threads persist, so their page-locked staging
+// buffers (host_stage.hpp: per thread) are allocated once.  PLX_PARQUET_THREADS=1 reads the columns one after another on the caller's stream.
+class ColumnWorkers {
+ public:
+  static ColumnWorkers& get() { static ColumnWorkers* w = new ColumnWorkers(); return *w; }      // (never destroyed: the threads outlive static destruction)
+  int size() const { return (int)threads_.size(); }
+  // runs every task; rethrows the first exception (after all tasks have finished)
+  void run(std::vector<std::function<void()>>& tasks) {
+    std::vector<std::exception_ptr> errs(tasks.size());
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (size_t i = 0; i < tasks.size(); i++) queue_.push_back([&tasks, &errs, i] { try { tasks[i](); } catch (...) { errs[i] = std::current_exception(); } });
+      pending_ += tasks.size();
+    }
+    cv_.notify_all();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this] { return pending_ == 0; });
+    lk.unlock();
+    for (auto& e : errs) if (e) std::rethrow_exception(e);
+  }
+
+ private:
+  ColumnWorkers() {
+    int n = 4;
+    if (const char* e = getenv("PLX_PARQUET_THREADS")) n = std::max(1, std::min(16, atoi(e)));
+    const int ordinal = device().ordinal;
+    for (int i = 0; i < n; i++) {
+      threads_.emplace_back([this, ordinal] {
+        (void)hipSetDevice(ordinal);
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess) set_thread_stream(s);
+        for (;;) {
+          std::function<void()> job;
+          {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [this] { return !queue_.empty(); });
+            job = std::move(queue_.front());
+            queue_.pop_front();
+          }
+          job();
+          (void)hipStreamSynchronize(stream());          // what the task produced is complete before anybody on another stream looks at it
+          std::lock_guard<std::mutex> lk(mu_);
+          if (--pending_ == 0) done_cv_.notify_all();
+        }
+      });
+      threads_.back().detach();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  std::deque<std::function<void()>> queue_;
+  size_t pending_ = 0;
+  std::vector<std::thread> threads_;
 };
 
 std::mutex g_mu;
@@ -204,7 +268,8 @@ int plx_parquet_read(plx_parquet file, const int32_t* row_groups, int32_t n_row_
   std::vector<int> rgs(row_groups, row_groups + n_row_groups);
   auto frame = std::make_shared<Frame>();
   try {
-    for (int32_t i = 0; i < n_columns; i++) {
+    std::vector<ColumnPtr> cols((size_t)n_columns);
+    auto read_one = [&](int32_t i) {
       check_cancel();
       HipBackend be;       // the page-locked staging buffers behind it belong to the host thread and are kept (host_stage.hpp)
       pq::ReadStats st;
@@ -213,9 +278,20 @@ int plx_parquet_read(plx_parquet file, const int32_t* row_groups, int32_t n_row_
       col->dtype = r.dtype; col->len = r.len; col->values = r.values;
       if (r.has_validity) col->validity = r.validity;
       col->null_count = r.null_count;
+      cols[(size_t)i] = col;
+    };
+    static const bool serial = [] { const char* e = getenv("PLX_PARQUET_THREADS"); return e && atoi(e) == 1; }();
+    if (n_columns > 1 && !serial) {
+      std::vector<std::function<void()>> tasks;
+      for (int32_t i = 0; i < n_columns; i++) tasks.push_back([&read_one, i] { read_one(i); });
+      ColumnWorkers::get().run(tasks);
+    } else {
+      for (int32_t i = 0; i < n_columns; i++) read_one(i);
+    }
+    for (int32_t i = 0; i < n_columns; i++) {
       frame->names.push_back(f.md.leaves[columns[i]].name);
-      frame->cols.push_back(col);
-      frame->height = r.len;
+      frame->cols.push_back(cols[(size_t)i]);
+      frame->height = cols[(size_t)i]->len;
     }
   } catch (...) {
     (void)hipStreamSynchronize(stream());   // descriptor vectors / staging of the failed column may still be in flight

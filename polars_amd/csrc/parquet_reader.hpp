@@ -14,6 +14,7 @@
 // parquet/read/compression.rs:70-135 (decompress per page), arrow/read/deserialize/{primitive,boolean,dictionary_encoded,binview}
 // (decode per page into an Arrow array), crates/polars-io/src/parquet/read/read_impl.rs (row groups x projected columns).
 #pragma once
+#include <mutex>
 #include <algorithm>
 #include <cstdlib>
 #include <map>
@@ -45,6 +46,8 @@ struct File : FileReader {
   std::unordered_map<int, std::vector<std::string>> categories;
   // ... or, for string columns with PLAIN pages (dictionary built on the device), the handle of that dictionary (plx_strdict; 0: none)
   std::unordered_map<int, uint64_t> strdicts;
+  // the columns of one read run on several host threads (parquet.cpp: one HIP stream each): the two maps above are only touched under this lock
+  std::mutex meta_mu;
 };
 
 inline std::unique_ptr<File> open_file(const std::string& path) {
@@ -282,7 +285,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
   auto out_bytes = [&](int64_t n) { return lt.dtype == PLX_BOOL ? (size_t)(((n + 63) / 64) * 8 + 8) : (size_t)n * out_width; };
   if (n_rows == 0) {
     res.values = be.alloc(out_bytes(0));
-    if (is_bytes) f.categories[leaf_idx].clear();
+    if (is_bytes) { std::lock_guard<std::mutex> lk(f.meta_mu); f.categories[leaf_idx].clear(); }
     return res;
   }
 
@@ -540,7 +543,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     remap_mem = be.alloc(remap.size() * 4 + 64);
     if (!remap.empty()) be.upload_small(be.addr(remap_mem), remap.data(), remap.size() * 4);
     for (size_t i = 0; i < dicts.size(); i++) dicts[i].values = be.addr(remap_mem) + remap_base_of_dict[i] * 4;
-    f.categories[leaf_idx] = std::move(categories);
+    { std::lock_guard<std::mutex> lk(f.meta_mu); f.categories[leaf_idx] = std::move(categories); }
   }
 
   const uint32_t n_pages = (uint32_t)pages.size();
