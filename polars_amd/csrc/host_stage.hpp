@@ -19,7 +19,7 @@ struct PinnedStage {
     if (s.pending) { PLX_HIP(hipEventSynchronize(s.ev)); s.pending = false; }
     if (s.cap < bytes) {
       if (s.p) { PLX_HIP(hipHostFree(s.p)); s.p = nullptr; s.cap = 0; }
-      size_t cap = std::max(bytes, size_t(8) << 20);
+      size_t cap = std::max(bytes + bytes / 8, size_t(8) << 20);      // headroom: the next column / chunk a little larger than this one does not re-allocate
       PLX_HIP(hipHostMalloc(&s.p, cap, hipHostMallocDefault));
       s.cap = cap;
     }

@@ -5,6 +5,7 @@
 // chunk through a page-locked double buffer) and decodes them there (parquet_reader.hpp orchestrates, kernels_parquet.hip runs
 // the bodies of parquet_device.hpp).  Reference: crates/polars-io/src/parquet/read/read_impl.rs (row groups x projection),
 // crates/polars-parquet/src/{parquet/read,arrow/read/deserialize}; crates/polars-stream/src/nodes/io_sources/parquet.
+#include <algorithm>
 #include <memory>
 #include <mutex>
 #include <exception>
@@ -88,13 +89,23 @@ struct HipBackend {
 class ColumnWorkers {
  public:
   static ColumnWorkers& get() { static ColumnWorkers* w = new ColumnWorkers(); return *w; }      // (never destroyed: the threads outlive static destruction)
-  int size() const { return (int)threads_.size(); }
-  // runs every task; rethrows the first exception (after all tasks have finished)
-  void run(std::vector<std::function<void()>>& tasks) {
+  int size() const { return (int)queues_.size(); }
+  // Runs every task; rethrows the first exception (after all tasks have finished).  Task -> worker is a function of the weights alone
+  // (heaviest first onto the least loaded worker): reading the same columns again puts each column on the thread whose page-locked
+  // staging buffers already have its size -- a worker that meets a larger column than it has seen re-allocates them (tens of ms).
+  void run(std::vector<std::function<void()>>& tasks, const std::vector<uint64_t>& weights) {
     std::vector<std::exception_ptr> errs(tasks.size());
+    std::vector<size_t> order(tasks.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weights[a] > weights[b]; });
+    std::vector<uint64_t> load(queues_.size(), 0);
     {
       std::lock_guard<std::mutex> lk(mu_);
-      for (size_t i = 0; i < tasks.size(); i++) queue_.push_back([&tasks, &errs, i] { try { tasks[i](); } catch (...) { errs[i] = std::current_exception(); } });
+      for (size_t i : order) {
+        const size_t w = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[w] += std::max<uint64_t>(weights[i], 1);
+        queues_[w].push_back([&tasks, &errs, i] { try { tasks[i](); } catch (...) { errs[i] = std::current_exception(); } });
+      }
       pending_ += tasks.size();
     }
     cv_.notify_all();
@@ -109,33 +120,34 @@ class ColumnWorkers {
     int n = 4;
     if (const char* e = getenv("PLX_PARQUET_THREADS")) n = std::max(1, std::min(16, atoi(e)));
     const int ordinal = device().ordinal;
+    queues_.resize((size_t)n);
     for (int i = 0; i < n; i++) {
-      threads_.emplace_back([this, ordinal] {
+      std::thread([this, ordinal, i] {
         (void)hipSetDevice(ordinal);
         hipStream_t s = nullptr;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess) set_thread_stream(s);
+        pq::host_thread_share = std::max<size_t>(8, 128 / queues_.size());
+        std::deque<std::function<void()>>& q = queues_[(size_t)i];
         for (;;) {
           std::function<void()> job;
           {
             std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [this] { return !queue_.empty(); });
-            job = std::move(queue_.front());
-            queue_.pop_front();
+            cv_.wait(lk, [&q] { return !q.empty(); });
+            job = std::move(q.front());
+            q.pop_front();
           }
           job();
           (void)hipStreamSynchronize(stream());          // what the task produced is complete before anybody on another stream looks at it
           std::lock_guard<std::mutex> lk(mu_);
           if (--pending_ == 0) done_cv_.notify_all();
         }
-      });
-      threads_.back().detach();
+      }).detach();
     }
   }
   std::mutex mu_;
   std::condition_variable cv_, done_cv_;
-  std::deque<std::function<void()>> queue_;
+  std::vector<std::deque<std::function<void()>>> queues_;      // one per worker; sized once, before the threads start
   size_t pending_ = 0;
-  std::vector<std::thread> threads_;
 };
 
 std::mutex g_mu;
@@ -283,8 +295,14 @@ int plx_parquet_read(plx_parquet file, const int32_t* row_groups, int32_t n_row_
     static const bool serial = [] { const char* e = getenv("PLX_PARQUET_THREADS"); return e && atoi(e) == 1; }();
     if (n_columns > 1 && !serial) {
       std::vector<std::function<void()>> tasks;
-      for (int32_t i = 0; i < n_columns; i++) tasks.push_back([&read_one, i] { read_one(i); });
-      ColumnWorkers::get().run(tasks);
+      std::vector<uint64_t> weights((size_t)n_columns, 0);      // stored bytes of the column's selected chunks
+      for (int32_t i = 0; i < n_columns; i++) {
+        tasks.push_back([&read_one, i] { read_one(i); });
+        if (columns[i] >= 0 && (size_t)columns[i] < f.md.leaves.size())
+          for (int g : rgs)
+            if (g >= 0 && (size_t)g < f.md.row_groups.size()) weights[(size_t)i] += (uint64_t)std::max<int64_t>(f.md.row_groups[g].columns[columns[i]].total_uncompressed_size, 0);
+      }
+      ColumnWorkers::get().run(tasks, weights);
     } else {
       for (int32_t i = 0; i < n_columns; i++) read_one(i);
     }

@@ -115,10 +115,14 @@ inline LeafType leaf_type(const Leaf& l) {
   }
 }
 
-// host threads for page-sized tasks: half the hardware threads (the other half is the caller's: other columns, the GPU driver), 2 .. 64 (PLX_HOST_THREADS overrides the cap; 128 measured no faster on a 256-thread host)
+// host threads for page-sized tasks: half the hardware threads (the other half is the caller's: other columns, the GPU driver), 2 .. 64 (PLX_HOST_THREADS overrides the cap; 128 measured
+// no faster on a 256-thread host).  A thread that reads one column of several at a time (parquet.cpp ColumnWorkers) lowers its own cap to its share: 4 columns x 32 threads inflate a zstd
+// file in 34-36 ms where 4 x 64 take 36-53 and 1 x 64 takes 142 (tools/scan_threads.py, 2e7 rows).
+inline thread_local size_t host_thread_share = 0;       // 0 = this thread has the host to itself
 inline size_t host_threads(size_t tasks) {
-  static const size_t cap = [] { const char* e = getenv("PLX_HOST_THREADS"); const long v = e ? atol(e) : 0; return v >= 1 && v <= 1024 ? (size_t)v : (size_t)64; }();
-  return std::min<size_t>(std::min<size_t>(cap, std::max(2u, std::thread::hardware_concurrency() / 2)), tasks);
+  static const size_t cap = [] { const char* e = getenv("PLX_HOST_THREADS"); const long v = e ? atol(e) : 0; return v >= 1 && v <= 1024 ? (size_t)v : (size_t)0; }();
+  const size_t mine = cap ? cap : host_thread_share ? host_thread_share : (size_t)64;
+  return std::min<size_t>(std::min<size_t>(mine, std::max(2u, std::thread::hardware_concurrency() / 2)), tasks);
 }
 
 inline uint32_t out_width_of(int dtype) {
