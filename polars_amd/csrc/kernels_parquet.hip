@@ -82,59 +82,79 @@ __global__ __launch_bounds__(kSnapLanes) void pq_snappy_kernel(const DecompJob* 
 }
 
 // second generation (the default; PLX_SNAPPY_KERNEL=1 selects the first): the same rounds with the batched-load bodies of next / mark / rank / jump
-// (parquet_snappy.hpp); timed against the first on hardware in round 3: 42.6 vs 51.4 ms
-__global__ __launch_bounds__(kSnapLanes) void pq_snappy_kernel_v2(const DecompJob* __restrict__ jobs, uint32_t n_jobs, uint32_t* __restrict__ err,
-                                                               unsigned long long* __restrict__ dbg) {
+// (parquet_snappy.hpp); timed against the first on hardware in round 3: 42.6 vs 51.4 ms.  The phase clock is an instantiation of its own (round 5: its
+// accumulators are 24 registers the decoder needs for its per-position arrays).
+#define PQ_TICK2(slot)                                     \
+  if constexpr (TIMING) {                                  \
+    if (lane == 0) {                                       \
+      const uint64_t now = wall_clock64();                 \
+      t_acc[slot] += now - t_last;                         \
+      t_last = now;                                        \
+    }                                                      \
+  }
+template <bool TIMING>
+__global__ __launch_bounds__(kSnapLanes, 2) void pq_snappy_kernel_v2(const DecompJob* __restrict__ jobs, uint32_t n_jobs, uint32_t* __restrict__ err,
+                                                                  unsigned long long* __restrict__ dbg) {
   __shared__ SnapShared sh;
   if (blockIdx.x >= n_jobs) return;
   const DecompJob job = jobs[blockIdx.x];
-  const uint32_t lane = threadIdx.x;
-  uint64_t t_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = dbg ? wall_clock64() : 0;
-  if (lane == 0) snappy_begin(sh, job);
+  const uint32_t lane0 = threadIdx.x;
+  uint64_t t_acc[TIMING ? 15 : 1] = {}, t_last = TIMING ? wall_clock64() : 0;
+  (void)t_acc; (void)t_last;
+  if (lane0 == 0) snappy_begin(sh, job);
   __syncthreads();
   while (sh.done == 0) {
+    // the lane index is made opaque once per round: everything the phases derive from it (19 LDS addresses per array and phase) would otherwise be
+    // hoisted out of this loop and held in registers for the whole kernel -- 255 registers and a spill, against 2 workgroups per CU
+    uint32_t lane = lane0;
+    asm volatile("" : "+v"(lane));
     snappy_stage(sh, job, lane);
     __syncthreads();
-    PQ_TICK(0)
+    PQ_TICK2(0)
     snappy_next_v2(sh, job, lane);
     __syncthreads();
-    PQ_TICK(1)
+    PQ_TICK2(1)
     for (uint32_t it = 0; it < kSnapSweeps && __syncthreads_or(snappy_mark_v2(sh, it, lane) ? 1 : 0); it++) {}   // barrier + "does any node still have a successor"
     __syncthreads();
-    PQ_TICK(2)
+    PQ_TICK2(2)
     snappy_rank_v2(sh, lane);
     __syncthreads();
+    PQ_TICK2(11)
     snappy_scan_v2_blocks(sh, lane);
     __syncthreads();
     if (lane == 0) snappy_scan_v2_totals(sh);
     __syncthreads();
     snappy_scan_v2_offsets(sh, lane);
     __syncthreads();
+    PQ_TICK2(12)
     snappy_place_v2(sh, job, lane);
     __syncthreads();
+    PQ_TICK2(13)
     if (lane == 0) snappy_finish(sh, job);
     __syncthreads();
-    PQ_TICK(3)
+    PQ_TICK2(3)
     if (sh.done == 2 || sh.bad) break;      // uniform: every lane reads the flags after the barrier
-    t_acc[8] += 1; t_acc[9] += sh.n_el;
+    if constexpr (TIMING) { t_acc[8] += 1; t_acc[9] += sh.n_el; }
     if (sh.direct) {
       snappy_direct(sh, job, lane);
     } else {
       snappy_point(sh, lane);
       __syncthreads();
-      PQ_TICK(4)
-      while (__syncthreads_or(snappy_jump_v2(sh, lane) ? 1 : 0)) { t_acc[10] += 1; }   // barrier + "did any lane still follow a pointer"
-      PQ_TICK(5)
+      PQ_TICK2(4)
+      while (__syncthreads_or(snappy_jump_v2(sh, lane) ? 1 : 0)) { if constexpr (TIMING) t_acc[10] += 1; }   // barrier + "did any lane still follow a pointer"
+      PQ_TICK2(5)
       snappy_gather(sh, job, lane);
     }
-    PQ_TICK(6)
+    PQ_TICK2(6)
     __threadfence();        // later rounds read this output from HBM: stores complete, L1 dropped
     __syncthreads();
-    PQ_TICK(7)
+    PQ_TICK2(7)
   }
-  if (lane == 0 && (sh.done == 2 || sh.bad)) atomicOr(err, (uint32_t)PE_SNAPPY);
-  if (dbg && lane == 0)
-    for (int i = 0; i < 11; i++) atomicAdd(dbg + i, (unsigned long long)t_acc[i]);
+  if (lane0 == 0 && (sh.done == 2 || sh.bad)) atomicOr(err, (uint32_t)PE_SNAPPY);
+  if constexpr (TIMING) {
+    if (lane0 == 0)
+      for (int i = 0; i < 15; i++) atomicAdd(dbg + i, (unsigned long long)t_acc[i]);
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void pq_page_prepare_kernel(PageDesc* __restrict__ pages, uint32_t n_pages, uint32_t* __restrict__ err) {
@@ -202,26 +222,30 @@ static unsigned blocks_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kB
 void pq_snappy(const DecompJob* jobs, uint32_t n_jobs, uint64_t bytes_out, uint32_t* err) {
   if (!n_jobs) return;
   static const bool timing = [] { const char* e = getenv("PLX_SNAPPY_TIMING"); return e && e[0] == '1'; }();
+  static const bool v2 = [] { const char* e = getenv("PLX_SNAPPY_KERNEL"); return !(e && e[0] == '1'); }();
   Buf dbg;
-  if (timing) dbg = dev_alloc_zero(11 * 8);
+  if (timing) dbg = dev_alloc_zero(15 * 8);
   {
     ProfileScope ps("pq_snappy", bytes_out * 2, n_jobs);
     // generation 2 (batched LDS loads) is the default since round 3: 42.6 vs 51.4 ms of pq_snappy on the 2e7-row file (gpurun_out/r03a), bit-identical
     // output on every stream of the GPU and CPU suites; PLX_SNAPPY_KERNEL=1 selects the first generation
-    static const bool v2 = [] { const char* e = getenv("PLX_SNAPPY_KERNEL"); return !(e && e[0] == '1'); }();
-    if (v2) hipLaunchKernelGGL(pq_snappy_kernel_v2, dim3(n_jobs), dim3(kSnapLanes), 0, stream(), jobs, n_jobs, err, timing ? dbg->as<unsigned long long>() : nullptr);
+    if (v2 && timing) hipLaunchKernelGGL(pq_snappy_kernel_v2<true>, dim3(n_jobs), dim3(kSnapLanes), 0, stream(), jobs, n_jobs, err, dbg->as<unsigned long long>());
+    else if (v2) hipLaunchKernelGGL(pq_snappy_kernel_v2<false>, dim3(n_jobs), dim3(kSnapLanes), 0, stream(), jobs, n_jobs, err, (unsigned long long*)nullptr);
     else hipLaunchKernelGGL(pq_snappy_kernel, dim3(n_jobs), dim3(kSnapLanes), 0, stream(), jobs, n_jobs, err, timing ? dbg->as<unsigned long long>() : nullptr);
     PLX_HIP(hipGetLastError());
   }
   if (timing) {
     int per_cu = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pq_snappy_kernel, (int)kSnapLanes, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pq_snappy_kernel_v2<false>, (int)kSnapLanes, 0);
     fprintf(stderr, "[pq_snappy] workgroups per CU: %d; ", per_cu);
-    unsigned long long h[11];
+    unsigned long long h[15];
     d2h_sync(h, dbg->ptr, sizeof h);
     static const char* names[8] = {"stage", "next", "mark", "rank_place", "point", "jump", "gather", "fence"};
     fprintf(stderr, "[pq_snappy] streams=%u out=%.1f MB rounds=%llu elements=%llu jump_sweeps=%llu; 100 MHz ticks summed over streams:", n_jobs, bytes_out / 1e6, h[8], h[9], h[10]);
+    const unsigned long long finish = h[3];
+    if (v2) h[3] += h[11] + h[12] + h[13];       // the second generation clocks the four steps of rank_place separately
     for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
+    if (v2) fprintf(stderr, " (rank_place = rank %llu + scan %llu + place %llu + finish %llu)", h[11], h[12], h[13], finish);
     fprintf(stderr, "\n");
   }
 }

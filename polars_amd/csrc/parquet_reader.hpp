@@ -22,6 +22,8 @@
 #include <exception>
 #include <string>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -123,6 +125,14 @@ inline size_t host_threads(size_t tasks) {
   static const size_t cap = [] { const char* e = getenv("PLX_HOST_THREADS"); const long v = e ? atol(e) : 0; return v >= 1 && v <= 1024 ? (size_t)v : (size_t)0; }();
   const size_t mine = cap ? cap : host_thread_share ? host_thread_share : (size_t)64;
   return std::min<size_t>(std::min<size_t>(mine, std::max(2u, std::thread::hardware_concurrency() / 2)), tasks);
+}
+
+// PLX_PARQUET_TRACE=1: where the host thread of a column is, in ms since the process' first traced event (stderr; measurement only)
+inline void trace_point(const std::string& column, const char* what) {
+  static const bool on = getenv("PLX_PARQUET_TRACE") != nullptr;
+  if (!on) return;
+  static const auto t0 = std::chrono::steady_clock::now();
+  fprintf(stderr, "[plx parquet] %9.2f ms  %-18s %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), column.c_str(), what);
 }
 
 inline uint32_t out_width_of(int dtype) {
@@ -249,6 +259,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
   if (lt.dtype < 0) throw Unsupported("column '" + leaf.name + "': " + lt.why + " is outside the hot path's dtypes");
   const bool is_bytes = leaf.type == PT_BYTE_ARRAY;
   const bool optional = leaf.repetition == REP_OPTIONAL;
+  trace_point(leaf.name, "start");
 
   ColumnResult<B> res;
   res.dtype = lt.dtype; res.logical = lt.logical;
@@ -529,6 +540,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     }
     row0 += (uint64_t)ch.rows;
   }
+  trace_point(leaf.name, "chunks read, uploads queued");
   // -- scratch for the decompressed streams ---------------------------------------------------------------------------------------------
   typename B::Mem scratch{};
   if (!jobs.empty()) {
@@ -581,6 +593,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
   be.run_count_runs(d_pages, n_pages, nulls_possible, (uint32_t*)be.addr(counts), err);   // level tables only when nulls are possible
   be.scan_u32((const uint32_t*)be.addr(counts), (uint64_t*)be.addr(offs), (int64_t)n_pages * 2);
   const uint64_t n_entries = be.read_u64(be.addr(offs) + (uint64_t)n_pages * 2 * 8);
+  trace_point(leaf.name, "streams inflated, runs counted (first host read)");
   if (stats) stats->run_entries += n_entries;
   typename B::Mem runs = be.alloc((size_t)n_entries * sizeof(RunEntry) + 64);
   be.run_fill_runs(d_pages, n_pages, (const uint64_t*)be.addr(offs), (RunEntry*)be.addr(runs));
@@ -613,6 +626,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
 
   // -- one synchronisation: error word (+ the valid-row total) ---------------------------------------------------------------------------
   uint32_t e = be.read_u32(be.addr(err_mem));
+  trace_point(leaf.name, "decoded");
   if (e) throw FormatError("column '" + leaf.name + "' of " + f.path + ": " + error_bits_text(e));
   if (nulls_possible) {
     uint64_t valid = be.read_u64(be.addr(word_prefix) + n_words * 8);

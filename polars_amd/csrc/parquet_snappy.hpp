@@ -59,7 +59,7 @@ constexpr uint32_t kSnapKindLit = 2u << 30;
 constexpr uint32_t kSnapPosMask = (1u << 30) - 1;
 constexpr uint32_t kSnapStop = 0xffffffffu;  // nl[] of a STOP node
 constexpr uint32_t kSnapLongNode = 0xfffffffeu;   // nl[] of a literal > kSnapDirect (or with a malformed length)
-constexpr uint16_t kSnapEnd = 0xffffu;       // jmp[] of a node without successor
+constexpr uint16_t kSnapEnd = (uint16_t)kSnapNodes;   // jmp[] of a node without successor: the index of a sentinel entry behind the nodes whose successor is itself (second-generation mark)
 static_assert(kSnapNodes >= kSnapWindow + 5 + kSnapDirect + 1, "chain positions must fit the node arrays");
 static_assert((1u << kSnapSweeps) > kSnapElems, "the node behind a full round must get its mark");
 
@@ -72,10 +72,10 @@ struct SnapShared {
   alignas(16) uint8_t win[kSnapWindow + 16];
   uint32_t nl[kSnapNodes];       // element nodes: output length << 16 | position of the next tag; else kSnapStop / kSnapLongNode
   union {
-    uint16_t jmp[2][kSnapNodes]; // mark phase: 2^k-th successor, double-buffered
+    uint16_t jmp[2][kSnapNodes + 2]; // mark phase: 2^k-th successor, double-buffered; [kSnapEnd] = the sentinel
     uint32_t ptr[kSnapRound];    // point / jump / gather phases
   };
-  uint8_t mark[kSnapNodes];
+  uint8_t mark[kSnapNodes + 4];      // (+ the sentinel's byte, written and never read)
   uint32_t part_cnt[kSnapLanes + 1], part_len[kSnapLanes + 1];   // per thread chunk: marked elements, their output bytes (then exclusive prefixes)
   SnapElem el[kSnapElems];
   uint32_t cut;         // first position of the chain that is not part of this round
@@ -116,6 +116,27 @@ PLX_HD uint32_t snappy_tag(const uint8_t* t, uint32_t* len, uint32_t* val, uint3
   } else if (kind == 1) { *len = ((tag >> 2) & 7) + 4; *val = ((tag >> 5) << 8) | t[1]; *hdr = 2; }
   else if (kind == 2) { *len = (tag >> 2) + 1; *val = t[1] | ((uint32_t)t[2] << 8); *hdr = 3; }
   else { *len = (tag >> 2) + 1; *val = t[1] | ((uint32_t)t[2] << 8) | ((uint32_t)t[3] << 16) | ((uint32_t)t[4] << 24); *hdr = 5; }
+  return kind;
+}
+
+// The same parse without a branch (second-generation bodies).  snappy_tag reads the bytes behind the tag inside the branch of its kind: on the device every kind
+// present in a wavefront is a serial pass with its own LDS round trip (measured: 11 us of a 56 us round in `next`, as much again in `place`).  Here the five bytes a
+// tag can span are fetched up front -- snappy_peek: two aligned dwords around position b, shifted into place -- and every field is a select.
+PLX_HD uint64_t snappy_peek(const uint8_t* win, uint32_t b) {          // bytes b .. b + 4 in bits 0 .. 39 (b <= kSnapWindow + 4: the pad behind the window is readable)
+  uint32_t w[2];
+  memcpy(w, __builtin_assume_aligned(win + (b & ~3u), 4), 8);      // (win is 16-byte aligned: two dword reads)
+  return (((uint64_t)w[1] << 32) | w[0]) >> (8 * (b & 3u));
+}
+PLX_HD uint32_t snappy_tag_x(uint64_t x, uint32_t* len, uint32_t* val, uint32_t* hdr) {
+  const uint32_t tag = (uint32_t)x & 0xffu, kind = tag & 3u, l = tag >> 2, rest = (uint32_t)(x >> 8);     // rest = the four bytes behind the tag
+  // literal: l < 60 -> l + 1 bytes; else l - 59 = 1..4 length bytes
+  const uint32_t nb = l >= 60 ? l - 59 : 0;
+  const uint32_t lv = nb == 0 ? l : (nb == 4 ? rest : rest & ((1u << (8 * (nb & 3u))) - 1u));
+  const uint32_t lit_len = (nb != 0 && lv >= kSnapPosMask) ? 0xffffffffu : lv + 1;
+  const uint32_t c1_len = (l & 7u) + 4, c1_val = ((tag >> 5) << 8) | (rest & 0xffu);
+  *len = kind == 0 ? lit_len : (kind == 1 ? c1_len : l + 1);
+  *val = kind == 0 ? 0u : (kind == 1 ? c1_val : (kind == 2 ? (rest & 0xffffu) : rest));
+  *hdr = kind == 0 ? 1 + nb : (kind == 3 ? 5u : kind + 1);
   return kind;
 }
 
@@ -199,57 +220,62 @@ PLX_HD bool snappy_mark(SnapShared& sh, uint32_t it, uint32_t lane) {
 // start of the sweep, what the any-order argument of the first generation already assumes).  Same results, checked by the CPU harness.
 PLX_HD void snappy_next_v2(SnapShared& sh, const DecompJob& job, uint32_t lane) {
   const uint32_t avail = job.comp_size - sh.in_pos;
-  uint32_t v[kSnapChunk];
-  uint16_t j[kSnapChunk];
-  for (uint32_t k = 0; k < kSnapChunk; k++) {
+  uint64_t x[kSnapChunk];
+  PLX_UNROLL
+  for (uint32_t k = 0; k < kSnapChunk; k++) { const uint32_t b = lane + k * kSnapLanes; x[k] = snappy_peek(sh.win, b < kSnapWindow ? b : kSnapWindow); }
+  PLX_UNROLL
+  for (uint32_t k = 0; k < kSnapChunk; k++) {       // (the stores cannot alias the window words already in registers)
     const uint32_t b = lane + k * kSnapLanes;
-    v[k] = kSnapStop; j[k] = kSnapEnd;
-    if (b + 5 <= kSnapWindow && b < avail) {
-      uint32_t len, val, hdr;
-      const uint32_t kind = snappy_tag(sh.win + b, &len, &val, &hdr);
-      if (kind == 0 && len > kSnapDirect) v[k] = kSnapLongNode;
-      else {
-        const uint32_t nxt = b + hdr + (kind == 0 ? len : 0);
-        v[k] = (len << 16) | nxt;
-        j[k] = (uint16_t)nxt;
-      }
-    }
-  }
-  for (uint32_t k = 0; k < kSnapChunk; k++) {
-    const uint32_t b = lane + k * kSnapLanes;
-    sh.nl[b] = v[k];
-    sh.jmp[0][b] = j[k];
+    uint32_t len, val, hdr;
+    const uint32_t kind = snappy_tag_x(x[k], &len, &val, &hdr);
+    const bool node = b + 5 <= kSnapWindow && b < avail;      // tag + up to 4 length / offset bytes inside the window, inside the input
+    const bool is_long = kind == 0 && len > kSnapDirect;
+    const uint32_t nxt = b + hdr + (kind == 0 ? len : 0);
+    sh.nl[b] = !node ? kSnapStop : (is_long ? kSnapLongNode : ((len << 16) | nxt));
+    sh.jmp[0][b] = (!node || is_long) ? kSnapEnd : (uint16_t)nxt;      // < kSnapNodes; may be a STOP node, which then ends the chain
     sh.mark[b] = b == 0;
   }
+  if (lane == 0) { sh.jmp[0][kSnapEnd] = kSnapEnd; sh.jmp[1][kSnapEnd] = kSnapEnd; }      // (the pointer phases of the last round wrote over the first)
 }
 
 PLX_HD bool snappy_mark_v2(SnapShared& sh, uint32_t it, uint32_t lane) {
+  // 11 sweeps x 19 nodes a lane: this loop IS the mark phase, and it was 24 instructions a node (466 a sweep: issue-bound, 16 us of a round).  The sentinel entry
+  // (its successor is itself, in both buffers) takes the "no successor" compare out of the dependent load and out of the mark store.
   const uint16_t* src = sh.jmp[it & 1];
   uint16_t* dst = sh.jmp[(it & 1) ^ 1];
   uint16_t j[kSnapChunk], jj[kSnapChunk];
   uint8_t m[kSnapChunk];
+  PLX_UNROLL
   for (uint32_t k = 0; k < kSnapChunk; k++) { const uint32_t b = lane + k * kSnapLanes; j[k] = src[b]; m[k] = sh.mark[b]; }
-  for (uint32_t k = 0; k < kSnapChunk; k++) jj[k] = j[k] == kSnapEnd ? kSnapEnd : src[j[k]];
-  bool changed = false;
+  PLX_UNROLL
+  for (uint32_t k = 0; k < kSnapChunk; k++) jj[k] = src[j[k]];
+  uint32_t nearest = kSnapEnd;
+  PLX_UNROLL
   for (uint32_t k = 0; k < kSnapChunk; k++) {
-    const uint32_t b = lane + k * kSnapLanes;
-    dst[b] = jj[k];
-    if (j[k] != kSnapEnd) { changed = true; if (m[k]) sh.mark[j[k]] = 1; }
+    dst[lane + k * kSnapLanes] = jj[k];
+    if (m[k]) sh.mark[j[k]] = 1;                          // (a marked node without successor marks the sentinel: nobody reads that byte)
+    nearest = j[k] < nearest ? j[k] : nearest;
   }
-  return changed;
+  return nearest != kSnapEnd;
 }
 
 PLX_HD void snappy_rank_v2(SnapShared& sh, uint32_t lane) {
-  uint8_t m[kSnapChunk];
+  uint32_t marked = 0, ends = 0;      // bit k: position k of the chunk is on the chain / is a STOP node or a long literal
   uint32_t v[kSnapChunk];
-  for (uint32_t k = 0; k < kSnapChunk; k++) { const uint32_t b = lane * kSnapChunk + k; m[k] = sh.mark[b]; v[k] = sh.nl[b]; }
-  uint32_t cnt = 0, len = 0;
+  PLX_UNROLL
   for (uint32_t k = 0; k < kSnapChunk; k++) {
-    if (!m[k]) continue;
-    if (v[k] >= kSnapLongNode) { snap_min(&sh.cut, lane * kSnapChunk + k); break; }
-    cnt++; len += v[k] >> 16;
+    const uint32_t b = lane * kSnapChunk + k;
+    marked |= (uint32_t)(sh.mark[b] != 0) << k;
+    v[k] = sh.nl[b];
+    ends |= (uint32_t)(v[k] >= kSnapLongNode) << k;
   }
-  sh.part_cnt[lane] = cnt; sh.part_len[lane] = len;
+  const uint32_t stop = marked & ends;                                 // the chain ends at the first of these (nothing behind a STOP is marked)
+  const uint32_t live = stop ? marked & ((stop & (0u - stop)) - 1u) : marked;
+  uint32_t len = 0;
+  PLX_UNROLL
+  for (uint32_t k = 0; k < kSnapChunk; k++) len += ((live >> k) & 1u) ? v[k] >> 16 : 0u;
+  if (stop) snap_min(&sh.cut, lane * kSnapChunk + (uint32_t)__builtin_ctz(stop));
+  sh.part_cnt[lane] = (uint32_t)__builtin_popcount(live); sh.part_len[lane] = len;
 }
 
 // rank, step 1: per thread chunk of kSnapChunk consecutive positions: marked elements, their output bytes; the first marked STOP
@@ -343,46 +369,43 @@ PLX_HD void snappy_place(SnapShared& sh, const DecompJob& job, uint32_t lane) {
   }
 }
 
-// second generation (pq_snappy_kernel_v2): marks and node words of the chunk loaded up front, elements kept in registers (indexed by
-// the position in the chunk, a compile-time constant once unrolled) and stored after the last window byte has been read
+// second generation (pq_snappy_kernel_v2).  Round 5: the loop runs over the MARKED positions of the chunk only (a wavefront makes as many trips as its busiest lane
+// has elements: 8-10 of 19 positions on integer columns; the fully unrolled body over all 19 positions was 4500 instructions and 10 us of a 56 us round), the window
+// bytes of the next marked position are fetched while the current one is decoded, and the tag is parsed without a branch (snappy_tag_x).  What `next` derived from
+// the same bytes (element / STOP / long literal) is derived once more instead of being read back.
 PLX_HD void snappy_place_v2(SnapShared& sh, const DecompJob& job, uint32_t lane) {
-  uint8_t m[kSnapChunk];
-  uint32_t v[kSnapChunk];
+  uint32_t todo = 0;            // bit k: position k of the chunk is on the chain
   PLX_UNROLL
-  for (uint32_t k = 0; k < kSnapChunk; k++) { const uint32_t b = lane * kSnapChunk + k; m[k] = sh.mark[b]; v[k] = sh.nl[b]; }
+  for (uint32_t k = 0; k < kSnapChunk; k++) todo |= (uint32_t)(sh.mark[lane * kSnapChunk + k] != 0) << k;
   uint32_t r = sh.part_cnt[lane], d = sh.part_len[lane];
   const uint32_t win0 = sh.win_pos, round0 = sh.round_out0;
-  SnapElem e[kSnapChunk];
-  uint32_t at[kSnapChunk];
-  bool stopped = false, bad = false;
-  PLX_UNROLL
-  for (uint32_t k = 0; k < kSnapChunk; k++) {
-    at[k] = 0xffffffffu;
-    if (stopped || !m[k]) continue;
-    const uint32_t b = lane * kSnapChunk + k;
-    if (v[k] >= kSnapLongNode) { stopped = true; continue; }
-    const uint32_t olen = v[k] >> 16;
-    if (r >= kSnapElems || d + olen > kSnapRound) { snap_min(&sh.cut, b); stopped = true; continue; }
-    uint32_t len, val, hdr;
-    const uint32_t kind = snappy_tag(sh.win + b, &len, &val, &hdr);
-    SnapElem el;
-    el.dst = (uint16_t)d; el.len = (uint16_t)len;
-    bool ok = len <= job.uncomp_size - (round0 + d);
-    if (kind == 0) {
-      const uint32_t src = win0 + b + hdr;
-      ok = ok && src <= job.comp_size && len <= job.comp_size - src;
-      el.src = 0x80000000u | src;
-    } else {
-      ok = ok && win0 + b + hdr <= job.comp_size && val >= 1 && val <= round0 + d;
-      el.src = val;
+  const uint32_t avail = job.comp_size - win0;      // (win_pos == in_pos until finish)
+  bool bad = false;
+  uint32_t b_next = todo ? lane * kSnapChunk + (uint32_t)__builtin_ctz(todo) : 0;
+  uint64_t x_next = snappy_peek(sh.win, b_next < kSnapWindow ? b_next : kSnapWindow);
+  while (todo) {
+    const uint32_t b = b_next;
+    const uint64_t x = x_next;
+    todo &= todo - 1;
+    if (todo) {
+      b_next = lane * kSnapChunk + (uint32_t)__builtin_ctz(todo);
+      x_next = snappy_peek(sh.win, b_next < kSnapWindow ? b_next : kSnapWindow);
     }
-    if (!ok) bad = true;
-    e[k] = el; at[k] = r;
-    r++; d += olen;
+    uint32_t len, val, hdr;
+    const uint32_t kind = snappy_tag_x(x, &len, &val, &hdr);
+    const bool node = b + 5 <= kSnapWindow && b < avail;
+    if (!node || (kind == 0 && len > kSnapDirect)) break;       // a STOP node or a long literal (nl[b] >= kSnapLongNode): the chain ends here
+    if (r >= kSnapElems || d + len > kSnapRound) { snap_min(&sh.cut, b); break; }   // monotone: everything behind it fails too
+    const uint32_t src = win0 + b + hdr;
+    const bool lit_ok = src <= job.comp_size && len <= job.comp_size - src;
+    const bool copy_ok = src <= job.comp_size && val >= 1 && val <= round0 + d;
+    if (!(len <= job.uncomp_size - (round0 + d) && (kind == 0 ? lit_ok : copy_ok))) bad = true;      // the round is abandoned before any pointer is formed
+    SnapElem el;
+    el.src = kind == 0 ? (0x80000000u | src) : val;
+    el.dst = (uint16_t)d; el.len = (uint16_t)len;
+    sh.el[r] = el;
+    r++; d += len;
   }
-  PLX_UNROLL
-  for (uint32_t k = 0; k < kSnapChunk; k++)
-    if (at[k] != 0xffffffffu) sh.el[at[k]] = e[k];
   if (bad) sh.bad = 1;
 }
 
@@ -471,12 +494,17 @@ PLX_HD bool snappy_jump_v2(SnapShared& sh, uint32_t lane) {
   const uint32_t n_bytes = sh.out_pos - sh.round_out0;
   constexpr uint32_t kPer = kSnapRound / kSnapLanes;
   uint32_t p[kPer], q[kPer];
+  PLX_UNROLL
   for (uint32_t k = 0; k < kPer; k++) { const uint32_t i = lane + k * kSnapLanes; p[k] = i < n_bytes ? sh.ptr[i] : (1u << 30); }
-  for (uint32_t k = 0; k < kPer; k++) q[k] = (p[k] >> 30) ? p[k] : sh.ptr[p[k]];
-  bool changed = false;
-  for (uint32_t k = 0; k < kPer; k++)
-    if (!(p[k] >> 30)) { sh.ptr[lane + k * kSnapLanes] = q[k]; changed = true; }
-  return changed;
+  PLX_UNROLL
+  for (uint32_t k = 0; k < kPer; k++) q[k] = sh.ptr[p[k] & (kSnapRound - 1)];      // (read for resolved pointers too -- some entry of the array -- and not used then)
+  uint32_t least = 1u << 30;
+  PLX_UNROLL
+  for (uint32_t k = 0; k < kPer; k++) {
+    if (!(p[k] >> 30)) sh.ptr[lane + k * kSnapLanes] = q[k];
+    least = p[k] < least ? p[k] : least;
+  }
+  return !(least >> 30);
 }
 
 // gather: load every byte through its resolved pointer and store it

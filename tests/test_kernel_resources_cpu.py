@@ -72,7 +72,7 @@ def test_parquet_kernels_do_not_spill_and_fit_two_snappy_workgroups_per_cu():
         if "pq_snappy" in name:
             assert int(r["LDS Size [bytes/block]"]) <= 80 * 1024, (name, r)
             assert int(r["VGPRs"]) <= 256, (name, r)          # two 256-thread workgroups per CU = two waves per SIMD: 256 registers each at most
-    assert sum("pq_snappy" in n for n in res) == 2           # generation 2 (the default since round 3) and generation 1 (PLX_SNAPPY_KERNEL=1)
+    assert sum("pq_snappy" in n for n in res) == 3           # generation 2 (the default since round 3) with and without its phase clock, generation 1 (PLX_SNAPPY_KERNEL=1)
 
 
 def test_string_group_by_kernels_do_not_spill():
