@@ -12,6 +12,10 @@ import os
 import threading
 from typing import Optional
 
+# hardware queues for the reader's per-column streams (core.cpp init_device has the measurement): set here as well because another library of the process
+# (torch.distributed creating the RCCL communicator) may start the HIP runtime before plx_init does; a value the user has set wins
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpolars_amd.so")
 

@@ -34,6 +34,10 @@ void init_device(int ordinal) {
   std::lock_guard<std::mutex> lk(g_dev_mu);
   if (g_dev.ordinal == ordinal) return;
   if (g_dev.ordinal >= 0) fail(PLX_ERR_INVALID, "plx_init: process already bound to device " + std::to_string(g_dev.ordinal) + " (one process per GPU)");
+  // The Parquet reader decodes the columns of a read on up to six HIP streams (parquet.cpp ColumnWorkers).  The runtime multiplexes a process' streams onto
+  // GPU_MAX_HW_QUEUES hardware queues -- four by default -- and kernels of streams that share a queue run one after the other: with eight, the Snappy read of the
+  // 2e7-row file takes 27.6 instead of 35-36 ms.  Only effective when this is the process' first HIP call; a value the caller has set is left alone.
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n == 0) fail(PLX_ERR_HIP, std::string("plx_init: no HIP device: ") + hipGetErrorString(e));
