@@ -246,4 +246,29 @@ int pqemu_snappy_host(const uint8_t* in, uint32_t n_in, uint8_t* out, uint32_t n
   } catch (const std::exception& e) { t_err = e.what(); return 1; }
 }
 
+// the branch-free tag parse of the second-generation bodies against the branching one (parquet_snappy.hpp): every tag byte x `n_rest` pseudo-random
+// and edge-valued tails, at every byte alignment of the window; returns the number of disagreements (0 expected)
+int64_t pqemu_snappy_tag_selfcheck(uint32_t n_rest, uint64_t seed) {
+  alignas(16) uint8_t win[64];
+  int64_t bad = 0;
+  const uint32_t edges[] = {0u, 1u, 0xffu, 0x100u, 0xffffu, 0x10000u, 0xffffffu, 0x1000000u, 0x3ffffffeu, 0x3fffffffu, 0x40000000u, 0x7fffffffu, 0x80000000u, 0xffffffffu};
+  const uint32_t n_edges = (uint32_t)(sizeof edges / sizeof edges[0]);
+  uint64_t x = seed | 1;
+  for (uint32_t tag = 0; tag < 256; tag++)
+    for (uint32_t r = 0; r < n_rest + n_edges; r++) {
+      x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+      const uint32_t rest = r < n_edges ? edges[r] : (uint32_t)(x >> 17);
+      for (uint32_t b = 8; b < 12; b++) {           // the four alignments of a window position
+        for (uint32_t i = 0; i < 64; i++) win[i] = (uint8_t)(x >> (i & 31));
+        win[b] = (uint8_t)tag;
+        memcpy(win + b + 1, &rest, 4);
+        uint32_t l0, v0, h0, l1, v1, h1;
+        const uint32_t k0 = snappy_tag(win + b, &l0, &v0, &h0);
+        const uint32_t k1 = snappy_tag_x(snappy_peek(win, b), &l1, &v1, &h1);
+        if (k0 != k1 || l0 != l1 || v0 != v1 || h0 != h1) bad++;
+      }
+    }
+  return bad;
+}
+
 }  // extern "C"

@@ -42,6 +42,8 @@ def lib():
         l.pqemu_snappy.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
         l.pqemu_snappy_host.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32]
         l.pqemu_host_codec.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        l.pqemu_snappy_tag_selfcheck.argtypes = [C.c_uint32, C.c_uint64]
+        l.pqemu_snappy_tag_selfcheck.restype = C.c_int64
         _lib = l
     return _lib
 

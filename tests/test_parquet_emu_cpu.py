@@ -368,6 +368,12 @@ def test_snappy_rounds_on_random_element_streams(seed):
     assert rc == 0 and got == want
 
 
+def test_snappy_branch_free_tag_parse_agrees_with_the_branching_one():
+    """snappy_tag_x (next / place of the second-generation kernel: the five bytes a tag can span fetched up front, every field a select) against snappy_tag,
+    for every tag byte x 2000 pseudo-random tails + the edge values of the length / offset fields, at all four alignments of a window position."""
+    assert E.lib().pqemu_snappy_tag_selfcheck(2000, 12345) == 0
+
+
 def test_snappy_on_pyarrow_compressed_buffers():
     for payload in (b"", b"a", b"abc" * 10000, RNG.integers(0, 256, 100_000, dtype=np.uint8).tobytes(), np.arange(50_000, dtype=np.int64).tobytes(),
                     (b"x" * 70000 + b"y") * 3):
