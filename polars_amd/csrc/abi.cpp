@@ -965,6 +965,11 @@ void strview_encode_device(const uint64_t* views, const ColumnPtr& validity_hold
   Buf bb = dev_alloc_zero(8);
   encode_on_device(views, validity_holder, data, bb, n, out_codes, out_dict);
 }
+// ... with the long strings' bytes in several concatenated buffers: `buf_base` = the device array of their start offsets inside `data` (what plx_strview_dict_encode
+// builds from its host buffers; the Parquet reader's host-string path brings everything to the device itself: parquet.cpp)
+void strview_encode_device_bases(const uint64_t* views, const ColumnPtr& validity_holder, Buf data, Buf buf_base, int64_t n, plx_column* out_codes, plx_strdict* out_dict) {
+  encode_on_device(views, validity_holder, data, buf_base, n, out_codes, out_dict);
+}
 }  // namespace plx
 }  // extern "C++"
 

@@ -41,4 +41,5 @@ bool int_range(const ColumnPtr& c, int64_t* mn, int64_t* mx, bool allow_assumed 
 
 }  // namespace ops
 void strview_encode_device(const uint64_t* views, const ColumnPtr& validity_holder, Buf data, int64_t n, plx_column* out_codes, uint64_t* out_dict);   // abi.cpp
+void strview_encode_device_bases(const uint64_t* views, const ColumnPtr& validity_holder, Buf data, Buf buf_base, int64_t n, plx_column* out_codes, uint64_t* out_dict);   // abi.cpp
 }  // namespace plx
