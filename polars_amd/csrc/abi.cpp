@@ -990,7 +990,12 @@ int plx_strview_dict_encode(const void* views, const uint8_t* validity, int64_t 
   std::vector<uint64_t> base((size_t)std::max(n_data_buffers, 1), 0);
   for (int i = 0; i < n_data_buffers; i++) { base[i] = total; total += (uint64_t)data_sizes[i]; }
   Buf data = dev_alloc((size_t)total + 64), bb = dev_alloc(sizeof(uint64_t) * base.size());
-  for (int i = 0; i < n_data_buffers; i++) if (data_sizes[i]) h2d_sync_pinned((uint8_t*)data->ptr + base[i], data_buffers[i], (size_t)data_sizes[i]);
+  for (int i = 0; i < n_data_buffers; i++) {
+    if (!data_sizes[i]) continue;
+    // large buffers are page-locked for their copy (h2d_sync_pinned); the many small ones of a page-per-buffer source are queued and waited for once, below
+    if ((uint64_t)data_sizes[i] >= ((uint64_t)32 << 20)) h2d_sync_pinned((uint8_t*)data->ptr + base[i], data_buffers[i], (size_t)data_sizes[i]);
+    else h2d_async((uint8_t*)data->ptr + base[i], data_buffers[i], (size_t)data_sizes[i]);
+  }
   h2d_async(bb->ptr, base.data(), sizeof(uint64_t) * base.size());
   PLX_HIP(hipStreamSynchronize(stream()));
   encode_on_device(dv->as<uint64_t>(), vh, data, bb, n, out_codes, out_dict);
