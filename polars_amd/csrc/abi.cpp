@@ -883,6 +883,10 @@ int plx_jit_selftest(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int
     jobs = {{shapes[0], jit::REGAGG}, {shapes[1], jit::JOIN_BUILD}, {shapes[1], jit::DIRECT_BUILD}, {shapes[2], jit::PROBE_AGG}, {shapes[2], jit::DIRECT_PROBE}};
     for (size_t i = 3; i + 1 < shapes.size(); i++) jobs.push_back({shapes[i], jit::BITMAP_BUILD});
     for (uint32_t tiles : {2u, 4u}) jobs.push_back({shapes.back(), jit::part3_scatter_sink(fused::kP2Direct, tiles, fused::kPackRowid, false)});   // the partitioned probe's scatter
+  } else if (rn.kind == PLX_IR_FILTER) {
+    fused::Shape sh{};
+    PLX_REQUIRE(engine::describe_filter_fusion(p, root, &sh, &why), PLX_ERR_UNSUPPORTED, "not fusable: " + why);
+    jobs = {{sh, jit::FILTER_COMPACT}};
   } else {
     fused::Shape sh{}; int sid = -1;
     PLX_REQUIRE(engine::describe_fusion(p, root, &sh, &sid, &why), PLX_ERR_UNSUPPORTED, "not fusable: " + why);

@@ -1986,7 +1986,98 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
 // ----------------------------------------------------------------- executors ----
 static FramePtr exec_node(Plan& plan, int node_id);
 
+// [Filter]* over a materialised frame in ONE pass (k::fused_filter): the conjunction of the predicates compiled into a register program, the kept rows of every
+// fixed-width column written densely by the same kernel that evaluates it (inputs read once, outputs written once: SURVEY.md 8(d) a4's algorithmic bytes); validity
+// bitmaps and Boolean columns are compacted with the selection the kernel leaves behind (mask + per-tile offsets).  `want_rows`: also the kept row indices.
+// false: the predicate does not compile (f32 arithmetic, null literals...) -- the per-node path runs it.
+static bool fused_filter_frame(Plan& plan, const std::vector<int>& preds, const FramePtr& src, FramePtr& out, std::string* why, ColumnPtr* want_rows = nullptr, bool rows_only = false) {
+  Compiler c(plan, *src);
+  try {
+    int p = -1;
+    for (int pe : preds) { int n = c.lower(pe); if (c.nodes[n].ty != 'b') throw Unsupported("predicate is not boolean"); p = p < 0 ? n : c.mk(OP_AND, p, n, 'b'); }
+    if (p < 0) throw Unsupported("no predicate");
+    c.pred = p;
+    c.finish();
+  } catch (const Unsupported& u) { if (why) *why = u.why; return false; }
+  const int64_t n = src->height;
+  out = std::make_shared<Frame>();
+  out->names = src->names;
+  if (n == 0) { out->cols = src->cols; out->height = 0; if (want_rows) { auto e = std::make_shared<Column>(); e->dtype = PLX_U32; e->len = 0; e->null_count = 0; e->values = dev_alloc(8); *want_rows = e; } return true; }
+  PLX_REQUIRE(n < 0xffffffffll || !want_rows, PLX_ERR_UNSUPPORTED, "filter: row indices beyond u32 IdxSize");
+  FilterCompact fc{};
+  std::vector<ColumnPtr> outs(src->cols.size());
+  std::vector<int> in_kernel;
+  if (!rows_only) {
+    for (size_t i = 0; i < src->cols.size(); i++) {
+      const ColumnPtr& col = src->cols[i];
+      auto o = std::make_shared<Column>();
+      o->dtype = col->dtype; o->values = nullptr;
+      outs[i] = o;
+      const int w = dtype_width(col->dtype);
+      if (col->dtype == PLX_BOOL || !(w == 1 || w == 2 || w == 4 || w == 8) || fc.n_cols >= kFilterMaxCols) continue;
+      o->values = dev_alloc(values_bytes(col->dtype, n));                  // sized for every row: the kept count is only known when the pass is over
+      fc.in[fc.n_cols] = col->data(); fc.out[fc.n_cols] = o->values->ptr; fc.width[fc.n_cols] = (uint8_t)w; fc.n_cols++;
+      in_kernel.push_back((int)i);
+    }
+  }
+  ColumnPtr rows;
+  if (want_rows) {
+    rows = std::make_shared<Column>();
+    rows->dtype = PLX_U32; rows->null_count = 0; rows->values = dev_alloc(values_bytes(PLX_U32, n));
+    fc.row_ids = rows->values->as<unsigned int>();
+  }
+  Buf mask;
+  const k::FilterPlan fp = k::fused_filter(c.shape, c.args, fc, &mask);
+  const int64_t m = fp.n_out;
+  out->height = m;
+  // an output that kept few rows gives its full-size buffer back (a copy of m rows: cheap exactly when it matters)
+  auto shrink = [&](const ColumnPtr& col) {
+    const size_t need = (size_t)values_bytes(col->dtype, m);
+    if (col->values && m * 4 < n && n >= ((int64_t)1 << 20)) {
+      Buf small = dev_alloc(std::max<size_t>(need, 8));
+      if (need) PLX_HIP(hipMemcpyAsync(small->ptr, col->values->ptr, need, hipMemcpyDeviceToDevice, stream()));
+      col->values = small;
+    }
+  };
+  if (want_rows) { rows->len = m; shrink(rows); *want_rows = rows; }
+  if (!rows_only) {
+    for (size_t i = 0; i < src->cols.size(); i++) {
+      const ColumnPtr& col = src->cols[i];
+      const ColumnPtr& o = outs[i];
+      o->len = m;
+      if (m == n) { outs[i] = col; continue; }                                   // every row kept (filter/mod.rs:47-49)
+      if (o->values) {
+        shrink(o);
+        if (col->validity) {
+          o->validity = dev_alloc_zero(bitmap_bytes(m));
+          k::filter_apply(fp, 0, col->valid_words(), nullptr, o->validity->ptr, nullptr);      // the validity bitmap compacted as a bitmap
+        } else o->null_count = 0;
+      } else {
+        o->values = col->dtype == PLX_BOOL ? dev_alloc_zero(bitmap_bytes(m)) : dev_alloc(values_bytes(col->dtype, m));
+        if (col->validity) o->validity = dev_alloc_zero(bitmap_bytes(m)); else o->null_count = 0;
+        k::filter_apply(fp, dtype_width(col->dtype), col->data(), col->valid_words(), o->values->ptr, o->validity ? o->validity->as<uint64_t>() : nullptr);
+      }
+    }
+    out->cols = outs;
+  }
+  PLX_HIP(hipStreamSynchronize(stream()));       // `mask` and the plan's offsets live until the compactions that read them are done
+  plan.desc += "FusedFilter{fused_filter_compact[" + std::string(jit::program_mode(-1, n)) + "] one pass: predicate + ordered compaction of " + std::to_string(fc.n_cols) + " columns" +
+               (src->cols.size() > (size_t)fc.n_cols && !rows_only ? " (+" + std::to_string(src->cols.size() - (size_t)fc.n_cols) + " through the selection bitmap)" : "") +
+               (want_rows ? ", row ids" : "") + ", kept=" + std::to_string(m) + "/" + std::to_string(n) + "}; ";
+  return true;
+}
+
 static FramePtr exec_filter(Plan& plan, const IRN& n) {
+  if (!(plan.flags & PLX_PLAN_NO_FUSION)) {
+    std::vector<int> preds;
+    const int src_node = peel_filters(plan, n.input, preds);
+    preds.push_back(n.predicate);
+    FramePtr src = exec_node(plan, src_node);
+    FramePtr out; std::string why;
+    if (fused_filter_frame(plan, preds, src, out, &why)) return out;
+    plan.desc += "(filter not fused: " + why + ") ";
+    plan.memo[src_node] = src;
+  }
   FramePtr in = exec_node(plan, n.input);
   Evaluated m = eval(plan, n.predicate, *in, nullptr);
   ColumnPtr mask = broadcast(m, in->height);
@@ -2000,8 +2091,8 @@ static FramePtr exec_filter(Plan& plan, const IRN& n) {
   return out;
 }
 
-static FramePtr exec_select(Plan& plan, const IRN& n, bool hstack) {
-  FramePtr in = exec_node(plan, n.input);
+static FramePtr exec_select(Plan& plan, const IRN& n, bool hstack, FramePtr in_given = nullptr) {
+  FramePtr in = in_given ? in_given : exec_node(plan, n.input);
   auto out = std::make_shared<Frame>();
   std::vector<Evaluated> evs;
   bool all_scalar = true;
@@ -2056,7 +2147,181 @@ static FramePtr exec_groupby_materialised(Plan& plan, const IRN& n, const FrameP
 }
 
 
+// ------------------------------------------------ fused Join -> frame pipeline ----
+// Join(inner | left; one plain integer key pair) of two [Filter]* inputs that RETURNS A FRAME (the reference: JoinExec polars-mem-engine/src/executors/join.rs:41-121 ->
+// _inner_join_from_series / _left_join_from_series polars-ops/src/frame/join/mod.rs:564-652 -> hash_join_tuples_inner single_keys_inner.rs:40-149 -> gathers).
+// The filters never materialise their frames: the build side's predicate is fused into the build scan (k::fused_join_build: 16-byte {key, row} slots, chains of
+// rows for duplicate keys), the probe side's into the scatter of the partitioned probe (k::partitioned_hash_probe_hits: rows radix-partitioned by the key's hash,
+// each partition tested against an LDS filter of its region of the table) or -- joins that keep most probe rows, left joins, small tables -- into the one-pass
+// row-id compaction (k::fused_filter); join::join_pairs then looks every CANDIDATE up once and lays the (probe row, build row) pairs out, and the payload columns
+// `want` names (null: all) are gathered at them, several columns per launch.  PLX_JOIN_MATERIALISE: 0 = never, 2 = any size (tests), default from 2^24 probe rows.
+static int join_materialise_mode() { const char* e = getenv("PLX_JOIN_MATERIALISE"); return e && e[0] == '0' ? 0 : e && e[0] == '2' ? 2 : 1; }
+static bool fused_join_frame(Plan& plan, const IRN& jn, const std::set<std::string>* want, FramePtr& out, std::string* why) {
+  auto no = [&](const char* m) { if (why) *why = m; return false; };
+  const int mode = join_materialise_mode();
+  if (mode == 0) return no("disabled (PLX_JOIN_MATERIALISE=0)");
+  if ((jn.how != PLX_JOIN_INNER && jn.how != PLX_JOIN_LEFT) || jn.keys.size() != 1 || jn.keys_right.size() != 1) return no("not a single-key inner or left join");
+  const bool left_join = jn.how == PLX_JOIN_LEFT;
+  auto plain = [&](int e) -> const AE* { const AE* x = &plan.ae[e]; while (x->kind == PLX_AE_ALIAS) x = &plan.ae[x->lhs]; return x->kind == PLX_AE_COLUMN ? x : nullptr; };
+  const AE* lkx = plain(jn.keys[0]);
+  const AE* rkx = plain(jn.keys_right[0]);
+  if (!lkx || !rkx) return no("join keys are expressions");
+  std::vector<int> lpreds, rpreds;
+  const int lsrc = peel_filters(plan, jn.input, lpreds), rsrc = peel_filters(plan, jn.input_right, rpreds);
+  // (cheap checks on scans first: a join this path does not take must not have executed its inputs twice)
+  auto height_of = [&](int node) -> int64_t { return plan.ir[node].kind == PLX_IR_SCAN ? get_frame(plan.ir[node].frame)->height : -1; };
+  if (mode == 1 && height_of(lsrc) >= 0 && height_of(rsrc) >= 0 && std::max(height_of(lsrc), height_of(rsrc)) < ((int64_t)1 << 24)) return no("small inputs");
+  FramePtr L = exec_node(plan, lsrc), R = exec_node(plan, rsrc);
+  plan.memo[lsrc] = L; plan.memo[rsrc] = R;
+  const int lki = L->find(lkx->name), rki = R->find(rkx->name);
+  if (lki < 0 || rki < 0) return no("join key column not found");
+  const int kdt = L->cols[lki]->dtype;
+  if (kdt != R->cols[rki]->dtype || !dtype_is_int(kdt)) return no("join key is not an integer column pair of one dtype");
+  if (L->height >= 0xffffffffll || R->height >= 0xffffffffll) return no("side exceeds u32 row indices");
+  const bool build_right = left_join || L->height > R->height;       // det_hash_prone_order (hash_join/mod.rs:41-50); a left join probes with its left table
+  const FramePtr& B = build_right ? R : L;
+  const FramePtr& P = build_right ? L : R;
+  if (mode == 1 && P->height < ((int64_t)1 << 24)) return no("small inputs");
+  const int bki = build_right ? rki : lki, pki = build_right ? lki : rki;
+  const std::vector<int>& bpreds = build_right ? rpreds : lpreds;
+  const std::vector<int>& ppreds = build_right ? lpreds : rpreds;
+  // output columns (_finish_join, general.rs:17-49): left columns, then right columns except the coalesced right key; clashes get the suffix
+  struct OutCol { std::string name; int side; int idx; };     // side 0 = left, 1 = right
+  std::vector<OutCol> outs;
+  {
+    std::set<std::string> seen;
+    for (size_t i = 0; i < L->names.size(); i++) { outs.push_back({L->names[i], 0, (int)i}); seen.insert(L->names[i]); }
+    for (size_t i = 0; i < R->names.size(); i++) {
+      if ((int)i == rki) continue;
+      std::string name = R->names[i];
+      if (seen.count(name)) name += jn.suffix;
+      if (seen.count(name)) return no("duplicate output column name");
+      seen.insert(name);
+      outs.push_back({name, 1, (int)i});
+    }
+  }
+  Compiler cnt(plan, *B), cb(plan, *B), cs(plan, *P);
+  try {
+    auto and_preds = [&](Compiler& c, const std::vector<int>& preds) {
+      int p = -1;
+      for (int pe : preds) { int n = c.lower(pe); if (c.nodes[n].ty != 'b') throw Unsupported("predicate is not boolean"); p = p < 0 ? n : c.mk(OP_AND, p, n, 'b'); }
+      return p;
+    };
+    cnt.pred = and_preds(cnt, bpreds);
+    const int bk_cnt = cnt.load(bki);
+    cnt.add_agg(cnt.nodes[bk_cnt].nullable ? AGG_COUNT : AGG_LEN, cnt.nodes[bk_cnt].nullable ? bk_cnt : -1);
+    cnt.finish();
+    cb.pred = and_preds(cb, bpreds);
+    cb.key = cb.load(bki);
+    cb.finish();
+    cs.pred = and_preds(cs, ppreds);
+    cs.key = cs.load(pki);
+    cs.add_agg(AGG_FIRST_ROW, -1);
+    cs.finish();
+  } catch (const Unsupported& u) { if (why) *why = u.why; return false; }
+  // ---- build (the hash-table pipeline of fused_join_groupby: sized from a strided sample of the count program, rebuilt once if the sample misjudged; duplicate keys -> chains)
+  auto exact_count = [&]() -> uint64_t { std::vector<uint64_t> host(kMaxAggs, 0); k::fused_regagg(cnt.shape, cnt.args, find_static_shape(cnt.shape), host.data()); return host[0]; };
+  uint64_t nb = 0;
+  bool sized_by_sample = false;
+  if (B->height > 0) {
+    if (B->height >= ((int64_t)1 << 24)) {
+      constexpr int kCountBlocks = 4;
+      const int64_t per = (int64_t)1 << 18, stride = (B->height / kCountBlocks) & ~(int64_t)127;
+      uint64_t hits = 0, seen = 0;
+      for (int b = 0; b < kCountBlocks; b++) {
+        const int64_t row0 = (int64_t)b * stride, rows_b = std::min<int64_t>(per, B->height - row0);
+        if (rows_b <= 0) continue;
+        std::vector<uint64_t> host(kMaxAggs, 0);
+        k::fused_regagg(cnt.shape, offset_args(cnt.shape, cnt.args, row0, rows_b), -1, host.data());
+        hits += host[0]; seen += (uint64_t)rows_b;
+      }
+      nb = (uint64_t)((double)hits / (double)std::max<uint64_t>(seen, 1) * (double)B->height * 1.25) + 4096;
+      sized_by_sample = true;
+    } else nb = exact_count();
+  }
+  Buf keys, flags, links;
+  JoinAggTable t{};
+  int log2_cap = 4;
+  uint64_t cap = 0;
+  bool multi = B->height > 0 && B->cols[bki]->repeats_as_build_key, resized = false;
+  for (int attempt = 0; attempt < 4; attempt++) {
+    if (multi && !links) links = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(B->height, 1));
+    log2_cap = std::max(8, ceil_log2_u64((uint64_t)((double)std::max<uint64_t>(nb, 1) * (sized_by_sample ? 1.6 : 2.0))));
+    cap = 1ull << log2_cap;
+    keys = dev_alloc(sizeof(uint64_t) * 2 * (cap + 1)); flags = dev_alloc_zero(32);
+    PLX_HIP(hipMemsetAsync(keys->ptr, 0xff, sizeof(uint64_t) * 2 * (cap + 1), stream()));
+    t.slots = keys->as<unsigned long long>(); t.flags = flags->as<unsigned int>(); t.acc = nullptr;
+    t.count = flags->as<unsigned long long>() + 1; t.log2_cap = (uint32_t)log2_cap;
+    t.links = multi ? links->as<unsigned long long>() : nullptr;
+    k::fused_join_build(cb.shape, cb.args, t, find_static_shape(cb.shape));
+    uint64_t fl64[2] = {0, 0};
+    d2h_sync(fl64, flags->ptr, 16);
+    const uint32_t dup = (uint32_t)fl64[0], ovf = (uint32_t)(fl64[0] >> 32);
+    if (dup && !multi) { B->cols[bki]->repeats_as_build_key = true; multi = true; continue; }      // build once more, chaining the rows of a key
+    if (!resized && (ovf || fl64[1] * 10 > cap * 7)) { nb = ovf ? exact_count() : fl64[1]; sized_by_sample = false; resized = true; continue; }      // the sample misjudged: once more, from the exact count
+    PLX_REQUIRE(!ovf, PLX_ERR_OOM, "join build: probe sequence overflow");
+    nb = fl64[1];
+    break;
+  }
+  // ---- candidates
+  ColumnPtr cand;
+  std::string cand_how;
+  const int pmode = partitioned_probe_mode();
+  if (!left_join && (pmode == 2 || (pmode == 1 && P->height >= ((int64_t)1 << 24) && (cap + 1) * 16 > ((uint64_t)64 << 20) && nb * 16 <= (uint64_t)P->height))) {
+    std::string pd;
+    if (k::partitioned_hash_probe_hits(cs.shape, cs.args, t, nb, find_static_shape(cs.shape), &cand, &pd)) cand_how = pd;
+    else cand = nullptr;
+  }
+  if (!cand && !ppreds.empty()) {
+    FramePtr none; std::string fwhy;
+    const size_t mark = plan.desc.size();
+    if (!fused_filter_frame(plan, ppreds, P, none, &fwhy, &cand, true)) { if (why) *why = "probe-side predicate: " + fwhy; return false; }
+    cand_how = "probe rows by " + plan.desc.substr(mark);
+    plan.desc.resize(mark);
+    while (!cand_how.empty() && (cand_how.back() == ' ' || cand_how.back() == ';')) cand_how.pop_back();
+  }
+  if (!cand && cand_how.empty()) cand_how = "every probe row";
+  // ---- pairs
+  ColumnPtr pidx, bidx;
+  std::string pd;
+  join::join_pairs(jn.how, P->cols[pki], cand, t, pidx, bidx, &pd);
+  // ---- payload: one multi-column gather per side
+  const ColumnPtr& lidx = build_right ? pidx : bidx;
+  const ColumnPtr& ridx = build_right ? bidx : pidx;
+  out = std::make_shared<Frame>();
+  out->height = pidx->len;
+  std::vector<int> pick[2];
+  std::vector<size_t> slot_of[2];
+  for (size_t i = 0; i < outs.size(); i++) {
+    if (want && !want->count(outs[i].name)) continue;
+    out->names.push_back(outs[i].name); out->cols.push_back(nullptr);
+    pick[outs[i].side].push_back(outs[i].idx); slot_of[outs[i].side].push_back(out->cols.size() - 1);
+  }
+  int n_gathered = 0;
+  for (int side = 0; side < 2; side++) {
+    const FramePtr& F = side == 0 ? L : R;
+    const ColumnPtr& idx = side == 0 ? lidx : ridx;
+    for (size_t b0 = 0; b0 < pick[side].size(); b0 += (size_t)k::kGatherMultiMax) {
+      std::vector<ColumnPtr> srcs;
+      for (size_t j = b0; j < std::min(pick[side].size(), b0 + (size_t)k::kGatherMultiMax); j++) srcs.push_back(F->cols[pick[side][j]]);
+      std::vector<ColumnPtr> got = ops::gather_columns(srcs, idx);
+      for (size_t j = 0; j < got.size(); j++) out->cols[slot_of[side][b0 + j]] = got[j];
+      n_gathered += (int)got.size();
+    }
+  }
+  PLX_HIP(hipStreamSynchronize(stream()));
+  plan.desc += std::string("FusedJoinFrame{") + (left_join ? "left" : "inner") + ", build=" + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " hash table cap=2^" +
+               std::to_string(log2_cap) + (multi ? " multi-value (row chains)" : " unique-keys") + ", probe rows=" + std::to_string(P->height) + ", candidates: " + cand_how + ", " + pd + ", gather x" +
+               std::to_string(n_gathered) + "}; ";
+  return true;
+}
+
 static FramePtr exec_join(Plan& plan, const IRN& n) {
+  if (!(plan.flags & PLX_PLAN_NO_FUSION)) {
+    FramePtr out; std::string why;
+    if (fused_join_frame(plan, n, nullptr, out, &why)) return out;
+    if (why != "small inputs") plan.desc += "(join not fused: " + why + ") ";
+  }
   FramePtr left = exec_node(plan, n.input);
   FramePtr right = exec_node(plan, n.input_right);
   PLX_REQUIRE(!n.keys.empty() && n.keys.size() == n.keys_right.size(), PLX_ERR_INVALID, "join: left_on / right_on length mismatch");
@@ -2194,6 +2459,14 @@ static FramePtr exec_node(Plan& plan, int node_id) {
     case PLX_IR_FILTER: return exec_filter(plan, n);
     case PLX_IR_HSTACK: return exec_select(plan, n, true);
     case PLX_IR_SELECT: {
+      if (fuse && n.input >= 0 && plan.ir[n.input].kind == PLX_IR_JOIN) {
+        // projection pushed into the join: only the columns the select reads are gathered at the pairs
+        std::set<std::string> want;
+        for (int e : n.exprs) collect_columns(plan, e, want);
+        FramePtr j; std::string why;
+        if (fused_join_frame(plan, plan.ir[n.input], &want, j, &why)) return exec_select(plan, n, false, j);
+        if (why != "small inputs") plan.desc += "(join not fused: " + why + ") ";
+      }
       if (fuse) {
         std::vector<int> preds;
         int src_node = peel_filters(plan, n.input, preds);
@@ -2243,6 +2516,25 @@ bool describe_join_fusion(Plan& plan, int root, std::vector<Shape>* shapes, std:
   const IRN& n = plan.ir.at(root);
   FramePtr out;
   return fused_join_groupby(plan, n, out, why_not, shapes, true);
+}
+
+bool describe_filter_fusion(Plan& plan, int root, Shape* shape, std::string* why_not) {
+  const IRN& n = plan.ir.at(root);
+  PLX_REQUIRE(n.kind == PLX_IR_FILTER, PLX_ERR_INVALID, "describe_filter_fusion: root is not a Filter");
+  std::vector<int> preds;
+  const int src_node = peel_filters(plan, n.input, preds);
+  preds.push_back(n.predicate);
+  PLX_REQUIRE(plan.ir[src_node].kind == PLX_IR_SCAN, PLX_ERR_UNSUPPORTED, "describe_filter_fusion: source must be a scan");
+  FramePtr src = get_frame(plan.ir[src_node].frame);
+  Compiler c(plan, *src);
+  try {
+    int p = -1;
+    for (int pe : preds) { int nn = c.lower(pe); if (c.nodes[nn].ty != 'b') throw Unsupported("predicate is not boolean"); p = p < 0 ? nn : c.mk(OP_AND, p, nn, 'b'); }
+    c.pred = p;
+    c.finish();
+  } catch (const Unsupported& u) { if (why_not) *why_not = u.why; return false; }
+  if (shape) *shape = c.shape;
+  return true;
 }
 
 bool describe_fusion(Plan& plan, int root, Shape* shape, int* static_id, std::string* why_not) {

@@ -65,6 +65,8 @@ bool dump_program_json(Plan& plan, int root, std::string* json, std::string* why
 // GroupBy directly over an inner Join: the three programs (count, build, probe) of the fused
 // join->aggregate pipeline, or false + reason when the per-node path would run.
 bool describe_join_fusion(Plan& plan, int root, std::vector<fused::Shape>* shapes, std::string* why_not);
+// root = a Filter node: the predicate program of the one-pass filter -> frame kernel (k::fused_filter); false + why_not when it does not compile
+bool describe_filter_fusion(Plan& plan, int root, fused::Shape* shape, std::string* why_not);
 
 }  // namespace engine
 }  // namespace plx

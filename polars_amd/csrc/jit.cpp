@@ -35,6 +35,7 @@ double g_ms = 0;
 const char* sink_type(Sink s) {
   static const char* n[] = {"RegAggSink", "LdsAggSink", "DenseAggSink", "HashAggSink", "WideAggSink", "JoinBuildSink", "ProbeAggSink", "DirectBuildSink", "DirectProbeAggSink", "BitmapBuildSink",
                             "part_count", "part_scatter", "part_agg", "part2_scatter_hash", "part2_scatter_direct", "part2_agg_hash", "part2_agg_direct", "part2_scatter_hash_t2", "part2_scatter_direct_t2"};
+  if (s == FILTER_COMPACT) return "filter_compact";
   if (s >= PART3_AGG) return "part3_agg";
   if (s >= PART3_SCATTER) return "part3_scatter";
   return n[s];
@@ -84,7 +85,7 @@ std::string source_for(const Shape& sh, Sink sink) {
   std::ostringstream o;
   const std::string sym = kernel_symbol(sh, sink);
   o << "#define plx_jit_kernel " << sym << "\n";
-  o << (sink >= PART3_SCATTER ? "#include \"partition3_device.hpp\"\n" : sink >= PART2_SCATTER_HASH ? "#include \"partition2_device.hpp\"\n" : sink >= PART_COUNT ? "#include \"partition_device.hpp\"\n" : "#include \"fused_sinks.hpp\"\n") << "namespace plx { namespace k {\n"
+  o << (sink == FILTER_COMPACT ? "#include \"fused_sinks.hpp\"\n" : sink >= PART3_SCATTER ? "#include \"partition3_device.hpp\"\n" : sink >= PART2_SCATTER_HASH ? "#include \"partition2_device.hpp\"\n" : sink >= PART_COUNT ? "#include \"partition_device.hpp\"\n" : "#include \"fused_sinks.hpp\"\n") << "namespace plx { namespace k {\n"
        "struct JitProg {\n  static constexpr bool kStatic = true; static constexpr int kId = -2;\n  static constexpr Shape shape() {\n    Shape s{};\n";
   o << "    s.n_inputs = " << (int)sh.n_inputs << "; s.n_ops = " << (int)sh.n_ops << "; s.n_aggs = " << (int)sh.n_aggs << "; s.pred = " << (int)sh.pred
     << "; s.key = " << (int)sh.key << "; s.n_keys = " << (int)sh.n_keys << ";\n";
@@ -116,6 +117,10 @@ std::string source_for(const Shape& sh, Sink sink) {
       o << "extern \"C\" __global__ __launch_bounds__(kP2AggBlock) void plx_jit_kernel(PartPlan2 pp, AggParams2 ap) {\n"
            "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout2 cl = rec_layout2(JitProg::shape(), " << (sink == PART2_AGG_DIRECT ? 1 : 0) << "u);\n"
            "  part2_agg_body<Shape, " << (sink == PART2_AGG_DIRECT ? 1 : 0) << ", p2_agg_chunks_in_flight(cl.rec_words)>(csh, cl, pp, ap);\n}\n}}\n";
+      break;
+    case FILTER_COMPACT:
+      o << "extern \"C\" __global__ __launch_bounds__(kBlock) void plx_jit_kernel(Shape dsh, Args args, FilterCompact fc) {\n"
+           "  fused_filter_body<JitProg>(dsh, args, fc);\n}\n}}\n";
       break;
     default:
       if (sink >= PART3_AGG) {

@@ -6,12 +6,17 @@
 #include <string>
 
 #include "core.hpp"
+#include "fused.hpp"
 
 namespace plx {
 namespace join {
 
 // (left_idx, right_idx) as PLX_U32 columns; LEFT join: right_idx nullable.
 void join_indices(int how, const ColumnPtr& left_key, const ColumnPtr& right_key, ColumnPtr& left_idx, ColumnPtr& right_idx, std::string* desc);
+
+// Pairs of an inner / left join from a build table the fused build scan filled (fused::JoinAggTable: unique keys, or chains of rows per key) over a candidate
+// list of probe rows (`cand`: PLX_U32, null = every row of probe_key).  Pair order = candidate order; a left join keeps every candidate (build_idx nullable).
+void join_pairs(int how, const ColumnPtr& probe_key, const ColumnPtr& cand, const fused::JoinAggTable& t, ColumnPtr& probe_idx, ColumnPtr& build_idx, std::string* desc);
 
 // HashPartitioner (polars-utils/src/hashing.rs:72-121): rows grouped by partition.
 void hash_partition(const ColumnPtr& key, int n_partitions, uint64_t seed, ColumnPtr& perm, int64_t* counts_out);

@@ -96,6 +96,8 @@ FilterPlan filter_prepare(const uint64_t* mask, int64_t n);  // synchronises (ne
 // width 1/2/4/8 bytes; width 0 compacts a bitmap (`values` = bits). out_validity may be null.
 void filter_apply(const FilterPlan& p, int width, const void* values, const uint64_t* validity, void* out_values,
                   uint64_t* out_validity);
+// kept row indices of a selection, ascending
+void filter_rowids(const FilterPlan& p, uint32_t* out);
 void gather(int width, const void* values, const uint64_t* validity, const uint32_t* idx, const uint64_t* idx_validity,
             int64_t n_idx, void* out, uint64_t* out_validity);
 constexpr int kGatherMultiMax = 8;

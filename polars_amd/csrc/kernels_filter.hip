@@ -136,6 +136,37 @@ void filter_apply(const FilterPlan& p, int width, const void* values, const uint
   PLX_HIP(hipGetLastError());
 }
 
+// the kept ROW INDICES of a selection (the probe-side index of a join whose candidates are all rows)
+__global__ __launch_bounds__(kBlock) void filter_rowids_kernel(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ tile_off, int64_t n, int64_t ntiles, uint32_t* __restrict__ out) {
+  const int lane = lane_id();
+  const int64_t nwords = (n + 63) >> 6;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    uint64_t mw = (lane < kTileWords) ? mask_word(mask, t * kTileWords + lane, nwords, n) : 0;
+    uint32_t pc = (uint32_t)popc64(mw), incl = pc;
+#pragma unroll
+    for (int s = 1; s < 32; s <<= 1) { uint32_t o = __shfl_up(incl, s, 64); if (lane >= s) incl += o; }
+    uint32_t excl = incl - pc;
+    const uint64_t base_out = tile_off[t];
+    if (__shfl(incl, 31, 64) == 0) continue;
+#pragma unroll 4
+    for (int j = 0; j < kTileWords; j++) {
+      const uint64_t m = shfl_u64(mw, j);
+      if (m == 0) continue;
+      const uint64_t o = base_out + (uint64_t)__shfl(excl, j, 64);
+      if ((m >> lane) & 1) out[o + prefix_rank(m)] = (uint32_t)((t * kTileWords + j) * 64 + lane);
+    }
+  }
+}
+void filter_rowids(const FilterPlan& p, uint32_t* out) {
+  if (p.n == 0 || p.n_out == 0) return;
+  const int64_t ntiles = (p.n + kTileRows - 1) / kTileRows;
+  ProfileScope ps("filter_rowids", (uint64_t)p.n / 8 + (uint64_t)p.n_out * 4, (uint64_t)p.n);
+  hipLaunchKernelGGL(filter_rowids_kernel, dim3(grid_for(ntiles, 4)), dim3(kBlock), 0, stream(), p.mask, p.tile_offsets->as<uint64_t>(), p.n, ntiles, out);
+  PLX_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------- gather ---
 template <class W, bool BITS>
 __global__ __launch_bounds__(kBlock) void gather_kernel(const W* __restrict__ values, const uint64_t* __restrict__ bits_values,

@@ -14,6 +14,7 @@
 // 64-bit key copy); floats are canonicalised (-0 -> +0, one NaN: total_ord.rs:40-48).
 // Null keys never match (nulls_equal = false).
 #include "dev.hpp"
+#include "fused.hpp"
 #include "join.hpp"
 #include "kernels.hpp"
 #include "ops.hpp"
@@ -204,6 +205,126 @@ void join_indices(int how, const ColumnPtr& left_key, const ColumnPtr& right_key
   }
   if (left_join || !swapped) { left_idx = pidx; right_idx = bidx; }
   else { left_idx = bidx; right_idx = pidx; }
+}
+
+// ------------------------------------------------ materialising join: pairs over a candidate list ---
+// The frame-returning join of the reference (polars-ops/src/frame/join/mod.rs:564-652 _inner_join_from_series: pairs from hash_join/single_keys_inner.rs:40-149,
+// then one gather per side) on the machinery of the fused join -> group-by: the build side is the fused::JoinAggTable its build scan fills (16-byte {key, row}
+// slots; duplicate build keys: chains through links[]), the probe side arrives as a CANDIDATE list -- the rows that passed the probe side's predicate and the
+// partitioned LDS filters of kernels_partition.hip (probe_hits_impl), a few per cent of the probe side for a selective build -- so the only random walk through
+// HBM is one slot lookup per candidate, once: pass 1 leaves the build row (or chain head) and the pair count of every candidate, the pairs are then laid out by a
+// device scan (duplicate keys / left joins) or by the selection-bitmap compaction of kernels_filter.hip (unique keys: 0 / 1 pairs per candidate) -- no second probe.
+struct PairTable { const unsigned long long* slots; const unsigned long long* links; uint32_t log2_cap; };
+__device__ __forceinline__ unsigned int pair_lookup(const PairTable& t, uint64_t key) {
+  const uint64_t cap = 1ull << t.log2_cap;
+  if (key == fused::kEmptyKey) return (unsigned int)t.slots[cap * 2 + 1];                   // the key equal to the EMPTY pattern lives in slot `cap` (row kNoRow when absent)
+  uint64_t slot = (key * fused::kP2HashMult) >> (64 - t.log2_cap);
+  for (uint64_t n = 0; n <= cap; n++) {
+    const unsigned long long cur = t.slots[slot * 2];
+    if (cur == key) return (unsigned int)t.slots[slot * 2 + 1];
+    if (cur == fused::kEmptyKey) return kNoRow;
+    slot = (slot + 1) & (cap - 1);
+  }
+  return kNoRow;
+}
+// head[i] = build row (multi-value: head of the chain) of candidate i or kNoRow; cnt[i] (may be null) = pairs it emits; mask (may be null) bit i = it has a match
+__global__ __launch_bounds__(kBlock) void join_match_kernel(KeyCol probe, const uint32_t* __restrict__ cand, int64_t n, PairTable t, int left_join, uint32_t* __restrict__ head,
+                                                            uint32_t* __restrict__ cnt, unsigned long long* __restrict__ mask) {
+  const int lane = lane_id();
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t base = wave * 64; base < n; base += nwaves * 64) {
+    const int64_t i = base + lane;
+    unsigned int h = kNoRow, c = 0;
+    if (i < n) {
+      const int64_t row = cand ? (int64_t)cand[i] : i;
+      if (key_valid(probe, row)) h = pair_lookup(t, load_key(probe, row));
+      if (h != kNoRow) {
+        c = 1;
+        if (t.links) { unsigned int r = (unsigned int)t.links[h]; for (uint32_t g = 0; r != kNoRow && g < (1u << 24); g++) { c++; r = (unsigned int)t.links[r]; } }
+      } else if (left_join) c = 1;
+      head[i] = h;
+      if (cnt) cnt[i] = c;
+    }
+    if (mask) { const uint64_t m = ballot(h != kNoRow); if (lane == 0) mask[base >> 6] = m; }
+  }
+}
+__global__ __launch_bounds__(kBlock) void join_pairs_emit_kernel(const uint32_t* __restrict__ cand, int64_t n, const unsigned long long* __restrict__ links, const uint32_t* __restrict__ head,
+                                                                 const uint64_t* __restrict__ off, uint32_t* __restrict__ out_probe, uint32_t* __restrict__ out_build) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t o = off[i];
+    const uint64_t end = off[i + 1];
+    if (o == end) continue;
+    const uint32_t row = cand ? cand[i] : (uint32_t)i;
+    unsigned int r = head[i];
+    if (r == kNoRow) { out_probe[o] = row; out_build[o] = kNoRow; continue; }               // left join: no match
+    for (; o < end && r != kNoRow; o++) { out_probe[o] = row; out_build[o] = r; r = links ? (unsigned int)links[r] : kNoRow; }
+  }
+}
+__global__ __launch_bounds__(kBlock) void iota_u32_kernel(uint32_t* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (uint32_t)i;
+}
+
+void join_pairs(int how, const ColumnPtr& probe_key, const ColumnPtr& cand, const fused::JoinAggTable& jt, ColumnPtr& probe_idx, ColumnPtr& build_idx, std::string* desc) {
+  PLX_REQUIRE(how == PLX_JOIN_INNER || how == PLX_JOIN_LEFT, PLX_ERR_UNSUPPORTED, "join_pairs: inner and left joins");
+  PLX_REQUIRE(probe_key->len < 0xffffffffll, PLX_ERR_UNSUPPORTED, "join side exceeds u32 IdxSize");
+  const bool left = how == PLX_JOIN_LEFT, multi = jt.links != nullptr;
+  const int64_t n = cand ? cand->len : probe_key->len;
+  auto mk_idx = [&](int64_t m) { auto c = std::make_shared<Column>(); c->dtype = PLX_U32; c->len = m; c->values = dev_alloc(values_bytes(PLX_U32, std::max<int64_t>(m, 1))); c->null_count = 0; return c; };
+  auto null_out_no_row = [&](ColumnPtr& bidx) {          // unmatched rows of a left join carry the kNoRow sentinel -> validity bitmap
+    if (!bidx->len) return;
+    plx_scalar s; s.u = kNoRow;
+    ColumnPtr ok = ops::cmp_scalar(PLX_NE, bidx, s);
+    bidx->validity = ok->values; bidx->null_count = -1;
+    if (column_null_count(bidx) == 0) { bidx->validity = nullptr; bidx->null_count = 0; }
+  };
+  if (n == 0) { probe_idx = mk_idx(0); build_idx = mk_idx(0); if (desc) *desc = "join_pairs[no candidates]"; return; }
+  PairTable t; t.slots = jt.slots; t.links = jt.links; t.log2_cap = jt.log2_cap;
+  const uint32_t* cp = cand ? cand->values->as<uint32_t>() : nullptr;
+  const int kw = dtype_width(probe_key->dtype) ? dtype_width(probe_key->dtype) : 1;
+  ColumnPtr head = mk_idx(n);
+  const bool counted = multi;                           // unique build keys: 0 / 1 pairs per candidate (left join: exactly 1), no scan
+  Buf cnt = counted ? dev_alloc(sizeof(uint32_t) * (size_t)n) : nullptr;
+  const int64_t nwords = (n + 63) >> 6;
+  Buf mask = (!counted && !left) ? dev_alloc(sizeof(uint64_t) * (size_t)nwords) : nullptr;
+  {
+    ProfileScope ps("join_match", (uint64_t)n * (kw + 16 + (cand ? 4 : 0) + 4), (uint64_t)n);
+    hipLaunchKernelGGL(join_match_kernel, dim3(k::grid_for(n, kBlock * 2)), dim3(kBlock), 0, stream(), key_col(probe_key), cp, n, t, left ? 1 : 0, head->values->as<uint32_t>(),
+                       cnt ? cnt->as<uint32_t>() : nullptr, mask ? mask->as<unsigned long long>() : nullptr);
+    PLX_HIP(hipGetLastError());
+  }
+  uint64_t total = 0;
+  if (!counted && left) {
+    // one pair per candidate: the candidate list IS the probe index, the heads are the build index
+    if (cand) probe_idx = cand;
+    else { probe_idx = mk_idx(n); hipLaunchKernelGGL(iota_u32_kernel, dim3(k::grid_for(n, kBlock * 4)), dim3(kBlock), 0, stream(), probe_idx->values->as<uint32_t>(), n); PLX_HIP(hipGetLastError()); }
+    build_idx = head;
+    null_out_no_row(build_idx);
+    total = (uint64_t)n;
+  } else if (!counted) {
+    const k::FilterPlan fp = k::filter_prepare(mask->as<uint64_t>(), n);
+    total = (uint64_t)fp.n_out;
+    probe_idx = mk_idx(fp.n_out); build_idx = mk_idx(fp.n_out);
+    if (cand) k::filter_apply(fp, 4, cp, nullptr, probe_idx->values->ptr, nullptr);
+    else k::filter_rowids(fp, probe_idx->values->as<uint32_t>());
+    k::filter_apply(fp, 4, head->values->ptr, nullptr, build_idx->values->ptr, nullptr);
+    PLX_HIP(hipStreamSynchronize(stream()));             // `mask` / the plan's offsets are read by the compactions
+  } else {
+    Buf off = dev_alloc(sizeof(uint64_t) * (size_t)(n + 1));
+    k::exclusive_scan_u32(cnt->as<uint32_t>(), off->as<uint64_t>(), n);
+    d2h_sync(&total, off->as<uint64_t>() + n, 8);
+    PLX_REQUIRE(total < 0xffffffffull, PLX_ERR_UNSUPPORTED, "join output exceeds u32 IdxSize");
+    probe_idx = mk_idx((int64_t)total); build_idx = mk_idx((int64_t)total);
+    if (total) {
+      ProfileScope ps("join_pairs_emit", (uint64_t)n * 24 + total * 8, (uint64_t)n);
+      hipLaunchKernelGGL(join_pairs_emit_kernel, dim3(k::grid_for(n, kBlock * 2)), dim3(kBlock), 0, stream(), cp, n, t.links, head->values->as<uint32_t>(), off->as<uint64_t>(),
+                         probe_idx->values->as<uint32_t>(), build_idx->values->as<uint32_t>());
+      PLX_HIP(hipGetLastError());
+    }
+    if (left) null_out_no_row(build_idx);
+    PLX_HIP(hipStreamSynchronize(stream()));
+  }
+  if (desc) *desc = std::string("join_pairs[") + (cand ? "candidates=" : "rows=") + std::to_string(n) + (multi ? ", multi-value chains" : ", unique build keys") + " -> match" +
+                    (counted ? "+scan+emit" : left ? "" : "+bitmap compaction") + ", pairs=" + std::to_string(total) + "]";
 }
 
 // -------------------------------------------------------------- partitioning ---

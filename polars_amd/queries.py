@@ -73,6 +73,14 @@ def q3(lineitem, orders, date=Q3_DATE, seg_mod=5):
             .agg((c("l_extendedprice") * (1 - c("l_discount"))).sum().alias("revenue")))
 
 
+def q3_join_frame(lineitem, orders, date=Q3_DATE, seg_mod=5):
+    """Q3's two filtered tables joined into a FRAME (no group-by above the join): the materialising hash join, five output columns."""
+    c = E.col
+    o = orders.filter((c("o_orderdate") < date) & ((c("o_custkey") % seg_mod) == 0))
+    li = lineitem.filter(c("l_shipdate") > date)
+    return li.join(o, left_on="l_orderkey", right_on="o_orderkey").select("l_orderkey", "o_orderdate", "o_shippriority", "l_extendedprice", "l_discount")
+
+
 def q3_partsupp(lineitem, partsupp, date=Q3_DATE, group=5):
     """A join whose BUILD side repeats its keys: lineitem[l_shipdate > date] JOIN partsupp[ps_group == group] ON partkey (dbgen's partsupp holds four rows per part;
     the shape of TPC-H Q9 / Q20's partsupp joins), grouped by (l_partkey, ps_suppkey) -- a group is a build row, every lineitem row of a part contributes to each of the

@@ -48,3 +48,10 @@ def test_selftest_reports_unfusable():
     t, _ = frames()
     with pytest.raises(pl.UnsupportedError):
         t.lazy().select(pl.col("a").sum(), pl.col("k")).jit_selftest()
+
+
+def test_filter_to_frame_kernel():
+    # Filter -> frame in one pass (fused_sinks.hpp fused_filter_body): predicate program + ordered compaction, specialised at run time
+    t, _ = frames()
+    q = t.lazy().filter((pl.col("a") > 5) & ((pl.col("k") % 3) == 1) | pl.col("x").is_null())
+    q.jit_selftest()
