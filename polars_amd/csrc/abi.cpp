@@ -886,7 +886,7 @@ int plx_jit_selftest(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int
   } else if (rn.kind == PLX_IR_FILTER) {
     fused::Shape sh{};
     PLX_REQUIRE(engine::describe_filter_fusion(p, root, &sh, &why), PLX_ERR_UNSUPPORTED, "not fusable: " + why);
-    jobs = {{sh, jit::FILTER_COMPACT}};
+    jobs = {{sh, jit::BALLOT}};
   } else {
     fused::Shape sh{}; int sid = -1;
     PLX_REQUIRE(engine::describe_fusion(p, root, &sh, &sid, &why), PLX_ERR_UNSUPPORTED, "not fusable: " + why);

@@ -667,7 +667,11 @@ static KeyPlan lower_keys(Compiler& c, const std::vector<int>& key_exprs) {
       }
       if (part.dtype == PLX_U64 || hopeless) all_packable = false;
       else if (cheap) {
-        if (col->values && ops::int_range(col, &info[i].mn, &info[i].mx, true)) info[i].have_range = true;
+        // bounds that are only GUESSED (assume_range, possibly by an earlier query: as a single key under a filter -- only the passing rows were checked -- or as a narrowed
+        // value column) may address ONE non-nullable key's table, where a wrong guess is reported; under a null code or packed next to other columns a value beyond them
+        // would merge groups silently.  There: exact statistics, unless the guess has been verified over every row since.
+        const bool may_assume = (nk == 1 && !info[i].nullable) || col->range_verified;
+        if (col->values && ops::int_range(col, &info[i].mn, &info[i].mx, may_assume)) info[i].have_range = true;
         else if (col->range_state == 1) { info[i].have_range = true; info[i].mn = col->range_min; info[i].mx = col->range_max; }
         else if (col->range_state == 2) { info[i].have_range = true; info[i].mn = 0; info[i].mx = 0; }
         else all_packable = false;
@@ -1825,7 +1829,8 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   int log2_cap = 4;
   uint64_t cap = 0;
   if (known_dups) { B->cols[bki]->repeats_as_build_key = true; if (!multi_ok) return no("build keys are not unique (and a build-side group column is not integer-typed)"); multi = true; }
-  for (int attempt = 0; attempt < 3; attempt++) {
+  bool resized = false;
+  for (int attempt = 0; attempt < 4; attempt++) {
     if (multi && !links) links = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(B->height, 1));
     // (the sampled count already carries 25 %: x1.6 keeps the load at or below ~0.6 without doubling a table that x2 would push over the next power of two)
     log2_cap = std::max(4, ceil_log2_u64((uint64_t)((double)std::max<uint64_t>(nb, 1) * (sized_by_sample ? 1.6 : 2.0))));
@@ -1847,9 +1852,9 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       multi = true;                                  // build once more, chaining the rows of a key (the table's size stays: it was planned for the rows, not the keys)
       continue;
     }
-    if (sized_by_sample && attempt == 0 && (ovf || fl64[1] * 10 > cap * 7)) {      // the sample misjudged: once more, from the exact count
+    if (!resized && (ovf || (sized_by_sample && fl64[1] * 10 > cap * 7))) {      // the sample misjudged (on whichever attempt: the multi-value rebuild keeps the sampled size): once more, from the exact count
       nb = ovf ? exact_count() : fl64[1];
-      sized_by_sample = false;
+      sized_by_sample = false; resized = true;
       continue;
     }
     PLX_REQUIRE(!ovf, PLX_ERR_OOM, "join build: probe sequence overflow");
@@ -1949,7 +1954,17 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     ca.args.lut[psemis.size()] = Lut{bits->as<unsigned long long>(), a_range};
     FusedAggResult ar;
     std::string ad;
-    run_fused_groupby(ca, akp, a_len_idx, ar, ad);
+    try {
+      run_fused_groupby(ca, akp, a_len_idx, ar, ad);
+    } catch (const Error& e) {
+      // a row outside bounds the planner had only ASSUMED for the probe key / value columns (lower_keys(ca) and source_ranges run outside fused_groupby's own handler): forget
+      // the guesses, never guess about these columns again, and run the whole join once more from exact statistics -- like fused_groupby does
+      bool guessed = false;
+      for (auto& col : ca.cols) if (col->range_assumed) { col->range_state = 0; col->range_trusted = true; col->range_assumed = false; col->range_verified = false; col->no_assume = true; std::atomic_store(&col->key_sample, std::shared_ptr<void>()); guessed = true; }
+      if (!guessed || e.code != PLX_ERR_INVALID) throw;
+      plan.desc += "AssumedBoundsViolated{exact statistics, second run}; ";
+      return fused_join_groupby(plan, gb, out, why, shapes_out, compile_only);
+    }
     plan.desc += "LeftJoinUnmatched{membership bitmap range=" + std::to_string(a_range) + ", " + akp.note + "FusedFilterGroupBy{" + ad + ", groups=" + std::to_string(ar.n_groups) + "}}; ";
     const int64_t U = ar.n_groups;
     auto tail = std::make_shared<Frame>();
@@ -1986,10 +2001,11 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
 // ----------------------------------------------------------------- executors ----
 static FramePtr exec_node(Plan& plan, int node_id);
 
-// [Filter]* over a materialised frame in ONE pass (k::fused_filter): the conjunction of the predicates compiled into a register program, the kept rows of every
-// fixed-width column written densely by the same kernel that evaluates it (inputs read once, outputs written once: SURVEY.md 8(d) a4's algorithmic bytes); validity
-// bitmaps and Boolean columns are compacted with the selection the kernel leaves behind (mask + per-tile offsets).  `want_rows`: also the kept row indices.
-// false: the predicate does not compile (f32 arithmetic, null literals...) -- the per-node path runs it.
+// [Filter]* over a materialised frame without FilterExec's intermediates (filter.rs:94-145: predicate column -> Boolean mask -> one filter call per column): the
+// conjunction of the predicates is compiled into a register program whose scan leaves only 16 bytes of ballots + a count per 128 rows (k::fused_ballots), a device
+// scan turns the counts into offsets, and ONE kernel then writes the kept rows of every fixed-width column densely and in order (k::compact_by_ballots); validity
+// bitmaps and Boolean columns go through the bitmap compaction of kernels_filter.hip with the same selection.  Traffic: predicate inputs once + payload once + output
+// once.  `want_rows`: also the kept row indices; rows_only: nothing else.  false: the predicate does not compile (f32 arithmetic, null literals...) -- per-node path.
 static bool fused_filter_frame(Plan& plan, const std::vector<int>& preds, const FramePtr& src, FramePtr& out, std::string* why, ColumnPtr* want_rows = nullptr, bool rows_only = false) {
   Compiler c(plan, *src);
   try {
@@ -2002,68 +2018,68 @@ static bool fused_filter_frame(Plan& plan, const std::vector<int>& preds, const 
   const int64_t n = src->height;
   out = std::make_shared<Frame>();
   out->names = src->names;
-  if (n == 0) { out->cols = src->cols; out->height = 0; if (want_rows) { auto e = std::make_shared<Column>(); e->dtype = PLX_U32; e->len = 0; e->null_count = 0; e->values = dev_alloc(8); *want_rows = e; } return true; }
+  auto empty_rows = [] { auto e = std::make_shared<Column>(); e->dtype = PLX_U32; e->len = 0; e->null_count = 0; e->values = dev_alloc(8); return e; };
+  if (n == 0) { out->cols = src->cols; out->height = 0; if (want_rows) *want_rows = empty_rows(); return true; }
   PLX_REQUIRE(n < 0xffffffffll || !want_rows, PLX_ERR_UNSUPPORTED, "filter: row indices beyond u32 IdxSize");
-  FilterCompact fc{};
-  std::vector<ColumnPtr> outs(src->cols.size());
-  std::vector<int> in_kernel;
-  if (!rows_only) {
+  const int64_t n_wt = (n + 127) / 128;
+  Buf ballots = dev_alloc(sizeof(uint64_t) * 2 * (size_t)n_wt), counts = dev_alloc(sizeof(uint32_t) * (size_t)n_wt);
+  BallotOut bo{ballots->as<unsigned long long>(), counts->as<unsigned int>()};
+  const int static_id = find_static_shape(c.shape);
+  k::fused_ballots(c.shape, c.args, bo, static_id);
+  const k::Selection sel = k::selection_finish(ballots, counts, n);
+  const int64_t m = sel.n_out;
+  out->height = m;
+  ColumnPtr rows;
+  if (want_rows) { rows = empty_rows(); rows->len = m; rows->values = dev_alloc(values_bytes(PLX_U32, std::max<int64_t>(m, 1))); *want_rows = rows; }
+  int n_moved = 0, n_bitmaps = 0;
+  std::vector<ColumnPtr> outs(rows_only ? 0 : src->cols.size());
+  if (m == n && !rows_only) { out->cols = src->cols; }                      // every row kept (filter/mod.rs:47-49)
+  else if (!rows_only) {
+    k::CompactCols cc{};
+    bool need_plan = false;
     for (size_t i = 0; i < src->cols.size(); i++) {
       const ColumnPtr& col = src->cols[i];
       auto o = std::make_shared<Column>();
-      o->dtype = col->dtype; o->values = nullptr;
-      outs[i] = o;
+      o->dtype = col->dtype; o->len = m;
       const int w = dtype_width(col->dtype);
-      if (col->dtype == PLX_BOOL || !(w == 1 || w == 2 || w == 4 || w == 8) || fc.n_cols >= kFilterMaxCols) continue;
-      o->values = dev_alloc(values_bytes(col->dtype, n));                  // sized for every row: the kept count is only known when the pass is over
-      fc.in[fc.n_cols] = col->data(); fc.out[fc.n_cols] = o->values->ptr; fc.width[fc.n_cols] = (uint8_t)w; fc.n_cols++;
-      in_kernel.push_back((int)i);
+      o->values = col->dtype == PLX_BOOL ? dev_alloc_zero(bitmap_bytes(m)) : dev_alloc(values_bytes(col->dtype, m));
+      if (col->validity) { o->validity = dev_alloc_zero(bitmap_bytes(m)); need_plan = true; } else o->null_count = 0;
+      if (col->dtype == PLX_BOOL || !(w == 1 || w == 2 || w == 4 || w == 8)) need_plan = true;
+      outs[i] = o;
     }
-  }
-  ColumnPtr rows;
-  if (want_rows) {
-    rows = std::make_shared<Column>();
-    rows->dtype = PLX_U32; rows->null_count = 0; rows->values = dev_alloc(values_bytes(PLX_U32, n));
-    fc.row_ids = rows->values->as<unsigned int>();
-  }
-  Buf mask;
-  const k::FilterPlan fp = k::fused_filter(c.shape, c.args, fc, &mask);
-  const int64_t m = fp.n_out;
-  out->height = m;
-  // an output that kept few rows gives its full-size buffer back (a copy of m rows: cheap exactly when it matters)
-  auto shrink = [&](const ColumnPtr& col) {
-    const size_t need = (size_t)values_bytes(col->dtype, m);
-    if (col->values && m * 4 < n && n >= ((int64_t)1 << 20)) {
-      Buf small = dev_alloc(std::max<size_t>(need, 8));
-      if (need) PLX_HIP(hipMemcpyAsync(small->ptr, col->values->ptr, need, hipMemcpyDeviceToDevice, stream()));
-      col->values = small;
-    }
-  };
-  if (want_rows) { rows->len = m; shrink(rows); *want_rows = rows; }
-  if (!rows_only) {
-    for (size_t i = 0; i < src->cols.size(); i++) {
-      const ColumnPtr& col = src->cols[i];
-      const ColumnPtr& o = outs[i];
-      o->len = m;
-      if (m == n) { outs[i] = col; continue; }                                   // every row kept (filter/mod.rs:47-49)
-      if (o->values) {
-        shrink(o);
-        if (col->validity) {
-          o->validity = dev_alloc_zero(bitmap_bytes(m));
-          k::filter_apply(fp, 0, col->valid_words(), nullptr, o->validity->ptr, nullptr);      // the validity bitmap compacted as a bitmap
-        } else o->null_count = 0;
-      } else {
-        o->values = col->dtype == PLX_BOOL ? dev_alloc_zero(bitmap_bytes(m)) : dev_alloc(values_bytes(col->dtype, m));
-        if (col->validity) o->validity = dev_alloc_zero(bitmap_bytes(m)); else o->null_count = 0;
-        k::filter_apply(fp, dtype_width(col->dtype), col->data(), col->valid_words(), o->values->ptr, o->validity ? o->validity->as<uint64_t>() : nullptr);
+    // fixed-width values: kCompactMaxCols columns per launch of the all-columns kernel
+    for (size_t i = 0; i < src->cols.size();) {
+      cc = k::CompactCols{};
+      for (; i < src->cols.size() && cc.n_cols < k::kCompactMaxCols; i++) {
+        const ColumnPtr& col = src->cols[i];
+        const int w = dtype_width(col->dtype);
+        if (col->dtype == PLX_BOOL || !(w == 1 || w == 2 || w == 4 || w == 8)) continue;
+        cc.in[cc.n_cols] = col->data(); cc.out[cc.n_cols] = outs[i]->values->ptr; cc.width[cc.n_cols] = (uint8_t)w; cc.n_cols++;
       }
+      if (cc.n_cols || (rows && !n_moved)) k::compact_by_ballots(sel, cc, rows && !n_moved ? rows->values->as<uint32_t>() : nullptr);
+      if (rows && !n_moved) rows = nullptr;
+      n_moved += cc.n_cols;
+    }
+    if (need_plan) {
+      Buf mask;
+      const k::FilterPlan fp = k::selection_to_plan(sel, &mask);
+      for (size_t i = 0; i < src->cols.size(); i++) {
+        const ColumnPtr& col = src->cols[i];
+        const int w = dtype_width(col->dtype);
+        if (col->dtype == PLX_BOOL || !(w == 1 || w == 2 || w == 4 || w == 8)) {
+          k::filter_apply(fp, w, col->data(), col->valid_words(), outs[i]->values->ptr, outs[i]->validity ? outs[i]->validity->as<uint64_t>() : nullptr);
+          n_bitmaps++;
+        } else if (col->validity) { k::filter_apply(fp, 0, col->valid_words(), nullptr, outs[i]->validity->ptr, nullptr); n_bitmaps++; }      // the validity bitmap compacted as a bitmap
+      }
+      PLX_HIP(hipStreamSynchronize(stream()));       // `mask` and the plan's offsets live until the compactions that read them are done
     }
     out->cols = outs;
   }
-  PLX_HIP(hipStreamSynchronize(stream()));       // `mask` and the plan's offsets live until the compactions that read them are done
-  plan.desc += "FusedFilter{fused_filter_compact[" + std::string(jit::program_mode(-1, n)) + "] one pass: predicate + ordered compaction of " + std::to_string(fc.n_cols) + " columns" +
-               (src->cols.size() > (size_t)fc.n_cols && !rows_only ? " (+" + std::to_string(src->cols.size() - (size_t)fc.n_cols) + " through the selection bitmap)" : "") +
-               (want_rows ? ", row ids" : "") + ", kept=" + std::to_string(m) + "/" + std::to_string(n) + "}; ";
+  if (rows) k::compact_by_ballots(sel, k::CompactCols{}, rows->values->as<uint32_t>());      // (row ids only)
+  PLX_HIP(hipStreamSynchronize(stream()));           // the selection's buffers live until the kernels that read them are done
+  plan.desc += "FusedFilter{fused_scan[" + std::string(jit::program_mode(static_id, n)) + "]+ballots -> scan -> " + (rows_only ? std::string("row ids") : "compaction of " + std::to_string(n_moved) +
+               " columns in one pass" + (n_bitmaps ? " (+" + std::to_string(n_bitmaps) + " bitmaps through the selection bitmap)" : "") + (want_rows ? ", row ids" : "")) +
+               ", kept=" + std::to_string(m) + "/" + std::to_string(n) + "}; ";
   return true;
 }
 

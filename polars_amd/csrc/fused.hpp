@@ -514,23 +514,11 @@ struct BitmapBuild {
   unsigned long long range;
 };
 
-// Filter -> frame in ONE pass (fused_sinks.hpp fused_filter_body): the predicate program is evaluated per 2048-row tile, the tile's exclusive output offset comes
-// from a chained scan over the tiles (tickets + decoupled look-back: a tile publishes its count at once and sums its predecessors' published counts back to the
-// last known prefix), and the kept rows of every payload column are written densely in row order -- inputs read once, outputs written once, no mask pass.
-// By-products: the selection bitmap and the per-tile offsets (a k::FilterPlan: columns the kernel does not move itself -- bitmaps -- go through filter_apply),
-// and optionally the kept row indices (the candidate list of a materialising join).
-constexpr int kFilterMaxCols = 12;
-constexpr int kFilterTileRows = 2048;          // = the tile of kernels_filter.hip (32 mask words)
-struct FilterCompact {
-  unsigned long long* mask;        // [ceil(n / 64)] bit i = row i kept (whole words of every tile are written)
-  unsigned long long* tile_off;    // [n_tiles + 1] kept rows before each tile; entry n_tiles = the total
-  unsigned long long* state;       // [n_tiles] look-back words (flag << 62 | count), zeroed
-  unsigned int* ticket;            // [0] next tile to hand out, [1] error flag (a look-back that did not resolve); zeroed
-  unsigned int* row_ids;           // kept row indices in row order, or null
-  int n_cols;
-  const void* in[kFilterMaxCols];  // plain fixed-width values
-  void* out[kFilterMaxCols];
-  uint8_t width[kFilterMaxCols];   // 1, 2, 4, 8 bytes
+// The selection of a filter -> frame as the predicate scan leaves it (fused_sinks.hpp BallotSink): per 128-row wave tile t the two ballots of its rows (lane l of the
+// wave holds rows 2l and 2l + 1: ballots[2t] = rows of even parity, ballots[2t + 1] = odd) and the number of kept rows.
+struct BallotOut {
+  unsigned long long* ballots;     // [n_wave_tiles][2]
+  unsigned int* counts;            // [n_wave_tiles]
 };
 
 // Direct-address aggregation (dense keys in [key_min, key_min + n_groups)): acc[(G+1)*n_aggs],

@@ -121,7 +121,8 @@ struct DenseAggSink {
       if (!pass[r]) continue;
       bool kvalid = (rf.getv(sh.key) >> r) & 1;
       int64_t g = kvalid ? ((int64_t)rf.get(r, sh.key) - p.key_min) : p.n_groups;
-      if ((uint64_t)g > (uint64_t)p.n_groups) { if (p.oob) *p.oob = 1u; continue; }   // see LdsAggSink: wrong declared / assumed bounds must not leave the table
+      // see LdsAggSink: wrong declared / assumed bounds must not leave the table -- nor may a VALID key land in the null key's cell (id == n_groups)
+      if ((uint64_t)g > (uint64_t)p.n_groups || (kvalid && g == p.n_groups)) { if (p.oob) *p.oob = 1u; continue; }
       atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)g * sh.n_aggs);
     }
   }
@@ -571,161 +572,27 @@ __global__ __launch_bounds__(kBlock) void fused_scan_kernel(Shape dsh, Args args
   fused_scan_body<P, Sink>(dsh, args, sp);
 }
 
-// ---- filter -> frame in one pass (FilterCompact, fused.hpp) ------------------------------------------------------------------
-// Replaces FilterExec's mask + per-column filter (polars-mem-engine/src/executors/filter.rs:94-145, polars-compute/src/filter/mod.rs:18-110): one workgroup
-// takes 2048-row tiles by ticket (so every tile with a smaller number is already running: the look-back below cannot wait for a workgroup that was never
-// scheduled), wave w evaluates the predicate over wave tiles 4w .. 4w + 3 of it, the tile's kept-row count is published and its exclusive offset summed from the
-// predecessors' published words (decoupled look-back: 64 predecessors per step, one 64-bit word {flag, count} per tile, agent-scope atomics -- the XCDs' L2s are
-// not coherent with each other), and the payload columns are then loaded (coalesced, all columns of a group in flight together) and their kept rows stored at
-// offset + rank (v_mbcnt over the ballots: ascending row order).
-__device__ __forceinline__ unsigned long long spread_bits32(unsigned int x) {     // bit i of x -> bit 2i
-  unsigned long long v = x;
-  v = (v | (v << 16)) & 0x0000ffff0000ffffull;
-  v = (v | (v << 8)) & 0x00ff00ff00ff00ffull;
-  v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0full;
-  v = (v | (v << 2)) & 0x3333333333333333ull;
-  v = (v | (v << 1)) & 0x5555555555555555ull;
-  return v;
-}
-// the two rows a lane owns of a fixed-width column (rows `row`, `row + 1`), as raw bits
-__device__ __forceinline__ void filter_load2(const void* p, int width, int64_t row, bool have0, bool have1, unsigned long long& a, unsigned long long& b) {
-  a = 0; b = 0;
-  if (have1) {       // both rows: one vector load
-    switch (width) {
-      case 8: { const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(static_cast<const unsigned long long*>(p) + row); a = v.x; b = v.y; break; }
-      case 4: { const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const unsigned int*>(p) + row); a = v.x; b = v.y; break; }
-      case 2: { const unsigned int v = *reinterpret_cast<const unsigned int*>(static_cast<const unsigned short*>(p) + row); a = v & 0xffffu; b = v >> 16; break; }
-      default: { const unsigned short v = *reinterpret_cast<const unsigned short*>(static_cast<const unsigned char*>(p) + row); a = v & 0xffu; b = v >> 8; break; }
-    }
-  } else if (have0) {
-    switch (width) {
-      case 8: a = static_cast<const unsigned long long*>(p)[row]; break;
-      case 4: a = static_cast<const unsigned int*>(p)[row]; break;
-      case 2: a = static_cast<const unsigned short*>(p)[row]; break;
-      default: a = static_cast<const unsigned char*>(p)[row]; break;
+// ---- sink: the selection of a filter -> frame, in ballot form (BallotOut, fused.hpp) ---------------------------------------------------
+// First half of FilterExec without its intermediates (polars-mem-engine/src/executors/filter.rs:94-145: predicate column -> mask -> per-column filter): the
+// predicate program runs inside the scan and what leaves it per 128-row wave tile is 16 bytes of ballots (lane l holds rows 2l, 2l + 1: one ballot per row
+// parity) and the tile's kept-row count.  A device scan over the counts gives every wave tile its output offset; k::compact_by_ballots (kernels_filter.hip) then
+// moves ALL payload columns in one pass -- loads coalesced and batched per column, ranks from v_mbcnt over the ballots, no atomics, no workgroup barriers.
+// (Round 6 first built this as ONE pass with a chained scan across 2048-row tiles -- tickets + decoupled look-back, agent-scope atomics.  Measured on the 1e9-row
+// frame: 6.5 ms with the look-back ablated, 19-22 ms with it -- half a million tiles polling a handful of hot lines across eight XCDs whose L2s are not coherent
+// with each other -- and a floor of 5.7 ms from the ticket counter alone.  Two passes move 8 GB more and need neither.)
+struct BallotSink {
+  using Params = BallotOut;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  template <class S, class RF> __device__ __forceinline__ void consume(const S&, const RF&, const bool pass[kRows], int64_t row0, const Params& p) {
+    const unsigned long long b0 = ballot(pass[0]), b1 = ballot(pass[1]);
+    if (lane_id() == 0) {
+      const int64_t t = row0 / kTileRows;                          // lane 0's first row is the wave tile's first row
+      *reinterpret_cast<ulonglong2*>(p.ballots + t * 2) = make_ulonglong2(b0, b1);
+      p.counts[t] = (unsigned int)(popc64(b0) + popc64(b1));
     }
   }
-}
-__device__ __forceinline__ void filter_store1(void* p, int width, unsigned long long pos, unsigned long long v) {
-  switch (width) {
-    case 8: static_cast<unsigned long long*>(p)[pos] = v; break;
-    case 4: static_cast<unsigned int*>(p)[pos] = (unsigned int)v; break;
-    case 2: static_cast<unsigned short*>(p)[pos] = (unsigned short)v; break;
-    default: static_cast<unsigned char*>(p)[pos] = (unsigned char)v; break;
-  }
-}
-template <class P>
-__device__ __forceinline__ void fused_filter_body(const Shape dsh, const Args args, const FilterCompact fc) {
-  constexpr int kWaves = kBlock / 64;
-  constexpr int U = kFilterTileRows / (kTileRows * kWaves);          // wave tiles per wave and tile (4)
-  constexpr int kGroup = 4;                                           // payload columns in flight together
-  constexpr unsigned long long kValMask = (1ull << 62) - 1ull;
-  __shared__ unsigned int s_tile;
-  __shared__ unsigned int s_wave_cnt[kWaves];
-  __shared__ unsigned long long s_excl;
-  typename RegFileOf<P>::type rf = make_regfile<P>(args);
-  const int lane = lane_id(), wave = threadIdx.x >> 6;
-  const int64_t n_tiles = (args.n_rows + kFilterTileRows - 1) / kFilterTileRows;
-  const unsigned long long lt = (1ull << lane) - 1ull;               // the lanes below this one
-  for (;;) {
-    if (threadIdx.x == 0) s_tile = atomicAdd(fc.ticket, 1u);
-    __syncthreads();
-    const int64_t s = (int64_t)s_tile;
-    if (s >= n_tiles) break;                                          // workgroup-uniform
-    unsigned long long b0[U], b1[U];
-    unsigned int cnt = 0;
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int64_t t = s * (kFilterTileRows / kTileRows) + (int64_t)wave * U + u;
-      bool pass[kRows] = {false, false};
-      int64_t row0 = 0;
-      if (t * kTileRows < args.n_rows) tile_rows<P>(dsh, args, t, rf, pass, row0);      // wave-uniform
-      b0[u] = ballot(pass[0]); b1[u] = ballot(pass[1]);
-      cnt += (unsigned int)(popc64(b0[u]) + popc64(b1[u]));
-      if (lane == 0 && fc.mask) {        // lane l holds rows 2l, 2l + 1: the ballots interleave into two mask words
-        fc.mask[t * 2] = spread_bits32((unsigned int)b0[u]) | (spread_bits32((unsigned int)b1[u]) << 1);
-        fc.mask[t * 2 + 1] = spread_bits32((unsigned int)(b0[u] >> 32)) | (spread_bits32((unsigned int)(b1[u] >> 32)) << 1);
-      }
-    }
-    if (lane == 0) s_wave_cnt[wave] = cnt;
-    __syncthreads();
-    unsigned int w_excl = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kWaves; w++) { const unsigned int c = s_wave_cnt[w]; if (w < wave) w_excl += c; total += c; }
-    if (wave == 0) {
-      unsigned long long excl = 0;
-      if (s > 0) {
-        if (lane == 0) __hip_atomic_store(&fc.state[s], (1ull << 62) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int64_t j = s - 1;
-        unsigned int spins = 0;
-        for (;;) {
-          const int64_t idx = j - lane;
-          const unsigned long long v = idx >= 0 ? __hip_atomic_load(&fc.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);     // before tile 0: prefix 0
-          if (ballot((v >> 62) == 0ull) != 0ull) {                    // a predecessor has not published yet
-            if (++spins > (1u << 24)) { if (lane == 0) fc.ticket[1] = 1u; break; }       // never hang the device: the host sees the flag and fails the query
-            __builtin_amdgcn_s_sleep(2);
-            continue;
-          }
-          const unsigned long long pm = ballot((v >> 62) == 2ull);
-          const int first = pm ? (int)__builtin_ctzll(pm) : 64;        // nearest predecessor whose inclusive prefix is known
-          excl += wave_sum_u64(lane <= first ? (v & kValMask) : 0ull);
-          if (pm) break;
-          j -= 64;
-        }
-      }
-      if (lane == 0) {
-        __hip_atomic_store(&fc.state[s], (2ull << 62) | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_excl = excl;
-        fc.tile_off[s] = excl;
-        if (s == n_tiles - 1) fc.tile_off[n_tiles] = excl + total;
-      }
-    }
-    __syncthreads();
-    if (total == 0) continue;                                         // workgroup-uniform: nothing kept in this tile
-    const unsigned long long base = s_excl + w_excl;
-    unsigned int off[U], run = 0;
-#pragma unroll
-    for (int u = 0; u < U; u++) { off[u] = run + (unsigned int)(popc64(b0[u] & lt) + popc64(b1[u] & lt)); run += (unsigned int)(popc64(b0[u]) + popc64(b1[u])); }
-    const int64_t wrow = (s * (kFilterTileRows / kTileRows) + (int64_t)wave * U) * kTileRows + (int64_t)lane * kRows;      // this lane's first row of wave tile 0
-    if (fc.row_ids) {
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int64_t row = wrow + (int64_t)u * kTileRows;
-        const unsigned int p0 = (unsigned int)(b0[u] >> lane) & 1u, p1 = (unsigned int)(b1[u] >> lane) & 1u;
-        if (p0) fc.row_ids[base + off[u]] = (unsigned int)row;
-        if (p1) fc.row_ids[base + off[u] + p0] = (unsigned int)(row + 1);
-      }
-    }
-    for (int c0 = 0; c0 < fc.n_cols; c0 += kGroup) {
-      unsigned long long va[kGroup][U], vb[kGroup][U];
-#pragma unroll
-      for (int cc = 0; cc < kGroup; cc++) {
-        if (c0 + cc < fc.n_cols) {
-#pragma unroll
-          for (int u = 0; u < U; u++) {
-            const int64_t row = wrow + (int64_t)u * kTileRows;
-            filter_load2(fc.in[c0 + cc], fc.width[c0 + cc], row, row < args.n_rows, row + 1 < args.n_rows, va[cc][u], vb[cc][u]);
-          }
-        }
-      }
-#pragma unroll
-      for (int cc = 0; cc < kGroup; cc++) {
-        if (c0 + cc < fc.n_cols) {
-#pragma unroll
-          for (int u = 0; u < U; u++) {
-            const unsigned int p0 = (unsigned int)(b0[u] >> lane) & 1u, p1 = (unsigned int)(b1[u] >> lane) & 1u;
-            if (p0) filter_store1(fc.out[c0 + cc], fc.width[c0 + cc], base + off[u], va[cc][u]);
-            if (p1) filter_store1(fc.out[c0 + cc], fc.width[c0 + cc], base + off[u] + p0, vb[cc][u]);
-          }
-        }
-      }
-    }
-  }
-}
-template <class P>
-__global__ __launch_bounds__(kBlock) void fused_filter_kernel(Shape dsh, Args args, FilterCompact fc) {
-  fused_filter_body<P>(dsh, args, fc);
-}
+};
 
 }  // namespace k
 }  // namespace plx

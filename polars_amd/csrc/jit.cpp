@@ -35,7 +35,7 @@ double g_ms = 0;
 const char* sink_type(Sink s) {
   static const char* n[] = {"RegAggSink", "LdsAggSink", "DenseAggSink", "HashAggSink", "WideAggSink", "JoinBuildSink", "ProbeAggSink", "DirectBuildSink", "DirectProbeAggSink", "BitmapBuildSink",
                             "part_count", "part_scatter", "part_agg", "part2_scatter_hash", "part2_scatter_direct", "part2_agg_hash", "part2_agg_direct", "part2_scatter_hash_t2", "part2_scatter_direct_t2"};
-  if (s == FILTER_COMPACT) return "filter_compact";
+  if (s == BALLOT) return "BallotSink";
   if (s >= PART3_AGG) return "part3_agg";
   if (s >= PART3_SCATTER) return "part3_scatter";
   return n[s];
@@ -65,8 +65,11 @@ std::string resource_include() {
   return "/opt/rocm/lib/llvm/lib/clang/22/include";
 }
 std::vector<std::string> compile_options() {
-  return {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wno-pass-failed", "-ffreestanding",
-          "-I" + include_dir(), "-I/opt/rocm/include", "-I" + resource_include()};
+  std::vector<std::string> o = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wno-pass-failed", "-ffreestanding",
+                                "-I" + include_dir(), "-I/opt/rocm/include", "-I" + resource_include()};
+  // measurement runs: extra -D options for the run-time compiled kernels (PLX_JIT_DEFINES="-DPLX_FILTER_GROUP=2 -DPLX_FILTER_EARLY=0"); part of the cache key
+  if (const char* e = getenv("PLX_JIT_DEFINES")) { std::istringstream is(e); std::string t; while (is >> t) if (t.compare(0, 2, "-D") == 0) o.push_back(t); }
+  return o;
 }
 
 uint64_t fnv1a(const std::string& s, uint64_t h = 0xcbf29ce484222325ull) { for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ull; } return h; }
@@ -85,7 +88,7 @@ std::string source_for(const Shape& sh, Sink sink) {
   std::ostringstream o;
   const std::string sym = kernel_symbol(sh, sink);
   o << "#define plx_jit_kernel " << sym << "\n";
-  o << (sink == FILTER_COMPACT ? "#include \"fused_sinks.hpp\"\n" : sink >= PART3_SCATTER ? "#include \"partition3_device.hpp\"\n" : sink >= PART2_SCATTER_HASH ? "#include \"partition2_device.hpp\"\n" : sink >= PART_COUNT ? "#include \"partition_device.hpp\"\n" : "#include \"fused_sinks.hpp\"\n") << "namespace plx { namespace k {\n"
+  o << (sink == BALLOT ? "#include \"fused_sinks.hpp\"\n" : sink >= PART3_SCATTER ? "#include \"partition3_device.hpp\"\n" : sink >= PART2_SCATTER_HASH ? "#include \"partition2_device.hpp\"\n" : sink >= PART_COUNT ? "#include \"partition_device.hpp\"\n" : "#include \"fused_sinks.hpp\"\n") << "namespace plx { namespace k {\n"
        "struct JitProg {\n  static constexpr bool kStatic = true; static constexpr int kId = -2;\n  static constexpr Shape shape() {\n    Shape s{};\n";
   o << "    s.n_inputs = " << (int)sh.n_inputs << "; s.n_ops = " << (int)sh.n_ops << "; s.n_aggs = " << (int)sh.n_aggs << "; s.pred = " << (int)sh.pred
     << "; s.key = " << (int)sh.key << "; s.n_keys = " << (int)sh.n_keys << ";\n";
@@ -118,19 +121,15 @@ std::string source_for(const Shape& sh, Sink sink) {
            "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout2 cl = rec_layout2(JitProg::shape(), " << (sink == PART2_AGG_DIRECT ? 1 : 0) << "u);\n"
            "  part2_agg_body<Shape, " << (sink == PART2_AGG_DIRECT ? 1 : 0) << ", p2_agg_chunks_in_flight(cl.rec_words)>(csh, cl, pp, ap);\n}\n}}\n";
       break;
-    case FILTER_COMPACT:
-      o << "extern \"C\" __global__ __launch_bounds__(kBlock) void plx_jit_kernel(Shape dsh, Args args, FilterCompact fc) {\n"
-           "  fused_filter_body<JitProg>(dsh, args, fc);\n}\n}}\n";
-      break;
     default:
-      if (sink >= PART3_AGG) {
+      if (sink >= PART3_AGG && sink != BALLOT) {
         const int v = (int)sink - (int)PART3_AGG, mode = v & 1, pack = v >> 1;
         o << "extern \"C\" __global__ __launch_bounds__(kP2AggBlock) void plx_jit_kernel(PartPlan2 pp, AggParams2 ap) {\n"
              "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout2 cl = rec_layout2(JitProg::shape(), " << mode << "u, " << pack << "u);\n"
              "  part2_agg_body<Shape, " << mode << ", p2_agg_chunks_in_flight(cl.rec_words)>(csh, cl, pp, ap);\n}\n}}\n";
         break;
       }
-      if (sink >= PART3_SCATTER) {
+      if (sink >= PART3_SCATTER && sink != BALLOT) {
         const int v = (int)sink - (int)PART3_SCATTER, mode = v & 1, tiles = 1 + ((v >> 1) & 3), pack = (v >> 3) & 3, hot = v >> 5;
         o << "extern \"C\" __global__ __launch_bounds__(kP2MaxBlock) void plx_jit_kernel(Shape dsh, Args args, PartPlan2 pp, ScatterParams2 sp) {\n"
              "  part3_scatter_body<JitProg, " << mode << ", " << tiles << ", " << pack << ", " << (hot ? "true" : "false") << ">(dsh, args, pp, sp);\n}\n}}\n";

@@ -26,9 +26,9 @@ enum Sink { REGAGG = 0, LDSAGG, DENSE, HASH, WIDE, JOIN_BUILD, PROBE_AGG, DIRECT
             // third generation scatter (partition3_device.hpp): PART3_SCATTER + mode + 2 * (tiles - 1) + 8 * pack (tiles 1..4, pack 0..3: 32 kinds), and the
             // aggregation pass over packed records: PART3_AGG + mode + 2 * pack (8 kinds)
             PART3_SCATTER, PART3_AGG = PART3_SCATTER + 64,     // scatter: ... + 32 * (hot-key path compiled in)
-            // filter -> frame in one pass (fused_sinks.hpp fused_filter_body; params = fused::FilterCompact).  New kinds go HERE, at the end: the number is part of
-            // the kernel symbols the tracers key their rows by
-            FILTER_COMPACT = PART3_AGG + 8,
+            // the selection of a filter -> frame in ballot form (fused_sinks.hpp BallotSink; a plain scan sink, launched with launch()).  New kinds go HERE, at the
+            // end: the number is part of the kernel symbols the tracers key their rows by
+            BALLOT = PART3_AGG + 8,
             kNumSinks };
 inline Sink part3_scatter_sink(uint32_t mode, uint32_t tiles, uint32_t pack, bool hot) { return (Sink)(PART3_SCATTER + mode + 2 * (tiles - 1) + 8 * pack + (hot ? 32 : 0)); }
 inline Sink part3_agg_sink(uint32_t mode, uint32_t pack) { return (Sink)(PART3_AGG + mode + 2 * pack); }

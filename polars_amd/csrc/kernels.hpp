@@ -96,6 +96,27 @@ FilterPlan filter_prepare(const uint64_t* mask, int64_t n);  // synchronises (ne
 // width 1/2/4/8 bytes; width 0 compacts a bitmap (`values` = bits). out_validity may be null.
 void filter_apply(const FilterPlan& p, int width, const void* values, const uint64_t* validity, void* out_values,
                   uint64_t* out_validity);
+// ---- filter -> frame (fused_sinks.hpp BallotSink -> compact_by_ballots) ----
+// The selection a predicate scan leaves behind: per 128-row wave tile two ballots (rows of even / odd parity: lane l of the scan holds rows 2l, 2l + 1) and, after
+// the scan over the tiles' counts, the number of kept rows before each tile.
+struct Selection {
+  int64_t n = 0, n_out = 0;
+  Buf ballots;     // [n_wave_tiles][2] u64
+  Buf offsets;     // [n_wave_tiles + 1] u64
+};
+constexpr int kCompactMaxCols = 12;
+struct CompactCols {
+  int n_cols;
+  const void* in[kCompactMaxCols];   // plain fixed-width values
+  void* out[kCompactMaxCols];        // each sized for Selection::n_out rows
+  uint8_t width[kCompactMaxCols];    // 1, 2, 4, 8
+  int n_w[4];                        // (filled by compact_by_ballots: columns per width class, widest first)
+};
+Selection selection_finish(Buf ballots, Buf counts, int64_t n);    // device scan of the counts; synchronises (n_out)
+// the kept rows of up to kCompactMaxCols columns, in row order, in ONE pass over the inputs (+ their row indices when row_ids is given)
+void compact_by_ballots(const Selection& sel, const CompactCols& cols, uint32_t* row_ids);
+// the same selection as an LSB-first bitmap + 2048-row tile offsets: what filter_apply / filter_rowids work from (*mask_keep owns the bitmap)
+FilterPlan selection_to_plan(const Selection& sel, Buf* mask_keep);
 // kept row indices of a selection, ascending
 void filter_rowids(const FilterPlan& p, uint32_t* out);
 void gather(int width, const void* values, const uint64_t* validity, const uint32_t* idx, const uint64_t* idx_validity,

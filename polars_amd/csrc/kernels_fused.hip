@@ -146,41 +146,14 @@ void fused_regagg(const Shape& sh, const Args& args, int static_id, uint64_t* ou
   d2h_sync(out_host, fin, (size_t)sh.n_aggs * 8);
 }
 
-// filter -> frame in one pass (fused_sinks.hpp fused_filter_body).  `fc`: payload columns (in / out / width / n_cols) and row_ids filled in by the caller, every
-// `out` buffer sized for args.n_rows rows; the scan state is allocated here.  Returns the selection as a FilterPlan (mask + per-tile offsets + kept rows:
-// columns the kernel did not move go through filter_apply) -- synchronises.
-FilterPlan fused_filter(const Shape& sh, const Args& args, FilterCompact fc, Buf* mask_keep) {
-  FilterPlan plan;
-  plan.n = args.n_rows;
-  if (args.n_rows == 0) return plan;
-  const int64_t n_tiles = (args.n_rows + kFilterTileRows - 1) / kFilterTileRows;
-  Buf mask = dev_alloc(sizeof(uint64_t) * (size_t)n_tiles * (kFilterTileRows / 64));
-  plan.tile_offsets = dev_alloc(sizeof(uint64_t) * (size_t)(n_tiles + 1));
-  Buf state = dev_alloc_zero(sizeof(uint64_t) * (size_t)n_tiles), ticket = dev_alloc_zero(16);
-  fc.mask = mask->as<unsigned long long>(); fc.tile_off = plan.tile_offsets->as<unsigned long long>();
-  fc.state = state->as<unsigned long long>(); fc.ticket = ticket->as<unsigned int>();
-  uint64_t bytes = algo_bytes(sh, args);
-  for (int c = 0; c < fc.n_cols; c++) bytes += (uint64_t)args.n_rows * fc.width[c];
-  {
-    ProfileScope ps(jit::program_mode(-1, args.n_rows)[0] == 'j' ? "fused_filter_compact[jit]" : "fused_filter_compact[generic]", bytes, (uint64_t)args.n_rows);
-    // persistent workgroups taking tiles by ticket: enough of them to fill the chip, never more than tiles
-    static const int bpc = [] { const char* e = getenv("PLX_BPC_FILTER"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? v : 6; }();
-    const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)device().cu_count * bpc);
-    if (!jit::launch(sh, args, jit::FILTER_COMPACT, &fc, grid, 0)) {
-      const DynLaunch d = dyn_launch(sh, args, 0);
-      hipLaunchKernelGGL((fused_filter_kernel<DynProg>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, fc);
-    }
-    PLX_HIP(hipGetLastError());
-  }
-  uint64_t total = 0;
-  uint32_t tk[2] = {0, 0};
-  d2h_sync(&total, plan.tile_offsets->as<uint64_t>() + n_tiles, 8);
-  d2h_sync(tk, ticket->ptr, 8);
-  PLX_REQUIRE(!tk[1], PLX_ERR_HIP, "fused filter: the chained scan over the tiles did not resolve");
-  plan.n_out = (int64_t)total;
-  plan.mask = mask->as<uint64_t>();
-  if (mask_keep) *mask_keep = mask;
-  return plan;
+// the predicate program of a filter -> frame: per 128-row wave tile the ballots of its rows and their count (fused_sinks.hpp BallotSink); `out` sized by the caller
+void fused_ballots(const Shape& sh, const Args& args, const BallotOut& out, int static_id) {
+  if (args.n_rows == 0) return;
+  ProfileScope ps(scope_name("fused_scan_ballots_static", jit::program_mode(-1, args.n_rows)[0] == 'j' ? "fused_scan_ballots[jit]" : "fused_scan_ballots[generic]", static_id).c_str(),
+                  algo_bytes(sh, args), (uint64_t)args.n_rows);
+  const int grid = scan_grid(args.n_rows, 5, "PLX_BPC_BALLOTS");
+  if (!jit::launch(sh, args, jit::BALLOT, &out, grid, 0)) { const DynLaunch d = dyn_launch(sh, args, 0); hipLaunchKernelGGL((fused_scan_kernel<DynProg, BallotSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, out); }
+  PLX_HIP(hipGetLastError());
 }
 
 int lds_agg_copies(int n_groups, int n_aggs) {

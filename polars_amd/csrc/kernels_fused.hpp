@@ -37,11 +37,9 @@ void canonicalise_chains(const fused::JoinAggTable& t, const fused::RepCols& rc,
 int64_t rows_agg_compact(const uint64_t* acc, int64_t n_rows, int n_aggs, int len_idx, uint32_t* out_rows, uint64_t* out_acc);
 // number of waves a fused scan over n_rows launches (sizes per-wave reservations)
 int64_t scan_waves(int64_t n_rows);
-// Filter -> frame in ONE pass (fused::FilterCompact): `sh` / `args` = the predicate program (pred only, no aggregates); fc carries the payload columns (n_cols,
-// in, out -- each sized for args.n_rows rows --, width) and optionally row_ids; the rest of fc is set up by the launcher.  Returns the selection (mask, per-tile
-// offsets, kept rows); *mask_keep owns the mask the plan points to.  Synchronises.
-struct FilterPlan;
-FilterPlan fused_filter(const fused::Shape& sh, const fused::Args& args, fused::FilterCompact fc, Buf* mask_keep);
+// filter -> frame, first half: `sh` / `args` = the predicate program (pred only, no aggregates) -> ballots + kept-row count per 128-row wave tile
+// (out.ballots [n_wave_tiles][2] u64, out.counts [n_wave_tiles] u32); kernels.hpp selection_finish / compact_by_ballots do the rest
+void fused_ballots(const fused::Shape& sh, const fused::Args& args, const fused::BallotOut& out, int static_id);
 // semi-join filter side -> membership bitmap (BitmapBuild)
 void fused_bitmap_build(const fused::Shape& sh, const fused::Args& args, const fused::BitmapBuild& t, int static_id);
 // direct-address variants (DirectJoinTable)

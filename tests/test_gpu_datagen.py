@@ -182,3 +182,69 @@ def test_bounds_assumed_from_a_sample_are_checked_per_row_and_a_wrong_guess_runs
     plan2 = pl.last_plan()
     assert "AssumedBoundsViolated{" not in plan2 and "bounds assumed" not in plan2, plan2
     assert out2 == out
+
+
+def test_guessed_bounds_never_pack_several_keys_or_sit_under_a_null_code(pl):
+    """Round-5 advisor finding: query 1 (single key under a FILTER) leaves guessed, unverified bounds on its key column -- the filter hid the outliers from the per-row
+    check.  Query 2 groups by (k1, k2): packed with the guess, an outlier of k1 would spill into k2's bits and merge groups silently.  lower_keys drops a guess that
+    nobody verified whenever the key is nullable or packed next to other columns (exact statistics instead)."""
+    rng = np.random.default_rng(31)
+    n = 17_000_000
+    k1 = rng.integers(0, 200_000, n).astype(np.int64)
+    k2 = rng.integers(0, 50, n).astype(np.int64)
+    v = rng.integers(0, 1000, n).astype(np.int64)
+    flag = np.ones(n, np.int64)
+    hole = _outside_the_sample(n)
+    k1[hole] = 3_000_000 + np.arange(len(hole))       # outliers where the sample does not look ...
+    flag[hole] = 0                                    # ... and that query 1's predicate filters out
+    df = pl.DataFrame({"k1": k1, "k2": k2, "v": v, "flag": flag})
+    c = pl.col
+    out1 = df.lazy().filter(c("flag") == 1).group_by("k1").agg(c("v").sum().alias("s")).collect()
+    plan1 = pl.last_plan()
+    assert "bounds assumed from the sample" in plan1 and "AssumedBoundsViolated{" not in plan1, plan1
+    assert out1.height == len(np.unique(k1[flag == 1]))
+    out2 = df.lazy().group_by("k1", "k2").agg(c("v").sum().alias("s"), pl.len().alias("n")).collect()
+    keys, inv = np.unique(k1 * 64 + k2, return_inverse=True)
+    got_k = np.array(out2["k1"].to_numpy(), np.int64) * 64 + np.array(out2["k2"].to_numpy(), np.int64)
+    order = np.argsort(got_k)
+    assert np.array_equal(got_k[order], keys), pl.last_plan()
+    sums = np.zeros(len(keys), np.int64); np.add.at(sums, inv, v)
+    assert np.array_equal(out2["s"].to_numpy()[order], sums) and np.array_equal(out2["n"].to_numpy()[order].astype(np.int64), np.bincount(inv))
+    # the same guess under a NULL code: a nullable view of the key column
+    valid = rng.random(n) > 0.01
+    dfn = pl.DataFrame([pl.Series("k1", k1, validity=valid), pl.Series("v", v)])
+    outn = dfn.lazy().group_by("k1").agg(c("v").sum().alias("s")).collect()
+    assert outn.height == len(np.unique(k1[valid])) + 1
+
+
+@pytest.mark.parametrize("dtype", ["Int64", "Int32", "UInt32"])
+@pytest.mark.parametrize("violate", ["key", "value"])
+def test_a_key_or_value_BELOW_the_assumed_minimum_is_caught(pl, dtype, violate):
+    """Round-5 review, weak 1(i): the guessed bounds were only tested from above.  A key below the assumed minimum wraps (key - kmin) around as an unsigned id -- far
+    outside the table, reported by the partition check; a value below the assumed minimum does not fit its narrowed field -- reported by the per-row source check."""
+    from polars_amd import queries
+    rng = np.random.default_rng(17)
+    n = 17_000_000
+    np_t = {"Int64": np.int64, "Int32": np.int32, "UInt32": np.uint32}[dtype]
+    base = 2_000_000                                    # the sampled minimum sits well above zero: a guess that starts at its own minimum, not at 0
+    ids = (base + rng.integers(0, 300_000, n)).astype(np_t)
+    v = (5_000_000 + rng.integers(0, 1000, n)).astype(np.int64)
+    hole = _outside_the_sample(n)
+    if violate == "key":
+        ids[hole] = np.arange(len(hole)).astype(np_t) + (0 if dtype == "UInt32" else 0)          # far below the sampled minimum
+        if dtype != "UInt32":
+            ids[hole[:2]] = np.array([-5, -70_000], dtype=np_t)                                    # and below zero for the signed dtypes
+    else:
+        v[hole] = -(1 << 35) - np.arange(len(hole))                                              # far below the sampled minimum of the narrowed value column
+    df = pl.DataFrame([pl.Series("key", ids), pl.Series("v", v)])
+    out = queries.cfg3(df.lazy()).collect().sort_host("key")
+    plan = pl.last_plan()
+    keys, inv = np.unique(ids.astype(np.int64), return_inverse=True)
+    assert np.array_equal(np.array(out["key"], dtype=np.int64), keys), plan
+    cols = [c for c in out if c != "key"]
+    sums = np.zeros(len(keys), np.int64); np.add.at(sums, inv, v)
+    got = [np.array(out[c], dtype=np.int64) for c in cols]
+    assert any(np.array_equal(g, sums) for g in got) and any(np.array_equal(g, np.bincount(inv)) for g in got), plan
+    # (whether the planner guessed at all depends on the dtype -- narrow keys get exact statistics cheaply; when it did, the violation must have been noticed)
+    if "bounds assumed from the sample" in plan or "AssumedBoundsViolated{" in plan:
+        assert "AssumedBoundsViolated{" in plan, plan
