@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="q1", choices=["q1", "q3", "q3f", "q3h", "q3d", "joinm", "filterm", "gather", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s"])
+    ap.add_argument("--workload", default="q1", choices=["q1", "q3", "q3f", "q3h", "q3d", "q3dc", "joinm", "filterm", "gather", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the SF100 / 1e9-row size of the workload)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -454,6 +454,68 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
                        variants={"tpch_q3_sf100_order_by_limit10": step_top10}, verify=verify, scope="operator")
         wl3.inputs = [L, O]
         return wl3
+    if name == "q3dc":
+        # A join -> group-by whose AGGREGATE reads a build-side column (round-5 review, missing 2): the duplicate-key join's tables with a supplier cost on the build side,
+        # group_by(partkey, suppkey).agg(sum(l_extendedprice * ps_supplycost), len) -- the in-place form cannot evaluate it (its cells are fed by the probe scan alone);
+        # the pair form joins (probe row, build row) pairs, gathers the two referenced columns per side at them and runs the fused group-by over the joined columns.
+        nl = rows or SF100_LINEITEM
+        nb = max(nl * 2 // 15, 1000)
+        n_parts = max(nb // 4, 100)
+        lo_d, hi_d, date = datagen.us(1992, 1, 2), datagen.us(1998, 12, 1), datagen.us(1995, 3, 15)
+        L = pl.DataFrame([native_uniform_column(pl, "l_partkey", pl.Int64, "Int64", nl, seed, 0, 0, n_parts),
+                          native_uniform_column(pl, "l_extendedprice", pl.Float64, "Float64", nl, seed, 1, 90_000, 10_500_000, 0.01),
+                          native_uniform_column(pl, "l_shipdate", pl.Datetime, "Int64", nl, seed, 3, lo_d, hi_d)])
+        PS = pl.DataFrame([native_uniform_column(pl, "ps_partkey", pl.Int64, "Int64", nb, seed + 1000, 0, 0, n_parts),
+                           native_uniform_column(pl, "ps_suppkey", pl.Int64, "Int64", nb, seed + 1000, 1, 0, 1_000_000),
+                           native_uniform_column(pl, "ps_supplycost", pl.Float64, "Float64", nb, seed + 1000, 2, 100, 100_000, 0.01)])
+        PS = PS.with_columns((pl.col("ps_partkey") % 32).alias("ps_group"))
+        PS = pl.DataFrame([PS["ps_partkey"], PS["ps_suppkey"], PS["ps_supplycost"], PS["ps_group"]])
+        pl._ffi.check(pl._ffi.lib().plx_synchronize())
+        c_ = pl.col
+        lfc = (L.lazy().filter(c_("l_shipdate") > date).join(PS.lazy().filter(c_("ps_group") == 5), left_on="l_partkey", right_on="ps_partkey")
+               .group_by("l_partkey", "ps_suppkey").agg((c_("l_extendedprice") * c_("ps_supplycost")).sum().alias("cost"), pl.len().alias("n")))
+
+        def step_c():
+            return lfc.collect(), (L, PS)
+
+        def verify_c(res, budget):
+            from oracle import pyoracle as orc
+            t0 = time.perf_counter()
+            S, Cn = np.zeros(n_parts, np.float64), np.zeros(n_parts, np.int64)
+            done = 0
+            while done < nl and time.perf_counter() - t0 < budget:
+                m = min(100_000_000, nl - done)
+                k = datagen.uniform_native_host_mt("Int64", done, m, seed, 0, 0, n_parts)
+                keep = (datagen.uniform_native_host_mt("Int64", done, m, seed, 3, lo_d, hi_d) > date) & (k % 32 == 5)
+                orc.groupby_dense_partial(np.ascontiguousarray(k[keep]), np.ascontiguousarray(datagen.uniform_native_host_mt("Float64", done, m, seed, 1, 90_000, 10_500_000, 0.01)[keep]), S, Cn)
+                done += m
+            if done < nl:
+                return {"rows": done, "ok": None, "note": "host check ran out of its time budget before covering the input"}
+            bk = datagen.uniform_native_host_mt("Int64", 0, nb, seed + 1000, 0, 0, n_parts)
+            bs = datagen.uniform_native_host_mt("Int64", 0, nb, seed + 1000, 1, 0, 1_000_000)
+            bc = datagen.uniform_native_host_mt("Float64", 0, nb, seed + 1000, 2, 100, 100_000, 0.01)
+            keep = (bk % 32 == 5)
+            bk, bs, bc = bk[keep], bs[keep], bc[keep]
+            pairs, inv, mult = np.unique(bk * 1_000_000 + bs, return_inverse=True, return_counts=True)
+            csum = np.bincount(inv, weights=bc, minlength=len(pairs))           # the costs of the build rows that are ONE (partkey, suppkey) group
+            pk = pairs // 1_000_000
+            live = Cn[pk] > 0
+            pairs, mult, pk, csum = pairs[live], mult[live], pk[live], csum[live]
+            gk = res["l_partkey"].to_numpy().astype(np.int64) * 1_000_000 + res["ps_suppkey"].to_numpy().astype(np.int64)
+            order = np.argsort(gk, kind="stable")
+            ok = bool(np.array_equal(gk[order], pairs))
+            err = 0.0
+            if ok:
+                ok = bool(np.array_equal(res["n"].to_numpy().astype(np.int64)[order], mult * Cn[pk]))
+                err = _rel_err(res["cost"].to_numpy()[order], csum * S[pk])
+                ok = ok and err <= VERIFY_RTOL
+            return {"rows": nl + nb, "against": "host twin of both tables: per-part sum of l_extendedprice over the filtered probe side (oracle streaming group-by) times the summed "
+                    "ps_supplycost of every (partkey, suppkey) build group", "ok": ok, "max_rel_err": err, "rtol": VERIFY_RTOL, "groups": int(len(pairs))}
+        wlc = Workload("join_aggregate_reads_build_side_sf100", nl + nb, nl * 24 + nb * 32, step_c, "probe_scatter",
+                       f"lineitem-shaped probe side ({nl} rows) JOIN partsupp-shaped build side ({nb} rows, duplicate keys), filter both, "
+                       "group_by(partkey, suppkey).agg(sum(l_extendedprice * ps_supplycost), len): the aggregate reads a BUILD-side column (pair form)", verify=verify_c, scope="operator")
+        wlc.inputs = [L, PS]
+        return wlc
     if name == "joinm":
         # The MATERIALISING join (round-5 review, item 1): TPC-H Q3's two filtered tables joined into a FRAME -- no group-by above the join -- five output columns
         # (the reference: JoinExec -> _inner_join_from_series, crates/polars-ops/src/frame/join/mod.rs:564-652: pairs, then gathers).  Same rows as tpch_q3_sf100.
@@ -2019,7 +2081,7 @@ def compare_q1_dicts(a: dict, b: dict) -> bool:
 
 MULTI_EXTRAS = ("q3", "q3:shuffle", "cfg3", "cfg5", "q1", "q1:weak")     # ":weak" = the per-rank SF100 shard (weak scaling), labelled so in its config.workload
 LATE_WORKLOADS = ("filterm", "gather")       # frame-returning operators with multi-gigabyte results: timed and checked last, one at a time
-EXTRA_WORKLOADS = ("q3", "q3h", "q3d", "joinm", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "q1")      # the secondary workloads of the N = 1 line, in this order
+EXTRA_WORKLOADS = ("q3", "q3h", "q3d", "q3dc", "joinm", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "q1")      # the secondary workloads of the N = 1 line, in this order
 
 
 def run_multi(args, emit):

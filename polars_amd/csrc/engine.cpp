@@ -1011,6 +1011,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
         if (d >= 0) est2 = std::min(est, std::min(g_est, (double)n) * 1.3);
         desc += "sample(distinct=" + std::to_string(d) + ",hot=" + std::to_string(hot.size()) + ")+";
       }
+      if (c.plan.group_hint > 0) { est2 = std::min(est, c.plan.group_hint * 1.02 + 64.0); desc += "groups<=" + std::to_string((int64_t)c.plan.group_hint) + "(plan)+"; }
       PartPlan2 p2;
       k::SrcRange ranges[kMaxSrc];
       source_ranges(c, ranges);
@@ -1070,6 +1071,8 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
                                    : run_hash_agg(sh, sa, static_id, 23, len_idx, tmp, true));
     double G = d < 0 ? 1e18 : (g_est >= 0.0 ? g_est : estimate_groups((double)d, (double)Sd));
     G = std::min(G, (double)n);
+    const bool hinted = c.plan.group_hint > 0;
+    if (hinted) { G = std::min(c.plan.group_hint, (double)n); desc += "groups<=" + std::to_string((int64_t)c.plan.group_hint) + "(plan)+"; }
     log2_cap = std::max(12, ceil_log2_u64((uint64_t)(G * 2.0) + 1));
     desc += "sample(distinct=" + std::to_string(d) + "/" + std::to_string(Sd) + ")+";
     // many rows, many groups: per-row global atomics are bound by the ~24 G/s device atomic rate; partition the
@@ -1079,7 +1082,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
     if (kp.wide && may_partition && part_version() == 2 && G >= 4096.0) {
       k::SrcRange ranges[kMaxSrc];
       source_ranges(c, ranges);
-      double plan_for = G * 1.3;
+      double plan_for = hinted ? G * 1.02 + 64.0 : G * 1.3;
       for (int attempt = 0; attempt < 3; attempt++) {
         PartPlan2 p2;
         if (!k::partition_plan2(sh, plan_for, -1, len_idx, n, 0, &p2, ranges)) break;
@@ -1119,7 +1122,7 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
         // undercounts badly (zipf 1.1 over 1e6 keys: 1.5e5 distinct keys in 2^20 sampled rows, 1e6 in 1e9 rows): with skew the tables are planned for 4 x the
         // estimate.  A table that fills up anyway is reported by the aggregation pass; the plan is then doubled (more partitions) and the pass repeated -- never
         // the per-row HBM-table path, which a skewed input turns into seconds of same-address atomics.
-        double plan_for = (!hot.empty() && G < 1e17) ? G * 4.0 : G * 1.3;
+        double plan_for = hinted ? G * 1.02 + 64.0 : (!hot.empty() && G < 1e17) ? G * 4.0 : G * 1.3;      // (a bound from the plan is not an estimate: no safety factor)
         for (int attempt = 0; attempt < 3; attempt++) {
           PartPlan2 p2;
           if (!k::partition_plan2(sh, plan_for, -1, len_idx, n, (int)hot.size(), &p2, ranges)) {
@@ -1392,6 +1395,7 @@ static bool fused_groupby(Plan& plan, const IRN& node, const std::vector<int>& p
 }
 
 
+static int peel_filters_node(const Plan& plan, int input) { while (plan.ir[input].kind == PLX_IR_FILTER) input = plan.ir[input].input; return input; }
 // peel [Filter]* below an aggregation node
 static int peel_filters(const Plan& plan, int input, std::vector<int>& preds) {
   while (plan.ir[input].kind == PLX_IR_FILTER) { preds.push_back(plan.ir[input].predicate); input = plan.ir[input].input; }
@@ -2172,7 +2176,7 @@ static FramePtr exec_groupby_materialised(Plan& plan, const IRN& n, const FrameP
 // row-id compaction (k::fused_filter); join::join_pairs then looks every CANDIDATE up once and lays the (probe row, build row) pairs out, and the payload columns
 // `want` names (null: all) are gathered at them, several columns per launch.  PLX_JOIN_MATERIALISE: 0 = never, 2 = any size (tests), default from 2^24 probe rows.
 static int join_materialise_mode() { const char* e = getenv("PLX_JOIN_MATERIALISE"); return e && e[0] == '0' ? 0 : e && e[0] == '2' ? 2 : 1; }
-static bool fused_join_frame(Plan& plan, const IRN& jn, const std::set<std::string>* want, FramePtr& out, std::string* why) {
+static bool fused_join_frame(Plan& plan, const IRN& jn, const std::set<std::string>* want, FramePtr& out, std::string* why, uint64_t* build_rows_out = nullptr, int* build_side_out = nullptr) {
   auto no = [&](const char* m) { if (why) *why = m; return false; };
   const int mode = join_materialise_mode();
   if (mode == 0) return no("disabled (PLX_JOIN_MATERIALISE=0)");
@@ -2279,6 +2283,8 @@ static bool fused_join_frame(Plan& plan, const IRN& jn, const std::set<std::stri
     nb = fl64[1];
     break;
   }
+  if (build_rows_out) *build_rows_out = nb;
+  if (build_side_out) *build_side_out = build_right ? 1 : 0;
   // ---- candidates
   ColumnPtr cand;
   std::string cand_how;
@@ -2502,7 +2508,46 @@ static FramePtr exec_node(Plan& plan, int node_id) {
       if (fuse && n.input >= 0 && plan.ir[n.input].kind == PLX_IR_JOIN) {
         FramePtr out; std::string why;
         if (fused_join_groupby(plan, n, out, &why)) return out;
-        plan.desc += "(join+group_by not fused: " + why + ") ";
+        // The in-place form needs a group to be a build row and the aggregates to read the probe side.  Anything else -- aggregates over build-side columns
+        // (sum(l_quantity * ps_supplycost)), group keys without the join key or from the probe side -- takes the PAIR form: the fused join -> frame pipeline
+        // restricted to the columns the group-by reads (filters fused into build scan and candidate selection, pairs, one gather per side), then the ordinary fused
+        // group-by over those joined columns.  The reference has no such restriction either (JoinExec -> GroupByExec, executors/join.rs:41-121, group_by.rs:60-98).
+        std::set<std::string> want;
+        for (int e : n.keys) collect_columns(plan, e, want);
+        for (int e : n.exprs) collect_columns(plan, e, want);
+        const size_t mark = plan.desc.size();
+        FramePtr joined; std::string why2;
+        uint64_t build_rows = 0;
+        int build_side = 0;
+        if (fused_join_frame(plan, plan.ir[n.input], &want, joined, &why2, &build_rows, &build_side)) {
+          std::vector<int> no_preds;
+          std::string why3;
+          const std::string jd = plan.desc.substr(mark);
+          plan.desc.resize(mark);
+          const size_t mark2 = plan.desc.size();
+          // group keys that are all functions of the build row (the join key or plain build-side columns): at most one group per surviving build row
+          {
+            const IRN& jn = plan.ir[n.input];
+            FramePtr bf = exec_node(plan, peel_filters_node(plan, build_side ? jn.input_right : jn.input));
+            bool of_build = !n.keys.empty();
+            for (int e : n.keys) {
+              const AE* x = &plan.ae[e];
+              while (x->kind == PLX_AE_ALIAS) x = &plan.ae[x->lhs];
+              const AE* lk = &plan.ae[jn.keys[0]];
+              while (lk->kind == PLX_AE_ALIAS) lk = &plan.ae[lk->lhs];
+              of_build = of_build && x->kind == PLX_AE_COLUMN && (x->name == lk->name || bf->find(x->name) >= 0 || (x->name.size() > jn.suffix.size() && bf->find(x->name.substr(0, x->name.size() - jn.suffix.size())) >= 0));
+            }
+            plan.group_hint = of_build ? (double)std::max<uint64_t>(build_rows, 1) : 0.0;
+          }
+          const bool gb_fused = fused_groupby(plan, n, no_preds, joined, out, nullptr, nullptr, &why3, false);
+          plan.group_hint = 0;
+          if (!gb_fused) out = exec_groupby_materialised(plan, n, joined);
+          const std::string gd = plan.desc.substr(mark2);
+          plan.desc.resize(mark2);
+          plan.desc += "FusedJoinGroupBy{pair form (in-place form: " + why + "): " + jd + "then " + gd + "}; ";
+          return out;
+        }
+        plan.desc += "(join+group_by not fused: " + why + (why2 == "small inputs" ? "" : "; pair form: " + why2) + ") ";
       }
       if (fuse) {
         std::vector<int> preds;

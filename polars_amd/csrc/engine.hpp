@@ -41,6 +41,11 @@ struct Plan {
   uint32_t flags = 0;
   std::string desc;  // physical plan description (which kernels / pipelines ran)
   std::map<int, FramePtr> memo;  // subtrees already executed for a fusion attempt that then fell back: the per-node path reuses them
+  // An upper bound on the number of groups of the group-by about to run that the PLAN knows (0: none): the pair form of a join -> group-by whose keys are functions of the
+  // build row has at most as many groups as build rows survive the build side's predicate.  It replaces the planner's sampled estimate -- the joined rows arrive clustered by
+  // key hash, and a strided sample of clustered rows undercounts by orders of magnitude (2.5e6 groups estimated as 3e4: LDS tables overflow, the fall-back is the per-row
+  // HBM table at a fiftieth of the speed).
+  double group_hint = 0;
 };
 
 Plan import_plan(const plx_ir* ir, int n_ir, const plx_aexpr* ae, int n_ae, uint32_t flags);
