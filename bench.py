@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="q1", choices=["q1", "q3", "q3f", "q3h", "q3d", "q3dc", "joinm", "filterm", "gather", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s"])
+    ap.add_argument("--workload", default="q1", choices=["q1", "q1j", "q3", "q3f", "q3h", "q3d", "q3dc", "joinm", "filterm", "gather", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the SF100 / 1e9-row size of the workload)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -454,6 +454,79 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
                        variants={"tpch_q3_sf100_order_by_limit10": step_top10}, verify=verify, scope="operator")
         wl3.inputs = [L, O]
         return wl3
+    if name == "q1j":
+        # A shape WITHOUT an ahead-of-time kernel (round-5 review, weak 7 / item 8): TPC-H Q1 with a second predicate and a ninth and tenth aggregate -- not in
+        # fused_shapes.hpp, so the scan is specialised at run time (hiprtc; the kernel's symbol is plx_jit_LdsAggSink_1_<hash>) exactly like any query a drop-in
+        # executor meets first.  cold_first_step_ms includes the compilation when the disk cache does not hold it (a fresh box: always); `jit` reports what was compiled.
+        n = rows or SF100_LINEITEM
+        dfj = datagen.lineitem_native(pl, n, seed)
+        check_native_lineitem(pl, dfj, n, seed)
+        c_ = pl.col
+        cutoff = datagen.us(1998, 9, 2)
+        disc_price = c_("l_extendedprice") * (1 - c_("l_discount"))
+        lfj = (dfj.lazy().filter((c_("l_shipdate") <= cutoff) & (c_("l_quantity") < 45)).group_by("l_returnflag", "l_linestatus")
+               .agg(c_("l_quantity").sum().alias("sum_qty"), c_("l_extendedprice").sum().alias("sum_base_price"), disc_price.sum().alias("sum_disc_price"),
+                    (disc_price * (1 + c_("l_tax"))).sum().alias("sum_charge"), c_("l_quantity").mean().alias("avg_qty"), c_("l_extendedprice").mean().alias("avg_price"),
+                    c_("l_discount").mean().alias("avg_disc"), pl.len().alias("count_order"), c_("l_tax").max().alias("max_tax"), c_("l_extendedprice").min().alias("min_price")))
+        jit0 = jit_stats(pl)
+
+        def step_j():
+            out = lfj.collect()
+            return out.to_dict(), (dfj,)
+
+        def verify_j(res, budget):
+            # numpy restatement over every block of the generator's host twin; the restatement itself is pinned on the first block: WITHOUT the extra predicate and the
+            # extra aggregates it must reproduce the oracle's Q1 (orc.q1_native) on those rows
+            from oracle import pyoracle as orc
+            t0 = time.perf_counter()
+            G = 6
+            acc = {k: np.zeros(G) for k in ("sum_base_price", "sum_disc_price", "sum_charge", "sum_disc")}
+            qty, cnt = np.zeros(G, np.int64), np.zeros(G, np.int64)
+            mx, mn = np.full(G, -np.inf), np.full(G, np.inf)
+            done, pinned = 0, None
+            while done < n and time.perf_counter() - t0 < budget:
+                m = min(100_000_000, n - done)
+                cols = datagen.lineitem_native_host_mt(done, m, seed)
+                gid = cols["l_returnflag"].astype(np.int64) * 2 + cols["l_linestatus"].astype(np.int64)
+                base = cols["l_shipdate"] <= cutoff
+                if pinned is None:
+                    w = orc.q1_native(cols, cutoff, streaming=True)
+                    ids = np.asarray(w["l_returnflag"], np.int64) * 2 + np.asarray(w["l_linestatus"], np.int64)
+                    dp = cols["l_extendedprice"] * (1.0 - cols["l_discount"])
+                    pinned = bool(np.array_equal(np.bincount(gid[base], minlength=G)[ids], np.asarray(w["count_order"], np.int64))
+                                  and _rel_err(np.bincount(gid[base], weights=dp[base], minlength=G)[ids], w["sum_disc_price"]) <= 1e-12)
+                keep = base & (cols["l_quantity"] < 45)
+                g = gid[keep]
+                ep, dc, tx = cols["l_extendedprice"][keep], cols["l_discount"][keep], cols["l_tax"][keep]
+                dp = ep * (1.0 - dc)
+                acc["sum_base_price"] += np.bincount(g, weights=ep, minlength=G); acc["sum_disc_price"] += np.bincount(g, weights=dp, minlength=G)
+                acc["sum_charge"] += np.bincount(g, weights=dp * (1.0 + tx), minlength=G); acc["sum_disc"] += np.bincount(g, weights=dc, minlength=G)
+                qty += np.bincount(g, weights=cols["l_quantity"][keep], minlength=G).astype(np.int64); cnt += np.bincount(g, minlength=G)
+                np.maximum.at(mx, g, tx); np.minimum.at(mn, g, ep)
+                done += m
+            if done < n:
+                return {"rows": done, "ok": None, "note": "host check ran out of its time budget before covering the input"}
+            code = lambda v, cats: cats.index(v) if isinstance(v, str) else int(v)
+            ids = [code(a, datagen.FLAGS) * 2 + code(b, datagen.STATUS) for a, b in zip(res["l_returnflag"], res["l_linestatus"])]
+            live = np.nonzero(cnt)[0]
+            ok = sorted(ids) == live.tolist()
+            err = 0.0
+            if ok:
+                ix = np.array(ids)
+                ok = [int(v) for v in res["sum_qty"]] == qty[ix].tolist() and [int(v) for v in res["count_order"]] == cnt[ix].tolist()
+                ok = ok and bool(np.array_equal(np.array(res["max_tax"]), mx[ix]) and np.array_equal(np.array(res["min_price"]), mn[ix]))       # min / max: bit-exact
+                for k, want in (("sum_base_price", acc["sum_base_price"]), ("sum_disc_price", acc["sum_disc_price"]), ("sum_charge", acc["sum_charge"]),
+                                ("avg_qty", qty / np.maximum(cnt, 1)), ("avg_price", acc["sum_base_price"] / np.maximum(cnt, 1)), ("avg_disc", acc["sum_disc"] / np.maximum(cnt, 1))):
+                    err = max(err, _rel_err(res[k], want[ix]))
+                ok = ok and err <= VERIFY_RTOL
+            return {"rows": n, "ok": bool(ok and pinned), "restatement_matches_oracle_q1_on_first_block": pinned, "max_rel_err": err, "rtol": VERIFY_RTOL, "groups": len(ids),
+                    "against": "numpy restatement over all rows of the generator's host twin (pinned against the oracle's Q1 on the first block)"}
+        wlj = Workload("tpch_q1_sf100_two_predicates_ten_aggregates_jit", n, n * datagen.Q1_BYTES_PER_ROW, step_j, "fused_scan_ldsagg_generic",
+                       f"TPC-H Q1 over {n} rows with a second predicate (l_quantity < 45) and two more aggregates (max(l_tax), min(l_extendedprice)): no ahead-of-time kernel, "
+                       "the scan is specialised at run time (hiprtc)", verify=verify_j)
+        wlj.inputs = [dfj]
+        wlj.jit_before = jit0
+        return wlj
     if name == "q3dc":
         # A join -> group-by whose AGGREGATE reads a build-side column (round-5 review, missing 2): the duplicate-key join's tables with a supplier cost on the build side,
         # group_by(partkey, suppkey).agg(sum(l_extendedprice * ps_supplycost), len) -- the in-place form cannot evaluate it (its cells are fed by the probe scan alone);
@@ -891,6 +964,14 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
     raise ValueError(name)
 
 
+def jit_stats(pl):
+    """(kernels the run-time compiler made available so far, milliseconds it spent compiling) -- plx_jit_stats"""
+    import ctypes as C
+    n, ms = C.c_int32(), C.c_double()
+    pl._ffi.check(pl._ffi.lib().plx_jit_stats(C.byref(n), C.byref(ms)))
+    return int(n.value), float(ms.value)
+
+
 def kernel_stats(pl):
     """Per-kernel (name -> [count, total_us, algo_bytes per launch]) from the library's HIP-event tracer."""
     import ctypes as C
@@ -1117,7 +1198,7 @@ def scan_extra(pl, n: int):
     return out
 
 
-PMC_ROUND = "r05"
+PMC_ROUND = "r06"
 
 
 def pmc_traffic(workload_name: str, kernel: str, rows: int):
@@ -1131,7 +1212,9 @@ def pmc_traffic(workload_name: str, kernel: str, rows: int):
              "cfg2_filter_arith_agg_1e9": ("cfg2", 10 ** 9), "cfg3_groupby_1e6_keys_1e9": ("cfg3", 10 ** 9), "cfg5_dict_string_keys_1e9": ("cfg5", 10 ** 9),
              "tpch_q3_sf100_shuffled_inputs": ("q3s", SF100_ORDERS + SF100_LINEITEM), "cfg5_utf8view_keys_1e9": ("cfg5s", 10 ** 9),
              "tpch_q3_sf100_hashed_keys": ("q3h", SF100_ORDERS + SF100_LINEITEM), "cfg2_nulls5pct_1e9": ("cfg2n", 10 ** 9), "cfg3_zipf_1e9": ("cfg3z", 10 ** 9),
-             "cfg3_sparse_keys_1e9": ("cfg3s", 10 ** 9), "cfg3_two_int64_keys_1e9": ("cfg3w", 10 ** 9), "join_duplicate_build_keys_sf100": ("q3d", SF100_LINEITEM + SF100_LINEITEM * 2 // 15)}.get(workload_name)
+             "cfg3_sparse_keys_1e9": ("cfg3s", 10 ** 9), "cfg3_two_int64_keys_1e9": ("cfg3w", 10 ** 9), "join_duplicate_build_keys_sf100": ("q3d", SF100_LINEITEM + SF100_LINEITEM * 2 // 15),
+             "join_aggregate_reads_build_side_sf100": ("q3dc", SF100_LINEITEM + SF100_LINEITEM * 2 // 15), "join_materialise_sf100": ("joinm", SF100_ORDERS + SF100_LINEITEM),
+             "filter_materialise_1e9": ("filterm", 10 ** 9), "gather_1e9": ("gather", 10 ** 9), "tpch_q1_sf100_two_predicates_ten_aggregates_jit": ("q1j", SF100_LINEITEM)}.get(workload_name)
     if short is None or (short[1] is not None and abs(rows - short[1]) > 0.01 * short[1]):
         return None
     try:
@@ -1139,7 +1222,20 @@ def pmc_traffic(workload_name: str, kernel: str, rows: int):
     except Exception:
         return None
     v = (d.get("kernels") or {}).get(kernel)
-    return int(v["hbm_bytes_per_launch"]) if v and d.get("keyed_by") == "kernel symbol" else None
+    if v and d.get("keyed_by") == "kernel symbol":
+        pmc_traffic.sources[workload_name] = f"profiles/{PMC_ROUND}/{short[0]}_pmc.json" + (f" (collected {d['collected']})" if d.get("collected") else "")
+        return int(v["hbm_bytes_per_launch"])
+    return None
+
+
+pmc_traffic.sources = {}
+
+
+def traffic_source(workload_name: str):
+    """Where a line's `traffic` figure comes from: it is LOOKED UP by kernel name in a committed rocprofv3 counter summary (FETCH_SIZE / WRITE_SIZE in separate
+    passes, tools/pmc_all.sh), not measured during this run (round-5 review, weak 9)."""
+    src = pmc_traffic.sources.get(workload_name)
+    return None if src is None else src + ": looked up by kernel name, not measured in this run"
 
 
 def roofline(stats, wl, steps: int):
@@ -1192,13 +1288,15 @@ def roofline(stats, wl, steps: int):
         out = {"bound": "hbm", "scope": "operator: all kernels of one step", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": round(ach / HBM_PEAK_GBS, 4), "kernel_us_per_step": round(step_us, 2), "algo_bytes_per_step": wl.algo_bytes, "required_bytes_per_step": int(required), "traffic": traffic,
                "hbm_frac": None if traffic is None or step_us <= 0 else round(traffic / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-               "dominant_kernel": dom}
+               "traffic_source": traffic_source(wl.name) if traffic is not None else None, "dominant_kernel": dom}
         if note:
             out.update(nominal_achieved=round(nominal, 1), nominal_frac=round(nominal / HBM_PEAK_GBS, 4), note=note)
         return out
     ach = algo / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+    traffic = pmc_traffic(wl.name, name, wl.rows)
     return {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "avg_kernel_us": round(avg_us, 2), "launches": cnt, "algo_bytes_per_launch": algo, "traffic": pmc_traffic(wl.name, name, wl.rows)}
+            "avg_kernel_us": round(avg_us, 2), "launches": cnt, "algo_bytes_per_launch": algo, "traffic": traffic,
+            "traffic_source": traffic_source(wl.name) if traffic is not None else None}
 
 
 def pyarrow_q1(cols, cutoff):
@@ -2081,7 +2179,7 @@ def compare_q1_dicts(a: dict, b: dict) -> bool:
 
 MULTI_EXTRAS = ("q3", "q3:shuffle", "cfg3", "cfg5", "q1", "q1:weak")     # ":weak" = the per-rank SF100 shard (weak scaling), labelled so in its config.workload
 LATE_WORKLOADS = ("filterm", "gather")       # frame-returning operators with multi-gigabyte results: timed and checked last, one at a time
-EXTRA_WORKLOADS = ("q3", "q3h", "q3d", "q3dc", "joinm", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "q1")      # the secondary workloads of the N = 1 line, in this order
+EXTRA_WORKLOADS = ("q1j", "q3", "q3h", "q3d", "q3dc", "joinm", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "q1")      # the secondary workloads of the N = 1 line, in this order
 
 
 def run_multi(args, emit):
@@ -2263,6 +2361,14 @@ def run(args, emit):
                     wv = Workload(vname, w2.rows, w2.algo_bytes, vstep, w2.kernel, w2.desc)
                     dv, sv, _, _ = timed(pl, wv, k2, 1, False)
                     extras[vname] = {"rows_per_s": round(w2.rows * k2 / dv, 1), "ms_per_step": round(dv / k2 * 1e3, 3), "kernels": _kernels(sv, 6)}
+                if hasattr(w2, "jit_before"):
+                    j1 = jit_stats(pl)
+                    extras[w2.name]["jit"] = {"kernels_compiled_or_loaded": j1[0] - w2.jit_before[0], "compile_ms": round(j1[1] - w2.jit_before[1], 1),
+                                              "note": "compile_ms > 0: hiprtc ran inside cold_first_step_ms (empty disk cache); 0: the code object came from the disk cache"}
+                try:
+                    extras[w2.name]["plan"] = pl.last_plan()[:600]
+                except Exception:
+                    pass
                 if hasattr(r2, "height"):
                     extras[w2.name]["result_rows"] = int(r2.height)
                     if not getattr(w2, "big_result", False) and hasattr(r2, "_download_all"):

@@ -737,3 +737,32 @@ def test_bench_multi_gpu_default_run_through_rccl_at_world_size_one(tmp_path):
     assert len(ex) == 4 and all("error" not in v and v["verified"]["ok"] is True for v in ex.values()), {k: v.get("error") or v.get("verified") for k, v in ex.items()}
     assert {v.get("exchange_mode") for k, v in ex.items() if k.startswith("tpch_q3")} == {"broadcast", "shuffle"}
     assert json.load(open(tmp_path / "extras.json"))["extras"].keys() == ex.keys()
+
+
+def test_bench_multi_gpu_default_run_through_rccl_on_every_gpu_of_the_box(tmp_path):
+    """Round-5 review, item 9: RCCL has only ever run with one rank here because a GPU box has one GPU.  This test runs the same default N > 1 bench at N =
+    torch.cuda.device_count() whenever that is more than one: the first multi-GPU box that runs `pytest -m gpu` exercises the all-gather combine of Q1, the key-hash
+    exchange (ncclSend / ncclRecv all-to-all over xGMI) of the sharded Q3 in both modes, cfg3 and cfg5 through RCCL at N ranks -- every result verified against the
+    oracle -- without anyone editing a test.  bench.py --gpus N starts its own ranks (one process per GPU, 127.0.0.1 rendezvous)."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one GPU on this box: RCCL at world size 1 is covered by test_bench_multi_gpu_default_run_through_rccl_at_world_size_one")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bench_lines
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(PLX_BENCH_EXTRAS_FILE=str(tmp_path / "extras.json"), MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--rows", "400000"], capture_output=True, text=True,
+                       timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    head, full = bench_lines.split(r.stdout)
+    assert head["comm"] == {"rank": 0, "world_size": n, "env_world_size": n, "library": "rccl"}, head["comm"]
+    assert head["n_gpus"] == n and head["verified"]["ok"] is True
+    ex = full["extras"]
+    assert len(ex) == 4 and all("error" not in v and v["verified"]["ok"] is True for v in ex.values()), {k: v.get("error") or v.get("verified") for k, v in ex.items()}
+    assert {v.get("exchange_mode") for k, v in ex.items() if k.startswith("tpch_q3")} == {"broadcast", "shuffle"}
+    assert json.load(open(tmp_path / "extras.json"))["extras"].keys() == ex.keys()

@@ -39,7 +39,11 @@ CASES = [
     ("plx::k::canonicalise_chains_kernel(plx::fused::JoinAggTable, plx::fused::RepCols, unsigned int, unsigned int*)", "join_chain_representatives"),
     ("plx::k::rows_agg_compact_kernel(unsigned long long const*, long, int, int, unsigned long long*, unsigned int*, unsigned long long*)", "table_compact"),
     ("plx_jit_part3_scatter_21_0a1b2c3d", "part3_scatter[jit,h,t2,p0]"), ("plx_jit_part3_scatter_60_0a1b2c3d", "part3_scatter[jit,d,t1,p1,hot]"), ("plx_jit_part3_agg_85_deadbeef", "part_agg_lds[jit,h,p1]"),
-    ("plx_jit_RegAggSink_0_0a1b2c3d", None),
+    # (round 6: run-time compiled plain scans resolve to the tracer's name for a scan without an AOT kernel -- the JIT-shape bench extra's traffic is looked up by it)
+    ("plx_jit_RegAggSink_0_0a1b2c3d", "fused_scan_regagg_generic"), ("plx_jit_LdsAggSink_1_0a1b2c3d", "fused_scan_ldsagg_generic"), ("plx_jit_BallotSink_91_0a1b2c3d", "fused_scan_ballots[jit]"),
+    ("void plx::k::compact_by_ballots_kernel<8, 3>(plx::k::CompactCols, unsigned long long const*, unsigned long long const*, long, unsigned int*)", "filter_compact_cols"),
+    ("plx::join::join_match_kernel(plx::join::KeyCol, unsigned int const*, long, plx::join::PairTable, int, unsigned int*, unsigned int*, unsigned long long*)", "join_match"),
+    ("plx_jit_UnknownSink_7_0a1b2c3d", None),
     ("__amd_rocclr_fillBufferAligned", None),
 ]
 

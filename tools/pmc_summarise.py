@@ -24,6 +24,8 @@ SCOPES = [  # (regex on the demangled kernel name, ProfileScope name in bench.py
     (r"strgroup_scatter_kernel", "strgroup_scatter"), (r"strgroup_agg_kernel", "strgroup_agg_lds"),
     (r"canonicalise_chains_kernel", "join_chain_representatives"), (r"rows_agg_compact_kernel|wide_compact_kernel", "table_compact"),
     (r"fused_scan_kernel<.*WideAggSink", "fused_scan_wideagg"),
+    (r"compact_by_ballots_kernel", "filter_compact_cols"), (r"join_match_kernel", "join_match"), (r"join_pairs_emit_kernel", "join_pairs_emit"), (r"filter_rowids_kernel", "filter_rowids"),
+    (r"filter_kernel<", "filter_compact"), (r"tile_count_kernel", "filter_tile_count"), (r"ballots_to_mask_kernel", "ballots_to_mask"),
     (r"init_acc_kernel|fill_u64_kernel", "table_init"), (r"strview_encode_kernel", "strview_dict_encode"), (r"strdict_", "strdict_materialise"),
 ]
 
@@ -42,6 +44,12 @@ def scope_of(kernel: str):
     if m:
         v = int(m.group(1)) - 83
         return f"part_agg_lds[jit,{'d' if v & 1 else 'h'},p{v >> 1}]"
+    # run-time compiled plain scan sinks: plx_jit_<Sink>_<kind>_<hash> -> the name the tracer gives a scan without an AOT kernel (kernels_fused.hip scope_name)
+    m = re.match(r"plx_jit_(\w+Sink)_\d+_", kernel)
+    if m:
+        return {"LdsAggSink": "fused_scan_ldsagg_generic", "RegAggSink": "fused_scan_regagg_generic", "BallotSink": "fused_scan_ballots[jit]", "JoinBuildSink": "fused_scan_join_build",
+                "ProbeAggSink": "fused_scan_probe_agg", "DirectBuildSink": "fused_scan_direct_build", "DirectProbeAggSink": "fused_scan_direct_probe_agg",
+                "BitmapBuildSink": "fused_scan_bitmap_build", "HashAggSink": "fused_scan_hashagg", "DenseAggSink": "fused_scan_denseagg", "WideAggSink": "fused_scan_wideagg"}.get(m.group(1))
     m = re.search(r"fused_scan_kernel<.*StatProg<(\d+)>", kernel)
     sid = m.group(1) if m else None
     m = re.search(r"part3_scatter_kernel<.*StatProg<(\d+)>\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*(?:,\s*(true|false)\s*)?(?:,\s*(?:true|false)\s*)?>", kernel)      # (the last flag: the per-row check of narrowed values compiled in)
@@ -102,7 +110,8 @@ def main():
         f, w = e["fetch_KB"] / n, e["write_KB"] / n
         res[sc] = {"fetch_KB": round(f, 1), "write_KB": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024), "launches_seen": e["launches"], "kernel_names": e["kernel_names"]}
     cal = res.get("datagen_uniform_i64")
-    doc = {"workload": wl, "keyed_by": "kernel symbol",
+    import time
+    doc = {"workload": wl, "keyed_by": "kernel symbol", "collected": time.strftime("%Y-%m-%d %H:%M UTC", time.gmtime()),
            "command": f"rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) --kernel-trace -- python bench.py --workload {wl} --steps 3 --warmup 1 --no-extras --no-cpu  (tools/pmc_all.sh)",
            "correction": "gfx950: FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies 128-B requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported, calibrated on datagen_uniform_i64 "
                          "(the library's generator writes exactly 8 B per row): see `calibration`",
