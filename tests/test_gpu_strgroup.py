@@ -367,3 +367,63 @@ def test_reference_vector_null_string_key_group(pl, monkeypatch):
     assert set(got) == set(groups) and len(d["a"]) == 40 and got[None] == 3 and d["n"] == d["len"]
     assert all(got[g] == c for g, c in sizes.items())
     assert all(got[g] == sum(1 for v in values if v == g) for g in groups)
+
+
+def _long_key_views(pl, rng, n, n_keys, lo=13, hi=40, with_short=False):
+    """Utf8View column of n rows over n_keys distinct strings of lo..hi bytes (with_short: a third of them <= 12 bytes, inline), built the way an Arrow producer lays it
+    out: every row's bytes sit in ONE data buffer at the row's own offset, the view carries {length, 4-byte prefix, buffer 0, offset}."""
+    lens = rng.integers(lo, hi + 1, n_keys)
+    if with_short:
+        lens[::3] = rng.integers(0, 13, len(lens[::3]))
+    pool = [(b"k%06d-" % i + bytes(rng.integers(97, 123, 40).astype(np.uint8)))[:lens[i]] for i in range(n_keys)]
+    ids = rng.integers(0, n_keys, n)
+    row_len = lens[ids].astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(np.where(row_len > 12, row_len, 0))])
+    data = np.zeros(int(off[-1]) + 16, np.uint8)
+    views = np.zeros((n, 4), np.uint32)
+    padded = np.zeros((n_keys, 40), np.uint8)
+    for i, s in enumerate(pool):
+        padded[i, :len(s)] = np.frombuffer(s, np.uint8)
+    rows = padded[ids]                                   # [n, 40]
+    views[:, 0] = row_len
+    inline = row_len <= 12
+    v8 = views.view(np.uint8).reshape(n, 16)
+    v8[inline, 4:16] = rows[inline, :12]
+    v8[~inline, 4:8] = rows[~inline, :4]                 # prefix
+    views[~inline, 2] = 0                                # buffer index
+    views[~inline, 3] = off[:-1][~inline].astype(np.uint32)
+    long_rows = np.nonzero(~inline)[0]
+    for L in np.unique(row_len[long_rows]):              # bytes of the long strings at their offsets, one length class at a time
+        sel = long_rows[row_len[long_rows] == L]
+        idx = off[:-1][sel][:, None] + np.arange(L)[None, :]
+        data[idx] = rows[sel, :L]
+    vs = pl.Series("views", views.view(np.uint64).reshape(-1).copy(), pl.UInt64)
+    ds = pl.Series("data", data, pl.UInt8)
+    return vs, ds, [p.decode() for p in pool], ids
+
+
+@pytest.mark.parametrize("with_short", [False, True])
+def test_string_key_group_by_long_keys_three_value_columns_min_max(pl, with_short):
+    """Round-5 review, missing 4 / item 6: keys of 13-40 bytes (the view is NOT the string: get_long_key compares through the buffers, binview_index_map.rs:106-117), three value
+    columns, min / max -- everything the string-key operator's one fast shape declines.  The deferred column then encodes on the device (plx_strview_dict_encode_device reads the
+    bytes behind the views) and the group-by runs on the codes: same answers as pandas, whatever mix of inline and long strings the column holds."""
+    pd = pytest.importorskip("pandas")
+    rng = np.random.default_rng(2024 + with_short)
+    n, n_keys = 2_000_003, 30_000
+    vs, ds, pool, ids = _long_key_views(pl, rng, n, n_keys, with_short=with_short)
+    a = rng.normal(size=n)
+    b = rng.integers(-10 ** 9, 10 ** 9, n).astype(np.int64)
+    c = rng.integers(-1000, 1000, n).astype(np.int32)
+    cv = rng.random(n) > 0.1
+    k = pl.Series.from_device_views("k", vs, ds, encode="deferred")
+    df = pl.DataFrame([k, pl.Series("a", a), pl.Series("b", b), pl.Series("c", c, validity=cv)])
+    P = pl.col
+    out = df.lazy().group_by("k").agg(P("a").sum().alias("a_sum"), P("b").min().alias("b_min"), P("b").max().alias("b_max"), P("c").mean().alias("c_mean"), P("c").count().alias("c_n"), pl.len().alias("n")).collect()
+    got = _by_key(out)
+    ref = pd.DataFrame({"k": np.array(pool, dtype=object)[ids], "a": a, "b": b, "c": np.where(cv, c.astype(np.float64), np.nan)})
+    exp = ref.groupby("k").agg(a_sum=("a", "sum"), b_min=("b", "min"), b_max=("b", "max"), c_mean=("c", "mean"), c_n=("c", "count"), n=("a", "size")).reset_index().sort_values("k")
+    assert got["k"] == exp["k"].tolist()
+    assert got["b_min"] == exp["b_min"].tolist() and got["b_max"] == exp["b_max"].tolist() and got["c_n"] == exp["c_n"].tolist() and got["n"] == exp["n"].tolist()
+    assert np.allclose(got["a_sum"], exp["a_sum"].to_numpy(), rtol=1e-6, atol=1e-9)
+    cm = np.array([np.nan if x is None else x for x in got["c_mean"]], dtype=np.float64)
+    assert np.allclose(cm, exp["c_mean"].to_numpy(), rtol=1e-6, atol=1e-12, equal_nan=True)
