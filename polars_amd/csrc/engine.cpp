@@ -1876,7 +1876,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     if (cfl[0]) return no("a build key repeats more than 1024 times");
     merged_rows = cfl[1];
   }
-  const int64_t n_cells = multi ? std::max<int64_t>(B->height, 1) : (int64_t)cap + 1;      // multi-value mode: one cell set per build ROW
+  const int64_t n_cells = (int64_t)cap + 1;      // one cell set per KEY, also in multi-value mode (the groups are expanded from the key's cells by chains_agg_compact)
   acc = dev_alloc(sizeof(uint64_t) * (size_t)n_cells * cp.shape.n_aggs);
   t.acc = acc->as<unsigned long long>();
   k::init_agg_cells(acc->as<uint64_t>(), n_cells, cp.shape);
@@ -1912,15 +1912,17 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   JTRACE("probe done");
   // ONE compaction pass into buffers sized for every build row (G <= nb): no counting pass over the table first
   const int64_t g1 = std::max<int64_t>((int64_t)nb, 1);
-  r.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)g1);
-  r.acc = dev_alloc(sizeof(uint64_t) * (size_t)g1 * r.n_aggs);
-  rows->values = dev_alloc(values_bytes(PLX_U32, g1));
+  if (!multi) {
+    r.packed_keys = dev_alloc(sizeof(uint64_t) * (size_t)g1);
+    r.acc = dev_alloc(sizeof(uint64_t) * (size_t)g1 * r.n_aggs);
+    rows->values = dev_alloc(values_bytes(PLX_U32, g1));
+  }
   // (measured on SF100 Q3 with hashed keys: listing the touched slots from the candidates' probe -- one returning atomic per row -- costs that probe 0.5 ms, a
   // candidates' filter in front of the LEN cells 0.2 ms; streaming the LEN cells is 0.37 ms)
-  G = multi ? k::rows_agg_compact(acc->as<uint64_t>(), B->height, r.n_aggs, len_idx, rows->values->as<uint32_t>(), r.acc->as<uint64_t>())
-            : k::join_agg_compact(t, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
+  if (multi) G = k::chains_agg_compact(t, cp.shape, acc->as<uint64_t>(), len_idx, &rows->values, &r.acc);
+  else G = k::join_agg_compact(t, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
   JTRACE("compacted: %lld groups", (long long)G);
-  PLX_REQUIRE(G <= g1, PLX_ERR_INVALID, "join: more groups than build rows");
+  PLX_REQUIRE(multi || G <= g1, PLX_ERR_INVALID, "join: more groups than build rows");
   r.n_groups = G;
   rows->len = G;
   plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " hash table cap=2^" + std::to_string(log2_cap) +

@@ -546,7 +546,89 @@ void canonicalise_chains(const JoinAggTable& t, const RepCols& rc, unsigned int 
   hipLaunchKernelGGL(canonicalise_chains_kernel, dim3(grid_for(n_slots, kBlock * 4)), dim3(kBlock), 0, stream(), t, rc, max_chain, flags);
   PLX_HIP(hipGetLastError());
 }
-// groups of the multi-value table = build rows whose LEN cell is non-zero (a row that represents nobody, matched nobody or never passed the build predicate has none)
+// ---- multi-value table -> groups.  Cells are per KEY (slot); a group is a REPRESENTATIVE build row of the key's chain (canonicalise_chains) and stands for the m rows of
+// the chain it represents: its aggregate is m copies of the key's (every probe row of the key joins each of those m build rows) -- sums and counts times m, min / max /
+// first unchanged.  Pass 1 counts the representatives of every slot that matched (LEN != 0), a device scan lays them out, pass 2 writes row + scaled cells.
+__device__ __forceinline__ unsigned int chain_reps(const JoinAggTable& t, int64_t s, unsigned int* reps /* may be null */, unsigned int* mult /* may be null */, unsigned int cap_out) {
+  const unsigned int* rw = jt_row(t, (uint64_t)s);
+  const unsigned int head = rw[0];
+  if (head == kNoRow32) return 0;
+  if (rw[1] == 0xffffffffu) { if (reps) { reps[0] = head; mult[0] = 1; } return 1; }      // a key with ONE build row
+  unsigned int n = 0;
+  for (unsigned int o = head, g = 0; o != kNoRow32 && g < (1u << 20); g++) {
+    const unsigned long long l = t.links[o];
+    if ((unsigned int)(l >> 32) == o) {                    // o represents itself: a group
+      if (reps && n < cap_out) {
+        unsigned int m = 0;
+        for (unsigned int q = head, h = 0; q != kNoRow32 && h < (1u << 20); h++) { const unsigned long long lq = t.links[q]; m += (unsigned int)(lq >> 32) == o; q = (unsigned int)lq; }
+        reps[n] = o; mult[n] = m;
+      }
+      n++;
+    }
+    o = (unsigned int)l;
+  }
+  return n;
+}
+__global__ __launch_bounds__(kBlock) void chains_count_kernel(JoinAggTable t, const unsigned long long* __restrict__ acc, int n_aggs, int len_idx, uint32_t* __restrict__ counts) {
+  const int64_t cap = (int64_t)1 << t.log2_cap;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= cap; s += (int64_t)gridDim.x * blockDim.x)
+    counts[s] = acc[(size_t)s * n_aggs + len_idx] != 0 ? chain_reps(t, s, nullptr, nullptr, 0) : 0u;
+}
+__global__ __launch_bounds__(kBlock) void chains_emit_kernel(JoinAggTable t, Shape sh, const unsigned long long* __restrict__ acc, int len_idx, const uint64_t* __restrict__ off,
+                                                             unsigned int* __restrict__ out_rows, unsigned long long* __restrict__ out_acc) {
+  const int64_t cap = (int64_t)1 << t.log2_cap;
+  const int n_aggs = sh.n_aggs;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= cap; s += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t o0 = off[s], n = off[s + 1] - o0;
+    if (!n) continue;
+    // (chains are short -- dbgen's partsupp: 4 rows a key; a key repeated more than kChunk times is emitted in rounds)
+    constexpr unsigned int kChunk = 16;
+    unsigned int reps[kChunk], mult[kChunk];
+    if (n <= kChunk) chain_reps(t, s, reps, mult, kChunk);
+    for (uint64_t g = 0; g < n; g++) {
+      unsigned int row, m;
+      if (n <= kChunk) { row = reps[g]; m = mult[g]; }
+      else {      // the g-th representative of a long chain: walk for it
+        const unsigned int head = jt_row(t, (uint64_t)s)[0];
+        unsigned int seen = 0; row = head; m = 0;
+        for (unsigned int o = head, h = 0; o != kNoRow32 && h < (1u << 20); h++) { const unsigned long long l = t.links[o]; if ((unsigned int)(l >> 32) == o) { if (seen == g) { row = o; break; } seen++; } o = (unsigned int)l; }
+        for (unsigned int q = head, h = 0; q != kNoRow32 && h < (1u << 20); h++) { const unsigned long long lq = t.links[q]; m += (unsigned int)(lq >> 32) == row; q = (unsigned int)lq; }
+      }
+      out_rows[o0 + g] = row;
+      for (int k = 0; k < n_aggs; k++) {
+        unsigned long long c = acc[(size_t)s * n_aggs + k];
+        switch (sh.aggs[k].kind) {
+          case AGG_SUM_F: c = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)c) * (double)m); break;
+          case AGG_SUM_I: case AGG_COUNT: case AGG_COUNT_ORD: case AGG_LEN: c *= (unsigned long long)m; break;
+          default: break;       // min / max / first row: the same for every copy
+        }
+        out_acc[(o0 + g) * n_aggs + k] = c;
+      }
+    }
+  }
+}
+int64_t chains_agg_compact(const JoinAggTable& t, const Shape& sh, const uint64_t* acc, int len_idx, Buf* out_rows, Buf* out_acc) {
+  const int64_t n_slots = ((int64_t)1 << t.log2_cap) + 1;
+  Buf counts = dev_alloc(sizeof(uint32_t) * (size_t)n_slots), off = dev_alloc(sizeof(uint64_t) * (size_t)(n_slots + 1));
+  ProfileScope ps("table_compact", (uint64_t)n_slots * (8 * (uint64_t)sh.n_aggs + 16), (uint64_t)n_slots);
+  hipLaunchKernelGGL(chains_count_kernel, dim3(grid_for(n_slots, kBlock * 4)), dim3(kBlock), 0, stream(), t, (const unsigned long long*)acc, (int)sh.n_aggs, len_idx, counts->as<uint32_t>());
+  PLX_HIP(hipGetLastError());
+  exclusive_scan_u32(counts->as<uint32_t>(), off->as<uint64_t>(), n_slots);
+  uint64_t total = 0;
+  d2h_sync(&total, off->as<uint64_t>() + n_slots, 8);
+  const int64_t g1 = std::max<int64_t>((int64_t)total, 1);
+  *out_rows = dev_alloc(sizeof(uint32_t) * (size_t)g1);
+  *out_acc = dev_alloc(sizeof(uint64_t) * (size_t)g1 * sh.n_aggs);
+  if (total) {
+    hipLaunchKernelGGL(chains_emit_kernel, dim3(grid_for(n_slots, kBlock * 4)), dim3(kBlock), 0, stream(), t, sh, (const unsigned long long*)acc, len_idx, off->as<uint64_t>(),
+                       (*out_rows)->as<unsigned int>(), (*out_acc)->as<unsigned long long>());
+    PLX_HIP(hipGetLastError());
+    PLX_HIP(hipStreamSynchronize(stream()));
+  }
+  return (int64_t)total;
+}
+
+// groups of a table whose cells are per build ROW = build rows whose LEN cell is non-zero
 __global__ __launch_bounds__(kBlock) void rows_agg_compact_kernel(const unsigned long long* __restrict__ acc, int64_t n_rows, int n_aggs, int len_idx, unsigned long long* __restrict__ counter,
                                                                   unsigned int* __restrict__ out_rows, unsigned long long* __restrict__ out_acc) {
   compact_slots(n_rows, counter, [&](int64_t s) { return acc[(size_t)s * n_aggs + len_idx] != 0; },

@@ -35,6 +35,9 @@ int64_t join_agg_compact(const fused::JoinAggTable& t, int n_aggs, int len_idx, 
 // multi-value join table (duplicate build keys; fused::JoinAggTable::links): representatives of the rows of every key's chain, and the compaction of row-indexed cells
 void canonicalise_chains(const fused::JoinAggTable& t, const fused::RepCols& rc, unsigned int max_chain, unsigned int* flags);
 int64_t rows_agg_compact(const uint64_t* acc, int64_t n_rows, int n_aggs, int len_idx, uint32_t* out_rows, uint64_t* out_acc);
+// multi-value table whose cells are per KEY (slot): the groups are the representatives of every matched key's chain, each with the key's aggregate taken as many times as the
+// group has build rows (sums / counts scaled, min / max / first as they are).  Allocates *out_rows (u32 build rows) and *out_acc ([G][n_aggs]); returns G.  Synchronises.
+int64_t chains_agg_compact(const fused::JoinAggTable& t, const fused::Shape& sh, const uint64_t* acc, int len_idx, Buf* out_rows, Buf* out_acc);
 // number of waves a fused scan over n_rows launches (sizes per-wave reservations)
 int64_t scan_waves(int64_t n_rows);
 // filter -> frame, first half: `sh` / `args` = the predicate program (pred only, no aggregates) -> ballots + kept-row count per 128-row wave tile

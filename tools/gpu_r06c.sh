@@ -1,14 +1,13 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r06c
-timeout 900 python -m pytest tests/test_gpu_materialise.py -x -q -m gpu -k "beyond" 2>&1 | tail -15
-PLX_BENCH_EXTRAS=q3dc PLX_BENCH_Q3_SHUFFLED=0 PLX_BENCH_E2E=0 PLX_BENCH_SCAN=0 PLX_BENCH_DEADLINE_S=900 timeout 1200 python bench.py --steps 5 --warmup 2 --no-cpu > gpurun_out/r06c/bench.log 2> gpurun_out/r06c/bench.err
-tail -c 2000 gpurun_out/r06c/bench.err
+timeout 1200 python -m pytest tests/test_gpu_join_duplicate_keys.py tests/test_gpu_join_partitioned.py -x -q -m gpu 2>&1 | tail -15
+PLX_BENCH_EXTRAS=q3d PLX_BENCH_Q3_SHUFFLED=0 PLX_BENCH_E2E=0 PLX_BENCH_SCAN=0 PLX_BENCH_DEADLINE_S=900 timeout 1200 python bench.py --steps 5 --warmup 2 --no-cpu > gpurun_out/r06c/bench.log 2> gpurun_out/r06c/bench.err
+tail -c 1500 gpurun_out/r06c/bench.err
 python - <<'PY'
 import json
 d=json.load(open('bench_extras.json'))
 for k,v in d.get('extras',{}).items():
-    print(v.get("plan") or "", k, json.dumps({a:b for a,b in v.items() if a in ('ms_per_step','cold_first_step_ms','step_ms','result_rows','kernels','verified','error','result_download_ms')})[:1500])
+    print(k, json.dumps({a:b for a,b in v.items() if a in ('ms_per_step','cold_first_step_ms','step_ms','result_rows','kernels','verified','error','result_download_ms')})[:1500])
     print('   frac', (v.get('roofline') or {}).get('frac'))
 PY
-cp bench_extras.json gpurun_out/r06c/
