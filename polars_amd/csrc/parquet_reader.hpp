@@ -30,6 +30,8 @@
 
 #include "../../include/polars_amd.h"
 #include "file_io.hpp"
+#include <future>
+
 #include "host_codecs.hpp"
 #include "parquet_device.hpp"
 #include "parquet_format.hpp"
@@ -234,6 +236,12 @@ inline bool snappy_on_host() {
   const char* e = getenv("PLX_PARQUET_SNAPPY");        // read per column chunk: cheap, and a test can flip it
   return e && !strcmp(e, "host");
 }
+// Snappy dictionary pages from this many uncompressed bytes are inflated by host threads instead of the device kernel (PLX_PARQUET_HOST_DICT_BYTES; 0 = never)
+inline size_t host_dict_min_bytes() {
+  const char* e = getenv("PLX_PARQUET_HOST_DICT_BYTES");        // read per page: cheap, and a test can flip it
+  if (e) { const long long v = atoll(e); return v <= 0 ? (size_t)-1 : (size_t)v; }
+  return (size_t)192 << 10;
+}
 inline bool is_host_codec(int codec_id) {
   return codec_id == CODEC_ZSTD || codec_id == CODEC_LZ4_RAW || codec_id == CODEC_GZIP || (codec_id == CODEC_SNAPPY && snappy_on_host());
 }
@@ -361,9 +369,44 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     for (size_t k = i; k < j; k++) batch_last[k] = j - 1;
     i = j;
   }
+  // Device Snappy, optionally in BATCHES of chunks (PLX_PARQUET_SNAPPY_BATCH = stored bytes per launch): the streams of the chunks whose bytes are already on their way
+  // start while the host walks (and uploads) the next ones.  Measured on the 2e7-row file (steady state: walk + uploads 14 ms, then 8-12 ms of kernels): batches of 20 / 40 /
+  // 64 MB read in 25.9 / 28.3 / 30.4 ms against 26.4 with ONE launch at the end -- inside the box-to-box noise -- while the summed kernel time grows (33.6 / 24.5 / 22.3 vs
+  // 21.5 ms: every launch lasts as long as its longest stream).  So the default stays one launch; the knob stays for slower hosts.
+  typename B::Mem err_mem = be.alloc(64);
+  be.zero(be.addr(err_mem), 64);
+  uint32_t* err = (uint32_t*)be.addr(err_mem);
+  std::vector<typename B::Mem> snappy_mem;             // scratch + job arrays of the launches: alive until the column is decoded
+  // (a kernel launched early writes into `snappy_mem` while the walk goes on: if the walk throws -- a page this path does not decode -- the stream is drained BEFORE
+  //  the buffers above go back to the pool; declared after them, destroyed before them)
+  struct SyncOnUnwind { B& b; int n = std::uncaught_exceptions(); ~SyncOnUnwind() { if (std::uncaught_exceptions() > n) b.discard_pending(); } } sync_on_unwind{be};
+  size_t jobs_launched = 0, stored_since_launch = 0;
+  static const size_t kSnappyBatch = [] { const char* e = getenv("PLX_PARQUET_SNAPPY_BATCH"); const long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : (size_t)-1; }();
+  auto launch_snappy = [&]() {
+    if (jobs_launched == jobs.size()) return;
+    size_t total = 0;
+    std::vector<size_t> off(jobs.size() - jobs_launched);
+    for (size_t j = jobs_launched; j < jobs.size(); j++) { off[j - jobs_launched] = total; total += align16((size_t)jobs[j].uncomp_size + 16); }
+    typename B::Mem scratch = be.alloc(total + 64);
+    const uint64_t base = be.addr(scratch);
+    uint64_t bytes_out = 0;
+    for (size_t j = jobs_launched; j < jobs.size(); j++) { jobs[j].dst = base + off[j - jobs_launched]; bytes_out += jobs[j].uncomp_size; }
+    // one workgroup per stream, started in array order: the longest streams first.  Pages and dictionaries refer to the streams' output addresses, not to job indices.
+    std::vector<DecompJob> ordered(jobs.begin() + (std::ptrdiff_t)jobs_launched, jobs.end());
+    std::stable_sort(ordered.begin(), ordered.end(), [](const DecompJob& a, const DecompJob& b) { return a.uncomp_size > b.uncomp_size; });
+    typename B::Mem jm = be.alloc(ordered.size() * sizeof(DecompJob) + 64);
+    be.upload_small(be.addr(jm), ordered.data(), ordered.size() * sizeof(DecompJob));
+    be.run_snappy((const DecompJob*)be.addr(jm), (uint32_t)ordered.size(), bytes_out, err);
+    if (stats) { stats->snappy_streams += ordered.size(); stats->snappy_bytes_out += bytes_out; }
+    snappy_mem.push_back(scratch); snappy_mem.push_back(jm);
+    jobs_launched = jobs.size();
+    stored_since_launch = 0;
+  };
   uint8_t* batch_image = nullptr;
   size_t batch_base = 0;
   std::vector<Inflate> inflate_all;
+  struct HostDict { std::vector<uint8_t> comp, plain; size_t out = 0, dict_index = 0; std::future<void> done; };
+  std::vector<std::unique_ptr<HostDict>> host_dicts;     // long Snappy dictionary pages inflated by host threads while the walk goes on (below)
   std::vector<std::vector<uint8_t>> stored_all;          // the stored bytes of a batch's chunks stay alive until its pass has run
   struct ImageUpload { size_t blob_off, bytes; };
   std::vector<ImageUpload> image_uploads;
@@ -463,7 +506,21 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
           if ((uint64_t)d.n * lt.src_width > (uint64_t)h.uncompressed_size && lt.src_width) throw FormatError("dictionary page smaller than its entry count");
           if (lt.src_width == 0) throw Unsupported("dictionary-encoded booleans");
           d.values = payload;
-          if (codec_on) {
+          if (codec_on && (size_t)h.uncompressed_size >= host_dict_min_bytes()) {
+            // A LONG Snappy stream is the device kernel's critical path -- one workgroup, 4 KB a round: pyarrow's dictionary pages of up to 1 MB ran for 13 ms next to
+            // a thousand data pages of 2 ms each, and the launch lasts as long as its longest stream.  A host thread inflates such a page in about a millisecond while the
+            // walk goes on (the compressed bytes are copied out of the staging buffer first: the next chunk reuses it); the plain values travel in one upload behind it.
+            auto hd = std::make_unique<HostDict>();
+            hd->comp.assign(host + pos, host + pos + (size_t)h.compressed_size);
+            hd->plain.resize((size_t)h.uncompressed_size + 16);
+            hd->out = (size_t)h.uncompressed_size;
+            hd->dict_index = dicts.size();
+            HostDict* hp = hd.get();
+            hd->done = std::async(std::launch::async, [hp] { snappy_decompress_into(hp->comp.data(), hp->comp.size(), hp->plain.data(), hp->out); });
+            host_dicts.push_back(std::move(hd));
+            job_of_dict.push_back(npos);
+            if (stats) { stats->host_inflated_pages++; stats->host_inflated_bytes += (uint64_t)h.uncompressed_size; }
+          } else if (codec_on) {
             job_of_dict.push_back(jobs.size());
             jobs.push_back(DecompJob{payload, 0, (uint32_t)h.compressed_size, (uint32_t)h.uncompressed_size});
           } else job_of_dict.push_back(npos);
@@ -537,22 +594,32 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
       }
     } else {
       be.upload(blob_addr + ch.blob_off, host, sz);
+      stored_since_launch += sz;
+      if (codec_on && stored_since_launch >= kSnappyBatch && ci + 1 < chunks.size()) launch_snappy();
     }
     row0 += (uint64_t)ch.rows;
   }
   trace_point(leaf.name, "chunks read, uploads queued");
-  // -- scratch for the decompressed streams ---------------------------------------------------------------------------------------------
-  typename B::Mem scratch{};
-  if (!jobs.empty()) {
+  // -- the streams of the last chunks; pages and dictionaries learn where their bytes will be ------------------------------------------------------
+  launch_snappy();
+  for (size_t i = 0; i < pages.size(); i++) if (job_of_page[i] != npos) pages[i].dst = jobs[job_of_page[i]].dst;
+  for (size_t i = 0; i < dicts.size(); i++) if (job_of_dict[i] != npos) dicts[i].values = jobs[job_of_dict[i]].dst;
+  typename B::Mem host_dict_mem{};
+  if (!host_dicts.empty()) {
     size_t total = 0;
-    std::vector<size_t> off(jobs.size());
-    for (size_t j = 0; j < jobs.size(); j++) { off[j] = total; total += align16((size_t)jobs[j].uncomp_size + 16); }
-    scratch = be.alloc(total + 64);
-    const uint64_t base = be.addr(scratch);
-    for (size_t j = 0; j < jobs.size(); j++) jobs[j].dst = base + off[j];
-    for (size_t i = 0; i < pages.size(); i++) if (job_of_page[i] != npos) pages[i].dst = jobs[job_of_page[i]].dst;
-    for (size_t i = 0; i < dicts.size(); i++) if (job_of_dict[i] != npos) dicts[i].values = jobs[job_of_dict[i]].dst;
-    if (stats) { stats->snappy_streams += jobs.size(); for (auto& j : jobs) stats->snappy_bytes_out += j.uncomp_size; }
+    std::vector<size_t> off(host_dicts.size());
+    for (size_t i = 0; i < host_dicts.size(); i++) { off[i] = total; total += align16(host_dicts[i]->out + 16); }
+    host_dict_mem = be.alloc(total + 64);
+    uint8_t* st = be.host_stage(total + 64);
+    for (size_t i = 0; i < host_dicts.size(); i++) {
+      try { host_dicts[i]->done.get(); }
+      catch (const FormatError& e) { for (size_t j = i + 1; j < host_dicts.size(); j++) host_dicts[j]->done.wait(); throw FormatError(std::string("column '") + leaf.name + "': dictionary page: " + e.what()); }
+      memcpy(st + off[i], host_dicts[i]->plain.data(), host_dicts[i]->out);
+      dicts[host_dicts[i]->dict_index].values = be.addr(host_dict_mem) + off[i];
+    }
+    be.upload(be.addr(host_dict_mem), st, total);
+    host_dicts.clear();
+    trace_point(leaf.name, "long dictionary pages inflated on the host, uploaded");
   }
   typename B::Mem remap_mem{};
   if (is_bytes) {
@@ -565,26 +632,10 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
   const uint32_t n_pages = (uint32_t)pages.size();
   typename B::Mem pages_mem = be.alloc(pages.size() * sizeof(PageDesc) + 64);
   typename B::Mem dicts_mem = be.alloc(dicts.size() * sizeof(DictDesc) + 64);
-  typename B::Mem jobs_mem = be.alloc(jobs.size() * sizeof(DecompJob) + 64);
-  typename B::Mem err_mem = be.alloc(64);
   be.upload_small(be.addr(pages_mem), pages.data(), pages.size() * sizeof(PageDesc));
   if (!dicts.empty()) be.upload_small(be.addr(dicts_mem), dicts.data(), dicts.size() * sizeof(DictDesc));
-  if (!jobs.empty()) {
-    // One workgroup per stream, started in array order: the longest streams first (a 1 MB dictionary page next to 160 KB data pages
-    // would otherwise start last and finish alone).  Pages and dictionaries refer to the streams' output addresses, not to job indices.
-    std::vector<DecompJob> ordered(jobs);
-    std::stable_sort(ordered.begin(), ordered.end(), [](const DecompJob& a, const DecompJob& b) { return a.uncomp_size > b.uncomp_size; });
-    be.upload_small(be.addr(jobs_mem), ordered.data(), ordered.size() * sizeof(DecompJob));
-  }
-  be.zero(be.addr(err_mem), 64);
-  uint32_t* err = (uint32_t*)be.addr(err_mem);
 
-  // -- device passes ----------------------------------------------------------------------------------------------------------------------
-  if (!jobs.empty()) {
-    uint64_t bytes_out = 0;
-    for (const DecompJob& j : jobs) bytes_out += j.uncomp_size;
-    be.run_snappy((const DecompJob*)be.addr(jobs_mem), (uint32_t)jobs.size(), bytes_out, err);
-  }
+  // -- device passes (the Snappy streams are already running: launch_snappy) ---------------------------------------------------------------------
   PageDesc* d_pages = (PageDesc*)be.addr(pages_mem);
   be.run_page_prepare(d_pages, n_pages, err);
   // run tables: entries per (page, stream) -> exclusive prefix -> fill

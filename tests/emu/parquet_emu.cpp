@@ -196,7 +196,7 @@ void pqemu_info(void* h, int* dtype, int* logical, int64_t* len, int64_t* null_c
   *dtype = r->col.dtype; *logical = r->col.logical; *len = r->col.len; *null_count = r->col.null_count; *has_validity = r->col.has_validity ? 1 : 0;
   *n_categories = (int64_t)r->categories.size();
   stats6[0] = r->stats.file_bytes; stats6[1] = r->stats.data_pages; stats6[2] = r->stats.dict_pages; stats6[3] = r->stats.snappy_streams;
-  stats6[4] = r->stats.snappy_bytes_out; stats6[5] = r->stats.run_entries;
+  stats6[4] = r->stats.snappy_bytes_out; stats6[5] = r->stats.run_entries; stats6[6] = r->stats.host_inflated_pages; stats6[7] = r->stats.host_inflated_bytes;      // (the caller passes 8 words)
 }
 void pqemu_copy(void* h, void* values, size_t values_bytes, void* validity, size_t validity_bytes) {
   EmuResult* r = (EmuResult*)h;

@@ -64,7 +64,7 @@ def read_column(path, row_groups, column, thread_order=0):
         raise EmuError(rc, l.pqemu_last_error().decode())
     try:
         dt, lg, n, nc, hv, ncat = C.c_int(), C.c_int(), C.c_int64(), C.c_int64(), C.c_int(), C.c_int64()
-        st = (C.c_uint64 * 6)()
+        st = (C.c_uint64 * 8)()
         l.pqemu_info(h, C.byref(dt), C.byref(lg), C.byref(n), C.byref(nc), C.byref(hv), C.byref(ncat), st)
         n = n.value
         nw = (n + 63) // 64
@@ -83,7 +83,7 @@ def read_column(path, row_groups, column, thread_order=0):
             ln = l.pqemu_category(h, i, buf, len(buf))
             cats.append(buf.raw[:ln])
         return {"values": values, "valid": valid, "dtype": dt.value, "logical": lg.value, "null_count": nc.value, "categories": cats,
-                "stats": dict(zip(("file_bytes", "data_pages", "dict_pages", "snappy_streams", "snappy_bytes_out", "run_entries"), [int(x) for x in st])),
+                "stats": dict(zip(("file_bytes", "data_pages", "dict_pages", "snappy_streams", "snappy_bytes_out", "run_entries", "host_inflated_pages", "host_inflated_bytes"), [int(x) for x in st])),
                 "raw_validity_words": vraw if hv.value else None, "raw_value_words": raw if dt.value == 0 else None}
     finally:
         l.pqemu_free(h)

@@ -685,3 +685,24 @@ def test_second_generation_snappy_bodies(tmp_path, monkeypatch):
     pq.write_table(t, path, compression="snappy", row_group_size=3000, data_page_size=2500)
     for name in t.column_names:
         check_column(path, t, name, order=1)
+
+
+def test_long_snappy_dictionary_pages_are_inflated_by_host_threads(tmp_path, monkeypatch):
+    """A Snappy dictionary page of hundreds of kilobytes is ONE stream = one workgroup of the device kernel, 4 KB a round: the launch lasts as long as that stream (round-5
+    review, weak 6).  From 192 KB (PLX_PARQUET_HOST_DICT_BYTES) the reader hands such a page to a host thread while it walks on; the plain values follow the chunk in one upload
+    and the data pages still go through the device kernel.  Same values either way."""
+    rng = np.random.default_rng(8)
+    n = 120_000
+    vals = rng.integers(0, 60_000, n).astype(np.int64) * 1_000_003            # 60 000 distinct values: a 480 KB dictionary page per row group
+    small = rng.integers(0, 50, n).astype(np.int32)
+    nullable = pa.array(vals, mask=rng.random(n) < 0.1)
+    t = pa.table({"big": vals, "small": small, "bign": nullable})
+    path = str(tmp_path / "d.parquet")
+    pq.write_table(t, path, compression="snappy", row_group_size=60_000, dictionary_pagesize_limit=4 << 20)
+    r = check_column(path, t, "big")
+    assert r["stats"]["host_inflated_pages"] == 2 and r["stats"]["snappy_streams"] > 0, r["stats"]        # two row groups: two long dictionary pages on the host, the data pages on the device
+    assert check_column(path, t, "bign")["stats"]["host_inflated_pages"] == 2
+    assert check_column(path, t, "small")["stats"]["host_inflated_pages"] == 0                          # a 200-byte dictionary stays a device stream
+    monkeypatch.setenv("PLX_PARQUET_HOST_DICT_BYTES", "0")
+    r0 = check_column(path, t, "big")
+    assert r0["stats"]["host_inflated_pages"] == 0 and r0["stats"]["snappy_streams"] == r["stats"]["snappy_streams"] + 2

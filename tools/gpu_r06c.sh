@@ -1,13 +1,13 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r06c
-timeout 1200 python -m pytest tests/test_gpu_join_duplicate_keys.py tests/test_gpu_join_partitioned.py -x -q -m gpu 2>&1 | tail -15
-PLX_BENCH_EXTRAS=q3d PLX_BENCH_Q3_SHUFFLED=0 PLX_BENCH_E2E=0 PLX_BENCH_SCAN=0 PLX_BENCH_DEADLINE_S=900 timeout 1200 python bench.py --steps 5 --warmup 2 --no-cpu > gpurun_out/r06c/bench.log 2> gpurun_out/r06c/bench.err
-tail -c 1500 gpurun_out/r06c/bench.err
-python - <<'PY'
-import json
-d=json.load(open('bench_extras.json'))
-for k,v in d.get('extras',{}).items():
-    print(k, json.dumps({a:b for a,b in v.items() if a in ('ms_per_step','cold_first_step_ms','step_ms','result_rows','kernels','verified','error','result_download_ms')})[:1500])
-    print('   frac', (v.get('roofline') or {}).get('frac'))
+timeout 1200 python -m pytest tests/test_gpu_parquet.py tests/test_gpu_zzz_scan_host_paths.py tests/test_gpu_scan_strings.py tests/test_gpu_io.py -x -q -m gpu 2>&1 | tail -4
+for B in 0 20 40 64 1000; do
+PLX_PARQUET_SNAPPY_BATCH=$((B * 1048576)) python - <<PY
+import json, os, bench, polars_amd as pl
+pl.init(0)
+r = bench.scan_extra(pl, 20_000_000)
+f = r["files"]
+print("batch MB", os.environ.get("PLX_PARQUET_SNAPPY_BATCH"), {k: (v["read_ms"], v.get("kernel_us", {}).get("pq_snappy")) for k, v in f.items()})
 PY
+done
