@@ -22,7 +22,7 @@ SCOPES = [  # (regex on the demangled kernel name, ProfileScope name in bench.py
     (r"scan_block_kernel|scan_add_kernel|scan_", "exclusive_scan"), (r"gather_multi_kernel", "gather_multi"), (r"gather_multi_kernel", "gather_multi"), (r"gather_kernel", "gather_u32"), (r"finalize_batch_kernel", "finalize_batch"),
     (r"datagen_uniform_kernel<long", "datagen_uniform_i64"), (r"datagen_", "datagen_other"), (r"hot_candidates_kernel|hot_emit_kernel", "hot_keys"),
     (r"strgroup_scatter_kernel", "strgroup_scatter"), (r"strgroup_agg_kernel", "strgroup_agg_lds"),
-    (r"canonicalise_chains_kernel", "join_chain_representatives"), (r"rows_agg_compact_kernel|wide_compact_kernel", "table_compact"),
+    (r"canonicalise_chains_kernel", "join_chain_representatives"), (r"chains_count_kernel|chains_emit_kernel", "table_compact"), (r"rows_agg_compact_kernel|wide_compact_kernel", "table_compact"),
     (r"fused_scan_kernel<.*WideAggSink", "fused_scan_wideagg"),
     (r"compact_by_ballots_kernel", "filter_compact_cols"), (r"join_match_kernel", "join_match"), (r"join_pairs_emit_kernel", "join_pairs_emit"), (r"filter_rowids_kernel", "filter_rowids"),
     (r"filter_kernel<", "filter_compact"), (r"tile_count_kernel", "filter_tile_count"), (r"ballots_to_mask_kernel", "ballots_to_mask"),
@@ -107,6 +107,8 @@ def main():
             n = max(n // 2, 1)          # two kernels per pass of the chunk sort
         if sc == "direct_rank":
             n = max(n // 2, 1)
+        if sc == "table_compact" and any("chains_count_kernel" in k for k in e["kernel_names"]):
+            n = max(n // 2, 1)          # the multi-value compaction is two kernels (count, emit) under one tracer scope
         f, w = e["fetch_KB"] / n, e["write_KB"] / n
         res[sc] = {"fetch_KB": round(f, 1), "write_KB": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024), "launches_seen": e["launches"], "kernel_names": e["kernel_names"]}
     cal = res.get("datagen_uniform_i64")
