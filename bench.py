@@ -2373,7 +2373,11 @@ def run(args, emit):
                     extras[w2.name]["result_rows"] = int(r2.height)
                     if not getattr(w2, "big_result", False) and hasattr(r2, "_download_all"):
                         # a collect() of the reference ends with a host frame; these steps leave theirs in HBM -- what the download adds, measured beside `ms` (round-5 review, weak 8)
-                        t_dl = time.perf_counter(); r2._download_all(); extras[w2.name]["result_download_ms"] = round((time.perf_counter() - t_dl) * 1e3, 3)
+                        dls = []
+                        for _ in range(2):      # (the first download of a result also pays for the fresh numpy arrays it lands in: first-touch page faults of tens of MB)
+                            t_dl = time.perf_counter(); r2._download_all(); dls.append((time.perf_counter() - t_dl) * 1e3)
+                        extras[w2.name]["result_download_ms"] = round(min(dls), 3)
+                        extras[w2.name]["result_download_first_ms"] = round(dls[0], 3)
                 if os.environ.get("PLX_BENCH_VERIFY", "1") != "0":
                     pending_checks.append((w2.name, w2.verify, r2))       # checked after every secondary workload has been timed (below)
                 del w2, r2
