@@ -2241,9 +2241,82 @@ static bool fused_join_frame(Plan& plan, const IRN& jn, const std::set<std::stri
     cs.add_agg(AGG_FIRST_ROW, -1);
     cs.finish();
   } catch (const Unsupported& u) { if (why) *why = u.why; return false; }
+  // ---- direct-address table when the build keys have a dense range (cached column statistics): a bitmap over the key range + a rank per word + slot -> build row.  Probe
+  // keys in key order walk the bitmap out of the L2 (the hits come out of the probe scan itself, in ballot form: DirectHitsSink); keys in no order are partitioned first
+  // (k::partitioned_probe_hits).  Two pairs on one bit = duplicate build keys -> the hash-table pipeline below (chains).
+  uint64_t nb = 0;
+  bool done_direct = false, multi = B->height > 0 && B->cols[bki]->repeats_as_build_key;
+  ColumnPtr pidx, bidx;
+  std::string cand_how, pd, table_how;
+  const int pmode = partitioned_probe_mode();
+  int64_t kmn = 0, kmx = 0;
+  if (!(plan.flags & PLX_PLAN_NO_DIRECT_JOIN) && !multi && B->height > 0 && kdt != PLX_U64 && ops::int_range(B->cols[bki], &kmn, &kmx)) {
+    const unsigned __int128 range128 = (unsigned __int128)((__int128)kmx - (__int128)kmn) + 1;
+    const uint64_t ord_cap = (uint64_t)B->height + (uint64_t)k::scan_waves(B->height) * 1024 + 1024;
+    if (range128 <= ((unsigned __int128)1 << 34) && range128 <= (unsigned __int128)B->height * 256 && ord_cap < 0xfffffff0ull) {
+      const uint64_t range = (uint64_t)range128;
+      const size_t n_words = (size_t)(range / 512 + 1) * 8;
+      Buf bits = dev_alloc_zero(sizeof(uint64_t) * n_words), rank = dev_alloc(sizeof(uint32_t) * n_words);
+      Buf okey = dev_alloc(sizeof(uint64_t) * ord_cap), orow = dev_alloc(sizeof(uint32_t) * ord_cap), used = dev_alloc_zero(sizeof(uint32_t) * (ord_cap / 1024 + 2));
+      Buf meta = dev_alloc_zero(32);
+      DirectJoinTable dt{}; dt.bits = bits->as<unsigned long long>(); dt.rank = rank->as<unsigned int>(); dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>();
+      dt.chunk_used = used->as<unsigned int>(); dt.counter = meta->as<unsigned int>(); dt.flags = meta->as<unsigned int>() + 2; dt.acc = nullptr; dt.kmin = kmn; dt.range = range; dt.n_ord = (unsigned int)ord_cap;
+      k::fused_direct_build(cb.shape, cb.args, dt, find_static_shape(cb.shape));
+      uint64_t pairs = 0;
+      nb = k::direct_rank(dt, rank->as<uint32_t>(), (int64_t)ord_cap, meta->as<uint64_t>() + 2, &pairs);
+      uint32_t m4[4] = {0, 0, 0, 0};
+      d2h_sync(m4, meta->ptr, 16);
+      PLX_REQUIRE(!m4[3], PLX_ERR_INVALID, "direct join build: ordinal overflow");
+      if (pairs != nb) { multi = true; B->cols[bki]->repeats_as_build_key = true; }
+      else {
+        Buf slot_row = dev_alloc(sizeof(uint32_t) * (size_t)std::max<uint64_t>(nb, 1));
+        k::direct_slot_rows(dt, (int64_t)std::min<uint64_t>(m4[0], ord_cap), slot_row->as<uint32_t>());
+        ColumnPtr cand;
+        if (!left_join) {
+          const ColumnPtr& pk = P->cols[pki];
+          if (pmode == 2 || (pmode == 1 && P->height >= ((int64_t)1 << 24) && range >= ((uint64_t)1 << 28) && nb * 8 <= range)) {
+            if (pk->order_state == 0) pk->order_state = k::sample_sortedness(pk) >= 0.9 ? 1 : 2;
+            std::string ppd;
+            if ((pmode == 2 || pk->order_state == 2) && k::partitioned_probe_hits(cs.shape, cs.args, dt, nb, find_static_shape(cs.shape), &cand, &ppd)) cand_how = ppd;
+            else cand = nullptr;
+          }
+          if (!cand) {
+            // the probe scan itself: predicate + bitmap test per row, ballots out; the hit rows' indices from the ballots (every one of them matches)
+            const int64_t np = P->height, n_wt = (np + 127) / 128;
+            cand = std::make_shared<Column>();
+            cand->dtype = PLX_U32; cand->null_count = 0; cand->len = 0; cand->values = dev_alloc(8);
+            if (np > 0) {
+              Buf ballots = dev_alloc(sizeof(uint64_t) * 2 * (size_t)n_wt), counts = dev_alloc(sizeof(uint32_t) * (size_t)n_wt);
+              const int sid = find_static_shape(cs.shape);
+              k::fused_direct_hits(cs.shape, cs.args, dt, BallotOut{ballots->as<unsigned long long>(), counts->as<unsigned int>()}, sid);
+              const k::Selection sel = k::selection_finish(ballots, counts, np);
+              cand->len = sel.n_out;
+              cand->values = dev_alloc(values_bytes(PLX_U32, std::max<int64_t>(sel.n_out, 1)));
+              k::compact_by_ballots(sel, k::CompactCols{}, cand->values->as<uint32_t>());
+              PLX_HIP(hipStreamSynchronize(stream()));
+              cand_how = std::string("fused_scan[") + jit::program_mode(sid, np) + "]+direct hits (ballots -> row ids)";
+            }
+          }
+        } else if (!ppreds.empty()) {
+          FramePtr none; std::string fwhy;
+          const size_t mark = plan.desc.size();
+          if (!fused_filter_frame(plan, ppreds, P, none, &fwhy, &cand, true)) { if (why) *why = "probe-side predicate: " + fwhy; return false; }
+          cand_how = "probe rows by " + plan.desc.substr(mark);
+          plan.desc.resize(mark);
+          while (!cand_how.empty() && (cand_how.back() == ' ' || cand_how.back() == ';')) cand_how.pop_back();
+        } else cand_how = "every probe row";
+        join::join_pairs_direct(jn.how, P->cols[pki], cand, dt, slot_row->as<uint32_t>(), pidx, bidx, &pd);
+        PLX_HIP(hipStreamSynchronize(stream()));
+        table_how = "direct-address table range=" + std::to_string(range) + " (bitmap + rank + slot rows) unique-keys";
+        done_direct = true;
+      }
+    }
+  }
+  if (build_rows_out && done_direct) *build_rows_out = nb;
+  if (build_side_out) *build_side_out = build_right ? 1 : 0;
+  if (!done_direct) {
   // ---- build (the hash-table pipeline of fused_join_groupby: sized from a strided sample of the count program, rebuilt once if the sample misjudged; duplicate keys -> chains)
   auto exact_count = [&]() -> uint64_t { std::vector<uint64_t> host(kMaxAggs, 0); k::fused_regagg(cnt.shape, cnt.args, find_static_shape(cnt.shape), host.data()); return host[0]; };
-  uint64_t nb = 0;
   bool sized_by_sample = false;
   if (B->height > 0) {
     if (B->height >= ((int64_t)1 << 24)) {
@@ -2265,7 +2338,7 @@ static bool fused_join_frame(Plan& plan, const IRN& jn, const std::set<std::stri
   JoinAggTable t{};
   int log2_cap = 4;
   uint64_t cap = 0;
-  bool multi = B->height > 0 && B->cols[bki]->repeats_as_build_key, resized = false;
+  bool resized = false;
   for (int attempt = 0; attempt < 4; attempt++) {
     if (multi && !links) links = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(B->height, 1));
     log2_cap = std::max(8, ceil_log2_u64((uint64_t)((double)std::max<uint64_t>(nb, 1) * (sized_by_sample ? 1.6 : 2.0))));
@@ -2286,11 +2359,8 @@ static bool fused_join_frame(Plan& plan, const IRN& jn, const std::set<std::stri
     break;
   }
   if (build_rows_out) *build_rows_out = nb;
-  if (build_side_out) *build_side_out = build_right ? 1 : 0;
   // ---- candidates
   ColumnPtr cand;
-  std::string cand_how;
-  const int pmode = partitioned_probe_mode();
   if (!left_join && (pmode == 2 || (pmode == 1 && P->height >= ((int64_t)1 << 24) && (cap + 1) * 16 > ((uint64_t)64 << 20) && nb * 16 <= (uint64_t)P->height))) {
     std::string pd;
     if (k::partitioned_hash_probe_hits(cs.shape, cs.args, t, nb, find_static_shape(cs.shape), &cand, &pd)) cand_how = pd;
@@ -2306,9 +2376,10 @@ static bool fused_join_frame(Plan& plan, const IRN& jn, const std::set<std::stri
   }
   if (!cand && cand_how.empty()) cand_how = "every probe row";
   // ---- pairs
-  ColumnPtr pidx, bidx;
-  std::string pd;
   join::join_pairs(jn.how, P->cols[pki], cand, t, pidx, bidx, &pd);
+  PLX_HIP(hipStreamSynchronize(stream()));
+  table_how = "hash table cap=2^" + std::to_string(log2_cap) + (multi ? " multi-value (row chains)" : " unique-keys");
+  }  // hash-table pipeline
   // ---- payload: one multi-column gather per side
   const ColumnPtr& lidx = build_right ? pidx : bidx;
   const ColumnPtr& ridx = build_right ? bidx : pidx;
@@ -2334,9 +2405,8 @@ static bool fused_join_frame(Plan& plan, const IRN& jn, const std::set<std::stri
     }
   }
   PLX_HIP(hipStreamSynchronize(stream()));
-  plan.desc += std::string("FusedJoinFrame{") + (left_join ? "left" : "inner") + ", build=" + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " hash table cap=2^" +
-               std::to_string(log2_cap) + (multi ? " multi-value (row chains)" : " unique-keys") + ", probe rows=" + std::to_string(P->height) + ", candidates: " + cand_how + ", " + pd + ", gather x" +
-               std::to_string(n_gathered) + "}; ";
+  plan.desc += std::string("FusedJoinFrame{") + (left_join ? "left" : "inner") + ", build=" + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " " + table_how +
+               ", probe rows=" + std::to_string(P->height) + ", candidates: " + cand_how + ", " + pd + ", gather x" + std::to_string(n_gathered) + "}; ";
   return true;
 }
 

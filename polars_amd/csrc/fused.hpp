@@ -504,6 +504,20 @@ struct DirectJoinTable {
 };
 constexpr unsigned int kDirectLateLoads = 1u;   // probe: columns only the aggregates read are loaded under the hit mask (split_program)
 
+// The selection of a filter -> frame as the predicate scan leaves it (fused_sinks.hpp BallotSink): per 128-row wave tile t the two ballots of its rows (lane l of the
+// wave holds rows 2l and 2l + 1: ballots[2t] = rows of even parity, ballots[2t + 1] = odd) and the number of kept rows.
+struct BallotOut {
+  unsigned long long* ballots;     // [n_wave_tiles][2]
+  unsigned int* counts;            // [n_wave_tiles]
+};
+
+// Probe side of a join against a direct-address table, hits only: per 128-row wave tile the ballots of the rows that pass the probe predicate AND whose key's bit is set
+// (fused_sinks.hpp DirectHitsSink) -- the exact candidate rows of the materialising join when the probe keys arrive in key order (the bitmap is then walked out of the L2).
+struct DirectHits {
+  DirectJoinTable t;
+  BallotOut out;
+};
+
 // Semi-join filter side reduced to a bitmap over its key range (an inner join whose one side has unique keys and contributes
 // no column downstream only FILTERS the other side): the scan of the filter side sets bit (key - kmin) of every row that passes
 // its predicate and counts those rows (fewer set bits than rows = duplicate keys: the rewrite does not apply).
@@ -512,13 +526,6 @@ struct BitmapBuild {
   unsigned long long* count;     // [0] rows inserted
   long long kmin;
   unsigned long long range;
-};
-
-// The selection of a filter -> frame as the predicate scan leaves it (fused_sinks.hpp BallotSink): per 128-row wave tile t the two ballots of its rows (lane l of the
-// wave holds rows 2l and 2l + 1: ballots[2t] = rows of even parity, ballots[2t + 1] = odd) and the number of kept rows.
-struct BallotOut {
-  unsigned long long* ballots;     // [n_wave_tiles][2]
-  unsigned int* counts;            // [n_wave_tiles]
 };
 
 // Direct-address aggregation (dense keys in [key_min, key_min + n_groups)): acc[(G+1)*n_aggs],

@@ -488,6 +488,30 @@ struct BitmapBuildSink {
   }
 };
 
+// ---- sink: the rows of a probe side that hit a direct-address join table, in ballot form (DirectHits) -----------------------------------------
+struct DirectHitsSink {
+  using Params = DirectHits;
+  template <class S> __device__ __forceinline__ void init(const S&, const Params&) {}
+  template <class S> __device__ __forceinline__ void finish(const S&, const Params&) {}
+  template <class S, class RF> __device__ __forceinline__ void consume(const S& sh, const RF& rf, const bool pass[kRows], int64_t row0, const Params& p) {
+    bool hit[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      bool ok = pass[r] && ((rf.getv(sh.key) >> r) & 1);            // null keys never match
+      const uint64_t idx = rf.get(r, sh.key) - (uint64_t)p.t.kmin;
+      ok = ok && idx < p.t.range;
+      if (ok) ok = (p.t.bits[idx >> 6] >> (idx & 63)) & 1ull;
+      hit[r] = ok;
+    }
+    const unsigned long long b0 = ballot(hit[0]), b1 = ballot(hit[1]);
+    if (lane_id() == 0) {
+      const int64_t t = row0 / kTileRows;
+      *reinterpret_cast<ulonglong2*>(p.out.ballots + t * 2) = make_ulonglong2(b0, b1);
+      p.out.counts[t] = (unsigned int)(popc64(b0) + popc64(b1));
+    }
+  }
+};
+
 // AOT / JIT probe scan with late materialisation: predicate + key for the tile, bitmap test, then the rest of the program for
 // the lanes that hit (DirectJoinTable::opts & kDirectLateLoads; without it runs the whole program up front like every other sink)
 template <class P, bool FULL>

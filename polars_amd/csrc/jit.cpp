@@ -36,6 +36,7 @@ const char* sink_type(Sink s) {
   static const char* n[] = {"RegAggSink", "LdsAggSink", "DenseAggSink", "HashAggSink", "WideAggSink", "JoinBuildSink", "ProbeAggSink", "DirectBuildSink", "DirectProbeAggSink", "BitmapBuildSink",
                             "part_count", "part_scatter", "part_agg", "part2_scatter_hash", "part2_scatter_direct", "part2_agg_hash", "part2_agg_direct", "part2_scatter_hash_t2", "part2_scatter_direct_t2"};
   if (s == BALLOT) return "BallotSink";
+  if (s == DIRECT_HITS) return "DirectHitsSink";
   if (s >= PART3_AGG) return "part3_agg";
   if (s >= PART3_SCATTER) return "part3_scatter";
   return n[s];
@@ -88,7 +89,7 @@ std::string source_for(const Shape& sh, Sink sink) {
   std::ostringstream o;
   const std::string sym = kernel_symbol(sh, sink);
   o << "#define plx_jit_kernel " << sym << "\n";
-  o << (sink == BALLOT ? "#include \"fused_sinks.hpp\"\n" : sink >= PART3_SCATTER ? "#include \"partition3_device.hpp\"\n" : sink >= PART2_SCATTER_HASH ? "#include \"partition2_device.hpp\"\n" : sink >= PART_COUNT ? "#include \"partition_device.hpp\"\n" : "#include \"fused_sinks.hpp\"\n") << "namespace plx { namespace k {\n"
+  o << ((sink == BALLOT || sink == DIRECT_HITS) ? "#include \"fused_sinks.hpp\"\n" : sink >= PART3_SCATTER ? "#include \"partition3_device.hpp\"\n" : sink >= PART2_SCATTER_HASH ? "#include \"partition2_device.hpp\"\n" : sink >= PART_COUNT ? "#include \"partition_device.hpp\"\n" : "#include \"fused_sinks.hpp\"\n") << "namespace plx { namespace k {\n"
        "struct JitProg {\n  static constexpr bool kStatic = true; static constexpr int kId = -2;\n  static constexpr Shape shape() {\n    Shape s{};\n";
   o << "    s.n_inputs = " << (int)sh.n_inputs << "; s.n_ops = " << (int)sh.n_ops << "; s.n_aggs = " << (int)sh.n_aggs << "; s.pred = " << (int)sh.pred
     << "; s.key = " << (int)sh.key << "; s.n_keys = " << (int)sh.n_keys << ";\n";
@@ -122,14 +123,14 @@ std::string source_for(const Shape& sh, Sink sink) {
            "  part2_agg_body<Shape, " << (sink == PART2_AGG_DIRECT ? 1 : 0) << ", p2_agg_chunks_in_flight(cl.rec_words)>(csh, cl, pp, ap);\n}\n}}\n";
       break;
     default:
-      if (sink >= PART3_AGG && sink != BALLOT) {
+      if (sink >= PART3_AGG && sink != BALLOT && sink != DIRECT_HITS) {
         const int v = (int)sink - (int)PART3_AGG, mode = v & 1, pack = v >> 1;
         o << "extern \"C\" __global__ __launch_bounds__(kP2AggBlock) void plx_jit_kernel(PartPlan2 pp, AggParams2 ap) {\n"
              "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout2 cl = rec_layout2(JitProg::shape(), " << mode << "u, " << pack << "u);\n"
              "  part2_agg_body<Shape, " << mode << ", p2_agg_chunks_in_flight(cl.rec_words)>(csh, cl, pp, ap);\n}\n}}\n";
         break;
       }
-      if (sink >= PART3_SCATTER && sink != BALLOT) {
+      if (sink >= PART3_SCATTER && sink != BALLOT && sink != DIRECT_HITS) {
         const int v = (int)sink - (int)PART3_SCATTER, mode = v & 1, tiles = 1 + ((v >> 1) & 3), pack = (v >> 3) & 3, hot = v >> 5;
         o << "extern \"C\" __global__ __launch_bounds__(kP2MaxBlock) void plx_jit_kernel(Shape dsh, Args args, PartPlan2 pp, ScatterParams2 sp) {\n"
              "  part3_scatter_body<JitProg, " << mode << ", " << tiles << ", " << pack << ", " << (hot ? "true" : "false") << ">(dsh, args, pp, sp);\n}\n}}\n";

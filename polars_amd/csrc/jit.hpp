@@ -29,6 +29,7 @@ enum Sink { REGAGG = 0, LDSAGG, DENSE, HASH, WIDE, JOIN_BUILD, PROBE_AGG, DIRECT
             // the selection of a filter -> frame in ballot form (fused_sinks.hpp BallotSink; a plain scan sink, launched with launch()).  New kinds go HERE, at the
             // end: the number is part of the kernel symbols the tracers key their rows by
             BALLOT = PART3_AGG + 8,
+            DIRECT_HITS,        // fused_sinks.hpp DirectHitsSink (params = fused::DirectHits)
             kNumSinks };
 inline Sink part3_scatter_sink(uint32_t mode, uint32_t tiles, uint32_t pack, bool hot) { return (Sink)(PART3_SCATTER + mode + 2 * (tiles - 1) + 8 * pack + (hot ? 32 : 0)); }
 inline Sink part3_agg_sink(uint32_t mode, uint32_t pack) { return (Sink)(PART3_AGG + mode + 2 * pack); }

@@ -18,6 +18,10 @@ void join_indices(int how, const ColumnPtr& left_key, const ColumnPtr& right_key
 // list of probe rows (`cand`: PLX_U32, null = every row of probe_key).  Pair order = candidate order; a left join keeps every candidate (build_idx nullable).
 void join_pairs(int how, const ColumnPtr& probe_key, const ColumnPtr& cand, const fused::JoinAggTable& t, ColumnPtr& probe_idx, ColumnPtr& build_idx, std::string* desc);
 
+// the same against a direct-address build table (unique build keys over a dense range: bitmap + rank, fused::DirectJoinTable) and its slot -> build row map
+void join_pairs_direct(int how, const ColumnPtr& probe_key, const ColumnPtr& cand, const fused::DirectJoinTable& dt, const uint32_t* slot_row, ColumnPtr& probe_idx, ColumnPtr& build_idx,
+                       std::string* desc);
+
 // HashPartitioner (polars-utils/src/hashing.rs:72-121): rows grouped by partition.
 void hash_partition(const ColumnPtr& key, int n_partitions, uint64_t seed, ColumnPtr& perm, int64_t* counts_out);
 // same, the per-partition row counts stay on the device ([n_partitions] u64): no host round trip (the exchange all-gathers them)

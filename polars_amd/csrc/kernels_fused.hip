@@ -156,6 +156,35 @@ void fused_ballots(const Shape& sh, const Args& args, const BallotOut& out, int 
   PLX_HIP(hipGetLastError());
 }
 
+// probe rows that pass the probe program's predicate and hit the direct-address table `t` -> ballots + counts per wave tile (fused_sinks.hpp DirectHitsSink)
+void fused_direct_hits(const Shape& sh, const Args& args, const DirectJoinTable& t, const BallotOut& out, int static_id) {
+  if (args.n_rows == 0) return;
+  ProfileScope ps(scope_name("fused_scan_direct_hits_static", "fused_scan_direct_hits", static_id).c_str(), algo_bytes(sh, args), (uint64_t)args.n_rows);
+  const int grid = scan_grid(args.n_rows, 8, "PLX_BPC_DIRECT_HITS");
+  DirectHits p{t, out};
+  switch (static_id) {
+#ifdef PLX_HAVE_Q3_PROBE_SCATTER
+    case SHAPE_Q3_PROBE_SCATTER: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_PROBE_SCATTER>, DirectHitsSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, p); break;
+#endif
+    default: if (!jit::launch(sh, args, jit::DIRECT_HITS, &p, grid, 0)) { const DynLaunch d = dyn_launch(sh, args, 0); hipLaunchKernelGGL((fused_scan_kernel<DynProg, DirectHitsSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, p); } break;
+  }
+  PLX_HIP(hipGetLastError());
+}
+// slot (rank of the key in key order) -> build row, from the pair list of a direct-address build with unique keys
+__global__ __launch_bounds__(kBlock) void direct_slot_rows_kernel(DirectJoinTable t, int64_t n_used, unsigned int* __restrict__ slot_row) {
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_used; o += (int64_t)gridDim.x * blockDim.x) {
+    if ((unsigned int)(o % kOrdChunk) >= t.chunk_used[o / kOrdChunk]) continue;      // unused tail of a reserved chunk
+    const unsigned long long idx = t.ord_key[o] - (unsigned long long)t.kmin;
+    slot_row[direct_slot(t, idx, t.bits[idx >> 6])] = t.ord_row[o];
+  }
+}
+void direct_slot_rows(const DirectJoinTable& t, int64_t n_used, uint32_t* slot_row) {
+  if (n_used == 0) return;
+  ProfileScope ps("direct_slot_rows", (uint64_t)n_used * 28, (uint64_t)n_used);
+  hipLaunchKernelGGL(direct_slot_rows_kernel, dim3(grid_for(n_used, kBlock * 4)), dim3(kBlock), 0, stream(), t, n_used, (unsigned int*)slot_row);
+  PLX_HIP(hipGetLastError());
+}
+
 int lds_agg_copies(int n_groups, int n_aggs) {
   const size_t budget = 60 * 1024;  // leaves room for 2 workgroups per CU of the 160 KiB LDS
   int c = 16;

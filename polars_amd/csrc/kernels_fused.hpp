@@ -48,6 +48,10 @@ void fused_bitmap_build(const fused::Shape& sh, const fused::Args& args, const f
 // direct-address variants (DirectJoinTable)
 void fused_direct_build(const fused::Shape& sh, const fused::Args& args, const fused::DirectJoinTable& t, int static_id);
 void fused_direct_probe_agg(const fused::Shape& sh, const fused::Args& args, const fused::DirectJoinTable& t, int static_id);
+// probe rows that pass `sh`'s predicate and whose key's bit is set in `t`: ballots + counts per 128-row wave tile (kernels.hpp selection_finish / compact_by_ballots)
+void fused_direct_hits(const fused::Shape& sh, const fused::Args& args, const fused::DirectJoinTable& t, const fused::BallotOut& out, int static_id);
+// slot_row[rank of a build key in key order] = its build row (unique build keys; after direct_rank)
+void direct_slot_rows(const fused::DirectJoinTable& t, int64_t n_used, uint32_t* slot_row);
 // rank step (popcount per 512-bit block, exclusive scan over the blocks, u32 rank per word into rank_out[(range/512 + 1) * 8]);
 // returns the number of set bits and, in *pairs_out, the pairs the build scan appended (n_pairs_dev: a zeroed device word); more
 // pairs than bits = duplicate build keys (synchronises)

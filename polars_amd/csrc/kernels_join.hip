@@ -214,8 +214,19 @@ void join_indices(int how, const ColumnPtr& left_key, const ColumnPtr& right_key
 // partitioned LDS filters of kernels_partition.hip (probe_hits_impl), a few per cent of the probe side for a selective build -- so the only random walk through
 // HBM is one slot lookup per candidate, once: pass 1 leaves the build row (or chain head) and the pair count of every candidate, the pairs are then laid out by a
 // device scan (duplicate keys / left joins) or by the selection-bitmap compaction of kernels_filter.hip (unique keys: 0 / 1 pairs per candidate) -- no second probe.
-struct PairTable { const unsigned long long* slots; const unsigned long long* links; uint32_t log2_cap; };
+struct PairTable {
+  const unsigned long long* slots; const unsigned long long* links; uint32_t log2_cap;
+  // direct-address variant (bits != null; unique build keys): bitmap over the key range + rank per word + slot -> build row (fused::DirectJoinTable, k::direct_slot_rows)
+  const unsigned long long* bits; const unsigned int* rank; const unsigned int* slot_row; long long kmin; unsigned long long range;
+};
 __device__ __forceinline__ unsigned int pair_lookup(const PairTable& t, uint64_t key) {
+  if (t.bits) {                                   // wave-uniform
+    const uint64_t idx = key - (uint64_t)t.kmin;
+    if (idx >= t.range) return kNoRow;
+    const unsigned long long w = t.bits[idx >> 6];
+    if (!((w >> (idx & 63)) & 1ull)) return kNoRow;
+    return t.slot_row[(unsigned long long)t.rank[idx >> 6] + (unsigned long long)__popcll(w & ((1ull << (idx & 63)) - 1ull))];
+  }
   const uint64_t cap = 1ull << t.log2_cap;
   if (key == fused::kEmptyKey) return (unsigned int)t.slots[cap * 2 + 1];                   // the key equal to the EMPTY pattern lives in slot `cap` (row kNoRow when absent)
   uint64_t slot = (key * fused::kP2HashMult) >> (64 - t.log2_cap);
@@ -264,10 +275,20 @@ __global__ __launch_bounds__(kBlock) void iota_u32_kernel(uint32_t* __restrict__
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (uint32_t)i;
 }
 
+static void join_pairs_impl(int how, const ColumnPtr& probe_key, const ColumnPtr& cand, const PairTable& t, ColumnPtr& probe_idx, ColumnPtr& build_idx, std::string* desc);
 void join_pairs(int how, const ColumnPtr& probe_key, const ColumnPtr& cand, const fused::JoinAggTable& jt, ColumnPtr& probe_idx, ColumnPtr& build_idx, std::string* desc) {
+  PairTable t{}; t.slots = jt.slots; t.links = jt.links; t.log2_cap = jt.log2_cap;
+  join_pairs_impl(how, probe_key, cand, t, probe_idx, build_idx, desc);
+}
+void join_pairs_direct(int how, const ColumnPtr& probe_key, const ColumnPtr& cand, const fused::DirectJoinTable& dt, const uint32_t* slot_row, ColumnPtr& probe_idx, ColumnPtr& build_idx,
+                       std::string* desc) {
+  PairTable t{}; t.bits = dt.bits; t.rank = dt.rank; t.slot_row = slot_row; t.kmin = dt.kmin; t.range = dt.range;
+  join_pairs_impl(how, probe_key, cand, t, probe_idx, build_idx, desc);
+}
+static void join_pairs_impl(int how, const ColumnPtr& probe_key, const ColumnPtr& cand, const PairTable& t, ColumnPtr& probe_idx, ColumnPtr& build_idx, std::string* desc) {
   PLX_REQUIRE(how == PLX_JOIN_INNER || how == PLX_JOIN_LEFT, PLX_ERR_UNSUPPORTED, "join_pairs: inner and left joins");
   PLX_REQUIRE(probe_key->len < 0xffffffffll, PLX_ERR_UNSUPPORTED, "join side exceeds u32 IdxSize");
-  const bool left = how == PLX_JOIN_LEFT, multi = jt.links != nullptr;
+  const bool left = how == PLX_JOIN_LEFT, multi = t.links != nullptr;
   const int64_t n = cand ? cand->len : probe_key->len;
   auto mk_idx = [&](int64_t m) { auto c = std::make_shared<Column>(); c->dtype = PLX_U32; c->len = m; c->values = dev_alloc(values_bytes(PLX_U32, std::max<int64_t>(m, 1))); c->null_count = 0; return c; };
   auto null_out_no_row = [&](ColumnPtr& bidx) {          // unmatched rows of a left join carry the kNoRow sentinel -> validity bitmap
@@ -278,7 +299,6 @@ void join_pairs(int how, const ColumnPtr& probe_key, const ColumnPtr& cand, cons
     if (column_null_count(bidx) == 0) { bidx->validity = nullptr; bidx->null_count = 0; }
   };
   if (n == 0) { probe_idx = mk_idx(0); build_idx = mk_idx(0); if (desc) *desc = "join_pairs[no candidates]"; return; }
-  PairTable t; t.slots = jt.slots; t.links = jt.links; t.log2_cap = jt.log2_cap;
   const uint32_t* cp = cand ? cand->values->as<uint32_t>() : nullptr;
   const int kw = dtype_width(probe_key->dtype) ? dtype_width(probe_key->dtype) : 1;
   ColumnPtr head = mk_idx(n);
@@ -323,7 +343,7 @@ void join_pairs(int how, const ColumnPtr& probe_key, const ColumnPtr& cand, cons
     if (left) null_out_no_row(build_idx);
     PLX_HIP(hipStreamSynchronize(stream()));
   }
-  if (desc) *desc = std::string("join_pairs[") + (cand ? "candidates=" : "rows=") + std::to_string(n) + (multi ? ", multi-value chains" : ", unique build keys") + " -> match" +
+  if (desc) *desc = std::string("join_pairs[") + (cand ? "candidates=" : "rows=") + std::to_string(n) + (multi ? ", multi-value chains" : t.bits ? ", direct-address table" : ", unique build keys") + " -> match" +
                     (counted ? "+scan+emit" : left ? "" : "+bitmap compaction") + ", pairs=" + std::to_string(total) + "]";
 }
 

@@ -24,7 +24,7 @@ SCOPES = [  # (regex on the demangled kernel name, ProfileScope name in bench.py
     (r"strgroup_scatter_kernel", "strgroup_scatter"), (r"strgroup_agg_kernel", "strgroup_agg_lds"),
     (r"canonicalise_chains_kernel", "join_chain_representatives"), (r"chains_count_kernel|chains_emit_kernel", "table_compact"), (r"rows_agg_compact_kernel|wide_compact_kernel", "table_compact"),
     (r"fused_scan_kernel<.*WideAggSink", "fused_scan_wideagg"),
-    (r"compact_by_ballots_kernel", "filter_compact_cols"), (r"join_match_kernel", "join_match"), (r"join_pairs_emit_kernel", "join_pairs_emit"), (r"filter_rowids_kernel", "filter_rowids"),
+    (r"compact_by_ballots_kernel", "filter_compact_cols"), (r"join_match_kernel", "join_match"), (r"join_pairs_emit_kernel", "join_pairs_emit"), (r"filter_rowids_kernel|ballots_to_rowids_kernel", "filter_rowids"), (r"direct_slot_rows_kernel", "direct_slot_rows"), (r"fused_scan_kernel<.*DirectHitsSink", "fused_scan_direct_hits_static"),
     (r"filter_kernel<", "filter_compact"), (r"tile_count_kernel", "filter_tile_count"), (r"ballots_to_mask_kernel", "ballots_to_mask"),
     (r"init_acc_kernel|fill_u64_kernel", "table_init"), (r"strview_encode_kernel", "strview_dict_encode"), (r"strdict_", "strdict_materialise"),
 ]
@@ -49,7 +49,7 @@ def scope_of(kernel: str):
     if m:
         return {"LdsAggSink": "fused_scan_ldsagg_generic", "RegAggSink": "fused_scan_regagg_generic", "BallotSink": "fused_scan_ballots[jit]", "JoinBuildSink": "fused_scan_join_build",
                 "ProbeAggSink": "fused_scan_probe_agg", "DirectBuildSink": "fused_scan_direct_build", "DirectProbeAggSink": "fused_scan_direct_probe_agg",
-                "BitmapBuildSink": "fused_scan_bitmap_build", "HashAggSink": "fused_scan_hashagg", "DenseAggSink": "fused_scan_denseagg", "WideAggSink": "fused_scan_wideagg"}.get(m.group(1))
+                "BitmapBuildSink": "fused_scan_bitmap_build", "DirectHitsSink": "fused_scan_direct_hits", "HashAggSink": "fused_scan_hashagg", "DenseAggSink": "fused_scan_denseagg", "WideAggSink": "fused_scan_wideagg"}.get(m.group(1))
     m = re.search(r"fused_scan_kernel<.*StatProg<(\d+)>", kernel)
     sid = m.group(1) if m else None
     m = re.search(r"part3_scatter_kernel<.*StatProg<(\d+)>\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*(?:,\s*(true|false)\s*)?(?:,\s*(?:true|false)\s*)?>", kernel)      # (the last flag: the per-row check of narrowed values compiled in)
