@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="q1", choices=["q1", "q1j", "q3", "q3f", "q3h", "q3d", "q3dc", "joinm", "filterm", "gather", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s"])
+    ap.add_argument("--workload", default="q1", choices=["q1", "q1j", "q3", "q3f", "q3h", "q3d", "q3dc", "joinm", "joinmh", "filterm", "gather", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the SF100 / 1e9-row size of the workload)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -589,12 +589,19 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
                        "group_by(partkey, suppkey).agg(sum(l_extendedprice * ps_supplycost), len): the aggregate reads a BUILD-side column (pair form)", verify=verify_c, scope="operator")
         wlc.inputs = [L, PS]
         return wlc
-    if name == "joinm":
+    if name in ("joinm", "joinmh"):
         # The MATERIALISING join (round-5 review, item 1): TPC-H Q3's two filtered tables joined into a FRAME -- no group-by above the join -- five output columns
         # (the reference: JoinExec -> _inner_join_from_series, crates/polars-ops/src/frame/join/mod.rs:564-652: pairs, then gathers).  Same rows as tpch_q3_sf100.
         no = (rows // 4) if rows else SF100_ORDERS
         O, L = datagen.orders_lineitem_native(pl, no, seed)
         check_native_q3(pl, O, L, no, seed)
+        hashed_m = name == "joinmh"
+        if hashed_m:
+            # the same rows with orderkey * 0x9E3779B97F4A7C15 mod 2^64 on both sides (as in tpch_q3_sf100_hashed_keys): no key range, the join has to hash --
+            # 16-byte-slot table, radix-partitioned probe against LDS filters, candidates looked up once
+            O = O.with_columns((pl.col("o_orderkey") * HASHED_KEY_MULT).alias("o_orderkey"))
+            L = L.with_columns((pl.col("l_orderkey") * HASHED_KEY_MULT).alias("l_orderkey"))
+            pl._ffi.check(pl._ffi.lib().plx_synchronize())
         nl = L.height
         lfm = queries.q3_join_frame(L.lazy(), O.lazy())
 
@@ -606,6 +613,8 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
             # the Q3 aggregate of the joined rows, taken on the host, through Q3's own all-rows check: a missing / duplicated / mismatched pair changes its order's
             # revenue by a seventh or more; the build-side columns must be constant within an order
             k = res["l_orderkey"].to_numpy().astype(np.int64)
+            if hashed_m:
+                k = (k.astype(np.uint64) * np.uint64(HASHED_KEY_INV)).astype(np.int64)       # the keys mapped back through the inverse multiplier
             order = np.argsort(k, kind="stable")
             k = k[order]
             od = res["o_orderdate"].to_numpy().astype(np.int64)[order]
@@ -627,7 +636,7 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
             if out.get("ok") is not None:
                 out["ok"] = bool(out["ok"]) and consistent
             return out
-        wlm = Workload("join_materialise_sf100", nl + no, nl * datagen.Q3_LINEITEM_BYTES_PER_ROW + no * datagen.Q3_ORDERS_BYTES_PER_ROW, step_m, "probe_scatter",
+        wlm = Workload("join_materialise_sf100_hashed_keys" if hashed_m else "join_materialise_sf100", nl + no, nl * datagen.Q3_LINEITEM_BYTES_PER_ROW + no * datagen.Q3_ORDERS_BYTES_PER_ROW, step_m, "probe_scatter",
                        f"TPC-H Q3's two filtered tables (orders {no} x lineitem {nl}) joined into a frame: filter both -> hash join -> 5 output columns (no group-by); "
                        "algorithmic bytes = the input columns once (+ the joined rows, added from the result)", verify=verify_m, scope="operator")
         wlm.inputs = [L, O]
@@ -1213,7 +1222,7 @@ def pmc_traffic(workload_name: str, kernel: str, rows: int):
              "tpch_q3_sf100_shuffled_inputs": ("q3s", SF100_ORDERS + SF100_LINEITEM), "cfg5_utf8view_keys_1e9": ("cfg5s", 10 ** 9),
              "tpch_q3_sf100_hashed_keys": ("q3h", SF100_ORDERS + SF100_LINEITEM), "cfg2_nulls5pct_1e9": ("cfg2n", 10 ** 9), "cfg3_zipf_1e9": ("cfg3z", 10 ** 9),
              "cfg3_sparse_keys_1e9": ("cfg3s", 10 ** 9), "cfg3_two_int64_keys_1e9": ("cfg3w", 10 ** 9), "join_duplicate_build_keys_sf100": ("q3d", SF100_LINEITEM + SF100_LINEITEM * 2 // 15),
-             "join_aggregate_reads_build_side_sf100": ("q3dc", SF100_LINEITEM + SF100_LINEITEM * 2 // 15), "join_materialise_sf100": ("joinm", SF100_ORDERS + SF100_LINEITEM),
+             "join_aggregate_reads_build_side_sf100": ("q3dc", SF100_LINEITEM + SF100_LINEITEM * 2 // 15), "join_materialise_sf100": ("joinm", SF100_ORDERS + SF100_LINEITEM), "join_materialise_sf100_hashed_keys": ("joinmh", SF100_ORDERS + SF100_LINEITEM),
              "filter_materialise_1e9": ("filterm", 10 ** 9), "gather_1e9": ("gather", 10 ** 9), "tpch_q1_sf100_two_predicates_ten_aggregates_jit": ("q1j", SF100_LINEITEM)}.get(workload_name)
     if short is None or (short[1] is not None and abs(rows - short[1]) > 0.01 * short[1]):
         return None
@@ -2179,7 +2188,7 @@ def compare_q1_dicts(a: dict, b: dict) -> bool:
 
 MULTI_EXTRAS = ("q3", "q3:shuffle", "cfg3", "cfg5", "q1", "q1:weak")     # ":weak" = the per-rank SF100 shard (weak scaling), labelled so in its config.workload
 LATE_WORKLOADS = ("filterm", "gather")       # frame-returning operators with multi-gigabyte results: timed and checked last, one at a time
-EXTRA_WORKLOADS = ("q1j", "q3", "q3h", "q3d", "q3dc", "joinm", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "q1")      # the secondary workloads of the N = 1 line, in this order
+EXTRA_WORKLOADS = ("q1j", "q3", "q3h", "q3d", "q3dc", "joinm", "joinmh", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "q1")      # the secondary workloads of the N = 1 line, in this order
 
 
 def run_multi(args, emit):

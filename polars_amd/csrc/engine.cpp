@@ -878,6 +878,15 @@ static int64_t sample_keys(const Shape& full, const Args& args, int static_id, i
   return d;
 }
 // PLX_PROBE_PARTITIONED: 0 = never, 2 = whenever the kernels are available (tests: small inputs, any key order), default = by size / density / key order
+// The partitioned (LDS-filled) build of a join hash table: PLX_JOIN_PART_BUILD = 0 never | 1 (default) build sides of >= 2^24 rows | 2 whenever the geometry allows.
+// Windows of 2^13 slots (96 KB of LDS: 8-byte keys + 4-byte rows), no larger than a region of the partitioned probe (256 regions: kernels_partition.hip probe_pass_kernel).
+static const uint32_t kJoinWindowLog2 = [] { const char* e = getenv("PLX_JOIN_WINDOW_LOG2"); const int v = e ? atoi(e) : 13; return (uint32_t)(v >= 10 && v <= 13 ? v : 13); }();      // (PLX_JOIN_WINDOW_LOG2: measurement)
+static bool partitioned_build_wanted(int64_t build_rows, int log2_cap) {
+  const char* e = getenv("PLX_JOIN_PART_BUILD");      // (read at every build: the tests switch it)
+  const int mode = e ? atoi(e) : 1;
+  if (mode <= 0 || log2_cap < (int)kJoinWindowLog2 + 8) return false;
+  return mode >= 2 || build_rows >= ((int64_t)1 << 24);
+}
 static int partitioned_probe_mode() { const char* e = getenv("PLX_PROBE_PARTITIONED"); return e && e[0] == '0' ? 0 : e && e[0] == '2' ? 2 : 1; }
 static bool probe_late_loads() { static const bool v = [] { const char* e = getenv("PLX_PROBE_LATE"); return !(e && e[0] == '0'); }(); return v; }
 static int part_version() { static const int v = [] { const char* e = getenv("PLX_PART_V"); return (e && e[0] == '1') ? 1 : 2; }(); return v; }
@@ -1832,6 +1841,9 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   JoinAggTable t{};
   int log2_cap = 4;
   uint64_t cap = 0;
+  std::string build_how;
+  bool pbuild_off = false;
+  k::JoinCells jcells;
   if (known_dups) { B->cols[bki]->repeats_as_build_key = true; if (!multi_ok) return no("build keys are not unique (and a build-side group column is not integer-typed)"); multi = true; }
   bool resized = false;
   for (int attempt = 0; attempt < 4; attempt++) {
@@ -1840,12 +1852,24 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     log2_cap = std::max(4, ceil_log2_u64((uint64_t)((double)std::max<uint64_t>(nb, 1) * (sized_by_sample ? 1.6 : 2.0))));
     cap = 1ull << log2_cap;
     keys = dev_alloc(sizeof(uint64_t) * 2 * (cap + 1)); flags = dev_alloc_zero(32);       // {key, row} slots: kEmptyKey and kNoRow32 are both all-ones
-    PLX_HIP(hipMemsetAsync(keys->ptr, 0xff, sizeof(uint64_t) * 2 * (cap + 1), stream()));
     t.slots = keys->as<unsigned long long>(); t.flags = flags->as<unsigned int>(); t.acc = nullptr;
     t.count = flags->as<unsigned long long>() + 1; t.log2_cap = (uint32_t)log2_cap;
     t.links = multi ? links->as<unsigned long long>() : nullptr;
     JTRACE("build attempt %d multi=%d cap=2^%d nb=%llu", attempt, (int)multi, log2_cap, (unsigned long long)nb);
-    k::fused_join_build(cb.shape, cb.args, t, find_static_shape(cb.shape));
+    // a large build side with (so far) unique keys: partitioned, the table filled window by window from LDS -- no device atomic per row (k::partitioned_join_build)
+    t.log2_window = 0;
+    build_how = "join_build";
+    bool pbuilt = false;
+    if (!multi && !pbuild_off && partitioned_build_wanted(B->height, log2_cap)) {
+      t.log2_window = kJoinWindowLog2;
+      std::string bd;
+      pbuilt = k::partitioned_join_build(cb.shape, cb.args, find_static_shape(cb.shape), t, &jcells, &bd);
+      if (pbuilt) build_how = bd; else t.log2_window = 0;
+    }
+    if (!pbuilt) {
+      PLX_HIP(hipMemsetAsync(keys->ptr, 0xff, sizeof(uint64_t) * 2 * (cap + 1), stream()));
+      k::fused_join_build(cb.shape, cb.args, t, find_static_shape(cb.shape));
+    }
     JTRACE("build done");
     uint64_t fl64[2] = {0, 0};
     d2h_sync(fl64, flags->ptr, 16);
@@ -1861,6 +1885,7 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
       sized_by_sample = false; resized = true;
       continue;
     }
+    if (ovf && pbuilt) { pbuild_off = true; continue; }                             // a window filled up although the table is sized right (keys that crowd one window): the plain build probes the whole table
     PLX_REQUIRE(!ovf, PLX_ERR_OOM, "join build: probe sequence overflow");
     nb = fl64[1];                                                                   // exact from here on
     break;
@@ -1876,7 +1901,9 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
     if (cfl[0]) return no("a build key repeats more than 1024 times");
     merged_rows = cfl[1];
   }
-  const int64_t n_cells = (int64_t)cap + 1;      // one cell set per KEY, also in multi-value mode (the groups are expanded from the key's cells by chains_agg_compact)
+  // one cell set per KEY, also in multi-value mode (the groups are expanded from the key's cells by chains_agg_compact): a slot's cells, or -- a windowed table numbers
+  // its keys -- the key's
+  const int64_t n_cells = t.log2_window ? (int64_t)nb + 1 : (int64_t)cap + 1;
   acc = dev_alloc(sizeof(uint64_t) * (size_t)n_cells * cp.shape.n_aggs);
   t.acc = acc->as<unsigned long long>();
   k::init_agg_cells(acc->as<uint64_t>(), n_cells, cp.shape);
@@ -1920,12 +1947,13 @@ static bool fused_join_groupby(Plan& plan, const IRN& gb, FramePtr& out, std::st
   // (measured on SF100 Q3 with hashed keys: listing the touched slots from the candidates' probe -- one returning atomic per row -- costs that probe 0.5 ms, a
   // candidates' filter in front of the LEN cells 0.2 ms; streaming the LEN cells is 0.37 ms)
   if (multi) G = k::chains_agg_compact(t, cp.shape, acc->as<uint64_t>(), len_idx, &rows->values, &r.acc);
+  else if (t.log2_window) G = k::cells_agg_compact(jcells, acc->as<uint64_t>(), n_cells, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
   else G = k::join_agg_compact(t, r.n_aggs, len_idx, r.packed_keys->as<uint64_t>(), rows->values->as<uint32_t>(), r.acc->as<uint64_t>());
   JTRACE("compacted: %lld groups", (long long)G);
   PLX_REQUIRE(multi || G <= g1, PLX_ERR_INVALID, "join: more groups than build rows");
   r.n_groups = G;
   rows->len = G;
-  plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " hash table cap=2^" + std::to_string(log2_cap) +
+  plan.desc += std::string("FusedJoinGroupBy{build=") + (build_right ? "right" : "left") + " rows=" + std::to_string(nb) + "/" + std::to_string(B->height) + " hash table cap=2^" + std::to_string(log2_cap) + " [" + build_how + "]" +
                (multi ? " multi-value (row chains, a group = a build row; " + std::to_string(merged_rows) + " rows share another row's group), probe rows=" : " unique-keys, probe rows=") + std::to_string(P->height) + ", fused_scan[" + jit::program_mode(probe_static_id, cp.args.n_rows) + "]+" + hprobe_how + ", aggs=" + std::to_string(r.n_aggs) + ", groups=" + std::to_string(G) + "}; ";
   }  // hash-table path
   // ---- output frame: keys, then aggregates
@@ -2338,22 +2366,35 @@ static bool fused_join_frame(Plan& plan, const IRN& jn, const std::set<std::stri
   JoinAggTable t{};
   int log2_cap = 4;
   uint64_t cap = 0;
-  bool resized = false;
+  bool resized = false, pbuild_off = false;
+  std::string build_how;
   for (int attempt = 0; attempt < 4; attempt++) {
     if (multi && !links) links = dev_alloc(sizeof(uint64_t) * (size_t)std::max<int64_t>(B->height, 1));
     log2_cap = std::max(8, ceil_log2_u64((uint64_t)((double)std::max<uint64_t>(nb, 1) * (sized_by_sample ? 1.6 : 2.0))));
     cap = 1ull << log2_cap;
     keys = dev_alloc(sizeof(uint64_t) * 2 * (cap + 1)); flags = dev_alloc_zero(32);
-    PLX_HIP(hipMemsetAsync(keys->ptr, 0xff, sizeof(uint64_t) * 2 * (cap + 1), stream()));
     t.slots = keys->as<unsigned long long>(); t.flags = flags->as<unsigned int>(); t.acc = nullptr;
     t.count = flags->as<unsigned long long>() + 1; t.log2_cap = (uint32_t)log2_cap;
     t.links = multi ? links->as<unsigned long long>() : nullptr;
-    k::fused_join_build(cb.shape, cb.args, t, find_static_shape(cb.shape));
+    // (as in fused_join_groupby: a large build side with unique keys is binned into the table's windows and filled from LDS)
+    t.log2_window = 0;
+    build_how.clear();
+    bool pbuilt = false;
+    if (!multi && !pbuild_off && partitioned_build_wanted(B->height, log2_cap)) {
+      t.log2_window = kJoinWindowLog2;
+      pbuilt = k::partitioned_join_build(cb.shape, cb.args, find_static_shape(cb.shape), t, nullptr, &build_how);
+      if (!pbuilt) t.log2_window = 0;
+    }
+    if (!pbuilt) {
+      PLX_HIP(hipMemsetAsync(keys->ptr, 0xff, sizeof(uint64_t) * 2 * (cap + 1), stream()));
+      k::fused_join_build(cb.shape, cb.args, t, find_static_shape(cb.shape));
+    }
     uint64_t fl64[2] = {0, 0};
     d2h_sync(fl64, flags->ptr, 16);
     const uint32_t dup = (uint32_t)fl64[0], ovf = (uint32_t)(fl64[0] >> 32);
     if (dup && !multi) { B->cols[bki]->repeats_as_build_key = true; multi = true; continue; }      // build once more, chaining the rows of a key
     if (!resized && (ovf || fl64[1] * 10 > cap * 7)) { nb = ovf ? exact_count() : fl64[1]; sized_by_sample = false; resized = true; continue; }      // the sample misjudged: once more, from the exact count
+    if (ovf && pbuilt) { pbuild_off = true; continue; }
     PLX_REQUIRE(!ovf, PLX_ERR_OOM, "join build: probe sequence overflow");
     nb = fl64[1];
     break;
@@ -2378,7 +2419,7 @@ static bool fused_join_frame(Plan& plan, const IRN& jn, const std::set<std::stri
   // ---- pairs
   join::join_pairs(jn.how, P->cols[pki], cand, t, pidx, bidx, &pd);
   PLX_HIP(hipStreamSynchronize(stream()));
-  table_how = "hash table cap=2^" + std::to_string(log2_cap) + (multi ? " multi-value (row chains)" : " unique-keys");
+  table_how = "hash table cap=2^" + std::to_string(log2_cap) + (build_how.empty() ? "" : " [" + build_how + "]") + (multi ? " multi-value (row chains)" : " unique-keys");
   }  // hash-table pipeline
   // ---- payload: one multi-column gather per side
   const ColumnPtr& lidx = build_right ? pidx : bidx;

@@ -465,12 +465,22 @@ struct JoinAggTable {
   // a build ROW: `acc` is [build rows][n_aggs] and a probe row adds to the cells of the representative of every row of its key's chain -- the representative of a
   // row is the first row of the chain that agrees with it on the build-side group columns (canonicalise_chains), so build rows that are ONE group share one cell set.
   unsigned long long* links;
+  // Probe sequences wrap inside aligned WINDOWS of 2^log2_window slots (0: inside the whole table).  A table filled region by region from LDS (k::partitioned_join_build)
+  // is made of such windows: each is built by one workgroup with nothing of its keys outside it.  Every site that walks a probe sequence goes through jt_next.
+  // A windowed table numbers its keys densely: the high 32 bits of a slot's second word hold the key's CELL index (jt_cell), so `acc` is [keys + 1][n_aggs] instead of
+  // [cap + 1][n_aggs] -- less than half the cells to initialise and to stream through at the output step.
+  uint32_t log2_window;
 };
+PLX_HD inline uint64_t jt_next(const JoinAggTable& t, uint64_t slot) {
+  const uint64_t wmask = (1ull << (t.log2_window ? t.log2_window : t.log2_cap)) - 1ull;
+  return (slot & ~wmask) | ((slot + 1) & wmask);
+}
 // build-side columns on which two build rows of one key must agree to be ONE group (canonicalise_chains): plain fixed-width values + optional validity bitmap
 constexpr int kMaxRepCols = 6;
 struct RepCols { int n; const void* vals[kMaxRepCols]; const unsigned long long* valid[kMaxRepCols]; int width[kMaxRepCols]; };
 PLX_HD inline unsigned long long* jt_key(const JoinAggTable& t, uint64_t s) { return t.slots + 2 * s; }
 PLX_HD inline unsigned int* jt_row(const JoinAggTable& t, uint64_t s) { return reinterpret_cast<unsigned int*>(t.slots + 2 * s + 1); }
+PLX_HD inline uint64_t jt_cell(const JoinAggTable& t, uint64_t s) { return t.log2_window ? (uint64_t)jt_row(t, s)[1] : s; }      // index of the slot's aggregate cells
 
 // Direct-address ("perfect hash") variant of the fused join -> aggregate table, used when the build
 // key range is small (max - min + 1 <= a few x the build rows, e.g. TPC-H orderkeys).  One BIT per key of the
@@ -484,6 +494,7 @@ PLX_HD inline unsigned int* jt_row(const JoinAggTable& t, uint64_t s) { return r
 //   probe  : bit test + rank -> the row's aggregates land in acc[slot];
 //   output : ONE pass over the pair list: pairs whose slot was hit by a probe row are compacted together with their cells
 //            (no key-ordered copy of the pairs, no pass over the slots).
+constexpr unsigned int kOrdChunk = 1024;     // ordinals a wave reserves at a time (fused_sinks.hpp DirectBuildSink)
 struct DirectJoinTable {
   unsigned long long* bits;      // [(range / 512 + 1) * 8] bitmap words, padded to whole blocks
   const unsigned int* rank;      // [(range / 512 + 1) * 8] set bits before each bitmap word (valid after the rank step)

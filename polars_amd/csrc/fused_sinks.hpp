@@ -344,7 +344,7 @@ struct JoinBuildSink {
             if (old == key) atomicAdd(jt_row(p, slot) + 1, 1u);                                           // marks the slot as one with duplicates (the word starts at 0xffffffff)
             break;
           }
-          slot = (slot + 1) & (cap - 1);
+          slot = jt_next(p, slot);
           if (probe > (1u << 16)) { p.flags[1] = 1u; break; }
         }
         continue;
@@ -355,7 +355,7 @@ struct JoinBuildSink {
         const unsigned long long old = atomicCAS(jt_key(p, slot), (unsigned long long)kEmptyKey, (unsigned long long)key);
         if (old == kEmptyKey) { *jt_row(p, slot) = (unsigned int)(row0 + r); break; }
         if (old == key) { p.flags[0] = 1u; break; }
-        slot = (slot + 1) & (cap - 1);
+        slot = jt_next(p, slot);
         if (probe > (1u << 16)) { p.flags[1] = 1u; break; }
       }
     }
@@ -380,14 +380,14 @@ struct ProbeAggSink {
             const unsigned long long cur = *jt_key(p, s);
             if (cur == key) { slot = (int64_t)s; break; }
             if (cur == kEmptyKey) break;
-            s = (s + 1) & (cap - 1);
+            s = jt_next(p, s);
           }
         }
         // One contribution per probe row, into the cells of its KEY -- also when build keys repeat (multi-value mode).  The aggregates read the probe side only, so every
         // build row of the key would receive the very same contributions: the groups (build rows, or the rows of a key that agree on the build-side group columns) are
         // expanded from the key's cells when the table is compacted (k::chains_agg_compact: a group of m build rows = m copies of the key's aggregate).  Round 5 walked the
         // key's chain here and added into the cells of every row's representative: 8e7 x 2 device atomics for 2e7 candidates (3.6 ms of the duplicate-key join's 10.9).
-        if (slot >= 0) atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)slot * sh.n_aggs);
+        if (slot >= 0) atomic_row(sh, rf, r, row0 + r, p.acc + (size_t)jt_cell(p, (uint64_t)slot) * sh.n_aggs);
       }
     }
   }
@@ -397,7 +397,6 @@ struct ProbeAggSink {
 // Ordinals are handed out in per-wave chunks: a wave reserves kOrdChunk ordinals with ONE device atomic
 // and sub-allocates from them (one atomic per wave-row on a single counter word took 26 ms for the 1.5e8-row
 // TPC-H orders scan; ~12 k atomics this way).  Unused tails of chunks stay empty (LEN cell 0).
-constexpr unsigned int kOrdChunk = 1024;
 // slot of key index idx (its bit is set in `word` = bits[idx >> 6]): build rows numbered in key order
 __device__ __forceinline__ unsigned long long direct_slot(const DirectJoinTable& t, unsigned long long idx, unsigned long long word) {
   return (unsigned long long)t.rank[idx >> 6] + (unsigned long long)__popcll(word & ((1ull << (idx & 63)) - 1ull));
@@ -438,6 +437,7 @@ struct DirectBuildSink {
       p.ord_row[ord] = (unsigned int)(row0 + r);
       part[r] = true; word[r] = (unsigned int)(idx >> 6); bit[r] = 1ull << (idx & 63);     // range <= 2^34: the word index fits 28 bits
     }
+    if (!p.bits) return;                                   // (wave-uniform) pairs only: k::partitioned_join_build
     // fire-and-forget (no-return) atomics: a duplicate build key shows up as popcount(bits) < number of pairs, which the rank step
     // counts (the caller then falls back).  The two rows of a lane usually share a bitmap word when the build table is scanned in
     // key order: one atomic then.  (Merging across lanes with a segmented wave scan was measured: no faster, the scan is not

@@ -525,6 +525,29 @@ int64_t join_agg_compact(const JoinAggTable& t, int n_aggs, int len_idx, uint64_
   return (int64_t)n;
 }
 
+__global__ __launch_bounds__(kBlock) void cells_agg_compact_kernel(const unsigned long long* __restrict__ cell_key, const unsigned int* __restrict__ cell_row, const unsigned long long* __restrict__ acc,
+                                                                   int64_t n_cells, int n_aggs, int len_idx, unsigned long long* __restrict__ counter,
+                                                                   unsigned long long* __restrict__ out_keys, unsigned int* __restrict__ out_rows, unsigned long long* __restrict__ out_acc) {
+  compact_slots(n_cells, counter, [&](int64_t c) { return acc[(size_t)c * n_aggs + len_idx] != 0; },
+                [&](int64_t c, uint64_t o) {
+                  if (!out_keys) return;
+                  out_keys[o] = cell_key[c];
+                  out_rows[o] = cell_row[c];
+                  for (int k = 0; k < n_aggs; k++) out_acc[o * n_aggs + k] = acc[(size_t)c * n_aggs + k];
+                });
+}
+int64_t cells_agg_compact(const JoinCells& cells, const uint64_t* acc, int64_t n_cells, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc) {
+  if (n_cells <= 0) return 0;
+  Buf counter = dev_alloc_zero(8);
+  ProfileScope ps("table_compact", (uint64_t)n_cells * (12 + 8 * (uint64_t)n_aggs), (uint64_t)n_cells);
+  hipLaunchKernelGGL(cells_agg_compact_kernel, dim3(compact_grid(n_cells)), dim3(kBlock), 0, stream(), cells.key->as<unsigned long long>(), cells.row->as<unsigned int>(),
+                     (const unsigned long long*)acc, n_cells, n_aggs, len_idx, counter->as<unsigned long long>(), (unsigned long long*)out_keys, (unsigned int*)out_rows, (unsigned long long*)out_acc);
+  PLX_HIP(hipGetLastError());
+  uint64_t n = 0;
+  d2h_sync(&n, counter->ptr, 8);
+  return (int64_t)n;
+}
+
 // ---- multi-value join table (duplicate build keys): representatives and row-indexed compaction --------------------------------
 // One thread per slot of the build table.  Slots whose key was inserted once are skipped by the duplicate counter in the slot itself (no access to the links).  For a
 // key with several build rows the thread walks the chain and gives every row its representative: the first row of the chain (in chain order) that agrees with it on all

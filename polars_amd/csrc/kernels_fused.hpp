@@ -102,6 +102,14 @@ int64_t partitioned_agg2(const fused::Shape& sh, const fused::Args& args, const 
 void touch_filter_set(const int64_t* keys, const uint64_t* validity, int64_t n, unsigned int log2_bits, uint64_t* filter);
 bool partitioned_probe_hits(const fused::Shape& sh, const fused::Args& args, const fused::DirectJoinTable& dt, uint64_t n_build, int static_id, ColumnPtr* hits, std::string* desc);
 bool partitioned_hash_probe_hits(const fused::Shape& sh, const fused::Args& args, const fused::JoinAggTable& ht, uint64_t n_build, int static_id, ColumnPtr* hits, std::string* desc);
+// Build of a join table WITHOUT a device atomic per row: the rows that pass `sh`'s predicate (sh: the plain build's predicate + key program) become {key, row} pairs, the
+// pairs are binned by the WINDOW of the table their hash falls into and every window is filled from an LDS image (t.log2_window set by the caller; t.flags / t.count
+// zeroed; the table needs no memset).  The keys are numbered densely (fused::jt_cell): `cells`, when given, receives key and build row of every cell for
+// cells_agg_compact.  false: not available for this shape / size -- nothing was touched, build the plain way.  Duplicate keys: t.flags[0]; a full window: t.flags[1].
+struct JoinCells { Buf key, row; };
+bool partitioned_join_build(const fused::Shape& sh, const fused::Args& args, int static_id, const fused::JoinAggTable& t, JoinCells* cells, std::string* desc);
+// output step of the fused join -> aggregate over a windowed table: cells whose LEN aggregate is not 0 -> dense (key, build row, cells); n_cells = keys + 1
+int64_t cells_agg_compact(const JoinCells& cells, const uint64_t* acc, int64_t n_cells, int n_aggs, int len_idx, uint64_t* out_keys, uint32_t* out_rows, uint64_t* out_acc);
 // fraction of adjacent pairs (strided sample) of an integer column that are non-decreasing: 1.0 = sorted ascending
 double sample_sortedness(const ColumnPtr& c);
 // smallest / largest valid value among 65536 rows (64 evenly spaced runs); false: no valid value in the sample / not an integer column

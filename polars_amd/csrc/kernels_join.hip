@@ -215,7 +215,7 @@ void join_indices(int how, const ColumnPtr& left_key, const ColumnPtr& right_key
 // HBM is one slot lookup per candidate, once: pass 1 leaves the build row (or chain head) and the pair count of every candidate, the pairs are then laid out by a
 // device scan (duplicate keys / left joins) or by the selection-bitmap compaction of kernels_filter.hip (unique keys: 0 / 1 pairs per candidate) -- no second probe.
 struct PairTable {
-  const unsigned long long* slots; const unsigned long long* links; uint32_t log2_cap;
+  const unsigned long long* slots; const unsigned long long* links; uint32_t log2_cap, log2_window;
   // direct-address variant (bits != null; unique build keys): bitmap over the key range + rank per word + slot -> build row (fused::DirectJoinTable, k::direct_slot_rows)
   const unsigned long long* bits; const unsigned int* rank; const unsigned int* slot_row; long long kmin; unsigned long long range;
 };
@@ -234,7 +234,8 @@ __device__ __forceinline__ unsigned int pair_lookup(const PairTable& t, uint64_t
     const unsigned long long cur = t.slots[slot * 2];
     if (cur == key) return (unsigned int)t.slots[slot * 2 + 1];
     if (cur == fused::kEmptyKey) return kNoRow;
-    slot = (slot + 1) & (cap - 1);
+    const uint64_t wmask = (1ull << (t.log2_window ? t.log2_window : t.log2_cap)) - 1ull;      // probe sequences wrap inside the table's windows (fused::jt_next)
+    slot = (slot & ~wmask) | ((slot + 1) & wmask);
   }
   return kNoRow;
 }
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void iota_u32_kernel(uint32_t* __restrict__
 
 static void join_pairs_impl(int how, const ColumnPtr& probe_key, const ColumnPtr& cand, const PairTable& t, ColumnPtr& probe_idx, ColumnPtr& build_idx, std::string* desc);
 void join_pairs(int how, const ColumnPtr& probe_key, const ColumnPtr& cand, const fused::JoinAggTable& jt, ColumnPtr& probe_idx, ColumnPtr& build_idx, std::string* desc) {
-  PairTable t{}; t.slots = jt.slots; t.links = jt.links; t.log2_cap = jt.log2_cap;
+  PairTable t{}; t.slots = jt.slots; t.links = jt.links; t.log2_cap = jt.log2_cap; t.log2_window = jt.log2_window;
   join_pairs_impl(how, probe_key, cand, t, probe_idx, build_idx, desc);
 }
 void join_pairs_direct(int how, const ColumnPtr& probe_key, const ColumnPtr& cand, const fused::DirectJoinTable& dt, const uint32_t* slot_row, ColumnPtr& probe_idx, ColumnPtr& build_idx,

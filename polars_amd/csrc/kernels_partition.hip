@@ -655,6 +655,7 @@ struct ProbeHashedBuild {
   const unsigned long long* table_slots;   // [cap + 1][2] {key, build row} slots of the build table (JoinAggTable); slot `cap` = the key whose bits equal kEmptyKey (present iff its row is set)
   uint32_t log2_cap;
   uint32_t hash_bits;                      // 0: the bitmap source
+  uint32_t windowed;                       // the table's probe sequences wrap inside windows (JoinAggTable::log2_window): no key of a region sits behind its end
 };
 __global__ __launch_bounds__(kP2AggBlock) void probe_pass_kernel(const unsigned int* __restrict__ recs, const unsigned int* __restrict__ chunk_fill, const unsigned long long* __restrict__ cl_off,
                                                                  const unsigned int* __restrict__ cl_ids, const unsigned long long* __restrict__ bits, unsigned long long range,
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(kP2AggBlock) void probe_pass_kernel(const unsigned 
     for (unsigned long long j = threadIdx.x; j < region; j += blockDim.x) { const unsigned long long key = hb.table_slots[((unsigned long long)p * region + j) * 2]; if (key != kEmptyKey) add(key); }
     if (threadIdx.x == 0) {
       // the run of occupied slots behind the region: keys of this partition that linear probing pushed past its end (short: the table is at most half full)
-      for (unsigned long long s = (((unsigned long long)p + 1) * region) & (cap - 1), n = 0; n < cap; s = (s + 1) & (cap - 1), n++) { const unsigned long long key = hb.table_slots[s * 2]; if (key == kEmptyKey) break; add(key); }
+      for (unsigned long long s = (((unsigned long long)p + 1) * region) & (cap - 1), n = 0; n < cap && !hb.windowed; s = (s + 1) & (cap - 1), n++) { const unsigned long long key = hb.table_slots[s * 2]; if (key == kEmptyKey) break; add(key); }
       if ((unsigned int)hb.table_slots[cap * 2 + 1] != kNoRow32) add(kEmptyKey);                                  // the key equal to the EMPTY pattern lives in slot `cap`
     }
   }
@@ -860,6 +861,7 @@ static bool probe_hits_impl(const Shape& sh, const Args& args, const DirectJoinT
   if (hashed) {
     if (ht->log2_cap < pp.log2_parts) return false;                           // a table smaller than the partition count needs no partitioned probe
     hb.table_slots = ht->slots; hb.log2_cap = ht->log2_cap; hb.hash_bits = pp.hash_bits;
+    hb.windowed = ht->log2_window && ht->log2_window + pp.log2_parts <= ht->log2_cap ? 1u : 0u;      // (windows no larger than a partition's region)
   }
   {
     ProfileScope ps("probe_pass_lds",     // one kernel symbol for the bitmap-slice, Bloom-from-bitmap and Bloom-from-hash-table sources: one tracer name (the plan description says which)
@@ -896,6 +898,149 @@ bool partitioned_probe_hits(const Shape& sh, const Args& args, const DirectJoinT
 // per-partition Bloom filters in LDS from the table's keys; the candidates then go through the ordinary hash probe (fused_probe_agg), which compares whole keys.
 bool partitioned_hash_probe_hits(const Shape& sh, const Args& args, const JoinAggTable& ht, uint64_t n_build, int static_id, ColumnPtr* hits_out, std::string* desc) {
   return probe_hits_impl(sh, args, nullptr, &ht, n_build, static_id, hits_out, desc);
+}
+
+// ======================================================================================================================
+// Partitioned join BUILD (kernels_fused.hpp: partitioned_join_build)
+// ======================================================================================================================
+// The plain build (JoinBuildSink) claims a slot per build row with a compare-and-swap on a random line of a table far beyond the caches: every insert is a line across
+// the fabric and back (SF100 orders: 1.46e7 inserts into 512 MB, 1.4 of the scan's 2.0 ms).  Here the table is made of WINDOWS of 2^log2_window slots that one workgroup
+// each fills from an LDS image and writes out in whole lines (empty slots included: the table needs no memset); probe sequences wrap inside the window
+// (JoinAggTable::log2_window, jt_next), so nothing of a window's keys lives outside it.  Three kernels:
+//   pairs  the build side's predicate + key scan appends {key, row} pairs in per-wave ordinal chunks (the direct-address build's sink without its bitmap: one device atomic
+//          per 1024 pairs);
+//   bin    a workgroup per 32768 ordinals: counts its pairs per window in LDS, reserves room in each window's record region with ONE device atomic per (workgroup, window)
+//          and copies the pairs there (a window's region holds as many records as the window has slots: more cannot be inserted anyway -> flags[1]);
+//   fill   a workgroup per window: LDS compare-and-swap inserts, then the image goes out.
+// A duplicate key raises flags[0] (the caller builds again in multi-value mode, the plain way), a window that fills up flags[1].  (Measured and dropped first: records
+// radix-partitioned 256 / 512 ways by the scatter of §4.2 and windows that re-read their partition's chunk lists -- scatter 0.95 / 1.6 ms + fill 3.7 ms.)
+constexpr uint32_t kFillBlock = 1024, kBinBlock = 1024, kBinTile = 32768;
+__device__ __forceinline__ bool ord_live(const DirectJoinTable& dt, uint32_t ord) { return (ord & (kOrdChunk - 1)) < dt.chunk_used[ord / kOrdChunk]; }
+__global__ __launch_bounds__(kBinBlock) void join_bin_kernel(DirectJoinTable dt, JoinAggTable t, ulonglong2* __restrict__ recs, unsigned int* __restrict__ win_fill) {
+  extern __shared__ unsigned int bin_lds[];
+  const uint32_t log2_nw = t.log2_cap - t.log2_window, NW = 1u << log2_nw, W = 1u << t.log2_window;
+  unsigned int* cnt = bin_lds;            // [NW] pairs of this tile per window, then the cursor inside the reserved run
+  unsigned int* base = bin_lds + NW;      // [NW] first record of the run reserved in the window's region
+  const uint32_t n_res = min(*dt.counter, dt.n_ord);
+  const uint64_t o0 = (uint64_t)blockIdx.x * kBinTile;
+  if (o0 >= n_res) return;
+  const uint32_t n = (uint32_t)min((uint64_t)kBinTile, n_res - o0);
+  for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t ord = (uint32_t)o0 + i;
+    if (!ord_live(dt, ord)) continue;
+    const unsigned long long key = dt.ord_key[ord];
+    if (key == kEmptyKey) continue;
+    atomicAdd(&cnt[(uint32_t)((key * kP2HashMult) >> (64 - log2_nw))], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) { const unsigned int c = cnt[i]; base[i] = c ? atomicAdd(&win_fill[i], c) : 0u; cnt[i] = 0; }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t ord = (uint32_t)o0 + i;
+    if (!ord_live(dt, ord)) continue;
+    const unsigned long long key = dt.ord_key[ord];
+    const unsigned int row = dt.ord_row[ord];
+    if (key == kEmptyKey) {                               // the key equal to the EMPTY pattern lives in slot `cap`, outside every window
+      const unsigned int old = atomicExch(jt_row(t, 1ull << t.log2_cap), row);
+      if (old != kNoRow32) t.flags[0] = 1u;
+      if (t.count) atomicAdd(t.count, 1ull);
+      continue;
+    }
+    const uint32_t w = (uint32_t)((key * kP2HashMult) >> (64 - log2_nw));
+    const unsigned int pos = base[w] + atomicAdd(&cnt[w], 1u);
+    if (pos < W) recs[((uint64_t)w << t.log2_window) + pos] = make_ulonglong2(key, (unsigned long long)row);
+    else t.flags[1] = 1u;
+  }
+}
+__global__ __launch_bounds__(kFillBlock) void join_fill_kernel(const ulonglong2* __restrict__ recs, const unsigned int* __restrict__ win_fill, const unsigned long long* __restrict__ win_base,
+                                                               JoinAggTable t, unsigned long long* __restrict__ cell_key, unsigned int* __restrict__ cell_row) {
+  extern __shared__ unsigned long long fill_lds[];
+  const uint32_t W = 1u << t.log2_window;
+  unsigned long long* lkeys = fill_lds;            // [W]
+  unsigned long long* lvals = fill_lds + W;        // [W] {row, cell index << 32}
+  __shared__ unsigned int s_count;
+  const uint64_t w = blockIdx.x;
+  const uint32_t n = min(uniform_ld(win_fill, w), W);
+  const uint64_t cell0 = uniform_ld(win_base, w);  // cells are numbered in record order: window by window
+  for (uint32_t i = threadIdx.x; i < W; i += blockDim.x) { lkeys[i] = kEmptyKey; lvals[i] = ~0ull; }
+  if (threadIdx.x == 0) s_count = 0;
+  if (w == 0 && threadIdx.x == 0) {                // the key equal to the EMPTY pattern (slot `cap`): the cell behind every window's
+    const uint64_t total = win_base[1ull << (t.log2_cap - t.log2_window)];
+    jt_row(t, 1ull << t.log2_cap)[1] = (unsigned int)total;
+    if (cell_key) { cell_key[total] = kEmptyKey; cell_row[total] = *jt_row(t, 1ull << t.log2_cap); }
+  }
+  __syncthreads();
+  unsigned int mine = 0;
+  const ulonglong2* in = recs + (w << t.log2_window);
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const ulonglong2 rec = in[i];
+    const unsigned long long key = rec.x;
+    if (cell_key) { cell_key[cell0 + i] = key; cell_row[cell0 + i] = (unsigned int)rec.y; }
+    uint32_t ls = (uint32_t)((key * kP2HashMult) >> (64 - t.log2_cap)) & (W - 1);
+    for (uint32_t probe = 0;; probe++) {
+      const unsigned long long old = atomicCAS(&lkeys[ls], (unsigned long long)kEmptyKey, key);
+      if (old == kEmptyKey) { lvals[ls] = (rec.y & 0xffffffffull) | ((cell0 + i) << 32); mine++; break; }
+      if (old == key) { t.flags[0] = 1u; break; }                             // duplicate build key
+      ls = (ls + 1) & (W - 1);
+      if (probe >= W) { t.flags[1] = 1u; break; }                             // window full
+    }
+  }
+  if (mine) atomicAdd(&s_count, mine);
+  __syncthreads();
+  ulonglong2* out = reinterpret_cast<ulonglong2*>(t.slots) + (w << t.log2_window);
+  for (uint32_t i = threadIdx.x; i < W; i += blockDim.x) out[i] = make_ulonglong2(lkeys[i], lvals[i]);
+  if (threadIdx.x == 0 && t.count && s_count) atomicAdd(t.count, (unsigned long long)s_count);
+}
+
+// sh / args: the build side's predicate + key program (no aggregates: what the plain build runs).  t: slots allocated ([cap + 1][2] words, NOT initialised), flags and count
+// zeroed, log2_window set by the caller.  cells (may be null): the keys and build rows in cell order ([keys + 1], allocated here) for the output step of a join ->
+// aggregate.  false: the geometry does not fit (nothing was touched: memset the table and build the plain way).
+bool partitioned_join_build(const Shape& sh, const Args& args, int static_id, const JoinAggTable& t, JoinCells* cells, std::string* desc) {
+  if (sh.key == kNone || sh.n_keys || t.links || !t.log2_window || t.log2_cap < t.log2_window + 3) return false;
+  const uint32_t log2_nw = t.log2_cap - t.log2_window;
+  if (log2_nw > 14) return false;                                  // window counters in LDS (bin kernel: 8 bytes a window)
+  const uint64_t ord_cap = (uint64_t)args.n_rows + (uint64_t)scan_waves(args.n_rows) * kOrdChunk + kOrdChunk;
+  if (ord_cap >= 0xfffffff0ull) return false;
+  const uint64_t NW = 1ull << log2_nw;
+  Buf okey = dev_alloc_transient(sizeof(uint64_t) * ord_cap), orow = dev_alloc_transient(sizeof(uint32_t) * ord_cap), used = dev_alloc_zero(sizeof(uint32_t) * (ord_cap / kOrdChunk + 2));
+  Buf meta = dev_alloc_zero(32);                                   // [0] ordinal counter, [2..3] the pair sink's flags
+  Buf win_fill = dev_alloc_zero(sizeof(uint32_t) * (NW + 1)), win_base = dev_alloc(sizeof(uint64_t) * (NW + 2));
+  Buf recs = dev_alloc_transient((size_t)16 << t.log2_cap);
+  DirectJoinTable dt{};
+  dt.bits = nullptr; dt.ord_key = okey->as<unsigned long long>(); dt.ord_row = orow->as<unsigned int>(); dt.chunk_used = used->as<unsigned int>();
+  dt.counter = meta->as<unsigned int>(); dt.flags = meta->as<unsigned int>() + 2; dt.n_ord = (unsigned int)ord_cap;
+  fused_direct_build(sh, args, dt, static_id);                     // (a null bitmap: the sink appends pairs only)
+  PLX_HIP(hipMemsetAsync(t.slots + ((size_t)2 << t.log2_cap), 0xff, 16, stream()));       // slot `cap`
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)join_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)join_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError(); attr_set = true;
+  }
+  {
+    // every reserved ordinal is visited (live or not: the capacity bounds the grid, workgroups past the counter leave at once)
+    const uint64_t n_tiles = (ord_cap + kBinTile - 1) / kBinTile;
+    ProfileScope ps("join_bin_windows", (uint64_t)args.n_rows / 4, (uint64_t)args.n_rows);
+    hipLaunchKernelGGL(join_bin_kernel, dim3((unsigned int)n_tiles), dim3(kBinBlock), (size_t)NW * 8, stream(), dt, t, reinterpret_cast<ulonglong2*>(recs->ptr), win_fill->as<unsigned int>());
+    PLX_HIP(hipGetLastError());
+  }
+  exclusive_scan_u32(win_fill->as<uint32_t>(), win_base->as<uint64_t>(), (int64_t)NW);       // win_base[NW] = records in all windows
+  if (cells) {
+    // (at most one record per row that passed; the table was sized for them: cap slots bound the cells whatever the count turns out to be)
+    cells->key = dev_alloc(sizeof(uint64_t) * (((size_t)1 << t.log2_cap) + 1));
+    cells->row = dev_alloc(sizeof(uint32_t) * (((size_t)1 << t.log2_cap) + 1));
+  }
+  {
+    const size_t lds = ((size_t)16 << t.log2_window);
+    ProfileScope ps("join_fill_lds", ((uint64_t)16 << t.log2_cap) * 3 / 2, NW);
+    hipLaunchKernelGGL(join_fill_kernel, dim3((unsigned int)NW), dim3(kFillBlock), lds, stream(), reinterpret_cast<const ulonglong2*>(recs->ptr), win_fill->as<unsigned int>(),
+                       win_base->as<unsigned long long>(), t, cells ? cells->key->as<unsigned long long>() : nullptr, cells ? cells->row->as<unsigned int>() : nullptr);
+    PLX_HIP(hipGetLastError());
+  }
+  if (desc) *desc = "partitioned build(pairs -> " + std::to_string(NW) + " windows of " + std::to_string(1u << t.log2_window) + " slots filled from LDS)";
+  return true;
 }
 
 // ---- is a key column (roughly) sorted?  fraction of non-decreasing adjacent pairs over 64 evenly spaced runs of 1024 rows ----------------
