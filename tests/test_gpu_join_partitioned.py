@@ -172,3 +172,44 @@ def test_partitioned_hash_probe_edge_keys(pl, monkeypatch, dt):
     g0 = q().sort_host("k")
     assert "partitioned_hash_probe(" not in pl.last_plan()
     assert g0["k"] == g["k"] and g0["sx"] == g["sx"] and g0["n"] == g["n"] and g0["a"] == g["a"]
+
+
+@pytest.mark.parametrize("dt", [np.int64, np.uint64])
+def test_join_group_by_on_a_table_filled_from_lds(pl, monkeypatch, dt):
+    """PLX_JOIN_PART_BUILD=2 forces the windowed build (k::partitioned_join_build) at a size numpy checks: 1.5e6 sparse 64-bit build keys with the EMPTY pattern, 0 and the
+    extreme values among them, nulls on both sides, a predicate on the build side; the aggregates live in cells numbered per KEY (not per slot), the output step walks the
+    cells.  The plain and the partitioned probe agree with numpy, and so does the plain build."""
+    rng = np.random.default_rng(12)
+    nb, n = 1_500_000, (1 << 22) + 4321
+    edge = np.array([-1, 0, np.iinfo(np.int64).min, np.iinfo(np.int64).max], np.int64)
+    bkey = np.unique(np.concatenate([rng.integers(-(1 << 62), 1 << 62, nb).astype(np.int64), edge])).view(dt)
+    bkey = bkey[rng.permutation(len(bkey))]
+    bvalid = rng.random(len(bkey)) > 0.02
+    bvalid[np.isin(bkey, edge.view(dt))] = True
+    battr = rng.integers(0, 100, len(bkey)).astype(np.int64)
+    bsel = rng.integers(0, 10, len(bkey)).astype(np.int32)
+    bsel[np.isin(bkey, edge.view(dt))] = 1
+    pkey = np.where(rng.random(n) < 0.3, bkey[rng.integers(0, len(bkey), n)], rng.integers(-(1 << 62), 1 << 62, n).astype(np.int64).view(dt))
+    pkey[:4] = edge.view(dt)
+    valid = rng.random(n) > 0.05
+    valid[:4] = True
+    x = rng.integers(-50, 50, n).astype(np.int64)
+    B = pl.DataFrame([pl.Series("k", bkey, validity=bvalid), pl.Series("a", battr), pl.Series("s", bsel)])
+    P = pl.DataFrame([pl.Series("k", pkey, validity=valid), pl.Series("x", x)])
+    c = pl.col
+    q = lambda: P.lazy().join(B.lazy().filter(c("s") != 0), on="k").group_by("k", "a").agg(c("x").sum().alias("sx"), pl.len().alias("n")).collect()
+    live = bkey[bvalid & (bsel != 0)]
+    order = np.argsort(live, kind="stable")
+    live_attr = battr[bvalid & (bsel != 0)][order]
+    live = live[order]
+    inb = valid & np.isin(pkey, live)
+    keys, inv = np.unique(pkey[inb], return_inverse=True)
+    want = (keys.tolist(), np.bincount(inv, weights=x[inb]).astype(np.int64).tolist(), np.bincount(inv).tolist(), live_attr[np.searchsorted(live, keys)].tolist())
+    for build, probe in (("2", "2"), ("2", "0"), ("0", "2")):
+        monkeypatch.setenv("PLX_JOIN_PART_BUILD", build)
+        monkeypatch.setenv("PLX_PROBE_PARTITIONED", probe)
+        g = q().sort_host("k")
+        plan = pl.last_plan()
+        assert ("partitioned build(" in plan) == (build == "2") and ("partitioned_hash_probe(" in plan) == (probe == "2"), plan
+        assert (g["k"], g["sx"], g["n"], g["a"]) == want, plan
+        assert {int(v) for v in edge.view(dt)} <= set(g["k"])

@@ -179,6 +179,37 @@ def test_join_to_frame_with_predicates_on_both_sides(pl, orc, monkeypatch, dup, 
     _same_rows(_got_join(ref), want)
 
 
+@pytest.mark.parametrize("how,partitioned,dup", [("inner", True, False), ("inner", False, False), ("left", False, False), ("inner", True, True)])
+def test_join_to_frame_on_a_table_filled_from_lds(pl, orc, monkeypatch, how, partitioned, dup):
+    """PLX_JOIN_PART_BUILD=2: the build side's pairs are binned into the table's windows and every window is filled from an LDS image (k::partitioned_join_build); probe
+    sequences wrap inside the windows.  Unique hashed keys with the key equal to the table's EMPTY pattern (-1) and the extreme Int64 values among them, null keys on
+    both sides, a predicate on the build side.  Duplicate build keys are noticed by the fill and the table is built again the plain way in multi-value mode."""
+    monkeypatch.setenv("PLX_JOIN_MATERIALISE", "2")
+    monkeypatch.setenv("PLX_JOIN_PART_BUILD", "2")
+    monkeypatch.setenv("PLX_PROBE_PARTITIONED", "2" if partitioned else "0")
+    rng = np.random.default_rng(970 + 2 * (how == "left") + partitioned + 4 * dup)
+    n_probe, n_build = (1 << 22) + 999, 1_300_000
+    h = _join_inputs(rng, n_probe, n_build, dup, hashed=True)
+    if not dup:
+        edge = np.array([-1, np.iinfo(np.int64).min, np.iinfo(np.int64).max], np.int64)
+        assert not np.isin(edge, h["bk"]).any()
+        h["bk"][:3] = edge; h["bv"][:3] = True; h["bz"][:3] = 1
+        h["pk"][:6] = np.tile(edge, 2); h["pv"][:6] = True
+    P, B = _frames(pl, h)
+    c = pl.col
+    q = P.lazy().join(B.lazy().filter(c("z") != 3), on="k", how=how)
+    out = q.collect()
+    plan = pl.last_plan()
+    assert "FusedJoinFrame{" in plan and ("partitioned build(" in plan) == (not dup) and ("multi-value" in plan) == dup, plan
+    if partitioned:
+        assert "partitioned_hash_probe(" in plan, plan
+    want = _expected_join(orc, h, how, bmask=h["bz"] != 3)
+    got = _got_join(out)
+    _same_rows(got, want)
+    if not dup:
+        assert {-1, int(np.iinfo(np.int64).min), int(np.iinfo(np.int64).max)} <= set(got["k"][got["rvalid"]].tolist())
+
+
 def test_join_to_frame_select_gathers_only_the_named_columns(pl, orc, monkeypatch):
     monkeypatch.setenv("PLX_JOIN_MATERIALISE", "2")
     rng = np.random.default_rng(5)
