@@ -11,6 +11,7 @@ import re
 import sys
 
 SCOPES = [  # (regex on the demangled kernel name, ProfileScope name in bench.py)
+    (r"fused_scan_kernel<.*DirectHitsSink", "fused_scan_direct_hits_static"), (r"fused_scan_kernel<.*BallotSink", "fused_scan_ballots_static"),
     (r"fused_scan_kernel<.*LdsAggSink", "fused_scan_ldsagg_static"), (r"fused_scan_kernel<.*RegAggSink", "fused_scan_regagg_static"),
     (r"fused_scan_kernel<.*DirectProbeAggSink", "fused_scan_direct_probe_agg_static"), (r"fused_scan_kernel<.*DirectBuildSink", "fused_scan_direct_build_static"),
     (r"fused_scan_kernel<.*BitmapBuildSink", "fused_scan_bitmap_build_static"), (r"fused_scan_kernel<.*HashAggSink", "fused_scan_hashagg"),
@@ -24,7 +25,8 @@ SCOPES = [  # (regex on the demangled kernel name, ProfileScope name in bench.py
     (r"strgroup_scatter_kernel", "strgroup_scatter"), (r"strgroup_agg_kernel", "strgroup_agg_lds"),
     (r"canonicalise_chains_kernel", "join_chain_representatives"), (r"chains_count_kernel|chains_emit_kernel", "table_compact"), (r"rows_agg_compact_kernel|wide_compact_kernel", "table_compact"),
     (r"fused_scan_kernel<.*WideAggSink", "fused_scan_wideagg"),
-    (r"compact_by_ballots_kernel", "filter_compact_cols"), (r"join_match_kernel", "join_match"), (r"join_pairs_emit_kernel", "join_pairs_emit"), (r"filter_rowids_kernel|ballots_to_rowids_kernel", "filter_rowids"), (r"direct_slot_rows_kernel", "direct_slot_rows"), (r"fused_scan_kernel<.*DirectHitsSink", "fused_scan_direct_hits_static"),
+    (r"compact_by_ballots_kernel", "filter_compact_cols"), (r"join_match_kernel", "join_match"), (r"join_pairs_emit_kernel", "join_pairs_emit"), (r"filter_rowids_kernel|ballots_to_rowids_kernel", "filter_rowids"), (r"direct_slot_rows_kernel", "direct_slot_rows"),
+    (r"join_bin_kernel", "join_bin_windows"), (r"join_fill_kernel", "join_fill_lds"), (r"cells_agg_compact_kernel", "table_compact"),
     (r"filter_kernel<", "filter_compact"), (r"tile_count_kernel", "filter_tile_count"), (r"ballots_to_mask_kernel", "ballots_to_mask"),
     (r"init_acc_kernel|fill_u64_kernel", "table_init"), (r"strview_encode_kernel", "strview_dict_encode"), (r"strdict_", "strdict_materialise"),
 ]
