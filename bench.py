@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="q1", choices=["q1", "q1j", "q3", "q3f", "q3h", "q3d", "q3dc", "joinm", "joinmh", "filterm", "gather", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s"])
+    ap.add_argument("--workload", default="q1", choices=["q1", "q1j", "q3", "q3f", "q3h", "q3d", "q3dc", "joinm", "joinmh", "filterm", "gather", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "cfg5l"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the SF100 / 1e9-row size of the workload)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -970,6 +970,35 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
                         verify=verify, scope="operator")
         wl5s.inputs = [views, v]
         return wl5s
+    if name == "cfg5l":
+        # config 5 with keys the view does not hold: 20-byte strings "id%010d-longkey" (views {20, prefix, buffer, offset} into a pool of the 1e6 distinct strings).  The
+        # string-key operator's fast path is inline keys only (kernels_strgroup.hip); a deferred views column of long keys is encoded on the device -- the encoder compares
+        # THROUGH the buffers (binview_index_map.rs:106-117 get_long_key) -- and the group-by runs on the codes.  The round-5 review's 20-byte-key extra.
+        n = rows or 1_000_000_000
+        views, data = datagen.long_id_views_native(pl, n, seed, 0, 1, 1_000_001)
+        v = native_uniform_column(pl, "v", pl.Float64, "Float64", n, seed, 1, 0, 10 ** 9, 1e-7)
+
+        def step():
+            k = pl.Series.from_device_views("k", views, data, encode="deferred")
+            return queries.cfg5(pl.DataFrame([k, v]).lazy()).collect(), (views, data, v, k)
+
+        def verify(res, budget):
+            import numpy as np
+            cats = list(res["k"].dtype.categories)
+            assert all(len(c) == 20 and c.endswith("-longkey") for c in cats[:1000])
+            ids = np.array([int(c[2:12]) for c in cats], dtype=np.int64)
+
+            class Mapped:
+                def __init__(self, a): self.a = a
+                def to_numpy(self): return self.a
+            codes = res["k"].to_numpy()
+            frame = {"k": Mapped(ids[codes] - 1), "v_sum": res["v_sum"], "v_mean": res["v_mean"]}
+            return verify_groupby_dense(frame, "k", "v_sum", n, seed, 1_000_000, "Int64", "Float64", (0, 10 ** 9, 1e-7), ("mean", "v_mean"), budget, key_args=(1, 1_000_001), key_shift=-1)
+        wl5l = Workload("cfg5_utf8view_20_byte_keys_1e9", n, n * 44 + 1_000_000 * 36, step, "strview_dict_encode",
+                        f"config 5 from raw strings the views do not hold: {n} rows, Utf8View keys (views into a pool of 1e6 distinct 20-byte strings) -> device-side dictionary "
+                        "encoding through the buffers -> group_by(k).agg(sum, mean) on the codes", verify=verify, scope="operator")
+        wl5l.inputs = [views, data, v]
+        return wl5l
     raise ValueError(name)
 
 
@@ -1219,7 +1248,7 @@ def pmc_traffic(workload_name: str, kernel: str, rows: int):
     never a number.  Only meaningful at the workload's full size."""
     short = {"tpch_q1_sf100": ("q1", SF100_LINEITEM), "tpch_q3_sf100": ("q3", SF100_ORDERS + SF100_LINEITEM), "tpch_q3_three_tables_sf100": ("q3f", None),
              "cfg2_filter_arith_agg_1e9": ("cfg2", 10 ** 9), "cfg3_groupby_1e6_keys_1e9": ("cfg3", 10 ** 9), "cfg5_dict_string_keys_1e9": ("cfg5", 10 ** 9),
-             "tpch_q3_sf100_shuffled_inputs": ("q3s", SF100_ORDERS + SF100_LINEITEM), "cfg5_utf8view_keys_1e9": ("cfg5s", 10 ** 9),
+             "tpch_q3_sf100_shuffled_inputs": ("q3s", SF100_ORDERS + SF100_LINEITEM), "cfg5_utf8view_keys_1e9": ("cfg5s", 10 ** 9), "cfg5_utf8view_20_byte_keys_1e9": ("cfg5l", 10 ** 9),
              "tpch_q3_sf100_hashed_keys": ("q3h", SF100_ORDERS + SF100_LINEITEM), "cfg2_nulls5pct_1e9": ("cfg2n", 10 ** 9), "cfg3_zipf_1e9": ("cfg3z", 10 ** 9),
              "cfg3_sparse_keys_1e9": ("cfg3s", 10 ** 9), "cfg3_two_int64_keys_1e9": ("cfg3w", 10 ** 9), "join_duplicate_build_keys_sf100": ("q3d", SF100_LINEITEM + SF100_LINEITEM * 2 // 15),
              "join_aggregate_reads_build_side_sf100": ("q3dc", SF100_LINEITEM + SF100_LINEITEM * 2 // 15), "join_materialise_sf100": ("joinm", SF100_ORDERS + SF100_LINEITEM), "join_materialise_sf100_hashed_keys": ("joinmh", SF100_ORDERS + SF100_LINEITEM),
@@ -2188,7 +2217,7 @@ def compare_q1_dicts(a: dict, b: dict) -> bool:
 
 MULTI_EXTRAS = ("q3", "q3:shuffle", "cfg3", "cfg5", "q1", "q1:weak")     # ":weak" = the per-rank SF100 shard (weak scaling), labelled so in its config.workload
 LATE_WORKLOADS = ("filterm", "gather")       # frame-returning operators with multi-gigabyte results: timed and checked last, one at a time
-EXTRA_WORKLOADS = ("q1j", "q3", "q3h", "q3d", "q3dc", "joinm", "joinmh", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "q1")      # the secondary workloads of the N = 1 line, in this order
+EXTRA_WORKLOADS = ("q1j", "q3", "q3h", "q3d", "q3dc", "joinm", "joinmh", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "cfg5l", "q1")      # the secondary workloads of the N = 1 line, in this order
 
 
 def run_multi(args, emit):

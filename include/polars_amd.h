@@ -489,6 +489,10 @@ int plx_strdict_free(plx_strdict dict);
 /* synthetic Utf8View column (benchmark support, BASELINE config 5 from raw strings): 2 n PLX_U64 words = the inline views of
  * "id%010d" % (lo + floor(U * (hi - lo))) with the same counter-based U as plx_datagen_uniform(stream) */
 int plx_datagen_id_views(int64_t n_rows, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, plx_column* out_views);
+/* the same for keys the view does NOT hold: 20-byte strings "id%010d-longkey"; out_views = 2 n PLX_U64 words {length 20 | 4-byte prefix, buffer 0 | offset}, out_data = the
+ * (hi - lo) * 20 bytes of the distinct strings, each once, at (value - lo) * 20 -- rows with equal keys share their bytes, as after a gather of a string column
+ * (the reference compares such keys through the buffers: crates/polars-compute/src/binview_index_map.rs:106-117 get_long_key) */
+int plx_datagen_long_id_views(int64_t n_rows, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, plx_column* out_views, plx_column* out_data);
 
 /* ---- Parquet scan -> device columns ------------------------------------
  * The scan in front of the hot path: the reference decodes Parquet on the CPU (crates/polars-parquet/src/parquet/read/page/reader.rs:183-300

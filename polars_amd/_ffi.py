@@ -128,6 +128,7 @@ SIGNATURES = {
     "plx_strdict_to_host": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p]),
     "plx_strdict_free": (C.c_int, [C.c_uint64]),
     "plx_datagen_id_views": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, _u64p]),
+    "plx_datagen_long_id_views": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, _u64p, _u64p]),
     "plx_parquet_open": (C.c_int, [C.c_char_p, _u64p]),
     "plx_parquet_close": (C.c_int, [C.c_uint64]),
     "plx_parquet_shape": (C.c_int, [C.c_uint64, _i64p, _i32p, _i32p]),

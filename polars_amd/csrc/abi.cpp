@@ -1113,6 +1113,17 @@ int plx_datagen_id_views(int64_t n_rows, uint64_t seed, uint32_t stream_id, int6
   PLX_CATCH
 }
 
+int plx_datagen_long_id_views(int64_t n_rows, uint64_t seed, uint32_t stream_id, int64_t lo, int64_t hi, plx_column* out_views, plx_column* out_data) {
+  PLX_TRY
+  PLX_REQUIRE(n_rows >= 0 && out_views && out_data && hi > lo && lo >= 0 && hi <= 10000000000ll && (hi - lo) * 20 < ((int64_t)1 << 32) && stream_id < 8, PLX_ERR_INVALID, "datagen_long_id_views: bad arguments");
+  ColumnPtr c = make_column(PLX_U64, n_rows * 2, false); c->null_count = 0;
+  ColumnPtr d = make_column(PLX_U8, (hi - lo) * 20, false); d->null_count = 0;
+  k::datagen_long_id_views(n_rows, seed, stream_id, lo, hi, c->values->as<uint64_t>(), d->values->as<uint8_t>());
+  *out_views = register_column(c);
+  *out_data = register_column(d);
+  PLX_CATCH
+}
+
 // ---- multi-GPU exchange (comm.cpp) -----------------------------------------------------
 int plx_comm_unique_id(uint8_t* out) { PLX_TRY PLX_REQUIRE(out, PLX_ERR_INVALID, "null pointer"); comm::unique_id(out); PLX_CATCH }
 int plx_comm_init(const uint8_t* id, int32_t rank, int32_t world_size, plx_comm* out) { PLX_TRY PLX_REQUIRE(out, PLX_ERR_INVALID, "null pointer"); *out = comm::init(id, rank, world_size); PLX_CATCH }

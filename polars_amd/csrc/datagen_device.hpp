@@ -121,5 +121,22 @@ PLX_HD inline void id_view(uint64_t v, uint64_t* w0, uint64_t* w1) {
   *w0 = a; *w1 = b;
 }
 
+// ---- Utf8View of the 20-byte string "id%010d-longkey" % v: NOT inline -- {length 20, prefix "id00".., buffer 0, offset} into a pool that holds every distinct string
+// once at (v - lo) * 20 (views of several rows may share bytes: what a gather of a string column leaves behind) ----------------------------------------------------
+constexpr int kLongIdLen = 20;
+PLX_HD inline void long_id_bytes(uint64_t v, unsigned char* s) {
+  s[0] = 'i'; s[1] = 'd';
+  for (int d = 11; d >= 2; d--) { s[d] = (unsigned char)('0' + v % 10); v /= 10; }
+  const char* tail = "-longkey";
+  for (int i = 0; i < 8; i++) s[12 + i] = (unsigned char)tail[i];
+}
+PLX_HD inline void long_id_view(uint64_t v, uint64_t lo, uint64_t* w0, uint64_t* w1) {
+  unsigned char s[kLongIdLen];
+  long_id_bytes(v, s);
+  uint64_t a = (uint64_t)kLongIdLen;
+  for (int i = 0; i < 4; i++) a |= (uint64_t)s[i] << (32 + 8 * i);
+  *w0 = a; *w1 = ((v - lo) * (uint64_t)kLongIdLen) << 32;      // buffer index 0 | offset << 32
+}
+
 }  // namespace datagen
 }  // namespace plx

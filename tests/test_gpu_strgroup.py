@@ -427,3 +427,30 @@ def test_string_key_group_by_long_keys_three_value_columns_min_max(pl, with_shor
     assert np.allclose(got["a_sum"], exp["a_sum"].to_numpy(), rtol=1e-6, atol=1e-9)
     cm = np.array([np.nan if x is None else x for x in got["c_mean"]], dtype=np.float64)
     assert np.allclose(cm, exp["c_mean"].to_numpy(), rtol=1e-6, atol=1e-12, equal_nan=True)
+
+
+def test_generated_20_byte_keys_views_pool_and_group_by(pl):
+    """plx_datagen_long_id_views (bench workload cfg5l): the views are {20, "id00".., buffer 0, (id - lo) * 20}, the pool holds "id%010d-longkey" of every id once;
+    the deferred column of such keys groups through device encoding (the string-key operator's fast path declines: the view is not the string) and equals numpy."""
+    from polars_amd import datagen
+    n, seed, lo, hi = 3_000_017, 21, 1, 50_001
+    views, data = datagen.long_id_views_native(pl, n, seed, 0, lo, hi)
+    ids = datagen.uniform_native_host("Int64", 0, n, seed, 0, lo, hi)
+    pool = data.to_numpy()
+    assert pool.dtype == np.uint8 and len(pool) == (hi - lo) * 20
+    want_pool = np.frombuffer(b"".join(b"id%010d-longkey" % i for i in range(lo, hi)), np.uint8)
+    assert np.array_equal(pool, want_pool)
+    w = views.to_numpy().reshape(n, 2)
+    prefix = np.frombuffer(b"".join(b"id%010d" % i for i in range(lo, hi)), np.uint8).reshape(-1, 12)[:, :4].copy().view(np.uint32).reshape(-1).astype(np.uint64)
+    assert np.array_equal(w[:, 0], np.uint64(20) | (prefix[ids - lo] << np.uint64(32)))
+    assert np.array_equal(w[:, 1], ((ids - lo).astype(np.uint64) * np.uint64(20)) << np.uint64(32))
+    v = datagen.uniform_native(pl, "v", pl.Float64, n, seed, 1, 0, 10 ** 9, 1e-7)
+    k = pl.Series.from_device_views("k", views, data, encode="deferred")
+    out = pl.DataFrame([k, v]).lazy().group_by("k").agg(pl.col("v").sum().alias("v_sum"), pl.col("v").mean().alias("v_mean"), pl.len()).collect()
+    assert "StringViewGroupBy" not in pl.last_plan(), pl.last_plan()
+    vals = datagen.uniform_native_host("Float64", 0, n, seed, 1, 0, 10 ** 9, 1e-7)
+    s, c = np.bincount(ids, weights=vals, minlength=hi), np.bincount(ids, minlength=hi)
+    present = np.nonzero(c)[0]
+    got = _by_key(out)
+    assert got["k"] == ["id%010d-longkey" % i for i in present]
+    assert np.allclose(got["v_sum"], s[present], rtol=1e-9) and np.allclose(got["v_mean"], s[present] / c[present], rtol=1e-9) and got["len"] == c[present].tolist()
