@@ -904,6 +904,10 @@ int plx_jit_selftest(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int
           jobs.push_back({sh, jit::part3_agg_sink(mode, pack)});
         }
       }
+      if (fused::pair_pack_ok(sh, fused::kP2Direct)) {      // two rows a record (a 64-bit value that does not narrow over direct-address slots)
+        for (uint32_t tiles : {1u, 2u, 3u, 4u}) { jobs.push_back({sh, jit::part3_scatter_sink(fused::kP2Direct, tiles, fused::kPackPair, false)}); jobs.push_back({sh, jit::part3_scatter_sink(fused::kP2Direct, tiles, fused::kPackPair, true)}); }
+        jobs.push_back({sh, jit::part3_agg_sink(fused::kP2Direct, fused::kPackPair)});
+      }
     }
     if (sh.n_keys >= 2) {
       // wide key: the HBM table sink, and the partitioned path -- hash partitions, plain or narrowed records, no hot keys
@@ -948,13 +952,17 @@ void materialise(StrDict& d) {
   d.materialised = true;
 }
 // shared tail of both entry points: views / validity / data are on the device
-void encode_on_device(const uint64_t* views, const ColumnPtr& validity_holder, Buf data, Buf buf_base, int64_t n, plx_column* out_codes, plx_strdict* out_dict) {
-  Buf codes, dviews;
-  int64_t nd = 0;
-  k::strview_dict_encode(views, validity_holder ? validity_holder->valid_words() : nullptr, data ? data->as<uint8_t>() : nullptr, buf_base ? buf_base->as<uint64_t>() : nullptr, n, &codes, &dviews, &nd);
+// from_stamps: the column has no bitmap, its nulls are stamped views (the raw-view interfaces) -- the encoder reads the bitmap off the stamps in its own pass
+void encode_on_device(const uint64_t* views, const ColumnPtr& validity_holder, Buf data, Buf buf_base, int64_t n, plx_column* out_codes, plx_strdict* out_dict, bool from_stamps = false) {
+  Buf codes, dviews, svalid;
+  int64_t nd = 0, snulls = 0;
+  k::strview_dict_encode(views, validity_holder ? validity_holder->valid_words() : nullptr, data ? data->as<uint8_t>() : nullptr, buf_base ? buf_base->as<uint64_t>() : nullptr, n, &codes, &dviews, &nd,
+                         from_stamps && !validity_holder ? &svalid : nullptr, &snulls);
   auto c = std::make_shared<Column>();
   c->dtype = PLX_U32; c->len = n; c->values = codes;
-  if (validity_holder && validity_holder->validity) c->validity = validity_holder->validity; else c->null_count = 0;
+  if (validity_holder && validity_holder->validity) c->validity = validity_holder->validity;
+  else if (snulls > 0) { c->validity = svalid; c->null_count = snulls; }
+  else c->null_count = 0;
   if (nd > 0) { c->range_state = 1; c->range_min = 0; c->range_max = nd - 1; c->range_trusted = true; }   // codes are dense by construction
   auto d = std::make_unique<StrDict>();
   d->views = dviews; d->data = data; d->n = nd;
@@ -1013,14 +1021,8 @@ int plx_strview_dict_encode_device(plx_column views_u64_pairs, plx_column data_u
   Buf data, bb = dev_alloc_zero(8);
   if (data_u8) { ColumnPtr d = get_column(data_u8); PLX_REQUIRE(d->dtype == PLX_U8, PLX_ERR_INVALID, "data must be a UInt8 column"); data = d->values; }
   // nulls arrive as stamped views (plx_strview_stamp_nulls / plx_ipc_read_string_views): the bitmap the encoder and the code column want is read off the stamps
-  ColumnPtr vh;
   const int64_t n = v->len / 2;
-  if (n > 0) {
-    Buf bits = dev_alloc(bitmap_bytes(n));
-    const int64_t nulls = k::strview_validity_from_stamps(v->values->as<uint64_t>(), n, bits->as<uint64_t>());
-    if (nulls > 0) { vh = std::make_shared<Column>(); vh->dtype = PLX_U8; vh->len = n; vh->validity = bits; vh->null_count = nulls; }
-  }
-  encode_on_device(v->values ? v->values->as<uint64_t>() : nullptr, vh, data, bb, n, out_codes, out_dict);
+  encode_on_device(v->values ? v->values->as<uint64_t>() : nullptr, nullptr, data, bb, n, out_codes, out_dict, /*from_stamps=*/true);
   // the dictionary's views point into nothing else than `data`; inline strings need no buffer at all
   PLX_CATCH
 }

@@ -270,7 +270,13 @@ constexpr uint32_t kNoChunk = 0xffffffffu;
 //                (the planner checks key_shift + bits(max - min) <= 32)
 //   kPackRowid   direct mode, no source, row id payload (the partitioned join probe): two dwords, key_low | row << key_shift (a 64-bit
 //                field: key_shift + 32 row bits always fit); null keys never become records, so there is no validity dword
-constexpr uint32_t kPackNone = 0, kPackNarrow = 1, kPackFused = 2, kPackRowid = 3;
+//   kPackPair    direct mode, ONE 64-bit source that does not narrow (an f64 sum over dictionary codes: config 5), no validity, no row id, slots < 2^16 - 1: the rows of a
+//                partition travel TWO to a record of five dwords {slot0 | slot1 << 16, value0, value1} -- 10 bytes a row instead of 12.  Pairs are formed in the scatter's
+//                tile sort (rank r of a partition's rows in the tile -> pair r / 2, half r % 2); a partition with an odd number of rows in a tile closes its last pair
+//                with the slot 0xffff ("absent": ~1.5 % more pairs at 8192-row tiles and 256 partitions).  RecLayout2 describes ONE ROW (three dwords, as kPackNone) and
+//                says rec_words = 5: the unit of the record stream, of the chunks and of chunk_fill is the PAIR
+constexpr uint32_t kPackNone = 0, kPackNarrow = 1, kPackFused = 2, kPackRowid = 3, kPackPair = 4;
+constexpr uint32_t kPairAbsent = 0xffffu;
 struct RecLayout2 {
   uint8_t n_key_cols;            // 0: one key slot (Shape::key); 2..kMaxKeys: a wide key -- Shape::keys, one 64-bit word per key column, null keys flagged in the validity dword
   uint8_t key_words;             // 1 | 2 dwords (wide key: 2 per key column)
@@ -339,7 +345,7 @@ PLX_FHD constexpr RecLayout2 rec_layout2(const Shape& sh, uint32_t mode, uint32_
   L.n_src = (uint8_t)n_src;
   for (uint32_t j = 0; j < n_src && j < (uint32_t)kMaxSrc; j++) {
     L.src_kind[j] = narrow_kind(sh, L.src_slot[j]);
-    if (pack != kPackNone && slot_is_int64_column(sh, L.src_slot[j])) L.src_kind[j] = 3;
+    if (pack != kPackNone && pack != kPackPair && slot_is_int64_column(sh, L.src_slot[j])) L.src_kind[j] = 3;      // (a pair's values travel whole)
     L.src_off[j] = (uint8_t)w;
     w += L.src_kind[j] ? 1 : 2;
   }
@@ -349,8 +355,16 @@ PLX_FHD constexpr RecLayout2 rec_layout2(const Shape& sh, uint32_t mode, uint32_
   L.valid_off = (uint8_t)w; w += L.has_valid;
   L.rowid_off = (uint8_t)w; w += 2 * L.has_rowid;
   L.rec_words = (uint8_t)w;
+  if (pack == kPackPair) L.rec_words = 5;      // planner-checked (pair_pack_ok): a row is {slot, value lo, value hi}; two rows share a record
   return L;
 }
+// does the shape admit kPackPair at all (the planner still checks the slot count)?
+PLX_FHD constexpr bool pair_pack_ok(const Shape& sh, uint32_t mode) {
+  const RecLayout2 L = rec_layout2(sh, mode, kPackNone);
+  return mode == kP2Direct && !sh.n_keys && L.n_src == 1 && L.src_kind[0] == 0 && !L.has_valid && !L.has_rowid && L.rec_words == 3;
+}
+// dwords a ROW occupies in the scatter's registers and LDS tile (kPackPair: three, like the unpacked row; two rows then share a five-dword record)
+PLX_FHD constexpr uint32_t scatter_row_words(const RecLayout2& L) { return L.pack == kPackPair ? 3u : (uint32_t)L.rec_words; }
 struct PartPlan2 {
   uint32_t mode;               // kP2Hash | kP2Direct
   uint32_t log2_parts;         // P = 1 << log2_parts partitions

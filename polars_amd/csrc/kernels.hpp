@@ -50,8 +50,10 @@ void datagen_customer(int64_t n, uint64_t seed, int64_t* custkey, uint8_t* segme
 // ---- raw Utf8View / BinaryView keys (kernels_strview.hip) ---------------------------------------
 // device-side dictionary encoding of 16-byte views (+ concatenated data buffers): u32 code per row (first-claim order), the number
 // of distinct strings and their views ([n_distinct][2] u64; long strings carry their absolute offset into `data`).  Synchronises.
+// stamps_valid (may be null; used when validity == null): the nulls of the column are STAMPED views (kStrviewNullLen, below) -- they become null keys, and the bitmap read off
+// the stamps comes back in *stamps_valid with their number in *stamps_nulls (the encode's own pass over the views: no separate one).
 void strview_dict_encode(const uint64_t* views, const uint64_t* validity, const uint8_t* data, const uint64_t* buf_base, int64_t n, Buf* out_codes, Buf* out_dict_views,
-                         int64_t* n_distinct);
+                         int64_t* n_distinct, Buf* stamps_valid = nullptr, int64_t* stamps_nulls = nullptr);
 // dictionary -> offsets[n + 1] (u64) + contiguous bytes on the device
 // Utf8 / LargeUtf8 arrays (offsets + bytes, already in HBM) -> 16-byte views: {len, 12 inline bytes} or {len, 4-byte prefix, buffer 0, offset
 // data_base + start}; null rows (validity bit row0 + i clear) become all-zero views, or null stamps (below) with stamp_nulls.  *err (device u32) is set when an offset pair is not
@@ -59,11 +61,10 @@ void strview_dict_encode(const uint64_t* views, const uint64_t* validity, const 
 void strviews_from_offsets(const void* offsets, bool large, const uint8_t* data, uint64_t data_base, int64_t data_len, int64_t n, uint64_t* views_out, const uint64_t* validity, int64_t row0, bool stamp_nulls,
                            unsigned int* err);
 // A null entry of a view column that travels WITHOUT a bitmap (plx_strview_groupby, plx_strview_dict_encode_device, plx_ipc_read_string_views) is a view whose length
-// word is kStrviewNullLen -- no Arrow view has it (lengths are non-negative int32).  strview_stamp_nulls writes the stamps from a bitmap (in place),
-// strview_validity_from_stamps gives the bitmap back ([ceil(n / 64)] words) and returns the number of nulls.
+// word is kStrviewNullLen -- no Arrow view has it (lengths are non-negative int32).  strview_stamp_nulls writes the stamps from a bitmap (in place);
+// strview_dict_encode reads the bitmap back off the stamps in its own pass (stamps_valid).
 constexpr uint32_t kStrviewNullLen = 0xffffffffu;
 void strview_stamp_nulls(uint64_t* views, const uint64_t* validity, int64_t n);
-int64_t strview_validity_from_stamps(const uint64_t* views, int64_t n, uint64_t* valid);
 // group_by(raw Utf8View key).agg(sum / count / len of one 8-byte numeric column) without a dictionary-encode pass (kernels_strgroup.hip); -1 = not on the fast path.
 // A stamped (null) key is a key of its own; strview_null_group finds its group among the G result views (-> 0 or 1), clears its bit of `valid` and empties its view.
 int64_t strview_groupby(const uint64_t* views, const uint64_t* values, const uint64_t* val_validity, int64_t n, bool is_f64, Buf* out_views, Buf* out_sum, Buf* out_cnt, Buf* out_len,

@@ -204,7 +204,9 @@ static void plan2_geometry(PartPlan2& pp, int64_t n_rows, uint32_t tiles) {
   const int64_t nrounds = (n_rows + rows_per_round - 1) / rows_per_round;
   pp.scatter_grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(nrounds, (int64_t)device().cu_count * std::max(1, kEnvP2Wgs)));
   const int64_t rounds_per_wg = (nrounds + pp.scatter_grid - 1) / pp.scatter_grid;
-  pp.chunks_per_wg = (uint32_t)(rounds_per_wg * rows_per_round / kP2ChunkRecs + (1u << pp.log2_parts) + 2);
+  // records a round leaves at most (kPackPair: two rows a record, every partition may close one pair alone)
+  const int64_t recs_per_round = pp.pack == kPackPair ? rows_per_round / 2 + (int64_t)(1u << pp.log2_parts) / 2 + 1 : rows_per_round;
+  pp.chunks_per_wg = (uint32_t)(rounds_per_wg * recs_per_round / kP2ChunkRecs + (1u << pp.log2_parts) + 2);
 }
 
 static uint32_t bits_for(uint64_t span) { uint32_t b = 0; while (b < 64 && (span >> b)) b++; return b; }     // bits that hold 0..span
@@ -227,7 +229,10 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
     if (pack_cap >= 2 && best_static_pack(sh, pp.mode) == kPackFused && ranges[0].known && ranges[0].mx >= ranges[0].mn &&
         pp.key_shift + bits_for((uint64_t)ranges[0].mx - (uint64_t)ranges[0].mn) <= 32) pack = kPackFused;
   }
-  const RecLayout2 L = rec_layout2(sh, pp.mode, pack);
+  // a 64-bit value that does not narrow (f64) over direct-address slots: two rows a record, 10 bytes a row (fused.hpp kPackPair; PLX_PART_PAIR=0: measurement)
+  static const bool pair_off = getenv("PLX_PART_PAIR") && getenv("PLX_PART_PAIR")[0] == '0';
+  if (pack == kPackNone && !pair_off && pair_pack_ok(sh, pp.mode) && pp.key_shift <= 15) pack = kPackPair;      // (the tile must hold the lone halves too: checked below)
+  RecLayout2 L = rec_layout2(sh, pp.mode, pack);
   if (L.n_src > (uint32_t)kMaxSrc || L.rec_words > 13) return false;
   for (int j = 0; j < kMaxSrc; j++) pp.src_base[j] = (pack != kPackNone && ranges && ranges[j].known && (L.src_kind[j] == 3 || pack == kPackFused)) ? ranges[j].mn : 0;
   pp.check_src = 0;
@@ -238,7 +243,7 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
   for (uint32_t t : {4u, 3u, 2u, 1u}) {
     if (kEnvP2Tiles > 0 && t > (uint32_t)kEnvP2Tiles) continue;
     if ((pp.mode == kP2Hash || pp.n_hot) && t > 3) continue;      // hash partitions keep the 64-bit key and its hash live, the hot-key path its lookups: four tiles spill (12-24 B / lane; a scratch reload waits for every load in flight)
-    if (part3_scatter_lds(block * kRows * t, L.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies) <= lds_total) { tiles = t; break; }
+    if (part3_scatter_lds(block * kRows * t, scatter_row_words(L), NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies) <= lds_total) { tiles = t; break; }
   }
   if (!tiles) return false;
   // The per-round cost of the scatter is per PARTITION, so what counts is rows per round.  When the LDS holds only one or two tiles of a full 1024-thread workgroup
@@ -248,9 +253,11 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
   if (!(kEnvP3Block >= 64) && !(kEnvP2Tiles > 0) && tiles < ((pp.mode == kP2Hash || pp.n_hot) ? 3u : 4u)) {
     for (uint32_t b = (uint32_t)kP2MaxBlock - 64; b >= 768 && b >= NP; b -= 64) {
       if (b * (tiles + 1) <= block * tiles) break;                       // no more rows a round than what we have
-      if (part3_scatter_lds(b * kRows * (tiles + 1), L.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies) <= lds_total) { block = b; tiles = tiles + 1; break; }
+      if (part3_scatter_lds(b * kRows * (tiles + 1), scatter_row_words(L), NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies) <= lds_total) { block = b; tiles = tiles + 1; break; }
     }
   }
+  // (pairs need room for the partitions' lone halves in the tile: at most T / 2 + NP / 2 five-dword records in 3 T dwords)
+  if (pack == kPackPair && NP * 5 > block * kRows * tiles) { pack = kPackNone; L = rec_layout2(sh, pp.mode, pack); }
   pp.gen = 3; pp.pack = pack; pp.rec_words = L.rec_words; pp.block = block; pp.ring_lines = 0;
   plan2_geometry(pp, n_rows, tiles);
   // chunks are filled completely (the carry line keeps the remainder): whole chunks of the rows + one partial chunk per partition + slack
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(kBlock) void hot_emit_kernel(const unsigned long lo
 #define PLX_P3_COMBOS(X)                                                                                                              \
   X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow)                                      \
   X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackFused) \
-  X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackNone)                              \
+  X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackPair) \
   X(SHAPE_GB2_SUM_CNT_I64, kP2Hash, 2, kPackNarrow)       /* two-column key at 512 partitions: 20-byte records, two tiles of an 896-thread workgroup (values that do not narrow: 24-byte records, run-time compiled) */
 // ... and with the hot-key path compiled in (skewed keys: heavy hitters are summed in the scatter), for config 3's two runs -- key range unknown / known
 #define PLX_P3_HOT_COMBOS(X) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 3, kPackFused)
@@ -512,6 +519,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
                                    (gen3 && pp.n_hot ? ",hot]" : "]");
   const std::string agg_name = "part_agg_lds[" + sid + (direct ? ",d,p" : ",h,p") + std::to_string(pp.pack) + "]";
   PLX_REQUIRE(pp.n_hot == hot_keys.size(), PLX_ERR_INVALID, "partitioned_agg2: plan / hot key list mismatch");
+  const uint32_t row_bytes = pp.pack == kPackPair ? 10u : pp.rec_words * 4u;      // bytes a row travels as (a pair of rows shares a 20-byte record)
   const uint32_t chunk_dw = kP2ChunkRecs * pp.rec_words;
   const int64_t n_chunks = (int64_t)pp.scatter_grid * pp.chunks_per_wg;
   Buf recs = dev_alloc_transient((size_t)n_chunks * chunk_dw * 4 + 256);
@@ -551,11 +559,11 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
     PLX_HIP(hipStreamSynchronize(stream()));     // `init` is a stack object
     sp.key_minmax = minmax->as<long long>();
   }
-  const size_t slds = gen3 ? part3_scatter_lds(pp.block * kRows * pp.tiles, pp.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies)
+  const size_t slds = gen3 ? part3_scatter_lds(pp.block * kRows * pp.tiles, pp.pack == kPackPair ? 3u : pp.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies)
                            : part2_scatter_lds(NP, pp.ring_lines, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies);
   {
     // pass traffic: inputs read once + every surviving row written as one record (upper bound: all rows)
-    ProfileScope ps(scatter_name.c_str(), scan_bytes(sh, args) + (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
+    ProfileScope ps(scatter_name.c_str(), scan_bytes(sh, args) + (uint64_t)args.n_rows * row_bytes, (uint64_t)args.n_rows);
     if (!use_jit && gen3) part3_static_scatter(static_id, sh, args, pp, sp, slds);
     else if (use_jit) {
       Shape shc = sh; Args ac = args; PartPlan2 ppc = pp; ScatterParams2 spc = sp;
@@ -597,7 +605,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   ap.max_groups = (uint32_t)std::min<uint64_t>(max_groups, 0xffffffffull);
   if (wide_stride_out) *wide_stride_out = (int64_t)ap.max_groups;
   {
-    ProfileScope ps(agg_name.c_str(), (uint64_t)args.n_rows * pp.rec_words * 4, (uint64_t)args.n_rows);
+    ProfileScope ps(agg_name.c_str(), (uint64_t)args.n_rows * row_bytes, (uint64_t)args.n_rows);
     const size_t lds = wide ? (size_t)pp.n_tags * 4 + n_slots * 8 * ((size_t)sh.n_keys + pp.wide_null_word + sh.n_aggs) : n_slots * 8 * ((direct ? 0 : 1) + sh.n_aggs);
     if (!use_jit && gen3) part3_static_agg(static_id, pp, ap, NP, lds);
     else if (use_jit) {
@@ -623,7 +631,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
   PLX_REQUIRE(!res[5], PLX_ERR_INVALID, "aggregated value outside the bounds assumed for its column");
   if (res[2]) return -1;
   if (minmax) { long long mm[2]; d2h_sync(mm, minmax->ptr, 16); key_range_out[0] = mm[0]; key_range_out[1] = mm[1]; }
-  if (desc) *desc = std::string(gen3 ? "partitioned(v3," : "partitioned(v2,") + (direct ? "direct" : "hash") + ",P=" + std::to_string(NP) + ",rec=" + std::to_string(pp.rec_words * 4) +
+  if (desc) *desc = std::string(gen3 ? "partitioned(v3," : "partitioned(v2,") + (direct ? "direct" : "hash") + ",P=" + std::to_string(NP) + ",rec=" + std::to_string(row_bytes) +
                     (gen3 ? "B,pack=" + std::to_string(pp.pack) + ",tile=" + std::to_string(pp.block * kRows * pp.tiles) : "B,ring=" + std::to_string(pp.ring_lines * 128) + "B") +
                     ",block=" + std::to_string(pp.block) + ",hot=" + std::to_string(pp.n_hot) + (use_jit ? ",kernels=jit" : ",kernels=aot") + ")+" + (direct ? "lds_direct_table(slots=" : wide ? "lds_wide_key_table(words=" + std::to_string(sh.n_keys + pp.wide_null_word) + ",slots=" : "lds_hash_table(slots=") +
                     std::to_string(direct ? 1u << pp.log2_slots : pp.n_slots) + ")";

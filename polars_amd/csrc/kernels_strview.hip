@@ -50,6 +50,11 @@ struct StrEncode {
   unsigned int* out_codes;            // [n] (null for a counting-only sample pass)
   unsigned long long* dict_views;     // [max_codes][2] view of every code's string (long strings rebased: absolute offset in w1's high half)
   uint32_t max_codes;
+  // a view column that travels without a bitmap (validity == null) marks its nulls by STAMPED views (length kStrviewNullLen: plx_strview_stamp_nulls): stamps = 1 makes
+  // such rows null keys; stamp_valid (may be null) receives the validity bitmap read off the stamps, stamp_nulls[0] their number -- no pass of its own over the views
+  uint32_t stamps;
+  unsigned long long* stamp_valid;
+  unsigned long long* stamp_nulls;
 };
 
 __device__ __forceinline__ unsigned long long ld(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -89,7 +94,7 @@ struct StrKey { uint64_t w0, w1, tag, slot; const unsigned char* bytes; uint32_t
 
 __device__ __forceinline__ StrKey str_key(const StrEncode& e, const StrTable& t, int64_t row, ulonglong2 v) {
   StrKey k;
-  k.valid = !e.validity || ((e.validity[row >> 6] >> (row & 63)) & 1);
+  k.valid = e.validity ? ((e.validity[row >> 6] >> (row & 63)) & 1) : (!e.stamps || (uint32_t)v.x != kStrviewNullLen);
   k.len = (uint32_t)v.x;
   k.is_long = k.len > 12;
   k.w0 = v.x; k.w1 = v.y; k.bytes = nullptr;
@@ -136,6 +141,15 @@ __global__ __launch_bounds__(kBlock) void strview_encode_kernel(StrEncode e, Str
       if (row >= e.n) key[r].valid = false;
       code[r] = key[r].valid ? -1 : 0;
       probes[r] = 0;
+      if (e.stamp_valid) {        // (wave-uniform) the 64 rows of this wave and r are one word of the bitmap: lane 0's row is a multiple of 64
+        const uint64_t m = ballot(key[r].valid);
+        const int64_t row_l0 = __shfl(row, 0, 64);
+        if (lane_id() == 0 && row_l0 < e.n) {
+          e.stamp_valid[row_l0 >> 6] = m;
+          const int64_t rows = e.n - row_l0 < 64 ? e.n - row_l0 : 64;
+          if (rows != popc64(m)) atomicAdd(e.stamp_nulls, (unsigned long long)(rows - popc64(m)));
+        }
+      }
     }
     // plain probes, kStrRows independent lines in flight
     bool any = true;
@@ -236,25 +250,30 @@ __global__ __launch_bounds__(kBlock) void strdict_copy_kernel(const unsigned lon
 // views / validity / data: device buffers.  Returns the codes (device, u32 per row), the number of distinct strings and the
 // dictionary's views (device, [n_distinct][2], long strings carrying their absolute data offset).
 void strview_dict_encode(const uint64_t* views, const uint64_t* validity, const uint8_t* data, const uint64_t* buf_base, int64_t n, Buf* out_codes, Buf* out_dict_views,
-                         int64_t* n_distinct) {
+                         int64_t* n_distinct, Buf* stamps_valid, int64_t* stamps_nulls) {
   *out_codes = dev_alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1));
+  if (stamps_nulls) *stamps_nulls = 0;
   if (n == 0) { *out_dict_views = dev_alloc(16); *n_distinct = 0; return; }
+  const bool stamps = stamps_valid && !validity;
+  if (stamps) *stamps_valid = dev_alloc(bitmap_bytes(n));
   auto run = [&](int64_t rows, uint32_t log2_cap, uint32_t max_codes, unsigned int* codes, Buf* dict, uint32_t* distinct) -> bool {
     const uint64_t cap = 1ull << log2_cap;
-    Buf slots = dev_alloc(sizeof(StrSlot) * cap), ctr = dev_alloc_zero(8);
+    Buf slots = dev_alloc(sizeof(StrSlot) * cap), ctr = dev_alloc_zero(16);      // [0] codes handed out, [1] overflow, [2..3] nulls read off the stamps (u64)
     PLX_HIP(hipMemsetAsync(slots->ptr, 0xff, sizeof(StrSlot) * cap, stream()));
     if (dict) *dict = dev_alloc(16 * (size_t)std::max<uint32_t>(max_codes, 1));
     StrTable t{slots->as<StrSlot>(), ctr->as<unsigned int>(), log2_cap,
                (uint32_t)std::min<uint64_t>(cap, 1u << 12)};
-    StrEncode e{(const unsigned long long*)views, validity, data, (const unsigned long long*)buf_base, rows, codes, dict ? (*dict)->as<unsigned long long>() : nullptr, max_codes};
+    StrEncode e{(const unsigned long long*)views, validity, data, (const unsigned long long*)buf_base, rows, codes, dict ? (*dict)->as<unsigned long long>() : nullptr, max_codes,
+                stamps ? 1u : 0u, stamps && codes ? (*stamps_valid)->as<unsigned long long>() : nullptr, ctr->as<unsigned long long>() + 1};
     {
       ProfileScope ps("strview_dict_encode", (uint64_t)rows * (16 + (codes ? 4 : 0)), (uint64_t)rows);
       hipLaunchKernelGGL(strview_encode_kernel, dim3(grid_for(rows, kBlock * kStrRows, 8)), dim3(kBlock), 0, stream(), e, t);
       PLX_HIP(hipGetLastError());
     }
-    uint32_t res[2] = {0, 0};
-    d2h_sync(res, ctr->ptr, 8);
+    uint32_t res[4] = {0, 0, 0, 0};
+    d2h_sync(res, ctr->ptr, 16);
     *distinct = res[0];
+    if (stamps && codes && stamps_nulls) *stamps_nulls = (int64_t)((uint64_t)res[2] | ((uint64_t)res[3] << 32));
     return res[1] == 0;
   };
   // table size from a sample of the first rows: d distinct in S rows -> G ~ solution of d = G (1 - exp(-S / G))
@@ -326,36 +345,12 @@ __global__ __launch_bounds__(kBlock) void strview_stamp_kernel(unsigned long lon
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     if (!((validity[i >> 6] >> (i & 63)) & 1)) { views[i * 2] = (unsigned long long)kStrviewNullLen; views[i * 2 + 1] = 0ull; }
 }
-__global__ __launch_bounds__(kBlock) void strview_unstamp_kernel(const unsigned long long* __restrict__ views, int64_t n, unsigned long long* __restrict__ valid, unsigned long long* __restrict__ n_null) {
-  const int lane = lane_id();
-  const int64_t nwords = (n + 63) >> 6;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  unsigned long long mine = 0;
-  for (int64_t w = wave; w < nwords; w += nwaves) {
-    const int64_t i = w * 64 + lane;
-    const bool ok = i < n && (uint32_t)views[i * 2] != kStrviewNullLen;
-    const uint64_t m = ballot(ok);
-    if (lane == 0) { valid[w] = m; const int64_t rows = n - w * 64 < 64 ? n - w * 64 : 64; mine += (unsigned long long)(rows - popc64(m)); }
-  }
-  if (lane == 0 && mine) atomicAdd(n_null, mine);
-}
 }  // namespace
 void strview_stamp_nulls(uint64_t* views, const uint64_t* validity, int64_t n) {
   if (n <= 0 || !validity) return;
   hipLaunchKernelGGL(strview_stamp_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, stream(), (unsigned long long*)views, validity, n);
   PLX_HIP(hipGetLastError());
 }
-int64_t strview_validity_from_stamps(const uint64_t* views, int64_t n, uint64_t* valid) {
-  if (n <= 0) return 0;
-  Buf cnt = dev_alloc_zero(8);
-  ProfileScope ps("strview_nulls", (uint64_t)n * 8, (uint64_t)n);
-  hipLaunchKernelGGL(strview_unstamp_kernel, dim3(grid_for(n, kBlock * 2)), dim3(kBlock), 0, stream(), (const unsigned long long*)views, n, (unsigned long long*)valid, cnt->as<unsigned long long>());
-  PLX_HIP(hipGetLastError());
-  uint64_t c = 0;
-  d2h_sync(&c, cnt->ptr, 8);
-  return (int64_t)c;
-}
-
 // dictionary -> contiguous bytes + offsets[n + 1] on the device
 void strdict_materialise(const uint64_t* dict_views, const uint8_t* data, int64_t n, Buf* out_offsets, Buf* out_bytes, uint64_t* total_bytes) {
   *out_offsets = dev_alloc(sizeof(uint64_t) * (size_t)(n + 2));

@@ -675,6 +675,29 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   };
   auto process = [&](unsigned int (*cur)[16], uint32_t cnt_cur) __attribute__((always_inline)) {
     if (wide) { process_wide(cur, cnt_cur); return; }
+    if (L.pack == kPackPair) {
+      // a record is a PAIR of rows {slot0 | slot1 << 16, value0, value1} of a direct-address partition (fused.hpp kPackPair); slot 0xffff = the half is absent
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) {
+        if ((uint32_t)lane + u * 64u >= cnt_cur) continue;
+        const unsigned int* rec = cur[u];
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+          const uint32_t sl = h ? rec[0] >> 16 : rec[0] & 0xffffu;
+          if (sl == kPairAbsent) continue;
+          const uint64_t v = (uint64_t)rec[1 + 2 * h] | ((uint64_t)rec[2 + 2 * h] << 32);
+          unsigned long long* cell = cells + (size_t)sl * n_aggs;
+#pragma unroll
+          for (uint32_t k = 0; k < (uint32_t)kMaxAggs; k++) {
+            if (k >= n_aggs) break;
+            const uint8_t kind = sh.aggs[k].kind;
+            const uint64_t x = agg_row_value(kind, L.agg_src[k] != kNone ? v : 0ull, true, true, 0ull);
+            if (x != agg_identity_dev(kind) || kind == AGG_SUM_F) lds_atomic_agg(kind, cell + k, x);
+          }
+        }
+      }
+      return;
+    }
     // the lane's records of the chunk are handled in three passes so that their LDS round trips overlap: (1) decode the key and
     // read the table word of its home slot for every record, (2) resolve the slot (hit on the first probe in the common case; the
     // CAS / linear-probe loop otherwise), (3) update the cells

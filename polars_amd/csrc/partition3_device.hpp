@@ -44,7 +44,10 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
   extern __shared__ __attribute__((aligned(16))) unsigned long long p2_lds[];
   constexpr Shape sh = P::shape();
   constexpr RecLayout2 L = rec_layout2(P::shape(), (uint32_t)MODE, (uint32_t)PACK);
-  constexpr uint32_t RW = L.rec_words;
+  constexpr uint32_t RW = L.rec_words;                  // dwords of a record of the stream (kPackPair: a PAIR of rows)
+  constexpr bool PAIR = PACK == (int)kPackPair;
+  constexpr uint32_t SW = scatter_row_words(L);         // dwords of a row in registers / of the tile's budget per row
+  static_assert(!PAIR || (MODE == (int)kP2Direct && RW == 5 && SW == 3), "kPackPair: direct mode, {slot, 64-bit value} rows");
   constexpr uint32_t chunk_dw = kP2ChunkRecs * RW, cap_lines = chunk_dw / 32;      // a chunk holds whole records AND whole lines
   const uint32_t NP = 1u << pp.log2_parts;
   const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0u;
@@ -53,7 +56,7 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
   unsigned long long* hot_k = p2_lds + (size_t)NP * 2;
   unsigned long long* hot_acc = hot_k + hot_slots;
   unsigned int* sorted = reinterpret_cast<unsigned int*>(hot_acc + (size_t)pp.n_hot * sh.n_aggs * pp.hot_copies);
-  unsigned int* carry = sorted + (size_t)T * RW;
+  unsigned int* carry = sorted + (size_t)T * SW;       // (pairs: at most T / 2 + NP / 2 records of five dwords <= 3 T)
   unsigned int* cnt = carry + (size_t)NP * 32;
   unsigned int* off = cnt + NP;
   unsigned int* carry_dw = off + NP + 1;
@@ -69,7 +72,7 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
   for (uint32_t i = threadIdx.x; i < hot_slots; i += blockDim.x) { hot_k[i] = sp.hot_tbl_keys[i]; hot_i[i] = sp.hot_tbl_idx[i]; }
   for (uint32_t i = threadIdx.x; i < pp.n_hot * sh.n_aggs * pp.hot_copies; i += blockDim.x) hot_acc[i] = agg_identity_dev(sh.aggs[(i / pp.hot_copies) % sh.n_aggs].kind);
   if (threadIdx.x < 4) misc[threadIdx.x] = 0;
-  if (threadIdx.x == 0 && (pp.tiles != (uint32_t)TILES || pp.pack != (uint32_t)PACK || pp.rec_words != RW)) sp.flags[0] = 1u;     // host and kernel disagree about the geometry: fail the query
+  if (threadIdx.x == 0 && (pp.tiles != (uint32_t)TILES || pp.pack != (uint32_t)PACK || pp.rec_words != RW || (PAIR && pp.key_shift > 15))) sp.flags[0] = 1u;     // host and kernel disagree about the geometry: fail the query
   __syncthreads();
   const uint32_t chunk0 = blockIdx.x * pp.chunks_per_wg;     // this workgroup's private chunk region
   // `need` fresh consecutive chunks for partition p -> the first one
@@ -87,7 +90,7 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
   RegFile rf[TILES];          // indexed by compile-time constants only (p2_static_for)
   long long kmin_seen = 0x7fffffffffffffffll, kmax_seen = (long long)0x8000000000000000ull;   // by-product statistics of the key
   uint64_t narrow_viol = 0;     // wave-uniform (scalar registers): lanes whose value did not fit its narrowed field (make_record2, pp.check_src)
-  unsigned int rec[TILES][kRows][RW];
+  unsigned int rec[TILES][kRows][SW];
   uint32_t part[TILES][kRows];     // partition of a row that becomes a record (later: | rank << 10); kNotPending otherwise
   constexpr uint32_t kNotPending = 0xffffffffu;
   // evaluates the TILES tiles of round rd (their column loads may already be in flight) into rec / part / pending; rows of hot keys
@@ -178,12 +181,13 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
     });
     __syncthreads();                                                                  // A: the counts are complete
     // ---- scan, one partition per thread: tile offsets, lines and destinations of every partition
-    uint32_t sc_c = 0, sc_cd = 0, sc_ln = 0, sc_ch = 0, sc_v = 0, sc_incl = 0, sc_opened = 0;
+    uint32_t sc_c = 0, sc_cd = 0, sc_ln = 0, sc_ch = 0, sc_v = 0, sc_incl = 0, sc_opened = 0, sc_odd = 0;
     if (threadIdx.x < NP) {
       const uint32_t p = threadIdx.x;
-      sc_c = cnt[p]; sc_cd = carry_dw[p]; sc_ln = cur_lines[p]; sc_ch = cur_chunk[p]; sc_opened = misc[0];
+      sc_c = cnt[p]; sc_odd = sc_c & 1u; sc_cd = carry_dw[p]; sc_ln = cur_lines[p]; sc_ch = cur_chunk[p]; sc_opened = misc[0];
+      if (PAIR) sc_c = (sc_c + 1u) >> 1;                                               // records = pairs: an odd row closes its pair alone
       const uint32_t nl = (sc_cd + sc_c * RW) >> 5, left = cap_lines - sc_ln;          // left: 0 when no chunk is open (cur_lines == cap_lines)
-      sc_v = sc_c | (nl > left ? (nl - left + cap_lines - 1) / cap_lines : 0u) << 16;   // rows (<= T < 2^16 in all) and chunks to open, scanned together
+      sc_v = sc_c | (nl > left ? (nl - left + cap_lines - 1) / cap_lines : 0u) << 16;   // records (<= T < 2^16 in all) and chunks to open, scanned together
       sc_incl = sc_v;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)sc_incl, d, 64); if (lane >= d) sc_incl += o; }
@@ -201,6 +205,8 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
       const uint32_t cd = sc_cd, total = cd + c * RW, nl = total >> 5, rem = total & 31u, left = cap_lines - sc_ln;
       uint32_t ln = sc_ln, ch = sc_ch, y = cd | rem << 5 | nl << 10 | (c ? 1u << 24 : 0u), first_line = 0;
       off[p] = o; cnt[p] = 0; carry_dw[p] = rem;
+      // (the previous round's copy-out is behind barrier A: the tile may be written) the second half of an odd partition's last pair is absent
+      if (PAIR && sc_odd) reinterpret_cast<unsigned short*>(sorted + (size_t)(o + c - 1u) * RW)[1] = (unsigned short)kPairAbsent;
       if (nl) {
         first_line = ch * cap_lines + ln;
         if (nl > left) {
@@ -222,6 +228,13 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
 #pragma unroll
       for (int r = 0; r < kRows; r++) {
         if (part[t][r] == kNotPending) continue;
+        if constexpr (PAIR) {
+          const uint32_t rk = part[t][r] >> 10, h = rk & 1u;                           // rank r of the partition's rows in the tile -> pair r / 2, half r % 2
+          unsigned int* dst = sorted + (size_t)(off[part[t][r] & 1023u] + (rk >> 1)) * RW;
+          reinterpret_cast<unsigned short*>(dst)[h] = (unsigned short)rec[t][r][0];
+          dst[1 + 2 * h] = rec[t][r][1]; dst[2 + 2 * h] = rec[t][r][2];
+          continue;
+        }
         unsigned int* dst = sorted + (size_t)(off[part[t][r] & 1023u] + (part[t][r] >> 10)) * RW;
 #pragma unroll
         for (uint32_t w = 0; w < RW; w++) if (!(pp.ablate & 2u)) dst[w] = rec[t][r][w];

@@ -1,7 +1,7 @@
 """One partitioned group-by under the geometry the environment dictates (PLX_PART_LOG2_PARTS / PLX_PART_DIRECT_LOG2_PARTS / PLX_PART_TILES /
 PLX_PART_PACK are read once per process: tests/test_gpu_partition_geometry.py starts this script once per geometry).  argv: mode (hash | direct), input
-(hot: a stretch of rows from 48 keys, which the sample makes heavy hitters -- the scatter's hot-key build; flat: uniform keys) and the substrings the
-plan description of the second run must contain.  Checks the result against numpy and prints the plan."""
+(hot: a stretch of rows from 48 keys, which the sample makes heavy hitters -- the scatter's hot-key build; flat: uniform keys; hot1 / flat1: the same with
+ONE f64 value column -- what travels two rows a record, fused::kPackPair) and the substrings the plan description of the second run must contain.  Checks the result against numpy and prints the plan."""
 import os
 import sys
 
@@ -17,7 +17,7 @@ def main():
     rng = np.random.default_rng(97)
     n, G = 17_300_001, 200_000
     ids = rng.integers(0, G, n)
-    if shape == "hot":
+    if shape.startswith("hot"):
         ids[n // 2: n // 2 + n // 50] = rng.integers(0, 48, n // 50)
     v = rng.integers(-10 ** 6, 10 ** 6, n).astype(np.int64)
     x = rng.uniform(-1, 1, n)
@@ -27,7 +27,9 @@ def main():
     else:
         key = ids.astype(np.uint32)                                 # dense ids: direct-address partitions
         df = pl.DataFrame([pl.Series("k", key, dtype=pl.Categorical([], pl.UInt32)), pl.Series("v", v), pl.Series("x", x)])
-    q = df.lazy().group_by("k").agg(pl.col("v").sum().alias("s"), pl.col("x").sum().alias("xs"), pl.len().alias("n"))
+    one = shape.endswith("1")
+    q = (df.lazy().group_by("k").agg(pl.col("x").sum().alias("xs"), pl.col("x").mean().alias("xm"), pl.len().alias("n")) if one else
+         df.lazy().group_by("k").agg(pl.col("v").sum().alias("s"), pl.col("x").sum().alias("xs"), pl.len().alias("n")))
     for run in range(2):                                            # the second run knows the key range (packed / fused records)
         out = q.collect()
         plan = pl.last_plan()
@@ -41,7 +43,11 @@ def main():
         present = np.unique(ids)
         assert np.array_equal(k[order], np.unique(key)), "keys"
         assert np.array_equal(out["n"].to_numpy()[order], np.bincount(ids, minlength=G)[present]), "len"
-        assert np.array_equal(out["s"].to_numpy()[order], np.bincount(ids, v, minlength=G)[present].astype(np.int64)), "int sum"       # |sums| < 2^53: exact in the float accumulator of bincount
+        if one:
+            cnt = np.bincount(ids, minlength=G)[present]
+            assert np.allclose(out["xm"].to_numpy()[order], np.bincount(ids, x, minlength=G)[present] / cnt, rtol=1e-9, atol=1e-9), "mean"
+        else:
+            assert np.array_equal(out["s"].to_numpy()[order], np.bincount(ids, v, minlength=G)[present].astype(np.int64)), "int sum"       # |sums| < 2^53: exact in the float accumulator of bincount
         assert np.allclose(out["xs"].to_numpy()[order], np.bincount(ids, x, minlength=G)[present], rtol=1e-9, atol=1e-9), "float sum"
     print("OK")
 

@@ -22,6 +22,12 @@ GEOMETRIES = [      # (what the second run -- key range known -- must report; th
     ("hash", "flat", {"PLX_PART_LOG2_PARTS": "8", "PLX_PART_TILES": "3", "PLX_PART_PACK": "0"}, ["hash,P=256,", "rec=24B,pack=0,", "tile=4096,"]),
     ("hash", "hot", {"PLX_PART_LOG2_PARTS": "8", "PLX_PART_TILES": "3"}, ["hash,P=256,", "rec=20B,", "tile=4096,", "slots=4606)"]),     # an LDS table that is not a power of two
     ("direct", "hot", {"PLX_PART_DIRECT_LOG2_PARTS": "8", "PLX_PART_INTERLEAVE": "0"}, ["direct,P=256,"]),          # partition = the id's high bits (the join probe's mapping)
+    # one f64 value over dense ids: two rows a record (fused::kPackPair), pairs formed in the tile sort, lone halves closed with the absent slot
+    ("direct", "flat1", {"PLX_PART_DIRECT_LOG2_PARTS": "8"}, ["direct,P=256,", "rec=10B,pack=4,", "tile=8192,"]),
+    ("direct", "hot1", {"PLX_PART_DIRECT_LOG2_PARTS": "9", "PLX_PART_TILES": "2"}, ["direct,P=512,", "rec=10B,pack=4,", "tile=4096,"]),
+    ("direct", "hot1", {"PLX_PART_DIRECT_LOG2_PARTS": "6"}, ["direct,P=64,", "pack=4,"]),
+    ("direct", "flat1", {"PLX_PART_DIRECT_LOG2_PARTS": "9", "PLX_PART_TILES": "1"}, ["direct,P=512,", "rec=12B,pack=0,", "tile=2048,"]),      # no room for 512 lone halves in a 2048-row tile
+    ("direct", "flat1", {"PLX_PART_PAIR": "0"}, ["rec=12B,pack=0,"]),
 ]
 
 

@@ -650,7 +650,7 @@ def test_wrong_declared_bounds_on_a_value_column_never_narrow_it(pl):
     sv = pl.Series("v", v)
     pl._ffi.check(pl._ffi.lib().plx_column_set_bounds(sv._h, 0, 999))       # a lie: the values span 2^40
     out = queries.cfg3(pl.DataFrame([pl.Series("key", key), sv]).lazy()).collect(); plan = pl.last_plan()
-    assert "partitioned(" in plan and "pack=0" in plan, plan
+    assert "partitioned(" in plan and ("pack=0" in plan or "pack=4" in plan), plan          # whole 64-bit values: plain records, or two rows a record (kPackPair)
     o = np.argsort(out["key"].to_numpy())
     want = np.zeros(300_000, np.int64); np.add.at(want, key, v)
     present = np.nonzero(np.bincount(key, minlength=300_000))[0]

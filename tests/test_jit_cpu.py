@@ -55,3 +55,13 @@ def test_filter_to_frame_kernel():
     t, _ = frames()
     q = t.lazy().filter((pl.col("a") > 5) & ((pl.col("k") % 3) == 1) | pl.col("x").is_null())
     q.jit_selftest()
+
+
+def test_groupby_pair_packed_records():
+    # one f64 value without nulls over integer keys: the partitioned path may send two rows a record (fused::kPackPair) -- its scatter (1-4 tiles, with and without the
+    # hot-key path) and aggregation kernels compile at run time
+    t = pl.DataFrame([ph("k", pl.Int64), ph("y", pl.Float64), ph("a", pl.Int32)])
+    q = t.lazy().filter(pl.col("a") > 3).group_by("k").agg(pl.col("y").sum().alias("s"), pl.col("y").mean().alias("m"), pl.len())
+    fusable, sid, why, _ = q.describe_fusion()
+    assert fusable and sid == -1, why
+    q.jit_selftest()

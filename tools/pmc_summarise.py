@@ -26,6 +26,7 @@ SCOPES = [  # (regex on the demangled kernel name, ProfileScope name in bench.py
     (r"canonicalise_chains_kernel", "join_chain_representatives"), (r"chains_count_kernel|chains_emit_kernel", "table_compact"), (r"rows_agg_compact_kernel|wide_compact_kernel", "table_compact"),
     (r"fused_scan_kernel<.*WideAggSink", "fused_scan_wideagg"),
     (r"compact_by_ballots_kernel", "filter_compact_cols"), (r"join_match_kernel", "join_match"), (r"join_pairs_emit_kernel", "join_pairs_emit"), (r"filter_rowids_kernel|ballots_to_rowids_kernel", "filter_rowids"), (r"direct_slot_rows_kernel", "direct_slot_rows"),
+    (r"strview_stamp_kernel", "strview_stamp_nulls"),
     (r"join_bin_kernel", "join_bin_windows"), (r"join_fill_kernel", "join_fill_lds"), (r"cells_agg_compact_kernel", "table_compact"),
     (r"filter_kernel<", "filter_compact"), (r"tile_count_kernel", "filter_tile_count"), (r"ballots_to_mask_kernel", "ballots_to_mask"),
     (r"init_acc_kernel|fill_u64_kernel", "table_init"), (r"strview_encode_kernel", "strview_dict_encode"), (r"strdict_", "strdict_materialise"),
