@@ -904,9 +904,10 @@ int plx_jit_selftest(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int
           jobs.push_back({sh, jit::part3_agg_sink(mode, pack)});
         }
       }
-      if (fused::pair_pack_ok(sh, fused::kP2Direct)) {      // two rows a record (a 64-bit value that does not narrow over direct-address slots)
-        for (uint32_t tiles : {1u, 2u, 3u, 4u}) { jobs.push_back({sh, jit::part3_scatter_sink(fused::kP2Direct, tiles, fused::kPackPair, false)}); jobs.push_back({sh, jit::part3_scatter_sink(fused::kP2Direct, tiles, fused::kPackPair, true)}); }
-        jobs.push_back({sh, jit::part3_agg_sink(fused::kP2Direct, fused::kPackPair)});
+      for (uint32_t mode = 0; mode < 2; mode++) {            // two rows a record (one 64-bit value that does not narrow; direct-address slots or 48-bit key offsets)
+        if (!fused::pair_pack_ok(sh, mode)) continue;
+        for (uint32_t tiles : {1u, 2u, 3u, 4u}) { if (mode == fused::kP2Hash && tiles > 3) continue; jobs.push_back({sh, jit::part3_scatter_sink(mode, tiles, fused::kPackPair, false)}); jobs.push_back({sh, jit::part3_scatter_sink(mode, tiles, fused::kPackPair, true)}); }
+        jobs.push_back({sh, jit::part3_agg_sink(mode, fused::kPackPair)});
       }
     }
     if (sh.n_keys >= 2) {

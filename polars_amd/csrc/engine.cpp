@@ -1024,7 +1024,11 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
       PartPlan2 p2;
       k::SrcRange ranges[kMaxSrc];
       source_ranges(c, ranges);
-      if (k::partition_plan2(sh, est2, kp.total_bits, len_idx, n, (int)hot.size(), &p2, ranges)) {
+      // (too many id bits for direct-address tables -> hash partitions of the packed id: its range is [0, 2^total_bits) by construction -- when the bounds behind the
+      // packing were measured, not guessed -- so ids of < 48 bits travel as 48-bit offsets, two rows a record: fused::kPackPair)
+      k::SrcRange id_rng;
+      if (kp.total_bits < 48 && !untrusted_key_bounds(c)) { id_rng.known = true; id_rng.mn = 0; id_rng.mx = (int64_t)(((uint64_t)1 << kp.total_bits) - 1); }
+      if (k::partition_plan2(sh, est2, kp.total_bits, len_idx, n, (int)hot.size(), &p2, ranges, &id_rng)) {
         std::string pd;
         Buf ok, okv, oacc;
         const int64_t g = k::partitioned_agg2(sh, args, p2, static_id, hot, &ok, &okv, &oacc, &pd);
@@ -1127,6 +1131,17 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
           while (x->kind == PLX_AE_ALIAS) x = &c.plan.ae[x->lhs];
           if (x->kind == PLX_AE_COLUMN) { const int ci = c.df->find(x->name); if (ci >= 0 && c.df->cols[ci]->range_state == 0 && c.df->cols[ci]->len == n) stat_col = c.df->cols[ci]; }
         }
+        // ... and once the exact range of such a key is known (learned that way, or computed): 64-bit keys spanning < 2^48 travel as 48-bit offsets, two rows a record
+        // (fused::kPackPair in hash mode; only ranges the library computed itself: a declared or assumed range is never used unchecked)
+        k::SrcRange key_rng;
+        if (kp.parts.size() == 1 && dtype_is_int(kp.parts[0].dtype) && kp.parts[0].dtype != PLX_U64) {
+          const AE* x = &c.plan.ae[kp.parts[0].expr];
+          while (x->kind == PLX_AE_ALIAS) x = &c.plan.ae[x->lhs];
+          if (x->kind == PLX_AE_COLUMN) {
+            const int ci = c.df->find(x->name);
+            if (ci >= 0 && c.df->cols[ci]->range_state == 1 && c.df->cols[ci]->range_trusted) { key_rng.known = true; key_rng.mn = c.df->cols[ci]->range_min; key_rng.mx = c.df->cols[ci]->range_max; }
+          }
+        }
         // How many groups to plan for.  The estimate assumes equally likely keys; heavy hitters in the sample mean a heavy TAIL too, and a tail the sample
         // undercounts badly (zipf 1.1 over 1e6 keys: 1.5e5 distinct keys in 2^20 sampled rows, 1e6 in 1e9 rows): with skew the tables are planned for 4 x the
         // estimate.  A table that fills up anyway is reported by the aggregation pass; the plan is then doubled (more partitions) and the pass repeated -- never
@@ -1134,8 +1149,8 @@ static void run_fused_groupby(Compiler& c, const KeyPlan& kp, int len_idx, Fused
         double plan_for = hinted ? G * 1.02 + 64.0 : (!hot.empty() && G < 1e17) ? G * 4.0 : G * 1.3;      // (a bound from the plan is not an estimate: no safety factor)
         for (int attempt = 0; attempt < 3; attempt++) {
           PartPlan2 p2;
-          if (!k::partition_plan2(sh, plan_for, -1, len_idx, n, (int)hot.size(), &p2, ranges)) {
-            if (attempt == 0 && !hot.empty() && k::partition_plan2(sh, G * 1.3, -1, len_idx, n, (int)hot.size(), &p2, ranges)) { /* 4 x does not fit 512 partitions: the plain estimate does */ }
+          if (!k::partition_plan2(sh, plan_for, -1, len_idx, n, (int)hot.size(), &p2, ranges, &key_rng)) {
+            if (attempt == 0 && !hot.empty() && k::partition_plan2(sh, G * 1.3, -1, len_idx, n, (int)hot.size(), &p2, ranges, &key_rng)) { /* 4 x does not fit 512 partitions: the plain estimate does */ }
             else break;
           }
           std::string pd;

@@ -274,9 +274,12 @@ constexpr uint32_t kNoChunk = 0xffffffffu;
 //                partition travel TWO to a record of five dwords {slot0 | slot1 << 16, value0, value1} -- 10 bytes a row instead of 12.  Pairs are formed in the scatter's
 //                tile sort (rank r of a partition's rows in the tile -> pair r / 2, half r % 2); a partition with an odd number of rows in a tile closes its last pair
 //                with the slot 0xffff ("absent": ~1.5 % more pairs at 8192-row tiles and 256 partitions).  RecLayout2 describes ONE ROW (three dwords, as kPackNone) and
-//                says rec_words = 5: the unit of the record stream, of the chunks and of chunk_fill is the PAIR
+//                says rec_words = 5: the unit of the record stream, of the chunks and of chunk_fill is the PAIR.
+//                Hash mode (a 64-bit key whose range is KNOWN to span < 2^48 - 1, one 64-bit value): seven dwords {off0 lo, off1 lo, off0 hi16 | off1 hi16 << 16, value0,
+//                value1} with off = key - PartPlan2::key_base -- 14 bytes a row instead of 16; an absent half has the offset 2^48 - 1
 constexpr uint32_t kPackNone = 0, kPackNarrow = 1, kPackFused = 2, kPackRowid = 3, kPackPair = 4;
 constexpr uint32_t kPairAbsent = 0xffffu;
+constexpr unsigned long long kPairAbsent48 = 0xffffffffffffull;
 struct RecLayout2 {
   uint8_t n_key_cols;            // 0: one key slot (Shape::key); 2..kMaxKeys: a wide key -- Shape::keys, one 64-bit word per key column, null keys flagged in the validity dword
   uint8_t key_words;             // 1 | 2 dwords (wide key: 2 per key column)
@@ -286,6 +289,7 @@ struct RecLayout2 {
   uint8_t has_valid, valid_off;  // one dword: bit j = source j valid, bit 31 = key valid (wide key: bit 24 + i = key column i valid)
   uint8_t has_rowid, rowid_off;  // two dwords
   uint8_t rec_words;
+  uint8_t row_words;             // dwords ONE ROW occupies in the scatter's registers and in its tile budget (== rec_words but for kPackPair)
   uint8_t src_kind[kMaxSrc], src_off[kMaxSrc];   // kind 0: 64-bit, 1: i32, 2: u32, 3: u32 offset from PartPlan2::src_base[j] (packing)
   uint8_t src_slot[kMaxAggs];    // program slot of source j
   uint8_t agg_src[kMaxAggs];     // aggregate k reads source agg_src[k] (kNone: LEN / FIRST_ROW)
@@ -351,20 +355,20 @@ PLX_FHD constexpr RecLayout2 rec_layout2(const Shape& sh, uint32_t mode, uint32_
   }
   if (pack == kPackFused) { w = 1; L.src_off[0] = 0; }      // planner-checked: direct mode, one integer source, no validity, no row id
   L.has_valid = shape_may_have_nulls(sh) ? 1 : 0;
-  if (pack == kPackRowid) { L.has_valid = 0; L.valid_off = 0; L.rowid_off = 0; L.rec_words = 2; return L; }
+  if (pack == kPackRowid) { L.has_valid = 0; L.valid_off = 0; L.rowid_off = 0; L.rec_words = 2; L.row_words = 2; return L; }
   L.valid_off = (uint8_t)w; w += L.has_valid;
   L.rowid_off = (uint8_t)w; w += 2 * L.has_rowid;
-  L.rec_words = (uint8_t)w;
-  if (pack == kPackPair) L.rec_words = 5;      // planner-checked (pair_pack_ok): a row is {slot, value lo, value hi}; two rows share a record
+  L.rec_words = (uint8_t)w; L.row_words = (uint8_t)w;
+  if (pack == kPackPair) L.rec_words = mode == kP2Direct ? 5 : 7;      // planner-checked (pair_pack_ok): a row is {slot | 64-bit key, 64-bit value}; two rows share a record
   return L;
 }
 // does the shape admit kPackPair at all (the planner still checks the slot count)?
 PLX_FHD constexpr bool pair_pack_ok(const Shape& sh, uint32_t mode) {
   const RecLayout2 L = rec_layout2(sh, mode, kPackNone);
-  return mode == kP2Direct && !sh.n_keys && L.n_src == 1 && L.src_kind[0] == 0 && !L.has_valid && !L.has_rowid && L.rec_words == 3;
+  return !sh.n_keys && L.n_src == 1 && L.src_kind[0] == 0 && !L.has_valid && !L.has_rowid && L.rec_words == (mode == kP2Direct ? 3 : 4);      // (hash mode: a 64-bit key)
 }
-// dwords a ROW occupies in the scatter's registers and LDS tile (kPackPair: three, like the unpacked row; two rows then share a five-dword record)
-PLX_FHD constexpr uint32_t scatter_row_words(const RecLayout2& L) { return L.pack == kPackPair ? 3u : (uint32_t)L.rec_words; }
+// dwords a ROW occupies in the scatter's registers and LDS tile (kPackPair: as unpacked; two rows then share a record of 2 x row_words - 1 dwords)
+PLX_FHD constexpr uint32_t scatter_row_words(const RecLayout2& L) { return (uint32_t)L.row_words; }
 struct PartPlan2 {
   uint32_t mode;               // kP2Hash | kP2Direct
   uint32_t log2_parts;         // P = 1 << log2_parts partitions

@@ -35,7 +35,7 @@ double g_ms = 0;
 const char* sink_type(Sink s) {
   static const char* n[] = {"RegAggSink", "LdsAggSink", "DenseAggSink", "HashAggSink", "WideAggSink", "JoinBuildSink", "ProbeAggSink", "DirectBuildSink", "DirectProbeAggSink", "BitmapBuildSink",
                             "part_count", "part_scatter", "part_agg", "part2_scatter_hash", "part2_scatter_direct", "part2_agg_hash", "part2_agg_direct", "part2_scatter_hash_t2", "part2_scatter_direct_t2"};
-  if (s == PART3_AGG_PAIR) return "part3_agg";
+  if (s == PART3_AGG_PAIR || s == PART3_AGG_PAIR_DIRECT) return "part3_agg";
   if (s >= PART3_SCATTER_PAIR && s < PART3_AGG_PAIR) return "part3_scatter";
   if (s == BALLOT) return "BallotSink";
   if (s == DIRECT_HITS) return "DirectHitsSink";
@@ -125,16 +125,17 @@ std::string source_for(const Shape& sh, Sink sink) {
            "  part2_agg_body<Shape, " << (sink == PART2_AGG_DIRECT ? 1 : 0) << ", p2_agg_chunks_in_flight(cl.rec_words)>(csh, cl, pp, ap);\n}\n}}\n";
       break;
     default:
-      if (sink == PART3_AGG_PAIR) {
+      if (sink == PART3_AGG_PAIR || sink == PART3_AGG_PAIR_DIRECT) {
+        const int mode = sink == PART3_AGG_PAIR_DIRECT ? 1 : 0;
         o << "extern \"C\" __global__ __launch_bounds__(kP2AggBlock) void plx_jit_kernel(PartPlan2 pp, AggParams2 ap) {\n"
-             "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout2 cl = rec_layout2(JitProg::shape(), 1u, " << fused::kPackPair << "u);\n"
-             "  part2_agg_body<Shape, 1, p2_agg_chunks_in_flight(cl.rec_words)>(csh, cl, pp, ap);\n}\n}}\n";
+             "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout2 cl = rec_layout2(JitProg::shape(), " << mode << "u, " << fused::kPackPair << "u);\n"
+             "  part2_agg_body<Shape, " << mode << ", p2_agg_chunks_in_flight(cl.rec_words)>(csh, cl, pp, ap);\n}\n}}\n";
         break;
       }
       if (sink >= PART3_SCATTER_PAIR && sink < PART3_AGG_PAIR) {
-        const int v = (int)sink - (int)PART3_SCATTER_PAIR, tiles = 1 + (v & 3), hot = v >> 2;
+        const int v = (int)sink - (int)PART3_SCATTER_PAIR, tiles = 1 + (v & 3), hot = (v >> 2) & 1, mode = v >> 3;
         o << "extern \"C\" __global__ __launch_bounds__(kP2MaxBlock) void plx_jit_kernel(Shape dsh, Args args, PartPlan2 pp, ScatterParams2 sp) {\n"
-             "  part3_scatter_body<JitProg, 1, " << tiles << ", " << fused::kPackPair << ", " << (hot ? "true" : "false") << ">(dsh, args, pp, sp);\n}\n}}\n";
+             "  part3_scatter_body<JitProg, " << mode << ", " << tiles << ", " << fused::kPackPair << ", " << (hot ? "true" : "false") << ">(dsh, args, pp, sp);\n}\n}}\n";
         break;
       }
       if (sink >= PART3_AGG && sink != BALLOT && sink != DIRECT_HITS) {

@@ -80,7 +80,7 @@ int64_t partitioned_agg(const fused::Shape& sh, const fused::Args& args, const f
 // generation scatter pack records (fused::kPackNarrow / kPackFused)
 struct SrcRange { bool known = false; int64_t mn = 0, mx = 0; bool check = false; /* bounds nobody verified (the planner's sample): narrow with a per-row check */ };
 bool partition_plan2(const fused::Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, fused::PartPlan2* out,
-                     const SrcRange* src_ranges = nullptr /* [fused::kMaxSrc] */);
+                     const SrcRange* src_ranges = nullptr /* [fused::kMaxSrc] */, const SrcRange* key_range = nullptr /* exact range of a single 64-bit key, if known */);
 // hot_rows: sample rows the returned keys account for
 void select_hot_keys(const fused::HashTable& t, int n_aggs, int len_idx, uint64_t threshold, std::vector<uint64_t>* out, uint64_t* hot_rows = nullptr);
 // key_range_out (may be null): [2] receives the exact signed min / max of the valid keys the scatter pass streamed (hash mode

@@ -212,7 +212,7 @@ static void plan2_geometry(PartPlan2& pp, int64_t n_rows, uint32_t tiles) {
 static uint32_t bits_for(uint64_t span) { uint32_t b = 0; while (b < 64 && (span >> b)) b++; return b; }     // bits that hold 0..span
 
 // third generation: packing from the value ranges, tile size from the LDS budget.  false: this shape / geometry stays on generation 2
-static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange* ranges, size_t lds_total) {
+static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange* ranges, size_t lds_total, const SrcRange* key_range) {
   const uint32_t NP = 1u << pp.log2_parts;
   if (NP < 64 || NP > (uint32_t)kP2MaxBlock) return false;                    // the scan takes one partition per thread, in whole waves
   uint32_t pack = kPackNone;
@@ -231,7 +231,13 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
   }
   // a 64-bit value that does not narrow (f64) over direct-address slots: two rows a record, 10 bytes a row (fused.hpp kPackPair; PLX_PART_PAIR=0: measurement)
   static const bool pair_off = getenv("PLX_PART_PAIR") && getenv("PLX_PART_PAIR")[0] == '0';
-  if (pack == kPackNone && !pair_off && pair_pack_ok(sh, pp.mode) && pp.key_shift <= 15) pack = kPackPair;      // (the tile must hold the lone halves too: checked below)
+  // (the tile must hold the lone halves too: checked below)
+  if (pack == kPackNone && !pair_off && pair_pack_ok(sh, pp.mode)) {
+    if (pp.mode == kP2Direct) { if (pp.key_shift <= 15) pack = kPackPair; }
+    else if (key_range && key_range->known && !key_range->check && key_range->mx >= key_range->mn && (uint64_t)key_range->mx - (uint64_t)key_range->mn < kPairAbsent48) {
+      pack = kPackPair; pp.key_base = key_range->mn;      // hash partitions of 64-bit keys whose exact range spans < 2^48 - 1: 48-bit offsets, 14 bytes a row
+    }
+  }
   RecLayout2 L = rec_layout2(sh, pp.mode, pack);
   if (L.n_src > (uint32_t)kMaxSrc || L.rec_words > 13) return false;
   for (int j = 0; j < kMaxSrc; j++) pp.src_base[j] = (pack != kPackNone && ranges && ranges[j].known && (L.src_kind[j] == 3 || pack == kPackFused)) ? ranges[j].mn : 0;
@@ -257,14 +263,14 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
     }
   }
   // (pairs need room for the partitions' lone halves in the tile: at most T / 2 + NP / 2 five-dword records in 3 T dwords)
-  if (pack == kPackPair && NP * 5 > block * kRows * tiles) { pack = kPackNone; L = rec_layout2(sh, pp.mode, pack); }
+  if (pack == kPackPair && NP * L.rec_words > block * kRows * tiles) { pack = kPackNone; L = rec_layout2(sh, pp.mode, pack); if (pp.mode == kP2Hash) pp.key_base = 0; }
   pp.gen = 3; pp.pack = pack; pp.rec_words = L.rec_words; pp.block = block; pp.ring_lines = 0;
   plan2_geometry(pp, n_rows, tiles);
   // chunks are filled completely (the carry line keeps the remainder): whole chunks of the rows + one partial chunk per partition + slack
   return true;
 }
 
-bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, PartPlan2* out, const SrcRange* src_ranges) {
+bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int len_idx, int64_t n_rows, int n_hot, PartPlan2* out, const SrcRange* src_ranges, const SrcRange* key_range) {
   PartPlan2 pp{};
   pp.gen = 2;
   if (sh.key == kNone && !sh.n_keys) return false;
@@ -320,7 +326,7 @@ bool partition_plan2(const Shape& sh, double est_groups, int packed_bits, int le
   pp.hot_copies = 1;
   if (pp.n_hot) { uint32_t c = 16; while (c > 1 && (size_t)pp.n_hot * sh.n_aggs * 8 * c > 8 * 1024) c >>= 1; pp.hot_copies = c; }
   pp.ablate = kEnvP2Ablate > 0 ? (uint32_t)kEnvP2Ablate : 0u;
-  if (kEnvP2Gen != 2 && plan3(sh, pp, n_rows, src_ranges, lds_total)) { *out = pp; return true; }
+  if (kEnvP2Gen != 2 && plan3(sh, pp, n_rows, src_ranges, lds_total, key_range)) { *out = pp; return true; }
   // ---- generation 2.  rings: as many 128-B lines per partition as the LDS holds (power of two)
   const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0;
   const size_t fixed = part2_scatter_lds(NP, 0, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies);
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void hot_emit_kernel(const unsigned long lo
 // the value narrowed to a u32 offset, 4 B with key_low and value fused into one dword.  config 5 (u32 dictionary codes, Float64 value): 12 B.
 #ifdef PLX_HAVE_Q3_SHAPES
 #define PLX_P3_COMBOS(X)                                                                                                              \
-  X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow)                                      \
+  X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackPair) \
   X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackFused) \
   X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackPair) \
   X(SHAPE_GB2_SUM_CNT_I64, kP2Hash, 2, kPackNarrow)       /* two-column key at 512 partitions: 20-byte records, two tiles of an 896-thread workgroup (values that do not narrow: 24-byte records, run-time compiled) */
@@ -519,7 +525,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
                                    (gen3 && pp.n_hot ? ",hot]" : "]");
   const std::string agg_name = "part_agg_lds[" + sid + (direct ? ",d,p" : ",h,p") + std::to_string(pp.pack) + "]";
   PLX_REQUIRE(pp.n_hot == hot_keys.size(), PLX_ERR_INVALID, "partitioned_agg2: plan / hot key list mismatch");
-  const uint32_t row_bytes = pp.pack == kPackPair ? 10u : pp.rec_words * 4u;      // bytes a row travels as (a pair of rows shares a 20-byte record)
+  const uint32_t row_bytes = pp.pack == kPackPair ? pp.rec_words * 2u : pp.rec_words * 4u;      // bytes a row travels as (a pair of rows shares a 20- / 28-byte record)
   const uint32_t chunk_dw = kP2ChunkRecs * pp.rec_words;
   const int64_t n_chunks = (int64_t)pp.scatter_grid * pp.chunks_per_wg;
   Buf recs = dev_alloc_transient((size_t)n_chunks * chunk_dw * 4 + 256);
@@ -559,7 +565,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
     PLX_HIP(hipStreamSynchronize(stream()));     // `init` is a stack object
     sp.key_minmax = minmax->as<long long>();
   }
-  const size_t slds = gen3 ? part3_scatter_lds(pp.block * kRows * pp.tiles, pp.pack == kPackPair ? 3u : pp.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies)
+  const size_t slds = gen3 ? part3_scatter_lds(pp.block * kRows * pp.tiles, pp.pack == kPackPair ? (direct ? 3u : 4u) : pp.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies)
                            : part2_scatter_lds(NP, pp.ring_lines, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies);
   {
     // pass traffic: inputs read once + every surviving row written as one record (upper bound: all rows)

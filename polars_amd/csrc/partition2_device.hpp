@@ -675,6 +675,59 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   };
   auto process = [&](unsigned int (*cur)[16], uint32_t cnt_cur) __attribute__((always_inline)) {
     if (wide) { process_wide(cur, cnt_cur); return; }
+    if (L.pack == kPackPair && !direct) {
+      // a record is a PAIR of rows {off0 lo, off1 lo, off0 hi16 | off1 hi16 << 16, value0, value1}, key = key_base + 48-bit offset (fused.hpp kPackPair, hash mode); the
+      // offset 2^48 - 1 = the half is absent.  The same three passes as below (decode + first table word, resolve, update) over 2 x kPerLane rows.
+      constexpr uint32_t NH = 2 * kPerLane;
+      uint32_t slot[NH]; uint64_t key[NH], val[NH]; unsigned long long first[NH]; bool live[NH];
+#pragma unroll
+      for (uint32_t u = 0; u < kPerLane; u++) {
+        const unsigned int* rec = cur[u];
+        const bool in = (uint32_t)lane + u * 64u < cnt_cur;
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+          const uint32_t i = 2 * u + h;
+          const uint64_t koff = (uint64_t)rec[h] | ((uint64_t)((rec[2] >> (16 * h)) & 0xffffu) << 32);
+          live[i] = in && koff != kPairAbsent48;
+          key[i] = (uint64_t)pp.key_base + koff; val[i] = (uint64_t)rec[3 + 2 * h] | ((uint64_t)rec[4 + 2 * h] << 32);
+          slot[i] = 0; first[i] = 0;
+          if (!live[i]) continue;
+          if (key[i] == kEmptyKey) { slot[i] = NS + 1; first[i] = kEmptyKey - 1; }
+          else { slot[i] = (uint32_t)((((key[i] * 0x9e3779b97f4a7c15ull) >> 32) * (uint64_t)NS) >> 32); first[i] = keys[slot[i]]; }
+        }
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < NH; i++) {
+        if (!live[i]) continue;
+        if (slot[i] >= NS) { keys[slot[i]] = 0; continue; }
+        unsigned long long c = first[i];
+        uint32_t sl = slot[i], probe = 0;
+        for (;; probe++) {
+          if (c == key[i]) break;
+          if (c == kEmptyKey) {
+            const unsigned long long old = atomicCAS(&keys[sl], (unsigned long long)kEmptyKey, (unsigned long long)key[i]);
+            if (old == kEmptyKey || old == key[i]) break;
+          }
+          sl = sl + 1 == NS ? 0u : sl + 1;
+          if (probe >= NS) { full = 1; live[i] = false; break; }
+          c = keys[sl];
+        }
+        slot[i] = sl;
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < NH; i++) {
+        if (!live[i]) continue;
+        unsigned long long* cell = cells + (size_t)slot[i] * n_aggs;
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)kMaxAggs; k++) {
+          if (k >= n_aggs) break;
+          const uint8_t kind = sh.aggs[k].kind;
+          const uint64_t x = agg_row_value(kind, L.agg_src[k] != kNone ? val[i] : 0ull, true, true, 0ull);
+          if (x != agg_identity_dev(kind) || kind == AGG_SUM_F) lds_atomic_agg(kind, cell + k, x);
+        }
+      }
+      return;
+    }
     if (L.pack == kPackPair) {
       // a record is a PAIR of rows {slot0 | slot1 << 16, value0, value1} of a direct-address partition (fused.hpp kPackPair); slot 0xffff = the half is absent
 #pragma unroll

@@ -47,7 +47,7 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
   constexpr uint32_t RW = L.rec_words;                  // dwords of a record of the stream (kPackPair: a PAIR of rows)
   constexpr bool PAIR = PACK == (int)kPackPair;
   constexpr uint32_t SW = scatter_row_words(L);         // dwords of a row in registers / of the tile's budget per row
-  static_assert(!PAIR || (MODE == (int)kP2Direct && RW == 5 && SW == 3), "kPackPair: direct mode, {slot, 64-bit value} rows");
+  static_assert(!PAIR || (MODE == (int)kP2Direct ? (RW == 5 && SW == 3) : (RW == 7 && SW == 4)), "kPackPair: {slot | 64-bit key, 64-bit value} rows");
   constexpr uint32_t chunk_dw = kP2ChunkRecs * RW, cap_lines = chunk_dw / 32;      // a chunk holds whole records AND whole lines
   const uint32_t NP = 1u << pp.log2_parts;
   const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0u;
@@ -56,7 +56,7 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
   unsigned long long* hot_k = p2_lds + (size_t)NP * 2;
   unsigned long long* hot_acc = hot_k + hot_slots;
   unsigned int* sorted = reinterpret_cast<unsigned int*>(hot_acc + (size_t)pp.n_hot * sh.n_aggs * pp.hot_copies);
-  unsigned int* carry = sorted + (size_t)T * SW;       // (pairs: at most T / 2 + NP / 2 records of five dwords <= 3 T)
+  unsigned int* carry = sorted + (size_t)T * SW;       // (pairs: at most T / 2 + NP / 2 records of RW = 2 SW - 1 dwords <= SW T: the planner checks NP * RW <= T)
   unsigned int* cnt = carry + (size_t)NP * 32;
   unsigned int* off = cnt + NP;
   unsigned int* carry_dw = off + NP + 1;
@@ -72,7 +72,7 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
   for (uint32_t i = threadIdx.x; i < hot_slots; i += blockDim.x) { hot_k[i] = sp.hot_tbl_keys[i]; hot_i[i] = sp.hot_tbl_idx[i]; }
   for (uint32_t i = threadIdx.x; i < pp.n_hot * sh.n_aggs * pp.hot_copies; i += blockDim.x) hot_acc[i] = agg_identity_dev(sh.aggs[(i / pp.hot_copies) % sh.n_aggs].kind);
   if (threadIdx.x < 4) misc[threadIdx.x] = 0;
-  if (threadIdx.x == 0 && (pp.tiles != (uint32_t)TILES || pp.pack != (uint32_t)PACK || pp.rec_words != RW || (PAIR && pp.key_shift > 15))) sp.flags[0] = 1u;     // host and kernel disagree about the geometry: fail the query
+  if (threadIdx.x == 0 && (pp.tiles != (uint32_t)TILES || pp.pack != (uint32_t)PACK || pp.rec_words != RW || (PAIR && MODE == (int)kP2Direct && pp.key_shift > 15))) sp.flags[0] = 1u;     // host and kernel disagree about the geometry: fail the query
   __syncthreads();
   const uint32_t chunk0 = blockIdx.x * pp.chunks_per_wg;     // this workgroup's private chunk region
   // `need` fresh consecutive chunks for partition p -> the first one
@@ -206,7 +206,11 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
       uint32_t ln = sc_ln, ch = sc_ch, y = cd | rem << 5 | nl << 10 | (c ? 1u << 24 : 0u), first_line = 0;
       off[p] = o; cnt[p] = 0; carry_dw[p] = rem;
       // (the previous round's copy-out is behind barrier A: the tile may be written) the second half of an odd partition's last pair is absent
-      if (PAIR && sc_odd) reinterpret_cast<unsigned short*>(sorted + (size_t)(o + c - 1u) * RW)[1] = (unsigned short)kPairAbsent;
+      if (PAIR && sc_odd) {
+        unsigned int* last = sorted + (size_t)(o + c - 1u) * RW;
+        if (MODE == (int)kP2Direct) reinterpret_cast<unsigned short*>(last)[1] = (unsigned short)kPairAbsent;
+        else { last[1] = 0xffffffffu; reinterpret_cast<unsigned short*>(last + 2)[1] = (unsigned short)0xffffu; }      // offset 2^48 - 1
+      }
       if (nl) {
         first_line = ch * cap_lines + ln;
         if (nl > left) {
@@ -231,8 +235,14 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
         if constexpr (PAIR) {
           const uint32_t rk = part[t][r] >> 10, h = rk & 1u;                           // rank r of the partition's rows in the tile -> pair r / 2, half r % 2
           unsigned int* dst = sorted + (size_t)(off[part[t][r] & 1023u] + (rk >> 1)) * RW;
-          reinterpret_cast<unsigned short*>(dst)[h] = (unsigned short)rec[t][r][0];
-          dst[1 + 2 * h] = rec[t][r][1]; dst[2 + 2 * h] = rec[t][r][2];
+          if constexpr (MODE == (int)kP2Direct) {
+            reinterpret_cast<unsigned short*>(dst)[h] = (unsigned short)rec[t][r][0];
+            dst[1 + 2 * h] = rec[t][r][1]; dst[2 + 2 * h] = rec[t][r][2];
+          } else {
+            const uint64_t koff = ((uint64_t)rec[t][r][0] | ((uint64_t)rec[t][r][1] << 32)) - (uint64_t)pp.key_base;      // < 2^48 - 1: the key range is known (plan3)
+            dst[h] = (uint32_t)koff; reinterpret_cast<unsigned short*>(dst + 2)[h] = (unsigned short)(koff >> 32);
+            dst[3 + 2 * h] = rec[t][r][2]; dst[4 + 2 * h] = rec[t][r][3];
+          }
           continue;
         }
         unsigned int* dst = sorted + (size_t)(off[part[t][r] & 1023u] + (part[t][r] >> 10)) * RW;

@@ -28,6 +28,10 @@ GEOMETRIES = [      # (what the second run -- key range known -- must report; th
     ("direct", "hot1", {"PLX_PART_DIRECT_LOG2_PARTS": "6"}, ["direct,P=64,", "pack=4,"]),
     ("direct", "flat1", {"PLX_PART_DIRECT_LOG2_PARTS": "9", "PLX_PART_TILES": "1"}, ["direct,P=512,", "rec=12B,pack=0,", "tile=2048,"]),      # no room for 512 lone halves in a 2048-row tile
     ("direct", "flat1", {"PLX_PART_PAIR": "0"}, ["rec=12B,pack=0,"]),
+    # ... and over sparse 64-bit keys once their exact range is known (the first run learns it): 48-bit key offsets, seven dwords for two rows
+    ("hash", "flat1", {"PLX_PART_LOG2_PARTS": "8", "PLX_PART_TILES": "3"}, ["hash,P=256,", "rec=14B,pack=4,", "tile=6144,"]),
+    ("hash", "hot1", {"PLX_PART_LOG2_PARTS": "7"}, ["hash,P=128,", "rec=14B,pack=4,"]),
+    ("hash", "flat1", {"PLX_PART_LOG2_PARTS": "9", "PLX_PART_TILES": "1"}, ["hash,P=512,", "rec=16B,pack=0,", "tile=2048,"]),
 ]
 
 
