@@ -43,6 +43,8 @@ CASES = [
     ("plx_jit_RegAggSink_0_0a1b2c3d", "fused_scan_regagg_generic"), ("plx_jit_LdsAggSink_1_0a1b2c3d", "fused_scan_ldsagg_generic"), ("plx_jit_BallotSink_91_0a1b2c3d", "fused_scan_ballots[jit]"),
     ("void plx::k::compact_by_ballots_kernel<8, 3>(plx::k::CompactCols, unsigned long long const*, unsigned long long const*, long, unsigned int*)", "filter_compact_cols"),
     ("void plx::k::fused_scan_kernel<plx::k::StatProg<12>, plx::k::DirectHitsSink>(plx::fused::Shape, plx::fused::Args, plx::k::DirectHitsSink::Params)", "fused_scan_direct_hits_static#12"),
+    ("plx_jit_part3_scatter_94_0badf00d", "part3_scatter[jit,h,t2,p4]"), ("plx_jit_part3_scatter_108_0badf00d", "part3_scatter[jit,d,t4,p4,hot]"),
+    ("plx_jit_part3_agg_109_0badf00d", "part_agg_lds[jit,h,p4]"), ("plx_jit_part3_agg_110_0badf00d", "part_agg_lds[jit,d,p4]"),
     ("plx::k::join_bin_kernel(plx::fused::DirectJoinTable, plx::fused::JoinAggTable, HIP_vector_type<unsigned long long, 2u>*, unsigned int*)", "join_bin_windows"),
     ("plx::k::join_fill_kernel(HIP_vector_type<unsigned long long, 2u> const*, unsigned int const*, unsigned long long const*, plx::fused::JoinAggTable, unsigned long long*, unsigned int*)", "join_fill_lds"),
     ("plx::k::cells_agg_compact_kernel(unsigned long long const*, unsigned int const*, unsigned long long const*, long, int, int, unsigned long long*, unsigned long long*, unsigned int*, unsigned long long*)", "table_compact"),
