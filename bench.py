@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="q1", choices=["q1", "q1j", "q3", "q3f", "q3h", "q3d", "q3dc", "joinm", "joinmh", "filterm", "gather", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "cfg5l"])
+    ap.add_argument("--workload", default="q1", choices=["q1", "q1j", "q3", "q3f", "q3h", "q3d", "q3dc", "joinm", "joinmh", "semim", "filterm", "gather", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "cfg5l"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the SF100 / 1e9-row size of the workload)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -642,6 +642,40 @@ def make_workload(pl, name: str, rows: int, seed: int, ws: int = 1) -> Workload:
         wlm.inputs = [L, O]
         wlm.out_row_bytes = 8 + 8 + 8 + 8 + 8
         return wlm
+    if name == "semim":
+        # SEMI JOIN -> FRAME: the lineitem side of Q3's join (rows whose order survives the orders predicate), all four lineitem columns out, left order.  The reference:
+        # a hash set of the right keys, one lookup per left row (single_keys_semi_anti.rs), then a gather of the left columns.  Here: the right side -> membership bitmap,
+        # the left side filtered by predicate AND bitmap test in one program (engine.cpp fused_semi_anti_frame).
+        no = (rows // 4) if rows else SF100_ORDERS
+        O, L = datagen.orders_lineitem_native(pl, no, seed)
+        check_native_q3(pl, O, L, no, seed)
+        nl = L.height
+        lfs = queries.q3_semi_frame(L.lazy(), O.lazy())
+
+        def step_semi():
+            return lfs.collect(), (L, O)
+
+        def verify_semi(res, budget):
+            # orders' keys are unique, so the semi join's rows ARE the inner join's (join_materialise_sf100: verified through Q3's all-rows check in its own extra),
+            # projected on the lineitem columns: compared as sorted row sets; the semi join must also keep the left order (dbgen order: non-decreasing order keys)
+            inner = queries.q3_join_frame(L.lazy(), O.lazy()).collect()
+            k = res["l_orderkey"].to_numpy(); pr = res["l_extendedprice"].to_numpy(); di = res["l_discount"].to_numpy()
+            ik = inner["l_orderkey"].to_numpy(); ip = inner["l_extendedprice"].to_numpy(); idc = inner["l_discount"].to_numpy()
+            same_n = len(k) == len(ik)
+            o1, o2 = np.lexsort((di, pr, k)), np.lexsort((idc, ip, ik))
+            same = same_n and bool(np.array_equal(k[o1], ik[o2]) and np.array_equal(pr[o1].view(np.int64), ip[o2].view(np.int64)) and np.array_equal(di[o1].view(np.int64), idc[o2].view(np.int64)))
+            in_order = bool(np.all(k[1:] >= k[:-1])) if len(k) else True
+            date = datagen.us(1995, 3, 15)
+            ship_ok = bool(np.all(res["l_shipdate"].to_numpy().astype(np.int64) > date)) if len(k) else True
+            return {"ok": bool(same and in_order and ship_ok), "rows": int(len(k)), "inner_join_rows": int(len(ik)), "same_rows_as_the_inner_join": same, "left_order_kept": in_order,
+                    "covers_whole_input": True, "against": "the inner join of the same tables (join_materialise_sf100, itself checked through Q3's all-rows oracle check) projected on the lineitem columns, "
+                    "as sorted row sets; left order; the left predicate on every output row"}
+        wls = Workload("semi_join_materialise_sf100", nl + no, nl * 16 + no * 24, step_semi, "fused_scan",
+                       f"TPC-H Q3's tables as a SEMI join (lineitem {nl} rows filtered, against filtered orders {no}): right side -> membership bitmap, left side filtered by predicate AND "
+                       "bitmap test, four lineitem columns out; algorithmic bytes = the columns the predicates read, once (+ the output rows, in and out)", verify=verify_semi, scope="operator")
+        wls.inputs = [L, O]
+        wls.out_row_bytes = 2 * 32
+        return wls
     if name == "filterm":
         # FILTER -> FRAME (round-5 review, item 1b): config 2's frame, filter(a > 2^30) -> all three columns out (~half of the rows): 24 GB in + ~12 GB out.
         # The reference: FilterExec (filter.rs:94-145) -> a mask, then filter/mod.rs:18-110 per column.  The result stays in HBM (a 12 GB frame: the next operator's input).
@@ -1251,7 +1285,7 @@ def pmc_traffic(workload_name: str, kernel: str, rows: int):
              "tpch_q3_sf100_shuffled_inputs": ("q3s", SF100_ORDERS + SF100_LINEITEM), "cfg5_utf8view_keys_1e9": ("cfg5s", 10 ** 9), "cfg5_utf8view_20_byte_keys_1e9": ("cfg5l", 10 ** 9),
              "tpch_q3_sf100_hashed_keys": ("q3h", SF100_ORDERS + SF100_LINEITEM), "cfg2_nulls5pct_1e9": ("cfg2n", 10 ** 9), "cfg3_zipf_1e9": ("cfg3z", 10 ** 9),
              "cfg3_sparse_keys_1e9": ("cfg3s", 10 ** 9), "cfg3_two_int64_keys_1e9": ("cfg3w", 10 ** 9), "join_duplicate_build_keys_sf100": ("q3d", SF100_LINEITEM + SF100_LINEITEM * 2 // 15),
-             "join_aggregate_reads_build_side_sf100": ("q3dc", SF100_LINEITEM + SF100_LINEITEM * 2 // 15), "join_materialise_sf100": ("joinm", SF100_ORDERS + SF100_LINEITEM), "join_materialise_sf100_hashed_keys": ("joinmh", SF100_ORDERS + SF100_LINEITEM),
+             "join_aggregate_reads_build_side_sf100": ("q3dc", SF100_LINEITEM + SF100_LINEITEM * 2 // 15), "join_materialise_sf100": ("joinm", SF100_ORDERS + SF100_LINEITEM), "join_materialise_sf100_hashed_keys": ("joinmh", SF100_ORDERS + SF100_LINEITEM), "semi_join_materialise_sf100": ("semim", SF100_ORDERS + SF100_LINEITEM),
              "filter_materialise_1e9": ("filterm", 10 ** 9), "gather_1e9": ("gather", 10 ** 9), "tpch_q1_sf100_two_predicates_ten_aggregates_jit": ("q1j", SF100_LINEITEM)}.get(workload_name)
     if short is None or (short[1] is not None and abs(rows - short[1]) > 0.01 * short[1]):
         return None
@@ -2217,7 +2251,7 @@ def compare_q1_dicts(a: dict, b: dict) -> bool:
 
 MULTI_EXTRAS = ("q3", "q3:shuffle", "cfg3", "cfg5", "q1", "q1:weak")     # ":weak" = the per-rank SF100 shard (weak scaling), labelled so in its config.workload
 LATE_WORKLOADS = ("filterm", "gather")       # frame-returning operators with multi-gigabyte results: timed and checked last, one at a time
-EXTRA_WORKLOADS = ("q1j", "q3", "q3h", "q3d", "q3dc", "joinm", "joinmh", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "cfg5l", "q1")      # the secondary workloads of the N = 1 line, in this order
+EXTRA_WORKLOADS = ("q1j", "q3", "q3h", "q3d", "q3dc", "joinm", "joinmh", "semim", "q3f", "cfg2", "cfg2n", "cfg3", "cfg3z", "cfg3s", "cfg3w", "cfg5", "cfg5s", "cfg5l", "q1")      # the secondary workloads of the N = 1 line, in this order
 
 
 def run_multi(args, emit):

@@ -2055,14 +2055,25 @@ static FramePtr exec_node(Plan& plan, int node_id);
 // scan turns the counts into offsets, and ONE kernel then writes the kept rows of every fixed-width column densely and in order (k::compact_by_ballots); validity
 // bitmaps and Boolean columns go through the bitmap compaction of kernels_filter.hip with the same selection.  Traffic: predicate inputs once + payload once + output
 // once.  `want_rows`: also the kept row indices; rows_only: nothing else.  false: the predicate does not compile (f32 arithmetic, null literals...) -- per-node path.
-static bool fused_filter_frame(Plan& plan, const std::vector<int>& preds, const FramePtr& src, FramePtr& out, std::string* why, ColumnPtr* want_rows = nullptr, bool rows_only = false) {
+// member (may be null): one more conjunct -- the row's key column `key_col` is (anti: is NOT) a member of the bitmap `bits` over [kmin, kmin + range): the probe side of a semi /
+// anti join whose other side has become a membership bitmap (fused_semi_anti_frame).  A null key is nobody's member: semi drops it, anti keeps it.
+struct MemberTest { int key_col; const unsigned long long* bits; int64_t kmin; uint64_t range; bool anti; };
+static bool fused_filter_frame(Plan& plan, const std::vector<int>& preds, const FramePtr& src, FramePtr& out, std::string* why, ColumnPtr* want_rows = nullptr, bool rows_only = false,
+                               const MemberTest* member = nullptr) {
   Compiler c(plan, *src);
   try {
     int p = -1;
     for (int pe : preds) { int n = c.lower(pe); if (c.nodes[n].ty != 'b') throw Unsupported("predicate is not boolean"); p = p < 0 ? n : c.mk(OP_AND, p, n, 'b'); }
+    if (member) {
+      const int kn = c.load(member->key_col);
+      int m = c.ifnull(c.bit_lookup(p < 0 ? kn : c.mask_valid(kn, p), 0, member->kmin), 0);      // (rows the predicates already rejected do not look the bitmap up: OP_MASKV)
+      if (member->anti) m = c.mk(OP_NOT, m, m, 'b');
+      p = p < 0 ? m : c.mk(OP_AND, p, m, 'b');
+    }
     if (p < 0) throw Unsupported("no predicate");
     c.pred = p;
     c.finish();
+    if (member) c.args.lut[0] = Lut{member->bits, member->range};
   } catch (const Unsupported& u) { if (why) *why = u.why; return false; }
   const int64_t n = src->height;
   out = std::make_shared<Frame>();
@@ -2082,6 +2093,24 @@ static bool fused_filter_frame(Plan& plan, const std::vector<int>& preds, const 
   if (want_rows) { rows = empty_rows(); rows->len = m; rows->values = dev_alloc(values_bytes(PLX_U32, std::max<int64_t>(m, 1))); *want_rows = rows; }
   int n_moved = 0, n_bitmaps = 0;
   std::vector<ColumnPtr> outs(rows_only ? 0 : src->cols.size());
+  // A SPARSE selection (under a sixteenth of the rows: a selective predicate, a semi join against a small side) does not stream every column through the compaction
+  // kernel -- that reads all of them whatever is kept -- but takes the kept ROW IDS (one thread per wave tile walks the ballots) and gathers: the lines of the kept rows only.
+  static const bool no_sparse = getenv("PLX_FILTER_SPARSE") && getenv("PLX_FILTER_SPARSE")[0] == '0';
+  if (!rows_only && !no_sparse && m < n && m * 16 <= n && n < 0xffffffffll) {
+    ColumnPtr ids = rows;
+    if (!ids) { ids = empty_rows(); ids->len = m; ids->values = dev_alloc(values_bytes(PLX_U32, std::max<int64_t>(m, 1))); }
+    k::compact_by_ballots(sel, k::CompactCols{}, ids->values->as<uint32_t>());
+    out->cols.assign(src->cols.size(), nullptr);
+    for (size_t b0 = 0; b0 < src->cols.size(); b0 += (size_t)k::kGatherMultiMax) {
+      std::vector<ColumnPtr> part(src->cols.begin() + b0, src->cols.begin() + std::min(src->cols.size(), b0 + (size_t)k::kGatherMultiMax));
+      std::vector<ColumnPtr> got = ops::gather_columns(part, ids);
+      for (size_t j = 0; j < got.size(); j++) out->cols[b0 + j] = got[j];
+    }
+    PLX_HIP(hipStreamSynchronize(stream()));
+    plan.desc += "FusedFilter{fused_scan[" + std::string(jit::program_mode(static_id, n)) + "]+ballots -> scan -> row ids -> gather x" + std::to_string(src->cols.size()) + (want_rows ? ", row ids" : "") +
+                 ", kept=" + std::to_string(m) + "/" + std::to_string(n) + "}; ";
+    return true;
+  }
   if (m == n && !rows_only) { out->cols = src->cols; }                      // every row kept (filter/mod.rs:47-49)
   else if (!rows_only) {
     k::CompactCols cc{};
@@ -2466,8 +2495,65 @@ static bool fused_join_frame(Plan& plan, const IRN& jn, const std::set<std::stri
   return true;
 }
 
+// Join(semi | anti, one integer key pair) over two `[Filter]*` inputs -> the left rows whose key is (not) among the right side's, left columns, left order
+// (polars-ops/src/frame/join/hash_join/single_keys_semi_anti.rs: a hash SET of the right keys, one lookup per left row; dispatch_left_right.rs).  Here the right side
+// -- its predicate fused into the scan -- becomes a membership BITMAP over its key range (BitmapBuildSink: the sink of the filter joins of §4.1), and the join is a
+// FILTER of the left side: its own predicates AND the bitmap test in one predicate program, ballots -> one compaction pass over all left columns (fused_filter_frame).
+// No pairs, no gathers.  Needs a right key range a bitmap can cover (<= 2^34 keys and <= 256 x the right rows); otherwise the per-node join runs.
+static bool fused_semi_anti_frame(Plan& plan, const IRN& jn, FramePtr& out, std::string* why) {
+  auto no = [&](const char* m) { if (why) *why = m; return false; };
+  if (join_materialise_mode() == 0) return no("disabled (PLX_JOIN_MATERIALISE=0)");
+  if ((jn.how != PLX_JOIN_SEMI && jn.how != PLX_JOIN_ANTI) || jn.keys.size() != 1 || jn.keys_right.size() != 1) return no("not a single-key semi or anti join");
+  auto plain = [&](int e) -> const AE* { const AE* x = &plan.ae[e]; while (x->kind == PLX_AE_ALIAS) x = &plan.ae[x->lhs]; return x->kind == PLX_AE_COLUMN ? x : nullptr; };
+  const AE* lkx = plain(jn.keys[0]);
+  const AE* rkx = plain(jn.keys_right[0]);
+  if (!lkx || !rkx) return no("join keys are expressions");
+  std::vector<int> lpreds, rpreds;
+  const int lsrc = peel_filters(plan, jn.input, lpreds), rsrc = peel_filters(plan, jn.input_right, rpreds);
+  FramePtr L = exec_node(plan, lsrc), R = exec_node(plan, rsrc);
+  plan.memo[lsrc] = L; plan.memo[rsrc] = R;
+  const int lki = L->find(lkx->name), rki = R->find(rkx->name);
+  if (lki < 0 || rki < 0) return no("join key column not found");
+  const int kdt = L->cols[lki]->dtype;
+  if (kdt != R->cols[rki]->dtype || !dtype_is_int(kdt) || kdt == PLX_U64) return no("join key is not a signed / narrow integer column pair of one dtype");
+  int64_t mn = 0, mx = 0;
+  const bool have = R->height > 0 && R->cols[rki]->values && ops::int_range(R->cols[rki], &mn, &mx);
+  const unsigned __int128 range128 = have ? (unsigned __int128)((__int128)mx - (__int128)mn) + 1 : 1;
+  if (range128 > ((unsigned __int128)1 << 34) || (have && range128 > (unsigned __int128)R->height * 256 + 4096)) return no("right key range too wide for a membership bitmap");
+  const uint64_t range = (uint64_t)range128;
+  Buf bits = dev_alloc_zero(sizeof(uint64_t) * (size_t)(range / 64 + 2)), rows_dev = dev_alloc_zero(8);
+  uint64_t rows_in = 0;
+  if (have) {
+    Compiler cb(plan, *R);
+    try {
+      int p = -1;
+      for (int pe : rpreds) { int n = cb.lower(pe); if (cb.nodes[n].ty != 'b') throw Unsupported("predicate is not boolean"); p = p < 0 ? n : cb.mk(OP_AND, p, n, 'b'); }
+      cb.pred = p;
+      cb.key = cb.load(rki);
+      cb.finish();
+    } catch (const Unsupported& u) { if (why) *why = "right side: " + u.why; return false; }
+    BitmapBuild bb; bb.bits = bits->as<unsigned long long>(); bb.count = rows_dev->as<unsigned long long>(); bb.kmin = mn; bb.range = range;
+    k::fused_bitmap_build(cb.shape, cb.args, bb, find_static_shape(cb.shape));
+    d2h_sync(&rows_in, rows_dev->ptr, 8);
+  }
+  const MemberTest mt{lki, bits->as<unsigned long long>(), mn, range, jn.how == PLX_JOIN_ANTI};
+  const size_t mark = plan.desc.size();
+  std::string fwhy;
+  if (!fused_filter_frame(plan, lpreds, L, out, &fwhy, nullptr, false, &mt)) { if (why) *why = "left side: " + fwhy; return false; }
+  std::string fd = plan.desc.substr(mark);
+  plan.desc.resize(mark);
+  while (!fd.empty() && (fd.back() == ' ' || fd.back() == ';')) fd.pop_back();
+  plan.desc += std::string("FusedSemiAntiJoin{") + (jn.how == PLX_JOIN_ANTI ? "anti" : "semi") + ", right rows=" + std::to_string(rows_in) + "/" + std::to_string(R->height) + " -> membership bitmap range=" +
+               std::to_string(range) + ", left rows=" + std::to_string(L->height) + " filtered by " + fd + "}; ";
+  return true;
+}
+
 static FramePtr exec_join(Plan& plan, const IRN& n) {
-  if (!(plan.flags & PLX_PLAN_NO_FUSION)) {
+  if (!(plan.flags & PLX_PLAN_NO_FUSION) && (n.how == PLX_JOIN_SEMI || n.how == PLX_JOIN_ANTI)) {
+    FramePtr out; std::string why;
+    if (fused_semi_anti_frame(plan, n, out, &why)) return out;
+    plan.desc += "(semi / anti join not fused: " + why + ") ";
+  } else if (!(plan.flags & PLX_PLAN_NO_FUSION)) {
     FramePtr out; std::string why;
     if (fused_join_frame(plan, n, nullptr, out, &why)) return out;
     if (why != "small inputs") plan.desc += "(join not fused: " + why + ") ";

@@ -81,6 +81,15 @@ def q3_join_frame(lineitem, orders, date=Q3_DATE, seg_mod=5):
     return li.join(o, left_on="l_orderkey", right_on="o_orderkey").select("l_orderkey", "o_orderdate", "o_shippriority", "l_extendedprice", "l_discount")
 
 
+def q3_semi_frame(lineitem, orders, date=Q3_DATE, seg_mod=5):
+    """The lineitem rows of Q3's join as a SEMI join: lineitem[l_shipdate > date] whose order is among orders[o_orderdate < date, o_custkey % seg_mod == 0] --
+    left columns only, left order (single_keys_semi_anti.rs)."""
+    c = E.col
+    o = orders.filter((c("o_orderdate") < date) & ((c("o_custkey") % seg_mod) == 0))
+    li = lineitem.filter(c("l_shipdate") > date)
+    return li.join(o, left_on="l_orderkey", right_on="o_orderkey", how="semi")
+
+
 def q3_partsupp(lineitem, partsupp, date=Q3_DATE, group=5):
     """A join whose BUILD side repeats its keys: lineitem[l_shipdate > date] JOIN partsupp[ps_group == group] ON partkey (dbgen's partsupp holds four rows per part;
     the shape of TPC-H Q9 / Q20's partsupp joins), grouped by (l_partkey, ps_suppkey) -- a group is a build row, every lineitem row of a part contributes to each of the

@@ -250,6 +250,39 @@ def test_join_to_frame_edge_cases(pl, orc, monkeypatch):
     assert P.lazy().join(empty.lazy(), on="k", how="left").collect().height == 6
 
 
+@pytest.mark.parametrize("how", ["semi", "anti"])
+@pytest.mark.parametrize("hashed", [False, True])
+def test_semi_anti_join_is_a_filter_against_a_membership_bitmap(pl, orc, how, hashed):
+    """Join(semi | anti) over filtered inputs: the right side becomes a membership bitmap over its key range (its predicate fused into the build scan), the left side is
+    FILTERED by its own predicates AND the bitmap test in one predicate program -- left columns, left order, no pairs (single_keys_semi_anti.rs).  Null keys on both
+    sides (a null key is nobody's member: semi drops it, anti keeps it), duplicate right keys, a sparse and a dense result; hashed keys have no range a bitmap could
+    cover and take the per-node join.  Checked against the oracle's semi / anti join and the per-node path."""
+    rng = np.random.default_rng(990 + 2 * hashed + (how == "anti"))
+    n_probe, n_build = (1 << 22) + 999, 300_000
+    h = _join_inputs(rng, n_probe, n_build, dup=True, hashed=hashed)
+    P, B = _frames(pl, h)
+    c = pl.col
+    for ppred, pmask, bpred, bmask in ((c("d") < 60, h["pd"] < 60, c("z") != 3, h["bz"] != 3), (None, np.ones(n_probe, bool), c("z") == 7, h["bz"] == 7)):
+        lf = P.lazy().filter(ppred) if ppred is not None else P.lazy()
+        q = lf.join(B.lazy().filter(bpred), on="k", how=how)
+        out = q.collect()
+        plan = pl.last_plan()
+        assert ("FusedSemiAntiJoin{" in plan) == (not hashed), plan
+        if hashed:
+            assert "semi / anti join not fused: right key range too wide" in plan, plan
+        psel, bsel = np.nonzero(pmask)[0], np.nonzero(bmask)[0]
+        idx = orc.semi_anti_join(orc.JOIN_SEMI if how == "semi" else orc.JOIN_ANTI, h["pk"][psel], h["pv"][psel], h["bk"][bsel], h["bv"][bsel])
+        rows = psel[idx]
+        assert out.columns == ["k", "x", "w", "d"] and out.height == len(rows)
+        k, kv = out["k"]._download()
+        kv = kv if kv is not None else np.ones(len(rows), bool)
+        assert np.array_equal(kv, h["pv"][rows]) and np.array_equal(np.where(kv, k, 0), np.where(h["pv"][rows], h["pk"][rows], 0))
+        assert np.array_equal(out["x"].to_numpy(), h["px"][rows]) and np.array_equal(out["d"].to_numpy(), h["pd"][rows])
+        assert np.array_equal(out["w"].to_numpy().view(np.int64), h["pw"][rows].view(np.int64))
+        ref = q.collect(no_fusion=True)
+        assert "FusedSemiAntiJoin{" not in pl.last_plan() and ref.height == out.height and np.array_equal(ref["x"].to_numpy(), out["x"].to_numpy())
+
+
 # ------------------------------------------------------------------------------------------- join -> group-by, pair form
 @pytest.mark.parametrize("dup", [False, True])
 @pytest.mark.parametrize("shape", ["agg_reads_build", "key_is_build_column", "key_is_probe_column"])

@@ -3,7 +3,7 @@
 # (FETCH_SIZE and WRITE_SIZE in SEPARATE passes: they do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"; never
 # combined with sys/hip/hsa tracing).  usage (GPU box): bash tools/pmc_all.sh <tag> [workloads...]  -> gpurun_out/<tag>/profiles/
 TAG=${1:-r02p}; shift
-WLS=${@:-q1 q1j q3 q3s q3h q3d q3dc joinm joinmh q3f filterm gather cfg2 cfg2n cfg3 cfg3z cfg3s cfg3w cfg5 cfg5s cfg5l}
+WLS=${@:-q1 q1j q3 q3s q3h q3d q3dc joinm joinmh semim q3f filterm gather cfg2 cfg2n cfg3 cfg3z cfg3s cfg3w cfg5 cfg5s cfg5l}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 P=$OUT/profiles
