@@ -364,11 +364,24 @@ void fused_probe_agg(const Shape& sh, const Args& args, const JoinAggTable& t, i
   PLX_HIP(hipGetLastError());
 }
 
+// (only some of the ahead-of-time shapes have a BitmapBuildSink instantiation: the tracer's name must say what actually ran)
+static bool bitmap_build_has_static(int id) {
+#ifdef PLX_HAVE_Q3_SHAPES
+  if (id == SHAPE_Q3_BUILD) return true;
+#ifdef PLX_HAVE_Q3FULL_SHAPES
+  if (id == SHAPE_Q3F_SEMI) return true;
+#endif
+#endif
+  return false;
+}
 void fused_bitmap_build(const Shape& sh, const Args& args, const BitmapBuild& t, int static_id) {
   if (args.n_rows == 0) return;
-  ProfileScope ps(scope_name("fused_scan_bitmap_build_static", "fused_scan_bitmap_build", static_id).c_str(), algo_bytes(sh, args), (uint64_t)args.n_rows);
+  ProfileScope ps(scope_name("fused_scan_bitmap_build_static", "fused_scan_bitmap_build", bitmap_build_has_static(static_id) ? static_id : -1).c_str(), algo_bytes(sh, args), (uint64_t)args.n_rows);
   const int grid = scan_grid(args.n_rows, 8);
   switch (static_id) {
+#ifdef PLX_HAVE_Q3_SHAPES
+    case SHAPE_Q3_BUILD: hipLaunchKernelGGL((fused_scan_kernel<StatProg<SHAPE_Q3_BUILD>, BitmapBuildSink>), dim3(grid), dim3(kBlock), 0, stream(), sh, args, t); break;      // the semi join of Q3's tables
+#endif
     PLX_STATIC_BITMAP_BUILD_CASES
     default: if (!jit::launch(sh, args, jit::BITMAP_BUILD, &t, grid, 0)) { const DynLaunch d = dyn_launch(sh, args, 0); hipLaunchKernelGGL((fused_scan_kernel<DynProg, BitmapBuildSink>), dim3(grid), dim3(kBlock), d.lds, stream(), sh, d.args, t); } break;
   }
