@@ -909,6 +909,10 @@ int plx_jit_selftest(const plx_ir* ir, int32_t n_ir, const plx_aexpr* exprs, int
         for (uint32_t tiles : {1u, 2u, 3u, 4u}) { if (mode == fused::kP2Hash && tiles > 3) continue; jobs.push_back({sh, jit::part3_scatter_sink(mode, tiles, fused::kPackPair, false)}); jobs.push_back({sh, jit::part3_scatter_sink(mode, tiles, fused::kPackPair, true)}); }
         jobs.push_back({sh, jit::part3_agg_sink(mode, fused::kPackPair)});
       }
+      if (fused::pairv_pack_ok(sh, fused::kP2Hash)) {        // ... with the value as a 48-bit offset
+        for (uint32_t tiles : {1u, 2u, 3u}) { jobs.push_back({sh, jit::part3_scatter_sink(fused::kP2Hash, tiles, fused::kPackPairV, false)}); jobs.push_back({sh, jit::part3_scatter_sink(fused::kP2Hash, tiles, fused::kPackPairV, true)}); }
+        jobs.push_back({sh, jit::part3_agg_sink(fused::kP2Hash, fused::kPackPairV)});
+      }
     }
     if (sh.n_keys >= 2) {
       // wide key: the HBM table sink, and the partitioned path -- hash partitions, plain or narrowed records, no hot keys

@@ -277,7 +277,11 @@ constexpr uint32_t kNoChunk = 0xffffffffu;
 //                says rec_words = 5: the unit of the record stream, of the chunks and of chunk_fill is the PAIR.
 //                Hash mode (a 64-bit key whose range is KNOWN to span < 2^48 - 1, one 64-bit value): seven dwords {off0 lo, off1 lo, off0 hi16 | off1 hi16 << 16, value0,
 //                value1} with off = key - PartPlan2::key_base -- 14 bytes a row instead of 16; an absent half has the offset 2^48 - 1
-constexpr uint32_t kPackNone = 0, kPackNarrow = 1, kPackFused = 2, kPackRowid = 3, kPackPair = 4;
+//   kPackPairV   hash mode, a 64-bit key of ANY range and one Int64 value COLUMN whose range spans < 2^48 - 2^32 (config 3 on sparse keys: values spanning 2^41): the same
+//                seven-dword pair with the roles swapped -- {key0, key1, voff0 lo, voff1 lo, voff0 hi16 | voff1 hi16 << 16}, voff = value - PartPlan2::src_base[0]; an absent
+//                half has the high half-word 0xffff.  Bounds the planner only assumed are checked per row (pp.check_src) like every narrowed value
+constexpr uint32_t kPackNone = 0, kPackNarrow = 1, kPackFused = 2, kPackRowid = 3, kPackPair = 4, kPackPairV = 5;
+constexpr unsigned long long kPairVLimit = 0xffff00000000ull;      // value offsets stay below: the half-word 0xffff marks an absent half
 constexpr uint32_t kPairAbsent = 0xffffu;
 constexpr unsigned long long kPairAbsent48 = 0xffffffffffffull;
 struct RecLayout2 {
@@ -349,7 +353,7 @@ PLX_FHD constexpr RecLayout2 rec_layout2(const Shape& sh, uint32_t mode, uint32_
   L.n_src = (uint8_t)n_src;
   for (uint32_t j = 0; j < n_src && j < (uint32_t)kMaxSrc; j++) {
     L.src_kind[j] = narrow_kind(sh, L.src_slot[j]);
-    if (pack != kPackNone && pack != kPackPair && slot_is_int64_column(sh, L.src_slot[j])) L.src_kind[j] = 3;      // (a pair's values travel whole)
+    if (pack != kPackNone && pack != kPackPair && pack != kPackPairV && slot_is_int64_column(sh, L.src_slot[j])) L.src_kind[j] = 3;      // (a pair's values travel whole, or as 48-bit offsets formed in the tile sort)
     L.src_off[j] = (uint8_t)w;
     w += L.src_kind[j] ? 1 : 2;
   }
@@ -360,12 +364,17 @@ PLX_FHD constexpr RecLayout2 rec_layout2(const Shape& sh, uint32_t mode, uint32_
   L.rowid_off = (uint8_t)w; w += 2 * L.has_rowid;
   L.rec_words = (uint8_t)w; L.row_words = (uint8_t)w;
   if (pack == kPackPair) L.rec_words = mode == kP2Direct ? 5 : 7;      // planner-checked (pair_pack_ok): a row is {slot | 64-bit key, 64-bit value}; two rows share a record
+  if (pack == kPackPairV) L.rec_words = 7;
   return L;
 }
 // does the shape admit kPackPair at all (the planner still checks the slot count)?
 PLX_FHD constexpr bool pair_pack_ok(const Shape& sh, uint32_t mode) {
   const RecLayout2 L = rec_layout2(sh, mode, kPackNone);
   return !sh.n_keys && L.n_src == 1 && L.src_kind[0] == 0 && !L.has_valid && !L.has_rowid && L.rec_words == (mode == kP2Direct ? 3 : 4);      // (hash mode: a 64-bit key)
+}
+PLX_FHD constexpr bool pairv_pack_ok(const Shape& sh, uint32_t mode) {
+  const RecLayout2 L = rec_layout2(sh, mode, kPackNone);
+  return mode == kP2Hash && !sh.n_keys && L.key_words == 2 && L.n_src == 1 && L.src_kind[0] == 0 && slot_is_int64_column(sh, L.src_slot[0]) && !L.has_valid && !L.has_rowid && L.rec_words == 4;
 }
 // dwords a ROW occupies in the scatter's registers and LDS tile (kPackPair: as unpacked; two rows then share a record of 2 x row_words - 1 dwords)
 PLX_FHD constexpr uint32_t scatter_row_words(const RecLayout2& L) { return (uint32_t)L.row_words; }

@@ -35,6 +35,8 @@ double g_ms = 0;
 const char* sink_type(Sink s) {
   static const char* n[] = {"RegAggSink", "LdsAggSink", "DenseAggSink", "HashAggSink", "WideAggSink", "JoinBuildSink", "ProbeAggSink", "DirectBuildSink", "DirectProbeAggSink", "BitmapBuildSink",
                             "part_count", "part_scatter", "part_agg", "part2_scatter_hash", "part2_scatter_direct", "part2_agg_hash", "part2_agg_direct", "part2_scatter_hash_t2", "part2_scatter_direct_t2"};
+  if (s == PART3_AGG_PAIRV) return "part3_agg";
+  if (s >= PART3_SCATTER_PAIRV && s < PART3_AGG_PAIRV) return "part3_scatter";
   if (s == PART3_AGG_PAIR || s == PART3_AGG_PAIR_DIRECT) return "part3_agg";
   if (s >= PART3_SCATTER_PAIR && s < PART3_AGG_PAIR) return "part3_scatter";
   if (s == BALLOT) return "BallotSink";
@@ -125,6 +127,18 @@ std::string source_for(const Shape& sh, Sink sink) {
            "  part2_agg_body<Shape, " << (sink == PART2_AGG_DIRECT ? 1 : 0) << ", p2_agg_chunks_in_flight(cl.rec_words)>(csh, cl, pp, ap);\n}\n}}\n";
       break;
     default:
+      if (sink == PART3_AGG_PAIRV) {
+        o << "extern \"C\" __global__ __launch_bounds__(kP2AggBlock) void plx_jit_kernel(PartPlan2 pp, AggParams2 ap) {\n"
+             "  constexpr Shape csh = JitProg::shape(); constexpr RecLayout2 cl = rec_layout2(JitProg::shape(), 0u, " << fused::kPackPairV << "u);\n"
+             "  part2_agg_body<Shape, 0, p2_agg_chunks_in_flight(cl.rec_words)>(csh, cl, pp, ap);\n}\n}}\n";
+        break;
+      }
+      if (sink >= PART3_SCATTER_PAIRV && sink < PART3_AGG_PAIRV) {
+        const int v = (int)sink - (int)PART3_SCATTER_PAIRV, tiles = 1 + (v & 3), hot = (v >> 2) & 1;
+        o << "extern \"C\" __global__ __launch_bounds__(kP2MaxBlock) void plx_jit_kernel(Shape dsh, Args args, PartPlan2 pp, ScatterParams2 sp) {\n"
+             "  part3_scatter_body<JitProg, 0, " << tiles << ", " << fused::kPackPairV << ", " << (hot ? "true" : "false") << ">(dsh, args, pp, sp);\n}\n}}\n";
+        break;
+      }
       if (sink == PART3_AGG_PAIR || sink == PART3_AGG_PAIR_DIRECT) {
         const int mode = sink == PART3_AGG_PAIR_DIRECT ? 1 : 0;
         o << "extern \"C\" __global__ __launch_bounds__(kP2AggBlock) void plx_jit_kernel(PartPlan2 pp, AggParams2 ap) {\n"

@@ -32,12 +32,15 @@ enum Sink { REGAGG = 0, LDSAGG, DENSE, HASH, WIDE, JOIN_BUILD, PROBE_AGG, DIRECT
             DIRECT_HITS,        // fused_sinks.hpp DirectHitsSink (params = fused::DirectHits)
             // the third-generation scatter / aggregation with two rows a record (fused::kPackPair): PART3_SCATTER_PAIR + (tiles - 1) + 4 * hot + 8 * mode, PART3_AGG_PAIR + mode
             PART3_SCATTER_PAIR, PART3_AGG_PAIR = PART3_SCATTER_PAIR + 16, PART3_AGG_PAIR_DIRECT,
+            // ... and with the value as a 48-bit offset (fused::kPackPairV, hash mode): PART3_SCATTER_PAIRV + (tiles - 1) + 4 * hot
+            PART3_SCATTER_PAIRV, PART3_AGG_PAIRV = PART3_SCATTER_PAIRV + 8,
             kNumSinks };
 inline Sink part3_scatter_sink(uint32_t mode, uint32_t tiles, uint32_t pack, bool hot) {
+  if (pack == fused::kPackPairV) return (Sink)(PART3_SCATTER_PAIRV + (tiles - 1) + (hot ? 4 : 0));
   if (pack == fused::kPackPair) return (Sink)(PART3_SCATTER_PAIR + (tiles - 1) + (hot ? 4 : 0) + 8 * mode);
   return (Sink)(PART3_SCATTER + mode + 2 * (tiles - 1) + 8 * pack + (hot ? 32 : 0));
 }
-inline Sink part3_agg_sink(uint32_t mode, uint32_t pack) { return pack == fused::kPackPair ? (Sink)(PART3_AGG_PAIR + mode) : (Sink)(PART3_AGG + mode + 2 * pack); }
+inline Sink part3_agg_sink(uint32_t mode, uint32_t pack) { return pack == fused::kPackPairV ? PART3_AGG_PAIRV : pack == fused::kPackPair ? (Sink)(PART3_AGG_PAIR + mode) : (Sink)(PART3_AGG + mode + 2 * pack); }
 
 bool launch(const fused::Shape& sh, const fused::Args& args, Sink sink, const void* params, int grid, size_t lds_bytes);
 // Compile (or fetch) the specialised kernel of (shape, kind) without launching: lets a multi-kernel pipeline decide up

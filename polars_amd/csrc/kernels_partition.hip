@@ -205,7 +205,7 @@ static void plan2_geometry(PartPlan2& pp, int64_t n_rows, uint32_t tiles) {
   pp.scatter_grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(nrounds, (int64_t)device().cu_count * std::max(1, kEnvP2Wgs)));
   const int64_t rounds_per_wg = (nrounds + pp.scatter_grid - 1) / pp.scatter_grid;
   // records a round leaves at most (kPackPair: two rows a record, every partition may close one pair alone)
-  const int64_t recs_per_round = pp.pack == kPackPair ? rows_per_round / 2 + (int64_t)(1u << pp.log2_parts) / 2 + 1 : rows_per_round;
+  const int64_t recs_per_round = (pp.pack == kPackPair || pp.pack == kPackPairV) ? rows_per_round / 2 + (int64_t)(1u << pp.log2_parts) / 2 + 1 : rows_per_round;
   pp.chunks_per_wg = (uint32_t)(rounds_per_wg * recs_per_round / kP2ChunkRecs + (1u << pp.log2_parts) + 2);
 }
 
@@ -238,11 +238,15 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
       pack = kPackPair; pp.key_base = key_range->mn;      // hash partitions of 64-bit keys whose exact range spans < 2^48 - 1: 48-bit offsets, 14 bytes a row
     }
   }
+  // ... or, with a key of any range, an Int64 value column whose range spans < 2^48 - 2^32 as a 48-bit offset (kPackPairV; assumed bounds are checked per row)
+  bool pairv = false;
+  if (pack == kPackNone && !pair_off && pairv_pack_ok(sh, pp.mode) && ranges && ranges[0].known && ranges[0].mx >= ranges[0].mn && (uint64_t)ranges[0].mx - (uint64_t)ranges[0].mn < kPairVLimit) { pack = kPackPairV; pairv = true; }
   RecLayout2 L = rec_layout2(sh, pp.mode, pack);
   if (L.n_src > (uint32_t)kMaxSrc || L.rec_words > 13) return false;
   for (int j = 0; j < kMaxSrc; j++) pp.src_base[j] = (pack != kPackNone && ranges && ranges[j].known && (L.src_kind[j] == 3 || pack == kPackFused)) ? ranges[j].mn : 0;
   pp.check_src = 0;
   for (uint32_t j = 0; j < L.n_src && j < (uint32_t)kMaxSrc; j++) if (pack != kPackNone && ranges && ranges[j].known && ranges[j].check && (L.src_kind[j] == 3 || pack == kPackFused)) pp.check_src = 1;
+  if (pairv) { pp.src_base[0] = ranges[0].mn; pp.check_src = ranges[0].check ? 1u : 0u; }
   const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0;
   uint32_t tiles = 0;
   uint32_t block = kEnvP3Block >= 64 && (uint32_t)kEnvP3Block >= NP && kEnvP3Block % 64 == 0 ? (uint32_t)kEnvP3Block : (uint32_t)kP2MaxBlock;
@@ -263,7 +267,7 @@ static bool plan3(const Shape& sh, PartPlan2& pp, int64_t n_rows, const SrcRange
     }
   }
   // (pairs need room for the partitions' lone halves in the tile: at most T / 2 + NP / 2 five-dword records in 3 T dwords)
-  if (pack == kPackPair && NP * L.rec_words > block * kRows * tiles) { pack = kPackNone; L = rec_layout2(sh, pp.mode, pack); if (pp.mode == kP2Hash) pp.key_base = 0; }
+  if ((pack == kPackPair || pack == kPackPairV) && NP * L.rec_words > block * kRows * tiles) { pack = kPackNone; L = rec_layout2(sh, pp.mode, pack); if (pp.mode == kP2Hash) pp.key_base = 0; pp.src_base[0] = 0; pp.check_src = 0; }
   pp.gen = 3; pp.pack = pack; pp.rec_words = L.rec_words; pp.block = block; pp.ring_lines = 0;
   plan2_geometry(pp, n_rows, tiles);
   // chunks are filled completely (the carry line keeps the remainder): whole chunks of the rows + one partial chunk per partition + slack
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(kBlock) void hot_emit_kernel(const unsigned long lo
 // the value narrowed to a u32 offset, 4 B with key_low and value fused into one dword.  config 5 (u32 dictionary codes, Float64 value): 12 B.
 #ifdef PLX_HAVE_Q3_SHAPES
 #define PLX_P3_COMBOS(X)                                                                                                              \
-  X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackPair) \
+  X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackPair) X(SHAPE_GB_SUM_CNT_I64, kP2Hash, 3, kPackPairV) \
   X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNone) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackNarrow) X(SHAPE_GB_SUM_CNT_I64, kP2Direct, 4, kPackFused) \
   X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Hash, 3, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackNone) X(SHAPE_GB_SUM_MEAN_U32_F64, kP2Direct, 4, kPackPair) \
   X(SHAPE_GB2_SUM_CNT_I64, kP2Hash, 2, kPackNarrow)       /* two-column key at 512 partitions: 20-byte records, two tiles of an 896-thread workgroup (values that do not narrow: 24-byte records, run-time compiled) */
@@ -525,7 +529,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
                                    (gen3 && pp.n_hot ? ",hot]" : "]");
   const std::string agg_name = "part_agg_lds[" + sid + (direct ? ",d,p" : ",h,p") + std::to_string(pp.pack) + "]";
   PLX_REQUIRE(pp.n_hot == hot_keys.size(), PLX_ERR_INVALID, "partitioned_agg2: plan / hot key list mismatch");
-  const uint32_t row_bytes = pp.pack == kPackPair ? pp.rec_words * 2u : pp.rec_words * 4u;      // bytes a row travels as (a pair of rows shares a 20- / 28-byte record)
+  const uint32_t row_bytes = (pp.pack == kPackPair || pp.pack == kPackPairV) ? pp.rec_words * 2u : pp.rec_words * 4u;      // bytes a row travels as (a pair of rows shares a 20- / 28-byte record)
   const uint32_t chunk_dw = kP2ChunkRecs * pp.rec_words;
   const int64_t n_chunks = (int64_t)pp.scatter_grid * pp.chunks_per_wg;
   Buf recs = dev_alloc_transient((size_t)n_chunks * chunk_dw * 4 + 256);
@@ -565,7 +569,7 @@ int64_t partitioned_agg2(const Shape& sh, const Args& args, const PartPlan2& pla
     PLX_HIP(hipStreamSynchronize(stream()));     // `init` is a stack object
     sp.key_minmax = minmax->as<long long>();
   }
-  const size_t slds = gen3 ? part3_scatter_lds(pp.block * kRows * pp.tiles, pp.pack == kPackPair ? (direct ? 3u : 4u) : pp.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies)
+  const size_t slds = gen3 ? part3_scatter_lds(pp.block * kRows * pp.tiles, (pp.pack == kPackPair || pp.pack == kPackPairV) ? (direct ? 3u : 4u) : pp.rec_words, NP, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies)
                            : part2_scatter_lds(NP, pp.ring_lines, hot_slots, pp.n_hot, sh.n_aggs, pp.hot_copies);
   {
     // pass traffic: inputs read once + every surviving row written as one record (upper bound: all rows)

@@ -675,7 +675,7 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
   };
   auto process = [&](unsigned int (*cur)[16], uint32_t cnt_cur) __attribute__((always_inline)) {
     if (wide) { process_wide(cur, cnt_cur); return; }
-    if (L.pack == kPackPair && !direct) {
+    if ((L.pack == kPackPair || L.pack == kPackPairV) && !direct) {
       // a record is a PAIR of rows {off0 lo, off1 lo, off0 hi16 | off1 hi16 << 16, value0, value1}, key = key_base + 48-bit offset (fused.hpp kPackPair, hash mode); the
       // offset 2^48 - 1 = the half is absent.  The same three passes as below (decode + first table word, resolve, update) over 2 x kPerLane rows.
       constexpr uint32_t NH = 2 * kPerLane;
@@ -687,9 +687,16 @@ __device__ __forceinline__ void part2_agg_body(const S& sh, const RecLayout2& L,
 #pragma unroll
         for (uint32_t h = 0; h < 2; h++) {
           const uint32_t i = 2 * u + h;
-          const uint64_t koff = (uint64_t)rec[h] | ((uint64_t)((rec[2] >> (16 * h)) & 0xffffu) << 32);
-          live[i] = in && koff != kPairAbsent48;
-          key[i] = (uint64_t)pp.key_base + koff; val[i] = (uint64_t)rec[3 + 2 * h] | ((uint64_t)rec[4 + 2 * h] << 32);
+          if (L.pack == kPackPairV) {      // {key0, key1, voff0 lo, voff1 lo, voff0 hi16 | voff1 hi16 << 16}: whole keys, values as 48-bit offsets
+            const uint32_t hi = (rec[6] >> (16 * h)) & 0xffffu;
+            live[i] = in && hi != 0xffffu;
+            key[i] = (uint64_t)rec[2 * h] | ((uint64_t)rec[2 * h + 1] << 32);
+            val[i] = (uint64_t)pp.src_base[0] + ((uint64_t)rec[4 + h] | ((uint64_t)hi << 32));
+          } else {
+            const uint64_t koff = (uint64_t)rec[h] | ((uint64_t)((rec[2] >> (16 * h)) & 0xffffu) << 32);
+            live[i] = in && koff != kPairAbsent48;
+            key[i] = (uint64_t)pp.key_base + koff; val[i] = (uint64_t)rec[3 + 2 * h] | ((uint64_t)rec[4 + 2 * h] << 32);
+          }
           slot[i] = 0; first[i] = 0;
           if (!live[i]) continue;
           if (key[i] == kEmptyKey) { slot[i] = NS + 1; first[i] = kEmptyKey - 1; }

@@ -45,9 +45,11 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
   constexpr Shape sh = P::shape();
   constexpr RecLayout2 L = rec_layout2(P::shape(), (uint32_t)MODE, (uint32_t)PACK);
   constexpr uint32_t RW = L.rec_words;                  // dwords of a record of the stream (kPackPair: a PAIR of rows)
-  constexpr bool PAIR = PACK == (int)kPackPair;
+  constexpr bool PAIRV = PACK == (int)kPackPairV;      // pairs with the VALUE as a 48-bit offset (hash mode)
+  constexpr bool PAIR = PACK == (int)kPackPair || PAIRV;
   constexpr uint32_t SW = scatter_row_words(L);         // dwords of a row in registers / of the tile's budget per row
   static_assert(!PAIR || (MODE == (int)kP2Direct ? (RW == 5 && SW == 3) : (RW == 7 && SW == 4)), "kPackPair: {slot | 64-bit key, 64-bit value} rows");
+  static_assert(!PAIRV || MODE == (int)kP2Hash, "kPackPairV: hash partitions");
   constexpr uint32_t chunk_dw = kP2ChunkRecs * RW, cap_lines = chunk_dw / 32;      // a chunk holds whole records AND whole lines
   const uint32_t NP = 1u << pp.log2_parts;
   const uint32_t hot_slots = pp.n_hot ? (1u << pp.log2_hot_slots) : 0u;
@@ -209,6 +211,7 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
       if (PAIR && sc_odd) {
         unsigned int* last = sorted + (size_t)(o + c - 1u) * RW;
         if (MODE == (int)kP2Direct) reinterpret_cast<unsigned short*>(last)[1] = (unsigned short)kPairAbsent;
+        else if (PAIRV) reinterpret_cast<unsigned short*>(last + 6)[1] = (unsigned short)0xffffu;
         else { last[1] = 0xffffffffu; reinterpret_cast<unsigned short*>(last + 2)[1] = (unsigned short)0xffffu; }      // offset 2^48 - 1
       }
       if (nl) {
@@ -231,7 +234,19 @@ __device__ __forceinline__ void part3_scatter_body(const Shape dsh, const Args a
       constexpr int t = decltype(tc)::value;
 #pragma unroll
       for (int r = 0; r < kRows; r++) {
+        if constexpr (PAIRV) {      // (every lane takes part: narrow_viol is wave-uniform) a value outside the bounds its 48-bit offset assumed
+          const uint64_t voff = ((uint64_t)rec[t][r][2] | ((uint64_t)rec[t][r][3] << 32)) - (uint64_t)pp.src_base[0];
+          if (CHECK && pp.check_src) narrow_viol |= __ballot(part[t][r] != kNotPending && voff >= kPairVLimit);
+        }
         if (part[t][r] == kNotPending) continue;
+        if constexpr (PAIRV) {
+          const uint32_t rk = part[t][r] >> 10, h = rk & 1u;
+          unsigned int* dst = sorted + (size_t)(off[part[t][r] & 1023u] + (rk >> 1)) * RW;
+          const uint64_t voff = ((uint64_t)rec[t][r][2] | ((uint64_t)rec[t][r][3] << 32)) - (uint64_t)pp.src_base[0];
+          dst[2 * h] = rec[t][r][0]; dst[2 * h + 1] = rec[t][r][1];
+          dst[4 + h] = (uint32_t)voff; reinterpret_cast<unsigned short*>(dst + 6)[h] = (unsigned short)(voff >> 32);      // (a violating value is reported, the query runs again: never the marker)
+          continue;
+        }
         if constexpr (PAIR) {
           const uint32_t rk = part[t][r] >> 10, h = rk & 1u;                           // rank r of the partition's rows in the tile -> pair r / 2, half r % 2
           unsigned int* dst = sorted + (size_t)(off[part[t][r] & 1023u] + (rk >> 1)) * RW;

@@ -21,14 +21,21 @@ def main():
         ids[n // 2: n // 2 + n // 50] = rng.integers(0, 48, n // 50)
     v = rng.integers(-10 ** 6, 10 ** 6, n).astype(np.int64)
     x = rng.uniform(-1, 1, n)
-    if mode == "hash":
+    wide_v = shape.endswith("v")                                    # flatv / hotv: keys over all 64 bits, ONE Int64 value spanning 2^41 (fused::kPackPairV)
+    if wide_v:
+        v = rng.integers(-(1 << 40), 1 << 40, n).astype(np.int64)
+    if mode == "hash" and wide_v:
+        key = (ids.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).astype(np.int64)
+        df = pl.DataFrame({"k": key, "v": v, "x": x})
+    elif mode == "hash":
         key = ids.astype(np.int64) * 1_000_003 - 10 ** 12           # sparse 64-bit keys: hash partitions
         df = pl.DataFrame({"k": key, "v": v, "x": x})
     else:
         key = ids.astype(np.uint32)                                 # dense ids: direct-address partitions
         df = pl.DataFrame([pl.Series("k", key, dtype=pl.Categorical([], pl.UInt32)), pl.Series("v", v), pl.Series("x", x)])
     one = shape.endswith("1")
-    q = (df.lazy().group_by("k").agg(pl.col("x").sum().alias("xs"), pl.col("x").mean().alias("xm"), pl.len().alias("n")) if one else
+    q = (df.lazy().group_by("k").agg(pl.col("v").sum().alias("s"), pl.col("v").count().alias("n")) if wide_v else
+         df.lazy().group_by("k").agg(pl.col("x").sum().alias("xs"), pl.col("x").mean().alias("xm"), pl.len().alias("n")) if one else
          df.lazy().group_by("k").agg(pl.col("v").sum().alias("s"), pl.col("x").sum().alias("xs"), pl.len().alias("n")))
     for run in range(2):                                            # the second run knows the key range (packed / fused records)
         out = q.collect()
@@ -42,6 +49,12 @@ def main():
         order = np.argsort(k)
         present = np.unique(ids)
         assert np.array_equal(k[order], np.unique(key)), "keys"
+        if wide_v:                                                  # (sums up to 2^40 x rows per key: exact integer arithmetic on both sides)
+            order = np.argsort(k)
+            uk, inv = np.unique(key, return_inverse=True)
+            wsum = np.zeros(len(uk), np.int64); np.add.at(wsum, inv, v)
+            assert np.array_equal(k[order], uk) and np.array_equal(out["s"].to_numpy()[order], wsum) and np.array_equal(out["n"].to_numpy()[order], np.bincount(inv)), "wide values"
+            continue
         assert np.array_equal(out["n"].to_numpy()[order], np.bincount(ids, minlength=G)[present]), "len"
         if one:
             cnt = np.bincount(ids, minlength=G)[present]

@@ -248,3 +248,29 @@ def test_a_key_or_value_BELOW_the_assumed_minimum_is_caught(pl, dtype, violate):
     # (whether the planner guessed at all depends on the dtype -- narrow keys get exact statistics cheaply; when it did, the violation must have been noticed)
     if "bounds assumed from the sample" in plan or "AssumedBoundsViolated{" in plan:
         assert "AssumedBoundsViolated{" in plan, plan
+
+
+@pytest.mark.parametrize("violate", [False, True])
+def test_a_value_sent_as_a_48_bit_offset_is_checked_against_its_assumed_bounds(pl, violate):
+    """Sparse 64-bit keys (hash partitions) and an Int64 value spanning 2^41: the value travels as a 48-bit offset from its minimum, two rows a record (fused::kPackPairV).  On the
+    first run that minimum is the planner's GUESS from a strided sample: a value the offset cannot hold, placed where the sample does not look, must be reported by the
+    scatter's per-row check and the query planned again from exact statistics -- never a truncated sum."""
+    from polars_amd import queries
+    rng = np.random.default_rng(14)
+    n = 17_000_000
+    key = (rng.integers(0, 300_000, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).astype(np.int64)
+    v = rng.integers(-(1 << 40), 1 << 40, n).astype(np.int64)
+    if violate:
+        v[_outside_the_sample(n)] = (1 << 60) + np.arange(6)
+    df = pl.DataFrame({"key": key, "v": v})
+    out = queries.cfg3(df.lazy()).collect().sort_host("key")
+    plan = pl.last_plan()
+    assert ("AssumedBoundsViolated{" in plan) == violate, plan
+    assert "partitioned(v3,hash" in plan and ("pack=5" in plan) == (not violate), plan      # (exact bounds of 2^60: the values travel whole)
+    uk, inv = np.unique(key, return_inverse=True)
+    sums = np.zeros(len(uk), np.int64); np.add.at(sums, inv, v)
+    assert np.array_equal(np.array(out["key"], dtype=np.int64), uk)
+    got = [np.array(out[c], dtype=np.int64) for c in out if c != "key"]
+    assert any(np.array_equal(g, sums) for g in got) and any(np.array_equal(g, np.bincount(inv)) for g in got)
+    out2 = queries.cfg3(df.lazy()).collect().sort_host("key")
+    assert "AssumedBoundsViolated{" not in pl.last_plan() and out2 == out

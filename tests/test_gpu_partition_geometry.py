@@ -32,6 +32,9 @@ GEOMETRIES = [      # (what the second run -- key range known -- must report; th
     ("hash", "flat1", {"PLX_PART_LOG2_PARTS": "8", "PLX_PART_TILES": "3"}, ["hash,P=256,", "rec=14B,pack=4,", "tile=6144,"]),
     ("hash", "hot1", {"PLX_PART_LOG2_PARTS": "7"}, ["hash,P=128,", "rec=14B,pack=4,"]),
     ("hash", "flat1", {"PLX_PART_LOG2_PARTS": "9", "PLX_PART_TILES": "1"}, ["hash,P=512,", "rec=16B,pack=0,", "tile=2048,"]),
+    # keys over all 64 bits, an Int64 value spanning 2^41: the VALUE travels as a 48-bit offset (fused::kPackPairV); the first run takes sampled bounds, checked per row
+    ("hash", "flatv", {"PLX_PART_LOG2_PARTS": "8", "PLX_PART_TILES": "3"}, ["hash,P=256,", "rec=14B,pack=5,", "tile=6144,"]),
+    ("hash", "hotv", {"PLX_PART_LOG2_PARTS": "7"}, ["hash,P=256,", "rec=14B,pack=5,", "hot=48,"]),      # (hot keys: tables planned for 4 x the estimate)
 ]
 
 

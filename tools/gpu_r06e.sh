@@ -1,13 +1,3 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_strgroup.py tests/test_gpu_strview.py -x -q -m gpu 2>&1 | tail -15
-PLX_BENCH_EXTRAS=cfg5l PLX_BENCH_Q3_SHUFFLED=0 PLX_BENCH_E2E=0 PLX_BENCH_SCAN=0 PLX_BENCH_DEADLINE_S=900 timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu > gpurun_out/bench_cfg5l.log 2> gpurun_out/bench_cfg5l.err
-tail -c 800 gpurun_out/bench_cfg5l.err
-python - <<'PY'
-import json
-d=json.load(open('bench_extras.json'))
-for k,v in d.get('extras',{}).items():
-    if 'q1' in k: continue
-    print(k, json.dumps({a:b for a,b in v.items() if a in ('ms_per_step','cold_first_step_ms','step_ms','result_rows','kernels','error','plan')})[:2200])
-    print('  verified', (v.get('verified') or {}).get('ok'), 'frac', (v.get('roofline') or {}).get('frac'))
-PY
+timeout 900 python -m pytest tests/test_gpu_datagen.py -x -q -m gpu -k "48_bit" 2>&1 | tail -15

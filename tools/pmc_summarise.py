@@ -39,6 +39,9 @@ def scope_of(kernel: str):
     with the very instantiation it timed."""
     # run-time compiled kernels carry their kind in the symbol (jit.cpp kernel_symbol: plx_jit_<kind>_<sink number>_<shape hash>)
     m = re.match(r"plx_jit_part3_scatter_(\d+)_", kernel)
+    if m and int(m.group(1)) >= 111:     # ... with the value as a 48-bit offset (PART3_SCATTER_PAIRV = 111: + (tiles - 1) + 4 * hot; hash mode)
+        v = int(m.group(1)) - 111
+        return f"part3_scatter[jit,h,t{1 + (v & 3)},p5{',hot' if (v >> 2) & 1 else ''}]"
     if m and int(m.group(1)) >= 93:      # two rows a record (jit.hpp PART3_SCATTER_PAIR = 93: + (tiles - 1) + 4 * hot + 8 * mode)
         v = int(m.group(1)) - 93
         return f"part3_scatter[jit,{'d' if v >> 3 else 'h'},t{1 + (v & 3)},p4{',hot' if (v >> 2) & 1 else ''}]"
@@ -47,6 +50,8 @@ def scope_of(kernel: str):
         mode, tiles, pack, hot = v & 1, 1 + ((v >> 1) & 3), (v >> 3) & 3, v >> 5
         return f"{'probe_scatter' if pack == 3 else 'part3_scatter'}[jit,{'d' if mode else 'h'},t{tiles},p{pack}{',hot' if hot else ''}]"
     m = re.match(r"plx_jit_part3_agg_(\d+)_", kernel)
+    if m and int(m.group(1)) == 119:     # PART3_AGG_PAIRV
+        return "part_agg_lds[jit,h,p5]"
     if m and int(m.group(1)) >= 109:     # PART3_AGG_PAIR = 109 (hash), 110 (direct)
         return f"part_agg_lds[jit,{'d' if int(m.group(1)) == 110 else 'h'},p4]"
     if m:
