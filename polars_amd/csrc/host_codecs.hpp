@@ -443,13 +443,12 @@ inline void fse_build(const int16_t* freq, int nsym, int log, FseTable& t) {
   }
 }
 
-// 4.1.1: FSE table description -> table; returns the bytes it took
-inline size_t fse_read(const uint8_t* p, size_t n, int max_log, int max_sym, FseTable& t) {
+// 4.1.1: FSE table description -> normalised counts (-1 = "less than one"); returns the bytes it took
+inline size_t fse_read_norm(const uint8_t* p, size_t n, int max_log, int max_sym, int16_t* freq, int* nsym, int* log_out) {
   FwdBits br{p, n};
   const int log = 5 + (int)br.read(4);
   if (log > max_log) throw CodecError("zstd: FSE accuracy log too large");
   int remaining = 1 << log, sym = 0;
-  int16_t freq[256];
   while (remaining > 0 && sym <= max_sym) {
     int bits = highest_bit((uint64_t)remaining + 1) + 1;
     uint32_t val = br.read(bits);
@@ -469,8 +468,17 @@ inline size_t fse_read(const uint8_t* p, size_t n, int max_log, int max_sym, Fse
     }
   }
   if (remaining != 0 || sym > max_sym + 1) throw CodecError("zstd: malformed FSE distribution");
-  fse_build(freq, sym, log, t);
+  *nsym = sym; *log_out = log;
   return br.bytes_used();
+}
+
+// ... -> table
+inline size_t fse_read(const uint8_t* p, size_t n, int max_log, int max_sym, FseTable& t) {
+  int16_t freq[256];
+  int sym = 0, log = 0;
+  const size_t used = fse_read_norm(p, n, max_log, max_sym, freq, &sym, &log);
+  fse_build(freq, sym, log, t);
+  return used;
 }
 
 struct HufTable {
@@ -509,8 +517,8 @@ inline void huf_build(const uint8_t* bits, int nsym, HufTable& t) {
   for (uint32_t k = 0; k < size; k++) t.entry[k] = (uint16_t)((uint16_t)t.nbits[k] << 8 | t.symbol[k]);
 }
 
-// 4.2.1: Huffman tree description -> table; returns the bytes it took
-inline size_t huf_read(const uint8_t* p, size_t n, HufTable& t) {
+// 4.2.1: Huffman tree description -> code length per symbol (bits[0 .. *nsym)); returns the bytes it took
+inline size_t huf_read_bits(const uint8_t* p, size_t n, uint8_t* bits, int* nsym) {
   if (n < 1) throw CodecError("zstd: missing Huffman tree description");
   const int hb = p[0];
   uint8_t weights[260];
@@ -553,10 +561,18 @@ inline size_t huf_read(const uint8_t* p, size_t n, HufTable& t) {
   const uint64_t left = ((uint64_t)1 << max_bits) - sum;
   if (left & (left - 1)) throw CodecError("zstd: Huffman weights do not leave a power of two");
   const int last_weight = highest_bit(left) + 1;
-  uint8_t bits[260];
   for (int i = 0; i < nw; i++) bits[i] = weights[i] ? (uint8_t)(max_bits + 1 - weights[i]) : 0;
   bits[nw] = (uint8_t)(max_bits + 1 - last_weight);
-  huf_build(bits, nw + 1, t);
+  *nsym = nw + 1;
+  return used;
+}
+
+// ... -> table
+inline size_t huf_read(const uint8_t* p, size_t n, HufTable& t) {
+  uint8_t bits[260];
+  int nsym = 0;
+  const size_t used = huf_read_bits(p, n, bits, &nsym);
+  huf_build(bits, nsym, t);
   return used;
 }
 

@@ -249,6 +249,42 @@ void pq_snappy(const DecompJob* jobs, uint32_t n_jobs, uint64_t bytes_out, uint3
     fprintf(stderr, "\n");
   }
 }
+// ---- zstd (parquet_zstd.hpp): the wavefront of its bodies, and the two passes -----------------------------------------------------------------------------------
+struct ZstdDevWave {
+  template <class F> __device__ __forceinline__ void lanes(F&& f) { f((uint32_t)threadIdx.x); }
+  __device__ __forceinline__ void sync() { __syncthreads(); }
+  __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_wave_barrier(); }     // orders the wavefront's LDS accesses for the compiler; the hardware runs them in order
+};
+// one wavefront per compressed block (index list: longest blocks first)
+__global__ __launch_bounds__(kZLanes) void pq_zstd_entropy_kernel(ZstdBlock* __restrict__ blocks, const uint32_t* __restrict__ order, uint32_t n, const ZstdHufDesc* __restrict__ hufs,
+                                                                  const ZstdFseDesc* __restrict__ fses) {
+  __shared__ ZstdEntropyShared sh;
+  if (blockIdx.x >= n) return;
+  ZstdDevWave w;
+  zstd_entropy_block(w, sh, blocks, order[blockIdx.x], hufs, fses);
+}
+// one wavefront per page
+__global__ __launch_bounds__(kZLanes) void pq_zstd_execute_kernel(const ZstdStream* __restrict__ streams, uint32_t n, const ZstdBlock* __restrict__ blocks, uint32_t* __restrict__ err) {
+  __shared__ ZstdExecShared sh;
+  if (blockIdx.x >= n) return;
+  ZstdDevWave w;
+  const ZstdStream s = streams[blockIdx.x];
+  const bool ok = zstd_exec_stream(w, sh, s, blocks);
+  if (!ok && threadIdx.x == 0) atomicOr(err, (uint32_t)PE_ZSTD);
+}
+void pq_zstd(ZstdBlock* blocks, const uint32_t* order, uint32_t n_compressed, const ZstdHufDesc* hufs, const ZstdFseDesc* fses, const ZstdStream* streams, uint32_t n_streams,
+             uint64_t bytes_in, uint64_t bytes_out, uint32_t* err) {
+  if (n_compressed) {
+    ProfileScope ps("pq_zstd_entropy", bytes_in, n_compressed);
+    hipLaunchKernelGGL(pq_zstd_entropy_kernel, dim3(n_compressed), dim3(kZLanes), 0, stream(), blocks, order, n_compressed, hufs, fses);
+    PLX_HIP(hipGetLastError());
+  }
+  if (n_streams) {
+    ProfileScope ps("pq_zstd_execute", bytes_out * 2, n_streams);
+    hipLaunchKernelGGL(pq_zstd_execute_kernel, dim3(n_streams), dim3(kZLanes), 0, stream(), streams, n_streams, (const ZstdBlock*)blocks, err);
+    PLX_HIP(hipGetLastError());
+  }
+}
 void pq_page_prepare(PageDesc* pages, uint32_t n_pages, uint32_t* err) {
   if (!n_pages) return;
   hipLaunchKernelGGL(pq_page_prepare_kernel, dim3(blocks_for(n_pages)), dim3(kBlock), 0, stream(), pages, n_pages, err);

@@ -93,6 +93,7 @@ enum ErrorBits : uint32_t {
   PE_DICT_INDEX = 8u,   // dictionary index out of range
   PE_SNAPPY = 16u,      // malformed Snappy stream
   PE_DEF_LEVEL = 32u,   // definition level > 1 in a flat column
+  PE_ZSTD = 64u,        // malformed zstd stream
 };
 
 PLX_HD uint32_t load_u32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }

@@ -35,6 +35,7 @@
 #include "host_codecs.hpp"
 #include "parquet_device.hpp"
 #include "parquet_format.hpp"
+#include "parquet_zstd_index.hpp"
 
 namespace plx {
 namespace pq {
@@ -202,6 +203,7 @@ inline void snappy_decompress_into(const uint8_t* in, size_t n, uint8_t* out, si
 // ---- read one column --------------------------------------------------------------------------------------------------------------------
 struct ReadStats {
   uint64_t file_bytes = 0, data_pages = 0, dict_pages = 0, snappy_streams = 0, snappy_bytes_out = 0, run_entries = 0, host_inflated_pages = 0, host_inflated_bytes = 0;
+  uint64_t zstd_streams = 0, zstd_blocks = 0, zstd_bytes_out = 0;
 };
 
 template <class B> struct ColumnResult {
@@ -223,13 +225,15 @@ inline std::string error_bits_text(uint32_t e) {
   add(PE_DICT_INDEX, "dictionary index out of range");
   add(PE_SNAPPY, "malformed Snappy stream");
   add(PE_DEF_LEVEL, "definition level > 1 in a flat column");
+  add(PE_ZSTD, "malformed zstd stream");
   return s;
 }
 
 inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // pages of the codecs without a device kernel are inflated by host threads (host_codecs.hpp)
-// Which codecs are inflated by host threads.  ZSTD / GZIP / LZ4_RAW always (no device kernel).  SNAPPY has one (pq_snappy), the default;
+// Which codecs are inflated by host threads.  GZIP / LZ4_RAW always (no device kernel).  ZSTD has one since round 6 (pq_zstd_entropy + pq_zstd_execute, parquet_zstd.hpp), the
+// default; PLX_PARQUET_ZSTD=host keeps its pages on the host threads.  SNAPPY has one (pq_snappy), the default;
 // PLX_PARQUET_SNAPPY=host sends Snappy pages through the host threads too -- on a many-core host the column-wide parallel inflate may
 // outrun the device kernel, whose time is set by the longest single stream; an experiment switch until both are timed.
 inline bool snappy_on_host() {
@@ -242,8 +246,12 @@ inline size_t host_dict_min_bytes() {
   if (e) { const long long v = atoll(e); return v <= 0 ? (size_t)-1 : (size_t)v; }
   return (size_t)192 << 10;
 }
+inline bool zstd_on_host() {
+  const char* e = getenv("PLX_PARQUET_ZSTD");          // read per column chunk: cheap, and a test can flip it
+  return e && !strcmp(e, "host");
+}
 inline bool is_host_codec(int codec_id) {
-  return codec_id == CODEC_ZSTD || codec_id == CODEC_LZ4_RAW || codec_id == CODEC_GZIP || (codec_id == CODEC_SNAPPY && snappy_on_host());
+  return (codec_id == CODEC_ZSTD && zstd_on_host()) || codec_id == CODEC_LZ4_RAW || codec_id == CODEC_GZIP || (codec_id == CODEC_SNAPPY && snappy_on_host());
 }
 
 inline void host_inflate(int codec_id, const uint8_t* src, size_t n, uint8_t* dst, size_t out) {
@@ -286,7 +294,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     if (c.external_file) throw Unsupported("column chunk stored in another file");
     if (c.type != leaf.type) throw FormatError("column chunk type differs from the schema");
     const bool host_codec = is_host_codec(c.codec);       // decompressed by host threads (host_codecs.hpp)
-    if (c.codec != CODEC_UNCOMPRESSED && c.codec != CODEC_SNAPPY && !host_codec)
+    if (c.codec != CODEC_UNCOMPRESSED && c.codec != CODEC_SNAPPY && c.codec != CODEC_ZSTD && !host_codec)
       throw Unsupported(std::string("column '") + leaf.name + "': codec " + codec_name(c.codec) + " has no decompressor here (UNCOMPRESSED, SNAPPY, ZSTD, GZIP and LZ4_RAW do)");
     if (c.num_values != rg.num_rows) throw FormatError("flat column chunk whose value count differs from the row group's rows");
     if (rg.num_rows == 0) continue;            // an empty row group has nothing to fetch (writers leave its data page offset at 0)
@@ -382,6 +390,8 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
   struct SyncOnUnwind { B& b; int n = std::uncaught_exceptions(); ~SyncOnUnwind() { if (std::uncaught_exceptions() > n) b.discard_pending(); } } sync_on_unwind{be};
   size_t jobs_launched = 0, stored_since_launch = 0;
   static const size_t kSnappyBatch = [] { const char* e = getenv("PLX_PARQUET_SNAPPY_BATCH"); const long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : (size_t)-1; }();
+  ZstdPlan zplan;                                      // the zstd pages since the last launch, indexed while their stored bytes were at hand (parquet_zstd_index.hpp)
+  std::vector<size_t> zjobs;                           // ... and their job indices, in the plan's stream order
   auto launch_snappy = [&]() {
     if (jobs_launched == jobs.size()) return;
     size_t total = 0;
@@ -389,16 +399,51 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     for (size_t j = jobs_launched; j < jobs.size(); j++) { off[j - jobs_launched] = total; total += align16((size_t)jobs[j].uncomp_size + 16); }
     typename B::Mem scratch = be.alloc(total + 64);
     const uint64_t base = be.addr(scratch);
-    uint64_t bytes_out = 0;
-    for (size_t j = jobs_launched; j < jobs.size(); j++) { jobs[j].dst = base + off[j - jobs_launched]; bytes_out += jobs[j].uncomp_size; }
+    for (size_t j = jobs_launched; j < jobs.size(); j++) jobs[j].dst = base + off[j - jobs_launched];
+    snappy_mem.push_back(scratch);
     // one workgroup per stream, started in array order: the longest streams first.  Pages and dictionaries refer to the streams' output addresses, not to job indices.
-    std::vector<DecompJob> ordered(jobs.begin() + (std::ptrdiff_t)jobs_launched, jobs.end());
-    std::stable_sort(ordered.begin(), ordered.end(), [](const DecompJob& a, const DecompJob& b) { return a.uncomp_size > b.uncomp_size; });
-    typename B::Mem jm = be.alloc(ordered.size() * sizeof(DecompJob) + 64);
-    be.upload_small(be.addr(jm), ordered.data(), ordered.size() * sizeof(DecompJob));
-    be.run_snappy((const DecompJob*)be.addr(jm), (uint32_t)ordered.size(), bytes_out, err);
-    if (stats) { stats->snappy_streams += ordered.size(); stats->snappy_bytes_out += bytes_out; }
-    snappy_mem.push_back(scratch); snappy_mem.push_back(jm);
+    std::vector<DecompJob> ordered;
+    uint64_t bytes_out = 0;
+    {
+      size_t z = 0;
+      for (size_t j = jobs_launched; j < jobs.size(); j++) {
+        if (z < zjobs.size() && zjobs[z] == j) { z++; continue; }
+        ordered.push_back(jobs[j]); bytes_out += jobs[j].uncomp_size;
+      }
+    }
+    if (!ordered.empty()) {
+      std::stable_sort(ordered.begin(), ordered.end(), [](const DecompJob& a, const DecompJob& b) { return a.uncomp_size > b.uncomp_size; });
+      typename B::Mem jm = be.alloc(ordered.size() * sizeof(DecompJob) + 64);
+      be.upload_small(be.addr(jm), ordered.data(), ordered.size() * sizeof(DecompJob));
+      be.run_snappy((const DecompJob*)be.addr(jm), (uint32_t)ordered.size(), bytes_out, err);
+      if (stats) { stats->snappy_streams += ordered.size(); stats->snappy_bytes_out += bytes_out; }
+      snappy_mem.push_back(jm);
+    }
+    if (!zjobs.empty()) {
+      // zstd: literal buffers + sequence records of all blocks, the plan's arrays, then the two passes (entropy: a wavefront per block; execute: a wavefront per page)
+      uint64_t z_in = 0, z_out = 0;
+      for (size_t i = 0; i < zjobs.size(); i++) { zplan.streams[i].dst = jobs[zjobs[i]].dst; z_in += jobs[zjobs[i]].comp_size; z_out += jobs[zjobs[i]].uncomp_size; }
+      typename B::Mem lit = be.alloc((size_t)zplan.lit_bytes + 64), seq = be.alloc((size_t)zplan.n_seq * 16 + 64);
+      zstd_plan_place(zplan, be.addr(lit), be.addr(seq));
+      const std::vector<uint32_t> order_idx = zstd_plan_order(zplan);
+      const size_t nb = zplan.blocks.size() * sizeof(ZstdBlock), no = order_idx.size() * 4, nh = zplan.hufs.size() * sizeof(ZstdHufDesc), nf = zplan.fses.size() * sizeof(ZstdFseDesc),
+                   ns = zplan.streams.size() * sizeof(ZstdStream);
+      const size_t ob = 0, oo = align16(ob + nb), oh = align16(oo + no), of = align16(oh + nh), os = align16(of + nf), all = align16(os + ns);
+      std::vector<uint8_t> image(all, 0);            // one upload for the five arrays
+      if (nb) memcpy(image.data() + ob, zplan.blocks.data(), nb);
+      if (no) memcpy(image.data() + oo, order_idx.data(), no);
+      if (nh) memcpy(image.data() + oh, zplan.hufs.data(), nh);
+      memcpy(image.data() + of, zplan.fses.data(), nf);
+      memcpy(image.data() + os, zplan.streams.data(), ns);
+      typename B::Mem zm = be.alloc(all + 64);
+      const uint64_t za = be.addr(zm);
+      be.upload_small(za, image.data(), all);
+      be.run_zstd((ZstdBlock*)(za + ob), (const uint32_t*)(za + oo), (uint32_t)order_idx.size(), (const ZstdHufDesc*)(za + oh), (const ZstdFseDesc*)(za + of), (const ZstdStream*)(za + os),
+                  (uint32_t)zplan.streams.size(), z_in, z_out, err);
+      if (stats) { stats->zstd_streams += zplan.streams.size(); stats->zstd_blocks += zplan.blocks.size(); stats->zstd_bytes_out += z_out; }
+      snappy_mem.push_back(lit); snappy_mem.push_back(seq); snappy_mem.push_back(zm);
+      zplan.reset(); zjobs.clear();
+    }
     jobs_launched = jobs.size();
     stored_since_launch = 0;
   };
@@ -420,7 +465,17 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     }
     const size_t sz = (size_t)c.total_compressed_size;
     const bool host_codec = is_host_codec(c.codec);
-    const bool codec_on = c.codec == CODEC_SNAPPY && !host_codec;          // pages decompressed on the device
+    const bool codec_on = (c.codec == CODEC_SNAPPY || c.codec == CODEC_ZSTD) && !host_codec;          // pages decompressed on the device
+    const bool zstd_on = codec_on && c.codec == CODEC_ZSTD;
+    // a device stream: Snappy as it is; zstd with its headers indexed now, while the stored bytes are in the staging buffer
+    auto push_job = [&](const uint8_t* stored, uint64_t dev, uint32_t comp, uint32_t uncomp) {
+      if (zstd_on) {
+        try { zstd_index_stream(zplan, stored, comp, dev, uncomp); }
+        catch (const codec::CodecError& e) { throw FormatError(std::string("column '") + leaf.name + "': " + e.what()); }
+        zjobs.push_back(jobs.size());
+      }
+      jobs.push_back(DecompJob{dev, 0, comp, uncomp});
+    };
     // Device codec / none: the stored bytes are staged and uploaded as they are.  Host codec: the stored bytes stay in pageable memory;
     // what is staged and uploaded is the chunk's IMAGE -- the page payloads decompressed, back to back -- and the pages then look
     // like pages of an uncompressed file to every kernel.
@@ -478,8 +533,8 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
           std::vector<uint8_t> plain;
           const uint8_t* p = host + pos;
           size_t n = (size_t)h.compressed_size;
-          if (codec_on) { plain = snappy_decompress_host(p, n, (size_t)h.uncompressed_size); p = plain.data(); n = plain.size(); }
-          else if (host_codec) {
+          if (codec_on && !zstd_on) { plain = snappy_decompress_host(p, n, (size_t)h.uncompressed_size); p = plain.data(); n = plain.size(); }
+          else if (host_codec || zstd_on) {
             plain.resize((size_t)h.uncompressed_size);
             try {
               host_inflate(c.codec, p, n, plain.data(), plain.size());
@@ -506,7 +561,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
           if ((uint64_t)d.n * lt.src_width > (uint64_t)h.uncompressed_size && lt.src_width) throw FormatError("dictionary page smaller than its entry count");
           if (lt.src_width == 0) throw Unsupported("dictionary-encoded booleans");
           d.values = payload;
-          if (codec_on && (size_t)h.uncompressed_size >= host_dict_min_bytes()) {
+          if (codec_on && !zstd_on && (size_t)h.uncompressed_size >= host_dict_min_bytes()) {
             // A LONG Snappy stream is the device kernel's critical path -- one workgroup, 4 KB a round: pyarrow's dictionary pages of up to 1 MB ran for 13 ms next to
             // a thousand data pages of 2 ms each, and the launch lasts as long as its longest stream.  A host thread inflates such a page in about a millisecond while the
             // walk goes on (the compressed bytes are copied out of the staging buffer first: the next chunk reuses it); the plain values travel in one upload behind it.
@@ -522,7 +577,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
             if (stats) { stats->host_inflated_pages++; stats->host_inflated_bytes += (uint64_t)h.uncompressed_size; }
           } else if (codec_on) {
             job_of_dict.push_back(jobs.size());
-            jobs.push_back(DecompJob{payload, 0, (uint32_t)h.compressed_size, (uint32_t)h.uncompressed_size});
+            push_job(host + pos, payload, (uint32_t)h.compressed_size, (uint32_t)h.uncompressed_size);
           } else job_of_dict.push_back(npos);
           remap_base_of_dict.push_back(npos);
         }
@@ -557,16 +612,16 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
           if (h.is_compressed && h.compressed_size == h.def_len && h.uncompressed_size != h.def_len) throw FormatError("v2 page without value bytes whose sizes differ");
           if (codec_on && h.is_compressed && h.compressed_size > h.def_len) {
             p.flags |= PF_COMPRESSED;
-            job = jobs.size();
-            jobs.push_back(DecompJob{payload + (uint64_t)h.def_len, 0, (uint32_t)(h.compressed_size - h.def_len), (uint32_t)(h.uncompressed_size - h.def_len)});
             if (h.uncompressed_size < h.def_len) throw FormatError("v2 page smaller than its level bytes");
+            job = jobs.size();
+            push_job(host + pos + (size_t)h.def_len, payload + (uint64_t)h.def_len, (uint32_t)(h.compressed_size - h.def_len), (uint32_t)(h.uncompressed_size - h.def_len));
           }
         } else {
           if (optional && h.def_encoding != ENC_RLE) throw Unsupported(std::string("definition levels encoded as ") + encoding_name(h.def_encoding));
           if (codec_on) {
             p.flags |= PF_COMPRESSED;
             job = jobs.size();
-            jobs.push_back(DecompJob{payload, 0, (uint32_t)h.compressed_size, (uint32_t)h.uncompressed_size});
+            push_job(host + pos, payload, (uint32_t)h.compressed_size, (uint32_t)h.uncompressed_size);
           }
         }
         if (c.codec == CODEC_UNCOMPRESSED && h.compressed_size != h.uncompressed_size) throw FormatError("uncompressed page whose two sizes differ");

@@ -1,0 +1,544 @@
+// parquet_zstd.hpp -- Zstandard on the device (part of the Parquet scan: host + device bodies, like parquet_snappy.hpp).
+//
+// The reference inflates zstd pages with the zstd crate, one page after another (crates/polars-parquet/src/parquet/compression.rs:137-138,
+// 221-236); Polars WRITES zstd by default (compression.rs:103-120).  Format: RFC 8878.
+//
+// A zstd frame is a chain four times over -- Huffman literals, FSE-coded sequences (one bit stream three state machines share), repeat
+// offsets, LZ77 execution -- but the chains of the ENTROPY stages end at every block (<= 128 KB of output), and a 1 MB page is eight of them:
+//
+//   index    (host, while the page walk goes on: metadata only)  frame / block / section HEADERS are parsed into ZstdBlock records and the
+//            table DESCRIPTIONS into normalised counts / code lengths (a few dozen bytes per block; repeat / treeless modes resolved to the
+//            block that defined the table).  Nothing of the payload is decoded on the host.
+//   entropy  one wavefront per compressed block, all blocks of all pages of the column at once: lanes build the Huffman table and the three
+//            FSE tables in LDS; lanes 0..3 decode the (up to four) Huffman streams into the block's literal buffer; lane 0 decodes the
+//            sequences into {literal length, match length, offset} records.  Repeat offsets cross block borders: the records keep them
+//            SYMBOLIC (tag j + decrement k = "the block's incoming rep[j] - k"), so no block waits for its predecessor.
+//   execute  one wavefront per page: blocks in order; 64 sequences at a time -- every lane places its own sequence's literals at their
+//            final position (prefix sums), then the matches run in sequence order with all lanes copying bytes.  The last 32 KB of output
+//            live in an LDS ring (a match that reads what the previous match wrote costs an LDS round trip, not an HBM one); the ring is
+//            flushed to HBM in 16-byte stores, matches that reach further back read the flushed bytes.
+//
+// Every phase is a function of (lane) between barriers, so the CPU harness (tests/emu/parquet_emu.cpp) runs the very same bodies lane after
+// lane; W is the wavefront: W::lanes(f) runs f for every lane, W::sync() is the barrier.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "parquet_device.hpp"
+
+namespace plx {
+namespace pq {
+
+constexpr uint32_t kZLanes = 64;                 // one wavefront per block (entropy) / per page (execute)
+constexpr uint32_t kZRing = 32768;               // bytes of recent output held in LDS by the execute pass
+constexpr uint32_t kZRingMask = kZRing - 1;
+constexpr uint32_t kZPiece = 4096;               // bytes one cooperative copy step moves (long literal runs / long matches are cut into pieces)
+constexpr uint32_t kZBatchSpan = kZRing / 2;     // output bytes of one batch of sequences
+constexpr uint32_t kZLitLane = 64;               // literal bytes a lane places for its own sequence; longer runs go through the cooperative copy
+constexpr uint32_t kZOfMask = (1u << 30) - 1;    // sequence offsets: bits 31:30 = 0 -> the offset itself; j + 1 -> (incoming rep[j]) - low bits
+constexpr uint64_t kZRepBase = (uint64_t)1 << 40;   // symbolic repeat offsets while a block is decoded: incoming rep[j] = (j + 1) * kZRepBase
+constexpr uint32_t kZBlockMax = 128 * 1024;
+
+enum ZstdBlockType : uint8_t { ZB_RAW = 0, ZB_RLE = 1, ZB_COMPRESSED = 2 };
+enum ZstdLitType : uint8_t { ZL_RAW = 0, ZL_RLE = 1, ZL_HUFFMAN = 2 };
+
+struct ZstdSeqEntry { uint32_t base_value; uint16_t next_base; uint8_t extra_bits, nbits; };   // one state of a sequence table (8 bytes)
+
+struct ZstdHufDesc {       // code length per symbol (the implied last weight resolved by the index pass)
+  uint8_t bits[256];
+  uint32_t nsym, max_bits;
+};
+struct ZstdFseDesc {       // normalised counts of one sequence table (-1 = "less than one"), or its RLE symbol
+  int16_t norm[64];
+  uint8_t log, nsym, rle, rle_sym;
+  uint32_t pad;
+};
+
+struct ZstdBlock {         // one block of a frame
+  uint64_t src;            // block content (behind the 3-byte block header), in HBM
+  uint64_t lit;            // literals: raw -> their address inside src; Huffman -> the block's literal buffer; RLE -> the byte
+  uint64_t seq;            // the block's sequence records (uint4 each)
+  uint32_t src_len;        // content bytes (RLE: 1)
+  uint32_t out_len;        // raw / RLE: bytes the block regenerates; compressed: written by the entropy pass
+  uint32_t regen;          // literal bytes
+  uint32_t nseq;
+  uint32_t huf_off, huf_len;     // Huffman streams (jump table first when there are four) relative to src
+  uint32_t bits_off, bits_len;   // sequence bit stream relative to src
+  uint32_t huf;            // index of the ZstdHufDesc in force
+  uint32_t tab[3];         // index of the ZstdFseDesc in force: literal lengths, offsets, match lengths
+  uint8_t type, lit_type, lit_streams, first_in_frame;
+  // ---- written by the entropy pass ----
+  uint32_t rep_out[3];     // repeat offsets behind the block, encoded like sequence offsets
+  uint32_t lit_used;       // literal bytes the sequences consume
+  uint32_t bad;
+  uint32_t pad;
+};
+
+struct ZstdStream {        // one compressed page (or dictionary page): frames back to back
+  uint64_t dst;
+  uint32_t uncomp_size;
+  uint32_t first_block, n_blocks;
+  uint32_t pad;
+};
+
+// ---- bit streams ---------------------------------------------------------------------------------------------------------------------------
+PLX_HD int z_hb(uint32_t v) { return 31 - __builtin_clz(v); }      // v != 0
+
+// eight bytes at p + byte; bytes outside [0, n) read as zero
+PLX_HD uint64_t z_ld64(const uint8_t* p, uint32_t n, int64_t byte) {
+  if (byte >= 0 && (uint64_t)byte + 8 <= (uint64_t)n) return load_u64(p + byte);
+  uint64_t v = 0;
+  for (int i = 0; i < 8; i++) {
+    const int64_t b = byte + i;
+    if (b >= 0 && b < (int64_t)n) v |= (uint64_t)p[b] << (8 * i);
+  }
+  return v;
+}
+// the 57 bits below bit `off` of a backward stream (bit i of the result = stream bit off - 57 + i; bits outside the stream read as zero)
+PLX_HD uint64_t z_window(const uint8_t* p, uint32_t n, int64_t off) {
+  const int64_t lo = off - 57;
+  return (z_ld64(p, n, lo >> 3) >> (int)(lo & 7)) & (((uint64_t)1 << 57) - 1);
+}
+// `nb` bits of a window, `used` bits below its top already handed out
+PLX_HD uint32_t z_field(uint64_t w, uint32_t used, uint32_t nb) { return (uint32_t)(w >> (57 - used - nb)) & (uint32_t)(((uint64_t)1 << nb) - 1); }
+
+// first bit position of a backward stream (the bits are [0, off)); -1: no end mark
+PLX_HD int64_t z_back_start(const uint8_t* p, uint32_t n) {
+  if (n == 0 || p[n - 1] == 0) return -1;
+  return (int64_t)n * 8 - (8 - z_hb(p[n - 1]));
+}
+
+// ---- entropy pass --------------------------------------------------------------------------------------------------------------------------
+struct ZstdEntropyShared {
+  uint16_t huf[2048];              // (code length << 8) | symbol, indexed by the next max_bits bits
+  uint16_t huf_start[256];         // first table index of a symbol's codes
+  ZstdSeqEntry ll[512], of[256], ml[512];
+  uint8_t sym[3][512];             // FSE build: symbol of a state
+  uint16_t cnt[3][64];             // FSE build: occurrences of a symbol so far
+  uint32_t bad;
+};
+
+// sequence code -> base value / extra bits (RFC 8878 3.1.1.3.2.1.1)
+PLX_HD uint32_t z_ll_base(uint32_t c) { return c < 16 ? c : c < 20 ? 16 + 2 * (c - 16) : c < 22 ? 24 + 4 * (c - 20) : c < 24 ? 32 + 8 * (c - 22) : c == 24 ? 48 : (uint32_t)64 << (c - 25); }
+PLX_HD uint32_t z_ll_bits(uint32_t c) { return c < 16 ? 0 : c < 20 ? 1 : c < 22 ? 2 : c < 24 ? 3 : c == 24 ? 4 : c - 19; }
+PLX_HD uint32_t z_ml_bits(uint32_t c) { return c < 32 ? 0 : c < 36 ? 1 : c < 38 ? 2 : c < 40 ? 3 : c < 42 ? 4 : c == 42 ? 5 : c - 36; }
+PLX_HD uint32_t z_ml_base(uint32_t c) {
+  if (c < 32) return c + 3;
+  if (c < 36) return 35 + 2 * (c - 32);
+  if (c < 38) return 43 + 4 * (c - 36);
+  if (c < 40) return 51 + 8 * (c - 38);
+  if (c < 42) return 67 + 16 * (c - 40);
+  if (c == 42) return 99;
+  return ((uint32_t)1 << (c - 36)) + 3;
+}
+
+// lane 0: where every symbol's codes start (codes of one length are consecutive, symbols ascending, longest codes first: 4.2.1)
+PLX_HD void zstd_huf_starts(ZstdEntropyShared& sh, const ZstdHufDesc& d) {
+  uint32_t rank_count[13], rank_idx[13];
+  const uint32_t mb = d.max_bits < 1 ? 1 : d.max_bits > 11 ? 11 : d.max_bits, nsym = d.nsym > 256 ? 256 : d.nsym;
+  for (uint32_t i = 0; i <= 12; i++) rank_count[i] = 0;
+  for (uint32_t s = 0; s < nsym; s++) rank_count[d.bits[s] > 12 ? 12 : d.bits[s]]++;
+  rank_idx[mb] = 0;
+  for (uint32_t i = mb; i >= 1; i--) rank_idx[i - 1] = rank_idx[i] + rank_count[i] * (1u << (mb - i));
+  for (uint32_t s = 0; s < nsym; s++) {
+    const uint32_t b = d.bits[s];
+    if (b == 0 || b > mb) { sh.huf_start[s] = 0xffff; continue; }
+    sh.huf_start[s] = (uint16_t)rank_idx[b];
+    rank_idx[b] += 1u << (mb - b);
+  }
+}
+// every lane: the table entries of its symbols
+PLX_HD void zstd_huf_fill(ZstdEntropyShared& sh, const ZstdHufDesc& d, uint32_t lane) {
+  const uint32_t mb = d.max_bits < 1 ? 1 : d.max_bits > 11 ? 11 : d.max_bits, nsym = d.nsym > 256 ? 256 : d.nsym;
+  for (uint32_t s = lane; s < nsym; s += kZLanes) {
+    const uint32_t st = sh.huf_start[s];
+    if (st == 0xffff) continue;
+    const uint32_t b = d.bits[s], len = 1u << (mb - b);
+    const uint16_t e = (uint16_t)(b << 8 | s);
+    for (uint32_t k = 0; k < len && st + k < 2048; k++) sh.huf[st + k] = e;
+  }
+}
+
+// one Huffman stream: p[0, n) -> out[0, out_len); false = malformed
+PLX_HD bool zstd_huf_stream(const uint16_t* tbl, uint32_t mb, const uint8_t* p, uint32_t n, uint8_t* out, uint32_t out_len) {
+  int64_t off = z_back_start(p, n);
+  if (off < 0) return false;
+  uint32_t o = 0;
+  const uint32_t top = 64 - mb;
+  // a 64-bit container (the next bits of the stream at its top, first-read bit most significant) gives five symbols: 5 x 11 <= 56
+  while (off >= 64 && o + 5 <= out_len) {
+    const int64_t lo = off - 56, byte = lo >> 3;
+    uint64_t b = load_u64(p + byte) << (64 - (off - byte * 8));
+    uint32_t used = 0;
+    for (int k = 0; k < 5; k++) {
+      const uint32_t e = tbl[b >> top];
+      out[o + k] = (uint8_t)e;
+      b <<= e >> 8;
+      used += e >> 8;
+    }
+    o += 5;
+    off -= used;
+  }
+  while (off > 0) {
+    if (o >= out_len) return false;
+    const uint32_t idx = z_field(z_window(p, n, off), 0, mb);
+    const uint32_t e = tbl[idx];
+    out[o++] = (uint8_t)e;
+    off -= e >> 8;
+  }
+  return off == 0 && o == out_len;
+}
+
+// lanes 0 .. streams - 1: the block's Huffman-coded literals
+PLX_HD void zstd_huf_decode(ZstdEntropyShared& sh, const ZstdBlock& blk, const ZstdHufDesc& d, uint32_t lane) {
+  if (lane >= blk.lit_streams) return;
+  const uint8_t* p = PQ_GPTR(const uint8_t, blk.src) + blk.huf_off;
+  uint8_t* out = PQ_GPTR(uint8_t, blk.lit);
+  const uint32_t mb = d.max_bits < 1 ? 1 : d.max_bits > 11 ? 11 : d.max_bits;
+  bool ok;
+  if (blk.lit_streams == 1) ok = zstd_huf_stream(sh.huf, mb, p, blk.huf_len, out, blk.regen);
+  else {
+    // jump table: three 16-bit sizes; the fourth stream takes the rest (validated by the index pass, clamped here all the same)
+    if (blk.huf_len < 6) { sh.bad = 1; return; }
+    const uint32_t s1 = p[0] | (uint32_t)p[1] << 8, s2 = p[2] | (uint32_t)p[3] << 8, s3 = p[4] | (uint32_t)p[5] << 8, body = blk.huf_len - 6;
+    if ((uint64_t)s1 + s2 + s3 > body) { sh.bad = 1; return; }
+    const uint32_t each = (blk.regen + 3) / 4;
+    if ((uint64_t)each * 3 > blk.regen) { sh.bad = 1; return; }
+    const uint32_t start = lane == 0 ? 0 : lane == 1 ? s1 : lane == 2 ? s1 + s2 : s1 + s2 + s3;
+    const uint32_t len = lane == 0 ? s1 : lane == 1 ? s2 : lane == 2 ? s3 : body - s1 - s2 - s3;
+    const uint32_t olen = lane < 3 ? each : blk.regen - 3 * each;
+    ok = zstd_huf_stream(sh.huf, mb, p + 6 + start, len, out + (size_t)lane * each, olen);
+  }
+  if (!ok) sh.bad = 1;
+}
+
+// lane t < 3: sequence table t (0 literal lengths, 1 offsets, 2 match lengths) from its normalised counts (4.1.1)
+PLX_HD void zstd_fse_build(ZstdEntropyShared& sh, const ZstdFseDesc& d, uint32_t t) {
+  ZstdSeqEntry* tab = t == 0 ? sh.ll : t == 1 ? sh.of : sh.ml;
+  const uint32_t max_log = t == 1 ? 8 : 9, max_code = t == 0 ? 35 : t == 1 ? 31 : 52;
+  auto entry = [&](uint32_t c, uint32_t next_base, uint32_t nbits) {
+    ZstdSeqEntry e;
+    if (c > max_code) { sh.bad = 1; c = 0; }
+    if (t == 0) { e.base_value = z_ll_base(c); e.extra_bits = (uint8_t)z_ll_bits(c); }
+    else if (t == 2) { e.base_value = z_ml_base(c); e.extra_bits = (uint8_t)z_ml_bits(c); }
+    else { e.base_value = (uint32_t)1 << c; e.extra_bits = (uint8_t)c; }
+    e.next_base = (uint16_t)next_base; e.nbits = (uint8_t)nbits;
+    return e;
+  };
+  if (d.rle) { tab[0] = entry(d.rle_sym, 0, 0); return; }
+  const uint32_t log = d.log > max_log ? max_log : d.log, size = 1u << log, nsym = d.nsym > 64 ? 64 : d.nsym;
+  uint8_t* sym = sh.sym[t];
+  uint16_t* cnt = sh.cnt[t];
+  uint32_t high = size;
+  for (uint32_t s = 0; s < nsym; s++) {
+    cnt[s] = (uint16_t)(d.norm[s] == -1 ? 1 : d.norm[s] > 0 ? d.norm[s] : 0);
+    if (d.norm[s] == -1 && high > 0) sym[--high] = (uint8_t)s;
+  }
+  const uint32_t step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+  uint32_t pos = 0;
+  for (uint32_t s = 0; s < nsym; s++) {
+    if (d.norm[s] <= 0) continue;
+    for (int i = 0; i < d.norm[s]; i++) {
+      sym[pos] = (uint8_t)s;
+      uint32_t guard = 0;
+      do { pos = (pos + step) & mask; } while (pos >= high && ++guard < 1024);
+    }
+  }
+  if (pos != 0) sh.bad = 1;
+  for (uint32_t i = 0; i < size; i++) {
+    const uint32_t s = sym[i] < nsym ? sym[i] : 0;
+    const uint32_t next = cnt[s]++;
+    const uint32_t nb = next ? log - (uint32_t)z_hb(next) : log;
+    tab[i] = entry(s, ((next << nb) - size) & 0xffff, nb);
+  }
+}
+
+// a repeat-offset value of the decode loop (symbolic or real) -> the 32-bit form of the records; false = not representable
+PLX_HD bool zstd_encode_offset(uint64_t v, uint32_t* out) {
+  if (v >= (kZRepBase >> 1)) {
+    const uint64_t tag = (v + (kZRepBase >> 1)) >> 40;
+    const uint64_t k = tag * kZRepBase - v;
+    if (tag > 3 || k > kZOfMask) return false;
+    *out = (uint32_t)tag << 30 | (uint32_t)k;
+    return true;
+  }
+  if (v > kZOfMask) return false;
+  *out = (uint32_t)v;
+  return true;
+}
+PLX_HD uint32_t zstd_resolve_offset(uint32_t enc, const uint32_t* rep) {
+  const uint32_t tag = enc >> 30, v = enc & kZOfMask;
+  if (tag == 0) return v;
+  const uint32_t r = rep[tag - 1];
+  return r > v ? r - v : 0;          // 0 = invalid (caught by the execute pass)
+}
+
+// lane 0: the block's sequences -> records; literal / match totals; the repeat offsets behind the block (3.1.1.3.2, 3.1.1.5)
+PLX_HD void zstd_seq_decode(ZstdEntropyShared& sh, ZstdBlock& blk, const ZstdFseDesc* fd) {
+  const uint8_t* p = PQ_GPTR(const uint8_t, blk.src) + blk.bits_off;
+  const uint32_t n = blk.bits_len;
+  uint32_t* rec = PQ_GPTR(uint32_t, blk.seq);
+  int64_t off = z_back_start(p, n);
+  if (off < 0) { sh.bad = 1; return; }
+  const uint32_t log_ll = fd[0].rle ? 0 : fd[0].log, log_of = fd[1].rle ? 0 : fd[1].log, log_ml = fd[2].rle ? 0 : fd[2].log;
+  uint64_t w = z_window(p, n, off);
+  uint32_t sl = z_field(w, 0, log_ll), so = z_field(w, log_ll, log_of), sm = z_field(w, log_ll + log_of, log_ml);
+  off -= log_ll + log_of + log_ml;
+  uint64_t rep0 = kZRepBase, rep1 = 2 * kZRepBase, rep2 = 3 * kZRepBase;
+  uint64_t lit_sum = 0, match_sum = 0;
+  bool bad = off < 0;
+  for (uint32_t i = 0; i < blk.nseq && !bad; i++) {
+    const ZstdSeqEntry el = sh.ll[sl & 511], eo = sh.of[so & 255], em = sh.ml[sm & 511];
+    const uint64_t w1 = z_window(p, n, off);                // offset extra bits (<= 31) + match length extra bits (<= 16)
+    const uint64_t ov = (uint64_t)eo.base_value + z_field(w1, 0, eo.extra_bits);
+    const uint32_t ml = em.base_value + z_field(w1, eo.extra_bits, em.extra_bits);
+    off -= eo.extra_bits + em.extra_bits;
+    const uint64_t w2 = z_window(p, n, off);                // literal length extra bits (<= 16) + the three state updates (<= 9 + 9 + 8)
+    const uint32_t ll = el.base_value + z_field(w2, 0, el.extra_bits);
+    off -= el.extra_bits;
+    if (i + 1 < blk.nseq) {
+      uint32_t used = el.extra_bits;
+      sl = el.next_base + z_field(w2, used, el.nbits); used += el.nbits;
+      sm = em.next_base + z_field(w2, used, em.nbits); used += em.nbits;
+      so = eo.next_base + z_field(w2, used, eo.nbits);
+      off -= el.nbits + em.nbits + eo.nbits;
+    }
+    if (off < 0) { bad = true; break; }
+    uint64_t offset;
+    if (ov > 3) { offset = ov - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
+    else {
+      uint32_t idx = (uint32_t)ov - 1 + (ll == 0 ? 1 : 0);
+      if (idx == 0) offset = rep0;
+      else {
+        offset = idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
+        if (idx > 1) rep2 = rep1;
+        rep1 = rep0; rep0 = offset;
+      }
+    }
+    uint32_t enc;
+    if (!zstd_encode_offset(offset, &enc)) { bad = true; break; }
+    rec[4 * (size_t)i + 0] = ll; rec[4 * (size_t)i + 1] = ml; rec[4 * (size_t)i + 2] = enc; rec[4 * (size_t)i + 3] = 0;
+    lit_sum += ll; match_sum += ml;
+  }
+  if (off != 0 || lit_sum > blk.regen || match_sum > ((uint64_t)1 << 31)) bad = true;
+  uint32_t r0 = 0, r1 = 0, r2 = 0;
+  if (!zstd_encode_offset(rep0, &r0) || !zstd_encode_offset(rep1, &r1) || !zstd_encode_offset(rep2, &r2)) bad = true;
+  blk.rep_out[0] = r0; blk.rep_out[1] = r1; blk.rep_out[2] = r2;
+  blk.lit_used = (uint32_t)lit_sum;
+  blk.out_len = bad ? 0 : (uint32_t)(blk.regen + match_sum);
+  if (bad) sh.bad = 1;
+}
+
+// one compressed block, one wavefront
+template <class W> PLX_HD void zstd_entropy_block(W& w, ZstdEntropyShared& sh, ZstdBlock* blocks, uint32_t bi, const ZstdHufDesc* hufs, const ZstdFseDesc* fses) {
+  ZstdBlock& blk = blocks[bi];
+  w.lanes([&](uint32_t lane) { if (lane == 0) sh.bad = 0; });
+  w.sync();
+  if (blk.lit_type == ZL_HUFFMAN) {
+    const ZstdHufDesc& hd = hufs[blk.huf];
+    w.lanes([&](uint32_t lane) { if (lane == 0) zstd_huf_starts(sh, hd); });
+    w.sync();
+    w.lanes([&](uint32_t lane) { zstd_huf_fill(sh, hd, lane); });
+    w.sync();
+    w.lanes([&](uint32_t lane) { zstd_huf_decode(sh, blk, hd, lane); });
+  }
+  if (blk.nseq) {
+    w.lanes([&](uint32_t lane) { if (lane < 3) zstd_fse_build(sh, fses[blk.tab[lane]], lane); });
+    w.sync();
+    w.lanes([&](uint32_t lane) {
+      if (lane == 0) {
+        const ZstdFseDesc fd[3] = {fses[blk.tab[0]], fses[blk.tab[1]], fses[blk.tab[2]]};
+        zstd_seq_decode(sh, blk, fd);
+      }
+    });
+  } else {
+    w.lanes([&](uint32_t lane) {
+      if (lane == 0) { blk.rep_out[0] = 1u << 30; blk.rep_out[1] = 2u << 30; blk.rep_out[2] = 3u << 30; blk.lit_used = 0; blk.out_len = blk.regen; }
+    });
+  }
+  w.sync();
+  w.lanes([&](uint32_t lane) { if (lane == 0) blk.bad = sh.bad; });
+}
+
+// ---- execute pass --------------------------------------------------------------------------------------------------------------------------
+struct ZstdExecShared {
+  alignas(16) uint8_t ring[kZRing];
+  uint32_t b_ll[kZLanes], b_ml[kZLanes], b_of[kZLanes];      // the batch's records (offsets resolved)
+  uint32_t b_lit[kZLanes], b_out[kZLanes];                   // exclusive prefixes: literal bytes / output bytes before the sequence
+  uint32_t cnt, span, lit_span, bad;
+};
+
+// the state of a page's wavefront (uniform: every lane holds the same values)
+struct ZstdExecState {
+  uint8_t* dst;
+  uint32_t cap;            // bytes the page must decode to
+  uint32_t cur;            // output position
+  uint32_t flushed;        // ring bytes below this position are in HBM (a multiple of 16)
+  uint32_t frame_start;
+  uint32_t rep[3];
+};
+
+// sixteen bytes ring -> HBM (both addresses are multiples of 16: the page's output starts on one)
+PLX_HD void z_copy16(uint8_t* dst, const uint8_t* src) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+  *(v4*)dst = *(const v4*)src;
+#else
+  memcpy(dst, src, 16);
+#endif
+}
+// ring -> HBM: whole 16-byte units below `to`; with `tail` (the page's end) the last bytes too
+template <class W> PLX_HD void zstd_flush(W& w, ZstdExecShared& sh, ZstdExecState& st, uint32_t to, bool tail) {
+  const uint32_t from = st.flushed, end16 = to & ~15u;
+  if (end16 <= from && !tail) return;
+  uint8_t* dst = st.dst;
+  w.lanes([&](uint32_t lane) {
+    for (uint32_t a = from + lane * 16; a < end16; a += kZLanes * 16) z_copy16(dst + a, &sh.ring[a & kZRingMask]);
+    if (tail)
+      for (uint32_t a = (end16 > from ? end16 : from) + lane; a < to; a += kZLanes) dst[a] = sh.ring[a & kZRingMask];
+  });
+  st.flushed = tail ? to : (end16 > from ? end16 : from);
+}
+// before `span` more bytes enter the ring: what they overwrite must be in HBM
+template <class W> PLX_HD void zstd_room(W& w, ZstdExecShared& sh, ZstdExecState& st, uint32_t span) {
+  if (st.cur + span - st.flushed > kZRing) { zstd_flush(w, sh, st, st.cur, false); w.sync(); }
+}
+
+// n literal bytes (from src, or n copies of `fill`) at the output position, in pieces
+template <class W> PLX_HD bool zstd_emit_literals(W& w, ZstdExecShared& sh, ZstdExecState& st, const uint8_t* src, uint32_t n, bool rle, uint8_t fill) {
+  if (n > st.cap - st.cur) return false;
+  while (n) {
+    const uint32_t piece = n < kZPiece ? n : kZPiece;
+    zstd_room(w, sh, st, piece);
+    const uint32_t cur = st.cur;
+    w.lanes([&](uint32_t lane) {
+      for (uint32_t t = lane; t < piece; t += kZLanes) sh.ring[(cur + t) & kZRingMask] = rle ? fill : src[t];
+    });
+    w.sync();
+    st.cur += piece; n -= piece;
+    if (!rle) src += piece;
+  }
+  return true;
+}
+
+// the bytes of one match piece: byte t of [d, d + n) = byte d - off + (t mod off): sources below `floor` have left the ring and are read from HBM
+PLX_HD void zstd_copy_match(ZstdExecShared& sh, const uint8_t* dst, uint32_t d, uint32_t off, uint32_t n, uint32_t floor, uint32_t lane) {
+  const bool overlap = off < n;
+  for (uint32_t t = lane; t < n; t += kZLanes) {
+    const uint32_t q = d - off + (overlap ? t % off : t);
+    sh.ring[(d + t) & kZRingMask] = q >= floor ? sh.ring[q & kZRingMask] : dst[q];
+  }
+}
+template <class W> PLX_HD bool zstd_emit_match(W& w, ZstdExecShared& sh, ZstdExecState& st, uint32_t off, uint32_t n) {
+  if (off == 0 || off > st.cur - st.frame_start || n > st.cap - st.cur) return false;
+  while (n) {
+    const uint32_t piece = n < kZPiece ? n : kZPiece;
+    zstd_room(w, sh, st, piece);
+    const uint32_t cur = st.cur, floor = cur + piece > kZRing ? cur + piece - kZRing : 0;
+    const uint8_t* dst = st.dst;
+    w.lanes([&](uint32_t lane) { zstd_copy_match(sh, dst, cur, off, piece, floor, lane); });
+    w.sync();
+    st.cur += piece; n -= piece;
+  }
+  return true;
+}
+
+// lane 0: how many sequences of the batch run in the fast path, and where their bytes go
+PLX_HD void zstd_plan_batch(ZstdExecShared& sh, uint32_t n_in, uint32_t lit_left, uint32_t room_left) {
+  uint32_t lit = 0, out = 0, k = 0;
+  for (; k < n_in; k++) {
+    const uint32_t ll = sh.b_ll[k], ml = sh.b_ml[k];
+    if (ll > kZLitLane || ml > kZPiece || out + ll + ml > kZBatchSpan) break;
+    if (ll > lit_left - lit || ll + ml > room_left - out) { sh.bad = 1; break; }
+    sh.b_lit[k] = lit; sh.b_out[k] = out;
+    lit += ll; out += ll + ml;
+  }
+  sh.cnt = k; sh.span = out; sh.lit_span = lit;
+}
+
+// one compressed block
+template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExecState& st, const ZstdBlock& blk) {
+  const bool lit_rle = blk.lit_type == ZL_RLE;
+  const uint8_t fill = (uint8_t)blk.lit;
+  const uint8_t* lits = lit_rle ? nullptr : PQ_GPTR(const uint8_t, blk.lit);
+  const uint32_t* rec = PQ_GPTR(const uint32_t, blk.seq);
+  if (blk.bad || blk.lit_used > blk.regen) return false;
+  uint32_t lp = 0;
+  const uint32_t rep_in[3] = {st.rep[0], st.rep[1], st.rep[2]};
+  for (uint32_t base = 0; base < blk.nseq;) {
+    const uint32_t n_in = blk.nseq - base < kZLanes ? blk.nseq - base : kZLanes;
+    w.lanes([&](uint32_t lane) {
+      if (lane < n_in) {
+        const uint32_t* r = rec + 4 * (size_t)(base + lane);
+        sh.b_ll[lane] = r[0]; sh.b_ml[lane] = r[1]; sh.b_of[lane] = zstd_resolve_offset(r[2], rep_in);
+      }
+      if (lane == 0) sh.bad = 0;
+    });
+    w.sync();
+    w.lanes([&](uint32_t lane) { if (lane == 0) zstd_plan_batch(sh, n_in, blk.regen - lp, st.cap - st.cur); });
+    w.sync();
+    if (sh.bad) return false;
+    const uint32_t cnt = sh.cnt, span = sh.span, lit_span = sh.lit_span;
+    if (cnt == 0) {
+      // a sequence with a long literal run or a long match: cooperative copies, one piece at a time
+      const uint32_t ll = sh.b_ll[0], ml = sh.b_ml[0], off = sh.b_of[0];
+      w.sync();
+      if (ll > blk.regen - lp) return false;
+      if (!zstd_emit_literals(w, sh, st, lit_rle ? nullptr : lits + lp, ll, lit_rle, fill)) return false;
+      lp += ll;
+      if (!zstd_emit_match(w, sh, st, off, ml)) return false;
+      base += 1;
+      continue;
+    }
+    zstd_room(w, sh, st, span);
+    const uint32_t cur = st.cur, frame_start = st.frame_start, floor = cur + span > kZRing ? cur + span - kZRing : 0;
+    // every lane: its sequence's literals at their final place; its match must stay inside the frame
+    w.lanes([&](uint32_t lane) {
+      if (lane < cnt) {
+        const uint32_t ll = sh.b_ll[lane], pos = cur + sh.b_out[lane];
+        const uint8_t* s = lit_rle ? nullptr : lits + lp + sh.b_lit[lane];
+        for (uint32_t t = 0; t < ll; t++) sh.ring[(pos + t) & kZRingMask] = lit_rle ? fill : s[t];
+        const uint32_t off = sh.b_of[lane];
+        if (off == 0 || off > pos + ll - frame_start) sh.bad = 1;
+      }
+    });
+    w.sync();
+    if (sh.bad) return false;
+    const uint8_t* dst = st.dst;
+    for (uint32_t k = 0; k < cnt; k++) {
+      const uint32_t d = cur + sh.b_out[k] + sh.b_ll[k], off = sh.b_of[k], n = sh.b_ml[k];
+      w.lanes([&](uint32_t lane) { zstd_copy_match(sh, dst, d, off, n, floor, lane); });
+      w.wave_fence();
+    }
+    w.sync();
+    st.cur += span; lp += lit_span; base += cnt;
+  }
+  // the literals behind the last sequence
+  if (!zstd_emit_literals(w, sh, st, lit_rle ? nullptr : lits + lp, blk.regen - lp, lit_rle, fill)) return false;
+  st.rep[0] = zstd_resolve_offset(blk.rep_out[0], rep_in);
+  st.rep[1] = zstd_resolve_offset(blk.rep_out[1], rep_in);
+  st.rep[2] = zstd_resolve_offset(blk.rep_out[2], rep_in);
+  return true;
+}
+
+// one page: its blocks in order; false = malformed
+template <class W> PLX_HD bool zstd_exec_stream(W& w, ZstdExecShared& sh, const ZstdStream& s, const ZstdBlock* blocks) {
+  ZstdExecState st;
+  st.dst = PQ_GPTR(uint8_t, s.dst); st.cap = s.uncomp_size; st.cur = 0; st.flushed = 0; st.frame_start = 0;
+  st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8;
+  for (uint32_t b = 0; b < s.n_blocks; b++) {
+    const ZstdBlock& blk = blocks[s.first_block + b];
+    if (blk.first_in_frame) { st.frame_start = st.cur; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; }
+    bool ok;
+    if (blk.type == ZB_RAW) ok = zstd_emit_literals(w, sh, st, PQ_GPTR(const uint8_t, blk.src), blk.src_len, false, 0);
+    else if (blk.type == ZB_RLE) ok = zstd_emit_literals(w, sh, st, nullptr, blk.out_len, true, (uint8_t)blk.lit);
+    else ok = zstd_exec_block(w, sh, st, blk);
+    if (!ok) return false;
+  }
+  if (st.cur != st.cap) return false;
+  zstd_flush(w, sh, st, st.cur, true);
+  return true;
+}
+
+}  // namespace pq
+}  // namespace plx

@@ -64,6 +64,39 @@ uint32_t snappy_stream(const DecompJob& job, int order, uint32_t* rounds) {
   return (sh.done == 2 || sh.bad) ? (uint32_t)PE_SNAPPY : 0u;
 }
 
+// the wavefront of the zstd bodies (parquet_zstd.hpp): the lanes of a phase one after another
+struct EmuWave {
+  int order = 0;
+  template <class F> void lanes(F&& f) {
+    if (order == 0) for (uint32_t lane = 0; lane < kZLanes; lane++) f(lane);
+    else for (uint32_t lane = kZLanes; lane-- > 0;) f(lane);
+  }
+  void sync() {}
+  void wave_fence() {}
+};
+// pq_zstd_entropy + pq_zstd_execute (kernels_parquet.hip) as loops: one wavefront per compressed block, then one per page; returns PE_ZSTD or 0
+uint32_t zstd_run(ZstdBlock* blocks, const uint32_t* order_idx, uint32_t n_compressed, const ZstdHufDesc* hufs, const ZstdFseDesc* fses, const ZstdStream* streams, uint32_t n_streams,
+                  int order) {
+  EmuWave w;
+  w.order = order;
+  uint32_t err = 0;
+  auto each = [&](size_t n, auto&& f) {
+    if (order == 0) for (size_t i = 0; i < n; i++) f(i);
+    else for (size_t i = n; i-- > 0;) f(i);
+  };
+  each(n_compressed, [&](size_t i) {
+    auto sh = std::make_unique<ZstdEntropyShared>();
+    memset(sh.get(), 0xA5, sizeof *sh);     // LDS is not zeroed
+    zstd_entropy_block(w, *sh, blocks, order_idx[i], hufs, fses);
+  });
+  each(n_streams, [&](size_t i) {
+    auto sh = std::make_unique<ZstdExecShared>();
+    memset(sh.get(), 0xA5, sizeof *sh);
+    if (!zstd_exec_stream(w, *sh, streams[i], blocks)) err |= (uint32_t)PE_ZSTD;
+  });
+  return err;
+}
+
 struct HostBackend {
   using Mem = std::shared_ptr<std::vector<uint8_t>>;
   std::vector<uint8_t> stage_[2];
@@ -131,6 +164,10 @@ struct HostBackend {
   void run_snappy(const DecompJob* jobs, uint32_t n, uint64_t, uint32_t* err) {
     for_threads(n, [&](uint64_t j) { *err |= snappy_stream(jobs[j], order, nullptr); });
   }
+  void run_zstd(ZstdBlock* blocks, const uint32_t* order_idx, uint32_t n_compressed, const ZstdHufDesc* hufs, const ZstdFseDesc* fses, const ZstdStream* streams, uint32_t n_streams,
+                uint64_t, uint64_t, uint32_t* err) {
+    *err |= zstd_run(blocks, order_idx, n_compressed, hufs, fses, streams, n_streams, order);
+  }
   void run_page_prepare(PageDesc* pages, uint32_t n, uint32_t* err) { for_threads(n, [&](uint64_t i) { *err |= page_prepare(pages[i]); }); }
   void run_count_runs(const PageDesc* pages, uint32_t n, bool levels, uint32_t* counts, uint32_t* err) {
     for_threads(2ull * n, [&](uint64_t t) {
@@ -196,7 +233,8 @@ void pqemu_info(void* h, int* dtype, int* logical, int64_t* len, int64_t* null_c
   *dtype = r->col.dtype; *logical = r->col.logical; *len = r->col.len; *null_count = r->col.null_count; *has_validity = r->col.has_validity ? 1 : 0;
   *n_categories = (int64_t)r->categories.size();
   stats6[0] = r->stats.file_bytes; stats6[1] = r->stats.data_pages; stats6[2] = r->stats.dict_pages; stats6[3] = r->stats.snappy_streams;
-  stats6[4] = r->stats.snappy_bytes_out; stats6[5] = r->stats.run_entries; stats6[6] = r->stats.host_inflated_pages; stats6[7] = r->stats.host_inflated_bytes;      // (the caller passes 8 words)
+  stats6[4] = r->stats.snappy_bytes_out; stats6[5] = r->stats.run_entries; stats6[6] = r->stats.host_inflated_pages; stats6[7] = r->stats.host_inflated_bytes;
+  stats6[8] = r->stats.zstd_streams; stats6[9] = r->stats.zstd_blocks;      // (the caller passes 10 words)
 }
 void pqemu_copy(void* h, void* values, size_t values_bytes, void* validity, size_t validity_bytes) {
   EmuResult* r = (EmuResult*)h;
@@ -221,6 +259,33 @@ int pqemu_snappy(const uint8_t* in, uint32_t n_in, uint8_t* out, uint32_t n_out,
   uint32_t err = snappy_stream(job, thread_order, &nr);
   if (rounds) *rounds = nr;
   return (int)err;
+}
+
+// device zstd alone: index pass (host) + entropy / execute bodies over an arbitrary compressed buffer.  Returns 0, PE_ZSTD (the kernels flagged the stream) or -1 (the
+// index pass rejected a header: t_err says why)
+int pqemu_zstd(const uint8_t* in, uint32_t n_in, uint8_t* out, uint32_t n_out, int thread_order, uint32_t* counts) {
+  try {
+    std::vector<uint8_t> src(in, in + n_in);           // exact-size heap blocks: a sanitizer build sees any access past the stream or past the output
+    std::vector<uint8_t> dst((size_t)n_out);
+    ZstdPlan plan;
+    zstd_index_stream(plan, src.data(), n_in, (uint64_t)src.data(), n_out);
+    std::vector<uint8_t> lits(plan.lit_bytes, 0xA5), seqs(plan.n_seq * 16, 0xA5);
+    plan.streams[0].dst = (uint64_t)dst.data();
+    zstd_plan_place(plan, (uint64_t)lits.data(), (uint64_t)seqs.data());
+    if (counts) { counts[0] = (uint32_t)plan.blocks.size(); counts[1] = (uint32_t)plan.n_compressed; counts[2] = (uint32_t)plan.n_seq; counts[3] = (uint32_t)plan.hufs.size(); counts[4] = (uint32_t)plan.fses.size(); }
+    const std::vector<uint32_t> order_idx = zstd_plan_order(plan);
+    const uint32_t err = zstd_run(plan.blocks.data(), order_idx.data(), (uint32_t)order_idx.size(), plan.hufs.data(), plan.fses.data(), plan.streams.data(), 1, thread_order);
+    if (n_out) memcpy(out, dst.data(), n_out);
+    return (int)err;
+  } catch (const std::exception& e) { t_err = e.what(); return -1; }
+}
+// the closed forms of the sequence code tables against the RFC's tables (host_codecs.hpp); returns the number of disagreements
+int pqemu_zstd_code_selfcheck() {
+  using namespace plx::codec::zstd_detail;
+  int bad = 0;
+  for (uint32_t c = 0; c < 36; c++) bad += (z_ll_base(c) != kLLBase[c]) + (z_ll_bits(c) != kLLBits[c]);
+  for (uint32_t c = 0; c < 53; c++) bad += (z_ml_base(c) != kMLBase[c]) + (z_ml_bits(c) != kMLBits[c]);
+  return bad;
 }
 
 // the host decompressors of the product (polars_amd/csrc/host_codecs.hpp): codec 0 = zstd, 1 = lz4 raw block, 2 = lz4 frame, 3 = gzip / zlib / raw deflate

@@ -1,6 +1,7 @@
 // parquet_emu_main.cpp -- stand-alone driver of the CPU harness, built with -fsanitize=address,undefined by the tests: every column
 // of every file given (well-formed and deliberately corrupted ones) goes through the product's reader; *.snappy files hold
-// [u32 uncompressed length][raw Snappy stream] and go through the wavefront rounds.  Any out-of-bounds access aborts the process.
+// [u32 uncompressed length][raw Snappy stream] and go through the wavefront rounds, *.zst files [u32 uncompressed length][zstd frames] and go through
+// the index pass + the entropy / execute bodies.  Any out-of-bounds access aborts the process.
 #include "parquet_emu.cpp"
 
 int main(int argc, char** argv) {
@@ -23,6 +24,24 @@ int main(int argc, char** argv) {
       for (int order = 0; order < 2; order++) {
         uint32_t rounds = 0;
         int e = pqemu_snappy(buf.data() + 4, (uint32_t)buf.size() - 4, out.data(), n_out, order, &rounds);
+        (e ? invalid : ok)++;
+      }
+      continue;
+    }
+    if (path.size() > 4 && path.substr(path.size() - 4) == ".zst") {
+      FILE* f = fopen(path.c_str(), "rb");
+      if (!f) return 2;
+      std::vector<uint8_t> buf;
+      uint8_t tmp[4096];
+      size_t n;
+      while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+      fclose(f);
+      if (buf.size() < 4) return 2;
+      uint32_t n_out;
+      memcpy(&n_out, buf.data(), 4);
+      std::vector<uint8_t> out(n_out);
+      for (int order = 0; order < 2; order++) {
+        int e = pqemu_zstd(buf.data() + 4, (uint32_t)buf.size() - 4, out.data(), n_out, order, nullptr);
         (e ? invalid : ok)++;
       }
       continue;

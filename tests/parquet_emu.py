@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "emu", "parquet_emu.cpp")
 SO = os.path.join(HERE, "emu", "libparquet_emu.so")
 CSRC = os.path.join(os.path.dirname(HERE), "polars_amd", "csrc")
-_DEPS = [SRC] + [os.path.join(CSRC, h) for h in ("parquet_reader.hpp", "parquet_device.hpp", "parquet_snappy.hpp", "parquet_format.hpp", "host_codecs.hpp", "file_io.hpp")]
+_DEPS = [SRC] + [os.path.join(CSRC, h) for h in ("parquet_reader.hpp", "parquet_device.hpp", "parquet_snappy.hpp", "parquet_zstd.hpp", "parquet_zstd_index.hpp", "parquet_format.hpp", "host_codecs.hpp", "file_io.hpp")]
 NP = {0: None, 1: np.int8, 2: np.int16, 3: np.int32, 4: np.int64, 5: np.uint8, 6: np.uint16, 7: np.uint32, 8: np.uint64, 9: np.float32, 10: np.float64}
 
 _lib = None
@@ -43,6 +43,7 @@ def lib():
         l.pqemu_snappy_host.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32]
         l.pqemu_host_codec.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32]
         l.pqemu_snappy_tag_selfcheck.argtypes = [C.c_uint32, C.c_uint64]
+        l.pqemu_zstd.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
         l.pqemu_snappy_tag_selfcheck.restype = C.c_int64
         _lib = l
     return _lib
@@ -64,7 +65,7 @@ def read_column(path, row_groups, column, thread_order=0):
         raise EmuError(rc, l.pqemu_last_error().decode())
     try:
         dt, lg, n, nc, hv, ncat = C.c_int(), C.c_int(), C.c_int64(), C.c_int64(), C.c_int(), C.c_int64()
-        st = (C.c_uint64 * 8)()
+        st = (C.c_uint64 * 10)()
         l.pqemu_info(h, C.byref(dt), C.byref(lg), C.byref(n), C.byref(nc), C.byref(hv), C.byref(ncat), st)
         n = n.value
         nw = (n + 63) // 64
@@ -83,7 +84,7 @@ def read_column(path, row_groups, column, thread_order=0):
             ln = l.pqemu_category(h, i, buf, len(buf))
             cats.append(buf.raw[:ln])
         return {"values": values, "valid": valid, "dtype": dt.value, "logical": lg.value, "null_count": nc.value, "categories": cats,
-                "stats": dict(zip(("file_bytes", "data_pages", "dict_pages", "snappy_streams", "snappy_bytes_out", "run_entries", "host_inflated_pages", "host_inflated_bytes"), [int(x) for x in st])),
+                "stats": dict(zip(("file_bytes", "data_pages", "dict_pages", "snappy_streams", "snappy_bytes_out", "run_entries", "host_inflated_pages", "host_inflated_bytes", "zstd_streams", "zstd_blocks"), [int(x) for x in st])),
                 "raw_validity_words": vraw if hv.value else None, "raw_value_words": raw if dt.value == 0 else None}
     finally:
         l.pqemu_free(h)
@@ -107,3 +108,12 @@ def host_codec(codec: str, data: bytes, n_out: int):
     out = np.zeros(max(n_out, 1), np.uint8)
     rc = lib().pqemu_host_codec({"zstd": 0, "lz4_raw": 1, "lz4_frame": 2, "gzip": 3}[codec], data, len(data), out.ctypes.data_as(C.c_void_p), n_out)
     return rc, out[:n_out].tobytes(), lib().pqemu_last_error().decode() if rc else ""
+
+
+def zstd_device(data: bytes, n_out: int, thread_order=0):
+    """The device zstd decoder's bodies (parquet_zstd.hpp) behind the host index pass -> (rc, bytes, counts, error text); rc 0 = ok, 64 = the
+    kernels flagged the stream, -1 = the index pass rejected a header.  counts = blocks, compressed blocks, sequences, Huffman tables, FSE tables."""
+    out = np.zeros(max(n_out, 1), np.uint8)
+    counts = (C.c_uint32 * 8)()
+    rc = lib().pqemu_zstd(data, len(data), out.ctypes.data_as(C.c_void_p), n_out, thread_order, counts)
+    return rc, out[:n_out].tobytes(), list(counts)[:5], lib().pqemu_last_error().decode() if rc < 0 else ""

@@ -410,7 +410,7 @@ def test_snappy_corrupt_streams_fail_cleanly():
 
 def test_reader_under_address_sanitizer(tmp_path):
     """The same reader, built with -fsanitize=address,undefined as a stand-alone program (tests/emu/parquet_emu_main.cpp), over
-    well-formed files, ~150 bit-flipped / truncated copies and corrupt Snappy streams: error codes, never an out-of-bounds access."""
+    well-formed files, ~150 bit-flipped / truncated copies and corrupt Snappy / zstd streams: error codes, never an out-of-bounds access."""
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
     exe = str(tmp_path / "pq_asan")
@@ -443,6 +443,19 @@ def test_reader_under_address_sanitizer(tmp_path):
         q = str(tmp_path / f"s{k}.snappy")
         open(q, "wb").write(struct.pack("<I", len(payload)) + bytes(b))
         files.append(q)
+    zpayload = payload * 3 + np.sort(RNG.integers(0, 1 << 40, 30_000)).astype(np.int64).tobytes()
+    for lvl in (1, 9):
+        zgood = pa.Codec("zstd", compression_level=lvl).compress(zpayload, asbytes=True)
+        for k in range(100):
+            b = bytearray(zgood)
+            if k:
+                for _ in range(1 + k % 3):
+                    b[int(RNG.integers(0, len(b)))] ^= 1 << int(RNG.integers(0, 8))
+            if k % 7 == 3:
+                b = b[:int(RNG.integers(1, len(b)))]
+            q = str(tmp_path / f"z{lvl}_{k}.zst")
+            open(q, "wb").write(struct.pack("<I", len(zpayload)) + bytes(b))
+            files.append(q)
     for seed in range(6):
         data, n = random_stream(np.random.default_rng(100 + seed), 20_000)
         q = str(tmp_path / f"r{seed}.snappy")
@@ -706,3 +719,88 @@ def test_long_snappy_dictionary_pages_are_inflated_by_host_threads(tmp_path, mon
     monkeypatch.setenv("PLX_PARQUET_HOST_DICT_BYTES", "0")
     r0 = check_column(path, t, "big")
     assert r0["stats"]["host_inflated_pages"] == 0 and r0["stats"]["snappy_streams"] == r["stats"]["snappy_streams"] + 2
+
+
+# ---- zstd on the device: the bodies of pq_zstd_entropy / pq_zstd_execute behind the host index pass (parquet_zstd.hpp, parquet_zstd_index.hpp) -------------------
+
+
+ZPAYLOADS = dict(PAYLOADS)
+ZPAYLOADS.update({
+    "sorted keys": np.sort(np.random.default_rng(11).integers(0, 1 << 40, 150_000)).astype(np.int64).tobytes(),          # a match per value that reads what the previous match wrote
+    "zeros": bytes(300_000),                                                                                             # RLE blocks, a 128 KB match at offset 1
+    "random": np.random.default_rng(12).integers(0, 256, 300_000, dtype=np.uint8).tobytes(),                             # raw blocks
+    "far matches": (np.random.default_rng(13).integers(0, 256, 70_000, dtype=np.uint8).tobytes()) * 5,                   # matches 70 KB back: beyond the LDS ring, across blocks
+    "prices": np.round(np.random.default_rng(14).uniform(900, 105_000, 120_000), 2).tobytes(),                           # Huffman literals in four streams, few matches
+    "codes": np.random.default_rng(15).integers(0, 7, 400_000, dtype=np.uint8).tobytes(),                                # short codes: a small Huffman table
+    "one byte": b"x",
+})
+
+
+def test_zstd_sequence_code_tables():
+    assert E.lib().pqemu_zstd_code_selfcheck() == 0
+
+
+@pytest.mark.parametrize("name", sorted(ZPAYLOADS))
+def test_zstd_device_bodies_against_the_real_codec(name):
+    """Streams of the real library, levels 1..19 (raw / RLE / Huffman literals in one and four streams, predefined / RLE / FSE / repeat sequence tables, treeless literals,
+    repeat offsets across blocks, multi-block frames, matches beyond the LDS ring), lanes in ascending and descending order."""
+    p = ZPAYLOADS[name]
+    for lvl in (1, 3, 7, 12, 19):
+        c = pa.Codec("zstd", compression_level=lvl).compress(p, asbytes=True)
+        for order in (0, 1):
+            rc, out, counts, err = E.zstd_device(c, len(p), order)
+            assert rc == 0 and out == p, (lvl, order, rc, err, counts)
+    if p:
+        # two frames back to back decode as their concatenation (repeat offsets and the window start over); a skippable frame in between is skipped
+        z = pa.Codec("zstd").compress(p, asbytes=True)
+        skip = struct.pack("<II", 0x184D2A53, 5) + b"hello"
+        rc, out, counts, err = E.zstd_device(z + skip + z, 2 * len(p))
+        assert rc == 0 and out == p + p, (rc, err)
+
+
+def test_zstd_device_agrees_with_the_host_decoder_on_corrupt_streams():
+    """Bit flips and truncations: whatever the host decoder (host_codecs.hpp) makes of a stream, the device bodies make the same -- the same bytes or an error --
+    and the page header's size stays the authority."""
+    rng = np.random.default_rng(78)
+    p = ZPAYLOADS["mixed"] + ZPAYLOADS["sorted keys"][:200_000]
+    outcomes = set()
+    for lvl in (1, 9):
+        good = pa.Codec("zstd", compression_level=lvl).compress(p, asbytes=True)
+        for trial in range(150):
+            b = bytearray(good)
+            for _ in range(1 + trial % 3):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            if trial % 10 == 0:
+                b = b[:int(rng.integers(1, len(b)))]
+            rc_h, out_h, _ = E.host_codec("zstd", bytes(b), len(p))
+            rc_d, out_d, _, err = E.zstd_device(bytes(b), len(p))
+            assert (rc_h == 0) == (rc_d == 0), (lvl, trial, rc_h, rc_d, err)
+            if rc_h == 0:
+                assert out_h == out_d
+            outcomes.add("error" if rc_d else "ok")
+        rc, _, _, _ = E.zstd_device(good, len(p) + 1)
+        assert rc != 0
+        rc, _, _, _ = E.zstd_device(good, len(p) - 1)
+        assert rc != 0
+    assert "error" in outcomes
+
+
+@pytest.mark.parametrize("version,dictionary", [("1.0", True), ("2.0", True), ("2.0", False)])
+def test_zstd_pages_take_the_device_passes(tmp_path, monkeypatch, version, dictionary):
+    """zstd pages are streams for the device passes (every page a stream, its blocks counted); PLX_PARQUET_ZSTD=host sends them through the host threads instead: same
+    results."""
+    n = 9000
+    t = mixed_table(n)
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression="zstd", data_page_version=version, use_dictionary=dictionary, row_group_size=2500, data_page_size=2000)
+    seen = 0
+    for name in t.column_names:
+        r = check_column(path, t, name)
+        assert r["stats"]["host_inflated_pages"] == 0, name
+        seen += r["stats"]["zstd_streams"]
+        assert r["stats"]["zstd_blocks"] >= r["stats"]["zstd_streams"]
+    assert seen > 0
+    monkeypatch.setenv("PLX_PARQUET_ZSTD", "host")
+    for name in t.column_names:
+        r = check_column(path, t, name)
+        assert r["stats"]["zstd_streams"] == 0, name
