@@ -254,6 +254,22 @@ struct ZstdDevWave {
   template <class F> __device__ __forceinline__ void lanes(F&& f) { f((uint32_t)threadIdx.x); }
   __device__ __forceinline__ void sync() { __syncthreads(); }
   __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_wave_barrier(); }     // orders the wavefront's LDS accesses for the compiler; the hardware runs them in order
+  // a[lane] -> the sum of a[0 .. lane) (callers put barriers around it)
+  __device__ __forceinline__ void exclusive_scan(uint32_t* a) {
+    const uint32_t lane = threadIdx.x, v = a[lane];
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d, 64);
+      if ((int)lane >= d) x += y;
+    }
+    a[lane] = x - v;
+  }
+  // index of the first nonzero flag[lane]; 64 if there is none
+  __device__ __forceinline__ uint32_t first_flag(const uint32_t* flag) {
+    const unsigned long long m = __ballot(flag[threadIdx.x] != 0);
+    return m ? (uint32_t)__ffsll((long long)m) - 1 : 64u;
+  }
 };
 // one wavefront per compressed block (index list: longest blocks first)
 __global__ __launch_bounds__(kZLanes) void pq_zstd_entropy_kernel(ZstdBlock* __restrict__ blocks, const uint32_t* __restrict__ order, uint32_t n, const ZstdHufDesc* __restrict__ hufs,

@@ -38,6 +38,18 @@ constexpr uint32_t kZLitLane = 64;               // literal bytes a lane places 
 constexpr uint32_t kZOfMask = (1u << 30) - 1;    // sequence offsets: bits 31:30 = 0 -> the offset itself; j + 1 -> (incoming rep[j]) - low bits
 constexpr uint64_t kZRepBase = (uint64_t)1 << 40;   // symbolic repeat offsets while a block is decoded: incoming rep[j] = (j + 1) * kZRepBase
 constexpr uint32_t kZBlockMax = 128 * 1024;
+constexpr uint32_t kZStageWords = 256;           // 8-byte words of a sequence bit stream staged in LDS at a time (+ 2 below them)
+
+// a per-lane variable that lives across phases: a register on the device, one slot per lane on the CPU harness
+template <class T> struct ZLaneVar {
+#if defined(__HIP_DEVICE_COMPILE__)
+  T x;
+  PLX_HD T& operator[](uint32_t) { return x; }
+#else
+  T x[kZLanes];
+  PLX_HD T& operator[](uint32_t lane) { return x[lane]; }
+#endif
+};
 
 enum ZstdBlockType : uint8_t { ZB_RAW = 0, ZB_RLE = 1, ZB_COMPRESSED = 2 };
 enum ZstdLitType : uint8_t { ZL_RAW = 0, ZL_RLE = 1, ZL_HUFFMAN = 2 };
@@ -115,6 +127,9 @@ struct ZstdEntropyShared {
   ZstdSeqEntry ll[512], of[256], ml[512];
   uint8_t sym[3][512];             // FSE build: symbol of a state
   uint16_t cnt[3][64];             // FSE build: occurrences of a symbol so far
+  uint64_t stage[kZStageWords + 2];   // sequence bit stream: words stage_base .. of the stream (words below the stream's start are zero)
+  int32_t stage_base, stage_top;   // word index of stage[0]; word that holds the next bit to read
+  uint32_t seq_more;
   uint32_t bad;
 };
 
@@ -165,19 +180,27 @@ PLX_HD bool zstd_huf_stream(const uint16_t* tbl, uint32_t mb, const uint8_t* p, 
   if (off < 0) return false;
   uint32_t o = 0;
   const uint32_t top = 64 - mb;
-  // a 64-bit container (the next bits of the stream at its top, first-read bit most significant) gives five symbols: 5 x 11 <= 56
-  while (off >= 64 && o + 5 <= out_len) {
-    const int64_t lo = off - 56, byte = lo >> 3;
-    uint64_t b = load_u64(p + byte) << (64 - (off - byte * 8));
-    uint32_t used = 0;
-    for (int k = 0; k < 5; k++) {
-      const uint32_t e = tbl[b >> top];
-      out[o + k] = (uint8_t)e;
-      b <<= e >> 8;
-      used += e >> 8;
+  // Five symbols (<= 55 bits) per round from a 64-bit container whose top bit is the next bit of the stream.  The sixteen bytes the NEXT round's container will be cut
+  // from are loaded a round ahead -- wherever this round ends (5 .. 55 bits further down), its 64 bits lie inside [off - 119, off - 5) -- so the load's latency hides behind
+  // the five dependent table reads.
+  if (off >= 128 && o + 5 <= out_len) {
+    int64_t a = (off - 64) >> 3;
+    uint64_t lo = z_ld64(p, n, a), hi = z_ld64(p, n, a + 8);
+    while (off >= 128 && o + 5 <= out_len) {
+      const uint32_t s = (uint32_t)(off - 8 * a - 64) & 63;       // 0 .. 57
+      uint64_t b = s ? (lo >> s) | (hi << (64 - s)) : lo;
+      a = (off - 119) >> 3;
+      lo = load_u64(p + a); hi = z_ld64(p, n, a + 8);
+      uint32_t used = 0;
+      for (int k = 0; k < 5; k++) {
+        const uint32_t e = tbl[b >> top];
+        out[o + k] = (uint8_t)e;
+        b <<= e >> 8;
+        used += e >> 8;
+      }
+      o += 5;
+      off -= used;
     }
-    o += 5;
-    off -= used;
   }
   while (off > 0) {
     if (o >= out_len) return false;
@@ -273,41 +296,67 @@ PLX_HD uint32_t zstd_resolve_offset(uint32_t enc, const uint32_t* rep) {
   return r > v ? r - v : 0;          // 0 = invalid (caught by the execute pass)
 }
 
-// lane 0: the block's sequences -> records; literal / match totals; the repeat offsets behind the block (3.1.1.3.2, 3.1.1.5)
-PLX_HD void zstd_seq_decode(ZstdEntropyShared& sh, ZstdBlock& blk, const ZstdFseDesc* fd) {
-  const uint8_t* p = PQ_GPTR(const uint8_t, blk.src) + blk.bits_off;
-  const uint32_t n = blk.bits_len;
+// lane 0's state between two stagings of the sequence bit stream
+struct ZstdSeqState {
+  int64_t off;                 // next bit to read (the bits are [0, off))
+  uint32_t sl, so, sm, i, started, bad;
+  uint64_t rep0, rep1, rep2, lit_sum, match_sum;
+};
+// the 128 bits below bit `off` (off >= 1) from the staged words: *hi = bits [off - 64, off), *lo = the 64 below
+PLX_HD void zstd_staged_window(const ZstdEntropyShared& sh, int64_t off, uint64_t* hi, uint64_t* lo) {
+  const int32_t wi = (int32_t)((off - 1) >> 6) - sh.stage_base;     // slot of the word that holds bit off - 1 (>= 2 by the caller's loop condition)
+  const uint32_t r = (uint32_t)(off - (((off - 1) >> 6) << 6));      // valid bits in that word: 1 .. 64
+  const uint64_t w2 = sh.stage[wi], w1 = sh.stage[wi - 1], w0 = sh.stage[wi - 2];
+  if (r == 64) { *hi = w2; *lo = w1; }
+  else { *hi = (w2 << (64 - r)) | (w1 >> r); *lo = (w1 << (64 - r)) | (w0 >> r); }
+}
+// the top nb (0 .. 63) bits of x
+PLX_HD uint64_t z_top(uint64_t x, uint32_t nb) { return (x >> 1) >> (63 - nb); }
+
+// lane 0: sequences -> records while their bits are staged (3.1.1.3.2, 3.1.1.5); sets seq_more / stage_top for the next staging
+PLX_HD void zstd_seq_run(ZstdEntropyShared& sh, ZstdBlock& blk, const ZstdFseDesc* fd, ZstdSeqState& st) {
   uint32_t* rec = PQ_GPTR(uint32_t, blk.seq);
-  int64_t off = z_back_start(p, n);
-  if (off < 0) { sh.bad = 1; return; }
-  const uint32_t log_ll = fd[0].rle ? 0 : fd[0].log, log_of = fd[1].rle ? 0 : fd[1].log, log_ml = fd[2].rle ? 0 : fd[2].log;
-  uint64_t w = z_window(p, n, off);
-  uint32_t sl = z_field(w, 0, log_ll), so = z_field(w, log_ll, log_of), sm = z_field(w, log_ll + log_of, log_ml);
-  off -= log_ll + log_of + log_ml;
-  uint64_t rep0 = kZRepBase, rep1 = 2 * kZRepBase, rep2 = 3 * kZRepBase;
-  uint64_t lit_sum = 0, match_sum = 0;
-  bool bad = off < 0;
-  for (uint32_t i = 0; i < blk.nseq && !bad; i++) {
+  const int32_t base = sh.stage_base;
+  const bool last_stage = base < 0;            // the words down to the stream's start (and the zero words below it) are staged
+  int64_t off = st.off;
+  uint32_t sl = st.sl, so = st.so, sm = st.sm, i = st.i;
+  uint64_t rep0 = st.rep0, rep1 = st.rep1, rep2 = st.rep2, lit_sum = st.lit_sum, match_sum = st.match_sum;
+  bool bad = st.bad != 0;
+  auto staged = [&](int64_t o) { return o >= 1 && (last_stage || (int32_t)((o - 1) >> 6) - 2 >= base); };
+  if (!st.started && !bad && (staged(off) || off == 0)) {
+    const uint32_t log_ll = fd[0].rle ? 0 : fd[0].log, log_of = fd[1].rle ? 0 : fd[1].log, log_ml = fd[2].rle ? 0 : fd[2].log;
+    uint64_t hi = 0, lo = 0;
+    if (off >= 1) zstd_staged_window(sh, off, &hi, &lo);
+    sl = (uint32_t)z_top(hi, log_ll); so = (uint32_t)z_top(hi << log_ll, log_of); sm = (uint32_t)z_top(hi << (log_ll + log_of), log_ml);
+    off -= log_ll + log_of + log_ml;
+    st.started = 1;
+    if (off < 0) bad = true;
+  }
+  const uint32_t nseq = blk.nseq;
+  while (st.started && !bad && i < nseq && (staged(off) || off == 0)) {
     const ZstdSeqEntry el = sh.ll[sl & 511], eo = sh.of[so & 255], em = sh.ml[sm & 511];
-    const uint64_t w1 = z_window(p, n, off);                // offset extra bits (<= 31) + match length extra bits (<= 16)
-    const uint64_t ov = (uint64_t)eo.base_value + z_field(w1, 0, eo.extra_bits);
-    const uint32_t ml = em.base_value + z_field(w1, eo.extra_bits, em.extra_bits);
-    off -= eo.extra_bits + em.extra_bits;
-    const uint64_t w2 = z_window(p, n, off);                // literal length extra bits (<= 16) + the three state updates (<= 9 + 9 + 8)
-    const uint32_t ll = el.base_value + z_field(w2, 0, el.extra_bits);
-    off -= el.extra_bits;
-    if (i + 1 < blk.nseq) {
-      uint32_t used = el.extra_bits;
-      sl = el.next_base + z_field(w2, used, el.nbits); used += el.nbits;
-      sm = em.next_base + z_field(w2, used, em.nbits); used += em.nbits;
-      so = eo.next_base + z_field(w2, used, eo.nbits);
-      off -= el.nbits + em.nbits + eo.nbits;
+    uint64_t hi = 0, lo = 0;
+    if (off >= 1) zstd_staged_window(sh, off, &hi, &lo);
+    // offset extra bits (<= 31), match length extra bits (<= 16), literal length extra bits (<= 16): all inside the top 63
+    const uint64_t ov = (uint64_t)eo.base_value + z_top(hi, eo.extra_bits);
+    const uint32_t ml = em.base_value + (uint32_t)z_top(hi << eo.extra_bits, em.extra_bits);
+    const uint32_t u1 = eo.extra_bits + em.extra_bits;
+    const uint32_t ll = el.base_value + (uint32_t)z_top(hi << u1, el.extra_bits);
+    uint32_t used = u1 + el.extra_bits;                            // <= 63
+    if (i + 1 < nseq) {
+      const uint64_t y = used ? (hi << used) | ((lo >> 1) >> (63 - used)) : hi;      // the state updates: <= 9 + 9 + 8 bits
+      const uint32_t y32 = (uint32_t)(y >> 32);
+      sl = el.next_base + (uint32_t)(((uint64_t)y32 << el.nbits) >> 32);
+      sm = em.next_base + (uint32_t)(((uint64_t)(y32 << el.nbits) << em.nbits) >> 32);
+      so = eo.next_base + (uint32_t)(((uint64_t)(y32 << (el.nbits + em.nbits)) << eo.nbits) >> 32);
+      used += el.nbits + em.nbits + eo.nbits;
     }
+    off -= used;
     if (off < 0) { bad = true; break; }
     uint64_t offset;
     if (ov > 3) { offset = ov - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
     else {
-      uint32_t idx = (uint32_t)ov - 1 + (ll == 0 ? 1 : 0);
+      const uint32_t idx = (uint32_t)ov - 1 + (ll == 0 ? 1 : 0);
       if (idx == 0) offset = rep0;
       else {
         offset = idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
@@ -317,16 +366,32 @@ PLX_HD void zstd_seq_decode(ZstdEntropyShared& sh, ZstdBlock& blk, const ZstdFse
     }
     uint32_t enc;
     if (!zstd_encode_offset(offset, &enc)) { bad = true; break; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    v4 r4 = {ll, ml, enc, 0u};
+    *(v4*)(rec + 4 * (size_t)i) = r4;
+#else
     rec[4 * (size_t)i + 0] = ll; rec[4 * (size_t)i + 1] = ml; rec[4 * (size_t)i + 2] = enc; rec[4 * (size_t)i + 3] = 0;
+#endif
     lit_sum += ll; match_sum += ml;
+    i++;
   }
-  if (off != 0 || lit_sum > blk.regen || match_sum > ((uint64_t)1 << 31)) bad = true;
-  uint32_t r0 = 0, r1 = 0, r2 = 0;
-  if (!zstd_encode_offset(rep0, &r0) || !zstd_encode_offset(rep1, &r1) || !zstd_encode_offset(rep2, &r2)) bad = true;
-  blk.rep_out[0] = r0; blk.rep_out[1] = r1; blk.rep_out[2] = r2;
-  blk.lit_used = (uint32_t)lit_sum;
-  blk.out_len = bad ? 0 : (uint32_t)(blk.regen + match_sum);
-  if (bad) sh.bad = 1;
+  st.off = off; st.sl = sl; st.so = so; st.sm = sm; st.i = i;
+  st.rep0 = rep0; st.rep1 = rep1; st.rep2 = rep2; st.lit_sum = lit_sum; st.match_sum = match_sum; st.bad = bad ? 1 : 0;
+  if (bad || i >= nseq || last_stage || off < 1) {
+    // finished (or stuck: a stream that ends early)
+    if (i < nseq || off != 0 || lit_sum > blk.regen || match_sum > ((uint64_t)1 << 31)) bad = true;
+    uint32_t r0 = 0, r1 = 0, r2 = 0;
+    if (!zstd_encode_offset(rep0, &r0) || !zstd_encode_offset(rep1, &r1) || !zstd_encode_offset(rep2, &r2)) bad = true;
+    blk.rep_out[0] = r0; blk.rep_out[1] = r1; blk.rep_out[2] = r2;
+    blk.lit_used = (uint32_t)lit_sum;
+    blk.out_len = bad ? 0 : (uint32_t)(blk.regen + match_sum);
+    if (bad) sh.bad = 1;
+    sh.seq_more = 0;
+  } else {
+    sh.seq_more = 1;
+    sh.stage_top = (int32_t)((off - 1) >> 6);
+  }
 }
 
 // one compressed block, one wavefront
@@ -343,14 +408,41 @@ template <class W> PLX_HD void zstd_entropy_block(W& w, ZstdEntropyShared& sh, Z
     w.lanes([&](uint32_t lane) { zstd_huf_decode(sh, blk, hd, lane); });
   }
   if (blk.nseq) {
-    w.lanes([&](uint32_t lane) { if (lane < 3) zstd_fse_build(sh, fses[blk.tab[lane]], lane); });
-    w.sync();
+    const uint8_t* bits = PQ_GPTR(const uint8_t, blk.src) + blk.bits_off;
+    const uint32_t bits_len = blk.bits_len;
+    ZLaneVar<ZstdSeqState> st;
     w.lanes([&](uint32_t lane) {
+      if (lane < 3) zstd_fse_build(sh, fses[blk.tab[lane]], lane);
       if (lane == 0) {
-        const ZstdFseDesc fd[3] = {fses[blk.tab[0]], fses[blk.tab[1]], fses[blk.tab[2]]};
-        zstd_seq_decode(sh, blk, fd);
+        ZstdSeqState& s0 = st[0];
+        s0.off = z_back_start(bits, bits_len);
+        s0.sl = s0.so = s0.sm = 0; s0.i = 0; s0.started = 0; s0.bad = s0.off < 0 ? 1 : 0;
+        s0.rep0 = kZRepBase; s0.rep1 = 2 * kZRepBase; s0.rep2 = 3 * kZRepBase; s0.lit_sum = 0; s0.match_sum = 0;
+        sh.seq_more = 1;
+        sh.stage_top = s0.off >= 1 ? (int32_t)((s0.off - 1) >> 6) : 0;
       }
     });
+    for (;;) {
+      w.sync();
+      if (!sh.seq_more) break;
+      // the next kZStageWords words of the bit stream (downwards from the word of the next bit), two more below them; words below the stream's start are zero
+      const int32_t top = sh.stage_top, lo_word = top >= (int32_t)kZStageWords ? top - (int32_t)kZStageWords + 1 : 0, base = lo_word - 2;
+      w.sync();
+      w.lanes([&](uint32_t lane) {
+        for (uint32_t k = lane; k < kZStageWords + 2; k += kZLanes) {
+          const int64_t word = (int64_t)base + k;
+          if (word <= top) sh.stage[k] = z_ld64(bits, bits_len, word * 8);
+        }
+        if (lane == 0) sh.stage_base = base;
+      });
+      w.sync();
+      w.lanes([&](uint32_t lane) {
+        if (lane == 0) {
+          const ZstdFseDesc fd[3] = {fses[blk.tab[0]], fses[blk.tab[1]], fses[blk.tab[2]]};
+          zstd_seq_run(sh, blk, fd, st[0]);
+        }
+      });
+    }
   } else {
     w.lanes([&](uint32_t lane) {
       if (lane == 0) { blk.rep_out[0] = 1u << 30; blk.rep_out[1] = 2u << 30; blk.rep_out[2] = 3u << 30; blk.lit_used = 0; blk.out_len = blk.regen; }
@@ -363,9 +455,11 @@ template <class W> PLX_HD void zstd_entropy_block(W& w, ZstdEntropyShared& sh, Z
 // ---- execute pass --------------------------------------------------------------------------------------------------------------------------
 struct ZstdExecShared {
   alignas(16) uint8_t ring[kZRing];
+  alignas(16) uint32_t b_m[kZLanes][4];                      // per sequence of the batch: {match start relative to the batch, offset, match length, -}
   uint32_t b_ll[kZLanes], b_ml[kZLanes], b_of[kZLanes];      // the batch's records (offsets resolved)
   uint32_t b_lit[kZLanes], b_out[kZLanes];                   // exclusive prefixes: literal bytes / output bytes before the sequence
-  uint32_t cnt, span, lit_span, bad;
+  uint32_t b_flag[kZLanes];                                  // the sequence does not fit the fast path (or the batch)
+  uint32_t bad;
 };
 
 // the state of a page's wavefront (uniform: every lane holds the same values)
@@ -443,19 +537,6 @@ template <class W> PLX_HD bool zstd_emit_match(W& w, ZstdExecShared& sh, ZstdExe
   return true;
 }
 
-// lane 0: how many sequences of the batch run in the fast path, and where their bytes go
-PLX_HD void zstd_plan_batch(ZstdExecShared& sh, uint32_t n_in, uint32_t lit_left, uint32_t room_left) {
-  uint32_t lit = 0, out = 0, k = 0;
-  for (; k < n_in; k++) {
-    const uint32_t ll = sh.b_ll[k], ml = sh.b_ml[k];
-    if (ll > kZLitLane || ml > kZPiece || out + ll + ml > kZBatchSpan) break;
-    if (ll > lit_left - lit || ll + ml > room_left - out) { sh.bad = 1; break; }
-    sh.b_lit[k] = lit; sh.b_out[k] = out;
-    lit += ll; out += ll + ml;
-  }
-  sh.cnt = k; sh.span = out; sh.lit_span = lit;
-}
-
 // one compressed block
 template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExecState& st, const ZstdBlock& blk) {
   const bool lit_rle = blk.lit_type == ZL_RLE;
@@ -465,24 +546,47 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
   if (blk.bad || blk.lit_used > blk.regen) return false;
   uint32_t lp = 0;
   const uint32_t rep_in[3] = {st.rep[0], st.rep[1], st.rep[2]};
-  for (uint32_t base = 0; base < blk.nseq;) {
-    const uint32_t n_in = blk.nseq - base < kZLanes ? blk.nseq - base : kZLanes;
+  const uint32_t nseq = blk.nseq;
+  struct Rec { uint32_t ll, ml, of; };
+  ZLaneVar<Rec> nxt;             // the next batch's records: loaded while the current batch's matches run
+  auto fetch = [&](uint32_t first, uint32_t lane) {
+    Rec r = {0, 0, 0};
+    if (first + lane < nseq) {
+      const uint32_t* q = rec + 4 * (size_t)(first + lane);
+#if defined(__HIP_DEVICE_COMPILE__)
+      typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+      const v4 v = *(const v4*)q;
+      r.ll = v.x; r.ml = v.y; r.of = v.z;
+#else
+      r.ll = q[0]; r.ml = q[1]; r.of = q[2];
+#endif
+    }
+    return r;
+  };
+  w.lanes([&](uint32_t lane) { nxt[lane] = fetch(0, lane); if (lane == 0) sh.bad = 0; });
+  for (uint32_t base = 0; base < nseq;) {
+    const uint32_t n_in = nseq - base < kZLanes ? nseq - base : kZLanes;
     w.lanes([&](uint32_t lane) {
-      if (lane < n_in) {
-        const uint32_t* r = rec + 4 * (size_t)(base + lane);
-        sh.b_ll[lane] = r[0]; sh.b_ml[lane] = r[1]; sh.b_of[lane] = zstd_resolve_offset(r[2], rep_in);
-      }
-      if (lane == 0) sh.bad = 0;
+      const Rec r = nxt[lane];
+      sh.b_ll[lane] = r.ll; sh.b_ml[lane] = r.ml; sh.b_of[lane] = zstd_resolve_offset(r.of, rep_in);
+      sh.b_lit[lane] = lane < n_in ? r.ll : 0; sh.b_out[lane] = lane < n_in ? r.ll + r.ml : 0;
     });
     w.sync();
-    w.lanes([&](uint32_t lane) { if (lane == 0) zstd_plan_batch(sh, n_in, blk.regen - lp, st.cap - st.cur); });
+    w.exclusive_scan(sh.b_lit); w.exclusive_scan(sh.b_out);
     w.sync();
-    if (sh.bad) return false;
-    const uint32_t cnt = sh.cnt, span = sh.span, lit_span = sh.lit_span;
+    // the batch ends in front of the first sequence that does not fit: a long literal run / match (cooperative copies below), the batch's span, the literal buffer, the page
+    const uint32_t lit_left = blk.regen - lp, room_left = st.cap - st.cur;
+    w.lanes([&](uint32_t lane) {
+      const uint32_t ll = sh.b_ll[lane], ml = sh.b_ml[lane], le = sh.b_lit[lane], oe = sh.b_out[lane];
+      sh.b_flag[lane] = lane >= n_in || ll > kZLitLane || ml > kZPiece || oe + ll + ml > kZBatchSpan || le + ll > lit_left || oe + ll + ml > room_left;
+    });
+    w.sync();
+    const uint32_t cnt = w.first_flag(sh.b_flag);
     if (cnt == 0) {
       // a sequence with a long literal run or a long match: cooperative copies, one piece at a time
       const uint32_t ll = sh.b_ll[0], ml = sh.b_ml[0], off = sh.b_of[0];
       w.sync();
+      w.lanes([&](uint32_t lane) { nxt[lane] = fetch(base + 1, lane); });
       if (ll > blk.regen - lp) return false;
       if (!zstd_emit_literals(w, sh, st, lit_rle ? nullptr : lits + lp, ll, lit_rle, fill)) return false;
       lp += ll;
@@ -490,23 +594,31 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
       base += 1;
       continue;
     }
+    const uint32_t span = sh.b_out[cnt - 1] + sh.b_ll[cnt - 1] + sh.b_ml[cnt - 1], lit_span = sh.b_lit[cnt - 1] + sh.b_ll[cnt - 1];
     zstd_room(w, sh, st, span);
     const uint32_t cur = st.cur, frame_start = st.frame_start, floor = cur + span > kZRing ? cur + span - kZRing : 0;
-    // every lane: its sequence's literals at their final place; its match must stay inside the frame
+    // every lane: the next batch's records on their way; its sequence's literals at their final place; its match must stay inside the frame
     w.lanes([&](uint32_t lane) {
+      nxt[lane] = fetch(base + cnt, lane);
       if (lane < cnt) {
-        const uint32_t ll = sh.b_ll[lane], pos = cur + sh.b_out[lane];
-        const uint8_t* s = lit_rle ? nullptr : lits + lp + sh.b_lit[lane];
-        for (uint32_t t = 0; t < ll; t++) sh.ring[(pos + t) & kZRingMask] = lit_rle ? fill : s[t];
+        const uint32_t ll = sh.b_ll[lane], rel = sh.b_out[lane], pos = cur + rel, lo = lp + sh.b_lit[lane];
+        if (lit_rle) { for (uint32_t t = 0; t < ll; t++) sh.ring[(pos + t) & kZRingMask] = fill; }
+        else if (ll && ll <= 8 && blk.regen - lo >= 8) {
+          uint64_t v = load_u64(lits + lo);                    // one load for the common short run
+          for (uint32_t t = 0; t < ll; t++) { sh.ring[(pos + t) & kZRingMask] = (uint8_t)v; v >>= 8; }
+        } else { for (uint32_t t = 0; t < ll; t++) sh.ring[(pos + t) & kZRingMask] = lits[lo + t]; }
         const uint32_t off = sh.b_of[lane];
         if (off == 0 || off > pos + ll - frame_start) sh.bad = 1;
+        sh.b_m[lane][0] = rel + ll; sh.b_m[lane][1] = off; sh.b_m[lane][2] = sh.b_ml[lane]; sh.b_m[lane][3] = 0;
       }
     });
     w.sync();
     if (sh.bad) return false;
     const uint8_t* dst = st.dst;
+    uint32_t m0 = sh.b_m[0][0], m1 = sh.b_m[0][1], m2 = sh.b_m[0][2];
     for (uint32_t k = 0; k < cnt; k++) {
-      const uint32_t d = cur + sh.b_out[k] + sh.b_ll[k], off = sh.b_of[k], n = sh.b_ml[k];
+      const uint32_t d = cur + m0, off = m1, n = m2;
+      if (k + 1 < cnt) { m0 = sh.b_m[k + 1][0]; m1 = sh.b_m[k + 1][1]; m2 = sh.b_m[k + 1][2]; }      // the next match's parameters before this match's bytes
       w.lanes([&](uint32_t lane) { zstd_copy_match(sh, dst, d, off, n, floor, lane); });
       w.wave_fence();
     }

@@ -73,6 +73,8 @@ struct EmuWave {
   }
   void sync() {}
   void wave_fence() {}
+  void exclusive_scan(uint32_t* a) { uint32_t run = 0; for (uint32_t l = 0; l < kZLanes; l++) { const uint32_t v = a[l]; a[l] = run; run += v; } }
+  uint32_t first_flag(const uint32_t* flag) { for (uint32_t l = 0; l < kZLanes; l++) if (flag[l]) return l; return kZLanes; }
 };
 // pq_zstd_entropy + pq_zstd_execute (kernels_parquet.hip) as loops: one wavefront per compressed block, then one per page; returns PE_ZSTD or 0
 uint32_t zstd_run(ZstdBlock* blocks, const uint32_t* order_idx, uint32_t n_compressed, const ZstdHufDesc* hufs, const ZstdFseDesc* fses, const ZstdStream* streams, uint32_t n_streams,

@@ -49,8 +49,10 @@ def main():
     F = pl._ffi
     import bench
     d = tempfile.mkdtemp()
-    for codec in ("none", "snappy", "snappy@kernel2", "snappy@host", "zstd", "lz4", "gzip"):          # zstd / lz4 (raw) / gzip: pages inflated by host threads, then the uncompressed device path
+    codecs = tuple(os.environ.get("PLX_PQBENCH_CODECS", "none,snappy,snappy@kernel2,snappy@host,zstd,zstd@host,lz4,gzip").split(","))
+    for codec in codecs:          # lz4 (raw) / gzip: pages inflated by host threads, then the uncompressed device path; zstd: device passes (round 6), zstd@host: the host threads
         os.environ.pop("PLX_PARQUET_SNAPPY", None)
+        os.environ.pop("PLX_PARQUET_ZSTD", None)
         if codec == "snappy@kernel2":        # the same file through pq_snappy_kernel_v2 (batched LDS loads); needs its own process: the switch is read once
             import subprocess
             r = subprocess.run([sys.executable, os.path.abspath(__file__), str(n), "--only-snappy", os.path.join(d, "li_snappy.parquet")], capture_output=True, text=True,
@@ -61,6 +63,9 @@ def main():
         if codec == "snappy@host":           # the same file, Snappy pages inflated by the host threads instead of pq_snappy (experiment switch)
             os.environ["PLX_PARQUET_SNAPPY"] = "host"
             path = os.path.join(d, "li_snappy.parquet")
+        elif codec == "zstd@host":           # the same file, zstd pages inflated by the host threads instead of the device passes
+            os.environ["PLX_PARQUET_ZSTD"] = "host"
+            path = os.path.join(d, "li_zstd.parquet")
         else:
             path = os.path.join(d, f"li_{codec}.parquet")
             pq.write_table(t, path, compression=codec, row_group_size=1 << 20)
@@ -79,6 +84,9 @@ def main():
                           "pyarrow_read_table_s": round(t_pa, 4), "pyarrow_threads": pa.cpu_count()}))
         del df
     os.environ.pop("PLX_PARQUET_SNAPPY", None)
+    os.environ.pop("PLX_PARQUET_ZSTD", None)
+    if os.environ.get("PLX_PQBENCH_NO_IPC"):
+        return
     # the same table as an uncompressed Arrow IPC file: no decode at all, buffers are DMA'd into place (strings: device dictionary encode)
     import pyarrow.ipc as ipc
     path = os.path.join(d, "li.arrow")
