@@ -354,6 +354,14 @@ inline int highest_bit(uint64_t v) { return v ? 63 - __builtin_clzll(v) : -1; }
 struct FwdBits {
   const uint8_t* p; size_t n; size_t bit = 0;
   uint32_t read(int nb) {
+    const size_t first = bit >> 3;
+    if (nb <= 24 && first + 4 <= n) {              // the common case: one unaligned 4-byte load covers shift (<= 7) + nb bits
+      uint32_t w;
+      memcpy(&w, p + first, 4);
+      const uint32_t v = (w >> (bit & 7)) & (((uint32_t)1 << nb) - 1);
+      bit += nb;
+      return v;
+    }
     uint32_t v = 0;
     for (int i = 0; i < nb; i++) {
       size_t byte = (bit + i) >> 3;

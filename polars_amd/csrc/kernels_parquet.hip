@@ -250,10 +250,26 @@ void pq_snappy(const DecompJob* jobs, uint32_t n_jobs, uint64_t bytes_out, uint3
   }
 }
 // ---- zstd (parquet_zstd.hpp): the wavefront of its bodies, and the two passes -----------------------------------------------------------------------------------
-struct ZstdDevWave {
+// TIMING (PLX_ZSTD_TIMING=1): lane 0 adds the 100 MHz ticks between two tick() calls to slot t_acc[slot]; count() adds to a counter slot
+template <bool TIMING> struct ZstdDevWave {
+  uint64_t t_acc[TIMING ? 8 : 1] = {};
+  uint64_t t_last = TIMING ? wall_clock64() : 0;
   template <class F> __device__ __forceinline__ void lanes(F&& f) { f((uint32_t)threadIdx.x); }
   __device__ __forceinline__ void sync() { __syncthreads(); }
   __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_wave_barrier(); }     // orders the wavefront's LDS accesses for the compiler; the hardware runs them in order
+  __device__ __forceinline__ uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }      // a value every lane holds -> a scalar register
+  __device__ __forceinline__ void tick(int slot) {
+    if constexpr (TIMING) { const uint64_t now = wall_clock64(); t_acc[slot] += now - t_last; t_last = now; }
+  }
+  __device__ __forceinline__ void count(int slot, uint32_t n) {
+    if constexpr (TIMING) t_acc[slot] += n;
+  }
+  __device__ __forceinline__ void report(unsigned long long* dbg) {
+    if constexpr (TIMING) {
+      if (threadIdx.x == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(dbg + i, (unsigned long long)t_acc[i]);
+    }
+  }
   // a[lane] -> the sum of a[0 .. lane) (callers put barriers around it)
   __device__ __forceinline__ void exclusive_scan(uint32_t* a) {
     const uint32_t lane = threadIdx.x, v = a[lane];
@@ -272,33 +288,51 @@ struct ZstdDevWave {
   }
 };
 // one wavefront per compressed block (index list: longest blocks first)
+template <bool TIMING>
 __global__ __launch_bounds__(kZLanes) void pq_zstd_entropy_kernel(ZstdBlock* __restrict__ blocks, const uint32_t* __restrict__ order, uint32_t n, const ZstdHufDesc* __restrict__ hufs,
-                                                                  const ZstdFseDesc* __restrict__ fses) {
+                                                                  const ZstdFseDesc* __restrict__ fses, unsigned long long* __restrict__ dbg) {
   __shared__ ZstdEntropyShared sh;
   if (blockIdx.x >= n) return;
-  ZstdDevWave w;
+  ZstdDevWave<TIMING> w;
   zstd_entropy_block(w, sh, blocks, order[blockIdx.x], hufs, fses);
+  w.report(dbg);
 }
 // one wavefront per page
-__global__ __launch_bounds__(kZLanes) void pq_zstd_execute_kernel(const ZstdStream* __restrict__ streams, uint32_t n, const ZstdBlock* __restrict__ blocks, uint32_t* __restrict__ err) {
+template <bool TIMING>
+__global__ __launch_bounds__(kZLanes) void pq_zstd_execute_kernel(const ZstdStream* __restrict__ streams, uint32_t n, const ZstdBlock* __restrict__ blocks, uint32_t* __restrict__ err,
+                                                                  unsigned long long* __restrict__ dbg) {
   __shared__ ZstdExecShared sh;
   if (blockIdx.x >= n) return;
-  ZstdDevWave w;
+  ZstdDevWave<TIMING> w;
   const ZstdStream s = streams[blockIdx.x];
   const bool ok = zstd_exec_stream(w, sh, s, blocks);
   if (!ok && threadIdx.x == 0) atomicOr(err, (uint32_t)PE_ZSTD);
+  w.report(dbg + 8);
 }
 void pq_zstd(ZstdBlock* blocks, const uint32_t* order, uint32_t n_compressed, const ZstdHufDesc* hufs, const ZstdFseDesc* fses, const ZstdStream* streams, uint32_t n_streams,
              uint64_t bytes_in, uint64_t bytes_out, uint32_t* err) {
+  static const bool timing = [] { const char* e = getenv("PLX_ZSTD_TIMING"); return e && e[0] == '1'; }();
+  Buf dbg;
+  if (timing) dbg = dev_alloc_zero(16 * 8);
+  unsigned long long* d = timing ? dbg->as<unsigned long long>() : nullptr;
   if (n_compressed) {
     ProfileScope ps("pq_zstd_entropy", bytes_in, n_compressed);
-    hipLaunchKernelGGL(pq_zstd_entropy_kernel, dim3(n_compressed), dim3(kZLanes), 0, stream(), blocks, order, n_compressed, hufs, fses);
+    if (timing) hipLaunchKernelGGL(pq_zstd_entropy_kernel<true>, dim3(n_compressed), dim3(kZLanes), 0, stream(), blocks, order, n_compressed, hufs, fses, d);
+    else hipLaunchKernelGGL(pq_zstd_entropy_kernel<false>, dim3(n_compressed), dim3(kZLanes), 0, stream(), blocks, order, n_compressed, hufs, fses, d);
     PLX_HIP(hipGetLastError());
   }
   if (n_streams) {
     ProfileScope ps("pq_zstd_execute", bytes_out * 2, n_streams);
-    hipLaunchKernelGGL(pq_zstd_execute_kernel, dim3(n_streams), dim3(kZLanes), 0, stream(), streams, n_streams, (const ZstdBlock*)blocks, err);
+    if (timing) hipLaunchKernelGGL(pq_zstd_execute_kernel<true>, dim3(n_streams), dim3(kZLanes), 0, stream(), streams, n_streams, (const ZstdBlock*)blocks, err, d);
+    else hipLaunchKernelGGL(pq_zstd_execute_kernel<false>, dim3(n_streams), dim3(kZLanes), 0, stream(), streams, n_streams, (const ZstdBlock*)blocks, err, d);
     PLX_HIP(hipGetLastError());
+  }
+  if (timing) {
+    unsigned long long h[16];
+    d2h_sync(h, dbg->ptr, sizeof h);
+    fprintf(stderr, "[pq_zstd] blocks=%u pages=%u in=%.1f MB out=%.1f MB; 100 MHz ticks summed over wavefronts: entropy huf_build=%llu huf_decode=%llu fse_build=%llu stage=%llu seq=%llu (sequences=%llu) | "
+            "execute plan=%llu room=%llu literals=%llu matches=%llu long/raw=%llu (sequences in batches=%llu, long=%llu, batches=%llu)\n",
+            n_compressed, n_streams, bytes_in / 1e6, bytes_out / 1e6, h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
   }
 }
 void pq_page_prepare(PageDesc* pages, uint32_t n_pages, uint32_t* err) {

@@ -390,6 +390,9 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
   struct SyncOnUnwind { B& b; int n = std::uncaught_exceptions(); ~SyncOnUnwind() { if (std::uncaught_exceptions() > n) b.discard_pending(); } } sync_on_unwind{be};
   size_t jobs_launched = 0, stored_since_launch = 0;
   static const size_t kSnappyBatch = [] { const char* e = getenv("PLX_PARQUET_SNAPPY_BATCH"); const long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : (size_t)-1; }();
+  // zstd: every 32 MB of stored bytes (PLX_PARQUET_ZSTD_BATCH; 0 = one launch at the end).  Its passes are a wavefront per block / per page and last as long as the batch's
+  // longest page, not the column's: the kernels of batch k run while the host walks, indexes and uploads batch k + 1.
+  static const size_t kZstdBatch = [] { const char* e = getenv("PLX_PARQUET_ZSTD_BATCH"); const long long v = e ? atoll(e) : (32ll << 20); return v > 0 ? (size_t)v : (size_t)-1; }();
   ZstdPlan zplan;                                      // the zstd pages since the last launch, indexed while their stored bytes were at hand (parquet_zstd_index.hpp)
   std::vector<size_t> zjobs;                           // ... and their job indices, in the plan's stream order
   auto launch_snappy = [&]() {
@@ -561,7 +564,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
           if ((uint64_t)d.n * lt.src_width > (uint64_t)h.uncompressed_size && lt.src_width) throw FormatError("dictionary page smaller than its entry count");
           if (lt.src_width == 0) throw Unsupported("dictionary-encoded booleans");
           d.values = payload;
-          if (codec_on && !zstd_on && (size_t)h.uncompressed_size >= host_dict_min_bytes()) {
+          if (codec_on && (size_t)h.uncompressed_size >= host_dict_min_bytes()) {
             // A LONG Snappy stream is the device kernel's critical path -- one workgroup, 4 KB a round: pyarrow's dictionary pages of up to 1 MB ran for 13 ms next to
             // a thousand data pages of 2 ms each, and the launch lasts as long as its longest stream.  A host thread inflates such a page in about a millisecond while the
             // walk goes on (the compressed bytes are copied out of the staging buffer first: the next chunk reuses it); the plain values travel in one upload behind it.
@@ -571,7 +574,11 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
             hd->out = (size_t)h.uncompressed_size;
             hd->dict_index = dicts.size();
             HostDict* hp = hd.get();
-            hd->done = std::async(std::launch::async, [hp] { snappy_decompress_into(hp->comp.data(), hp->comp.size(), hp->plain.data(), hp->out); });
+            const int dict_codec = c.codec;      // (zstd: the page's execute pass is one wavefront walking its sequences in order -- 1.3e5 of them in a 1 MB dictionary of sorted keys)
+            hd->done = std::async(std::launch::async, [hp, dict_codec] {
+              if (dict_codec == CODEC_SNAPPY) snappy_decompress_into(hp->comp.data(), hp->comp.size(), hp->plain.data(), hp->out);
+              else host_inflate(dict_codec, hp->comp.data(), hp->comp.size(), hp->plain.data(), hp->out);
+            });
             host_dicts.push_back(std::move(hd));
             job_of_dict.push_back(npos);
             if (stats) { stats->host_inflated_pages++; stats->host_inflated_bytes += (uint64_t)h.uncompressed_size; }
@@ -650,7 +657,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     } else {
       be.upload(blob_addr + ch.blob_off, host, sz);
       stored_since_launch += sz;
-      if (codec_on && stored_since_launch >= kSnappyBatch && ci + 1 < chunks.size()) launch_snappy();
+      if (codec_on && stored_since_launch >= (zstd_on ? kZstdBatch : kSnappyBatch) && ci + 1 < chunks.size()) launch_snappy();
     }
     row0 += (uint64_t)ch.rows;
   }
@@ -669,6 +676,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     for (size_t i = 0; i < host_dicts.size(); i++) {
       try { host_dicts[i]->done.get(); }
       catch (const FormatError& e) { for (size_t j = i + 1; j < host_dicts.size(); j++) host_dicts[j]->done.wait(); throw FormatError(std::string("column '") + leaf.name + "': dictionary page: " + e.what()); }
+      catch (const codec::CodecError& e) { for (size_t j = i + 1; j < host_dicts.size(); j++) host_dicts[j]->done.wait(); throw FormatError(std::string("column '") + leaf.name + "': dictionary page: " + e.what()); }
       memcpy(st + off[i], host_dicts[i]->plain.data(), host_dicts[i]->out);
       dicts[host_dicts[i]->dict_index].values = be.addr(host_dict_mem) + off[i];
     }

@@ -36,7 +36,6 @@ constexpr uint32_t kZPiece = 4096;               // bytes one cooperative copy s
 constexpr uint32_t kZBatchSpan = kZRing / 2;     // output bytes of one batch of sequences
 constexpr uint32_t kZLitLane = 64;               // literal bytes a lane places for its own sequence; longer runs go through the cooperative copy
 constexpr uint32_t kZOfMask = (1u << 30) - 1;    // sequence offsets: bits 31:30 = 0 -> the offset itself; j + 1 -> (incoming rep[j]) - low bits
-constexpr uint64_t kZRepBase = (uint64_t)1 << 40;   // symbolic repeat offsets while a block is decoded: incoming rep[j] = (j + 1) * kZRepBase
 constexpr uint32_t kZBlockMax = 128 * 1024;
 constexpr uint32_t kZStageWords = 256;           // 8-byte words of a sequence bit stream staged in LDS at a time (+ 2 below them)
 
@@ -127,7 +126,7 @@ struct ZstdEntropyShared {
   ZstdSeqEntry ll[512], of[256], ml[512];
   uint8_t sym[3][512];             // FSE build: symbol of a state
   uint16_t cnt[3][64];             // FSE build: occurrences of a symbol so far
-  uint64_t stage[kZStageWords + 2];   // sequence bit stream: words stage_base .. of the stream (words below the stream's start are zero)
+  uint64_t stage[kZStageWords + 3];   // sequence bit stream: words stage_base .. of the stream (words below the stream's start are zero; one word of slack above)
   int32_t stage_base, stage_top;   // word index of stage[0]; word that holds the next bit to read
   uint32_t seq_more;
   uint32_t bad;
@@ -276,19 +275,7 @@ PLX_HD void zstd_fse_build(ZstdEntropyShared& sh, const ZstdFseDesc& d, uint32_t
   }
 }
 
-// a repeat-offset value of the decode loop (symbolic or real) -> the 32-bit form of the records; false = not representable
-PLX_HD bool zstd_encode_offset(uint64_t v, uint32_t* out) {
-  if (v >= (kZRepBase >> 1)) {
-    const uint64_t tag = (v + (kZRepBase >> 1)) >> 40;
-    const uint64_t k = tag * kZRepBase - v;
-    if (tag > 3 || k > kZOfMask) return false;
-    *out = (uint32_t)tag << 30 | (uint32_t)k;
-    return true;
-  }
-  if (v > kZOfMask) return false;
-  *out = (uint32_t)v;
-  return true;
-}
+// sequence offsets and repeat offsets in their 32-bit form -> bytes, given the block's incoming repeat offsets
 PLX_HD uint32_t zstd_resolve_offset(uint32_t enc, const uint32_t* rep) {
   const uint32_t tag = enc >> 30, v = enc & kZOfMask;
   if (tag == 0) return v;
@@ -296,101 +283,120 @@ PLX_HD uint32_t zstd_resolve_offset(uint32_t enc, const uint32_t* rep) {
   return r > v ? r - v : 0;          // 0 = invalid (caught by the execute pass)
 }
 
-// lane 0's state between two stagings of the sequence bit stream
+// lane 0's state between two stagings of the sequence bit stream.  Repeat offsets in the 32-bit form of the records (zstd_resolve_offset).
 struct ZstdSeqState {
-  int64_t off;                 // next bit to read (the bits are [0, off))
+  int32_t off;                 // next bit to read (the bits are [0, off)); a block's stream has < 2^20 bits
   uint32_t sl, so, sm, i, started, bad;
-  uint64_t rep0, rep1, rep2, lit_sum, match_sum;
+  uint32_t rep0, rep1, rep2, lit_sum;
+  uint64_t match_sum;
 };
-// the 128 bits below bit `off` (off >= 1) from the staged words: *hi = bits [off - 64, off), *lo = the 64 below
-PLX_HD void zstd_staged_window(const ZstdEntropyShared& sh, int64_t off, uint64_t* hi, uint64_t* lo) {
-  const int32_t wi = (int32_t)((off - 1) >> 6) - sh.stage_base;     // slot of the word that holds bit off - 1 (>= 2 by the caller's loop condition)
-  const uint32_t r = (uint32_t)(off - (((off - 1) >> 6) << 6));      // valid bits in that word: 1 .. 64
-  const uint64_t w2 = sh.stage[wi], w1 = sh.stage[wi - 1], w0 = sh.stage[wi - 2];
-  if (r == 64) { *hi = w2; *lo = w1; }
-  else { *hi = (w2 << (64 - r)) | (w1 >> r); *lo = (w1 << (64 - r)) | (w0 >> r); }
+// the 32 bits below bit e of the staged stream (bit 31 of the result = stream bit e - 1); e - 32 >= 64 * stage_base
+PLX_HD uint32_t z_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {       // ({hi, lo} >> sh)[31:0], sh in 0 .. 31
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+#endif
 }
-// the top nb (0 .. 63) bits of x
-PLX_HD uint64_t z_top(uint64_t x, uint32_t nb) { return (x >> 1) >> (63 - nb); }
+PLX_HD uint32_t zstd_staged32(const uint32_t* s32, int32_t dbase, int32_t e) {
+  const int32_t start = e - 32;
+  const uint32_t d0 = s32[(start >> 5) - dbase], d1 = s32[(start >> 5) - dbase + 1];
+  return z_alignbit(d1, d0, (uint32_t)start & 31);
+}
+// the 96 bits below bit `off`: v2 = bits [off - 32, off), v1 the 32 below, v0 the 32 below those; off - 96 >= 64 * stage_base
+PLX_HD void zstd_staged96(const uint32_t* s32, int32_t dbase, int32_t off, uint32_t* v2, uint32_t* v1, uint32_t* v0) {
+  const int32_t start = off - 96, d = (start >> 5) - dbase;
+  const uint32_t sh = (uint32_t)start & 31;
+  const uint32_t r0 = s32[d], r1 = s32[d + 1], r2 = s32[d + 2], r3 = s32[d + 3];
+  *v0 = z_alignbit(r1, r0, sh); *v1 = z_alignbit(r2, r1, sh); *v2 = z_alignbit(r3, r2, sh);
+}
+// the 32 bits that end `used` (0 .. 31) bits below the top of {hi, lo}
+PLX_HD uint32_t z_below(uint32_t hi, uint32_t lo, uint32_t used) { return (uint32_t)(((((uint64_t)hi << 32) | lo) << used) >> 32); }
+// the top nb (0 .. 31) bits of x
+PLX_HD uint32_t z_top32(uint32_t x, uint32_t nb) { return (x >> 1) >> (31 - nb); }
+PLX_HD void zstd_unpack_entry(uint64_t e, uint32_t* base_value, uint32_t* next_base, uint32_t* extra_bits, uint32_t* nbits) {
+  *base_value = (uint32_t)e; *next_base = (uint32_t)(e >> 32) & 0xffff; *extra_bits = (uint32_t)(e >> 48) & 0xff; *nbits = (uint32_t)(e >> 56);
+}
 
-// lane 0: sequences -> records while their bits are staged (3.1.1.3.2, 3.1.1.5); sets seq_more / stage_top for the next staging
+// lane 0: sequences -> records while their bits are staged (3.1.1.3.2, 3.1.1.5); sets seq_more / stage_top for the next staging.
+// A lane is a poor serial machine (an instruction every four cycles), so the loop is branch-free and 32 bits wide: three 32-bit windows per sequence (offset extra bits;
+// match + literal length extra bits; the three state updates), repeat offsets by selects, errors collected in a flag.
 PLX_HD void zstd_seq_run(ZstdEntropyShared& sh, ZstdBlock& blk, const ZstdFseDesc* fd, ZstdSeqState& st) {
   uint32_t* rec = PQ_GPTR(uint32_t, blk.seq);
-  const int32_t base = sh.stage_base;
-  const bool last_stage = base < 0;            // the words down to the stream's start (and the zero words below it) are staged
-  int64_t off = st.off;
+  const int32_t base = sh.stage_base, dbase = 2 * base;
+  const int32_t lo_bits = 64 * (base + 2);     // the 96 bits below a position at or above this bit are staged (the last staging: down to bit 0, zeros below)
+  const uint32_t* s32 = (const uint32_t*)sh.stage;
+  const uint64_t* tll = (const uint64_t*)sh.ll;
+  const uint64_t* tof = (const uint64_t*)sh.of;
+  const uint64_t* tml = (const uint64_t*)sh.ml;
+  int32_t off = st.off;
   uint32_t sl = st.sl, so = st.so, sm = st.sm, i = st.i;
-  uint64_t rep0 = st.rep0, rep1 = st.rep1, rep2 = st.rep2, lit_sum = st.lit_sum, match_sum = st.match_sum;
-  bool bad = st.bad != 0;
-  auto staged = [&](int64_t o) { return o >= 1 && (last_stage || (int32_t)((o - 1) >> 6) - 2 >= base); };
-  if (!st.started && !bad && (staged(off) || off == 0)) {
+  uint32_t rep0 = st.rep0, rep1 = st.rep1, rep2 = st.rep2, lit_sum = st.lit_sum, bad = st.bad;
+  uint64_t match_sum = st.match_sum;
+  if (!st.started && !bad && off >= lo_bits) {
     const uint32_t log_ll = fd[0].rle ? 0 : fd[0].log, log_of = fd[1].rle ? 0 : fd[1].log, log_ml = fd[2].rle ? 0 : fd[2].log;
-    uint64_t hi = 0, lo = 0;
-    if (off >= 1) zstd_staged_window(sh, off, &hi, &lo);
-    sl = (uint32_t)z_top(hi, log_ll); so = (uint32_t)z_top(hi << log_ll, log_of); sm = (uint32_t)z_top(hi << (log_ll + log_of), log_ml);
-    off -= log_ll + log_of + log_ml;
+    const uint32_t a = zstd_staged32(s32, dbase, off);
+    sl = z_top32(a, log_ll); so = z_top32(a << log_ll, log_of); sm = z_top32(a << (log_ll + log_of), log_ml);
+    off -= (int32_t)(log_ll + log_of + log_ml);
     st.started = 1;
-    if (off < 0) bad = true;
   }
   const uint32_t nseq = blk.nseq;
-  while (st.started && !bad && i < nseq && (staged(off) || off == 0)) {
-    const ZstdSeqEntry el = sh.ll[sl & 511], eo = sh.of[so & 255], em = sh.ml[sm & 511];
-    uint64_t hi = 0, lo = 0;
-    if (off >= 1) zstd_staged_window(sh, off, &hi, &lo);
-    // offset extra bits (<= 31), match length extra bits (<= 16), literal length extra bits (<= 16): all inside the top 63
-    const uint64_t ov = (uint64_t)eo.base_value + z_top(hi, eo.extra_bits);
-    const uint32_t ml = em.base_value + (uint32_t)z_top(hi << eo.extra_bits, em.extra_bits);
-    const uint32_t u1 = eo.extra_bits + em.extra_bits;
-    const uint32_t ll = el.base_value + (uint32_t)z_top(hi << u1, el.extra_bits);
-    uint32_t used = u1 + el.extra_bits;                            // <= 63
-    if (i + 1 < nseq) {
-      const uint64_t y = used ? (hi << used) | ((lo >> 1) >> (63 - used)) : hi;      // the state updates: <= 9 + 9 + 8 bits
-      const uint32_t y32 = (uint32_t)(y >> 32);
-      sl = el.next_base + (uint32_t)(((uint64_t)y32 << el.nbits) >> 32);
-      sm = em.next_base + (uint32_t)(((uint64_t)(y32 << el.nbits) << em.nbits) >> 32);
-      so = eo.next_base + (uint32_t)(((uint64_t)(y32 << (el.nbits + em.nbits)) << eo.nbits) >> 32);
-      used += el.nbits + em.nbits + eo.nbits;
-    }
-    off -= used;
-    if (off < 0) { bad = true; break; }
-    uint64_t offset;
-    if (ov > 3) { offset = ov - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
-    else {
-      const uint32_t idx = (uint32_t)ov - 1 + (ll == 0 ? 1 : 0);
-      if (idx == 0) offset = rep0;
-      else {
-        offset = idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
-        if (idx > 1) rep2 = rep1;
-        rep1 = rep0; rep0 = offset;
-      }
-    }
-    uint32_t enc;
-    if (!zstd_encode_offset(offset, &enc)) { bad = true; break; }
+  if (st.started) {
+    while (i < nseq && off >= lo_bits) {
+      uint32_t bl, nl, xl, kl, bo, no, xo, ko, bm, nm, xm, km;
+      zstd_unpack_entry(tll[sl & 511], &bl, &nl, &xl, &kl);
+      zstd_unpack_entry(tof[so & 255], &bo, &no, &xo, &ko);
+      zstd_unpack_entry(tml[sm & 511], &bm, &nm, &xm, &km);
+      xo = xo > 31 ? 31 : xo; xm &= 31; xl &= 31;       // (tables built from validated descriptions hold nothing larger)
+      // ONE read of the bit stream per sequence, at an address that depends on nothing but `off` (it goes out together with the three table reads): the 96 bits below
+      // `off` hold the extra bits (offset <= 31, match length + literal length <= 32) and the three state updates (<= 26) wherever they fall
+      uint32_t v2, v1, v0;
+      zstd_staged96(s32, dbase, off, &v2, &v1, &v0);
+      const uint32_t ov = bo + z_top32(v2, xo);
+      const uint32_t b = z_below(v2, v1, xo);
+      const uint32_t ml = bm + z_top32(b, xm);
+      const uint32_t ll = bl + z_top32(b << xm, xl);
+      const uint32_t u = xo + xm + xl;                      // 0 .. 63
+      const uint32_t c = z_below(u < 32 ? v2 : v1, u < 32 ? v1 : v0, u & 31);
+      const bool more = i + 1 < nseq;
+      sl = nl + z_top32(c, kl & 15);
+      sm = nm + z_top32(c << (kl & 15), km & 15);
+      so = no + z_top32(c << ((kl & 15) + (km & 15)), ko & 15);
+      off -= (int32_t)u + (more ? (int32_t)((kl & 15) + (km & 15) + (ko & 15)) : 0);
+      // repeat offsets (3.1.1.5): idx 0..2 = rep[idx], 3 = rep[0] - 1, 4 = a new offset
+      const uint32_t idx = ov > 3 ? 4u : ov - 1 + (ll == 0 ? 1u : 0u);
+      const uint32_t dec = rep0 + ((rep0 >> 30) ? 1u : 0xffffffffu);
+      const uint32_t fresh = ov - 3;
+      const uint32_t offset = idx == 0 ? rep0 : idx == 1 ? rep1 : idx == 2 ? rep2 : idx == 3 ? dec : fresh;
+      bad |= (idx == 4 && fresh > kZOfMask) ? 1u : 0u;
+      rep2 = idx >= 2 ? rep1 : rep2;
+      rep1 = idx >= 1 ? rep0 : rep1;
+      rep0 = offset;
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-    v4 r4 = {ll, ml, enc, 0u};
-    *(v4*)(rec + 4 * (size_t)i) = r4;
+      typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+      v4 r4 = {ll, ml, offset, 0u};
+      *(v4*)(rec + 4 * (size_t)i) = r4;
 #else
-    rec[4 * (size_t)i + 0] = ll; rec[4 * (size_t)i + 1] = ml; rec[4 * (size_t)i + 2] = enc; rec[4 * (size_t)i + 3] = 0;
+      rec[4 * (size_t)i + 0] = ll; rec[4 * (size_t)i + 1] = ml; rec[4 * (size_t)i + 2] = offset; rec[4 * (size_t)i + 3] = 0;
 #endif
-    lit_sum += ll; match_sum += ml;
-    i++;
+      lit_sum += ll; match_sum += ml;
+      i++;
+    }
   }
+  if (off < 0) bad = 1;
   st.off = off; st.sl = sl; st.so = so; st.sm = sm; st.i = i;
-  st.rep0 = rep0; st.rep1 = rep1; st.rep2 = rep2; st.lit_sum = lit_sum; st.match_sum = match_sum; st.bad = bad ? 1 : 0;
-  if (bad || i >= nseq || last_stage || off < 1) {
+  st.rep0 = rep0; st.rep1 = rep1; st.rep2 = rep2; st.lit_sum = lit_sum; st.match_sum = match_sum; st.bad = bad;
+  if (bad || i >= nseq || base < 0) {
     // finished (or stuck: a stream that ends early)
-    if (i < nseq || off != 0 || lit_sum > blk.regen || match_sum > ((uint64_t)1 << 31)) bad = true;
-    uint32_t r0 = 0, r1 = 0, r2 = 0;
-    if (!zstd_encode_offset(rep0, &r0) || !zstd_encode_offset(rep1, &r1) || !zstd_encode_offset(rep2, &r2)) bad = true;
-    blk.rep_out[0] = r0; blk.rep_out[1] = r1; blk.rep_out[2] = r2;
-    blk.lit_used = (uint32_t)lit_sum;
+    if (i < nseq || off != 0 || lit_sum > blk.regen || match_sum > ((uint64_t)1 << 31)) bad = 1;
+    blk.rep_out[0] = rep0; blk.rep_out[1] = rep1; blk.rep_out[2] = rep2;
+    blk.lit_used = lit_sum;
     blk.out_len = bad ? 0 : (uint32_t)(blk.regen + match_sum);
     if (bad) sh.bad = 1;
     sh.seq_more = 0;
   } else {
     sh.seq_more = 1;
-    sh.stage_top = (int32_t)((off - 1) >> 6);
+    sh.stage_top = (off - 1) >> 6;
   }
 }
 
@@ -405,7 +411,9 @@ template <class W> PLX_HD void zstd_entropy_block(W& w, ZstdEntropyShared& sh, Z
     w.sync();
     w.lanes([&](uint32_t lane) { zstd_huf_fill(sh, hd, lane); });
     w.sync();
+    w.tick(0);
     w.lanes([&](uint32_t lane) { zstd_huf_decode(sh, blk, hd, lane); });
+    w.tick(1);
   }
   if (blk.nseq) {
     const uint8_t* bits = PQ_GPTR(const uint8_t, blk.src) + blk.bits_off;
@@ -415,13 +423,15 @@ template <class W> PLX_HD void zstd_entropy_block(W& w, ZstdEntropyShared& sh, Z
       if (lane < 3) zstd_fse_build(sh, fses[blk.tab[lane]], lane);
       if (lane == 0) {
         ZstdSeqState& s0 = st[0];
-        s0.off = z_back_start(bits, bits_len);
-        s0.sl = s0.so = s0.sm = 0; s0.i = 0; s0.started = 0; s0.bad = s0.off < 0 ? 1 : 0;
-        s0.rep0 = kZRepBase; s0.rep1 = 2 * kZRepBase; s0.rep2 = 3 * kZRepBase; s0.lit_sum = 0; s0.match_sum = 0;
+        const int64_t start = bits_len <= kZBlockMax ? z_back_start(bits, bits_len) : -1;
+        s0.off = (int32_t)start;
+        s0.sl = s0.so = s0.sm = 0; s0.i = 0; s0.started = 0; s0.bad = start < 0 ? 1 : 0;
+        s0.rep0 = 1u << 30; s0.rep1 = 2u << 30; s0.rep2 = 3u << 30; s0.lit_sum = 0; s0.match_sum = 0;      // "the block's incoming rep[j] - 0"
         sh.seq_more = 1;
-        sh.stage_top = s0.off >= 1 ? (int32_t)((s0.off - 1) >> 6) : 0;
+        sh.stage_top = start >= 1 ? (int32_t)((start - 1) >> 6) : 0;
       }
     });
+    w.tick(2);
     for (;;) {
       w.sync();
       if (!sh.seq_more) break;
@@ -433,16 +443,19 @@ template <class W> PLX_HD void zstd_entropy_block(W& w, ZstdEntropyShared& sh, Z
           const int64_t word = (int64_t)base + k;
           if (word <= top) sh.stage[k] = z_ld64(bits, bits_len, word * 8);
         }
-        if (lane == 0) sh.stage_base = base;
+        if (lane == 0) { sh.stage_base = base; sh.stage[kZStageWords + 2] = 0; }
       });
       w.sync();
+      w.tick(3);
       w.lanes([&](uint32_t lane) {
         if (lane == 0) {
           const ZstdFseDesc fd[3] = {fses[blk.tab[0]], fses[blk.tab[1]], fses[blk.tab[2]]};
           zstd_seq_run(sh, blk, fd, st[0]);
         }
       });
+      w.tick(4);
     }
+    w.count(5, blk.nseq);
   } else {
     w.lanes([&](uint32_t lane) {
       if (lane == 0) { blk.rep_out[0] = 1u << 30; blk.rep_out[1] = 2u << 30; blk.rep_out[2] = 3u << 30; blk.lit_used = 0; blk.out_len = blk.regen; }
@@ -582,6 +595,7 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
     });
     w.sync();
     const uint32_t cnt = w.first_flag(sh.b_flag);
+    w.tick(0);
     if (cnt == 0) {
       // a sequence with a long literal run or a long match: cooperative copies, one piece at a time
       const uint32_t ll = sh.b_ll[0], ml = sh.b_ml[0], off = sh.b_of[0];
@@ -592,10 +606,12 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
       lp += ll;
       if (!zstd_emit_match(w, sh, st, off, ml)) return false;
       base += 1;
+      w.tick(4); w.count(6, 1);
       continue;
     }
     const uint32_t span = sh.b_out[cnt - 1] + sh.b_ll[cnt - 1] + sh.b_ml[cnt - 1], lit_span = sh.b_lit[cnt - 1] + sh.b_ll[cnt - 1];
     zstd_room(w, sh, st, span);
+    w.tick(1);
     const uint32_t cur = st.cur, frame_start = st.frame_start, floor = cur + span > kZRing ? cur + span - kZRing : 0;
     // every lane: the next batch's records on their way; its sequence's literals at their final place; its match must stay inside the frame
     w.lanes([&](uint32_t lane) {
@@ -609,24 +625,30 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
         } else { for (uint32_t t = 0; t < ll; t++) sh.ring[(pos + t) & kZRingMask] = lits[lo + t]; }
         const uint32_t off = sh.b_of[lane];
         if (off == 0 || off > pos + ll - frame_start) sh.bad = 1;
-        sh.b_m[lane][0] = rel + ll; sh.b_m[lane][1] = off; sh.b_m[lane][2] = sh.b_ml[lane]; sh.b_m[lane][3] = 0;
+        // the common match: one step of the wavefront, no overlap, its source still in the ring
+        const uint32_t ml = sh.b_ml[lane];
+        sh.b_m[lane][0] = rel + ll; sh.b_m[lane][1] = off; sh.b_m[lane][2] = ml; sh.b_m[lane][3] = (ml <= kZLanes && off >= ml && pos + ll >= off && pos + ll - off >= floor) ? 1u : 0u;
       }
     });
     w.sync();
+    w.tick(2);
     if (sh.bad) return false;
     const uint8_t* dst = st.dst;
-    uint32_t m0 = sh.b_m[0][0], m1 = sh.b_m[0][1], m2 = sh.b_m[0][2];
+    uint32_t m0 = sh.b_m[0][0], m1 = sh.b_m[0][1], m2 = sh.b_m[0][2], m3 = sh.b_m[0][3];
     for (uint32_t k = 0; k < cnt; k++) {
-      const uint32_t d = cur + m0, off = m1, n = m2;
-      if (k + 1 < cnt) { m0 = sh.b_m[k + 1][0]; m1 = sh.b_m[k + 1][1]; m2 = sh.b_m[k + 1][2]; }      // the next match's parameters before this match's bytes
-      w.lanes([&](uint32_t lane) { zstd_copy_match(sh, dst, d, off, n, floor, lane); });
+      const uint32_t d = cur + w.uniform(m0), off = w.uniform(m1), n = w.uniform(m2), fast = w.uniform(m3);
+      if (k + 1 < cnt) { m0 = sh.b_m[k + 1][0]; m1 = sh.b_m[k + 1][1]; m2 = sh.b_m[k + 1][2]; m3 = sh.b_m[k + 1][3]; }      // the next match's parameters before this match's bytes
+      if (fast) w.lanes([&](uint32_t lane) { if (lane < n) sh.ring[(d + lane) & kZRingMask] = sh.ring[(d - off + lane) & kZRingMask]; });
+      else w.lanes([&](uint32_t lane) { zstd_copy_match(sh, dst, d, off, n, floor, lane); });
       w.wave_fence();
     }
     w.sync();
+    w.tick(3); w.count(5, cnt); w.count(7, 1);
     st.cur += span; lp += lit_span; base += cnt;
   }
   // the literals behind the last sequence
   if (!zstd_emit_literals(w, sh, st, lit_rle ? nullptr : lits + lp, blk.regen - lp, lit_rle, fill)) return false;
+  w.tick(4);
   st.rep[0] = zstd_resolve_offset(blk.rep_out[0], rep_in);
   st.rep[1] = zstd_resolve_offset(blk.rep_out[1], rep_in);
   st.rep[2] = zstd_resolve_offset(blk.rep_out[2], rep_in);

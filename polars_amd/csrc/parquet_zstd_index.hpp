@@ -96,10 +96,14 @@ inline void index_compressed(ZstdPlan& plan, Tables& tb, ZstdBlock& blk, const u
       uint8_t bits[260];
       int nsym = 0;
       const size_t th = huf_read_bits(q, left, bits, &nsym);
-      HufTable check;
-      huf_build(bits, nsym, check);          // validates: code lengths <= 11, the codes fill the table exactly
+      // huf_read_bits made the weights complete (the implied last one fills the code space to a power of two), so the codes fill a table of 2^max_bits entries exactly;
+      // what is left to check is the longest code (4.2.1: 11 bits)
+      int max_bits = 0;
+      for (int i = 0; i < nsym; i++) max_bits = bits[i] > max_bits ? bits[i] : max_bits;
+      if (max_bits > 11) throw CodecError("zstd: Huffman code longer than 11 bits");
+      if (max_bits == 0) throw CodecError("zstd: empty Huffman tree");
       memcpy(d.bits, bits, (size_t)nsym);
-      d.nsym = (uint32_t)nsym; d.max_bits = (uint32_t)check.max_bits;
+      d.nsym = (uint32_t)nsym; d.max_bits = (uint32_t)max_bits;
       tb.huf = (int64_t)plan.hufs.size();
       plan.hufs.push_back(d);
       q += th; left -= th;
@@ -149,8 +153,7 @@ inline void index_compressed(ZstdPlan& plan, Tables& tb, ZstdBlock& blk, const u
       int16_t freq[256];
       int nsym = 0, log = 0;
       const size_t used = fse_read_norm(p + pos, n - pos, max_log[t], max_sym[t], freq, &nsym, &log);
-      FseTable check;
-      fse_build(freq, nsym, log, check);     // validates: the distribution fills its table
+      // (fse_read_norm checked that the counts sum to the table size; the spread step is odd, so every state is visited once: nothing else can go wrong in the build)
       ZstdFseDesc d = ZstdPlan::make(freq, nsym, log);
       tb.tab[t] = (int64_t)plan.fses.size();
       plan.fses.push_back(d);

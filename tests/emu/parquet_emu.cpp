@@ -73,6 +73,9 @@ struct EmuWave {
   }
   void sync() {}
   void wave_fence() {}
+  uint32_t uniform(uint32_t x) { return x; }
+  void tick(int) {}
+  void count(int, uint32_t) {}
   void exclusive_scan(uint32_t* a) { uint32_t run = 0; for (uint32_t l = 0; l < kZLanes; l++) { const uint32_t v = a[l]; a[l] = run; run += v; } }
   uint32_t first_flag(const uint32_t* flag) { for (uint32_t l = 0; l < kZLanes; l++) if (flag[l]) return l; return kZLanes; }
 };

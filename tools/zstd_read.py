@@ -15,7 +15,7 @@ import polars_amd as pl  # noqa: E402
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
 reads = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-level = int(sys.argv[3]) if len(sys.argv) > 3 else None
+level = int(sys.argv[3]) if len(sys.argv) > 3 and int(sys.argv[3]) > 0 else None
 rng = np.random.default_rng(3)
 t = pa.table({"l_orderkey": pa.array(np.sort(rng.integers(1, 4 * n, n))), "l_quantity": pa.array(rng.integers(1, 51, n)),
               "l_extendedprice": pa.array(rng.random(n) * 1e5), "l_discount": pa.array(rng.integers(0, 11, n) / 100.0),
