@@ -261,11 +261,16 @@ template <bool TIMING> struct ZstdDevWave {
   __device__ __forceinline__ void tick(int slot) {
     if constexpr (TIMING) { const uint64_t now = wall_clock64(); t_acc[slot] += now - t_last; t_last = now; }
   }
-  __device__ __forceinline__ void count(int slot, uint32_t n) {
-    if constexpr (TIMING) t_acc[slot] += n;
+  __device__ __forceinline__ void count(int slot, uint32_t n) {          // called by the whole wavefront with one value, or by the one lane that owns the value
+    if constexpr (TIMING) t_acc[slot] += (__builtin_popcountll(__ballot(1)) == 64 && threadIdx.x != 0) ? 0 : n;
   }
   __device__ __forceinline__ void report(unsigned long long* dbg) {
     if constexpr (TIMING) {
+      for (int i = 5; i < 8; i++) {          // counters: summed over the lanes that counted (clock slots are lane 0's)
+        uint32_t v = (uint32_t)t_acc[i];
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        t_acc[i] = v;
+      }
       if (threadIdx.x == 0)
         for (int i = 0; i < 8; i++) atomicAdd(dbg + i, (unsigned long long)t_acc[i]);
     }
@@ -281,20 +286,35 @@ template <bool TIMING> struct ZstdDevWave {
     }
     a[lane] = x - v;
   }
+  // repeat-offset maps (parquet_zstd.hpp): lane's map -> the composition of the maps of lanes 0 .. lane (inclusive)
+  __device__ __forceinline__ void rep_scan(uint32_t* r0, uint32_t* r1, uint32_t* r2) {
+    const uint32_t lane = threadIdx.x;
+    ZstdRepMap m;
+    m.s[0] = r0[lane]; m.s[1] = r1[lane]; m.s[2] = r2[lane];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      ZstdRepMap e;
+      e.s[0] = __shfl_up(m.s[0], d, 64); e.s[1] = __shfl_up(m.s[1], d, 64); e.s[2] = __shfl_up(m.s[2], d, 64);
+      if ((int)lane >= d) m = zstd_rep_compose(e, m);
+    }
+    r0[lane] = m.s[0]; r1[lane] = m.s[1]; r2[lane] = m.s[2];
+  }
   // index of the first nonzero flag[lane]; 64 if there is none
   __device__ __forceinline__ uint32_t first_flag(const uint32_t* flag) {
     const unsigned long long m = __ballot(flag[threadIdx.x] != 0);
     return m ? (uint32_t)__ffsll((long long)m) - 1 : 64u;
   }
 };
-// one wavefront per compressed block (index list: longest blocks first)
+// one wavefront per kZGroups compressed blocks (index list: longest blocks first, so a wavefront's four are of a size)
 template <bool TIMING>
 __global__ __launch_bounds__(kZLanes) void pq_zstd_entropy_kernel(ZstdBlock* __restrict__ blocks, const uint32_t* __restrict__ order, uint32_t n, const ZstdHufDesc* __restrict__ hufs,
                                                                   const ZstdFseDesc* __restrict__ fses, unsigned long long* __restrict__ dbg) {
-  __shared__ ZstdEntropyShared sh;
-  if (blockIdx.x >= n) return;
+  extern __shared__ __align__(16) unsigned char zstd_lds[];
+  ZstdEntropyShared* shs = (ZstdEntropyShared*)zstd_lds;
+  const uint32_t first = blockIdx.x * kZGroups;
+  if (first >= n) return;
   ZstdDevWave<TIMING> w;
-  zstd_entropy_block(w, sh, blocks, order[blockIdx.x], hufs, fses);
+  zstd_entropy_group(w, shs, blocks, order, first, n, hufs, fses);
   w.report(dbg);
 }
 // one wavefront per page
@@ -317,8 +337,17 @@ void pq_zstd(ZstdBlock* blocks, const uint32_t* order, uint32_t n_compressed, co
   unsigned long long* d = timing ? dbg->as<unsigned long long>() : nullptr;
   if (n_compressed) {
     ProfileScope ps("pq_zstd_entropy", bytes_in, n_compressed);
-    if (timing) hipLaunchKernelGGL(pq_zstd_entropy_kernel<true>, dim3(n_compressed), dim3(kZLanes), 0, stream(), blocks, order, n_compressed, hufs, fses, d);
-    else hipLaunchKernelGGL(pq_zstd_entropy_kernel<false>, dim3(n_compressed), dim3(kZLanes), 0, stream(), blocks, order, n_compressed, hufs, fses, d);
+    const uint32_t grid = (n_compressed + kZGroups - 1) / kZGroups;
+    const size_t lds = kZGroups * sizeof(ZstdEntropyShared);        // 4 x 17 KB: beyond the 64 KB a kernel gets without asking
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[timing ? 1 : 0]) {
+      if (timing) (void)hipFuncSetAttribute((const void*)pq_zstd_entropy_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      else (void)hipFuncSetAttribute((const void*)pq_zstd_entropy_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipGetLastError();
+      attr_set[timing ? 1 : 0] = true;
+    }
+    if (timing) hipLaunchKernelGGL(pq_zstd_entropy_kernel<true>, dim3(grid), dim3(kZLanes), lds, stream(), blocks, order, n_compressed, hufs, fses, d);
+    else hipLaunchKernelGGL(pq_zstd_entropy_kernel<false>, dim3(grid), dim3(kZLanes), lds, stream(), blocks, order, n_compressed, hufs, fses, d);
     PLX_HIP(hipGetLastError());
   }
   if (n_streams) {

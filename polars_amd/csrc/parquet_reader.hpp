@@ -131,8 +131,9 @@ inline size_t host_threads(size_t tasks) {
 }
 
 // PLX_PARQUET_TRACE=1: where the host thread of a column is, in ms since the process' first traced event (stderr; measurement only)
+inline bool trace_on() { static const bool on = getenv("PLX_PARQUET_TRACE") != nullptr; return on; }
 inline void trace_point(const std::string& column, const char* what) {
-  static const bool on = getenv("PLX_PARQUET_TRACE") != nullptr;
+  const bool on = trace_on();
   if (!on) return;
   static const auto t0 = std::chrono::steady_clock::now();
   fprintf(stderr, "[plx parquet] %9.2f ms  %-18s %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), column.c_str(), what);
@@ -390,11 +391,13 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
   struct SyncOnUnwind { B& b; int n = std::uncaught_exceptions(); ~SyncOnUnwind() { if (std::uncaught_exceptions() > n) b.discard_pending(); } } sync_on_unwind{be};
   size_t jobs_launched = 0, stored_since_launch = 0;
   static const size_t kSnappyBatch = [] { const char* e = getenv("PLX_PARQUET_SNAPPY_BATCH"); const long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : (size_t)-1; }();
-  // zstd: every 32 MB of stored bytes (PLX_PARQUET_ZSTD_BATCH; 0 = one launch at the end).  Its passes are a wavefront per block / per page and last as long as the batch's
-  // longest page, not the column's: the kernels of batch k run while the host walks, indexes and uploads batch k + 1.
-  static const size_t kZstdBatch = [] { const char* e = getenv("PLX_PARQUET_ZSTD_BATCH"); const long long v = e ? atoll(e) : (32ll << 20); return v > 0 ? (size_t)v : (size_t)-1; }();
+  // zstd: the same knob (PLX_PARQUET_ZSTD_BATCH, off by default).  Measured on the 2e7-row file: one launch 37-45 ms, 64 MB batches 44-48, 32 MB 51, 16 MB 72-90 -- every launch
+  // uploads its descriptor arrays and waits for the stream, which stalls the walk.
+  static const size_t kZstdBatch = [] { const char* e = getenv("PLX_PARQUET_ZSTD_BATCH"); const long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : (size_t)-1; }();
   ZstdPlan zplan;                                      // the zstd pages since the last launch, indexed while their stored bytes were at hand (parquet_zstd_index.hpp)
   std::vector<size_t> zjobs;                           // ... and their job indices, in the plan's stream order
+  double index_ms = 0, pread_ms = 0, stage_ms = 0, upload_ms = 0;
+  auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto launch_snappy = [&]() {
     if (jobs_launched == jobs.size()) return;
     size_t total = 0;
@@ -473,9 +476,11 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     // a device stream: Snappy as it is; zstd with its headers indexed now, while the stored bytes are in the staging buffer
     auto push_job = [&](const uint8_t* stored, uint64_t dev, uint32_t comp, uint32_t uncomp) {
       if (zstd_on) {
+        const auto t0 = std::chrono::steady_clock::now();
         try { zstd_index_stream(zplan, stored, comp, dev, uncomp); }
         catch (const codec::CodecError& e) { throw FormatError(std::string("column '") + leaf.name + "': " + e.what()); }
         zjobs.push_back(jobs.size());
+        index_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       }
       jobs.push_back(DecompJob{dev, 0, comp, uncomp});
     };
@@ -490,8 +495,8 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
       std::vector<uint8_t>& stored = all_host ? (stored_all.emplace_back(), stored_all.back()) : stored_here;
       stored.resize(sz + 16); host = stored.data();
       image = all_host ? batch_image + (ch.blob_off - batch_base) : be.host_stage(ch.blob_cap + 16);
-    } else host = be.host_stage(sz + 16);
-    f.pread_sliced(host, sz, c.start());
+    } else { const double t0 = now_ms(); host = be.host_stage(sz + 16); stage_ms += now_ms() - t0; }
+    { const double t0 = now_ms(); f.pread_sliced(host, sz, c.start()); pread_ms += now_ms() - t0; }
     if (stats) stats->file_bytes += sz;
     std::vector<Inflate> inflate;
     size_t pos = 0;
@@ -655,13 +660,14 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
         be.upload(blob_addr + ch.blob_off, image, ipos);
       }
     } else {
-      be.upload(blob_addr + ch.blob_off, host, sz);
+      { const double t0 = now_ms(); be.upload(blob_addr + ch.blob_off, host, sz); upload_ms += now_ms() - t0; }
       stored_since_launch += sz;
       if (codec_on && stored_since_launch >= (zstd_on ? kZstdBatch : kSnappyBatch) && ci + 1 < chunks.size()) launch_snappy();
     }
     row0 += (uint64_t)ch.rows;
   }
   trace_point(leaf.name, "chunks read, uploads queued");
+  if (trace_on()) fprintf(stderr, "[plx parquet]    %s: of the walk -- file reads %.2f ms, waits for a staging buffer %.2f, upload calls %.2f, zstd index pass %.2f\n", leaf.name.c_str(), pread_ms, stage_ms, upload_ms, index_ms);
   // -- the streams of the last chunks; pages and dictionaries learn where their bytes will be ------------------------------------------------------
   launch_snappy();
   for (size_t i = 0; i < pages.size(); i++) if (job_of_page[i] != npos) pages[i].dst = jobs[job_of_page[i]].dst;

@@ -11,10 +11,11 @@
 //            block that defined the table).  Nothing of the payload is decoded on the host.
 //   entropy  one wavefront per compressed block, all blocks of all pages of the column at once: lanes build the Huffman table and the three
 //            FSE tables in LDS; lanes 0..3 decode the (up to four) Huffman streams into the block's literal buffer; lane 0 decodes the
-//            sequences into {literal length, match length, offset} records.  Repeat offsets cross block borders: the records keep them
-//            SYMBOLIC (tag j + decrement k = "the block's incoming rep[j] - k"), so no block waits for its predecessor.
+//            sequences into {literal length, match length, offset VALUE} records.  Repeat offsets cross block borders and are a chain of their own: they are
+//            left to the execute pass, so no block waits for its predecessor and lane 0's loop stays short.
 //   execute  one wavefront per page: blocks in order; 64 sequences at a time -- every lane places its own sequence's literals at their
-//            final position (prefix sums), then the matches run in sequence order with all lanes copying bytes.  The last 32 KB of output
+//            final position (prefix sums); the repeat-offset history is a prefix "sum" too (every sequence is a small map on the three offsets, maps compose:
+//            a wavefront scan); then the matches run in sequence order with all lanes copying bytes.  The last 32 KB of output
 //            live in an LDS ring (a match that reads what the previous match wrote costs an LDS round trip, not an HBM one); the ring is
 //            flushed to HBM in 16-byte stores, matches that reach further back read the flushed bytes.
 //
@@ -35,8 +36,10 @@ constexpr uint32_t kZRingMask = kZRing - 1;
 constexpr uint32_t kZPiece = 4096;               // bytes one cooperative copy step moves (long literal runs / long matches are cut into pieces)
 constexpr uint32_t kZBatchSpan = kZRing / 2;     // output bytes of one batch of sequences
 constexpr uint32_t kZLitLane = 64;               // literal bytes a lane places for its own sequence; longer runs go through the cooperative copy
-constexpr uint32_t kZOfMask = (1u << 30) - 1;    // sequence offsets: bits 31:30 = 0 -> the offset itself; j + 1 -> (incoming rep[j]) - low bits
+constexpr uint32_t kZOfMask = (1u << 30) - 1;    // repeat-offset maps (execute pass): a slot's bits 31:30 = 0 -> an offset; j + 1 -> (incoming rep[j]) - low bits
 constexpr uint32_t kZBlockMax = 128 * 1024;
+constexpr uint32_t kZGroups = 4;                 // entropy pass: blocks per wavefront (a block's chains run on single lanes: four blocks share the instruction stream)
+constexpr uint32_t kZGroupLanes = kZLanes / kZGroups;
 constexpr uint32_t kZStageWords = 256;           // 8-byte words of a sequence bit stream staged in LDS at a time (+ 2 below them)
 
 // a per-lane variable that lives across phases: a register on the device, one slot per lane on the CPU harness
@@ -79,7 +82,7 @@ struct ZstdBlock {         // one block of a frame
   uint32_t tab[3];         // index of the ZstdFseDesc in force: literal lengths, offsets, match lengths
   uint8_t type, lit_type, lit_streams, first_in_frame;
   // ---- written by the entropy pass ----
-  uint32_t rep_out[3];     // repeat offsets behind the block, encoded like sequence offsets
+  uint32_t pad1[3];
   uint32_t lit_used;       // literal bytes the sequences consume
   uint32_t bad;
   uint32_t pad;
@@ -124,9 +127,13 @@ struct ZstdEntropyShared {
   uint16_t huf[2048];              // (code length << 8) | symbol, indexed by the next max_bits bits
   uint16_t huf_start[256];         // first table index of a symbol's codes
   ZstdSeqEntry ll[512], of[256], ml[512];
-  uint8_t sym[3][512];             // FSE build: symbol of a state
-  uint16_t cnt[3][64];             // FSE build: occurrences of a symbol so far
-  uint64_t stage[kZStageWords + 3];   // sequence bit stream: words stage_base .. of the stream (words below the stream's start are zero; one word of slack above)
+  union {
+    struct {
+      uint8_t sym[3][512];         // FSE build: symbol of a state
+      uint16_t cnt[3][64];         // FSE build: occurrences of a symbol so far
+    };
+    uint64_t stage[kZStageWords + 3];   // (after the build) sequence bit stream: words stage_base .. of the stream (words below the stream's start are zero; one word of slack above)
+  };
   int32_t stage_base, stage_top;   // word index of stage[0]; word that holds the next bit to read
   uint32_t seq_more;
   uint32_t bad;
@@ -162,9 +169,9 @@ PLX_HD void zstd_huf_starts(ZstdEntropyShared& sh, const ZstdHufDesc& d) {
   }
 }
 // every lane: the table entries of its symbols
-PLX_HD void zstd_huf_fill(ZstdEntropyShared& sh, const ZstdHufDesc& d, uint32_t lane) {
+PLX_HD void zstd_huf_fill(ZstdEntropyShared& sh, const ZstdHufDesc& d, uint32_t lane, uint32_t lanes) {
   const uint32_t mb = d.max_bits < 1 ? 1 : d.max_bits > 11 ? 11 : d.max_bits, nsym = d.nsym > 256 ? 256 : d.nsym;
-  for (uint32_t s = lane; s < nsym; s += kZLanes) {
+  for (uint32_t s = lane; s < nsym; s += lanes) {
     const uint32_t st = sh.huf_start[s];
     if (st == 0xffff) continue;
     const uint32_t b = d.bits[s], len = 1u << (mb - b);
@@ -275,19 +282,44 @@ PLX_HD void zstd_fse_build(ZstdEntropyShared& sh, const ZstdFseDesc& d, uint32_t
   }
 }
 
-// sequence offsets and repeat offsets in their 32-bit form -> bytes, given the block's incoming repeat offsets
-PLX_HD uint32_t zstd_resolve_offset(uint32_t enc, const uint32_t* rep) {
-  const uint32_t tag = enc >> 30, v = enc & kZOfMask;
-  if (tag == 0) return v;
-  const uint32_t r = rep[tag - 1];
-  return r > v ? r - v : 0;          // 0 = invalid (caught by the execute pass)
+// ---- repeat offsets (3.1.1.5) as maps on the history {rep0, rep1, rep2} --------------------------------------------------------------------------
+// A slot of a map is an offset (bits 31:30 = 0; 0 = invalid) or "incoming rep[j] - k" ((j + 1) << 30 | k).  A sequence's map depends on its offset value and on whether
+// its literal length is zero; the offset the sequence uses is slot 0 of the history AFTER its map.
+struct ZstdRepMap { uint32_t s[3]; };
+PLX_HD ZstdRepMap zstd_rep_identity() { ZstdRepMap m; m.s[0] = 1u << 30; m.s[1] = 2u << 30; m.s[2] = 3u << 30; return m; }
+PLX_HD ZstdRepMap zstd_rep_of_sequence(uint32_t ov, uint32_t ll) {
+  const uint32_t in0 = 1u << 30, in1 = 2u << 30, in2 = 3u << 30;
+  ZstdRepMap m;
+  if (ov > 3) { const uint32_t v = ov - 3; m.s[0] = v > kZOfMask ? 0 : v; m.s[1] = in0; m.s[2] = in1; return m; }
+  const uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);       // ov = 0 cannot come out of the offset table (base values are >= 1): idx wraps to a large value -> invalid below
+  if (idx == 0) { m.s[0] = in0; m.s[1] = in1; m.s[2] = in2; }
+  else if (idx == 1) { m.s[0] = in1; m.s[1] = in0; m.s[2] = in2; }
+  else if (idx == 2) { m.s[0] = in2; m.s[1] = in0; m.s[2] = in1; }
+  else if (idx == 3) { m.s[0] = in0 | 1; m.s[1] = in0; m.s[2] = in1; }
+  else { m.s[0] = 0; m.s[1] = in0; m.s[2] = in1; }
+  return m;
+}
+// slot x of a later map, seen through the earlier map (or through the history itself: three offsets)
+PLX_HD uint32_t zstd_rep_through(uint32_t x, const uint32_t* earlier) {
+  const uint32_t tag = x >> 30, k = x & kZOfMask;
+  const uint32_t y = tag == 1 ? earlier[0] : tag == 2 ? earlier[1] : earlier[2];
+  // still relative: the decrements add up (a batch has 64 sequences: they stay far below 2^30); an offset: it shrinks, to "invalid" at worst
+  const uint32_t moved = (y >> 30) ? y + k : (y > k ? y - k : 0);
+  return tag ? moved : x;
+}
+// first `a`, then `b`
+PLX_HD ZstdRepMap zstd_rep_compose(const ZstdRepMap& a, const ZstdRepMap& b) {
+  ZstdRepMap r;
+  r.s[0] = zstd_rep_through(b.s[0], a.s); r.s[1] = zstd_rep_through(b.s[1], a.s); r.s[2] = zstd_rep_through(b.s[2], a.s);
+  return r;
 }
 
-// lane 0's state between two stagings of the sequence bit stream.  Repeat offsets in the 32-bit form of the records (zstd_resolve_offset).
+// lane 0's state between two stagings of the sequence bit stream
 struct ZstdSeqState {
   int32_t off;                 // next bit to read (the bits are [0, off)); a block's stream has < 2^20 bits
   uint32_t sl, so, sm, i, started, bad;
-  uint32_t rep0, rep1, rep2, lit_sum;
+  uint32_t log_ll, log_of, log_ml;
+  uint32_t lit_sum;
   uint64_t match_sum;
 };
 // the 32 bits below bit e of the staged stream (bit 31 of the result = stream bit e - 1); e - 32 >= 64 * stage_base
@@ -320,8 +352,8 @@ PLX_HD void zstd_unpack_entry(uint64_t e, uint32_t* base_value, uint32_t* next_b
 
 // lane 0: sequences -> records while their bits are staged (3.1.1.3.2, 3.1.1.5); sets seq_more / stage_top for the next staging.
 // A lane is a poor serial machine (an instruction every four cycles), so the loop is branch-free and 32 bits wide: three 32-bit windows per sequence (offset extra bits;
-// match + literal length extra bits; the three state updates), repeat offsets by selects, errors collected in a flag.
-PLX_HD void zstd_seq_run(ZstdEntropyShared& sh, ZstdBlock& blk, const ZstdFseDesc* fd, ZstdSeqState& st) {
+// match + literal length extra bits; the three state updates); the repeat-offset history is the execute pass' business.
+PLX_HD void zstd_seq_run(ZstdEntropyShared& sh, ZstdBlock& blk, ZstdSeqState& st) {
   uint32_t* rec = PQ_GPTR(uint32_t, blk.seq);
   const int32_t base = sh.stage_base, dbase = 2 * base;
   const int32_t lo_bits = 64 * (base + 2);     // the 96 bits below a position at or above this bit are staged (the last staging: down to bit 0, zeros below)
@@ -331,10 +363,10 @@ PLX_HD void zstd_seq_run(ZstdEntropyShared& sh, ZstdBlock& blk, const ZstdFseDes
   const uint64_t* tml = (const uint64_t*)sh.ml;
   int32_t off = st.off;
   uint32_t sl = st.sl, so = st.so, sm = st.sm, i = st.i;
-  uint32_t rep0 = st.rep0, rep1 = st.rep1, rep2 = st.rep2, lit_sum = st.lit_sum, bad = st.bad;
+  uint32_t lit_sum = st.lit_sum, bad = st.bad;
   uint64_t match_sum = st.match_sum;
   if (!st.started && !bad && off >= lo_bits) {
-    const uint32_t log_ll = fd[0].rle ? 0 : fd[0].log, log_of = fd[1].rle ? 0 : fd[1].log, log_ml = fd[2].rle ? 0 : fd[2].log;
+    const uint32_t log_ll = st.log_ll, log_of = st.log_of, log_ml = st.log_ml;
     const uint32_t a = zstd_staged32(s32, dbase, off);
     sl = z_top32(a, log_ll); so = z_top32(a << log_ll, log_of); sm = z_top32(a << (log_ll + log_of), log_ml);
     off -= (int32_t)(log_ll + log_of + log_ml);
@@ -363,21 +395,12 @@ PLX_HD void zstd_seq_run(ZstdEntropyShared& sh, ZstdBlock& blk, const ZstdFseDes
       sm = nm + z_top32(c << (kl & 15), km & 15);
       so = no + z_top32(c << ((kl & 15) + (km & 15)), ko & 15);
       off -= (int32_t)u + (more ? (int32_t)((kl & 15) + (km & 15) + (ko & 15)) : 0);
-      // repeat offsets (3.1.1.5): idx 0..2 = rep[idx], 3 = rep[0] - 1, 4 = a new offset
-      const uint32_t idx = ov > 3 ? 4u : ov - 1 + (ll == 0 ? 1u : 0u);
-      const uint32_t dec = rep0 + ((rep0 >> 30) ? 1u : 0xffffffffu);
-      const uint32_t fresh = ov - 3;
-      const uint32_t offset = idx == 0 ? rep0 : idx == 1 ? rep1 : idx == 2 ? rep2 : idx == 3 ? dec : fresh;
-      bad |= (idx == 4 && fresh > kZOfMask) ? 1u : 0u;
-      rep2 = idx >= 2 ? rep1 : rep2;
-      rep1 = idx >= 1 ? rep0 : rep1;
-      rep0 = offset;
 #if defined(__HIP_DEVICE_COMPILE__)
       typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-      v4 r4 = {ll, ml, offset, 0u};
+      v4 r4 = {ll, ml, ov, 0u};
       *(v4*)(rec + 4 * (size_t)i) = r4;
 #else
-      rec[4 * (size_t)i + 0] = ll; rec[4 * (size_t)i + 1] = ml; rec[4 * (size_t)i + 2] = offset; rec[4 * (size_t)i + 3] = 0;
+      rec[4 * (size_t)i + 0] = ll; rec[4 * (size_t)i + 1] = ml; rec[4 * (size_t)i + 2] = ov; rec[4 * (size_t)i + 3] = 0;
 #endif
       lit_sum += ll; match_sum += ml;
       i++;
@@ -385,11 +408,10 @@ PLX_HD void zstd_seq_run(ZstdEntropyShared& sh, ZstdBlock& blk, const ZstdFseDes
   }
   if (off < 0) bad = 1;
   st.off = off; st.sl = sl; st.so = so; st.sm = sm; st.i = i;
-  st.rep0 = rep0; st.rep1 = rep1; st.rep2 = rep2; st.lit_sum = lit_sum; st.match_sum = match_sum; st.bad = bad;
+  st.lit_sum = lit_sum; st.match_sum = match_sum; st.bad = bad;
   if (bad || i >= nseq || base < 0) {
     // finished (or stuck: a stream that ends early)
     if (i < nseq || off != 0 || lit_sum > blk.regen || match_sum > ((uint64_t)1 << 31)) bad = 1;
-    blk.rep_out[0] = rep0; blk.rep_out[1] = rep1; blk.rep_out[2] = rep2;
     blk.lit_used = lit_sum;
     blk.out_len = bad ? 0 : (uint32_t)(blk.regen + match_sum);
     if (bad) sh.bad = 1;
@@ -400,69 +422,94 @@ PLX_HD void zstd_seq_run(ZstdEntropyShared& sh, ZstdBlock& blk, const ZstdFseDes
   }
 }
 
-// one compressed block, one wavefront
-template <class W> PLX_HD void zstd_entropy_block(W& w, ZstdEntropyShared& sh, ZstdBlock* blocks, uint32_t bi, const ZstdHufDesc* hufs, const ZstdFseDesc* fses) {
-  ZstdBlock& blk = blocks[bi];
-  w.lanes([&](uint32_t lane) { if (lane == 0) sh.bad = 0; });
+// kZGroups compressed blocks, one wavefront: group g (lanes 16 g .. 16 g + 15) takes block order[first + g].  The chains of a block run on single lanes (Huffman
+// streams: sub-lanes 0..3, sequences: sub-lane 0) and an instruction costs the wavefront the same whether one lane or four are live, so four blocks share the stream.
+template <class W> PLX_HD void zstd_entropy_group(W& w, ZstdEntropyShared* shs, ZstdBlock* blocks, const uint32_t* order, uint32_t first, uint32_t n, const ZstdHufDesc* hufs,
+                                                  const ZstdFseDesc* fses) {
+  auto block_of = [&](uint32_t lane) -> ZstdBlock* { const uint32_t g = lane / kZGroupLanes; return first + g < n ? &blocks[order[first + g]] : nullptr; };
+  w.lanes([&](uint32_t lane) { if (lane % kZGroupLanes == 0) { ZstdEntropyShared& sh = shs[lane / kZGroupLanes]; sh.bad = 0; sh.seq_more = 0; } });
   w.sync();
-  if (blk.lit_type == ZL_HUFFMAN) {
-    const ZstdHufDesc& hd = hufs[blk.huf];
-    w.lanes([&](uint32_t lane) { if (lane == 0) zstd_huf_starts(sh, hd); });
-    w.sync();
-    w.lanes([&](uint32_t lane) { zstd_huf_fill(sh, hd, lane); });
-    w.sync();
-    w.tick(0);
-    w.lanes([&](uint32_t lane) { zstd_huf_decode(sh, blk, hd, lane); });
-    w.tick(1);
-  }
-  if (blk.nseq) {
-    const uint8_t* bits = PQ_GPTR(const uint8_t, blk.src) + blk.bits_off;
-    const uint32_t bits_len = blk.bits_len;
-    ZLaneVar<ZstdSeqState> st;
-    w.lanes([&](uint32_t lane) {
-      if (lane < 3) zstd_fse_build(sh, fses[blk.tab[lane]], lane);
-      if (lane == 0) {
-        ZstdSeqState& s0 = st[0];
-        const int64_t start = bits_len <= kZBlockMax ? z_back_start(bits, bits_len) : -1;
+  w.lanes([&](uint32_t lane) {
+    ZstdBlock* blk = block_of(lane);
+    if (blk && blk->lit_type == ZL_HUFFMAN && lane % kZGroupLanes == 0) zstd_huf_starts(shs[lane / kZGroupLanes], hufs[blk->huf]);
+  });
+  w.sync();
+  w.lanes([&](uint32_t lane) {
+    ZstdBlock* blk = block_of(lane);
+    if (blk && blk->lit_type == ZL_HUFFMAN) zstd_huf_fill(shs[lane / kZGroupLanes], hufs[blk->huf], lane % kZGroupLanes, kZGroupLanes);
+  });
+  w.sync();
+  w.tick(0);
+  w.lanes([&](uint32_t lane) {
+    ZstdBlock* blk = block_of(lane);
+    if (blk && blk->lit_type == ZL_HUFFMAN) zstd_huf_decode(shs[lane / kZGroupLanes], *blk, hufs[blk->huf], lane % kZGroupLanes);
+  });
+  w.sync();
+  w.tick(1);
+  ZLaneVar<ZstdSeqState> st;
+  w.lanes([&](uint32_t lane) {
+    ZstdBlock* blk = block_of(lane);
+    if (!blk) return;
+    ZstdEntropyShared& sh = shs[lane / kZGroupLanes];
+    const uint32_t sub = lane % kZGroupLanes;
+    if (blk->nseq) {
+      if (sub < 3) zstd_fse_build(sh, fses[blk->tab[sub]], sub);
+      if (sub == 0) {
+        const uint8_t* bits = PQ_GPTR(const uint8_t, blk->src) + blk->bits_off;
+        ZstdSeqState& s0 = st[lane];
+        const int64_t start = blk->bits_len <= kZBlockMax ? z_back_start(bits, blk->bits_len) : -1;
         s0.off = (int32_t)start;
         s0.sl = s0.so = s0.sm = 0; s0.i = 0; s0.started = 0; s0.bad = start < 0 ? 1 : 0;
-        s0.rep0 = 1u << 30; s0.rep1 = 2u << 30; s0.rep2 = 3u << 30; s0.lit_sum = 0; s0.match_sum = 0;      // "the block's incoming rep[j] - 0"
+        s0.log_ll = fses[blk->tab[0]].rle ? 0 : fses[blk->tab[0]].log; s0.log_of = fses[blk->tab[1]].rle ? 0 : fses[blk->tab[1]].log;
+        s0.log_ml = fses[blk->tab[2]].rle ? 0 : fses[blk->tab[2]].log;
+        s0.lit_sum = 0; s0.match_sum = 0;
         sh.seq_more = 1;
         sh.stage_top = start >= 1 ? (int32_t)((start - 1) >> 6) : 0;
       }
-    });
-    w.tick(2);
-    for (;;) {
-      w.sync();
-      if (!sh.seq_more) break;
-      // the next kZStageWords words of the bit stream (downwards from the word of the next bit), two more below them; words below the stream's start are zero
-      const int32_t top = sh.stage_top, lo_word = top >= (int32_t)kZStageWords ? top - (int32_t)kZStageWords + 1 : 0, base = lo_word - 2;
-      w.sync();
-      w.lanes([&](uint32_t lane) {
-        for (uint32_t k = lane; k < kZStageWords + 2; k += kZLanes) {
-          const int64_t word = (int64_t)base + k;
-          if (word <= top) sh.stage[k] = z_ld64(bits, bits_len, word * 8);
-        }
-        if (lane == 0) { sh.stage_base = base; sh.stage[kZStageWords + 2] = 0; }
-      });
-      w.sync();
-      w.tick(3);
-      w.lanes([&](uint32_t lane) {
-        if (lane == 0) {
-          const ZstdFseDesc fd[3] = {fses[blk.tab[0]], fses[blk.tab[1]], fses[blk.tab[2]]};
-          zstd_seq_run(sh, blk, fd, st[0]);
-        }
-      });
-      w.tick(4);
-    }
-    w.count(5, blk.nseq);
-  } else {
+    } else if (sub == 0) { blk->lit_used = 0; blk->out_len = blk->regen; }
+  });
+  w.tick(2);
+  for (;;) {
+    w.sync();
+    uint32_t any = 0;
+    for (uint32_t g = 0; g < kZGroups; g++) any |= shs[g].seq_more;
+    if (!any) break;
+    w.sync();
+    // per group with sequences left: the next kZStageWords words of its bit stream (downwards from the word of the next bit), two more below them; words below the
+    // stream's start are zero
     w.lanes([&](uint32_t lane) {
-      if (lane == 0) { blk.rep_out[0] = 1u << 30; blk.rep_out[1] = 2u << 30; blk.rep_out[2] = 3u << 30; blk.lit_used = 0; blk.out_len = blk.regen; }
+      ZstdBlock* blk = block_of(lane);
+      ZstdEntropyShared& sh = shs[lane / kZGroupLanes];
+      if (!blk || !sh.seq_more) return;
+      const uint8_t* bits = PQ_GPTR(const uint8_t, blk->src) + blk->bits_off;
+      const int32_t top = sh.stage_top, lo_word = top >= (int32_t)kZStageWords ? top - (int32_t)kZStageWords + 1 : 0, base = lo_word - 2;
+      for (uint32_t k = lane % kZGroupLanes; k < kZStageWords + 2; k += kZGroupLanes) {
+        const int64_t word = (int64_t)base + k;
+        if (word <= top) sh.stage[k] = z_ld64(bits, blk->bits_len, word * 8);
+      }
     });
+    w.sync();
+    w.lanes([&](uint32_t lane) {
+      ZstdEntropyShared& sh = shs[lane / kZGroupLanes];
+      if (lane % kZGroupLanes == 0 && sh.seq_more) {
+        const int32_t top = sh.stage_top;
+        sh.stage_base = (top >= (int32_t)kZStageWords ? top - (int32_t)kZStageWords + 1 : 0) - 2;
+        sh.stage[kZStageWords + 2] = 0;
+      }
+    });
+    w.sync();
+    w.tick(3);
+    w.lanes([&](uint32_t lane) {
+      ZstdBlock* blk = block_of(lane);
+      ZstdEntropyShared& sh = shs[lane / kZGroupLanes];
+      if (blk && lane % kZGroupLanes == 0 && sh.seq_more) zstd_seq_run(sh, *blk, st[lane]);
+    });
+    w.tick(4);
   }
-  w.sync();
-  w.lanes([&](uint32_t lane) { if (lane == 0) blk.bad = sh.bad; });
+  w.lanes([&](uint32_t lane) {
+    ZstdBlock* blk = block_of(lane);
+    if (blk && lane % kZGroupLanes == 0) { blk->bad = shs[lane / kZGroupLanes].bad; w.count(5, blk->nseq); }
+  });
 }
 
 // ---- execute pass --------------------------------------------------------------------------------------------------------------------------
@@ -470,6 +517,7 @@ struct ZstdExecShared {
   alignas(16) uint8_t ring[kZRing];
   alignas(16) uint32_t b_m[kZLanes][4];                      // per sequence of the batch: {match start relative to the batch, offset, match length, -}
   uint32_t b_ll[kZLanes], b_ml[kZLanes], b_of[kZLanes];      // the batch's records (offsets resolved)
+  uint32_t b_r0[kZLanes], b_r1[kZLanes], b_r2[kZLanes];      // repeat-offset maps: the sequence's own, then (scan) of the batch up to and including it
   uint32_t b_lit[kZLanes], b_out[kZLanes];                   // exclusive prefixes: literal bytes / output bytes before the sequence
   uint32_t b_flag[kZLanes];                                  // the sequence does not fit the fast path (or the batch)
   uint32_t bad;
@@ -558,7 +606,6 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
   const uint32_t* rec = PQ_GPTR(const uint32_t, blk.seq);
   if (blk.bad || blk.lit_used > blk.regen) return false;
   uint32_t lp = 0;
-  const uint32_t rep_in[3] = {st.rep[0], st.rep[1], st.rep[2]};
   const uint32_t nseq = blk.nseq;
   struct Rec { uint32_t ll, ml, of; };
   ZLaneVar<Rec> nxt;             // the next batch's records: loaded while the current batch's matches run
@@ -581,16 +628,20 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
     const uint32_t n_in = nseq - base < kZLanes ? nseq - base : kZLanes;
     w.lanes([&](uint32_t lane) {
       const Rec r = nxt[lane];
-      sh.b_ll[lane] = r.ll; sh.b_ml[lane] = r.ml; sh.b_of[lane] = zstd_resolve_offset(r.of, rep_in);
+      sh.b_ll[lane] = r.ll; sh.b_ml[lane] = r.ml;
       sh.b_lit[lane] = lane < n_in ? r.ll : 0; sh.b_out[lane] = lane < n_in ? r.ll + r.ml : 0;
+      const ZstdRepMap m = lane < n_in ? zstd_rep_of_sequence(r.of, r.ll) : zstd_rep_identity();
+      sh.b_r0[lane] = m.s[0]; sh.b_r1[lane] = m.s[1]; sh.b_r2[lane] = m.s[2];
     });
     w.sync();
-    w.exclusive_scan(sh.b_lit); w.exclusive_scan(sh.b_out);
+    w.exclusive_scan(sh.b_lit); w.exclusive_scan(sh.b_out); w.rep_scan(sh.b_r0, sh.b_r1, sh.b_r2);
     w.sync();
+    const uint32_t rep_in[3] = {st.rep[0], st.rep[1], st.rep[2]};
     // the batch ends in front of the first sequence that does not fit: a long literal run / match (cooperative copies below), the batch's span, the literal buffer, the page
     const uint32_t lit_left = blk.regen - lp, room_left = st.cap - st.cur;
     w.lanes([&](uint32_t lane) {
       const uint32_t ll = sh.b_ll[lane], ml = sh.b_ml[lane], le = sh.b_lit[lane], oe = sh.b_out[lane];
+      sh.b_of[lane] = zstd_rep_through(sh.b_r0[lane], rep_in);         // the history behind the sequence, slot 0
       sh.b_flag[lane] = lane >= n_in || ll > kZLitLane || ml > kZPiece || oe + ll + ml > kZBatchSpan || le + ll > lit_left || oe + ll + ml > room_left;
     });
     w.sync();
@@ -605,6 +656,7 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
       if (!zstd_emit_literals(w, sh, st, lit_rle ? nullptr : lits + lp, ll, lit_rle, fill)) return false;
       lp += ll;
       if (!zstd_emit_match(w, sh, st, off, ml)) return false;
+      { const uint32_t r1 = zstd_rep_through(sh.b_r1[0], rep_in), r2 = zstd_rep_through(sh.b_r2[0], rep_in); st.rep[0] = off; st.rep[1] = r1; st.rep[2] = r2; }
       base += 1;
       w.tick(4); w.count(6, 1);
       continue;
@@ -644,14 +696,13 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
     }
     w.sync();
     w.tick(3); w.count(5, cnt); w.count(7, 1);
+    { const uint32_t r0 = zstd_rep_through(sh.b_r0[cnt - 1], rep_in), r1 = zstd_rep_through(sh.b_r1[cnt - 1], rep_in), r2 = zstd_rep_through(sh.b_r2[cnt - 1], rep_in);
+      st.rep[0] = r0; st.rep[1] = r1; st.rep[2] = r2; }
     st.cur += span; lp += lit_span; base += cnt;
   }
   // the literals behind the last sequence
   if (!zstd_emit_literals(w, sh, st, lit_rle ? nullptr : lits + lp, blk.regen - lp, lit_rle, fill)) return false;
   w.tick(4);
-  st.rep[0] = zstd_resolve_offset(blk.rep_out[0], rep_in);
-  st.rep[1] = zstd_resolve_offset(blk.rep_out[1], rep_in);
-  st.rep[2] = zstd_resolve_offset(blk.rep_out[2], rep_in);
   return true;
 }
 

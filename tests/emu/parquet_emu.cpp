@@ -77,6 +77,14 @@ struct EmuWave {
   void tick(int) {}
   void count(int, uint32_t) {}
   void exclusive_scan(uint32_t* a) { uint32_t run = 0; for (uint32_t l = 0; l < kZLanes; l++) { const uint32_t v = a[l]; a[l] = run; run += v; } }
+  void rep_scan(uint32_t* r0, uint32_t* r1, uint32_t* r2) {
+    ZstdRepMap run = zstd_rep_identity();
+    for (uint32_t l = 0; l < kZLanes; l++) {
+      ZstdRepMap m; m.s[0] = r0[l]; m.s[1] = r1[l]; m.s[2] = r2[l];
+      run = zstd_rep_compose(run, m);
+      r0[l] = run.s[0]; r1[l] = run.s[1]; r2[l] = run.s[2];
+    }
+  }
   uint32_t first_flag(const uint32_t* flag) { for (uint32_t l = 0; l < kZLanes; l++) if (flag[l]) return l; return kZLanes; }
 };
 // pq_zstd_entropy + pq_zstd_execute (kernels_parquet.hip) as loops: one wavefront per compressed block, then one per page; returns PE_ZSTD or 0
@@ -89,10 +97,10 @@ uint32_t zstd_run(ZstdBlock* blocks, const uint32_t* order_idx, uint32_t n_compr
     if (order == 0) for (size_t i = 0; i < n; i++) f(i);
     else for (size_t i = n; i-- > 0;) f(i);
   };
-  each(n_compressed, [&](size_t i) {
-    auto sh = std::make_unique<ZstdEntropyShared>();
-    memset(sh.get(), 0xA5, sizeof *sh);     // LDS is not zeroed
-    zstd_entropy_block(w, *sh, blocks, order_idx[i], hufs, fses);
+  each((n_compressed + kZGroups - 1) / kZGroups, [&](size_t i) {
+    auto sh = std::make_unique<ZstdEntropyShared[]>(kZGroups);
+    memset(sh.get(), 0xA5, sizeof(ZstdEntropyShared) * kZGroups);     // LDS is not zeroed
+    zstd_entropy_group(w, sh.get(), blocks, order_idx, (uint32_t)(i * kZGroups), n_compressed, hufs, fses);
   });
   each(n_streams, [&](size_t i) {
     auto sh = std::make_unique<ZstdExecShared>();
