@@ -26,6 +26,12 @@
 #include <string.h>
 
 #include "parquet_device.hpp"
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(PLX_ZSTD_DEBUG)
+#include <cstdio>
+#define ZDBG(...) fprintf(stderr, __VA_ARGS__)
+#else
+#define ZDBG(...)
+#endif
 
 namespace plx {
 namespace pq {
@@ -238,7 +244,7 @@ PLX_HD void zstd_huf_decode(ZstdEntropyShared& sh, const ZstdBlock& blk, const Z
     const uint32_t olen = lane < 3 ? each : blk.regen - 3 * each;
     ok = zstd_huf_stream(sh.huf, mb, p + 6 + start, len, out + (size_t)lane * each, olen);
   }
-  if (!ok) sh.bad = 1;
+  if (!ok) { sh.bad = 1; ZDBG("huf stream %u failed\n", lane); }
 }
 
 // lane t < 3: sequence table t (0 literal lengths, 1 offsets, 2 match lengths) from its normalised counts (4.1.1)
@@ -247,7 +253,7 @@ PLX_HD void zstd_fse_build(ZstdEntropyShared& sh, const ZstdFseDesc& d, uint32_t
   const uint32_t max_log = t == 1 ? 8 : 9, max_code = t == 0 ? 35 : t == 1 ? 31 : 52;
   auto entry = [&](uint32_t c, uint32_t next_base, uint32_t nbits) {
     ZstdSeqEntry e;
-    if (c > max_code) { sh.bad = 1; c = 0; }
+    if (c > max_code) { sh.bad = 1; ZDBG("fse code %u > max t=%u\n", c, t); c = 0; }
     if (t == 0) { e.base_value = z_ll_base(c); e.extra_bits = (uint8_t)z_ll_bits(c); }
     else if (t == 2) { e.base_value = z_ml_base(c); e.extra_bits = (uint8_t)z_ml_bits(c); }
     else { e.base_value = (uint32_t)1 << c; e.extra_bits = (uint8_t)c; }
@@ -273,7 +279,7 @@ PLX_HD void zstd_fse_build(ZstdEntropyShared& sh, const ZstdFseDesc& d, uint32_t
       do { pos = (pos + step) & mask; } while (pos >= high && ++guard < 1024);
     }
   }
-  if (pos != 0) sh.bad = 1;
+  if (pos != 0) { sh.bad = 1; ZDBG("fse spread pos=%u t=%u\n", pos, t); }
   for (uint32_t i = 0; i < size; i++) {
     const uint32_t s = sym[i] < nsym ? sym[i] : 0;
     const uint32_t next = cnt[s]++;
@@ -409,9 +415,9 @@ PLX_HD void zstd_seq_run(ZstdEntropyShared& sh, ZstdBlock& blk, ZstdSeqState& st
   if (off < 0) bad = 1;
   st.off = off; st.sl = sl; st.so = so; st.sm = sm; st.i = i;
   st.lit_sum = lit_sum; st.match_sum = match_sum; st.bad = bad;
-  if (bad || i >= nseq || base < 0) {
+  if (bad || i >= nseq || lo_bits <= 0) {          // (lo_bits == 0: the stream's first word was staged -- nothing is left to stage)
     // finished (or stuck: a stream that ends early)
-    if (i < nseq || off != 0 || lit_sum > blk.regen || match_sum > ((uint64_t)1 << 31)) bad = 1;
+    if (i < nseq || off != 0 || lit_sum > blk.regen || match_sum > ((uint64_t)1 << 31)) { bad = 1; ZDBG("seq end: i=%u nseq=%u off=%d lit_sum=%u regen=%u\n", i, nseq, off, lit_sum, blk.regen); }
     blk.lit_used = lit_sum;
     blk.out_len = bad ? 0 : (uint32_t)(blk.regen + match_sum);
     if (bad) sh.bad = 1;
@@ -604,7 +610,7 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
   const uint8_t fill = (uint8_t)blk.lit;
   const uint8_t* lits = lit_rle ? nullptr : PQ_GPTR(const uint8_t, blk.lit);
   const uint32_t* rec = PQ_GPTR(const uint32_t, blk.seq);
-  if (blk.bad || blk.lit_used > blk.regen) return false;
+  if (blk.bad || blk.lit_used > blk.regen) { ZDBG("exec: block flagged bad=%u lit_used=%u regen=%u\n", blk.bad, blk.lit_used, blk.regen); return false; }
   uint32_t lp = 0;
   const uint32_t nseq = blk.nseq;
   struct Rec { uint32_t ll, ml, of; };
@@ -676,7 +682,7 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
           for (uint32_t t = 0; t < ll; t++) { sh.ring[(pos + t) & kZRingMask] = (uint8_t)v; v >>= 8; }
         } else { for (uint32_t t = 0; t < ll; t++) sh.ring[(pos + t) & kZRingMask] = lits[lo + t]; }
         const uint32_t off = sh.b_of[lane];
-        if (off == 0 || off > pos + ll - frame_start) sh.bad = 1;
+        if (off == 0 || off > pos + ll - frame_start) { sh.bad = 1; ZDBG("exec: offset %u at %u (lane %u)\n", off, pos + ll, lane); }
         // the common match: one step of the wavefront, no overlap, its source still in the ring
         const uint32_t ml = sh.b_ml[lane];
         sh.b_m[lane][0] = rel + ll; sh.b_m[lane][1] = off; sh.b_m[lane][2] = ml; sh.b_m[lane][3] = (ml <= kZLanes && off >= ml && pos + ll >= off && pos + ll - off >= floor) ? 1u : 0u;
@@ -720,7 +726,7 @@ template <class W> PLX_HD bool zstd_exec_stream(W& w, ZstdExecShared& sh, const 
     else ok = zstd_exec_block(w, sh, st, blk);
     if (!ok) return false;
   }
-  if (st.cur != st.cap) return false;
+  if (st.cur != st.cap) { ZDBG("exec: page ends at %u of %u\n", st.cur, st.cap); return false; }
   zstd_flush(w, sh, st, st.cur, true);
   return true;
 }

@@ -758,6 +758,20 @@ def test_zstd_device_bodies_against_the_real_codec(name):
         assert rc == 0 and out == p + p, (rc, err)
 
 
+def test_zstd_sequence_bit_streams_of_every_length():
+    """The sequence bit stream of a block is staged through LDS 256 words at a time, downwards; where the last stagings fall depends on the stream's length (a stream
+    whose next-to-last staging started at word 1 was once taken for finished).  ~160 KB pages of prices and of sorted keys, their lengths swept: bit streams of 2 .. 60 KB."""
+    rng = np.random.default_rng(606)
+    price = np.round(rng.uniform(900, 105_000, 30_000), 2)
+    keys = np.sort(rng.integers(0, 1 << 40, 30_000))
+    for src in (price, keys):
+        for m in list(range(18_000, 21_000, 41)) + list(range(300, 6_000, 173)):
+            p = src[:m].tobytes()
+            c = pa.Codec("zstd", compression_level=1).compress(p, asbytes=True)
+            rc, out, counts, err = E.zstd_device(c, len(p))
+            assert rc == 0 and out == p, (m, rc, counts, err)
+
+
 def test_zstd_device_agrees_with_the_host_decoder_on_corrupt_streams():
     """Bit flips and truncations: whatever the host decoder (host_codecs.hpp) makes of a stream, the device bodies make the same -- the same bytes or an error --
     and the page header's size stays the authority."""
