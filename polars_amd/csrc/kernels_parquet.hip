@@ -299,6 +299,22 @@ template <bool TIMING> struct ZstdDevWave {
     }
     r0[lane] = m.s[0]; r1[lane] = m.s[1]; r2[lane] = m.s[2];
   }
+  // the three scans of a batch in one go: five shuffles a round (one LDS-crossbar latency), everything else in registers
+  __device__ __forceinline__ void batch_scan(uint32_t* lit, uint32_t* out, uint32_t* r0, uint32_t* r1, uint32_t* r2) {
+    const uint32_t lane = threadIdx.x, l0 = lit[lane], o0 = out[lane];
+    uint32_t l = l0, o = o0;
+    ZstdRepMap m;
+    m.s[0] = r0[lane]; m.s[1] = r1[lane]; m.s[2] = r2[lane];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t yl = __shfl_up(l, d, 64), yo = __shfl_up(o, d, 64);
+      ZstdRepMap e;
+      e.s[0] = __shfl_up(m.s[0], d, 64); e.s[1] = __shfl_up(m.s[1], d, 64); e.s[2] = __shfl_up(m.s[2], d, 64);
+      if ((int)lane >= d) { l += yl; o += yo; m = zstd_rep_compose(e, m); }
+    }
+    lit[lane] = l - l0; out[lane] = o - o0;
+    r0[lane] = m.s[0]; r1[lane] = m.s[1]; r2[lane] = m.s[2];
+  }
   // index of the first nonzero flag[lane]; 64 if there is none
   __device__ __forceinline__ uint32_t first_flag(const uint32_t* flag) {
     const unsigned long long m = __ballot(flag[threadIdx.x] != 0);

@@ -48,6 +48,12 @@ constexpr uint32_t kZGroups = 4;                 // entropy pass: blocks per wav
 constexpr uint32_t kZGroupLanes = kZLanes / kZGroups;
 constexpr uint32_t kZStageWords = 256;           // 8-byte words of a sequence bit stream staged in LDS at a time (+ 2 below them)
 
+#if defined(__clang__)
+#define PLX_UNROLL_Z _Pragma("unroll")
+#else
+#define PLX_UNROLL_Z
+#endif
+
 // a per-lane variable that lives across phases: a register on the device, one slot per lane on the CPU harness
 template <class T> struct ZLaneVar {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -521,7 +527,7 @@ template <class W> PLX_HD void zstd_entropy_group(W& w, ZstdEntropyShared* shs, 
 // ---- execute pass --------------------------------------------------------------------------------------------------------------------------
 struct ZstdExecShared {
   alignas(16) uint8_t ring[kZRing];
-  alignas(16) uint32_t b_m[kZLanes][4];                      // per sequence of the batch: {match start relative to the batch, offset, match length, -}
+  alignas(16) uint32_t b_m[kZLanes + 4][4];                  // per sequence of the batch: {match start relative to the batch, offset, match length, one-step flag} (+ a group of slack)
   uint32_t b_ll[kZLanes], b_ml[kZLanes], b_of[kZLanes];      // the batch's records (offsets resolved)
   uint32_t b_r0[kZLanes], b_r1[kZLanes], b_r2[kZLanes];      // repeat-offset maps: the sequence's own, then (scan) of the batch up to and including it
   uint32_t b_lit[kZLanes], b_out[kZLanes];                   // exclusive prefixes: literal bytes / output bytes before the sequence
@@ -640,7 +646,7 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
       sh.b_r0[lane] = m.s[0]; sh.b_r1[lane] = m.s[1]; sh.b_r2[lane] = m.s[2];
     });
     w.sync();
-    w.exclusive_scan(sh.b_lit); w.exclusive_scan(sh.b_out); w.rep_scan(sh.b_r0, sh.b_r1, sh.b_r2);
+    w.batch_scan(sh.b_lit, sh.b_out, sh.b_r0, sh.b_r1, sh.b_r2);       // exclusive sums of the two lengths, inclusive composition of the repeat-offset maps
     w.sync();
     const uint32_t rep_in[3] = {st.rep[0], st.rep[1], st.rep[2]};
     // the batch ends in front of the first sequence that does not fit: a long literal run / match (cooperative copies below), the batch's span, the literal buffer, the page
@@ -692,13 +698,23 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
     w.tick(2);
     if (sh.bad) return false;
     const uint8_t* dst = st.dst;
-    uint32_t m0 = sh.b_m[0][0], m1 = sh.b_m[0][1], m2 = sh.b_m[0][2], m3 = sh.b_m[0][3];
-    for (uint32_t k = 0; k < cnt; k++) {
-      const uint32_t d = cur + w.uniform(m0), off = w.uniform(m1), n = w.uniform(m2), fast = w.uniform(m3);
-      if (k + 1 < cnt) { m0 = sh.b_m[k + 1][0]; m1 = sh.b_m[k + 1][1]; m2 = sh.b_m[k + 1][2]; m3 = sh.b_m[k + 1][3]; }      // the next match's parameters before this match's bytes
-      if (fast) w.lanes([&](uint32_t lane) { if (lane < n) sh.ring[(d + lane) & kZRingMask] = sh.ring[(d - off + lane) & kZRingMask]; });
-      else w.lanes([&](uint32_t lane) { zstd_copy_match(sh, dst, d, off, n, floor, lane); });
-      w.wave_fence();
+    // matches in sequence order, four at a time: the parameters of the next four are read from LDS while these four copy (a match waits for ONE thing: the bytes it reads)
+    uint32_t m[4][4];
+    PLX_UNROLL_Z for (int j = 0; j < 4; j++) { m[j][0] = sh.b_m[j][0]; m[j][1] = sh.b_m[j][1]; m[j][2] = sh.b_m[j][2]; m[j][3] = sh.b_m[j][3]; }
+    for (uint32_t k = 0; k < cnt; k += 4) {
+      uint32_t q[4][4];
+      PLX_UNROLL_Z for (int j = 0; j < 4; j++) { q[j][0] = w.uniform(m[j][0]); q[j][1] = w.uniform(m[j][1]); q[j][2] = w.uniform(m[j][2]); q[j][3] = w.uniform(m[j][3]); }
+      if (k + 4 < cnt) {
+        PLX_UNROLL_Z for (int j = 0; j < 4; j++) { m[j][0] = sh.b_m[k + 4 + j][0]; m[j][1] = sh.b_m[k + 4 + j][1]; m[j][2] = sh.b_m[k + 4 + j][2]; m[j][3] = sh.b_m[k + 4 + j][3]; }
+      }
+      PLX_UNROLL_Z for (int j = 0; j < 4; j++) {
+        if (k + j < cnt) {
+          const uint32_t d = cur + q[j][0], off = q[j][1], n = q[j][2];
+          if (q[j][3]) w.lanes([&](uint32_t lane) { if (lane < n) sh.ring[(d + lane) & kZRingMask] = sh.ring[(d - off + lane) & kZRingMask]; });
+          else w.lanes([&](uint32_t lane) { zstd_copy_match(sh, dst, d, off, n, floor, lane); });
+          w.wave_fence();
+        }
+      }
     }
     w.sync();
     w.tick(3); w.count(5, cnt); w.count(7, 1);
