@@ -1208,8 +1208,9 @@ def end_to_end_q1(pl, n: int, reps: int = 3) -> dict:
 
 def scan_extra(pl, n: int):
     """File -> device columns (no query): a lineitem-like table of n rows written by pyarrow as Parquet (uncompressed / Snappy /
-    Zstandard) and as an Arrow IPC file, read with the library's own scan (metadata parsed by the library, Snappy and all page decoding
-    on the device, zstd inflated by the library's host threads); every read is checked against the source columns; pyarrow's own
+    Zstandard) and as an Arrow IPC file, read with the library's own scan (metadata parsed by the library; Snappy, Zstandard (round 6: pq_zstd_entropy +
+    pq_zstd_execute) and all page decoding on the device; `parquet_zstd_host_threads` = the same file with PLX_PARQUET_ZSTD=host, the round-5 path, for
+    comparison); every read is checked against the source columns; pyarrow's own
     multi-threaded read of the same file is the CPU yardstick.  Files live in a temporary directory (page cache)."""
     import shutil
     import tempfile
@@ -1259,6 +1260,12 @@ def scan_extra(pl, n: int):
             path = os.path.join(d, f"li_{codec}.parquet")
             pq.write_table(t, path, compression=codec, row_group_size=1 << 20)
             out["files"][f"parquet_{codec}"] = measure(pl.read_parquet, path, pq.read_table)
+            if codec == "zstd":
+                os.environ["PLX_PARQUET_ZSTD"] = "host"
+                try:
+                    out["files"]["parquet_zstd_host_threads"] = measure(pl.read_parquet, path, pq.read_table)
+                finally:
+                    del os.environ["PLX_PARQUET_ZSTD"]
             os.remove(path)
         path = os.path.join(d, "li.arrow")
         with ipc.new_file(path, t.schema) as w:

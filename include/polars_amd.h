@@ -509,8 +509,8 @@ int plx_datagen_long_id_views(int64_t n_rows, uint64_t seed, uint32_t stream, in
  *                               call on the same thread.
  *   plx_parquet_chunk_info      codec, bit mask of the page encodings, sizes, and the chunk statistics as scalars of the column's
  *                               dtype (has_min_max = 0 when absent or not usable, e.g. strings); null_count -1 = unknown
- *   plx_parquet_read            row_groups x columns -> frame (rows in row-group order as given).  Codecs: UNCOMPRESSED, SNAPPY (device
- *                               kernel), ZSTD, GZIP and LZ4_RAW (pages inflated by host threads with the library's own decoders, then the same kernels);
+ *   plx_parquet_read            row_groups x columns -> frame (rows in row-group order as given).  Codecs: UNCOMPRESSED, SNAPPY and ZSTD (device
+ *                               kernels), GZIP and LZ4_RAW (pages inflated by host threads with the library's own decoders, then the same kernels);
  *                               encodings: PLAIN (strings: see plx_parquet_column_strdict), PLAIN_DICTIONARY / RLE_DICTIONARY, RLE levels;
  *                               DELTA_BINARY_PACKED / BYTE_STREAM_SPLIT / DELTA_*_BYTE_ARRAY / INT96 (decoded by host threads);
  *                               data pages v1 and v2; anything else

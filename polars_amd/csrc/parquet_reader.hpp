@@ -391,8 +391,9 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
   struct SyncOnUnwind { B& b; int n = std::uncaught_exceptions(); ~SyncOnUnwind() { if (std::uncaught_exceptions() > n) b.discard_pending(); } } sync_on_unwind{be};
   size_t jobs_launched = 0, stored_since_launch = 0;
   static const size_t kSnappyBatch = [] { const char* e = getenv("PLX_PARQUET_SNAPPY_BATCH"); const long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : (size_t)-1; }();
-  // zstd: the same knob (PLX_PARQUET_ZSTD_BATCH, off by default).  Measured on the 2e7-row file: one launch 37-45 ms, 64 MB batches 44-48, 32 MB 51, 16 MB 72-90 -- every launch
-  // uploads its descriptor arrays and waits for the stream, which stalls the walk.
+  // zstd: the same knob (PLX_PARQUET_ZSTD_BATCH, off by default).  Measured on the 2e7-row file: one launch 31 ms; 64 MB batches 40-44, 32 MB 39-48, 16 MB 56-65 -- also with the
+  // uploads on a stream of their own and the descriptor arrays queued without a wait (tried, removed).  The passes are bound by their longest CHAIN (a block's sequences,
+  // a page's matches: milliseconds whatever the launch holds), so k launches one after the other on the column's stream cost k chains where one launch costs one.
   static const size_t kZstdBatch = [] { const char* e = getenv("PLX_PARQUET_ZSTD_BATCH"); const long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : (size_t)-1; }();
   ZstdPlan zplan;                                      // the zstd pages since the last launch, indexed while their stored bytes were at hand (parquet_zstd_index.hpp)
   std::vector<size_t> zjobs;                           // ... and their job indices, in the plan's stream order

@@ -588,13 +588,19 @@ template <class W> PLX_HD bool zstd_emit_literals(W& w, ZstdExecShared& sh, Zstd
   return true;
 }
 
-// the bytes of one match piece: byte t of [d, d + n) = byte d - off + (t mod off): sources below `floor` have left the ring and are read from HBM
-PLX_HD void zstd_copy_match(ZstdExecShared& sh, const uint8_t* dst, uint32_t d, uint32_t off, uint32_t n, uint32_t floor, uint32_t lane) {
+// the bytes of one match piece: byte t of [d, d + n) = byte d - off + (t mod off): sources below `floor` have left the ring and are read from HBM (dst_addr: the page's
+// output as an integer, made a global pointer where it is used: a pointer chosen between LDS and HBM would make every read a FLAT one)
+PLX_HD void zstd_copy_match(ZstdExecShared& sh, uint64_t dst_addr, uint32_t d, uint32_t off, uint32_t n, uint32_t floor, uint32_t lane) {
   const bool overlap = off < n;
   for (uint32_t t = lane; t < n; t += kZLanes) {
     const uint32_t q = d - off + (overlap ? t % off : t);
-    sh.ring[(d + t) & kZRingMask] = q >= floor ? sh.ring[q & kZRingMask] : dst[q];
+    if (q >= floor) sh.ring[(d + t) & kZRingMask] = sh.ring[q & kZRingMask];
   }
+  if (d - off < floor)
+    for (uint32_t t = lane; t < n; t += kZLanes) {
+      const uint32_t q = d - off + (overlap ? t % off : t);
+      if (q < floor) sh.ring[(d + t) & kZRingMask] = PQ_GPTR(const uint8_t, dst_addr)[q];
+    }
 }
 template <class W> PLX_HD bool zstd_emit_match(W& w, ZstdExecShared& sh, ZstdExecState& st, uint32_t off, uint32_t n) {
   if (off == 0 || off > st.cur - st.frame_start || n > st.cap - st.cur) return false;
@@ -602,7 +608,7 @@ template <class W> PLX_HD bool zstd_emit_match(W& w, ZstdExecShared& sh, ZstdExe
     const uint32_t piece = n < kZPiece ? n : kZPiece;
     zstd_room(w, sh, st, piece);
     const uint32_t cur = st.cur, floor = cur + piece > kZRing ? cur + piece - kZRing : 0;
-    const uint8_t* dst = st.dst;
+    const uint64_t dst = (uint64_t)st.dst;
     w.lanes([&](uint32_t lane) { zstd_copy_match(sh, dst, cur, off, piece, floor, lane); });
     w.sync();
     st.cur += piece; n -= piece;
@@ -697,7 +703,7 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
     w.sync();
     w.tick(2);
     if (sh.bad) return false;
-    const uint8_t* dst = st.dst;
+    const uint64_t dst = (uint64_t)st.dst;
     // matches in sequence order, four at a time: the parameters of the next four are read from LDS while these four copy (a match waits for ONE thing: the bytes it reads)
     uint32_t m[4][4];
     PLX_UNROLL_Z for (int j = 0; j < 4; j++) { m[j][0] = sh.b_m[j][0]; m[j][1] = sh.b_m[j][1]; m[j][2] = sh.b_m[j][2]; m[j][3] = sh.b_m[j][3]; }

@@ -6,7 +6,7 @@ row-group skipping by statistics: crates/polars-io/src/predicates.rs).  Here:
 
 * the DECODER is on the device (decoder="device", the default): the library parses the footer itself, the selected column chunks
   cross PCIe exactly as they are stored -- compressed and encoded -- and are decompressed / decoded in HBM
-  (`plx_parquet_*`, polars_amd/csrc/parquet*.{hpp,cpp} + kernels_parquet.hip; Snappy on the device, zstd / gzip / lz4-raw pages inflated by the
+  (`plx_parquet_*`, polars_amd/csrc/parquet*.{hpp,cpp} + kernels_parquet.hip; Snappy and Zstandard on the device, gzip / lz4-raw pages inflated by the
   library's own host threads first).  decoder="host" keeps the round-1 path (pyarrow decodes, Arrow buffers are uploaded) for files
   outside the device decoder's codecs / types (brotli, decimals, nested columns),
 * projection pushdown -- only the columns the plan reads are fetched (TPC-H Q1 touches 7 of lineitem's 16),
