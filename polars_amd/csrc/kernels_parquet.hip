@@ -11,6 +11,7 @@
 //
 // Bound: HBM / PCIe -- the decoded column is written once, the encoded bytes are read once or twice (Snappy output is re-read by the
 // decode pass); nothing here is arithmetic.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -321,16 +322,20 @@ template <bool TIMING> struct ZstdDevWave {
     return m ? (uint32_t)__ffsll((long long)m) - 1 : 64u;
   }
 };
-// one wavefront per kZGroups compressed blocks (index list: longest blocks first, so a wavefront's four are of a size)
+// one wavefront per kZHufGroups compressed blocks without sequences (the first n_huf of the index list), then one per kZGroups of the others (each part longest blocks
+// first, so a wavefront's blocks are of a size)
 template <bool TIMING>
-__global__ __launch_bounds__(kZLanes) void pq_zstd_entropy_kernel(ZstdBlock* __restrict__ blocks, const uint32_t* __restrict__ order, uint32_t n, const ZstdHufDesc* __restrict__ hufs,
-                                                                  const ZstdFseDesc* __restrict__ fses, unsigned long long* __restrict__ dbg) {
+__global__ __launch_bounds__(kZLanes) void pq_zstd_entropy_kernel(ZstdBlock* __restrict__ blocks, const uint32_t* __restrict__ order, uint32_t n, uint32_t n_huf, uint32_t waves_huf,
+                                                                  const ZstdHufDesc* __restrict__ hufs, const ZstdFseDesc* __restrict__ fses, unsigned long long* __restrict__ dbg) {
   extern __shared__ __align__(16) unsigned char zstd_lds[];
-  ZstdEntropyShared* shs = (ZstdEntropyShared*)zstd_lds;
-  const uint32_t first = blockIdx.x * kZGroups;
-  if (first >= n) return;
   ZstdDevWave<TIMING> w;
-  zstd_entropy_group(w, shs, blocks, order, first, n, hufs, fses);
+  if (blockIdx.x < waves_huf) {
+    zstd_huf_group(w, (ZstdHufShared*)zstd_lds, blocks, order, blockIdx.x * kZHufGroups, n_huf, hufs);
+  } else {
+    const uint32_t first = (blockIdx.x - waves_huf) * kZGroups;
+    if (first >= n - n_huf) return;
+    zstd_entropy_group(w, (ZstdEntropyShared*)zstd_lds, blocks, order + n_huf, first, n - n_huf, hufs, fses);
+  }
   w.report(dbg);
 }
 // one wavefront per page
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(kZLanes) void pq_zstd_execute_kernel(const ZstdStre
   if (!ok && threadIdx.x == 0) atomicOr(err, (uint32_t)PE_ZSTD);
   w.report(dbg + 8);
 }
-void pq_zstd(ZstdBlock* blocks, const uint32_t* order, uint32_t n_compressed, const ZstdHufDesc* hufs, const ZstdFseDesc* fses, const ZstdStream* streams, uint32_t n_streams,
+void pq_zstd(ZstdBlock* blocks, const uint32_t* order, uint32_t n_compressed, uint32_t n_huf_only, const ZstdHufDesc* hufs, const ZstdFseDesc* fses, const ZstdStream* streams, uint32_t n_streams,
              uint64_t bytes_in, uint64_t bytes_out, uint32_t* err) {
   static const bool timing = [] { const char* e = getenv("PLX_ZSTD_TIMING"); return e && e[0] == '1'; }();
   Buf dbg;
@@ -353,8 +358,8 @@ void pq_zstd(ZstdBlock* blocks, const uint32_t* order, uint32_t n_compressed, co
   unsigned long long* d = timing ? dbg->as<unsigned long long>() : nullptr;
   if (n_compressed) {
     ProfileScope ps("pq_zstd_entropy", bytes_in, n_compressed);
-    const uint32_t grid = (n_compressed + kZGroups - 1) / kZGroups;
-    const size_t lds = kZGroups * sizeof(ZstdEntropyShared);        // 4 x 17 KB: beyond the 64 KB a kernel gets without asking
+    const uint32_t waves_huf = (n_huf_only + kZHufGroups - 1) / kZHufGroups, grid = waves_huf + (n_compressed - n_huf_only + kZGroups - 1) / kZGroups;
+    const size_t lds = std::max(kZGroups * sizeof(ZstdEntropyShared), kZHufGroups * sizeof(ZstdHufShared));        // 4 x 17 KB / 16 x 4.6 KB: beyond the 64 KB a kernel gets without asking
     static bool attr_set[2] = {false, false};
     if (!attr_set[timing ? 1 : 0]) {
       if (timing) (void)hipFuncSetAttribute((const void*)pq_zstd_entropy_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -362,8 +367,8 @@ void pq_zstd(ZstdBlock* blocks, const uint32_t* order, uint32_t n_compressed, co
       (void)hipGetLastError();
       attr_set[timing ? 1 : 0] = true;
     }
-    if (timing) hipLaunchKernelGGL(pq_zstd_entropy_kernel<true>, dim3(grid), dim3(kZLanes), lds, stream(), blocks, order, n_compressed, hufs, fses, d);
-    else hipLaunchKernelGGL(pq_zstd_entropy_kernel<false>, dim3(grid), dim3(kZLanes), lds, stream(), blocks, order, n_compressed, hufs, fses, d);
+    if (timing) hipLaunchKernelGGL(pq_zstd_entropy_kernel<true>, dim3(grid), dim3(kZLanes), lds, stream(), blocks, order, n_compressed, n_huf_only, waves_huf, hufs, fses, d);
+    else hipLaunchKernelGGL(pq_zstd_entropy_kernel<false>, dim3(grid), dim3(kZLanes), lds, stream(), blocks, order, n_compressed, n_huf_only, waves_huf, hufs, fses, d);
     PLX_HIP(hipGetLastError());
   }
   if (n_streams) {

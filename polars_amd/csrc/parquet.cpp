@@ -89,9 +89,9 @@ struct HipBackend {
   void scan_u32(const uint32_t* in, uint64_t* out, int64_t n) { k::exclusive_scan_u32(in, out, n); }
 
   void run_snappy(const pq::DecompJob* jobs, uint32_t n, uint64_t bytes_out, uint32_t* err) { k::pq_snappy(jobs, n, bytes_out, err); }
-  void run_zstd(pq::ZstdBlock* blocks, const uint32_t* order, uint32_t n_compressed, const pq::ZstdHufDesc* hufs, const pq::ZstdFseDesc* fses, const pq::ZstdStream* streams,
+  void run_zstd(pq::ZstdBlock* blocks, const uint32_t* order, uint32_t n_compressed, uint32_t n_huf_only, const pq::ZstdHufDesc* hufs, const pq::ZstdFseDesc* fses, const pq::ZstdStream* streams,
                 uint32_t n_streams, uint64_t bytes_in, uint64_t bytes_out, uint32_t* err) {
-    k::pq_zstd(blocks, order, n_compressed, hufs, fses, streams, n_streams, bytes_in, bytes_out, err);
+    k::pq_zstd(blocks, order, n_compressed, n_huf_only, hufs, fses, streams, n_streams, bytes_in, bytes_out, err);
   }
   void run_page_prepare(pq::PageDesc* pages, uint32_t n, uint32_t* err) { k::pq_page_prepare(pages, n, err); }
   void run_count_runs(const pq::PageDesc* pages, uint32_t n, bool with_levels, uint32_t* counts, uint32_t* err) { k::pq_count_runs(pages, n, with_levels, counts, err); }

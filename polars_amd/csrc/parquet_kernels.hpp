@@ -7,7 +7,7 @@
 namespace plx {
 namespace k {
 void pq_snappy(const pq::DecompJob* jobs, uint32_t n_jobs, uint64_t bytes_out, uint32_t* err);
-void pq_zstd(pq::ZstdBlock* blocks, const uint32_t* order, uint32_t n_compressed, const pq::ZstdHufDesc* hufs, const pq::ZstdFseDesc* fses, const pq::ZstdStream* streams,
+void pq_zstd(pq::ZstdBlock* blocks, const uint32_t* order, uint32_t n_compressed, uint32_t n_huf_only, const pq::ZstdHufDesc* hufs, const pq::ZstdFseDesc* fses, const pq::ZstdStream* streams,
              uint32_t n_streams, uint64_t bytes_in, uint64_t bytes_out, uint32_t* err);
 void pq_page_prepare(pq::PageDesc* pages, uint32_t n_pages, uint32_t* err);
 void pq_count_runs(const pq::PageDesc* pages, uint32_t n_pages, bool levels, uint32_t* counts, uint32_t* err);

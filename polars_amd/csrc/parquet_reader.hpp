@@ -432,7 +432,8 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
       for (size_t i = 0; i < zjobs.size(); i++) { zplan.streams[i].dst = jobs[zjobs[i]].dst; z_in += jobs[zjobs[i]].comp_size; z_out += jobs[zjobs[i]].uncomp_size; }
       typename B::Mem lit = be.alloc((size_t)zplan.lit_bytes + 64), seq = be.alloc((size_t)zplan.n_seq * 16 + 64);
       zstd_plan_place(zplan, be.addr(lit), be.addr(seq));
-      const std::vector<uint32_t> order_idx = zstd_plan_order(zplan);
+      uint32_t n_huf_only = 0;
+      const std::vector<uint32_t> order_idx = zstd_plan_order(zplan, &n_huf_only);
       const size_t nb = zplan.blocks.size() * sizeof(ZstdBlock), no = order_idx.size() * 4, nh = zplan.hufs.size() * sizeof(ZstdHufDesc), nf = zplan.fses.size() * sizeof(ZstdFseDesc),
                    ns = zplan.streams.size() * sizeof(ZstdStream);
       const size_t ob = 0, oo = align16(ob + nb), oh = align16(oo + no), of = align16(oh + nh), os = align16(of + nf), all = align16(os + ns);
@@ -445,7 +446,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
       typename B::Mem zm = be.alloc(all + 64);
       const uint64_t za = be.addr(zm);
       be.upload_small(za, image.data(), all);
-      be.run_zstd((ZstdBlock*)(za + ob), (const uint32_t*)(za + oo), (uint32_t)order_idx.size(), (const ZstdHufDesc*)(za + oh), (const ZstdFseDesc*)(za + of), (const ZstdStream*)(za + os),
+      be.run_zstd((ZstdBlock*)(za + ob), (const uint32_t*)(za + oo), (uint32_t)order_idx.size(), n_huf_only, (const ZstdHufDesc*)(za + oh), (const ZstdFseDesc*)(za + of), (const ZstdStream*)(za + os),
                   (uint32_t)zplan.streams.size(), z_in, z_out, err);
       if (stats) { stats->zstd_streams += zplan.streams.size(); stats->zstd_blocks += zplan.blocks.size(); stats->zstd_bytes_out += z_out; }
       snappy_mem.push_back(lit); snappy_mem.push_back(seq); snappy_mem.push_back(zm);

@@ -46,6 +46,8 @@ constexpr uint32_t kZOfMask = (1u << 30) - 1;    // repeat-offset maps (execute 
 constexpr uint32_t kZBlockMax = 128 * 1024;
 constexpr uint32_t kZGroups = 4;                 // entropy pass: blocks per wavefront (a block's chains run on single lanes: four blocks share the instruction stream)
 constexpr uint32_t kZGroupLanes = kZLanes / kZGroups;
+constexpr uint32_t kZHufGroups = 16;             // ... blocks without sequences (Huffman literals only: 4.6 KB of LDS each): sixteen a wavefront, four lanes each
+constexpr uint32_t kZHufGroupLanes = kZLanes / kZHufGroups;
 constexpr uint32_t kZStageWords = 256;           // 8-byte words of a sequence bit stream staged in LDS at a time (+ 2 below them)
 
 #if defined(__clang__)
@@ -94,7 +96,9 @@ struct ZstdBlock {         // one block of a frame
   uint32_t tab[3];         // index of the ZstdFseDesc in force: literal lengths, offsets, match lengths
   uint8_t type, lit_type, lit_streams, first_in_frame;
   // ---- written by the entropy pass ----
-  uint32_t pad1[3];
+  uint32_t direct;         // the page holds nothing but such blocks: `lit` is the block's place in the page's output, the execute pass has nothing to do
+  uint32_t page_off;       // ... and this is its offset there
+  uint32_t pad1;
   uint32_t lit_used;       // literal bytes the sequences consume
   uint32_t bad;
   uint32_t pad;
@@ -104,7 +108,7 @@ struct ZstdStream {        // one compressed page (or dictionary page): frames b
   uint64_t dst;
   uint32_t uncomp_size;
   uint32_t first_block, n_blocks;
-  uint32_t pad;
+  uint32_t direct;         // every block is a compressed block of Huffman literals without sequences: decoded in place by the entropy pass
 };
 
 // ---- bit streams ---------------------------------------------------------------------------------------------------------------------------
@@ -151,6 +155,13 @@ struct ZstdEntropyShared {
   uint32_t bad;
 };
 
+// what a block WITHOUT sequences needs of it
+struct ZstdHufShared {
+  uint16_t huf[2048];
+  uint16_t huf_start[256];
+  uint32_t bad;
+};
+
 // sequence code -> base value / extra bits (RFC 8878 3.1.1.3.2.1.1)
 PLX_HD uint32_t z_ll_base(uint32_t c) { return c < 16 ? c : c < 20 ? 16 + 2 * (c - 16) : c < 22 ? 24 + 4 * (c - 20) : c < 24 ? 32 + 8 * (c - 22) : c == 24 ? 48 : (uint32_t)64 << (c - 25); }
 PLX_HD uint32_t z_ll_bits(uint32_t c) { return c < 16 ? 0 : c < 20 ? 1 : c < 22 ? 2 : c < 24 ? 3 : c == 24 ? 4 : c - 19; }
@@ -166,7 +177,7 @@ PLX_HD uint32_t z_ml_base(uint32_t c) {
 }
 
 // lane 0: where every symbol's codes start (codes of one length are consecutive, symbols ascending, longest codes first: 4.2.1)
-PLX_HD void zstd_huf_starts(ZstdEntropyShared& sh, const ZstdHufDesc& d) {
+template <class SH> PLX_HD void zstd_huf_starts(SH& sh, const ZstdHufDesc& d) {
   uint32_t rank_count[13], rank_idx[13];
   const uint32_t mb = d.max_bits < 1 ? 1 : d.max_bits > 11 ? 11 : d.max_bits, nsym = d.nsym > 256 ? 256 : d.nsym;
   for (uint32_t i = 0; i <= 12; i++) rank_count[i] = 0;
@@ -181,7 +192,7 @@ PLX_HD void zstd_huf_starts(ZstdEntropyShared& sh, const ZstdHufDesc& d) {
   }
 }
 // every lane: the table entries of its symbols
-PLX_HD void zstd_huf_fill(ZstdEntropyShared& sh, const ZstdHufDesc& d, uint32_t lane, uint32_t lanes) {
+template <class SH> PLX_HD void zstd_huf_fill(SH& sh, const ZstdHufDesc& d, uint32_t lane, uint32_t lanes) {
   const uint32_t mb = d.max_bits < 1 ? 1 : d.max_bits > 11 ? 11 : d.max_bits, nsym = d.nsym > 256 ? 256 : d.nsym;
   for (uint32_t s = lane; s < nsym; s += lanes) {
     const uint32_t st = sh.huf_start[s];
@@ -231,7 +242,7 @@ PLX_HD bool zstd_huf_stream(const uint16_t* tbl, uint32_t mb, const uint8_t* p, 
 }
 
 // lanes 0 .. streams - 1: the block's Huffman-coded literals
-PLX_HD void zstd_huf_decode(ZstdEntropyShared& sh, const ZstdBlock& blk, const ZstdHufDesc& d, uint32_t lane) {
+template <class SH> PLX_HD void zstd_huf_decode(SH& sh, const ZstdBlock& blk, const ZstdHufDesc& d, uint32_t lane) {
   if (lane >= blk.lit_streams) return;
   const uint8_t* p = PQ_GPTR(const uint8_t, blk.src) + blk.huf_off;
   uint8_t* out = PQ_GPTR(uint8_t, blk.lit);
@@ -524,6 +535,32 @@ template <class W> PLX_HD void zstd_entropy_group(W& w, ZstdEntropyShared* shs, 
   });
 }
 
+// kZHufGroups blocks WITHOUT sequences, one wavefront: group g (lanes 4 g .. 4 g + 3) takes block order[first + g] -- its Huffman table, then its (up to four) streams
+template <class W> PLX_HD void zstd_huf_group(W& w, ZstdHufShared* shs, ZstdBlock* blocks, const uint32_t* order, uint32_t first, uint32_t n, const ZstdHufDesc* hufs) {
+  auto block_of = [&](uint32_t lane) -> ZstdBlock* { const uint32_t g = lane / kZHufGroupLanes; return first + g < n ? &blocks[order[first + g]] : nullptr; };
+  w.lanes([&](uint32_t lane) {
+    ZstdBlock* blk = block_of(lane);
+    if (blk && lane % kZHufGroupLanes == 0) { ZstdHufShared& sh = shs[lane / kZHufGroupLanes]; sh.bad = 0; zstd_huf_starts(sh, hufs[blk->huf]); }
+  });
+  w.sync();
+  w.lanes([&](uint32_t lane) {
+    ZstdBlock* blk = block_of(lane);
+    if (blk) zstd_huf_fill(shs[lane / kZHufGroupLanes], hufs[blk->huf], lane % kZHufGroupLanes, kZHufGroupLanes);
+  });
+  w.sync();
+  w.tick(0);
+  w.lanes([&](uint32_t lane) {
+    ZstdBlock* blk = block_of(lane);
+    if (blk) zstd_huf_decode(shs[lane / kZHufGroupLanes], *blk, hufs[blk->huf], lane % kZHufGroupLanes);
+  });
+  w.sync();
+  w.tick(1);
+  w.lanes([&](uint32_t lane) {
+    ZstdBlock* blk = block_of(lane);
+    if (blk && lane % kZHufGroupLanes == 0) { blk->lit_used = 0; blk->out_len = blk->regen; blk->bad = shs[lane / kZHufGroupLanes].bad; }
+  });
+}
+
 // ---- execute pass --------------------------------------------------------------------------------------------------------------------------
 struct ZstdExecShared {
   alignas(16) uint8_t ring[kZRing];
@@ -736,6 +773,10 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
 
 // one page: its blocks in order; false = malformed
 template <class W> PLX_HD bool zstd_exec_stream(W& w, ZstdExecShared& sh, const ZstdStream& s, const ZstdBlock* blocks) {
+  if (s.direct) {            // decoded in place by the entropy pass: only its verdict is left to collect
+    for (uint32_t b = 0; b < s.n_blocks; b++) if (blocks[s.first_block + b].bad) return false;
+    return true;
+  }
   ZstdExecState st;
   st.dst = PQ_GPTR(uint8_t, s.dst); st.cap = s.uncomp_size; st.cur = 0; st.flushed = 0; st.frame_start = 0;
   st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8;

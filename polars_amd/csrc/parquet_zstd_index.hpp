@@ -248,24 +248,56 @@ inline void zstd_index_stream(ZstdPlan& plan, const uint8_t* in, size_t n, uint6
     if (checksum) { if (n - ip < 4) throw CodecError("zstd: truncated checksum"); ip += 4; }
   }
   s.n_blocks = (uint32_t)plan.blocks.size() - s.first_block;
+  // a page of nothing but sequence-free blocks of Huffman literals (prices, timestamps: zstd finds no matches in them) is decoded IN PLACE: the sizes are all in the headers
+  {
+    bool direct = s.n_blocks > 0;
+    uint64_t total = 0;
+    for (uint32_t b = 0; b < s.n_blocks; b++) {
+      const ZstdBlock& k = plan.blocks[s.first_block + b];
+      direct = direct && k.type == ZB_COMPRESSED && k.nseq == 0 && k.lit_type == ZL_HUFFMAN;
+      total += k.regen;
+    }
+    if (direct) {
+      if (total != uncomp_size) throw CodecError("zstd: frames decode to a different length than the page header says");
+      uint32_t off = 0;
+      for (uint32_t b = 0; b < s.n_blocks; b++) {
+        ZstdBlock& k = plan.blocks[s.first_block + b];
+        // (its slice of the literal scratch goes unused: a few KB per page)
+        k.direct = 1; k.page_off = off;
+        off += k.regen;
+      }
+      s.direct = 1;
+    }
+  }
   plan.streams.push_back(s);
 }
 
-// scratch addresses into the records (once the launch has allocated the literal buffers and the sequence records)
+// scratch addresses into the records (once the launch has allocated the literal buffers, the sequence records and the pages' outputs: streams[i].dst)
 inline void zstd_plan_place(ZstdPlan& plan, uint64_t lit_base, uint64_t seq_base) {
-  for (ZstdBlock& b : plan.blocks) {
-    if (b.type != ZB_COMPRESSED) continue;
-    if (b.lit_type == ZL_HUFFMAN) b.lit += lit_base;
-    b.seq = seq_base + b.seq * 16;
-  }
+  for (const ZstdStream& st : plan.streams)
+    for (uint32_t b = 0; b < st.n_blocks; b++) {
+      ZstdBlock& k = plan.blocks[st.first_block + b];
+      if (k.type != ZB_COMPRESSED) continue;
+      if (k.direct) k.lit = st.dst + k.page_off;
+      else if (k.lit_type == ZL_HUFFMAN) k.lit += lit_base;
+      k.seq = seq_base + k.seq * 16;
+    }
 }
-// indices of the compressed blocks, longest first (one wavefront each; a launch lasts as long as its longest block started last)
-inline std::vector<uint32_t> zstd_plan_order(const ZstdPlan& plan) {
-  std::vector<uint32_t> idx;
-  idx.reserve(plan.n_compressed);
-  for (size_t i = 0; i < plan.blocks.size(); i++) if (plan.blocks[i].type == ZB_COMPRESSED) idx.push_back((uint32_t)i);
-  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return plan.blocks[a].src_len > plan.blocks[b].src_len; });
-  return idx;
+// indices of the compressed blocks: first the blocks without sequences (Huffman literals only: sixteen a wavefront), then the others (four a wavefront); each part longest
+// first (a launch lasts as long as its longest block started last, and a wavefront's blocks should be of a size)
+inline std::vector<uint32_t> zstd_plan_order(const ZstdPlan& plan, uint32_t* n_huf_only) {
+  std::vector<uint32_t> h, o;
+  for (size_t i = 0; i < plan.blocks.size(); i++) {
+    const ZstdBlock& k = plan.blocks[i];
+    if (k.type != ZB_COMPRESSED) continue;
+    (k.nseq == 0 && k.lit_type == ZL_HUFFMAN ? h : o).push_back((uint32_t)i);
+  }
+  auto longer = [&](uint32_t a, uint32_t b) { return plan.blocks[a].src_len > plan.blocks[b].src_len; };
+  std::stable_sort(h.begin(), h.end(), longer);
+  std::stable_sort(o.begin(), o.end(), longer);
+  *n_huf_only = (uint32_t)h.size();
+  h.insert(h.end(), o.begin(), o.end());
+  return h;
 }
 
 }  // namespace pq

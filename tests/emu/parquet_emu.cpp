@@ -89,7 +89,7 @@ struct EmuWave {
   uint32_t first_flag(const uint32_t* flag) { for (uint32_t l = 0; l < kZLanes; l++) if (flag[l]) return l; return kZLanes; }
 };
 // pq_zstd_entropy + pq_zstd_execute (kernels_parquet.hip) as loops: one wavefront per compressed block, then one per page; returns PE_ZSTD or 0
-uint32_t zstd_run(ZstdBlock* blocks, const uint32_t* order_idx, uint32_t n_compressed, const ZstdHufDesc* hufs, const ZstdFseDesc* fses, const ZstdStream* streams, uint32_t n_streams,
+uint32_t zstd_run(ZstdBlock* blocks, const uint32_t* order_idx, uint32_t n_compressed, uint32_t n_huf_only, const ZstdHufDesc* hufs, const ZstdFseDesc* fses, const ZstdStream* streams, uint32_t n_streams,
                   int order) {
   EmuWave w;
   w.order = order;
@@ -98,10 +98,18 @@ uint32_t zstd_run(ZstdBlock* blocks, const uint32_t* order_idx, uint32_t n_compr
     if (order == 0) for (size_t i = 0; i < n; i++) f(i);
     else for (size_t i = n; i-- > 0;) f(i);
   };
-  each((n_compressed + kZGroups - 1) / kZGroups, [&](size_t i) {
-    auto sh = std::make_unique<ZstdEntropyShared[]>(kZGroups);
-    memset(sh.get(), 0xA5, sizeof(ZstdEntropyShared) * kZGroups);     // LDS is not zeroed
-    zstd_entropy_group(w, sh.get(), blocks, order_idx, (uint32_t)(i * kZGroups), n_compressed, hufs, fses);
+  // the grid of pq_zstd_entropy_kernel: wavefronts of sixteen sequence-free blocks first, then wavefronts of four blocks
+  const uint32_t waves_h = (n_huf_only + kZHufGroups - 1) / kZHufGroups, n_other = n_compressed - n_huf_only, waves_o = (n_other + kZGroups - 1) / kZGroups;
+  each(waves_h + waves_o, [&](size_t i) {
+    if (i < waves_h) {
+      auto sh = std::make_unique<ZstdHufShared[]>(kZHufGroups);
+      memset(sh.get(), 0xA5, sizeof(ZstdHufShared) * kZHufGroups);     // LDS is not zeroed
+      zstd_huf_group(w, sh.get(), blocks, order_idx, (uint32_t)(i * kZHufGroups), n_huf_only, hufs);
+    } else {
+      auto sh = std::make_unique<ZstdEntropyShared[]>(kZGroups);
+      memset(sh.get(), 0xA5, sizeof(ZstdEntropyShared) * kZGroups);
+      zstd_entropy_group(w, sh.get(), blocks, order_idx + n_huf_only, (uint32_t)((i - waves_h) * kZGroups), n_other, hufs, fses);
+    }
   });
   each(n_streams, [&](size_t i) {
     auto sh = std::make_unique<ZstdExecShared>();
@@ -178,9 +186,9 @@ struct HostBackend {
   void run_snappy(const DecompJob* jobs, uint32_t n, uint64_t, uint32_t* err) {
     for_threads(n, [&](uint64_t j) { *err |= snappy_stream(jobs[j], order, nullptr); });
   }
-  void run_zstd(ZstdBlock* blocks, const uint32_t* order_idx, uint32_t n_compressed, const ZstdHufDesc* hufs, const ZstdFseDesc* fses, const ZstdStream* streams, uint32_t n_streams,
+  void run_zstd(ZstdBlock* blocks, const uint32_t* order_idx, uint32_t n_compressed, uint32_t n_huf_only, const ZstdHufDesc* hufs, const ZstdFseDesc* fses, const ZstdStream* streams, uint32_t n_streams,
                 uint64_t, uint64_t, uint32_t* err) {
-    *err |= zstd_run(blocks, order_idx, n_compressed, hufs, fses, streams, n_streams, order);
+    *err |= zstd_run(blocks, order_idx, n_compressed, n_huf_only, hufs, fses, streams, n_streams, order);
   }
   void run_page_prepare(PageDesc* pages, uint32_t n, uint32_t* err) { for_threads(n, [&](uint64_t i) { *err |= page_prepare(pages[i]); }); }
   void run_count_runs(const PageDesc* pages, uint32_t n, bool levels, uint32_t* counts, uint32_t* err) {
@@ -287,8 +295,9 @@ int pqemu_zstd(const uint8_t* in, uint32_t n_in, uint8_t* out, uint32_t n_out, i
     plan.streams[0].dst = (uint64_t)dst.data();
     zstd_plan_place(plan, (uint64_t)lits.data(), (uint64_t)seqs.data());
     if (counts) { counts[0] = (uint32_t)plan.blocks.size(); counts[1] = (uint32_t)plan.n_compressed; counts[2] = (uint32_t)plan.n_seq; counts[3] = (uint32_t)plan.hufs.size(); counts[4] = (uint32_t)plan.fses.size(); }
-    const std::vector<uint32_t> order_idx = zstd_plan_order(plan);
-    const uint32_t err = zstd_run(plan.blocks.data(), order_idx.data(), (uint32_t)order_idx.size(), plan.hufs.data(), plan.fses.data(), plan.streams.data(), 1, thread_order);
+    uint32_t n_huf_only = 0;
+    const std::vector<uint32_t> order_idx = zstd_plan_order(plan, &n_huf_only);
+    const uint32_t err = zstd_run(plan.blocks.data(), order_idx.data(), (uint32_t)order_idx.size(), n_huf_only, plan.hufs.data(), plan.fses.data(), plan.streams.data(), 1, thread_order);
     if (n_out) memcpy(out, dst.data(), n_out);
     return (int)err;
   } catch (const std::exception& e) { t_err = e.what(); return -1; }
