@@ -381,7 +381,7 @@ void pq_zstd(ZstdBlock* blocks, const uint32_t* order, uint32_t n_compressed, ui
     unsigned long long h[16];
     d2h_sync(h, dbg->ptr, sizeof h);
     fprintf(stderr, "[pq_zstd] blocks=%u pages=%u in=%.1f MB out=%.1f MB; 100 MHz ticks summed over wavefronts: entropy huf_build=%llu huf_decode=%llu fse_build=%llu stage=%llu seq=%llu (sequences=%llu) | "
-            "execute plan=%llu room=%llu literals=%llu matches=%llu long/raw=%llu (sequences in batches=%llu, long=%llu, batches=%llu)\n",
+            "execute plan=%llu room=%llu literals=%llu matches=%llu long/raw=%llu (sequences in batches=%llu, batches resolved then copied at once=%llu, batches=%llu)\n",
             n_compressed, n_streams, bytes_in / 1e6, bytes_out / 1e6, h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
   }
 }

@@ -569,6 +569,8 @@ struct ZstdExecShared {
   uint32_t b_r0[kZLanes], b_r1[kZLanes], b_r2[kZLanes];      // repeat-offset maps: the sequence's own, then (scan) of the batch up to and including it
   uint32_t b_lit[kZLanes], b_out[kZLanes];                   // exclusive prefixes: literal bytes / output bytes before the sequence
   uint32_t b_flag[kZLanes];                                  // the sequence does not fit the fast path (or the batch)
+  uint32_t b_src[kZLanes];                                   // resolve-then-copy: where the match's bytes really come from (an output position)
+  int32_t b_par[kZLanes];                                    // ... the earlier match of the batch whose bytes it copies, or -1
   uint32_t bad;
 };
 
@@ -713,7 +715,7 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
       if (!zstd_emit_match(w, sh, st, off, ml)) return false;
       { const uint32_t r1 = zstd_rep_through(sh.b_r1[0], rep_in), r2 = zstd_rep_through(sh.b_r2[0], rep_in); st.rep[0] = off; st.rep[1] = r1; st.rep[2] = r2; }
       base += 1;
-      w.tick(4); w.count(6, 1);
+      w.tick(4);
       continue;
     }
     const uint32_t span = sh.b_out[cnt - 1] + sh.b_ll[cnt - 1] + sh.b_ml[cnt - 1], lit_span = sh.b_lit[cnt - 1] + sh.b_ll[cnt - 1];
@@ -741,10 +743,71 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
     w.tick(2);
     if (sh.bad) return false;
     const uint64_t dst = (uint64_t)st.dst;
+    // RESOLVE, THEN COPY.  On sorted keys every match copies what the match before it wrote (the key's high bytes, offset 8): in sequence order that is 64 LDS round trips a
+    // batch.  But a match that lies inside an earlier match of the batch only repeats that match's SOURCE: follow the chain in the index domain -- the earlier match by binary
+    // search over the sequence starts, then pointer doubling (source += the parent's shift, parent = the parent's parent: 6 rounds for 64) -- and when every source lies in
+    // literals or in earlier output, all matches copy at once.  Taken when every match of the batch is a one-step match whose bytes come from ONE place (not across the border
+    // of a literal run and a match); anything else runs in sequence order below.
+    bool parallel = false;
+    if (cnt >= 8) {
+      w.lanes([&](uint32_t lane) {
+        uint32_t flag = 0, src = 0;
+        int32_t par = -1;
+        if (lane < cnt) {
+          const uint32_t dm = cur + sh.b_m[lane][0], off = sh.b_m[lane][1], n = sh.b_m[lane][2];
+          if (!sh.b_m[lane][3]) flag = 1;
+          else {
+            src = dm - off;
+            if (src + n <= cur) par = -1;                  // earlier output
+            else if (src < cur) flag = 1;                  // across the batch's start
+            else {
+              uint32_t lo = 0, hi = lane;                  // the last sequence that starts at or below src (starts ascend; sequence 0 starts at cur <= src)
+              while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (cur + sh.b_out[mid] <= src) lo = mid; else hi = mid - 1; }
+              const uint32_t dmj = cur + sh.b_m[lo][0], nj = sh.b_m[lo][2];
+              if (src >= dmj) { if (lo < lane && src + n <= dmj + nj) par = (int32_t)lo; else flag = 1; }       // inside that sequence's match
+              else if (src + n > dmj) flag = 1;            // across its literal run and its match
+            }
+          }
+        }
+        sh.b_src[lane] = src; sh.b_par[lane] = par; sh.b_flag[lane] = flag;
+      });
+      w.sync();
+      parallel = w.first_flag(sh.b_flag) == kZLanes;
+      for (uint32_t round = 0; parallel && round < 6; round++) {
+        w.lanes([&](uint32_t lane) { sh.b_flag[lane] = lane < cnt && sh.b_par[lane] >= 0; });
+        w.sync();
+        if (w.first_flag(sh.b_flag) == kZLanes) break;
+        struct Hop { uint32_t src; int32_t par; };
+        ZLaneVar<Hop> hop;
+        w.lanes([&](uint32_t lane) {
+          Hop h = {sh.b_src[lane], sh.b_par[lane]};
+          if (lane < cnt && h.par >= 0) { const uint32_t p = (uint32_t)h.par; h.src = sh.b_src[p] + (h.src - (cur + sh.b_m[p][0])); h.par = sh.b_par[p]; }
+          hop[lane] = h;
+        });
+        w.sync();
+        w.lanes([&](uint32_t lane) { sh.b_src[lane] = hop[lane].src; sh.b_par[lane] = hop[lane].par; });
+        w.sync();
+      }
+      if (parallel) {
+        w.lanes([&](uint32_t lane) { sh.b_flag[lane] = lane < cnt && (sh.b_par[lane] >= 0 || sh.b_src[lane] < floor); });       // (a source that has left the ring: rare, in order below)
+        w.sync();
+        parallel = w.first_flag(sh.b_flag) == kZLanes;
+      }
+      if (parallel) {
+        w.lanes([&](uint32_t lane) {
+          if (lane < cnt) {
+            const uint32_t dm = cur + sh.b_m[lane][0], n = sh.b_m[lane][2], src = sh.b_src[lane];
+            for (uint32_t t = 0; t < n; t++) sh.ring[(dm + t) & kZRingMask] = sh.ring[(src + t) & kZRingMask];
+          }
+        });
+        w.count(6, 1);
+        ZDBG("resolved batch of %u\n", cnt);
+      }
+    }
     // matches in sequence order, four at a time: the parameters of the next four are read from LDS while these four copy (a match waits for ONE thing: the bytes it reads)
     uint32_t m[4][4];
     PLX_UNROLL_Z for (int j = 0; j < 4; j++) { m[j][0] = sh.b_m[j][0]; m[j][1] = sh.b_m[j][1]; m[j][2] = sh.b_m[j][2]; m[j][3] = sh.b_m[j][3]; }
-    for (uint32_t k = 0; k < cnt; k += 4) {
+    for (uint32_t k = parallel ? cnt : 0; k < cnt; k += 4) {
       uint32_t q[4][4];
       PLX_UNROLL_Z for (int j = 0; j < 4; j++) { q[j][0] = w.uniform(m[j][0]); q[j][1] = w.uniform(m[j][1]); q[j][2] = w.uniform(m[j][2]); q[j][3] = w.uniform(m[j][3]); }
       if (k + 4 < cnt) {

@@ -818,3 +818,37 @@ def test_zstd_pages_take_the_device_passes(tmp_path, monkeypatch, version, dicti
     for name in t.column_names:
         r = check_column(path, t, name)
         assert r["stats"]["zstd_streams"] == 0, name
+
+
+def test_long_zstd_dictionary_pages_are_inflated_by_host_threads(tmp_path, monkeypatch):
+    """The same switch for zstd: a page's execute pass is one wavefront walking its sequences in order, and a 480 KB dictionary of sorted values is tens of thousands of
+    them.  The data pages stay streams of the device passes; with the switch off the dictionary pages are streams too."""
+    rng = np.random.default_rng(8)
+    n = 120_000
+    vals = np.sort(rng.integers(0, 60_000, n)).astype(np.int64) * 1_000_003
+    t = pa.table({"big": vals, "small": rng.integers(0, 50, n).astype(np.int32)})
+    path = str(tmp_path / "d.parquet")
+    pq.write_table(t, path, compression="zstd", row_group_size=60_000, dictionary_pagesize_limit=4 << 20)
+    r = check_column(path, t, "big")
+    assert r["stats"]["host_inflated_pages"] == 2 and r["stats"]["zstd_streams"] > 0, r["stats"]
+    assert check_column(path, t, "small")["stats"]["host_inflated_pages"] == 0
+    monkeypatch.setenv("PLX_PARQUET_HOST_DICT_BYTES", "0")
+    r0 = check_column(path, t, "big")
+    assert r0["stats"]["host_inflated_pages"] == 0 and r0["stats"]["zstd_streams"] == r["stats"]["zstd_streams"] + 2
+
+
+def test_zstd_match_chains_resolved_before_they_are_copied():
+    """The execute pass' resolve-then-copy path (a batch whose matches copy what earlier matches of the batch wrote: sorted keys, dictionaries in first-appearance order)
+    next to batches it must leave to the in-order loop: overlapping matches (runs), matches across a literal run and a match (text), long matches.  Interleaved
+    in one stream so that batches of both kinds follow each other and share the LDS ring."""
+    rng = np.random.default_rng(21)
+    keys = np.sort(rng.integers(0, 1 << 40, 40_000)).astype(np.int64).tobytes()
+    firsts = rng.integers(0, 1 << 30, 40_000).astype(np.int64).tobytes()
+    runs = np.repeat(rng.integers(0, 256, 2000, dtype=np.uint8), 37).tobytes()
+    text = b"the quick brown fox jumps over the lazy dog. " * 900
+    p = b"".join(x[i * 8000:(i + 1) * 8000] for i in range(5) for x in (keys, runs, firsts, text))
+    for lvl in (1, 3, 9):
+        c = pa.Codec("zstd", compression_level=lvl).compress(p, asbytes=True)
+        for order in (0, 1):
+            rc, out, counts, err = E.zstd_device(c, len(p), order)
+            assert rc == 0 and out == p, (lvl, order, rc, counts, err)
