@@ -316,6 +316,7 @@ template <bool TIMING> struct ZstdDevWave {
     lit[lane] = l - l0; out[lane] = o - o0;
     r0[lane] = m.s[0]; r1[lane] = m.s[1]; r2[lane] = m.s[2];
   }
+  template <class F> __device__ __forceinline__ uint64_t ballot(F&& pred) { return (uint64_t)__ballot(pred((uint32_t)threadIdx.x) ? 1 : 0); }
   // index of the first nonzero flag[lane]; 64 if there is none
   __device__ __forceinline__ uint32_t first_flag(const uint32_t* flag) {
     const unsigned long long m = __ballot(flag[threadIdx.x] != 0);

@@ -48,6 +48,7 @@ constexpr uint32_t kZGroups = 4;                 // entropy pass: blocks per wav
 constexpr uint32_t kZGroupLanes = kZLanes / kZGroups;
 constexpr uint32_t kZHufGroups = 16;             // ... blocks without sequences (Huffman literals only: 4.6 KB of LDS each): sixteen a wavefront, four lanes each
 constexpr uint32_t kZHufGroupLanes = kZLanes / kZHufGroups;
+constexpr uint32_t kZRowWidth = 32;              // execute pass: widest fixed-width value whose batches take the row path
 constexpr uint32_t kZStageWords = 256;           // 8-byte words of a sequence bit stream staged in LDS at a time (+ 2 below them)
 
 #if defined(__clang__)
@@ -569,6 +570,7 @@ struct ZstdExecShared {
   uint32_t b_r0[kZLanes], b_r1[kZLanes], b_r2[kZLanes];      // repeat-offset maps: the sequence's own, then (scan) of the batch up to and including it
   uint32_t b_lit[kZLanes], b_out[kZLanes];                   // exclusive prefixes: literal bytes / output bytes before the sequence
   uint32_t b_flag[kZLanes];                                  // the sequence does not fit the fast path (or the batch)
+  uint32_t b_rowlit[4 * kZLanes];                            // row path: literal bytes at the head of each row of the batch
   uint32_t b_src[kZLanes];                                   // resolve-then-copy: where the match's bytes really come from (an output position)
   int32_t b_par[kZLanes];                                    // ... the earlier match of the batch whose bytes it copies, or -1
   uint32_t bad;
@@ -748,8 +750,52 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
     // search over the sequence starts, then pointer doubling (source += the parent's shift, parent = the parent's parent: 6 rounds for 64) -- and when every source lies in
     // literals or in earlier output, all matches copy at once.  Taken when every match of the batch is a one-step match whose bytes come from ONE place (not across the border
     // of a literal run and a match); anything else runs in sequence order below.
+    // ROWS.  PLAIN fixed-width values whose high bytes repeat (sorted keys, timestamps, small integers in eight bytes) compress to one sequence a value: a few literal
+    // bytes, then a match of the rest at offset = the value's width S -- "the other columns of this row are the previous row's" (a value equal to its predecessor just makes
+    // the match S bytes longer).  When every sequence of the batch is of that kind (offset = S, literal run <= S, length a multiple of S), byte (row r, column c) is the
+    // literal of the LAST row r' <= r whose literal run reaches column c, or the row in front of the batch: one ballot per column and 64 rows says which rows hold a literal
+    // there, a count-leading-zeros per lane finds r'.  No chain is walked: S ballots and S byte moves a lane, where the in-order loop pays 64 LDS round trips.
     bool parallel = false;
     if (cnt >= 8) {
+      const uint32_t S = sh.b_m[0][1];
+      const uint32_t rows = S ? span / S : 0;
+      if (S >= 1 && S <= kZRowWidth && rows * S == span && rows <= 4 * kZLanes) {
+        w.lanes([&](uint32_t lane) {
+          const uint32_t ll = sh.b_ll[lane], len = ll + sh.b_m[lane][2];
+          sh.b_flag[lane] = lane < cnt && (sh.b_m[lane][1] != S || ll > S || len % S != 0);
+          for (uint32_t r = lane; r < rows; r += kZLanes) sh.b_rowlit[r] = 0;
+        });
+        w.sync();
+        if (w.first_flag(sh.b_flag) == kZLanes) {
+          w.lanes([&](uint32_t lane) { if (lane < cnt) sh.b_rowlit[sh.b_out[lane] / S] = sh.b_ll[lane]; });        // literal bytes of the row a sequence starts; the rows it continues into have none
+          w.sync();
+          ZLaneVar<uint32_t[4]> my;          // the literal runs of this lane's rows (row = 64 q + lane); behind the batch: "all literal", nothing to move
+          w.lanes([&](uint32_t lane) { PLX_UNROLL_Z for (uint32_t q = 0; q < 4; q++) my[lane][q] = q * kZLanes + lane < rows ? sh.b_rowlit[q * kZLanes + lane] : 0xffffffffu; });
+          for (uint32_t c = 0; c < S; c++) {
+            int32_t last = -1;               // the last row so far with a literal in column c (-1: the row in front of the batch)
+            PLX_UNROLL_Z for (uint32_t q = 0; q < 4; q++) {              // (unrolled: the lane's four row slots stay in registers)
+              if (q * kZLanes >= rows) break;
+              const uint64_t lit = w.ballot([&](uint32_t lane) { return q * kZLanes + lane < rows && my[lane][q] > c; });
+              const int32_t carry = last;
+              w.lanes([&](uint32_t lane) {
+                if (my[lane][q] <= c) {
+                  const uint64_t below = lit & (((uint64_t)2 << lane) - 1);
+                  const int32_t from_row = below ? (int32_t)(q * kZLanes + 63u - (uint32_t)__builtin_clzll(below)) : carry;
+                  const uint32_t from = cur + (uint32_t)(from_row * (int32_t)S) + c;
+                  sh.ring[(cur + (q * kZLanes + lane) * S + c) & kZRingMask] = sh.ring[from & kZRingMask];
+                }
+              });
+              if (lit) last = (int32_t)(q * kZLanes + 63u - (uint32_t)__builtin_clzll(lit));
+            }
+          }
+          parallel = true;
+          w.count(6, 1);
+          ZDBG("rows batch of %u, width %u, %u rows\n", cnt, S, rows);
+        }
+        w.sync();
+      }
+    }
+    if (cnt >= 8 && !parallel) {
       w.lanes([&](uint32_t lane) {
         uint32_t flag = 0, src = 0;
         int32_t par = -1;

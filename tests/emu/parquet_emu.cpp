@@ -86,6 +86,7 @@ struct EmuWave {
     }
   }
   void batch_scan(uint32_t* lit, uint32_t* out, uint32_t* r0, uint32_t* r1, uint32_t* r2) { exclusive_scan(lit); exclusive_scan(out); rep_scan(r0, r1, r2); }
+  template <class F> uint64_t ballot(F&& pred) { uint64_t m = 0; for (uint32_t l = 0; l < kZLanes; l++) if (pred(l)) m |= (uint64_t)1 << l; return m; }
   uint32_t first_flag(const uint32_t* flag) { for (uint32_t l = 0; l < kZLanes; l++) if (flag[l]) return l; return kZLanes; }
 };
 // pq_zstd_entropy + pq_zstd_execute (kernels_parquet.hip) as loops: one wavefront per compressed block, then one per page; returns PE_ZSTD or 0

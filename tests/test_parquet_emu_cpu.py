@@ -852,3 +852,25 @@ def test_zstd_match_chains_resolved_before_they_are_copied():
         for order in (0, 1):
             rc, out, counts, err = E.zstd_device(c, len(p), order)
             assert rc == 0 and out == p, (lvl, order, rc, counts, err)
+
+
+def test_zstd_batches_of_fixed_width_rows():
+    """The execute pass' row path: sequences "a few literal bytes, then the rest of the value from the value before it" (offset = the value's width; a repeated value makes the
+    match a width longer).  Sorted 8-byte keys with duplicates, 4-byte running sums, 16-byte rows (two keys side by side), 2-byte values, and widths the path must refuse
+    (24-byte rows at offset 8, values of 3 bytes) -- each alone and spliced together so that batches of both kinds follow each other."""
+    rng = np.random.default_rng(31)
+    n = 30_000
+    k8 = np.sort(rng.integers(1, 2 * n, n)).astype(np.int64)                        # many equal neighbours
+    k4 = np.cumsum(rng.integers(0, 3, 2 * n)).astype(np.int32)
+    k16 = np.stack([np.sort(rng.integers(1, 1 << 33, n)), np.sort(rng.integers(1, 4 * n, n))], axis=1).astype(np.int64)
+    k2 = np.cumsum(rng.integers(0, 2, 3 * n)).astype(np.uint16)
+    k24 = np.stack([k8, k8 // 3, k8 // 7], axis=1)
+    k3 = np.sort(rng.integers(0, 1 << 20, 2 * n)).astype("<u4").view(np.uint8).reshape(-1, 4)[:, :3].copy()
+    parts = [x.tobytes() for x in (k8, k4, k16, k2, k24, k3)]
+    spliced = b"".join(p[i * 20_000:(i + 1) * 20_000] for i in range(6) for p in parts)
+    for p in parts + [spliced]:
+        for lvl in (1, 3):
+            c = pa.Codec("zstd", compression_level=lvl).compress(p, asbytes=True)
+            for order in (0, 1):
+                rc, out, counts, err = E.zstd_device(c, len(p), order)
+                assert rc == 0 and out == p, (lvl, order, rc, counts, err)
