@@ -306,15 +306,25 @@ template <bool TIMING> struct ZstdDevWave {
     uint32_t l = l0, o = o0;
     ZstdRepMap m;
     m.s[0] = r0[lane]; m.s[1] = r1[lane]; m.s[2] = r2[lane];
+    // a batch of nothing but "the last offset again" (sorted values: every sequence) composes to the identity: no map needs to travel
+    const bool maps = __ballot(m.s[0] != (1u << 30) || m.s[1] != (2u << 30) || m.s[2] != (3u << 30)) != 0;
+    if (maps) {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t yl = __shfl_up(l, d, 64), yo = __shfl_up(o, d, 64);
-      ZstdRepMap e;
-      e.s[0] = __shfl_up(m.s[0], d, 64); e.s[1] = __shfl_up(m.s[1], d, 64); e.s[2] = __shfl_up(m.s[2], d, 64);
-      if ((int)lane >= d) { l += yl; o += yo; m = zstd_rep_compose(e, m); }
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t yl = __shfl_up(l, d, 64), yo = __shfl_up(o, d, 64);
+        ZstdRepMap e;
+        e.s[0] = __shfl_up(m.s[0], d, 64); e.s[1] = __shfl_up(m.s[1], d, 64); e.s[2] = __shfl_up(m.s[2], d, 64);
+        if ((int)lane >= d) { l += yl; o += yo; m = zstd_rep_compose(e, m); }
+      }
+      r0[lane] = m.s[0]; r1[lane] = m.s[1]; r2[lane] = m.s[2];
+    } else {
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t yl = __shfl_up(l, d, 64), yo = __shfl_up(o, d, 64);
+        if ((int)lane >= d) { l += yl; o += yo; }
+      }
     }
     lit[lane] = l - l0; out[lane] = o - o0;
-    r0[lane] = m.s[0]; r1[lane] = m.s[1]; r2[lane] = m.s[2];
   }
   template <class F> __device__ __forceinline__ uint64_t ballot(F&& pred) { return (uint64_t)__ballot(pred((uint32_t)threadIdx.x) ? 1 : 0); }
   // index of the first nonzero flag[lane]; 64 if there is none

@@ -67,7 +67,9 @@ def payload_table(n):
     zeros = np.zeros(n, np.int64)                                                   # RLE blocks / one long match at offset 1 or 8
     codes = RNG.integers(0, 7, n).astype(np.int8)                                   # short Huffman codes
     runs = np.repeat(RNG.integers(0, 1 << 30, (n + 96) // 97), 97)[:n]              # long matches (cooperative copies), repeat offsets
-    return pa.table({"key": key, "far": far, "price": price, "rnd": rnd, "zeros": zeros, "codes": codes, "runs": runs,
+    dense = np.sort(RNG.integers(1, 4 * n, n))                                      # one sequence a value: a literal byte or two, the rest from the value above (the row path)
+    ticks = np.cumsum(RNG.integers(0, 3, n)).astype(np.int32)                       # ... four bytes wide, many equal neighbours (matches of several rows)
+    return pa.table({"key": key, "dense": dense, "ticks": ticks, "far": far, "price": price, "rnd": rnd, "zeros": zeros, "codes": codes, "runs": runs,
                      "nullable": pa.array(RNG.integers(0, 1 << 30, n), mask=RNG.random(n) < 0.1)})
 
 
