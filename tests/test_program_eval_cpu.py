@@ -52,7 +52,8 @@ def by_key(res, key_names):
 def close(a, b, rtol=1e-9):
     if a is None or b is None or isinstance(a, str) or isinstance(b, str):
         return a == b
-    return a == b or math.isclose(a, b, rel_tol=rtol)
+    # (abs_tol: a sum of standard normals that nearly cancels -- -8.9e-7 from ~50 terms -- differs in the 15th digit of its TERMS, not of itself)
+    return a == b or math.isclose(a, b, rel_tol=rtol, abs_tol=1e-12)
 
 
 def test_cfg2_program_matches_oracle(orc):
@@ -84,7 +85,8 @@ def test_q1_program_matches_oracle(orc):
 
 @pytest.mark.parametrize("shape", ["packed_nullable_keys", "wide_keys", "raw_float_key", "raw_i64_key"])
 def test_group_by_programs_match_oracle(orc, shape):
-    rng = np.random.default_rng(hash(shape) % 1000)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(shape.encode()) % 1000)       # (hash() of a str changes from process to process: the data must not)
     n = 60_000
     v = rng.integers(-1000, 1000, n).astype(np.int64); vm = rng.random(n) < 0.9
     x = rng.normal(size=n); x[rng.random(n) < 0.02] = np.nan; xm = rng.random(n) < 0.85
