@@ -2,6 +2,7 @@
 // parquet_device.hpp (host + device, also executed by the CPU harness of the tests); this file only maps them onto the grid.
 //
 //   pq_snappy          one 256-thread workgroup per compressed stream: parquet_snappy.hpp
+//   pq_zstd_entropy    one wavefront per four (sixteen: no sequences) compressed zstd blocks; pq_zstd_execute one wavefront per zstd page: parquet_zstd.hpp
 //   pq_page_prepare    one thread per page: split the payload into level / value streams
 //   pq_count_runs      one thread per (page, stream): entries its run table needs       } the only serial walks: run HEADERS of one
 //   pq_fill_runs       one thread per (page, stream): the run table                      } stream of one page

@@ -1,10 +1,11 @@
 // parquet_reader.hpp -- Parquet column chunks -> device columns, host orchestration.
 //
-// The host only touches METADATA (and, for the codecs without a device kernel yet -- ZSTD, GZIP, LZ4_RAW -- decompresses pages on a pool of
-// threads: host_codecs.hpp): the footer (parquet_format.hpp), the Thrift page headers inside each column chunk, and the
+// The host only touches METADATA (and, for the codecs without a device kernel -- GZIP, LZ4_RAW -- decompresses pages on a pool of
+// threads: host_codecs.hpp): the footer (parquet_format.hpp), the Thrift page headers inside each column chunk, the block headers and table
+// descriptions inside zstd pages (parquet_zstd_index.hpp), and the
 // dictionary pages of string columns (a few KB each, unified into one column-wide dictionary).  The chunk bytes themselves go to HBM
 // exactly as they are in the file -- compressed, encoded -- in one copy per chunk, and everything else happens there
-// (parquet_device.hpp): Snappy, level / index run tables, validity, dense -> row expansion, dictionary lookup, integer narrowing.
+// (parquet_device.hpp): Snappy, Zstandard, level / index run tables, validity, dense -> row expansion, dictionary lookup, integer narrowing.
 //
 // `read_column<B>` is a template over the execution backend B (HBM + kernel launches in parquet.cpp; host memory + the same bodies
 // run thread by thread in tests/emu/parquet_emu.cpp), so the page walk, the stream planning and the dictionary handling below are

@@ -9,15 +9,17 @@
 //   index    (host, while the page walk goes on: metadata only)  frame / block / section HEADERS are parsed into ZstdBlock records and the
 //            table DESCRIPTIONS into normalised counts / code lengths (a few dozen bytes per block; repeat / treeless modes resolved to the
 //            block that defined the table).  Nothing of the payload is decoded on the host.
-//   entropy  one wavefront per compressed block, all blocks of all pages of the column at once: lanes build the Huffman table and the three
-//            FSE tables in LDS; lanes 0..3 decode the (up to four) Huffman streams into the block's literal buffer; lane 0 decodes the
-//            sequences into {literal length, match length, offset VALUE} records.  Repeat offsets cross block borders and are a chain of their own: they are
-//            left to the execute pass, so no block waits for its predecessor and lane 0's loop stays short.
-//   execute  one wavefront per page: blocks in order; 64 sequences at a time -- every lane places its own sequence's literals at their
-//            final position (prefix sums); the repeat-offset history is a prefix "sum" too (every sequence is a small map on the three offsets, maps compose:
-//            a wavefront scan); then the matches run in sequence order with all lanes copying bytes.  The last 32 KB of output
-//            live in an LDS ring (a match that reads what the previous match wrote costs an LDS round trip, not an HBM one); the ring is
-//            flushed to HBM in 16-byte stores, matches that reach further back read the flushed bytes.
+//   entropy  all compressed blocks of all pages of the column at once, FOUR blocks a wavefront (sixteen lanes each; sixteen blocks a wavefront when they hold no
+//            sequences): a block's chains run on single lanes -- sub-lanes build the Huffman table and the three FSE tables in LDS, sub-lanes 0..3 decode the (up to four)
+//            Huffman streams into the block's literal buffer (or, for a page of nothing but such blocks, straight into the page's output), sub-lane 0 decodes the
+//            sequences into {literal length, match length, offset VALUE} records -- and an instruction costs the wavefront the same whether one lane or four are live.
+//            Repeat offsets cross block borders and are a chain of their own: they are left to the execute pass, so no block waits for its predecessor.
+//   execute  one wavefront per page: blocks in order; 64 sequences at a time -- every lane places its own sequence's literals at their final position (prefix sums);
+//            the repeat-offset history is a prefix "sum" too (every sequence is a small map on the three offsets, maps compose: a wavefront scan); then the matches:
+//            batches of fixed-width ROWS ("a few literal bytes, the rest from the row above": sorted keys, timestamps) by one ballot per column, batches whose matches
+//            copy earlier matches of the batch by pointer doubling over the matches, anything else in sequence order with all lanes copying bytes.  The last 32 KB of
+//            output live in an LDS ring (a match that reads what the previous match wrote costs an LDS round trip, not an HBM one); the ring is flushed to HBM in
+//            16-byte stores, matches that reach further back read the flushed bytes.
 //
 // Every phase is a function of (lane) between barriers, so the CPU harness (tests/emu/parquet_emu.cpp) runs the very same bodies lane after
 // lane; W is the wavefront: W::lanes(f) runs f for every lane, W::sync() is the barrier.
