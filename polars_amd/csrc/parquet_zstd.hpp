@@ -17,7 +17,7 @@
 //   execute  one wavefront per page: blocks in order; 64 sequences at a time -- every lane places its own sequence's literals at their final position (prefix sums);
 //            the repeat-offset history is a prefix "sum" too (every sequence is a small map on the three offsets, maps compose: a wavefront scan); then the matches:
 //            batches of fixed-width ROWS ("a few literal bytes, the rest from the row above": sorted keys, timestamps) by one ballot per column, batches whose matches
-//            copy earlier matches of the batch by pointer doubling over the matches, anything else in sequence order with all lanes copying bytes.  The last 32 KB of
+//            copy earlier matches of the batch by pointer doubling over the matches, anything else in sequence order with all lanes copying bytes.  The last 16 KB of
 //            output live in an LDS ring (a match that reads what the previous match wrote costs an LDS round trip, not an HBM one); the ring is flushed to HBM in
 //            16-byte stores, matches that reach further back read the flushed bytes.
 //
@@ -39,7 +39,7 @@ namespace plx {
 namespace pq {
 
 constexpr uint32_t kZLanes = 64;                 // one wavefront per block (entropy) / per page (execute)
-constexpr uint32_t kZRing = 32768;               // bytes of recent output held in LDS by the execute pass
+constexpr uint32_t kZRing = 16384;               // bytes of recent output held in LDS by the execute pass (16 KB: seven page wavefronts a CU; 32 KB: four -- a file of PLAIN values in 20 000-row pages read in 33-39 vs 40-48 ms)
 constexpr uint32_t kZRingMask = kZRing - 1;
 constexpr uint32_t kZPiece = 4096;               // bytes one cooperative copy step moves (long literal runs / long matches are cut into pieces)
 constexpr uint32_t kZBatchSpan = kZRing / 2;     // output bytes of one batch of sequences

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-PLX_PARQUET_TRACE=1 timeout 300 python tools/zstd_read.py 2e7 4 0 2>&1 | grep -v "^W\|^I" | tail -44
+timeout 900 python -m pytest tests/test_gpu_zstd.py tests/test_gpu_parquet.py tests/test_gpu_zzz_scan_host_paths.py -x -q -m gpu 2>&1 | tail -3
