@@ -740,7 +740,18 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
         if (off == 0 || off > pos + ll - frame_start) { sh.bad = 1; ZDBG("exec: offset %u at %u (lane %u)\n", off, pos + ll, lane); }
         // the common match: one step of the wavefront, no overlap, its source still in the ring
         const uint32_t ml = sh.b_ml[lane];
-        sh.b_m[lane][0] = rel + ll; sh.b_m[lane][1] = off; sh.b_m[lane][2] = ml; sh.b_m[lane][3] = (ml <= kZLanes && off >= ml && pos + ll >= off && pos + ll - off >= floor) ? 1u : 0u;
+        uint32_t kind = (ml <= kZLanes && off >= ml && pos + ll >= off && pos + ll - off >= floor) ? 1u : 0u;
+        // ... and the match whose source has LEFT the ring (all of it: flushed, final): its lane fetches it from HBM now, next to the literals -- in the in-order loop every
+        // such match is a trip to HBM of its own (a 16 KB ring sees them: values repeated from a few thousand rows up)
+        if (!kind && ml <= kZLanes && off >= ml && pos + ll >= off && pos + ll - off + ml <= floor && sh.bad == 0) {
+          const uint8_t* far = PQ_GPTR(const uint8_t, (uint64_t)st.dst) + (pos + ll - off);
+          for (uint32_t t = 0; t < ml; t += 8) {
+            uint64_t v = load_u64(far + t);
+            for (uint32_t e = 0; e < 8 && t + e < ml; e++) { sh.ring[(pos + ll + t + e) & kZRingMask] = (uint8_t)v; v >>= 8; }
+          }
+          kind = 2;
+        }
+        sh.b_m[lane][0] = rel + ll; sh.b_m[lane][1] = off; sh.b_m[lane][2] = ml; sh.b_m[lane][3] = kind;
       }
     });
     w.sync();
@@ -804,6 +815,7 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
         if (lane < cnt) {
           const uint32_t dm = cur + sh.b_m[lane][0], off = sh.b_m[lane][1], n = sh.b_m[lane][2];
           if (!sh.b_m[lane][3]) flag = 1;
+          else if (sh.b_m[lane][3] == 2) src = dm;            // fetched from HBM above: nothing to do (a copy onto itself)
           else {
             src = dm - off;
             if (src + n <= cur) par = -1;                  // earlier output
@@ -812,7 +824,7 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
               uint32_t lo = 0, hi = lane;                  // the last sequence that starts at or below src (starts ascend; sequence 0 starts at cur <= src)
               while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (cur + sh.b_out[mid] <= src) lo = mid; else hi = mid - 1; }
               const uint32_t dmj = cur + sh.b_m[lo][0], nj = sh.b_m[lo][2];
-              if (src >= dmj) { if (lo < lane && src + n <= dmj + nj) par = (int32_t)lo; else flag = 1; }       // inside that sequence's match
+              if (src >= dmj) { if (lo < lane && src + n <= dmj + nj) par = sh.b_m[lo][3] == 2 ? -1 : (int32_t)lo; else flag = 1; }       // inside that sequence's match (one fetched from HBM above is final already)
               else if (src + n > dmj) flag = 1;            // across its literal run and its match
             }
           }
@@ -864,6 +876,7 @@ template <class W> PLX_HD bool zstd_exec_block(W& w, ZstdExecShared& sh, ZstdExe
       PLX_UNROLL_Z for (int j = 0; j < 4; j++) {
         if (k + j < cnt) {
           const uint32_t d = cur + q[j][0], off = q[j][1], n = q[j][2];
+          if (q[j][3] == 2) continue;        // fetched from HBM by its lane
           if (q[j][3]) w.lanes([&](uint32_t lane) { if (lane < n) sh.ring[(d + lane) & kZRingMask] = sh.ring[(d - off + lane) & kZRingMask]; });
           else w.lanes([&](uint32_t lane) { zstd_copy_match(sh, dst, d, off, n, floor, lane); });
           w.wave_fence();
