@@ -69,7 +69,8 @@ def payload_table(n):
     runs = np.repeat(RNG.integers(0, 1 << 30, (n + 96) // 97), 97)[:n]              # long matches (cooperative copies), repeat offsets
     dense = np.sort(RNG.integers(1, 4 * n, n))                                      # one sequence a value: a literal byte or two, the rest from the value above (the row path)
     ticks = np.cumsum(RNG.integers(0, 3, n)).astype(np.int32)                       # ... four bytes wide, many equal neighbours (matches of several rows)
-    return pa.table({"key": key, "dense": dense, "ticks": ticks, "far": far, "price": price, "rnd": rnd, "zeros": zeros, "codes": codes, "runs": runs,
+    disc = RNG.integers(0, 11, n) / 100.0                                           # eleven distinct doubles: every value a match a few rows (near) or a few thousand rows (beyond the ring) up
+    return pa.table({"key": key, "dense": dense, "ticks": ticks, "disc": disc, "far": far, "price": price, "rnd": rnd, "zeros": zeros, "codes": codes, "runs": runs,
                      "nullable": pa.array(RNG.integers(0, 1 << 30, n), mask=RNG.random(n) < 0.1)})
 
 

@@ -874,3 +874,20 @@ def test_zstd_batches_of_fixed_width_rows():
             for order in (0, 1):
                 rc, out, counts, err = E.zstd_device(c, len(p), order)
                 assert rc == 0 and out == p, (lvl, order, rc, counts, err)
+
+
+def test_zstd_matches_whose_source_has_left_the_ring():
+    """Values repeated from a few rows up (in the LDS ring) and from tens of kilobytes up (flushed: fetched from HBM by the match's own lane next to the literals), in
+    the same batches: a few distinct doubles / integers in 8-byte slots, 200 KB and more of them, levels that search far."""
+    rng = np.random.default_rng(41)
+    n = 60_000
+    disc = (rng.integers(0, 11, n) / 100.0).tobytes()
+    qty = rng.integers(1, 51, n).astype(np.int64).tobytes()
+    codes = np.tile(rng.integers(0, 1 << 50, 3000), n // 3000).astype(np.int64)
+    codes[rng.integers(0, n, n // 50)] = rng.integers(0, 1 << 50, n // 50)         # a long period (24 KB) with scattered changes: matches of every length, all far
+    for p in (disc, qty, codes.tobytes(), disc[:100_000] + qty[:100_000] + codes.tobytes()[:100_000]):
+        for lvl in (1, 3, 9, 15):
+            c = pa.Codec("zstd", compression_level=lvl).compress(p, asbytes=True)
+            for order in (0, 1):
+                rc, out, counts, err = E.zstd_device(c, len(p), order)
+                assert rc == 0 and out == p, (lvl, order, rc, counts, err)
