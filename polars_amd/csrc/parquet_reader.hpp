@@ -392,10 +392,11 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
   struct SyncOnUnwind { B& b; int n = std::uncaught_exceptions(); ~SyncOnUnwind() { if (std::uncaught_exceptions() > n) b.discard_pending(); } } sync_on_unwind{be};
   size_t jobs_launched = 0, stored_since_launch = 0;
   static const size_t kSnappyBatch = [] { const char* e = getenv("PLX_PARQUET_SNAPPY_BATCH"); const long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : (size_t)-1; }();
-  // zstd: the same knob (PLX_PARQUET_ZSTD_BATCH, off by default).  Measured on the 2e7-row file: one launch 31 ms; 64 MB batches 40-44, 32 MB 39-48, 16 MB 56-65 -- also with the
+  // zstd: the same knob (PLX_PARQUET_ZSTD_BATCH, 1 GB by default: no effect on a column chunk set below that).  Measured on the 2e7-row file: one launch 31 ms; 64 MB batches 40-44, 32 MB 39-48, 16 MB 56-65 -- also with the
   // uploads on a stream of their own and the descriptor arrays queued without a wait (tried, removed).  The passes are bound by their longest CHAIN (a block's sequences,
   // a page's matches: milliseconds whatever the launch holds), so k launches one after the other on the column's stream cost k chains where one launch costs one.
-  static const size_t kZstdBatch = [] { const char* e = getenv("PLX_PARQUET_ZSTD_BATCH"); const long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : (size_t)-1; }();
+  // The default of 1 GB of stored bytes only bounds the scratch of a very large read (16 bytes a sequence, up to one a value: a 1e9-row column would ask for 16 GB at once).
+  static const size_t kZstdBatch = [] { const char* e = getenv("PLX_PARQUET_ZSTD_BATCH"); const long long v = e ? atoll(e) : (1ll << 30); return v > 0 ? (size_t)v : (size_t)-1; }();
   ZstdPlan zplan;                                      // the zstd pages since the last launch, indexed while their stored bytes were at hand (parquet_zstd_index.hpp)
   std::vector<size_t> zjobs;                           // ... and their job indices, in the plan's stream order
   double index_ms = 0, pread_ms = 0, stage_ms = 0, upload_ms = 0;
