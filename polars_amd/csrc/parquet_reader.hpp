@@ -252,6 +252,14 @@ inline bool zstd_on_host() {
   const char* e = getenv("PLX_PARQUET_ZSTD");          // read per column chunk: cheap, and a test can flip it
   return e && !strcmp(e, "host");
 }
+// A zstd page's execute pass is ONE wavefront walking the page's sequences in order (parquet_zstd.hpp): a 1 MB page of sorted keys -- what a writer with 1 MB pages, the
+// reference's own, produces -- is 1.3e5 of them, several milliseconds that no other wavefront can shorten.  A page with more sequences than this (counted by the index
+// pass; PLX_PARQUET_ZSTD_HOST_SEQS, 0 = no limit) is inflated by a host thread instead, while the column's device passes run.
+inline size_t zstd_host_sequences() {
+  const char* e = getenv("PLX_PARQUET_ZSTD_HOST_SEQS");        // read per page: cheap, and a test can flip it
+  if (e) { const long long v = atoll(e); return v <= 0 ? (size_t)-1 : (size_t)v; }
+  return 50000;
+}
 inline bool is_host_codec(int codec_id) {
   return (codec_id == CODEC_ZSTD && zstd_on_host()) || codec_id == CODEC_LZ4_RAW || codec_id == CODEC_GZIP || (codec_id == CODEC_SNAPPY && snappy_on_host());
 }
@@ -461,6 +469,8 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
   size_t batch_base = 0;
   std::vector<Inflate> inflate_all;
   struct HostDict { std::vector<uint8_t> comp, plain; size_t out = 0, dict_index = 0; std::future<void> done; };
+  struct HostPage { std::vector<uint8_t> comp; size_t out = 0, page_index = 0; };
+  std::vector<std::unique_ptr<HostPage>> host_pages;     // zstd data pages of too many sequences for one wavefront: inflated by host threads behind the launch (below)
   std::vector<std::unique_ptr<HostDict>> host_dicts;     // long Snappy dictionary pages inflated by host threads while the walk goes on (below)
   std::vector<std::vector<uint8_t>> stored_all;          // the stored bytes of a batch's chunks stay alive until its pass has run
   struct ImageUpload { size_t blob_off, bytes; };
@@ -478,15 +488,28 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
     const bool codec_on = (c.codec == CODEC_SNAPPY || c.codec == CODEC_ZSTD) && !host_codec;          // pages decompressed on the device
     const bool zstd_on = codec_on && c.codec == CODEC_ZSTD;
     // a device stream: Snappy as it is; zstd with its headers indexed now, while the stored bytes are in the staging buffer
-    auto push_job = [&](const uint8_t* stored, uint64_t dev, uint32_t comp, uint32_t uncomp) {
+    // (page_index: the data page the stream belongs to, npos for a dictionary page; false = the page went to the host threads instead of becoming a job)
+    auto push_job = [&](const uint8_t* stored, uint64_t dev, uint32_t comp, uint32_t uncomp, size_t page_index) -> bool {
       if (zstd_on) {
         const auto t0 = std::chrono::steady_clock::now();
+        const size_t n_streams = zplan.streams.size(), n_blocks = zplan.blocks.size(), n_hufs = zplan.hufs.size(), n_fses = zplan.fses.size();
+        const uint64_t lit0 = zplan.lit_bytes, seq0 = zplan.n_seq, comp0 = zplan.n_compressed;
         try { zstd_index_stream(zplan, stored, comp, dev, uncomp); }
         catch (const codec::CodecError& e) { throw FormatError(std::string("column '") + leaf.name + "': " + e.what()); }
-        zjobs.push_back(jobs.size());
         index_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (page_index != npos && zplan.n_seq - seq0 > zstd_host_sequences()) {
+          zplan.streams.resize(n_streams); zplan.blocks.resize(n_blocks); zplan.hufs.resize(n_hufs); zplan.fses.resize(n_fses);
+          zplan.lit_bytes = lit0; zplan.n_seq = seq0; zplan.n_compressed = comp0;
+          auto hp = std::make_unique<HostPage>();
+          hp->comp.assign(stored, stored + comp); hp->out = uncomp; hp->page_index = page_index;
+          host_pages.push_back(std::move(hp));
+          if (stats) { stats->host_inflated_pages++; stats->host_inflated_bytes += uncomp; }
+          return false;
+        }
+        zjobs.push_back(jobs.size());
       }
       jobs.push_back(DecompJob{dev, 0, comp, uncomp});
+      return true;
     };
     // Device codec / none: the stored bytes are staged and uploaded as they are.  Host codec: the stored bytes stay in pageable memory;
     // what is staged and uploaded is the chunk's IMAGE -- the page payloads decompressed, back to back -- and the pages then look
@@ -593,7 +616,7 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
             if (stats) { stats->host_inflated_pages++; stats->host_inflated_bytes += (uint64_t)h.uncompressed_size; }
           } else if (codec_on) {
             job_of_dict.push_back(jobs.size());
-            push_job(host + pos, payload, (uint32_t)h.compressed_size, (uint32_t)h.uncompressed_size);
+            push_job(host + pos, payload, (uint32_t)h.compressed_size, (uint32_t)h.uncompressed_size, npos);
           } else job_of_dict.push_back(npos);
           remap_base_of_dict.push_back(npos);
         }
@@ -630,14 +653,14 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
             p.flags |= PF_COMPRESSED;
             if (h.uncompressed_size < h.def_len) throw FormatError("v2 page smaller than its level bytes");
             job = jobs.size();
-            push_job(host + pos + (size_t)h.def_len, payload + (uint64_t)h.def_len, (uint32_t)(h.compressed_size - h.def_len), (uint32_t)(h.uncompressed_size - h.def_len));
+            if (!push_job(host + pos + (size_t)h.def_len, payload + (uint64_t)h.def_len, (uint32_t)(h.compressed_size - h.def_len), (uint32_t)(h.uncompressed_size - h.def_len), pages.size())) job = npos;
           }
         } else {
           if (optional && h.def_encoding != ENC_RLE) throw Unsupported(std::string("definition levels encoded as ") + encoding_name(h.def_encoding));
           if (codec_on) {
             p.flags |= PF_COMPRESSED;
             job = jobs.size();
-            push_job(host + pos, payload, (uint32_t)h.compressed_size, (uint32_t)h.uncompressed_size);
+            if (!push_job(host + pos, payload, (uint32_t)h.compressed_size, (uint32_t)h.uncompressed_size, pages.size())) job = npos;
           }
         }
         if (c.codec == CODEC_UNCOMPRESSED && h.compressed_size != h.uncompressed_size) throw FormatError("uncompressed page whose two sizes differ");
@@ -676,6 +699,22 @@ template <class B> ColumnResult<B> read_column_device(B& be, File& f, const std:
   launch_snappy();
   for (size_t i = 0; i < pages.size(); i++) if (job_of_page[i] != npos) pages[i].dst = jobs[job_of_page[i]].dst;
   for (size_t i = 0; i < dicts.size(); i++) if (job_of_dict[i] != npos) dicts[i].values = jobs[job_of_dict[i]].dst;
+  typename B::Mem host_page_mem{};
+  if (!host_pages.empty()) {
+    // (the column's device passes are running: these pages are inflated next to them, by the bounded pool of the host codecs)
+    size_t total = 0;
+    std::vector<size_t> off(host_pages.size());
+    for (size_t i = 0; i < host_pages.size(); i++) { off[i] = total; total += align16(host_pages[i]->out + 16); }
+    host_page_mem = be.alloc(total + 64);
+    uint8_t* st = be.host_stage(total + 64);
+    std::vector<Inflate> tasks;
+    for (size_t i = 0; i < host_pages.size(); i++) tasks.push_back({host_pages[i]->comp.data(), host_pages[i]->comp.size(), st + off[i], host_pages[i]->out, false, CODEC_ZSTD});
+    run_inflate(tasks);
+    for (size_t i = 0; i < host_pages.size(); i++) pages[host_pages[i]->page_index].dst = be.addr(host_page_mem) + off[i];
+    be.upload(be.addr(host_page_mem), st, total);
+    host_pages.clear();
+    trace_point(leaf.name, "zstd pages of many sequences inflated on the host, uploaded");
+  }
   typename B::Mem host_dict_mem{};
   if (!host_dicts.empty()) {
     size_t total = 0;

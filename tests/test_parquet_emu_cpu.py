@@ -891,3 +891,21 @@ def test_zstd_matches_whose_source_has_left_the_ring():
             for order in (0, 1):
                 rc, out, counts, err = E.zstd_device(c, len(p), order)
                 assert rc == 0 and out == p, (lvl, order, rc, counts, err)
+
+
+def test_zstd_pages_of_many_sequences_go_to_host_threads(tmp_path, monkeypatch):
+    """A page's execute pass is one wavefront walking its sequences in order: a page with more of them than PLX_PARQUET_ZSTD_HOST_SEQS (default 50 000; the index pass
+    counts them) is inflated by a host thread instead while the column's other pages stay device streams.  Same values with the limit at 300 (most pages of the sorted
+    column to the host), at its default (none of these 2 000-row pages) and switched off."""
+    n = 40_000
+    t = pa.table({"k": pa.array(np.sort(RNG.integers(1, 4 * n, n))), "f": pa.array(RNG.normal(size=n)), "few": pa.array(RNG.integers(0, 5, n), mask=RNG.random(n) < 0.2)})
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression="zstd", use_dictionary=False, row_group_size=15_000, max_rows_per_page=2000)
+    base = {name: check_column(path, t, name)["stats"] for name in t.column_names}
+    assert all(st["host_inflated_pages"] == 0 and st["zstd_streams"] > 0 for st in base.values()), base
+    monkeypatch.setenv("PLX_PARQUET_ZSTD_HOST_SEQS", "300")
+    st = {name: check_column(path, t, name)["stats"] for name in t.column_names}
+    assert st["k"]["host_inflated_pages"] > 0 and st["k"]["host_inflated_pages"] + st["k"]["zstd_streams"] == base["k"]["zstd_streams"], (st["k"], base["k"])
+    assert st["f"]["host_inflated_pages"] == 0            # doubles: Huffman literals, hardly a sequence
+    monkeypatch.setenv("PLX_PARQUET_ZSTD_HOST_SEQS", "0")
+    assert check_column(path, t, "k")["stats"]["host_inflated_pages"] == 0

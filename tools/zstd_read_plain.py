@@ -22,7 +22,7 @@ t = pa.table({"l_orderkey": pa.array(np.sort(rng.integers(1, 4 * n, n))), "l_qua
               "l_nullable": pa.array(rng.integers(0, 1 << 30, n), mask=rng.random(n) < 0.1)})
 d = tempfile.mkdtemp()
 path = os.path.join(d, "li_plain_zstd.parquet")
-pq.write_table(t, path, compression="zstd", compression_level=3, use_dictionary=False, data_page_size=1 << 20, row_group_size=1 << 20)
+pq.write_table(t, path, compression="zstd", compression_level=3, use_dictionary=False, data_page_size=1 << 20, row_group_size=1 << 20, max_rows_per_page=int(os.environ.get("PAGE_ROWS", "20000")))
 print("file_MB", round(os.path.getsize(path) / 1e6, 1), "pages", sum(1 for _ in range(1)))
 pl.init(0)
 F = pl._ffi
