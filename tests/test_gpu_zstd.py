@@ -155,3 +155,22 @@ def test_q1_from_a_zstd_file(pl, orc, tmp_path):
     assert out["count_order"] == want["count_order"].tolist() and out["sum_qty"] == want["sum_qty"].tolist()
     for c in ("sum_base_price", "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc"):
         assert np.allclose(np.array(out[c]), want[c], rtol=1e-6, atol=0), c
+
+
+def test_pages_of_many_sequences_take_the_host_threads(pl, tmp_path, monkeypatch):
+    """1 MB pages of sorted keys are 1.3e5 sequences each: beyond PLX_PARQUET_ZSTD_HOST_SEQS (50 000) a page is inflated by the host pool while the column's other pages stay
+    device streams; the price column of the same file (Huffman literals, no sequences) stays on the device whatever its pages' size.  Same columns with the limit off."""
+    n = 1_200_000
+    t = pa.table({"k": pa.array(np.sort(RNG.integers(1, 4 * n, n))), "price": pa.array(np.round(RNG.uniform(900, 105_000, n), 2)),
+                  "mixed": pa.array(np.where(np.arange(n) < n // 2, np.sort(RNG.integers(1, 4 * n, n)), RNG.integers(-2**62, 2**62, n)))})        # chunks of both kinds of page
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(t, path, compression="zstd", compression_level=3, use_dictionary=False, data_page_size=1 << 20, max_rows_per_page=1 << 20, row_group_size=400_000)
+    df, seen = kernels_of(pl, lambda: pl.read_parquet(path))
+    assert seen.get("pq_zstd_entropy", 0) > 0, seen
+    compare(df, t, t.column_names)
+    monkeypatch.setenv("PLX_PARQUET_ZSTD_HOST_SEQS", "0")
+    d0 = pl.read_parquet(path)
+    for name in t.column_names:
+        a, _ = df[name]._download()
+        b, _ = d0[name]._download()
+        assert np.array_equal(a, b), name
